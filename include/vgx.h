@@ -1,0 +1,225 @@
+/*
+ * vgx.h -- C-ABI of the MI355X-native batch geometry path (libvgx.so).
+ *
+ * This is the drop-in boundary for vg-renderer's CPU geometry hot path:
+ *   vg::Path     bezier flattener        (reference include/vg/path.h:19-38,    src/path.cpp)
+ *   vg::Stroker  stroke/fill/AA mesher   (reference include/vg/stroker.h:11-85, src/stroker.cpp)
+ * The reference calls those once per path per frame (src/vg.cpp:2969-3059, 3061-3179, 3401-3492);
+ * this ABI takes MANY path instances ("draws") at once so that one launch sequence on a gfx950
+ * device does the work of millions of pathXXX/strokerXXX calls. Everything is plain pointers and
+ * sizes; no C++ or torch types cross the boundary. The C++ header include/vgx_compat.hpp layers the
+ * reference's own vg::pathXXX / vg::strokerXXX names on top of this ABI.
+ *
+ * Conventions
+ *   - "host" pointers are ordinary CPU memory, "device" pointers are HIP device memory on the
+ *     context's device. Each parameter says which one it is.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream). Calls are asynchronous
+ *     unless they return data to the host (documented per function).
+ *   - All functions return a vgx_status; they never abort and never print.
+ *   - Numeric contract: IEEE binary32, no FMA contraction, transcendentals from csrc/vgmath.h.
+ *     Indices are mesh-local uint16 (reference vg::Mesh, include/vg/vg.h:353-360), colours are
+ *     uint32 0xAABBGGRR (include/vg/vg.h:80-86).
+ */
+#ifndef VGX_H
+#define VGX_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VGX_VERSION 1
+
+typedef enum vgx_status {
+	VGX_OK = 0,
+	VGX_E_INVALID_ARG = 1,   /* null pointer, bad enum, count out of range */
+	VGX_E_INVALID_PATH = 2,  /* command stream violates the path grammar (see vgx_pathset_create) */
+	VGX_E_NONFINITE = 3,     /* NaN/Inf in path arguments (would hang the reference, path.cpp:109) */
+	VGX_E_NOSPACE = 4,       /* caller-provided output capacity too small; vgx_sizes holds the need */
+	VGX_E_MESH_TOO_LARGE = 5,/* a mesh needs > 65536 vertices (uint16 indices, vg.cpp:734) */
+	VGX_E_HIP = 6,           /* a HIP runtime call failed; vgx_last_hip_error() has the code */
+	VGX_E_NO_DEVICE = 7,     /* no gfx950 device / HIP runtime unavailable */
+	VGX_E_RANGE = 8          /* batch exceeds 2^32-1 polyline vertices or commands; split the batch */
+} vgx_status;
+
+/* Path commands. One opcode per vg::pathXXX builder call (reference include/vg/path.h:24-35).
+ * Arguments are float32, in the order of the reference's function parameters. */
+typedef enum vgx_cmd {
+	VGX_CMD_MOVE_TO = 0,   /* x, y                     pathMoveTo       path.cpp:62-78   */
+	VGX_CMD_LINE_TO = 1,   /* x, y                     pathLineTo       path.cpp:80-84   */
+	VGX_CMD_CUBIC_TO = 2,  /* c1x,c1y,c2x,c2y,x,y      pathCubicTo      path.cpp:86-182  */
+	VGX_CMD_QUAD_TO = 3,   /* cx,cy,x,y                pathQuadraticTo  path.cpp:184-201 */
+	VGX_CMD_CLOSE = 4,     /* -                        pathClose        path.cpp:707-726 */
+	VGX_CMD_ARC_TO = 5,    /* x1,y1,x2,y2,r            pathArcTo        path.cpp:203-273 */
+	VGX_CMD_ARC = 6,       /* cx,cy,r,a0,a1,dir(0|1)   pathArc          path.cpp:633-682 */
+	VGX_CMD_RECT = 7,      /* x,y,w,h                  pathRect         path.cpp:275-286 */
+	VGX_CMD_ROUNDED_RECT = 8,         /* x,y,w,h,r     pathRoundedRect  path.cpp:288-409 */
+	VGX_CMD_ROUNDED_RECT_VARYING = 9, /* x,y,w,h,rtl,rtr,rbr,rbl        path.cpp:411-559 */
+	VGX_CMD_CIRCLE = 10,   /* cx,cy,r                  pathCircle       path.cpp:561-597 */
+	VGX_CMD_ELLIPSE = 11,  /* cx,cy,rx,ry              pathEllipse      path.cpp:599-631 */
+	VGX_CMD_POLYLINE = 12, /* x0,y0,...,xn-1,yn-1      pathPolyline     path.cpp:684-705 */
+	VGX_CMD_COUNT_ = 13
+} vgx_cmd;
+
+/* Values are the reference's vg::LineCap / vg::LineJoin (include/vg/vg.h:156-174); they are ABI. */
+enum { VGX_CAP_BUTT = 0, VGX_CAP_ROUND = 1, VGX_CAP_SQUARE = 2 };
+enum { VGX_JOIN_MITER = 0, VGX_JOIN_ROUND = 1, VGX_JOIN_BEVEL = 2 };
+
+/* vgx_draw.fill_flags */
+#define VGX_FILL_ENABLE 0x1u /* strokerConvexFill / strokerConvexFillAA per sub-path (vg.cpp:3099-3131) */
+#define VGX_FILL_AA 0x2u
+/* vgx_draw.stroke_flags */
+#define VGX_STROKE_ENABLE 0x1u
+#define VGX_STROKE_AA 0x2u
+#define VGX_STROKE_THIN 0x4u /* strokerPolylineStrokeAAThin (vg.cpp:3417, 3464-3466); needs AA */
+#define VGX_STROKE_CAP(flags) (((flags) >> 4) & 0x3u)
+#define VGX_STROKE_JOIN(flags) (((flags) >> 6) & 0x3u)
+#define VGX_STROKE_FLAGS(cap, join, aa, thin) \
+	(VGX_STROKE_ENABLE | ((aa) ? VGX_STROKE_AA : 0u) | ((thin) ? VGX_STROKE_THIN : 0u) | ((uint32_t)(cap) << 4) | ((uint32_t)(join) << 6))
+
+/* One path instance: what the reference does between vg::beginPath and vg::fillPath/strokePath for
+ * one path under one state transform (vg.cpp:2969-2981 pathReset+strokerReset, vg.cpp:4957-4975
+ * transformPath, vg.cpp:3061-3179 / 3401-3492 the stroker calls). 64 bytes, 16 dwords. */
+typedef struct vgx_draw {
+	uint32_t path;         /* index into the path set */
+	uint32_t fill_flags;   /* VGX_FILL_* */
+	uint32_t fill_color;   /* colour handed to strokerConvexFillAA */
+	uint32_t stroke_flags; /* VGX_STROKE_* */
+	uint32_t stroke_color; /* colour handed to strokerPolylineStrokeAA[Thin] */
+	float stroke_width;    /* strokeWidth handed to strokerPolylineStroke[AA] (already scaled/clamped) */
+	float scale;           /* pathReset/strokerReset scale (State::m_AvgScale) */
+	float tess_tol;        /* tesselationTolerance (Context::m_TesselationTolerance) */
+	float fringe;          /* fringeWidth (Context::m_FringeWidth) */
+	float mtx[6];          /* 2x3 state transform [m0 m2 m4; m1 m3 m5] used by transformPath */
+	uint32_t reserved;     /* must be 0 */
+} vgx_draw;
+
+/* Path definitions ("path set"), host-side description handed to vgx_pathset_create.
+ * cmd_arg_off has ncmd+1 entries: command k owns args[cmd_arg_off[k] .. cmd_arg_off[k+1]).
+ * path p owns commands [path_cmd_begin[p], path_cmd_begin[p+1]). */
+typedef struct vgx_pathset_desc {
+	const uint8_t* cmd_type;        /* [ncmd]   vgx_cmd */
+	const uint32_t* cmd_arg_off;    /* [ncmd+1] */
+	const float* args;              /* [cmd_arg_off[ncmd]] */
+	const uint32_t* path_cmd_begin; /* [npaths+1] */
+	uint32_t npaths;
+	uint32_t ncmd;
+} vgx_pathset_desc;
+
+/* vg::SubPath (include/vg/path.h:11-16) with batch-global addressing. 16 bytes. */
+typedef struct vgx_subpath {
+	uint64_t first_vertex; /* index into the batch's polyline vertex array */
+	uint32_t num_vertices;
+	uint32_t flags;        /* bit0 = isClosed */
+} vgx_subpath;
+
+/* Where one draw's data lives in the flatten output. 40 bytes. */
+typedef struct vgx_draw_info {
+	uint64_t first_poly_vertex;
+	uint64_t first_subpath;
+	uint64_t first_mesh;
+	uint32_t num_poly_vertices; /* pathGetNumVertices */
+	uint32_t num_subpaths;      /* pathGetNumSubPaths */
+	uint32_t num_meshes;
+	uint32_t flags;             /* bit0: went through the serial (exact, slow) lane path */
+} vgx_draw_info;
+
+/* vg::Mesh (include/vg/vg.h:353-360) with batch-global addressing. 32 bytes.
+ * Meshes of a draw appear in the reference's call order: fill meshes by sub-path, then stroke
+ * meshes by sub-path. Indices are mesh-local. */
+typedef struct vgx_mesh {
+	uint64_t first_vertex; /* into pos / color streams */
+	uint64_t first_index;  /* into idx stream */
+	uint32_t num_vertices;
+	uint32_t num_indices;
+	uint32_t draw;
+	uint32_t subpath_kind; /* bits 0-27 sub-path index within the draw, bits 28-31 VGX_MESH_* */
+} vgx_mesh;
+enum { VGX_MESH_FILL = 0, VGX_MESH_FILL_AA = 1, VGX_MESH_STROKE = 2, VGX_MESH_STROKE_AA = 3, VGX_MESH_STROKE_AA_THIN = 4 };
+
+/* Totals of a batch. Filled by the *_count calls (host struct). */
+typedef struct vgx_sizes {
+	uint64_t num_poly_vertices;
+	uint64_t num_subpaths;
+	uint64_t num_meshes;
+	uint64_t num_vertices;
+	uint64_t num_indices;
+	uint64_t num_serial_draws; /* draws that needed the exact serial lane path (degenerate input) */
+} vgx_sizes;
+
+/* Flatten output (pathGetVertices / pathGetSubPaths for every draw). NULL members are skipped. */
+typedef struct vgx_flat_out {
+	float* poly;              /* [cap_poly_vertices][2] */
+	vgx_subpath* subpaths;    /* [cap_subpaths] */
+	vgx_draw_info* draw_info; /* [ndraws] */
+	uint64_t cap_poly_vertices;
+	uint64_t cap_subpaths;
+} vgx_flat_out;
+
+/* Tessellation output: the three vg::Mesh streams concatenated mesh after mesh + a mesh table. */
+typedef struct vgx_mesh_out {
+	float* pos;       /* [cap_vertices][2] */
+	uint32_t* color;  /* [cap_vertices]; non-AA meshes get the draw's colour on every vertex */
+	uint16_t* idx;    /* [cap_indices] */
+	vgx_mesh* meshes; /* [cap_meshes] */
+	uint64_t cap_vertices;
+	uint64_t cap_indices;
+	uint64_t cap_meshes;
+} vgx_mesh_out;
+
+typedef struct vgx_ctx vgx_ctx;         /* per-device context: scratch, scan storage, error state */
+typedef struct vgx_pathset vgx_pathset; /* validated path definitions resident in device memory */
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* Replaces createPath/createStroker (path.cpp:23-32, stroker.cpp:194-203): owns all scratch. */
+int vgx_create(int device, vgx_ctx** out_ctx);
+int vgx_destroy(vgx_ctx* ctx);
+int vgx_last_hip_error(const vgx_ctx* ctx);
+const char* vgx_status_string(int status);
+uint32_t vgx_version(void);
+/* Bytes of device scratch currently held by the context (polyline staging, tables, scan temp). */
+uint64_t vgx_scratch_bytes(const vgx_ctx* ctx);
+
+/* ---- path definitions --------------------------------------------------------------------- */
+/* Validates (host) and uploads a path set. Grammar per path: first command must start a sub-path
+ * (MOVE_TO, ARC, or a closed shape RECT, ROUNDED_RECT[_VARYING], CIRCLE, ELLIPSE); after CLOSE or a closed
+ * shape the next command must start a sub-path again (the reference only VG_CHECKs this in debug
+ * builds, path.cpp:82,88,764-765). Non-finite arguments are rejected. Synchronous. */
+int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset** out_ps);
+int vgx_pathset_destroy(vgx_ctx* ctx, vgx_pathset* ps);
+
+/* ---- flatten: pathReset + path commands (+ optional transformPath) ------------------------- */
+/* `draws` is a DEVICE pointer to ndraws vgx_draw records. apply_transform != 0 writes the
+ * transformed polyline (what the stroker consumes); 0 writes pathGetVertices as-is.
+ * _count runs count+scan and returns totals (synchronises the stream once to read them back);
+ * _emit must follow with the same arguments and DEVICE output buffers of at least those sizes. */
+int vgx_flatten_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, vgx_sizes* out_sizes, void* stream);
+int vgx_flatten_emit(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, int apply_transform, const vgx_flat_out* out, void* stream);
+
+/* ---- tessellate: flatten + transformPath + one strokerXXX call per sub-path per op --------- */
+/* _count: flatten into context scratch, size every mesh, scan; returns totals (one stream sync).
+ * _emit: writes pos/color/idx/meshes (DEVICE buffers). Must follow _count with the same batch. */
+int vgx_tessellate_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, vgx_sizes* out_sizes, void* stream);
+int vgx_tessellate_emit(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, const vgx_mesh_out* out, void* stream);
+/* Single asynchronous call for steady state: count + scan + emit with NO host round trip. Output
+ * capacities are checked on the device; `dev_sizes` (DEVICE vgx_sizes, may be NULL) receives the
+ * totals and `dev_status` (DEVICE uint32, may be NULL) receives VGX_OK / VGX_E_NOSPACE / ... . */
+int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream);
+
+/* Per-kernel timing of the last vgx_tessellate.. / vgx_flatten.. sequence, measured with HIP events
+ * on the stream the kernels ran on. Enable before the call; read after synchronising. */
+#define VGX_MAX_STAGES 16
+typedef struct vgx_stage_times {
+	uint32_t num_stages;
+	float ms[VGX_MAX_STAGES];
+	const char* name[VGX_MAX_STAGES];
+} vgx_stage_times;
+int vgx_set_profiling(vgx_ctx* ctx, int enable);
+int vgx_get_stage_times(vgx_ctx* ctx, vgx_stage_times* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VGX_H */

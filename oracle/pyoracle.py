@@ -1,0 +1,102 @@
+"""ctypes loader for the CPU oracles.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package never does (the HIP path fails loudly instead of falling back to it).
+
+kind="reference": oracle/_ref/libvgref.so  = the reference's own src/path.cpp + src/stroker.cpp compiled
+                  against oracle/bx_shim + csrc/vgmath.h (built by oracle/Makefile when /root/reference exists)
+kind="port":      oracle/libvgoracle.so    = the restatement oracle/vgo_port.cpp
+Parity status: pinned against the reference source itself run here; the bx transcendentals
+(acos/atan2/cos/sin/tan/rsqrt) are UNPINNED upstream (bx not vendored, no version) and are defined by
+csrc/vgmath.h for oracle and kernels alike.
+"""
+import ctypes as C
+import importlib
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_pkg = importlib.import_module("vg-renderer_amd")
+capi = _pkg.capi
+
+_PATHS = {
+    "reference": os.path.join(_HERE, "_ref", "libvgref.so"),
+    "reference_sse": os.path.join(_HERE, "_ref", "libvgref_sse.so"),
+    "port": os.path.join(_HERE, "libvgoracle.so"),
+}
+_libs = {}
+
+
+def available(kind):
+    return os.path.exists(_PATHS[kind])
+
+
+def load(kind="port"):
+    if kind in _libs:
+        return _libs[kind]
+    lib = C.CDLL(_PATHS[kind])
+    lib.vgo_flatten.restype = C.c_int
+    lib.vgo_flatten.argtypes = [C.POINTER(capi.PathSetDesc), C.c_void_p, C.c_uint64, C.c_int, C.POINTER(capi.FlatOut), C.POINTER(capi.Sizes)]
+    lib.vgo_tessellate.restype = C.c_int
+    lib.vgo_tessellate.argtypes = [C.POINTER(capi.PathSetDesc), C.c_void_p, C.c_uint64, C.POINTER(capi.FlatOut), C.POINTER(capi.MeshOut), C.POINTER(capi.Sizes)]
+    lib.vgo_engine_name.restype = C.c_char_p
+    _libs[kind] = lib
+    return lib
+
+
+class FlatResult:
+    pass
+
+
+class MeshResult:
+    pass
+
+
+def flatten(ps, draws, apply_transform=False, kind="port"):
+    """ps: PathSetArrays, draws: ndarray(draw_dtype). Returns FlatResult with numpy arrays."""
+    lib = load(kind)
+    draws = np.ascontiguousarray(draws)
+    n = draws.shape[0]
+    desc = ps.desc()
+    sizes = capi.Sizes()
+    st = lib.vgo_flatten(C.byref(desc), draws.ctypes.data, n, int(apply_transform), None, C.byref(sizes))
+    assert st == 0, st
+    r = FlatResult()
+    r.poly = np.zeros((sizes.num_poly_vertices, 2), dtype=np.float32)
+    r.subpaths = np.zeros(sizes.num_subpaths, dtype=capi.subpath_dtype)
+    r.draw_info = np.zeros(n, dtype=capi.draw_info_dtype)
+    fo = capi.FlatOut(r.poly.ctypes.data, r.subpaths.ctypes.data, r.draw_info.ctypes.data, sizes.num_poly_vertices, sizes.num_subpaths)
+    st = lib.vgo_flatten(C.byref(desc), draws.ctypes.data, n, int(apply_transform), C.byref(fo), C.byref(sizes))
+    assert st == 0, st
+    r.sizes = sizes.as_dict()
+    return r
+
+
+def tessellate(ps, draws, kind="port", want_flat=False, count_only=False):
+    lib = load(kind)
+    draws = np.ascontiguousarray(draws)
+    n = draws.shape[0]
+    desc = ps.desc()
+    sizes = capi.Sizes()
+    st = lib.vgo_tessellate(C.byref(desc), draws.ctypes.data, n, None, None, C.byref(sizes))
+    assert st == 0, st
+    r = MeshResult()
+    r.sizes = sizes.as_dict()
+    if count_only:
+        return r
+    r.pos = np.zeros((sizes.num_vertices, 2), dtype=np.float32)
+    r.color = np.zeros(sizes.num_vertices, dtype=np.uint32)
+    r.idx = np.zeros(sizes.num_indices, dtype=np.uint16)
+    r.meshes = np.zeros(sizes.num_meshes, dtype=capi.mesh_dtype)
+    mo = capi.MeshOut(r.pos.ctypes.data, r.color.ctypes.data, r.idx.ctypes.data, r.meshes.ctypes.data,
+                      sizes.num_vertices, sizes.num_indices, sizes.num_meshes)
+    fo_ref = None
+    if want_flat:
+        r.poly = np.zeros((sizes.num_poly_vertices, 2), dtype=np.float32)
+        r.subpaths = np.zeros(sizes.num_subpaths, dtype=capi.subpath_dtype)
+        r.draw_info = np.zeros(n, dtype=capi.draw_info_dtype)
+        fo = capi.FlatOut(r.poly.ctypes.data, r.subpaths.ctypes.data, r.draw_info.ctypes.data, sizes.num_poly_vertices, sizes.num_subpaths)
+        fo_ref = C.byref(fo)
+    st = lib.vgo_tessellate(C.byref(desc), draws.ctypes.data, n, fo_ref, C.byref(mo), C.byref(sizes))
+    assert st == 0, st
+    return r

@@ -1,0 +1,229 @@
+// vgo_driver.inl -- batch driver shared by the two CPU oracles (TEST INFRASTRUCTURE, not product).
+//
+// Included by oracle/ref_capi.cpp  with VGO_ENGINE = vg   (the reference's own compiled sources) and
+// by          oracle/port_capi.cpp with VGO_ENGINE = vgo  (the restatement in oracle/vgo_port.cpp).
+// VGO_XFORM names the scalar batchTransformPositions of that engine.
+//
+// For every draw it does exactly what the reference's callers do around the hot path:
+//   ctxBeginPath     -> pathReset + strokerReset                      (src/vg.cpp:2969-2981)
+//   ctxMoveTo/...    -> pathXXX                                       (src/vg.cpp:2983-3059)
+//   transformPath    -> vgutil::batchTransformPositions               (src/vg.cpp:4957-4975)
+//   ctxFillPathColor -> strokerConvexFill[AA] per sub-path >= 3 verts (src/vg.cpp:3099-3131)
+//   ctxStrokePath... -> strokerPolylineStroke[AA|AAThin] per sub-path >= 2 verts (src/vg.cpp:3448-3485)
+// and appends the returned vg::Mesh to contiguous streams, the way createDrawCommand_VertexColor
+// copies them (src/vg.cpp:5207-5244). Output layout is the one documented in include/vgx.h.
+
+#include "../include/vgx.h"
+#include <vector>
+#include <string.h>
+
+namespace {
+
+struct VgoArgCount { int n; };
+static const int kArgCount[VGX_CMD_COUNT_] = { 2, 2, 6, 4, 0, 5, 6, 4, 5, 8, 3, 4, -1 };
+
+struct VgoEngineState
+{
+	bx::ShimAllocator alloc;
+	VGO_ENGINE::Path* path;
+	VGO_ENGINE::Stroker* stroker;
+	std::vector<float> xf;
+	VgoEngineState() { path = VGO_ENGINE::createPath(&alloc); stroker = VGO_ENGINE::createStroker(&alloc); }
+	~VgoEngineState() { VGO_ENGINE::destroyStroker(stroker); VGO_ENGINE::destroyPath(path); }
+};
+
+static void vgoReplay(VGO_ENGINE::Path* path, const vgx_pathset_desc* ps, uint32_t pathID)
+{
+	using namespace VGO_ENGINE;
+	const uint32_t c0 = ps->path_cmd_begin[pathID];
+	const uint32_t c1 = ps->path_cmd_begin[pathID + 1];
+	for (uint32_t c = c0; c < c1; ++c) {
+		const float* a = &ps->args[ps->cmd_arg_off[c]];
+		const uint32_t na = ps->cmd_arg_off[c + 1] - ps->cmd_arg_off[c];
+		switch (ps->cmd_type[c]) {
+		case VGX_CMD_MOVE_TO: pathMoveTo(path, a[0], a[1]); break;
+		case VGX_CMD_LINE_TO: pathLineTo(path, a[0], a[1]); break;
+		case VGX_CMD_CUBIC_TO: pathCubicTo(path, a[0], a[1], a[2], a[3], a[4], a[5]); break;
+		case VGX_CMD_QUAD_TO: pathQuadraticTo(path, a[0], a[1], a[2], a[3]); break;
+		case VGX_CMD_CLOSE: pathClose(path); break;
+		case VGX_CMD_ARC_TO: pathArcTo(path, a[0], a[1], a[2], a[3], a[4]); break;
+		case VGX_CMD_ARC: pathArc(path, a[0], a[1], a[2], a[3], a[4], a[5] != 0.0f ? Winding::CW : Winding::CCW); break;
+		case VGX_CMD_RECT: pathRect(path, a[0], a[1], a[2], a[3]); break;
+		case VGX_CMD_ROUNDED_RECT: pathRoundedRect(path, a[0], a[1], a[2], a[3], a[4]); break;
+		case VGX_CMD_ROUNDED_RECT_VARYING: pathRoundedRectVarying(path, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]); break;
+		case VGX_CMD_CIRCLE: pathCircle(path, a[0], a[1], a[2]); break;
+		case VGX_CMD_ELLIPSE: pathEllipse(path, a[0], a[1], a[2], a[3]); break;
+		case VGX_CMD_POLYLINE: pathPolyline(path, a, na / 2); break;
+		default: break;
+		}
+	}
+}
+
+struct VgoSink
+{
+	vgx_mesh_out* out;
+	vgx_sizes* sizes;
+	bool overflow;
+
+	void add(const VGO_ENGINE::Mesh& m, uint32_t uniformColor, uint32_t draw, uint32_t subpath, uint32_t kind)
+	{
+		const uint64_t v0 = sizes->num_vertices;
+		const uint64_t i0 = sizes->num_indices;
+		const uint64_t m0 = sizes->num_meshes;
+		sizes->num_vertices += m.m_NumVertices;
+		sizes->num_indices += m.m_NumIndices;
+		sizes->num_meshes += 1;
+		if (!out) {
+			return;
+		}
+		if (sizes->num_vertices > out->cap_vertices || sizes->num_indices > out->cap_indices || sizes->num_meshes > out->cap_meshes) {
+			overflow = true;
+			return;
+		}
+		if (out->pos) { memcpy(out->pos + v0 * 2, m.m_PosBuffer, sizeof(float) * 2 * m.m_NumVertices); }
+		if (out->color) {
+			if (m.m_ColorBuffer) {
+				memcpy(out->color + v0, m.m_ColorBuffer, sizeof(uint32_t) * m.m_NumVertices);
+			} else {
+				for (uint32_t i = 0; i < m.m_NumVertices; ++i) { out->color[v0 + i] = uniformColor; }
+			}
+		}
+		if (out->idx) { memcpy(out->idx + i0, m.m_IndexBuffer, sizeof(uint16_t) * m.m_NumIndices); }
+		if (out->meshes) {
+			vgx_mesh& r = out->meshes[m0];
+			r.first_vertex = v0;
+			r.first_index = i0;
+			r.num_vertices = m.m_NumVertices;
+			r.num_indices = m.m_NumIndices;
+			r.draw = draw;
+			r.subpath_kind = (subpath & 0x0FFFFFFFu) | (kind << 28);
+		}
+	}
+};
+
+static int vgoRun(const vgx_pathset_desc* ps, const vgx_draw* draws, uint64_t ndraws, int applyTransform, const vgx_flat_out* flat, vgx_mesh_out* meshOut, bool tessellate, vgx_sizes* sizes)
+{
+	using namespace VGO_ENGINE;
+	if (!ps || (!draws && ndraws) || !sizes) {
+		return VGX_E_INVALID_ARG;
+	}
+	memset(sizes, 0, sizeof(*sizes));
+	VgoEngineState st;
+	VgoSink sink = { meshOut, sizes, false };
+	bool flatOverflow = false;
+
+	for (uint64_t d = 0; d < ndraws; ++d) {
+		const vgx_draw& dr = draws[d];
+		if (dr.path >= ps->npaths) {
+			return VGX_E_INVALID_ARG;
+		}
+		pathReset(st.path, dr.scale, dr.tess_tol);
+		strokerReset(st.stroker, dr.scale, dr.tess_tol, dr.fringe);
+		vgoReplay(st.path, ps, dr.path);
+
+		const uint32_t nv = pathGetNumVertices(st.path);
+		const uint32_t nsp = pathGetNumSubPaths(st.path);
+		const float* verts = pathGetVertices(st.path);
+		const SubPath* sp = pathGetSubPaths(st.path);
+		if (st.xf.size() < (size_t)nv * 2 + 2) { st.xf.resize((size_t)nv * 2 + 2); }
+		if (nv) { VGO_XFORM(verts, nv, st.xf.data(), dr.mtx); }
+
+		const uint64_t pv0 = sizes->num_poly_vertices;
+		const uint64_t sp0 = sizes->num_subpaths;
+		const uint64_t mesh0 = sizes->num_meshes;
+		sizes->num_poly_vertices += nv;
+		sizes->num_subpaths += nsp;
+
+		if (flat) {
+			if (sizes->num_poly_vertices > flat->cap_poly_vertices || sizes->num_subpaths > flat->cap_subpaths) {
+				flatOverflow = true;
+			} else {
+				if (flat->poly && nv) { memcpy(flat->poly + pv0 * 2, applyTransform ? st.xf.data() : verts, sizeof(float) * 2 * nv); }
+				if (flat->subpaths) {
+					for (uint32_t i = 0; i < nsp; ++i) {
+						vgx_subpath& o = flat->subpaths[sp0 + i];
+						o.first_vertex = pv0 + sp[i].m_FirstVertexID;
+						o.num_vertices = sp[i].m_NumVertices;
+						o.flags = sp[i].m_IsClosed ? 1u : 0u;
+					}
+				}
+			}
+		}
+
+		if (tessellate) {
+			const float* tv = st.xf.data();
+			if (dr.fill_flags & VGX_FILL_ENABLE) {
+				for (uint32_t i = 0; i < nsp; ++i) {
+					if (sp[i].m_NumVertices < 3) { continue; }
+					Mesh mesh;
+					const float* vtx = &tv[sp[i].m_FirstVertexID << 1];
+					if (dr.fill_flags & VGX_FILL_AA) {
+						strokerConvexFillAA(st.stroker, &mesh, vtx, sp[i].m_NumVertices, dr.fill_color);
+						sink.add(mesh, dr.fill_color, (uint32_t)d, i, VGX_MESH_FILL_AA);
+					} else {
+						strokerConvexFill(st.stroker, &mesh, vtx, sp[i].m_NumVertices);
+						sink.add(mesh, dr.fill_color, (uint32_t)d, i, VGX_MESH_FILL);
+					}
+				}
+			}
+			if (dr.stroke_flags & VGX_STROKE_ENABLE) {
+				const LineCap::Enum cap = (LineCap::Enum)VGX_STROKE_CAP(dr.stroke_flags);
+				const LineJoin::Enum join = (LineJoin::Enum)VGX_STROKE_JOIN(dr.stroke_flags);
+				if ((uint32_t)cap > 2 || (uint32_t)join > 2) {
+					return VGX_E_INVALID_ARG;
+				}
+				for (uint32_t i = 0; i < nsp; ++i) {
+					if (sp[i].m_NumVertices < 2) { continue; }
+					Mesh mesh;
+					const float* vtx = &tv[sp[i].m_FirstVertexID << 1];
+					const bool closed = sp[i].m_IsClosed;
+					if (dr.stroke_flags & VGX_STROKE_AA) {
+						if (dr.stroke_flags & VGX_STROKE_THIN) {
+							strokerPolylineStrokeAAThin(st.stroker, &mesh, vtx, sp[i].m_NumVertices, closed, dr.stroke_color, cap, join);
+							sink.add(mesh, dr.stroke_color, (uint32_t)d, i, VGX_MESH_STROKE_AA_THIN);
+						} else {
+							strokerPolylineStrokeAA(st.stroker, &mesh, vtx, sp[i].m_NumVertices, closed, dr.stroke_color, dr.stroke_width, cap, join);
+							sink.add(mesh, dr.stroke_color, (uint32_t)d, i, VGX_MESH_STROKE_AA);
+						}
+					} else {
+						strokerPolylineStroke(st.stroker, &mesh, vtx, sp[i].m_NumVertices, closed, dr.stroke_width, cap, join);
+						sink.add(mesh, dr.stroke_color, (uint32_t)d, i, VGX_MESH_STROKE);
+					}
+				}
+			}
+		}
+
+		if (flat && flat->draw_info && !flatOverflow) {
+			vgx_draw_info& di = flat->draw_info[d];
+			di.first_poly_vertex = pv0;
+			di.first_subpath = sp0;
+			di.first_mesh = mesh0;
+			di.num_poly_vertices = nv;
+			di.num_subpaths = nsp;
+			di.num_meshes = (uint32_t)(sizes->num_meshes - mesh0);
+			di.flags = 0;
+		}
+	}
+	return (flatOverflow || sink.overflow) ? VGX_E_NOSPACE : VGX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+// Flatten only. flat == NULL -> count only.
+int vgo_flatten(const vgx_pathset_desc* ps, const vgx_draw* draws, uint64_t ndraws, int applyTransform, const vgx_flat_out* flat, vgx_sizes* sizes)
+{
+	return vgoRun(ps, draws, ndraws, applyTransform, flat, nullptr, false, sizes);
+}
+
+// Flatten + transform + stroker. out == NULL -> count only. flat (optional) also receives the
+// transformed polyline and sub-path tables.
+int vgo_tessellate(const vgx_pathset_desc* ps, const vgx_draw* draws, uint64_t ndraws, const vgx_flat_out* flat, vgx_mesh_out* out, vgx_sizes* sizes)
+{
+	return vgoRun(ps, draws, ndraws, 1, flat, out, true, sizes);
+}
+
+const char* vgo_engine_name(void) { return VGO_ENGINE_NAME; }
+
+} // extern "C"

@@ -1,0 +1,120 @@
+"""ctypes/numpy mirror of include/vgx.h (the C-ABI of libvgx.so).
+
+Plumbing only: struct layouts, enums and the function prototypes. The same struct layouts are used by
+the CPU oracles under oracle/ (they export vgo_* entry points with host pointers).
+"""
+import ctypes as C
+import numpy as np
+
+# ---- enums (include/vgx.h) -------------------------------------------------------------------
+VGX_OK = 0
+VGX_E_INVALID_ARG = 1
+VGX_E_INVALID_PATH = 2
+VGX_E_NONFINITE = 3
+VGX_E_NOSPACE = 4
+VGX_E_MESH_TOO_LARGE = 5
+VGX_E_HIP = 6
+VGX_E_NO_DEVICE = 7
+VGX_E_RANGE = 8
+
+CMD_MOVE_TO, CMD_LINE_TO, CMD_CUBIC_TO, CMD_QUAD_TO, CMD_CLOSE = 0, 1, 2, 3, 4
+CMD_ARC_TO, CMD_ARC, CMD_RECT, CMD_ROUNDED_RECT, CMD_ROUNDED_RECT_VARYING = 5, 6, 7, 8, 9
+CMD_CIRCLE, CMD_ELLIPSE, CMD_POLYLINE = 10, 11, 12
+CMD_ARG_COUNT = [2, 2, 6, 4, 0, 5, 6, 4, 5, 8, 3, 4, -1]
+
+CAP_BUTT, CAP_ROUND, CAP_SQUARE = 0, 1, 2
+JOIN_MITER, JOIN_ROUND, JOIN_BEVEL = 0, 1, 2
+
+FILL_ENABLE, FILL_AA = 0x1, 0x2
+STROKE_ENABLE, STROKE_AA, STROKE_THIN = 0x1, 0x2, 0x4
+
+MESH_FILL, MESH_FILL_AA, MESH_STROKE, MESH_STROKE_AA, MESH_STROKE_AA_THIN = 0, 1, 2, 3, 4
+
+
+def stroke_flags(cap, join, aa=True, thin=False):
+    return STROKE_ENABLE | (STROKE_AA if aa else 0) | (STROKE_THIN if thin else 0) | (cap << 4) | (join << 6)
+
+
+def fill_flags(aa=True):
+    return FILL_ENABLE | (FILL_AA if aa else 0)
+
+
+# ---- numpy record layouts ---------------------------------------------------------------------
+draw_dtype = np.dtype([
+    ("path", "<u4"), ("fill_flags", "<u4"), ("fill_color", "<u4"), ("stroke_flags", "<u4"),
+    ("stroke_color", "<u4"), ("stroke_width", "<f4"), ("scale", "<f4"), ("tess_tol", "<f4"),
+    ("fringe", "<f4"), ("mtx", "<f4", (6,)), ("reserved", "<u4")])
+assert draw_dtype.itemsize == 64
+
+subpath_dtype = np.dtype([("first_vertex", "<u8"), ("num_vertices", "<u4"), ("flags", "<u4")])
+assert subpath_dtype.itemsize == 16
+
+draw_info_dtype = np.dtype([
+    ("first_poly_vertex", "<u8"), ("first_subpath", "<u8"), ("first_mesh", "<u8"),
+    ("num_poly_vertices", "<u4"), ("num_subpaths", "<u4"), ("num_meshes", "<u4"), ("flags", "<u4")])
+assert draw_info_dtype.itemsize == 40
+
+mesh_dtype = np.dtype([
+    ("first_vertex", "<u8"), ("first_index", "<u8"), ("num_vertices", "<u4"), ("num_indices", "<u4"),
+    ("draw", "<u4"), ("subpath_kind", "<u4")])
+assert mesh_dtype.itemsize == 32
+
+
+# ---- ctypes structs ---------------------------------------------------------------------------
+class Sizes(C.Structure):
+    _fields_ = [("num_poly_vertices", C.c_uint64), ("num_subpaths", C.c_uint64), ("num_meshes", C.c_uint64),
+                ("num_vertices", C.c_uint64), ("num_indices", C.c_uint64), ("num_serial_draws", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class PathSetDesc(C.Structure):
+    _fields_ = [("cmd_type", C.c_void_p), ("cmd_arg_off", C.c_void_p), ("args", C.c_void_p),
+                ("path_cmd_begin", C.c_void_p), ("npaths", C.c_uint32), ("ncmd", C.c_uint32)]
+
+
+class FlatOut(C.Structure):
+    _fields_ = [("poly", C.c_void_p), ("subpaths", C.c_void_p), ("draw_info", C.c_void_p),
+                ("cap_poly_vertices", C.c_uint64), ("cap_subpaths", C.c_uint64)]
+
+
+class MeshOut(C.Structure):
+    _fields_ = [("pos", C.c_void_p), ("color", C.c_void_p), ("idx", C.c_void_p), ("meshes", C.c_void_p),
+                ("cap_vertices", C.c_uint64), ("cap_indices", C.c_uint64), ("cap_meshes", C.c_uint64)]
+
+
+VGX_MAX_STAGES = 16
+
+
+class StageTimes(C.Structure):
+    _fields_ = [("num_stages", C.c_uint32), ("ms", C.c_float * VGX_MAX_STAGES), ("name", C.c_char_p * VGX_MAX_STAGES)]
+
+
+# Every symbol include/vgx.h declares, with (restype, argtypes). tests/test_capi_symbols.py checks the
+# built library exports all of them.
+VGX_SYMBOLS = {
+    "vgx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "vgx_destroy": (C.c_int, [C.c_void_p]),
+    "vgx_last_hip_error": (C.c_int, [C.c_void_p]),
+    "vgx_status_string": (C.c_char_p, [C.c_int]),
+    "vgx_version": (C.c_uint32, []),
+    "vgx_scratch_bytes": (C.c_uint64, [C.c_void_p]),
+    "vgx_pathset_create": (C.c_int, [C.c_void_p, C.POINTER(PathSetDesc), C.POINTER(C.c_void_p)]),
+    "vgx_pathset_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vgx_flatten_count": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Sizes), C.c_void_p]),
+    "vgx_flatten_emit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(FlatOut), C.c_void_p]),
+    "vgx_tessellate_count": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Sizes), C.c_void_p]),
+    "vgx_tessellate_emit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(MeshOut), C.c_void_p]),
+    "vgx_tessellate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(MeshOut), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vgx_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "vgx_get_stage_times": (C.c_int, [C.c_void_p, C.POINTER(StageTimes)]),
+}
+
+
+def bind(lib, symbols):
+    for name, (res, args) in symbols.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib

@@ -1,0 +1,270 @@
+"""Seeded synthetic workloads for BASELINE.json's configs.
+
+All generators are pure numpy on np.random.RandomState (frozen stream => identical inputs in this
+container and on the GPU box) and return (PathSetArrays, draws ndarray[draw_dtype]).
+
+config 0  single_cubic()            one cubic -> 16-segment polyline, Butt/Miter AA stroke
+config 1  random_cubics(1M)         independent cubics, flatten only
+config 2  tiger(K)                  "tiger-like" 240-path drawing x K instances, convexFillAA + strokeAA
+config 3  random_walk_polylines()   10k polylines x 1k segments, Round caps + Round joins
+config 4  tiger(80k) sharded 8 ways (see dist.py)
+
+The Ghostscript tiger itself is not in the reference (only a screenshot, img/vgrenderer_tiger.png) and
+there is no network, so config 2 uses a seeded generator with the tiger's structure: 240 paths, closed
+smooth cubic sub-paths of very different sizes, every path filled, about a third also stroked with a
+mix of hairline (Thin) and regular widths.
+"""
+import numpy as np
+from . import capi
+from .pathset import PathSetBuilder, make_draws
+
+
+def _color(r, g, b, a=255):
+    return (a << 24) | (b << 16) | (g << 8) | r
+
+
+def set_fill(draws, sel, color, aa=True):
+    draws["fill_flags"][sel] = capi.fill_flags(aa)
+    draws["fill_color"][sel] = color
+
+
+def set_stroke(draws, sel, color, width, cap=capi.CAP_BUTT, join=capi.JOIN_MITER, aa=True, avg_scale=1.0,
+               fringe=1.0, global_alpha=1.0, fixed_width=False):
+    """Mirror of the caller logic in ctxStrokePathColor (reference src/vg.cpp:3416-3433): scales and
+    clamps the width, switches to the Thin stroker when width <= fringe and scales alpha by width^2."""
+    sw = np.float32(width) if fixed_width else np.float32(min(max(np.float32(width) * np.float32(avg_scale), 0.0), 200.0))
+    thin = bool(sw <= np.float32(fringe))
+    alpha_scale = np.float32(global_alpha)
+    if thin:
+        c = np.float32(min(max(sw, np.float32(0.0)), np.float32(fringe)))
+        alpha_scale = np.float32(global_alpha) * (c * c)
+    a = (color >> 24) & 0xFF
+    col = (color & 0x00FFFFFF) | (int(np.uint8(np.float32(alpha_scale) * np.float32(a))) << 24)
+    draws["stroke_flags"][sel] = capi.stroke_flags(cap, join, aa, thin and aa)
+    draws["stroke_color"][sel] = col
+    draws["stroke_width"][sel] = np.float32(fringe) if thin else sw
+    return thin
+
+
+# ---- config 0 ----------------------------------------------------------------------------------
+def single_cubic():
+    b = PathSetBuilder()
+    b.begin_path()
+    b.move_to(0, 0)
+    b.cubic_to(22.5, 0, 45, 22.5, 45, 45)
+    b.end_path()
+    d = make_draws(1)
+    set_stroke(d, 0, 0xFF0000FF, 10.0)
+    return b.arrays(), d
+
+
+# ---- config 1 ----------------------------------------------------------------------------------
+def random_cubics(n, seed=1234, box=1000.0):
+    """n independent paths, each moveTo + cubicTo with 8 coordinates uniform in [0, box).
+    Portable mapping: 24 random bits * 2^-24 * box (SURVEY 8d, config 2 note)."""
+    rs = np.random.RandomState(seed)
+    bits = rs.randint(0, 1 << 24, size=(n, 8)).astype(np.float32)
+    pts = bits * np.float32(2.0 ** -24) * np.float32(box)
+    cmd_type = np.tile(np.array([capi.CMD_MOVE_TO, capi.CMD_CUBIC_TO], dtype=np.uint8), n)
+    arg_off = np.zeros(2 * n + 1, dtype=np.uint32)
+    arg_off[1::2] = np.arange(n, dtype=np.uint32) * 8 + 2
+    arg_off[2::2] = np.arange(1, n + 1, dtype=np.uint32) * 8
+    path_begin = np.arange(n + 1, dtype=np.uint32) * 2
+    from .pathset import PathSetArrays
+    ps = PathSetArrays(cmd_type, arg_off, pts.reshape(-1), path_begin)
+    d = make_draws(n)
+    d["path"] = np.arange(n, dtype=np.uint32)
+    return ps, d
+
+
+# ---- config 2 ----------------------------------------------------------------------------------
+TIGER_PALETTE = [_color(*c) for c in [
+    (255, 255, 255), (0, 0, 0), (204, 114, 38), (233, 127, 58), (242, 204, 153), (229, 102, 140),
+    (178, 52, 41), (165, 38, 12), (255, 114, 127), (101, 153, 0), (153, 204, 50), (76, 0, 0),
+    (153, 38, 0), (234, 142, 81), (76, 76, 76), (204, 204, 204)]]
+
+
+def tiger_paths(seed=2024, npaths=240):
+    """Seeded tiger-like drawing: returns (PathSetArrays, per-path op table).
+    ops[p] = dict(fill_color, stroke (bool), stroke_color, stroke_width)."""
+    rs = np.random.RandomState(seed)
+    b = PathSetBuilder()
+    ops = []
+    for p in range(npaths):
+        b.begin_path()
+        nsub = int(rs.choice([1, 2, 3], p=[0.7, 0.2, 0.1]))
+        radius = float(np.exp(rs.uniform(np.log(4.0), np.log(120.0))))
+        cx0, cy0 = rs.uniform(100.0, 800.0, size=2)
+        for s in range(nsub):
+            m = int(rs.randint(4, 25))  # cubic segments in this closed sub-path
+            cx = cx0 + rs.uniform(-radius, radius) * 0.5
+            cy = cy0 + rs.uniform(-radius, radius) * 0.5
+            r_s = radius * rs.uniform(0.4, 1.0)
+            ang = np.sort(rs.uniform(0.0, 2.0 * np.pi, size=m)) + rs.uniform(0, 2 * np.pi)
+            rad = r_s * rs.uniform(0.55, 1.0, size=m)
+            P = np.stack([cx + rad * np.cos(ang), cy + rad * np.sin(ang)], axis=1).astype(np.float32).astype(np.float64)
+            # closed Catmull-Rom spline -> cubic beziers
+            b.move_to(P[0, 0], P[0, 1])
+            for i in range(m):
+                p0, p1, p2, p3 = P[(i - 1) % m], P[i], P[(i + 1) % m], P[(i + 2) % m]
+                c1 = p1 + (p2 - p0) / 6.0
+                c2 = p2 - (p3 - p1) / 6.0
+                b.cubic_to(c1[0], c1[1], c2[0], c2[1], p2[0], p2[1])
+            b.close()
+        b.end_path()
+        stroke = bool(rs.uniform() < (1.0 / 3.0))
+        ops.append(dict(fill_color=TIGER_PALETTE[int(rs.randint(0, 16))], stroke=stroke,
+                        stroke_color=TIGER_PALETTE[int(rs.randint(0, 16))],
+                        stroke_width=float(rs.choice([0.5, 0.75, 1.0, 1.5, 2.0, 3.0]))))
+    return b.arrays(), ops
+
+
+def tiger_draws(ops, instances, first_instance=0):
+    """Draw records for `instances` copies of the drawing; instance i is translated by
+    (37*(i%100), 41*(i//100)) at scale 1. Draw order = instance-major."""
+    npaths = len(ops)
+    one = make_draws(npaths)
+    one["path"] = np.arange(npaths, dtype=np.uint32)
+    for p, op in enumerate(ops):
+        set_fill(one, p, op["fill_color"], aa=True)
+        if op["stroke"]:
+            set_stroke(one, p, op["stroke_color"], op["stroke_width"], capi.CAP_BUTT, capi.JOIN_MITER, aa=True)
+    d = np.tile(one, instances)
+    inst = np.repeat(np.arange(first_instance, first_instance + instances, dtype=np.int64), npaths)
+    d["mtx"][:, 4] = (37.0 * (inst % 100)).astype(np.float32)
+    d["mtx"][:, 5] = (41.0 * (inst // 100)).astype(np.float32)
+    return d
+
+
+def tiger(instances, seed=2024, first_instance=0):
+    ps, ops = tiger_paths(seed)
+    return ps, tiger_draws(ops, instances, first_instance)
+
+
+# ---- config 3 ----------------------------------------------------------------------------------
+def random_walk_polylines(n=10000, nseg=1000, seed=5678, width=6.0, cap=capi.CAP_ROUND, join=capi.JOIN_ROUND,
+                          step=8.0, turn_sigma=0.5):
+    """n open polylines of nseg segments: start uniform in [0,1000)^2, fixed step, heading += N(0, sigma)."""
+    rs = np.random.RandomState(seed)
+    start = rs.uniform(0.0, 1000.0, size=(n, 2))
+    heading = np.cumsum(rs.normal(0.0, turn_sigma, size=(n, nseg)), axis=1) + rs.uniform(0, 2 * np.pi, size=(n, 1))
+    dxy = np.stack([np.cos(heading), np.sin(heading)], axis=2) * step
+    pts = np.concatenate([start[:, None, :], start[:, None, :] + np.cumsum(dxy, axis=1)], axis=1).astype(np.float32)
+    ncmd_per = nseg + 1
+    cmd_type = np.full((n, ncmd_per), capi.CMD_LINE_TO, dtype=np.uint8)
+    cmd_type[:, 0] = capi.CMD_MOVE_TO
+    arg_off = np.arange(n * ncmd_per + 1, dtype=np.uint32) * 2
+    path_begin = np.arange(n + 1, dtype=np.uint32) * ncmd_per
+    from .pathset import PathSetArrays
+    ps = PathSetArrays(cmd_type.reshape(-1), arg_off, pts.reshape(-1), path_begin)
+    d = make_draws(n)
+    d["path"] = np.arange(n, dtype=np.uint32)
+    set_stroke(d, slice(None), 0xFF2080FF, width, cap, join, aa=True)
+    return ps, d
+
+
+# ---- mixed fuzz set used by the parity tests ---------------------------------------------------
+def fuzz_paths(seed, npaths=64, with_shapes=True, degenerate=True):
+    """Random paths exercising every command and the degenerate cases the reference has branches for
+    (zero-length segments, coincident control points, closing onto the start point, tiny curves)."""
+    rs = np.random.RandomState(seed)
+    b = PathSetBuilder()
+    for p in range(npaths):
+        b.begin_path()
+        nsub = int(rs.randint(1, 4))
+        for s in range(nsub):
+            kind = int(rs.randint(0, 10)) if with_shapes else 0
+            scale = float(rs.choice([1.0, 10.0, 100.0, 400.0]))
+            ox, oy = rs.uniform(-50, 50, size=2)
+            if kind == 6:
+                b.rect(ox, oy, rs.uniform(-1, 1) * scale, rs.uniform(-1, 1) * scale)
+                continue
+            if kind == 7:
+                w, h = rs.uniform(0.2, 1, size=2) * scale
+                if rs.uniform() < 0.3:
+                    h = w
+                if rs.uniform() < 0.5:
+                    b.rounded_rect(ox, oy, w, h, rs.uniform(0, 0.6) * scale)
+                else:
+                    r4 = rs.uniform(0, 0.6, size=4) * scale * (rs.uniform(size=4) < 0.8)
+                    b.rounded_rect_varying(ox, oy, w, h, *r4)
+                continue
+            if kind == 8:
+                if rs.uniform() < 0.5:
+                    b.circle(ox, oy, rs.uniform(0.05, 1) * scale)
+                else:
+                    b.ellipse(ox, oy, rs.uniform(0.05, 1) * scale, rs.uniform(0.05, 1) * scale)
+                continue
+            if kind == 9:
+                b.arc(ox, oy, rs.uniform(0.1, 1) * scale, rs.uniform(-7, 7), rs.uniform(-7, 7), rs.uniform() < 0.5)
+                ncont = int(rs.randint(0, 3))
+            else:
+                b.move_to(ox, oy)
+                ncont = int(rs.randint(1, 12))
+            cx, cy = ox, oy
+            for c in range(ncont):
+                t = int(rs.randint(0, 8))
+                nx, ny = cx + rs.uniform(-1, 1) * scale, cy + rs.uniform(-1, 1) * scale
+                if degenerate and rs.uniform() < 0.08:
+                    nx, ny = cx, cy  # zero-length step
+                if degenerate and rs.uniform() < 0.05:
+                    nx, ny = cx + 1e-3, cy - 2e-3  # inside the epsilon ball
+                if t <= 1:
+                    b.line_to(nx, ny)
+                elif t <= 4:
+                    c1 = (cx + rs.uniform(-1, 1) * scale, cy + rs.uniform(-1, 1) * scale)
+                    c2 = (nx + rs.uniform(-1, 1) * scale, ny + rs.uniform(-1, 1) * scale)
+                    if degenerate and rs.uniform() < 0.1:
+                        c1 = (cx, cy)
+                    if degenerate and rs.uniform() < 0.1:
+                        c2 = (nx, ny)
+                    b.cubic_to(c1[0], c1[1], c2[0], c2[1], nx, ny)
+                elif t == 5:
+                    b.quadratic_to(cx + rs.uniform(-1, 1) * scale, cy + rs.uniform(-1, 1) * scale, nx, ny)
+                elif t == 6 and with_shapes:
+                    b.arc_to(cx + rs.uniform(-1, 1) * scale, cy + rs.uniform(-1, 1) * scale, nx, ny, rs.uniform(0.05, 0.5) * scale)
+                    nx, ny = None, None
+                elif t == 7 and with_shapes:
+                    k = int(rs.randint(1, 6))
+                    pts = np.cumsum(rs.uniform(-1, 1, size=(k, 2)) * scale, axis=0) + np.array([cx, cy])
+                    if degenerate and rs.uniform() < 0.3:
+                        pts[0] = (cx, cy)
+                    b.polyline(pts)
+                    nx, ny = float(np.float32(pts[-1, 0])), float(np.float32(pts[-1, 1]))
+                else:
+                    b.line_to(nx, ny)
+                if nx is None:
+                    # arcTo end point is computed; continue from a fresh random point
+                    cx, cy = cx + rs.uniform(-1, 1) * scale, cy + rs.uniform(-1, 1) * scale
+                else:
+                    cx, cy = nx, ny
+            r = rs.uniform()
+            if r < 0.35:
+                b.close()
+            elif r < 0.5 and ncont >= 2:
+                b.line_to(ox, oy)  # return exactly to the start, then close (pathClose pops it)
+                b.close()
+        b.end_path()
+    return b.arrays()
+
+
+def fuzz_draws(ps, seed, ndraws=None):
+    """Random op/parameter assignment over every stroker entry point the reference exposes."""
+    rs = np.random.RandomState(seed + 77)
+    n = ps.npaths if ndraws is None else ndraws
+    d = make_draws(n)
+    d["path"] = np.arange(n, dtype=np.uint32) % ps.npaths
+    for i in range(n):
+        sc = float(rs.choice([0.5, 1.0, 1.0, 2.0, 7.5]))
+        ang = rs.uniform(0, 2 * np.pi)
+        d["mtx"][i] = [sc * np.cos(ang), sc * np.sin(ang), -sc * np.sin(ang), sc * np.cos(ang), rs.uniform(-100, 100), rs.uniform(-100, 100)]
+        d["scale"][i] = np.float32(sc)
+        d["tess_tol"][i] = np.float32(rs.choice([0.25, 0.25, 0.1, 0.5]))
+        d["fringe"][i] = np.float32(rs.choice([1.0, 1.0, 0.5]))
+        if rs.uniform() < 0.6:
+            set_fill(d, i, int(rs.randint(0, 1 << 32, dtype=np.uint64)), aa=bool(rs.uniform() < 0.75))
+        if rs.uniform() < 0.8:
+            set_stroke(d, i, int(rs.randint(0, 1 << 32, dtype=np.uint64)), float(rs.choice([0.3, 0.9, 1.5, 3.0, 10.0, 40.0])),
+                       int(rs.randint(0, 3)), int(rs.randint(0, 3)), aa=bool(rs.uniform() < 0.75), avg_scale=sc,
+                       fringe=float(d["fringe"][i]))
+    return d

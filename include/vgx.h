@@ -188,6 +188,8 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx);
  * shape the next command must start a sub-path again (the reference only VG_CHECKs this in debug
  * builds, path.cpp:82,88,764-765). Non-finite arguments are rejected. Synchronous. */
 int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset** out_ps);
+/* The validation step of vgx_pathset_create alone (host only, needs no device). */
+int vgx_pathset_validate(const vgx_pathset_desc* desc);
 int vgx_pathset_destroy(vgx_ctx* ctx, vgx_pathset* ps);
 
 /* ---- flatten: pathReset + path commands (+ optional transformPath) ------------------------- */

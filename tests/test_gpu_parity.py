@@ -1,0 +1,106 @@
+"""GPU parity: HIP path (through the C-ABI) vs the CPU oracle on the same seeded inputs.
+Bar: indices / colours / mesh tables / sub-path tables bit-exact, positions bit-exact (0 ulp; the
+north-star tolerance is 1e-4)."""
+import importlib
+
+import numpy as np
+import pytest
+
+from util import assert_flat_equal, assert_mesh_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rt():
+    return importlib.import_module("vg-renderer_amd.runtime")
+
+
+def _run_flat(rt, ctx, ps, draws, xform):
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(draws)
+    r = rt.flatten(ctx, pset, dd, draws.shape[0], apply_transform=xform)
+    pset.close()
+    return r
+
+
+def _run_mesh(rt, ctx, ps, draws):
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(draws)
+    r = rt.tessellate(ctx, pset, dd, draws.shape[0])
+    pset.close()
+    return r
+
+
+def test_config0_single_cubic(rt, gpu_ctx, wl, oracle):
+    ps, d = wl.single_cubic()
+    got = _run_mesh(rt, gpu_ctx, ps, d)
+    ref = oracle.tessellate(ps, d)
+    assert got.sizes["num_poly_vertices"] == 17
+    assert (got.sizes["num_vertices"], got.sizes["num_indices"]) == (68, 300)
+    assert_mesh_equal(got, ref, "config0")
+
+
+@pytest.mark.parametrize("box", [10.0, 100.0, 1000.0])
+def test_flatten_random_cubics(rt, gpu_ctx, wl, oracle, box):
+    ps, d = wl.random_cubics(20000, seed=1234, box=box)
+    got = _run_flat(rt, gpu_ctx, ps, d, False)
+    ref = oracle.flatten(ps, d, apply_transform=False)
+    assert_flat_equal(got, ref, "cubics box=%g" % box)
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_flatten_fuzz_all_commands(rt, gpu_ctx, wl, oracle, seed):
+    ps = wl.fuzz_paths(seed, npaths=96)
+    d = wl.fuzz_draws(ps, seed)
+    for xform in (False, True):
+        got = _run_flat(rt, gpu_ctx, ps, d, xform)
+        ref = oracle.flatten(ps, d, apply_transform=xform)
+        assert_flat_equal(got, ref, "fuzz seed=%d xform=%s" % (seed, xform))
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_tessellate_fuzz_all_strokers(rt, gpu_ctx, wl, oracle, seed):
+    ps = wl.fuzz_paths(100 + seed, npaths=96)
+    d = wl.fuzz_draws(ps, 100 + seed)
+    got = _run_mesh(rt, gpu_ctx, ps, d)
+    ref = oracle.tessellate(ps, d)
+    assert_mesh_equal(got, ref, "fuzz seed=%d" % seed)
+
+
+def test_tiger_small(rt, gpu_ctx, wl, oracle):
+    ps, d = wl.tiger(3)
+    got = _run_mesh(rt, gpu_ctx, ps, d)
+    ref = oracle.tessellate(ps, d)
+    assert_mesh_equal(got, ref, "tiger x3")
+
+
+@pytest.mark.parametrize("cap,join", [(0, 0), (1, 1), (2, 2), (1, 0), (0, 1)])
+def test_long_polylines(rt, gpu_ctx, wl, oracle, cap, join):
+    ps, d = wl.random_walk_polylines(n=40, nseg=1000, seed=5678, cap=cap, join=join)
+    got = _run_mesh(rt, gpu_ctx, ps, d)
+    ref = oracle.tessellate(ps, d)
+    assert_mesh_equal(got, ref, "polylines cap=%d join=%d" % (cap, join))
+
+
+def test_async_entry_point_matches_two_phase(rt, gpu_ctx, wl):
+    import torch
+    ps, d = wl.tiger(2)
+    pset = rt.PathSet(gpu_ctx, ps)
+    dd = rt.upload_draws(d)
+    a = rt.tessellate(gpu_ctx, pset, dd, d.shape[0])
+    bufs = rt.MeshBuffers(dd.device, a.sizes["num_vertices"], a.sizes["num_indices"], a.sizes["num_meshes"])
+    rt.tessellate_async(gpu_ctx, pset, dd, d.shape[0], bufs)
+    torch.cuda.synchronize()
+    assert int(bufs.dev_status.item()) == 0
+    sz = bufs.dev_sizes.cpu().numpy()
+    assert int(sz[3]) == a.sizes["num_vertices"] and int(sz[4]) == a.sizes["num_indices"]
+    nv, ni = a.sizes["num_vertices"], a.sizes["num_indices"]
+    assert np.array_equal(bufs.idx[:ni].cpu().numpy().view(np.uint16), a.idx)
+    assert np.array_equal(bufs.pos[:nv].cpu().numpy().view(np.uint32), a.pos.view(np.uint32))
+    # too-small output buffers are reported, not overrun
+    small = rt.MeshBuffers(dd.device, nv // 2, ni // 2, a.sizes["num_meshes"])
+    rt.tessellate_async(gpu_ctx, pset, dd, d.shape[0], small)
+    torch.cuda.synchronize()
+    assert int(small.dev_status.item()) == 4  # VGX_E_NOSPACE
+    pset.close()

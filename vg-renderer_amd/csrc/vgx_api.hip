@@ -1,0 +1,745 @@
+// vgx_api.hip -- implementation of the C-ABI declared in include/vgx.h.
+//
+// Host side of the batch geometry path: context (device scratch, grow-only), path-set validation and
+// upload, the four device-wide scans and the launch sequence
+//   cmd-prefix scan -> flatten<count> -> draw scan -> flatten<emit> -> element-prefix scan
+//   -> stroke<count> -> mesh scan -> stroke<emit>
+// All lengths that are results of earlier kernels stay in device memory (VgxTotals); the asynchronous
+// entry point vgx_tessellate never synchronises with the host.
+#include "vgx_internal.h"
+#include "vgx_scan.h"
+#include <vector>
+#include <string.h>
+#include <math.h>
+#include <new>
+
+#define VGX_GRID_BLOCKS 4096 // persistent 1-wave workgroups; segments are grid-strided
+
+struct vgx_pathset
+{
+	VgxPathSetDev dev;
+	void* blob; // single device allocation holding every array
+	size_t blobBytes;
+	uint32_t maxCmdsPerPath;
+};
+
+struct DevBuf
+{
+	void* p;
+	size_t cap;
+};
+
+struct vgx_ctx
+{
+	int device;
+	int lastHipError;
+	// grow-only device scratch
+	DevBuf cmdPrefix, cmdCnt, dinfo, poly, subs, mdesc, elemPrefix, mtab, partial, totals;
+	VgxCaps caps; // element capacities matching the buffers above
+	uint64_t capDraws;
+	VgxTotals* hostTotals; // pinned
+	// state of the last *_count call (what _emit continues from)
+	const vgx_pathset* lastPs;
+	const vgx_draw* lastDraws;
+	uint64_t lastNDraws;
+	int lastStage; // 0 none, 1 flatten counted, 2 tessellate counted
+	// profiling
+	int profiling;
+	hipEvent_t ev[VGX_MAX_STAGES + 1];
+	const char* evName[VGX_MAX_STAGES];
+	uint32_t numEv;
+	bool evCreated;
+};
+
+namespace {
+
+const int kArgCount[VGX_CMD_COUNT_] = { 2, 2, 6, 4, 0, 5, 6, 4, 5, 8, 3, 4, -1 };
+
+#define HIPCHK(ctx, call)                                 \
+	do {                                                  \
+		hipError_t e_ = (call);                           \
+		if (e_ != hipSuccess) {                           \
+			(ctx)->lastHipError = (int)e_;                \
+			return VGX_E_HIP;                             \
+		}                                                 \
+	} while (0)
+
+int ensure(vgx_ctx* ctx, DevBuf& b, size_t bytes)
+{
+	if (bytes <= b.cap) {
+		return VGX_OK;
+	}
+	// grow with 12.5 % head room so that near-identical batches do not reallocate
+	size_t want = bytes + bytes / 8 + 256;
+	if (b.p) {
+		HIPCHK(ctx, hipFree(b.p));
+		b.p = nullptr;
+		b.cap = 0;
+	}
+	HIPCHK(ctx, hipMalloc(&b.p, want));
+	b.cap = want;
+	return VGX_OK;
+}
+
+void mark(vgx_ctx* ctx, hipStream_t s, const char* name)
+{
+	if (!ctx->profiling || ctx->numEv >= VGX_MAX_STAGES) {
+		return;
+	}
+	ctx->evName[ctx->numEv] = name;
+	++ctx->numEv;
+	(void)hipEventRecord(ctx->ev[ctx->numEv], s);
+}
+
+void markBegin(vgx_ctx* ctx, hipStream_t s)
+{
+	if (!ctx->profiling) {
+		return;
+	}
+	if (!ctx->evCreated) {
+		for (int i = 0; i <= VGX_MAX_STAGES; ++i) { (void)hipEventCreate(&ctx->ev[i]); }
+		ctx->evCreated = true;
+	}
+	ctx->numEv = 0;
+	(void)hipEventRecord(ctx->ev[0], s);
+}
+
+__device__ __forceinline__ void set_status(VgxTotals* t, uint32_t err)
+{
+	atomicCAS(&t->status, (uint32_t)VGX_OK, err);
+}
+
+// ---- scan operators ---------------------------------------------------------------------------------
+struct OpCmdPrefix // command instances per draw -> cmd_prefix
+{
+	const vgx_draw* draws;
+	const uint32_t* pathCmdBegin;
+	uint32_t npaths;
+	uint64_t ndraws;
+	uint64_t* prefix;
+	VgxTotals* totals;
+	uint64_t cap;
+	__device__ uint64_t size() const { return ndraws; }
+	__device__ Sum3 load(uint64_t i) const
+	{
+		Sum3 r = sum3_zero();
+		const vgx_draw* d = draws + i;
+		const uint32_t p = d->path;
+		const uint32_t sf = d->stroke_flags;
+		if (p >= npaths || ((sf & VGX_STROKE_ENABLE) && (VGX_STROKE_CAP(sf) > 2u || VGX_STROKE_JOIN(sf) > 2u))) {
+			set_status(totals, VGX_E_INVALID_ARG);
+			return r;
+		}
+		r.a = pathCmdBegin[p + 1] - pathCmdBegin[p];
+		return r;
+	}
+	__device__ void store(uint64_t i, Sum3 e) const { prefix[i] = e.a; }
+	__device__ void finish(Sum3 t) const
+	{
+		prefix[ndraws] = t.a;
+		totals->num_cmd_instances = t.a;
+		if (t.a > cap) { set_status(totals, VGX_E_NOSPACE); }
+	}
+};
+
+struct OpDrawInfo // per-draw polyline / sub-path / mesh counts -> first_* fields
+{
+	vgx_draw_info* dinfo;
+	uint64_t ndraws;
+	VgxTotals* totals;
+	VgxCaps caps;
+	__device__ uint64_t size() const { return totals->status == VGX_OK ? ndraws : 0; }
+	__device__ Sum3 load(uint64_t i) const
+	{
+		Sum3 r;
+		const vgx_draw_info* d = dinfo + i;
+		r.a = d->num_poly_vertices; r.b = d->num_subpaths; r.c = d->num_meshes; r.d = d->flags & 1u;
+		return r;
+	}
+	__device__ void store(uint64_t i, Sum3 e) const
+	{
+		vgx_draw_info* d = dinfo + i;
+		d->first_poly_vertex = e.a; d->first_subpath = e.b; d->first_mesh = e.c;
+	}
+	__device__ void finish(Sum3 t) const
+	{
+		totals->sizes.num_poly_vertices = t.a;
+		totals->sizes.num_subpaths = t.b;
+		totals->sizes.num_meshes = t.c;
+		totals->sizes.num_serial_draws = t.d;
+		if (t.a > caps.poly_vertices || t.b > caps.subpaths || t.c > caps.meshes) { set_status(totals, VGX_E_NOSPACE); }
+	}
+};
+
+struct OpElemPrefix // stroker elements per mesh -> elem_prefix
+{
+	const VgxMeshDesc* mdesc;
+	uint64_t* prefix;
+	VgxTotals* totals;
+	__device__ uint64_t size() const { return totals->status == VGX_OK ? totals->sizes.num_meshes : 0; }
+	__device__ Sum3 load(uint64_t i) const { Sum3 r = sum3_zero(); r.a = mdesc[i].poly_n; return r; }
+	__device__ void store(uint64_t i, Sum3 e) const { prefix[i] = e.a; }
+	__device__ void finish(Sum3 t) const
+	{
+		const uint64_t n = totals->status == VGX_OK ? totals->sizes.num_meshes : 0;
+		prefix[n] = t.a;
+		totals->num_elements = t.a;
+	}
+};
+
+struct OpMeshTab // per-mesh vertex / index counts -> first_vertex / first_index
+{
+	vgx_mesh* mtab;
+	VgxTotals* totals;
+	VgxCaps caps;
+	int checkCaps;
+	__device__ uint64_t size() const { return totals->status == VGX_OK ? totals->sizes.num_meshes : 0; }
+	__device__ Sum3 load(uint64_t i) const
+	{
+		Sum3 r = sum3_zero();
+		r.a = mtab[i].num_vertices; r.b = mtab[i].num_indices; r.c = mtab[i].num_vertices > 65536u ? 1u : 0u;
+		return r;
+	}
+	__device__ void store(uint64_t i, Sum3 e) const { mtab[i].first_vertex = e.a; mtab[i].first_index = e.b; }
+	__device__ void finish(Sum3 t) const
+	{
+		totals->sizes.num_vertices = t.a;
+		totals->sizes.num_indices = t.b;
+		if (t.c) { set_status(totals, VGX_E_MESH_TOO_LARGE); }
+		if (checkCaps && (t.a > caps.vertices || t.b > caps.indices || totals->sizes.num_meshes > caps.meshes)) { set_status(totals, VGX_E_NOSPACE); }
+	}
+};
+
+__global__ void k_publish(const VgxTotals* t, vgx_sizes* devSizes, uint32_t* devStatus)
+{
+	if (devSizes) { *devSizes = t->sizes; }
+	if (devStatus) { *devStatus = t->status; }
+}
+
+// ---- pipeline pieces ----------------------------------------------------------------------------------
+VgxFlattenArgs flattenArgs(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, int applyTransform)
+{
+	VgxFlattenArgs a;
+	a.ps = ps->dev;
+	a.draws = draws;
+	a.ndraws = ndraws;
+	a.cmd_prefix = (const uint64_t*)ctx->cmdPrefix.p;
+	a.cmd_cnt = (uint32_t*)ctx->cmdCnt.p;
+	a.dinfo = (vgx_draw_info*)ctx->dinfo.p;
+	a.poly = (float*)ctx->poly.p;
+	a.subs = (vgx_subpath*)ctx->subs.p;
+	a.mdesc = (VgxMeshDesc*)ctx->mdesc.p;
+	a.totals = (VgxTotals*)ctx->totals.p;
+	a.caps = ctx->caps;
+	a.apply_transform = applyTransform;
+	return a;
+}
+
+int ensureDrawBuffers(vgx_ctx* ctx, uint64_t ndraws)
+{
+	int st;
+	if ((st = ensure(ctx, ctx->cmdPrefix, (ndraws + 1) * sizeof(uint64_t))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->dinfo, (ndraws + 1) * sizeof(vgx_draw_info))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->partial, VGX_SCAN_BLOCKS * sizeof(Sum3))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->totals, sizeof(VgxTotals))) != VGX_OK) { return st; }
+	ctx->capDraws = ndraws;
+	return VGX_OK;
+}
+
+int readTotals(vgx_ctx* ctx, hipStream_t s)
+{
+	HIPCHK(ctx, hipMemcpyAsync(ctx->hostTotals, ctx->totals.p, sizeof(VgxTotals), hipMemcpyDeviceToHost, s));
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	return VGX_OK;
+}
+
+// stage 1: command-instance prefix
+void runCmdPrefix(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, hipStream_t s)
+{
+	(void)hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s);
+	OpCmdPrefix op;
+	op.draws = draws; op.pathCmdBegin = ps->dev.path_cmd_begin; op.npaths = ps->dev.npaths; op.ndraws = ndraws;
+	op.prefix = (uint64_t*)ctx->cmdPrefix.p; op.totals = (VgxTotals*)ctx->totals.p; op.cap = ctx->caps.cmd_instances;
+	vgx_device_scan(op, (Sum3*)ctx->partial.p, s);
+	mark(ctx, s, "scan_cmd_prefix");
+}
+
+// stage 2: flatten count + draw scan
+void runFlattenCount(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, hipStream_t s)
+{
+	(void)hipMemsetAsync(ctx->dinfo.p, 0, ndraws * sizeof(vgx_draw_info), s);
+	VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, 1);
+	vgx_launch_flatten(false, a, VGX_GRID_BLOCKS, s);
+	mark(ctx, s, "flatten_count");
+	OpDrawInfo op;
+	op.dinfo = (vgx_draw_info*)ctx->dinfo.p; op.ndraws = ndraws; op.totals = (VgxTotals*)ctx->totals.p; op.caps = ctx->caps;
+	vgx_device_scan(op, (Sum3*)ctx->partial.p, s);
+	mark(ctx, s, "scan_draws");
+}
+
+void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps, int checkCaps, hipStream_t s)
+{
+	OpElemPrefix ope;
+	ope.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; ope.prefix = (uint64_t*)ctx->elemPrefix.p; ope.totals = (VgxTotals*)ctx->totals.p;
+	vgx_device_scan(ope, (Sum3*)ctx->partial.p, s);
+	mark(ctx, s, "scan_elements");
+	VgxStrokeArgs a;
+	a.draws = draws; a.poly = (const float*)ctx->poly.p; a.mdesc = (const VgxMeshDesc*)ctx->mdesc.p;
+	a.elem_prefix = (const uint64_t*)ctx->elemPrefix.p; a.mtab = (vgx_mesh*)ctx->mtab.p;
+	a.pos = nullptr; a.color = nullptr; a.idx = nullptr; a.meshes_out = nullptr;
+	a.totals = (VgxTotals*)ctx->totals.p; a.caps = outCaps;
+	vgx_launch_stroke(false, a, VGX_GRID_BLOCKS, s);
+	mark(ctx, s, "stroke_count");
+	OpMeshTab opm;
+	opm.mtab = (vgx_mesh*)ctx->mtab.p; opm.totals = (VgxTotals*)ctx->totals.p; opm.caps = outCaps; opm.checkCaps = checkCaps;
+	vgx_device_scan(opm, (Sum3*)ctx->partial.p, s);
+	mark(ctx, s, "scan_meshes");
+}
+
+void runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out, hipStream_t s)
+{
+	VgxStrokeArgs a;
+	a.draws = draws; a.poly = (const float*)ctx->poly.p; a.mdesc = (const VgxMeshDesc*)ctx->mdesc.p;
+	a.elem_prefix = (const uint64_t*)ctx->elemPrefix.p; a.mtab = (vgx_mesh*)ctx->mtab.p;
+	a.pos = out->pos; a.color = out->color; a.idx = out->idx; a.meshes_out = out->meshes;
+	a.totals = (VgxTotals*)ctx->totals.p;
+	a.caps = ctx->caps;
+	vgx_launch_stroke(true, a, VGX_GRID_BLOCKS, s);
+	mark(ctx, s, "stroke_emit");
+}
+
+int ensureMeshBuffers(vgx_ctx* ctx, uint64_t polyVerts, uint64_t subpaths, uint64_t meshes)
+{
+	int st;
+	if ((st = ensure(ctx, ctx->poly, (polyVerts + 1) * 2 * sizeof(float))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->subs, (subpaths + 1) * sizeof(vgx_subpath))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->mdesc, (meshes + 1) * sizeof(VgxMeshDesc))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->elemPrefix, (meshes + 2) * sizeof(uint64_t))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->mtab, (meshes + 1) * sizeof(vgx_mesh))) != VGX_OK) { return st; }
+	ctx->caps.poly_vertices = ctx->poly.cap / (2 * sizeof(float)) - 1;
+	ctx->caps.subpaths = ctx->subs.cap / sizeof(vgx_subpath) - 1;
+	uint64_t m = ctx->mdesc.cap / sizeof(VgxMeshDesc) - 1;
+	const uint64_t m2 = ctx->elemPrefix.cap / sizeof(uint64_t) - 2;
+	const uint64_t m3 = ctx->mtab.cap / sizeof(vgx_mesh) - 1;
+	if (m2 < m) { m = m2; }
+	if (m3 < m) { m = m3; }
+	ctx->caps.meshes = m;
+	return VGX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t vgx_version(void) { return VGX_VERSION; }
+
+const char* vgx_status_string(int status)
+{
+	switch (status) {
+	case VGX_OK: return "VGX_OK";
+	case VGX_E_INVALID_ARG: return "VGX_E_INVALID_ARG";
+	case VGX_E_INVALID_PATH: return "VGX_E_INVALID_PATH";
+	case VGX_E_NONFINITE: return "VGX_E_NONFINITE";
+	case VGX_E_NOSPACE: return "VGX_E_NOSPACE";
+	case VGX_E_MESH_TOO_LARGE: return "VGX_E_MESH_TOO_LARGE";
+	case VGX_E_HIP: return "VGX_E_HIP";
+	case VGX_E_NO_DEVICE: return "VGX_E_NO_DEVICE";
+	case VGX_E_RANGE: return "VGX_E_RANGE";
+	default: return "VGX_E_UNKNOWN";
+	}
+}
+
+int vgx_create(int device, vgx_ctx** out_ctx)
+{
+	if (!out_ctx) {
+		return VGX_E_INVALID_ARG;
+	}
+	*out_ctx = nullptr;
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) {
+		return VGX_E_NO_DEVICE;
+	}
+	vgx_ctx* ctx = new (std::nothrow) vgx_ctx();
+	if (!ctx) {
+		return VGX_E_INVALID_ARG;
+	}
+	memset(ctx, 0, sizeof(*ctx));
+	ctx->device = device;
+	if (hipSetDevice(device) != hipSuccess) {
+		delete ctx;
+		return VGX_E_NO_DEVICE;
+	}
+	if (hipHostMalloc((void**)&ctx->hostTotals, sizeof(VgxTotals), hipHostMallocDefault) != hipSuccess) {
+		delete ctx;
+		return VGX_E_HIP;
+	}
+	*out_ctx = ctx;
+	return VGX_OK;
+}
+
+int vgx_destroy(vgx_ctx* ctx)
+{
+	if (!ctx) {
+		return VGX_E_INVALID_ARG;
+	}
+	DevBuf* bufs[] = { &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->mtab, &ctx->partial, &ctx->totals };
+	for (DevBuf* b : bufs) {
+		if (b->p) { (void)hipFree(b->p); }
+	}
+	if (ctx->hostTotals) { (void)hipHostFree(ctx->hostTotals); }
+	if (ctx->evCreated) {
+		for (int i = 0; i <= VGX_MAX_STAGES; ++i) { (void)hipEventDestroy(ctx->ev[i]); }
+	}
+	delete ctx;
+	return VGX_OK;
+}
+
+int vgx_last_hip_error(const vgx_ctx* ctx) { return ctx ? ctx->lastHipError : 0; }
+
+uint64_t vgx_scratch_bytes(const vgx_ctx* ctx)
+{
+	if (!ctx) {
+		return 0;
+	}
+	return ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
+}
+
+// ---- path set ---------------------------------------------------------------------------------------
+// Host-side validation of the command grammar (see include/vgx.h) and derivation of the static
+// per-command structure the kernels use (sub-path heads / tails, serial-path flag).
+} // extern "C"
+
+static int vgx_pathset_validate_host(const vgx_pathset_desc* d, std::vector<uint8_t>* cmdFlags, std::vector<uint32_t>* spStart, std::vector<uint8_t>* pathFlags, uint32_t* maxCmds)
+{
+	if (!d || !d->path_cmd_begin || (d->ncmd && (!d->cmd_type || !d->cmd_arg_off)) || !d->cmd_arg_off) {
+		return VGX_E_INVALID_ARG;
+	}
+	if (d->path_cmd_begin[0] != 0 || d->path_cmd_begin[d->npaths] != d->ncmd || d->cmd_arg_off[0] != 0) {
+		return VGX_E_INVALID_ARG;
+	}
+	cmdFlags->assign(d->ncmd, 0);
+	spStart->assign(d->ncmd, 0);
+	pathFlags->assign(d->npaths ? d->npaths : 1, 0);
+	*maxCmds = 0;
+	const uint32_t nargs = d->cmd_arg_off[d->ncmd];
+	if (nargs && !d->args) {
+		return VGX_E_INVALID_ARG;
+	}
+	for (uint32_t i = 0; i < nargs; ++i) {
+		if (!isfinite(d->args[i])) {
+			return VGX_E_NONFINITE;
+		}
+	}
+	for (uint32_t p = 0; p < d->npaths; ++p) {
+		const uint32_t c0 = d->path_cmd_begin[p], c1 = d->path_cmd_begin[p + 1];
+		if (c1 < c0 || c1 > d->ncmd) {
+			return VGX_E_INVALID_ARG;
+		}
+		if (c1 - c0 > *maxCmds) { *maxCmds = c1 - c0; }
+		bool open = false; // a sub-path is open and may take more vertices
+		uint32_t head = c0;
+		for (uint32_t c = c0; c < c1; ++c) {
+			const uint32_t t = d->cmd_type[c];
+			if (t >= VGX_CMD_COUNT_) {
+				return VGX_E_INVALID_ARG;
+			}
+			if (d->cmd_arg_off[c + 1] < d->cmd_arg_off[c]) {
+				return VGX_E_INVALID_ARG;
+			}
+			const uint32_t na = d->cmd_arg_off[c + 1] - d->cmd_arg_off[c];
+			if (t == VGX_CMD_POLYLINE) {
+				if (na < 2 || (na & 1)) { return VGX_E_INVALID_ARG; }
+			} else if ((int)na != kArgCount[t]) {
+				return VGX_E_INVALID_ARG;
+			}
+			const bool isShape = t >= VGX_CMD_RECT && t <= VGX_CMD_ELLIPSE;
+			bool starts = false;
+			if (t == VGX_CMD_MOVE_TO || isShape) {
+				starts = true;
+			} else if (t == VGX_CMD_ARC) {
+				starts = !open; // pathArc: moveTo when there is no open sub-path, else lineTo (path.cpp:663-667)
+				if (!open && c != c0) {
+					// a leading arc is only well defined at the very start of a path or after MOVE_TO-less state;
+					// after CLOSE / a closed shape the reference would append to a closed sub-path
+					return VGX_E_INVALID_PATH;
+				}
+			} else if (!open) {
+				return VGX_E_INVALID_PATH; // LINE_TO/CUBIC_TO/... need an open sub-path (path.cpp:82,88)
+			}
+			if (starts) { head = c; }
+			(*spStart)[c] = head;
+			if (starts) { (*cmdFlags)[c] |= VGX_CF_STARTS_SUB; }
+			if (t == VGX_CMD_ARC || t == VGX_CMD_ARC_TO) { (*pathFlags)[p] |= VGX_PF_SERIAL; }
+			open = !(t == VGX_CMD_CLOSE || isShape);
+		}
+		for (uint32_t c = c0; c < c1; ++c) {
+			const bool last = (c + 1 == c1);
+			if (last) { (*cmdFlags)[c] |= VGX_CF_LAST_IN_PATH | VGX_CF_LAST_IN_SUB; }
+			else {
+				if ((*cmdFlags)[c + 1] & VGX_CF_STARTS_SUB) { (*cmdFlags)[c] |= VGX_CF_LAST_IN_SUB; }
+				if (d->cmd_type[c + 1] == VGX_CMD_CLOSE) { (*cmdFlags)[c] |= VGX_CF_NEXT_IS_CLOSE; }
+			}
+		}
+	}
+	return VGX_OK;
+}
+
+extern "C" {
+
+int vgx_pathset_validate(const vgx_pathset_desc* desc)
+{
+	std::vector<uint8_t> cmdFlags, pathFlags;
+	std::vector<uint32_t> spStart;
+	uint32_t maxCmds = 0;
+	return vgx_pathset_validate_host(desc, &cmdFlags, &spStart, &pathFlags, &maxCmds);
+}
+
+int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset** out_ps)
+{
+	if (!ctx || !desc || !out_ps) {
+		return VGX_E_INVALID_ARG;
+	}
+	*out_ps = nullptr;
+	std::vector<uint8_t> cmdFlags, pathFlags;
+	std::vector<uint32_t> spStart;
+	uint32_t maxCmds = 0;
+	const int st = vgx_pathset_validate_host(desc, &cmdFlags, &spStart, &pathFlags, &maxCmds);
+	if (st != VGX_OK) {
+		return st;
+	}
+	const uint32_t ncmd = desc->ncmd, npaths = desc->npaths;
+	const uint32_t nargs = desc->cmd_arg_off[ncmd];
+	// one blob: [args (2 floats of padding in front: start-point gather of command 0 reads args[-2..-1])]
+	auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	const size_t oArgs = 0;
+	const size_t oArgOff = align(oArgs + (nargs + 4) * sizeof(float));
+	const size_t oSpStart = align(oArgOff + (ncmd + 1) * sizeof(uint32_t));
+	const size_t oPathBegin = align(oSpStart + (ncmd + 1) * sizeof(uint32_t));
+	const size_t oType = align(oPathBegin + (npaths + 1) * sizeof(uint32_t));
+	const size_t oFlags = align(oType + ncmd + 1);
+	const size_t oPathFlags = align(oFlags + ncmd + 1);
+	const size_t total = align(oPathFlags + npaths + 1);
+	std::vector<uint8_t> host(total, 0);
+	if (nargs) { memcpy(&host[oArgs + 2 * sizeof(float)], desc->args, nargs * sizeof(float)); }
+	memcpy(&host[oArgOff], desc->cmd_arg_off, (ncmd + 1) * sizeof(uint32_t));
+	if (ncmd) {
+		memcpy(&host[oSpStart], spStart.data(), ncmd * sizeof(uint32_t));
+		memcpy(&host[oType], desc->cmd_type, ncmd);
+		memcpy(&host[oFlags], cmdFlags.data(), ncmd);
+	}
+	memcpy(&host[oPathBegin], desc->path_cmd_begin, (npaths + 1) * sizeof(uint32_t));
+	if (npaths) { memcpy(&host[oPathFlags], pathFlags.data(), npaths); }
+
+	vgx_pathset* ps = new (std::nothrow) vgx_pathset();
+	if (!ps) {
+		return VGX_E_INVALID_ARG;
+	}
+	ps->blob = nullptr;
+	ps->blobBytes = total;
+	ps->maxCmdsPerPath = maxCmds;
+	hipError_t e = hipMalloc(&ps->blob, total);
+	if (e == hipSuccess) { e = hipMemcpy(ps->blob, host.data(), total, hipMemcpyHostToDevice); }
+	if (e != hipSuccess) {
+		ctx->lastHipError = (int)e;
+		if (ps->blob) { (void)hipFree(ps->blob); }
+		delete ps;
+		return VGX_E_HIP;
+	}
+	uint8_t* b = (uint8_t*)ps->blob;
+	ps->dev.args = (const float*)(b + oArgs) + 2;
+	ps->dev.cmd_arg_off = (const uint32_t*)(b + oArgOff);
+	ps->dev.cmd_sp_start = (const uint32_t*)(b + oSpStart);
+	ps->dev.path_cmd_begin = (const uint32_t*)(b + oPathBegin);
+	ps->dev.cmd_type = b + oType;
+	ps->dev.cmd_flags = b + oFlags;
+	ps->dev.path_flags = b + oPathFlags;
+	ps->dev.npaths = npaths;
+	ps->dev.ncmd = ncmd;
+	*out_ps = ps;
+	return VGX_OK;
+}
+
+int vgx_pathset_destroy(vgx_ctx* ctx, vgx_pathset* ps)
+{
+	if (!ctx || !ps) {
+		return VGX_E_INVALID_ARG;
+	}
+	if (ctx->lastPs == ps) { ctx->lastPs = nullptr; ctx->lastStage = 0; }
+	if (ps->blob) { (void)hipFree(ps->blob); }
+	delete ps;
+	return VGX_OK;
+}
+
+// ---- flatten ------------------------------------------------------------------------------------------
+static int flattenCountCommon(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, hipStream_t s)
+{
+	int st;
+	if ((st = ensureDrawBuffers(ctx, ndraws)) != VGX_OK) { return st; }
+	// pass 1: command instances (sizes the per-command scratch)
+	ctx->caps.cmd_instances = ~0ull; // not known yet: never trips the check in this sizing pass
+	runCmdPrefix(ctx, ps, draws, ndraws, s);
+	if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
+	if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; }
+	const uint64_t ncmdInst = ctx->hostTotals->num_cmd_instances;
+	if ((st = ensure(ctx, ctx->cmdCnt, (ncmdInst + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
+	ctx->caps.cmd_instances = ctx->cmdCnt.cap / sizeof(uint32_t) - 1;
+	// pass 2: per-draw counts (sizes polyline / sub-path / mesh scratch)
+	const VgxCaps saved = ctx->caps;
+	ctx->caps.poly_vertices = ~0ull; ctx->caps.subpaths = ~0ull; ctx->caps.meshes = ~0ull;
+	runFlattenCount(ctx, ps, draws, ndraws, s);
+	ctx->caps = saved;
+	if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
+	if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; }
+	if (ctx->hostTotals->sizes.num_poly_vertices > 0xFFFFFFF0ull) { return VGX_E_RANGE; }
+	return VGX_OK;
+}
+
+int vgx_flatten_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, vgx_sizes* out_sizes, void* stream)
+{
+	if (!ctx || !ps || (!draws && ndraws) || !out_sizes) {
+		return VGX_E_INVALID_ARG;
+	}
+	hipStream_t s = (hipStream_t)stream;
+	markBegin(ctx, s);
+	ctx->lastStage = 0;
+	const int st = flattenCountCommon(ctx, ps, draws, ndraws, s);
+	if (st != VGX_OK) { return st; }
+	*out_sizes = ctx->hostTotals->sizes;
+	out_sizes->num_vertices = 0;
+	out_sizes->num_indices = 0;
+	ctx->lastPs = ps; ctx->lastDraws = draws; ctx->lastNDraws = ndraws; ctx->lastStage = 1;
+	return VGX_OK;
+}
+
+int vgx_flatten_emit(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, int apply_transform, const vgx_flat_out* out, void* stream)
+{
+	if (!ctx || !ps || !out || (!draws && ndraws)) {
+		return VGX_E_INVALID_ARG;
+	}
+	if (ctx->lastStage < 1 || ctx->lastPs != ps || ctx->lastDraws != draws || ctx->lastNDraws != ndraws) {
+		return VGX_E_INVALID_ARG; // must follow vgx_flatten_count on the same batch
+	}
+	const vgx_sizes& sz = ctx->hostTotals->sizes;
+	if ((out->poly && out->cap_poly_vertices < sz.num_poly_vertices) || (out->subpaths && out->cap_subpaths < sz.num_subpaths)) {
+		return VGX_E_NOSPACE;
+	}
+	hipStream_t s = (hipStream_t)stream;
+	markBegin(ctx, s);
+	int st;
+	// outputs the caller does not want still need somewhere to go
+	if (!out->poly) { if ((st = ensure(ctx, ctx->poly, (sz.num_poly_vertices + 1) * 2 * sizeof(float))) != VGX_OK) { return st; } }
+	if (!out->subpaths) { if ((st = ensure(ctx, ctx->subs, (sz.num_subpaths + 1) * sizeof(vgx_subpath))) != VGX_OK) { return st; } }
+	VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, apply_transform);
+	a.poly = out->poly ? out->poly : (float*)ctx->poly.p;
+	a.subs = out->subpaths ? out->subpaths : (vgx_subpath*)ctx->subs.p;
+	a.mdesc = nullptr;
+	a.caps.poly_vertices = ~0ull; a.caps.subpaths = ~0ull; a.caps.meshes = ~0ull;
+	vgx_launch_flatten(true, a, VGX_GRID_BLOCKS, s);
+	mark(ctx, s, "flatten_emit");
+	if (out->draw_info && ndraws) {
+		HIPCHK(ctx, hipMemcpyAsync(out->draw_info, ctx->dinfo.p, ndraws * sizeof(vgx_draw_info), hipMemcpyDeviceToDevice, s));
+	}
+	return VGX_OK;
+}
+
+// ---- tessellate ---------------------------------------------------------------------------------------
+int vgx_tessellate_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, vgx_sizes* out_sizes, void* stream)
+{
+	if (!ctx || !ps || (!draws && ndraws) || !out_sizes) {
+		return VGX_E_INVALID_ARG;
+	}
+	hipStream_t s = (hipStream_t)stream;
+	markBegin(ctx, s);
+	ctx->lastStage = 0;
+	int st = flattenCountCommon(ctx, ps, draws, ndraws, s);
+	if (st != VGX_OK) { return st; }
+	const vgx_sizes sz = ctx->hostTotals->sizes;
+	if ((st = ensureMeshBuffers(ctx, sz.num_poly_vertices, sz.num_subpaths, sz.num_meshes)) != VGX_OK) { return st; }
+	VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, 1);
+	vgx_launch_flatten(true, a, VGX_GRID_BLOCKS, s);
+	mark(ctx, s, "flatten_emit");
+	VgxCaps outCaps = ctx->caps;
+	outCaps.vertices = ~0ull; outCaps.indices = ~0ull;
+	runStrokeCount(ctx, draws, outCaps, 0, s);
+	if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
+	*out_sizes = ctx->hostTotals->sizes;
+	ctx->lastPs = ps; ctx->lastDraws = draws; ctx->lastNDraws = ndraws; ctx->lastStage = 2;
+	if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; }
+	return VGX_OK;
+}
+
+int vgx_tessellate_emit(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, const vgx_mesh_out* out, void* stream)
+{
+	if (!ctx || !ps || !out || (!draws && ndraws) || !out->pos || !out->color || !out->idx) {
+		return VGX_E_INVALID_ARG;
+	}
+	if (ctx->lastStage != 2 || ctx->lastPs != ps || ctx->lastDraws != draws || ctx->lastNDraws != ndraws) {
+		return VGX_E_INVALID_ARG; // must follow vgx_tessellate_count on the same batch
+	}
+	const vgx_sizes& sz = ctx->hostTotals->sizes;
+	if (out->cap_vertices < sz.num_vertices || out->cap_indices < sz.num_indices || (out->meshes && out->cap_meshes < sz.num_meshes)) {
+		return VGX_E_NOSPACE;
+	}
+	hipStream_t s = (hipStream_t)stream;
+	markBegin(ctx, s);
+	runStrokeEmit(ctx, draws, out, s);
+	return VGX_OK;
+}
+
+int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream)
+{
+	if (!ctx || !ps || !out || (!draws && ndraws) || !out->pos || !out->color || !out->idx) {
+		return VGX_E_INVALID_ARG;
+	}
+	if (ndraws > ctx->capDraws || !ctx->cmdCnt.p || !ctx->poly.p || !ctx->mtab.p) {
+		return VGX_E_NOSPACE; // scratch was never sized for a batch like this: run vgx_tessellate_count once
+	}
+	hipStream_t s = (hipStream_t)stream;
+	markBegin(ctx, s);
+	ctx->lastStage = 0;
+	runCmdPrefix(ctx, ps, draws, ndraws, s);
+	runFlattenCount(ctx, ps, draws, ndraws, s);
+	VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, 1);
+	vgx_launch_flatten(true, a, VGX_GRID_BLOCKS, s);
+	mark(ctx, s, "flatten_emit");
+	VgxCaps outCaps = ctx->caps;
+	outCaps.vertices = out->cap_vertices;
+	outCaps.indices = out->cap_indices;
+	if (out->meshes && out->cap_meshes < outCaps.meshes) { outCaps.meshes = out->cap_meshes; }
+	runStrokeCount(ctx, draws, outCaps, 1, s);
+	runStrokeEmit(ctx, draws, out, s);
+	if (dev_sizes || dev_status) {
+		hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, s, (const VgxTotals*)ctx->totals.p, dev_sizes, dev_status);
+	}
+	return VGX_OK;
+}
+
+int vgx_set_profiling(vgx_ctx* ctx, int enable)
+{
+	if (!ctx) {
+		return VGX_E_INVALID_ARG;
+	}
+	ctx->profiling = enable ? 1 : 0;
+	return VGX_OK;
+}
+
+int vgx_get_stage_times(vgx_ctx* ctx, vgx_stage_times* out)
+{
+	if (!ctx || !out) {
+		return VGX_E_INVALID_ARG;
+	}
+	memset(out, 0, sizeof(*out));
+	if (!ctx->profiling || !ctx->evCreated) {
+		return VGX_OK;
+	}
+	out->num_stages = ctx->numEv;
+	for (uint32_t i = 0; i < ctx->numEv; ++i) {
+		float ms = 0.0f;
+		if (hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]) != hipSuccess) { ms = -1.0f; }
+		out->ms[i] = ms;
+		out->name[i] = ctx->evName[i];
+	}
+	return VGX_OK;
+}
+
+} // extern "C"

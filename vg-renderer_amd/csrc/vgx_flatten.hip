@@ -1,0 +1,381 @@
+// vgx_flatten.hip -- batch path flattening on gfx950 (replaces vg::pathXXX, reference src/path.cpp).
+//
+// Work decomposition
+//   The batch is a flat stream of "command instances" (draw d, command k of its path). A wavefront owns
+//   a SEGMENT = all draws whose first command instance falls into one 64-instance bucket, i.e. whole
+//   draws, and walks their command instances 64 at a time: one lane = one path command.
+//     - MOVE_TO / LINE_TO / CUBIC_TO / QUAD_TO / POLYLINE: the lane's start point is the previous
+//       command's end point, which sits right in front of the lane's own arguments (args[-2..-1]); no
+//       sequential dependency. Cubics run the reference's adaptive subdivision as a per-lane DFS with
+//       the 10-entry pending stack in LDS (lane-interleaved float2 -> conflict free).
+//     - closed shapes (RECT, ROUNDED_RECT*, CIRCLE, ELLIPSE) are self-contained sub-paths: the lane
+//       simulates the reference's builder exactly (PathSim) for its own command.
+//     - the growing polyline's bookkeeping (vertex offsets inside the draw, sub-path table, pathClose,
+//       per-draw totals, mesh ranks) is done with wave ballots + prefix scans segmented by draw and by
+//       sub-path, with carries across 64-command chunks.
+//   Two passes (template<EMIT>): count -> device-wide scan over draws -> emit. The count pass stores one
+//   word per command instance (cmd_cnt) so the emit pass runs every DFS exactly once.
+//
+// Exactness
+//   pathAddVertex's epsilon de-duplication (path.cpp:767-777) and the silent piece drop when the
+//   pending stack is full (path.cpp:168-179) make "the last vertex" differ from the previous
+//   command's nominal end point. Both are detected lane-locally; a draw where either happens (and any
+//   path containing ARC / ARC_TO, whose end points are computed) is re-done by ONE lane running the
+//   exact sequential algorithm (PathSim over the whole draw). Degenerate input is slow, never wrong.
+#include "vgx_internal.h"
+#include "vgx_wave.h"
+#include "vgx_pathsim.h"
+
+namespace {
+
+// ---- pending stack of the cubic DFS in LDS: [level][3 points][64 lanes] float2 ---------------------
+struct LdsStack
+{
+	float2* base; // &s_stack[lane]
+	__device__ __forceinline__ void push(int level, float ax, float ay, float bx, float by, float cx, float cy)
+	{
+		float2* p = base + level * 3 * VGX_WAVE;
+		p[0] = make_float2(ax, ay);
+		p[VGX_WAVE] = make_float2(bx, by);
+		p[2 * VGX_WAVE] = make_float2(cx, cy);
+	}
+	__device__ __forceinline__ void pop(int level, float& ax, float& ay, float& bx, float& by, float& cx, float& cy)
+	{
+		const float2* p = base + level * 3 * VGX_WAVE;
+		const float2 a = p[0], b = p[VGX_WAVE], c = p[2 * VGX_WAVE];
+		ax = a.x; ay = a.y; bx = b.x; by = b.y; cx = c.x; cy = c.y;
+	}
+};
+
+// ---- sink of the lane-parallel cubic: counts leaves, flags the cases that need the serial path -------
+template<bool EMIT, bool XFORM>
+struct FastCubicSink
+{
+	V2 prev;            // previous vertex of the polyline (for the epsilon test)
+	uint32_t n;
+	bool slow;
+	// emit
+	float* out;         // &poly[2 * first vertex of this command]
+	uint32_t writeLimit;// vertices [0, writeLimit) are written (excludes a vertex popped by CLOSE)
+	const float* mtx;   // state transform (used only when XFORM)
+	__device__ __forceinline__ void leaf(float x, float y)
+	{
+		if (!EMIT) {
+			slow = slow || v2near(prev, v2(x, y));
+			prev = v2(x, y);
+		} else if (n < writeLimit) {
+			V2 p = v2(x, y);
+			if (XFORM) { p = v2xform(p, mtx); }
+			*(float2*)(out + 2 * (size_t)n) = make_float2(p.x, p.y);
+		}
+		++n;
+	}
+	__device__ __forceinline__ void dropped() { slow = true; }
+};
+
+__device__ __forceinline__ bool is_shape_cmd(uint32_t t) { return t >= VGX_CMD_RECT && t <= VGX_CMD_ELLIPSE; }
+
+// ------------------------------------------------------------------------------------------------
+template<bool EMIT, bool XFORM>
+__global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
+{
+	__shared__ float2 s_stack[VGX_CUBIC_MAX_PENDING * 3 * VGX_WAVE];
+	const int lane = threadIdx.x;
+	LdsStack stack;
+	stack.base = &s_stack[lane];
+
+	const VgxPathSetDev& ps = A.ps;
+	const uint64_t totalCmds = A.cmd_prefix[A.ndraws];
+	if (A.totals->status != VGX_OK) { return; } // capacity / range errors detected by the scan steps
+	const uint64_t numSegments = (totalCmds + VGX_WAVE - 1) / VGX_WAVE;
+
+	for (uint64_t seg = blockIdx.x; seg < numSegments; seg += gridDim.x) {
+		const uint64_t d0 = lower_bound_u64(A.cmd_prefix, 0, A.ndraws, seg * VGX_WAVE);
+		const uint64_t d1 = lower_bound_u64(A.cmd_prefix, d0, A.ndraws, (seg + 1) * VGX_WAVE);
+		if (d0 == d1) {
+			continue;
+		}
+		const uint64_t C0 = A.cmd_prefix[d0];
+		const uint64_t C1 = A.cmd_prefix[d1];
+
+		// carries of the draw / sub-path that continue across 64-command chunks (wave-uniform)
+		int carryDrawVerts = 0, carrySpVerts = 0, carrySubs = 0, carryFill = 0, carryStroke = 0;
+		int carrySlow = 0, carrySpExists = 0;
+
+		for (uint64_t chunk = C0; chunk < C1; chunk += VGX_WAVE) {
+			const uint64_t ci = chunk + lane;
+			const bool valid = ci < C1;
+
+			// ---- decode my command instance ------------------------------------------------------
+			uint64_t d = d0;
+			uint32_t c = 0, type = VGX_CMD_CLOSE, cflags = 0, na = 0;
+			const float* a = ps.args;
+			bool drawHead = false, drawLast = false, serialDraw = false;
+			float scale = 1.0f, tol = 0.25f;
+			uint32_t fillFlags = 0, strokeFlags = 0;
+			const vgx_draw* dr = A.draws;
+			if (valid) {
+				d = find_owner_u64(A.cmd_prefix, d0, d1, ci);
+				dr = A.draws + d;
+				const uint32_t path = dr->path;
+				const uint32_t pc0 = ps.path_cmd_begin[path];
+				const uint32_t k = (uint32_t)(ci - A.cmd_prefix[d]);
+				c = pc0 + k;
+				type = ps.cmd_type[c];
+				cflags = ps.cmd_flags[c];
+				const uint32_t ao = ps.cmd_arg_off[c];
+				na = ps.cmd_arg_off[c + 1] - ao;
+				a = ps.args + ao;
+				drawHead = (k == 0);
+				drawLast = (cflags & VGX_CF_LAST_IN_PATH) != 0;
+				scale = dr->scale;
+				tol = dr->tess_tol;
+				fillFlags = dr->fill_flags;
+				strokeFlags = dr->stroke_flags;
+				serialDraw = EMIT ? ((A.dinfo[d].flags & 1u) != 0) : ((ps.path_flags[path] & VGX_PF_SERIAL) != 0);
+			}
+			const float* mtx = dr->mtx;
+
+			// ---- per-lane vertex count (count pass: compute; emit pass: read back) -----------------
+			int cnt = 0;
+			bool slow = false, exists = false, closedHere = false, pop = false;
+			if (valid && !serialDraw) {
+				if (!EMIT) {
+					const V2 start = v2(a[-2], a[-1]); // previous command's end point (unused by sub-path starters)
+					switch (type) {
+					case VGX_CMD_MOVE_TO: cnt = 1; exists = true; break;
+					case VGX_CMD_LINE_TO: cnt = 1; slow = v2near(start, v2(a[0], a[1])); break;
+					case VGX_CMD_CUBIC_TO:
+					case VGX_CMD_QUAD_TO: {
+						FastCubicSink<false, false> sink;
+						sink.prev = start; sink.n = 0; sink.slow = false;
+						float c1x = a[0], c1y = a[1], c2x = a[2], c2y = a[3], ex, ey;
+						if (type == VGX_CMD_QUAD_TO) {
+							ex = a[2]; ey = a[3];
+							vgx_quad_to_cubic(start.x, start.y, a[0], a[1], ex, ey, &c1x, &c1y, &c2x, &c2y);
+						} else {
+							ex = a[4]; ey = a[5];
+						}
+						vgx_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tol / (scale * scale), stack, sink);
+						cnt = (int)sink.n;
+						slow = sink.slow;
+					} break;
+					case VGX_CMD_POLYLINE: {
+						const uint32_t npts = na >> 1;
+						cnt = (int)npts - ((npts > 0 && v2near(start, v2(a[0], a[1]))) ? 1 : 0);
+					} break;
+					case VGX_CMD_CLOSE: break; // decided below, needs the sub-path's vertex count
+					default: { // closed shape: exact builder for this one command
+						PathSim<false, false> sim;
+						sim.scale = scale; sim.tol = tol; sim.mtx = nullptr; sim.poly = nullptr; sim.polyBase = 0; sim.subs = nullptr; sim.subBase = 0;
+						sim.mdesc = nullptr; sim.meshBase = 0; sim.drawIndex = 0; sim.fillFlags = 0; sim.strokeFlags = 0; sim.numFillTotal = 0;
+						sim.init();
+						sim.shape(type, a);
+						cnt = (int)sim.nverts;
+						exists = sim.laneExists;
+						closedHere = sim.laneClosed;
+					} break;
+					}
+				} else {
+					const uint32_t w = A.cmd_cnt[ci];
+					exists = (w & VGX_CC_EXISTS) != 0;
+					closedHere = (w & VGX_CC_CLOSED) != 0;
+					pop = (w & VGX_CC_POP) != 0;
+					cnt = pop ? -1 : (int)(w & VGX_CC_COUNT_MASK);
+				}
+			}
+
+			// ---- segmented bookkeeping ----------------------------------------------------------
+			const uint64_t drawHeads = wave_ballot(valid && drawHead);
+			const uint64_t subHeads = wave_ballot(valid && (cflags & VGX_CF_STARTS_SUB));
+			const int dh = seg_head(drawHeads, lane);
+			const int sh = seg_head(subHeads, lane);
+
+			if (!EMIT) {
+				// pathClose (path.cpp:707-726) needs the vertex count of its sub-path so far.
+				const int incl1 = wave_incl_scan(cnt, lane);
+				const int spBefore = seg_rel(incl1 - cnt, sh, carrySpVerts);
+				if (valid && !serialDraw && type == VGX_CMD_CLOSE && spBefore > 2) {
+					closedHere = true;
+					const float* fa = ps.args + ps.cmd_arg_off[ps.cmd_sp_start[c]];
+					if (v2near(v2(a[-2], a[-1]), v2(fa[0], fa[1]))) {
+						pop = true;
+						cnt = -1;
+					}
+				}
+			}
+			const int incl = wave_incl_scan(cnt, lane);
+			const int excl = incl - cnt;
+			const int inDrawBefore = seg_rel(excl, dh, carryDrawVerts);
+			const int spBefore = seg_rel(excl, sh, carrySpVerts);
+			const int spTotal = spBefore + cnt; // vertices of my sub-path up to and including me
+
+			const uint64_t existMask = wave_ballot(valid && exists);
+			const uint64_t mine = seg_mask_upto(dh, lane);
+			const int subsIncl = __popcll(existMask & mine) + (dh < 0 ? carrySubs : 0);
+			const int headExists = (sh < 0) ? carrySpExists : (int)((existMask >> sh) & 1ull);
+
+			const bool lastInSub = valid && (cflags & VGX_CF_LAST_IN_SUB) && headExists;
+			const uint64_t fillMask = wave_ballot(lastInSub && (fillFlags & VGX_FILL_ENABLE) && spTotal >= 3);
+			const uint64_t strokeMask = wave_ballot(lastInSub && (strokeFlags & VGX_STROKE_ENABLE) && spTotal >= 2);
+			const int fillIncl = __popcll(fillMask & mine) + (dh < 0 ? carryFill : 0);
+			const int strokeIncl = __popcll(strokeMask & mine) + (dh < 0 ? carryStroke : 0);
+			const uint64_t slowMask = wave_ballot(valid && slow);
+			const bool slowDraw = ((slowMask & mine) != 0) || (dh < 0 && carrySlow);
+
+			if (!EMIT) {
+				if (valid) {
+					uint32_t w = (uint32_t)(cnt < 0 ? 0 : cnt) & VGX_CC_COUNT_MASK;
+					if (exists) { w |= VGX_CC_EXISTS; }
+					if (closedHere) { w |= VGX_CC_CLOSED; }
+					if (pop) { w |= VGX_CC_POP; }
+					A.cmd_cnt[ci] = w;
+				}
+				if (valid && drawLast) {
+					vgx_draw_info di;
+					di.first_poly_vertex = 0; di.first_subpath = 0; di.first_mesh = 0;
+					if (serialDraw || slowDraw) {
+						PathSim<false, false> sim;
+						sim.scale = scale; sim.tol = tol; sim.mtx = nullptr; sim.poly = nullptr; sim.polyBase = 0; sim.subs = nullptr; sim.subBase = 0;
+						sim.mdesc = nullptr; sim.meshBase = 0; sim.drawIndex = (uint32_t)d; sim.fillFlags = fillFlags; sim.strokeFlags = strokeFlags; sim.numFillTotal = 0;
+						sim.init();
+						const uint32_t pc0 = ps.path_cmd_begin[dr->path];
+						sim.run(ps, pc0, c + 1, stack);
+						di.num_poly_vertices = sim.nverts;
+						di.num_subpaths = sim.nsubs;
+						di.num_meshes = sim.nfill + sim.nstroke;
+						di.flags = 1u | (sim.nfill << 1);
+					} else {
+						di.num_poly_vertices = (uint32_t)(inDrawBefore + cnt);
+						di.num_subpaths = (uint32_t)subsIncl;
+						di.num_meshes = (uint32_t)(fillIncl + strokeIncl);
+						di.flags = ((uint32_t)fillIncl << 1);
+					}
+					A.dinfo[d] = di;
+				}
+			} else if (valid) {
+				const vgx_draw_info di = A.dinfo[d];
+				if (!serialDraw) {
+					// ---- vertices ---------------------------------------------------------------
+					const uint64_t vbase = di.first_poly_vertex + (uint64_t)inDrawBefore;
+					float* out = A.poly + 2 * vbase;
+					uint32_t limit = (uint32_t)(cnt < 0 ? 0 : cnt);
+					if ((cflags & VGX_CF_NEXT_IS_CLOSE) && limit > 0 && (A.cmd_cnt[ci + 1] & VGX_CC_POP)) {
+						--limit; // my last vertex is the one pathClose removes
+					}
+					const V2 start = v2(a[-2], a[-1]);
+					switch (type) {
+					case VGX_CMD_MOVE_TO:
+					case VGX_CMD_LINE_TO:
+						if (limit > 0) {
+							V2 p = v2(a[0], a[1]);
+							if (XFORM) { p = v2xform(p, mtx); }
+							*(float2*)out = make_float2(p.x, p.y);
+						}
+						break;
+					case VGX_CMD_CUBIC_TO:
+					case VGX_CMD_QUAD_TO: {
+						FastCubicSink<true, XFORM> sink;
+						sink.prev = start; sink.n = 0; sink.slow = false; sink.out = out; sink.writeLimit = limit; sink.mtx = mtx;
+						float c1x = a[0], c1y = a[1], c2x = a[2], c2y = a[3], ex, ey;
+						if (type == VGX_CMD_QUAD_TO) {
+							ex = a[2]; ey = a[3];
+							vgx_quad_to_cubic(start.x, start.y, a[0], a[1], ex, ey, &c1x, &c1y, &c2x, &c2y);
+						} else {
+							ex = a[4]; ey = a[5];
+						}
+						vgx_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tol / (scale * scale), stack, sink);
+					} break;
+					case VGX_CMD_POLYLINE: {
+						const uint32_t npts = na >> 1;
+						const uint32_t skip = npts - (uint32_t)(cnt < 0 ? 0 : cnt);
+						for (uint32_t i = 0; i < limit; ++i) {
+							V2 p = v2(a[2 * (i + skip)], a[2 * (i + skip) + 1]);
+							if (XFORM) { p = v2xform(p, mtx); }
+							*(float2*)(out + 2 * i) = make_float2(p.x, p.y);
+						}
+					} break;
+					case VGX_CMD_CLOSE: break;
+					default: {
+						PathSim<true, XFORM> sim;
+						sim.scale = scale; sim.tol = tol; sim.mtx = mtx; sim.poly = A.poly; sim.polyBase = vbase; sim.subs = nullptr; sim.subBase = 0;
+						sim.mdesc = nullptr; sim.meshBase = 0; sim.drawIndex = 0; sim.fillFlags = 0; sim.strokeFlags = 0; sim.numFillTotal = 0;
+						sim.init();
+						sim.shape(type, a);
+						sim.flushPending();
+					} break;
+					}
+					// ---- sub-path record + mesh descriptors, written by the sub-path's last command --
+					if (lastInSub) {
+						const uint32_t subIndex = (uint32_t)(subsIncl - 1);
+						const uint32_t n = (uint32_t)spTotal;
+						const uint64_t firstV = di.first_poly_vertex + (uint64_t)(inDrawBefore - spBefore);
+						vgx_subpath r;
+						r.first_vertex = firstV;
+						r.num_vertices = n;
+						r.flags = closedHere ? 1u : 0u;
+						A.subs[di.first_subpath + subIndex] = r;
+						if (A.mdesc) {
+							const uint32_t numFill = di.flags >> 1;
+							if ((fillFlags & VGX_FILL_ENABLE) && n >= 3) {
+								VgxMeshDesc m;
+								m.poly_first = firstV; m.poly_n = n; m.draw = (uint32_t)d; m.subpath = subIndex;
+								m.kind = ((fillFlags & VGX_FILL_AA) ? VGX_MESH_FILL_AA : VGX_MESH_FILL) | (closedHere ? 0x100u : 0u);
+								A.mdesc[di.first_mesh + (uint32_t)(fillIncl - 1)] = m;
+							}
+							if ((strokeFlags & VGX_STROKE_ENABLE) && n >= 2) {
+								VgxMeshDesc m;
+								m.poly_first = firstV; m.poly_n = n; m.draw = (uint32_t)d; m.subpath = subIndex;
+								const uint32_t kd = !(strokeFlags & VGX_STROKE_AA) ? VGX_MESH_STROKE : ((strokeFlags & VGX_STROKE_THIN) ? VGX_MESH_STROKE_AA_THIN : VGX_MESH_STROKE_AA);
+								m.kind = kd | (closedHere ? 0x100u : 0u);
+								A.mdesc[di.first_mesh + numFill + (uint32_t)(strokeIncl - 1)] = m;
+							}
+						}
+					}
+				} else if (drawLast) {
+					// exact sequential re-run of the whole draw by this one lane
+					PathSim<true, XFORM> sim;
+					sim.scale = scale; sim.tol = tol; sim.mtx = mtx; sim.poly = A.poly; sim.polyBase = di.first_poly_vertex; sim.subs = A.subs; sim.subBase = di.first_subpath;
+					sim.mdesc = A.mdesc; sim.meshBase = di.first_mesh; sim.drawIndex = (uint32_t)d; sim.fillFlags = fillFlags; sim.strokeFlags = strokeFlags;
+					sim.numFillTotal = di.flags >> 1;
+					sim.init();
+					const uint32_t pc0 = ps.path_cmd_begin[dr->path];
+					sim.run(ps, pc0, c + 1, stack);
+				}
+			}
+
+			// ---- carries into the next chunk (taken from the last valid lane) ---------------------
+			const int nvalid = (int)((C1 - chunk) < (uint64_t)VGX_WAVE ? (C1 - chunk) : (uint64_t)VGX_WAVE);
+			const int L = nvalid - 1;
+			const int lastIsDrawLast = __shfl((int)drawLast, L);
+			const int lastIsSubLast = __shfl((int)((cflags & VGX_CF_LAST_IN_SUB) != 0), L);
+			const int nDraw = __shfl(inDrawBefore + cnt, L);
+			const int nSp = __shfl(spTotal, L);
+			const int nSubs = __shfl(subsIncl, L);
+			const int nFill = __shfl(fillIncl, L);
+			const int nStroke = __shfl(strokeIncl, L);
+			const int nSlow = __shfl((int)slowDraw, L);
+			const int nHeadExists = __shfl(headExists, L);
+			carryDrawVerts = lastIsDrawLast ? 0 : nDraw;
+			carrySubs = lastIsDrawLast ? 0 : nSubs;
+			carryFill = lastIsDrawLast ? 0 : nFill;
+			carryStroke = lastIsDrawLast ? 0 : nStroke;
+			carrySlow = lastIsDrawLast ? 0 : nSlow;
+			carrySpVerts = (lastIsDrawLast || lastIsSubLast) ? 0 : nSp;
+			carrySpExists = (lastIsDrawLast || lastIsSubLast) ? 0 : nHeadExists;
+		}
+	}
+}
+
+} // namespace
+
+void vgx_launch_flatten(bool emit, const VgxFlattenArgs& a, int numBlocks, hipStream_t s)
+{
+	if (!emit) {
+		hipLaunchKernelGGL((k_flatten<false, false>), dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
+	} else if (a.apply_transform) {
+		hipLaunchKernelGGL((k_flatten<true, true>), dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
+	} else {
+		hipLaunchKernelGGL((k_flatten<true, false>), dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
+	}
+}

@@ -1,0 +1,64 @@
+// vgx_hosttest.cpp -- CPU build of the lane-level product code (vgx_lane.h, vgx_pathsim.h) for unit tests.
+// This is NOT a fallback path: nothing in the package loads it; tests/test_host_lane_logic.py uses it to
+// check the per-lane builder logic against the oracle without a GPU.
+#include "vgx_pathsim.h"
+#include <string.h>
+
+namespace {
+struct HostStack
+{
+	float s[VGX_CUBIC_MAX_PENDING][6];
+	void push(int level, float ax, float ay, float bx, float by, float cx, float cy)
+	{
+		float* p = s[level];
+		p[0] = ax; p[1] = ay; p[2] = bx; p[3] = by; p[4] = cx; p[5] = cy;
+	}
+	void pop(int level, float& ax, float& ay, float& bx, float& by, float& cx, float& cy)
+	{
+		const float* p = s[level];
+		ax = p[0]; ay = p[1]; bx = p[2]; by = p[3]; cx = p[4]; cy = p[5];
+	}
+};
+}
+
+extern "C" {
+
+// Runs the exact serial builder (the device's slow path) for ONE draw on the host.
+// counts[4] = { num_poly_vertices, num_subpaths, num_fill_meshes, num_stroke_meshes }
+int vgxt_serial_flatten(const vgx_pathset_desc* d, const vgx_draw* draw, int applyTransform, float* poly, vgx_subpath* subs, uint32_t* counts)
+{
+	VgxPathSetDev ps;
+	memset(&ps, 0, sizeof(ps));
+	ps.cmd_type = d->cmd_type; ps.cmd_arg_off = d->cmd_arg_off; ps.args = d->args; ps.path_cmd_begin = d->path_cmd_begin;
+	ps.npaths = d->npaths; ps.ncmd = d->ncmd;
+	HostStack st;
+	const uint32_t c0 = d->path_cmd_begin[draw->path], c1 = d->path_cmd_begin[draw->path + 1];
+	if (poly && applyTransform) {
+		PathSim<true, true> sim;
+		sim.scale = draw->scale; sim.tol = draw->tess_tol; sim.mtx = draw->mtx; sim.poly = poly; sim.polyBase = 0;
+		sim.subs = subs; sim.subBase = 0; sim.mdesc = nullptr; sim.meshBase = 0; sim.drawIndex = 0;
+		sim.fillFlags = draw->fill_flags; sim.strokeFlags = draw->stroke_flags; sim.numFillTotal = 0;
+		sim.init();
+		sim.run(ps, c0, c1, st);
+		counts[0] = sim.nverts; counts[1] = sim.nsubs; counts[2] = sim.nfill; counts[3] = sim.nstroke;
+	} else if (poly) {
+		PathSim<true, false> sim;
+		sim.scale = draw->scale; sim.tol = draw->tess_tol; sim.mtx = draw->mtx; sim.poly = poly; sim.polyBase = 0;
+		sim.subs = subs; sim.subBase = 0; sim.mdesc = nullptr; sim.meshBase = 0; sim.drawIndex = 0;
+		sim.fillFlags = draw->fill_flags; sim.strokeFlags = draw->stroke_flags; sim.numFillTotal = 0;
+		sim.init();
+		sim.run(ps, c0, c1, st);
+		counts[0] = sim.nverts; counts[1] = sim.nsubs; counts[2] = sim.nfill; counts[3] = sim.nstroke;
+	} else {
+		PathSim<false, false> sim;
+		sim.scale = draw->scale; sim.tol = draw->tess_tol; sim.mtx = nullptr; sim.poly = nullptr; sim.polyBase = 0;
+		sim.subs = nullptr; sim.subBase = 0; sim.mdesc = nullptr; sim.meshBase = 0; sim.drawIndex = 0;
+		sim.fillFlags = draw->fill_flags; sim.strokeFlags = draw->stroke_flags; sim.numFillTotal = 0;
+		sim.init();
+		sim.run(ps, c0, c1, st);
+		counts[0] = sim.nverts; counts[1] = sim.nsubs; counts[2] = sim.nfill; counts[3] = sim.nstroke;
+	}
+	return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,47 @@
+// vgx_internal.h -- device-side data layout shared by the kernels and the C-ABI implementation.
+#ifndef VGX_INTERNAL_H
+#define VGX_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vgx.h"
+#include "vgx_lane.h"
+
+#include "vgx_internal_types.h"
+
+struct VgxFlattenArgs
+{
+	VgxPathSetDev ps;
+	const vgx_draw* draws;
+	uint64_t ndraws;
+	const uint64_t* cmd_prefix; // [ndraws+1]
+	uint32_t* cmd_cnt;          // [num_cmd_instances]
+	vgx_draw_info* dinfo;       // [ndraws]
+	float* poly;                // emit: [cap][2]
+	vgx_subpath* subs;          // emit
+	VgxMeshDesc* mdesc;         // emit (may be null: flatten-only API)
+	VgxTotals* totals;
+	VgxCaps caps;
+	int apply_transform;
+};
+
+struct VgxStrokeArgs
+{
+	const vgx_draw* draws;
+	const float* poly;
+	const VgxMeshDesc* mdesc;
+	const uint64_t* elem_prefix; // [num_meshes+1] exclusive prefix of poly_n over meshes
+	vgx_mesh* mtab;              // [num_meshes] count: writes num_*, scan fills first_*, emit reads
+	float* pos;
+	uint32_t* color;
+	uint16_t* idx;
+	vgx_mesh* meshes_out;        // caller's mesh table (emit copies mtab into it)
+	VgxTotals* totals;
+	VgxCaps caps;
+};
+
+// launchers (defined in the .hip files)
+void vgx_launch_flatten(bool emit, const VgxFlattenArgs& a, int numBlocks, hipStream_t s);
+void vgx_launch_stroke(bool emit, const VgxStrokeArgs& a, int numBlocks, hipStream_t s);
+
+#endif

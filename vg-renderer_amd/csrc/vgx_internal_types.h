@@ -1,0 +1,77 @@
+// vgx_internal_types.h -- plain data layouts shared by device code and the host unit-test build.
+#ifndef VGX_INTERNAL_TYPES_H
+#define VGX_INTERNAL_TYPES_H
+
+#include <stdint.h>
+#include "../../include/vgx.h"
+
+// ---- path set resident in HBM ----------------------------------------------------------------
+// Same SoA arrays as vgx_pathset_desc plus two per-command arrays derived on the host when the set is
+// created (static structure of the command stream, independent of draws):
+//   cmd_flags    bit0 STARTS_SUB   command opens a sub-path (MOVE_TO, closed shapes, leading ARC)
+//                bit1 LAST_IN_SUB  next command opens a sub-path or the path ends
+//                bit2 NEXT_IS_CLOSE
+//                bit3 LAST_IN_PATH
+//   cmd_sp_start absolute index of the command that opened this command's sub-path
+//   path_flags   bit0 SERIAL       path contains ARC / ARC_TO: their end points are computed, so the
+//                                  lane-parallel start-point gather is impossible -> exact serial lane path
+#define VGX_CF_STARTS_SUB 0x1u
+#define VGX_CF_LAST_IN_SUB 0x2u
+#define VGX_CF_NEXT_IS_CLOSE 0x4u
+#define VGX_CF_LAST_IN_PATH 0x8u
+#define VGX_PF_SERIAL 0x1u
+
+struct VgxPathSetDev
+{
+	const uint8_t* cmd_type;
+	const uint8_t* cmd_flags;
+	const uint32_t* cmd_arg_off;
+	const uint32_t* cmd_sp_start;
+	const float* args;
+	const uint32_t* path_cmd_begin;
+	const uint8_t* path_flags;
+	uint32_t npaths;
+	uint32_t ncmd;
+};
+
+// ---- per-command-instance word written by the count pass, read by the emit pass ------------------
+// bits 0..27 vertex count contributed by the command; bit28 EXISTS (command opened a sub-path that
+// really exists), bit29 CLOSED (this command closed its sub-path), bit30 POP (CLOSE removed the
+// previous vertex, pathClose path.cpp:716-725).
+#define VGX_CC_COUNT_MASK 0x0FFFFFFFu
+#define VGX_CC_EXISTS 0x10000000u
+#define VGX_CC_CLOSED 0x20000000u
+#define VGX_CC_POP 0x40000000u
+
+// ---- one mesh to generate (sub-path x op), written by flatten-emit, consumed by the stroker ---------
+struct VgxMeshDesc
+{
+	uint64_t poly_first; // first polyline vertex (batch-global)
+	uint32_t poly_n;
+	uint32_t draw;
+	uint32_t subpath;    // sub-path index within the draw
+	uint32_t kind;       // VGX_MESH_* | closed << 8
+};
+
+// ---- batch totals kept in device memory (mirrors vgx_sizes + internal counters) -------------------
+struct VgxTotals
+{
+	vgx_sizes sizes;
+	uint64_t num_cmd_instances;
+	uint64_t num_elements; // stroker work items (one per polyline vertex per mesh)
+	uint32_t status;       // vgx_status, sticky (first error wins)
+	uint32_t pad;
+};
+
+// Capacities the device-side checks compare against.
+struct VgxCaps
+{
+	uint64_t cmd_instances;
+	uint64_t poly_vertices;
+	uint64_t subpaths;
+	uint64_t meshes;
+	uint64_t vertices;
+	uint64_t indices;
+};
+
+#endif

@@ -1,0 +1,177 @@
+// vgx_lane.h -- per-lane geometry used by the HIP kernels (flatten + stroker).
+//
+// Everything here is what ONE lane does for ONE path command or ONE polyline vertex; the kernels in
+// vgx_flatten.hip / vgx_stroke.hip add the wavefront-level parts (ballot, prefix scans, offsets).
+// Functions are __host__ __device__ so the same arithmetic can be unit-tested on the CPU
+// (csrc/vgx_hosttest.cpp); the product path only ever runs them on the device.
+//
+// Arithmetic contract: binary32, evaluation order exactly as in the cited reference lines, no FMA
+// contraction (-ffp-contract=off), transcendentals from vgmath.h.
+#ifndef VGX_LANE_H
+#define VGX_LANE_H
+
+#include "vgmath.h"
+#include "../../include/vgx.h"
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define VGX_HD __host__ __device__ __forceinline__
+#define VGX_HDM __host__ __device__ __forceinline__ /* member functions */
+#else
+#define VGX_HD static inline
+#define VGX_HDM inline
+#endif
+
+struct V2 { float x, y; };
+
+VGX_HD V2 v2(float x, float y) { V2 r; r.x = x; r.y = y; return r; }
+VGX_HD V2 v2add(V2 a, V2 b) { return v2(a.x + b.x, a.y + b.y); }
+VGX_HD V2 v2sub(V2 a, V2 b) { return v2(a.x - b.x, a.y - b.y); }
+VGX_HD V2 v2mul(V2 a, float s) { return v2(a.x * s, a.y * s); }
+VGX_HD V2 v2ccw(V2 a) { return v2(-a.y, a.x); }
+VGX_HD V2 v2cw(V2 a) { return v2(a.y, -a.x); }
+VGX_HD float v2dot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
+VGX_HD float v2cross(V2 a, V2 b) { return a.x * b.y - b.x * a.y; }
+
+// vec2Dir, stroker.cpp:31-38
+VGX_HD V2 v2dir(V2 a, V2 b)
+{
+	const float dx = b.x - a.x;
+	const float dy = b.y - a.y;
+	const float lenSqr = dx * dx + dy * dy;
+	const float invLen = lenSqr < VGM_EPSILON ? 0.0f : vgm_rsqrt(lenSqr);
+	return v2(dx * invLen, dy * invLen);
+}
+
+// calcExtrusionVector, stroker.cpp:40-53
+VGX_HD V2 v2extrude(V2 d01, V2 d12)
+{
+	V2 v = v2ccw(d01);
+	const float c = v2cross(d12, d01);
+	if (vgm_abs(c) > (1.0f / 100.0f)) {
+		v = v2mul(v2sub(d01, d12), 1.0f / c);
+	}
+	return v;
+}
+
+// transformPos2D, vg_util.h:24-28 (scalar association (m0*x + m2*y) + m4)
+VGX_HD V2 v2xform(V2 p, const float* m)
+{
+	return v2(m[0] * p.x + m[2] * p.y + m[4], m[1] * p.x + m[3] * p.y + m[5]);
+}
+
+VGX_HD bool v2near(V2 a, V2 b) // the epsilon test of pathAddVertex / pathClose (path.cpp:769-775, 718-722)
+{
+	const float dx = a.x - b.x;
+	const float dy = a.y - b.y;
+	return dx * dx + dy * dy < VGM_EPSILON;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adaptive cubic flattening (pathCubicTo, path.cpp:86-182) as a per-lane depth-first walk.
+//
+// STACK keeps the pending right halves (at most 10, path.cpp:90). Only three points per entry are
+// stored: the right half's first point is always the current piece's end point at pop time.
+// SINK receives leaves in curve order: sink.leaf(x, y); sink.dropped() is called when a piece is
+// discarded because the stack is full (path.cpp:168-179).
+// ------------------------------------------------------------------------------------------------
+#define VGX_CUBIC_MAX_PENDING 10
+
+template<class STACK, class SINK>
+VGX_HD void vgx_flatten_cubic(float x1, float y1, float x2, float y2, float x3, float y3, float x4, float y4, float tessTol, STACK& stack, SINK& sink)
+{
+	int pending = 0;
+	for (;;) {
+		const float dx = x4 - x1;
+		const float dy = y4 - y1;
+		const float d2 = vgm_abs((x2 - x4) * dy - (y2 - y4) * dx);
+		const float d3 = vgm_abs((x3 - x4) * dy - (y3 - y4) * dx);
+		const float d23 = d2 + d3;
+		if (d23 * d23 <= tessTol * (dx * dx + dy * dy)) {
+			sink.leaf(x4, y4);
+		} else if (pending < VGX_CUBIC_MAX_PENDING) {
+			const float x12 = (x1 + x2) * 0.5f, y12 = (y1 + y2) * 0.5f;
+			const float x23 = (x2 + x3) * 0.5f, y23 = (y2 + y3) * 0.5f;
+			const float x34 = (x3 + x4) * 0.5f, y34 = (y3 + y4) * 0.5f;
+			const float x123 = (x12 + x23) * 0.5f, y123 = (y12 + y23) * 0.5f;
+			const float x234 = (x23 + x34) * 0.5f, y234 = (y23 + y34) * 0.5f;
+			const float x1234 = (x123 + x234) * 0.5f, y1234 = (y123 + y234) * 0.5f;
+			stack.push(pending, x234, y234, x34, y34, x4, y4);
+			++pending;
+			x2 = x12; y2 = y12;
+			x3 = x123; y3 = y123;
+			x4 = x1234; y4 = y1234;
+			continue;
+		} else {
+			sink.dropped();
+		}
+		if (pending == 0) {
+			return;
+		}
+		--pending;
+		x1 = x4; y1 = y4; // right half starts where the finished left subtree ended
+		stack.pop(pending, x2, y2, x3, y3, x4, y4);
+	}
+}
+
+// Quadratic -> cubic control points (pathQuadraticTo, path.cpp:184-201)
+VGX_HD void vgx_quad_to_cubic(float x0, float y0, float cx, float cy, float x, float y, float* c1x, float* c1y, float* c2x, float* c2y)
+{
+	*c1x = x0 + (2.0f / 3.0f) * (cx - x0);
+	*c1y = y0 + (2.0f / 3.0f) * (cy - y0);
+	*c2x = x + (2.0f / 3.0f) * (cx - x);
+	*c2y = y + (2.0f / 3.0f) * (cy - y);
+}
+
+// da = 2*acos(s*r/(s*r+tol)) (path.cpp:307,602,654; stroker.cpp:1013,1398)
+VGX_HD float vgx_step_angle(float scale, float r, float tol)
+{
+	return vgm_acos((scale * r) / ((scale * r) + tol)) * 2.0f;
+}
+
+VGX_HD uint32_t vgx_half_circle_points(float da) // max(2, ceil(pi/da))
+{
+	return vgm_umax(2u, (uint32_t)vgm_ceil(VGM_PI / da));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stroker join geometry shared by the three polyline strokers.
+// ------------------------------------------------------------------------------------------------
+struct VgxJoin
+{
+	V2 d01, d12, v; // unit directions of the two segments, unit-width extrusion vector
+	bool leftInner; // dot(d12, v*w) >= 0 (stroker.cpp:1099-1100, 1534-1535, 2072-2073)
+};
+
+VGX_HD VgxJoin vgx_join(V2 p0, V2 p1, V2 p2, float sideWidth)
+{
+	VgxJoin j;
+	j.d01 = v2dir(p0, p1);
+	j.d12 = v2dir(p1, p2);
+	j.v = v2extrude(j.d01, j.d12);
+	const V2 vw = v2mul(j.v, sideWidth);
+	j.leftInner = (j.d12.x * vw.x + j.d12.y * vw.y) >= 0.0f;
+	return j;
+}
+
+struct VgxArc { float a01, arcDa; uint32_t n; };
+
+// Round-join arc (stroker.cpp:1140-1147 / 1238-1245 / 1588-1595 / 1744-1751). n01/n12 are the
+// outer-side normals (perpCW for a left-inner join, perpCCW for a right-inner one).
+VGX_HD VgxArc vgx_round_join_arc(V2 n01, V2 n12, bool leftInner, float da)
+{
+	VgxArc r;
+	const float a01 = vgm_atan2(n01.y, n01.x);
+	float a12 = vgm_atan2(n12.y, n12.x);
+	if (leftInner) {
+		if (a12 < a01) { a12 += VGM_PI2; }
+		r.n = vgm_umax(2u, (uint32_t)((a12 - a01) / da));
+	} else {
+		if (a12 > a01) { a12 -= VGM_PI2; }
+		r.n = vgm_umax(2u, (uint32_t)((a01 - a12) / da));
+	}
+	r.a01 = a01;
+	r.arcDa = (a12 - a01) / (float)r.n;
+	return r;
+}
+
+#endif // VGX_LANE_H

@@ -1,0 +1,694 @@
+// vgx_stroke.hip -- batch stroke / convex-fill / AA-fringe mesh generation on gfx950
+// (replaces vg::strokerXXX, reference src/stroker.cpp).
+//
+// Work decomposition
+//   One lane = one ELEMENT = one polyline vertex of one mesh: a cap (first/last vertex of an open
+//   stroke), a join, or a polygon corner of a convex fill. The batch is a flat stream of elements
+//   (elem_prefix = exclusive scan of poly_n over meshes); a wavefront owns all meshes whose first
+//   element falls into one 64-element bucket and walks them 64 elements at a time.
+//   The reference builds each mesh sequentially (running m_NumVertices / m_NumIndices and the
+//   prevSegment*ID bookkeeping, stroker.cpp:1401-1410). Here every element
+//     A. computes its geometry and its own vertex / index counts (data dependent only for Round
+//        joins / caps: numArcPoints, numPointsHalfCircle),
+//     B. gets its vertex / index base inside the mesh from a wave prefix scan segmented by mesh (with a
+//        carry across chunks) -- the "running counters" of the reference,
+//     C. gets the previous element's exit rail IDs (prevSegment{LeftAA,Left,Right,RightAA}ID) from the
+//        neighbouring lane (shuffle, carry across chunks), and
+//     D. writes its vertices, colours and indices straight to their final place.
+//   Two passes (template<EMIT>): count (A+B, per-mesh totals) -> device-wide scan over meshes -> emit.
+//
+// Every emitted position / colour / index follows the cited reference lines; the rails formulation is
+// the one of SURVEY.md appendix B.
+#include "vgx_internal.h"
+#include "vgx_wave.h"
+
+namespace {
+
+struct Rails { uint32_t a, b, c, d; }; // AA: laa,l,r,raa   non-AA: l,r,-,-   thin: laa,m,raa,-
+
+__device__ __forceinline__ Rails rails(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { Rails r; r.a = a; r.b = b; r.c = c; r.d = d; return r; }
+__device__ __forceinline__ uint64_t rails_pack(Rails r) { return (uint64_t)(r.a & 0xFFFFu) | ((uint64_t)(r.b & 0xFFFFu) << 16) | ((uint64_t)(r.c & 0xFFFFu) << 32) | ((uint64_t)(r.d & 0xFFFFu) << 48); }
+__device__ __forceinline__ Rails rails_unpack(uint64_t p) { return rails((uint32_t)(p & 0xFFFFu), (uint32_t)((p >> 16) & 0xFFFFu), (uint32_t)((p >> 32) & 0xFFFFu), (uint32_t)(p >> 48)); }
+
+template<bool EMIT>
+struct MeshWriter
+{
+	float* pos;       // mesh's first vertex
+	uint32_t* col;
+	uint16_t* idx;    // mesh's first index
+	uint32_t color, c0;
+	__device__ __forceinline__ void v(uint32_t i, V2 p, uint32_t c) const
+	{
+		if (EMIT) {
+			*(float2*)(pos + 2 * (size_t)i) = make_float2(p.x, p.y);
+			col[i] = c;
+		}
+	}
+	__device__ __forceinline__ void tri(uint32_t k, uint32_t a, uint32_t b, uint32_t c) const
+	{
+		if (EMIT) {
+			idx[k] = (uint16_t)a; idx[k + 1] = (uint16_t)b; idx[k + 2] = (uint16_t)c;
+		}
+	}
+	// 18 indices joining two 4-rail cross sections (stroker.cpp:1557-1564, 1714-1721, 1973-1980)
+	__device__ __forceinline__ void bridge4(uint32_t k, Rails p, Rails c) const
+	{
+		tri(k, p.a, p.b, c.b); tri(k + 3, p.a, c.b, c.a);
+		tri(k + 6, p.b, p.c, c.c); tri(k + 9, p.b, c.c, c.b);
+		tri(k + 12, p.c, p.d, c.d); tri(k + 15, p.c, c.d, c.c);
+	}
+	// 6 indices, 2 rails (stroker.cpp:1119-1122, 1217-1220, 1374-1377)
+	__device__ __forceinline__ void bridge2(uint32_t k, Rails p, Rails c) const
+	{
+		tri(k, p.a, p.b, c.b); tri(k + 3, p.a, c.b, c.a);
+	}
+	// 12 indices, 3 rails (stroker.cpp:2093-2098, 2175-2180, 2299-2304)
+	__device__ __forceinline__ void bridge3(uint32_t k, Rails p, Rails c) const
+	{
+		tri(k, p.a, p.b, c.b); tri(k + 3, p.a, c.b, c.a);
+		tri(k + 6, p.b, p.c, c.c); tri(k + 9, p.b, c.c, c.b);
+	}
+};
+
+enum { ET_CAP_FIRST = 0, ET_JOIN = 1, ET_CAP_LAST = 2, ET_FILL = 3 };
+
+// Everything step A computes for one element and step D needs again.
+struct Elem
+{
+	uint32_t nv, ni;  // my vertex / index count (ni excludes the connect / closing part handled below)
+	uint32_t et;
+	V2 p1;            // the polyline vertex this element sits on
+	V2 d01, d12, v;   // join: segment directions + extrusion; caps: d01 = cap direction
+	bool leftInner;
+	bool hasConnect;  // a bridge from the previous element precedes my own indices
+	bool closesLoop;  // I am the last join of a closed stroke: closing bridge follows my indices
+	VgxArc arc;       // Round/Bevel joins (n = 1 for Bevel)
+	uint32_t H;       // numPointsHalfCircle (Round caps)
+};
+
+struct MeshCtx
+{
+	uint32_t kind, N, j, cap, join;
+	bool closed;
+	float hsw, hswAA, fringe, da;
+	uint32_t color;
+	const float* vtx; // mesh's first polyline vertex
+};
+
+__device__ __forceinline__ V2 ldv(const float* vtx, uint32_t i)
+{
+	const float2 t = *(const float2*)(vtx + 2 * (size_t)i);
+	return v2(t.x, t.y);
+}
+
+// ---- step A ---------------------------------------------------------------------------------------
+__device__ __forceinline__ Elem elem_geometry(const MeshCtx& m)
+{
+	Elem e;
+	e.nv = 0; e.ni = 0; e.et = ET_FILL; e.leftInner = true; e.hasConnect = false; e.closesLoop = false;
+	e.arc.a01 = 0.0f; e.arc.arcDa = 0.0f; e.arc.n = 1; e.H = 2;
+	const uint32_t N = m.N, j = m.j;
+	e.p1 = ldv(m.vtx, j);
+	e.d01 = v2(0.0f, 0.0f); e.d12 = e.d01; e.v = e.d01;
+
+	if (m.kind == VGX_MESH_FILL) { // strokerConvexFill, stroker.cpp:334-365
+		e.nv = 1;
+		e.ni = (j + 2 < N) ? 3 : 0;
+		return e;
+	}
+	const V2 pPrev = ldv(m.vtx, j == 0 ? N - 1 : j - 1);
+	const V2 pNext = ldv(m.vtx, j == N - 1 ? 0 : j + 1);
+	if (m.kind == VGX_MESH_FILL_AA) { // strokerConvexFillAA, stroker.cpp:713-807
+		e.d01 = v2dir(pPrev, e.p1);
+		e.d12 = v2dir(e.p1, pNext);
+		e.v = v2extrude(e.d01, e.d12);
+		e.nv = 2;
+		e.ni = ((j + 2 < N) ? 3 : 0) + 6;
+		return e;
+	}
+	// polyline strokes
+	const bool isCapFirst = !m.closed && j == 0;
+	const bool isCapLast = !m.closed && j == N - 1;
+	const uint32_t railCount = (m.kind == VGX_MESH_STROKE) ? 2u : (m.kind == VGX_MESH_STROKE_AA ? 4u : 3u);
+	const uint32_t bridgeIdx = (railCount - 1) * 6; // 6 / 18 / 12
+	if (isCapFirst || isCapLast) {
+		e.et = isCapFirst ? ET_CAP_FIRST : ET_CAP_LAST;
+		e.d01 = isCapFirst ? v2dir(e.p1, pNext) : v2dir(pPrev, e.p1);
+		e.hasConnect = isCapLast;
+		const bool roundCap = (m.cap == VGX_CAP_ROUND) && m.kind != VGX_MESH_STROKE_AA_THIN;
+		if (roundCap) {
+			const uint32_t H = vgx_half_circle_points(m.da);
+			e.H = H;
+			if (m.kind == VGX_MESH_STROKE_AA) {
+				e.nv = 2 * H;
+				e.ni = isCapFirst ? (9 * H - 12) : (3 * (H - 2) + 6 * (H - 1)); // stroker.cpp:1490, 1949-1966
+			} else {
+				e.nv = H;
+				e.ni = 3 * (H - 2); // stroker.cpp:1071, 1362
+			}
+		} else {
+			e.nv = railCount;
+			e.ni = (m.kind == VGX_MESH_STROKE_AA) ? 6u : 0u; // cap quad only exists in the AA stroker
+		}
+		return e;
+	}
+	e.et = ET_JOIN;
+	const float sideWidth = (m.kind == VGX_MESH_STROKE) ? m.hsw : (m.kind == VGX_MESH_STROKE_AA ? m.hswAA : m.fringe);
+	const VgxJoin jn = vgx_join(pPrev, e.p1, pNext, sideWidth);
+	e.d01 = jn.d01; e.d12 = jn.d12; e.v = jn.v; e.leftInner = jn.leftInner;
+	e.hasConnect = !(m.closed && j == 0);
+	e.closesLoop = m.closed && j == N - 1;
+	if (m.kind == VGX_MESH_STROKE_AA_THIN) { // stroker.cpp:2060-2240; Round join -> Bevel (:318-327)
+		const bool bevel = m.join != VGX_JOIN_MITER;
+		e.nv = bevel ? 4 : 3;
+		e.ni = bevel ? 3 : 0;
+		return e;
+	}
+	if (m.join == VGX_JOIN_MITER) {
+		e.nv = railCount;
+		e.ni = 0;
+		return e;
+	}
+	if (m.join == VGX_JOIN_ROUND) {
+		const V2 n01 = e.leftInner ? v2cw(e.d01) : v2ccw(e.d01);
+		const V2 n12 = e.leftInner ? v2cw(e.d12) : v2ccw(e.d12);
+		e.arc = vgx_round_join_arc(n01, n12, e.leftInner, m.da);
+	}
+	const uint32_t n = e.arc.n;
+	if (m.kind == VGX_MESH_STROKE_AA) {
+		e.nv = 2 * n + 4; // stroker.cpp:1599
+		e.ni = 9 * n;     // :1675
+	} else {
+		e.nv = n + 2;     // :1156
+		e.ni = 3 * n;     // :1186
+	}
+	(void)bridgeIdx;
+	return e;
+}
+
+__device__ __forceinline__ uint32_t elem_total_indices(const MeshCtx& m, const Elem& e)
+{
+	if (m.kind == VGX_MESH_FILL || m.kind == VGX_MESH_FILL_AA) {
+		return e.ni;
+	}
+	const uint32_t bridgeIdx = (m.kind == VGX_MESH_STROKE) ? 6u : (m.kind == VGX_MESH_STROKE_AA ? 18u : 12u);
+	return e.ni + (e.hasConnect ? bridgeIdx : 0u) + (e.closesLoop ? bridgeIdx : 0u);
+}
+
+// ---- exit rails (what the next element connects to) ---------------------------------------------------
+__device__ __forceinline__ Rails elem_exit_rails(const MeshCtx& m, const Elem& e, uint32_t b)
+{
+	if (m.kind == VGX_MESH_STROKE_AA) {
+		if (e.et == ET_CAP_FIRST) {
+			if (m.cap == VGX_CAP_ROUND) { return rails(1, 0, (e.H - 1) * 2, (e.H - 1) * 2 + 1); } // :1512-1515
+			return rails(0, 1, 2, 3);
+		}
+		if (m.join == VGX_JOIN_MITER) {
+			return e.leftInner ? rails(b, b + 1, b + 2, b + 3) : rails(b + 3, b + 2, b + 1, b);
+		}
+		const uint32_t arcID = b + 2 + 2 * e.arc.n;
+		return e.leftInner ? rails(b, b + 1, arcID, arcID + 1) : rails(arcID + 1, arcID, b + 1, b);
+	}
+	if (m.kind == VGX_MESH_STROKE) {
+		if (e.et == ET_CAP_FIRST) {
+			if (m.cap == VGX_CAP_ROUND) { return rails(0, e.H - 1, 0, 0); } // :1079-1080
+			return rails(0, 1, 0, 0);
+		}
+		if (m.join == VGX_JOIN_MITER) {
+			return e.leftInner ? rails(b, b + 1, 0, 0) : rails(b + 1, b, 0, 0);
+		}
+		const uint32_t endID = b + e.arc.n + 1;
+		return e.leftInner ? rails(b, endID, 0, 0) : rails(endID, b, 0, 0);
+	}
+	// thin
+	if (e.et == ET_CAP_FIRST) {
+		return rails(0, 1, 2, 0);
+	}
+	if (m.join == VGX_JOIN_MITER) {
+		return e.leftInner ? rails(b, b + 1, b + 2, 0) : rails(b + 2, b + 1, b, 0);
+	}
+	return e.leftInner ? rails(b, b + 1, b + 3, 0) : rails(b + 3, b + 1, b, 0);
+}
+
+// entry rails of join 0 of a closed stroke = the firstSegment*ID of the reference
+__device__ __forceinline__ Rails first_join_entry(const MeshCtx& m, bool leftInner0)
+{
+	if (m.kind == VGX_MESH_STROKE_AA) { return leftInner0 ? rails(0, 1, 2, 3) : rails(3, 2, 1, 0); }
+	if (m.kind == VGX_MESH_STROKE) { return leftInner0 ? rails(0, 1, 0, 0) : rails(1, 0, 0, 0); }
+	return leftInner0 ? rails(0, 1, 2, 0) : rails(2, 1, 0, 0);
+}
+
+// ---- step D: emit one element ---------------------------------------------------------------------
+template<bool EMIT>
+__device__ void elem_emit(const MeshCtx& m, const Elem& e, uint32_t b, uint32_t k, Rails prev, const MeshWriter<EMIT>& w)
+{
+	const uint32_t N = m.N, j = m.j;
+	const uint32_t color = w.color, c0 = w.c0;
+	const V2 p1 = e.p1;
+
+	if (m.kind == VGX_MESH_FILL) {
+		w.v(j, p1, color);
+		if (j + 2 < N) { w.tri(3 * j, 0, j + 1, j + 2); }
+		return;
+	}
+	if (m.kind == VGX_MESH_FILL_AA) {
+		// orientation from the first triangle only (stroker.cpp:721-723)
+		const V2 q0 = ldv(m.vtx, 0), q1 = ldv(m.vtx, 1), q2 = ldv(m.vtx, 2);
+		const float orient = v2cross(v2sub(q1, q0), v2sub(q2, q0));
+		const float aa = m.fringe * 0.5f * vgm_sign(orient);
+		const V2 vaa = v2mul(e.v, aa);
+		w.v(2 * j, v2add(p1, vaa), color);
+		w.v(2 * j + 1, v2sub(p1, vaa), c0);
+		if (j + 2 < N) { w.tri(3 * j, 0, 2 * j + 2, 2 * j + 4); } // fan, :769-776
+		const uint32_t q = 3 * (N - 2) + 6 * j;
+		const uint32_t fb = 2 * j;
+		if (j + 1 < N) { // :779-787
+			w.tri(q, fb, fb + 1, fb + 3);
+			w.tri(q + 3, fb, fb + 3, fb + 2);
+		} else {         // :789-795
+			w.tri(q, fb, fb + 1, 1);
+			w.tri(q + 3, fb, 1, 0);
+		}
+		return;
+	}
+
+	const float hsw = m.hsw, hswAA = m.hswAA, fringe = m.fringe;
+
+	// ------------------------------- AA stroke, 4 rails -------------------------------------------
+	if (m.kind == VGX_MESH_STROKE_AA) {
+		if (e.et != ET_JOIN) {
+			const bool firstCap = e.et == ET_CAP_FIRST;
+			const V2 d = e.d01;
+			const V2 l = v2ccw(d);
+			if (m.cap == VGX_CAP_ROUND) { // :1475-1515, 1917-1968
+				const uint32_t H = e.H;
+				const float startAngle = vgm_atan2(l.y, l.x);
+				for (uint32_t i = 0; i < H; ++i) {
+					const float t = i * VGM_PI / (float)(H - 1);
+					const float a = firstCap ? startAngle + t : startAngle - t;
+					float sa, ca;
+					vgm_sincos(a, &sa, &ca);
+					w.v(b + 2 * i, v2(p1.x + ca * hsw, p1.y + sa * hsw), color);
+					w.v(b + 2 * i + 1, v2(p1.x + ca * hswAA, p1.y + sa * hswAA), c0);
+				}
+				if (firstCap) {
+					uint32_t q = k;
+					for (uint32_t i = 0; i + 2 < H; ++i, q += 3) { w.tri(q, 0, (i << 1) + 2, (i << 1) + 4); }
+					for (uint32_t i = 0; i + 1 < H; ++i, q += 6) {
+						const uint32_t base = i << 1;
+						w.tri(q, base, base + 1, base + 3);
+						w.tri(q + 3, base, base + 3, base + 2);
+					}
+				} else {
+					const uint32_t en = b + (H - 1) * 2;
+					w.bridge4(k, prev, rails(b + 1, b, en, en + 1));
+					uint32_t q = k + 18;
+					for (uint32_t i = 0; i + 2 < H; ++i, q += 3) {
+						const uint32_t base = b + (i << 1);
+						w.tri(q, b, base + 4, base + 2);
+					}
+					for (uint32_t i = 0; i + 1 < H; ++i, q += 6) {
+						const uint32_t base = b + (i << 1);
+						w.tri(q, base, base + 3, base + 1);
+						w.tri(q + 3, base, base + 2, base + 3);
+					}
+				}
+				return;
+			}
+			const V2 lh = v2mul(l, hsw);
+			const V2 lhaa = v2mul(l, hswAA);
+			if (m.cap == VGX_CAP_BUTT) { // :1422-1447, 1858-1886
+				const V2 daa = v2mul(d, fringe);
+				if (firstCap) {
+					w.v(b, v2add(p1, v2sub(lhaa, daa)), c0);
+					w.v(b + 1, v2add(p1, lh), color);
+					w.v(b + 2, v2sub(p1, lh), color);
+					w.v(b + 3, v2sub(p1, v2add(lhaa, daa)), c0);
+				} else {
+					w.v(b, v2add(p1, v2add(lhaa, daa)), c0);
+					w.v(b + 1, v2add(p1, lh), color);
+					w.v(b + 2, v2sub(p1, lh), color);
+					w.v(b + 3, v2sub(p1, v2sub(lhaa, daa)), c0);
+				}
+			} else { // Square, :1448-1474, 1887-1916
+				const V2 dh = v2mul(d, hsw);
+				const V2 dhaa = v2mul(d, hswAA);
+				if (firstCap) {
+					w.v(b, v2add(p1, v2sub(lhaa, dhaa)), c0);
+					w.v(b + 1, v2add(p1, v2sub(lh, dh)), color);
+					w.v(b + 2, v2sub(p1, v2add(lh, dh)), color);
+					w.v(b + 3, v2sub(p1, v2add(lhaa, dhaa)), c0);
+				} else {
+					w.v(b, v2add(p1, v2add(lhaa, dhaa)), c0);
+					w.v(b + 1, v2add(p1, v2add(lh, dh)), color);
+					w.v(b + 2, v2sub(p1, v2sub(lh, dh)), color);
+					w.v(b + 3, v2sub(p1, v2sub(lhaa, dhaa)), c0);
+				}
+			}
+			if (firstCap) {
+				w.tri(k, 0, 2, 1);
+				w.tri(k + 3, 0, 3, 2);
+			} else {
+				w.bridge4(k, prev, rails(b, b + 1, b + 2, b + 3));
+				w.tri(k + 18, b, b + 1, b + 2);
+				w.tri(k + 21, b, b + 2, b + 3);
+			}
+			return;
+		}
+		// join, :1524-1850
+		const V2 vhaa = v2mul(e.v, hswAA);
+		const V2 vh = v2mul(e.v, hsw);
+		const bool L = e.leftInner;
+		const V2 innerAA = L ? v2add(p1, vhaa) : v2sub(p1, vhaa);
+		const V2 inner = L ? v2add(p1, vh) : v2sub(p1, vh);
+		const Rails entry = L ? rails(b, b + 1, b + 2, b + 3) : rails(b + 3, b + 2, b + 1, b);
+		uint32_t q = k;
+		w.v(b, innerAA, c0);
+		w.v(b + 1, inner, color);
+		if (m.join == VGX_JOIN_MITER) {
+			w.v(b + 2, L ? v2sub(p1, vh) : v2add(p1, vh), color);
+			w.v(b + 3, L ? v2sub(p1, vhaa) : v2add(p1, vhaa), c0);
+			if (e.hasConnect) { w.bridge4(q, prev, entry); q += 18; }
+		} else {
+			const V2 n01 = L ? v2cw(e.d01) : v2ccw(e.d01);
+			const V2 n12 = L ? v2cw(e.d12) : v2ccw(e.d12);
+			const uint32_t n = e.arc.n;
+			{
+				V2 a = v2add(p1, v2mul(n01, hsw));
+				const V2 aAA = v2add(p1, v2mul(n01, hswAA));
+				if (m.join == VGX_JOIN_BEVEL) {
+					const float cosAngle = vgm_abs(v2dot(n01, n12));
+					a = v2sub(a, v2mul(e.d01, cosAngle * fringe));
+				}
+				w.v(b + 2, a, color);
+				w.v(b + 3, aAA, c0);
+			}
+			for (uint32_t i = 1; i < n; ++i) {
+				const float ang = e.arc.a01 + i * e.arc.arcDa;
+				float sa, ca;
+				vgm_sincos(ang, &sa, &ca);
+				const V2 dir = v2(ca, sa);
+				w.v(b + 2 + 2 * i, v2add(p1, v2mul(dir, hsw)), color);
+				w.v(b + 3 + 2 * i, v2add(p1, v2mul(dir, hswAA)), c0);
+			}
+			{
+				V2 a = v2add(p1, v2mul(n12, hsw));
+				const V2 aAA = v2add(p1, v2mul(n12, hswAA));
+				if (m.join == VGX_JOIN_BEVEL) {
+					const float cosAngle = vgm_abs(v2dot(n01, n12));
+					a = v2add(a, v2mul(e.d12, cosAngle * fringe));
+				}
+				w.v(b + 2 + 2 * n, a, color);
+				w.v(b + 3 + 2 * n, aAA, c0);
+			}
+			if (e.hasConnect) { w.bridge4(q, prev, entry); q += 18; }
+			uint32_t arcID = b + 2;
+			for (uint32_t i = 0; i < n; ++i, arcID += 2, q += 9) {
+				if (L) {
+					w.tri(q, b + 1, arcID, arcID + 2);
+					w.tri(q + 3, arcID, arcID + 1, arcID + 3);
+					w.tri(q + 6, arcID, arcID + 3, arcID + 2);
+				} else {
+					w.tri(q, b + 1, arcID + 2, arcID);
+					w.tri(q + 3, arcID, arcID + 3, arcID + 1);
+					w.tri(q + 6, arcID, arcID + 2, arcID + 3);
+				}
+			}
+		}
+		if (e.closesLoop) { // :1970-1984
+			const VgxJoin j0 = vgx_join(p1, ldv(m.vtx, 0), ldv(m.vtx, N > 1 ? 1 : 0), hswAA);
+			w.bridge4(q, elem_exit_rails(m, e, b), first_join_entry(m, j0.leftInner));
+		}
+		return;
+	}
+
+	// ------------------------------- non-AA stroke, 2 rails ---------------------------------------
+	if (m.kind == VGX_MESH_STROKE) {
+		if (e.et != ET_JOIN) {
+			const bool firstCap = e.et == ET_CAP_FIRST;
+			const V2 d = e.d01;
+			const V2 l = v2ccw(d);
+			if (m.cap == VGX_CAP_ROUND) { // :1059-1080, 1342-1370
+				const uint32_t H = e.H;
+				const float startAngle = vgm_atan2(l.y, l.x);
+				for (uint32_t i = 0; i < H; ++i) {
+					const float t = i * VGM_PI / (float)(H - 1);
+					const float a = firstCap ? startAngle + t : startAngle - t;
+					float sa, ca;
+					vgm_sincos(a, &sa, &ca);
+					w.v(b + i, v2(p1.x + ca * hsw, p1.y + sa * hsw), color);
+				}
+				if (firstCap) {
+					uint32_t q = k;
+					for (uint32_t i = 0; i + 2 < H; ++i, q += 3) { w.tri(q, 0, i + 1, i + 2); }
+				} else {
+					w.bridge2(k, prev, rails(b, b + (H - 1), 0, 0));
+					uint32_t q = k + 6;
+					for (uint32_t i = 0; i + 2 < H; ++i, q += 3) { w.tri(q, b, b + i + 2, b + i + 1); }
+				}
+				return;
+			}
+			const V2 lh = v2mul(l, hsw);
+			if (m.cap == VGX_CAP_BUTT) { // :1032-1044, 1303-1321
+				w.v(b, v2add(p1, lh), color);
+				w.v(b + 1, v2sub(p1, lh), color);
+			} else { // Square :1045-1058, 1322-1341
+				const V2 dh = v2mul(d, hsw);
+				if (firstCap) {
+					w.v(b, v2add(p1, v2sub(lh, dh)), color);
+					w.v(b + 1, v2sub(p1, v2add(lh, dh)), color);
+				} else {
+					w.v(b, v2add(p1, v2add(lh, dh)), color);
+					w.v(b + 1, v2sub(p1, v2sub(lh, dh)), color);
+				}
+			}
+			if (!firstCap) { w.bridge2(k, prev, rails(b, b + 1, 0, 0)); }
+			return;
+		}
+		// join, :1088-1296
+		const V2 vh = v2mul(e.v, hsw);
+		const bool L = e.leftInner;
+		const V2 inner = L ? v2add(p1, vh) : v2sub(p1, vh);
+		const Rails entry = L ? rails(b, b + 1, 0, 0) : rails(b + 1, b, 0, 0);
+		uint32_t q = k;
+		w.v(b, inner, color);
+		if (m.join == VGX_JOIN_MITER) {
+			w.v(b + 1, L ? v2sub(p1, vh) : v2add(p1, vh), color);
+			if (e.hasConnect) { w.bridge2(q, prev, entry); q += 6; }
+		} else {
+			const V2 n01 = L ? v2cw(e.d01) : v2ccw(e.d01);
+			const V2 n12 = L ? v2cw(e.d12) : v2ccw(e.d12);
+			const uint32_t n = e.arc.n;
+			w.v(b + 1, v2add(p1, v2mul(n01, hsw)), color);
+			for (uint32_t i = 1; i < n; ++i) {
+				const float ang = e.arc.a01 + i * e.arc.arcDa;
+				float sa, ca;
+				vgm_sincos(ang, &sa, &ca);
+				w.v(b + 1 + i, v2(p1.x + hsw * ca, p1.y + hsw * sa), color);
+			}
+			w.v(b + 1 + n, v2add(p1, v2mul(n12, hsw)), color);
+			if (e.hasConnect) { w.bridge2(q, prev, entry); q += 6; }
+			for (uint32_t i = 0; i < n; ++i, q += 3) {
+				const uint32_t base = b + i;
+				if (L) { w.tri(q, b, base + 1, base + 2); } else { w.tri(q, b, base + 2, base + 1); }
+			}
+		}
+		if (e.closesLoop) { // :1372-1380
+			const VgxJoin j0 = vgx_join(p1, ldv(m.vtx, 0), ldv(m.vtx, N > 1 ? 1 : 0), hsw);
+			w.bridge2(q, elem_exit_rails(m, e, b), first_join_entry(m, j0.leftInner));
+		}
+		return;
+	}
+
+	// ------------------------------- thin AA stroke, 3 rails --------------------------------------
+	{
+		const float f = fringe; // stroker.cpp:1999
+		if (e.et != ET_JOIN) { // :2012-2058, 2242-2294
+			const bool firstCap = e.et == ET_CAP_FIRST;
+			const V2 d = e.d01;
+			const V2 l = v2ccw(d);
+			const V2 lf = v2mul(l, f);
+			if (m.cap == VGX_CAP_BUTT) {
+				w.v(b, v2add(p1, lf), c0);
+				w.v(b + 1, p1, color);
+				w.v(b + 2, v2sub(p1, lf), c0);
+			} else {
+				const V2 df = v2mul(d, f);
+				if (firstCap) {
+					w.v(b, v2add(p1, v2sub(lf, df)), c0);
+					w.v(b + 1, p1, color);
+					w.v(b + 2, v2sub(p1, v2add(lf, df)), c0);
+				} else {
+					w.v(b, v2add(p1, v2add(lf, df)), c0);
+					w.v(b + 1, p1, color);
+					w.v(b + 2, v2sub(p1, v2sub(lf, df)), c0);
+				}
+			}
+			if (!firstCap) { w.bridge3(k, prev, rails(b, b + 1, b + 2, 0)); }
+			return;
+		}
+		const V2 vf = v2mul(e.v, f);
+		const bool L = e.leftInner;
+		const V2 inner = L ? v2add(p1, vf) : v2sub(p1, vf);
+		const Rails entry = L ? rails(b, b + 1, b + 2, 0) : rails(b + 2, b + 1, b, 0);
+		uint32_t q = k;
+		w.v(b, inner, c0);
+		w.v(b + 1, p1, color);
+		if (m.join == VGX_JOIN_MITER) {
+			w.v(b + 2, L ? v2sub(p1, vf) : v2add(p1, vf), c0);
+			if (e.hasConnect) { w.bridge3(q, prev, entry); q += 12; }
+		} else {
+			const V2 n01 = L ? v2cw(e.d01) : v2ccw(e.d01);
+			const V2 n12 = L ? v2cw(e.d12) : v2ccw(e.d12);
+			w.v(b + 2, v2add(p1, v2mul(n01, f)), c0);
+			w.v(b + 3, v2add(p1, v2mul(n12, f)), c0);
+			if (e.hasConnect) { w.bridge3(q, prev, entry); q += 12; }
+			if (L) { w.tri(q, b + 1, b + 2, b + 3); } else { w.tri(q, b + 1, b + 3, b + 2); }
+			q += 3;
+		}
+		if (e.closesLoop) { // :2295-2306
+			const VgxJoin j0 = vgx_join(p1, ldv(m.vtx, 0), ldv(m.vtx, N > 1 ? 1 : 0), f);
+			w.bridge3(q, elem_exit_rails(m, e, b), first_join_entry(m, j0.leftInner));
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+template<bool EMIT>
+__global__ __launch_bounds__(VGX_WAVE) void k_stroke(VgxStrokeArgs A)
+{
+	const int lane = threadIdx.x;
+	if (A.totals->status != VGX_OK) {
+		return;
+	}
+	const uint64_t numMeshes = A.totals->sizes.num_meshes;
+	const uint64_t totalElems = A.elem_prefix[numMeshes];
+	const uint64_t numSegments = (totalElems + VGX_WAVE - 1) / VGX_WAVE;
+
+	for (uint64_t seg = blockIdx.x; seg < numSegments; seg += gridDim.x) {
+		const uint64_t m0 = lower_bound_u64(A.elem_prefix, 0, numMeshes, seg * VGX_WAVE);
+		const uint64_t m1 = lower_bound_u64(A.elem_prefix, m0, numMeshes, (seg + 1) * VGX_WAVE);
+		if (m0 == m1) {
+			continue;
+		}
+		const uint64_t E0 = A.elem_prefix[m0];
+		const uint64_t E1 = A.elem_prefix[m1];
+		uint32_t carryV = 0, carryI = 0;
+		uint64_t carryRails = 0;
+
+		for (uint64_t chunk = E0; chunk < E1; chunk += VGX_WAVE) {
+			const uint64_t ei = chunk + lane;
+			const bool valid = ei < E1;
+			MeshCtx mc;
+			mc.kind = VGX_MESH_FILL; mc.N = 3; mc.j = 0; mc.cap = 0; mc.join = 0; mc.closed = false;
+			mc.hsw = 0.0f; mc.hswAA = 0.0f; mc.fringe = 1.0f; mc.da = 1.0f; mc.color = 0; mc.vtx = A.poly;
+			uint64_t mi = m0;
+			Elem e;
+			e.nv = 0; e.ni = 0; e.et = ET_FILL; e.leftInner = true; e.hasConnect = false; e.closesLoop = false;
+			e.arc.a01 = 0.0f; e.arc.arcDa = 0.0f; e.arc.n = 1; e.H = 2; e.p1 = v2(0.0f, 0.0f); e.d01 = e.p1; e.d12 = e.p1; e.v = e.p1;
+			uint32_t totalIdx = 0;
+			if (valid) {
+				mi = find_owner_u64(A.elem_prefix, m0, m1, ei);
+				const VgxMeshDesc md = A.mdesc[mi];
+				const vgx_draw* dr = A.draws + md.draw;
+				mc.kind = md.kind & 0xFFu;
+				mc.closed = (md.kind & 0x100u) != 0;
+				mc.N = md.poly_n;
+				mc.j = (uint32_t)(ei - A.elem_prefix[mi]);
+				mc.vtx = A.poly + 2 * md.poly_first;
+				mc.fringe = dr->fringe;
+				const bool isFill = mc.kind == VGX_MESH_FILL || mc.kind == VGX_MESH_FILL_AA;
+				mc.color = isFill ? dr->fill_color : dr->stroke_color;
+				if (!isFill) {
+					const uint32_t sf = dr->stroke_flags;
+					mc.cap = VGX_STROKE_CAP(sf);
+					mc.join = VGX_STROKE_JOIN(sf);
+					if (mc.closed) { mc.cap = VGX_CAP_BUTT; } // closed strokes ignore the cap (dispatch tables :246-268)
+					const float sw = dr->stroke_width;
+					if (mc.kind == VGX_MESH_STROKE_AA) {
+						mc.hsw = (sw - mc.fringe) * 0.5f;  // :1396
+						mc.hswAA = mc.hsw + mc.fringe;     // :1397
+					} else if (mc.kind == VGX_MESH_STROKE) {
+						mc.hsw = sw * 0.5f;                // :1012
+						mc.hswAA = mc.hsw;
+					} else {
+						// thin: Round cap -> Square, Round join -> Bevel (:318-327)
+						if (mc.cap == VGX_CAP_ROUND) { mc.cap = VGX_CAP_SQUARE; }
+						if (mc.join == VGX_JOIN_ROUND) { mc.join = VGX_JOIN_BEVEL; }
+						mc.hsw = mc.fringe;
+						mc.hswAA = mc.fringe;
+					}
+					mc.da = vgx_step_angle(dr->scale, mc.hsw, dr->tess_tol); // :1013, 1398
+				}
+				e = elem_geometry(mc);
+				totalIdx = elem_total_indices(mc, e);
+			}
+
+			// ---- step B: running vertex / index counters of the mesh (segmented wave scan) -----------
+			const uint64_t heads = wave_ballot(valid && mc.j == 0);
+			const int mh = seg_head(heads, lane);
+			const uint32_t inclV = wave_incl_scan_u32(e.nv, lane);
+			const uint32_t inclI = wave_incl_scan_u32(totalIdx, lane);
+			const uint32_t exV = inclV - e.nv, exI = inclI - totalIdx;
+			const uint32_t hV = wave_read_u32(exV, mh < 0 ? 0 : mh), hI = wave_read_u32(exI, mh < 0 ? 0 : mh);
+			const uint32_t vbase = mh < 0 ? carryV + exV : exV - hV;
+			const uint32_t ibase = mh < 0 ? carryI + exI : exI - hI;
+
+			// ---- step C: previous element's exit rails -------------------------------------------
+			const bool isStroke = mc.kind >= VGX_MESH_STROKE;
+			const uint64_t myExit = (valid && isStroke) ? rails_pack(elem_exit_rails(mc, e, vbase)) : 0ull;
+			uint64_t prevPacked = __shfl_up((unsigned long long)myExit, 1);
+			if (lane == 0) { prevPacked = carryRails; }
+
+			const bool meshLast = valid && (mc.j == mc.N - 1);
+			if (!EMIT) {
+				if (meshLast) {
+					const bool isFill = !isStroke;
+					const uint32_t nv = isFill ? (mc.kind == VGX_MESH_FILL_AA ? 2 * mc.N : mc.N) : vbase + e.nv;
+					const uint32_t ni = isFill ? (mc.kind == VGX_MESH_FILL_AA ? 9 * mc.N - 6 : 3 * (mc.N - 2)) : ibase + totalIdx;
+					const VgxMeshDesc md = A.mdesc[mi];
+					vgx_mesh r;
+					r.first_vertex = 0; r.first_index = 0;
+					r.num_vertices = nv; r.num_indices = ni;
+					r.draw = md.draw;
+					r.subpath_kind = (md.subpath & 0x0FFFFFFFu) | ((md.kind & 0xFu) << 28);
+					A.mtab[mi] = r;
+				}
+			} else if (valid) {
+				const vgx_mesh mr = A.mtab[mi];
+				MeshWriter<true> w;
+				w.pos = A.pos + 2 * mr.first_vertex;
+				w.col = A.color + mr.first_vertex;
+				w.idx = A.idx + mr.first_index;
+				w.color = mc.color;
+				w.c0 = mc.color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
+				elem_emit<true>(mc, e, vbase, ibase, rails_unpack(prevPacked), w);
+				if (meshLast && A.meshes_out) {
+					A.meshes_out[mi] = mr;
+				}
+			}
+
+			// ---- carries (from the last valid lane) ------------------------------------------------
+			const int nvalid = (int)((E1 - chunk) < (uint64_t)VGX_WAVE ? (E1 - chunk) : (uint64_t)VGX_WAVE);
+			const int Lz = nvalid - 1;
+			const int lastIsMeshLast = __shfl((int)meshLast, Lz);
+			const uint32_t endV = wave_read_u32(vbase + e.nv, Lz);
+			const uint32_t endI = wave_read_u32(ibase + totalIdx, Lz);
+			const uint64_t endRails = __shfl((unsigned long long)myExit, Lz);
+			carryV = lastIsMeshLast ? 0u : endV;
+			carryI = lastIsMeshLast ? 0u : endI;
+			carryRails = lastIsMeshLast ? 0ull : endRails;
+		}
+	}
+}
+
+} // namespace
+
+void vgx_launch_stroke(bool emit, const VgxStrokeArgs& a, int numBlocks, hipStream_t s)
+{
+	if (emit) {
+		hipLaunchKernelGGL(k_stroke<true>, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
+	} else {
+		hipLaunchKernelGGL(k_stroke<false>, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
+	}
+}

@@ -1,0 +1,82 @@
+// vgx_wave.h -- wavefront (64-lane) primitives for gfx950: ballot masks, segment heads, prefix scans.
+// Device only. A "segment" is a run of consecutive lanes that belong to the same draw / sub-path /
+// mesh; its head lane is flagged in a 64-bit ballot mask.
+#ifndef VGX_WAVE_H
+#define VGX_WAVE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VGX_WAVE 64
+
+__device__ __forceinline__ uint64_t wave_ballot(bool p) { return __ballot(p ? 1 : 0); }
+__device__ __forceinline__ uint64_t lanemask_le(int lane) { return (2ull << lane) - 1ull; }      // bits 0..lane
+__device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }      // bits 0..lane-1
+__device__ __forceinline__ uint64_t lanemask_ge(int lane) { return ~((1ull << lane) - 1ull); }   // bits lane..63
+
+// Highest flagged lane <= `lane`, or -1 when the segment started in an earlier chunk.
+__device__ __forceinline__ int seg_head(uint64_t heads, int lane)
+{
+	const uint64_t m = heads & lanemask_le(lane);
+	return m ? 63 - __clzll((long long)m) : -1;
+}
+
+// Lanes of my segment up to and including me (segment = [head, lane]); head < 0 means from lane 0.
+__device__ __forceinline__ uint64_t seg_mask_upto(int head, int lane)
+{
+	return lanemask_le(lane) & (head < 0 ? ~0ull : lanemask_ge(head));
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+	for (int d = 1; d < VGX_WAVE; d <<= 1) {
+		const int t = __shfl_up(v, d);
+		if (lane >= d) { v += t; }
+	}
+	return v;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
+{
+#pragma unroll
+	for (int d = 1; d < VGX_WAVE; d <<= 1) {
+		const uint32_t t = __shfl_up(v, d);
+		if (lane >= d) { v += t; }
+	}
+	return v;
+}
+
+// Value of `v` on lane `src` (src may differ per lane).
+__device__ __forceinline__ int wave_read(int v, int src) { return __shfl(v, src); }
+__device__ __forceinline__ uint32_t wave_read_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src); }
+
+// Exclusive-scan value relative to the segment head: excl[lane] - excl[head], or carry + excl[lane]
+// when the segment continues from the previous chunk.
+__device__ __forceinline__ int seg_rel(int excl, int head, int carry)
+{
+	const int base = __shfl(excl, head < 0 ? 0 : head);
+	return head < 0 ? carry + excl : excl - base;
+}
+
+// lower_bound over a device array of uint64 (first index i in [lo,hi) with a[i] >= key, else hi)
+__device__ __forceinline__ uint64_t lower_bound_u64(const uint64_t* a, uint64_t lo, uint64_t hi, uint64_t key)
+{
+	while (lo < hi) {
+		const uint64_t mid = (lo + hi) >> 1;
+		if (a[mid] < key) { lo = mid + 1; } else { hi = mid; }
+	}
+	return lo;
+}
+
+// upper_bound - 1: last index i in [lo,hi) with a[i] <= key (assumes a[lo] <= key)
+__device__ __forceinline__ uint64_t find_owner_u64(const uint64_t* a, uint64_t lo, uint64_t hi, uint64_t key)
+{
+	while (hi - lo > 1) {
+		const uint64_t mid = (lo + hi) >> 1;
+		if (a[mid] <= key) { lo = mid; } else { hi = mid; }
+	}
+	return lo;
+}
+
+#endif

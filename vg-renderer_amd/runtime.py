@@ -1,0 +1,209 @@
+"""Python plumbing over the C-ABI (libvgx.so): context, path sets, batch calls on torch device memory.
+
+PyTorch is used only for device allocations and streams; every geometry computation happens in the
+HIP kernels behind include/vgx.h. There is NO CPU fallback: if libvgx.so is missing or no gfx950 device is
+present, construction raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+from . import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvgx.so")
+_lib = None
+
+
+class VgxError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        name = lib().vgx_status_string(status).decode() if _lib is not None else str(status)
+        super().__init__("%s failed: %s (%d)" % (where, name, status))
+
+
+def lib():
+    """Load libvgx.so (built in-tree by `__graft_entry__.build()` / csrc/Makefile). Fails loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libvgx.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` (HIP extension is mandatory, there is no CPU fallback)")
+        # import torch first so that its HIP runtime (same SONAME) is the one both sides use
+        import torch  # noqa: F401
+        _lib = capi.bind(C.CDLL(LIB_PATH), capi.VGX_SYMBOLS)
+    return _lib
+
+
+def _check(st, where):
+    if st != capi.VGX_OK:
+        raise VgxError(st, where)
+
+
+def validate_pathset(ps):
+    """Host-only grammar / finiteness validation (no device needed)."""
+    d = ps.desc()
+    return lib().vgx_pathset_validate(C.byref(d))
+
+
+class Context:
+    def __init__(self, device=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: vg-renderer_amd has no CPU fallback")
+        self.device = device
+        self._h = C.c_void_p()
+        torch.cuda.set_device(device)
+        torch.zeros(1, device="cuda:%d" % device)  # make sure the primary context exists
+        _check(lib().vgx_create(device, C.byref(self._h)), "vgx_create")
+
+    def close(self):
+        if self._h:
+            lib().vgx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def scratch_bytes(self):
+        return int(lib().vgx_scratch_bytes(self._h))
+
+    def set_profiling(self, on):
+        _check(lib().vgx_set_profiling(self._h, 1 if on else 0), "vgx_set_profiling")
+
+    def stage_times(self):
+        st = capi.StageTimes()
+        _check(lib().vgx_get_stage_times(self._h, C.byref(st)), "vgx_get_stage_times")
+        return [(st.name[i].decode(), float(st.ms[i])) for i in range(st.num_stages)]
+
+
+class PathSet:
+    """Path definitions resident in HBM (vgx_pathset)."""
+
+    def __init__(self, ctx, arrays):
+        self.ctx = ctx
+        self.arrays = arrays
+        self._h = C.c_void_p()
+        d = arrays.desc()
+        _check(lib().vgx_pathset_create(ctx.handle, C.byref(d), C.byref(self._h)), "vgx_pathset_create")
+
+    def close(self):
+        if self._h and self.ctx.handle:
+            lib().vgx_pathset_destroy(self.ctx.handle, self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+
+def upload_draws(draws, device=0):
+    """numpy draw records -> uint8 torch tensor in HBM (64 bytes per draw)."""
+    import torch
+    raw = np.ascontiguousarray(draws).view(np.uint8).reshape(-1)
+    return torch.from_numpy(raw.copy()).to("cuda:%d" % device)
+
+
+def _stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class FlatResult:
+    pass
+
+
+class MeshResult:
+    pass
+
+
+def flatten(ctx, pset, draws_dev, ndraws, apply_transform=False, to_host=True):
+    """vgx_flatten_count + vgx_flatten_emit. draws_dev: uint8 torch tensor from upload_draws."""
+    import torch
+    L = lib()
+    sizes = capi.Sizes()
+    s = _stream_ptr()
+    _check(L.vgx_flatten_count(ctx.handle, pset.handle, draws_dev.data_ptr(), ndraws, C.byref(sizes), s), "vgx_flatten_count")
+    dev = draws_dev.device
+    npv, nsp = int(sizes.num_poly_vertices), int(sizes.num_subpaths)
+    poly = torch.empty((max(npv, 1), 2), dtype=torch.float32, device=dev)
+    subs = torch.empty(max(nsp, 1) * 16, dtype=torch.uint8, device=dev)
+    dinfo = torch.empty(max(ndraws, 1) * 40, dtype=torch.uint8, device=dev)
+    out = capi.FlatOut(poly.data_ptr(), subs.data_ptr(), dinfo.data_ptr(), npv, nsp)
+    _check(L.vgx_flatten_emit(ctx.handle, pset.handle, draws_dev.data_ptr(), ndraws, int(apply_transform), C.byref(out), s), "vgx_flatten_emit")
+    torch.cuda.synchronize()
+    r = FlatResult()
+    r.sizes = sizes.as_dict()
+    r.poly_dev, r.subs_dev, r.dinfo_dev = poly, subs, dinfo
+    if to_host:
+        r.poly = poly[:npv].cpu().numpy()
+        r.subpaths = subs[:nsp * 16].cpu().numpy().view(capi.subpath_dtype)
+        r.draw_info = dinfo[:ndraws * 40].cpu().numpy().view(capi.draw_info_dtype)
+    return r
+
+
+class MeshBuffers:
+    """Caller-owned output buffers in HBM (vgx_mesh_out)."""
+
+    def __init__(self, device, nverts, nidx, nmeshes):
+        import torch
+        self.cap = (int(nverts), int(nidx), int(nmeshes))
+        self.pos = torch.empty((max(nverts, 1), 2), dtype=torch.float32, device=device)
+        self.color = torch.empty(max(nverts, 1), dtype=torch.int32, device=device)
+        self.idx = torch.empty(max(nidx, 1), dtype=torch.int16, device=device)
+        self.meshes = torch.empty(max(nmeshes, 1) * 32, dtype=torch.uint8, device=device)
+        self.dev_sizes = torch.zeros(6, dtype=torch.int64, device=device)
+        self.dev_status = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def out_struct(self):
+        return capi.MeshOut(self.pos.data_ptr(), self.color.data_ptr(), self.idx.data_ptr(), self.meshes.data_ptr(),
+                            self.cap[0], self.cap[1], self.cap[2])
+
+
+def tessellate_count(ctx, pset, draws_dev, ndraws):
+    sizes = capi.Sizes()
+    _check(lib().vgx_tessellate_count(ctx.handle, pset.handle, draws_dev.data_ptr(), ndraws, C.byref(sizes), _stream_ptr()), "vgx_tessellate_count")
+    return sizes.as_dict()
+
+
+def tessellate_emit(ctx, pset, draws_dev, ndraws, bufs):
+    out = bufs.out_struct()
+    _check(lib().vgx_tessellate_emit(ctx.handle, pset.handle, draws_dev.data_ptr(), ndraws, C.byref(out), _stream_ptr()), "vgx_tessellate_emit")
+
+
+def tessellate_async(ctx, pset, draws_dev, ndraws, bufs):
+    """Steady-state call: whole pipeline, no host round trip; totals/status land in bufs.dev_*."""
+    out = bufs.out_struct()
+    _check(lib().vgx_tessellate(ctx.handle, pset.handle, draws_dev.data_ptr(), ndraws, C.byref(out),
+                                bufs.dev_sizes.data_ptr(), bufs.dev_status.data_ptr(), _stream_ptr()), "vgx_tessellate")
+
+
+def tessellate(ctx, pset, draws_dev, ndraws, to_host=True):
+    """count -> allocate exact -> emit. Returns MeshResult (numpy copies when to_host)."""
+    import torch
+    sizes = tessellate_count(ctx, pset, draws_dev, ndraws)
+    bufs = MeshBuffers(draws_dev.device, sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"])
+    tessellate_emit(ctx, pset, draws_dev, ndraws, bufs)
+    torch.cuda.synchronize()
+    r = MeshResult()
+    r.sizes = sizes
+    r.bufs = bufs
+    if to_host:
+        nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
+        r.pos = bufs.pos[:nv].cpu().numpy()
+        r.color = bufs.color[:nv].cpu().numpy().view(np.uint32)
+        r.idx = bufs.idx[:ni].cpu().numpy().view(np.uint16)
+        r.meshes = bufs.meshes[:nm * 32].cpu().numpy().view(capi.mesh_dtype)
+    return r

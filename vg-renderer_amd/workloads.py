@@ -172,8 +172,13 @@ def fuzz_paths(seed, npaths=64, with_shapes=True, degenerate=True):
     for p in range(npaths):
         b.begin_path()
         nsub = int(rs.randint(1, 4))
+        prev_open = True  # an ARC may only lead a sub-path at the path start or after an OPEN sub-path
         for s in range(nsub):
             kind = int(rs.randint(0, 10)) if with_shapes else 0
+            if kind == 9 and not prev_open:
+                kind = 0
+            if kind in (6, 7, 8):
+                prev_open = False
             scale = float(rs.choice([1.0, 10.0, 100.0, 400.0]))
             ox, oy = rs.uniform(-50, 50, size=2)
             if kind == 6:
@@ -239,11 +244,16 @@ def fuzz_paths(seed, npaths=64, with_shapes=True, degenerate=True):
                 else:
                     cx, cy = nx, ny
             r = rs.uniform()
-            if r < 0.35:
+            prev_open = True
+            if kind == 9 and ncont == 0:
+                pass  # a lone arc stays open (CLOSE directly after ARC is fine too, but keep some open)
+            elif r < 0.35:
                 b.close()
-            elif r < 0.5 and ncont >= 2:
+                prev_open = False
+            elif r < 0.5 and ncont >= 2 and kind != 9:
                 b.line_to(ox, oy)  # return exactly to the start, then close (pathClose pops it)
                 b.close()
+                prev_open = False
         b.end_path()
     return b.arrays()
 

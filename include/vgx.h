@@ -147,6 +147,8 @@ typedef struct vgx_sizes {
 	uint64_t num_vertices;
 	uint64_t num_indices;
 	uint64_t num_serial_draws; /* draws that needed the exact serial lane path (degenerate input) */
+	uint64_t num_cmd_instances;/* path commands summed over draws (flatten work items) */
+	uint64_t num_elements;     /* polyline vertices summed over meshes (stroker work items) */
 } vgx_sizes;
 
 /* Flatten output (pathGetVertices / pathGetSubPaths for every draw). NULL members are skipped. */

@@ -100,3 +100,28 @@ def tessellate(ps, draws, kind="port", want_flat=False, count_only=False):
     st = lib.vgo_tessellate(C.byref(desc), draws.ctypes.data, n, fo_ref, C.byref(mo), C.byref(sizes))
     assert st == 0, st
     return r
+
+
+def tessellate_timed(ps, draws, kind="port", reps=1):
+    """Time `reps` single-pass vgo_tessellate calls into preallocated (already touched) buffers.
+    Returns (seconds, sizes dict). Used by bench.py's cpu_baseline leg."""
+    import time
+    lib = load(kind)
+    draws = np.ascontiguousarray(draws)
+    n = draws.shape[0]
+    desc = ps.desc()
+    sizes = capi.Sizes()
+    st = lib.vgo_tessellate(C.byref(desc), draws.ctypes.data, n, None, None, C.byref(sizes))
+    assert st == 0, st
+    pos = np.ones((sizes.num_vertices, 2), dtype=np.float32)
+    color = np.ones(sizes.num_vertices, dtype=np.uint32)
+    idx = np.ones(sizes.num_indices, dtype=np.uint16)
+    meshes = np.zeros(sizes.num_meshes, dtype=capi.mesh_dtype)
+    mo = capi.MeshOut(pos.ctypes.data, color.ctypes.data, idx.ctypes.data, meshes.ctypes.data, sizes.num_vertices, sizes.num_indices, sizes.num_meshes)
+    s2 = capi.Sizes()
+    st = lib.vgo_tessellate(C.byref(desc), draws.ctypes.data, n, None, C.byref(mo), C.byref(s2))  # warm-up
+    assert st == 0, st
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        lib.vgo_tessellate(C.byref(desc), draws.ctypes.data, n, None, C.byref(mo), C.byref(s2))
+    return time.perf_counter() - t0, sizes.as_dict()

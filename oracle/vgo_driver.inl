@@ -65,8 +65,9 @@ struct VgoSink
 	vgx_sizes* sizes;
 	bool overflow;
 
-	void add(const VGO_ENGINE::Mesh& m, uint32_t uniformColor, uint32_t draw, uint32_t subpath, uint32_t kind)
+	void add(const VGO_ENGINE::Mesh& m, uint32_t uniformColor, uint32_t draw, uint32_t subpath, uint32_t kind, uint32_t polyN)
 	{
+		sizes->num_elements += polyN;
 		const uint64_t v0 = sizes->num_vertices;
 		const uint64_t i0 = sizes->num_indices;
 		const uint64_t m0 = sizes->num_meshes;
@@ -133,6 +134,7 @@ static int vgoRun(const vgx_pathset_desc* ps, const vgx_draw* draws, uint64_t nd
 		const uint64_t mesh0 = sizes->num_meshes;
 		sizes->num_poly_vertices += nv;
 		sizes->num_subpaths += nsp;
+		sizes->num_cmd_instances += ps->path_cmd_begin[dr.path + 1] - ps->path_cmd_begin[dr.path];
 
 		if (flat) {
 			if (sizes->num_poly_vertices > flat->cap_poly_vertices || sizes->num_subpaths > flat->cap_subpaths) {
@@ -159,10 +161,10 @@ static int vgoRun(const vgx_pathset_desc* ps, const vgx_draw* draws, uint64_t nd
 					const float* vtx = &tv[sp[i].m_FirstVertexID << 1];
 					if (dr.fill_flags & VGX_FILL_AA) {
 						strokerConvexFillAA(st.stroker, &mesh, vtx, sp[i].m_NumVertices, dr.fill_color);
-						sink.add(mesh, dr.fill_color, (uint32_t)d, i, VGX_MESH_FILL_AA);
+						sink.add(mesh, dr.fill_color, (uint32_t)d, i, VGX_MESH_FILL_AA, sp[i].m_NumVertices);
 					} else {
 						strokerConvexFill(st.stroker, &mesh, vtx, sp[i].m_NumVertices);
-						sink.add(mesh, dr.fill_color, (uint32_t)d, i, VGX_MESH_FILL);
+						sink.add(mesh, dr.fill_color, (uint32_t)d, i, VGX_MESH_FILL, sp[i].m_NumVertices);
 					}
 				}
 			}
@@ -180,14 +182,14 @@ static int vgoRun(const vgx_pathset_desc* ps, const vgx_draw* draws, uint64_t nd
 					if (dr.stroke_flags & VGX_STROKE_AA) {
 						if (dr.stroke_flags & VGX_STROKE_THIN) {
 							strokerPolylineStrokeAAThin(st.stroker, &mesh, vtx, sp[i].m_NumVertices, closed, dr.stroke_color, cap, join);
-							sink.add(mesh, dr.stroke_color, (uint32_t)d, i, VGX_MESH_STROKE_AA_THIN);
+							sink.add(mesh, dr.stroke_color, (uint32_t)d, i, VGX_MESH_STROKE_AA_THIN, sp[i].m_NumVertices);
 						} else {
 							strokerPolylineStrokeAA(st.stroker, &mesh, vtx, sp[i].m_NumVertices, closed, dr.stroke_color, dr.stroke_width, cap, join);
-							sink.add(mesh, dr.stroke_color, (uint32_t)d, i, VGX_MESH_STROKE_AA);
+							sink.add(mesh, dr.stroke_color, (uint32_t)d, i, VGX_MESH_STROKE_AA, sp[i].m_NumVertices);
 						}
 					} else {
 						strokerPolylineStroke(st.stroker, &mesh, vtx, sp[i].m_NumVertices, closed, dr.stroke_width, cap, join);
-						sink.add(mesh, dr.stroke_color, (uint32_t)d, i, VGX_MESH_STROKE);
+						sink.add(mesh, dr.stroke_color, (uint32_t)d, i, VGX_MESH_STROKE, sp[i].m_NumVertices);
 					}
 				}
 			}

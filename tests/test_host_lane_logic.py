@@ -1,0 +1,73 @@
+"""CPU tests of the product's lane-level logic (csrc/vgx_lane.h, csrc/vgx_pathsim.h) compiled for the host
+(libvgx_hosttest.so). Not a fallback path -- nothing in the package loads that library."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "vg-renderer_amd", "libvgx_hosttest.so")
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    src = os.path.join(ROOT, "vg-renderer_amd", "csrc", "vgx_hosttest.cpp")
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-shared", "-o", LIB, src])
+    lib = C.CDLL(LIB)
+    lib.vgxt_serial_flatten.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.vgxt_mesh_closed_form.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
+    return lib
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 6, 9])
+def test_serial_builder_matches_oracle(hostlib, vgr, wl, oracle, seed):
+    """The exact sequential builder the device uses for degenerate draws and for closed shapes."""
+    capi = vgr.capi
+    ps = wl.fuzz_paths(seed, npaths=96)
+    d = wl.fuzz_draws(ps, seed)
+    desc = ps.desc()
+    for xform in (0, 1):
+        ref = oracle.flatten(ps, d, apply_transform=bool(xform))
+        for i in range(d.shape[0]):
+            n = int(ref.draw_info["num_poly_vertices"][i])
+            ns = int(ref.draw_info["num_subpaths"][i])
+            poly = np.full((n + 8, 2), 7777.0, dtype=np.float32)
+            subs = np.zeros(ns + 4, dtype=capi.subpath_dtype)
+            cnt = np.zeros(4, dtype=np.uint32)
+            hostlib.vgxt_serial_flatten(C.addressof(desc), d[i:i + 1].ctypes.data, xform, poly.ctypes.data, subs.ctypes.data, cnt.ctypes.data)
+            a = int(ref.draw_info["first_poly_vertex"][i])
+            s0 = int(ref.draw_info["first_subpath"][i])
+            assert (int(cnt[0]), int(cnt[1])) == (n, ns), (seed, i)
+            assert np.array_equal(poly[:n].view(np.uint32), ref.poly[a:a + n].view(np.uint32)), (seed, i, xform)
+            assert np.array_equal(subs["num_vertices"][:ns], ref.subpaths["num_vertices"][s0:s0 + ns])
+            assert np.array_equal(subs["flags"][:ns], ref.subpaths["flags"][s0:s0 + ns])
+            assert np.array_equal(subs["first_vertex"][:ns] + a, ref.subpaths["first_vertex"][s0:s0 + ns])
+            assert poly[n, 0] == 7777.0  # nothing written past the end (the vertex pathClose pops is never stored)
+
+
+@pytest.mark.parametrize("seed", [100, 101, 102, 103])
+def test_closed_form_mesh_sizes_match_oracle(hostlib, vgr, wl, oracle, seed):
+    """vgx_mesh_closed_form (used instead of a count pass) vs the meshes the oracle really builds."""
+    ps = wl.fuzz_paths(seed, npaths=96)
+    d = wl.fuzz_draws(ps, seed)
+    ref = oracle.tessellate(ps, d, want_flat=True)
+    checked = 0
+    for m in ref.meshes:
+        dr = int(m["draw"])
+        kind = int(m["subpath_kind"]) >> 28
+        sub = int(m["subpath_kind"]) & 0x0FFFFFFF
+        sp = ref.subpaths[int(ref.draw_info["first_subpath"][dr]) + sub]
+        nv = C.c_uint32(0)
+        ni = C.c_uint32(0)
+        ok = hostlib.vgxt_mesh_closed_form(d[dr:dr + 1].ctypes.data, kind, int(sp["flags"]) & 1, int(sp["num_vertices"]), C.addressof(nv), C.addressof(ni))
+        join = (int(d["stroke_flags"][dr]) >> 6) & 3
+        if kind in (2, 3) and join == 1:
+            assert ok == 0  # Round joins are data dependent
+            continue
+        assert ok == 1
+        assert (nv.value, ni.value) == (int(m["num_vertices"]), int(m["num_indices"])), (seed, dr, kind, sp)
+        checked += 1
+    assert checked > 50

@@ -137,7 +137,7 @@ struct OpCmdPrefix // command instances per draw -> cmd_prefix
 	__device__ void finish(Sum3 t) const
 	{
 		prefix[ndraws] = t.a;
-		totals->num_cmd_instances = t.a;
+		totals->sizes.num_cmd_instances = t.a;
 		if (t.a > cap) { set_status(totals, VGX_E_NOSPACE); }
 	}
 };
@@ -183,7 +183,7 @@ struct OpElemPrefix // stroker elements per mesh -> elem_prefix
 	{
 		const uint64_t n = totals->status == VGX_OK ? totals->sizes.num_meshes : 0;
 		prefix[n] = t.a;
-		totals->num_elements = t.a;
+		totals->sizes.num_elements = t.a;
 	}
 };
 
@@ -229,6 +229,7 @@ VgxFlattenArgs flattenArgs(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* 
 	a.poly = (float*)ctx->poly.p;
 	a.subs = (vgx_subpath*)ctx->subs.p;
 	a.mdesc = (VgxMeshDesc*)ctx->mdesc.p;
+	a.mtab = (vgx_mesh*)ctx->mtab.p;
 	a.totals = (VgxTotals*)ctx->totals.p;
 	a.caps = ctx->caps;
 	a.apply_transform = applyTransform;
@@ -288,8 +289,8 @@ void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps,
 	a.elem_prefix = (const uint64_t*)ctx->elemPrefix.p; a.mtab = (vgx_mesh*)ctx->mtab.p;
 	a.pos = nullptr; a.color = nullptr; a.idx = nullptr; a.meshes_out = nullptr;
 	a.totals = (VgxTotals*)ctx->totals.p; a.caps = outCaps;
-	vgx_launch_stroke(false, a, VGX_GRID_BLOCKS, s);
-	mark(ctx, s, "stroke_count");
+	vgx_launch_round_count(a, s);
+	mark(ctx, s, "round_join_count");
 	OpMeshTab opm;
 	opm.mtab = (vgx_mesh*)ctx->mtab.p; opm.totals = (VgxTotals*)ctx->totals.p; opm.caps = outCaps; opm.checkCaps = checkCaps;
 	vgx_device_scan(opm, (Sum3*)ctx->partial.p, s);
@@ -580,7 +581,7 @@ static int flattenCountCommon(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_dra
 	runCmdPrefix(ctx, ps, draws, ndraws, s);
 	if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
 	if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; }
-	const uint64_t ncmdInst = ctx->hostTotals->num_cmd_instances;
+	const uint64_t ncmdInst = ctx->hostTotals->sizes.num_cmd_instances;
 	if ((st = ensure(ctx, ctx->cmdCnt, (ncmdInst + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
 	ctx->caps.cmd_instances = ctx->cmdCnt.cap / sizeof(uint32_t) - 1;
 	// pass 2: per-draw counts (sizes polyline / sub-path / mesh scratch)
@@ -633,6 +634,7 @@ int vgx_flatten_emit(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 	a.poly = out->poly ? out->poly : (float*)ctx->poly.p;
 	a.subs = out->subpaths ? out->subpaths : (vgx_subpath*)ctx->subs.p;
 	a.mdesc = nullptr;
+	a.mtab = nullptr;
 	a.caps.poly_vertices = ~0ull; a.caps.subpaths = ~0ull; a.caps.meshes = ~0ull;
 	vgx_launch_flatten(true, a, VGX_GRID_BLOCKS, s);
 	mark(ctx, s, "flatten_emit");

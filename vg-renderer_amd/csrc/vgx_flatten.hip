@@ -168,7 +168,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 					default: { // closed shape: exact builder for this one command
 						PathSim<false, false> sim;
 						sim.scale = scale; sim.tol = tol; sim.mtx = nullptr; sim.poly = nullptr; sim.polyBase = 0; sim.subs = nullptr; sim.subBase = 0;
-						sim.mdesc = nullptr; sim.meshBase = 0; sim.drawIndex = 0; sim.fillFlags = 0; sim.strokeFlags = 0; sim.numFillTotal = 0;
+						sim.mdesc = nullptr; sim.mtab = nullptr; sim.draw = nullptr; sim.meshBase = 0; sim.drawIndex = 0; sim.fillFlags = 0; sim.strokeFlags = 0; sim.numFillTotal = 0;
 						sim.init();
 						sim.shape(type, a);
 						cnt = (int)sim.nverts;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 					if (serialDraw || slowDraw) {
 						PathSim<false, false> sim;
 						sim.scale = scale; sim.tol = tol; sim.mtx = nullptr; sim.poly = nullptr; sim.polyBase = 0; sim.subs = nullptr; sim.subBase = 0;
-						sim.mdesc = nullptr; sim.meshBase = 0; sim.drawIndex = (uint32_t)d; sim.fillFlags = fillFlags; sim.strokeFlags = strokeFlags; sim.numFillTotal = 0;
+						sim.mdesc = nullptr; sim.mtab = nullptr; sim.draw = nullptr; sim.meshBase = 0; sim.drawIndex = (uint32_t)d; sim.fillFlags = fillFlags; sim.strokeFlags = strokeFlags; sim.numFillTotal = 0;
 						sim.init();
 						const uint32_t pc0 = ps.path_cmd_begin[dr->path];
 						sim.run(ps, pc0, c + 1, stack);
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 					default: {
 						PathSim<true, XFORM> sim;
 						sim.scale = scale; sim.tol = tol; sim.mtx = mtx; sim.poly = A.poly; sim.polyBase = vbase; sim.subs = nullptr; sim.subBase = 0;
-						sim.mdesc = nullptr; sim.meshBase = 0; sim.drawIndex = 0; sim.fillFlags = 0; sim.strokeFlags = 0; sim.numFillTotal = 0;
+						sim.mdesc = nullptr; sim.mtab = nullptr; sim.draw = nullptr; sim.meshBase = 0; sim.drawIndex = 0; sim.fillFlags = 0; sim.strokeFlags = 0; sim.numFillTotal = 0;
 						sim.init();
 						sim.shape(type, a);
 						sim.flushPending();
@@ -318,17 +318,13 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 						if (A.mdesc) {
 							const uint32_t numFill = di.flags >> 1;
 							if ((fillFlags & VGX_FILL_ENABLE) && n >= 3) {
-								VgxMeshDesc m;
-								m.poly_first = firstV; m.poly_n = n; m.draw = (uint32_t)d; m.subpath = subIndex;
-								m.kind = ((fillFlags & VGX_FILL_AA) ? VGX_MESH_FILL_AA : VGX_MESH_FILL) | (closedHere ? 0x100u : 0u);
-								A.mdesc[di.first_mesh + (uint32_t)(fillIncl - 1)] = m;
+								vgx_write_mesh(A.mdesc, A.mtab, di.first_mesh + (uint32_t)(fillIncl - 1), dr, (uint32_t)d, subIndex, (fillFlags & VGX_FILL_AA) ? VGX_MESH_FILL_AA : VGX_MESH_FILL, closedHere, firstV, n);
 							}
 							if ((strokeFlags & VGX_STROKE_ENABLE) && n >= 2) {
-								VgxMeshDesc m;
-								m.poly_first = firstV; m.poly_n = n; m.draw = (uint32_t)d; m.subpath = subIndex;
 								const uint32_t kd = !(strokeFlags & VGX_STROKE_AA) ? VGX_MESH_STROKE : ((strokeFlags & VGX_STROKE_THIN) ? VGX_MESH_STROKE_AA_THIN : VGX_MESH_STROKE_AA);
-								m.kind = kd | (closedHere ? 0x100u : 0u);
-								A.mdesc[di.first_mesh + numFill + (uint32_t)(strokeIncl - 1)] = m;
+								if (vgx_write_mesh(A.mdesc, A.mtab, di.first_mesh + numFill + (uint32_t)(strokeIncl - 1), dr, (uint32_t)d, subIndex, kd, closedHere, firstV, n)) {
+									atomicAdd(&A.totals->num_round_meshes, 1u);
+								}
 							}
 						}
 					}
@@ -336,11 +332,12 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 					// exact sequential re-run of the whole draw by this one lane
 					PathSim<true, XFORM> sim;
 					sim.scale = scale; sim.tol = tol; sim.mtx = mtx; sim.poly = A.poly; sim.polyBase = di.first_poly_vertex; sim.subs = A.subs; sim.subBase = di.first_subpath;
-					sim.mdesc = A.mdesc; sim.meshBase = di.first_mesh; sim.drawIndex = (uint32_t)d; sim.fillFlags = fillFlags; sim.strokeFlags = strokeFlags;
+					sim.mdesc = A.mdesc; sim.mtab = A.mtab; sim.draw = dr; sim.meshBase = di.first_mesh; sim.drawIndex = (uint32_t)d; sim.fillFlags = fillFlags; sim.strokeFlags = strokeFlags;
 					sim.numFillTotal = di.flags >> 1;
 					sim.init();
 					const uint32_t pc0 = ps.path_cmd_begin[dr->path];
 					sim.run(ps, pc0, c + 1, stack);
+					if (sim.numRound) { atomicAdd(&A.totals->num_round_meshes, sim.numRound); }
 				}
 			}
 

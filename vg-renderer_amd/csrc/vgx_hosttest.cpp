@@ -36,7 +36,7 @@ int vgxt_serial_flatten(const vgx_pathset_desc* d, const vgx_draw* draw, int app
 	if (poly && applyTransform) {
 		PathSim<true, true> sim;
 		sim.scale = draw->scale; sim.tol = draw->tess_tol; sim.mtx = draw->mtx; sim.poly = poly; sim.polyBase = 0;
-		sim.subs = subs; sim.subBase = 0; sim.mdesc = nullptr; sim.meshBase = 0; sim.drawIndex = 0;
+		sim.subs = subs; sim.subBase = 0; sim.mdesc = nullptr; sim.mtab = nullptr; sim.draw = nullptr; sim.meshBase = 0; sim.drawIndex = 0;
 		sim.fillFlags = draw->fill_flags; sim.strokeFlags = draw->stroke_flags; sim.numFillTotal = 0;
 		sim.init();
 		sim.run(ps, c0, c1, st);
@@ -44,7 +44,7 @@ int vgxt_serial_flatten(const vgx_pathset_desc* d, const vgx_draw* draw, int app
 	} else if (poly) {
 		PathSim<true, false> sim;
 		sim.scale = draw->scale; sim.tol = draw->tess_tol; sim.mtx = draw->mtx; sim.poly = poly; sim.polyBase = 0;
-		sim.subs = subs; sim.subBase = 0; sim.mdesc = nullptr; sim.meshBase = 0; sim.drawIndex = 0;
+		sim.subs = subs; sim.subBase = 0; sim.mdesc = nullptr; sim.mtab = nullptr; sim.draw = nullptr; sim.meshBase = 0; sim.drawIndex = 0;
 		sim.fillFlags = draw->fill_flags; sim.strokeFlags = draw->stroke_flags; sim.numFillTotal = 0;
 		sim.init();
 		sim.run(ps, c0, c1, st);
@@ -52,13 +52,23 @@ int vgxt_serial_flatten(const vgx_pathset_desc* d, const vgx_draw* draw, int app
 	} else {
 		PathSim<false, false> sim;
 		sim.scale = draw->scale; sim.tol = draw->tess_tol; sim.mtx = nullptr; sim.poly = nullptr; sim.polyBase = 0;
-		sim.subs = nullptr; sim.subBase = 0; sim.mdesc = nullptr; sim.meshBase = 0; sim.drawIndex = 0;
+		sim.subs = nullptr; sim.subBase = 0; sim.mdesc = nullptr; sim.mtab = nullptr; sim.draw = nullptr; sim.meshBase = 0; sim.drawIndex = 0;
 		sim.fillFlags = draw->fill_flags; sim.strokeFlags = draw->stroke_flags; sim.numFillTotal = 0;
 		sim.init();
 		sim.run(ps, c0, c1, st);
 		counts[0] = sim.nverts; counts[1] = sim.nsubs; counts[2] = sim.nfill; counts[3] = sim.nstroke;
 	}
 	return 0;
+}
+
+// closed-form mesh sizes (vgx_lane.h) for one mesh of a draw; returns 1 when the size is closed-form
+int vgxt_mesh_closed_form(const vgx_draw* dr, uint32_t kind, int closed, uint32_t n, uint32_t* nv, uint32_t* ni)
+{
+	if (kind >= VGX_MESH_STROKE) {
+		const VgxStrokeParams sp = vgx_stroke_params(kind, closed != 0, dr->stroke_flags, dr->stroke_width, dr->fringe, dr->scale, dr->tess_tol);
+		return vgx_mesh_closed_form(kind, closed != 0, sp.cap, sp.join, n, vgx_half_circle_points(sp.da), nv, ni) ? 1 : 0;
+	}
+	return vgx_mesh_closed_form(kind, closed != 0, 0, 0, n, 2, nv, ni) ? 1 : 0;
 }
 
 } // extern "C"

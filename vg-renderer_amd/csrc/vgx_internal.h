@@ -20,6 +20,7 @@ struct VgxFlattenArgs
 	float* poly;                // emit: [cap][2]
 	vgx_subpath* subs;          // emit
 	VgxMeshDesc* mdesc;         // emit (may be null: flatten-only API)
+	vgx_mesh* mtab;             // emit: closed-form mesh sizes are written together with mdesc
 	VgxTotals* totals;
 	VgxCaps caps;
 	int apply_transform;
@@ -43,5 +44,6 @@ struct VgxStrokeArgs
 // launchers (defined in the .hip files)
 void vgx_launch_flatten(bool emit, const VgxFlattenArgs& a, int numBlocks, hipStream_t s);
 void vgx_launch_stroke(bool emit, const VgxStrokeArgs& a, int numBlocks, hipStream_t s);
+void vgx_launch_round_count(const VgxStrokeArgs& a, hipStream_t s);
 
 #endif

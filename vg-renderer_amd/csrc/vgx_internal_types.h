@@ -53,14 +53,14 @@ struct VgxMeshDesc
 	uint32_t kind;       // VGX_MESH_* | closed << 8
 };
 
+#define VGX_MESH_NEEDS_COUNT 0xFFFFFFFFu // mtab.num_vertices marker: Round joins, sized by k_mesh_round_count
+
 // ---- batch totals kept in device memory (mirrors vgx_sizes + internal counters) -------------------
 struct VgxTotals
 {
 	vgx_sizes sizes;
-	uint64_t num_cmd_instances;
-	uint64_t num_elements; // stroker work items (one per polyline vertex per mesh)
 	uint32_t status;       // vgx_status, sticky (first error wins)
-	uint32_t pad;
+	uint32_t num_round_meshes; // meshes with Round joins (their sizes need the geometry)
 };
 
 // Capacities the device-side checks compare against.

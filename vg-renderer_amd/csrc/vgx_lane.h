@@ -174,4 +174,68 @@ VGX_HD VgxArc vgx_round_join_arc(V2 n01, V2 n12, bool leftInner, float da)
 	return r;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Closed-form mesh sizes. Every stroker entry point except Round JOINS produces a vertex / index count
+// that depends only on the polyline length N, closed flag, cap, join and (Round caps) the half-circle
+// point count H -- the sums of the per-element counts listed in SURVEY.md 8a / appendix B.
+// Returns false when the mesh contains Round joins (numArcPoints is data dependent, stroker.cpp:1146).
+// ------------------------------------------------------------------------------------------------
+VGX_HD bool vgx_mesh_closed_form(uint32_t kind, bool closed, uint32_t cap, uint32_t join, uint32_t N, uint32_t H, uint32_t* nv, uint32_t* ni)
+{
+	if (kind == VGX_MESH_FILL) { *nv = N; *ni = 3 * (N - 2); return true; }          // stroker.cpp:336-337
+	if (kind == VGX_MESH_FILL_AA) { *nv = 2 * N; *ni = 9 * N - 6; return true; }    // stroker.cpp:728-732
+	if (kind == VGX_MESH_STROKE_AA_THIN) {
+		const bool bevel = join != VGX_JOIN_MITER; // Round -> Bevel, stroker.cpp:318-327
+		if (closed) { *nv = bevel ? 4 * N : 3 * N; *ni = bevel ? 15 * N : 12 * N; }
+		else { *nv = bevel ? 4 * N - 2 : 3 * N; *ni = bevel ? 15 * N - 18 : 12 * (N - 1); }
+		return true;
+	}
+	if (join == VGX_JOIN_ROUND) { return false; }
+	const bool bevel = join == VGX_JOIN_BEVEL;
+	const bool roundCap = !closed && cap == VGX_CAP_ROUND;
+	if (kind == VGX_MESH_STROKE_AA) {
+		if (closed) { *nv = bevel ? 6 * N : 4 * N; *ni = bevel ? 27 * N : 18 * N; return true; }
+		const uint32_t joins = N - 2;
+		const uint32_t capV = roundCap ? 4 * H : 8;
+		const uint32_t capI = roundCap ? (9 * H - 12) + (18 + 3 * (H - 2) + 6 * (H - 1)) : 30;
+		*nv = capV + joins * (bevel ? 6 : 4);
+		*ni = capI + joins * (bevel ? 27 : 18);
+		return true;
+	}
+	// VGX_MESH_STROKE
+	if (closed) { *nv = bevel ? 3 * N : 2 * N; *ni = bevel ? 9 * N : 6 * N; return true; }
+	const uint32_t joins = N - 2;
+	const uint32_t capV = roundCap ? 2 * H : 4;
+	const uint32_t capI = roundCap ? 3 * (H - 2) + 6 + 3 * (H - 2) : 6;
+	*nv = capV + joins * (bevel ? 3 : 2);
+	*ni = capI + joins * (bevel ? 9 : 6);
+	return true;
+}
+
+// Stroker parameters of one mesh derived from its draw record (the values the reference computes at the top
+// of polylineStroke / polylineStrokeAA / polylineStrokeAAThin, stroker.cpp:1011-1014, 1396-1399, 1999).
+struct VgxStrokeParams { uint32_t cap, join; float hsw, hswAA, da; };
+
+VGX_HD VgxStrokeParams vgx_stroke_params(uint32_t kind, bool closed, uint32_t strokeFlags, float strokeWidth, float fringe, float scale, float tol)
+{
+	VgxStrokeParams p;
+	p.cap = VGX_STROKE_CAP(strokeFlags);
+	p.join = VGX_STROKE_JOIN(strokeFlags);
+	if (closed) { p.cap = VGX_CAP_BUTT; } // closed strokes ignore the cap (dispatch tables stroker.cpp:246-268)
+	if (kind == VGX_MESH_STROKE_AA) {
+		p.hsw = (strokeWidth - fringe) * 0.5f;
+		p.hswAA = p.hsw + fringe;
+	} else if (kind == VGX_MESH_STROKE) {
+		p.hsw = strokeWidth * 0.5f;
+		p.hswAA = p.hsw;
+	} else {
+		if (p.cap == VGX_CAP_ROUND) { p.cap = VGX_CAP_SQUARE; }
+		if (p.join == VGX_JOIN_ROUND) { p.join = VGX_JOIN_BEVEL; }
+		p.hsw = fringe;
+		p.hswAA = fringe;
+	}
+	p.da = vgx_step_angle(scale, p.hsw, tol);
+	return p;
+}
+
 #endif // VGX_LANE_H

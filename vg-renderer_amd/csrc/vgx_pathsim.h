@@ -7,6 +7,32 @@
 #include "vgx_lane.h"
 #include "vgx_internal_types.h"
 
+// Writes the descriptor of one mesh and, when the stroker's output size is closed-form, its mesh-table
+// entry. Returns true when the mesh has Round joins (caller counts those).
+VGX_HD bool vgx_write_mesh(VgxMeshDesc* mdesc, vgx_mesh* mtab, uint64_t meshIndex, const vgx_draw* dr, uint32_t drawIndex, uint32_t subIndex, uint32_t kind, bool closed, uint64_t polyFirst, uint32_t n)
+{
+	VgxMeshDesc m;
+	m.poly_first = polyFirst; m.poly_n = n; m.draw = drawIndex; m.subpath = subIndex;
+	m.kind = kind | (closed ? 0x100u : 0u);
+	mdesc[meshIndex] = m;
+	uint32_t nv = VGX_MESH_NEEDS_COUNT, ni = 0;
+	bool needsCount = false;
+	if (kind >= VGX_MESH_STROKE) {
+		const VgxStrokeParams sp = vgx_stroke_params(kind, closed, dr->stroke_flags, dr->stroke_width, dr->fringe, dr->scale, dr->tess_tol);
+		needsCount = !vgx_mesh_closed_form(kind, closed, sp.cap, sp.join, n, vgx_half_circle_points(sp.da), &nv, &ni);
+	} else {
+		vgx_mesh_closed_form(kind, closed, 0, 0, n, 2, &nv, &ni);
+	}
+	vgx_mesh r;
+	r.first_vertex = 0; r.first_index = 0;
+	r.num_vertices = needsCount ? VGX_MESH_NEEDS_COUNT : nv;
+	r.num_indices = ni;
+	r.draw = drawIndex;
+	r.subpath_kind = (subIndex & 0x0FFFFFFFu) | ((kind & 0xFu) << 28);
+	mtab[meshIndex] = r;
+	return needsCount;
+}
+
 // ---- exact sequential path builder (one lane): vg::Path semantics with direct output ---------------
 // Used (a) for one closed-shape command in the lane-parallel path, (b) for a whole draw in the serial
 // path. Mirrors createPath..pathClose of src/path.cpp; each method cites its lines.
@@ -21,6 +47,9 @@ struct PathSim
 	vgx_subpath* subs;       // batch sub-path array (serial mode only; null in lane mode)
 	uint64_t subBase;
 	VgxMeshDesc* mdesc;      // serial mode only
+	vgx_mesh* mtab;          // serial mode only
+	const vgx_draw* draw;    // serial mode only
+	uint32_t numRound;       // Round-join meshes written
 	uint64_t meshBase;
 	uint32_t drawIndex;
 	uint32_t fillFlags, strokeFlags;
@@ -39,7 +68,7 @@ struct PathSim
 
 	VGX_HDM void init()
 	{
-		nverts = 0; nsubs = 0; nfill = 0; nstroke = 0; open = false; spFirst = 0; spN = 0; spClosed = false;
+		nverts = 0; nsubs = 0; nfill = 0; nstroke = 0; numRound = 0; open = false; spFirst = 0; spN = 0; spClosed = false;
 		first = v2(0.0f, 0.0f); last = first; havePending = false; laneExists = false; laneClosed = false;
 	}
 	VGX_HDM void store(uint32_t i, V2 p)
@@ -69,20 +98,14 @@ struct PathSim
 		}
 		if ((fillFlags & VGX_FILL_ENABLE) && spN >= 3) {
 			if (EMIT && mdesc) {
-				VgxMeshDesc m;
-				m.poly_first = polyBase + spFirst; m.poly_n = spN; m.draw = drawIndex; m.subpath = subIndex;
-				m.kind = ((fillFlags & VGX_FILL_AA) ? VGX_MESH_FILL_AA : VGX_MESH_FILL) | (spClosed ? 0x100u : 0u);
-				mdesc[meshBase + nfill] = m;
+				vgx_write_mesh(mdesc, mtab, meshBase + nfill, draw, drawIndex, subIndex, (fillFlags & VGX_FILL_AA) ? VGX_MESH_FILL_AA : VGX_MESH_FILL, spClosed, polyBase + spFirst, spN);
 			}
 			++nfill;
 		}
 		if ((strokeFlags & VGX_STROKE_ENABLE) && spN >= 2) {
 			if (EMIT && mdesc) {
-				VgxMeshDesc m;
-				m.poly_first = polyBase + spFirst; m.poly_n = spN; m.draw = drawIndex; m.subpath = subIndex;
 				const uint32_t k = !(strokeFlags & VGX_STROKE_AA) ? VGX_MESH_STROKE : ((strokeFlags & VGX_STROKE_THIN) ? VGX_MESH_STROKE_AA_THIN : VGX_MESH_STROKE_AA);
-				m.kind = k | (spClosed ? 0x100u : 0u);
-				mdesc[meshBase + numFillTotal + nstroke] = m;
+				if (vgx_write_mesh(mdesc, mtab, meshBase + numFillTotal + nstroke, draw, drawIndex, subIndex, k, spClosed, polyBase + spFirst, spN)) { ++numRound; }
 			}
 			++nstroke;
 		}

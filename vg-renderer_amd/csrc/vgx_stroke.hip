@@ -101,6 +101,25 @@ __device__ __forceinline__ V2 ldv(const float* vtx, uint32_t i)
 	return v2(t.x, t.y);
 }
 
+__device__ __forceinline__ MeshCtx make_mesh_ctx(const VgxMeshDesc& md, const vgx_draw* dr, uint32_t j, const float* poly)
+{
+	MeshCtx mc;
+	mc.kind = md.kind & 0xFFu;
+	mc.closed = (md.kind & 0x100u) != 0;
+	mc.N = md.poly_n;
+	mc.j = j;
+	mc.vtx = poly + 2 * md.poly_first;
+	mc.fringe = dr->fringe;
+	mc.cap = 0; mc.join = 0; mc.hsw = 0.0f; mc.hswAA = 0.0f; mc.da = 1.0f;
+	const bool isFill = mc.kind == VGX_MESH_FILL || mc.kind == VGX_MESH_FILL_AA;
+	mc.color = isFill ? dr->fill_color : dr->stroke_color;
+	if (!isFill) {
+		const VgxStrokeParams sp = vgx_stroke_params(mc.kind, mc.closed, dr->stroke_flags, dr->stroke_width, dr->fringe, dr->scale, dr->tess_tol);
+		mc.cap = sp.cap; mc.join = sp.join; mc.hsw = sp.hsw; mc.hswAA = sp.hswAA; mc.da = sp.da;
+	}
+	return mc;
+}
+
 // ---- step A ---------------------------------------------------------------------------------------
 __device__ __forceinline__ Elem elem_geometry(const MeshCtx& m)
 {
@@ -590,36 +609,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_stroke(VgxStrokeArgs A)
 			if (valid) {
 				mi = find_owner_u64(A.elem_prefix, m0, m1, ei);
 				const VgxMeshDesc md = A.mdesc[mi];
-				const vgx_draw* dr = A.draws + md.draw;
-				mc.kind = md.kind & 0xFFu;
-				mc.closed = (md.kind & 0x100u) != 0;
-				mc.N = md.poly_n;
-				mc.j = (uint32_t)(ei - A.elem_prefix[mi]);
-				mc.vtx = A.poly + 2 * md.poly_first;
-				mc.fringe = dr->fringe;
-				const bool isFill = mc.kind == VGX_MESH_FILL || mc.kind == VGX_MESH_FILL_AA;
-				mc.color = isFill ? dr->fill_color : dr->stroke_color;
-				if (!isFill) {
-					const uint32_t sf = dr->stroke_flags;
-					mc.cap = VGX_STROKE_CAP(sf);
-					mc.join = VGX_STROKE_JOIN(sf);
-					if (mc.closed) { mc.cap = VGX_CAP_BUTT; } // closed strokes ignore the cap (dispatch tables :246-268)
-					const float sw = dr->stroke_width;
-					if (mc.kind == VGX_MESH_STROKE_AA) {
-						mc.hsw = (sw - mc.fringe) * 0.5f;  // :1396
-						mc.hswAA = mc.hsw + mc.fringe;     // :1397
-					} else if (mc.kind == VGX_MESH_STROKE) {
-						mc.hsw = sw * 0.5f;                // :1012
-						mc.hswAA = mc.hsw;
-					} else {
-						// thin: Round cap -> Square, Round join -> Bevel (:318-327)
-						if (mc.cap == VGX_CAP_ROUND) { mc.cap = VGX_CAP_SQUARE; }
-						if (mc.join == VGX_JOIN_ROUND) { mc.join = VGX_JOIN_BEVEL; }
-						mc.hsw = mc.fringe;
-						mc.hswAA = mc.fringe;
-					}
-					mc.da = vgx_step_angle(dr->scale, mc.hsw, dr->tess_tol); // :1013, 1398
-				}
+				mc = make_mesh_ctx(md, A.draws + md.draw, (uint32_t)(ei - A.elem_prefix[mi]), A.poly);
 				e = elem_geometry(mc);
 				totalIdx = elem_total_indices(mc, e);
 			}
@@ -682,13 +672,41 @@ __global__ __launch_bounds__(VGX_WAVE) void k_stroke(VgxStrokeArgs A)
 	}
 }
 
+// Sizes of meshes with Round joins (the only data-dependent sizes): one lane walks one mesh's joins and sums
+// the per-element counts of step A. Exits immediately when the batch has no such mesh.
+__global__ __launch_bounds__(256) void k_mesh_round_count(VgxStrokeArgs A)
+{
+	if (A.totals->status != VGX_OK || A.totals->num_round_meshes == 0) {
+		return;
+	}
+	const uint64_t numMeshes = A.totals->sizes.num_meshes;
+	for (uint64_t mi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; mi < numMeshes; mi += (uint64_t)gridDim.x * blockDim.x) {
+		if (A.mtab[mi].num_vertices != VGX_MESH_NEEDS_COUNT) {
+			continue;
+		}
+		const VgxMeshDesc md = A.mdesc[mi];
+		const vgx_draw* dr = A.draws + md.draw;
+		uint32_t nv = 0, ni = 0;
+		for (uint32_t j = 0; j < md.poly_n; ++j) {
+			const MeshCtx mc = make_mesh_ctx(md, dr, j, A.poly);
+			const Elem e = elem_geometry(mc);
+			nv += e.nv;
+			ni += elem_total_indices(mc, e);
+		}
+		A.mtab[mi].num_vertices = nv;
+		A.mtab[mi].num_indices = ni;
+	}
+}
+
 } // namespace
+
+void vgx_launch_round_count(const VgxStrokeArgs& a, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_mesh_round_count, dim3(2048), dim3(256), 0, s, a);
+}
 
 void vgx_launch_stroke(bool emit, const VgxStrokeArgs& a, int numBlocks, hipStream_t s)
 {
-	if (emit) {
-		hipLaunchKernelGGL(k_stroke<true>, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
-	} else {
-		hipLaunchKernelGGL(k_stroke<false>, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
-	}
+	(void)emit; // sizes come from flatten-emit (closed form) and k_mesh_round_count; only the emit pass remains
+	hipLaunchKernelGGL(k_stroke<true>, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
 }

@@ -1,0 +1,42 @@
+"""Turn rocprofv3 (ROCm 7.2, rocpd SQLite output) result databases into the small text summaries that are
+committed under profiles/. Usage:
+  python profiles/summarize.py trace gpurun_out/prof_rNN_trace/trace_results.db > profiles/rNN_kernel_stats.txt
+  python profiles/summarize.py pmc   gpurun_out/prof_rNN_fetch/fetch_results.db FETCH_SIZE > profiles/rNN_pmc_fetch.txt
+"""
+import sqlite3
+import sys
+
+
+def trace(db):
+    c = sqlite3.connect(db).cursor()
+    print("# rocprofv3 --kernel-trace --stats summary (durations in us)")
+    print("%-100s %6s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
+    for name, calls, total, avg, pct in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc limit 25"):
+        print("%-100s %6d %14.1f %12.1f %6.2f%%" % (name[:100], calls, total, avg, pct))
+    print()
+    print("# launch geometry / registers of the vgx kernels")
+    seen = set()
+    for r in c.execute("select name, grid_x, workgroup_x, lds_size, scratch_size, vgpr_count, accum_vgpr_count, sgpr_count from kernels"):
+        if r[0] in seen or ("k_" not in r[0]):
+            continue
+        seen.add(r[0])
+        print("%-90s grid=%d wg=%d lds=%d scratch=%d vgpr=%d agpr=%d sgpr=%d" % ((r[0][:90],) + tuple(r[1:])))
+
+
+def pmc(db, counter):
+    c = sqlite3.connect(db).cursor()
+    print("# rocprofv3 --pmc %s, per-kernel average over dispatches (value is KB as rocprofv3 reports it)" % counter)
+    print("# gfx950 note (MI355X_MICROARCH.md, HBM section): FETCH_SIZE under-reports wide coalesced reads by 2x;")
+    print("# 'x2' column applies that correction for FETCH_SIZE; WRITE_SIZE is uncalibrated and shown raw.")
+    rows = c.execute("select kernel_name, count(*), avg(value), avg(duration) from counters_collection where counter_name=? group by kernel_name order by avg(value)*count(*) desc limit 20", (counter,)).fetchall()
+    print("%-90s %6s %14s %14s %12s" % ("kernel", "calls", "avg_KB", "avg_MB(x2)" if counter == "FETCH_SIZE" else "avg_MB", "avg_us"))
+    for name, n, kb, dur in rows:
+        mb = kb / 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0)
+        print("%-90s %6d %14.1f %14.1f %12.1f" % (name[:90], n, kb, mb, dur / 1000.0))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "trace":
+        trace(sys.argv[2])
+    else:
+        pmc(sys.argv[2], sys.argv[3])

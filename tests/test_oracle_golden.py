@@ -1,0 +1,84 @@
+"""CPU: the restatement oracle (oracle/vgo_port.cpp) against the golden vectors that were generated from the
+reference's own compiled sources, and -- when oracle/_ref is present -- against the reference directly."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from util import assert_flat_equal, assert_mesh_equal
+
+
+def test_known_answer_counts_survey_table(vgr, oracle):
+    """zig-zag polyline in every cap/join/closed combination, cubics, circle."""
+    ps = gu.zigzag_set()
+    n = 0
+    for rec in gu.known_answers():
+        if rec["mode"] not in ("aa", "plain", "thin"):
+            continue
+        r = oracle.tessellate(ps, gu.known_answer_draw(vgr, rec), kind="port")
+        assert (r.sizes["num_vertices"], r.sizes["num_indices"]) == (rec["verts"], rec["idx"]), rec
+        assert gu.sha(r.idx) == rec["idx_sha"] and gu.sha(r.color) == rec["col_sha"] and gu.sha(r.pos) == rec["pos_sha"], rec
+        n += 1
+    assert n == 81
+    table = {(r["path"], r["mode"], r["cap"], r["join"]): (r["verts"], r["idx"]) for r in gu.known_answers() if "cap" in r}
+    # a few rows spelled out (open = path 0, closed = path 1; caps 0 Butt 1 Round 2 Square; joins 0 Miter 1 Round 2 Bevel)
+    assert table[(0, "aa", 0, 0)] == (24, 102) and table[(0, "aa", 1, 1)] == (54, 237) and table[(1, "aa", 0, 2)] == (36, 162)
+    assert table[(0, "plain", 0, 0)] == (12, 30) and table[(0, "plain", 1, 1)] == (29, 81) and table[(1, "plain", 0, 1)] == (29, 87)
+    assert table[(0, "thin", 0, 0)] == (18, 60) and table[(0, "thin", 0, 2)] == (22, 72) and table[(1, "thin", 0, 2)] == (24, 90)
+    assert table[(2, "aa", 0, 0)] == (132, 588) and table[(2, "aa", 1, 1)] == (268, 1200)
+
+
+def test_flatten_known_answers(vgr, oracle):
+    ps = gu.zigzag_set()
+    d = vgr.make_draws(ps.npaths)
+    d["path"] = np.arange(ps.npaths)
+    f = oracle.flatten(ps, d, kind="port")
+    rec = [r for r in gu.known_answers() if r["mode"] == "flatten"][0]
+    assert [int(x) for x in f.draw_info["num_poly_vertices"]] == rec["poly_per_path"] == [6, 6, 33, 32, 17]
+    assert gu.sha(f.poly) == rec["poly_sha"]
+
+
+@pytest.mark.parametrize("seed", [7, 8])
+def test_port_reproduces_golden_fuzz(oracle, seed):
+    ps, draws, g = gu.load_fuzz(seed)
+    r = oracle.tessellate(ps, draws, kind="port", want_flat=True)
+    assert_mesh_equal(r, g, "golden fuzz %d" % seed)
+    assert_flat_equal(r, g, "golden fuzz %d (transformed polyline)" % seed)
+    fr = oracle.flatten(ps, draws, apply_transform=False, kind="port")
+    assert np.array_equal(fr.poly.view(np.uint32), g.poly_raw.view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["config0_single_cubic", "tiger_x1", "tiger_x3", "polylines_round_round_20x300", "cubics_2000_box1000"])
+def test_port_reproduces_golden_checksums(wl, oracle, name):
+    ps, d = gu.workload_by_name(wl, name)
+    r = oracle.tessellate(ps, d, kind="port", want_flat=True)
+    c = gu.checksums()[name]
+    for k in ("num_poly_vertices", "num_subpaths", "num_meshes", "num_vertices", "num_indices"):
+        assert r.sizes[k] == c["sizes"][k], (name, k)
+    for k in ("poly", "subpaths", "pos", "color", "idx", "meshes"):
+        assert gu.sha(getattr(r, k)) == c[k], (name, k)
+
+
+@pytest.mark.parametrize("seed", list(range(20, 32)))
+def test_port_vs_reference_sources(wl, oracle, seed):
+    """Only where oracle/_ref/libvgref.so exists (built from /root/reference by oracle/Makefile)."""
+    if not oracle.available("reference"):
+        pytest.skip("oracle/_ref not built (no /root/reference on this box)")
+    ps = wl.fuzz_paths(seed, npaths=64)
+    d = wl.fuzz_draws(ps, seed)
+    a = oracle.tessellate(ps, d, kind="reference", want_flat=True)
+    b = oracle.tessellate(ps, d, kind="port", want_flat=True)
+    assert_mesh_equal(b, a, "port vs reference seed %d" % seed)
+    assert_flat_equal(b, a, "port vs reference seed %d" % seed)
+
+
+def test_sse_reference_differs_only_where_documented(wl, oracle):
+    """The reference's default x86 build uses an SSE strokerConvexFillAA with rcpps/rsqrtps and a different
+    index order (src/stroker.cpp:368-711). It is a speed baseline, not the parity target: check that the
+    vertex/index COUNTS agree with the scalar build while the streams differ."""
+    if not (oracle.available("reference") and oracle.available("reference_sse")):
+        pytest.skip("oracle/_ref not built")
+    ps, d = wl.tiger(1)
+    a = oracle.tessellate(ps, d, kind="reference")
+    b = oracle.tessellate(ps, d, kind="reference_sse")
+    assert a.sizes == b.sizes
+    assert not np.array_equal(a.idx, b.idx)

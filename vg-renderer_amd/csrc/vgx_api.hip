@@ -12,8 +12,9 @@
 #include <string.h>
 #include <math.h>
 #include <new>
+#include <stdlib.h>
 
-#define VGX_GRID_BLOCKS 4096 // persistent 1-wave workgroups; segments are grid-strided
+#define VGX_GRID_BLOCKS 32768 // one-wave workgroups, each owning a contiguous run of segments (>> resident waves: no tail)
 
 struct vgx_pathset
 {
@@ -34,7 +35,7 @@ struct vgx_ctx
 	int device;
 	int lastHipError;
 	// grow-only device scratch
-	DevBuf cmdPrefix, cmdCnt, dinfo, poly, subs, mdesc, elemPrefix, mtab, partial, totals;
+	DevBuf cmdPrefix, cmdCnt, dinfo, poly, subs, mdesc, elemPrefix, elemPrefixS, mprep, mtab, partial, totals;
 	VgxCaps caps; // element capacities matching the buffers above
 	uint64_t capDraws;
 	VgxTotals* hostTotals; // pinned
@@ -171,19 +172,27 @@ struct OpDrawInfo // per-draw polyline / sub-path / mesh counts -> first_* field
 	}
 };
 
-struct OpElemPrefix // stroker elements per mesh -> elem_prefix
+struct OpElemPrefix // stroker elements per mesh -> two prefix arrays (convex fills / polyline strokes)
 {
 	const VgxMeshDesc* mdesc;
-	uint64_t* prefix;
+	uint64_t* prefixFill;
+	uint64_t* prefixStroke;
 	VgxTotals* totals;
 	__device__ uint64_t size() const { return totals->status == VGX_OK ? totals->sizes.num_meshes : 0; }
-	__device__ Sum3 load(uint64_t i) const { Sum3 r = sum3_zero(); r.a = mdesc[i].poly_n; return r; }
-	__device__ void store(uint64_t i, Sum3 e) const { prefix[i] = e.a; }
+	__device__ Sum3 load(uint64_t i) const
+	{
+		Sum3 r = sum3_zero();
+		const VgxMeshDesc m = mdesc[i];
+		if (VGX_MD_KIND(m.kind) >= VGX_MESH_STROKE) { r.b = m.poly_n; } else { r.a = m.poly_n; }
+		return r;
+	}
+	__device__ void store(uint64_t i, Sum3 e) const { prefixFill[i] = e.a; prefixStroke[i] = e.b; }
 	__device__ void finish(Sum3 t) const
 	{
 		const uint64_t n = totals->status == VGX_OK ? totals->sizes.num_meshes : 0;
-		prefix[n] = t.a;
-		totals->sizes.num_elements = t.a;
+		prefixFill[n] = t.a;
+		prefixStroke[n] = t.b;
+		totals->sizes.num_elements = t.a + t.b;
 	}
 };
 
@@ -281,16 +290,17 @@ void runFlattenCount(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps, int checkCaps, hipStream_t s)
 {
 	OpElemPrefix ope;
-	ope.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; ope.prefix = (uint64_t*)ctx->elemPrefix.p; ope.totals = (VgxTotals*)ctx->totals.p;
+	ope.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; ope.prefixFill = (uint64_t*)ctx->elemPrefix.p; ope.prefixStroke = (uint64_t*)ctx->elemPrefixS.p; ope.totals = (VgxTotals*)ctx->totals.p;
 	vgx_device_scan(ope, (Sum3*)ctx->partial.p, s);
 	mark(ctx, s, "scan_elements");
 	VgxStrokeArgs a;
 	a.draws = draws; a.poly = (const float*)ctx->poly.p; a.mdesc = (const VgxMeshDesc*)ctx->mdesc.p;
-	a.elem_prefix = (const uint64_t*)ctx->elemPrefix.p; a.mtab = (vgx_mesh*)ctx->mtab.p;
-	a.pos = nullptr; a.color = nullptr; a.idx = nullptr; a.meshes_out = nullptr;
+	a.elem_prefix = nullptr; a.elem_prefix_fill = (const uint64_t*)ctx->elemPrefix.p; a.elem_prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
+	a.mprep = (VgxMeshPrep*)ctx->mprep.p; a.mtab = (vgx_mesh*)ctx->mtab.p;
+	a.pos = nullptr; a.color = nullptr; a.idx = nullptr; a.meshes_out = nullptr; a.stage_output = 0;
 	a.totals = (VgxTotals*)ctx->totals.p; a.caps = outCaps;
-	vgx_launch_round_count(a, s);
-	mark(ctx, s, "round_join_count");
+	vgx_launch_mesh_prepare(a, s);
+	mark(ctx, s, "mesh_prepare");
 	OpMeshTab opm;
 	opm.mtab = (vgx_mesh*)ctx->mtab.p; opm.totals = (VgxTotals*)ctx->totals.p; opm.caps = outCaps; opm.checkCaps = checkCaps;
 	vgx_device_scan(opm, (Sum3*)ctx->partial.p, s);
@@ -301,10 +311,16 @@ void runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out,
 {
 	VgxStrokeArgs a;
 	a.draws = draws; a.poly = (const float*)ctx->poly.p; a.mdesc = (const VgxMeshDesc*)ctx->mdesc.p;
-	a.elem_prefix = (const uint64_t*)ctx->elemPrefix.p; a.mtab = (vgx_mesh*)ctx->mtab.p;
+	a.elem_prefix = nullptr; a.elem_prefix_fill = (const uint64_t*)ctx->elemPrefix.p; a.elem_prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
+	a.mprep = (VgxMeshPrep*)ctx->mprep.p; a.mtab = (vgx_mesh*)ctx->mtab.p;
 	a.pos = out->pos; a.color = out->color; a.idx = out->idx; a.meshes_out = out->meshes;
+	{ const char* e = getenv("VGX_STAGE_OUTPUT"); a.stage_output = e ? atoi(e) : 1; } // tuning knob
 	a.totals = (VgxTotals*)ctx->totals.p;
 	a.caps = ctx->caps;
+	a.elem_prefix = a.elem_prefix_fill;
+	vgx_launch_fill(a, VGX_GRID_BLOCKS, s);
+	mark(ctx, s, "fill_emit");
+	a.elem_prefix = a.elem_prefix_stroke;
 	vgx_launch_stroke(true, a, VGX_GRID_BLOCKS, s);
 	mark(ctx, s, "stroke_emit");
 }
@@ -316,11 +332,14 @@ int ensureMeshBuffers(vgx_ctx* ctx, uint64_t polyVerts, uint64_t subpaths, uint6
 	if ((st = ensure(ctx, ctx->subs, (subpaths + 1) * sizeof(vgx_subpath))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->mdesc, (meshes + 1) * sizeof(VgxMeshDesc))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->elemPrefix, (meshes + 2) * sizeof(uint64_t))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->elemPrefixS, (meshes + 2) * sizeof(uint64_t))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->mprep, (meshes + 1) * sizeof(VgxMeshPrep))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->mtab, (meshes + 1) * sizeof(vgx_mesh))) != VGX_OK) { return st; }
 	ctx->caps.poly_vertices = ctx->poly.cap / (2 * sizeof(float)) - 1;
 	ctx->caps.subpaths = ctx->subs.cap / sizeof(vgx_subpath) - 1;
 	uint64_t m = ctx->mdesc.cap / sizeof(VgxMeshDesc) - 1;
-	const uint64_t m2 = ctx->elemPrefix.cap / sizeof(uint64_t) - 2;
+	uint64_t m2 = ctx->elemPrefix.cap / sizeof(uint64_t) - 2;
+	{ const uint64_t m4 = ctx->elemPrefixS.cap / sizeof(uint64_t) - 2, m5 = ctx->mprep.cap / sizeof(VgxMeshPrep) - 1; if (m4 < m2) { m2 = m4; } if (m5 < m2) { m2 = m5; } }
 	const uint64_t m3 = ctx->mtab.cap / sizeof(vgx_mesh) - 1;
 	if (m2 < m) { m = m2; }
 	if (m3 < m) { m = m3; }
@@ -383,7 +402,7 @@ int vgx_destroy(vgx_ctx* ctx)
 	if (!ctx) {
 		return VGX_E_INVALID_ARG;
 	}
-	DevBuf* bufs[] = { &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DevBuf* bufs[] = { &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
@@ -402,7 +421,7 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx)
 	if (!ctx) {
 		return 0;
 	}
-	return ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
+	return ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
 }
 
 // ---- path set ---------------------------------------------------------------------------------------

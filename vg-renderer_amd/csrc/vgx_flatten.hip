@@ -88,15 +88,25 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 	const uint64_t totalCmds = A.cmd_prefix[A.ndraws];
 	if (A.totals->status != VGX_OK) { return; } // capacity / range errors detected by the scan steps
 	const uint64_t numSegments = (totalCmds + VGX_WAVE - 1) / VGX_WAVE;
+	// contiguous run of segments per wave: one binary search per wave, then cooperative advance (vgx_wave.h)
+	const uint64_t segsPerWave = (numSegments + gridDim.x - 1) / gridDim.x;
+	const uint64_t seg0 = (uint64_t)blockIdx.x * segsPerWave;
+	const uint64_t seg1 = (seg0 + segsPerWave < numSegments) ? seg0 + segsPerWave : numSegments;
+	if (seg0 >= seg1) {
+		return;
+	}
+	uint64_t dNext = lower_bound_u64(A.cmd_prefix, 0, A.ndraws, seg0 * VGX_WAVE);
 
-	for (uint64_t seg = blockIdx.x; seg < numSegments; seg += gridDim.x) {
-		const uint64_t d0 = lower_bound_u64(A.cmd_prefix, 0, A.ndraws, seg * VGX_WAVE);
-		const uint64_t d1 = lower_bound_u64(A.cmd_prefix, d0, A.ndraws, (seg + 1) * VGX_WAVE);
+	for (uint64_t seg = seg0; seg < seg1; ++seg) {
+		const uint64_t d0 = dNext;
+		const uint64_t d1 = advance_lower_bound(A.cmd_prefix, d0, A.ndraws, (seg + 1) * VGX_WAVE, lane);
+		dNext = d1;
 		if (d0 == d1) {
 			continue;
 		}
 		const uint64_t C0 = A.cmd_prefix[d0];
 		const uint64_t C1 = A.cmd_prefix[d1];
+		uint64_t dcur = d0; // draw that owns the chunk's first command instance
 
 		// carries of the draw / sub-path that continue across 64-command chunks (wave-uniform)
 		int carryDrawVerts = 0, carrySpVerts = 0, carrySubs = 0, carryFill = 0, carryStroke = 0;
@@ -114,12 +124,23 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 			float scale = 1.0f, tol = 0.25f;
 			uint32_t fillFlags = 0, strokeFlags = 0;
 			const vgx_draw* dr = A.draws;
+			// owner draw of every lane from a 64-entry window of cmd_prefix (no global binary search)
+			const uint64_t widx = dcur + (uint64_t)lane;
+			const uint64_t wv = (widx <= d1) ? A.cmd_prefix[widx] : ~0ull;
+			const bool windowCovers = __shfl((unsigned long long)wv, VGX_WAVE - 1) > chunk + (VGX_WAVE - 1);
+			uint64_t ownerBase = 0;
+			const int ownerOfs = window_owner(wv, valid ? ci : chunk, &ownerBase);
 			if (valid) {
-				d = find_owner_u64(A.cmd_prefix, d0, d1, ci);
+				if (windowCovers) {
+					d = dcur + (uint64_t)ownerOfs;
+				} else { // more than 63 draws begin inside this chunk (1-command or empty paths)
+					d = find_owner_u64(A.cmd_prefix, d0, d1, ci);
+					ownerBase = A.cmd_prefix[d];
+				}
 				dr = A.draws + d;
 				const uint32_t path = dr->path;
 				const uint32_t pc0 = ps.path_cmd_begin[path];
-				const uint32_t k = (uint32_t)(ci - A.cmd_prefix[d]);
+				const uint32_t k = (uint32_t)(ci - ownerBase);
 				c = pc0 + k;
 				type = ps.cmd_type[c];
 				cflags = ps.cmd_flags[c];
@@ -360,6 +381,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 			carrySlow = lastIsDrawLast ? 0 : nSlow;
 			carrySpVerts = (lastIsDrawLast || lastIsSubLast) ? 0 : nSp;
 			carrySpExists = (lastIsDrawLast || lastIsSubLast) ? 0 : nHeadExists;
+			dcur = __shfl((unsigned long long)d, L); // draw of the last command; its prefix <= next chunk's first key
 		}
 	}
 }

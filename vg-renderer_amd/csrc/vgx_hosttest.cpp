@@ -66,7 +66,8 @@ int vgxt_mesh_closed_form(const vgx_draw* dr, uint32_t kind, int closed, uint32_
 {
 	if (kind >= VGX_MESH_STROKE) {
 		const VgxStrokeParams sp = vgx_stroke_params(kind, closed != 0, dr->stroke_flags, dr->stroke_width, dr->fringe, dr->scale, dr->tess_tol);
-		return vgx_mesh_closed_form(kind, closed != 0, sp.cap, sp.join, n, vgx_half_circle_points(sp.da), nv, ni) ? 1 : 0;
+		const uint32_t H = vgx_half_circle_points(vgx_step_angle(dr->scale, sp.hsw, dr->tess_tol));
+		return vgx_mesh_closed_form(kind, closed != 0, sp.cap, sp.join, n, H, nv, ni) ? 1 : 0;
 	}
 	return vgx_mesh_closed_form(kind, closed != 0, 0, 0, n, 2, nv, ni) ? 1 : 0;
 }

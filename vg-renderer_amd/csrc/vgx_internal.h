@@ -31,12 +31,16 @@ struct VgxStrokeArgs
 	const vgx_draw* draws;
 	const float* poly;
 	const VgxMeshDesc* mdesc;
-	const uint64_t* elem_prefix; // [num_meshes+1] exclusive prefix of poly_n over meshes
+	const uint64_t* elem_prefix; // [num_meshes+1] exclusive prefix of poly_n over the meshes of this kernel's kind class
+	const uint64_t* elem_prefix_fill;   // fills only (strokes contribute 0)
+	const uint64_t* elem_prefix_stroke; // strokes only
+	VgxMeshPrep* mprep;          // [num_meshes]
 	vgx_mesh* mtab;              // [num_meshes] count: writes num_*, scan fills first_*, emit reads
 	float* pos;
 	uint32_t* color;
 	uint16_t* idx;
 	vgx_mesh* meshes_out;        // caller's mesh table (emit copies mtab into it)
+	int stage_output;            // 1: stage each chunk in LDS and copy out coalesced; 0: direct global stores
 	VgxTotals* totals;
 	VgxCaps caps;
 };
@@ -44,6 +48,7 @@ struct VgxStrokeArgs
 // launchers (defined in the .hip files)
 void vgx_launch_flatten(bool emit, const VgxFlattenArgs& a, int numBlocks, hipStream_t s);
 void vgx_launch_stroke(bool emit, const VgxStrokeArgs& a, int numBlocks, hipStream_t s);
-void vgx_launch_round_count(const VgxStrokeArgs& a, hipStream_t s);
+void vgx_launch_mesh_prepare(const VgxStrokeArgs& a, hipStream_t s);
+void vgx_launch_fill(const VgxStrokeArgs& a, int numBlocks, hipStream_t s);
 
 #endif

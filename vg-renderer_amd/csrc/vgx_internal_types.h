@@ -50,7 +50,20 @@ struct VgxMeshDesc
 	uint32_t poly_n;
 	uint32_t draw;
 	uint32_t subpath;    // sub-path index within the draw
-	uint32_t kind;       // VGX_MESH_* | closed << 8
+	uint32_t kind;       // bits 0-7 VGX_MESH_*, bit 8 closed, bits 9-10 effective cap, bits 11-12 effective join
+};
+#define VGX_MD_KIND(k) ((k) & 0xFFu)
+#define VGX_MD_CLOSED(k) (((k) >> 8) & 1u)
+#define VGX_MD_CAP(k) (((k) >> 9) & 3u)
+#define VGX_MD_JOIN(k) (((k) >> 11) & 3u)
+
+// Per-mesh constants computed once by k_mesh_prepare so that the element kernels do not touch the draw record:
+//   fills   f0 = aa = fringe/2 * sign(first triangle) (stroker.cpp:721-723)
+//   strokes f0 = hsw, f1 = hsw_aa, f2 = fringe        (stroker.cpp:1011-1012, 1396-1397, 1999)
+struct VgxMeshPrep
+{
+	float f0, f1, f2;
+	uint32_t color;
 };
 
 #define VGX_MESH_NEEDS_COUNT 0xFFFFFFFFu // mtab.num_vertices marker: Round joins, sized by k_mesh_round_count

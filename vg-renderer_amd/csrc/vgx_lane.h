@@ -142,6 +142,17 @@ struct VgxJoin
 	bool leftInner; // dot(d12, v*w) >= 0 (stroker.cpp:1099-1100, 1534-1535, 2072-2073)
 };
 
+VGX_HD VgxJoin vgx_join_dirs(V2 d01, V2 d12, float sideWidth)
+{
+	VgxJoin j;
+	j.d01 = d01;
+	j.d12 = d12;
+	j.v = v2extrude(j.d01, j.d12);
+	const V2 vw = v2mul(j.v, sideWidth);
+	j.leftInner = (j.d12.x * vw.x + j.d12.y * vw.y) >= 0.0f;
+	return j;
+}
+
 VGX_HD VgxJoin vgx_join(V2 p0, V2 p1, V2 p2, float sideWidth)
 {
 	VgxJoin j;
@@ -214,7 +225,7 @@ VGX_HD bool vgx_mesh_closed_form(uint32_t kind, bool closed, uint32_t cap, uint3
 
 // Stroker parameters of one mesh derived from its draw record (the values the reference computes at the top
 // of polylineStroke / polylineStrokeAA / polylineStrokeAAThin, stroker.cpp:1011-1014, 1396-1399, 1999).
-struct VgxStrokeParams { uint32_t cap, join; float hsw, hswAA, da; };
+struct VgxStrokeParams { uint32_t cap, join; float hsw, hswAA; };
 
 VGX_HD VgxStrokeParams vgx_stroke_params(uint32_t kind, bool closed, uint32_t strokeFlags, float strokeWidth, float fringe, float scale, float tol)
 {
@@ -234,7 +245,7 @@ VGX_HD VgxStrokeParams vgx_stroke_params(uint32_t kind, bool closed, uint32_t st
 		p.hsw = fringe;
 		p.hswAA = fringe;
 	}
-	p.da = vgx_step_angle(scale, p.hsw, tol);
+	(void)scale; (void)tol; // da = vgx_step_angle(scale, hsw, tol) is only needed for Round caps / joins: callers compute it lazily
 	return p;
 }
 

@@ -14,15 +14,17 @@ VGX_HD bool vgx_write_mesh(VgxMeshDesc* mdesc, vgx_mesh* mtab, uint64_t meshInde
 	VgxMeshDesc m;
 	m.poly_first = polyFirst; m.poly_n = n; m.draw = drawIndex; m.subpath = subIndex;
 	m.kind = kind | (closed ? 0x100u : 0u);
-	mdesc[meshIndex] = m;
 	uint32_t nv = VGX_MESH_NEEDS_COUNT, ni = 0;
 	bool needsCount = false;
 	if (kind >= VGX_MESH_STROKE) {
 		const VgxStrokeParams sp = vgx_stroke_params(kind, closed, dr->stroke_flags, dr->stroke_width, dr->fringe, dr->scale, dr->tess_tol);
-		needsCount = !vgx_mesh_closed_form(kind, closed, sp.cap, sp.join, n, vgx_half_circle_points(sp.da), &nv, &ni);
+		m.kind |= (sp.cap << 9) | (sp.join << 11);
+		const uint32_t H = (!closed && sp.cap == VGX_CAP_ROUND) ? vgx_half_circle_points(vgx_step_angle(dr->scale, sp.hsw, dr->tess_tol)) : 2u;
+		needsCount = !vgx_mesh_closed_form(kind, closed, sp.cap, sp.join, n, H, &nv, &ni);
 	} else {
 		vgx_mesh_closed_form(kind, closed, 0, 0, n, 2, &nv, &ni);
 	}
+	mdesc[meshIndex] = m;
 	vgx_mesh r;
 	r.first_vertex = 0; r.first_index = 0;
 	r.num_vertices = needsCount ? VGX_MESH_NEEDS_COUNT : nv;

@@ -2,23 +2,26 @@
 // (replaces vg::strokerXXX, reference src/stroker.cpp).
 //
 // Work decomposition
-//   One lane = one ELEMENT = one polyline vertex of one mesh: a cap (first/last vertex of an open
-//   stroke), a join, or a polygon corner of a convex fill. The batch is a flat stream of elements
-//   (elem_prefix = exclusive scan of poly_n over meshes); a wavefront owns all meshes whose first
-//   element falls into one 64-element bucket and walks them 64 elements at a time.
-//   The reference builds each mesh sequentially (running m_NumVertices / m_NumIndices and the
-//   prevSegment*ID bookkeeping, stroker.cpp:1401-1410). Here every element
-//     A. computes its geometry and its own vertex / index counts (data dependent only for Round
-//        joins / caps: numArcPoints, numPointsHalfCircle),
-//     B. gets its vertex / index base inside the mesh from a wave prefix scan segmented by mesh (with a
-//        carry across chunks) -- the "running counters" of the reference,
+//   One lane = one ELEMENT = one polyline vertex of one mesh: a polygon corner of a convex fill, or a cap /
+//   join of a polyline stroke. Fills and strokes run in two kernels (k_fill, k_stroke), each over its own flat
+//   element stream (exclusive scan of the polyline length over the meshes of that class); a wavefront owns a
+//   contiguous run of 64-element segments and therefore whole meshes, walks the prefix array cooperatively
+//   (vgx_wave.h) and finds every lane's mesh with six shuffles.
+//   The reference builds each mesh sequentially (running m_NumVertices / m_NumIndices and the prevSegment*ID
+//   bookkeeping, stroker.cpp:1401-1410). Here every element
+//     A. gets its neighbours' vertices and the previous segment's direction from the adjacent lanes (one vertex
+//        load and one vec2Dir per element) and computes its own vertex / index counts (data dependent only for
+//        Round joins / caps),
+//     B. gets its vertex / index base inside the mesh from a wave prefix scan segmented by mesh with a carry across
+//        chunks (strokes) or in closed form (fills),
 //     C. gets the previous element's exit rail IDs (prevSegment{LeftAA,Left,Right,RightAA}ID) from the
 //        neighbouring lane (shuffle, carry across chunks), and
-//     D. writes its vertices, colours and indices straight to their final place.
-//   Two passes (template<EMIT>): count (A+B, per-mesh totals) -> device-wide scan over meshes -> emit.
+//     D. writes its vertices, colours and uint16 indices straight to their final place.
+//   k_mesh_prepare (one lane per mesh) precomputes the per-mesh constants (half widths, fill orientation, colour)
+//   and sizes the meshes with Round joins -- every other mesh size is closed-form and was written by flatten-emit.
 //
-// Every emitted position / colour / index follows the cited reference lines; the rails formulation is
-// the one of SURVEY.md appendix B.
+// Every emitted position / colour / index follows the cited reference lines; the rails formulation is the one of
+// SURVEY.md appendix B.
 #include "vgx_internal.h"
 #include "vgx_wave.h"
 
@@ -30,12 +33,13 @@ __device__ __forceinline__ Rails rails(uint32_t a, uint32_t b, uint32_t c, uint3
 __device__ __forceinline__ uint64_t rails_pack(Rails r) { return (uint64_t)(r.a & 0xFFFFu) | ((uint64_t)(r.b & 0xFFFFu) << 16) | ((uint64_t)(r.c & 0xFFFFu) << 32) | ((uint64_t)(r.d & 0xFFFFu) << 48); }
 __device__ __forceinline__ Rails rails_unpack(uint64_t p) { return rails((uint32_t)(p & 0xFFFFu), (uint32_t)((p >> 16) & 0xFFFFu), (uint32_t)((p >> 32) & 0xFFFFu), (uint32_t)(p >> 48)); }
 
+// Direct writer: pointers to the mesh's first vertex / index in the output streams.
 template<bool EMIT>
 struct MeshWriter
 {
-	float* pos;       // mesh's first vertex
+	float* pos;
 	uint32_t* col;
-	uint16_t* idx;    // mesh's first index
+	uint16_t* idx;
 	uint32_t color, c0;
 	__device__ __forceinline__ void v(uint32_t i, V2 p, uint32_t c) const
 	{
@@ -70,12 +74,12 @@ struct MeshWriter
 	}
 };
 
-enum { ET_CAP_FIRST = 0, ET_JOIN = 1, ET_CAP_LAST = 2, ET_FILL = 3 };
+enum { ET_CAP_FIRST = 0, ET_JOIN = 1, ET_CAP_LAST = 2 };
 
-// Everything step A computes for one element and step D needs again.
+// Everything step A computes for one stroke element and step D needs again.
 struct Elem
 {
-	uint32_t nv, ni;  // my vertex / index count (ni excludes the connect / closing part handled below)
+	uint32_t nv, ni;  // my vertex / index count (ni excludes the connect / closing bridges)
 	uint32_t et;
 	V2 p1;            // the polyline vertex this element sits on
 	V2 d01, d12, v;   // join: segment directions + extrusion; caps: d01 = cap direction
@@ -90,9 +94,9 @@ struct MeshCtx
 {
 	uint32_t kind, N, j, cap, join;
 	bool closed;
-	float hsw, hswAA, fringe, da;
-	uint32_t color;
-	const float* vtx; // mesh's first polyline vertex
+	float hsw, hswAA, fringe;
+	const vgx_draw* dr; // scale / tolerance are only read where Round caps / joins need da
+	const float* vtx;   // mesh's first polyline vertex
 };
 
 __device__ __forceinline__ V2 ldv(const float* vtx, uint32_t i)
@@ -101,50 +105,36 @@ __device__ __forceinline__ V2 ldv(const float* vtx, uint32_t i)
 	return v2(t.x, t.y);
 }
 
-__device__ __forceinline__ MeshCtx make_mesh_ctx(const VgxMeshDesc& md, const vgx_draw* dr, uint32_t j, const float* poly)
+__device__ __forceinline__ float mesh_da(const MeshCtx& m) // stroker.cpp:1013, 1398 (da uses hsw WITHOUT the fringe)
+{
+	return vgx_step_angle(m.dr->scale, m.hsw, m.dr->tess_tol);
+}
+
+__device__ __forceinline__ MeshCtx make_mesh_ctx(const VgxMeshDesc& md, const VgxMeshPrep& pr, const vgx_draw* draws, uint32_t j, const float* poly)
 {
 	MeshCtx mc;
-	mc.kind = md.kind & 0xFFu;
-	mc.closed = (md.kind & 0x100u) != 0;
+	mc.kind = VGX_MD_KIND(md.kind);
+	mc.closed = VGX_MD_CLOSED(md.kind) != 0;
+	mc.cap = VGX_MD_CAP(md.kind);
+	mc.join = VGX_MD_JOIN(md.kind);
 	mc.N = md.poly_n;
 	mc.j = j;
 	mc.vtx = poly + 2 * md.poly_first;
-	mc.fringe = dr->fringe;
-	mc.cap = 0; mc.join = 0; mc.hsw = 0.0f; mc.hswAA = 0.0f; mc.da = 1.0f;
-	const bool isFill = mc.kind == VGX_MESH_FILL || mc.kind == VGX_MESH_FILL_AA;
-	mc.color = isFill ? dr->fill_color : dr->stroke_color;
-	if (!isFill) {
-		const VgxStrokeParams sp = vgx_stroke_params(mc.kind, mc.closed, dr->stroke_flags, dr->stroke_width, dr->fringe, dr->scale, dr->tess_tol);
-		mc.cap = sp.cap; mc.join = sp.join; mc.hsw = sp.hsw; mc.hswAA = sp.hswAA; mc.da = sp.da;
-	}
+	mc.hsw = pr.f0; mc.hswAA = pr.f1; mc.fringe = pr.f2;
+	mc.dr = draws + md.draw;
 	return mc;
 }
 
-// ---- step A ---------------------------------------------------------------------------------------
-__device__ __forceinline__ Elem elem_geometry(const MeshCtx& m)
+// ---- step A (strokes) --------------------------------------------------------------------------------
+// p1 = the element's polyline vertex, dPrev = vec2Dir(previous vertex, p1), d12 = vec2Dir(p1, next vertex) (cyclic).
+__device__ __forceinline__ Elem elem_geometry(const MeshCtx& m, V2 p1, V2 dPrev, V2 d12)
 {
 	Elem e;
-	e.nv = 0; e.ni = 0; e.et = ET_FILL; e.leftInner = true; e.hasConnect = false; e.closesLoop = false;
+	e.nv = 0; e.ni = 0; e.et = ET_JOIN; e.leftInner = true; e.hasConnect = false; e.closesLoop = false;
 	e.arc.a01 = 0.0f; e.arc.arcDa = 0.0f; e.arc.n = 1; e.H = 2;
 	const uint32_t N = m.N, j = m.j;
-	e.p1 = ldv(m.vtx, j);
+	e.p1 = p1;
 	e.d01 = v2(0.0f, 0.0f); e.d12 = e.d01; e.v = e.d01;
-
-	if (m.kind == VGX_MESH_FILL) { // strokerConvexFill, stroker.cpp:334-365
-		e.nv = 1;
-		e.ni = (j + 2 < N) ? 3 : 0;
-		return e;
-	}
-	const V2 pPrev = ldv(m.vtx, j == 0 ? N - 1 : j - 1);
-	const V2 pNext = ldv(m.vtx, j == N - 1 ? 0 : j + 1);
-	if (m.kind == VGX_MESH_FILL_AA) { // strokerConvexFillAA, stroker.cpp:713-807
-		e.d01 = v2dir(pPrev, e.p1);
-		e.d12 = v2dir(e.p1, pNext);
-		e.v = v2extrude(e.d01, e.d12);
-		e.nv = 2;
-		e.ni = ((j + 2 < N) ? 3 : 0) + 6;
-		return e;
-	}
 	// polyline strokes
 	const bool isCapFirst = !m.closed && j == 0;
 	const bool isCapLast = !m.closed && j == N - 1;
@@ -152,11 +142,11 @@ __device__ __forceinline__ Elem elem_geometry(const MeshCtx& m)
 	const uint32_t bridgeIdx = (railCount - 1) * 6; // 6 / 18 / 12
 	if (isCapFirst || isCapLast) {
 		e.et = isCapFirst ? ET_CAP_FIRST : ET_CAP_LAST;
-		e.d01 = isCapFirst ? v2dir(e.p1, pNext) : v2dir(pPrev, e.p1);
+		e.d01 = isCapFirst ? d12 : dPrev;
 		e.hasConnect = isCapLast;
 		const bool roundCap = (m.cap == VGX_CAP_ROUND) && m.kind != VGX_MESH_STROKE_AA_THIN;
 		if (roundCap) {
-			const uint32_t H = vgx_half_circle_points(m.da);
+			const uint32_t H = vgx_half_circle_points(mesh_da(m));
 			e.H = H;
 			if (m.kind == VGX_MESH_STROKE_AA) {
 				e.nv = 2 * H;
@@ -173,7 +163,7 @@ __device__ __forceinline__ Elem elem_geometry(const MeshCtx& m)
 	}
 	e.et = ET_JOIN;
 	const float sideWidth = (m.kind == VGX_MESH_STROKE) ? m.hsw : (m.kind == VGX_MESH_STROKE_AA ? m.hswAA : m.fringe);
-	const VgxJoin jn = vgx_join(pPrev, e.p1, pNext, sideWidth);
+	const VgxJoin jn = vgx_join_dirs(dPrev, d12, sideWidth);
 	e.d01 = jn.d01; e.d12 = jn.d12; e.v = jn.v; e.leftInner = jn.leftInner;
 	e.hasConnect = !(m.closed && j == 0);
 	e.closesLoop = m.closed && j == N - 1;
@@ -191,7 +181,7 @@ __device__ __forceinline__ Elem elem_geometry(const MeshCtx& m)
 	if (m.join == VGX_JOIN_ROUND) {
 		const V2 n01 = e.leftInner ? v2cw(e.d01) : v2ccw(e.d01);
 		const V2 n12 = e.leftInner ? v2cw(e.d12) : v2ccw(e.d12);
-		e.arc = vgx_round_join_arc(n01, n12, e.leftInner, m.da);
+		e.arc = vgx_round_join_arc(n01, n12, e.leftInner, mesh_da(m));
 	}
 	const uint32_t n = e.arc.n;
 	if (m.kind == VGX_MESH_STROKE_AA) {
@@ -207,9 +197,6 @@ __device__ __forceinline__ Elem elem_geometry(const MeshCtx& m)
 
 __device__ __forceinline__ uint32_t elem_total_indices(const MeshCtx& m, const Elem& e)
 {
-	if (m.kind == VGX_MESH_FILL || m.kind == VGX_MESH_FILL_AA) {
-		return e.ni;
-	}
 	const uint32_t bridgeIdx = (m.kind == VGX_MESH_STROKE) ? 6u : (m.kind == VGX_MESH_STROKE_AA ? 18u : 12u);
 	return e.ni + (e.hasConnect ? bridgeIdx : 0u) + (e.closesLoop ? bridgeIdx : 0u);
 }
@@ -257,40 +244,13 @@ __device__ __forceinline__ Rails first_join_entry(const MeshCtx& m, bool leftInn
 	return leftInner0 ? rails(0, 1, 2, 0) : rails(2, 1, 0, 0);
 }
 
-// ---- step D: emit one element ---------------------------------------------------------------------
+// ---- step D: emit one stroke element ------------------------------------------------------------------
 template<bool EMIT>
-__device__ void elem_emit(const MeshCtx& m, const Elem& e, uint32_t b, uint32_t k, Rails prev, const MeshWriter<EMIT>& w)
+__device__ __forceinline__ void elem_emit(const MeshCtx& m, const Elem& e, uint32_t b, uint32_t k, Rails prev, const MeshWriter<EMIT>& w)
 {
-	const uint32_t N = m.N, j = m.j;
+	const uint32_t N = m.N;
 	const uint32_t color = w.color, c0 = w.c0;
 	const V2 p1 = e.p1;
-
-	if (m.kind == VGX_MESH_FILL) {
-		w.v(j, p1, color);
-		if (j + 2 < N) { w.tri(3 * j, 0, j + 1, j + 2); }
-		return;
-	}
-	if (m.kind == VGX_MESH_FILL_AA) {
-		// orientation from the first triangle only (stroker.cpp:721-723)
-		const V2 q0 = ldv(m.vtx, 0), q1 = ldv(m.vtx, 1), q2 = ldv(m.vtx, 2);
-		const float orient = v2cross(v2sub(q1, q0), v2sub(q2, q0));
-		const float aa = m.fringe * 0.5f * vgm_sign(orient);
-		const V2 vaa = v2mul(e.v, aa);
-		w.v(2 * j, v2add(p1, vaa), color);
-		w.v(2 * j + 1, v2sub(p1, vaa), c0);
-		if (j + 2 < N) { w.tri(3 * j, 0, 2 * j + 2, 2 * j + 4); } // fan, :769-776
-		const uint32_t q = 3 * (N - 2) + 6 * j;
-		const uint32_t fb = 2 * j;
-		if (j + 1 < N) { // :779-787
-			w.tri(q, fb, fb + 1, fb + 3);
-			w.tri(q + 3, fb, fb + 3, fb + 2);
-		} else {         // :789-795
-			w.tri(q, fb, fb + 1, 1);
-			w.tri(q + 3, fb, 1, 0);
-		}
-		return;
-	}
-
 	const float hsw = m.hsw, hswAA = m.hswAA, fringe = m.fringe;
 
 	// ------------------------------- AA stroke, 4 rails -------------------------------------------
@@ -572,8 +532,214 @@ __device__ void elem_emit(const MeshCtx& m, const Elem& e, uint32_t b, uint32_t 
 	}
 }
 
+// ---- per-mesh preparation ------------------------------------------------------------------------------
+__device__ __forceinline__ VgxMeshPrep mesh_prep(const VgxMeshDesc& md, const vgx_draw* dr, const float* poly)
+{
+	VgxMeshPrep pr;
+	const uint32_t kind = VGX_MD_KIND(md.kind);
+	if (kind >= VGX_MESH_STROKE) {
+		const VgxStrokeParams sp = vgx_stroke_params(kind, VGX_MD_CLOSED(md.kind) != 0, dr->stroke_flags, dr->stroke_width, dr->fringe, dr->scale, dr->tess_tol);
+		pr.f0 = sp.hsw; pr.f1 = sp.hswAA; pr.f2 = dr->fringe;
+		pr.color = dr->stroke_color;
+	} else {
+		pr.f0 = 0.0f; pr.f1 = 0.0f; pr.f2 = dr->fringe;
+		if (kind == VGX_MESH_FILL_AA) {
+			// orientation from the first triangle only (stroker.cpp:721-723, "might not work in all cases")
+			const float* vtx = poly + 2 * md.poly_first;
+			const V2 q0 = ldv(vtx, 0), q1 = ldv(vtx, 1), q2 = ldv(vtx, 2);
+			const float orient = v2cross(v2sub(q1, q0), v2sub(q2, q0));
+			pr.f0 = dr->fringe * 0.5f * vgm_sign(orient);
+		}
+		pr.color = dr->fill_color;
+	}
+	return pr;
+}
+
+// One lane per mesh: per-mesh constants for the element kernels, and the sizes of meshes with Round joins (the only
+// data-dependent sizes; every other mesh was sized in closed form by flatten-emit).
+__global__ __launch_bounds__(256) void k_mesh_prepare(VgxStrokeArgs A)
+{
+	if (A.totals->status != VGX_OK) {
+		return;
+	}
+	const uint64_t numMeshes = A.totals->sizes.num_meshes;
+	const bool anyRound = A.totals->num_round_meshes != 0;
+	for (uint64_t mi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; mi < numMeshes; mi += (uint64_t)gridDim.x * blockDim.x) {
+		const VgxMeshDesc md = A.mdesc[mi];
+		const vgx_draw* dr = A.draws + md.draw;
+		const VgxMeshPrep pr = mesh_prep(md, dr, A.poly);
+		A.mprep[mi] = pr;
+		if (anyRound && A.mtab[mi].num_vertices == VGX_MESH_NEEDS_COUNT) {
+			uint32_t nv = 0, ni = 0;
+			const float* vtx = A.poly + 2 * md.poly_first;
+			const uint32_t N = md.poly_n;
+			V2 dPrev = v2dir(ldv(vtx, N - 1), ldv(vtx, 0));
+			for (uint32_t j = 0; j < N; ++j) {
+				const MeshCtx mc = make_mesh_ctx(md, pr, A.draws, j, A.poly);
+				const V2 p1 = ldv(vtx, j);
+				const V2 d12 = v2dir(p1, ldv(vtx, j == N - 1 ? 0 : j + 1));
+				const Elem e = elem_geometry(mc, p1, dPrev, d12);
+				nv += e.nv;
+				ni += elem_total_indices(mc, e);
+				dPrev = d12;
+			}
+			A.mtab[mi].num_vertices = nv;
+			A.mtab[mi].num_indices = ni;
+		}
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
-template<bool EMIT>
+// k_fill: strokerConvexFill / strokerConvexFillAA (stroker.cpp:334-365, 713-807)
+//   FILL_AA element j: vertices 2j (inner, colour c) and 2j+1 (outer, colour c0) and the 9 (last element: 3)
+//   index positions [9j, 9j+9) of the mesh, whose values are closed-form in (N, position).
+//   FILL element j: vertex j (= polyline vertex) and fan triangle (0, j+1, j+2).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_idx_run(uint16_t* dst, const uint32_t* val, uint32_t cnt)
+{
+	// cnt is 9 or 3; all stores naturally aligned: a leading or a trailing 16-bit store fixes the phase
+	uint32_t r = 0;
+	if (((uintptr_t)dst) & 2u) { dst[0] = (uint16_t)val[0]; r = 1; }
+	for (; r + 1 < cnt; r += 2) {
+		*(uint32_t*)(dst + r) = (val[r] & 0xFFFFu) | (val[r + 1] << 16);
+	}
+	if (r < cnt) { dst[r] = (uint16_t)val[r]; }
+}
+
+__global__ __launch_bounds__(VGX_WAVE) void k_fill(VgxStrokeArgs A)
+{
+	const int lane = threadIdx.x;
+	if (A.totals->status != VGX_OK) {
+		return;
+	}
+	const uint64_t numMeshes = A.totals->sizes.num_meshes;
+	const uint64_t totalElems = A.elem_prefix[numMeshes];
+	const uint64_t numSegments = (totalElems + VGX_WAVE - 1) / VGX_WAVE;
+	const uint64_t segsPerWave = (numSegments + gridDim.x - 1) / gridDim.x;
+	const uint64_t seg0 = (uint64_t)blockIdx.x * segsPerWave;
+	const uint64_t seg1 = (seg0 + segsPerWave < numSegments) ? seg0 + segsPerWave : numSegments;
+	if (seg0 >= seg1) {
+		return;
+	}
+	uint64_t mNext = lower_bound_u64(A.elem_prefix, 0, numMeshes, seg0 * VGX_WAVE);
+	for (uint64_t seg = seg0; seg < seg1; ++seg) {
+		const uint64_t m0 = mNext;
+		const uint64_t m1 = advance_lower_bound(A.elem_prefix, m0, numMeshes, (seg + 1) * VGX_WAVE, lane);
+		mNext = m1;
+		if (m0 == m1) {
+			continue;
+		}
+		const uint64_t E0 = A.elem_prefix[m0];
+		const uint64_t E1 = A.elem_prefix[m1];
+		uint64_t mcur = m0;
+		for (uint64_t chunk = E0; chunk < E1; chunk += VGX_WAVE) {
+			const uint64_t ei = chunk + lane;
+			const bool valid = ei < E1;
+			const uint64_t widx = mcur + (uint64_t)lane;
+			const uint64_t wv = (widx <= m1) ? A.elem_prefix[widx] : ~0ull;
+			const bool windowCovers = __shfl((unsigned long long)wv, VGX_WAVE - 1) > chunk + (VGX_WAVE - 1);
+			uint64_t ownerBase = 0;
+			const int ownerOfs = window_owner(wv, valid ? ei : chunk, &ownerBase);
+			uint64_t mi = m0;
+			uint32_t kind = VGX_MESH_FILL, N = 3, j = 0;
+			const float* vtx = A.poly;
+			VgxMeshPrep pr;
+			pr.f0 = 0.0f; pr.f1 = 0.0f; pr.f2 = 0.0f; pr.color = 0;
+			uint64_t firstV = 0, firstI = 0;
+			V2 p1 = v2(0.0f, 0.0f);
+			if (valid) {
+				if (windowCovers) {
+					mi = mcur + (uint64_t)ownerOfs;
+				} else { // the window is full of zero-length (stroke) entries: rare, fall back to a search
+					mi = find_owner_u64(A.elem_prefix, m0, m1, ei);
+					ownerBase = A.elem_prefix[mi];
+				}
+				const VgxMeshDesc md = A.mdesc[mi];
+				pr = A.mprep[mi];
+				firstV = A.mtab[mi].first_vertex;
+				firstI = A.mtab[mi].first_index;
+				kind = VGX_MD_KIND(md.kind);
+				N = md.poly_n;
+				j = (uint32_t)(ei - ownerBase);
+				vtx = A.poly + 2 * md.poly_first;
+				p1 = ldv(vtx, j);
+			}
+			const bool aaElem = valid && kind == VGX_MESH_FILL_AA;
+			// neighbours from the adjacent lanes (same mesh); only lanes at a mesh / chunk edge load or recompute
+			const bool prevInWave = lane > 0 && j > 0;
+			const bool nextInWave = lane < VGX_WAVE - 1 && j + 1 < N && ei + 1 < E1;
+			V2 pNext;
+			pNext.x = __shfl_down(p1.x, 1); pNext.y = __shfl_down(p1.y, 1);
+			if (aaElem && !nextInWave) { pNext = ldv(vtx, j + 1 < N ? j + 1 : 0); }
+			V2 d12 = v2(0.0f, 0.0f);
+			if (aaElem) { d12 = v2dir(p1, pNext); }
+			V2 dPrev;
+			dPrev.x = __shfl_up(d12.x, 1); dPrev.y = __shfl_up(d12.y, 1);
+			if (aaElem && !prevInWave) { dPrev = v2dir(ldv(vtx, j > 0 ? j - 1 : N - 1), p1); }
+
+			if (valid) {
+				const uint32_t color = pr.color;
+				if (kind == VGX_MESH_FILL_AA) {
+					const V2 vaa = v2mul(v2extrude(dPrev, d12), pr.f0);
+					const V2 vin = v2add(p1, vaa), vout = v2sub(p1, vaa);
+					const uint64_t gv = firstV + 2 * (uint64_t)j;
+					float* pp = A.pos + 2 * gv;
+					uint32_t* pc = A.color + gv;
+					if ((gv & 1ull) == 0) { // 16-byte aligned pair
+						*(float4*)pp = make_float4(vin.x, vin.y, vout.x, vout.y);
+						*(uint2*)pc = make_uint2(color, color & 0x00FFFFFFu);
+					} else {
+						*(float2*)pp = make_float2(vin.x, vin.y);
+						*(float2*)(pp + 2) = make_float2(vout.x, vout.y);
+						pc[0] = color; pc[1] = color & 0x00FFFFFFu;
+					}
+					// indices: k = 9j is a multiple of 3 and so is the fan size F = 3(N-2): position k+r is fan corner
+					// (r%3) of triangle 3j + r/3 while k+r < F, else fringe position q = k+r-F = 3u+r with
+					// u = 3j-(N-2) >= -2. With U = u+2 = 2a+b: q = 6(a-1) + (3b+r), i.e. quad a-1+[3b+r >= 6],
+					// corner (3b+r) mod 6 -- no division (fan stroker.cpp:769-776, fringe :779-795).
+					const uint32_t cnt = (j + 1 < N) ? 9u : 3u;
+					const uint32_t k = 9 * j;
+					const uint32_t fan = 3 * (N - 2);
+					const int U = 3 * (int)j - (int)N + 4;
+					const uint32_t Ua = (uint32_t)(U > 0 ? U : 0) >> 1, Ub = (uint32_t)(U > 0 ? U : 0) & 1u;
+					uint32_t val[9];
+#pragma unroll
+					for (uint32_t r = 0; r < 9; ++r) {
+						const uint32_t t = 3 * j + r / 3, c3 = r % 3;
+						const uint32_t fanVal = (c3 == 0) ? 0u : (2 * t + 2 * c3);
+						const uint32_t q6 = r + 3 * Ub;
+						const uint32_t ed = Ua - 1u + (q6 >= 6 ? 1u : 0u); // wraps for fan positions, whose frVal is unused
+						const uint32_t c = q6 - (q6 >= 6 ? 6u : 0u);
+						const uint32_t fb = 2 * ed;
+						const bool lastEdge = ed + 1 == N;
+						const uint32_t nextInner = lastEdge ? 0u : fb + 2, nextOuter = lastEdge ? 1u : fb + 3;
+						const uint32_t frVal = (c == 0 || c == 3) ? fb : (c == 1 ? fb + 1 : (c == 5 ? nextInner : nextOuter));
+						val[r] = (k + r < fan) ? fanVal : frVal;
+					}
+					uint16_t* pi = A.idx + firstI + k;
+					if (cnt == 9) { store_idx_run(pi, val, 9); } else { store_idx_run(pi, val, 3); }
+				} else {
+					const uint64_t gv = firstV + j;
+					*(float2*)(A.pos + 2 * gv) = make_float2(p1.x, p1.y);
+					A.color[gv] = color;
+					if (j + 2 < N) {
+						uint16_t* pi = A.idx + firstI + 3 * j;
+						pi[0] = 0; pi[1] = (uint16_t)(j + 1); pi[2] = (uint16_t)(j + 2);
+					}
+				}
+				if (j == N - 1 && A.meshes_out) {
+					A.meshes_out[mi] = A.mtab[mi];
+				}
+			}
+			const int nvalid = (int)((E1 - chunk) < (uint64_t)VGX_WAVE ? (E1 - chunk) : (uint64_t)VGX_WAVE);
+			mcur = __shfl((unsigned long long)mi, nvalid - 1);
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_stroke: strokerPolylineStroke / StrokeAA / StrokeAAThin (stroker.cpp:1008-2314)
+// ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(VGX_WAVE) void k_stroke(VgxStrokeArgs A)
 {
 	const int lane = threadIdx.x;
@@ -583,10 +749,17 @@ __global__ __launch_bounds__(VGX_WAVE) void k_stroke(VgxStrokeArgs A)
 	const uint64_t numMeshes = A.totals->sizes.num_meshes;
 	const uint64_t totalElems = A.elem_prefix[numMeshes];
 	const uint64_t numSegments = (totalElems + VGX_WAVE - 1) / VGX_WAVE;
-
-	for (uint64_t seg = blockIdx.x; seg < numSegments; seg += gridDim.x) {
-		const uint64_t m0 = lower_bound_u64(A.elem_prefix, 0, numMeshes, seg * VGX_WAVE);
-		const uint64_t m1 = lower_bound_u64(A.elem_prefix, m0, numMeshes, (seg + 1) * VGX_WAVE);
+	const uint64_t segsPerWave = (numSegments + gridDim.x - 1) / gridDim.x;
+	const uint64_t seg0 = (uint64_t)blockIdx.x * segsPerWave;
+	const uint64_t seg1 = (seg0 + segsPerWave < numSegments) ? seg0 + segsPerWave : numSegments;
+	if (seg0 >= seg1) {
+		return;
+	}
+	uint64_t mNext = lower_bound_u64(A.elem_prefix, 0, numMeshes, seg0 * VGX_WAVE);
+	for (uint64_t seg = seg0; seg < seg1; ++seg) {
+		const uint64_t m0 = mNext;
+		const uint64_t m1 = advance_lower_bound(A.elem_prefix, m0, numMeshes, (seg + 1) * VGX_WAVE, lane);
+		mNext = m1;
 		if (m0 == m1) {
 			continue;
 		}
@@ -594,27 +767,56 @@ __global__ __launch_bounds__(VGX_WAVE) void k_stroke(VgxStrokeArgs A)
 		const uint64_t E1 = A.elem_prefix[m1];
 		uint32_t carryV = 0, carryI = 0;
 		uint64_t carryRails = 0;
+		uint64_t mcur = m0; // mesh that owns the chunk's first element
 
 		for (uint64_t chunk = E0; chunk < E1; chunk += VGX_WAVE) {
 			const uint64_t ei = chunk + lane;
 			const bool valid = ei < E1;
-			MeshCtx mc;
-			mc.kind = VGX_MESH_FILL; mc.N = 3; mc.j = 0; mc.cap = 0; mc.join = 0; mc.closed = false;
-			mc.hsw = 0.0f; mc.hswAA = 0.0f; mc.fringe = 1.0f; mc.da = 1.0f; mc.color = 0; mc.vtx = A.poly;
+			const uint64_t widx = mcur + (uint64_t)lane;
+			const uint64_t wv = (widx <= m1) ? A.elem_prefix[widx] : ~0ull;
+			const bool windowCovers = __shfl((unsigned long long)wv, VGX_WAVE - 1) > chunk + (VGX_WAVE - 1);
+			uint64_t ownerBase = 0;
+			const int ownerOfs = window_owner(wv, valid ? ei : chunk, &ownerBase);
 			uint64_t mi = m0;
+			MeshCtx mc;
+			mc.kind = VGX_MESH_STROKE_AA; mc.N = 2; mc.j = 0; mc.cap = 0; mc.join = 0; mc.closed = false;
+			mc.hsw = 0.0f; mc.hswAA = 0.0f; mc.fringe = 1.0f; mc.dr = A.draws; mc.vtx = A.poly;
+			uint32_t color = 0;
+			if (valid) {
+				if (windowCovers) {
+					mi = mcur + (uint64_t)ownerOfs;
+				} else { // the window is full of zero-length (fill) entries: rare, fall back to a search
+					mi = find_owner_u64(A.elem_prefix, m0, m1, ei);
+					ownerBase = A.elem_prefix[mi];
+				}
+				const VgxMeshDesc md = A.mdesc[mi];
+				const VgxMeshPrep pr = A.mprep[mi];
+				mc = make_mesh_ctx(md, pr, A.draws, (uint32_t)(ei - ownerBase), A.poly);
+				color = pr.color;
+			}
+			// step A: one vertex load and one vec2Dir per element; neighbours come from the adjacent lanes
+			V2 p1 = v2(0.0f, 0.0f);
+			if (valid) { p1 = ldv(mc.vtx, mc.j); }
+			const bool prevInWave = lane > 0 && mc.j > 0;
+			const bool nextInWave = lane < VGX_WAVE - 1 && mc.j + 1 < mc.N && ei + 1 < E1;
+			V2 pNext;
+			pNext.x = __shfl_down(p1.x, 1); pNext.y = __shfl_down(p1.y, 1);
+			if (valid && !nextInWave) { pNext = ldv(mc.vtx, mc.j + 1 < mc.N ? mc.j + 1 : 0); }
+			V2 d12 = v2(0.0f, 0.0f);
+			if (valid) { d12 = v2dir(p1, pNext); }
+			V2 dPrev;
+			dPrev.x = __shfl_up(d12.x, 1); dPrev.y = __shfl_up(d12.y, 1);
+			if (valid && !prevInWave) { dPrev = v2dir(ldv(mc.vtx, mc.j > 0 ? mc.j - 1 : mc.N - 1), p1); }
 			Elem e;
-			e.nv = 0; e.ni = 0; e.et = ET_FILL; e.leftInner = true; e.hasConnect = false; e.closesLoop = false;
-			e.arc.a01 = 0.0f; e.arc.arcDa = 0.0f; e.arc.n = 1; e.H = 2; e.p1 = v2(0.0f, 0.0f); e.d01 = e.p1; e.d12 = e.p1; e.v = e.p1;
+			e.nv = 0; e.ni = 0; e.et = ET_JOIN; e.leftInner = true; e.hasConnect = false; e.closesLoop = false;
+			e.arc.a01 = 0.0f; e.arc.arcDa = 0.0f; e.arc.n = 1; e.H = 2; e.p1 = p1; e.d01 = dPrev; e.d12 = d12; e.v = d12;
 			uint32_t totalIdx = 0;
 			if (valid) {
-				mi = find_owner_u64(A.elem_prefix, m0, m1, ei);
-				const VgxMeshDesc md = A.mdesc[mi];
-				mc = make_mesh_ctx(md, A.draws + md.draw, (uint32_t)(ei - A.elem_prefix[mi]), A.poly);
-				e = elem_geometry(mc);
+				e = elem_geometry(mc, p1, dPrev, d12);
 				totalIdx = elem_total_indices(mc, e);
 			}
 
-			// ---- step B: running vertex / index counters of the mesh (segmented wave scan) -----------
+			// step B: running vertex / index counters of the mesh (segmented wave scan)
 			const uint64_t heads = wave_ballot(valid && mc.j == 0);
 			const int mh = seg_head(heads, lane);
 			const uint32_t inclV = wave_incl_scan_u32(e.nv, lane);
@@ -624,41 +826,27 @@ __global__ __launch_bounds__(VGX_WAVE) void k_stroke(VgxStrokeArgs A)
 			const uint32_t vbase = mh < 0 ? carryV + exV : exV - hV;
 			const uint32_t ibase = mh < 0 ? carryI + exI : exI - hI;
 
-			// ---- step C: previous element's exit rails -------------------------------------------
-			const bool isStroke = mc.kind >= VGX_MESH_STROKE;
-			const uint64_t myExit = (valid && isStroke) ? rails_pack(elem_exit_rails(mc, e, vbase)) : 0ull;
+			// step C: previous element's exit rails
+			const uint64_t myExit = valid ? rails_pack(elem_exit_rails(mc, e, vbase)) : 0ull;
 			uint64_t prevPacked = __shfl_up((unsigned long long)myExit, 1);
 			if (lane == 0) { prevPacked = carryRails; }
 
 			const bool meshLast = valid && (mc.j == mc.N - 1);
-			if (!EMIT) {
-				if (meshLast) {
-					const bool isFill = !isStroke;
-					const uint32_t nv = isFill ? (mc.kind == VGX_MESH_FILL_AA ? 2 * mc.N : mc.N) : vbase + e.nv;
-					const uint32_t ni = isFill ? (mc.kind == VGX_MESH_FILL_AA ? 9 * mc.N - 6 : 3 * (mc.N - 2)) : ibase + totalIdx;
-					const VgxMeshDesc md = A.mdesc[mi];
-					vgx_mesh r;
-					r.first_vertex = 0; r.first_index = 0;
-					r.num_vertices = nv; r.num_indices = ni;
-					r.draw = md.draw;
-					r.subpath_kind = (md.subpath & 0x0FFFFFFFu) | ((md.kind & 0xFu) << 28);
-					A.mtab[mi] = r;
-				}
-			} else if (valid) {
+			if (valid) {
 				const vgx_mesh mr = A.mtab[mi];
 				MeshWriter<true> w;
 				w.pos = A.pos + 2 * mr.first_vertex;
 				w.col = A.color + mr.first_vertex;
 				w.idx = A.idx + mr.first_index;
-				w.color = mc.color;
-				w.c0 = mc.color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
+				w.color = color;
+				w.c0 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
 				elem_emit<true>(mc, e, vbase, ibase, rails_unpack(prevPacked), w);
 				if (meshLast && A.meshes_out) {
 					A.meshes_out[mi] = mr;
 				}
 			}
 
-			// ---- carries (from the last valid lane) ------------------------------------------------
+			// carries (from the last valid lane)
 			const int nvalid = (int)((E1 - chunk) < (uint64_t)VGX_WAVE ? (E1 - chunk) : (uint64_t)VGX_WAVE);
 			const int Lz = nvalid - 1;
 			const int lastIsMeshLast = __shfl((int)meshLast, Lz);
@@ -668,45 +856,25 @@ __global__ __launch_bounds__(VGX_WAVE) void k_stroke(VgxStrokeArgs A)
 			carryV = lastIsMeshLast ? 0u : endV;
 			carryI = lastIsMeshLast ? 0u : endI;
 			carryRails = lastIsMeshLast ? 0ull : endRails;
+			mcur = __shfl((unsigned long long)mi, Lz);
 		}
-	}
-}
-
-// Sizes of meshes with Round joins (the only data-dependent sizes): one lane walks one mesh's joins and sums
-// the per-element counts of step A. Exits immediately when the batch has no such mesh.
-__global__ __launch_bounds__(256) void k_mesh_round_count(VgxStrokeArgs A)
-{
-	if (A.totals->status != VGX_OK || A.totals->num_round_meshes == 0) {
-		return;
-	}
-	const uint64_t numMeshes = A.totals->sizes.num_meshes;
-	for (uint64_t mi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; mi < numMeshes; mi += (uint64_t)gridDim.x * blockDim.x) {
-		if (A.mtab[mi].num_vertices != VGX_MESH_NEEDS_COUNT) {
-			continue;
-		}
-		const VgxMeshDesc md = A.mdesc[mi];
-		const vgx_draw* dr = A.draws + md.draw;
-		uint32_t nv = 0, ni = 0;
-		for (uint32_t j = 0; j < md.poly_n; ++j) {
-			const MeshCtx mc = make_mesh_ctx(md, dr, j, A.poly);
-			const Elem e = elem_geometry(mc);
-			nv += e.nv;
-			ni += elem_total_indices(mc, e);
-		}
-		A.mtab[mi].num_vertices = nv;
-		A.mtab[mi].num_indices = ni;
 	}
 }
 
 } // namespace
 
-void vgx_launch_round_count(const VgxStrokeArgs& a, hipStream_t s)
+void vgx_launch_mesh_prepare(const VgxStrokeArgs& a, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_mesh_round_count, dim3(2048), dim3(256), 0, s, a);
+	hipLaunchKernelGGL(k_mesh_prepare, dim3(2048), dim3(256), 0, s, a);
+}
+
+void vgx_launch_fill(const VgxStrokeArgs& a, int numBlocks, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_fill, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
 }
 
 void vgx_launch_stroke(bool emit, const VgxStrokeArgs& a, int numBlocks, hipStream_t s)
 {
-	(void)emit; // sizes come from flatten-emit (closed form) and k_mesh_round_count; only the emit pass remains
-	hipLaunchKernelGGL(k_stroke<true>, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
+	(void)emit; // sizes come from flatten-emit (closed form) and k_mesh_prepare; only the emit pass exists
+	hipLaunchKernelGGL(k_stroke, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
 }

@@ -79,4 +79,39 @@ __device__ __forceinline__ uint64_t find_owner_u64(const uint64_t* a, uint64_t l
 	return lo;
 }
 
+// ---- walking a sorted uint64 prefix array without per-segment binary searches ----------------------------
+// A wave processes a CONTIGUOUS run of 64-item segments, so the owner range of segment s+1 starts where the
+// range of segment s ended. advance_lower_bound moves forward with one coalesced 64-entry load per step.
+
+// First index i in [start, n) with P[i] >= key, or n when there is none (P has n+1 sorted entries and P[n]
+// is the grand total). Wave-uniform result.
+__device__ __forceinline__ uint64_t advance_lower_bound(const uint64_t* P, uint64_t start, uint64_t n, uint64_t key, int lane)
+{
+	uint64_t m = start;
+	for (;;) {
+		const uint64_t idx = m + (uint64_t)lane;
+		const uint64_t v = (idx < n) ? P[idx] : ~0ull;
+		const int cnt = __popcll(wave_ballot(v < key)); // sorted: the lanes below the key form a prefix
+		m += (uint64_t)cnt;
+		if (cnt < VGX_WAVE) { return m; }
+	}
+}
+
+// 64-entry window of the prefix array held one entry per lane: w = P[first + lane] (or ~0 past `last`).
+// window_owner returns the offset k (0..63) of the LAST window entry <= key (requires W[0] <= key); *pv gets
+// that entry. Six shuffle steps, no memory traffic.
+__device__ __forceinline__ int window_owner(uint64_t w, uint64_t key, uint64_t* pv)
+{
+	int lo = 0;
+	uint64_t vlo = __shfl((unsigned long long)w, 0);
+#pragma unroll
+	for (int step = 32; step >= 1; step >>= 1) {
+		const int cand = lo + step;
+		const uint64_t v = __shfl((unsigned long long)w, cand & 63);
+		if (cand < VGX_WAVE && v <= key) { lo = cand; vlo = v; }
+	}
+	*pv = vlo;
+	return lo;
+}
+
 #endif

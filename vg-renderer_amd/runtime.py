@@ -11,7 +11,7 @@ import numpy as np
 from . import capi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvgx.so")
+LIB_PATH = os.environ.get("VGX_LIB", os.path.join(_HERE, "libvgx.so"))  # VGX_LIB: tuning experiments only
 _lib = None
 
 

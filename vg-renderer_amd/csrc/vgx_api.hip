@@ -489,7 +489,7 @@ static int vgx_pathset_validate_host(const vgx_pathset_desc* d, std::vector<uint
 			if (starts) { head = c; }
 			(*spStart)[c] = head;
 			if (starts) { (*cmdFlags)[c] |= VGX_CF_STARTS_SUB; }
-			if (t == VGX_CMD_ARC || t == VGX_CMD_ARC_TO) { (*pathFlags)[p] |= VGX_PF_SERIAL; }
+			if (t == VGX_CMD_ARC || t == VGX_CMD_ARC_TO || isShape) { (*pathFlags)[p] |= VGX_PF_SERIAL; }
 			open = !(t == VGX_CMD_CLOSE || isShape);
 		}
 		for (uint32_t c = c0; c < c1; ++c) {
@@ -538,7 +538,8 @@ int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset**
 	const size_t oType = align(oPathBegin + (npaths + 1) * sizeof(uint32_t));
 	const size_t oFlags = align(oType + ncmd + 1);
 	const size_t oPathFlags = align(oFlags + ncmd + 1);
-	const size_t total = align(oPathFlags + npaths + 1);
+	const size_t oRec = align(oPathFlags + npaths + 1);
+	const size_t total = align(oRec + (size_t)(ncmd + 1) * sizeof(VgxCmdRec));
 	std::vector<uint8_t> host(total, 0);
 	if (nargs) { memcpy(&host[oArgs + 2 * sizeof(float)], desc->args, nargs * sizeof(float)); }
 	memcpy(&host[oArgOff], desc->cmd_arg_off, (ncmd + 1) * sizeof(uint32_t));
@@ -549,6 +550,25 @@ int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset**
 	}
 	memcpy(&host[oPathBegin], desc->path_cmd_begin, (npaths + 1) * sizeof(uint32_t));
 	if (npaths) { memcpy(&host[oPathFlags], pathFlags.data(), npaths); }
+	{
+		VgxCmdRec* rec = (VgxCmdRec*)&host[oRec];
+		for (uint32_t c = 0; c < ncmd; ++c) {
+			VgxCmdRec& r = rec[c];
+			const uint32_t ao = desc->cmd_arg_off[c];
+			r.type = desc->cmd_type[c];
+			r.flags = cmdFlags[c];
+			r.na = desc->cmd_arg_off[c + 1] - ao;
+			r.arg_off = ao;
+			r.start[0] = ao >= 2 ? desc->args[ao - 2] : 0.0f;
+			r.start[1] = ao >= 2 ? desc->args[ao - 1] : 0.0f;
+			for (uint32_t i = 0; i < 8; ++i) { r.a[i] = (i < r.na && r.type != VGX_CMD_POLYLINE) ? desc->args[ao + i] : 0.0f; }
+			if (r.type == VGX_CMD_CLOSE) {
+				const uint32_t ho = desc->cmd_arg_off[spStart[c]];
+				r.a[6] = desc->args[ho]; r.a[7] = desc->args[ho + 1];
+			}
+			r.pad[0] = 0.0f; r.pad[1] = 0.0f;
+		}
+	}
 
 	vgx_pathset* ps = new (std::nothrow) vgx_pathset();
 	if (!ps) {
@@ -573,6 +593,7 @@ int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset**
 	ps->dev.cmd_type = b + oType;
 	ps->dev.cmd_flags = b + oFlags;
 	ps->dev.path_flags = b + oPathFlags;
+	ps->dev.cmdrec = (const VgxCmdRec*)(b + oRec);
 	ps->dev.npaths = npaths;
 	ps->dev.ncmd = ncmd;
 	*out_ps = ps;

@@ -28,22 +28,36 @@
 
 namespace {
 
-// ---- pending stack of the cubic DFS in LDS: [level][3 points][64 lanes] float2 ---------------------
+// ---- pending stack of the cubic DFS: the first VGX_LDS_LEVELS levels in LDS as [level][3 points][64 lanes]
+// float2 (lane-interleaved -> conflict free for any mix of levels), deeper levels (only very fine subdivisions
+// reach them) in per-lane private memory. Fewer LDS bytes per wave = more resident waves to hide latency.
+#define VGX_LDS_LEVELS 6
 struct LdsStack
 {
 	float2* base; // &s_stack[lane]
+	float deep[(VGX_CUBIC_MAX_PENDING - VGX_LDS_LEVELS) * 6];
 	__device__ __forceinline__ void push(int level, float ax, float ay, float bx, float by, float cx, float cy)
 	{
-		float2* p = base + level * 3 * VGX_WAVE;
-		p[0] = make_float2(ax, ay);
-		p[VGX_WAVE] = make_float2(bx, by);
-		p[2 * VGX_WAVE] = make_float2(cx, cy);
+		if (level < VGX_LDS_LEVELS) {
+			float2* p = base + level * 3 * VGX_WAVE;
+			p[0] = make_float2(ax, ay);
+			p[VGX_WAVE] = make_float2(bx, by);
+			p[2 * VGX_WAVE] = make_float2(cx, cy);
+		} else {
+			float* p = deep + (level - VGX_LDS_LEVELS) * 6;
+			p[0] = ax; p[1] = ay; p[2] = bx; p[3] = by; p[4] = cx; p[5] = cy;
+		}
 	}
 	__device__ __forceinline__ void pop(int level, float& ax, float& ay, float& bx, float& by, float& cx, float& cy)
 	{
-		const float2* p = base + level * 3 * VGX_WAVE;
-		const float2 a = p[0], b = p[VGX_WAVE], c = p[2 * VGX_WAVE];
-		ax = a.x; ay = a.y; bx = b.x; by = b.y; cx = c.x; cy = c.y;
+		if (level < VGX_LDS_LEVELS) {
+			const float2* p = base + level * 3 * VGX_WAVE;
+			const float2 a = p[0], b = p[VGX_WAVE], c = p[2 * VGX_WAVE];
+			ax = a.x; ay = a.y; bx = b.x; by = b.y; cx = c.x; cy = c.y;
+		} else {
+			const float* p = deep + (level - VGX_LDS_LEVELS) * 6;
+			ax = p[0]; ay = p[1]; bx = p[2]; by = p[3]; cx = p[4]; cy = p[5];
+		}
 	}
 };
 
@@ -75,11 +89,34 @@ struct FastCubicSink
 
 __device__ __forceinline__ bool is_shape_cmd(uint32_t t) { return t >= VGX_CMD_RECT && t <= VGX_CMD_ELLIPSE; }
 
+// Per-draw record held one per lane for a window of 64 consecutive draws (refilled when the walk leaves it): the
+// command lanes get their draw's command base with a shuffle instead of a chain of dependent global loads.
+struct DrawWindow
+{
+	uint64_t prefix; // cmd_prefix[wbase + lane] (or ~0 past the end)
+	uint32_t pc0;    // first command of the draw's path
+	uint32_t serial; // path must take the serial lane path (ARC / ARC_TO)
+};
+
+__device__ __forceinline__ DrawWindow draw_window_load(const VgxFlattenArgs& A, uint64_t wbase, int lane)
+{
+	DrawWindow w;
+	const uint64_t idx = wbase + (uint64_t)lane;
+	w.prefix = (idx <= A.ndraws) ? A.cmd_prefix[idx] : ~0ull;
+	w.pc0 = 0; w.serial = 0;
+	if (idx < A.ndraws) {
+		const uint32_t path = A.draws[idx].path;
+		w.pc0 = A.ps.path_cmd_begin[path];
+		w.serial = A.ps.path_flags[path] & VGX_PF_SERIAL;
+	}
+	return w;
+}
+
 // ------------------------------------------------------------------------------------------------
 template<bool EMIT, bool XFORM>
 __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 {
-	__shared__ float2 s_stack[VGX_CUBIC_MAX_PENDING * 3 * VGX_WAVE];
+	__shared__ float2 s_stack[VGX_LDS_LEVELS * 3 * VGX_WAVE];
 	const int lane = threadIdx.x;
 	LdsStack stack;
 	stack.base = &s_stack[lane];
@@ -96,6 +133,8 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 		return;
 	}
 	uint64_t dNext = lower_bound_u64(A.cmd_prefix, 0, A.ndraws, seg0 * VGX_WAVE);
+	uint64_t wbase = dNext;
+	DrawWindow W = draw_window_load(A, wbase, lane);
 
 	for (uint64_t seg = seg0; seg < seg1; ++seg) {
 		const uint64_t d0 = dNext;
@@ -119,42 +158,52 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 			// ---- decode my command instance ------------------------------------------------------
 			uint64_t d = d0;
 			uint32_t c = 0, type = VGX_CMD_CLOSE, cflags = 0, na = 0;
-			const float* a = ps.args;
 			bool drawHead = false, drawLast = false, serialDraw = false;
 			float scale = 1.0f, tol = 0.25f;
 			uint32_t fillFlags = 0, strokeFlags = 0;
 			const vgx_draw* dr = A.draws;
-			// owner draw of every lane from a 64-entry window of cmd_prefix (no global binary search)
-			const uint64_t widx = dcur + (uint64_t)lane;
-			const uint64_t wv = (widx <= d1) ? A.cmd_prefix[widx] : ~0ull;
-			const bool windowCovers = __shfl((unsigned long long)wv, VGX_WAVE - 1) > chunk + (VGX_WAVE - 1);
+			// owner draw of every lane from the lane-resident draw window (no global binary search)
+			const uint64_t lastKey = chunk + (VGX_WAVE - 1);
+			if (!(__shfl((unsigned long long)W.prefix, VGX_WAVE - 1) > lastKey)) {
+				wbase = dcur;
+				W = draw_window_load(A, wbase, lane);
+			}
+			const bool windowCovers = __shfl((unsigned long long)W.prefix, VGX_WAVE - 1) > lastKey;
 			uint64_t ownerBase = 0;
-			const int ownerOfs = window_owner(wv, valid ? ci : chunk, &ownerBase);
+			const int ownerOfs = window_owner(W.prefix, valid ? ci : chunk, &ownerBase);
+			uint32_t pc0 = (uint32_t)__shfl((int)W.pc0, ownerOfs);
+			uint32_t serialStatic = (uint32_t)__shfl((int)W.serial, ownerOfs);
+			VgxCmdRec rec;
+			rec.type = VGX_CMD_CLOSE; rec.flags = 0; rec.na = 0; rec.arg_off = 0;
+			rec.start[0] = 0.0f; rec.start[1] = 0.0f;
+			for (int i = 0; i < 8; ++i) { rec.a[i] = 0.0f; }
 			if (valid) {
 				if (windowCovers) {
-					d = dcur + (uint64_t)ownerOfs;
+					d = wbase + (uint64_t)ownerOfs;
 				} else { // more than 63 draws begin inside this chunk (1-command or empty paths)
 					d = find_owner_u64(A.cmd_prefix, d0, d1, ci);
 					ownerBase = A.cmd_prefix[d];
+					const uint32_t path = A.draws[d].path;
+					pc0 = ps.path_cmd_begin[path];
+					serialStatic = ps.path_flags[path] & VGX_PF_SERIAL;
 				}
 				dr = A.draws + d;
-				const uint32_t path = dr->path;
-				const uint32_t pc0 = ps.path_cmd_begin[path];
 				const uint32_t k = (uint32_t)(ci - ownerBase);
 				c = pc0 + k;
-				type = ps.cmd_type[c];
-				cflags = ps.cmd_flags[c];
-				const uint32_t ao = ps.cmd_arg_off[c];
-				na = ps.cmd_arg_off[c + 1] - ao;
-				a = ps.args + ao;
+				rec = ps.cmdrec[c]; // one 64-byte record: type, flags, start point, arguments, sub-path first point
+				type = rec.type;
+				cflags = rec.flags;
+				na = rec.na;
 				drawHead = (k == 0);
 				drawLast = (cflags & VGX_CF_LAST_IN_PATH) != 0;
 				scale = dr->scale;
 				tol = dr->tess_tol;
 				fillFlags = dr->fill_flags;
 				strokeFlags = dr->stroke_flags;
-				serialDraw = EMIT ? ((A.dinfo[d].flags & 1u) != 0) : ((ps.path_flags[path] & VGX_PF_SERIAL) != 0);
+				serialDraw = EMIT ? ((A.dinfo[d].flags & 1u) != 0) : (serialStatic != 0);
 			}
+			const float* a = rec.a;                 // arguments 0..7 (CLOSE: a[6..7] = its sub-path's first point)
+			const float* pa = ps.args + rec.arg_off; // POLYLINE's variable-length arguments
 			const float* mtx = dr->mtx;
 
 			// ---- per-lane vertex count (count pass: compute; emit pass: read back) -----------------
@@ -162,7 +211,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 			bool slow = false, exists = false, closedHere = false, pop = false;
 			if (valid && !serialDraw) {
 				if (!EMIT) {
-					const V2 start = v2(a[-2], a[-1]); // previous command's end point (unused by sub-path starters)
+					const V2 start = v2(rec.start[0], rec.start[1]); // previous command's end point (unused by sub-path starters)
 					switch (type) {
 					case VGX_CMD_MOVE_TO: cnt = 1; exists = true; break;
 					case VGX_CMD_LINE_TO: cnt = 1; slow = v2near(start, v2(a[0], a[1])); break;
@@ -183,19 +232,11 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 					} break;
 					case VGX_CMD_POLYLINE: {
 						const uint32_t npts = na >> 1;
-						cnt = (int)npts - ((npts > 0 && v2near(start, v2(a[0], a[1]))) ? 1 : 0);
+						cnt = (int)npts - ((npts > 0 && v2near(start, v2(pa[0], pa[1]))) ? 1 : 0);
+						slow = cnt == 0; // a fully de-duplicated polyline leaves the last vertex unchanged: not its nominal end point
 					} break;
 					case VGX_CMD_CLOSE: break; // decided below, needs the sub-path's vertex count
-					default: { // closed shape: exact builder for this one command
-						PathSim<false, false> sim;
-						sim.scale = scale; sim.tol = tol; sim.mtx = nullptr; sim.poly = nullptr; sim.polyBase = 0; sim.subs = nullptr; sim.subBase = 0;
-						sim.mdesc = nullptr; sim.mtab = nullptr; sim.draw = nullptr; sim.meshBase = 0; sim.drawIndex = 0; sim.fillFlags = 0; sim.strokeFlags = 0; sim.numFillTotal = 0;
-						sim.init();
-						sim.shape(type, a);
-						cnt = (int)sim.nverts;
-						exists = sim.laneExists;
-						closedHere = sim.laneClosed;
-					} break;
+					default: break; // shapes / arcs only occur in serial paths (k_flatten_serial)
 					}
 				} else {
 					const uint32_t w = A.cmd_cnt[ci];
@@ -218,8 +259,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 				const int spBefore = seg_rel(incl1 - cnt, sh, carrySpVerts);
 				if (valid && !serialDraw && type == VGX_CMD_CLOSE && spBefore > 2) {
 					closedHere = true;
-					const float* fa = ps.args + ps.cmd_arg_off[ps.cmd_sp_start[c]];
-					if (v2near(v2(a[-2], a[-1]), v2(fa[0], fa[1]))) {
+					if (v2near(v2(rec.start[0], rec.start[1]), v2(rec.a[6], rec.a[7]))) {
 						pop = true;
 						cnt = -1;
 					}
@@ -252,20 +292,13 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 					if (pop) { w |= VGX_CC_POP; }
 					A.cmd_cnt[ci] = w;
 				}
-				if (valid && drawLast) {
+				if (valid && drawLast && !(serialStatic != 0)) {
 					vgx_draw_info di;
 					di.first_poly_vertex = 0; di.first_subpath = 0; di.first_mesh = 0;
-					if (serialDraw || slowDraw) {
-						PathSim<false, false> sim;
-						sim.scale = scale; sim.tol = tol; sim.mtx = nullptr; sim.poly = nullptr; sim.polyBase = 0; sim.subs = nullptr; sim.subBase = 0;
-						sim.mdesc = nullptr; sim.mtab = nullptr; sim.draw = nullptr; sim.meshBase = 0; sim.drawIndex = (uint32_t)d; sim.fillFlags = fillFlags; sim.strokeFlags = strokeFlags; sim.numFillTotal = 0;
-						sim.init();
-						const uint32_t pc0 = ps.path_cmd_begin[dr->path];
-						sim.run(ps, pc0, c + 1, stack);
-						di.num_poly_vertices = sim.nverts;
-						di.num_subpaths = sim.nsubs;
-						di.num_meshes = sim.nfill + sim.nstroke;
-						di.flags = 1u | (sim.nfill << 1);
+					if (slowDraw) {
+						// degenerate input (epsilon de-dup hit / dropped piece): k_flatten_serial redoes this draw exactly
+						di.num_poly_vertices = 0; di.num_subpaths = 0; di.num_meshes = 0;
+						di.flags = 1u;
 					} else {
 						di.num_poly_vertices = (uint32_t)(inDrawBefore + cnt);
 						di.num_subpaths = (uint32_t)subsIncl;
@@ -284,7 +317,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 					if ((cflags & VGX_CF_NEXT_IS_CLOSE) && limit > 0 && (A.cmd_cnt[ci + 1] & VGX_CC_POP)) {
 						--limit; // my last vertex is the one pathClose removes
 					}
-					const V2 start = v2(a[-2], a[-1]);
+					const V2 start = v2(rec.start[0], rec.start[1]);
 					switch (type) {
 					case VGX_CMD_MOVE_TO:
 					case VGX_CMD_LINE_TO:
@@ -311,20 +344,13 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 						const uint32_t npts = na >> 1;
 						const uint32_t skip = npts - (uint32_t)(cnt < 0 ? 0 : cnt);
 						for (uint32_t i = 0; i < limit; ++i) {
-							V2 p = v2(a[2 * (i + skip)], a[2 * (i + skip) + 1]);
+							V2 p = v2(pa[2 * (i + skip)], pa[2 * (i + skip) + 1]);
 							if (XFORM) { p = v2xform(p, mtx); }
 							*(float2*)(out + 2 * i) = make_float2(p.x, p.y);
 						}
 					} break;
 					case VGX_CMD_CLOSE: break;
-					default: {
-						PathSim<true, XFORM> sim;
-						sim.scale = scale; sim.tol = tol; sim.mtx = mtx; sim.poly = A.poly; sim.polyBase = vbase; sim.subs = nullptr; sim.subBase = 0;
-						sim.mdesc = nullptr; sim.mtab = nullptr; sim.draw = nullptr; sim.meshBase = 0; sim.drawIndex = 0; sim.fillFlags = 0; sim.strokeFlags = 0; sim.numFillTotal = 0;
-						sim.init();
-						sim.shape(type, a);
-						sim.flushPending();
-					} break;
+					default: break;
 					}
 					// ---- sub-path record + mesh descriptors, written by the sub-path's last command --
 					if (lastInSub) {
@@ -349,16 +375,6 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 							}
 						}
 					}
-				} else if (drawLast) {
-					// exact sequential re-run of the whole draw by this one lane
-					PathSim<true, XFORM> sim;
-					sim.scale = scale; sim.tol = tol; sim.mtx = mtx; sim.poly = A.poly; sim.polyBase = di.first_poly_vertex; sim.subs = A.subs; sim.subBase = di.first_subpath;
-					sim.mdesc = A.mdesc; sim.mtab = A.mtab; sim.draw = dr; sim.meshBase = di.first_mesh; sim.drawIndex = (uint32_t)d; sim.fillFlags = fillFlags; sim.strokeFlags = strokeFlags;
-					sim.numFillTotal = di.flags >> 1;
-					sim.init();
-					const uint32_t pc0 = ps.path_cmd_begin[dr->path];
-					sim.run(ps, pc0, c + 1, stack);
-					if (sim.numRound) { atomicAdd(&A.totals->num_round_meshes, sim.numRound); }
 				}
 			}
 
@@ -381,7 +397,65 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 			carrySlow = lastIsDrawLast ? 0 : nSlow;
 			carrySpVerts = (lastIsDrawLast || lastIsSubLast) ? 0 : nSp;
 			carrySpExists = (lastIsDrawLast || lastIsSubLast) ? 0 : nHeadExists;
-			dcur = __shfl((unsigned long long)d, L); // draw of the last command; its prefix <= next chunk's first key
+			dcur = __shfl((unsigned long long)d, L); // draw of the last command: the next window (if needed) starts here
+		}
+	}
+}
+
+// ---- private (per-lane) pending stack for the serial kernel ---------------------------------------------
+struct PrivStack
+{
+	float s[VGX_CUBIC_MAX_PENDING * 6];
+	__device__ __forceinline__ void push(int level, float ax, float ay, float bx, float by, float cx, float cy)
+	{
+		float* p = s + level * 6;
+		p[0] = ax; p[1] = ay; p[2] = bx; p[3] = by; p[4] = cx; p[5] = cy;
+	}
+	__device__ __forceinline__ void pop(int level, float& ax, float& ay, float& bx, float& by, float& cx, float& cy)
+	{
+		const float* p = s + level * 6;
+		ax = p[0]; ay = p[1]; bx = p[2]; by = p[3]; cx = p[4]; cy = p[5];
+	}
+};
+
+// k_flatten_serial: ONE LANE PER DRAW runs the exact sequential builder (PathSim = vg::Path semantics) for
+//   - paths with closed shapes / arcs (statically flagged at upload: their vertices depend on trigonometry
+//     recurrences and, for arcs, on computed end points), and
+//   - draws the lane-parallel kernel flagged as degenerate (epsilon de-dup hit, dropped subdivision piece).
+// Slow by construction, exact by construction; everything else never enters this kernel.
+template<bool EMIT, bool XFORM>
+__global__ __launch_bounds__(256) void k_flatten_serial(VgxFlattenArgs A)
+{
+	if (A.totals->status != VGX_OK) { return; }
+	const VgxPathSetDev& ps = A.ps;
+	PrivStack stack;
+	for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < A.ndraws; d += (uint64_t)gridDim.x * blockDim.x) {
+		const vgx_draw* dr = A.draws + d;
+		const uint32_t path = dr->path;
+		const bool serial = (ps.path_flags[path] & VGX_PF_SERIAL) || (A.dinfo[d].flags & 1u);
+		const uint32_t pc0 = ps.path_cmd_begin[path], pc1 = ps.path_cmd_begin[path + 1];
+		if (!serial || pc0 == pc1) { continue; }
+		PathSim<EMIT, XFORM> sim;
+		sim.scale = dr->scale; sim.tol = dr->tess_tol; sim.mtx = dr->mtx; sim.poly = A.poly;
+		sim.drawIndex = (uint32_t)d; sim.fillFlags = dr->fill_flags; sim.strokeFlags = dr->stroke_flags; sim.draw = dr;
+		if (!EMIT) {
+			sim.polyBase = 0; sim.subs = nullptr; sim.subBase = 0; sim.mdesc = nullptr; sim.mtab = nullptr; sim.meshBase = 0;
+			sim.numFillTotal = 0; sim.limit = 0;
+			sim.init();
+			sim.run(ps, pc0, pc1, stack);
+			vgx_draw_info di;
+			di.first_poly_vertex = 0; di.first_subpath = 0; di.first_mesh = 0;
+			di.num_poly_vertices = sim.nverts; di.num_subpaths = sim.nsubs; di.num_meshes = sim.nfill + sim.nstroke;
+			di.flags = 1u | (sim.nfill << 1);
+			A.dinfo[d] = di;
+		} else {
+			const vgx_draw_info di = A.dinfo[d];
+			sim.polyBase = di.first_poly_vertex; sim.subs = A.subs; sim.subBase = di.first_subpath;
+			sim.mdesc = A.mdesc; sim.mtab = A.mtab; sim.meshBase = di.first_mesh; sim.numFillTotal = di.flags >> 1;
+			sim.limit = di.num_poly_vertices;
+			sim.init();
+			sim.run(ps, pc0, pc1, stack);
+			if (sim.numRound) { atomicAdd(&A.totals->num_round_meshes, sim.numRound); }
 		}
 	}
 }
@@ -390,11 +464,16 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 
 void vgx_launch_flatten(bool emit, const VgxFlattenArgs& a, int numBlocks, hipStream_t s)
 {
+	// lane-parallel kernel first (it flags degenerate draws), then the one-lane-per-draw exact kernel
+	const int sb = 1024;
 	if (!emit) {
 		hipLaunchKernelGGL((k_flatten<false, false>), dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
+		hipLaunchKernelGGL((k_flatten_serial<false, false>), dim3(sb), dim3(256), 0, s, a);
 	} else if (a.apply_transform) {
 		hipLaunchKernelGGL((k_flatten<true, true>), dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
+		hipLaunchKernelGGL((k_flatten_serial<true, true>), dim3(sb), dim3(256), 0, s, a);
 	} else {
 		hipLaunchKernelGGL((k_flatten<true, false>), dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
+		hipLaunchKernelGGL((k_flatten_serial<true, false>), dim3(sb), dim3(256), 0, s, a);
 	}
 }

@@ -33,10 +33,16 @@ int vgxt_serial_flatten(const vgx_pathset_desc* d, const vgx_draw* draw, int app
 	ps.npaths = d->npaths; ps.ncmd = d->ncmd;
 	HostStack st;
 	const uint32_t c0 = d->path_cmd_begin[draw->path], c1 = d->path_cmd_begin[draw->path + 1];
+	uint32_t limit = 0;
+	if (poly) { // the emit pass knows the final vertex count from the count pass
+		uint32_t tmp[4];
+		vgxt_serial_flatten(d, draw, 0, nullptr, nullptr, tmp);
+		limit = tmp[0];
+	}
 	if (poly && applyTransform) {
 		PathSim<true, true> sim;
 		sim.scale = draw->scale; sim.tol = draw->tess_tol; sim.mtx = draw->mtx; sim.poly = poly; sim.polyBase = 0;
-		sim.subs = subs; sim.subBase = 0; sim.mdesc = nullptr; sim.mtab = nullptr; sim.draw = nullptr; sim.meshBase = 0; sim.drawIndex = 0;
+		sim.subs = subs; sim.subBase = 0; sim.mdesc = nullptr; sim.mtab = nullptr; sim.draw = nullptr; sim.limit = limit; sim.meshBase = 0; sim.drawIndex = 0;
 		sim.fillFlags = draw->fill_flags; sim.strokeFlags = draw->stroke_flags; sim.numFillTotal = 0;
 		sim.init();
 		sim.run(ps, c0, c1, st);
@@ -44,7 +50,7 @@ int vgxt_serial_flatten(const vgx_pathset_desc* d, const vgx_draw* draw, int app
 	} else if (poly) {
 		PathSim<true, false> sim;
 		sim.scale = draw->scale; sim.tol = draw->tess_tol; sim.mtx = draw->mtx; sim.poly = poly; sim.polyBase = 0;
-		sim.subs = subs; sim.subBase = 0; sim.mdesc = nullptr; sim.mtab = nullptr; sim.draw = nullptr; sim.meshBase = 0; sim.drawIndex = 0;
+		sim.subs = subs; sim.subBase = 0; sim.mdesc = nullptr; sim.mtab = nullptr; sim.draw = nullptr; sim.limit = limit; sim.meshBase = 0; sim.drawIndex = 0;
 		sim.fillFlags = draw->fill_flags; sim.strokeFlags = draw->stroke_flags; sim.numFillTotal = 0;
 		sim.init();
 		sim.run(ps, c0, c1, st);
@@ -52,7 +58,7 @@ int vgxt_serial_flatten(const vgx_pathset_desc* d, const vgx_draw* draw, int app
 	} else {
 		PathSim<false, false> sim;
 		sim.scale = draw->scale; sim.tol = draw->tess_tol; sim.mtx = nullptr; sim.poly = nullptr; sim.polyBase = 0;
-		sim.subs = nullptr; sim.subBase = 0; sim.mdesc = nullptr; sim.mtab = nullptr; sim.draw = nullptr; sim.meshBase = 0; sim.drawIndex = 0;
+		sim.subs = nullptr; sim.subBase = 0; sim.mdesc = nullptr; sim.mtab = nullptr; sim.draw = nullptr; sim.limit = limit; sim.meshBase = 0; sim.drawIndex = 0;
 		sim.fillFlags = draw->fill_flags; sim.strokeFlags = draw->stroke_flags; sim.numFillTotal = 0;
 		sim.init();
 		sim.run(ps, c0, c1, st);

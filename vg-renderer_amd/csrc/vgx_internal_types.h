@@ -21,8 +21,22 @@
 #define VGX_CF_LAST_IN_PATH 0x8u
 #define VGX_PF_SERIAL 0x1u
 
+// One fixed-size record per path command, built on the host at upload: everything a lane needs for its command in
+// ONE 64-byte load (the SoA arrays above stay for the serial path and for POLYLINE's variable arguments).
+struct VgxCmdRec
+{
+	uint32_t type;      // vgx_cmd
+	uint32_t flags;     // VGX_CF_*
+	uint32_t na;        // argument count
+	uint32_t arg_off;   // into args (POLYLINE)
+	float start[2];     // previous command's end point (the lane's start point; unused by sub-path starters)
+	float a[8];         // arguments 0..7; for CLOSE a[6..7] = first point of its sub-path (the MOVE_TO point)
+	float pad[2];
+};
+
 struct VgxPathSetDev
 {
+	const VgxCmdRec* cmdrec;
 	const uint8_t* cmd_type;
 	const uint8_t* cmd_flags;
 	const uint32_t* cmd_arg_off;

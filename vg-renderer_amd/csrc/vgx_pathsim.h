@@ -64,14 +64,16 @@ struct PathSim
 	uint32_t spFirst, spN;
 	bool spClosed;
 	V2 first, last;          // untransformed first / last vertex of the current sub-path
-	bool havePending;        // last vertex not yet stored (it may still be popped by close())
+	uint32_t limit;          // emit: vertices [0, limit) are stored. limit = the FINAL vertex count (known from the
+	                         // count pass), so the vertex pathClose pops at the very end is never written; earlier
+	                         // popped slots are simply overwritten by the next sub-path's first vertex (same lane).
 	// lane-mode results
 	bool laneExists, laneClosed;
 
 	VGX_HDM void init()
 	{
 		nverts = 0; nsubs = 0; nfill = 0; nstroke = 0; numRound = 0; open = false; spFirst = 0; spN = 0; spClosed = false;
-		first = v2(0.0f, 0.0f); last = first; havePending = false; laneExists = false; laneClosed = false;
+		first = v2(0.0f, 0.0f); last = first; laneExists = false; laneClosed = false;
 	}
 	VGX_HDM void store(uint32_t i, V2 p)
 	{
@@ -82,13 +84,8 @@ struct PathSim
 			o[1] = p.y;
 		}
 	}
-	VGX_HDM void flushPending()
-	{
-		if (havePending) { store(nverts - 1, last); havePending = false; }
-	}
 	VGX_HDM void endSub() // sub-path is complete: write its record and its mesh descriptors
 	{
-		flushPending();
 		if (!open) { return; }
 		const uint32_t subIndex = nsubs - 1;
 		if (EMIT && subs) {
@@ -115,9 +112,8 @@ struct PathSim
 	}
 	VGX_HDM void raw(float x, float y) // pathAllocVertices + write, no dedup (path.cpp:748-759)
 	{
-		flushPending();
 		last = v2(x, y);
-		havePending = true;
+		if (nverts < limit) { store(nverts, last); }
 		++nverts;
 		++spN;
 	}
@@ -149,7 +145,6 @@ struct PathSim
 		spClosed = true;
 		laneClosed = true;
 		if (v2near(last, first)) {
-			havePending = false; // the popped vertex is never stored
 			--spN;
 			--nverts;
 		}

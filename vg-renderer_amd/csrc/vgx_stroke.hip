@@ -595,15 +595,40 @@ __global__ __launch_bounds__(256) void k_mesh_prepare(VgxStrokeArgs A)
 //   index positions [9j, 9j+9) of the mesh, whose values are closed-form in (N, position).
 //   FILL element j: vertex j (= polyline vertex) and fan triangle (0, j+1, j+2).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void store_idx_run(uint16_t* dst, const uint32_t* val, uint32_t cnt)
+// Unaligned wide stores: the output streams are only element-aligned (8 / 4 / 2 bytes), gfx950 global stores
+// handle that natively (unaligned access mode), so every lane issues ONE dwordx4 for its two positions, ONE
+// dwordx2 for its two colours and ONE dwordx4 + ONE short for its nine indices -- no alignment-dependent
+// divergence.
+struct __attribute__((packed, aligned(8))) PosPair { float x0, y0, x1, y1; };
+struct __attribute__((packed, aligned(4))) ColPair { uint32_t c0, c1; };
+struct __attribute__((packed, aligned(2))) Idx9 { uint32_t a, b, c, d; uint16_t e; };
+struct __attribute__((packed, aligned(2))) Idx3 { uint32_t a; uint16_t b; };
+
+// Per-mesh record held one per lane for a window of 64 consecutive meshes (refilled every few dozen chunks):
+// the element lanes fetch their mesh's fields with shuffles instead of a dependent chain of global loads.
+struct FillWindow
 {
-	// cnt is 9 or 3; all stores naturally aligned: a leading or a trailing 16-bit store fixes the phase
-	uint32_t r = 0;
-	if (((uintptr_t)dst) & 2u) { dst[0] = (uint16_t)val[0]; r = 1; }
-	for (; r + 1 < cnt; r += 2) {
-		*(uint32_t*)(dst + r) = (val[r] & 0xFFFFu) | (val[r + 1] << 16);
+	uint64_t prefix;   // elem_prefix[wbase + lane] (or ~0 past the end)
+	uint64_t polyFirst, firstV, firstI;
+	uint32_t N, kind, color;
+	float aa;
+};
+
+__device__ __forceinline__ FillWindow fill_window_load(const VgxStrokeArgs& A, uint64_t wbase, uint64_t numMeshes, int lane)
+{
+	FillWindow w;
+	const uint64_t idx = wbase + (uint64_t)lane;
+	w.prefix = (idx <= numMeshes) ? A.elem_prefix[idx] : ~0ull;
+	w.polyFirst = 0; w.firstV = 0; w.firstI = 0; w.N = 3; w.kind = VGX_MESH_FILL; w.color = 0; w.aa = 0.0f;
+	if (idx < numMeshes) {
+		const VgxMeshDesc md = A.mdesc[idx];
+		const VgxMeshPrep pr = A.mprep[idx];
+		w.polyFirst = md.poly_first; w.N = md.poly_n; w.kind = VGX_MD_KIND(md.kind);
+		w.color = pr.color; w.aa = pr.f0;
+		w.firstV = A.mtab[idx].first_vertex;
+		w.firstI = A.mtab[idx].first_index;
 	}
-	if (r < cnt) { dst[r] = (uint16_t)val[r]; }
+	return w;
 }
 
 __global__ __launch_bounds__(VGX_WAVE) void k_fill(VgxStrokeArgs A)
@@ -621,119 +646,115 @@ __global__ __launch_bounds__(VGX_WAVE) void k_fill(VgxStrokeArgs A)
 	if (seg0 >= seg1) {
 		return;
 	}
-	uint64_t mNext = lower_bound_u64(A.elem_prefix, 0, numMeshes, seg0 * VGX_WAVE);
-	for (uint64_t seg = seg0; seg < seg1; ++seg) {
-		const uint64_t m0 = mNext;
-		const uint64_t m1 = advance_lower_bound(A.elem_prefix, m0, numMeshes, (seg + 1) * VGX_WAVE, lane);
-		mNext = m1;
-		if (m0 == m1) {
-			continue;
-		}
-		const uint64_t E0 = A.elem_prefix[m0];
-		const uint64_t E1 = A.elem_prefix[m1];
-		uint64_t mcur = m0;
-		for (uint64_t chunk = E0; chunk < E1; chunk += VGX_WAVE) {
-			const uint64_t ei = chunk + lane;
-			const bool valid = ei < E1;
-			const uint64_t widx = mcur + (uint64_t)lane;
-			const uint64_t wv = (widx <= m1) ? A.elem_prefix[widx] : ~0ull;
-			const bool windowCovers = __shfl((unsigned long long)wv, VGX_WAVE - 1) > chunk + (VGX_WAVE - 1);
-			uint64_t ownerBase = 0;
-			const int ownerOfs = window_owner(wv, valid ? ei : chunk, &ownerBase);
-			uint64_t mi = m0;
-			uint32_t kind = VGX_MESH_FILL, N = 3, j = 0;
-			const float* vtx = A.poly;
-			VgxMeshPrep pr;
-			pr.f0 = 0.0f; pr.f1 = 0.0f; pr.f2 = 0.0f; pr.color = 0;
-			uint64_t firstV = 0, firstI = 0;
-			V2 p1 = v2(0.0f, 0.0f);
-			if (valid) {
-				if (windowCovers) {
-					mi = mcur + (uint64_t)ownerOfs;
-				} else { // the window is full of zero-length (stroke) entries: rare, fall back to a search
-					mi = find_owner_u64(A.elem_prefix, m0, m1, ei);
-					ownerBase = A.elem_prefix[mi];
-				}
-				const VgxMeshDesc md = A.mdesc[mi];
-				pr = A.mprep[mi];
-				firstV = A.mtab[mi].first_vertex;
-				firstI = A.mtab[mi].first_index;
-				kind = VGX_MD_KIND(md.kind);
-				N = md.poly_n;
-				j = (uint32_t)(ei - ownerBase);
-				vtx = A.poly + 2 * md.poly_first;
-				p1 = ldv(vtx, j);
-			}
-			const bool aaElem = valid && kind == VGX_MESH_FILL_AA;
-			// neighbours from the adjacent lanes (same mesh); only lanes at a mesh / chunk edge load or recompute
-			const bool prevInWave = lane > 0 && j > 0;
-			const bool nextInWave = lane < VGX_WAVE - 1 && j + 1 < N && ei + 1 < E1;
-			V2 pNext;
-			pNext.x = __shfl_down(p1.x, 1); pNext.y = __shfl_down(p1.y, 1);
-			if (aaElem && !nextInWave) { pNext = ldv(vtx, j + 1 < N ? j + 1 : 0); }
-			V2 d12 = v2(0.0f, 0.0f);
-			if (aaElem) { d12 = v2dir(p1, pNext); }
-			V2 dPrev;
-			dPrev.x = __shfl_up(d12.x, 1); dPrev.y = __shfl_up(d12.y, 1);
-			if (aaElem && !prevInWave) { dPrev = v2dir(ldv(vtx, j > 0 ? j - 1 : N - 1), p1); }
+	// This wave's elements are the contiguous range [chunk0, chunkEnd); whole meshes are NOT required here (a fill
+	// element only needs its own mesh record and its two neighbours), so the walk is a plain 64-element stride.
+	const uint64_t elem0 = seg0 * VGX_WAVE;
+	const uint64_t elemEnd = (seg1 * VGX_WAVE < totalElems) ? seg1 * VGX_WAVE : totalElems;
+	uint64_t mcur = find_owner_u64(A.elem_prefix, 0, numMeshes, elem0); // last mesh with prefix <= elem0
+	uint64_t wbase = mcur;
+	FillWindow W = fill_window_load(A, wbase, numMeshes, lane);
 
-			if (valid) {
-				const uint32_t color = pr.color;
-				if (kind == VGX_MESH_FILL_AA) {
-					const V2 vaa = v2mul(v2extrude(dPrev, d12), pr.f0);
-					const V2 vin = v2add(p1, vaa), vout = v2sub(p1, vaa);
-					const uint64_t gv = firstV + 2 * (uint64_t)j;
-					float* pp = A.pos + 2 * gv;
-					uint32_t* pc = A.color + gv;
-					if ((gv & 1ull) == 0) { // 16-byte aligned pair
-						*(float4*)pp = make_float4(vin.x, vin.y, vout.x, vout.y);
-						*(uint2*)pc = make_uint2(color, color & 0x00FFFFFFu);
-					} else {
-						*(float2*)pp = make_float2(vin.x, vin.y);
-						*(float2*)(pp + 2) = make_float2(vout.x, vout.y);
-						pc[0] = color; pc[1] = color & 0x00FFFFFFu;
-					}
-					// indices: k = 9j is a multiple of 3 and so is the fan size F = 3(N-2): position k+r is fan corner
-					// (r%3) of triangle 3j + r/3 while k+r < F, else fringe position q = k+r-F = 3u+r with
-					// u = 3j-(N-2) >= -2. With U = u+2 = 2a+b: q = 6(a-1) + (3b+r), i.e. quad a-1+[3b+r >= 6],
-					// corner (3b+r) mod 6 -- no division (fan stroker.cpp:769-776, fringe :779-795).
-					const uint32_t cnt = (j + 1 < N) ? 9u : 3u;
-					const uint32_t k = 9 * j;
-					const uint32_t fan = 3 * (N - 2);
-					const int U = 3 * (int)j - (int)N + 4;
-					const uint32_t Ua = (uint32_t)(U > 0 ? U : 0) >> 1, Ub = (uint32_t)(U > 0 ? U : 0) & 1u;
-					uint32_t val[9];
+	for (uint64_t chunk = elem0; chunk < elemEnd; chunk += VGX_WAVE) {
+		const uint64_t ei = chunk + lane;
+		const bool valid = ei < elemEnd;
+		const uint64_t lastKey = chunk + (VGX_WAVE - 1);
+		if (!(__shfl((unsigned long long)W.prefix, VGX_WAVE - 1) > lastKey)) {
+			wbase = mcur;
+			W = fill_window_load(A, wbase, numMeshes, lane);
+		}
+		const bool windowCovers = __shfl((unsigned long long)W.prefix, VGX_WAVE - 1) > lastKey;
+		uint64_t ownerBase = 0;
+		const int k = window_owner(W.prefix, valid ? ei : chunk, &ownerBase);
+		uint64_t mi = wbase + (uint64_t)k;
+		uint64_t polyFirst = __shfl((unsigned long long)W.polyFirst, k);
+		uint64_t firstV = __shfl((unsigned long long)W.firstV, k);
+		uint64_t firstI = __shfl((unsigned long long)W.firstI, k);
+		uint32_t N = (uint32_t)__shfl((int)W.N, k);
+		uint32_t kind = (uint32_t)__shfl((int)W.kind, k);
+		uint32_t color = (uint32_t)__shfl((int)W.color, k);
+		float aa = __shfl(W.aa, k);
+		if (!windowCovers && valid) { // > 63 mesh records (mostly zero-length stroke entries) inside one chunk: rare
+			mi = find_owner_u64(A.elem_prefix, wbase, numMeshes, ei);
+			ownerBase = A.elem_prefix[mi];
+			const VgxMeshDesc md = A.mdesc[mi];
+			const VgxMeshPrep pr = A.mprep[mi];
+			polyFirst = md.poly_first; N = md.poly_n; kind = VGX_MD_KIND(md.kind); color = pr.color; aa = pr.f0;
+			firstV = A.mtab[mi].first_vertex; firstI = A.mtab[mi].first_index;
+		}
+		const uint32_t j = valid ? (uint32_t)(ei - ownerBase) : 0u;
+		const float* vtx = A.poly + 2 * polyFirst;
+		const bool aaElem = valid && kind == VGX_MESH_FILL_AA;
+		// all vertex loads of the chunk are issued together: my own vertex, and -- only for lanes whose neighbour is
+		// not in the adjacent lane (mesh boundary / chunk edge) -- the cyclic next / previous vertex
+		const bool prevInWave = lane > 0 && j > 0;
+		const bool nextInWave = lane < VGX_WAVE - 1 && j + 1 < N && ei + 1 < elemEnd;
+		V2 p1 = v2(0.0f, 0.0f), pNextB = p1, pPrevB = p1;
+		if (valid) { p1 = ldv(vtx, j); }
+		if (aaElem && !nextInWave) { pNextB = ldv(vtx, j + 1 < N ? j + 1 : 0); }
+		if (aaElem && !prevInWave) { pPrevB = ldv(vtx, j > 0 ? j - 1 : N - 1); }
+		V2 pNext;
+		pNext.x = __shfl_down(p1.x, 1); pNext.y = __shfl_down(p1.y, 1);
+		if (!nextInWave) { pNext = pNextB; }
+		V2 d12 = v2(0.0f, 0.0f);
+		if (aaElem) { d12 = v2dir(p1, pNext); }
+		V2 dPrev;
+		dPrev.x = __shfl_up(d12.x, 1); dPrev.y = __shfl_up(d12.y, 1);
+		if (aaElem && !prevInWave) { dPrev = v2dir(pPrevB, p1); }
+
+		if (valid) {
+			if (kind == VGX_MESH_FILL_AA) {
+				const V2 vaa = v2mul(v2extrude(dPrev, d12), aa);
+				const V2 vin = v2add(p1, vaa), vout = v2sub(p1, vaa);
+				const uint64_t gv = firstV + 2 * (uint64_t)j;
+				PosPair pp; pp.x0 = vin.x; pp.y0 = vin.y; pp.x1 = vout.x; pp.y1 = vout.y;
+				*(PosPair*)(A.pos + 2 * gv) = pp;
+				ColPair cp; cp.c0 = color; cp.c1 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
+				*(ColPair*)(A.color + gv) = cp;
+				// indices: k9 = 9j is a multiple of 3 and so is the fan size F = 3(N-2): position k9+r is fan corner
+				// (r%3) of triangle 3j + r/3 while k9+r < F, else fringe position q = k9+r-F = 3u+r with
+				// u = 3j-(N-2) >= -2. With U = u+2 = 2a+b: q = 6(a-1) + (3b+r), i.e. quad a-1+[3b+r >= 6],
+				// corner (3b+r) mod 6 -- no division (fan stroker.cpp:769-776, fringe :779-795).
+				const uint32_t k9 = 9 * j;
+				const uint32_t fan = 3 * (N - 2);
+				const int U = 3 * (int)j - (int)N + 4;
+				const uint32_t Ua = (uint32_t)(U > 0 ? U : 0) >> 1, Ub = (uint32_t)(U > 0 ? U : 0) & 1u;
+				uint32_t val[9];
 #pragma unroll
-					for (uint32_t r = 0; r < 9; ++r) {
-						const uint32_t t = 3 * j + r / 3, c3 = r % 3;
-						const uint32_t fanVal = (c3 == 0) ? 0u : (2 * t + 2 * c3);
-						const uint32_t q6 = r + 3 * Ub;
-						const uint32_t ed = Ua - 1u + (q6 >= 6 ? 1u : 0u); // wraps for fan positions, whose frVal is unused
-						const uint32_t c = q6 - (q6 >= 6 ? 6u : 0u);
-						const uint32_t fb = 2 * ed;
-						const bool lastEdge = ed + 1 == N;
-						const uint32_t nextInner = lastEdge ? 0u : fb + 2, nextOuter = lastEdge ? 1u : fb + 3;
-						const uint32_t frVal = (c == 0 || c == 3) ? fb : (c == 1 ? fb + 1 : (c == 5 ? nextInner : nextOuter));
-						val[r] = (k + r < fan) ? fanVal : frVal;
-					}
-					uint16_t* pi = A.idx + firstI + k;
-					if (cnt == 9) { store_idx_run(pi, val, 9); } else { store_idx_run(pi, val, 3); }
-				} else {
-					const uint64_t gv = firstV + j;
-					*(float2*)(A.pos + 2 * gv) = make_float2(p1.x, p1.y);
-					A.color[gv] = color;
-					if (j + 2 < N) {
-						uint16_t* pi = A.idx + firstI + 3 * j;
-						pi[0] = 0; pi[1] = (uint16_t)(j + 1); pi[2] = (uint16_t)(j + 2);
-					}
+				for (uint32_t r = 0; r < 9; ++r) {
+					const uint32_t t = 3 * j + r / 3, c3 = r % 3;
+					const uint32_t fanVal = (c3 == 0) ? 0u : (2 * t + 2 * c3);
+					const uint32_t q6 = r + 3 * Ub;
+					const uint32_t ed = Ua - 1u + (q6 >= 6 ? 1u : 0u); // wraps for fan positions, whose frVal is unused
+					const uint32_t c = q6 - (q6 >= 6 ? 6u : 0u);
+					const uint32_t fb = 2 * ed;
+					const bool lastEdge = ed + 1 == N;
+					const uint32_t nextInner = lastEdge ? 0u : fb + 2, nextOuter = lastEdge ? 1u : fb + 3;
+					const uint32_t frVal = (c == 0 || c == 3) ? fb : (c == 1 ? fb + 1 : (c == 5 ? nextInner : nextOuter));
+					val[r] = ((k9 + r < fan) ? fanVal : frVal) & 0xFFFFu;
 				}
-				if (j == N - 1 && A.meshes_out) {
-					A.meshes_out[mi] = A.mtab[mi];
+				uint16_t* pi = A.idx + firstI + k9;
+				if (j + 1 < N) {
+					Idx9 q; q.a = val[0] | (val[1] << 16); q.b = val[2] | (val[3] << 16); q.c = val[4] | (val[5] << 16); q.d = val[6] | (val[7] << 16); q.e = (uint16_t)val[8];
+					*(Idx9*)pi = q;
+				} else {
+					Idx3 q; q.a = val[0] | (val[1] << 16); q.b = (uint16_t)val[2];
+					*(Idx3*)pi = q;
+				}
+			} else {
+				const uint64_t gv = firstV + j;
+				*(float2*)(A.pos + 2 * gv) = make_float2(p1.x, p1.y);
+				A.color[gv] = color;
+				if (j + 2 < N) {
+					uint16_t* pi = A.idx + firstI + 3 * j;
+					pi[0] = 0; pi[1] = (uint16_t)(j + 1); pi[2] = (uint16_t)(j + 2);
 				}
 			}
-			const int nvalid = (int)((E1 - chunk) < (uint64_t)VGX_WAVE ? (E1 - chunk) : (uint64_t)VGX_WAVE);
-			mcur = __shfl((unsigned long long)mi, nvalid - 1);
+			if (j == N - 1 && A.meshes_out) {
+				A.meshes_out[mi] = A.mtab[mi];
+			}
 		}
+		const int nvalid = (int)((elemEnd - chunk) < (uint64_t)VGX_WAVE ? (elemEnd - chunk) : (uint64_t)VGX_WAVE);
+		mcur = __shfl((unsigned long long)mi, nvalid - 1);
 	}
 }
 

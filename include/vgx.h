@@ -212,6 +212,16 @@ int vgx_tessellate_emit(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* dra
  * totals and `dev_status` (DEVICE uint32, may be NULL) receives VGX_OK / VGX_E_NOSPACE / ... . */
 int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream);
 
+/* ---- stroker level: polylines in, meshes out ----------------------------------------------------- */
+/* What the reference hands to strokerConvexFill[AA] / strokerPolylineStroke[AA|AAThin] (include/vg/stroker.h:29-72):
+ * vertex lists that are ALREADY flattened and transformed. `poly` (DEVICE, [.][2]) holds the vertices, `subpaths`
+ * (DEVICE) one record per vertex list {first_vertex, num_vertices, flags bit0 = isClosed}, `subpath_draw` (DEVICE)
+ * the index of the vgx_draw whose fill_* / stroke_* / fringe / scale / tess_tol fields parameterise the calls for that
+ * list (path and mtx are ignored). Mesh order: list after list, fill mesh (>= 3 vertices) before stroke mesh (>= 2).
+ * vgx_mesh.subpath_kind carries the list index. _count sizes the output (one stream sync), _emit must follow. */
+int vgx_stroke_count(vgx_ctx* ctx, const float* poly, const vgx_subpath* subpaths, const uint32_t* subpath_draw, uint64_t nsubpaths, const vgx_draw* draws, uint64_t ndraws, vgx_sizes* out_sizes, void* stream);
+int vgx_stroke_emit(vgx_ctx* ctx, const float* poly, const vgx_subpath* subpaths, const uint32_t* subpath_draw, uint64_t nsubpaths, const vgx_draw* draws, uint64_t ndraws, const vgx_mesh_out* out, void* stream);
+
 /* Per-kernel timing of the last vgx_tessellate.. / vgx_flatten.. sequence, measured with HIP events
  * on the stream the kernels ran on. Enable before the call; read after synchronising. */
 #define VGX_MAX_STAGES 16

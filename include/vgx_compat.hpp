@@ -1,0 +1,91 @@
+// vgx_compat.hpp -- the reference's own vg::pathXXX / vg::strokerXXX API on top of the C-ABI (include/vgx.h).
+//
+// Drop-in replacement for <vg/path.h> (reference include/vg/path.h:19-38) and <vg/stroker.h>
+// (include/vg/stroker.h:11-72): same namespace, names, argument order and POD layouts, so the call sites in the
+// reference's src/vg.cpp compile unchanged. Every call is served by the HIP kernels of libvgx.so with a batch of
+// ONE path / ONE vertex list (a launch + copy round trip per call, ~0.1 ms): this layer exists for source
+// compatibility and incremental adoption; throughput comes from batching through vgx.h.
+// There is no CPU implementation behind it: without a gfx950 device the create functions return nullptr.
+//
+// Differences from the reference, all documented in DESIGN.md:
+//   - command grammar the reference leaves undefined (lineTo before moveTo, appending to a closed sub-path) yields an
+//     empty path instead of undefined behaviour; NaN/Inf arguments likewise (they hang the reference, path.cpp:109);
+//   - the bx transcendentals are the pinned ones of csrc/vgmath.h;
+//   - strokerConcaveFill* (libtess2) is not provided (out of scope).
+#ifndef VGX_COMPAT_HPP
+#define VGX_COMPAT_HPP
+
+#include <stdint.h>
+
+namespace bx { struct AllocatorI; }
+
+namespace vg
+{
+#ifndef VG_H // the reference's include/vg/vg.h already defines these (identical layouts, vg.h:102,156-174,252-259,353-360)
+typedef uint32_t Color;
+struct LineCap { enum Enum : uint32_t { Butt = 0, Round = 1, Square = 2 }; };
+struct LineJoin { enum Enum : uint32_t { Miter = 0, Round = 1, Bevel = 2 }; };
+struct Winding { enum Enum : uint32_t { CCW = 0, CW = 1 }; };
+struct Mesh
+{
+	const float* m_PosBuffer;
+	const uint32_t* m_ColorBuffer;
+	const uint16_t* m_IndexBuffer;
+	uint32_t m_NumVertices;
+	uint32_t m_NumIndices;
+};
+#endif
+
+#ifndef VG_PATH_H
+struct SubPath // include/vg/path.h:11-16
+{
+	uint32_t m_FirstVertexID;
+	uint32_t m_NumVertices;
+	bool m_IsClosed;
+};
+#endif
+
+struct Path;
+struct Stroker;
+
+// ---- include/vg/path.h:19-38 ----
+Path* createPath(bx::AllocatorI* allocator);
+void destroyPath(Path* path);
+void pathReset(Path* path, float scale, float tesselationTolerance);
+void pathMoveTo(Path* path, float x, float y);
+void pathLineTo(Path* path, float x, float y);
+void pathCubicTo(Path* path, float c1x, float c1y, float c2x, float c2y, float x, float y);
+void pathQuadraticTo(Path* path, float cx, float cy, float x, float y);
+void pathArcTo(Path* path, float x1, float y1, float x2, float y2, float r);
+void pathRect(Path* path, float x, float y, float w, float h);
+void pathRoundedRect(Path* path, float x, float y, float w, float h, float r);
+void pathRoundedRectVarying(Path* path, float x, float y, float w, float h, float rtl, float rtr, float rbr, float rbl);
+void pathCircle(Path* path, float x, float y, float r);
+void pathEllipse(Path* path, float x, float y, float rx, float ry);
+void pathArc(Path* path, float x, float y, float r, float a0, float a1, Winding::Enum dir);
+void pathPolyline(Path* path, const float* coords, uint32_t numPoints);
+void pathClose(Path* path);
+const float* pathGetVertices(const Path* path);   // valid until the next mutation of `path`
+uint32_t pathGetNumVertices(const Path* path);
+const SubPath* pathGetSubPaths(const Path* path);
+uint32_t pathGetNumSubPaths(const Path* path);
+
+// ---- include/vg/stroker.h:11-72 ----
+Stroker* createStroker(bx::AllocatorI* allocator);
+void destroyStroker(Stroker* stroker);
+void strokerReset(Stroker* stroker, float scale, float tesselationTolerance, float fringeWidth);
+// Mesh pointers stay valid until the next strokerXXX call on the same Stroker (reference stroker.cpp:2316-2320).
+void strokerPolylineStroke(Stroker* stroker, Mesh* mesh, const float* vertexList, uint32_t numVertices, bool isClosed, float strokeWidth, LineCap::Enum lineCap, LineJoin::Enum lineJoin);
+void strokerPolylineStrokeAA(Stroker* stroker, Mesh* mesh, const float* vertexList, uint32_t numVertices, bool isClosed, Color color, float strokeWidth, LineCap::Enum lineCap, LineJoin::Enum lineJoin);
+void strokerPolylineStrokeAAThin(Stroker* stroker, Mesh* mesh, const float* vertexList, uint32_t numVertices, bool isClosed, Color color, LineCap::Enum lineCap, LineJoin::Enum lineJoin);
+void strokerConvexFill(Stroker* stroker, Mesh* mesh, const float* vertexList, uint32_t numVertices);
+void strokerConvexFillAA(Stroker* stroker, Mesh* mesh, const float* vertexList, uint32_t numVertices, uint32_t color);
+
+// ---- not in the reference ----
+// Device used by subsequently created Path / Stroker objects (default 0). Last status of an object (vgx_status).
+void vgxCompatSetDevice(int device);
+int vgxCompatLastStatus(const Path* path);
+int vgxCompatLastStatus(const Stroker* stroker);
+}
+
+#endif

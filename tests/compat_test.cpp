@@ -1,0 +1,126 @@
+// compat_test.cpp -- drives the SAME sequence of vg::pathXXX / vg::strokerXXX calls through
+//   (a) include/vgx_compat.hpp  (product: C++ API over the C-ABI, HIP kernels), and
+//   (b) oracle/vgo_port.h       (CPU oracle, test infrastructure)
+// and compares every vertex, sub-path, colour and index bit for bit. Built and run by tests/test_gpu_compat.py.
+#include "vgx_compat.hpp"
+#include "vgo_port.h"
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+static uint32_t g_rng = 12345u;
+static float frand(float lo, float hi) { g_rng = g_rng * 1664525u + 1013904223u; return lo + (hi - lo) * (float)((g_rng >> 8) & 0xFFFFFF) / 16777216.0f; }
+static uint32_t irand(uint32_t n) { g_rng = g_rng * 1664525u + 1013904223u; return (g_rng >> 10) % n; }
+
+static int g_fail = 0, g_checks = 0;
+#define CHECK(cond, ...) do { ++g_checks; if (!(cond)) { ++g_fail; if (g_fail < 10) { printf("FAIL line %d: ", __LINE__); printf(__VA_ARGS__); printf("\n"); } } } while (0)
+
+template<class M1, class M2>
+static void compareMesh(const M1& a, const M2& b, bool posAliased, const char* what)
+{
+	CHECK(a.m_NumVertices == b.m_NumVertices && a.m_NumIndices == b.m_NumIndices, "%s counts %u/%u vs %u/%u", what, a.m_NumVertices, a.m_NumIndices, b.m_NumVertices, b.m_NumIndices);
+	if (a.m_NumVertices != b.m_NumVertices || a.m_NumIndices != b.m_NumIndices) { return; }
+	CHECK(memcmp(a.m_IndexBuffer, b.m_IndexBuffer, a.m_NumIndices * 2) == 0, "%s indices", what);
+	CHECK(memcmp(a.m_PosBuffer, b.m_PosBuffer, a.m_NumVertices * 8) == 0, "%s positions", what);
+	CHECK((a.m_ColorBuffer == nullptr) == (b.m_ColorBuffer == nullptr), "%s colour presence", what);
+	if (a.m_ColorBuffer && b.m_ColorBuffer) { CHECK(memcmp(a.m_ColorBuffer, b.m_ColorBuffer, a.m_NumVertices * 4) == 0, "%s colours", what); }
+	(void)posAliased;
+}
+
+int main()
+{
+	bx::ShimAllocator alloc;
+	vg::Path* gp = vg::createPath(nullptr);
+	vg::Stroker* gs = vg::createStroker(nullptr);
+	if (!gp || !gs) { printf("no device\n"); return 2; }
+	vgo::Path* op = vgo::createPath(&alloc);
+	vgo::Stroker* os = vgo::createStroker(&alloc);
+
+	for (int iter = 0; iter < 60; ++iter) {
+		const float scale = (iter % 3 == 0) ? 2.0f : 1.0f, tol = (iter % 4 == 0) ? 0.1f : 0.25f, fringe = (iter % 5 == 0) ? 0.5f : 1.0f;
+		vg::pathReset(gp, scale, tol); vgo::pathReset(op, scale, tol);
+		vg::strokerReset(gs, scale, tol, fringe); vgo::strokerReset(os, scale, tol, fringe);
+		const uint32_t nsub = 1 + irand(3);
+		for (uint32_t s = 0; s < nsub; ++s) {
+			const float sz = (irand(2) ? 20.0f : 200.0f);
+			const float ox = frand(-50, 50), oy = frand(-50, 50);
+			const uint32_t shape = irand(8);
+			if (shape == 0) { vg::pathRect(gp, ox, oy, frand(1, sz), frand(1, sz)); vgo::pathRect(op, ox, oy, 0, 0); }
+			if (shape == 0) { // keep both in sync: re-issue with identical arguments
+				vgo::pathReset(op, scale, tol); vg::pathReset(gp, scale, tol);
+				const float w = frand(1, sz), h = frand(1, sz);
+				vg::pathRect(gp, ox, oy, w, h); vgo::pathRect(op, ox, oy, w, h);
+				continue;
+			}
+			if (shape == 1) { const float w = frand(5, sz), h = frand(5, sz), r = frand(0, sz * 0.5f); vg::pathRoundedRect(gp, ox, oy, w, h, r); vgo::pathRoundedRect(op, ox, oy, w, h, r); continue; }
+			if (shape == 2) { const float r = frand(1, sz); vg::pathCircle(gp, ox, oy, r); vgo::pathCircle(op, ox, oy, r); continue; }
+			if (shape == 3) { const float w = frand(5, sz), h = frand(5, sz), a = frand(0, 10), b = frand(0, 10), c = frand(0, 10), d = frand(0, 10); vg::pathRoundedRectVarying(gp, ox, oy, w, h, a, b, c, d); vgo::pathRoundedRectVarying(op, ox, oy, w, h, a, b, c, d); continue; }
+			vg::pathMoveTo(gp, ox, oy); vgo::pathMoveTo(op, ox, oy);
+			const uint32_t ncmd = 1 + irand(10);
+			for (uint32_t c = 0; c < ncmd; ++c) {
+				const float x = ox + frand(-sz, sz), y = oy + frand(-sz, sz);
+				const uint32_t t = irand(5);
+				if (t == 0) { vg::pathLineTo(gp, x, y); vgo::pathLineTo(op, x, y); }
+				else if (t <= 2) { const float a = frand(-sz, sz), b = frand(-sz, sz), cc = frand(-sz, sz), d = frand(-sz, sz); vg::pathCubicTo(gp, ox + a, oy + b, ox + cc, oy + d, x, y); vgo::pathCubicTo(op, ox + a, oy + b, ox + cc, oy + d, x, y); }
+				else if (t == 3) { const float a = frand(-sz, sz), b = frand(-sz, sz); vg::pathQuadraticTo(gp, ox + a, oy + b, x, y); vgo::pathQuadraticTo(op, ox + a, oy + b, x, y); }
+				else { const float a = frand(-sz, sz), b = frand(-sz, sz), r = frand(1, sz * 0.3f); vg::pathArcTo(gp, ox + a, oy + b, x, y, r); vgo::pathArcTo(op, ox + a, oy + b, x, y, r); }
+			}
+			if (irand(2)) { vg::pathClose(gp); vgo::pathClose(op); }
+		}
+		const uint32_t nv = vg::pathGetNumVertices(gp), nsp = vg::pathGetNumSubPaths(gp);
+		CHECK(vg::vgxCompatLastStatus(gp) == 0, "path status %d", vg::vgxCompatLastStatus(gp));
+		CHECK(nv == vgo::pathGetNumVertices(op) && nsp == vgo::pathGetNumSubPaths(op), "iter %d path counts %u/%u vs %u/%u", iter, nv, nsp, vgo::pathGetNumVertices(op), vgo::pathGetNumSubPaths(op));
+		if (nv != vgo::pathGetNumVertices(op) || nsp != vgo::pathGetNumSubPaths(op)) { continue; }
+		CHECK(memcmp(vg::pathGetVertices(gp), vgo::pathGetVertices(op), nv * 8) == 0, "iter %d path vertices", iter);
+		const vg::SubPath* gsp = vg::pathGetSubPaths(gp);
+		const vgo::SubPath* osp = vgo::pathGetSubPaths(op);
+		for (uint32_t i = 0; i < nsp; ++i) {
+			CHECK(gsp[i].m_FirstVertexID == osp[i].m_FirstVertexID && gsp[i].m_NumVertices == osp[i].m_NumVertices && gsp[i].m_IsClosed == osp[i].m_IsClosed, "iter %d sub-path %u", iter, i);
+			const float* vtx = vg::pathGetVertices(gp) + 2 * gsp[i].m_FirstVertexID;
+			const uint32_t n = gsp[i].m_NumVertices;
+			const bool closed = gsp[i].m_IsClosed;
+			const uint32_t color = 0x80000000u | g_rng;
+			const float width = (irand(2) ? 3.0f : 12.0f) * scale;
+			const vg::LineCap::Enum cap = (vg::LineCap::Enum)irand(3);
+			const vg::LineJoin::Enum join = (vg::LineJoin::Enum)irand(3);
+			vg::Mesh gm; vgo::Mesh om;
+			if (n >= 2) {
+				vg::strokerPolylineStrokeAA(gs, &gm, vtx, n, closed, color, width, cap, join);
+				vgo::strokerPolylineStrokeAA(os, &om, vtx, n, closed, color, width, (vgo::LineCap::Enum)cap, (vgo::LineJoin::Enum)join);
+				compareMesh(gm, om, false, "strokeAA");
+				vg::strokerPolylineStroke(gs, &gm, vtx, n, closed, width, cap, join);
+				vgo::strokerPolylineStroke(os, &om, vtx, n, closed, width, (vgo::LineCap::Enum)cap, (vgo::LineJoin::Enum)join);
+				compareMesh(gm, om, false, "stroke");
+				vg::strokerPolylineStrokeAAThin(gs, &gm, vtx, n, closed, color, cap, join);
+				vgo::strokerPolylineStrokeAAThin(os, &om, vtx, n, closed, color, (vgo::LineCap::Enum)cap, (vgo::LineJoin::Enum)join);
+				compareMesh(gm, om, false, "strokeThin");
+			}
+			if (n >= 3) {
+				vg::strokerConvexFillAA(gs, &gm, vtx, n, color);
+				vgo::strokerConvexFillAA(os, &om, vtx, n, color);
+				compareMesh(gm, om, false, "fillAA");
+				vg::strokerConvexFill(gs, &gm, vtx, n);
+				vgo::strokerConvexFill(os, &om, vtx, n);
+				compareMesh(gm, om, true, "fill");
+				CHECK(gm.m_PosBuffer == vtx, "convexFill aliases the caller's vertex list");
+			}
+		}
+	}
+	// invalid stroke configuration leaves the mesh untouched (reference stroker.cpp:269-271)
+	{
+		const float tri[] = { 0, 0, 10, 0, 10, 10 };
+		vg::Mesh m; memset(&m, 0x5A, sizeof(m)); vg::Mesh before = m;
+		vg::strokerPolylineStrokeAA(gs, &m, tri, 3, false, 0xFFFFFFFFu, 4.0f, (vg::LineCap::Enum)3, vg::LineJoin::Miter);
+		CHECK(memcmp(&m, &before, sizeof(m)) == 0, "invalid cap must not touch the mesh");
+	}
+	// grammar the reference leaves undefined: empty result + status instead of UB
+	{
+		vg::pathReset(gp, 1.0f, 0.25f);
+		vg::pathLineTo(gp, 1, 1);
+		CHECK(vg::pathGetNumVertices(gp) == 0 && vg::vgxCompatLastStatus(gp) == 2, "lineTo before moveTo");
+	}
+	vg::destroyStroker(gs); vg::destroyPath(gp);
+	vgo::destroyStroker(os); vgo::destroyPath(op);
+	printf("%s: %d checks, %d failures\n", g_fail ? "FAILED" : "OK", g_checks, g_fail);
+	return g_fail ? 1 : 0;
+}

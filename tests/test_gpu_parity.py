@@ -104,3 +104,36 @@ def test_async_entry_point_matches_two_phase(rt, gpu_ctx, wl):
     torch.cuda.synchronize()
     assert int(small.dev_status.item()) == 4  # VGX_E_NOSPACE
     pset.close()
+
+
+@pytest.mark.parametrize("seed", [200, 201, 202])
+def test_stroker_level_entry(rt, gpu_ctx, wl, oracle, seed):
+    """vgx_stroke_*: the strokerXXX-level boundary (vertex lists in, meshes out). Feed it the oracle's own
+    transformed polylines and compare every mesh with the oracle's mesh for the same (draw, sub-path, kind)."""
+    import torch
+    ps = wl.fuzz_paths(seed, npaths=64)
+    d = wl.fuzz_draws(ps, seed)
+    ref = oracle.tessellate(ps, d, want_flat=True)
+    nsubs = ref.subpaths.shape[0]
+    sub_draw = np.repeat(np.arange(d.shape[0], dtype=np.int32), ref.draw_info["num_subpaths"])
+    poly = torch.from_numpy(ref.poly.copy()).cuda()
+    subs = torch.from_numpy(ref.subpaths.view(np.uint8).copy()).cuda()
+    sd = torch.from_numpy(sub_draw).cuda()
+    dd = rt.upload_draws(d)
+    got = rt.stroke(gpu_ctx, poly, subs, sd, nsubs, dd, d.shape[0])
+    assert got.sizes["num_meshes"] == ref.sizes["num_meshes"]
+    assert got.sizes["num_vertices"] == ref.sizes["num_vertices"] and got.sizes["num_indices"] == ref.sizes["num_indices"]
+    sub0 = ref.draw_info["first_subpath"]
+    key_ref = {}
+    for m in ref.meshes:
+        dr = int(m["draw"])
+        gsub = int(sub0[dr]) + (int(m["subpath_kind"]) & 0x0FFFFFFF)
+        key_ref[(gsub, int(m["subpath_kind"]) >> 28)] = m
+    for m in got.meshes:
+        r = key_ref[(int(m["subpath_kind"]) & 0x0FFFFFFF, int(m["subpath_kind"]) >> 28)]
+        assert int(m["num_vertices"]) == int(r["num_vertices"]) and int(m["num_indices"]) == int(r["num_indices"])
+        gv, gi, rv, ri = int(m["first_vertex"]), int(m["first_index"]), int(r["first_vertex"]), int(r["first_index"])
+        nv, ni = int(m["num_vertices"]), int(m["num_indices"])
+        assert np.array_equal(got.idx[gi:gi + ni], ref.idx[ri:ri + ni])
+        assert np.array_equal(got.color[gv:gv + nv], ref.color[rv:rv + nv])
+        assert np.array_equal(got.pos[gv:gv + nv].view(np.uint32), ref.pos[rv:rv + nv].view(np.uint32))

@@ -8,6 +8,7 @@
 // entry point vgx_tessellate never synchronises with the host.
 #include "vgx_internal.h"
 #include "vgx_scan.h"
+#include "vgx_pathsim.h"
 #include <vector>
 #include <string.h>
 #include <math.h>
@@ -219,6 +220,55 @@ struct OpMeshTab // per-mesh vertex / index counts -> first_vertex / first_index
 	}
 };
 
+struct OpSubMeshes // stroker-level entry: one or two meshes per vertex list -> mesh descriptors + closed-form sizes
+{
+	const vgx_subpath* subs;
+	const uint32_t* subDraw;
+	const vgx_draw* draws;
+	uint64_t nsubs, ndraws;
+	VgxMeshDesc* mdesc;
+	vgx_mesh* mtab;
+	VgxTotals* totals;
+	__device__ uint64_t size() const { return nsubs; }
+	__device__ Sum3 load(uint64_t i) const
+	{
+		Sum3 r = sum3_zero();
+		const uint32_t di = subDraw[i];
+		if (di >= ndraws) { set_status(totals, VGX_E_INVALID_ARG); return r; }
+		const vgx_draw* d = draws + di;
+		const uint32_t n = subs[i].num_vertices;
+		const uint32_t sf = d->stroke_flags;
+		if ((sf & VGX_STROKE_ENABLE) && (VGX_STROKE_CAP(sf) > 2u || VGX_STROKE_JOIN(sf) > 2u)) { set_status(totals, VGX_E_INVALID_ARG); return r; }
+		r.a = (((d->fill_flags & VGX_FILL_ENABLE) && n >= 3) ? 1u : 0u) + (((sf & VGX_STROKE_ENABLE) && n >= 2) ? 1u : 0u);
+		r.b = n;
+		return r;
+	}
+	__device__ void store(uint64_t i, Sum3 e) const
+	{
+		const uint32_t di = subDraw[i];
+		if (di >= ndraws) { return; }
+		const vgx_draw* d = draws + di;
+		const vgx_subpath sp = subs[i];
+		const bool closed = (sp.flags & 1u) != 0;
+		uint64_t m = e.a;
+		if ((d->fill_flags & VGX_FILL_ENABLE) && sp.num_vertices >= 3) {
+			vgx_write_mesh(mdesc, mtab, m, d, di, (uint32_t)i, (d->fill_flags & VGX_FILL_AA) ? VGX_MESH_FILL_AA : VGX_MESH_FILL, closed, sp.first_vertex, sp.num_vertices);
+			++m;
+		}
+		const uint32_t sf = d->stroke_flags;
+		if ((sf & VGX_STROKE_ENABLE) && sp.num_vertices >= 2) {
+			const uint32_t k = !(sf & VGX_STROKE_AA) ? VGX_MESH_STROKE : ((sf & VGX_STROKE_THIN) ? VGX_MESH_STROKE_AA_THIN : VGX_MESH_STROKE_AA);
+			if (vgx_write_mesh(mdesc, mtab, m, d, di, (uint32_t)i, k, closed, sp.first_vertex, sp.num_vertices)) { atomicAdd(&totals->num_round_meshes, 1u); }
+		}
+	}
+	__device__ void finish(Sum3 t) const
+	{
+		totals->sizes.num_meshes = t.a;
+		totals->sizes.num_poly_vertices = t.b;
+		totals->sizes.num_subpaths = nsubs;
+	}
+};
+
 __global__ void k_publish(const VgxTotals* t, vgx_sizes* devSizes, uint32_t* devStatus)
 {
 	if (devSizes) { *devSizes = t->sizes; }
@@ -287,14 +337,14 @@ void runFlattenCount(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 	mark(ctx, s, "scan_draws");
 }
 
-void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps, int checkCaps, hipStream_t s)
+void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps, int checkCaps, hipStream_t s, const float* poly = nullptr)
 {
 	OpElemPrefix ope;
 	ope.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; ope.prefixFill = (uint64_t*)ctx->elemPrefix.p; ope.prefixStroke = (uint64_t*)ctx->elemPrefixS.p; ope.totals = (VgxTotals*)ctx->totals.p;
 	vgx_device_scan(ope, (Sum3*)ctx->partial.p, s);
 	mark(ctx, s, "scan_elements");
 	VgxStrokeArgs a;
-	a.draws = draws; a.poly = (const float*)ctx->poly.p; a.mdesc = (const VgxMeshDesc*)ctx->mdesc.p;
+	a.draws = draws; a.poly = poly ? poly : (const float*)ctx->poly.p; a.mdesc = (const VgxMeshDesc*)ctx->mdesc.p;
 	a.elem_prefix = nullptr; a.elem_prefix_fill = (const uint64_t*)ctx->elemPrefix.p; a.elem_prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
 	a.mprep = (VgxMeshPrep*)ctx->mprep.p; a.mtab = (vgx_mesh*)ctx->mtab.p;
 	a.pos = nullptr; a.color = nullptr; a.idx = nullptr; a.meshes_out = nullptr; a.stage_output = 0;
@@ -307,10 +357,10 @@ void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps,
 	mark(ctx, s, "scan_meshes");
 }
 
-void runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out, hipStream_t s)
+void runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out, hipStream_t s, const float* poly = nullptr)
 {
 	VgxStrokeArgs a;
-	a.draws = draws; a.poly = (const float*)ctx->poly.p; a.mdesc = (const VgxMeshDesc*)ctx->mdesc.p;
+	a.draws = draws; a.poly = poly ? poly : (const float*)ctx->poly.p; a.mdesc = (const VgxMeshDesc*)ctx->mdesc.p;
 	a.elem_prefix = nullptr; a.elem_prefix_fill = (const uint64_t*)ctx->elemPrefix.p; a.elem_prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
 	a.mprep = (VgxMeshPrep*)ctx->mprep.p; a.mtab = (vgx_mesh*)ctx->mtab.p;
 	a.pos = out->pos; a.color = out->color; a.idx = out->idx; a.meshes_out = out->meshes;
@@ -753,6 +803,55 @@ int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 	if (dev_sizes || dev_status) {
 		hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, s, (const VgxTotals*)ctx->totals.p, dev_sizes, dev_status);
 	}
+	return VGX_OK;
+}
+
+// ---- stroker-level entry ------------------------------------------------------------------------------
+int vgx_stroke_count(vgx_ctx* ctx, const float* poly, const vgx_subpath* subpaths, const uint32_t* subpath_draw, uint64_t nsubpaths, const vgx_draw* draws, uint64_t ndraws, vgx_sizes* out_sizes, void* stream)
+{
+	if (!ctx || !out_sizes || (nsubpaths && (!poly || !subpaths || !subpath_draw || !draws))) {
+		return VGX_E_INVALID_ARG;
+	}
+	hipStream_t s = (hipStream_t)stream;
+	markBegin(ctx, s);
+	ctx->lastStage = 0;
+	int st;
+	if ((st = ensure(ctx, ctx->partial, VGX_SCAN_BLOCKS * sizeof(Sum3))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->totals, sizeof(VgxTotals))) != VGX_OK) { return st; }
+	// at most two meshes per vertex list: scratch can be sized without a device round trip
+	if ((st = ensureMeshBuffers(ctx, 0, 0, 2 * nsubpaths)) != VGX_OK) { return st; }
+	(void)hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s);
+	OpSubMeshes op;
+	op.subs = subpaths; op.subDraw = subpath_draw; op.draws = draws; op.nsubs = nsubpaths; op.ndraws = ndraws;
+	op.mdesc = (VgxMeshDesc*)ctx->mdesc.p; op.mtab = (vgx_mesh*)ctx->mtab.p; op.totals = (VgxTotals*)ctx->totals.p;
+	vgx_device_scan(op, (Sum3*)ctx->partial.p, s);
+	mark(ctx, s, "scan_subpath_meshes");
+	VgxCaps outCaps = ctx->caps;
+	outCaps.vertices = ~0ull; outCaps.indices = ~0ull;
+	runStrokeCount(ctx, draws, outCaps, 0, s, poly);
+	if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
+	*out_sizes = ctx->hostTotals->sizes;
+	if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; }
+	ctx->lastPs = nullptr; ctx->lastDraws = draws; ctx->lastNDraws = nsubpaths; ctx->lastStage = 3;
+	return VGX_OK;
+}
+
+int vgx_stroke_emit(vgx_ctx* ctx, const float* poly, const vgx_subpath* subpaths, const uint32_t* subpath_draw, uint64_t nsubpaths, const vgx_draw* draws, uint64_t ndraws, const vgx_mesh_out* out, void* stream)
+{
+	(void)subpaths; (void)subpath_draw; (void)ndraws;
+	if (!ctx || !out || !out->pos || !out->color || !out->idx) {
+		return VGX_E_INVALID_ARG;
+	}
+	if (ctx->lastStage != 3 || ctx->lastDraws != draws || ctx->lastNDraws != nsubpaths) {
+		return VGX_E_INVALID_ARG; // must follow vgx_stroke_count on the same batch
+	}
+	const vgx_sizes& sz = ctx->hostTotals->sizes;
+	if (out->cap_vertices < sz.num_vertices || out->cap_indices < sz.num_indices || (out->meshes && out->cap_meshes < sz.num_meshes)) {
+		return VGX_E_NOSPACE;
+	}
+	hipStream_t s = (hipStream_t)stream;
+	markBegin(ctx, s);
+	runStrokeEmit(ctx, draws, out, s, poly);
 	return VGX_OK;
 }
 

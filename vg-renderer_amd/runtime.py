@@ -207,3 +207,28 @@ def tessellate(ctx, pset, draws_dev, ndraws, to_host=True):
         r.idx = bufs.idx[:ni].cpu().numpy().view(np.uint16)
         r.meshes = bufs.meshes[:nm * 32].cpu().numpy().view(capi.mesh_dtype)
     return r
+
+
+def stroke(ctx, poly_dev, subs_dev, subdraw_dev, nsubs, draws_dev, ndraws, to_host=True):
+    """Stroker-level entry (vgx_stroke_count + vgx_stroke_emit): already flattened + transformed vertex lists in,
+    meshes out. poly_dev float32 [n,2], subs_dev uint8 (16-byte vgx_subpath records), subdraw_dev int32 [nsubs]."""
+    import torch
+    L = lib()
+    sizes = capi.Sizes()
+    s = _stream_ptr()
+    _check(L.vgx_stroke_count(ctx.handle, poly_dev.data_ptr(), subs_dev.data_ptr(), subdraw_dev.data_ptr(), nsubs, draws_dev.data_ptr(), ndraws, C.byref(sizes), s), "vgx_stroke_count")
+    sz = sizes.as_dict()
+    bufs = MeshBuffers(poly_dev.device, sz["num_vertices"], sz["num_indices"], sz["num_meshes"])
+    out = bufs.out_struct()
+    _check(L.vgx_stroke_emit(ctx.handle, poly_dev.data_ptr(), subs_dev.data_ptr(), subdraw_dev.data_ptr(), nsubs, draws_dev.data_ptr(), ndraws, C.byref(out), s), "vgx_stroke_emit")
+    torch.cuda.synchronize()
+    r = MeshResult()
+    r.sizes = sz
+    r.bufs = bufs
+    if to_host:
+        nv, ni, nm = sz["num_vertices"], sz["num_indices"], sz["num_meshes"]
+        r.pos = bufs.pos[:nv].cpu().numpy()
+        r.color = bufs.color[:nv].cpu().numpy().view(np.uint32)
+        r.idx = bufs.idx[:ni].cpu().numpy().view(np.uint16)
+        r.meshes = bufs.meshes[:nm * 32].cpu().numpy().view(capi.mesh_dtype)
+    return r

@@ -137,3 +137,53 @@ def test_stroker_level_entry(rt, gpu_ctx, wl, oracle, seed):
         assert np.array_equal(got.idx[gi:gi + ni], ref.idx[ri:ri + ni])
         assert np.array_equal(got.color[gv:gv + nv], ref.color[rv:rv + nv])
         assert np.array_equal(got.pos[gv:gv + nv].view(np.uint32), ref.pos[rv:rv + nv].view(np.uint32))
+
+
+@pytest.mark.parametrize("seed", [300, 301, 302, 303, 304, 305])
+def test_async_single_pass_fuzz(rt, gpu_ctx, wl, oracle, seed):
+    """vgx_tessellate (steady-state entry: single-pass flatten into the polyline heap, no host round trip) on fuzz
+    batches with every command / stroker kind, against the oracle."""
+    import torch
+    ps = wl.fuzz_paths(seed, npaths=96)
+    d = wl.fuzz_draws(ps, seed)
+    d = np.concatenate([d, d[::-1], d])  # several instances, different order
+    ref = oracle.tessellate(ps, d)
+    pset = rt.PathSet(gpu_ctx, ps)
+    dd = rt.upload_draws(d)
+    sizes = rt.tessellate_count(gpu_ctx, pset, dd, d.shape[0])
+    assert sizes["num_vertices"] == ref.sizes["num_vertices"]
+    bufs = rt.MeshBuffers(dd.device, sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"])
+    bufs.pos.fill_(float("nan"))
+    rt.tessellate_async(gpu_ctx, pset, dd, d.shape[0], bufs)
+    torch.cuda.synchronize()
+    assert int(bufs.dev_status.item()) == 0
+    nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
+
+    class G:
+        pass
+    got = G()
+    got.sizes = sizes
+    got.pos = bufs.pos[:nv].cpu().numpy()
+    got.color = bufs.color[:nv].cpu().numpy().view(np.uint32)
+    got.idx = bufs.idx[:ni].cpu().numpy().view(np.uint16)
+    got.meshes = bufs.meshes[:nm * 32].cpu().numpy().view(rt.capi.mesh_dtype)
+    assert_mesh_equal(got, ref, "async fuzz seed=%d" % seed)
+    pset.close()
+
+
+def test_async_single_pass_long_paths(rt, gpu_ctx, wl, oracle):
+    """Draws larger than a heap block (exactly sized regions) and many-chunk segments."""
+    import torch
+    ps, d = wl.random_walk_polylines(n=12, nseg=5000, seed=99, cap=1, join=1)
+    ref = oracle.tessellate(ps, d)
+    pset = rt.PathSet(gpu_ctx, ps)
+    dd = rt.upload_draws(d)
+    sizes = rt.tessellate_count(gpu_ctx, pset, dd, d.shape[0])
+    bufs = rt.MeshBuffers(dd.device, sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"])
+    rt.tessellate_async(gpu_ctx, pset, dd, d.shape[0], bufs)
+    torch.cuda.synchronize()
+    assert int(bufs.dev_status.item()) == 0
+    nv, ni = sizes["num_vertices"], sizes["num_indices"]
+    assert np.array_equal(bufs.idx[:ni].cpu().numpy().view(np.uint16), ref.idx)
+    assert np.array_equal(bufs.pos[:nv].cpu().numpy().view(np.uint32), ref.pos.view(np.uint32))
+    pset.close()

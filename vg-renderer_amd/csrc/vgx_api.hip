@@ -15,7 +15,14 @@
 #include <new>
 #include <stdlib.h>
 
-#define VGX_GRID_BLOCKS 32768 // one-wave workgroups, each owning a contiguous run of segments (>> resident waves: no tail)
+
+static int vgxGridBlocks()
+{
+	static int g = 0;
+	if (!g) { const char* e = getenv("VGX_GRID_BLOCKS"); g = e ? atoi(e) : 32768; if (g < 256) { g = 256; } }
+	return g;
+}
+#define VGX_GRID_BLOCKS vgxGridBlocks() // one-wave workgroups, each owning a contiguous run of segments (>> resident waves: no tail)
 
 struct vgx_pathset
 {
@@ -36,7 +43,7 @@ struct vgx_ctx
 	int device;
 	int lastHipError;
 	// grow-only device scratch
-	DevBuf cmdPrefix, cmdCnt, dinfo, poly, subs, mdesc, elemPrefix, elemPrefixS, mprep, mtab, partial, totals;
+	DevBuf cmdPrefix, cmdCnt, subFirst, leafOverflow, dinfo, poly, subs, mdesc, elemPrefix, elemPrefixS, mprep, mtab, partial, totals;
 	VgxCaps caps; // element capacities matching the buffers above
 	uint64_t capDraws;
 	VgxTotals* hostTotals; // pinned
@@ -150,6 +157,7 @@ struct OpDrawInfo // per-draw polyline / sub-path / mesh counts -> first_* field
 	uint64_t ndraws;
 	VgxTotals* totals;
 	VgxCaps caps;
+	int keepPolyBase; // BUILD mode: first_poly_vertex already holds the draw's heap position
 	__device__ uint64_t size() const { return totals->status == VGX_OK ? ndraws : 0; }
 	__device__ Sum3 load(uint64_t i) const
 	{
@@ -161,7 +169,8 @@ struct OpDrawInfo // per-draw polyline / sub-path / mesh counts -> first_* field
 	__device__ void store(uint64_t i, Sum3 e) const
 	{
 		vgx_draw_info* d = dinfo + i;
-		d->first_poly_vertex = e.a; d->first_subpath = e.b; d->first_mesh = e.c;
+		if (!keepPolyBase) { d->first_poly_vertex = e.a; }
+		d->first_subpath = e.b; d->first_mesh = e.c;
 	}
 	__device__ void finish(Sum3 t) const
 	{
@@ -169,7 +178,7 @@ struct OpDrawInfo // per-draw polyline / sub-path / mesh counts -> first_* field
 		totals->sizes.num_subpaths = t.b;
 		totals->sizes.num_meshes = t.c;
 		totals->sizes.num_serial_draws = t.d;
-		if (t.a > caps.poly_vertices || t.b > caps.subpaths || t.c > caps.meshes) { set_status(totals, VGX_E_NOSPACE); }
+		if ((!keepPolyBase && t.a > caps.poly_vertices) || t.b > caps.subpaths || t.c > caps.meshes) { set_status(totals, VGX_E_NOSPACE); }
 	}
 };
 
@@ -292,6 +301,10 @@ VgxFlattenArgs flattenArgs(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* 
 	a.totals = (VgxTotals*)ctx->totals.p;
 	a.caps = ctx->caps;
 	a.apply_transform = applyTransform;
+	a.sub_first = (unsigned long long*)ctx->subFirst.p;
+	a.sub_info = (uint32_t*)ctx->cmdCnt.p;
+	a.build_mode = 0;
+	a.leaf_overflow = (float*)ctx->leafOverflow.p;
 	return a;
 }
 
@@ -332,9 +345,25 @@ void runFlattenCount(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 	vgx_launch_flatten(false, a, VGX_GRID_BLOCKS, s);
 	mark(ctx, s, "flatten_count");
 	OpDrawInfo op;
-	op.dinfo = (vgx_draw_info*)ctx->dinfo.p; op.ndraws = ndraws; op.totals = (VgxTotals*)ctx->totals.p; op.caps = ctx->caps;
+	op.dinfo = (vgx_draw_info*)ctx->dinfo.p; op.ndraws = ndraws; op.totals = (VgxTotals*)ctx->totals.p; op.caps = ctx->caps; op.keepPolyBase = 0;
 	vgx_device_scan(op, (Sum3*)ctx->partial.p, s);
 	mark(ctx, s, "scan_draws");
+}
+
+// single-pass flatten of the steady-state entry point: build (subdivide once, polyline -> heap) -> scan -> gather
+void runFlattenBuild(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, hipStream_t s)
+{
+	(void)hipMemsetAsync(ctx->dinfo.p, 0, ndraws * sizeof(vgx_draw_info), s);
+	VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, 1);
+	a.build_mode = 1;
+	vgx_launch_flatten_build(a, s);
+	mark(ctx, s, "flatten_build");
+	OpDrawInfo op;
+	op.dinfo = (vgx_draw_info*)ctx->dinfo.p; op.ndraws = ndraws; op.totals = (VgxTotals*)ctx->totals.p; op.caps = ctx->caps; op.keepPolyBase = 1;
+	vgx_device_scan(op, (Sum3*)ctx->partial.p, s);
+	mark(ctx, s, "scan_draws");
+	vgx_launch_flatten_gather(a, s);
+	mark(ctx, s, "flatten_gather");
 }
 
 void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps, int checkCaps, hipStream_t s, const float* poly = nullptr)
@@ -452,7 +481,7 @@ int vgx_destroy(vgx_ctx* ctx)
 	if (!ctx) {
 		return VGX_E_INVALID_ARG;
 	}
-	DevBuf* bufs[] = { &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DevBuf* bufs[] = { &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
@@ -471,7 +500,7 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx)
 	if (!ctx) {
 		return 0;
 	}
-	return ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
+	return ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
 }
 
 // ---- path set ---------------------------------------------------------------------------------------
@@ -612,9 +641,14 @@ int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset**
 			r.start[0] = ao >= 2 ? desc->args[ao - 2] : 0.0f;
 			r.start[1] = ao >= 2 ? desc->args[ao - 1] : 0.0f;
 			for (uint32_t i = 0; i < 8; ++i) { r.a[i] = (i < r.na && r.type != VGX_CMD_POLYLINE) ? desc->args[ao + i] : 0.0f; }
-			if (r.type == VGX_CMD_CLOSE) {
-				const uint32_t ho = desc->cmd_arg_off[spStart[c]];
-				r.a[6] = desc->args[ho]; r.a[7] = desc->args[ho + 1];
+			if (r.type <= VGX_CMD_CLOSE || r.type == VGX_CMD_POLYLINE) {
+				// first point of the command's sub-path (its MOVE_TO): pathClose's last-vs-first test (path.cpp:716-722)
+				// is evaluated by the CLOSE lane and by the lane in front of it
+				const uint32_t hc = spStart[c];
+				if (desc->cmd_type[hc] == VGX_CMD_MOVE_TO) {
+					const uint32_t ho = desc->cmd_arg_off[hc];
+					r.a[6] = desc->args[ho]; r.a[7] = desc->args[ho + 1];
+				}
 			}
 			r.pad[0] = 0.0f; r.pad[1] = 0.0f;
 		}
@@ -673,7 +707,10 @@ static int flattenCountCommon(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_dra
 	if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; }
 	const uint64_t ncmdInst = ctx->hostTotals->sizes.num_cmd_instances;
 	if ((st = ensure(ctx, ctx->cmdCnt, (ncmdInst + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->subFirst, (ncmdInst + 1) * sizeof(unsigned long long))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->leafOverflow, (size_t)VGX_BUILD_WAVES * VGX_BUILD_OVERFLOW * 64 * 2 * sizeof(float))) != VGX_OK) { return st; }
 	ctx->caps.cmd_instances = ctx->cmdCnt.cap / sizeof(uint32_t) - 1;
+	{ const uint64_t c2 = ctx->subFirst.cap / sizeof(unsigned long long) - 1; if (c2 < ctx->caps.cmd_instances) { ctx->caps.cmd_instances = c2; } }
 	// pass 2: per-draw counts (sizes polyline / sub-path / mesh scratch)
 	const VgxCaps saved = ctx->caps;
 	ctx->caps.poly_vertices = ~0ull; ctx->caps.subpaths = ~0ull; ctx->caps.meshes = ~0ull;
@@ -746,7 +783,9 @@ int vgx_tessellate_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* dr
 	int st = flattenCountCommon(ctx, ps, draws, ndraws, s);
 	if (st != VGX_OK) { return st; }
 	const vgx_sizes sz = ctx->hostTotals->sizes;
-	if ((st = ensureMeshBuffers(ctx, sz.num_poly_vertices, sz.num_subpaths, sz.num_meshes)) != VGX_OK) { return st; }
+	// polyline scratch doubles as the heap of the single-pass path: head room for block fragmentation
+	const uint64_t heapVerts = sz.num_poly_vertices + sz.num_poly_vertices / 4 + (uint64_t)VGX_BUILD_WAVES * VGX_BUILD_BLOCK;
+	if ((st = ensureMeshBuffers(ctx, heapVerts, sz.num_subpaths, sz.num_meshes)) != VGX_OK) { return st; }
 	VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, 1);
 	vgx_launch_flatten(true, a, VGX_GRID_BLOCKS, s);
 	mark(ctx, s, "flatten_emit");
@@ -783,17 +822,21 @@ int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 	if (!ctx || !ps || !out || (!draws && ndraws) || !out->pos || !out->color || !out->idx) {
 		return VGX_E_INVALID_ARG;
 	}
-	if (ndraws > ctx->capDraws || !ctx->cmdCnt.p || !ctx->poly.p || !ctx->mtab.p) {
+	if (ndraws > ctx->capDraws || !ctx->cmdCnt.p || !ctx->subFirst.p || !ctx->poly.p || !ctx->mtab.p) {
 		return VGX_E_NOSPACE; // scratch was never sized for a batch like this: run vgx_tessellate_count once
 	}
 	hipStream_t s = (hipStream_t)stream;
 	markBegin(ctx, s);
 	ctx->lastStage = 0;
 	runCmdPrefix(ctx, ps, draws, ndraws, s);
-	runFlattenCount(ctx, ps, draws, ndraws, s);
-	VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, 1);
-	vgx_launch_flatten(true, a, VGX_GRID_BLOCKS, s);
-	mark(ctx, s, "flatten_emit");
+	if (getenv("VGX_TWO_PASS_FLATTEN")) { // tuning / debugging knob: the ordered two-pass flatten
+		runFlattenCount(ctx, ps, draws, ndraws, s);
+		VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, 1);
+		vgx_launch_flatten(true, a, VGX_GRID_BLOCKS, s);
+		mark(ctx, s, "flatten_emit");
+	} else {
+		runFlattenBuild(ctx, ps, draws, ndraws, s);
+	}
 	VgxCaps outCaps = ctx->caps;
 	outCaps.vertices = out->cap_vertices;
 	outCaps.indices = out->cap_indices;

@@ -31,7 +31,7 @@ namespace {
 // ---- pending stack of the cubic DFS: the first VGX_LDS_LEVELS levels in LDS as [level][3 points][64 lanes]
 // float2 (lane-interleaved -> conflict free for any mix of levels), deeper levels (only very fine subdivisions
 // reach them) in per-lane private memory. Fewer LDS bytes per wave = more resident waves to hide latency.
-#define VGX_LDS_LEVELS 6
+#define VGX_LDS_LEVELS 4
 struct LdsStack
 {
 	float2* base; // &s_stack[lane]
@@ -402,6 +402,337 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 	}
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k_flatten_build -- single-pass flatten used by vgx_tessellate (steady state).
+//
+// The two-pass kernel above runs every subdivision twice (count -> scan over draws -> emit) because the ordered
+// polyline of the flatten API needs global offsets first. Inside vgx_tessellate the polyline is scratch: only a
+// sub-path's vertices must be contiguous. So this kernel subdivides ONCE:
+//   - each lane keeps the first VGX_LEAF_SLOTS leaves of its command in LDS (98 % of real-world cubics fit); after the
+//     chunk's prefix scan it copies them to the polyline HEAP (transformPos2D applied on the way); only lanes with more
+//     leaves re-run their subdivision writing straight to memory;
+//   - a wave owns a contiguous run of segments (whole draws) and places them back to back in wave-private blocks of a
+//     bump-allocated heap (one atomic per VGX_BUILD_BLOCK vertices, none per chunk); a segment that does not fit the
+//     current block is restarted in a fresh block (or in an exactly sized region if it is larger than a block);
+//   - per sub-path it records {first vertex, count, closed} sparsely at the command-instance index of the sub-path's
+//     last command; k_flatten_gather (after the scan over draws has produced ordered mesh indices) turns those into
+//     mesh descriptors in the reference's call order.
+// Degenerate / serial draws are flagged exactly as in the two-pass kernel and handled by k_flatten_serial.
+// ------------------------------------------------------------------------------------------------
+#define VGX_LEAF_SLOTS 8
+
+struct BuildCubicSink // counts leaves, detects the serial-path cases, keeps the first leaves in the lane's LDS slots
+{
+	V2 prev;
+	uint32_t n;
+	bool slow;
+	float2* slots; // &s_leaf[lane], stride VGX_WAVE
+	float2* over;  // &overflow[lane], stride VGX_WAVE: leaves VGX_LEAF_SLOTS .. VGX_LEAF_SLOTS + VGX_BUILD_OVERFLOW - 1
+	__device__ __forceinline__ void leaf(float x, float y)
+	{
+		slow = slow || v2near(prev, v2(x, y));
+		prev = v2(x, y);
+		if (n < VGX_LEAF_SLOTS) { slots[n * VGX_WAVE] = make_float2(x, y); }
+		else if (n < VGX_LEAF_SLOTS + VGX_BUILD_OVERFLOW) { over[(n - VGX_LEAF_SLOTS) * VGX_WAVE] = make_float2(x, y); }
+		++n;
+	}
+	__device__ __forceinline__ void dropped() { slow = true; }
+};
+
+__global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
+{
+	__shared__ float2 s_stack[VGX_LDS_LEVELS * 3 * VGX_WAVE];
+	__shared__ float2 s_leaf[VGX_LEAF_SLOTS * VGX_WAVE];
+	const int lane = threadIdx.x;
+	LdsStack stack;
+	stack.base = &s_stack[lane];
+
+	const VgxPathSetDev& ps = A.ps;
+	const uint64_t totalCmds = A.cmd_prefix[A.ndraws];
+	if (A.totals->status != VGX_OK) { return; }
+	const uint64_t numSegments = (totalCmds + VGX_WAVE - 1) / VGX_WAVE;
+	const uint64_t segsPerWave = (numSegments + gridDim.x - 1) / gridDim.x;
+	const uint64_t seg0 = (uint64_t)blockIdx.x * segsPerWave;
+	const uint64_t seg1 = (seg0 + segsPerWave < numSegments) ? seg0 + segsPerWave : numSegments;
+	if (seg0 >= seg1) {
+		return;
+	}
+	uint64_t dNext = lower_bound_u64(A.cmd_prefix, 0, A.ndraws, seg0 * VGX_WAVE);
+	uint64_t wbase = dNext;
+	DrawWindow W = draw_window_load(A, wbase, lane);
+	uint64_t blockCur = 0, blockEnd = 0; // wave-private heap block [blockCur, blockEnd)
+
+	for (uint64_t seg = seg0; seg < seg1; ++seg) {
+		const uint64_t d0 = dNext;
+		const uint64_t d1 = advance_lower_bound(A.cmd_prefix, d0, A.ndraws, (seg + 1) * VGX_WAVE, lane);
+		dNext = d1;
+		if (d0 == d1) {
+			continue;
+		}
+		const uint64_t C0 = A.cmd_prefix[d0];
+		const uint64_t C1 = A.cmd_prefix[d1];
+
+		for (int attempt = 0; attempt < 3; ++attempt) {
+			bool writing = true;     // false after the segment overflowed its block: keep counting, stop writing
+			uint64_t cur = blockCur; // next free heap vertex
+			uint64_t segTotal = 0;
+			uint64_t dcur = d0;
+			int carryDrawVerts = 0, carrySpVerts = 0, carrySubs = 0, carryFill = 0, carryStroke = 0, carrySlow = 0;
+
+			for (uint64_t chunk = C0; chunk < C1; chunk += VGX_WAVE) {
+				const uint64_t ci = chunk + lane;
+				const bool valid = ci < C1;
+				// ---- decode (same as k_flatten) ------------------------------------------------------
+				const uint64_t lastKey = chunk + (VGX_WAVE - 1);
+				if (!(__shfl((unsigned long long)W.prefix, VGX_WAVE - 1) > lastKey) || dcur < wbase) {
+					wbase = dcur;
+					W = draw_window_load(A, wbase, lane);
+				}
+				const bool windowCovers = __shfl((unsigned long long)W.prefix, VGX_WAVE - 1) > lastKey;
+				uint64_t ownerBase = 0;
+				const int ownerOfs = window_owner(W.prefix, valid ? ci : chunk, &ownerBase);
+				uint32_t pc0 = (uint32_t)__shfl((int)W.pc0, ownerOfs);
+				uint32_t serialStatic = (uint32_t)__shfl((int)W.serial, ownerOfs);
+				uint64_t d = d0;
+				uint32_t type = VGX_CMD_CLOSE, cflags = 0, na = 0;
+				bool drawHead = false, drawLast = false;
+				float scale = 1.0f, tol = 0.25f;
+				uint32_t fillFlags = 0, strokeFlags = 0;
+				const vgx_draw* dr = A.draws;
+				VgxCmdRec rec;
+				rec.type = VGX_CMD_CLOSE; rec.flags = 0; rec.na = 0; rec.arg_off = 0; rec.start[0] = 0.0f; rec.start[1] = 0.0f;
+				for (int i = 0; i < 8; ++i) { rec.a[i] = 0.0f; }
+				if (valid) {
+					if (windowCovers) {
+						d = wbase + (uint64_t)ownerOfs;
+					} else {
+						d = find_owner_u64(A.cmd_prefix, d0, d1, ci);
+						ownerBase = A.cmd_prefix[d];
+						const uint32_t path = A.draws[d].path;
+						pc0 = ps.path_cmd_begin[path];
+						serialStatic = ps.path_flags[path] & VGX_PF_SERIAL;
+					}
+					dr = A.draws + d;
+					const uint32_t k = (uint32_t)(ci - ownerBase);
+					rec = ps.cmdrec[pc0 + k];
+					type = rec.type; cflags = rec.flags; na = rec.na;
+					drawHead = (k == 0);
+					drawLast = (cflags & VGX_CF_LAST_IN_PATH) != 0;
+					scale = dr->scale; tol = dr->tess_tol;
+					fillFlags = dr->fill_flags; strokeFlags = dr->stroke_flags;
+				}
+				const bool serialDraw = serialStatic != 0;
+				const float* a = rec.a;
+				const float* pa = ps.args + rec.arg_off;
+				const float* mtx = dr->mtx;
+				const V2 start = v2(rec.start[0], rec.start[1]);
+
+				// ---- subdivide ONCE: count, detect degenerate cases, keep the first leaves in LDS -------
+				int cnt = 0;
+				bool slow = false, exists = false, closedHere = false;
+				float c1x = a[0], c1y = a[1], c2x = a[2], c2y = a[3], ex = a[4], ey = a[5];
+				if (valid && !serialDraw) {
+					switch (type) {
+					case VGX_CMD_MOVE_TO: cnt = 1; exists = true; break;
+					case VGX_CMD_LINE_TO: cnt = 1; slow = v2near(start, v2(a[0], a[1])); break;
+					case VGX_CMD_CUBIC_TO:
+					case VGX_CMD_QUAD_TO: {
+						if (type == VGX_CMD_QUAD_TO) {
+							ex = a[2]; ey = a[3];
+							vgx_quad_to_cubic(start.x, start.y, a[0], a[1], ex, ey, &c1x, &c1y, &c2x, &c2y);
+						}
+						BuildCubicSink sink;
+						sink.prev = start; sink.n = 0; sink.slow = false; sink.slots = &s_leaf[lane];
+						sink.over = (float2*)A.leaf_overflow + (size_t)blockIdx.x * VGX_BUILD_OVERFLOW * VGX_WAVE + lane;
+						vgx_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tol / (scale * scale), stack, sink);
+						cnt = (int)sink.n;
+						slow = sink.slow;
+					} break;
+					case VGX_CMD_POLYLINE: {
+						const uint32_t npts = na >> 1;
+						cnt = (int)npts - ((npts > 0 && v2near(start, v2(pa[0], pa[1]))) ? 1 : 0);
+						slow = cnt == 0;
+					} break;
+					default: break;
+					}
+				}
+				const int rawCnt = cnt;
+
+				// ---- segmented bookkeeping (same as the count pass of k_flatten) ---------------------------
+				const uint64_t drawHeads = wave_ballot(valid && drawHead);
+				const uint64_t subHeads = wave_ballot(valid && (cflags & VGX_CF_STARTS_SUB));
+				const int dh = seg_head(drawHeads, lane);
+				const int sh = seg_head(subHeads, lane);
+				{
+					const int incl1 = wave_incl_scan(cnt, lane);
+					const int spBefore1 = seg_rel(incl1 - cnt, sh, carrySpVerts);
+					if (valid && !serialDraw && type == VGX_CMD_CLOSE && spBefore1 > 2) { // pathClose, path.cpp:707-726
+						closedHere = true;
+						if (v2near(start, v2(rec.a[6], rec.a[7]))) { cnt = -1; } // pop: the previous vertex is removed
+					}
+				}
+				const int incl = wave_incl_scan(cnt, lane);
+				const int excl = incl - cnt;
+				const int inDrawBefore = seg_rel(excl, dh, carryDrawVerts);
+				const int spBefore = seg_rel(excl, sh, carrySpVerts);
+				const int spTotal = spBefore + cnt;
+				const uint64_t existMask = wave_ballot(valid && exists);
+				const uint64_t mine = seg_mask_upto(dh, lane);
+				const int subsIncl = __popcll(existMask & mine) + (dh < 0 ? carrySubs : 0);
+				const bool lastInSub = valid && !serialDraw && (cflags & VGX_CF_LAST_IN_SUB);
+				const uint64_t fillMask = wave_ballot(lastInSub && (fillFlags & VGX_FILL_ENABLE) && spTotal >= 3);
+				const uint64_t strokeMask = wave_ballot(lastInSub && (strokeFlags & VGX_STROKE_ENABLE) && spTotal >= 2);
+				const int fillIncl = __popcll(fillMask & mine) + (dh < 0 ? carryFill : 0);
+				const int strokeIncl = __popcll(strokeMask & mine) + (dh < 0 ? carryStroke : 0);
+				const uint64_t slowMask = wave_ballot(valid && slow);
+				const bool slowDraw = ((slowMask & mine) != 0) || (dh < 0 && carrySlow);
+
+				const int nvalid = (int)((C1 - chunk) < (uint64_t)VGX_WAVE ? (C1 - chunk) : (uint64_t)VGX_WAVE);
+				const int L = nvalid - 1;
+				const int chunkTotal = __shfl(incl, L);
+				if (writing && cur + (uint64_t)(chunkTotal > 0 ? chunkTotal : 0) > blockEnd) {
+					writing = false; // this segment does not fit the block any more: finish counting, then retry elsewhere
+				}
+				if (writing) {
+					const uint64_t g = cur + (uint64_t)excl; // heap index of my first vertex
+					if (valid && !serialDraw) {
+						// my last vertex is the one pathClose removes (same decision the CLOSE lane takes)
+						uint32_t limit = (uint32_t)(rawCnt < 0 ? 0 : rawCnt);
+						if ((cflags & VGX_CF_NEXT_IS_CLOSE) && limit > 0 && spTotal > 2) {
+							const V2 endp = (type == VGX_CMD_POLYLINE) ? v2(pa[na - 2], pa[na - 1]) : (type == VGX_CMD_CUBIC_TO ? v2(a[4], a[5]) : (type == VGX_CMD_QUAD_TO ? v2(a[2], a[3]) : v2(a[0], a[1])));
+							if (v2near(endp, v2(rec.a[6], rec.a[7]))) { --limit; }
+						}
+						float* out = A.poly + 2 * g;
+						if (type == VGX_CMD_MOVE_TO || type == VGX_CMD_LINE_TO) {
+							if (limit > 0) {
+								const V2 p = v2xform(v2(a[0], a[1]), mtx);
+								*(float2*)out = make_float2(p.x, p.y);
+							}
+						} else if (type == VGX_CMD_CUBIC_TO || type == VGX_CMD_QUAD_TO) {
+							if ((uint32_t)rawCnt <= VGX_LEAF_SLOTS + VGX_BUILD_OVERFLOW) {
+								const uint32_t nl = limit < VGX_LEAF_SLOTS ? limit : VGX_LEAF_SLOTS;
+								for (uint32_t i = 0; i < nl; ++i) {
+									const float2 q = s_leaf[i * VGX_WAVE + lane];
+									const V2 p = v2xform(v2(q.x, q.y), mtx);
+									*(float2*)(out + 2 * i) = make_float2(p.x, p.y);
+								}
+								const float2* ov = (const float2*)A.leaf_overflow + (size_t)blockIdx.x * VGX_BUILD_OVERFLOW * VGX_WAVE + lane;
+								for (uint32_t i = VGX_LEAF_SLOTS; i < limit; ++i) { // same lane wrote these during its subdivision
+									const float2 q = ov[(i - VGX_LEAF_SLOTS) * VGX_WAVE];
+									const V2 p = v2xform(v2(q.x, q.y), mtx);
+									*(float2*)(out + 2 * i) = make_float2(p.x, p.y);
+								}
+							} else { // more leaves than slots + overflow area: subdivide again, straight to memory
+								FastCubicSink<true, true> sink;
+								sink.prev = start; sink.n = 0; sink.slow = false; sink.out = out; sink.writeLimit = limit; sink.mtx = mtx;
+								vgx_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tol / (scale * scale), stack, sink);
+							}
+						} else if (type == VGX_CMD_POLYLINE) {
+							const uint32_t skip = (na >> 1) - (uint32_t)rawCnt;
+							for (uint32_t i = 0; i < limit; ++i) {
+								const V2 p = v2xform(v2(pa[2 * (i + skip)], pa[2 * (i + skip) + 1]), mtx);
+								*(float2*)(out + 2 * i) = make_float2(p.x, p.y);
+							}
+						}
+						if (lastInSub) { // sub-path record, consumed by k_flatten_gather
+							A.sub_first[ci] = g - (uint64_t)spBefore;
+							A.sub_info[ci] = (uint32_t)spTotal | (closedHere ? 0x80000000u : 0u);
+						}
+					}
+					if (valid && drawLast && !serialDraw) {
+						vgx_draw_info di;
+						di.first_poly_vertex = g - (uint64_t)inDrawBefore; di.first_subpath = 0; di.first_mesh = 0;
+						if (slowDraw) {
+							di.num_poly_vertices = 0; di.num_subpaths = 0; di.num_meshes = 0; di.flags = 1u;
+						} else {
+							di.num_poly_vertices = (uint32_t)(inDrawBefore + cnt);
+							di.num_subpaths = (uint32_t)subsIncl;
+							di.num_meshes = (uint32_t)(fillIncl + strokeIncl);
+							di.flags = ((uint32_t)fillIncl << 1);
+						}
+						A.dinfo[d] = di;
+					}
+					cur += (uint64_t)(chunkTotal > 0 ? chunkTotal : 0);
+				}
+				segTotal += (uint64_t)(chunkTotal > 0 ? chunkTotal : 0);
+
+				// carries into the next chunk
+				const int lastIsDrawLast = __shfl((int)drawLast, L);
+				const int lastIsSubLast = __shfl((int)((cflags & VGX_CF_LAST_IN_SUB) != 0), L);
+				const int nDraw = __shfl(inDrawBefore + cnt, L);
+				const int nSp = __shfl(spTotal, L);
+				const int nSubs = __shfl(subsIncl, L);
+				const int nFill = __shfl(fillIncl, L);
+				const int nStroke = __shfl(strokeIncl, L);
+				const int nSlow = __shfl((int)slowDraw, L);
+				carryDrawVerts = lastIsDrawLast ? 0 : nDraw;
+				carrySubs = lastIsDrawLast ? 0 : nSubs;
+				carryFill = lastIsDrawLast ? 0 : nFill;
+				carryStroke = lastIsDrawLast ? 0 : nStroke;
+				carrySlow = lastIsDrawLast ? 0 : nSlow;
+				carrySpVerts = (lastIsDrawLast || lastIsSubLast) ? 0 : nSp;
+				dcur = __shfl((unsigned long long)d, L);
+			}
+			if (writing) {
+				blockCur = cur;
+				break;
+			}
+			// the segment overflowed the block: take a fresh block (or an exactly sized region) and redo it
+			const uint64_t want = segTotal > (uint64_t)VGX_BUILD_BLOCK ? segTotal : (uint64_t)VGX_BUILD_BLOCK;
+			unsigned long long base = 0;
+			if (lane == 0) { base = atomicAdd(&A.totals->poly_heap_cursor, (unsigned long long)want); }
+			base = __shfl(base, 0);
+			if (base + want > A.caps.poly_vertices) {
+				if (lane == 0) { atomicCAS(&A.totals->status, (uint32_t)VGX_OK, (uint32_t)VGX_E_NOSPACE); }
+				return;
+			}
+			blockCur = base;
+			blockEnd = base + want;
+		}
+	}
+}
+
+// One lane per draw, after the scan over draws: turns the sparse sub-path records of k_flatten_build into mesh
+// descriptors (+ closed-form mesh-table sizes) at their ORDERED indices: fill meshes by sub-path, then stroke meshes
+// (the reference's call order, vg.cpp:3099-3131 then 3448-3485). Serial draws were written by k_flatten_serial.
+__global__ __launch_bounds__(256) void k_flatten_gather(VgxFlattenArgs A)
+{
+	if (A.totals->status != VGX_OK) { return; }
+	const VgxPathSetDev& ps = A.ps;
+	for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < A.ndraws; d += (uint64_t)gridDim.x * blockDim.x) {
+		const vgx_draw_info di = A.dinfo[d];
+		if ((di.flags & 1u) || di.num_meshes == 0) { continue; }
+		const vgx_draw* dr = A.draws + d;
+		const uint32_t path = dr->path;
+		const uint32_t pc0 = ps.path_cmd_begin[path], pc1 = ps.path_cmd_begin[path + 1];
+		const uint64_t cbase = A.cmd_prefix[d];
+		const uint32_t fillFlags = dr->fill_flags, strokeFlags = dr->stroke_flags;
+		const uint32_t numFill = di.flags >> 1;
+		uint32_t f = 0, s = 0, subIndex = 0;
+		for (uint32_t c = pc0; c < pc1; ++c) {
+			if (!(ps.cmd_flags[c] & VGX_CF_LAST_IN_SUB)) { continue; }
+			const uint64_t ci = cbase + (c - pc0);
+			const uint32_t info = A.sub_info[ci];
+			const uint32_t n = info & 0x7FFFFFFFu;
+			const bool closed = (info >> 31) != 0;
+			const uint64_t first = A.sub_first[ci];
+			if ((fillFlags & VGX_FILL_ENABLE) && n >= 3) {
+				vgx_write_mesh(A.mdesc, A.mtab, di.first_mesh + f, dr, (uint32_t)d, subIndex, (fillFlags & VGX_FILL_AA) ? VGX_MESH_FILL_AA : VGX_MESH_FILL, closed, first, n);
+				++f;
+			}
+			if ((strokeFlags & VGX_STROKE_ENABLE) && n >= 2) {
+				const uint32_t kd = !(strokeFlags & VGX_STROKE_AA) ? VGX_MESH_STROKE : ((strokeFlags & VGX_STROKE_THIN) ? VGX_MESH_STROKE_AA_THIN : VGX_MESH_STROKE_AA);
+				if (vgx_write_mesh(A.mdesc, A.mtab, di.first_mesh + numFill + s, dr, (uint32_t)d, subIndex, kd, closed, first, n)) {
+					atomicAdd(&A.totals->num_round_meshes, 1u);
+				}
+				++s;
+			}
+			++subIndex;
+		}
+	}
+}
+
 // ---- private (per-lane) pending stack for the serial kernel ---------------------------------------------
 struct PrivStack
 {
@@ -447,6 +778,10 @@ __global__ __launch_bounds__(256) void k_flatten_serial(VgxFlattenArgs A)
 			di.first_poly_vertex = 0; di.first_subpath = 0; di.first_mesh = 0;
 			di.num_poly_vertices = sim.nverts; di.num_subpaths = sim.nsubs; di.num_meshes = sim.nfill + sim.nstroke;
 			di.flags = 1u | (sim.nfill << 1);
+			if (A.build_mode) { // the polyline heap of the single-pass path: exact allocation for this draw
+				di.first_poly_vertex = atomicAdd(&A.totals->poly_heap_cursor, (unsigned long long)sim.nverts);
+				if (di.first_poly_vertex + sim.nverts > A.caps.poly_vertices) { atomicCAS(&A.totals->status, (uint32_t)VGX_OK, (uint32_t)VGX_E_NOSPACE); }
+			}
 			A.dinfo[d] = di;
 		} else {
 			const vgx_draw_info di = A.dinfo[d];
@@ -461,6 +796,18 @@ __global__ __launch_bounds__(256) void k_flatten_serial(VgxFlattenArgs A)
 }
 
 } // namespace
+
+void vgx_launch_flatten_build(const VgxFlattenArgs& a, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_flatten_build, dim3(VGX_BUILD_WAVES), dim3(VGX_WAVE), 0, s, a);
+	hipLaunchKernelGGL((k_flatten_serial<false, false>), dim3(1024), dim3(256), 0, s, a); // count + heap allocation
+}
+
+void vgx_launch_flatten_gather(const VgxFlattenArgs& a, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_flatten_gather, dim3(2048), dim3(256), 0, s, a);
+	hipLaunchKernelGGL((k_flatten_serial<true, true>), dim3(1024), dim3(256), 0, s, a);
+}
 
 void vgx_launch_flatten(bool emit, const VgxFlattenArgs& a, int numBlocks, hipStream_t s)
 {

@@ -24,6 +24,12 @@ struct VgxFlattenArgs
 	VgxTotals* totals;
 	VgxCaps caps;
 	int apply_transform;
+	// BUILD mode (single-pass flatten of vgx_tessellate): per-sub-path records stored sparsely at the command-instance
+	// index of the sub-path's last command
+	unsigned long long* sub_first; // [num_cmd_instances] global index of the sub-path's first polyline vertex
+	uint32_t* sub_info;            // [num_cmd_instances] vertex count | closed << 31 (aliases cmd_cnt)
+	int build_mode;                // k_flatten_serial<count>: allocate the draw's vertices from the polyline heap
+	float* leaf_overflow;          // [VGX_BUILD_WAVES][VGX_BUILD_OVERFLOW][64][2] leaves that did not fit the LDS slots
 };
 
 struct VgxStrokeArgs
@@ -47,6 +53,11 @@ struct VgxStrokeArgs
 
 // launchers (defined in the .hip files)
 void vgx_launch_flatten(bool emit, const VgxFlattenArgs& a, int numBlocks, hipStream_t s);
+void vgx_launch_flatten_build(const VgxFlattenArgs& a, hipStream_t s);   // single-pass: subdivide once, polyline -> heap
+void vgx_launch_flatten_gather(const VgxFlattenArgs& a, hipStream_t s);  // after the draw scan: ordered mesh descriptors
+#define VGX_BUILD_WAVES 4096
+#define VGX_BUILD_BLOCK 8192 /* polyline vertices per wave-private heap block */
+#define VGX_BUILD_OVERFLOW 120 /* leaves per lane beyond the LDS slots kept in the wave's global overflow area */
 void vgx_launch_stroke(bool emit, const VgxStrokeArgs& a, int numBlocks, hipStream_t s);
 void vgx_launch_mesh_prepare(const VgxStrokeArgs& a, hipStream_t s);
 void vgx_launch_fill(const VgxStrokeArgs& a, int numBlocks, hipStream_t s);

@@ -88,6 +88,7 @@ struct VgxTotals
 	vgx_sizes sizes;
 	uint32_t status;       // vgx_status, sticky (first error wins)
 	uint32_t num_round_meshes; // meshes with Round joins (their sizes need the geometry)
+	unsigned long long poly_heap_cursor; // BUILD mode: bump allocator of the polyline heap (vertices)
 };
 
 // Capacities the device-side checks compare against.

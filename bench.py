@@ -29,24 +29,28 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
-def algorithmic_bytes(ps, draws_one_instance, instances, sizes):
+def algorithmic_bytes(ps, draws_one_instance, instances, sizes, fill_verts, fill_idx, fill_meshes):
     """Algorithmic HBM bytes per launch of each kernel (stated in DESIGN.md):
     commands read once per instance (1 B opcode + 4 B arg offset + 4 B per argument), one 64 B draw record
-    per path instance, 8 B per polyline vertex, 16 B per sub-path record, 12 B per output vertex
-    (float2 position + uint32 colour), 2 B per index, 32 B per mesh record. Scratch the kernels exchange
-    (per-command counts, mesh descriptors, scan partials) is NOT counted: it is overhead, not algorithm."""
+    per path instance, 8 B per polyline vertex, 12 B per output vertex (float2 position + uint32 colour), 2 B per
+    index, 32 B per mesh record. Scratch the kernels exchange (per-command words, mesh descriptors, prefix arrays,
+    scan partials) is NOT counted: it is overhead, not algorithm."""
     import numpy as np
     pcb = ps.path_cmd_begin.astype(np.int64)
     aoff = ps.cmd_arg_off.astype(np.int64)
     per_path_cmd_bytes = (pcb[1:] - pcb[:-1]) * 5 + (aoff[pcb[1:]] - aoff[pcb[:-1]]) * 4
     cmd_bytes = int(per_path_cmd_bytes[draws_one_instance["path"]].sum()) * instances
     ndraws = draws_one_instance.shape[0] * instances
+    nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
+    ef = sizes["num_fill_elements"]
+    es = sizes["num_elements"] - ef
     b = {}
+    b["flatten_build"] = cmd_bytes + 64 * ndraws + 8 * sizes["num_poly_vertices"]
     b["flatten_count"] = cmd_bytes + 64 * ndraws
     b["flatten_emit"] = cmd_bytes + 64 * ndraws + 8 * sizes["num_poly_vertices"] + 16 * sizes["num_subpaths"]
-    b["stroke_count"] = 0  # closed-form for Butt/Miter strokes and fills; reads descriptors only
-    b["stroke_emit"] = 8 * sizes["num_elements"] + 12 * sizes["num_vertices"] + 2 * sizes["num_indices"] + 32 * sizes["num_meshes"]
-    b["pipeline"] = cmd_bytes + 64 * ndraws + 12 * sizes["num_vertices"] + 2 * sizes["num_indices"] + 32 * sizes["num_meshes"]
+    b["fill_emit"] = 8 * ef + 12 * fill_verts + 2 * fill_idx + 32 * fill_meshes
+    b["stroke_emit"] = 8 * es + 12 * (nv - fill_verts) + 2 * (ni - fill_idx) + 32 * (nm - fill_meshes)
+    b["pipeline"] = cmd_bytes + 64 * ndraws + 12 * nv + 2 * ni + 32 * nm
     return b
 
 
@@ -176,8 +180,15 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = total_verts * args.steps / dt / 1e6
-        ab = algorithmic_bytes(ps, one, K, sizes)
-        dom = max((k for k in stage_sum if k in ("flatten_count", "flatten_emit", "stroke_count", "stroke_emit")), key=lambda k: stage_sum[k])
+        mt = bufs.meshes[:sizes["num_meshes"] * 32].view(torch.int32).view(-1, 8)
+        is_fill = (mt[:, 7] >> 28) <= 1  # VGX_MESH_FILL / VGX_MESH_FILL_AA
+        fill_verts = int(mt[is_fill, 4].to(torch.int64).sum().item())
+        fill_idx = int(mt[is_fill, 5].to(torch.int64).sum().item())
+        fill_meshes = int(is_fill.sum().item())
+        sizes["num_fill_elements"] = int(got[8])
+        sizes["num_elements"] = int(got[7])
+        ab = algorithmic_bytes(ps, one, K, sizes, fill_verts, fill_idx, fill_meshes)
+        dom = max((k for k in stage_sum if k in ab and k != "pipeline"), key=lambda k: stage_sum[k])
         dom_ms = stage_sum[dom]
         achieved = ab[dom] / (dom_ms * 1e-3) / 1e9
         out = {

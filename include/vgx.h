@@ -149,6 +149,7 @@ typedef struct vgx_sizes {
 	uint64_t num_serial_draws; /* draws that needed the exact serial lane path (degenerate input) */
 	uint64_t num_cmd_instances;/* path commands summed over draws (flatten work items) */
 	uint64_t num_elements;     /* polyline vertices summed over meshes (stroker work items) */
+	uint64_t num_fill_elements;/* ... of which belong to convex-fill meshes (the rest to polyline strokes) */
 } vgx_sizes;
 
 /* Flatten output (pathGetVertices / pathGetSubPaths for every draw). NULL members are skipped. */

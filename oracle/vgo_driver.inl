@@ -68,6 +68,7 @@ struct VgoSink
 	void add(const VGO_ENGINE::Mesh& m, uint32_t uniformColor, uint32_t draw, uint32_t subpath, uint32_t kind, uint32_t polyN)
 	{
 		sizes->num_elements += polyN;
+		if (kind == VGX_MESH_FILL || kind == VGX_MESH_FILL_AA) { sizes->num_fill_elements += polyN; }
 		const uint64_t v0 = sizes->num_vertices;
 		const uint64_t i0 = sizes->num_indices;
 		const uint64_t m0 = sizes->num_meshes;

@@ -64,7 +64,7 @@ assert mesh_dtype.itemsize == 32
 class Sizes(C.Structure):
     _fields_ = [("num_poly_vertices", C.c_uint64), ("num_subpaths", C.c_uint64), ("num_meshes", C.c_uint64),
                 ("num_vertices", C.c_uint64), ("num_indices", C.c_uint64), ("num_serial_draws", C.c_uint64),
-                ("num_cmd_instances", C.c_uint64), ("num_elements", C.c_uint64)]
+                ("num_cmd_instances", C.c_uint64), ("num_elements", C.c_uint64), ("num_fill_elements", C.c_uint64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

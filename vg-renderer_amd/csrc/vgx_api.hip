@@ -203,6 +203,7 @@ struct OpElemPrefix // stroker elements per mesh -> two prefix arrays (convex fi
 		prefixFill[n] = t.a;
 		prefixStroke[n] = t.b;
 		totals->sizes.num_elements = t.a + t.b;
+		totals->sizes.num_fill_elements = t.a;
 	}
 };
 
@@ -514,6 +515,9 @@ static int vgx_pathset_validate_host(const vgx_pathset_desc* d, std::vector<uint
 		return VGX_E_INVALID_ARG;
 	}
 	if (d->path_cmd_begin[0] != 0 || d->path_cmd_begin[d->npaths] != d->ncmd || d->cmd_arg_off[0] != 0) {
+		return VGX_E_INVALID_ARG;
+	}
+	if (d->ncmd >= 0x7FFFFFFFu) { // bit 31 of a command index carries a flag in the draw window
 		return VGX_E_INVALID_ARG;
 	}
 	cmdFlags->assign(d->ncmd, 0);

@@ -164,15 +164,20 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 			const vgx_draw* dr = A.draws;
 			// owner draw of every lane from the lane-resident draw window (no global binary search)
 			const uint64_t lastKey = chunk + (VGX_WAVE - 1);
-			if (!(__shfl((unsigned long long)W.prefix, VGX_WAVE - 1) > lastKey)) {
+			if (!(wave_bcast_u64(W.prefix, VGX_WAVE - 1) > lastKey)) {
 				wbase = dcur;
 				W = draw_window_load(A, wbase, lane);
 			}
-			const bool windowCovers = __shfl((unsigned long long)W.prefix, VGX_WAVE - 1) > lastKey;
-			uint64_t ownerBase = 0;
-			const int ownerOfs = window_owner(W.prefix, valid ? ci : chunk, &ownerBase);
-			uint32_t pc0 = (uint32_t)__shfl((int)W.pc0, ownerOfs);
-			uint32_t serialStatic = (uint32_t)__shfl((int)W.serial, ownerOfs);
+			const bool windowCovers = wave_bcast_u64(W.prefix, VGX_WAVE - 1) > lastKey;
+			// owner = last window entry <= my key, searched on 32-bit offsets relative to the chunk start
+			const uint32_t wrel = window_rel(W.prefix, chunk);
+			const int ownerOfs = window_owner_rel(wrel, valid ? (uint32_t)lane : 0u);
+			const uint32_t orel = (uint32_t)__shfl((int)wrel, ownerOfs);
+			const int firstOwner = __popcll(wave_ballot(W.prefix <= chunk)) - 1; // draw that owns the chunk's first command
+			uint64_t ownerBase = orel > 0 ? chunk + orel : wave_bcast_u64(W.prefix, firstOwner < 0 ? 0 : firstOwner);
+			uint32_t pc0 = (uint32_t)__shfl((int)(W.pc0 | (W.serial << 31)), ownerOfs);
+			uint32_t serialStatic = pc0 >> 31;
+			pc0 &= 0x7FFFFFFFu;
 			VgxCmdRec rec;
 			rec.type = VGX_CMD_CLOSE; rec.flags = 0; rec.na = 0; rec.arg_off = 0;
 			rec.start[0] = 0.0f; rec.start[1] = 0.0f;
@@ -381,15 +386,15 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 			// ---- carries into the next chunk (taken from the last valid lane) ---------------------
 			const int nvalid = (int)((C1 - chunk) < (uint64_t)VGX_WAVE ? (C1 - chunk) : (uint64_t)VGX_WAVE);
 			const int L = nvalid - 1;
-			const int lastIsDrawLast = __shfl((int)drawLast, L);
-			const int lastIsSubLast = __shfl((int)((cflags & VGX_CF_LAST_IN_SUB) != 0), L);
-			const int nDraw = __shfl(inDrawBefore + cnt, L);
-			const int nSp = __shfl(spTotal, L);
-			const int nSubs = __shfl(subsIncl, L);
-			const int nFill = __shfl(fillIncl, L);
-			const int nStroke = __shfl(strokeIncl, L);
-			const int nSlow = __shfl((int)slowDraw, L);
-			const int nHeadExists = __shfl(headExists, L);
+			const int lastIsDrawLast = wave_bcast((int)drawLast, L);
+			const int lastIsSubLast = wave_bcast((int)((cflags & VGX_CF_LAST_IN_SUB) != 0), L);
+			const int nDraw = wave_bcast(inDrawBefore + cnt, L);
+			const int nSp = wave_bcast(spTotal, L);
+			const int nSubs = wave_bcast(subsIncl, L);
+			const int nFill = wave_bcast(fillIncl, L);
+			const int nStroke = wave_bcast(strokeIncl, L);
+			const int nSlow = wave_bcast((int)slowDraw, L);
+			const int nHeadExists = wave_bcast(headExists, L);
 			carryDrawVerts = lastIsDrawLast ? 0 : nDraw;
 			carrySubs = lastIsDrawLast ? 0 : nSubs;
 			carryFill = lastIsDrawLast ? 0 : nFill;
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 			carrySlow = lastIsDrawLast ? 0 : nSlow;
 			carrySpVerts = (lastIsDrawLast || lastIsSubLast) ? 0 : nSp;
 			carrySpExists = (lastIsDrawLast || lastIsSubLast) ? 0 : nHeadExists;
-			dcur = __shfl((unsigned long long)d, L); // draw of the last command: the next window (if needed) starts here
+			dcur = wave_bcast_u64(d, L); // draw of the last command: the next window (if needed) starts here
 		}
 	}
 }
@@ -485,15 +490,20 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 				const bool valid = ci < C1;
 				// ---- decode (same as k_flatten) ------------------------------------------------------
 				const uint64_t lastKey = chunk + (VGX_WAVE - 1);
-				if (!(__shfl((unsigned long long)W.prefix, VGX_WAVE - 1) > lastKey) || dcur < wbase) {
+				if (!(wave_bcast_u64(W.prefix, VGX_WAVE - 1) > lastKey) || dcur < wbase) {
 					wbase = dcur;
 					W = draw_window_load(A, wbase, lane);
 				}
-				const bool windowCovers = __shfl((unsigned long long)W.prefix, VGX_WAVE - 1) > lastKey;
-				uint64_t ownerBase = 0;
-				const int ownerOfs = window_owner(W.prefix, valid ? ci : chunk, &ownerBase);
-				uint32_t pc0 = (uint32_t)__shfl((int)W.pc0, ownerOfs);
-				uint32_t serialStatic = (uint32_t)__shfl((int)W.serial, ownerOfs);
+				const bool windowCovers = wave_bcast_u64(W.prefix, VGX_WAVE - 1) > lastKey;
+				// owner = last window entry <= my key, searched on 32-bit offsets relative to the chunk start
+				const uint32_t wrel = window_rel(W.prefix, chunk);
+				const int ownerOfs = window_owner_rel(wrel, valid ? (uint32_t)lane : 0u);
+				const uint32_t orel = (uint32_t)__shfl((int)wrel, ownerOfs);
+				const int firstOwner = __popcll(wave_ballot(W.prefix <= chunk)) - 1; // draw that owns the chunk's first command
+				uint64_t ownerBase = orel > 0 ? chunk + orel : wave_bcast_u64(W.prefix, firstOwner < 0 ? 0 : firstOwner);
+				uint32_t pc0 = (uint32_t)__shfl((int)(W.pc0 | (W.serial << 31)), ownerOfs);
+				uint32_t serialStatic = pc0 >> 31;
+				pc0 &= 0x7FFFFFFFu;
 				uint64_t d = d0;
 				uint32_t type = VGX_CMD_CLOSE, cflags = 0, na = 0;
 				bool drawHead = false, drawLast = false;
@@ -590,7 +600,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 
 				const int nvalid = (int)((C1 - chunk) < (uint64_t)VGX_WAVE ? (C1 - chunk) : (uint64_t)VGX_WAVE);
 				const int L = nvalid - 1;
-				const int chunkTotal = __shfl(incl, L);
+				const int chunkTotal = wave_bcast(incl, L);
 				if (writing && cur + (uint64_t)(chunkTotal > 0 ? chunkTotal : 0) > blockEnd) {
 					writing = false; // this segment does not fit the block any more: finish counting, then retry elsewhere
 				}
@@ -658,21 +668,21 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 				segTotal += (uint64_t)(chunkTotal > 0 ? chunkTotal : 0);
 
 				// carries into the next chunk
-				const int lastIsDrawLast = __shfl((int)drawLast, L);
-				const int lastIsSubLast = __shfl((int)((cflags & VGX_CF_LAST_IN_SUB) != 0), L);
-				const int nDraw = __shfl(inDrawBefore + cnt, L);
-				const int nSp = __shfl(spTotal, L);
-				const int nSubs = __shfl(subsIncl, L);
-				const int nFill = __shfl(fillIncl, L);
-				const int nStroke = __shfl(strokeIncl, L);
-				const int nSlow = __shfl((int)slowDraw, L);
+				const int lastIsDrawLast = wave_bcast((int)drawLast, L);
+				const int lastIsSubLast = wave_bcast((int)((cflags & VGX_CF_LAST_IN_SUB) != 0), L);
+				const int nDraw = wave_bcast(inDrawBefore + cnt, L);
+				const int nSp = wave_bcast(spTotal, L);
+				const int nSubs = wave_bcast(subsIncl, L);
+				const int nFill = wave_bcast(fillIncl, L);
+				const int nStroke = wave_bcast(strokeIncl, L);
+				const int nSlow = wave_bcast((int)slowDraw, L);
 				carryDrawVerts = lastIsDrawLast ? 0 : nDraw;
 				carrySubs = lastIsDrawLast ? 0 : nSubs;
 				carryFill = lastIsDrawLast ? 0 : nFill;
 				carryStroke = lastIsDrawLast ? 0 : nStroke;
 				carrySlow = lastIsDrawLast ? 0 : nSlow;
 				carrySpVerts = (lastIsDrawLast || lastIsSubLast) ? 0 : nSp;
-				dcur = __shfl((unsigned long long)d, L);
+				dcur = wave_bcast_u64(d, L);
 			}
 			if (writing) {
 				blockCur = cur;
@@ -682,7 +692,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 			const uint64_t want = segTotal > (uint64_t)VGX_BUILD_BLOCK ? segTotal : (uint64_t)VGX_BUILD_BLOCK;
 			unsigned long long base = 0;
 			if (lane == 0) { base = atomicAdd(&A.totals->poly_heap_cursor, (unsigned long long)want); }
-			base = __shfl(base, 0);
+			base = wave_bcast_u64(base, 0);
 			if (base + want > A.caps.poly_vertices) {
 				if (lane == 0) { atomicCAS(&A.totals->status, (uint32_t)VGX_OK, (uint32_t)VGX_E_NOSPACE); }
 				return;

@@ -658,13 +658,16 @@ __global__ __launch_bounds__(VGX_WAVE) void k_fill(VgxStrokeArgs A)
 		const uint64_t ei = chunk + lane;
 		const bool valid = ei < elemEnd;
 		const uint64_t lastKey = chunk + (VGX_WAVE - 1);
-		if (!(__shfl((unsigned long long)W.prefix, VGX_WAVE - 1) > lastKey)) {
+		if (!(wave_bcast_u64(W.prefix, VGX_WAVE - 1) > lastKey)) {
 			wbase = mcur;
 			W = fill_window_load(A, wbase, numMeshes, lane);
 		}
-		const bool windowCovers = __shfl((unsigned long long)W.prefix, VGX_WAVE - 1) > lastKey;
-		uint64_t ownerBase = 0;
-		const int k = window_owner(W.prefix, valid ? ei : chunk, &ownerBase);
+		const bool windowCovers = wave_bcast_u64(W.prefix, VGX_WAVE - 1) > lastKey;
+		const uint32_t wrel = window_rel(W.prefix, chunk);
+		const int k = window_owner_rel(wrel, valid ? (uint32_t)lane : 0u);
+		const uint32_t orel = (uint32_t)__shfl((int)wrel, k);
+		const int firstOwner = __popcll(wave_ballot(W.prefix <= chunk)) - 1;
+		uint64_t ownerBase = orel > 0 ? chunk + orel : wave_bcast_u64(W.prefix, firstOwner < 0 ? 0 : firstOwner);
 		uint64_t mi = wbase + (uint64_t)k;
 		uint64_t polyFirst = __shfl((unsigned long long)W.polyFirst, k);
 		uint64_t firstV = __shfl((unsigned long long)W.firstV, k);
@@ -693,12 +696,12 @@ __global__ __launch_bounds__(VGX_WAVE) void k_fill(VgxStrokeArgs A)
 		if (aaElem && !nextInWave) { pNextB = ldv(vtx, j + 1 < N ? j + 1 : 0); }
 		if (aaElem && !prevInWave) { pPrevB = ldv(vtx, j > 0 ? j - 1 : N - 1); }
 		V2 pNext;
-		pNext.x = __shfl_down(p1.x, 1); pNext.y = __shfl_down(p1.y, 1);
+		pNext.x = wave_from_next(p1.x, 0.0f); pNext.y = wave_from_next(p1.y, 0.0f);
 		if (!nextInWave) { pNext = pNextB; }
 		V2 d12 = v2(0.0f, 0.0f);
 		if (aaElem) { d12 = v2dir(p1, pNext); }
 		V2 dPrev;
-		dPrev.x = __shfl_up(d12.x, 1); dPrev.y = __shfl_up(d12.y, 1);
+		dPrev.x = wave_from_prev(d12.x, 0.0f); dPrev.y = wave_from_prev(d12.y, 0.0f);
 		if (aaElem && !prevInWave) { dPrev = v2dir(pPrevB, p1); }
 
 		if (valid) {
@@ -754,7 +757,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_fill(VgxStrokeArgs A)
 			}
 		}
 		const int nvalid = (int)((elemEnd - chunk) < (uint64_t)VGX_WAVE ? (elemEnd - chunk) : (uint64_t)VGX_WAVE);
-		mcur = __shfl((unsigned long long)mi, nvalid - 1);
+		mcur = wave_bcast_u64(mi, nvalid - 1);
 	}
 }
 
@@ -795,9 +798,12 @@ __global__ __launch_bounds__(VGX_WAVE) void k_stroke(VgxStrokeArgs A)
 			const bool valid = ei < E1;
 			const uint64_t widx = mcur + (uint64_t)lane;
 			const uint64_t wv = (widx <= m1) ? A.elem_prefix[widx] : ~0ull;
-			const bool windowCovers = __shfl((unsigned long long)wv, VGX_WAVE - 1) > chunk + (VGX_WAVE - 1);
-			uint64_t ownerBase = 0;
-			const int ownerOfs = window_owner(wv, valid ? ei : chunk, &ownerBase);
+			const bool windowCovers = wave_bcast_u64(wv, VGX_WAVE - 1) > chunk + (VGX_WAVE - 1);
+			const uint32_t wrel = window_rel(wv, chunk);
+			const int ownerOfs = window_owner_rel(wrel, valid ? (uint32_t)lane : 0u);
+			const uint32_t orel = (uint32_t)__shfl((int)wrel, ownerOfs);
+			const int firstOwner = __popcll(wave_ballot(wv <= chunk)) - 1;
+			uint64_t ownerBase = orel > 0 ? chunk + orel : wave_bcast_u64(wv, firstOwner < 0 ? 0 : firstOwner);
 			uint64_t mi = m0;
 			MeshCtx mc;
 			mc.kind = VGX_MESH_STROKE_AA; mc.N = 2; mc.j = 0; mc.cap = 0; mc.join = 0; mc.closed = false;
@@ -821,12 +827,12 @@ __global__ __launch_bounds__(VGX_WAVE) void k_stroke(VgxStrokeArgs A)
 			const bool prevInWave = lane > 0 && mc.j > 0;
 			const bool nextInWave = lane < VGX_WAVE - 1 && mc.j + 1 < mc.N && ei + 1 < E1;
 			V2 pNext;
-			pNext.x = __shfl_down(p1.x, 1); pNext.y = __shfl_down(p1.y, 1);
+			pNext.x = wave_from_next(p1.x, 0.0f); pNext.y = wave_from_next(p1.y, 0.0f);
 			if (valid && !nextInWave) { pNext = ldv(mc.vtx, mc.j + 1 < mc.N ? mc.j + 1 : 0); }
 			V2 d12 = v2(0.0f, 0.0f);
 			if (valid) { d12 = v2dir(p1, pNext); }
 			V2 dPrev;
-			dPrev.x = __shfl_up(d12.x, 1); dPrev.y = __shfl_up(d12.y, 1);
+			dPrev.x = wave_from_prev(d12.x, 0.0f); dPrev.y = wave_from_prev(d12.y, 0.0f);
 			if (valid && !prevInWave) { dPrev = v2dir(ldv(mc.vtx, mc.j > 0 ? mc.j - 1 : mc.N - 1), p1); }
 			Elem e;
 			e.nv = 0; e.ni = 0; e.et = ET_JOIN; e.leftInner = true; e.hasConnect = false; e.closesLoop = false;
@@ -849,8 +855,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_stroke(VgxStrokeArgs A)
 
 			// step C: previous element's exit rails
 			const uint64_t myExit = valid ? rails_pack(elem_exit_rails(mc, e, vbase)) : 0ull;
-			uint64_t prevPacked = __shfl_up((unsigned long long)myExit, 1);
-			if (lane == 0) { prevPacked = carryRails; }
+			uint64_t prevPacked = (uint64_t)wave_from_prev_u32((uint32_t)myExit, (uint32_t)carryRails) | ((uint64_t)wave_from_prev_u32((uint32_t)(myExit >> 32), (uint32_t)(carryRails >> 32)) << 32);
 
 			const bool meshLast = valid && (mc.j == mc.N - 1);
 			if (valid) {
@@ -870,14 +875,14 @@ __global__ __launch_bounds__(VGX_WAVE) void k_stroke(VgxStrokeArgs A)
 			// carries (from the last valid lane)
 			const int nvalid = (int)((E1 - chunk) < (uint64_t)VGX_WAVE ? (E1 - chunk) : (uint64_t)VGX_WAVE);
 			const int Lz = nvalid - 1;
-			const int lastIsMeshLast = __shfl((int)meshLast, Lz);
+			const int lastIsMeshLast = wave_bcast((int)meshLast, Lz);
 			const uint32_t endV = wave_read_u32(vbase + e.nv, Lz);
 			const uint32_t endI = wave_read_u32(ibase + totalIdx, Lz);
-			const uint64_t endRails = __shfl((unsigned long long)myExit, Lz);
+			const uint64_t endRails = wave_bcast_u64(myExit, Lz);
 			carryV = lastIsMeshLast ? 0u : endV;
 			carryI = lastIsMeshLast ? 0u : endI;
 			carryRails = lastIsMeshLast ? 0ull : endRails;
-			mcur = __shfl((unsigned long long)mi, Lz);
+			mcur = wave_bcast_u64(mi, Lz);
 		}
 	}
 }

@@ -5,6 +5,7 @@
 #define VGX_WAVE_H
 
 #include <hip/hip_runtime.h>
+#include <rocprim/warp/warp_scan.hpp>
 #include <stdint.h>
 
 #define VGX_WAVE 64
@@ -27,24 +28,51 @@ __device__ __forceinline__ uint64_t seg_mask_upto(int head, int lane)
 	return lanemask_le(lane) & (head < 0 ? ~0ull : lanemask_ge(head));
 }
 
+// Inclusive prefix sums over the wavefront: rocprim's wave64 scan lowers to DPP row_shr / row_bcast moves (no LDS
+// crossbar round trips, unlike a ds_bpermute shuffle ladder).
 __device__ __forceinline__ int wave_incl_scan(int v, int lane)
 {
-#pragma unroll
-	for (int d = 1; d < VGX_WAVE; d <<= 1) {
-		const int t = __shfl_up(v, d);
-		if (lane >= d) { v += t; }
-	}
-	return v;
+	(void)lane;
+	using WS = rocprim::warp_scan<int, VGX_WAVE>;
+	typename WS::storage_type st;
+	int out;
+	WS().inclusive_scan(v, out, st);
+	return out;
 }
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
 {
-#pragma unroll
-	for (int d = 1; d < VGX_WAVE; d <<= 1) {
-		const uint32_t t = __shfl_up(v, d);
-		if (lane >= d) { v += t; }
-	}
-	return v;
+	(void)lane;
+	using WS = rocprim::warp_scan<uint32_t, VGX_WAVE>;
+	typename WS::storage_type st;
+	uint32_t out;
+	WS().inclusive_scan(v, out, st);
+	return out;
+}
+
+// Broadcast of lane `src`'s value where `src` is WAVE-UNIFORM: v_readlane, no LDS crossbar.
+__device__ __forceinline__ int wave_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ uint32_t wave_bcast_u32(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+__device__ __forceinline__ uint64_t wave_bcast_u64(uint64_t v, int src)
+{
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+	const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+	return ((uint64_t)hi << 32) | lo;
+}
+
+// Neighbour lanes through DPP whole-wave shifts (gfx9 wave_shr:1 / wave_shl:1): lane l reads lane l-1 / l+1.
+// Lane 0 (resp. 63) receives `edge`.
+__device__ __forceinline__ float wave_from_prev(float v, float edge)
+{
+	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_from_next(float v, float edge)
+{
+	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ uint32_t wave_from_prev_u32(uint32_t v, uint32_t edge)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xf, 0xf, false);
 }
 
 // Value of `v` on lane `src` (src may differ per lane).
@@ -112,6 +140,25 @@ __device__ __forceinline__ int window_owner(uint64_t w, uint64_t key, uint64_t* 
 	}
 	*pv = vlo;
 	return lo;
+}
+
+// Same search on a window that was reduced to 32-bit offsets relative to the chunk start: rel[k] = clamp(W[k] - chunk,
+// 0, 64) (entries at or before the chunk start become 0, entries past the chunk 64), key = lane. Half the shuffles.
+__device__ __forceinline__ int window_owner_rel(uint32_t rel, uint32_t key)
+{
+	int lo = 0;
+#pragma unroll
+	for (int step = 32; step >= 1; step >>= 1) {
+		const int cand = lo + step;
+		const uint32_t v = (uint32_t)__shfl((int)rel, cand & 63);
+		if (cand < VGX_WAVE && v <= key) { lo = cand; }
+	}
+	return lo;
+}
+
+__device__ __forceinline__ uint32_t window_rel(uint64_t prefix, uint64_t chunk)
+{
+	return prefix <= chunk ? 0u : (prefix - chunk > 64ull ? 64u : (uint32_t)(prefix - chunk));
 }
 
 #endif

@@ -164,7 +164,7 @@ class MeshBuffers:
         self.color = torch.empty(max(nverts, 1), dtype=torch.int32, device=device)
         self.idx = torch.empty(max(nidx, 1), dtype=torch.int16, device=device)
         self.meshes = torch.empty(max(nmeshes, 1) * 32, dtype=torch.uint8, device=device)
-        self.dev_sizes = torch.zeros(8, dtype=torch.int64, device=device)
+        self.dev_sizes = torch.zeros(9, dtype=torch.int64, device=device)
         self.dev_status = torch.zeros(1, dtype=torch.int32, device=device)
 
     def out_struct(self):

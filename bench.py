@@ -54,30 +54,57 @@ def algorithmic_bytes(ps, draws_one_instance, instances, sizes, fill_verts, fill
     return b
 
 
-def cpu_baseline(instances_total_hint, seconds_target=12.0):
-    """Reference CPU path on the host cores of THIS box, one process per core, bounded sample of the same
-    workload (Tiger instances). Returns the dict for the JSON line."""
+def effective_cores():
+    """Host cores this process may actually use: affinity mask clipped by the cgroup CPU quota (the GPU boxes
+    report 256 logical CPUs but run the container under a quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            q, p = f.read().split()
+            if q != "max":
+                n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                p = int(f.read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def cpu_baseline(budget_seconds=10.0, max_procs=256):
+    """Reference CPU path on the host cores of THIS box: one process per usable core, every process loops over
+    its own 16 Tiger instances for `budget_seconds` of wall time after a common start. Returns the dict for the
+    JSON line (value = sum of verts / slowest process's wall)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
     kind = "reference" if pyoracle.available("reference") else "port"
     if kind == "port" and not pyoracle.available("port"):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libvgoracle.so"], stdout=subprocess.DEVNULL)
-    cores = os.cpu_count() or 1
+    procs = max(1, min(effective_cores(), max_procs))
     worker = os.path.join(ROOT, "oracle", "cpu_bench.py")
 
-    def run(procs, inst, reps):
-        ps = [subprocess.Popen([sys.executable, worker, kind, str(inst), str(i * inst), str(reps)], stdout=subprocess.PIPE, text=True) for i in range(procs)]
+    def run(nproc, budget):
+        ps = [subprocess.Popen([sys.executable, worker, kind, "16", str(i * 16), str(budget)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+              for i in range(nproc)]
+        for p in ps:
+            assert p.stdout.readline().strip() == "ready"
+        for p in ps:
+            p.stdin.write("go\n")
+            p.stdin.flush()
         outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in ps]
-        return sum(o["verts"] for o in outs), max(o["seconds"] for o in outs)
+        return sum(o["verts"] for o in outs), max(o["seconds"] for o in outs), sum(o["cpu_seconds"] for o in outs)
 
-    # calibrate on one process, then size the all-core run to ~seconds_target of CPU work per core
-    v1, t1 = run(1, 2, 1)
-    rate1 = v1 / t1
-    reps = max(1, int(seconds_target * rate1 / (v1 / 2 * 16)))  # 16 instances per process per rep
-    vN, tN = run(cores, 16, reps)
-    return {"value": round(vN / tN / 1e6, 2), "unit": "M verts/s", "cores": cores, "kind": kind,
-            "single_core_value": round(rate1 / 1e6, 2),
-            "sample": "Tiger x%d instances per process x %d reps x %d processes (one per host core), wall = slowest process" % (16, reps, cores)}
+    v1, t1, _ = run(1, min(2.0, budget_seconds))
+    vN, tN, cN = run(procs, budget_seconds)
+    return {"value": round(vN / tN / 1e6, 2), "unit": "M verts/s", "cores": procs, "kind": kind,
+            "single_core_value": round(v1 / t1 / 1e6, 2), "cpu_seconds_per_wall_second": round(cN / tN, 1),
+            "sample": "Tiger x16 instances per process, looped for %.0f s of wall time, %d processes (one per usable host core; "
+                      "%d logical CPUs visible)" % (budget_seconds, procs, os.cpu_count() or 0)}
 
 
 def main():
@@ -107,7 +134,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(args.instances)  # before any GPU work, in separate processes
+        cpu = cpu_baseline()  # before any GPU work, in separate processes
 
     K = args.instances
     ps, ops = wl.tiger_paths()

@@ -2,7 +2,9 @@
 
 Launched as a separate PROCESS per host core by bench.py's cpu_baseline leg (processes, not threads: the
 reference's pathCubicTo keeps its subdivision stack in a function-local `static`, src/path.cpp:91).
-Prints one JSON line: {"verts": ..., "seconds": ...}. Input generation is excluded from the timing; the
+Protocol: prints "ready" once its input is generated, waits for a line on stdin (so all workers start
+together), runs whole passes over its shard until `budget` seconds have elapsed, then prints one JSON line:
+{"verts": ..., "seconds": ..., "cpu_seconds": ...}. Input generation is excluded from the timing; the
 timed region is exactly oracle.vgo_tessellate = per draw pathReset + commands + batchTransformPositions +
 one strokerXXX call per sub-path + the memcpy of each Mesh into contiguous output (the stand-in for
 createDrawCommand_VertexColor, reference src/vg.cpp:5207-5244)."""
@@ -18,12 +20,26 @@ sys.path.insert(0, HERE)
 
 
 def main():
-    kind, instances, first, reps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    kind, instances, first, budget = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4])
     wl = importlib.import_module("vg-renderer_amd.workloads")
     import pyoracle
     ps, draws = wl.tiger(instances, first_instance=first)
-    dt, sizes = pyoracle.tessellate_timed(ps, draws, kind=kind, reps=reps)
-    print(json.dumps({"verts": sizes["num_vertices"] * reps, "seconds": dt}))
+    pyoracle.tessellate_timed(ps, draws, kind=kind, reps=1)  # load the library, touch the buffers
+    sys.stdout.write("ready\n")
+    sys.stdout.flush()
+    sys.stdin.readline()
+    verts, reps = 0, 1
+    c0 = time.process_time()
+    t0 = time.perf_counter()
+    while True:
+        dt, sizes = pyoracle.tessellate_timed(ps, draws, kind=kind, reps=reps)
+        verts += sizes["num_vertices"] * reps
+        el = time.perf_counter() - t0
+        if el >= budget:
+            break
+        if dt < 0.2:  # grow the pass count per call until one call is ~0.25 s (timer overhead negligible)
+            reps = min(reps * 2, 1 << 16)
+    print(json.dumps({"verts": verts, "seconds": time.perf_counter() - t0, "cpu_seconds": time.process_time() - c0}))
 
 
 if __name__ == "__main__":

@@ -32,7 +32,25 @@ namespace {
 // float2 (lane-interleaved -> conflict free for any mix of levels), deeper levels (only very fine subdivisions
 // reach them) in per-lane private memory. Fewer LDS bytes per wave = more resident waves to hide latency.
 #define VGX_LDS_LEVELS 4
-struct LdsStack
+struct LdsLevels // the first VGX_LDS_LEVELS levels only (hot loop: no private-memory branch)
+{
+	float2* base; // &s_stack[lane]
+	__device__ __forceinline__ void push(int level, float ax, float ay, float bx, float by, float cx, float cy)
+	{
+		float2* p = base + level * 3 * VGX_WAVE;
+		p[0] = make_float2(ax, ay);
+		p[VGX_WAVE] = make_float2(bx, by);
+		p[2 * VGX_WAVE] = make_float2(cx, cy);
+	}
+	__device__ __forceinline__ void pop(int level, float& ax, float& ay, float& bx, float& by, float& cx, float& cy)
+	{
+		const float2* p = base + level * 3 * VGX_WAVE;
+		const float2 a = p[0], b = p[VGX_WAVE], c = p[2 * VGX_WAVE];
+		ax = a.x; ay = a.y; bx = b.x; by = b.y; cx = c.x; cy = c.y;
+	}
+};
+
+struct LdsStack // full depth: LDS levels first, the rest in private memory
 {
 	float2* base; // &s_stack[lane]
 	float deep[(VGX_CUBIC_MAX_PENDING - VGX_LDS_LEVELS) * 6];
@@ -60,6 +78,20 @@ struct LdsStack
 		}
 	}
 };
+
+// Common case on the LDS-only stack; a cubic that nests deeper than VGX_LDS_LEVELS pending halves is redone from its
+// root with the full-depth stack (it gives up on its first too-deep descent, i.e. after a handful of steps).
+template<class SINK>
+__device__ __forceinline__ void wave_flatten_cubic(float x1, float y1, float x2, float y2, float x3, float y3, float x4, float y4, float tessTol, LdsStack& stack, SINK& sink)
+{
+	const SINK fresh = sink;
+	LdsLevels hot;
+	hot.base = stack.base;
+	if (vgx_flatten_cubic_n<VGX_LDS_LEVELS, true>(x1, y1, x2, y2, x3, y3, x4, y4, tessTol, hot, sink)) {
+		sink = fresh;
+		vgx_flatten_cubic(x1, y1, x2, y2, x3, y3, x4, y4, tessTol, stack, sink);
+	}
+}
 
 // ---- sink of the lane-parallel cubic: counts leaves, flags the cases that need the serial path -------
 template<bool EMIT, bool XFORM>
@@ -231,7 +263,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 						} else {
 							ex = a[4]; ey = a[5];
 						}
-						vgx_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tol / (scale * scale), stack, sink);
+						wave_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tol / (scale * scale), stack, sink);
 						cnt = (int)sink.n;
 						slow = sink.slow;
 					} break;
@@ -343,7 +375,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 						} else {
 							ex = a[4]; ey = a[5];
 						}
-						vgx_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tol / (scale * scale), stack, sink);
+						wave_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tol / (scale * scale), stack, sink);
 					} break;
 					case VGX_CMD_POLYLINE: {
 						const uint32_t npts = na >> 1;
@@ -555,7 +587,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 						BuildCubicSink sink;
 						sink.prev = start; sink.n = 0; sink.slow = false; sink.slots = &s_leaf[lane];
 						sink.over = (float2*)A.leaf_overflow + (size_t)blockIdx.x * VGX_BUILD_OVERFLOW * VGX_WAVE + lane;
-						vgx_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tol / (scale * scale), stack, sink);
+						wave_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tol / (scale * scale), stack, sink);
 						cnt = (int)sink.n;
 						slow = sink.slow;
 					} break;
@@ -636,7 +668,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 							} else { // more leaves than slots + overflow area: subdivide again, straight to memory
 								FastCubicSink<true, true> sink;
 								sink.prev = start; sink.n = 0; sink.slow = false; sink.out = out; sink.writeLimit = limit; sink.mtx = mtx;
-								vgx_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tol / (scale * scale), stack, sink);
+								wave_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tol / (scale * scale), stack, sink);
 							}
 						} else if (type == VGX_CMD_POLYLINE) {
 							const uint32_t skip = (na >> 1) - (uint32_t)rawCnt;

@@ -76,41 +76,51 @@ VGX_HD bool v2near(V2 a, V2 b) // the epsilon test of pathAddVertex / pathClose 
 // ------------------------------------------------------------------------------------------------
 #define VGX_CUBIC_MAX_PENDING 10
 
-template<class STACK, class SINK>
-VGX_HD void vgx_flatten_cubic(float x1, float y1, float x2, float y2, float x3, float y3, float x4, float y4, float tessTol, STACK& stack, SINK& sink)
+// vgx_flatten_cubic_n<LIMIT, ABORT>: LIMIT = capacity of STACK. With ABORT the walk gives up (returns true, the
+// sink is left in an undefined state) the first time a push would exceed LIMIT; callers then redo the cubic with the
+// full-depth stack. That lets the wave-parallel kernels run their common case on a small LDS-only stack.
+template<int LIMIT, bool ABORT, class STACK, class SINK>
+VGX_HD bool vgx_flatten_cubic_n(float x1, float y1, float x2, float y2, float x3, float y3, float x4, float y4, float tessTol, STACK& stack, SINK& sink)
 {
+	// One loop exit and select-style state updates: the wave runs this loop in lockstep, so every extra branch target
+	// costs exec-mask bookkeeping on ALL lanes. Same arithmetic, same order as path.cpp:107-170.
 	int pending = 0;
-	for (;;) {
+	bool more = true, aborted = false;
+	while (more) {
 		const float dx = x4 - x1;
 		const float dy = y4 - y1;
 		const float d2 = vgm_abs((x2 - x4) * dy - (y2 - y4) * dx);
 		const float d3 = vgm_abs((x3 - x4) * dy - (y3 - y4) * dx);
 		const float d23 = d2 + d3;
-		if (d23 * d23 <= tessTol * (dx * dx + dy * dy)) {
-			sink.leaf(x4, y4);
-		} else if (pending < VGX_CUBIC_MAX_PENDING) {
-			const float x12 = (x1 + x2) * 0.5f, y12 = (y1 + y2) * 0.5f;
-			const float x23 = (x2 + x3) * 0.5f, y23 = (y2 + y3) * 0.5f;
-			const float x34 = (x3 + x4) * 0.5f, y34 = (y3 + y4) * 0.5f;
-			const float x123 = (x12 + x23) * 0.5f, y123 = (y12 + y23) * 0.5f;
-			const float x234 = (x23 + x34) * 0.5f, y234 = (y23 + y34) * 0.5f;
-			const float x1234 = (x123 + x234) * 0.5f, y1234 = (y123 + y234) * 0.5f;
-			stack.push(pending, x234, y234, x34, y34, x4, y4);
-			++pending;
-			x2 = x12; y2 = y12;
-			x3 = x123; y3 = y123;
-			x4 = x1234; y4 = y1234;
-			continue;
+		const bool flat = d23 * d23 <= tessTol * (dx * dx + dy * dy);
+		const bool push = !flat && pending < LIMIT;
+		const float x12 = (x1 + x2) * 0.5f, y12 = (y1 + y2) * 0.5f;
+		const float x23 = (x2 + x3) * 0.5f, y23 = (y2 + y3) * 0.5f;
+		const float x34 = (x3 + x4) * 0.5f, y34 = (y3 + y4) * 0.5f;
+		const float x123 = (x12 + x23) * 0.5f, y123 = (y12 + y23) * 0.5f;
+		const float x234 = (x23 + x34) * 0.5f, y234 = (y23 + y34) * 0.5f;
+		const float x1234 = (x123 + x234) * 0.5f, y1234 = (y123 + y234) * 0.5f;
+		float nx2 = x12, ny2 = y12, nx3 = x123, ny3 = y123, nx4 = x1234, ny4 = y1234;
+		if (push) {
+			stack.push(pending, x234, y234, x34, y34, x4, y4); // the right half waits; descend into the left half
 		} else {
-			sink.dropped();
+			if (flat) { sink.leaf(x4, y4); }
+			else if (ABORT) { aborted = true; }
+			else { sink.dropped(); } // stack full: the node is silently skipped
+			x1 = x4; y1 = y4; // the next sibling starts where this subtree ended
+			if (pending > 0) { stack.pop(pending - 1, nx2, ny2, nx3, ny3, nx4, ny4); }
 		}
-		if (pending == 0) {
-			return;
-		}
-		--pending;
-		x1 = x4; y1 = y4; // right half starts where the finished left subtree ended
-		stack.pop(pending, x2, y2, x3, y3, x4, y4);
+		more = (push || pending > 0) && !aborted;
+		pending += push ? 1 : -1;
+		x2 = nx2; y2 = ny2; x3 = nx3; y3 = ny3; x4 = nx4; y4 = ny4;
 	}
+	return aborted;
+}
+
+template<class STACK, class SINK>
+VGX_HD void vgx_flatten_cubic(float x1, float y1, float x2, float y2, float x3, float y3, float x4, float y4, float tessTol, STACK& stack, SINK& sink)
+{
+	(void)vgx_flatten_cubic_n<VGX_CUBIC_MAX_PENDING, false>(x1, y1, x2, y2, x3, y3, x4, y4, tessTol, stack, sink);
 }
 
 // Quadratic -> cubic control points (pathQuadraticTo, path.cpp:184-201)

@@ -33,44 +33,119 @@ __device__ __forceinline__ Rails rails(uint32_t a, uint32_t b, uint32_t c, uint3
 __device__ __forceinline__ uint64_t rails_pack(Rails r) { return (uint64_t)(r.a & 0xFFFFu) | ((uint64_t)(r.b & 0xFFFFu) << 16) | ((uint64_t)(r.c & 0xFFFFu) << 32) | ((uint64_t)(r.d & 0xFFFFu) << 48); }
 __device__ __forceinline__ Rails rails_unpack(uint64_t p) { return rails((uint32_t)(p & 0xFFFFu), (uint32_t)((p >> 16) & 0xFFFFu), (uint32_t)((p >> 32) & 0xFFFFu), (uint32_t)(p >> 48)); }
 
-// Direct writer: pointers to the mesh's first vertex / index in the output streams.
-template<bool EMIT>
-struct MeshWriter
+// Unaligned wide stores: the output streams are only element-aligned (8 / 4 / 2 bytes); gfx950 global stores handle
+// that natively (unaligned access mode), so one lane can issue ONE dwordx4 for two positions, ONE dwordx3 for six
+// indices ... without alignment-dependent divergence.
+struct __attribute__((packed, aligned(8))) PosPair { float x0, y0, x1, y1; };
+struct __attribute__((packed, aligned(4))) ColPair { uint32_t c0, c1; };
+struct __attribute__((packed, aligned(2))) Idx9 { uint32_t a, b, c, d; uint16_t e; };
+struct __attribute__((packed, aligned(2))) Idx6 { uint32_t a, b, c; };
+struct __attribute__((packed, aligned(2))) Idx3 { uint32_t a; uint16_t b; };
+
+// Stroke writer: pointers to the mesh's first vertex / index in the output streams, plus a register stage for the
+// fixed-size part of an element (up to 4 vertices at b.., up to 24 indices at k..). The element code runs under
+// divergent branches (cap / join / kind); without the stage every branch carries its own train of narrow stores
+// (~60 store instructions per 64-element chunk), with it the chunk leaves in ~10 wide ones (flush()).
+struct StrokeWriter
 {
 	float* pos;
 	uint32_t* col;
 	uint16_t* idx;
 	uint32_t color, c0;
+	float sx[4], sy[4];
+	uint32_t sc[4];
+	uint32_t si[24];
+	uint32_t nvS, niS; // staged vertex / index counts (niS is a multiple of 6)
+	__device__ __forceinline__ void reset()
+	{
+		for (int i = 0; i < 4; ++i) { sx[i] = 0.0f; sy[i] = 0.0f; sc[i] = 0; }
+		for (int i = 0; i < 24; ++i) { si[i] = 0; }
+		nvS = 0; niS = 0;
+	}
+	// ---- staged (slot = compile-time constant at every call site) ----
+	__device__ __forceinline__ void sv(uint32_t slot, V2 p, uint32_t c)
+	{
+		sx[slot] = p.x; sy[slot] = p.y; sc[slot] = c;
+		nvS = nvS > slot + 1 ? nvS : slot + 1;
+	}
+	__device__ __forceinline__ void stri(uint32_t slot, uint32_t a, uint32_t b, uint32_t c)
+	{
+		si[slot] = a; si[slot + 1] = b; si[slot + 2] = c;
+		niS = niS > slot + 3 ? niS : slot + 3;
+	}
+	__device__ __forceinline__ void sbridge4(uint32_t slot, Rails p, Rails c) // stroker.cpp:1557-1564, 1714-1721, 1973-1980
+	{
+		stri(slot, p.a, p.b, c.b); stri(slot + 3, p.a, c.b, c.a);
+		stri(slot + 6, p.b, p.c, c.c); stri(slot + 9, p.b, c.c, c.b);
+		stri(slot + 12, p.c, p.d, c.d); stri(slot + 15, p.c, c.d, c.c);
+	}
+	__device__ __forceinline__ void sbridge2(uint32_t slot, Rails p, Rails c) // stroker.cpp:1119-1122, 1217-1220, 1374-1377
+	{
+		stri(slot, p.a, p.b, c.b); stri(slot + 3, p.a, c.b, c.a);
+	}
+	__device__ __forceinline__ void sbridge3(uint32_t slot, Rails p, Rails c) // stroker.cpp:2093-2098, 2175-2180, 2299-2304
+	{
+		stri(slot, p.a, p.b, c.b); stri(slot + 3, p.a, c.b, c.a);
+		stri(slot + 6, p.b, p.c, c.c); stri(slot + 9, p.b, c.c, c.b);
+	}
+	// ---- direct ----
 	__device__ __forceinline__ void v(uint32_t i, V2 p, uint32_t c) const
 	{
-		if (EMIT) {
-			*(float2*)(pos + 2 * (size_t)i) = make_float2(p.x, p.y);
-			col[i] = c;
-		}
+		*(float2*)(pos + 2 * (size_t)i) = make_float2(p.x, p.y);
+		col[i] = c;
 	}
 	__device__ __forceinline__ void tri(uint32_t k, uint32_t a, uint32_t b, uint32_t c) const
 	{
-		if (EMIT) {
-			idx[k] = (uint16_t)a; idx[k + 1] = (uint16_t)b; idx[k + 2] = (uint16_t)c;
-		}
+		Idx3 t; t.a = (a & 0xFFFFu) | (b << 16); t.b = (uint16_t)c;
+		*(Idx3*)(idx + k) = t;
 	}
-	// 18 indices joining two 4-rail cross sections (stroker.cpp:1557-1564, 1714-1721, 1973-1980)
 	__device__ __forceinline__ void bridge4(uint32_t k, Rails p, Rails c) const
 	{
 		tri(k, p.a, p.b, c.b); tri(k + 3, p.a, c.b, c.a);
 		tri(k + 6, p.b, p.c, c.c); tri(k + 9, p.b, c.c, c.b);
 		tri(k + 12, p.c, p.d, c.d); tri(k + 15, p.c, c.d, c.c);
 	}
-	// 6 indices, 2 rails (stroker.cpp:1119-1122, 1217-1220, 1374-1377)
 	__device__ __forceinline__ void bridge2(uint32_t k, Rails p, Rails c) const
 	{
 		tri(k, p.a, p.b, c.b); tri(k + 3, p.a, c.b, c.a);
 	}
-	// 12 indices, 3 rails (stroker.cpp:2093-2098, 2175-2180, 2299-2304)
 	__device__ __forceinline__ void bridge3(uint32_t k, Rails p, Rails c) const
 	{
 		tri(k, p.a, p.b, c.b); tri(k + 3, p.a, c.b, c.a);
 		tri(k + 6, p.b, p.c, c.c); tri(k + 9, p.b, c.c, c.b);
+	}
+	// the staged part of the element whose first vertex is b and first index k
+	__device__ __forceinline__ void flush(uint32_t b, uint32_t k) const
+	{
+		float* pp = pos + 2 * (size_t)b;
+		uint32_t* pc = col + b;
+		if (nvS >= 2) {
+			PosPair q; q.x0 = sx[0]; q.y0 = sy[0]; q.x1 = sx[1]; q.y1 = sy[1];
+			*(PosPair*)pp = q;
+			ColPair c; c.c0 = sc[0]; c.c1 = sc[1];
+			*(ColPair*)pc = c;
+		}
+		if (nvS == 4) {
+			PosPair q; q.x0 = sx[2]; q.y0 = sy[2]; q.x1 = sx[3]; q.y1 = sy[3];
+			*(PosPair*)(pp + 4) = q;
+			ColPair c; c.c0 = sc[2]; c.c1 = sc[3];
+			*(ColPair*)(pc + 2) = c;
+		}
+		if (nvS == 3) {
+			*(float2*)(pp + 4) = make_float2(sx[2], sy[2]);
+			pc[2] = sc[2];
+		}
+		uint16_t* pi = idx + k;
+#pragma unroll
+		for (uint32_t g = 0; g < 4; ++g) {
+			if (niS > 6 * g) {
+				Idx6 t;
+				t.a = (si[6 * g] & 0xFFFFu) | (si[6 * g + 1] << 16);
+				t.b = (si[6 * g + 2] & 0xFFFFu) | (si[6 * g + 3] << 16);
+				t.c = (si[6 * g + 4] & 0xFFFFu) | (si[6 * g + 5] << 16);
+				*(Idx6*)(pi + 6 * g) = t;
+			}
+		}
 	}
 };
 
@@ -245,8 +320,11 @@ __device__ __forceinline__ Rails first_join_entry(const MeshCtx& m, bool leftInn
 }
 
 // ---- step D: emit one stroke element ------------------------------------------------------------------
-template<bool EMIT>
-__device__ __forceinline__ void elem_emit(const MeshCtx& m, const Elem& e, uint32_t b, uint32_t k, Rails prev, const MeshWriter<EMIT>& w)
+// Fixed-size pieces (Butt / Square caps, the four corner vertices of a join, the connect bridge) go through the
+// writer's register stage (sv / stri / sbridgeN, slot numbers relative to b / k) and leave in a handful of wide stores
+// after the call; variable-size pieces (Round caps and joins, the closing bridge) are written directly.
+template<class W>
+__device__ __forceinline__ void elem_emit(const MeshCtx& m, const Elem& e, uint32_t b, uint32_t k, Rails prev, W& w)
 {
 	const uint32_t N = m.N;
 	const uint32_t color = w.color, c0 = w.c0;
@@ -299,38 +377,38 @@ __device__ __forceinline__ void elem_emit(const MeshCtx& m, const Elem& e, uint3
 			if (m.cap == VGX_CAP_BUTT) { // :1422-1447, 1858-1886
 				const V2 daa = v2mul(d, fringe);
 				if (firstCap) {
-					w.v(b, v2add(p1, v2sub(lhaa, daa)), c0);
-					w.v(b + 1, v2add(p1, lh), color);
-					w.v(b + 2, v2sub(p1, lh), color);
-					w.v(b + 3, v2sub(p1, v2add(lhaa, daa)), c0);
+					w.sv(0, v2add(p1, v2sub(lhaa, daa)), c0);
+					w.sv(1, v2add(p1, lh), color);
+					w.sv(2, v2sub(p1, lh), color);
+					w.sv(3, v2sub(p1, v2add(lhaa, daa)), c0);
 				} else {
-					w.v(b, v2add(p1, v2add(lhaa, daa)), c0);
-					w.v(b + 1, v2add(p1, lh), color);
-					w.v(b + 2, v2sub(p1, lh), color);
-					w.v(b + 3, v2sub(p1, v2sub(lhaa, daa)), c0);
+					w.sv(0, v2add(p1, v2add(lhaa, daa)), c0);
+					w.sv(1, v2add(p1, lh), color);
+					w.sv(2, v2sub(p1, lh), color);
+					w.sv(3, v2sub(p1, v2sub(lhaa, daa)), c0);
 				}
 			} else { // Square, :1448-1474, 1887-1916
 				const V2 dh = v2mul(d, hsw);
 				const V2 dhaa = v2mul(d, hswAA);
 				if (firstCap) {
-					w.v(b, v2add(p1, v2sub(lhaa, dhaa)), c0);
-					w.v(b + 1, v2add(p1, v2sub(lh, dh)), color);
-					w.v(b + 2, v2sub(p1, v2add(lh, dh)), color);
-					w.v(b + 3, v2sub(p1, v2add(lhaa, dhaa)), c0);
+					w.sv(0, v2add(p1, v2sub(lhaa, dhaa)), c0);
+					w.sv(1, v2add(p1, v2sub(lh, dh)), color);
+					w.sv(2, v2sub(p1, v2add(lh, dh)), color);
+					w.sv(3, v2sub(p1, v2add(lhaa, dhaa)), c0);
 				} else {
-					w.v(b, v2add(p1, v2add(lhaa, dhaa)), c0);
-					w.v(b + 1, v2add(p1, v2add(lh, dh)), color);
-					w.v(b + 2, v2sub(p1, v2sub(lh, dh)), color);
-					w.v(b + 3, v2sub(p1, v2sub(lhaa, dhaa)), c0);
+					w.sv(0, v2add(p1, v2add(lhaa, dhaa)), c0);
+					w.sv(1, v2add(p1, v2add(lh, dh)), color);
+					w.sv(2, v2sub(p1, v2sub(lh, dh)), color);
+					w.sv(3, v2sub(p1, v2sub(lhaa, dhaa)), c0);
 				}
 			}
 			if (firstCap) {
-				w.tri(k, 0, 2, 1);
-				w.tri(k + 3, 0, 3, 2);
+				w.stri(0, 0, 2, 1);
+				w.stri(3, 0, 3, 2);
 			} else {
-				w.bridge4(k, prev, rails(b, b + 1, b + 2, b + 3));
-				w.tri(k + 18, b, b + 1, b + 2);
-				w.tri(k + 21, b, b + 2, b + 3);
+				w.sbridge4(0, prev, rails(b, b + 1, b + 2, b + 3));
+				w.stri(18, b, b + 1, b + 2);
+				w.stri(21, b, b + 2, b + 3);
 			}
 			return;
 		}
@@ -342,12 +420,12 @@ __device__ __forceinline__ void elem_emit(const MeshCtx& m, const Elem& e, uint3
 		const V2 inner = L ? v2add(p1, vh) : v2sub(p1, vh);
 		const Rails entry = L ? rails(b, b + 1, b + 2, b + 3) : rails(b + 3, b + 2, b + 1, b);
 		uint32_t q = k;
-		w.v(b, innerAA, c0);
-		w.v(b + 1, inner, color);
+		w.sv(0, innerAA, c0);
+		w.sv(1, inner, color);
+		if (e.hasConnect) { w.sbridge4(0, prev, entry); q += 18; }
 		if (m.join == VGX_JOIN_MITER) {
-			w.v(b + 2, L ? v2sub(p1, vh) : v2add(p1, vh), color);
-			w.v(b + 3, L ? v2sub(p1, vhaa) : v2add(p1, vhaa), c0);
-			if (e.hasConnect) { w.bridge4(q, prev, entry); q += 18; }
+			w.sv(2, L ? v2sub(p1, vh) : v2add(p1, vh), color);
+			w.sv(3, L ? v2sub(p1, vhaa) : v2add(p1, vhaa), c0);
 		} else {
 			const V2 n01 = L ? v2cw(e.d01) : v2ccw(e.d01);
 			const V2 n12 = L ? v2cw(e.d12) : v2ccw(e.d12);
@@ -359,8 +437,8 @@ __device__ __forceinline__ void elem_emit(const MeshCtx& m, const Elem& e, uint3
 					const float cosAngle = vgm_abs(v2dot(n01, n12));
 					a = v2sub(a, v2mul(e.d01, cosAngle * fringe));
 				}
-				w.v(b + 2, a, color);
-				w.v(b + 3, aAA, c0);
+				w.sv(2, a, color);
+				w.sv(3, aAA, c0);
 			}
 			for (uint32_t i = 1; i < n; ++i) {
 				const float ang = e.arc.a01 + i * e.arc.arcDa;
@@ -380,7 +458,6 @@ __device__ __forceinline__ void elem_emit(const MeshCtx& m, const Elem& e, uint3
 				w.v(b + 2 + 2 * n, a, color);
 				w.v(b + 3 + 2 * n, aAA, c0);
 			}
-			if (e.hasConnect) { w.bridge4(q, prev, entry); q += 18; }
 			uint32_t arcID = b + 2;
 			for (uint32_t i = 0; i < n; ++i, arcID += 2, q += 9) {
 				if (L) {
@@ -429,19 +506,19 @@ __device__ __forceinline__ void elem_emit(const MeshCtx& m, const Elem& e, uint3
 			}
 			const V2 lh = v2mul(l, hsw);
 			if (m.cap == VGX_CAP_BUTT) { // :1032-1044, 1303-1321
-				w.v(b, v2add(p1, lh), color);
-				w.v(b + 1, v2sub(p1, lh), color);
+				w.sv(0, v2add(p1, lh), color);
+				w.sv(1, v2sub(p1, lh), color);
 			} else { // Square :1045-1058, 1322-1341
 				const V2 dh = v2mul(d, hsw);
 				if (firstCap) {
-					w.v(b, v2add(p1, v2sub(lh, dh)), color);
-					w.v(b + 1, v2sub(p1, v2add(lh, dh)), color);
+					w.sv(0, v2add(p1, v2sub(lh, dh)), color);
+					w.sv(1, v2sub(p1, v2add(lh, dh)), color);
 				} else {
-					w.v(b, v2add(p1, v2add(lh, dh)), color);
-					w.v(b + 1, v2sub(p1, v2sub(lh, dh)), color);
+					w.sv(0, v2add(p1, v2add(lh, dh)), color);
+					w.sv(1, v2sub(p1, v2sub(lh, dh)), color);
 				}
 			}
-			if (!firstCap) { w.bridge2(k, prev, rails(b, b + 1, 0, 0)); }
+			if (!firstCap) { w.sbridge2(0, prev, rails(b, b + 1, 0, 0)); }
 			return;
 		}
 		// join, :1088-1296
@@ -450,15 +527,15 @@ __device__ __forceinline__ void elem_emit(const MeshCtx& m, const Elem& e, uint3
 		const V2 inner = L ? v2add(p1, vh) : v2sub(p1, vh);
 		const Rails entry = L ? rails(b, b + 1, 0, 0) : rails(b + 1, b, 0, 0);
 		uint32_t q = k;
-		w.v(b, inner, color);
+		w.sv(0, inner, color);
+		if (e.hasConnect) { w.sbridge2(0, prev, entry); q += 6; }
 		if (m.join == VGX_JOIN_MITER) {
-			w.v(b + 1, L ? v2sub(p1, vh) : v2add(p1, vh), color);
-			if (e.hasConnect) { w.bridge2(q, prev, entry); q += 6; }
+			w.sv(1, L ? v2sub(p1, vh) : v2add(p1, vh), color);
 		} else {
 			const V2 n01 = L ? v2cw(e.d01) : v2ccw(e.d01);
 			const V2 n12 = L ? v2cw(e.d12) : v2ccw(e.d12);
 			const uint32_t n = e.arc.n;
-			w.v(b + 1, v2add(p1, v2mul(n01, hsw)), color);
+			w.sv(1, v2add(p1, v2mul(n01, hsw)), color);
 			for (uint32_t i = 1; i < n; ++i) {
 				const float ang = e.arc.a01 + i * e.arc.arcDa;
 				float sa, ca;
@@ -466,7 +543,6 @@ __device__ __forceinline__ void elem_emit(const MeshCtx& m, const Elem& e, uint3
 				w.v(b + 1 + i, v2(p1.x + hsw * ca, p1.y + hsw * sa), color);
 			}
 			w.v(b + 1 + n, v2add(p1, v2mul(n12, hsw)), color);
-			if (e.hasConnect) { w.bridge2(q, prev, entry); q += 6; }
 			for (uint32_t i = 0; i < n; ++i, q += 3) {
 				const uint32_t base = b + i;
 				if (L) { w.tri(q, b, base + 1, base + 2); } else { w.tri(q, b, base + 2, base + 1); }
@@ -488,22 +564,22 @@ __device__ __forceinline__ void elem_emit(const MeshCtx& m, const Elem& e, uint3
 			const V2 l = v2ccw(d);
 			const V2 lf = v2mul(l, f);
 			if (m.cap == VGX_CAP_BUTT) {
-				w.v(b, v2add(p1, lf), c0);
-				w.v(b + 1, p1, color);
-				w.v(b + 2, v2sub(p1, lf), c0);
+				w.sv(0, v2add(p1, lf), c0);
+				w.sv(1, p1, color);
+				w.sv(2, v2sub(p1, lf), c0);
 			} else {
 				const V2 df = v2mul(d, f);
 				if (firstCap) {
-					w.v(b, v2add(p1, v2sub(lf, df)), c0);
-					w.v(b + 1, p1, color);
-					w.v(b + 2, v2sub(p1, v2add(lf, df)), c0);
+					w.sv(0, v2add(p1, v2sub(lf, df)), c0);
+					w.sv(1, p1, color);
+					w.sv(2, v2sub(p1, v2add(lf, df)), c0);
 				} else {
-					w.v(b, v2add(p1, v2add(lf, df)), c0);
-					w.v(b + 1, p1, color);
-					w.v(b + 2, v2sub(p1, v2sub(lf, df)), c0);
+					w.sv(0, v2add(p1, v2add(lf, df)), c0);
+					w.sv(1, p1, color);
+					w.sv(2, v2sub(p1, v2sub(lf, df)), c0);
 				}
 			}
-			if (!firstCap) { w.bridge3(k, prev, rails(b, b + 1, b + 2, 0)); }
+			if (!firstCap) { w.sbridge3(0, prev, rails(b, b + 1, b + 2, 0)); }
 			return;
 		}
 		const V2 vf = v2mul(e.v, f);
@@ -511,17 +587,16 @@ __device__ __forceinline__ void elem_emit(const MeshCtx& m, const Elem& e, uint3
 		const V2 inner = L ? v2add(p1, vf) : v2sub(p1, vf);
 		const Rails entry = L ? rails(b, b + 1, b + 2, 0) : rails(b + 2, b + 1, b, 0);
 		uint32_t q = k;
-		w.v(b, inner, c0);
-		w.v(b + 1, p1, color);
+		w.sv(0, inner, c0);
+		w.sv(1, p1, color);
+		if (e.hasConnect) { w.sbridge3(0, prev, entry); q += 12; }
 		if (m.join == VGX_JOIN_MITER) {
-			w.v(b + 2, L ? v2sub(p1, vf) : v2add(p1, vf), c0);
-			if (e.hasConnect) { w.bridge3(q, prev, entry); q += 12; }
+			w.sv(2, L ? v2sub(p1, vf) : v2add(p1, vf), c0);
 		} else {
 			const V2 n01 = L ? v2cw(e.d01) : v2ccw(e.d01);
 			const V2 n12 = L ? v2cw(e.d12) : v2ccw(e.d12);
-			w.v(b + 2, v2add(p1, v2mul(n01, f)), c0);
-			w.v(b + 3, v2add(p1, v2mul(n12, f)), c0);
-			if (e.hasConnect) { w.bridge3(q, prev, entry); q += 12; }
+			w.sv(2, v2add(p1, v2mul(n01, f)), c0);
+			w.sv(3, v2add(p1, v2mul(n12, f)), c0);
 			if (L) { w.tri(q, b + 1, b + 2, b + 3); } else { w.tri(q, b + 1, b + 3, b + 2); }
 			q += 3;
 		}
@@ -599,11 +674,6 @@ __global__ __launch_bounds__(256) void k_mesh_prepare(VgxStrokeArgs A)
 // handle that natively (unaligned access mode), so every lane issues ONE dwordx4 for its two positions, ONE
 // dwordx2 for its two colours and ONE dwordx4 + ONE short for its nine indices -- no alignment-dependent
 // divergence.
-struct __attribute__((packed, aligned(8))) PosPair { float x0, y0, x1, y1; };
-struct __attribute__((packed, aligned(4))) ColPair { uint32_t c0, c1; };
-struct __attribute__((packed, aligned(2))) Idx9 { uint32_t a, b, c, d; uint16_t e; };
-struct __attribute__((packed, aligned(2))) Idx3 { uint32_t a; uint16_t b; };
-
 // Per-mesh record held one per lane for a window of 64 consecutive meshes (refilled every few dozen chunks):
 // the element lanes fetch their mesh's fields with shuffles instead of a dependent chain of global loads.
 struct FillWindow
@@ -764,7 +834,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_fill(VgxStrokeArgs A)
 // ------------------------------------------------------------------------------------------------
 // k_stroke: strokerPolylineStroke / StrokeAA / StrokeAAThin (stroker.cpp:1008-2314)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(VGX_WAVE) void k_stroke(VgxStrokeArgs A)
+__global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_stroke(VgxStrokeArgs A)
 {
 	const int lane = threadIdx.x;
 	if (A.totals->status != VGX_OK) {
@@ -860,13 +930,15 @@ __global__ __launch_bounds__(VGX_WAVE) void k_stroke(VgxStrokeArgs A)
 			const bool meshLast = valid && (mc.j == mc.N - 1);
 			if (valid) {
 				const vgx_mesh mr = A.mtab[mi];
-				MeshWriter<true> w;
+				StrokeWriter w;
 				w.pos = A.pos + 2 * mr.first_vertex;
 				w.col = A.color + mr.first_vertex;
 				w.idx = A.idx + mr.first_index;
 				w.color = color;
 				w.c0 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
-				elem_emit<true>(mc, e, vbase, ibase, rails_unpack(prevPacked), w);
+				w.reset();
+				elem_emit(mc, e, vbase, ibase, rails_unpack(prevPacked), w);
+				w.flush(vbase, ibase);
 				if (meshLast && A.meshes_out) {
 					A.meshes_out[mi] = mr;
 				}

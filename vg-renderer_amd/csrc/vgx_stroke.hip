@@ -783,27 +783,25 @@ __global__ __launch_bounds__(VGX_WAVE) void k_fill(VgxStrokeArgs A)
 				*(PosPair*)(A.pos + 2 * gv) = pp;
 				ColPair cp; cp.c0 = color; cp.c1 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
 				*(ColPair*)(A.color + gv) = cp;
-				// indices: k9 = 9j is a multiple of 3 and so is the fan size F = 3(N-2): position k9+r is fan corner
-				// (r%3) of triangle 3j + r/3 while k9+r < F, else fringe position q = k9+r-F = 3u+r with
-				// u = 3j-(N-2) >= -2. With U = u+2 = 2a+b: q = 6(a-1) + (3b+r), i.e. quad a-1+[3b+r >= 6],
-				// corner (3b+r) mod 6 -- no division (fan stroker.cpp:769-776, fringe :779-795).
+				// indices: my nine positions [9j, 9j+9) are three whole triangles T = 3j + g (the fan size 3(N-2) and the
+				// fringe quads are multiples of 3): T < N-2 is fan triangle (0, 2T+2, 2T+4) (stroker.cpp:769-776), else
+				// fringe triangle F = T-(N-2) = half (F&1) of the quad on edge F>>1: (fb, fb+1, nextOuter) /
+				// (fb, nextOuter, nextInner) with fb = 2*edge (stroker.cpp:779-795). No division, no per-index select.
 				const uint32_t k9 = 9 * j;
-				const uint32_t fan = 3 * (N - 2);
-				const int U = 3 * (int)j - (int)N + 4;
-				const uint32_t Ua = (uint32_t)(U > 0 ? U : 0) >> 1, Ub = (uint32_t)(U > 0 ? U : 0) & 1u;
 				uint32_t val[9];
 #pragma unroll
-				for (uint32_t r = 0; r < 9; ++r) {
-					const uint32_t t = 3 * j + r / 3, c3 = r % 3;
-					const uint32_t fanVal = (c3 == 0) ? 0u : (2 * t + 2 * c3);
-					const uint32_t q6 = r + 3 * Ub;
-					const uint32_t ed = Ua - 1u + (q6 >= 6 ? 1u : 0u); // wraps for fan positions, whose frVal is unused
-					const uint32_t c = q6 - (q6 >= 6 ? 6u : 0u);
+				for (uint32_t g = 0; g < 3; ++g) {
+					const uint32_t T = 3 * j + g;
+					const bool isFan = T + 2 < N;
+					const uint32_t F = T + 2 - N; // wraps for fan triangles, unused there
+					const uint32_t ed = F >> 1;
+					const bool second = (F & 1u) != 0;
 					const uint32_t fb = 2 * ed;
 					const bool lastEdge = ed + 1 == N;
 					const uint32_t nextInner = lastEdge ? 0u : fb + 2, nextOuter = lastEdge ? 1u : fb + 3;
-					const uint32_t frVal = (c == 0 || c == 3) ? fb : (c == 1 ? fb + 1 : (c == 5 ? nextInner : nextOuter));
-					val[r] = ((k9 + r < fan) ? fanVal : frVal) & 0xFFFFu;
+					val[3 * g] = isFan ? 0u : fb;
+					val[3 * g + 1] = (isFan ? 2 * T + 2 : (second ? nextOuter : fb + 1)) & 0xFFFFu;
+					val[3 * g + 2] = (isFan ? 2 * T + 4 : (second ? nextInner : nextOuter)) & 0xFFFFu;
 				}
 				uint16_t* pi = A.idx + firstI + k9;
 				if (j + 1 < N) {

@@ -787,8 +787,11 @@ int vgx_tessellate_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* dr
 	int st = flattenCountCommon(ctx, ps, draws, ndraws, s);
 	if (st != VGX_OK) { return st; }
 	const vgx_sizes sz = ctx->hostTotals->sizes;
-	// polyline scratch doubles as the heap of the single-pass path: head room for block fragmentation
-	const uint64_t heapVerts = sz.num_poly_vertices + sz.num_poly_vertices / 4 + (uint64_t)VGX_BUILD_WAVES * VGX_BUILD_BLOCK;
+	// Polyline scratch doubles as the heap of the single-pass path (k_flatten_build). Its waves switch to a fresh block
+	// when a chunk does not fit: the unused tail of the old block is smaller than that chunk (<= 1x the real vertices
+	// over the whole batch), the moved prefix of a spanning sub-path is < VGX_LONG_SUBPATH per >= VGX_BUILD_BLOCK block
+	// (<= 1/4), and longer sub-paths grow geometrically (<= 4x their own size). Plus every wave's last open block.
+	const uint64_t heapVerts = sz.num_poly_vertices * 9 / 4 + 4 * ctx->hostTotals->long_subpath_vertices + 2 * (uint64_t)VGX_BUILD_WAVES * VGX_BUILD_BLOCK;
 	if ((st = ensureMeshBuffers(ctx, heapVerts, sz.num_subpaths, sz.num_meshes)) != VGX_OK) { return st; }
 	VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, 1);
 	vgx_launch_flatten(true, a, VGX_GRID_BLOCKS, s);

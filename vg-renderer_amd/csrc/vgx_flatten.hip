@@ -156,7 +156,8 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 	const VgxPathSetDev& ps = A.ps;
 	const uint64_t totalCmds = A.cmd_prefix[A.ndraws];
 	if (A.totals->status != VGX_OK) { return; } // capacity / range errors detected by the scan steps
-	const uint64_t numSegments = (totalCmds + VGX_WAVE - 1) / VGX_WAVE;
+	const uint64_t segItems = vgx_segment_items(totalCmds, gridDim.x);
+	const uint64_t numSegments = (totalCmds + segItems - 1) / segItems;
 	// contiguous run of segments per wave: one binary search per wave, then cooperative advance (vgx_wave.h)
 	const uint64_t segsPerWave = (numSegments + gridDim.x - 1) / gridDim.x;
 	const uint64_t seg0 = (uint64_t)blockIdx.x * segsPerWave;
@@ -164,13 +165,13 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 	if (seg0 >= seg1) {
 		return;
 	}
-	uint64_t dNext = lower_bound_u64(A.cmd_prefix, 0, A.ndraws, seg0 * VGX_WAVE);
+	uint64_t dNext = lower_bound_u64(A.cmd_prefix, 0, A.ndraws, seg0 * segItems);
 	uint64_t wbase = dNext;
 	DrawWindow W = draw_window_load(A, wbase, lane);
 
 	for (uint64_t seg = seg0; seg < seg1; ++seg) {
 		const uint64_t d0 = dNext;
-		const uint64_t d1 = advance_lower_bound(A.cmd_prefix, d0, A.ndraws, (seg + 1) * VGX_WAVE, lane);
+		const uint64_t d1 = advance_lower_bound(A.cmd_prefix, d0, A.ndraws, (seg + 1) * segItems, lane);
 		dNext = d1;
 		if (d0 == d1) {
 			continue;
@@ -322,6 +323,9 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 			const bool slowDraw = ((slowMask & mine) != 0) || (dh < 0 && carrySlow);
 
 			if (!EMIT) {
+				if (lastInSub && spTotal > VGX_LONG_SUBPATH) { // sizing input of the single-pass heap (vgx_tessellate_count)
+					atomicAdd(&A.totals->long_subpath_vertices, (unsigned long long)spTotal);
+				}
 				if (valid) {
 					uint32_t w = (uint32_t)(cnt < 0 ? 0 : cnt) & VGX_CC_COUNT_MASK;
 					if (exists) { w |= VGX_CC_EXISTS; }
@@ -449,9 +453,10 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 //   - each lane keeps the first VGX_LEAF_SLOTS leaves of its command in LDS (98 % of real-world cubics fit); after the
 //     chunk's prefix scan it copies them to the polyline HEAP (transformPos2D applied on the way); only lanes with more
 //     leaves re-run their subdivision writing straight to memory;
-//   - a wave owns a contiguous run of segments (whole draws) and places them back to back in wave-private blocks of a
-//     bump-allocated heap (one atomic per VGX_BUILD_BLOCK vertices, none per chunk); a segment that does not fit the
-//     current block is restarted in a fresh block (or in an exactly sized region if it is larger than a block);
+//   - a wave owns a contiguous run of segments (whole draws) and places their vertices back to back in wave-private
+//     blocks of a bump-allocated heap (one atomic per VGX_BUILD_BLOCK vertices, none per chunk); when a chunk does not
+//     fit the current block the wave continues in a fresh block, moving along the vertices of the one sub-path that
+//     spans into the chunk (only sub-paths must be contiguous);
 //   - per sub-path it records {first vertex, count, closed} sparsely at the command-instance index of the sub-path's
 //     last command; k_flatten_gather (after the scan over draws has produced ordered mesh indices) turns those into
 //     mesh descriptors in the reference's call order.
@@ -477,6 +482,68 @@ struct BuildCubicSink // counts leaves, detects the serial-path cases, keeps the
 	__device__ __forceinline__ void dropped() { slow = true; }
 };
 
+// Hand-shaped hot loop of the build kernel: the same walk as vgx_flatten_cubic_n<VGX_LDS_LEVELS, true> + BuildCubicSink,
+// with the points kept as packed float pairs (v_pk_add/mul_f32), running LDS addresses instead of level * stride
+// multiplies, and the epsilon test folded into a running minimum. Arithmetic and its order are unchanged
+// (path.cpp:107-170, 769-775). Returns false when the cubic nests deeper than the LDS levels (caller redoes it).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ bool build_flatten_hot(v2f P1, v2f P2, v2f P3, v2f P4, float tessTol, float2* stackLane, float2* slots, float2* over, uint32_t* nOut, bool* slowOut)
+{
+	int pending = 0;
+	uint32_t n = 0;
+	float minD2 = 3.0e38f; // smallest squared distance between consecutive vertices
+	v2f prev = P1;
+	bool more = true, aborted = false;
+	uint32_t sp = 0; // next free stack entry, in float2 units relative to stackLane
+	while (more) {
+		const v2f d = P4 - P1;
+		const v2f a2 = P2 - P4, a3 = P3 - P4;
+		const v2f dsw = d.yx;
+		const v2f m2 = a2 * dsw, m3 = a3 * dsw;
+		const float d2 = __builtin_fabsf(m2.x - m2.y), d3 = __builtin_fabsf(m3.x - m3.y);
+		const float d23 = d2 + d3;
+		const v2f dd = d * d;
+		const bool flat = d23 * d23 <= tessTol * (dd.x + dd.y);
+		const bool push = !flat && pending < VGX_LDS_LEVELS;
+		const v2f P12 = (P1 + P2) * 0.5f, P23 = (P2 + P3) * 0.5f, P34 = (P3 + P4) * 0.5f;
+		const v2f P123 = (P12 + P23) * 0.5f, P234 = (P23 + P34) * 0.5f;
+		const v2f P1234 = (P123 + P234) * 0.5f;
+		v2f N2 = P12, N3 = P123, N4 = P1234;
+		if (push) {
+			stackLane[sp] = make_float2(P234.x, P234.y);
+			stackLane[sp + VGX_WAVE] = make_float2(P34.x, P34.y);
+			stackLane[sp + 2 * VGX_WAVE] = make_float2(P4.x, P4.y);
+			sp += 3 * VGX_WAVE;
+		} else {
+			if (flat) {
+				const v2f e = prev - P4;
+				const v2f ee = e * e;
+				const float dist2 = ee.x + ee.y;
+				minD2 = dist2 < minD2 ? dist2 : minD2;
+				prev = P4;
+				if (n < VGX_LEAF_SLOTS) { slots[n * VGX_WAVE] = make_float2(P4.x, P4.y); }
+				else if (n < VGX_LEAF_SLOTS + VGX_BUILD_OVERFLOW) { over[(n - VGX_LEAF_SLOTS) * VGX_WAVE] = make_float2(P4.x, P4.y); }
+				++n;
+			} else {
+				aborted = true;
+			}
+			P1 = P4;
+			if (pending > 0) {
+				sp -= 3 * VGX_WAVE;
+				const float2 q2 = stackLane[sp], q3 = stackLane[sp + VGX_WAVE], q4 = stackLane[sp + 2 * VGX_WAVE];
+				N2.x = q2.x; N2.y = q2.y; N3.x = q3.x; N3.y = q3.y; N4.x = q4.x; N4.y = q4.y;
+			}
+		}
+		more = (push || pending > 0) && !aborted;
+		pending += push ? 1 : -1;
+		P2 = N2; P3 = N3; P4 = N4;
+	}
+	*nOut = n;
+	*slowOut = minD2 < VGM_EPSILON;
+	return !aborted;
+}
+
 __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 {
 	__shared__ float2 s_stack[VGX_LDS_LEVELS * 3 * VGX_WAVE];
@@ -488,21 +555,22 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 	const VgxPathSetDev& ps = A.ps;
 	const uint64_t totalCmds = A.cmd_prefix[A.ndraws];
 	if (A.totals->status != VGX_OK) { return; }
-	const uint64_t numSegments = (totalCmds + VGX_WAVE - 1) / VGX_WAVE;
+	const uint64_t segItems = vgx_segment_items(totalCmds, gridDim.x);
+	const uint64_t numSegments = (totalCmds + segItems - 1) / segItems;
 	const uint64_t segsPerWave = (numSegments + gridDim.x - 1) / gridDim.x;
 	const uint64_t seg0 = (uint64_t)blockIdx.x * segsPerWave;
 	const uint64_t seg1 = (seg0 + segsPerWave < numSegments) ? seg0 + segsPerWave : numSegments;
 	if (seg0 >= seg1) {
 		return;
 	}
-	uint64_t dNext = lower_bound_u64(A.cmd_prefix, 0, A.ndraws, seg0 * VGX_WAVE);
+	uint64_t dNext = lower_bound_u64(A.cmd_prefix, 0, A.ndraws, seg0 * segItems);
 	uint64_t wbase = dNext;
 	DrawWindow W = draw_window_load(A, wbase, lane);
 	uint64_t blockCur = 0, blockEnd = 0; // wave-private heap block [blockCur, blockEnd)
 
 	for (uint64_t seg = seg0; seg < seg1; ++seg) {
 		const uint64_t d0 = dNext;
-		const uint64_t d1 = advance_lower_bound(A.cmd_prefix, d0, A.ndraws, (seg + 1) * VGX_WAVE, lane);
+		const uint64_t d1 = advance_lower_bound(A.cmd_prefix, d0, A.ndraws, (seg + 1) * segItems, lane);
 		dNext = d1;
 		if (d0 == d1) {
 			continue;
@@ -510,10 +578,8 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 		const uint64_t C0 = A.cmd_prefix[d0];
 		const uint64_t C1 = A.cmd_prefix[d1];
 
-		for (int attempt = 0; attempt < 3; ++attempt) {
-			bool writing = true;     // false after the segment overflowed its block: keep counting, stop writing
+		{
 			uint64_t cur = blockCur; // next free heap vertex
-			uint64_t segTotal = 0;
 			uint64_t dcur = d0;
 			int carryDrawVerts = 0, carrySpVerts = 0, carrySubs = 0, carryFill = 0, carryStroke = 0, carrySlow = 0;
 
@@ -584,12 +650,19 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 							ex = a[2]; ey = a[3];
 							vgx_quad_to_cubic(start.x, start.y, a[0], a[1], ex, ey, &c1x, &c1y, &c2x, &c2y);
 						}
-						BuildCubicSink sink;
-						sink.prev = start; sink.n = 0; sink.slow = false; sink.slots = &s_leaf[lane];
-						sink.over = (float2*)A.leaf_overflow + (size_t)blockIdx.x * VGX_BUILD_OVERFLOW * VGX_WAVE + lane;
-						wave_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tol / (scale * scale), stack, sink);
-						cnt = (int)sink.n;
-						slow = sink.slow;
+						float2* over = (float2*)A.leaf_overflow + (size_t)blockIdx.x * VGX_BUILD_OVERFLOW * VGX_WAVE + lane;
+						const float tessTol = tol / (scale * scale);
+						uint32_t nLeaves = 0;
+						v2f q1, q2, q3, q4;
+						q1.x = start.x; q1.y = start.y; q2.x = c1x; q2.y = c1y; q3.x = c2x; q3.y = c2y; q4.x = ex; q4.y = ey;
+						if (!build_flatten_hot(q1, q2, q3, q4, tessTol, &s_stack[lane], &s_leaf[lane], over, &nLeaves, &slow)) {
+							BuildCubicSink sink; // nests deeper than the LDS levels: full-depth walk from the root
+							sink.prev = start; sink.n = 0; sink.slow = false; sink.slots = &s_leaf[lane]; sink.over = over;
+							vgx_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tessTol, stack, sink);
+							nLeaves = sink.n;
+							slow = sink.slow;
+						}
+						cnt = (int)nLeaves;
 					} break;
 					case VGX_CMD_POLYLINE: {
 						const uint32_t npts = na >> 1;
@@ -633,10 +706,31 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 				const int nvalid = (int)((C1 - chunk) < (uint64_t)VGX_WAVE ? (C1 - chunk) : (uint64_t)VGX_WAVE);
 				const int L = nvalid - 1;
 				const int chunkTotal = wave_bcast(incl, L);
-				if (writing && cur + (uint64_t)(chunkTotal > 0 ? chunkTotal : 0) > blockEnd) {
-					writing = false; // this segment does not fit the block any more: finish counting, then retry elsewhere
+				if (cur + (uint64_t)(chunkTotal > 0 ? chunkTotal : 0) > blockEnd) {
+					// The chunk does not fit the wave's block: continue in a fresh one. Only a sub-path's vertices must be
+					// contiguous, so the vertices the sub-path that spans into this chunk already has are moved along;
+					// the new block has room for twice that prefix, so a very long sub-path is moved O(1) times per
+					// vertex.
+					const uint64_t carry = (uint64_t)(carrySpVerts > 0 ? carrySpVerts : 0);
+					const uint64_t need = carry + (uint64_t)(chunkTotal > 0 ? chunkTotal : 0);
+					const uint64_t want = need + carry > (uint64_t)VGX_BUILD_BLOCK ? need + carry : (uint64_t)VGX_BUILD_BLOCK; // doubles the spanning sub-path only
+					unsigned long long base = 0;
+					if (lane == 0) { base = atomicAdd(&A.totals->poly_heap_cursor, (unsigned long long)want); }
+					base = wave_bcast_u64(base, 0);
+					if (base + want > A.caps.poly_vertices) {
+						if (lane == 0) { atomicCAS(&A.totals->status, (uint32_t)VGX_OK, (uint32_t)VGX_E_NOSPACE); }
+						return;
+					}
+					if (carry > 0) {
+						__threadfence_block(); // the prefix was written by other lanes of this wave
+						const float2* src = (const float2*)A.poly + (cur - carry);
+						float2* dst = (float2*)A.poly + base;
+						for (uint64_t i = (uint64_t)lane; i < carry; i += VGX_WAVE) { dst[i] = src[i]; }
+					}
+					cur = base + carry;
+					blockEnd = base + want;
 				}
-				if (writing) {
+				{
 					const uint64_t g = cur + (uint64_t)excl; // heap index of my first vertex
 					if (valid && !serialDraw) {
 						// my last vertex is the one pathClose removes (same decision the CLOSE lane takes)
@@ -697,7 +791,6 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 					}
 					cur += (uint64_t)(chunkTotal > 0 ? chunkTotal : 0);
 				}
-				segTotal += (uint64_t)(chunkTotal > 0 ? chunkTotal : 0);
 
 				// carries into the next chunk
 				const int lastIsDrawLast = wave_bcast((int)drawLast, L);
@@ -716,21 +809,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 				carrySpVerts = (lastIsDrawLast || lastIsSubLast) ? 0 : nSp;
 				dcur = wave_bcast_u64(d, L);
 			}
-			if (writing) {
-				blockCur = cur;
-				break;
-			}
-			// the segment overflowed the block: take a fresh block (or an exactly sized region) and redo it
-			const uint64_t want = segTotal > (uint64_t)VGX_BUILD_BLOCK ? segTotal : (uint64_t)VGX_BUILD_BLOCK;
-			unsigned long long base = 0;
-			if (lane == 0) { base = atomicAdd(&A.totals->poly_heap_cursor, (unsigned long long)want); }
-			base = wave_bcast_u64(base, 0);
-			if (base + want > A.caps.poly_vertices) {
-				if (lane == 0) { atomicCAS(&A.totals->status, (uint32_t)VGX_OK, (uint32_t)VGX_E_NOSPACE); }
-				return;
-			}
-			blockCur = base;
-			blockEnd = base + want;
+			blockCur = cur;
 		}
 	}
 }

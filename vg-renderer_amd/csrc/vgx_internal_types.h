@@ -89,7 +89,9 @@ struct VgxTotals
 	uint32_t status;       // vgx_status, sticky (first error wins)
 	uint32_t num_round_meshes; // meshes with Round joins (their sizes need the geometry)
 	unsigned long long poly_heap_cursor; // BUILD mode: bump allocator of the polyline heap (vertices)
+	unsigned long long long_subpath_vertices; // count pass: vertices in sub-paths longer than VGX_LONG_SUBPATH (heap sizing)
 };
+#define VGX_LONG_SUBPATH 2048
 
 // Capacities the device-side checks compare against.
 struct VgxCaps

@@ -840,17 +840,18 @@ __global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
 	}
 	const uint64_t numMeshes = A.totals->sizes.num_meshes;
 	const uint64_t totalElems = A.elem_prefix[numMeshes];
-	const uint64_t numSegments = (totalElems + VGX_WAVE - 1) / VGX_WAVE;
+	const uint64_t segItems = vgx_segment_items(totalElems, gridDim.x);
+	const uint64_t numSegments = (totalElems + segItems - 1) / segItems;
 	const uint64_t segsPerWave = (numSegments + gridDim.x - 1) / gridDim.x;
 	const uint64_t seg0 = (uint64_t)blockIdx.x * segsPerWave;
 	const uint64_t seg1 = (seg0 + segsPerWave < numSegments) ? seg0 + segsPerWave : numSegments;
 	if (seg0 >= seg1) {
 		return;
 	}
-	uint64_t mNext = lower_bound_u64(A.elem_prefix, 0, numMeshes, seg0 * VGX_WAVE);
+	uint64_t mNext = lower_bound_u64(A.elem_prefix, 0, numMeshes, seg0 * segItems);
 	for (uint64_t seg = seg0; seg < seg1; ++seg) {
 		const uint64_t m0 = mNext;
-		const uint64_t m1 = advance_lower_bound(A.elem_prefix, m0, numMeshes, (seg + 1) * VGX_WAVE, lane);
+		const uint64_t m1 = advance_lower_bound(A.elem_prefix, m0, numMeshes, (seg + 1) * segItems, lane);
 		mNext = m1;
 		if (m0 == m1) {
 			continue;

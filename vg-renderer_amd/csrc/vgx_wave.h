@@ -125,6 +125,17 @@ __device__ __forceinline__ uint64_t advance_lower_bound(const uint64_t* P, uint6
 	}
 }
 
+// Items per segment. Draws (flatten) and meshes (stroke) are bucketed whole into segments of the flat item stream and
+// a segment is walked in 64-item chunks, so the last chunk of every segment is partly empty: with ~25-item draws,
+// 64-item segments run at ~67 % lane use, 512-item segments at ~94 %. Small batches keep small segments so that
+// they still spread over many waves (>= 4 segments per wave before growing). Wave-uniform.
+__device__ __forceinline__ uint64_t vgx_segment_items(uint64_t total, uint32_t grid)
+{
+	uint64_t per = total / ((uint64_t)grid * 4 * VGX_WAVE);
+	per = per < 1 ? 1 : (per > 8 ? 8 : per);
+	return per * VGX_WAVE;
+}
+
 // 64-entry window of the prefix array held one entry per lane: w = P[first + lane] (or ~0 past `last`).
 // window_owner returns the offset k (0..63) of the LAST window entry <= key (requires W[0] <= key); *pv gets
 // that entry. Six shuffle steps, no memory traffic.

@@ -622,8 +622,21 @@ int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset**
 	const size_t oFlags = align(oType + ncmd + 1);
 	const size_t oPathFlags = align(oFlags + ncmd + 1);
 	const size_t oRec = align(oPathFlags + npaths + 1);
-	const size_t total = align(oRec + (size_t)(ncmd + 1) * sizeof(VgxCmdRec));
+	// per path: the commands that end a sub-path (k_flatten_gather walks these instead of every command)
+	std::vector<uint32_t> pathSubBegin(npaths + 1, 0), subLastCmd;
+	for (uint32_t p = 0; p < npaths; ++p) {
+		pathSubBegin[p] = (uint32_t)subLastCmd.size();
+		for (uint32_t c = desc->path_cmd_begin[p]; c < desc->path_cmd_begin[p + 1]; ++c) {
+			if (cmdFlags[c] & VGX_CF_LAST_IN_SUB) { subLastCmd.push_back(c - desc->path_cmd_begin[p]); }
+		}
+	}
+	pathSubBegin[npaths] = (uint32_t)subLastCmd.size();
+	const size_t oSubBegin = align(oRec + (size_t)(ncmd + 1) * sizeof(VgxCmdRec));
+	const size_t oSubLast = align(oSubBegin + (npaths + 1) * sizeof(uint32_t));
+	const size_t total = align(oSubLast + (subLastCmd.size() + 1) * sizeof(uint32_t));
 	std::vector<uint8_t> host(total, 0);
+	memcpy(&host[oSubBegin], pathSubBegin.data(), (npaths + 1) * sizeof(uint32_t));
+	if (!subLastCmd.empty()) { memcpy(&host[oSubLast], subLastCmd.data(), subLastCmd.size() * sizeof(uint32_t)); }
 	if (nargs) { memcpy(&host[oArgs + 2 * sizeof(float)], desc->args, nargs * sizeof(float)); }
 	memcpy(&host[oArgOff], desc->cmd_arg_off, (ncmd + 1) * sizeof(uint32_t));
 	if (ncmd) {
@@ -682,6 +695,8 @@ int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset**
 	ps->dev.cmd_flags = b + oFlags;
 	ps->dev.path_flags = b + oPathFlags;
 	ps->dev.cmdrec = (const VgxCmdRec*)(b + oRec);
+	ps->dev.path_sub_begin = (const uint32_t*)(b + oSubBegin);
+	ps->dev.sub_last_cmd = (const uint32_t*)(b + oSubLast);
 	ps->dev.npaths = npaths;
 	ps->dev.ncmd = ncmd;
 	*out_ps = ps;

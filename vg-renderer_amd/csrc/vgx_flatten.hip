@@ -826,14 +826,13 @@ __global__ __launch_bounds__(256) void k_flatten_gather(VgxFlattenArgs A)
 		if ((di.flags & 1u) || di.num_meshes == 0) { continue; }
 		const vgx_draw* dr = A.draws + d;
 		const uint32_t path = dr->path;
-		const uint32_t pc0 = ps.path_cmd_begin[path], pc1 = ps.path_cmd_begin[path + 1];
+		const uint32_t sb0 = ps.path_sub_begin[path], sb1 = ps.path_sub_begin[path + 1];
 		const uint64_t cbase = A.cmd_prefix[d];
 		const uint32_t fillFlags = dr->fill_flags, strokeFlags = dr->stroke_flags;
 		const uint32_t numFill = di.flags >> 1;
 		uint32_t f = 0, s = 0, subIndex = 0;
-		for (uint32_t c = pc0; c < pc1; ++c) {
-			if (!(ps.cmd_flags[c] & VGX_CF_LAST_IN_SUB)) { continue; }
-			const uint64_t ci = cbase + (c - pc0);
+		for (uint32_t sb = sb0; sb < sb1; ++sb) {
+			const uint64_t ci = cbase + ps.sub_last_cmd[sb];
 			const uint32_t info = A.sub_info[ci];
 			const uint32_t n = info & 0x7FFFFFFFu;
 			const bool closed = (info >> 31) != 0;

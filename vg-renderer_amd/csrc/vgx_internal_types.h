@@ -44,6 +44,8 @@ struct VgxPathSetDev
 	const float* args;
 	const uint32_t* path_cmd_begin;
 	const uint8_t* path_flags;
+	const uint32_t* path_sub_begin; // [npaths + 1] first entry of the path in sub_last_cmd
+	const uint32_t* sub_last_cmd;   // command index (relative to the path's first command) of every LAST_IN_SUB command
 	uint32_t npaths;
 	uint32_t ncmd;
 };

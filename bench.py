@@ -218,6 +218,16 @@ def main():
         dom = max((k for k in stage_sum if k in ab and k != "pipeline"), key=lambda k: stage_sum[k])
         dom_ms = stage_sum[dom]
         achieved = ab[dom] / (dom_ms * 1e-3) / 1e9
+        # HBM traffic of that kernel per launch: not measurable from inside the process; taken from the committed
+        # rocprofv3 --pmc passes of this same command (profiles/traffic.json), only for the workload they were made on
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                tj = json.load(f)
+            if tj.get("instances_per_gpu") == K and dom in tj["kernels"]:
+                traffic = tj["kernels"][dom]["traffic_bytes"]
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "M tessellated verts/sec (stroke+fill AA), Tiger x10k batch",
             "value": round(value, 2), "unit": "M verts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -228,7 +238,7 @@ def main():
                        "verts_per_gpu": sizes["num_vertices"], "indices_per_gpu": sizes["num_indices"], "meshes_per_gpu": sizes["num_meshes"],
                        "poly_verts_per_gpu": sizes["num_poly_vertices"], "serial_draws": sizes["num_serial_draws"]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms": round(dom_ms, 3), "algorithmic_bytes": ab[dom],
                          "pipeline_achieved": round(ab["pipeline"] / (ms_per_step * 1e-3) / 1e9, 1)},
             "stage_ms": {k: round(v, 3) for k, v in stage_sum.items()},

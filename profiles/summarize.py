@@ -35,8 +35,28 @@ def pmc(db, counter):
         print("%-90s %6d %14.1f %14.1f %12.1f" % (name[:90], n, kb, mb, dur / 1000.0))
 
 
+def traffic(fetch_db, write_db, label):
+    """JSON for bench.py's roofline.traffic: HBM bytes per launch of the three big kernels = FETCH_SIZE x 2 (gfx950
+    correction for wide coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE (raw), from two separate --pmc passes."""
+    import json
+    names = {"k_flatten_build": "flatten_build", "k_fill": "fill_emit", "k_stroke": "stroke_emit", "k_flatten_gather": "flatten_gather", "k_mesh_prepare": "mesh_prepare"}
+    out = {"source": label, "instances_per_gpu": 10000, "kernels": {}}
+    for db, ctr, mul in ((fetch_db, "FETCH_SIZE", 2.0), (write_db, "WRITE_SIZE", 1.0)):
+        c = sqlite3.connect(db).cursor()
+        for name, kb in c.execute("select kernel_name, avg(value) from counters_collection where counter_name=? group by kernel_name", (ctr,)):
+            for k, stage in names.items():
+                if k + "(" in name:
+                    d = out["kernels"].setdefault(stage, {"fetch_bytes": 0, "write_bytes": 0})
+                    d["fetch_bytes" if ctr == "FETCH_SIZE" else "write_bytes"] = int(kb * 1024 * mul)
+    for d in out["kernels"].values():
+        d["traffic_bytes"] = d["fetch_bytes"] + d["write_bytes"]
+    print(json.dumps(out, indent=1))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "trace":
         trace(sys.argv[2])
+    elif sys.argv[1] == "traffic":
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
         pmc(sys.argv[2], sys.argv[3])

@@ -43,7 +43,7 @@ struct vgx_ctx
 	int device;
 	int lastHipError;
 	// grow-only device scratch
-	DevBuf cmdPrefix, cmdCnt, subFirst, leafOverflow, dinfo, poly, subs, mdesc, elemPrefix, elemPrefixS, mprep, mtab, partial, totals;
+	DevBuf cmdPrefix, cmdCnt, subFirst, leafOverflow, serialList, dinfo, poly, subs, mdesc, elemPrefix, elemPrefixS, mprep, mtab, partial, totals;
 	VgxCaps caps; // element capacities matching the buffers above
 	uint64_t capDraws;
 	VgxTotals* hostTotals; // pinned
@@ -306,6 +306,7 @@ VgxFlattenArgs flattenArgs(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* 
 	a.sub_info = (uint32_t*)ctx->cmdCnt.p;
 	a.build_mode = 0;
 	a.leaf_overflow = (float*)ctx->leafOverflow.p;
+	a.serial_list = (uint32_t*)ctx->serialList.p;
 	return a;
 }
 
@@ -314,6 +315,7 @@ int ensureDrawBuffers(vgx_ctx* ctx, uint64_t ndraws)
 	int st;
 	if ((st = ensure(ctx, ctx->cmdPrefix, (ndraws + 1) * sizeof(uint64_t))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->dinfo, (ndraws + 1) * sizeof(vgx_draw_info))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->serialList, (ndraws + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->partial, VGX_SCAN_BLOCKS * sizeof(Sum3))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->totals, sizeof(VgxTotals))) != VGX_OK) { return st; }
 	ctx->capDraws = ndraws;
@@ -482,7 +484,7 @@ int vgx_destroy(vgx_ctx* ctx)
 	if (!ctx) {
 		return VGX_E_INVALID_ARG;
 	}
-	DevBuf* bufs[] = { &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DevBuf* bufs[] = { &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
@@ -501,7 +503,7 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx)
 	if (!ctx) {
 		return 0;
 	}
-	return ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
+	return ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
 }
 
 // ---- path set ---------------------------------------------------------------------------------------

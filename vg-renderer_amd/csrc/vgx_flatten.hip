@@ -776,6 +776,16 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 							A.sub_info[ci] = (uint32_t)spTotal | (closedHere ? 0x80000000u : 0u);
 						}
 					}
+					{ // draws the serial kernel has to (re)do: static serial paths and degenerate draws, wave-aggregated append
+						const bool toSerial = valid && drawLast && (serialDraw || slowDraw);
+						const uint64_t sm = wave_ballot(toSerial);
+						if (sm) {
+							unsigned long long sbase = 0;
+							if (lane == 0) { sbase = atomicAdd(&A.totals->num_serial_list, (unsigned long long)__popcll(sm)); }
+							sbase = wave_bcast_u64(sbase, 0);
+							if (toSerial) { A.serial_list[sbase + (uint64_t)__popcll(sm & lanemask_lt(lane))] = (uint32_t)d; }
+						}
+					}
 					if (valid && drawLast && !serialDraw) {
 						vgx_draw_info di;
 						di.first_poly_vertex = g - (uint64_t)inDrawBefore; di.first_subpath = 0; di.first_mesh = 0;
@@ -880,7 +890,10 @@ __global__ __launch_bounds__(256) void k_flatten_serial(VgxFlattenArgs A)
 	if (A.totals->status != VGX_OK) { return; }
 	const VgxPathSetDev& ps = A.ps;
 	PrivStack stack;
-	for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < A.ndraws; d += (uint64_t)gridDim.x * blockDim.x) {
+	// BUILD mode: k_flatten_build listed the draws to do; otherwise every draw is inspected
+	const uint64_t nwork = A.build_mode ? (uint64_t)A.totals->num_serial_list : A.ndraws;
+	for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwork; w += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t d = A.build_mode ? (uint64_t)A.serial_list[w] : w;
 		const vgx_draw* dr = A.draws + d;
 		const uint32_t path = dr->path;
 		const bool serial = (ps.path_flags[path] & VGX_PF_SERIAL) || (A.dinfo[d].flags & 1u);

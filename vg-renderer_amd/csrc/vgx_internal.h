@@ -29,6 +29,7 @@ struct VgxFlattenArgs
 	unsigned long long* sub_first; // [num_cmd_instances] global index of the sub-path's first polyline vertex
 	uint32_t* sub_info;            // [num_cmd_instances] vertex count | closed << 31 (aliases cmd_cnt)
 	int build_mode;                // k_flatten_serial<count>: allocate the draw's vertices from the polyline heap
+	uint32_t* serial_list;         // BUILD mode: draws for k_flatten_serial (static serial paths + degenerate draws), unordered
 	float* leaf_overflow;          // [VGX_BUILD_WAVES][VGX_BUILD_OVERFLOW][64][2] leaves that did not fit the LDS slots
 };
 

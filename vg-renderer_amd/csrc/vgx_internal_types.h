@@ -92,6 +92,7 @@ struct VgxTotals
 	uint32_t num_round_meshes; // meshes with Round joins (their sizes need the geometry)
 	unsigned long long poly_heap_cursor; // BUILD mode: bump allocator of the polyline heap (vertices)
 	unsigned long long long_subpath_vertices; // count pass: vertices in sub-paths longer than VGX_LONG_SUBPATH (heap sizing)
+	unsigned long long num_serial_list;  // BUILD mode: entries of serial_list (draws k_flatten_serial has to redo)
 };
 #define VGX_LONG_SUBPATH 2048
 

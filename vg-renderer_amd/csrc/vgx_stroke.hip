@@ -832,8 +832,23 @@ __global__ __launch_bounds__(VGX_WAVE) void k_fill(VgxStrokeArgs A)
 // ------------------------------------------------------------------------------------------------
 // k_stroke: strokerPolylineStroke / StrokeAA / StrokeAAThin (stroker.cpp:1008-2314)
 // ------------------------------------------------------------------------------------------------
+// Window of 64 consecutive mesh records kept in LDS (64 B each): loaded cooperatively (one mesh per lane) when the
+// walk leaves the previous window, read back by the element lanes with four ds_read_b128. This takes the per-element
+// mesh-table gathers (a chain of dependent global loads per chunk: prefix -> descriptor -> vertex) off the critical
+// path: the only global load a chunk waits for is its polyline vertices.
+struct __attribute__((aligned(16))) StrokeRec
+{
+	uint64_t polyFirst;
+	uint32_t N, kind;
+	uint32_t draw;
+	float hsw, hswAA, fringe;
+	uint64_t firstV, firstI;
+	uint32_t color, pad0, pad1, pad2;
+};
+
 __global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_stroke(VgxStrokeArgs A)
 {
+	__shared__ StrokeRec s_win[VGX_WAVE];
 	const int lane = threadIdx.x;
 	if (A.totals->status != VGX_OK) {
 		return;
@@ -849,6 +864,8 @@ __global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
 		return;
 	}
 	uint64_t mNext = lower_bound_u64(A.elem_prefix, 0, numMeshes, seg0 * segItems);
+	uint64_t wbase = ~0ull; // first mesh of the LDS window (none yet)
+	uint64_t wv = 0;        // elem_prefix[wbase + lane], ~0 past the table
 	for (uint64_t seg = seg0; seg < seg1; ++seg) {
 		const uint64_t m0 = mNext;
 		const uint64_t m1 = advance_lower_bound(A.elem_prefix, m0, numMeshes, (seg + 1) * segItems, lane);
@@ -865,9 +882,27 @@ __global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
 		for (uint64_t chunk = E0; chunk < E1; chunk += VGX_WAVE) {
 			const uint64_t ei = chunk + lane;
 			const bool valid = ei < E1;
-			const uint64_t widx = mcur + (uint64_t)lane;
-			const uint64_t wv = (widx <= m1) ? A.elem_prefix[widx] : ~0ull;
-			const bool windowCovers = wave_bcast_u64(wv, VGX_WAVE - 1) > chunk + (VGX_WAVE - 1);
+			const uint64_t lastKey = chunk + (VGX_WAVE - 1);
+			if (wbase == ~0ull || mcur < wbase || !(wave_bcast_u64(wv, VGX_WAVE - 1) > lastKey)) { // wave-uniform
+				wbase = mcur;
+				const uint64_t widx = wbase + (uint64_t)lane;
+				wv = (widx <= numMeshes) ? A.elem_prefix[widx] : ~0ull;
+				StrokeRec r;
+				r.polyFirst = 0; r.N = 2; r.kind = VGX_MESH_STROKE_AA; r.draw = 0; r.hsw = 0.0f; r.hswAA = 0.0f; r.fringe = 1.0f;
+				r.firstV = 0; r.firstI = 0; r.color = 0; r.pad0 = 0; r.pad1 = 0; r.pad2 = 0;
+				if (widx < numMeshes) {
+					const VgxMeshDesc md = A.mdesc[widx];
+					const VgxMeshPrep pr = A.mprep[widx];
+					const vgx_mesh mr = A.mtab[widx];
+					r.polyFirst = md.poly_first; r.N = md.poly_n; r.kind = md.kind; r.draw = md.draw;
+					r.hsw = pr.f0; r.hswAA = pr.f1; r.fringe = pr.f2; r.color = pr.color;
+					r.firstV = mr.first_vertex; r.firstI = mr.first_index;
+				}
+				__syncthreads(); // lanes may still be reading the previous window
+				s_win[lane] = r;
+				__syncthreads();
+			}
+			const bool windowCovers = wave_bcast_u64(wv, VGX_WAVE - 1) > lastKey;
 			const uint32_t wrel = window_rel(wv, chunk);
 			const int ownerOfs = window_owner_rel(wrel, valid ? (uint32_t)lane : 0u);
 			const uint32_t orel = (uint32_t)__shfl((int)wrel, ownerOfs);
@@ -878,17 +913,32 @@ __global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
 			mc.kind = VGX_MESH_STROKE_AA; mc.N = 2; mc.j = 0; mc.cap = 0; mc.join = 0; mc.closed = false;
 			mc.hsw = 0.0f; mc.hswAA = 0.0f; mc.fringe = 1.0f; mc.dr = A.draws; mc.vtx = A.poly;
 			uint32_t color = 0;
+			uint64_t firstV = 0, firstI = 0;
 			if (valid) {
+				StrokeRec r;
 				if (windowCovers) {
-					mi = mcur + (uint64_t)ownerOfs;
+					mi = wbase + (uint64_t)ownerOfs;
+					r = s_win[ownerOfs];
 				} else { // the window is full of zero-length (fill) entries: rare, fall back to a search
 					mi = find_owner_u64(A.elem_prefix, m0, m1, ei);
 					ownerBase = A.elem_prefix[mi];
+					const VgxMeshDesc md = A.mdesc[mi];
+					const VgxMeshPrep pr = A.mprep[mi];
+					r.polyFirst = md.poly_first; r.N = md.poly_n; r.kind = md.kind; r.draw = md.draw;
+					r.hsw = pr.f0; r.hswAA = pr.f1; r.fringe = pr.f2; r.color = pr.color;
+					r.firstV = A.mtab[mi].first_vertex; r.firstI = A.mtab[mi].first_index;
 				}
-				const VgxMeshDesc md = A.mdesc[mi];
-				const VgxMeshPrep pr = A.mprep[mi];
-				mc = make_mesh_ctx(md, pr, A.draws, (uint32_t)(ei - ownerBase), A.poly);
-				color = pr.color;
+				mc.kind = VGX_MD_KIND(r.kind);
+				mc.closed = VGX_MD_CLOSED(r.kind) != 0;
+				mc.cap = VGX_MD_CAP(r.kind);
+				mc.join = VGX_MD_JOIN(r.kind);
+				mc.N = r.N;
+				mc.j = (uint32_t)(ei - ownerBase);
+				mc.vtx = A.poly + 2 * r.polyFirst;
+				mc.hsw = r.hsw; mc.hswAA = r.hswAA; mc.fringe = r.fringe;
+				mc.dr = A.draws + r.draw;
+				color = r.color;
+				firstV = r.firstV; firstI = r.firstI;
 			}
 			// step A: one vertex load and one vec2Dir per element; neighbours come from the adjacent lanes
 			V2 p1 = v2(0.0f, 0.0f);
@@ -928,18 +978,17 @@ __global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
 
 			const bool meshLast = valid && (mc.j == mc.N - 1);
 			if (valid) {
-				const vgx_mesh mr = A.mtab[mi];
 				StrokeWriter w;
-				w.pos = A.pos + 2 * mr.first_vertex;
-				w.col = A.color + mr.first_vertex;
-				w.idx = A.idx + mr.first_index;
+				w.pos = A.pos + 2 * firstV;
+				w.col = A.color + firstV;
+				w.idx = A.idx + firstI;
 				w.color = color;
 				w.c0 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
 				w.reset();
 				elem_emit(mc, e, vbase, ibase, rails_unpack(prevPacked), w);
 				w.flush(vbase, ibase);
 				if (meshLast && A.meshes_out) {
-					A.meshes_out[mi] = mr;
+					A.meshes_out[mi] = A.mtab[mi];
 				}
 			}
 

@@ -20,12 +20,12 @@ __global__ __launch_bounds__(64) void k_write(uint8_t* out, uint64_t bytes)
 }
 
 // three streams like k_fill: 16 B, 8 B, 18 B (as 16 + 2) per lane per iteration
-__global__ __launch_bounds__(64) void k_write3(uint8_t* a, uint8_t* b, uint8_t* c, uint64_t iters)
+__global__ __launch_bounds__(64) void k_write3(uint8_t* a, uint8_t* b, uint8_t* c, uint64_t iters, int mis)
 {
 	const uint64_t perWave = iters / gridDim.x;
-	uint8_t* pa = a + (uint64_t)blockIdx.x * perWave * 1024;
-	uint8_t* pb = b + (uint64_t)blockIdx.x * perWave * 512;
-	uint8_t* pc = c + (uint64_t)blockIdx.x * perWave * 1152;
+	uint8_t* pa = a + (uint64_t)blockIdx.x * perWave * 1024 + mis * 24;
+	uint8_t* pb = b + (uint64_t)blockIdx.x * perWave * 512 + mis * 12;
+	uint8_t* pc = c + (uint64_t)blockIdx.x * perWave * 1152 + mis * 54;
 	Vec<16> x; Vec<8> y;
 	for (int i = 0; i < 4; ++i) { x.v[i] = threadIdx.x + i; }
 	y.v[0] = 1; y.v[1] = 2;
@@ -61,15 +61,17 @@ int main()
 			printf("write grid=%d %2d B/lane: %.3f ms  %.2f TB/s\n", g, w, best, (double)bytes / best / 1e9);
 		}
 		const uint64_t iters = (bytes / (1024 + 512 + 1152)) / g * g;
-		float best = 1e9f;
-		for (int rep = 0; rep < 4; ++rep) {
-			hipEventRecord(e0);
-			hipLaunchKernelGGL(k_write3, dim3(g), dim3(64), 0, 0, buf, buf + iters * 1024, buf + iters * 1536, iters);
-			hipEventRecord(e1); hipEventSynchronize(e1);
-			float ms; hipEventElapsedTime(&ms, e0, e1);
-			if (ms < best) { best = ms; }
+		for (int mis = 0; mis < 2; ++mis) {
+			float best = 1e9f;
+			for (int rep = 0; rep < 4; ++rep) {
+				hipEventRecord(e0);
+				hipLaunchKernelGGL(k_write3, dim3(g), dim3(64), 0, 0, buf, buf + iters * 1024 + 4096, buf + iters * 1536 + 8192, iters, mis);
+				hipEventRecord(e1); hipEventSynchronize(e1);
+				float ms; hipEventElapsedTime(&ms, e0, e1);
+				if (ms < best) { best = ms; }
+			}
+			printf("write3 (16+8+18 B/lane, 3 streams, misaligned=%d) grid=%d: %.3f ms  %.2f TB/s\n", mis, g, best, (double)iters * 2688 / best / 1e9);
 		}
-		printf("write3 (16+8+18 B/lane, 3 streams) grid=%d: %.3f ms  %.2f TB/s\n", g, best, (double)iters * 2688 / best / 1e9);
 	}
 	return 0;
 }

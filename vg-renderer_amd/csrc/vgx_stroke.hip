@@ -701,6 +701,134 @@ __device__ __forceinline__ FillWindow fill_window_load(const VgxStrokeArgs& A, u
 	return w;
 }
 
+// Everything one fill element needs, fetched one chunk AHEAD of its use (k_fill is a dependent chain per chunk:
+// owner search -> vertex load -> stores; with the next chunk's loads already in flight while the current chunk
+// computes and stores, a wave keeps two vertex loads outstanding instead of one).
+struct FillFetch
+{
+	bool valid, aaElem, nextInWave, prevInWave;
+	uint32_t j, N, color;
+	float aa;
+	uint64_t firstV, firstI, mi;
+	V2 p1, pNextB, pPrevB;
+};
+
+__device__ __forceinline__ FillFetch fill_fetch(const VgxStrokeArgs& A, uint64_t chunk, uint64_t elemEnd, uint64_t numMeshes, int lane, FillWindow& W, uint64_t& wbase, uint64_t& mcur)
+{
+	FillFetch F;
+	const uint64_t ei = chunk + lane;
+	const bool valid = ei < elemEnd;
+	const uint64_t lastKey = chunk + (VGX_WAVE - 1);
+	if (!(wave_bcast_u64(W.prefix, VGX_WAVE - 1) > lastKey)) {
+		wbase = mcur;
+		W = fill_window_load(A, wbase, numMeshes, lane);
+		// wait for the window HERE: otherwise the compiler parks an s_waitcnt vmcnt(0) at the join below, which every
+		// chunk would pay -- and on gfx9 vmcnt also counts the previous chunk's stores
+		__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+	}
+	const bool windowCovers = wave_bcast_u64(W.prefix, VGX_WAVE - 1) > lastKey;
+	const uint32_t wrel = window_rel(W.prefix, chunk);
+	const int k = window_owner_rel(wrel, valid ? (uint32_t)lane : 0u);
+	const uint32_t orel = (uint32_t)__shfl((int)wrel, k);
+	const int firstOwner = __popcll(wave_ballot(W.prefix <= chunk)) - 1;
+	uint64_t ownerBase = orel > 0 ? chunk + orel : wave_bcast_u64(W.prefix, firstOwner < 0 ? 0 : firstOwner);
+	uint64_t mi = wbase + (uint64_t)k;
+	uint64_t polyFirst = __shfl((unsigned long long)W.polyFirst, k);
+	uint64_t firstV = __shfl((unsigned long long)W.firstV, k);
+	uint64_t firstI = __shfl((unsigned long long)W.firstI, k);
+	uint32_t N = (uint32_t)__shfl((int)W.N, k);
+	uint32_t kind = (uint32_t)__shfl((int)W.kind, k);
+	uint32_t color = (uint32_t)__shfl((int)W.color, k);
+	float aa = __shfl(W.aa, k);
+	if (!windowCovers && valid) { // > 63 mesh records (mostly zero-length stroke entries) inside one chunk: rare
+		mi = find_owner_u64(A.elem_prefix, wbase, numMeshes, ei);
+		ownerBase = A.elem_prefix[mi];
+		const VgxMeshDesc md = A.mdesc[mi];
+		const VgxMeshPrep pr = A.mprep[mi];
+		polyFirst = md.poly_first; N = md.poly_n; kind = VGX_MD_KIND(md.kind); color = pr.color; aa = pr.f0;
+		firstV = A.mtab[mi].first_vertex; firstI = A.mtab[mi].first_index;
+	}
+	const uint32_t j = valid ? (uint32_t)(ei - ownerBase) : 0u;
+	const float* vtx = A.poly + 2 * polyFirst;
+	F.valid = valid;
+	F.aaElem = valid && kind == VGX_MESH_FILL_AA;
+	// all vertex loads of the chunk are issued together: my own vertex, and -- only for lanes whose neighbour is
+	// not in the adjacent lane (mesh boundary / chunk edge) -- the cyclic next / previous vertex
+	F.prevInWave = lane > 0 && j > 0;
+	F.nextInWave = lane < VGX_WAVE - 1 && j + 1 < N && ei + 1 < elemEnd;
+	F.p1 = v2(0.0f, 0.0f); F.pNextB = F.p1; F.pPrevB = F.p1;
+	if (valid) { F.p1 = ldv(vtx, j); }
+	if (F.aaElem && !F.nextInWave) { F.pNextB = ldv(vtx, j + 1 < N ? j + 1 : 0); }
+	if (F.aaElem && !F.prevInWave) { F.pPrevB = ldv(vtx, j > 0 ? j - 1 : N - 1); }
+	F.j = j; F.N = N; F.color = color; F.aa = aa; F.firstV = firstV; F.firstI = firstI; F.mi = mi;
+	const int nvalid = (int)((elemEnd - chunk) < (uint64_t)VGX_WAVE ? (elemEnd - chunk) : (uint64_t)VGX_WAVE);
+	mcur = wave_bcast_u64(mi, nvalid - 1);
+	return F;
+}
+
+__device__ __forceinline__ void fill_emit_chunk(const VgxStrokeArgs& A, const FillFetch& F)
+{
+	const bool valid = F.valid;
+	const uint32_t j = F.j, N = F.N, color = F.color;
+	const V2 p1 = F.p1;
+	V2 pNext;
+	pNext.x = wave_from_next(p1.x, 0.0f); pNext.y = wave_from_next(p1.y, 0.0f);
+	if (!F.nextInWave) { pNext = F.pNextB; }
+	V2 d12 = v2(0.0f, 0.0f);
+	if (F.aaElem) { d12 = v2dir(p1, pNext); }
+	V2 dPrev;
+	dPrev.x = wave_from_prev(d12.x, 0.0f); dPrev.y = wave_from_prev(d12.y, 0.0f);
+	if (F.aaElem && !F.prevInWave) { dPrev = v2dir(F.pPrevB, p1); }
+
+	if (valid) {
+		if (F.aaElem) {
+			const V2 vaa = v2mul(v2extrude(dPrev, d12), F.aa);
+			const V2 vin = v2add(p1, vaa), vout = v2sub(p1, vaa);
+			const uint64_t gv = F.firstV + 2 * (uint64_t)j;
+			PosPair pp; pp.x0 = vin.x; pp.y0 = vin.y; pp.x1 = vout.x; pp.y1 = vout.y;
+			*(PosPair*)(A.pos + 2 * gv) = pp;
+			ColPair cp; cp.c0 = color; cp.c1 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
+			*(ColPair*)(A.color + gv) = cp;
+			// indices: my nine positions [9j, 9j+9) are three whole triangles T = 3j + g (the fan size 3(N-2) and the
+			// fringe quads are multiples of 3): T < N-2 is fan triangle (0, 2T+2, 2T+4) (stroker.cpp:769-776), else
+			// fringe triangle F = T-(N-2) = half (F&1) of the quad on edge F>>1: (fb, fb+1, nextOuter) /
+			// (fb, nextOuter, nextInner) with fb = 2*edge (stroker.cpp:779-795). No division, no per-index select.
+			const uint32_t k9 = 9 * j;
+			uint32_t val[9];
+#pragma unroll
+			for (uint32_t g = 0; g < 3; ++g) {
+				const uint32_t T = 3 * j + g;
+				const bool isFan = T + 2 < N;
+				const uint32_t Fq = T + 2 - N; // wraps for fan triangles, unused there
+				const uint32_t ed = Fq >> 1;
+				const bool second = (Fq & 1u) != 0;
+				const uint32_t fb = 2 * ed;
+				const bool lastEdge = ed + 1 == N;
+				const uint32_t nextInner = lastEdge ? 0u : fb + 2, nextOuter = lastEdge ? 1u : fb + 3;
+				val[3 * g] = isFan ? 0u : fb;
+				val[3 * g + 1] = (isFan ? 2 * T + 2 : (second ? nextOuter : fb + 1)) & 0xFFFFu;
+				val[3 * g + 2] = (isFan ? 2 * T + 4 : (second ? nextInner : nextOuter)) & 0xFFFFu;
+			}
+			uint16_t* pi = A.idx + F.firstI + k9;
+			if (j + 1 < N) {
+				Idx9 q; q.a = val[0] | (val[1] << 16); q.b = val[2] | (val[3] << 16); q.c = val[4] | (val[5] << 16); q.d = val[6] | (val[7] << 16); q.e = (uint16_t)val[8];
+				*(Idx9*)pi = q;
+			} else {
+				Idx3 q; q.a = val[0] | (val[1] << 16); q.b = (uint16_t)val[2];
+				*(Idx3*)pi = q;
+			}
+		} else {
+			const uint64_t gv = F.firstV + j;
+			*(float2*)(A.pos + 2 * gv) = make_float2(p1.x, p1.y);
+			A.color[gv] = color;
+			if (j + 2 < N) {
+				uint16_t* pi = A.idx + F.firstI + 3 * j;
+				pi[0] = 0; pi[1] = (uint16_t)(j + 1); pi[2] = (uint16_t)(j + 2);
+			}
+		}
+	}
+}
+
 __global__ __launch_bounds__(VGX_WAVE) void k_fill(VgxStrokeArgs A)
 {
 	const int lane = threadIdx.x;
@@ -724,108 +852,16 @@ __global__ __launch_bounds__(VGX_WAVE) void k_fill(VgxStrokeArgs A)
 	uint64_t wbase = mcur;
 	FillWindow W = fill_window_load(A, wbase, numMeshes, lane);
 
-	for (uint64_t chunk = elem0; chunk < elemEnd; chunk += VGX_WAVE) {
-		const uint64_t ei = chunk + lane;
-		const bool valid = ei < elemEnd;
-		const uint64_t lastKey = chunk + (VGX_WAVE - 1);
-		if (!(wave_bcast_u64(W.prefix, VGX_WAVE - 1) > lastKey)) {
-			wbase = mcur;
-			W = fill_window_load(A, wbase, numMeshes, lane);
-		}
-		const bool windowCovers = wave_bcast_u64(W.prefix, VGX_WAVE - 1) > lastKey;
-		const uint32_t wrel = window_rel(W.prefix, chunk);
-		const int k = window_owner_rel(wrel, valid ? (uint32_t)lane : 0u);
-		const uint32_t orel = (uint32_t)__shfl((int)wrel, k);
-		const int firstOwner = __popcll(wave_ballot(W.prefix <= chunk)) - 1;
-		uint64_t ownerBase = orel > 0 ? chunk + orel : wave_bcast_u64(W.prefix, firstOwner < 0 ? 0 : firstOwner);
-		uint64_t mi = wbase + (uint64_t)k;
-		uint64_t polyFirst = __shfl((unsigned long long)W.polyFirst, k);
-		uint64_t firstV = __shfl((unsigned long long)W.firstV, k);
-		uint64_t firstI = __shfl((unsigned long long)W.firstI, k);
-		uint32_t N = (uint32_t)__shfl((int)W.N, k);
-		uint32_t kind = (uint32_t)__shfl((int)W.kind, k);
-		uint32_t color = (uint32_t)__shfl((int)W.color, k);
-		float aa = __shfl(W.aa, k);
-		if (!windowCovers && valid) { // > 63 mesh records (mostly zero-length stroke entries) inside one chunk: rare
-			mi = find_owner_u64(A.elem_prefix, wbase, numMeshes, ei);
-			ownerBase = A.elem_prefix[mi];
-			const VgxMeshDesc md = A.mdesc[mi];
-			const VgxMeshPrep pr = A.mprep[mi];
-			polyFirst = md.poly_first; N = md.poly_n; kind = VGX_MD_KIND(md.kind); color = pr.color; aa = pr.f0;
-			firstV = A.mtab[mi].first_vertex; firstI = A.mtab[mi].first_index;
-		}
-		const uint32_t j = valid ? (uint32_t)(ei - ownerBase) : 0u;
-		const float* vtx = A.poly + 2 * polyFirst;
-		const bool aaElem = valid && kind == VGX_MESH_FILL_AA;
-		// all vertex loads of the chunk are issued together: my own vertex, and -- only for lanes whose neighbour is
-		// not in the adjacent lane (mesh boundary / chunk edge) -- the cyclic next / previous vertex
-		const bool prevInWave = lane > 0 && j > 0;
-		const bool nextInWave = lane < VGX_WAVE - 1 && j + 1 < N && ei + 1 < elemEnd;
-		V2 p1 = v2(0.0f, 0.0f), pNextB = p1, pPrevB = p1;
-		if (valid) { p1 = ldv(vtx, j); }
-		if (aaElem && !nextInWave) { pNextB = ldv(vtx, j + 1 < N ? j + 1 : 0); }
-		if (aaElem && !prevInWave) { pPrevB = ldv(vtx, j > 0 ? j - 1 : N - 1); }
-		V2 pNext;
-		pNext.x = wave_from_next(p1.x, 0.0f); pNext.y = wave_from_next(p1.y, 0.0f);
-		if (!nextInWave) { pNext = pNextB; }
-		V2 d12 = v2(0.0f, 0.0f);
-		if (aaElem) { d12 = v2dir(p1, pNext); }
-		V2 dPrev;
-		dPrev.x = wave_from_prev(d12.x, 0.0f); dPrev.y = wave_from_prev(d12.y, 0.0f);
-		if (aaElem && !prevInWave) { dPrev = v2dir(pPrevB, p1); }
-
-		if (valid) {
-			if (kind == VGX_MESH_FILL_AA) {
-				const V2 vaa = v2mul(v2extrude(dPrev, d12), aa);
-				const V2 vin = v2add(p1, vaa), vout = v2sub(p1, vaa);
-				const uint64_t gv = firstV + 2 * (uint64_t)j;
-				PosPair pp; pp.x0 = vin.x; pp.y0 = vin.y; pp.x1 = vout.x; pp.y1 = vout.y;
-				*(PosPair*)(A.pos + 2 * gv) = pp;
-				ColPair cp; cp.c0 = color; cp.c1 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
-				*(ColPair*)(A.color + gv) = cp;
-				// indices: my nine positions [9j, 9j+9) are three whole triangles T = 3j + g (the fan size 3(N-2) and the
-				// fringe quads are multiples of 3): T < N-2 is fan triangle (0, 2T+2, 2T+4) (stroker.cpp:769-776), else
-				// fringe triangle F = T-(N-2) = half (F&1) of the quad on edge F>>1: (fb, fb+1, nextOuter) /
-				// (fb, nextOuter, nextInner) with fb = 2*edge (stroker.cpp:779-795). No division, no per-index select.
-				const uint32_t k9 = 9 * j;
-				uint32_t val[9];
-#pragma unroll
-				for (uint32_t g = 0; g < 3; ++g) {
-					const uint32_t T = 3 * j + g;
-					const bool isFan = T + 2 < N;
-					const uint32_t F = T + 2 - N; // wraps for fan triangles, unused there
-					const uint32_t ed = F >> 1;
-					const bool second = (F & 1u) != 0;
-					const uint32_t fb = 2 * ed;
-					const bool lastEdge = ed + 1 == N;
-					const uint32_t nextInner = lastEdge ? 0u : fb + 2, nextOuter = lastEdge ? 1u : fb + 3;
-					val[3 * g] = isFan ? 0u : fb;
-					val[3 * g + 1] = (isFan ? 2 * T + 2 : (second ? nextOuter : fb + 1)) & 0xFFFFu;
-					val[3 * g + 2] = (isFan ? 2 * T + 4 : (second ? nextInner : nextOuter)) & 0xFFFFu;
-				}
-				uint16_t* pi = A.idx + firstI + k9;
-				if (j + 1 < N) {
-					Idx9 q; q.a = val[0] | (val[1] << 16); q.b = val[2] | (val[3] << 16); q.c = val[4] | (val[5] << 16); q.d = val[6] | (val[7] << 16); q.e = (uint16_t)val[8];
-					*(Idx9*)pi = q;
-				} else {
-					Idx3 q; q.a = val[0] | (val[1] << 16); q.b = (uint16_t)val[2];
-					*(Idx3*)pi = q;
-				}
-			} else {
-				const uint64_t gv = firstV + j;
-				*(float2*)(A.pos + 2 * gv) = make_float2(p1.x, p1.y);
-				A.color[gv] = color;
-				if (j + 2 < N) {
-					uint16_t* pi = A.idx + firstI + 3 * j;
-					pi[0] = 0; pi[1] = (uint16_t)(j + 1); pi[2] = (uint16_t)(j + 2);
-				}
-			}
-			if (j == N - 1 && A.meshes_out) {
-				A.meshes_out[mi] = A.mtab[mi];
-			}
-		}
-		const int nvalid = (int)((elemEnd - chunk) < (uint64_t)VGX_WAVE ? (elemEnd - chunk) : (uint64_t)VGX_WAVE);
-		mcur = wave_bcast_u64(mi, nvalid - 1);
+	// two fetch records in ping-pong (no register copies at the loop edge: the wait for a chunk's vertices sits right
+	// before their first use, after the NEXT chunk's loads have been issued)
+	FillFetch F0 = fill_fetch(A, elem0, elemEnd, numMeshes, lane, W, wbase, mcur);
+	FillFetch F1 = F0;
+	for (uint64_t chunk = elem0; chunk < elemEnd; chunk += 2 * VGX_WAVE) {
+		const bool has1 = chunk + VGX_WAVE < elemEnd, has2 = chunk + 2 * VGX_WAVE < elemEnd; // wave-uniform
+		if (has1) { F1 = fill_fetch(A, chunk + VGX_WAVE, elemEnd, numMeshes, lane, W, wbase, mcur); }
+		fill_emit_chunk(A, F0);
+		if (has2) { F0 = fill_fetch(A, chunk + 2 * VGX_WAVE, elemEnd, numMeshes, lane, W, wbase, mcur); }
+		if (has1) { fill_emit_chunk(A, F1); }
 	}
 }
 
@@ -987,9 +1023,6 @@ __global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
 				w.reset();
 				elem_emit(mc, e, vbase, ibase, rails_unpack(prevPacked), w);
 				w.flush(vbase, ibase);
-				if (meshLast && A.meshes_out) {
-					A.meshes_out[mi] = A.mtab[mi];
-				}
 			}
 
 			// carries (from the last valid lane)
@@ -1007,6 +1040,18 @@ __global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
 	}
 }
 
+// The caller's mesh table = the internal one once the scan over meshes has filled first_vertex / first_index.
+__global__ __launch_bounds__(256) void k_copy_meshes(VgxStrokeArgs A)
+{
+	if (A.totals->status != VGX_OK) { return; }
+	const uint64_t n = A.totals->sizes.num_meshes * (sizeof(vgx_mesh) / sizeof(uint4));
+	const uint4* src = (const uint4*)A.mtab;
+	uint4* dst = (uint4*)A.meshes_out;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		dst[i] = src[i];
+	}
+}
+
 } // namespace
 
 void vgx_launch_mesh_prepare(const VgxStrokeArgs& a, hipStream_t s)
@@ -1016,6 +1061,9 @@ void vgx_launch_mesh_prepare(const VgxStrokeArgs& a, hipStream_t s)
 
 void vgx_launch_fill(const VgxStrokeArgs& a, int numBlocks, hipStream_t s)
 {
+	if (a.meshes_out) { // the caller's mesh table, in one streaming copy (not a dependent load + store inside every chunk)
+		hipLaunchKernelGGL(k_copy_meshes, dim3(1024), dim3(256), 0, s, a);
+	}
 	hipLaunchKernelGGL(k_fill, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
 }
 

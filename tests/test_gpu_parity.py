@@ -187,3 +187,64 @@ def test_async_single_pass_long_paths(rt, gpu_ctx, wl, oracle):
     assert np.array_equal(bufs.idx[:ni].cpu().numpy().view(np.uint16), ref.idx)
     assert np.array_equal(bufs.pos[:nv].cpu().numpy().view(np.uint32), ref.pos.view(np.uint32))
     pset.close()
+
+
+def _async_result(rt, gpu_ctx, ps, d):
+    import torch
+    pset = rt.PathSet(gpu_ctx, ps)
+    dd = rt.upload_draws(d)
+    sizes = rt.tessellate_count(gpu_ctx, pset, dd, d.shape[0])
+    bufs = rt.MeshBuffers(dd.device, sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"])
+    bufs.pos.fill_(float("nan"))
+    rt.tessellate_async(gpu_ctx, pset, dd, d.shape[0], bufs)
+    torch.cuda.synchronize()
+    status = int(bufs.dev_status.item())
+    nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
+
+    class G:
+        pass
+    got = G()
+    got.sizes = sizes
+    got.status = status
+    got.pos = bufs.pos[:nv].cpu().numpy()
+    got.color = bufs.color[:nv].cpu().numpy().view(np.uint32)
+    got.idx = bufs.idx[:ni].cpu().numpy().view(np.uint16)
+    got.meshes = bufs.meshes[:nm * 32].cpu().numpy().view(rt.capi.mesh_dtype)
+    pset.close()
+    return got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("waves", ["3", "17"])
+def test_async_heap_block_switches(rt, gpu_ctx, wl, oracle, waves, monkeypatch):
+    """The single-pass flatten with only a few waves: every wave fills many 8192-vertex heap blocks, so chunks that do
+    not fit, block switches and the move of the sub-path that spans the switch all happen in a batch the oracle can
+    check completely (at the default 4096 waves that needs > 33 M polyline vertices)."""
+    monkeypatch.setenv("VGX_BUILD_WAVES", waves)
+    ps, d = wl.tiger(24)
+    ref = oracle.tessellate(ps, d)
+    got = _async_result(rt, gpu_ctx, ps, d)
+    assert got.status == 0
+    assert_mesh_equal(got, ref, "tiger x24, %s build waves" % waves)
+    ps = wl.fuzz_paths(411, npaths=128)
+    d = wl.fuzz_draws(ps, 411)
+    d = np.concatenate([d] * 12)
+    ref = oracle.tessellate(ps, d)
+    got = _async_result(rt, gpu_ctx, ps, d)
+    assert got.status == 0
+    assert_mesh_equal(got, ref, "fuzz x12, %s build waves" % waves)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("waves", ["2", None])
+def test_async_very_long_subpaths(rt, gpu_ctx, wl, oracle, waves, monkeypatch):
+    """Sub-paths of 30 001 vertices built from single LINE_TO commands (470 chunks each): they outgrow several heap
+    blocks, are moved with geometric growth, and their total feeds the heap sizing (long_subpath_vertices)."""
+    if waves:
+        monkeypatch.setenv("VGX_BUILD_WAVES", waves)
+    ps, d = wl.random_walk_polylines(n=5, nseg=30000, seed=7, cap=0, join=0, width=3.0)
+    d["stroke_flags"] &= ~np.uint32(rt.capi.STROKE_AA)  # 2 rails: 60 002 vertices per mesh stay below 65 536
+    ref = oracle.tessellate(ps, d)
+    got = _async_result(rt, gpu_ctx, ps, d)
+    assert got.status == 0
+    assert_mesh_equal(got, ref, "5 x 30001-vertex polylines")

@@ -22,6 +22,7 @@
 //   command's nominal end point. Both are detected lane-locally; a draw where either happens (and any
 //   path containing ARC / ARC_TO, whose end points are computed) is re-done by ONE lane running the
 //   exact sequential algorithm (PathSim over the whole draw). Degenerate input is slow, never wrong.
+#include <stdlib.h>
 #include "vgx_internal.h"
 #include "vgx_wave.h"
 #include "vgx_pathsim.h"
@@ -932,7 +933,11 @@ __global__ __launch_bounds__(256) void k_flatten_serial(VgxFlattenArgs A)
 
 void vgx_launch_flatten_build(const VgxFlattenArgs& a, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_flatten_build, dim3(VGX_BUILD_WAVES), dim3(VGX_WAVE), 0, s, a);
+	// VGX_BUILD_WAVES (environment, read per launch): testing knob -- a handful of waves makes small batches run
+	// through the heap's block switches and sub-path moves that otherwise need > 8192 vertices per wave
+	int waves = VGX_BUILD_WAVES;
+	if (const char* e = getenv("VGX_BUILD_WAVES")) { const int v = atoi(e); if (v >= 1 && v < waves) { waves = v; } }
+	hipLaunchKernelGGL(k_flatten_build, dim3(waves), dim3(VGX_WAVE), 0, s, a);
 	hipLaunchKernelGGL((k_flatten_serial<false, false>), dim3(1024), dim3(256), 0, s, a); // count + heap allocation
 }
 

@@ -122,11 +122,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # VGX_BENCH_SHARE_GPU=1 (testing only): all ranks on cuda:0 with the gloo backend, to exercise the multi-rank code
+    # path on a one-GPU box (RCCL refuses two ranks on one device)
+    share_gpu = os.environ.get("VGX_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
     rt = importlib.import_module("vg-renderer_amd.runtime")
@@ -195,8 +203,9 @@ def main():
         gather_ms = (time.perf_counter() - g0) * 1e3
         del res
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    vtot = torch.tensor([float(sizes["num_vertices"])], dtype=torch.float64, device=dev)
+    red_dev = torch.device("cpu") if share_gpu else dev
+    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    vtot = torch.tensor([float(sizes["num_vertices"])], dtype=torch.float64, device=red_dev)
     if world > 1:
         import torch.distributed as dist
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+timeout 600 python -m pytest tests/test_gpu_golden.py -m gpu -x -q -k "round_joins" 2>&1 | tail -15

@@ -139,3 +139,60 @@ def vgr_subset(ps, p0, p1):
     c0, c1 = int(ps.path_cmd_begin[p0]), int(ps.path_cmd_begin[p1])
     a0, a1 = int(ps.cmd_arg_off[c0]), int(ps.cmd_arg_off[c1])
     return vgr.PathSetArrays(ps.cmd_type[c0:c1], ps.cmd_arg_off[c0:c1 + 1] - a0, ps.args[a0:a1], ps.path_cmd_begin[p0:p1 + 1] - c0)
+
+
+def test_full_size_round_joins_polylines(rt, gpu_ctx, wl, oracle):
+    """BASELINE config 4 at full size: 10 000 random-walk polylines x 1000 segments, strokeAA width 6, Round caps and
+    Round joins (the only data-dependent mesh sizes: k_mesh_prepare counts them). ~80 M vertices / 360 M indices.
+      - mesh table is a consistent exclusive scan, one stroke mesh per polyline, every mesh below 65 536 vertices,
+      - every index addresses a vertex of its own mesh,
+      - colours are the stroke colour on the core rails and colour & 0x00FFFFFF on the fringe rails,
+      - sampled polylines match the oracle bit-exactly (positions, colours, indices)."""
+    import torch
+    n = 10000
+    ps, d = wl.random_walk_polylines(n=n, nseg=1000, seed=5678)
+    pset = rt.PathSet(gpu_ctx, ps)
+    dd = rt.upload_draws(d)
+    r = rt.tessellate(gpu_ctx, pset, dd, n, to_host=False)
+    assert r.sizes["num_meshes"] == n and r.sizes["num_serial_draws"] == 0
+    meshes = r.bufs.meshes[:n * 32].cpu().numpy().view(rt.capi.mesh_dtype)
+    nvm = meshes["num_vertices"].astype(np.int64)
+    nim = meshes["num_indices"].astype(np.int64)
+    assert int(nvm.sum()) == r.sizes["num_vertices"] and int(nim.sum()) == r.sizes["num_indices"]
+    assert int(nvm.max()) < 65536 and 70_000_000 < r.sizes["num_vertices"] < 90_000_000
+    assert np.array_equal(meshes["first_vertex"][1:], np.cumsum(nvm.astype(np.uint64))[:-1])
+    assert np.array_equal(meshes["first_index"][1:], np.cumsum(nim.astype(np.uint64))[:-1])
+    assert np.array_equal(meshes["draw"], np.arange(n, dtype=np.uint32))
+    ni = r.sizes["num_indices"]
+    nv = r.sizes["num_vertices"]
+    owner = torch.repeat_interleave(torch.arange(n, device=r.bufs.idx.device), torch.from_numpy(nim).to(r.bufs.idx.device))
+    lim = torch.from_numpy(nvm).to(owner.device)[owner]
+    idx = r.bufs.idx[:ni].view(torch.int16).to(torch.int32) & 0xFFFF
+    assert bool((idx < lim).all().item())
+    del owner, lim, idx
+    col = r.bufs.color[:nv].view(torch.int32)
+    c = int(d["stroke_color"][0])
+    c_signed = c - (1 << 32) if c >= (1 << 31) else c
+    assert bool(((col == c_signed) | (col == (c & 0x00FFFFFF))).all().item())
+    rs = np.random.RandomState(4)
+    for p in [0, n - 1] + [int(x) for x in rs.randint(1, n - 1, size=6)]:
+        sub = vgr_subset(ps, p, p + 1)
+        dsub = d[p:p + 1].copy()
+        dsub["path"] = 0
+        ref = oracle.tessellate(sub, dsub)
+        fv, fi = int(meshes["first_vertex"][p]), int(meshes["first_index"][p])
+        assert int(nvm[p]) == ref.sizes["num_vertices"] and int(nim[p]) == ref.sizes["num_indices"], p
+        assert np.array_equal(r.bufs.pos[fv:fv + int(nvm[p])].cpu().numpy().view(np.uint32), ref.pos.view(np.uint32)), p
+        assert np.array_equal(r.bufs.idx[fi:fi + int(nim[p])].cpu().numpy().view(np.uint16), ref.idx), p
+        assert np.array_equal(r.bufs.color[fv:fv + int(nvm[p])].cpu().numpy().view(np.uint32), ref.color), p
+    # the steady-state entry (single-pass flatten into the heap) must produce the same streams byte for byte
+    bufs2 = rt.MeshBuffers(dd.device, nv, ni, n)
+    rt.tessellate_async(gpu_ctx, pset, dd, n, bufs2)
+    torch.cuda.synchronize()
+    assert int(bufs2.dev_status.item()) == 0
+    assert torch.equal(bufs2.pos[:nv].view(torch.int32), r.bufs.pos[:nv].view(torch.int32))
+    assert torch.equal(bufs2.idx[:ni], r.bufs.idx[:ni]) and torch.equal(bufs2.color[:nv], r.bufs.color[:nv])
+    assert torch.equal(bufs2.meshes[:n * 32], r.bufs.meshes[:n * 32])
+    del r, col, bufs2
+    torch.cuda.empty_cache()
+    pset.close()

@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_golden.py -m gpu -x -q -k "round_joins" 2>&1 | tail -15
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout 200 python profiles/stage_times.py polylines 2>&1 | tail -1
+timeout 200 python profiles/stage_times.py 2>&1 | tail -1

@@ -12,9 +12,16 @@ wl = importlib.import_module("vg-renderer_amd.workloads")
 
 
 def main():
-    K = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-    ps, ops = wl.tiger_paths()
-    draws = wl.tiger_draws(ops, K)
+    which = sys.argv[1] if len(sys.argv) > 1 else "tiger"
+    if which == "polylines":      # BASELINE config 4: 10k x 1000-segment polylines, strokeAA Round/Round
+        ps, draws = wl.random_walk_polylines(n=10000, nseg=1000, seed=5678)
+    elif which == "cubics":       # BASELINE config 2: 1 M independent cubics (stroked AA, Butt/Miter, so the stroker runs too)
+        ps, draws = wl.random_cubics(1000000, seed=1234, box=1000.0)
+        wl.set_stroke(draws, slice(None), 0xFF2080FF, 3.0, 0, 0, aa=True)
+    else:
+        K = int(which) if which.isdigit() else 10000
+        ps, ops = wl.tiger_paths()
+        draws = wl.tiger_draws(ops, K)
     n = draws.shape[0]
     ctx = rt.Context(0)
     pset = rt.PathSet(ctx, ps)
@@ -32,7 +39,7 @@ def main():
         torch.cuda.synchronize()
         for k, v in ctx.stage_times():
             acc[k] = acc.get(k, 0.0) + v / R
-    print(os.environ.get("VGX_LIB", "default"), "total %.3f" % sum(acc.values()), {k: round(v, 3) for k, v in acc.items()})
+    print(os.environ.get("VGX_LIB", "default"), which, "verts %d" % sizes["num_vertices"], "total %.3f" % sum(acc.values()), {k: round(v, 3) for k, v in acc.items()})
 
 
 if __name__ == "__main__":

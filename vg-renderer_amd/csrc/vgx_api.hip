@@ -382,6 +382,8 @@ void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps,
 	a.pos = nullptr; a.color = nullptr; a.idx = nullptr; a.meshes_out = nullptr; a.stage_output = 0;
 	a.totals = (VgxTotals*)ctx->totals.p; a.caps = outCaps;
 	vgx_launch_mesh_prepare(a, s);
+	a.elem_prefix = a.elem_prefix_stroke;
+	vgx_launch_stroke(false, a, VGX_GRID_BLOCKS, s); // Round-join mesh sizes (exits immediately without Round joins)
 	mark(ctx, s, "mesh_prepare");
 	OpMeshTab opm;
 	opm.mtab = (vgx_mesh*)ctx->mtab.p; opm.totals = (VgxTotals*)ctx->totals.p; opm.caps = outCaps; opm.checkCaps = checkCaps;

@@ -630,37 +630,19 @@ __device__ __forceinline__ VgxMeshPrep mesh_prep(const VgxMeshDesc& md, const vg
 	return pr;
 }
 
-// One lane per mesh: per-mesh constants for the element kernels, and the sizes of meshes with Round joins (the only
-// data-dependent sizes; every other mesh was sized in closed form by flatten-emit).
+// One lane per mesh: per-mesh constants for the element kernels. (Meshes with Round joins -- the only data-dependent
+// sizes -- are sized by k_stroke<COUNT>, one lane per element; every other mesh was sized in closed form by flatten.)
 __global__ __launch_bounds__(256) void k_mesh_prepare(VgxStrokeArgs A)
 {
 	if (A.totals->status != VGX_OK) {
 		return;
 	}
 	const uint64_t numMeshes = A.totals->sizes.num_meshes;
-	const bool anyRound = A.totals->num_round_meshes != 0;
 	for (uint64_t mi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; mi < numMeshes; mi += (uint64_t)gridDim.x * blockDim.x) {
 		const VgxMeshDesc md = A.mdesc[mi];
 		const vgx_draw* dr = A.draws + md.draw;
 		const VgxMeshPrep pr = mesh_prep(md, dr, A.poly);
 		A.mprep[mi] = pr;
-		if (anyRound && A.mtab[mi].num_vertices == VGX_MESH_NEEDS_COUNT) {
-			uint32_t nv = 0, ni = 0;
-			const float* vtx = A.poly + 2 * md.poly_first;
-			const uint32_t N = md.poly_n;
-			V2 dPrev = v2dir(ldv(vtx, N - 1), ldv(vtx, 0));
-			for (uint32_t j = 0; j < N; ++j) {
-				const MeshCtx mc = make_mesh_ctx(md, pr, A.draws, j, A.poly);
-				const V2 p1 = ldv(vtx, j);
-				const V2 d12 = v2dir(p1, ldv(vtx, j == N - 1 ? 0 : j + 1));
-				const Elem e = elem_geometry(mc, p1, dPrev, d12);
-				nv += e.nv;
-				ni += elem_total_indices(mc, e);
-				dPrev = d12;
-			}
-			A.mtab[mi].num_vertices = nv;
-			A.mtab[mi].num_indices = ni;
-		}
 	}
 }
 
@@ -882,12 +864,16 @@ struct __attribute__((aligned(16))) StrokeRec
 	uint32_t color, pad0, pad1, pad2;
 };
 
+template<bool COUNT>
 __global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_stroke(VgxStrokeArgs A)
 {
 	__shared__ StrokeRec s_win[VGX_WAVE];
 	const int lane = threadIdx.x;
 	if (A.totals->status != VGX_OK) {
 		return;
+	}
+	if (COUNT && A.totals->num_round_meshes == 0) {
+		return; // sizing pass: only batches with Round joins have meshes whose size depends on the geometry
 	}
 	const uint64_t numMeshes = A.totals->sizes.num_meshes;
 	const uint64_t totalElems = A.elem_prefix[numMeshes];
@@ -1013,7 +999,14 @@ __global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
 			uint64_t prevPacked = (uint64_t)wave_from_prev_u32((uint32_t)myExit, (uint32_t)carryRails) | ((uint64_t)wave_from_prev_u32((uint32_t)(myExit >> 32), (uint32_t)(carryRails >> 32)) << 32);
 
 			const bool meshLast = valid && (mc.j == mc.N - 1);
-			if (valid) {
+			if (COUNT) {
+				// the running bases after the mesh's last element ARE its vertex / index counts (the reference's
+				// m_NumVertices / m_NumIndices at the end of the call)
+				if (meshLast && A.mtab[mi].num_vertices == VGX_MESH_NEEDS_COUNT) {
+					A.mtab[mi].num_vertices = vbase + e.nv;
+					A.mtab[mi].num_indices = ibase + totalIdx;
+				}
+			} else if (valid) {
 				StrokeWriter w;
 				w.pos = A.pos + 2 * firstV;
 				w.col = A.color + firstV;
@@ -1069,6 +1062,9 @@ void vgx_launch_fill(const VgxStrokeArgs& a, int numBlocks, hipStream_t s)
 
 void vgx_launch_stroke(bool emit, const VgxStrokeArgs& a, int numBlocks, hipStream_t s)
 {
-	(void)emit; // sizes come from flatten-emit (closed form) and k_mesh_prepare; only the emit pass exists
-	hipLaunchKernelGGL(k_stroke, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
+	if (emit) {
+		hipLaunchKernelGGL(k_stroke<false>, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
+	} else { // sizes Round-join meshes; returns at once when the batch has none (every other size is closed-form)
+		hipLaunchKernelGGL(k_stroke<true>, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
+	}
 }

@@ -150,6 +150,7 @@ typedef struct vgx_sizes {
 	uint64_t num_cmd_instances;/* path commands summed over draws (flatten work items) */
 	uint64_t num_elements;     /* polyline vertices summed over meshes (stroker work items) */
 	uint64_t num_fill_elements;/* ... of which belong to convex-fill meshes (the rest to polyline strokes) */
+	uint64_t num_drawcmds;     /* draw commands / vertex buffers of the assembly step (0 unless vgx_set_assembly armed it) */
 } vgx_sizes;
 
 /* Flatten output (pathGetVertices / pathGetSubPaths for every draw). NULL members are skipped. */
@@ -171,6 +172,30 @@ typedef struct vgx_mesh_out {
 	uint64_t cap_indices;
 	uint64_t cap_meshes;
 } vgx_mesh_out;
+
+/* ---- draw-command assembly (optional next step of the frame) ------------------
+ * What createDrawCommand_VertexColor does after every stroker call (src/vg.cpp:5207-5244): vertices go to the
+ * current vertex buffer until it would exceed m_MaxVBVertices (allocVertices, :5321-5342), a new vertex buffer
+ * forces a new draw command, meshes otherwise merge into the previous command (allocDrawCommand, :5359-5407), and
+ * indices are rebased by the vertices already in the command (vgutil::batchTransformDrawIndices,
+ * vg_util.cpp:447-520). One vgx_drawcmd per vertex buffer; 40 bytes. */
+typedef struct vgx_drawcmd {
+	uint64_t first_vertex;  /* where this vertex buffer starts in the pos / color streams (its m_FirstVertexID is 0) */
+	uint64_t first_index;   /* DrawCommand::m_FirstIndexID: into the idx stream = the frame's single index buffer */
+	uint64_t first_mesh;    /* first mesh merged into the command */
+	uint32_t num_vertices;  /* DrawCommand::m_NumVertices = vertices in the vertex buffer (<= max_vb_vertices) */
+	uint32_t num_indices;   /* DrawCommand::m_NumIndices */
+	uint32_t num_meshes;
+	uint32_t vertex_buffer; /* DrawCommand::m_VertexBufferID, counted from 0 for the batch */
+} vgx_drawcmd;
+
+typedef struct vgx_assembly {
+	vgx_drawcmd* drawcmds;       /* DEVICE [cap_drawcmds]; 2 * vertices / max_vb_vertices + 2 entries always suffice */
+	uint64_t cap_drawcmds;
+	uint64_t* dev_num_drawcmds;  /* DEVICE, may be NULL: receives the number of draw commands */
+	uint32_t max_vb_vertices;    /* Config::m_MaxVBVertices (vg.cpp:726, <= 65536); 0 = 65536 */
+	uint32_t reserved;
+} vgx_assembly;
 
 typedef struct vgx_ctx vgx_ctx;         /* per-device context: scratch, scan storage, error state */
 typedef struct vgx_pathset vgx_pathset; /* validated path definitions resident in device memory */
@@ -222,6 +247,15 @@ int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
  * vgx_mesh.subpath_kind carries the list index. _count sizes the output (one stream sync), _emit must follow. */
 int vgx_stroke_count(vgx_ctx* ctx, const float* poly, const vgx_subpath* subpaths, const uint32_t* subpath_draw, uint64_t nsubpaths, const vgx_draw* draws, uint64_t ndraws, vgx_sizes* out_sizes, void* stream);
 int vgx_stroke_emit(vgx_ctx* ctx, const float* poly, const vgx_subpath* subpaths, const uint32_t* subpath_draw, uint64_t nsubpaths, const vgx_draw* draws, uint64_t ndraws, const vgx_mesh_out* out, void* stream);
+
+/* ---- draw-command assembly (see vgx_drawcmd / vgx_assembly above) ------------
+ * Arms (asm_ != NULL) or disarms (NULL) assembly for the following vgx_tessellate_emit / vgx_tessellate calls on this
+ * context. While armed, the uint16 indices in `idx` are vertex-buffer relative (mesh-local index + vertices in front of
+ * the mesh inside its vertex buffer, uint16 wrap like the reference's cast, vg_util.cpp:447-520), `drawcmds` receives
+ * one record per vertex buffer and vgx_sizes.num_drawcmds their number; pos / color / meshes are unchanged (the vertex
+ * streams already are in vertex-buffer order). A mesh with more than max_vb_vertices vertices sets
+ * VGX_E_MESH_TOO_LARGE (the reference VG_CHECKs it, vg.cpp:5323); a too small table VGX_E_NOSPACE. The struct is copied. */
+int vgx_set_assembly(vgx_ctx* ctx, const vgx_assembly* asm_);
 
 /* Per-kernel timing of the last vgx_tessellate.. / vgx_flatten.. sequence, measured with HIP events
  * on the stream the kernels ran on. Enable before the call; read after synchronising. */

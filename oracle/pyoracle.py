@@ -39,6 +39,8 @@ def load(kind="port"):
     lib.vgo_flatten.argtypes = [C.POINTER(capi.PathSetDesc), C.c_void_p, C.c_uint64, C.c_int, C.POINTER(capi.FlatOut), C.POINTER(capi.Sizes)]
     lib.vgo_tessellate.restype = C.c_int
     lib.vgo_tessellate.argtypes = [C.POINTER(capi.PathSetDesc), C.c_void_p, C.c_uint64, C.POINTER(capi.FlatOut), C.POINTER(capi.MeshOut), C.POINTER(capi.Sizes)]
+    lib.vgo_assemble.restype = C.c_int
+    lib.vgo_assemble.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.vgo_engine_name.restype = C.c_char_p
     _libs[kind] = lib
     return lib
@@ -100,6 +102,19 @@ def tessellate(ps, draws, kind="port", want_flat=False, count_only=False):
     st = lib.vgo_tessellate(C.byref(desc), draws.ctypes.data, n, fo_ref, C.byref(mo), C.byref(sizes))
     assert st == 0, st
     return r
+
+
+def assemble(meshes, idx, max_vb_vertices=0, kind="port"):
+    """Draw-command assembly (vgo_assemble): returns (status, drawcmds ndarray, rebased index buffer)."""
+    lib = load(kind)
+    meshes = np.ascontiguousarray(meshes)
+    idx = np.ascontiguousarray(idx)
+    out = np.zeros_like(idx)
+    n = C.c_uint64(0)
+    cap = max(int(meshes.shape[0]), 1)
+    cmds = np.zeros(cap, dtype=capi.drawcmd_dtype)
+    st = lib.vgo_assemble(meshes.ctypes.data, meshes.shape[0], idx.ctypes.data, out.ctypes.data, max_vb_vertices, cmds.ctypes.data, cap, C.byref(n))
+    return st, cmds[:n.value], out
 
 
 def tessellate_timed(ps, draws, kind="port", reps=1):

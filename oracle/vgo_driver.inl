@@ -227,6 +227,78 @@ int vgo_tessellate(const vgx_pathset_desc* ps, const vgx_draw* draws, uint64_t n
 	return vgoRun(ps, draws, ndraws, 1, flat, out, true, sizes);
 }
 
+// Draw-command assembly of a frame of meshes that all share one draw state: CPU statement of what
+// src/vg.cpp does per mesh in createDrawCommand_VertexColor (:5207-5244) via allocVertices (:5321-5342), allocIndices
+// (:5344-5357) and allocDrawCommand (:5359-5407), starting from an empty first vertex buffer and an empty index
+// buffer:
+//   allocVertices     if (vb.count + numVertices > maxVBVertices) { new vertex buffer; forceNewDrawCommand = true; }
+//                     firstVertexID = vb.count; vb.count += numVertices;
+//   allocIndices      firstIndexID = ib.count; ib.count += numIndices;       (one index buffer per frame)
+//   allocDrawCommand  if (!forceNew && a previous command exists && same type/handle) reuse it, else create
+//                     {vb id, firstVertexID, firstIndexID, numVertices = 0, numIndices = 0}; forceNew = false;
+//   createDrawCommand dstIndex = ib + cmd.firstIndexID + cmd.numIndices; rebase(indices, numIndices, dstIndex,
+//                     (uint16_t)cmd.numVertices); cmd.numVertices += numVertices; cmd.numIndices += numIndices;
+// PARITY UNPINNED for this bookkeeping: vg.cpp cannot be compiled without bgfx and the reference has no tests; only the
+// rebase primitive is the reference's own code in the `reference` oracle (VGO_REBASE = vgutil::batchTransformDrawIndices,
+// vg_util.cpp:447-520). idx_in holds mesh-local indices (vgo_tessellate's idx stream), idx_out receives the index buffer.
+int vgo_assemble(const vgx_mesh* meshes, uint64_t nmeshes, const uint16_t* idx_in, uint16_t* idx_out, uint32_t maxVBVertices,
+	vgx_drawcmd* cmds, uint64_t capCmds, uint64_t* numCmds)
+{
+	if (maxVBVertices == 0) { maxVBVertices = 65536u; }
+	uint32_t vbCount = 0, vbID = 0;      // current vertex buffer (vg.cpp:5326)
+	uint64_t ibCount = 0;                // IndexBuffer::m_Count
+	uint64_t vbGlobalStart = 0;          // where the current vertex buffer starts in the concatenated vertex streams
+	bool forceNew = false;
+	uint64_t ncmd = 0;
+	vgx_drawcmd cur = {};
+	bool have = false;
+	int status = VGX_OK;
+	for (uint64_t m = 0; m < nmeshes; ++m) {
+		const uint32_t nv = meshes[m].num_vertices, ni = meshes[m].num_indices;
+		if (nv > maxVBVertices) { status = VGX_E_MESH_TOO_LARGE; } // VG_CHECK(numVertices < m_MaxVBVertices), vg.cpp:5323
+		// allocVertices
+		if (vbCount + (uint64_t)nv > maxVBVertices) {
+			vbGlobalStart += vbCount;
+			++vbID;
+			vbCount = 0;
+			forceNew = true;
+		}
+		const uint32_t firstVertexID = vbCount;
+		vbCount += nv;
+		// allocIndices
+		const uint64_t firstIndexID = ibCount;
+		ibCount += ni;
+		// allocDrawCommand
+		if (forceNew || !have) {
+			if (have) {
+				if (ncmd < capCmds) { cmds[ncmd] = cur; }
+				++ncmd;
+			}
+			cur.vertex_buffer = vbID;
+			cur.first_vertex = vbGlobalStart + firstVertexID; // m_FirstVertexID is firstVertexID (0 for a new buffer)
+			cur.first_index = firstIndexID;
+			cur.first_mesh = m;
+			cur.num_vertices = 0; cur.num_indices = 0; cur.num_meshes = 0;
+			have = true;
+			forceNew = false;
+		}
+		// createDrawCommand_VertexColor: index rebase into the frame's index buffer
+		if (idx_in && idx_out) {
+			VGO_REBASE(idx_in + meshes[m].first_index, ni, idx_out + cur.first_index + cur.num_indices, (uint16_t)cur.num_vertices);
+		}
+		cur.num_vertices += nv;
+		cur.num_indices += ni;
+		cur.num_meshes += 1;
+	}
+	if (have) {
+		if (ncmd < capCmds) { cmds[ncmd] = cur; }
+		++ncmd;
+	}
+	*numCmds = ncmd;
+	if (ncmd > capCmds && status == VGX_OK) { status = VGX_E_NOSPACE; }
+	return status;
+}
+
 const char* vgo_engine_name(void) { return VGO_ENGINE_NAME; }
 
 } // extern "C"

@@ -58,13 +58,18 @@ mesh_dtype = np.dtype([
     ("first_vertex", "<u8"), ("first_index", "<u8"), ("num_vertices", "<u4"), ("num_indices", "<u4"),
     ("draw", "<u4"), ("subpath_kind", "<u4")])
 assert mesh_dtype.itemsize == 32
+drawcmd_dtype = np.dtype([
+    ("first_vertex", "<u8"), ("first_index", "<u8"), ("first_mesh", "<u8"), ("num_vertices", "<u4"), ("num_indices", "<u4"),
+    ("num_meshes", "<u4"), ("vertex_buffer", "<u4")])
+assert drawcmd_dtype.itemsize == 40
 
 
 # ---- ctypes structs ---------------------------------------------------------------------------
 class Sizes(C.Structure):
     _fields_ = [("num_poly_vertices", C.c_uint64), ("num_subpaths", C.c_uint64), ("num_meshes", C.c_uint64),
                 ("num_vertices", C.c_uint64), ("num_indices", C.c_uint64), ("num_serial_draws", C.c_uint64),
-                ("num_cmd_instances", C.c_uint64), ("num_elements", C.c_uint64), ("num_fill_elements", C.c_uint64)]
+                ("num_cmd_instances", C.c_uint64), ("num_elements", C.c_uint64), ("num_fill_elements", C.c_uint64),
+                ("num_drawcmds", C.c_uint64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -78,6 +83,11 @@ class PathSetDesc(C.Structure):
 class FlatOut(C.Structure):
     _fields_ = [("poly", C.c_void_p), ("subpaths", C.c_void_p), ("draw_info", C.c_void_p),
                 ("cap_poly_vertices", C.c_uint64), ("cap_subpaths", C.c_uint64)]
+
+
+class Assembly(C.Structure):
+    _fields_ = [("drawcmds", C.c_void_p), ("cap_drawcmds", C.c_uint64), ("dev_num_drawcmds", C.c_void_p),
+                ("max_vb_vertices", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class MeshOut(C.Structure):
@@ -97,6 +107,7 @@ class StageTimes(C.Structure):
 VGX_SYMBOLS = {
     "vgx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "vgx_destroy": (C.c_int, [C.c_void_p]),
+    "vgx_set_assembly": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vgx_last_hip_error": (C.c_int, [C.c_void_p]),
     "vgx_status_string": (C.c_char_p, [C.c_int]),
     "vgx_version": (C.c_uint32, []),

@@ -43,6 +43,9 @@ struct vgx_ctx
 	int device;
 	int lastHipError;
 	// grow-only device scratch
+	DevBuf asmJump0, asmJump1, asmStart, meshBase; // draw-command assembly scratch (only when armed)
+	vgx_assembly asmCfg;
+	bool asmArmed;
 	DevBuf cmdPrefix, cmdCnt, subFirst, leafOverflow, serialList, dinfo, poly, subs, mdesc, elemPrefix, elemPrefixS, mprep, mtab, partial, totals;
 	VgxCaps caps; // element capacities matching the buffers above
 	uint64_t capDraws;
@@ -379,7 +382,7 @@ void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps,
 	a.draws = draws; a.poly = poly ? poly : (const float*)ctx->poly.p; a.mdesc = (const VgxMeshDesc*)ctx->mdesc.p;
 	a.elem_prefix = nullptr; a.elem_prefix_fill = (const uint64_t*)ctx->elemPrefix.p; a.elem_prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
 	a.mprep = (VgxMeshPrep*)ctx->mprep.p; a.mtab = (vgx_mesh*)ctx->mtab.p;
-	a.pos = nullptr; a.color = nullptr; a.idx = nullptr; a.meshes_out = nullptr; a.stage_output = 0;
+	a.pos = nullptr; a.color = nullptr; a.idx = nullptr; a.meshes_out = nullptr; a.stage_output = 0; a.mesh_base = nullptr;
 	a.totals = (VgxTotals*)ctx->totals.p; a.caps = outCaps;
 	vgx_launch_mesh_prepare(a, s);
 	a.elem_prefix = a.elem_prefix_stroke;
@@ -391,9 +394,42 @@ void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps,
 	mark(ctx, s, "scan_meshes");
 }
 
-void runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out, hipStream_t s, const float* poly = nullptr)
+// Draw-command assembly (armed by vgx_set_assembly): partition of the mesh sequence into vertex buffers, per-mesh index
+// base, draw-command table. Runs between the scan over meshes and the emit kernels, which add the base to every index.
+int runAssemble(vgx_ctx* ctx, const vgx_mesh_out* out, hipStream_t s)
 {
+	const uint32_t maxVB = ctx->asmCfg.max_vb_vertices ? ctx->asmCfg.max_vb_vertices : 65536u;
+	const uint64_t meshCap = ctx->mtab.cap / sizeof(vgx_mesh);
+	uint64_t need = 2 * (out->cap_vertices / maxVB) + 4; // two consecutive vertex buffers always hold > maxVB vertices
+	if (need > meshCap + 1) { need = meshCap + 1; }
+	uint64_t capStart = 2;
+	while (capStart < need) { capStart <<= 1; }
+	int st;
+	if ((st = ensure(ctx, ctx->asmJump0, (meshCap + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->asmJump1, (meshCap + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->asmStart, capStart * sizeof(uint32_t))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->meshBase, (meshCap + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
+	VgxAsmArgs a;
+	a.mtab = (const vgx_mesh*)ctx->mtab.p;
+	a.jump0 = (uint32_t*)ctx->asmJump0.p; a.jump1 = (uint32_t*)ctx->asmJump1.p;
+	a.start = (uint32_t*)ctx->asmStart.p; a.cap_start = capStart;
+	a.mesh_base = (uint32_t*)ctx->meshBase.p;
+	a.drawcmds = ctx->asmCfg.drawcmds; a.cap_drawcmds = ctx->asmCfg.cap_drawcmds; a.dev_num_drawcmds = ctx->asmCfg.dev_num_drawcmds;
+	a.max_vb = maxVB;
+	a.totals = (VgxTotals*)ctx->totals.p;
+	vgx_launch_assemble(a, s);
+	mark(ctx, s, "assemble");
+	return VGX_OK;
+}
+
+int runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out, hipStream_t s, const float* poly = nullptr)
+{
+	if (ctx->asmArmed) {
+		const int st = runAssemble(ctx, out, s);
+		if (st != VGX_OK) { return st; }
+	}
 	VgxStrokeArgs a;
+	a.mesh_base = ctx->asmArmed ? (const uint32_t*)ctx->meshBase.p : nullptr;
 	a.draws = draws; a.poly = poly ? poly : (const float*)ctx->poly.p; a.mdesc = (const VgxMeshDesc*)ctx->mdesc.p;
 	a.elem_prefix = nullptr; a.elem_prefix_fill = (const uint64_t*)ctx->elemPrefix.p; a.elem_prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
 	a.mprep = (VgxMeshPrep*)ctx->mprep.p; a.mtab = (vgx_mesh*)ctx->mtab.p;
@@ -407,6 +443,7 @@ void runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out,
 	a.elem_prefix = a.elem_prefix_stroke;
 	vgx_launch_stroke(true, a, VGX_GRID_BLOCKS, s);
 	mark(ctx, s, "stroke_emit");
+	return VGX_OK;
 }
 
 int ensureMeshBuffers(vgx_ctx* ctx, uint64_t polyVerts, uint64_t subpaths, uint64_t meshes)
@@ -486,7 +523,7 @@ int vgx_destroy(vgx_ctx* ctx)
 	if (!ctx) {
 		return VGX_E_INVALID_ARG;
 	}
-	DevBuf* bufs[] = { &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DevBuf* bufs[] = { &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
@@ -505,7 +542,7 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx)
 	if (!ctx) {
 		return 0;
 	}
-	return ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
+	return ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
 }
 
 // ---- path set ---------------------------------------------------------------------------------------
@@ -839,8 +876,7 @@ int vgx_tessellate_emit(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* dra
 	}
 	hipStream_t s = (hipStream_t)stream;
 	markBegin(ctx, s);
-	runStrokeEmit(ctx, draws, out, s);
-	return VGX_OK;
+	return runStrokeEmit(ctx, draws, out, s);
 }
 
 int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream)
@@ -868,7 +904,10 @@ int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 	outCaps.indices = out->cap_indices;
 	if (out->meshes && out->cap_meshes < outCaps.meshes) { outCaps.meshes = out->cap_meshes; }
 	runStrokeCount(ctx, draws, outCaps, 1, s);
-	runStrokeEmit(ctx, draws, out, s);
+	{
+		const int st = runStrokeEmit(ctx, draws, out, s);
+		if (st != VGX_OK) { return st; }
+	}
 	if (dev_sizes || dev_status) {
 		hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, s, (const VgxTotals*)ctx->totals.p, dev_sizes, dev_status);
 	}
@@ -920,7 +959,23 @@ int vgx_stroke_emit(vgx_ctx* ctx, const float* poly, const vgx_subpath* subpaths
 	}
 	hipStream_t s = (hipStream_t)stream;
 	markBegin(ctx, s);
-	runStrokeEmit(ctx, draws, out, s, poly);
+	return runStrokeEmit(ctx, draws, out, s, poly);
+}
+
+int vgx_set_assembly(vgx_ctx* ctx, const vgx_assembly* asm_)
+{
+	if (!ctx) {
+		return VGX_E_INVALID_ARG;
+	}
+	if (!asm_) {
+		ctx->asmArmed = false;
+		return VGX_OK;
+	}
+	if (!asm_->drawcmds || asm_->cap_drawcmds == 0 || asm_->max_vb_vertices > 65536u) { // vg.cpp:734: indices are uint16
+		return VGX_E_INVALID_ARG;
+	}
+	ctx->asmCfg = *asm_;
+	ctx->asmArmed = true;
 	return VGX_OK;
 }
 

@@ -47,6 +47,7 @@ struct VgxStrokeArgs
 	uint32_t* color;
 	uint16_t* idx;
 	vgx_mesh* meshes_out;        // caller's mesh table (emit copies mtab into it)
+	const uint32_t* mesh_base;   // assembly armed: vertices in front of each mesh inside its vertex buffer (added to every index); else null
 	int stage_output;            // 1: stage each chunk in LDS and copy out coalesced; 0: direct global stores
 	VgxTotals* totals;
 	VgxCaps caps;
@@ -61,6 +62,23 @@ void vgx_launch_flatten_gather(const VgxFlattenArgs& a, hipStream_t s);  // afte
 #define VGX_BUILD_OVERFLOW 120 /* leaves per lane beyond the LDS slots kept in the wave's global overflow area */
 void vgx_launch_stroke(bool emit, const VgxStrokeArgs& a, int numBlocks, hipStream_t s);
 void vgx_launch_mesh_prepare(const VgxStrokeArgs& a, hipStream_t s);
+
+// draw-command assembly (vgx_assemble.hip)
+struct VgxAsmArgs
+{
+	const vgx_mesh* mtab;      // after the scan over meshes (first_vertex / first_index filled)
+	uint32_t* jump0;           // [meshes + 1] next / doubled jump table (ping)
+	uint32_t* jump1;           // [meshes + 1] (pong)
+	uint32_t* start;           // [cap_start] first mesh of every vertex buffer; cap_start is a power of two
+	uint64_t cap_start;
+	uint32_t* mesh_base;       // [meshes] out: vertices in front of the mesh inside its vertex buffer
+	vgx_drawcmd* drawcmds;     // caller's table
+	uint64_t cap_drawcmds;
+	uint64_t* dev_num_drawcmds;
+	uint32_t max_vb;
+	VgxTotals* totals;
+};
+void vgx_launch_assemble(const VgxAsmArgs& a, hipStream_t s);
 void vgx_launch_fill(const VgxStrokeArgs& a, int numBlocks, hipStream_t s);
 
 #endif

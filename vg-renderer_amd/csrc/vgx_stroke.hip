@@ -52,6 +52,7 @@ struct StrokeWriter
 	uint32_t* col;
 	uint16_t* idx;
 	uint32_t color, c0;
+	uint32_t ib; // added to every index written (assembly: vertices in front of the mesh inside its vertex buffer)
 	float sx[4], sy[4];
 	uint32_t sc[4];
 	uint32_t si[24];
@@ -96,7 +97,7 @@ struct StrokeWriter
 	}
 	__device__ __forceinline__ void tri(uint32_t k, uint32_t a, uint32_t b, uint32_t c) const
 	{
-		Idx3 t; t.a = (a & 0xFFFFu) | (b << 16); t.b = (uint16_t)c;
+		Idx3 t; t.a = ((a + ib) & 0xFFFFu) | ((b + ib) << 16); t.b = (uint16_t)(c + ib);
 		*(Idx3*)(idx + k) = t;
 	}
 	__device__ __forceinline__ void bridge4(uint32_t k, Rails p, Rails c) const
@@ -140,9 +141,9 @@ struct StrokeWriter
 		for (uint32_t g = 0; g < 4; ++g) {
 			if (niS > 6 * g) {
 				Idx6 t;
-				t.a = (si[6 * g] & 0xFFFFu) | (si[6 * g + 1] << 16);
-				t.b = (si[6 * g + 2] & 0xFFFFu) | (si[6 * g + 3] << 16);
-				t.c = (si[6 * g + 4] & 0xFFFFu) | (si[6 * g + 5] << 16);
+				t.a = ((si[6 * g] + ib) & 0xFFFFu) | ((si[6 * g + 1] + ib) << 16);
+				t.b = ((si[6 * g + 2] + ib) & 0xFFFFu) | ((si[6 * g + 3] + ib) << 16);
+				t.c = ((si[6 * g + 4] + ib) & 0xFFFFu) | ((si[6 * g + 5] + ib) << 16);
 				*(Idx6*)(pi + 6 * g) = t;
 			}
 		}
@@ -664,6 +665,7 @@ struct FillWindow
 	uint64_t polyFirst, firstV, firstI;
 	uint32_t N, kind, color;
 	float aa;
+	uint32_t ibase;    // assembly: vertices in front of the mesh inside its vertex buffer (0 when not armed)
 };
 
 __device__ __forceinline__ FillWindow fill_window_load(const VgxStrokeArgs& A, uint64_t wbase, uint64_t numMeshes, int lane)
@@ -671,7 +673,7 @@ __device__ __forceinline__ FillWindow fill_window_load(const VgxStrokeArgs& A, u
 	FillWindow w;
 	const uint64_t idx = wbase + (uint64_t)lane;
 	w.prefix = (idx <= numMeshes) ? A.elem_prefix[idx] : ~0ull;
-	w.polyFirst = 0; w.firstV = 0; w.firstI = 0; w.N = 3; w.kind = VGX_MESH_FILL; w.color = 0; w.aa = 0.0f;
+	w.polyFirst = 0; w.firstV = 0; w.firstI = 0; w.N = 3; w.kind = VGX_MESH_FILL; w.color = 0; w.aa = 0.0f; w.ibase = 0;
 	if (idx < numMeshes) {
 		const VgxMeshDesc md = A.mdesc[idx];
 		const VgxMeshPrep pr = A.mprep[idx];
@@ -679,6 +681,7 @@ __device__ __forceinline__ FillWindow fill_window_load(const VgxStrokeArgs& A, u
 		w.color = pr.color; w.aa = pr.f0;
 		w.firstV = A.mtab[idx].first_vertex;
 		w.firstI = A.mtab[idx].first_index;
+		if (A.mesh_base) { w.ibase = A.mesh_base[idx]; }
 	}
 	return w;
 }
@@ -689,7 +692,7 @@ __device__ __forceinline__ FillWindow fill_window_load(const VgxStrokeArgs& A, u
 struct FillFetch
 {
 	bool valid, aaElem, nextInWave, prevInWave;
-	uint32_t j, N, color;
+	uint32_t j, N, color, ibase;
 	float aa;
 	uint64_t firstV, firstI, mi;
 	V2 p1, pNextB, pPrevB;
@@ -722,6 +725,7 @@ __device__ __forceinline__ FillFetch fill_fetch(const VgxStrokeArgs& A, uint64_t
 	uint32_t kind = (uint32_t)__shfl((int)W.kind, k);
 	uint32_t color = (uint32_t)__shfl((int)W.color, k);
 	float aa = __shfl(W.aa, k);
+	uint32_t ibase = (uint32_t)__shfl((int)W.ibase, k);
 	if (!windowCovers && valid) { // > 63 mesh records (mostly zero-length stroke entries) inside one chunk: rare
 		mi = find_owner_u64(A.elem_prefix, wbase, numMeshes, ei);
 		ownerBase = A.elem_prefix[mi];
@@ -729,10 +733,12 @@ __device__ __forceinline__ FillFetch fill_fetch(const VgxStrokeArgs& A, uint64_t
 		const VgxMeshPrep pr = A.mprep[mi];
 		polyFirst = md.poly_first; N = md.poly_n; kind = VGX_MD_KIND(md.kind); color = pr.color; aa = pr.f0;
 		firstV = A.mtab[mi].first_vertex; firstI = A.mtab[mi].first_index;
+		ibase = A.mesh_base ? A.mesh_base[mi] : 0u;
 	}
 	const uint32_t j = valid ? (uint32_t)(ei - ownerBase) : 0u;
 	const float* vtx = A.poly + 2 * polyFirst;
 	F.valid = valid;
+	F.ibase = ibase;
 	F.aaElem = valid && kind == VGX_MESH_FILL_AA;
 	// all vertex loads of the chunk are issued together: my own vertex, and -- only for lanes whose neighbour is
 	// not in the adjacent lane (mesh boundary / chunk edge) -- the cyclic next / previous vertex
@@ -787,9 +793,10 @@ __device__ __forceinline__ void fill_emit_chunk(const VgxStrokeArgs& A, const Fi
 				const uint32_t fb = 2 * ed;
 				const bool lastEdge = ed + 1 == N;
 				const uint32_t nextInner = lastEdge ? 0u : fb + 2, nextOuter = lastEdge ? 1u : fb + 3;
-				val[3 * g] = isFan ? 0u : fb;
-				val[3 * g + 1] = (isFan ? 2 * T + 2 : (second ? nextOuter : fb + 1)) & 0xFFFFu;
-				val[3 * g + 2] = (isFan ? 2 * T + 4 : (second ? nextInner : nextOuter)) & 0xFFFFu;
+				// + F.ibase: vertex-buffer relative when assembly is armed (uint16 wrap = the reference's cast, vg_util.cpp:447)
+				val[3 * g] = ((isFan ? 0u : fb) + F.ibase) & 0xFFFFu;
+				val[3 * g + 1] = ((isFan ? 2 * T + 2 : (second ? nextOuter : fb + 1)) + F.ibase) & 0xFFFFu;
+				val[3 * g + 2] = ((isFan ? 2 * T + 4 : (second ? nextInner : nextOuter)) + F.ibase) & 0xFFFFu;
 			}
 			uint16_t* pi = A.idx + F.firstI + k9;
 			if (j + 1 < N) {
@@ -805,7 +812,7 @@ __device__ __forceinline__ void fill_emit_chunk(const VgxStrokeArgs& A, const Fi
 			A.color[gv] = color;
 			if (j + 2 < N) {
 				uint16_t* pi = A.idx + F.firstI + 3 * j;
-				pi[0] = 0; pi[1] = (uint16_t)(j + 1); pi[2] = (uint16_t)(j + 2);
+				pi[0] = (uint16_t)F.ibase; pi[1] = (uint16_t)(j + 1 + F.ibase); pi[2] = (uint16_t)(j + 2 + F.ibase);
 			}
 		}
 	}
@@ -861,7 +868,7 @@ struct __attribute__((aligned(16))) StrokeRec
 	uint32_t draw;
 	float hsw, hswAA, fringe;
 	uint64_t firstV, firstI;
-	uint32_t color, pad0, pad1, pad2;
+	uint32_t color, ibase, pad1, pad2; // ibase: assembly index base of the mesh (0 when not armed)
 };
 
 template<bool COUNT>
@@ -911,7 +918,7 @@ __global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
 				wv = (widx <= numMeshes) ? A.elem_prefix[widx] : ~0ull;
 				StrokeRec r;
 				r.polyFirst = 0; r.N = 2; r.kind = VGX_MESH_STROKE_AA; r.draw = 0; r.hsw = 0.0f; r.hswAA = 0.0f; r.fringe = 1.0f;
-				r.firstV = 0; r.firstI = 0; r.color = 0; r.pad0 = 0; r.pad1 = 0; r.pad2 = 0;
+				r.firstV = 0; r.firstI = 0; r.color = 0; r.ibase = 0; r.pad1 = 0; r.pad2 = 0;
 				if (widx < numMeshes) {
 					const VgxMeshDesc md = A.mdesc[widx];
 					const VgxMeshPrep pr = A.mprep[widx];
@@ -919,6 +926,7 @@ __global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
 					r.polyFirst = md.poly_first; r.N = md.poly_n; r.kind = md.kind; r.draw = md.draw;
 					r.hsw = pr.f0; r.hswAA = pr.f1; r.fringe = pr.f2; r.color = pr.color;
 					r.firstV = mr.first_vertex; r.firstI = mr.first_index;
+					if (A.mesh_base) { r.ibase = A.mesh_base[widx]; }
 				}
 				__syncthreads(); // lanes may still be reading the previous window
 				s_win[lane] = r;
@@ -936,6 +944,7 @@ __global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
 			mc.hsw = 0.0f; mc.hswAA = 0.0f; mc.fringe = 1.0f; mc.dr = A.draws; mc.vtx = A.poly;
 			uint32_t color = 0;
 			uint64_t firstV = 0, firstI = 0;
+			uint32_t idxBase = 0;
 			if (valid) {
 				StrokeRec r;
 				if (windowCovers) {
@@ -949,6 +958,7 @@ __global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
 					r.polyFirst = md.poly_first; r.N = md.poly_n; r.kind = md.kind; r.draw = md.draw;
 					r.hsw = pr.f0; r.hswAA = pr.f1; r.fringe = pr.f2; r.color = pr.color;
 					r.firstV = A.mtab[mi].first_vertex; r.firstI = A.mtab[mi].first_index;
+					r.ibase = A.mesh_base ? A.mesh_base[mi] : 0u;
 				}
 				mc.kind = VGX_MD_KIND(r.kind);
 				mc.closed = VGX_MD_CLOSED(r.kind) != 0;
@@ -960,7 +970,7 @@ __global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
 				mc.hsw = r.hsw; mc.hswAA = r.hswAA; mc.fringe = r.fringe;
 				mc.dr = A.draws + r.draw;
 				color = r.color;
-				firstV = r.firstV; firstI = r.firstI;
+				firstV = r.firstV; firstI = r.firstI; idxBase = r.ibase;
 			}
 			// step A: one vertex load and one vec2Dir per element; neighbours come from the adjacent lanes
 			V2 p1 = v2(0.0f, 0.0f);
@@ -1013,6 +1023,7 @@ __global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
 				w.idx = A.idx + firstI;
 				w.color = color;
 				w.c0 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
+				w.ib = idxBase;
 				w.reset();
 				elem_emit(mc, e, vbase, ibase, rails_unpack(prevPacked), w);
 				w.flush(vbase, ibase);

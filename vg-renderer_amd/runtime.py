@@ -77,6 +77,22 @@ class Context:
     def set_profiling(self, on):
         _check(lib().vgx_set_profiling(self._h, 1 if on else 0), "vgx_set_profiling")
 
+    def set_assembly(self, drawcmds=None, max_vb_vertices=0, dev_num=None):
+        """Arms draw-command assembly (vgx_set_assembly) with a uint8 device tensor of 40-byte vgx_drawcmd records,
+        or disarms it (drawcmds=None). The tensors must stay alive while armed."""
+        if drawcmds is None:
+            _check(lib().vgx_set_assembly(self._h, None), "vgx_set_assembly")
+            self._asm_keep = None
+            return
+        a = capi.Assembly()
+        a.drawcmds = drawcmds.data_ptr()
+        a.cap_drawcmds = drawcmds.numel() // capi.drawcmd_dtype.itemsize
+        a.dev_num_drawcmds = dev_num.data_ptr() if dev_num is not None else None
+        a.max_vb_vertices = max_vb_vertices
+        a.reserved = 0
+        _check(lib().vgx_set_assembly(self._h, C.byref(a)), "vgx_set_assembly")
+        self._asm_keep = (drawcmds, dev_num)
+
     def stage_times(self):
         st = capi.StageTimes()
         _check(lib().vgx_get_stage_times(self._h, C.byref(st)), "vgx_get_stage_times")
@@ -164,7 +180,7 @@ class MeshBuffers:
         self.color = torch.empty(max(nverts, 1), dtype=torch.int32, device=device)
         self.idx = torch.empty(max(nidx, 1), dtype=torch.int16, device=device)
         self.meshes = torch.empty(max(nmeshes, 1) * 32, dtype=torch.uint8, device=device)
-        self.dev_sizes = torch.zeros(9, dtype=torch.int64, device=device)
+        self.dev_sizes = torch.zeros(10, dtype=torch.int64, device=device)
         self.dev_status = torch.zeros(1, dtype=torch.int32, device=device)
 
     def out_struct(self):

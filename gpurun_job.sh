@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -12
-timeout 200 python profiles/stage_times.py 2>&1 | tail -1
+timeout 600 python -m pytest tests/test_gpu_golden.py -m gpu -x -q -k "tiger_assembly" 2>&1 | tail -12

@@ -28,6 +28,10 @@ def main():
     dd = rt.upload_draws(draws, 0)
     sizes = rt.tessellate_count(ctx, pset, dd, n)
     bufs = rt.MeshBuffers(torch.device("cuda", 0), sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"])
+    if os.environ.get("VGX_ASSEMBLE"):  # also run the draw-command assembly step (65536-vertex buffers)
+        cap = 2 * (sizes["num_vertices"] // 65536) + 2
+        cmds = torch.zeros(cap * 40, dtype=torch.uint8, device="cuda:0")
+        ctx.set_assembly(cmds, 0, None)
     for _ in range(3):
         rt.tessellate_async(ctx, pset, dd, n, bufs)
     torch.cuda.synchronize()

@@ -196,3 +196,66 @@ def test_full_size_round_joins_polylines(rt, gpu_ctx, wl, oracle):
     del r, col, bufs2
     torch.cuda.empty_cache()
     pset.close()
+
+
+def test_full_size_tiger_assembly(rt, gpu_ctx, wl):
+    """Draw-command assembly at full size (Tiger x10k, 65 536-vertex buffers, ~6 300 draw commands): size-independent
+    properties of the greedy partition and of the rebased index stream.
+      - the commands tile the vertex / index / mesh streams in order, each holds <= 65 536 vertices,
+      - greedy rule (vg.cpp:5327): the first mesh of command k+1 would not have fitted into command k,
+      - rebased index - plain index == vertices in front of the mesh inside its vertex buffer (mod 2^16), checked on
+        three 40 M-index windows of the stream; vertex streams are byte-identical to the unassembled run."""
+    import torch
+    K = 10000
+    ps, ops = wl.tiger_paths()
+    draws = wl.tiger_draws(ops, K)
+    n = draws.shape[0]
+    pset = rt.PathSet(gpu_ctx, ps)
+    dd = rt.upload_draws(draws)
+    del draws
+    sizes = rt.tessellate_count(gpu_ctx, pset, dd, n)
+    nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
+    plain = rt.MeshBuffers(dd.device, nv, ni, nm)
+    rt.tessellate_async(gpu_ctx, pset, dd, n, plain)
+    asm = rt.MeshBuffers(dd.device, nv, ni, nm)
+    cap = 2 * (nv // 65536) + 2
+    cmds_dev = torch.zeros(cap * 40, dtype=torch.uint8, device=dd.device)
+    ncmd = torch.zeros(1, dtype=torch.int64, device=dd.device)
+    gpu_ctx.set_assembly(cmds_dev, 0, ncmd)
+    try:
+        rt.tessellate_async(gpu_ctx, pset, dd, n, asm)
+        torch.cuda.synchronize()
+    finally:
+        gpu_ctx.set_assembly(None)
+    assert int(plain.dev_status.item()) == 0 and int(asm.dev_status.item()) == 0
+    T = int(ncmd.item())
+    assert int(asm.dev_sizes[9].item()) == T and nv // 65536 <= T <= cap
+    c = cmds_dev[:T * 40].cpu().numpy().view(rt.capi.drawcmd_dtype)
+    m = asm.meshes[:nm * 32].cpu().numpy().view(rt.capi.mesh_dtype)
+    assert np.array_equal(c["vertex_buffer"], np.arange(T, dtype=np.uint32))
+    assert int(c["num_vertices"].max()) <= 65536
+    assert int(c["first_vertex"][0]) == 0 and np.array_equal(c["first_vertex"][1:], np.cumsum(c["num_vertices"].astype(np.uint64))[:-1])
+    assert int(c["first_index"][0]) == 0 and np.array_equal(c["first_index"][1:], np.cumsum(c["num_indices"].astype(np.uint64))[:-1])
+    assert int(c["first_mesh"][0]) == 0 and np.array_equal(c["first_mesh"][1:], np.cumsum(c["num_meshes"].astype(np.uint64))[:-1])
+    assert int(c["num_vertices"].astype(np.uint64).sum()) == nv and int(c["num_meshes"].astype(np.uint64).sum()) == nm
+    assert np.array_equal(c["first_vertex"], m["first_vertex"][c["first_mesh"].astype(np.int64)])
+    nxt = m["num_vertices"][c["first_mesh"][1:].astype(np.int64)].astype(np.int64)
+    assert bool((c["num_vertices"][:-1].astype(np.int64) + nxt > 65536).all())
+    assert torch.equal(asm.pos.view(torch.int32), plain.pos.view(torch.int32)) and torch.equal(asm.color, plain.color)
+    assert torch.equal(asm.meshes, plain.meshes)
+    # per-mesh base = first_vertex(mesh) - first_vertex(first mesh of its command)
+    cmd_of_mesh = np.repeat(np.arange(T), c["num_meshes"].astype(np.int64))
+    base = (m["first_vertex"] - c["first_vertex"][cmd_of_mesh]).astype(np.int64)
+    assert int(base.max()) < 65536
+    fi = m["first_index"].astype(np.int64)
+    for lo_mesh in (0, nm // 2, nm - 120000):
+        hi_mesh = min(nm, lo_mesh + 100000)
+        a, b = int(fi[lo_mesh]), int(fi[hi_mesh]) if hi_mesh < nm else ni
+        cnt = torch.from_numpy(m["num_indices"][lo_mesh:hi_mesh].astype(np.int64)).to(dd.device)
+        per_index_base = torch.repeat_interleave(torch.from_numpy(base[lo_mesh:hi_mesh]).to(dd.device), cnt)
+        diff = (asm.idx[a:b].to(torch.int64) - plain.idx[a:b].to(torch.int64)) & 0xFFFF
+        assert torch.equal(diff, per_index_base & 0xFFFF), lo_mesh
+        del per_index_base, diff
+    del plain, asm
+    torch.cuda.empty_cache()
+    pset.close()

@@ -101,7 +101,24 @@ def cpu_baseline(budget_seconds=10.0, max_procs=256):
 
     v1, t1, _ = run(1, min(2.0, budget_seconds))
     vN, tN, cN = run(procs, budget_seconds)
+    sse = None
+    if kind == "reference" and pyoracle.available("reference_sse"):
+        # the reference's fastest configuration (SSE2 strokerConvexFillAA, stroker.cpp:368-711): speed only, its
+        # indices / rounding differ from the scalar build, so it is not a parity oracle
+        def run_sse(nproc, budget):
+            ps = [subprocess.Popen([sys.executable, worker, "reference_sse", "16", str(i * 16), str(budget)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+                  for i in range(nproc)]
+            for p in ps:
+                assert p.stdout.readline().strip() == "ready"
+            for p in ps:
+                p.stdin.write("go\n")
+                p.stdin.flush()
+            outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in ps]
+            return sum(o["verts"] for o in outs), max(o["seconds"] for o in outs)
+        vs, ts = run_sse(procs, budget_seconds / 2)
+        sse = round(vs / ts / 1e6, 2)
     return {"value": round(vN / tN / 1e6, 2), "unit": "M verts/s", "cores": procs, "kind": kind,
+            "value_sse_stroker": sse,
             "single_core_value": round(v1 / t1 / 1e6, 2), "cpu_seconds_per_wall_second": round(cN / tN, 1),
             "sample": "Tiger x16 instances per process, looped for %.0f s of wall time, %d processes (one per usable host core; "
                       "%d logical CPUs visible)" % (budget_seconds, procs, os.cpu_count() or 0)}

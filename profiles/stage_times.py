@@ -18,6 +18,27 @@ def main():
     elif which == "cubics":       # BASELINE config 2: 1 M independent cubics (stroked AA, Butt/Miter, so the stroker runs too)
         ps, draws = wl.random_cubics(1000000, seed=1234, box=1000.0)
         wl.set_stroke(draws, slice(None), 0xFF2080FF, 3.0, 0, 0, aa=True)
+    elif which == "ui":           # widget-like batch: 200 k rounded rects / circles / ellipses, fill AA + stroke AA (serial-lane shapes)
+        import numpy as np
+        pm = importlib.import_module("vg-renderer_amd.pathset")
+        b = pm.PathSetBuilder()
+        rs = np.random.RandomState(3)
+        for i in range(64):
+            b.begin_path()
+            k = i % 4
+            if k == 0: b.rounded_rect(10, 10, float(rs.uniform(40, 200)), float(rs.uniform(20, 60)), float(rs.uniform(3, 12)))
+            elif k == 1: b.circle(50, 50, float(rs.uniform(5, 40)))
+            elif k == 2: b.ellipse(50, 50, float(rs.uniform(10, 60)), float(rs.uniform(5, 30)))
+            else: b.rect(0, 0, float(rs.uniform(20, 300)), float(rs.uniform(10, 80)))
+            b.end_path()
+        ps = b.arrays()
+        n = 200000
+        draws = pm.make_draws(n)
+        draws["path"] = np.arange(n, dtype=np.uint32) % 64
+        draws["mtx"][:, 4] = rs.uniform(0, 1000, n).astype(np.float32)
+        draws["mtx"][:, 5] = rs.uniform(0, 1000, n).astype(np.float32)
+        wl.set_fill(draws, slice(None), 0xFF808080, aa=True)
+        wl.set_stroke(draws, slice(None), 0xFF202020, 2.0, 0, 0, aa=True)
     else:
         K = int(which) if which.isdigit() else 10000
         ps, ops = wl.tiger_paths()

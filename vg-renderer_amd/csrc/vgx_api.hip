@@ -382,7 +382,7 @@ void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps,
 	a.draws = draws; a.poly = poly ? poly : (const float*)ctx->poly.p; a.mdesc = (const VgxMeshDesc*)ctx->mdesc.p;
 	a.elem_prefix = nullptr; a.elem_prefix_fill = (const uint64_t*)ctx->elemPrefix.p; a.elem_prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
 	a.mprep = (VgxMeshPrep*)ctx->mprep.p; a.mtab = (vgx_mesh*)ctx->mtab.p;
-	a.pos = nullptr; a.color = nullptr; a.idx = nullptr; a.meshes_out = nullptr; a.stage_output = 0; a.mesh_base = nullptr;
+	a.pos = nullptr; a.color = nullptr; a.idx = nullptr; a.meshes_out = nullptr; a.mesh_base = nullptr;
 	a.totals = (VgxTotals*)ctx->totals.p; a.caps = outCaps;
 	vgx_launch_mesh_prepare(a, s);
 	a.elem_prefix = a.elem_prefix_stroke;
@@ -434,7 +434,6 @@ int runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out, 
 	a.elem_prefix = nullptr; a.elem_prefix_fill = (const uint64_t*)ctx->elemPrefix.p; a.elem_prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
 	a.mprep = (VgxMeshPrep*)ctx->mprep.p; a.mtab = (vgx_mesh*)ctx->mtab.p;
 	a.pos = out->pos; a.color = out->color; a.idx = out->idx; a.meshes_out = out->meshes;
-	{ const char* e = getenv("VGX_STAGE_OUTPUT"); a.stage_output = e ? atoi(e) : 1; } // tuning knob
 	a.totals = (VgxTotals*)ctx->totals.p;
 	a.caps = ctx->caps;
 	a.elem_prefix = a.elem_prefix_fill;

@@ -48,7 +48,6 @@ struct VgxStrokeArgs
 	uint16_t* idx;
 	vgx_mesh* meshes_out;        // caller's mesh table (emit copies mtab into it)
 	const uint32_t* mesh_base;   // assembly armed: vertices in front of each mesh inside its vertex buffer (added to every index); else null
-	int stage_output;            // 1: stage each chunk in LDS and copy out coalesced; 0: direct global stores
 	VgxTotals* totals;
 	VgxCaps caps;
 };

@@ -266,6 +266,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms": round(dom_ms, 3), "algorithmic_bytes": ab[dom],
+                         "by_kernel": {k: {"ms": round(stage_sum[k], 3), "achieved": round(ab[k] / (stage_sum[k] * 1e-3) / 1e9, 1),
+                                           "frac": round(ab[k] / (stage_sum[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                       for k in ("flatten_build", "fill_emit", "stroke_emit") if k in stage_sum and k in ab},
                          "pipeline_achieved": round(ab["pipeline"] / (ms_per_step * 1e-3) / 1e9, 1)},
             "stage_ms": {k: round(v, 3) for k, v in stage_sum.items()},
             "cpu_baseline": cpu,

@@ -339,7 +339,7 @@ void runCmdPrefix(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, ui
 	OpCmdPrefix op;
 	op.draws = draws; op.pathCmdBegin = ps->dev.path_cmd_begin; op.npaths = ps->dev.npaths; op.ndraws = ndraws;
 	op.prefix = (uint64_t*)ctx->cmdPrefix.p; op.totals = (VgxTotals*)ctx->totals.p; op.cap = ctx->caps.cmd_instances;
-	vgx_device_scan(op, (Sum3*)ctx->partial.p, s);
+	vgx_device_scan(op, (Sum3*)ctx->partial.p, s, ndraws);
 	mark(ctx, s, "scan_cmd_prefix");
 }
 
@@ -352,7 +352,7 @@ void runFlattenCount(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 	mark(ctx, s, "flatten_count");
 	OpDrawInfo op;
 	op.dinfo = (vgx_draw_info*)ctx->dinfo.p; op.ndraws = ndraws; op.totals = (VgxTotals*)ctx->totals.p; op.caps = ctx->caps; op.keepPolyBase = 0;
-	vgx_device_scan(op, (Sum3*)ctx->partial.p, s);
+	vgx_device_scan(op, (Sum3*)ctx->partial.p, s, ndraws);
 	mark(ctx, s, "scan_draws");
 }
 
@@ -366,7 +366,7 @@ void runFlattenBuild(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 	mark(ctx, s, "flatten_build");
 	OpDrawInfo op;
 	op.dinfo = (vgx_draw_info*)ctx->dinfo.p; op.ndraws = ndraws; op.totals = (VgxTotals*)ctx->totals.p; op.caps = ctx->caps; op.keepPolyBase = 1;
-	vgx_device_scan(op, (Sum3*)ctx->partial.p, s);
+	vgx_device_scan(op, (Sum3*)ctx->partial.p, s, ndraws);
 	mark(ctx, s, "scan_draws");
 	vgx_launch_flatten_gather(a, s);
 	mark(ctx, s, "flatten_gather");
@@ -376,7 +376,7 @@ void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps,
 {
 	OpElemPrefix ope;
 	ope.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; ope.prefixFill = (uint64_t*)ctx->elemPrefix.p; ope.prefixStroke = (uint64_t*)ctx->elemPrefixS.p; ope.totals = (VgxTotals*)ctx->totals.p;
-	vgx_device_scan(ope, (Sum3*)ctx->partial.p, s);
+	vgx_device_scan(ope, (Sum3*)ctx->partial.p, s, ctx->caps.meshes);
 	mark(ctx, s, "scan_elements");
 	VgxStrokeArgs a;
 	a.draws = draws; a.poly = poly ? poly : (const float*)ctx->poly.p; a.mdesc = (const VgxMeshDesc*)ctx->mdesc.p;
@@ -390,7 +390,7 @@ void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps,
 	mark(ctx, s, "mesh_prepare");
 	OpMeshTab opm;
 	opm.mtab = (vgx_mesh*)ctx->mtab.p; opm.totals = (VgxTotals*)ctx->totals.p; opm.caps = outCaps; opm.checkCaps = checkCaps;
-	vgx_device_scan(opm, (Sum3*)ctx->partial.p, s);
+	vgx_device_scan(opm, (Sum3*)ctx->partial.p, s, ctx->caps.meshes);
 	mark(ctx, s, "scan_meshes");
 }
 
@@ -931,7 +931,7 @@ int vgx_stroke_count(vgx_ctx* ctx, const float* poly, const vgx_subpath* subpath
 	OpSubMeshes op;
 	op.subs = subpaths; op.subDraw = subpath_draw; op.draws = draws; op.nsubs = nsubpaths; op.ndraws = ndraws;
 	op.mdesc = (VgxMeshDesc*)ctx->mdesc.p; op.mtab = (vgx_mesh*)ctx->mtab.p; op.totals = (VgxTotals*)ctx->totals.p;
-	vgx_device_scan(op, (Sum3*)ctx->partial.p, s);
+	vgx_device_scan(op, (Sum3*)ctx->partial.p, s, nsubpaths);
 	mark(ctx, s, "scan_subpath_meshes");
 	VgxCaps outCaps = ctx->caps;
 	outCaps.vertices = ~0ull; outCaps.indices = ~0ull;

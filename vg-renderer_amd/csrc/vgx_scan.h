@@ -131,9 +131,39 @@ __global__ __launch_bounds__(VGX_SCAN_THREADS) void k_scan_apply(OP op, const Su
 	}
 }
 
+// Small inputs: the whole scan in ONE workgroup (a frame-sized batch is launch-latency bound: three dependent
+// launches per scan x five scans cost ~8 us of a 127 us single-drawing call; beyond one tile the three-pass form is faster).
+#define VGX_SCAN_SINGLE_THREADS 1024
+#define VGX_SCAN_SINGLE_MAX 1024
 template<class OP>
-static inline void vgx_device_scan(const OP& op, Sum3* partial /* [VGX_SCAN_BLOCKS] device */, hipStream_t s)
+__global__ __launch_bounds__(VGX_SCAN_SINGLE_THREADS) void k_scan_single(OP op)
 {
+	__shared__ Sum3 s_wave[VGX_SCAN_SINGLE_THREADS / 64];
+	const uint64_t n = op.size();
+	Sum3 carry = sum3_zero();
+	for (uint64_t base = 0; base < n; base += VGX_SCAN_SINGLE_THREADS) {
+		const uint64_t i = base + threadIdx.x;
+		const Sum3 v = (i < n) ? op.load(i) : sum3_zero();
+		Sum3 tot;
+		const Sum3 incl = block_incl_scan<VGX_SCAN_SINGLE_THREADS>(v, s_wave, &tot);
+		if (i < n) {
+			Sum3 e;
+			e.a = carry.a + incl.a - v.a; e.b = carry.b + incl.b - v.b; e.c = carry.c + incl.c - v.c; e.d = carry.d + incl.d - v.d;
+			op.store(i, e);
+		}
+		carry = sum3_add(carry, tot);
+	}
+	if (threadIdx.x == 0) { op.finish(carry); }
+}
+
+// maxItems: an upper bound of op.size() the HOST knows (the size itself lives in device memory); picks the launch shape.
+template<class OP>
+static inline void vgx_device_scan(const OP& op, Sum3* partial /* [VGX_SCAN_BLOCKS] device */, hipStream_t s, uint64_t maxItems = ~0ull)
+{
+	if (maxItems <= VGX_SCAN_SINGLE_MAX) {
+		hipLaunchKernelGGL(k_scan_single<OP>, dim3(1), dim3(VGX_SCAN_SINGLE_THREADS), 0, s, op);
+		return;
+	}
 	hipLaunchKernelGGL(k_scan_reduce<OP>, dim3(VGX_SCAN_BLOCKS), dim3(VGX_SCAN_THREADS), 0, s, op, partial);
 	hipLaunchKernelGGL(k_scan_partials<OP>, dim3(1), dim3(VGX_SCAN_BLOCKS), 0, s, op, partial);
 	hipLaunchKernelGGL(k_scan_apply<OP>, dim3(VGX_SCAN_BLOCKS), dim3(VGX_SCAN_THREADS), 0, s, op, partial);

@@ -24,6 +24,16 @@ static int vgxGridBlocks()
 }
 #define VGX_GRID_BLOCKS vgxGridBlocks() // one-wave workgroups, each owning a contiguous run of segments (>> resident waves: no tail)
 
+// Grid of the element kernels for a batch whose element count is at most `maxElements` (a bound the host knows: the
+// caller's vertex capacity -- every element emits at least one vertex). Frame-sized batches should not pay for
+// dispatching 32768 workgroups that exit at once (~8 us per kernel).
+static int vgxElementGrid(uint64_t maxElements)
+{
+	const uint64_t want = maxElements / (2 * 64) + 1; // >= 2 chunks per wave
+	const uint64_t full = (uint64_t)VGX_GRID_BLOCKS;
+	return (int)(want < 256 ? 256 : (want > full ? full : want));
+}
+
 struct vgx_pathset
 {
 	VgxPathSetDev dev;
@@ -386,7 +396,7 @@ void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps,
 	a.totals = (VgxTotals*)ctx->totals.p; a.caps = outCaps;
 	vgx_launch_mesh_prepare(a, s);
 	a.elem_prefix = a.elem_prefix_stroke;
-	vgx_launch_stroke(false, a, VGX_GRID_BLOCKS, s); // Round-join mesh sizes (exits immediately without Round joins)
+	vgx_launch_stroke(false, a, vgxElementGrid(outCaps.vertices), s); // Round-join mesh sizes (exits immediately without Round joins)
 	mark(ctx, s, "mesh_prepare");
 	OpMeshTab opm;
 	opm.mtab = (vgx_mesh*)ctx->mtab.p; opm.totals = (VgxTotals*)ctx->totals.p; opm.caps = outCaps; opm.checkCaps = checkCaps;
@@ -437,10 +447,10 @@ int runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out, 
 	a.totals = (VgxTotals*)ctx->totals.p;
 	a.caps = ctx->caps;
 	a.elem_prefix = a.elem_prefix_fill;
-	vgx_launch_fill(a, VGX_GRID_BLOCKS, s);
+	vgx_launch_fill(a, vgxElementGrid(out->cap_vertices), s);
 	mark(ctx, s, "fill_emit");
 	a.elem_prefix = a.elem_prefix_stroke;
-	vgx_launch_stroke(true, a, VGX_GRID_BLOCKS, s);
+	vgx_launch_stroke(true, a, vgxElementGrid(out->cap_vertices), s);
 	mark(ctx, s, "stroke_emit");
 	return VGX_OK;
 }

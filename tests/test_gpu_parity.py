@@ -248,3 +248,34 @@ def test_async_very_long_subpaths(rt, gpu_ctx, wl, oracle, waves, monkeypatch):
     got = _async_result(rt, gpu_ctx, ps, d)
     assert got.status == 0
     assert_mesh_equal(got, ref, "5 x 30001-vertex polylines")
+
+
+@pytest.mark.gpu
+def test_async_call_is_graph_capturable(rt, gpu_ctx, wl, oracle):
+    """Steady state: vgx_tessellate only enqueues kernels / memsets on the caller's stream (no allocation, no host
+    sync), so a frame can be captured into a HIP graph once and replayed; the replay must reproduce the oracle."""
+    import torch
+    ps, d = wl.tiger(3)
+    ref = oracle.tessellate(ps, d)
+    pset = rt.PathSet(gpu_ctx, ps)
+    dd = rt.upload_draws(d)
+    sizes = rt.tessellate_count(gpu_ctx, pset, dd, d.shape[0])
+    nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
+    bufs = rt.MeshBuffers(dd.device, nv, ni, nm)
+    rt.tessellate_async(gpu_ctx, pset, dd, d.shape[0], bufs)  # warm: scratch is sized, nothing left to allocate
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        rt.tessellate_async(gpu_ctx, pset, dd, d.shape[0], bufs)
+    for _ in range(3):
+        bufs.pos.fill_(float("nan"))
+        bufs.idx.zero_()
+        bufs.dev_status.fill_(77)
+        g.replay()
+        torch.cuda.synchronize()
+        assert int(bufs.dev_status.item()) == 0
+        assert np.array_equal(bufs.pos[:nv].cpu().numpy().view(np.uint32), ref.pos.view(np.uint32))
+        assert np.array_equal(bufs.idx[:ni].cpu().numpy().view(np.uint16), ref.idx)
+        assert np.array_equal(bufs.color[:nv].cpu().numpy().view(np.uint32), ref.color)
+    del g
+    pset.close()

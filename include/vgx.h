@@ -257,6 +257,35 @@ int vgx_stroke_emit(vgx_ctx* ctx, const float* poly, const vgx_subpath* subpaths
  * VGX_E_MESH_TOO_LARGE (the reference VG_CHECKs it, vg.cpp:5323); a too small table VGX_E_NOSPACE. The struct is copied. */
 int vgx_set_assembly(vgx_ctx* ctx, const vgx_assembly* asm_);
 
+/* ---- shape cache: tessellate a drawing once, submit it many times -------------
+ * The reference keeps the meshes of a cached command list in the drawing's LOCAL space (addCachedCommand,
+ * src/vg.cpp:5808-5841: positions times the inverse of the state transform at record time) and a later submission
+ * only transforms them with the current state transform and appends positions, colours and indices to the frame
+ * (submitCachedMesh, vg.cpp:6137-6166). All pointers below are DEVICE pointers. */
+typedef struct vgx_cache_desc {   /* CommandListCache::m_Meshes as four streams: what vgx_tessellate[_emit] wrote */
+	const float* pos;             /* [num_vertices][2], local space (after vgx_cache_localize) */
+	const uint32_t* color;        /* [num_vertices] */
+	const uint16_t* idx;          /* [num_indices], mesh-local */
+	const vgx_mesh* meshes;       /* [num_meshes] */
+	uint64_t num_meshes, num_vertices, num_indices;
+} vgx_cache_desc;
+
+typedef struct vgx_cache_instance { /* one submission of a cached command (clCacheRender, vg.cpp:5845-6135). 40 bytes */
+	uint64_t first_mesh;          /* CachedCommand::m_FirstMeshID */
+	uint32_t num_meshes;          /* CachedCommand::m_NumMeshes */
+	uint32_t reserved;
+	float mtx[6];                 /* State::m_TransformMtx at submission */
+} vgx_cache_instance;
+
+/* addCachedCommand: pos[v] <- inverse(draws[meshes[m].draw].mtx) * pos[v] for every vertex of every mesh, with the
+ * reference's arithmetic (vgutil::invertMatrix3 in double precision, vg_util.cpp:14-33; transformPos2D). In place. */
+int vgx_cache_localize(vgx_ctx* ctx, const vgx_draw* draws, uint64_t ndraws, float* pos, const vgx_mesh* meshes, uint64_t num_meshes, void* stream);
+/* submitCachedMesh for `ninst` instances in order: for every mesh of every instance's range, positions through the
+ * instance transform (batchTransformPositions), colours and indices copied; mesh records get the instance index as
+ * `draw`. Asynchronous like vgx_tessellate (capacities checked on the device, totals in dev_sizes, status in
+ * dev_status); honours vgx_set_assembly (createDrawCommand_VertexColor is what submitCachedMesh calls). */
+int vgx_cache_submit(vgx_ctx* ctx, const vgx_cache_desc* cache, const vgx_cache_instance* instances, uint64_t ninst, const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream);
+
 /* Per-kernel timing of the last vgx_tessellate.. / vgx_flatten.. sequence, measured with HIP events
  * on the stream the kernels ran on. Enable before the call; read after synchronising. */
 #define VGX_MAX_STAGES 16

@@ -41,6 +41,10 @@ def load(kind="port"):
     lib.vgo_tessellate.argtypes = [C.POINTER(capi.PathSetDesc), C.c_void_p, C.c_uint64, C.POINTER(capi.FlatOut), C.POINTER(capi.MeshOut), C.POINTER(capi.Sizes)]
     lib.vgo_assemble.restype = C.c_int
     lib.vgo_assemble.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.vgo_cache_localize.restype = C.c_int
+    lib.vgo_cache_localize.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.vgo_cache_submit.restype = C.c_int
+    lib.vgo_cache_submit.argtypes = [C.POINTER(capi.CacheDesc), C.c_void_p, C.c_uint64, C.POINTER(capi.MeshOut), C.POINTER(capi.Sizes)]
     lib.vgo_engine_name.restype = C.c_char_p
     _libs[kind] = lib
     return lib
@@ -115,6 +119,36 @@ def assemble(meshes, idx, max_vb_vertices=0, kind="port"):
     cmds = np.zeros(cap, dtype=capi.drawcmd_dtype)
     st = lib.vgo_assemble(meshes.ctypes.data, meshes.shape[0], idx.ctypes.data, out.ctypes.data, max_vb_vertices, cmds.ctypes.data, cap, C.byref(n))
     return st, cmds[:n.value], out
+
+
+def cache_localize(draws, res, kind="port"):
+    """In place: res.pos <- local space (addCachedCommand). res: MeshResult of tessellate(ps, draws)."""
+    lib = load(kind)
+    draws = np.ascontiguousarray(draws)
+    st = lib.vgo_cache_localize(draws.ctypes.data, draws.shape[0], res.pos.ctypes.data, res.meshes.ctypes.data, res.meshes.shape[0])
+    assert st == 0, st
+    return res
+
+
+def cache_submit(res, instances, kind="port"):
+    """res: localised MeshResult; instances: ndarray(cache_instance_dtype). Returns a MeshResult of the frame."""
+    lib = load(kind)
+    instances = np.ascontiguousarray(instances)
+    cd = capi.CacheDesc(res.pos.ctypes.data, res.color.ctypes.data, res.idx.ctypes.data, res.meshes.ctypes.data,
+                        res.meshes.shape[0], res.pos.shape[0], res.idx.shape[0])
+    sizes = capi.Sizes()
+    st = lib.vgo_cache_submit(C.byref(cd), instances.ctypes.data, instances.shape[0], None, C.byref(sizes))
+    assert st == 0, st
+    r = MeshResult()
+    r.sizes = sizes.as_dict()
+    r.pos = np.zeros((sizes.num_vertices, 2), dtype=np.float32)
+    r.color = np.zeros(sizes.num_vertices, dtype=np.uint32)
+    r.idx = np.zeros(sizes.num_indices, dtype=np.uint16)
+    r.meshes = np.zeros(sizes.num_meshes, dtype=capi.mesh_dtype)
+    mo = capi.MeshOut(r.pos.ctypes.data, r.color.ctypes.data, r.idx.ctypes.data, r.meshes.ctypes.data, sizes.num_vertices, sizes.num_indices, sizes.num_meshes)
+    st = lib.vgo_cache_submit(C.byref(cd), instances.ctypes.data, instances.shape[0], C.byref(mo), C.byref(sizes))
+    assert st == 0, st
+    return r
 
 
 def tessellate_timed(ps, draws, kind="port", reps=1):

@@ -12,4 +12,5 @@
 #define VGO_ENGINE_NAME "reference(vg-renderer src @ /root/reference, scalar build, bx_shim+vgmath)"
 #define VGO_XFORM vgutil::batchTransformPositions
 #define VGO_REBASE(src, n, dst, delta) vgutil::batchTransformDrawIndices((src), (n), (dst), (delta)) // the reference's own (vg_util.cpp:447-520)
+#define VGO_INVERT3(t, inv) vgutil::invertMatrix3((t), (inv))                      // vg_util.cpp:14-33
 #include "vgo_driver.inl"

@@ -299,6 +299,55 @@ int vgo_assemble(const vgx_mesh* meshes, uint64_t nmeshes, const uint16_t* idx_i
 	return status;
 }
 
+// Shape cache. vgo_cache_localize = addCachedCommand (src/vg.cpp:5808-5841): every mesh's positions times
+// the inverse of the state transform its draw was recorded under (beginCachedCommand :5773-5790 takes the inverse with
+// vgutil::invertMatrix3). vgo_cache_submit = submitCachedMesh(Color) (vg.cpp:6137-6166) for a list of instances:
+// batchTransformPositions with the instance transform, then what createDrawCommand_VertexColor copies (positions,
+// colours, indices) appended mesh after mesh. The arithmetic (VGO_INVERT3 / VGO_XFORM) is the reference's own
+// vg_util.cpp code in the `reference` oracle; the loops around it are restated (vg.cpp cannot be built without bgfx).
+int vgo_cache_localize(const vgx_draw* draws, uint64_t ndraws, float* pos, const vgx_mesh* meshes, uint64_t nmeshes)
+{
+	for (uint64_t m = 0; m < nmeshes; ++m) {
+		if (meshes[m].draw >= ndraws) { return VGX_E_INVALID_ARG; }
+		float inv[6];
+		VGO_INVERT3(draws[meshes[m].draw].mtx, inv);
+		float* p = pos + 2 * meshes[m].first_vertex;
+		std::vector<float> tmp(p, p + 2 * (size_t)meshes[m].num_vertices);
+		VGO_XFORM(tmp.data(), meshes[m].num_vertices, p, inv);
+	}
+	return VGX_OK;
+}
+
+int vgo_cache_submit(const vgx_cache_desc* cache, const vgx_cache_instance* inst, uint64_t ninst, const vgx_mesh_out* out, vgx_sizes* sizes)
+{
+	memset(sizes, 0, sizeof(*sizes));
+	uint64_t nv = 0, ni = 0, nm = 0;
+	bool overflow = false;
+	for (uint64_t i = 0; i < ninst; ++i) {
+		if (inst[i].first_mesh > cache->num_meshes || inst[i].num_meshes > cache->num_meshes - inst[i].first_mesh) { return VGX_E_INVALID_ARG; }
+		for (uint64_t k = 0; k < inst[i].num_meshes; ++k) {
+			const vgx_mesh& src = cache->meshes[inst[i].first_mesh + k];
+			if (out) {
+				if (nv + src.num_vertices > out->cap_vertices || ni + src.num_indices > out->cap_indices || (out->meshes && nm + 1 > out->cap_meshes)) {
+					overflow = true;
+				} else {
+					VGO_XFORM(cache->pos + 2 * src.first_vertex, src.num_vertices, out->pos + 2 * nv, inst[i].mtx);
+					memcpy(out->color + nv, cache->color + src.first_vertex, sizeof(uint32_t) * src.num_vertices);
+					memcpy(out->idx + ni, cache->idx + src.first_index, sizeof(uint16_t) * src.num_indices);
+					if (out->meshes) {
+						vgx_mesh r = src;
+						r.first_vertex = nv; r.first_index = ni; r.draw = (uint32_t)i;
+						out->meshes[nm] = r;
+					}
+				}
+			}
+			nv += src.num_vertices; ni += src.num_indices; nm += 1;
+		}
+	}
+	sizes->num_vertices = nv; sizes->num_indices = ni; sizes->num_meshes = nm;
+	return overflow ? VGX_E_NOSPACE : VGX_OK;
+}
+
 const char* vgo_engine_name(void) { return VGO_ENGINE_NAME; }
 
 } // extern "C"

@@ -1,0 +1,94 @@
+"""Shape-cache oracle (vgo_cache_localize / vgo_cache_submit): restatement vs the build whose arithmetic is the
+reference's own vg_util.cpp (invertMatrix3, batchTransformPositions), plus properties of the round trip."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import pyoracle
+
+capi = importlib.import_module("vg-renderer_amd.capi")
+wl = importlib.import_module("vg-renderer_amd.workloads")
+KINDS = [k for k in ("port", "reference") if pyoracle.available(k)]
+
+
+def make_instances(rs, res, per_draw_ranges, n):
+    inst = np.zeros(n, dtype=capi.cache_instance_dtype)
+    nm = res.meshes.shape[0]
+    for i in range(n):
+        a = int(rs.randint(0, nm))
+        b = int(rs.randint(a, min(nm, a + 40) + 1))
+        inst["first_mesh"][i] = a
+        inst["num_meshes"][i] = b - a
+        ang = rs.uniform(0, 6.28)
+        sc = rs.uniform(0.5, 2.0)
+        inst["mtx"][i] = [sc * np.cos(ang), sc * np.sin(ang), -sc * np.sin(ang), sc * np.cos(ang), rs.uniform(-500, 500), rs.uniform(-500, 500)]
+    return inst
+
+
+def rotated_draws(d, rs):
+    d = d.copy()
+    for k in range(d.shape[0]):
+        ang = rs.uniform(0, 6.28)
+        d["mtx"][k] = [np.cos(ang), np.sin(ang), -np.sin(ang), np.cos(ang), rs.uniform(-50, 50), rs.uniform(-50, 50)]
+    return d
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_identity_round_trip(kind):
+    """Recorded under the identity, submitted under the identity: the cache returns the tessellation bit for bit
+    (inverse of identity is exact, 1*x + 0*y + 0 is exact)."""
+    ps, d = wl.tiger(1)
+    ref = pyoracle.tessellate(ps, d, kind=kind)
+    res = pyoracle.tessellate(ps, d, kind=kind)
+    pyoracle.cache_localize(d, res, kind=kind)
+    assert np.array_equal(res.pos.view(np.uint32), ref.pos.view(np.uint32))
+    inst = np.zeros(1, dtype=capi.cache_instance_dtype)
+    inst["num_meshes"] = res.meshes.shape[0]
+    inst["mtx"][0] = [1, 0, 0, 1, 0, 0]
+    out = pyoracle.cache_submit(res, inst, kind=kind)
+    assert np.array_equal(out.pos.view(np.uint32), ref.pos.view(np.uint32))
+    assert np.array_equal(out.idx, ref.idx) and np.array_equal(out.color, ref.color)
+    assert np.array_equal(out.meshes["first_vertex"], ref.meshes["first_vertex"]) and int(out.meshes["draw"].max()) == 0
+
+
+@pytest.mark.skipif(len(KINDS) < 2, reason="needs oracle/_ref")
+@pytest.mark.parametrize("seed", [5, 6])
+def test_port_equals_reference(seed):
+    rs = np.random.RandomState(seed)
+    ps, d = wl.tiger(2)
+    d = rotated_draws(d, rs)
+    a = pyoracle.cache_localize(d, pyoracle.tessellate(ps, d, kind="port"), kind="port")
+    b = pyoracle.cache_localize(d, pyoracle.tessellate(ps, d, kind="reference"), kind="reference")
+    assert np.array_equal(a.pos.view(np.uint32), b.pos.view(np.uint32))
+    inst = make_instances(rs, a, None, 50)
+    oa = pyoracle.cache_submit(a, inst, kind="port")
+    ob = pyoracle.cache_submit(b, inst, kind="reference")
+    assert oa.sizes == ob.sizes
+    for f in ("pos", "color", "idx"):
+        assert np.array_equal(getattr(oa, f).view(np.uint8), getattr(ob, f).view(np.uint8)), f
+    assert np.array_equal(oa.meshes.view(np.uint8), ob.meshes.view(np.uint8))
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_singular_transform_and_empty_ranges(kind):
+    ps, d = wl.tiger(1)
+    d = d.copy()
+    d["mtx"][0] = [0, 0, 0, 0, 3, 4]  # det == 0: invertMatrix3 returns {1, 0, 1, 0, 0, 0} (vg_util.cpp:18-22)
+    res = pyoracle.tessellate(ps, d, kind=kind)
+    before = res.pos.copy()
+    pyoracle.cache_localize(d, res, kind=kind)
+    m0 = res.meshes[res.meshes["draw"] == 0]
+    assert len(m0) > 0
+    a, n = int(m0["first_vertex"][0]), int(m0["num_vertices"][0])
+    want = np.stack([before[a:a + n, 0] + before[a:a + n, 1], np.zeros(n, np.float32)], axis=1)  # x' = 1*x + 1*y, y' = 0
+    assert np.array_equal(res.pos[a:a + n], want.astype(np.float32))
+    inst = np.zeros(3, dtype=capi.cache_instance_dtype)
+    inst["mtx"][:] = [1, 0, 0, 1, 0, 0]
+    inst["first_mesh"] = [2, 5, 5]
+    inst["num_meshes"] = [0, 2, 0]
+    out = pyoracle.cache_submit(res, inst, kind=kind)
+    assert out.sizes["num_meshes"] == 2 and out.meshes["draw"].tolist() == [1, 1]

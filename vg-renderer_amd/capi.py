@@ -85,6 +85,15 @@ class FlatOut(C.Structure):
                 ("cap_poly_vertices", C.c_uint64), ("cap_subpaths", C.c_uint64)]
 
 
+cache_instance_dtype = np.dtype([("first_mesh", "<u8"), ("num_meshes", "<u4"), ("reserved", "<u4"), ("mtx", "<f4", (6,))])
+assert cache_instance_dtype.itemsize == 40
+
+
+class CacheDesc(C.Structure):
+    _fields_ = [("pos", C.c_void_p), ("color", C.c_void_p), ("idx", C.c_void_p), ("meshes", C.c_void_p),
+                ("num_meshes", C.c_uint64), ("num_vertices", C.c_uint64), ("num_indices", C.c_uint64)]
+
+
 class Assembly(C.Structure):
     _fields_ = [("drawcmds", C.c_void_p), ("cap_drawcmds", C.c_uint64), ("dev_num_drawcmds", C.c_void_p),
                 ("max_vb_vertices", C.c_uint32), ("reserved", C.c_uint32)]
@@ -108,6 +117,8 @@ VGX_SYMBOLS = {
     "vgx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "vgx_destroy": (C.c_int, [C.c_void_p]),
     "vgx_set_assembly": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vgx_cache_localize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "vgx_cache_submit": (C.c_int, [C.c_void_p, C.POINTER(CacheDesc), C.c_void_p, C.c_uint64, C.POINTER(MeshOut), C.c_void_p, C.c_void_p, C.c_void_p]),
     "vgx_last_hip_error": (C.c_int, [C.c_void_p]),
     "vgx_status_string": (C.c_char_p, [C.c_int]),
     "vgx_version": (C.c_uint32, []),

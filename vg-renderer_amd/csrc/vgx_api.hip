@@ -243,6 +243,40 @@ struct OpMeshTab // per-mesh vertex / index counts -> first_vertex / first_index
 	}
 };
 
+struct OpCacheInst // shape cache: vertices / indices / meshes of every instance's mesh range -> output offsets
+{
+	vgx_cache_desc cache;
+	const vgx_cache_instance* inst;
+	uint64_t ninst;
+	uint64_t* meshPrefix;
+	uint64_t* vertPrefix;
+	uint64_t* idxPrefix;
+	VgxTotals* totals;
+	VgxCaps caps;
+	__device__ uint64_t size() const { return ninst; }
+	__device__ uint64_t cv(uint64_t k) const { return k < cache.num_meshes ? cache.meshes[k].first_vertex : cache.num_vertices; }
+	__device__ uint64_t ci(uint64_t k) const { return k < cache.num_meshes ? cache.meshes[k].first_index : cache.num_indices; }
+	__device__ Sum3 load(uint64_t i) const
+	{
+		Sum3 r = sum3_zero();
+		const vgx_cache_instance in = inst[i];
+		if (in.first_mesh > cache.num_meshes || (uint64_t)in.num_meshes > cache.num_meshes - in.first_mesh) { set_status(totals, VGX_E_INVALID_ARG); return r; }
+		r.a = in.num_meshes;
+		r.b = cv(in.first_mesh + in.num_meshes) - cv(in.first_mesh);
+		r.c = ci(in.first_mesh + in.num_meshes) - ci(in.first_mesh);
+		return r;
+	}
+	__device__ void store(uint64_t i, Sum3 e) const { meshPrefix[i] = e.a; vertPrefix[i] = e.b; idxPrefix[i] = e.c; }
+	__device__ void finish(Sum3 t) const
+	{
+		meshPrefix[ninst] = t.a; vertPrefix[ninst] = t.b; idxPrefix[ninst] = t.c;
+		totals->sizes.num_meshes = t.a;
+		totals->sizes.num_vertices = t.b;
+		totals->sizes.num_indices = t.c;
+		if (t.a > caps.meshes || t.b > caps.vertices || t.c > caps.indices) { set_status(totals, VGX_E_NOSPACE); }
+	}
+};
+
 struct OpSubMeshes // stroker-level entry: one or two meshes per vertex list -> mesh descriptors + closed-form sizes
 {
 	const vgx_subpath* subs;
@@ -969,6 +1003,67 @@ int vgx_stroke_emit(vgx_ctx* ctx, const float* poly, const vgx_subpath* subpaths
 	hipStream_t s = (hipStream_t)stream;
 	markBegin(ctx, s);
 	return runStrokeEmit(ctx, draws, out, s, poly);
+}
+
+// ---- shape cache ------------------------------------------------------------------------------------
+int vgx_cache_localize(vgx_ctx* ctx, const vgx_draw* draws, uint64_t ndraws, float* pos, const vgx_mesh* meshes, uint64_t num_meshes, void* stream)
+{
+	if (!ctx || (num_meshes && (!draws || !pos || !meshes))) {
+		return VGX_E_INVALID_ARG;
+	}
+	if (num_meshes) {
+		vgx_launch_cache_localize(draws, ndraws, pos, meshes, num_meshes, (hipStream_t)stream);
+	}
+	return VGX_OK;
+}
+
+int vgx_cache_submit(vgx_ctx* ctx, const vgx_cache_desc* cache, const vgx_cache_instance* instances, uint64_t ninst, const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream)
+{
+	if (!ctx || !cache || !out || (!instances && ninst) || !out->pos || !out->color || !out->idx
+		|| (cache->num_meshes && (!cache->pos || !cache->color || !cache->idx || !cache->meshes))) {
+		return VGX_E_INVALID_ARG;
+	}
+	hipStream_t s = (hipStream_t)stream;
+	markBegin(ctx, s);
+	ctx->lastStage = 0;
+	int st;
+	if ((st = ensure(ctx, ctx->totals, sizeof(VgxTotals))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->partial, VGX_SCAN_BLOCKS * sizeof(Sum3))) != VGX_OK) { return st; }
+	// the three instance prefix arrays share one scratch buffer; the output mesh table lives in the mesh-table scratch
+	if ((st = ensure(ctx, ctx->cmdPrefix, 3 * (ninst + 1) * sizeof(uint64_t))) != VGX_OK) { return st; }
+	const uint64_t meshCap = out->cap_meshes ? out->cap_meshes : 1;
+	if ((st = ensure(ctx, ctx->mtab, (meshCap + 1) * sizeof(vgx_mesh))) != VGX_OK) { return st; }
+	(void)hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s);
+	uint64_t* prefix = (uint64_t*)ctx->cmdPrefix.p;
+	OpCacheInst op;
+	op.cache = *cache; op.inst = instances; op.ninst = ninst;
+	op.meshPrefix = prefix; op.vertPrefix = prefix + (ninst + 1); op.idxPrefix = prefix + 2 * (ninst + 1);
+	op.totals = (VgxTotals*)ctx->totals.p;
+	op.caps = ctx->caps;
+	op.caps.meshes = ctx->mtab.cap / sizeof(vgx_mesh) - 1;
+	if (out->meshes && out->cap_meshes < op.caps.meshes) { op.caps.meshes = out->cap_meshes; }
+	op.caps.vertices = out->cap_vertices; op.caps.indices = out->cap_indices;
+	vgx_device_scan(op, (Sum3*)ctx->partial.p, s, ninst);
+	mark(ctx, s, "scan_instances");
+	VgxCacheArgs a;
+	a.cache = *cache; a.inst = instances; a.ninst = ninst;
+	a.inst_mesh_prefix = op.meshPrefix; a.inst_vert_prefix = op.vertPrefix; a.inst_idx_prefix = op.idxPrefix;
+	a.mtab = (vgx_mesh*)ctx->mtab.p; a.meshes_out = out->meshes;
+	a.pos = out->pos; a.color = out->color; a.idx = out->idx;
+	a.mesh_base = nullptr;
+	a.totals = (VgxTotals*)ctx->totals.p;
+	vgx_launch_cache_meshes(a, s);
+	mark(ctx, s, "cache_meshes");
+	if (ctx->asmArmed) {
+		if ((st = runAssemble(ctx, out, s)) != VGX_OK) { return st; }
+		a.mesh_base = (const uint32_t*)ctx->meshBase.p;
+	}
+	vgx_launch_cache_copy(a, vgxElementGrid(out->cap_vertices), s);
+	mark(ctx, s, "cache_copy");
+	if (dev_sizes || dev_status) {
+		hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, s, (const VgxTotals*)ctx->totals.p, dev_sizes, dev_status);
+	}
+	return VGX_OK;
 }
 
 int vgx_set_assembly(vgx_ctx* ctx, const vgx_assembly* asm_)

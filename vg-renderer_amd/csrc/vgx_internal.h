@@ -78,6 +78,27 @@ struct VgxAsmArgs
 	VgxTotals* totals;
 };
 void vgx_launch_assemble(const VgxAsmArgs& a, hipStream_t s);
+
+// shape-cache instancing (vgx_cache.hip)
+struct VgxCacheArgs
+{
+	vgx_cache_desc cache;
+	const vgx_cache_instance* inst;
+	uint64_t ninst;
+	const uint64_t* inst_mesh_prefix; // [ninst + 1] exclusive scans over the instances
+	const uint64_t* inst_vert_prefix;
+	const uint64_t* inst_idx_prefix;
+	vgx_mesh* mtab;                   // output mesh table (context scratch; the assembly step reads it)
+	vgx_mesh* meshes_out;             // caller's copy (may be null)
+	float* pos;
+	uint32_t* color;
+	uint16_t* idx;
+	const uint32_t* mesh_base;        // assembly armed: index base per output mesh; else null
+	VgxTotals* totals;
+};
+void vgx_launch_cache_localize(const vgx_draw* draws, uint64_t ndraws, float* pos, const vgx_mesh* meshes, uint64_t numMeshes, hipStream_t s);
+void vgx_launch_cache_meshes(const VgxCacheArgs& a, hipStream_t s);
+void vgx_launch_cache_copy(const VgxCacheArgs& a, int numBlocks, hipStream_t s);
 void vgx_launch_fill(const VgxStrokeArgs& a, int numBlocks, hipStream_t s);
 
 #endif

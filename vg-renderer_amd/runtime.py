@@ -248,3 +248,26 @@ def stroke(ctx, poly_dev, subs_dev, subdraw_dev, nsubs, draws_dev, ndraws, to_ho
         r.idx = bufs.idx[:ni].cpu().numpy().view(np.uint16)
         r.meshes = bufs.meshes[:nm * 32].cpu().numpy().view(capi.mesh_dtype)
     return r
+
+
+# ---- shape cache (vgx_cache_localize / vgx_cache_submit) ---------------------------------------------
+class MeshCache:
+    """A tessellated drawing kept in HBM in local space (the reference's CommandListCache, vg.cpp:249-256)."""
+
+    def __init__(self, ctx, bufs, sizes, draws_dev, ndraws):
+        """bufs: MeshBuffers that vgx_tessellate[_emit] filled for `draws_dev`; positions are localised in place."""
+        self.bufs = bufs
+        self.nv, self.ni, self.nm = int(sizes["num_vertices"]), int(sizes["num_indices"]), int(sizes["num_meshes"])
+        _check(lib().vgx_cache_localize(ctx.handle, draws_dev.data_ptr(), ndraws, bufs.pos.data_ptr(), bufs.meshes.data_ptr(), self.nm, _stream_ptr()), "vgx_cache_localize")
+
+    def desc(self):
+        b = self.bufs
+        return capi.CacheDesc(b.pos.data_ptr(), b.color.data_ptr(), b.idx.data_ptr(), b.meshes.data_ptr(), self.nm, self.nv, self.ni)
+
+
+def cache_submit(ctx, cache, instances_dev, ninst, bufs):
+    """instances_dev: uint8 device tensor of 40-byte vgx_cache_instance records. Asynchronous."""
+    d = cache.desc()
+    out = bufs.out_struct()
+    _check(lib().vgx_cache_submit(ctx.handle, C.byref(d), instances_dev.data_ptr(), ninst, C.byref(out),
+                                  bufs.dev_sizes.data_ptr(), bufs.dev_status.data_ptr(), _stream_ptr()), "vgx_cache_submit")

@@ -11,8 +11,45 @@ rt = importlib.import_module("vg-renderer_amd.runtime")
 wl = importlib.import_module("vg-renderer_amd.workloads")
 
 
+def cache_mode():
+    """Tiger x10k through the shape cache: tessellate ONE drawing, submit it 10 000 times under different transforms."""
+    import numpy as np
+    K = 10000
+    ps, d1 = wl.tiger(1)
+    ctx = rt.Context(0)
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(d1)
+    sizes = rt.tessellate_count(ctx, pset, dd, d1.shape[0])
+    cb = rt.MeshBuffers(torch.device("cuda", 0), sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"])
+    rt.tessellate_emit(ctx, pset, dd, d1.shape[0], cb)
+    cache = rt.MeshCache(ctx, cb, sizes, dd, d1.shape[0])
+    inst = np.zeros(K, dtype=rt.capi.cache_instance_dtype)
+    inst["num_meshes"] = cache.nm
+    inst["mtx"][:, 0] = 1
+    inst["mtx"][:, 3] = 1
+    inst["mtx"][:, 4] = 37.0 * (np.arange(K) % 100)
+    inst["mtx"][:, 5] = 41.0 * (np.arange(K) // 100)
+    raw = torch.from_numpy(inst.view(np.uint8).reshape(-1).copy()).to("cuda:0")
+    out = rt.MeshBuffers(torch.device("cuda", 0), cache.nv * K, cache.ni * K, cache.nm * K)
+    for _ in range(3):
+        rt.cache_submit(ctx, cache, raw, K, out)
+    torch.cuda.synchronize()
+    assert int(out.dev_status.item()) == 0
+    ctx.set_profiling(True)
+    acc = {}
+    for _ in range(5):
+        rt.cache_submit(ctx, cache, raw, K, out)
+        torch.cuda.synchronize()
+        for k, v in ctx.stage_times():
+            acc[k] = acc.get(k, 0.0) + v / 5
+    tot = sum(acc.values())
+    print("cache submit x%d: verts %d total %.3f ms = %.0f M verts/s" % (K, cache.nv * K, tot, cache.nv * K / tot / 1e3), {k: round(v, 3) for k, v in acc.items()})
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "tiger"
+    if which == "cache":
+        return cache_mode()
     if which == "polylines":      # BASELINE config 4: 10k x 1000-segment polylines, strokeAA Round/Round
         ps, draws = wl.random_walk_polylines(n=10000, nseg=1000, seed=5678)
     elif which == "cubics":       # BASELINE config 2: 1 M independent cubics (stroked AA, Butt/Miter, so the stroker runs too)

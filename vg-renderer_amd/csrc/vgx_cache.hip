@@ -8,7 +8,8 @@
 //   k_cache_localize  one wave per mesh: pos <- inverse(draw.mtx) * pos                      (record time)
 //   scan over the instances (vertices / indices / meshes of each instance's mesh range)      (submit time)
 //   k_cache_meshes    one lane per (instance, mesh) pair: the output mesh table
-//   k_cache_copy      one wave per pair: transformed positions, colours, indices (+ the assembly base when armed)
+//   k_cache_copy_flat instance-wise streaming copy: transformed positions + colours, and indices
+//   k_cache_copy_idx_mesh  (assembly armed) indices per output mesh, plus its index base
 // It is a pure streaming path: 21 B written per vertex, the cached drawing stays in L2.
 #include "vgx_internal.h"
 #include "vgx_wave.h"
@@ -79,8 +80,59 @@ __global__ __launch_bounds__(256) void k_cache_meshes(VgxCacheArgs A)
 
 struct __attribute__((packed, aligned(2))) Idx4 { uint32_t a, b; };
 
-// one wave per output mesh: positions through the instance transform, colours and indices copied
-__global__ __launch_bounds__(VGX_WAVE) void k_cache_copy(VgxCacheArgs A)
+// An instance's mesh range is ONE contiguous block of the cached vertex / index streams and lands in one contiguous
+// block of the output, so positions, colours and (unless the assembly step needs a per-mesh base) indices are copied
+// instance-wise: a wave owns a contiguous range of the OUTPUT stream and walks the instances that intersect it --
+// full 64-lane accesses whatever the mesh sizes are, no dependent per-mesh record loads in the loop.
+template<int WHAT> // 0: positions + colours (item = vertex), 1: indices (item = 4 indices)
+__global__ __launch_bounds__(VGX_WAVE) void k_cache_copy_flat(VgxCacheArgs A)
+{
+	if (A.totals->status != VGX_OK) { return; }
+	const int lane = threadIdx.x;
+	const uint64_t* prefix = WHAT == 0 ? A.inst_vert_prefix : A.inst_idx_prefix;
+	const uint64_t total = prefix[A.ninst];
+	// ranges are multiples of 256 items so that the 4x-unrolled loop below mostly runs full
+	uint64_t per = (total + gridDim.x - 1) / gridDim.x;
+	per = (per + 255) / 256 * 256;
+	const uint64_t o0 = (uint64_t)blockIdx.x * per;
+	const uint64_t o1 = o0 + per < total ? o0 + per : total;
+	if (o0 >= o1) { return; }
+	uint64_t i = find_owner_u64(prefix, 0, A.ninst, o0); // instance that owns output item o0 (skips empty ranges)
+	uint64_t o = o0;
+	while (o < o1) {
+		const uint64_t ib = prefix[i], ie = prefix[i + 1];
+		if (ie <= o) { ++i; continue; }
+		const vgx_cache_instance in = A.inst[i];
+		const uint64_t end = ie < o1 ? ie : o1;
+		if (WHAT == 0) {
+			const uint64_t sbase = cache_v(A, in.first_mesh) + (o - ib);
+			const float2* sp = (const float2*)A.cache.pos + sbase;
+			const uint32_t* sc = A.cache.color + sbase;
+			float2* dp = (float2*)A.pos + o;
+			uint32_t* dc = A.color + o;
+			const uint64_t n = end - o;
+			for (uint64_t k = lane; k < n; k += VGX_WAVE) {
+				const float2 q = sp[k];
+				const V2 r = v2xform(v2(q.x, q.y), in.mtx); // batchTransformPositions, vg.cpp:6162
+				dp[k] = make_float2(r.x, r.y);
+				dc[k] = sc[k];
+			}
+		} else {
+			const uint16_t* si = A.cache.idx + cache_i(A, in.first_mesh) + (o - ib);
+			uint16_t* di = A.idx + o;
+			const uint64_t n = end - o;
+			const uint64_t n4 = n >> 2;
+			for (uint64_t k = lane; k < n4; k += VGX_WAVE) {
+				*(Idx4*)(di + 4 * k) = *(const Idx4*)(si + 4 * k);
+			}
+			for (uint64_t k = 4 * n4 + lane; k < n; k += VGX_WAVE) { di[k] = si[k]; }
+		}
+		o = end;
+	}
+}
+
+// Assembly armed: every mesh has its own index base -> one wave per output mesh for the index stream.
+__global__ __launch_bounds__(VGX_WAVE) void k_cache_copy_idx_mesh(VgxCacheArgs A)
 {
 	if (A.totals->status != VGX_OK) { return; }
 	const int lane = threadIdx.x;
@@ -94,17 +146,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_cache_copy(VgxCacheArgs A)
 		const vgx_cache_instance in = A.inst[i];
 		const uint64_t cm = in.first_mesh + (p - A.inst_mesh_prefix[i]);
 		const vgx_mesh src = A.cache.meshes[cm];
-		const float2* sp = (const float2*)A.cache.pos + src.first_vertex;
-		const uint32_t* sc = A.cache.color + src.first_vertex;
-		float2* dp = (float2*)A.pos + dst.first_vertex;
-		uint32_t* dc = A.color + dst.first_vertex;
-		for (uint32_t k = lane; k < src.num_vertices; k += VGX_WAVE) {
-			const float2 q = sp[k];
-			const V2 r = v2xform(v2(q.x, q.y), in.mtx); // batchTransformPositions, vg.cpp:6162
-			dp[k] = make_float2(r.x, r.y);
-			dc[k] = sc[k];
-		}
-		const uint32_t base = A.mesh_base ? A.mesh_base[p] : 0u; // assembly armed: vertex-buffer relative indices
+		const uint32_t base = A.mesh_base[p]; // vertices in front of the mesh inside its vertex buffer
 		const uint32_t base2 = (base & 0xFFFFu) * 0x10001u;
 		const uint16_t* si = A.cache.idx + src.first_index;
 		uint16_t* di = A.idx + dst.first_index;
@@ -137,5 +179,10 @@ void vgx_launch_cache_meshes(const VgxCacheArgs& a, hipStream_t s)
 
 void vgx_launch_cache_copy(const VgxCacheArgs& a, int numBlocks, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_cache_copy, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
+	hipLaunchKernelGGL(k_cache_copy_flat<0>, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
+	if (a.mesh_base) {
+		hipLaunchKernelGGL(k_cache_copy_idx_mesh, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
+	} else {
+		hipLaunchKernelGGL(k_cache_copy_flat<1>, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
+	}
 }

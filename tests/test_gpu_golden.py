@@ -259,3 +259,46 @@ def test_full_size_tiger_assembly(rt, gpu_ctx, wl):
     del plain, asm
     torch.cuda.empty_cache()
     pset.close()
+
+
+def test_full_size_tiger_through_shape_cache(rt, gpu_ctx, wl, oracle):
+    """Tiger x10k through the shape cache (one drawing tessellated once, 10 000 submissions): totals, mesh-table scan,
+    every instance's colour / index block identical to the cache, sampled instances bit-exact against the oracle."""
+    import torch
+    K = 10000
+    ps, d1 = wl.tiger(1)
+    pset = rt.PathSet(gpu_ctx, ps)
+    dd = rt.upload_draws(d1)
+    sizes = rt.tessellate_count(gpu_ctx, pset, dd, d1.shape[0])
+    cb = rt.MeshBuffers(dd.device, sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"])
+    rt.tessellate_emit(gpu_ctx, pset, dd, d1.shape[0], cb)
+    cache = rt.MeshCache(gpu_ctx, cb, sizes, dd, d1.shape[0])
+    ref_cache = oracle.cache_localize(d1, oracle.tessellate(ps, d1))
+    inst = np.zeros(K, dtype=rt.capi.cache_instance_dtype)
+    inst["num_meshes"] = cache.nm
+    rs = np.random.RandomState(9)
+    ang = rs.uniform(0, 6.28, K).astype(np.float32)
+    inst["mtx"][:, 0] = np.cos(ang); inst["mtx"][:, 1] = np.sin(ang); inst["mtx"][:, 2] = -np.sin(ang); inst["mtx"][:, 3] = np.cos(ang)
+    inst["mtx"][:, 4] = 37.0 * (np.arange(K) % 100)
+    inst["mtx"][:, 5] = 41.0 * (np.arange(K) // 100)
+    raw = torch.from_numpy(inst.view(np.uint8).reshape(-1).copy()).to(dd.device)
+    nv1, ni1, nm1 = cache.nv, cache.ni, cache.nm
+    out = rt.MeshBuffers(dd.device, nv1 * K, ni1 * K, nm1 * K)
+    rt.cache_submit(gpu_ctx, cache, raw, K, out)
+    torch.cuda.synchronize()
+    assert int(out.dev_status.item()) == 0
+    sz = out.dev_sizes.cpu().numpy()
+    assert (int(sz[3]), int(sz[4]), int(sz[2])) == (nv1 * K, ni1 * K, nm1 * K)
+    assert bool((out.color[:nv1 * K].view(K, nv1) == cb.color[:nv1].view(1, nv1)).all().item())
+    assert bool((out.idx[:ni1 * K].view(K, ni1) == cb.idx[:ni1].view(1, ni1)).all().item())
+    m = out.meshes[:nm1 * K * 32].cpu().numpy().view(rt.capi.mesh_dtype)
+    assert np.array_equal(m["first_vertex"][1:], np.cumsum(m["num_vertices"].astype(np.uint64))[:-1])
+    assert np.array_equal(m["first_index"][1:], np.cumsum(m["num_indices"].astype(np.uint64))[:-1])
+    assert np.array_equal(m["draw"], np.repeat(np.arange(K, dtype=np.uint32), nm1))
+    for i in [0, K - 1] + [int(x) for x in rs.randint(1, K - 1, size=6)]:
+        ref = oracle.cache_submit(ref_cache, inst[i:i + 1])
+        got = out.pos[i * nv1:(i + 1) * nv1].cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), ref.pos.view(np.uint32)), i
+    del out
+    torch.cuda.empty_cache()
+    pset.close()

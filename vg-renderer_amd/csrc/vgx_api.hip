@@ -103,6 +103,18 @@ int ensure(vgx_ctx* ctx, DevBuf& b, size_t bytes)
 	return VGX_OK;
 }
 
+// Launch failures (bad configuration, device lost) surface as hipGetLastError: every entry point that enqueues kernels
+// ends with this instead of pretending success.
+int launchStatus(vgx_ctx* ctx)
+{
+	const hipError_t e = hipGetLastError();
+	if (e != hipSuccess) {
+		ctx->lastHipError = (int)e;
+		return VGX_E_HIP;
+	}
+	return VGX_OK;
+}
+
 void mark(vgx_ctx* ctx, hipStream_t s, const char* name)
 {
 	if (!ctx->profiling || ctx->numEv >= VGX_MAX_STAGES) {
@@ -446,6 +458,7 @@ int runAssemble(vgx_ctx* ctx, const vgx_mesh_out* out, hipStream_t s)
 	const uint64_t meshCap = ctx->mtab.cap / sizeof(vgx_mesh);
 	uint64_t need = 2 * (out->cap_vertices / maxVB) + 4; // two consecutive vertex buffers always hold > maxVB vertices
 	if (need > meshCap + 1) { need = meshCap + 1; }
+	if (meshCap >= 0xFFFFFFFFull) { return VGX_E_RANGE; } // the jump tables hold 32-bit mesh indices
 	uint64_t capStart = 2;
 	while (capStart < need) { capStart <<= 1; }
 	int st;
@@ -486,7 +499,7 @@ int runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out, 
 	a.elem_prefix = a.elem_prefix_stroke;
 	vgx_launch_stroke(true, a, vgxElementGrid(out->cap_vertices), s);
 	mark(ctx, s, "stroke_emit");
-	return VGX_OK;
+	return launchStatus(ctx);
 }
 
 int ensureMeshBuffers(vgx_ctx* ctx, uint64_t polyVerts, uint64_t subpaths, uint64_t meshes)
@@ -954,7 +967,7 @@ int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 	if (dev_sizes || dev_status) {
 		hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, s, (const VgxTotals*)ctx->totals.p, dev_sizes, dev_status);
 	}
-	return VGX_OK;
+	return launchStatus(ctx);
 }
 
 // ---- stroker-level entry ------------------------------------------------------------------------------
@@ -1063,7 +1076,7 @@ int vgx_cache_submit(vgx_ctx* ctx, const vgx_cache_desc* cache, const vgx_cache_
 	if (dev_sizes || dev_status) {
 		hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, s, (const VgxTotals*)ctx->totals.p, dev_sizes, dev_status);
 	}
-	return VGX_OK;
+	return launchStatus(ctx);
 }
 
 int vgx_set_assembly(vgx_ctx* ctx, const vgx_assembly* asm_)

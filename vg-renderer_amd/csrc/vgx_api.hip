@@ -207,34 +207,16 @@ struct OpDrawInfo // per-draw polyline / sub-path / mesh counts -> first_* field
 	}
 };
 
-struct OpElemPrefix // stroker elements per mesh -> two prefix arrays (convex fills / polyline strokes)
+// One scan over the meshes for everything the emit kernels need: element offsets (convex fills / polyline strokes
+// have separate streams) and vertex / index offsets. Field d carries the index sum in its low 48 bits and the number
+// of meshes with more than 65536 vertices above them (a batch cannot hold 2^48 indices: positions are 32-bit counted).
+#define VGX_IDX_SUM_MASK ((1ull << 48) - 1)
+struct OpMeshAll
 {
 	const VgxMeshDesc* mdesc;
+	vgx_mesh* mtab;
 	uint64_t* prefixFill;
 	uint64_t* prefixStroke;
-	VgxTotals* totals;
-	__device__ uint64_t size() const { return totals->status == VGX_OK ? totals->sizes.num_meshes : 0; }
-	__device__ Sum3 load(uint64_t i) const
-	{
-		Sum3 r = sum3_zero();
-		const VgxMeshDesc m = mdesc[i];
-		if (VGX_MD_KIND(m.kind) >= VGX_MESH_STROKE) { r.b = m.poly_n; } else { r.a = m.poly_n; }
-		return r;
-	}
-	__device__ void store(uint64_t i, Sum3 e) const { prefixFill[i] = e.a; prefixStroke[i] = e.b; }
-	__device__ void finish(Sum3 t) const
-	{
-		const uint64_t n = totals->status == VGX_OK ? totals->sizes.num_meshes : 0;
-		prefixFill[n] = t.a;
-		prefixStroke[n] = t.b;
-		totals->sizes.num_elements = t.a + t.b;
-		totals->sizes.num_fill_elements = t.a;
-	}
-};
-
-struct OpMeshTab // per-mesh vertex / index counts -> first_vertex / first_index
-{
-	vgx_mesh* mtab;
 	VgxTotals* totals;
 	VgxCaps caps;
 	int checkCaps;
@@ -242,16 +224,29 @@ struct OpMeshTab // per-mesh vertex / index counts -> first_vertex / first_index
 	__device__ Sum3 load(uint64_t i) const
 	{
 		Sum3 r = sum3_zero();
-		r.a = mtab[i].num_vertices; r.b = mtab[i].num_indices; r.c = mtab[i].num_vertices > 65536u ? 1u : 0u;
+		const VgxMeshDesc m = mdesc[i];
+		if (VGX_MD_KIND(m.kind) >= VGX_MESH_STROKE) { r.b = m.poly_n; } else { r.a = m.poly_n; }
+		const uint32_t nv = mtab[i].num_vertices;
+		r.c = nv;
+		r.d = (uint64_t)mtab[i].num_indices + (nv > 65536u ? (1ull << 48) : 0ull);
 		return r;
 	}
-	__device__ void store(uint64_t i, Sum3 e) const { mtab[i].first_vertex = e.a; mtab[i].first_index = e.b; }
+	__device__ void store(uint64_t i, Sum3 e) const
+	{
+		prefixFill[i] = e.a; prefixStroke[i] = e.b;
+		mtab[i].first_vertex = e.c; mtab[i].first_index = e.d & VGX_IDX_SUM_MASK;
+	}
 	__device__ void finish(Sum3 t) const
 	{
-		totals->sizes.num_vertices = t.a;
-		totals->sizes.num_indices = t.b;
-		if (t.c) { set_status(totals, VGX_E_MESH_TOO_LARGE); }
-		if (checkCaps && (t.a > caps.vertices || t.b > caps.indices || totals->sizes.num_meshes > caps.meshes)) { set_status(totals, VGX_E_NOSPACE); }
+		const uint64_t n = totals->status == VGX_OK ? totals->sizes.num_meshes : 0;
+		prefixFill[n] = t.a;
+		prefixStroke[n] = t.b;
+		totals->sizes.num_elements = t.a + t.b;
+		totals->sizes.num_fill_elements = t.a;
+		totals->sizes.num_vertices = t.c;
+		totals->sizes.num_indices = t.d & VGX_IDX_SUM_MASK;
+		if (t.d >> 48) { set_status(totals, VGX_E_MESH_TOO_LARGE); }
+		if (checkCaps && (t.c > caps.vertices || (t.d & VGX_IDX_SUM_MASK) > caps.indices || totals->sizes.num_meshes > caps.meshes)) { set_status(totals, VGX_E_NOSPACE); }
 	}
 };
 
@@ -430,10 +425,6 @@ void runFlattenBuild(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 
 void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps, int checkCaps, hipStream_t s, const float* poly = nullptr)
 {
-	OpElemPrefix ope;
-	ope.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; ope.prefixFill = (uint64_t*)ctx->elemPrefix.p; ope.prefixStroke = (uint64_t*)ctx->elemPrefixS.p; ope.totals = (VgxTotals*)ctx->totals.p;
-	vgx_device_scan(ope, (Sum3*)ctx->partial.p, s, ctx->caps.meshes);
-	mark(ctx, s, "scan_elements");
 	VgxStrokeArgs a;
 	a.draws = draws; a.poly = poly ? poly : (const float*)ctx->poly.p; a.mdesc = (const VgxMeshDesc*)ctx->mdesc.p;
 	a.elem_prefix = nullptr; a.elem_prefix_fill = (const uint64_t*)ctx->elemPrefix.p; a.elem_prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
@@ -441,12 +432,13 @@ void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps,
 	a.pos = nullptr; a.color = nullptr; a.idx = nullptr; a.meshes_out = nullptr; a.mesh_base = nullptr;
 	a.totals = (VgxTotals*)ctx->totals.p; a.caps = outCaps;
 	vgx_launch_mesh_prepare(a, s);
-	a.elem_prefix = a.elem_prefix_stroke;
-	vgx_launch_stroke(false, a, vgxElementGrid(outCaps.vertices), s); // Round-join mesh sizes (exits immediately without Round joins)
+	vgx_launch_stroke(false, a, 4096, s); // k_round_sizes: Round-join mesh sizes (exits immediately without Round joins)
 	mark(ctx, s, "mesh_prepare");
-	OpMeshTab opm;
-	opm.mtab = (vgx_mesh*)ctx->mtab.p; opm.totals = (VgxTotals*)ctx->totals.p; opm.caps = outCaps; opm.checkCaps = checkCaps;
-	vgx_device_scan(opm, (Sum3*)ctx->partial.p, s, ctx->caps.meshes);
+	OpMeshAll op;
+	op.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; op.mtab = (vgx_mesh*)ctx->mtab.p;
+	op.prefixFill = (uint64_t*)ctx->elemPrefix.p; op.prefixStroke = (uint64_t*)ctx->elemPrefixS.p;
+	op.totals = (VgxTotals*)ctx->totals.p; op.caps = outCaps; op.checkCaps = checkCaps;
+	vgx_device_scan(op, (Sum3*)ctx->partial.p, s, ctx->caps.meshes);
 	mark(ctx, s, "scan_meshes");
 }
 

@@ -632,7 +632,7 @@ __device__ __forceinline__ VgxMeshPrep mesh_prep(const VgxMeshDesc& md, const vg
 }
 
 // One lane per mesh: per-mesh constants for the element kernels. (Meshes with Round joins -- the only data-dependent
-// sizes -- are sized by k_stroke<COUNT>, one lane per element; every other mesh was sized in closed form by flatten.)
+// sizes -- are sized by k_round_sizes, one wave per mesh; every other mesh was sized in closed form by flatten.)
 __global__ __launch_bounds__(256) void k_mesh_prepare(VgxStrokeArgs A)
 {
 	if (A.totals->status != VGX_OK) {
@@ -644,6 +644,44 @@ __global__ __launch_bounds__(256) void k_mesh_prepare(VgxStrokeArgs A)
 		const vgx_draw* dr = A.draws + md.draw;
 		const VgxMeshPrep pr = mesh_prep(md, dr, A.poly);
 		A.mprep[mi] = pr;
+	}
+}
+
+// Sizes of meshes with Round joins, the only ones whose vertex / index counts depend on the geometry (numArcPoints per
+// join, stroker.cpp:1146, 1592): one wave per such mesh, lanes stride over its elements and sum what k_stroke will
+// emit for each. Needs no element prefix, so the scan over meshes can produce element and vertex / index offsets
+// together afterwards. Returns at once when the batch has no Round joins.
+__global__ __launch_bounds__(VGX_WAVE) void k_round_sizes(VgxStrokeArgs A)
+{
+	if (A.totals->status != VGX_OK || A.totals->num_round_meshes == 0) {
+		return;
+	}
+	const int lane = threadIdx.x;
+	const uint64_t numMeshes = A.totals->sizes.num_meshes;
+	for (uint64_t mi = blockIdx.x; mi < numMeshes; mi += gridDim.x) {
+		if (A.mtab[mi].num_vertices != VGX_MESH_NEEDS_COUNT) { // wave-uniform
+			continue;
+		}
+		const VgxMeshDesc md = A.mdesc[mi];
+		const VgxMeshPrep pr = A.mprep[mi];
+		const uint32_t N = md.poly_n;
+		const float* vtx = A.poly + 2 * md.poly_first;
+		uint32_t nv = 0, ni = 0;
+		for (uint32_t j = lane; j < N; j += VGX_WAVE) {
+			const MeshCtx mc = make_mesh_ctx(md, pr, A.draws, j, A.poly);
+			const V2 p1 = ldv(vtx, j);
+			const V2 d12 = v2dir(p1, ldv(vtx, j + 1 < N ? j + 1 : 0));
+			const V2 dPrev = v2dir(ldv(vtx, j > 0 ? j - 1 : N - 1), p1);
+			const Elem e = elem_geometry(mc, p1, dPrev, d12);
+			nv += e.nv;
+			ni += elem_total_indices(mc, e);
+		}
+		const uint32_t sv = wave_bcast_u32(wave_incl_scan_u32(nv, lane), VGX_WAVE - 1);
+		const uint32_t si = wave_bcast_u32(wave_incl_scan_u32(ni, lane), VGX_WAVE - 1);
+		if (lane == 0) {
+			A.mtab[mi].num_vertices = sv;
+			A.mtab[mi].num_indices = si;
+		}
 	}
 }
 
@@ -871,16 +909,12 @@ struct __attribute__((aligned(16))) StrokeRec
 	uint32_t color, ibase, pad1, pad2; // ibase: assembly index base of the mesh (0 when not armed)
 };
 
-template<bool COUNT>
 __global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_stroke(VgxStrokeArgs A)
 {
 	__shared__ StrokeRec s_win[VGX_WAVE];
 	const int lane = threadIdx.x;
 	if (A.totals->status != VGX_OK) {
 		return;
-	}
-	if (COUNT && A.totals->num_round_meshes == 0) {
-		return; // sizing pass: only batches with Round joins have meshes whose size depends on the geometry
 	}
 	const uint64_t numMeshes = A.totals->sizes.num_meshes;
 	const uint64_t totalElems = A.elem_prefix[numMeshes];
@@ -1009,14 +1043,7 @@ __global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
 			uint64_t prevPacked = (uint64_t)wave_from_prev_u32((uint32_t)myExit, (uint32_t)carryRails) | ((uint64_t)wave_from_prev_u32((uint32_t)(myExit >> 32), (uint32_t)(carryRails >> 32)) << 32);
 
 			const bool meshLast = valid && (mc.j == mc.N - 1);
-			if (COUNT) {
-				// the running bases after the mesh's last element ARE its vertex / index counts (the reference's
-				// m_NumVertices / m_NumIndices at the end of the call)
-				if (meshLast && A.mtab[mi].num_vertices == VGX_MESH_NEEDS_COUNT) {
-					A.mtab[mi].num_vertices = vbase + e.nv;
-					A.mtab[mi].num_indices = ibase + totalIdx;
-				}
-			} else if (valid) {
+			if (valid) {
 				StrokeWriter w;
 				w.pos = A.pos + 2 * firstV;
 				w.col = A.color + firstV;
@@ -1074,8 +1101,8 @@ void vgx_launch_fill(const VgxStrokeArgs& a, int numBlocks, hipStream_t s)
 void vgx_launch_stroke(bool emit, const VgxStrokeArgs& a, int numBlocks, hipStream_t s)
 {
 	if (emit) {
-		hipLaunchKernelGGL(k_stroke<false>, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
+		hipLaunchKernelGGL(k_stroke, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
 	} else { // sizes Round-join meshes; returns at once when the batch has none (every other size is closed-form)
-		hipLaunchKernelGGL(k_stroke<true>, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
+		hipLaunchKernelGGL(k_round_sizes, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
 	}
 }

@@ -36,7 +36,9 @@ typedef enum vgx_status {
 	VGX_OK = 0,
 	VGX_E_INVALID_ARG = 1,   /* null pointer, bad enum, count out of range */
 	VGX_E_INVALID_PATH = 2,  /* command stream violates the path grammar (see vgx_pathset_create) */
-	VGX_E_NONFINITE = 3,     /* NaN/Inf in path arguments (would hang the reference, path.cpp:109) */
+	VGX_E_NONFINITE = 3,     /* NaN/Inf in path arguments (would hang the reference, path.cpp:109), or a draw whose
+	                          * scale / tess_tol / fringe / stroke_width / mtx is NaN, Inf, negative, or scale, tess_tol <= 0,
+	                          * or tess_tol / scale^2 < 1e-12 (checked on the device, reported in the status word) */
 	VGX_E_NOSPACE = 4,       /* caller-provided output capacity too small; vgx_sizes holds the need */
 	VGX_E_MESH_TOO_LARGE = 5,/* a mesh needs > 65536 vertices (uint16 indices, vg.cpp:734) */
 	VGX_E_HIP = 6,           /* a HIP runtime call failed; vgx_last_hip_error() has the code */

@@ -279,3 +279,30 @@ def test_async_call_is_graph_capturable(rt, gpu_ctx, wl, oracle):
         assert np.array_equal(bufs.color[:nv].cpu().numpy().view(np.uint32), ref.color)
     del g
     pset.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field,value", [("scale", 0.0), ("scale", float("nan")), ("tess_tol", 0.0), ("tess_tol", -1.0), ("tess_tol", 1e-30),
+                                          ("fringe", float("inf")), ("stroke_width", float("nan")), ("mtx", float("nan"))])
+def test_hostile_draw_records_are_rejected_not_subdivided(rt, gpu_ctx, wl, field, value):
+    """Draw records live in device memory the host never reads. Parameters that would drive the adaptive subdivision
+    to the limits of float (zero / NaN tolerance or scale ...) must come back as a status, quickly, not as a hang."""
+    import torch
+    ps, d = wl.tiger(1)
+    d = d.copy()
+    if field == "mtx":
+        d["mtx"][5, 2] = value
+    else:
+        d[field][7] = value
+    pset = rt.PathSet(gpu_ctx, ps)
+    dd = rt.upload_draws(d)
+    with pytest.raises(rt.VgxError) as ei:
+        rt.tessellate_count(gpu_ctx, pset, dd, d.shape[0])
+    assert ei.value.status == rt.capi.VGX_E_NONFINITE
+    good = wl.tiger(1)[1]
+    sizes = rt.tessellate_count(gpu_ctx, pset, rt.upload_draws(good), good.shape[0])
+    bufs = rt.MeshBuffers(dd.device, sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"])
+    rt.tessellate_async(gpu_ctx, pset, dd, d.shape[0], bufs)  # the asynchronous entry reports through the status word
+    torch.cuda.synchronize()
+    assert int(bufs.dev_status.item()) == rt.capi.VGX_E_NONFINITE
+    pset.close()

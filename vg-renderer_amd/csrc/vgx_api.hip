@@ -164,6 +164,20 @@ struct OpCmdPrefix // command instances per draw -> cmd_prefix
 			set_status(totals, VGX_E_INVALID_ARG);
 			return r;
 		}
+		// The draw records are device memory the host never sees: reject parameters that would make the subdivision
+		// (flat iff d23^2 <= tol / scale^2 * len^2, path.cpp:105-116) run to the limits of float -- NaN / Inf / zero /
+		// negative scale or tolerance, a tolerance below 1e-12 of a unit -- instead of spending hours on them (the
+		// reference loops forever on NaN, path.cpp:109). Comparisons are written so that NaN fails them.
+		{
+			const float sc = d->scale, tt = d->tess_tol, fr = d->fringe, sw = d->stroke_width;
+			bool ok = sc > 0.0f && sc < 3.0e38f && tt > 0.0f && tt < 3.0e38f && fr >= 0.0f && fr < 3.0e38f && sw >= 0.0f && sw < 3.0e38f;
+			ok = ok && (tt / (sc * sc) >= 1.0e-12f);
+			for (int k = 0; k < 6; ++k) { ok = ok && (d->mtx[k] > -3.0e38f && d->mtx[k] < 3.0e38f); }
+			if (!ok) {
+				set_status(totals, VGX_E_NONFINITE);
+				return r;
+			}
+		}
 		r.a = pathCmdBegin[p + 1] - pathCmdBegin[p];
 		return r;
 	}

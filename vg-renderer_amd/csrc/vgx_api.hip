@@ -663,6 +663,11 @@ static int vgx_pathset_validate_host(const vgx_pathset_desc* d, std::vector<uint
 			if (t == VGX_CMD_MOVE_TO || isShape) {
 				starts = true;
 			} else if (t == VGX_CMD_ARC) {
+				// pathArc wraps its angles with `while (a > 2pi) a -= 2pi` loops (path.cpp:637-652): beyond ~1e8 the
+				// subtraction no longer changes a float and the reference spins forever; keep them where the loops
+				// are short (the same loops run on the device, bit for bit)
+				const float* aa = d->args + d->cmd_arg_off[c];
+				if (fabsf(aa[3]) > 1.0e5f || fabsf(aa[4]) > 1.0e5f) { return VGX_E_INVALID_ARG; }
 				starts = !open; // pathArc: moveTo when there is no open sub-path, else lineTo (path.cpp:663-667)
 				if (!open && c != c0) {
 					// a leading arc is only well defined at the very start of a path or after MOVE_TO-less state;

@@ -138,9 +138,19 @@ VGX_HD float vgx_step_angle(float scale, float r, float tol)
 	return vgm_acos((scale * r) / ((scale * r) + tol)) * 2.0f;
 }
 
+// float -> point count. The reference casts with (uint32_t) (stroker.cpp:1014, 1146; path.cpp:307, 655): undefined for
+// Inf / NaN / >= 2^32, which is what a radius beyond ~4e6 tolerances produces (acos(1) = 0 -> pi / 0). Here the
+// count saturates at VGX_MAX_ARC_POINTS: more than any valid mesh can hold (65536 vertices, vg.cpp:734), so such a
+// shape ends as VGX_E_MESH_TOO_LARGE after a bounded amount of work instead of a 4-billion-step loop. NaN -> 0.
+#define VGX_MAX_ARC_POINTS 131072u
+VGX_HD uint32_t vgx_point_count(float x)
+{
+	return (x >= (float)VGX_MAX_ARC_POINTS) ? VGX_MAX_ARC_POINTS : ((x > 0.0f) ? (uint32_t)x : 0u);
+}
+
 VGX_HD uint32_t vgx_half_circle_points(float da) // max(2, ceil(pi/da))
 {
-	return vgm_umax(2u, (uint32_t)vgm_ceil(VGM_PI / da));
+	return vgm_umax(2u, vgx_point_count(vgm_ceil(VGM_PI / da)));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -185,10 +195,10 @@ VGX_HD VgxArc vgx_round_join_arc(V2 n01, V2 n12, bool leftInner, float da)
 	float a12 = vgm_atan2(n12.y, n12.x);
 	if (leftInner) {
 		if (a12 < a01) { a12 += VGM_PI2; }
-		r.n = vgm_umax(2u, (uint32_t)((a12 - a01) / da));
+		r.n = vgm_umax(2u, vgx_point_count((a12 - a01) / da));
 	} else {
 		if (a12 > a01) { a12 -= VGM_PI2; }
-		r.n = vgm_umax(2u, (uint32_t)((a01 - a12) / da));
+		r.n = vgm_umax(2u, vgx_point_count((a01 - a12) / da));
 	}
 	r.a01 = a01;
 	r.arcDa = (a12 - a01) / (float)r.n;

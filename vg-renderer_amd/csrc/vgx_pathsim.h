@@ -230,7 +230,7 @@ struct PathSim
 	VGX_HDM void variedCorner(float rc, float cx, float cy, float ca, float sa) // path.cpp:428-455
 	{
 		const float halfDa = vgm_acos((scale * rc) / ((scale * rc) + tol));
-		const uint32_t half = vgm_umax(2u, (uint32_t)vgm_ceil(VGM_PIHALF / halfDa));
+		const uint32_t half = vgm_umax(2u, vgx_point_count(vgm_ceil(VGM_PIHALF / halfDa)));
 		const uint32_t quarter = (half >> 1) + 1;
 		const float dtheta = -VGM_PIHALF / (float)(quarter - 1);
 		rotated(cx, cy, rc, rc, ca, sa, vgm_cos(dtheta), vgm_sin(dtheta), quarter - 1);
@@ -263,7 +263,7 @@ struct PathSim
 			while (a1 < a0) { a1 += VGM_PI2; }
 		}
 		const float da = vgx_step_angle(scale, r, tol);
-		const uint32_t numPoints = vgm_umax(2u, (uint32_t)vgm_ceil(vgm_abs(a1 - a0) / da));
+		const uint32_t numPoints = vgm_umax(2u, vgx_point_count(vgm_ceil(vgm_abs(a1 - a0) / da)));
 		const float dtheta = (a1 - a0) / (float)numPoints;
 		const float cosD = vgm_cos(dtheta);
 		const float sinD = vgm_sin(dtheta);

@@ -82,7 +82,7 @@ struct VgxMeshPrep
 	uint32_t color;
 };
 
-#define VGX_MESH_NEEDS_COUNT 0xFFFFFFFFu // mtab.num_vertices marker: Round joins, sized by k_mesh_round_count
+#define VGX_MESH_NEEDS_COUNT 0xFFFFFFFFu // mtab.num_vertices marker: Round joins, sized by k_round_sizes
 
 // ---- batch totals kept in device memory (mirrors vgx_sizes + internal counters) -------------------
 struct VgxTotals

@@ -17,8 +17,9 @@
 //     C. gets the previous element's exit rail IDs (prevSegment{LeftAA,Left,Right,RightAA}ID) from the
 //        neighbouring lane (shuffle, carry across chunks), and
 //     D. writes its vertices, colours and uint16 indices straight to their final place.
-//   k_mesh_prepare (one lane per mesh) precomputes the per-mesh constants (half widths, fill orientation, colour)
-//   and sizes the meshes with Round joins -- every other mesh size is closed-form and was written by flatten-emit.
+//   k_mesh_prepare (one lane per mesh) precomputes the per-mesh constants (half widths, fill orientation, colour);
+//   k_round_sizes (one wave per mesh) sizes the meshes with Round joins -- every other mesh size is closed-form and
+//   was written together with the mesh descriptor.
 //
 // Every emitted position / colour / index follows the cited reference lines; the rails formulation is the one of
 // SURVEY.md appendix B.

@@ -262,7 +262,8 @@ def main():
             "config": {"workload": "tiger-like 240-path drawing (seed 2024) x %d instances per GPU: convexFillAA on every sub-path + polylineStrokeAA/AAThin (Butt/Miter) on 1/3 of the paths" % K,
                        "instances_per_gpu": K, "draws_per_gpu": ndraws, "parallelism": "shard%d" % world,
                        "verts_per_gpu": sizes["num_vertices"], "indices_per_gpu": sizes["num_indices"], "meshes_per_gpu": sizes["num_meshes"],
-                       "poly_verts_per_gpu": sizes["num_poly_vertices"], "serial_draws": sizes["num_serial_draws"]},
+                       "poly_verts_per_gpu": sizes["num_poly_vertices"], "serial_draws": sizes["num_serial_draws"],
+                       "scratch_bytes_per_gpu": ctx.scratch_bytes()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms": round(dom_ms, 3), "algorithmic_bytes": ab[dom],

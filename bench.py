@@ -230,14 +230,71 @@ def main():
     dt = float(tmax.item())
     total_verts = float(vtot.item())
 
+    fill_verts = fill_idx = fill_meshes = 0
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        value = total_verts * args.steps / dt / 1e6
         mt = bufs.meshes[:sizes["num_meshes"] * 32].view(torch.int32).view(-1, 8)
         is_fill = (mt[:, 7] >> 28) <= 1  # VGX_MESH_FILL / VGX_MESH_FILL_AA
         fill_verts = int(mt[is_fill, 4].to(torch.int64).sum().item())
         fill_idx = int(mt[is_fill, 5].to(torch.int64).sum().item())
         fill_meshes = int(is_fill.sum().item())
+        del mt, is_fill
+
+    # ---- next rows, measured beside the headline on rank 0 of a 1-GPU run: not part of `value` ----
+    next_rows = None
+    if rank == 0 and world == 1:
+        import numpy as np
+        nv_all, ni_all = sizes["num_vertices"], sizes["num_indices"]
+        # draw-command assembly armed: cost of the partition kernels inside one step
+        cap = 2 * (nv_all // 65536) + 2
+        cmds = torch.zeros(cap * 40, dtype=torch.uint8, device=dev)
+        ncmd = torch.zeros(1, dtype=torch.int64, device=dev)
+        ctx.set_assembly(cmds, 0, ncmd)
+        rt.tessellate_async(ctx, pset, dd, ndraws, bufs)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            rt.tessellate_async(ctx, pset, dd, ndraws, bufs)
+        torch.cuda.synchronize()
+        asm_ms = (time.perf_counter() - t1) / 3 * 1e3
+        asm_stage = dict(ctx.stage_times()).get("assemble")
+        ctx.set_assembly(None)
+        assert int(bufs.dev_status.item()) == 0
+        # shape cache: ONE drawing tessellated, submitted K times (same transforms as the instances of the headline run)
+        ps1, d1 = wl.tiger(1)
+        dd1 = rt.upload_draws(d1, local_rank)
+        s1 = rt.tessellate_count(ctx, pset, dd1, d1.shape[0])
+        cb = rt.MeshBuffers(dev, s1["num_vertices"], s1["num_indices"], s1["num_meshes"])
+        rt.tessellate_emit(ctx, pset, dd1, d1.shape[0], cb)
+        cache = rt.MeshCache(ctx, cb, s1, dd1, d1.shape[0])
+        inst = np.zeros(K, dtype=rt.capi.cache_instance_dtype)
+        inst["num_meshes"] = cache.nm
+        inst["mtx"][:, 0] = 1
+        inst["mtx"][:, 3] = 1
+        inst["mtx"][:, 4] = 37.0 * (np.arange(K) % 100)
+        inst["mtx"][:, 5] = 41.0 * (np.arange(K) // 100)
+        raw = torch.from_numpy(inst.view(np.uint8).reshape(-1).copy()).to(dev)
+        for _ in range(2):
+            rt.cache_submit(ctx, cache, raw, K, bufs)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(5):
+            rt.cache_submit(ctx, cache, raw, K, bufs)
+        torch.cuda.synchronize()
+        cache_ms = (time.perf_counter() - t2) / 5 * 1e3
+        assert int(bufs.dev_status.item()) == 0
+        cache_bytes = 12 * nv_all + 2 * ni_all + 32 * sizes["num_meshes"]
+        next_rows = {
+            "draw_command_assembly": {"ms_per_step_armed": round(asm_ms, 3), "assemble_kernels_ms": None if asm_stage is None else round(asm_stage, 3),
+                                      "draw_commands": int(ncmd.item()), "max_vb_vertices": 65536},
+            "shape_cache_submit": {"value": round(nv_all / cache_ms / 1e3, 1), "unit": "M verts/s", "ms": round(cache_ms, 3),
+                                   "achieved": round(cache_bytes / (cache_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "bound": "hbm",
+                                   "frac": round(cache_bytes / (cache_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "workload": "one tiger-like drawing tessellated once, submitted %d times (vgx_cache_submit)" % K},
+        }
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = total_verts * args.steps / dt / 1e6
         sizes["num_fill_elements"] = int(got[8])
         sizes["num_elements"] = int(got[7])
         ab = algorithmic_bytes(ps, one, K, sizes, fill_verts, fill_idx, fill_meshes)
@@ -273,6 +330,7 @@ def main():
                          "pipeline_achieved": round(ab["pipeline"] / (ms_per_step * 1e-3) / 1e9, 1)},
             "stage_ms": {k: round(v, 3) for k, v in stage_sum.items()},
             "cpu_baseline": cpu,
+            "next_rows": next_rows,
         }
         if gather_ms is not None:
             out["gather_ms"] = round(gather_ms, 2)

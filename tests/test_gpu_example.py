@@ -1,0 +1,19 @@
+"""The C-ABI used directly from C++ (examples/vgx_example.cpp, no Python / torch in the process): builds, runs, and
+reports the config-0 known answer (68 vertices / 300 indices per stroked cubic) for every instance."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_example_runs(tmp_path):
+    exe = str(tmp_path / "vgx_example")
+    pkg = os.path.join(ROOT, "vg-renderer_amd")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "vgx_example.cpp"),
+                           "-L", pkg, "-lvgx", "-Wl,-rpath," + pkg, "-o", exe])
+    out = subprocess.check_output([exe, "1000"], text=True)
+    assert "instances 1000  meshes 1000  vertices 68000  indices 300000  polyline vertices 17000" in out
+    assert "mesh 0: 68 vertices, 300 indices" in out

@@ -312,7 +312,7 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         out = {
-            "metric": "M tessellated verts/sec (stroke+fill AA), Tiger x10k batch",
+            "metric": "M tessellated verts/sec (stroke+fill AA), Tiger\u00d710k batch, 1/2/4/8 GPUs",
             "value": round(value, 2), "unit": "M verts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

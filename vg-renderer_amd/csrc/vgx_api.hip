@@ -370,8 +370,7 @@ VgxFlattenArgs flattenArgs(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* 
 	a.totals = (VgxTotals*)ctx->totals.p;
 	a.caps = ctx->caps;
 	a.apply_transform = applyTransform;
-	a.sub_first = (unsigned long long*)ctx->subFirst.p;
-	a.sub_info = (uint32_t*)ctx->cmdCnt.p;
+	a.sub_rec = (VgxSubRec*)ctx->subFirst.p;
 	a.build_mode = 0;
 	a.leaf_overflow = (float*)ctx->leafOverflow.p;
 	a.serial_list = (uint32_t*)ctx->serialList.p;
@@ -834,10 +833,10 @@ static int flattenCountCommon(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_dra
 	if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; }
 	const uint64_t ncmdInst = ctx->hostTotals->sizes.num_cmd_instances;
 	if ((st = ensure(ctx, ctx->cmdCnt, (ncmdInst + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
-	if ((st = ensure(ctx, ctx->subFirst, (ncmdInst + 1) * sizeof(unsigned long long))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->subFirst, (ncmdInst + 1) * sizeof(VgxSubRec))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->leafOverflow, (size_t)VGX_BUILD_WAVES * VGX_BUILD_OVERFLOW * 64 * 2 * sizeof(float))) != VGX_OK) { return st; }
 	ctx->caps.cmd_instances = ctx->cmdCnt.cap / sizeof(uint32_t) - 1;
-	{ const uint64_t c2 = ctx->subFirst.cap / sizeof(unsigned long long) - 1; if (c2 < ctx->caps.cmd_instances) { ctx->caps.cmd_instances = c2; } }
+	{ const uint64_t c2 = ctx->subFirst.cap / sizeof(VgxSubRec) - 1; if (c2 < ctx->caps.cmd_instances) { ctx->caps.cmd_instances = c2; } }
 	// pass 2: per-draw counts (sizes polyline / sub-path / mesh scratch)
 	const VgxCaps saved = ctx->caps;
 	ctx->caps.poly_vertices = ~0ull; ctx->caps.subpaths = ~0ull; ctx->caps.meshes = ~0ull;

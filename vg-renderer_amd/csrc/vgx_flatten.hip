@@ -773,8 +773,9 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 							}
 						}
 						if (lastInSub) { // sub-path record, consumed by k_flatten_gather
-							A.sub_first[ci] = g - (uint64_t)spBefore;
-							A.sub_info[ci] = (uint32_t)spTotal | (closedHere ? 0x80000000u : 0u);
+							VgxSubRec sr;
+							sr.first = g - (uint64_t)spBefore; sr.info = (uint32_t)spTotal | (closedHere ? 0x80000000u : 0u); sr.pad = 0;
+							A.sub_rec[ci] = sr;
 						}
 					}
 					{ // draws the serial kernel has to (re)do: static serial paths and degenerate draws, wave-aggregated append
@@ -844,10 +845,11 @@ __global__ __launch_bounds__(256) void k_flatten_gather(VgxFlattenArgs A)
 		uint32_t f = 0, s = 0, subIndex = 0;
 		for (uint32_t sb = sb0; sb < sb1; ++sb) {
 			const uint64_t ci = cbase + ps.sub_last_cmd[sb];
-			const uint32_t info = A.sub_info[ci];
+			const VgxSubRec sr = A.sub_rec[ci];
+			const uint32_t info = sr.info;
 			const uint32_t n = info & 0x7FFFFFFFu;
 			const bool closed = (info >> 31) != 0;
-			const uint64_t first = A.sub_first[ci];
+			const uint64_t first = sr.first;
 			if ((fillFlags & VGX_FILL_ENABLE) && n >= 3) {
 				vgx_write_mesh(A.mdesc, A.mtab, di.first_mesh + f, dr, (uint32_t)d, subIndex, (fillFlags & VGX_FILL_AA) ? VGX_MESH_FILL_AA : VGX_MESH_FILL, closed, first, n);
 				++f;

@@ -26,8 +26,7 @@ struct VgxFlattenArgs
 	int apply_transform;
 	// BUILD mode (single-pass flatten of vgx_tessellate): per-sub-path records stored sparsely at the command-instance
 	// index of the sub-path's last command
-	unsigned long long* sub_first; // [num_cmd_instances] global index of the sub-path's first polyline vertex
-	uint32_t* sub_info;            // [num_cmd_instances] vertex count | closed << 31 (aliases cmd_cnt)
+	VgxSubRec* sub_rec;            // [num_cmd_instances] sparse: written at the sub-path's last command instance (BUILD mode)
 	int build_mode;                // k_flatten_serial<count>: allocate the draw's vertices from the polyline heap
 	uint32_t* serial_list;         // BUILD mode: draws for k_flatten_serial (static serial paths + degenerate draws), unordered
 	float* leaf_overflow;          // [VGX_BUILD_WAVES][VGX_BUILD_OVERFLOW][64][2] leaves that did not fit the LDS slots

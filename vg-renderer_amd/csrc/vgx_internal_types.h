@@ -84,6 +84,15 @@ struct VgxMeshPrep
 
 #define VGX_MESH_NEEDS_COUNT 0xFFFFFFFFu // mtab.num_vertices marker: Round joins, sized by k_round_sizes
 
+// Sub-path record of the single-pass flatten, stored sparsely at the command-instance index of the sub-path's last
+// command: one 16-byte record = one sector for k_flatten_gather to fetch (two separate arrays cost two).
+struct VgxSubRec
+{
+	uint64_t first; // heap index of the sub-path's first polyline vertex
+	uint32_t info;  // vertex count | closed << 31
+	uint32_t pad;
+};
+
 // ---- batch totals kept in device memory (mirrors vgx_sizes + internal counters) -------------------
 struct VgxTotals
 {

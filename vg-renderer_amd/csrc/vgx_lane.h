@@ -211,35 +211,48 @@ VGX_HD VgxArc vgx_round_join_arc(V2 n01, V2 n12, bool leftInner, float da)
 // point count H -- the sums of the per-element counts listed in SURVEY.md 8a / appendix B.
 // Returns false when the mesh contains Round joins (numArcPoints is data dependent, stroker.cpp:1146).
 // ------------------------------------------------------------------------------------------------
-VGX_HD bool vgx_mesh_closed_form(uint32_t kind, bool closed, uint32_t cap, uint32_t join, uint32_t N, uint32_t H, uint32_t* nv, uint32_t* ni)
+// Sizes are computed in 64 bits and saturate (vertices at 0xFFFFFFFE -- above the 65536 a mesh may hold, so the
+// scan over the meshes reports VGX_E_MESH_TOO_LARGE -- indices at 0xFFFFFFFF): a hostile draw cannot wrap a count
+// back into the valid range (N up to 2^32-16 polyline vertices, H up to VGX_MAX_ARC_POINTS).
+VGX_HD uint32_t vgx_sat_nv(uint64_t v) { return v > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)v; }
+VGX_HD uint32_t vgx_sat_ni(uint64_t v) { return v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v; }
+
+VGX_HD bool vgx_mesh_closed_form(uint32_t kind, bool closed, uint32_t cap, uint32_t join, uint32_t N32, uint32_t H32, uint32_t* nv, uint32_t* ni)
 {
-	if (kind == VGX_MESH_FILL) { *nv = N; *ni = 3 * (N - 2); return true; }          // stroker.cpp:336-337
-	if (kind == VGX_MESH_FILL_AA) { *nv = 2 * N; *ni = 9 * N - 6; return true; }    // stroker.cpp:728-732
-	if (kind == VGX_MESH_STROKE_AA_THIN) {
+	const uint64_t N = N32, H = H32;
+	uint64_t v = 0, i = 0;
+	if (kind == VGX_MESH_FILL) { v = N; i = 3 * (N - 2); }                            // stroker.cpp:336-337
+	else if (kind == VGX_MESH_FILL_AA) { v = 2 * N; i = 9 * N - 6; }                  // stroker.cpp:728-732
+	else if (kind == VGX_MESH_STROKE_AA_THIN) {
 		const bool bevel = join != VGX_JOIN_MITER; // Round -> Bevel, stroker.cpp:318-327
-		if (closed) { *nv = bevel ? 4 * N : 3 * N; *ni = bevel ? 15 * N : 12 * N; }
-		else { *nv = bevel ? 4 * N - 2 : 3 * N; *ni = bevel ? 15 * N - 18 : 12 * (N - 1); }
-		return true;
+		if (closed) { v = bevel ? 4 * N : 3 * N; i = bevel ? 15 * N : 12 * N; }
+		else { v = bevel ? 4 * N - 2 : 3 * N; i = bevel ? 15 * N - 18 : 12 * (N - 1); }
+	} else {
+		if (join == VGX_JOIN_ROUND) { return false; }
+		const bool bevel = join == VGX_JOIN_BEVEL;
+		const bool roundCap = !closed && cap == VGX_CAP_ROUND;
+		if (kind == VGX_MESH_STROKE_AA) {
+			if (closed) { v = bevel ? 6 * N : 4 * N; i = bevel ? 27 * N : 18 * N; }
+			else {
+				const uint64_t joins = N - 2;
+				const uint64_t capV = roundCap ? 4 * H : 8;
+				const uint64_t capI = roundCap ? (9 * H - 12) + (18 + 3 * (H - 2) + 6 * (H - 1)) : 30;
+				v = capV + joins * (bevel ? 6 : 4);
+				i = capI + joins * (bevel ? 27 : 18);
+			}
+		} else { // VGX_MESH_STROKE
+			if (closed) { v = bevel ? 3 * N : 2 * N; i = bevel ? 9 * N : 6 * N; }
+			else {
+				const uint64_t joins = N - 2;
+				const uint64_t capV = roundCap ? 2 * H : 4;
+				const uint64_t capI = roundCap ? 3 * (H - 2) + 6 + 3 * (H - 2) : 6;
+				v = capV + joins * (bevel ? 3 : 2);
+				i = capI + joins * (bevel ? 9 : 6);
+			}
+		}
 	}
-	if (join == VGX_JOIN_ROUND) { return false; }
-	const bool bevel = join == VGX_JOIN_BEVEL;
-	const bool roundCap = !closed && cap == VGX_CAP_ROUND;
-	if (kind == VGX_MESH_STROKE_AA) {
-		if (closed) { *nv = bevel ? 6 * N : 4 * N; *ni = bevel ? 27 * N : 18 * N; return true; }
-		const uint32_t joins = N - 2;
-		const uint32_t capV = roundCap ? 4 * H : 8;
-		const uint32_t capI = roundCap ? (9 * H - 12) + (18 + 3 * (H - 2) + 6 * (H - 1)) : 30;
-		*nv = capV + joins * (bevel ? 6 : 4);
-		*ni = capI + joins * (bevel ? 27 : 18);
-		return true;
-	}
-	// VGX_MESH_STROKE
-	if (closed) { *nv = bevel ? 3 * N : 2 * N; *ni = bevel ? 9 * N : 6 * N; return true; }
-	const uint32_t joins = N - 2;
-	const uint32_t capV = roundCap ? 2 * H : 4;
-	const uint32_t capI = roundCap ? 3 * (H - 2) + 6 + 3 * (H - 2) : 6;
-	*nv = capV + joins * (bevel ? 3 : 2);
-	*ni = capI + joins * (bevel ? 9 : 6);
+	*nv = vgx_sat_nv(v);
+	*ni = vgx_sat_ni(i);
 	return true;
 }
 

@@ -25,612 +25,9 @@
 // SURVEY.md appendix B.
 #include "vgx_internal.h"
 #include "vgx_wave.h"
+#include "vgx_elem.h"
 
 namespace {
-
-struct Rails { uint32_t a, b, c, d; }; // AA: laa,l,r,raa   non-AA: l,r,-,-   thin: laa,m,raa,-
-
-__device__ __forceinline__ Rails rails(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { Rails r; r.a = a; r.b = b; r.c = c; r.d = d; return r; }
-__device__ __forceinline__ uint64_t rails_pack(Rails r) { return (uint64_t)(r.a & 0xFFFFu) | ((uint64_t)(r.b & 0xFFFFu) << 16) | ((uint64_t)(r.c & 0xFFFFu) << 32) | ((uint64_t)(r.d & 0xFFFFu) << 48); }
-__device__ __forceinline__ Rails rails_unpack(uint64_t p) { return rails((uint32_t)(p & 0xFFFFu), (uint32_t)((p >> 16) & 0xFFFFu), (uint32_t)((p >> 32) & 0xFFFFu), (uint32_t)(p >> 48)); }
-
-// Unaligned wide stores: the output streams are only element-aligned (8 / 4 / 2 bytes); gfx950 global stores handle
-// that natively (unaligned access mode), so one lane can issue ONE dwordx4 for two positions, ONE dwordx3 for six
-// indices ... without alignment-dependent divergence.
-struct __attribute__((packed, aligned(8))) PosPair { float x0, y0, x1, y1; };
-struct __attribute__((packed, aligned(4))) ColPair { uint32_t c0, c1; };
-struct __attribute__((packed, aligned(2))) Idx9 { uint32_t a, b, c, d; uint16_t e; };
-struct __attribute__((packed, aligned(2))) Idx6 { uint32_t a, b, c; };
-struct __attribute__((packed, aligned(2))) Idx3 { uint32_t a; uint16_t b; };
-
-// Stroke writer: pointers to the mesh's first vertex / index in the output streams, plus a register stage for the
-// fixed-size part of an element (up to 4 vertices at b.., up to 24 indices at k..). The element code runs under
-// divergent branches (cap / join / kind); without the stage every branch carries its own train of narrow stores
-// (~60 store instructions per 64-element chunk), with it the chunk leaves in ~10 wide ones (flush()).
-struct StrokeWriter
-{
-	float* pos;
-	uint32_t* col;
-	uint16_t* idx;
-	uint32_t color, c0;
-	uint32_t ib; // added to every index written (assembly: vertices in front of the mesh inside its vertex buffer)
-	float sx[4], sy[4];
-	uint32_t sc[4];
-	uint32_t si[24];
-	uint32_t nvS, niS; // staged vertex / index counts (niS is a multiple of 6)
-	__device__ __forceinline__ void reset()
-	{
-		for (int i = 0; i < 4; ++i) { sx[i] = 0.0f; sy[i] = 0.0f; sc[i] = 0; }
-		for (int i = 0; i < 24; ++i) { si[i] = 0; }
-		nvS = 0; niS = 0;
-	}
-	// ---- staged (slot = compile-time constant at every call site) ----
-	__device__ __forceinline__ void sv(uint32_t slot, V2 p, uint32_t c)
-	{
-		sx[slot] = p.x; sy[slot] = p.y; sc[slot] = c;
-		nvS = nvS > slot + 1 ? nvS : slot + 1;
-	}
-	__device__ __forceinline__ void stri(uint32_t slot, uint32_t a, uint32_t b, uint32_t c)
-	{
-		si[slot] = a; si[slot + 1] = b; si[slot + 2] = c;
-		niS = niS > slot + 3 ? niS : slot + 3;
-	}
-	__device__ __forceinline__ void sbridge4(uint32_t slot, Rails p, Rails c) // stroker.cpp:1557-1564, 1714-1721, 1973-1980
-	{
-		stri(slot, p.a, p.b, c.b); stri(slot + 3, p.a, c.b, c.a);
-		stri(slot + 6, p.b, p.c, c.c); stri(slot + 9, p.b, c.c, c.b);
-		stri(slot + 12, p.c, p.d, c.d); stri(slot + 15, p.c, c.d, c.c);
-	}
-	__device__ __forceinline__ void sbridge2(uint32_t slot, Rails p, Rails c) // stroker.cpp:1119-1122, 1217-1220, 1374-1377
-	{
-		stri(slot, p.a, p.b, c.b); stri(slot + 3, p.a, c.b, c.a);
-	}
-	__device__ __forceinline__ void sbridge3(uint32_t slot, Rails p, Rails c) // stroker.cpp:2093-2098, 2175-2180, 2299-2304
-	{
-		stri(slot, p.a, p.b, c.b); stri(slot + 3, p.a, c.b, c.a);
-		stri(slot + 6, p.b, p.c, c.c); stri(slot + 9, p.b, c.c, c.b);
-	}
-	// ---- direct ----
-	__device__ __forceinline__ void v(uint32_t i, V2 p, uint32_t c) const
-	{
-		*(float2*)(pos + 2 * (size_t)i) = make_float2(p.x, p.y);
-		col[i] = c;
-	}
-	__device__ __forceinline__ void tri(uint32_t k, uint32_t a, uint32_t b, uint32_t c) const
-	{
-		Idx3 t; t.a = ((a + ib) & 0xFFFFu) | ((b + ib) << 16); t.b = (uint16_t)(c + ib);
-		*(Idx3*)(idx + k) = t;
-	}
-	__device__ __forceinline__ void bridge4(uint32_t k, Rails p, Rails c) const
-	{
-		tri(k, p.a, p.b, c.b); tri(k + 3, p.a, c.b, c.a);
-		tri(k + 6, p.b, p.c, c.c); tri(k + 9, p.b, c.c, c.b);
-		tri(k + 12, p.c, p.d, c.d); tri(k + 15, p.c, c.d, c.c);
-	}
-	__device__ __forceinline__ void bridge2(uint32_t k, Rails p, Rails c) const
-	{
-		tri(k, p.a, p.b, c.b); tri(k + 3, p.a, c.b, c.a);
-	}
-	__device__ __forceinline__ void bridge3(uint32_t k, Rails p, Rails c) const
-	{
-		tri(k, p.a, p.b, c.b); tri(k + 3, p.a, c.b, c.a);
-		tri(k + 6, p.b, p.c, c.c); tri(k + 9, p.b, c.c, c.b);
-	}
-	// the staged part of the element whose first vertex is b and first index k
-	__device__ __forceinline__ void flush(uint32_t b, uint32_t k) const
-	{
-		float* pp = pos + 2 * (size_t)b;
-		uint32_t* pc = col + b;
-		if (nvS >= 2) {
-			PosPair q; q.x0 = sx[0]; q.y0 = sy[0]; q.x1 = sx[1]; q.y1 = sy[1];
-			*(PosPair*)pp = q;
-			ColPair c; c.c0 = sc[0]; c.c1 = sc[1];
-			*(ColPair*)pc = c;
-		}
-		if (nvS == 4) {
-			PosPair q; q.x0 = sx[2]; q.y0 = sy[2]; q.x1 = sx[3]; q.y1 = sy[3];
-			*(PosPair*)(pp + 4) = q;
-			ColPair c; c.c0 = sc[2]; c.c1 = sc[3];
-			*(ColPair*)(pc + 2) = c;
-		}
-		if (nvS == 3) {
-			*(float2*)(pp + 4) = make_float2(sx[2], sy[2]);
-			pc[2] = sc[2];
-		}
-		uint16_t* pi = idx + k;
-#pragma unroll
-		for (uint32_t g = 0; g < 4; ++g) {
-			if (niS > 6 * g) {
-				Idx6 t;
-				t.a = ((si[6 * g] + ib) & 0xFFFFu) | ((si[6 * g + 1] + ib) << 16);
-				t.b = ((si[6 * g + 2] + ib) & 0xFFFFu) | ((si[6 * g + 3] + ib) << 16);
-				t.c = ((si[6 * g + 4] + ib) & 0xFFFFu) | ((si[6 * g + 5] + ib) << 16);
-				*(Idx6*)(pi + 6 * g) = t;
-			}
-		}
-	}
-};
-
-enum { ET_CAP_FIRST = 0, ET_JOIN = 1, ET_CAP_LAST = 2 };
-
-// Everything step A computes for one stroke element and step D needs again.
-struct Elem
-{
-	uint32_t nv, ni;  // my vertex / index count (ni excludes the connect / closing bridges)
-	uint32_t et;
-	V2 p1;            // the polyline vertex this element sits on
-	V2 d01, d12, v;   // join: segment directions + extrusion; caps: d01 = cap direction
-	bool leftInner;
-	bool hasConnect;  // a bridge from the previous element precedes my own indices
-	bool closesLoop;  // I am the last join of a closed stroke: closing bridge follows my indices
-	VgxArc arc;       // Round/Bevel joins (n = 1 for Bevel)
-	uint32_t H;       // numPointsHalfCircle (Round caps)
-};
-
-struct MeshCtx
-{
-	uint32_t kind, N, j, cap, join;
-	bool closed;
-	float hsw, hswAA, fringe;
-	const vgx_draw* dr; // scale / tolerance are only read where Round caps / joins need da
-	const float* vtx;   // mesh's first polyline vertex
-};
-
-__device__ __forceinline__ V2 ldv(const float* vtx, uint32_t i)
-{
-	const float2 t = *(const float2*)(vtx + 2 * (size_t)i);
-	return v2(t.x, t.y);
-}
-
-__device__ __forceinline__ float mesh_da(const MeshCtx& m) // stroker.cpp:1013, 1398 (da uses hsw WITHOUT the fringe)
-{
-	return vgx_step_angle(m.dr->scale, m.hsw, m.dr->tess_tol);
-}
-
-__device__ __forceinline__ MeshCtx make_mesh_ctx(const VgxMeshDesc& md, const VgxMeshPrep& pr, const vgx_draw* draws, uint32_t j, const float* poly)
-{
-	MeshCtx mc;
-	mc.kind = VGX_MD_KIND(md.kind);
-	mc.closed = VGX_MD_CLOSED(md.kind) != 0;
-	mc.cap = VGX_MD_CAP(md.kind);
-	mc.join = VGX_MD_JOIN(md.kind);
-	mc.N = md.poly_n;
-	mc.j = j;
-	mc.vtx = poly + 2 * md.poly_first;
-	mc.hsw = pr.f0; mc.hswAA = pr.f1; mc.fringe = pr.f2;
-	mc.dr = draws + md.draw;
-	return mc;
-}
-
-// ---- step A (strokes) --------------------------------------------------------------------------------
-// p1 = the element's polyline vertex, dPrev = vec2Dir(previous vertex, p1), d12 = vec2Dir(p1, next vertex) (cyclic).
-__device__ __forceinline__ Elem elem_geometry(const MeshCtx& m, V2 p1, V2 dPrev, V2 d12)
-{
-	Elem e;
-	e.nv = 0; e.ni = 0; e.et = ET_JOIN; e.leftInner = true; e.hasConnect = false; e.closesLoop = false;
-	e.arc.a01 = 0.0f; e.arc.arcDa = 0.0f; e.arc.n = 1; e.H = 2;
-	const uint32_t N = m.N, j = m.j;
-	e.p1 = p1;
-	e.d01 = v2(0.0f, 0.0f); e.d12 = e.d01; e.v = e.d01;
-	// polyline strokes
-	const bool isCapFirst = !m.closed && j == 0;
-	const bool isCapLast = !m.closed && j == N - 1;
-	const uint32_t railCount = (m.kind == VGX_MESH_STROKE) ? 2u : (m.kind == VGX_MESH_STROKE_AA ? 4u : 3u);
-	const uint32_t bridgeIdx = (railCount - 1) * 6; // 6 / 18 / 12
-	if (isCapFirst || isCapLast) {
-		e.et = isCapFirst ? ET_CAP_FIRST : ET_CAP_LAST;
-		e.d01 = isCapFirst ? d12 : dPrev;
-		e.hasConnect = isCapLast;
-		const bool roundCap = (m.cap == VGX_CAP_ROUND) && m.kind != VGX_MESH_STROKE_AA_THIN;
-		if (roundCap) {
-			const uint32_t H = vgx_half_circle_points(mesh_da(m));
-			e.H = H;
-			if (m.kind == VGX_MESH_STROKE_AA) {
-				e.nv = 2 * H;
-				e.ni = isCapFirst ? (9 * H - 12) : (3 * (H - 2) + 6 * (H - 1)); // stroker.cpp:1490, 1949-1966
-			} else {
-				e.nv = H;
-				e.ni = 3 * (H - 2); // stroker.cpp:1071, 1362
-			}
-		} else {
-			e.nv = railCount;
-			e.ni = (m.kind == VGX_MESH_STROKE_AA) ? 6u : 0u; // cap quad only exists in the AA stroker
-		}
-		return e;
-	}
-	e.et = ET_JOIN;
-	const float sideWidth = (m.kind == VGX_MESH_STROKE) ? m.hsw : (m.kind == VGX_MESH_STROKE_AA ? m.hswAA : m.fringe);
-	const VgxJoin jn = vgx_join_dirs(dPrev, d12, sideWidth);
-	e.d01 = jn.d01; e.d12 = jn.d12; e.v = jn.v; e.leftInner = jn.leftInner;
-	e.hasConnect = !(m.closed && j == 0);
-	e.closesLoop = m.closed && j == N - 1;
-	if (m.kind == VGX_MESH_STROKE_AA_THIN) { // stroker.cpp:2060-2240; Round join -> Bevel (:318-327)
-		const bool bevel = m.join != VGX_JOIN_MITER;
-		e.nv = bevel ? 4 : 3;
-		e.ni = bevel ? 3 : 0;
-		return e;
-	}
-	if (m.join == VGX_JOIN_MITER) {
-		e.nv = railCount;
-		e.ni = 0;
-		return e;
-	}
-	if (m.join == VGX_JOIN_ROUND) {
-		const V2 n01 = e.leftInner ? v2cw(e.d01) : v2ccw(e.d01);
-		const V2 n12 = e.leftInner ? v2cw(e.d12) : v2ccw(e.d12);
-		e.arc = vgx_round_join_arc(n01, n12, e.leftInner, mesh_da(m));
-	}
-	const uint32_t n = e.arc.n;
-	if (m.kind == VGX_MESH_STROKE_AA) {
-		e.nv = 2 * n + 4; // stroker.cpp:1599
-		e.ni = 9 * n;     // :1675
-	} else {
-		e.nv = n + 2;     // :1156
-		e.ni = 3 * n;     // :1186
-	}
-	(void)bridgeIdx;
-	return e;
-}
-
-__device__ __forceinline__ uint32_t elem_total_indices(const MeshCtx& m, const Elem& e)
-{
-	const uint32_t bridgeIdx = (m.kind == VGX_MESH_STROKE) ? 6u : (m.kind == VGX_MESH_STROKE_AA ? 18u : 12u);
-	return e.ni + (e.hasConnect ? bridgeIdx : 0u) + (e.closesLoop ? bridgeIdx : 0u);
-}
-
-// ---- exit rails (what the next element connects to) ---------------------------------------------------
-__device__ __forceinline__ Rails elem_exit_rails(const MeshCtx& m, const Elem& e, uint32_t b)
-{
-	if (m.kind == VGX_MESH_STROKE_AA) {
-		if (e.et == ET_CAP_FIRST) {
-			if (m.cap == VGX_CAP_ROUND) { return rails(1, 0, (e.H - 1) * 2, (e.H - 1) * 2 + 1); } // :1512-1515
-			return rails(0, 1, 2, 3);
-		}
-		if (m.join == VGX_JOIN_MITER) {
-			return e.leftInner ? rails(b, b + 1, b + 2, b + 3) : rails(b + 3, b + 2, b + 1, b);
-		}
-		const uint32_t arcID = b + 2 + 2 * e.arc.n;
-		return e.leftInner ? rails(b, b + 1, arcID, arcID + 1) : rails(arcID + 1, arcID, b + 1, b);
-	}
-	if (m.kind == VGX_MESH_STROKE) {
-		if (e.et == ET_CAP_FIRST) {
-			if (m.cap == VGX_CAP_ROUND) { return rails(0, e.H - 1, 0, 0); } // :1079-1080
-			return rails(0, 1, 0, 0);
-		}
-		if (m.join == VGX_JOIN_MITER) {
-			return e.leftInner ? rails(b, b + 1, 0, 0) : rails(b + 1, b, 0, 0);
-		}
-		const uint32_t endID = b + e.arc.n + 1;
-		return e.leftInner ? rails(b, endID, 0, 0) : rails(endID, b, 0, 0);
-	}
-	// thin
-	if (e.et == ET_CAP_FIRST) {
-		return rails(0, 1, 2, 0);
-	}
-	if (m.join == VGX_JOIN_MITER) {
-		return e.leftInner ? rails(b, b + 1, b + 2, 0) : rails(b + 2, b + 1, b, 0);
-	}
-	return e.leftInner ? rails(b, b + 1, b + 3, 0) : rails(b + 3, b + 1, b, 0);
-}
-
-// entry rails of join 0 of a closed stroke = the firstSegment*ID of the reference
-__device__ __forceinline__ Rails first_join_entry(const MeshCtx& m, bool leftInner0)
-{
-	if (m.kind == VGX_MESH_STROKE_AA) { return leftInner0 ? rails(0, 1, 2, 3) : rails(3, 2, 1, 0); }
-	if (m.kind == VGX_MESH_STROKE) { return leftInner0 ? rails(0, 1, 0, 0) : rails(1, 0, 0, 0); }
-	return leftInner0 ? rails(0, 1, 2, 0) : rails(2, 1, 0, 0);
-}
-
-// ---- step D: emit one stroke element ------------------------------------------------------------------
-// Fixed-size pieces (Butt / Square caps, the four corner vertices of a join, the connect bridge) go through the
-// writer's register stage (sv / stri / sbridgeN, slot numbers relative to b / k) and leave in a handful of wide stores
-// after the call; variable-size pieces (Round caps and joins, the closing bridge) are written directly.
-template<class W>
-__device__ __forceinline__ void elem_emit(const MeshCtx& m, const Elem& e, uint32_t b, uint32_t k, Rails prev, W& w)
-{
-	const uint32_t N = m.N;
-	const uint32_t color = w.color, c0 = w.c0;
-	const V2 p1 = e.p1;
-	const float hsw = m.hsw, hswAA = m.hswAA, fringe = m.fringe;
-
-	// ------------------------------- AA stroke, 4 rails -------------------------------------------
-	if (m.kind == VGX_MESH_STROKE_AA) {
-		if (e.et != ET_JOIN) {
-			const bool firstCap = e.et == ET_CAP_FIRST;
-			const V2 d = e.d01;
-			const V2 l = v2ccw(d);
-			if (m.cap == VGX_CAP_ROUND) { // :1475-1515, 1917-1968
-				const uint32_t H = e.H;
-				const float startAngle = vgm_atan2(l.y, l.x);
-				for (uint32_t i = 0; i < H; ++i) {
-					const float t = i * VGM_PI / (float)(H - 1);
-					const float a = firstCap ? startAngle + t : startAngle - t;
-					float sa, ca;
-					vgm_sincos(a, &sa, &ca);
-					w.v(b + 2 * i, v2(p1.x + ca * hsw, p1.y + sa * hsw), color);
-					w.v(b + 2 * i + 1, v2(p1.x + ca * hswAA, p1.y + sa * hswAA), c0);
-				}
-				if (firstCap) {
-					uint32_t q = k;
-					for (uint32_t i = 0; i + 2 < H; ++i, q += 3) { w.tri(q, 0, (i << 1) + 2, (i << 1) + 4); }
-					for (uint32_t i = 0; i + 1 < H; ++i, q += 6) {
-						const uint32_t base = i << 1;
-						w.tri(q, base, base + 1, base + 3);
-						w.tri(q + 3, base, base + 3, base + 2);
-					}
-				} else {
-					const uint32_t en = b + (H - 1) * 2;
-					w.bridge4(k, prev, rails(b + 1, b, en, en + 1));
-					uint32_t q = k + 18;
-					for (uint32_t i = 0; i + 2 < H; ++i, q += 3) {
-						const uint32_t base = b + (i << 1);
-						w.tri(q, b, base + 4, base + 2);
-					}
-					for (uint32_t i = 0; i + 1 < H; ++i, q += 6) {
-						const uint32_t base = b + (i << 1);
-						w.tri(q, base, base + 3, base + 1);
-						w.tri(q + 3, base, base + 2, base + 3);
-					}
-				}
-				return;
-			}
-			const V2 lh = v2mul(l, hsw);
-			const V2 lhaa = v2mul(l, hswAA);
-			if (m.cap == VGX_CAP_BUTT) { // :1422-1447, 1858-1886
-				const V2 daa = v2mul(d, fringe);
-				if (firstCap) {
-					w.sv(0, v2add(p1, v2sub(lhaa, daa)), c0);
-					w.sv(1, v2add(p1, lh), color);
-					w.sv(2, v2sub(p1, lh), color);
-					w.sv(3, v2sub(p1, v2add(lhaa, daa)), c0);
-				} else {
-					w.sv(0, v2add(p1, v2add(lhaa, daa)), c0);
-					w.sv(1, v2add(p1, lh), color);
-					w.sv(2, v2sub(p1, lh), color);
-					w.sv(3, v2sub(p1, v2sub(lhaa, daa)), c0);
-				}
-			} else { // Square, :1448-1474, 1887-1916
-				const V2 dh = v2mul(d, hsw);
-				const V2 dhaa = v2mul(d, hswAA);
-				if (firstCap) {
-					w.sv(0, v2add(p1, v2sub(lhaa, dhaa)), c0);
-					w.sv(1, v2add(p1, v2sub(lh, dh)), color);
-					w.sv(2, v2sub(p1, v2add(lh, dh)), color);
-					w.sv(3, v2sub(p1, v2add(lhaa, dhaa)), c0);
-				} else {
-					w.sv(0, v2add(p1, v2add(lhaa, dhaa)), c0);
-					w.sv(1, v2add(p1, v2add(lh, dh)), color);
-					w.sv(2, v2sub(p1, v2sub(lh, dh)), color);
-					w.sv(3, v2sub(p1, v2sub(lhaa, dhaa)), c0);
-				}
-			}
-			if (firstCap) {
-				w.stri(0, 0, 2, 1);
-				w.stri(3, 0, 3, 2);
-			} else {
-				w.sbridge4(0, prev, rails(b, b + 1, b + 2, b + 3));
-				w.stri(18, b, b + 1, b + 2);
-				w.stri(21, b, b + 2, b + 3);
-			}
-			return;
-		}
-		// join, :1524-1850
-		const V2 vhaa = v2mul(e.v, hswAA);
-		const V2 vh = v2mul(e.v, hsw);
-		const bool L = e.leftInner;
-		const V2 innerAA = L ? v2add(p1, vhaa) : v2sub(p1, vhaa);
-		const V2 inner = L ? v2add(p1, vh) : v2sub(p1, vh);
-		const Rails entry = L ? rails(b, b + 1, b + 2, b + 3) : rails(b + 3, b + 2, b + 1, b);
-		uint32_t q = k;
-		w.sv(0, innerAA, c0);
-		w.sv(1, inner, color);
-		if (e.hasConnect) { w.sbridge4(0, prev, entry); q += 18; }
-		if (m.join == VGX_JOIN_MITER) {
-			w.sv(2, L ? v2sub(p1, vh) : v2add(p1, vh), color);
-			w.sv(3, L ? v2sub(p1, vhaa) : v2add(p1, vhaa), c0);
-		} else {
-			const V2 n01 = L ? v2cw(e.d01) : v2ccw(e.d01);
-			const V2 n12 = L ? v2cw(e.d12) : v2ccw(e.d12);
-			const uint32_t n = e.arc.n;
-			{
-				V2 a = v2add(p1, v2mul(n01, hsw));
-				const V2 aAA = v2add(p1, v2mul(n01, hswAA));
-				if (m.join == VGX_JOIN_BEVEL) {
-					const float cosAngle = vgm_abs(v2dot(n01, n12));
-					a = v2sub(a, v2mul(e.d01, cosAngle * fringe));
-				}
-				w.sv(2, a, color);
-				w.sv(3, aAA, c0);
-			}
-			for (uint32_t i = 1; i < n; ++i) {
-				const float ang = e.arc.a01 + i * e.arc.arcDa;
-				float sa, ca;
-				vgm_sincos(ang, &sa, &ca);
-				const V2 dir = v2(ca, sa);
-				w.v(b + 2 + 2 * i, v2add(p1, v2mul(dir, hsw)), color);
-				w.v(b + 3 + 2 * i, v2add(p1, v2mul(dir, hswAA)), c0);
-			}
-			{
-				V2 a = v2add(p1, v2mul(n12, hsw));
-				const V2 aAA = v2add(p1, v2mul(n12, hswAA));
-				if (m.join == VGX_JOIN_BEVEL) {
-					const float cosAngle = vgm_abs(v2dot(n01, n12));
-					a = v2add(a, v2mul(e.d12, cosAngle * fringe));
-				}
-				w.v(b + 2 + 2 * n, a, color);
-				w.v(b + 3 + 2 * n, aAA, c0);
-			}
-			uint32_t arcID = b + 2;
-			for (uint32_t i = 0; i < n; ++i, arcID += 2, q += 9) {
-				if (L) {
-					w.tri(q, b + 1, arcID, arcID + 2);
-					w.tri(q + 3, arcID, arcID + 1, arcID + 3);
-					w.tri(q + 6, arcID, arcID + 3, arcID + 2);
-				} else {
-					w.tri(q, b + 1, arcID + 2, arcID);
-					w.tri(q + 3, arcID, arcID + 3, arcID + 1);
-					w.tri(q + 6, arcID, arcID + 2, arcID + 3);
-				}
-			}
-		}
-		if (e.closesLoop) { // :1970-1984
-			const VgxJoin j0 = vgx_join(p1, ldv(m.vtx, 0), ldv(m.vtx, N > 1 ? 1 : 0), hswAA);
-			w.bridge4(q, elem_exit_rails(m, e, b), first_join_entry(m, j0.leftInner));
-		}
-		return;
-	}
-
-	// ------------------------------- non-AA stroke, 2 rails ---------------------------------------
-	if (m.kind == VGX_MESH_STROKE) {
-		if (e.et != ET_JOIN) {
-			const bool firstCap = e.et == ET_CAP_FIRST;
-			const V2 d = e.d01;
-			const V2 l = v2ccw(d);
-			if (m.cap == VGX_CAP_ROUND) { // :1059-1080, 1342-1370
-				const uint32_t H = e.H;
-				const float startAngle = vgm_atan2(l.y, l.x);
-				for (uint32_t i = 0; i < H; ++i) {
-					const float t = i * VGM_PI / (float)(H - 1);
-					const float a = firstCap ? startAngle + t : startAngle - t;
-					float sa, ca;
-					vgm_sincos(a, &sa, &ca);
-					w.v(b + i, v2(p1.x + ca * hsw, p1.y + sa * hsw), color);
-				}
-				if (firstCap) {
-					uint32_t q = k;
-					for (uint32_t i = 0; i + 2 < H; ++i, q += 3) { w.tri(q, 0, i + 1, i + 2); }
-				} else {
-					w.bridge2(k, prev, rails(b, b + (H - 1), 0, 0));
-					uint32_t q = k + 6;
-					for (uint32_t i = 0; i + 2 < H; ++i, q += 3) { w.tri(q, b, b + i + 2, b + i + 1); }
-				}
-				return;
-			}
-			const V2 lh = v2mul(l, hsw);
-			if (m.cap == VGX_CAP_BUTT) { // :1032-1044, 1303-1321
-				w.sv(0, v2add(p1, lh), color);
-				w.sv(1, v2sub(p1, lh), color);
-			} else { // Square :1045-1058, 1322-1341
-				const V2 dh = v2mul(d, hsw);
-				if (firstCap) {
-					w.sv(0, v2add(p1, v2sub(lh, dh)), color);
-					w.sv(1, v2sub(p1, v2add(lh, dh)), color);
-				} else {
-					w.sv(0, v2add(p1, v2add(lh, dh)), color);
-					w.sv(1, v2sub(p1, v2sub(lh, dh)), color);
-				}
-			}
-			if (!firstCap) { w.sbridge2(0, prev, rails(b, b + 1, 0, 0)); }
-			return;
-		}
-		// join, :1088-1296
-		const V2 vh = v2mul(e.v, hsw);
-		const bool L = e.leftInner;
-		const V2 inner = L ? v2add(p1, vh) : v2sub(p1, vh);
-		const Rails entry = L ? rails(b, b + 1, 0, 0) : rails(b + 1, b, 0, 0);
-		uint32_t q = k;
-		w.sv(0, inner, color);
-		if (e.hasConnect) { w.sbridge2(0, prev, entry); q += 6; }
-		if (m.join == VGX_JOIN_MITER) {
-			w.sv(1, L ? v2sub(p1, vh) : v2add(p1, vh), color);
-		} else {
-			const V2 n01 = L ? v2cw(e.d01) : v2ccw(e.d01);
-			const V2 n12 = L ? v2cw(e.d12) : v2ccw(e.d12);
-			const uint32_t n = e.arc.n;
-			w.sv(1, v2add(p1, v2mul(n01, hsw)), color);
-			for (uint32_t i = 1; i < n; ++i) {
-				const float ang = e.arc.a01 + i * e.arc.arcDa;
-				float sa, ca;
-				vgm_sincos(ang, &sa, &ca);
-				w.v(b + 1 + i, v2(p1.x + hsw * ca, p1.y + hsw * sa), color);
-			}
-			w.v(b + 1 + n, v2add(p1, v2mul(n12, hsw)), color);
-			for (uint32_t i = 0; i < n; ++i, q += 3) {
-				const uint32_t base = b + i;
-				if (L) { w.tri(q, b, base + 1, base + 2); } else { w.tri(q, b, base + 2, base + 1); }
-			}
-		}
-		if (e.closesLoop) { // :1372-1380
-			const VgxJoin j0 = vgx_join(p1, ldv(m.vtx, 0), ldv(m.vtx, N > 1 ? 1 : 0), hsw);
-			w.bridge2(q, elem_exit_rails(m, e, b), first_join_entry(m, j0.leftInner));
-		}
-		return;
-	}
-
-	// ------------------------------- thin AA stroke, 3 rails --------------------------------------
-	{
-		const float f = fringe; // stroker.cpp:1999
-		if (e.et != ET_JOIN) { // :2012-2058, 2242-2294
-			const bool firstCap = e.et == ET_CAP_FIRST;
-			const V2 d = e.d01;
-			const V2 l = v2ccw(d);
-			const V2 lf = v2mul(l, f);
-			if (m.cap == VGX_CAP_BUTT) {
-				w.sv(0, v2add(p1, lf), c0);
-				w.sv(1, p1, color);
-				w.sv(2, v2sub(p1, lf), c0);
-			} else {
-				const V2 df = v2mul(d, f);
-				if (firstCap) {
-					w.sv(0, v2add(p1, v2sub(lf, df)), c0);
-					w.sv(1, p1, color);
-					w.sv(2, v2sub(p1, v2add(lf, df)), c0);
-				} else {
-					w.sv(0, v2add(p1, v2add(lf, df)), c0);
-					w.sv(1, p1, color);
-					w.sv(2, v2sub(p1, v2sub(lf, df)), c0);
-				}
-			}
-			if (!firstCap) { w.sbridge3(0, prev, rails(b, b + 1, b + 2, 0)); }
-			return;
-		}
-		const V2 vf = v2mul(e.v, f);
-		const bool L = e.leftInner;
-		const V2 inner = L ? v2add(p1, vf) : v2sub(p1, vf);
-		const Rails entry = L ? rails(b, b + 1, b + 2, 0) : rails(b + 2, b + 1, b, 0);
-		uint32_t q = k;
-		w.sv(0, inner, c0);
-		w.sv(1, p1, color);
-		if (e.hasConnect) { w.sbridge3(0, prev, entry); q += 12; }
-		if (m.join == VGX_JOIN_MITER) {
-			w.sv(2, L ? v2sub(p1, vf) : v2add(p1, vf), c0);
-		} else {
-			const V2 n01 = L ? v2cw(e.d01) : v2ccw(e.d01);
-			const V2 n12 = L ? v2cw(e.d12) : v2ccw(e.d12);
-			w.sv(2, v2add(p1, v2mul(n01, f)), c0);
-			w.sv(3, v2add(p1, v2mul(n12, f)), c0);
-			if (L) { w.tri(q, b + 1, b + 2, b + 3); } else { w.tri(q, b + 1, b + 3, b + 2); }
-			q += 3;
-		}
-		if (e.closesLoop) { // :2295-2306
-			const VgxJoin j0 = vgx_join(p1, ldv(m.vtx, 0), ldv(m.vtx, N > 1 ? 1 : 0), f);
-			w.bridge3(q, elem_exit_rails(m, e, b), first_join_entry(m, j0.leftInner));
-		}
-	}
-}
-
-// ---- per-mesh preparation ------------------------------------------------------------------------------
-__device__ __forceinline__ VgxMeshPrep mesh_prep(const VgxMeshDesc& md, const vgx_draw* dr, const float* poly)
-{
-	VgxMeshPrep pr;
-	const uint32_t kind = VGX_MD_KIND(md.kind);
-	if (kind >= VGX_MESH_STROKE) {
-		const VgxStrokeParams sp = vgx_stroke_params(kind, VGX_MD_CLOSED(md.kind) != 0, dr->stroke_flags, dr->stroke_width, dr->fringe, dr->scale, dr->tess_tol);
-		pr.f0 = sp.hsw; pr.f1 = sp.hswAA; pr.f2 = dr->fringe;
-		pr.color = dr->stroke_color;
-	} else {
-		pr.f0 = 0.0f; pr.f1 = 0.0f; pr.f2 = dr->fringe;
-		if (kind == VGX_MESH_FILL_AA) {
-			// orientation from the first triangle only (stroker.cpp:721-723, "might not work in all cases")
-			const float* vtx = poly + 2 * md.poly_first;
-			const V2 q0 = ldv(vtx, 0), q1 = ldv(vtx, 1), q2 = ldv(vtx, 2);
-			const float orient = v2cross(v2sub(q1, q0), v2sub(q2, q0));
-			pr.f0 = dr->fringe * 0.5f * vgm_sign(orient);
-		}
-		pr.color = dr->fill_color;
-	}
-	return pr;
-}
 
 // One lane per mesh: per-mesh constants for the element kernels. (Meshes with Round joins -- the only data-dependent
 // sizes -- are sized by k_round_sizes, one wave per mesh; every other mesh was sized in closed form by flatten.)
@@ -665,20 +62,8 @@ __global__ __launch_bounds__(VGX_WAVE) void k_round_sizes(VgxStrokeArgs A)
 		}
 		const VgxMeshDesc md = A.mdesc[mi];
 		const VgxMeshPrep pr = A.mprep[mi];
-		const uint32_t N = md.poly_n;
-		const float* vtx = A.poly + 2 * md.poly_first;
-		uint32_t nv = 0, ni = 0;
-		for (uint32_t j = lane; j < N; j += VGX_WAVE) {
-			const MeshCtx mc = make_mesh_ctx(md, pr, A.draws, j, A.poly);
-			const V2 p1 = ldv(vtx, j);
-			const V2 d12 = v2dir(p1, ldv(vtx, j + 1 < N ? j + 1 : 0));
-			const V2 dPrev = v2dir(ldv(vtx, j > 0 ? j - 1 : N - 1), p1);
-			const Elem e = elem_geometry(mc, p1, dPrev, d12);
-			nv += e.nv;
-			ni += elem_total_indices(mc, e);
-		}
-		const uint32_t sv = wave_bcast_u32(wave_incl_scan_u32(nv, lane), VGX_WAVE - 1);
-		const uint32_t si = wave_bcast_u32(wave_incl_scan_u32(ni, lane), VGX_WAVE - 1);
+		uint32_t sv, si;
+		round_mesh_size(make_mesh_ctx(md, pr, A.draws, 0, A.poly), lane, &sv, &si);
 		if (lane == 0) {
 			A.mtab[mi].num_vertices = sv;
 			A.mtab[mi].num_indices = si;
@@ -724,18 +109,6 @@ __device__ __forceinline__ FillWindow fill_window_load(const VgxStrokeArgs& A, u
 	}
 	return w;
 }
-
-// Everything one fill element needs, fetched one chunk AHEAD of its use (k_fill is a dependent chain per chunk:
-// owner search -> vertex load -> stores; with the next chunk's loads already in flight while the current chunk
-// computes and stores, a wave keeps two vertex loads outstanding instead of one).
-struct FillFetch
-{
-	bool valid, aaElem, nextInWave, prevInWave;
-	uint32_t j, N, color, ibase;
-	float aa;
-	uint64_t firstV, firstI, mi;
-	V2 p1, pNextB, pPrevB;
-};
 
 __device__ __forceinline__ FillFetch fill_fetch(const VgxStrokeArgs& A, uint64_t chunk, uint64_t elemEnd, uint64_t numMeshes, int lane, FillWindow& W, uint64_t& wbase, uint64_t& mcur)
 {
@@ -793,70 +166,6 @@ __device__ __forceinline__ FillFetch fill_fetch(const VgxStrokeArgs& A, uint64_t
 	return F;
 }
 
-__device__ __forceinline__ void fill_emit_chunk(const VgxStrokeArgs& A, const FillFetch& F)
-{
-	const bool valid = F.valid;
-	const uint32_t j = F.j, N = F.N, color = F.color;
-	const V2 p1 = F.p1;
-	V2 pNext;
-	pNext.x = wave_from_next(p1.x, 0.0f); pNext.y = wave_from_next(p1.y, 0.0f);
-	if (!F.nextInWave) { pNext = F.pNextB; }
-	V2 d12 = v2(0.0f, 0.0f);
-	if (F.aaElem) { d12 = v2dir(p1, pNext); }
-	V2 dPrev;
-	dPrev.x = wave_from_prev(d12.x, 0.0f); dPrev.y = wave_from_prev(d12.y, 0.0f);
-	if (F.aaElem && !F.prevInWave) { dPrev = v2dir(F.pPrevB, p1); }
-
-	if (valid) {
-		if (F.aaElem) {
-			const V2 vaa = v2mul(v2extrude(dPrev, d12), F.aa);
-			const V2 vin = v2add(p1, vaa), vout = v2sub(p1, vaa);
-			const uint64_t gv = F.firstV + 2 * (uint64_t)j;
-			PosPair pp; pp.x0 = vin.x; pp.y0 = vin.y; pp.x1 = vout.x; pp.y1 = vout.y;
-			*(PosPair*)(A.pos + 2 * gv) = pp;
-			ColPair cp; cp.c0 = color; cp.c1 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
-			*(ColPair*)(A.color + gv) = cp;
-			// indices: my nine positions [9j, 9j+9) are three whole triangles T = 3j + g (the fan size 3(N-2) and the
-			// fringe quads are multiples of 3): T < N-2 is fan triangle (0, 2T+2, 2T+4) (stroker.cpp:769-776), else
-			// fringe triangle F = T-(N-2) = half (F&1) of the quad on edge F>>1: (fb, fb+1, nextOuter) /
-			// (fb, nextOuter, nextInner) with fb = 2*edge (stroker.cpp:779-795). No division, no per-index select.
-			const uint32_t k9 = 9 * j;
-			uint32_t val[9];
-#pragma unroll
-			for (uint32_t g = 0; g < 3; ++g) {
-				const uint32_t T = 3 * j + g;
-				const bool isFan = T + 2 < N;
-				const uint32_t Fq = T + 2 - N; // wraps for fan triangles, unused there
-				const uint32_t ed = Fq >> 1;
-				const bool second = (Fq & 1u) != 0;
-				const uint32_t fb = 2 * ed;
-				const bool lastEdge = ed + 1 == N;
-				const uint32_t nextInner = lastEdge ? 0u : fb + 2, nextOuter = lastEdge ? 1u : fb + 3;
-				// + F.ibase: vertex-buffer relative when assembly is armed (uint16 wrap = the reference's cast, vg_util.cpp:447)
-				val[3 * g] = ((isFan ? 0u : fb) + F.ibase) & 0xFFFFu;
-				val[3 * g + 1] = ((isFan ? 2 * T + 2 : (second ? nextOuter : fb + 1)) + F.ibase) & 0xFFFFu;
-				val[3 * g + 2] = ((isFan ? 2 * T + 4 : (second ? nextInner : nextOuter)) + F.ibase) & 0xFFFFu;
-			}
-			uint16_t* pi = A.idx + F.firstI + k9;
-			if (j + 1 < N) {
-				Idx9 q; q.a = val[0] | (val[1] << 16); q.b = val[2] | (val[3] << 16); q.c = val[4] | (val[5] << 16); q.d = val[6] | (val[7] << 16); q.e = (uint16_t)val[8];
-				*(Idx9*)pi = q;
-			} else {
-				Idx3 q; q.a = val[0] | (val[1] << 16); q.b = (uint16_t)val[2];
-				*(Idx3*)pi = q;
-			}
-		} else {
-			const uint64_t gv = F.firstV + j;
-			*(float2*)(A.pos + 2 * gv) = make_float2(p1.x, p1.y);
-			A.color[gv] = color;
-			if (j + 2 < N) {
-				uint16_t* pi = A.idx + F.firstI + 3 * j;
-				pi[0] = (uint16_t)F.ibase; pi[1] = (uint16_t)(j + 1 + F.ibase); pi[2] = (uint16_t)(j + 2 + F.ibase);
-			}
-		}
-	}
-}
-
 __global__ __launch_bounds__(VGX_WAVE) void k_fill(VgxStrokeArgs A)
 {
 	const int lane = threadIdx.x;
@@ -887,9 +196,9 @@ __global__ __launch_bounds__(VGX_WAVE) void k_fill(VgxStrokeArgs A)
 	for (uint64_t chunk = elem0; chunk < elemEnd; chunk += 2 * VGX_WAVE) {
 		const bool has1 = chunk + VGX_WAVE < elemEnd, has2 = chunk + 2 * VGX_WAVE < elemEnd; // wave-uniform
 		if (has1) { F1 = fill_fetch(A, chunk + VGX_WAVE, elemEnd, numMeshes, lane, W, wbase, mcur); }
-		fill_emit_chunk(A, F0);
+		fill_emit_chunk(A.pos, A.color, A.idx, F0);
 		if (has2) { F0 = fill_fetch(A, chunk + 2 * VGX_WAVE, elemEnd, numMeshes, lane, W, wbase, mcur); }
-		if (has1) { fill_emit_chunk(A, F1); }
+		if (has1) { fill_emit_chunk(A.pos, A.color, A.idx, F1); }
 	}
 }
 
@@ -939,8 +248,8 @@ __global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
 		}
 		const uint64_t E0 = A.elem_prefix[m0];
 		const uint64_t E1 = A.elem_prefix[m1];
-		uint32_t carryV = 0, carryI = 0;
-		uint64_t carryRails = 0;
+		StrokeCarry carry;
+		carry.v = 0; carry.i = 0; carry.rails = 0;
 		uint64_t mcur = m0; // mesh that owns the chunk's first element
 
 		for (uint64_t chunk = E0; chunk < E1; chunk += VGX_WAVE) {
@@ -976,7 +285,7 @@ __global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
 			uint64_t mi = m0;
 			MeshCtx mc;
 			mc.kind = VGX_MESH_STROKE_AA; mc.N = 2; mc.j = 0; mc.cap = 0; mc.join = 0; mc.closed = false;
-			mc.hsw = 0.0f; mc.hswAA = 0.0f; mc.fringe = 1.0f; mc.dr = A.draws; mc.vtx = A.poly;
+			mc.hsw = 0.0f; mc.hswAA = 0.0f; mc.fringe = 1.0f; mc.dr = A.draws; mc.vtx.p = (const float2*)A.poly;
 			uint32_t color = 0;
 			uint64_t firstV = 0, firstI = 0;
 			uint32_t idxBase = 0;
@@ -1001,72 +310,15 @@ __global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))
 				mc.join = VGX_MD_JOIN(r.kind);
 				mc.N = r.N;
 				mc.j = (uint32_t)(ei - ownerBase);
-				mc.vtx = A.poly + 2 * r.polyFirst;
+				mc.vtx.p = (const float2*)A.poly + r.polyFirst;
 				mc.hsw = r.hsw; mc.hswAA = r.hswAA; mc.fringe = r.fringe;
 				mc.dr = A.draws + r.draw;
 				color = r.color;
 				firstV = r.firstV; firstI = r.firstI; idxBase = r.ibase;
 			}
-			// step A: one vertex load and one vec2Dir per element; neighbours come from the adjacent lanes
-			V2 p1 = v2(0.0f, 0.0f);
-			if (valid) { p1 = ldv(mc.vtx, mc.j); }
-			const bool prevInWave = lane > 0 && mc.j > 0;
-			const bool nextInWave = lane < VGX_WAVE - 1 && mc.j + 1 < mc.N && ei + 1 < E1;
-			V2 pNext;
-			pNext.x = wave_from_next(p1.x, 0.0f); pNext.y = wave_from_next(p1.y, 0.0f);
-			if (valid && !nextInWave) { pNext = ldv(mc.vtx, mc.j + 1 < mc.N ? mc.j + 1 : 0); }
-			V2 d12 = v2(0.0f, 0.0f);
-			if (valid) { d12 = v2dir(p1, pNext); }
-			V2 dPrev;
-			dPrev.x = wave_from_prev(d12.x, 0.0f); dPrev.y = wave_from_prev(d12.y, 0.0f);
-			if (valid && !prevInWave) { dPrev = v2dir(ldv(mc.vtx, mc.j > 0 ? mc.j - 1 : mc.N - 1), p1); }
-			Elem e;
-			e.nv = 0; e.ni = 0; e.et = ET_JOIN; e.leftInner = true; e.hasConnect = false; e.closesLoop = false;
-			e.arc.a01 = 0.0f; e.arc.arcDa = 0.0f; e.arc.n = 1; e.H = 2; e.p1 = p1; e.d01 = dPrev; e.d12 = d12; e.v = d12;
-			uint32_t totalIdx = 0;
-			if (valid) {
-				e = elem_geometry(mc, p1, dPrev, d12);
-				totalIdx = elem_total_indices(mc, e);
-			}
-
-			// step B: running vertex / index counters of the mesh (segmented wave scan)
-			const uint64_t heads = wave_ballot(valid && mc.j == 0);
-			const int mh = seg_head(heads, lane);
-			const uint32_t inclV = wave_incl_scan_u32(e.nv, lane);
-			const uint32_t inclI = wave_incl_scan_u32(totalIdx, lane);
-			const uint32_t exV = inclV - e.nv, exI = inclI - totalIdx;
-			const uint32_t hV = wave_read_u32(exV, mh < 0 ? 0 : mh), hI = wave_read_u32(exI, mh < 0 ? 0 : mh);
-			const uint32_t vbase = mh < 0 ? carryV + exV : exV - hV;
-			const uint32_t ibase = mh < 0 ? carryI + exI : exI - hI;
-
-			// step C: previous element's exit rails
-			const uint64_t myExit = valid ? rails_pack(elem_exit_rails(mc, e, vbase)) : 0ull;
-			uint64_t prevPacked = (uint64_t)wave_from_prev_u32((uint32_t)myExit, (uint32_t)carryRails) | ((uint64_t)wave_from_prev_u32((uint32_t)(myExit >> 32), (uint32_t)(carryRails >> 32)) << 32);
-
-			const bool meshLast = valid && (mc.j == mc.N - 1);
-			if (valid) {
-				StrokeWriter w;
-				w.pos = A.pos + 2 * firstV;
-				w.col = A.color + firstV;
-				w.idx = A.idx + firstI;
-				w.color = color;
-				w.c0 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
-				w.ib = idxBase;
-				w.reset();
-				elem_emit(mc, e, vbase, ibase, rails_unpack(prevPacked), w);
-				w.flush(vbase, ibase);
-			}
-
-			// carries (from the last valid lane)
 			const int nvalid = (int)((E1 - chunk) < (uint64_t)VGX_WAVE ? (E1 - chunk) : (uint64_t)VGX_WAVE);
 			const int Lz = nvalid - 1;
-			const int lastIsMeshLast = wave_bcast((int)meshLast, Lz);
-			const uint32_t endV = wave_read_u32(vbase + e.nv, Lz);
-			const uint32_t endI = wave_read_u32(ibase + totalIdx, Lz);
-			const uint64_t endRails = wave_bcast_u64(myExit, Lz);
-			carryV = lastIsMeshLast ? 0u : endV;
-			carryI = lastIsMeshLast ? 0u : endI;
-			carryRails = lastIsMeshLast ? 0ull : endRails;
+			stroke_chunk(valid, lane < VGX_WAVE - 1 && ei + 1 < E1, nvalid, lane, mc, color, A.pos + 2 * firstV, A.color + firstV, A.idx + firstI, idxBase, carry);
 			mcur = wave_bcast_u64(mi, Lz);
 		}
 	}

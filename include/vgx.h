@@ -43,7 +43,8 @@ typedef enum vgx_status {
 	VGX_E_MESH_TOO_LARGE = 5,/* a mesh needs > 65536 vertices (uint16 indices, vg.cpp:734) */
 	VGX_E_HIP = 6,           /* a HIP runtime call failed; vgx_last_hip_error() has the code */
 	VGX_E_NO_DEVICE = 7,     /* no gfx950 device / HIP runtime unavailable */
-	VGX_E_RANGE = 8          /* batch exceeds 2^32-1 polyline vertices or commands; split the batch */
+	VGX_E_RANGE = 8,         /* batch exceeds 2^32-1 polyline vertices or commands; split the batch */
+	VGX_E_INTERNAL = 9       /* device-side protocol error (a wait inside the single-pass kernel timed out): a bug, report it */
 } vgx_status;
 
 /* Path commands. One opcode per vg::pathXXX builder call (reference include/vg/path.h:24-35).
@@ -139,7 +140,8 @@ typedef struct vgx_mesh {
 	uint32_t draw;
 	uint32_t subpath_kind; /* bits 0-27 sub-path index within the draw, bits 28-31 VGX_MESH_* */
 } vgx_mesh;
-enum { VGX_MESH_FILL = 0, VGX_MESH_FILL_AA = 1, VGX_MESH_STROKE = 2, VGX_MESH_STROKE_AA = 3, VGX_MESH_STROKE_AA_THIN = 4 };
+enum { VGX_MESH_FILL = 0, VGX_MESH_FILL_AA = 1, VGX_MESH_STROKE = 2, VGX_MESH_STROKE_AA = 3, VGX_MESH_STROKE_AA_THIN = 4,
+       VGX_MESH_CONCAVE_FILL_AA = 5 /* vgx_concave_emit */ };
 
 /* Totals of a batch. Filled by the *_count calls (host struct). */
 typedef struct vgx_sizes {
@@ -287,6 +289,57 @@ int vgx_cache_localize(vgx_ctx* ctx, const vgx_draw* draws, uint64_t ndraws, flo
  * `draw`. Asynchronous like vgx_tessellate (capacities checked on the device, totals in dev_sizes, status in
  * dev_status); honours vgx_set_assembly (createDrawCommand_VertexColor is what submitCachedMesh calls). */
 int vgx_cache_submit(vgx_ctx* ctx, const vgx_cache_desc* cache, const vgx_cache_instance* instances, uint64_t ninst, const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream);
+
+/* ---- concave fills with AA fringes -------------------------------------------------
+ * strokerConcaveFillEndAA (src/stroker.cpp:868-1006) alternates libtess2 and the stroker's own loops:
+ *   (1) tessTesselate(TESS_BOUNDARY_CONTOURS) of the contours added with strokerConcaveFillAddContour     [caller, CPU]
+ *   (2) per boundary-contour vertex two fringe vertices + six indices; the contour vertex moves to the inner fringe
+ *       vertex (:887-973)                                                                                  [vgx_concave_move / _emit]
+ *   (3) tessAddContour of the moved contours, tessTesselate(TESS_POLYGONS)                                 [caller, CPU]
+ *   (4) the interior appended behind the fringe, indices rebased (:976-994)                                [vgx_concave_emit]
+ * libtess2 stays on the CPU side of the caller; these two calls do (2) and (4) for a BATCH of concave fills.
+ * All pointers are DEVICE pointers. The boundary contours of one fill must be stored back to back in `contour_verts`
+ * in tessGetElements order (what tessGetVertices returns), contours sorted by first_vertex. */
+typedef struct vgx_contour {       /* one boundary contour of step (1): contourData[2i], contourData[2i+1]. 16 bytes */
+	uint64_t first_vertex;         /* into contour_verts */
+	uint32_t num_vertices;
+	uint32_t fill;                 /* index of the concave fill it belongs to */
+} vgx_contour;
+typedef struct vgx_concave_fill {  /* one strokerConcaveFillBegin .. EndAA. 48 bytes */
+	uint64_t first_contour;        /* its boundary contours [first_contour, first_contour + num_contours) */
+	uint32_t num_contours;
+	uint32_t color;                /* colour handed to strokerConcaveFillEndAA */
+	float fringe;                  /* Stroker::m_FringeWidth */
+	uint32_t num_tess_vertices;    /* step (3): tessGetVertexCount            (vgx_concave_emit only) */
+	uint32_t num_tess_indices;     /*           tessGetElementCount * 3 */
+	uint32_t reserved;
+	uint64_t first_tess_vertex;    /* into tess_pos */
+	uint64_t first_tess_index;     /* into tess_idx */
+} vgx_concave_fill;
+/* Step (2), first half: moved[v] = the inner fringe vertex of contour vertex v (what the reference writes back into the
+ * contour before it hands it to libtess2 again). `moved` has the layout of contour_verts. Asynchronous. */
+int vgx_concave_move(vgx_ctx* ctx, const float* contour_verts, uint64_t num_contour_vertices, const vgx_contour* contours, uint64_t ncontours,
+                     const vgx_concave_fill* fills, uint64_t nfills, float* moved, void* stream);
+/* Steps (2) + (4): one mesh per fill = [2 vertices, 6 indices per contour vertex][interior from tess_pos / tess_idx with
+ * indices rebased by the fringe's vertex count], meshes concatenated in fill order; mesh records carry draw = fill index,
+ * kind VGX_MESH_CONCAVE_FILL_AA. contour_verts are the ORIGINAL boundary contours (not the moved ones). Asynchronous
+ * like vgx_tessellate (capacities checked on the device, totals in dev_sizes, status in dev_status). */
+int vgx_concave_emit(vgx_ctx* ctx, const float* contour_verts, uint64_t num_contour_vertices, const vgx_contour* contours, uint64_t ncontours,
+                     const vgx_concave_fill* fills, uint64_t nfills, const float* tess_pos, const uint16_t* tess_idx,
+                     const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream);
+
+/* Diagnostics of the last asynchronous call on this context: the device status word and, when the single-pass kernel of
+ * vgx_tessellate gave up on a segment, why (reason = one of the VGX_FAIL_* codes of csrc/vgx_internal_types.h: a table of
+ * the kernel was too small for the batch -- run vgx_tessellate_count on a batch like it --, the polyline heap or the
+ * caller's output capacity was exhausted, ...). Synchronises `stream`. Not needed on the happy path. */
+typedef struct vgx_failure_info {
+	uint32_t status;        /* vgx_status of the device status word */
+	uint32_t reason;        /* 0 = none */
+	uint32_t aux;           /* reason specific (a count) */
+	uint32_t segment_items; /* commands per segment the context currently uses (0 = multi-kernel pipeline) */
+	uint64_t segment;       /* segment that failed first */
+} vgx_failure_info;
+int vgx_get_failure_info(vgx_ctx* ctx, vgx_failure_info* out, void* stream);
 
 /* Per-kernel timing of the last vgx_tessellate.. / vgx_flatten.. sequence, measured with HIP events
  * on the stream the kernels ran on. Enable before the call; read after synchronising. */

@@ -31,7 +31,14 @@ def available(kind):
     return os.path.exists(_PATHS[kind])
 
 
-def load(kind="port"):
+def default_kind():
+    """The checker the tests use when they do not name one: the reference's own sources (oracle/_ref, built from
+    /root/reference and shipped to the GPU box as a prebuilt .so) when present, else the restatement."""
+    return "reference" if available("reference") else "port"
+
+
+def load(kind=None):
+    kind = kind or default_kind()
     if kind in _libs:
         return _libs[kind]
     lib = C.CDLL(_PATHS[kind])
@@ -58,7 +65,7 @@ class MeshResult:
     pass
 
 
-def flatten(ps, draws, apply_transform=False, kind="port"):
+def flatten(ps, draws, apply_transform=False, kind=None):
     """ps: PathSetArrays, draws: ndarray(draw_dtype). Returns FlatResult with numpy arrays."""
     lib = load(kind)
     draws = np.ascontiguousarray(draws)
@@ -78,7 +85,7 @@ def flatten(ps, draws, apply_transform=False, kind="port"):
     return r
 
 
-def tessellate(ps, draws, kind="port", want_flat=False, count_only=False):
+def tessellate(ps, draws, kind=None, want_flat=False, count_only=False):
     lib = load(kind)
     draws = np.ascontiguousarray(draws)
     n = draws.shape[0]
@@ -108,7 +115,7 @@ def tessellate(ps, draws, kind="port", want_flat=False, count_only=False):
     return r
 
 
-def assemble(meshes, idx, max_vb_vertices=0, kind="port"):
+def assemble(meshes, idx, max_vb_vertices=0, kind=None):
     """Draw-command assembly (vgo_assemble): returns (status, drawcmds ndarray, rebased index buffer)."""
     lib = load(kind)
     meshes = np.ascontiguousarray(meshes)
@@ -121,7 +128,7 @@ def assemble(meshes, idx, max_vb_vertices=0, kind="port"):
     return st, cmds[:n.value], out
 
 
-def cache_localize(draws, res, kind="port"):
+def cache_localize(draws, res, kind=None):
     """In place: res.pos <- local space (addCachedCommand). res: MeshResult of tessellate(ps, draws)."""
     lib = load(kind)
     draws = np.ascontiguousarray(draws)
@@ -130,7 +137,7 @@ def cache_localize(draws, res, kind="port"):
     return res
 
 
-def cache_submit(res, instances, kind="port"):
+def cache_submit(res, instances, kind=None):
     """res: localised MeshResult; instances: ndarray(cache_instance_dtype). Returns a MeshResult of the frame."""
     lib = load(kind)
     instances = np.ascontiguousarray(instances)
@@ -151,7 +158,7 @@ def cache_submit(res, instances, kind="port"):
     return r
 
 
-def tessellate_timed(ps, draws, kind="port", reps=1):
+def tessellate_timed(ps, draws, kind=None, reps=1):
     """Time `reps` single-pass vgo_tessellate calls into preallocated (already touched) buffers.
     Returns (seconds, sizes dict). Used by bench.py's cpu_baseline leg."""
     import time

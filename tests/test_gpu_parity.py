@@ -216,11 +216,14 @@ def _async_result(rt, gpu_ctx, ps, d):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("waves", ["3", "17"])
-def test_async_heap_block_switches(rt, gpu_ctx, wl, oracle, waves, monkeypatch):
-    """The single-pass flatten with only a few waves: every wave fills many 8192-vertex heap blocks, so chunks that do
-    not fit, block switches and the move of the sub-path that spans the switch all happen in a batch the oracle can
-    check completely (at the default 4096 waves that needs > 33 M polyline vertices)."""
+def test_async_heap_block_switches(rt, wl, oracle, waves, monkeypatch):
+    """The multi-kernel pipeline's single-pass flatten (k_flatten_build; what vgx_tessellate runs when the fused kernel
+    is not used) with only a few waves: every wave fills many 8192-vertex heap blocks, so chunks that do not fit, block
+    switches and the move of the sub-path that spans the switch all happen in a batch the oracle can check completely
+    (at the default 4096 waves that needs > 33 M polyline vertices). Options are read at vgx_create: own context."""
     monkeypatch.setenv("VGX_BUILD_WAVES", waves)
+    monkeypatch.setenv("VGX_NO_FUSED", "1")
+    gpu_ctx = rt.Context(0)
     ps, d = wl.tiger(24)
     ref = oracle.tessellate(ps, d)
     got = _async_result(rt, gpu_ctx, ps, d)
@@ -233,21 +236,27 @@ def test_async_heap_block_switches(rt, gpu_ctx, wl, oracle, waves, monkeypatch):
     got = _async_result(rt, gpu_ctx, ps, d)
     assert got.status == 0
     assert_mesh_equal(got, ref, "fuzz x12, %s build waves" % waves)
+    gpu_ctx.close()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("waves", ["2", None])
-def test_async_very_long_subpaths(rt, gpu_ctx, wl, oracle, waves, monkeypatch):
-    """Sub-paths of 30 001 vertices built from single LINE_TO commands (470 chunks each): they outgrow several heap
-    blocks, are moved with geometric growth, and their total feeds the heap sizing (long_subpath_vertices)."""
-    if waves:
-        monkeypatch.setenv("VGX_BUILD_WAVES", waves)
+@pytest.mark.parametrize("waves", ["2", None, "fused"])
+def test_async_very_long_subpaths(rt, wl, oracle, waves, monkeypatch):
+    """Sub-paths of 30 001 vertices built from single LINE_TO commands (470 chunks each). Multi-kernel pipeline: they
+    outgrow several heap blocks, are moved with geometric growth, and their total feeds the heap sizing
+    (long_subpath_vertices). Fused kernel: they do not fit the LDS window, so every segment takes the heap path."""
+    if waves != "fused":
+        monkeypatch.setenv("VGX_NO_FUSED", "1")
+        if waves:
+            monkeypatch.setenv("VGX_BUILD_WAVES", waves)
+    gpu_ctx = rt.Context(0)
     ps, d = wl.random_walk_polylines(n=5, nseg=30000, seed=7, cap=0, join=0, width=3.0)
     d["stroke_flags"] &= ~np.uint32(rt.capi.STROKE_AA)  # 2 rails: 60 002 vertices per mesh stay below 65 536
     ref = oracle.tessellate(ps, d)
     got = _async_result(rt, gpu_ctx, ps, d)
     assert got.status == 0
     assert_mesh_equal(got, ref, "5 x 30001-vertex polylines")
+    gpu_ctx.close()
 
 
 @pytest.mark.gpu

@@ -40,3 +40,75 @@ def assert_mesh_equal(got, ref, what="", pos_tol=0.0):
         assert bytes_equal(got.pos, ref.pos), (what, "pos", first_diff(got.pos.view(np.uint32), ref.pos.view(np.uint32)))
     else:
         assert np.max(np.abs(got.pos - ref.pos)) <= pos_tol, (what, "pos")
+
+
+def run_async(rt, ctx, ps, d, shrink=None, profile=False):
+    """vgx_tessellate_count (sizes + scratch) then the steady-state entry point vgx_tessellate into exactly sized
+    buffers. Returns an object with sizes / status / pos / color / idx / meshes and `stages` (names of the kernels'
+    profiling stages when profile=True: 'fused' = the single-pass kernel ran)."""
+    import torch
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(d)
+    sizes = rt.tessellate_count(ctx, pset, dd, d.shape[0])
+    nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
+    if shrink:
+        bufs = rt.MeshBuffers(dd.device, int(nv * shrink), int(ni * shrink), nm)
+    else:
+        bufs = rt.MeshBuffers(dd.device, nv, ni, nm)
+    bufs.pos.fill_(float("nan"))
+    bufs.idx.fill_(-1)
+    if profile:
+        ctx.set_profiling(True)
+    rt.tessellate_async(ctx, pset, dd, d.shape[0], bufs)
+    torch.cuda.synchronize()
+
+    class G:
+        pass
+    got = G()
+    got.stages = [n for n, _ in ctx.stage_times()] if profile else None
+    if profile:
+        ctx.set_profiling(False)
+    got.status = int(bufs.dev_status.item())
+    got.failure = ctx.failure_info() if got.status != 0 else None
+    got.sizes = dict(sizes)
+    dev = bufs.dev_sizes.cpu().numpy()
+    got.dev_sizes = {k: int(dev[i]) for i, k in enumerate(
+        ["num_poly_vertices", "num_subpaths", "num_meshes", "num_vertices", "num_indices", "num_serial_draws",
+         "num_cmd_instances", "num_elements", "num_fill_elements", "num_drawcmds"])}
+    if not shrink:
+        got.pos = bufs.pos[:nv].cpu().numpy()
+        got.color = bufs.color[:nv].cpu().numpy().view(np.uint32)
+        got.idx = bufs.idx[:ni].cpu().numpy().view(np.uint16)
+        got.meshes = bufs.meshes[:nm * 32].cpu().numpy().view(rt.capi.mesh_dtype)
+    pset.close()
+    return got
+
+
+def describe_mesh_diff(got, ref):
+    """Which mesh holds the first difference (for failure messages: a GPU run is expensive, say as much as possible)."""
+    out = {}
+    for k in ("first_vertex", "first_index", "num_vertices", "num_indices", "draw", "subpath_kind"):
+        if got.meshes.shape == ref.meshes.shape and not np.array_equal(got.meshes[k], ref.meshes[k]):
+            w = np.flatnonzero(got.meshes[k] != ref.meshes[k])
+            out["meshes." + k] = (int(w[0]), int(w.shape[0]), int(got.meshes[k][w[0]]), int(ref.meshes[k][w[0]]))
+    if got.meshes.shape != ref.meshes.shape:
+        out["num_meshes"] = (got.meshes.shape[0], ref.meshes.shape[0])
+        return out
+    m = ref.meshes
+    if got.pos.shape == ref.pos.shape:
+        w = np.flatnonzero((got.pos.view(np.uint32) != ref.pos.view(np.uint32)).any(axis=1))
+        if w.shape[0]:
+            mi = int(np.searchsorted(m["first_vertex"], w[0], side="right") - 1)
+            out["pos"] = {"first_vertex": int(w[0]), "count": int(w.shape[0]), "mesh": mi, "mesh_rec": {k: int(m[k][mi]) for k in m.dtype.names},
+                          "got": got.pos[w[0]].tolist(), "ref": ref.pos[w[0]].tolist()}
+    if got.idx.shape == ref.idx.shape:
+        w = np.flatnonzero(got.idx != ref.idx)
+        if w.shape[0]:
+            mi = int(np.searchsorted(m["first_index"], w[0], side="right") - 1)
+            out["idx"] = {"first_index": int(w[0]), "count": int(w.shape[0]), "mesh": mi, "mesh_rec": {k: int(m[k][mi]) for k in m.dtype.names},
+                          "got": got.idx[w[0]:w[0] + 6].tolist(), "ref": ref.idx[w[0]:w[0] + 6].tolist()}
+    if got.color.shape == ref.color.shape:
+        w = np.flatnonzero(got.color != ref.color)
+        if w.shape[0]:
+            out["color"] = {"first": int(w[0]), "count": int(w.shape[0])}
+    return out

@@ -16,6 +16,7 @@ VGX_E_MESH_TOO_LARGE = 5
 VGX_E_HIP = 6
 VGX_E_NO_DEVICE = 7
 VGX_E_RANGE = 8
+VGX_E_INTERNAL = 9
 
 CMD_MOVE_TO, CMD_LINE_TO, CMD_CUBIC_TO, CMD_QUAD_TO, CMD_CLOSE = 0, 1, 2, 3, 4
 CMD_ARC_TO, CMD_ARC, CMD_RECT, CMD_ROUNDED_RECT, CMD_ROUNDED_RECT_VARYING = 5, 6, 7, 8, 9
@@ -28,7 +29,7 @@ JOIN_MITER, JOIN_ROUND, JOIN_BEVEL = 0, 1, 2
 FILL_ENABLE, FILL_AA = 0x1, 0x2
 STROKE_ENABLE, STROKE_AA, STROKE_THIN = 0x1, 0x2, 0x4
 
-MESH_FILL, MESH_FILL_AA, MESH_STROKE, MESH_STROKE_AA, MESH_STROKE_AA_THIN = 0, 1, 2, 3, 4
+MESH_FILL, MESH_FILL_AA, MESH_STROKE, MESH_STROKE_AA, MESH_STROKE_AA_THIN, MESH_CONCAVE_FILL_AA = 0, 1, 2, 3, 4, 5
 
 
 def stroke_flags(cap, join, aa=True, thin=False):
@@ -58,6 +59,12 @@ mesh_dtype = np.dtype([
     ("first_vertex", "<u8"), ("first_index", "<u8"), ("num_vertices", "<u4"), ("num_indices", "<u4"),
     ("draw", "<u4"), ("subpath_kind", "<u4")])
 assert mesh_dtype.itemsize == 32
+contour_dtype = np.dtype([("first_vertex", "<u8"), ("num_vertices", "<u4"), ("fill", "<u4")])
+assert contour_dtype.itemsize == 16
+concave_fill_dtype = np.dtype([("first_contour", "<u8"), ("num_contours", "<u4"), ("color", "<u4"), ("fringe", "<f4"),
+                               ("num_tess_vertices", "<u4"), ("num_tess_indices", "<u4"), ("reserved", "<u4"),
+                               ("first_tess_vertex", "<u8"), ("first_tess_index", "<u8")])
+assert concave_fill_dtype.itemsize == 48
 drawcmd_dtype = np.dtype([
     ("first_vertex", "<u8"), ("first_index", "<u8"), ("first_mesh", "<u8"), ("num_vertices", "<u4"), ("num_indices", "<u4"),
     ("num_meshes", "<u4"), ("vertex_buffer", "<u4")])
@@ -111,6 +118,13 @@ class StageTimes(C.Structure):
     _fields_ = [("num_stages", C.c_uint32), ("ms", C.c_float * VGX_MAX_STAGES), ("name", C.c_char_p * VGX_MAX_STAGES)]
 
 
+class FailureInfo(C.Structure):
+    _fields_ = [("status", C.c_uint32), ("reason", C.c_uint32), ("aux", C.c_uint32), ("segment_items", C.c_uint32), ("segment", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
 # Every symbol include/vgx.h declares, with (restype, argtypes). tests/test_capi_symbols.py checks the
 # built library exports all of them.
 VGX_SYMBOLS = {
@@ -133,6 +147,10 @@ VGX_SYMBOLS = {
     "vgx_tessellate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(MeshOut), C.c_void_p, C.c_void_p, C.c_void_p]),
     "vgx_stroke_count": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(Sizes), C.c_void_p]),
     "vgx_stroke_emit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(MeshOut), C.c_void_p]),
+    "vgx_concave_move": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "vgx_concave_emit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                   C.POINTER(MeshOut), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vgx_get_failure_info": (C.c_int, [C.c_void_p, C.POINTER(FailureInfo), C.c_void_p]),
     "vgx_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "vgx_get_stage_times": (C.c_int, [C.c_void_p, C.POINTER(StageTimes)]),
 }

@@ -52,11 +52,18 @@ struct vgx_ctx
 {
 	int device;
 	int lastHipError;
+	int pendingHipError; // first failure of an asynchronous helper call (memset) inside the current entry point
 	// grow-only device scratch
 	DevBuf asmJump0, asmJump1, asmStart, meshBase; // draw-command assembly scratch (only when armed)
 	vgx_assembly asmCfg;
 	bool asmArmed;
 	DevBuf cmdPrefix, cmdCnt, subFirst, leafOverflow, serialList, dinfo, poly, subs, mdesc, elemPrefix, elemPrefixS, mprep, mtab, partial, totals;
+	DevBuf segStart, segState, probeOut; // fused single-pass path: segment table, look-back granules + ticket, probe counters
+	uint32_t fusedSegItems;      // commands per segment chosen by the last vgx_tessellate_count (0 = multi-kernel pipeline)
+	uint64_t fusedSegCap;        // segments the tables above hold
+	uint64_t* hostProbe;         // pinned
+	// options, read from the environment ONCE at vgx_create (tuning / testing knobs)
+	int optTwoPass, optNoFused, optBuildWaves, optFusedWaves;
 	VgxCaps caps; // element capacities matching the buffers above
 	uint64_t capDraws;
 	VgxTotals* hostTotals; // pinned
@@ -93,15 +100,36 @@ int ensure(vgx_ctx* ctx, DevBuf& b, size_t bytes)
 	}
 	// grow with 12.5 % head room so that near-identical batches do not reallocate
 	size_t want = bytes + bytes / 8 + 256;
-	if (b.p) {
-		HIPCHK(ctx, hipFree(b.p));
+	void* fresh = nullptr;
+	hipError_t e = hipMalloc(&fresh, want);
+	if (e != hipSuccess && b.p) { // not enough room for old + new at once: release the old block first (contents are scratch)
+		(void)hipFree(b.p);
 		b.p = nullptr;
 		b.cap = 0;
+		e = hipMalloc(&fresh, want);
 	}
-	HIPCHK(ctx, hipMalloc(&b.p, want));
+	if (e != hipSuccess) {
+		ctx->lastHipError = (int)e;
+		return VGX_E_HIP;
+	}
+	if (b.p) { (void)hipFree(b.p); }
+	b.p = fresh;
 	b.cap = want;
 	return VGX_OK;
 }
+
+// Every entry point that takes a context runs on the context's device, whatever device is current on the calling
+// thread (a torch rank, another context), and leaves the caller's current device as it found it.
+struct DeviceGuard
+{
+	int prev;
+	bool switched;
+	explicit DeviceGuard(const vgx_ctx* ctx) : prev(-1), switched(false)
+	{
+		if (ctx && hipGetDevice(&prev) == hipSuccess && prev != ctx->device) { switched = hipSetDevice(ctx->device) == hipSuccess; }
+	}
+	~DeviceGuard() { if (switched) { (void)hipSetDevice(prev); } }
+};
 
 // Launch failures (bad configuration, device lost) surface as hipGetLastError: every entry point that enqueues kernels
 // ends with this instead of pretending success.
@@ -112,7 +140,17 @@ int launchStatus(vgx_ctx* ctx)
 		ctx->lastHipError = (int)e;
 		return VGX_E_HIP;
 	}
+	if (ctx->pendingHipError) { // an asynchronous memset of this call failed
+		ctx->lastHipError = ctx->pendingHipError;
+		ctx->pendingHipError = 0;
+		return VGX_E_HIP;
+	}
 	return VGX_OK;
+}
+
+void noteHip(vgx_ctx* ctx, hipError_t e)
+{
+	if (e != hipSuccess && !ctx->pendingHipError) { ctx->pendingHipError = (int)e; }
 }
 
 void mark(vgx_ctx* ctx, hipStream_t s, const char* name)
@@ -298,6 +336,62 @@ struct OpCacheInst // shape cache: vertices / indices / meshes of every instance
 	}
 };
 
+struct OpConcaveFills // concave fills: vertices / indices of every fill's mesh -> offsets + mesh records
+{
+	const vgx_contour* contours;
+	uint64_t ncontours;
+	const vgx_concave_fill* fills;
+	uint64_t nfills;
+	vgx_mesh* mtab;
+	vgx_mesh* meshesOut; // caller's table (may be null)
+	VgxTotals* totals;
+	VgxCaps caps;
+	__device__ uint64_t size() const { return nfills; }
+	__device__ bool counts(uint64_t i, uint64_t* nv, uint64_t* ni) const
+	{
+		const vgx_concave_fill f = fills[i];
+		*nv = 0; *ni = 0;
+		if (f.first_contour > ncontours || (uint64_t)f.num_contours > ncontours - f.first_contour) { return false; }
+		uint64_t cv = 0; // contour vertices of the fill (its contours are stored back to back)
+		if (f.num_contours) {
+			const vgx_contour c0 = contours[f.first_contour], c1 = contours[f.first_contour + f.num_contours - 1];
+			if (c1.first_vertex < c0.first_vertex) { return false; }
+			cv = c1.first_vertex + c1.num_vertices - c0.first_vertex;
+		}
+		*nv = 2 * cv + f.num_tess_vertices;
+		*ni = 6 * cv + f.num_tess_indices;
+		return true;
+	}
+	__device__ Sum3 load(uint64_t i) const
+	{
+		Sum3 r = sum3_zero();
+		uint64_t nv, ni;
+		if (!counts(i, &nv, &ni)) { set_status(totals, VGX_E_INVALID_ARG); return r; }
+		if (nv > 65536u) { set_status(totals, VGX_E_MESH_TOO_LARGE); } // uint16 indices
+		r.a = nv; r.b = ni;
+		return r;
+	}
+	__device__ void store(uint64_t i, Sum3 e) const
+	{
+		uint64_t nv, ni;
+		(void)counts(i, &nv, &ni);
+		vgx_mesh m;
+		m.first_vertex = e.a; m.first_index = e.b;
+		m.num_vertices = (uint32_t)nv; m.num_indices = (uint32_t)ni;
+		m.draw = (uint32_t)i;
+		m.subpath_kind = (uint32_t)VGX_MESH_CONCAVE_FILL_AA << 28;
+		mtab[i] = m;
+		if (meshesOut && i < caps.meshes) { meshesOut[i] = m; }
+	}
+	__device__ void finish(Sum3 t) const
+	{
+		totals->sizes.num_meshes = nfills;
+		totals->sizes.num_vertices = t.a;
+		totals->sizes.num_indices = t.b;
+		if (t.a > caps.vertices || t.b > caps.indices || nfills > caps.meshes) { set_status(totals, VGX_E_NOSPACE); }
+	}
+};
+
 struct OpSubMeshes // stroker-level entry: one or two meshes per vertex list -> mesh descriptors + closed-form sizes
 {
 	const vgx_subpath* subs;
@@ -385,7 +479,10 @@ int ensureDrawBuffers(vgx_ctx* ctx, uint64_t ndraws)
 	if ((st = ensure(ctx, ctx->serialList, (ndraws + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->partial, VGX_SCAN_BLOCKS * sizeof(Sum3))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->totals, sizeof(VgxTotals))) != VGX_OK) { return st; }
-	ctx->capDraws = ndraws;
+	// what the grow-only buffers hold, not the last batch's size
+	uint64_t cap = ctx->cmdPrefix.cap / sizeof(uint64_t) - 1;
+	{ const uint64_t c2 = ctx->dinfo.cap / sizeof(vgx_draw_info) - 1, c3 = ctx->serialList.cap / sizeof(uint32_t) - 1; if (c2 < cap) { cap = c2; } if (c3 < cap) { cap = c3; } }
+	ctx->capDraws = cap;
 	return VGX_OK;
 }
 
@@ -399,7 +496,7 @@ int readTotals(vgx_ctx* ctx, hipStream_t s)
 // stage 1: command-instance prefix
 void runCmdPrefix(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, hipStream_t s)
 {
-	(void)hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s);
+	noteHip(ctx, hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s));
 	OpCmdPrefix op;
 	op.draws = draws; op.pathCmdBegin = ps->dev.path_cmd_begin; op.npaths = ps->dev.npaths; op.ndraws = ndraws;
 	op.prefix = (uint64_t*)ctx->cmdPrefix.p; op.totals = (VgxTotals*)ctx->totals.p; op.cap = ctx->caps.cmd_instances;
@@ -410,7 +507,7 @@ void runCmdPrefix(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, ui
 // stage 2: flatten count + draw scan
 void runFlattenCount(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, hipStream_t s)
 {
-	(void)hipMemsetAsync(ctx->dinfo.p, 0, ndraws * sizeof(vgx_draw_info), s);
+	noteHip(ctx, hipMemsetAsync(ctx->dinfo.p, 0, ndraws * sizeof(vgx_draw_info), s));
 	VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, 1);
 	vgx_launch_flatten(false, a, VGX_GRID_BLOCKS, s);
 	mark(ctx, s, "flatten_count");
@@ -423,10 +520,10 @@ void runFlattenCount(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 // single-pass flatten of the steady-state entry point: build (subdivide once, polyline -> heap) -> scan -> gather
 void runFlattenBuild(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, hipStream_t s)
 {
-	(void)hipMemsetAsync(ctx->dinfo.p, 0, ndraws * sizeof(vgx_draw_info), s);
+	noteHip(ctx, hipMemsetAsync(ctx->dinfo.p, 0, ndraws * sizeof(vgx_draw_info), s));
 	VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, 1);
 	a.build_mode = 1;
-	vgx_launch_flatten_build(a, s);
+	vgx_launch_flatten_build(a, ctx->optBuildWaves, s);
 	mark(ctx, s, "flatten_build");
 	OpDrawInfo op;
 	op.dinfo = (vgx_draw_info*)ctx->dinfo.p; op.ndraws = ndraws; op.totals = (VgxTotals*)ctx->totals.p; op.caps = ctx->caps; op.keepPolyBase = 1;
@@ -507,6 +604,70 @@ int runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out, 
 	return launchStatus(ctx);
 }
 
+// vgx_tessellate_count's last step: can the single-pass kernel (vgx_fused.hip) take batches like this one, and with which
+// segment size? k_fused_probe walks the segments of every candidate bucket size over the per-draw counts the count pass
+// just produced; the largest candidate whose segments all fit the kernel's tables (and rarely overflow its LDS window)
+// wins, none = the multi-kernel pipeline stays. Sizes the segment tables. Reads the totals back as well (one sync).
+int probeFused(vgx_ctx* ctx, uint64_t ndraws, hipStream_t s)
+{
+	static const uint32_t kCand[VGX_FUSED_CANDIDATES] = { 1024, 512, 256, 128, 64, 32 };
+	ctx->fusedSegItems = 0;
+	int st;
+	if ((st = ensure(ctx, ctx->probeOut, 4 * VGX_FUSED_CANDIDATES * sizeof(uint64_t))) != VGX_OK) { return st; }
+	noteHip(ctx, hipMemsetAsync(ctx->probeOut.p, 0, 4 * VGX_FUSED_CANDIDATES * sizeof(uint64_t), s));
+	VgxFusedProbe pr;
+	for (int c = 0; c < VGX_FUSED_CANDIDATES; ++c) { pr.seg_items[c] = kCand[c]; }
+	pr.out = (uint64_t*)ctx->probeOut.p;
+	vgx_launch_fused_probe((const uint64_t*)ctx->cmdPrefix.p, (const vgx_draw_info*)ctx->dinfo.p, ndraws, pr, s);
+	HIPCHK(ctx, hipMemcpyAsync(ctx->hostProbe, ctx->probeOut.p, 4 * VGX_FUSED_CANDIDATES * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+	if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
+	if (ctx->optNoFused || ctx->hostTotals->status != VGX_OK) { return VGX_OK; }
+	int best = -1;
+	for (int c = 0; c < VGX_FUSED_CANDIDATES; ++c) {
+		const uint64_t segs = ctx->hostProbe[4 * c + 0], viol = ctx->hostProbe[4 * c + 1], over = ctx->hostProbe[4 * c + 2];
+		if (viol != 0) { continue; }
+		if (over * 50 <= segs) { best = c; break; } // at most 2 % of the segments take the heap path
+		if (best < 0 || over * ctx->hostProbe[4 * best + 0] < ctx->hostProbe[4 * best + 2] * segs) { best = c; }
+	}
+	if (best < 0) { return VGX_OK; }
+	const uint64_t ncmdInst = ctx->hostTotals->sizes.num_cmd_instances;
+	const uint64_t segCap = ncmdInst / kCand[best] + ncmdInst / (8 * (uint64_t)kCand[best]) + 64;
+	if ((st = ensure(ctx, ctx->segStart, (segCap + 2) * sizeof(uint64_t))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->segState, (segCap + 2) * 4 * sizeof(uint64_t))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->leafOverflow, (size_t)VGX_BUILD_WAVES * VGX_BUILD_OVERFLOW * 64 * 2 * sizeof(float))) != VGX_OK) { return st; }
+	ctx->fusedSegCap = ctx->segStart.cap / sizeof(uint64_t) - 2;
+	{ const uint64_t c2 = ctx->segState.cap / (4 * sizeof(uint64_t)) - 2; if (c2 < ctx->fusedSegCap) { ctx->fusedSegCap = c2; } }
+	ctx->fusedSegItems = kCand[best];
+	return VGX_OK;
+}
+
+// vgx_tessellate, single pass: command-prefix scan (+ validation of the draw records) -> segment table -> k_tess_fused
+int runFused(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, const vgx_mesh_out* out, hipStream_t s)
+{
+	runCmdPrefix(ctx, ps, draws, ndraws, s);
+	// look-back granules of every segment + the ticket counter (last 8 bytes of the state buffer's last slot)
+	noteHip(ctx, hipMemsetAsync(ctx->segState.p, 0, (ctx->fusedSegCap + 2) * 4 * sizeof(uint64_t), s));
+	VgxFusedArgs a;
+	a.ps = ps->dev;
+	a.draws = draws; a.ndraws = ndraws;
+	a.cmd_prefix = (const uint64_t*)ctx->cmdPrefix.p;
+	a.seg_start = (uint64_t*)ctx->segStart.p;
+	a.seg_state = (uint64_t*)ctx->segState.p;
+	a.ticket = (uint32_t*)((uint64_t*)ctx->segState.p + (ctx->fusedSegCap + 1) * 4);
+	a.seg_items = ctx->fusedSegItems;
+	a.seg_cap = ctx->fusedSegCap;
+	a.heap = (float*)ctx->poly.p; a.heap_cap = ctx->caps.poly_vertices;
+	a.leaf_overflow = (float*)ctx->leafOverflow.p;
+	a.pos = out->pos; a.color = out->color; a.idx = out->idx; a.meshes_out = out->meshes;
+	a.totals = (VgxTotals*)ctx->totals.p;
+	a.caps = ctx->caps;
+	a.caps.vertices = out->cap_vertices; a.caps.indices = out->cap_indices;
+	a.caps.meshes = out->meshes ? out->cap_meshes : ~0ull;
+	vgx_launch_fused(a, ctx->optFusedWaves, s);
+	mark(ctx, s, "fused");
+	return launchStatus(ctx);
+}
+
 int ensureMeshBuffers(vgx_ctx* ctx, uint64_t polyVerts, uint64_t subpaths, uint64_t meshes)
 {
 	int st;
@@ -547,6 +708,7 @@ const char* vgx_status_string(int status)
 	case VGX_E_HIP: return "VGX_E_HIP";
 	case VGX_E_NO_DEVICE: return "VGX_E_NO_DEVICE";
 	case VGX_E_RANGE: return "VGX_E_RANGE";
+	case VGX_E_INTERNAL: return "VGX_E_INTERNAL";
 	default: return "VGX_E_UNKNOWN";
 	}
 }
@@ -567,13 +729,29 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	}
 	memset(ctx, 0, sizeof(*ctx));
 	ctx->device = device;
-	if (hipSetDevice(device) != hipSuccess) {
+	DeviceGuard guard(ctx); // the caller's current device is restored on return
+	int cur = -1;
+	if (hipGetDevice(&cur) != hipSuccess || cur != device) {
 		delete ctx;
 		return VGX_E_NO_DEVICE;
 	}
-	if (hipHostMalloc((void**)&ctx->hostTotals, sizeof(VgxTotals), hipHostMallocDefault) != hipSuccess) {
+	if (hipHostMalloc((void**)&ctx->hostTotals, sizeof(VgxTotals), hipHostMallocDefault) != hipSuccess
+		|| hipHostMalloc((void**)&ctx->hostProbe, 4 * VGX_FUSED_CANDIDATES * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
+		if (ctx->hostTotals) { (void)hipHostFree(ctx->hostTotals); }
 		delete ctx;
 		return VGX_E_HIP;
+	}
+	// tuning / testing knobs: read once here, never on the call path
+	ctx->optTwoPass = getenv("VGX_TWO_PASS_FLATTEN") ? 1 : 0;
+	ctx->optNoFused = getenv("VGX_NO_FUSED") ? 1 : 0;
+	ctx->optBuildWaves = VGX_BUILD_WAVES;
+	if (const char* e = getenv("VGX_BUILD_WAVES")) { const int v = atoi(e); if (v >= 1 && v < VGX_BUILD_WAVES) { ctx->optBuildWaves = v; } }
+	{
+		int cus = 256;
+		hipDeviceProp_t prop;
+		if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) { cus = prop.multiProcessorCount; }
+		ctx->optFusedWaves = cus * 8; // the fused kernel's LDS footprint admits 8 one-wave workgroups per CU
+		if (const char* e = getenv("VGX_FUSED_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= VGX_BUILD_WAVES) { ctx->optFusedWaves = v; } }
 	}
 	*out_ctx = ctx;
 	return VGX_OK;
@@ -584,11 +762,13 @@ int vgx_destroy(vgx_ctx* ctx)
 	if (!ctx) {
 		return VGX_E_INVALID_ARG;
 	}
-	DevBuf* bufs[] = { &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DeviceGuard guard(ctx);
+	DevBuf* bufs[] = { &ctx->segStart, &ctx->segState, &ctx->probeOut, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
 	if (ctx->hostTotals) { (void)hipHostFree(ctx->hostTotals); }
+	if (ctx->hostProbe) { (void)hipHostFree(ctx->hostProbe); }
 	if (ctx->evCreated) {
 		for (int i = 0; i <= VGX_MAX_STAGES; ++i) { (void)hipEventDestroy(ctx->ev[i]); }
 	}
@@ -603,7 +783,7 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx)
 	if (!ctx) {
 		return 0;
 	}
-	return ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
+	return ctx->segStart.cap + ctx->segState.cap + ctx->probeOut.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
 }
 
 // ---- path set ---------------------------------------------------------------------------------------
@@ -706,6 +886,7 @@ int vgx_pathset_validate(const vgx_pathset_desc* desc)
 
 int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset** out_ps)
 {
+	DeviceGuard guard(ctx);
 	if (!ctx || !desc || !out_ps) {
 		return VGX_E_INVALID_ARG;
 	}
@@ -812,6 +993,7 @@ int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset**
 
 int vgx_pathset_destroy(vgx_ctx* ctx, vgx_pathset* ps)
 {
+	DeviceGuard guard(ctx);
 	if (!ctx || !ps) {
 		return VGX_E_INVALID_ARG;
 	}
@@ -850,6 +1032,7 @@ static int flattenCountCommon(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_dra
 
 int vgx_flatten_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, vgx_sizes* out_sizes, void* stream)
 {
+	DeviceGuard guard(ctx);
 	if (!ctx || !ps || (!draws && ndraws) || !out_sizes) {
 		return VGX_E_INVALID_ARG;
 	}
@@ -867,11 +1050,12 @@ int vgx_flatten_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws
 
 int vgx_flatten_emit(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, int apply_transform, const vgx_flat_out* out, void* stream)
 {
+	DeviceGuard guard(ctx);
 	if (!ctx || !ps || !out || (!draws && ndraws)) {
 		return VGX_E_INVALID_ARG;
 	}
-	if (ctx->lastStage < 1 || ctx->lastPs != ps || ctx->lastDraws != draws || ctx->lastNDraws != ndraws) {
-		return VGX_E_INVALID_ARG; // must follow vgx_flatten_count on the same batch
+	if (ctx->lastStage != 1 || ctx->lastPs != ps || ctx->lastDraws != draws || ctx->lastNDraws != ndraws) {
+		return VGX_E_INVALID_ARG; // must follow vgx_flatten_count on the same batch (not vgx_tessellate_count: its polyline scratch is live)
 	}
 	const vgx_sizes& sz = ctx->hostTotals->sizes;
 	if ((out->poly && out->cap_poly_vertices < sz.num_poly_vertices) || (out->subpaths && out->cap_subpaths < sz.num_subpaths)) {
@@ -900,6 +1084,7 @@ int vgx_flatten_emit(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 // ---- tessellate ---------------------------------------------------------------------------------------
 int vgx_tessellate_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, vgx_sizes* out_sizes, void* stream)
 {
+	DeviceGuard guard(ctx);
 	if (!ctx || !ps || (!draws && ndraws) || !out_sizes) {
 		return VGX_E_INVALID_ARG;
 	}
@@ -921,15 +1106,16 @@ int vgx_tessellate_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* dr
 	VgxCaps outCaps = ctx->caps;
 	outCaps.vertices = ~0ull; outCaps.indices = ~0ull;
 	runStrokeCount(ctx, draws, outCaps, 0, s);
-	if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
+	if ((st = probeFused(ctx, ndraws, s)) != VGX_OK) { return st; } // also brings the totals to the host
 	*out_sizes = ctx->hostTotals->sizes;
+	if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; } // _emit must not follow a failed count
 	ctx->lastPs = ps; ctx->lastDraws = draws; ctx->lastNDraws = ndraws; ctx->lastStage = 2;
-	if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; }
 	return VGX_OK;
 }
 
 int vgx_tessellate_emit(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, const vgx_mesh_out* out, void* stream)
 {
+	DeviceGuard guard(ctx);
 	if (!ctx || !ps || !out || (!draws && ndraws) || !out->pos || !out->color || !out->idx) {
 		return VGX_E_INVALID_ARG;
 	}
@@ -947,6 +1133,7 @@ int vgx_tessellate_emit(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* dra
 
 int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream)
 {
+	DeviceGuard guard(ctx);
 	if (!ctx || !ps || !out || (!draws && ndraws) || !out->pos || !out->color || !out->idx) {
 		return VGX_E_INVALID_ARG;
 	}
@@ -956,8 +1143,18 @@ int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 	hipStream_t s = (hipStream_t)stream;
 	markBegin(ctx, s);
 	ctx->lastStage = 0;
+	if (ctx->fusedSegItems && !ctx->asmArmed && !ctx->optTwoPass) {
+		// single pass, polyline in LDS (vgx_fused.hip). Draw-command assembly needs every mesh size before the first index
+		// is written (a sequential partition over ALL meshes), so it keeps the multi-kernel pipeline below.
+		const int st = runFused(ctx, ps, draws, ndraws, out, s);
+		if (st != VGX_OK) { return st; }
+		if (dev_sizes || dev_status) {
+			hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, s, (const VgxTotals*)ctx->totals.p, dev_sizes, dev_status);
+		}
+		return launchStatus(ctx);
+	}
 	runCmdPrefix(ctx, ps, draws, ndraws, s);
-	if (getenv("VGX_TWO_PASS_FLATTEN")) { // tuning / debugging knob: the ordered two-pass flatten
+	if (ctx->optTwoPass) { // tuning / debugging knob: the ordered two-pass flatten
 		runFlattenCount(ctx, ps, draws, ndraws, s);
 		VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, 1);
 		vgx_launch_flatten(true, a, VGX_GRID_BLOCKS, s);
@@ -983,6 +1180,7 @@ int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 // ---- stroker-level entry ------------------------------------------------------------------------------
 int vgx_stroke_count(vgx_ctx* ctx, const float* poly, const vgx_subpath* subpaths, const uint32_t* subpath_draw, uint64_t nsubpaths, const vgx_draw* draws, uint64_t ndraws, vgx_sizes* out_sizes, void* stream)
 {
+	DeviceGuard guard(ctx);
 	if (!ctx || !out_sizes || (nsubpaths && (!poly || !subpaths || !subpath_draw || !draws))) {
 		return VGX_E_INVALID_ARG;
 	}
@@ -994,7 +1192,7 @@ int vgx_stroke_count(vgx_ctx* ctx, const float* poly, const vgx_subpath* subpath
 	if ((st = ensure(ctx, ctx->totals, sizeof(VgxTotals))) != VGX_OK) { return st; }
 	// at most two meshes per vertex list: scratch can be sized without a device round trip
 	if ((st = ensureMeshBuffers(ctx, 0, 0, 2 * nsubpaths)) != VGX_OK) { return st; }
-	(void)hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s);
+	noteHip(ctx, hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s));
 	OpSubMeshes op;
 	op.subs = subpaths; op.subDraw = subpath_draw; op.draws = draws; op.nsubs = nsubpaths; op.ndraws = ndraws;
 	op.mdesc = (VgxMeshDesc*)ctx->mdesc.p; op.mtab = (vgx_mesh*)ctx->mtab.p; op.totals = (VgxTotals*)ctx->totals.p;
@@ -1012,6 +1210,7 @@ int vgx_stroke_count(vgx_ctx* ctx, const float* poly, const vgx_subpath* subpath
 
 int vgx_stroke_emit(vgx_ctx* ctx, const float* poly, const vgx_subpath* subpaths, const uint32_t* subpath_draw, uint64_t nsubpaths, const vgx_draw* draws, uint64_t ndraws, const vgx_mesh_out* out, void* stream)
 {
+	DeviceGuard guard(ctx);
 	(void)subpaths; (void)subpath_draw; (void)ndraws;
 	if (!ctx || !out || !out->pos || !out->color || !out->idx) {
 		return VGX_E_INVALID_ARG;
@@ -1031,6 +1230,7 @@ int vgx_stroke_emit(vgx_ctx* ctx, const float* poly, const vgx_subpath* subpaths
 // ---- shape cache ------------------------------------------------------------------------------------
 int vgx_cache_localize(vgx_ctx* ctx, const vgx_draw* draws, uint64_t ndraws, float* pos, const vgx_mesh* meshes, uint64_t num_meshes, void* stream)
 {
+	DeviceGuard guard(ctx);
 	if (!ctx || (num_meshes && (!draws || !pos || !meshes))) {
 		return VGX_E_INVALID_ARG;
 	}
@@ -1042,6 +1242,7 @@ int vgx_cache_localize(vgx_ctx* ctx, const vgx_draw* draws, uint64_t ndraws, flo
 
 int vgx_cache_submit(vgx_ctx* ctx, const vgx_cache_desc* cache, const vgx_cache_instance* instances, uint64_t ninst, const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream)
 {
+	DeviceGuard guard(ctx);
 	if (!ctx || !cache || !out || (!instances && ninst) || !out->pos || !out->color || !out->idx
 		|| (cache->num_meshes && (!cache->pos || !cache->color || !cache->idx || !cache->meshes))) {
 		return VGX_E_INVALID_ARG;
@@ -1054,9 +1255,11 @@ int vgx_cache_submit(vgx_ctx* ctx, const vgx_cache_desc* cache, const vgx_cache_
 	if ((st = ensure(ctx, ctx->partial, VGX_SCAN_BLOCKS * sizeof(Sum3))) != VGX_OK) { return st; }
 	// the three instance prefix arrays share one scratch buffer; the output mesh table lives in the mesh-table scratch
 	if ((st = ensure(ctx, ctx->cmdPrefix, 3 * (ninst + 1) * sizeof(uint64_t))) != VGX_OK) { return st; }
-	const uint64_t meshCap = out->cap_meshes ? out->cap_meshes : 1;
+	// the internal mesh table must hold every output mesh even when the caller does not want the table
+	uint64_t meshCap = out->meshes ? out->cap_meshes : cache->num_meshes * ninst;
+	if (meshCap == 0) { meshCap = 1; }
 	if ((st = ensure(ctx, ctx->mtab, (meshCap + 1) * sizeof(vgx_mesh))) != VGX_OK) { return st; }
-	(void)hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s);
+	noteHip(ctx, hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s));
 	uint64_t* prefix = (uint64_t*)ctx->cmdPrefix.p;
 	OpCacheInst op;
 	op.cache = *cache; op.inst = instances; op.ninst = ninst;
@@ -1106,6 +1309,80 @@ int vgx_set_assembly(vgx_ctx* ctx, const vgx_assembly* asm_)
 	return VGX_OK;
 }
 
+// ---- concave fills ------------------------------------------------------------------------------------
+int vgx_concave_move(vgx_ctx* ctx, const float* contour_verts, uint64_t num_contour_vertices, const vgx_contour* contours, uint64_t ncontours,
+                     const vgx_concave_fill* fills, uint64_t nfills, float* moved, void* stream)
+{
+	DeviceGuard guard(ctx);
+	if (!ctx || (num_contour_vertices && (!contour_verts || !contours || !fills || !moved || !ncontours || !nfills))) {
+		return VGX_E_INVALID_ARG;
+	}
+	if (!num_contour_vertices) { return VGX_OK; }
+	VgxConcaveArgs a;
+	memset(&a, 0, sizeof(a));
+	a.contour_verts = contour_verts; a.contours = contours; a.ncontours = ncontours; a.num_contour_vertices = num_contour_vertices;
+	a.fills = fills; a.nfills = nfills; a.moved = moved;
+	vgx_launch_concave_move(a, (hipStream_t)stream);
+	return launchStatus(ctx);
+}
+
+int vgx_concave_emit(vgx_ctx* ctx, const float* contour_verts, uint64_t num_contour_vertices, const vgx_contour* contours, uint64_t ncontours,
+                     const vgx_concave_fill* fills, uint64_t nfills, const float* tess_pos, const uint16_t* tess_idx,
+                     const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream)
+{
+	DeviceGuard guard(ctx);
+	if (!ctx || !out || !out->pos || !out->color || !out->idx || (nfills && !fills) || (ncontours && (!contours || !contour_verts))) {
+		return VGX_E_INVALID_ARG;
+	}
+	hipStream_t s = (hipStream_t)stream;
+	markBegin(ctx, s);
+	ctx->lastStage = 0;
+	int st;
+	if ((st = ensure(ctx, ctx->totals, sizeof(VgxTotals))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->partial, VGX_SCAN_BLOCKS * sizeof(Sum3))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->mtab, (nfills + 1) * sizeof(vgx_mesh))) != VGX_OK) { return st; }
+	noteHip(ctx, hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s));
+	OpConcaveFills op;
+	op.contours = contours; op.ncontours = ncontours; op.fills = fills; op.nfills = nfills;
+	op.mtab = (vgx_mesh*)ctx->mtab.p; op.meshesOut = out->meshes; op.totals = (VgxTotals*)ctx->totals.p;
+	op.caps = ctx->caps;
+	op.caps.vertices = out->cap_vertices; op.caps.indices = out->cap_indices; op.caps.meshes = out->meshes ? out->cap_meshes : ~0ull;
+	vgx_device_scan(op, (Sum3*)ctx->partial.p, s, nfills);
+	mark(ctx, s, "scan_concave_fills");
+	VgxConcaveArgs a;
+	memset(&a, 0, sizeof(a));
+	a.contour_verts = contour_verts; a.contours = contours; a.ncontours = ncontours; a.num_contour_vertices = num_contour_vertices;
+	a.fills = fills; a.nfills = nfills; a.tess_pos = tess_pos; a.tess_idx = tess_idx;
+	a.mtab = (const vgx_mesh*)ctx->mtab.p; a.pos = out->pos; a.color = out->color; a.idx = out->idx;
+	a.totals = (VgxTotals*)ctx->totals.p;
+	vgx_launch_concave_emit(a, s);
+	mark(ctx, s, "concave_emit");
+	if (dev_sizes || dev_status) {
+		hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, s, (const VgxTotals*)ctx->totals.p, dev_sizes, dev_status);
+	}
+	return launchStatus(ctx);
+}
+
+int vgx_get_failure_info(vgx_ctx* ctx, vgx_failure_info* out, void* stream)
+{
+	if (!ctx || !out) {
+		return VGX_E_INVALID_ARG;
+	}
+	DeviceGuard guard(ctx);
+	memset(out, 0, sizeof(*out));
+	if (!ctx->totals.p) {
+		return VGX_OK;
+	}
+	const int st = readTotals(ctx, (hipStream_t)stream);
+	if (st != VGX_OK) { return st; }
+	out->status = ctx->hostTotals->status;
+	out->reason = ctx->hostTotals->fail_reason;
+	out->aux = ctx->hostTotals->fail_aux;
+	out->segment = ctx->hostTotals->fail_segment;
+	out->segment_items = ctx->fusedSegItems;
+	return VGX_OK;
+}
+
 int vgx_set_profiling(vgx_ctx* ctx, int enable)
 {
 	if (!ctx) {
@@ -1117,6 +1394,7 @@ int vgx_set_profiling(vgx_ctx* ctx, int enable)
 
 int vgx_get_stage_times(vgx_ctx* ctx, vgx_stage_times* out)
 {
+	DeviceGuard guard(ctx);
 	if (!ctx || !out) {
 		return VGX_E_INVALID_ARG;
 	}

@@ -1,0 +1,148 @@
+// vgx_concave.hip -- the stroker's own arithmetic inside strokerConcaveFillEndAA (reference src/stroker.cpp:868-1006)
+// for a batch of concave fills; libtess2 stays with the caller on the CPU.
+//
+// The reference alternates libtess2 and its own loops:
+//   (1) tessTesselate(TESS_BOUNDARY_CONTOURS) of the added contours                              [caller, CPU]
+//   (2) per contour vertex: two fringe vertices {p[inner], colour} {p[1 - inner], colour & 0x00FFFFFF}, six indices per
+//       contour segment, and the contour vertex MOVES to p[inner] (stroker.cpp:887-973)           [k_concave_move, k_concave_fringe]
+//   (3) tessAddContour of the moved contours + tessTesselate(TESS_POLYGONS)                       [caller, CPU]
+//   (4) interior appended behind the fringe: positions copied, colour replicated, indices rebased by the fringe's
+//       vertex count with vgutil::batchTransformDrawIndices (stroker.cpp:976-994)                  [k_concave_interior]
+// One lane = one contour vertex (2) or one interior vertex / index (4).
+//
+// Quirk reproduced: the loop of (2) updates the contour in place, so the LAST vertex of a contour takes its outgoing
+// direction towards the ALREADY MOVED vertex 0 (stroker.cpp:900-901, 920); every other vertex sees original neighbours.
+#include "vgx_internal.h"
+#include "vgx_wave.h"
+
+namespace {
+
+__device__ __forceinline__ V2 ldc(const float* v, uint64_t i)
+{
+	const float2 t = *(const float2*)(v + 2 * i);
+	return v2(t.x, t.y);
+}
+
+struct FringePair { V2 in, out; }; // p[inner], p[1 - inner]
+
+// contour-wide constants: aa = fringe / 2 * sign(cross(d(last,0), d(0,1))), inner = sign < 0 ? 0 : 1 (stroker.cpp:895-898)
+__device__ __forceinline__ float contour_cross_sign(const float* v, uint32_t n)
+{
+	const V2 d01 = v2dir(ldc(v, n - 1), ldc(v, 0));
+	return vgm_sign(v2cross(d01, v2dir(ldc(v, 0), ldc(v, n > 1 ? 1 : 0))));
+}
+
+__device__ __forceinline__ FringePair fringe_of(V2 p1, V2 d01, V2 d12, float aa, bool innerIsSecond)
+{
+	const V2 vaa = v2mul(v2extrude(d01, d12), aa);
+	const V2 p0 = v2sub(p1, vaa), pp1 = v2add(p1, vaa);
+	FringePair r;
+	r.in = innerIsSecond ? pp1 : p0;
+	r.out = innerIsSecond ? p0 : pp1;
+	return r;
+}
+
+// vertex j of a contour of n original vertices v[0..n): both fringe vertices (stroker.cpp:899-927)
+__device__ __forceinline__ FringePair contour_vertex(const float* v, uint32_t n, uint32_t j, float fringe)
+{
+	const float crossSign = contour_cross_sign(v, n);
+	const float aa = fringe * 0.5f * crossSign;
+	const bool innerIsSecond = !(crossSign < 0.0f);
+	const V2 p1 = ldc(v, j);
+	const V2 pPrev = ldc(v, j > 0 ? j - 1 : n - 1);
+	const V2 d01 = v2dir(pPrev, p1); // iteration j's d01 = iteration j-1's d12 = dir(original v[j-1], original v[j]); j = 0: dir(v[n-1], v[0])
+	V2 p2 = ldc(v, j + 1 < n ? j + 1 : 0);
+	if (j + 1 == n && n > 1) { // the closing iteration reads vertex 0 AFTER iteration 0 moved it
+		const V2 q0 = ldc(v, 0);
+		const FringePair f0 = fringe_of(q0, v2dir(ldc(v, n - 1), q0), v2dir(q0, ldc(v, 1)), aa, innerIsSecond);
+		p2 = f0.in;
+	}
+	return fringe_of(p1, d01, v2dir(p1, p2), aa, innerIsSecond);
+}
+
+// owner contour of flat contour-vertex index e: last contour with first_vertex <= e (contours are stored back to back)
+__device__ __forceinline__ uint64_t contour_of(const vgx_contour* c, uint64_t n, uint64_t e)
+{
+	uint64_t lo = 0, hi = n;
+	while (hi - lo > 1) {
+		const uint64_t mid = (lo + hi) >> 1;
+		if (c[mid].first_vertex <= e) { lo = mid; } else { hi = mid; }
+	}
+	return lo;
+}
+
+__global__ __launch_bounds__(256) void k_concave_move(VgxConcaveArgs A)
+{
+	for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < A.num_contour_vertices; e += (uint64_t)gridDim.x * blockDim.x) {
+		const vgx_contour c = A.contours[contour_of(A.contours, A.ncontours, e)];
+		const uint32_t j = (uint32_t)(e - c.first_vertex);
+		if (j >= c.num_vertices || c.fill >= A.nfills) { continue; }
+		const FringePair f = contour_vertex(A.contour_verts + 2 * c.first_vertex, c.num_vertices, j, A.fills[c.fill].fringe);
+		*(float2*)(A.moved + 2 * e) = make_float2(f.in.x, f.in.y); // "Update contour vertex", stroker.cpp:917
+	}
+}
+
+// per fill: vertex / index counts -> offsets + mesh record (scan operator, see vgx_scan.h); defined in vgx_api.hip
+
+__global__ __launch_bounds__(256) void k_concave_fringe(VgxConcaveArgs A)
+{
+	if (A.totals->status != VGX_OK) { return; }
+	for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < A.num_contour_vertices; e += (uint64_t)gridDim.x * blockDim.x) {
+		const vgx_contour c = A.contours[contour_of(A.contours, A.ncontours, e)];
+		const uint32_t j = (uint32_t)(e - c.first_vertex);
+		if (j >= c.num_vertices) { continue; }
+		const vgx_concave_fill fl = A.fills[c.fill];
+		const vgx_mesh m = A.mtab[c.fill];
+		const uint32_t n = c.num_vertices;
+		const FringePair f = contour_vertex(A.contour_verts + 2 * c.first_vertex, n, j, fl.fringe);
+		// nextVertexID / nextIndexID of this contour inside its mesh: two vertices and six indices per contour vertex in front
+		const uint32_t before = (uint32_t)(c.first_vertex - A.contours[fl.first_contour].first_vertex);
+		const uint32_t vb = 2 * before, ib = 6 * before;
+		const uint64_t gv = m.first_vertex + vb + 2 * (uint64_t)j;
+		*(float4*)(A.pos + 2 * gv) = make_float4(f.in.x, f.in.y, f.out.x, f.out.y);
+		*(uint2*)(A.color + gv) = make_uint2(fl.color, fl.color & 0x00FFFFFFu); // colorSetAlpha(color, 0)
+		// segment j: (id0, id2, id1) (id2, id3, id1); the closing segment wraps to the contour's first pair (stroker.cpp:934-967)
+		const uint32_t id0 = vb + 2 * j, id1 = id0 + 1;
+		const uint32_t id2 = (j + 1 < n) ? id0 + 2 : vb, id3 = id2 + 1;
+		uint16_t* pi = A.idx + m.first_index + ib + 6 * (uint64_t)j;
+		pi[0] = (uint16_t)id0; pi[1] = (uint16_t)id2; pi[2] = (uint16_t)id1;
+		pi[3] = (uint16_t)id2; pi[4] = (uint16_t)id3; pi[5] = (uint16_t)id1;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_concave_interior(VgxConcaveArgs A)
+{
+	if (A.totals->status != VGX_OK) { return; }
+	// one wave per fill walks its interior: vertices (copy + colour), then indices (rebase by the fringe's vertex count)
+	const int lane = threadIdx.x & 63;
+	const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+	for (uint64_t fi = wave; fi < A.nfills; fi += nwaves) {
+		const vgx_concave_fill fl = A.fills[fi];
+		const vgx_mesh m = A.mtab[fi];
+		const uint32_t fringeV = m.num_vertices - fl.num_tess_vertices; // = nextVertexID after the last contour
+		const uint32_t fringeI = m.num_indices - fl.num_tess_indices;
+		for (uint32_t i = lane; i < fl.num_tess_vertices; i += 64) {
+			const float2 p = *(const float2*)(A.tess_pos + 2 * (fl.first_tess_vertex + i));
+			*(float2*)(A.pos + 2 * (m.first_vertex + fringeV + i)) = p;
+			A.color[m.first_vertex + fringeV + i] = fl.color; // memset32, stroker.cpp:985
+		}
+		const uint16_t delta = (uint16_t)fringeV; // batchTransformDrawIndices(src, n, dst, (uint16_t)nextVertexID), stroker.cpp:992
+		for (uint32_t i = lane; i < fl.num_tess_indices; i += 64) {
+			A.idx[m.first_index + fringeI + i] = (uint16_t)(A.tess_idx[fl.first_tess_index + i] + delta);
+		}
+	}
+}
+
+} // namespace
+
+void vgx_launch_concave_move(const VgxConcaveArgs& a, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_concave_move, dim3(1024), dim3(256), 0, s, a);
+}
+
+void vgx_launch_concave_emit(const VgxConcaveArgs& a, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_concave_fringe, dim3(1024), dim3(256), 0, s, a);
+	hipLaunchKernelGGL(k_concave_interior, dim3(1024), dim3(256), 0, s, a);
+}

@@ -736,12 +736,10 @@ __global__ __launch_bounds__(256) void k_flatten_serial(VgxFlattenArgs A)
 
 } // namespace
 
-void vgx_launch_flatten_build(const VgxFlattenArgs& a, hipStream_t s)
+void vgx_launch_flatten_build(const VgxFlattenArgs& a, int waves, hipStream_t s)
 {
-	// VGX_BUILD_WAVES (environment, read per launch): testing knob -- a handful of waves makes small batches run
-	// through the heap's block switches and sub-path moves that otherwise need > 8192 vertices per wave
-	int waves = VGX_BUILD_WAVES;
-	if (const char* e = getenv("VGX_BUILD_WAVES")) { const int v = atoi(e); if (v >= 1 && v < waves) { waves = v; } }
+	// waves < VGX_BUILD_WAVES is a testing knob (VGX_BUILD_WAVES in the environment at vgx_create): a handful of waves makes
+	// small batches run through the heap's block switches and sub-path moves that otherwise need > 8192 vertices per wave
 	hipLaunchKernelGGL(k_flatten_build, dim3(waves), dim3(VGX_WAVE), 0, s, a);
 	hipLaunchKernelGGL((k_flatten_serial<false, false>), dim3(1024), dim3(256), 0, s, a); // count + heap allocation
 }

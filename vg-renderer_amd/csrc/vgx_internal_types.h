@@ -93,6 +93,17 @@ struct VgxSubRec
 	uint32_t pad;
 };
 
+// Sub-path record of the fused single-pass kernel (vgx_fused.hip), one per sub-path that produces a mesh, kept in the
+// wave's LDS: where the sub-path's vertices start inside the wave's polyline window (or heap block), its length and
+// closed flag, and where its meshes go inside the segment (local draw index, ranks among the draw's fill / stroke meshes).
+struct VgxSegSub
+{
+	uint32_t first;     // first vertex, relative to the segment's first polyline vertex
+	uint32_t info;      // vertex count | closed << 31
+	uint32_t packed;    // local draw index (bits 0-7) | fill rank << 8 (12 bits) | stroke rank << 20 (12 bits)
+	uint32_t sub_index; // sub-path index within its draw (vgx_mesh.subpath_kind)
+};
+
 // ---- batch totals kept in device memory (mirrors vgx_sizes + internal counters) -------------------
 struct VgxTotals
 {
@@ -102,6 +113,24 @@ struct VgxTotals
 	unsigned long long poly_heap_cursor; // BUILD mode: bump allocator of the polyline heap (vertices)
 	unsigned long long long_subpath_vertices; // count pass: vertices in sub-paths longer than VGX_LONG_SUBPATH (heap sizing)
 	unsigned long long num_serial_list;  // BUILD mode: entries of serial_list (draws k_flatten_serial has to redo)
+	// diagnostics of the first failure inside the fused kernel (vgx_get_failure_info)
+	uint32_t fail_reason;  // VGX_FAIL_*
+	uint32_t fail_aux;
+	unsigned long long fail_segment;
+};
+enum {
+	VGX_FAIL_NONE = 0,
+	VGX_FAIL_SEG_DRAWS = 1,      // more draws in a segment than the table holds (aux = draws)
+	VGX_FAIL_SEG_SUBRECS = 2,    // more mesh-producing sub-paths (aux = records)
+	VGX_FAIL_SEG_MESHES = 3,     // more meshes (aux = meshes)
+	VGX_FAIL_HEAP = 4,           // polyline heap exhausted (aux = vertices wanted)
+	VGX_FAIL_OUT_CAPACITY = 5,   // caller's vertex / index / mesh capacity exceeded (aux: 1 vertices, 2 indices, 4 meshes)
+	VGX_FAIL_SEG_TABLE = 6,      // more segments than the segment tables hold
+	VGX_FAIL_SERIAL_HEAP = 7,
+	VGX_FAIL_SERIAL_SUBRECS = 8,
+	VGX_FAIL_LOOKBACK_TIMEOUT = 9,
+	VGX_FAIL_AGG_RANGE = 10,
+	VGX_FAIL_MESH_TOO_LARGE = 11
 };
 #define VGX_LONG_SUBPATH 2048
 

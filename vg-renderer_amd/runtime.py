@@ -93,6 +93,12 @@ class Context:
         _check(lib().vgx_set_assembly(self._h, C.byref(a)), "vgx_set_assembly")
         self._asm_keep = (drawcmds, dev_num)
 
+    def failure_info(self):
+        """Device status + why the single-pass kernel gave up, if it did (vgx_get_failure_info; synchronises)."""
+        fi = capi.FailureInfo()
+        _check(lib().vgx_get_failure_info(self._h, C.byref(fi), _stream_ptr()), "vgx_get_failure_info")
+        return fi.as_dict()
+
     def stage_times(self):
         st = capi.StageTimes()
         _check(lib().vgx_get_stage_times(self._h, C.byref(st)), "vgx_get_stage_times")

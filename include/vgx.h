@@ -338,6 +338,8 @@ typedef struct vgx_failure_info {
 	uint32_t aux;           /* reason specific (a count) */
 	uint32_t segment_items; /* commands per segment the context currently uses (0 = multi-kernel pipeline) */
 	uint64_t segment;       /* segment that failed first */
+	uint64_t prof[16];      /* -DVGX_FUSED_PROFILE builds of libvgx only (else 0): wave clock ticks (100 MHz) summed over all
+	                         * waves of the single-pass kernel: ticket, flatten, meshes, look-back, table + fills, strokes; [6] = segments */
 } vgx_failure_info;
 int vgx_get_failure_info(vgx_ctx* ctx, vgx_failure_info* out, void* stream);
 

@@ -16,6 +16,21 @@ def rt():
     return importlib.import_module("vg-renderer_amd.runtime")
 
 
+@pytest.fixture(scope="module")
+def gpu_ctx(rt):
+    """The single-pass kernel is opt-in (VGX_FUSED=1, read at vgx_create): these tests run on their own context."""
+    import os
+    old = os.environ.get("VGX_FUSED")
+    os.environ["VGX_FUSED"] = "1"
+    ctx = rt.Context(0)
+    if old is None:
+        del os.environ["VGX_FUSED"]
+    else:
+        os.environ["VGX_FUSED"] = old
+    yield ctx
+    ctx.close()
+
+
 def _check(got, ref, what, expect_fused=True):
     assert got.status == 0, (what, "status", got.status, got.failure)
     if expect_fused and got.stages is not None:
@@ -110,6 +125,7 @@ def test_fused_shapes_batch(rt, gpu_ctx, wl, oracle):
 def test_fused_few_waves(rt, wl, oracle, waves, monkeypatch):
     """The look-back with one wave (every predecessor already has its prefix), three, and sixty-four waves."""
     monkeypatch.setenv("VGX_FUSED_WAVES", waves)
+    monkeypatch.setenv("VGX_FUSED", "1")
     ctx = rt.Context(0)
     ps, d = wl.tiger(24)
     _check(run_async(rt, ctx, ps, d, profile=True), oracle.tessellate(ps, d), "tiger x24, %s waves" % waves)
@@ -130,7 +146,7 @@ def test_fused_matches_multi_kernel_pipeline(rt, gpu_ctx, wl, monkeypatch):
     ps, d = wl.tiger(200)
     a = run_async(rt, gpu_ctx, ps, d, profile=True)
     assert "fused" in a.stages
-    monkeypatch.setenv("VGX_NO_FUSED", "1")
+    monkeypatch.delenv("VGX_FUSED", raising=False)
     ctx2 = rt.Context(0)
     b = run_async(rt, ctx2, ps, d, profile=True)
     assert "fused" not in b.stages and "flatten_build" in b.stages

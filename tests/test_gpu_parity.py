@@ -222,7 +222,6 @@ def test_async_heap_block_switches(rt, wl, oracle, waves, monkeypatch):
     switches and the move of the sub-path that spans the switch all happen in a batch the oracle can check completely
     (at the default 4096 waves that needs > 33 M polyline vertices). Options are read at vgx_create: own context."""
     monkeypatch.setenv("VGX_BUILD_WAVES", waves)
-    monkeypatch.setenv("VGX_NO_FUSED", "1")
     gpu_ctx = rt.Context(0)
     ps, d = wl.tiger(24)
     ref = oracle.tessellate(ps, d)
@@ -246,8 +245,7 @@ def test_async_very_long_subpaths(rt, wl, oracle, waves, monkeypatch):
     outgrow several heap blocks, are moved with geometric growth, and their total feeds the heap sizing
     (long_subpath_vertices). Fused kernel: they do not fit the LDS window, so every segment takes the heap path."""
     if waves != "fused":
-        monkeypatch.setenv("VGX_NO_FUSED", "1")
-        if waves:
+            if waves:
             monkeypatch.setenv("VGX_BUILD_WAVES", waves)
     gpu_ctx = rt.Context(0)
     ps, d = wl.random_walk_polylines(n=5, nseg=30000, seed=7, cap=0, join=0, width=3.0)

@@ -119,10 +119,12 @@ class StageTimes(C.Structure):
 
 
 class FailureInfo(C.Structure):
-    _fields_ = [("status", C.c_uint32), ("reason", C.c_uint32), ("aux", C.c_uint32), ("segment_items", C.c_uint32), ("segment", C.c_uint64)]
+    _fields_ = [("status", C.c_uint32), ("reason", C.c_uint32), ("aux", C.c_uint32), ("segment_items", C.c_uint32), ("segment", C.c_uint64), ("prof", C.c_uint64 * 16)]
 
     def as_dict(self):
-        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+        d = {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "prof"}
+        d["prof"] = [int(x) for x in self.prof]
+        return d
 
 
 # Every symbol include/vgx.h declares, with (restype, argtypes). tests/test_capi_symbols.py checks the

@@ -604,6 +604,10 @@ int runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out, 
 	return launchStatus(ctx);
 }
 
+// 64-bit words of the fused kernel's look-back state for `segCap` segments (layout: look_state() in vgx_fused.hip):
+// agg[segCap + 2], four per-block arrays of segCap / 64 + 2 words, the ticket counter in the last word.
+uint64_t fusedStateWords(uint64_t segCap) { return (segCap + 2) + 4 * (segCap / 64 + 2) + 1; }
+
 // vgx_tessellate_count's last step: can the single-pass kernel (vgx_fused.hip) take batches like this one, and with which
 // segment size? k_fused_probe walks the segments of every candidate bucket size over the per-draw counts the count pass
 // just produced; the largest candidate whose segments all fit the kernel's tables (and rarely overflow its LDS window)
@@ -633,10 +637,9 @@ int probeFused(vgx_ctx* ctx, uint64_t ndraws, hipStream_t s)
 	const uint64_t ncmdInst = ctx->hostTotals->sizes.num_cmd_instances;
 	const uint64_t segCap = ncmdInst / kCand[best] + ncmdInst / (8 * (uint64_t)kCand[best]) + 64;
 	if ((st = ensure(ctx, ctx->segStart, (segCap + 2) * sizeof(uint64_t))) != VGX_OK) { return st; }
-	if ((st = ensure(ctx, ctx->segState, (segCap + 2) * 4 * sizeof(uint64_t))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->segState, fusedStateWords(segCap + 2) * sizeof(uint64_t))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->leafOverflow, (size_t)VGX_BUILD_WAVES * VGX_BUILD_OVERFLOW * 64 * 2 * sizeof(float))) != VGX_OK) { return st; }
-	ctx->fusedSegCap = ctx->segStart.cap / sizeof(uint64_t) - 2;
-	{ const uint64_t c2 = ctx->segState.cap / (4 * sizeof(uint64_t)) - 2; if (c2 < ctx->fusedSegCap) { ctx->fusedSegCap = c2; } }
+	ctx->fusedSegCap = segCap; // both tables hold at least this many (they only grow)
 	ctx->fusedSegItems = kCand[best];
 	return VGX_OK;
 }
@@ -646,14 +649,14 @@ int runFused(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_
 {
 	runCmdPrefix(ctx, ps, draws, ndraws, s);
 	// look-back granules of every segment + the ticket counter (last 8 bytes of the state buffer's last slot)
-	noteHip(ctx, hipMemsetAsync(ctx->segState.p, 0, (ctx->fusedSegCap + 2) * 4 * sizeof(uint64_t), s));
+	noteHip(ctx, hipMemsetAsync(ctx->segState.p, 0, fusedStateWords(ctx->fusedSegCap) * sizeof(uint64_t), s));
 	VgxFusedArgs a;
 	a.ps = ps->dev;
 	a.draws = draws; a.ndraws = ndraws;
 	a.cmd_prefix = (const uint64_t*)ctx->cmdPrefix.p;
 	a.seg_start = (uint64_t*)ctx->segStart.p;
 	a.seg_state = (uint64_t*)ctx->segState.p;
-	a.ticket = (uint32_t*)((uint64_t*)ctx->segState.p + (ctx->fusedSegCap + 1) * 4);
+	a.ticket = (uint32_t*)((uint64_t*)ctx->segState.p + fusedStateWords(ctx->fusedSegCap) - 1);
 	a.seg_items = ctx->fusedSegItems;
 	a.seg_cap = ctx->fusedSegCap;
 	a.heap = (float*)ctx->poly.p; a.heap_cap = ctx->caps.poly_vertices;
@@ -743,7 +746,7 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	}
 	// tuning / testing knobs: read once here, never on the call path
 	ctx->optTwoPass = getenv("VGX_TWO_PASS_FLATTEN") ? 1 : 0;
-	ctx->optNoFused = getenv("VGX_NO_FUSED") ? 1 : 0;
+	ctx->optNoFused = getenv("VGX_FUSED") ? 0 : 1; // the single-pass kernel is opt-in (VGX_FUSED=1): measured slower than the multi-kernel pipeline, DESIGN.md section 4
 	ctx->optBuildWaves = VGX_BUILD_WAVES;
 	if (const char* e = getenv("VGX_BUILD_WAVES")) { const int v = atoi(e); if (v >= 1 && v < VGX_BUILD_WAVES) { ctx->optBuildWaves = v; } }
 	{
@@ -1380,6 +1383,7 @@ int vgx_get_failure_info(vgx_ctx* ctx, vgx_failure_info* out, void* stream)
 	out->aux = ctx->hostTotals->fail_aux;
 	out->segment = ctx->hostTotals->fail_segment;
 	out->segment_items = ctx->fusedSegItems;
+	for (int i = 0; i < 16; ++i) { out->prof[i] = ctx->hostTotals->prof[i]; }
 	return VGX_OK;
 }
 

@@ -35,9 +35,22 @@
 
 namespace {
 
+#ifdef VGX_FUSED_PROFILE
+#define PROF_T(var) const uint64_t var = wall_clock64()
+#define PROF_ADD(A, slot, t0, t1) do { if (threadIdx.x == 0) { atomicAdd(&(A).totals->prof[slot], (unsigned long long)((t1) - (t0))); } } while (0)
+#define PROF_INC(A, slot, n) do { if (threadIdx.x == 0) { atomicAdd(&(A).totals->prof[slot], (unsigned long long)(n)); } } while (0)
+#else
+#define PROF_T(var) do {} while (0)
+#define PROF_ADD(A, slot, t0, t1) do {} while (0)
+#define PROF_INC(A, slot, n) do {} while (0)
+#endif
+
 #define FUSED_P VGX_FUSED_P
 #define FUSED_T VGX_FUSED_T
-#define FUSED_LV 3 /* LDS levels of the walk's pending stack (deeper cubics are redone with the private-memory stack) */
+#ifndef FUSED_LV
+#define FUSED_LV 3
+#endif
+/* FUSED_LV:  LDS levels of the walk's pending stack (deeper cubics are redone with the private-memory stack) */
 
 struct FDraw { uint32_t num_fill, num_stroke, mesh_base, serial; };
 
@@ -76,16 +89,25 @@ __device__ __forceinline__ void fused_fail(VgxTotals* t, uint32_t err, uint32_t 
 	atomicCAS(&t->status, (uint32_t)VGX_OK, err);
 }
 
-// ---- look-back granules ------------------------------------------------------------------------------
-// seg_state[4 * s + 0] aggregate {meshes 8 bits, vertices 26 bits, indices 29 bits} of segment s,
-// seg_state[4 * s + 1 / + 2] inclusive prefix {vertices 40 | meshes low 23} / {indices 42 | meshes high 21}; bit 0 of
-// every granule = valid. Written with one 8-byte agent-scope store each, read with agent-scope loads (L2 / fabric, never a
-// stale L1 line): a granule validates itself, so no fence (and no L2 write-back of the streaming output) is needed.
+// ---- look-back: two levels, self-validating 8-byte words, no fences ---------------------------------------------
+// Segment s publishes, right after its meshes are sized,
+//   agg[s]            = its totals {meshes 8 bits, vertices 26, indices 29} | valid, one agent-scope store, and
+//   blk0/blk1[s / 64] += {1 << 57 | vertices (32 bits) | meshes << 32 (16 bits)} / {1 << 57 | indices (40 bits)}: one
+//                       atomic add per word; a block's word is complete when its count field equals the block's size.
+// Its exclusive prefix = sum of agg over the earlier segments of its own block (one 512-byte read, one lane each)
+//                      + prefix at the end of the previous block: the nearest earlier block whose prefix is known
+//                        (pre0/pre1[b]: {vertices 40 | meshes low 23} / {indices 42 | meshes high 21} | valid) plus the
+//                        complete sums of the blocks in between, 64 blocks per round.
+// Every wave that learns the prefix at the end of block b - 1 publishes it, so a stalled range of thousands of
+// segments drains in two or three hops once the slow segment arrives, instead of one hop per 64 segments. All words
+// are read with agent-scope loads (L2 / fabric, never a stale L1 line) and validate themselves: no fence, no L2
+// write-back of the streaming output. Waiting waves back off (s_sleep) so that polling does not eat the memory pipeline.
 __device__ __forceinline__ void granule_store(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint64_t granule_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 #define FUSED_AGG_MAX_V ((1u << 26) - 1)
 #define FUSED_AGG_MAX_I ((1u << 29) - 1)
+#define FUSED_BLK 64
 
 __device__ __forceinline__ uint64_t agg_pack(uint32_t m, uint32_t v, uint32_t i)
 {
@@ -101,49 +123,106 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v)
 	return v;
 }
 
-// Exclusive prefix {meshes, vertices, indices} of segment `seg`: sums the aggregates of the predecessors back to the
-// nearest one that has published its inclusive prefix, 64 predecessors per round (one per lane). Returns false on
-// timeout (a predecessor never published: cannot happen unless a wave died).
-__device__ __forceinline__ bool fused_lookback(const uint64_t* state, uint64_t seg, int lane, uint64_t* baseM, uint64_t* baseV, uint64_t* baseI)
+struct LookState // device arrays of one call (zeroed before the launch)
 {
-	uint64_t sumM = 0, sumV = 0, sumI = 0;
-	int64_t pos = (int64_t)seg - 1; // lane 0 looks at pos, lane l at pos - l
+	uint64_t* agg;   // [segments]
+	uint64_t* blk0;  // [blocks]
+	uint64_t* blk1;
+	uint64_t* pre0;  // [blocks] prefix at the END of block b
+	uint64_t* pre1;
+};
+
+__device__ __forceinline__ LookState look_state(const VgxFusedArgs& A)
+{
+	LookState L;
+	const uint64_t nb = A.seg_cap / FUSED_BLK + 2;
+	L.agg = A.seg_state;
+	L.blk0 = A.seg_state + (A.seg_cap + 2);
+	L.blk1 = L.blk0 + nb;
+	L.pre0 = L.blk1 + nb;
+	L.pre1 = L.pre0 + nb;
+	return L;
+}
+
+__device__ __forceinline__ void fused_publish(const LookState& L, uint64_t seg, int lane, uint32_t m, uint32_t v, uint32_t i)
+{
+	if (lane == 0) {
+		granule_store(L.agg + seg, agg_pack(m, v, i));
+		const uint64_t b = seg / FUSED_BLK;
+		atomicAdd((unsigned long long*)(L.blk0 + b), (1ull << 57) | (uint64_t)v | ((uint64_t)m << 32));
+		atomicAdd((unsigned long long*)(L.blk1 + b), (1ull << 57) | (uint64_t)i);
+	}
+}
+
+// Exclusive prefix {meshes, vertices, indices} of segment `seg`. Returns false on timeout (a predecessor never
+// published: cannot happen unless a wave died).
+__device__ __forceinline__ bool fused_lookback(const LookState& L, uint64_t seg, uint64_t numSegments, int lane, uint64_t* baseM, uint64_t* baseV, uint64_t* baseI)
+{
 	const uint64_t t0 = wall_clock64();
 	uint32_t spins = 0;
-	for (;;) {
-		const int64_t idx = pos - lane;
-		bool hasP = idx < 0, hasA = false; // in front of segment 0: prefix 0
-		uint64_t m = 0, v = 0, i = 0;
-		if (idx >= 0) {
-			const uint64_t* g = state + 4 * (uint64_t)idx;
-			const uint64_t p0 = granule_load(g + 1), p1 = granule_load(g + 2);
-			if ((p0 & 1ull) && (p1 & 1ull)) {
-				hasP = true;
-				v = (p0 >> 1) & ((1ull << 40) - 1);
-				i = (p1 >> 1) & ((1ull << 42) - 1);
-				m = (p0 >> 41) | ((p1 >> 43) << 23);
-			} else {
-				const uint64_t a = granule_load(g);
-				if (a & 1ull) {
-					hasA = true;
-					m = (a >> 1) & 0xFFu; v = (a >> 9) & FUSED_AGG_MAX_V; i = a >> 35;
+	uint64_t sumM = 0, sumV = 0, sumI = 0;
+	// level 1: the earlier segments of my own block
+	const uint64_t b = seg / FUSED_BLK;
+	const int k = (int)(seg - b * FUSED_BLK);
+	if (k > 0) {
+		for (;;) {
+			uint64_t a = 1;
+			if (lane < k) { a = granule_load(L.agg + (seg - 1 - (uint64_t)lane)); }
+			if (wave_ballot((a & 1ull) == 0) == 0) {
+				const bool take = lane < k;
+				sumM = wave_sum_u64(take ? ((a >> 1) & 0xFFu) : 0);
+				sumV = wave_sum_u64(take ? ((a >> 9) & FUSED_AGG_MAX_V) : 0);
+				sumI = wave_sum_u64(take ? (a >> 35) : 0);
+				break;
+			}
+			__builtin_amdgcn_s_sleep(32);
+			if ((++spins & 63u) == 0 && wall_clock64() - t0 > 200000000ull) { return false; } // 2 s at 100 MHz
+		}
+	}
+	// level 2: prefix at the end of block b - 1
+	if (b > 0) {
+		uint64_t bm = 0, bv = 0, bi = 0;
+		int64_t pos = (int64_t)b - 1; // lane l looks at block pos - l
+		for (;;) {
+			const int64_t idx = pos - lane;
+			bool hasP = idx < 0, full = false;
+			uint64_t m = 0, v = 0, i = 0;
+			if (idx >= 0) {
+				const uint64_t p0 = granule_load(L.pre0 + idx), p1 = granule_load(L.pre1 + idx);
+				if ((p0 & 1ull) && (p1 & 1ull)) {
+					hasP = true;
+					v = (p0 >> 1) & ((1ull << 40) - 1);
+					i = (p1 >> 1) & ((1ull << 42) - 1);
+					m = (p0 >> 41) | ((p1 >> 43) << 23);
+				} else {
+					const uint64_t w0 = granule_load(L.blk0 + idx), w1 = granule_load(L.blk1 + idx);
+					const uint64_t segsInBlock = ((uint64_t)idx + 1) * FUSED_BLK <= numSegments ? (uint64_t)FUSED_BLK : numSegments - (uint64_t)idx * FUSED_BLK;
+					if ((w0 >> 57) == segsInBlock && (w1 >> 57) == segsInBlock) {
+						full = true;
+						v = w0 & 0xFFFFFFFFull; m = (w0 >> 32) & 0xFFFFull; i = w1 & ((1ull << 40) - 1);
+					}
 				}
 			}
+			const uint64_t mP = wave_ballot(hasP), mR = wave_ballot(hasP || full);
+			const int firstP = mP ? (int)__builtin_ctzll(mP) : VGX_WAVE;
+			const uint64_t need = (firstP >= VGX_WAVE) ? ~0ull : lanemask_le(firstP);
+			if ((mR & need) != need) { // a block in front of the nearest known prefix is not complete yet
+				__builtin_amdgcn_s_sleep(64);
+				if ((++spins & 63u) == 0 && wall_clock64() - t0 > 200000000ull) { return false; }
+				continue;
+			}
+			const bool take = lane <= firstP;
+			bm += wave_sum_u64(take ? m : 0);
+			bv += wave_sum_u64(take ? v : 0);
+			bi += wave_sum_u64(take ? i : 0);
+			if (firstP < VGX_WAVE) { break; }
+			pos -= VGX_WAVE;
 		}
-		const uint64_t mP = wave_ballot(hasP), mR = wave_ballot(hasP || hasA);
-		const int firstP = mP ? (int)__builtin_ctzll(mP) : VGX_WAVE;
-		const uint64_t need = (firstP >= VGX_WAVE) ? ~0ull : lanemask_le(firstP);
-		if ((mR & need) != need) { // a predecessor in front of the nearest prefix has not published yet
-			__builtin_amdgcn_s_sleep(8);
-			if ((++spins & 63u) == 0 && wall_clock64() - t0 > 200000000ull) { return false; } // 2 s at 100 MHz
-			continue;
+		if (lane == 0) { // what I just learnt helps everybody behind me
+			granule_store(L.pre0 + (b - 1), pre0_pack(bm, bv));
+			granule_store(L.pre1 + (b - 1), pre1_pack(bm, bi));
 		}
-		const bool take = lane <= firstP;
-		sumM += wave_sum_u64(take ? m : 0);
-		sumV += wave_sum_u64(take ? v : 0);
-		sumI += wave_sum_u64(take ? i : 0);
-		if (firstP < VGX_WAVE) { break; }
-		pos -= VGX_WAVE;
+		sumM += bm; sumV += bv; sumI += bi;
 	}
 	*baseM = sumM; *baseV = sumV; *baseI = sumI;
 	return true;
@@ -176,6 +255,7 @@ __device__ __forceinline__ FlatResult fused_flatten(const VgxFusedArgs& A, uint6
 	for (uint64_t chunk = C0; chunk < C1; chunk += VGX_WAVE) {
 		const uint64_t ci = chunk + lane;
 		const bool valid = ci < C1;
+		PROF_T(tc0);
 		// ---- decode: owner draw from the lane-resident window (all draws of the segment are in it) ----------------
 		const uint32_t wrel = window_rel(W.prefix, chunk);
 		const int ownerOfs = window_owner_rel(wrel, valid ? (uint32_t)lane : 0u);
@@ -209,6 +289,11 @@ __device__ __forceinline__ FlatResult fused_flatten(const VgxFusedArgs& A, uint6
 		const float* mtx = dr->mtx;
 		const V2 start = v2(rec.start[0], rec.start[1]);
 
+#ifdef VGX_FUSED_PROFILE
+		{ float sink_ = rec.a[0] + scale + (float)fillFlags; asm volatile("" :: "v"(sink_)); } // the decode loads have landed
+#endif
+		PROF_T(tc1);
+		PROF_ADD(A, 8, tc0, tc1);
 		// ---- subdivide ONCE: count, detect degenerate cases, keep the first leaves in LDS ------------------------
 		int cnt = 0;
 		bool slow = false, exists = false, closedHere = false;
@@ -246,6 +331,8 @@ __device__ __forceinline__ FlatResult fused_flatten(const VgxFusedArgs& A, uint6
 			}
 		}
 		const int rawCnt = cnt;
+		PROF_T(tc2);
+		PROF_ADD(A, 9, tc1, tc2);
 
 		// ---- segmented bookkeeping (as k_flatten_build) -----------------------------------------------------------
 		const uint64_t drawHeads = wave_ballot(valid && drawHead);
@@ -284,6 +371,8 @@ __device__ __forceinline__ FlatResult fused_flatten(const VgxFusedArgs& A, uint6
 		const int pops = __popcll(wave_ballot(cnt < 0));
 		if ((uint32_t)(cur + chunkTotal + pops) > cap) { R.overflowP = true; } // from here on the window is only counted
 		const bool store = !R.overflowP;
+		PROF_T(tc3);
+		PROF_ADD(A, 10, tc2, tc3);
 		{
 			const int g = cur + excl; // window index of my first vertex
 			if (valid && !serialDraw && store) {
@@ -351,6 +440,9 @@ __device__ __forceinline__ FlatResult fused_flatten(const VgxFusedArgs& A, uint6
 			R.polyTrue += chunkTotal;
 		}
 
+		PROF_T(tc4);
+		PROF_ADD(A, 11, tc3, tc4);
+		PROF_INC(A, 12, 1);
 		// carries into the next chunk
 		const int lastIsDrawLast = wave_bcast((int)drawLast, L);
 		const int lastIsSubLast = wave_bcast((int)((cflags & VGX_CF_LAST_IN_SUB) != 0), L);
@@ -460,12 +552,17 @@ __device__ __forceinline__ MeshCtxT<VS> mesh_ctx_from(const FMesh& r, const vgx_
 }
 
 struct SegCounts { uint32_t polyVerts, numSubs, subRecs, numSerial; };
+// batch totals summed per WAVE and added to the device totals once, when the wave runs out of tickets: one atomic per
+// segment on the same cache line (a million per Tiger x10k step) serialises in the L2's atomic unit and holds up every
+// other access to that memory channel (measured: the whole kernel ran at 8.5 segments / us whatever the wave count)
+struct WaveTotals { uint64_t polyVerts, numSubs, numSerial, elems, fillElems; };
 
 template<class VS>
 __device__ __forceinline__ void fused_finish(const VgxFusedArgs& A, uint64_t seg, uint64_t numSegments, uint64_t d0, uint32_t nd, const SegCounts& sc, bool failed, int lane,
-	const VS polyBase, const VgxSegSub* s_sub, FDraw* s_draw, FMesh* s_mesh)
+	const VS polyBase, const VgxSegSub* s_sub, FDraw* s_draw, FMesh* s_mesh, WaveTotals& wt)
 {
-	uint64_t* state = A.seg_state + 4 * seg;
+	const LookState LS = look_state(A);
+	PROF_T(tM0);
 	// ---- M: mesh bases per draw, mesh records -------------------------------------------------------------------
 	uint32_t totalMeshes = 0;
 	if (!failed) {
@@ -547,23 +644,19 @@ __device__ __forceinline__ void fused_finish(const VgxFusedArgs& A, uint64_t seg
 	const uint32_t preS = ((uint32_t)lane < totalMeshes) ? inclS - (isFill ? 0u : N) : totS;
 
 	// ---- L: publish the aggregate, look back, publish the inclusive prefix -----------------------------------------
-	if (lane == 0) { granule_store(state, agg_pack(totalMeshes, totV, totI)); }
+	PROF_T(tL0);
+	PROF_ADD(A, 2, tM0, tL0);
+	fused_publish(LS, seg, lane, totalMeshes, totV, totI);
 	uint64_t baseM = 0, baseV = 0, baseI = 0;
-	if (!fused_lookback(A.seg_state, seg, lane, &baseM, &baseV, &baseI)) { fused_fail(A.totals, VGX_E_INTERNAL, VGX_FAIL_LOOKBACK_TIMEOUT, seg, 0); failed = true; }
-	if (lane == 0) {
-		granule_store(state + 1, pre0_pack(baseM + totalMeshes, baseV + totV));
-		granule_store(state + 2, pre1_pack(baseM + totalMeshes, baseI + totI));
-	}
+	if (!fused_lookback(LS, seg, numSegments, lane, &baseM, &baseV, &baseI)) { fused_fail(A.totals, VGX_E_INTERNAL, VGX_FAIL_LOOKBACK_TIMEOUT, seg, 0); failed = true; }
+	PROF_T(tE0);
+	PROF_ADD(A, 3, tL0, tE0);
 	if (baseV + totV > A.caps.vertices || baseI + totI > A.caps.indices || baseM + totalMeshes > A.caps.meshes) {
 		fused_fail(A.totals, VGX_E_NOSPACE, VGX_FAIL_OUT_CAPACITY, seg, (baseV + totV > A.caps.vertices ? 1u : 0u) | (baseI + totI > A.caps.indices ? 2u : 0u) | (baseM + totalMeshes > A.caps.meshes ? 4u : 0u));
 		failed = true;
 	}
+	wt.polyVerts += sc.polyVerts; wt.numSubs += sc.numSubs; wt.numSerial += sc.numSerial; wt.elems += totF + totS; wt.fillElems += totF;
 	if (lane == 0) { // batch totals
-		if (sc.polyVerts) { atomicAdd((unsigned long long*)&A.totals->sizes.num_poly_vertices, (unsigned long long)sc.polyVerts); }
-		if (sc.numSubs) { atomicAdd((unsigned long long*)&A.totals->sizes.num_subpaths, (unsigned long long)sc.numSubs); }
-		if (sc.numSerial) { atomicAdd((unsigned long long*)&A.totals->sizes.num_serial_draws, (unsigned long long)sc.numSerial); }
-		if (totF + totS) { atomicAdd((unsigned long long*)&A.totals->sizes.num_elements, (unsigned long long)(totF + totS)); }
-		if (totF) { atomicAdd((unsigned long long*)&A.totals->sizes.num_fill_elements, (unsigned long long)totF); }
 		if (seg + 1 == numSegments) {
 			A.totals->sizes.num_meshes = baseM + totalMeshes;
 			A.totals->sizes.num_vertices = baseV + totV;
@@ -610,6 +703,8 @@ __device__ __forceinline__ void fused_finish(const VgxFusedArgs& A, uint64_t seg
 		fill_emit_chunk(A.pos, A.color, A.idx, F);
 	}
 
+	PROF_T(tS0);
+	PROF_ADD(A, 4, tE0, tS0);
 	StrokeCarry carry;
 	carry.v = 0; carry.i = 0; carry.rails = 0;
 	for (uint32_t chunk = 0; chunk < totS; chunk += VGX_WAVE) { // polyline strokes
@@ -625,6 +720,9 @@ __device__ __forceinline__ void fused_finish(const VgxFusedArgs& A, uint64_t seg
 		const uint64_t firstV = baseV + r.vOff, firstI = baseI + r.iOff;
 		stroke_chunk(valid, lane < VGX_WAVE - 1 && e + 1 < totS, nvalid, lane, mc, r.color, A.pos + 2 * firstV, A.color + firstV, A.idx + firstI, 0u, carry);
 	}
+	PROF_T(tS1);
+	PROF_ADD(A, 5, tS0, tS1);
+	PROF_INC(A, 6, 1);
 }
 
 __global__ __launch_bounds__(VGX_WAVE) void k_tess_fused(VgxFusedArgs A)
@@ -643,11 +741,16 @@ __global__ __launch_bounds__(VGX_WAVE) void k_tess_fused(VgxFusedArgs A)
 	const uint64_t segItems = A.seg_items;
 	const uint64_t numSegments = (totalCmds + segItems - 1) / segItems;
 	if (numSegments > A.seg_cap) { return; } // k_seg_starts reported VGX_E_NOSPACE
+	WaveTotals wt;
+	wt.polyVerts = 0; wt.numSubs = 0; wt.numSerial = 0; wt.elems = 0; wt.fillElems = 0;
 
 	for (;;) {
+		PROF_T(tT0);
 		uint32_t t = 0;
 		if (lane == 0) { t = atomicAdd(A.ticket, (uint32_t)VGX_FUSED_TICKET); }
 		t = wave_bcast_u32(t, 0);
+		PROF_T(tT1);
+		PROF_ADD(A, 0, tT0, tT1);
 		if ((uint64_t)t >= numSegments) { break; }
 		const uint64_t segEnd = ((uint64_t)t + VGX_FUSED_TICKET < numSegments) ? (uint64_t)t + VGX_FUSED_TICKET : numSegments;
 		for (uint64_t seg = t; seg < segEnd; ++seg) {
@@ -660,6 +763,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_tess_fused(VgxFusedArgs A)
 			sc.polyVerts = 0; sc.numSubs = 0; sc.subRecs = 0; sc.numSerial = 0;
 			bool toHeap = false;
 			float2* heap = nullptr;
+			PROF_T(tF0);
 			if (!failed) {
 				// the segment's draws, one per lane
 				FusedWindow W;
@@ -712,16 +816,25 @@ __global__ __launch_bounds__(VGX_WAVE) void k_tess_fused(VgxFusedArgs A)
 				}
 				__syncthreads(); // window / tables written by all lanes, read by all lanes
 			}
+			PROF_T(tF1);
+			PROF_ADD(A, 1, tF0, tF1);
 			if (toHeap) {
 				__threadfence_block();
 				VtxGlobal vs; vs.p = heap;
-				fused_finish<VtxGlobal>(A, seg, numSegments, d0, nd, sc, failed, lane, vs, s_sub, s_draw, s_mesh);
+				fused_finish<VtxGlobal>(A, seg, numSegments, d0, nd, sc, failed, lane, vs, s_sub, s_draw, s_mesh, wt);
 			} else {
 				VtxLds vs; vs.p = (vgx_lds_cf2p)s_poly;
-				fused_finish<VtxLds>(A, seg, numSegments, d0, nd, sc, failed, lane, vs, s_sub, s_draw, s_mesh);
+				fused_finish<VtxLds>(A, seg, numSegments, d0, nd, sc, failed, lane, vs, s_sub, s_draw, s_mesh, wt);
 			}
 			__syncthreads(); // the next segment overwrites window and tables
 		}
+	}
+	if (lane == 0) {
+		if (wt.polyVerts) { atomicAdd((unsigned long long*)&A.totals->sizes.num_poly_vertices, (unsigned long long)wt.polyVerts); }
+		if (wt.numSubs) { atomicAdd((unsigned long long*)&A.totals->sizes.num_subpaths, (unsigned long long)wt.numSubs); }
+		if (wt.numSerial) { atomicAdd((unsigned long long*)&A.totals->sizes.num_serial_draws, (unsigned long long)wt.numSerial); }
+		if (wt.elems) { atomicAdd((unsigned long long*)&A.totals->sizes.num_elements, (unsigned long long)wt.elems); }
+		if (wt.fillElems) { atomicAdd((unsigned long long*)&A.totals->sizes.num_fill_elements, (unsigned long long)wt.fillElems); }
 	}
 }
 

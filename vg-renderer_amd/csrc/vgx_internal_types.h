@@ -117,6 +117,8 @@ struct VgxTotals
 	uint32_t fail_reason;  // VGX_FAIL_*
 	uint32_t fail_aux;
 	unsigned long long fail_segment;
+	// -DVGX_FUSED_PROFILE builds only: wave clock ticks (100 MHz) summed over all waves per phase of the fused kernel
+	unsigned long long prof[16]; // ticket, flatten, meshes, look-back, mesh table + fills, strokes, segments, lookback rounds
 };
 enum {
 	VGX_FAIL_NONE = 0,

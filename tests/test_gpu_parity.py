@@ -244,9 +244,10 @@ def test_async_very_long_subpaths(rt, wl, oracle, waves, monkeypatch):
     """Sub-paths of 30 001 vertices built from single LINE_TO commands (470 chunks each). Multi-kernel pipeline: they
     outgrow several heap blocks, are moved with geometric growth, and their total feeds the heap sizing
     (long_subpath_vertices). Fused kernel: they do not fit the LDS window, so every segment takes the heap path."""
-    if waves != "fused":
-            if waves:
-            monkeypatch.setenv("VGX_BUILD_WAVES", waves)
+    if waves == "fused":
+        monkeypatch.setenv("VGX_FUSED", "1")
+    elif waves:
+        monkeypatch.setenv("VGX_BUILD_WAVES", waves)
     gpu_ctx = rt.Context(0)
     ps, d = wl.random_walk_polylines(n=5, nseg=30000, seed=7, cap=0, join=0, width=3.0)
     d["stroke_flags"] &= ~np.uint32(rt.capi.STROKE_AA)  # 2 rails: 60 002 vertices per mesh stay below 65 536

@@ -259,6 +259,29 @@ def test_async_very_long_subpaths(rt, wl, oracle, waves, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["tiger", "fuzz", "bigcubics"])
+def test_async_pooled_walk(rt, wl, oracle, workload, monkeypatch):
+    """VGX_WALK=pool: the wave subdivides all cubics of a chunk together (task LIFO in LDS, ballot + popcount compaction,
+    leaf ranks from per-command bit masks) instead of one cubic per lane; deeper cubics fall back to the per-lane walk."""
+    monkeypatch.setenv("VGX_WALK", "pool")
+    ctx = rt.Context(0)
+    if workload == "tiger":
+        ps, d = wl.tiger(24)
+    elif workload == "fuzz":
+        ps = wl.fuzz_paths(512, npaths=200, with_shapes=False, degenerate=False)
+        d = wl.fuzz_draws(ps, 512, ndraws=1500)
+    else:
+        ps, d = wl.random_cubics(3000, seed=78, box=1000.0)
+        wl.set_fill(d, slice(None), 0xFF336699, aa=True)
+        wl.set_stroke(d, slice(None), 0xFF2080FF, 2.0, 0, 0, aa=True)
+    ref = oracle.tessellate(ps, d)
+    got = _async_result(rt, ctx, ps, d)
+    assert got.status == 0
+    assert_mesh_equal(got, ref, "pooled walk, %s" % workload)
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_async_call_is_graph_capturable(rt, gpu_ctx, wl, oracle):
     """Steady state: vgx_tessellate only enqueues kernels / memsets on the caller's stream (no allocation, no host
     sync), so a frame can be captured into a HIP graph once and replayed; the replay must reproduce the oracle."""

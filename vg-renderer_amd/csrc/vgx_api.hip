@@ -63,7 +63,7 @@ struct vgx_ctx
 	uint64_t fusedSegCap;        // segments the tables above hold
 	uint64_t* hostProbe;         // pinned
 	// options, read from the environment ONCE at vgx_create (tuning / testing knobs)
-	int optTwoPass, optNoFused, optBuildWaves, optFusedWaves;
+	int optTwoPass, optNoFused, optBuildWaves, optFusedWaves, optPoolWalk;
 	VgxCaps caps; // element capacities matching the buffers above
 	uint64_t capDraws;
 	VgxTotals* hostTotals; // pinned
@@ -466,6 +466,7 @@ VgxFlattenArgs flattenArgs(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* 
 	a.apply_transform = applyTransform;
 	a.sub_rec = (VgxSubRec*)ctx->subFirst.p;
 	a.build_mode = 0;
+	a.pool_walk = ctx->optPoolWalk;
 	a.leaf_overflow = (float*)ctx->leafOverflow.p;
 	a.serial_list = (uint32_t*)ctx->serialList.p;
 	return a;
@@ -748,6 +749,8 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	ctx->optTwoPass = getenv("VGX_TWO_PASS_FLATTEN") ? 1 : 0;
 	ctx->optNoFused = getenv("VGX_FUSED") ? 0 : 1; // the single-pass kernel is opt-in (VGX_FUSED=1): measured slower than the multi-kernel pipeline, DESIGN.md section 4
 	ctx->optBuildWaves = VGX_BUILD_WAVES;
+	ctx->optPoolWalk = 0; // VGX_WALK=pool: the wave-cooperative walk of vgx_walk.h (same output, same speed: DESIGN.md section 4)
+	if (const char* e = getenv("VGX_WALK")) { ctx->optPoolWalk = strcmp(e, "pool") == 0; }
 	if (const char* e = getenv("VGX_BUILD_WAVES")) { const int v = atoi(e); if (v >= 1 && v < VGX_BUILD_WAVES) { ctx->optBuildWaves = v; } }
 	{
 		int cus = 256;

@@ -348,10 +348,15 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 //     mesh descriptors in the reference's call order.
 // Degenerate / serial draws are flagged exactly as in the two-pass kernel and handled by k_flatten_serial.
 // ------------------------------------------------------------------------------------------------
+// POOL: the cubics of a chunk are subdivided by the whole wave together (pool_sweep, vgx_walk.h) instead of one cubic per
+// lane in lock-step; same LDS footprint (the pool's task LIFO takes the place of the per-lane stack + leaf slots).
+template<bool POOL>
 __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 {
-	__shared__ float2 s_stack[VGX_LDS_LEVELS * 3 * VGX_WAVE];
-	__shared__ float2 s_leaf[VGX_LEAF_SLOTS * VGX_WAVE];
+	__shared__ __attribute__((aligned(16))) unsigned char s_mem[(VGX_LDS_LEVELS * 3 + VGX_LEAF_SLOTS) * VGX_WAVE * 8 > VGX_POOL_BYTES ? (VGX_LDS_LEVELS * 3 + VGX_LEAF_SLOTS) * VGX_WAVE * 8 : VGX_POOL_BYTES];
+	float2* s_stack = (float2*)s_mem;                            // per-lane walk: pending stack, then the leaf slots
+	float2* s_leaf = s_stack + VGX_LDS_LEVELS * 3 * VGX_WAVE;
+	const PoolLds pool = pool_carve(s_mem);                      // pooled walk: the same memory
 	const int lane = threadIdx.x;
 	LdsStack stack;
 	stack.base = &s_stack[lane];
@@ -444,29 +449,56 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 				int cnt = 0;
 				bool slow = false, exists = false, closedHere = false;
 				float c1x = a[0], c1y = a[1], c2x = a[2], c2y = a[3], ex = a[4], ey = a[5];
+				const bool isCubic = valid && !serialDraw && (type == VGX_CMD_CUBIC_TO || type == VGX_CMD_QUAD_TO);
+				if (isCubic && type == VGX_CMD_QUAD_TO) {
+					ex = a[2]; ey = a[3];
+					vgx_quad_to_cubic(start.x, start.y, a[0], a[1], ex, ey, &c1x, &c1y, &c2x, &c2y);
+				}
+				const float tessTol = tol / (scale * scale);
+				v2f q1, q2, q3, q4;
+				q1.x = start.x; q1.y = start.y; q2.x = c1x; q2.y = c1y; q3.x = c2x; q3.y = c2y; q4.x = ex; q4.y = ey;
+				bool poolDeep = false; // POOL: my cubic left the pooled path (deeper than VGX_POOL_MAXD / lists full)
+				uint32_t poolMask = 0;
+				int poolLeaves = 0;
+				if (POOL) {
+					const uint64_t rootMask = wave_ballot(isCubic);
+					if (rootMask) {
+						poolLeaves = pool_walk(pool, lane, rootMask, q1, q2, q3, q4, tessTol);
+						if (isCubic) {
+							const uint32_t fl = pool.flags[lane];
+							poolDeep = (fl & VGX_POOL_F_DEEP) != 0;
+							poolMask = pool.mask[lane];
+							cnt = __popc(poolMask);
+							slow = (fl & VGX_POOL_F_SLOW) != 0;
+						}
+					}
+				}
 				if (valid && !serialDraw) {
 					switch (type) {
 					case VGX_CMD_MOVE_TO: cnt = 1; exists = true; break;
 					case VGX_CMD_LINE_TO: cnt = 1; slow = v2near(start, v2(a[0], a[1])); break;
 					case VGX_CMD_CUBIC_TO:
 					case VGX_CMD_QUAD_TO: {
-						if (type == VGX_CMD_QUAD_TO) {
-							ex = a[2]; ey = a[3];
-							vgx_quad_to_cubic(start.x, start.y, a[0], a[1], ex, ey, &c1x, &c1y, &c2x, &c2y);
+						if (POOL) {
+							if (poolDeep) { // count with the per-lane walk; the emit below walks it again, straight to memory
+								FastCubicSink<false, false> sink;
+								sink.prev = start; sink.n = 0; sink.slow = false;
+								wave_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tessTol, stack, sink);
+								cnt = (int)sink.n;
+								slow = sink.slow;
+							}
+						} else {
+							float2* over = (float2*)A.leaf_overflow + (size_t)blockIdx.x * VGX_BUILD_OVERFLOW * VGX_WAVE + lane;
+							uint32_t nLeaves = 0;
+							if (!build_flatten_hot<VGX_LDS_LEVELS>(q1, q2, q3, q4, tessTol, &s_stack[lane], &s_leaf[lane], over, &nLeaves, &slow)) {
+								BuildCubicSink sink; // nests deeper than the LDS levels: full-depth walk from the root
+								sink.prev = start; sink.n = 0; sink.slow = false; sink.slots = &s_leaf[lane]; sink.over = over;
+								vgx_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tessTol, stack, sink);
+								nLeaves = sink.n;
+								slow = sink.slow;
+							}
+							cnt = (int)nLeaves;
 						}
-						float2* over = (float2*)A.leaf_overflow + (size_t)blockIdx.x * VGX_BUILD_OVERFLOW * VGX_WAVE + lane;
-						const float tessTol = tol / (scale * scale);
-						uint32_t nLeaves = 0;
-						v2f q1, q2, q3, q4;
-						q1.x = start.x; q1.y = start.y; q2.x = c1x; q2.y = c1y; q3.x = c2x; q3.y = c2y; q4.x = ex; q4.y = ey;
-						if (!build_flatten_hot<VGX_LDS_LEVELS>(q1, q2, q3, q4, tessTol, &s_stack[lane], &s_leaf[lane], over, &nLeaves, &slow)) {
-							BuildCubicSink sink; // nests deeper than the LDS levels: full-depth walk from the root
-							sink.prev = start; sink.n = 0; sink.slow = false; sink.slots = &s_leaf[lane]; sink.over = over;
-							vgx_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tessTol, stack, sink);
-							nLeaves = sink.n;
-							slow = sink.slow;
-						}
-						cnt = (int)nLeaves;
 					} break;
 					case VGX_CMD_POLYLINE: {
 						const uint32_t npts = na >> 1;
@@ -536,13 +568,18 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 				}
 				{
 					const uint64_t g = cur + (uint64_t)excl; // heap index of my first vertex
+					// my last vertex is the one pathClose removes (same decision the CLOSE lane takes)
+					uint32_t limit = (valid && !serialDraw) ? (uint32_t)(rawCnt < 0 ? 0 : rawCnt) : 0u;
+					if ((cflags & VGX_CF_NEXT_IS_CLOSE) && limit > 0 && spTotal > 2) {
+						const V2 endp = (type == VGX_CMD_POLYLINE) ? v2(pa[na - 2], pa[na - 1]) : (type == VGX_CMD_CUBIC_TO ? v2(a[4], a[5]) : (type == VGX_CMD_QUAD_TO ? v2(a[2], a[3]) : v2(a[0], a[1])));
+						if (v2near(endp, v2(rec.a[6], rec.a[7]))) { --limit; }
+					}
+					if (POOL && poolLeaves > 0) { // the listed leaves go straight to their places in the heap
+						PoolOutGlobal o;
+						o.p = (float2*)A.poly + cur - 64; // excl is -1 at most (a pathClose pop at the chunk's start)
+						pool_place(pool, lane, poolLeaves, poolMask, isCubic && !poolDeep, (uint32_t)(excl + 64), limit, mtx, o);
+					}
 					if (valid && !serialDraw) {
-						// my last vertex is the one pathClose removes (same decision the CLOSE lane takes)
-						uint32_t limit = (uint32_t)(rawCnt < 0 ? 0 : rawCnt);
-						if ((cflags & VGX_CF_NEXT_IS_CLOSE) && limit > 0 && spTotal > 2) {
-							const V2 endp = (type == VGX_CMD_POLYLINE) ? v2(pa[na - 2], pa[na - 1]) : (type == VGX_CMD_CUBIC_TO ? v2(a[4], a[5]) : (type == VGX_CMD_QUAD_TO ? v2(a[2], a[3]) : v2(a[0], a[1])));
-							if (v2near(endp, v2(rec.a[6], rec.a[7]))) { --limit; }
-						}
 						float* out = A.poly + 2 * g;
 						if (type == VGX_CMD_MOVE_TO || type == VGX_CMD_LINE_TO) {
 							if (limit > 0) {
@@ -550,7 +587,13 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 								*(float2*)out = make_float2(p.x, p.y);
 							}
 						} else if (type == VGX_CMD_CUBIC_TO || type == VGX_CMD_QUAD_TO) {
-							if ((uint32_t)rawCnt <= VGX_LEAF_SLOTS + VGX_BUILD_OVERFLOW) {
+							if (POOL) {
+								if (poolDeep) {
+									FastCubicSink<true, true> sink;
+									sink.prev = start; sink.n = 0; sink.slow = false; sink.out = out; sink.writeLimit = limit; sink.mtx = mtx;
+									wave_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tol / (scale * scale), stack, sink);
+								}
+							} else if ((uint32_t)rawCnt <= VGX_LEAF_SLOTS + VGX_BUILD_OVERFLOW) {
 								const uint32_t nl = limit < VGX_LEAF_SLOTS ? limit : VGX_LEAF_SLOTS;
 								for (uint32_t i = 0; i < nl; ++i) {
 									const float2 q = s_leaf[i * VGX_WAVE + lane];
@@ -740,7 +783,11 @@ void vgx_launch_flatten_build(const VgxFlattenArgs& a, int waves, hipStream_t s)
 {
 	// waves < VGX_BUILD_WAVES is a testing knob (VGX_BUILD_WAVES in the environment at vgx_create): a handful of waves makes
 	// small batches run through the heap's block switches and sub-path moves that otherwise need > 8192 vertices per wave
-	hipLaunchKernelGGL(k_flatten_build, dim3(waves), dim3(VGX_WAVE), 0, s, a);
+	if (a.pool_walk) {
+		hipLaunchKernelGGL(k_flatten_build<true>, dim3(waves), dim3(VGX_WAVE), 0, s, a);
+	} else {
+		hipLaunchKernelGGL(k_flatten_build<false>, dim3(waves), dim3(VGX_WAVE), 0, s, a);
+	}
 	hipLaunchKernelGGL((k_flatten_serial<false, false>), dim3(1024), dim3(256), 0, s, a); // count + heap allocation
 }
 

@@ -30,6 +30,7 @@ struct VgxFlattenArgs
 	int build_mode;                // k_flatten_serial<count>: allocate the draw's vertices from the polyline heap
 	uint32_t* serial_list;         // BUILD mode: draws for k_flatten_serial (static serial paths + degenerate draws), unordered
 	float* leaf_overflow;          // [VGX_BUILD_WAVES][VGX_BUILD_OVERFLOW][64][2] leaves that did not fit the LDS slots
+	int pool_walk;                 // k_flatten_build: pooled cubic walk (vgx_walk.h) instead of one cubic per lane
 };
 
 struct VgxStrokeArgs

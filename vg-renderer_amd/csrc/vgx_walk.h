@@ -213,6 +213,163 @@ __device__ __forceinline__ bool build_flatten_hot(v2f P1, v2f P2, v2f P3, v2f P4
 	return !aborted;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pooled cubic walk: the wave subdivides ALL cubics of a 64-command chunk together.
+//
+// The per-lane walk above runs in lock-step: a chunk costs as many iterations as its deepest cubic needs while most
+// lanes (MOVE_TO / LINE_TO / CLOSE commands, one-segment cubics) idle -- 31 % lane use on the Tiger workload, ~100
+// instructions per iteration. Here every curve piece is a TASK on a LIFO in LDS: a round pops up to 64 tasks (one per
+// lane), tests flatness (path.cpp:105-116, same expressions in the same order), appends the flat pieces' end points to
+// a leaf list and pushes the two halves of the others, all at positions given by ballot + popcount (the wavefront-
+// level compaction of north_star). Rounds are full except at the tail of a chunk; the subdivision arithmetic is
+// untouched, so the leaves are bit-identical.
+//
+// Order: a piece at depth d reached by the left/right decisions `path` (d bits) covers the dyadic interval
+// [path << (MAXD - d), (path + 1) << (MAXD - d)) of its cubic; a leaf sets bit (path << (MAXD - d)) in its command's
+// 32-bit mask (ds_or). Afterwards a command has popcount(mask) vertices and the rank of a leaf is the popcount of the
+// mask below its bit: pool_place writes every listed leaf, transformed, straight to its final place (the owner lane's
+// base / limit / transform come through shuffles). No per-lane leaf slots, no global overflow area, no copy loop.
+// Off the pooled path (per-lane walk, two passes: count, then emit to the final place): cubics that are still not flat
+// at depth VGX_POOL_MAXD, and whatever does not fit the task LIFO or the leaf list. pathAddVertex's epsilon test
+// (path.cpp:769-775) compares a leaf with the previous vertex, which is the piece's own first point.
+// ------------------------------------------------------------------------------------------------
+#define VGX_POOL_CAP 160      /* tasks; the first 6144 bytes double as the per-lane walk's LDS stack */
+#define VGX_POOL_LEAVES 224   /* leaf list entries */
+#define VGX_POOL_MAXD 5
+#define VGX_POOL_F_DEEP 1u
+#define VGX_POOL_F_SLOW 2u
+
+struct __attribute__((aligned(8))) PoolTaskTail { uint32_t meta; float tol; }; // owner lane | depth << 6 | path << 9
+
+struct PoolLds // the wave's pool memory (VGX_POOL_BYTES of LDS, 16-byte aligned)
+{
+	float4* task;       // [CAP][2] {P1, P2} {P3, P4}
+	PoolTaskTail* tail; // [CAP]
+	float2* leaf;       // [LEAVES] end point of a flat piece (untransformed)
+	uint32_t* leafMeta; // [LEAVES] owner lane | start << 6
+	uint32_t* mask;     // [64] leaf-start bits of the lane's cubic
+	uint32_t* flags;    // [64] VGX_POOL_F_*
+};
+#define VGX_POOL_BYTES (VGX_POOL_CAP * 40 + VGX_POOL_LEAVES * 12 + 2 * 256)
+
+__device__ __forceinline__ PoolLds pool_carve(unsigned char* mem)
+{
+	PoolLds L;
+	L.task = (float4*)mem;
+	L.tail = (PoolTaskTail*)(mem + VGX_POOL_CAP * 32);
+	L.leaf = (float2*)(mem + VGX_POOL_CAP * 40);
+	L.leafMeta = (uint32_t*)(mem + VGX_POOL_CAP * 40 + VGX_POOL_LEAVES * 8);
+	L.mask = L.leafMeta + VGX_POOL_LEAVES;
+	L.flags = L.mask + 64;
+	return L;
+}
+
+// Subdivides the cubics of the lanes in rootMask (root control points P1..P4 and tessTol of my lane's cubic). Fills the
+// leaf list, mask[] and flags[] (both zeroed here). Returns the number of listed leaves.
+__device__ __forceinline__ int pool_walk(const PoolLds& L, int lane, uint64_t rootMask, v2f P1r, v2f P2r, v2f P3r, v2f P4r, float tolr)
+{
+	int top = __popcll(rootMask), leaves = 0;
+	L.mask[lane] = 0; L.flags[lane] = 0;
+	if ((rootMask >> lane) & 1ull) {
+		const int ti = __popcll(rootMask & lanemask_lt(lane));
+		L.task[2 * ti] = make_float4(P1r.x, P1r.y, P2r.x, P2r.y);
+		L.task[2 * ti + 1] = make_float4(P3r.x, P3r.y, P4r.x, P4r.y);
+		PoolTaskTail t; t.meta = (uint32_t)lane; t.tol = tolr;
+		L.tail[ti] = t;
+	}
+	__syncthreads(); // one-wave workgroup: LDS wait only
+	while (top > 0) {
+		const int n = top < VGX_WAVE ? top : VGX_WAVE;
+		const bool active = lane < n;
+		const int ti = top - 1 - lane;
+		float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a;
+		PoolTaskTail tt; tt.meta = 0; tt.tol = 0.0f;
+		if (active) { a = L.task[2 * ti]; b = L.task[2 * ti + 1]; tt = L.tail[ti]; }
+		const uint32_t cl = tt.meta & 63u, depth = (tt.meta >> 6) & 7u, path = tt.meta >> 9;
+		v2f P1, P2, P3, P4;
+		P1.x = a.x; P1.y = a.y; P2.x = a.z; P2.y = a.w; P3.x = b.x; P3.y = b.y; P4.x = b.z; P4.y = b.w;
+		// flatness (path.cpp:105-116) and de Casteljau halves (:118-129), as in build_flatten_hot
+		const v2f d = P4 - P1;
+		const v2f a2 = P2 - P4, a3 = P3 - P4;
+		const v2f dsw = d.yx;
+		const v2f m2 = a2 * dsw, m3 = a3 * dsw;
+		const float d2 = __builtin_fabsf(m2.x - m2.y), d3 = __builtin_fabsf(m3.x - m3.y);
+		const float d23 = d2 + d3;
+		const v2f dd = d * d;
+		const bool flat = d23 * d23 <= tt.tol * (dd.x + dd.y);
+		const v2f P12 = (P1 + P2) * 0.5f, P23 = (P2 + P3) * 0.5f, P34 = (P3 + P4) * 0.5f;
+		const v2f P123 = (P12 + P23) * 0.5f, P234 = (P23 + P34) * 0.5f;
+		const v2f P1234 = (P123 + P234) * 0.5f;
+		const bool isLeaf = active && flat;
+		bool split = active && !flat && depth < VGX_POOL_MAXD;
+		const int newBase = top - n;
+		if (split && newBase + 2 * (int)__popcll(wave_ballot(split) & lanemask_le(lane)) > VGX_POOL_CAP) { split = false; } // no room
+		const uint64_t splitMask = wave_ballot(split);
+		const uint64_t leafMask = wave_ballot(isLeaf);
+		const int li = leaves + (int)__popcll(leafMask & lanemask_lt(lane));
+		const bool listed = isLeaf && li < VGX_POOL_LEAVES;
+		const uint32_t start = path << (VGX_POOL_MAXD - depth);
+		if (listed) {
+			L.leaf[li] = make_float2(P4.x, P4.y);
+			L.leafMeta[li] = cl | (start << 6);
+			atomicOr(&L.mask[cl], 1u << start);
+			const v2f e = P1 - P4;
+			const v2f ee = e * e;
+			if (ee.x + ee.y < VGM_EPSILON) { atomicOr(&L.flags[cl], VGX_POOL_F_SLOW); }
+		}
+		if (active && ((!flat && !split) || (isLeaf && !listed))) { atomicOr(&L.flags[cl], VGX_POOL_F_DEEP); } // to the per-lane walk
+		if (split) {
+			const int pp = newBase + 2 * (int)__popcll(splitMask & lanemask_lt(lane));
+			const uint32_t cm = cl | ((depth + 1) << 6);
+			L.task[2 * pp] = make_float4(P1.x, P1.y, P12.x, P12.y);
+			L.task[2 * pp + 1] = make_float4(P123.x, P123.y, P1234.x, P1234.y);
+			L.task[2 * pp + 2] = make_float4(P1234.x, P1234.y, P234.x, P234.y);
+			L.task[2 * pp + 3] = make_float4(P34.x, P34.y, P4.x, P4.y);
+			PoolTaskTail t0, t1;
+			t0.meta = cm | ((path << 1) << 9); t0.tol = tt.tol;
+			t1.meta = cm | (((path << 1) | 1u) << 9); t1.tol = tt.tol;
+			L.tail[pp] = t0;
+			L.tail[pp + 1] = t1;
+		}
+		top = newBase + 2 * (int)__popcll(splitMask);
+		leaves += (int)__popcll(leafMask);
+		__syncthreads();
+	}
+	return leaves < VGX_POOL_LEAVES ? leaves : VGX_POOL_LEAVES;
+}
+
+// Writes the listed leaves to their final places. Per OWNER lane (in registers): mask / pooled (a cubic that stayed on the
+// pooled path) / base (first vertex of the command, any consistent origin) / limit (vertices [0, limit) are written)
+// / mtx (the draw's transform). out.put(index, transformed point).
+template<class OUT>
+__device__ __forceinline__ void pool_place(const PoolLds& L, int lane, int leaves, uint32_t mask, bool pooled, uint32_t base, uint32_t limit, const float* mtx, OUT& out)
+{
+	const float m0 = mtx[0], m1 = mtx[1], m2 = mtx[2], m3 = mtx[3], m4 = mtx[4], m5 = mtx[5];
+	const uint32_t lim = pooled ? limit : 0u;
+	for (int l0 = 0; l0 < leaves; l0 += VGX_WAVE) {
+		const int li = l0 + lane;
+		const bool valid = li < leaves;
+		float2 q = make_float2(0.0f, 0.0f);
+		uint32_t lm = 0;
+		if (valid) { q = L.leaf[li]; lm = L.leafMeta[li]; }
+		const int cl = (int)(lm & 63u);
+		const uint32_t start = lm >> 6;
+		const uint32_t om = (uint32_t)__shfl((int)mask, cl), ob = (uint32_t)__shfl((int)base, cl), ol = (uint32_t)__shfl((int)lim, cl);
+		const float t0 = __shfl(m0, cl), t1 = __shfl(m1, cl), t2 = __shfl(m2, cl), t3 = __shfl(m3, cl), t4 = __shfl(m4, cl), t5 = __shfl(m5, cl);
+		const uint32_t rank = (uint32_t)__popc(om & ((1u << start) - 1u));
+		if (valid && rank < ol) {
+			// transformPos2D, vg_util.h:24-28: (m0 * x + m2 * y) + m4
+			out.put(ob + rank, v2(t0 * q.x + t2 * q.y + t4, t1 * q.x + t3 * q.y + t5));
+		}
+	}
+}
+
+struct PoolOutGlobal // destination: polyline heap
+{
+	float2* p;
+	__device__ __forceinline__ void put(uint32_t i, V2 v) const { p[i] = make_float2(v.x, v.y); }
+};
+
 } // namespace
 
 #endif

@@ -11,7 +11,9 @@
 //   - command grammar the reference leaves undefined (lineTo before moveTo, appending to a closed sub-path) yields an
 //     empty path instead of undefined behaviour; NaN/Inf arguments likewise (they hang the reference, path.cpp:109);
 //   - the bx transcendentals are the pinned ones of csrc/vgmath.h;
-//   - strokerConcaveFill* (libtess2) is not provided (out of scope).
+//   - strokerConcaveFill* need the host's libtess2 (the reference vendors it under src/libtess2 and links it into the same
+//     binary): hand its eight entry points over once with vgxCompatSetTessellator(); libtess2 itself stays on the CPU, the
+//     stroker's own fringe / rebase loops of strokerConcaveFillEndAA run on the device (vgx_concave_move / _emit).
 #ifndef VGX_COMPAT_HPP
 #define VGX_COMPAT_HPP
 
@@ -26,6 +28,7 @@ typedef uint32_t Color;
 struct LineCap { enum Enum : uint32_t { Butt = 0, Round = 1, Square = 2 }; };
 struct LineJoin { enum Enum : uint32_t { Miter = 0, Round = 1, Bevel = 2 }; };
 struct Winding { enum Enum : uint32_t { CCW = 0, CW = 1 }; };
+struct FillRule { enum Enum : uint32_t { NonZero = 0, EvenOdd = 1 }; };
 struct Mesh
 {
 	const float* m_PosBuffer;
@@ -81,7 +84,31 @@ void strokerPolylineStrokeAAThin(Stroker* stroker, Mesh* mesh, const float* vert
 void strokerConvexFill(Stroker* stroker, Mesh* mesh, const float* vertexList, uint32_t numVertices);
 void strokerConvexFillAA(Stroker* stroker, Mesh* mesh, const float* vertexList, uint32_t numVertices, uint32_t color);
 
+// include/vg/stroker.h:73-85. false (and *mesh untouched) when no tessellator was set or libtess2 fails.
+bool strokerConcaveFillBegin(Stroker* stroker);
+void strokerConcaveFillAddContour(Stroker* stroker, const float* vertexList, uint32_t numVertices);
+bool strokerConcaveFillEnd(Stroker* stroker, Mesh* mesh, FillRule::Enum fillRule);
+bool strokerConcaveFillEndAA(Stroker* stroker, Mesh* mesh, uint32_t color, FillRule::Enum fillRule);
+
 // ---- not in the reference ----
+// The host's libtess2: the eight functions of src/libtess2/tesselator.h that src/stroker.cpp:809-1006 calls, with their
+// own signatures (TESStesselator* and TESSalloc* as void*). Typical binding:
+//   static const vg::VgxTessApi api = { (void* (*)(void*))tessNewTess, (void (*)(void*))tessDeleteTess, (void (*)(void*, int, const void*, int, int))tessAddContour,
+//       (int (*)(void*, int, int, int, int, const float*))tessTesselate, (int (*)(void*))tessGetVertexCount, (const float* (*)(void*))tessGetVertices,
+//       (int (*)(void*))tessGetElementCount, (const unsigned short* (*)(void*))tessGetElements };
+//   vg::vgxCompatSetTessellator(&api);
+struct VgxTessApi
+{
+	void* (*newTess)(void* alloc);
+	void (*deleteTess)(void* tess);
+	void (*addContour)(void* tess, int size, const void* pointer, int stride, int count);
+	int (*tesselate)(void* tess, int windingRule, int elementType, int polySize, int vertexSize, const float* normal);
+	int (*getVertexCount)(void* tess);
+	const float* (*getVertices)(void* tess);
+	int (*getElementCount)(void* tess);
+	const unsigned short* (*getElements)(void* tess);
+};
+void vgxCompatSetTessellator(const VgxTessApi* api); // copied; nullptr removes it
 // Device used by subsequently created Path / Stroker objects (default 0). Last status of an object (vgx_status).
 void vgxCompatSetDevice(int device);
 int vgxCompatLastStatus(const Path* path);

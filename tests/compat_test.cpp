@@ -7,6 +7,8 @@
 #include <stdio.h>
 #include <string.h>
 #include <vector>
+#include <dlfcn.h>
+#include <math.h>
 
 static uint32_t g_rng = 12345u;
 static float frand(float lo, float hi) { g_rng = g_rng * 1664525u + 1013904223u; return lo + (hi - lo) * (float)((g_rng >> 8) & 0xFFFFFF) / 16777216.0f; }
@@ -118,6 +120,63 @@ int main()
 		vg::pathReset(gp, 1.0f, 0.25f);
 		vg::pathLineTo(gp, 1, 1);
 		CHECK(vg::pathGetNumVertices(gp) == 0 && vg::vgxCompatLastStatus(gp) == 2, "lineTo before moveTo");
+	}
+	// concave fills (stroker.h:73-85): the host's libtess2 = the one inside oracle/_ref/libvgref.so (dlopen'ed privately: that
+	// library also holds the reference's own vg::strokerConcaveFill*, reached through its C wrapper vgo_concave_fill_aa)
+	{
+		const char* refPath = getenv("VGX_TEST_LIBVGREF");
+		void* h = refPath ? dlopen(refPath, RTLD_NOW | RTLD_LOCAL) : nullptr;
+		if (!h) {
+			printf("concave: skipped (no oracle/_ref/libvgref.so)\n");
+		} else {
+			vg::VgxTessApi api;
+			api.newTess = (void* (*)(void*))dlsym(h, "tessNewTess");
+			api.deleteTess = (void (*)(void*))dlsym(h, "tessDeleteTess");
+			api.addContour = (void (*)(void*, int, const void*, int, int))dlsym(h, "tessAddContour");
+			api.tesselate = (int (*)(void*, int, int, int, int, const float*))dlsym(h, "tessTesselate");
+			api.getVertexCount = (int (*)(void*))dlsym(h, "tessGetVertexCount");
+			api.getVertices = (const float* (*)(void*))dlsym(h, "tessGetVertices");
+			api.getElementCount = (int (*)(void*))dlsym(h, "tessGetElementCount");
+			api.getElements = (const unsigned short* (*)(void*))dlsym(h, "tessGetElements");
+			typedef int (*RefFn)(const float*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, float, int, float*, uint32_t*, uint16_t*, uint32_t, uint32_t, uint32_t*, uint32_t*);
+			RefFn refFill = (RefFn)dlsym(h, "vgo_concave_fill_aa");
+			CHECK(api.newTess && api.tesselate && refFill, "libvgref.so symbols");
+			vg::vgxCompatSetTessellator(&api);
+			for (int iter = 0; iter < 12 && refFill; ++iter) {
+				// a star with a hole (opposite winding) and, every other time, a self-intersecting polygon
+				std::vector<float> v;
+				std::vector<uint32_t> first, count;
+				const int pts = 5 + (int)irand(6);
+				const float cx = frand(50, 500), cy = frand(50, 500), r0 = frand(40, 120), r1 = r0 * frand(0.3f, 0.7f);
+				first.push_back(0); count.push_back(2 * pts);
+				for (int k = 0; k < 2 * pts; ++k) { const float a = 3.14159265f * k / pts, r = (k & 1) ? r1 : r0; v.push_back(cx + r * cosf(a)); v.push_back(cy + r * sinf(a)); }
+				first.push_back((uint32_t)(v.size() / 2)); count.push_back(8);
+				for (int k = 0; k < 8; ++k) { const float a = -6.2831853f * k / 8, r = r1 * 0.5f; v.push_back(cx + r * cosf(a)); v.push_back(cy + r * sinf(a)); }
+				if (iter & 1) {
+					first.push_back((uint32_t)(v.size() / 2)); count.push_back(5);
+					for (int k = 0; k < 5; ++k) { const float a = 6.2831853f * (2 * k % 5) / 5, r = r0 * 0.9f; v.push_back(cx + 30 + r * cosf(a)); v.push_back(cy - 20 + r * sinf(a)); }
+				}
+				const float fringe = (iter % 3 == 0) ? 0.5f : 1.0f;
+				const uint32_t color = 0xC0000000u | (g_rng & 0xFFFFFFu);
+				const int evenOdd = (iter >> 1) & 1;
+				vg::strokerReset(gs, 1.0f, 0.25f, fringe);
+				CHECK(vg::strokerConcaveFillBegin(gs), "concave begin");
+				for (size_t c = 0; c < first.size(); ++c) { vg::strokerConcaveFillAddContour(gs, &v[2 * first[c]], count[c]); }
+				vg::Mesh gm; memset(&gm, 0, sizeof(gm));
+				CHECK(vg::strokerConcaveFillEndAA(gs, &gm, color, evenOdd ? vg::FillRule::EvenOdd : vg::FillRule::NonZero), "concave endAA status %d", vg::vgxCompatLastStatus(gs));
+				std::vector<float> rp(65536 * 2); std::vector<uint32_t> rc(65536); std::vector<uint16_t> ri(65536 * 6);
+				uint32_t rnv = 0, rni = 0;
+				CHECK(refFill(v.data(), first.data(), count.data(), (uint32_t)first.size(), color, fringe, evenOdd, rp.data(), rc.data(), ri.data(), 65536, 65536 * 6, &rnv, &rni) == 0, "reference concave fill");
+				vg::Mesh rm; rm.m_PosBuffer = rp.data(); rm.m_ColorBuffer = rc.data(); rm.m_IndexBuffer = ri.data(); rm.m_NumVertices = rnv; rm.m_NumIndices = rni;
+				compareMesh(gm, rm, false, "concaveFillAA");
+				// the non-AA variant is libtess2 alone: same library on both sides, must agree trivially
+				CHECK(vg::strokerConcaveFillBegin(gs), "concave begin");
+				for (size_t c = 0; c < first.size(); ++c) { vg::strokerConcaveFillAddContour(gs, &v[2 * first[c]], count[c]); }
+				CHECK(vg::strokerConcaveFillEnd(gs, &gm, vg::FillRule::NonZero) && gm.m_NumVertices > 0 && gm.m_ColorBuffer == nullptr, "concave end");
+			}
+			vg::strokerConcaveFillBegin(gs); // drops the tessellator's last result before the library goes away
+			vg::vgxCompatSetTessellator(nullptr);
+		}
 	}
 	vg::destroyStroker(gs); vg::destroyPath(gp);
 	vgo::destroyStroker(os); vgo::destroyPath(op);

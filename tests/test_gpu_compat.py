@@ -15,8 +15,12 @@ def test_compat_layer_matches_oracle(oracle):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tests", "compat_test.cpp"),
                            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "oracle"), "-I" + os.path.join(ROOT, "oracle", "bx_shim"),
                            "-I" + os.path.join(PKG, "csrc"), "-L" + PKG, "-lvgx_compat", "-lvgx", "-L" + os.path.join(ROOT, "oracle"), "-lvgoracle",
-                           "-Wl,-rpath," + PKG, "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
-    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+                           "-ldl", "-Wl,-rpath," + PKG, "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
+    env = dict(os.environ)
+    libref = os.path.join(ROOT, "oracle", "_ref", "libvgref.so")
+    if os.path.exists(libref):  # concave fills: libtess2 + the reference's strokerConcaveFillEndAA live in there
+        env["VGX_TEST_LIBVGREF"] = libref
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env)
     print(r.stdout)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "OK:" in r.stdout

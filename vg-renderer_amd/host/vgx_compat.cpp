@@ -12,6 +12,10 @@ namespace vg
 namespace {
 
 int g_device = 0;
+VgxTessApi g_tess = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+bool g_hasTess = false;
+// libtess2's public constants (src/libtess2/tesselator.h:41-48, 110-115)
+enum { kTessWindingOdd = 0, kTessWindingNonZero = 1, kTessPolygons = 0, kTessBoundaryContours = 2 };
 
 struct DevBuf
 {
@@ -165,6 +169,9 @@ struct Stroker
 	std::vector<uint32_t> col;
 	std::vector<uint16_t> idx;
 	DevBuf dPoly, dSub, dSubDraw, dDraw, dPos, dCol, dIdx;
+	void* tess = nullptr;                    // strokerConcaveFill*: the host's libtess2 object
+	DevBuf dContour, dCont, dFill, dMoved, dTessPos, dTessIdx;
+	std::vector<float> moved;
 
 	// One strokerXXX call = one vertex list, one op.
 	void run(Mesh* mesh, const float* vertexList, uint32_t n, bool closed, const vgx_draw& d, bool wantColor, bool aliasPos)
@@ -220,6 +227,7 @@ Stroker* createStroker(bx::AllocatorI*)
 void destroyStroker(Stroker* s)
 {
 	if (!s) { return; }
+	if (s->tess && g_hasTess) { g_tess.deleteTess(s->tess); }
 	vgx_ctx* c = s->ctx;
 	delete s;
 	(void)vgx_destroy(c);
@@ -273,5 +281,99 @@ void strokerConvexFillAA(Stroker* s, Mesh* mesh, const float* vertexList, uint32
 	d.fill_flags = VGX_FILL_ENABLE | VGX_FILL_AA;
 	d.fill_color = color;
 	s->run(mesh, vertexList, n, false, d, true, false);
+}
+
+// ---- concave fills (include/vg/stroker.h:73-85, src/stroker.cpp:809-1006) ---------------------------------------------
+void vgxCompatSetTessellator(const VgxTessApi* api)
+{
+	g_hasTess = api && api->newTess && api->deleteTess && api->addContour && api->tesselate && api->getVertexCount && api->getVertices && api->getElementCount && api->getElements;
+	if (g_hasTess) { g_tess = *api; }
+}
+
+bool strokerConcaveFillBegin(Stroker* s) // stroker.cpp:809-845 (the scratch allocator is the host library's business)
+{
+	if (!g_hasTess) { s->status = VGX_E_INVALID_ARG; return false; }
+	if (s->tess) { g_tess.deleteTess(s->tess); }
+	s->tess = g_tess.newTess(nullptr);
+	return s->tess != nullptr;
+}
+
+void strokerConcaveFillAddContour(Stroker* s, const float* vertexList, uint32_t numVertices) // stroker.cpp:847-850
+{
+	if (s->tess) { g_tess.addContour(s->tess, 2, vertexList, (int)(sizeof(float) * 2), (int)numVertices); }
+}
+
+bool strokerConcaveFillEnd(Stroker* s, Mesh* mesh, FillRule::Enum fillRule) // stroker.cpp:852-866: libtess2 only
+{
+	if (!s->tess) { return false; }
+	if (!g_tess.tesselate(s->tess, fillRule == FillRule::NonZero ? kTessWindingNonZero : kTessWindingOdd, kTessPolygons, 3, 2, nullptr)) { return false; }
+	mesh->m_PosBuffer = g_tess.getVertices(s->tess);
+	mesh->m_ColorBuffer = nullptr;
+	mesh->m_IndexBuffer = g_tess.getElements(s->tess);
+	mesh->m_NumVertices = (uint32_t)g_tess.getVertexCount(s->tess);
+	mesh->m_NumIndices = (uint32_t)g_tess.getElementCount(s->tess) * 3;
+	return true;
+}
+
+bool strokerConcaveFillEndAA(Stroker* s, Mesh* mesh, uint32_t color, FillRule::Enum fillRule) // stroker.cpp:868-1006
+{
+	if (!s->tess) { return false; }
+	const int rule = fillRule == FillRule::NonZero ? kTessWindingNonZero : kTessWindingOdd;
+	const float normal[3] = { 0.0f, 0.0f, 1.0f };
+	s->status = VGX_OK;
+	// (1) boundary contours: libtess2, CPU
+	if (!g_tess.tesselate(s->tess, rule, kTessBoundaryContours, 1, 2, normal)) { return false; }
+	const float* contourVerts = g_tess.getVertices(s->tess);
+	const unsigned short* contourData = g_tess.getElements(s->tess);
+	const int numContours = g_tess.getElementCount(s->tess);
+	const uint32_t numContourVerts = (uint32_t)g_tess.getVertexCount(s->tess);
+	std::vector<vgx_contour> contours((size_t)numContours);
+	uint32_t used = 0;
+	for (int i = 0; i < numContours; ++i) {
+		contours[i].first_vertex = contourData[2 * i]; contours[i].num_vertices = contourData[2 * i + 1]; contours[i].fill = 0;
+		used += contourData[2 * i + 1];
+	}
+	vgx_concave_fill fill;
+	memset(&fill, 0, sizeof(fill));
+	fill.first_contour = 0; fill.num_contours = (uint32_t)numContours; fill.color = color; fill.fringe = s->fringe;
+	// (2) moved contours: device
+	s->moved.assign((size_t)numContourVerts * 2, 0.0f);
+	if (numContours > 0) {
+		if (!s->dContour.ensure((size_t)numContourVerts * 8) || !s->dMoved.ensure((size_t)numContourVerts * 8) || !s->dCont.ensure(contours.size() * sizeof(vgx_contour)) || !s->dFill.ensure(sizeof(fill)) ||
+		    hipMemcpy(s->dContour.p, contourVerts, (size_t)numContourVerts * 8, hipMemcpyHostToDevice) != hipSuccess ||
+		    hipMemcpy(s->dCont.p, contours.data(), contours.size() * sizeof(vgx_contour), hipMemcpyHostToDevice) != hipSuccess ||
+		    hipMemcpy(s->dFill.p, &fill, sizeof(fill), hipMemcpyHostToDevice) != hipSuccess) { s->status = VGX_E_HIP; return false; }
+		s->status = vgx_concave_move(s->ctx, (const float*)s->dContour.p, numContourVerts, (const vgx_contour*)s->dCont.p, (uint64_t)numContours, (const vgx_concave_fill*)s->dFill.p, 1, (float*)s->dMoved.p, nullptr);
+		if (s->status != VGX_OK || hipMemcpy(s->moved.data(), s->dMoved.p, (size_t)numContourVerts * 8, hipMemcpyDeviceToHost) != hipSuccess) { if (s->status == VGX_OK) { s->status = VGX_E_HIP; } return false; }
+	}
+	// (3) polygons of the moved contours: libtess2, CPU (the contour table above was copied: the tessellator's arrays die here)
+	for (int i = 0; i < numContours; ++i) {
+		g_tess.addContour(s->tess, 2, &s->moved[(size_t)contours[i].first_vertex * 2], (int)(sizeof(float) * 2), (int)contours[i].num_vertices);
+	}
+	if (!g_tess.tesselate(s->tess, rule, kTessPolygons, 3, 2, normal)) { return false; }
+	fill.num_tess_vertices = (uint32_t)g_tess.getVertexCount(s->tess);
+	fill.num_tess_indices = (uint32_t)g_tess.getElementCount(s->tess) * 3;
+	const uint32_t nv = 2 * used + fill.num_tess_vertices, ni = 6 * used + fill.num_tess_indices;
+	// (2) + (4) the mesh: device
+	if (!s->dTessPos.ensure((size_t)fill.num_tess_vertices * 8 + 8) || !s->dTessIdx.ensure((size_t)fill.num_tess_indices * 2 + 8) ||
+	    !s->dPos.ensure((size_t)nv * 8 + 16) || !s->dCol.ensure((size_t)nv * 4 + 16) || !s->dIdx.ensure((size_t)ni * 2 + 16) || !s->dFill.ensure(sizeof(fill)) ||
+	    (fill.num_tess_vertices && hipMemcpy(s->dTessPos.p, g_tess.getVertices(s->tess), (size_t)fill.num_tess_vertices * 8, hipMemcpyHostToDevice) != hipSuccess) ||
+	    (fill.num_tess_indices && hipMemcpy(s->dTessIdx.p, g_tess.getElements(s->tess), (size_t)fill.num_tess_indices * 2, hipMemcpyHostToDevice) != hipSuccess) ||
+	    hipMemcpy(s->dFill.p, &fill, sizeof(fill), hipMemcpyHostToDevice) != hipSuccess) { s->status = VGX_E_HIP; return false; }
+	vgx_mesh_out out;
+	out.pos = (float*)s->dPos.p; out.color = (uint32_t*)s->dCol.p; out.idx = (uint16_t*)s->dIdx.p; out.meshes = nullptr;
+	out.cap_vertices = nv; out.cap_indices = ni; out.cap_meshes = 0;
+	s->status = vgx_concave_emit(s->ctx, (const float*)s->dContour.p, numContourVerts, (const vgx_contour*)s->dCont.p, (uint64_t)numContours, (const vgx_concave_fill*)s->dFill.p, 1,
+	                             (const float*)s->dTessPos.p, (const uint16_t*)s->dTessIdx.p, &out, nullptr, nullptr, nullptr);
+	if (s->status != VGX_OK) { return false; }
+	s->pos.resize((size_t)nv * 2); s->col.resize(nv); s->idx.resize(ni);
+	if ((nv && (hipMemcpy(s->pos.data(), s->dPos.p, (size_t)nv * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(s->col.data(), s->dCol.p, (size_t)nv * 4, hipMemcpyDeviceToHost) != hipSuccess)) ||
+	    (ni && hipMemcpy(s->idx.data(), s->dIdx.p, (size_t)ni * 2, hipMemcpyDeviceToHost) != hipSuccess)) { s->status = VGX_E_HIP; return false; }
+	mesh->m_PosBuffer = s->pos.data();
+	mesh->m_ColorBuffer = s->col.data();
+	mesh->m_IndexBuffer = s->idx.data();
+	mesh->m_NumVertices = nv;
+	mesh->m_NumIndices = ni;
+	return true;
 }
 }

@@ -277,3 +277,25 @@ def cache_submit(ctx, cache, instances_dev, ninst, bufs):
     out = bufs.out_struct()
     _check(lib().vgx_cache_submit(ctx.handle, C.byref(d), instances_dev.data_ptr(), ninst, C.byref(out),
                                   bufs.dev_sizes.data_ptr(), bufs.dev_status.data_ptr(), _stream_ptr()), "vgx_cache_submit")
+
+
+# ---- concave fills (vgx_concave_move / vgx_concave_emit): libtess2 stays with the caller -----------------------------
+def concave_move(ctx, contour_verts_dev, contours_dev, ncontours, fills_dev, nfills):
+    """Inner fringe vertex of every boundary-contour vertex (what the reference writes back into the contour before the
+    second libtess2 pass). contour_verts_dev float32 [n,2]; contours_dev / fills_dev uint8 tensors of 16-byte vgx_contour /
+    48-byte vgx_concave_fill records. Returns a float32 [n,2] device tensor."""
+    import torch
+    n = int(contour_verts_dev.shape[0])
+    moved = torch.empty_like(contour_verts_dev)
+    _check(lib().vgx_concave_move(ctx.handle, contour_verts_dev.data_ptr(), n, contours_dev.data_ptr(), ncontours,
+                                  fills_dev.data_ptr(), nfills, moved.data_ptr(), _stream_ptr()), "vgx_concave_move")
+    return moved
+
+
+def concave_emit(ctx, contour_verts_dev, contours_dev, ncontours, fills_dev, nfills, tess_pos_dev, tess_idx_dev, bufs):
+    """One mesh per fill: fringe + interior (see include/vgx.h). Asynchronous; totals / status land in bufs.dev_*."""
+    n = int(contour_verts_dev.shape[0])
+    out = bufs.out_struct()
+    _check(lib().vgx_concave_emit(ctx.handle, contour_verts_dev.data_ptr(), n, contours_dev.data_ptr(), ncontours,
+                                  fills_dev.data_ptr(), nfills, tess_pos_dev.data_ptr(), tess_idx_dev.data_ptr(), C.byref(out),
+                                  bufs.dev_sizes.data_ptr(), bufs.dev_status.data_ptr(), _stream_ptr()), "vgx_concave_emit")

@@ -328,6 +328,37 @@ int vgx_concave_emit(vgx_ctx* ctx, const float* contour_verts, uint64_t num_cont
                      const vgx_concave_fill* fills, uint64_t nfills, const float* tess_pos, const uint16_t* tess_idx,
                      const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream);
 
+/* ---- command-list byte-code as input ---------------------------------------------
+ * vg::CommandList::m_CommandBuffer as the reference's cl* functions write it (src/vg.cpp:243-247, 2403-2690, 5694-5723):
+ * {CommandHeader{uint32 type, uint32 size}, 16-byte aligned}{payload, 16-byte aligned}... in HOST memory.
+ * vgx_cmdlist_decode replays it the way ctxSubmitCommandList does (:4332-4625) into what the batch entry points take: one
+ * path per BeginPath group (vgx_pathset_desc arrays) and one vgx_draw per FillPathColor / StrokePathColor, with the
+ * interpreter's state folded in (PushState / PopState / Transform* / SetViewBox / SetGlobalAlpha; stroke width scaling,
+ * clamping and the Thin switch of ctxStrokePathColor :3401-3433; alpha scaling). Commands vgx_tessellate cannot express
+ * (gradient / image paint, IndexedTriList, clip, scissor, text, nested lists, concave fills) are counted in num_skipped.
+ * Host only, no device needed. Call with the array members NULL to get the counts, allocate, call again. */
+typedef struct vgx_cmdlist_state { /* the Context / State values at submission */
+	float mtx[6];          /* State::m_TransformMtx */
+	float global_alpha;    /* State::m_GlobalAlpha */
+	float tess_tol;        /* Context::m_TesselationTolerance */
+	float fringe;          /* Context::m_FringeWidth */
+	float canvas_width;    /* Context::m_CanvasWidth / Height (SetViewBox only) */
+	float canvas_height;
+	uint32_t reserved;
+} vgx_cmdlist_state;
+typedef struct vgx_cmdlist_out {
+	uint8_t* cmd_type;        /* HOST [cap_cmds]      -> vgx_pathset_desc.cmd_type */
+	uint32_t* cmd_arg_off;    /* HOST [cap_cmds + 1] */
+	float* args;              /* HOST [cap_args] */
+	uint32_t* path_cmd_begin; /* HOST [cap_paths + 1] */
+	vgx_draw* draws;          /* HOST [cap_draws]; vgx_draw.path indexes the paths produced here */
+	uint32_t cap_cmds, cap_args, cap_paths, cap_draws;
+	uint32_t num_cmds, num_args, num_paths, num_draws; /* out */
+	uint32_t num_skipped;     /* out: commands without an equivalent in this path */
+	uint32_t reserved;
+} vgx_cmdlist_out;
+int vgx_cmdlist_decode(const void* bytes, uint32_t size, const vgx_cmdlist_state* state, vgx_cmdlist_out* out);
+
 /* Diagnostics of the last asynchronous call on this context: the device status word and, when the single-pass kernel of
  * vgx_tessellate gave up on a segment, why (reason = one of the VGX_FAIL_* codes of csrc/vgx_internal_types.h: a table of
  * the kernel was too small for the batch -- run vgx_tessellate_count on a batch like it --, the polyline heap or the

@@ -1,0 +1,205 @@
+"""the reference's command-list byte-code as input (vgx_cmdlist_decode, host only). Parity UNPINNED in the
+sense of the task: src/vg.cpp needs bgfx and cannot be compiled, so the decoder is pinned by (1) a byte stream written out
+by hand below, byte for byte, with its expected decode, (2) the interpreter's state arithmetic restated independently in
+numpy, and (3) the Tiger drawing recorded through the test-side writer and compared with the direct vgx_pathset_desc route."""
+import importlib
+import struct
+
+import numpy as np
+import pytest
+
+import cmdlist_util as cu
+
+
+@pytest.fixture(scope="module")
+def rt():
+    return importlib.import_module("vg-renderer_amd.runtime")
+
+
+def _hdr(t, size):
+    return struct.pack("<II", t, size) + b"\0" * 8
+
+
+def test_hand_assembled_stream(rt):
+    """BeginPath; MoveTo(1,2); LineTo(3,4); CubicTo(5..10); ClosePath; FillPathColor(ConvexAA, 0x80112233); StrokePathColor(2.0, ButtMiterAA, 0xFF445566)
+    written as the raw bytes clAllocCommand would lay out (header 16 B = type, aligned size, 8 B padding; payload padded to 16)."""
+    f = lambda *v: struct.pack("<%df" % len(v), *v)
+    data = b"".join([
+        _hdr(0, 0),                                            # BeginPath, no payload
+        _hdr(1, 16), f(1, 2) + b"\0" * 8,                      # MoveTo: 8 B payload -> 16
+        _hdr(2, 16), f(3, 4) + b"\0" * 8,                      # LineTo
+        _hdr(3, 32), f(5, 6, 7, 8, 9, 10) + b"\0" * 8,         # CubicTo: 24 B -> 32
+        _hdr(13, 0),                                           # ClosePath
+        _hdr(14, 16), struct.pack("<II", 0x04, 0x80112233) + b"\0" * 8,           # FillPathColor: flags ConvexAA = 4
+        _hdr(17, 16), struct.pack("<fII", 2.0, 0x10, 0xFF445566) + b"\0" * 4,     # StrokePathColor: ButtMiterAA = 0x10
+    ])
+    assert len(data) == 16 * 7 + 16 + 16 + 32 + 16 + 16
+    rc, ps, draws, n = cu.decode(rt, data, global_alpha=0.5)
+    assert rc == 0 and n == {"cmds": 4, "args": 10, "paths": 1, "draws": 2, "skipped": 0}
+    capi = rt.capi
+    assert ps.cmd_type.tolist() == [capi.CMD_MOVE_TO, capi.CMD_LINE_TO, capi.CMD_CUBIC_TO, capi.CMD_CLOSE]
+    assert ps.cmd_arg_off.tolist() == [0, 2, 4, 10, 10]
+    assert ps.args.tolist() == [1, 2, 3, 4, 5, 6, 7, 8, 9, 10]
+    assert ps.path_cmd_begin.tolist() == [0, 4]
+    d0, d1 = draws[0], draws[1]
+    assert (int(d0["path"]), int(d0["fill_flags"]), int(d0["stroke_flags"])) == (0, capi.FILL_ENABLE | capi.FILL_AA, 0)
+    assert int(d0["fill_color"]) == 0x40112233  # alpha 0x80 * global alpha 0.5, truncated (vg.cpp:3072)
+    assert (float(d0["scale"]), float(d0["tess_tol"]), float(d0["fringe"])) == (1.0, 0.25, 1.0)
+    assert d0["mtx"].tolist() == [1, 0, 0, 1, 0, 0]
+    assert int(d1["stroke_flags"]) == capi.stroke_flags(capi.CAP_BUTT, capi.JOIN_MITER, True, False)
+    assert float(d1["stroke_width"]) == 2.0 and int(d1["stroke_color"]) == 0x7F445566  # 255 * 0.5 = 127.5 -> 127
+
+
+def test_state_commands_and_stroke_scaling(rt, wl):
+    """PushState / Transform* / SetGlobalAlpha / PopState folded into the draws; width scaling, clamping, Thin switch and
+    alpha scaling of ctxStrokePathColor (vg.cpp:3401-3433) against workloads.set_stroke's independent mirror."""
+    r = cu.Recorder()
+    r.push_state()
+    r.transform_translate(10, 20)
+    r.transform_scale(2, 3)
+    r.transform_rotate(0.5)
+    r.begin_path(); r.rect(0, 0, 5, 5)
+    r.stroke_path(0xFF0000FF, 0.3, cu.stroke_flags(1, 2, aa=True))     # thin after scaling? 0.3 * avgScale
+    r.set_global_alpha(0.25)
+    r.stroke_path(0xFF00FF00, 300.0, cu.stroke_flags(2, 1, aa=False))  # clamped to 200
+    r.stroke_path(0xFF00FF00, 7.0, cu.stroke_flags(0, 0, aa=True, fixed_width=True))
+    r.pop_state()
+    r.begin_path(); r.circle(1, 1, 4)
+    r.fill_path(0xFFFFFFFF, cu.fill_flags(aa=False))
+    r.set_scissor(0, 0, 10, 10)                                          # skipped (counted)
+    r.fill_path(0xFFFFFFFF, cu.fill_flags(concave=True))                # concave: skipped
+    r.fill_path(0x00FFFFFF, cu.fill_flags())                            # alpha 0: the reference returns early, not "skipped"
+    r.fill_path_gradient(cu.fill_flags(), 1, 0)                         # gradient paint: skipped
+    rc, ps, draws, n = cu.decode(rt, r.bytes())
+    assert rc == 0 and n["paths"] == 2 and n["draws"] == 4 and n["skipped"] == 3
+    # the state arithmetic, restated (float32 throughout, vg.cpp:4044-4082, 4927-4935; cos / sin are csrc/vgmath.h's)
+    f32 = np.float32
+    m = np.array([1, 0, 0, 1, 0, 0], f32)
+    m[4] += m[0] * f32(10) + m[2] * f32(20); m[5] += m[1] * f32(10) + m[3] * f32(20)
+    m[0] = f32(2) * m[0]; m[1] = f32(2) * m[1]; m[2] = f32(3) * m[2]; m[3] = f32(3) * m[3]
+    import ctypes as C
+    vm = C.CDLL(rt.LIB_PATH.replace("libvgx.so", "libvgx_hosttest.so"))
+    vm.vgxt_cos.restype = C.c_float; vm.vgxt_cos.argtypes = [C.c_float]
+    vm.vgxt_sin.restype = C.c_float; vm.vgxt_sin.argtypes = [C.c_float]
+    c, s = f32(vm.vgxt_cos(0.5)), f32(vm.vgxt_sin(0.5))
+    m = np.array([c * m[0] + s * m[2], c * m[1] + s * m[3], -s * m[0] + c * m[2], -s * m[1] + c * m[3], m[4], m[5]], f32)
+    avg = (np.sqrt(m[0] * m[0] + m[2] * m[2]) + np.sqrt(m[1] * m[1] + m[3] * m[3])) * f32(0.5)
+    assert draws["mtx"][0].tolist() == m.tolist() and float(draws["scale"][0]) == float(avg)
+    pb = importlib.import_module("vg-renderer_amd.pathset")
+    exp = pb.make_draws(3)
+    wl.set_stroke(exp, 0, 0xFF0000FF, 0.3, 1, 2, aa=True, avg_scale=float(avg), fringe=1.0, global_alpha=1.0)
+    wl.set_stroke(exp, 1, 0xFF00FF00, 300.0, 2, 1, aa=False, avg_scale=float(avg), fringe=1.0, global_alpha=0.25)
+    wl.set_stroke(exp, 2, 0xFF00FF00, 7.0, 0, 0, aa=True, avg_scale=float(avg), fringe=1.0, global_alpha=0.25, fixed_width=True)
+    for k in ("stroke_flags", "stroke_color", "stroke_width"):
+        assert draws[k][:3].tolist() == exp[k].tolist(), k
+    assert float(draws["stroke_width"][1]) == 200.0
+    # after PopState: identity again, scale 1, global alpha back to 1
+    assert draws["mtx"][3].tolist() == [1, 0, 0, 1, 0, 0] and int(draws["fill_color"][3]) == 0xFFFFFFFF and int(draws["path"][3]) == 1
+    assert int(draws["fill_flags"][3]) == rt.capi.FILL_ENABLE
+
+
+def test_path_continues_after_fill(rt):
+    """BeginPath, rect, Fill, circle, Stroke: the reference's Path keeps growing, the stroke sees rect + circle."""
+    r = cu.Recorder()
+    r.begin_path(); r.rect(0, 0, 5, 5)
+    r.fill_path(0xFF0000FF, cu.fill_flags())
+    r.circle(9, 9, 2)
+    r.stroke_path(0xFF00FF00, 3.0, cu.stroke_flags(0, 0))
+    rc, ps, draws, n = cu.decode(rt, r.bytes())
+    capi = rt.capi
+    assert rc == 0 and n["paths"] == 2 and n["draws"] == 2
+    assert ps.path_cmd_begin.tolist() == [0, 1, 3]
+    assert ps.cmd_type.tolist() == [capi.CMD_RECT, capi.CMD_RECT, capi.CMD_CIRCLE]
+    assert draws["path"].tolist() == [0, 1]
+
+
+def test_malformed_streams_are_rejected(rt):
+    r = cu.Recorder()
+    r.begin_path(); r.move_to(0, 0); r.cubic_to(1, 2, 3, 4, 5, 6)
+    good = r.bytes()
+    assert cu.decode(rt, good)[0] == 0
+    assert cu.decode(rt, good[:-8])[0] == rt.capi.VGX_E_INVALID_ARG            # not a multiple of 16
+    assert cu.decode(rt, good[:-16])[0] == rt.capi.VGX_E_INVALID_ARG           # payload cut off
+    bad = bytearray(good); bad[0:4] = struct.pack("<I", 99)
+    assert cu.decode(rt, bytes(bad))[0] == rt.capi.VGX_E_INVALID_ARG           # unknown command
+    bad = bytearray(good); bad[20:24] = struct.pack("<I", 8)                    # MoveTo header: size 8 is not 16-aligned
+    assert cu.decode(rt, bytes(bad))[0] == rt.capi.VGX_E_INVALID_ARG
+    r = cu.Recorder(); r.pop_state()
+    assert cu.decode(rt, r.bytes())[0] == rt.capi.VGX_E_INVALID_ARG            # state stack underflow
+    assert cu.decode(rt, b"")[0] == 0
+
+
+def record_tiger(wl, instances):
+    """The Tiger drawing as an immediate-mode caller would record it: per instance PushState, TransformTranslate, then per
+    path BeginPath, its commands, FillPath (ConvexAA) and, for a third of the paths, StrokePath (ButtMiterAA); PopState."""
+    ps, ops = wl.tiger_paths()
+    capi = importlib.import_module("vg-renderer_amd.capi")
+    r = cu.Recorder()
+    names = {capi.CMD_MOVE_TO: r.move_to, capi.CMD_CUBIC_TO: r.cubic_to, capi.CMD_LINE_TO: r.line_to}
+    for i in range(instances):
+        r.push_state()
+        r.transform_translate(37.0 * (i % 100), 41.0 * (i // 100))
+        for p, op in enumerate(ops):
+            r.begin_path()
+            for c in range(ps.path_cmd_begin[p], ps.path_cmd_begin[p + 1]):
+                a = ps.args[ps.cmd_arg_off[c]:ps.cmd_arg_off[c + 1]]
+                t = int(ps.cmd_type[c])
+                if t == capi.CMD_CLOSE:
+                    r.close_path()
+                else:
+                    names[t](*a.tolist())
+            r.fill_path(op["fill_color"], cu.fill_flags(aa=True))
+            if op["stroke"]:
+                r.stroke_path(op["stroke_color"], op["stroke_width"], cu.stroke_flags(0, 0, aa=True))
+        r.pop_state()
+    return r.bytes()
+
+
+def test_tiger_recorded_as_bytecode_decodes_to_the_same_batch(rt, wl):
+    K = 3
+    data = record_tiger(wl, K)
+    rc, ps, draws, n = cu.decode(rt, data)
+    assert rc == 0 and n["skipped"] == 0
+    ref_ps, ref_draws = wl.tiger(K)
+    npaths = ref_ps.npaths
+    assert n["paths"] == K * npaths
+    # every recorded path = the path of the direct route, command for command, bit for bit
+    for k in range(K * npaths):
+        p = k % npaths
+        a0, a1 = ps.path_cmd_begin[k], ps.path_cmd_begin[k + 1]
+        b0, b1 = ref_ps.path_cmd_begin[p], ref_ps.path_cmd_begin[p + 1]
+        assert np.array_equal(ps.cmd_type[a0:a1], ref_ps.cmd_type[b0:b1])
+        assert np.array_equal(ps.args[ps.cmd_arg_off[a0]:ps.cmd_arg_off[a1]].view(np.uint32), ref_ps.args[ref_ps.cmd_arg_off[b0]:ref_ps.cmd_arg_off[b1]].view(np.uint32))
+    # draws: the direct route has one draw per path with fill + stroke; the byte-code has one per FillPath / StrokePath
+    it = iter(draws)
+    for k, rd in enumerate(ref_draws):
+        d = next(it)
+        assert int(d["path"]) == k and int(d["fill_flags"]) == int(rd["fill_flags"]) and int(d["fill_color"]) == int(rd["fill_color"]) and int(d["stroke_flags"]) == 0
+        assert d["mtx"].tolist() == rd["mtx"].tolist() and float(d["scale"]) == float(rd["scale"])
+        if int(rd["stroke_flags"]):
+            d = next(it)
+            assert int(d["path"]) == k and int(d["fill_flags"]) == 0
+            for f in ("stroke_flags", "stroke_color", "stroke_width"):
+                assert d[f] == rd[f], f
+            assert d["mtx"].tolist() == rd["mtx"].tolist()
+    assert next(it, None) is None
+
+
+@pytest.mark.gpu
+def test_tiger_bytecode_route_gives_the_same_meshes(rt, wl, gpu_ctx, oracle):
+    """Done-criterion of the row: Tiger recorded as a byte stream -> the same meshes as the vgx_pathset_desc route.
+    The byte-code route emits a draw's fill meshes and stroke meshes as two draws (same order in the streams)."""
+    K = 2
+    rc, ps, draws, n = cu.decode(rt, record_tiger(wl, K))
+    assert rc == 0
+    ref_ps, ref_draws = wl.tiger(K)
+    pset = rt.PathSet(gpu_ctx, ps)
+    got = rt.tessellate(gpu_ctx, pset, rt.upload_draws(draws), draws.shape[0])
+    pset.close()
+    ref = oracle.tessellate(ref_ps, ref_draws)
+    assert got.sizes["num_vertices"] == ref.sizes["num_vertices"] and got.sizes["num_indices"] == ref.sizes["num_indices"] and got.sizes["num_meshes"] == ref.sizes["num_meshes"]
+    assert np.array_equal(got.idx, ref.idx) and np.array_equal(got.color, ref.color)
+    assert np.array_equal(got.pos.view(np.uint32), ref.pos.view(np.uint32))
+    for f in ("first_vertex", "first_index", "num_vertices", "num_indices"):
+        assert np.array_equal(got.meshes[f], ref.meshes[f]), f
+    assert np.array_equal(got.meshes["subpath_kind"], ref.meshes["subpath_kind"])

@@ -118,6 +118,18 @@ class StageTimes(C.Structure):
     _fields_ = [("num_stages", C.c_uint32), ("ms", C.c_float * VGX_MAX_STAGES), ("name", C.c_char_p * VGX_MAX_STAGES)]
 
 
+class CmdListState(C.Structure):
+    _fields_ = [("mtx", C.c_float * 6), ("global_alpha", C.c_float), ("tess_tol", C.c_float), ("fringe", C.c_float),
+                ("canvas_width", C.c_float), ("canvas_height", C.c_float), ("reserved", C.c_uint32)]
+
+
+class CmdListOut(C.Structure):
+    _fields_ = [("cmd_type", C.c_void_p), ("cmd_arg_off", C.c_void_p), ("args", C.c_void_p), ("path_cmd_begin", C.c_void_p), ("draws", C.c_void_p),
+                ("cap_cmds", C.c_uint32), ("cap_args", C.c_uint32), ("cap_paths", C.c_uint32), ("cap_draws", C.c_uint32),
+                ("num_cmds", C.c_uint32), ("num_args", C.c_uint32), ("num_paths", C.c_uint32), ("num_draws", C.c_uint32),
+                ("num_skipped", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class FailureInfo(C.Structure):
     _fields_ = [("status", C.c_uint32), ("reason", C.c_uint32), ("aux", C.c_uint32), ("segment_items", C.c_uint32), ("segment", C.c_uint64), ("prof", C.c_uint64 * 16)]
 
@@ -152,6 +164,7 @@ VGX_SYMBOLS = {
     "vgx_concave_move": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "vgx_concave_emit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                    C.POINTER(MeshOut), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vgx_cmdlist_decode": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(CmdListState), C.POINTER(CmdListOut)]),
     "vgx_get_failure_info": (C.c_int, [C.c_void_p, C.POINTER(FailureInfo), C.c_void_p]),
     "vgx_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "vgx_get_stage_times": (C.c_int, [C.c_void_p, C.POINTER(StageTimes)]),

@@ -78,4 +78,8 @@ int vgxt_mesh_closed_form(const vgx_draw* dr, uint32_t kind, int closed, uint32_
 	return vgx_mesh_closed_form(kind, closed != 0, 0, 0, n, 2, nv, ni) ? 1 : 0;
 }
 
+// the pinned transcendentals (csrc/vgmath.h), for tests that restate arithmetic in numpy
+float vgxt_cos(float a) { return vgm_cos(a); }
+float vgxt_sin(float a) { return vgm_sin(a); }
+
 } // extern "C"

@@ -45,7 +45,7 @@ def traffic(fetch_db, write_db, label):
         c = sqlite3.connect(db).cursor()
         for name, kb in c.execute("select kernel_name, avg(value) from counters_collection where counter_name=? group by kernel_name", (ctr,)):
             for k, stage in names.items():
-                if k + "(" in name:
+                if k + "(" in name or k + "<" in name:
                     d = out["kernels"].setdefault(stage, {"fetch_bytes": 0, "write_bytes": 0})
                     d["fetch_bytes" if ctr == "FETCH_SIZE" else "write_bytes"] = int(kb * 1024 * mul)
     for d in out["kernels"].values():

@@ -22,6 +22,7 @@ capi = _pkg.capi
 _PATHS = {
     "reference": os.path.join(_HERE, "_ref", "libvgref.so"),
     "reference_sse": os.path.join(_HERE, "_ref", "libvgref_sse.so"),
+    "reference_libm": os.path.join(_HERE, "_ref", "libvgref_libm.so"),  # sensitivity probe only (libm_sensitivity.py)
     "port": os.path.join(_HERE, "libvgoracle.so"),
 }
 _libs = {}

@@ -12,6 +12,15 @@
 
 namespace {
 
+// Tuning builds only (profiles/ab_variants.sh): VGX_EXP_NOSTORE makes every output store of the element kernels conditional
+// on a value that never occurs (the address arithmetic and the data stay live), VGX_EXP_NOLOAD replaces the polyline
+// reads by synthetic vertices. Neither is ever defined in the product build.
+#ifdef VGX_EXP_NOSTORE
+#define VGX_ST_GUARD(x) if ((x) == 0x7FEDCBA9u)
+#else
+#define VGX_ST_GUARD(x)
+#endif
+
 struct Rails { uint32_t a, b, c, d; }; // AA: laa,l,r,raa   non-AA: l,r,-,-   thin: laa,m,raa,-
 
 __device__ __forceinline__ Rails rails(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { Rails r; r.a = a; r.b = b; r.c = c; r.d = d; return r; }
@@ -77,13 +86,15 @@ struct StrokeWriter
 	// ---- direct ----
 	__device__ __forceinline__ void v(uint32_t i, V2 p, uint32_t c) const
 	{
+		VGX_ST_GUARD(c) {
 		*(float2*)(pos + 2 * (size_t)i) = make_float2(p.x, p.y);
 		col[i] = c;
+		}
 	}
 	__device__ __forceinline__ void tri(uint32_t k, uint32_t a, uint32_t b, uint32_t c) const
 	{
 		Idx3 t; t.a = ((a + ib) & 0xFFFFu) | ((b + ib) << 16); t.b = (uint16_t)(c + ib);
-		*(Idx3*)(idx + k) = t;
+		VGX_ST_GUARD(t.a) { *(Idx3*)(idx + k) = t; }
 	}
 	__device__ __forceinline__ void bridge4(uint32_t k, Rails p, Rails c) const
 	{
@@ -102,6 +113,10 @@ struct StrokeWriter
 	}
 	// the staged part of the element whose first vertex is b and first index k
 	__device__ __forceinline__ void flush(uint32_t b, uint32_t k) const
+	{
+		VGX_ST_GUARD(sc[0] ^ si[0] ^ si[7] ^ __float_as_uint(sx[3]) ^ __float_as_uint(sy[1]) ^ sc[3] ^ si[23] ^ si[13]) { flush_(b, k); }
+	}
+	__device__ __forceinline__ void flush_(uint32_t b, uint32_t k) const
 	{
 		float* pp = pos + 2 * (size_t)b;
 		uint32_t* pc = col + b;
@@ -157,7 +172,11 @@ struct Elem
 struct VtxGlobal
 {
 	const float2* p;
+#ifdef VGX_EXP_NOLOAD
+	__device__ __forceinline__ V2 ld(uint32_t i) const { const uint32_t h = (i + (uint32_t)(size_t)p) * 2654435761u; return v2((float)(h & 1023u), (float)((h >> 10) & 1023u)); }
+#else
 	__device__ __forceinline__ V2 ld(uint32_t i) const { const float2 t = p[i]; return v2(t.x, t.y); }
+#endif
 };
 typedef float vgx_f2 __attribute__((ext_vector_type(2)));
 typedef const vgx_f2 __attribute__((address_space(3)))* vgx_lds_cf2p;
@@ -181,6 +200,9 @@ typedef MeshCtxT<VtxGlobal> MeshCtx;
 
 __device__ __forceinline__ V2 ldv(const float* vtx, uint32_t i)
 {
+#ifdef VGX_EXP_NOLOAD
+	{ const uint32_t h = (i + (uint32_t)(size_t)vtx) * 2654435761u; return v2((float)(h & 1023u), (float)((h >> 10) & 1023u)); }
+#endif
 	const float2 t = *(const float2*)(vtx + 2 * (size_t)i);
 	return v2(t.x, t.y);
 }
@@ -769,26 +791,47 @@ __device__ __forceinline__ void fill_emit_chunk(float* pos, uint32_t* color_out,
 	pNext.x = wave_from_next(p1.x, 0.0f); pNext.y = wave_from_next(p1.y, 0.0f);
 	if (!F.nextInWave) { pNext = F.pNextB; }
 	V2 d12 = v2(0.0f, 0.0f);
+#ifdef VGX_EXP_CHEAPMATH
+	if (F.aaElem) { d12 = v2sub(pNext, p1); }
+#else
 	if (F.aaElem) { d12 = v2dir(p1, pNext); }
+#endif
 	V2 dPrev;
 	dPrev.x = wave_from_prev(d12.x, 0.0f); dPrev.y = wave_from_prev(d12.y, 0.0f);
+#ifdef VGX_EXP_CHEAPMATH
+	if (F.aaElem && !F.prevInWave) { dPrev = v2sub(p1, F.pPrevB); }
+#else
 	if (F.aaElem && !F.prevInWave) { dPrev = v2dir(F.pPrevB, p1); }
+#endif
 
 	if (valid) {
 		if (F.aaElem) {
+#ifdef VGX_EXP_CHEAPMATH
+			const V2 vaa = v2mul(v2add(dPrev, d12), F.aa);
+#else
 			const V2 vaa = v2mul(v2extrude(dPrev, d12), F.aa);
+#endif
 			const V2 vin = v2add(p1, vaa), vout = v2sub(p1, vaa);
 			const uint64_t gv = F.firstV + 2 * (uint64_t)j;
 			PosPair pp; pp.x0 = vin.x; pp.y0 = vin.y; pp.x1 = vout.x; pp.y1 = vout.y;
-			*(PosPair*)(pos + 2 * gv) = pp;
+#ifdef VGX_EXP_NOPOS
+			if ((__float_as_uint(pp.x0) ^ __float_as_uint(pp.y1)) == 0x7FEDCBA9u)
+#endif
+			VGX_ST_GUARD(__float_as_uint(pp.x0) ^ __float_as_uint(pp.y1)) { *(PosPair*)(pos + 2 * gv) = pp; }
 			ColPair cp; cp.c0 = color; cp.c1 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
-			*(ColPair*)(color_out + gv) = cp;
+#ifdef VGX_EXP_NOCOL
+			if (cp.c0 == 0x7FEDCBA9u)
+#endif
+			VGX_ST_GUARD(cp.c0) { *(ColPair*)(color_out + gv) = cp; }
 			// indices: my nine positions [9j, 9j+9) are three whole triangles T = 3j + g (the fan size 3(N-2) and the
 			// fringe quads are multiples of 3): T < N-2 is fan triangle (0, 2T+2, 2T+4) (stroker.cpp:769-776), else
 			// fringe triangle F = T-(N-2) = half (F&1) of the quad on edge F>>1: (fb, fb+1, nextOuter) /
 			// (fb, nextOuter, nextInner) with fb = 2*edge (stroker.cpp:779-795). No division, no per-index select.
 			const uint32_t k9 = 9 * j;
 			uint32_t val[9];
+#ifdef VGX_EXP_CHEAPMATH
+			for (uint32_t g = 0; g < 9; ++g) { val[g] = (j + g) & 0xFFFFu; }
+#else
 #pragma unroll
 			for (uint32_t g = 0; g < 3; ++g) {
 				const uint32_t T = 3 * j + g;
@@ -804,12 +847,19 @@ __device__ __forceinline__ void fill_emit_chunk(float* pos, uint32_t* color_out,
 				val[3 * g + 1] = ((isFan ? 2 * T + 2 : (second ? nextOuter : fb + 1)) + F.ibase) & 0xFFFFu;
 				val[3 * g + 2] = ((isFan ? 2 * T + 4 : (second ? nextInner : nextOuter)) + F.ibase) & 0xFFFFu;
 			}
+#endif
 			uint16_t* pi = idx_out + F.firstI + k9;
 			if (j + 1 < N) {
 				Idx9 q; q.a = val[0] | (val[1] << 16); q.b = val[2] | (val[3] << 16); q.c = val[4] | (val[5] << 16); q.d = val[6] | (val[7] << 16); q.e = (uint16_t)val[8];
-				*(Idx9*)pi = q;
+#ifdef VGX_EXP_NOIDX
+				if ((q.a ^ q.b ^ q.c ^ q.d ^ q.e) == 0x7FEDCBA9u)
+#endif
+				VGX_ST_GUARD(q.a ^ q.b ^ q.c ^ q.d ^ q.e) { *(Idx9*)pi = q; }
 			} else {
 				Idx3 q; q.a = val[0] | (val[1] << 16); q.b = (uint16_t)val[2];
+#ifdef VGX_EXP_NOIDX3
+				if ((q.a ^ q.b) == 0x7FEDCBA9u)
+#endif
 				*(Idx3*)pi = q;
 			}
 		} else {

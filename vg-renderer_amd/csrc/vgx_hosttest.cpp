@@ -81,5 +81,20 @@ int vgxt_mesh_closed_form(const vgx_draw* dr, uint32_t kind, int closed, uint32_
 // the pinned transcendentals (csrc/vgmath.h), for tests that restate arithmetic in numpy
 float vgxt_cos(float a) { return vgm_cos(a); }
 float vgxt_sin(float a) { return vgm_sin(a); }
+// vectors of them (tests/test_oracle_libm.py: ULP distance of every pinned transcendental from glibc's):
+// fn 0 cos, 1 sin, 2 tan, 3 acos, 4 atan2(a, b), 5 rsqrt
+void vgxt_math_vec(int fn, const float* a, const float* b, float* out, uint64_t n)
+{
+	for (uint64_t i = 0; i < n; ++i) {
+		switch (fn) {
+		case 0: out[i] = vgm_cos(a[i]); break;
+		case 1: out[i] = vgm_sin(a[i]); break;
+		case 2: out[i] = vgm_tan(a[i]); break;
+		case 3: out[i] = vgm_acos(a[i]); break;
+		case 4: out[i] = vgm_atan2(a[i], b[i]); break;
+		default: out[i] = vgm_rsqrt(a[i]); break;
+		}
+	}
+}
 
 } // extern "C"

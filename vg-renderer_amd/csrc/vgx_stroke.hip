@@ -83,91 +83,223 @@ __global__ __launch_bounds__(VGX_WAVE) void k_round_sizes(VgxStrokeArgs A)
 // divergence.
 // Per-mesh record held one per lane for a window of 64 consecutive meshes (refilled every few dozen chunks):
 // the element lanes fetch their mesh's fields with shuffles instead of a dependent chain of global loads.
-struct FillWindow
+struct __attribute__((aligned(16))) FillRec // 48 bytes, one per mesh of the window, in LDS
 {
-	uint64_t prefix;   // elem_prefix[wbase + lane] (or ~0 past the end)
 	uint64_t polyFirst, firstV, firstI;
 	uint32_t N, kind, color;
 	float aa;
 	uint32_t ibase;    // assembly: vertices in front of the mesh inside its vertex buffer (0 when not armed)
+	uint32_t pad;
 };
 
-__device__ __forceinline__ FillWindow fill_window_load(const VgxStrokeArgs& A, uint64_t wbase, uint64_t numMeshes, int lane)
+struct FillWindow
 {
-	FillWindow w;
+	uint64_t prefix;   // elem_prefix[wbase + lane] (or ~0 past the end), read back from LDS: no VMEM-pending register
+	                   // lives across the pipelined loop (the compiler would guard it with s_waitcnt vmcnt(0))
+	FillRec* rec;      // s_win
+	uint64_t* pre;     // s_pre
+};
+
+// Loads the window of 64 mesh records starting at wbase into LDS (one mesh per lane) and waits for it.
+__device__ __forceinline__ void fill_window_load(const VgxStrokeArgs& A, FillWindow& W, uint64_t wbase, uint64_t numMeshes, int lane)
+{
 	const uint64_t idx = wbase + (uint64_t)lane;
-	w.prefix = (idx <= numMeshes) ? A.elem_prefix[idx] : ~0ull;
-	w.polyFirst = 0; w.firstV = 0; w.firstI = 0; w.N = 3; w.kind = VGX_MESH_FILL; w.color = 0; w.aa = 0.0f; w.ibase = 0;
+	const uint64_t prefix = (idx <= numMeshes) ? A.elem_prefix[idx] : ~0ull;
+	FillRec r;
+	r.polyFirst = 0; r.firstV = 0; r.firstI = 0; r.N = 3; r.kind = VGX_MESH_FILL; r.color = 0; r.aa = 0.0f; r.ibase = 0; r.pad = 0;
 	if (idx < numMeshes) {
 		const VgxMeshDesc md = A.mdesc[idx];
 		const VgxMeshPrep pr = A.mprep[idx];
-		w.polyFirst = md.poly_first; w.N = md.poly_n; w.kind = VGX_MD_KIND(md.kind);
-		w.color = pr.color; w.aa = pr.f0;
-		w.firstV = A.mtab[idx].first_vertex;
-		w.firstI = A.mtab[idx].first_index;
-		if (A.mesh_base) { w.ibase = A.mesh_base[idx]; }
+		r.polyFirst = md.poly_first; r.N = md.poly_n; r.kind = VGX_MD_KIND(md.kind);
+		r.color = pr.color; r.aa = pr.f0;
+		r.firstV = A.mtab[idx].first_vertex;
+		r.firstI = A.mtab[idx].first_index;
+		if (A.mesh_base) { r.ibase = A.mesh_base[idx]; }
 	}
-	return w;
+	__syncthreads(); // one-wave workgroup: lanes may still be reading the previous window
+	W.rec[lane] = r;
+	W.pre[lane] = prefix;
+	__syncthreads();
+	W.prefix = W.pre[lane];
 }
 
-__device__ __forceinline__ FillFetch fill_fetch(const VgxStrokeArgs& A, uint64_t chunk, uint64_t elemEnd, uint64_t numMeshes, int lane, FillWindow& W, uint64_t& wbase, uint64_t& mcur)
+// ---- the pipelined walk of k_fill -------------------------------------------------------------------------------
+// gfx9 has ONE counter (vmcnt) for loads and stores, in issue order: a wave that needs a load it issued AFTER a batch of
+// stores can only wait for "everything", i.e. for the write acknowledgements of those stores (microseconds under a
+// saturated write stream). So the vertices of the NEXT run of chunks are requested before the current run's stores are
+// issued, and a run is VGX_FILL_RUN chunks: reads and stores reach the memory system in batches (a read stream mixed
+// chunk by chunk into the store streams costs ~40 % of the write rate on this part, batches of 4-8 chunks half of that;
+// profiles/micro/fillshape2-4.hip). Everything else a chunk needs (mesh fields) is re-read from the lane-resident window
+// when the chunk is emitted: the only state carried from request to emit is {owner, j, three vertices}.
+#ifndef VGX_FILL_RUN
+#define VGX_FILL_RUN 4
+#endif
+
+struct FillChunk // one 64-element chunk between vertex request and emit
 {
-	FillFetch F;
-	const uint64_t ei = chunk + lane;
+	int k;          // owner mesh = window entry k (valid lanes)
+	uint32_t j;     // element index inside the mesh; 0xFFFFFFFF = lane has no element
+	V2 p1, pNextB, pPrevB;
+};
+
+struct FillRun { FillChunk c[VGX_FILL_RUN]; int n; uint64_t first; }; // n chunks starting at element `first`
+
+// Requests the vertices of one chunk. The window covers the chunk (W.prefix[63] > chunk + 63, W.prefix[0] <= chunk).
+__device__ __forceinline__ FillChunk fill_request(const VgxStrokeArgs& A, const FillWindow& W, uint64_t chunk, uint64_t elemEnd, int lane)
+{
+	FillChunk C;
+	const uint64_t ei = chunk + (uint64_t)lane;
 	const bool valid = ei < elemEnd;
-	const uint64_t lastKey = chunk + (VGX_WAVE - 1);
-	if (!(wave_bcast_u64(W.prefix, VGX_WAVE - 1) > lastKey)) {
-		wbase = mcur;
-		W = fill_window_load(A, wbase, numMeshes, lane);
-		// wait for the window HERE: otherwise the compiler parks an s_waitcnt vmcnt(0) at the join below, which every
-		// chunk would pay -- and on gfx9 vmcnt also counts the previous chunk's stores
-		__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
-	}
-	const bool windowCovers = wave_bcast_u64(W.prefix, VGX_WAVE - 1) > lastKey;
 	const uint32_t wrel = window_rel(W.prefix, chunk);
 	const int k = window_owner_rel(wrel, valid ? (uint32_t)lane : 0u);
 	const uint32_t orel = (uint32_t)__shfl((int)wrel, k);
 	const int firstOwner = __popcll(wave_ballot(W.prefix <= chunk)) - 1;
-	uint64_t ownerBase = orel > 0 ? chunk + orel : wave_bcast_u64(W.prefix, firstOwner < 0 ? 0 : firstOwner);
-	uint64_t mi = wbase + (uint64_t)k;
-	uint64_t polyFirst = __shfl((unsigned long long)W.polyFirst, k);
-	uint64_t firstV = __shfl((unsigned long long)W.firstV, k);
-	uint64_t firstI = __shfl((unsigned long long)W.firstI, k);
-	uint32_t N = (uint32_t)__shfl((int)W.N, k);
-	uint32_t kind = (uint32_t)__shfl((int)W.kind, k);
-	uint32_t color = (uint32_t)__shfl((int)W.color, k);
-	float aa = __shfl(W.aa, k);
-	uint32_t ibase = (uint32_t)__shfl((int)W.ibase, k);
-	if (!windowCovers && valid) { // > 63 mesh records (mostly zero-length stroke entries) inside one chunk: rare
-		mi = find_owner_u64(A.elem_prefix, wbase, numMeshes, ei);
-		ownerBase = A.elem_prefix[mi];
-		const VgxMeshDesc md = A.mdesc[mi];
-		const VgxMeshPrep pr = A.mprep[mi];
-		polyFirst = md.poly_first; N = md.poly_n; kind = VGX_MD_KIND(md.kind); color = pr.color; aa = pr.f0;
-		firstV = A.mtab[mi].first_vertex; firstI = A.mtab[mi].first_index;
-		ibase = A.mesh_base ? A.mesh_base[mi] : 0u;
-	}
-	const uint32_t j = valid ? (uint32_t)(ei - ownerBase) : 0u;
+	const uint64_t headBase = wave_bcast_u64(W.prefix, firstOwner < 0 ? 0 : firstOwner); // mesh that owns the chunk's first element
+	const uint32_t j = orel > 0 ? (uint32_t)lane - orel : (uint32_t)(ei - headBase);
+	const FillRec r = W.rec[k];
+	const uint64_t polyFirst = r.polyFirst;
+	const uint32_t N = r.N, kind = r.kind;
 	const float* vtx = A.poly + 2 * polyFirst;
-	F.valid = valid;
-	F.ibase = ibase;
-	F.aaElem = valid && kind == VGX_MESH_FILL_AA;
-	// all vertex loads of the chunk are issued together: my own vertex, and -- only for lanes whose neighbour is
-	// not in the adjacent lane (mesh boundary / chunk edge) -- the cyclic next / previous vertex
-	F.prevInWave = lane > 0 && j > 0;
-	F.nextInWave = lane < VGX_WAVE - 1 && j + 1 < N && ei + 1 < elemEnd;
-	F.p1 = v2(0.0f, 0.0f); F.pNextB = F.p1; F.pPrevB = F.p1;
-	if (valid) { F.p1 = ldv(vtx, j); }
-	if (F.aaElem && !F.nextInWave) { F.pNextB = ldv(vtx, j + 1 < N ? j + 1 : 0); }
-	if (F.aaElem && !F.prevInWave) { F.pPrevB = ldv(vtx, j > 0 ? j - 1 : N - 1); }
-	F.j = j; F.N = N; F.color = color; F.aa = aa; F.firstV = firstV; F.firstI = firstI; F.mi = mi;
-	const int nvalid = (int)((elemEnd - chunk) < (uint64_t)VGX_WAVE ? (elemEnd - chunk) : (uint64_t)VGX_WAVE);
-	mcur = wave_bcast_u64(mi, nvalid - 1);
-	return F;
+	const bool aaElem = valid && kind == VGX_MESH_FILL_AA;
+	const bool prevInWave = lane > 0 && j > 0;
+	const bool nextInWave = lane < VGX_WAVE - 1 && j + 1 < N && ei + 1 < elemEnd;
+	C.k = k;
+	C.j = valid ? j : 0xFFFFFFFFu;
+	C.p1 = v2(0.0f, 0.0f); C.pNextB = C.p1; C.pPrevB = C.p1;
+	// my own vertex, and -- only where the neighbour is not in the adjacent lane (mesh boundary / chunk edge) -- the
+	// cyclic next / previous vertex
+	if (valid) { C.p1 = ldv(vtx, j); }
+	if (aaElem && !nextInWave) { C.pNextB = ldv(vtx, j + 1 < N ? j + 1 : 0); }
+	if (aaElem && !prevInWave) { C.pPrevB = ldv(vtx, j > 0 ? j - 1 : N - 1); }
+	return C;
 }
 
-__global__ __launch_bounds__(VGX_WAVE) void k_fill(VgxStrokeArgs A)
+__device__ __forceinline__ void fill_emit_one(const VgxStrokeArgs& A, const FillWindow& W, const FillChunk& C, uint64_t chunk, uint64_t elemEnd, int lane)
 {
+	FillFetch F;
+	const int k = C.k;
+	F.valid = C.j != 0xFFFFFFFFu;
+	F.j = F.valid ? C.j : 0u;
+	const FillRec r = W.rec[k];
+	F.N = r.N;
+	const uint32_t kind = r.kind;
+	F.color = r.color;
+	F.aa = r.aa;
+	F.firstV = r.firstV;
+	F.firstI = r.firstI;
+	F.ibase = r.ibase;
+	F.mi = 0;
+	F.aaElem = F.valid && kind == VGX_MESH_FILL_AA;
+	F.prevInWave = lane > 0 && F.j > 0;
+	F.nextInWave = lane < VGX_WAVE - 1 && F.j + 1 < F.N && chunk + (uint64_t)lane + 1 < elemEnd;
+	F.p1 = C.p1; F.pNextB = C.pNextB; F.pPrevB = C.pPrevB;
+	fill_emit_chunk(A.pos, A.color, A.idx, F);
+}
+
+__device__ __forceinline__ void fill_emit_run(const VgxStrokeArgs& A, const FillWindow& W, FillRun& R, uint64_t elemEnd, int lane)
+{
+#pragma unroll
+	for (int i = 0; i < VGX_FILL_RUN; ++i) {
+		if (i < R.n) { fill_emit_one(A, W, R.c[i], R.first + (uint64_t)i * VGX_WAVE, elemEnd, lane); }
+	}
+	R.n = 0;
+}
+
+// A chunk in which more than 63 mesh records begin (zero-length entries of stroke-only sub-paths between fills): every
+// lane searches its mesh in memory. Not pipelined; rare.
+__device__ __forceinline__ uint64_t fill_chunk_slow(const VgxStrokeArgs& A, uint64_t chunk, uint64_t elemEnd, uint64_t mlo, uint64_t numMeshes, int lane)
+{
+	FillFetch F;
+	const uint64_t ei = chunk + (uint64_t)lane;
+	const bool valid = ei < elemEnd;
+	F.valid = valid; F.j = 0; F.N = 3; F.color = 0; F.aa = 0.0f; F.firstV = 0; F.firstI = 0; F.ibase = 0; F.mi = mlo;
+	F.aaElem = false; F.prevInWave = false; F.nextInWave = false;
+	F.p1 = v2(0.0f, 0.0f); F.pNextB = F.p1; F.pPrevB = F.p1;
+	if (valid) {
+		const uint64_t mi = find_owner_u64(A.elem_prefix, mlo, numMeshes, ei);
+		const VgxMeshDesc md = A.mdesc[mi];
+		const VgxMeshPrep pr = A.mprep[mi];
+		F.mi = mi;
+		F.j = (uint32_t)(ei - A.elem_prefix[mi]);
+		F.N = md.poly_n; F.color = pr.color; F.aa = pr.f0;
+		F.firstV = A.mtab[mi].first_vertex; F.firstI = A.mtab[mi].first_index;
+		F.ibase = A.mesh_base ? A.mesh_base[mi] : 0u;
+		F.aaElem = VGX_MD_KIND(md.kind) == VGX_MESH_FILL_AA;
+		const float* vtx = A.poly + 2 * md.poly_first;
+		F.p1 = ldv(vtx, F.j);
+		if (F.aaElem) { // no neighbour shortcuts here: both loads, always
+			F.pNextB = ldv(vtx, F.j + 1 < F.N ? F.j + 1 : 0);
+			F.pPrevB = ldv(vtx, F.j > 0 ? F.j - 1 : F.N - 1);
+		}
+	}
+	fill_emit_chunk(A.pos, A.color, A.idx, F);
+	const int nvalid = (int)((elemEnd - chunk) < (uint64_t)VGX_WAVE ? (elemEnd - chunk) : (uint64_t)VGX_WAVE);
+	return wave_bcast_u64(F.mi, nvalid - 1);
+}
+
+struct FillWalk // wave-uniform position of the walk
+{
+	uint64_t pos;     // next element to request
+	uint64_t elemEnd;
+	uint64_t mcur;    // a mesh at or before the owner of element `pos`
+	uint64_t wbase;   // first mesh of the window
+	uint64_t numMeshes;
+};
+
+// One half step of the software pipeline: request the next run into `next`, then emit `pending` (requested one half step
+// earlier). When the window runs out, `pending` is emitted first (its fields come from the old window), then the
+// window is reloaded.
+__device__ __forceinline__ void fill_half_step(const VgxStrokeArgs& A, FillWindow& W, FillWalk& P, FillRun& next, FillRun& pending, int lane)
+{
+	next.n = 0;
+	if (P.pos < P.elemEnd) { // wave-uniform
+		uint64_t wlast = wave_bcast_u64(W.prefix, VGX_WAVE - 1);
+		if (!(wlast > P.pos + (VGX_WAVE - 1))) {
+			fill_emit_run(A, W, pending, P.elemEnd, lane);
+			P.wbase = P.mcur;
+			fill_window_load(A, W, P.wbase, P.numMeshes, lane);
+			wlast = wave_bcast_u64(W.prefix, VGX_WAVE - 1);
+			while (P.pos < P.elemEnd && !(wlast > P.pos + (VGX_WAVE - 1))) { // more than 63 mesh records inside one chunk
+				P.mcur = fill_chunk_slow(A, P.pos, P.elemEnd, P.wbase, P.numMeshes, lane);
+				P.pos += VGX_WAVE;
+				P.wbase = P.mcur;
+				fill_window_load(A, W, P.wbase, P.numMeshes, lane);
+				wlast = wave_bcast_u64(W.prefix, VGX_WAVE - 1);
+			}
+		}
+		if (P.pos < P.elemEnd) {
+			const uint64_t covered = (wlast - P.pos) >> 6;                       // chunks the window covers from pos on
+			const uint64_t left = (P.elemEnd - P.pos + (VGX_WAVE - 1)) >> 6;
+			uint64_t n = covered < left ? covered : left;
+			n = n < (uint64_t)VGX_FILL_RUN ? n : (uint64_t)VGX_FILL_RUN;
+			next.n = (int)n;
+			next.first = P.pos;
+#pragma unroll
+			for (int i = 0; i < VGX_FILL_RUN; ++i) {
+				if (i < next.n) { next.c[i] = fill_request(A, W, P.pos + (uint64_t)i * VGX_WAVE, P.elemEnd, lane); }
+			}
+			// owner of the run's last element: where the next window (if one is needed) starts
+			const uint64_t lastChunk = P.pos + (n - 1) * VGX_WAVE;
+			const int nvalid = (int)((P.elemEnd - lastChunk) < (uint64_t)VGX_WAVE ? (P.elemEnd - lastChunk) : (uint64_t)VGX_WAVE);
+			int kLast = 0;
+#pragma unroll
+			for (int i = 0; i < VGX_FILL_RUN; ++i) {
+				if (i == next.n - 1) { kLast = wave_bcast(next.c[i].k, nvalid - 1); }
+			}
+			P.mcur = P.wbase + (uint64_t)kLast;
+			P.pos += n * VGX_WAVE;
+		}
+	}
+	fill_emit_run(A, W, pending, P.elemEnd, lane);
+}
+
+#ifndef VGX_FILL_OCC
+#define VGX_FILL_OCC
+#endif
+__global__ __launch_bounds__(VGX_WAVE) VGX_FILL_OCC void k_fill(VgxStrokeArgs A)
+{
+	__shared__ FillRec s_win[VGX_WAVE];
+	__shared__ uint64_t s_pre[VGX_WAVE];
 	const int lane = threadIdx.x;
 	if (A.totals->status != VGX_OK) {
 		return;
@@ -181,25 +313,24 @@ __global__ __launch_bounds__(VGX_WAVE) void k_fill(VgxStrokeArgs A)
 	if (seg0 >= seg1) {
 		return;
 	}
-	// This wave's elements are the contiguous range [chunk0, chunkEnd); whole meshes are NOT required here (a fill
-	// element only needs its own mesh record and its two neighbours), so the walk is a plain 64-element stride.
-	const uint64_t elem0 = seg0 * VGX_WAVE;
-	const uint64_t elemEnd = (seg1 * VGX_WAVE < totalElems) ? seg1 * VGX_WAVE : totalElems;
-	uint64_t mcur = find_owner_u64(A.elem_prefix, 0, numMeshes, elem0); // last mesh with prefix <= elem0
-	uint64_t wbase = mcur;
-	FillWindow W = fill_window_load(A, wbase, numMeshes, lane);
-
-	// two fetch records in ping-pong (no register copies at the loop edge: the wait for a chunk's vertices sits right
-	// before their first use, after the NEXT chunk's loads have been issued)
-	FillFetch F0 = fill_fetch(A, elem0, elemEnd, numMeshes, lane, W, wbase, mcur);
-	FillFetch F1 = F0;
-	for (uint64_t chunk = elem0; chunk < elemEnd; chunk += 2 * VGX_WAVE) {
-		const bool has1 = chunk + VGX_WAVE < elemEnd, has2 = chunk + 2 * VGX_WAVE < elemEnd; // wave-uniform
-		if (has1) { F1 = fill_fetch(A, chunk + VGX_WAVE, elemEnd, numMeshes, lane, W, wbase, mcur); }
-		fill_emit_chunk(A.pos, A.color, A.idx, F0);
-		if (has2) { F0 = fill_fetch(A, chunk + 2 * VGX_WAVE, elemEnd, numMeshes, lane, W, wbase, mcur); }
-		if (has1) { fill_emit_chunk(A.pos, A.color, A.idx, F1); }
-	}
+	// This wave's elements are the contiguous range [pos, elemEnd); whole meshes are NOT required here (a fill element
+	// only needs its own mesh record and its two neighbours), so the walk is a plain 64-element stride.
+	FillWalk P;
+	P.pos = seg0 * VGX_WAVE;
+	P.elemEnd = (seg1 * VGX_WAVE < totalElems) ? seg1 * VGX_WAVE : totalElems;
+	P.numMeshes = numMeshes;
+	P.mcur = find_owner_u64(A.elem_prefix, 0, numMeshes, P.pos); // last mesh with prefix <= pos
+	P.wbase = P.mcur;
+	FillWindow W;
+	W.rec = s_win; W.pre = s_pre;
+	fill_window_load(A, W, P.wbase, numMeshes, lane);
+	FillRun R0, R1;
+	R0.n = 0; R1.n = 0; R0.first = 0; R1.first = 0;
+	// two run records in ping-pong (no register copies at the loop edge)
+	do {
+		fill_half_step(A, W, P, R0, R1, lane);
+		fill_half_step(A, W, P, R1, R0, lane);
+	} while (P.pos < P.elemEnd || R0.n > 0 || R1.n > 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -209,6 +340,9 @@ __global__ __launch_bounds__(VGX_WAVE) void k_fill(VgxStrokeArgs A)
 // walk leaves the previous window, read back by the element lanes with four ds_read_b128. This takes the per-element
 // mesh-table gathers (a chain of dependent global loads per chunk: prefix -> descriptor -> vertex) off the critical
 // path: the only global load a chunk waits for is its polyline vertices.
+#ifndef VGX_STROKE_OCC
+#define VGX_STROKE_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
 struct __attribute__((aligned(16))) StrokeRec
 {
 	uint64_t polyFirst;
@@ -219,7 +353,7 @@ struct __attribute__((aligned(16))) StrokeRec
 	uint32_t color, ibase, pad1, pad2; // ibase: assembly index base of the mesh (0 when not armed)
 };
 
-__global__ __launch_bounds__(VGX_WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_stroke(VgxStrokeArgs A)
+__global__ __launch_bounds__(VGX_WAVE) VGX_STROKE_OCC void k_stroke(VgxStrokeArgs A)
 {
 	__shared__ StrokeRec s_win[VGX_WAVE];
 	const int lane = threadIdx.x;

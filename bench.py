@@ -10,10 +10,14 @@ through the asynchronous C-ABI entry point vgx_tessellate (no host round trip in
 Launch contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver runs it under
 torch.distributed.run with one rank per GPU. Every rank tessellates its own contiguous range of Tiger
 instances (independent path instances shard embarrassingly, no data-path collective) => weak scaling;
-`value` = vertices produced by ALL ranks per second of the slowest rank. The RCCL gather of the streams to
-rank 0 (vg-renderer_amd/dist.py) is timed separately (--gather) and reported as extra fields.
+`value` = vertices produced by ALL ranks per second of the slowest rank. With more than one rank the RCCL gather of
+the streams to rank 0 (vg-renderer_amd/dist.py; SURVEY 8e counts it into the scaling target) is timed too, by default,
+and reported as `gather_ms` / `value_with_gather` beside `value`.
 
-Rank 0 prints ONE JSON line (fields documented in DESIGN.md "Measurement").
+Rank 0 prints ONE JSON line (fields documented in DESIGN.md "Measurement"): the headline (Tiger x10k = BASELINE's
+metric) with `roofline` and `cpu_baseline`, and -- on 1-GPU runs -- the other two single-GPU BASELINE configs (1M
+cubics flatten-only, 10k x 1k-segment Round/Round polylines) under `configs`, each with its own roofline object.
+`--config NAME` makes another config the headline of the line.
 """
 import argparse
 import importlib
@@ -29,18 +33,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
-def algorithmic_bytes(ps, draws_one_instance, instances, sizes, fill_verts, fill_idx, fill_meshes):
+def command_bytes(ps, draw_paths):
+    """Bytes of path commands the batch reads: 1 B opcode + 4 B argument offset + 4 B per argument, per command instance."""
+    import numpy as np
+    pcb = ps.path_cmd_begin.astype(np.int64)
+    aoff = ps.cmd_arg_off.astype(np.int64)
+    per_path = (pcb[1:] - pcb[:-1]) * 5 + (aoff[pcb[1:]] - aoff[pcb[:-1]]) * 4
+    return int(per_path[draw_paths].sum())
+
+
+def algorithmic_bytes(cmd_bytes, ndraws, sizes, fill_verts, fill_idx, fill_meshes):
     """Algorithmic HBM bytes per launch of each kernel (stated in DESIGN.md):
     commands read once per instance (1 B opcode + 4 B arg offset + 4 B per argument), one 64 B draw record
     per path instance, 8 B per polyline vertex, 12 B per output vertex (float2 position + uint32 colour), 2 B per
     index, 32 B per mesh record. Scratch the kernels exchange (per-command words, mesh descriptors, prefix arrays,
     scan partials) is NOT counted: it is overhead, not algorithm."""
-    import numpy as np
-    pcb = ps.path_cmd_begin.astype(np.int64)
-    aoff = ps.cmd_arg_off.astype(np.int64)
-    per_path_cmd_bytes = (pcb[1:] - pcb[:-1]) * 5 + (aoff[pcb[1:]] - aoff[pcb[:-1]]) * 4
-    cmd_bytes = int(per_path_cmd_bytes[draws_one_instance["path"]].sum()) * instances
-    ndraws = draws_one_instance.shape[0] * instances
     nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
     ef = sizes["num_fill_elements"]
     es = sizes["num_elements"] - ef
@@ -125,13 +132,158 @@ def cpu_baseline(budget_seconds=10.0, max_procs=256):
                       "%d logical CPUs visible)" % (budget_seconds, procs, os.cpu_count() or 0)}
 
 
+WORKLOADS = {
+    "tiger10k": "BASELINE configs[2]: Tiger x10k, convexFillAA + polylineStrokeAA (the headline)",
+    "cubics1m": "BASELINE configs[1]: 1M independent cubics, adaptive flatten only",
+    "round10k": "BASELINE configs[3]: 10k polylines x 1k segments, Round joins + Round caps",
+}
+
+
+def make_workload(wl, name, instances, rank):
+    """(path set, draw records, description, kind) of one BASELINE config; kind 'tessellate' or 'flatten'."""
+    if name == "tiger10k":
+        ps, ops = wl.tiger_paths()
+        d = wl.tiger_draws(ops, instances, first_instance=rank * instances)
+        return ps, d, ("tiger-like 240-path drawing (seed 2024) x %d instances per GPU: convexFillAA on every sub-path + "
+                       "polylineStrokeAA/AAThin (Butt/Miter) on 1/3 of the paths" % instances), "tessellate"
+    if name == "cubics1m":
+        ps, d = wl.random_cubics(1000000, seed=1234 + rank, box=1000.0)
+        return ps, d, "1 000 000 independent paths (moveTo + cubicTo, 8 coordinates uniform in [0,1000)) per GPU: pathXXX only (vgx_flatten_count + vgx_flatten_emit)", "flatten"
+    if name == "round10k":
+        ps, d = wl.random_walk_polylines(10000, 1000, seed=5678 + rank)
+        return ps, d, "10 000 open polylines x 1000 segments per GPU, strokerPolylineStrokeAA with Round joins + Round caps, width 6", "tessellate"
+    raise SystemExit("unknown --config %s (one of %s)" % (name, ", ".join(WORKLOADS)))
+
+
+def run_config(rt, torch, ctx, local_rank, name, ps, draws, kind, steps, warmup, barrier):
+    """Times `steps` steps of one workload (inputs resident in HBM) between barriers. Returns a dict with the wall time,
+    the output sizes, the per-kernel HIP-event times (averaged over a few extra steps outside the timed region) and the
+    algorithmic bytes per kernel."""
+    import numpy as np
+    dev = torch.device("cuda", local_rank)
+    ndraws = draws.shape[0]
+    cmd_bytes = command_bytes(ps, draws["path"])
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(draws, local_rank)
+    res = {"ndraws": ndraws}
+    stage_sum = {}
+    if kind == "flatten":
+        L, C, capi = rt.lib(), rt.C, rt.capi
+        sizes_c = capi.Sizes()
+        rt._check(L.vgx_flatten_count(ctx.handle, pset.handle, dd.data_ptr(), ndraws, C.byref(sizes_c), rt._stream_ptr()), "vgx_flatten_count")
+        sizes = sizes_c.as_dict()
+        npv, nsp = sizes["num_poly_vertices"], sizes["num_subpaths"]
+        poly = torch.empty((max(npv, 1), 2), dtype=torch.float32, device=dev)
+        subs = torch.empty(max(nsp, 1) * 16, dtype=torch.uint8, device=dev)
+        dinfo = torch.empty(max(ndraws, 1) * 40, dtype=torch.uint8, device=dev)
+        out = capi.FlatOut(poly.data_ptr(), subs.data_ptr(), dinfo.data_ptr(), npv, nsp)
+
+        def step(collect=None):
+            rt._check(L.vgx_flatten_count(ctx.handle, pset.handle, dd.data_ptr(), ndraws, C.byref(sizes_c), rt._stream_ptr()), "vgx_flatten_count")
+            if collect is not None:
+                collect.update(dict(ctx.stage_times()))
+            rt._check(L.vgx_flatten_emit(ctx.handle, pset.handle, dd.data_ptr(), ndraws, 1, C.byref(out), rt._stream_ptr()), "vgx_flatten_emit")
+            if collect is not None:
+                torch.cuda.synchronize()
+                for k, v in ctx.stage_times():
+                    collect[k] = collect.get(k, 0.0) + v
+        units = npv
+        unit_name = "polyline vertices"
+        bufs = None
+    else:
+        sizes = rt.tessellate_count(ctx, pset, dd, ndraws)
+        bufs = rt.MeshBuffers(dev, sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"])
+
+        def step(collect=None):
+            rt.tessellate_async(ctx, pset, dd, ndraws, bufs)
+            if collect is not None:
+                torch.cuda.synchronize()
+                collect.update(dict(ctx.stage_times()))
+        units = sizes["num_vertices"]
+        unit_name = "output vertices"
+    for _ in range(warmup):
+        step()
+    barrier()
+    if bufs is not None:
+        status = int(bufs.dev_status.item())
+        assert status == 0, "device status %d" % status
+    ctx.set_profiling(True)  # HIP events between kernels on the launch stream (cheap; part of the timed region)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    samples = []
+    for _ in range(min(5, max(1, steps))):
+        c = {}
+        step(c)
+        samples.append(c)
+    for c in samples:
+        for k, v in c.items():
+            stage_sum[k] = stage_sum.get(k, 0.0) + v / len(samples)
+    ctx.set_profiling(False)
+    fill_verts = fill_idx = fill_meshes = 0
+    if bufs is not None:
+        assert int(bufs.dev_status.item()) == 0
+        got = bufs.dev_sizes.cpu().numpy()
+        assert int(got[3]) == sizes["num_vertices"] and int(got[4]) == sizes["num_indices"]
+        sizes["num_fill_elements"] = int(got[8])
+        sizes["num_elements"] = int(got[7])
+        mt = bufs.meshes[:sizes["num_meshes"] * 32].view(torch.int32).view(-1, 8)
+        is_fill = (mt[:, 7] >> 28) <= 1  # VGX_MESH_FILL / VGX_MESH_FILL_AA
+        fill_verts = int(mt[is_fill, 4].to(torch.int64).sum().item())
+        fill_idx = int(mt[is_fill, 5].to(torch.int64).sum().item())
+        fill_meshes = int(is_fill.sum().item())
+        del mt, is_fill
+    else:
+        sizes.setdefault("num_fill_elements", 0)
+        sizes.setdefault("num_elements", 0)
+    ab = algorithmic_bytes(cmd_bytes, ndraws, sizes, fill_verts, fill_idx, fill_meshes)
+    if kind == "flatten":
+        ab["pipeline"] = ab["flatten_emit"]
+    res.update(dt=dt, sizes=sizes, stage=stage_sum, ab=ab, units=units, unit_name=unit_name, bufs=bufs, pset=pset, dd=dd, scratch=ctx.scratch_bytes())
+    return res
+
+
+def roofline(res, steps, traffic_for=None):
+    """Roofline object of the dominant kernel (by HIP-event time) + the per-kernel table."""
+    stage_sum, ab = res["stage"], res["ab"]
+    cands = [k for k in stage_sum if k in ab and k != "pipeline"]
+    dom = max(cands, key=lambda k: stage_sum[k])
+    dom_ms = stage_sum[dom]
+    achieved = ab[dom] / (dom_ms * 1e-3) / 1e9
+    ms_per_step = res["dt"] / steps * 1e3
+    traffic = None
+    if traffic_for is not None:
+        # HBM traffic of that kernel per launch: not measurable from inside the process; taken from the committed
+        # rocprofv3 --pmc passes of this same command (profiles/traffic.json), only for the workload they were made on
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                tj = json.load(f)
+            if tj.get("instances_per_gpu") == traffic_for and dom in tj["kernels"]:
+                traffic = tj["kernels"][dom]["traffic_bytes"]
+        except (OSError, ValueError, KeyError):
+            pass
+    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "kernel_ms": round(dom_ms, 3), "algorithmic_bytes": ab[dom],
+            "by_kernel": {k: {"ms": round(stage_sum[k], 3), "achieved": round(ab[k] / (stage_sum[k] * 1e-3) / 1e9, 1),
+                              "frac": round(ab[k] / (stage_sum[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                          for k in ("fused", "flatten_build", "flatten_count", "flatten_emit", "fill_emit", "stroke_emit") if k in stage_sum and k in ab and stage_sum[k] > 0},
+            "pipeline_achieved": round(ab["pipeline"] / (ms_per_step * 1e-3) / 1e9, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--instances", type=int, default=10000, help="Tiger instances PER GPU (BASELINE config: 10000)")
-    ap.add_argument("--gather", action="store_true", help="also time the RCCL gather of the streams to rank 0")
+    ap.add_argument("--config", default="tiger10k", choices=sorted(WORKLOADS), help="workload of the headline line (default: the BASELINE metric's)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs reported under 'configs' (1-GPU runs)")
+    ap.add_argument("--gather", action="store_true", help="(default for --gpus > 1) also time the RCCL gather of the streams to rank 0")
+    ap.add_argument("--no-gather", action="store_true", help="multi-GPU: skip the gather leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -162,94 +314,52 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline()  # before any GPU work, in separate processes
 
-    K = args.instances
-    ps, ops = wl.tiger_paths()
-    draws = wl.tiger_draws(ops, K, first_instance=rank * K)
-    one = draws[:len(ops)]
-    ndraws = draws.shape[0]
-
-    ctx = rt.Context(local_rank)
-    pset = rt.PathSet(ctx, ps)
-    dd = rt.upload_draws(draws, local_rank)
-    del draws
-    sizes = rt.tessellate_count(ctx, pset, dd, ndraws)  # sizes scratch + tells us the output sizes
-    bufs = rt.MeshBuffers(dev, sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"])
-
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        rt.tessellate_async(ctx, pset, dd, ndraws, bufs)
-    barrier()
-    status = int(bufs.dev_status.item())
-    assert status == 0, "device status %d" % status
+    K = args.instances
+    ps, draws, workload_desc, kind = make_workload(wl, args.config, K, rank)
+    ctx = rt.Context(local_rank)
+    res = run_config(rt, torch, ctx, local_rank, args.config, ps, draws, kind, args.steps, args.warmup, barrier)
+    del draws
+    sizes, bufs, pset, dd, ndraws = res["sizes"], res["bufs"], res["pset"], res["dd"], res["ndraws"]
+    dt = res["dt"]
 
-    ctx.set_profiling(True)  # HIP events between kernels on the launch stream (cheap; part of the timed region)
-    stage_sum = {}
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rt.tessellate_async(ctx, pset, dd, ndraws, bufs)
-        if args.steps <= 64:
-            pass
-    barrier()
-    dt = time.perf_counter() - t0
-    # per-kernel durations of the LAST step (events are re-recorded every step); sample a few more steps
-    # outside the timed region for an average
-    samples = []
-    for _ in range(min(5, max(1, args.steps))):
-        rt.tessellate_async(ctx, pset, dd, ndraws, bufs)
-        torch.cuda.synchronize()
-        samples.append(dict(ctx.stage_times()))
-    for s in samples:
-        for k, v in s.items():
-            stage_sum[k] = stage_sum.get(k, 0.0) + v / len(samples)
-    assert int(bufs.dev_status.item()) == 0
-    got = bufs.dev_sizes.cpu().numpy()
-    assert int(got[3]) == sizes["num_vertices"] and int(got[4]) == sizes["num_indices"]
-
+    # ---- multi-GPU: the gather of the final streams to rank 0, timed by default, reported beside `value` ----
     gather_ms = None
-    if args.gather and world > 1:
+    if world > 1 and not args.no_gather and bufs is not None:
         dm = importlib.import_module("vg-renderer_amd.dist")
         barrier()
         g0 = time.perf_counter()
-        res = dm.gather_streams(bufs.pos, bufs.color, bufs.idx, bufs.meshes, sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"], ndraws)
+        gres = dm.gather_streams(bufs.pos, bufs.color, bufs.idx, bufs.meshes, sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"], ndraws)
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
-        del res
+        del gres
 
     red_dev = torch.device("cpu") if share_gpu else dev
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-    vtot = torch.tensor([float(sizes["num_vertices"])], dtype=torch.float64, device=red_dev)
+    vtot = torch.tensor([float(res["units"])], dtype=torch.float64, device=red_dev)
     if world > 1:
         import torch.distributed as dist
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(vtot, op=dist.ReduceOp.SUM)
     dt = float(tmax.item())
-    total_verts = float(vtot.item())
-
-    fill_verts = fill_idx = fill_meshes = 0
-    if rank == 0:
-        mt = bufs.meshes[:sizes["num_meshes"] * 32].view(torch.int32).view(-1, 8)
-        is_fill = (mt[:, 7] >> 28) <= 1  # VGX_MESH_FILL / VGX_MESH_FILL_AA
-        fill_verts = int(mt[is_fill, 4].to(torch.int64).sum().item())
-        fill_idx = int(mt[is_fill, 5].to(torch.int64).sum().item())
-        fill_meshes = int(is_fill.sum().item())
-        del mt, is_fill
+    res["dt"] = dt
+    total_units = float(vtot.item())
 
     # ---- next rows, measured beside the headline on rank 0 of a 1-GPU run: not part of `value` ----
     next_rows = None
-    if rank == 0 and world == 1:
-        import numpy as np
+    if rank == 0 and world == 1 and args.config == "tiger10k":
         nv_all, ni_all = sizes["num_vertices"], sizes["num_indices"]
         # draw-command assembly armed: cost of the partition kernels inside one step
         cap = 2 * (nv_all // 65536) + 2
         cmds = torch.zeros(cap * 40, dtype=torch.uint8, device=dev)
         ncmd = torch.zeros(1, dtype=torch.int64, device=dev)
         ctx.set_assembly(cmds, 0, ncmd)
+        ctx.set_profiling(True)
         rt.tessellate_async(ctx, pset, dd, ndraws, bufs)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -258,6 +368,7 @@ def main():
         torch.cuda.synchronize()
         asm_ms = (time.perf_counter() - t1) / 3 * 1e3
         asm_stage = dict(ctx.stage_times()).get("assemble")
+        ctx.set_profiling(False)
         ctx.set_assembly(None)
         assert int(bufs.dev_status.item()) == 0
         # shape cache: ONE drawing tessellated, submitted K times (same transforms as the instances of the headline run)
@@ -292,50 +403,59 @@ def main():
                                    "frac": round(cache_bytes / (cache_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                    "workload": "one tiger-like drawing tessellated once, submitted %d times (vgx_cache_submit)" % K},
         }
+        del cache, cb, raw
+
+    # ---- the other BASELINE configs north_star names ("N cubics, M-segment strokes"), 1-GPU runs, beside the headline ----
+    other = None
+    if rank == 0 and world == 1 and not args.no_configs:
+        other = {}
+        del bufs
+        res["bufs"] = None
+        pset.close()
+        torch.cuda.empty_cache()
+        for name in WORKLOADS:
+            if name == args.config:
+                continue
+            ps2, d2, desc2, kind2 = make_workload(wl, name, K, 0)
+            steps2 = min(args.steps, 5)
+            r2 = run_config(rt, torch, ctx, local_rank, name, ps2, d2, kind2, steps2, min(args.warmup, 2), barrier)
+            ms2 = r2["dt"] / steps2 * 1e3
+            other[name] = {"config": WORKLOADS[name], "workload": desc2,
+                           "value": round(r2["units"] / (ms2 * 1e-3) / 1e6, 2), "unit": "M %s/s" % r2["unit_name"], "ms_per_step": round(ms2, 3), "steps": steps2,
+                           "verts_per_gpu": r2["sizes"].get("num_vertices", 0), "indices_per_gpu": r2["sizes"].get("num_indices", 0),
+                           "poly_verts_per_gpu": r2["sizes"]["num_poly_vertices"], "meshes_per_gpu": r2["sizes"].get("num_meshes", 0),
+                           "roofline": roofline(r2, steps2), "stage_ms": {k: round(v, 3) for k, v in r2["stage"].items()}}
+            r2["pset"].close()
+            del r2, ps2, d2
+            torch.cuda.empty_cache()
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = total_verts * args.steps / dt / 1e6
-        sizes["num_fill_elements"] = int(got[8])
-        sizes["num_elements"] = int(got[7])
-        ab = algorithmic_bytes(ps, one, K, sizes, fill_verts, fill_idx, fill_meshes)
-        dom = max((k for k in stage_sum if k in ab and k != "pipeline"), key=lambda k: stage_sum[k])
-        dom_ms = stage_sum[dom]
-        achieved = ab[dom] / (dom_ms * 1e-3) / 1e9
-        # HBM traffic of that kernel per launch: not measurable from inside the process; taken from the committed
-        # rocprofv3 --pmc passes of this same command (profiles/traffic.json), only for the workload they were made on
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                tj = json.load(f)
-            if tj.get("instances_per_gpu") == K and dom in tj["kernels"]:
-                traffic = tj["kernels"][dom]["traffic_bytes"]
-        except (OSError, ValueError, KeyError):
-            pass
+        value = total_units * args.steps / dt / 1e6
+        metric = "M tessellated verts/sec (stroke+fill AA), Tiger×10k batch, 1/2/4/8 GPUs"
+        if args.config != "tiger10k":
+            metric = "M %s/sec, %s" % (res["unit_name"], WORKLOADS[args.config])
         out = {
-            "metric": "M tessellated verts/sec (stroke+fill AA), Tiger\u00d710k batch, 1/2/4/8 GPUs",
+            "metric": metric,
             "value": round(value, 2), "unit": "M verts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "tiger-like 240-path drawing (seed 2024) x %d instances per GPU: convexFillAA on every sub-path + polylineStrokeAA/AAThin (Butt/Miter) on 1/3 of the paths" % K,
-                       "instances_per_gpu": K, "draws_per_gpu": ndraws, "parallelism": "shard%d" % world,
-                       "verts_per_gpu": sizes["num_vertices"], "indices_per_gpu": sizes["num_indices"], "meshes_per_gpu": sizes["num_meshes"],
+            "config": {"workload": workload_desc, "name": args.config,
+                       "instances_per_gpu": K if args.config == "tiger10k" else None, "draws_per_gpu": ndraws, "parallelism": "shard%d" % world,
+                       "verts_per_gpu": sizes.get("num_vertices", 0), "indices_per_gpu": sizes.get("num_indices", 0), "meshes_per_gpu": sizes.get("num_meshes", 0),
                        "poly_verts_per_gpu": sizes["num_poly_vertices"], "serial_draws": sizes["num_serial_draws"],
-                       "scratch_bytes_per_gpu": ctx.scratch_bytes()},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel_ms": round(dom_ms, 3), "algorithmic_bytes": ab[dom],
-                         "by_kernel": {k: {"ms": round(stage_sum[k], 3), "achieved": round(ab[k] / (stage_sum[k] * 1e-3) / 1e9, 1),
-                                           "frac": round(ab[k] / (stage_sum[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-                                       for k in ("fused", "flatten_build", "fill_emit", "stroke_emit") if k in stage_sum and k in ab},
-                         "pipeline_achieved": round(ab["pipeline"] / (ms_per_step * 1e-3) / 1e9, 1)},
-            "stage_ms": {k: round(v, 3) for k, v in stage_sum.items()},
+                       "scratch_bytes_per_gpu": res["scratch"]},
+            "roofline": roofline(res, args.steps, traffic_for=K if args.config == "tiger10k" else None),
+            "stage_ms": {k: round(v, 3) for k, v in res["stage"].items()},
             "cpu_baseline": cpu,
             "next_rows": next_rows,
+            "configs": other,
         }
         if gather_ms is not None:
+            # SURVEY 8e defines the scaling target INCLUDING the gather of the final streams to the root: `value` is the
+            # tessellation rate of all ranks, `value_with_gather` the rate with one (un-overlapped) gather per step added
             out["gather_ms"] = round(gather_ms, 2)
-            out["value_with_gather"] = round(total_verts / ((dt / args.steps) + gather_ms * 1e-3) / 1e6, 2)
+            out["value_with_gather"] = round(total_units / ((dt / args.steps) + gather_ms * 1e-3) / 1e6, 2)
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

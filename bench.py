@@ -329,15 +329,67 @@ def main():
     dt = res["dt"]
 
     # ---- multi-GPU: the gather of the final streams to rank 0, timed by default, reported beside `value` ----
+    # Preferred: libvgx's own RCCL gather behind the C-ABI (vgx_gather) on a dedicated communicator; the torch.distributed
+    # version of the same layout (vg-renderer_amd/dist.py) when that cannot be set up (e.g. the shared-GPU test mode).
+    # A watchdog thread bounds the C-ABI leg so that a stuck transfer can never swallow the bench line.
     gather_ms = None
-    if world > 1 and not args.no_gather and bufs is not None:
+    gather_via = None
+    if (world > 1 or os.environ.get("VGX_BENCH_FORCE_GATHER") == "1") and not args.no_gather and bufs is not None:
         dm = importlib.import_module("vg-renderer_amd.dist")
-        barrier()
-        g0 = time.perf_counter()
-        gres = dm.gather_streams(bufs.pos, bufs.color, bufs.idx, bufs.meshes, sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"], ndraws)
-        barrier()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        del gres
+        import threading
+        if world == 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        box = {}
+
+        def capi_leg():
+            try:
+                cg = dm.CapiGather(ctx, local_rank)
+                allz = cg.sizes(sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"], ndraws)
+                gb = None
+                if rank == 0:
+                    gb = rt.MeshBuffers(dev, sum(z.num_vertices for z in allz), sum(z.num_indices for z in allz), sum(z.num_meshes for z in allz))
+                cg.gather(bufs, allz, 0, gb)  # warm-up: connection set-up is not part of a steady-state gather
+                barrier()
+                g0 = time.perf_counter()
+                cg.gather(bufs, allz, 0, gb)
+                barrier()
+                box["ms"] = (time.perf_counter() - g0) * 1e3
+                if rank == 0 and world == 1:  # one rank: the gathered streams are the local ones
+                    nv = sizes["num_vertices"]
+                    box["check"] = bool(torch.equal(gb.pos[:nv], bufs.pos[:nv]) and torch.equal(gb.meshes, bufs.meshes))
+                del gb
+                cg.close()
+            except Exception as e:  # noqa: BLE001 -- any failure falls back to the torch.distributed gather
+                box["err"] = repr(e)
+
+        if os.environ.get("VGX_BENCH_GATHER", "capi") == "capi" and not share_gpu:
+            th = threading.Thread(target=capi_leg, daemon=True)
+            th.start()
+            th.join(timeout=float(os.environ.get("VGX_BENCH_GATHER_TIMEOUT", "180")))
+            if th.is_alive():
+                box["err"] = "timeout"
+        else:
+            box["err"] = "disabled"
+        ok = torch.tensor([1 if "ms" in box else 0], dtype=torch.int32, device=torch.device("cpu") if share_gpu else dev)
+        if world > 1 and box.get("err") != "timeout":
+            import torch.distributed as dist
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            gather_ms, gather_via = box["ms"], "vgx_gather (C-ABI, dedicated RCCL communicator)"
+        elif box.get("err") != "timeout" and world > 1:
+            barrier()
+            g0 = time.perf_counter()
+            gres = dm.gather_streams(bufs.pos, bufs.color, bufs.idx, bufs.meshes, sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"], ndraws)
+            barrier()
+            gather_ms = (time.perf_counter() - g0) * 1e3
+            gather_via = "torch.distributed isend/irecv (vg-renderer_amd/dist.py); C-ABI leg: %s" % box.get("err")
+            del gres
+        else:
+            gather_via = "not measured: %s" % box.get("err")
+        res["gather_check"] = box.get("check")
 
     red_dev = torch.device("cpu") if share_gpu else dev
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
@@ -456,7 +508,16 @@ def main():
             # tessellation rate of all ranks, `value_with_gather` the rate with one (un-overlapped) gather per step added
             out["gather_ms"] = round(gather_ms, 2)
             out["value_with_gather"] = round(total_units / ((dt / args.steps) + gather_ms * 1e-3) / 1e6, 2)
-        print(json.dumps(out))
+        if gather_via is not None:
+            out["gather_via"] = gather_via
+            if res.get("gather_check") is not None:
+                out["gather_check"] = res["gather_check"]
+        try:  # RCCL writes a version banner to the C stdout at communicator creation: get it out BEFORE the JSON line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -374,6 +374,30 @@ typedef struct vgx_failure_info {
 } vgx_failure_info;
 int vgx_get_failure_info(vgx_ctx* ctx, vgx_failure_info* out, void* stream);
 
+/* ---- multi-GPU: gather of the per-rank streams to one root over RCCL / xGMI ---------------------------------
+ * Independent path instances shard embarrassingly: one process per GPU, rank r tessellates a contiguous range of the
+ * draws, no data-path collective. Indices are mesh-local, so the single-GPU result is the per-rank streams concatenated
+ * in rank order; only the mesh table's first_vertex / first_index / draw need the rank's base added. This is the one
+ * exchange step, for a C / C++ host that owns an RCCL communicator (`rccl_comm` is its ncclComm_t, created on the
+ * context's device; librccl is bound at the first call from the library already loaded in the process, libvgx.so itself
+ * has no link-time dependency on it). vg-renderer_amd/dist.py is the same layout over torch.distributed.
+ *
+ *   vgx_gather_sizes  all-gathers the four per-rank totals on the device (ncclAllGather of 4 x uint64 through context
+ *                     scratch) and copies them to `all` (HOST, [nranks], rank order). Synchronises `stream`. Batches that
+ *                     keep their shape from frame to frame call it once.
+ *   vgx_gather        enqueues on `stream`, without any host synchronisation: on every other rank four ncclSend (positions,
+ *                     colours, indices, mesh table) to `root`; on the root the matching ncclRecv straight into `global` at
+ *                     each rank's offset, all inside ONE group (each peer -> root transfer rides its own xGMI link), a
+ *                     device-to-device copy of the root's own block, and the rebase of the gathered mesh table (one
+ *                     kernel). `global` is only read on the root (capacities checked against the totals: VGX_E_NOSPACE).
+ *                     To overlap the gather of frame i with the tessellation of frame i + 1, call it on a second stream
+ *                     with double-buffered outputs: nothing in it touches context scratch that vgx_tessellate uses.
+ * Errors: VGX_E_NO_DEVICE when no RCCL library can be bound, VGX_E_HIP when an RCCL call fails (vgx_last_hip_error() then
+ * holds 10000 + the ncclResult_t). */
+typedef struct vgx_rank_sizes { uint64_t num_vertices, num_indices, num_meshes, num_draws; } vgx_rank_sizes;
+int vgx_gather_sizes(vgx_ctx* ctx, void* rccl_comm, const vgx_rank_sizes* mine, vgx_rank_sizes* all, void* stream);
+int vgx_gather(vgx_ctx* ctx, void* rccl_comm, int root, const vgx_mesh_out* local, const vgx_rank_sizes* all, const vgx_mesh_out* global, void* stream);
+
 /* Per-kernel timing of the last vgx_tessellate.. / vgx_flatten.. sequence, measured with HIP events
  * on the stream the kernels ran on. Enable before the call; read after synchronising. */
 #define VGX_MAX_STAGES 16

@@ -1,0 +1,39 @@
+"""vgx_gather_sizes / vgx_gather (the RCCL gather behind the C-ABI) driven from C++ (tests/native/gather_test.cpp):
+  - 1 rank over the REAL librccl (binding by dlopen, ncclAllGather, local copies, capacity check),
+  - 2 and 3 ranks as threads on the one GPU over tests/native/fake_rccl.cpp (RCCL refuses two ranks on one device): shard ->
+    tessellate -> gather -> byte-identical streams and mesh table to a single context tessellating the whole batch,
+    root = first and last rank (so the root's own block is rebased too).
+The real multi-GPU transfer is only exercised by the driver's N-GPU bench (bench.py --gpus N)."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "vg-renderer_amd")
+
+
+@pytest.fixture(scope="module")
+def binaries(tmp_path_factory):
+    d = tmp_path_factory.mktemp("gather")
+    exe, fake = str(d / "gather_test"), str(d / "libfake_rccl.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "gather_test.cpp"),
+                           "-L", PKG, "-lvgx", "-L/opt/rocm/lib", "-lrccl", "-ldl", "-lpthread", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    subprocess.check_call(["g++", "-shared", "-fPIC", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "native", "fake_rccl.cpp"),
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-o", fake])
+    return exe, fake
+
+
+def test_gather_one_rank_real_rccl(binaries):
+    exe, _ = binaries
+    out = subprocess.check_output([exe, "real"], text=True, timeout=300)
+    assert "ranks 1 root 0" in out and "identical to the single-context run" in out
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_gather_threaded_ranks(binaries, nranks):
+    exe, fake = binaries
+    out = subprocess.check_output([exe, "fake", fake, str(nranks)], text=True, timeout=300)
+    assert out.count("identical to the single-context run") == 2, out
+    assert "MISMATCH" not in out

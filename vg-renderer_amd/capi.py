@@ -139,6 +139,10 @@ class FailureInfo(C.Structure):
         return d
 
 
+class RankSizes(C.Structure):
+    _fields_ = [("num_vertices", C.c_uint64), ("num_indices", C.c_uint64), ("num_meshes", C.c_uint64), ("num_draws", C.c_uint64)]
+
+
 # Every symbol include/vgx.h declares, with (restype, argtypes). tests/test_capi_symbols.py checks the
 # built library exports all of them.
 VGX_SYMBOLS = {
@@ -166,6 +170,8 @@ VGX_SYMBOLS = {
                                    C.POINTER(MeshOut), C.c_void_p, C.c_void_p, C.c_void_p]),
     "vgx_cmdlist_decode": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(CmdListState), C.POINTER(CmdListOut)]),
     "vgx_get_failure_info": (C.c_int, [C.c_void_p, C.POINTER(FailureInfo), C.c_void_p]),
+    "vgx_gather_sizes": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(RankSizes), C.POINTER(RankSizes), C.c_void_p]),
+    "vgx_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(MeshOut), C.POINTER(RankSizes), C.POINTER(MeshOut), C.c_void_p]),
     "vgx_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "vgx_get_stage_times": (C.c_int, [C.c_void_p, C.POINTER(StageTimes)]),
 }

@@ -58,6 +58,8 @@ struct vgx_ctx
 	vgx_assembly asmCfg;
 	bool asmArmed;
 	DevBuf cmdPrefix, cmdCnt, subFirst, leafOverflow, serialList, dinfo, poly, subs, mdesc, elemPrefix, elemPrefixS, mprep, mtab, partial, totals;
+	DevBuf gatherSizes;                  // vgx_gather_sizes: [nranks][4] uint64
+	struct VgxRccl* rccl;                // RCCL entry points, bound at the first vgx_gather* call
 	DevBuf segStart, segState, probeOut; // fused single-pass path: segment table, look-back granules + ticket, probe counters
 	uint32_t fusedSegItems;      // commands per segment chosen by the last vgx_tessellate_count (0 = multi-kernel pipeline)
 	uint64_t fusedSegCap;        // segments the tables above hold
@@ -79,6 +81,8 @@ struct vgx_ctx
 	uint32_t numEv;
 	bool evCreated;
 };
+
+static void vgx_rccl_release(vgx_ctx* ctx);
 
 namespace {
 
@@ -769,12 +773,13 @@ int vgx_destroy(vgx_ctx* ctx)
 		return VGX_E_INVALID_ARG;
 	}
 	DeviceGuard guard(ctx);
-	DevBuf* bufs[] = { &ctx->segStart, &ctx->segState, &ctx->probeOut, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DevBuf* bufs[] = { &ctx->gatherSizes, &ctx->segStart, &ctx->segState, &ctx->probeOut, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
 	if (ctx->hostTotals) { (void)hipHostFree(ctx->hostTotals); }
 	if (ctx->hostProbe) { (void)hipHostFree(ctx->hostProbe); }
+	vgx_rccl_release(ctx);
 	if (ctx->evCreated) {
 		for (int i = 0; i <= VGX_MAX_STAGES; ++i) { (void)hipEventDestroy(ctx->ev[i]); }
 	}
@@ -789,7 +794,7 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx)
 	if (!ctx) {
 		return 0;
 	}
-	return ctx->segStart.cap + ctx->segState.cap + ctx->probeOut.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
+	return ctx->gatherSizes.cap + ctx->segStart.cap + ctx->segState.cap + ctx->probeOut.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
 }
 
 // ---- path set ---------------------------------------------------------------------------------------
@@ -1420,3 +1425,192 @@ int vgx_get_stage_times(vgx_ctx* ctx, vgx_stage_times* out)
 }
 
 } // extern "C"
+
+// ---- multi-GPU gather over RCCL (the layout of vg-renderer_amd/dist.py behind the C-ABI) ------------------
+// librccl is bound with dlopen / dlsym from the copy the process already has (a C++ host links it; a torch process
+// carries its own), never linked: libvgx.so loads on boxes without it and cannot pull a second copy into a process.
+#include <dlfcn.h>
+
+struct VgxRccl
+{
+	void* lib;
+	int (*GroupStart)();
+	int (*GroupEnd)();
+	int (*Send)(const void*, size_t, int, int, void*, hipStream_t);
+	int (*Recv)(void*, size_t, int, int, void*, hipStream_t);
+	int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t);
+	int (*CommCount)(void*, int*);
+	int (*CommUserRank)(void*, int*);
+};
+enum { kNcclUint8 = 1, kNcclUint64 = 5 }; // ncclDataType_t values (rccl.h)
+
+static void vgx_rccl_release(vgx_ctx* ctx)
+{
+	if (ctx->rccl) {
+		if (ctx->rccl->lib) { (void)dlclose(ctx->rccl->lib); }
+		delete ctx->rccl;
+		ctx->rccl = nullptr;
+	}
+}
+
+namespace {
+
+int bindRccl(vgx_ctx* ctx)
+{
+	if (ctx->rccl) {
+		return VGX_OK;
+	}
+	void* h = nullptr;
+	if (const char* over = getenv("VGX_RCCL_LIB")) { h = dlopen(over, RTLD_NOW | RTLD_LOCAL); } // testing knob: tests/native/fake_rccl.cpp
+	const char* names[] = { "librccl.so.1", "librccl.so" };
+	for (const char* n : names) { if (!h) { h = dlopen(n, RTLD_NOW | RTLD_NOLOAD); } } // the copy the process already uses
+	for (const char* n : names) { if (!h) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); } }
+	if (!h) { h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL); }
+	if (!h) {
+		return VGX_E_NO_DEVICE;
+	}
+	VgxRccl* r = new VgxRccl;
+	r->lib = h;
+	r->GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
+	r->GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
+	r->Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclSend");
+	r->Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclRecv");
+	r->AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+	r->CommCount = (int (*)(void*, int*))dlsym(h, "ncclCommCount");
+	r->CommUserRank = (int (*)(void*, int*))dlsym(h, "ncclCommUserRank");
+	if (!r->GroupStart || !r->GroupEnd || !r->Send || !r->Recv || !r->AllGather || !r->CommCount || !r->CommUserRank) {
+		(void)dlclose(h);
+		delete r;
+		return VGX_E_NO_DEVICE;
+	}
+	ctx->rccl = r;
+	return VGX_OK;
+}
+
+#define RCCLCHK(ctx, call)                                    \
+	do {                                                      \
+		const int r_ = (call);                                \
+		if (r_ != 0) {                                        \
+			(ctx)->lastHipError = 10000 + r_;                 \
+			return VGX_E_HIP;                                 \
+		}                                                     \
+	} while (0)
+
+// mesh records of rank r sit at [mesh0, mesh1): add the rank's vertex / index / draw bases
+struct GatherRebase { uint64_t mesh0, mesh1, vbase, ibase; uint32_t dbase; };
+#define VGX_GATHER_MAX_RANKS 64
+struct GatherRebaseArgs { vgx_mesh* meshes; int n; GatherRebase r[VGX_GATHER_MAX_RANKS]; };
+
+__global__ __launch_bounds__(256) void k_gather_rebase(GatherRebaseArgs A)
+{
+	const GatherRebase R = A.r[blockIdx.y];
+	for (uint64_t m = R.mesh0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; m < R.mesh1; m += (uint64_t)gridDim.x * blockDim.x) {
+		vgx_mesh rec = A.meshes[m];
+		rec.first_vertex += R.vbase;
+		rec.first_index += R.ibase;
+		rec.draw += R.dbase;
+		A.meshes[m] = rec;
+	}
+}
+
+} // namespace
+
+extern "C" int vgx_gather_sizes(vgx_ctx* ctx, void* rccl_comm, const vgx_rank_sizes* mine, vgx_rank_sizes* all, void* stream)
+{
+	DeviceGuard guard(ctx);
+	if (!ctx || !rccl_comm || !mine || !all) {
+		return VGX_E_INVALID_ARG;
+	}
+	int st = bindRccl(ctx);
+	if (st != VGX_OK) { return st; }
+	int nranks = 0, rank = 0;
+	RCCLCHK(ctx, ctx->rccl->CommCount(rccl_comm, &nranks));
+	RCCLCHK(ctx, ctx->rccl->CommUserRank(rccl_comm, &rank));
+	if (nranks < 1 || rank < 0 || rank >= nranks) { return VGX_E_INVALID_ARG; }
+	if ((st = ensure(ctx, ctx->gatherSizes, (size_t)nranks * sizeof(vgx_rank_sizes))) != VGX_OK) { return st; }
+	hipStream_t s = (hipStream_t)stream;
+	vgx_rank_sizes* dev = (vgx_rank_sizes*)ctx->gatherSizes.p;
+	HIPCHK(ctx, hipMemcpyAsync(dev + rank, mine, sizeof(vgx_rank_sizes), hipMemcpyHostToDevice, s));
+	RCCLCHK(ctx, ctx->rccl->AllGather(dev + rank, dev, 4, kNcclUint64, rccl_comm, s)); // in place: my slot is my send buffer
+	HIPCHK(ctx, hipMemcpyAsync(all, dev, (size_t)nranks * sizeof(vgx_rank_sizes), hipMemcpyDeviceToHost, s));
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	return VGX_OK;
+}
+
+extern "C" int vgx_gather(vgx_ctx* ctx, void* rccl_comm, int root, const vgx_mesh_out* local, const vgx_rank_sizes* all, const vgx_mesh_out* global, void* stream)
+{
+	DeviceGuard guard(ctx);
+	if (!ctx || !rccl_comm || !local || !all) {
+		return VGX_E_INVALID_ARG;
+	}
+	int st = bindRccl(ctx);
+	if (st != VGX_OK) { return st; }
+	int nranks = 0, rank = 0;
+	RCCLCHK(ctx, ctx->rccl->CommCount(rccl_comm, &nranks));
+	RCCLCHK(ctx, ctx->rccl->CommUserRank(rccl_comm, &rank));
+	if (nranks < 1 || nranks > VGX_GATHER_MAX_RANKS || root < 0 || root >= nranks) { return VGX_E_INVALID_ARG; }
+	hipStream_t s = (hipStream_t)stream;
+	const vgx_rank_sizes& me = all[rank];
+	if (me.num_vertices > local->cap_vertices || me.num_indices > local->cap_indices || (local->meshes && me.num_meshes > local->cap_meshes)) {
+		return VGX_E_INVALID_ARG; // the sizes do not describe `local`
+	}
+	if (rank != root) {
+		RCCLCHK(ctx, ctx->rccl->GroupStart());
+		if (me.num_vertices) {
+			RCCLCHK(ctx, ctx->rccl->Send(local->pos, me.num_vertices * 8, kNcclUint8, root, rccl_comm, s));
+			RCCLCHK(ctx, ctx->rccl->Send(local->color, me.num_vertices * 4, kNcclUint8, root, rccl_comm, s));
+		}
+		if (me.num_indices) { RCCLCHK(ctx, ctx->rccl->Send(local->idx, me.num_indices * 2, kNcclUint8, root, rccl_comm, s)); }
+		if (me.num_meshes) { RCCLCHK(ctx, ctx->rccl->Send(local->meshes, me.num_meshes * sizeof(vgx_mesh), kNcclUint8, root, rccl_comm, s)); }
+		RCCLCHK(ctx, ctx->rccl->GroupEnd());
+		return VGX_OK;
+	}
+	if (!global || !global->pos || !global->color || !global->idx || !global->meshes) {
+		return VGX_E_INVALID_ARG;
+	}
+	uint64_t tv = 0, ti = 0, tm = 0;
+	for (int r = 0; r < nranks; ++r) { tv += all[r].num_vertices; ti += all[r].num_indices; tm += all[r].num_meshes; }
+	if (tv > global->cap_vertices || ti > global->cap_indices || tm > global->cap_meshes) {
+		return VGX_E_NOSPACE;
+	}
+	GatherRebaseArgs ra;
+	ra.meshes = global->meshes;
+	ra.n = 0;
+	uint64_t maxMeshes = 0;
+	uint64_t vo = 0, io = 0, mo = 0, dofs = 0;
+	RCCLCHK(ctx, ctx->rccl->GroupStart());
+	for (int r = 0; r < nranks; ++r) {
+		const vgx_rank_sizes& z = all[r];
+		if (r == root) {
+			// my own block: plain copies on the same stream (they overlap with the incoming transfers)
+			if (z.num_vertices) {
+				noteHip(ctx, hipMemcpyAsync(global->pos + 2 * vo, local->pos, z.num_vertices * 8, hipMemcpyDeviceToDevice, s));
+				noteHip(ctx, hipMemcpyAsync(global->color + vo, local->color, z.num_vertices * 4, hipMemcpyDeviceToDevice, s));
+			}
+			if (z.num_indices) { noteHip(ctx, hipMemcpyAsync(global->idx + io, local->idx, z.num_indices * 2, hipMemcpyDeviceToDevice, s)); }
+			if (z.num_meshes) { noteHip(ctx, hipMemcpyAsync(global->meshes + mo, local->meshes, z.num_meshes * sizeof(vgx_mesh), hipMemcpyDeviceToDevice, s)); }
+		} else {
+			if (z.num_vertices) {
+				RCCLCHK(ctx, ctx->rccl->Recv(global->pos + 2 * vo, z.num_vertices * 8, kNcclUint8, r, rccl_comm, s));
+				RCCLCHK(ctx, ctx->rccl->Recv(global->color + vo, z.num_vertices * 4, kNcclUint8, r, rccl_comm, s));
+			}
+			if (z.num_indices) { RCCLCHK(ctx, ctx->rccl->Recv(global->idx + io, z.num_indices * 2, kNcclUint8, r, rccl_comm, s)); }
+			if (z.num_meshes) { RCCLCHK(ctx, ctx->rccl->Recv(global->meshes + mo, z.num_meshes * sizeof(vgx_mesh), kNcclUint8, r, rccl_comm, s)); }
+		}
+		if (z.num_meshes && (vo || io || dofs)) {
+			GatherRebase& g = ra.r[ra.n++];
+			g.mesh0 = mo; g.mesh1 = mo + z.num_meshes; g.vbase = vo; g.ibase = io; g.dbase = (uint32_t)dofs;
+			if (z.num_meshes > maxMeshes) { maxMeshes = z.num_meshes; }
+		}
+		vo += z.num_vertices; io += z.num_indices; mo += z.num_meshes; dofs += z.num_draws;
+	}
+	RCCLCHK(ctx, ctx->rccl->GroupEnd());
+	if (ra.n) {
+		const uint64_t blocks = (maxMeshes + 255) / 256;
+		hipLaunchKernelGGL(k_gather_rebase, dim3((unsigned)(blocks > 4096 ? 4096 : blocks), (unsigned)ra.n), dim3(256), 0, s, ra);
+	}
+	if (ctx->pendingHipError) { ctx->lastHipError = ctx->pendingHipError; ctx->pendingHipError = 0; return VGX_E_HIP; }
+	const hipError_t e = hipGetLastError();
+	if (e != hipSuccess) { ctx->lastHipError = (int)e; return VGX_E_HIP; }
+	return VGX_OK;
+}

@@ -86,3 +86,70 @@ def gather_streams(pos, color, idx, meshes_u8, nverts, nidx, nmeshes, ndraws_loc
                 rec64[a:b, 1] += int(io[r])
                 rec32[a:b, 6] += int(do[r])
     return dict(pos=gpos, color=gcol, idx=gidx, meshes_u8=gm, counts=counts)
+
+
+# ---- the same gather through the C-ABI (vgx_gather_sizes / vgx_gather, include/vgx.h) ------------------------------------
+class CapiGather:
+    """Runs libvgx's own RCCL gather from a torch.distributed job: creates a dedicated RCCL communicator on the copy of
+    librccl the process already carries (torch's), one rank per process, and hands it to vgx_gather. This is what a C++
+    host would do with its own communicator; torch is only used to broadcast the 128-byte unique id."""
+
+    def __init__(self, ctx, device_index, group=None):
+        import ctypes as C
+        import os
+        from . import capi, runtime
+        self.C, self.capi, self.rt, self.ctx = C, capi, runtime, ctx
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        cand = [os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"]
+        self.lib = None
+        for c in cand:
+            try:
+                self.lib = C.CDLL(c)
+                break
+            except OSError:
+                continue
+        if self.lib is None:
+            raise RuntimeError("no librccl found")
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        uid = UniqueId()
+        if self.rank == 0:
+            r = self.lib.ncclGetUniqueId(C.byref(uid))
+            if r != 0:
+                raise RuntimeError("ncclGetUniqueId -> %d" % r)
+        backend = dist.get_backend(group)
+        raw = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone()
+        if backend == "nccl":
+            raw = raw.to(torch.device("cuda", device_index))
+        dist.broadcast(raw, 0, group=group)
+        C.memmove(C.byref(uid), bytes(raw.cpu().numpy().tobytes()), 128)
+        self.comm = C.c_void_p()
+        self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        torch.cuda.set_device(device_index)
+        r = self.lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank)
+        if r != 0:
+            raise RuntimeError("ncclCommInitRank -> %d" % r)
+
+    def sizes(self, nverts, nidx, nmeshes, ndraws):
+        C = self.C
+        mine = self.capi.RankSizes(nverts, nidx, nmeshes, ndraws)
+        allz = (self.capi.RankSizes * self.world)()
+        self.rt._check(self.rt.lib().vgx_gather_sizes(self.ctx.handle, self.comm, C.byref(mine), allz, self.rt._stream_ptr()), "vgx_gather_sizes")
+        return allz
+
+    def gather(self, bufs, allz, root=0, global_bufs=None):
+        """bufs / global_bufs: runtime.MeshBuffers. Enqueues on the current stream; no host synchronisation."""
+        C = self.C
+        local = bufs.out_struct()
+        me = allz[self.rank]
+        local.cap_vertices = max(local.cap_vertices, me.num_vertices)
+        g = global_bufs.out_struct() if global_bufs is not None else None
+        self.rt._check(self.rt.lib().vgx_gather(self.ctx.handle, self.comm, root, C.byref(local), allz, C.byref(g) if g is not None else None, self.rt._stream_ptr()), "vgx_gather")
+
+    def close(self):
+        if self.comm:
+            self.lib.ncclCommDestroy.argtypes = [self.C.c_void_p]
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = None

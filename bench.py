@@ -408,7 +408,7 @@ def main():
         nv_all, ni_all = sizes["num_vertices"], sizes["num_indices"]
         # draw-command assembly armed: cost of the partition kernels inside one step
         cap = 2 * (nv_all // 65536) + 2
-        cmds = torch.zeros(cap * 40, dtype=torch.uint8, device=dev)
+        cmds = torch.zeros(cap * 48, dtype=torch.uint8, device=dev)
         ncmd = torch.zeros(1, dtype=torch.int64, device=dev)
         ctx.set_assembly(cmds, 0, ncmd)
         ctx.set_profiling(True)

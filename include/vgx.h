@@ -96,7 +96,11 @@ typedef struct vgx_draw {
 	float tess_tol;        /* tesselationTolerance (Context::m_TesselationTolerance) */
 	float fringe;          /* fringeWidth (Context::m_FringeWidth) */
 	float mtx[6];          /* 2x3 state transform [m0 m2 m4; m1 m3 m5] used by transformPath */
-	uint32_t reserved;     /* must be 0 */
+	uint32_t state_key;    /* draw-command assembly only (VGX_ASM_SPLIT_STATE): what allocDrawCommand / allocClipCommand compare
+	                        * before merging a mesh into the previous command (vg.cpp:5376-5379, 5418-5428), folded by the host
+	                        * into one word: DrawCommand::m_Type << 16 | m_HandleID in the low 20 bits, and above them a
+	                        * generation the host bumps whenever it would set m_ForceNewDrawCommand / m_ForceNewClipCommand
+	                        * (beginClip / endClip / resetClip / scissor changes, vg.cpp:3682-4026). 0 everywhere = one draw state */
 } vgx_draw;
 
 /* Path definitions ("path set"), host-side description handed to vgx_pathset_create.
@@ -178,26 +182,37 @@ typedef struct vgx_mesh_out {
 } vgx_mesh_out;
 
 /* ---- draw-command assembly (optional next step of the frame) ------------------
- * What createDrawCommand_VertexColor does after every stroker call (src/vg.cpp:5207-5244): vertices go to the
- * current vertex buffer until it would exceed m_MaxVBVertices (allocVertices, :5321-5342), a new vertex buffer
- * forces a new draw command, meshes otherwise merge into the previous command (allocDrawCommand, :5359-5407), and
- * indices are rebased by the vertices already in the command (vgutil::batchTransformDrawIndices,
- * vg_util.cpp:447-520). One vgx_drawcmd per vertex buffer; 40 bytes. */
+ * What createDrawCommand_VertexColor / _Clip do after every stroker call (src/vg.cpp:5207-5244, 5297-5317): vertices go to
+ * the current vertex buffer until it would exceed m_MaxVBVertices (allocVertices, :5321-5342), a new vertex buffer
+ * forces a new draw command, meshes otherwise merge into the previous command when type and handle agree
+ * (allocDrawCommand, :5359-5407), and indices are rebased by the vertices already in the COMMAND
+ * (vgutil::batchTransformDrawIndices, vg_util.cpp:447-520). One vgx_drawcmd per draw command; 48 bytes. */
 typedef struct vgx_drawcmd {
-	uint64_t first_vertex;  /* where this vertex buffer starts in the pos / color streams (its m_FirstVertexID is 0) */
+	uint64_t first_vertex;  /* where the command's vertices start in the pos / color / uv streams */
 	uint64_t first_index;   /* DrawCommand::m_FirstIndexID: into the idx stream = the frame's single index buffer */
 	uint64_t first_mesh;    /* first mesh merged into the command */
-	uint32_t num_vertices;  /* DrawCommand::m_NumVertices = vertices in the vertex buffer (<= max_vb_vertices) */
+	uint32_t num_vertices;  /* DrawCommand::m_NumVertices */
 	uint32_t num_indices;   /* DrawCommand::m_NumIndices */
 	uint32_t num_meshes;
 	uint32_t vertex_buffer; /* DrawCommand::m_VertexBufferID, counted from 0 for the batch */
+	uint32_t first_vertex_in_vb; /* DrawCommand::m_FirstVertexID: offset inside its vertex buffer (0 for the buffer's first command) */
+	uint32_t state_key;     /* the vgx_draw::state_key its meshes share (type / handle / generation); 0 without VGX_ASM_SPLIT_STATE */
 } vgx_drawcmd;
 
+enum { VGX_ASM_SPLIT_STATE = 1u }; /* vgx_assembly::flags: a change of vgx_draw::state_key between consecutive meshes starts a new
+                                    * draw command inside the same vertex buffer (otherwise: one command per vertex buffer) */
+
 typedef struct vgx_assembly {
-	vgx_drawcmd* drawcmds;       /* DEVICE [cap_drawcmds]; 2 * vertices / max_vb_vertices + 2 entries always suffice */
+	vgx_drawcmd* drawcmds;       /* DEVICE [cap_drawcmds]; 2 * vertices / max_vb_vertices + 2 (+ number of state changes) entries always suffice */
 	uint64_t cap_drawcmds;
 	uint64_t* dev_num_drawcmds;  /* DEVICE, may be NULL: receives the number of draw commands */
 	uint32_t max_vb_vertices;    /* Config::m_MaxVBVertices (vg.cpp:726, <= 65536); 0 = 65536 */
+	uint32_t flags;              /* VGX_ASM_* */
+	/* the third vertex stream of createDrawCommand_VertexColor: every vertex gets the white-pixel UV (vg.cpp:5218-5225,
+	 * vgutil::memset32 / memset64 of getWhitePixelUV): uv_bytes = 4 (VG_CONFIG_UV_INT16: int16 x 2) or 8 (float x 2) */
+	void* uv;                    /* DEVICE [cap_vertices][uv_bytes], may be NULL */
+	uint32_t uv_bytes;           /* 0 (no UV stream), 4 or 8 */
+	uint32_t uv_value[2];        /* the constant, as raw bits (uv_value[1] unused for uv_bytes = 4) */
 	uint32_t reserved;
 } vgx_assembly;
 

@@ -48,7 +48,7 @@ def load(kind=None):
     lib.vgo_tessellate.restype = C.c_int
     lib.vgo_tessellate.argtypes = [C.POINTER(capi.PathSetDesc), C.c_void_p, C.c_uint64, C.POINTER(capi.FlatOut), C.POINTER(capi.MeshOut), C.POINTER(capi.Sizes)]
     lib.vgo_assemble.restype = C.c_int
-    lib.vgo_assemble.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.vgo_assemble.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]
     lib.vgo_cache_localize.restype = C.c_int
     lib.vgo_cache_localize.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
     lib.vgo_cache_submit.restype = C.c_int
@@ -116,8 +116,9 @@ def tessellate(ps, draws, kind=None, want_flat=False, count_only=False):
     return r
 
 
-def assemble(meshes, idx, max_vb_vertices=0, kind=None):
-    """Draw-command assembly (vgo_assemble): returns (status, drawcmds ndarray, rebased index buffer)."""
+def assemble(meshes, idx, max_vb_vertices=0, kind=None, mesh_keys=None):
+    """Draw-command assembly (vgo_assemble): returns (status, drawcmds ndarray, rebased index buffer).
+    mesh_keys: uint32 per mesh (its draw's state_key), None = one draw state."""
     lib = load(kind)
     meshes = np.ascontiguousarray(meshes)
     idx = np.ascontiguousarray(idx)
@@ -125,7 +126,9 @@ def assemble(meshes, idx, max_vb_vertices=0, kind=None):
     n = C.c_uint64(0)
     cap = max(int(meshes.shape[0]), 1)
     cmds = np.zeros(cap, dtype=capi.drawcmd_dtype)
-    st = lib.vgo_assemble(meshes.ctypes.data, meshes.shape[0], idx.ctypes.data, out.ctypes.data, max_vb_vertices, cmds.ctypes.data, cap, C.byref(n))
+    keys = None if mesh_keys is None else np.ascontiguousarray(mesh_keys, dtype=np.uint32)
+    st = lib.vgo_assemble(meshes.ctypes.data, meshes.shape[0], idx.ctypes.data, out.ctypes.data, max_vb_vertices, cmds.ctypes.data, cap, C.byref(n),
+                          None if keys is None else keys.ctypes.data)
     return st, cmds[:n.value], out
 
 

@@ -241,8 +241,10 @@ int vgo_tessellate(const vgx_pathset_desc* ps, const vgx_draw* draws, uint64_t n
 // PARITY UNPINNED for this bookkeeping: vg.cpp cannot be compiled without bgfx and the reference has no tests; only the
 // rebase primitive is the reference's own code in the `reference` oracle (VGO_REBASE = vgutil::batchTransformDrawIndices,
 // vg_util.cpp:447-520). idx_in holds mesh-local indices (vgo_tessellate's idx stream), idx_out receives the index buffer.
+// mesh_key (may be NULL = one state): what allocDrawCommand compares before merging into the previous command (type and
+// handle, vg.cpp:5376-5379), one word per mesh; a change starts a new command inside the same vertex buffer.
 int vgo_assemble(const vgx_mesh* meshes, uint64_t nmeshes, const uint16_t* idx_in, uint16_t* idx_out, uint32_t maxVBVertices,
-	vgx_drawcmd* cmds, uint64_t capCmds, uint64_t* numCmds)
+	vgx_drawcmd* cmds, uint64_t capCmds, uint64_t* numCmds, const uint32_t* mesh_key)
 {
 	if (maxVBVertices == 0) { maxVBVertices = 65536u; }
 	uint32_t vbCount = 0, vbID = 0;      // current vertex buffer (vg.cpp:5326)
@@ -268,8 +270,9 @@ int vgo_assemble(const vgx_mesh* meshes, uint64_t nmeshes, const uint16_t* idx_i
 		// allocIndices
 		const uint64_t firstIndexID = ibCount;
 		ibCount += ni;
-		// allocDrawCommand
-		if (forceNew || !have) {
+		// allocDrawCommand: merge only when nothing forced a new command and type / handle agree (vg.cpp:5368-5381)
+		const uint32_t key = mesh_key ? mesh_key[m] : 0u;
+		if (forceNew || !have || cur.state_key != key) {
 			if (have) {
 				if (ncmd < capCmds) { cmds[ncmd] = cur; }
 				++ncmd;
@@ -278,6 +281,8 @@ int vgo_assemble(const vgx_mesh* meshes, uint64_t nmeshes, const uint16_t* idx_i
 			cur.first_vertex = vbGlobalStart + firstVertexID; // m_FirstVertexID is firstVertexID (0 for a new buffer)
 			cur.first_index = firstIndexID;
 			cur.first_mesh = m;
+			cur.first_vertex_in_vb = firstVertexID;
+			cur.state_key = key;
 			cur.num_vertices = 0; cur.num_indices = 0; cur.num_meshes = 0;
 			have = true;
 			forceNew = false;

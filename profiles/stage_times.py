@@ -88,7 +88,7 @@ def main():
     bufs = rt.MeshBuffers(torch.device("cuda", 0), sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"])
     if os.environ.get("VGX_ASSEMBLE"):  # also run the draw-command assembly step (65536-vertex buffers)
         cap = 2 * (sizes["num_vertices"] // 65536) + 2
-        cmds = torch.zeros(cap * 40, dtype=torch.uint8, device="cuda:0")
+        cmds = torch.zeros(cap * 48, dtype=torch.uint8, device="cuda:0")
         ctx.set_assembly(cmds, 0, None)
     for _ in range(3):
         rt.tessellate_async(ctx, pset, dd, n, bufs)

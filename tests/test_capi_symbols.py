@@ -36,7 +36,7 @@ def test_struct_layouts_match_header(vgr):
     capi = vgr.capi
     assert capi.draw_dtype.itemsize == 64 and capi.mesh_dtype.itemsize == 32
     assert capi.subpath_dtype.itemsize == 16 and capi.draw_info_dtype.itemsize == 40
-    assert C.sizeof(capi.Sizes) == 80 and C.sizeof(capi.Assembly) == 32 and C.sizeof(capi.MeshOut) == 56 and C.sizeof(capi.FlatOut) == 40
+    assert C.sizeof(capi.Sizes) == 80 and C.sizeof(capi.Assembly) == 56 and C.sizeof(capi.MeshOut) == 56 and C.sizeof(capi.FlatOut) == 40
     assert C.sizeof(capi.PathSetDesc) == 40
 
 

@@ -21,7 +21,7 @@ def run_assembled(rt, gpu_ctx, ps, d, max_vb, use_async):
     nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
     bufs = rt.MeshBuffers(dd.device, nv, ni, nm)
     cap = 2 * (nv // (max_vb or 65536)) + 2
-    cmds = torch.zeros(cap * 40, dtype=torch.uint8, device=dd.device)
+    cmds = torch.zeros(cap * 48, dtype=torch.uint8, device=dd.device)
     ncmd = torch.zeros(1, dtype=torch.int64, device=dd.device)
     gpu_ctx.set_assembly(cmds, max_vb, ncmd)
     try:
@@ -36,7 +36,7 @@ def run_assembled(rt, gpu_ctx, ps, d, max_vb, use_async):
     out = dict(
         status=int(bufs.dev_status.item()) if use_async else 0,
         num=n,
-        cmds=cmds[:n * 40].cpu().numpy().view(rt.capi.drawcmd_dtype),
+        cmds=cmds[:n * 48].cpu().numpy().view(rt.capi.drawcmd_dtype),
         idx=bufs.idx[:ni].cpu().numpy().view(np.uint16),
         pos=bufs.pos[:nv].cpu().numpy(),
         color=bufs.color[:nv].cpu().numpy().view(np.uint32),
@@ -98,13 +98,70 @@ def test_assembly_mesh_too_large_and_capacity(rt, gpu_ctx, wl, oracle):
     dd = rt.upload_draws(d)
     sizes = rt.tessellate_count(gpu_ctx, pset, dd, d.shape[0])
     bufs = rt.MeshBuffers(dd.device, sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"])
-    cmds = torch.full((2 * 40 + 40,), 0xAB, dtype=torch.uint8, device=dd.device)
-    gpu_ctx.set_assembly(cmds[:80], 500)
+    cmds = torch.full((2 * 48 + 48,), 0xAB, dtype=torch.uint8, device=dd.device)
+    gpu_ctx.set_assembly(cmds[:96], 500)
     try:
         rt.tessellate_async(gpu_ctx, pset, dd, d.shape[0], bufs)
         torch.cuda.synchronize()
     finally:
         gpu_ctx.set_assembly(None)
     assert int(bufs.dev_status.item()) == rt.capi.VGX_E_NOSPACE
-    assert bool((cmds[80:] == 0xAB).all().item())
+    assert bool((cmds[96:] == 0xAB).all().item())
+    pset.close()
+
+
+@pytest.mark.parametrize("max_vb", [0, 2048, 700])
+def test_state_key_split_and_uv_stream(rt, gpu_ctx, wl, oracle, max_vb):
+    """VGX_ASM_SPLIT_STATE: draws carry a state key (DrawCommand type / handle / forced-new generation folded by the host);
+    a key change between consecutive meshes starts a draw command inside the same vertex buffer (vg.cpp:5376-5379), the
+    index rebase is relative to the COMMAND. Plus the white-pixel UV stream (vg.cpp:5218-5225), int16 x 2 and float x 2."""
+    import torch
+    ps, d = wl.tiger(3)
+    rs = np.random.RandomState(11)
+    # runs of 1..40 draws share a key; some runs return to an earlier key (merging must still not cross the other run)
+    keys = np.repeat(rs.randint(1, 6, size=d.shape[0]).astype(np.uint32) << 16 | 3, rs.randint(1, 40, size=d.shape[0]))[:d.shape[0]]
+    d = d.copy()
+    d["state_key"] = keys
+    ref = oracle.tessellate(ps, d)
+    mesh_keys = d["state_key"][ref.meshes["draw"]]
+    st, rcmds, ridx = oracle.assemble(ref.meshes, ref.idx, max_vb, mesh_keys=mesh_keys)
+    assert st == 0
+    pset = rt.PathSet(gpu_ctx, ps)
+    dd = rt.upload_draws(d)
+    sizes = rt.tessellate_count(gpu_ctx, pset, dd, d.shape[0])
+    nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
+    for uv_dtype, uv_value in ((torch.int16, (0x7FFF0001,)), (torch.float32, (0x3F000000, 0x3E800000))):
+        bufs = rt.MeshBuffers(dd.device, nv, ni, nm)
+        cmds = torch.zeros((len(rcmds) + 4) * 48, dtype=torch.uint8, device=dd.device)
+        ncmd = torch.zeros(1, dtype=torch.int64, device=dd.device)
+        uv = torch.zeros((nv + 3, 2), dtype=uv_dtype, device=dd.device)
+        gpu_ctx.set_assembly(cmds, max_vb, ncmd, split_state=True, uv=uv, uv_value=uv_value)
+        try:
+            rt.tessellate_async(gpu_ctx, pset, dd, d.shape[0], bufs)
+            torch.cuda.synchronize()
+        finally:
+            gpu_ctx.set_assembly(None)
+        assert int(bufs.dev_status.item()) == 0
+        n = int(ncmd.item())
+        assert n == len(rcmds)
+        got = cmds[:n * 48].cpu().numpy().view(rt.capi.drawcmd_dtype)
+        for f in rt.capi.drawcmd_dtype.names:
+            assert np.array_equal(got[f], rcmds[f]), f
+        assert np.array_equal(bufs.idx[:ni].cpu().numpy().view(np.uint16), ridx)
+        assert np.array_equal(bufs.pos[:nv].cpu().numpy().view(np.uint32), ref.pos.view(np.uint32))
+        raw = uv.cpu().numpy().view(np.uint32).reshape(nv + 3, -1)
+        assert (raw[:nv, 0] == uv_value[0]).all() and (raw[nv:] == 0).all()  # every vertex, nothing past the last one
+        if uv_dtype == torch.float32:
+            assert (raw[:nv, 1] == uv_value[1]).all()
+    # a table one entry too small is reported, never overrun
+    bufs = rt.MeshBuffers(dd.device, nv, ni, nm)
+    cmds = torch.full((len(rcmds) * 48,), 0xAB, dtype=torch.uint8, device=dd.device)
+    gpu_ctx.set_assembly(cmds[:(len(rcmds) - 1) * 48], max_vb, None, split_state=True)
+    try:
+        rt.tessellate_async(gpu_ctx, pset, dd, d.shape[0], bufs)
+        torch.cuda.synchronize()
+    finally:
+        gpu_ctx.set_assembly(None)
+    assert int(bufs.dev_status.item()) == rt.capi.VGX_E_NOSPACE
+    assert bool((cmds[(len(rcmds) - 1) * 48:] == 0xAB).all().item())
     pset.close()

@@ -97,7 +97,7 @@ def test_cache_with_assembly_and_capacity(rt, gpu_ctx, wl, oracle):
     ref = oracle.cache_submit(ref_cache, inst)
     st, rcmds, ridx = oracle.assemble(ref.meshes, ref.idx, 8192)
     assert st == 0 and len(rcmds) > 10
-    cmds = torch.zeros((2 * (ref.sizes["num_vertices"] // 8192) + 2) * 40, dtype=torch.uint8, device="cuda:0")
+    cmds = torch.zeros((2 * (ref.sizes["num_vertices"] // 8192) + 2) * 48, dtype=torch.uint8, device="cuda:0")
     ncmd = torch.zeros(1, dtype=torch.int64, device="cuda:0")
     gpu_ctx.set_assembly(cmds, 8192, ncmd)
     try:
@@ -105,7 +105,7 @@ def test_cache_with_assembly_and_capacity(rt, gpu_ctx, wl, oracle):
     finally:
         gpu_ctx.set_assembly(None)
     assert int(bufs.dev_status.item()) == 0 and int(ncmd.item()) == len(rcmds)
-    gc = cmds[:len(rcmds) * 40].cpu().numpy().view(rt.capi.drawcmd_dtype)
+    gc = cmds[:len(rcmds) * 48].cpu().numpy().view(rt.capi.drawcmd_dtype)
     for f in rcmds.dtype.names:
         assert np.array_equal(gc[f], rcmds[f]), f
     assert np.array_equal(bufs.idx[:ni].cpu().numpy().view(np.uint16), ridx)

@@ -241,7 +241,7 @@ def test_full_size_tiger_assembly(rt, gpu_ctx, wl):
     rt.tessellate_async(gpu_ctx, pset, dd, n, plain)
     asm = rt.MeshBuffers(dd.device, nv, ni, nm)
     cap = 2 * (nv // 65536) + 2
-    cmds_dev = torch.zeros(cap * 40, dtype=torch.uint8, device=dd.device)
+    cmds_dev = torch.zeros(cap * 48, dtype=torch.uint8, device=dd.device)
     ncmd = torch.zeros(1, dtype=torch.int64, device=dd.device)
     gpu_ctx.set_assembly(cmds_dev, 0, ncmd)
     try:
@@ -252,7 +252,7 @@ def test_full_size_tiger_assembly(rt, gpu_ctx, wl):
     assert int(plain.dev_status.item()) == 0 and int(asm.dev_status.item()) == 0
     T = int(ncmd.item())
     assert int(asm.dev_sizes[9].item()) == T and nv // 65536 <= T <= cap
-    c = cmds_dev[:T * 40].cpu().numpy().view(rt.capi.drawcmd_dtype)
+    c = cmds_dev[:T * 48].cpu().numpy().view(rt.capi.drawcmd_dtype)
     m = asm.meshes[:nm * 32].cpu().numpy().view(rt.capi.mesh_dtype)
     assert np.array_equal(c["vertex_buffer"], np.arange(T, dtype=np.uint32))
     assert int(c["num_vertices"].max()) <= 65536

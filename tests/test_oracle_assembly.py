@@ -84,3 +84,27 @@ def test_port_equals_reference_on_random_tables(seed):
         for k in range(len(c) - 1):
             nxt = int(m["num_vertices"][int(c["first_mesh"][k + 1])])
             assert int(c["num_vertices"][k]) + nxt > max_vb
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_hand_computed_state_key_split(kind):
+    """allocDrawCommand merges into the previous command only when type and handle agree (vg.cpp:5376-5379): with maxVB = 10
+    and keys [A A B B B A], buffers are [4,4] [4,3] [8,2] as before, commands split additionally where the key changes INSIDE
+    a buffer: [4,4]A | [4]B... wait the third mesh starts buffer 1 anyway -> commands: (vb0: m0,m1 key A) (vb1: m2,m3 key B)
+    (vb2: m4 key B) (vb2: m5 key A); the last command starts at vertex 8 of its buffer and its indices are rebased by 0."""
+    m = mesh_table([4, 4, 4, 3, 8, 2], [6, 6, 6, 3, 12, 3])
+    keys = np.array([7, 7, 9, 9, 9, 7], dtype=np.uint32)
+    idx = np.concatenate([np.arange(n, dtype=np.uint16) % np.uint16(v) for n, v in zip(m["num_indices"], m["num_vertices"])]).astype(np.uint16)
+    st, cmds, out = pyoracle.assemble(m, idx, 10, kind=kind, mesh_keys=keys)
+    assert st == 0
+    assert cmds["vertex_buffer"].tolist() == [0, 1, 2, 2]
+    assert cmds["state_key"].tolist() == [7, 9, 9, 7]
+    assert cmds["first_mesh"].tolist() == [0, 2, 4, 5] and cmds["num_meshes"].tolist() == [2, 2, 1, 1]
+    assert cmds["first_vertex"].tolist() == [0, 8, 15, 23] and cmds["num_vertices"].tolist() == [8, 7, 8, 2]
+    assert cmds["first_vertex_in_vb"].tolist() == [0, 0, 0, 8]
+    assert cmds["first_index"].tolist() == [0, 12, 21, 33] and cmds["num_indices"].tolist() == [12, 9, 12, 3]
+    # rebase = vertices already in the COMMAND: mesh 1 by 4, mesh 3 by 4, mesh 5 (own command) by 0
+    assert np.array_equal(out[6:12], idx[6:12] + 4) and np.array_equal(out[18:21], idx[18:21] + 4) and np.array_equal(out[33:36], idx[33:36])
+    # a key change between two buffers' boundary meshes costs nothing extra; without keys the table is the 3-command one
+    st2, cmds2, _ = pyoracle.assemble(m, idx, 10, kind=kind)
+    assert cmds2["first_mesh"].tolist() == [0, 2, 4] and cmds2["state_key"].tolist() == [0, 0, 0]

@@ -44,7 +44,7 @@ def fill_flags(aa=True):
 draw_dtype = np.dtype([
     ("path", "<u4"), ("fill_flags", "<u4"), ("fill_color", "<u4"), ("stroke_flags", "<u4"),
     ("stroke_color", "<u4"), ("stroke_width", "<f4"), ("scale", "<f4"), ("tess_tol", "<f4"),
-    ("fringe", "<f4"), ("mtx", "<f4", (6,)), ("reserved", "<u4")])
+    ("fringe", "<f4"), ("mtx", "<f4", (6,)), ("state_key", "<u4")])
 assert draw_dtype.itemsize == 64
 
 subpath_dtype = np.dtype([("first_vertex", "<u8"), ("num_vertices", "<u4"), ("flags", "<u4")])
@@ -67,8 +67,9 @@ concave_fill_dtype = np.dtype([("first_contour", "<u8"), ("num_contours", "<u4")
 assert concave_fill_dtype.itemsize == 48
 drawcmd_dtype = np.dtype([
     ("first_vertex", "<u8"), ("first_index", "<u8"), ("first_mesh", "<u8"), ("num_vertices", "<u4"), ("num_indices", "<u4"),
-    ("num_meshes", "<u4"), ("vertex_buffer", "<u4")])
-assert drawcmd_dtype.itemsize == 40
+    ("num_meshes", "<u4"), ("vertex_buffer", "<u4"), ("first_vertex_in_vb", "<u4"), ("state_key", "<u4")])
+assert drawcmd_dtype.itemsize == 48
+ASM_SPLIT_STATE = 1
 
 
 # ---- ctypes structs ---------------------------------------------------------------------------
@@ -103,7 +104,8 @@ class CacheDesc(C.Structure):
 
 class Assembly(C.Structure):
     _fields_ = [("drawcmds", C.c_void_p), ("cap_drawcmds", C.c_uint64), ("dev_num_drawcmds", C.c_void_p),
-                ("max_vb_vertices", C.c_uint32), ("reserved", C.c_uint32)]
+                ("max_vb_vertices", C.c_uint32), ("flags", C.c_uint32), ("uv", C.c_void_p), ("uv_bytes", C.c_uint32),
+                ("uv_value", C.c_uint32 * 2), ("reserved", C.c_uint32)]
 
 
 class MeshOut(C.Structure):

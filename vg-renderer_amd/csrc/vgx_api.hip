@@ -559,7 +559,7 @@ void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps,
 
 // Draw-command assembly (armed by vgx_set_assembly): partition of the mesh sequence into vertex buffers, per-mesh index
 // base, draw-command table. Runs between the scan over meshes and the emit kernels, which add the base to every index.
-int runAssemble(vgx_ctx* ctx, const vgx_mesh_out* out, hipStream_t s)
+int runAssemble(vgx_ctx* ctx, const vgx_mesh_out* out, hipStream_t s, const vgx_draw* draws = nullptr)
 {
 	const uint32_t maxVB = ctx->asmCfg.max_vb_vertices ? ctx->asmCfg.max_vb_vertices : 65536u;
 	const uint64_t meshCap = ctx->mtab.cap / sizeof(vgx_mesh);
@@ -581,6 +581,12 @@ int runAssemble(vgx_ctx* ctx, const vgx_mesh_out* out, hipStream_t s)
 	a.drawcmds = ctx->asmCfg.drawcmds; a.cap_drawcmds = ctx->asmCfg.cap_drawcmds; a.dev_num_drawcmds = ctx->asmCfg.dev_num_drawcmds;
 	a.max_vb = maxVB;
 	a.totals = (VgxTotals*)ctx->totals.p;
+	a.flags = draws ? ctx->asmCfg.flags : 0u; // no draw records at this level (shape cache): one state
+	a.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; a.draws = draws;
+	a.mesh_cmd = a.jump0;
+	a.partial = ctx->partial.p;
+	a.max_meshes = meshCap;
+	a.uv = ctx->asmCfg.uv; a.uv_bytes = ctx->asmCfg.uv ? ctx->asmCfg.uv_bytes : 0u; a.uv_value[0] = ctx->asmCfg.uv_value[0]; a.uv_value[1] = ctx->asmCfg.uv_value[1];
 	vgx_launch_assemble(a, s);
 	mark(ctx, s, "assemble");
 	return VGX_OK;
@@ -589,7 +595,7 @@ int runAssemble(vgx_ctx* ctx, const vgx_mesh_out* out, hipStream_t s)
 int runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out, hipStream_t s, const float* poly = nullptr)
 {
 	if (ctx->asmArmed) {
-		const int st = runAssemble(ctx, out, s);
+		const int st = runAssemble(ctx, out, s, draws);
 		if (st != VGX_OK) { return st; }
 	}
 	VgxStrokeArgs a;
@@ -1313,6 +1319,9 @@ int vgx_set_assembly(vgx_ctx* ctx, const vgx_assembly* asm_)
 		return VGX_OK;
 	}
 	if (!asm_->drawcmds || asm_->cap_drawcmds == 0 || asm_->max_vb_vertices > 65536u) { // vg.cpp:734: indices are uint16
+		return VGX_E_INVALID_ARG;
+	}
+	if ((asm_->flags & ~(uint32_t)VGX_ASM_SPLIT_STATE) || (asm_->uv && asm_->uv_bytes != 4 && asm_->uv_bytes != 8)) {
 		return VGX_E_INVALID_ARG;
 	}
 	ctx->asmCfg = *asm_;

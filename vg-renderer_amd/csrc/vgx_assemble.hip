@@ -20,20 +20,56 @@
 //                start[n + t] = J[start[t]] for t < n, then J <- J o J. log2(#buffers) rounds;
 //   k_asm_assign per mesh: its vertex buffer by binary search in start[], base = V[i] - V[start], and one thread per
 //                buffer writes the draw command.
+// With VGX_ASM_SPLIT_STATE a draw command also ends where the draws' state_key changes between consecutive meshes (type /
+// handle mismatch in allocDrawCommand, vg.cpp:5376-5379; a clip command list or a forced new command is a key change the
+// host folded into the word, include/vgx.h): command starts = vertex-buffer starts UNION key changes. After the chain
+// of vertex buffers is known, k_asm_vb marks every mesh that starts a vertex buffer, a device scan over the start flags
+// numbers the commands, and k_asm_cmd_finish fills the per-mesh index base (vertices in front of the mesh inside its
+// COMMAND, the value the reference rebases by) and the command sizes.
+// The white-pixel UV stream of createDrawCommand_VertexColor (vg.cpp:5218-5225) is one constant per vertex: k_asm_uv.
 #include "vgx_internal.h"
+#include "vgx_scan.h"
 
 namespace {
 
-// first j in (i, M] with V(j) + nv(j) - V(i) > maxVB, where mesh M is a sentinel that never fits
+// first j in (i, M] with V(j) + nv(j) - V(i) > maxVB, where mesh M is a sentinel that never fits.
+// The answer moves with i (next[i] - i ~ maxVB / average mesh size), so the search gallops outwards from that estimate
+// and finishes with a binary search inside the bracket: ~2 log2(error) probes that neighbouring threads share in cache,
+// instead of log2(M) scattered ones.
 __global__ __launch_bounds__(256) void k_asm_next(VgxAsmArgs A)
 {
 	if (A.totals->status != VGX_OK) { return; }
 	const uint64_t M = A.totals->sizes.num_meshes;
+	const uint64_t totalV = A.totals->sizes.num_vertices;
+	const uint64_t est = M && totalV ? (uint64_t)A.max_vb * M / totalV : 1; // meshes per vertex buffer, on average
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= M; i += (uint64_t)gridDim.x * blockDim.x) {
 		if (i == M) { A.jump0[M] = (uint32_t)M; continue; }
 		const uint64_t limit = A.mtab[i].first_vertex + (uint64_t)A.max_vb;
-		// meshes i..j-1 fit iff end(j-1) = V[j-1] + nv[j-1] <= limit; ends are non-decreasing
-		uint64_t lo = i + 1, hi = M; // answer in [i+1, M]: mesh i itself always goes in (the reference VG_CHECKs nv < maxVB)
+		// meshes i..j-1 fit iff end(j-1) = V[j-1] + nv[j-1] <= limit; ends are non-decreasing.
+		// fits(j) := end(j) <= limit for j in [i+1, M); the answer is the first j in [i+1, M] that does not fit (M: none).
+		uint64_t lo = i + 1, hi = M; // invariant: every j < lo fits, hi does not fit (or hi == M)
+		uint64_t g = i + (est > 0 ? est : 1);
+		if (g < lo) { g = lo; }
+		if (g < hi) {
+			const vgx_mesh m = A.mtab[g];
+			if (m.first_vertex + m.num_vertices <= limit) { // estimate fits: gallop upwards
+				lo = g + 1;
+				uint64_t step = 1;
+				while (lo < hi) {
+					const uint64_t p = lo + step - 1 < hi ? lo + step - 1 : hi - 1;
+					const vgx_mesh q = A.mtab[p];
+					if (q.first_vertex + q.num_vertices <= limit) { lo = p + 1; step <<= 1; } else { hi = p; break; }
+				}
+			} else { // gallop downwards
+				hi = g;
+				uint64_t step = 1;
+				while (lo < hi) {
+					const uint64_t p = hi - lo > step ? hi - step : lo;
+					const vgx_mesh q = A.mtab[p];
+					if (q.first_vertex + q.num_vertices <= limit) { lo = p + 1; break; } else { hi = p; step <<= 1; }
+				}
+			}
+		}
 		while (lo < hi) {
 			const uint64_t mid = (lo + hi) >> 1;
 			const vgx_mesh m = A.mtab[mid];
@@ -104,8 +140,111 @@ __global__ __launch_bounds__(256) void k_asm_assign(VgxAsmArgs A)
 			c.num_indices = (uint32_t)(endI - mi.first_index);
 			c.num_meshes = (uint32_t)(e - s);
 			c.vertex_buffer = (uint32_t)a;
+			c.first_vertex_in_vb = 0;
+			c.state_key = 0;
 			A.drawcmds[a] = c;
 		}
+	}
+}
+
+// ---- VGX_ASM_SPLIT_STATE -------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t asm_num_vbs(const VgxAsmArgs& A, uint64_t M)
+{
+	uint64_t lo = 0, hi = A.cap_start; // entries of start[] below M (increasing until it saturates at M / unset)
+	while (lo < hi) {
+		const uint64_t mid = (lo + hi) >> 1;
+		if ((uint64_t)A.start[mid] < M) { lo = mid + 1; } else { hi = mid; }
+	}
+	return lo;
+}
+
+// per mesh: its vertex buffer (bit 31: the mesh starts it). Written over jump1 (the doubling is done).
+__global__ __launch_bounds__(256) void k_asm_vb(VgxAsmArgs A, uint32_t* meshVb)
+{
+	if (A.totals->status != VGX_OK) { return; }
+	const uint64_t M = A.totals->sizes.num_meshes;
+	const uint64_t T = asm_num_vbs(A, M);
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (uint64_t)gridDim.x * blockDim.x) {
+		uint64_t a = 0, b = T; // last t with start[t] <= i
+		while (b - a > 1) {
+			const uint64_t mid = (a + b) >> 1;
+			if ((uint64_t)A.start[mid] <= i) { a = mid; } else { b = mid; }
+		}
+		meshVb[i] = (uint32_t)a | ((uint64_t)A.start[a] == i ? 0x80000000u : 0u);
+		if (A.mtab[i].num_vertices > A.max_vb) { atomicCAS(&A.totals->status, (uint32_t)VGX_OK, (uint32_t)VGX_E_MESH_TOO_LARGE); }
+	}
+}
+
+struct OpAsmCmd // scan over the meshes of "this mesh starts a draw command"
+{
+	VgxAsmArgs A;
+	const uint32_t* meshVb;
+	__device__ uint64_t size() const { return A.totals->status == VGX_OK ? A.totals->sizes.num_meshes : 0; }
+	__device__ uint32_t key(uint64_t i) const { return A.draws[A.mdesc[i].draw].state_key; }
+	__device__ bool starts(uint64_t i) const { return (meshVb[i] >> 31) != 0 || i == 0 || key(i) != key(i - 1); }
+	__device__ Sum3 load(uint64_t i) const { Sum3 r = sum3_zero(); r.a = starts(i) ? 1 : 0; return r; }
+	__device__ void store(uint64_t i, Sum3 e) const
+	{
+		const bool st = starts(i);
+		const uint64_t c = e.a + (st ? 1 : 0) - 1; // command of mesh i
+		A.mesh_cmd[i] = (uint32_t)c;
+		if (st && c < A.cap_drawcmds) {
+			const uint32_t vb = meshVb[i] & 0x7FFFFFFFu;
+			const vgx_mesh m = A.mtab[i];
+			vgx_drawcmd d;
+			d.first_vertex = m.first_vertex; d.first_index = m.first_index; d.first_mesh = i;
+			d.num_vertices = 0; d.num_indices = 0; d.num_meshes = 0; // k_asm_cmd_finish
+			d.vertex_buffer = vb;
+			d.first_vertex_in_vb = (uint32_t)(m.first_vertex - A.mtab[A.start[vb]].first_vertex);
+			d.state_key = key(i);
+			A.drawcmds[c] = d;
+		}
+	}
+	__device__ void finish(Sum3 t) const
+	{
+		A.totals->sizes.num_drawcmds = t.a;
+		if (t.a > A.cap_drawcmds) { atomicCAS(&A.totals->status, (uint32_t)VGX_OK, (uint32_t)VGX_E_NOSPACE); }
+		if (A.dev_num_drawcmds) { *A.dev_num_drawcmds = t.a; }
+	}
+};
+
+__global__ __launch_bounds__(256) void k_asm_cmd_finish(VgxAsmArgs A)
+{
+	if (A.totals->status != VGX_OK) { return; }
+	const uint64_t M = A.totals->sizes.num_meshes;
+	const uint64_t T = A.totals->sizes.num_drawcmds;
+	const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	for (uint64_t i = tid; i < M; i += (uint64_t)gridDim.x * blockDim.x) {
+		A.mesh_base[i] = (uint32_t)(A.mtab[i].first_vertex - A.drawcmds[A.mesh_cmd[i]].first_vertex);
+	}
+	for (uint64_t c = tid; c < T; c += (uint64_t)gridDim.x * blockDim.x) {
+		vgx_drawcmd d = A.drawcmds[c];
+		const bool last = c + 1 == T;
+		const uint64_t endV = last ? A.totals->sizes.num_vertices : A.drawcmds[c + 1].first_vertex;
+		const uint64_t endI = last ? A.totals->sizes.num_indices : A.drawcmds[c + 1].first_index;
+		const uint64_t endM = last ? M : A.drawcmds[c + 1].first_mesh;
+		A.drawcmds[c].num_vertices = (uint32_t)(endV - d.first_vertex);
+		A.drawcmds[c].num_indices = (uint32_t)(endI - d.first_index);
+		A.drawcmds[c].num_meshes = (uint32_t)(endM - d.first_mesh);
+	}
+}
+
+// vgutil::memset32 / memset64 of the white-pixel UV over the frame's vertices (vg.cpp:5218-5225)
+__global__ __launch_bounds__(256) void k_asm_uv(VgxAsmArgs A)
+{
+	if (A.totals->status != VGX_OK) { return; }
+	const uint64_t n = A.totals->sizes.num_vertices;
+	const uint64_t words = A.uv_bytes == 8 ? 2 * n : n; // 32-bit words
+	const uint64_t quads = words / 4;
+	uint32_t* p = (uint32_t*)A.uv;
+	const uint32_t v0 = A.uv_value[0], v1 = A.uv_bytes == 8 ? A.uv_value[1] : A.uv_value[0];
+	const uint4 q = make_uint4(v0, v1, v0, v1);
+	const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+	if (((uintptr_t)p & 15u) == 0) {
+		for (uint64_t i = tid; i < quads; i += stride) { ((uint4*)p)[i] = q; }
+		for (uint64_t i = quads * 4 + tid; i < words; i += stride) { p[i] = (i & 1) ? v1 : v0; }
+	} else {
+		for (uint64_t i = tid; i < words; i += stride) { p[i] = (i & 1) ? v1 : v0; }
 	}
 }
 
@@ -121,5 +260,17 @@ void vgx_launch_assemble(const VgxAsmArgs& a, hipStream_t s)
 		hipLaunchKernelGGL(k_asm_round, dim3(2048), dim3(256), 0, s, a, J, Jn, n);
 		const uint32_t* t = J; J = Jn; Jn = (uint32_t*)t;
 	}
-	hipLaunchKernelGGL(k_asm_assign, dim3(2048), dim3(256), 0, s, a);
+	if ((a.flags & VGX_ASM_SPLIT_STATE) && a.draws) {
+		// the jump tables are dead now: jump1 holds every mesh's vertex buffer, jump0 (= mesh_cmd) its draw command
+		hipLaunchKernelGGL(k_asm_vb, dim3(2048), dim3(256), 0, s, a, a.jump1);
+		OpAsmCmd op;
+		op.A = a; op.meshVb = a.jump1;
+		vgx_device_scan(op, (Sum3*)a.partial, s, a.max_meshes);
+		hipLaunchKernelGGL(k_asm_cmd_finish, dim3(2048), dim3(256), 0, s, a);
+	} else {
+		hipLaunchKernelGGL(k_asm_assign, dim3(2048), dim3(256), 0, s, a);
+	}
+	if (a.uv && a.uv_bytes) {
+		hipLaunchKernelGGL(k_asm_uv, dim3(4096), dim3(256), 0, s, a);
+	}
 }

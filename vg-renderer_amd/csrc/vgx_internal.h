@@ -133,6 +133,15 @@ struct VgxAsmArgs
 	uint64_t* dev_num_drawcmds;
 	uint32_t max_vb;
 	VgxTotals* totals;
+	// VGX_ASM_SPLIT_STATE: a change of the draws' state_key between consecutive meshes also starts a draw command
+	uint32_t flags;
+	const VgxMeshDesc* mdesc;  // mesh -> draw
+	const vgx_draw* draws;     // draw -> state_key (null: no draws at this level, e.g. the shape cache)
+	uint32_t* mesh_cmd;        // [meshes] scratch: draw command of every mesh (aliases jump0 once the doubling is done)
+	void* partial;             // scan partials (Sum3[VGX_SCAN_BLOCKS])
+	uint64_t max_meshes;       // host-known bound of the mesh count (launch shape of the scan)
+	// white-pixel UV stream (vg.cpp:5218-5225)
+	void* uv; uint32_t uv_bytes; uint32_t uv_value[2];
 };
 void vgx_launch_assemble(const VgxAsmArgs& a, hipStream_t s);
 

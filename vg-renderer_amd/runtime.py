@@ -77,9 +77,11 @@ class Context:
     def set_profiling(self, on):
         _check(lib().vgx_set_profiling(self._h, 1 if on else 0), "vgx_set_profiling")
 
-    def set_assembly(self, drawcmds=None, max_vb_vertices=0, dev_num=None):
-        """Arms draw-command assembly (vgx_set_assembly) with a uint8 device tensor of 40-byte vgx_drawcmd records,
-        or disarms it (drawcmds=None). The tensors must stay alive while armed."""
+    def set_assembly(self, drawcmds=None, max_vb_vertices=0, dev_num=None, split_state=False, uv=None, uv_value=None):
+        """Arms draw-command assembly (vgx_set_assembly) with a uint8 device tensor of 48-byte vgx_drawcmd records,
+        or disarms it (drawcmds=None). split_state: VGX_ASM_SPLIT_STATE. uv: device tensor of the UV stream (int16 [n,2]
+        = 4 bytes per vertex, or float32 [n,2] = 8), uv_value: the white-pixel UV as a tuple of raw uint32 words.
+        The tensors must stay alive while armed."""
         if drawcmds is None:
             _check(lib().vgx_set_assembly(self._h, None), "vgx_set_assembly")
             self._asm_keep = None
@@ -89,9 +91,15 @@ class Context:
         a.cap_drawcmds = drawcmds.numel() // capi.drawcmd_dtype.itemsize
         a.dev_num_drawcmds = dev_num.data_ptr() if dev_num is not None else None
         a.max_vb_vertices = max_vb_vertices
+        a.flags = capi.ASM_SPLIT_STATE if split_state else 0
         a.reserved = 0
+        if uv is not None:
+            a.uv = uv.data_ptr()
+            a.uv_bytes = uv.element_size() * 2
+            a.uv_value[0] = int(uv_value[0]) & 0xFFFFFFFF
+            a.uv_value[1] = int(uv_value[1]) & 0xFFFFFFFF if len(uv_value) > 1 else 0
         _check(lib().vgx_set_assembly(self._h, C.byref(a)), "vgx_set_assembly")
-        self._asm_keep = (drawcmds, dev_num)
+        self._asm_keep = (drawcmds, dev_num, uv)
 
     def failure_info(self):
         """Device status + why the single-pass kernel gave up, if it did (vgx_get_failure_info; synchronises)."""

@@ -464,6 +464,7 @@ VgxFlattenArgs flattenArgs(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* 
 	a.poly = (float*)ctx->poly.p;
 	a.subs = (vgx_subpath*)ctx->subs.p;
 	a.mdesc = (VgxMeshDesc*)ctx->mdesc.p;
+	a.mprep = nullptr;
 	a.mtab = (vgx_mesh*)ctx->mtab.p;
 	a.totals = (VgxTotals*)ctx->totals.p;
 	a.caps = ctx->caps;
@@ -528,6 +529,7 @@ void runFlattenBuild(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 	noteHip(ctx, hipMemsetAsync(ctx->dinfo.p, 0, ndraws * sizeof(vgx_draw_info), s));
 	VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, 1);
 	a.build_mode = 1;
+	a.mprep = (VgxMeshPrep*)ctx->mprep.p; // k_flatten_gather / k_flatten_serial write the per-mesh constants with the descriptors
 	vgx_launch_flatten_build(a, ctx->optBuildWaves, s);
 	mark(ctx, s, "flatten_build");
 	OpDrawInfo op;
@@ -538,7 +540,8 @@ void runFlattenBuild(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 	mark(ctx, s, "flatten_gather");
 }
 
-void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps, int checkCaps, hipStream_t s, const float* poly = nullptr)
+// prepDone: the flatten stage already wrote the per-mesh constants (single-pass pipeline), no k_mesh_prepare pass
+void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps, int checkCaps, hipStream_t s, const float* poly = nullptr, bool prepDone = false)
 {
 	VgxStrokeArgs a;
 	a.draws = draws; a.poly = poly ? poly : (const float*)ctx->poly.p; a.mdesc = (const VgxMeshDesc*)ctx->mdesc.p;
@@ -546,7 +549,7 @@ void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps,
 	a.mprep = (VgxMeshPrep*)ctx->mprep.p; a.mtab = (vgx_mesh*)ctx->mtab.p;
 	a.pos = nullptr; a.color = nullptr; a.idx = nullptr; a.meshes_out = nullptr; a.mesh_base = nullptr;
 	a.totals = (VgxTotals*)ctx->totals.p; a.caps = outCaps;
-	vgx_launch_mesh_prepare(a, s);
+	if (!prepDone) { vgx_launch_mesh_prepare(a, s); }
 	vgx_launch_stroke(false, a, 4096, s); // k_round_sizes: Round-join mesh sizes (exits immediately without Round joins)
 	mark(ctx, s, "mesh_prepare");
 	OpMeshAll op;
@@ -1183,7 +1186,7 @@ int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 	outCaps.vertices = out->cap_vertices;
 	outCaps.indices = out->cap_indices;
 	if (out->meshes && out->cap_meshes < outCaps.meshes) { outCaps.meshes = out->cap_meshes; }
-	runStrokeCount(ctx, draws, outCaps, 1, s);
+	runStrokeCount(ctx, draws, outCaps, 1, s, nullptr, !ctx->optTwoPass);
 	{
 		const int st = runStrokeEmit(ctx, draws, out, s);
 		if (st != VGX_OK) { return st; }

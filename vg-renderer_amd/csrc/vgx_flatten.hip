@@ -350,10 +350,16 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 // ------------------------------------------------------------------------------------------------
 // POOL: the cubics of a chunk are subdivided by the whole wave together (pool_sweep, vgx_walk.h) instead of one cubic per
 // lane in lock-step; same LDS footprint (the pool's task LIFO takes the place of the per-lane stack + leaf slots).
+// Leaves of the per-lane walk kept in LDS per lane before they spill to the wave's global staging area (L2-resident:
+// written and read back by the same wave within one chunk). Fewer LDS bytes per wave = more resident waves.
+#ifndef VGX_BUILD_LEAF_SLOTS
+#define VGX_BUILD_LEAF_SLOTS 8
+#endif
+#define BLS VGX_BUILD_LEAF_SLOTS
 template<bool POOL>
 __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 {
-	__shared__ __attribute__((aligned(16))) unsigned char s_mem[(VGX_LDS_LEVELS * 3 + VGX_LEAF_SLOTS) * VGX_WAVE * 8 > VGX_POOL_BYTES ? (VGX_LDS_LEVELS * 3 + VGX_LEAF_SLOTS) * VGX_WAVE * 8 : VGX_POOL_BYTES];
+	__shared__ __attribute__((aligned(16))) unsigned char s_mem[POOL ? ((VGX_LDS_LEVELS * 3 + BLS) * VGX_WAVE * 8 > VGX_POOL_BYTES ? (VGX_LDS_LEVELS * 3 + BLS) * VGX_WAVE * 8 : VGX_POOL_BYTES) : (VGX_LDS_LEVELS * 3 + BLS) * VGX_WAVE * 8];
 	float2* s_stack = (float2*)s_mem;                            // per-lane walk: pending stack, then the leaf slots
 	float2* s_leaf = s_stack + VGX_LDS_LEVELS * 3 * VGX_WAVE;
 	const PoolLds pool = pool_carve(s_mem);                      // pooled walk: the same memory
@@ -752,7 +758,7 @@ __global__ __launch_bounds__(256) void k_flatten_serial(VgxFlattenArgs A)
 		sim.scale = dr->scale; sim.tol = dr->tess_tol; sim.mtx = dr->mtx; sim.poly = A.poly;
 		sim.drawIndex = (uint32_t)d; sim.fillFlags = dr->fill_flags; sim.strokeFlags = dr->stroke_flags; sim.draw = dr;
 		if (!EMIT) {
-			sim.polyBase = 0; sim.subs = nullptr; sim.subBase = 0; sim.mdesc = nullptr; sim.mtab = nullptr; sim.meshBase = 0;
+			sim.polyBase = 0; sim.subs = nullptr; sim.subBase = 0; sim.mdesc = nullptr; sim.mprep = nullptr; sim.mtab = nullptr; sim.meshBase = 0;
 			sim.numFillTotal = 0; sim.limit = 0;
 			sim.init();
 			sim.run(ps, pc0, pc1, stack);
@@ -768,7 +774,7 @@ __global__ __launch_bounds__(256) void k_flatten_serial(VgxFlattenArgs A)
 		} else {
 			const vgx_draw_info di = A.dinfo[d];
 			sim.polyBase = di.first_poly_vertex; sim.subs = A.subs; sim.subBase = di.first_subpath;
-			sim.mdesc = A.mdesc; sim.mtab = A.mtab; sim.meshBase = di.first_mesh; sim.numFillTotal = di.flags >> 1;
+			sim.mdesc = A.mdesc; sim.mprep = A.mprep; sim.mtab = A.mtab; sim.meshBase = di.first_mesh; sim.numFillTotal = di.flags >> 1;
 			sim.limit = di.num_poly_vertices;
 			sim.init();
 			sim.run(ps, pc0, pc1, stack);

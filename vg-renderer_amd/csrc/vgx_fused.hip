@@ -491,7 +491,7 @@ __device__ __noinline__ void fused_serial_segment(const vgx_draw* draws, const u
 		PathSim<false, false> sim;
 		sim.scale = dr->scale; sim.tol = dr->tess_tol; sim.mtx = dr->mtx; sim.poly = nullptr;
 		sim.drawIndex = (uint32_t)d; sim.fillFlags = dr->fill_flags; sim.strokeFlags = dr->stroke_flags; sim.draw = dr;
-		sim.polyBase = 0; sim.subs = nullptr; sim.subBase = 0; sim.mdesc = nullptr; sim.mtab = nullptr; sim.meshBase = 0; sim.numFillTotal = 0; sim.limit = 0;
+		sim.polyBase = 0; sim.subs = nullptr; sim.subBase = 0; sim.mdesc = nullptr; sim.mprep = nullptr; sim.mtab = nullptr; sim.meshBase = 0; sim.numFillTotal = 0; sim.limit = 0;
 		sim.init();
 		sim.segSubs = s_sub; sim.segSubCap = 0; // count only
 		sim.run(ps, pc0, pc1, st);
@@ -524,7 +524,7 @@ __device__ __noinline__ void fused_serial_segment(const vgx_draw* draws, const u
 		PathSim<true, true> sim;
 		sim.scale = dr->scale; sim.tol = dr->tess_tol; sim.mtx = dr->mtx; sim.poly = dst;
 		sim.drawIndex = (uint32_t)d; sim.fillFlags = dr->fill_flags; sim.strokeFlags = dr->stroke_flags; sim.draw = dr;
-		sim.polyBase = inclV - nverts; sim.subs = nullptr; sim.subBase = 0; sim.mdesc = nullptr; sim.mtab = nullptr; sim.meshBase = 0; sim.numFillTotal = nfill;
+		sim.polyBase = inclV - nverts; sim.subs = nullptr; sim.subBase = 0; sim.mdesc = nullptr; sim.mprep = nullptr; sim.mtab = nullptr; sim.meshBase = 0; sim.numFillTotal = nfill;
 		sim.limit = nverts;
 		sim.init();
 		sim.segSubs = s_sub + (inclR - nrec); sim.segSubCap = nrec; sim.segDrawLocal = (uint32_t)lane;

@@ -42,7 +42,7 @@ int vgxt_serial_flatten(const vgx_pathset_desc* d, const vgx_draw* draw, int app
 	if (poly && applyTransform) {
 		PathSim<true, true> sim;
 		sim.scale = draw->scale; sim.tol = draw->tess_tol; sim.mtx = draw->mtx; sim.poly = poly; sim.polyBase = 0;
-		sim.subs = subs; sim.subBase = 0; sim.mdesc = nullptr; sim.mtab = nullptr; sim.draw = nullptr; sim.limit = limit; sim.meshBase = 0; sim.drawIndex = 0;
+		sim.subs = subs; sim.subBase = 0; sim.mdesc = nullptr; sim.mprep = nullptr; sim.mtab = nullptr; sim.draw = nullptr; sim.limit = limit; sim.meshBase = 0; sim.drawIndex = 0;
 		sim.fillFlags = draw->fill_flags; sim.strokeFlags = draw->stroke_flags; sim.numFillTotal = 0;
 		sim.init();
 		sim.run(ps, c0, c1, st);
@@ -50,7 +50,7 @@ int vgxt_serial_flatten(const vgx_pathset_desc* d, const vgx_draw* draw, int app
 	} else if (poly) {
 		PathSim<true, false> sim;
 		sim.scale = draw->scale; sim.tol = draw->tess_tol; sim.mtx = draw->mtx; sim.poly = poly; sim.polyBase = 0;
-		sim.subs = subs; sim.subBase = 0; sim.mdesc = nullptr; sim.mtab = nullptr; sim.draw = nullptr; sim.limit = limit; sim.meshBase = 0; sim.drawIndex = 0;
+		sim.subs = subs; sim.subBase = 0; sim.mdesc = nullptr; sim.mprep = nullptr; sim.mtab = nullptr; sim.draw = nullptr; sim.limit = limit; sim.meshBase = 0; sim.drawIndex = 0;
 		sim.fillFlags = draw->fill_flags; sim.strokeFlags = draw->stroke_flags; sim.numFillTotal = 0;
 		sim.init();
 		sim.run(ps, c0, c1, st);
@@ -58,7 +58,7 @@ int vgxt_serial_flatten(const vgx_pathset_desc* d, const vgx_draw* draw, int app
 	} else {
 		PathSim<false, false> sim;
 		sim.scale = draw->scale; sim.tol = draw->tess_tol; sim.mtx = nullptr; sim.poly = nullptr; sim.polyBase = 0;
-		sim.subs = nullptr; sim.subBase = 0; sim.mdesc = nullptr; sim.mtab = nullptr; sim.draw = nullptr; sim.limit = limit; sim.meshBase = 0; sim.drawIndex = 0;
+		sim.subs = nullptr; sim.subBase = 0; sim.mdesc = nullptr; sim.mprep = nullptr; sim.mtab = nullptr; sim.draw = nullptr; sim.limit = limit; sim.meshBase = 0; sim.drawIndex = 0;
 		sim.fillFlags = draw->fill_flags; sim.strokeFlags = draw->stroke_flags; sim.numFillTotal = 0;
 		sim.init();
 		sim.run(ps, c0, c1, st);

@@ -20,6 +20,7 @@ struct VgxFlattenArgs
 	float* poly;                // emit: [cap][2]
 	vgx_subpath* subs;          // emit
 	VgxMeshDesc* mdesc;         // emit (may be null: flatten-only API)
+	VgxMeshPrep* mprep;         // single-pass pipeline: per-mesh constants written together with mdesc (else null: k_mesh_prepare does it)
 	vgx_mesh* mtab;             // emit: closed-form mesh sizes are written together with mdesc
 	VgxTotals* totals;
 	VgxCaps caps;

@@ -9,7 +9,12 @@
 
 // Writes the descriptor of one mesh and, when the stroker's output size is closed-form, its mesh-table
 // entry. Returns true when the mesh has Round joins (caller counts those).
-VGX_HD bool vgx_write_mesh(VgxMeshDesc* mdesc, vgx_mesh* mtab, uint64_t meshIndex, const vgx_draw* dr, uint32_t drawIndex, uint32_t subIndex, uint32_t kind, bool closed, uint64_t polyFirst, uint32_t n)
+// mprep != null (single-pass pipeline: k_flatten_gather / k_flatten_serial): the per-mesh constants of the element kernels
+// are written here too -- half widths from the stroke parameters computed below anyway, fill orientation from the first
+// triangle of the mesh's (already written) polyline `poly` (stroker.cpp:721-723) -- instead of by a k_mesh_prepare pass
+// that would read the descriptor and the draw record again.
+VGX_HD bool vgx_write_mesh(VgxMeshDesc* mdesc, vgx_mesh* mtab, uint64_t meshIndex, const vgx_draw* dr, uint32_t drawIndex, uint32_t subIndex, uint32_t kind, bool closed, uint64_t polyFirst, uint32_t n,
+	VgxMeshPrep* mprep = nullptr, const float* poly = nullptr)
 {
 	VgxMeshDesc m;
 	m.poly_first = polyFirst; m.poly_n = n; m.draw = drawIndex; m.subpath = subIndex;
@@ -21,8 +26,24 @@ VGX_HD bool vgx_write_mesh(VgxMeshDesc* mdesc, vgx_mesh* mtab, uint64_t meshInde
 		m.kind |= (sp.cap << 9) | (sp.join << 11);
 		const uint32_t H = (!closed && sp.cap == VGX_CAP_ROUND) ? vgx_half_circle_points(vgx_step_angle(dr->scale, sp.hsw, dr->tess_tol)) : 2u;
 		needsCount = !vgx_mesh_closed_form(kind, closed, sp.cap, sp.join, n, H, &nv, &ni);
+		if (mprep) {
+			VgxMeshPrep pr;
+			pr.f0 = sp.hsw; pr.f1 = sp.hswAA; pr.f2 = dr->fringe; pr.color = dr->stroke_color;
+			mprep[meshIndex] = pr;
+		}
 	} else {
 		vgx_mesh_closed_form(kind, closed, 0, 0, n, 2, &nv, &ni);
+		if (mprep) {
+			VgxMeshPrep pr;
+			pr.f0 = 0.0f; pr.f1 = 0.0f; pr.f2 = dr->fringe; pr.color = dr->fill_color;
+			if (kind == VGX_MESH_FILL_AA) { // same arithmetic as mesh_prep (vgx_elem.h)
+				const float* q = poly + 2 * polyFirst;
+				const V2 q0 = v2(q[0], q[1]), q1 = v2(q[2], q[3]), q2 = v2(q[4], q[5]);
+				const float orient = v2cross(v2sub(q1, q0), v2sub(q2, q0));
+				pr.f0 = dr->fringe * 0.5f * vgm_sign(orient);
+			}
+			mprep[meshIndex] = pr;
+		}
 	}
 	mdesc[meshIndex] = m;
 	vgx_mesh r;
@@ -49,6 +70,7 @@ struct PathSim
 	vgx_subpath* subs;       // batch sub-path array (serial mode only; null in lane mode)
 	uint64_t subBase;
 	VgxMeshDesc* mdesc;      // serial mode only
+	VgxMeshPrep* mprep;      // serial mode of the single-pass pipeline only (else null): see vgx_write_mesh
 	vgx_mesh* mtab;          // serial mode only
 	const vgx_draw* draw;    // serial mode only
 	uint32_t numRound;       // Round-join meshes written
@@ -112,14 +134,14 @@ struct PathSim
 		}
 		if ((fillFlags & VGX_FILL_ENABLE) && spN >= 3) {
 			if (EMIT && mdesc) {
-				vgx_write_mesh(mdesc, mtab, meshBase + nfill, draw, drawIndex, subIndex, (fillFlags & VGX_FILL_AA) ? VGX_MESH_FILL_AA : VGX_MESH_FILL, spClosed, polyBase + spFirst, spN);
+				vgx_write_mesh(mdesc, mtab, meshBase + nfill, draw, drawIndex, subIndex, (fillFlags & VGX_FILL_AA) ? VGX_MESH_FILL_AA : VGX_MESH_FILL, spClosed, polyBase + spFirst, spN, mprep, poly);
 			}
 			++nfill;
 		}
 		if ((strokeFlags & VGX_STROKE_ENABLE) && spN >= 2) {
 			if (EMIT && mdesc) {
 				const uint32_t k = !(strokeFlags & VGX_STROKE_AA) ? VGX_MESH_STROKE : ((strokeFlags & VGX_STROKE_THIN) ? VGX_MESH_STROKE_AA_THIN : VGX_MESH_STROKE_AA);
-				if (vgx_write_mesh(mdesc, mtab, meshBase + numFillTotal + nstroke, draw, drawIndex, subIndex, k, spClosed, polyBase + spFirst, spN)) { ++numRound; }
+				if (vgx_write_mesh(mdesc, mtab, meshBase + numFillTotal + nstroke, draw, drawIndex, subIndex, k, spClosed, polyBase + spFirst, spN, mprep, poly)) { ++numRound; }
 			}
 			++nstroke;
 		}

@@ -132,7 +132,8 @@ __device__ __forceinline__ DrawWindow draw_window_load(const VgxFlattenArgs& A, 
 
 #define VGX_LEAF_SLOTS 8
 
-struct BuildCubicSink // counts leaves, detects the serial-path cases, keeps the first leaves in the lane's LDS slots
+template<int SLOTS>
+struct BuildCubicSinkT // counts leaves, detects the serial-path cases, keeps the first leaves in the lane's LDS slots
 {
 	V2 prev;
 	uint32_t n;
@@ -143,12 +144,13 @@ struct BuildCubicSink // counts leaves, detects the serial-path cases, keeps the
 	{
 		slow = slow || v2near(prev, v2(x, y));
 		prev = v2(x, y);
-		if (n < VGX_LEAF_SLOTS) { slots[n * VGX_WAVE] = make_float2(x, y); }
-		else if (n < VGX_LEAF_SLOTS + VGX_BUILD_OVERFLOW) { over[(n - VGX_LEAF_SLOTS) * VGX_WAVE] = make_float2(x, y); }
+		if (n < (uint32_t)SLOTS) { slots[n * VGX_WAVE] = make_float2(x, y); }
+		else if (n < (uint32_t)SLOTS + VGX_BUILD_OVERFLOW) { over[(n - SLOTS) * VGX_WAVE] = make_float2(x, y); }
 		++n;
 	}
 	__device__ __forceinline__ void dropped() { slow = true; }
 };
+typedef BuildCubicSinkT<VGX_LEAF_SLOTS> BuildCubicSink;
 
 // Hand-shaped hot loop of the build kernel: the same walk as vgx_flatten_cubic_n<VGX_LDS_LEVELS, true> + BuildCubicSink,
 // with the points kept as packed float pairs (v_pk_add/mul_f32), running LDS addresses instead of level * stride
@@ -156,7 +158,7 @@ struct BuildCubicSink // counts leaves, detects the serial-path cases, keeps the
 // (path.cpp:107-170, 769-775). Returns false when the cubic nests deeper than the LDS levels (caller redoes it).
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template<int LV>
+template<int LV, int SLOTS = VGX_LEAF_SLOTS>
 __device__ __forceinline__ bool build_flatten_hot(v2f P1, v2f P2, v2f P3, v2f P4, float tessTol, float2* stackLane, float2* slots, float2* over, uint32_t* nOut, bool* slowOut)
 {
 	int pending = 0;

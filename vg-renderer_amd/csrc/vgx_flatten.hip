@@ -31,12 +31,18 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------
+// LDS levels of the pending stack in the ordered two-pass kernels (count / emit of vgx_flatten_*): they run every
+// subdivision twice, have no leaf slots to pay for, and long curves (BASELINE config 1: ~46 segments per cubic, 6-7
+// pending halves) would leave a 4-level stack on almost every cubic.
+#ifndef VGX_FLAT_LDS_LEVELS
+#define VGX_FLAT_LDS_LEVELS 6 /* measured on 1 M random cubics: 4 levels 1.93 ms per count + emit, 6: 1.45, 8: 1.51, 10: 1.66 */
+#endif
 template<bool EMIT, bool XFORM>
 __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 {
-	__shared__ float2 s_stack[VGX_LDS_LEVELS * 3 * VGX_WAVE];
+	__shared__ float2 s_stack[VGX_FLAT_LDS_LEVELS * 3 * VGX_WAVE];
 	const int lane = threadIdx.x;
-	LdsStack stack;
+	LdsStackT<VGX_FLAT_LDS_LEVELS> stack;
 	stack.base = &s_stack[lane];
 
 	const VgxPathSetDev& ps = A.ps;

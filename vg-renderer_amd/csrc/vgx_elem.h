@@ -91,6 +91,25 @@ struct StrokeWriter
 		col[i] = c;
 		}
 	}
+	// two consecutive vertices in one 16-byte + one 8-byte store (the arc loops of Round joins / caps write pairs)
+	__device__ __forceinline__ void v2(uint32_t i, V2 p, uint32_t c, V2 q, uint32_t d) const
+	{
+		VGX_ST_GUARD(c ^ d) {
+		PosPair pp; pp.x0 = p.x; pp.y0 = p.y; pp.x1 = q.x; pp.y1 = q.y;
+		*(PosPair*)(pos + 2 * (size_t)i) = pp;
+		ColPair cp; cp.c0 = c; cp.c1 = d;
+		*(ColPair*)(col + i) = cp;
+		}
+	}
+	// three consecutive triangles (18 contiguous bytes) in one 16-byte + one 2-byte store
+	__device__ __forceinline__ void tri3(uint32_t k, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t c0, uint32_t c1, uint32_t c2) const
+	{
+		Idx9 t;
+		t.a = ((a0 + ib) & 0xFFFFu) | ((a1 + ib) << 16); t.b = ((a2 + ib) & 0xFFFFu) | ((b0 + ib) << 16);
+		t.c = ((b1 + ib) & 0xFFFFu) | ((b2 + ib) << 16); t.d = ((c0 + ib) & 0xFFFFu) | ((c1 + ib) << 16);
+		t.e = (uint16_t)(c2 + ib);
+		VGX_ST_GUARD(t.a ^ t.d) { *(Idx9*)(idx + k) = t; }
+	}
 	__device__ __forceinline__ void tri(uint32_t k, uint32_t a, uint32_t b, uint32_t c) const
 	{
 		Idx3 t; t.a = ((a + ib) & 0xFFFFu) | ((b + ib) << 16); t.b = (uint16_t)(c + ib);
@@ -377,8 +396,7 @@ __device__ __forceinline__ void elem_emit(const MeshCtxT<VS>& m, const Elem& e, 
 					const float a = firstCap ? startAngle + t : startAngle - t;
 					float sa, ca;
 					vgm_sincos(a, &sa, &ca);
-					w.v(b + 2 * i, v2(p1.x + ca * hsw, p1.y + sa * hsw), color);
-					w.v(b + 2 * i + 1, v2(p1.x + ca * hswAA, p1.y + sa * hswAA), c0);
+					w.v2(b + 2 * i, v2(p1.x + ca * hsw, p1.y + sa * hsw), color, v2(p1.x + ca * hswAA, p1.y + sa * hswAA), c0);
 				}
 				if (firstCap) {
 					uint32_t q = k;
@@ -477,8 +495,7 @@ __device__ __forceinline__ void elem_emit(const MeshCtxT<VS>& m, const Elem& e, 
 				float sa, ca;
 				vgm_sincos(ang, &sa, &ca);
 				const V2 dir = v2(ca, sa);
-				w.v(b + 2 + 2 * i, v2add(p1, v2mul(dir, hsw)), color);
-				w.v(b + 3 + 2 * i, v2add(p1, v2mul(dir, hswAA)), c0);
+				w.v2(b + 2 + 2 * i, v2add(p1, v2mul(dir, hsw)), color, v2add(p1, v2mul(dir, hswAA)), c0);
 			}
 			{
 				V2 a = v2add(p1, v2mul(n12, hsw));
@@ -487,19 +504,14 @@ __device__ __forceinline__ void elem_emit(const MeshCtxT<VS>& m, const Elem& e, 
 					const float cosAngle = vgm_abs(v2dot(n01, n12));
 					a = v2add(a, v2mul(e.d12, cosAngle * fringe));
 				}
-				w.v(b + 2 + 2 * n, a, color);
-				w.v(b + 3 + 2 * n, aAA, c0);
+				w.v2(b + 2 + 2 * n, a, color, aAA, c0);
 			}
 			uint32_t arcID = b + 2;
 			for (uint32_t i = 0; i < n; ++i, arcID += 2, q += 9) {
 				if (L) {
-					w.tri(q, b + 1, arcID, arcID + 2);
-					w.tri(q + 3, arcID, arcID + 1, arcID + 3);
-					w.tri(q + 6, arcID, arcID + 3, arcID + 2);
+					w.tri3(q, b + 1, arcID, arcID + 2, arcID, arcID + 1, arcID + 3, arcID, arcID + 3, arcID + 2);
 				} else {
-					w.tri(q, b + 1, arcID + 2, arcID);
-					w.tri(q + 3, arcID, arcID + 3, arcID + 1);
-					w.tri(q + 6, arcID, arcID + 2, arcID + 3);
+					w.tri3(q, b + 1, arcID + 2, arcID, arcID, arcID + 3, arcID + 1, arcID, arcID + 2, arcID + 3);
 				}
 			}
 		}

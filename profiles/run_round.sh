@@ -13,7 +13,7 @@ if [ "$2" != "--skip-tests" ]; then
 fi
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json
-BENCH="python bench.py --no-cpu --steps 16 --warmup 2"
+BENCH="python bench.py --no-cpu --no-configs --steps 16 --warmup 2"  # headline workload only: per-kernel averages must not mix batch sizes
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- $BENCH > $OUT/fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o write -- $BENCH > $OUT/write.log 2>&1

@@ -123,31 +123,33 @@ __device__ __forceinline__ void fill_window_load(const VgxStrokeArgs& A, FillWin
 	W.prefix = W.pre[lane];
 }
 
-// ---- the pipelined walk of k_fill -------------------------------------------------------------------------------
-// gfx9 has ONE counter (vmcnt) for loads and stores, in issue order: a wave that needs a load it issued AFTER a batch of
-// stores can only wait for "everything", i.e. for the write acknowledgements of those stores (microseconds under a
-// saturated write stream). So the vertices of the NEXT run of chunks are requested before the current run's stores are
-// issued, and a run is VGX_FILL_RUN chunks: reads and stores reach the memory system in batches (a read stream mixed
-// chunk by chunk into the store streams costs ~40 % of the write rate on this part, batches of 4-8 chunks half of that;
-// profiles/micro/fillshape2-4.hip). Everything else a chunk needs (mesh fields) is re-read from the lane-resident window
-// when the chunk is emitted: the only state carried from request to emit is {owner, j, three vertices}.
+// ---- the walk of k_fill: runs of chunks through an LDS ring ----------------------------------------------------------
+// What bounds this kernel is how its 8 B / element read stream mixes with its 42 B / element store streams in the memory
+// system, not its own waits: chunk-by-chunk interleaving (one 512 B read, then 2.7 KB of stores, per wave) runs the
+// access mix at ~3.3 TB/s of writes whatever the prefetch depth (even with the reads decoupled from vmcnt altogether,
+// profiles/micro/fillshape6.hip), a wave that requests the vertices of 8-16 chunks back to back and then emits them
+// reaches 4.2-4.3 TB/s (profiles/micro/fillshape4.hip, fillshape6.hip). The real kernel gains far less from it (2-5 %:
+// with its loads issued but never waited for it runs no faster, with its stores removed it takes 1.1 ms instead of 2.0,
+// i.e. it is the traffic itself, not a wait) but the structure is also the simplest: a wave processes its elements in RUNS of
+// VGX_FILL_RUN chunks: (1) owner search and vertex address of every chunk of the run, all vertex loads issued back to
+// back, (2) the run's vertices parked in an LDS ring, (3) the chunks emitted one after the other. A corner's two
+// neighbours come from the adjacent lanes (DPP) or, at chunk edges and where a polygon wraps around, from the ring --
+// not from extra loads; only the four vertices just outside the run (the first mesh's vertex 0 and the vertex in front
+// of the run, the last mesh's last vertex and the vertex behind the run) are loaded with the burst.
 #ifndef VGX_FILL_RUN
-#define VGX_FILL_RUN 4
+#define VGX_FILL_RUN 8 /* measured on Tiger x10k, same box: 4: 2.15 ms, 8: 2.02-2.09, 12: 2.07, 16: 2.07-2.13 (146 VGPRs) */
 #endif
+#define VGX_FILL_RING (VGX_FILL_RUN * VGX_WAVE)
 
-struct FillChunk // one 64-element chunk between vertex request and emit
+struct FillRunState // what the emit phase of a run needs besides the ring
 {
-	int k;          // owner mesh = window entry k (valid lanes)
-	uint32_t j;     // element index inside the mesh; 0xFFFFFFFF = lane has no element
-	V2 p1, pNextB, pPrevB;
+	int k[VGX_FILL_RUN];        // owner mesh = window entry (valid lanes)
+	uint32_t j[VGX_FILL_RUN];   // element index inside the mesh; 0xFFFFFFFF = lane has no element
 };
 
-struct FillRun { FillChunk c[VGX_FILL_RUN]; int n; uint64_t first; }; // n chunks starting at element `first`
-
-// Requests the vertices of one chunk. The window covers the chunk (W.prefix[63] > chunk + 63, W.prefix[0] <= chunk).
-__device__ __forceinline__ FillChunk fill_request(const VgxStrokeArgs& A, const FillWindow& W, uint64_t chunk, uint64_t elemEnd, int lane)
+// Owner search of one chunk (window covers it): window entry and element index of every lane.
+__device__ __forceinline__ void fill_owner(const FillWindow& W, uint64_t chunk, uint64_t elemEnd, int lane, int* kOut, uint32_t* jOut)
 {
-	FillChunk C;
 	const uint64_t ei = chunk + (uint64_t)lane;
 	const bool valid = ei < elemEnd;
 	const uint32_t wrel = window_rel(W.prefix, chunk);
@@ -155,58 +157,47 @@ __device__ __forceinline__ FillChunk fill_request(const VgxStrokeArgs& A, const 
 	const uint32_t orel = (uint32_t)__shfl((int)wrel, k);
 	const int firstOwner = __popcll(wave_ballot(W.prefix <= chunk)) - 1;
 	const uint64_t headBase = wave_bcast_u64(W.prefix, firstOwner < 0 ? 0 : firstOwner); // mesh that owns the chunk's first element
-	const uint32_t j = orel > 0 ? (uint32_t)lane - orel : (uint32_t)(ei - headBase);
-	const FillRec r = W.rec[k];
-	const uint64_t polyFirst = r.polyFirst;
-	const uint32_t N = r.N, kind = r.kind;
-	const float* vtx = A.poly + 2 * polyFirst;
-	const bool aaElem = valid && kind == VGX_MESH_FILL_AA;
-	const bool prevInWave = lane > 0 && j > 0;
-	const bool nextInWave = lane < VGX_WAVE - 1 && j + 1 < N && ei + 1 < elemEnd;
-	C.k = k;
-	C.j = valid ? j : 0xFFFFFFFFu;
-	C.p1 = v2(0.0f, 0.0f); C.pNextB = C.p1; C.pPrevB = C.p1;
-	// my own vertex, and -- only where the neighbour is not in the adjacent lane (mesh boundary / chunk edge) -- the
-	// cyclic next / previous vertex
-	if (valid) { C.p1 = ldv(vtx, j); }
-	if (aaElem && !nextInWave) { C.pNextB = ldv(vtx, j + 1 < N ? j + 1 : 0); }
-	if (aaElem && !prevInWave) { C.pPrevB = ldv(vtx, j > 0 ? j - 1 : N - 1); }
-	return C;
+	*kOut = k;
+	*jOut = valid ? (orel > 0 ? (uint32_t)lane - orel : (uint32_t)(ei - headBase)) : 0xFFFFFFFFu;
 }
 
-__device__ __forceinline__ void fill_emit_one(const VgxStrokeArgs& A, const FillWindow& W, const FillChunk& C, uint64_t chunk, uint64_t elemEnd, int lane)
+// Emits chunk i of the run [run0, run0 + runLen). ring[r] = vertex of the run's element r, ring[VGX_FILL_RING + 0..3] =
+// the four outside vertices {in front of the run, first mesh's vertex 0, behind the run, last mesh's last vertex}.
+__device__ __forceinline__ void fill_emit_ring(const VgxStrokeArgs& A, const FillWindow& W, const float2* ring, int i, int k, uint32_t jj, uint64_t run0, uint32_t runLen, uint64_t elemEnd, int lane)
 {
 	FillFetch F;
-	const int k = C.k;
-	F.valid = C.j != 0xFFFFFFFFu;
-	F.j = F.valid ? C.j : 0u;
+	F.valid = jj != 0xFFFFFFFFu;
+	F.j = F.valid ? jj : 0u;
 	const FillRec r = W.rec[k];
 	F.N = r.N;
-	const uint32_t kind = r.kind;
-	F.color = r.color;
-	F.aa = r.aa;
-	F.firstV = r.firstV;
-	F.firstI = r.firstI;
-	F.ibase = r.ibase;
-	F.mi = 0;
-	F.aaElem = F.valid && kind == VGX_MESH_FILL_AA;
+	F.color = r.color; F.aa = r.aa; F.firstV = r.firstV; F.firstI = r.firstI; F.ibase = r.ibase; F.mi = 0;
+	F.aaElem = F.valid && r.kind == VGX_MESH_FILL_AA;
+	const uint32_t e = (uint32_t)i * VGX_WAVE + (uint32_t)lane; // my element, relative to the run
+	const uint64_t ei = run0 + e;
 	F.prevInWave = lane > 0 && F.j > 0;
-	F.nextInWave = lane < VGX_WAVE - 1 && F.j + 1 < F.N && chunk + (uint64_t)lane + 1 < elemEnd;
-	F.p1 = C.p1; F.pNextB = C.pNextB; F.pPrevB = C.pPrevB;
+	F.nextInWave = lane < VGX_WAVE - 1 && F.j + 1 < F.N && ei + 1 < elemEnd;
+	const float2 me = ring[F.valid ? e : 0u];
+	F.p1 = v2(me.x, me.y);
+	F.pNextB = F.p1; F.pPrevB = F.p1;
+	if (F.aaElem && !F.nextInWave) {
+		uint32_t slot;
+		if (F.j + 1 < F.N) { slot = e + 1 < runLen ? e + 1 : VGX_FILL_RING + 2; }       // next corner: in the run, or the vertex behind it
+		else { slot = e >= F.j ? e - F.j : VGX_FILL_RING + 1; }                           // wrap to the mesh's vertex 0: in the run, or the first mesh's
+		const float2 q = ring[slot];
+		F.pNextB = v2(q.x, q.y);
+	}
+	if (F.aaElem && !F.prevInWave) {
+		uint32_t slot;
+		if (F.j > 0) { slot = e > 0 ? e - 1 : VGX_FILL_RING + 0; }                         // previous corner: in the run, or the vertex in front of it
+		else { slot = e + (F.N - 1) < runLen ? e + (F.N - 1) : VGX_FILL_RING + 3; }       // wrap to the mesh's last vertex: in the run, or the last mesh's
+		const float2 q = ring[slot];
+		F.pPrevB = v2(q.x, q.y);
+	}
 	fill_emit_chunk(A.pos, A.color, A.idx, F);
 }
 
-__device__ __forceinline__ void fill_emit_run(const VgxStrokeArgs& A, const FillWindow& W, FillRun& R, uint64_t elemEnd, int lane)
-{
-#pragma unroll
-	for (int i = 0; i < VGX_FILL_RUN; ++i) {
-		if (i < R.n) { fill_emit_one(A, W, R.c[i], R.first + (uint64_t)i * VGX_WAVE, elemEnd, lane); }
-	}
-	R.n = 0;
-}
-
 // A chunk in which more than 63 mesh records begin (zero-length entries of stroke-only sub-paths between fills): every
-// lane searches its mesh in memory. Not pipelined; rare.
+// lane searches its mesh in memory. Rare.
 __device__ __forceinline__ uint64_t fill_chunk_slow(const VgxStrokeArgs& A, uint64_t chunk, uint64_t elemEnd, uint64_t mlo, uint64_t numMeshes, int lane)
 {
 	FillFetch F;
@@ -237,62 +228,6 @@ __device__ __forceinline__ uint64_t fill_chunk_slow(const VgxStrokeArgs& A, uint
 	return wave_bcast_u64(F.mi, nvalid - 1);
 }
 
-struct FillWalk // wave-uniform position of the walk
-{
-	uint64_t pos;     // next element to request
-	uint64_t elemEnd;
-	uint64_t mcur;    // a mesh at or before the owner of element `pos`
-	uint64_t wbase;   // first mesh of the window
-	uint64_t numMeshes;
-};
-
-// One half step of the software pipeline: request the next run into `next`, then emit `pending` (requested one half step
-// earlier). When the window runs out, `pending` is emitted first (its fields come from the old window), then the
-// window is reloaded.
-__device__ __forceinline__ void fill_half_step(const VgxStrokeArgs& A, FillWindow& W, FillWalk& P, FillRun& next, FillRun& pending, int lane)
-{
-	next.n = 0;
-	if (P.pos < P.elemEnd) { // wave-uniform
-		uint64_t wlast = wave_bcast_u64(W.prefix, VGX_WAVE - 1);
-		if (!(wlast > P.pos + (VGX_WAVE - 1))) {
-			fill_emit_run(A, W, pending, P.elemEnd, lane);
-			P.wbase = P.mcur;
-			fill_window_load(A, W, P.wbase, P.numMeshes, lane);
-			wlast = wave_bcast_u64(W.prefix, VGX_WAVE - 1);
-			while (P.pos < P.elemEnd && !(wlast > P.pos + (VGX_WAVE - 1))) { // more than 63 mesh records inside one chunk
-				P.mcur = fill_chunk_slow(A, P.pos, P.elemEnd, P.wbase, P.numMeshes, lane);
-				P.pos += VGX_WAVE;
-				P.wbase = P.mcur;
-				fill_window_load(A, W, P.wbase, P.numMeshes, lane);
-				wlast = wave_bcast_u64(W.prefix, VGX_WAVE - 1);
-			}
-		}
-		if (P.pos < P.elemEnd) {
-			const uint64_t covered = (wlast - P.pos) >> 6;                       // chunks the window covers from pos on
-			const uint64_t left = (P.elemEnd - P.pos + (VGX_WAVE - 1)) >> 6;
-			uint64_t n = covered < left ? covered : left;
-			n = n < (uint64_t)VGX_FILL_RUN ? n : (uint64_t)VGX_FILL_RUN;
-			next.n = (int)n;
-			next.first = P.pos;
-#pragma unroll
-			for (int i = 0; i < VGX_FILL_RUN; ++i) {
-				if (i < next.n) { next.c[i] = fill_request(A, W, P.pos + (uint64_t)i * VGX_WAVE, P.elemEnd, lane); }
-			}
-			// owner of the run's last element: where the next window (if one is needed) starts
-			const uint64_t lastChunk = P.pos + (n - 1) * VGX_WAVE;
-			const int nvalid = (int)((P.elemEnd - lastChunk) < (uint64_t)VGX_WAVE ? (P.elemEnd - lastChunk) : (uint64_t)VGX_WAVE);
-			int kLast = 0;
-#pragma unroll
-			for (int i = 0; i < VGX_FILL_RUN; ++i) {
-				if (i == next.n - 1) { kLast = wave_bcast(next.c[i].k, nvalid - 1); }
-			}
-			P.mcur = P.wbase + (uint64_t)kLast;
-			P.pos += n * VGX_WAVE;
-		}
-	}
-	fill_emit_run(A, W, pending, P.elemEnd, lane);
-}
-
 #ifndef VGX_FILL_OCC
 #define VGX_FILL_OCC
 #endif
@@ -300,6 +235,7 @@ __global__ __launch_bounds__(VGX_WAVE) VGX_FILL_OCC void k_fill(VgxStrokeArgs A)
 {
 	__shared__ FillRec s_win[VGX_WAVE];
 	__shared__ uint64_t s_pre[VGX_WAVE];
+	__shared__ float2 s_ring[VGX_FILL_RING + 4];
 	const int lane = threadIdx.x;
 	if (A.totals->status != VGX_OK) {
 		return;
@@ -315,22 +251,92 @@ __global__ __launch_bounds__(VGX_WAVE) VGX_FILL_OCC void k_fill(VgxStrokeArgs A)
 	}
 	// This wave's elements are the contiguous range [pos, elemEnd); whole meshes are NOT required here (a fill element
 	// only needs its own mesh record and its two neighbours), so the walk is a plain 64-element stride.
-	FillWalk P;
-	P.pos = seg0 * VGX_WAVE;
-	P.elemEnd = (seg1 * VGX_WAVE < totalElems) ? seg1 * VGX_WAVE : totalElems;
-	P.numMeshes = numMeshes;
-	P.mcur = find_owner_u64(A.elem_prefix, 0, numMeshes, P.pos); // last mesh with prefix <= pos
-	P.wbase = P.mcur;
+	uint64_t pos = seg0 * VGX_WAVE;
+	const uint64_t elemEnd = (seg1 * VGX_WAVE < totalElems) ? seg1 * VGX_WAVE : totalElems;
+	uint64_t mcur = find_owner_u64(A.elem_prefix, 0, numMeshes, pos); // last mesh with prefix <= pos
+	uint64_t wbase = mcur;
 	FillWindow W;
 	W.rec = s_win; W.pre = s_pre;
-	fill_window_load(A, W, P.wbase, numMeshes, lane);
-	FillRun R0, R1;
-	R0.n = 0; R1.n = 0; R0.first = 0; R1.first = 0;
-	// two run records in ping-pong (no register copies at the loop edge)
-	do {
-		fill_half_step(A, W, P, R0, R1, lane);
-		fill_half_step(A, W, P, R1, R0, lane);
-	} while (P.pos < P.elemEnd || R0.n > 0 || R1.n > 0);
+	fill_window_load(A, W, wbase, numMeshes, lane);
+
+	while (pos < elemEnd) { // wave-uniform
+		uint64_t wlast = wave_bcast_u64(W.prefix, VGX_WAVE - 1);
+		if (!(wlast > pos + (VGX_WAVE - 1))) { // the window does not cover the next chunk
+			wbase = mcur;
+			fill_window_load(A, W, wbase, numMeshes, lane);
+			wlast = wave_bcast_u64(W.prefix, VGX_WAVE - 1);
+			if (!(wlast > pos + (VGX_WAVE - 1))) { // more than 63 mesh records inside one chunk
+				mcur = fill_chunk_slow(A, pos, elemEnd, wbase, numMeshes, lane);
+				pos += VGX_WAVE;
+				continue;
+			}
+		}
+		const uint64_t covered = (wlast - pos) >> 6;                    // chunks the window covers from pos on
+		const uint64_t left = (elemEnd - pos + (VGX_WAVE - 1)) >> 6;
+		uint64_t nn = covered < left ? covered : left;
+		nn = nn < (uint64_t)VGX_FILL_RUN ? nn : (uint64_t)VGX_FILL_RUN;
+		const int n = (int)nn;
+		const uint64_t run0 = pos;
+		const uint64_t runEnd = run0 + nn * VGX_WAVE < elemEnd ? run0 + nn * VGX_WAVE : elemEnd;
+		const uint32_t runLen = (uint32_t)(runEnd - run0);
+
+		// (1) owner search + vertex request of every chunk of the run
+		FillRunState R;
+		float2 v[VGX_FILL_RUN];
+		const float2* src[VGX_FILL_RUN];
+#pragma unroll
+		for (int i = 0; i < VGX_FILL_RUN; ++i) {
+			R.k[i] = 0; R.j[i] = 0xFFFFFFFFu; v[i] = make_float2(0.0f, 0.0f); src[i] = (const float2*)A.poly;
+			if (i < n) { // wave-uniform
+				fill_owner(W, run0 + (uint64_t)i * VGX_WAVE, elemEnd, lane, &R.k[i], &R.j[i]);
+				const uint64_t polyFirst = W.rec[R.k[i]].polyFirst;
+				if (R.j[i] != 0xFFFFFFFFu) { src[i] = (const float2*)(A.poly + 2 * (polyFirst + R.j[i])); }
+			}
+		}
+		// all vertex loads of the run back to back (every lane loads: lanes without an element re-read the heap's first vertex)
+		__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+		for (int i = 0; i < VGX_FILL_RUN; ++i) {
+			if (i < n) { v[i] = *src[i]; }
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		// the four vertices just outside the run, lanes 0..3: {in front of the run, first mesh's vertex 0, behind the run,
+		// last mesh's last vertex}; the first / last element's mesh and index come from lane 0 of chunk 0 / the last valid lane
+		float2 edge = make_float2(0.0f, 0.0f);
+		{
+			const int lastChunkValid = (int)(runLen - (uint32_t)(n - 1) * VGX_WAVE); // valid lanes of the run's last chunk, >= 1
+			int kF = wave_bcast(R.k[0], 0), kL = 0;
+			uint32_t jF = wave_bcast_u32(R.j[0], 0), jL = 0;
+#pragma unroll
+			for (int i = 0; i < VGX_FILL_RUN; ++i) {
+				if (i == n - 1) { kL = wave_bcast(R.k[i], lastChunkValid - 1); jL = wave_bcast_u32(R.j[i], lastChunkValid - 1); }
+			}
+			if (lane < 4) {
+				const FillRec rr = W.rec[lane < 2 ? kF : kL];
+				uint32_t idx;
+				if (lane == 0) { idx = jF > 0 ? jF - 1 : 0; }
+				else if (lane == 1) { idx = 0; }
+				else if (lane == 2) { idx = jL + 1 < rr.N ? jL + 1 : 0; }
+				else { idx = rr.N - 1; }
+				edge = *(const float2*)(A.poly + 2 * (rr.polyFirst + idx));
+			}
+			mcur = wbase + (uint64_t)kL; // owner of the run's last element: where the next window (if one is needed) starts
+		}
+		// (2) park the run in the ring
+		__syncthreads(); // one-wave workgroup: lanes may still be reading the previous run
+#pragma unroll
+		for (int i = 0; i < VGX_FILL_RUN; ++i) {
+			if (i < n) { s_ring[i * VGX_WAVE + lane] = v[i]; }
+		}
+		if (lane < 4) { s_ring[VGX_FILL_RING + lane] = edge; }
+		__syncthreads();
+		// (3) emit
+#pragma unroll
+		for (int i = 0; i < VGX_FILL_RUN; ++i) {
+			if (i < n) { fill_emit_ring(A, W, s_ring, i, R.k[i], R.j[i], run0, runLen, elemEnd, lane); }
+		}
+		pos = run0 + nn * VGX_WAVE;
+	}
 }
 
 // ------------------------------------------------------------------------------------------------

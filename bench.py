@@ -328,12 +328,24 @@ def main():
     sizes, bufs, pset, dd, ndraws = res["sizes"], res["bufs"], res["pset"], res["dd"], res["ndraws"]
     dt = res["dt"]
 
+    red_dev = torch.device("cpu") if share_gpu else dev
+    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    vtot = torch.tensor([float(res["units"])], dtype=torch.float64, device=red_dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(vtot, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    res["dt"] = dt
+    total_units = float(vtot.item())
+
     # ---- multi-GPU: the gather of the final streams to rank 0, timed by default, reported beside `value` ----
     # Preferred: libvgx's own RCCL gather behind the C-ABI (vgx_gather) on a dedicated communicator; the torch.distributed
     # version of the same layout (vg-renderer_amd/dist.py) when that cannot be set up (e.g. the shared-GPU test mode).
     # A watchdog thread bounds the C-ABI leg so that a stuck transfer can never swallow the bench line.
     gather_ms = None
     gather_via = None
+    bail = False  # the C-ABI gather leg got stuck: print the line with what is measured and leave without touching the communicators again
     if (world > 1 or os.environ.get("VGX_BENCH_FORCE_GATHER") == "1") and not args.no_gather and bufs is not None:
         dm = importlib.import_module("vg-renderer_amd.dist")
         import threading
@@ -371,6 +383,7 @@ def main():
             th.join(timeout=float(os.environ.get("VGX_BENCH_GATHER_TIMEOUT", "180")))
             if th.is_alive():
                 box["err"] = "timeout"
+                bail = True
         else:
             box["err"] = "disabled"
         ok = torch.tensor([1 if "ms" in box else 0], dtype=torch.int32, device=torch.device("cpu") if share_gpu else dev)
@@ -390,17 +403,6 @@ def main():
         else:
             gather_via = "not measured: %s" % box.get("err")
         res["gather_check"] = box.get("check")
-
-    red_dev = torch.device("cpu") if share_gpu else dev
-    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-    vtot = torch.tensor([float(res["units"])], dtype=torch.float64, device=red_dev)
-    if world > 1:
-        import torch.distributed as dist
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(vtot, op=dist.ReduceOp.SUM)
-    dt = float(tmax.item())
-    res["dt"] = dt
-    total_units = float(vtot.item())
 
     # ---- next rows, measured beside the headline on rank 0 of a 1-GPU run: not part of `value` ----
     next_rows = None
@@ -518,6 +520,8 @@ def main():
         except OSError:
             pass
         print(json.dumps(out), flush=True)
+    if bail:
+        os._exit(0)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -271,6 +271,7 @@ struct OpMeshAll
 {
 	const VgxMeshDesc* mdesc;
 	vgx_mesh* mtab;
+	vgx_mesh* meshesOut; // caller's mesh table, written here when the emit follows at once (vgx_tessellate); else null
 	uint64_t* prefixFill;
 	uint64_t* prefixStroke;
 	VgxTotals* totals;
@@ -291,6 +292,11 @@ struct OpMeshAll
 	{
 		prefixFill[i] = e.a; prefixStroke[i] = e.b;
 		mtab[i].first_vertex = e.c; mtab[i].first_index = e.d & VGX_IDX_SUM_MASK;
+		if (meshesOut && i < caps.meshes) { // the caller's table = the internal one, in the same pass (no k_copy_meshes)
+			vgx_mesh r = mtab[i];
+			r.first_vertex = e.c; r.first_index = e.d & VGX_IDX_SUM_MASK;
+			meshesOut[i] = r;
+		}
 	}
 	__device__ void finish(Sum3 t) const
 	{
@@ -541,7 +547,7 @@ void runFlattenBuild(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 }
 
 // prepDone: the flatten stage already wrote the per-mesh constants (single-pass pipeline), no k_mesh_prepare pass
-void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps, int checkCaps, hipStream_t s, const float* poly = nullptr, bool prepDone = false)
+void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps, int checkCaps, hipStream_t s, const float* poly = nullptr, bool prepDone = false, vgx_mesh* meshesOut = nullptr)
 {
 	VgxStrokeArgs a;
 	a.draws = draws; a.poly = poly ? poly : (const float*)ctx->poly.p; a.mdesc = (const VgxMeshDesc*)ctx->mdesc.p;
@@ -556,6 +562,7 @@ void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps,
 	op.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; op.mtab = (vgx_mesh*)ctx->mtab.p;
 	op.prefixFill = (uint64_t*)ctx->elemPrefix.p; op.prefixStroke = (uint64_t*)ctx->elemPrefixS.p;
 	op.totals = (VgxTotals*)ctx->totals.p; op.caps = outCaps; op.checkCaps = checkCaps;
+	op.meshesOut = meshesOut;
 	vgx_device_scan(op, (Sum3*)ctx->partial.p, s, ctx->caps.meshes);
 	mark(ctx, s, "scan_meshes");
 }
@@ -595,7 +602,8 @@ int runAssemble(vgx_ctx* ctx, const vgx_mesh_out* out, hipStream_t s, const vgx_
 	return VGX_OK;
 }
 
-int runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out, hipStream_t s, const float* poly = nullptr)
+// tableDone: the scan over the meshes already wrote the caller's mesh table
+int runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out, hipStream_t s, const float* poly = nullptr, bool tableDone = false)
 {
 	if (ctx->asmArmed) {
 		const int st = runAssemble(ctx, out, s, draws);
@@ -606,7 +614,7 @@ int runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out, 
 	a.draws = draws; a.poly = poly ? poly : (const float*)ctx->poly.p; a.mdesc = (const VgxMeshDesc*)ctx->mdesc.p;
 	a.elem_prefix = nullptr; a.elem_prefix_fill = (const uint64_t*)ctx->elemPrefix.p; a.elem_prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
 	a.mprep = (VgxMeshPrep*)ctx->mprep.p; a.mtab = (vgx_mesh*)ctx->mtab.p;
-	a.pos = out->pos; a.color = out->color; a.idx = out->idx; a.meshes_out = out->meshes;
+	a.pos = out->pos; a.color = out->color; a.idx = out->idx; a.meshes_out = tableDone ? nullptr : out->meshes;
 	a.totals = (VgxTotals*)ctx->totals.p;
 	a.caps = ctx->caps;
 	a.elem_prefix = a.elem_prefix_fill;
@@ -1186,9 +1194,9 @@ int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 	outCaps.vertices = out->cap_vertices;
 	outCaps.indices = out->cap_indices;
 	if (out->meshes && out->cap_meshes < outCaps.meshes) { outCaps.meshes = out->cap_meshes; }
-	runStrokeCount(ctx, draws, outCaps, 1, s, nullptr, !ctx->optTwoPass);
+	runStrokeCount(ctx, draws, outCaps, 1, s, nullptr, !ctx->optTwoPass, out->meshes);
 	{
-		const int st = runStrokeEmit(ctx, draws, out, s);
+		const int st = runStrokeEmit(ctx, draws, out, s, nullptr, true);
 		if (st != VGX_OK) { return st; }
 	}
 	if (dev_sizes || dev_status) {

@@ -171,6 +171,50 @@ def test_async_single_pass_fuzz(rt, gpu_ctx, wl, oracle, seed):
     pset.close()
 
 
+def test_async_steady_state_with_changed_draw_parameters(rt, gpu_ctx, wl, oracle):
+    """The steady-state entry point must not depend on anything the sizing pass (vgx_tessellate_count) left in the scratch:
+    after ONE count on a batch, the draws are rewritten in place -- other colours, stroke widths, fringe, a mirrored
+    transform (flips the fill orientation sign the per-mesh constants carry, stroker.cpp:721-723), other caps / joins of
+    the same size class -- and vgx_tessellate alone must reproduce the oracle for the NEW parameters. (Regression: the
+    per-mesh constants are written by the single-pass flatten stage itself, not by a k_mesh_prepare pass of the count.)"""
+    import torch
+    ps, d = wl.tiger(3)
+    rs = np.random.RandomState(5)
+    pset = rt.PathSet(gpu_ctx, ps)
+    dd = rt.upload_draws(d)
+    sizes = rt.tessellate_count(gpu_ctx, pset, dd, d.shape[0])
+    bufs = rt.MeshBuffers(dd.device, sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"])
+    rt.tessellate_async(gpu_ctx, pset, dd, d.shape[0], bufs)
+    torch.cuda.synchronize()
+    d2 = d.copy()
+    d2["fill_color"] = rs.randint(0, 2 ** 32, size=d.shape[0], dtype=np.uint64).astype(np.uint32)
+    d2["stroke_color"] = rs.randint(0, 2 ** 32, size=d.shape[0], dtype=np.uint64).astype(np.uint32)
+    stroked = (d2["stroke_flags"] & rt.capi.STROKE_ENABLE) != 0
+    d2["stroke_width"][stroked] = rs.uniform(1.5, 6.0, size=int(stroked.sum())).astype(np.float32)
+    d2["fringe"] = np.float32(0.75)
+    d2["mtx"][:, 0] = -1.0  # mirror in x: every polygon changes orientation
+    d2["mtx"][:, 4] = 900.0 - d2["mtx"][:, 4]
+    ref = oracle.tessellate(ps, d2)
+    assert ref.sizes["num_vertices"] == sizes["num_vertices"] and ref.sizes["num_indices"] == sizes["num_indices"]
+    dd.copy_(torch.from_numpy(d2.view(np.uint8).reshape(-1).copy()))
+    bufs.pos.fill_(float("nan"))
+    rt.tessellate_async(gpu_ctx, pset, dd, d.shape[0], bufs)
+    torch.cuda.synchronize()
+    assert int(bufs.dev_status.item()) == 0
+    nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
+
+    class G:
+        pass
+    got = G()
+    got.sizes = sizes
+    got.pos = bufs.pos[:nv].cpu().numpy()
+    got.color = bufs.color[:nv].cpu().numpy().view(np.uint32)
+    got.idx = bufs.idx[:ni].cpu().numpy().view(np.uint16)
+    got.meshes = bufs.meshes[:nm * 32].cpu().numpy().view(rt.capi.mesh_dtype)
+    assert_mesh_equal(got, ref, "steady state, changed draws")
+    pset.close()
+
+
 def test_async_single_pass_long_paths(rt, gpu_ctx, wl, oracle):
     """Draws larger than a heap block (exactly sized regions) and many-chunk segments."""
     import torch

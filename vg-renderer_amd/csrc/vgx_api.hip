@@ -8,6 +8,7 @@
 // entry point vgx_tessellate never synchronises with the host.
 #include "vgx_internal.h"
 #include "vgx_scan.h"
+#include "vgx_scan_ops.h"
 #include "vgx_pathsim.h"
 #include <vector>
 #include <string.h>
@@ -179,138 +180,6 @@ void markBegin(vgx_ctx* ctx, hipStream_t s)
 	ctx->numEv = 0;
 	(void)hipEventRecord(ctx->ev[0], s);
 }
-
-__device__ __forceinline__ void set_status(VgxTotals* t, uint32_t err)
-{
-	atomicCAS(&t->status, (uint32_t)VGX_OK, err);
-}
-
-// ---- scan operators ---------------------------------------------------------------------------------
-struct OpCmdPrefix // command instances per draw -> cmd_prefix
-{
-	const vgx_draw* draws;
-	const uint32_t* pathCmdBegin;
-	uint32_t npaths;
-	uint64_t ndraws;
-	uint64_t* prefix;
-	VgxTotals* totals;
-	uint64_t cap;
-	__device__ uint64_t size() const { return ndraws; }
-	__device__ Sum3 load(uint64_t i) const
-	{
-		Sum3 r = sum3_zero();
-		const vgx_draw* d = draws + i;
-		const uint32_t p = d->path;
-		const uint32_t sf = d->stroke_flags;
-		if (p >= npaths || ((sf & VGX_STROKE_ENABLE) && (VGX_STROKE_CAP(sf) > 2u || VGX_STROKE_JOIN(sf) > 2u))) {
-			set_status(totals, VGX_E_INVALID_ARG);
-			return r;
-		}
-		// The draw records are device memory the host never sees: reject parameters that would make the subdivision
-		// (flat iff d23^2 <= tol / scale^2 * len^2, path.cpp:105-116) run to the limits of float -- NaN / Inf / zero /
-		// negative scale or tolerance, a tolerance below 1e-12 of a unit -- instead of spending hours on them (the
-		// reference loops forever on NaN, path.cpp:109). Comparisons are written so that NaN fails them.
-		{
-			const float sc = d->scale, tt = d->tess_tol, fr = d->fringe, sw = d->stroke_width;
-			bool ok = sc > 0.0f && sc < 3.0e38f && tt > 0.0f && tt < 3.0e38f && fr >= 0.0f && fr < 3.0e38f && sw >= 0.0f && sw < 3.0e38f;
-			ok = ok && (tt / (sc * sc) >= 1.0e-12f);
-			for (int k = 0; k < 6; ++k) { ok = ok && (d->mtx[k] > -3.0e38f && d->mtx[k] < 3.0e38f); }
-			if (!ok) {
-				set_status(totals, VGX_E_NONFINITE);
-				return r;
-			}
-		}
-		r.a = pathCmdBegin[p + 1] - pathCmdBegin[p];
-		return r;
-	}
-	__device__ void store(uint64_t i, Sum3 e) const { prefix[i] = e.a; }
-	__device__ void finish(Sum3 t) const
-	{
-		prefix[ndraws] = t.a;
-		totals->sizes.num_cmd_instances = t.a;
-		if (t.a > cap) { set_status(totals, VGX_E_NOSPACE); }
-	}
-};
-
-struct OpDrawInfo // per-draw polyline / sub-path / mesh counts -> first_* fields
-{
-	vgx_draw_info* dinfo;
-	uint64_t ndraws;
-	VgxTotals* totals;
-	VgxCaps caps;
-	int keepPolyBase; // BUILD mode: first_poly_vertex already holds the draw's heap position
-	__device__ uint64_t size() const { return totals->status == VGX_OK ? ndraws : 0; }
-	__device__ Sum3 load(uint64_t i) const
-	{
-		Sum3 r;
-		const vgx_draw_info* d = dinfo + i;
-		r.a = d->num_poly_vertices; r.b = d->num_subpaths; r.c = d->num_meshes; r.d = d->flags & 1u;
-		return r;
-	}
-	__device__ void store(uint64_t i, Sum3 e) const
-	{
-		vgx_draw_info* d = dinfo + i;
-		if (!keepPolyBase) { d->first_poly_vertex = e.a; }
-		d->first_subpath = e.b; d->first_mesh = e.c;
-	}
-	__device__ void finish(Sum3 t) const
-	{
-		totals->sizes.num_poly_vertices = t.a;
-		totals->sizes.num_subpaths = t.b;
-		totals->sizes.num_meshes = t.c;
-		totals->sizes.num_serial_draws = t.d;
-		if ((!keepPolyBase && t.a > caps.poly_vertices) || t.b > caps.subpaths || t.c > caps.meshes) { set_status(totals, VGX_E_NOSPACE); }
-	}
-};
-
-// One scan over the meshes for everything the emit kernels need: element offsets (convex fills / polyline strokes
-// have separate streams) and vertex / index offsets. Field d carries the index sum in its low 48 bits and the number
-// of meshes with more than 65536 vertices above them (a batch cannot hold 2^48 indices: positions are 32-bit counted).
-#define VGX_IDX_SUM_MASK ((1ull << 48) - 1)
-struct OpMeshAll
-{
-	const VgxMeshDesc* mdesc;
-	vgx_mesh* mtab;
-	vgx_mesh* meshesOut; // caller's mesh table, written here when the emit follows at once (vgx_tessellate); else null
-	uint64_t* prefixFill;
-	uint64_t* prefixStroke;
-	VgxTotals* totals;
-	VgxCaps caps;
-	int checkCaps;
-	__device__ uint64_t size() const { return totals->status == VGX_OK ? totals->sizes.num_meshes : 0; }
-	__device__ Sum3 load(uint64_t i) const
-	{
-		Sum3 r = sum3_zero();
-		const VgxMeshDesc m = mdesc[i];
-		if (VGX_MD_KIND(m.kind) >= VGX_MESH_STROKE) { r.b = m.poly_n; } else { r.a = m.poly_n; }
-		const uint32_t nv = mtab[i].num_vertices;
-		r.c = nv;
-		r.d = (uint64_t)mtab[i].num_indices + (nv > 65536u ? (1ull << 48) : 0ull);
-		return r;
-	}
-	__device__ void store(uint64_t i, Sum3 e) const
-	{
-		prefixFill[i] = e.a; prefixStroke[i] = e.b;
-		mtab[i].first_vertex = e.c; mtab[i].first_index = e.d & VGX_IDX_SUM_MASK;
-		if (meshesOut && i < caps.meshes) { // the caller's table = the internal one, in the same pass (no k_copy_meshes)
-			vgx_mesh r = mtab[i];
-			r.first_vertex = e.c; r.first_index = e.d & VGX_IDX_SUM_MASK;
-			meshesOut[i] = r;
-		}
-	}
-	__device__ void finish(Sum3 t) const
-	{
-		const uint64_t n = totals->status == VGX_OK ? totals->sizes.num_meshes : 0;
-		prefixFill[n] = t.a;
-		prefixStroke[n] = t.b;
-		totals->sizes.num_elements = t.a + t.b;
-		totals->sizes.num_fill_elements = t.a;
-		totals->sizes.num_vertices = t.c;
-		totals->sizes.num_indices = t.d & VGX_IDX_SUM_MASK;
-		if (t.d >> 48) { set_status(totals, VGX_E_MESH_TOO_LARGE); }
-		if (checkCaps && (t.c > caps.vertices || (t.d & VGX_IDX_SUM_MASK) > caps.indices || totals->sizes.num_meshes > caps.meshes)) { set_status(totals, VGX_E_NOSPACE); }
-	}
-};
 
 struct OpCacheInst // shape cache: vertices / indices / meshes of every instance's mesh range -> output offsets
 {

@@ -687,11 +687,10 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 // One lane per draw, after the scan over draws: turns the sparse sub-path records of k_flatten_build into mesh
 // descriptors (+ closed-form mesh-table sizes) at their ORDERED indices: fill meshes by sub-path, then stroke meshes
 // (the reference's call order, vg.cpp:3099-3131 then 3448-3485). Serial draws were written by k_flatten_serial.
-__global__ __launch_bounds__(256) void k_flatten_gather(VgxFlattenArgs A)
+__device__ __forceinline__ void flatten_gather_body(const VgxFlattenArgs& A, uint64_t tid, uint64_t nthreads)
 {
-	if (A.totals->status != VGX_OK) { return; }
 	const VgxPathSetDev& ps = A.ps;
-	for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < A.ndraws; d += (uint64_t)gridDim.x * blockDim.x) {
+	for (uint64_t d = tid; d < A.ndraws; d += nthreads) {
 		const vgx_draw_info di = A.dinfo[d];
 		if ((di.flags & 1u) || di.num_meshes == 0) { continue; }
 		const vgx_draw* dr = A.draws + d;
@@ -709,12 +708,12 @@ __global__ __launch_bounds__(256) void k_flatten_gather(VgxFlattenArgs A)
 			const bool closed = (info >> 31) != 0;
 			const uint64_t first = sr.first;
 			if ((fillFlags & VGX_FILL_ENABLE) && n >= 3) {
-				vgx_write_mesh(A.mdesc, A.mtab, di.first_mesh + f, dr, (uint32_t)d, subIndex, (fillFlags & VGX_FILL_AA) ? VGX_MESH_FILL_AA : VGX_MESH_FILL, closed, first, n);
+				vgx_write_mesh(A.mdesc, A.mtab, di.first_mesh + f, dr, (uint32_t)d, subIndex, (fillFlags & VGX_FILL_AA) ? VGX_MESH_FILL_AA : VGX_MESH_FILL, closed, first, n, A.mprep, A.poly);
 				++f;
 			}
 			if ((strokeFlags & VGX_STROKE_ENABLE) && n >= 2) {
 				const uint32_t kd = !(strokeFlags & VGX_STROKE_AA) ? VGX_MESH_STROKE : ((strokeFlags & VGX_STROKE_THIN) ? VGX_MESH_STROKE_AA_THIN : VGX_MESH_STROKE_AA);
-				if (vgx_write_mesh(A.mdesc, A.mtab, di.first_mesh + numFill + s, dr, (uint32_t)d, subIndex, kd, closed, first, n)) {
+				if (vgx_write_mesh(A.mdesc, A.mtab, di.first_mesh + numFill + s, dr, (uint32_t)d, subIndex, kd, closed, first, n, A.mprep, A.poly)) {
 					atomicAdd(&A.totals->num_round_meshes, 1u);
 				}
 				++s;
@@ -722,6 +721,12 @@ __global__ __launch_bounds__(256) void k_flatten_gather(VgxFlattenArgs A)
 			++subIndex;
 		}
 	}
+}
+
+__global__ __launch_bounds__(256) void k_flatten_gather(VgxFlattenArgs A)
+{
+	if (A.totals->status != VGX_OK) { return; }
+	flatten_gather_body(A, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
 }
 
 // ---- private (per-lane) pending stack for the serial kernel ---------------------------------------------

@@ -135,17 +135,18 @@ __global__ __launch_bounds__(VGX_SCAN_THREADS) void k_scan_apply(OP op, const Su
 // launches per scan x five scans cost ~8 us of a 127 us single-drawing call; beyond one tile the three-pass form is faster).
 #define VGX_SCAN_SINGLE_THREADS 1024
 #define VGX_SCAN_SINGLE_MAX 1024
-template<class OP>
-__global__ __launch_bounds__(VGX_SCAN_SINGLE_THREADS) void k_scan_single(OP op)
+// The whole scan by ONE workgroup of T threads; callable from inside a larger single-workgroup kernel (every thread of
+// the block must call it; s_wave holds T / 64 entries; ends with the block synchronised).
+template<class OP, int T>
+__device__ __forceinline__ void block_scan_all(const OP& op, Sum3* s_wave)
 {
-	__shared__ Sum3 s_wave[VGX_SCAN_SINGLE_THREADS / 64];
 	const uint64_t n = op.size();
 	Sum3 carry = sum3_zero();
-	for (uint64_t base = 0; base < n; base += VGX_SCAN_SINGLE_THREADS) {
+	for (uint64_t base = 0; base < n; base += T) {
 		const uint64_t i = base + threadIdx.x;
 		const Sum3 v = (i < n) ? op.load(i) : sum3_zero();
 		Sum3 tot;
-		const Sum3 incl = block_incl_scan<VGX_SCAN_SINGLE_THREADS>(v, s_wave, &tot);
+		const Sum3 incl = block_incl_scan<T>(v, s_wave, &tot);
 		if (i < n) {
 			Sum3 e;
 			e.a = carry.a + incl.a - v.a; e.b = carry.b + incl.b - v.b; e.c = carry.c + incl.c - v.c; e.d = carry.d + incl.d - v.d;
@@ -154,6 +155,14 @@ __global__ __launch_bounds__(VGX_SCAN_SINGLE_THREADS) void k_scan_single(OP op)
 		carry = sum3_add(carry, tot);
 	}
 	if (threadIdx.x == 0) { op.finish(carry); }
+	__syncthreads();
+}
+
+template<class OP>
+__global__ __launch_bounds__(VGX_SCAN_SINGLE_THREADS) void k_scan_single(OP op)
+{
+	__shared__ Sum3 s_wave[VGX_SCAN_SINGLE_THREADS / 64];
+	block_scan_all<OP, VGX_SCAN_SINGLE_THREADS>(op, s_wave);
 }
 
 // maxItems: an upper bound of op.size() the HOST knows (the size itself lives in device memory); picks the launch shape.

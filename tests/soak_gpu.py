@@ -10,13 +10,16 @@ ctx_default = rt.Context(0)
 os.environ["VGX_BUILD_WAVES"] = "3"
 ctx_few = rt.Context(0)
 os.environ.pop("VGX_BUILD_WAVES", None)
+os.environ["VGX_NO_SMALL"] = "1"
+ctx_large = rt.Context(0)  # the large-batch launch sequence on these small batches
+os.environ.pop("VGX_NO_SMALL", None)
 bad = 0
 for seed in range(2000, 2000 + int(sys.argv[1] if len(sys.argv) > 1 else 300)):
     ps = wl.fuzz_paths(seed, npaths=64)
     d = wl.fuzz_draws(ps, seed)
     rs = np.random.RandomState(seed)
     d = np.concatenate([d, d[rs.permutation(d.shape[0])]])
-    ctx = ctx_few if seed % 3 == 0 else ctx_default
+    ctx = ctx_few if seed % 3 == 0 else (ctx_large if seed % 3 == 1 else ctx_default)
     ref = pyoracle.tessellate(ps, d)
     pset = rt.PathSet(ctx, ps); dd = rt.upload_draws(d)
     sizes = rt.tessellate_count(ctx, pset, dd, d.shape[0])

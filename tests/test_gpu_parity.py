@@ -212,6 +212,19 @@ def test_async_steady_state_with_changed_draw_parameters(rt, gpu_ctx, wl, oracle
     got.idx = bufs.idx[:ni].cpu().numpy().view(np.uint16)
     got.meshes = bufs.meshes[:nm * 32].cpu().numpy().view(rt.capi.mesh_dtype)
     assert_mesh_equal(got, ref, "steady state, changed draws")
+    # and a different batch of the same capacity: the draws in another order (other offsets everywhere)
+    d3 = d2[rs.permutation(d2.shape[0])]
+    ref3 = oracle.tessellate(ps, d3)
+    dd.copy_(torch.from_numpy(d3.view(np.uint8).reshape(-1).copy()))
+    bufs.pos.fill_(float("nan"))
+    rt.tessellate_async(gpu_ctx, pset, dd, d.shape[0], bufs)
+    torch.cuda.synchronize()
+    assert int(bufs.dev_status.item()) == 0
+    got.pos = bufs.pos[:nv].cpu().numpy()
+    got.color = bufs.color[:nv].cpu().numpy().view(np.uint32)
+    got.idx = bufs.idx[:ni].cpu().numpy().view(np.uint16)
+    got.meshes = bufs.meshes[:nm * 32].cpu().numpy().view(rt.capi.mesh_dtype)
+    assert_mesh_equal(got, ref3, "steady state, permuted draws")
     pset.close()
 
 
@@ -256,6 +269,25 @@ def _async_result(rt, gpu_ctx, ps, d):
     got.meshes = bufs.meshes[:nm * 32].cpu().numpy().view(rt.capi.mesh_dtype)
     pset.close()
     return got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 5, 8])
+def test_async_large_batch_launch_sequence_on_small_batches(rt, wl, oracle, seed, monkeypatch):
+    """Batches of at most VGX_SMALL_DRAWS draws take the frame-sized path of vgx_tessellate (three one-workgroup kernels
+    around k_flatten_build). VGX_NO_SMALL=1 (read at vgx_create) sends the same fuzz batches -- every command, degenerate
+    draws, serial shapes, Round joins -- through the large-batch launch sequence, which the full-size tests only exercise
+    with the Tiger drawing."""
+    monkeypatch.setenv("VGX_NO_SMALL", "1")
+    ctx = rt.Context(0)
+    ps = wl.fuzz_paths(seed, npaths=96)
+    d = wl.fuzz_draws(ps, seed)
+    d = np.concatenate([d, d[::-1]])
+    ref = oracle.tessellate(ps, d)
+    got = _async_result(rt, ctx, ps, d)
+    assert got.status == 0
+    assert_mesh_equal(got, ref, "large-batch sequence, fuzz seed=%d" % seed)
+    ctx.close()
 
 
 @pytest.mark.gpu

@@ -66,7 +66,7 @@ struct vgx_ctx
 	uint64_t fusedSegCap;        // segments the tables above hold
 	uint64_t* hostProbe;         // pinned
 	// options, read from the environment ONCE at vgx_create (tuning / testing knobs)
-	int optTwoPass, optNoFused, optBuildWaves, optFusedWaves, optPoolWalk;
+	int optTwoPass, optNoFused, optBuildWaves, optFusedWaves, optPoolWalk, optNoSmall;
 	VgxCaps caps; // element capacities matching the buffers above
 	uint64_t capDraws;
 	VgxTotals* hostTotals; // pinned
@@ -639,6 +639,7 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	ctx->optTwoPass = getenv("VGX_TWO_PASS_FLATTEN") ? 1 : 0;
 	ctx->optNoFused = getenv("VGX_FUSED") ? 0 : 1; // the single-pass kernel is opt-in (VGX_FUSED=1): measured slower than the multi-kernel pipeline, DESIGN.md section 4
 	ctx->optBuildWaves = VGX_BUILD_WAVES;
+	ctx->optNoSmall = getenv("VGX_NO_SMALL") ? 1 : 0; // testing knob: frame-sized batches through the large-batch launch sequence
 	ctx->optPoolWalk = 0; // VGX_WALK=pool: the wave-cooperative walk of vgx_walk.h (same output, same speed: DESIGN.md section 4)
 	if (const char* e = getenv("VGX_WALK")) { ctx->optPoolWalk = strcmp(e, "pool") == 0; }
 	if (const char* e = getenv("VGX_BUILD_WAVES")) { const int v = atoi(e); if (v >= 1 && v < VGX_BUILD_WAVES) { ctx->optBuildWaves = v; } }
@@ -1050,6 +1051,38 @@ int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 		}
 		return launchStatus(ctx);
 	}
+	VgxCaps outCaps = ctx->caps;
+	outCaps.vertices = out->cap_vertices;
+	outCaps.indices = out->cap_indices;
+	if (out->meshes && out->cap_meshes < outCaps.meshes) { outCaps.meshes = out->cap_meshes; }
+	if (ndraws <= VGX_SMALL_DRAWS && !ctx->asmArmed && !ctx->optTwoPass && !ctx->optNoSmall) {
+		// frame-sized batch: five launches instead of seventeen (vgx_flatten.hip, "Frame-sized batches")
+		OpCmdPrefix opC;
+		opC.draws = draws; opC.pathCmdBegin = ps->dev.path_cmd_begin; opC.npaths = ps->dev.npaths; opC.ndraws = ndraws;
+		opC.prefix = (uint64_t*)ctx->cmdPrefix.p; opC.totals = (VgxTotals*)ctx->totals.p; opC.cap = ctx->caps.cmd_instances;
+		vgx_launch_small_front(&opC, (vgx_draw_info*)ctx->dinfo.p, s);
+		mark(ctx, s, "small_front");
+		VgxFlattenArgs f = flattenArgs(ctx, ps, draws, ndraws, 1);
+		f.build_mode = 1;
+		f.mprep = (VgxMeshPrep*)ctx->mprep.p;
+		vgx_launch_flatten_build(f, ctx->optBuildWaves, s, false);
+		mark(ctx, s, "flatten_build");
+		VgxStrokeArgs sa;
+		sa.draws = draws; sa.poly = (const float*)ctx->poly.p; sa.mdesc = (const VgxMeshDesc*)ctx->mdesc.p;
+		sa.elem_prefix = nullptr; sa.elem_prefix_fill = (const uint64_t*)ctx->elemPrefix.p; sa.elem_prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
+		sa.mprep = (VgxMeshPrep*)ctx->mprep.p; sa.mtab = (vgx_mesh*)ctx->mtab.p;
+		sa.pos = nullptr; sa.color = nullptr; sa.idx = nullptr; sa.meshes_out = nullptr; sa.mesh_base = nullptr;
+		sa.totals = (VgxTotals*)ctx->totals.p; sa.caps = outCaps;
+		OpDrawInfo opD;
+		opD.dinfo = (vgx_draw_info*)ctx->dinfo.p; opD.ndraws = ndraws; opD.totals = (VgxTotals*)ctx->totals.p; opD.caps = ctx->caps; opD.keepPolyBase = 1;
+		OpMeshAll opM;
+		opM.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; opM.mtab = (vgx_mesh*)ctx->mtab.p; opM.meshesOut = out->meshes;
+		opM.prefixFill = (uint64_t*)ctx->elemPrefix.p; opM.prefixStroke = (uint64_t*)ctx->elemPrefixS.p;
+		opM.totals = (VgxTotals*)ctx->totals.p; opM.caps = outCaps; opM.checkCaps = 1;
+		vgx_launch_small_middle(f, sa, &opD, &opM, dev_sizes, dev_status, s);
+		mark(ctx, s, "small_middle");
+		return runStrokeEmit(ctx, draws, out, s, nullptr, true);
+	}
 	runCmdPrefix(ctx, ps, draws, ndraws, s);
 	if (ctx->optTwoPass) { // tuning / debugging knob: the ordered two-pass flatten
 		runFlattenCount(ctx, ps, draws, ndraws, s);
@@ -1059,10 +1092,6 @@ int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 	} else {
 		runFlattenBuild(ctx, ps, draws, ndraws, s);
 	}
-	VgxCaps outCaps = ctx->caps;
-	outCaps.vertices = out->cap_vertices;
-	outCaps.indices = out->cap_indices;
-	if (out->meshes && out->cap_meshes < outCaps.meshes) { outCaps.meshes = out->cap_meshes; }
 	runStrokeCount(ctx, draws, outCaps, 1, s, nullptr, !ctx->optTwoPass, out->meshes);
 	{
 		const int st = runStrokeEmit(ctx, draws, out, s, nullptr, true);

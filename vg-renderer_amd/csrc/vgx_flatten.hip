@@ -27,6 +27,8 @@
 #include "vgx_wave.h"
 #include "vgx_pathsim.h"
 #include "vgx_walk.h"
+#include "vgx_elem.h"
+#include "vgx_scan_ops.h"
 
 namespace {
 
@@ -751,14 +753,13 @@ struct PrivStack
 //   - draws the lane-parallel kernel flagged as degenerate (epsilon de-dup hit, dropped subdivision piece).
 // Slow by construction, exact by construction; everything else never enters this kernel.
 template<bool EMIT, bool XFORM>
-__global__ __launch_bounds__(256) void k_flatten_serial(VgxFlattenArgs A)
+__device__ __forceinline__ void flatten_serial_body(const VgxFlattenArgs& A, uint64_t tid, uint64_t nthreads)
 {
-	if (A.totals->status != VGX_OK) { return; }
 	const VgxPathSetDev& ps = A.ps;
 	PrivStack stack;
 	// BUILD mode: k_flatten_build listed the draws to do; otherwise every draw is inspected
 	const uint64_t nwork = A.build_mode ? (uint64_t)A.totals->num_serial_list : A.ndraws;
-	for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwork; w += (uint64_t)gridDim.x * blockDim.x) {
+	for (uint64_t w = tid; w < nwork; w += nthreads) {
 		const uint64_t d = A.build_mode ? (uint64_t)A.serial_list[w] : w;
 		const vgx_draw* dr = A.draws + d;
 		const uint32_t path = dr->path;
@@ -794,9 +795,114 @@ __global__ __launch_bounds__(256) void k_flatten_serial(VgxFlattenArgs A)
 	}
 }
 
+template<bool EMIT, bool XFORM>
+__global__ __launch_bounds__(256) void k_flatten_serial(VgxFlattenArgs A)
+{
+	if (A.totals->status != VGX_OK) { return; }
+	flatten_serial_body<EMIT, XFORM>(A, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Frame-sized batches (at most VGX_SMALL_DRAWS draws: one vg-renderer frame is a few hundred paths) are bound by the
+// number of DEPENDENT launches, ~7 us each on this platform whether launched or graph-replayed: 17 of them made a
+// 240-path drawing cost 125 us. Everything between the lane-parallel flatten and the element kernels needs device-wide
+// results but only a few thousand items, so ONE workgroup does it with block barriers instead of kernel boundaries:
+//   k_small_front   zero the totals + per-draw records, scan of command instances per draw
+//   k_flatten_build (unchanged)
+//   k_small_middle  exact serial builder for the listed draws (count), scan over the draws, mesh descriptors (gather +
+//                   serial emit), Round-join mesh sizes, scan over the meshes (+ the caller's mesh table), totals published
+//   k_fill, k_stroke (unchanged)
+// Same device functions as the large-batch kernels, so the results are identical by construction.
+// Values another thread produced with an ATOMIC (status word, heap cursor, Round-mesh counter) are read with agent-scope
+// atomic loads: atomics execute in L2 and do not refresh this CU's L1 line.
+// ------------------------------------------------------------------------------------------------
+#define VGX_SMALL_THREADS 1024
+
+__device__ __forceinline__ uint32_t small_status(const VgxTotals* t) { return __hip_atomic_load(&t->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(VGX_SMALL_THREADS) void k_small_front(OpCmdPrefix op, vgx_draw_info* dinfo)
+{
+	__shared__ Sum3 s_wave[VGX_SMALL_THREADS / 64];
+	{ // the zeroing the large-batch path does with two memsets
+		uint32_t* t = (uint32_t*)op.totals;
+		for (uint32_t i = threadIdx.x; i < sizeof(VgxTotals) / 4; i += VGX_SMALL_THREADS) { t[i] = 0u; }
+		uint32_t* d = (uint32_t*)dinfo;
+		for (uint64_t i = threadIdx.x; i < op.ndraws * (sizeof(vgx_draw_info) / 4); i += VGX_SMALL_THREADS) { d[i] = 0u; }
+	}
+	__syncthreads();
+	block_scan_all<OpCmdPrefix, VGX_SMALL_THREADS>(op, s_wave);
+}
+
+struct VgxSmallArgs
+{
+	VgxFlattenArgs F;   // build_mode = 1, mprep set
+	VgxStrokeArgs S;    // draws / poly / mdesc / mprep / mtab / totals for the Round-join sizing
+	OpDrawInfo opDraws;
+	OpMeshAll opMeshes;
+	vgx_sizes* dev_sizes;   // may be null
+	uint32_t* dev_status;   // may be null
+};
+
+__global__ __launch_bounds__(VGX_SMALL_THREADS) void k_small_middle(VgxSmallArgs K)
+{
+	__shared__ Sum3 s_wave[VGX_SMALL_THREADS / 64];
+	VgxTotals* T = K.F.totals;
+	const uint64_t tid = threadIdx.x;
+	// (1) draws the lane-parallel kernel handed to the exact serial builder: count + heap allocation
+	if (small_status(T) == VGX_OK) { flatten_serial_body<false, false>(K.F, tid, VGX_SMALL_THREADS); }
+	__syncthreads();
+	// (2) scan over the draws (reads status through size(): plain load of a word only atomics write -> use the fresh value)
+	{
+		OpDrawInfo op = K.opDraws;
+		if (small_status(T) != VGX_OK) { op.ndraws = 0; }
+		block_scan_all<OpDrawInfo, VGX_SMALL_THREADS>(op, s_wave);
+	}
+	// (3) mesh descriptors + per-mesh constants: sub-path records of the lane-parallel kernel, then the serial draws' emit pass
+	if (small_status(T) == VGX_OK) {
+		flatten_gather_body(K.F, tid, VGX_SMALL_THREADS);
+		flatten_serial_body<true, true>(K.F, tid, VGX_SMALL_THREADS);
+	}
+	__syncthreads();
+	// (4) meshes with Round joins: one wave per mesh
+	const bool ok4 = small_status(T) == VGX_OK;
+	const uint64_t numMeshes = ok4 ? T->sizes.num_meshes : 0;
+	if (ok4 && __hip_atomic_load(&T->num_round_meshes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+		const int lane = threadIdx.x & 63;
+		for (uint64_t mi = threadIdx.x >> 6; mi < numMeshes; mi += VGX_SMALL_THREADS / 64) {
+			if (K.S.mtab[mi].num_vertices != VGX_MESH_NEEDS_COUNT) { continue; } // wave-uniform
+			uint32_t sv, si;
+			round_mesh_size(make_mesh_ctx(K.S.mdesc[mi], K.S.mprep[mi], K.S.draws, 0, K.S.poly), lane, &sv, &si);
+			if (lane == 0) { K.S.mtab[mi].num_vertices = sv; K.S.mtab[mi].num_indices = si; }
+		}
+	}
+	__syncthreads();
+	// (5) scan over the meshes: element / vertex / index offsets, the caller's mesh table, totals
+	{
+		OpMeshAll op = K.opMeshes;
+		block_scan_all<OpMeshAll, VGX_SMALL_THREADS>(op, s_wave);
+	}
+	// (6) publish
+	if (threadIdx.x == 0) {
+		if (K.dev_sizes) { *K.dev_sizes = T->sizes; }
+		if (K.dev_status) { *K.dev_status = small_status(T); }
+	}
+}
+
 } // namespace
 
-void vgx_launch_flatten_build(const VgxFlattenArgs& a, int waves, hipStream_t s)
+void vgx_launch_small_front(const void* opCmdPrefix, vgx_draw_info* dinfo, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_small_front, dim3(1), dim3(VGX_SMALL_THREADS), 0, s, *(const OpCmdPrefix*)opCmdPrefix, dinfo);
+}
+
+void vgx_launch_small_middle(const VgxFlattenArgs& f, const VgxStrokeArgs& st, const void* opDraws, const void* opMeshes, vgx_sizes* devSizes, uint32_t* devStatus, hipStream_t s)
+{
+	VgxSmallArgs k;
+	k.F = f; k.S = st; k.opDraws = *(const OpDrawInfo*)opDraws; k.opMeshes = *(const OpMeshAll*)opMeshes; k.dev_sizes = devSizes; k.dev_status = devStatus;
+	hipLaunchKernelGGL(k_small_middle, dim3(1), dim3(VGX_SMALL_THREADS), 0, s, k);
+}
+
+void vgx_launch_flatten_build(const VgxFlattenArgs& a, int waves, hipStream_t s, bool serialCount)
 {
 	// waves < VGX_BUILD_WAVES is a testing knob (VGX_BUILD_WAVES in the environment at vgx_create): a handful of waves makes
 	// small batches run through the heap's block switches and sub-path moves that otherwise need > 8192 vertices per wave
@@ -805,7 +911,7 @@ void vgx_launch_flatten_build(const VgxFlattenArgs& a, int waves, hipStream_t s)
 	} else {
 		hipLaunchKernelGGL(k_flatten_build<false>, dim3(waves), dim3(VGX_WAVE), 0, s, a);
 	}
-	hipLaunchKernelGGL((k_flatten_serial<false, false>), dim3(1024), dim3(256), 0, s, a); // count + heap allocation
+	if (serialCount) { hipLaunchKernelGGL((k_flatten_serial<false, false>), dim3(1024), dim3(256), 0, s, a); } // count + heap allocation
 }
 
 void vgx_launch_flatten_gather(const VgxFlattenArgs& a, hipStream_t s)

@@ -112,7 +112,13 @@ void vgx_launch_concave_emit(const VgxConcaveArgs& a, hipStream_t s);
 
 // launchers (defined in the .hip files)
 void vgx_launch_flatten(bool emit, const VgxFlattenArgs& a, int numBlocks, hipStream_t s);
-void vgx_launch_flatten_build(const VgxFlattenArgs& a, int waves, hipStream_t s);   // single-pass: subdivide once, polyline -> heap
+void vgx_launch_flatten_build(const VgxFlattenArgs& a, int waves, hipStream_t s, bool serialCount = true);   // single-pass: subdivide once, polyline -> heap
+// frame-sized batches (vgx_flatten.hip): one-workgroup kernels instead of chains of dependent launches; the operators are
+// the OpCmdPrefix / OpDrawInfo / OpMeshAll of vgx_scan_ops.h, passed type-erased (the header is device code)
+#define VGX_SMALL_DRAWS 2048
+struct VgxStrokeArgs;
+void vgx_launch_small_front(const void* opCmdPrefix, vgx_draw_info* dinfo, hipStream_t s);
+void vgx_launch_small_middle(const VgxFlattenArgs& f, const VgxStrokeArgs& st, const void* opDraws, const void* opMeshes, vgx_sizes* devSizes, uint32_t* devStatus, hipStream_t s);
 void vgx_launch_flatten_gather(const VgxFlattenArgs& a, hipStream_t s);  // after the draw scan: ordered mesh descriptors
 #define VGX_BUILD_WAVES 4096
 #define VGX_BUILD_BLOCK 8192 /* polyline vertices per wave-private heap block */

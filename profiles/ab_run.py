@@ -27,12 +27,19 @@ for r in range(rounds):
         env = dict(os.environ)
         if v != "default":
             env["VGX_LIB"] = os.path.join(ROOT, "vg-renderer_amd", "dbg", "libvgx_%s.so" % v)
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "stage_times.py"), which], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout.strip().splitlines()[-1]
-        d = ast.literal_eval(out[out.index("{"):])
+        try:
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "stage_times.py"), which], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120).stdout.strip().splitlines()[-1]
+            d = ast.literal_eval(out[out.index("{"):])
+        except (subprocess.TimeoutExpired, IndexError, ValueError, SyntaxError):
+            print("variant %s: run failed (round %d)" % (v, r), flush=True)
+            continue
         d["total"] = sum(d.values())
         for k, x in d.items():
             acc[v].setdefault(k, []).append(x)
 keys = stages or ["total", "flatten_build", "fill_emit", "stroke_emit"]
 print("%-14s" % "variant" + "".join("%26s" % (k + " min/med") for k in keys))
 for v in args:
+    if not acc[v]:
+        print("%-14s no successful run" % v)
+        continue
     print("%-14s" % v + "".join("%26s" % ("%.3f / %.3f" % (min(acc[v][k]), statistics.median(acc[v][k]))) for k in keys))

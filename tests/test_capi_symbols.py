@@ -85,3 +85,21 @@ def test_product_code_never_touches_the_oracle():
                     if re.search(r"pyoracle|libvgoracle|libvgref|vgo_tessellate|vgo_flatten|vgo_port|ref_capi", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_cpp_hosts_compile_and_link_against_the_c_abi(rt, tmp_path):
+    """The C++ programs that drive the C-ABI (the example, the multi-rank gather test with its stand-in RCCL, the
+    reference-API compat test) compile and link here, without a GPU: catches header / symbol drift on the CPU round."""
+    import subprocess
+    pkg = os.path.join(ROOT, "vg-renderer_amd")
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-I", inc, os.path.join(ROOT, "examples", "vgx_example.cpp"),
+                           "-L", pkg, "-lvgx", "-Wl,-rpath," + pkg, "-o", str(tmp_path / "vgx_example")])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-I", inc, os.path.join(ROOT, "tests", "native", "gather_test.cpp"),
+                           "-L", pkg, "-lvgx", "-L/opt/rocm/lib", "-lrccl", "-ldl", "-lpthread", "-Wl,-rpath," + pkg, "-o", str(tmp_path / "gather_test")])
+    subprocess.check_call(["g++", "-shared", "-fPIC", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "native", "fake_rccl.cpp"),
+                           "-L/opt/rocm/lib", "-lamdhip64", "-o", str(tmp_path / "libfake_rccl.so")])
+    # the stand-in exports exactly the entry points vgx_gather binds
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", str(tmp_path / "libfake_rccl.so")], text=True)
+    for name in ("ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv", "ncclAllGather", "ncclCommCount", "ncclCommUserRank"):
+        assert (" T " + name) in syms, name

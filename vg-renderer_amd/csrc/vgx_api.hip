@@ -66,7 +66,8 @@ struct vgx_ctx
 	uint64_t fusedSegCap;        // segments the tables above hold
 	uint64_t* hostProbe;         // pinned
 	// options, read from the environment ONCE at vgx_create (tuning / testing knobs)
-	int optTwoPass, optNoFused, optBuildWaves, optFusedWaves, optPoolWalk, optNoSmall;
+	int optTwoPass, optNoFused, optBuildWaves, optFusedWaves, optPoolWalk, optNoSmall, optConcurrentEmit;
+	hipStream_t sideStream; hipEvent_t forkEv, joinEv; // optConcurrentEmit only
 	VgxCaps caps; // element capacities matching the buffers above
 	uint64_t capDraws;
 	VgxTotals* hostTotals; // pinned
@@ -486,6 +487,26 @@ int runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out, 
 	a.pos = out->pos; a.color = out->color; a.idx = out->idx; a.meshes_out = tableDone ? nullptr : out->meshes;
 	a.totals = (VgxTotals*)ctx->totals.p;
 	a.caps = ctx->caps;
+	if (ctx->optConcurrentEmit) {
+		// tuning experiment (VGX_EXP_CONCURRENT_EMIT=1 at vgx_create): k_stroke on a side stream beside k_fill (they write disjoint
+		// meshes); joined before the call returns control of `s`
+		if (!ctx->sideStream) {
+			(void)hipStreamCreateWithFlags(&ctx->sideStream, hipStreamNonBlocking);
+			(void)hipEventCreateWithFlags(&ctx->forkEv, hipEventDisableTiming);
+			(void)hipEventCreateWithFlags(&ctx->joinEv, hipEventDisableTiming);
+		}
+		(void)hipEventRecord(ctx->forkEv, s);
+		(void)hipStreamWaitEvent(ctx->sideStream, ctx->forkEv, 0);
+		VgxStrokeArgs b = a;
+		b.elem_prefix = a.elem_prefix_stroke;
+		vgx_launch_stroke(true, b, vgxElementGrid(out->cap_vertices), ctx->sideStream);
+		(void)hipEventRecord(ctx->joinEv, ctx->sideStream);
+		a.elem_prefix = a.elem_prefix_fill;
+		vgx_launch_fill(a, vgxElementGrid(out->cap_vertices), s);
+		(void)hipStreamWaitEvent(s, ctx->joinEv, 0);
+		mark(ctx, s, "fill_emit");
+		return launchStatus(ctx);
+	}
 	a.elem_prefix = a.elem_prefix_fill;
 	vgx_launch_fill(a, vgxElementGrid(out->cap_vertices), s);
 	mark(ctx, s, "fill_emit");
@@ -639,6 +660,7 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	ctx->optTwoPass = getenv("VGX_TWO_PASS_FLATTEN") ? 1 : 0;
 	ctx->optNoFused = getenv("VGX_FUSED") ? 0 : 1; // the single-pass kernel is opt-in (VGX_FUSED=1): measured slower than the multi-kernel pipeline, DESIGN.md section 4
 	ctx->optBuildWaves = VGX_BUILD_WAVES;
+	ctx->optConcurrentEmit = getenv("VGX_EXP_CONCURRENT_EMIT") ? 1 : 0;
 	ctx->optNoSmall = getenv("VGX_NO_SMALL") ? 1 : 0; // testing knob: frame-sized batches through the large-batch launch sequence
 	ctx->optPoolWalk = 0; // VGX_WALK=pool: the wave-cooperative walk of vgx_walk.h (same output, same speed: DESIGN.md section 4)
 	if (const char* e = getenv("VGX_WALK")) { ctx->optPoolWalk = strcmp(e, "pool") == 0; }
@@ -667,6 +689,7 @@ int vgx_destroy(vgx_ctx* ctx)
 	if (ctx->hostTotals) { (void)hipHostFree(ctx->hostTotals); }
 	if (ctx->hostProbe) { (void)hipHostFree(ctx->hostProbe); }
 	vgx_rccl_release(ctx);
+	if (ctx->sideStream) { (void)hipStreamDestroy(ctx->sideStream); (void)hipEventDestroy(ctx->forkEv); (void)hipEventDestroy(ctx->joinEv); }
 	if (ctx->evCreated) {
 		for (int i = 0; i <= VGX_MAX_STAGES; ++i) { (void)hipEventDestroy(ctx->ev[i]); }
 	}

@@ -128,8 +128,9 @@ int main(int argc, char** argv)
 {
 	const bool fake = argc > 1 && strcmp(argv[1], "fake") == 0;
 	const int nranks = fake ? atoi(argv[3]) : 1;
+	const uint64_t ndraws = (fake && argc > 4) ? strtoull(argv[4], nullptr, 10) : 1000; // fewer draws than ranks: empty shards
 	HIPOK(hipSetDevice(0));
-	const std::vector<vgx_draw> all = make_draws(1000);
+	const std::vector<vgx_draw> all = make_draws(ndraws);
 	Tess whole = tessellate(all, 0, all.size(), nullptr);
 	HIPOK(hipDeviceSynchronize());
 	const Streams ref = download(whole.out, whole.sz.num_vertices, whole.sz.num_indices, whole.sz.num_meshes);

@@ -31,9 +31,10 @@ def test_gather_one_rank_real_rccl(binaries):
     assert "ranks 1 root 0" in out and "identical to the single-context run" in out
 
 
-@pytest.mark.parametrize("nranks", [2, 3])
-def test_gather_threaded_ranks(binaries, nranks):
+@pytest.mark.parametrize("nranks,ndraws", [(2, 1000), (3, 1000), (4, 3), (4, 7)])
+def test_gather_threaded_ranks(binaries, nranks, ndraws):
+    """(4, 3): fewer draws than ranks -- empty shards send and receive nothing and still take part in the size exchange."""
     exe, fake = binaries
-    out = subprocess.check_output([exe, "fake", fake, str(nranks)], text=True, timeout=300)
+    out = subprocess.check_output([exe, "fake", fake, str(nranks), str(ndraws)], text=True, timeout=300)
     assert out.count("identical to the single-context run") == 2, out
     assert "MISMATCH" not in out

@@ -1,6 +1,7 @@
 """GPU soak (not collected by pytest): N extra fuzz seeds through the steady-state entry point against the oracle,
 every third seed on a context with a handful of build waves (heap block switches; the knob is read at vgx_create).
-`python tests/soak_gpu.py 2000` ran clean on the round-1 build, `... 1500` on the round-2 build (0 mismatches)."""
+`python tests/soak_gpu.py 2000` ran clean on the round-1 build, `... 6000` on the round-2 build (0 mismatches; default,
+few-waves and large-sequence contexts in turn)."""
 import importlib, sys, os, numpy as np, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/oracle"); sys.path.insert(0, "/root/repo/tests")
 import pyoracle

@@ -18,6 +18,7 @@ def hostlib():
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-shared", "-o", LIB, src])
     lib = C.CDLL(LIB)
     lib.vgxt_serial_flatten.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.vgxt_inst_flatten.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.vgxt_mesh_closed_form.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
     return lib
 
@@ -46,6 +47,64 @@ def test_serial_builder_matches_oracle(hostlib, vgr, wl, oracle, seed):
             assert np.array_equal(subs["flags"][:ns], ref.subpaths["flags"][s0:s0 + ns])
             assert np.array_equal(subs["first_vertex"][:ns] + a, ref.subpaths["first_vertex"][s0:s0 + ns])
             assert poly[n, 0] == 7777.0  # nothing written past the end (the vertex pathClose pops is never stored)
+
+
+SUBREC = np.dtype([("first", np.uint64), ("info", np.uint32), ("pad", np.uint32)])
+
+
+@pytest.mark.parametrize("seed,lb", [(0, 256), (1, 4), (2, 1), (3, 7), (6, 16), (9, 3)])
+def test_instanced_lane_matches_oracle(hostlib, vgr, wl, oracle, seed, lb):
+    """InstCore (vgx_inst.h), the per-lane sequential builder of k_flatten_inst: sub-path records, counts and the vertices
+    in its lane-private heap blocks against the oracle, with blocks small enough that sub-paths are moved many times."""
+    ps = wl.fuzz_paths(seed, npaths=96, with_shapes=False, with_polylines=True)
+    d = wl.fuzz_draws(ps, seed)
+    desc = ps.desc()
+    ref = oracle.flatten(ps, d, apply_transform=True)
+    cap = 8 * int(ref.draw_info["num_poly_vertices"].sum()) + 64 * max(lb, 4) * d.shape[0] + 4096
+    heap = np.full((cap + 1, 2), 7777.0, dtype=np.float32)
+    cursor = np.zeros(1, dtype=np.uint64)
+    pcb = ps.path_cmd_begin
+    for i in range(d.shape[0]):
+        p = int(d["path"][i])
+        ncmd = int(pcb[p + 1] - pcb[p])
+        rec = np.zeros(ncmd + 1, dtype=SUBREC)
+        cnt = np.zeros(5, dtype=np.uint32)
+        rc = hostlib.vgxt_inst_flatten(C.addressof(desc), d[i:i + 1].ctypes.data, heap.ctypes.data, cap, lb, cursor.ctypes.data, rec.ctypes.data, cnt.ctypes.data)
+        assert rc == 0 and cnt[4] == 0
+        n = int(ref.draw_info["num_poly_vertices"][i])
+        ns = int(ref.draw_info["num_subpaths"][i])
+        s0 = int(ref.draw_info["first_subpath"][i])
+        assert (int(cnt[0]), int(cnt[1])) == (n, ns), (seed, i)
+        ends = [k for k in range(ncmd) if k + 1 == ncmd or ps.cmd_type[pcb[p] + k + 1] == vgr.capi.CMD_MOVE_TO]
+        assert len(ends) == ns
+        for j, k in enumerate(ends):
+            sub = ref.subpaths[s0 + j]
+            cntv = int(rec["info"][k]) & 0x7FFFFFFF
+            assert cntv == int(sub["num_vertices"]) and (int(rec["info"][k]) >> 31) == int(sub["flags"] & 1), (seed, i, j)
+            f = int(rec["first"][k])
+            a = int(sub["first_vertex"])
+            assert np.array_equal(heap[f:f + cntv].view(np.uint32), ref.poly[a:a + cntv].view(np.uint32)), (seed, i, j)
+    assert heap[cap, 0] == 7777.0
+
+
+def test_instanced_lane_survives_a_full_heap(hostlib, vgr, wl):
+    """Heap exhausted in the middle of a draw: the lane reports it and never writes outside [0, cap)."""
+    ps = wl.fuzz_paths(5, npaths=32, with_shapes=False, with_polylines=True)
+    d = wl.fuzz_draws(ps, 5)
+    desc = ps.desc()
+    cap = 24
+    heap = np.full((cap + 8, 2), 7777.0, dtype=np.float32)
+    cursor = np.zeros(1, dtype=np.uint64)
+    failed = 0
+    for i in range(d.shape[0]):
+        p = int(d["path"][i])
+        ncmd = int(ps.path_cmd_begin[p + 1] - ps.path_cmd_begin[p])
+        rec = np.zeros(ncmd + 1, dtype=SUBREC)
+        cnt = np.zeros(5, dtype=np.uint32)
+        assert hostlib.vgxt_inst_flatten(C.addressof(desc), d[i:i + 1].ctypes.data, heap.ctypes.data, cap, 8, cursor.ctypes.data, rec.ctypes.data, cnt.ctypes.data) == 0
+        failed += int(cnt[4])
+    assert failed > 0
+    assert np.all(heap[cap:] == 7777.0)
 
 
 @pytest.mark.parametrize("seed", [100, 101, 102, 103])

@@ -10,6 +10,7 @@
 #include "vgx_scan.h"
 #include "vgx_scan_ops.h"
 #include "vgx_pathsim.h"
+#include "vgx_inst.h"
 #include <vector>
 #include <string.h>
 #include <math.h>
@@ -67,6 +68,10 @@ struct vgx_ctx
 	uint64_t* hostProbe;         // pinned
 	// options, read from the environment ONCE at vgx_create (tuning / testing knobs)
 	int optTwoPass, optNoFused, optBuildWaves, optFusedWaves, optPoolWalk, optNoSmall, optConcurrentEmit;
+	int optInst, optInstWaves; uint32_t optInstBlock; // instanced flatten kernel (vgx_inst.hip): on / grid / lane block
+	// instanced batches: period of the path sequence found by the last vgx_tessellate_count (0 = none). vgx_tessellate
+	// re-checks it on the device for the draws it is given.
+	uint32_t instPeriod;
 	hipStream_t sideStream; hipEvent_t forkEv, joinEv; // optConcurrentEmit only
 	VgxCaps caps; // element capacities matching the buffers above
 	uint64_t capDraws;
@@ -350,7 +355,17 @@ VgxFlattenArgs flattenArgs(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* 
 	a.pool_walk = ctx->optPoolWalk;
 	a.leaf_overflow = (float*)ctx->leafOverflow.p;
 	a.serial_list = (uint32_t*)ctx->serialList.p;
+	a.inst_period = 0; a.inst_block = ctx->optInstBlock; a.inst_waves = ctx->optInstWaves;
 	return a;
+}
+
+// Period the instanced kernel may assume for a batch of `ndraws` draws (0: command-parallel kernel). The device checks
+// draws[i].path == draws[i % period].path again on every call (OpCmdPrefix).
+uint32_t instPeriodFor(const vgx_ctx* ctx, uint64_t ndraws)
+{
+	const uint32_t P = ctx->instPeriod;
+	if (!P || !ctx->optInst || ndraws % P != 0 || ndraws / P < VGX_INST_MIN_INSTANCES) { return 0; }
+	return P;
 }
 
 int ensureDrawBuffers(vgx_ctx* ctx, uint64_t ndraws)
@@ -376,12 +391,13 @@ int readTotals(vgx_ctx* ctx, hipStream_t s)
 }
 
 // stage 1: command-instance prefix
-void runCmdPrefix(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, hipStream_t s)
+void runCmdPrefix(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, hipStream_t s, uint32_t instPeriod = 0)
 {
 	noteHip(ctx, hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s));
 	OpCmdPrefix op;
 	op.draws = draws; op.pathCmdBegin = ps->dev.path_cmd_begin; op.npaths = ps->dev.npaths; op.ndraws = ndraws;
 	op.prefix = (uint64_t*)ctx->cmdPrefix.p; op.totals = (VgxTotals*)ctx->totals.p; op.cap = ctx->caps.cmd_instances;
+	op.period = instPeriod;
 	vgx_device_scan(op, (Sum3*)ctx->partial.p, s, ndraws);
 	mark(ctx, s, "scan_cmd_prefix");
 }
@@ -405,6 +421,7 @@ void runFlattenBuild(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 	noteHip(ctx, hipMemsetAsync(ctx->dinfo.p, 0, ndraws * sizeof(vgx_draw_info), s));
 	VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, 1);
 	a.build_mode = 1;
+	a.inst_period = instPeriodFor(ctx, ndraws); // the same value runCmdPrefix checked the draws against
 	a.mprep = (VgxMeshPrep*)ctx->mprep.p; // k_flatten_gather / k_flatten_serial write the per-mesh constants with the descriptors
 	vgx_launch_flatten_build(a, ctx->optBuildWaves, s);
 	mark(ctx, s, "flatten_build");
@@ -662,6 +679,10 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	ctx->optBuildWaves = VGX_BUILD_WAVES;
 	ctx->optConcurrentEmit = getenv("VGX_EXP_CONCURRENT_EMIT") ? 1 : 0;
 	ctx->optNoSmall = getenv("VGX_NO_SMALL") ? 1 : 0; // testing knob: frame-sized batches through the large-batch launch sequence
+	ctx->optInst = 1; ctx->optInstWaves = VGX_INST_WAVES; ctx->optInstBlock = VGX_INST_BLOCK; // VGX_INST=0: instanced batches through k_flatten_build as well
+	if (const char* e = getenv("VGX_INST")) { ctx->optInst = atoi(e) != 0; }
+	if (const char* e = getenv("VGX_INST_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { ctx->optInstWaves = v; } }
+	if (const char* e = getenv("VGX_INST_BLOCK")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { ctx->optInstBlock = (uint32_t)v; } }
 	ctx->optPoolWalk = 0; // VGX_WALK=pool: the wave-cooperative walk of vgx_walk.h (same output, same speed: DESIGN.md section 4)
 	if (const char* e = getenv("VGX_WALK")) { ctx->optPoolWalk = strcmp(e, "pool") == 0; }
 	if (const char* e = getenv("VGX_BUILD_WAVES")) { const int v = atoi(e); if (v >= 1 && v < VGX_BUILD_WAVES) { ctx->optBuildWaves = v; } }
@@ -931,9 +952,16 @@ static int flattenCountCommon(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_dra
 	if ((st = ensureDrawBuffers(ctx, ndraws)) != VGX_OK) { return st; }
 	// pass 1: command instances (sizes the per-command scratch)
 	ctx->caps.cmd_instances = ~0ull; // not known yet: never trips the check in this sizing pass
+	ctx->instPeriod = 0;
 	runCmdPrefix(ctx, ps, draws, ndraws, s);
+	if (ctx->optInst && ndraws > VGX_SMALL_DRAWS) { vgx_launch_inst_detect(draws, ndraws, (VgxTotals*)ctx->totals.p, s); }
 	if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
 	if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; }
+	if (ctx->hostTotals->inst_detect_inv != 0 && !ctx->hostTotals->inst_detect_bad) {
+		// the draws repeat one sequence of paths (a drawing submitted for many instances): vgx_inst.hip
+		const unsigned long long P = ~0ull - ctx->hostTotals->inst_detect_inv;
+		if (P <= 0xFFFFFFFFull) { ctx->instPeriod = (uint32_t)P; }
+	}
 	const uint64_t ncmdInst = ctx->hostTotals->sizes.num_cmd_instances;
 	if ((st = ensure(ctx, ctx->cmdCnt, (ncmdInst + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->subFirst, (ncmdInst + 1) * sizeof(VgxSubRec))) != VGX_OK) { return st; }
@@ -1019,7 +1047,16 @@ int vgx_tessellate_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* dr
 	// when a chunk does not fit: the unused tail of the old block is smaller than that chunk (<= 1x the real vertices
 	// over the whole batch), the moved prefix of a spanning sub-path is < VGX_LONG_SUBPATH per >= VGX_BUILD_BLOCK block
 	// (<= 1/4), and longer sub-paths grow geometrically (<= 4x their own size). Plus every wave's last open block.
-	const uint64_t heapVerts = sz.num_poly_vertices * 9 / 4 + 4 * ctx->hostTotals->long_subpath_vertices + 2 * (uint64_t)VGX_BUILD_WAVES * VGX_BUILD_BLOCK;
+	uint64_t heapVerts = sz.num_poly_vertices * 9 / 4 + 4 * ctx->hostTotals->long_subpath_vertices + 2 * (uint64_t)VGX_BUILD_WAVES * VGX_BUILD_BLOCK;
+	if (instPeriodFor(ctx, ndraws)) {
+		// k_flatten_inst's lane-private blocks (vgx_inst.h): a block left behind wastes less than the one sub-path that did
+		// not fit (< the block's useful vertices while sub-paths are at most half a block long), longer sub-paths grow
+		// geometrically (<= 4x their size + a block, counted with head room), plus every lane's last open block
+		const uint64_t V = sz.num_poly_vertices;
+		const uint64_t grown = (ctx->optInstBlock >= VGX_INST_BLOCK) ? V * 9 / 4 + 8 * ctx->hostTotals->inst_long_subpath_vertices : V * 10;
+		const uint64_t instVerts = grown + (uint64_t)ctx->optInstWaves * 64 * ctx->optInstBlock + 4096;
+		if (instVerts > heapVerts) { heapVerts = instVerts; }
+	}
 	if ((st = ensureMeshBuffers(ctx, heapVerts, sz.num_subpaths, sz.num_meshes)) != VGX_OK) { return st; }
 	VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, 1);
 	vgx_launch_flatten(true, a, VGX_GRID_BLOCKS, s);
@@ -1083,6 +1120,7 @@ int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 		OpCmdPrefix opC;
 		opC.draws = draws; opC.pathCmdBegin = ps->dev.path_cmd_begin; opC.npaths = ps->dev.npaths; opC.ndraws = ndraws;
 		opC.prefix = (uint64_t*)ctx->cmdPrefix.p; opC.totals = (VgxTotals*)ctx->totals.p; opC.cap = ctx->caps.cmd_instances;
+		opC.period = 0;
 		vgx_launch_small_front(&opC, (vgx_draw_info*)ctx->dinfo.p, s);
 		mark(ctx, s, "small_front");
 		VgxFlattenArgs f = flattenArgs(ctx, ps, draws, ndraws, 1);
@@ -1106,7 +1144,7 @@ int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 		mark(ctx, s, "small_middle");
 		return runStrokeEmit(ctx, draws, out, s, nullptr, true);
 	}
-	runCmdPrefix(ctx, ps, draws, ndraws, s);
+	runCmdPrefix(ctx, ps, draws, ndraws, s, ctx->optTwoPass ? 0u : instPeriodFor(ctx, ndraws));
 	if (ctx->optTwoPass) { // tuning / debugging knob: the ordered two-pass flatten
 		runFlattenCount(ctx, ps, draws, ndraws, s);
 		VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, 1);

@@ -2,6 +2,7 @@
 // This is NOT a fallback path: nothing in the package loads it; tests/test_host_lane_logic.py uses it to
 // check the per-lane builder logic against the oracle without a GPU.
 #include "vgx_pathsim.h"
+#include "vgx_inst.h"
 #include <string.h>
 
 namespace {
@@ -64,6 +65,55 @@ int vgxt_serial_flatten(const vgx_pathset_desc* d, const vgx_draw* draw, int app
 		sim.run(ps, c0, c1, st);
 		counts[0] = sim.nverts; counts[1] = sim.nsubs; counts[2] = sim.nfill; counts[3] = sim.nstroke;
 	}
+	return 0;
+}
+
+// One lane of the instanced flatten kernel (InstCore, vgx_inst.h) for ONE draw on the host: the command loop of
+// k_flatten_inst with the generic cubic walk, a bump allocator over `heap` (cap vertices, lane blocks of `lb` vertices) in
+// place of the wave-aggregated one. `cursor` carries the heap position from draw to draw (lane-private blocks persist in
+// the kernel; here every call starts a fresh block). sub_rec[k] is written at the sub-path-ending commands (k relative to
+// the path's first command); counts[5] = { poly vertices, sub-paths, fill meshes, stroke meshes, 1 if the heap ran out }.
+namespace {
+struct HostInstEnv
+{
+	float* poly; uint64_t cap; uint32_t lb; uint64_t* cursor; bool failed;
+	bool alloc(uint64_t want, uint64_t* base)
+	{
+		if (*cursor + want > cap) { failed = true; return false; }
+		*base = *cursor; *cursor += want;
+		return true;
+	}
+	void emit(float* wp, float x, float y) { wp[0] = x; wp[1] = y; }
+	void flushForMove(float*) {}
+};
+}
+int vgxt_inst_flatten(const vgx_pathset_desc* d, const vgx_draw* draw, float* heap, uint64_t cap, uint32_t lb, uint64_t* cursor, VgxSubRec* sub_rec, uint32_t* counts)
+{
+	HostStack st;
+	InstCore<HostInstEnv> L;
+	L.env.poly = heap; L.env.cap = cap; L.env.lb = lb; L.env.cursor = cursor; L.env.failed = false;
+	L.initLane();
+	L.beginDraw(draw->mtx, draw->scale, draw->tess_tol, draw->fill_flags, draw->stroke_flags);
+	const uint32_t c0 = d->path_cmd_begin[draw->path], c1 = d->path_cmd_begin[draw->path + 1];
+	for (uint32_t c = c0; c < c1; ++c) {
+		const float* a = d->args + d->cmd_arg_off[c];
+		const uint32_t na = d->cmd_arg_off[c + 1] - d->cmd_arg_off[c];
+		const uint32_t type = d->cmd_type[c];
+		switch (type) {
+		case VGX_CMD_MOVE_TO: L.moveTo(a[0], a[1]); break;
+		case VGX_CMD_LINE_TO: L.lineTo(a[0], a[1]); break;
+		case VGX_CMD_CUBIC_TO: L.cubicTo(a[0], a[1], a[2], a[3], a[4], a[5], st); break;
+		case VGX_CMD_QUAD_TO: L.quadTo(a[0], a[1], a[2], a[3], st); break;
+		case VGX_CMD_CLOSE: L.close(); break;
+		case VGX_CMD_POLYLINE: L.polyline(a, na >> 1); break;
+		default: return -1; // statically serial paths never reach the instanced lane
+		}
+		const bool lastInSub = (c + 1 == c1) || d->cmd_type[c + 1] == VGX_CMD_MOVE_TO;
+		if (lastInSub) { L.endSub(sub_rec + (c - c0)); }
+	}
+	const vgx_draw_info di = L.drawInfo();
+	counts[0] = di.num_poly_vertices; counts[1] = di.num_subpaths; counts[2] = di.flags >> 1; counts[3] = di.num_meshes - (di.flags >> 1);
+	counts[4] = L.env.failed ? 1u : 0u;
 	return 0;
 }
 

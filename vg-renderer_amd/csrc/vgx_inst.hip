@@ -1,0 +1,424 @@
+// vgx_inst.hip -- k_flatten_inst: single-pass flatten of INSTANCED batches, one lane per instance.
+//
+// vgx_tessellate's flatten stage for batches whose draws repeat the same sequence of P paths (draws[i].path ==
+// draws[i mod P].path: a drawing submitted for many instances -- the shape vgx_draw was designed around, 64 B of input per
+// path instance). k_flatten_build maps one LANE to one path COMMAND; neighbouring lanes then hold different commands
+// and the adaptive subdivision of pathCubicTo (path.cpp:86-182) runs in lock-step at 31 % lane use (26 % of the
+// cubics of the headline drawing are one segment, 2.5 % need >= 17 steps). Here the 64 lanes of a wave are 64 INSTANCES
+// of the same path: every lane executes the path's commands in order with its own draw record (transform, scale,
+// tolerance, flags), i.e. vg::Path's own sequential algorithm (InstCore, vgx_inst.h), and the walk diverges only as far
+// as the instances' tolerances differ. What falls away with the command-parallel mapping: the segmented scans and
+// carries, the leaf slots in LDS and their copy loop, the owner windows, the exactness escape hatch (epsilon
+// de-duplication and pathClose are evaluated in order, so no draw is ever handed to k_flatten_serial as "degenerate").
+//   - command records come through the SCALAR cache (one s_load_dwordx16 per command per wave: the path is wave-uniform);
+//   - a lane appends its vertices to a lane-private block of the polyline heap (InstCore::grow); the wave's lanes take
+//     their blocks with ONE atomic per round of allocations;
+//   - sub-path records, per-draw counts and the list of statically serial draws (arcs / closed shapes) are written in
+//     the format k_flatten_build writes, so everything downstream (scan over draws, k_flatten_gather, k_fill, k_stroke)
+//     is unchanged and the meshes are bit-identical.
+// The periodic structure is found by vgx_tessellate_count (k_inst_find / k_inst_verify below) and re-checked on the
+// device by every vgx_tessellate (OpCmdPrefix, vgx_scan_ops.h): when the draw records were rewritten in a way that
+// breaks it, this kernel exits at once and k_flatten_build does the batch.
+#include "vgx_internal.h"
+#include "vgx_wave.h"
+#include "vgx_walk.h"
+#include "vgx_inst.h"
+
+namespace {
+
+#define VGX_INST_LDS_LEVELS 4
+#ifndef VGX_INST_STAGE
+#define VGX_INST_STAGE 8 /* vertices a lane parks in LDS before it writes them as one aligned piece (8: 64 bytes, 4: 32 bytes) */
+#endif
+
+// loads of data no kernel of the sequence writes after upload / after the preceding scan: constant address space, so
+// that wave-uniform addresses become scalar loads
+template<class T> __device__ __forceinline__ const __attribute__((address_space(4))) T* as_const(const T* p)
+{
+	return (const __attribute__((address_space(4))) T*)(uintptr_t)p;
+}
+
+struct InstEnvDev
+{
+	float* poly;
+	uint64_t cap;
+	uint32_t lb;
+	unsigned long long* cursor;
+	uint32_t* status;
+	int lane;
+	float2* stage; // &s_stage[lane]: the lane's 8 staged vertices, [slot][64 lanes]
+
+	// Vertex stores. A lane's vertices go to consecutive heap addresses; written one by one, 64 lanes x 8 bytes land in 64
+	// different cache lines per store instruction and every line stays partly written for several commands (measured:
+	// 1.15 of the kernel's 2.1 ms). So a vertex is parked in LDS at slot (address / 8) mod 8 and a lane writes a whole
+	// aligned 64-byte piece (four 16-byte stores back to back) when it has filled the last slot. Blocks start on piece
+	// boundaries (InstCore::grow), a moved sub-path is re-emitted through here, and a vertex pathClose pops leaves its
+	// slot behind unchanged, so the slots below the write position always hold the current piece's vertices.
+	__device__ __forceinline__ void emit(float* wp, float x, float y)
+	{
+		const uint32_t slot = ((uint32_t)(uintptr_t)wp >> 3) & (VGX_INST_STAGE - 1u);
+		stage[slot * VGX_WAVE] = make_float2(x, y);
+		if (slot == VGX_INST_STAGE - 1u) {
+			float4* dst = (float4*)(wp - 2 * (VGX_INST_STAGE - 1));
+			const float2 v0 = stage[0], v1 = stage[VGX_WAVE], v2 = stage[2 * VGX_WAVE];
+#if VGX_INST_STAGE == 8
+			const float2 v3 = stage[3 * VGX_WAVE], v4 = stage[4 * VGX_WAVE], v5 = stage[5 * VGX_WAVE], v6 = stage[6 * VGX_WAVE];
+#endif
+#ifndef VGX_EXP_INST_NOSTORE
+			dst[0] = make_float4(v0.x, v0.y, v1.x, v1.y);
+#if VGX_INST_STAGE == 8
+			dst[1] = make_float4(v2.x, v2.y, v3.x, v3.y);
+			dst[2] = make_float4(v4.x, v4.y, v5.x, v5.y);
+			dst[3] = make_float4(v6.x, v6.y, x, y);
+#else
+			dst[1] = make_float4(v2.x, v2.y, x, y);
+#endif
+#endif
+		}
+	}
+	// the staged part of the current piece (slots below the write position) goes to the heap: before a sub-path is
+	// moved (its tail is read back from the heap) and when the wave is done
+	__device__ __forceinline__ void flushPartial(float* wp)
+	{
+		const uint32_t n = ((uint32_t)(uintptr_t)wp >> 3) & (VGX_INST_STAGE - 1u);
+		float2* dst = (float2*)(wp - 2 * n);
+		for (uint32_t i = 0; i < n; ++i) { dst[i] = stage[i * VGX_WAVE]; }
+	}
+	// The write position went BACK from wpOld to wpNew (a cubic is redone): if that left the piece wpOld was in, the slots
+	// have been reused by later pieces; the piece wpNew is in was written out completely meanwhile, so its vertices below
+	// wpNew come back from the heap.
+	__device__ __forceinline__ void rewind(float* wpNew, float* wpOld)
+	{
+		if (((uintptr_t)wpNew / (8 * VGX_INST_STAGE)) == ((uintptr_t)wpOld / (8 * VGX_INST_STAGE))) { return; }
+		__threadfence_block();
+		const uint32_t n = ((uint32_t)(uintptr_t)wpNew >> 3) & (VGX_INST_STAGE - 1u);
+		const float2* src = (const float2*)(wpNew - 2 * n);
+		for (uint32_t i = 0; i < n; ++i) { stage[i * VGX_WAVE] = src[i]; }
+	}
+	__device__ __forceinline__ void flushForMove(float* wp)
+	{
+		flushPartial(wp);
+		__threadfence_block(); // the copy loop reads what this lane wrote
+	}
+	// Called by whichever lanes ran out of room (any subset of the wave): one atomic for all of them.
+	__device__ __forceinline__ bool alloc(uint64_t want, uint64_t* base)
+	{
+		const uint64_t mask = __ballot(1);
+		const uint32_t wlo = (uint32_t)want, whi = (uint32_t)(want >> 32);
+		uint64_t total = 0, off = 0;
+		for (uint64_t m = mask; m != 0; m &= m - 1) {
+			const int l = __builtin_ctzll(m);
+			const uint64_t w = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)whi, l) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)wlo, l);
+			if (lane == l) { off = total; }
+			total += w;
+		}
+		const int leader = __builtin_ctzll(mask);
+		unsigned long long b = 0;
+		if (lane == leader) { b = atomicAdd(cursor, (unsigned long long)total); }
+		b = wave_bcast_u64(b, leader);
+		if (b + total > cap || b + total < b) {
+			if (lane == leader) { atomicCAS(status, (uint32_t)VGX_OK, (uint32_t)VGX_E_NOSPACE); }
+			return false;
+		}
+		*base = b + off;
+		return true;
+	}
+};
+
+typedef InstCore<InstEnvDev> InstLane;
+
+// value of lane `l` (wave-uniform l): v_readlane_b32, whatever the exec mask
+__device__ __forceinline__ uint32_t rl_u32(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ float rl_f32(float v, uint32_t l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)l)); }
+
+// pathCubicTo for one lane of the instanced kernel: the hand-shaped walk of build_flatten_hot (vgx_walk.h: packed float
+// pairs, single exit, pending right halves in LDS as [level][3][64] float2) with pathAddVertex inlined at the leaves --
+// epsilon test against the last STORED vertex (path.cpp:769-775), transform, store to the lane's heap block. Arithmetic and
+// its order are those of path.cpp:107-170. Returns false when the cubic nests deeper than LV pending halves; the caller
+// restores the lane and redoes the cubic with the full-depth stack (vertices already written are simply overwritten).
+template<int LV>
+__device__ __forceinline__ bool inst_cubic_hot(InstLane& L, v2f P2, v2f P3, v2f P4, float2* stackLane)
+{
+	v2f P1;
+	P1.x = L.last.x; P1.y = L.last.y;
+	v2f prev = P1;
+	const float tessTol = L.tessTol;
+	int pending = 0;
+	bool more = true, aborted = false;
+	uint32_t sp = 0;
+	while (more) {
+		const v2f d = P4 - P1;
+		const v2f a2 = P2 - P4, a3 = P3 - P4;
+		const v2f dsw = d.yx;
+		const v2f m2 = a2 * dsw, m3 = a3 * dsw;
+		const float d2 = __builtin_fabsf(m2.x - m2.y), d3 = __builtin_fabsf(m3.x - m3.y);
+		const float d23 = d2 + d3;
+		const v2f dd = d * d;
+		const bool flat = d23 * d23 <= tessTol * (dd.x + dd.y);
+		const bool push = !flat && pending < LV;
+		const v2f P12 = (P1 + P2) * 0.5f, P23 = (P2 + P3) * 0.5f, P34 = (P3 + P4) * 0.5f;
+		const v2f P123 = (P12 + P23) * 0.5f, P234 = (P23 + P34) * 0.5f;
+		const v2f P1234 = (P123 + P234) * 0.5f;
+		v2f N2 = P12, N3 = P123, N4 = P1234;
+		if (push) {
+			stackLane[sp] = make_float2(P234.x, P234.y);
+			stackLane[sp + VGX_WAVE] = make_float2(P34.x, P34.y);
+			stackLane[sp + 2 * VGX_WAVE] = make_float2(P4.x, P4.y);
+			sp += 3 * VGX_WAVE;
+		} else {
+			if (flat) {
+				const v2f e = prev - P4; // pathAddVertex: lastVertex - (x, y)
+				const v2f ee = e * e;
+				if (!(ee.x + ee.y < VGM_EPSILON)) {
+					if (L.room == 0) { L.grow(); }
+					float2 o;
+					o.x = L.m0 * P4.x + L.m2 * P4.y + L.m4; // transformPos2D, vg_util.h:24-28
+					o.y = L.m1 * P4.x + L.m3 * P4.y + L.m5;
+					L.env.emit(L.wp, o.x, o.y);
+					L.wp += 2;
+					--L.room;
+					++L.spN;
+					prev = P4;
+				}
+			} else {
+				aborted = true;
+			}
+			P1 = P4;
+			if (pending > 0) {
+				sp -= 3 * VGX_WAVE;
+				const float2 q2 = stackLane[sp], q3 = stackLane[sp + VGX_WAVE], q4 = stackLane[sp + 2 * VGX_WAVE];
+				N2.x = q2.x; N2.y = q2.y; N3.x = q3.x; N3.y = q3.y; N4.x = q4.x; N4.y = q4.y;
+			}
+		}
+		more = (push || pending > 0) && !aborted;
+		pending += push ? 1 : -1;
+		P2 = N2; P3 = N3; P4 = N4;
+	}
+	L.last = v2(prev.x, prev.y);
+	return !aborted;
+}
+
+// stackLane = &s_stack[lane], handed down from the kernel as an expression on the __shared__ array (NOT through stack.base:
+// `stack` lives in private memory because of its deep[] levels, and a pointer loaded from there is a flat pointer -- the
+// hot loop's pushes and pops would become flat_store / flat_load instead of ds_write / ds_read).
+__device__ __forceinline__ void inst_cubic(InstLane& L, float c1x, float c1y, float c2x, float c2y, float x, float y, LdsStackT<VGX_INST_LDS_LEVELS>& stack, float2* stackLane)
+{
+	const uint32_t n0 = L.spN;
+	const V2 last0 = L.last;
+	v2f P2, P3, P4;
+	P2.x = c1x; P2.y = c1y; P3.x = c2x; P3.y = c2y; P4.x = x; P4.y = y;
+	if (!inst_cubic_hot<VGX_INST_LDS_LEVELS>(L, P2, P3, P4, stackLane)) {
+		// deeper than the LDS levels: back to the state before the cubic (the write position follows the vertex count; a
+		// block switch that happened meanwhile stays), then the full-depth walk
+		const uint32_t back = L.spN - n0;
+		if (!L.dead) {
+			float* const now = L.wp;
+			L.wp -= 2 * (uint64_t)back; L.room += back;
+			L.env.rewind(L.wp, now);
+		}
+		L.spN = n0;
+		L.last = last0;
+		L.cubicTo(c1x, c1y, c2x, c2y, x, y, stack);
+	}
+}
+
+#ifdef VGX_INST_WAVES_PER_EU
+__attribute__((amdgpu_waves_per_eu(VGX_INST_WAVES_PER_EU)))
+#endif
+__global__ __launch_bounds__(VGX_WAVE) void k_flatten_inst(VgxFlattenArgs A)
+{
+	__shared__ float2 s_stack[VGX_INST_LDS_LEVELS * 3 * VGX_WAVE];
+	__shared__ float2 s_stage[VGX_INST_STAGE * VGX_WAVE];
+	const int lane = threadIdx.x;
+	if (A.totals->status != VGX_OK || A.totals->inst_mismatch != 0) { return; }
+	LdsStackT<VGX_INST_LDS_LEVELS> stack;
+	stack.base = &s_stack[lane];
+
+	const VgxPathSetDev& ps = A.ps;
+	const uint32_t P = A.inst_period;
+	const uint64_t ninst = A.ndraws / P;
+	const auto cprefix = as_const(A.cmd_prefix); // of the first instance = command offsets inside every instance
+	const uint64_t C = cprefix[P];                // commands per instance
+	const uint64_t G = (ninst + VGX_WAVE - 1) / VGX_WAVE;
+	if (C == 0) { return; }
+	// the wave's share of the (instance group, command) axis; a (group, path) task belongs to the wave whose share holds
+	// the path's first command
+	const uint64_t axis = G * C;
+	const uint64_t share = (axis + gridDim.x - 1) / gridDim.x;
+	const uint64_t a0 = (uint64_t)blockIdx.x * share;
+	const uint64_t a1 = (a0 + share < axis) ? a0 + share : axis;
+	if (a0 >= a1) { return; }
+	uint64_t g = a0 / C;
+	uint32_t p;
+	{
+		const uint64_t r = a0 - g * C;
+		uint32_t lo = 0, hi = P; // first path with cprefix[p] >= r
+		while (lo < hi) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if (cprefix[mid] < r) { lo = mid + 1; } else { hi = mid; }
+		}
+		p = lo;
+	}
+
+	InstLane L;
+	L.env.poly = A.poly; L.env.cap = A.caps.poly_vertices; L.env.lb = A.inst_block; L.env.cursor = &A.totals->poly_heap_cursor;
+	L.env.status = &A.totals->status; L.env.lane = lane; L.env.stage = &s_stage[lane];
+	L.initLane();
+
+	for (;;) {
+		if (p >= P) { ++g; p = 0; }
+		if (g >= G) { break; }
+		const uint64_t pos = g * C + cprefix[p];
+		if (pos >= a1) { break; }
+		const uint32_t pcur = p++;
+		const uint32_t path = as_const(A.draws)[pcur].path; // == draws[i * P + pcur].path for every instance i (verified)
+		const uint32_t pc0 = as_const(ps.path_cmd_begin)[path], pc1 = as_const(ps.path_cmd_begin)[path + 1];
+		if (pc0 == pc1) { continue; } // nothing to build: the draw's (zeroed) record stands
+		const uint64_t inst = g * VGX_WAVE + (uint64_t)lane;
+		const bool valid = inst < ninst;
+		const uint64_t d = inst * P + pcur;
+		if (as_const(ps.path_flags)[path] & VGX_PF_SERIAL) {
+			// arcs / closed shapes: the exact one-lane-per-draw builder (k_flatten_serial), as in k_flatten_build
+			const uint64_t sm = wave_ballot(valid);
+			unsigned long long sbase = 0;
+			if (lane == 0) { sbase = atomicAdd(&A.totals->num_serial_list, (unsigned long long)__popcll(sm)); }
+			sbase = wave_bcast_u64(sbase, 0);
+			if (valid) { A.serial_list[sbase + (uint64_t)__popcll(sm & lanemask_lt(lane))] = (uint32_t)d; }
+			continue;
+		}
+#ifndef VGX_INST_SCALAR_RECS
+		// The path's command records: lane l fetches record k0 + l (one coalesced read per 64 commands), the command loop
+		// takes record k from lane k - k0 with v_readlane -- no memory latency per command.
+		const VgxCmdRec* recs = ps.cmdrec + pc0;
+		const uint32_t ncmd = pc1 - pc0;
+		const vgx_draw* dr = A.draws + d;
+		VgxSubRec* srec = A.sub_rec + (inst * C + cprefix[pcur]);
+		if (valid) { L.beginDraw(dr->mtx, dr->scale, dr->tess_tol, dr->fill_flags, dr->stroke_flags); }
+		for (uint32_t k0 = 0; k0 < ncmd; k0 += VGX_WAVE) {
+			const uint32_t kc = (ncmd - k0 < VGX_WAVE) ? ncmd - k0 : VGX_WAVE;
+			const VgxCmdRec* mine = recs + k0 + ((uint32_t)lane < kc ? (uint32_t)lane : kc - 1);
+			const uint4 h = *(const uint4*)mine;               // type, flags, na, arg_off
+			const float2 a01 = *(const float2*)&mine->a[0];   // byte 24
+			const float4 a25 = *(const float4*)&mine->a[2];   // byte 32
+			// wait for the records HERE: left to the first v_readlane, the wait sits inside the command loop, where it also
+			// waits for the vertex stores of the previous command (vmcnt counts loads and stores in order)
+			asm volatile("" :: "v"(h.x), "v"(h.y), "v"(h.z), "v"(h.w), "v"(a01.x), "v"(a01.y), "v"(a25.x), "v"(a25.y), "v"(a25.z), "v"(a25.w));
+			// The broadcasts stay OUTSIDE `if (valid)`: every lane has to execute the loads above (a load that is only used
+			// under the condition may be sunk into it, and v_readlane would then read lanes that never loaded).
+			for (uint32_t kk = 0; kk < kc; ++kk) {
+				const uint32_t type = rl_u32(h.x, kk), cflags = rl_u32(h.y, kk), na = rl_u32(h.z, kk), argOff = rl_u32(h.w, kk);
+				const float a0f = rl_f32(a01.x, kk), a1f = rl_f32(a01.y, kk);
+				const float a2f = rl_f32(a25.x, kk), a3f = rl_f32(a25.y, kk), a4f = rl_f32(a25.z, kk), a5f = rl_f32(a25.w, kk);
+				if (valid) {
+					switch (type) {
+					case VGX_CMD_MOVE_TO: L.moveTo(a0f, a1f); break;
+					case VGX_CMD_LINE_TO: L.lineTo(a0f, a1f); break;
+					case VGX_CMD_CUBIC_TO: inst_cubic(L, a0f, a1f, a2f, a3f, a4f, a5f, stack, &s_stack[lane]); break;
+					case VGX_CMD_QUAD_TO: {
+						float c1x, c1y, c2x, c2y;
+						vgx_quad_to_cubic(L.last.x, L.last.y, a0f, a1f, a2f, a3f, &c1x, &c1y, &c2x, &c2y);
+						inst_cubic(L, c1x, c1y, c2x, c2y, a2f, a3f, stack, &s_stack[lane]);
+					} break;
+					case VGX_CMD_CLOSE: L.close(); break;
+					case VGX_CMD_POLYLINE: {
+						const auto pa = as_const(ps.args) + argOff;
+						uint32_t n = na >> 1, i0 = 0;
+						if (L.spN > 0 && n > 0 && v2near(L.last, v2(pa[0], pa[1]))) { i0 = 1; } // path.cpp:691-696
+						for (uint32_t i = i0; i < n; ++i) {
+							const V2 q = v2(pa[2 * i], pa[2 * i + 1]);
+							if (L.spN == 0) { L.first = q; }
+							L.put(q);
+						}
+					} break;
+					default: break; // shapes / arcs only occur in statically serial paths
+					}
+					if (cflags & VGX_CF_LAST_IN_SUB) { L.endSub(srec + k0 + kk); }
+				}
+			}
+		}
+		if (valid) { A.dinfo[d] = L.drawInfo(); }
+	}
+	L.env.flushPartial(L.wp);
+}
+#else
+		if (!valid) { continue; }
+		const vgx_draw* dr = A.draws + d;
+		L.beginDraw(dr->mtx, dr->scale, dr->tess_tol, dr->fill_flags, dr->stroke_flags);
+		VgxSubRec* srec = A.sub_rec + (inst * C + cprefix[pcur]);
+		const auto recs = as_const(ps.cmdrec) + pc0;
+		const uint32_t ncmd = pc1 - pc0;
+		for (uint32_t k = 0; k < ncmd; ++k) {
+			const uint32_t type = recs[k].type, cflags = recs[k].flags;
+			const float a0f = recs[k].a[0], a1f = recs[k].a[1];
+			switch (type) {
+			case VGX_CMD_MOVE_TO: L.moveTo(a0f, a1f); break;
+			case VGX_CMD_LINE_TO: L.lineTo(a0f, a1f); break;
+			case VGX_CMD_CUBIC_TO: inst_cubic(L, a0f, a1f, recs[k].a[2], recs[k].a[3], recs[k].a[4], recs[k].a[5], stack, &s_stack[lane]); break;
+			case VGX_CMD_QUAD_TO: {
+				float c1x, c1y, c2x, c2y;
+				const float ex = recs[k].a[2], ey = recs[k].a[3];
+				vgx_quad_to_cubic(L.last.x, L.last.y, a0f, a1f, ex, ey, &c1x, &c1y, &c2x, &c2y);
+				inst_cubic(L, c1x, c1y, c2x, c2y, ex, ey, stack, &s_stack[lane]);
+			} break;
+			case VGX_CMD_CLOSE: L.close(); break;
+			case VGX_CMD_POLYLINE: {
+				const auto pa = as_const(ps.args) + recs[k].arg_off;
+				uint32_t n = recs[k].na >> 1, i0 = 0;
+				if (L.spN > 0 && n > 0 && v2near(L.last, v2(pa[0], pa[1]))) { i0 = 1; } // path.cpp:691-696
+				for (uint32_t i = i0; i < n; ++i) {
+					const V2 q = v2(pa[2 * i], pa[2 * i + 1]);
+					if (L.spN == 0) { L.first = q; }
+					L.put(q);
+				}
+			} break;
+			default: break; // shapes / arcs only occur in statically serial paths
+			}
+			if (cflags & VGX_CF_LAST_IN_SUB) { L.endSub(srec + k); }
+		}
+		A.dinfo[d] = L.drawInfo();
+	}
+	L.env.flushPartial(L.wp);
+}
+#endif
+
+// ---- finding the period (vgx_tessellate_count) ----------------------------------------------------------------
+// P = distance to the first repetition of draws[0].path; then every draw is compared with its image in the first
+// period. A drawing that uses one path twice gets a too small candidate and fails the check: command-parallel kernel.
+__global__ __launch_bounds__(256) void k_inst_find(const vgx_draw* draws, uint64_t ndraws, VgxTotals* totals)
+{
+	const uint32_t p0 = draws[0].path;
+	unsigned long long best = ~0ull;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; i < ndraws; i += (uint64_t)gridDim.x * blockDim.x) {
+		if (draws[i].path == p0) { best = i; break; } // a thread's indices ascend
+	}
+	if (best != ~0ull) { atomicMax(&totals->inst_detect_inv, ~0ull - best); } // totals are zeroed: keep the minimum as a maximum
+}
+
+__global__ __launch_bounds__(256) void k_inst_verify(const vgx_draw* draws, uint64_t ndraws, VgxTotals* totals)
+{
+	const unsigned long long inv = totals->inst_detect_inv;
+	const unsigned long long P = ~0ull - inv;
+	if (inv == 0 || ndraws % P != 0) {
+		if (blockIdx.x == 0 && threadIdx.x == 0) { totals->inst_detect_bad = 1u; }
+		return;
+	}
+	bool bad = false;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ndraws; i += (uint64_t)gridDim.x * blockDim.x) {
+		bad = bad || (draws[i].path != draws[i % P].path);
+	}
+	if (bad) { totals->inst_detect_bad = 1u; }
+}
+
+} // namespace
+
+void vgx_launch_flatten_inst(const VgxFlattenArgs& a, int waves, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_flatten_inst, dim3(waves), dim3(VGX_WAVE), 0, s, a);
+}
+
+void vgx_launch_inst_detect(const vgx_draw* draws, uint64_t ndraws, VgxTotals* totals, hipStream_t s)
+{
+	if (ndraws < 2) { return; }
+	hipLaunchKernelGGL(k_inst_find, dim3(512), dim3(256), 0, s, draws, ndraws, totals);
+	hipLaunchKernelGGL(k_inst_verify, dim3(512), dim3(256), 0, s, draws, ndraws, totals);
+}

@@ -32,6 +32,11 @@ struct VgxFlattenArgs
 	uint32_t* serial_list;         // BUILD mode: draws for k_flatten_serial (static serial paths + degenerate draws), unordered
 	float* leaf_overflow;          // [VGX_BUILD_WAVES][VGX_BUILD_OVERFLOW][64][2] leaves that did not fit the LDS slots
 	int pool_walk;                 // k_flatten_build: pooled cubic walk (vgx_walk.h) instead of one cubic per lane
+	// instanced batches (vgx_inst.hip): draws[i].path == draws[i % inst_period].path; 0 = not instanced. When set and the
+	// device-side check of this call agrees, k_flatten_inst builds the batch and k_flatten_build exits at once.
+	uint32_t inst_period;
+	uint32_t inst_block;           // vertices per lane-private heap block
+	int inst_waves;                // grid of k_flatten_inst
 };
 
 struct VgxStrokeArgs
@@ -113,6 +118,8 @@ void vgx_launch_concave_emit(const VgxConcaveArgs& a, hipStream_t s);
 // launchers (defined in the .hip files)
 void vgx_launch_flatten(bool emit, const VgxFlattenArgs& a, int numBlocks, hipStream_t s);
 void vgx_launch_flatten_build(const VgxFlattenArgs& a, int waves, hipStream_t s, bool serialCount = true);   // single-pass: subdivide once, polyline -> heap
+void vgx_launch_flatten_inst(const VgxFlattenArgs& a, int waves, hipStream_t s);  // instanced batches: one lane per instance (vgx_inst.hip)
+void vgx_launch_inst_detect(const vgx_draw* draws, uint64_t ndraws, VgxTotals* totals, hipStream_t s); // count pass: period of the path sequence
 // frame-sized batches (vgx_flatten.hip): one-workgroup kernels instead of chains of dependent launches; the operators are
 // the OpCmdPrefix / OpDrawInfo / OpMeshAll of vgx_scan_ops.h, passed type-erased (the header is device code)
 #define VGX_SMALL_DRAWS 2048

@@ -113,6 +113,11 @@ struct VgxTotals
 	unsigned long long poly_heap_cursor; // BUILD mode: bump allocator of the polyline heap (vertices)
 	unsigned long long long_subpath_vertices; // count pass: vertices in sub-paths longer than VGX_LONG_SUBPATH (heap sizing)
 	unsigned long long num_serial_list;  // BUILD mode: entries of serial_list (draws k_flatten_serial has to redo)
+	// instanced batches (vgx_inst.hip)
+	unsigned long long inst_long_subpath_vertices; // count pass: vertices in sub-paths longer than VGX_INST_LONG_SUBPATH (heap sizing)
+	unsigned long long inst_detect_inv;  // vgx_tessellate_count: ~0 - (index of the first repetition of draws[0].path); 0 = none
+	uint32_t inst_detect_bad;            // vgx_tessellate_count: some draw differs from its image in the first period
+	uint32_t inst_mismatch;              // vgx_tessellate: the draws no longer repeat with the context's period -> k_flatten_build does the batch
 	// diagnostics of the first failure inside the fused kernel (vgx_get_failure_info)
 	uint32_t fail_reason;  // VGX_FAIL_*
 	uint32_t fail_aux;

@@ -24,12 +24,14 @@ struct OpCmdPrefix // command instances per draw -> cmd_prefix
 	uint64_t* prefix;
 	VgxTotals* totals;
 	uint64_t cap;
+	uint32_t period; // instanced batch (vgx_inst.hip): the context expects draws[i].path == draws[i % period].path; 0 = no check
 	__device__ uint64_t size() const { return ndraws; }
 	__device__ Sum3 load(uint64_t i) const
 	{
 		Sum3 r = sum3_zero();
 		const vgx_draw* d = draws + i;
 		const uint32_t p = d->path;
+		if (period && draws[i % period].path != p) { totals->inst_mismatch = 1u; } // k_flatten_build does this batch
 		const uint32_t sf = d->stroke_flags;
 		if (p >= npaths || ((sf & VGX_STROKE_ENABLE) && (VGX_STROKE_CAP(sf) > 2u || VGX_STROKE_JOIN(sf) > 2u))) {
 			set_status(totals, VGX_E_INVALID_ARG);

@@ -164,9 +164,11 @@ def random_walk_polylines(n=10000, nseg=1000, seed=5678, width=6.0, cap=capi.CAP
 
 
 # ---- mixed fuzz set used by the parity tests ---------------------------------------------------
-def fuzz_paths(seed, npaths=64, with_shapes=True, degenerate=True):
+def fuzz_paths(seed, npaths=64, with_shapes=True, degenerate=True, with_polylines=None):
     """Random paths exercising every command and the degenerate cases the reference has branches for
     (zero-length segments, coincident control points, closing onto the start point, tiny curves)."""
+    if with_polylines is None:
+        with_polylines = with_shapes
     rs = np.random.RandomState(seed)
     b = PathSetBuilder()
     for p in range(npaths):
@@ -229,7 +231,7 @@ def fuzz_paths(seed, npaths=64, with_shapes=True, degenerate=True):
                 elif t == 6 and with_shapes:
                     b.arc_to(cx + rs.uniform(-1, 1) * scale, cy + rs.uniform(-1, 1) * scale, nx, ny, rs.uniform(0.05, 0.5) * scale)
                     nx, ny = None, None
-                elif t == 7 and with_shapes:
+                elif t == 7 and with_polylines:
                     k = int(rs.randint(1, 6))
                     pts = np.cumsum(rs.uniform(-1, 1, size=(k, 2)) * scale, axis=0) + np.array([cx, cy])
                     if degenerate and rs.uniform() < 0.3:

@@ -26,7 +26,9 @@
 
 namespace {
 
+#ifndef VGX_INST_LDS_LEVELS
 #define VGX_INST_LDS_LEVELS 4
+#endif
 #ifndef VGX_INST_STAGE
 #define VGX_INST_STAGE 8 /* vertices a lane parks in LDS before it writes them as one aligned piece (8: 64 bytes, 4: 32 bytes) */
 #endif
@@ -60,19 +62,13 @@ struct InstEnvDev
 		stage[slot * VGX_WAVE] = make_float2(x, y);
 		if (slot == VGX_INST_STAGE - 1u) {
 			float4* dst = (float4*)(wp - 2 * (VGX_INST_STAGE - 1));
-			const float2 v0 = stage[0], v1 = stage[VGX_WAVE], v2 = stage[2 * VGX_WAVE];
-#if VGX_INST_STAGE == 8
-			const float2 v3 = stage[3 * VGX_WAVE], v4 = stage[4 * VGX_WAVE], v5 = stage[5 * VGX_WAVE], v6 = stage[6 * VGX_WAVE];
-#endif
+			float2 v[VGX_INST_STAGE];
+#pragma unroll
+			for (int i = 0; i < VGX_INST_STAGE - 1; ++i) { v[i] = stage[i * VGX_WAVE]; }
+			v[VGX_INST_STAGE - 1] = make_float2(x, y);
 #ifndef VGX_EXP_INST_NOSTORE
-			dst[0] = make_float4(v0.x, v0.y, v1.x, v1.y);
-#if VGX_INST_STAGE == 8
-			dst[1] = make_float4(v2.x, v2.y, v3.x, v3.y);
-			dst[2] = make_float4(v4.x, v4.y, v5.x, v5.y);
-			dst[3] = make_float4(v6.x, v6.y, x, y);
-#else
-			dst[1] = make_float4(v2.x, v2.y, x, y);
-#endif
+#pragma unroll
+			for (int j = 0; j < VGX_INST_STAGE / 2; ++j) { dst[j] = make_float4(v[2 * j].x, v[2 * j].y, v[2 * j + 1].x, v[2 * j + 1].y); }
 #endif
 		}
 	}
@@ -241,36 +237,31 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_inst(VgxFlattenArgs A)
 	const uint64_t C = cprefix[P];                // commands per instance
 	const uint64_t G = (ninst + VGX_WAVE - 1) / VGX_WAVE;
 	if (C == 0) { return; }
-	// the wave's share of the (instance group, command) axis; a (group, path) task belongs to the wave whose share holds
-	// the path's first command
-	const uint64_t axis = G * C;
-	const uint64_t share = (axis + gridDim.x - 1) / gridDim.x;
-	const uint64_t a0 = (uint64_t)blockIdx.x * share;
-	const uint64_t a1 = (a0 + share < axis) ? a0 + share : axis;
-	if (a0 >= a1) { return; }
-	uint64_t g = a0 / C;
-	uint32_t p;
-	{
-		const uint64_t r = a0 - g * C;
-		uint32_t lo = 0, hi = P; // first path with cprefix[p] >= r
-		while (lo < hi) {
-			const uint32_t mid = (lo + hi) >> 1;
-			if (cprefix[mid] < r) { lo = mid + 1; } else { hi = mid; }
-		}
-		p = lo;
-	}
+	const uint64_t numTasks = G * P; // task t = instance group t / P, path slot t % P
 
 	InstLane L;
 	L.env.poly = A.poly; L.env.cap = A.caps.poly_vertices; L.env.lb = A.inst_block; L.env.cursor = &A.totals->poly_heap_cursor;
 	L.env.status = &A.totals->status; L.env.lane = lane; L.env.stage = &s_stage[lane];
 	L.initLane();
 
+#ifdef VGX_INST_STATIC
+	// contiguous share of the task list per wave (paths differ a lot in cost: the slowest wave decides)
+	const uint64_t share = (numTasks + gridDim.x - 1) / gridDim.x;
+	uint64_t t = (uint64_t)blockIdx.x * share;
+	const uint64_t tEnd = (t + share < numTasks) ? t + share : numTasks;
+	for (; t < tEnd; ++t) {
+#else
+	// Tasks are handed out one at a time through a ticket counter (paths differ a lot in cost; a static share per wave left
+	// the average wave idle for a third of the kernel). The next ticket is requested before the current task is processed.
+	unsigned long long ticket = 0;
+	if (lane == 0) { ticket = atomicAdd(&A.totals->inst_ticket, 1ull); }
 	for (;;) {
-		if (p >= P) { ++g; p = 0; }
-		if (g >= G) { break; }
-		const uint64_t pos = g * C + cprefix[p];
-		if (pos >= a1) { break; }
-		const uint32_t pcur = p++;
+		const uint64_t t = wave_bcast_u64(ticket, 0);
+		if (t >= numTasks) { break; }
+		if (lane == 0) { ticket = atomicAdd(&A.totals->inst_ticket, 1ull); }
+#endif
+		const uint64_t g = t / P;
+		const uint32_t pcur = (uint32_t)(t - g * P);
 		const uint32_t path = as_const(A.draws)[pcur].path; // == draws[i * P + pcur].path for every instance i (verified)
 		const uint32_t pc0 = as_const(ps.path_cmd_begin)[path], pc1 = as_const(ps.path_cmd_begin)[path + 1];
 		if (pc0 == pc1) { continue; } // nothing to build: the draw's (zeroed) record stands
@@ -286,7 +277,6 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_inst(VgxFlattenArgs A)
 			if (valid) { A.serial_list[sbase + (uint64_t)__popcll(sm & lanemask_lt(lane))] = (uint32_t)d; }
 			continue;
 		}
-#ifndef VGX_INST_SCALAR_RECS
 		// The path's command records: lane l fetches record k0 + l (one coalesced read per 64 commands), the command loop
 		// takes record k from lane k - k0 with v_readlane -- no memory latency per command.
 		const VgxCmdRec* recs = ps.cmdrec + pc0;
@@ -340,46 +330,6 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_inst(VgxFlattenArgs A)
 	}
 	L.env.flushPartial(L.wp);
 }
-#else
-		if (!valid) { continue; }
-		const vgx_draw* dr = A.draws + d;
-		L.beginDraw(dr->mtx, dr->scale, dr->tess_tol, dr->fill_flags, dr->stroke_flags);
-		VgxSubRec* srec = A.sub_rec + (inst * C + cprefix[pcur]);
-		const auto recs = as_const(ps.cmdrec) + pc0;
-		const uint32_t ncmd = pc1 - pc0;
-		for (uint32_t k = 0; k < ncmd; ++k) {
-			const uint32_t type = recs[k].type, cflags = recs[k].flags;
-			const float a0f = recs[k].a[0], a1f = recs[k].a[1];
-			switch (type) {
-			case VGX_CMD_MOVE_TO: L.moveTo(a0f, a1f); break;
-			case VGX_CMD_LINE_TO: L.lineTo(a0f, a1f); break;
-			case VGX_CMD_CUBIC_TO: inst_cubic(L, a0f, a1f, recs[k].a[2], recs[k].a[3], recs[k].a[4], recs[k].a[5], stack, &s_stack[lane]); break;
-			case VGX_CMD_QUAD_TO: {
-				float c1x, c1y, c2x, c2y;
-				const float ex = recs[k].a[2], ey = recs[k].a[3];
-				vgx_quad_to_cubic(L.last.x, L.last.y, a0f, a1f, ex, ey, &c1x, &c1y, &c2x, &c2y);
-				inst_cubic(L, c1x, c1y, c2x, c2y, ex, ey, stack, &s_stack[lane]);
-			} break;
-			case VGX_CMD_CLOSE: L.close(); break;
-			case VGX_CMD_POLYLINE: {
-				const auto pa = as_const(ps.args) + recs[k].arg_off;
-				uint32_t n = recs[k].na >> 1, i0 = 0;
-				if (L.spN > 0 && n > 0 && v2near(L.last, v2(pa[0], pa[1]))) { i0 = 1; } // path.cpp:691-696
-				for (uint32_t i = i0; i < n; ++i) {
-					const V2 q = v2(pa[2 * i], pa[2 * i + 1]);
-					if (L.spN == 0) { L.first = q; }
-					L.put(q);
-				}
-			} break;
-			default: break; // shapes / arcs only occur in statically serial paths
-			}
-			if (cflags & VGX_CF_LAST_IN_SUB) { L.endSub(srec + k); }
-		}
-		A.dinfo[d] = L.drawInfo();
-	}
-	L.env.flushPartial(L.wp);
-}
-#endif
 
 // ---- finding the period (vgx_tessellate_count) ----------------------------------------------------------------
 // P = distance to the first repetition of draws[0].path; then every draw is compared with its image in the first

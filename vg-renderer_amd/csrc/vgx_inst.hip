@@ -48,7 +48,10 @@ struct InstEnvDev
 	unsigned long long* cursor;
 	uint32_t* status;
 	int lane;
-	float2* stage; // &s_stage[lane]: the lane's 8 staged vertices, [slot][64 lanes]
+	float2* stage; // s_stage: 8 staged vertices per lane, slot j of lane l at [j][(l + 4 j) mod 64] (the rotation keeps the
+	               // cooperative flush, which reads four slots of sixteen lanes at once, off the same banks)
+	__device__ __forceinline__ float2* slotOf(uint32_t j, uint32_t l) const { return stage + j * VGX_WAVE + ((l + 4u * j) & (VGX_WAVE - 1u)); }
+	__device__ __forceinline__ float2* slot(uint32_t j) const { return slotOf(j, (uint32_t)lane); }
 
 	// Vertex stores. A lane's vertices go to consecutive heap addresses; written one by one, 64 lanes x 8 bytes land in 64
 	// different cache lines per store instruction and every line stays partly written for several commands (measured:
@@ -58,13 +61,17 @@ struct InstEnvDev
 	// slot behind unchanged, so the slots below the write position always hold the current piece's vertices.
 	__device__ __forceinline__ void emit(float* wp, float x, float y)
 	{
+#ifdef VGX_EXP_INST_NOEMIT
+		asm volatile("" :: "v"(x), "v"(y), "v"(wp));
+		return;
+#endif
 		const uint32_t slot = ((uint32_t)(uintptr_t)wp >> 3) & (VGX_INST_STAGE - 1u);
-		stage[slot * VGX_WAVE] = make_float2(x, y);
+		*this->slot(slot) = make_float2(x, y);
 		if (slot == VGX_INST_STAGE - 1u) {
 			float4* dst = (float4*)(wp - 2 * (VGX_INST_STAGE - 1));
 			float2 v[VGX_INST_STAGE];
 #pragma unroll
-			for (int i = 0; i < VGX_INST_STAGE - 1; ++i) { v[i] = stage[i * VGX_WAVE]; }
+			for (int i = 0; i < VGX_INST_STAGE - 1; ++i) { v[i] = *this->slot((uint32_t)i); }
 			v[VGX_INST_STAGE - 1] = make_float2(x, y);
 #ifndef VGX_EXP_INST_NOSTORE
 #pragma unroll
@@ -72,13 +79,42 @@ struct InstEnvDev
 #endif
 		}
 	}
+	// emit() of the lock-step walk (all lanes of `act` arrive together). When the whole wave fills its last slot in the
+	// same step -- instances of one scale, whose write positions advance together -- the pieces leave TRANSPOSED: store i
+	// covers the lanes' pieces 16 i .. 16 i + 15, four lanes per 64-byte piece, so that a store instruction presents 16
+	// whole pieces to the memory pipeline instead of 64 quarter pieces. The owner lane's address comes through a shuffle.
+	__device__ __forceinline__ void emitLockstep(float* wp, float x, float y, uint64_t act)
+	{
+#if VGX_INST_STAGE == 8 && !defined(VGX_INST_NO_COOP_FLUSH) && !defined(VGX_EXP_INST_NOEMIT)
+		const uint32_t slotIdx = ((uint32_t)(uintptr_t)wp >> 3) & 7u;
+		if (act == ~0ull && __ballot(slotIdx == 7u) == ~0ull) {
+			*this->slot(7u) = make_float2(x, y);
+			const uint64_t piece = (uint64_t)(uintptr_t)(wp - 14);
+			const uint32_t q = (uint32_t)lane & 3u;
+#pragma unroll
+			for (uint32_t i = 0; i < 4; ++i) {
+				const uint32_t s = 16u * i + ((uint32_t)lane >> 2);
+				const float2 a = *slotOf(2u * q, s), b = *slotOf(2u * q + 1u, s);
+				const uint64_t dst = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)piece, (int)s) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(piece >> 32), (int)s) << 32)) + 16u * q;
+#ifndef VGX_EXP_INST_NOSTORE
+				typedef float f4v __attribute__((ext_vector_type(4)));
+				f4v v; v.x = a.x; v.y = a.y; v.z = b.x; v.w = b.y;
+				*(__attribute__((address_space(1))) f4v*)dst = v; // a shuffled address is an integer: global space, explicitly
+#endif
+			}
+			return;
+		}
+#endif
+		(void)act;
+		emit(wp, x, y);
+	}
 	// the staged part of the current piece (slots below the write position) goes to the heap: before a sub-path is
 	// moved (its tail is read back from the heap) and when the wave is done
 	__device__ __forceinline__ void flushPartial(float* wp)
 	{
 		const uint32_t n = ((uint32_t)(uintptr_t)wp >> 3) & (VGX_INST_STAGE - 1u);
 		float2* dst = (float2*)(wp - 2 * n);
-		for (uint32_t i = 0; i < n; ++i) { dst[i] = stage[i * VGX_WAVE]; }
+		for (uint32_t i = 0; i < n; ++i) { dst[i] = *slot(i); }
 	}
 	// The write position went BACK from wpOld to wpNew (a cubic is redone): if that left the piece wpOld was in, the slots
 	// have been reused by later pieces; the piece wpNew is in was written out completely meanwhile, so its vertices below
@@ -89,7 +125,7 @@ struct InstEnvDev
 		__threadfence_block();
 		const uint32_t n = ((uint32_t)(uintptr_t)wpNew >> 3) & (VGX_INST_STAGE - 1u);
 		const float2* src = (const float2*)(wpNew - 2 * n);
-		for (uint32_t i = 0; i < n; ++i) { stage[i * VGX_WAVE] = src[i]; }
+		for (uint32_t i = 0; i < n; ++i) { *slot(i) = src[i]; }
 	}
 	__device__ __forceinline__ void flushForMove(float* wp)
 	{
@@ -123,9 +159,89 @@ struct InstEnvDev
 
 typedef InstCore<InstEnvDev> InstLane;
 
+// -DVGX_INST_PROFILE: wave clock (100 MHz) summed over all waves per phase of k_flatten_inst, read back through
+// vgx_get_failure_info().prof: 0 task prologue, 1 cubic walks, 2 command loops (cubic walks included), 3 whole waves,
+// 4 tasks, 5 cubics
+#ifdef VGX_INST_PROFILE
+#define IPROF_T(var) const uint64_t var = wall_clock64()
+#define IPROF_ACC(acc, t0, t1) acc += (t1) - (t0)
+#else
+#define IPROF_T(var) do {} while (0)
+#define IPROF_ACC(acc, t0, t1) do {} while (0)
+#endif
+
 // value of lane `l` (wave-uniform l): v_readlane_b32, whatever the exec mask
 __device__ __forceinline__ uint32_t rl_u32(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ float rl_f32(float v, uint32_t l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)l)); }
+
+// Lock-step walk. The lanes of a wave hold the same cubic, and as long as they also take the same decisions (instances of
+// one scale: always) the walk needs no per-lane control flow: one ballot per node, wave-uniform (scalar) branches, the
+// pending count and the stack position in scalar registers, no midpoints on leaf nodes. Returns true when the cubic was
+// finished that way. On the first node where the lanes disagree -- and on anything rare: a vertex inside the epsilon
+// ball, a full heap block, more than LV pending halves -- it returns false: the caller takes the lane back to the state
+// before the cubic and walks it with the per-lane loop (keeping the two loops' variables apart is what keeps this one
+// free of register copies; a hand-over in the middle of the cubic cost ~25 v_mov per node).
+template<int LV>
+__device__ __forceinline__ bool inst_cubic_lockstep(InstLane& L, v2f P2, v2f P3, v2f P4, float2* stackLane)
+{
+	v2f P1;
+	P1.x = L.last.x; P1.y = L.last.y;
+	v2f prev = P1;
+	const float tessTol = L.tessTol;
+	int pendU = 0;
+	uint32_t spU = 0;
+	const uint64_t act = __ballot(1);
+	// One latch, one exit, two wave-uniform `if`s that update the node in place: with early returns / continues the
+	// compiler turned the loop into a state machine that copied every loop variable twice per node (~25 v_mov).
+	bool cont, ok;
+	do {
+		const v2f d = P4 - P1;
+		const v2f a2 = P2 - P4, a3 = P3 - P4;
+		const v2f dsw = d.yx;
+		const v2f m2 = a2 * dsw, m3 = a3 * dsw;
+		const float d2 = __builtin_fabsf(m2.x - m2.y), d3 = __builtin_fabsf(m3.x - m3.y);
+		const float d23 = d2 + d3;
+		const v2f dd = d * d;
+		const bool flat = d23 * d23 <= tessTol * (dd.x + dd.y);
+		const v2f e = prev - P4; // pathAddVertex: lastVertex - (x, y)
+		const v2f ee = e * e;
+		const uint64_t fm = __ballot(flat);
+		const uint64_t rare = __ballot((ee.x + ee.y < VGM_EPSILON) || L.room == 0);
+		const bool desc = fm == 0 && pendU < LV;        // every lane descends into the left half
+		const bool leaf = fm == act && rare == 0;       // every lane has a flat piece and stores its end point
+		const bool pop = leaf && pendU > 0;
+		if (desc) {
+			const v2f P12 = (P1 + P2) * 0.5f, P23 = (P2 + P3) * 0.5f, P34 = (P3 + P4) * 0.5f;
+			const v2f P123 = (P12 + P23) * 0.5f, P234 = (P23 + P34) * 0.5f;
+			const v2f P1234 = (P123 + P234) * 0.5f;
+			stackLane[spU] = make_float2(P234.x, P234.y);
+			stackLane[spU + VGX_WAVE] = make_float2(P34.x, P34.y);
+			stackLane[spU + 2 * VGX_WAVE] = make_float2(P4.x, P4.y);
+			spU += 3 * VGX_WAVE;
+			++pendU;
+			P2 = P12; P3 = P123; P4 = P1234;
+		}
+		if (leaf) {
+			L.env.emitLockstep(L.wp, L.m0 * P4.x + L.m2 * P4.y + L.m4, L.m1 * P4.x + L.m3 * P4.y + L.m5, act); // transformPos2D, vg_util.h:24-28
+			L.wp += 2;
+			--L.room;
+			++L.spN;
+			prev = P4;
+			P1 = P4;
+			if (pop) {
+				spU -= 3 * VGX_WAVE;
+				--pendU;
+				const float2 q2 = stackLane[spU], q3 = stackLane[spU + VGX_WAVE], q4 = stackLane[spU + 2 * VGX_WAVE];
+				P2.x = q2.x; P2.y = q2.y; P3.x = q3.x; P3.y = q3.y; P4.x = q4.x; P4.y = q4.y;
+			}
+		}
+		cont = desc || pop;
+		ok = desc || leaf;
+	} while (cont);
+	if (!ok) { return false; }
+	L.last = v2(prev.x, prev.y);
+	return true;
+}
 
 // pathCubicTo for one lane of the instanced kernel: the hand-shaped walk of build_flatten_hot (vgx_walk.h: packed float
 // pairs, single exit, pending right halves in LDS as [level][3][64] float2) with pathAddVertex inlined at the leaves --
@@ -194,6 +310,20 @@ __device__ __forceinline__ bool inst_cubic_hot(InstLane& L, v2f P2, v2f P3, v2f 
 	return !aborted;
 }
 
+// Back to the state before the cubic: the write position follows the vertex count (a block switch that happened
+// meanwhile stays), the staged piece is re-primed (InstEnvDev::rewind); vertices already written are simply overwritten.
+__device__ __forceinline__ void inst_cubic_back(InstLane& L, uint32_t n0, V2 last0)
+{
+	const uint32_t back = L.spN - n0;
+	if (back != 0 && !L.dead) {
+		float* const now = L.wp;
+		L.wp -= 2 * (uint64_t)back; L.room += back;
+		L.env.rewind(L.wp, now);
+	}
+	L.spN = n0;
+	L.last = last0;
+}
+
 // stackLane = &s_stack[lane], handed down from the kernel as an expression on the __shared__ array (NOT through stack.base:
 // `stack` lives in private memory because of its deep[] levels, and a pointer loaded from there is a flat pointer -- the
 // hot loop's pushes and pops would become flat_store / flat_load instead of ds_write / ds_read).
@@ -203,17 +333,13 @@ __device__ __forceinline__ void inst_cubic(InstLane& L, float c1x, float c1y, fl
 	const V2 last0 = L.last;
 	v2f P2, P3, P4;
 	P2.x = c1x; P2.y = c1y; P3.x = c2x; P3.y = c2y; P4.x = x; P4.y = y;
+#ifndef VGX_INST_NO_LOCKSTEP
+	if (inst_cubic_lockstep<VGX_INST_LDS_LEVELS>(L, P2, P3, P4, stackLane)) { return; }
+	inst_cubic_back(L, n0, last0);
+#endif
 	if (!inst_cubic_hot<VGX_INST_LDS_LEVELS>(L, P2, P3, P4, stackLane)) {
-		// deeper than the LDS levels: back to the state before the cubic (the write position follows the vertex count; a
-		// block switch that happened meanwhile stays), then the full-depth walk
-		const uint32_t back = L.spN - n0;
-		if (!L.dead) {
-			float* const now = L.wp;
-			L.wp -= 2 * (uint64_t)back; L.room += back;
-			L.env.rewind(L.wp, now);
-		}
-		L.spN = n0;
-		L.last = last0;
+		// deeper than the LDS levels: the full-depth walk from the cubic's root
+		inst_cubic_back(L, n0, last0);
 		L.cubicTo(c1x, c1y, c2x, c2y, x, y, stack);
 	}
 }
@@ -239,9 +365,12 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_inst(VgxFlattenArgs A)
 	if (C == 0) { return; }
 	const uint64_t numTasks = G * P; // task t = instance group t / P, path slot t % P
 
+	uint64_t profPro = 0, profCubic = 0, profLoop = 0, profTasks = 0, profCubics = 0;
+	(void)profPro; (void)profCubic; (void)profLoop; (void)profTasks; (void)profCubics;
+	IPROF_T(tWave0);
 	InstLane L;
 	L.env.poly = A.poly; L.env.cap = A.caps.poly_vertices; L.env.lb = A.inst_block; L.env.cursor = &A.totals->poly_heap_cursor;
-	L.env.status = &A.totals->status; L.env.lane = lane; L.env.stage = &s_stage[lane];
+	L.env.status = &A.totals->status; L.env.lane = lane; L.env.stage = s_stage;
 	L.initLane();
 
 #ifdef VGX_INST_STATIC
@@ -251,15 +380,28 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_inst(VgxFlattenArgs A)
 	const uint64_t tEnd = (t + share < numTasks) ? t + share : numTasks;
 	for (; t < tEnd; ++t) {
 #else
-	// Tasks are handed out one at a time through a ticket counter (paths differ a lot in cost; a static share per wave left
-	// the average wave idle for a third of the kernel). The next ticket is requested before the current task is processed.
+	// Tasks are handed out one at a time through ticket counters (paths differ a lot in cost; a static share per wave left
+	// the average wave idle for a third of the kernel). ONE counter does not keep up: 41 776 device-scope atomics on one
+	// address take 0.5 ms (measured with the command loop compiled out), half of the kernel. So the task list is cut
+	// into VGX_INST_POOLS contiguous pools with a counter each (128 bytes apart); a wave starts in pool blockIdx mod
+	// POOLS and moves on to the next pool when its pool is empty. The next ticket is requested before the current task
+	// is processed.
+	const uint64_t poolTasks = (numTasks + VGX_INST_POOLS - 1) / VGX_INST_POOLS;
+	uint32_t pool = blockIdx.x % VGX_INST_POOLS, poolsLeft = VGX_INST_POOLS;
 	unsigned long long ticket = 0;
-	if (lane == 0) { ticket = atomicAdd(&A.totals->inst_ticket, 1ull); }
+	if (lane == 0) { ticket = atomicAdd(&A.totals->inst_ticket[pool * 16], 1ull); }
 	for (;;) {
-		const uint64_t t = wave_bcast_u64(ticket, 0);
-		if (t >= numTasks) { break; }
-		if (lane == 0) { ticket = atomicAdd(&A.totals->inst_ticket, 1ull); }
+		const uint64_t tl = wave_bcast_u64(ticket, 0);
+		const uint64_t t = (uint64_t)pool * poolTasks + tl;
+		if (tl >= poolTasks || t >= numTasks) { // this pool is empty: try the next one
+			if (--poolsLeft == 0) { break; }
+			pool = (pool + 1) % VGX_INST_POOLS;
+			if (lane == 0) { ticket = atomicAdd(&A.totals->inst_ticket[pool * 16], 1ull); }
+			continue;
+		}
+		if (lane == 0) { ticket = atomicAdd(&A.totals->inst_ticket[pool * 16], 1ull); }
 #endif
+		IPROF_T(tTask0);
 		const uint64_t g = t / P;
 		const uint32_t pcur = (uint32_t)(t - g * P);
 		const uint32_t path = as_const(A.draws)[pcur].path; // == draws[i * P + pcur].path for every instance i (verified)
@@ -284,6 +426,15 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_inst(VgxFlattenArgs A)
 		const vgx_draw* dr = A.draws + d;
 		VgxSubRec* srec = A.sub_rec + (inst * C + cprefix[pcur]);
 		if (valid) { L.beginDraw(dr->mtx, dr->scale, dr->tess_tol, dr->fill_flags, dr->stroke_flags); }
+#ifdef VGX_EXP_INST_FLAT
+		L.tessTol = 3.0e38f; // experiment: every cubic is one segment
+#endif
+#ifdef VGX_INST_PROFILE
+		asm volatile("" :: "v"(L.m0), "v"(L.m5), "v"(L.tessTol)); // the draw record has arrived
+#endif
+		IPROF_T(tLoop0);
+		IPROF_ACC(profPro, tTask0, tLoop0);
+		++profTasks;
 		for (uint32_t k0 = 0; k0 < ncmd; k0 += VGX_WAVE) {
 			const uint32_t kc = (ncmd - k0 < VGX_WAVE) ? ncmd - k0 : VGX_WAVE;
 			const VgxCmdRec* mine = recs + k0 + ((uint32_t)lane < kc ? (uint32_t)lane : kc - 1);
@@ -299,11 +450,24 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_inst(VgxFlattenArgs A)
 				const uint32_t type = rl_u32(h.x, kk), cflags = rl_u32(h.y, kk), na = rl_u32(h.z, kk), argOff = rl_u32(h.w, kk);
 				const float a0f = rl_f32(a01.x, kk), a1f = rl_f32(a01.y, kk);
 				const float a2f = rl_f32(a25.x, kk), a3f = rl_f32(a25.y, kk), a4f = rl_f32(a25.z, kk), a5f = rl_f32(a25.w, kk);
+#ifdef VGX_EXP_INST_NOCMD
+				asm volatile("" :: "s"(type), "s"(cflags), "s"(na), "s"(argOff), "s"(a0f), "s"(a1f), "s"(a2f), "s"(a3f), "s"(a4f), "s"(a5f));
+				continue;
+#endif
 				if (valid) {
 					switch (type) {
 					case VGX_CMD_MOVE_TO: L.moveTo(a0f, a1f); break;
 					case VGX_CMD_LINE_TO: L.lineTo(a0f, a1f); break;
-					case VGX_CMD_CUBIC_TO: inst_cubic(L, a0f, a1f, a2f, a3f, a4f, a5f, stack, &s_stack[lane]); break;
+					case VGX_CMD_CUBIC_TO: {
+#ifdef VGX_EXP_INST_NOCUBIC
+						break;
+#endif
+						IPROF_T(tc0);
+						inst_cubic(L, a0f, a1f, a2f, a3f, a4f, a5f, stack, &s_stack[lane]);
+						IPROF_T(tc1);
+						IPROF_ACC(profCubic, tc0, tc1);
+						++profCubics;
+					} break;
 					case VGX_CMD_QUAD_TO: {
 						float c1x, c1y, c2x, c2y;
 						vgx_quad_to_cubic(L.last.x, L.last.y, a0f, a1f, a2f, a3f, &c1x, &c1y, &c2x, &c2y);
@@ -322,13 +486,27 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_inst(VgxFlattenArgs A)
 					} break;
 					default: break; // shapes / arcs only occur in statically serial paths
 					}
+#ifndef VGX_EXP_INST_NOSUB
 					if (cflags & VGX_CF_LAST_IN_SUB) { L.endSub(srec + k0 + kk); }
+#endif
 				}
 			}
 		}
 		if (valid) { A.dinfo[d] = L.drawInfo(); }
+		IPROF_T(tLoop1);
+		IPROF_ACC(profLoop, tLoop0, tLoop1);
 	}
 	L.env.flushPartial(L.wp);
+#ifdef VGX_INST_PROFILE
+	{
+		const uint64_t tWave1 = wall_clock64();
+		if (lane == 0) {
+			atomicAdd(&A.totals->prof[0], (unsigned long long)profPro); atomicAdd(&A.totals->prof[1], (unsigned long long)profCubic);
+			atomicAdd(&A.totals->prof[2], (unsigned long long)profLoop); atomicAdd(&A.totals->prof[3], (unsigned long long)(tWave1 - tWave0));
+			atomicAdd(&A.totals->prof[4], (unsigned long long)profTasks); atomicAdd(&A.totals->prof[5], (unsigned long long)profCubics);
+		}
+	}
+#endif
 }
 
 // ---- finding the period (vgx_tessellate_count) ----------------------------------------------------------------

@@ -104,6 +104,7 @@ struct VgxSegSub
 	uint32_t sub_index; // sub-path index within its draw (vgx_mesh.subpath_kind)
 };
 
+#define VGX_INST_POOLS 16
 // ---- batch totals kept in device memory (mirrors vgx_sizes + internal counters) -------------------
 struct VgxTotals
 {
@@ -116,7 +117,7 @@ struct VgxTotals
 	// instanced batches (vgx_inst.hip)
 	unsigned long long inst_long_subpath_vertices; // count pass: vertices in sub-paths longer than VGX_INST_LONG_SUBPATH (heap sizing)
 	unsigned long long inst_detect_inv;  // vgx_tessellate_count: ~0 - (index of the first repetition of draws[0].path); 0 = none
-	unsigned long long inst_ticket;      // vgx_tessellate: next (instance group, path) task of k_flatten_inst
+	unsigned long long inst_ticket[VGX_INST_POOLS * 16]; // vgx_tessellate: next task of every task pool of k_flatten_inst, one counter per 128 bytes
 	uint32_t inst_detect_bad;            // vgx_tessellate_count: some draw differs from its image in the first period
 	uint32_t inst_mismatch;              // vgx_tessellate: the draws no longer repeat with the context's period -> k_flatten_build does the batch
 	// diagnostics of the first failure inside the fused kernel (vgx_get_failure_info)

@@ -1,0 +1,42 @@
+"""GPU soak of the instanced flatten kernel (not collected by pytest): N fuzz drawings x 33..96 instances with per-instance
+scale / tolerance / flags through vgx_tessellate against the reference oracle, on a default context and on one with
+8-vertex lane blocks and 7 waves (the knobs are read at vgx_create). `python tests/soak_gpu_inst.py 300`."""
+import importlib, sys, os, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+import pyoracle
+from util import assert_mesh_equal
+from test_gpu_inst import _instances
+rt = importlib.import_module("vg-renderer_amd.runtime"); wl = importlib.import_module("vg-renderer_amd.workloads")
+ctx_default = rt.Context(0)
+os.environ["VGX_INST_BLOCK"] = "8"; os.environ["VGX_INST_WAVES"] = "7"
+ctx_small = rt.Context(0)
+os.environ.pop("VGX_INST_BLOCK"); os.environ.pop("VGX_INST_WAVES")
+bad = 0
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+for seed in range(5000, 5000 + n):
+    rs = np.random.RandomState(seed)
+    npaths = int(rs.randint(8, 48))
+    ps = wl.fuzz_paths(seed, npaths=npaths, with_shapes=bool(seed % 2), with_polylines=True)
+    ninst = int(rs.randint(33, 97))
+    while ninst * npaths <= 2048:
+        ninst += 17
+    d = _instances(wl, ps, seed, ninst, vary=bool(seed % 5))
+    ctx = ctx_small if seed % 3 == 0 else ctx_default
+    ref = pyoracle.tessellate(ps, d)
+    pset = rt.PathSet(ctx, ps); dd = rt.upload_draws(d)
+    sizes = rt.tessellate_count(ctx, pset, dd, d.shape[0])
+    bufs = rt.MeshBuffers(dd.device, sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"])
+    rt.tessellate_async(ctx, pset, dd, d.shape[0], bufs); torch.cuda.synchronize()
+    class G: pass
+    g = G(); g.sizes = sizes
+    nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
+    g.pos = bufs.pos[:nv].cpu().numpy(); g.color = bufs.color[:nv].cpu().numpy().view(np.uint32)
+    g.idx = bufs.idx[:ni].cpu().numpy().view(np.uint16); g.meshes = bufs.meshes[:nm * 32].cpu().numpy().view(rt.capi.mesh_dtype)
+    try:
+        assert int(bufs.dev_status.item()) == 0
+        assert_mesh_equal(g, ref, "inst soak %d" % seed)
+    except AssertionError as e:
+        bad += 1; print("MISMATCH seed", seed, npaths, ninst, str(e)[:200])
+    pset.close()
+print("instanced soak done: %d seeds, mismatches: %d" % (n, bad))

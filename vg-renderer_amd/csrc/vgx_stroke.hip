@@ -283,21 +283,25 @@ __global__ __launch_bounds__(VGX_WAVE) VGX_FILL_OCC void k_fill(VgxStrokeArgs A)
 		// (1) owner search + vertex request of every chunk of the run
 		FillRunState R;
 		float2 v[VGX_FILL_RUN];
-		const float2* src[VGX_FILL_RUN];
+		// heap INDEX of every chunk's vertex, not a pointer: the selected pointers lost their address space on the way
+		// through the unrolled loop and the eight vertex loads of a run became flat_load (which also counts on lgkmcnt,
+		// so every LDS wait of the emit phase waited for the heap as well)
+		uint64_t src[VGX_FILL_RUN];
+		const float2* const heap = (const float2*)A.poly;
 #pragma unroll
 		for (int i = 0; i < VGX_FILL_RUN; ++i) {
-			R.k[i] = 0; R.j[i] = 0xFFFFFFFFu; v[i] = make_float2(0.0f, 0.0f); src[i] = (const float2*)A.poly;
+			R.k[i] = 0; R.j[i] = 0xFFFFFFFFu; v[i] = make_float2(0.0f, 0.0f); src[i] = 0;
 			if (i < n) { // wave-uniform
 				fill_owner(W, run0 + (uint64_t)i * VGX_WAVE, elemEnd, lane, &R.k[i], &R.j[i]);
 				const uint64_t polyFirst = W.rec[R.k[i]].polyFirst;
-				if (R.j[i] != 0xFFFFFFFFu) { src[i] = (const float2*)(A.poly + 2 * (polyFirst + R.j[i])); }
+				if (R.j[i] != 0xFFFFFFFFu) { src[i] = polyFirst + R.j[i]; }
 			}
 		}
 		// all vertex loads of the run back to back (every lane loads: lanes without an element re-read the heap's first vertex)
 		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 		for (int i = 0; i < VGX_FILL_RUN; ++i) {
-			if (i < n) { v[i] = *src[i]; }
+			if (i < n) { v[i] = heap[src[i]]; }
 		}
 		__builtin_amdgcn_sched_barrier(0);
 		// the four vertices just outside the run, lanes 0..3: {in front of the run, first mesh's vertex 0, behind the run,

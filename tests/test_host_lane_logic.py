@@ -84,6 +84,12 @@ def test_instanced_lane_matches_oracle(hostlib, vgr, wl, oracle, seed, lb):
             f = int(rec["first"][k])
             a = int(sub["first_vertex"])
             assert np.array_equal(heap[f:f + cntv].view(np.uint32), ref.poly[a:a + cntv].view(np.uint32)), (seed, i, j)
+            if cntv >= 3:  # orientation code of the first triangle (VGX_ORIENT_*): what vgx_write_mesh would compute from the heap
+                q = ref.poly[a:a + 3]
+                ax, ay, bx, by = q[1, 0] - q[0, 0], q[1, 1] - q[0, 1], q[2, 0] - q[0, 0], q[2, 1] - q[0, 1]
+                orient = np.float32(ax * by) - np.float32(bx * ay)
+                want = 1 | (2 if orient > 0 else 0) | (4 if orient < 0 else 0)
+                assert int(rec["pad"][k]) == want, (seed, i, j)
     assert heap[cap, 0] == 7777.0
 
 

@@ -715,7 +715,7 @@ __device__ __forceinline__ void flatten_gather_body(const VgxFlattenArgs& A, uin
 			const bool closed = (info >> 31) != 0;
 			const uint64_t first = sr.first;
 			if ((fillFlags & VGX_FILL_ENABLE) && n >= 3) {
-				vgx_write_mesh(A.mdesc, A.mtab, di.first_mesh + f, dr, (uint32_t)d, subIndex, (fillFlags & VGX_FILL_AA) ? VGX_MESH_FILL_AA : VGX_MESH_FILL, closed, first, n, A.mprep, A.poly);
+				vgx_write_mesh(A.mdesc, A.mtab, di.first_mesh + f, dr, (uint32_t)d, subIndex, (fillFlags & VGX_FILL_AA) ? VGX_MESH_FILL_AA : VGX_MESH_FILL, closed, first, n, A.mprep, A.poly, sr.pad);
 				++f;
 			}
 			if ((strokeFlags & VGX_STROKE_ENABLE) && n >= 2) {

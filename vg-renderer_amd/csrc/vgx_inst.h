@@ -50,6 +50,7 @@ struct InstCore
 	bool spClosed;
 	bool dead;        // the heap is exhausted (grow): the write position no longer follows the vertex count
 	V2 first, last;   // untransformed first / last vertex of the current sub-path
+	V2 q0, q1, q2;    // TRANSFORMED first three vertices of the current sub-path (fill orientation, endSub)
 	// per-draw counters
 	uint32_t nverts, nsubs, nfill, nstroke;
 	uint64_t drawFirst;
@@ -57,7 +58,7 @@ struct InstCore
 	VGX_HDM void initLane()
 	{
 		wp = env.poly; room = 0; spFirst = 0; spN = 0; spClosed = false; dead = false;
-		first = v2(0.0f, 0.0f); last = first;
+		first = v2(0.0f, 0.0f); last = first; q0 = first; q1 = first; q2 = first;
 		nverts = 0; nsubs = 0; nfill = 0; nstroke = 0; drawFirst = 0;
 	}
 	VGX_HDM void beginDraw(const float* mtx, float scale, float tol, uint32_t ff, uint32_t sf)
@@ -98,10 +99,17 @@ struct InstCore
 	}
 	// pathAllocVertices(1) + write (path.cpp:748-759, 779-783), with transformPath's arithmetic applied on the way out
 	// (vg_util.h:24-28: (m0 * x + m2 * y) + m4)
+	// vertex number spN of the sub-path is (ox, oy): the first three are kept for the orientation test of the fill mesh
+	VGX_HDM void note(float ox, float oy)
+	{
+		if (spN == 0) { q0 = v2(ox, oy); } else if (spN == 1) { q1 = v2(ox, oy); } else if (spN == 2) { q2 = v2(ox, oy); }
+	}
 	VGX_HDM void put(V2 p)
 	{
 		if (room == 0) { grow(); }
-		env.emit(wp, m0 * p.x + m2 * p.y + m4, m1 * p.x + m3 * p.y + m5);
+		const float ox = m0 * p.x + m2 * p.y + m4, oy = m1 * p.x + m3 * p.y + m5;
+		if (spN < 3) { note(ox, oy); }
+		env.emit(wp, ox, oy);
 		wp += 2;
 		--room;
 		++spN;
@@ -160,7 +168,11 @@ struct InstCore
 	VGX_HDM void endSub(VgxSubRec* rec)
 	{
 		VgxSubRec sr;
-		sr.first = spFirst; sr.info = spN | (spClosed ? 0x80000000u : 0u); sr.pad = 0;
+		sr.first = spFirst; sr.info = spN | (spClosed ? 0x80000000u : 0u);
+		// sign of the first triangle, evaluated as mesh_prep / vgx_write_mesh do (stroker.cpp:721-723): k_flatten_gather then
+		// does not have to fetch three vertices per fill mesh from the heap (0.11 of its 0.48 ms)
+		const float orient = v2cross(v2sub(q1, q0), v2sub(q2, q0));
+		sr.pad = VGX_ORIENT_KNOWN | (0.0f < orient ? VGX_ORIENT_POS : 0u) | (0.0f > orient ? VGX_ORIENT_NEG : 0u);
 		*rec = sr;
 		if ((fillFlags & VGX_FILL_ENABLE) && spN >= 3) { ++nfill; }     // vg.cpp:3099-3131
 		if ((strokeFlags & VGX_STROKE_ENABLE) && spN >= 2) { ++nstroke; } // vg.cpp:3448-3485

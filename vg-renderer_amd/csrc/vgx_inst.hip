@@ -222,7 +222,9 @@ __device__ __forceinline__ bool inst_cubic_lockstep(InstLane& L, v2f P2, v2f P3,
 			P2 = P12; P3 = P123; P4 = P1234;
 		}
 		if (leaf) {
-			L.env.emitLockstep(L.wp, L.m0 * P4.x + L.m2 * P4.y + L.m4, L.m1 * P4.x + L.m3 * P4.y + L.m5, act); // transformPos2D, vg_util.h:24-28
+			const float ox = L.m0 * P4.x + L.m2 * P4.y + L.m4, oy = L.m1 * P4.x + L.m3 * P4.y + L.m5; // transformPos2D, vg_util.h:24-28
+			if (__ballot(L.spN < 3u) != 0) { L.note(ox, oy); }
+			L.env.emitLockstep(L.wp, ox, oy, act);
 			L.wp += 2;
 			--L.room;
 			++L.spN;
@@ -286,6 +288,7 @@ __device__ __forceinline__ bool inst_cubic_hot(InstLane& L, v2f P2, v2f P3, v2f 
 					float2 o;
 					o.x = L.m0 * P4.x + L.m2 * P4.y + L.m4; // transformPos2D, vg_util.h:24-28
 					o.y = L.m1 * P4.x + L.m3 * P4.y + L.m5;
+					if (L.spN < 3u) { L.note(o.x, o.y); }
 					L.env.emit(L.wp, o.x, o.y);
 					L.wp += 2;
 					--L.room;

@@ -90,8 +90,11 @@ struct VgxSubRec
 {
 	uint64_t first; // heap index of the sub-path's first polyline vertex
 	uint32_t info;  // vertex count | closed << 31
-	uint32_t pad;
+	uint32_t pad;   // VGX_ORIENT_*: sign of the sub-path's first triangle (fill orientation, stroker.cpp:721-723), when the writer knew it
 };
+#define VGX_ORIENT_KNOWN 1u
+#define VGX_ORIENT_POS 2u
+#define VGX_ORIENT_NEG 4u
 
 // Sub-path record of the fused single-pass kernel (vgx_fused.hip), one per sub-path that produces a mesh, kept in the
 // wave's LDS: where the sub-path's vertices start inside the wave's polyline window (or heap block), its length and

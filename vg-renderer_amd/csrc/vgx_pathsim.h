@@ -14,7 +14,7 @@
 // triangle of the mesh's (already written) polyline `poly` (stroker.cpp:721-723) -- instead of by a k_mesh_prepare pass
 // that would read the descriptor and the draw record again.
 VGX_HD bool vgx_write_mesh(VgxMeshDesc* mdesc, vgx_mesh* mtab, uint64_t meshIndex, const vgx_draw* dr, uint32_t drawIndex, uint32_t subIndex, uint32_t kind, bool closed, uint64_t polyFirst, uint32_t n,
-	VgxMeshPrep* mprep = nullptr, const float* poly = nullptr)
+	VgxMeshPrep* mprep = nullptr, const float* poly = nullptr, uint32_t orientCode = 0)
 {
 	VgxMeshDesc m;
 	m.poly_first = polyFirst; m.poly_n = n; m.draw = drawIndex; m.subpath = subIndex;
@@ -37,10 +37,15 @@ VGX_HD bool vgx_write_mesh(VgxMeshDesc* mdesc, vgx_mesh* mtab, uint64_t meshInde
 			VgxMeshPrep pr;
 			pr.f0 = 0.0f; pr.f1 = 0.0f; pr.f2 = dr->fringe; pr.color = dr->fill_color;
 			if (kind == VGX_MESH_FILL_AA) { // same arithmetic as mesh_prep (vgx_elem.h)
-				const float* q = poly + 2 * polyFirst;
-				const V2 q0 = v2(q[0], q[1]), q1 = v2(q[2], q[3]), q2 = v2(q[4], q[5]);
-				const float orient = v2cross(v2sub(q1, q0), v2sub(q2, q0));
-				pr.f0 = dr->fringe * 0.5f * vgm_sign(orient);
+				float sgn;
+				if (orientCode & VGX_ORIENT_KNOWN) { // k_flatten_inst evaluated the first triangle while it held the vertices
+					sgn = (orientCode & VGX_ORIENT_POS) ? 1.0f : ((orientCode & VGX_ORIENT_NEG) ? -1.0f : 0.0f);
+				} else {
+					const float* q = poly + 2 * polyFirst;
+					const V2 q0 = v2(q[0], q[1]), q1 = v2(q[2], q[3]), q2 = v2(q[4], q[5]);
+					sgn = vgm_sign(v2cross(v2sub(q1, q0), v2sub(q2, q0)));
+				}
+				pr.f0 = dr->fringe * 0.5f * sgn;
 			}
 			mprep[meshIndex] = pr;
 		}

@@ -76,6 +76,13 @@ def main():
         draws["mtx"][:, 5] = rs.uniform(0, 1000, n).astype(np.float32)
         wl.set_fill(draws, slice(None), 0xFF808080, aa=True)
         wl.set_stroke(draws, slice(None), 0xFF202020, 2.0, 0, 0, aa=True)
+    elif which == "shuffled":     # Tiger x10k with the draws in random order and 10 % of them culled: grouped mode of k_flatten_inst
+        import numpy as np
+        ps, ops = wl.tiger_paths()
+        draws = wl.tiger_draws(ops, 10000)
+        rs = np.random.RandomState(1)
+        draws = draws[rs.uniform(size=draws.shape[0]) > 0.1]
+        draws = draws[rs.permutation(draws.shape[0])]
     else:
         K = int(which) if which.isdigit() else 10000
         ps, ops = wl.tiger_paths()

@@ -176,3 +176,61 @@ def test_instanced_period_is_rechecked_on_every_call(rt, gpu_ctx, wl, oracle):
     got = _async(rt, gpu_ctx, ps, d, d_steady=dinst)
     assert got.status == 0
     assert_mesh_equal(got, ref, "instances reordered")
+
+
+@pytest.mark.parametrize("seed,shapes", [(740, False), (741, True)])
+def test_grouped_mode_shuffled_and_culled_instances(rt, gpu_ctx, wl, oracle, seed, shapes):
+    """Paths reused by many draws WITHOUT a repeating sequence -- instances in shuffled draw order, a tenth of the draws
+    culled, a second drawing's draws mixed in: the count pass chooses the grouped mode (draws sorted by path on the device
+    at every call) and the instanced kernel still builds the batch. Without shapes no draw reaches the serial kernel."""
+    ps = wl.fuzz_paths(seed, npaths=56, with_shapes=shapes, with_polylines=True)
+    d = _instances(wl, ps, seed, 60)
+    rs = np.random.RandomState(seed)
+    keep = rs.uniform(size=d.shape[0]) > 0.1
+    d = d[keep][rs.permutation(int(keep.sum()))]
+    assert d.shape[0] > 2048
+    ref = oracle.tessellate(ps, d)
+    got = _async(rt, gpu_ctx, ps, d)
+    assert got.status == 0
+    assert_mesh_equal(got, ref, "grouped mode seed=%d" % seed)
+    if not shapes:
+        assert int(got.dev_sizes[NUM_SERIAL]) == 0  # the instanced lanes built it (k_flatten_build would list degenerate draws)
+    # steady state on ANOTHER arrangement of the same size: the sort is redone by every call
+    d2 = d[rs.permutation(d.shape[0])]
+    d2["mtx"][:, 4] += np.float32(3.0)
+    ref2 = oracle.tessellate(ps, d2)
+    got2 = _async(rt, gpu_ctx, ps, d, d_steady=d2)
+    assert got2.status == 0
+    assert_mesh_equal(got2, ref2, "grouped mode, rearranged at the call")
+
+
+def test_grouped_mode_is_not_chosen_for_one_off_paths(rt, gpu_ctx, wl, oracle):
+    """A batch whose paths are used once or twice stays on the command-parallel kernel (degenerate draws are listed as
+    serial there)."""
+    ps = wl.fuzz_paths(750, npaths=1500, with_shapes=False, with_polylines=True)
+    d = wl.fuzz_draws(ps, 750, ndraws=3000)
+    ref = oracle.tessellate(ps, d)
+    got = _async(rt, gpu_ctx, ps, d)
+    assert got.status == 0
+    assert_mesh_equal(got, ref, "one-off paths")
+    assert int(got.dev_sizes[NUM_SERIAL]) > 0
+
+
+def test_grouped_mode_small_lane_blocks_uneven_groups(rt, wl, oracle, monkeypatch):
+    """Very different use counts per path (1 ... 300 draws), 8-vertex lane blocks, 5 waves."""
+    monkeypatch.setenv("VGX_INST_BLOCK", "8")
+    monkeypatch.setenv("VGX_INST_WAVES", "5")
+    ctx = rt.Context(0)
+    ps = wl.fuzz_paths(760, npaths=40, with_shapes=True)
+    base = wl.fuzz_draws(ps, 760)
+    rs = np.random.RandomState(760)
+    reps = np.minimum(300, np.maximum(1, (rs.pareto(0.7, size=base.shape[0]) * 20).astype(np.int64)))
+    d = np.repeat(base, reps)
+    d["mtx"][:, 4] += rs.uniform(-50, 50, size=d.shape[0]).astype(np.float32)
+    d = d[rs.permutation(d.shape[0])]
+    assert d.shape[0] > 2048 and d.shape[0] / 40 >= 32
+    ref = oracle.tessellate(ps, d)
+    got = _async(rt, ctx, ps, d)
+    assert got.status == 0
+    assert_mesh_equal(got, ref, "uneven groups, small lane blocks")
+    ctx.close()

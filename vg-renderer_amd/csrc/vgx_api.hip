@@ -72,6 +72,11 @@ struct vgx_ctx
 	// instanced batches: period of the path sequence found by the last vgx_tessellate_count (0 = none). vgx_tessellate
 	// re-checks it on the device for the draws it is given.
 	uint32_t instPeriod;
+	// ... or, when the draws reuse paths without repeating one sequence (at least 32 draws per used path on average): 1 =
+	// grouped mode, every vgx_tessellate sorts the draws by path first (k_inst_hist / k_inst_plan / k_inst_scatter)
+	int instGrouped;
+	DevBuf instHist, instCursor, instStart, instTaskStart, instTaskPath, instOrder;
+	uint64_t instCapPaths, instCapTasks, instCapDraws;
 	hipStream_t sideStream; hipEvent_t forkEv, joinEv; // optConcurrentEmit only
 	VgxCaps caps; // element capacities matching the buffers above
 	uint64_t capDraws;
@@ -356,6 +361,7 @@ VgxFlattenArgs flattenArgs(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* 
 	a.leaf_overflow = (float*)ctx->leafOverflow.p;
 	a.serial_list = (uint32_t*)ctx->serialList.p;
 	a.inst_period = 0; a.inst_block = ctx->optInstBlock; a.inst_waves = ctx->optInstWaves;
+	a.inst_order = nullptr; a.inst_start = nullptr; a.inst_task_start = nullptr; a.inst_task_path = nullptr;
 	return a;
 }
 
@@ -366,6 +372,44 @@ uint32_t instPeriodFor(const vgx_ctx* ctx, uint64_t ndraws)
 	const uint32_t P = ctx->instPeriod;
 	if (!P || !ctx->optInst || ndraws % P != 0 || ndraws / P < VGX_INST_MIN_INSTANCES) { return 0; }
 	return P;
+}
+
+// Grouped mode for this call: the count pass chose it and the sort buffers hold a batch of this size over this path set.
+bool instGroupedFor(const vgx_ctx* ctx, const vgx_pathset* ps, uint64_t ndraws)
+{
+	return ctx->instGrouped && ctx->optInst && !instPeriodFor(ctx, ndraws) && ndraws > VGX_SMALL_DRAWS && ndraws <= ctx->instCapDraws
+		&& ps->dev.npaths <= ctx->instCapPaths && ndraws < 0xFFFFFFFFull;
+}
+
+// scratch of the grouped mode: histogram / cursor / ranges per path, task table, draw order
+int ensureInstGroup(vgx_ctx* ctx, uint32_t npaths, uint64_t ndraws, bool full)
+{
+	int st;
+	if ((st = ensure(ctx, ctx->instHist, ((size_t)npaths + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->instStart, ((size_t)npaths + 1) * sizeof(uint64_t))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->instTaskStart, ((size_t)npaths + 1) * sizeof(uint64_t))) != VGX_OK) { return st; }
+	if (full) {
+		const uint64_t tasks = ndraws / 64 + (uint64_t)npaths + 2; // every used path rounds up once
+		if ((st = ensure(ctx, ctx->instCursor, ((size_t)npaths + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
+		if ((st = ensure(ctx, ctx->instTaskPath, tasks * sizeof(uint32_t))) != VGX_OK) { return st; }
+		if ((st = ensure(ctx, ctx->instOrder, (ndraws + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
+		ctx->instCapTasks = ctx->instTaskPath.cap / sizeof(uint32_t);
+		ctx->instCapDraws = ctx->instOrder.cap / sizeof(uint32_t) - 1;
+		uint64_t cp = ctx->instHist.cap / sizeof(uint32_t) - 1;
+		{ const uint64_t c2 = ctx->instCursor.cap / sizeof(uint32_t) - 1, c3 = ctx->instStart.cap / sizeof(uint64_t) - 1, c4 = ctx->instTaskStart.cap / sizeof(uint64_t) - 1;
+		  if (c2 < cp) { cp = c2; } if (c3 < cp) { cp = c3; } if (c4 < cp) { cp = c4; } }
+		ctx->instCapPaths = cp;
+	}
+	return VGX_OK;
+}
+
+void setInstArgs(vgx_ctx* ctx, const vgx_pathset* ps, uint64_t ndraws, VgxFlattenArgs& a)
+{
+	a.inst_period = instPeriodFor(ctx, ndraws);
+	if (instGroupedFor(ctx, ps, ndraws)) {
+		a.inst_order = (const uint32_t*)ctx->instOrder.p; a.inst_start = (const uint64_t*)ctx->instStart.p;
+		a.inst_task_start = (const uint64_t*)ctx->instTaskStart.p; a.inst_task_path = (const uint32_t*)ctx->instTaskPath.p;
+	}
 }
 
 int ensureDrawBuffers(vgx_ctx* ctx, uint64_t ndraws)
@@ -421,7 +465,12 @@ void runFlattenBuild(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 	noteHip(ctx, hipMemsetAsync(ctx->dinfo.p, 0, ndraws * sizeof(vgx_draw_info), s));
 	VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, 1);
 	a.build_mode = 1;
-	a.inst_period = instPeriodFor(ctx, ndraws); // the same value runCmdPrefix checked the draws against
+	setInstArgs(ctx, ps, ndraws, a); // periodic: the same value runCmdPrefix checked the draws against
+	if (a.inst_order) { // grouped mode: this batch's draws sorted by path
+		vgx_launch_inst_group(draws, ndraws, ps->dev.npaths, (uint32_t*)ctx->instHist.p, (uint32_t*)ctx->instCursor.p, (uint64_t*)ctx->instStart.p,
+			(uint64_t*)ctx->instTaskStart.p, (uint32_t*)ctx->instTaskPath.p, ctx->instCapTasks, (uint32_t*)ctx->instOrder.p, (VgxTotals*)ctx->totals.p, s);
+		mark(ctx, s, "inst_group");
+	}
 	a.mprep = (VgxMeshPrep*)ctx->mprep.p; // k_flatten_gather / k_flatten_serial write the per-mesh constants with the descriptors
 	vgx_launch_flatten_build(a, ctx->optBuildWaves, s);
 	mark(ctx, s, "flatten_build");
@@ -703,7 +752,7 @@ int vgx_destroy(vgx_ctx* ctx)
 		return VGX_E_INVALID_ARG;
 	}
 	DeviceGuard guard(ctx);
-	DevBuf* bufs[] = { &ctx->gatherSizes, &ctx->segStart, &ctx->segState, &ctx->probeOut, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DevBuf* bufs[] = { &ctx->instHist, &ctx->instCursor, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->segStart, &ctx->segState, &ctx->probeOut, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
@@ -952,15 +1001,27 @@ static int flattenCountCommon(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_dra
 	if ((st = ensureDrawBuffers(ctx, ndraws)) != VGX_OK) { return st; }
 	// pass 1: command instances (sizes the per-command scratch)
 	ctx->caps.cmd_instances = ~0ull; // not known yet: never trips the check in this sizing pass
-	ctx->instPeriod = 0;
+	ctx->instPeriod = 0; ctx->instGrouped = 0;
 	runCmdPrefix(ctx, ps, draws, ndraws, s);
-	if (ctx->optInst && ndraws > VGX_SMALL_DRAWS) { vgx_launch_inst_detect(draws, ndraws, (VgxTotals*)ctx->totals.p, s); }
+	if (ctx->optInst && ndraws > VGX_SMALL_DRAWS) {
+		vgx_launch_inst_detect(draws, ndraws, (VgxTotals*)ctx->totals.p, s);
+		// ... and how many different paths the draws use (grouped mode, when the sequence does not repeat)
+		if ((st = ensureInstGroup(ctx, ps->dev.npaths, ndraws, false)) != VGX_OK) { return st; }
+		vgx_launch_inst_group(draws, ndraws, ps->dev.npaths, (uint32_t*)ctx->instHist.p, nullptr, (uint64_t*)ctx->instStart.p, (uint64_t*)ctx->instTaskStart.p,
+			nullptr, 0, nullptr, (VgxTotals*)ctx->totals.p, s);
+	}
 	if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
 	if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; }
 	if (ctx->hostTotals->inst_detect_inv != 0 && !ctx->hostTotals->inst_detect_bad) {
 		// the draws repeat one sequence of paths (a drawing submitted for many instances): vgx_inst.hip
 		const unsigned long long P = ~0ull - ctx->hostTotals->inst_detect_inv;
 		if (P <= 0xFFFFFFFFull) { ctx->instPeriod = (uint32_t)P; }
+	}
+	if (!instPeriodFor(ctx, ndraws) && ctx->optInst && ndraws > VGX_SMALL_DRAWS && ndraws < 0xFFFFFFFFull && ctx->hostTotals->inst_distinct != 0
+		&& ndraws / ctx->hostTotals->inst_distinct >= VGX_INST_MIN_INSTANCES) {
+		// paths are reused (>= 32 draws per used path on average) but not as a repeating sequence: grouped mode
+		if ((st = ensureInstGroup(ctx, ps->dev.npaths, ndraws, true)) != VGX_OK) { return st; }
+		ctx->instGrouped = 1;
 	}
 	const uint64_t ncmdInst = ctx->hostTotals->sizes.num_cmd_instances;
 	if ((st = ensure(ctx, ctx->cmdCnt, (ncmdInst + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
@@ -1048,7 +1109,7 @@ int vgx_tessellate_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* dr
 	// over the whole batch), the moved prefix of a spanning sub-path is < VGX_LONG_SUBPATH per >= VGX_BUILD_BLOCK block
 	// (<= 1/4), and longer sub-paths grow geometrically (<= 4x their own size). Plus every wave's last open block.
 	uint64_t heapVerts = sz.num_poly_vertices * 9 / 4 + 4 * ctx->hostTotals->long_subpath_vertices + 2 * (uint64_t)VGX_BUILD_WAVES * VGX_BUILD_BLOCK;
-	if (instPeriodFor(ctx, ndraws)) {
+	if (instPeriodFor(ctx, ndraws) || instGroupedFor(ctx, ps, ndraws)) {
 		// k_flatten_inst's lane-private blocks (vgx_inst.h): a block left behind wastes less than the one sub-path that did
 		// not fit (< the block's useful vertices while sub-paths are at most half a block long), longer sub-paths grow
 		// geometrically (<= 4x their size + a block, counted with head room), plus every lane's last open block

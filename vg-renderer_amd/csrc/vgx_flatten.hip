@@ -382,7 +382,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 	const VgxPathSetDev& ps = A.ps;
 	const uint64_t totalCmds = A.cmd_prefix[A.ndraws];
 	if (A.totals->status != VGX_OK) { return; }
-	if (A.inst_period != 0 && A.totals->inst_mismatch == 0) { return; } // instanced batch: k_flatten_inst builds it
+	if (A.inst_order != nullptr || (A.inst_period != 0 && A.totals->inst_mismatch == 0)) { return; } // instanced batch: k_flatten_inst builds it
 	const uint64_t segItems = vgx_segment_items(totalCmds, gridDim.x);
 	const uint64_t numSegments = (totalCmds + segItems - 1) / segItems;
 	const uint64_t segsPerWave = (numSegments + gridDim.x - 1) / gridDim.x;
@@ -909,7 +909,7 @@ void vgx_launch_small_middle(const VgxFlattenArgs& f, const VgxStrokeArgs& st, c
 
 void vgx_launch_flatten_build(const VgxFlattenArgs& a, int waves, hipStream_t s, bool serialCount)
 {
-	if (a.inst_period) { vgx_launch_flatten_inst(a, a.inst_waves, s); } // one of the two exits at once (device-side check)
+	if (a.inst_period || a.inst_order) { vgx_launch_flatten_inst(a, a.inst_waves, s); } // one of the two exits at once (device-side check)
 	// waves < VGX_BUILD_WAVES is a testing knob (VGX_BUILD_WAVES in the environment at vgx_create): a handful of waves makes
 	// small batches run through the heap's block switches and sub-path moves that otherwise need > 8192 vertices per wave
 	if (a.pool_walk) {

@@ -355,18 +355,20 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_inst(VgxFlattenArgs A)
 	__shared__ float2 s_stack[VGX_INST_LDS_LEVELS * 3 * VGX_WAVE];
 	__shared__ float2 s_stage[VGX_INST_STAGE * VGX_WAVE];
 	const int lane = threadIdx.x;
-	if (A.totals->status != VGX_OK || A.totals->inst_mismatch != 0) { return; }
+	const bool grouped = A.inst_order != nullptr; // draws grouped by path through inst_order (else: periodic batch, closed form)
+	if (A.totals->status != VGX_OK || (!grouped && A.totals->inst_mismatch != 0)) { return; }
 	LdsStackT<VGX_INST_LDS_LEVELS> stack;
 	stack.base = &s_stack[lane];
 
 	const VgxPathSetDev& ps = A.ps;
-	const uint32_t P = A.inst_period;
+	const uint32_t P = grouped ? 1u : A.inst_period;
 	const uint64_t ninst = A.ndraws / P;
-	const auto cprefix = as_const(A.cmd_prefix); // of the first instance = command offsets inside every instance
-	const uint64_t C = cprefix[P];                // commands per instance
+	const auto cprefix = as_const(A.cmd_prefix); // periodic: of the first instance = command offsets inside every instance
+	const uint64_t C = grouped ? 1ull : cprefix[P]; // commands per instance
 	const uint64_t G = (ninst + VGX_WAVE - 1) / VGX_WAVE;
 	if (C == 0) { return; }
-	const uint64_t numTasks = G * P; // task t = instance group t / P, path slot t % P
+	// periodic: task t = instance group t / P, path slot t % P; grouped: task t = 64 draws of path inst_task_path[t]
+	const uint64_t numTasks = grouped ? (uint64_t)A.totals->inst_num_tasks : G * P;
 
 	uint64_t profPro = 0, profCubic = 0, profLoop = 0, profTasks = 0, profCubics = 0;
 	(void)profPro; (void)profCubic; (void)profLoop; (void)profTasks; (void)profCubics;
@@ -405,14 +407,27 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_inst(VgxFlattenArgs A)
 		if (lane == 0) { ticket = atomicAdd(&A.totals->inst_ticket[pool * 16], 1ull); }
 #endif
 		IPROF_T(tTask0);
-		const uint64_t g = t / P;
-		const uint32_t pcur = (uint32_t)(t - g * P);
-		const uint32_t path = as_const(A.draws)[pcur].path; // == draws[i * P + pcur].path for every instance i (verified)
+		uint32_t path;
+		bool valid;
+		uint64_t d, srecBase;
+		if (!grouped) {
+			const uint64_t g = t / P;
+			const uint32_t pcur = (uint32_t)(t - g * P);
+			path = as_const(A.draws)[pcur].path; // == draws[i * P + pcur].path for every instance i (verified)
+			const uint64_t inst = g * VGX_WAVE + (uint64_t)lane;
+			valid = inst < ninst;
+			d = inst * P + pcur;
+			srecBase = inst * C + cprefix[pcur];
+		} else {
+			path = as_const(A.inst_task_path)[t];
+			const uint64_t first = as_const(A.inst_start)[path], end = as_const(A.inst_start)[path + 1];
+			const uint64_t idx = first + (t - as_const(A.inst_task_start)[path]) * VGX_WAVE + (uint64_t)lane;
+			valid = idx < end;
+			d = valid ? (uint64_t)A.inst_order[idx] : 0ull;
+			srecBase = A.cmd_prefix[d];
+		}
 		const uint32_t pc0 = as_const(ps.path_cmd_begin)[path], pc1 = as_const(ps.path_cmd_begin)[path + 1];
 		if (pc0 == pc1) { continue; } // nothing to build: the draw's (zeroed) record stands
-		const uint64_t inst = g * VGX_WAVE + (uint64_t)lane;
-		const bool valid = inst < ninst;
-		const uint64_t d = inst * P + pcur;
 		if (as_const(ps.path_flags)[path] & VGX_PF_SERIAL) {
 			// arcs / closed shapes: the exact one-lane-per-draw builder (k_flatten_serial), as in k_flatten_build
 			const uint64_t sm = wave_ballot(valid);
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_inst(VgxFlattenArgs A)
 		const VgxCmdRec* recs = ps.cmdrec + pc0;
 		const uint32_t ncmd = pc1 - pc0;
 		const vgx_draw* dr = A.draws + d;
-		VgxSubRec* srec = A.sub_rec + (inst * C + cprefix[pcur]);
+		VgxSubRec* srec = A.sub_rec + srecBase;
 		if (valid) { L.beginDraw(dr->mtx, dr->scale, dr->tess_tol, dr->fill_flags, dr->stroke_flags); }
 #ifdef VGX_EXP_INST_FLAT
 		L.tessTol = 3.0e38f; // experiment: every cubic is one segment
@@ -540,7 +555,146 @@ __global__ __launch_bounds__(256) void k_inst_verify(const vgx_draw* draws, uint
 	if (bad) { totals->inst_detect_bad = 1u; }
 }
 
+// ---- grouped mode: the draws sorted by path ------------------------------------------------------------------------
+// For batches that reuse paths without repeating one sequence (culled or shuffled instances, several drawings mixed): a
+// counting sort by path id. The order inside a path's range is whatever the atomics give -- any lane may take any draw
+// of its path; only the heap locality of the emit kernels' reads depends on it.
+// Atomics on neighbouring counters serialise per cache line in the memory-side cache (2.2 M draws over 240 paths = 8 lines:
+// the two passes took 2.1 ms with plain global atomics), so a workgroup counts its slice of the draws in LDS and touches
+// the global counters once per used path. Path sets with more than VGX_INST_LDS_PATHS paths take the plain form.
+#define VGX_INST_LDS_PATHS 4096
+#define VGX_INST_GROUP_THREADS 1024
+#define VGX_INST_GROUP_BLOCKS 256
+__device__ __forceinline__ void inst_slice(uint64_t n, uint64_t* lo, uint64_t* hi)
+{
+	const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
+	const uint64_t l = per * blockIdx.x;
+	*lo = l < n ? l : n;
+	*hi = l + per < n ? l + per : n;
+}
+
+__global__ __launch_bounds__(VGX_INST_GROUP_THREADS) void k_inst_hist(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, uint32_t* hist)
+{
+	__shared__ uint32_t s_cnt[VGX_INST_LDS_PATHS];
+	uint64_t lo, hi;
+	inst_slice(ndraws, &lo, &hi);
+	if (npaths > VGX_INST_LDS_PATHS) {
+		for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+			const uint32_t p = draws[i].path;
+			if (p < npaths) { atomicAdd(&hist[p], 1u); } // an invalid path id was reported by the command scan
+		}
+		return;
+	}
+	for (uint32_t p = threadIdx.x; p < npaths; p += blockDim.x) { s_cnt[p] = 0; }
+	__syncthreads();
+	for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+		const uint32_t p = draws[i].path;
+		if (p < npaths) { atomicAdd(&s_cnt[p], 1u); }
+	}
+	__syncthreads();
+	for (uint32_t p = threadIdx.x; p < npaths; p += blockDim.x) {
+		const uint32_t c = s_cnt[p];
+		if (c) { atomicAdd(&hist[p], c); }
+	}
+}
+
+// One workgroup: exclusive scans of the histogram (draw ranges, task ranges), the task -> path table, the totals.
+#define VGX_INST_PLAN_THREADS 1024
+__global__ __launch_bounds__(VGX_INST_PLAN_THREADS) void k_inst_plan(const uint32_t* hist, uint32_t npaths, uint64_t* start, uint64_t* taskStart, uint32_t* taskPath, uint64_t capTasks, VgxTotals* totals)
+{
+	__shared__ uint64_t s_wave[3 * (VGX_INST_PLAN_THREADS / 64)];
+	__shared__ uint64_t s_carry[3];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	if (threadIdx.x < 3) { s_carry[threadIdx.x] = 0; }
+	__syncthreads();
+	for (uint32_t base = 0; base < npaths; base += VGX_INST_PLAN_THREADS) {
+		const uint32_t p = base + threadIdx.x;
+		const uint64_t cnt = p < npaths ? hist[p] : 0u;
+		const uint64_t nt = (cnt + VGX_WAVE - 1) / VGX_WAVE;
+		uint64_t v[3] = { cnt, nt, cnt ? 1ull : 0ull };
+		uint64_t incl[3];
+		for (int f = 0; f < 3; ++f) {
+			uint64_t x = v[f];
+			for (int dd = 1; dd < 64; dd <<= 1) {
+				const uint64_t y = __shfl_up((unsigned long long)x, dd);
+				if (lane >= dd) { x += y; }
+			}
+			incl[f] = x;
+			if (lane == 63) { s_wave[f * (VGX_INST_PLAN_THREADS / 64) + wave] = x; }
+		}
+		__syncthreads();
+		uint64_t excl[3];
+		for (int f = 0; f < 3; ++f) {
+			uint64_t b = s_carry[f];
+			for (int w = 0; w < wave; ++w) { b += s_wave[f * (VGX_INST_PLAN_THREADS / 64) + w]; }
+			excl[f] = b + incl[f] - v[f];
+		}
+		if (p < npaths) {
+			start[p] = excl[0];
+			taskStart[p] = excl[1];
+			if (taskPath) {
+				for (uint64_t j = 0; j < nt; ++j) { if (excl[1] + j < capTasks) { taskPath[excl[1] + j] = p; } }
+			}
+		}
+		__syncthreads();
+		if (threadIdx.x == VGX_INST_PLAN_THREADS - 1) { for (int f = 0; f < 3; ++f) { s_carry[f] = excl[f] + v[f]; } }
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		start[npaths] = s_carry[0];
+		taskStart[npaths] = s_carry[1];
+		totals->inst_num_tasks = s_carry[1];
+		totals->inst_distinct = s_carry[2];
+		if (taskPath && s_carry[1] > capTasks) { atomicCAS(&totals->status, (uint32_t)VGX_OK, (uint32_t)VGX_E_NOSPACE); }
+	}
+}
+
+__global__ __launch_bounds__(VGX_INST_GROUP_THREADS) void k_inst_scatter(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, const uint64_t* start, uint32_t* cursor, uint32_t* order)
+{
+	__shared__ uint32_t s_cnt[VGX_INST_LDS_PATHS];
+	__shared__ uint32_t s_base[VGX_INST_LDS_PATHS];
+	uint64_t lo, hi;
+	inst_slice(ndraws, &lo, &hi);
+	if (npaths > VGX_INST_LDS_PATHS) {
+		for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+			const uint32_t p = draws[i].path;
+			if (p < npaths) { order[start[p] + atomicAdd(&cursor[p], 1u)] = (uint32_t)i; }
+		}
+		return;
+	}
+	// the slice's own histogram -> one reservation per used path in the path's range -> ranks inside the reservation
+	for (uint32_t p = threadIdx.x; p < npaths; p += blockDim.x) { s_cnt[p] = 0; }
+	__syncthreads();
+	for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+		const uint32_t p = draws[i].path;
+		if (p < npaths) { atomicAdd(&s_cnt[p], 1u); }
+	}
+	__syncthreads();
+	for (uint32_t p = threadIdx.x; p < npaths; p += blockDim.x) {
+		const uint32_t c = s_cnt[p];
+		s_base[p] = c ? atomicAdd(&cursor[p], c) : 0u;
+		s_cnt[p] = 0;
+	}
+	__syncthreads();
+	for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+		const uint32_t p = draws[i].path;
+		if (p < npaths) { order[start[p] + s_base[p] + atomicAdd(&s_cnt[p], 1u)] = (uint32_t)i; }
+	}
+}
+
 } // namespace
+
+void vgx_launch_inst_group(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, uint32_t* hist, uint32_t* cursor, uint64_t* start, uint64_t* taskStart,
+	uint32_t* taskPath, uint64_t capTasks, uint32_t* order, VgxTotals* totals, hipStream_t s)
+{
+	(void)hipMemsetAsync(hist, 0, ((size_t)npaths + 1) * sizeof(uint32_t), s);
+	hipLaunchKernelGGL(k_inst_hist, dim3(VGX_INST_GROUP_BLOCKS), dim3(VGX_INST_GROUP_THREADS), 0, s, draws, ndraws, npaths, hist);
+	hipLaunchKernelGGL(k_inst_plan, dim3(1), dim3(VGX_INST_PLAN_THREADS), 0, s, (const uint32_t*)hist, npaths, start, taskStart, taskPath, capTasks, totals);
+	if (order) {
+		(void)hipMemsetAsync(cursor, 0, ((size_t)npaths + 1) * sizeof(uint32_t), s);
+		hipLaunchKernelGGL(k_inst_scatter, dim3(VGX_INST_GROUP_BLOCKS), dim3(VGX_INST_GROUP_THREADS), 0, s, draws, ndraws, npaths, (const uint64_t*)start, cursor, order);
+	}
+}
 
 void vgx_launch_flatten_inst(const VgxFlattenArgs& a, int waves, hipStream_t s)
 {

@@ -37,6 +37,12 @@ struct VgxFlattenArgs
 	uint32_t inst_period;
 	uint32_t inst_block;           // vertices per lane-private heap block
 	int inst_waves;                // grid of k_flatten_inst
+	// grouped mode of k_flatten_inst (draws that share paths in ANY order; null = periodic mode / off): the draws sorted by
+	// path (k_inst_hist / k_inst_plan / k_inst_scatter, run by every vgx_tessellate in this mode)
+	const uint32_t* inst_order;      // [ndraws] draw indices, grouped by path
+	const uint64_t* inst_start;      // [npaths + 1] first entry of every path in inst_order
+	const uint64_t* inst_task_start; // [npaths + 1] first task of every path
+	const uint32_t* inst_task_path;  // [tasks] path of every task
 };
 
 struct VgxStrokeArgs
@@ -120,6 +126,9 @@ void vgx_launch_flatten(bool emit, const VgxFlattenArgs& a, int numBlocks, hipSt
 void vgx_launch_flatten_build(const VgxFlattenArgs& a, int waves, hipStream_t s, bool serialCount = true);   // single-pass: subdivide once, polyline -> heap
 void vgx_launch_flatten_inst(const VgxFlattenArgs& a, int waves, hipStream_t s);  // instanced batches: one lane per instance (vgx_inst.hip)
 void vgx_launch_inst_detect(const vgx_draw* draws, uint64_t ndraws, VgxTotals* totals, hipStream_t s); // count pass: period of the path sequence
+// grouped mode: histogram of the draws' paths -> per-path ranges and task list (taskPath may be null: counts only) -> draw order
+void vgx_launch_inst_group(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, uint32_t* hist, uint32_t* cursor, uint64_t* start, uint64_t* taskStart,
+	uint32_t* taskPath, uint64_t capTasks, uint32_t* order, VgxTotals* totals, hipStream_t s);
 // frame-sized batches (vgx_flatten.hip): one-workgroup kernels instead of chains of dependent launches; the operators are
 // the OpCmdPrefix / OpDrawInfo / OpMeshAll of vgx_scan_ops.h, passed type-erased (the header is device code)
 #define VGX_SMALL_DRAWS 2048

@@ -121,6 +121,8 @@ struct VgxTotals
 	unsigned long long inst_long_subpath_vertices; // count pass: vertices in sub-paths longer than VGX_INST_LONG_SUBPATH (heap sizing)
 	unsigned long long inst_detect_inv;  // vgx_tessellate_count: ~0 - (index of the first repetition of draws[0].path); 0 = none
 	unsigned long long inst_ticket[VGX_INST_POOLS * 16]; // vgx_tessellate: next task of every task pool of k_flatten_inst, one counter per 128 bytes
+	unsigned long long inst_num_tasks;   // grouped mode (k_inst_plan): (path, 64-draw chunk) tasks of this batch
+	unsigned long long inst_distinct;    // grouped mode: paths that at least one draw uses
 	uint32_t inst_detect_bad;            // vgx_tessellate_count: some draw differs from its image in the first period
 	uint32_t inst_mismatch;              // vgx_tessellate: the draws no longer repeat with the context's period -> k_flatten_build does the batch
 	// diagnostics of the first failure inside the fused kernel (vgx_get_failure_info)

@@ -59,6 +59,7 @@ struct vgx_ctx
 	DevBuf asmJump0, asmJump1, asmStart, meshBase; // draw-command assembly scratch (only when armed)
 	vgx_assembly asmCfg;
 	bool asmArmed;
+	DevBuf subPrefix; // exclusive scan of the draws' static sub-path counts
 	DevBuf cmdPrefix, cmdCnt, subFirst, leafOverflow, serialList, dinfo, poly, subs, mdesc, elemPrefix, elemPrefixS, mprep, mtab, partial, totals;
 	DevBuf gatherSizes;                  // vgx_gather_sizes: [nranks][4] uint64
 	struct VgxRccl* rccl;                // RCCL entry points, bound at the first vgx_gather* call
@@ -345,6 +346,7 @@ VgxFlattenArgs flattenArgs(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* 
 	a.draws = draws;
 	a.ndraws = ndraws;
 	a.cmd_prefix = (const uint64_t*)ctx->cmdPrefix.p;
+	a.sub_prefix = (const uint64_t*)ctx->subPrefix.p;
 	a.cmd_cnt = (uint32_t*)ctx->cmdCnt.p;
 	a.dinfo = (vgx_draw_info*)ctx->dinfo.p;
 	a.poly = (float*)ctx->poly.p;
@@ -416,13 +418,14 @@ int ensureDrawBuffers(vgx_ctx* ctx, uint64_t ndraws)
 {
 	int st;
 	if ((st = ensure(ctx, ctx->cmdPrefix, (ndraws + 1) * sizeof(uint64_t))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->subPrefix, (ndraws + 1) * sizeof(uint64_t))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->dinfo, (ndraws + 1) * sizeof(vgx_draw_info))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->serialList, (ndraws + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->partial, VGX_SCAN_BLOCKS * sizeof(Sum3))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->totals, sizeof(VgxTotals))) != VGX_OK) { return st; }
 	// what the grow-only buffers hold, not the last batch's size
 	uint64_t cap = ctx->cmdPrefix.cap / sizeof(uint64_t) - 1;
-	{ const uint64_t c2 = ctx->dinfo.cap / sizeof(vgx_draw_info) - 1, c3 = ctx->serialList.cap / sizeof(uint32_t) - 1; if (c2 < cap) { cap = c2; } if (c3 < cap) { cap = c3; } }
+	{ const uint64_t c2 = ctx->dinfo.cap / sizeof(vgx_draw_info) - 1, c3 = ctx->serialList.cap / sizeof(uint32_t) - 1, c4 = ctx->subPrefix.cap / sizeof(uint64_t) - 1; if (c2 < cap) { cap = c2; } if (c3 < cap) { cap = c3; } if (c4 < cap) { cap = c4; } }
 	ctx->capDraws = cap;
 	return VGX_OK;
 }
@@ -441,6 +444,7 @@ void runCmdPrefix(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, ui
 	OpCmdPrefix op;
 	op.draws = draws; op.pathCmdBegin = ps->dev.path_cmd_begin; op.npaths = ps->dev.npaths; op.ndraws = ndraws;
 	op.prefix = (uint64_t*)ctx->cmdPrefix.p; op.totals = (VgxTotals*)ctx->totals.p; op.cap = ctx->caps.cmd_instances;
+	op.pathSubBegin = ps->dev.path_sub_begin; op.subPrefix = (uint64_t*)ctx->subPrefix.p;
 	op.period = instPeriod;
 	vgx_device_scan(op, (Sum3*)ctx->partial.p, s, ndraws);
 	mark(ctx, s, "scan_cmd_prefix");
@@ -752,7 +756,7 @@ int vgx_destroy(vgx_ctx* ctx)
 		return VGX_E_INVALID_ARG;
 	}
 	DeviceGuard guard(ctx);
-	DevBuf* bufs[] = { &ctx->instHist, &ctx->instCursor, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->segStart, &ctx->segState, &ctx->probeOut, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DevBuf* bufs[] = { &ctx->instHist, &ctx->instCursor, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->segStart, &ctx->segState, &ctx->probeOut, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
@@ -774,7 +778,7 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx)
 	if (!ctx) {
 		return 0;
 	}
-	return ctx->gatherSizes.cap + ctx->segStart.cap + ctx->segState.cap + ctx->probeOut.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
+	return ctx->gatherSizes.cap + ctx->segStart.cap + ctx->segState.cap + ctx->probeOut.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
 }
 
 // ---- path set ---------------------------------------------------------------------------------------
@@ -1181,7 +1185,7 @@ int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 		OpCmdPrefix opC;
 		opC.draws = draws; opC.pathCmdBegin = ps->dev.path_cmd_begin; opC.npaths = ps->dev.npaths; opC.ndraws = ndraws;
 		opC.prefix = (uint64_t*)ctx->cmdPrefix.p; opC.totals = (VgxTotals*)ctx->totals.p; opC.cap = ctx->caps.cmd_instances;
-		opC.period = 0;
+		opC.period = 0; opC.pathSubBegin = ps->dev.path_sub_begin; opC.subPrefix = (uint64_t*)ctx->subPrefix.p;
 		vgx_launch_small_front(&opC, (vgx_draw_info*)ctx->dinfo.p, s);
 		mark(ctx, s, "small_front");
 		VgxFlattenArgs f = flattenArgs(ctx, ps, draws, ndraws, 1);

@@ -417,14 +417,14 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_inst(VgxFlattenArgs A)
 			const uint64_t inst = g * VGX_WAVE + (uint64_t)lane;
 			valid = inst < ninst;
 			d = inst * P + pcur;
-			srecBase = inst * C + cprefix[pcur];
+			srecBase = inst * as_const(A.sub_prefix)[P] + as_const(A.sub_prefix)[pcur]; // sub-paths in front of this draw (periodic: closed form)
 		} else {
 			path = as_const(A.inst_task_path)[t];
 			const uint64_t first = as_const(A.inst_start)[path], end = as_const(A.inst_start)[path + 1];
 			const uint64_t idx = first + (t - as_const(A.inst_task_start)[path]) * VGX_WAVE + (uint64_t)lane;
 			valid = idx < end;
 			d = valid ? (uint64_t)A.inst_order[idx] : 0ull;
-			srecBase = A.cmd_prefix[d];
+			srecBase = A.sub_prefix[d];
 		}
 		const uint32_t pc0 = as_const(ps.path_cmd_begin)[path], pc1 = as_const(ps.path_cmd_begin)[path + 1];
 		if (pc0 == pc1) { continue; } // nothing to build: the draw's (zeroed) record stands
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_inst(VgxFlattenArgs A)
 					default: break; // shapes / arcs only occur in statically serial paths
 					}
 #ifndef VGX_EXP_INST_NOSUB
-					if (cflags & VGX_CF_LAST_IN_SUB) { L.endSub(srec + k0 + kk); }
+					if (cflags & VGX_CF_LAST_IN_SUB) { L.endSub(srec + L.nsubs); } // dense: one 16-byte record per sub-path, in draw order
 #endif
 				}
 			}

@@ -15,6 +15,8 @@ struct VgxFlattenArgs
 	const vgx_draw* draws;
 	uint64_t ndraws;
 	const uint64_t* cmd_prefix; // [ndraws+1]
+	const uint64_t* sub_prefix; // [ndraws+1] exclusive scan of the draws' static sub-path counts: k_flatten_inst stores its sub-path records densely,
+	                            // record j of draw d at sub_rec[sub_prefix[d] + j] (k_flatten_build: sparsely at the command instance)
 	uint32_t* cmd_cnt;          // [num_cmd_instances]
 	vgx_draw_info* dinfo;       // [ndraws]
 	float* poly;                // emit: [cap][2]

@@ -24,6 +24,8 @@ struct OpCmdPrefix // command instances per draw -> cmd_prefix
 	uint64_t* prefix;
 	VgxTotals* totals;
 	uint64_t cap;
+	const uint32_t* pathSubBegin; // [npaths + 1] sub-path ending commands per path (static)
+	uint64_t* subPrefix;          // [ndraws + 1] out: exclusive scan of the draws' static sub-path counts (dense sub-path records of k_flatten_inst)
 	uint32_t period; // instanced batch (vgx_inst.hip): the context expects draws[i].path == draws[i % period].path; 0 = no check
 	__device__ uint64_t size() const { return ndraws; }
 	__device__ Sum3 load(uint64_t i) const
@@ -52,12 +54,14 @@ struct OpCmdPrefix // command instances per draw -> cmd_prefix
 			}
 		}
 		r.a = pathCmdBegin[p + 1] - pathCmdBegin[p];
+		r.b = pathSubBegin[p + 1] - pathSubBegin[p];
 		return r;
 	}
-	__device__ void store(uint64_t i, Sum3 e) const { prefix[i] = e.a; }
+	__device__ void store(uint64_t i, Sum3 e) const { prefix[i] = e.a; subPrefix[i] = e.b; }
 	__device__ void finish(Sum3 t) const
 	{
 		prefix[ndraws] = t.a;
+		subPrefix[ndraws] = t.b;
 		totals->sizes.num_cmd_instances = t.a;
 		if (t.a > cap) { set_status(totals, VGX_E_NOSPACE); }
 	}

@@ -640,7 +640,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 						if (lastInSub) { // sub-path record, consumed by k_flatten_gather
 							VgxSubRec sr;
 							sr.first = g - (uint64_t)spBefore; sr.info = (uint32_t)spTotal | (closedHere ? 0x80000000u : 0u); sr.pad = 0;
-							A.sub_rec[ci] = sr;
+							A.sub_rec[A.sub_prefix[d] + (uint64_t)(subsIncl - 1)] = sr; // dense, in draw order: record j of draw d at sub_prefix[d] + j
 						}
 					}
 					{ // draws the serial kernel has to (re)do: static serial paths and degenerate draws, wave-aggregated append
@@ -703,15 +703,12 @@ __device__ __forceinline__ void flatten_gather_body(const VgxFlattenArgs& A, uin
 		const vgx_draw* dr = A.draws + d;
 		const uint32_t path = dr->path;
 		const uint32_t sb0 = ps.path_sub_begin[path], sb1 = ps.path_sub_begin[path + 1];
-		// k_flatten_inst stores the records densely in draw order, k_flatten_build at the command instance of the sub-path's
-		// last command (which of the two built the batch: same conditions as their own first lines)
-		const bool dense = A.inst_order != nullptr || (A.inst_period != 0 && A.totals->inst_mismatch == 0);
-		const uint64_t cbase = dense ? A.sub_prefix[d] : A.cmd_prefix[d];
+		const uint64_t cbase = A.sub_prefix[d]; // both flatten kernels store record j of draw d at sub_prefix[d] + j
 		const uint32_t fillFlags = dr->fill_flags, strokeFlags = dr->stroke_flags;
 		const uint32_t numFill = di.flags >> 1;
 		uint32_t f = 0, s = 0, subIndex = 0;
 		for (uint32_t sb = sb0; sb < sb1; ++sb) {
-			const uint64_t ci = dense ? cbase + subIndex : cbase + ps.sub_last_cmd[sb];
+			const uint64_t ci = cbase + subIndex;
 			const VgxSubRec sr = A.sub_rec[ci];
 			const uint32_t info = sr.info;
 			const uint32_t n = info & 0x7FFFFFFFu;

@@ -15,8 +15,8 @@ struct VgxFlattenArgs
 	const vgx_draw* draws;
 	uint64_t ndraws;
 	const uint64_t* cmd_prefix; // [ndraws+1]
-	const uint64_t* sub_prefix; // [ndraws+1] exclusive scan of the draws' static sub-path counts: k_flatten_inst stores its sub-path records densely,
-	                            // record j of draw d at sub_rec[sub_prefix[d] + j] (k_flatten_build: sparsely at the command instance)
+	const uint64_t* sub_prefix; // [ndraws+1] exclusive scan of the draws' static sub-path counts: the flatten kernels of vgx_tessellate store their sub-path records
+	                            // densely, record j of draw d at sub_rec[sub_prefix[d] + j]
 	uint32_t* cmd_cnt;          // [num_cmd_instances]
 	vgx_draw_info* dinfo;       // [ndraws]
 	float* poly;                // emit: [cap][2]
@@ -29,7 +29,7 @@ struct VgxFlattenArgs
 	int apply_transform;
 	// BUILD mode (single-pass flatten of vgx_tessellate): per-sub-path records stored sparsely at the command-instance
 	// index of the sub-path's last command
-	VgxSubRec* sub_rec;            // [num_cmd_instances] sparse: written at the sub-path's last command instance (BUILD mode)
+	VgxSubRec* sub_rec;            // [>= static sub-paths of the batch] record j of draw d at sub_prefix[d] + j (BUILD mode)
 	int build_mode;                // k_flatten_serial<count>: allocate the draw's vertices from the polyline heap
 	uint32_t* serial_list;         // BUILD mode: draws for k_flatten_serial (static serial paths + degenerate draws), unordered
 	float* leaf_overflow;          // [VGX_BUILD_WAVES][VGX_BUILD_OVERFLOW][64][2] leaves that did not fit the LDS slots

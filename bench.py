@@ -552,7 +552,10 @@ def main():
                        "instances_per_gpu": K if args.config == "tiger10k" else None, "draws_per_gpu": ndraws, "parallelism": "shard%d" % world,
                        "verts_per_gpu": sizes.get("num_vertices", 0), "indices_per_gpu": sizes.get("num_indices", 0), "meshes_per_gpu": sizes.get("num_meshes", 0),
                        "poly_verts_per_gpu": sizes["num_poly_vertices"], "serial_draws": sizes["num_serial_draws"],
-                       "scratch_bytes_per_gpu": res["scratch"], "output_placement": res.get("output_placement")},
+                       "scratch_bytes_per_gpu": res["scratch"], "output_placement": res.get("output_placement"),
+                       # which flatten kernel the 'flatten_build' stage is (the library decides per batch)
+                       "flatten_kernel": ("k_flatten_inst (one lane per instance: the draws repeat one sequence of paths)"
+                                          if args.config == "tiger10k" and os.environ.get("VGX_INST", "1") != "0" else "k_flatten_build (one lane per path command)")},
             "roofline": roofline(res, args.steps, traffic_for=K if args.config == "tiger10k" else None),
             "stage_ms": {k: round(v, 3) for k, v in res["stage"].items()},
             "cpu_baseline": cpu,

@@ -5,6 +5,7 @@
 
 #include "bx.h"
 #include <stdlib.h>
+#include <new>
 
 namespace bx
 {
@@ -45,6 +46,8 @@ inline void* realloc(AllocatorI* a, void* ptr, size_t size, size_t align = 0) { 
 inline void* alignedAlloc(AllocatorI* a, size_t size, size_t align) { return a->realloc(nullptr, size, align, "", 0); }
 inline void alignedFree(AllocatorI* a, void* ptr, size_t align) { if (ptr) { a->realloc(ptr, 0, align, "", 0); } }
 inline void* alignedRealloc(AllocatorI* a, void* ptr, size_t size, size_t align) { return a->realloc(ptr, size, align, "", 0); }
+template<typename T> inline void deleteObject(AllocatorI* a, T* obj, size_t align = 0) { if (obj) { obj->~T(); bx::free(a, obj, align); } }
 }
+#define BX_NEW(_allocator, _type) ::new (bx::alloc(_allocator, sizeof(_type))) _type
 
 #endif

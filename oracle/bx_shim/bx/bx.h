@@ -27,6 +27,12 @@
 #define BX_PRAGMA_DIAGNOSTIC_POP()
 #define BX_COUNTOF(_x) (sizeof(_x) / sizeof((_x)[0]))
 #define BX_FILE_LINE_LITERAL ""
+#ifndef BX_CONFIG_SUPPORTS_THREADING
+#define BX_CONFIG_SUPPORTS_THREADING 1
+#endif
+#ifndef BX_PLATFORM_EMSCRIPTEN
+#define BX_PLATFORM_EMSCRIPTEN 0
+#endif
 
 namespace bx
 {
@@ -34,6 +40,14 @@ template<typename... Args> inline void unusedArgs(Args&&...) {}
 inline void memSet(void* dst, uint8_t ch, size_t n) { ::memset(dst, ch, n); }
 inline void memCopy(void* dst, const void* src, size_t n) { ::memcpy(dst, src, n); }
 inline void memMove(void* dst, const void* src, size_t n) { ::memmove(dst, src, n); }
+inline int32_t memCmp(const void* a, const void* b, size_t n) { return ::memcmp(a, b, n); }
+// strided rows -> packed (vg.cpp:2288, texture sub-rect upload)
+inline void gather(void* dst, const void* src, uint32_t srcStride, uint32_t size, uint32_t num)
+{
+	uint8_t* d = (uint8_t*)dst; const uint8_t* s = (const uint8_t*)src;
+	for (uint32_t i = 0; i < num; ++i) { ::memcpy(d, s, size); d += size; s += srcStride; }
+}
+template<typename T> inline constexpr bool isPowerOf2(T a) { return a && !(a & (a - 1)); }
 }
 #define BX_UNUSED(...) bx::unusedArgs(__VA_ARGS__)
 

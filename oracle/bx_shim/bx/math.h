@@ -23,6 +23,20 @@ inline float ceil(float a) { return vgm_ceil(a); }
 inline float sqrt(float a) { return vgm_sqrt(a); }
 inline float square(float a) { return a * a; }
 inline float mod(float a, float b) { return ::fmodf(a, b); }
+// Only text / font-atlas code reaches these two (fontstash.h:1373 blur, stb_truetype): outside the parity scope.
+inline float exp(float a) { return ::expf(a); }
+inline float pow(float a, float b) { return ::powf(a, b); }
+// View / projection set-up of vg::end (vg.cpp:1151-1153); the matrices only travel to bgfx::setViewTransform.
+inline void mtxIdentity(float* m) { ::memset(m, 0, sizeof(float) * 16); m[0] = m[5] = m[10] = m[15] = 1.0f; }
+inline void mtxOrtho(float* m, float l, float r, float b, float t, float n, float f, float offset, bool homogeneousNdc)
+{
+	const float aa = 2.0f / (r - l), bb = 2.0f / (t - b);
+	const float cc = (homogeneousNdc ? 2.0f : 1.0f) / (f - n);
+	const float dd = (l + r) / (l - r), ee = (t + b) / (b - t);
+	const float ff = homogeneousNdc ? (n + f) / (n - f) : n / (n - f);
+	::memset(m, 0, sizeof(float) * 16);
+	m[0] = aa; m[5] = bb; m[10] = cc; m[12] = dd + offset; m[13] = ee; m[14] = ff; m[15] = 1.0f;
+}
 #ifdef VGO_SHIM_LIBM
 inline float rsqrt(float a) { return 1.0f / ::sqrtf(a); }
 inline float cos(float a) { return ::cosf(a); }

@@ -346,30 +346,84 @@ int vgx_concave_emit(vgx_ctx* ctx, const float* contour_verts, uint64_t num_cont
 /* ---- command-list byte-code as input ---------------------------------------------
  * vg::CommandList::m_CommandBuffer as the reference's cl* functions write it (src/vg.cpp:243-247, 2403-2690, 5694-5723):
  * {CommandHeader{uint32 type, uint32 size}, 16-byte aligned}{payload, 16-byte aligned}... in HOST memory.
- * vgx_cmdlist_decode replays it the way ctxSubmitCommandList does (:4332-4625) into what the batch entry points take: one
- * path per BeginPath group (vgx_pathset_desc arrays) and one vgx_draw per FillPathColor / StrokePathColor, with the
- * interpreter's state folded in (PushState / PopState / Transform* / SetViewBox / SetGlobalAlpha; stroke width scaling,
- * clamping and the Thin switch of ctxStrokePathColor :3401-3433; alpha scaling). Commands vgx_tessellate cannot express
- * (gradient / image paint, IndexedTriList, clip, scissor, text, nested lists, concave fills) are counted in num_skipped.
+ * vgx_cmdlist_decode replays it the way ctxSubmitCommandList does (:4273-4637) into what the batch entry points take: one
+ * path per BeginPath group (vgx_pathset_desc arrays) and one vgx_draw per fill / stroke command -- all six of them:
+ * FillPathColor / Gradient / ImagePattern (ctxFillPath*, :3061-3399), StrokePathColor / Gradient / ImagePattern
+ * (ctxStrokePath*, :3401-3668) -- with the interpreter's state folded in: transform stack (PushState / PopState /
+ * Transform* / SetViewBox, :3934-4122; the transform is latched at the path's first fill / stroke like transformPath
+ * :4957-4975), global alpha, stroke width scaling / clamping / Thin switch, scissor (per draw, vgx_draw_state), clip
+ * regions (BeginClip / EndClip / ResetClip, :3670-3709: the draws recorded inside are non-AA black DrawCommand::Type::Clip
+ * draws), gradients and image patterns created by the list (vgx_paint records, :3711-3932), command culling
+ * (CommandListFlags::AllowCommandCulling), and nested lists (SubmitCommandList, :4611-4620, through `lists`).
+ * vgx_draw::state_key = generation << 20 | DrawCommand::Type << 16 | handle: what allocDrawCommand / allocClipCommand
+ * compare before merging (:5359-5460); the generation changes whenever the reference sets m_ForceNewDrawCommand /
+ * m_ForceNewClipCommand between two draws (scissor changes, PopState onto a different scissor, EndClip, ResetClip).
+ * Commands without an equivalent here are counted in num_skipped and otherwise ignored: Text / TextBox, IndexedTriList,
+ * concave fills (libtess2 stays with the caller: vgx_concave_*), path commands issued after a path's first fill / stroke
+ * without a new BeginPath (the reference VG_CHECKs this, :2984-3059), nested lists without a table entry.
  * Host only, no device needed. Call with the array members NULL to get the counts, allocate, call again. */
+typedef struct vgx_cmdlist_ref {   /* one vg::CommandList, addressed by CommandListHandle::idx (SubmitCommandList) */
+	const void* bytes;             /* HOST CommandList::m_CommandBuffer */
+	uint32_t size;                 /* m_CommandBufferPos */
+	uint32_t flags;                /* m_Flags (VGX_CL_*) */
+} vgx_cmdlist_ref;
+enum { VGX_CL_CACHEABLE = 1u,      /* CommandListFlags::Cacheable: fills / strokes ignore the global alpha and transparent
+                                    * colours are not dropped while the list populates its cache (hasCache, :3063-3075) */
+       VGX_CL_ALLOW_CULLING = 2u };/* CommandListFlags::AllowCommandCulling (:4299-4300, 4548-4577) */
 typedef struct vgx_cmdlist_state { /* the Context / State values at submission */
 	float mtx[6];          /* State::m_TransformMtx */
 	float global_alpha;    /* State::m_GlobalAlpha */
 	float tess_tol;        /* Context::m_TesselationTolerance */
 	float fringe;          /* Context::m_FringeWidth */
-	float canvas_width;    /* Context::m_CanvasWidth / Height (SetViewBox only) */
+	float canvas_width;    /* Context::m_CanvasWidth / Height (SetViewBox, scissor clamps) */
 	float canvas_height;
-	uint32_t reserved;
+	uint32_t flags;        /* VGX_CL_* of the list being decoded */
+	float scissor[4];      /* State::m_ScissorRect; all zero = {0, 0, canvas_width, canvas_height} (resetScissor) */
+	uint32_t first_gradient;      /* Context::m_NextGradientID at submission (local handles are relative to it) */
+	uint32_t first_image_pattern; /* Context::m_NextImagePatternID */
+	uint32_t max_gradients;       /* Config::m_MaxGradients, 0 = 64 */
+	uint32_t max_image_patterns;  /* Config::m_MaxImagePatterns, 0 = 64 */
+	uint32_t max_depth;           /* Config::m_MaxCommandListDepth, 0 = 16 */
+	uint32_t num_lists;           /* entries of `lists` */
+	const vgx_cmdlist_ref* lists; /* HOST handle -> list table for SubmitCommandList; NULL: nested lists are skipped */
+	uint16_t prev_cmd_scissor[4]; /* scissor of the frame's last draw command before this list (PopState rule, :3950-3965) */
+	uint32_t prev_cmd_valid;      /* 0: the frame has no draw command yet */
+	uint32_t first_generation;    /* generation of the first draw's state_key (chain successive decodes of one frame) */
 } vgx_cmdlist_state;
+typedef struct vgx_draw_state {   /* per draw: what allocDrawCommand copies into the DrawCommand (vg.cpp:5391-5400). 24 bytes */
+	uint16_t scissor[4];          /* (uint16_t) State::m_ScissorRect */
+	uint32_t clip_rule;           /* ClipState::m_Rule (0 In, 1 Out) */
+	uint32_t clip_first_draw;     /* the active clip region = the Clip draws [clip_first_draw, + clip_num_draws) of this
+	                               * decode (the reference stores the range of clip COMMANDS they merge into); 0xFFFFFFFF = none */
+	uint32_t clip_num_draws;
+	uint32_t reserved;
+} vgx_draw_state;
+typedef struct vgx_paint {        /* vg::Gradient / vg::ImagePattern as the Create* calls compute them (vg.cpp:84-96). 96 bytes */
+	uint32_t type;                /* DrawCommand::Type of the draws that use it: 1 ColorGradient, 2 ImagePattern */
+	uint32_t handle;              /* the id in the low 16 bits of those draws' state_key */
+	float matrix[9];              /* m_Matrix */
+	float params[4];              /* Gradient::m_Params {extent.x, extent.y, radius, feather} */
+	float inner_color[4];
+	float outer_color[4];
+	uint32_t image;               /* ImagePattern::m_ImageHandle */
+} vgx_paint;
 typedef struct vgx_cmdlist_out {
 	uint8_t* cmd_type;        /* HOST [cap_cmds]      -> vgx_pathset_desc.cmd_type */
 	uint32_t* cmd_arg_off;    /* HOST [cap_cmds + 1] */
 	float* args;              /* HOST [cap_args] */
 	uint32_t* path_cmd_begin; /* HOST [cap_paths + 1] */
 	vgx_draw* draws;          /* HOST [cap_draws]; vgx_draw.path indexes the paths produced here */
-	uint32_t cap_cmds, cap_args, cap_paths, cap_draws;
-	uint32_t num_cmds, num_args, num_paths, num_draws; /* out */
+	vgx_draw_state* draw_state; /* HOST [cap_draws], may be NULL */
+	vgx_paint* paints;        /* HOST [cap_paints], may be NULL */
+	uint32_t cap_cmds, cap_args, cap_paths, cap_draws, cap_paints;
+	uint32_t num_cmds, num_args, num_paths, num_draws, num_paints; /* out */
 	uint32_t num_skipped;     /* out: commands without an equivalent in this path */
+	uint32_t next_gradient;   /* out: Context::m_NextGradientID / m_NextImagePatternID after the list */
+	uint32_t next_image_pattern;
+	uint32_t next_generation; /* out: first_generation for the next decode of the same frame */
+	float end_mtx[6];         /* out: State::m_TransformMtx / m_GlobalAlpha after the list (state changes of a list leak into
+	                           * its caller unless VG_CONFIG_COMMAND_LIST_PRESERVE_STATE, vg.cpp:4323-4325) */
+	float end_global_alpha;
 	uint32_t reserved;
 } vgx_cmdlist_out;
 int vgx_cmdlist_decode(const void* bytes, uint32_t size, const vgx_cmdlist_state* state, vgx_cmdlist_out* out);

@@ -26,7 +26,7 @@ struct ShimAllocator : public AllocatorI
 			return nullptr;
 		}
 		const size_t total = size + align + sizeof(void*) * 2;
-		uint8_t* base = (uint8_t*)::malloc(total);
+		uint8_t* base = (uint8_t*)::calloc(1, total); // zeroed: padding bytes of command lists / pooled vertex buffers are deterministic
 		uintptr_t p = ((uintptr_t)base + sizeof(void*) * 2 + (align - 1)) & ~(uintptr_t)(align - 1);
 		void** hdr = (void**)p;
 		hdr[-2] = base;

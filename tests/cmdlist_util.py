@@ -71,8 +71,10 @@ class Recorder:
         return bytes(self.buf)
 
 
-def decode(rt, data, mtx=(1, 0, 0, 1, 0, 0), global_alpha=1.0, tess_tol=0.25, fringe=1.0, canvas=(1280.0, 720.0)):
-    """vgx_cmdlist_decode, count pass + store pass. Returns (status, PathSetArrays or None, draws ndarray, info dict)."""
+def decode(rt, data, mtx=(1, 0, 0, 1, 0, 0), global_alpha=1.0, tess_tol=0.25, fringe=1.0, canvas=(1280.0, 720.0), flags=0,
+           lists=None, first_gradient=0, first_image_pattern=0, extra=None):
+    """vgx_cmdlist_decode, count pass + store pass. Returns (status, PathSetArrays or None, draws ndarray, info dict).
+    lists: {handle: (bytes, flags)} for SubmitCommandList. extra: dict that receives draw_state / paints / the out struct."""
     import ctypes as C
     import importlib
     capi = rt.capi
@@ -82,19 +84,38 @@ def decode(rt, data, mtx=(1, 0, 0, 1, 0, 0), global_alpha=1.0, tess_tol=0.25, fr
         st.mtx[i] = mtx[i]
     st.global_alpha = global_alpha; st.tess_tol = tess_tol; st.fringe = fringe
     st.canvas_width, st.canvas_height = canvas
+    st.flags = flags
+    st.first_gradient = first_gradient; st.first_image_pattern = first_image_pattern
+    keep = []
+    if lists:
+        n = max(lists) + 1
+        arr = (capi.CmdListRef * n)()
+        for h, (b, fl) in lists.items():
+            cb = (C.c_uint8 * max(len(b), 1)).from_buffer_copy(b if len(b) else b"\0")
+            keep.append(cb)
+            arr[h].bytes = C.cast(cb, C.c_void_p); arr[h].size = len(b); arr[h].flags = fl
+        st.lists = arr; st.num_lists = n
     out = capi.CmdListOut()
     buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data if len(data) else b"\0")
     rc = rt.lib().vgx_cmdlist_decode(buf, len(data), C.byref(st), C.byref(out))
     if rc != 0:
         return rc, None, None, None
     n = {k: int(getattr(out, "num_" + k)) for k in ("cmds", "args", "paths", "draws", "skipped")}
+    npaints = int(out.num_paints)
     cmd_type = np.zeros(max(n["cmds"], 1), np.uint8)
     arg_off = np.zeros(n["cmds"] + 1, np.uint32)
     args = np.zeros(max(n["args"], 1), np.float32)
     pcb = np.zeros(n["paths"] + 1, np.uint32)
     draws = np.zeros(max(n["draws"], 1), capi.draw_dtype)
+    dstate = np.zeros(max(n["draws"], 1), capi.draw_state_dtype)
+    paints = np.zeros(max(npaints, 1), capi.paint_dtype)
     out.cmd_type, out.cmd_arg_off, out.args, out.path_cmd_begin, out.draws = (cmd_type.ctypes.data, arg_off.ctypes.data, args.ctypes.data, pcb.ctypes.data, draws.ctypes.data)
-    out.cap_cmds, out.cap_args, out.cap_paths, out.cap_draws = n["cmds"], n["args"], n["paths"], n["draws"]
+    out.draw_state, out.paints = dstate.ctypes.data, paints.ctypes.data
+    out.cap_cmds, out.cap_args, out.cap_paths, out.cap_draws, out.cap_paints = n["cmds"], n["args"], n["paths"], n["draws"], npaints
     rc = rt.lib().vgx_cmdlist_decode(buf, len(data), C.byref(st), C.byref(out))
     ps = pathset.PathSetArrays(cmd_type[:n["cmds"]], arg_off, args[:n["args"]], pcb)
+    if extra is not None:
+        extra["draw_state"] = dstate[:n["draws"]]
+        extra["paints"] = paints[:npaints]
+        extra["out"] = out
     return rc, ps, draws[:n["draws"]], n

@@ -1,7 +1,9 @@
-"""the reference's command-list byte-code as input (vgx_cmdlist_decode, host only). Parity UNPINNED in the
-sense of the task: src/vg.cpp needs bgfx and cannot be compiled, so the decoder is pinned by (1) a byte stream written out
-by hand below, byte for byte, with its expected decode, (2) the interpreter's state arithmetic restated independently in
-numpy, and (3) the Tiger drawing recorded through the test-side writer and compared with the direct vgx_pathset_desc route."""
+"""the reference's command-list byte-code as input (vgx_cmdlist_decode, host only). These cases need no
+reference build: (1) a byte stream written out by hand below, byte for byte, with its expected decode, (2) the interpreter's
+state arithmetic restated independently in numpy, and (3) the Tiger drawing recorded through the test-side writer
+(tests/cmdlist_util.py, itself checked byte for byte against the reference's vg::clXxx writers in test_cmdlist_ref.py) and
+compared with the direct vgx_pathset_desc route. The reference-pinned tests (lists recorded by the reference's own writers,
+frames compared with what vg::submitCommandList + vg::end produce) are in tests/test_cmdlist_ref.py."""
 import importlib
 import struct
 
@@ -66,12 +68,15 @@ def test_state_commands_and_stroke_scaling(rt, wl):
     r.pop_state()
     r.begin_path(); r.circle(1, 1, 4)
     r.fill_path(0xFFFFFFFF, cu.fill_flags(aa=False))
-    r.set_scissor(0, 0, 10, 10)                                          # skipped (counted)
-    r.fill_path(0xFFFFFFFF, cu.fill_flags(concave=True))                # concave: skipped
+    r.set_scissor(0, 0, 10, 10)                                          # folded into the draws' scissor + state_key generation
+    r.fill_path(0xFFFFFFFF, cu.fill_flags(concave=True))                # concave: skipped (libtess2 stays with the caller)
     r.fill_path(0x00FFFFFF, cu.fill_flags())                            # alpha 0: the reference returns early, not "skipped"
-    r.fill_path_gradient(cu.fill_flags(), 1, 0)                         # gradient paint: skipped
-    rc, ps, draws, n = cu.decode(rt, r.bytes())
-    assert rc == 0 and n["paths"] == 2 and n["draws"] == 4 and n["skipped"] == 3
+    r.fill_path_gradient(cu.fill_flags(), 1, 0)                         # gradient paint: a draw of type ColorGradient, handle 1
+    extra = {}
+    rc, ps, draws, n = cu.decode(rt, r.bytes(), extra=extra)
+    assert rc == 0 and n["paths"] == 2 and n["draws"] == 5 and n["skipped"] == 1
+    assert int(draws["state_key"][4]) == (1 << 20) | (1 << 16) | 1 and int(draws["fill_color"][4]) == 0xFF000000
+    assert extra["draw_state"]["scissor"][4].tolist() == [0, 0, 10, 10] and extra["draw_state"]["scissor"][3].tolist() == [0, 0, 1280, 720]
     # the state arithmetic, restated (float32 throughout, vg.cpp:4044-4082, 4927-4935; cos / sin are csrc/vgmath.h's)
     f32 = np.float32
     m = np.array([1, 0, 0, 1, 0, 0], f32)
@@ -98,8 +103,9 @@ def test_state_commands_and_stroke_scaling(rt, wl):
     assert int(draws["fill_flags"][3]) == rt.capi.FILL_ENABLE
 
 
-def test_path_continues_after_fill(rt):
-    """BeginPath, rect, Fill, circle, Stroke: the reference's Path keeps growing, the stroke sees rect + circle."""
+def test_path_commands_after_the_first_fill(rt):
+    """BeginPath, rect, Fill, circle, Stroke: the reference VG_CHECKs path commands after a path's first fill / stroke
+    (vg.cpp:2984-3059); the decoder does not replay them (counted in num_skipped), the stroke sees the rect."""
     r = cu.Recorder()
     r.begin_path(); r.rect(0, 0, 5, 5)
     r.fill_path(0xFF0000FF, cu.fill_flags())
@@ -107,10 +113,10 @@ def test_path_continues_after_fill(rt):
     r.stroke_path(0xFF00FF00, 3.0, cu.stroke_flags(0, 0))
     rc, ps, draws, n = cu.decode(rt, r.bytes())
     capi = rt.capi
-    assert rc == 0 and n["paths"] == 2 and n["draws"] == 2
-    assert ps.path_cmd_begin.tolist() == [0, 1, 3]
-    assert ps.cmd_type.tolist() == [capi.CMD_RECT, capi.CMD_RECT, capi.CMD_CIRCLE]
-    assert draws["path"].tolist() == [0, 1]
+    assert rc == 0 and n["paths"] == 1 and n["draws"] == 2 and n["skipped"] == 1
+    assert ps.path_cmd_begin.tolist() == [0, 1]
+    assert ps.cmd_type.tolist() == [capi.CMD_RECT]
+    assert draws["path"].tolist() == [0, 0]
 
 
 def test_malformed_streams_are_rejected(rt):

@@ -1,0 +1,339 @@
+"""SURVEY 8(f)-1 + 8(f)-2 pinned against the reference ITSELF (oracle/_ref/libvgref_vg.so = the reference's src/vg.cpp
+compiled unmodified behind a recording bgfx stand-in, oracle/ref_vg_capi.cpp):
+
+  frames are recorded with the reference's own vg::clXxx writers (vg.cpp:2403-2967), the bytes of
+  CommandList::m_CommandBuffer go through vgx_cmdlist_decode, the decoded batch through the tessellator and the
+  draw-command assembly, and the result is compared bit for bit with what vg::submitCommandList + vg::end hand to bgfx
+  for the same list (vertex buffers, index buffer, draw / clip command tables: vg.cpp:1076-1288, 4273-4637, 5207-5460).
+
+CPU tests run the decoded batch through the reference's path / stroker sources (oracle/_ref/libvgref.so) and the restated
+assembler (which pins that restatement); the -m gpu tests run it through vgx_tessellate with vgx_set_assembly armed."""
+import importlib
+
+import numpy as np
+import pytest
+
+import pyvgref as R
+import cmdlist_util as cu
+import frameref as F
+from vgscript import Script, LOCAL, add_path
+
+pytestmark = pytest.mark.skipif(not R.available(), reason="oracle/_ref/libvgref_vg.so not built (needs /root/reference)")
+
+AA = R.fill_flags(True)
+NOAA = R.fill_flags(False)
+
+
+@pytest.fixture(scope="module")
+def rt():
+    return importlib.import_module("vg-renderer_amd.runtime")
+
+
+# ---- scenarios -------------------------------------------------------------------------------------------------------------
+def s_tiger(wl, K=2):
+    ps, ops = wl.tiger_paths()
+    s = Script()
+    for i in range(K):
+        s.push().translate(37.0 * (i % 100), 41.0 * (i // 100))
+        for p, o in enumerate(ops):
+            add_path(s, ps, p)
+            s.fill(o["fill_color"], AA)
+            if o["stroke"]:
+                s.stroke(o["stroke_color"], o["stroke_width"], R.stroke_flags(0, 0, True))
+        s.pop()
+    return s
+
+
+def s_paints(wl=None):
+    """All six fill / stroke commands, AA and not, local gradient / image-pattern handles, type / handle changes between
+    consecutive meshes (allocDrawCommand's merge rule), global alpha, rotated and scaled states."""
+    s = Script()
+    g0 = 0 | LOCAL
+    s.linear_gradient(10, 10, 200, 120, 0xFF0000FF, 0x8000FF00)         # local gradient 0
+    s.push().translate(50, 40).rotate(0.3).scale(1.5, 0.75)
+    s.box_gradient(0, 0, 100, 60, 8, 12, 0xFFFFFFFF, 0x00000000)        # local gradient 1, under the transformed state
+    s.begin_path().rounded_rect(0, 0, 100, 60, 8).fill_gradient(1 | LOCAL, AA)
+    s.begin_path().rect(120, 0, 40, 40).fill_gradient(1 | LOCAL, NOAA)  # same handle: merges into the previous command
+    s.begin_path().circle(60, 120, 30).fill_gradient(g0, AA)            # handle changes: new command
+    s.begin_path().circle(160, 120, 30).fill(0xC0336699, AA)            # type changes
+    s.global_alpha(0.6)
+    s.begin_path().ellipse(60, 200, 40, 20).fill(0xC0336699, NOAA)
+    s.begin_path().ellipse(160, 200, 40, 20).fill_gradient(g0, NOAA)    # black with alpha 0xff * globalAlpha
+    s.radial_gradient(300, 100, 10, 80, 0xFF102030, 0xFFF0E0D0)         # local gradient 2
+    s.begin_path().move_to(250, 50).line_to(350, 60).line_to(340, 150).line_to(260, 140).close_path()
+    s.stroke_gradient(2 | LOCAL, 6.0, R.stroke_flags(1, 1, True))
+    s.stroke_gradient(2 | LOCAL, 0.4, R.stroke_flags(0, 2, True))        # thin: AAThin
+    s.stroke_gradient(2 | LOCAL, 3.0, R.stroke_flags(2, 0, False))
+    s.image_pattern(0, 0, 64, 32, 0.7, 0)                                # image 0 = the font atlas image the Context creates
+    s.begin_path().rect(400, 50, 90, 70)
+    s.fill_image(0 | LOCAL, 0xFFFFFFFF, AA)
+    s.stroke_image(0 | LOCAL, 0x80FFFFFF, 5.0, R.stroke_flags(0, 0, True))
+    s.stroke_image(0 | LOCAL, 0xFFFFFFFF, 0.5, R.stroke_flags(0, 0, True))   # thin, alpha scaled the image-pattern way (sic)
+    s.stroke_image(0 | LOCAL, 0x01FFFFFF, 5.0, R.stroke_flags(0, 0, True))   # alpha 1 * 0.6 -> 0: dropped
+    s.pop()
+    s.begin_path().rect(600, 300, 50, 50).fill_image(0 | LOCAL, 0x40FFFFFF, NOAA)
+    s.begin_path().rect(700, 300, 50, 50).fill(0xFF00FFFF, AA).stroke(0xFF000000, 2.0, R.stroke_flags(0, 0, True))
+    return s
+
+
+def s_scissor_clip(wl=None):
+    s = Script()
+    s.begin_path().rect(10, 10, 100, 100).fill(0xFF0000FF, AA)
+    s.begin_path().rect(20, 20, 100, 100).fill(0xFF00FF00, AA)          # merges
+    s.set_scissor(0, 0, 300, 200)
+    s.begin_path().rect(30, 30, 100, 100).fill(0xFFFF0000, AA)          # scissor changed: new command
+    s.push().intersect_scissor(50, 50, 100, 100)
+    s.begin_path().circle(100, 100, 60).fill(0xFFFFFFFF, AA)
+    s.pop()                                                             # back to the 300 x 200 scissor: differs from the last command's
+    s.begin_path().circle(100, 100, 20).fill(0xFF808080, AA)
+    s.push().translate(5, 5)
+    s.begin_path().circle(100, 100, 10).fill(0xFF808080, AA)
+    s.pop()                                                             # same scissor as the last command: no new command
+    s.begin_path().circle(100, 100, 5).fill(0xFF808080, AA)
+    s.reset_scissor()
+    s.begin_clip(0)
+    s.begin_path().rect(200, 200, 300, 300).fill(0xFF123456, AA)        # clip mesh: black, no AA
+    s.begin_path().move_to(210, 210).line_to(400, 220).line_to(300, 400).stroke(0x00123456, 12.0, R.stroke_flags(1, 1, True))
+    s.end_clip()
+    s.begin_path().rect(250, 250, 100, 100).fill(0xFF0000FF, AA)
+    s.begin_path().rect(260, 260, 100, 100).fill(0xFF0000FF, NOAA)
+    s.reset_clip()
+    s.begin_path().rect(270, 270, 100, 100).fill(0xFF0000FF, AA)        # clip state changed: new command
+    s.reset_clip()                                                      # no clip active: no effect
+    s.begin_path().rect(280, 280, 100, 100).fill(0xFF0000FF, AA)        # merges
+    s.begin_clip(1)
+    s.begin_path().circle(600, 300, 50).fill(0xFFFFFFFF, NOAA)
+    s.end_clip()
+    s.set_scissor(500, 200, 300, 300)
+    s.begin_path().circle(620, 320, 50).stroke(0xFFFFFFFF, 0.5, R.stroke_flags(0, 0, True))
+    return s
+
+
+def s_latch(wl=None):
+    """The path is transformed ONCE, at its first fill / stroke (transformPath, vg.cpp:4957-4975)."""
+    s = Script()
+    s.begin_path().rect(10, 10, 50, 50)
+    s.fill(0xFF0000FF, AA)
+    s.translate(100, 0).scale(2, 2)
+    s.stroke(0xFF00FF00, 3.0, R.stroke_flags(0, 0, True))   # drawn where the fill was; width scaled by the CURRENT avgScale
+    s.begin_path().circle(30, 30, 10)                       # new path: latched scale 2, tolerance follows
+    s.fill(0x00FFFFFF, AA)                                   # transparent: returns before transformPath
+    s.translate(7, 9)
+    s.fill(0xFFFFFFFF, AA)                                   # first transformPath of this path: translated
+    s.rotate(1.0)
+    s.fill(0xFF0000FF, NOAA)                                 # still the latched transform
+    return s
+
+
+def s_every_command(wl):
+    """Arcs, rounded rects, polylines, quads ... with every cap / join, thin and fixed-width strokes."""
+    ps = wl.fuzz_paths(3, npaths=40)
+    rs = np.random.RandomState(5)
+    s = Script()
+    s.scale(1.25, 1.25).translate(300, 300)
+    for p in range(ps.npaths):
+        add_path(s, ps, p)
+        if rs.uniform() < 0.6:
+            s.fill(int(rs.randint(0, 1 << 32, dtype=np.uint64)) | 0x40000000, AA if rs.uniform() < 0.7 else NOAA)
+        if rs.uniform() < 0.8:
+            s.stroke(int(rs.randint(0, 1 << 32, dtype=np.uint64)) | 0x40000000, float(rs.choice([0.3, 0.9, 1.5, 3.0, 10.0, 40.0, 300.0])),
+                     R.stroke_flags(int(rs.randint(0, 3)), int(rs.randint(0, 3)), bool(rs.uniform() < 0.75), bool(rs.uniform() < 0.2)))
+    return s
+
+
+SCENARIOS = {"tiger": s_tiger, "paints": s_paints, "scissor_clip": s_scissor_clip, "latch": s_latch, "every_command": s_every_command}
+
+
+# ---- CPU: decoder + restated assembler against the reference's frame ---------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+@pytest.mark.parametrize("max_vb", [65536, 3000])
+def test_decoded_frame_matches_reference_frame(rt, wl, oracle, name, max_vb):
+    if name == "every_command" and max_vb == 3000:
+        pytest.skip("round-join meshes exceed 3000 vertices")
+    script = SCENARIOS[name](wl)
+    ref = F.reference_frame(script, max_vb=max_vb)
+    ps, draws, n, extra = F.decode(rt, ref)
+    assert n["skipped"] == 0
+    res, cmds, idx = F.cpu_frame(oracle, ps, draws, max_vb)
+    F.assert_frame_equal(ref["frame"], res.pos, res.color, idx, res.meshes, cmds, draws, extra["draw_state"], max_vb, what=name)
+
+
+def test_immediate_mode_frame_equals_submitted_list(wl):
+    """The reference with itself: playing the calls on the Context and submitting the recorded list give the same frame
+    (what makes the list's bytes a complete description of the frame)."""
+    s = s_paints()
+    a = F.reference_frame(s)["frame"]
+    # immediate mode hands out global handles: play the same script with the LOCAL flag stripped
+    g = Script()
+    for code, f, u in s.ops:
+        if code in (R.FillPathGradient, R.FillPathImagePattern, R.StrokePathGradient, R.StrokePathImagePattern):
+            u = (u[0], u[1], 0) + tuple(u[3:])
+        g.add(code, f, u)
+    b = F.reference_frame(g, immediate=True)["frame"]
+    assert np.array_equal(a.idx, b.idx) and len(a.drawcmds) == len(b.drawcmds)
+    for k in a.drawcmds.dtype.names:
+        assert np.array_equal(a.drawcmds[k], b.drawcmds[k]), k
+    pa, ca, _ = R.frame_streams(a)
+    pb, cb, _ = R.frame_streams(b)
+    assert np.array_equal(pa.view(np.uint32), pb.view(np.uint32)) and np.array_equal(ca, cb)
+
+
+def test_paint_records_match_the_uniforms_the_reference_submits(rt, wl):
+    """vgx_paint = Gradient / ImagePattern as ctxCreate* compute them (vg.cpp:3711-3932), compared with the uniforms
+    vg::end sets for the draw commands that use them (:1252-1283)."""
+    ref = F.reference_frame(s_paints())
+    ps, draws, n, extra = F.decode(rt, ref)
+    paints = extra["paints"]
+    assert len(paints) == 4 and paints["type"].tolist() == [1, 1, 1, 2] and paints["handle"].tolist() == [0, 1, 2, 0]
+    seen = set()
+    for sub in ref["frame"].submits:
+        t = int(sub["program"])
+        if t not in (1, 2):
+            continue
+        cmd = [c for c in ref["frame"].drawcmds if int(c["first_index"]) == int(sub["first_index"])][0]
+        p = paints[(paints["type"] == t) & (paints["handle"] == int(cmd["handle"]))][0]
+        assert np.array_equal(p["matrix"].view(np.uint32), sub["paint_mat"].view(np.uint32)), (t, p["matrix"], sub["paint_mat"])
+        if t == 1:
+            for k in ("params", "inner_color", "outer_color"):
+                assert np.array_equal(p[k].view(np.uint32), sub[k].view(np.uint32)), k
+        seen.add((t, int(cmd["handle"])))
+    assert seen == {(1, 0), (1, 1), (1, 2), (2, 0)}
+
+
+def test_nested_lists_and_local_handles(rt, wl, oracle):
+    """SubmitCommandList (vg.cpp:4611-4620): a parent submits two children, one of them twice under different
+    transforms; each submission gets its own block of gradient ids (firstGradientID = m_NextGradientID, :4304)."""
+    child_a = Script()
+    child_a.linear_gradient(0, 0, 50, 50, 0xFF0000FF, 0xFFFF0000)
+    child_a.begin_path().rect(0, 0, 50, 50).fill_gradient(0 | LOCAL, AA)
+    child_a.begin_path().circle(25, 25, 12).fill(0xFFFFFFFF, AA)
+    child_b = Script()
+    child_b.translate(3, 4)                                   # leaks into the parent (no PRESERVE_STATE)
+    child_b.begin_path().rounded_rect(0, 0, 80, 40, 6).stroke(0xFF00FF00, 2.5, R.stroke_flags(1, 1, True))
+    parent = Script()
+    parent.radial_gradient(100, 100, 5, 50, 0xFFFFFFFF, 0xFF000000)     # parent's local gradient 0
+    parent.push().translate(100, 100).submit(0).pop()
+    parent.push().translate(300, 100).scale(2, 2).submit(0).pop()
+    parent.submit(1)
+    parent.begin_path().circle(100, 100, 50).fill_gradient(0 | LOCAL, AA)
+    parent.submit(1)                                          # again, now on top of the leaked translation
+    parent.submit(7)                                          # not a list: ignored
+    ref = F.reference_frame(parent, children=[(child_a, 0), (child_b, 0)])
+    assert ref["root"] == 2
+    ps, draws, n, extra = F.decode(rt, ref)
+    assert n["skipped"] == 1  # the submit of the invalid handle
+    res, cmds, idx = F.cpu_frame(oracle, ps, draws, 65536)
+    F.assert_frame_equal(ref["frame"], res.pos, res.color, idx, res.meshes, cmds, draws, extra["draw_state"], 65536, what="nested")
+    assert extra["paints"]["handle"].tolist() == [0, 1, 2]
+    assert int(extra["out"].next_gradient) == 3
+
+
+def test_command_culling(rt, wl, oracle):
+    """CommandListFlags::AllowCommandCulling: fills / strokes under a zero-sized scissor are not executed (vg.cpp:4335-4338)."""
+    s = Script()
+    s.begin_path().rect(0, 0, 10, 10).fill(0xFF0000FF, AA)
+    s.set_scissor(2000, 2000, 50, 50)                         # outside the canvas: clamps to zero size
+    s.begin_path().rect(0, 0, 10, 10).fill(0xFF0000FF, AA).stroke(0xFF0000FF, 2.0, R.stroke_flags(0, 0, True))
+    s.push().set_scissor(10, 10, 50, 50)
+    s.begin_path().rect(20, 20, 10, 10).fill(0xFF00FF00, AA)
+    s.intersect_scissor(500, 500, 10, 10)                     # empty intersection
+    s.begin_path().rect(20, 20, 10, 10).fill(0xFF00FF00, AA)
+    s.pop()                                                   # back to the zero-sized scissor
+    s.begin_path().rect(20, 20, 10, 10).fill(0xFF00FF00, AA)
+    s.reset_scissor()
+    s.begin_path().rect(40, 40, 10, 10).fill(0xFFFF0000, AA)
+    for flags in (R.CL_ALLOW_CULLING, 0):
+        ref = F.reference_frame(s, flags=flags)
+        ps, draws, n, extra = F.decode(rt, ref, flags=flags)
+        assert len(draws) == (3 if flags else 7)
+        res, cmds, idx = F.cpu_frame(oracle, ps, draws, 65536)
+        F.assert_frame_equal(ref["frame"], res.pos, res.color, idx, res.meshes, cmds, draws, extra["draw_state"], 65536, what="cull%d" % flags)
+
+
+def test_path_commands_after_the_first_fill_are_not_replayed(rt):
+    """The reference VG_CHECKs (debug builds only) that no path command follows a path's first fill / stroke without a
+    new BeginPath (vg.cpp:2984-3059); release builds would read stale transformed vertices. The decoder counts them."""
+    s = Script()
+    s.begin_path().rect(0, 0, 5, 5).fill(0xFF0000FF, AA)
+    s.circle(9, 9, 2)
+    s.stroke(0xFF00FF00, 3.0, R.stroke_flags(0, 0, True))
+    with R.RefContext() as rc:
+        cl, data = F.record(rc, s)
+    rc_, ps, draws, n = cu.decode(rt, data)
+    assert rc_ == 0 and n["paths"] == 1 and n["draws"] == 2 and n["skipped"] == 1
+    assert ps.cmd_type.tolist() == [rt.capi.CMD_RECT] and draws["path"].tolist() == [0, 0]
+
+
+def test_test_side_writer_produces_the_reference_bytes(wl):
+    """tests/cmdlist_util.Recorder (used where libvgref_vg.so is absent) against the reference's writers, byte for byte."""
+    r = cu.Recorder()
+    s = Script()
+    for o in (r, s):
+        o.push_state() if o is r else o.push()
+        o.transform_translate(10, 20) if o is r else o.translate(10, 20)
+        o.begin_path(); o.move_to(1, 2); o.line_to(3, 4); o.cubic_to(5, 6, 7, 8, 9, 10); o.close_path()
+        o.rect(0, 0, 5, 5); o.circle(1, 1, 4)
+    r.fill_path(0xFF112233, AA); s.fill(0xFF112233, AA)
+    r.stroke_path(0xFF445566, 2.0, R.stroke_flags(1, 2, True)); s.stroke(0xFF445566, 2.0, R.stroke_flags(1, 2, True))
+    r.pop_state(); s.pop()
+    with R.RefContext() as rc:
+        cl, data = F.record(rc, s)
+    assert data == r.bytes()
+
+
+# ---- GPU: the same frames through vgx_tessellate + vgx_set_assembly ------------------------------------------------------------
+def gpu_frame(rt, gpu_ctx, ps, draws, max_vb, uv_bytes=4, uv_value=0):
+    import torch
+    pset = rt.PathSet(gpu_ctx, ps)
+    dd = rt.upload_draws(draws)
+    sizes = rt.tessellate_count(gpu_ctx, pset, dd, draws.shape[0])
+    nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
+    bufs = rt.MeshBuffers(dd.device, nv, ni, nm)
+    cap = nm + 2
+    cmds = torch.zeros(cap * 48, dtype=torch.uint8, device=dd.device)
+    ncmd = torch.zeros(1, dtype=torch.int64, device=dd.device)
+    assert uv_bytes == 4  # VG_CONFIG_UV_INT16 (the reference's default build)
+    uv = torch.zeros((max(nv, 1), 2), dtype=torch.int16, device=dd.device)
+    gpu_ctx.set_assembly(cmds, max_vb, ncmd, split_state=True, uv=uv, uv_value=(uv_value, 0))
+    try:
+        rt.tessellate_async(gpu_ctx, pset, dd, draws.shape[0], bufs)
+        torch.cuda.synchronize()
+    finally:
+        gpu_ctx.set_assembly(None)
+    assert int(bufs.dev_status.item()) == 0
+    n = int(ncmd.item())
+    out = dict(cmds=cmds[:n * 48].cpu().numpy().view(rt.capi.drawcmd_dtype), idx=bufs.idx[:ni].cpu().numpy().view(np.uint16),
+               pos=bufs.pos[:nv].cpu().numpy(), color=bufs.color[:nv].cpu().numpy().view(np.uint32),
+               meshes=bufs.meshes[:nm * 32].cpu().numpy().view(rt.capi.mesh_dtype), uv=uv[:nv].cpu().numpy())
+    pset.close()
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+@pytest.mark.parametrize("max_vb", [65536, 3000])
+def test_gpu_frame_matches_reference_frame(rt, wl, gpu_ctx, name, max_vb):
+    if name == "every_command" and max_vb == 3000:
+        pytest.skip("round-join meshes exceed 3000 vertices")
+    script = SCENARIOS[name](wl, 4) if name == "tiger" else SCENARIOS[name](wl)
+    ref = F.reference_frame(script, max_vb=max_vb)
+    ps, draws, n, extra = F.decode(rt, ref)
+    white, nb = ref["white_uv"]
+    got = gpu_frame(rt, gpu_ctx, ps, draws, max_vb, uv_bytes=nb, uv_value=int(white[0]))
+    F.assert_frame_equal(ref["frame"], got["pos"], got["color"], got["idx"], got["meshes"], got["cmds"], draws, extra["draw_state"], max_vb,
+                         uv=got["uv"], what=name)
+
+
+@pytest.mark.gpu
+def test_gpu_nested_lists(rt, wl, gpu_ctx):
+    child = Script()
+    child.linear_gradient(0, 0, 50, 50, 0xFF0000FF, 0xFFFF0000)
+    child.begin_path().rect(0, 0, 50, 50).fill_gradient(0 | LOCAL, AA)
+    child.begin_path().circle(25, 25, 12).fill(0xFFFFFFFF, AA).stroke(0xFF000000, 0.7, R.stroke_flags(0, 0, True))
+    parent = Script()
+    for i in range(40):
+        parent.push().translate(30.0 * (i % 8), 60.0 * (i // 8)).rotate(0.1 * i).submit(0).pop()
+    ref = F.reference_frame(parent, children=[(child, 0)], max_vb=2048)
+    ps, draws, n, extra = F.decode(rt, ref)
+    got = gpu_frame(rt, gpu_ctx, ps, draws, 2048)
+    F.assert_frame_equal(ref["frame"], got["pos"], got["color"], got["idx"], got["meshes"], got["cmds"], draws, extra["draw_state"], 2048, what="nested")

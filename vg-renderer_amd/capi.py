@@ -120,16 +120,33 @@ class StageTimes(C.Structure):
     _fields_ = [("num_stages", C.c_uint32), ("ms", C.c_float * VGX_MAX_STAGES), ("name", C.c_char_p * VGX_MAX_STAGES)]
 
 
+class CmdListRef(C.Structure):
+    _fields_ = [("bytes", C.c_void_p), ("size", C.c_uint32), ("flags", C.c_uint32)]
+
+
 class CmdListState(C.Structure):
     _fields_ = [("mtx", C.c_float * 6), ("global_alpha", C.c_float), ("tess_tol", C.c_float), ("fringe", C.c_float),
-                ("canvas_width", C.c_float), ("canvas_height", C.c_float), ("reserved", C.c_uint32)]
+                ("canvas_width", C.c_float), ("canvas_height", C.c_float), ("flags", C.c_uint32),
+                ("scissor", C.c_float * 4), ("first_gradient", C.c_uint32), ("first_image_pattern", C.c_uint32),
+                ("max_gradients", C.c_uint32), ("max_image_patterns", C.c_uint32), ("max_depth", C.c_uint32),
+                ("num_lists", C.c_uint32), ("lists", C.POINTER(CmdListRef)), ("prev_cmd_scissor", C.c_uint16 * 4),
+                ("prev_cmd_valid", C.c_uint32), ("first_generation", C.c_uint32)]
 
 
 class CmdListOut(C.Structure):
     _fields_ = [("cmd_type", C.c_void_p), ("cmd_arg_off", C.c_void_p), ("args", C.c_void_p), ("path_cmd_begin", C.c_void_p), ("draws", C.c_void_p),
-                ("cap_cmds", C.c_uint32), ("cap_args", C.c_uint32), ("cap_paths", C.c_uint32), ("cap_draws", C.c_uint32),
-                ("num_cmds", C.c_uint32), ("num_args", C.c_uint32), ("num_paths", C.c_uint32), ("num_draws", C.c_uint32),
-                ("num_skipped", C.c_uint32), ("reserved", C.c_uint32)]
+                ("draw_state", C.c_void_p), ("paints", C.c_void_p),
+                ("cap_cmds", C.c_uint32), ("cap_args", C.c_uint32), ("cap_paths", C.c_uint32), ("cap_draws", C.c_uint32), ("cap_paints", C.c_uint32),
+                ("num_cmds", C.c_uint32), ("num_args", C.c_uint32), ("num_paths", C.c_uint32), ("num_draws", C.c_uint32), ("num_paints", C.c_uint32),
+                ("num_skipped", C.c_uint32), ("next_gradient", C.c_uint32), ("next_image_pattern", C.c_uint32), ("next_generation", C.c_uint32),
+                ("end_mtx", C.c_float * 6), ("end_global_alpha", C.c_float), ("reserved", C.c_uint32)]
+
+
+draw_state_dtype = np.dtype([("scissor", "<u2", (4,)), ("clip_rule", "<u4"), ("clip_first_draw", "<u4"), ("clip_num_draws", "<u4"), ("reserved", "<u4")])
+paint_dtype = np.dtype([("type", "<u4"), ("handle", "<u4"), ("matrix", "<f4", (9,)), ("params", "<f4", (4,)), ("inner_color", "<f4", (4,)),
+                        ("outer_color", "<f4", (4,)), ("image", "<u4")])
+assert draw_state_dtype.itemsize == 24 and paint_dtype.itemsize == 96
+CL_CACHEABLE, CL_ALLOW_CULLING = 1, 2
 
 
 class FailureInfo(C.Structure):

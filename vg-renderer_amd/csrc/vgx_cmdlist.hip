@@ -2,25 +2,28 @@
 //
 // A vg::CommandList is a HOST byte buffer (CommandList::m_CommandBuffer, reference src/vg.cpp:243-247, 5694-5723):
 // records of {CommandHeader{uint32 type, uint32 size}, padded to 16 bytes}{payload, padded to 16 bytes}, written by the cl*
-// functions (:2403-2690) and replayed by ctxSubmitCommandList's switch (:4332-4625) through the same ctxXXX calls an
+// functions (:2403-2967) and replayed by ctxSubmitCommandList's switch (:4273-4637) through the same ctxXXX calls an
 // immediate-mode caller makes. vgx_cmdlist_decode walks that buffer ONCE and produces what the batch entry points take:
 //   - one path per ctxBeginPath .. group (vgx_pathset_desc arrays: the cl* payloads are the pathXXX arguments verbatim), and
-//   - one vgx_draw per FillPathColor / StrokePathColor with the state the interpreter would have at that point folded in:
-//     transform and m_AvgScale (PushState / PopState / Transform* / SetViewBox, :3934-4122, updateState :4927-4944), the
-//     colour's alpha scaled by the global alpha, the stroke width scaled / clamped and the Thin switch (:3401-3433).
+//   - one vgx_draw per fill / stroke command (colour, gradient and image-pattern paint alike: they call the same strokerXXX
+//     functions and differ in the createDrawCommand_XXX they end in, :3061-3668) with the state the interpreter would have at
+//     that point folded in: transform and m_AvgScale (PushState / PopState / Transform* / SetViewBox, :3934-4122, updateState
+//     :4927-4944; the transform a path is drawn with is the one of its FIRST fill / stroke, transformPath :4957-4975), the
+//     colour's alpha scaled by the global alpha, the stroke width scaled / clamped and the Thin switch, the scissor and clip
+//     state the draw command would carry, and vgx_draw::state_key = what allocDrawCommand compares before merging.
 // The walk is sequential by nature (variable-size records, a state stack) and the buffer lives in host memory; decoding it
 // on the host next to vgx_pathset_create's validation costs nothing measurable (a memory-speed pass, once per recorded
 // list, not per frame) -- uploading it to decode with dependent 16-byte loads would be slower and still need the host pass.
-// What vgx_tessellate cannot express is counted in num_skipped and otherwise ignored: gradient / image fills and strokes,
-// IndexedTriList, clip and scissor commands, text, nested command lists, concave fills (libtess2 stays with the caller:
-// vgx_concave_*).
-// Parity unpinned: vg.cpp needs bgfx and cannot be compiled here; the byte layout and the state arithmetic are restated
-// from the cited lines and pinned by hand-assembled streams in tests/test_cmdlist.py.
+// Parity: pinned against the reference's own writers and interpreter (the test suite compiles src/vg.cpp unmodified behind
+// a recording bgfx stand-in): tests/test_cmdlist_ref.py records lists with vg::clXxx, decodes the bytes here and compares the
+// frame with what vg::submitCommandList + vg::end produce.
 #include <hip/hip_runtime.h>
 #include "../../include/vgx.h"
 #include "vgmath.h"
 #include <string.h>
 #include <vector>
+
+static_assert(sizeof(vgx_draw_state) == 24 && sizeof(vgx_paint) == 96 && sizeof(vgx_cmdlist_ref) == 16, "vgx.h layout");
 
 namespace {
 
@@ -35,10 +38,12 @@ enum {
 	CT_TransformIdentity, CT_TransformScale, CT_TransformTranslate, CT_TransformRotate, CT_TransformMult, CT_SetViewBox, CT_SetGlobalAlpha,
 	CT_Text, CT_TextBox, CT_SubmitCommandList, CT_Count_
 };
+enum { DT_Textured = 0, DT_ColorGradient = 1, DT_ImagePattern = 2, DT_Clip = 3 }; // DrawCommand::Type, vg.cpp:110-118
 const uint32_t kAlign = 16;       // VG_CONFIG_COMMAND_LIST_ALIGNMENT, vg.cpp:40
 const uint32_t kHeaderSize = 16;  // alignSize(sizeof(CommandHeader), 16), vg.cpp:708
+const uint32_t kBlack = 0xFF000000u; // Colors::Black
 
-struct St { float m[6]; float avgScale; float alpha; };
+struct St { float m[6]; float scissor[4]; float alpha; float avgScale; }; // vg::State, vg.cpp:62-69
 
 void updateState(St& s) // vg.cpp:4927-4935
 {
@@ -57,31 +62,62 @@ void mul3(const float* a, const float* b, float* r) // vgutil::multiplyMatrix3, 
 	r[5] = a[1] * b[4] + a[3] * b[5] + a[5];
 }
 
-float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
-struct Builder
+void invert3(const float* t, float* inv) // vgutil::invertMatrix3, vg_util.cpp:14-33 (double precision inside)
 {
+	const double det = (double)t[0] * t[3] - (double)t[2] * t[1];
+	if (det > -1e-6 && det < 1e-6) {
+		inv[0] = 1.0f; inv[1] = 0.0f; inv[2] = 1.0f; inv[3] = 0.0f; inv[4] = 0.0f; inv[5] = 0.0f; // sic: the reference's "identity"
+		return;
+	}
+	const double invdet = 1.0 / det;
+	inv[0] = (float)(t[3] * invdet);
+	inv[2] = (float)(-t[2] * invdet);
+	inv[4] = (float)(((double)t[2] * t[5] - (double)t[3] * t[4]) * invdet);
+	inv[1] = (float)(-t[1] * invdet);
+	inv[3] = (float)(t[0] * invdet);
+	inv[5] = (float)(((double)t[1] * t[4] - (double)t[0] * t[5]) * invdet);
+}
+
+inline float clampf(float v, float lo, float hi) { return vgm_max(vgm_min(v, hi), lo); } // bx::clamp = max(min(a, hi), lo)
+inline uint32_t setAlpha(uint32_t c, uint8_t a) { return (c & 0x00FFFFFFu) | ((uint32_t)a << 24); } // colorSetAlpha, vg.inl:95-98
+
+struct Decoder
+{
+	const vgx_cmdlist_state* st0;
 	vgx_cmdlist_out* out;
 	bool store;
-	uint32_t npaths, ncmd, nargs, ndraws, nskipped;
-	// current path = commands [pathCmd0, ncmd); referenced = a draw already points at it
-	uint32_t pathCmd0, pathArg0;
-	bool havePath, referenced, overflow;
+	bool overflow;
+	uint32_t npaths, ncmd, nargs, ndraws, nskipped, npaints;
+	// the Path object: commands [pathCmd0, ncmd) once BeginPath was seen
+	bool havePath;       // a BeginPath group is open
+	bool transformed;    // Context::m_PathTransformed: transformPath ran for this path (latches pathMtx)
+	float pathMtx[6];
+	float pathScale;     // pathReset / strokerReset scale (ctxBeginPath, vg.cpp:2969-2981)
+	std::vector<St> stack;
+	// draw-command bookkeeping
+	bool forceNew;       // m_ForceNewDrawCommand / m_ForceNewClipCommand raised since the last draw
+	uint32_t generation;
+	bool haveLastScissor;
+	uint16_t lastScissor[4]; // scissor of the last draw COMMAND (= of the last non-clip draw emitted)
+	// clip state (ClipState, vg.cpp:71-76) in units of draws
+	bool recordClip;
+	uint32_t clipRule, clipFirst, clipNum;
+	uint32_t nextGradient, nextImagePattern, maxGradients, maxImagePatterns;
+	uint32_t depth, maxDepth;
+
+	St& S() { return stack.back(); }
+
 	void pathCmd(uint8_t type, const float* a, uint32_t n)
 	{
 		if (store) {
-			if (ncmd >= out->cap_cmds || nargs + n > out->cap_args) { overflow = true; return; }
-			out->cmd_type[ncmd] = type;
-			memcpy(out->args + nargs, a, n * sizeof(float));
-			out->cmd_arg_off[ncmd + 1] = nargs + n;
+			if (ncmd >= out->cap_cmds || nargs + n > out->cap_args) { overflow = true; }
+			else {
+				out->cmd_type[ncmd] = type;
+				if (n) { memcpy(out->args + nargs, a, n * sizeof(float)); }
+				out->cmd_arg_off[ncmd + 1] = nargs + n;
+			}
 		}
 		++ncmd; nargs += n;
-	}
-	void beginPath()
-	{
-		closePathRecord();
-		havePath = true; referenced = false;
-		pathCmd0 = ncmd; pathArg0 = nargs;
 	}
 	void closePathRecord() // the current path is complete: path_cmd_begin[npaths + 1]
 	{
@@ -92,30 +128,82 @@ struct Builder
 		++npaths;
 		havePath = false;
 	}
+	void beginPath()
+	{
+		closePathRecord();
+		havePath = true; transformed = false;
+		pathScale = S().avgScale;
+	}
+	// transformPath (vg.cpp:4957-4975): the first caller fixes the matrix the path's vertices are transformed with
+	void latch() { if (!transformed) { memcpy(pathMtx, S().m, sizeof(pathMtx)); transformed = true; } }
+
+	void emit(uint32_t type, uint32_t handle, uint32_t fillFlags, uint32_t fillColor, uint32_t strokeFlags, uint32_t strokeColor, float strokeWidth)
+	{
+		const St& s = S();
+		uint16_t sc[4];
+		for (int i = 0; i < 4; ++i) { sc[i] = (uint16_t)s.scissor[i]; }
+		if (forceNew) { ++generation; forceNew = false; }
+		if (store) {
+			if (ndraws >= out->cap_draws) { overflow = true; }
+			else {
+				vgx_draw& dr = out->draws[ndraws];
+				memset(&dr, 0, sizeof(dr));
+				dr.path = npaths; // index of the current (not yet closed) path
+				dr.fill_flags = fillFlags; dr.fill_color = fillColor;
+				dr.stroke_flags = strokeFlags; dr.stroke_color = strokeColor; dr.stroke_width = strokeWidth;
+				dr.scale = pathScale; dr.tess_tol = st0->tess_tol; dr.fringe = st0->fringe;
+				memcpy(dr.mtx, pathMtx, sizeof(float) * 6);
+				dr.state_key = (generation << 20) | (type << 16) | (handle & 0xFFFFu);
+				if (out->draw_state) {
+					vgx_draw_state& ds = out->draw_state[ndraws];
+					memcpy(ds.scissor, sc, sizeof(sc));
+					if (type == DT_Clip) { ds.clip_rule = 0; ds.clip_first_draw = 0xFFFFFFFFu; ds.clip_num_draws = 0; } // allocClipCommand, vg.cpp:5449-5450
+					else { ds.clip_rule = clipRule; ds.clip_first_draw = clipFirst; ds.clip_num_draws = clipNum; }
+					ds.reserved = 0;
+				}
+			}
+		}
+		if (type != DT_Clip) { memcpy(lastScissor, sc, sizeof(sc)); haveLastScissor = true; }
+		if (recordClip && type == DT_Clip) { ++clipNum; }
+		++ndraws;
+	}
+
+	vgx_paint* newPaint(uint32_t type, uint32_t handle, const float* inv)
+	{
+		vgx_paint* p = nullptr;
+		static vgx_paint dummy;
+		if (store && out->paints) {
+			if (npaints >= out->cap_paints) { overflow = true; p = &dummy; } else { p = &out->paints[npaints]; }
+		} else { p = &dummy; }
+		++npaints;
+		memset(p, 0, sizeof(*p));
+		p->type = type; p->handle = handle;
+		p->matrix[0] = inv[0]; p->matrix[1] = inv[1]; p->matrix[2] = 0.0f;
+		p->matrix[3] = inv[2]; p->matrix[4] = inv[3]; p->matrix[5] = 0.0f;
+		p->matrix[6] = inv[4]; p->matrix[7] = inv[5]; p->matrix[8] = 1.0f;
+		return p;
+	}
+	static void colors(vgx_paint* p, uint32_t icol, uint32_t ocol) // colorGetRed.. / 255.0f, vg.cpp:3764-3771
+	{
+		for (int i = 0; i < 4; ++i) {
+			p->inner_color[i] = (float)((icol >> (8 * i)) & 0xFFu) / 255.0f;
+			p->outer_color[i] = (float)((ocol >> (8 * i)) & 0xFFu) / 255.0f;
+		}
+	}
+
+	int run(const uint8_t* p, uint32_t size, uint32_t listFlags);
 };
 
-} // namespace
-
-extern "C" int vgx_cmdlist_decode(const void* bytes, uint32_t size, const vgx_cmdlist_state* st0, vgx_cmdlist_out* out)
+int Decoder::run(const uint8_t* p, uint32_t size, uint32_t listFlags)
 {
-	if ((!bytes && size) || !st0 || !out || (size % kAlign) != 0) {
-		return VGX_E_INVALID_ARG;
-	}
-	const bool store = out->cmd_type && out->cmd_arg_off && out->args && out->path_cmd_begin && out->draws; // else: count only
-	Builder B;
-	memset(&B, 0, sizeof(B));
-	B.out = out; B.store = store;
-	if (store) { out->cmd_arg_off[0] = 0; out->path_cmd_begin[0] = 0; }
-
-	std::vector<St> stack(1);
-	memcpy(stack[0].m, st0->mtx, sizeof(float) * 6);
-	stack[0].alpha = st0->global_alpha;
-	updateState(stack[0]);
-	// per-command argument counts of the current path (count pass of a fork needs them without stored arrays)
-	std::vector<uint32_t> curArgCounts;
-	float pathScale = stack[0].avgScale; // pathReset / strokerReset scale of the current path (ctxBeginPath, vg.cpp:2969-2981)
-
-	const uint8_t* p = (const uint8_t*)bytes;
+	// ctxSubmitCommandList, vg.cpp:4273-4330
+	if (depth >= maxDepth) { return VGX_OK; }
+	++depth;
+	const bool hasCache = (listFlags & VGX_CL_CACHEABLE) != 0;                    // getCommandListCacheStackTop() != nullptr
+	const bool cullCmds = !hasCache && (listFlags & VGX_CL_ALLOW_CULLING) != 0;   // :4299-4300
+	const uint32_t firstGradientID = nextGradient & 0xFFFFu, firstImagePatternID = nextImagePattern & 0xFFFFu;
+	bool skipCmds = false;
+	const float fringe = st0->fringe;
 	const uint8_t* end = p + size;
 	while (p < end) {
 		if ((uint32_t)(end - p) < kHeaderSize) { return VGX_E_INVALID_ARG; }
@@ -125,145 +213,312 @@ extern "C" int vgx_cmdlist_decode(const void* bytes, uint32_t size, const vgx_cm
 		if ((psize % kAlign) != 0 || psize > (uint32_t)(end - p) || type >= CT_Count_) { return VGX_E_INVALID_ARG; }
 		const uint8_t* d = p;
 		p += psize;
+		if (skipCmds && type >= CT_FillPathColor && type <= CT_StrokePathImagePattern) { continue; } // :4335-4338
 		const float* f = (const float*)d;
-		St& S = stack.back();
 		auto need = [&](uint32_t n) { return psize >= n; };
-		auto pathArgs = [&](uint8_t vt, uint32_t nfloats) -> int {
-			if (!need(nfloats * 4)) { return VGX_E_INVALID_ARG; }
-			if (!B.havePath) { ++B.nskipped; return VGX_OK; } // path command before any BeginPath: the reference would append to a stale path
-			// a path command after a fill / stroke of the same path (no BeginPath in between): the reference keeps appending
-			// to the Path object, so the next fill / stroke sees all of it. Paths are immutable here: continue on a copy.
-			if (B.referenced) {
-				const uint32_t c0 = B.pathCmd0, c1 = B.ncmd;
-				B.closePathRecord();
-				B.havePath = true; B.referenced = false;
-				B.pathCmd0 = B.ncmd; B.pathArg0 = B.nargs;
-				for (uint32_t c = c0; c < c1; ++c) {
-					const uint32_t n = curArgCounts[c - c0];
-					if (store && !B.overflow) {
-						std::vector<float> tmp(out->args + out->cmd_arg_off[c], out->args + out->cmd_arg_off[c] + n);
-						B.pathCmd(out->cmd_type[c], tmp.data(), n);
-					} else { ++B.ncmd; B.nargs += n; }
-				}
-			}
-			float tmp[8];
-			memcpy(tmp, f, nfloats * 4);
-			B.pathCmd(vt, tmp, nfloats);
-			curArgCounts.push_back(nfloats);
-			return VGX_OK;
+		auto u32at = [&](uint32_t off) { uint32_t v; memcpy(&v, d + off, 4); return v; };
+		auto u16at = [&](uint32_t off) { uint16_t v; memcpy(&v, d + off, 2); return v; };
+		auto f32at = [&](uint32_t off) { float v; memcpy(&v, d + off, 4); return v; };
+		// a path command: legal while the path has not been transformed yet (VG_CHECK(!m_PathTransformed), :2984-3059)
+		auto pathArgs = [&](uint8_t vt, const float* a, uint32_t nfloats) {
+			if (!havePath || transformed) { ++nskipped; return; }
+			pathCmd(vt, a, nfloats);
 		};
-		int rc = VGX_OK;
+		auto globalAlpha = [&]() { return hasCache ? 1.0f : S().alpha; };
+		// alpha of the colour a Color / ImagePattern fill or stroke hands to the stroker (:3071-3075 and siblings)
+		auto scaledColor = [&](uint32_t color, float alphaScale) { return setAlpha(color, (uint8_t)(alphaScale * (uint8_t)(color >> 24))); };
+		// stroke width rules shared by the three strokePath flavours (:3416-3420, 3516-3522, 3597-3601)
+		struct Width { float scaled; bool thin; float width; };
+		auto strokeWidth = [&](float width, uint32_t flags) {
+			Width w;
+			w.scaled = (flags & (1u << 5)) ? width : clampf(width * S().avgScale, 0.0f, 200.0f); // StrokeFlags::FixedWidth
+			w.thin = w.scaled <= fringe;
+			w.width = w.thin ? fringe : w.scaled;
+			return w;
+		};
+		auto strokeFlagsOf = [&](uint32_t flags, bool aa, bool thin) { return VGX_STROKE_FLAGS((flags >> 2) & 3u, flags & 3u, aa, thin && aa); };
+		auto localHandle = [&](uint16_t handle, uint16_t hflags, uint32_t first) { return (hflags & 0x0001u) ? (uint32_t)(uint16_t)(handle + first) : (uint32_t)handle; }; // isLocal, :4427
 		switch (type) {
-		case CT_BeginPath: B.beginPath(); curArgCounts.clear(); pathScale = S.avgScale; break;
-		case CT_MoveTo: rc = pathArgs(VGX_CMD_MOVE_TO, 2); break;
-		case CT_LineTo: rc = pathArgs(VGX_CMD_LINE_TO, 2); break;
-		case CT_CubicTo: rc = pathArgs(VGX_CMD_CUBIC_TO, 6); break;
-		case CT_QuadraticTo: rc = pathArgs(VGX_CMD_QUAD_TO, 4); break;
-		case CT_ArcTo: rc = pathArgs(VGX_CMD_ARC_TO, 5); break;
+		case CT_BeginPath: beginPath(); break;
+		case CT_MoveTo: if (!need(8)) { return VGX_E_INVALID_ARG; } pathArgs(VGX_CMD_MOVE_TO, f, 2); break;
+		case CT_LineTo: if (!need(8)) { return VGX_E_INVALID_ARG; } pathArgs(VGX_CMD_LINE_TO, f, 2); break;
+		case CT_CubicTo: if (!need(24)) { return VGX_E_INVALID_ARG; } pathArgs(VGX_CMD_CUBIC_TO, f, 6); break;
+		case CT_QuadraticTo: if (!need(16)) { return VGX_E_INVALID_ARG; } pathArgs(VGX_CMD_QUAD_TO, f, 4); break;
+		case CT_ArcTo: if (!need(20)) { return VGX_E_INVALID_ARG; } pathArgs(VGX_CMD_ARC_TO, f, 5); break;
 		case CT_Arc: { // five floats + Winding::Enum (vg.cpp:2459-2472); vgx: sixth argument 1 = CW
 			if (!need(24)) { return VGX_E_INVALID_ARG; }
-			uint32_t dir; memcpy(&dir, d + 20, 4);
-			float a[6]; memcpy(a, f, 20); a[5] = dir == 1u ? 1.0f : 0.0f;
-			const float* keep = f; f = a; rc = pathArgs(VGX_CMD_ARC, 6); f = keep;
+			float a[6]; memcpy(a, d, 20); a[5] = u32at(20) == 1u ? 1.0f : 0.0f;
+			pathArgs(VGX_CMD_ARC, a, 6);
 		} break;
-		case CT_Rect: rc = pathArgs(VGX_CMD_RECT, 4); break;
-		case CT_RoundedRect: rc = pathArgs(VGX_CMD_ROUNDED_RECT, 5); break;
-		case CT_RoundedRectVarying: rc = pathArgs(VGX_CMD_ROUNDED_RECT_VARYING, 8); break;
-		case CT_Circle: rc = pathArgs(VGX_CMD_CIRCLE, 3); break;
-		case CT_Ellipse: rc = pathArgs(VGX_CMD_ELLIPSE, 4); break;
-		case CT_ClosePath: rc = pathArgs(VGX_CMD_CLOSE, 0); break;
+		case CT_Rect: if (!need(16)) { return VGX_E_INVALID_ARG; } pathArgs(VGX_CMD_RECT, f, 4); break;
+		case CT_RoundedRect: if (!need(20)) { return VGX_E_INVALID_ARG; } pathArgs(VGX_CMD_ROUNDED_RECT, f, 5); break;
+		case CT_RoundedRectVarying: if (!need(32)) { return VGX_E_INVALID_ARG; } pathArgs(VGX_CMD_ROUNDED_RECT_VARYING, f, 8); break;
+		case CT_Circle: if (!need(12)) { return VGX_E_INVALID_ARG; } pathArgs(VGX_CMD_CIRCLE, f, 3); break;
+		case CT_Ellipse: if (!need(16)) { return VGX_E_INVALID_ARG; } pathArgs(VGX_CMD_ELLIPSE, f, 4); break;
+		case CT_ClosePath: pathArgs(VGX_CMD_CLOSE, f, 0); break;
 		case CT_Polyline: { // uint32 numPoints + coordinates (vg.cpp:2551-2559)
 			if (!need(4)) { return VGX_E_INVALID_ARG; }
-			uint32_t np; memcpy(&np, d, 4);
+			const uint32_t np = u32at(0);
 			if (np == 0 || np > (psize - 4) / 8) { return VGX_E_INVALID_ARG; }
-			if (!B.havePath) { ++B.nskipped; break; }
-			if (B.referenced) { const float* keep = f; rc = pathArgs(VGX_CMD_CLOSE, 0); f = keep; if (rc == VGX_OK) { --B.ncmd; curArgCounts.pop_back(); } } // fork only
-			std::vector<float> pts((size_t)np * 2);
-			memcpy(pts.data(), d + 4, (size_t)np * 8);
-			B.pathCmd(VGX_CMD_POLYLINE, pts.data(), np * 2);
-			curArgCounts.push_back(np * 2);
+			pathArgs(VGX_CMD_POLYLINE, (const float*)(d + 4), np * 2);
 		} break;
-		case CT_FillPathColor: { // uint32 flags, Color (vg.cpp:2619-2627); ctxFillPathColor :3061-3179
+
+		case CT_FillPathColor: // uint32 flags, Color (vg.cpp:2619-2627); ctxFillPathColor :3061-3179
+		case CT_FillPathImagePattern: { // uint32 flags, Color, uint16 handle, uint16 handle flags (:2640-2651); ctxFillPathImagePattern :3286-3399
+			const bool img = type == CT_FillPathImagePattern;
+			if (!need(img ? 12u : 8u)) { return VGX_E_INVALID_ARG; }
+			const uint32_t flags = u32at(0), color = u32at(4);
+			const bool clip = recordClip && !img;
+			const uint32_t col = clip ? kBlack : scaledColor(color, globalAlpha());
+			if (!clip && !hasCache && (col >> 24) == 0) { break; } // transparent: the reference returns before transformPath
+			if (!havePath) { ++nskipped; break; }
+			latch();
+			if (flags & 0x01u) { ++nskipped; break; } // PathType::Concave: libtess2 (vgx_concave_*)
+			const bool aa = clip ? false : (flags & 0x04u) != 0;
+			const uint32_t dt = clip ? (uint32_t)DT_Clip : (img ? (uint32_t)DT_ImagePattern : (uint32_t)DT_Textured);
+			const uint32_t handle = clip ? 0xFFFFu : (img ? localHandle(u16at(8), u16at(10), firstImagePatternID) : 0u);
+			emit(dt, handle, VGX_FILL_ENABLE | (aa ? VGX_FILL_AA : 0u), col, 0, 0, 0.0f);
+		} break;
+		case CT_FillPathGradient: { // uint32 flags, uint16 handle, uint16 handle flags (:2629-2638); ctxFillPathGradient :3181-3284
 			if (!need(8)) { return VGX_E_INVALID_ARG; }
-			uint32_t flags, color; memcpy(&flags, d, 4); memcpy(&color, d + 4, 4);
-			const uint32_t a = (uint32_t)(uint8_t)(S.alpha * (float)(color >> 24));
-			if (a == 0 || !B.havePath) { if (a != 0) { ++B.nskipped; } break; } // transparent: the reference returns before any geometry
-			if (flags & 0x01u) { ++B.nskipped; break; } // PathType::Concave: libtess2 (vgx_concave_*)
-			if (store) {
-				if (B.ndraws >= out->cap_draws) { B.overflow = true; }
-				else {
-					vgx_draw& dr = out->draws[B.ndraws];
-					memset(&dr, 0, sizeof(dr));
-					dr.path = B.npaths; // index of the current (not yet closed) path
-					dr.fill_flags = VGX_FILL_ENABLE | ((flags & 0x04u) ? VGX_FILL_AA : 0u);
-					dr.fill_color = (color & 0x00FFFFFFu) | (a << 24);
-					dr.scale = pathScale; dr.tess_tol = st0->tess_tol; dr.fringe = st0->fringe;
-					memcpy(dr.mtx, S.m, sizeof(float) * 6);
-				}
-			}
-			++B.ndraws; B.referenced = true;
+			const uint32_t flags = u32at(0);
+			if (!havePath) { ++nskipped; break; }
+			latch();
+			if (flags & 0x01u) { ++nskipped; break; }
+			const bool aa = (flags & 0x04u) != 0;
+			// AA: strokerConvexFillAA(Colors::Black); else one colour = black with alpha 0xff * globalAlpha (:3212, 3228)
+			const uint32_t col = aa ? kBlack : setAlpha(kBlack, (uint8_t)(0xff * S().alpha));
+			emit(DT_ColorGradient, localHandle(u16at(4), u16at(6), firstGradientID), VGX_FILL_ENABLE | (aa ? VGX_FILL_AA : 0u), col, 0, 0, 0.0f);
 		} break;
-		case CT_StrokePathColor: { // float width, uint32 flags, Color (vg.cpp:2660-2669); ctxStrokePathColor :3401-3433
+
+		case CT_StrokePathColor: { // float width, uint32 flags, Color (vg.cpp:2660-2669); ctxStrokePathColor :3401-3492
 			if (!need(12)) { return VGX_E_INVALID_ARG; }
-			float width; uint32_t flags, color; memcpy(&width, d, 4); memcpy(&flags, d + 4, 4); memcpy(&color, d + 8, 4);
-			const float fringe = st0->fringe;
-			const float scaled = (flags & (1u << 5)) ? width : clampf(width * S.avgScale, 0.0f, 200.0f); // StrokeFlags::FixedWidth
-			const bool thin = scaled <= fringe;
-			const float c = clampf(scaled, 0.0f, fringe);
-			const float alphaScale = !thin ? S.alpha : S.alpha * (c * c);
-			const uint32_t a = (uint32_t)(uint8_t)(alphaScale * (float)(color >> 24));
-			if (a == 0 || !B.havePath) { if (a != 0) { ++B.nskipped; } break; }
-			if (store) {
-				if (B.ndraws >= out->cap_draws) { B.overflow = true; }
-				else {
-					vgx_draw& dr = out->draws[B.ndraws];
-					memset(&dr, 0, sizeof(dr));
-					dr.path = B.npaths;
-					const bool aa = (flags & 0x10u) != 0;
-					dr.stroke_flags = VGX_STROKE_FLAGS((flags >> 2) & 3u, flags & 3u, aa, thin && aa);
-					dr.stroke_color = (color & 0x00FFFFFFu) | (a << 24);
-					dr.stroke_width = thin ? fringe : scaled;
-					dr.scale = pathScale; dr.tess_tol = st0->tess_tol; dr.fringe = fringe;
-					memcpy(dr.mtx, S.m, sizeof(float) * 6);
-				}
-			}
-			++B.ndraws; B.referenced = true;
+			const float width = f32at(0); const uint32_t flags = u32at(4), color = u32at(8);
+			const Width w = strokeWidth(width, flags);
+			const float ga = globalAlpha();
+			const float c = clampf(w.scaled, 0.0f, fringe);
+			const float alphaScale = !w.thin ? ga : ga * (c * c);
+			const uint32_t col = recordClip ? kBlack : scaledColor(color, alphaScale);
+			if (!hasCache && (col >> 24) == 0) { break; }
+			if (!havePath) { ++nskipped; break; }
+			latch();
+			const bool aa = recordClip ? false : (flags & 0x10u) != 0;
+			emit(recordClip ? (uint32_t)DT_Clip : (uint32_t)DT_Textured, recordClip ? 0xFFFFu : 0u, 0, 0, strokeFlagsOf(flags, aa, w.thin), col, w.width);
 		} break;
+		case CT_StrokePathGradient: { // float width, uint32 flags, uint16 handle, uint16 handle flags (:2671-2681); ctxStrokePathGradient :3494-3576
+			if (!need(12)) { return VGX_E_INVALID_ARG; }
+			const float width = f32at(0); const uint32_t flags = u32at(4);
+			if (!havePath) { ++nskipped; break; }
+			const bool aa = (flags & 0x10u) != 0;
+			latch();
+			const Width w = strokeWidth(width, flags);
+			const uint32_t col = aa ? kBlack : setAlpha(kBlack, (uint8_t)(0xff * S().alpha)); // :3545-3546, 3550-3554
+			emit(DT_ColorGradient, localHandle(u16at(8), u16at(10), firstGradientID), 0, 0, strokeFlagsOf(flags, aa, w.thin), col, w.width);
+		} break;
+		case CT_StrokePathImagePattern: { // float width, uint32 flags, Color, uint16 handle, uint16 handle flags (:2683-2695); ctxStrokePathImagePattern :3578-3668
+			if (!need(16)) { return VGX_E_INVALID_ARG; }
+			const float width = f32at(0); const uint32_t flags = u32at(4), color = u32at(8);
+			const Width w = strokeWidth(width, flags);
+			const float ga = globalAlpha();
+			const float c = clampf(w.scaled, 0.0f, fringe);
+			const float alphaScale = w.thin ? ga : ga * (c * c); // sic (:3603): the Color flavour has the test the other way round
+			const uint32_t col = scaledColor(color, alphaScale);
+			if (!hasCache && (col >> 24) == 0) { break; }
+			if (!havePath) { ++nskipped; break; }
+			latch();
+			const bool aa = (flags & 0x10u) != 0;
+			emit(DT_ImagePattern, localHandle(u16at(12), u16at(14), firstImagePatternID), 0, 0, strokeFlagsOf(flags, aa, w.thin), col, w.width);
+		} break;
+
+		case CT_BeginClip: // ctxBeginClip, vg.cpp:3670-3683
+			if (!need(4)) { return VGX_E_INVALID_ARG; }
+			clipRule = u32at(0); clipFirst = ndraws; clipNum = 0;
+			recordClip = true; forceNew = true;
+			break;
+		case CT_EndClip: recordClip = false; forceNew = true; break; // :3685-3697
+		case CT_ResetClip: // :3699-3709
+			if (clipFirst != 0xFFFFFFFFu) { clipFirst = 0xFFFFFFFFu; clipNum = 0; forceNew = true; }
+			break;
+
+		case CT_CreateLinearGradient: { // four floats, two colours (:2716-2733); ctxCreateLinearGradient :3711-3774
+			if (!need(24)) { return VGX_E_INVALID_ARG; }
+			if (nextGradient >= maxGradients) { break; }
+			const uint32_t handle = nextGradient++;
+			const float sx = f[0], sy = f[1], ex = f[2], ey = f[3];
+			const float large = 1e5;
+			float dx = ex - sx, dy = ey - sy;
+			const float dd = vgm_sqrt(dx * dx + dy * dy);
+			if (dd > 0.0001f) { dx /= dd; dy /= dd; } else { dx = 0; dy = 1; }
+			const float g[6] = { dy, -dx, dx, dy, sx - dx * large, sy - dy * large };
+			float pm[6], inv[6];
+			mul3(S().m, g, pm); invert3(pm, inv);
+			vgx_paint* pt = newPaint(DT_ColorGradient, handle, inv);
+			pt->params[0] = large; pt->params[1] = large + dd * 0.5f; pt->params[2] = 0.0f; pt->params[3] = vgm_max(1.0f, dd);
+			colors(pt, u32at(16), u32at(20));
+		} break;
+		case CT_CreateBoxGradient: { // six floats, two colours (:2735-2754); ctxCreateBoxGradient :3776-3826
+			if (!need(32)) { return VGX_E_INVALID_ARG; }
+			if (nextGradient >= maxGradients) { break; }
+			const uint32_t handle = nextGradient++;
+			const float g[6] = { 1.0f, 0.0f, 0.0f, 1.0f, f[0] + f[2] * 0.5f, f[1] + f[3] * 0.5f };
+			float pm[6], inv[6];
+			mul3(S().m, g, pm); invert3(pm, inv);
+			vgx_paint* pt = newPaint(DT_ColorGradient, handle, inv);
+			pt->params[0] = f[2] * 0.5f; pt->params[1] = f[3] * 0.5f; pt->params[2] = f[4]; pt->params[3] = vgm_max(1.0f, f[5]);
+			colors(pt, u32at(24), u32at(28));
+		} break;
+		case CT_CreateRadialGradient: { // four floats, two colours (:2756-2773); ctxCreateRadialGradient :3828-3881
+			if (!need(24)) { return VGX_E_INVALID_ARG; }
+			if (nextGradient >= maxGradients) { break; }
+			const uint32_t handle = nextGradient++;
+			const float g[6] = { 1.0f, 0.0f, 0.0f, 1.0f, f[0], f[1] };
+			float pm[6], inv[6];
+			mul3(S().m, g, pm); invert3(pm, inv);
+			const float r = (f[2] + f[3]) * 0.5f, fe = (f[3] - f[2]);
+			vgx_paint* pt = newPaint(DT_ColorGradient, handle, inv);
+			pt->params[0] = r; pt->params[1] = r; pt->params[2] = r; pt->params[3] = vgm_max(1.0f, fe);
+			colors(pt, u32at(16), u32at(20));
+		} break;
+		case CT_CreateImagePattern: { // five floats + ImageHandle (:2775-2791); ctxCreateImagePattern :3883-3932
+			if (!need(22)) { return VGX_E_INVALID_ARG; }
+			const uint16_t image = u16at(20);
+			if (image == 0xFFFFu || nextImagePattern >= maxImagePatterns) { break; }
+			const uint32_t handle = nextImagePattern++;
+			const float cs = vgm_cos(f[4]), sn = vgm_sin(f[4]);
+			const float g[6] = { cs, sn, -sn, cs, f[0], f[1] };
+			float pm[6], inv[6];
+			mul3(S().m, g, pm); invert3(pm, inv);
+			inv[0] /= f[2]; inv[1] /= f[3]; inv[2] /= f[2]; inv[3] /= f[3]; inv[4] /= f[2]; inv[5] /= f[3];
+			vgx_paint* pt = newPaint(DT_ImagePattern, handle, inv);
+			pt->image = image;
+		} break;
+
 		case CT_PushState: { const St top = stack.back(); stack.push_back(top); } break; // vg.cpp:3934-3943
-		case CT_PopState: if (stack.size() > 1) { stack.pop_back(); } else { return VGX_E_INVALID_ARG; } break;
-		case CT_TransformIdentity: S.m[0] = 1; S.m[1] = 0; S.m[2] = 0; S.m[3] = 1; S.m[4] = 0; S.m[5] = 0; updateState(S); break;
-		case CT_TransformScale: if (!need(8)) { return VGX_E_INVALID_ARG; } S.m[0] = f[0] * S.m[0]; S.m[1] = f[0] * S.m[1]; S.m[2] = f[1] * S.m[2]; S.m[3] = f[1] * S.m[3]; updateState(S); break; // :4044-4053
-		case CT_TransformTranslate: if (!need(8)) { return VGX_E_INVALID_ARG; } S.m[4] += S.m[0] * f[0] + S.m[2] * f[1]; S.m[5] += S.m[1] * f[0] + S.m[3] * f[1]; updateState(S); break; // :4055-4062
+		case CT_PopState: { // :3945-3966
+			if (stack.size() <= 1) { return VGX_E_INVALID_ARG; }
+			stack.pop_back();
+			if (haveLastScissor) {
+				const St& s = S();
+				for (int i = 0; i < 4; ++i) { if (lastScissor[i] != (uint16_t)s.scissor[i]) { forceNew = true; } }
+			}
+			if (cullCmds) { skipCmds = (S().scissor[2] < 1.0f) || (S().scissor[3] < 1.0f); } // :4572-4576
+		} break;
+		case CT_ResetScissor: { // :3968-3976
+			St& s = S();
+			s.scissor[0] = s.scissor[1] = 0.0f; s.scissor[2] = st0->canvas_width; s.scissor[3] = st0->canvas_height;
+			forceNew = true; skipCmds = false;
+		} break;
+		case CT_SetScissor: { // :3978-4000
+			if (!need(16)) { return VGX_E_INVALID_ARG; }
+			St& s = S();
+			const float px = s.m[0] * f[0] + s.m[2] * f[1] + s.m[4], py = s.m[1] * f[0] + s.m[3] * f[1] + s.m[5]; // transformPos2D
+			const float wx = s.m[0] * f[2] + s.m[2] * f[3], wy = s.m[1] * f[2] + s.m[3] * f[3];                   // transformVec2D
+			const float cw = st0->canvas_width, ch = st0->canvas_height;
+			const float minx = clampf(px, 0.0f, cw), miny = clampf(py, 0.0f, ch);
+			const float maxx = clampf(px + wx, 0.0f, cw), maxy = clampf(py + wy, 0.0f, ch);
+			s.scissor[0] = minx; s.scissor[1] = miny; s.scissor[2] = maxx - minx; s.scissor[3] = maxy - miny;
+			forceNew = true;
+			if (cullCmds) { skipCmds = (s.scissor[2] < 1.0f) || (s.scissor[3] < 1.0f); }
+		} break;
+		case CT_IntersectScissor: { // :4002-4030
+			if (!need(16)) { return VGX_E_INVALID_ARG; }
+			St& s = S();
+			const float px = s.m[0] * f[0] + s.m[2] * f[1] + s.m[4], py = s.m[1] * f[0] + s.m[3] * f[1] + s.m[5];
+			const float wx = s.m[0] * f[2] + s.m[2] * f[3], wy = s.m[1] * f[2] + s.m[3] * f[3];
+			const float minx = vgm_max(px, s.scissor[0]), miny = vgm_max(py, s.scissor[1]);
+			const float maxx = vgm_min(px + wx, s.scissor[0] + s.scissor[2]), maxy = vgm_min(py + wy, s.scissor[1] + s.scissor[3]);
+			const float nw = vgm_max(0.0f, maxx - minx), nh = vgm_max(0.0f, maxy - miny);
+			s.scissor[0] = minx; s.scissor[1] = miny; s.scissor[2] = nw; s.scissor[3] = nh;
+			forceNew = true;
+			if (cullCmds) { skipCmds = !(nw >= 1.0f && nh >= 1.0f); }
+		} break;
+		case CT_TransformIdentity: { St& s = S(); s.m[0] = 1; s.m[1] = 0; s.m[2] = 0; s.m[3] = 1; s.m[4] = 0; s.m[5] = 0; updateState(s); } break;
+		case CT_TransformScale: { if (!need(8)) { return VGX_E_INVALID_ARG; } St& s = S(); s.m[0] = f[0] * s.m[0]; s.m[1] = f[0] * s.m[1]; s.m[2] = f[1] * s.m[2]; s.m[3] = f[1] * s.m[3]; updateState(s); } break; // :4044-4053
+		case CT_TransformTranslate: { if (!need(8)) { return VGX_E_INVALID_ARG; } St& s = S(); s.m[4] += s.m[0] * f[0] + s.m[2] * f[1]; s.m[5] += s.m[1] * f[0] + s.m[3] * f[1]; updateState(s); } break; // :4055-4062
 		case CT_TransformRotate: { // :4064-4082, bx::cos / bx::sin = the pinned ones of vgmath.h
 			if (!need(4)) { return VGX_E_INVALID_ARG; }
-			const float c = vgm_cos(f[0]), s = vgm_sin(f[0]);
+			St& s = S();
+			const float c = vgm_cos(f[0]), sn = vgm_sin(f[0]);
 			float m[6];
-			m[0] = c * S.m[0] + s * S.m[2]; m[1] = c * S.m[1] + s * S.m[3];
-			m[2] = -s * S.m[0] + c * S.m[2]; m[3] = -s * S.m[1] + c * S.m[3];
-			m[4] = S.m[4]; m[5] = S.m[5];
-			memcpy(S.m, m, sizeof(m)); updateState(S);
+			m[0] = c * s.m[0] + sn * s.m[2]; m[1] = c * s.m[1] + sn * s.m[3];
+			m[2] = -sn * s.m[0] + c * s.m[2]; m[3] = -sn * s.m[1] + c * s.m[3];
+			m[4] = s.m[4]; m[5] = s.m[5];
+			memcpy(s.m, m, sizeof(m)); updateState(s);
 		} break;
 		case CT_TransformMult: { // six floats + TransformOrder::Enum (Pre = 0, Post = 1), :4084-4100
 			if (!need(28)) { return VGX_E_INVALID_ARG; }
-			uint32_t order; memcpy(&order, d + 24, 4);
-			float m[6], r[6]; memcpy(m, f, 24);
-			if (order == 1u) { mul3(S.m, m, r); } else { mul3(m, S.m, r); }
-			memcpy(S.m, r, sizeof(r)); updateState(S);
+			St& s = S();
+			float m[6], r[6]; memcpy(m, d, 24);
+			if (u32at(24) == 1u) { mul3(s.m, m, r); } else { mul3(m, s.m, r); }
+			memcpy(s.m, r, sizeof(r)); updateState(s);
 		} break;
-		case CT_SetViewBox: { // :4102-4121 needs the canvas size
+		case CT_SetViewBox: { // :4102-4121
 			if (!need(16)) { return VGX_E_INVALID_ARG; }
+			St& s = S();
 			const float sxv = st0->canvas_width / f[2], syv = st0->canvas_height / f[3];
-			S.m[0] = sxv * S.m[0]; S.m[1] = sxv * S.m[1]; S.m[2] = syv * S.m[2]; S.m[3] = syv * S.m[3];
-			S.m[4] -= S.m[0] * f[0] + S.m[2] * f[1]; S.m[5] -= S.m[1] * f[0] + S.m[3] * f[1];
-			updateState(S);
+			s.m[0] = sxv * s.m[0]; s.m[1] = sxv * s.m[1]; s.m[2] = syv * s.m[2]; s.m[3] = syv * s.m[3];
+			s.m[4] -= s.m[0] * f[0] + s.m[2] * f[1]; s.m[5] -= s.m[1] * f[0] + s.m[3] * f[1];
+			updateState(s);
 		} break;
-		case CT_SetGlobalAlpha: if (!need(4)) { return VGX_E_INVALID_ARG; } S.alpha = f[0]; break;
-		default: ++B.nskipped; break; // gradients, images, IndexedTriList, clip, scissor, text, nested lists
+		case CT_SetGlobalAlpha: if (!need(4)) { return VGX_E_INVALID_ARG; } S().alpha = f[0]; break;
+		case CT_SubmitCommandList: { // uint16 handle (:2960-2967); :4611-4620
+			if (!need(2)) { return VGX_E_INVALID_ARG; }
+			const uint16_t h = u16at(0);
+			if (!st0->lists || h >= st0->num_lists || (!st0->lists[h].bytes && st0->lists[h].size)) { ++nskipped; break; }
+			const vgx_cmdlist_ref& L = st0->lists[h];
+			if ((L.size % kAlign) != 0) { return VGX_E_INVALID_ARG; }
+			const int rc = run((const uint8_t*)L.bytes, L.size, L.flags);
+			if (rc != VGX_OK) { return rc; }
+		} break;
+		default: ++nskipped; break; // Text, TextBox, IndexedTriList
 		}
-		if (rc != VGX_OK) { return rc; }
 	}
-	B.closePathRecord();
-	out->num_paths = B.npaths; out->num_cmds = B.ncmd; out->num_args = B.nargs; out->num_draws = B.ndraws; out->num_skipped = B.nskipped;
-	if (store && B.overflow) { return VGX_E_NOSPACE; }
+	--depth;
+	return VGX_OK;
+}
+
+} // namespace
+
+extern "C" int vgx_cmdlist_decode(const void* bytes, uint32_t size, const vgx_cmdlist_state* st0, vgx_cmdlist_out* out)
+{
+	if ((!bytes && size) || !st0 || !out || (size % kAlign) != 0) {
+		return VGX_E_INVALID_ARG;
+	}
+	Decoder D;
+	D.st0 = st0; D.out = out;
+	D.store = out->cmd_type && out->cmd_arg_off && out->args && out->path_cmd_begin && out->draws; // else: count only
+	D.overflow = false;
+	D.npaths = D.ncmd = D.nargs = D.ndraws = D.nskipped = D.npaints = 0;
+	D.havePath = false; D.transformed = false; D.pathScale = 1.0f;
+	memset(D.pathMtx, 0, sizeof(D.pathMtx));
+	if (D.store) { out->cmd_arg_off[0] = 0; out->path_cmd_begin[0] = 0; }
+	D.stack.resize(1);
+	St& s0 = D.stack[0];
+	memcpy(s0.m, st0->mtx, sizeof(float) * 6);
+	memcpy(s0.scissor, st0->scissor, sizeof(float) * 4);
+	if (s0.scissor[0] == 0.0f && s0.scissor[1] == 0.0f && s0.scissor[2] == 0.0f && s0.scissor[3] == 0.0f) {
+		s0.scissor[2] = st0->canvas_width; s0.scissor[3] = st0->canvas_height;
+	}
+	s0.alpha = st0->global_alpha;
+	updateState(s0);
+	D.forceNew = false; D.generation = st0->first_generation;
+	D.haveLastScissor = st0->prev_cmd_valid != 0;
+	memcpy(D.lastScissor, st0->prev_cmd_scissor, sizeof(D.lastScissor));
+	D.recordClip = false; D.clipRule = 0; D.clipFirst = 0xFFFFFFFFu; D.clipNum = 0;
+	D.nextGradient = st0->first_gradient; D.nextImagePattern = st0->first_image_pattern;
+	D.maxGradients = st0->max_gradients ? st0->max_gradients : 64u;
+	D.maxImagePatterns = st0->max_image_patterns ? st0->max_image_patterns : 64u;
+	D.depth = 0; D.maxDepth = st0->max_depth ? st0->max_depth : 16u;
+
+	const int rc = D.run((const uint8_t*)bytes, size, st0->flags);
+	if (rc != VGX_OK) { return rc; }
+	D.closePathRecord();
+	out->num_paths = D.npaths; out->num_cmds = D.ncmd; out->num_args = D.nargs; out->num_draws = D.ndraws; out->num_paints = D.npaints;
+	out->num_skipped = D.nskipped;
+	out->next_gradient = D.nextGradient; out->next_image_pattern = D.nextImagePattern;
+	out->next_generation = D.generation + (D.forceNew ? 1u : 0u);
+	memcpy(out->end_mtx, D.S().m, sizeof(float) * 6);
+	out->end_global_alpha = D.S().alpha;
+	if (D.store && D.overflow) { return VGX_E_NOSPACE; }
 	return VGX_OK;
 }

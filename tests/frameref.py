@@ -14,6 +14,27 @@ def record(rc, script, flags=0):
     return cl, data
 
 
+def reference_frames(script, pres, canvas=(1280, 720), max_vb=65536, flags=0):
+    """One command list submitted in len(pres) consecutive frames of ONE Context; pres[i] = Script played on the Context
+    before the submission of frame i (the state the list is submitted under). Returns one dict per frame like
+    reference_frame; with CommandListFlags::Cacheable the first frame populates the list's shape cache and the later
+    ones render from it (clCacheRender, vg.cpp:5845-6135) as long as the average scale stays the same."""
+    outs = []
+    with R.RefContext(max_vb_vertices=max_vb) as rc:
+        root, data = record(rc, script, flags)
+        for pre in pres:
+            rc.begin(canvas[0], canvas[1], 1.0)
+            if pre is not None:
+                pre.play(rc, R.IMMEDIATE)
+            st0 = rc.state()
+            rc.op(R.IMMEDIATE, R.SubmitCommandList, (), (root,))
+            fr = rc.end()
+            outs.append(dict(frame=fr, bytes=data, lists={root: (data, flags)}, root=root, params=rc.params(), state0=st0,
+                             white_uv=rc.white_uv(), cache=rc.cache(root) if (flags & R.CL_CACHEABLE) else None))
+            rc.next_frame()
+    return outs
+
+
 def reference_frame(script, canvas=(1280, 720), max_vb=65536, flags=0, children=(), immediate=False, pre=None, frames=1):
     """Play one frame on the reference. children: [(Script, flags)] recorded first (handles 0..), the root list after
     them. Returns dict(frame=Frame, bytes=root bytes, lists={handle: (bytes, flags)}, root=handle, params, state0)."""
@@ -118,3 +139,17 @@ def cpu_frame(oracle, ps, draws, max_vb):
     st, cmds, idx = oracle.assemble(res.meshes, res.idx, max_vb, mesh_keys=keys)
     assert st == 0, st
     return res, cmds, idx
+
+
+def cache_instances(capi, meshes, draws_now):
+    """One vgx_cache_instance per draw (= per CachedCommand, vg.cpp:5773-5806): its mesh range in the cached drawing and the
+    transform the state has when the fill / stroke command is replayed (submitCachedMesh, :6137-6166)."""
+    n = draws_now.shape[0]
+    inst = np.zeros(n, dtype=capi.cache_instance_dtype)
+    d = meshes["draw"].astype(np.int64)
+    first = np.searchsorted(d, np.arange(n), side="left")
+    last = np.searchsorted(d, np.arange(n), side="right")
+    inst["first_mesh"] = first
+    inst["num_meshes"] = last - first
+    inst["mtx"] = draws_now["mtx"]
+    return inst

@@ -281,6 +281,61 @@ def test_test_side_writer_produces_the_reference_bytes(wl):
     assert data == r.bytes()
 
 
+# ---- shape cache against the reference's own CommandListCache ----------------------------------------------------
+def s_cached_drawing(wl):
+    """A Cacheable list: sub-drawings under their own transforms (state commands are replayed from the list, path commands
+    are not), colour fills and strokes, AA and not. Transforms only change between paths: the reference inverts the state
+    transform of each fill / stroke command (beginCachedCommand, vg.cpp:5773-5790), which is only the transform the path was
+    drawn with when it did not change since the path's first fill / stroke."""
+    ps, ops = wl.tiger_paths()
+    s = Script()
+    for i in range(2):
+        s.push().translate(40.0 * i, 25.0 * i).rotate(0.25 * i)
+        for p, o in list(enumerate(ops))[i::7]:
+            add_path(s, ps, p)
+            s.fill(o["fill_color"], AA if p % 3 else NOAA)
+            if o["stroke"]:
+                s.stroke(o["stroke_color"], o["stroke_width"] * 2, R.stroke_flags(p % 3, (p // 3) % 3, p % 2 == 0))
+        s.pop()
+    return s
+
+
+def cached_frames(wl):
+    pre1 = Script().global_alpha(0.5).translate(100, 50)      # hasCache: the global alpha is ignored while the cache is filled
+    pre2 = Script().translate(300, 200).rotate(0.5)           # same average scale: rendered from the cache
+    return F.reference_frames(s_cached_drawing(wl), [pre1, pre2], flags=R.CL_CACHEABLE)
+
+
+def check_local_cache(ref_cache, pos, color, idx, meshes, draws):
+    """The reference's CommandListCache (local-space meshes per cached command) == the tessellated + localised batch."""
+    assert len(ref_cache["meshes"]) == meshes.shape[0] and len(ref_cache["commands"]) == draws.shape[0]
+    for m, (rpos, rcol, ridx) in zip(meshes, ref_cache["meshes"]):
+        v0, nv, i0, ni = int(m["first_vertex"]), int(m["num_vertices"]), int(m["first_index"]), int(m["num_indices"])
+        assert nv == rpos.shape[0] and ni == ridx.shape[0]
+        assert np.array_equal(pos[v0:v0 + nv].view(np.uint32), rpos.view(np.uint32))
+        assert np.array_equal(idx[i0:i0 + ni], ridx)
+        if rcol is not None:
+            assert np.array_equal(color[v0:v0 + nv], rcol)
+
+
+def test_shape_cache_cpu(rt, wl, oracle):
+    f1, f2 = cached_frames(wl)
+    assert f2["cache"] is not None and f2["cache"]["avg_scale"] == 1.0
+    ps, d1, n, extra = F.decode(rt, f1, flags=R.CL_CACHEABLE)
+    # frame 1: drawn while caching (colours without the global alpha)
+    res, cmds, idx = F.cpu_frame(oracle, ps, d1, 65536)
+    F.assert_frame_equal(f1["frame"], res.pos, res.color, idx, res.meshes, cmds, d1, extra["draw_state"], 65536, what="caching frame")
+    oracle.cache_localize(d1, res)
+    check_local_cache(f2["cache"], res.pos, res.color, res.idx, res.meshes, d1)
+    # frame 2: every cached command re-submitted under the transform its fill / stroke command sees now
+    ps2, d2, n2, extra2 = F.decode(rt, f2, flags=R.CL_CACHEABLE)
+    inst = F.cache_instances(rt.capi, res.meshes, d2)
+    got = oracle.cache_submit(res, inst)
+    st, cmds2, idx2 = oracle.assemble(got.meshes, got.idx, 65536)
+    assert st == 0
+    F.assert_frame_equal(f2["frame"], got.pos, got.color, idx2, got.meshes, cmds2, d2, None, 65536, what="cached frame")
+
+
 # ---- GPU: the same frames through vgx_tessellate + vgx_set_assembly ------------------------------------------------------------
 def gpu_frame(rt, gpu_ctx, ps, draws, max_vb, uv_bytes=4, uv_value=0):
     import torch
@@ -337,3 +392,40 @@ def test_gpu_nested_lists(rt, wl, gpu_ctx):
     ps, draws, n, extra = F.decode(rt, ref)
     got = gpu_frame(rt, gpu_ctx, ps, draws, 2048)
     F.assert_frame_equal(ref["frame"], got["pos"], got["color"], got["idx"], got["meshes"], got["cmds"], draws, extra["draw_state"], 2048, what="nested")
+
+
+@pytest.mark.gpu
+def test_shape_cache_gpu(rt, wl, gpu_ctx):
+    """vgx_cache_localize == the reference's CommandListCache, vgx_cache_submit == the frame the reference renders from it."""
+    import torch
+    f1, f2 = cached_frames(wl)
+    ps, d1, n, extra = F.decode(rt, f1, flags=R.CL_CACHEABLE)
+    pset = rt.PathSet(gpu_ctx, ps)
+    dd = rt.upload_draws(d1)
+    sizes = rt.tessellate_count(gpu_ctx, pset, dd, d1.shape[0])
+    bufs = rt.MeshBuffers(dd.device, sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"])
+    rt.tessellate_emit(gpu_ctx, pset, dd, d1.shape[0], bufs)
+    cache = rt.MeshCache(gpu_ctx, bufs, sizes, dd, d1.shape[0])  # vgx_cache_localize
+    torch.cuda.synchronize()
+    pset.close()
+    nv, ni, nm = cache.nv, sizes["num_indices"], cache.nm
+    meshes = bufs.meshes[:nm * 32].cpu().numpy().view(rt.capi.mesh_dtype)
+    check_local_cache(f2["cache"], bufs.pos[:nv].cpu().numpy(), bufs.color[:nv].cpu().numpy().view(np.uint32),
+                      bufs.idx[:ni].cpu().numpy().view(np.uint16), meshes, d1)
+    ps2, d2, n2, extra2 = F.decode(rt, f2, flags=R.CL_CACHEABLE)
+    inst = F.cache_instances(rt.capi, meshes, d2)
+    raw = torch.from_numpy(np.ascontiguousarray(inst).view(np.uint8).reshape(-1).copy()).to("cuda:0")
+    out = rt.MeshBuffers(raw.device, nv, ni, nm)
+    cmds = torch.zeros((nm + 2) * 48, dtype=torch.uint8, device="cuda:0")
+    ncmd = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+    gpu_ctx.set_assembly(cmds, 65536, ncmd)
+    try:
+        rt.cache_submit(gpu_ctx, cache, raw, inst.shape[0], out)
+        torch.cuda.synchronize()
+    finally:
+        gpu_ctx.set_assembly(None)
+    assert int(out.dev_status.item()) == 0
+    k = int(ncmd.item())
+    F.assert_frame_equal(f2["frame"], out.pos[:nv].cpu().numpy(), out.color[:nv].cpu().numpy().view(np.uint32), out.idx[:ni].cpu().numpy().view(np.uint16),
+                         out.meshes[:nm * 32].cpu().numpy().view(rt.capi.mesh_dtype), cmds[:k * 48].cpu().numpy().view(rt.capi.drawcmd_dtype),
+                         d2, None, 65536, what="cached frame")

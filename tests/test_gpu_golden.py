@@ -63,7 +63,7 @@ def test_golden_checksums_on_gpu(rt, gpu_ctx, wl, name):
         assert gu.sha(getattr(got, k)) == c[k], (name, k)
 
 
-def test_full_size_tiger_properties(rt, gpu_ctx, wl, oracle):
+def test_full_size_tiger_properties(rt, gpu_ctx, wl, oracle, monkeypatch):
     """BASELINE config 2 at full size (Tiger x10k = 2.4 M draws, 415 M vertices): size-independent checks.
       - totals = 10 000 x the single-instance totals of the golden run (flatten is translation invariant),
       - mesh table is a consistent exclusive scan,
@@ -126,7 +126,27 @@ def test_full_size_tiger_properties(rt, gpu_ctx, wl, oracle):
         assert np.array_equal(b2.pos[inst * nv1:(inst + 1) * nv1].cpu().numpy().view(np.uint32), ref.pos.view(np.uint32)), inst
         assert np.array_equal(b2.idx[inst * ni1:(inst + 1) * ni1].cpu().numpy().view(np.uint16), ref.idx), inst
         assert np.array_equal(b2.color[inst * nv1:(inst + 1) * nv1].cpu().numpy().view(np.uint32), ref.color), inst
-    del r, idx, col, b2
+    del idx, col, b2
+    torch.cuda.empty_cache()
+    # The same batch through the command-parallel single-pass kernel (k_flatten_build: what every batch that is NOT
+    # instanced runs, with its heap-block switches at 140 M polyline vertices): byte-identical streams.
+    monkeypatch.setenv("VGX_INST", "0")
+    ctx0 = rt.Context(0)
+    pset0 = rt.PathSet(ctx0, ps)
+    rt.tessellate_count(ctx0, pset0, dd, draws.shape[0])
+    b3 = rt.MeshBuffers(dd.device, nv, ni, nm)
+    ctx0.set_profiling(True)
+    rt.tessellate_async(ctx0, pset0, dd, draws.shape[0], b3)
+    torch.cuda.synchronize()
+    assert "flatten_build" in [n for n, _ in ctx0.stage_times()]
+    assert int(b3.dev_status.item()) == 0
+    assert torch.equal(b3.pos[:nv].view(torch.int32), r.bufs.pos[:nv].view(torch.int32))
+    assert torch.equal(b3.color[:nv], r.bufs.color[:nv])
+    assert torch.equal(b3.idx[:ni], r.bufs.idx[:ni])
+    assert torch.equal(b3.meshes[:nm * 32], r.bufs.meshes[:nm * 32])
+    pset0.close()
+    ctx0.close()
+    del r, b3
     torch.cuda.empty_cache()
     pset.close()
 

@@ -234,3 +234,21 @@ def test_grouped_mode_small_lane_blocks_uneven_groups(rt, wl, oracle, monkeypatc
     assert got.status == 0
     assert_mesh_equal(got, ref, "uneven groups, small lane blocks")
     ctx.close()
+
+
+def test_grouped_mode_path_set_larger_than_the_lds_table(rt, gpu_ctx, wl, oracle):
+    """More than 4096 paths in the set: the counting sort's LDS table is a one-probe hash (slot = path mod 4096, first comer
+    owns the slot, the others take the global counters). Used paths collide on purpose (p and p + 4096)."""
+    ps = wl.fuzz_paths(770, npaths=4400, with_shapes=False, with_polylines=True)
+    base = wl.fuzz_draws(ps, 770)
+    rs = np.random.RandomState(770)
+    hot = np.concatenate([np.arange(3, 3 + 40), np.arange(4099, 4099 + 24)])  # 3 .. 26 collide with 4099 .. 4122
+    d = np.concatenate([np.repeat(base[hot], 64), base[rs.randint(0, 4400, size=40)]])
+    d["mtx"][:, 4] += rs.uniform(-50, 50, size=d.shape[0]).astype(np.float32)
+    d = d[rs.permutation(d.shape[0])]
+    assert d.shape[0] > 2048 and d.shape[0] // len(np.unique(d["path"])) >= 32
+    ref = oracle.tessellate(ps, d)
+    got = _async(rt, gpu_ctx, ps, d)
+    assert got.status == 0
+    assert_mesh_equal(got, ref, "grouped mode, hashed LDS table")
+    assert int(got.dev_sizes[NUM_SERIAL]) == 0  # built by the instanced lanes

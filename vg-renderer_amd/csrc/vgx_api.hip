@@ -472,7 +472,7 @@ void runFlattenBuild(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 	setInstArgs(ctx, ps, ndraws, a); // periodic: the same value runCmdPrefix checked the draws against
 	if (a.inst_order) { // grouped mode: this batch's draws sorted by path
 		vgx_launch_inst_group(draws, ndraws, ps->dev.npaths, (uint32_t*)ctx->instHist.p, (uint32_t*)ctx->instCursor.p, (uint64_t*)ctx->instStart.p,
-			(uint64_t*)ctx->instTaskStart.p, (uint32_t*)ctx->instTaskPath.p, ctx->instCapTasks, (uint32_t*)ctx->instOrder.p, (VgxTotals*)ctx->totals.p, s);
+			(uint64_t*)ctx->instTaskStart.p, (uint32_t*)ctx->instTaskPath.p, ctx->instCapTasks, (uint32_t*)ctx->instOrder.p, (VgxTotals*)ctx->totals.p, ctx->partial.p, s);
 		mark(ctx, s, "inst_group");
 	}
 	a.mprep = (VgxMeshPrep*)ctx->mprep.p; // k_flatten_gather / k_flatten_serial write the per-mesh constants with the descriptors
@@ -502,7 +502,7 @@ void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps,
 	op.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; op.mtab = (vgx_mesh*)ctx->mtab.p;
 	op.prefixFill = (uint64_t*)ctx->elemPrefix.p; op.prefixStroke = (uint64_t*)ctx->elemPrefixS.p;
 	op.totals = (VgxTotals*)ctx->totals.p; op.caps = outCaps; op.checkCaps = checkCaps;
-	op.meshesOut = meshesOut;
+	op.meshesOut = meshesOut; op.fixedSize = 0; op.fixedCount = 0;
 	vgx_device_scan(op, (Sum3*)ctx->partial.p, s, ctx->caps.meshes);
 	mark(ctx, s, "scan_meshes");
 }
@@ -1012,7 +1012,7 @@ static int flattenCountCommon(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_dra
 		// ... and how many different paths the draws use (grouped mode, when the sequence does not repeat)
 		if ((st = ensureInstGroup(ctx, ps->dev.npaths, ndraws, false)) != VGX_OK) { return st; }
 		vgx_launch_inst_group(draws, ndraws, ps->dev.npaths, (uint32_t*)ctx->instHist.p, nullptr, (uint64_t*)ctx->instStart.p, (uint64_t*)ctx->instTaskStart.p,
-			nullptr, 0, nullptr, (VgxTotals*)ctx->totals.p, s);
+			nullptr, 0, nullptr, (VgxTotals*)ctx->totals.p, ctx->partial.p, s);
 	}
 	if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
 	if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; }
@@ -1204,7 +1204,7 @@ int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 		OpMeshAll opM;
 		opM.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; opM.mtab = (vgx_mesh*)ctx->mtab.p; opM.meshesOut = out->meshes;
 		opM.prefixFill = (uint64_t*)ctx->elemPrefix.p; opM.prefixStroke = (uint64_t*)ctx->elemPrefixS.p;
-		opM.totals = (VgxTotals*)ctx->totals.p; opM.caps = outCaps; opM.checkCaps = 1;
+		opM.totals = (VgxTotals*)ctx->totals.p; opM.caps = outCaps; opM.checkCaps = 1; opM.fixedSize = 0; opM.fixedCount = 0;
 		vgx_launch_small_middle(f, sa, &opD, &opM, dev_sizes, dev_status, s);
 		mark(ctx, s, "small_middle");
 		return runStrokeEmit(ctx, draws, out, s, nullptr, true);
@@ -1598,15 +1598,24 @@ extern "C" int vgx_gather(vgx_ctx* ctx, void* rccl_comm, int root, const vgx_mes
 	if (me.num_vertices > local->cap_vertices || me.num_indices > local->cap_indices || (local->meshes && me.num_meshes > local->cap_meshes)) {
 		return VGX_E_INVALID_ARG; // the sizes do not describe `local`
 	}
+	if ((me.num_vertices && (!local->pos || !local->color)) || (me.num_indices && !local->idx) || (me.num_meshes && !local->meshes)) {
+		return VGX_E_INVALID_ARG;
+	}
+	// Inside a group a failed call must not return at once: the group stays open on this thread and every later collective
+	// would be queued and never issued. Remember the first error, skip the rest, always close the group.
+	int rcclErr = 0;
+#define RCCLGRP(call) do { if (!rcclErr) { rcclErr = (call); } } while (0)
 	if (rank != root) {
 		RCCLCHK(ctx, ctx->rccl->GroupStart());
 		if (me.num_vertices) {
-			RCCLCHK(ctx, ctx->rccl->Send(local->pos, me.num_vertices * 8, kNcclUint8, root, rccl_comm, s));
-			RCCLCHK(ctx, ctx->rccl->Send(local->color, me.num_vertices * 4, kNcclUint8, root, rccl_comm, s));
+			RCCLGRP(ctx->rccl->Send(local->pos, me.num_vertices * 8, kNcclUint8, root, rccl_comm, s));
+			RCCLGRP(ctx->rccl->Send(local->color, me.num_vertices * 4, kNcclUint8, root, rccl_comm, s));
 		}
-		if (me.num_indices) { RCCLCHK(ctx, ctx->rccl->Send(local->idx, me.num_indices * 2, kNcclUint8, root, rccl_comm, s)); }
-		if (me.num_meshes) { RCCLCHK(ctx, ctx->rccl->Send(local->meshes, me.num_meshes * sizeof(vgx_mesh), kNcclUint8, root, rccl_comm, s)); }
-		RCCLCHK(ctx, ctx->rccl->GroupEnd());
+		if (me.num_indices) { RCCLGRP(ctx->rccl->Send(local->idx, me.num_indices * 2, kNcclUint8, root, rccl_comm, s)); }
+		if (me.num_meshes) { RCCLGRP(ctx->rccl->Send(local->meshes, me.num_meshes * sizeof(vgx_mesh), kNcclUint8, root, rccl_comm, s)); }
+		const int endErr = ctx->rccl->GroupEnd();
+		if (!rcclErr) { rcclErr = endErr; }
+		if (rcclErr) { ctx->lastHipError = 10000 + rcclErr; return VGX_E_HIP; }
 		return VGX_OK;
 	}
 	if (!global || !global->pos || !global->color || !global->idx || !global->meshes) {
@@ -1635,11 +1644,11 @@ extern "C" int vgx_gather(vgx_ctx* ctx, void* rccl_comm, int root, const vgx_mes
 			if (z.num_meshes) { noteHip(ctx, hipMemcpyAsync(global->meshes + mo, local->meshes, z.num_meshes * sizeof(vgx_mesh), hipMemcpyDeviceToDevice, s)); }
 		} else {
 			if (z.num_vertices) {
-				RCCLCHK(ctx, ctx->rccl->Recv(global->pos + 2 * vo, z.num_vertices * 8, kNcclUint8, r, rccl_comm, s));
-				RCCLCHK(ctx, ctx->rccl->Recv(global->color + vo, z.num_vertices * 4, kNcclUint8, r, rccl_comm, s));
+				RCCLGRP(ctx->rccl->Recv(global->pos + 2 * vo, z.num_vertices * 8, kNcclUint8, r, rccl_comm, s));
+				RCCLGRP(ctx->rccl->Recv(global->color + vo, z.num_vertices * 4, kNcclUint8, r, rccl_comm, s));
 			}
-			if (z.num_indices) { RCCLCHK(ctx, ctx->rccl->Recv(global->idx + io, z.num_indices * 2, kNcclUint8, r, rccl_comm, s)); }
-			if (z.num_meshes) { RCCLCHK(ctx, ctx->rccl->Recv(global->meshes + mo, z.num_meshes * sizeof(vgx_mesh), kNcclUint8, r, rccl_comm, s)); }
+			if (z.num_indices) { RCCLGRP(ctx->rccl->Recv(global->idx + io, z.num_indices * 2, kNcclUint8, r, rccl_comm, s)); }
+			if (z.num_meshes) { RCCLGRP(ctx->rccl->Recv(global->meshes + mo, z.num_meshes * sizeof(vgx_mesh), kNcclUint8, r, rccl_comm, s)); }
 		}
 		if (z.num_meshes && (vo || io || dofs)) {
 			GatherRebase& g = ra.r[ra.n++];
@@ -1648,7 +1657,12 @@ extern "C" int vgx_gather(vgx_ctx* ctx, void* rccl_comm, int root, const vgx_mes
 		}
 		vo += z.num_vertices; io += z.num_indices; mo += z.num_meshes; dofs += z.num_draws;
 	}
-	RCCLCHK(ctx, ctx->rccl->GroupEnd());
+	{
+		const int endErr = ctx->rccl->GroupEnd();
+		if (!rcclErr) { rcclErr = endErr; }
+		if (rcclErr) { ctx->lastHipError = 10000 + rcclErr; return VGX_E_HIP; }
+	}
+#undef RCCLGRP
 	if (ra.n) {
 		const uint64_t blocks = (maxMeshes + 255) / 256;
 		hipLaunchKernelGGL(k_gather_rebase, dim3((unsigned)(blocks > 4096 ? 4096 : blocks), (unsigned)ra.n), dim3(256), 0, s, ra);

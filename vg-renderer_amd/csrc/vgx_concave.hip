@@ -84,6 +84,26 @@ __global__ __launch_bounds__(256) void k_concave_move(VgxConcaveArgs A)
 
 // per fill: vertex / index counts -> offsets + mesh record (scan operator, see vgx_scan.h); defined in vgx_api.hip
 
+// The contour table is device memory the host never sees: before anything is written through it, every contour must point
+// back at the fill whose range holds it, lie inside the vertex array and follow its predecessor (the fringe kernel derives a
+// contour's place in its mesh from first_vertex differences). A bad table ends as VGX_E_INVALID_ARG, never as a stray write.
+__global__ __launch_bounds__(256) void k_concave_validate(VgxConcaveArgs A)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.ncontours; i += (uint64_t)gridDim.x * blockDim.x) {
+		const vgx_contour c = A.contours[i];
+		bool ok = c.fill < A.nfills && c.first_vertex <= A.num_contour_vertices && c.num_vertices <= A.num_contour_vertices - c.first_vertex;
+		if (ok) {
+			const vgx_concave_fill fl = A.fills[c.fill];
+			ok = i >= fl.first_contour && i - fl.first_contour < fl.num_contours;
+		}
+		if (ok && i > 0) {
+			const vgx_contour q = A.contours[i - 1];
+			ok = q.first_vertex <= c.first_vertex && q.num_vertices <= c.first_vertex - q.first_vertex;
+		}
+		if (!ok) { atomicCAS(&A.totals->status, (uint32_t)VGX_OK, (uint32_t)VGX_E_INVALID_ARG); }
+	}
+}
+
 __global__ __launch_bounds__(256) void k_concave_fringe(VgxConcaveArgs A)
 {
 	if (A.totals->status != VGX_OK) { return; }
@@ -143,6 +163,7 @@ void vgx_launch_concave_move(const VgxConcaveArgs& a, hipStream_t s)
 
 void vgx_launch_concave_emit(const VgxConcaveArgs& a, hipStream_t s)
 {
+	hipLaunchKernelGGL(k_concave_validate, dim3(256), dim3(256), 0, s, a);
 	hipLaunchKernelGGL(k_concave_fringe, dim3(1024), dim3(256), 0, s, a);
 	hipLaunchKernelGGL(k_concave_interior, dim3(1024), dim3(256), 0, s, a);
 }

@@ -884,6 +884,9 @@ __global__ __launch_bounds__(VGX_SMALL_THREADS) void k_small_middle(VgxSmallArgs
 	// (5) scan over the meshes: element / vertex / index offsets, the caller's mesh table, totals
 	{
 		OpMeshAll op = K.opMeshes;
+		// the status word may have been set by an atomic in (3) / (4): a plain load could differ between waves (stale L1 line)
+		op.fixedSize = 1;
+		op.fixedCount = (small_status(T) == VGX_OK) ? T->sizes.num_meshes : 0;
 		block_scan_all<OpMeshAll, VGX_SMALL_THREADS>(op, s_wave);
 	}
 	// (6) publish

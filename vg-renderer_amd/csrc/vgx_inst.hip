@@ -23,6 +23,7 @@
 #include "vgx_wave.h"
 #include "vgx_walk.h"
 #include "vgx_inst.h"
+#include "vgx_scan.h"
 
 namespace {
 
@@ -561,10 +562,14 @@ __global__ __launch_bounds__(256) void k_inst_verify(const vgx_draw* draws, uint
 // of its path; only the heap locality of the emit kernels' reads depends on it.
 // Atomics on neighbouring counters serialise per cache line in the memory-side cache (2.2 M draws over 240 paths = 8 lines:
 // the two passes took 2.1 ms with plain global atomics), so a workgroup counts its slice of the draws in LDS and touches
-// the global counters once per used path. Path sets with more than VGX_INST_LDS_PATHS paths take the plain form.
+// the global counters once per used path. The LDS table is direct for path sets of up to VGX_INST_LDS_PATHS paths and a
+// one-probe hash (slot = path mod table size, first comer owns the slot) beyond: draws of a slot's owner count in LDS,
+// everything else goes to the global counter at once -- many draws on few paths stay in LDS, a million draws on a million
+// paths are a million atomics on a million different addresses, which do not serialise.
 #define VGX_INST_LDS_PATHS 4096
 #define VGX_INST_GROUP_THREADS 1024
 #define VGX_INST_GROUP_BLOCKS 256
+#define VGX_INST_NO_KEY 0xFFFFFFFFu
 __device__ __forceinline__ void inst_slice(uint64_t n, uint64_t* lo, uint64_t* hi)
 {
 	const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
@@ -572,124 +577,122 @@ __device__ __forceinline__ void inst_slice(uint64_t n, uint64_t* lo, uint64_t* h
 	*lo = l < n ? l : n;
 	*hi = l + per < n ? l + per : n;
 }
+// true: path p counts in LDS slot *slot of this workgroup
+__device__ __forceinline__ bool inst_slot(uint32_t* s_key, uint32_t p, uint32_t npaths, uint32_t* slot)
+{
+	if (npaths <= VGX_INST_LDS_PATHS) { *slot = p; return true; }
+	const uint32_t sl = p & (VGX_INST_LDS_PATHS - 1);
+	*slot = sl;
+	const uint32_t old = atomicCAS(&s_key[sl], VGX_INST_NO_KEY, p);
+	return old == VGX_INST_NO_KEY || old == p;
+}
 
 __global__ __launch_bounds__(VGX_INST_GROUP_THREADS) void k_inst_hist(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, uint32_t* hist)
 {
 	__shared__ uint32_t s_cnt[VGX_INST_LDS_PATHS];
+	__shared__ uint32_t s_key[VGX_INST_LDS_PATHS];
 	uint64_t lo, hi;
 	inst_slice(ndraws, &lo, &hi);
-	if (npaths > VGX_INST_LDS_PATHS) {
-		for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-			const uint32_t p = draws[i].path;
-			if (p < npaths) { atomicAdd(&hist[p], 1u); } // an invalid path id was reported by the command scan
-		}
-		return;
-	}
-	for (uint32_t p = threadIdx.x; p < npaths; p += blockDim.x) { s_cnt[p] = 0; }
+	const bool hashed = npaths > VGX_INST_LDS_PATHS;
+	const uint32_t nslots = hashed ? (uint32_t)VGX_INST_LDS_PATHS : npaths;
+	for (uint32_t p = threadIdx.x; p < nslots; p += blockDim.x) { s_cnt[p] = 0; s_key[p] = hashed ? VGX_INST_NO_KEY : p; }
 	__syncthreads();
 	for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
 		const uint32_t p = draws[i].path;
-		if (p < npaths) { atomicAdd(&s_cnt[p], 1u); }
+		if (p >= npaths) { continue; } // an invalid path id was reported by the command scan
+		uint32_t slot;
+		if (inst_slot(s_key, p, npaths, &slot)) { atomicAdd(&s_cnt[slot], 1u); } else { atomicAdd(&hist[p], 1u); }
 	}
 	__syncthreads();
-	for (uint32_t p = threadIdx.x; p < npaths; p += blockDim.x) {
-		const uint32_t c = s_cnt[p];
-		if (c) { atomicAdd(&hist[p], c); }
+	for (uint32_t sl = threadIdx.x; sl < nslots; sl += blockDim.x) {
+		const uint32_t c = s_cnt[sl];
+		if (c) { atomicAdd(&hist[s_key[sl]], c); }
 	}
 }
 
-// One workgroup: exclusive scans of the histogram (draw ranges, task ranges), the task -> path table, the totals.
-#define VGX_INST_PLAN_THREADS 1024
-__global__ __launch_bounds__(VGX_INST_PLAN_THREADS) void k_inst_plan(const uint32_t* hist, uint32_t npaths, uint64_t* start, uint64_t* taskStart, uint32_t* taskPath, uint64_t capTasks, VgxTotals* totals)
+// Exclusive scans of the histogram (draw ranges, task ranges), the task -> path table, the totals: a device scan over the
+// paths (one workgroup up to 1024 paths, three passes beyond -- a path set may hold a million one-cubic paths).
+struct OpInstPlan
 {
-	__shared__ uint64_t s_wave[3 * (VGX_INST_PLAN_THREADS / 64)];
-	__shared__ uint64_t s_carry[3];
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	if (threadIdx.x < 3) { s_carry[threadIdx.x] = 0; }
-	__syncthreads();
-	for (uint32_t base = 0; base < npaths; base += VGX_INST_PLAN_THREADS) {
-		const uint32_t p = base + threadIdx.x;
-		const uint64_t cnt = p < npaths ? hist[p] : 0u;
-		const uint64_t nt = (cnt + VGX_WAVE - 1) / VGX_WAVE;
-		uint64_t v[3] = { cnt, nt, cnt ? 1ull : 0ull };
-		uint64_t incl[3];
-		for (int f = 0; f < 3; ++f) {
-			uint64_t x = v[f];
-			for (int dd = 1; dd < 64; dd <<= 1) {
-				const uint64_t y = __shfl_up((unsigned long long)x, dd);
-				if (lane >= dd) { x += y; }
-			}
-			incl[f] = x;
-			if (lane == 63) { s_wave[f * (VGX_INST_PLAN_THREADS / 64) + wave] = x; }
-		}
-		__syncthreads();
-		uint64_t excl[3];
-		for (int f = 0; f < 3; ++f) {
-			uint64_t b = s_carry[f];
-			for (int w = 0; w < wave; ++w) { b += s_wave[f * (VGX_INST_PLAN_THREADS / 64) + w]; }
-			excl[f] = b + incl[f] - v[f];
-		}
-		if (p < npaths) {
-			start[p] = excl[0];
-			taskStart[p] = excl[1];
-			if (taskPath) {
-				for (uint64_t j = 0; j < nt; ++j) { if (excl[1] + j < capTasks) { taskPath[excl[1] + j] = p; } }
-			}
-		}
-		__syncthreads();
-		if (threadIdx.x == VGX_INST_PLAN_THREADS - 1) { for (int f = 0; f < 3; ++f) { s_carry[f] = excl[f] + v[f]; } }
-		__syncthreads();
+	const uint32_t* hist;
+	uint32_t npaths;
+	uint64_t* start;
+	uint64_t* taskStart;
+	uint32_t* taskPath;
+	uint64_t capTasks;
+	VgxTotals* totals;
+	__device__ uint64_t size() const { return npaths; }
+	__device__ Sum3 load(uint64_t p) const
+	{
+		Sum3 r = sum3_zero();
+		const uint64_t cnt = hist[p];
+		r.a = cnt; r.b = (cnt + VGX_WAVE - 1) / VGX_WAVE; r.c = cnt ? 1ull : 0ull;
+		return r;
 	}
-	if (threadIdx.x == 0) {
-		start[npaths] = s_carry[0];
-		taskStart[npaths] = s_carry[1];
-		totals->inst_num_tasks = s_carry[1];
-		totals->inst_distinct = s_carry[2];
-		if (taskPath && s_carry[1] > capTasks) { atomicCAS(&totals->status, (uint32_t)VGX_OK, (uint32_t)VGX_E_NOSPACE); }
+	__device__ void store(uint64_t p, Sum3 e) const
+	{
+		start[p] = e.a;
+		taskStart[p] = e.b;
+		if (taskPath) {
+			const uint64_t nt = ((uint64_t)hist[p] + VGX_WAVE - 1) / VGX_WAVE;
+			for (uint64_t j = 0; j < nt; ++j) { if (e.b + j < capTasks) { taskPath[e.b + j] = (uint32_t)p; } }
+		}
 	}
-}
+	__device__ void finish(Sum3 t) const
+	{
+		start[npaths] = t.a;
+		taskStart[npaths] = t.b;
+		totals->inst_num_tasks = t.b;
+		totals->inst_distinct = t.c;
+		if (taskPath && t.b > capTasks) { atomicCAS(&totals->status, (uint32_t)VGX_OK, (uint32_t)VGX_E_NOSPACE); }
+	}
+};
 
 __global__ __launch_bounds__(VGX_INST_GROUP_THREADS) void k_inst_scatter(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, const uint64_t* start, uint32_t* cursor, uint32_t* order)
 {
 	__shared__ uint32_t s_cnt[VGX_INST_LDS_PATHS];
 	__shared__ uint32_t s_base[VGX_INST_LDS_PATHS];
+	__shared__ uint32_t s_key[VGX_INST_LDS_PATHS];
 	uint64_t lo, hi;
 	inst_slice(ndraws, &lo, &hi);
-	if (npaths > VGX_INST_LDS_PATHS) {
-		for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-			const uint32_t p = draws[i].path;
-			if (p < npaths) { order[start[p] + atomicAdd(&cursor[p], 1u)] = (uint32_t)i; }
-		}
-		return;
-	}
+	const bool hashed = npaths > VGX_INST_LDS_PATHS;
+	const uint32_t nslots = hashed ? (uint32_t)VGX_INST_LDS_PATHS : npaths;
 	// the slice's own histogram -> one reservation per used path in the path's range -> ranks inside the reservation
-	for (uint32_t p = threadIdx.x; p < npaths; p += blockDim.x) { s_cnt[p] = 0; }
+	// (draws whose path does not own its hash slot take their place with a global atomic in the first pass)
+	for (uint32_t p = threadIdx.x; p < nslots; p += blockDim.x) { s_cnt[p] = 0; s_key[p] = hashed ? VGX_INST_NO_KEY : p; }
 	__syncthreads();
 	for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
 		const uint32_t p = draws[i].path;
-		if (p < npaths) { atomicAdd(&s_cnt[p], 1u); }
+		if (p >= npaths) { continue; }
+		uint32_t slot;
+		if (inst_slot(s_key, p, npaths, &slot)) { atomicAdd(&s_cnt[slot], 1u); }
+		else { order[start[p] + atomicAdd(&cursor[p], 1u)] = (uint32_t)i; }
 	}
 	__syncthreads();
-	for (uint32_t p = threadIdx.x; p < npaths; p += blockDim.x) {
-		const uint32_t c = s_cnt[p];
-		s_base[p] = c ? atomicAdd(&cursor[p], c) : 0u;
-		s_cnt[p] = 0;
+	for (uint32_t sl = threadIdx.x; sl < nslots; sl += blockDim.x) {
+		const uint32_t c = s_cnt[sl];
+		s_base[sl] = c ? atomicAdd(&cursor[s_key[sl]], c) : 0u;
+		s_cnt[sl] = 0;
 	}
 	__syncthreads();
 	for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
 		const uint32_t p = draws[i].path;
-		if (p < npaths) { order[start[p] + s_base[p] + atomicAdd(&s_cnt[p], 1u)] = (uint32_t)i; }
+		if (p >= npaths) { continue; }
+		const uint32_t sl = hashed ? (p & (VGX_INST_LDS_PATHS - 1)) : p;
+		if (s_key[sl] == p) { order[start[p] + s_base[sl] + atomicAdd(&s_cnt[sl], 1u)] = (uint32_t)i; }
 	}
 }
 
 } // namespace
 
 void vgx_launch_inst_group(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, uint32_t* hist, uint32_t* cursor, uint64_t* start, uint64_t* taskStart,
-	uint32_t* taskPath, uint64_t capTasks, uint32_t* order, VgxTotals* totals, hipStream_t s)
+	uint32_t* taskPath, uint64_t capTasks, uint32_t* order, VgxTotals* totals, void* scanPartial, hipStream_t s)
 {
 	(void)hipMemsetAsync(hist, 0, ((size_t)npaths + 1) * sizeof(uint32_t), s);
 	hipLaunchKernelGGL(k_inst_hist, dim3(VGX_INST_GROUP_BLOCKS), dim3(VGX_INST_GROUP_THREADS), 0, s, draws, ndraws, npaths, hist);
-	hipLaunchKernelGGL(k_inst_plan, dim3(1), dim3(VGX_INST_PLAN_THREADS), 0, s, (const uint32_t*)hist, npaths, start, taskStart, taskPath, capTasks, totals);
+	OpInstPlan op;
+	op.hist = hist; op.npaths = npaths; op.start = start; op.taskStart = taskStart; op.taskPath = taskPath; op.capTasks = capTasks; op.totals = totals;
+	vgx_device_scan(op, (Sum3*)scanPartial, s, npaths);
 	if (order) {
 		(void)hipMemsetAsync(cursor, 0, ((size_t)npaths + 1) * sizeof(uint32_t), s);
 		hipLaunchKernelGGL(k_inst_scatter, dim3(VGX_INST_GROUP_BLOCKS), dim3(VGX_INST_GROUP_THREADS), 0, s, draws, ndraws, npaths, (const uint64_t*)start, cursor, order);

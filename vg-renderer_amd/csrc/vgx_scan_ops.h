@@ -112,7 +112,9 @@ struct OpMeshAll
 	VgxTotals* totals;
 	VgxCaps caps;
 	int checkCaps;
-	__device__ uint64_t size() const { return totals->status == VGX_OK ? totals->sizes.num_meshes : 0; }
+	int fixedSize;       // 1: the item count is fixedCount (single-workgroup callers read it once, uniformly, with a fresh load:
+	uint64_t fixedCount; // every thread must see the same count or the block barriers inside the scan mismatch)
+	__device__ uint64_t size() const { return fixedSize ? fixedCount : (totals->status == VGX_OK ? totals->sizes.num_meshes : 0); }
 	__device__ Sum3 load(uint64_t i) const
 	{
 		Sum3 r = sum3_zero();
@@ -135,7 +137,7 @@ struct OpMeshAll
 	}
 	__device__ void finish(Sum3 t) const
 	{
-		const uint64_t n = totals->status == VGX_OK ? totals->sizes.num_meshes : 0;
+		const uint64_t n = size();
 		prefixFill[n] = t.a;
 		prefixStroke[n] = t.b;
 		totals->sizes.num_elements = t.a + t.b;

@@ -83,6 +83,10 @@ def main():
         rs = np.random.RandomState(1)
         draws = draws[rs.uniform(size=draws.shape[0]) > 0.1]
         draws = draws[rs.permutation(draws.shape[0])]
+    elif which == "fillonly":     # Tiger x10k without its strokes: the fill meshes' output streams have no gaps
+        ps, ops = wl.tiger_paths()
+        draws = wl.tiger_draws(ops, 10000)
+        draws["stroke_flags"] = 0
     else:
         K = int(which) if which.isdigit() else 10000
         ps, ops = wl.tiger_paths()

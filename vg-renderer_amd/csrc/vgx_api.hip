@@ -69,6 +69,7 @@ struct vgx_ctx
 	uint64_t* hostProbe;         // pinned
 	// options, read from the environment ONCE at vgx_create (tuning / testing knobs)
 	int optTwoPass, optNoFused, optBuildWaves, optFusedWaves, optPoolWalk, optNoSmall, optConcurrentEmit;
+	int optFill; // convex-fill kernel: 0 = k_fill, 1 / 2 / 4 = k_fill2 with that run length (VGX_FILL)
 	int optInst, optInstWaves; uint32_t optInstBlock; // instanced flatten kernel (vgx_inst.hip): on / grid / lane block
 	// instanced batches: period of the path sequence found by the last vgx_tessellate_count (0 = none). vgx_tessellate
 	// re-checks it on the device for the draws it is given.
@@ -572,13 +573,13 @@ int runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out, 
 		vgx_launch_stroke(true, b, vgxElementGrid(out->cap_vertices), ctx->sideStream);
 		(void)hipEventRecord(ctx->joinEv, ctx->sideStream);
 		a.elem_prefix = a.elem_prefix_fill;
-		vgx_launch_fill(a, vgxElementGrid(out->cap_vertices), s);
+		vgx_launch_fill(a, vgxElementGrid(out->cap_vertices), s, ctx->optFill);
 		(void)hipStreamWaitEvent(s, ctx->joinEv, 0);
 		mark(ctx, s, "fill_emit");
 		return launchStatus(ctx);
 	}
 	a.elem_prefix = a.elem_prefix_fill;
-	vgx_launch_fill(a, vgxElementGrid(out->cap_vertices), s);
+	vgx_launch_fill(a, vgxElementGrid(out->cap_vertices), s, ctx->optFill);
 	mark(ctx, s, "fill_emit");
 	a.elem_prefix = a.elem_prefix_stroke;
 	vgx_launch_stroke(true, a, vgxElementGrid(out->cap_vertices), s);
@@ -732,6 +733,8 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	ctx->optBuildWaves = VGX_BUILD_WAVES;
 	ctx->optConcurrentEmit = getenv("VGX_EXP_CONCURRENT_EMIT") ? 1 : 0;
 	ctx->optNoSmall = getenv("VGX_NO_SMALL") ? 1 : 0; // testing knob: frame-sized batches through the large-batch launch sequence
+	ctx->optFill = 0;
+	if (const char* e = getenv("VGX_FILL")) { const int v = atoi(e); if (v == 0 || v == 1 || v == 2 || v == 4 || v == 31 || v == 32 || v == 34) { ctx->optFill = v; } }
 	ctx->optInst = 1; ctx->optInstWaves = VGX_INST_WAVES; ctx->optInstBlock = VGX_INST_BLOCK; // VGX_INST=0: instanced batches through k_flatten_build as well
 	if (const char* e = getenv("VGX_INST")) { ctx->optInst = atoi(e) != 0; }
 	if (const char* e = getenv("VGX_INST_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { ctx->optInstWaves = v; } }

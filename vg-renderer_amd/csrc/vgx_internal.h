@@ -190,6 +190,6 @@ struct VgxCacheArgs
 void vgx_launch_cache_localize(const vgx_draw* draws, uint64_t ndraws, float* pos, const vgx_mesh* meshes, uint64_t numMeshes, hipStream_t s);
 void vgx_launch_cache_meshes(const VgxCacheArgs& a, hipStream_t s);
 void vgx_launch_cache_copy(const VgxCacheArgs& a, int numBlocks, hipStream_t s);
-void vgx_launch_fill(const VgxStrokeArgs& a, int numBlocks, hipStream_t s);
+void vgx_launch_fill(const VgxStrokeArgs& a, int numBlocks, hipStream_t s, int variant = 0); // variant: 0 k_fill, 1 / 2 / 4 k_fill2 with that run length
 
 #endif

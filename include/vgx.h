@@ -428,18 +428,18 @@ typedef struct vgx_cmdlist_out {
 } vgx_cmdlist_out;
 int vgx_cmdlist_decode(const void* bytes, uint32_t size, const vgx_cmdlist_state* state, vgx_cmdlist_out* out);
 
-/* Diagnostics of the last asynchronous call on this context: the device status word and, when the single-pass kernel of
- * vgx_tessellate gave up on a segment, why (reason = one of the VGX_FAIL_* codes of csrc/vgx_internal_types.h: a table of
+/* Diagnostics of the last asynchronous call on this context: the device status word and, when a kernel of
+ * vgx_tessellate gave up, why (reason = one of the VGX_FAIL_* codes of csrc/vgx_internal_types.h: a table of
  * the kernel was too small for the batch -- run vgx_tessellate_count on a batch like it --, the polyline heap or the
  * caller's output capacity was exhausted, ...). Synchronises `stream`. Not needed on the happy path. */
 typedef struct vgx_failure_info {
 	uint32_t status;        /* vgx_status of the device status word */
 	uint32_t reason;        /* 0 = none */
 	uint32_t aux;           /* reason specific (a count) */
-	uint32_t segment_items; /* commands per segment the context currently uses (0 = multi-kernel pipeline) */
-	uint64_t segment;       /* segment that failed first */
-	uint64_t prof[16];      /* -DVGX_FUSED_PROFILE builds of libvgx only (else 0): wave clock ticks (100 MHz) summed over all
-	                         * waves of the single-pass kernel: ticket, flatten, meshes, look-back, table + fills, strokes; [6] = segments */
+	uint32_t segment_items; /* reserved (0) */
+	uint64_t segment;       /* work item (segment / task) that failed first */
+	uint64_t prof[16];      /* -DVGX_INST_PROFILE builds of libvgx only (else 0): wave clock ticks (100 MHz) summed over all waves
+	                         * per phase of k_flatten_inst (profiles/inst_phases.py) */
 } vgx_failure_info;
 int vgx_get_failure_info(vgx_ctx* ctx, vgx_failure_info* out, void* stream);
 

@@ -330,8 +330,8 @@ def test_async_interleaved_mesh_classes_force_the_search_paths(rt, wl, vgr, orac
 @pytest.mark.gpu
 @pytest.mark.parametrize("waves", ["3", "17"])
 def test_async_heap_block_switches(rt, wl, oracle, waves, monkeypatch):
-    """The multi-kernel pipeline's single-pass flatten (k_flatten_build; what vgx_tessellate runs when the fused kernel
-    is not used) with only a few waves: every wave fills many 8192-vertex heap blocks, so chunks that do not fit, block
+    """The multi-kernel pipeline's single-pass flatten (k_flatten_build: what vgx_tessellate runs for batches that are not
+    instanced) with only a few waves: every wave fills many 8192-vertex heap blocks, so chunks that do not fit, block
     switches and the move of the sub-path that spans the switch all happen in a batch the oracle can check completely
     (at the default 4096 waves that needs > 33 M polyline vertices). Options are read at vgx_create: own context."""
     monkeypatch.setenv("VGX_BUILD_WAVES", waves)
@@ -352,14 +352,12 @@ def test_async_heap_block_switches(rt, wl, oracle, waves, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("waves", ["2", None, "fused"])
+@pytest.mark.parametrize("waves", ["2", None])
 def test_async_very_long_subpaths(rt, wl, oracle, waves, monkeypatch):
     """Sub-paths of 30 001 vertices built from single LINE_TO commands (470 chunks each). Multi-kernel pipeline: they
     outgrow several heap blocks, are moved with geometric growth, and their total feeds the heap sizing
-    (long_subpath_vertices). Fused kernel: they do not fit the LDS window, so every segment takes the heap path."""
-    if waves == "fused":
-        monkeypatch.setenv("VGX_FUSED", "1")
-    elif waves:
+    (long_subpath_vertices)."""
+    if waves:
         monkeypatch.setenv("VGX_BUILD_WAVES", waves)
     gpu_ctx = rt.Context(0)
     ps, d = wl.random_walk_polylines(n=5, nseg=30000, seed=7, cap=0, join=0, width=3.0)

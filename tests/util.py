@@ -45,7 +45,7 @@ def assert_mesh_equal(got, ref, what="", pos_tol=0.0):
 def run_async(rt, ctx, ps, d, shrink=None, profile=False):
     """vgx_tessellate_count (sizes + scratch) then the steady-state entry point vgx_tessellate into exactly sized
     buffers. Returns an object with sizes / status / pos / color / idx / meshes and `stages` (names of the kernels'
-    profiling stages when profile=True: 'fused' = the single-pass kernel ran)."""
+    profiling stages when profile=True)."""
     import torch
     pset = rt.PathSet(ctx, ps)
     dd = rt.upload_draws(d)

@@ -63,13 +63,8 @@ struct vgx_ctx
 	DevBuf cmdPrefix, cmdCnt, subFirst, leafOverflow, serialList, dinfo, poly, subs, mdesc, elemPrefix, elemPrefixS, mprep, mtab, partial, totals;
 	DevBuf gatherSizes;                  // vgx_gather_sizes: [nranks][4] uint64
 	struct VgxRccl* rccl;                // RCCL entry points, bound at the first vgx_gather* call
-	DevBuf segStart, segState, probeOut; // fused single-pass path: segment table, look-back granules + ticket, probe counters
-	uint32_t fusedSegItems;      // commands per segment chosen by the last vgx_tessellate_count (0 = multi-kernel pipeline)
-	uint64_t fusedSegCap;        // segments the tables above hold
-	uint64_t* hostProbe;         // pinned
 	// options, read from the environment ONCE at vgx_create (tuning / testing knobs)
-	int optTwoPass, optNoFused, optBuildWaves, optFusedWaves, optPoolWalk, optNoSmall, optConcurrentEmit;
-	int optFill; // convex-fill kernel: 0 = k_fill, 1 / 2 / 4 = k_fill2 with that run length (VGX_FILL)
+	int optTwoPass, optBuildWaves, optPoolWalk, optNoSmall, optConcurrentEmit;
 	int optInst, optInstWaves; uint32_t optInstBlock; // instanced flatten kernel (vgx_inst.hip): on / grid / lane block
 	// instanced batches: period of the path sequence found by the last vgx_tessellate_count (0 = none). vgx_tessellate
 	// re-checks it on the device for the draws it is given.
@@ -573,84 +568,17 @@ int runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out, 
 		vgx_launch_stroke(true, b, vgxElementGrid(out->cap_vertices), ctx->sideStream);
 		(void)hipEventRecord(ctx->joinEv, ctx->sideStream);
 		a.elem_prefix = a.elem_prefix_fill;
-		vgx_launch_fill(a, vgxElementGrid(out->cap_vertices), s, ctx->optFill);
+		vgx_launch_fill(a, vgxElementGrid(out->cap_vertices), s);
 		(void)hipStreamWaitEvent(s, ctx->joinEv, 0);
 		mark(ctx, s, "fill_emit");
 		return launchStatus(ctx);
 	}
 	a.elem_prefix = a.elem_prefix_fill;
-	vgx_launch_fill(a, vgxElementGrid(out->cap_vertices), s, ctx->optFill);
+	vgx_launch_fill(a, vgxElementGrid(out->cap_vertices), s);
 	mark(ctx, s, "fill_emit");
 	a.elem_prefix = a.elem_prefix_stroke;
 	vgx_launch_stroke(true, a, vgxElementGrid(out->cap_vertices), s);
 	mark(ctx, s, "stroke_emit");
-	return launchStatus(ctx);
-}
-
-// 64-bit words of the fused kernel's look-back state for `segCap` segments (layout: look_state() in vgx_fused.hip):
-// agg[segCap + 2], four per-block arrays of segCap / 64 + 2 words, the ticket counter in the last word.
-uint64_t fusedStateWords(uint64_t segCap) { return (segCap + 2) + 4 * (segCap / 64 + 2) + 1; }
-
-// vgx_tessellate_count's last step: can the single-pass kernel (vgx_fused.hip) take batches like this one, and with which
-// segment size? k_fused_probe walks the segments of every candidate bucket size over the per-draw counts the count pass
-// just produced; the largest candidate whose segments all fit the kernel's tables (and rarely overflow its LDS window)
-// wins, none = the multi-kernel pipeline stays. Sizes the segment tables. Reads the totals back as well (one sync).
-int probeFused(vgx_ctx* ctx, uint64_t ndraws, hipStream_t s)
-{
-	static const uint32_t kCand[VGX_FUSED_CANDIDATES] = { 1024, 512, 256, 128, 64, 32 };
-	ctx->fusedSegItems = 0;
-	int st;
-	if ((st = ensure(ctx, ctx->probeOut, 4 * VGX_FUSED_CANDIDATES * sizeof(uint64_t))) != VGX_OK) { return st; }
-	noteHip(ctx, hipMemsetAsync(ctx->probeOut.p, 0, 4 * VGX_FUSED_CANDIDATES * sizeof(uint64_t), s));
-	VgxFusedProbe pr;
-	for (int c = 0; c < VGX_FUSED_CANDIDATES; ++c) { pr.seg_items[c] = kCand[c]; }
-	pr.out = (uint64_t*)ctx->probeOut.p;
-	vgx_launch_fused_probe((const uint64_t*)ctx->cmdPrefix.p, (const vgx_draw_info*)ctx->dinfo.p, ndraws, pr, s);
-	HIPCHK(ctx, hipMemcpyAsync(ctx->hostProbe, ctx->probeOut.p, 4 * VGX_FUSED_CANDIDATES * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-	if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
-	if (ctx->optNoFused || ctx->hostTotals->status != VGX_OK) { return VGX_OK; }
-	int best = -1;
-	for (int c = 0; c < VGX_FUSED_CANDIDATES; ++c) {
-		const uint64_t segs = ctx->hostProbe[4 * c + 0], viol = ctx->hostProbe[4 * c + 1], over = ctx->hostProbe[4 * c + 2];
-		if (viol != 0) { continue; }
-		if (over * 50 <= segs) { best = c; break; } // at most 2 % of the segments take the heap path
-		if (best < 0 || over * ctx->hostProbe[4 * best + 0] < ctx->hostProbe[4 * best + 2] * segs) { best = c; }
-	}
-	if (best < 0) { return VGX_OK; }
-	const uint64_t ncmdInst = ctx->hostTotals->sizes.num_cmd_instances;
-	const uint64_t segCap = ncmdInst / kCand[best] + ncmdInst / (8 * (uint64_t)kCand[best]) + 64;
-	if ((st = ensure(ctx, ctx->segStart, (segCap + 2) * sizeof(uint64_t))) != VGX_OK) { return st; }
-	if ((st = ensure(ctx, ctx->segState, fusedStateWords(segCap + 2) * sizeof(uint64_t))) != VGX_OK) { return st; }
-	if ((st = ensure(ctx, ctx->leafOverflow, (size_t)VGX_BUILD_WAVES * VGX_BUILD_OVERFLOW * 64 * 2 * sizeof(float))) != VGX_OK) { return st; }
-	ctx->fusedSegCap = segCap; // both tables hold at least this many (they only grow)
-	ctx->fusedSegItems = kCand[best];
-	return VGX_OK;
-}
-
-// vgx_tessellate, single pass: command-prefix scan (+ validation of the draw records) -> segment table -> k_tess_fused
-int runFused(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, const vgx_mesh_out* out, hipStream_t s)
-{
-	runCmdPrefix(ctx, ps, draws, ndraws, s);
-	// look-back granules of every segment + the ticket counter (last 8 bytes of the state buffer's last slot)
-	noteHip(ctx, hipMemsetAsync(ctx->segState.p, 0, fusedStateWords(ctx->fusedSegCap) * sizeof(uint64_t), s));
-	VgxFusedArgs a;
-	a.ps = ps->dev;
-	a.draws = draws; a.ndraws = ndraws;
-	a.cmd_prefix = (const uint64_t*)ctx->cmdPrefix.p;
-	a.seg_start = (uint64_t*)ctx->segStart.p;
-	a.seg_state = (uint64_t*)ctx->segState.p;
-	a.ticket = (uint32_t*)((uint64_t*)ctx->segState.p + fusedStateWords(ctx->fusedSegCap) - 1);
-	a.seg_items = ctx->fusedSegItems;
-	a.seg_cap = ctx->fusedSegCap;
-	a.heap = (float*)ctx->poly.p; a.heap_cap = ctx->caps.poly_vertices;
-	a.leaf_overflow = (float*)ctx->leafOverflow.p;
-	a.pos = out->pos; a.color = out->color; a.idx = out->idx; a.meshes_out = out->meshes;
-	a.totals = (VgxTotals*)ctx->totals.p;
-	a.caps = ctx->caps;
-	a.caps.vertices = out->cap_vertices; a.caps.indices = out->cap_indices;
-	a.caps.meshes = out->meshes ? out->cap_meshes : ~0ull;
-	vgx_launch_fused(a, ctx->optFusedWaves, s);
-	mark(ctx, s, "fused");
 	return launchStatus(ctx);
 }
 
@@ -721,20 +649,15 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 		delete ctx;
 		return VGX_E_NO_DEVICE;
 	}
-	if (hipHostMalloc((void**)&ctx->hostTotals, sizeof(VgxTotals), hipHostMallocDefault) != hipSuccess
-		|| hipHostMalloc((void**)&ctx->hostProbe, 4 * VGX_FUSED_CANDIDATES * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
-		if (ctx->hostTotals) { (void)hipHostFree(ctx->hostTotals); }
+	if (hipHostMalloc((void**)&ctx->hostTotals, sizeof(VgxTotals), hipHostMallocDefault) != hipSuccess) {
 		delete ctx;
 		return VGX_E_HIP;
 	}
 	// tuning / testing knobs: read once here, never on the call path
 	ctx->optTwoPass = getenv("VGX_TWO_PASS_FLATTEN") ? 1 : 0;
-	ctx->optNoFused = getenv("VGX_FUSED") ? 0 : 1; // the single-pass kernel is opt-in (VGX_FUSED=1): measured slower than the multi-kernel pipeline, DESIGN.md section 4
 	ctx->optBuildWaves = VGX_BUILD_WAVES;
 	ctx->optConcurrentEmit = getenv("VGX_EXP_CONCURRENT_EMIT") ? 1 : 0;
 	ctx->optNoSmall = getenv("VGX_NO_SMALL") ? 1 : 0; // testing knob: frame-sized batches through the large-batch launch sequence
-	ctx->optFill = 0;
-	if (const char* e = getenv("VGX_FILL")) { const int v = atoi(e); if (v == 0 || v == 1 || v == 2 || v == 4 || v == 31 || v == 32 || v == 34) { ctx->optFill = v; } }
 	ctx->optInst = 1; ctx->optInstWaves = VGX_INST_WAVES; ctx->optInstBlock = VGX_INST_BLOCK; // VGX_INST=0: instanced batches through k_flatten_build as well
 	if (const char* e = getenv("VGX_INST")) { ctx->optInst = atoi(e) != 0; }
 	if (const char* e = getenv("VGX_INST_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { ctx->optInstWaves = v; } }
@@ -742,13 +665,6 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	ctx->optPoolWalk = 0; // VGX_WALK=pool: the wave-cooperative walk of vgx_walk.h (same output, same speed: DESIGN.md section 4)
 	if (const char* e = getenv("VGX_WALK")) { ctx->optPoolWalk = strcmp(e, "pool") == 0; }
 	if (const char* e = getenv("VGX_BUILD_WAVES")) { const int v = atoi(e); if (v >= 1 && v < VGX_BUILD_WAVES) { ctx->optBuildWaves = v; } }
-	{
-		int cus = 256;
-		hipDeviceProp_t prop;
-		if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) { cus = prop.multiProcessorCount; }
-		ctx->optFusedWaves = cus * 8; // the fused kernel's LDS footprint admits 8 one-wave workgroups per CU
-		if (const char* e = getenv("VGX_FUSED_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= VGX_BUILD_WAVES) { ctx->optFusedWaves = v; } }
-	}
 	*out_ctx = ctx;
 	return VGX_OK;
 }
@@ -759,12 +675,11 @@ int vgx_destroy(vgx_ctx* ctx)
 		return VGX_E_INVALID_ARG;
 	}
 	DeviceGuard guard(ctx);
-	DevBuf* bufs[] = { &ctx->instHist, &ctx->instCursor, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->segStart, &ctx->segState, &ctx->probeOut, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DevBuf* bufs[] = { &ctx->instHist, &ctx->instCursor, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
 	if (ctx->hostTotals) { (void)hipHostFree(ctx->hostTotals); }
-	if (ctx->hostProbe) { (void)hipHostFree(ctx->hostProbe); }
 	vgx_rccl_release(ctx);
 	if (ctx->sideStream) { (void)hipStreamDestroy(ctx->sideStream); (void)hipEventDestroy(ctx->forkEv); (void)hipEventDestroy(ctx->joinEv); }
 	if (ctx->evCreated) {
@@ -781,7 +696,7 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx)
 	if (!ctx) {
 		return 0;
 	}
-	return ctx->gatherSizes.cap + ctx->segStart.cap + ctx->segState.cap + ctx->probeOut.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
+	return ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
 }
 
 // ---- path set ---------------------------------------------------------------------------------------
@@ -1132,7 +1047,7 @@ int vgx_tessellate_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* dr
 	VgxCaps outCaps = ctx->caps;
 	outCaps.vertices = ~0ull; outCaps.indices = ~0ull;
 	runStrokeCount(ctx, draws, outCaps, 0, s);
-	if ((st = probeFused(ctx, ndraws, s)) != VGX_OK) { return st; } // also brings the totals to the host
+	if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
 	*out_sizes = ctx->hostTotals->sizes;
 	if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; } // _emit must not follow a failed count
 	ctx->lastPs = ps; ctx->lastDraws = draws; ctx->lastNDraws = ndraws; ctx->lastStage = 2;
@@ -1169,16 +1084,6 @@ int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 	hipStream_t s = (hipStream_t)stream;
 	markBegin(ctx, s);
 	ctx->lastStage = 0;
-	if (ctx->fusedSegItems && !ctx->asmArmed && !ctx->optTwoPass) {
-		// single pass, polyline in LDS (vgx_fused.hip). Draw-command assembly needs every mesh size before the first index
-		// is written (a sequential partition over ALL meshes), so it keeps the multi-kernel pipeline below.
-		const int st = runFused(ctx, ps, draws, ndraws, out, s);
-		if (st != VGX_OK) { return st; }
-		if (dev_sizes || dev_status) {
-			hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, s, (const VgxTotals*)ctx->totals.p, dev_sizes, dev_status);
-		}
-		return launchStatus(ctx);
-	}
 	VgxCaps outCaps = ctx->caps;
 	outCaps.vertices = out->cap_vertices;
 	outCaps.indices = out->cap_indices;
@@ -1437,7 +1342,7 @@ int vgx_get_failure_info(vgx_ctx* ctx, vgx_failure_info* out, void* stream)
 	out->reason = ctx->hostTotals->fail_reason;
 	out->aux = ctx->hostTotals->fail_aux;
 	out->segment = ctx->hostTotals->fail_segment;
-	out->segment_items = ctx->fusedSegItems;
+	out->segment_items = 0;
 	for (int i = 0; i < 16; ++i) { out->prof[i] = ctx->hostTotals->prof[i]; }
 	return VGX_OK;
 }

@@ -66,41 +66,6 @@ struct VgxStrokeArgs
 	VgxCaps caps;
 };
 
-// Fused single-pass tessellation (vgx_fused.hip): flatten -> transform -> stroker with the polyline in LDS.
-#define VGX_FUSED_P 1024      /* polyline window per wave (vertices); longer segments go through the polyline heap */
-#define VGX_FUSED_T 64        /* draws / mesh-producing sub-paths / meshes per segment (one table entry per lane) */
-#define VGX_FUSED_TICKET 1    /* segments per ticket. MUST stay 1: a wave that holds several segments publishes the later
-                               * aggregates only after its own look-back waits, and those delays chain from wave to wave
-                               * (measured with 4: the whole batch serialises, 9.9 s instead of milliseconds) */
-#define VGX_FUSED_CANDIDATES 6
-struct VgxFusedArgs
-{
-	VgxPathSetDev ps;
-	const vgx_draw* draws;
-	uint64_t ndraws;
-	const uint64_t* cmd_prefix;  // [ndraws + 1]
-	uint64_t* seg_start;         // [numSegments + 1] first draw of every segment (k_seg_starts)
-	uint64_t* seg_state;         // [numSegments][4] look-back granules (zeroed before the launch)
-	uint32_t* ticket;            // segment counter (zeroed before the launch)
-	uint32_t seg_items;          // commands per segment bucket, chosen by vgx_tessellate_count
-	uint64_t seg_cap;            // segments seg_start / seg_state hold
-	float* heap;                 // polyline heap: blocks for segments that do not fit the LDS window
-	uint64_t heap_cap;           // ... in vertices
-	float* leaf_overflow;        // [waves][VGX_BUILD_OVERFLOW][64][2] leaves that did not fit the LDS slots
-	float* pos;
-	uint32_t* color;
-	uint16_t* idx;
-	vgx_mesh* meshes_out;        // caller's mesh table (may be null)
-	VgxTotals* totals;
-	VgxCaps caps;                // vertices / indices / meshes: the caller's capacities
-};
-struct VgxFusedProbe
-{
-	uint32_t seg_items[VGX_FUSED_CANDIDATES];
-	uint64_t* out;               // DEVICE [4 * VGX_FUSED_CANDIDATES], zeroed: segments, table violations, window overflows, -
-};
-void vgx_launch_fused(const VgxFusedArgs& a, int waves, hipStream_t s);
-void vgx_launch_fused_probe(const uint64_t* cmd_prefix, const vgx_draw_info* dinfo, uint64_t ndraws, const VgxFusedProbe& p, hipStream_t s);
 
 // concave-fill fringes (vgx_concave.hip)
 struct VgxConcaveArgs
@@ -190,6 +155,6 @@ struct VgxCacheArgs
 void vgx_launch_cache_localize(const vgx_draw* draws, uint64_t ndraws, float* pos, const vgx_mesh* meshes, uint64_t numMeshes, hipStream_t s);
 void vgx_launch_cache_meshes(const VgxCacheArgs& a, hipStream_t s);
 void vgx_launch_cache_copy(const VgxCacheArgs& a, int numBlocks, hipStream_t s);
-void vgx_launch_fill(const VgxStrokeArgs& a, int numBlocks, hipStream_t s, int variant = 0); // variant: 0 k_fill, 1 / 2 / 4 k_fill2 with that run length
+void vgx_launch_fill(const VgxStrokeArgs& a, int numBlocks, hipStream_t s);
 
 #endif

@@ -12,6 +12,9 @@
 
 #include "vgmath.h"
 #include "../../include/vgx.h"
+#if defined(__HIPCC__) || defined(__HIP__)
+#include "vgx_fastmath.h"
+#endif
 
 #if defined(__HIPCC__) || defined(__HIP__)
 #define VGX_HD __host__ __device__ __forceinline__
@@ -33,12 +36,21 @@ VGX_HD float v2dot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
 VGX_HD float v2cross(V2 a, V2 b) { return a.x * b.y - b.x * a.y; }
 
 // vec2Dir, stroker.cpp:31-38
+// Device code takes 1 / sqrt(lenSqr) from vgx_fastmath.h: the same correctly rounded value as vgm_rsqrt in a third of the
+// instructions (checked over every float of its domain by tests/native/exact_math_test.hip); values outside the checked
+// domain -- coordinates beyond 1e15, NaN / Inf -- take the generic sequence under a branch that never runs.
 VGX_HD V2 v2dir(V2 a, V2 b)
 {
 	const float dx = b.x - a.x;
 	const float dy = b.y - a.y;
 	const float lenSqr = dx * dx + dy * dy;
+#if defined(__HIP_DEVICE_COMPILE__)
+	float inv = vgx_rsqrt_rn(lenSqr);
+	if (__builtin_expect(!(lenSqr <= 0x1p100f), 0)) { inv = vgm_rsqrt(lenSqr); }
+	const float invLen = lenSqr < VGM_EPSILON ? 0.0f : inv;
+#else
 	const float invLen = lenSqr < VGM_EPSILON ? 0.0f : vgm_rsqrt(lenSqr);
+#endif
 	return v2(dx * invLen, dy * invLen);
 }
 
@@ -47,8 +59,15 @@ VGX_HD V2 v2extrude(V2 d01, V2 d12)
 {
 	V2 v = v2ccw(d01);
 	const float c = v2cross(d12, d01);
-	if (vgm_abs(c) > (1.0f / 100.0f)) {
-		v = v2mul(v2sub(d01, d12), 1.0f / c);
+	const float ac = vgm_abs(c);
+	if (ac > (1.0f / 100.0f)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+		float r = vgx_rcp_rn(c);
+		if (__builtin_expect(!(ac <= 0x1p100f), 0)) { r = 1.0f / c; }
+#else
+		const float r = 1.0f / c;
+#endif
+		v = v2mul(v2sub(d01, d12), r);
 	}
 	return v;
 }

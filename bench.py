@@ -42,7 +42,7 @@ def command_bytes(ps, draw_paths):
     return int(per_path[draw_paths].sum())
 
 
-def algorithmic_bytes(cmd_bytes, ndraws, sizes, fill_verts, fill_idx, fill_meshes):
+def algorithmic_bytes(cmd_bytes, ndraws, sizes, fill_verts, fill_idx, fill_meshes, instanced=False):
     """Algorithmic HBM bytes per launch of each kernel (stated in DESIGN.md):
     commands read once per instance (1 B opcode + 4 B arg offset + 4 B per argument), one 64 B draw record
     per path instance, 8 B per polyline vertex, 12 B per output vertex (float2 position + uint32 colour), 2 B per
@@ -52,13 +52,14 @@ def algorithmic_bytes(cmd_bytes, ndraws, sizes, fill_verts, fill_idx, fill_meshe
     ef = sizes["num_fill_elements"]
     es = sizes["num_elements"] - ef
     b = {}
-    b["flatten_build"] = cmd_bytes + 64 * ndraws + 8 * sizes["num_poly_vertices"]
+    # the instanced kernel (one lane per instance, 64 instances of a path per wave) reads a path's commands once per wave,
+    # not once per instance; both write one 16-byte record per sub-path besides the vertices
+    b["flatten_build"] = (cmd_bytes // 64 if instanced else cmd_bytes) + 64 * ndraws + 8 * sizes["num_poly_vertices"] + 16 * sizes["num_subpaths"]
     b["flatten_count"] = cmd_bytes + 64 * ndraws
     b["flatten_emit"] = cmd_bytes + 64 * ndraws + 8 * sizes["num_poly_vertices"] + 16 * sizes["num_subpaths"]
     b["fill_emit"] = 8 * ef + 12 * fill_verts + 2 * fill_idx + 32 * fill_meshes
     b["stroke_emit"] = 8 * es + 12 * (nv - fill_verts) + 2 * (ni - fill_idx) + 32 * (nm - fill_meshes)
     b["pipeline"] = cmd_bytes + 64 * ndraws + 12 * nv + 2 * ni + 32 * nm
-    b["fused"] = b["pipeline"]  # the single-pass kernel reads the commands / draws and writes the meshes: nothing in between touches HBM
     return b
 
 
@@ -136,6 +137,8 @@ WORKLOADS = {
     "tiger10k": "BASELINE configs[2]: Tiger x10k, convexFillAA + polylineStrokeAA (the headline)",
     "cubics1m": "BASELINE configs[1]: 1M independent cubics, adaptive flatten only",
     "round10k": "BASELINE configs[3]: 10k polylines x 1k segments, Round joins + Round caps",
+    "tiger10k_varied": "Tiger x10k with per-instance scale (0.5 .. 3.5) and rotation: the instanced flatten without its lock-step walk",
+    "tigerspec10k": "SURVEY 8(d) config 3 as specified: 240 paths x (1-4 sub-paths x 8-60 cubics), x10k instances",
 }
 
 
@@ -146,6 +149,16 @@ def make_workload(wl, name, instances, rank):
         d = wl.tiger_draws(ops, instances, first_instance=rank * instances)
         return ps, d, ("tiger-like 240-path drawing (seed 2024) x %d instances per GPU: convexFillAA on every sub-path + "
                        "polylineStrokeAA/AAThin (Butt/Miter) on 1/3 of the paths" % instances), "tessellate"
+    if name == "tiger10k_varied":
+        ps, ops = wl.tiger_paths()
+        d = wl.tiger_varied_draws(ops, instances, first_instance=rank * instances)
+        return ps, d, ("tiger-like drawing (seed 2024) x %d instances per GPU, every instance at its own scale in {0.5 .. 3.5} and "
+                       "rotation (tolerance and stroke widths follow the scale)" % instances), "tessellate"
+    if name == "tigerspec10k":
+        ps, ops = wl.tiger_spec_paths()
+        d = wl.tiger_draws(ops, instances, first_instance=rank * instances)
+        return ps, d, ("SURVEY 8(d) drawing (seed 2025: 240 paths, 1-4 closed sub-paths of 8-60 cubics, 1/3 stroked with widths 0.5-3) "
+                       "x %d instances per GPU" % instances), "tessellate"
     if name == "cubics1m":
         ps, d = wl.random_cubics(1000000, seed=1234 + rank, box=1000.0)
         return ps, d, "1 000 000 independent paths (moveTo + cubicTo, 8 coordinates uniform in [0,1000)) per GPU: pathXXX only (vgx_flatten_count + vgx_flatten_emit)", "flatten"
@@ -260,7 +273,9 @@ def run_config(rt, torch, ctx, local_rank, name, ps, draws, kind, steps, warmup,
     else:
         sizes.setdefault("num_fill_elements", 0)
         sizes.setdefault("num_elements", 0)
-    ab = algorithmic_bytes(cmd_bytes, ndraws, sizes, fill_verts, fill_idx, fill_meshes)
+    mode = ctx.failure_info()["segment_items"] if kind != "flatten" else 0  # which flatten kernel the library chose (0 command-parallel, 1 / 2 instanced)
+    res["flatten_mode"] = mode
+    ab = algorithmic_bytes(cmd_bytes, ndraws, sizes, fill_verts, fill_idx, fill_meshes, instanced=mode != 0)
     if kind == "flatten":
         ab["pipeline"] = ab["flatten_emit"]
     res.update(dt=dt, sizes=sizes, stage=stage_sum, ab=ab, units=units, unit_name=unit_name, bufs=bufs, pset=pset, dd=dd, scratch=ctx.scratch_bytes())
@@ -282,16 +297,19 @@ def roofline(res, steps, traffic_for=None):
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 tj = json.load(f)
-            if tj.get("instances_per_gpu") == traffic_for and dom in tj["kernels"]:
+            if isinstance(traffic_for, str):
+                traffic = tj["configs"][traffic_for]["kernels"][dom]["traffic_bytes"]
+            elif tj.get("instances_per_gpu") == traffic_for and dom in tj["kernels"]:
                 traffic = tj["kernels"][dom]["traffic_bytes"]
         except (OSError, ValueError, KeyError):
             pass
     return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_ratio": None if traffic is None else round(traffic / ab[dom], 3),
             "kernel_ms": round(dom_ms, 3), "algorithmic_bytes": ab[dom],
             "by_kernel": {k: {"ms": round(stage_sum[k], 3), "achieved": round(ab[k] / (stage_sum[k] * 1e-3) / 1e9, 1),
                               "frac": round(ab[k] / (stage_sum[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-                          for k in ("fused", "flatten_build", "flatten_count", "flatten_emit", "fill_emit", "stroke_emit") if k in stage_sum and k in ab and stage_sum[k] > 0},
+                          for k in ("flatten_build", "flatten_count", "flatten_emit", "fill_emit", "stroke_emit") if k in stage_sum and k in ab and stage_sum[k] > 0},
             "pipeline_achieved": round(ab["pipeline"] / (ms_per_step * 1e-3) / 1e9, 1)}
 
 
@@ -532,7 +550,8 @@ def main():
                            "value": round(r2["units"] / (ms2 * 1e-3) / 1e6, 2), "unit": "M %s/s" % r2["unit_name"], "ms_per_step": round(ms2, 3), "steps": steps2,
                            "verts_per_gpu": r2["sizes"].get("num_vertices", 0), "indices_per_gpu": r2["sizes"].get("num_indices", 0),
                            "poly_verts_per_gpu": r2["sizes"]["num_poly_vertices"], "meshes_per_gpu": r2["sizes"].get("num_meshes", 0),
-                           "roofline": roofline(r2, steps2), "stage_ms": {k: round(v, 3) for k, v in r2["stage"].items()}}
+                           "flatten_kernel": {0: "k_flatten_build", 1: "k_flatten_inst", 2: "k_flatten_inst (grouped)"}.get(r2.get("flatten_mode"), "k_flatten"),
+                           "roofline": roofline(r2, steps2, traffic_for=name), "stage_ms": {k: round(v, 3) for k, v in r2["stage"].items()}}
             r2["pset"].close()
             del r2, ps2, d2
             torch.cuda.empty_cache()
@@ -554,8 +573,9 @@ def main():
                        "poly_verts_per_gpu": sizes["num_poly_vertices"], "serial_draws": sizes["num_serial_draws"],
                        "scratch_bytes_per_gpu": res["scratch"], "output_placement": res.get("output_placement"),
                        # which flatten kernel the 'flatten_build' stage is (the library decides per batch)
-                       "flatten_kernel": ("k_flatten_inst (one lane per instance: the draws repeat one sequence of paths)"
-                                          if args.config == "tiger10k" and os.environ.get("VGX_INST", "1") != "0" else "k_flatten_build (one lane per path command)")},
+                       "flatten_kernel": ("k_flatten_inst (one lane per instance: the draws repeat one sequence of paths)" if res.get("flatten_mode") == 1
+                                          else "k_flatten_inst, grouped (draws sorted by path on the device)" if res.get("flatten_mode") == 2
+                                          else "k_flatten_build (one lane per path command)")},
             "roofline": roofline(res, args.steps, traffic_for=K if args.config == "tiger10k" else None),
             "stage_ms": {k: round(v, 3) for k, v in res["stage"].items()},
             "cpu_baseline": cpu,

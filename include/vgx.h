@@ -436,7 +436,8 @@ typedef struct vgx_failure_info {
 	uint32_t status;        /* vgx_status of the device status word */
 	uint32_t reason;        /* 0 = none */
 	uint32_t aux;           /* reason specific (a count) */
-	uint32_t segment_items; /* reserved (0) */
+	uint32_t segment_items; /* (historic name) flatten kernel the last vgx_tessellate_count chose for batches like its own:
+	                         * 0 = k_flatten_build (one lane per path command), 1 = k_flatten_inst, periodic draws, 2 = k_flatten_inst, grouped */
 	uint64_t segment;       /* work item (segment / task) that failed first */
 	uint64_t prof[16];      /* -DVGX_INST_PROFILE builds of libvgx only (else 0): wave clock ticks (100 MHz) summed over all waves
 	                         * per phase of k_flatten_inst (profiles/inst_phases.py) */
@@ -461,11 +462,21 @@ int vgx_get_failure_info(vgx_ctx* ctx, vgx_failure_info* out, void* stream);
  *                     kernel). `global` is only read on the root (capacities checked against the totals: VGX_E_NOSPACE).
  *                     To overlap the gather of frame i with the tessellation of frame i + 1, call it on a second stream
  *                     with double-buffered outputs: nothing in it touches context scratch that vgx_tessellate uses.
+ *                     Transfers go out in pieces of at most VGX_GATHER_CHUNK_MB (default 256 MiB), one group per piece.
  * Errors: VGX_E_NO_DEVICE when no RCCL library can be bound, VGX_E_HIP when an RCCL call fails (vgx_last_hip_error() then
  * holds 10000 + the ncclResult_t). */
 typedef struct vgx_rank_sizes { uint64_t num_vertices, num_indices, num_meshes, num_draws; } vgx_rank_sizes;
 int vgx_gather_sizes(vgx_ctx* ctx, void* rccl_comm, const vgx_rank_sizes* mine, vgx_rank_sizes* all, void* stream);
 int vgx_gather(vgx_ctx* ctx, void* rccl_comm, int root, const vgx_mesh_out* local, const vgx_rank_sizes* all, const vgx_mesh_out* global, void* stream);
+/* vgx_gather with explicit placement: rank r's block (all[r] elements of `local` on rank r) lands at place[r] in `global` --
+ * {num_vertices, num_indices, num_meshes} = first vertex / index / mesh of the block, num_draws = what is added to the `draw`
+ * of its mesh records (vgx_gather = the exclusive prefix of `all`). This is what a frame tessellated in TILES needs: a rank cuts
+ * its draws into sub-batches, tessellates tile t into the local buffers behind tile t - 1 and gathers tile t (local = a view of
+ * the tile's part of the buffers, place = the rank's base + the tiles in front) on a second stream while tile t + 1 is being
+ * tessellated -- the gathered frame is the same bytes, in the same order. Messages larger than VGX_GATHER_CHUNK_MB (default
+ * 256 MiB) are split into pieces, one RCCL group per piece index. Capacities are checked against place + all. */
+int vgx_gather_at(vgx_ctx* ctx, void* rccl_comm, int root, const vgx_mesh_out* local, const vgx_rank_sizes* all, const vgx_rank_sizes* place,
+                  const vgx_mesh_out* global, void* stream);
 
 /* Per-kernel timing of the last vgx_tessellate.. / vgx_flatten.. sequence, measured with HIP events
  * on the stream the kernels ran on. Enable before the call; read after synchronising. */

@@ -38,3 +38,28 @@ def test_gather_threaded_ranks(binaries, nranks, ndraws):
     out = subprocess.check_output([exe, "fake", fake, str(nranks), str(ndraws)], text=True, timeout=300)
     assert out.count("identical to the single-context run") == 2, out
     assert "MISMATCH" not in out
+
+
+@pytest.mark.parametrize("nranks,ndraws,tiles", [(2, 4000, 3), (3, 2000, 2), (4, 5, 2)])
+def test_gather_at_tiled_frames(binaries, nranks, ndraws, tiles):
+    """vgx_gather_at: every rank cuts its draws into tiles, tessellates them one after the other and gathers tile by tile
+    (what lets the gather of tile t overlap the tessellation of tile t + 1); with VGX_GATHER_CHUNK_MB=1 every transfer
+    leaves in several pieces. The gathered frame must be byte-identical to a single context tessellating everything."""
+    exe, fake = binaries
+    env = dict(os.environ, VGX_GATHER_CHUNK_MB="1")
+    out = subprocess.check_output([exe, "tiles", fake, str(nranks), str(ndraws), str(tiles)], text=True, timeout=300, env=env)
+    assert out.count("identical to the single-context run") == 2, out
+    assert "MISMATCH" not in out
+
+
+def test_gather_eight_ranks_into_a_70_gb_destination(binaries):
+    """The root of BASELINE config 4 (Tiger x80k over 8 GPUs) receives 8 x 8.75 GB. Eight thread-ranks on the one GPU send the
+    same 8.75 GB local block (one tessellation, shared) into one 70 GB destination: 64-bit offsets, capacity checks and the
+    piece splitting (default 256 MiB) at full size; first / last megabyte of every block and the rebased mesh records checked."""
+    import torch
+    free, total = torch.cuda.mem_get_info(0)
+    if free < 110 * (1 << 30):
+        pytest.skip("needs ~95 GB of free device memory")
+    exe, fake = binaries
+    out = subprocess.check_output([exe, "big", fake, "8", "8.75"], text=True, timeout=900)
+    assert "blocks identical, mesh records rebased" in out and "MISMATCH" not in out, out

@@ -191,6 +191,7 @@ VGX_SYMBOLS = {
     "vgx_get_failure_info": (C.c_int, [C.c_void_p, C.POINTER(FailureInfo), C.c_void_p]),
     "vgx_gather_sizes": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(RankSizes), C.POINTER(RankSizes), C.c_void_p]),
     "vgx_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(MeshOut), C.POINTER(RankSizes), C.POINTER(MeshOut), C.c_void_p]),
+    "vgx_gather_at": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(MeshOut), C.POINTER(RankSizes), C.POINTER(RankSizes), C.POINTER(MeshOut), C.c_void_p]),
     "vgx_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "vgx_get_stage_times": (C.c_int, [C.c_void_p, C.POINTER(StageTimes)]),
 }

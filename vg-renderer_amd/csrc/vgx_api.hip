@@ -1342,7 +1342,7 @@ int vgx_get_failure_info(vgx_ctx* ctx, vgx_failure_info* out, void* stream)
 	out->reason = ctx->hostTotals->fail_reason;
 	out->aux = ctx->hostTotals->fail_aux;
 	out->segment = ctx->hostTotals->fail_segment;
-	out->segment_items = 0;
+	out->segment_items = ctx->optInst ? (ctx->instPeriod ? 1u : (ctx->instGrouped ? 2u : 0u)) : 0u; // flatten mode chosen by the last count call
 	for (int i = 0; i < 16; ++i) { out->prof[i] = ctx->hostTotals->prof[i]; }
 	return VGX_OK;
 }
@@ -1489,10 +1489,24 @@ extern "C" int vgx_gather_sizes(vgx_ctx* ctx, void* rccl_comm, const vgx_rank_si
 	return VGX_OK;
 }
 
-extern "C" int vgx_gather(vgx_ctx* ctx, void* rccl_comm, int root, const vgx_mesh_out* local, const vgx_rank_sizes* all, const vgx_mesh_out* global, void* stream)
+// Transfers larger than this leave in several pieces: piece c of every (rank, stream) pair goes out in group c, so that no
+// single RCCL operation is gigabytes long and the proxy threads can pipeline (VGX_GATHER_CHUNK_MB, default 256 MiB).
+static size_t gatherChunkBytes()
+{
+	static size_t v = 0;
+	if (!v) {
+		const char* e = getenv("VGX_GATHER_CHUNK_MB");
+		const long mb = e ? atol(e) : 256;
+		v = (size_t)(mb >= 1 ? mb : 256) << 20;
+	}
+	return v;
+}
+
+extern "C" int vgx_gather_at(vgx_ctx* ctx, void* rccl_comm, int root, const vgx_mesh_out* local, const vgx_rank_sizes* all, const vgx_rank_sizes* place,
+	const vgx_mesh_out* global, void* stream)
 {
 	DeviceGuard guard(ctx);
-	if (!ctx || !rccl_comm || !local || !all) {
+	if (!ctx || !rccl_comm || !local || !all || !place) {
 		return VGX_E_INVALID_ARG;
 	}
 	int st = bindRccl(ctx);
@@ -1509,74 +1523,104 @@ extern "C" int vgx_gather(vgx_ctx* ctx, void* rccl_comm, int root, const vgx_mes
 	if ((me.num_vertices && (!local->pos || !local->color)) || (me.num_indices && !local->idx) || (me.num_meshes && !local->meshes)) {
 		return VGX_E_INVALID_ARG;
 	}
+	if (rank == root) {
+		if (!global || !global->pos || !global->color || !global->idx || !global->meshes) { return VGX_E_INVALID_ARG; }
+		for (int r = 0; r < nranks; ++r) { // every block inside the destination
+			if (place[r].num_vertices + all[r].num_vertices > global->cap_vertices || place[r].num_indices + all[r].num_indices > global->cap_indices
+				|| place[r].num_meshes + all[r].num_meshes > global->cap_meshes) {
+				return VGX_E_NOSPACE;
+			}
+		}
+	}
+	// the four streams of one rank's block as byte ranges: {local source, destination in global, bytes}
+	struct Piece { const uint8_t* src; uint8_t* dst; size_t bytes; };
+	auto blockOf = [&](int r, Piece out[4]) {
+		const vgx_rank_sizes& z = all[r];
+		const vgx_rank_sizes& o = place[r];
+		const bool isRoot = rank == root;
+		out[0] = Piece{ (const uint8_t*)local->pos, isRoot ? (uint8_t*)(global->pos + 2 * o.num_vertices) : nullptr, (size_t)z.num_vertices * 8 };
+		out[1] = Piece{ (const uint8_t*)local->color, isRoot ? (uint8_t*)(global->color + o.num_vertices) : nullptr, (size_t)z.num_vertices * 4 };
+		out[2] = Piece{ (const uint8_t*)local->idx, isRoot ? (uint8_t*)(global->idx + o.num_indices) : nullptr, (size_t)z.num_indices * 2 };
+		out[3] = Piece{ (const uint8_t*)local->meshes, isRoot ? (uint8_t*)(global->meshes + o.num_meshes) : nullptr, (size_t)z.num_meshes * sizeof(vgx_mesh) };
+	};
+	const size_t chunk = gatherChunkBytes();
+	size_t maxBytes = 0;
+	for (int r = 0; r < nranks; ++r) {
+		if (rank != root && r != rank) { continue; }
+		Piece b[4]; blockOf(r, b);
+		for (int k = 0; k < 4; ++k) { if (b[k].bytes > maxBytes) { maxBytes = b[k].bytes; } }
+	}
+	const size_t nchunks = maxBytes ? (maxBytes + chunk - 1) / chunk : 0;
 	// Inside a group a failed call must not return at once: the group stays open on this thread and every later collective
 	// would be queued and never issued. Remember the first error, skip the rest, always close the group.
 	int rcclErr = 0;
 #define RCCLGRP(call) do { if (!rcclErr) { rcclErr = (call); } } while (0)
-	if (rank != root) {
+	if (rank == root) { // my own block: plain copies on the same stream (they overlap with the incoming transfers)
+		Piece b[4]; blockOf(root, b);
+		for (int k = 0; k < 4; ++k) { if (b[k].bytes) { noteHip(ctx, hipMemcpyAsync(b[k].dst, b[k].src, b[k].bytes, hipMemcpyDeviceToDevice, s)); } }
+	}
+	for (size_t c = 0; c < nchunks && !rcclErr; ++c) {
 		RCCLCHK(ctx, ctx->rccl->GroupStart());
-		if (me.num_vertices) {
-			RCCLGRP(ctx->rccl->Send(local->pos, me.num_vertices * 8, kNcclUint8, root, rccl_comm, s));
-			RCCLGRP(ctx->rccl->Send(local->color, me.num_vertices * 4, kNcclUint8, root, rccl_comm, s));
+		for (int r = 0; r < nranks; ++r) {
+			if (r == root || (rank != root && r != rank)) { continue; }
+			Piece b[4]; blockOf(r, b);
+			for (int k = 0; k < 4; ++k) {
+				const size_t off = c * chunk;
+				if (off >= b[k].bytes) { continue; }
+				const size_t n = b[k].bytes - off < chunk ? b[k].bytes - off : chunk;
+				if (rank == root) { RCCLGRP(ctx->rccl->Recv(b[k].dst + off, n, kNcclUint8, r, rccl_comm, s)); }
+				else { RCCLGRP(ctx->rccl->Send(b[k].src + off, n, kNcclUint8, root, rccl_comm, s)); }
+			}
 		}
-		if (me.num_indices) { RCCLGRP(ctx->rccl->Send(local->idx, me.num_indices * 2, kNcclUint8, root, rccl_comm, s)); }
-		if (me.num_meshes) { RCCLGRP(ctx->rccl->Send(local->meshes, me.num_meshes * sizeof(vgx_mesh), kNcclUint8, root, rccl_comm, s)); }
 		const int endErr = ctx->rccl->GroupEnd();
 		if (!rcclErr) { rcclErr = endErr; }
-		if (rcclErr) { ctx->lastHipError = 10000 + rcclErr; return VGX_E_HIP; }
-		return VGX_OK;
-	}
-	if (!global || !global->pos || !global->color || !global->idx || !global->meshes) {
-		return VGX_E_INVALID_ARG;
-	}
-	uint64_t tv = 0, ti = 0, tm = 0;
-	for (int r = 0; r < nranks; ++r) { tv += all[r].num_vertices; ti += all[r].num_indices; tm += all[r].num_meshes; }
-	if (tv > global->cap_vertices || ti > global->cap_indices || tm > global->cap_meshes) {
-		return VGX_E_NOSPACE;
-	}
-	GatherRebaseArgs ra;
-	ra.meshes = global->meshes;
-	ra.n = 0;
-	uint64_t maxMeshes = 0;
-	uint64_t vo = 0, io = 0, mo = 0, dofs = 0;
-	RCCLCHK(ctx, ctx->rccl->GroupStart());
-	for (int r = 0; r < nranks; ++r) {
-		const vgx_rank_sizes& z = all[r];
-		if (r == root) {
-			// my own block: plain copies on the same stream (they overlap with the incoming transfers)
-			if (z.num_vertices) {
-				noteHip(ctx, hipMemcpyAsync(global->pos + 2 * vo, local->pos, z.num_vertices * 8, hipMemcpyDeviceToDevice, s));
-				noteHip(ctx, hipMemcpyAsync(global->color + vo, local->color, z.num_vertices * 4, hipMemcpyDeviceToDevice, s));
-			}
-			if (z.num_indices) { noteHip(ctx, hipMemcpyAsync(global->idx + io, local->idx, z.num_indices * 2, hipMemcpyDeviceToDevice, s)); }
-			if (z.num_meshes) { noteHip(ctx, hipMemcpyAsync(global->meshes + mo, local->meshes, z.num_meshes * sizeof(vgx_mesh), hipMemcpyDeviceToDevice, s)); }
-		} else {
-			if (z.num_vertices) {
-				RCCLGRP(ctx->rccl->Recv(global->pos + 2 * vo, z.num_vertices * 8, kNcclUint8, r, rccl_comm, s));
-				RCCLGRP(ctx->rccl->Recv(global->color + vo, z.num_vertices * 4, kNcclUint8, r, rccl_comm, s));
-			}
-			if (z.num_indices) { RCCLGRP(ctx->rccl->Recv(global->idx + io, z.num_indices * 2, kNcclUint8, r, rccl_comm, s)); }
-			if (z.num_meshes) { RCCLGRP(ctx->rccl->Recv(global->meshes + mo, z.num_meshes * sizeof(vgx_mesh), kNcclUint8, r, rccl_comm, s)); }
-		}
-		if (z.num_meshes && (vo || io || dofs)) {
-			GatherRebase& g = ra.r[ra.n++];
-			g.mesh0 = mo; g.mesh1 = mo + z.num_meshes; g.vbase = vo; g.ibase = io; g.dbase = (uint32_t)dofs;
-			if (z.num_meshes > maxMeshes) { maxMeshes = z.num_meshes; }
-		}
-		vo += z.num_vertices; io += z.num_indices; mo += z.num_meshes; dofs += z.num_draws;
-	}
-	{
-		const int endErr = ctx->rccl->GroupEnd();
-		if (!rcclErr) { rcclErr = endErr; }
-		if (rcclErr) { ctx->lastHipError = 10000 + rcclErr; return VGX_E_HIP; }
 	}
 #undef RCCLGRP
-	if (ra.n) {
-		const uint64_t blocks = (maxMeshes + 255) / 256;
-		hipLaunchKernelGGL(k_gather_rebase, dim3((unsigned)(blocks > 4096 ? 4096 : blocks), (unsigned)ra.n), dim3(256), 0, s, ra);
+	if (rcclErr) { ctx->lastHipError = 10000 + rcclErr; return VGX_E_HIP; }
+	if (rank == root) { // mesh records of rank r sit at [place, place + n): add the block's vertex / index / draw bases
+		GatherRebaseArgs ra;
+		ra.meshes = global->meshes;
+		ra.n = 0;
+		uint64_t maxMeshes = 0;
+		for (int r = 0; r < nranks; ++r) {
+			const vgx_rank_sizes& z = all[r];
+			const vgx_rank_sizes& o = place[r];
+			if (z.num_meshes && (o.num_vertices || o.num_indices || o.num_draws)) {
+				GatherRebase& g = ra.r[ra.n++];
+				g.mesh0 = o.num_meshes; g.mesh1 = o.num_meshes + z.num_meshes; g.vbase = o.num_vertices; g.ibase = o.num_indices; g.dbase = (uint32_t)o.num_draws;
+				if (z.num_meshes > maxMeshes) { maxMeshes = z.num_meshes; }
+			}
+		}
+		if (ra.n) {
+			const uint64_t blocks = (maxMeshes + 255) / 256;
+			hipLaunchKernelGGL(k_gather_rebase, dim3((unsigned)(blocks > 4096 ? 4096 : blocks), (unsigned)ra.n), dim3(256), 0, s, ra);
+		}
 	}
 	if (ctx->pendingHipError) { ctx->lastHipError = ctx->pendingHipError; ctx->pendingHipError = 0; return VGX_E_HIP; }
 	const hipError_t e = hipGetLastError();
 	if (e != hipSuccess) { ctx->lastHipError = (int)e; return VGX_E_HIP; }
 	return VGX_OK;
+}
+
+extern "C" int vgx_gather(vgx_ctx* ctx, void* rccl_comm, int root, const vgx_mesh_out* local, const vgx_rank_sizes* all, const vgx_mesh_out* global, void* stream)
+{
+	if (!ctx || !rccl_comm || !local || !all) {
+		return VGX_E_INVALID_ARG;
+	}
+	int st;
+	{
+		DeviceGuard guard(ctx);
+		st = bindRccl(ctx);
+	}
+	if (st != VGX_OK) { return st; }
+	int nranks = 0;
+	RCCLCHK(ctx, ctx->rccl->CommCount(rccl_comm, &nranks));
+	if (nranks < 1 || nranks > VGX_GATHER_MAX_RANKS) { return VGX_E_INVALID_ARG; }
+	vgx_rank_sizes place[VGX_GATHER_MAX_RANKS];
+	uint64_t vo = 0, io = 0, mo = 0, dofs = 0;
+	for (int r = 0; r < nranks; ++r) { // rank order = draw order: exclusive prefix of the sizes
+		place[r].num_vertices = vo; place[r].num_indices = io; place[r].num_meshes = mo; place[r].num_draws = dofs;
+		vo += all[r].num_vertices; io += all[r].num_indices; mo += all[r].num_meshes; dofs += all[r].num_draws;
+	}
+	return vgx_gather_at(ctx, rccl_comm, root, local, all, place, global, stream);
 }

@@ -141,6 +141,77 @@ def tiger(instances, seed=2024, first_instance=0):
     return ps, tiger_draws(ops, instances, first_instance)
 
 
+def tiger_varied_draws(ops, instances, first_instance=0, seed=77):
+    """Tiger instances that do NOT share one subdivision: instance i is drawn at scale s_i in {0.5, 1, 1.5, 2, 2.5, 3, 3.5}
+    under a rotation, i.e. what a caller's State would hold after transformScale / transformRotate / transformTranslate
+    (updateState: avgScale = mean of the column norms, vg.cpp:4927-4935). The flatten tolerance and the stroke widths
+    follow the scale (pathReset(avgScale), ctxStrokePathColor :3416-3433), so the 64 lanes of an instanced wave walk
+    different subdivisions. Same draw order as tiger_draws."""
+    npaths = len(ops)
+    rs = np.random.RandomState(seed)
+    scales = np.float32([0.5, 1.0, 1.5, 2.0, 2.5, 3.0, 3.5])
+    d = np.zeros(0, dtype=capi.draw_dtype)
+    inst = np.arange(first_instance, first_instance + instances, dtype=np.int64)
+    sc = scales[rs.randint(0, len(scales), size=first_instance + instances)[first_instance:]]
+    ang = rs.uniform(0.0, 2.0 * np.pi, size=first_instance + instances)[first_instance:]
+    c, sn = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+    m = np.zeros((instances, 6), np.float32)
+    m[:, 0] = sc * c; m[:, 1] = sc * sn; m[:, 2] = -(sc * sn); m[:, 3] = sc * c
+    m[:, 4] = (37.0 * (inst % 100)).astype(np.float32)
+    m[:, 5] = (41.0 * (inst // 100)).astype(np.float32)
+    avg = ((np.sqrt(m[:, 0] * m[:, 0] + m[:, 2] * m[:, 2]) + np.sqrt(m[:, 1] * m[:, 1] + m[:, 3] * m[:, 3])) * np.float32(0.5)).astype(np.float32)
+    # one table of per-path records per distinct scale value (set_stroke is scalar in the scale)
+    tables = {}
+    for a in np.unique(avg):
+        one = make_draws(npaths)
+        one["path"] = np.arange(npaths, dtype=np.uint32)
+        one["scale"] = a
+        for p, op in enumerate(ops):
+            set_fill(one, p, op["fill_color"], aa=True)
+            if op["stroke"]:
+                set_stroke(one, p, op["stroke_color"], op["stroke_width"], capi.CAP_BUTT, capi.JOIN_MITER, aa=True, avg_scale=float(a))
+        tables[float(a)] = one
+    d = np.concatenate([tables[float(a)] for a in avg])
+    d["mtx"] = np.repeat(m, npaths, axis=0)
+    return d
+
+
+def tiger_spec_paths(seed=2025, npaths=240):
+    """The drawing of SURVEY.md 8(d) config 3 as written: 240 paths, each 1-4 closed sub-paths of 8-60 cubic segments
+    (smooth random closed splines in a 900^2 view box), about 2/3 fill-only and 1/3 fill + stroke (widths 0.5-3: a mix of
+    Thin and AA strokes), colours from a 16-entry palette. Heavier than tiger_paths (which keeps the round-1 shape so that
+    rounds compare): about 2.6x the commands per instance."""
+    rs = np.random.RandomState(seed)
+    b = PathSetBuilder()
+    ops = []
+    for p in range(npaths):
+        b.begin_path()
+        nsub = int(rs.randint(1, 5))
+        radius = float(np.exp(rs.uniform(np.log(6.0), np.log(140.0))))
+        cx0, cy0 = rs.uniform(120.0, 780.0, size=2)
+        for s in range(nsub):
+            m = int(rs.randint(8, 61))
+            cx = cx0 + rs.uniform(-radius, radius) * 0.5
+            cy = cy0 + rs.uniform(-radius, radius) * 0.5
+            r_s = radius * rs.uniform(0.4, 1.0)
+            ang = np.sort(rs.uniform(0.0, 2.0 * np.pi, size=m)) + rs.uniform(0, 2 * np.pi)
+            rad = r_s * rs.uniform(0.6, 1.0, size=m)
+            P = np.stack([cx + rad * np.cos(ang), cy + rad * np.sin(ang)], axis=1).astype(np.float32).astype(np.float64)
+            b.move_to(P[0, 0], P[0, 1])
+            for i in range(m):
+                p0, p1, p2, p3 = P[(i - 1) % m], P[i], P[(i + 1) % m], P[(i + 2) % m]
+                c1 = p1 + (p2 - p0) / 6.0
+                c2 = p2 - (p3 - p1) / 6.0
+                b.cubic_to(c1[0], c1[1], c2[0], c2[1], p2[0], p2[1])
+            b.close()
+        b.end_path()
+        stroke = bool(rs.uniform() < (1.0 / 3.0))
+        ops.append(dict(fill_color=TIGER_PALETTE[int(rs.randint(0, 16))], stroke=stroke,
+                        stroke_color=TIGER_PALETTE[int(rs.randint(0, 16))],
+                        stroke_width=float(rs.uniform(0.5, 3.0))))
+    return b.arrays(), ops
+
+
 # ---- config 3 ----------------------------------------------------------------------------------
 def random_walk_polylines(n=10000, nseg=1000, seed=5678, width=6.0, cap=capi.CAP_ROUND, join=capi.JOIN_ROUND,
                           step=8.0, turn_sigma=0.5):

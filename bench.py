@@ -371,8 +371,12 @@ def main():
     red_dev = torch.device("cpu") if share_gpu else dev
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     vtot = torch.tensor([float(res["units"])], dtype=torch.float64, device=red_dev)
+    by_rank = None
     if world > 1:
         import torch.distributed as dist
+        each = [torch.zeros(1, dtype=torch.float64, device=red_dev) for _ in range(world)]
+        dist.all_gather(each, tmax.clone())
+        by_rank = [round(float(x.item()) / args.steps * 1e3, 3) for x in each]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(vtot, op=dist.ReduceOp.SUM)
     dt = float(tmax.item())
@@ -442,6 +446,55 @@ def main():
                     del b2
                 except Exception as e:  # noqa: BLE001 -- the un-overlapped number above stands
                     box["overlap_err"] = repr(e)
+                # Tiled form ("emit chunk k + 1 while sending chunk k"): the frame is tessellated in T sub-batches of
+                # whole instances, tile t into the local buffers behind tile t - 1; its gather (vgx_gather_at: place = the rank's
+                # base + the tiles in front) runs on the second stream while tile t + 1 is tessellated. One frame's latency,
+                # gather included, without a second set of output buffers. Tiles have the same shape (same drawing per instance),
+                # so one count call sizes them all.
+                try:
+                    T = int(os.environ.get("VGX_BENCH_GATHER_TILES", "4"))
+                    if args.config.startswith("tiger") and K % T == 0 and ndraws % T == 0:
+                        nd_t = ndraws // T
+                        dd_tiles = [dd[t * nd_t * 64:(t + 1) * nd_t * 64] for t in range(T)]
+                        st = rt.tessellate_count(ctx, pset, dd_tiles[0], nd_t)
+                        tv, ti, tm = st["num_vertices"], st["num_indices"], st["num_meshes"]
+                        if (tv * T, ti * T, tm * T) == (sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]):
+                            views = [bufs.view(t * tv, tv, t * ti, ti, t * tm, tm) for t in range(T)]
+                            RS = rt.capi.RankSizes
+                            tile_all = (RS * world)(*[RS(tv, ti, tm, nd_t) for _ in range(world)])
+                            places = []
+                            for t in range(T):
+                                places.append((RS * world)(*[RS(r * tv * T + t * tv, r * ti * T + t * ti, r * tm * T + t * tm, r * ndraws + t * nd_t) for r in range(world)]))
+                            gb2 = rt.MeshBuffers(dev, tv * T * world, ti * T * world, tm * T * world) if rank == 0 else None
+                            side = torch.cuda.Stream(device=dev)
+                            main = torch.cuda.current_stream(dev)
+
+                            def tiled_frame():
+                                for t in range(T):
+                                    rt.tessellate_async(ctx, pset, dd_tiles[t], nd_t, views[t])
+                                    ready = torch.cuda.Event()
+                                    ready.record(main)
+                                    side.wait_event(ready)
+                                    with torch.cuda.stream(side):
+                                        cg.gather_at(views[t], tile_all, places[t], 0, gb2)
+                                fin = torch.cuda.Event()
+                                fin.record(side)
+                                main.wait_event(fin)
+                            tiled_frame()  # warm-up
+                            barrier()
+                            o1 = time.perf_counter()
+                            for it in range(args.steps):
+                                tiled_frame()
+                            barrier()
+                            box["tiled_ms_per_step"] = (time.perf_counter() - o1) / args.steps * 1e3
+                            box["tiles"] = T
+                            if rank == 0 and world == 1:
+                                nv = sizes["num_vertices"]
+                                box["tiled_check"] = bool(torch.equal(gb2.pos[:nv], bufs.pos[:nv]) and int(views[-1].dev_status.item()) == 0)
+                            del gb2, views
+                            rt.tessellate_count(ctx, pset, dd, ndraws)  # scratch back to the whole-frame shape
+                except Exception as e:  # noqa: BLE001
+                    box["tiled_err"] = repr(e)
                 del gb
                 cg.close()
             except Exception as e:  # noqa: BLE001 -- any failure falls back to the torch.distributed gather
@@ -475,6 +528,8 @@ def main():
         res["gather_check"] = box.get("check")
         res["overlap_ms_per_step"] = box.get("overlap_ms_per_step")
         res["overlap_err"] = box.get("overlap_err")
+        for k in ("tiled_ms_per_step", "tiles", "tiled_check", "tiled_err"):
+            res[k] = box.get(k)
 
     # ---- next rows, measured beside the headline on rank 0 of a 1-GPU run: not part of `value` ----
     next_rows = None
@@ -582,6 +637,8 @@ def main():
             "next_rows": next_rows,
             "configs": other,
         }
+        if by_rank is not None:
+            out["ms_per_step_by_rank"] = by_rank
         if gather_ms is not None:
             # SURVEY 8e defines the scaling target INCLUDING the gather of the final streams to the root: `value` is the
             # tessellation rate of all ranks, `value_with_gather` the rate with one (un-overlapped) gather per step added
@@ -593,6 +650,15 @@ def main():
             out["value_with_overlapped_gather"] = round(total_units / (res["overlap_ms_per_step"] * 1e-3) / 1e6, 2)
         elif res.get("overlap_err"):
             out["overlapped_gather_error"] = res["overlap_err"]
+        if res.get("tiled_ms_per_step") is not None:
+            # the frame tessellated in tiles, every tile gathered (vgx_gather_at) while the next one is tessellated
+            out["ms_per_step_with_tiled_gather"] = round(res["tiled_ms_per_step"], 3)
+            out["value_with_tiled_gather"] = round(total_units / (res["tiled_ms_per_step"] * 1e-3) / 1e6, 2)
+            out["gather_tiles"] = res["tiles"]
+            if res.get("tiled_check") is not None:
+                out["tiled_gather_check"] = res["tiled_check"]
+        elif res.get("tiled_err"):
+            out["tiled_gather_error"] = res["tiled_err"]
         if gather_via is not None:
             out["gather_via"] = gather_via
             if res.get("gather_check") is not None:

@@ -1,0 +1,51 @@
+"""bench.py's output contract, on small batches: the one-rank line (metric, value, roofline with traffic_ratio, cpu_baseline
+when asked, configs) and the multi-rank code path -- two ranks launched the way the driver launches them (torch.distributed.run,
+one process per rank), both on cuda:0 over gloo (VGX_BENCH_SHARE_GPU=1: RCCL refuses two ranks on one device, the GPU test
+boxes have one): weak scaling, max over ranks, per-rank times, the gather leg through vg-renderer_amd/dist.py."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(out):
+    for l in reversed(out.strip().splitlines()):
+        if l.startswith("{"):
+            return json.loads(l)
+    raise AssertionError(out[-2000:])
+
+
+def test_one_rank_line():
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--instances", "300", "--no-cpu",
+                                   "--placements", "1"], text=True, timeout=600, cwd=ROOT)
+    d = _line(out)
+    assert d["metric"].startswith("M tessellated verts/sec") and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["unit"] == "M verts/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "f32"
+    assert d["value"] > 0 and abs(d["value"] - d["config"]["verts_per_gpu"] / d["ms_per_step"] / 1e3) / d["value"] < 0.02
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert set(r["by_kernel"]) >= {"flatten_build", "fill_emit", "stroke_emit"}
+    assert d["config"]["flatten_kernel"].startswith("k_flatten_inst")
+    assert set(d["configs"]) == {"cubics1m", "round10k", "tiger10k_varied", "tigerspec10k"}
+    for name, c in d["configs"].items():
+        assert c["value"] > 0 and c["roofline"]["frac"] > 0, name
+    assert d["configs"]["tiger10k_varied"]["flatten_kernel"] == "k_flatten_inst"
+
+
+def test_two_ranks_share_one_gpu():
+    env = dict(os.environ, VGX_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                   "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                                   "--instances", "200", "--no-cpu", "--placements", "1"], text=True, timeout=900, cwd=ROOT, env=env, stderr=subprocess.STDOUT)
+    d = _line(out)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert len(d["ms_per_step_by_rank"]) == 2 and abs(max(d["ms_per_step_by_rank"]) - d["ms_per_step"]) < 1e-2
+    # whole-job value = both ranks' vertices over the slowest rank's time
+    assert abs(d["value"] - 2 * d["config"]["verts_per_gpu"] / d["ms_per_step"] / 1e3) / d["value"] < 0.02
+    assert d["gather_ms"] > 0 and d["value_with_gather"] < d["value"]
+    assert d["configs"] is None and d["cpu_baseline"] is None

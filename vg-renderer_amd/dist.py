@@ -148,6 +148,14 @@ class CapiGather:
         g = global_bufs.out_struct() if global_bufs is not None else None
         self.rt._check(self.rt.lib().vgx_gather(self.ctx.handle, self.comm, root, C.byref(local), allz, C.byref(g) if g is not None else None, self.rt._stream_ptr()), "vgx_gather")
 
+    def gather_at(self, bufs, allz, place, root=0, global_bufs=None):
+        """vgx_gather_at: rank r's block lands at place[r] (RankSizes used as offsets). For frames tessellated in tiles."""
+        C = self.C
+        local = bufs.out_struct()
+        g = global_bufs.out_struct() if global_bufs is not None else None
+        self.rt._check(self.rt.lib().vgx_gather_at(self.ctx.handle, self.comm, root, C.byref(local), allz, place, C.byref(g) if g is not None else None,
+                                                   self.rt._stream_ptr()), "vgx_gather_at")
+
     def close(self):
         if self.comm:
             self.lib.ncclCommDestroy.argtypes = [self.C.c_void_p]

@@ -201,6 +201,20 @@ class MeshBuffers:
         return capi.MeshOut(self.pos.data_ptr(), self.color.data_ptr(), self.idx.data_ptr(), self.meshes.data_ptr(),
                             self.cap[0], self.cap[1], self.cap[2])
 
+    def view(self, v0, nv, i0, ni, m0, nm):
+        """A tile of these buffers: vertices [v0, v0 + nv), indices [i0, i0 + ni), mesh records [m0, m0 + nm) as buffers of
+        their own (same memory; own totals / status words) -- what one sub-batch of a frame is tessellated into."""
+        import torch
+        t = MeshBuffers.__new__(MeshBuffers)
+        t.cap = (int(nv), int(ni), int(nm))
+        t.pos = self.pos[v0:v0 + max(nv, 1)]
+        t.color = self.color[v0:v0 + max(nv, 1)]
+        t.idx = self.idx[i0:i0 + max(ni, 1)]
+        t.meshes = self.meshes[m0 * 32:(m0 + max(nm, 1)) * 32]
+        t.dev_sizes = torch.zeros(10, dtype=torch.int64, device=self.pos.device)
+        t.dev_status = torch.zeros(1, dtype=torch.int32, device=self.pos.device)
+        return t
+
 
 def tessellate_count(ctx, pset, draws_dev, ndraws):
     sizes = capi.Sizes()

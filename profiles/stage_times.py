@@ -83,6 +83,9 @@ def main():
         rs = np.random.RandomState(1)
         draws = draws[rs.uniform(size=draws.shape[0]) > 0.1]
         draws = draws[rs.permutation(draws.shape[0])]
+    elif which == "varied":       # Tiger x10k, every instance at its own scale (0.5 .. 3.5) and rotation
+        ps, ops = wl.tiger_paths()
+        draws = wl.tiger_varied_draws(ops, 10000)
     elif which == "fillonly":     # Tiger x10k without its strokes: the fill meshes' output streams have no gaps
         ps, ops = wl.tiger_paths()
         draws = wl.tiger_draws(ops, 10000)

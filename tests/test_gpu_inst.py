@@ -252,3 +252,65 @@ def test_grouped_mode_path_set_larger_than_the_lds_table(rt, gpu_ctx, wl, oracle
     assert got.status == 0
     assert_mesh_equal(got, ref, "grouped mode, hashed LDS table")
     assert int(got.dev_sizes[NUM_SERIAL]) == 0  # built by the instanced lanes
+
+
+def _continuous_scales(wl, ps, seed, ninst):
+    """Instances with a scale of their own each (0.5 .. 3.5, continuous) and a rotation."""
+    rs = np.random.RandomState(seed + 2000)
+    base = wl.fuzz_draws(ps, seed)
+    P = base.shape[0]
+    d = np.tile(base, ninst)
+    f = np.repeat(rs.uniform(0.5, 3.5, size=ninst).astype(np.float32), P)
+    ang = np.repeat(rs.uniform(0, 2 * np.pi, size=ninst), P)
+    c, sn = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+    m = d["mtx"].copy()
+    d["mtx"][:, 0] = (m[:, 0] * c - m[:, 1] * sn) * f
+    d["mtx"][:, 1] = (m[:, 0] * sn + m[:, 1] * c) * f
+    d["mtx"][:, 2] = (m[:, 2] * c - m[:, 3] * sn) * f
+    d["mtx"][:, 3] = (m[:, 2] * sn + m[:, 3] * c) * f
+    d["scale"] *= f
+    return d
+
+
+@pytest.mark.parametrize("classes,mode", [(None, 3), ("1", 1), ("4", 3), ("65536", 3)])
+def test_instances_of_different_scales_are_sorted_by_tolerance_class(rt, wl, oracle, classes, mode, monkeypatch):
+    """A periodic batch whose instances differ in scale: lane = instance would leave the lock-step walk at nearly every
+    cubic, so the count pass picks the grouped mode with (path, tolerance class) keys (flatten mode 3). VGX_INST_CLASSES=1
+    keeps the periodic mapping; few / very many classes only change the order inside a path's range. Same bits in all cases."""
+    if classes is not None:
+        monkeypatch.setenv("VGX_INST_CLASSES", classes)
+    ps = wl.fuzz_paths(780, npaths=48, with_shapes=False, with_polylines=True)
+    d = _continuous_scales(wl, ps, 780, 70)
+    assert d.shape[0] > 2048
+    ref = oracle.tessellate(ps, d)
+    ctx = rt.Context()
+    try:
+        got = _async(rt, ctx, ps, d)
+        assert got.status == 0
+        assert ctx.failure_info()["segment_items"] == mode
+        assert_mesh_equal(got, ref, "tolerance classes=%s" % classes)
+        assert int(got.dev_sizes[NUM_SERIAL]) == 0
+        # the same context, a batch of ONE scale per path position: back to the periodic mapping
+        d1 = _instances(wl, ps, 780, 70, vary=False)
+        got1 = _async(rt, ctx, ps, d1)
+        assert ctx.failure_info()["segment_items"] == 1
+        assert_mesh_equal(got1, oracle.tessellate(ps, d1), "uniform scale after a varied batch")
+    finally:
+        ctx.close()
+
+
+def test_tolerance_classes_with_outliers(rt, gpu_ctx, wl, oracle):
+    """Shuffled instances of many scales plus a few draws whose tolerance is ten orders of magnitude away from the rest
+    (1e-4 and 1e6): the classes quantise the RANGE of the batch, so most draws share a handful of classes then -- still
+    the same bits. (tess_tol -> 0 is not a case: the reference's subdivision does not terminate in reasonable time.)"""
+    ps = wl.fuzz_paths(781, npaths=40, with_shapes=False, with_polylines=True)
+    d = _continuous_scales(wl, ps, 781, 64)
+    rs = np.random.RandomState(781)
+    d = d[rs.permutation(d.shape[0])]
+    d["tess_tol"][rs.randint(0, d.shape[0], size=12)] = np.float32(1e-4)
+    d["tess_tol"][rs.randint(0, d.shape[0], size=12)] = np.float32(1e6)
+    ref = oracle.tessellate(ps, d)
+    got = _async(rt, gpu_ctx, ps, d)
+    assert got.status == 0
+    assert gpu_ctx.failure_info()["segment_items"] == 3
+    assert_mesh_equal(got, ref, "tolerance classes, outliers")

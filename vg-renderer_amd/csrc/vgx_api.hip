@@ -66,14 +66,18 @@ struct vgx_ctx
 	// options, read from the environment ONCE at vgx_create (tuning / testing knobs)
 	int optTwoPass, optBuildWaves, optPoolWalk, optNoSmall, optConcurrentEmit;
 	int optInst, optInstWaves; uint32_t optInstBlock; // instanced flatten kernel (vgx_inst.hip): on / grid / lane block
+	uint32_t optInstClasses;                          // grouped mode: tolerance classes per path when the instances differ in scale (VGX_INST_CLASSES)
 	// instanced batches: period of the path sequence found by the last vgx_tessellate_count (0 = none). vgx_tessellate
 	// re-checks it on the device for the draws it is given.
 	uint32_t instPeriod;
 	// ... or, when the draws reuse paths without repeating one sequence (at least 32 draws per used path on average): 1 =
 	// grouped mode, every vgx_tessellate sorts the draws by path first (k_inst_hist / k_inst_plan / k_inst_scatter)
 	int instGrouped;
-	DevBuf instHist, instCursor, instStart, instTaskStart, instTaskPath, instOrder;
-	uint64_t instCapPaths, instCapTasks, instCapDraws;
+	// grouped mode, instances of different scales: the sort key is (path, tolerance class) with this many classes per path
+	// (1 = by path only), so that the lanes of a wave flatten with nearly the same tolerance and stay in lock-step
+	uint32_t instClasses;
+	DevBuf instHist, instCursor, instKeyStart, instStart, instTaskStart, instTaskPath, instOrder;
+	uint64_t instCapPaths, instCapKeys, instCapTasks, instCapDraws;
 	hipStream_t sideStream; hipEvent_t forkEv, joinEv; // optConcurrentEmit only
 	VgxCaps caps; // element capacities matching the buffers above
 	uint64_t capDraws;
@@ -376,26 +380,30 @@ uint32_t instPeriodFor(const vgx_ctx* ctx, uint64_t ndraws)
 bool instGroupedFor(const vgx_ctx* ctx, const vgx_pathset* ps, uint64_t ndraws)
 {
 	return ctx->instGrouped && ctx->optInst && !instPeriodFor(ctx, ndraws) && ndraws > VGX_SMALL_DRAWS && ndraws <= ctx->instCapDraws
-		&& ps->dev.npaths <= ctx->instCapPaths && ndraws < 0xFFFFFFFFull;
+		&& ps->dev.npaths <= ctx->instCapPaths && (uint64_t)ps->dev.npaths * ctx->instClasses <= ctx->instCapKeys && ndraws < 0xFFFFFFFFull;
 }
 
 // scratch of the grouped mode: histogram / cursor / ranges per path, task table, draw order
-int ensureInstGroup(vgx_ctx* ctx, uint32_t npaths, uint64_t ndraws, bool full)
+int ensureInstGroup(vgx_ctx* ctx, uint32_t npaths, uint32_t nc, uint64_t ndraws, bool full)
 {
 	int st;
-	if ((st = ensure(ctx, ctx->instHist, ((size_t)npaths + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
+	const size_t nkeys = (size_t)npaths * nc;
+	if ((st = ensure(ctx, ctx->instHist, (nkeys + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->instStart, ((size_t)npaths + 1) * sizeof(uint64_t))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->instTaskStart, ((size_t)npaths + 1) * sizeof(uint64_t))) != VGX_OK) { return st; }
 	if (full) {
 		const uint64_t tasks = ndraws / 64 + (uint64_t)npaths + 2; // every used path rounds up once
-		if ((st = ensure(ctx, ctx->instCursor, ((size_t)npaths + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
+		if ((st = ensure(ctx, ctx->instCursor, (nkeys + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
+		if ((st = ensure(ctx, ctx->instKeyStart, (nkeys + 1) * sizeof(uint64_t))) != VGX_OK) { return st; }
 		if ((st = ensure(ctx, ctx->instTaskPath, tasks * sizeof(uint32_t))) != VGX_OK) { return st; }
 		if ((st = ensure(ctx, ctx->instOrder, (ndraws + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
 		ctx->instCapTasks = ctx->instTaskPath.cap / sizeof(uint32_t);
 		ctx->instCapDraws = ctx->instOrder.cap / sizeof(uint32_t) - 1;
-		uint64_t cp = ctx->instHist.cap / sizeof(uint32_t) - 1;
-		{ const uint64_t c2 = ctx->instCursor.cap / sizeof(uint32_t) - 1, c3 = ctx->instStart.cap / sizeof(uint64_t) - 1, c4 = ctx->instTaskStart.cap / sizeof(uint64_t) - 1;
-		  if (c2 < cp) { cp = c2; } if (c3 < cp) { cp = c3; } if (c4 < cp) { cp = c4; } }
+		uint64_t ck = ctx->instHist.cap / sizeof(uint32_t) - 1;
+		{ const uint64_t c2 = ctx->instCursor.cap / sizeof(uint32_t) - 1, c3 = ctx->instKeyStart.cap / sizeof(uint64_t) - 1; if (c2 < ck) { ck = c2; } if (c3 < ck) { ck = c3; } }
+		ctx->instCapKeys = ck;
+		uint64_t cp = ctx->instStart.cap / sizeof(uint64_t) - 1;
+		{ const uint64_t c4 = ctx->instTaskStart.cap / sizeof(uint64_t) - 1; if (c4 < cp) { cp = c4; } }
 		ctx->instCapPaths = cp;
 	}
 	return VGX_OK;
@@ -467,8 +475,9 @@ void runFlattenBuild(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 	a.build_mode = 1;
 	setInstArgs(ctx, ps, ndraws, a); // periodic: the same value runCmdPrefix checked the draws against
 	if (a.inst_order) { // grouped mode: this batch's draws sorted by path
-		vgx_launch_inst_group(draws, ndraws, ps->dev.npaths, (uint32_t*)ctx->instHist.p, (uint32_t*)ctx->instCursor.p, (uint64_t*)ctx->instStart.p,
-			(uint64_t*)ctx->instTaskStart.p, (uint32_t*)ctx->instTaskPath.p, ctx->instCapTasks, (uint32_t*)ctx->instOrder.p, (VgxTotals*)ctx->totals.p, ctx->partial.p, s);
+		vgx_launch_inst_group(draws, ndraws, ps->dev.npaths, ctx->instClasses, (uint32_t*)ctx->instHist.p, (uint32_t*)ctx->instCursor.p, (uint64_t*)ctx->instKeyStart.p,
+			(uint64_t*)ctx->instStart.p, (uint64_t*)ctx->instTaskStart.p, (uint32_t*)ctx->instTaskPath.p, ctx->instCapTasks, (uint32_t*)ctx->instOrder.p,
+			(VgxTotals*)ctx->totals.p, ctx->partial.p, s);
 		mark(ctx, s, "inst_group");
 	}
 	a.mprep = (VgxMeshPrep*)ctx->mprep.p; // k_flatten_gather / k_flatten_serial write the per-mesh constants with the descriptors
@@ -660,6 +669,8 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	ctx->optNoSmall = getenv("VGX_NO_SMALL") ? 1 : 0; // testing knob: frame-sized batches through the large-batch launch sequence
 	ctx->optInst = 1; ctx->optInstWaves = VGX_INST_WAVES; ctx->optInstBlock = VGX_INST_BLOCK; // VGX_INST=0: instanced batches through k_flatten_build as well
 	if (const char* e = getenv("VGX_INST")) { ctx->optInst = atoi(e) != 0; }
+	ctx->optInstClasses = 256;
+	if (const char* e = getenv("VGX_INST_CLASSES")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { uint32_t p2 = 1; while (p2 * 2 <= (uint32_t)v) { p2 *= 2; } ctx->optInstClasses = p2; } }
 	if (const char* e = getenv("VGX_INST_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { ctx->optInstWaves = v; } }
 	if (const char* e = getenv("VGX_INST_BLOCK")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { ctx->optInstBlock = (uint32_t)v; } }
 	ctx->optPoolWalk = 0; // VGX_WALK=pool: the wave-cooperative walk of vgx_walk.h (same output, same speed: DESIGN.md section 4)
@@ -675,7 +686,7 @@ int vgx_destroy(vgx_ctx* ctx)
 		return VGX_E_INVALID_ARG;
 	}
 	DeviceGuard guard(ctx);
-	DevBuf* bufs[] = { &ctx->instHist, &ctx->instCursor, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DevBuf* bufs[] = { &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
@@ -923,13 +934,13 @@ static int flattenCountCommon(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_dra
 	if ((st = ensureDrawBuffers(ctx, ndraws)) != VGX_OK) { return st; }
 	// pass 1: command instances (sizes the per-command scratch)
 	ctx->caps.cmd_instances = ~0ull; // not known yet: never trips the check in this sizing pass
-	ctx->instPeriod = 0; ctx->instGrouped = 0;
+	ctx->instPeriod = 0; ctx->instGrouped = 0; ctx->instClasses = 1;
 	runCmdPrefix(ctx, ps, draws, ndraws, s);
 	if (ctx->optInst && ndraws > VGX_SMALL_DRAWS) {
 		vgx_launch_inst_detect(draws, ndraws, (VgxTotals*)ctx->totals.p, s);
 		// ... and how many different paths the draws use (grouped mode, when the sequence does not repeat)
-		if ((st = ensureInstGroup(ctx, ps->dev.npaths, ndraws, false)) != VGX_OK) { return st; }
-		vgx_launch_inst_group(draws, ndraws, ps->dev.npaths, (uint32_t*)ctx->instHist.p, nullptr, (uint64_t*)ctx->instStart.p, (uint64_t*)ctx->instTaskStart.p,
+		if ((st = ensureInstGroup(ctx, ps->dev.npaths, 1, ndraws, false)) != VGX_OK) { return st; }
+		vgx_launch_inst_group(draws, ndraws, ps->dev.npaths, 1, (uint32_t*)ctx->instHist.p, nullptr, nullptr, (uint64_t*)ctx->instStart.p, (uint64_t*)ctx->instTaskStart.p,
 			nullptr, 0, nullptr, (VgxTotals*)ctx->totals.p, ctx->partial.p, s);
 	}
 	if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
@@ -939,10 +950,20 @@ static int flattenCountCommon(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_dra
 		const unsigned long long P = ~0ull - ctx->hostTotals->inst_detect_inv;
 		if (P <= 0xFFFFFFFFull) { ctx->instPeriod = (uint32_t)P; }
 	}
+	const VgxTotals& ht = *ctx->hostTotals;
+	const bool reused = ctx->optInst && ndraws > VGX_SMALL_DRAWS && ndraws < 0xFFFFFFFFull && ht.inst_distinct != 0 && ndraws / ht.inst_distinct >= VGX_INST_MIN_INSTANCES;
+	if (reused && ctx->optInstClasses > 1 && (instPeriodFor(ctx, ndraws) ? ht.inst_tol_varies != 0 : (uint32_t)~ht.inst_tol_lo_inv != ht.inst_tol_hi)) {
+		// The instances of a path differ in scale: in the periodic mapping (lane = instance) the lanes of a wave would
+		// disagree about nearly every cubic. Grouped mode sorted by (path, tolerance class) instead.
+		uint32_t nc = ctx->optInstClasses;
+		while (nc > 1 && (uint64_t)ps->dev.npaths * nc > (1ull << 22)) { nc >>= 1; } // scratch of at most 4 M keys
+		ctx->instClasses = nc;
+		if (nc > 1) { ctx->instPeriod = 0; }
+	}
 	if (!instPeriodFor(ctx, ndraws) && ctx->optInst && ndraws > VGX_SMALL_DRAWS && ndraws < 0xFFFFFFFFull && ctx->hostTotals->inst_distinct != 0
 		&& ndraws / ctx->hostTotals->inst_distinct >= VGX_INST_MIN_INSTANCES) {
 		// paths are reused (>= 32 draws per used path on average) but not as a repeating sequence: grouped mode
-		if ((st = ensureInstGroup(ctx, ps->dev.npaths, ndraws, true)) != VGX_OK) { return st; }
+		if ((st = ensureInstGroup(ctx, ps->dev.npaths, ctx->instClasses, ndraws, true)) != VGX_OK) { return st; }
 		ctx->instGrouped = 1;
 	}
 	const uint64_t ncmdInst = ctx->hostTotals->sizes.num_cmd_instances;
@@ -1342,7 +1363,7 @@ int vgx_get_failure_info(vgx_ctx* ctx, vgx_failure_info* out, void* stream)
 	out->reason = ctx->hostTotals->fail_reason;
 	out->aux = ctx->hostTotals->fail_aux;
 	out->segment = ctx->hostTotals->fail_segment;
-	out->segment_items = ctx->optInst ? (ctx->instPeriod ? 1u : (ctx->instGrouped ? 2u : 0u)) : 0u; // flatten mode chosen by the last count call
+	out->segment_items = ctx->optInst ? (ctx->instPeriod ? 1u : (ctx->instGrouped ? (ctx->instClasses > 1 ? 3u : 2u) : 0u)) : 0u; // flatten mode chosen by the last count call
 	for (int i = 0; i < 16; ++i) { out->prof[i] = ctx->hostTotals->prof[i]; }
 	return VGX_OK;
 }

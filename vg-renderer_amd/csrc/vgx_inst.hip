@@ -541,6 +541,15 @@ __global__ __launch_bounds__(256) void k_inst_find(const vgx_draw* draws, uint64
 	if (best != ~0ull) { atomicMax(&totals->inst_detect_inv, ~0ull - best); } // totals are zeroed: keep the minimum as a maximum
 }
 
+// Effective flattening tolerance of a draw (InstLane::beginDraw) as an ordered integer: the bit patterns of positive finite
+// floats ascend with their values. Anything else (a zero scale, NaN) is class 0.
+__device__ __forceinline__ uint32_t inst_tol_bits(const vgx_draw* d)
+{
+	const float t = d->tess_tol / (d->scale * d->scale);
+	const uint32_t b = __float_as_uint(t);
+	return (t > 0.0f && b < 0x7F800000u) ? b : 0u;
+}
+
 __global__ __launch_bounds__(256) void k_inst_verify(const vgx_draw* draws, uint64_t ndraws, VgxTotals* totals)
 {
 	const unsigned long long inv = totals->inst_detect_inv;
@@ -549,11 +558,34 @@ __global__ __launch_bounds__(256) void k_inst_verify(const vgx_draw* draws, uint
 		if (blockIdx.x == 0 && threadIdx.x == 0) { totals->inst_detect_bad = 1u; }
 		return;
 	}
-	bool bad = false;
+	bool bad = false, varies = false;
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ndraws; i += (uint64_t)gridDim.x * blockDim.x) {
-		bad = bad || (draws[i].path != draws[i % P].path);
+		const vgx_draw* img = draws + i % P;
+		bad = bad || (draws[i].path != img->path);
+		varies = varies || (inst_tol_bits(draws + i) != inst_tol_bits(img));
 	}
 	if (bad) { totals->inst_detect_bad = 1u; }
+	if (varies) { totals->inst_tol_varies = 1u; }
+}
+
+// Range of the draws' tolerances (grouped mode with tolerance classes; the count pass, to decide on them)
+__global__ __launch_bounds__(256) void k_inst_tol_range(const vgx_draw* draws, uint64_t ndraws, VgxTotals* totals)
+{
+	__shared__ uint32_t s_lo, s_hi;
+	if (threadIdx.x == 0) { s_lo = 0xFFFFFFFFu; s_hi = 0u; }
+	__syncthreads();
+	uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ndraws; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t b = inst_tol_bits(draws + i);
+		lo = b < lo ? b : lo; hi = b > hi ? b : hi;
+	}
+	for (int o = 32; o > 0; o >>= 1) {
+		const uint32_t l2 = (uint32_t)__shfl_xor((int)lo, o), h2 = (uint32_t)__shfl_xor((int)hi, o);
+		lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+	}
+	if ((threadIdx.x & 63) == 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+	__syncthreads();
+	if (threadIdx.x == 0 && s_lo <= s_hi) { atomicMax(&totals->inst_tol_lo_inv, ~s_lo); atomicMax(&totals->inst_tol_hi, s_hi); }
 }
 
 // ---- grouped mode: the draws sorted by path ------------------------------------------------------------------------
@@ -566,6 +598,15 @@ __global__ __launch_bounds__(256) void k_inst_verify(const vgx_draw* draws, uint
 // one-probe hash (slot = path mod table size, first comer owns the slot) beyond: draws of a slot's owner count in LDS,
 // everything else goes to the global counter at once -- many draws on few paths stay in LDS, a million draws on a million
 // paths are a million atomics on a million different addresses, which do not serialise.
+//
+// Tolerance classes. Lanes of a wave walk a cubic in lock-step only while they take the same flat / split decisions, i.e.
+// while their draws have (nearly) the same tess_tol / scale^2. When the instances differ in scale the sort key becomes
+// (path, class), class = the draw's tolerance quantised into `nc` steps over the batch's range [lo, hi] of bit patterns
+// (k_inst_tol_range): a path's range in `order` is then ascending in tolerance, and the 64 consecutive entries a wave
+// takes differ by about 64 / (instances of the path) of the range. Tasks stay (path, 64 entries) -- a task may straddle
+// two classes, which costs a few per-lane cubics, not correctness: the order inside a path's range is free.
+// Tiger x 9216 with scales 0.5 .. 3.5 (bench.py tiger10k_varied): flatten_build 7.9 ms in the periodic mapping, 1.6 ms +
+// 0.33 ms of sorting with 64 .. 1024 classes (256 by default, VGX_INST_CLASSES).
 #define VGX_INST_LDS_PATHS 4096
 #define VGX_INST_GROUP_THREADS 1024
 #define VGX_INST_GROUP_BLOCKS 256
@@ -577,7 +618,34 @@ __device__ __forceinline__ void inst_slice(uint64_t n, uint64_t* lo, uint64_t* h
 	*lo = l < n ? l : n;
 	*hi = l + per < n ? l + per : n;
 }
-// true: path p counts in LDS slot *slot of this workgroup
+struct InstKeys
+{
+	uint32_t npaths, nc, lo, shift; // nc = 1: the key is the path
+	__device__ __forceinline__ uint32_t nkeys() const { return npaths * nc; }
+	__device__ __forceinline__ uint32_t key(const vgx_draw* d) const
+	{
+		const uint32_t p = d->path;
+		if (p >= npaths) { return VGX_INST_NO_KEY; } // an invalid path id was reported by the command scan
+		if (nc == 1u) { return p; }
+		const uint32_t b = inst_tol_bits(d);
+		uint32_t c = b > lo ? (b - lo) >> shift : 0u;
+		c = c < nc ? c : nc - 1u;
+		return p * nc + c;
+	}
+};
+__device__ __forceinline__ InstKeys inst_keys(uint32_t npaths, uint32_t nc, const VgxTotals* totals)
+{
+	InstKeys k;
+	k.npaths = npaths; k.nc = nc; k.lo = 0; k.shift = 0;
+	if (nc > 1u) {
+		const uint32_t lo = ~totals->inst_tol_lo_inv, hi = totals->inst_tol_hi;
+		k.lo = lo;
+		const uint32_t span = hi > lo ? hi - lo : 0u;
+		while ((span >> k.shift) >= nc) { ++k.shift; }
+	}
+	return k;
+}
+// true: key p counts in LDS slot *slot of this workgroup
 __device__ __forceinline__ bool inst_slot(uint32_t* s_key, uint32_t p, uint32_t npaths, uint32_t* slot)
 {
 	if (npaths <= VGX_INST_LDS_PATHS) { *slot = p; return true; }
@@ -587,8 +655,10 @@ __device__ __forceinline__ bool inst_slot(uint32_t* s_key, uint32_t p, uint32_t 
 	return old == VGX_INST_NO_KEY || old == p;
 }
 
-__global__ __launch_bounds__(VGX_INST_GROUP_THREADS) void k_inst_hist(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, uint32_t* hist)
+__global__ __launch_bounds__(VGX_INST_GROUP_THREADS) void k_inst_hist(const vgx_draw* draws, uint64_t ndraws, uint32_t npathsIn, uint32_t nc, const VgxTotals* totals, uint32_t* hist)
 {
+	const InstKeys K = inst_keys(npathsIn, nc, totals);
+	const uint32_t npaths = K.nkeys(); // below: "path" = sort key
 	__shared__ uint32_t s_cnt[VGX_INST_LDS_PATHS];
 	__shared__ uint32_t s_key[VGX_INST_LDS_PATHS];
 	uint64_t lo, hi;
@@ -598,8 +668,8 @@ __global__ __launch_bounds__(VGX_INST_GROUP_THREADS) void k_inst_hist(const vgx_
 	for (uint32_t p = threadIdx.x; p < nslots; p += blockDim.x) { s_cnt[p] = 0; s_key[p] = hashed ? VGX_INST_NO_KEY : p; }
 	__syncthreads();
 	for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-		const uint32_t p = draws[i].path;
-		if (p >= npaths) { continue; } // an invalid path id was reported by the command scan
+		const uint32_t p = K.key(draws + i);
+		if (p == VGX_INST_NO_KEY) { continue; }
 		uint32_t slot;
 		if (inst_slot(s_key, p, npaths, &slot)) { atomicAdd(&s_cnt[slot], 1u); } else { atomicAdd(&hist[p], 1u); }
 	}
@@ -612,9 +682,23 @@ __global__ __launch_bounds__(VGX_INST_GROUP_THREADS) void k_inst_hist(const vgx_
 
 // Exclusive scans of the histogram (draw ranges, task ranges), the task -> path table, the totals: a device scan over the
 // paths (one workgroup up to 1024 paths, three passes beyond -- a path set may hold a million one-cubic paths).
-struct OpInstPlan
+// exclusive scan of the (path, class) histogram: first entry of every key in `order`
+struct OpInstKeyStart
 {
 	const uint32_t* hist;
+	uint64_t nkeys;
+	uint64_t* keyStart;
+	__device__ uint64_t size() const { return nkeys; }
+	__device__ Sum3 load(uint64_t k) const { Sum3 r = sum3_zero(); r.a = hist[k]; return r; }
+	__device__ void store(uint64_t k, Sum3 e) const { keyStart[k] = e.a; }
+	__device__ void finish(Sum3 t) const { keyStart[nkeys] = t.a; }
+};
+
+struct OpInstPlan
+{
+	const uint32_t* hist;     // nc == 1: draws per path
+	const uint64_t* keyStart; // nc > 1: scan of the (path, class) histogram
+	uint32_t nc;
 	uint32_t npaths;
 	uint64_t* start;
 	uint64_t* taskStart;
@@ -625,16 +709,17 @@ struct OpInstPlan
 	__device__ Sum3 load(uint64_t p) const
 	{
 		Sum3 r = sum3_zero();
-		const uint64_t cnt = hist[p];
+		const uint64_t cnt = count(p);
 		r.a = cnt; r.b = (cnt + VGX_WAVE - 1) / VGX_WAVE; r.c = cnt ? 1ull : 0ull;
 		return r;
 	}
+	__device__ uint64_t count(uint64_t p) const { return nc == 1u ? (uint64_t)hist[p] : keyStart[(p + 1) * nc] - keyStart[p * nc]; }
 	__device__ void store(uint64_t p, Sum3 e) const
 	{
 		start[p] = e.a;
 		taskStart[p] = e.b;
 		if (taskPath) {
-			const uint64_t nt = ((uint64_t)hist[p] + VGX_WAVE - 1) / VGX_WAVE;
+			const uint64_t nt = (count(p) + VGX_WAVE - 1) / VGX_WAVE;
 			for (uint64_t j = 0; j < nt; ++j) { if (e.b + j < capTasks) { taskPath[e.b + j] = (uint32_t)p; } }
 		}
 	}
@@ -648,8 +733,10 @@ struct OpInstPlan
 	}
 };
 
-__global__ __launch_bounds__(VGX_INST_GROUP_THREADS) void k_inst_scatter(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, const uint64_t* start, uint32_t* cursor, uint32_t* order)
+__global__ __launch_bounds__(VGX_INST_GROUP_THREADS) void k_inst_scatter(const vgx_draw* draws, uint64_t ndraws, uint32_t npathsIn, uint32_t nc, const VgxTotals* totals, const uint64_t* start, uint32_t* cursor, uint32_t* order)
 {
+	const InstKeys K = inst_keys(npathsIn, nc, totals);
+	const uint32_t npaths = K.nkeys(); // below: "path" = sort key, start[] = first entry of every key
 	__shared__ uint32_t s_cnt[VGX_INST_LDS_PATHS];
 	__shared__ uint32_t s_base[VGX_INST_LDS_PATHS];
 	__shared__ uint32_t s_key[VGX_INST_LDS_PATHS];
@@ -662,8 +749,8 @@ __global__ __launch_bounds__(VGX_INST_GROUP_THREADS) void k_inst_scatter(const v
 	for (uint32_t p = threadIdx.x; p < nslots; p += blockDim.x) { s_cnt[p] = 0; s_key[p] = hashed ? VGX_INST_NO_KEY : p; }
 	__syncthreads();
 	for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-		const uint32_t p = draws[i].path;
-		if (p >= npaths) { continue; }
+		const uint32_t p = K.key(draws + i);
+		if (p == VGX_INST_NO_KEY) { continue; }
 		uint32_t slot;
 		if (inst_slot(s_key, p, npaths, &slot)) { atomicAdd(&s_cnt[slot], 1u); }
 		else { order[start[p] + atomicAdd(&cursor[p], 1u)] = (uint32_t)i; }
@@ -676,8 +763,8 @@ __global__ __launch_bounds__(VGX_INST_GROUP_THREADS) void k_inst_scatter(const v
 	}
 	__syncthreads();
 	for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-		const uint32_t p = draws[i].path;
-		if (p >= npaths) { continue; }
+		const uint32_t p = K.key(draws + i);
+		if (p == VGX_INST_NO_KEY) { continue; }
 		const uint32_t sl = hashed ? (p & (VGX_INST_LDS_PATHS - 1)) : p;
 		if (s_key[sl] == p) { order[start[p] + s_base[sl] + atomicAdd(&s_cnt[sl], 1u)] = (uint32_t)i; }
 	}
@@ -685,17 +772,25 @@ __global__ __launch_bounds__(VGX_INST_GROUP_THREADS) void k_inst_scatter(const v
 
 } // namespace
 
-void vgx_launch_inst_group(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, uint32_t* hist, uint32_t* cursor, uint64_t* start, uint64_t* taskStart,
-	uint32_t* taskPath, uint64_t capTasks, uint32_t* order, VgxTotals* totals, void* scanPartial, hipStream_t s)
+void vgx_launch_inst_group(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, uint32_t nc, uint32_t* hist, uint32_t* cursor, uint64_t* keyStart, uint64_t* start,
+	uint64_t* taskStart, uint32_t* taskPath, uint64_t capTasks, uint32_t* order, VgxTotals* totals, void* scanPartial, hipStream_t s)
 {
-	(void)hipMemsetAsync(hist, 0, ((size_t)npaths + 1) * sizeof(uint32_t), s);
-	hipLaunchKernelGGL(k_inst_hist, dim3(VGX_INST_GROUP_BLOCKS), dim3(VGX_INST_GROUP_THREADS), 0, s, draws, ndraws, npaths, hist);
+	const uint64_t nkeys = (uint64_t)npaths * nc;
+	(void)hipMemsetAsync(hist, 0, (nkeys + 1) * sizeof(uint32_t), s);
+	if (nc > 1) { hipLaunchKernelGGL(k_inst_tol_range, dim3(512), dim3(256), 0, s, draws, ndraws, totals); }
+	hipLaunchKernelGGL(k_inst_hist, dim3(VGX_INST_GROUP_BLOCKS), dim3(VGX_INST_GROUP_THREADS), 0, s, draws, ndraws, npaths, nc, (const VgxTotals*)totals, hist);
+	if (nc > 1) {
+		OpInstKeyStart ks;
+		ks.hist = hist; ks.nkeys = nkeys; ks.keyStart = keyStart;
+		vgx_device_scan(ks, (Sum3*)scanPartial, s, nkeys);
+	}
 	OpInstPlan op;
-	op.hist = hist; op.npaths = npaths; op.start = start; op.taskStart = taskStart; op.taskPath = taskPath; op.capTasks = capTasks; op.totals = totals;
+	op.hist = hist; op.keyStart = keyStart; op.nc = nc; op.npaths = npaths; op.start = start; op.taskStart = taskStart; op.taskPath = taskPath; op.capTasks = capTasks; op.totals = totals;
 	vgx_device_scan(op, (Sum3*)scanPartial, s, npaths);
 	if (order) {
-		(void)hipMemsetAsync(cursor, 0, ((size_t)npaths + 1) * sizeof(uint32_t), s);
-		hipLaunchKernelGGL(k_inst_scatter, dim3(VGX_INST_GROUP_BLOCKS), dim3(VGX_INST_GROUP_THREADS), 0, s, draws, ndraws, npaths, (const uint64_t*)start, cursor, order);
+		(void)hipMemsetAsync(cursor, 0, (nkeys + 1) * sizeof(uint32_t), s);
+		hipLaunchKernelGGL(k_inst_scatter, dim3(VGX_INST_GROUP_BLOCKS), dim3(VGX_INST_GROUP_THREADS), 0, s, draws, ndraws, npaths, nc, (const VgxTotals*)totals,
+			(const uint64_t*)(nc > 1 ? keyStart : start), cursor, order);
 	}
 }
 
@@ -709,4 +804,5 @@ void vgx_launch_inst_detect(const vgx_draw* draws, uint64_t ndraws, VgxTotals* t
 	if (ndraws < 2) { return; }
 	hipLaunchKernelGGL(k_inst_find, dim3(512), dim3(256), 0, s, draws, ndraws, totals);
 	hipLaunchKernelGGL(k_inst_verify, dim3(512), dim3(256), 0, s, draws, ndraws, totals);
+	hipLaunchKernelGGL(k_inst_tol_range, dim3(512), dim3(256), 0, s, draws, ndraws, totals);
 }

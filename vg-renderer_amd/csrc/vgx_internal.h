@@ -94,8 +94,9 @@ void vgx_launch_flatten_build(const VgxFlattenArgs& a, int waves, hipStream_t s,
 void vgx_launch_flatten_inst(const VgxFlattenArgs& a, int waves, hipStream_t s);  // instanced batches: one lane per instance (vgx_inst.hip)
 void vgx_launch_inst_detect(const vgx_draw* draws, uint64_t ndraws, VgxTotals* totals, hipStream_t s); // count pass: period of the path sequence
 // grouped mode: histogram of the draws' paths -> per-path ranges and task list (taskPath may be null: counts only) -> draw order
-void vgx_launch_inst_group(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, uint32_t* hist, uint32_t* cursor, uint64_t* start, uint64_t* taskStart,
-	uint32_t* taskPath, uint64_t capTasks, uint32_t* order, VgxTotals* totals, void* scanPartial /* Sum3[VGX_SCAN_BLOCKS] */, hipStream_t s);
+// nc: tolerance classes per path (1 = sort by path only); hist / cursor / keyStart hold npaths * nc + 1 entries (keyStart unused when nc == 1)
+void vgx_launch_inst_group(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, uint32_t nc, uint32_t* hist, uint32_t* cursor, uint64_t* keyStart, uint64_t* start,
+	uint64_t* taskStart, uint32_t* taskPath, uint64_t capTasks, uint32_t* order, VgxTotals* totals, void* scanPartial /* Sum3[VGX_SCAN_BLOCKS] */, hipStream_t s);
 // frame-sized batches (vgx_flatten.hip): one-workgroup kernels instead of chains of dependent launches; the operators are
 // the OpCmdPrefix / OpDrawInfo / OpMeshAll of vgx_scan_ops.h, passed type-erased (the header is device code)
 #define VGX_SMALL_DRAWS 2048

@@ -125,12 +125,16 @@ struct VgxTotals
 	unsigned long long inst_distinct;    // grouped mode: paths that at least one draw uses
 	uint32_t inst_detect_bad;            // vgx_tessellate_count: some draw differs from its image in the first period
 	uint32_t inst_mismatch;              // vgx_tessellate: the draws no longer repeat with the context's period -> k_flatten_build does the batch
-	// diagnostics of the first failure inside the fused kernel (vgx_get_failure_info)
+	uint32_t inst_tol_lo_inv;            // ~(smallest bit pattern of tess_tol / scale^2 over the draws), k_inst_tol_range (totals are zeroed: a minimum kept as a maximum)
+	uint32_t inst_tol_hi;                // largest one. lo != hi: instances differ in scale -> grouped mode sorts by (path, tolerance class)
+	uint32_t inst_tol_varies;            // vgx_tessellate_count, periodic batch: some draw's tolerance differs from its image in the first period
+	uint32_t inst_pad0;
+	// diagnostics of the first failure (vgx_get_failure_info)
 	uint32_t fail_reason;  // VGX_FAIL_*
 	uint32_t fail_aux;
 	unsigned long long fail_segment;
-	// -DVGX_FUSED_PROFILE builds only: wave clock ticks (100 MHz) summed over all waves per phase of the fused kernel
-	unsigned long long prof[16]; // ticket, flatten, meshes, look-back, mesh table + fills, strokes, segments, lookback rounds
+	// -DVGX_INST_PROFILE builds only: wave clock ticks (100 MHz) summed over all waves per phase of k_flatten_inst
+	unsigned long long prof[16];
 };
 enum {
 	VGX_FAIL_NONE = 0,

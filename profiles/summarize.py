@@ -39,13 +39,14 @@ def traffic(fetch_db, write_db, label):
     """JSON for bench.py's roofline.traffic: HBM bytes per launch of the three big kernels = FETCH_SIZE x 2 (gfx950
     correction for wide coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE (raw), from two separate --pmc passes."""
     import json
-    names = {"k_flatten_build": "flatten_build", "k_flatten_inst": "flatten_build", "k_fill": "fill_emit", "k_stroke": "stroke_emit", "k_flatten_gather": "flatten_gather", "k_mesh_prepare": "mesh_prepare"}
+    names = {"k_flatten_build": "flatten_build", "k_flatten_inst": "flatten_build", "k_fill": "fill_emit", "k_stroke": "stroke_emit", "k_flatten_gather": "flatten_gather", "k_mesh_prepare": "mesh_prepare",
+             "k_flatten<false": "flatten_count", "k_flatten<true": "flatten_emit"}  # vgx_flatten (config 0 / cubics1m): count pass, emit pass
     out = {"source": label, "instances_per_gpu": 10000, "kernels": {}}
     for db, ctr, mul in ((fetch_db, "FETCH_SIZE", 2.0), (write_db, "WRITE_SIZE", 1.0)):
         c = sqlite3.connect(db).cursor()
         for name, kb in c.execute("select kernel_name, avg(value) from counters_collection where counter_name=? group by kernel_name", (ctr,)):
             for k, stage in names.items():
-                if k + "(" in name or k + "<" in name:
+                if k + "(" in name or k + "<" in name or ("<" in k and k in name):
                     d = out["kernels"].setdefault(stage, {"fetch_bytes": 0, "write_bytes": 0})
                     d["fetch_bytes" if ctr == "FETCH_SIZE" else "write_bytes"] += int(kb * 1024 * mul)  # flatten_build = k_flatten_inst + the k_flatten_build launch that exits at once (or the other way round)
     for d in out["kernels"].values():
@@ -53,8 +54,24 @@ def traffic(fetch_db, write_db, label):
     print(json.dumps(out, indent=1))
 
 
+def merge(label, parts):
+    """profiles/traffic.json: the headline set at the top level (bench.py's headline line), every config's under "configs"."""
+    import json
+    out = {"source": label, "instances_per_gpu": 10000, "kernels": {}, "configs": {}}
+    for part in parts:
+        cfg, path = part.split("=", 1)
+        with open(path) as f:
+            t = json.load(f)
+        out["configs"][cfg] = {"kernels": t["kernels"]}
+        if cfg == "tiger10k":
+            out["kernels"] = t["kernels"]
+    print(json.dumps(out, indent=1))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "trace":
+    if sys.argv[1] == "merge":
+        merge(sys.argv[2], sys.argv[3:])
+    elif sys.argv[1] == "trace":
         trace(sys.argv[2])
     elif sys.argv[1] == "traffic":
         traffic(sys.argv[2], sys.argv[3], sys.argv[4])

@@ -31,10 +31,15 @@ struct OpCmdPrefix // command instances per draw -> cmd_prefix
 	__device__ Sum3 load(uint64_t i) const
 	{
 		Sum3 r = sum3_zero();
-		const vgx_draw* d = draws + i;
-		const uint32_t p = d->path;
-		if (period && draws[i % period].path != p) { totals->inst_mismatch = 1u; } // k_flatten_build does this batch
-		const uint32_t sf = d->stroke_flags;
+		// The whole 64-byte record in 16-byte loads issued together, and the checks below as ONE expression without
+		// short-circuit evaluation: written field by field with `&&`, every field became its own load -> s_waitcnt vmcnt(0) ->
+		// branch, a chain of twelve dependent memory round trips per draw (the scan over 2.2 M draws: 0.165 -> 0.12 ms).
+		const uint4* q = (const uint4*)(draws + i);
+		const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+		const uint32_t pimg = period ? draws[i % period].path : 0u;
+		const uint32_t p = q0.x;          // path
+		const uint32_t sf = q0.w;         // stroke_flags
+		if (period && pimg != p) { totals->inst_mismatch = 1u; } // k_flatten_build does this batch
 		if (p >= npaths || ((sf & VGX_STROKE_ENABLE) && (VGX_STROKE_CAP(sf) > 2u || VGX_STROKE_JOIN(sf) > 2u))) {
 			set_status(totals, VGX_E_INVALID_ARG);
 			return r;
@@ -44,10 +49,14 @@ struct OpCmdPrefix // command instances per draw -> cmd_prefix
 		// negative scale or tolerance, a tolerance below 1e-12 of a unit -- instead of spending hours on them (the
 		// reference loops forever on NaN, path.cpp:109). Comparisons are written so that NaN fails them.
 		{
-			const float sc = d->scale, tt = d->tess_tol, fr = d->fringe, sw = d->stroke_width;
-			bool ok = sc > 0.0f && sc < 3.0e38f && tt > 0.0f && tt < 3.0e38f && fr >= 0.0f && fr < 3.0e38f && sw >= 0.0f && sw < 3.0e38f;
-			ok = ok && (tt / (sc * sc) >= 1.0e-12f);
-			for (int k = 0; k < 6; ++k) { ok = ok && (d->mtx[k] > -3.0e38f && d->mtx[k] < 3.0e38f); }
+			const float sw = __uint_as_float(q1.y), sc = __uint_as_float(q1.z), tt = __uint_as_float(q1.w), fr = __uint_as_float(q2.x);
+			const float m0 = __uint_as_float(q2.y), m1 = __uint_as_float(q2.z), m2 = __uint_as_float(q2.w);
+			const float m3 = __uint_as_float(q3.x), m4 = __uint_as_float(q3.y), m5 = __uint_as_float(q3.z);
+			const float big = 3.0e38f;
+			bool ok = (sc > 0.0f) & (sc < big) & (tt > 0.0f) & (tt < big) & (fr >= 0.0f) & (fr < big) & (sw >= 0.0f) & (sw < big);
+			ok = ok & (tt / (sc * sc) >= 1.0e-12f);
+			ok = ok & (m0 > -big) & (m0 < big) & (m1 > -big) & (m1 < big) & (m2 > -big) & (m2 < big);
+			ok = ok & (m3 > -big) & (m3 < big) & (m4 > -big) & (m4 < big) & (m5 > -big) & (m5 < big);
 			if (!ok) {
 				set_status(totals, VGX_E_NONFINITE);
 				return r;

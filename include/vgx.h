@@ -73,6 +73,12 @@ enum { VGX_JOIN_MITER = 0, VGX_JOIN_ROUND = 1, VGX_JOIN_BEVEL = 2 };
 /* vgx_draw.fill_flags */
 #define VGX_FILL_ENABLE 0x1u /* strokerConvexFill / strokerConvexFillAA per sub-path (vg.cpp:3099-3131) */
 #define VGX_FILL_AA 0x2u
+/* Index ORDER of strokerConvexFillAA meshes as the reference's default x86 build writes it (the SSE2 variant,
+ * stroker.cpp:610-701: first fringe quad, then per fan triangle the triangle followed by the next edge's fringe quad, last
+ * quad) instead of the scalar variant's (all fan triangles, then all fringe quads, stroker.cpp:769-795). Same triangles,
+ * same counts, same vertices; for callers that compare index streams with an SSE build of the reference. Positions stay
+ * the scalar build's (the SSE variant computes them with rcpps / rsqrtps approximations). */
+#define VGX_FILL_INDEX_ORDER_SSE 0x100u
 /* vgx_draw.stroke_flags */
 #define VGX_STROKE_ENABLE 0x1u
 #define VGX_STROKE_AA 0x2u

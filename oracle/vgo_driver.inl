@@ -32,6 +32,27 @@ struct VgoEngineState
 	~VgoEngineState() { VGO_ENGINE::destroyStroker(stroker); VGO_ENGINE::destroyPath(path); }
 };
 
+#ifndef VGO_REFERENCE_IS_SSE
+#define VGO_REFERENCE_IS_SSE 0 /* 1 in oracle/_ref/libvgref_sse.so: strokerConvexFillAA is the reference's SSE2 variant */
+#endif
+// Index stream of the SSE2 strokerConvexFillAA (stroker.cpp:610-701) for a polygon of n corners: the first fringe quad (:616-618),
+// per fan triangle t the triangle (0, s, s + 2) followed by the fringe quad of the next edge (s, s + 1, s + 3, s, s + 3, s + 2) with
+// s = 2 t + 2 (:622-690: four at a time from delta tables, then the remainder), the wrap-around quad (:693-699). 9 n - 6 indices.
+static void vgo_fill_aa_sse_order(uint32_t n, std::vector<uint16_t>& out)
+{
+	out.clear();
+	const uint16_t q0[6] = { 0, 1, 3, 0, 3, 2 };
+	out.insert(out.end(), q0, q0 + 6);
+	uint32_t s = 2;
+	for (uint32_t t = 0; t + 2 < n; ++t, s += 2) {
+		const uint32_t g[9] = { 0, s, s + 2, s, s + 1, s + 3, s, s + 3, s + 2 };
+		for (int k = 0; k < 9; ++k) { out.push_back((uint16_t)g[k]); }
+	}
+	const uint32_t last = (n - 1) << 1;
+	const uint32_t ql[6] = { last, last + 1, 1, last, 1, 0 };
+	for (int k = 0; k < 6; ++k) { out.push_back((uint16_t)ql[k]); }
+}
+
 static void vgoReplay(VGO_ENGINE::Path* path, const vgx_pathset_desc* ps, uint32_t pathID)
 {
 	using namespace VGO_ENGINE;
@@ -162,6 +183,16 @@ static int vgoRun(const vgx_pathset_desc* ps, const vgx_draw* draws, uint64_t nd
 					const float* vtx = &tv[sp[i].m_FirstVertexID << 1];
 					if (dr.fill_flags & VGX_FILL_AA) {
 						strokerConvexFillAA(st.stroker, &mesh, vtx, sp[i].m_NumVertices, dr.fill_color);
+#if !VGO_REFERENCE_IS_SSE
+						// VGX_FILL_INDEX_ORDER_SSE: the index order of the reference's SSE2 variant, restated (the values depend on
+						// the vertex count only). In the SSE build of oracle/_ref the reference writes this order by itself --
+						// tests/test_oracle_golden.py compares the two.
+						std::vector<uint16_t> sseIdx;
+						if (dr.fill_flags & VGX_FILL_INDEX_ORDER_SSE) {
+							vgo_fill_aa_sse_order(sp[i].m_NumVertices, sseIdx);
+							mesh.m_IndexBuffer = sseIdx.data();
+						}
+#endif
 						sink.add(mesh, dr.fill_color, (uint32_t)d, i, VGX_MESH_FILL_AA, sp[i].m_NumVertices);
 					} else {
 						strokerConvexFill(st.stroker, &mesh, vtx, sp[i].m_NumVertices);

@@ -479,3 +479,56 @@ def test_unbounded_shapes_end_as_status_not_as_a_hang(rt, gpu_ctx, wl):
     with pytest.raises(rt.VgxError) as ei:
         rt.PathSet(gpu_ctx, b.arrays())
     assert ei.value.status == rt.capi.VGX_E_INVALID_ARG
+
+
+@pytest.mark.parametrize("seed", [300, 301, 302])
+def test_sse_index_order_option(rt, gpu_ctx, wl, oracle, seed):
+    """VGX_FILL_INDEX_ORDER_SSE on every AA fill: the index stream is the one the reference's SSE2 strokerConvexFillAA writes
+    (stroker.cpp:610-701; the oracle's restated order is pinned against that build in tests/test_oracle_golden.py), everything
+    else is the scalar build's -- through the two-phase entry, the asynchronous one, the instanced kernel (tiger instances) and
+    with draw-command assembly armed (the index base is added to the reordered values as well)."""
+    import torch
+    flag = np.uint32(rt.capi.FILL_INDEX_ORDER_SSE)
+    if seed == 300:
+        ps, d = wl.tiger(40)       # > 2048 draws: k_flatten_inst + the large-batch launch sequence
+    else:
+        ps = wl.fuzz_paths(seed, npaths=96)
+        d = wl.fuzz_draws(ps, seed)
+    d = d.copy()
+    half = np.arange(d.shape[0]) % 2 == 0
+    d["fill_flags"][half] |= flag  # mixed: meshes with and without the option in one batch
+    ref = oracle.tessellate(ps, d)
+    assert not np.array_equal(ref.idx, oracle.tessellate(ps, wl_without(d, flag)).idx)
+    got = _run_mesh(rt, gpu_ctx, ps, d)
+    assert_mesh_equal(got, ref, "sse order, two-phase, seed=%d" % seed)
+    pset = rt.PathSet(gpu_ctx, ps)
+    dd = rt.upload_draws(d)
+    sizes = rt.tessellate_count(gpu_ctx, pset, dd, d.shape[0])
+    nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
+    bufs = rt.MeshBuffers(dd.device, nv, ni, nm)
+    rt.tessellate_async(gpu_ctx, pset, dd, d.shape[0], bufs)
+    torch.cuda.synchronize()
+    assert int(bufs.dev_status.item()) == 0
+    assert np.array_equal(bufs.idx[:ni].cpu().numpy().view(np.uint16), ref.idx)
+    assert np.array_equal(bufs.pos[:nv].cpu().numpy().view(np.uint32), ref.pos.view(np.uint32))
+    # assembly armed: the rebased index buffer of the oracle's assembler over the reordered meshes
+    max_vb = int(max(700, ref.meshes["num_vertices"].max()))  # a mesh larger than a vertex buffer is an error of its own
+    st, rcmds, ridx = oracle.assemble(ref.meshes, ref.idx, max_vb)
+    assert st == 0
+    cmds = torch.zeros((2 * (nv // max_vb) + 2) * 48, dtype=torch.uint8, device=dd.device)
+    ncmd = torch.zeros(1, dtype=torch.int64, device=dd.device)
+    gpu_ctx.set_assembly(cmds, max_vb, ncmd)
+    try:
+        rt.tessellate_async(gpu_ctx, pset, dd, d.shape[0], bufs)
+        torch.cuda.synchronize()
+    finally:
+        gpu_ctx.set_assembly(None)
+    assert int(ncmd.item()) == len(rcmds)
+    assert np.array_equal(bufs.idx[:ni].cpu().numpy().view(np.uint16), ridx)
+    pset.close()
+
+
+def wl_without(d, flag):
+    e = d.copy()
+    e["fill_flags"] &= ~flag
+    return e

@@ -82,3 +82,34 @@ def test_sse_reference_differs_only_where_documented(wl, oracle):
     b = oracle.tessellate(ps, d, kind="reference_sse")
     assert a.sizes == b.sizes
     assert not np.array_equal(a.idx, b.idx)
+
+
+@pytest.mark.parametrize("seed", [40, 41, 42])
+def test_sse_index_order_option_is_the_sse_build_s_order(wl, oracle, seed):
+    """VGX_FILL_INDEX_ORDER_SSE: the scalar reference build + the driver's restated order (oracle/vgo_driver.inl,
+    vgo_fill_aa_sse_order) and the port give exactly the index stream the reference's SSE2 strokerConvexFillAA writes by itself
+    (oracle/_ref/libvgref_sse.so, stroker.cpp:610-701) -- for every mesh of the fuzz drawings and of the tiger; positions,
+    colours and mesh tables stay those of the scalar build."""
+    if not (oracle.available("reference") and oracle.available("reference_sse")):
+        pytest.skip("oracle/_ref not built")
+    import importlib
+    capi = importlib.import_module("vg-renderer_amd.capi")
+    if seed == 40:
+        ps, d = wl.tiger(2)
+    else:
+        ps = wl.fuzz_paths(seed, npaths=64)
+        d = wl.fuzz_draws(ps, seed)
+    plain = oracle.tessellate(ps, d, kind="reference")
+    sse = oracle.tessellate(ps, d, kind="reference_sse")
+    d2 = d.copy()
+    d2["fill_flags"] |= np.uint32(capi.FILL_INDEX_ORDER_SSE)
+    for kind in ("reference", "port"):
+        got = oracle.tessellate(ps, d2, kind=kind)
+        assert got.sizes == plain.sizes
+        assert np.array_equal(got.idx, sse.idx), kind                   # the SSE build's order ...
+        assert np.array_equal(got.pos.view(np.uint32), plain.pos.view(np.uint32)), kind  # ... on the scalar build's vertices
+        assert np.array_equal(got.color, plain.color) and np.array_equal(got.meshes, plain.meshes), kind
+    # the SSE build itself ignores the flag (it has one order)
+    assert np.array_equal(oracle.tessellate(ps, d2, kind="reference_sse").idx, sse.idx)
+    has_aa_fill = bool(((d["fill_flags"] & 3) == 3).any())
+    assert has_aa_fill and not np.array_equal(plain.idx, sse.idx)

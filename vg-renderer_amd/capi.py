@@ -27,6 +27,7 @@ CAP_BUTT, CAP_ROUND, CAP_SQUARE = 0, 1, 2
 JOIN_MITER, JOIN_ROUND, JOIN_BEVEL = 0, 1, 2
 
 FILL_ENABLE, FILL_AA = 0x1, 0x2
+FILL_INDEX_ORDER_SSE = 0x100  # strokerConvexFillAA indices in the order of the reference's SSE2 variant (stroker.cpp:610-701)
 STROKE_ENABLE, STROKE_AA, STROKE_THIN = 0x1, 0x2, 0x4
 
 MESH_FILL, MESH_FILL_AA, MESH_STROKE, MESH_STROKE_AA, MESH_STROKE_AA_THIN, MESH_CONCAVE_FILL_AA = 0, 1, 2, 3, 4, 5

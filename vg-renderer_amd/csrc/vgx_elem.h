@@ -787,7 +787,7 @@ __device__ __forceinline__ void round_mesh_size(MeshCtxT<VS> mc, int lane, uint3
 // computes and stores, a wave keeps two vertex loads outstanding instead of one).
 struct FillFetch
 {
-	bool valid, aaElem, nextInWave, prevInWave;
+	bool valid, aaElem, nextInWave, prevInWave, sseOrder;
 	uint32_t j, N, color, ibase;
 	float aa;
 	uint64_t firstV, firstI, mi;
@@ -858,6 +858,19 @@ __device__ __forceinline__ void fill_emit_chunk(float* pos, uint32_t* color_out,
 				val[3 * g] = ((isFan ? 0u : fb) + F.ibase) & 0xFFFFu;
 				val[3 * g + 1] = ((isFan ? 2 * T + 2 : (second ? nextOuter : fb + 1)) + F.ibase) & 0xFFFFu;
 				val[3 * g + 2] = ((isFan ? 2 * T + 4 : (second ? nextInner : nextOuter)) + F.ibase) & 0xFFFFu;
+			}
+			if (F.sseOrder) {
+				// VGX_FILL_INDEX_ORDER_SSE (stroker.cpp:610-701): [quad 0] then per fan triangle t {(0, s, s+2), quad of edge t+1 =
+				// (s, s+1, s+3, s, s+3, s+2)} with s = 2t+2, then the wrap-around quad (L, L+1, 1, L, 1, 0), L = 2N-2. Positions
+				// [9j, 9j+9) are therefore: the quad of edge j, then fan triangle j -- or, for the last two corners, the halves of
+				// the wrap-around quad.
+				const uint32_t b = 2 * j;
+				const bool lastFan = j + 2 >= N; // corner N-2: its three trailing positions start the wrap-around quad
+				val[0] = b; val[1] = b + 1; val[2] = b + 3; val[3] = b; val[4] = b + 3; val[5] = b + 2;
+				val[6] = lastFan ? b + 2 : 0u; val[7] = lastFan ? b + 3 : b + 2; val[8] = lastFan ? 1u : b + 4;
+				if (j + 1 == N) { val[0] = b; val[1] = 1u; val[2] = 0u; } // corner N-1: (L, 1, 0)
+#pragma unroll
+				for (uint32_t g = 0; g < 9; ++g) { val[g] = (val[g] + F.ibase) & 0xFFFFu; }
 			}
 #endif
 			uint16_t* pi = idx_out + F.firstI + k9;

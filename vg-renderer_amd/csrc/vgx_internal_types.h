@@ -66,8 +66,9 @@ struct VgxMeshDesc
 	uint32_t poly_n;
 	uint32_t draw;
 	uint32_t subpath;    // sub-path index within the draw
-	uint32_t kind;       // bits 0-7 VGX_MESH_*, bit 8 closed, bits 9-10 effective cap, bits 11-12 effective join
+	uint32_t kind;       // bits 0-7 VGX_MESH_*, bit 8 closed, bits 9-10 effective cap, bits 11-12 effective join, bit 13 SSE index order (FILL_AA)
 };
+#define VGX_MD_SSE_ORDER(k) (((k) >> 13) & 1u)
 #define VGX_MD_KIND(k) ((k) & 0xFFu)
 #define VGX_MD_CLOSED(k) (((k) >> 8) & 1u)
 #define VGX_MD_CAP(k) (((k) >> 9) & 3u)

@@ -33,6 +33,7 @@ VGX_HD bool vgx_write_mesh(VgxMeshDesc* mdesc, vgx_mesh* mtab, uint64_t meshInde
 		}
 	} else {
 		vgx_mesh_closed_form(kind, closed, 0, 0, n, 2, &nv, &ni);
+		if (kind == VGX_MESH_FILL_AA && (dr->fill_flags & VGX_FILL_INDEX_ORDER_SSE)) { m.kind |= 1u << 13; }
 		if (mprep) {
 			VgxMeshPrep pr;
 			pr.f0 = 0.0f; pr.f1 = 0.0f; pr.f2 = dr->fringe; pr.color = dr->fill_color;

@@ -89,7 +89,7 @@ struct __attribute__((aligned(16))) FillRec // 48 bytes, one per mesh of the win
 	uint32_t N, kind, color;
 	float aa;
 	uint32_t ibase;    // assembly: vertices in front of the mesh inside its vertex buffer (0 when not armed)
-	uint32_t pad;
+	uint32_t pad;      // 1: VGX_FILL_INDEX_ORDER_SSE
 };
 
 struct FillWindow
@@ -110,7 +110,7 @@ __device__ __forceinline__ void fill_window_load(const VgxStrokeArgs& A, FillWin
 	if (idx < numMeshes) {
 		const VgxMeshDesc md = A.mdesc[idx];
 		const VgxMeshPrep pr = A.mprep[idx];
-		r.polyFirst = md.poly_first; r.N = md.poly_n; r.kind = VGX_MD_KIND(md.kind);
+		r.polyFirst = md.poly_first; r.N = md.poly_n; r.kind = VGX_MD_KIND(md.kind); r.pad = VGX_MD_SSE_ORDER(md.kind);
 		r.color = pr.color; r.aa = pr.f0;
 		r.firstV = A.mtab[idx].first_vertex;
 		r.firstI = A.mtab[idx].first_index;
@@ -172,6 +172,7 @@ __device__ __forceinline__ void fill_emit_ring(const VgxStrokeArgs& A, const Fil
 	F.N = r.N;
 	F.color = r.color; F.aa = r.aa; F.firstV = r.firstV; F.firstI = r.firstI; F.ibase = r.ibase; F.mi = 0;
 	F.aaElem = F.valid && r.kind == VGX_MESH_FILL_AA;
+	F.sseOrder = r.pad != 0;
 	const uint32_t e = (uint32_t)i * VGX_WAVE + (uint32_t)lane; // my element, relative to the run
 	const uint64_t ei = run0 + e;
 	F.prevInWave = lane > 0 && F.j > 0;
@@ -204,7 +205,7 @@ __device__ __forceinline__ uint64_t fill_chunk_slow(const VgxStrokeArgs& A, uint
 	const uint64_t ei = chunk + (uint64_t)lane;
 	const bool valid = ei < elemEnd;
 	F.valid = valid; F.j = 0; F.N = 3; F.color = 0; F.aa = 0.0f; F.firstV = 0; F.firstI = 0; F.ibase = 0; F.mi = mlo;
-	F.aaElem = false; F.prevInWave = false; F.nextInWave = false;
+	F.aaElem = false; F.prevInWave = false; F.nextInWave = false; F.sseOrder = false;
 	F.p1 = v2(0.0f, 0.0f); F.pNextB = F.p1; F.pPrevB = F.p1;
 	if (valid) {
 		const uint64_t mi = find_owner_u64(A.elem_prefix, mlo, numMeshes, ei);
@@ -216,6 +217,7 @@ __device__ __forceinline__ uint64_t fill_chunk_slow(const VgxStrokeArgs& A, uint
 		F.firstV = A.mtab[mi].first_vertex; F.firstI = A.mtab[mi].first_index;
 		F.ibase = A.mesh_base ? A.mesh_base[mi] : 0u;
 		F.aaElem = VGX_MD_KIND(md.kind) == VGX_MESH_FILL_AA;
+		F.sseOrder = VGX_MD_SSE_ORDER(md.kind) != 0;
 		const float* vtx = A.poly + 2 * md.poly_first;
 		F.p1 = ldv(vtx, F.j);
 		if (F.aaElem) { // no neighbour shortcuts here: both loads, always

@@ -928,7 +928,8 @@ int vgx_pathset_destroy(vgx_ctx* ctx, vgx_pathset* ps)
 }
 
 // ---- flatten ------------------------------------------------------------------------------------------
-static int flattenCountCommon(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, hipStream_t s)
+// detectInst: look for reused paths (instanced flatten kernel of vgx_tessellate); the flatten-only entry points have no use for it
+static int flattenCountCommon(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, hipStream_t s, bool detectInst)
 {
 	int st;
 	if ((st = ensureDrawBuffers(ctx, ndraws)) != VGX_OK) { return st; }
@@ -936,7 +937,7 @@ static int flattenCountCommon(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_dra
 	ctx->caps.cmd_instances = ~0ull; // not known yet: never trips the check in this sizing pass
 	ctx->instPeriod = 0; ctx->instGrouped = 0; ctx->instClasses = 1;
 	runCmdPrefix(ctx, ps, draws, ndraws, s);
-	if (ctx->optInst && ndraws > VGX_SMALL_DRAWS) {
+	if (detectInst && ctx->optInst && ndraws > VGX_SMALL_DRAWS) {
 		vgx_launch_inst_detect(draws, ndraws, (VgxTotals*)ctx->totals.p, s);
 		// ... and how many different paths the draws use (grouped mode, when the sequence does not repeat)
 		if ((st = ensureInstGroup(ctx, ps->dev.npaths, 1, ndraws, false)) != VGX_OK) { return st; }
@@ -992,7 +993,7 @@ int vgx_flatten_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws
 	hipStream_t s = (hipStream_t)stream;
 	markBegin(ctx, s);
 	ctx->lastStage = 0;
-	const int st = flattenCountCommon(ctx, ps, draws, ndraws, s);
+	const int st = flattenCountCommon(ctx, ps, draws, ndraws, s, false);
 	if (st != VGX_OK) { return st; }
 	*out_sizes = ctx->hostTotals->sizes;
 	out_sizes->num_vertices = 0;
@@ -1044,7 +1045,7 @@ int vgx_tessellate_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* dr
 	hipStream_t s = (hipStream_t)stream;
 	markBegin(ctx, s);
 	ctx->lastStage = 0;
-	int st = flattenCountCommon(ctx, ps, draws, ndraws, s);
+	int st = flattenCountCommon(ctx, ps, draws, ndraws, s, true);
 	if (st != VGX_OK) { return st; }
 	const vgx_sizes sz = ctx->hostTotals->sizes;
 	// Polyline scratch doubles as the heap of the single-pass path (k_flatten_build). Its waves switch to a fresh block

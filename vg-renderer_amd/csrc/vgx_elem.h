@@ -750,6 +750,126 @@ __device__ __forceinline__ void stroke_chunk(bool valid, bool laneHasNext, int n
 	carry.rails = lastIsMeshLast ? 0ull : endRails;
 }
 
+// The same chunk when every element in it belongs to a CLOSED stroke with MITER joins, AA (4 rails) or Thin (3 rails) --
+// e.g. every stroke of the tiger: each element is one join with R vertices at R j and, from the second element on, one
+// bridge of 6 (R - 1) indices at 6 (R - 1) (j - 1); the last element adds the closing bridge (stroker.cpp:1524-1579,
+// 1970-1984; thin :2060-2110, 2295-2306). Nothing is data dependent, so steps B (segmented scans of the counts) and the
+// register stage of step D fall away: positions, colours and indices are computed and stored directly, same values and
+// same addresses as stroke_chunk (which handles a chunk as soon as one of its elements is anything else; the carry
+// both maintain makes the two interchangeable chunk by chunk). 568 -> ~250 VALU instructions per chunk on the tiger.
+__device__ __forceinline__ bool stroke_elem_is_simple(uint32_t kind, bool closed, uint32_t join)
+{
+	return closed && join == VGX_JOIN_MITER && (kind == VGX_MESH_STROKE_AA || kind == VGX_MESH_STROKE_AA_THIN);
+}
+
+template<class VS>
+__device__ __forceinline__ void stroke_chunk_simple(bool valid, bool laneHasNext, int nvalid, int lane, const MeshCtxT<VS>& mc, uint32_t color,
+	float* posMesh, uint32_t* colMesh, uint16_t* idxMesh, uint32_t idxBase, StrokeCarry& carry)
+{
+	// step A, as in stroke_chunk
+	V2 p1 = v2(0.0f, 0.0f);
+	if (valid) { p1 = mc.vtx.ld(mc.j); }
+	const bool prevInWave = lane > 0 && mc.j > 0;
+	const bool nextInWave = laneHasNext && mc.j + 1 < mc.N;
+	V2 pNext;
+	pNext.x = wave_from_next(p1.x, 0.0f); pNext.y = wave_from_next(p1.y, 0.0f);
+	if (valid && !nextInWave) { pNext = mc.vtx.ld(mc.j + 1 < mc.N ? mc.j + 1 : 0); }
+	V2 d12 = v2(0.0f, 0.0f);
+	if (valid) { d12 = v2dir(p1, pNext); }
+	V2 dPrev;
+	dPrev.x = wave_from_prev(d12.x, 0.0f); dPrev.y = wave_from_prev(d12.y, 0.0f);
+	if (valid && !prevInWave) { dPrev = v2dir(mc.vtx.ld(mc.j > 0 ? mc.j - 1 : mc.N - 1), p1); }
+
+	const bool thin = mc.kind == VGX_MESH_STROKE_AA_THIN;
+	const uint32_t R = thin ? 3u : 4u;
+	const uint32_t bridgeIdx = thin ? 12u : 18u;
+	const float sideWidth = thin ? mc.fringe : mc.hswAA; // elem_geometry
+	const VgxJoin jn = vgx_join_dirs(dPrev, d12, sideWidth);
+	const bool L = jn.leftInner;
+	const uint32_t N = mc.N, j = mc.j;
+	const uint32_t b = R * j;
+	// entry = exit rails of a Miter join (elem_exit_rails)
+	const uint32_t top = b + R - 1;
+	const Rails mine = thin ? (L ? rails(b, b + 1, b + 2, 0) : rails(top, b + 1, b, 0)) : (L ? rails(b, b + 1, b + 2, b + 3) : rails(top, b + 2, b + 1, b));
+	const uint64_t myExit = valid ? rails_pack(mine) : 0ull;
+	const uint64_t prevPacked = (uint64_t)wave_from_prev_u32((uint32_t)myExit, (uint32_t)carry.rails) | ((uint64_t)wave_from_prev_u32((uint32_t)(myExit >> 32), (uint32_t)(carry.rails >> 32)) << 32);
+
+	const bool meshLast = valid && (j == N - 1);
+	if (valid) {
+		const uint32_t c0 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
+		float* pp = posMesh + 2 * (size_t)b;
+		uint32_t* pc = colMesh + b;
+		if (thin) { // stroker.cpp:2060-2110
+			const V2 vf = v2mul(jn.v, mc.fringe);
+			const V2 q0 = L ? v2add(p1, vf) : v2sub(p1, vf);
+			const V2 q2 = L ? v2sub(p1, vf) : v2add(p1, vf);
+			PosPair q; q.x0 = q0.x; q.y0 = q0.y; q.x1 = p1.x; q.y1 = p1.y;
+			*(PosPair*)pp = q;
+			*(float2*)(pp + 4) = make_float2(q2.x, q2.y);
+			ColPair c; c.c0 = c0; c.c1 = color;
+			*(ColPair*)pc = c;
+			pc[2] = c0;
+		} else { // :1524-1579
+			const V2 vhaa = v2mul(jn.v, mc.hswAA);
+			const V2 vh = v2mul(jn.v, mc.hsw);
+			const V2 q0 = L ? v2add(p1, vhaa) : v2sub(p1, vhaa);
+			const V2 q1 = L ? v2add(p1, vh) : v2sub(p1, vh);
+			const V2 q2 = L ? v2sub(p1, vh) : v2add(p1, vh);
+			const V2 q3 = L ? v2sub(p1, vhaa) : v2add(p1, vhaa);
+			PosPair q; q.x0 = q0.x; q.y0 = q0.y; q.x1 = q1.x; q.y1 = q1.y;
+			*(PosPair*)pp = q;
+			PosPair r; r.x0 = q2.x; r.y0 = q2.y; r.x1 = q3.x; r.y1 = q3.y;
+			*(PosPair*)(pp + 4) = r;
+			ColPair c; c.c0 = c0; c.c1 = color;
+			*(ColPair*)pc = c;
+			ColPair d; d.c0 = color; d.c1 = c0;
+			*(ColPair*)(pc + 2) = d;
+		}
+		const uint32_t ib = idxBase;
+		if (j > 0) { // the bridge from the previous join (bridge4 / bridge3 of the writer)
+			const Rails p = rails_unpack(prevPacked);
+			const uint32_t pa = p.a + ib, pb = p.b + ib, pcc = p.c + ib, pd = p.d + ib;
+			const uint32_t ca = mine.a + ib, cb = mine.b + ib, cc = mine.c + ib, cd = mine.d + ib;
+			uint16_t* pi = idxMesh + (size_t)bridgeIdx * (j - 1);
+			Idx6 t0; t0.a = (pa & 0xFFFFu) | (pb << 16); t0.b = (cb & 0xFFFFu) | (pa << 16); t0.c = (cb & 0xFFFFu) | (ca << 16);
+			Idx6 t1; t1.a = (pb & 0xFFFFu) | (pcc << 16); t1.b = (cc & 0xFFFFu) | (pb << 16); t1.c = (cc & 0xFFFFu) | (cb << 16);
+			*(Idx6*)pi = t0;
+			*(Idx6*)(pi + 6) = t1;
+			if (!thin) {
+				Idx6 t2; t2.a = (pcc & 0xFFFFu) | (pd << 16); t2.b = (cd & 0xFFFFu) | (pcc << 16); t2.c = (cd & 0xFFFFu) | (cc << 16);
+				*(Idx6*)(pi + 12) = t2;
+			}
+		}
+		if (meshLast) { // closing bridge to join 0 (:1970-1984, 2295-2306); d12 = vec2Dir(last vertex, vertex 0) already
+			const V2 v0 = pNext;
+			const V2 v1 = mc.vtx.ld(N > 1 ? 1 : 0);
+			const VgxJoin j0 = vgx_join_dirs(d12, v2dir(v0, v1), sideWidth);
+			const Rails f = thin ? (j0.leftInner ? rails(0, 1, 2, 0) : rails(2, 1, 0, 0)) : (j0.leftInner ? rails(0, 1, 2, 3) : rails(3, 2, 1, 0));
+			const uint32_t pa = mine.a + ib, pb = mine.b + ib, pcc = mine.c + ib, pd = mine.d + ib;
+			const uint32_t ca = f.a + ib, cb = f.b + ib, cc = f.c + ib, cd = f.d + ib;
+			uint16_t* pi = idxMesh + (size_t)bridgeIdx * (N - 1);
+			Idx6 t0; t0.a = (pa & 0xFFFFu) | (pb << 16); t0.b = (cb & 0xFFFFu) | (pa << 16); t0.c = (cb & 0xFFFFu) | (ca << 16);
+			Idx6 t1; t1.a = (pb & 0xFFFFu) | (pcc << 16); t1.b = (cc & 0xFFFFu) | (pb << 16); t1.c = (cc & 0xFFFFu) | (cb << 16);
+			*(Idx6*)pi = t0;
+			*(Idx6*)(pi + 6) = t1;
+			if (!thin) {
+				Idx6 t2; t2.a = (pcc & 0xFFFFu) | (pd << 16); t2.b = (cd & 0xFFFFu) | (pcc << 16); t2.c = (cd & 0xFFFFu) | (cc << 16);
+				*(Idx6*)(pi + 12) = t2;
+			}
+		}
+	}
+
+	// carries, in stroke_chunk's terms: vertices / indices of the mesh written so far, exit rails of the last element
+	const int Lz = nvalid - 1;
+	const int lastIsMeshLast = wave_bcast((int)meshLast, Lz);
+	const uint32_t endV = wave_read_u32(b + R, Lz);
+	const uint32_t endI = wave_read_u32(bridgeIdx * j, Lz);
+	const uint64_t endRails = wave_bcast_u64(myExit, Lz);
+	carry.v = lastIsMeshLast ? 0u : endV;
+	carry.i = lastIsMeshLast ? 0u : endI;
+	carry.rails = lastIsMeshLast ? 0ull : endRails;
+}
+
 // Vertex / index counts of a whole stroke mesh with Round joins (the only data-dependent sizes, numArcPoints per join,
 // stroker.cpp:1146, 1592): the wave's lanes stride over the mesh's elements and sum what stroke_chunk will emit for
 // each. 64-bit sums, saturated: a hostile draw (arc counts saturate at 131072 per join) cannot wrap back into range.

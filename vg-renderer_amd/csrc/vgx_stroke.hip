@@ -461,7 +461,16 @@ __device__ __forceinline__ void stroke_range(const VgxStrokeArgs& A, StrokeRec* 
 		}
 		const int nvalid = (int)((E1 - chunk) < (uint64_t)VGX_WAVE ? (E1 - chunk) : (uint64_t)VGX_WAVE);
 		const int Lz = nvalid - 1;
+#ifndef VGX_EXP_NO_SIMPLE_STROKE
+		if (wave_ballot(valid && !stroke_elem_is_simple(mc.kind, mc.closed, mc.join)) == 0) { // wave-uniform: closed Miter AA / Thin strokes only
+			stroke_chunk_simple(valid, lane < VGX_WAVE - 1 && ei + 1 < E1, nvalid, lane, mc, color, A.pos + 2 * firstV, A.color + firstV, A.idx + firstI, idxBase, carry);
+		} else
+#endif
+#ifndef VGX_EXP_ONLY_SIMPLE_STROKE /* tuning experiment: the kernel without the general element code (wrong for anything but closed Miter strokes) */
 		stroke_chunk(valid, lane < VGX_WAVE - 1 && ei + 1 < E1, nvalid, lane, mc, color, A.pos + 2 * firstV, A.color + firstV, A.idx + firstI, idxBase, carry);
+#else
+		{ }
+#endif
 		mcur = wave_bcast_u64(mi, Lz);
 	}
 }

@@ -697,13 +697,16 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 __device__ __forceinline__ void flatten_gather_body(const VgxFlattenArgs& A, uint64_t tid, uint64_t nthreads)
 {
 	const VgxPathSetDev& ps = A.ps;
+	const uint64_t P = A.inst_period;
+	const bool periodic = A.inst_order == nullptr && P != 0 && A.totals->inst_mismatch == 0u; // k_flatten_inst built the batch, OpCmdPrefix::apply_size
 	for (uint64_t d = tid; d < A.ndraws; d += nthreads) {
 		const vgx_draw_info di = A.dinfo[d];
 		if ((di.flags & 1u) || di.num_meshes == 0) { continue; }
 		const vgx_draw* dr = A.draws + d;
 		const uint32_t path = dr->path;
 		const uint32_t sb0 = ps.path_sub_begin[path], sb1 = ps.path_sub_begin[path + 1];
-		const uint64_t cbase = A.sub_prefix[d]; // both flatten kernels store record j of draw d at sub_prefix[d] + j
+		// both flatten kernels store record j of draw d at sub_prefix[d] + j; periodic batches keep the first period's prefixes only
+		const uint64_t cbase = periodic ? (d / P) * A.sub_prefix[P] + A.sub_prefix[d % P] : A.sub_prefix[d];
 		const uint32_t fillFlags = dr->fill_flags, strokeFlags = dr->stroke_flags;
 		const uint32_t numFill = di.flags >> 1;
 		uint32_t f = 0, s = 0, subIndex = 0;

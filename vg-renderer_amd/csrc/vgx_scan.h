@@ -11,11 +11,15 @@
 //   Sum3     load(uint64_t i) const;       // up to four uint64 fields per item
 //   void     store(uint64_t i, Sum3 excl); // exclusive prefix for item i
 //   void     finish(Sum3 total);           // called once by one thread with the grand total
+//   uint64_t apply_size() const;           // OPTIONAL: only the prefixes of items [0, apply_size()) are needed (<= size());
+//                                          // evaluated in the third pass, i.e. it may depend on what load() found in the first
 #ifndef VGX_SCAN_H
 #define VGX_SCAN_H
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
+#include <utility>
 
 #define VGX_SCAN_BLOCKS 512
 #define VGX_SCAN_THREADS 256
@@ -110,12 +114,24 @@ __global__ __launch_bounds__(VGX_SCAN_BLOCKS) void k_scan_partials(OP op, Sum3* 
 	if (threadIdx.x == 0) { op.finish(tot); }
 }
 
+template<class OP, class = void>
+struct ScanApplyLimit { static __device__ __forceinline__ uint64_t get(const OP&, uint64_t n) { return n; } };
+template<class OP>
+struct ScanApplyLimit<OP, std::void_t<decltype(std::declval<const OP&>().apply_size())>>
+{
+	static __device__ __forceinline__ uint64_t get(const OP& op, uint64_t n) { const uint64_t a = op.apply_size(); return a < n ? a : n; }
+};
+
 template<class OP>
 __global__ __launch_bounds__(VGX_SCAN_THREADS) void k_scan_apply(OP op, const Sum3* partial)
 {
 	__shared__ Sum3 s_wave[VGX_SCAN_THREADS / 64];
 	uint64_t lo, hi;
-	scan_slice(op.size(), &lo, &hi);
+	const uint64_t n = op.size();
+	scan_slice(n, &lo, &hi);
+	const uint64_t lim = ScanApplyLimit<OP>::get(op, n); // block-uniform
+	if (lo >= lim) { return; }
+	if (hi > lim) { hi = lim; }
 	Sum3 carry = partial[blockIdx.x];
 	for (uint64_t base = lo; base < hi; base += VGX_SCAN_THREADS) {
 		const uint64_t i = base + threadIdx.x;

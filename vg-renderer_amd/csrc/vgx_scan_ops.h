@@ -67,6 +67,9 @@ struct OpCmdPrefix // command instances per draw -> cmd_prefix
 		return r;
 	}
 	__device__ void store(uint64_t i, Sum3 e) const { prefix[i] = e.a; subPrefix[i] = e.b; }
+	// A periodic batch that passed the check needs the prefixes of its first period only (+ entry `period` = the sums over one
+	// period): k_flatten_inst and k_flatten_gather derive every other draw's in closed form (vgx_sub_prefix_at).
+	__device__ uint64_t apply_size() const { return (period && totals->inst_mismatch == 0u) ? (uint64_t)period + 1 : ndraws; }
 	__device__ void finish(Sum3 t) const
 	{
 		prefix[ndraws] = t.a;

@@ -1,17 +1,22 @@
 """GPU soak of the instanced flatten kernel (not collected by pytest): N fuzz drawings x 33..96 instances with per-instance
-scale / tolerance / flags through vgx_tessellate against the reference oracle, on a default context and on one with
-8-vertex lane blocks and 7 waves (the knobs are read at vgx_create). `python tests/soak_gpu_inst.py 300`."""
+scale / tolerance / flags through vgx_tessellate against the reference oracle, on a default context, on one with
+8-vertex lane blocks and 7 waves and on one with 4 tolerance classes (the knobs are read at vgx_create). Per seed: one
+scale for all instances / a few discrete scales / a scale of its own per instance (tolerance classes), draws in order or
+shuffled (grouped mode), VGX_FILL_INDEX_ORDER_SSE on a random half of the draws. `python tests/soak_gpu_inst.py 300`."""
 import importlib, sys, os, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 import pyoracle
 from util import assert_mesh_equal
-from test_gpu_inst import _instances
+from test_gpu_inst import _instances, _continuous_scales
 rt = importlib.import_module("vg-renderer_amd.runtime"); wl = importlib.import_module("vg-renderer_amd.workloads")
 ctx_default = rt.Context(0)
 os.environ["VGX_INST_BLOCK"] = "8"; os.environ["VGX_INST_WAVES"] = "7"
 ctx_small = rt.Context(0)
 os.environ.pop("VGX_INST_BLOCK"); os.environ.pop("VGX_INST_WAVES")
+os.environ["VGX_INST_CLASSES"] = "4"
+ctx_classes = rt.Context(0)
+os.environ.pop("VGX_INST_CLASSES")
 bad = 0
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 for seed in range(5000, 5000 + n):
@@ -21,8 +26,12 @@ for seed in range(5000, 5000 + n):
     ninst = int(rs.randint(33, 97))
     while ninst * npaths <= 2048:
         ninst += 17
-    d = _instances(wl, ps, seed, ninst, vary=bool(seed % 5))
-    ctx = ctx_small if seed % 3 == 0 else ctx_default
+    mode = seed % 5
+    d = _continuous_scales(wl, ps, seed, ninst) if mode in (1, 3) else _instances(wl, ps, seed, ninst, vary=bool(mode))
+    if seed % 4 == 1:
+        d = d[rs.permutation(d.shape[0])]
+    d["fill_flags"][rs.uniform(size=d.shape[0]) < 0.5] |= np.uint32(rt.capi.FILL_INDEX_ORDER_SSE)
+    ctx = ctx_small if seed % 3 == 0 else (ctx_classes if seed % 3 == 1 else ctx_default)
     ref = pyoracle.tessellate(ps, d)
     pset = rt.PathSet(ctx, ps); dd = rt.upload_draws(d)
     sizes = rt.tessellate_count(ctx, pset, dd, d.shape[0])

@@ -451,6 +451,17 @@ typedef struct vgx_failure_info {
 } vgx_failure_info;
 int vgx_get_failure_info(vgx_ctx* ctx, vgx_failure_info* out, void* stream);
 
+/* ---- multi-GPU: partition of a batch into contiguous draw ranges of about equal predicted output ----------------
+ * "Partitioning: contiguous ranges of path instances per GPU ...; for heterogeneous batches balance on the count-pass result
+ * (predicted out-verts)". Runs the flatten count pass over the whole batch (per-draw polyline vertex counts; no output buffers,
+ * no mesh scratch), weights every draw with polyline vertices x output vertices per polyline vertex of its fill / stroke
+ * flavour (+ 1), and cuts the draw sequence where the weight prefix crosses k / nparts of the total:
+ *   out_bounds[0] = 0 <= out_bounds[1] <= ... <= out_bounds[nparts] = ndraws   (HOST, nparts + 1 entries)
+ *   out_weights[k] = predicted weight of part k (HOST, nparts entries; may be NULL)
+ * Rank r then tessellates draws [out_bounds[r], out_bounds[r + 1]); rank order = draw order, so the gathered streams are the
+ * single-GPU result. Homogeneous batches (Tiger x K) come out as equal instance counts. Synchronises the stream. */
+int vgx_partition(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, uint32_t nparts, uint64_t* out_bounds, uint64_t* out_weights, void* stream);
+
 /* ---- multi-GPU: gather of the per-rank streams to one root over RCCL / xGMI ---------------------------------
  * Independent path instances shard embarrassingly: one process per GPU, rank r tessellates a contiguous range of the
  * draws, no data-path collective. Indices are mesh-local, so the single-GPU result is the per-rank streams concatenated

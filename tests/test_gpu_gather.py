@@ -7,6 +7,7 @@ The real multi-GPU transfer is only exercised by the driver's N-GPU bench (bench
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -63,3 +64,72 @@ def test_gather_eight_ranks_into_a_70_gb_destination(binaries):
     exe, fake = binaries
     out = subprocess.check_output([exe, "big", fake, "8", "8.75"], text=True, timeout=900)
     assert "blocks identical, mesh records rebased" in out and "MISMATCH" not in out, out
+
+
+def _expected_partition(oracle, ps, d, nparts):
+    """The bounds vgx_partition must produce, from the reference's own per-draw polyline counts (include/vgx.h)."""
+    import importlib
+    capi = importlib.import_module("vg-renderer_amd.capi")
+    di = oracle.flatten(ps, d).draw_info
+    ff, sf = d["fill_flags"].astype(np.uint64), d["stroke_flags"].astype(np.uint64)
+    f = np.where(ff & 1, np.where(ff & 2, 2, 1), 0) + np.where(sf & 1, np.where((sf & capi.STROKE_AA) == 0, 2, np.where(sf & capi.STROKE_THIN, 3, 4)), 0)
+    w = di["num_poly_vertices"].astype(np.uint64) * f.astype(np.uint64) + 1
+    prefix = np.concatenate([[0], np.cumsum(w)]).astype(np.uint64)
+    total = int(prefix[-1])
+    bounds = [int(np.searchsorted(prefix[:-1], (total * k) // nparts, side="left")) for k in range(nparts)] + [d.shape[0]]
+    weights = [int(prefix[bounds[k + 1]] - prefix[bounds[k]]) for k in range(nparts)]
+    return bounds, weights
+
+
+@pytest.mark.parametrize("nparts", [1, 3, 8])
+def test_partition_balances_a_heterogeneous_batch(wl, oracle, nparts):
+    """vgx_partition ("for heterogeneous batches balance on the count-pass result"): a batch whose draws differ 100x in
+    size, sorted so that equal draw counts per rank would be badly unbalanced. Bounds = the cut points of the predicted-output
+    prefix (checked against the reference's per-draw counts); every part within one draw's weight of total / nparts; tessellating
+    the parts separately and concatenating them in part order reproduces the whole batch byte for byte."""
+    import importlib
+    import torch
+    rt = importlib.import_module("vg-renderer_amd.runtime")
+    ps = wl.fuzz_paths(910, npaths=64, with_shapes=True, with_polylines=True)
+    base = wl.fuzz_draws(ps, 910)
+    d = np.concatenate([base] * 6)
+    ref_counts = oracle.flatten(ps, d).draw_info["num_poly_vertices"]
+    d = d[np.argsort(ref_counts, kind="stable")]  # small draws first: equal counts per rank = unequal work
+    ctx = rt.Context(0)
+    try:
+        pset = rt.PathSet(ctx, ps)
+        dd = rt.upload_draws(d)
+        bounds, weights = rt.partition(ctx, pset, dd, d.shape[0], nparts)
+        eb, ew = _expected_partition(oracle, ps, d, nparts)
+        assert bounds == eb and weights == ew
+        assert bounds[0] == 0 and bounds[-1] == d.shape[0] and all(a <= b for a, b in zip(bounds, bounds[1:]))
+        total = sum(weights)
+        biggest = int(_per_draw_weight(oracle, ps, d).max())
+        assert max(weights) - total / nparts <= biggest, (weights, total / nparts, biggest)
+        if nparts == 3:
+            equal = [sum(ew2) for ew2 in np.array_split(_per_draw_weight(oracle, ps, d), nparts)]
+            assert max(equal) > 1.5 * max(weights)  # what the naive split would have cost the slowest rank
+        # parts tessellated separately == the whole batch (mesh-local indices: no rebase of the streams)
+        whole = rt.tessellate(ctx, pset, dd, d.shape[0])
+        pos, idx, col = [], [], []
+        for k in range(nparts):
+            lo, hi = bounds[k], bounds[k + 1]
+            if lo == hi:
+                continue
+            part = rt.tessellate(ctx, pset, rt.upload_draws(d[lo:hi]), hi - lo)
+            pos.append(part.pos); idx.append(part.idx); col.append(part.color)
+        assert np.array_equal(np.concatenate(pos).view(np.uint32), whole.pos.view(np.uint32))
+        assert np.array_equal(np.concatenate(idx), whole.idx) and np.array_equal(np.concatenate(col), whole.color)
+        pset.close()
+    finally:
+        ctx.close()
+        torch.cuda.synchronize()
+
+
+def _per_draw_weight(oracle, ps, d):
+    import importlib
+    capi = importlib.import_module("vg-renderer_amd.capi")
+    di = oracle.flatten(ps, d).draw_info
+    ff, sf = d["fill_flags"].astype(np.uint64), d["stroke_flags"].astype(np.uint64)
+    f = np.where(ff & 1, np.where(ff & 2, 2, 1), 0) + np.where(sf & 1, np.where((sf & capi.STROKE_AA) == 0, 2, np.where(sf & capi.STROKE_THIN, 3, 4)), 0)
+    return (di["num_poly_vertices"].astype(np.uint64) * f.astype(np.uint64) + 1).astype(np.int64)

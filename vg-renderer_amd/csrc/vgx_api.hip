@@ -62,6 +62,7 @@ struct vgx_ctx
 	DevBuf subPrefix; // exclusive scan of the draws' static sub-path counts
 	DevBuf cmdPrefix, cmdCnt, subFirst, leafOverflow, serialList, dinfo, poly, subs, mdesc, elemPrefix, elemPrefixS, mprep, mtab, partial, totals;
 	DevBuf gatherSizes;                  // vgx_gather_sizes: [nranks][4] uint64
+	DevBuf partBounds;                   // vgx_partition: [nparts + 1] bounds + [nparts] weights
 	struct VgxRccl* rccl;                // RCCL entry points, bound at the first vgx_gather* call
 	// options, read from the environment ONCE at vgx_create (tuning / testing knobs)
 	int optTwoPass, optBuildWaves, optPoolWalk, optNoSmall, optConcurrentEmit;
@@ -686,7 +687,7 @@ int vgx_destroy(vgx_ctx* ctx)
 		return VGX_E_INVALID_ARG;
 	}
 	DeviceGuard guard(ctx);
-	DevBuf* bufs[] = { &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DevBuf* bufs[] = { &ctx->partBounds, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
@@ -1032,6 +1033,55 @@ int vgx_flatten_emit(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 	if (out->draw_info && ndraws) {
 		HIPCHK(ctx, hipMemcpyAsync(out->draw_info, ctx->dinfo.p, ndraws * sizeof(vgx_draw_info), hipMemcpyDeviceToDevice, s));
 	}
+	return VGX_OK;
+}
+
+// ---- partition (contiguous ranges per GPU, balanced on the count pass for heterogeneous batches) -------------
+namespace {
+__global__ void k_partition_bounds(const uint64_t* prefix, uint64_t ndraws, uint32_t nparts, uint64_t* bounds, uint64_t* weights)
+{
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k > nparts) { return; }
+	const uint64_t total = prefix[ndraws];
+	// bounds[k] = first draw whose prefix reaches k / nparts of the total (draw granularity; 128-bit product avoided: total < 2^40)
+	uint64_t b = ndraws;
+	if (k < nparts) {
+		const uint64_t target = (uint64_t)(((unsigned __int128)total * k) / nparts);
+		uint64_t lo = 0, hi = ndraws;
+		while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (prefix[mid] < target) { lo = mid + 1; } else { hi = mid; } }
+		b = lo;
+	}
+	bounds[k] = b;
+	if (weights && k < nparts) {
+		const uint64_t target2 = (uint64_t)(((unsigned __int128)total * (k + 1)) / nparts);
+		uint64_t lo = 0, hi = ndraws;
+		if (k + 1 < nparts) { while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (prefix[mid] < target2) { lo = mid + 1; } else { hi = mid; } } } else { lo = ndraws; }
+		weights[k] = prefix[lo] - prefix[b];
+	}
+}
+}
+
+int vgx_partition(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, uint32_t nparts, uint64_t* out_bounds, uint64_t* out_weights, void* stream)
+{
+	DeviceGuard guard(ctx);
+	if (!ctx || !ps || (!draws && ndraws) || !out_bounds || nparts == 0 || nparts > 65536u) {
+		return VGX_E_INVALID_ARG;
+	}
+	hipStream_t s = (hipStream_t)stream;
+	markBegin(ctx, s);
+	ctx->lastStage = 0;
+	int st = flattenCountCommon(ctx, ps, draws, ndraws, s, false); // per-draw polyline vertex counts in dinfo
+	if (st != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->partBounds, ((size_t)nparts + 1) * 2 * sizeof(uint64_t))) != VGX_OK) { return st; }
+	OpPartWeight op;
+	op.draws = draws; op.dinfo = (const vgx_draw_info*)ctx->dinfo.p; op.ndraws = ndraws; op.prefix = (uint64_t*)ctx->cmdPrefix.p; // the command prefix is not needed any more
+	vgx_device_scan(op, (Sum3*)ctx->partial.p, s, ndraws);
+	uint64_t* dBounds = (uint64_t*)ctx->partBounds.p;
+	uint64_t* dWeights = dBounds + nparts + 1;
+	hipLaunchKernelGGL(k_partition_bounds, dim3((nparts + 1 + 255) / 256), dim3(256), 0, s, (const uint64_t*)ctx->cmdPrefix.p, ndraws, nparts, dBounds, dWeights);
+	HIPCHK(ctx, hipMemcpyAsync(out_bounds, dBounds, ((size_t)nparts + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+	if (out_weights) { HIPCHK(ctx, hipMemcpyAsync(out_weights, dWeights, (size_t)nparts * sizeof(uint64_t), hipMemcpyDeviceToHost, s)); }
+	HIPCHK(ctx, hipStreamSynchronize(s));
 	return VGX_OK;
 }
 

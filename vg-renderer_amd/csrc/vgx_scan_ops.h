@@ -110,6 +110,30 @@ struct OpDrawInfo // per-draw polyline / sub-path / mesh counts -> first_* field
 	}
 };
 
+// vgx_partition: predicted output vertices per draw = polyline vertices (count pass) x output vertices per polyline vertex of
+// the draw's fill / stroke flavour (convexFill 1, convexFillAA 2, stroke 2, strokeAA 4, strokeAAThin 3; Round joins / caps add
+// a little that the prediction ignores).
+struct OpPartWeight
+{
+	const vgx_draw* draws;
+	const vgx_draw_info* dinfo;
+	uint64_t ndraws;
+	uint64_t* prefix; // [ndraws + 1]
+	__device__ uint64_t size() const { return ndraws; }
+	__device__ Sum3 load(uint64_t i) const
+	{
+		Sum3 r = sum3_zero();
+		const uint32_t ff = draws[i].fill_flags, sf = draws[i].stroke_flags;
+		uint32_t f = 0;
+		if (ff & VGX_FILL_ENABLE) { f += (ff & VGX_FILL_AA) ? 2u : 1u; }
+		if (sf & VGX_STROKE_ENABLE) { f += !(sf & VGX_STROKE_AA) ? 2u : ((sf & VGX_STROKE_THIN) ? 3u : 4u); }
+		r.a = (uint64_t)dinfo[i].num_poly_vertices * f + 1; // + 1: empty draws still cost a record each, and every range gets a positive weight
+		return r;
+	}
+	__device__ void store(uint64_t i, Sum3 e) const { prefix[i] = e.a; }
+	__device__ void finish(Sum3 t) const { prefix[ndraws] = t.a; }
+};
+
 // One scan over the meshes for everything the emit kernels need: element offsets (convex fills / polyline strokes
 // have separate streams) and vertex / index offsets. Field d carries the index sum in its low 48 bits and the number
 // of meshes with more than 65536 vertices above them (a batch cannot hold 2^48 indices: positions are 32-bit counted).

@@ -23,6 +23,15 @@ def shard_range(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_range_balanced(ctx, pset, draws_dev, ndraws, rank, world):
+    """Contiguous draw range of `rank` when the batch is heterogeneous ("balance on the count-pass result"): every
+    rank holds the whole batch's draw records, runs vgx_partition on them (deterministic: all ranks compute the same bounds) and
+    takes its own range. Homogeneous batches give the ranges of shard_range."""
+    from . import runtime as rt
+    bounds, _ = rt.partition(ctx, pset, draws_dev, ndraws, world)
+    return bounds[rank], bounds[rank + 1]
+
+
 def gather_streams(pos, color, idx, meshes_u8, nverts, nidx, nmeshes, ndraws_local, root=0, group=None):
     """Gather variable-length device streams to `root`.
     pos [nv,2] f32, color [nv] i32, idx [ni] i16, meshes_u8 [nm*32] u8 (vgx_mesh records).

@@ -216,6 +216,14 @@ class MeshBuffers:
         return t
 
 
+def partition(ctx, pset, draws_dev, ndraws, nparts):
+    """vgx_partition: contiguous draw ranges of about equal predicted output. Returns (bounds [nparts + 1], weights [nparts])."""
+    bounds = (C.c_uint64 * (nparts + 1))()
+    weights = (C.c_uint64 * nparts)()
+    _check(lib().vgx_partition(ctx.handle, pset.handle, draws_dev.data_ptr(), ndraws, nparts, bounds, weights, _stream_ptr()), "vgx_partition")
+    return list(bounds), list(weights)
+
+
 def tessellate_count(ctx, pset, draws_dev, ndraws):
     sizes = capi.Sizes()
     _check(lib().vgx_tessellate_count(ctx.handle, pset.handle, draws_dev.data_ptr(), ndraws, C.byref(sizes), _stream_ptr()), "vgx_tessellate_count")

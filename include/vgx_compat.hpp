@@ -7,6 +7,9 @@
 // compatibility and incremental adoption; throughput comes from batching through vgx.h.
 // There is no CPU implementation behind it: without a gfx950 device the create functions return nullptr.
 //
+// createPath / createStroker honour the caller's bx::AllocatorI (bx/allocator.h's interface: a virtual destructor and realloc(ptr,
+// size, align, file, line)): the object and every host-side array come from it, nullptr = the C heap; device buffers are hipMalloc.
+//
 // Differences from the reference, all documented in DESIGN.md:
 //   - command grammar the reference leaves undefined (lineTo before moveTo, appending to a closed sub-path) yields an
 //     empty path instead of undefined behaviour; NaN/Inf arguments likewise (they hang the reference, path.cpp:109);

@@ -32,8 +32,19 @@ static void compareMesh(const M1& a, const M2& b, bool posAliased, const char* w
 int main()
 {
 	bx::ShimAllocator alloc;
-	vg::Path* gp = vg::createPath(nullptr);
-	vg::Stroker* gs = vg::createStroker(nullptr);
+	// the caller's allocator (bx::AllocatorI, path.cpp:23-30 / stroker.cpp:194-200): object + host arrays must come from it
+	struct Counting : public bx::ShimAllocator
+	{
+		long live = 0, allocs = 0;
+		void* realloc(void* ptr, size_t size, size_t align, const char* f, uint32_t l) override
+		{
+			if (!ptr && size) { ++live; ++allocs; }
+			if (ptr && !size) { --live; }
+			return bx::ShimAllocator::realloc(ptr, size, align, f, l);
+		}
+	} counting;
+	vg::Path* gp = vg::createPath(&counting);
+	vg::Stroker* gs = vg::createStroker(&counting);
 	if (!gp || !gs) { printf("no device\n"); return 2; }
 	vgo::Path* op = vgo::createPath(&alloc);
 	vgo::Stroker* os = vgo::createStroker(&alloc);
@@ -178,7 +189,10 @@ int main()
 			vg::vgxCompatSetTessellator(nullptr);
 		}
 	}
+	CHECK(counting.allocs > 10, "allocator used: %ld allocations", counting.allocs);
 	vg::destroyStroker(gs); vg::destroyPath(gp);
+	CHECK(counting.live == 0, "allocator balance after destroy: %ld live blocks", counting.live);
+	{ vg::Path* p0 = vg::createPath(nullptr); vg::pathMoveTo(p0, 0, 0); vg::pathLineTo(p0, 3, 4); CHECK(vg::pathGetNumVertices(p0) == 2, "null allocator = C heap"); vg::destroyPath(p0); }
 	vgo::destroyStroker(os); vgo::destroyPath(op);
 	printf("%s: %d checks, %d failures\n", g_fail ? "FAILED" : "OK", g_checks, g_fail);
 	return g_fail ? 1 : 0;

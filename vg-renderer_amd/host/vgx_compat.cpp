@@ -5,11 +5,52 @@
 #include "../../include/vgx.h"
 #include <hip/hip_runtime_api.h>
 #include <vector>
+#include <new>
 #include <string.h>
+#include <stdlib.h>
+
+// bx's allocator interface (bx/allocator.h: a virtual destructor and ONE virtual function; alloc = realloc(nullptr, size),
+// free = realloc(ptr, 0)) -- the reference's createPath / createStroker take it (path.cpp:23-30, stroker.cpp:194-200) and
+// allocate the object and its growable arrays through it. bx itself is not vendored by the reference, so the interface is
+// restated here; a caller that has bx passes its own allocator object, whose vtable has this layout.
+namespace bx
+{
+struct AllocatorI
+{
+	virtual ~AllocatorI() = 0;
+	virtual void* realloc(void* ptr, size_t size, size_t align, const char* file, uint32_t line) = 0;
+};
+}
 
 namespace vg
 {
 namespace {
+
+void* hostAlloc(bx::AllocatorI* a, size_t bytes)
+{
+	void* p = a ? a->realloc(nullptr, bytes, 0, __FILE__, __LINE__) : malloc(bytes);
+	if (!p) { throw std::bad_alloc(); }
+	return p;
+}
+void hostFree(bx::AllocatorI* a, void* p)
+{
+	if (!p) { return; }
+	if (a) { (void)a->realloc(p, 0, 0, __FILE__, __LINE__); } else { free(p); }
+}
+// std allocator over the caller's bx allocator (nullptr: the C heap): every host array of a Path / Stroker comes from it
+template<class T>
+struct BxAlloc
+{
+	typedef T value_type;
+	bx::AllocatorI* a;
+	BxAlloc(bx::AllocatorI* alloc = nullptr) : a(alloc) {}
+	template<class U> BxAlloc(const BxAlloc<U>& o) : a(o.a) {}
+	T* allocate(size_t n) { return (T*)hostAlloc(a, n * sizeof(T)); }
+	void deallocate(T* p, size_t) { hostFree(a, p); }
+	template<class U> bool operator==(const BxAlloc<U>& o) const { return a == o.a; }
+	template<class U> bool operator!=(const BxAlloc<U>& o) const { return a != o.a; }
+};
+template<class T> using Vec = std::vector<T, BxAlloc<T>>;
 
 int g_device = 0;
 VgxTessApi g_tess = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
@@ -50,14 +91,16 @@ struct Path
 	vgx_ctx* ctx = nullptr;
 	int status = VGX_OK;
 	float scale = 1.0f, tol = 0.25f; // createPath defaults, reference path.cpp:28-29
-	std::vector<uint8_t> types;
-	std::vector<uint32_t> argOff;
-	std::vector<float> args;
+	bx::AllocatorI* alloc;
+	Vec<uint8_t> types;
+	Vec<uint32_t> argOff;
+	Vec<float> args;
 	// flattened result (lazy)
 	bool dirty = true;
-	std::vector<float> verts;
-	std::vector<SubPath> subs;
+	Vec<float> verts;
+	Vec<SubPath> subs;
 	DevBuf dDraw, dPoly, dSubs;
+	explicit Path(bx::AllocatorI* a) : alloc(a), types(BxAlloc<uint8_t>(a)), argOff(BxAlloc<uint32_t>(a)), args(BxAlloc<float>(a)), verts(BxAlloc<float>(a)), subs(BxAlloc<SubPath>(a)) {}
 
 	void cmd(uint8_t t, const float* a, uint32_t n)
 	{
@@ -88,7 +131,7 @@ struct Path
 		if (!dDraw.ensure(sizeof(d)) || hipMemcpy(dDraw.p, &d, sizeof(d), hipMemcpyHostToDevice) != hipSuccess) { status = VGX_E_HIP; }
 		if (status == VGX_OK) { status = vgx_flatten_count(ctx, ps, (const vgx_draw*)dDraw.p, 1, &sz, nullptr); }
 		if (status == VGX_OK && sz.num_poly_vertices) {
-			std::vector<vgx_subpath> hs(sz.num_subpaths);
+			Vec<vgx_subpath> hs(sz.num_subpaths, vgx_subpath(), BxAlloc<vgx_subpath>(alloc));
 			if (!dPoly.ensure(sz.num_poly_vertices * 8) || !dSubs.ensure(sz.num_subpaths * sizeof(vgx_subpath))) { status = VGX_E_HIP; }
 			vgx_flat_out out;
 			out.poly = (float*)dPoly.p; out.subpaths = (vgx_subpath*)dSubs.p; out.draw_info = nullptr;
@@ -117,10 +160,10 @@ struct Path
 void vgxCompatSetDevice(int device) { g_device = device; }
 int vgxCompatLastStatus(const Path* path) { return path ? path->status : VGX_E_INVALID_ARG; }
 
-Path* createPath(bx::AllocatorI*)
+Path* createPath(bx::AllocatorI* allocator) // path.cpp:23-30: the object and its arrays come from `allocator`
 {
-	Path* p = new Path();
-	if (vgx_create(g_device, &p->ctx) != VGX_OK) { delete p; return nullptr; }
+	Path* p = ::new (hostAlloc(allocator, sizeof(Path))) Path(allocator);
+	if (vgx_create(g_device, &p->ctx) != VGX_OK) { p->~Path(); hostFree(allocator, p); return nullptr; }
 	p->argOff.push_back(0);
 	return p;
 }
@@ -129,7 +172,9 @@ void destroyPath(Path* path)
 {
 	if (!path) { return; }
 	vgx_ctx* c = path->ctx;
-	delete path;
+	bx::AllocatorI* a = path->alloc;
+	path->~Path();
+	hostFree(a, path);
 	(void)vgx_destroy(c);
 }
 
@@ -165,13 +210,15 @@ struct Stroker
 	vgx_ctx* ctx = nullptr;
 	int status = VGX_OK;
 	float scale = 1.0f, tol = 0.25f, fringe = 1.0f; // createStroker defaults, reference stroker.cpp:199-201
-	std::vector<float> pos;
-	std::vector<uint32_t> col;
-	std::vector<uint16_t> idx;
+	bx::AllocatorI* alloc;
+	Vec<float> pos;
+	Vec<uint32_t> col;
+	Vec<uint16_t> idx;
 	DevBuf dPoly, dSub, dSubDraw, dDraw, dPos, dCol, dIdx;
 	void* tess = nullptr;                    // strokerConcaveFill*: the host's libtess2 object
 	DevBuf dContour, dCont, dFill, dMoved, dTessPos, dTessIdx;
-	std::vector<float> moved;
+	Vec<float> moved;
+	explicit Stroker(bx::AllocatorI* a) : alloc(a), pos(BxAlloc<float>(a)), col(BxAlloc<uint32_t>(a)), idx(BxAlloc<uint16_t>(a)), moved(BxAlloc<float>(a)) {}
 
 	// One strokerXXX call = one vertex list, one op.
 	void run(Mesh* mesh, const float* vertexList, uint32_t n, bool closed, const vgx_draw& d, bool wantColor, bool aliasPos)
@@ -217,10 +264,10 @@ struct Stroker
 
 int vgxCompatLastStatus(const Stroker* s) { return s ? s->status : VGX_E_INVALID_ARG; }
 
-Stroker* createStroker(bx::AllocatorI*)
+Stroker* createStroker(bx::AllocatorI* allocator) // stroker.cpp:194-200
 {
-	Stroker* s = new Stroker();
-	if (vgx_create(g_device, &s->ctx) != VGX_OK) { delete s; return nullptr; }
+	Stroker* s = ::new (hostAlloc(allocator, sizeof(Stroker))) Stroker(allocator);
+	if (vgx_create(g_device, &s->ctx) != VGX_OK) { s->~Stroker(); hostFree(allocator, s); return nullptr; }
 	return s;
 }
 
@@ -229,7 +276,9 @@ void destroyStroker(Stroker* s)
 	if (!s) { return; }
 	if (s->tess && g_hasTess) { g_tess.deleteTess(s->tess); }
 	vgx_ctx* c = s->ctx;
-	delete s;
+	bx::AllocatorI* a = s->alloc;
+	s->~Stroker();
+	hostFree(a, s);
 	(void)vgx_destroy(c);
 }
 
@@ -327,7 +376,7 @@ bool strokerConcaveFillEndAA(Stroker* s, Mesh* mesh, uint32_t color, FillRule::E
 	const unsigned short* contourData = g_tess.getElements(s->tess);
 	const int numContours = g_tess.getElementCount(s->tess);
 	const uint32_t numContourVerts = (uint32_t)g_tess.getVertexCount(s->tess);
-	std::vector<vgx_contour> contours((size_t)numContours);
+	Vec<vgx_contour> contours((size_t)numContours, vgx_contour(), BxAlloc<vgx_contour>(s->alloc));
 	uint32_t used = 0;
 	for (int i = 0; i < numContours; ++i) {
 		contours[i].first_vertex = contourData[2 * i]; contours[i].num_vertices = contourData[2 * i + 1]; contours[i].fill = 0;

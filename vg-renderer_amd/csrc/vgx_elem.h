@@ -1,7 +1,6 @@
 // vgx_elem.h -- one stroker ELEMENT per lane: geometry, counts, exit rails and the emitter of one polyline vertex of
-// one mesh (convex-fill corner, stroke cap or join). Shared by the element kernels of vgx_stroke.hip (polyline in
-// HBM) and the fused single-pass kernel of vgx_fused.hip (polyline in LDS): the vertex source is a template
-// parameter (VS: `V2 ld(uint32_t i) const` returns vertex i of the mesh's polyline), everything else is identical.
+// one mesh (convex-fill corner, stroke cap or join), used by the element kernels of vgx_stroke.hip. The vertex source
+// is a template parameter (VS: `V2 ld(uint32_t i) const` returns vertex i of the mesh's polyline; VtxGlobal = the heap).
 // Every emitted position / colour / index follows the cited reference lines (src/stroker.cpp); the rails
 // formulation is the one of SURVEY.md appendix B.
 #ifndef VGX_ELEM_H
@@ -185,9 +184,7 @@ struct Elem
 	uint32_t H;       // numPointsHalfCircle (Round caps)
 };
 
-// Vertex sources: the mesh's polyline in HBM (flat pipeline, heap mode of the fused kernel) or in the wave's LDS
-// window (fused kernel). The LDS form carries an address-space-3 pointer so that every access is a ds_read, never
-// a flat load (a flat load would also wait on the wave's outstanding global stores through vmcnt).
+// Vertex source: the mesh's polyline in the heap (HBM).
 struct VtxGlobal
 {
 	const float2* p;
@@ -197,15 +194,6 @@ struct VtxGlobal
 	__device__ __forceinline__ V2 ld(uint32_t i) const { const float2 t = p[i]; return v2(t.x, t.y); }
 #endif
 };
-typedef float vgx_f2 __attribute__((ext_vector_type(2)));
-typedef const vgx_f2 __attribute__((address_space(3)))* vgx_lds_cf2p;
-typedef vgx_f2 __attribute__((address_space(3)))* vgx_lds_f2p;
-struct VtxLds
-{
-	vgx_lds_cf2p p;
-	__device__ __forceinline__ V2 ld(uint32_t i) const { const vgx_f2 t = p[i]; return v2(t.x, t.y); }
-};
-
 template<class VS>
 struct MeshCtxT
 {

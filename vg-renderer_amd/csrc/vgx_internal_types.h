@@ -97,17 +97,6 @@ struct VgxSubRec
 #define VGX_ORIENT_POS 2u
 #define VGX_ORIENT_NEG 4u
 
-// Sub-path record of the fused single-pass kernel (vgx_fused.hip), one per sub-path that produces a mesh, kept in the
-// wave's LDS: where the sub-path's vertices start inside the wave's polyline window (or heap block), its length and
-// closed flag, and where its meshes go inside the segment (local draw index, ranks among the draw's fill / stroke meshes).
-struct VgxSegSub
-{
-	uint32_t first;     // first vertex, relative to the segment's first polyline vertex
-	uint32_t info;      // vertex count | closed << 31
-	uint32_t packed;    // local draw index (bits 0-7) | fill rank << 8 (12 bits) | stroke rank << 20 (12 bits)
-	uint32_t sub_index; // sub-path index within its draw (vgx_mesh.subpath_kind)
-};
-
 #define VGX_INST_POOLS 16
 // ---- batch totals kept in device memory (mirrors vgx_sizes + internal counters) -------------------
 struct VgxTotals

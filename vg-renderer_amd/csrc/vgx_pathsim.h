@@ -84,8 +84,6 @@ struct PathSim
 	uint32_t drawIndex;
 	uint32_t fillFlags, strokeFlags;
 	uint32_t numFillTotal;   // emit/serial: fill meshes of the draw (stroke meshes come after them)
-	VgxSegSub* segSubs;      // fused kernel only (else null): records of the sub-paths that produce a mesh, segSubs[segSubN++]
-	uint32_t segSubN, segSubCap, segDrawLocal;
 	// state
 	uint32_t nverts;         // path.cpp:10 m_NumVertices (relative to polyBase)
 	uint32_t nsubs;
@@ -103,7 +101,6 @@ struct PathSim
 	VGX_HDM void init()
 	{
 		nverts = 0; nsubs = 0; nfill = 0; nstroke = 0; numRound = 0; open = false; spFirst = 0; spN = 0; spClosed = false;
-		segSubs = nullptr; segSubN = 0; segSubCap = 0; segDrawLocal = 0; // the fused kernel sets these AFTER init()
 		first = v2(0.0f, 0.0f); last = first; laneExists = false; laneClosed = false;
 	}
 	VGX_HDM void store(uint32_t i, V2 p)
@@ -125,18 +122,6 @@ struct PathSim
 			r.num_vertices = spN;
 			r.flags = spClosed ? 1u : 0u;
 			subs[subBase + subIndex] = r;
-		}
-		const bool hasFill = (fillFlags & VGX_FILL_ENABLE) && spN >= 3, hasStroke = (strokeFlags & VGX_STROKE_ENABLE) && spN >= 2;
-		if (segSubs && (hasFill || hasStroke)) {
-			if (EMIT && segSubN < segSubCap) {
-				VgxSegSub r;
-				r.first = (uint32_t)polyBase + spFirst;
-				r.info = spN | (spClosed ? 0x80000000u : 0u);
-				r.packed = segDrawLocal | (nfill << 8) | (nstroke << 20);
-				r.sub_index = subIndex;
-				segSubs[segSubN] = r;
-			}
-			++segSubN;
 		}
 		if ((fillFlags & VGX_FILL_ENABLE) && spN >= 3) {
 			if (EMIT && mdesc) {

@@ -1,6 +1,5 @@
 // vgx_walk.h -- the per-lane adaptive cubic walk (pathCubicTo, reference src/path.cpp:86-182) with its pending
-// stack in LDS, the leaf sinks and the lane-resident draw window: shared by the flatten kernels (vgx_flatten.hip) and
-// the fused single-pass kernel (vgx_fused.hip). Device only.
+// stack in LDS, the leaf sinks and the lane-resident draw window of the flatten kernels (vgx_flatten.hip). Device only.
 #ifndef VGX_WALK_H
 #define VGX_WALK_H
 

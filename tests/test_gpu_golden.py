@@ -151,6 +151,61 @@ def test_full_size_tiger_properties(rt, gpu_ctx, wl, oracle, monkeypatch):
     pset.close()
 
 
+def test_full_size_tiger_varied_scales(rt, wl, oracle, monkeypatch):
+    """bench.py's tiger10k_varied at full size (every instance at its own scale and rotation: 2.4 M draws, ~0.63 G vertices):
+    the count pass must choose the instanced kernel with (path, tolerance class) keys (flatten mode 3); the streams of the
+    asynchronous entry point are compared byte for byte with the command-parallel kernel's (VGX_INST=0: k_flatten_build, an
+    independent implementation of the flatten) and, instance by instance for a sample, with the reference oracle."""
+    import torch
+    K = 10000
+    ps, ops = wl.tiger_paths()
+    draws = wl.tiger_varied_draws(ops, K)
+    P = len(ops)
+    ctx = rt.Context(0)
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(draws)
+    sizes = rt.tessellate_count(ctx, pset, dd, draws.shape[0])
+    assert ctx.failure_info()["segment_items"] == 3
+    nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
+    b = rt.MeshBuffers(dd.device, nv, ni, nm)
+    for _ in range(2):
+        rt.tessellate_async(ctx, pset, dd, draws.shape[0], b)
+    torch.cuda.synchronize()
+    assert int(b.dev_status.item()) == 0
+    got = b.dev_sizes.cpu().numpy()
+    assert int(got[3]) == nv and int(got[4]) == ni and int(got[2]) == nm
+    meshes = b.meshes[:nm * 32].cpu().numpy().view(rt.capi.mesh_dtype)
+    assert np.array_equal(meshes["first_vertex"][1:], np.cumsum(meshes["num_vertices"].astype(np.uint64))[:-1])
+    assert np.array_equal(meshes["first_index"][1:], np.cumsum(meshes["num_indices"].astype(np.uint64))[:-1])
+    first_mesh_of_draw = np.searchsorted(meshes["draw"], np.arange(K * P + 1, dtype=np.uint64), side="left")
+    rs = np.random.RandomState(3)
+    for inst in [0, K - 1] + [int(x) for x in rs.randint(1, K - 1, size=6)]:
+        ref = oracle.tessellate(ps, draws[inst * P:(inst + 1) * P])
+        m0, m1 = int(first_mesh_of_draw[inst * P]), int(first_mesh_of_draw[(inst + 1) * P])
+        assert m1 - m0 == ref.meshes.shape[0], inst
+        v0, i0 = int(meshes["first_vertex"][m0]), int(meshes["first_index"][m0])
+        v1, i1 = v0 + ref.pos.shape[0], i0 + ref.idx.shape[0]
+        assert np.array_equal(b.pos[v0:v1].cpu().numpy().view(np.uint32), ref.pos.view(np.uint32)), inst
+        assert np.array_equal(b.idx[i0:i1].cpu().numpy().view(np.uint16), ref.idx), inst
+        assert np.array_equal(b.color[v0:v1].cpu().numpy().view(np.uint32), ref.color), inst
+    monkeypatch.setenv("VGX_INST", "0")
+    ctx0 = rt.Context(0)
+    pset0 = rt.PathSet(ctx0, ps)
+    rt.tessellate_count(ctx0, pset0, dd, draws.shape[0])
+    assert ctx0.failure_info()["segment_items"] == 0
+    b0 = rt.MeshBuffers(dd.device, nv, ni, nm)
+    rt.tessellate_async(ctx0, pset0, dd, draws.shape[0], b0)
+    torch.cuda.synchronize()
+    assert int(b0.dev_status.item()) == 0
+    assert torch.equal(b0.pos[:nv].view(torch.int32), b.pos[:nv].view(torch.int32))
+    assert torch.equal(b0.color[:nv], b.color[:nv])
+    assert torch.equal(b0.idx[:ni], b.idx[:ni])
+    assert torch.equal(b0.meshes[:nm * 32], b.meshes[:nm * 32])
+    pset0.close(); ctx0.close(); pset.close(); ctx.close()
+    del b, b0
+    torch.cuda.empty_cache()
+
+
 def test_full_size_flatten_1m_cubics(rt, gpu_ctx, wl, oracle):
     """BASELINE config 1: 1 M independent cubics, flatten only. Oracle on a 20 k sample + global properties."""
     n = 1000000

@@ -118,7 +118,7 @@ struct VgxTotals
 	uint32_t inst_tol_lo_inv;            // ~(smallest bit pattern of tess_tol / scale^2 over the draws), k_inst_tol_range (totals are zeroed: a minimum kept as a maximum)
 	uint32_t inst_tol_hi;                // largest one. lo != hi: instances differ in scale -> grouped mode sorts by (path, tolerance class)
 	uint32_t inst_tol_varies;            // vgx_tessellate_count, periodic batch: some draw's tolerance differs from its image in the first period
-	uint32_t inst_pad0;
+	uint32_t has_general_stroke;         // scan over the meshes: some stroke mesh is not a closed Miter AA / Thin stroke -> k_stroke emits the strokes, else k_stroke_simple
 	// diagnostics of the first failure (vgx_get_failure_info)
 	uint32_t fail_reason;  // VGX_FAIL_*
 	uint32_t fail_aux;

@@ -154,11 +154,20 @@ struct OpMeshAll
 	__device__ Sum3 load(uint64_t i) const
 	{
 		Sum3 r = sum3_zero();
-		const VgxMeshDesc m = mdesc[i];
-		if (VGX_MD_KIND(m.kind) >= VGX_MESH_STROKE) { r.b = m.poly_n; } else { r.a = m.poly_n; }
-		const uint32_t nv = mtab[i].num_vertices;
+		// all loads first: the conditional store below would otherwise sit between them (possible alias) and turn two
+		// parallel loads into a dependent chain (measured: +0.035 ms over 4.35 M meshes)
+		const uint32_t kindWord = mdesc[i].kind, polyN = mdesc[i].poly_n;
+		const uint32_t nv = mtab[i].num_vertices, nidx = mtab[i].num_indices;
+		if (VGX_MD_KIND(kindWord) >= VGX_MESH_STROKE) {
+			r.b = polyN;
+			// which stroke kernel emits this batch (vgx_stroke.hip): a plain store, at most once per mesh that is not "simple"
+			// (closed, Miter join, AA or Thin: bits 0-7 kind, 8 closed, 11-12 join)
+			const uint32_t key = kindWord & 0x19FFu;
+			const bool simple = key == (0x100u | VGX_MESH_STROKE_AA) || key == (0x100u | VGX_MESH_STROKE_AA_THIN);
+			if (!simple) { totals->has_general_stroke = 1u; }
+		} else { r.a = polyN; }
 		r.c = nv;
-		r.d = (uint64_t)mtab[i].num_indices + (nv > 65536u ? (1ull << 48) : 0ull);
+		r.d = (uint64_t)nidx + (nv > 65536u ? (1ull << 48) : 0ull);
 		return r;
 	}
 	__device__ void store(uint64_t i, Sum3 e) const

@@ -382,6 +382,7 @@ struct __attribute__((aligned(16))) StrokeRec
 
 // The stroke meshes [m0, m1) (whole meshes; A.elem_prefix = the strokes' prefix): elements walked in 64-element chunks with
 // the carries of a mesh that spans chunks. wbase / wv = the LDS window of 64 mesh records (s_win), kept between calls.
+template<bool ONLY_SIMPLE>
 __device__ __forceinline__ void stroke_range(const VgxStrokeArgs& A, StrokeRec* s_win, uint64_t& wbase, uint64_t& wv, const uint64_t m0, const uint64_t m1,
 	const uint64_t numMeshes, const int lane)
 {
@@ -461,25 +462,26 @@ __device__ __forceinline__ void stroke_range(const VgxStrokeArgs& A, StrokeRec* 
 		}
 		const int nvalid = (int)((E1 - chunk) < (uint64_t)VGX_WAVE ? (E1 - chunk) : (uint64_t)VGX_WAVE);
 		const int Lz = nvalid - 1;
-#ifndef VGX_EXP_NO_SIMPLE_STROKE
-		if (wave_ballot(valid && !stroke_elem_is_simple(mc.kind, mc.closed, mc.join)) == 0) { // wave-uniform: closed Miter AA / Thin strokes only
+		if (ONLY_SIMPLE) { // k_stroke_simple: the scan over the meshes found closed Miter AA / Thin strokes only
 			stroke_chunk_simple(valid, lane < VGX_WAVE - 1 && ei + 1 < E1, nvalid, lane, mc, color, A.pos + 2 * firstV, A.color + firstV, A.idx + firstI, idxBase, carry);
-		} else
-#endif
-#ifndef VGX_EXP_ONLY_SIMPLE_STROKE /* tuning experiment: the kernel without the general element code (wrong for anything but closed Miter strokes) */
-		stroke_chunk(valid, lane < VGX_WAVE - 1 && ei + 1 < E1, nvalid, lane, mc, color, A.pos + 2 * firstV, A.color + firstV, A.idx + firstI, idxBase, carry);
-#else
-		{ }
-#endif
+		} else if (wave_ballot(valid && !stroke_elem_is_simple(mc.kind, mc.closed, mc.join)) == 0) { // wave-uniform
+			stroke_chunk_simple(valid, lane < VGX_WAVE - 1 && ei + 1 < E1, nvalid, lane, mc, color, A.pos + 2 * firstV, A.color + firstV, A.idx + firstI, idxBase, carry);
+		} else {
+			stroke_chunk(valid, lane < VGX_WAVE - 1 && ei + 1 < E1, nvalid, lane, mc, color, A.pos + 2 * firstV, A.color + firstV, A.idx + firstI, idxBase, carry);
+		}
 		mcur = wave_bcast_u64(mi, Lz);
 	}
 }
 
-__global__ __launch_bounds__(VGX_WAVE) VGX_STROKE_OCC void k_stroke(VgxStrokeArgs A)
+// Two instantiations, both launched, one exits at once (the scan over the meshes decided: totals->has_general_stroke):
+//   k_stroke         every kind of stroke (128 VGPRs, 4 waves per SIMD)
+//   k_stroke_simple  batches whose strokes are all closed, Miter, AA or Thin -- e.g. the tiger: stroke_chunk_simple only, 56 VGPRs,
+//                    8 waves per SIMD: 1.21 ms against 1.29 ms on the same box
+template<bool ONLY_SIMPLE>
+__device__ __forceinline__ void stroke_kernel_body(const VgxStrokeArgs& A, StrokeRec* s_win)
 {
-	__shared__ StrokeRec s_win[VGX_WAVE];
 	const int lane = threadIdx.x;
-	if (A.totals->status != VGX_OK) {
+	if (A.totals->status != VGX_OK || (A.totals->has_general_stroke != 0u) == ONLY_SIMPLE) {
 		return;
 	}
 	const uint64_t numMeshes = A.totals->sizes.num_meshes;
@@ -502,8 +504,20 @@ __global__ __launch_bounds__(VGX_WAVE) VGX_STROKE_OCC void k_stroke(VgxStrokeArg
 		if (m0 == m1) {
 			continue;
 		}
-		stroke_range(A, s_win, wbase, wv, m0, m1, numMeshes, lane);
+		stroke_range<ONLY_SIMPLE>(A, s_win, wbase, wv, m0, m1, numMeshes, lane);
 	}
+}
+
+__global__ __launch_bounds__(VGX_WAVE) VGX_STROKE_OCC void k_stroke(VgxStrokeArgs A)
+{
+	__shared__ StrokeRec s_win[VGX_WAVE];
+	stroke_kernel_body<false>(A, s_win);
+}
+
+__global__ __launch_bounds__(VGX_WAVE) void k_stroke_simple(VgxStrokeArgs A)
+{
+	__shared__ StrokeRec s_win[VGX_WAVE];
+	stroke_kernel_body<true>(A, s_win);
 }
 
 // The caller's mesh table = the internal one once the scan over meshes has filled first_vertex / first_index.
@@ -536,6 +550,7 @@ void vgx_launch_fill(const VgxStrokeArgs& a, int numBlocks, hipStream_t s)
 void vgx_launch_stroke(bool emit, const VgxStrokeArgs& a, int numBlocks, hipStream_t s)
 {
 	if (emit) {
+		hipLaunchKernelGGL(k_stroke_simple, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a); // one of the two exits at once
 		hipLaunchKernelGGL(k_stroke, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
 	} else { // sizes Round-join meshes; returns at once when the batch has none (every other size is closed-form)
 		hipLaunchKernelGGL(k_round_sizes, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);

@@ -702,7 +702,11 @@ __device__ __forceinline__ void flatten_gather_body(const VgxFlattenArgs& A, uin
 	for (uint64_t d = tid; d < A.ndraws; d += nthreads) {
 		const vgx_draw_info di = A.dinfo[d];
 		if ((di.flags & 1u) || di.num_meshes == 0) { continue; }
-		const vgx_draw* dr = A.draws + d;
+		// Everything the loop reads is loaded BEFORE its first store (the draw record as a local copy, the first sub-path
+		// records into registers): a load issued after a store waits for that store as well (vmcnt counts both, in order),
+		// and the compiler cannot move it up past a store that may alias.
+		const vgx_draw drLocal = A.draws[d];
+		const vgx_draw* dr = &drLocal;
 		const uint32_t path = dr->path;
 		const uint32_t sb0 = ps.path_sub_begin[path], sb1 = ps.path_sub_begin[path + 1];
 		// both flatten kernels store record j of draw d at sub_prefix[d] + j; periodic batches keep the first period's prefixes only
@@ -710,9 +714,14 @@ __device__ __forceinline__ void flatten_gather_body(const VgxFlattenArgs& A, uin
 		const uint32_t fillFlags = dr->fill_flags, strokeFlags = dr->stroke_flags;
 		const uint32_t numFill = di.flags >> 1;
 		uint32_t f = 0, s = 0, subIndex = 0;
+		VgxSubRec pre[4];
+#pragma unroll
+		for (uint32_t j = 0; j < 4; ++j) { if (sb0 + j < sb1) { pre[j] = A.sub_rec[cbase + j]; } }
 		for (uint32_t sb = sb0; sb < sb1; ++sb) {
 			const uint64_t ci = cbase + subIndex;
-			const VgxSubRec sr = A.sub_rec[ci];
+			VgxSubRec sr;
+			if (subIndex == 0) { sr = pre[0]; } else if (subIndex == 1) { sr = pre[1]; } else if (subIndex == 2) { sr = pre[2]; } else if (subIndex == 3) { sr = pre[3]; }
+			else { sr = A.sub_rec[ci]; }
 			const uint32_t info = sr.info;
 			const uint32_t n = info & 0x7FFFFFFFu;
 			const bool closed = (info >> 31) != 0;

@@ -172,10 +172,13 @@ struct OpMeshAll
 	}
 	__device__ void store(uint64_t i, Sum3 e) const
 	{
+		// the record is read BEFORE the stores below (a load behind stores waits for them: vmcnt counts both, in order)
+		const bool toCaller = meshesOut && i < caps.meshes;
+		vgx_mesh r;
+		if (toCaller) { r = mtab[i]; }
 		prefixFill[i] = e.a; prefixStroke[i] = e.b;
 		mtab[i].first_vertex = e.c; mtab[i].first_index = e.d & VGX_IDX_SUM_MASK;
-		if (meshesOut && i < caps.meshes) { // the caller's table = the internal one, in the same pass (no k_copy_meshes)
-			vgx_mesh r = mtab[i];
+		if (toCaller) { // the caller's table = the internal one, in the same pass (no k_copy_meshes)
 			r.first_vertex = e.c; r.first_index = e.d & VGX_IDX_SUM_MASK;
 			meshesOut[i] = r;
 		}

@@ -399,8 +399,11 @@ typedef struct vgx_cmdlist_state { /* the Context / State values at submission *
 typedef struct vgx_draw_state {   /* per draw: what allocDrawCommand copies into the DrawCommand (vg.cpp:5391-5400). 24 bytes */
 	uint16_t scissor[4];          /* (uint16_t) State::m_ScissorRect */
 	uint32_t clip_rule;           /* ClipState::m_Rule (0 In, 1 Out) */
-	uint32_t clip_first_draw;     /* the active clip region = the Clip draws [clip_first_draw, + clip_num_draws) of this
-	                               * decode (the reference stores the range of clip COMMANDS they merge into); 0xFFFFFFFF = none */
+	uint32_t clip_first_draw;     /* the active clip region = the draws of type Clip among [clip_first_draw, + clip_num_draws) of
+	                               * this decode (the reference stores the range of clip COMMANDS they merge into; gradient and
+	                               * image-pattern paints inside BeginClip .. EndClip are ordinary draws and may lie between
+	                               * them); 0xFFFFFFFF = none. A draw recorded while the region is still open sees it empty
+	                               * (clip_num_draws = 0), as in the reference (vg.cpp:3670-3697) */
 	uint32_t clip_num_draws;
 	uint32_t reserved;
 } vgx_draw_state;

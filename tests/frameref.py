@@ -118,7 +118,8 @@ def assert_frame_equal(fr, pos, color, idx, meshes, cmds, draws, dstate, max_vb,
                 if rf != 0xFFFFFFFF:
                     assert int(dstate["clip_rule"][d0]) == int(rcmd["clip_rule"])
                     rv = sum(int(fr.clipcmds[k]["num_vertices"]) for k in range(rf, rf + rn))
-                    sel = (meshes["draw"] >= gf) & (meshes["draw"] < gf + gn)
+                    is_clip_draw = ((draws["state_key"] >> 16) & 3) == 3  # the region = the Clip draws inside the range
+                    sel = (meshes["draw"] >= gf) & (meshes["draw"] < gf + gn) & is_clip_draw[meshes["draw"]]
                     assert rv == int(meshes["num_vertices"][sel].sum()), (what, i, "clip region")
                     if rn:
                         fv = int(vb_first[int(fr.clipcmds[rf]["vertex_buffer"])]) + int(fr.clipcmds[rf]["first_vertex"])

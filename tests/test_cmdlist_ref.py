@@ -141,6 +141,158 @@ def s_every_command(wl):
     return s
 
 
+def s_random(seed):
+    """A random frame: shapes, all six paint commands with local gradients / image patterns, balanced push / pop with
+    transforms and global alpha, scissor changes, clip regions, several paints per path (latch), transparent colours."""
+    rs = np.random.RandomState(seed)
+    s = Script()
+    ngrad, nimg, depth, in_clip = 0, 0, 0, False
+    u = rs.uniform
+
+    def col():
+        c = int(rs.randint(0, 1 << 32, dtype=np.uint64))
+        r = u()
+        return (c & 0x00FFFFFF) if r < 0.08 else (c | 0xFF000000 if r < 0.5 else c)
+
+    def shape():
+        s.begin_path()
+        k = int(rs.randint(0, 7))
+        x, y = float(u(20, 900)), float(u(20, 500))
+        if k == 0:
+            s.rect(x, y, float(u(5, 200)), float(u(5, 200)))
+        elif k == 1:
+            s.circle(x, y, float(u(2, 90)))
+        elif k == 2:
+            s.ellipse(x, y, float(u(2, 120)), float(u(2, 60)))
+        elif k == 3:
+            s.rounded_rect(x, y, float(u(20, 200)), float(u(20, 120)), float(u(0.0, 25)))
+        elif k == 4:  # closed polygon of line segments and curves
+            n = int(rs.randint(3, 9))
+            ang = np.sort(u(0, 2 * np.pi, size=n))
+            rad = u(20, 120, size=n)
+            pts = np.stack([x + rad * np.cos(ang), y + rad * np.sin(ang)], 1)
+            s.move_to(*pts[0])
+            for i in range(1, n):
+                if u() < 0.5:
+                    s.line_to(*pts[i])
+                else:
+                    m = (pts[i - 1] + pts[i]) * 0.5 + u(-15, 15, size=2)
+                    s.quadratic_to(m[0], m[1], pts[i][0], pts[i][1])
+            s.close_path()
+        elif k == 5:  # open polyline / cubic strip, stroked with caps
+            s.move_to(x, y)
+            for i in range(int(rs.randint(1, 6))):
+                if u() < 0.5:
+                    s.line_to(x + float(u(-150, 150)), y + float(u(-150, 150)))
+                else:
+                    s.cubic_to(*[float(v) for v in (x + u(-150, 150), y + u(-150, 150), x + u(-150, 150), y + u(-150, 150), x + u(-150, 150), y + u(-150, 150))])
+        else:  # two sub-paths in one path
+            s.rect(x, y, float(u(10, 80)), float(u(10, 80)))
+            s.circle(x + 100, y, float(u(5, 40)))
+
+    def paint():
+        aa = AA if u() < 0.7 else NOAA
+        sf = R.stroke_flags(int(rs.randint(0, 3)), int(rs.randint(0, 3)), bool(u() < 0.8), bool(u() < 0.15))
+        w = float(rs.choice([0.3, 0.8, 1.0, 2.5, 7.0, 25.0]))
+        k = int(rs.randint(0, 6))
+        if in_clip:  # the reference VG_CHECKs that only fillPath(Color) / strokePath(Color) are used inside BeginClip .. EndClip
+            k = 0 if k < 3 else 3
+        if k in (1, 4) and ngrad == 0:
+            k -= 1
+        if k in (2, 5) and nimg == 0:
+            k = 0 if k == 2 else 3
+        if k == 0:
+            s.fill(col(), aa)
+        elif k == 1:
+            s.fill_gradient(int(rs.randint(0, ngrad)) | LOCAL, aa)
+        elif k == 2:
+            s.fill_image(int(rs.randint(0, nimg)) | LOCAL, col(), aa)
+        elif k == 3:
+            s.stroke(col(), w, sf)
+        elif k == 4:
+            s.stroke_gradient(int(rs.randint(0, ngrad)) | LOCAL, w, sf)
+        else:
+            s.stroke_image(int(rs.randint(0, nimg)) | LOCAL, col(), w, sf)
+
+    for _ in range(int(rs.randint(25, 60))):
+        r = u()
+        if r < 0.45:
+            shape()
+            for _ in range(int(rs.randint(1, 4))):
+                paint()
+                if u() < 0.15:
+                    s.translate(float(u(-20, 20)), float(u(-20, 20)))  # after the first paint: the path stays latched
+        elif r < 0.55 and ngrad < 20:
+            k = int(rs.randint(0, 3))
+            if k == 0:
+                s.linear_gradient(float(u(0, 500)), float(u(0, 300)), float(u(0, 500)), float(u(0, 300)), col(), col())
+            elif k == 1:
+                s.box_gradient(float(u(0, 500)), float(u(0, 300)), float(u(10, 200)), float(u(10, 200)), float(u(0, 30)), float(u(1, 40)), col(), col())
+            else:
+                s.radial_gradient(float(u(0, 500)), float(u(0, 300)), float(u(1, 50)), float(u(51, 200)), col(), col())
+            ngrad += 1
+        elif r < 0.60 and nimg < 10:
+            s.image_pattern(float(u(0, 300)), float(u(0, 300)), float(u(8, 128)), float(u(8, 128)), float(u(0, 6.2)), 0)
+            nimg += 1
+        elif r < 0.68:
+            s.push()
+            depth += 1
+            k = int(rs.randint(0, 4))
+            if k == 0:
+                s.translate(float(u(-100, 100)), float(u(-100, 100)))
+            elif k == 1:
+                s.rotate(float(u(-3, 3)))
+            elif k == 2:
+                s.scale(float(u(0.3, 3.0)), float(u(0.3, 3.0)))
+            else:
+                s.global_alpha(float(u(0.0, 1.0)))
+        elif r < 0.76 and depth > 0:
+            s.pop()
+            depth -= 1
+        elif r < 0.82:
+            k = int(rs.randint(0, 3))
+            if k == 0:
+                s.set_scissor(float(u(0, 600)), float(u(0, 300)), float(u(1, 700)), float(u(1, 500)))
+            elif k == 1:
+                s.intersect_scissor(float(u(0, 600)), float(u(0, 300)), float(u(1, 700)), float(u(1, 500)))
+            else:
+                s.reset_scissor()
+        elif r < 0.88 and not in_clip:
+            s.begin_clip(int(rs.randint(0, 2)))
+            in_clip = True
+        elif r < 0.94 and in_clip:
+            s.end_clip()
+            in_clip = False
+        elif r < 0.97 and not in_clip:  # "must be called outside beginClip() / endClip()" (vg.cpp:3700)
+            s.reset_clip()
+        else:
+            s.global_alpha(float(u(0.2, 1.0)))
+    if in_clip:
+        s.end_clip()
+    while depth > 0:
+        s.pop()
+        depth -= 1
+    return s
+
+
+@pytest.mark.parametrize("seed", list(range(40)) + [4026, 4098, 4851])
+def test_random_frames_match_the_reference(rt, wl, oracle, seed):
+    """Forty random frames recorded with the reference's own writers and played by its own interpreter, against
+    vgx_cmdlist_decode + the reference's tessellator + the restated assembler: every buffer and command table bit for bit."""
+    script = s_random(1000 + seed)
+    max_vb = 65536 if seed % 2 else 8192
+    ref = F.reference_frame(script, max_vb=max_vb)
+    ps, draws, n, extra = F.decode(rt, ref)
+    assert n["skipped"] == 0
+    if len(ref["frame"].drawcmds) == 0:
+        # a frame without a single draw command (everything transparent, or recorded as clip geometry): vg::end() returns before
+        # it hands anything to bgfx (vg.cpp:1076-1083), so there is nothing to compare but the absence of ordinary draws
+        assert not (((draws["state_key"] >> 16) & 3) != 3).any()
+        return
+    res, cmds, idx = F.cpu_frame(oracle, ps, draws, max_vb)
+    F.assert_frame_equal(ref["frame"], res.pos, res.color, idx, res.meshes, cmds, draws, extra["draw_state"], max_vb, what="random %d" % seed)
+
+
 SCENARIOS = {"tiger": s_tiger, "paints": s_paints, "scissor_clip": s_scissor_clip, "latch": s_latch, "every_command": s_every_command}
 
 
@@ -377,6 +529,22 @@ def test_gpu_frame_matches_reference_frame(rt, wl, gpu_ctx, name, max_vb):
     got = gpu_frame(rt, gpu_ctx, ps, draws, max_vb, uv_bytes=nb, uv_value=int(white[0]))
     F.assert_frame_equal(ref["frame"], got["pos"], got["color"], got["idx"], got["meshes"], got["cmds"], draws, extra["draw_state"], max_vb,
                          uv=got["uv"], what=name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_gpu_random_frames_match_the_reference(rt, wl, gpu_ctx, seed):
+    """The random frames of test_random_frames_match_the_reference through the device: decode -> vgx_tessellate with assembly
+    armed (state-key splits, UV stream) against what the reference's own Context hands to bgfx."""
+    script = s_random(1000 + seed)
+    max_vb = 65536 if seed % 2 else 8192
+    ref = F.reference_frame(script, max_vb=max_vb)
+    ps, draws, n, extra = F.decode(rt, ref)
+    assert n["skipped"] == 0 and len(ref["frame"].drawcmds) > 0
+    white, nb = ref["white_uv"]
+    got = gpu_frame(rt, gpu_ctx, ps, draws, max_vb, uv_bytes=nb, uv_value=int(white[0]))
+    F.assert_frame_equal(ref["frame"], got["pos"], got["color"], got["idx"], got["meshes"], got["cmds"], draws, extra["draw_state"], max_vb,
+                         uv=got["uv"], what="random %d" % seed)
 
 
 @pytest.mark.gpu

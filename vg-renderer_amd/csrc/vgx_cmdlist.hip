@@ -158,13 +158,14 @@ struct Decoder
 					vgx_draw_state& ds = out->draw_state[ndraws];
 					memcpy(ds.scissor, sc, sizeof(sc));
 					if (type == DT_Clip) { ds.clip_rule = 0; ds.clip_first_draw = 0xFFFFFFFFu; ds.clip_num_draws = 0; } // allocClipCommand, vg.cpp:5449-5450
-					else { ds.clip_rule = clipRule; ds.clip_first_draw = clipFirst; ds.clip_num_draws = clipNum; }
+					// a non-clip draw INSIDE an open region (gradient / image-pattern paints do not look at m_RecordClipCommands) sees the
+					// region still empty: ctxBeginClip sets m_NumCmds = 0, ctxEndClip fills it in (vg.cpp:3670-3697)
+					else { ds.clip_rule = clipRule; ds.clip_first_draw = clipFirst; ds.clip_num_draws = recordClip ? 0u : clipNum; }
 					ds.reserved = 0;
 				}
 			}
 		}
 		if (type != DT_Clip) { memcpy(lastScissor, sc, sizeof(sc)); haveLastScissor = true; }
-		if (recordClip && type == DT_Clip) { ++clipNum; }
 		++ndraws;
 	}
 
@@ -335,7 +336,9 @@ int Decoder::run(const uint8_t* p, uint32_t size, uint32_t listFlags)
 			clipRule = u32at(0); clipFirst = ndraws; clipNum = 0;
 			recordClip = true; forceNew = true;
 			break;
-		case CT_EndClip: recordClip = false; forceNew = true; break; // :3685-3697
+		case CT_EndClip: // :3685-3697. The region = the Clip draws among [clipFirst, clipFirst + clipNum): other draws may lie between them
+			if (recordClip) { clipNum = ndraws - clipFirst; }
+			recordClip = false; forceNew = true; break;
 		case CT_ResetClip: // :3699-3709
 			if (clipFirst != 0xFFFFFFFFu) { clipFirst = 0xFFFFFFFFu; clipNum = 0; forceNew = true; }
 			break;

@@ -141,8 +141,9 @@ def s_every_command(wl):
     return s
 
 
-def s_random(seed):
-    """A random frame: shapes, all six paint commands with local gradients / image patterns, balanced push / pop with
+def s_random(seed, nchildren=0, top=True):
+    """A random frame (nchildren > 0: the list also submits child lists 0 .. nchildren - 1; top = False: a child list, which
+    must not leave a clip region or pushed states behind -- it does neither anyway): shapes, all six paint commands with local gradients / image patterns, balanced push / pop with
     transforms and global alpha, scissor changes, clip regions, several paints per path (latch), transparent colours."""
     rs = np.random.RandomState(seed)
     s = Script()
@@ -237,21 +238,29 @@ def s_random(seed):
         elif r < 0.68:
             s.push()
             depth += 1
-            k = int(rs.randint(0, 4))
+            k = int(rs.randint(0, 7))
             if k == 0:
                 s.translate(float(u(-100, 100)), float(u(-100, 100)))
             elif k == 1:
                 s.rotate(float(u(-3, 3)))
             elif k == 2:
                 s.scale(float(u(0.3, 3.0)), float(u(0.3, 3.0)))
-            else:
+            elif k == 3:
                 s.global_alpha(float(u(0.0, 1.0)))
+            elif k == 4:
+                s.mult([float(v) for v in (u(0.5, 1.5), u(-0.5, 0.5), u(-0.5, 0.5), u(0.5, 1.5), u(-50, 50), u(-50, 50))], bool(u() < 0.5))
+            elif k == 5:
+                s.view_box(float(u(0, 200)), float(u(0, 200)), float(u(300, 1500)), float(u(200, 900)))
+            else:
+                s.identity()
         elif r < 0.76 and depth > 0:
             s.pop()
             depth -= 1
         elif r < 0.82:
             k = int(rs.randint(0, 3))
-            if k == 0:
+            if k == 0 and u() < 0.15:
+                s.set_scissor(float(u(1300, 3000)), float(u(800, 3000)), float(u(1, 700)), float(u(1, 500)))  # off the canvas: zero sized (culling)
+            elif k == 0:
                 s.set_scissor(float(u(0, 600)), float(u(0, 300)), float(u(1, 700)), float(u(1, 500)))
             elif k == 1:
                 s.intersect_scissor(float(u(0, 600)), float(u(0, 300)), float(u(1, 700)), float(u(1, 500)))
@@ -265,6 +274,8 @@ def s_random(seed):
             in_clip = False
         elif r < 0.97 and not in_clip:  # "must be called outside beginClip() / endClip()" (vg.cpp:3700)
             s.reset_clip()
+        elif r < 0.985 and nchildren > 0 and not in_clip:
+            s.submit(int(rs.randint(0, nchildren)))
         else:
             s.global_alpha(float(u(0.2, 1.0)))
     if in_clip:
@@ -291,6 +302,24 @@ def test_random_frames_match_the_reference(rt, wl, oracle, seed):
         return
     res, cmds, idx = F.cpu_frame(oracle, ps, draws, max_vb)
     F.assert_frame_equal(ref["frame"], res.pos, res.color, idx, res.meshes, cmds, draws, extra["draw_state"], max_vb, what="random %d" % seed)
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_frames_with_culling_and_nested_lists(rt, wl, oracle, seed):
+    """Random parents that submit random children (local handles per submission, state leaking out of a child), and lists with
+    CommandListFlags::AllowCommandCulling under scissors that are sometimes empty."""
+    nchild = seed % 3
+    flags = R.CL_ALLOW_CULLING if seed % 2 else 0
+    children = [(s_random(2000 + 10 * seed + c, top=False), 0) for c in range(nchild)]
+    script = s_random(3000 + seed, nchildren=nchild)
+    ref = F.reference_frame(script, flags=flags, children=children)
+    ps, draws, n, extra = F.decode(rt, ref, flags=flags)
+    assert n["skipped"] == 0
+    if len(ref["frame"].drawcmds) == 0:
+        assert not (((draws["state_key"] >> 16) & 3) != 3).any()
+        return
+    res, cmds, idx = F.cpu_frame(oracle, ps, draws, 65536)
+    F.assert_frame_equal(ref["frame"], res.pos, res.color, idx, res.meshes, cmds, draws, extra["draw_state"], 65536, what="nested random %d" % seed)
 
 
 SCENARIOS = {"tiger": s_tiger, "paints": s_paints, "scissor_clip": s_scissor_clip, "latch": s_latch, "every_command": s_every_command}

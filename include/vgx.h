@@ -298,7 +298,10 @@ typedef struct vgx_cache_desc {   /* CommandListCache::m_Meshes as four streams:
 typedef struct vgx_cache_instance { /* one submission of a cached command (clCacheRender, vg.cpp:5845-6135). 40 bytes */
 	uint64_t first_mesh;          /* CachedCommand::m_FirstMeshID */
 	uint32_t num_meshes;          /* CachedCommand::m_NumMeshes */
-	uint32_t reserved;
+	uint32_t color;               /* the Color operand of the fill / stroke command being replayed (clCacheRender hands it to
+	                               * submitCachedMesh, vg.cpp:5896-5902): meshes cached WITHOUT per-vertex colours -- the non-AA
+	                               * flavours, numColors == 1 in addCachedCommand (:5826-5834) -- are drawn with it
+	                               * (:6159-6160), the AA flavours with the colours stored at cache time */
 	float mtx[6];                 /* State::m_TransformMtx at submission */
 } vgx_cache_instance;
 
@@ -306,7 +309,8 @@ typedef struct vgx_cache_instance { /* one submission of a cached command (clCac
  * reference's arithmetic (vgutil::invertMatrix3 in double precision, vg_util.cpp:14-33; transformPos2D). In place. */
 int vgx_cache_localize(vgx_ctx* ctx, const vgx_draw* draws, uint64_t ndraws, float* pos, const vgx_mesh* meshes, uint64_t num_meshes, void* stream);
 /* submitCachedMesh for `ninst` instances in order: for every mesh of every instance's range, positions through the
- * instance transform (batchTransformPositions), colours and indices copied; mesh records get the instance index as
+ * instance transform (batchTransformPositions), colours (stored ones for AA meshes, the instance's colour for non-AA meshes)
+ * and indices copied; mesh records get the instance index as
  * `draw`. Asynchronous like vgx_tessellate (capacities checked on the device, totals in dev_sizes, status in
  * dev_status); honours vgx_set_assembly (createDrawCommand_VertexColor is what submitCachedMesh calls). */
 int vgx_cache_submit(vgx_ctx* ctx, const vgx_cache_desc* cache, const vgx_cache_instance* instances, uint64_t ninst, const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream);
@@ -405,7 +409,8 @@ typedef struct vgx_draw_state {   /* per draw: what allocDrawCommand copies into
 	                               * them); 0xFFFFFFFF = none. A draw recorded while the region is still open sees it empty
 	                               * (clip_num_draws = 0), as in the reference (vg.cpp:3670-3697) */
 	uint32_t clip_num_draws;
-	uint32_t reserved;
+	uint32_t raw_color;           /* the Color operand of the fill / stroke command as recorded (0 for gradient paints): what a
+	                               * replay from the shape cache uses for non-AA meshes (vgx_cache_instance::color) */
 } vgx_draw_state;
 typedef struct vgx_paint {        /* vg::Gradient / vg::ImagePattern as the Create* calls compute them (vg.cpp:84-96). 96 bytes */
 	uint32_t type;                /* DrawCommand::Type of the draws that use it: 1 ColorGradient, 2 ImagePattern */

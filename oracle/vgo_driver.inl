@@ -368,7 +368,12 @@ int vgo_cache_submit(const vgx_cache_desc* cache, const vgx_cache_instance* inst
 					overflow = true;
 				} else {
 					VGO_XFORM(cache->pos + 2 * src.first_vertex, src.num_vertices, out->pos + 2 * nv, inst[i].mtx);
-					memcpy(out->color + nv, cache->color + src.first_vertex, sizeof(uint32_t) * src.num_vertices);
+					const uint32_t kind = src.subpath_kind >> 28;
+					if (kind == VGX_MESH_FILL || kind == VGX_MESH_STROKE) { // cached without colours (numColors == 1, vg.cpp:5826-5834): the replaying command's colour (:6159-6160)
+						for (uint32_t v = 0; v < src.num_vertices; ++v) { out->color[nv + v] = inst[i].color; }
+					} else {
+						memcpy(out->color + nv, cache->color + src.first_vertex, sizeof(uint32_t) * src.num_vertices);
+					}
 					memcpy(out->idx + ni, cache->idx + src.first_index, sizeof(uint16_t) * src.num_indices);
 					if (out->meshes) {
 						vgx_mesh r = src;

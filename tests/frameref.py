@@ -142,7 +142,7 @@ def cpu_frame(oracle, ps, draws, max_vb):
     return res, cmds, idx
 
 
-def cache_instances(capi, meshes, draws_now):
+def cache_instances(capi, meshes, draws_now, dstate_now=None):
     """One vgx_cache_instance per draw (= per CachedCommand, vg.cpp:5773-5806): its mesh range in the cached drawing and the
     transform the state has when the fill / stroke command is replayed (submitCachedMesh, :6137-6166)."""
     n = draws_now.shape[0]
@@ -153,4 +153,6 @@ def cache_instances(capi, meshes, draws_now):
     inst["first_mesh"] = first
     inst["num_meshes"] = last - first
     inst["mtx"] = draws_now["mtx"]
+    if dstate_now is not None:
+        inst["color"] = dstate_now["raw_color"]  # what clCacheRender hands to submitCachedMesh: the command's Color operand
     return inst

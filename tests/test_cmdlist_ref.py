@@ -510,11 +510,85 @@ def test_shape_cache_cpu(rt, wl, oracle):
     check_local_cache(f2["cache"], res.pos, res.color, res.idx, res.meshes, d1)
     # frame 2: every cached command re-submitted under the transform its fill / stroke command sees now
     ps2, d2, n2, extra2 = F.decode(rt, f2, flags=R.CL_CACHEABLE)
-    inst = F.cache_instances(rt.capi, res.meshes, d2)
+    inst = F.cache_instances(rt.capi, res.meshes, d2, extra2["draw_state"])
     got = oracle.cache_submit(res, inst)
     st, cmds2, idx2 = oracle.assemble(got.meshes, got.idx, 65536)
     assert st == 0
     F.assert_frame_equal(f2["frame"], got.pos, got.color, idx2, got.meshes, cmds2, d2, None, 65536, what="cached frame")
+
+
+def s_random_cacheable(seed):
+    """A random Cacheable list within what the cache reproduces exactly: colour fills and strokes, transforms that change only
+    between paths (see s_cached_drawing)."""
+    rs = np.random.RandomState(seed)
+    u = rs.uniform
+    s = Script()
+    for _ in range(int(rs.randint(1, 5))):
+        s.push()
+        for _ in range(int(rs.randint(0, 3))):
+            k = int(rs.randint(0, 3))
+            if k == 0:
+                s.translate(float(u(-80, 80)), float(u(-80, 80)))
+            elif k == 1:
+                s.rotate(float(u(-3, 3)))
+            else:
+                s.scale(float(u(0.5, 2.0)), float(u(0.5, 2.0)))
+        for _ in range(int(rs.randint(1, 6))):
+            s.begin_path()
+            k = int(rs.randint(0, 5))
+            x, y = float(u(0, 600)), float(u(0, 400))
+            if k == 0:
+                s.rect(x, y, float(u(5, 150)), float(u(5, 150)))
+            elif k == 1:
+                s.circle(x, y, float(u(3, 70)))
+            elif k == 2:
+                s.rounded_rect(x, y, float(u(20, 150)), float(u(20, 100)), float(u(0, 20)))
+            elif k == 3:
+                s.move_to(x, y).cubic_to(x + 40, y - 60, x + 120, y + 80, x + 160, y).line_to(x + 80, y + 90).close_path()
+            else:
+                s.ellipse(x, y, float(u(5, 90)), float(u(5, 50)))
+            for _ in range(int(rs.randint(1, 3))):
+                c = int(rs.randint(0, 1 << 32, dtype=np.uint64)) | 0x20000000
+                if u() < 0.55:
+                    s.fill(c, AA if u() < 0.7 else NOAA)
+                else:
+                    s.stroke(c, float(rs.choice([0.4, 1.0, 3.0, 12.0])), R.stroke_flags(int(rs.randint(0, 3)), int(rs.randint(0, 3)), bool(u() < 0.8)))
+        s.pop()
+    return s
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_shape_cache_random_drawings(rt, wl, oracle, seed):
+    """Random Cacheable lists over nine frames of one Context: a frame whose state has the cache's average scale is rendered from the
+    cache, any other frame (the first; rotations that move the scale by an ulp) fills it again (global alpha ignored). The reference's CommandListCache ==
+    the tessellated + localised batch; the frames rendered from the cache == vgx_cache_submit's restatement, bit for bit."""
+    rs = np.random.RandomState(900 + seed)
+    pres = [Script().global_alpha(float(rs.uniform(0.2, 1.0))).translate(float(rs.uniform(0, 200)), float(rs.uniform(0, 100))).rotate(float(rs.uniform(-1, 1)))]
+    for _ in range(4):  # translations keep the average scale; most rotations do too, some change its last bit
+        pres.append(Script().translate(float(rs.uniform(0, 400)), float(rs.uniform(0, 300))))
+        pres.append(Script().translate(float(rs.uniform(0, 400)), float(rs.uniform(0, 300))).rotate(float(rs.uniform(-3, 3))))
+    frames = F.reference_frames(s_random_cacheable(700 + seed), pres, flags=R.CL_CACHEABLE)
+    res, d_cached, scale, from_cache = None, None, None, 0
+    for k, fk in enumerate(frames):
+        assert fk["cache"] is not None
+        psk, dk, nk, extrak = F.decode(rt, fk, flags=R.CL_CACHEABLE)
+        if res is None or fk["cache"]["avg_scale"] != scale:
+            # the list (re)builds its cache in this frame: a rotation changes the state's average scale in the last bit
+            # (mean of the column norms, vg.cpp:4927-4935), which invalidates the cache (:4284-4300). Drawn while caching.
+            res, cmds, idx = F.cpu_frame(oracle, psk, dk, 65536)
+            F.assert_frame_equal(fk["frame"], res.pos, res.color, idx, res.meshes, cmds, dk, extrak["draw_state"], 65536, what="caching frame %d.%d" % (seed, k))
+            oracle.cache_localize(dk, res)
+            d_cached, scale = dk, fk["cache"]["avg_scale"]
+            check_local_cache(fk["cache"], res.pos, res.color, res.idx, res.meshes, d_cached)
+            continue
+        from_cache += 1
+        check_local_cache(fk["cache"], res.pos, res.color, res.idx, res.meshes, d_cached)
+        inst = F.cache_instances(rt.capi, res.meshes, dk, extrak["draw_state"])
+        got = oracle.cache_submit(res, inst)
+        st, cmdsk, idxk = oracle.assemble(got.meshes, got.idx, 65536)
+        assert st == 0
+        F.assert_frame_equal(fk["frame"], got.pos, got.color, idxk, got.meshes, cmdsk, dk, None, 65536, what="cached frame %d.%d" % (seed, k))
+    assert from_cache >= 1  # the pure translations at least
 
 
 # ---- GPU: the same frames through vgx_tessellate + vgx_set_assembly ------------------------------------------------------------
@@ -592,10 +666,16 @@ def test_gpu_nested_lists(rt, wl, gpu_ctx):
 
 
 @pytest.mark.gpu
-def test_shape_cache_gpu(rt, wl, gpu_ctx):
-    """vgx_cache_localize == the reference's CommandListCache, vgx_cache_submit == the frame the reference renders from it."""
+@pytest.mark.parametrize("source", ["tiger", 700, 703, 705])
+def test_shape_cache_gpu(rt, wl, gpu_ctx, source):
+    """vgx_cache_localize == the reference's CommandListCache, vgx_cache_submit == the frame the reference renders from it
+    (random drawings: non-AA meshes replayed with the command's colour, thin non-AA strokes included)."""
     import torch
-    f1, f2 = cached_frames(wl)
+    if source == "tiger":
+        f1, f2 = cached_frames(wl)
+    else:  # a pure translation keeps the average scale: frame 2 is rendered from the cache
+        f1, f2 = F.reference_frames(s_random_cacheable(source), [Script().global_alpha(0.4).rotate(0.3), Script().translate(123.0, 45.0).rotate(0.3)], flags=R.CL_CACHEABLE)
+        assert f2["cache"]["avg_scale"] == f1["cache"]["avg_scale"]
     ps, d1, n, extra = F.decode(rt, f1, flags=R.CL_CACHEABLE)
     pset = rt.PathSet(gpu_ctx, ps)
     dd = rt.upload_draws(d1)
@@ -610,7 +690,7 @@ def test_shape_cache_gpu(rt, wl, gpu_ctx):
     check_local_cache(f2["cache"], bufs.pos[:nv].cpu().numpy(), bufs.color[:nv].cpu().numpy().view(np.uint32),
                       bufs.idx[:ni].cpu().numpy().view(np.uint16), meshes, d1)
     ps2, d2, n2, extra2 = F.decode(rt, f2, flags=R.CL_CACHEABLE)
-    inst = F.cache_instances(rt.capi, meshes, d2)
+    inst = F.cache_instances(rt.capi, meshes, d2, extra2["draw_state"])
     raw = torch.from_numpy(np.ascontiguousarray(inst).view(np.uint8).reshape(-1).copy()).to("cuda:0")
     out = rt.MeshBuffers(raw.device, nv, ni, nm)
     cmds = torch.zeros((nm + 2) * 48, dtype=torch.uint8, device="cuda:0")

@@ -23,6 +23,7 @@ def make_instances(rs, res, per_draw_ranges, n):
         b = int(rs.randint(a, min(nm, a + 40) + 1))
         inst["first_mesh"][i] = a
         inst["num_meshes"][i] = b - a
+        inst["color"][i] = int(rs.randint(0, 1 << 32, dtype=np.uint64))  # drawn on the meshes cached without colours (non-AA)
         ang = rs.uniform(0, 6.28)
         sc = rs.uniform(0.5, 2.0)
         inst["mtx"][i] = [sc * np.cos(ang), sc * np.sin(ang), -sc * np.sin(ang), sc * np.cos(ang), rs.uniform(-500, 500), rs.uniform(-500, 500)]

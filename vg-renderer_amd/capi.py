@@ -94,7 +94,7 @@ class FlatOut(C.Structure):
                 ("cap_poly_vertices", C.c_uint64), ("cap_subpaths", C.c_uint64)]
 
 
-cache_instance_dtype = np.dtype([("first_mesh", "<u8"), ("num_meshes", "<u4"), ("reserved", "<u4"), ("mtx", "<f4", (6,))])
+cache_instance_dtype = np.dtype([("first_mesh", "<u8"), ("num_meshes", "<u4"), ("color", "<u4"), ("mtx", "<f4", (6,))])
 assert cache_instance_dtype.itemsize == 40
 
 
@@ -143,7 +143,7 @@ class CmdListOut(C.Structure):
                 ("end_mtx", C.c_float * 6), ("end_global_alpha", C.c_float), ("reserved", C.c_uint32)]
 
 
-draw_state_dtype = np.dtype([("scissor", "<u2", (4,)), ("clip_rule", "<u4"), ("clip_first_draw", "<u4"), ("clip_num_draws", "<u4"), ("reserved", "<u4")])
+draw_state_dtype = np.dtype([("scissor", "<u2", (4,)), ("clip_rule", "<u4"), ("clip_first_draw", "<u4"), ("clip_num_draws", "<u4"), ("raw_color", "<u4")])
 paint_dtype = np.dtype([("type", "<u4"), ("handle", "<u4"), ("matrix", "<f4", (9,)), ("params", "<f4", (4,)), ("inner_color", "<f4", (4,)),
                         ("outer_color", "<f4", (4,)), ("image", "<u4")])
 assert draw_state_dtype.itemsize == 24 and paint_dtype.itemsize == 96

@@ -131,6 +131,24 @@ __global__ __launch_bounds__(VGX_WAVE) void k_cache_copy_flat(VgxCacheArgs A)
 	}
 }
 
+// Meshes cached WITHOUT per-vertex colours (the non-AA flavours: CachedMesh::m_Colors == nullptr, addCachedCommand
+// vg.cpp:5826-5834) are drawn with the colour of the command that replays them (submitCachedMesh :6159-6160), not with what
+// the caching frame wrote -- the two differ for thin non-AA strokes, whose alpha ctxStrokePathColor scales only while
+// caching. After the flat copy: one lane per output mesh, AA meshes are skipped at once.
+__global__ __launch_bounds__(256) void k_cache_uniform_colors(VgxCacheArgs A)
+{
+	if (A.totals->status != VGX_OK) { return; }
+	const uint64_t P = A.totals->sizes.num_meshes;
+	for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (uint64_t)gridDim.x * blockDim.x) {
+		const vgx_mesh m = A.mtab[p];
+		const uint32_t kind = m.subpath_kind >> 28;
+		if (kind != VGX_MESH_FILL && kind != VGX_MESH_STROKE) { continue; }
+		const uint32_t c = A.inst[m.draw].color; // draw = instance index (k_cache_meshes)
+		uint32_t* dc = A.color + m.first_vertex;
+		for (uint32_t v = 0; v < m.num_vertices; ++v) { dc[v] = c; }
+	}
+}
+
 // Assembly armed: every mesh has its own index base -> one wave per output mesh for the index stream.
 __global__ __launch_bounds__(VGX_WAVE) void k_cache_copy_idx_mesh(VgxCacheArgs A)
 {
@@ -180,6 +198,7 @@ void vgx_launch_cache_meshes(const VgxCacheArgs& a, hipStream_t s)
 void vgx_launch_cache_copy(const VgxCacheArgs& a, int numBlocks, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_cache_copy_flat<0>, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
+	hipLaunchKernelGGL(k_cache_uniform_colors, dim3(2048), dim3(256), 0, s, a);
 	if (a.mesh_base) {
 		hipLaunchKernelGGL(k_cache_copy_idx_mesh, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
 	} else {

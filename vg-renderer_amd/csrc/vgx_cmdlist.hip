@@ -137,6 +137,7 @@ struct Decoder
 	// transformPath (vg.cpp:4957-4975): the first caller fixes the matrix the path's vertices are transformed with
 	void latch() { if (!transformed) { memcpy(pathMtx, S().m, sizeof(pathMtx)); transformed = true; } }
 
+	uint32_t rawColor = 0; // Color operand of the paint command being decoded (vgx_draw_state::raw_color)
 	void emit(uint32_t type, uint32_t handle, uint32_t fillFlags, uint32_t fillColor, uint32_t strokeFlags, uint32_t strokeColor, float strokeWidth)
 	{
 		const St& s = S();
@@ -161,7 +162,7 @@ struct Decoder
 					// a non-clip draw INSIDE an open region (gradient / image-pattern paints do not look at m_RecordClipCommands) sees the
 					// region still empty: ctxBeginClip sets m_NumCmds = 0, ctxEndClip fills it in (vg.cpp:3670-3697)
 					else { ds.clip_rule = clipRule; ds.clip_first_draw = clipFirst; ds.clip_num_draws = recordClip ? 0u : clipNum; }
-					ds.reserved = 0;
+					ds.raw_color = rawColor;
 				}
 			}
 		}
@@ -269,6 +270,7 @@ int Decoder::run(const uint8_t* p, uint32_t size, uint32_t listFlags)
 			const bool img = type == CT_FillPathImagePattern;
 			if (!need(img ? 12u : 8u)) { return VGX_E_INVALID_ARG; }
 			const uint32_t flags = u32at(0), color = u32at(4);
+			rawColor = color;
 			const bool clip = recordClip && !img;
 			const uint32_t col = clip ? kBlack : scaledColor(color, globalAlpha());
 			if (!clip && !hasCache && (col >> 24) == 0) { break; } // transparent: the reference returns before transformPath
@@ -283,6 +285,7 @@ int Decoder::run(const uint8_t* p, uint32_t size, uint32_t listFlags)
 		case CT_FillPathGradient: { // uint32 flags, uint16 handle, uint16 handle flags (:2629-2638); ctxFillPathGradient :3181-3284
 			if (!need(8)) { return VGX_E_INVALID_ARG; }
 			const uint32_t flags = u32at(0);
+			rawColor = 0;
 			if (!havePath) { ++nskipped; break; }
 			latch();
 			if (flags & 0x01u) { ++nskipped; break; }
@@ -295,6 +298,7 @@ int Decoder::run(const uint8_t* p, uint32_t size, uint32_t listFlags)
 		case CT_StrokePathColor: { // float width, uint32 flags, Color (vg.cpp:2660-2669); ctxStrokePathColor :3401-3492
 			if (!need(12)) { return VGX_E_INVALID_ARG; }
 			const float width = f32at(0); const uint32_t flags = u32at(4), color = u32at(8);
+			rawColor = color;
 			const Width w = strokeWidth(width, flags);
 			const float ga = globalAlpha();
 			const float c = clampf(w.scaled, 0.0f, fringe);
@@ -309,6 +313,7 @@ int Decoder::run(const uint8_t* p, uint32_t size, uint32_t listFlags)
 		case CT_StrokePathGradient: { // float width, uint32 flags, uint16 handle, uint16 handle flags (:2671-2681); ctxStrokePathGradient :3494-3576
 			if (!need(12)) { return VGX_E_INVALID_ARG; }
 			const float width = f32at(0); const uint32_t flags = u32at(4);
+			rawColor = 0;
 			if (!havePath) { ++nskipped; break; }
 			const bool aa = (flags & 0x10u) != 0;
 			latch();
@@ -319,6 +324,7 @@ int Decoder::run(const uint8_t* p, uint32_t size, uint32_t listFlags)
 		case CT_StrokePathImagePattern: { // float width, uint32 flags, Color, uint16 handle, uint16 handle flags (:2683-2695); ctxStrokePathImagePattern :3578-3668
 			if (!need(16)) { return VGX_E_INVALID_ARG; }
 			const float width = f32at(0); const uint32_t flags = u32at(4), color = u32at(8);
+			rawColor = color;
 			const Width w = strokeWidth(width, flags);
 			const float ga = globalAlpha();
 			const float c = clampf(w.scaled, 0.0f, fringe);

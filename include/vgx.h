@@ -399,6 +399,14 @@ typedef struct vgx_cmdlist_state { /* the Context / State values at submission *
 	uint16_t prev_cmd_scissor[4]; /* scissor of the frame's last draw command before this list (PopState rule, :3950-3965) */
 	uint32_t prev_cmd_valid;      /* 0: the frame has no draw command yet */
 	uint32_t first_generation;    /* generation of the first draw's state_key (chain successive decodes of one frame) */
+	/* Context::m_ClipState / m_RecordClipCommands at submission: a clip region outlives the list that recorded it (vg.cpp:71-76,
+	 * 3670-3709). All zero = no region. Indices are in the frame's draw numbering: this decode's draw i is draw draw_base + i. */
+	uint32_t clip_valid;          /* 1: a region is active (m_ClipState.m_FirstCmdID != ~0) */
+	uint32_t clip_rule;
+	uint32_t clip_first_draw;
+	uint32_t clip_num_draws;
+	uint32_t clip_recording;      /* 1: submitted between BeginClip and EndClip */
+	uint32_t draw_base;           /* draws decoded earlier in this frame */
 } vgx_cmdlist_state;
 typedef struct vgx_draw_state {   /* per draw: what allocDrawCommand copies into the DrawCommand (vg.cpp:5391-5400). 24 bytes */
 	uint16_t scissor[4];          /* (uint16_t) State::m_ScissorRect */
@@ -438,6 +446,9 @@ typedef struct vgx_cmdlist_out {
 	float end_mtx[6];         /* out: State::m_TransformMtx / m_GlobalAlpha after the list (state changes of a list leak into
 	                           * its caller unless VG_CONFIG_COMMAND_LIST_PRESERVE_STATE, vg.cpp:4323-4325) */
 	float end_global_alpha;
+	uint32_t end_clip_valid;  /* out: the clip state after the list, for the next decode's vgx_cmdlist_state::clip_* */
+	uint32_t end_clip_rule, end_clip_first_draw, end_clip_num_draws, end_clip_recording;
+	float end_scissor[4];     /* out: State::m_ScissorRect after the list */
 	uint32_t reserved;
 } vgx_cmdlist_out;
 int vgx_cmdlist_decode(const void* bytes, uint32_t size, const vgx_cmdlist_state* state, vgx_cmdlist_out* out);

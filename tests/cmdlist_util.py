@@ -72,7 +72,7 @@ class Recorder:
 
 
 def decode(rt, data, mtx=(1, 0, 0, 1, 0, 0), global_alpha=1.0, tess_tol=0.25, fringe=1.0, canvas=(1280.0, 720.0), flags=0,
-           lists=None, first_gradient=0, first_image_pattern=0, extra=None):
+           lists=None, first_gradient=0, first_image_pattern=0, extra=None, scissor=None, prev_cmd_scissor=None, first_generation=0, clip=None, draw_base=0):
     """vgx_cmdlist_decode, count pass + store pass. Returns (status, PathSetArrays or None, draws ndarray, info dict).
     lists: {handle: (bytes, flags)} for SubmitCommandList. extra: dict that receives draw_state / paints / the out struct."""
     import ctypes as C
@@ -86,6 +86,17 @@ def decode(rt, data, mtx=(1, 0, 0, 1, 0, 0), global_alpha=1.0, tess_tol=0.25, fr
     st.canvas_width, st.canvas_height = canvas
     st.flags = flags
     st.first_gradient = first_gradient; st.first_image_pattern = first_image_pattern
+    if scissor is not None:            # State::m_ScissorRect at submission (all zero = the whole canvas)
+        for i in range(4):
+            st.scissor[i] = float(scissor[i])
+    if prev_cmd_scissor is not None:   # scissor of the frame's last draw command so far (PopState rule, vg.cpp:3950-3965)
+        for i in range(4):
+            st.prev_cmd_scissor[i] = int(prev_cmd_scissor[i])
+        st.prev_cmd_valid = 1
+    st.first_generation = first_generation
+    st.draw_base = draw_base
+    if clip is not None:               # (valid, rule, first draw, draws, recording): the previous decode's end_clip_*
+        st.clip_valid, st.clip_rule, st.clip_first_draw, st.clip_num_draws, st.clip_recording = [int(x) for x in clip]
     keep = []
     if lists:
         n = max(lists) + 1

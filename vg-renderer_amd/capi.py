@@ -131,7 +131,9 @@ class CmdListState(C.Structure):
                 ("scissor", C.c_float * 4), ("first_gradient", C.c_uint32), ("first_image_pattern", C.c_uint32),
                 ("max_gradients", C.c_uint32), ("max_image_patterns", C.c_uint32), ("max_depth", C.c_uint32),
                 ("num_lists", C.c_uint32), ("lists", C.POINTER(CmdListRef)), ("prev_cmd_scissor", C.c_uint16 * 4),
-                ("prev_cmd_valid", C.c_uint32), ("first_generation", C.c_uint32)]
+                ("prev_cmd_valid", C.c_uint32), ("first_generation", C.c_uint32),
+                ("clip_valid", C.c_uint32), ("clip_rule", C.c_uint32), ("clip_first_draw", C.c_uint32), ("clip_num_draws", C.c_uint32),
+                ("clip_recording", C.c_uint32), ("draw_base", C.c_uint32)]
 
 
 class CmdListOut(C.Structure):
@@ -140,7 +142,9 @@ class CmdListOut(C.Structure):
                 ("cap_cmds", C.c_uint32), ("cap_args", C.c_uint32), ("cap_paths", C.c_uint32), ("cap_draws", C.c_uint32), ("cap_paints", C.c_uint32),
                 ("num_cmds", C.c_uint32), ("num_args", C.c_uint32), ("num_paths", C.c_uint32), ("num_draws", C.c_uint32), ("num_paints", C.c_uint32),
                 ("num_skipped", C.c_uint32), ("next_gradient", C.c_uint32), ("next_image_pattern", C.c_uint32), ("next_generation", C.c_uint32),
-                ("end_mtx", C.c_float * 6), ("end_global_alpha", C.c_float), ("reserved", C.c_uint32)]
+                ("end_mtx", C.c_float * 6), ("end_global_alpha", C.c_float),
+                ("end_clip_valid", C.c_uint32), ("end_clip_rule", C.c_uint32), ("end_clip_first_draw", C.c_uint32), ("end_clip_num_draws", C.c_uint32),
+                ("end_clip_recording", C.c_uint32), ("end_scissor", C.c_float * 4), ("reserved", C.c_uint32)]
 
 
 draw_state_dtype = np.dtype([("scissor", "<u2", (4,)), ("clip_rule", "<u4"), ("clip_first_draw", "<u4"), ("clip_num_draws", "<u4"), ("raw_color", "<u4")])

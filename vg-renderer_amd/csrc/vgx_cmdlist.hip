@@ -102,6 +102,7 @@ struct Decoder
 	// clip state (ClipState, vg.cpp:71-76) in units of draws
 	bool recordClip;
 	uint32_t clipRule, clipFirst, clipNum;
+	uint32_t drawBase; // this decode's draw i is draw drawBase + i of the frame (vgx_cmdlist_state::draw_base)
 	uint32_t nextGradient, nextImagePattern, maxGradients, maxImagePatterns;
 	uint32_t depth, maxDepth;
 
@@ -133,10 +134,12 @@ struct Decoder
 		closePathRecord();
 		havePath = true; transformed = false;
 		pathScale = S().avgScale;
+		subPts = 0; pathMaxPts = 0; pathCurved = false;
 	}
 	// transformPath (vg.cpp:4957-4975): the first caller fixes the matrix the path's vertices are transformed with
 	void latch() { if (!transformed) { memcpy(pathMtx, S().m, sizeof(pathMtx)); transformed = true; } }
 
+	uint32_t subPts = 0, pathMaxPts = 0; bool pathCurved = false; // vertex upper bound of the current path's line-only sub-paths
 	uint32_t rawColor = 0; // Color operand of the paint command being decoded (vgx_draw_state::raw_color)
 	void emit(uint32_t type, uint32_t handle, uint32_t fillFlags, uint32_t fillColor, uint32_t strokeFlags, uint32_t strokeColor, float strokeWidth)
 	{
@@ -166,7 +169,13 @@ struct Decoder
 				}
 			}
 		}
-		if (type != DT_Clip) { memcpy(lastScissor, sc, sizeof(sc)); haveLastScissor = true; }
+		// PopState compares the restored scissor with the frame's last draw COMMAND (vg.cpp:3950-3965), and a draw whose path
+		// yields no mesh allocates none (a filled 2-point path ...). The meshes are not known here; what is known is an upper
+		// bound of the vertex count of sub-paths made of line segments only -- draws that certainly have no mesh do not count.
+		// (A curve or coincident points can still leave a sub-path below the stroker's minimum: that case is not seen here.)
+		const bool isFill = fillFlags != 0;
+		const bool noMesh = !pathCurved && pathMaxPts < (isFill ? 3u : 2u);
+		if (type != DT_Clip && !noMesh) { memcpy(lastScissor, sc, sizeof(sc)); haveLastScissor = true; }
 		++ndraws;
 	}
 
@@ -225,6 +234,12 @@ int Decoder::run(const uint8_t* p, uint32_t size, uint32_t listFlags)
 		auto pathArgs = [&](uint8_t vt, const float* a, uint32_t nfloats) {
 			if (!havePath || transformed) { ++nskipped; return; }
 			pathCmd(vt, a, nfloats);
+			// most vertices any sub-path of this path can have, as far as line segments tell (see emit())
+			if (vt == VGX_CMD_MOVE_TO) { subPts = 1; }
+			else if (vt == VGX_CMD_LINE_TO) { subPts += 1; }
+			else if (vt == VGX_CMD_POLYLINE) { subPts += nfloats / 2; }
+			else if (vt != VGX_CMD_CLOSE) { pathCurved = true; } // curves, arcs, shapes: any number of vertices
+			if (subPts > pathMaxPts) { pathMaxPts = subPts; }
 		};
 		auto globalAlpha = [&]() { return hasCache ? 1.0f : S().alpha; };
 		// alpha of the colour a Color / ImagePattern fill or stroke hands to the stroker (:3071-3075 and siblings)
@@ -339,11 +354,11 @@ int Decoder::run(const uint8_t* p, uint32_t size, uint32_t listFlags)
 
 		case CT_BeginClip: // ctxBeginClip, vg.cpp:3670-3683
 			if (!need(4)) { return VGX_E_INVALID_ARG; }
-			clipRule = u32at(0); clipFirst = ndraws; clipNum = 0;
+			clipRule = u32at(0); clipFirst = drawBase + ndraws; clipNum = 0;
 			recordClip = true; forceNew = true;
 			break;
 		case CT_EndClip: // :3685-3697. The region = the Clip draws among [clipFirst, clipFirst + clipNum): other draws may lie between them
-			if (recordClip) { clipNum = ndraws - clipFirst; }
+			if (recordClip) { clipNum = drawBase + ndraws - clipFirst; }
 			recordClip = false; forceNew = true; break;
 		case CT_ResetClip: // :3699-3709
 			if (clipFirst != 0xFFFFFFFFu) { clipFirst = 0xFFFFFFFFu; clipNum = 0; forceNew = true; }
@@ -513,7 +528,9 @@ extern "C" int vgx_cmdlist_decode(const void* bytes, uint32_t size, const vgx_cm
 	D.forceNew = false; D.generation = st0->first_generation;
 	D.haveLastScissor = st0->prev_cmd_valid != 0;
 	memcpy(D.lastScissor, st0->prev_cmd_scissor, sizeof(D.lastScissor));
-	D.recordClip = false; D.clipRule = 0; D.clipFirst = 0xFFFFFFFFu; D.clipNum = 0;
+	D.drawBase = st0->draw_base;
+	D.recordClip = st0->clip_recording != 0; D.clipRule = st0->clip_valid ? st0->clip_rule : 0u;
+	D.clipFirst = st0->clip_valid ? st0->clip_first_draw : 0xFFFFFFFFu; D.clipNum = st0->clip_valid ? st0->clip_num_draws : 0u;
 	D.nextGradient = st0->first_gradient; D.nextImagePattern = st0->first_image_pattern;
 	D.maxGradients = st0->max_gradients ? st0->max_gradients : 64u;
 	D.maxImagePatterns = st0->max_image_patterns ? st0->max_image_patterns : 64u;
@@ -528,6 +545,10 @@ extern "C" int vgx_cmdlist_decode(const void* bytes, uint32_t size, const vgx_cm
 	out->next_generation = D.generation + (D.forceNew ? 1u : 0u);
 	memcpy(out->end_mtx, D.S().m, sizeof(float) * 6);
 	out->end_global_alpha = D.S().alpha;
+	out->end_clip_valid = D.clipFirst != 0xFFFFFFFFu ? 1u : 0u; out->end_clip_rule = D.clipRule;
+	out->end_clip_first_draw = D.clipFirst != 0xFFFFFFFFu ? D.clipFirst : 0u; out->end_clip_num_draws = D.clipNum; out->end_clip_recording = D.recordClip ? 1u : 0u;
+	memcpy(out->end_scissor, D.S().scissor, sizeof(float) * 4);
+	out->reserved = 0;
 	if (D.store && D.overflow) { return VGX_E_NOSPACE; }
 	return VGX_OK;
 }

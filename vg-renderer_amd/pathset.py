@@ -39,6 +39,23 @@ class PathSetArrays:
         return d
 
 
+def concat(sets):
+    """One path set holding the paths of several, in order (draws of set k refer to it with their path index + the path
+    counts of the sets in front of it): how successive vgx_cmdlist_decode results of one frame become one batch."""
+    cmd_type, args, arg_off, pcb = [], [], [np.zeros(1, np.uint32)], [np.zeros(1, np.uint32)]
+    nargs = ncmd = 0
+    for ps in sets:
+        na = int(ps.cmd_arg_off[-1])
+        cmd_type.append(ps.cmd_type)
+        args.append(ps.args[:na])
+        arg_off.append(ps.cmd_arg_off[1:] + np.uint32(nargs))
+        pcb.append(ps.path_cmd_begin[1:] + np.uint32(ncmd))
+        nargs += na
+        ncmd += ps.ncmd
+    return PathSetArrays(np.concatenate(cmd_type) if cmd_type else np.zeros(0, np.uint8), np.concatenate(arg_off),
+                         np.concatenate(args) if args else np.zeros(0, np.float32), np.concatenate(pcb))
+
+
 class PathSetBuilder:
     def __init__(self):
         self._types = []

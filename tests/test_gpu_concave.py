@@ -22,6 +22,10 @@ def rt():
 def ref(oracle):
     if not oracle.available("reference"):
         pytest.skip("oracle/_ref/libvgref.so (the reference's sources + libtess2) is not built")
+    return load_ref(oracle)
+
+
+def load_ref(oracle):
     lib = oracle.load("reference")
     lib.vgo_concave_fill_aa.restype = C.c_int
     lib.vgo_concave_fill_aa.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_int,
@@ -113,10 +117,43 @@ def _reference_mesh(ref, contours, color, fringe, even_odd):
     return pos[:nv.value].copy(), col[:nv.value].copy(), idx[:ni.value].copy()
 
 
+def _random_fills(seed):
+    """Random concave fills: wobbly rings, stars, random (self-intersecting) polygons, holes and overlaps of either winding,
+    both fill rules, fringes 0.5 .. 2."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(int(rs.randint(4, 10))):
+        contours = []
+        cx, cy = rs.uniform(100, 900), rs.uniform(100, 600)
+        for _ in range(int(rs.randint(1, 4))):
+            k = int(rs.randint(0, 3))
+            ox, oy = cx + rs.uniform(-60, 60), cy + rs.uniform(-60, 60)
+            if k == 0:
+                contours.append(_ring(ox, oy, rs.uniform(15, 90), int(rs.randint(5, 40)), phase=rs.uniform(0, 6.28), cw=bool(rs.uniform() < 0.5),
+                                      wobble=rs.uniform(0, 0.45), seed=int(rs.randint(0, 1 << 30))))
+            elif k == 1:
+                contours.append(_star(ox, oy, rs.uniform(40, 100), rs.uniform(10, 60), int(rs.randint(3, 9)), phase=rs.uniform(0, 6.28)))
+            else:  # random polygon, usually self-intersecting
+                n = int(rs.randint(3, 9))
+                contours.append(np.stack([ox + rs.uniform(-90, 90, size=n), oy + rs.uniform(-90, 90, size=n)], axis=1).astype(np.float32))
+        out.append((contours, int(rs.randint(0, 1 << 32, dtype=np.uint64)) | 0x10000000, float(rs.choice([0.5, 1.0, 1.5, 2.0])), int(rs.randint(0, 2))))
+    return out
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_concave_fills_match_reference(rt, gpu_ctx, ref, seed):
+    """Random polygons through strokerConcaveFillEndAA of the reference (libtess2 included, oracle/_ref) and through
+    vgx_concave_move / vgx_concave_emit around the same libtess2 passes: bit-identical meshes."""
+    _check_fills(rt, gpu_ctx, ref, _random_fills(100 + seed))
+
+
 def test_concave_fringes_match_reference(rt, gpu_ctx, ref):
+    _check_fills(rt, gpu_ctx, ref, _fills())
+
+
+def _check_fills(rt, gpu_ctx, ref, fills):
     import torch
     capi = rt.capi
-    fills = _fills()
     # (1) caller: boundary contours of every fill
     tess, bverts, cont, frec = [], [], [], []
     vbase = 0

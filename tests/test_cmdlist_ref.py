@@ -376,6 +376,32 @@ def test_two_lists_in_one_frame_chained_decodes(rt, wl, oracle, seed):
     F.assert_frame_equal(fr, res.pos, res.color, idx, res.meshes, cmds, draws, dstate, max_vb, what="two lists %d" % seed)
 
 
+def test_decoder_survives_malformed_streams(rt):
+    """Byte streams are input from outside: truncated, bit-flipped, with corrupted header words or garbage behind them, the decoder
+    returns VGX_OK or VGX_E_INVALID_ARG (count and store pass alike) -- it neither reads out of bounds nor loops."""
+    rs = np.random.RandomState(1)
+    codes = set()
+    for seed in range(25):
+        with R.RefContext() as rc:
+            h, data = F.record(rc, s_random(40000 + seed))
+        for trial in range(12):
+            b = bytearray(data)
+            k = trial % 4
+            if k == 0:
+                b = b[:int(rs.randint(0, len(b) + 1))]
+            elif k == 1:
+                for _ in range(int(rs.randint(1, 8))):
+                    b[int(rs.randint(0, len(b)))] = int(rs.randint(0, 256))
+            elif k == 2:
+                off = int(rs.randint(0, max(1, len(b) // 4))) * 4
+                if off + 4 <= len(b):
+                    b[off:off + 4] = int(rs.randint(0, 1 << 32, dtype=np.uint64)).to_bytes(4, "little")
+            else:
+                b += bytes(rs.randint(0, 256, size=int(rs.randint(1, 64))).astype(np.uint8))
+            codes.add(cu.decode(rt, bytes(b))[0])
+    assert codes <= {0, 1}, codes
+
+
 SCENARIOS = {"tiger": s_tiger, "paints": s_paints, "scissor_clip": s_scissor_clip, "latch": s_latch, "every_command": s_every_command}
 
 

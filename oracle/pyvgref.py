@@ -49,11 +49,16 @@ def available():
     return os.path.exists(PATH)
 
 
-def load():
+PATH_UV_FLOAT = os.path.join(_HERE, "_ref", "libvgref_vg_uvf.so")  # the same sources with -DVG_CONFIG_UV_INT16=0 (float UVs)
+_libs = {}
+
+
+def load(path=None):
     global _lib
-    if _lib is not None:
-        return _lib
-    lib = C.CDLL(PATH)
+    path = path or PATH
+    if path in _libs:
+        return _libs[path]
+    lib = C.CDLL(path)
     lib.vgr_create.restype = C.c_void_p
     lib.vgr_create.argtypes = [C.c_uint32] * 4
     lib.vgr_destroy.argtypes = [C.c_void_p]
@@ -89,7 +94,9 @@ def load():
     lib.vgr_cache_command.restype = C.c_int
     lib.vgr_cache_command.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p]
     lib.vgr_engine_name.restype = C.c_char_p
-    _lib = lib
+    _libs[path] = lib
+    if path == PATH:
+        _lib = lib
     return lib
 
 
@@ -108,8 +115,9 @@ class RefContext:
     """One vg::Context of the reference. `cl` arguments: IMMEDIATE plays a call on the Context (vg::xxx), a command
     list handle records it with the reference's own vg::clXxx writer."""
 
-    def __init__(self, max_vb_vertices=65536, max_command_lists=256, max_gradients=64, max_image_patterns=64):
-        self.lib = load()
+    def __init__(self, max_vb_vertices=65536, max_command_lists=256, max_gradients=64, max_image_patterns=64, uv_float=False):
+        self.lib = load(PATH_UV_FLOAT if uv_float else None)
+        self.uv_dtype = np.float32 if uv_float else np.int16
         self.h = self.lib.vgr_create(max_vb_vertices, max_command_lists, max_gradients, max_image_patterns)
 
     def close(self):
@@ -195,7 +203,7 @@ class RefContext:
             return fr
         for i in range(nvb):
             vb = {}
-            for s, (name, dt, w) in enumerate((("pos", np.float32, 2), ("uv", np.int16, 2), ("color", np.uint32, 1))):
+            for s, (name, dt, w) in enumerate((("pos", np.float32, 2), ("uv", self.uv_dtype, 2), ("color", np.uint32, 1))):
                 rc = self.lib.vgr_vertex_buffer(self.h, i, s, C.byref(p), C.byref(n))
                 assert rc == 0, (rc, i, s)
                 a = np.frombuffer(_bytes_at(p.value, n.value), dtype=dt)

@@ -35,10 +35,10 @@ def reference_frames(script, pres, canvas=(1280, 720), max_vb=65536, flags=0):
     return outs
 
 
-def reference_frame(script, canvas=(1280, 720), max_vb=65536, flags=0, children=(), immediate=False, pre=None, frames=1):
+def reference_frame(script, canvas=(1280, 720), max_vb=65536, flags=0, children=(), immediate=False, pre=None, frames=1, uv_float=False):
     """Play one frame on the reference. children: [(Script, flags)] recorded first (handles 0..), the root list after
     them. Returns dict(frame=Frame, bytes=root bytes, lists={handle: (bytes, flags)}, root=handle, params, state0)."""
-    with R.RefContext(max_vb_vertices=max_vb) as rc:
+    with R.RefContext(max_vb_vertices=max_vb, uv_float=uv_float) as rc:  # uv_float: the VG_CONFIG_UV_INT16=0 build of the reference
         lists = {}
         for cs, cf in children:
             h, b = record(rc, cs, cf)

@@ -682,9 +682,10 @@ def gpu_frame(rt, gpu_ctx, ps, draws, max_vb, uv_bytes=4, uv_value=0):
     cap = nm + 2
     cmds = torch.zeros(cap * 48, dtype=torch.uint8, device=dd.device)
     ncmd = torch.zeros(1, dtype=torch.int64, device=dd.device)
-    assert uv_bytes == 4  # VG_CONFIG_UV_INT16 (the reference's default build)
-    uv = torch.zeros((max(nv, 1), 2), dtype=torch.int16, device=dd.device)
-    gpu_ctx.set_assembly(cmds, max_vb, ncmd, split_state=True, uv=uv, uv_value=(uv_value, 0))
+    assert uv_bytes in (4, 8)  # VG_CONFIG_UV_INT16 = 1 (the reference's default build: int16 x 2) or 0 (float x 2)
+    uv = torch.zeros((max(nv, 1), 2), dtype=torch.int16 if uv_bytes == 4 else torch.float32, device=dd.device)
+    uvw = uv_value if isinstance(uv_value, (tuple, list)) else (uv_value, 0)
+    gpu_ctx.set_assembly(cmds, max_vb, ncmd, split_state=True, uv=uv, uv_value=tuple(int(x) for x in uvw))
     try:
         rt.tessellate_async(gpu_ctx, pset, dd, draws.shape[0], bufs)
         torch.cuda.synchronize()
@@ -712,6 +713,22 @@ def test_gpu_frame_matches_reference_frame(rt, wl, gpu_ctx, name, max_vb):
     got = gpu_frame(rt, gpu_ctx, ps, draws, max_vb, uv_bytes=nb, uv_value=int(white[0]))
     F.assert_frame_equal(ref["frame"], got["pos"], got["color"], got["idx"], got["meshes"], got["cmds"], draws, extra["draw_state"], max_vb,
                          uv=got["uv"], what=name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiger", "paints"])
+def test_gpu_float_uv_stream(rt, wl, gpu_ctx, name):
+    """vgx_set_assembly's float x 2 UV stream against the reference built with VG_CONFIG_UV_INT16 = 0 (include/vg/vg.h:27-29):
+    the white-pixel UV on the vertices of Textured draw commands (createDrawCommand_VertexColor, vg.cpp:5218-5225)."""
+    script = SCENARIOS[name](wl, 3) if name == "tiger" else SCENARIOS[name](wl)
+    ref = F.reference_frame(script, max_vb=4096, uv_float=True)
+    ps, draws, n, extra = F.decode(rt, ref)
+    white, nb = ref["white_uv"]
+    assert nb == 8
+    got = gpu_frame(rt, gpu_ctx, ps, draws, 4096, uv_bytes=nb, uv_value=(int(white[0]), int(white[1])))
+    assert got["uv"].dtype == np.float32
+    F.assert_frame_equal(ref["frame"], got["pos"], got["color"], got["idx"], got["meshes"], got["cmds"], draws, extra["draw_state"], 4096,
+                         uv=got["uv"], what="float uv " + name)
 
 
 @pytest.mark.gpu

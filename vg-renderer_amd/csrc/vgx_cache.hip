@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void k_cache_meshes(VgxCacheArgs A)
 		r.subpath_kind = src.subpath_kind;
 		A.mtab[p] = r;
 		if (A.meshes_out) { A.meshes_out[p] = r; }
+		{ const uint32_t kind = src.subpath_kind >> 28; if (kind == VGX_MESH_FILL || kind == VGX_MESH_STROKE) { A.totals->cache_has_uniform = 1u; } } // plain store, rare
 	}
 }
 
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_cache_copy_flat(VgxCacheArgs A)
 // caching. After the flat copy: one lane per output mesh, AA meshes are skipped at once.
 __global__ __launch_bounds__(256) void k_cache_uniform_colors(VgxCacheArgs A)
 {
-	if (A.totals->status != VGX_OK) { return; }
+	if (A.totals->status != VGX_OK || A.totals->cache_has_uniform == 0u) { return; } // nothing but AA meshes: all colours were stored
 	const uint64_t P = A.totals->sizes.num_meshes;
 	for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (uint64_t)gridDim.x * blockDim.x) {
 		const vgx_mesh m = A.mtab[p];

@@ -119,6 +119,8 @@ struct VgxTotals
 	uint32_t inst_tol_hi;                // largest one. lo != hi: instances differ in scale -> grouped mode sorts by (path, tolerance class)
 	uint32_t inst_tol_varies;            // vgx_tessellate_count, periodic batch: some draw's tolerance differs from its image in the first period
 	uint32_t has_general_stroke;         // scan over the meshes: some stroke mesh is not a closed Miter AA / Thin stroke -> k_stroke emits the strokes, else k_stroke_simple
+	uint32_t cache_has_uniform;          // vgx_cache_submit: some submitted mesh was cached without per-vertex colours (k_cache_meshes -> k_cache_uniform_colors)
+	uint32_t pad_u32[3];
 	// diagnostics of the first failure (vgx_get_failure_info)
 	uint32_t fail_reason;  // VGX_FAIL_*
 	uint32_t fail_aux;

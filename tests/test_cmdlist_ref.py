@@ -157,9 +157,22 @@ def s_random(seed, nchildren=0, top=True):
 
     def shape():
         s.begin_path()
-        k = int(rs.randint(0, 7))
+        k = int(rs.randint(0, 8))
         x, y = float(u(20, 900)), float(u(20, 500))
-        if k == 0:
+        if k == 7:  # degenerate line paths: too few vertices for a mesh (no draw command, which PopState's scissor rule notices)
+            j = int(rs.randint(0, 5))
+            s.move_to(x, y)
+            if j == 0:
+                s.line_to(x + 30, y + 10)                                   # 2 vertices: strokes only
+            elif j == 1:
+                s.line_to(x, y)                                             # coincident: 1 vertex, nothing at all
+            elif j == 2:
+                s.line_to(x + 40, y).line_to(x + 40, y).line_to(x, y).close_path()   # 3 points, one repeated, closes onto its start: 2 vertices
+            elif j == 3:
+                s.polyline([x, y, x + 25, y + 25])                          # first polyline point coincides: 2 vertices
+            else:
+                s.line_to(x + 50, y).line_to(x + 25, y + 40).close_path()   # a proper triangle for contrast
+        elif k == 0:
             s.rect(x, y, float(u(5, 200)), float(u(5, 200)))
         elif k == 1:
             s.circle(x, y, float(u(2, 90)))

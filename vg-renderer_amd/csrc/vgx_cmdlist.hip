@@ -139,7 +139,8 @@ struct Decoder
 	// transformPath (vg.cpp:4957-4975): the first caller fixes the matrix the path's vertices are transformed with
 	void latch() { if (!transformed) { memcpy(pathMtx, S().m, sizeof(pathMtx)); transformed = true; } }
 
-	uint32_t subPts = 0, pathMaxPts = 0; bool pathCurved = false; // vertex upper bound of the current path's line-only sub-paths
+	uint32_t subPts = 0, pathMaxPts = 0; bool pathCurved = false; // vertices of the current path's line-only sub-paths (current one / largest finished one)
+	float subFirst[2] = { 0, 0 }, subLast[2] = { 0, 0 };
 	uint32_t rawColor = 0; // Color operand of the paint command being decoded (vgx_draw_state::raw_color)
 	void emit(uint32_t type, uint32_t handle, uint32_t fillFlags, uint32_t fillColor, uint32_t strokeFlags, uint32_t strokeColor, float strokeWidth)
 	{
@@ -170,11 +171,12 @@ struct Decoder
 			}
 		}
 		// PopState compares the restored scissor with the frame's last draw COMMAND (vg.cpp:3950-3965), and a draw whose path
-		// yields no mesh allocates none (a filled 2-point path ...). The meshes are not known here; what is known is an upper
-		// bound of the vertex count of sub-paths made of line segments only -- draws that certainly have no mesh do not count.
-		// (A curve or coincident points can still leave a sub-path below the stroker's minimum: that case is not seen here.)
+		// yields no mesh allocates none (a filled 2-point path ...). The meshes are not known here; what is known are the vertex
+		// counts of sub-paths made of line segments only (pathArgs) -- draws that certainly have no mesh do not count.
+		// (A curve that flattens to fewer vertices than the stroker's minimum is not seen here.)
 		const bool isFill = fillFlags != 0;
-		const bool noMesh = !pathCurved && pathMaxPts < (isFill ? 3u : 2u);
+		const uint32_t mostPts = subPts > pathMaxPts ? subPts : pathMaxPts;
+		const bool noMesh = !pathCurved && mostPts < (isFill ? 3u : 2u);
 		if (type != DT_Clip && !noMesh) { memcpy(lastScissor, sc, sizeof(sc)); haveLastScissor = true; }
 		++ndraws;
 	}
@@ -234,12 +236,21 @@ int Decoder::run(const uint8_t* p, uint32_t size, uint32_t listFlags)
 		auto pathArgs = [&](uint8_t vt, const float* a, uint32_t nfloats) {
 			if (!havePath || transformed) { ++nskipped; return; }
 			pathCmd(vt, a, nfloats);
-			// most vertices any sub-path of this path can have, as far as line segments tell (see emit())
-			if (vt == VGX_CMD_MOVE_TO) { subPts = 1; }
-			else if (vt == VGX_CMD_LINE_TO) { subPts += 1; }
-			else if (vt == VGX_CMD_POLYLINE) { subPts += nfloats / 2; }
-			else if (vt != VGX_CMD_CLOSE) { pathCurved = true; } // curves, arcs, shapes: any number of vertices
-			if (subPts > pathMaxPts) { pathMaxPts = subPts; }
+			// vertices of the sub-paths made of line segments only, counted the way vg::Path does (pathAddVertex's epsilon test
+			// path.cpp:769-775, pathPolyline's on its first point only :684-704, pathClose's pop :707-726), see emit()
+			auto nearPt = [](float ax, float ay, float bx, float by) { const float dx = ax - bx, dy = ay - by; return dx * dx + dy * dy < VGM_EPSILON; };
+			if (vt == VGX_CMD_MOVE_TO) {
+				if (subPts > pathMaxPts) { pathMaxPts = subPts; } // the previous sub-path is finished
+				subPts = 1; subFirst[0] = subLast[0] = a[0]; subFirst[1] = subLast[1] = a[1];
+			} else if (vt == VGX_CMD_LINE_TO) {
+				if (subPts == 0 || !nearPt(subLast[0], subLast[1], a[0], a[1])) { ++subPts; subLast[0] = a[0]; subLast[1] = a[1]; }
+			} else if (vt == VGX_CMD_POLYLINE && nfloats >= 2) {
+				uint32_t np = nfloats / 2;
+				if (subPts > 0 && nearPt(subLast[0], subLast[1], a[0], a[1])) { --np; }
+				if (np > 0) { subPts += np; subLast[0] = a[nfloats - 2]; subLast[1] = a[nfloats - 1]; }
+			} else if (vt == VGX_CMD_CLOSE) {
+				if (subPts > 2 && nearPt(subLast[0], subLast[1], subFirst[0], subFirst[1])) { --subPts; }
+			} else { pathCurved = true; } // curves, arcs, shapes: any number of vertices
 		};
 		auto globalAlpha = [&]() { return hasCache ? 1.0f : S().alpha; };
 		// alpha of the colour a Color / ImagePattern fill or stroke hands to the stroker (:3071-3075 and siblings)

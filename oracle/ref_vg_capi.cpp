@@ -70,6 +70,7 @@ struct vgr_submit // one bgfx::submit as vg::end() issued it (vg.cpp:1160-1288)
 void* vgr_create(uint32_t maxVBVertices, uint32_t maxCommandLists, uint32_t maxGradients, uint32_t maxImagePatterns)
 {
 	Ref* r = new Ref;
+	++g_liveContexts;
 	vg::ContextConfig cfg;
 	cfg.m_MaxGradients = (uint16_t)(maxGradients ? maxGradients : 64);
 	cfg.m_MaxImagePatterns = (uint16_t)(maxImagePatterns ? maxImagePatterns : 64);
@@ -85,11 +86,15 @@ void* vgr_create(uint32_t maxVBVertices, uint32_t maxCommandLists, uint32_t maxG
 	return r;
 }
 
+static int g_liveContexts = 0;
 void vgr_destroy(void* h)
 {
 	Ref* r = (Ref*)h;
 	vg::destroyContext(r->ctx);
 	delete r;
+	// The stand-in hands out buffer / texture / shader handles by counting up (uint16): with no Context alive nothing refers
+	// to them any more, so start over -- a test process may create tens of thousands of Contexts one after the other.
+	if (--g_liveContexts == 0) { bgfx::g_stub = bgfx::Stub(); }
 }
 
 void vgr_begin(void* h, uint32_t w, uint32_t hgt, float dpr)

@@ -67,6 +67,7 @@ struct vgr_submit // one bgfx::submit as vg::end() issued it (vg.cpp:1160-1288)
 	float outer_color[4];
 };
 
+static int g_liveContexts = 0;
 void* vgr_create(uint32_t maxVBVertices, uint32_t maxCommandLists, uint32_t maxGradients, uint32_t maxImagePatterns)
 {
 	Ref* r = new Ref;
@@ -86,7 +87,6 @@ void* vgr_create(uint32_t maxVBVertices, uint32_t maxCommandLists, uint32_t maxG
 	return r;
 }
 
-static int g_liveContexts = 0;
 void vgr_destroy(void* h)
 {
 	Ref* r = (Ref*)h;

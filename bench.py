@@ -605,7 +605,7 @@ def main():
                            "value": round(r2["units"] / (ms2 * 1e-3) / 1e6, 2), "unit": "M %s/s" % r2["unit_name"], "ms_per_step": round(ms2, 3), "steps": steps2,
                            "verts_per_gpu": r2["sizes"].get("num_vertices", 0), "indices_per_gpu": r2["sizes"].get("num_indices", 0),
                            "poly_verts_per_gpu": r2["sizes"]["num_poly_vertices"], "meshes_per_gpu": r2["sizes"].get("num_meshes", 0),
-                           "flatten_kernel": {0: "k_flatten_build", 1: "k_flatten_inst", 2: "k_flatten_inst (grouped)", 3: "k_flatten_inst (grouped by path and tolerance class)"}.get(r2.get("flatten_mode"), "k_flatten"),
+                           "flatten_kernel": {0: "k_flatten_build", 1: "k_flatten_inst", 2: "k_flatten_inst (grouped)", 3: "k_flatten_inst (grouped by path and tolerance class)", 4: "k_flatten_inst (instances sorted by tolerance class)"}.get(r2.get("flatten_mode"), "k_flatten"),
                            "roofline": roofline(r2, steps2, traffic_for=name), "stage_ms": {k: round(v, 3) for k, v in r2["stage"].items()}}
             r2["pset"].close()
             del r2, ps2, d2
@@ -631,6 +631,7 @@ def main():
                        "flatten_kernel": ("k_flatten_inst (one lane per instance: the draws repeat one sequence of paths)" if res.get("flatten_mode") == 1
                                           else "k_flatten_inst, grouped (draws sorted by path on the device)" if res.get("flatten_mode") == 2
                                           else "k_flatten_inst, grouped (draws sorted by path and tolerance class on the device)" if res.get("flatten_mode") == 3
+                                          else "k_flatten_inst, periodic with the instances sorted by tolerance class on the device" if res.get("flatten_mode") == 4
                                           else "k_flatten_build (one lane per path command)")},
             "roofline": roofline(res, args.steps, traffic_for=K if args.config == "tiger10k" else None),
             "stage_ms": {k: round(v, 3) for k, v in res["stage"].items()},

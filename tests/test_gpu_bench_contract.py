@@ -34,7 +34,7 @@ def test_one_rank_line():
     assert set(d["configs"]) == {"cubics1m", "round10k", "tiger10k_varied", "tigerspec10k"}
     for name, c in d["configs"].items():
         assert c["value"] > 0 and c["roofline"]["frac"] > 0, name
-    assert d["configs"]["tiger10k_varied"]["flatten_kernel"] == "k_flatten_inst (grouped by path and tolerance class)"
+    assert d["configs"]["tiger10k_varied"]["flatten_kernel"] == "k_flatten_inst (instances sorted by tolerance class)"
 
 
 def test_two_ranks_share_one_gpu():

@@ -153,7 +153,7 @@ def test_full_size_tiger_properties(rt, gpu_ctx, wl, oracle, monkeypatch):
 
 def test_full_size_tiger_varied_scales(rt, wl, oracle, monkeypatch):
     """bench.py's tiger10k_varied at full size (every instance at its own scale and rotation: 2.4 M draws, ~0.63 G vertices):
-    the count pass must choose the instanced kernel with (path, tolerance class) keys (flatten mode 3); the streams of the
+    the count pass must keep the instanced kernel's periodic mapping with the instances sorted by tolerance class (flatten mode 4); the streams of the
     asynchronous entry point are compared byte for byte with the command-parallel kernel's (VGX_INST=0: k_flatten_build, an
     independent implementation of the flatten) and, instance by instance for a sample, with the reference oracle."""
     import torch
@@ -165,7 +165,7 @@ def test_full_size_tiger_varied_scales(rt, wl, oracle, monkeypatch):
     pset = rt.PathSet(ctx, ps)
     dd = rt.upload_draws(draws)
     sizes = rt.tessellate_count(ctx, pset, dd, draws.shape[0])
-    assert ctx.failure_info()["segment_items"] == 3
+    assert ctx.failure_info()["segment_items"] == 4
     nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
     b = rt.MeshBuffers(dd.device, nv, ni, nm)
     for _ in range(2):

@@ -272,12 +272,15 @@ def _continuous_scales(wl, ps, seed, ninst):
     return d
 
 
-@pytest.mark.parametrize("classes,mode", [(None, 3), ("1", 1), ("4", 3), ("65536", 3)])
+@pytest.mark.parametrize("classes,mode", [(None, 4), ("1", 1), ("4", 4), ("65536", 4), ("perm0", 3), ("perm2", 4)])
 def test_instances_of_different_scales_are_sorted_by_tolerance_class(rt, wl, oracle, classes, mode, monkeypatch):
-    """A periodic batch whose instances differ in scale: lane = instance would leave the lock-step walk at nearly every
-    cubic, so the count pass picks the grouped mode with (path, tolerance class) keys (flatten mode 3). VGX_INST_CLASSES=1
-    keeps the periodic mapping; few / very many classes only change the order inside a path's range. Same bits in all cases."""
-    if classes is not None:
+    """A periodic batch whose instances differ in scale: lane = instance in draw order would leave the lock-step walk at nearly
+    every cubic, so the count pass keeps the periodic mapping but sorts the INSTANCES by tolerance class (flatten mode 4);
+    VGX_INST_PERM=0 sorts the draws by (path, tolerance class) instead (mode 3, what non-periodic batches get), VGX_INST_CLASSES=1
+    switches both off; few / very many classes only change which instances share a wave. Same bits in all cases."""
+    if classes in ("perm0", "perm2"):  # perm2: the several-kernel form of the instance sort (used beyond 2^18 instances)
+        monkeypatch.setenv("VGX_INST_PERM", classes[-1])
+    elif classes is not None:
         monkeypatch.setenv("VGX_INST_CLASSES", classes)
     ps = wl.fuzz_paths(780, npaths=48, with_shapes=False, with_polylines=True)
     d = _continuous_scales(wl, ps, 780, 70)

@@ -67,6 +67,7 @@ struct vgx_ctx
 	// options, read from the environment ONCE at vgx_create (tuning / testing knobs)
 	int optTwoPass, optBuildWaves, optPoolWalk, optNoSmall, optConcurrentEmit;
 	int optInst, optInstWaves; uint32_t optInstBlock; // instanced flatten kernel (vgx_inst.hip): on / grid / lane block
+	int optInstPerm;                                  // periodic batches of different scales: permute instances (1, default) or sort draws by (path, class) (0)
 	uint32_t optInstClasses;                          // grouped mode: tolerance classes per path when the instances differ in scale (VGX_INST_CLASSES)
 	// instanced batches: period of the path sequence found by the last vgx_tessellate_count (0 = none). vgx_tessellate
 	// re-checks it on the device for the draws it is given.
@@ -78,6 +79,9 @@ struct vgx_ctx
 	// (1 = by path only), so that the lanes of a wave flatten with nearly the same tolerance and stay in lock-step
 	uint32_t instClasses;
 	DevBuf instHist, instCursor, instKeyStart, instStart, instTaskStart, instTaskPath, instOrder;
+	// periodic mode, instances of different scales: every vgx_tessellate sorts the INSTANCES by tolerance class (vgx_launch_inst_perm)
+	int instPermOn;
+	DevBuf instPerm, instPermHist;
 	uint64_t instCapPaths, instCapKeys, instCapTasks, instCapDraws;
 	hipStream_t sideStream; hipEvent_t forkEv, joinEv; // optConcurrentEmit only
 	VgxCaps caps; // element capacities matching the buffers above
@@ -363,7 +367,7 @@ VgxFlattenArgs flattenArgs(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* 
 	a.pool_walk = ctx->optPoolWalk;
 	a.leaf_overflow = (float*)ctx->leafOverflow.p;
 	a.serial_list = (uint32_t*)ctx->serialList.p;
-	a.inst_period = 0; a.inst_block = ctx->optInstBlock; a.inst_waves = ctx->optInstWaves;
+	a.inst_period = 0; a.inst_block = ctx->optInstBlock; a.inst_waves = ctx->optInstWaves; a.inst_perm = nullptr;
 	a.inst_order = nullptr; a.inst_start = nullptr; a.inst_task_start = nullptr; a.inst_task_path = nullptr;
 	return a;
 }
@@ -413,6 +417,8 @@ int ensureInstGroup(vgx_ctx* ctx, uint32_t npaths, uint32_t nc, uint64_t ndraws,
 void setInstArgs(vgx_ctx* ctx, const vgx_pathset* ps, uint64_t ndraws, VgxFlattenArgs& a)
 {
 	a.inst_period = instPeriodFor(ctx, ndraws);
+	a.inst_perm = nullptr;
+	if (a.inst_period && ctx->instPermOn && ndraws / a.inst_period <= ctx->instPerm.cap / sizeof(uint32_t)) { a.inst_perm = (const uint32_t*)ctx->instPerm.p; }
 	if (instGroupedFor(ctx, ps, ndraws)) {
 		a.inst_order = (const uint32_t*)ctx->instOrder.p; a.inst_start = (const uint64_t*)ctx->instStart.p;
 		a.inst_task_start = (const uint64_t*)ctx->instTaskStart.p; a.inst_task_path = (const uint32_t*)ctx->instTaskPath.p;
@@ -475,6 +481,10 @@ void runFlattenBuild(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 	VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, 1);
 	a.build_mode = 1;
 	setInstArgs(ctx, ps, ndraws, a); // periodic: the same value runCmdPrefix checked the draws against
+	if (a.inst_perm) { // periodic mode, instances of different scales: this batch's instances sorted by tolerance class
+		vgx_launch_inst_perm(draws, ndraws / a.inst_period, a.inst_period, ctx->instClasses, (uint32_t*)ctx->instPermHist.p, (uint32_t*)ctx->instPerm.p, (VgxTotals*)ctx->totals.p, ctx->optInstPerm == 2, s);
+		mark(ctx, s, "inst_group");
+	}
 	if (a.inst_order) { // grouped mode: this batch's draws sorted by path
 		vgx_launch_inst_group(draws, ndraws, ps->dev.npaths, ctx->instClasses, (uint32_t*)ctx->instHist.p, (uint32_t*)ctx->instCursor.p, (uint64_t*)ctx->instKeyStart.p,
 			(uint64_t*)ctx->instStart.p, (uint64_t*)ctx->instTaskStart.p, (uint32_t*)ctx->instTaskPath.p, ctx->instCapTasks, (uint32_t*)ctx->instOrder.p,
@@ -670,7 +680,8 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	ctx->optNoSmall = getenv("VGX_NO_SMALL") ? 1 : 0; // testing knob: frame-sized batches through the large-batch launch sequence
 	ctx->optInst = 1; ctx->optInstWaves = VGX_INST_WAVES; ctx->optInstBlock = VGX_INST_BLOCK; // VGX_INST=0: instanced batches through k_flatten_build as well
 	if (const char* e = getenv("VGX_INST")) { ctx->optInst = atoi(e) != 0; }
-	ctx->optInstClasses = 256;
+	ctx->optInstClasses = 256; ctx->optInstPerm = 1;
+	if (const char* e = getenv("VGX_INST_PERM")) { const int v = atoi(e); ctx->optInstPerm = v == 2 ? 2 : (v != 0); } // 2: the several-kernel sort for any count (testing)
 	if (const char* e = getenv("VGX_INST_CLASSES")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { uint32_t p2 = 1; while (p2 * 2 <= (uint32_t)v) { p2 *= 2; } ctx->optInstClasses = p2; } }
 	if (const char* e = getenv("VGX_INST_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { ctx->optInstWaves = v; } }
 	if (const char* e = getenv("VGX_INST_BLOCK")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { ctx->optInstBlock = (uint32_t)v; } }
@@ -687,7 +698,7 @@ int vgx_destroy(vgx_ctx* ctx)
 		return VGX_E_INVALID_ARG;
 	}
 	DeviceGuard guard(ctx);
-	DevBuf* bufs[] = { &ctx->partBounds, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DevBuf* bufs[] = { &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
@@ -936,7 +947,7 @@ static int flattenCountCommon(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_dra
 	if ((st = ensureDrawBuffers(ctx, ndraws)) != VGX_OK) { return st; }
 	// pass 1: command instances (sizes the per-command scratch)
 	ctx->caps.cmd_instances = ~0ull; // not known yet: never trips the check in this sizing pass
-	ctx->instPeriod = 0; ctx->instGrouped = 0; ctx->instClasses = 1;
+	ctx->instPeriod = 0; ctx->instGrouped = 0; ctx->instClasses = 1; ctx->instPermOn = 0;
 	runCmdPrefix(ctx, ps, draws, ndraws, s);
 	if (detectInst && ctx->optInst && ndraws > VGX_SMALL_DRAWS) {
 		vgx_launch_inst_detect(draws, ndraws, (VgxTotals*)ctx->totals.p, s);
@@ -958,9 +969,19 @@ static int flattenCountCommon(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_dra
 		// The instances of a path differ in scale: in the periodic mapping (lane = instance) the lanes of a wave would
 		// disagree about nearly every cubic. Grouped mode sorted by (path, tolerance class) instead.
 		uint32_t nc = ctx->optInstClasses;
-		while (nc > 1 && (uint64_t)ps->dev.npaths * nc > (1ull << 22)) { nc >>= 1; } // scratch of at most 4 M keys
-		ctx->instClasses = nc;
-		if (nc > 1) { ctx->instPeriod = 0; }
+		if (instPeriodFor(ctx, ndraws) && ctx->optInstPerm) {
+			// the sequence repeats: keep the periodic mapping (closed-form offsets, no per-draw sort) and permute the INSTANCES
+			const uint64_t ninst = ndraws / ctx->instPeriod;
+			if (nc > 1024u) { nc = 1024u; }
+			if ((st = ensure(ctx, ctx->instPerm, (ninst + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
+			if ((st = ensure(ctx, ctx->instPermHist, ((size_t)nc + 2) * sizeof(uint32_t))) != VGX_OK) { return st; }
+			ctx->instClasses = nc;
+			ctx->instPermOn = 1;
+		} else {
+			while (nc > 1 && (uint64_t)ps->dev.npaths * nc > (1ull << 22)) { nc >>= 1; } // scratch of at most 4 M keys
+			ctx->instClasses = nc;
+			if (nc > 1) { ctx->instPeriod = 0; }
+		}
 	}
 	if (!instPeriodFor(ctx, ndraws) && ctx->optInst && ndraws > VGX_SMALL_DRAWS && ndraws < 0xFFFFFFFFull && ctx->hostTotals->inst_distinct != 0
 		&& ndraws / ctx->hostTotals->inst_distinct >= VGX_INST_MIN_INSTANCES) {
@@ -1414,7 +1435,7 @@ int vgx_get_failure_info(vgx_ctx* ctx, vgx_failure_info* out, void* stream)
 	out->reason = ctx->hostTotals->fail_reason;
 	out->aux = ctx->hostTotals->fail_aux;
 	out->segment = ctx->hostTotals->fail_segment;
-	out->segment_items = ctx->optInst ? (ctx->instPeriod ? 1u : (ctx->instGrouped ? (ctx->instClasses > 1 ? 3u : 2u) : 0u)) : 0u; // flatten mode chosen by the last count call
+	out->segment_items = ctx->optInst ? (ctx->instPeriod ? (ctx->instPermOn ? 4u : 1u) : (ctx->instGrouped ? (ctx->instClasses > 1 ? 3u : 2u) : 0u)) : 0u; // flatten mode chosen by the last count call
 	for (int i = 0; i < 16; ++i) { out->prof[i] = ctx->hostTotals->prof[i]; }
 	return VGX_OK;
 }

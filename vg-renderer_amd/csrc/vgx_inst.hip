@@ -415,8 +415,9 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_inst(VgxFlattenArgs A)
 			const uint64_t g = t / P;
 			const uint32_t pcur = (uint32_t)(t - g * P);
 			path = as_const(A.draws)[pcur].path; // == draws[i * P + pcur].path for every instance i (verified)
-			const uint64_t inst = g * VGX_WAVE + (uint64_t)lane;
-			valid = inst < ninst;
+			const uint64_t slot = g * VGX_WAVE + (uint64_t)lane;
+			valid = slot < ninst;
+			const uint64_t inst = (A.inst_perm != nullptr && valid) ? (uint64_t)A.inst_perm[slot] : slot;
 			d = inst * P + pcur;
 			srecBase = inst * as_const(A.sub_prefix)[P] + as_const(A.sub_prefix)[pcur]; // sub-paths in front of this draw (periodic: closed form)
 		} else {
@@ -792,6 +793,119 @@ void vgx_launch_inst_group(const vgx_draw* draws, uint64_t ndraws, uint32_t npat
 		hipLaunchKernelGGL(k_inst_scatter, dim3(VGX_INST_GROUP_BLOCKS), dim3(VGX_INST_GROUP_THREADS), 0, s, draws, ndraws, npaths, nc, (const VgxTotals*)totals,
 			(const uint64_t*)(nc > 1 ? keyStart : start), cursor, order);
 	}
+}
+
+// ---- periodic mode, instances of different scales: a permutation of the INSTANCES -------------------------------------
+// Counting sort of the instances by the tolerance class of their first draw (inst_tol_bits quantised over the range of those
+// draws, as in the grouped mode): ninst items, nc <= 1024 classes -- three small launches. Typical instancing gives every
+// instance ONE scale for all of its paths, so lanes that agree on the first path agree on all of them; where they do not,
+// a cubic falls back to the per-lane walk as always.
+namespace {
+__global__ __launch_bounds__(256) void k_inst_perm_range(const vgx_draw* draws, uint64_t ninst, uint32_t period, VgxTotals* totals)
+{
+	uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ninst; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t b = inst_tol_bits(draws + i * period);
+		lo = b < lo ? b : lo; hi = b > hi ? b : hi;
+	}
+	for (int o = 32; o > 0; o >>= 1) {
+		const uint32_t l2 = (uint32_t)__shfl_xor((int)lo, o), h2 = (uint32_t)__shfl_xor((int)hi, o);
+		lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+	}
+	if ((threadIdx.x & 63) == 0 && lo <= hi) { atomicMax(&totals->inst_tol_lo_inv, ~lo); atomicMax(&totals->inst_tol_hi, hi); }
+}
+__device__ __forceinline__ uint32_t inst_perm_class(const vgx_draw* d, const InstKeys& K)
+{
+	const uint32_t b = inst_tol_bits(d);
+	uint32_t c = b > K.lo ? (b - K.lo) >> K.shift : 0u;
+	return c < K.nc ? c : K.nc - 1u;
+}
+__global__ __launch_bounds__(256) void k_inst_perm_hist(const vgx_draw* draws, uint64_t ninst, uint32_t period, uint32_t nc, const VgxTotals* totals, uint32_t* hist)
+{
+	const InstKeys K = inst_keys(1u, nc, totals);
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ninst; i += (uint64_t)gridDim.x * blockDim.x) {
+		atomicAdd(&hist[inst_perm_class(draws + i * period, K)], 1u);
+	}
+}
+// one workgroup: exclusive scan of the class histogram in place (nc <= 1024)
+__global__ __launch_bounds__(1024) void k_inst_perm_scan(uint32_t nc, uint32_t* hist)
+{
+	__shared__ uint32_t s[1024];
+	const uint32_t t = threadIdx.x;
+	const uint32_t v = t < nc ? hist[t] : 0u;
+	s[t] = v;
+	__syncthreads();
+	for (uint32_t o = 1; o < 1024; o <<= 1) {
+		const uint32_t x = t >= o ? s[t - o] : 0u;
+		__syncthreads();
+		s[t] += x;
+		__syncthreads();
+	}
+	if (t < nc) { hist[t] = s[t] - v; }
+}
+__global__ __launch_bounds__(256) void k_inst_perm_scatter(const vgx_draw* draws, uint64_t ninst, uint32_t period, uint32_t nc, const VgxTotals* totals, uint32_t* cursor, uint32_t* perm)
+{
+	const InstKeys K = inst_keys(1u, nc, totals);
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ninst; i += (uint64_t)gridDim.x * blockDim.x) {
+		perm[atomicAdd(&cursor[inst_perm_class(draws + i * period, K)], 1u)] = (uint32_t)i;
+	}
+}
+}
+
+// up to 2^18 instances: the whole sort in ONE workgroup (range -> LDS histogram -> scan -> scatter): four dependent launches of
+// a handful of workgroups each cost 0.09 ms for 10 000 instances, this one 0.02
+__global__ __launch_bounds__(1024) void k_inst_perm_single(const vgx_draw* draws, uint32_t ninst, uint32_t period, uint32_t nc, uint32_t* perm)
+{
+	__shared__ uint32_t s_hist[1024];
+	__shared__ uint32_t s_lo, s_hi;
+	const uint32_t t = threadIdx.x;
+	if (t == 0) { s_lo = 0xFFFFFFFFu; s_hi = 0u; }
+	s_hist[t] = 0;
+	__syncthreads();
+	uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+	for (uint32_t i = t; i < ninst; i += 1024) {
+		const uint32_t b = inst_tol_bits(draws + (uint64_t)i * period);
+		lo = b < lo ? b : lo; hi = b > hi ? b : hi;
+	}
+	for (int o = 32; o > 0; o >>= 1) {
+		const uint32_t l2 = (uint32_t)__shfl_xor((int)lo, o), h2 = (uint32_t)__shfl_xor((int)hi, o);
+		lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+	}
+	if ((t & 63) == 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+	__syncthreads();
+	InstKeys K;
+	K.npaths = 1; K.nc = nc; K.lo = s_lo; K.shift = 0;
+	{ const uint32_t span = s_hi > s_lo ? s_hi - s_lo : 0u; while ((span >> K.shift) >= nc) { ++K.shift; } }
+	for (uint32_t i = t; i < ninst; i += 1024) { atomicAdd(&s_hist[inst_perm_class(draws + (uint64_t)i * period, K)], 1u); }
+	__syncthreads();
+	const uint32_t v = s_hist[t];
+	__syncthreads();
+	for (uint32_t o = 1; o < 1024; o <<= 1) {
+		const uint32_t x = t >= o ? s_hist[t - o] : 0u;
+		__syncthreads();
+		s_hist[t] += x;
+		__syncthreads();
+	}
+	const uint32_t excl = s_hist[t] - v;
+	__syncthreads();
+	s_hist[t] = excl; // running cursors
+	__syncthreads();
+	for (uint32_t i = t; i < ninst; i += 1024) { perm[atomicAdd(&s_hist[inst_perm_class(draws + (uint64_t)i * period, K)], 1u)] = i; }
+}
+
+void vgx_launch_inst_perm(const vgx_draw* draws, uint64_t ninst, uint32_t period, uint32_t nc, uint32_t* classHist, uint32_t* perm, VgxTotals* totals, bool multi, hipStream_t s)
+{
+	if (nc > 1024u) { nc = 1024u; }
+	if (ninst <= (1ull << 18) && !multi) {
+		hipLaunchKernelGGL(k_inst_perm_single, dim3(1), dim3(1024), 0, s, draws, (uint32_t)ninst, period, nc, perm);
+		return;
+	}
+	(void)hipMemsetAsync(classHist, 0, ((size_t)nc + 1) * sizeof(uint32_t), s);
+	const int blocks = (int)((ninst + 255) / 256 < 256 ? (ninst + 255) / 256 : 256);
+	hipLaunchKernelGGL(k_inst_perm_range, dim3(blocks ? blocks : 1), dim3(256), 0, s, draws, ninst, period, totals);
+	hipLaunchKernelGGL(k_inst_perm_hist, dim3(blocks ? blocks : 1), dim3(256), 0, s, draws, ninst, period, nc, (const VgxTotals*)totals, classHist);
+	hipLaunchKernelGGL(k_inst_perm_scan, dim3(1), dim3(1024), 0, s, nc, classHist);
+	hipLaunchKernelGGL(k_inst_perm_scatter, dim3(blocks ? blocks : 1), dim3(256), 0, s, draws, ninst, period, nc, (const VgxTotals*)totals, classHist, perm);
 }
 
 void vgx_launch_flatten_inst(const VgxFlattenArgs& a, int waves, hipStream_t s)

@@ -45,6 +45,10 @@ struct VgxFlattenArgs
 	const uint64_t* inst_start;      // [npaths + 1] first entry of every path in inst_order
 	const uint64_t* inst_task_start; // [npaths + 1] first task of every path
 	const uint32_t* inst_task_path;  // [tasks] path of every task
+	// periodic mode, instances of different scales: lane slot k of the instance walk takes instance inst_perm[k] -- the instances
+	// sorted by the tolerance class of their first draw, so that the lanes of a wave flatten with (nearly) the same tolerance and
+	// stay in lock-step. Any permutation is valid (null = identity): it only decides which instances share a wave.
+	const uint32_t* inst_perm;       // [ndraws / inst_period]
 };
 
 struct VgxStrokeArgs
@@ -92,6 +96,7 @@ void vgx_launch_concave_emit(const VgxConcaveArgs& a, hipStream_t s);
 void vgx_launch_flatten(bool emit, const VgxFlattenArgs& a, int numBlocks, hipStream_t s);
 void vgx_launch_flatten_build(const VgxFlattenArgs& a, int waves, hipStream_t s, bool serialCount = true);   // single-pass: subdivide once, polyline -> heap
 void vgx_launch_flatten_inst(const VgxFlattenArgs& a, int waves, hipStream_t s);  // instanced batches: one lane per instance (vgx_inst.hip)
+void vgx_launch_inst_perm(const vgx_draw* draws, uint64_t ninst, uint32_t period, uint32_t nc, uint32_t* classHist /* [nc + 1] */, uint32_t* perm /* [ninst] */, VgxTotals* totals, bool multi /* testing: the several-kernel form for any count */, hipStream_t s);
 void vgx_launch_inst_detect(const vgx_draw* draws, uint64_t ndraws, VgxTotals* totals, hipStream_t s); // count pass: period of the path sequence
 // grouped mode: histogram of the draws' paths -> per-path ranges and task list (taskPath may be null: counts only) -> draw order
 // nc: tolerance classes per path (1 = sort by path only); hist / cursor / keyStart hold npaths * nc + 1 entries (keyStart unused when nc == 1)

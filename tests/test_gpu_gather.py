@@ -133,3 +133,24 @@ def _per_draw_weight(oracle, ps, d):
     ff, sf = d["fill_flags"].astype(np.uint64), d["stroke_flags"].astype(np.uint64)
     f = np.where(ff & 1, np.where(ff & 2, 2, 1), 0) + np.where(sf & 1, np.where((sf & capi.STROKE_AA) == 0, 2, np.where(sf & capi.STROKE_THIN, 3, 4)), 0)
     return (di["num_poly_vertices"].astype(np.uint64) * f.astype(np.uint64) + 1).astype(np.int64)
+
+
+def test_partition_edge_cases(wl, oracle):
+    """More parts than draws (empty parts at the front of equal bounds), a single draw, one part."""
+    import importlib
+    rt = importlib.import_module("vg-renderer_amd.runtime")
+    ps = wl.fuzz_paths(911, npaths=8, with_shapes=False, with_polylines=True)
+    base = wl.fuzz_draws(ps, 911)
+    ctx = rt.Context(0)
+    try:
+        pset = rt.PathSet(ctx, ps)
+        for d, nparts in ((base[:3], 8), (base[:1], 4), (base, 1), (base[:5], 5)):
+            dd = rt.upload_draws(d)
+            bounds, weights = rt.partition(ctx, pset, dd, d.shape[0], nparts)
+            eb, ew = _expected_partition(oracle, ps, d, nparts)
+            assert bounds == eb and weights == ew, (bounds, eb)
+            assert bounds[0] == 0 and bounds[-1] == d.shape[0] and all(a <= b for a, b in zip(bounds, bounds[1:]))
+            assert sum(weights) == int(_per_draw_weight(oracle, ps, d).sum())
+        pset.close()
+    finally:
+        ctx.close()

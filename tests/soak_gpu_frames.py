@@ -1,6 +1,6 @@
 """GPU soak of whole frames (not collected by pytest): N random frames (tests/test_cmdlist_ref.py::s_random, recorded with the
 reference's own writers) through vgx_cmdlist_decode -> vgx_tessellate with assembly armed, against what the reference's own
-Context hands to bgfx; every 5th frame a shape-cache set. `python tests/soak_gpu_frames.py 500`."""
+Context hands to bgfx. `python tests/soak_gpu_frames.py 500 [tight]` (tight: vertex buffers sized just above the largest mesh)."""
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
@@ -10,6 +10,7 @@ import test_cmdlist_ref as T
 rt = importlib.import_module("vg-renderer_amd.runtime"); wl = importlib.import_module("vg-renderer_amd.workloads")
 ctx = rt.Context(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+tight = len(sys.argv) > 2 and sys.argv[2] == "tight"
 bad = skipped = 0
 for seed in range(300000, 300000 + n):
     script = T.s_random(seed)
@@ -20,6 +21,10 @@ for seed in range(300000, 300000 + n):
         if len(ref["frame"].drawcmds) == 0:
             skipped += 1
             continue
+        if tight:  # vertex buffers just above the frame's largest mesh: a buffer switch every few meshes
+            import pyoracle
+            max_vb = int(pyoracle.tessellate(ps, draws).meshes["num_vertices"].max()) + seed % 7
+            ref = F.reference_frame(script, max_vb=max_vb)
         white, nb = ref["white_uv"]
         got = T.gpu_frame(rt, ctx, ps, draws, max_vb, uv_bytes=nb, uv_value=int(white[0]))
         F.assert_frame_equal(ref["frame"], got["pos"], got["color"], got["idx"], got["meshes"], got["cmds"], draws, extra["draw_state"], max_vb,

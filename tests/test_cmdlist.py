@@ -209,3 +209,50 @@ def test_tiger_bytecode_route_gives_the_same_meshes(rt, wl, gpu_ctx, oracle):
     for f in ("first_vertex", "first_index", "num_vertices", "num_indices"):
         assert np.array_equal(got.meshes[f], ref.meshes[f]), f
     assert np.array_equal(got.meshes["subpath_kind"], ref.meshes["subpath_kind"])
+
+
+def test_capacity_and_depth_limits(rt):
+    """The store pass with too small arrays reports VGX_E_NOSPACE (and writes nothing out of bounds), recursion stops at
+    max_depth (Config::m_MaxCommandListDepth, vg.cpp:4278-4282: a list that submits itself)."""
+    import ctypes as C
+    capi = rt.capi
+    r = cu.Recorder()
+    for i in range(6):
+        r.begin_path(); r.rect(10.0 * i, 0, 5, 5); r.fill_path(0xFF0000FF, cu.fill_flags())
+    data = r.bytes()
+    st = capi.CmdListState()
+    st.mtx[0] = 1; st.mtx[3] = 1; st.global_alpha = 1.0; st.tess_tol = 0.25; st.fringe = 1.0; st.canvas_width = 1280; st.canvas_height = 720
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    out = capi.CmdListOut()
+    assert rt.lib().vgx_cmdlist_decode(buf, len(data), C.byref(st), C.byref(out)) == 0
+    assert (out.num_paths, out.num_draws) == (6, 6)
+    # store pass with room for 4 draws / 4 paths only: guard words behind the arrays must survive
+    GUARD = 0x5A
+    cmd_type = np.full(out.num_cmds + 8, GUARD, np.uint8)
+    arg_off = np.zeros(out.num_cmds + 1, np.uint32)
+    args = np.zeros(out.num_args, np.float32)
+    pcb = np.full(4 + 1 + 4, 0xA5A5A5A5, np.uint32)
+    draws = np.zeros(4 + 2, capi.draw_dtype)
+    draws["path"][4:] = 0xDEADBEEF
+    out2 = capi.CmdListOut()
+    out2.cmd_type, out2.cmd_arg_off, out2.args, out2.path_cmd_begin, out2.draws = cmd_type.ctypes.data, arg_off.ctypes.data, args.ctypes.data, pcb.ctypes.data, draws.ctypes.data
+    out2.cap_cmds, out2.cap_args, out2.cap_paths, out2.cap_draws = out.num_cmds, out.num_args, 4, 4
+    assert rt.lib().vgx_cmdlist_decode(buf, len(data), C.byref(st), C.byref(out2)) == capi.VGX_E_NOSPACE
+    assert (out2.num_paths, out2.num_draws) == (6, 6)                 # the counts are still the full ones
+    assert (draws["path"][4:] == 0xDEADBEEF).all() and (pcb[5:] == 0xA5A5A5A5).all() and (cmd_type[out.num_cmds:] == GUARD).all()
+    # a list that submits itself: max_depth levels, then the submit is skipped
+    rr = cu.Recorder()
+    rr.begin_path(); rr.rect(0, 0, 5, 5); rr.fill_path(0xFF0000FF, cu.fill_flags())
+    rr._cmd("SubmitCommandList", (0).to_bytes(2, "little") + bytes(2))
+    for depth in (1, 3, 16):
+        st2 = capi.CmdListState()
+        st2.mtx[0] = 1; st2.mtx[3] = 1; st2.global_alpha = 1.0; st2.tess_tol = 0.25; st2.fringe = 1.0; st2.canvas_width = 1280; st2.canvas_height = 720
+        st2.max_depth = depth
+        selfb = rr.bytes()
+        cb = (C.c_uint8 * len(selfb)).from_buffer_copy(selfb)
+        arr = (capi.CmdListRef * 1)()
+        arr[0].bytes = C.cast(cb, C.c_void_p); arr[0].size = len(selfb); arr[0].flags = 0
+        st2.lists = arr; st2.num_lists = 1
+        o3 = capi.CmdListOut()
+        assert rt.lib().vgx_cmdlist_decode(cb, len(selfb), C.byref(st2), C.byref(o3)) == 0
+        assert o3.num_draws == depth and o3.num_skipped == 0, (depth, o3.num_draws, o3.num_skipped)  # the cut-off submit returns silently, like the reference's

@@ -42,7 +42,7 @@ def command_bytes(ps, draw_paths):
     return int(per_path[draw_paths].sum())
 
 
-def algorithmic_bytes(cmd_bytes, ndraws, sizes, fill_verts, fill_idx, fill_meshes, instanced=False):
+def algorithmic_bytes(cmd_bytes, ndraws, sizes, fill_verts, fill_idx, fill_meshes, instanced=False, template=False):
     """Algorithmic HBM bytes per launch of each kernel (stated in DESIGN.md):
     commands read once per instance (1 B opcode + 4 B arg offset + 4 B per argument), one 64 B draw record
     per path instance, 8 B per polyline vertex, 12 B per output vertex (float2 position + uint32 colour), 2 B per
@@ -59,7 +59,15 @@ def algorithmic_bytes(cmd_bytes, ndraws, sizes, fill_verts, fill_idx, fill_meshe
     b["flatten_emit"] = cmd_bytes + 64 * ndraws + 8 * sizes["num_poly_vertices"] + 16 * sizes["num_subpaths"]
     b["fill_emit"] = 8 * ef + 12 * fill_verts + 2 * fill_idx + 32 * fill_meshes
     b["stroke_emit"] = 8 * es + 12 * (nv - fill_verts) + 2 * (ni - fill_idx) + 32 * (nm - fill_meshes)
-    b["pipeline"] = cmd_bytes + 64 * ndraws + 12 * nv + 2 * ni + 32 * nm
+    # the whole step: commands are read once per 64-instance task by the instanced flatten kernel, once per instance otherwise
+    b["pipeline"] = (cmd_bytes // 64 if instanced else cmd_bytes) + 64 * ndraws + 12 * nv + 2 * ni + 32 * nm
+    if template:
+        # template mode (vgx_tmpl.hip): the path commands are not read at all during a step (the first period was flattened by
+        # vgx_tessellate_count; its local polyline, a few hundred KB, stays in L2) -- a step reads the draw records and writes
+        # the output streams. k_tmpl_verify re-reads the draw records: overhead, counted as its own line only.
+        b["tmpl_verify"] = 64 * ndraws
+        b["tmpl_emit"] = 64 * ndraws + 12 * nv + 2 * ni + 32 * nm
+        b["pipeline"] = b["tmpl_emit"]
     return b
 
 
@@ -275,7 +283,7 @@ def run_config(rt, torch, ctx, local_rank, name, ps, draws, kind, steps, warmup,
         sizes.setdefault("num_elements", 0)
     mode = ctx.failure_info()["segment_items"] if kind != "flatten" else 0  # which flatten kernel the library chose (0 command-parallel, 1 / 2 / 3 instanced)
     res["flatten_mode"] = mode
-    ab = algorithmic_bytes(cmd_bytes, ndraws, sizes, fill_verts, fill_idx, fill_meshes, instanced=mode != 0)
+    ab = algorithmic_bytes(cmd_bytes, ndraws, sizes, fill_verts, fill_idx, fill_meshes, instanced=mode not in (0, 5), template=mode == 5)
     if kind == "flatten":
         ab["pipeline"] = ab["flatten_emit"]
     res.update(dt=dt, sizes=sizes, stage=stage_sum, ab=ab, units=units, unit_name=unit_name, bufs=bufs, pset=pset, dd=dd, scratch=ctx.scratch_bytes())
@@ -309,7 +317,7 @@ def roofline(res, steps, traffic_for=None):
             "kernel_ms": round(dom_ms, 3), "algorithmic_bytes": ab[dom],
             "by_kernel": {k: {"ms": round(stage_sum[k], 3), "achieved": round(ab[k] / (stage_sum[k] * 1e-3) / 1e9, 1),
                               "frac": round(ab[k] / (stage_sum[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-                          for k in ("flatten_build", "flatten_count", "flatten_emit", "fill_emit", "stroke_emit") if k in stage_sum and k in ab and stage_sum[k] > 0},
+                          for k in ("flatten_build", "flatten_count", "flatten_emit", "fill_emit", "stroke_emit", "tmpl_verify", "tmpl_emit") if k in stage_sum and k in ab and stage_sum[k] > 0},
             "pipeline_achieved": round(ab["pipeline"] / (ms_per_step * 1e-3) / 1e9, 1)}
 
 
@@ -540,6 +548,7 @@ def main():
         cmds = torch.zeros(cap * 48, dtype=torch.uint8, device=dev)
         ncmd = torch.zeros(1, dtype=torch.int64, device=dev)
         ctx.set_assembly(cmds, 0, ncmd)
+        rt.tessellate_count(ctx, pset, dd, ndraws)  # the template mode of the headline run does not assemble: scratch of the ordinary pipeline
         ctx.set_profiling(True)
         rt.tessellate_async(ctx, pset, dd, ndraws, bufs)
         torch.cuda.synchronize()
@@ -605,7 +614,7 @@ def main():
                            "value": round(r2["units"] / (ms2 * 1e-3) / 1e6, 2), "unit": "M %s/s" % r2["unit_name"], "ms_per_step": round(ms2, 3), "steps": steps2,
                            "verts_per_gpu": r2["sizes"].get("num_vertices", 0), "indices_per_gpu": r2["sizes"].get("num_indices", 0),
                            "poly_verts_per_gpu": r2["sizes"]["num_poly_vertices"], "meshes_per_gpu": r2["sizes"].get("num_meshes", 0),
-                           "flatten_kernel": {0: "k_flatten_build", 1: "k_flatten_inst", 2: "k_flatten_inst (grouped)", 3: "k_flatten_inst (grouped by path and tolerance class)", 4: "k_flatten_inst (instances sorted by tolerance class)"}.get(r2.get("flatten_mode"), "k_flatten"),
+                           "flatten_kernel": {0: "k_flatten_build", 1: "k_flatten_inst", 2: "k_flatten_inst (grouped)", 3: "k_flatten_inst (grouped by path and tolerance class)", 4: "k_flatten_inst (instances sorted by tolerance class)", 5: "none per step (template mode: first period flattened once by vgx_tessellate_count)"}.get(r2.get("flatten_mode"), "k_flatten"),
                            "roofline": roofline(r2, steps2, traffic_for=name), "stage_ms": {k: round(v, 3) for k, v in r2["stage"].items()}}
             r2["pset"].close()
             del r2, ps2, d2
@@ -628,7 +637,8 @@ def main():
                        "poly_verts_per_gpu": sizes["num_poly_vertices"], "serial_draws": sizes["num_serial_draws"],
                        "scratch_bytes_per_gpu": res["scratch"], "output_placement": res.get("output_placement"),
                        # which flatten kernel the 'flatten_build' stage is (the library decides per batch)
-                       "flatten_kernel": ("k_flatten_inst (one lane per instance: the draws repeat one sequence of paths)" if res.get("flatten_mode") == 1
+                       "flatten_kernel": ("none per step: template mode (the instances differ in transform / colours only; vgx_tessellate_count flattened the first period once, in local space)" if res.get("flatten_mode") == 5
+                                          else "k_flatten_inst (one lane per instance: the draws repeat one sequence of paths)" if res.get("flatten_mode") == 1
                                           else "k_flatten_inst, grouped (draws sorted by path on the device)" if res.get("flatten_mode") == 2
                                           else "k_flatten_inst, grouped (draws sorted by path and tolerance class on the device)" if res.get("flatten_mode") == 3
                                           else "k_flatten_inst, periodic with the instances sorted by tolerance class on the device" if res.get("flatten_mode") == 4

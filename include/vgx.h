@@ -44,7 +44,10 @@ typedef enum vgx_status {
 	VGX_E_HIP = 6,           /* a HIP runtime call failed; vgx_last_hip_error() has the code */
 	VGX_E_NO_DEVICE = 7,     /* no gfx950 device / HIP runtime unavailable */
 	VGX_E_RANGE = 8,         /* batch exceeds 2^32-1 polyline vertices or commands; split the batch */
-	VGX_E_INTERNAL = 9       /* device-side protocol error (a wait inside the single-pass kernel timed out): a bug, report it */
+	VGX_E_INTERNAL = 9,      /* device-side protocol error (a wait inside the single-pass kernel timed out): a bug, report it */
+	VGX_E_STALE = 10         /* vgx_tessellate: the draws no longer have the structure the last vgx_tessellate_count found (template
+	                          * mode, see vgx_tessellate): a field other than mtx / colours / state_key of some draw differs from the
+	                          * counted batch. Outputs are undefined; call vgx_tessellate_count on the new draws */
 } vgx_status;
 
 /* Path commands. One opcode per vg::pathXXX builder call (reference include/vg/path.h:24-35).

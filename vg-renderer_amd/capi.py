@@ -17,6 +17,7 @@ VGX_E_HIP = 6
 VGX_E_NO_DEVICE = 7
 VGX_E_RANGE = 8
 VGX_E_INTERNAL = 9
+VGX_E_STALE = 10
 
 CMD_MOVE_TO, CMD_LINE_TO, CMD_CUBIC_TO, CMD_QUAD_TO, CMD_CLOSE = 0, 1, 2, 3, 4
 CMD_ARC_TO, CMD_ARC, CMD_RECT, CMD_ROUNDED_RECT, CMD_ROUNDED_RECT_VARYING = 5, 6, 7, 8, 9

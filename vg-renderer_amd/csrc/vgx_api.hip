@@ -83,6 +83,14 @@ struct vgx_ctx
 	int instPermOn;
 	DevBuf instPerm, instPermHist;
 	uint64_t instCapPaths, instCapKeys, instCapTasks, instCapDraws;
+	// template mode (vgx_tmpl.hip): the first period of an instanced batch whose instances differ in transform / colours only,
+	// flattened once in local space by the last vgx_tessellate_count
+	int optTmpl; uint32_t optTmplTile, optTmplGroup;
+	bool tmplOn;
+	const vgx_pathset* tmplPs;
+	uint32_t tmplPeriod;
+	vgx_sizes tmplInst;                  // sizes of one instance
+	DevBuf tmplPoly, tmplMesh, tmplMtab, tmplElem, tmplDraws;
 	hipStream_t sideStream; hipEvent_t forkEv, joinEv; // optConcurrentEmit only
 	VgxCaps caps; // element capacities matching the buffers above
 	uint64_t capDraws;
@@ -643,6 +651,7 @@ const char* vgx_status_string(int status)
 	case VGX_E_NO_DEVICE: return "VGX_E_NO_DEVICE";
 	case VGX_E_RANGE: return "VGX_E_RANGE";
 	case VGX_E_INTERNAL: return "VGX_E_INTERNAL";
+	case VGX_E_STALE: return "VGX_E_STALE";
 	default: return "VGX_E_UNKNOWN";
 	}
 }
@@ -685,6 +694,10 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	if (const char* e = getenv("VGX_INST_CLASSES")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { uint32_t p2 = 1; while (p2 * 2 <= (uint32_t)v) { p2 *= 2; } ctx->optInstClasses = p2; } }
 	if (const char* e = getenv("VGX_INST_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { ctx->optInstWaves = v; } }
 	if (const char* e = getenv("VGX_INST_BLOCK")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { ctx->optInstBlock = (uint32_t)v; } }
+	ctx->optTmpl = 1; ctx->optTmplTile = 512; ctx->optTmplGroup = 8; // VGX_TMPL=0: no template mode (instanced batches through k_flatten_inst + k_fill + k_stroke)
+	if (const char* e = getenv("VGX_TMPL")) { ctx->optTmpl = atoi(e) != 0; }
+	if (const char* e = getenv("VGX_TMPL_TILE")) { const int v = atoi(e); if (v >= 64 && v <= (1 << 20)) { ctx->optTmplTile = (uint32_t)v / 64u * 64u; } }
+	if (const char* e = getenv("VGX_TMPL_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 4096) { ctx->optTmplGroup = (uint32_t)v; } }
 	ctx->optPoolWalk = 0; // VGX_WALK=pool: the wave-cooperative walk of vgx_walk.h (same output, same speed: DESIGN.md section 4)
 	if (const char* e = getenv("VGX_WALK")) { ctx->optPoolWalk = strcmp(e, "pool") == 0; }
 	if (const char* e = getenv("VGX_BUILD_WAVES")) { const int v = atoi(e); if (v >= 1 && v < VGX_BUILD_WAVES) { ctx->optBuildWaves = v; } }
@@ -698,7 +711,7 @@ int vgx_destroy(vgx_ctx* ctx)
 		return VGX_E_INVALID_ARG;
 	}
 	DeviceGuard guard(ctx);
-	DevBuf* bufs[] = { &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DevBuf* bufs[] = { &ctx->tmplPoly, &ctx->tmplMesh, &ctx->tmplMtab, &ctx->tmplElem, &ctx->tmplDraws, &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
@@ -719,7 +732,7 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx)
 	if (!ctx) {
 		return 0;
 	}
-	return ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
+	return ctx->tmplPoly.cap + ctx->tmplMesh.cap + ctx->tmplMtab.cap + ctx->tmplElem.cap + ctx->tmplDraws.cap + ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
 }
 
 // ---- path set ---------------------------------------------------------------------------------------
@@ -948,6 +961,7 @@ static int flattenCountCommon(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_dra
 	// pass 1: command instances (sizes the per-command scratch)
 	ctx->caps.cmd_instances = ~0ull; // not known yet: never trips the check in this sizing pass
 	ctx->instPeriod = 0; ctx->instGrouped = 0; ctx->instClasses = 1; ctx->instPermOn = 0;
+	ctx->tmplOn = false; // the scratch is re-sized for this batch; a template belongs to the count call that built it
 	runCmdPrefix(ctx, ps, draws, ndraws, s);
 	if (detectInst && ctx->optInst && ndraws > VGX_SMALL_DRAWS) {
 		vgx_launch_inst_detect(draws, ndraws, (VgxTotals*)ctx->totals.p, s);
@@ -1106,6 +1120,108 @@ int vgx_partition(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, ui
 	return VGX_OK;
 }
 
+// ---- template mode (vgx_tmpl.hip) ---------------------------------------------------------------------
+// One step in template mode: verify every draw against the saved first period, emit. No scratch besides the template.
+static int runTmpl(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, hipStream_t s)
+{
+	VgxTmplArgs a;
+	memset(&a, 0, sizeof(a));
+	a.draws = draws; a.ndraws = ndraws; a.period = ctx->tmplPeriod; a.ninst = ndraws / ctx->tmplPeriod; a.npaths = ps->dev.npaths;
+	a.tdraws = (const vgx_draw*)ctx->tmplDraws.p; a.tpoly = (const float2*)ctx->tmplPoly.p; a.tmesh = (const VgxTmplMesh*)ctx->tmplMesh.p;
+	a.tmtab = (const vgx_mesh*)ctx->tmplMtab.p; a.telem = (const VgxTmplElem*)ctx->tmplElem.p;
+	a.inst = ctx->tmplInst;
+	a.chunks_per_inst = (uint32_t)((ctx->tmplInst.num_elements + 63) / 64);
+	a.group_chunks = ctx->optTmplGroup;
+	a.groups_per_inst = (a.chunks_per_inst + a.group_chunks - 1) / a.group_chunks;
+	a.pos = out->pos; a.color = out->color; a.idx = out->idx; a.meshes_out = out->meshes;
+	a.caps = ctx->caps; a.caps.vertices = out->cap_vertices; a.caps.indices = out->cap_indices; a.caps.meshes = out->cap_meshes;
+	a.totals = (VgxTotals*)ctx->totals.p;
+	if (a.ninst * (uint64_t)a.groups_per_inst > 0x7FFFFFFFull * 4) { return VGX_E_RANGE; }
+	noteHip(ctx, hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s));
+	vgx_launch_tmpl_verify(a, s);
+	mark(ctx, s, "tmpl_verify");
+	vgx_launch_tmpl_emit(a, s);
+	mark(ctx, s, "tmpl_emit");
+	if (dev_sizes || dev_status) {
+		hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, s, (const VgxTotals*)ctx->totals.p, dev_sizes, dev_status);
+	}
+	return launchStatus(ctx);
+}
+
+static bool tmplFor(const vgx_ctx* ctx, const vgx_pathset* ps, uint64_t ndraws)
+{
+	return ctx->tmplOn && ctx->optTmpl && !ctx->asmArmed && ps == ctx->tmplPs && ctx->tmplPeriod && ndraws % ctx->tmplPeriod == 0 && ndraws >= ctx->tmplPeriod;
+}
+
+// vgx_tessellate_count, first thing: do the draws repeat their first period in everything but transform and colours, and are
+// that period's meshes all of the kinds k_tmpl_emit writes (fills; closed Miter AA / Thin strokes)? Then the period is
+// flattened ONCE, in local space, by the ordinary two-phase kernels and kept as the context's template. Returns VGX_OK with
+// ctx->tmplOn set (out_sizes filled), VGX_OK with it clear (not such a batch: the caller continues with the ordinary count),
+// or an error.
+static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, vgx_sizes* out_sizes, hipStream_t s)
+{
+	ctx->tmplOn = false;
+	if (!ctx->optTmpl || !ctx->optInst || ctx->asmArmed || ctx->optTwoPass || ndraws <= VGX_SMALL_DRAWS) { return VGX_OK; }
+	int st;
+	if ((st = ensure(ctx, ctx->totals, sizeof(VgxTotals))) != VGX_OK) { return st; }
+	noteHip(ctx, hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s));
+	vgx_launch_inst_detect(draws, ndraws, (VgxTotals*)ctx->totals.p, s);
+	vgx_launch_tmpl_check(draws, ndraws, ps->dev.npaths, (VgxTotals*)ctx->totals.p, s);
+	if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
+	if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; }
+	if (ctx->hostTotals->inst_detect_inv == 0 || ctx->hostTotals->inst_detect_bad || ctx->hostTotals->tmpl_bad) { return VGX_OK; }
+	const unsigned long long P = ~0ull - ctx->hostTotals->inst_detect_inv;
+	if (P == 0 || P > (1ull << 24) || ndraws % P != 0 || ndraws / P < VGX_INST_MIN_INSTANCES) { return VGX_OK; }
+	// the first period through the ordinary count + two-phase flatten (local space) + mesh sizing
+	if ((st = flattenCountCommon(ctx, ps, draws, P, s, false)) != VGX_OK) { return st; }
+	const vgx_sizes fsz = ctx->hostTotals->sizes;
+	if ((st = ensureMeshBuffers(ctx, fsz.num_poly_vertices, fsz.num_subpaths, fsz.num_meshes)) != VGX_OK) { return st; }
+	{
+		VgxFlattenArgs a = flattenArgs(ctx, ps, draws, P, 0);
+		vgx_launch_flatten(true, a, VGX_GRID_BLOCKS, s);
+	}
+	VgxCaps outCaps = ctx->caps;
+	outCaps.vertices = ~0ull; outCaps.indices = ~0ull;
+	runStrokeCount(ctx, draws, outCaps, 0, s);
+	if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
+	if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; }
+	const VgxTotals& ht = *ctx->hostTotals;
+	const vgx_sizes isz = ht.sizes;
+	if (ht.has_general_stroke || ht.num_round_meshes || isz.num_elements == 0 || isz.num_elements >= (1ull << 31) || isz.num_vertices >= (1ull << 32)
+		|| isz.num_indices >= (1ull << 32) || isz.num_poly_vertices >= (1ull << 32) || isz.num_meshes >= (1ull << 32)) {
+		return VGX_OK; // open / Bevel / Round strokes (or nothing to emit): the ordinary pipeline
+	}
+	const uint64_t M = isz.num_meshes, E = isz.num_elements, V = isz.num_poly_vertices;
+	if ((st = ensure(ctx, ctx->tmplPoly, (V + 1) * 2 * sizeof(float))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->tmplMesh, (M + 1) * sizeof(VgxTmplMesh))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->tmplMtab, (M + 1) * sizeof(vgx_mesh))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->tmplElem, (E + 64) * sizeof(VgxTmplElem))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->tmplDraws, (size_t)P * sizeof(vgx_draw))) != VGX_OK) { return st; }
+	VgxTmplBuild b;
+	b.draws = draws; b.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; b.mprep = (const VgxMeshPrep*)ctx->mprep.p; b.mtab = (const vgx_mesh*)ctx->mtab.p;
+	b.prefix_fill = (const uint64_t*)ctx->elemPrefix.p; b.prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
+	b.num_meshes = M; b.num_elems = E; b.tile = ctx->optTmplTile;
+	b.tmesh = (VgxTmplMesh*)ctx->tmplMesh.p; b.tmtab = (vgx_mesh*)ctx->tmplMtab.p; b.telem = (VgxTmplElem*)ctx->tmplElem.p;
+	vgx_launch_tmpl_build(b, s);
+	HIPCHK(ctx, hipMemcpyAsync(ctx->tmplPoly.p, ctx->poly.p, V * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+	HIPCHK(ctx, hipMemcpyAsync(ctx->tmplDraws.p, draws, (size_t)P * sizeof(vgx_draw), hipMemcpyDeviceToDevice, s));
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	if ((st = launchStatus(ctx)) != VGX_OK) { return st; }
+	ctx->tmplInst = isz;
+	ctx->tmplPeriod = (uint32_t)P;
+	ctx->tmplPs = ps;
+	ctx->tmplOn = true;
+	const uint64_t ninst = ndraws / P;
+	vgx_sizes z;
+	z.num_poly_vertices = ninst * isz.num_poly_vertices; z.num_subpaths = ninst * isz.num_subpaths; z.num_meshes = ninst * isz.num_meshes;
+	z.num_vertices = ninst * isz.num_vertices; z.num_indices = ninst * isz.num_indices; z.num_serial_draws = ninst * isz.num_serial_draws;
+	z.num_cmd_instances = ninst * isz.num_cmd_instances; z.num_elements = ninst * isz.num_elements; z.num_fill_elements = ninst * isz.num_fill_elements;
+	z.num_drawcmds = 0;
+	*out_sizes = z;
+	ctx->hostTotals->sizes = z; // what vgx_tessellate_emit checks the caller's capacities against
+	return VGX_OK;
+}
+
 // ---- tessellate ---------------------------------------------------------------------------------------
 int vgx_tessellate_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, vgx_sizes* out_sizes, void* stream)
 {
@@ -1116,7 +1232,13 @@ int vgx_tessellate_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* dr
 	hipStream_t s = (hipStream_t)stream;
 	markBegin(ctx, s);
 	ctx->lastStage = 0;
-	int st = flattenCountCommon(ctx, ps, draws, ndraws, s, true);
+	int st = tryTemplate(ctx, ps, draws, ndraws, out_sizes, s);
+	if (st != VGX_OK) { return st; }
+	if (ctx->tmplOn) {
+		ctx->lastPs = ps; ctx->lastDraws = draws; ctx->lastNDraws = ndraws; ctx->lastStage = 2;
+		return VGX_OK;
+	}
+	st = flattenCountCommon(ctx, ps, draws, ndraws, s, true);
 	if (st != VGX_OK) { return st; }
 	const vgx_sizes sz = ctx->hostTotals->sizes;
 	// Polyline scratch doubles as the heap of the single-pass path (k_flatten_build). Its waves switch to a fresh block
@@ -1162,6 +1284,7 @@ int vgx_tessellate_emit(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* dra
 	}
 	hipStream_t s = (hipStream_t)stream;
 	markBegin(ctx, s);
+	if (tmplFor(ctx, ps, ndraws)) { return runTmpl(ctx, ps, draws, ndraws, out, nullptr, nullptr, s); }
 	return runStrokeEmit(ctx, draws, out, s);
 }
 
@@ -1170,6 +1293,12 @@ int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 	DeviceGuard guard(ctx);
 	if (!ctx || !ps || !out || (!draws && ndraws) || !out->pos || !out->color || !out->idx) {
 		return VGX_E_INVALID_ARG;
+	}
+	if (tmplFor(ctx, ps, ndraws)) {
+		hipStream_t s = (hipStream_t)stream;
+		markBegin(ctx, s);
+		ctx->lastStage = 0;
+		return runTmpl(ctx, ps, draws, ndraws, out, dev_sizes, dev_status, s);
 	}
 	if (ndraws > ctx->capDraws || !ctx->cmdCnt.p || !ctx->subFirst.p || !ctx->poly.p || !ctx->mtab.p) {
 		return VGX_E_NOSPACE; // scratch was never sized for a batch like this: run vgx_tessellate_count once
@@ -1435,7 +1564,7 @@ int vgx_get_failure_info(vgx_ctx* ctx, vgx_failure_info* out, void* stream)
 	out->reason = ctx->hostTotals->fail_reason;
 	out->aux = ctx->hostTotals->fail_aux;
 	out->segment = ctx->hostTotals->fail_segment;
-	out->segment_items = ctx->optInst ? (ctx->instPeriod ? (ctx->instPermOn ? 4u : 1u) : (ctx->instGrouped ? (ctx->instClasses > 1 ? 3u : 2u) : 0u)) : 0u; // flatten mode chosen by the last count call
+	out->segment_items = ctx->tmplOn ? 5u : ctx->optInst ? (ctx->instPeriod ? (ctx->instPermOn ? 4u : 1u) : (ctx->instGrouped ? (ctx->instClasses > 1 ? 3u : 2u) : 0u)) : 0u; // flatten mode chosen by the last count call
 	for (int i = 0; i < 16; ++i) { out->prof[i] = ctx->hostTotals->prof[i]; }
 	return VGX_OK;
 }

@@ -902,10 +902,10 @@ struct FillFetch
 	V2 p1, pNextB, pPrevB;
 };
 
+__device__ __forceinline__ void fill_emit_store(float* pos, uint32_t* color_out, uint16_t* idx_out, const FillFetch& F, V2 dPrev, V2 d12);
+
 __device__ __forceinline__ void fill_emit_chunk(float* pos, uint32_t* color_out, uint16_t* idx_out, const FillFetch& F)
 {
-	const bool valid = F.valid;
-	const uint32_t j = F.j, N = F.N, color = F.color;
 	const V2 p1 = F.p1;
 	V2 pNext;
 	pNext.x = wave_from_next(p1.x, 0.0f); pNext.y = wave_from_next(p1.y, 0.0f);
@@ -923,7 +923,17 @@ __device__ __forceinline__ void fill_emit_chunk(float* pos, uint32_t* color_out,
 #else
 	if (F.aaElem && !F.prevInWave) { dPrev = v2dir(F.pPrevB, p1); }
 #endif
+	fill_emit_store(pos, color_out, idx_out, F, dPrev, d12);
+}
 
+// The stores of one fill element whose two edge directions are known (dPrev = vec2Dir(previous corner, p1), d12 =
+// vec2Dir(p1, next corner)); fill_emit_chunk gets them from the neighbouring lanes, the template emitter (vgx_tmpl.hip)
+// computes them per lane.
+__device__ __forceinline__ void fill_emit_store(float* pos, uint32_t* color_out, uint16_t* idx_out, const FillFetch& F, V2 dPrev, V2 d12)
+{
+	const bool valid = F.valid;
+	const uint32_t j = F.j, N = F.N, color = F.color;
+	const V2 p1 = F.p1;
 	if (valid) {
 		if (F.aaElem) {
 #ifdef VGX_EXP_CHEAPMATH

@@ -71,6 +71,49 @@ struct VgxStrokeArgs
 };
 
 
+// template mode (vgx_tmpl.hip)
+struct VgxTmplBuild // count pass: the first period's ordinary count + emit results -> template tables
+{
+	const vgx_draw* draws;       // the batch's first period
+	const VgxMeshDesc* mdesc;
+	const VgxMeshPrep* mprep;
+	const vgx_mesh* mtab;
+	const uint64_t* prefix_fill;   // [num_meshes + 1]
+	const uint64_t* prefix_stroke; // [num_meshes + 1]
+	uint64_t num_meshes, num_elems;
+	uint32_t tile;               // elements per tile of the processing order (a multiple of 64)
+	VgxTmplMesh* tmesh;
+	vgx_mesh* tmtab;
+	VgxTmplElem* telem;
+};
+struct VgxTmplArgs // one step
+{
+	const vgx_draw* draws;
+	uint64_t ndraws;
+	uint64_t ninst;
+	uint32_t period;
+	uint32_t npaths;
+	const vgx_draw* tdraws;      // the first period as vgx_tessellate_count saw it
+	const float2* tpoly;         // local polyline of one period
+	const VgxTmplMesh* tmesh;
+	const vgx_mesh* tmtab;       // mesh records of one instance (offsets relative to the instance)
+	const VgxTmplElem* telem;
+	vgx_sizes inst;              // sizes of ONE instance
+	uint32_t chunks_per_inst;    // ceil(elements / 64)
+	uint32_t group_chunks;       // chunks one wave processes
+	uint32_t groups_per_inst;
+	float* pos;
+	uint32_t* color;
+	uint16_t* idx;
+	vgx_mesh* meshes_out;        // may be null
+	VgxCaps caps;                // vertices / indices / meshes of the caller's buffers
+	VgxTotals* totals;
+};
+void vgx_launch_tmpl_check(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, VgxTotals* totals, hipStream_t s); // after vgx_launch_inst_detect
+void vgx_launch_tmpl_build(const VgxTmplBuild& b, hipStream_t s);
+void vgx_launch_tmpl_verify(const VgxTmplArgs& a, hipStream_t s);
+void vgx_launch_tmpl_emit(const VgxTmplArgs& a, hipStream_t s);
+
 // concave-fill fringes (vgx_concave.hip)
 struct VgxConcaveArgs
 {

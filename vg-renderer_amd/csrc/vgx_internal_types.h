@@ -120,7 +120,9 @@ struct VgxTotals
 	uint32_t inst_tol_varies;            // vgx_tessellate_count, periodic batch: some draw's tolerance differs from its image in the first period
 	uint32_t has_general_stroke;         // scan over the meshes: some stroke mesh is not a closed Miter AA / Thin stroke -> k_stroke emits the strokes, else k_stroke_simple
 	uint32_t cache_has_uniform;          // vgx_cache_submit: some submitted mesh was cached without per-vertex colours (k_cache_meshes -> k_cache_uniform_colors)
-	uint32_t pad_u32[3];
+	uint32_t tmpl_bad;                   // vgx_tessellate_count (k_tmpl_check): some draw differs from its image in the first period in a field the
+	                                     // flattener or the mesh sizes depend on -> no template mode (vgx_tmpl.hip)
+	uint32_t pad_u32[2];
 	// diagnostics of the first failure (vgx_get_failure_info)
 	uint32_t fail_reason;  // VGX_FAIL_*
 	uint32_t fail_aux;
@@ -143,6 +145,19 @@ enum {
 	VGX_FAIL_MESH_TOO_LARGE = 11
 };
 #define VGX_LONG_SUBPATH 2048
+
+// ---- template mode (vgx_tmpl.hip): one period of an instanced batch flattened once, in local space -----------------------
+struct VgxTmplMesh // one mesh of the template. 32 bytes
+{
+	uint32_t poly_first; // first vertex of its polyline in the template's LOCAL polyline
+	uint32_t n;          // polyline vertices = elements
+	uint32_t v_off;      // first output vertex inside one instance
+	uint32_t i_off;      // first output index inside one instance
+	uint32_t drawk;      // draw inside the period
+	uint32_t kind;       // VgxMeshDesc::kind word
+	float f0, f1;        // fills: fringe / 2 (the sign is per instance), -; strokes: hsw, hswAA (thin: fringe, fringe)
+};
+struct VgxTmplElem { uint32_t mesh, j; }; // one element (polyline vertex j of template mesh `mesh`), in processing order
 
 // Capacities the device-side checks compare against.
 struct VgxCaps

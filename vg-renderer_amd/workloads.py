@@ -351,3 +351,93 @@ def fuzz_draws(ps, seed, ndraws=None):
                        int(rs.randint(0, 3)), int(rs.randint(0, 3)), aa=bool(rs.uniform() < 0.75), avg_scale=sc,
                        fringe=float(d["fringe"][i]))
     return d
+
+
+# ---- closed-shape fuzz set (template mode: fills + closed Miter AA strokes) ----------------------
+def closed_fuzz_paths(seed, npaths=48):
+    """Random paths whose sub-paths are all CLOSED with at least three distinct vertices: move / line / cubic / quad /
+    polyline runs ending in CLOSE, rects, rounded rects, circles, ellipses -- i.e. every stroke of them is a closed
+    stroke (the kind vgx_tmpl.hip emits) and every command of the flattener is exercised."""
+    rs = np.random.RandomState(seed)
+    b = PathSetBuilder()
+    for p in range(npaths):
+        b.begin_path()
+        for s in range(int(rs.randint(1, 4))):
+            kind = int(rs.randint(0, 8))
+            scale = float(rs.choice([3.0, 20.0, 120.0]))
+            ox, oy = rs.uniform(-80, 80, size=2)
+            if kind == 5:
+                b.rect(ox, oy, rs.uniform(0.3, 1) * scale, rs.uniform(0.3, 1) * scale)
+            elif kind == 6:
+                w, h = rs.uniform(0.4, 1, size=2) * scale
+                if rs.uniform() < 0.5:
+                    b.rounded_rect(ox, oy, w, h, rs.uniform(0.05, 0.4) * scale)
+                else:
+                    b.rounded_rect_varying(ox, oy, w, h, *(rs.uniform(0.02, 0.4, size=4) * scale))
+            elif kind == 7:
+                if rs.uniform() < 0.5:
+                    b.circle(ox, oy, rs.uniform(0.2, 1) * scale)
+                else:
+                    b.ellipse(ox, oy, rs.uniform(0.2, 1) * scale, rs.uniform(0.2, 1) * scale)
+            else:
+                m = int(rs.randint(3, 14))
+                ang = np.sort(rs.uniform(0.0, 2.0 * np.pi, size=m))
+                rad = scale * rs.uniform(0.5, 1.0, size=m)
+                P = np.stack([ox + rad * np.cos(ang), oy + rad * np.sin(ang)], axis=1)
+                b.move_to(P[0, 0], P[0, 1])
+                for i in range(1, m + 1):
+                    q = P[i % m]
+                    a = P[i - 1]
+                    t = int(rs.randint(0, 5))
+                    if i == m and rs.uniform() < 0.5:
+                        break  # leave the last edge to CLOSE
+                    if t <= 1:
+                        b.line_to(q[0], q[1])
+                    elif t <= 3:
+                        c1 = a + (q - a) * 0.33 + rs.uniform(-0.2, 0.2, size=2) * scale
+                        c2 = a + (q - a) * 0.66 + rs.uniform(-0.2, 0.2, size=2) * scale
+                        b.cubic_to(c1[0], c1[1], c2[0], c2[1], q[0], q[1])
+                    else:
+                        c = (a + q) * 0.5 + rs.uniform(-0.3, 0.3, size=2) * scale
+                        b.quadratic_to(c[0], c[1], q[0], q[1])
+                b.close()
+        b.end_path()
+    return b.arrays()
+
+
+def template_draws(ps, seed, instances, same_colors=False):
+    """One drawing of `ps` (every path once; fills AA / plain / none, closed Miter AA strokes of hairline and regular
+    widths, per-path scale / tolerance / fringe) repeated for `instances` instances that differ only in what the template
+    mode allows to differ: the transform (any affine matrix; the record's `scale` stays the path's) and the colours."""
+    rs = np.random.RandomState(seed + 4242)
+    n = ps.npaths
+    one = make_draws(n)
+    one["path"] = np.arange(n, dtype=np.uint32)
+    for i in range(n):
+        sc = float(rs.choice([0.5, 1.0, 1.0, 2.0]))
+        one["scale"][i] = np.float32(sc)
+        one["tess_tol"][i] = np.float32(rs.choice([0.25, 0.25, 0.1, 0.5]))
+        one["fringe"][i] = np.float32(rs.choice([1.0, 1.0, 0.5]))
+        r = rs.uniform()
+        if r < 0.8:
+            set_fill(one, i, int(rs.randint(0, 1 << 32, dtype=np.uint64)), aa=bool(rs.uniform() < 0.8))
+            if rs.uniform() < 0.2:
+                one["fill_flags"][i] |= np.uint32(0x100)  # VGX_FILL_INDEX_ORDER_SSE
+        if r > 0.5 or rs.uniform() < 0.3:
+            set_stroke(one, i, int(rs.randint(0, 1 << 32, dtype=np.uint64)), float(rs.choice([0.3, 0.9, 1.5, 3.0, 12.0])),
+                       capi.CAP_BUTT, capi.JOIN_MITER, aa=True, avg_scale=sc, fringe=float(one["fringe"][i]))
+    d = np.tile(one, instances)
+    for k in range(instances):
+        s = slice(k * n, (k + 1) * n)
+        f = float(rs.choice([0.5, 1.0, 1.0, 3.0]))
+        ang = rs.uniform(0, 2 * np.pi)
+        sh = rs.uniform(-0.3, 0.3)
+        c, sn = np.cos(ang), np.sin(ang)
+        d["mtx"][s] = np.float32([f * c, f * sn, f * (-sn + sh * c), f * (c + sh * sn), rs.uniform(-500, 500), rs.uniform(-500, 500)])
+        if k % 7 == 3:
+            d["mtx"][s, 0] *= np.float32(-1.0)  # mirrored instance: fill orientation and the joins' inner sides flip
+            d["mtx"][s, 1] *= np.float32(-1.0)
+        if not same_colors:
+            d["fill_color"][s] = rs.randint(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+            d["stroke_color"][s] = rs.randint(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+    return d

@@ -90,15 +90,14 @@ def test_tiger_template_is_what_runs_and_equals_reference_and_ordinary_path(rt, 
     ctx.close()
 
 
-@pytest.mark.parametrize("seed,ninst,tile,group", [(900, 40, None, None), (901, 33, "64", "1"), (902, 64, "128", "3"), (903, 57, "4096", "8"), (904, 36, "192", "5")])
-def test_template_fuzz(rt, wl, oracle, monkeypatch, seed, ninst, tile, group):
+@pytest.mark.parametrize("seed,ninst,tile", [(900, 40, None), (901, 33, "64"), (902, 64, "128"), (903, 57, "960"), (904, 36, "192")])
+def test_template_fuzz(rt, wl, oracle, monkeypatch, seed, ninst, tile):
     """Closed-shape fuzz drawings (every path command, serial shapes included; fills AA / plain / SSE index order; hairline
     and regular closed Miter strokes; per-path scale / tolerance / fringe) under random affine instance transforms --
     rotations, shears, mirrored instances (orientation and inner sides flip per instance) -- and per-instance colours;
-    tile / group sizes of the processing order that do and do not divide the element count."""
+    tile sizes that do and do not divide the element count (meshes cut by tile borders fetch their neighbours from L2)."""
     if tile:
         monkeypatch.setenv("VGX_TMPL_TILE", tile)
-        monkeypatch.setenv("VGX_TMPL_GROUP", group)
     ps = wl.closed_fuzz_paths(seed, npaths=72)
     d = wl.template_draws(ps, seed, ninst)
     assert d.shape[0] > 2048
@@ -193,4 +192,33 @@ def test_batches_that_are_not_templates_take_the_ordinary_path(rt, wl, oracle):
         assert got.mode != MODE_TEMPLATE and "tmpl_emit" not in got.stages, name
         assert got.status == 0, name
         assert_mesh_equal(got, oracle.tessellate(ps, d), name)
+    ctx.close()
+
+
+def test_template_tiles_with_many_small_meshes(rt, wl, oracle):
+    """Rectangles and triangles only: a 1024-element tile touches more meshes than the LDS record table holds and takes the
+    per-lane fallback of k_tmpl_emit; mixed with larger shapes so that both forms run in one launch."""
+    pm = __import__("importlib").import_module("vg-renderer_amd.pathset")
+    rs = np.random.RandomState(77)
+    b = pm.PathSetBuilder()
+    for p in range(90):
+        b.begin_path()
+        for s in range(int(rs.randint(2, 7)) if p < 70 else 1):
+            x, y = rs.uniform(-200, 200, size=2)
+            if p >= 70:
+                b.circle(x, y, float(rs.uniform(30, 90)))
+            elif rs.uniform() < 0.5:
+                b.rect(x, y, float(rs.uniform(2, 30)), float(rs.uniform(2, 30)))
+            else:
+                b.move_to(x, y)
+                b.line_to(x + float(rs.uniform(5, 20)), y + float(rs.uniform(-3, 3)))
+                b.line_to(x + float(rs.uniform(-3, 3)), y + float(rs.uniform(5, 20)))
+                b.close()
+        b.end_path()
+    ps = b.arrays()
+    d = wl.template_draws(ps, 940, 35)
+    ctx = rt.Context(0)
+    got = _run(rt, ctx, ps, d)
+    assert got.mode == MODE_TEMPLATE and got.status == 0
+    assert_mesh_equal(got, oracle.tessellate(ps, d), "small meshes")
     ctx.close()

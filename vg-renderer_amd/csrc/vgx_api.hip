@@ -85,7 +85,9 @@ struct vgx_ctx
 	uint64_t instCapPaths, instCapKeys, instCapTasks, instCapDraws;
 	// template mode (vgx_tmpl.hip): the first period of an instanced batch whose instances differ in transform / colours only,
 	// flattened once in local space by the last vgx_tessellate_count
-	int optTmpl; uint32_t optTmplTile, optTmplGroup;
+	int optTmpl; uint32_t optTmplTile;
+	uint32_t tmplTileSize;               // elements per tile of the current template
+	DevBuf tmplTile;                     // [tiles] first mesh of every tile
 	bool tmplOn;
 	const vgx_pathset* tmplPs;
 	uint32_t tmplPeriod;
@@ -694,10 +696,9 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	if (const char* e = getenv("VGX_INST_CLASSES")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { uint32_t p2 = 1; while (p2 * 2 <= (uint32_t)v) { p2 *= 2; } ctx->optInstClasses = p2; } }
 	if (const char* e = getenv("VGX_INST_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { ctx->optInstWaves = v; } }
 	if (const char* e = getenv("VGX_INST_BLOCK")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { ctx->optInstBlock = (uint32_t)v; } }
-	ctx->optTmpl = 1; ctx->optTmplTile = 512; ctx->optTmplGroup = 8; // VGX_TMPL=0: no template mode (instanced batches through k_flatten_inst + k_fill + k_stroke)
+	ctx->optTmpl = 1; ctx->optTmplTile = 1024; // VGX_TMPL=0: no template mode (instanced batches through k_flatten_inst + k_fill + k_stroke)
 	if (const char* e = getenv("VGX_TMPL")) { ctx->optTmpl = atoi(e) != 0; }
-	if (const char* e = getenv("VGX_TMPL_TILE")) { const int v = atoi(e); if (v >= 64 && v <= (1 << 20)) { ctx->optTmplTile = (uint32_t)v / 64u * 64u; } }
-	if (const char* e = getenv("VGX_TMPL_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 4096) { ctx->optTmplGroup = (uint32_t)v; } }
+	if (const char* e = getenv("VGX_TMPL_TILE")) { const int v = atoi(e); if (v >= 64 && v <= 1024) { ctx->optTmplTile = (uint32_t)v / 64u * 64u; } } // testing: elements per tile (<= the LDS stage of k_tmpl_emit)
 	ctx->optPoolWalk = 0; // VGX_WALK=pool: the wave-cooperative walk of vgx_walk.h (same output, same speed: DESIGN.md section 4)
 	if (const char* e = getenv("VGX_WALK")) { ctx->optPoolWalk = strcmp(e, "pool") == 0; }
 	if (const char* e = getenv("VGX_BUILD_WAVES")) { const int v = atoi(e); if (v >= 1 && v < VGX_BUILD_WAVES) { ctx->optBuildWaves = v; } }
@@ -711,7 +712,7 @@ int vgx_destroy(vgx_ctx* ctx)
 		return VGX_E_INVALID_ARG;
 	}
 	DeviceGuard guard(ctx);
-	DevBuf* bufs[] = { &ctx->tmplPoly, &ctx->tmplMesh, &ctx->tmplMtab, &ctx->tmplElem, &ctx->tmplDraws, &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DevBuf* bufs[] = { &ctx->tmplTile, &ctx->tmplPoly, &ctx->tmplMesh, &ctx->tmplMtab, &ctx->tmplElem, &ctx->tmplDraws, &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
@@ -732,7 +733,7 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx)
 	if (!ctx) {
 		return 0;
 	}
-	return ctx->tmplPoly.cap + ctx->tmplMesh.cap + ctx->tmplMtab.cap + ctx->tmplElem.cap + ctx->tmplDraws.cap + ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
+	return ctx->tmplTile.cap + ctx->tmplPoly.cap + ctx->tmplMesh.cap + ctx->tmplMtab.cap + ctx->tmplElem.cap + ctx->tmplDraws.cap + ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
 }
 
 // ---- path set ---------------------------------------------------------------------------------------
@@ -1130,13 +1131,13 @@ static int runTmpl(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 	a.tdraws = (const vgx_draw*)ctx->tmplDraws.p; a.tpoly = (const float2*)ctx->tmplPoly.p; a.tmesh = (const VgxTmplMesh*)ctx->tmplMesh.p;
 	a.tmtab = (const vgx_mesh*)ctx->tmplMtab.p; a.telem = (const VgxTmplElem*)ctx->tmplElem.p;
 	a.inst = ctx->tmplInst;
-	a.chunks_per_inst = (uint32_t)((ctx->tmplInst.num_elements + 63) / 64);
-	a.group_chunks = ctx->optTmplGroup;
-	a.groups_per_inst = (a.chunks_per_inst + a.group_chunks - 1) / a.group_chunks;
+	a.tile_mesh0 = (const uint32_t*)ctx->tmplTile.p;
+	a.tile = ctx->tmplTileSize;
+	a.tiles_per_inst = (uint32_t)((ctx->tmplInst.num_elements + a.tile - 1) / a.tile);
 	a.pos = out->pos; a.color = out->color; a.idx = out->idx; a.meshes_out = out->meshes;
 	a.caps = ctx->caps; a.caps.vertices = out->cap_vertices; a.caps.indices = out->cap_indices; a.caps.meshes = out->cap_meshes;
 	a.totals = (VgxTotals*)ctx->totals.p;
-	if (a.ninst * (uint64_t)a.groups_per_inst > 0x7FFFFFFFull * 4) { return VGX_E_RANGE; }
+	if (a.ninst * (uint64_t)a.tiles_per_inst > 0x7FFFFFFFull) { return VGX_E_RANGE; } // one workgroup per (instance, tile)
 	noteHip(ctx, hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s));
 	vgx_launch_tmpl_verify(a, s);
 	mark(ctx, s, "tmpl_verify");
@@ -1197,10 +1198,12 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	if ((st = ensure(ctx, ctx->tmplMtab, (M + 1) * sizeof(vgx_mesh))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->tmplElem, (E + 64) * sizeof(VgxTmplElem))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->tmplDraws, (size_t)P * sizeof(vgx_draw))) != VGX_OK) { return st; }
+	const uint32_t tileSize = ctx->optTmplTile;
+	if ((st = ensure(ctx, ctx->tmplTile, ((E + tileSize - 1) / tileSize + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
 	VgxTmplBuild b;
 	b.draws = draws; b.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; b.mprep = (const VgxMeshPrep*)ctx->mprep.p; b.mtab = (const vgx_mesh*)ctx->mtab.p;
 	b.prefix_fill = (const uint64_t*)ctx->elemPrefix.p; b.prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
-	b.num_meshes = M; b.num_elems = E; b.tile = ctx->optTmplTile;
+	b.num_meshes = M; b.num_elems = E; b.tile = tileSize; b.tile_mesh0 = (uint32_t*)ctx->tmplTile.p;
 	b.tmesh = (VgxTmplMesh*)ctx->tmplMesh.p; b.tmtab = (vgx_mesh*)ctx->tmplMtab.p; b.telem = (VgxTmplElem*)ctx->tmplElem.p;
 	vgx_launch_tmpl_build(b, s);
 	HIPCHK(ctx, hipMemcpyAsync(ctx->tmplPoly.p, ctx->poly.p, V * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1208,6 +1211,7 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	HIPCHK(ctx, hipStreamSynchronize(s));
 	if ((st = launchStatus(ctx)) != VGX_OK) { return st; }
 	ctx->tmplInst = isz;
+	ctx->tmplTileSize = tileSize;
 	ctx->tmplPeriod = (uint32_t)P;
 	ctx->tmplPs = ps;
 	ctx->tmplOn = true;

@@ -85,6 +85,7 @@ struct VgxTmplBuild // count pass: the first period's ordinary count + emit resu
 	VgxTmplMesh* tmesh;
 	vgx_mesh* tmtab;
 	VgxTmplElem* telem;
+	uint32_t* tile_mesh0;        // [tiles] template mesh that owns the first element of every tile
 };
 struct VgxTmplArgs // one step
 {
@@ -98,10 +99,10 @@ struct VgxTmplArgs // one step
 	const VgxTmplMesh* tmesh;
 	const vgx_mesh* tmtab;       // mesh records of one instance (offsets relative to the instance)
 	const VgxTmplElem* telem;
+	const uint32_t* tile_mesh0;
+	uint32_t tile;               // elements per tile (= one workgroup of k_tmpl_emit)
+	uint32_t tiles_per_inst;
 	vgx_sizes inst;              // sizes of ONE instance
-	uint32_t chunks_per_inst;    // ceil(elements / 64)
-	uint32_t group_chunks;       // chunks one wave processes
-	uint32_t groups_per_inst;
 	float* pos;
 	uint32_t* color;
 	uint16_t* idx;

@@ -157,7 +157,11 @@ struct VgxTmplMesh // one mesh of the template. 32 bytes
 	uint32_t kind;       // VgxMeshDesc::kind word
 	float f0, f1;        // fills: fringe / 2 (the sign is per instance), -; strokes: hsw, hswAA (thin: fringe, fringe)
 };
-struct VgxTmplElem { uint32_t mesh, j; }; // one element (polyline vertex j of template mesh `mesh`), in processing order
+struct VgxTmplElem // one element (polyline vertex j of template mesh `mesh`), in processing order
+{
+	uint32_t mesh;
+	uint32_t jq;   // j | (position of the element inside its tile, in OUTPUT order) << 16
+};
 
 // Capacities the device-side checks compare against.
 struct VgxCaps

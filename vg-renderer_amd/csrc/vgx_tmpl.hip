@@ -143,8 +143,9 @@ __global__ __launch_bounds__(256) void k_tmpl_elems(VgxTmplBuild B)
 		const uint64_t slot = x0 + (isFill ? f - f0 : (f1 - f0) + (s - s0));
 		VgxTmplElem r;
 		r.mesh = (uint32_t)m;
-		r.j = j;
+		r.jq = j | ((uint32_t)(e - x0) << 16); // j < 65536 (a mesh holds at most 65536 vertices), position in the tile < tile <= 65536
 		B.telem[slot] = r;
+		if (e == x0) { B.tile_mesh0[e / T] = (uint32_t)m; }
 	}
 }
 
@@ -194,6 +195,18 @@ __global__ __launch_bounds__(256) void k_tmpl_verify(VgxTmplArgs A)
 }
 
 // ---- step: emit ------------------------------------------------------------------------------------------------------
+// One workgroup = one TILE of one instance: `tile` consecutive elements of the instance's output-ordered element stream, i.e.
+// a contiguous piece of each output stream (~40 KB), a contiguous range of the template's meshes and of its polyline.
+//   phase 0  one thread per mesh of the tile: template mesh record + the instance's draw record (transform, colour) -> a
+//            64-byte record in LDS; convex AA fills: the orientation of the TRANSFORMED polygon's first triangle
+//            (stroker.cpp:721-723), once per mesh instead of once per element
+//   phase 1  one lane per element: its template vertex from L2, transformPos2D (vg_util.h:24-28) ONCE, parked in LDS at the
+//            element's output-order position inside the tile ("the growing polyline staged in LDS")
+//   phase 2  one lane per element: the neighbouring corners (j - 2, j - 1, j + 1; the wrap-around corners of closed shapes)
+//            from LDS -- from L2 + transform for the handful of elements whose neighbour lies in another tile --, the
+//            stroker's per-element arithmetic, stores at closed-form addresses.
+// Per 64 elements the kernel issues two global loads (element record, vertex) beside its stores; everything shared by the
+// elements of a mesh comes from LDS.
 struct TmplXf { float m0, m1, m2, m3, m4, m5; };
 __device__ __forceinline__ V2 tmpl_xf(const TmplXf& m, float2 p) // transformPos2D, vg_util.h:24-28
 {
@@ -202,21 +215,20 @@ __device__ __forceinline__ V2 tmpl_xf(const TmplXf& m, float2 p) // transformPos
 
 // One element of a CLOSED stroke with MITER joins, AA (4 rails) or Thin (3 rails): stroke_chunk_simple (vgx_elem.h) without
 // its neighbour lanes -- the previous join's inner side and, on the last element, join 0's are recomputed from the
-// template's vertices instead of being carried (same inputs, same arithmetic, same bits).
-__device__ __forceinline__ void tmpl_stroke_elem(const VgxTmplMesh& tm, uint32_t j, const float2* vt, const TmplXf& xf, uint32_t color,
+// transformed vertices (vtx(jj) = transformed polyline vertex jj of the mesh) instead of being carried: same inputs, same
+// arithmetic, same bits.
+template<class VF>
+__device__ __forceinline__ void tmpl_stroke_elem(uint32_t kindWord, uint32_t N, float hsw, float hswAA, uint32_t j, V2 p1, const VF& vtx, uint32_t color,
 	float* posMesh, uint32_t* colMesh, uint16_t* idxMesh)
 {
-	const uint32_t N = tm.n;
-	const bool thin = VGX_MD_KIND(tm.kind) == VGX_MESH_STROKE_AA_THIN;
+	const bool thin = VGX_MD_KIND(kindWord) == VGX_MESH_STROKE_AA_THIN;
 	const uint32_t R = thin ? 3u : 4u;
 	const uint32_t bridgeIdx = thin ? 12u : 18u;
-	const float hsw = tm.f0, hswAA = tm.f1;
-	const float sideWidth = thin ? tm.f0 : tm.f1; // fringe : hswAA
+	const float sideWidth = thin ? hsw : hswAA; // fringe : hswAA
 	const uint32_t jn1 = j + 1 < N ? j + 1 : 0u;
 	const uint32_t jp1 = j > 0 ? j - 1 : N - 1;
-	const V2 p1 = tmpl_xf(xf, vt[j]);
-	const V2 pNext = tmpl_xf(xf, vt[jn1]);
-	const V2 pPrev = tmpl_xf(xf, vt[jp1]);
+	const V2 pNext = vtx(jn1);
+	const V2 pPrev = vtx(jp1);
 	const V2 d12 = v2dir(p1, pNext);
 	const V2 dPrev = v2dir(pPrev, p1);
 	const VgxJoin jn = vgx_join_dirs(dPrev, d12, sideWidth);
@@ -232,11 +244,13 @@ __device__ __forceinline__ void tmpl_stroke_elem(const VgxTmplMesh& tm, uint32_t
 		const V2 q0 = L ? v2add(p1, vf) : v2sub(p1, vf);
 		const V2 q2 = L ? v2sub(p1, vf) : v2add(p1, vf);
 		PosPair q; q.x0 = q0.x; q.y0 = q0.y; q.x1 = p1.x; q.y1 = p1.y;
+		VGX_ST_GUARD(c0) {
 		*(PosPair*)pp = q;
 		*(float2*)(pp + 4) = make_float2(q2.x, q2.y);
 		ColPair c; c.c0 = c0; c.c1 = color;
 		*(ColPair*)pc = c;
 		pc[2] = c0;
+		}
 	} else { // :1524-1579
 		const V2 vhaa = v2mul(jn.v, hswAA);
 		const V2 vh = v2mul(jn.v, hsw);
@@ -245,17 +259,19 @@ __device__ __forceinline__ void tmpl_stroke_elem(const VgxTmplMesh& tm, uint32_t
 		const V2 q2 = L ? v2sub(p1, vh) : v2add(p1, vh);
 		const V2 q3 = L ? v2sub(p1, vhaa) : v2add(p1, vhaa);
 		PosPair q; q.x0 = q0.x; q.y0 = q0.y; q.x1 = q1.x; q.y1 = q1.y;
-		*(PosPair*)pp = q;
 		PosPair r; r.x0 = q2.x; r.y0 = q2.y; r.x1 = q3.x; r.y1 = q3.y;
+		VGX_ST_GUARD(c0 ^ __float_as_uint(q.x0) ^ __float_as_uint(r.y1)) {
+		*(PosPair*)pp = q;
 		*(PosPair*)(pp + 4) = r;
 		ColPair c; c.c0 = c0; c.c1 = color;
 		*(ColPair*)pc = c;
 		ColPair d; d.c0 = color; d.c1 = c0;
 		*(ColPair*)(pc + 2) = d;
+		}
 	}
 	if (j > 0) { // the bridge from the previous join (stroker.cpp:1557-1564, 1714-1721; thin :2093-2098, 2175-2180)
 		const uint32_t jp2 = jp1 > 0 ? jp1 - 1 : N - 1;
-		const V2 pPrev2 = tmpl_xf(xf, vt[jp2]);
+		const V2 pPrev2 = vtx(jp2);
 		const VgxJoin jp = vgx_join_dirs(v2dir(pPrev2, pPrev), dPrev, sideWidth);
 		const uint32_t pb = R * (j - 1), ptop = pb + R - 1;
 		const Rails p = thin ? (jp.leftInner ? rails(pb, pb + 1, pb + 2, 0) : rails(ptop, pb + 1, pb, 0))
@@ -263,15 +279,17 @@ __device__ __forceinline__ void tmpl_stroke_elem(const VgxTmplMesh& tm, uint32_t
 		uint16_t* pi = idxMesh + (size_t)bridgeIdx * (j - 1);
 		Idx6 t0; t0.a = (p.a & 0xFFFFu) | (p.b << 16); t0.b = (mine.b & 0xFFFFu) | (p.a << 16); t0.c = (mine.b & 0xFFFFu) | (mine.a << 16);
 		Idx6 t1; t1.a = (p.b & 0xFFFFu) | (p.c << 16); t1.b = (mine.c & 0xFFFFu) | (p.b << 16); t1.c = (mine.c & 0xFFFFu) | (mine.b << 16);
+		VGX_ST_GUARD(t0.a ^ t1.c) {
 		*(Idx6*)pi = t0;
 		*(Idx6*)(pi + 6) = t1;
 		if (!thin) {
 			Idx6 t2; t2.a = (p.c & 0xFFFFu) | (p.d << 16); t2.b = (mine.d & 0xFFFFu) | (p.c << 16); t2.c = (mine.d & 0xFFFFu) | (mine.c << 16);
 			*(Idx6*)(pi + 12) = t2;
 		}
+		}
 	}
 	if (j + 1 == N) { // closing bridge to join 0 (:1970-1984, 2295-2306); d12 = vec2Dir(last vertex, vertex 0)
-		const V2 v1 = tmpl_xf(xf, vt[N > 1 ? 1 : 0]);
+		const V2 v1 = vtx(N > 1 ? 1u : 0u);
 		const VgxJoin j0 = vgx_join_dirs(d12, v2dir(pNext, v1), sideWidth);
 		const Rails f = thin ? (j0.leftInner ? rails(0, 1, 2, 0) : rails(2, 1, 0, 0)) : (j0.leftInner ? rails(0, 1, 2, 3) : rails(3, 2, 1, 0));
 		uint16_t* pi = idxMesh + (size_t)bridgeIdx * (N - 1);
@@ -286,75 +304,155 @@ __device__ __forceinline__ void tmpl_stroke_elem(const VgxTmplMesh& tm, uint32_t
 	}
 }
 
-#ifndef VGX_TMPL_THREADS
-#define VGX_TMPL_THREADS 256
-#endif
-__global__ __launch_bounds__(VGX_TMPL_THREADS) void k_tmpl_emit(VgxTmplArgs A)
+// Per-mesh record of a tile in LDS (phase 0). 64 bytes.
+struct __attribute__((aligned(16))) TmplRec
 {
+	uint32_t poly_first, n, v_off, i_off;
+	uint32_t kind, color; float f0, f1; // fills: f0 = aa WITH the instance's orientation sign; strokes: hsw, hswAA
+	float m0, m1, m2, m3;
+	float m4, m5; uint32_t pad0, pad1;
+};
+
+// The per-mesh values of one (instance, template mesh): what phase 0 parks in LDS and what the fallback computes per lane.
+__device__ __forceinline__ TmplRec tmpl_make_rec(const VgxTmplArgs& A, const vgx_draw* idraws, uint32_t m)
+{
+	const VgxTmplMesh tm = A.tmesh[m];
+	const uint4* dq = (const uint4*)(idraws + tm.drawk);
+	const uint32_t kind = VGX_MD_KIND(tm.kind);
+	const bool isFill = kind < VGX_MESH_STROKE;
+	const uint4 qc = dq[isFill ? 0 : 1]; // fill_color = q0.z, stroke_color = q1.x
+	const uint4 q2 = dq[2], q3 = dq[3];
+	TmplRec r;
+	r.poly_first = tm.poly_first; r.n = tm.n; r.v_off = tm.v_off; r.i_off = tm.i_off;
+	r.kind = tm.kind; r.color = isFill ? qc.z : qc.x; r.f0 = tm.f0; r.f1 = tm.f1;
+	r.m0 = __uint_as_float(q2.y); r.m1 = __uint_as_float(q2.z); r.m2 = __uint_as_float(q2.w);
+	r.m3 = __uint_as_float(q3.x); r.m4 = __uint_as_float(q3.y); r.m5 = __uint_as_float(q3.z);
+	r.pad0 = 0; r.pad1 = 0;
+	if (kind == VGX_MESH_FILL_AA) {
+		// orientation from the first triangle of the TRANSFORMED polygon (stroker.cpp:721-723)
+		TmplXf xf; xf.m0 = r.m0; xf.m1 = r.m1; xf.m2 = r.m2; xf.m3 = r.m3; xf.m4 = r.m4; xf.m5 = r.m5;
+		const float2* vt = A.tpoly + tm.poly_first;
+		const V2 a0 = tmpl_xf(xf, vt[0]), a1 = tmpl_xf(xf, vt[1]), a2 = tmpl_xf(xf, vt[2]);
+		const float orient = v2cross(v2sub(a1, a0), v2sub(a2, a0));
+		r.f0 = tm.f0 * vgm_sign(orient);
+	}
+	return r;
+}
+
+// One element once its mesh record, its own transformed vertex and a way to get the mesh's other transformed vertices exist.
+template<class VF>
+__device__ __forceinline__ void tmpl_elem_emit(const VgxTmplArgs& A, uint64_t inst, uint32_t mesh, uint32_t j, const TmplRec& r, V2 p1, const VF& vtx)
+{
+	const uint32_t kind = VGX_MD_KIND(r.kind);
+	const uint32_t N = r.n;
+	if (j == 0 && A.meshes_out) { // the caller's mesh table: the template's record moved to this instance
+		vgx_mesh mr = A.tmtab[mesh];
+		mr.first_vertex += inst * A.inst.num_vertices;
+		mr.first_index += inst * A.inst.num_indices;
+		mr.draw += (uint32_t)(inst * A.period);
+		A.meshes_out[inst * A.inst.num_meshes + mesh] = mr;
+	}
+	if (kind < VGX_MESH_STROKE) {
+		FillFetch F;
+		F.valid = true; F.j = j; F.N = N; F.color = r.color; F.ibase = 0; F.mi = 0;
+		F.firstV = inst * A.inst.num_vertices + r.v_off;
+		F.firstI = inst * A.inst.num_indices + r.i_off;
+		F.aaElem = kind == VGX_MESH_FILL_AA;
+		F.sseOrder = VGX_MD_SSE_ORDER(r.kind) != 0;
+		F.nextInWave = false; F.prevInWave = false;
+		F.p1 = p1; F.pNextB = p1; F.pPrevB = p1;
+		F.aa = r.f0;
+		V2 dPrev = v2(0.0f, 0.0f), d12 = dPrev;
+		if (F.aaElem) {
+			d12 = v2dir(p1, vtx(j + 1 < N ? j + 1 : 0u));
+			dPrev = v2dir(vtx(j > 0 ? j - 1 : N - 1), p1);
+		}
+		fill_emit_store(A.pos, A.color, A.idx, F, dPrev, d12);
+	} else {
+		const uint64_t v0 = inst * A.inst.num_vertices + r.v_off;
+		tmpl_stroke_elem(r.kind, N, r.f0, r.f1, j, p1, vtx, r.color, A.pos + 2 * v0, A.color + v0, A.idx + (inst * A.inst.num_indices + r.i_off));
+	}
+}
+
+#define VGX_TMPL_THREADS 256
+#define VGX_TMPL_MAX_TILE 1024 /* elements per tile the LDS vertex stage holds */
+#define VGX_TMPL_MAXM 96       /* meshes per tile the LDS record table holds; a tile that touches more takes the per-lane fallback */
+#define VGX_TMPL_CH (VGX_TMPL_MAX_TILE / VGX_TMPL_THREADS)
+#ifndef VGX_TMPL_OCC
+#define VGX_TMPL_OCC
+#endif
+__global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(VgxTmplArgs A)
+{
+	__shared__ TmplRec s_rec[VGX_TMPL_MAXM];
+	__shared__ float2 s_vtx[VGX_TMPL_MAX_TILE];
 	if (A.totals->status != VGX_OK) {
 		return;
 	}
-	const int lane = threadIdx.x & (VGX_WAVE - 1);
-	const uint64_t w = (uint64_t)blockIdx.x * (VGX_TMPL_THREADS / VGX_WAVE) + (threadIdx.x >> 6);
-	const uint64_t inst = w / A.groups_per_inst;
-	if (inst >= A.ninst) {
+	const uint32_t tid = threadIdx.x;
+	const uint32_t inst32 = blockIdx.x / A.tiles_per_inst;
+	const uint32_t t = blockIdx.x - inst32 * A.tiles_per_inst;
+	const uint64_t inst = inst32;
+	const uint32_t E = (uint32_t)A.inst.num_elements;
+	const uint32_t x0 = t * A.tile;
+	const uint32_t nel = x0 + A.tile < E ? A.tile : E - x0;
+	const uint32_t mA = A.tile_mesh0[t];
+	const uint32_t mB = t + 1 < A.tiles_per_inst ? A.tile_mesh0[t + 1] : (uint32_t)A.inst.num_meshes - 1;
+	const uint32_t nm = mB - mA + 1;
+	const vgx_draw* idraws = A.draws + inst * A.period;
+	const VgxTmplElem* telem = A.telem + x0;
+	if (nm > VGX_TMPL_MAXM) { // block-uniform. Many tiny meshes in one tile: every lane fetches its own records
+		for (uint32_t s = tid; s < nel; s += VGX_TMPL_THREADS) {
+			const VgxTmplElem er = telem[s];
+			const TmplRec r = tmpl_make_rec(A, idraws, er.mesh);
+			TmplXf xf; xf.m0 = r.m0; xf.m1 = r.m1; xf.m2 = r.m2; xf.m3 = r.m3; xf.m4 = r.m4; xf.m5 = r.m5;
+			const float2* vt = A.tpoly + r.poly_first;
+			const uint32_t j = er.jq & 0xFFFFu;
+			tmpl_elem_emit(A, inst, er.mesh, j, r, tmpl_xf(xf, vt[j]), [&](uint32_t jj) { return tmpl_xf(xf, vt[jj]); });
+		}
 		return;
 	}
-	const uint32_t grp = (uint32_t)(w - inst * A.groups_per_inst);
-	const uint32_t chunk0 = grp * A.group_chunks;
-	const uint32_t chunk1 = chunk0 + A.group_chunks < A.chunks_per_inst ? chunk0 + A.group_chunks : A.chunks_per_inst;
-	const vgx_draw* idraws = A.draws + inst * A.period;
-	float* const posI = A.pos + 2 * (inst * A.inst.num_vertices);
-	uint32_t* const colI = A.color + inst * A.inst.num_vertices;
-	uint16_t* const idxI = A.idx + inst * A.inst.num_indices;
-	const uint32_t E = (uint32_t)A.inst.num_elements;
-	for (uint32_t c = chunk0; c < chunk1; ++c) {
-		const uint32_t slot = c * VGX_WAVE + (uint32_t)lane;
-		if (slot >= E) { continue; }
-		const VgxTmplElem er = A.telem[slot];
-		const VgxTmplMesh tm = A.tmesh[er.mesh];
-		const uint4* dq = (const uint4*)(idraws + tm.drawk);
-		const uint32_t kind = VGX_MD_KIND(tm.kind);
-		const bool isFill = kind < VGX_MESH_STROKE;
-		const uint4 qc = dq[isFill ? 0 : 1];      // fill_color = q0.z, stroke_color = q1.x
-		const uint4 q2 = dq[2], q3 = dq[3];
-		TmplXf xf;
-		xf.m0 = __uint_as_float(q2.y); xf.m1 = __uint_as_float(q2.z); xf.m2 = __uint_as_float(q2.w);
-		xf.m3 = __uint_as_float(q3.x); xf.m4 = __uint_as_float(q3.y); xf.m5 = __uint_as_float(q3.z);
-		const float2* vt = A.tpoly + tm.poly_first;
-		const uint32_t j = er.j, N = tm.n;
-		if (j == 0 && A.meshes_out) { // the caller's mesh table: the template's record moved to this instance
-			vgx_mesh r = A.tmtab[er.mesh];
-			r.first_vertex += inst * A.inst.num_vertices;
-			r.first_index += inst * A.inst.num_indices;
-			r.draw += (uint32_t)(inst * A.period);
-			A.meshes_out[inst * A.inst.num_meshes + er.mesh] = r;
+	// phase 0
+	if (tid < nm) { s_rec[tid] = tmpl_make_rec(A, idraws, mA + tid); }
+	__syncthreads();
+	// phase 1: chunk k = c * 4 + wave of the tile (interleaved: the tile's stroke chunks, the heavier ones, spread over the waves)
+	VgxTmplElem er[VGX_TMPL_CH];
+	V2 p1[VGX_TMPL_CH];
+#pragma unroll
+	for (int c = 0; c < VGX_TMPL_CH; ++c) {
+		const uint32_t s = (uint32_t)c * VGX_TMPL_THREADS + tid;
+		er[c].mesh = mA; er[c].jq = 0;
+		if (s < nel) { er[c] = telem[s]; }
+	}
+#pragma unroll
+	for (int c = 0; c < VGX_TMPL_CH; ++c) {
+		const uint32_t s = (uint32_t)c * VGX_TMPL_THREADS + tid;
+		p1[c] = v2(0.0f, 0.0f);
+		if (s < nel) {
+			const TmplRec* r = &s_rec[er[c].mesh - mA];
+			const float2 lp = A.tpoly[r->poly_first + (er[c].jq & 0xFFFFu)];
+			TmplXf xf; xf.m0 = r->m0; xf.m1 = r->m1; xf.m2 = r->m2; xf.m3 = r->m3; xf.m4 = r->m4; xf.m5 = r->m5;
+			p1[c] = tmpl_xf(xf, lp);
+			s_vtx[er[c].jq >> 16] = make_float2(p1[c].x, p1[c].y);
 		}
-		if (isFill) {
-			FillFetch F;
-			F.valid = true; F.j = j; F.N = N; F.color = qc.z; F.ibase = 0; F.mi = 0;
-			F.firstV = inst * A.inst.num_vertices + tm.v_off;
-			F.firstI = inst * A.inst.num_indices + tm.i_off;
-			F.aaElem = kind == VGX_MESH_FILL_AA;
-			F.sseOrder = VGX_MD_SSE_ORDER(tm.kind) != 0;
-			F.nextInWave = false; F.prevInWave = false;
-			F.p1 = tmpl_xf(xf, vt[j]);
-			F.pNextB = F.p1; F.pPrevB = F.p1;
-			F.aa = 0.0f;
-			V2 dPrev = v2(0.0f, 0.0f), d12 = dPrev;
-			if (F.aaElem) {
-				const V2 pNext = tmpl_xf(xf, vt[j + 1 < N ? j + 1 : 0u]);
-				const V2 pPrev = tmpl_xf(xf, vt[j > 0 ? j - 1 : N - 1]);
-				d12 = v2dir(F.p1, pNext);
-				dPrev = v2dir(pPrev, F.p1);
-				// orientation from the first triangle of the TRANSFORMED polygon (stroker.cpp:721-723)
-				const V2 a0 = tmpl_xf(xf, vt[0]), a1 = tmpl_xf(xf, vt[1]), a2 = tmpl_xf(xf, vt[2]);
-				const float orient = v2cross(v2sub(a1, a0), v2sub(a2, a0));
-				F.aa = tm.f0 * vgm_sign(orient);
-			}
-			fill_emit_store(A.pos, A.color, A.idx, F, dPrev, d12);
-		} else {
-			tmpl_stroke_elem(tm, j, vt, xf, qc.x, posI + 2 * (size_t)tm.v_off, colI + tm.v_off, idxI + tm.i_off);
+	}
+	__syncthreads();
+	// phase 2
+#pragma unroll
+	for (int c = 0; c < VGX_TMPL_CH; ++c) {
+		const uint32_t s = (uint32_t)c * VGX_TMPL_THREADS + tid;
+		if (s < nel) {
+			const TmplRec* rp = &s_rec[er[c].mesh - mA];
+			TmplRec r;
+			r.poly_first = rp->poly_first; r.n = rp->n; r.v_off = rp->v_off; r.i_off = rp->i_off;
+			r.kind = rp->kind; r.color = rp->color; r.f0 = rp->f0; r.f1 = rp->f1;
+			const uint32_t j = er[c].jq & 0xFFFFu;
+			const int q0 = (int)(er[c].jq >> 16) - (int)j; // tile position of the mesh's vertex 0 (negative: in front of the tile)
+			tmpl_elem_emit(A, inst, er[c].mesh, j, r, p1[c], [&](uint32_t jj) {
+				const int qq = q0 + (int)jj;
+				if (qq >= 0 && qq < (int)nel) { const float2 v = s_vtx[qq]; return v2(v.x, v.y); }
+				TmplXf xf; xf.m0 = rp->m0; xf.m1 = rp->m1; xf.m2 = rp->m2; xf.m3 = rp->m3; xf.m4 = rp->m4; xf.m5 = rp->m5;
+				return tmpl_xf(xf, A.tpoly[r.poly_first + jj]); // the neighbour belongs to another tile
+			});
 		}
 	}
 }
@@ -381,8 +479,6 @@ void vgx_launch_tmpl_verify(const VgxTmplArgs& a, hipStream_t s)
 
 void vgx_launch_tmpl_emit(const VgxTmplArgs& a, hipStream_t s)
 {
-	const uint64_t waves = a.ninst * a.groups_per_inst;
-	const uint64_t wpb = VGX_TMPL_THREADS / VGX_WAVE;
-	const uint64_t blocks = (waves + wpb - 1) / wpb;
+	const uint64_t blocks = a.ninst * a.tiles_per_inst; // the host checked < 2^31
 	if (blocks) { hipLaunchKernelGGL(k_tmpl_emit, dim3((unsigned)blocks), dim3(VGX_TMPL_THREADS), 0, s, a); }
 }

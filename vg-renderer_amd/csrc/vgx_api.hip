@@ -87,7 +87,7 @@ struct vgx_ctx
 	// flattened once in local space by the last vgx_tessellate_count
 	int optTmpl; uint32_t optTmplTile;
 	uint32_t tmplTileSize;               // elements per tile of the current template
-	DevBuf tmplTile;                     // [tiles] first mesh of every tile
+	DevBuf tmplTile;                     // [tiles] VgxTmplTile
 	bool tmplOn;
 	const vgx_pathset* tmplPs;
 	uint32_t tmplPeriod;
@@ -346,6 +346,14 @@ struct OpSubMeshes // stroker-level entry: one or two meshes per vertex list -> 
 		totals->sizes.num_subpaths = nsubs;
 	}
 };
+
+__global__ void k_tmpl_nospace(VgxTotals* t, vgx_sizes need, uint32_t aux)
+{
+	t->sizes = need;
+	t->status = VGX_E_NOSPACE;
+	t->fail_reason = VGX_FAIL_OUT_CAPACITY;
+	t->fail_aux = aux;
+}
 
 __global__ void k_publish(const VgxTotals* t, vgx_sizes* devSizes, uint32_t* devStatus)
 {
@@ -1131,7 +1139,7 @@ static int runTmpl(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 	a.tdraws = (const vgx_draw*)ctx->tmplDraws.p; a.tpoly = (const float2*)ctx->tmplPoly.p; a.tmesh = (const VgxTmplMesh*)ctx->tmplMesh.p;
 	a.tmtab = (const vgx_mesh*)ctx->tmplMtab.p; a.telem = (const VgxTmplElem*)ctx->tmplElem.p;
 	a.inst = ctx->tmplInst;
-	a.tile_mesh0 = (const uint32_t*)ctx->tmplTile.p;
+	a.ttile = (const VgxTmplTile*)ctx->tmplTile.p;
 	a.tile = ctx->tmplTileSize;
 	a.tiles_per_inst = (uint32_t)((ctx->tmplInst.num_elements + a.tile - 1) / a.tile);
 	a.pos = out->pos; a.color = out->color; a.idx = out->idx; a.meshes_out = out->meshes;
@@ -1139,8 +1147,19 @@ static int runTmpl(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 	a.totals = (VgxTotals*)ctx->totals.p;
 	if (a.ninst * (uint64_t)a.tiles_per_inst > 0x7FFFFFFFull) { return VGX_E_RANGE; } // one workgroup per (instance, tile)
 	noteHip(ctx, hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s));
-	vgx_launch_tmpl_verify(a, s);
-	mark(ctx, s, "tmpl_verify");
+	{
+		// every size is known on the host: a batch that does not fit the caller's buffers ends here, with the need in dev_sizes
+		const uint64_t nv = a.ninst * a.inst.num_vertices, ni = a.ninst * a.inst.num_indices, nm = a.ninst * a.inst.num_meshes;
+		const uint32_t aux = (nv > out->cap_vertices ? 1u : 0u) | (ni > out->cap_indices ? 2u : 0u) | ((out->meshes && nm > out->cap_meshes) ? 4u : 0u);
+		if (aux) {
+			vgx_sizes z = a.inst;
+			z.num_poly_vertices *= a.ninst; z.num_subpaths *= a.ninst; z.num_meshes *= a.ninst; z.num_vertices *= a.ninst; z.num_indices *= a.ninst;
+			z.num_serial_draws *= a.ninst; z.num_cmd_instances *= a.ninst; z.num_elements *= a.ninst; z.num_fill_elements *= a.ninst; z.num_drawcmds = 0;
+			hipLaunchKernelGGL(k_tmpl_nospace, dim3(1), dim3(1), 0, s, (VgxTotals*)ctx->totals.p, z, aux);
+			if (dev_sizes || dev_status) { hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, s, (const VgxTotals*)ctx->totals.p, dev_sizes, dev_status); }
+			return launchStatus(ctx);
+		}
+	}
 	vgx_launch_tmpl_emit(a, s);
 	mark(ctx, s, "tmpl_emit");
 	if (dev_sizes || dev_status) {
@@ -1188,8 +1207,8 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; }
 	const VgxTotals& ht = *ctx->hostTotals;
 	const vgx_sizes isz = ht.sizes;
-	if (ht.has_general_stroke || ht.num_round_meshes || isz.num_elements == 0 || isz.num_elements >= (1ull << 31) || isz.num_vertices >= (1ull << 32)
-		|| isz.num_indices >= (1ull << 32) || isz.num_poly_vertices >= (1ull << 32) || isz.num_meshes >= (1ull << 32)) {
+	if (ht.has_general_stroke || ht.num_round_meshes || isz.num_elements == 0 || isz.num_elements >= (1ull << 31) || isz.num_vertices >= (1ull << 29)
+		|| isz.num_indices >= (1ull << 31) || isz.num_poly_vertices >= (1ull << 32) || isz.num_meshes >= (1ull << 32)) { // one instance: < 4 GB per output stream
 		return VGX_OK; // open / Bevel / Round strokes (or nothing to emit): the ordinary pipeline
 	}
 	const uint64_t M = isz.num_meshes, E = isz.num_elements, V = isz.num_poly_vertices;
@@ -1199,11 +1218,11 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	if ((st = ensure(ctx, ctx->tmplElem, (E + 64) * sizeof(VgxTmplElem))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->tmplDraws, (size_t)P * sizeof(vgx_draw))) != VGX_OK) { return st; }
 	const uint32_t tileSize = ctx->optTmplTile;
-	if ((st = ensure(ctx, ctx->tmplTile, ((E + tileSize - 1) / tileSize + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->tmplTile, ((E + tileSize - 1) / tileSize + 1) * sizeof(VgxTmplTile))) != VGX_OK) { return st; }
 	VgxTmplBuild b;
 	b.draws = draws; b.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; b.mprep = (const VgxMeshPrep*)ctx->mprep.p; b.mtab = (const vgx_mesh*)ctx->mtab.p;
 	b.prefix_fill = (const uint64_t*)ctx->elemPrefix.p; b.prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
-	b.num_meshes = M; b.num_elems = E; b.tile = tileSize; b.tile_mesh0 = (uint32_t*)ctx->tmplTile.p;
+	b.num_meshes = M; b.num_elems = E; b.tile = tileSize; b.ttile = (VgxTmplTile*)ctx->tmplTile.p; b.period = (uint32_t)P;
 	b.tmesh = (VgxTmplMesh*)ctx->tmplMesh.p; b.tmtab = (vgx_mesh*)ctx->tmplMtab.p; b.telem = (VgxTmplElem*)ctx->tmplElem.p;
 	vgx_launch_tmpl_build(b, s);
 	HIPCHK(ctx, hipMemcpyAsync(ctx->tmplPoly.p, ctx->poly.p, V * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -902,6 +902,44 @@ struct FillFetch
 	V2 p1, pNextB, pPrevB;
 };
 
+// The nine index values [9j, 9j+9) of a convex AA fill mesh with N corners (element j), scalar or SSE order.
+__device__ __forceinline__ void fill_idx9(uint32_t j, uint32_t N, uint32_t ibase, bool sseOrder, uint32_t* val)
+{
+	struct { uint32_t ibase; bool sseOrder; } F; F.ibase = ibase; F.sseOrder = sseOrder;
+#ifdef VGX_EXP_CHEAPMATH
+			for (uint32_t g = 0; g < 9; ++g) { val[g] = (j + g) & 0xFFFFu; }
+#else
+#pragma unroll
+			for (uint32_t g = 0; g < 3; ++g) {
+				const uint32_t T = 3 * j + g;
+				const bool isFan = T + 2 < N;
+				const uint32_t Fq = T + 2 - N; // wraps for fan triangles, unused there
+				const uint32_t ed = Fq >> 1;
+				const bool second = (Fq & 1u) != 0;
+				const uint32_t fb = 2 * ed;
+				const bool lastEdge = ed + 1 == N;
+				const uint32_t nextInner = lastEdge ? 0u : fb + 2, nextOuter = lastEdge ? 1u : fb + 3;
+				// + F.ibase: vertex-buffer relative when assembly is armed (uint16 wrap = the reference's cast, vg_util.cpp:447)
+				val[3 * g] = ((isFan ? 0u : fb) + F.ibase) & 0xFFFFu;
+				val[3 * g + 1] = ((isFan ? 2 * T + 2 : (second ? nextOuter : fb + 1)) + F.ibase) & 0xFFFFu;
+				val[3 * g + 2] = ((isFan ? 2 * T + 4 : (second ? nextInner : nextOuter)) + F.ibase) & 0xFFFFu;
+			}
+			if (F.sseOrder) {
+				// VGX_FILL_INDEX_ORDER_SSE (stroker.cpp:610-701): [quad 0] then per fan triangle t {(0, s, s+2), quad of edge t+1 =
+				// (s, s+1, s+3, s, s+3, s+2)} with s = 2t+2, then the wrap-around quad (L, L+1, 1, L, 1, 0), L = 2N-2. Positions
+				// [9j, 9j+9) are therefore: the quad of edge j, then fan triangle j -- or, for the last two corners, the halves of
+				// the wrap-around quad.
+				const uint32_t b = 2 * j;
+				const bool lastFan = j + 2 >= N; // corner N-2: its three trailing positions start the wrap-around quad
+				val[0] = b; val[1] = b + 1; val[2] = b + 3; val[3] = b; val[4] = b + 3; val[5] = b + 2;
+				val[6] = lastFan ? b + 2 : 0u; val[7] = lastFan ? b + 3 : b + 2; val[8] = lastFan ? 1u : b + 4;
+				if (j + 1 == N) { val[0] = b; val[1] = 1u; val[2] = 0u; } // corner N-1: (L, 1, 0)
+#pragma unroll
+				for (uint32_t g = 0; g < 9; ++g) { val[g] = (val[g] + F.ibase) & 0xFFFFu; }
+			}
+#endif
+}
+
 __device__ __forceinline__ void fill_emit_store(float* pos, uint32_t* color_out, uint16_t* idx_out, const FillFetch& F, V2 dPrev, V2 d12);
 
 __device__ __forceinline__ void fill_emit_chunk(float* pos, uint32_t* color_out, uint16_t* idx_out, const FillFetch& F)
@@ -959,38 +997,7 @@ __device__ __forceinline__ void fill_emit_store(float* pos, uint32_t* color_out,
 			// (fb, nextOuter, nextInner) with fb = 2*edge (stroker.cpp:779-795). No division, no per-index select.
 			const uint32_t k9 = 9 * j;
 			uint32_t val[9];
-#ifdef VGX_EXP_CHEAPMATH
-			for (uint32_t g = 0; g < 9; ++g) { val[g] = (j + g) & 0xFFFFu; }
-#else
-#pragma unroll
-			for (uint32_t g = 0; g < 3; ++g) {
-				const uint32_t T = 3 * j + g;
-				const bool isFan = T + 2 < N;
-				const uint32_t Fq = T + 2 - N; // wraps for fan triangles, unused there
-				const uint32_t ed = Fq >> 1;
-				const bool second = (Fq & 1u) != 0;
-				const uint32_t fb = 2 * ed;
-				const bool lastEdge = ed + 1 == N;
-				const uint32_t nextInner = lastEdge ? 0u : fb + 2, nextOuter = lastEdge ? 1u : fb + 3;
-				// + F.ibase: vertex-buffer relative when assembly is armed (uint16 wrap = the reference's cast, vg_util.cpp:447)
-				val[3 * g] = ((isFan ? 0u : fb) + F.ibase) & 0xFFFFu;
-				val[3 * g + 1] = ((isFan ? 2 * T + 2 : (second ? nextOuter : fb + 1)) + F.ibase) & 0xFFFFu;
-				val[3 * g + 2] = ((isFan ? 2 * T + 4 : (second ? nextInner : nextOuter)) + F.ibase) & 0xFFFFu;
-			}
-			if (F.sseOrder) {
-				// VGX_FILL_INDEX_ORDER_SSE (stroker.cpp:610-701): [quad 0] then per fan triangle t {(0, s, s+2), quad of edge t+1 =
-				// (s, s+1, s+3, s, s+3, s+2)} with s = 2t+2, then the wrap-around quad (L, L+1, 1, L, 1, 0), L = 2N-2. Positions
-				// [9j, 9j+9) are therefore: the quad of edge j, then fan triangle j -- or, for the last two corners, the halves of
-				// the wrap-around quad.
-				const uint32_t b = 2 * j;
-				const bool lastFan = j + 2 >= N; // corner N-2: its three trailing positions start the wrap-around quad
-				val[0] = b; val[1] = b + 1; val[2] = b + 3; val[3] = b; val[4] = b + 3; val[5] = b + 2;
-				val[6] = lastFan ? b + 2 : 0u; val[7] = lastFan ? b + 3 : b + 2; val[8] = lastFan ? 1u : b + 4;
-				if (j + 1 == N) { val[0] = b; val[1] = 1u; val[2] = 0u; } // corner N-1: (L, 1, 0)
-#pragma unroll
-				for (uint32_t g = 0; g < 9; ++g) { val[g] = (val[g] + F.ibase) & 0xFFFFu; }
-			}
-#endif
+			fill_idx9(j, N, F.ibase, F.sseOrder, val);
 			uint16_t* pi = idx_out + F.firstI + k9;
 			if (j + 1 < N) {
 				Idx9 q; q.a = val[0] | (val[1] << 16); q.b = val[2] | (val[3] << 16); q.c = val[4] | (val[5] << 16); q.d = val[6] | (val[7] << 16); q.e = (uint16_t)val[8];

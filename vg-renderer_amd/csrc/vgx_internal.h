@@ -85,7 +85,8 @@ struct VgxTmplBuild // count pass: the first period's ordinary count + emit resu
 	VgxTmplMesh* tmesh;
 	vgx_mesh* tmtab;
 	VgxTmplElem* telem;
-	uint32_t* tile_mesh0;        // [tiles] template mesh that owns the first element of every tile
+	VgxTmplTile* ttile;          // [tiles]
+	uint32_t period;
 };
 struct VgxTmplArgs // one step
 {
@@ -99,7 +100,7 @@ struct VgxTmplArgs // one step
 	const VgxTmplMesh* tmesh;
 	const vgx_mesh* tmtab;       // mesh records of one instance (offsets relative to the instance)
 	const VgxTmplElem* telem;
-	const uint32_t* tile_mesh0;
+	const VgxTmplTile* ttile;
 	uint32_t tile;               // elements per tile (= one workgroup of k_tmpl_emit)
 	uint32_t tiles_per_inst;
 	vgx_sizes inst;              // sizes of ONE instance
@@ -112,7 +113,6 @@ struct VgxTmplArgs // one step
 };
 void vgx_launch_tmpl_check(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, VgxTotals* totals, hipStream_t s); // after vgx_launch_inst_detect
 void vgx_launch_tmpl_build(const VgxTmplBuild& b, hipStream_t s);
-void vgx_launch_tmpl_verify(const VgxTmplArgs& a, hipStream_t s);
 void vgx_launch_tmpl_emit(const VgxTmplArgs& a, hipStream_t s);
 
 // concave-fill fringes (vgx_concave.hip)

@@ -157,10 +157,19 @@ struct VgxTmplMesh // one mesh of the template. 32 bytes
 	uint32_t kind;       // VgxMeshDesc::kind word
 	float f0, f1;        // fills: fringe / 2 (the sign is per instance), -; strokes: hsw, hswAA (thin: fringe, fringe)
 };
-struct VgxTmplElem // one element (polyline vertex j of template mesh `mesh`), in processing order
+struct VgxTmplElem // one element (polyline vertex j of template mesh `mesh`), in processing order. 16 bytes
 {
 	uint32_t mesh;
 	uint32_t jq;   // j | (position of the element inside its tile, in OUTPUT order) << 16
+	uint32_t vtx;  // its vertex in the template's local polyline (= mesh.poly_first + j)
+	uint32_t pad;
+};
+struct VgxTmplTile // one tile of the instance's element stream = one workgroup of k_tmpl_emit. 16 bytes
+{
+	uint32_t mesh0;     // template mesh that owns the tile's first element; bit 31: that element is the mesh's element 0
+	uint32_t mesh_last; // last mesh with an element in the tile
+	uint32_t draw0;     // draws of the period whose records the tile reads (and verifies): [draw0, draw0 + ndraws)
+	uint32_t ndraws;
 };
 
 // Capacities the device-side checks compare against.

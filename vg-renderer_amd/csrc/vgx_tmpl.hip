@@ -144,112 +144,171 @@ __global__ __launch_bounds__(256) void k_tmpl_elems(VgxTmplBuild B)
 		VgxTmplElem r;
 		r.mesh = (uint32_t)m;
 		r.jq = j | ((uint32_t)(e - x0) << 16); // j < 65536 (a mesh holds at most 65536 vertices), position in the tile < tile <= 65536
+		r.vtx = (uint32_t)B.mdesc[m].poly_first + j;
+		r.pad = 0;
 		B.telem[slot] = r;
-		if (e == x0) { B.tile_mesh0[e / T] = (uint32_t)m; }
-	}
-}
-
-// ---- step: verify ----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tmpl_verify(VgxTmplArgs A)
-{
-	if (blockIdx.x == 0 && threadIdx.x == 0) {
-		// totals of the batch = instances x template (the memset in front of this kernel zeroed them)
-		vgx_sizes z;
-		z.num_poly_vertices = A.ninst * A.inst.num_poly_vertices;
-		z.num_subpaths = A.ninst * A.inst.num_subpaths;
-		z.num_meshes = A.ninst * A.inst.num_meshes;
-		z.num_vertices = A.ninst * A.inst.num_vertices;
-		z.num_indices = A.ninst * A.inst.num_indices;
-		z.num_serial_draws = A.ninst * A.inst.num_serial_draws;
-		z.num_cmd_instances = A.ninst * A.inst.num_cmd_instances;
-		z.num_elements = A.ninst * A.inst.num_elements;
-		z.num_fill_elements = A.ninst * A.inst.num_fill_elements;
-		z.num_drawcmds = 0;
-		A.totals->sizes = z;
-		if (z.num_vertices > A.caps.vertices || z.num_indices > A.caps.indices || (A.meshes_out && z.num_meshes > A.caps.meshes)) {
-			set_status(A.totals, VGX_E_NOSPACE);
-			A.totals->fail_reason = VGX_FAIL_OUT_CAPACITY;
-			A.totals->fail_aux = (z.num_vertices > A.caps.vertices ? 1u : 0u) | (z.num_indices > A.caps.indices ? 2u : 0u) | ((A.meshes_out && z.num_meshes > A.caps.meshes) ? 4u : 0u);
+		if (e == x0) { // tile record, first half: the mesh that owns the tile's first element; bit 31: it begins exactly here
+			B.ttile[e / T].mesh0 = (uint32_t)m | (j == 0 ? 0x80000000u : 0u);
 		}
 	}
-	const uint64_t P = A.period;
-	bool bad = false;
-	uint32_t err = VGX_OK;
-	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	uint64_t k = i % P;
-	const uint64_t kstep = stride % P;
-	for (; i < A.ndraws; i += stride) {
-		const uint4* q = (const uint4*)(A.draws + i);
-		const uint4* t = (const uint4*)(A.tdraws + k);
-		const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-		const uint4 t0 = t[0], t1 = t[1], t2 = t[2];
-		bad = bad || !tmpl_same(q0, q1, q2, t0, t1, t2);
-		const uint32_t e = tmpl_validate(q0, q1, q2, q3, A.npaths);
-		if (e != VGX_OK && err == VGX_OK) { err = e; }
-		k += kstep;
-		if (k >= P) { k -= P; }
-	}
-	if (err != VGX_OK) { set_status(A.totals, err); }
-	if (bad) { set_status(A.totals, VGX_E_STALE); }
 }
 
-// ---- step: emit ------------------------------------------------------------------------------------------------------
+// Tile records, second half (after k_tmpl_elems): the draws of the period whose records the tile needs = the draws of its
+// meshes; the first / last tile also take the draws in front of / behind every mesh, so that the tiles together cover the period
+// (every draw record is verified by some workgroup of every instance).
+__global__ __launch_bounds__(256) void k_tmpl_tiles(VgxTmplBuild B)
+{
+	const uint32_t nt = (uint32_t)((B.num_elems + B.tile - 1) / B.tile);
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nt) { return; }
+	const uint32_t mA = B.ttile[t].mesh0 & 0x7FFFFFFFu;
+	uint32_t mB = (uint32_t)B.num_meshes - 1;
+	if (t + 1 < nt) { const uint32_t nx = B.ttile[t + 1].mesh0; mB = (nx & 0x7FFFFFFFu) - (nx >> 31); }
+	const uint32_t dA = t == 0 ? 0u : B.mdesc[mA].draw;
+	const uint32_t dB = t + 1 == nt ? B.period - 1 : B.mdesc[mB].draw;
+	B.ttile[t].mesh_last = mB;
+	B.ttile[t].draw0 = dA;
+	B.ttile[t].ndraws = dB - dA + 1;
+}
+
+// ---- step ------------------------------------------------------------------------------------------------------------
 // One workgroup = one TILE of one instance: `tile` consecutive elements of the instance's output-ordered element stream, i.e.
-// a contiguous piece of each output stream (~40 KB), a contiguous range of the template's meshes and of its polyline.
-//   phase 0  one thread per mesh of the tile: template mesh record + the instance's draw record (transform, colour) -> a
-//            64-byte record in LDS; convex AA fills: the orientation of the TRANSFORMED polygon's first triangle
-//            (stroker.cpp:721-723), once per mesh instead of once per element
-//   phase 1  one lane per element: its template vertex from L2, transformPos2D (vg_util.h:24-28) ONCE, parked in LDS at the
-//            element's output-order position inside the tile ("the growing polyline staged in LDS")
-//   phase 2  one lane per element: the neighbouring corners (j - 2, j - 1, j + 1; the wrap-around corners of closed shapes)
-//            from LDS -- from L2 + transform for the handful of elements whose neighbour lies in another tile --, the
-//            stroker's per-element arithmetic, stores at closed-form addresses.
-// Per 64 elements the kernel issues two global loads (element record, vertex) beside its stores; everything shared by the
-// elements of a mesh comes from LDS.
+// a contiguous piece of each output stream (~40 KB), a contiguous range of the template's meshes and of the period's draws.
+// What bounds the kernel is the latency of its dependent loads (measured with -DVGX_TMPL_PROFILE: a workgroup that fetched
+// tile -> mesh records -> draw records -> vertices one after the other spent 60 % of its life waiting for them), so everything
+// is addressed from the tile record and requested at once:
+//   phase 0  a) one thread per draw of the tile: the instance's draw record (HBM) -- verified against the saved first period,
+//               transform + colours parked in LDS;  one thread per mesh: the template's mesh record and, for AA fills, the
+//               polygon's first three vertices;  every thread: its elements' records and template vertices (phase 1's loads)
+//            b) one thread per mesh: per-mesh record in LDS -- colour, widths, output offsets, and for AA fills the orientation
+//               of the TRANSFORMED polygon's first triangle (stroker.cpp:721-723), once per mesh instead of once per corner;
+//               the caller's mesh table for the meshes that begin in this tile
+//   phase 1  one lane per element: transformPos2D (vg_util.h:24-28) of its vertex ONCE, parked in LDS at the element's
+//            output-order position inside the tile ("the growing polyline staged in LDS")
+//   phase 2  one lane per element: vec2Dir(own vertex, next vertex) (stroker.cpp:31-38) once, parked in LDS
+//   phase 3  one lane per element: the edge directions around it from LDS (from L2 + transform for the handful of elements
+//            whose neighbour lies in another tile), calcExtrusionVector and the rest of the stroker's per-element arithmetic,
+//            stores at closed-form addresses (workgroup-uniform stream bases + 32-bit offsets).
 struct TmplXf { float m0, m1, m2, m3, m4, m5; };
 __device__ __forceinline__ V2 tmpl_xf(const TmplXf& m, float2 p) // transformPos2D, vg_util.h:24-28
 {
 	return v2(m.m0 * p.x + m.m2 * p.y + m.m4, m.m1 * p.x + m.m3 * p.y + m.m5);
 }
 
+struct __attribute__((aligned(16))) TmplDraw // per draw of the tile, in LDS. 32 bytes
+{
+	float m0, m1, m2, m3;
+	float m4, m5; uint32_t fill_color, stroke_color;
+};
+struct __attribute__((aligned(16))) TmplRec // per mesh of the tile, in LDS. 32 bytes
+{
+	uint32_t dk, n, v_off, i_off;       // dk: the mesh's draw, relative to the tile's first draw
+	uint32_t kind, color; float f0, f1; // fills: f0 = aa WITH the instance's orientation sign; strokes: hsw, hswAA
+};
+__device__ __forceinline__ TmplXf tmpl_draw_xf(const TmplDraw* d)
+{
+	TmplXf xf; xf.m0 = d->m0; xf.m1 = d->m1; xf.m2 = d->m2; xf.m3 = d->m3; xf.m4 = d->m4; xf.m5 = d->m5;
+	return xf;
+}
+
+// One draw record of the instance: checks (the ordinary path's finiteness checks + equality with the saved first period in
+// every field the template depends on) and the part the emit needs.
+__device__ __forceinline__ TmplDraw tmpl_load_draw(const VgxTmplArgs& A, const vgx_draw* idraws, uint32_t k)
+{
+	const uint4* q = (const uint4*)(idraws + k);
+	const uint4* t = (const uint4*)(A.tdraws + k);
+	const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+	const uint4 t0 = t[0], t1 = t[1], t2 = t[2];
+	const uint32_t e = tmpl_validate(q0, q1, q2, q3, A.npaths);
+	if (e != VGX_OK) { set_status(A.totals, e); }
+	else if (!tmpl_same(q0, q1, q2, t0, t1, t2)) { set_status(A.totals, VGX_E_STALE); }
+	TmplDraw d;
+	d.m0 = __uint_as_float(q2.y); d.m1 = __uint_as_float(q2.z); d.m2 = __uint_as_float(q2.w);
+	d.m3 = __uint_as_float(q3.x); d.m4 = __uint_as_float(q3.y); d.m5 = __uint_as_float(q3.z);
+	d.fill_color = q0.z; d.stroke_color = q1.x;
+	return d;
+}
+
+// orientation of the first triangle of the TRANSFORMED polygon (stroker.cpp:721-723) -> aa with its sign
+__device__ __forceinline__ float tmpl_fill_aa(const TmplXf& xf, float2 l0, float2 l1, float2 l2, float halfFringe)
+{
+	const V2 a0 = tmpl_xf(xf, l0), a1 = tmpl_xf(xf, l1), a2 = tmpl_xf(xf, l2);
+	const float orient = v2cross(v2sub(a1, a0), v2sub(a2, a0));
+	return halfFringe * vgm_sign(orient);
+}
+
+// Output streams of ONE instance: workgroup-uniform bases (scalar registers) + 32-bit byte offsets per lane, so that every
+// store is `global_store saddr + voffset` instead of a 64-bit address built per lane (template mode requires an instance to
+// stay below 4 GB per stream).
+struct TmplOut { char* pos; char* col; char* idx; };
+
+// One convex-fill element: strokerConvexFill / strokerConvexFillAA (stroker.cpp:334-365, 713-807), as fill_emit_store (vgx_elem.h).
+__device__ __forceinline__ void tmpl_fill_elem(const TmplOut& O, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t color, float aa,
+	uint32_t j, V2 p1, V2 dPrev, V2 d12)
+{
+	if (VGX_MD_KIND(kindWord) == VGX_MESH_FILL_AA) {
+		const V2 vaa = v2mul(v2extrude(dPrev, d12), aa);
+		const V2 vin = v2add(p1, vaa), vout = v2sub(p1, vaa);
+		const uint32_t gv = vOff + 2u * j;
+		PosPair pp; pp.x0 = vin.x; pp.y0 = vin.y; pp.x1 = vout.x; pp.y1 = vout.y;
+		ColPair cp; cp.c0 = color; cp.c1 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
+		const uint32_t ib = (iOff + 9u * j) * 2u;
+		uint32_t val[9];
+		fill_idx9(j, N, 0u, VGX_MD_SSE_ORDER(kindWord) != 0, val);
+		VGX_ST_GUARD(cp.c0 ^ __float_as_uint(pp.x0)) {
+		*(PosPair*)(O.pos + gv * 8u) = pp;
+		*(ColPair*)(O.col + gv * 4u) = cp;
+		if (j + 1 < N) {
+			Idx9 q; q.a = val[0] | (val[1] << 16); q.b = val[2] | (val[3] << 16); q.c = val[4] | (val[5] << 16); q.d = val[6] | (val[7] << 16); q.e = (uint16_t)val[8];
+			*(Idx9*)(O.idx + ib) = q;
+		} else {
+			Idx3 q; q.a = val[0] | (val[1] << 16); q.b = (uint16_t)val[2];
+			*(Idx3*)(O.idx + ib) = q;
+		}
+		}
+	} else {
+		const uint32_t gv = vOff + j;
+		VGX_ST_GUARD(color) {
+		*(float2*)(O.pos + gv * 8u) = make_float2(p1.x, p1.y);
+		*(uint32_t*)(O.col + gv * 4u) = color;
+		if (j + 2 < N) { // fan (0, j + 1, j + 2), stroker.cpp:340-357
+			Idx3 q; q.a = (j + 1) << 16; q.b = (uint16_t)(j + 2);
+			*(Idx3*)(O.idx + (iOff + 3u * j) * 2u) = q;
+		}
+		}
+	}
+}
+
 // One element of a CLOSED stroke with MITER joins, AA (4 rails) or Thin (3 rails): stroke_chunk_simple (vgx_elem.h) without
-// its neighbour lanes -- the previous join's inner side and, on the last element, join 0's are recomputed from the
-// transformed vertices (vtx(jj) = transformed polyline vertex jj of the mesh) instead of being carried: same inputs, same
-// arithmetic, same bits.
-template<class VF>
-__device__ __forceinline__ void tmpl_stroke_elem(uint32_t kindWord, uint32_t N, float hsw, float hswAA, uint32_t j, V2 p1, const VF& vtx, uint32_t color,
-	float* posMesh, uint32_t* colMesh, uint16_t* idxMesh)
+// its neighbour lanes. dPrev2 = direction of the edge in front of the previous vertex (the previous join's inner side is
+// recomputed from it), dFirst = direction of edge 0 (join 0's inner side, for the closing bridge of the last element): same
+// inputs, same arithmetic, same bits as the values the sequential stroker carries along (stroker.cpp:1401-1410).
+__device__ __forceinline__ void tmpl_stroke_elem(const TmplOut& O, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t color, float hsw, float hswAA,
+	uint32_t j, V2 p1, V2 dPrev2, V2 dPrev, V2 d12, V2 dFirst)
 {
 	const bool thin = VGX_MD_KIND(kindWord) == VGX_MESH_STROKE_AA_THIN;
 	const uint32_t R = thin ? 3u : 4u;
 	const uint32_t bridgeIdx = thin ? 12u : 18u;
 	const float sideWidth = thin ? hsw : hswAA; // fringe : hswAA
-	const uint32_t jn1 = j + 1 < N ? j + 1 : 0u;
-	const uint32_t jp1 = j > 0 ? j - 1 : N - 1;
-	const V2 pNext = vtx(jn1);
-	const V2 pPrev = vtx(jp1);
-	const V2 d12 = v2dir(p1, pNext);
-	const V2 dPrev = v2dir(pPrev, p1);
 	const VgxJoin jn = vgx_join_dirs(dPrev, d12, sideWidth);
 	const bool L = jn.leftInner;
 	const uint32_t b = R * j;
 	const uint32_t top = b + R - 1;
 	const Rails mine = thin ? (L ? rails(b, b + 1, b + 2, 0) : rails(top, b + 1, b, 0)) : (L ? rails(b, b + 1, b + 2, b + 3) : rails(top, b + 2, b + 1, b));
 	const uint32_t c0 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
-	float* pp = posMesh + 2 * (size_t)b;
-	uint32_t* pc = colMesh + b;
+	char* pp = O.pos + (vOff + b) * 8u;
+	char* pc = O.col + (vOff + b) * 4u;
 	if (thin) { // stroker.cpp:2060-2110
 		const V2 vf = v2mul(jn.v, hsw);
 		const V2 q0 = L ? v2add(p1, vf) : v2sub(p1, vf);
 		const V2 q2 = L ? v2sub(p1, vf) : v2add(p1, vf);
 		PosPair q; q.x0 = q0.x; q.y0 = q0.y; q.x1 = p1.x; q.y1 = p1.y;
+		ColPair c; c.c0 = c0; c.c1 = color;
 		VGX_ST_GUARD(c0) {
 		*(PosPair*)pp = q;
-		*(float2*)(pp + 4) = make_float2(q2.x, q2.y);
-		ColPair c; c.c0 = c0; c.c1 = color;
+		*(float2*)(pp + 16) = make_float2(q2.x, q2.y);
 		*(ColPair*)pc = c;
-		pc[2] = c0;
+		*(uint32_t*)(pc + 8) = c0;
 		}
 	} else { // :1524-1579
 		const V2 vhaa = v2mul(jn.v, hswAA);
@@ -260,201 +319,243 @@ __device__ __forceinline__ void tmpl_stroke_elem(uint32_t kindWord, uint32_t N, 
 		const V2 q3 = L ? v2sub(p1, vhaa) : v2add(p1, vhaa);
 		PosPair q; q.x0 = q0.x; q.y0 = q0.y; q.x1 = q1.x; q.y1 = q1.y;
 		PosPair r; r.x0 = q2.x; r.y0 = q2.y; r.x1 = q3.x; r.y1 = q3.y;
+		ColPair c; c.c0 = c0; c.c1 = color;
+		ColPair d; d.c0 = color; d.c1 = c0;
 		VGX_ST_GUARD(c0 ^ __float_as_uint(q.x0) ^ __float_as_uint(r.y1)) {
 		*(PosPair*)pp = q;
-		*(PosPair*)(pp + 4) = r;
-		ColPair c; c.c0 = c0; c.c1 = color;
+		*(PosPair*)(pp + 16) = r;
 		*(ColPair*)pc = c;
-		ColPair d; d.c0 = color; d.c1 = c0;
-		*(ColPair*)(pc + 2) = d;
+		*(ColPair*)(pc + 8) = d;
 		}
 	}
 	if (j > 0) { // the bridge from the previous join (stroker.cpp:1557-1564, 1714-1721; thin :2093-2098, 2175-2180)
-		const uint32_t jp2 = jp1 > 0 ? jp1 - 1 : N - 1;
-		const V2 pPrev2 = vtx(jp2);
-		const VgxJoin jp = vgx_join_dirs(v2dir(pPrev2, pPrev), dPrev, sideWidth);
+		const VgxJoin jp = vgx_join_dirs(dPrev2, dPrev, sideWidth);
 		const uint32_t pb = R * (j - 1), ptop = pb + R - 1;
 		const Rails p = thin ? (jp.leftInner ? rails(pb, pb + 1, pb + 2, 0) : rails(ptop, pb + 1, pb, 0))
 		                     : (jp.leftInner ? rails(pb, pb + 1, pb + 2, pb + 3) : rails(ptop, pb + 2, pb + 1, pb));
-		uint16_t* pi = idxMesh + (size_t)bridgeIdx * (j - 1);
+		char* pi = O.idx + (iOff + bridgeIdx * (j - 1)) * 2u;
 		Idx6 t0; t0.a = (p.a & 0xFFFFu) | (p.b << 16); t0.b = (mine.b & 0xFFFFu) | (p.a << 16); t0.c = (mine.b & 0xFFFFu) | (mine.a << 16);
 		Idx6 t1; t1.a = (p.b & 0xFFFFu) | (p.c << 16); t1.b = (mine.c & 0xFFFFu) | (p.b << 16); t1.c = (mine.c & 0xFFFFu) | (mine.b << 16);
 		VGX_ST_GUARD(t0.a ^ t1.c) {
 		*(Idx6*)pi = t0;
-		*(Idx6*)(pi + 6) = t1;
+		*(Idx6*)(pi + 12) = t1;
 		if (!thin) {
 			Idx6 t2; t2.a = (p.c & 0xFFFFu) | (p.d << 16); t2.b = (mine.d & 0xFFFFu) | (p.c << 16); t2.c = (mine.d & 0xFFFFu) | (mine.c << 16);
-			*(Idx6*)(pi + 12) = t2;
+			*(Idx6*)(pi + 24) = t2;
 		}
 		}
 	}
 	if (j + 1 == N) { // closing bridge to join 0 (:1970-1984, 2295-2306); d12 = vec2Dir(last vertex, vertex 0)
-		const V2 v1 = vtx(N > 1 ? 1u : 0u);
-		const VgxJoin j0 = vgx_join_dirs(d12, v2dir(pNext, v1), sideWidth);
+		const VgxJoin j0 = vgx_join_dirs(d12, dFirst, sideWidth);
 		const Rails f = thin ? (j0.leftInner ? rails(0, 1, 2, 0) : rails(2, 1, 0, 0)) : (j0.leftInner ? rails(0, 1, 2, 3) : rails(3, 2, 1, 0));
-		uint16_t* pi = idxMesh + (size_t)bridgeIdx * (N - 1);
+		char* pi = O.idx + (iOff + bridgeIdx * (N - 1)) * 2u;
 		Idx6 t0; t0.a = (mine.a & 0xFFFFu) | (mine.b << 16); t0.b = (f.b & 0xFFFFu) | (mine.a << 16); t0.c = (f.b & 0xFFFFu) | (f.a << 16);
 		Idx6 t1; t1.a = (mine.b & 0xFFFFu) | (mine.c << 16); t1.b = (f.c & 0xFFFFu) | (mine.b << 16); t1.c = (f.c & 0xFFFFu) | (f.b << 16);
+		VGX_ST_GUARD(t0.a ^ t1.c) {
 		*(Idx6*)pi = t0;
-		*(Idx6*)(pi + 6) = t1;
+		*(Idx6*)(pi + 12) = t1;
 		if (!thin) {
 			Idx6 t2; t2.a = (mine.c & 0xFFFFu) | (mine.d << 16); t2.b = (f.d & 0xFFFFu) | (mine.c << 16); t2.c = (f.d & 0xFFFFu) | (f.c << 16);
-			*(Idx6*)(pi + 12) = t2;
+			*(Idx6*)(pi + 24) = t2;
+		}
 		}
 	}
 }
 
-// Per-mesh record of a tile in LDS (phase 0). 64 bytes.
-struct __attribute__((aligned(16))) TmplRec
+// the caller's mesh table: the template's record moved to this instance
+__device__ __forceinline__ void tmpl_mesh_out(const VgxTmplArgs& A, uint64_t inst, uint32_t mesh)
 {
-	uint32_t poly_first, n, v_off, i_off;
-	uint32_t kind, color; float f0, f1; // fills: f0 = aa WITH the instance's orientation sign; strokes: hsw, hswAA
-	float m0, m1, m2, m3;
-	float m4, m5; uint32_t pad0, pad1;
-};
-
-// The per-mesh values of one (instance, template mesh): what phase 0 parks in LDS and what the fallback computes per lane.
-__device__ __forceinline__ TmplRec tmpl_make_rec(const VgxTmplArgs& A, const vgx_draw* idraws, uint32_t m)
-{
-	const VgxTmplMesh tm = A.tmesh[m];
-	const uint4* dq = (const uint4*)(idraws + tm.drawk);
-	const uint32_t kind = VGX_MD_KIND(tm.kind);
-	const bool isFill = kind < VGX_MESH_STROKE;
-	const uint4 qc = dq[isFill ? 0 : 1]; // fill_color = q0.z, stroke_color = q1.x
-	const uint4 q2 = dq[2], q3 = dq[3];
-	TmplRec r;
-	r.poly_first = tm.poly_first; r.n = tm.n; r.v_off = tm.v_off; r.i_off = tm.i_off;
-	r.kind = tm.kind; r.color = isFill ? qc.z : qc.x; r.f0 = tm.f0; r.f1 = tm.f1;
-	r.m0 = __uint_as_float(q2.y); r.m1 = __uint_as_float(q2.z); r.m2 = __uint_as_float(q2.w);
-	r.m3 = __uint_as_float(q3.x); r.m4 = __uint_as_float(q3.y); r.m5 = __uint_as_float(q3.z);
-	r.pad0 = 0; r.pad1 = 0;
-	if (kind == VGX_MESH_FILL_AA) {
-		// orientation from the first triangle of the TRANSFORMED polygon (stroker.cpp:721-723)
-		TmplXf xf; xf.m0 = r.m0; xf.m1 = r.m1; xf.m2 = r.m2; xf.m3 = r.m3; xf.m4 = r.m4; xf.m5 = r.m5;
-		const float2* vt = A.tpoly + tm.poly_first;
-		const V2 a0 = tmpl_xf(xf, vt[0]), a1 = tmpl_xf(xf, vt[1]), a2 = tmpl_xf(xf, vt[2]);
-		const float orient = v2cross(v2sub(a1, a0), v2sub(a2, a0));
-		r.f0 = tm.f0 * vgm_sign(orient);
-	}
-	return r;
+	vgx_mesh mr = A.tmtab[mesh];
+	mr.first_vertex += inst * A.inst.num_vertices;
+	mr.first_index += inst * A.inst.num_indices;
+	mr.draw += (uint32_t)(inst * A.period);
+	A.meshes_out[inst * A.inst.num_meshes + mesh] = mr;
 }
 
-// One element once its mesh record, its own transformed vertex and a way to get the mesh's other transformed vertices exist.
-template<class VF>
-__device__ __forceinline__ void tmpl_elem_emit(const VgxTmplArgs& A, uint64_t inst, uint32_t mesh, uint32_t j, const TmplRec& r, V2 p1, const VF& vtx)
+// One element given its mesh's constants, its transformed vertex, its own edge direction and a way to get the mesh's other
+// edge directions (dir(jj) = direction of the edge jj -> jj + 1, cyclic).
+template<class DF>
+__device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t color, float f0, float f1,
+	V2 p1, V2 d12, const DF& dir)
 {
-	const uint32_t kind = VGX_MD_KIND(r.kind);
-	const uint32_t N = r.n;
-	if (j == 0 && A.meshes_out) { // the caller's mesh table: the template's record moved to this instance
-		vgx_mesh mr = A.tmtab[mesh];
-		mr.first_vertex += inst * A.inst.num_vertices;
-		mr.first_index += inst * A.inst.num_indices;
-		mr.draw += (uint32_t)(inst * A.period);
-		A.meshes_out[inst * A.inst.num_meshes + mesh] = mr;
-	}
+	const uint32_t kind = VGX_MD_KIND(kindWord);
+	const uint32_t jp1 = j > 0 ? j - 1 : N - 1;
 	if (kind < VGX_MESH_STROKE) {
-		FillFetch F;
-		F.valid = true; F.j = j; F.N = N; F.color = r.color; F.ibase = 0; F.mi = 0;
-		F.firstV = inst * A.inst.num_vertices + r.v_off;
-		F.firstI = inst * A.inst.num_indices + r.i_off;
-		F.aaElem = kind == VGX_MESH_FILL_AA;
-		F.sseOrder = VGX_MD_SSE_ORDER(r.kind) != 0;
-		F.nextInWave = false; F.prevInWave = false;
-		F.p1 = p1; F.pNextB = p1; F.pPrevB = p1;
-		F.aa = r.f0;
-		V2 dPrev = v2(0.0f, 0.0f), d12 = dPrev;
-		if (F.aaElem) {
-			d12 = v2dir(p1, vtx(j + 1 < N ? j + 1 : 0u));
-			dPrev = v2dir(vtx(j > 0 ? j - 1 : N - 1), p1);
-		}
-		fill_emit_store(A.pos, A.color, A.idx, F, dPrev, d12);
+		V2 dPrev = d12;
+		if (kind == VGX_MESH_FILL_AA) { dPrev = dir(jp1); }
+		tmpl_fill_elem(O, kindWord, N, vOff, iOff, color, f0, j, p1, dPrev, d12);
 	} else {
-		const uint64_t v0 = inst * A.inst.num_vertices + r.v_off;
-		tmpl_stroke_elem(r.kind, N, r.f0, r.f1, j, p1, vtx, r.color, A.pos + 2 * v0, A.color + v0, A.idx + (inst * A.inst.num_indices + r.i_off));
+		const V2 dPrev = dir(jp1);
+		V2 dPrev2 = dPrev, dFirst = dPrev;
+		if (j > 0) { dPrev2 = dir(jp1 > 0 ? jp1 - 1 : N - 1); }
+		if (j + 1 == N) { dFirst = dir(0u); }
+		tmpl_stroke_elem(O, kindWord, N, vOff, iOff, color, f0, f1, j, p1, dPrev2, dPrev, d12, dFirst);
 	}
 }
 
 #define VGX_TMPL_THREADS 256
-#define VGX_TMPL_MAX_TILE 1024 /* elements per tile the LDS vertex stage holds */
-#define VGX_TMPL_MAXM 96       /* meshes per tile the LDS record table holds; a tile that touches more takes the per-lane fallback */
+#define VGX_TMPL_MAX_TILE 1024 /* elements per tile the LDS stages hold */
+#define VGX_TMPL_MAXM 96       /* meshes / draws per tile the LDS tables hold; a tile that needs more takes the per-lane fallback */
 #define VGX_TMPL_CH (VGX_TMPL_MAX_TILE / VGX_TMPL_THREADS)
 #ifndef VGX_TMPL_OCC
 #define VGX_TMPL_OCC
 #endif
 __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(VgxTmplArgs A)
 {
+	__shared__ TmplDraw s_draw[VGX_TMPL_MAXM];
 	__shared__ TmplRec s_rec[VGX_TMPL_MAXM];
 	__shared__ float2 s_vtx[VGX_TMPL_MAX_TILE];
-	if (A.totals->status != VGX_OK) {
-		return;
-	}
+	__shared__ float2 s_dir[VGX_TMPL_MAX_TILE];
+	__shared__ uint32_t s_status;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t inst32 = blockIdx.x / A.tiles_per_inst;
 	const uint32_t t = blockIdx.x - inst32 * A.tiles_per_inst;
 	const uint64_t inst = inst32;
+	const VgxTmplTile tl = A.ttile[t]; // workgroup-uniform: scalar loads
 	const uint32_t E = (uint32_t)A.inst.num_elements;
 	const uint32_t x0 = t * A.tile;
 	const uint32_t nel = x0 + A.tile < E ? A.tile : E - x0;
-	const uint32_t mA = A.tile_mesh0[t];
-	const uint32_t mB = t + 1 < A.tiles_per_inst ? A.tile_mesh0[t + 1] : (uint32_t)A.inst.num_meshes - 1;
-	const uint32_t nm = mB - mA + 1;
+	const uint32_t mA = tl.mesh0 & 0x7FFFFFFFu;
+	const bool firstWhole = (tl.mesh0 >> 31) != 0; // mesh mA begins in this tile (else in an earlier one)
+	const uint32_t nm = tl.mesh_last - mA + 1;
+	const uint32_t dA = tl.draw0, nd = tl.ndraws;
 	const vgx_draw* idraws = A.draws + inst * A.period;
 	const VgxTmplElem* telem = A.telem + x0;
-	if (nm > VGX_TMPL_MAXM) { // block-uniform. Many tiny meshes in one tile: every lane fetches its own records
+	TmplOut O;
+	O.pos = (char*)(A.pos + 2 * (inst * A.inst.num_vertices));
+	O.col = (char*)(A.color + inst * A.inst.num_vertices);
+	O.idx = (char*)(A.idx + inst * A.inst.num_indices);
+	if (t == 0 && inst == 0 && tid == 0) { // totals of the batch = instances x template (the memset in front of this kernel zeroed them)
+		vgx_sizes z;
+		z.num_poly_vertices = A.ninst * A.inst.num_poly_vertices; z.num_subpaths = A.ninst * A.inst.num_subpaths; z.num_meshes = A.ninst * A.inst.num_meshes;
+		z.num_vertices = A.ninst * A.inst.num_vertices; z.num_indices = A.ninst * A.inst.num_indices; z.num_serial_draws = A.ninst * A.inst.num_serial_draws;
+		z.num_cmd_instances = A.ninst * A.inst.num_cmd_instances; z.num_elements = A.ninst * A.inst.num_elements; z.num_fill_elements = A.ninst * A.inst.num_fill_elements;
+		z.num_drawcmds = 0;
+		A.totals->sizes = z;
+	}
+	if (nm > VGX_TMPL_MAXM || nd > VGX_TMPL_MAXM) {
+		// workgroup-uniform. Many tiny meshes (or many draws without a mesh) in one tile: the draw records are verified in a loop,
+		// every lane fetches its own records and neighbours
+		for (uint32_t k = tid; k < nd; k += VGX_TMPL_THREADS) { (void)tmpl_load_draw(A, idraws, dA + k); }
 		for (uint32_t s = tid; s < nel; s += VGX_TMPL_THREADS) {
 			const VgxTmplElem er = telem[s];
-			const TmplRec r = tmpl_make_rec(A, idraws, er.mesh);
-			TmplXf xf; xf.m0 = r.m0; xf.m1 = r.m1; xf.m2 = r.m2; xf.m3 = r.m3; xf.m4 = r.m4; xf.m5 = r.m5;
-			const float2* vt = A.tpoly + r.poly_first;
-			const uint32_t j = er.jq & 0xFFFFu;
-			tmpl_elem_emit(A, inst, er.mesh, j, r, tmpl_xf(xf, vt[j]), [&](uint32_t jj) { return tmpl_xf(xf, vt[jj]); });
+			const VgxTmplMesh tm = A.tmesh[er.mesh];
+			const TmplDraw dr = tmpl_load_draw(A, idraws, tm.drawk);
+			const TmplXf xf = tmpl_draw_xf(&dr);
+			const float2* vt = A.tpoly + tm.poly_first;
+			const uint32_t kind = VGX_MD_KIND(tm.kind);
+			const uint32_t j = er.jq & 0xFFFFu, N = tm.n;
+			float f0 = tm.f0;
+			if (kind == VGX_MESH_FILL_AA) { f0 = tmpl_fill_aa(xf, vt[0], vt[1], vt[2], tm.f0); }
+			auto dir = [&](uint32_t jj) { return v2dir(tmpl_xf(xf, vt[jj]), tmpl_xf(xf, vt[jj + 1 < N ? jj + 1 : 0u])); };
+			if (j == 0 && A.meshes_out) { tmpl_mesh_out(A, inst, er.mesh); }
+			tmpl_elem_emit(O, j, tm.kind, N, tm.v_off, tm.i_off, kind < VGX_MESH_STROKE ? dr.fill_color : dr.stroke_color, f0, tm.f1, tmpl_xf(xf, vt[j]), dir(j), dir);
 		}
 		return;
 	}
-	// phase 0
-	if (tid < nm) { s_rec[tid] = tmpl_make_rec(A, idraws, mA + tid); }
-	__syncthreads();
-	// phase 1: chunk k = c * 4 + wave of the tile (interleaved: the tile's stroke chunks, the heavier ones, spread over the waves)
+#ifdef VGX_TMPL_PROFILE
+	const unsigned long long tp0 = wall_clock64();
+#define TMPL_PROF(i) do { if (tid == 0) { atomicAdd(&A.totals->prof[i], wall_clock64() - tp0); } } while (0)
+#else
+#define TMPL_PROF(i)
+#endif
+	// ---- phase 0a: every load the workgroup needs, requested at once
 	VgxTmplElem er[VGX_TMPL_CH];
-	V2 p1[VGX_TMPL_CH];
+	float2 lp[VGX_TMPL_CH];
 #pragma unroll
 	for (int c = 0; c < VGX_TMPL_CH; ++c) {
-		const uint32_t s = (uint32_t)c * VGX_TMPL_THREADS + tid;
-		er[c].mesh = mA; er[c].jq = 0;
+		const uint32_t s = (uint32_t)c * VGX_TMPL_THREADS + tid; // chunk c * 4 + wave of the tile: the tile's stroke chunks (the heavier ones) spread over the waves
+		er[c].mesh = mA; er[c].jq = 0; er[c].vtx = 0; er[c].pad = 0;
 		if (s < nel) { er[c] = telem[s]; }
 	}
+	VgxTmplMesh tm;
+	tm.poly_first = 0; tm.n = 3; tm.v_off = 0; tm.i_off = 0; tm.drawk = dA; tm.kind = VGX_MESH_FILL; tm.f0 = 0.0f; tm.f1 = 0.0f;
+	if (tid < nm) { tm = A.tmesh[mA + tid]; }
+	if (tid < nd) { s_draw[tid] = tmpl_load_draw(A, idraws, dA + tid); }
+#pragma unroll
+	for (int c = 0; c < VGX_TMPL_CH; ++c) { lp[c] = A.tpoly[er[c].vtx]; }
+	float2 l0 = make_float2(0.0f, 0.0f), l1 = l0, l2 = l0;
+	if (tid < nm && VGX_MD_KIND(tm.kind) == VGX_MESH_FILL_AA) { const float2* vt = A.tpoly + tm.poly_first; l0 = vt[0]; l1 = vt[1]; l2 = vt[2]; }
+	if (tid == 0) { s_status = A.totals->status; } // an earlier workgroup may have found the batch stale; ONE value for the whole workgroup (the exit below must be uniform)
+	__syncthreads();
+	const uint32_t status = s_status;
+	// ---- phase 0b: per-mesh records
+	if (tid < nm) {
+		const uint32_t kind = VGX_MD_KIND(tm.kind);
+		const TmplDraw* d = &s_draw[tm.drawk - dA];
+		TmplRec r;
+		r.dk = tm.drawk - dA; r.n = tm.n; r.v_off = tm.v_off; r.i_off = tm.i_off;
+		r.kind = tm.kind; r.color = kind < VGX_MESH_STROKE ? d->fill_color : d->stroke_color; r.f0 = tm.f0; r.f1 = tm.f1;
+		if (kind == VGX_MESH_FILL_AA) { r.f0 = tmpl_fill_aa(tmpl_draw_xf(d), l0, l1, l2, tm.f0); }
+		s_rec[tid] = r;
+		// the caller's mesh table for the meshes that BEGIN in this tile (every mesh of the range but possibly the first)
+		if ((tid > 0 || firstWhole) && A.meshes_out && status == VGX_OK) { tmpl_mesh_out(A, inst, mA + tid); }
+	}
+	__syncthreads();
+	TMPL_PROF(0);
+	if (status != VGX_OK) { // workgroup-uniform
+		return;
+	}
+	// ---- phase 1: own vertex, transformed once
+	V2 p1[VGX_TMPL_CH];
 #pragma unroll
 	for (int c = 0; c < VGX_TMPL_CH; ++c) {
 		const uint32_t s = (uint32_t)c * VGX_TMPL_THREADS + tid;
 		p1[c] = v2(0.0f, 0.0f);
 		if (s < nel) {
 			const TmplRec* r = &s_rec[er[c].mesh - mA];
-			const float2 lp = A.tpoly[r->poly_first + (er[c].jq & 0xFFFFu)];
-			TmplXf xf; xf.m0 = r->m0; xf.m1 = r->m1; xf.m2 = r->m2; xf.m3 = r->m3; xf.m4 = r->m4; xf.m5 = r->m5;
-			p1[c] = tmpl_xf(xf, lp);
+			p1[c] = tmpl_xf(tmpl_draw_xf(&s_draw[r->dk]), lp[c]);
 			s_vtx[er[c].jq >> 16] = make_float2(p1[c].x, p1[c].y);
 		}
 	}
 	__syncthreads();
-	// phase 2
+	TMPL_PROF(1);
+	// transformed vertex jj of mesh `mesh` whose vertex 0 sits at tile position q0 (negative: in front of the tile): LDS, or -- the
+	// vertex belongs to another tile -- L2 + transform
+	auto vtxAt = [&](uint32_t mesh, const TmplRec* rp, int q0, uint32_t jj) {
+		const uint32_t qq = (uint32_t)(q0 + (int)jj);
+		if (qq < nel) { const float2 v = s_vtx[qq]; return v2(v.x, v.y); }
+		return tmpl_xf(tmpl_draw_xf(&s_draw[rp->dk]), A.tpoly[A.tmesh[mesh].poly_first + jj]);
+	};
+	// ---- phase 2: own edge direction vec2Dir(p[j], p[j + 1]) (stroker.cpp:31-38), once per element
+	V2 d12[VGX_TMPL_CH];
+#pragma unroll
+	for (int c = 0; c < VGX_TMPL_CH; ++c) {
+		const uint32_t s = (uint32_t)c * VGX_TMPL_THREADS + tid;
+		d12[c] = v2(0.0f, 0.0f);
+		if (s < nel) {
+			const TmplRec* rp = &s_rec[er[c].mesh - mA];
+			const uint32_t j = er[c].jq & 0xFFFFu, N = rp->n;
+			const int q0 = (int)(er[c].jq >> 16) - (int)j;
+			d12[c] = v2dir(p1[c], vtxAt(er[c].mesh, rp, q0, j + 1 < N ? j + 1 : 0u));
+			s_dir[er[c].jq >> 16] = make_float2(d12[c].x, d12[c].y);
+		}
+	}
+	__syncthreads();
+	TMPL_PROF(2);
+	// ---- phase 3: the element
 #pragma unroll
 	for (int c = 0; c < VGX_TMPL_CH; ++c) {
 		const uint32_t s = (uint32_t)c * VGX_TMPL_THREADS + tid;
 		if (s < nel) {
-			const TmplRec* rp = &s_rec[er[c].mesh - mA];
-			TmplRec r;
-			r.poly_first = rp->poly_first; r.n = rp->n; r.v_off = rp->v_off; r.i_off = rp->i_off;
-			r.kind = rp->kind; r.color = rp->color; r.f0 = rp->f0; r.f1 = rp->f1;
-			const uint32_t j = er[c].jq & 0xFFFFu;
-			const int q0 = (int)(er[c].jq >> 16) - (int)j; // tile position of the mesh's vertex 0 (negative: in front of the tile)
-			tmpl_elem_emit(A, inst, er[c].mesh, j, r, p1[c], [&](uint32_t jj) {
-				const int qq = q0 + (int)jj;
-				if (qq >= 0 && qq < (int)nel) { const float2 v = s_vtx[qq]; return v2(v.x, v.y); }
-				TmplXf xf; xf.m0 = rp->m0; xf.m1 = rp->m1; xf.m2 = rp->m2; xf.m3 = rp->m3; xf.m4 = rp->m4; xf.m5 = rp->m5;
-				return tmpl_xf(xf, A.tpoly[r.poly_first + jj]); // the neighbour belongs to another tile
-			});
+			const uint32_t mesh = er[c].mesh;
+			const TmplRec* rp = &s_rec[mesh - mA];
+			const uint32_t j = er[c].jq & 0xFFFFu, N = rp->n;
+			const int q0 = (int)(er[c].jq >> 16) - (int)j;
+			auto dir = [&](uint32_t jj) {
+				const uint32_t qq = (uint32_t)(q0 + (int)jj);
+				if (qq < nel) { const float2 v = s_dir[qq]; return v2(v.x, v.y); }
+				return v2dir(vtxAt(mesh, rp, q0, jj), vtxAt(mesh, rp, q0, jj + 1 < N ? jj + 1 : 0u)); // the edge belongs to another tile
+			};
+			tmpl_elem_emit(O, j, rp->kind, N, rp->v_off, rp->i_off, rp->color, rp->f0, rp->f1, p1[c], d12[c], dir);
 		}
 	}
+	TMPL_PROF(3);
+#ifdef VGX_TMPL_PROFILE
+	__builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the wave's stores are out
+	TMPL_PROF(4);
+	if (tid == 0) { atomicAdd(&A.totals->prof[5], 1ull); }
+#endif
 }
 
 } // namespace
@@ -467,14 +568,12 @@ void vgx_launch_tmpl_check(const vgx_draw* draws, uint64_t ndraws, uint32_t npat
 void vgx_launch_tmpl_build(const VgxTmplBuild& b, hipStream_t s)
 {
 	const uint64_t gm = (b.num_meshes + 255) / 256, ge = (b.num_elems + 255) / 256;
+	const uint64_t nt = (b.num_elems + b.tile - 1) / b.tile;
 	if (b.num_meshes) { hipLaunchKernelGGL(k_tmpl_meshes, dim3((unsigned)(gm > 4096 ? 4096 : gm)), dim3(256), 0, s, b); }
-	if (b.num_elems) { hipLaunchKernelGGL(k_tmpl_elems, dim3((unsigned)(ge > 4096 ? 4096 : ge)), dim3(256), 0, s, b); }
-}
-
-void vgx_launch_tmpl_verify(const VgxTmplArgs& a, hipStream_t s)
-{
-	const uint64_t g = (a.ndraws + 255) / 256;
-	hipLaunchKernelGGL(k_tmpl_verify, dim3((unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g))), dim3(256), 0, s, a);
+	if (b.num_elems) {
+		hipLaunchKernelGGL(k_tmpl_elems, dim3((unsigned)(ge > 4096 ? 4096 : ge)), dim3(256), 0, s, b);
+		hipLaunchKernelGGL(k_tmpl_tiles, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, b);
+	}
 }
 
 void vgx_launch_tmpl_emit(const VgxTmplArgs& a, hipStream_t s)

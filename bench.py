@@ -93,10 +93,10 @@ def effective_cores():
     return n
 
 
-def cpu_baseline(budget_seconds=10.0, max_procs=256):
-    """Reference CPU path on the host cores of THIS box: one process per usable core, every process loops over
-    its own 16 Tiger instances for `budget_seconds` of wall time after a common start. Returns the dict for the
-    JSON line (value = sum of verts / slowest process's wall)."""
+def cpu_baseline(budget_seconds=10.0, max_procs=256, which="tiger"):
+    """Reference CPU path on the host cores of THIS box: one process per usable core, every process loops over its own shard
+    (tiger: 16 instances; cubics: 20 000 cubics; round: 8 polylines x 1000 segments) for `budget_seconds` of wall time after a
+    common start. Returns the dict for the JSON line (value = sum of units / slowest process's wall)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
     kind = "reference" if pyoracle.available("reference") else "port"
@@ -104,9 +104,12 @@ def cpu_baseline(budget_seconds=10.0, max_procs=256):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libvgoracle.so"], stdout=subprocess.DEVNULL)
     procs = max(1, min(effective_cores(), max_procs))
     worker = os.path.join(ROOT, "oracle", "cpu_bench.py")
+    shard = {"tiger": 16, "cubics": 20000, "round": 8}[which]
+    what = {"tiger": "Tiger x16 instances", "cubics": "20 000 independent cubics (flatten + transform only)", "round": "8 polylines x 1000 segments, Round joins + caps"}[which]
+    unit = "M polyline verts/s" if which == "cubics" else "M verts/s"
 
-    def run(nproc, budget):
-        ps = [subprocess.Popen([sys.executable, worker, kind, "16", str(i * 16), str(budget)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+    def run(k, nproc, budget):
+        ps = [subprocess.Popen([sys.executable, worker, k, str(shard), str(i * shard), str(budget), which], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
               for i in range(nproc)]
         for p in ps:
             assert p.stdout.readline().strip() == "ready"
@@ -116,29 +119,47 @@ def cpu_baseline(budget_seconds=10.0, max_procs=256):
         outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in ps]
         return sum(o["verts"] for o in outs), max(o["seconds"] for o in outs), sum(o["cpu_seconds"] for o in outs)
 
-    v1, t1, _ = run(1, min(2.0, budget_seconds))
-    vN, tN, cN = run(procs, budget_seconds)
+    v1, t1, _ = run(kind, 1, min(2.0, budget_seconds))
+    vN, tN, cN = run(kind, procs, budget_seconds)
     sse = None
-    if kind == "reference" and pyoracle.available("reference_sse"):
+    if which == "tiger" and kind == "reference" and pyoracle.available("reference_sse"):
         # the reference's fastest configuration (SSE2 strokerConvexFillAA, stroker.cpp:368-711): speed only, its
         # indices / rounding differ from the scalar build, so it is not a parity oracle
-        def run_sse(nproc, budget):
-            ps = [subprocess.Popen([sys.executable, worker, "reference_sse", "16", str(i * 16), str(budget)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
-                  for i in range(nproc)]
-            for p in ps:
-                assert p.stdout.readline().strip() == "ready"
-            for p in ps:
-                p.stdin.write("go\n")
-                p.stdin.flush()
-            outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in ps]
-            return sum(o["verts"] for o in outs), max(o["seconds"] for o in outs)
-        vs, ts = run_sse(procs, budget_seconds / 2)
+        vs, ts, _ = run("reference_sse", procs, budget_seconds / 2)
         sse = round(vs / ts / 1e6, 2)
-    return {"value": round(vN / tN / 1e6, 2), "unit": "M verts/s", "cores": procs, "kind": kind,
+    return {"value": round(vN / tN / 1e6, 2), "unit": unit, "cores": procs, "kind": kind,
             "value_sse_stroker": sse,
             "single_core_value": round(v1 / t1 / 1e6, 2), "cpu_seconds_per_wall_second": round(cN / tN, 1),
-            "sample": "Tiger x16 instances per process, looped for %.0f s of wall time, %d processes (one per usable host core; "
-                      "%d logical CPUs visible)" % (budget_seconds, procs, os.cpu_count() or 0)}
+            "sample": "%s per process, looped for %.0f s of wall time, %d processes (one per usable host core; "
+                      "%d logical CPUs visible)" % (what, budget_seconds, procs, os.cpu_count() or 0)}
+
+
+def gpu_environment():
+    """Clock / power-management state of GPU 0 as rocm-smi reports it (the run-to-run spread of the memory-bound kernels follows
+    it); best effort, never fails the bench."""
+    env = {}
+    try:
+        out = subprocess.run(["/opt/rocm/bin/rocm-smi", "-d", "0", "--showperflevel", "--showclocks", "--showcomputepartition", "--showmemorypartition", "--json"],
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=20).stdout
+        j = json.loads(out[out.index("{"):])
+        card = j.get("card0", {})
+        for k, v in card.items():
+            kl = k.lower()
+            if "performance level" in kl:
+                env["perf_level"] = v
+            elif "sclk" in kl and "clock" in kl:
+                env["sclk"] = v
+            elif "mclk" in kl and "clock" in kl:
+                env["mclk"] = v
+            elif "fclk" in kl and "clock" in kl:
+                env["fclk"] = v
+            elif "compute partition" in kl:
+                env["compute_partition"] = v
+            elif "memory partition" in kl:
+                env["memory_partition"] = v
+    except Exception as e:  # noqa: BLE001
+        env["error"] = repr(e)[:80]
+    return env
 
 
 WORKLOADS = {
@@ -147,12 +168,18 @@ WORKLOADS = {
     "round10k": "BASELINE configs[3]: 10k polylines x 1k segments, Round joins + Round caps",
     "tiger10k_varied": "Tiger x10k with per-instance scale (0.5 .. 3.5) and rotation: the instanced flatten without its lock-step walk",
     "tigerspec10k": "SURVEY 8(d) config 3 as specified: 240 paths x (1-4 sub-paths x 8-60 cubics), x10k instances",
+    # honesty configs: the headline batch WITHOUT the template mode (every instance flattened, polyline through HBM), and without
+    # any instancing shortcut (what a batch of 2.4 M unrelated draws costs)
+    "tiger10k_per_instance_flatten": "Tiger x10k with VGX_TMPL=0: k_flatten_inst (one lane per instance) + k_fill + k_stroke, the round-3 pipeline",
+    "tiger10k_command_parallel": "Tiger x10k with VGX_INST=0: k_flatten_build (one lane per path command) + k_fill + k_stroke, no instancing at all",
 }
+CONFIG_ENV = {"tiger10k_per_instance_flatten": {"VGX_TMPL": "0"}, "tiger10k_command_parallel": {"VGX_INST": "0"}}
+CONFIG_CPU = {"cubics1m": "cubics", "round10k": "round"}  # configs that get their own cpu_baseline (the tiger ones share the headline's)
 
 
 def make_workload(wl, name, instances, rank):
     """(path set, draw records, description, kind) of one BASELINE config; kind 'tessellate' or 'flatten'."""
-    if name == "tiger10k":
+    if name in ("tiger10k", "tiger10k_per_instance_flatten", "tiger10k_command_parallel"):
         ps, ops = wl.tiger_paths()
         d = wl.tiger_draws(ops, instances, first_instance=rank * instances)
         return ps, d, ("tiger-like 240-path drawing (seed 2024) x %d instances per GPU: convexFillAA on every sub-path + "
@@ -332,7 +359,8 @@ def main():
     ap.add_argument("--gather", action="store_true", help="(default for --gpus > 1) also time the RCCL gather of the streams to rank 0")
     ap.add_argument("--no-gather", action="store_true", help="multi-GPU: skip the gather leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--placements", type=int, default=3, help="output-buffer allocations to choose from before the warm-up (1 = take the first; see run_config)")
+    ap.add_argument("--placements", type=int, default=1, help="output-buffer allocations to probe before the warm-up (default 1 = the first allocation is the one that is timed; "
+                                                               "N > 1 reports every candidate and times the fastest -- a tuning aid, not the headline)")
     args = ap.parse_args()
 
     import numpy as np
@@ -359,8 +387,13 @@ def main():
     wl = importlib.import_module("vg-renderer_amd.workloads")
 
     cpu = None
+    other_cpu = {}
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline()  # before any GPU work, in separate processes
+        if not args.no_configs:
+            for name, which in CONFIG_CPU.items():  # the reference beside every BASELINE config, on a bounded sample (4 s each)
+                other_cpu[name] = cpu_baseline(budget_seconds=4.0, which=which)
+    genv = gpu_environment() if rank == 0 else None
 
     def barrier():
         if world > 1:
@@ -608,16 +641,29 @@ def main():
                 continue
             ps2, d2, desc2, kind2 = make_workload(wl, name, K, 0)
             steps2 = min(args.steps, 5)
-            r2 = run_config(rt, torch, ctx, local_rank, name, ps2, d2, kind2, steps2, min(args.warmup, 2), barrier)
+            ctx2 = ctx
+            if name in CONFIG_ENV:  # library options are read at vgx_create: these configs get a context of their own
+                saved = {k: os.environ.get(k) for k in CONFIG_ENV[name]}
+                os.environ.update(CONFIG_ENV[name])
+                ctx2 = rt.Context(local_rank)
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            r2 = run_config(rt, torch, ctx2, local_rank, name, ps2, d2, kind2, steps2, min(args.warmup, 2), barrier)
             ms2 = r2["dt"] / steps2 * 1e3
             other[name] = {"config": WORKLOADS[name], "workload": desc2,
                            "value": round(r2["units"] / (ms2 * 1e-3) / 1e6, 2), "unit": "M %s/s" % r2["unit_name"], "ms_per_step": round(ms2, 3), "steps": steps2,
                            "verts_per_gpu": r2["sizes"].get("num_vertices", 0), "indices_per_gpu": r2["sizes"].get("num_indices", 0),
                            "poly_verts_per_gpu": r2["sizes"]["num_poly_vertices"], "meshes_per_gpu": r2["sizes"].get("num_meshes", 0),
                            "flatten_kernel": {0: "k_flatten_build", 1: "k_flatten_inst", 2: "k_flatten_inst (grouped)", 3: "k_flatten_inst (grouped by path and tolerance class)", 4: "k_flatten_inst (instances sorted by tolerance class)", 5: "none per step (template mode: first period flattened once by vgx_tessellate_count)"}.get(r2.get("flatten_mode"), "k_flatten"),
-                           "roofline": roofline(r2, steps2, traffic_for=name), "stage_ms": {k: round(v, 3) for k, v in r2["stage"].items()}}
+                           "roofline": roofline(r2, steps2, traffic_for=name), "stage_ms": {k: round(v, 3) for k, v in r2["stage"].items()},
+                           "cpu_baseline": other_cpu.get(name)}
             r2["pset"].close()
             del r2, ps2, d2
+            if ctx2 is not ctx:
+                ctx2.close()
             torch.cuda.empty_cache()
 
     if rank == 0:
@@ -646,6 +692,7 @@ def main():
             "roofline": roofline(res, args.steps, traffic_for=K if args.config == "tiger10k" else None),
             "stage_ms": {k: round(v, 3) for k, v in res["stage"].items()},
             "cpu_baseline": cpu,
+            "gpu_environment": genv,
             "next_rows": next_rows,
             "configs": other,
         }

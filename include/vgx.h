@@ -263,7 +263,14 @@ int vgx_tessellate_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* dr
 int vgx_tessellate_emit(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, const vgx_mesh_out* out, void* stream);
 /* Single asynchronous call for steady state: count + scan + emit with NO host round trip. Output
  * capacities are checked on the device; `dev_sizes` (DEVICE vgx_sizes, may be NULL) receives the
- * totals and `dev_status` (DEVICE uint32, may be NULL) receives VGX_OK / VGX_E_NOSPACE / ... . */
+ * totals and `dev_status` (DEVICE uint32, may be NULL) receives VGX_OK / VGX_E_NOSPACE / ... .
+ * Template mode: when the last vgx_tessellate_count found that the draws repeat their first P draws (>= 32 times, > 2048 draws)
+ * in everything but mtx, fill_color, stroke_color and state_key, and every mesh of that period is a convex fill or a closed
+ * Miter AA / Thin stroke, it flattened the period ONCE in local space (the reference flattens before it transforms,
+ * vg.cpp:4957-4975) and vgx_tessellate on this path set with any whole number of periods is one kernel: per instance the
+ * template's vertices through the instance's transform, the stroker's per-element arithmetic, stores. Every call re-checks all
+ * draw records against the counted period on the device; a draw that differs in another field ends the call with
+ * VGX_E_STALE in dev_status (outputs undefined): count again. VGX_TMPL=0 in the environment at vgx_create turns the mode off. */
 int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream);
 
 /* ---- stroker level: polylines in, meshes out ----------------------------------------------------- */
@@ -282,7 +289,10 @@ int vgx_stroke_emit(vgx_ctx* ctx, const float* poly, const vgx_subpath* subpaths
  * the mesh inside its vertex buffer, uint16 wrap like the reference's cast, vg_util.cpp:447-520), `drawcmds` receives
  * one record per vertex buffer and vgx_sizes.num_drawcmds their number; pos / color / meshes are unchanged (the vertex
  * streams already are in vertex-buffer order). A mesh with more than max_vb_vertices vertices sets
- * VGX_E_MESH_TOO_LARGE (the reference VG_CHECKs it, vg.cpp:5323); a too small table VGX_E_NOSPACE. The struct is copied. */
+ * VGX_E_MESH_TOO_LARGE (the reference VG_CHECKs it, vg.cpp:5323); a too small table VGX_E_NOSPACE. The struct is copied.
+ * Arm / disarm BEFORE vgx_tessellate_count: the count sizes the scratch of the pipeline the batch will take, and an armed
+ * batch never takes the template mode (see vgx_tessellate); a vgx_tessellate that finds the scratch sized for the other
+ * pipeline returns VGX_E_NOSPACE. */
 int vgx_set_assembly(vgx_ctx* ctx, const vgx_assembly* asm_);
 
 /* ---- shape cache: tessellate a drawing once, submit it many times -------------

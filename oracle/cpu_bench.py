@@ -21,10 +21,20 @@ sys.path.insert(0, HERE)
 
 def main():
     kind, instances, first, budget = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4])
+    which = sys.argv[5] if len(sys.argv) > 5 else "tiger"  # tiger | cubics | round: the BASELINE config the shard belongs to
     wl = importlib.import_module("vg-renderer_amd.workloads")
     import pyoracle
-    ps, draws = wl.tiger(instances, first_instance=first)
-    pyoracle.tessellate_timed(ps, draws, kind=kind, reps=1)  # load the library, touch the buffers
+    unit = "num_vertices"
+    run = pyoracle.tessellate_timed
+    if which == "cubics":    # configs[1]: `instances` independent cubics, pathXXX + transformPath only
+        ps, draws = wl.random_cubics(instances, seed=1234 + first, box=1000.0)
+        unit = "num_poly_vertices"
+        run = pyoracle.flatten_timed
+    elif which == "round":   # configs[3]: `instances` polylines x 1000 segments, Round joins + Round caps
+        ps, draws = wl.random_walk_polylines(instances, 1000, seed=5678 + first)
+    else:
+        ps, draws = wl.tiger(instances, first_instance=first)
+    run(ps, draws, kind=kind, reps=1)  # load the library, touch the buffers
     sys.stdout.write("ready\n")
     sys.stdout.flush()
     sys.stdin.readline()
@@ -32,8 +42,8 @@ def main():
     c0 = time.process_time()
     t0 = time.perf_counter()
     while True:
-        dt, sizes = pyoracle.tessellate_timed(ps, draws, kind=kind, reps=reps)
-        verts += sizes["num_vertices"] * reps
+        dt, sizes = run(ps, draws, kind=kind, reps=reps)
+        verts += sizes[unit] * reps
         el = time.perf_counter() - t0
         if el >= budget:
             break

@@ -185,3 +185,27 @@ def tessellate_timed(ps, draws, kind=None, reps=1):
     for _ in range(reps):
         lib.vgo_tessellate(C.byref(desc), draws.ctypes.data, n, None, C.byref(mo), C.byref(s2))
     return time.perf_counter() - t0, sizes.as_dict()
+
+
+def flatten_timed(ps, draws, kind=None, reps=1, apply_transform=True):
+    """Time `reps` vgo_flatten calls (pathReset + commands + transformPath per draw) into preallocated buffers.
+    Returns (seconds, sizes dict). Used by bench.py's cpu_baseline leg of the flatten-only config."""
+    import time
+    lib = load(kind)
+    draws = np.ascontiguousarray(draws)
+    n = draws.shape[0]
+    desc = ps.desc()
+    sizes = capi.Sizes()
+    st = lib.vgo_flatten(C.byref(desc), draws.ctypes.data, n, int(apply_transform), None, C.byref(sizes))
+    assert st == 0, st
+    poly = np.ones((sizes.num_poly_vertices, 2), dtype=np.float32)
+    subs = np.zeros(sizes.num_subpaths, dtype=capi.subpath_dtype)
+    dinfo = np.zeros(n, dtype=capi.draw_info_dtype)
+    fo = capi.FlatOut(poly.ctypes.data, subs.ctypes.data, dinfo.ctypes.data, sizes.num_poly_vertices, sizes.num_subpaths)
+    s2 = capi.Sizes()
+    st = lib.vgo_flatten(C.byref(desc), draws.ctypes.data, n, int(apply_transform), C.byref(fo), C.byref(s2))  # warm-up
+    assert st == 0, st
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        lib.vgo_flatten(C.byref(desc), draws.ctypes.data, n, int(apply_transform), C.byref(fo), C.byref(s2))
+    return time.perf_counter() - t0, sizes.as_dict()

@@ -29,12 +29,17 @@ def test_one_rank_line():
     assert d["value"] > 0 and abs(d["value"] - d["config"]["verts_per_gpu"] / d["ms_per_step"] / 1e3) / d["value"] < 0.02
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert set(r["by_kernel"]) >= {"flatten_build", "fill_emit", "stroke_emit"}
-    assert d["config"]["flatten_kernel"].startswith("k_flatten_inst")
-    assert set(d["configs"]) == {"cubics1m", "round10k", "tiger10k_varied", "tigerspec10k"}
+    assert set(r["by_kernel"]) == {"tmpl_emit"} and r["kernel"] == "tmpl_emit"  # the headline batch is a template batch: one kernel per step
+    assert d["config"]["flatten_kernel"].startswith("none per step: template mode")
+    assert set(d["configs"]) == {"cubics1m", "round10k", "tiger10k_varied", "tigerspec10k", "tiger10k_per_instance_flatten", "tiger10k_command_parallel"}
     for name, c in d["configs"].items():
         assert c["value"] > 0 and c["roofline"]["frac"] > 0, name
     assert d["configs"]["tiger10k_varied"]["flatten_kernel"] == "k_flatten_inst (instances sorted by tolerance class)"
+    # the honesty configs really run the other pipelines
+    assert d["configs"]["tiger10k_per_instance_flatten"]["flatten_kernel"] == "k_flatten_inst" and "fill_emit" in d["configs"]["tiger10k_per_instance_flatten"]["stage_ms"]
+    assert d["configs"]["tiger10k_command_parallel"]["flatten_kernel"] == "k_flatten_build"
+    assert d["configs"]["tigerspec10k"]["flatten_kernel"].startswith("none per step")
+    assert isinstance(d["gpu_environment"], dict)
 
 
 def test_two_ranks_share_one_gpu():

@@ -1,0 +1,131 @@
+"""GPU: EVERY unit of the single-GPU BASELINE configs compared with the reference at full size -- every instance of
+Tiger x10k (configs[2], the headline), every mesh of the 10 000 round-join polylines (configs[3]), every path of the
+1 M cubics (configs[1]) -- through per-unit integer digests (tests/hashutil.py) computed on the device for the product's
+buffers and by one reference PROCESS per host core (tests/ref_hash_worker.py) for the oracle's. No sampling."""
+import importlib
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import hashutil as hu
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def rt():
+    return importlib.import_module("vg-renderer_amd.runtime")
+
+
+def _cores():
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+            if q != "max":
+                n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def _reference_rows(which, units):
+    """One worker process per host core over contiguous unit ranges; returns the concatenated rows."""
+    procs = _cores()
+    per = (units + procs - 1) // procs
+    tmp = tempfile.mkdtemp(prefix="vgxhash_")
+    jobs = []
+    for i in range(procs):
+        a = i * per
+        n = min(per, units - a)
+        if n <= 0:
+            break
+        out = os.path.join(tmp, "part%03d.npy" % i)
+        jobs.append((subprocess.Popen([sys.executable, os.path.join(HERE, "ref_hash_worker.py"), which, str(a), str(n), out]), out))
+    parts = []
+    for p, out in jobs:
+        assert p.wait() == 0, "reference worker failed"
+        parts.append(np.load(out))
+        os.remove(out)
+    os.rmdir(tmp)
+    return np.concatenate(parts)
+
+
+@pytest.mark.parametrize("which", ["tiger", "tigerspec"])
+def test_every_instance_of_tiger_x10k_matches_the_reference(rt, wl, which):
+    """BASELINE configs[2] (and the SURVEY 8(d) drawing as specified, bench.py's tigerspec10k) at full size through the entry
+    point bench.py times; digests of positions / colours / indices of all 10 000 instances against the reference's."""
+    import torch
+    K = 10000
+    ps, ops = wl.tiger_paths() if which == "tiger" else wl.tiger_spec_paths()
+    d = wl.tiger_draws(ops, K)
+    ctx = rt.Context(0)
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(d)
+    sizes = rt.tessellate_count(ctx, pset, dd, d.shape[0])
+    nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
+    assert nv % K == 0 and ni % K == 0
+    bufs = rt.MeshBuffers(dd.device, nv, ni, nm)
+    bufs.pos.fill_(float("nan"))
+    rt.tessellate_async(ctx, pset, dd, d.shape[0], bufs)
+    torch.cuda.synchronize()
+    assert int(bufs.dev_status.item()) == 0
+    ref = _reference_rows(which, K)  # [K, 3, 4]
+    got = np.stack([hu.digest_uniform_torch(bufs.pos[:nv].view(torch.int32).view(-1), K), hu.digest_uniform_torch(bufs.color[:nv], K),
+                    hu.digest_uniform_torch(bufs.idx[:ni], K)], axis=1)
+    bad = np.flatnonzero((got != ref).any(axis=(1, 2)))
+    assert bad.shape[0] == 0, ("instances that differ from the reference", bad[:10].tolist(), bad.shape[0])
+    pset.close()
+    ctx.close()
+
+
+def test_every_mesh_of_the_round_join_polylines_matches_the_reference(rt, wl):
+    """BASELINE configs[3]: 10 000 polylines x 1 000 segments, Round joins + Round caps (data-dependent mesh sizes)."""
+    import torch
+    ps, d = wl.random_walk_polylines(10000, 1000, seed=5678)
+    ctx = rt.Context(0)
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(d)
+    sizes = rt.tessellate_count(ctx, pset, dd, d.shape[0])
+    nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
+    assert nm == 10000
+    bufs = rt.MeshBuffers(dd.device, nv, ni, nm)
+    rt.tessellate_async(ctx, pset, dd, d.shape[0], bufs)
+    torch.cuda.synchronize()
+    assert int(bufs.dev_status.item()) == 0
+    ref = _reference_rows("round", 10000)  # [10000, 12 + 2]
+    mt = bufs.meshes[:nm * 32].view(torch.int64).view(-1, 4)  # first_vertex, first_index, (num_vertices | num_indices << 32), (draw | kind << 32)
+    fv, fi = mt[:, 0], mt[:, 1]
+    cv, ci = mt[:, 2] & 0xFFFFFFFF, (mt[:, 2] >> 32) & 0xFFFFFFFF
+    assert np.array_equal(cv.cpu().numpy(), ref[:, 12]) and np.array_equal(ci.cpu().numpy(), ref[:, 13])
+    got = np.concatenate([hu.digest_ragged_torch(bufs.pos[:nv].view(torch.int32), 2 * fv, 2 * cv), hu.digest_ragged_torch(bufs.color[:nv], fv, cv),
+                          hu.digest_ragged_torch(bufs.idx[:ni], fi, ci, is_u16=True)], axis=1)
+    bad = np.flatnonzero((got != ref[:, :12]).any(axis=1))
+    assert bad.shape[0] == 0, ("meshes that differ from the reference", bad[:10].tolist(), bad.shape[0])
+    pset.close()
+    ctx.close()
+
+
+def test_every_path_of_the_million_cubics_matches_the_reference(rt, wl):
+    """BASELINE configs[1]: 1 M independent cubics, flatten only (vgx_flatten_count + vgx_flatten_emit with transformPath)."""
+    import torch
+    ps, d = wl.random_cubics(1000000, seed=1234, box=1000.0)
+    ctx = rt.Context(0)
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(d)
+    r = rt.flatten(ctx, pset, dd, d.shape[0], apply_transform=True, to_host=False)
+    ref = _reference_rows("cubics", 1000000)  # [1M, 4 + 1]
+    di = r.dinfo_dev[:d.shape[0] * 40].view(torch.int64).view(-1, 5)  # first_poly_vertex, first_subpath, first_mesh, (num_poly_vertices | num_subpaths << 32), ...
+    fv, cv = di[:, 0], di[:, 3] & 0xFFFFFFFF
+    assert np.array_equal(cv.cpu().numpy(), ref[:, 4])
+    npv = r.sizes["num_poly_vertices"]
+    got = hu.digest_ragged_torch(r.poly_dev[:npv].view(torch.int32), 2 * fv, 2 * cv)
+    bad = np.flatnonzero((got != ref[:, :4]).any(axis=1))
+    assert bad.shape[0] == 0, ("paths that differ from the reference", bad[:10].tolist(), bad.shape[0])
+    pset.close()
+    ctx.close()

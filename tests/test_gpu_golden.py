@@ -320,6 +320,8 @@ def test_full_size_tiger_assembly(rt, gpu_ctx, wl):
     ncmd = torch.zeros(1, dtype=torch.int64, device=dd.device)
     gpu_ctx.set_assembly(cmds_dev, 0, ncmd)
     try:
+        # arming changes what a count sizes (the unarmed count above chose the template mode, which does not assemble): count again
+        assert rt.tessellate_count(gpu_ctx, pset, dd, n) == sizes
         rt.tessellate_async(gpu_ctx, pset, dd, n, asm)
         torch.cuda.synchronize()
     finally:

@@ -82,6 +82,13 @@ enum { VGX_JOIN_MITER = 0, VGX_JOIN_ROUND = 1, VGX_JOIN_BEVEL = 2 };
  * same counts, same vertices; for callers that compare index streams with an SSE build of the reference. Positions stay
  * the scalar build's (the SSE variant computes them with rcpps / rsqrtps approximations). */
 #define VGX_FILL_INDEX_ORDER_SSE 0x100u
+/* PathType::Concave fills (VG_FILL_FLAGS, include/vg/vg.h:229; ctxFillPath* src/vg.cpp:3133-3178): libtess2 triangulates them on
+ * the CPU side of the caller, so a draw with VGX_FILL_CONCAVE and WITHOUT VGX_FILL_ENABLE produces no mesh in vgx_tessellate; its
+ * mesh is built with vgx_flatten_* (contours) + libtess2 + vgx_concave_move / vgx_concave_emit and put at the draw's place in
+ * the frame by vgx_merge. vgx_cmdlist_decode emits concave FillPath* commands as such draws (VGX_FILL_AA / VGX_FILL_EVEN_ODD say
+ * which strokerConcaveFillEnd[AA] call and FillRule the reference would use). */
+#define VGX_FILL_CONCAVE 0x10u
+#define VGX_FILL_EVEN_ODD 0x20u
 /* vgx_draw.stroke_flags */
 #define VGX_STROKE_ENABLE 0x1u
 #define VGX_STROKE_AA 0x2u
@@ -249,7 +256,8 @@ int vgx_pathset_validate(const vgx_pathset_desc* desc);
 int vgx_pathset_destroy(vgx_ctx* ctx, vgx_pathset* ps);
 
 /* ---- flatten: pathReset + path commands (+ optional transformPath) ------------------------- */
-/* `draws` is a DEVICE pointer to ndraws vgx_draw records. apply_transform != 0 writes the
+/* `draws` is a DEVICE pointer to ndraws vgx_draw records, 16-byte aligned (the kernels read a record as four 16-byte
+ * words; hipMalloc memory and any offset that is a multiple of the 64-byte record are). apply_transform != 0 writes the
  * transformed polyline (what the stroker consumes); 0 writes pathGetVertices as-is.
  * _count runs count+scan and returns totals (synchronises the stream once to read them back);
  * _emit must follow with the same arguments and DEVICE output buffers of at least those sizes. */
@@ -366,6 +374,19 @@ int vgx_concave_emit(vgx_ctx* ctx, const float* contour_verts, uint64_t num_cont
                      const vgx_concave_fill* fills, uint64_t nfills, const float* tess_pos, const uint16_t* tess_idx,
                      const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream);
 
+/* ---- merging external meshes into a frame -----------------------------------------------------------------
+ * The reference appends every mesh to the frame in submission order (createDrawCommand_VertexColor, src/vg.cpp:5207-5244).
+ * vgx_merge builds that order from two mesh sequences that are each sorted by draw: `a` = what vgx_tessellate[_emit] wrote for
+ * the frame's draws, `b` = meshes built elsewhere for draws that have none in `a` (concave fills: vgx_concave_emit), with
+ * b_draw[j] (DEVICE, may be NULL: b->meshes[j].draw) = the frame draw of b's mesh j. Output = both sequences interleaved by draw
+ * index (a mesh of `a` before a mesh of `b` of the same draw), streams copied, mesh records renumbered (first_vertex /
+ * first_index = the merged offsets, draw = the frame draw). Honours vgx_set_assembly like vgx_tessellate does (`draws` / ndraws:
+ * the frame's draw records, DEVICE, only read for VGX_ASM_SPLIT_STATE; may be NULL otherwise). All pointers are DEVICE pointers;
+ * the num_* members of `a` / `b` are host values. Asynchronous (capacities checked on the device, totals in dev_sizes, status in
+ * dev_status); a sequence that is not sorted by draw sets VGX_E_INVALID_ARG. */
+int vgx_merge(vgx_ctx* ctx, const vgx_cache_desc* a, const vgx_cache_desc* b, const uint32_t* b_draw, const vgx_draw* draws, uint64_t ndraws,
+              const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream);
+
 /* ---- command-list byte-code as input ---------------------------------------------
  * vg::CommandList::m_CommandBuffer as the reference's cl* functions write it (src/vg.cpp:243-247, 2403-2690, 5694-5723):
  * {CommandHeader{uint32 type, uint32 size}, 16-byte aligned}{payload, 16-byte aligned}... in HOST memory.
@@ -381,10 +402,14 @@ int vgx_concave_emit(vgx_ctx* ctx, const float* contour_verts, uint64_t num_cont
  * vgx_draw::state_key = generation << 20 | DrawCommand::Type << 16 | handle: what allocDrawCommand / allocClipCommand
  * compare before merging (:5359-5460); the generation changes whenever the reference sets m_ForceNewDrawCommand /
  * m_ForceNewClipCommand between two draws (scissor changes, PopState onto a different scissor, EndClip, ResetClip).
+ * Concave fills (PathType::Concave) become draws with VGX_FILL_CONCAVE [| VGX_FILL_AA] [| VGX_FILL_EVEN_ODD] and no
+ * VGX_FILL_ENABLE: vgx_tessellate makes no mesh for them, the caller builds it (vgx_flatten_* -> libtess2 -> vgx_concave_move /
+ * vgx_concave_emit) and vgx_merge puts it at the draw's place in the frame.
  * Commands without an equivalent here are counted in num_skipped and otherwise ignored: Text / TextBox, IndexedTriList,
- * concave fills (libtess2 stays with the caller: vgx_concave_*), path commands issued after a path's first fill / stroke
+ * path commands issued after a path's first fill / stroke
  * without a new BeginPath (the reference VG_CHECKs this, :2984-3059), nested lists without a table entry.
- * Host only, no device needed. Call with the array members NULL to get the counts, allocate, call again. */
+ * Host only, no device needed; re-entrant (no shared state between calls). `bytes` must be 4-byte aligned (the reference's
+ * buffers are 16-byte aligned). Call with the array members NULL to get the counts, allocate, call again. */
 typedef struct vgx_cmdlist_ref {   /* one vg::CommandList, addressed by CommandListHandle::idx (SubmitCommandList) */
 	const void* bytes;             /* HOST CommandList::m_CommandBuffer */
 	uint32_t size;                 /* m_CommandBufferPos */
@@ -392,7 +417,9 @@ typedef struct vgx_cmdlist_ref {   /* one vg::CommandList, addressed by CommandL
 } vgx_cmdlist_ref;
 enum { VGX_CL_CACHEABLE = 1u,      /* CommandListFlags::Cacheable: fills / strokes ignore the global alpha and transparent
                                     * colours are not dropped while the list populates its cache (hasCache, :3063-3075) */
-       VGX_CL_ALLOW_CULLING = 2u };/* CommandListFlags::AllowCommandCulling (:4299-4300, 4548-4577) */
+       VGX_CL_ALLOW_CULLING = 2u, /* CommandListFlags::AllowCommandCulling (:4299-4300, 4548-4577) */
+       VGX_CL_SCISSOR_SET = 0x100u };/* not a reference flag: vgx_cmdlist_state::scissor holds a rectangle even when it is all zero (a real
+                                    * empty scissor left by an earlier list of the frame); set it when chaining vgx_cmdlist_out::end_scissor */
 typedef struct vgx_cmdlist_state { /* the Context / State values at submission */
 	float mtx[6];          /* State::m_TransformMtx */
 	float global_alpha;    /* State::m_GlobalAlpha */
@@ -401,7 +428,7 @@ typedef struct vgx_cmdlist_state { /* the Context / State values at submission *
 	float canvas_width;    /* Context::m_CanvasWidth / Height (SetViewBox, scissor clamps) */
 	float canvas_height;
 	uint32_t flags;        /* VGX_CL_* of the list being decoded */
-	float scissor[4];      /* State::m_ScissorRect; all zero = {0, 0, canvas_width, canvas_height} (resetScissor) */
+	float scissor[4];      /* State::m_ScissorRect; all zero WITHOUT VGX_CL_SCISSOR_SET in flags = {0, 0, canvas_width, canvas_height} (resetScissor) */
 	uint32_t first_gradient;      /* Context::m_NextGradientID at submission (local handles are relative to it) */
 	uint32_t first_image_pattern; /* Context::m_NextImagePatternID */
 	uint32_t max_gradients;       /* Config::m_MaxGradients, 0 = 64 */
@@ -461,7 +488,7 @@ typedef struct vgx_cmdlist_out {
 	float end_global_alpha;
 	uint32_t end_clip_valid;  /* out: the clip state after the list, for the next decode's vgx_cmdlist_state::clip_* */
 	uint32_t end_clip_rule, end_clip_first_draw, end_clip_num_draws, end_clip_recording;
-	float end_scissor[4];     /* out: State::m_ScissorRect after the list */
+	float end_scissor[4];     /* out: State::m_ScissorRect after the list (chain it with VGX_CL_SCISSOR_SET: it may be a real empty rectangle) */
 	uint32_t reserved;
 } vgx_cmdlist_out;
 int vgx_cmdlist_decode(const void* bytes, uint32_t size, const vgx_cmdlist_state* state, vgx_cmdlist_out* out);
@@ -492,7 +519,9 @@ int vgx_get_failure_info(vgx_ctx* ctx, vgx_failure_info* out, void* stream);
  *   out_bounds[0] = 0 <= out_bounds[1] <= ... <= out_bounds[nparts] = ndraws   (HOST, nparts + 1 entries)
  *   out_weights[k] = predicted weight of part k (HOST, nparts entries; may be NULL)
  * Rank r then tessellates draws [out_bounds[r], out_bounds[r + 1]); rank order = draw order, so the gathered streams are the
- * single-GPU result. Homogeneous batches (Tiger x K) come out as equal instance counts. Synchronises the stream. */
+ * single-GPU result. Homogeneous batches (Tiger x K) come out as equal instance counts. Synchronises the stream.
+ * vgx_partition is a count call over the WHOLE batch: it replaces what an earlier vgx_tessellate_count left in the context
+ * (scratch sizes, the instanced / template classification). Every rank calls vgx_tessellate_count on its own range afterwards. */
 int vgx_partition(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, uint32_t nparts, uint64_t* out_bounds, uint64_t* out_weights, void* stream);
 
 /* ---- multi-GPU: gather of the per-rank streams to one root over RCCL / xGMI ---------------------------------
@@ -513,7 +542,10 @@ int vgx_partition(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, ui
  *                     kernel). `global` is only read on the root (capacities checked against the totals: VGX_E_NOSPACE).
  *                     To overlap the gather of frame i with the tessellation of frame i + 1, call it on a second stream
  *                     with double-buffered outputs: nothing in it touches context scratch that vgx_tessellate uses.
- *                     Transfers go out in pieces of at most VGX_GATHER_CHUNK_MB (default 256 MiB), one group per piece.
+ *                     Transfers go out in pieces of at most VGX_GATHER_CHUNK_MB (default 256 MiB), one group per piece. The
+ *                     piece size is part of the wire protocol (sender and root cut a stream the same way) and is read once
+ *                     per process from the environment: it must be the same on every rank; vgx_gather_sizes compares the
+ *                     ranks' values and returns VGX_E_INVALID_ARG when they differ.
  * Errors: VGX_E_NO_DEVICE when no RCCL library can be bound, VGX_E_HIP when an RCCL call fails (vgx_last_hip_error() then
  * holds 10000 + the ncclResult_t). */
 typedef struct vgx_rank_sizes { uint64_t num_vertices, num_indices, num_meshes, num_draws; } vgx_rank_sizes;

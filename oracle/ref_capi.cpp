@@ -60,6 +60,11 @@ int vgo_tess_run(void* t, int evenOdd, int boundary)
 	const float normal[3] = { 0.0f, 0.0f, 1.0f };
 	return tessTesselate((TESStesselator*)t, evenOdd ? TESS_WINDING_ODD : TESS_WINDING_NONZERO, boundary ? TESS_BOUNDARY_CONTOURS : TESS_POLYGONS, boundary ? 1 : 3, 2, normal);
 }
+// strokerConcaveFillEnd's call (stroker.cpp:852): triangles, NO normal given (libtess2 derives the projection itself)
+int vgo_tess_run_plain(void* t, int evenOdd)
+{
+	return tessTesselate((TESStesselator*)t, evenOdd ? TESS_WINDING_ODD : TESS_WINDING_NONZERO, TESS_POLYGONS, 3, 2, nullptr);
+}
 int vgo_tess_vertex_count(void* t) { return tessGetVertexCount((TESStesselator*)t); }
 const float* vgo_tess_vertices(void* t) { return tessGetVertices((TESStesselator*)t); }
 int vgo_tess_element_count(void* t) { return tessGetElementCount((TESStesselator*)t); }

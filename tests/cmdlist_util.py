@@ -86,7 +86,8 @@ def decode(rt, data, mtx=(1, 0, 0, 1, 0, 0), global_alpha=1.0, tess_tol=0.25, fr
     st.canvas_width, st.canvas_height = canvas
     st.flags = flags
     st.first_gradient = first_gradient; st.first_image_pattern = first_image_pattern
-    if scissor is not None:            # State::m_ScissorRect at submission (all zero = the whole canvas)
+    if scissor is not None:            # State::m_ScissorRect at submission: an explicit rectangle, possibly empty (VGX_CL_SCISSOR_SET)
+        st.flags = flags | 0x100
         for i in range(4):
             st.scissor[i] = float(scissor[i])
     if prev_cmd_scissor is not None:   # scissor of the frame's last draw command so far (PopState rule, vg.cpp:3950-3965)

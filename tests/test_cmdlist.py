@@ -256,3 +256,28 @@ def test_capacity_and_depth_limits(rt):
         o3 = capi.CmdListOut()
         assert rt.lib().vgx_cmdlist_decode(cb, len(selfb), C.byref(st2), C.byref(o3)) == 0
         assert o3.num_draws == depth and o3.num_skipped == 0, (depth, o3.num_draws, o3.num_skipped)  # the cut-off submit returns silently, like the reference's
+
+
+def test_a_zero_area_scissor_survives_the_chaining_of_two_decodes(rt):
+    """ADVICE r3: list A leaves the empty scissor {0, 0, 0, 0} behind (state changes of a list leak into its caller, vg.cpp:4323-4325);
+    list B decoded with A's end_scissor must draw under that empty scissor -- as the same commands in ONE list do -- not under the
+    full canvas the all-zero sentinel used to mean."""
+    a = cu.Recorder()
+    a.set_scissor(0, 0, 0, 0)
+    b = cu.Recorder()
+    b.begin_path(); b.rect(10, 10, 50, 50); b.fill_path(0xFF0000FF, cu.fill_flags())
+    ex_a, ex_b, ex_one = {}, {}, {}
+    cu.decode(rt, a.bytes(), extra=ex_a)
+    end = [float(x) for x in ex_a["out"].end_scissor]
+    assert end == [0.0, 0.0, 0.0, 0.0]
+    cu.decode(rt, b.bytes(), scissor=end, extra=ex_b)
+    assert ex_b["draw_state"]["scissor"][0].tolist() == [0, 0, 0, 0]
+    one = cu.Recorder()
+    one.set_scissor(0, 0, 0, 0)
+    one.begin_path(); one.rect(10, 10, 50, 50); one.fill_path(0xFF0000FF, cu.fill_flags())
+    cu.decode(rt, one.bytes(), extra=ex_one)
+    assert ex_one["draw_state"]["scissor"][0].tolist() == [0, 0, 0, 0]
+    # without a scissor handed over: never set = the whole canvas
+    ex_c = {}
+    cu.decode(rt, b.bytes(), extra=ex_c)
+    assert ex_c["draw_state"]["scissor"][0].tolist() == [0, 0, 1280, 720]

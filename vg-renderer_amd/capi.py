@@ -18,6 +18,7 @@ VGX_E_NO_DEVICE = 7
 VGX_E_RANGE = 8
 VGX_E_INTERNAL = 9
 VGX_E_STALE = 10
+FILL_CONCAVE, FILL_EVEN_ODD = 0x10, 0x20  # vgx_draw.fill_flags: a concave fill (no GPU mesh: libtess2 + vgx_concave_* + vgx_merge)
 
 CMD_MOVE_TO, CMD_LINE_TO, CMD_CUBIC_TO, CMD_QUAD_TO, CMD_CLOSE = 0, 1, 2, 3, 4
 CMD_ARC_TO, CMD_ARC, CMD_RECT, CMD_ROUNDED_RECT, CMD_ROUNDED_RECT_VARYING = 5, 6, 7, 8, 9
@@ -175,6 +176,7 @@ VGX_SYMBOLS = {
     "vgx_destroy": (C.c_int, [C.c_void_p]),
     "vgx_set_assembly": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vgx_cache_localize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "vgx_merge": (C.c_int, [C.c_void_p, C.POINTER(CacheDesc), C.POINTER(CacheDesc), C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(MeshOut), C.c_void_p, C.c_void_p, C.c_void_p]),
     "vgx_cache_submit": (C.c_int, [C.c_void_p, C.POINTER(CacheDesc), C.c_void_p, C.c_uint64, C.POINTER(MeshOut), C.c_void_p, C.c_void_p, C.c_void_p]),
     "vgx_last_hip_error": (C.c_int, [C.c_void_p]),
     "vgx_status_string": (C.c_char_p, [C.c_int]),

@@ -1497,6 +1497,50 @@ int vgx_cache_submit(vgx_ctx* ctx, const vgx_cache_desc* cache, const vgx_cache_
 	return launchStatus(ctx);
 }
 
+int vgx_merge(vgx_ctx* ctx, const vgx_cache_desc* a, const vgx_cache_desc* b, const uint32_t* b_draw, const vgx_draw* draws, uint64_t ndraws,
+              const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream)
+{
+	DeviceGuard guard(ctx);
+	(void)ndraws;
+	if (!ctx || !a || !b || !out || !out->pos || !out->color || !out->idx
+		|| (a->num_meshes && (!a->pos || !a->color || !a->idx || !a->meshes)) || (b->num_meshes && (!b->pos || !b->color || !b->idx || !b->meshes))) {
+		return VGX_E_INVALID_ARG;
+	}
+	const uint64_t n = a->num_meshes + b->num_meshes;
+	if (n >= 0x7FFFFFFFull) { return VGX_E_RANGE; }
+	hipStream_t s = (hipStream_t)stream;
+	markBegin(ctx, s);
+	ctx->lastStage = 0;
+	ctx->tmplOn = false; // the mesh-table scratch is re-sized below
+	int st;
+	if ((st = ensure(ctx, ctx->totals, sizeof(VgxTotals))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->partial, VGX_SCAN_BLOCKS * sizeof(Sum3))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->mtab, (n + 1) * sizeof(vgx_mesh))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->mdesc, (n + 1) * sizeof(VgxMeshDesc))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->cmdPrefix, (n + 1) * sizeof(uint64_t))) != VGX_OK) { return st; } // the merged order lives in the command-prefix scratch
+	noteHip(ctx, hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s));
+	VgxMergeArgs m;
+	memset(&m, 0, sizeof(m));
+	m.a = *a; m.b = *b; m.b_draw = b_draw;
+	m.order = (uint32_t*)ctx->cmdPrefix.p; m.mtab = (vgx_mesh*)ctx->mtab.p; m.mdesc = (VgxMeshDesc*)ctx->mdesc.p;
+	m.meshes_out = out->meshes; m.pos = out->pos; m.color = out->color; m.idx = out->idx; m.mesh_base = nullptr;
+	m.totals = (VgxTotals*)ctx->totals.p;
+	m.caps = ctx->caps; m.caps.vertices = out->cap_vertices; m.caps.indices = out->cap_indices; m.caps.meshes = out->cap_meshes;
+	vgx_launch_merge_rank(m, s);
+	vgx_launch_merge_scan(m, ctx->partial.p, s);
+	mark(ctx, s, "merge_scan");
+	if (ctx->asmArmed) {
+		if ((st = runAssemble(ctx, out, s, draws)) != VGX_OK) { return st; }
+		m.mesh_base = (const uint32_t*)ctx->meshBase.p;
+	}
+	vgx_launch_merge_copy(m, s);
+	mark(ctx, s, "merge_copy");
+	if (dev_sizes || dev_status) {
+		hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, s, (const VgxTotals*)ctx->totals.p, dev_sizes, dev_status);
+	}
+	return launchStatus(ctx);
+}
+
 int vgx_set_assembly(vgx_ctx* ctx, const vgx_assembly* asm_)
 {
 	if (!ctx) {
@@ -1712,6 +1756,19 @@ __global__ __launch_bounds__(256) void k_gather_rebase(GatherRebaseArgs A)
 
 } // namespace
 
+// Transfers larger than this leave in several pieces: piece c of every (rank, stream) pair goes out in group c, so that no
+// single RCCL operation is gigabytes long and the proxy threads can pipeline (VGX_GATHER_CHUNK_MB, default 256 MiB).
+static size_t gatherChunkBytes()
+{
+	static size_t v = 0;
+	if (!v) {
+		const char* e = getenv("VGX_GATHER_CHUNK_MB");
+		const long mb = e ? atol(e) : 256;
+		v = (size_t)(mb >= 1 ? mb : 256) << 20;
+	}
+	return v;
+}
+
 extern "C" int vgx_gather_sizes(vgx_ctx* ctx, void* rccl_comm, const vgx_rank_sizes* mine, vgx_rank_sizes* all, void* stream)
 {
 	DeviceGuard guard(ctx);
@@ -1724,27 +1781,24 @@ extern "C" int vgx_gather_sizes(vgx_ctx* ctx, void* rccl_comm, const vgx_rank_si
 	RCCLCHK(ctx, ctx->rccl->CommCount(rccl_comm, &nranks));
 	RCCLCHK(ctx, ctx->rccl->CommUserRank(rccl_comm, &rank));
 	if (nranks < 1 || rank < 0 || rank >= nranks) { return VGX_E_INVALID_ARG; }
-	if ((st = ensure(ctx, ctx->gatherSizes, (size_t)nranks * sizeof(vgx_rank_sizes))) != VGX_OK) { return st; }
+	// five words per rank: the four totals + the rank's transfer piece size. The piece size is part of the wire protocol of
+	// vgx_gather_at (sender and root must cut a stream into the same pieces) but comes from each process's own environment
+	// (VGX_GATHER_CHUNK_MB): ranks that disagree are told here, before a gather could hang on mismatched Send / Recv sizes.
+	struct Wire { vgx_rank_sizes z; uint64_t chunk; };
+	if ((st = ensure(ctx, ctx->gatherSizes, (size_t)nranks * sizeof(Wire))) != VGX_OK) { return st; }
 	hipStream_t s = (hipStream_t)stream;
-	vgx_rank_sizes* dev = (vgx_rank_sizes*)ctx->gatherSizes.p;
-	HIPCHK(ctx, hipMemcpyAsync(dev + rank, mine, sizeof(vgx_rank_sizes), hipMemcpyHostToDevice, s));
-	RCCLCHK(ctx, ctx->rccl->AllGather(dev + rank, dev, 4, kNcclUint64, rccl_comm, s)); // in place: my slot is my send buffer
-	HIPCHK(ctx, hipMemcpyAsync(all, dev, (size_t)nranks * sizeof(vgx_rank_sizes), hipMemcpyDeviceToHost, s));
+	Wire* dev = (Wire*)ctx->gatherSizes.p;
+	std::vector<Wire> host((size_t)nranks);
+	host[(size_t)rank].z = *mine; host[(size_t)rank].chunk = gatherChunkBytes();
+	HIPCHK(ctx, hipMemcpyAsync(dev + rank, &host[(size_t)rank], sizeof(Wire), hipMemcpyHostToDevice, s));
+	RCCLCHK(ctx, ctx->rccl->AllGather(dev + rank, dev, 5, kNcclUint64, rccl_comm, s)); // in place: my slot is my send buffer
+	HIPCHK(ctx, hipMemcpyAsync(host.data(), dev, (size_t)nranks * sizeof(Wire), hipMemcpyDeviceToHost, s));
 	HIPCHK(ctx, hipStreamSynchronize(s));
-	return VGX_OK;
-}
-
-// Transfers larger than this leave in several pieces: piece c of every (rank, stream) pair goes out in group c, so that no
-// single RCCL operation is gigabytes long and the proxy threads can pipeline (VGX_GATHER_CHUNK_MB, default 256 MiB).
-static size_t gatherChunkBytes()
-{
-	static size_t v = 0;
-	if (!v) {
-		const char* e = getenv("VGX_GATHER_CHUNK_MB");
-		const long mb = e ? atol(e) : 256;
-		v = (size_t)(mb >= 1 ? mb : 256) << 20;
+	for (int r = 0; r < nranks; ++r) {
+		all[r] = host[(size_t)r].z;
+		if (host[(size_t)r].chunk != gatherChunkBytes()) { return VGX_E_INVALID_ARG; }
 	}
-	return v;
+	return VGX_OK;
 }
 
 extern "C" int vgx_gather_at(vgx_ctx* ctx, void* rccl_comm, int root, const vgx_mesh_out* local, const vgx_rank_sizes* all, const vgx_rank_sizes* place,

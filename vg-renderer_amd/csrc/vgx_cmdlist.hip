@@ -99,6 +99,7 @@ struct Decoder
 	uint32_t generation;
 	bool haveLastScissor;
 	uint16_t lastScissor[4]; // scissor of the last draw COMMAND (= of the last non-clip draw emitted)
+	vgx_paint dummyPaint;    // where newPaint() writes when nothing is stored
 	// clip state (ClipState, vg.cpp:71-76) in units of draws
 	bool recordClip;
 	uint32_t clipRule, clipFirst, clipNum;
@@ -184,7 +185,7 @@ struct Decoder
 	vgx_paint* newPaint(uint32_t type, uint32_t handle, const float* inv)
 	{
 		vgx_paint* p = nullptr;
-		static vgx_paint dummy;
+		vgx_paint& dummy = dummyPaint; // count pass / overflow: a member, not a function-local static (two threads may decode at once)
 		if (store && out->paints) {
 			if (npaints >= out->cap_paints) { overflow = true; p = &dummy; } else { p = &out->paints[npaints]; }
 		} else { p = &dummy; }
@@ -302,11 +303,12 @@ int Decoder::run(const uint8_t* p, uint32_t size, uint32_t listFlags)
 			if (!clip && !hasCache && (col >> 24) == 0) { break; } // transparent: the reference returns before transformPath
 			if (!havePath) { ++nskipped; break; }
 			latch();
-			if (flags & 0x01u) { ++nskipped; break; } // PathType::Concave: libtess2 (vgx_concave_*)
 			const bool aa = clip ? false : (flags & 0x04u) != 0;
 			const uint32_t dt = clip ? (uint32_t)DT_Clip : (img ? (uint32_t)DT_ImagePattern : (uint32_t)DT_Textured);
 			const uint32_t handle = clip ? 0xFFFFu : (img ? localHandle(u16at(8), u16at(10), firstImagePatternID) : 0u);
-			emit(dt, handle, VGX_FILL_ENABLE | (aa ? VGX_FILL_AA : 0u), col, 0, 0, 0.0f);
+			// PathType::Concave (:3133-3178): libtess2 stays with the caller -- a draw without a GPU mesh, see VGX_FILL_CONCAVE
+			const uint32_t how = (flags & 0x01u) ? (VGX_FILL_CONCAVE | ((flags & 0x10u) ? VGX_FILL_EVEN_ODD : 0u)) : (uint32_t)VGX_FILL_ENABLE;
+			emit(dt, handle, how | (aa ? VGX_FILL_AA : 0u), col, 0, 0, 0.0f);
 		} break;
 		case CT_FillPathGradient: { // uint32 flags, uint16 handle, uint16 handle flags (:2629-2638); ctxFillPathGradient :3181-3284
 			if (!need(8)) { return VGX_E_INVALID_ARG; }
@@ -314,11 +316,11 @@ int Decoder::run(const uint8_t* p, uint32_t size, uint32_t listFlags)
 			rawColor = 0;
 			if (!havePath) { ++nskipped; break; }
 			latch();
-			if (flags & 0x01u) { ++nskipped; break; }
 			const bool aa = (flags & 0x04u) != 0;
 			// AA: strokerConvexFillAA(Colors::Black); else one colour = black with alpha 0xff * globalAlpha (:3212, 3228)
 			const uint32_t col = aa ? kBlack : setAlpha(kBlack, (uint8_t)(0xff * S().alpha));
-			emit(DT_ColorGradient, localHandle(u16at(4), u16at(6), firstGradientID), VGX_FILL_ENABLE | (aa ? VGX_FILL_AA : 0u), col, 0, 0, 0.0f);
+			const uint32_t how = (flags & 0x01u) ? (VGX_FILL_CONCAVE | ((flags & 0x10u) ? VGX_FILL_EVEN_ODD : 0u)) : (uint32_t)VGX_FILL_ENABLE; // :3245-3277
+			emit(DT_ColorGradient, localHandle(u16at(4), u16at(6), firstGradientID), how | (aa ? VGX_FILL_AA : 0u), col, 0, 0, 0.0f);
 		} break;
 
 		case CT_StrokePathColor: { // float width, uint32 flags, Color (vg.cpp:2660-2669); ctxStrokePathColor :3401-3492
@@ -516,7 +518,7 @@ int Decoder::run(const uint8_t* p, uint32_t size, uint32_t listFlags)
 
 extern "C" int vgx_cmdlist_decode(const void* bytes, uint32_t size, const vgx_cmdlist_state* st0, vgx_cmdlist_out* out)
 {
-	if ((!bytes && size) || !st0 || !out || (size % kAlign) != 0) {
+	if ((!bytes && size) || !st0 || !out || (size % kAlign) != 0 || ((uintptr_t)bytes & 3u) != 0) { // float operands are read in place: 4-byte aligned buffer
 		return VGX_E_INVALID_ARG;
 	}
 	Decoder D;
@@ -531,7 +533,9 @@ extern "C" int vgx_cmdlist_decode(const void* bytes, uint32_t size, const vgx_cm
 	St& s0 = D.stack[0];
 	memcpy(s0.m, st0->mtx, sizeof(float) * 6);
 	memcpy(s0.scissor, st0->scissor, sizeof(float) * 4);
-	if (s0.scissor[0] == 0.0f && s0.scissor[1] == 0.0f && s0.scissor[2] == 0.0f && s0.scissor[3] == 0.0f) {
+	// all zero = "never set" (resetScissor) ONLY without VGX_CL_SCISSOR_SET: a decode chained from an earlier one of the frame
+	// carries that decode's end_scissor, which may be a real empty rectangle (SetScissor(0,0,0,0), an intersection that came out empty)
+	if (!(st0->flags & VGX_CL_SCISSOR_SET) && s0.scissor[0] == 0.0f && s0.scissor[1] == 0.0f && s0.scissor[2] == 0.0f && s0.scissor[3] == 0.0f) {
 		s0.scissor[2] = st0->canvas_width; s0.scissor[3] = st0->canvas_height;
 	}
 	s0.alpha = st0->global_alpha;

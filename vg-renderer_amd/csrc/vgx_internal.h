@@ -115,6 +115,26 @@ void vgx_launch_tmpl_check(const vgx_draw* draws, uint64_t ndraws, uint32_t npat
 void vgx_launch_tmpl_build(const VgxTmplBuild& b, hipStream_t s);
 void vgx_launch_tmpl_emit(const VgxTmplArgs& a, hipStream_t s);
 
+// merging two mesh sequences of a frame (vgx_merge.hip)
+struct VgxMergeArgs
+{
+	vgx_cache_desc a, b;       // sequence A (vgx_tessellate's meshes) and B (external meshes); both sorted by draw
+	const uint32_t* b_draw;    // frame draw of every B mesh (null: the records' own draw fields)
+	uint32_t* order;           // [na + nb] merged position -> source mesh (bit 31: from B)
+	vgx_mesh* mtab;            // [na + nb] merged mesh table (context scratch; assembly reads it)
+	VgxMeshDesc* mdesc;        // [na + nb] only .draw is written (assembly's mesh -> draw)
+	vgx_mesh* meshes_out;      // caller's table (may be null)
+	float* pos;
+	uint32_t* color;
+	uint16_t* idx;
+	const uint32_t* mesh_base; // assembly armed: index base per merged mesh; else null
+	VgxTotals* totals;
+	VgxCaps caps;
+};
+void vgx_launch_merge_rank(const VgxMergeArgs& a, hipStream_t s);
+void vgx_launch_merge_scan(const VgxMergeArgs& a, void* partial, hipStream_t s);
+void vgx_launch_merge_copy(const VgxMergeArgs& a, hipStream_t s);
+
 // concave-fill fringes (vgx_concave.hip)
 struct VgxConcaveArgs
 {

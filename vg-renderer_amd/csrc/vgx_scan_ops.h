@@ -4,6 +4,7 @@
 #ifndef VGX_SCAN_OPS_H
 #define VGX_SCAN_OPS_H
 
+#include <stddef.h>
 #include "vgx_internal.h"
 #include "vgx_scan.h"
 
@@ -34,7 +35,10 @@ struct OpCmdPrefix // command instances per draw -> cmd_prefix
 		// The whole 64-byte record in 16-byte loads issued together, and the checks below as ONE expression without
 		// short-circuit evaluation: written field by field with `&&`, every field became its own load -> s_waitcnt vmcnt(0) ->
 		// branch, a chain of twelve dependent memory round trips per draw (the scan over 2.2 M draws: 0.165 -> 0.12 ms).
-		const uint4* q = (const uint4*)(draws + i);
+		static_assert(sizeof(vgx_draw) == 64 && offsetof(vgx_draw, path) == 0 && offsetof(vgx_draw, stroke_flags) == 12 && offsetof(vgx_draw, stroke_width) == 20
+			&& offsetof(vgx_draw, scale) == 24 && offsetof(vgx_draw, tess_tol) == 28 && offsetof(vgx_draw, fringe) == 32 && offsetof(vgx_draw, mtx) == 36,
+			"the 16-byte loads below pick vgx_draw's fields by position");
+		const uint4* q = (const uint4*)(draws + i); // `draws` is 16-byte aligned (include/vgx.h)
 		const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
 		const uint32_t pimg = period ? draws[i % period].path : 0u;
 		const uint32_t p = q0.x;          // path

@@ -27,6 +27,7 @@
 //                   milliseconds apart).
 // Results are identical to the ordinary path's by construction and by test (tests/test_gpu_tmpl.py: VGX_TMPL=0 vs 1
 // byte for byte, both against the reference).
+#include <stddef.h>
 #include "vgx_internal.h"
 #include "vgx_wave.h"
 #include "vgx_elem.h"
@@ -36,6 +37,9 @@ namespace {
 
 // ---- count pass: is the batch a template batch? ---------------------------------------------------------------------
 // Bit patterns of the fields the flattener and the mesh sizes depend on; colours, transform and state_key may differ.
+static_assert(sizeof(vgx_draw) == 64 && offsetof(vgx_draw, path) == 0 && offsetof(vgx_draw, fill_flags) == 4 && offsetof(vgx_draw, fill_color) == 8
+	&& offsetof(vgx_draw, stroke_flags) == 12 && offsetof(vgx_draw, stroke_color) == 16 && offsetof(vgx_draw, stroke_width) == 20 && offsetof(vgx_draw, scale) == 24
+	&& offsetof(vgx_draw, tess_tol) == 28 && offsetof(vgx_draw, fringe) == 32 && offsetof(vgx_draw, mtx) == 36, "draw records are read as four 16-byte words");
 __device__ __forceinline__ bool tmpl_same(const uint4 a0, const uint4 a1, const uint4 a2, const uint4 b0, const uint4 b1, const uint4 b2)
 {
 	return ((a0.x == b0.x) & (a0.y == b0.y) & (a0.w == b0.w) & (a1.y == b1.y) & (a1.z == b1.z) & (a1.w == b1.w) & (a2.x == b2.x)) != 0;

@@ -329,3 +329,18 @@ def concave_emit(ctx, contour_verts_dev, contours_dev, ncontours, fills_dev, nfi
     _check(lib().vgx_concave_emit(ctx.handle, contour_verts_dev.data_ptr(), n, contours_dev.data_ptr(), ncontours,
                                   fills_dev.data_ptr(), nfills, tess_pos_dev.data_ptr(), tess_idx_dev.data_ptr(), C.byref(out),
                                   bufs.dev_sizes.data_ptr(), bufs.dev_status.data_ptr(), _stream_ptr()), "vgx_concave_emit")
+
+
+# ---- merging external meshes into a frame (vgx_merge) ---------------------------------------------------------------
+def mesh_seq(bufs, nv, ni, nm):
+    """A finished mesh sequence (what vgx_tessellate / vgx_concave_emit wrote into `bufs`) as a vgx_cache_desc."""
+    return capi.CacheDesc(bufs.pos.data_ptr(), bufs.color.data_ptr(), bufs.idx.data_ptr(), bufs.meshes.data_ptr(), int(nm), int(nv), int(ni))
+
+
+def merge(ctx, seq_a, seq_b, b_draw_dev, draws_dev, ndraws, bufs):
+    """Both sequences interleaved by draw index into `bufs` (honours an armed assembly). b_draw_dev: int32 device tensor, the
+    frame draw of every mesh of seq_b (or None). Asynchronous; totals / status land in bufs.dev_*."""
+    out = bufs.out_struct()
+    _check(lib().vgx_merge(ctx.handle, C.byref(seq_a), C.byref(seq_b), b_draw_dev.data_ptr() if b_draw_dev is not None else None,
+                           draws_dev.data_ptr() if draws_dev is not None else None, ndraws, C.byref(out),
+                           bufs.dev_sizes.data_ptr(), bufs.dev_status.data_ptr(), _stream_ptr()), "vgx_merge")

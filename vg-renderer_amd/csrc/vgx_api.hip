@@ -704,9 +704,9 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	if (const char* e = getenv("VGX_INST_CLASSES")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { uint32_t p2 = 1; while (p2 * 2 <= (uint32_t)v) { p2 *= 2; } ctx->optInstClasses = p2; } }
 	if (const char* e = getenv("VGX_INST_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { ctx->optInstWaves = v; } }
 	if (const char* e = getenv("VGX_INST_BLOCK")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { ctx->optInstBlock = (uint32_t)v; } }
-	ctx->optTmpl = 1; ctx->optTmplTile = 1024; // VGX_TMPL=0: no template mode (instanced batches through k_flatten_inst + k_fill + k_stroke)
+	ctx->optTmpl = 1; ctx->optTmplTile = VGX_TMPL_MAX_TILE; // VGX_TMPL=0: no template mode (instanced batches through k_flatten_inst + k_fill + k_stroke)
 	if (const char* e = getenv("VGX_TMPL")) { ctx->optTmpl = atoi(e) != 0; }
-	if (const char* e = getenv("VGX_TMPL_TILE")) { const int v = atoi(e); if (v >= 64 && v <= 1024) { ctx->optTmplTile = (uint32_t)v / 64u * 64u; } } // testing: elements per tile (<= the LDS stage of k_tmpl_emit)
+	if (const char* e = getenv("VGX_TMPL_TILE")) { const int v = atoi(e); if (v >= 64 && v <= VGX_TMPL_MAX_TILE) { ctx->optTmplTile = (uint32_t)v / 64u * 64u; } } // testing: elements per tile (<= the LDS stage of k_tmpl_emit)
 	ctx->optPoolWalk = 0; // VGX_WALK=pool: the wave-cooperative walk of vgx_walk.h (same output, same speed: DESIGN.md section 4)
 	if (const char* e = getenv("VGX_WALK")) { ctx->optPoolWalk = strcmp(e, "pool") == 0; }
 	if (const char* e = getenv("VGX_BUILD_WAVES")) { const int v = atoi(e); if (v >= 1 && v < VGX_BUILD_WAVES) { ctx->optBuildWaves = v; } }

@@ -72,6 +72,13 @@ struct VgxStrokeArgs
 
 
 // template mode (vgx_tmpl.hip)
+#ifndef VGX_TMPL_THREADS
+#define VGX_TMPL_THREADS 512   /* threads per workgroup of k_tmpl_emit */
+#endif
+#ifndef VGX_TMPL_MAX_TILE
+#define VGX_TMPL_MAX_TILE 2048 /* elements per tile = per workgroup (what its LDS stages hold); a multiple of VGX_TMPL_THREADS. Tiger x10k, same
+                                * box: 256 threads x 1024 elements 2.18 ms, 512 x 2048 2.06, 512 x 3072 2.15, 1024 x 4096 2.15, 128 x 1024 2.26 */
+#endif
 struct VgxTmplBuild // count pass: the first period's ordinary count + emit results -> template tables
 {
 	const vgx_draw* draws;       // the batch's first period

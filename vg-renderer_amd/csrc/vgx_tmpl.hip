@@ -397,14 +397,19 @@ __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uin
 	}
 }
 
-#define VGX_TMPL_THREADS 256
-#define VGX_TMPL_MAX_TILE 1024 /* elements per tile the LDS stages hold */
-#define VGX_TMPL_MAXM 96       /* meshes / draws per tile the LDS tables hold; a tile that needs more takes the per-lane fallback */
+// VGX_TMPL_THREADS / VGX_TMPL_MAX_TILE (vgx_internal.h): threads per workgroup, elements per tile the LDS stages hold
+#ifndef VGX_TMPL_MAXM
+#define VGX_TMPL_MAXM 160      /* meshes / draws per tile the LDS tables hold; a tile that needs more takes the per-lane fallback */
+#endif
 #define VGX_TMPL_CH (VGX_TMPL_MAX_TILE / VGX_TMPL_THREADS)
 #ifndef VGX_TMPL_OCC
 #define VGX_TMPL_OCC
 #endif
+#ifdef VGX_TMPL_MINWAVES
+__global__ __launch_bounds__(VGX_TMPL_THREADS, VGX_TMPL_MINWAVES) void k_tmpl_emit(VgxTmplArgs A)
+#else
 __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(VgxTmplArgs A)
+#endif
 {
 	__shared__ TmplDraw s_draw[VGX_TMPL_MAXM];
 	__shared__ TmplRec s_rec[VGX_TMPL_MAXM];
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 	float2 lp[VGX_TMPL_CH];
 #pragma unroll
 	for (int c = 0; c < VGX_TMPL_CH; ++c) {
-		const uint32_t s = (uint32_t)c * VGX_TMPL_THREADS + tid; // chunk c * 4 + wave of the tile: the tile's stroke chunks (the heavier ones) spread over the waves
+		const uint32_t s = (uint32_t)c * VGX_TMPL_THREADS + tid; // interleaved: the tile's stroke chunks (the heavier ones, at the tile's end) spread over the waves
 		er[c].mesh = mA; er[c].jq = 0; er[c].vtx = 0; er[c].pad = 0;
 		if (s < nel) { er[c] = telem[s]; }
 	}

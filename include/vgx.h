@@ -571,6 +571,11 @@ typedef struct vgx_stage_times {
 } vgx_stage_times;
 int vgx_set_profiling(vgx_ctx* ctx, int enable);
 int vgx_get_stage_times(vgx_ctx* ctx, vgx_stage_times* out);
+/* The same, averaged over the last `ncalls` profiled calls of this context (at most VGX_PROF_RING, and only calls with the
+ * same stage sequence as the last one): a caller that times K back-to-back calls reads the per-kernel durations of those
+ * very calls afterwards, without having synchronised between them. Read after synchronising. */
+#define VGX_PROF_RING 32
+int vgx_get_stage_times_avg(vgx_ctx* ctx, vgx_stage_times* out, uint32_t ncalls);
 
 #ifdef __cplusplus
 }

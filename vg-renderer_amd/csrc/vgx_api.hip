@@ -104,9 +104,13 @@ struct vgx_ctx
 	int lastStage; // 0 none, 1 flatten counted, 2 tessellate counted
 	// profiling
 	int profiling;
-	hipEvent_t ev[VGX_MAX_STAGES + 1];
-	const char* evName[VGX_MAX_STAGES];
-	uint32_t numEv;
+	// a ring of event sets, one per profiled call: vgx_get_stage_times reads the last call's, vgx_get_stage_times_avg the average over
+	// the last calls (a caller that times K back-to-back calls gets per-kernel durations of THOSE calls, without a sync in between)
+	hipEvent_t ev[VGX_PROF_RING][VGX_MAX_STAGES + 1];
+	const char* evName[VGX_PROF_RING][VGX_MAX_STAGES];
+	uint32_t numEv[VGX_PROF_RING];
+	uint64_t profCalls; // profiled calls since profiling was switched on
+	uint32_t evSet;     // set of the current call
 	bool evCreated;
 };
 
@@ -187,12 +191,13 @@ void noteHip(vgx_ctx* ctx, hipError_t e)
 
 void mark(vgx_ctx* ctx, hipStream_t s, const char* name)
 {
-	if (!ctx->profiling || ctx->numEv >= VGX_MAX_STAGES) {
+	const uint32_t k = ctx->evSet;
+	if (!ctx->profiling || ctx->numEv[k] >= VGX_MAX_STAGES) {
 		return;
 	}
-	ctx->evName[ctx->numEv] = name;
-	++ctx->numEv;
-	(void)hipEventRecord(ctx->ev[ctx->numEv], s);
+	ctx->evName[k][ctx->numEv[k]] = name;
+	++ctx->numEv[k];
+	(void)hipEventRecord(ctx->ev[k][ctx->numEv[k]], s);
 }
 
 void markBegin(vgx_ctx* ctx, hipStream_t s)
@@ -201,11 +206,13 @@ void markBegin(vgx_ctx* ctx, hipStream_t s)
 		return;
 	}
 	if (!ctx->evCreated) {
-		for (int i = 0; i <= VGX_MAX_STAGES; ++i) { (void)hipEventCreate(&ctx->ev[i]); }
+		for (int r = 0; r < VGX_PROF_RING; ++r) { for (int i = 0; i <= VGX_MAX_STAGES; ++i) { (void)hipEventCreate(&ctx->ev[r][i]); } }
 		ctx->evCreated = true;
 	}
-	ctx->numEv = 0;
-	(void)hipEventRecord(ctx->ev[0], s);
+	ctx->evSet = (uint32_t)(ctx->profCalls % VGX_PROF_RING);
+	++ctx->profCalls;
+	ctx->numEv[ctx->evSet] = 0;
+	(void)hipEventRecord(ctx->ev[ctx->evSet][0], s);
 }
 
 struct OpCacheInst // shape cache: vertices / indices / meshes of every instance's mesh range -> output offsets
@@ -728,7 +735,7 @@ int vgx_destroy(vgx_ctx* ctx)
 	vgx_rccl_release(ctx);
 	if (ctx->sideStream) { (void)hipStreamDestroy(ctx->sideStream); (void)hipEventDestroy(ctx->forkEv); (void)hipEventDestroy(ctx->joinEv); }
 	if (ctx->evCreated) {
-		for (int i = 0; i <= VGX_MAX_STAGES; ++i) { (void)hipEventDestroy(ctx->ev[i]); }
+		for (int r = 0; r < VGX_PROF_RING; ++r) { for (int i = 0; i <= VGX_MAX_STAGES; ++i) { (void)hipEventDestroy(ctx->ev[r][i]); } }
 	}
 	delete ctx;
 	return VGX_OK;
@@ -1642,25 +1649,47 @@ int vgx_set_profiling(vgx_ctx* ctx, int enable)
 		return VGX_E_INVALID_ARG;
 	}
 	ctx->profiling = enable ? 1 : 0;
+	ctx->profCalls = 0;
 	return VGX_OK;
 }
 
 int vgx_get_stage_times(vgx_ctx* ctx, vgx_stage_times* out)
+{
+	return vgx_get_stage_times_avg(ctx, out, 1);
+}
+
+int vgx_get_stage_times_avg(vgx_ctx* ctx, vgx_stage_times* out, uint32_t ncalls)
 {
 	DeviceGuard guard(ctx);
 	if (!ctx || !out) {
 		return VGX_E_INVALID_ARG;
 	}
 	memset(out, 0, sizeof(*out));
-	if (!ctx->profiling || !ctx->evCreated) {
+	if (!ctx->profiling || !ctx->evCreated || ctx->profCalls == 0) {
 		return VGX_OK;
 	}
-	out->num_stages = ctx->numEv;
-	for (uint32_t i = 0; i < ctx->numEv; ++i) {
-		float ms = 0.0f;
-		if (hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]) != hipSuccess) { ms = -1.0f; }
-		out->ms[i] = ms;
-		out->name[i] = ctx->evName[i];
+	uint64_t n = ncalls < 1 ? 1 : ncalls;
+	if (n > VGX_PROF_RING) { n = VGX_PROF_RING; }
+	if (n > ctx->profCalls) { n = ctx->profCalls; }
+	const uint32_t last = (uint32_t)((ctx->profCalls - 1) % VGX_PROF_RING);
+	out->num_stages = ctx->numEv[last];
+	uint32_t used = 0;
+	for (uint64_t c = 0; c < n; ++c) {
+		const uint32_t k = (uint32_t)((ctx->profCalls - 1 - c) % VGX_PROF_RING);
+		if (ctx->numEv[k] != ctx->numEv[last]) { continue; } // a call of another kind in between: not averaged in
+		bool same = true;
+		for (uint32_t i = 0; i < ctx->numEv[k]; ++i) { same = same && ctx->evName[k][i] == ctx->evName[last][i]; }
+		if (!same) { continue; }
+		for (uint32_t i = 0; i < ctx->numEv[k]; ++i) {
+			float ms = 0.0f;
+			if (hipEventElapsedTime(&ms, ctx->ev[k][i], ctx->ev[k][i + 1]) != hipSuccess) { ms = -1.0f; }
+			out->ms[i] += ms;
+		}
+		++used;
+	}
+	for (uint32_t i = 0; i < out->num_stages; ++i) {
+		out->ms[i] = used ? out->ms[i] / (float)used : -1.0f;
+		out->name[i] = ctx->evName[last][i];
 	}
 	return VGX_OK;
 }

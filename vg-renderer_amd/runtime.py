@@ -107,9 +107,10 @@ class Context:
         _check(lib().vgx_get_failure_info(self._h, C.byref(fi), _stream_ptr()), "vgx_get_failure_info")
         return fi.as_dict()
 
-    def stage_times(self):
+    def stage_times(self, ncalls=1):
+        """Per-kernel HIP-event times of the last profiled call, or their average over the last `ncalls` calls."""
         st = capi.StageTimes()
-        _check(lib().vgx_get_stage_times(self._h, C.byref(st)), "vgx_get_stage_times")
+        _check(lib().vgx_get_stage_times_avg(self._h, C.byref(st), int(ncalls)), "vgx_get_stage_times_avg")
         return [(st.name[i].decode(), float(st.ms[i])) for i in range(st.num_stages)]
 
 

@@ -588,7 +588,6 @@ def main():
         cmds = torch.zeros(cap * 48, dtype=torch.uint8, device=dev)
         ncmd = torch.zeros(1, dtype=torch.int64, device=dev)
         ctx.set_assembly(cmds, 0, ncmd)
-        rt.tessellate_count(ctx, pset, dd, ndraws)  # the template mode of the headline run does not assemble: scratch of the ordinary pipeline
         ctx.set_profiling(True)
         rt.tessellate_async(ctx, pset, dd, ndraws, bufs)
         torch.cuda.synchronize()

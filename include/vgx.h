@@ -298,9 +298,8 @@ int vgx_stroke_emit(vgx_ctx* ctx, const float* poly, const vgx_subpath* subpaths
  * one record per vertex buffer and vgx_sizes.num_drawcmds their number; pos / color / meshes are unchanged (the vertex
  * streams already are in vertex-buffer order). A mesh with more than max_vb_vertices vertices sets
  * VGX_E_MESH_TOO_LARGE (the reference VG_CHECKs it, vg.cpp:5323); a too small table VGX_E_NOSPACE. The struct is copied.
- * Arm / disarm BEFORE vgx_tessellate_count: the count sizes the scratch of the pipeline the batch will take, and an armed
- * batch never takes the template mode (see vgx_tessellate); a vgx_tessellate that finds the scratch sized for the other
- * pipeline returns VGX_E_NOSPACE. */
+ * Template batches (see vgx_tessellate) are assembled too: the template pass writes the batch's mesh table for the partition
+ * kernels and adds each mesh's base to the indices it emits. */
 int vgx_set_assembly(vgx_ctx* ctx, const vgx_assembly* asm_);
 
 /* ---- shape cache: tessellate a drawing once, submit it many times -------------

@@ -222,3 +222,67 @@ def test_template_tiles_with_many_small_meshes(rt, wl, oracle):
     assert got.mode == MODE_TEMPLATE and got.status == 0
     assert_mesh_equal(got, oracle.tessellate(ps, d), "small meshes")
     ctx.close()
+
+
+def _assembled(rt, ctx, ps, d, max_vb, split_state):
+    """count + vgx_tessellate with draw-command assembly armed (armed BEFORE the count)."""
+    import torch
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(d)
+    cmds = torch.zeros(200000 * 48, dtype=torch.uint8, device=dd.device)
+    ncmd = torch.zeros(1, dtype=torch.int64, device=dd.device)
+    ctx.set_assembly(cmds, max_vb, ncmd, split_state=split_state)
+    try:
+        sizes = rt.tessellate_count(ctx, pset, dd, d.shape[0])
+        mode = ctx.failure_info()["segment_items"]
+        nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
+        bufs = rt.MeshBuffers(dd.device, nv, ni, nm)
+        bufs.idx.fill_(-1)
+        ctx.set_profiling(True)
+        rt.tessellate_async(ctx, pset, dd, d.shape[0], bufs)
+        torch.cuda.synchronize()
+        stages = [n for n, _ in ctx.stage_times()]
+        ctx.set_profiling(False)
+    finally:
+        ctx.set_assembly(None)
+    g = _G()
+    g.mode, g.stages, g.status = mode, stages, int(bufs.dev_status.item())
+    g.ncmd = int(ncmd.item())
+    g.dev_sizes = bufs.dev_sizes.cpu().numpy().view(np.uint64)
+    g.cmds = cmds[:g.ncmd * 48].cpu().numpy().view(rt.capi.drawcmd_dtype)
+    g.pos = bufs.pos[:nv].cpu().numpy()
+    g.color = bufs.color[:nv].cpu().numpy().view(np.uint32)
+    g.idx = bufs.idx[:ni].cpu().numpy().view(np.uint16)
+    g.meshes = bufs.meshes[:nm * 32].cpu().numpy().view(rt.capi.mesh_dtype)
+    pset.close()
+    return g
+
+
+@pytest.mark.parametrize("seed,ninst,max_vb,split", [(950, 40, 65536, False), (951, 36, 2048, True), (952, 50, 700, True)])
+def test_template_mode_with_draw_command_assembly(rt, wl, oracle, monkeypatch, seed, ninst, max_vb, split):
+    """vgx_set_assembly armed: the template pass writes the batch's mesh table for the partition kernels and adds every mesh's base
+    inside its draw command to the indices it emits. Draw commands, rebased indices and vertex streams equal the ordinary
+    pipeline's (VGX_TMPL=0) byte for byte and the oracle's assembly of the reference's meshes; state keys differ per instance
+    (they are not part of the template)."""
+    ps = wl.closed_fuzz_paths(seed, npaths=72)
+    d = wl.template_draws(ps, seed, ninst)
+    rs = np.random.RandomState(seed)
+    d["state_key"] = np.repeat(rs.randint(0, 3, size=(d.shape[0] + 6) // 7), 7)[:d.shape[0]].astype(np.uint32)  # runs of 7 draws per state
+    ctx = rt.Context(0)
+    got = _assembled(rt, ctx, ps, d, max_vb, split)
+    ctx.close()
+    assert got.mode == MODE_TEMPLATE and got.stages[-1] == "tmpl_emit" and "assemble" in got.stages, (got.mode, got.stages)
+    assert got.status == 0 and int(got.dev_sizes[9]) == got.ncmd
+    monkeypatch.setenv("VGX_TMPL", "0")
+    ctx = rt.Context(0)
+    old = _assembled(rt, ctx, ps, d, max_vb, split)
+    ctx.close()
+    assert old.mode != MODE_TEMPLATE and old.status == 0
+    assert got.ncmd == old.ncmd and bytes_equal(got.cmds, old.cmds)
+    for k in ("pos", "color", "idx", "meshes"):
+        assert bytes_equal(getattr(got, k), getattr(old, k)), k
+    ref = oracle.tessellate(ps, d)
+    keys = d["state_key"][ref.meshes["draw"]] if split else None
+    st, rcmds, ridx = oracle.assemble(ref.meshes, ref.idx, max_vb, mesh_keys=keys)
+    assert st == 0 and rcmds.shape[0] == got.ncmd
+    assert np.array_equal(got.idx, ridx)

@@ -1167,6 +1167,17 @@ static int runTmpl(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 			return launchStatus(ctx);
 		}
 	}
+	if (ctx->asmArmed) {
+		// draw-command assembly: the partition kernels need the whole batch's mesh table and every mesh's draw in memory
+		const uint64_t nm = a.ninst * a.inst.num_meshes;
+		int st;
+		if ((st = ensure(ctx, ctx->mtab, (nm + 1) * sizeof(vgx_mesh))) != VGX_OK) { return st; }
+		if ((st = ensure(ctx, ctx->mdesc, (nm + 1) * sizeof(VgxMeshDesc))) != VGX_OK) { return st; }
+		vgx_launch_tmpl_mtab(a, (vgx_mesh*)ctx->mtab.p, (VgxMeshDesc*)ctx->mdesc.p, s);
+		mark(ctx, s, "tmpl_mesh_table");
+		if ((st = runAssemble(ctx, out, s, draws)) != VGX_OK) { return st; }
+		a.mesh_base = (const uint32_t*)ctx->meshBase.p;
+	}
 	vgx_launch_tmpl_emit(a, s);
 	mark(ctx, s, "tmpl_emit");
 	if (dev_sizes || dev_status) {
@@ -1177,7 +1188,7 @@ static int runTmpl(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 
 static bool tmplFor(const vgx_ctx* ctx, const vgx_pathset* ps, uint64_t ndraws)
 {
-	return ctx->tmplOn && ctx->optTmpl && !ctx->asmArmed && ps == ctx->tmplPs && ctx->tmplPeriod && ndraws % ctx->tmplPeriod == 0 && ndraws >= ctx->tmplPeriod;
+	return ctx->tmplOn && ctx->optTmpl && ps == ctx->tmplPs && ctx->tmplPeriod && ndraws % ctx->tmplPeriod == 0 && ndraws >= ctx->tmplPeriod;
 }
 
 // vgx_tessellate_count, first thing: do the draws repeat their first period in everything but transform and colours, and are
@@ -1188,7 +1199,7 @@ static bool tmplFor(const vgx_ctx* ctx, const vgx_pathset* ps, uint64_t ndraws)
 static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, vgx_sizes* out_sizes, hipStream_t s)
 {
 	ctx->tmplOn = false;
-	if (!ctx->optTmpl || !ctx->optInst || ctx->asmArmed || ctx->optTwoPass || ndraws <= VGX_SMALL_DRAWS) { return VGX_OK; }
+	if (!ctx->optTmpl || !ctx->optInst || ctx->optTwoPass || ndraws <= VGX_SMALL_DRAWS) { return VGX_OK; }
 	int st;
 	if ((st = ensure(ctx, ctx->totals, sizeof(VgxTotals))) != VGX_OK) { return st; }
 	noteHip(ctx, hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s));

@@ -115,9 +115,11 @@ struct VgxTmplArgs // one step
 	uint32_t* color;
 	uint16_t* idx;
 	vgx_mesh* meshes_out;        // may be null
+	const uint32_t* mesh_base;   // assembly armed: [ninst * meshes] vertices in front of each mesh inside its draw command; else null
 	VgxCaps caps;                // vertices / indices / meshes of the caller's buffers
 	VgxTotals* totals;
 };
+void vgx_launch_tmpl_mtab(const VgxTmplArgs& a, vgx_mesh* mtab, VgxMeshDesc* mdesc, hipStream_t s); // assembly armed: the whole batch's mesh table + mesh -> draw
 void vgx_launch_tmpl_check(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, VgxTotals* totals, hipStream_t s); // after vgx_launch_inst_detect
 void vgx_launch_tmpl_build(const VgxTmplBuild& b, hipStream_t s);
 void vgx_launch_tmpl_emit(const VgxTmplArgs& a, hipStream_t s);

@@ -206,9 +206,11 @@ struct __attribute__((aligned(16))) TmplDraw // per draw of the tile, in LDS. 32
 };
 struct __attribute__((aligned(16))) TmplRec // per mesh of the tile, in LDS. 32 bytes
 {
-	uint32_t dk, n, v_off, i_off;       // dk: the mesh's draw, relative to the tile's first draw
-	uint32_t kind, color; float f0, f1; // fills: f0 = aa WITH the instance's orientation sign; strokes: hsw, hswAA
+	uint32_t ibase, n, v_off, i_off;    // ibase: assembly armed: vertices in front of the mesh inside its draw command (added to every index); else 0
+	uint32_t kind, color; float f0, f1; // kind: VgxMeshDesc::kind word | (the mesh's draw, relative to the tile's first draw) << 16
+	                                    // fills: f0 = aa WITH the instance's orientation sign; strokes: hsw, hswAA
 };
+#define TMPL_REC_DK(r) ((r)->kind >> 16)
 __device__ __forceinline__ TmplXf tmpl_draw_xf(const TmplDraw* d)
 {
 	TmplXf xf; xf.m0 = d->m0; xf.m1 = d->m1; xf.m2 = d->m2; xf.m3 = d->m3; xf.m4 = d->m4; xf.m5 = d->m5;
@@ -247,7 +249,7 @@ __device__ __forceinline__ float tmpl_fill_aa(const TmplXf& xf, float2 l0, float
 struct TmplOut { char* pos; char* col; char* idx; };
 
 // One convex-fill element: strokerConvexFill / strokerConvexFillAA (stroker.cpp:334-365, 713-807), as fill_emit_store (vgx_elem.h).
-__device__ __forceinline__ void tmpl_fill_elem(const TmplOut& O, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t color, float aa,
+__device__ __forceinline__ void tmpl_fill_elem(const TmplOut& O, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color, float aa,
 	uint32_t j, V2 p1, V2 dPrev, V2 d12)
 {
 	if (VGX_MD_KIND(kindWord) == VGX_MESH_FILL_AA) {
@@ -258,7 +260,7 @@ __device__ __forceinline__ void tmpl_fill_elem(const TmplOut& O, uint32_t kindWo
 		ColPair cp; cp.c0 = color; cp.c1 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
 		const uint32_t ib = (iOff + 9u * j) * 2u;
 		uint32_t val[9];
-		fill_idx9(j, N, 0u, VGX_MD_SSE_ORDER(kindWord) != 0, val);
+		fill_idx9(j, N, ibase, VGX_MD_SSE_ORDER(kindWord) != 0, val); // + ibase: command relative when assembly is armed (uint16 wrap = the reference's cast, vg_util.cpp:447)
 		VGX_ST_GUARD(cp.c0 ^ __float_as_uint(pp.x0)) {
 		*(PosPair*)(O.pos + gv * 8u) = pp;
 		*(ColPair*)(O.col + gv * 4u) = cp;
@@ -276,7 +278,7 @@ __device__ __forceinline__ void tmpl_fill_elem(const TmplOut& O, uint32_t kindWo
 		*(float2*)(O.pos + gv * 8u) = make_float2(p1.x, p1.y);
 		*(uint32_t*)(O.col + gv * 4u) = color;
 		if (j + 2 < N) { // fan (0, j + 1, j + 2), stroker.cpp:340-357
-			Idx3 q; q.a = (j + 1) << 16; q.b = (uint16_t)(j + 2);
+			Idx3 q; q.a = (ibase & 0xFFFFu) | ((j + 1 + ibase) << 16); q.b = (uint16_t)(j + 2 + ibase);
 			*(Idx3*)(O.idx + (iOff + 3u * j) * 2u) = q;
 		}
 		}
@@ -287,7 +289,7 @@ __device__ __forceinline__ void tmpl_fill_elem(const TmplOut& O, uint32_t kindWo
 // its neighbour lanes. dPrev2 = direction of the edge in front of the previous vertex (the previous join's inner side is
 // recomputed from it), dFirst = direction of edge 0 (join 0's inner side, for the closing bridge of the last element): same
 // inputs, same arithmetic, same bits as the values the sequential stroker carries along (stroker.cpp:1401-1410).
-__device__ __forceinline__ void tmpl_stroke_elem(const TmplOut& O, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t color, float hsw, float hswAA,
+__device__ __forceinline__ void tmpl_stroke_elem(const TmplOut& O, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color, float hsw, float hswAA,
 	uint32_t j, V2 p1, V2 dPrev2, V2 dPrev, V2 d12, V2 dFirst)
 {
 	const bool thin = VGX_MD_KIND(kindWord) == VGX_MESH_STROKE_AA_THIN;
@@ -297,8 +299,8 @@ __device__ __forceinline__ void tmpl_stroke_elem(const TmplOut& O, uint32_t kind
 	const VgxJoin jn = vgx_join_dirs(dPrev, d12, sideWidth);
 	const bool L = jn.leftInner;
 	const uint32_t b = R * j;
-	const uint32_t top = b + R - 1;
-	const Rails mine = thin ? (L ? rails(b, b + 1, b + 2, 0) : rails(top, b + 1, b, 0)) : (L ? rails(b, b + 1, b + 2, b + 3) : rails(top, b + 2, b + 1, b));
+	const uint32_t bi = b + ibase, top = bi + R - 1; // index VALUES carry the assembly base, positions in the streams do not
+	const Rails mine = thin ? (L ? rails(bi, bi + 1, bi + 2, 0) : rails(top, bi + 1, bi, 0)) : (L ? rails(bi, bi + 1, bi + 2, bi + 3) : rails(top, bi + 2, bi + 1, bi));
 	const uint32_t c0 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
 	char* pp = O.pos + (vOff + b) * 8u;
 	char* pc = O.col + (vOff + b) * 4u;
@@ -334,7 +336,7 @@ __device__ __forceinline__ void tmpl_stroke_elem(const TmplOut& O, uint32_t kind
 	}
 	if (j > 0) { // the bridge from the previous join (stroker.cpp:1557-1564, 1714-1721; thin :2093-2098, 2175-2180)
 		const VgxJoin jp = vgx_join_dirs(dPrev2, dPrev, sideWidth);
-		const uint32_t pb = R * (j - 1), ptop = pb + R - 1;
+		const uint32_t pb = R * (j - 1) + ibase, ptop = pb + R - 1;
 		const Rails p = thin ? (jp.leftInner ? rails(pb, pb + 1, pb + 2, 0) : rails(ptop, pb + 1, pb, 0))
 		                     : (jp.leftInner ? rails(pb, pb + 1, pb + 2, pb + 3) : rails(ptop, pb + 2, pb + 1, pb));
 		char* pi = O.idx + (iOff + bridgeIdx * (j - 1)) * 2u;
@@ -351,7 +353,8 @@ __device__ __forceinline__ void tmpl_stroke_elem(const TmplOut& O, uint32_t kind
 	}
 	if (j + 1 == N) { // closing bridge to join 0 (:1970-1984, 2295-2306); d12 = vec2Dir(last vertex, vertex 0)
 		const VgxJoin j0 = vgx_join_dirs(d12, dFirst, sideWidth);
-		const Rails f = thin ? (j0.leftInner ? rails(0, 1, 2, 0) : rails(2, 1, 0, 0)) : (j0.leftInner ? rails(0, 1, 2, 3) : rails(3, 2, 1, 0));
+		const uint32_t z = ibase;
+		const Rails f = thin ? (j0.leftInner ? rails(z, z + 1, z + 2, 0) : rails(z + 2, z + 1, z, 0)) : (j0.leftInner ? rails(z, z + 1, z + 2, z + 3) : rails(z + 3, z + 2, z + 1, z));
 		char* pi = O.idx + (iOff + bridgeIdx * (N - 1)) * 2u;
 		Idx6 t0; t0.a = (mine.a & 0xFFFFu) | (mine.b << 16); t0.b = (f.b & 0xFFFFu) | (mine.a << 16); t0.c = (f.b & 0xFFFFu) | (f.a << 16);
 		Idx6 t1; t1.a = (mine.b & 0xFFFFu) | (mine.c << 16); t1.b = (f.c & 0xFFFFu) | (mine.b << 16); t1.c = (f.c & 0xFFFFu) | (f.b << 16);
@@ -379,7 +382,7 @@ __device__ __forceinline__ void tmpl_mesh_out(const VgxTmplArgs& A, uint64_t ins
 // One element given its mesh's constants, its transformed vertex, its own edge direction and a way to get the mesh's other
 // edge directions (dir(jj) = direction of the edge jj -> jj + 1, cyclic).
 template<class DF>
-__device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t color, float f0, float f1,
+__device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color, float f0, float f1,
 	V2 p1, V2 d12, const DF& dir)
 {
 	const uint32_t kind = VGX_MD_KIND(kindWord);
@@ -387,13 +390,13 @@ __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uin
 	if (kind < VGX_MESH_STROKE) {
 		V2 dPrev = d12;
 		if (kind == VGX_MESH_FILL_AA) { dPrev = dir(jp1); }
-		tmpl_fill_elem(O, kindWord, N, vOff, iOff, color, f0, j, p1, dPrev, d12);
+		tmpl_fill_elem(O, kindWord, N, vOff, iOff, ibase, color, f0, j, p1, dPrev, d12);
 	} else {
 		const V2 dPrev = dir(jp1);
 		V2 dPrev2 = dPrev, dFirst = dPrev;
 		if (j > 0) { dPrev2 = dir(jp1 > 0 ? jp1 - 1 : N - 1); }
 		if (j + 1 == N) { dFirst = dir(0u); }
-		tmpl_stroke_elem(O, kindWord, N, vOff, iOff, color, f0, f1, j, p1, dPrev2, dPrev, d12, dFirst);
+		tmpl_stroke_elem(O, kindWord, N, vOff, iOff, ibase, color, f0, f1, j, p1, dPrev2, dPrev, d12, dFirst);
 	}
 }
 
@@ -402,6 +405,32 @@ __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uin
 #define VGX_TMPL_MAXM 160      /* meshes / draws per tile the LDS tables hold; a tile that needs more takes the per-lane fallback */
 #endif
 #define VGX_TMPL_CH (VGX_TMPL_MAX_TILE / VGX_TMPL_THREADS)
+
+// Draw-command assembly armed: the partition of the mesh sequence into vertex buffers / draw commands (vgx_assemble.hip) reads
+// the WHOLE batch's mesh table and each mesh's draw; in template mode neither exists in memory, so this pass writes them
+// (template record + instance offsets) before the assembly kernels run. k_tmpl_emit then adds each mesh's base to its indices.
+__global__ __launch_bounds__(256) void k_tmpl_mtab(VgxTmplArgs A, vgx_mesh* mtab, VgxMeshDesc* mdesc)
+{
+	const uint64_t M = A.inst.num_meshes, total = A.ninst * M;
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		vgx_sizes z;
+		z.num_poly_vertices = A.ninst * A.inst.num_poly_vertices; z.num_subpaths = A.ninst * A.inst.num_subpaths; z.num_meshes = total;
+		z.num_vertices = A.ninst * A.inst.num_vertices; z.num_indices = A.ninst * A.inst.num_indices; z.num_serial_draws = A.ninst * A.inst.num_serial_draws;
+		z.num_cmd_instances = A.ninst * A.inst.num_cmd_instances; z.num_elements = A.ninst * A.inst.num_elements; z.num_fill_elements = A.ninst * A.inst.num_fill_elements;
+		z.num_drawcmds = 0;
+		A.totals->sizes = z;
+	}
+	for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t inst = k / M;
+		const uint32_t m = (uint32_t)(k - inst * M);
+		vgx_mesh r = A.tmtab[m];
+		r.first_vertex += inst * A.inst.num_vertices;
+		r.first_index += inst * A.inst.num_indices;
+		r.draw += (uint32_t)(inst * A.period);
+		mtab[k] = r;
+		mdesc[k].draw = r.draw;
+	}
+}
 #ifndef VGX_TMPL_OCC
 #define VGX_TMPL_OCC
 #endif
@@ -434,7 +463,7 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 	O.pos = (char*)(A.pos + 2 * (inst * A.inst.num_vertices));
 	O.col = (char*)(A.color + inst * A.inst.num_vertices);
 	O.idx = (char*)(A.idx + inst * A.inst.num_indices);
-	if (t == 0 && inst == 0 && tid == 0) { // totals of the batch = instances x template (the memset in front of this kernel zeroed them)
+	if (t == 0 && inst == 0 && tid == 0 && !A.mesh_base) { // (assembly armed: k_tmpl_mtab wrote them already) totals of the batch = instances x template (the memset in front of this kernel zeroed them)
 		vgx_sizes z;
 		z.num_poly_vertices = A.ninst * A.inst.num_poly_vertices; z.num_subpaths = A.ninst * A.inst.num_subpaths; z.num_meshes = A.ninst * A.inst.num_meshes;
 		z.num_vertices = A.ninst * A.inst.num_vertices; z.num_indices = A.ninst * A.inst.num_indices; z.num_serial_draws = A.ninst * A.inst.num_serial_draws;
@@ -458,7 +487,8 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 			if (kind == VGX_MESH_FILL_AA) { f0 = tmpl_fill_aa(xf, vt[0], vt[1], vt[2], tm.f0); }
 			auto dir = [&](uint32_t jj) { return v2dir(tmpl_xf(xf, vt[jj]), tmpl_xf(xf, vt[jj + 1 < N ? jj + 1 : 0u])); };
 			if (j == 0 && A.meshes_out) { tmpl_mesh_out(A, inst, er.mesh); }
-			tmpl_elem_emit(O, j, tm.kind, N, tm.v_off, tm.i_off, kind < VGX_MESH_STROKE ? dr.fill_color : dr.stroke_color, f0, tm.f1, tmpl_xf(xf, vt[j]), dir(j), dir);
+			const uint32_t ibase = A.mesh_base ? A.mesh_base[inst * A.inst.num_meshes + er.mesh] : 0u;
+			tmpl_elem_emit(O, j, tm.kind, N, tm.v_off, tm.i_off, ibase, kind < VGX_MESH_STROKE ? dr.fill_color : dr.stroke_color, f0, tm.f1, tmpl_xf(xf, vt[j]), dir(j), dir);
 		}
 		return;
 	}
@@ -479,7 +509,11 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 	}
 	VgxTmplMesh tm;
 	tm.poly_first = 0; tm.n = 3; tm.v_off = 0; tm.i_off = 0; tm.drawk = dA; tm.kind = VGX_MESH_FILL; tm.f0 = 0.0f; tm.f1 = 0.0f;
-	if (tid < nm) { tm = A.tmesh[mA + tid]; }
+	uint32_t ibase = 0;
+	if (tid < nm) {
+		tm = A.tmesh[mA + tid];
+		if (A.mesh_base) { ibase = A.mesh_base[inst * A.inst.num_meshes + mA + tid]; }
+	}
 	if (tid < nd) { s_draw[tid] = tmpl_load_draw(A, idraws, dA + tid); }
 #pragma unroll
 	for (int c = 0; c < VGX_TMPL_CH; ++c) { lp[c] = A.tpoly[er[c].vtx]; }
@@ -493,8 +527,8 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 		const uint32_t kind = VGX_MD_KIND(tm.kind);
 		const TmplDraw* d = &s_draw[tm.drawk - dA];
 		TmplRec r;
-		r.dk = tm.drawk - dA; r.n = tm.n; r.v_off = tm.v_off; r.i_off = tm.i_off;
-		r.kind = tm.kind; r.color = kind < VGX_MESH_STROKE ? d->fill_color : d->stroke_color; r.f0 = tm.f0; r.f1 = tm.f1;
+		r.ibase = ibase; r.n = tm.n; r.v_off = tm.v_off; r.i_off = tm.i_off;
+		r.kind = (tm.kind & 0xFFFFu) | ((tm.drawk - dA) << 16); r.color = kind < VGX_MESH_STROKE ? d->fill_color : d->stroke_color; r.f0 = tm.f0; r.f1 = tm.f1;
 		if (kind == VGX_MESH_FILL_AA) { r.f0 = tmpl_fill_aa(tmpl_draw_xf(d), l0, l1, l2, tm.f0); }
 		s_rec[tid] = r;
 		// the caller's mesh table for the meshes that BEGIN in this tile (every mesh of the range but possibly the first)
@@ -513,7 +547,7 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 		p1[c] = v2(0.0f, 0.0f);
 		if (s < nel) {
 			const TmplRec* r = &s_rec[er[c].mesh - mA];
-			p1[c] = tmpl_xf(tmpl_draw_xf(&s_draw[r->dk]), lp[c]);
+			p1[c] = tmpl_xf(tmpl_draw_xf(&s_draw[TMPL_REC_DK(r)]), lp[c]);
 			s_vtx[er[c].jq >> 16] = make_float2(p1[c].x, p1[c].y);
 		}
 	}
@@ -524,7 +558,7 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 	auto vtxAt = [&](uint32_t mesh, const TmplRec* rp, int q0, uint32_t jj) {
 		const uint32_t qq = (uint32_t)(q0 + (int)jj);
 		if (qq < nel) { const float2 v = s_vtx[qq]; return v2(v.x, v.y); }
-		return tmpl_xf(tmpl_draw_xf(&s_draw[rp->dk]), A.tpoly[A.tmesh[mesh].poly_first + jj]);
+		return tmpl_xf(tmpl_draw_xf(&s_draw[TMPL_REC_DK(rp)]), A.tpoly[A.tmesh[mesh].poly_first + jj]);
 	};
 	// ---- phase 2: own edge direction vec2Dir(p[j], p[j + 1]) (stroker.cpp:31-38), once per element
 	V2 d12[VGX_TMPL_CH];
@@ -556,7 +590,7 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 				if (qq < nel) { const float2 v = s_dir[qq]; return v2(v.x, v.y); }
 				return v2dir(vtxAt(mesh, rp, q0, jj), vtxAt(mesh, rp, q0, jj + 1 < N ? jj + 1 : 0u)); // the edge belongs to another tile
 			};
-			tmpl_elem_emit(O, j, rp->kind, N, rp->v_off, rp->i_off, rp->color, rp->f0, rp->f1, p1[c], d12[c], dir);
+			tmpl_elem_emit(O, j, rp->kind & 0xFFFFu, N, rp->v_off, rp->i_off, rp->ibase, rp->color, rp->f0, rp->f1, p1[c], d12[c], dir);
 		}
 	}
 	TMPL_PROF(3);
@@ -583,6 +617,11 @@ void vgx_launch_tmpl_build(const VgxTmplBuild& b, hipStream_t s)
 		hipLaunchKernelGGL(k_tmpl_elems, dim3((unsigned)(ge > 4096 ? 4096 : ge)), dim3(256), 0, s, b);
 		hipLaunchKernelGGL(k_tmpl_tiles, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, b);
 	}
+}
+
+void vgx_launch_tmpl_mtab(const VgxTmplArgs& a, vgx_mesh* mtab, VgxMeshDesc* mdesc, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_tmpl_mtab, dim3(2048), dim3(256), 0, s, a, mtab, mdesc);
 }
 
 void vgx_launch_tmpl_emit(const VgxTmplArgs& a, hipStream_t s)

@@ -1238,7 +1238,7 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	const uint32_t tileSize = ctx->optTmplTile;
 	if ((st = ensure(ctx, ctx->tmplTile, ((E + tileSize - 1) / tileSize + 1) * sizeof(VgxTmplTile))) != VGX_OK) { return st; }
 	VgxTmplBuild b;
-	b.draws = draws; b.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; b.mprep = (const VgxMeshPrep*)ctx->mprep.p; b.mtab = (const vgx_mesh*)ctx->mtab.p;
+	b.draws = draws; b.poly = (const float2*)ctx->poly.p; b.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; b.mprep = (const VgxMeshPrep*)ctx->mprep.p; b.mtab = (const vgx_mesh*)ctx->mtab.p;
 	b.prefix_fill = (const uint64_t*)ctx->elemPrefix.p; b.prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
 	b.num_meshes = M; b.num_elems = E; b.tile = tileSize; b.ttile = (VgxTmplTile*)ctx->tmplTile.p; b.period = (uint32_t)P;
 	b.tmesh = (VgxTmplMesh*)ctx->tmplMesh.p; b.tmtab = (vgx_mesh*)ctx->tmplMtab.p; b.telem = (VgxTmplElem*)ctx->tmplElem.p;

@@ -85,6 +85,7 @@ struct VgxTmplBuild // count pass: the first period's ordinary count + emit resu
 	const VgxMeshDesc* mdesc;
 	const VgxMeshPrep* mprep;
 	const vgx_mesh* mtab;
+	const float2* poly;            // the period's LOCAL polyline (two-phase flatten with apply_transform = 0)
 	const uint64_t* prefix_fill;   // [num_meshes + 1]
 	const uint64_t* prefix_stroke; // [num_meshes + 1]
 	uint64_t num_meshes, num_elems;

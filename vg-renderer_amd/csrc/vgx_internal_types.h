@@ -147,7 +147,7 @@ enum {
 #define VGX_LONG_SUBPATH 2048
 
 // ---- template mode (vgx_tmpl.hip): one period of an instanced batch flattened once, in local space -----------------------
-struct VgxTmplMesh // one mesh of the template. 32 bytes
+struct VgxTmplMesh // one mesh of the template. 64 bytes
 {
 	uint32_t poly_first; // first vertex of its polyline in the template's LOCAL polyline
 	uint32_t n;          // polyline vertices = elements
@@ -156,13 +156,14 @@ struct VgxTmplMesh // one mesh of the template. 32 bytes
 	uint32_t drawk;      // draw inside the period
 	uint32_t kind;       // VgxMeshDesc::kind word
 	float f0, f1;        // fills: fringe / 2 (the sign is per instance), -; strokes: hsw, hswAA (thin: fringe, fringe)
+	float l0[2], l1[2], l2[2]; // its first three LOCAL vertices: the fill orientation (stroker.cpp:721-723) is the sign of their transformed triangle
+	uint32_t pad[2];
 };
 struct VgxTmplElem // one element (polyline vertex j of template mesh `mesh`), in processing order. 16 bytes
 {
 	uint32_t mesh;
 	uint32_t jq;   // j | (position of the element inside its tile, in OUTPUT order) << 16
-	uint32_t vtx;  // its vertex in the template's local polyline (= mesh.poly_first + j)
-	uint32_t pad;
+	float lx, ly;  // its LOCAL vertex (= local polyline[mesh.poly_first + j]): one record is all an element reads from memory
 };
 struct VgxTmplTile // one tile of the instance's element stream = one workgroup of k_tmpl_emit. 16 bytes
 {

@@ -108,6 +108,10 @@ __global__ __launch_bounds__(256) void k_tmpl_meshes(VgxTmplBuild B)
 		t.kind = md.kind;
 		if (VGX_MD_KIND(md.kind) >= VGX_MESH_STROKE) { t.f0 = pr.f0; t.f1 = pr.f1; } // hsw / hswAA (thin: fringe, fringe)
 		else { t.f0 = B.draws[md.draw].fringe * 0.5f; t.f1 = 0.0f; }                // |aa| = fringe / 2 (stroker.cpp:723); the sign is per instance
+		const float2* v = B.poly + md.poly_first;
+		const float2 a = v[0], b = v[md.poly_n > 1 ? 1 : 0], c = v[md.poly_n > 2 ? 2 : 0];
+		t.l0[0] = a.x; t.l0[1] = a.y; t.l1[0] = b.x; t.l1[1] = b.y; t.l2[0] = c.x; t.l2[1] = c.y;
+		t.pad[0] = 0; t.pad[1] = 0;
 		B.tmesh[m] = t;
 		B.tmtab[m] = mt;
 	}
@@ -148,8 +152,8 @@ __global__ __launch_bounds__(256) void k_tmpl_elems(VgxTmplBuild B)
 		VgxTmplElem r;
 		r.mesh = (uint32_t)m;
 		r.jq = j | ((uint32_t)(e - x0) << 16); // j < 65536 (a mesh holds at most 65536 vertices), position in the tile < tile <= 65536
-		r.vtx = (uint32_t)B.mdesc[m].poly_first + j;
-		r.pad = 0;
+		const float2 lv = B.poly[B.mdesc[m].poly_first + j];
+		r.lx = lv.x; r.ly = lv.y;
 		B.telem[slot] = r;
 		if (e == x0) { // tile record, first half: the mesh that owns the tile's first element; bit 31: it begins exactly here
 			B.ttile[e / T].mesh0 = (uint32_t)m | (j == 0 ? 0x80000000u : 0u);
@@ -247,6 +251,11 @@ __device__ __forceinline__ float tmpl_fill_aa(const TmplXf& xf, float2 l0, float
 // store is `global_store saddr + voffset` instead of a 64-bit address built per lane (template mode requires an instance to
 // stay below 4 GB per stream).
 struct TmplOut { char* pos; char* col; char* idx; };
+#ifdef VGX_EXP_NOIDX /* tuning experiment: the index stream is not stored (wrong output) */
+#define TMPL_IDX_ON if (O.idx == nullptr)
+#else
+#define TMPL_IDX_ON
+#endif
 
 // One convex-fill element: strokerConvexFill / strokerConvexFillAA (stroker.cpp:334-365, 713-807), as fill_emit_store (vgx_elem.h).
 __device__ __forceinline__ void tmpl_fill_elem(const TmplOut& O, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color, float aa,
@@ -266,10 +275,10 @@ __device__ __forceinline__ void tmpl_fill_elem(const TmplOut& O, uint32_t kindWo
 		*(ColPair*)(O.col + gv * 4u) = cp;
 		if (j + 1 < N) {
 			Idx9 q; q.a = val[0] | (val[1] << 16); q.b = val[2] | (val[3] << 16); q.c = val[4] | (val[5] << 16); q.d = val[6] | (val[7] << 16); q.e = (uint16_t)val[8];
-			*(Idx9*)(O.idx + ib) = q;
+			TMPL_IDX_ON *(Idx9*)(O.idx + ib) = q;
 		} else {
 			Idx3 q; q.a = val[0] | (val[1] << 16); q.b = (uint16_t)val[2];
-			*(Idx3*)(O.idx + ib) = q;
+			TMPL_IDX_ON *(Idx3*)(O.idx + ib) = q;
 		}
 		}
 	} else {
@@ -279,7 +288,7 @@ __device__ __forceinline__ void tmpl_fill_elem(const TmplOut& O, uint32_t kindWo
 		*(uint32_t*)(O.col + gv * 4u) = color;
 		if (j + 2 < N) { // fan (0, j + 1, j + 2), stroker.cpp:340-357
 			Idx3 q; q.a = (ibase & 0xFFFFu) | ((j + 1 + ibase) << 16); q.b = (uint16_t)(j + 2 + ibase);
-			*(Idx3*)(O.idx + (iOff + 3u * j) * 2u) = q;
+			TMPL_IDX_ON *(Idx3*)(O.idx + (iOff + 3u * j) * 2u) = q;
 		}
 		}
 	}
@@ -342,7 +351,7 @@ __device__ __forceinline__ void tmpl_stroke_elem(const TmplOut& O, uint32_t kind
 		char* pi = O.idx + (iOff + bridgeIdx * (j - 1)) * 2u;
 		Idx6 t0; t0.a = (p.a & 0xFFFFu) | (p.b << 16); t0.b = (mine.b & 0xFFFFu) | (p.a << 16); t0.c = (mine.b & 0xFFFFu) | (mine.a << 16);
 		Idx6 t1; t1.a = (p.b & 0xFFFFu) | (p.c << 16); t1.b = (mine.c & 0xFFFFu) | (p.b << 16); t1.c = (mine.c & 0xFFFFu) | (mine.b << 16);
-		VGX_ST_GUARD(t0.a ^ t1.c) {
+		VGX_ST_GUARD(t0.a ^ t1.c) TMPL_IDX_ON {
 		*(Idx6*)pi = t0;
 		*(Idx6*)(pi + 12) = t1;
 		if (!thin) {
@@ -358,7 +367,7 @@ __device__ __forceinline__ void tmpl_stroke_elem(const TmplOut& O, uint32_t kind
 		char* pi = O.idx + (iOff + bridgeIdx * (N - 1)) * 2u;
 		Idx6 t0; t0.a = (mine.a & 0xFFFFu) | (mine.b << 16); t0.b = (f.b & 0xFFFFu) | (mine.a << 16); t0.c = (f.b & 0xFFFFu) | (f.a << 16);
 		Idx6 t1; t1.a = (mine.b & 0xFFFFu) | (mine.c << 16); t1.b = (f.c & 0xFFFFu) | (mine.b << 16); t1.c = (f.c & 0xFFFFu) | (f.b << 16);
-		VGX_ST_GUARD(t0.a ^ t1.c) {
+		VGX_ST_GUARD(t0.a ^ t1.c) TMPL_IDX_ON {
 		*(Idx6*)pi = t0;
 		*(Idx6*)(pi + 12) = t1;
 		if (!thin) {
@@ -500,25 +509,21 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 #endif
 	// ---- phase 0a: every load the workgroup needs, requested at once
 	VgxTmplElem er[VGX_TMPL_CH];
-	float2 lp[VGX_TMPL_CH];
 #pragma unroll
 	for (int c = 0; c < VGX_TMPL_CH; ++c) {
 		const uint32_t s = (uint32_t)c * VGX_TMPL_THREADS + tid; // interleaved: the tile's stroke chunks (the heavier ones, at the tile's end) spread over the waves
-		er[c].mesh = mA; er[c].jq = 0; er[c].vtx = 0; er[c].pad = 0;
+		er[c].mesh = mA; er[c].jq = 0; er[c].lx = 0.0f; er[c].ly = 0.0f;
 		if (s < nel) { er[c] = telem[s]; }
 	}
 	VgxTmplMesh tm;
-	tm.poly_first = 0; tm.n = 3; tm.v_off = 0; tm.i_off = 0; tm.drawk = dA; tm.kind = VGX_MESH_FILL; tm.f0 = 0.0f; tm.f1 = 0.0f;
+	memset(&tm, 0, sizeof(tm));
+	tm.n = 3; tm.drawk = dA; tm.kind = VGX_MESH_FILL;
 	uint32_t ibase = 0;
 	if (tid < nm) {
 		tm = A.tmesh[mA + tid];
 		if (A.mesh_base) { ibase = A.mesh_base[inst * A.inst.num_meshes + mA + tid]; }
 	}
 	if (tid < nd) { s_draw[tid] = tmpl_load_draw(A, idraws, dA + tid); }
-#pragma unroll
-	for (int c = 0; c < VGX_TMPL_CH; ++c) { lp[c] = A.tpoly[er[c].vtx]; }
-	float2 l0 = make_float2(0.0f, 0.0f), l1 = l0, l2 = l0;
-	if (tid < nm && VGX_MD_KIND(tm.kind) == VGX_MESH_FILL_AA) { const float2* vt = A.tpoly + tm.poly_first; l0 = vt[0]; l1 = vt[1]; l2 = vt[2]; }
 	if (tid == 0) { s_status = A.totals->status; } // an earlier workgroup may have found the batch stale; ONE value for the whole workgroup (the exit below must be uniform)
 	__syncthreads();
 	const uint32_t status = s_status;
@@ -529,7 +534,7 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 		TmplRec r;
 		r.ibase = ibase; r.n = tm.n; r.v_off = tm.v_off; r.i_off = tm.i_off;
 		r.kind = (tm.kind & 0xFFFFu) | ((tm.drawk - dA) << 16); r.color = kind < VGX_MESH_STROKE ? d->fill_color : d->stroke_color; r.f0 = tm.f0; r.f1 = tm.f1;
-		if (kind == VGX_MESH_FILL_AA) { r.f0 = tmpl_fill_aa(tmpl_draw_xf(d), l0, l1, l2, tm.f0); }
+		if (kind == VGX_MESH_FILL_AA) { r.f0 = tmpl_fill_aa(tmpl_draw_xf(d), make_float2(tm.l0[0], tm.l0[1]), make_float2(tm.l1[0], tm.l1[1]), make_float2(tm.l2[0], tm.l2[1]), tm.f0); }
 		s_rec[tid] = r;
 		// the caller's mesh table for the meshes that BEGIN in this tile (every mesh of the range but possibly the first)
 		if ((tid > 0 || firstWhole) && A.meshes_out && status == VGX_OK) { tmpl_mesh_out(A, inst, mA + tid); }
@@ -547,7 +552,7 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 		p1[c] = v2(0.0f, 0.0f);
 		if (s < nel) {
 			const TmplRec* r = &s_rec[er[c].mesh - mA];
-			p1[c] = tmpl_xf(tmpl_draw_xf(&s_draw[TMPL_REC_DK(r)]), lp[c]);
+			p1[c] = tmpl_xf(tmpl_draw_xf(&s_draw[TMPL_REC_DK(r)]), make_float2(er[c].lx, er[c].ly));
 			s_vtx[er[c].jq >> 16] = make_float2(p1[c].x, p1[c].y);
 		}
 	}

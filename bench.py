@@ -147,11 +147,11 @@ def gpu_environment():
             kl = k.lower()
             if "performance level" in kl:
                 env["perf_level"] = v
-            elif "sclk" in kl and "clock" in kl:
-                env["sclk"] = v
-            elif "mclk" in kl and "clock" in kl:
+            elif kl.startswith("sclk clock speed"):
+                env["sclk"] = v  # the clock at the moment of the query (idle between runs: the low state)
+            elif kl.startswith("mclk clock speed"):
                 env["mclk"] = v
-            elif "fclk" in kl and "clock" in kl:
+            elif kl.startswith("fclk clock speed"):
                 env["fclk"] = v
             elif "compute partition" in kl:
                 env["compute_partition"] = v

@@ -89,6 +89,10 @@ enum { VGX_JOIN_MITER = 0, VGX_JOIN_ROUND = 1, VGX_JOIN_BEVEL = 2 };
  * which strokerConcaveFillEnd[AA] call and FillRule the reference would use). */
 #define VGX_FILL_CONCAVE 0x10u
 #define VGX_FILL_EVEN_ODD 0x20u
+/* A user mesh (vg::indexedTriList, src/vg.cpp:4129-4175): the draw has no path and no GPU mesh; vgx_cmdlist_decode hands the mesh
+ * itself over in vgx_cmdlist_out::tri_* (positions already through the state transform, as ctxIndexedTriList does with
+ * batchTransformPositions) and vgx_merge puts it at the draw's place in the frame. */
+#define VGX_FILL_TRILIST 0x40u
 /* vgx_draw.stroke_flags */
 #define VGX_STROKE_ENABLE 0x1u
 #define VGX_STROKE_AA 0x2u
@@ -161,7 +165,7 @@ typedef struct vgx_mesh {
 	uint32_t subpath_kind; /* bits 0-27 sub-path index within the draw, bits 28-31 VGX_MESH_* */
 } vgx_mesh;
 enum { VGX_MESH_FILL = 0, VGX_MESH_FILL_AA = 1, VGX_MESH_STROKE = 2, VGX_MESH_STROKE_AA = 3, VGX_MESH_STROKE_AA_THIN = 4,
-       VGX_MESH_CONCAVE_FILL_AA = 5 /* vgx_concave_emit */ };
+       VGX_MESH_CONCAVE_FILL_AA = 5 /* vgx_concave_emit */, VGX_MESH_TRILIST = 6 /* vgx_cmdlist_out::tri_meshes */ };
 
 /* Totals of a batch. Filled by the *_count calls (host struct). */
 typedef struct vgx_sizes {
@@ -385,6 +389,11 @@ int vgx_concave_emit(vgx_ctx* ctx, const float* contour_verts, uint64_t num_cont
  * dev_status); a sequence that is not sorted by draw sets VGX_E_INVALID_ARG. */
 int vgx_merge(vgx_ctx* ctx, const vgx_cache_desc* a, const vgx_cache_desc* b, const uint32_t* b_draw, const vgx_draw* draws, uint64_t ndraws,
               const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream);
+/* The same with per-vertex UVs for the meshes of `b` (user meshes with texture coordinates): b_uv (DEVICE, [b->num_vertices] x the
+ * armed assembly's uv_bytes, or NULL) overwrites the white-pixel UV the assembly step writes for every vertex. Needs an armed
+ * assembly with a UV stream to have an effect. */
+int vgx_merge_uv(vgx_ctx* ctx, const vgx_cache_desc* a, const vgx_cache_desc* b, const uint32_t* b_draw, const void* b_uv, const vgx_draw* draws, uint64_t ndraws,
+                 const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream);
 
 /* ---- command-list byte-code as input ---------------------------------------------
  * vg::CommandList::m_CommandBuffer as the reference's cl* functions write it (src/vg.cpp:243-247, 2403-2690, 5694-5723):
@@ -404,7 +413,8 @@ int vgx_merge(vgx_ctx* ctx, const vgx_cache_desc* a, const vgx_cache_desc* b, co
  * Concave fills (PathType::Concave) become draws with VGX_FILL_CONCAVE [| VGX_FILL_AA] [| VGX_FILL_EVEN_ODD] and no
  * VGX_FILL_ENABLE: vgx_tessellate makes no mesh for them, the caller builds it (vgx_flatten_* -> libtess2 -> vgx_concave_move /
  * vgx_concave_emit) and vgx_merge puts it at the draw's place in the frame.
- * Commands without an equivalent here are counted in num_skipped and otherwise ignored: Text / TextBox, IndexedTriList,
+ * IndexedTriList commands become draws with VGX_FILL_TRILIST; their meshes come back in vgx_cmdlist_out::tri_*.
+ * Commands without an equivalent here are counted in num_skipped and otherwise ignored: Text / TextBox,
  * path commands issued after a path's first fill / stroke
  * without a new BeginPath (the reference VG_CHECKs this, :2984-3059), nested lists without a table entry.
  * Host only, no device needed; re-entrant (no shared state between calls). `bytes` must be 4-byte aligned (the reference's
@@ -417,6 +427,8 @@ typedef struct vgx_cmdlist_ref {   /* one vg::CommandList, addressed by CommandL
 enum { VGX_CL_CACHEABLE = 1u,      /* CommandListFlags::Cacheable: fills / strokes ignore the global alpha and transparent
                                     * colours are not dropped while the list populates its cache (hasCache, :3063-3075) */
        VGX_CL_ALLOW_CULLING = 2u, /* CommandListFlags::AllowCommandCulling (:4299-4300, 4548-4577) */
+       VGX_CL_UV_FLOAT = 0x200u,  /* not a reference flag: the build's uv_t is float (VG_CONFIG_UV_INT16 = 0, include/vg/vg.h:27-29): IndexedTriList payloads
+                                    * carry 8 bytes of UV per vertex instead of 4 */
        VGX_CL_SCISSOR_SET = 0x100u };/* not a reference flag: vgx_cmdlist_state::scissor holds a rectangle even when it is all zero (a real
                                     * empty scissor left by an earlier list of the frame); set it when chaining vgx_cmdlist_out::end_scissor */
 typedef struct vgx_cmdlist_state { /* the Context / State values at submission */
@@ -446,6 +458,8 @@ typedef struct vgx_cmdlist_state { /* the Context / State values at submission *
 	uint32_t clip_num_draws;
 	uint32_t clip_recording;      /* 1: submitted between BeginClip and EndClip */
 	uint32_t draw_base;           /* draws decoded earlier in this frame */
+	uint32_t white_uv[2];         /* getWhitePixelUV as raw words (one word with int16 UVs): the UV of IndexedTriList vertices that come without UVs (vg.cpp:4148-4156) */
+	uint32_t font_image;          /* Context::m_FontImages[0].idx: the image an IndexedTriList with an invalid handle is drawn with (:4131-4133) */
 } vgx_cmdlist_state;
 typedef struct vgx_draw_state {   /* per draw: what allocDrawCommand copies into the DrawCommand (vg.cpp:5391-5400). 24 bytes */
 	uint16_t scissor[4];          /* (uint16_t) State::m_ScissorRect */
@@ -489,6 +503,20 @@ typedef struct vgx_cmdlist_out {
 	uint32_t end_clip_rule, end_clip_first_draw, end_clip_num_draws, end_clip_recording;
 	float end_scissor[4];     /* out: State::m_ScissorRect after the list (chain it with VGX_CL_SCISSOR_SET: it may be a real empty rectangle) */
 	uint32_t reserved;
+	/* IndexedTriList commands (user meshes, vg.cpp:4129-4175 / 4461-4477): one draw each (VGX_FILL_TRILIST, state_key = Textured |
+	 * image) and the mesh in these HOST arrays, ready to be uploaded as a sequence for vgx_merge: positions through the state
+	 * transform at the command (batchTransformPositions), one colour per vertex (a single colour replicated, :4160-4165), the
+	 * command's UVs or the white-pixel UV, indices mesh-local; tri_meshes[k].draw = the draw's index in this decode,
+	 * subpath_kind = VGX_MESH_TRILIST << 28. The count pass reports num_tri_*; a store pass over a list that holds such commands
+	 * without these arrays (or with too small ones) returns VGX_E_NOSPACE -- never a frame with a mesh silently missing.
+	 * tri_uv alone may be NULL (no UVs wanted). */
+	float* tri_pos;           /* HOST [cap_tri_vertices][2] */
+	uint32_t* tri_color;      /* HOST [cap_tri_vertices] */
+	void* tri_uv;             /* HOST [cap_tri_vertices][4 or 8 bytes (VGX_CL_UV_FLOAT)] */
+	uint16_t* tri_idx;        /* HOST [cap_tri_indices] */
+	vgx_mesh* tri_meshes;     /* HOST [cap_tri_meshes] */
+	uint32_t cap_tri_vertices, cap_tri_indices, cap_tri_meshes;
+	uint32_t num_tri_vertices, num_tri_indices, num_tri_meshes; /* out */
 } vgx_cmdlist_out;
 int vgx_cmdlist_decode(const void* bytes, uint32_t size, const vgx_cmdlist_state* state, vgx_cmdlist_out* out);
 

@@ -78,6 +78,8 @@ def load(path=None):
     lib.vgr_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.vgr_get_params.argtypes = [C.c_void_p, C.c_void_p]
     lib.vgr_white_uv.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+    lib.vgr_font_image.restype = C.c_uint32
+    lib.vgr_font_image.argtypes = [C.c_void_p]
     lib.vgr_num_vertex_buffers.restype = C.c_uint32
     lib.vgr_num_vertex_buffers.argtypes = [C.c_void_p]
     lib.vgr_vertex_buffer.restype = C.c_int
@@ -172,6 +174,9 @@ class RefContext:
         p = np.zeros(2, np.float32)
         self.lib.vgr_get_params(self.h, p.ctypes.data)
         return dict(tess_tol=float(p[0]), fringe=float(p[1]))
+
+    def font_image(self):
+        return int(self.lib.vgr_font_image(self.h))
 
     def white_uv(self):
         raw = np.zeros(2, np.uint32)

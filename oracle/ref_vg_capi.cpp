@@ -197,6 +197,15 @@ uint32_t vgr_op(void* h, uint32_t cl, uint32_t op, const float* f, const uint32_
 	case CT::TransformMult: rec ? vg::clTransformMult(ctx, L, f, (vg::TransformOrder::Enum)u[0]) : vg::transformMult(ctx, f, (vg::TransformOrder::Enum)u[0]); break;
 	case CT::SetViewBox: rec ? vg::clSetViewBox(ctx, L, f[0], f[1], f[2], f[3]) : vg::setViewBox(ctx, f[0], f[1], f[2], f[3]); break;
 	case CT::SetGlobalAlpha: rec ? vg::clSetGlobalAlpha(ctx, L, f[0]) : vg::setGlobalAlpha(ctx, f[0]); break;
+	case CT::IndexedTriList: { // f = pos[2 * nv]; u = {nv, hasUV, nc, ni, image idx (0xFFFF = invalid), colours[nc], uv words[hasUV ? nv * sizeof(uv_t) * 2 / 4 : 0], indices packed two per word}
+		const uint32_t nv = u[0], hasUV = u[1], nc = u[2], ni = u[3];
+		const vg::ImageHandle img = { (uint16_t)u[4] };
+		const vg::Color* col = (const vg::Color*)(u + 5);
+		const uint32_t uvWords = hasUV ? nv * (uint32_t)(sizeof(vg::uv_t) * 2 / 4) : 0;
+		const vg::uv_t* uv = hasUV ? (const vg::uv_t*)(u + 5 + nc) : nullptr;
+		const uint16_t* idx = (const uint16_t*)(u + 5 + nc + uvWords);
+		if (rec) { vg::clIndexedTriList(ctx, L, f, uv, nv, col, nc, idx, ni, img); } else { vg::indexedTriList(ctx, f, uv, nv, col, nc, idx, ni, img); }
+	} break;
 	case CT::SubmitCommandList: rec ? vg::clSubmitCommandList(ctx, L, clh(u[0])) : vg::submitCommandList(ctx, clh(u[0])); break; // u = {child}
 	default: return 0xFFFFFFFFu;
 	}
@@ -216,6 +225,7 @@ void vgr_get_params(void* h, float* tessTolFringe2)
 	vg::Context* ctx = ((Ref*)h)->ctx;
 	tessTolFringe2[0] = ctx->m_TesselationTolerance; tessTolFringe2[1] = ctx->m_FringeWidth;
 }
+uint32_t vgr_font_image(void* h) { return ((Ref*)h)->ctx->m_FontImages[0].idx; } // the image ctxIndexedTriList falls back to (vg.cpp:4131-4133)
 void vgr_white_uv(void* h, void* out, uint32_t* bytesPerUV)
 {
 	const vg::uv_t* uv = vg::getWhitePixelUV(((Ref*)h)->ctx);

@@ -72,7 +72,8 @@ class Recorder:
 
 
 def decode(rt, data, mtx=(1, 0, 0, 1, 0, 0), global_alpha=1.0, tess_tol=0.25, fringe=1.0, canvas=(1280.0, 720.0), flags=0,
-           lists=None, first_gradient=0, first_image_pattern=0, extra=None, scissor=None, prev_cmd_scissor=None, first_generation=0, clip=None, draw_base=0):
+           lists=None, first_gradient=0, first_image_pattern=0, extra=None, scissor=None, prev_cmd_scissor=None, first_generation=0, clip=None, draw_base=0,
+           white_uv=None, font_image=0, uv_float=False):
     """vgx_cmdlist_decode, count pass + store pass. Returns (status, PathSetArrays or None, draws ndarray, info dict).
     lists: {handle: (bytes, flags)} for SubmitCommandList. extra: dict that receives draw_state / paints / the out struct."""
     import ctypes as C
@@ -96,6 +97,11 @@ def decode(rt, data, mtx=(1, 0, 0, 1, 0, 0), global_alpha=1.0, tess_tol=0.25, fr
         st.prev_cmd_valid = 1
     st.first_generation = first_generation
     st.draw_base = draw_base
+    st.font_image = font_image         # ctx->m_FontImages[0].idx: the image of colour draws and of IndexedTriList without one
+    if white_uv is not None:           # getWhitePixelUV: the UV of tri-list vertices that come without UVs
+        st.white_uv[0], st.white_uv[1] = int(white_uv[0]), int(white_uv[1])
+    if uv_float:
+        st.flags |= 0x200              # VGX_CL_UV_FLOAT: uv_t = float (VG_CONFIG_UV_INT16 = 0)
     if clip is not None:               # (valid, rule, first draw, draws, recording): the previous decode's end_clip_*
         st.clip_valid, st.clip_rule, st.clip_first_draw, st.clip_num_draws, st.clip_recording = [int(x) for x in clip]
     keep = []
@@ -124,10 +130,18 @@ def decode(rt, data, mtx=(1, 0, 0, 1, 0, 0), global_alpha=1.0, tess_tol=0.25, fr
     out.cmd_type, out.cmd_arg_off, out.args, out.path_cmd_begin, out.draws = (cmd_type.ctypes.data, arg_off.ctypes.data, args.ctypes.data, pcb.ctypes.data, draws.ctypes.data)
     out.draw_state, out.paints = dstate.ctypes.data, paints.ctypes.data
     out.cap_cmds, out.cap_args, out.cap_paths, out.cap_draws, out.cap_paints = n["cmds"], n["args"], n["paths"], n["draws"], npaints
+    tv, ti, tm = int(out.num_tri_vertices), int(out.num_tri_indices), int(out.num_tri_meshes)
+    tri = dict(pos=np.zeros((max(tv, 1), 2), np.float32), color=np.zeros(max(tv, 1), np.uint32),
+               uv=np.zeros((max(tv, 1), 2), np.float32 if uv_float else np.int16), idx=np.zeros(max(ti, 1), np.uint16),
+               meshes=np.zeros(max(tm, 1), capi.mesh_dtype))
+    if tm:
+        out.tri_pos, out.tri_color, out.tri_uv, out.tri_idx, out.tri_meshes = (tri[k].ctypes.data for k in ("pos", "color", "uv", "idx", "meshes"))
+        out.cap_tri_vertices, out.cap_tri_indices, out.cap_tri_meshes = tv, ti, tm
     rc = rt.lib().vgx_cmdlist_decode(buf, len(data), C.byref(st), C.byref(out))
     ps = pathset.PathSetArrays(cmd_type[:n["cmds"]], arg_off, args[:n["args"]], pcb)
     if extra is not None:
         extra["draw_state"] = dstate[:n["draws"]]
         extra["paints"] = paints[:npaints]
         extra["out"] = out
+        extra["tri"] = dict(pos=tri["pos"][:tv], color=tri["color"][:tv], uv=tri["uv"][:tv], idx=tri["idx"][:ti], meshes=tri["meshes"][:tm])
     return rc, ps, draws[:n["draws"]], n

@@ -30,7 +30,7 @@ def _polygons(ref, contours, even_odd):
     return verts, idx
 
 
-def gpu_frame(rt, ctx, ref, ps, draws, max_vb, uv_bytes=4, uv_value=0):
+def gpu_frame(rt, ctx, ref, ps, draws, max_vb, uv_bytes=4, uv_value=0, tri=None):
     """Whole frame on the device + libtess2 on the host. Returns the dict tests/test_cmdlist_ref.py::gpu_frame returns."""
     import torch
     capi = rt.capi
@@ -122,8 +122,34 @@ def gpu_frame(rt, ctx, ref, ps, draws, max_vb, uv_bytes=4, uv_value=0):
         bnv = bni = 0
         seq_b = rt.mesh_seq(B, 0, 0, 0)
         bd = None
-    # ---- the frame: A and B interleaved by draw, assembled
-    nv, ni, nm = sa["num_vertices"] + bnv, sa["num_indices"] + bni, sa["num_meshes"] + nf
+    seq_a = rt.mesh_seq(A, sa["num_vertices"], sa["num_indices"], sa["num_meshes"])
+    anv, ani, anm = sa["num_vertices"], sa["num_indices"], sa["num_meshes"]
+    b_uv = None
+    if tri is not None and tri["meshes"].shape[0]:
+        # ---- user meshes (IndexedTriList): the decoder's tri_* arrays, uploaded, are a third sequence. Both external
+        # sequences are sorted by draw on their own, so: (A + concave) first, without assembly, then (that + user meshes)
+        if nf:
+            AB = rt.MeshBuffers(dev, anv + bnv, ani + bni, anm + nf)
+            rt.merge(ctx, seq_a, seq_b, bd, dd, n, AB)
+            torch.cuda.synchronize()
+            assert int(AB.dev_status.item()) == 0
+            anv, ani, anm = anv + bnv, ani + bni, anm + nf
+            seq_a = rt.mesh_seq(AB, anv, ani, anm)
+        bnv, bni, nfb = tri["pos"].shape[0], tri["idx"].shape[0], tri["meshes"].shape[0]
+        B = rt.MeshBuffers(dev, bnv, bni, nfb)
+        if bnv:
+            B.pos[:bnv] = torch.from_numpy(tri["pos"]).to(dev)
+            B.color[:bnv] = torch.from_numpy(tri["color"].view(np.int32)).to(dev)
+            b_uv = torch.from_numpy(np.ascontiguousarray(tri["uv"])).to(dev)
+        if bni:
+            B.idx[:bni] = torch.from_numpy(tri["idx"].view(np.int16)).to(dev)
+        B.meshes[:nfb * 32] = torch.from_numpy(tri["meshes"].view(np.uint8).copy()).to(dev)
+        seq_b = rt.mesh_seq(B, bnv, bni, nfb)
+        bd = None  # the records' own draw fields
+    else:
+        nfb = nf
+    # ---- the frame: the sequences interleaved by draw, assembled
+    nv, ni, nm = anv + bnv, ani + bni, anm + nfb
     out = rt.MeshBuffers(dev, nv, ni, nm)
     cmds = torch.zeros((nm + 2) * 48, dtype=torch.uint8, device=dev)
     ncmd = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -131,7 +157,7 @@ def gpu_frame(rt, ctx, ref, ps, draws, max_vb, uv_bytes=4, uv_value=0):
     uvw = uv_value if isinstance(uv_value, (tuple, list)) else (uv_value, 0)
     ctx.set_assembly(cmds, max_vb, ncmd, split_state=True, uv=uv, uv_value=tuple(int(x) for x in uvw))
     try:
-        rt.merge(ctx, rt.mesh_seq(A, sa["num_vertices"], sa["num_indices"], sa["num_meshes"]), seq_b, bd, dd, n, out)
+        rt.merge(ctx, seq_a, seq_b, bd, dd, n, out, b_uv_dev=b_uv)
         torch.cuda.synchronize()
     finally:
         ctx.set_assembly(None)

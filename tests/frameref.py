@@ -35,11 +35,13 @@ def reference_frames(script, pres, canvas=(1280, 720), max_vb=65536, flags=0):
     return outs
 
 
-def reference_frame(script, canvas=(1280, 720), max_vb=65536, flags=0, children=(), immediate=False, pre=None, frames=1, uv_float=False):
+def reference_frame(script, canvas=(1280, 720), max_vb=65536, flags=0, children=(), immediate=False, pre=None, frames=1, uv_float=False, images=0):
     """Play one frame on the reference. children: [(Script, flags)] recorded first (handles 0..), the root list after
     them. Returns dict(frame=Frame, bytes=root bytes, lists={handle: (bytes, flags)}, root=handle, params, state0)."""
     with R.RefContext(max_vb_vertices=max_vb, uv_float=uv_float) as rc:  # uv_float: the VG_CONFIG_UV_INT16=0 build of the reference
         lists = {}
+        img = [rc.create_image(8, 8) for _ in range(images)]  # user images (handles after the font atlas) for IndexedTriList
+        assert all(h != 0xFFFF for h in img)
         for cs, cf in children:
             h, b = record(rc, cs, cf)
             lists[h] = (b, cf)
@@ -59,7 +61,8 @@ def reference_frame(script, canvas=(1280, 720), max_vb=65536, flags=0, children=
                 rc.op(R.IMMEDIATE, R.SubmitCommandList, (), (root,))
             fr = rc.end()
             cache = rc.cache(root) if (not immediate and (flags & R.CL_CACHEABLE)) else None
-            out = dict(frame=fr, bytes=data, lists=lists, root=root, params=rc.params(), state0=st0, white_uv=rc.white_uv(), cache=cache)
+            out = dict(frame=fr, bytes=data, lists=lists, root=root, params=rc.params(), state0=st0, white_uv=rc.white_uv(), cache=cache,
+                       font_image=rc.font_image(), uv_float=uv_float)
             rc.next_frame()
         return out
 
@@ -70,7 +73,8 @@ def decode(rt, ref, canvas=(1280, 720), flags=0):
     extra = {}
     rc, ps, draws, n = cu.decode(rt, ref["bytes"], mtx=st0["mtx"].tolist(), global_alpha=st0["global_alpha"], tess_tol=ref["params"]["tess_tol"],
                                  fringe=ref["params"]["fringe"], canvas=(float(canvas[0]), float(canvas[1])), flags=flags,
-                                 lists={h: v for h, v in ref["lists"].items() if h != ref["root"]}, extra=extra)
+                                 lists={h: v for h, v in ref["lists"].items() if h != ref["root"]}, extra=extra,
+                                 white_uv=ref["white_uv"][0] if "white_uv" in ref else None, font_image=ref.get("font_image", 0), uv_float=ref.get("uv_float", False))
     assert rc == 0, rc
     return ps, draws, n, extra
 

@@ -69,14 +69,16 @@ def test_state_commands_and_stroke_scaling(rt, wl):
     r.begin_path(); r.circle(1, 1, 4)
     r.fill_path(0xFFFFFFFF, cu.fill_flags(aa=False))
     r.set_scissor(0, 0, 10, 10)                                          # folded into the draws' scissor + state_key generation
-    r.fill_path(0xFFFFFFFF, cu.fill_flags(concave=True))                # concave: skipped (libtess2 stays with the caller)
+    r.fill_path(0xFFFFFFFF, cu.fill_flags(concave=True))                # concave: a draw without a GPU mesh (libtess2 stays with the caller)
     r.fill_path(0x00FFFFFF, cu.fill_flags())                            # alpha 0: the reference returns early, not "skipped"
     r.fill_path_gradient(cu.fill_flags(), 1, 0)                         # gradient paint: a draw of type ColorGradient, handle 1
     extra = {}
     rc, ps, draws, n = cu.decode(rt, r.bytes(), extra=extra)
-    assert rc == 0 and n["paths"] == 2 and n["draws"] == 5 and n["skipped"] == 1
-    assert int(draws["state_key"][4]) == (1 << 20) | (1 << 16) | 1 and int(draws["fill_color"][4]) == 0xFF000000
-    assert extra["draw_state"]["scissor"][4].tolist() == [0, 0, 10, 10] and extra["draw_state"]["scissor"][3].tolist() == [0, 0, 1280, 720]
+    assert rc == 0 and n["paths"] == 2 and n["draws"] == 6 and n["skipped"] == 0
+    capi = rt.capi
+    assert int(draws["fill_flags"][4]) == capi.FILL_CONCAVE | capi.FILL_AA and int(draws["fill_color"][4]) == 0xFFFFFFFF  # PopState restored the global alpha
+    assert int(draws["state_key"][5]) == (1 << 20) | (1 << 16) | 1 and int(draws["fill_color"][5]) == 0xFF000000
+    assert extra["draw_state"]["scissor"][5].tolist() == [0, 0, 10, 10] and extra["draw_state"]["scissor"][3].tolist() == [0, 0, 1280, 720]
     # the state arithmetic, restated (float32 throughout, vg.cpp:4044-4082, 4927-4935; cos / sin are csrc/vgmath.h's)
     f32 = np.float32
     m = np.array([1, 0, 0, 1, 0, 0], f32)

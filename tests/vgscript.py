@@ -57,6 +57,22 @@ class Script:
     def begin_clip(self, rule): return self.add(R.BeginClip, (), (rule,))
     def end_clip(self): return self.add(R.EndClip)
     def reset_clip(self): return self.add(R.ResetClip)
+    def indexed_tri_list(self, pos, colors, idx, uv=None, image=0xFFFF):
+        """vg::indexedTriList / clIndexedTriList (vg.h:476, 509). uv: None or an (nv, 2) array of the build's uv_t (int16 / float32)."""
+        pos = np.asarray(pos, np.float32).reshape(-1, 2)
+        colors = np.asarray(colors, np.uint32).reshape(-1)
+        idx = np.asarray(idx, np.uint16).reshape(-1)
+        words = [np.asarray([pos.shape[0], 0 if uv is None else 1, colors.shape[0], idx.shape[0], image], np.uint32), colors]
+        if uv is not None:
+            uv = np.ascontiguousarray(uv)
+            assert uv.shape == (pos.shape[0], 2) and uv.dtype in (np.int16, np.float32)
+            words.append(uv.reshape(-1).view(np.uint32))
+        packed = np.zeros((idx.shape[0] + 1) // 2 * 2, np.uint16)
+        packed[:idx.shape[0]] = idx
+        words.append(packed.view(np.uint32))
+        self.ops.append((R.IndexedTriList, pos.reshape(-1).copy(), np.concatenate(words)))
+        return self
+
     def submit(self, child): return self.add(R.SubmitCommandList, (), (child,))
 
     def play(self, rc, cl):

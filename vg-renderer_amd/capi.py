@@ -18,6 +18,7 @@ VGX_E_NO_DEVICE = 7
 VGX_E_RANGE = 8
 VGX_E_INTERNAL = 9
 VGX_E_STALE = 10
+FILL_TRILIST = 0x40  # vgx_draw.fill_flags: a user mesh (IndexedTriList): the decoder's tri_* arrays + vgx_merge_uv
 FILL_CONCAVE, FILL_EVEN_ODD = 0x10, 0x20  # vgx_draw.fill_flags: a concave fill (no GPU mesh: libtess2 + vgx_concave_* + vgx_merge)
 
 CMD_MOVE_TO, CMD_LINE_TO, CMD_CUBIC_TO, CMD_QUAD_TO, CMD_CLOSE = 0, 1, 2, 3, 4
@@ -32,7 +33,7 @@ FILL_ENABLE, FILL_AA = 0x1, 0x2
 FILL_INDEX_ORDER_SSE = 0x100  # strokerConvexFillAA indices in the order of the reference's SSE2 variant (stroker.cpp:610-701)
 STROKE_ENABLE, STROKE_AA, STROKE_THIN = 0x1, 0x2, 0x4
 
-MESH_FILL, MESH_FILL_AA, MESH_STROKE, MESH_STROKE_AA, MESH_STROKE_AA_THIN, MESH_CONCAVE_FILL_AA = 0, 1, 2, 3, 4, 5
+MESH_FILL, MESH_FILL_AA, MESH_STROKE, MESH_STROKE_AA, MESH_STROKE_AA_THIN, MESH_CONCAVE_FILL_AA, MESH_TRILIST = 0, 1, 2, 3, 4, 5, 6
 
 
 def stroke_flags(cap, join, aa=True, thin=False):
@@ -135,7 +136,7 @@ class CmdListState(C.Structure):
                 ("num_lists", C.c_uint32), ("lists", C.POINTER(CmdListRef)), ("prev_cmd_scissor", C.c_uint16 * 4),
                 ("prev_cmd_valid", C.c_uint32), ("first_generation", C.c_uint32),
                 ("clip_valid", C.c_uint32), ("clip_rule", C.c_uint32), ("clip_first_draw", C.c_uint32), ("clip_num_draws", C.c_uint32),
-                ("clip_recording", C.c_uint32), ("draw_base", C.c_uint32)]
+                ("clip_recording", C.c_uint32), ("draw_base", C.c_uint32), ("white_uv", C.c_uint32 * 2), ("font_image", C.c_uint32)]
 
 
 class CmdListOut(C.Structure):
@@ -146,7 +147,10 @@ class CmdListOut(C.Structure):
                 ("num_skipped", C.c_uint32), ("next_gradient", C.c_uint32), ("next_image_pattern", C.c_uint32), ("next_generation", C.c_uint32),
                 ("end_mtx", C.c_float * 6), ("end_global_alpha", C.c_float),
                 ("end_clip_valid", C.c_uint32), ("end_clip_rule", C.c_uint32), ("end_clip_first_draw", C.c_uint32), ("end_clip_num_draws", C.c_uint32),
-                ("end_clip_recording", C.c_uint32), ("end_scissor", C.c_float * 4), ("reserved", C.c_uint32)]
+                ("end_clip_recording", C.c_uint32), ("end_scissor", C.c_float * 4), ("reserved", C.c_uint32),
+                ("tri_pos", C.c_void_p), ("tri_color", C.c_void_p), ("tri_uv", C.c_void_p), ("tri_idx", C.c_void_p), ("tri_meshes", C.c_void_p),
+                ("cap_tri_vertices", C.c_uint32), ("cap_tri_indices", C.c_uint32), ("cap_tri_meshes", C.c_uint32),
+                ("num_tri_vertices", C.c_uint32), ("num_tri_indices", C.c_uint32), ("num_tri_meshes", C.c_uint32)]
 
 
 draw_state_dtype = np.dtype([("scissor", "<u2", (4,)), ("clip_rule", "<u4"), ("clip_first_draw", "<u4"), ("clip_num_draws", "<u4"), ("raw_color", "<u4")])
@@ -154,6 +158,7 @@ paint_dtype = np.dtype([("type", "<u4"), ("handle", "<u4"), ("matrix", "<f4", (9
                         ("outer_color", "<f4", (4,)), ("image", "<u4")])
 assert draw_state_dtype.itemsize == 24 and paint_dtype.itemsize == 96
 CL_CACHEABLE, CL_ALLOW_CULLING = 1, 2
+CL_SCISSOR_SET, CL_UV_FLOAT = 0x100, 0x200  # vgx_cmdlist_state.flags (host-side switches, not CommandListFlags)
 
 
 class FailureInfo(C.Structure):
@@ -177,6 +182,7 @@ VGX_SYMBOLS = {
     "vgx_set_assembly": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vgx_cache_localize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "vgx_merge": (C.c_int, [C.c_void_p, C.POINTER(CacheDesc), C.POINTER(CacheDesc), C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(MeshOut), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vgx_merge_uv": (C.c_int, [C.c_void_p, C.POINTER(CacheDesc), C.POINTER(CacheDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(MeshOut), C.c_void_p, C.c_void_p, C.c_void_p]),
     "vgx_cache_submit": (C.c_int, [C.c_void_p, C.POINTER(CacheDesc), C.c_void_p, C.c_uint64, C.POINTER(MeshOut), C.c_void_p, C.c_void_p, C.c_void_p]),
     "vgx_last_hip_error": (C.c_int, [C.c_void_p]),
     "vgx_status_string": (C.c_char_p, [C.c_int]),

@@ -1518,6 +1518,12 @@ int vgx_cache_submit(vgx_ctx* ctx, const vgx_cache_desc* cache, const vgx_cache_
 int vgx_merge(vgx_ctx* ctx, const vgx_cache_desc* a, const vgx_cache_desc* b, const uint32_t* b_draw, const vgx_draw* draws, uint64_t ndraws,
               const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream)
 {
+	return vgx_merge_uv(ctx, a, b, b_draw, nullptr, draws, ndraws, out, dev_sizes, dev_status, stream);
+}
+
+int vgx_merge_uv(vgx_ctx* ctx, const vgx_cache_desc* a, const vgx_cache_desc* b, const uint32_t* b_draw, const void* b_uv, const vgx_draw* draws, uint64_t ndraws,
+                 const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream)
+{
 	DeviceGuard guard(ctx);
 	(void)ndraws;
 	if (!ctx || !a || !b || !out || !out->pos || !out->color || !out->idx
@@ -1550,6 +1556,7 @@ int vgx_merge(vgx_ctx* ctx, const vgx_cache_desc* a, const vgx_cache_desc* b, co
 	if (ctx->asmArmed) {
 		if ((st = runAssemble(ctx, out, s, draws)) != VGX_OK) { return st; }
 		m.mesh_base = (const uint32_t*)ctx->meshBase.p;
+		if (b_uv && ctx->asmCfg.uv && ctx->asmCfg.uv_bytes) { m.b_uv = b_uv; m.uv_out = ctx->asmCfg.uv; m.uv_bytes = ctx->asmCfg.uv_bytes; }
 	}
 	vgx_launch_merge_copy(m, s);
 	mark(ctx, s, "merge_copy");

@@ -143,6 +143,8 @@ struct Decoder
 	uint32_t subPts = 0, pathMaxPts = 0; bool pathCurved = false; // vertices of the current path's line-only sub-paths (current one / largest finished one)
 	float subFirst[2] = { 0, 0 }, subLast[2] = { 0, 0 };
 	uint32_t rawColor = 0; // Color operand of the paint command being decoded (vgx_draw_state::raw_color)
+	bool emitHasMesh = false; // the draw being emitted certainly allocates a draw command (IndexedTriList)
+	uint32_t ntriM = 0, ntriV = 0, ntriI = 0; // IndexedTriList meshes / vertices / indices so far
 	void emit(uint32_t type, uint32_t handle, uint32_t fillFlags, uint32_t fillColor, uint32_t strokeFlags, uint32_t strokeColor, float strokeWidth)
 	{
 		const St& s = S();
@@ -177,7 +179,7 @@ struct Decoder
 		// (A curve that flattens to fewer vertices than the stroker's minimum is not seen here.)
 		const bool isFill = fillFlags != 0;
 		const uint32_t mostPts = subPts > pathMaxPts ? subPts : pathMaxPts;
-		const bool noMesh = !pathCurved && mostPts < (isFill ? 3u : 2u);
+		const bool noMesh = !emitHasMesh && !pathCurved && mostPts < (isFill ? 3u : 2u);
 		if (type != DT_Clip && !noMesh) { memcpy(lastScissor, sc, sizeof(sc)); haveLastScissor = true; }
 		++ndraws;
 	}
@@ -305,7 +307,7 @@ int Decoder::run(const uint8_t* p, uint32_t size, uint32_t listFlags)
 			latch();
 			const bool aa = clip ? false : (flags & 0x04u) != 0;
 			const uint32_t dt = clip ? (uint32_t)DT_Clip : (img ? (uint32_t)DT_ImagePattern : (uint32_t)DT_Textured);
-			const uint32_t handle = clip ? 0xFFFFu : (img ? localHandle(u16at(8), u16at(10), firstImagePatternID) : 0u);
+			const uint32_t handle = clip ? 0xFFFFu : (img ? localHandle(u16at(8), u16at(10), firstImagePatternID) : (st0->font_image & 0xFFFFu)); // colour = Textured on the font atlas (createDrawCommand_VertexColor, vg.cpp:5210-5211)
 			// PathType::Concave (:3133-3178): libtess2 stays with the caller -- a draw without a GPU mesh, see VGX_FILL_CONCAVE
 			const uint32_t how = (flags & 0x01u) ? (VGX_FILL_CONCAVE | ((flags & 0x10u) ? VGX_FILL_EVEN_ODD : 0u)) : (uint32_t)VGX_FILL_ENABLE;
 			emit(dt, handle, how | (aa ? VGX_FILL_AA : 0u), col, 0, 0, 0.0f);
@@ -336,7 +338,7 @@ int Decoder::run(const uint8_t* p, uint32_t size, uint32_t listFlags)
 			if (!havePath) { ++nskipped; break; }
 			latch();
 			const bool aa = recordClip ? false : (flags & 0x10u) != 0;
-			emit(recordClip ? (uint32_t)DT_Clip : (uint32_t)DT_Textured, recordClip ? 0xFFFFu : 0u, 0, 0, strokeFlagsOf(flags, aa, w.thin), col, w.width);
+			emit(recordClip ? (uint32_t)DT_Clip : (uint32_t)DT_Textured, recordClip ? 0xFFFFu : (st0->font_image & 0xFFFFu), 0, 0, strokeFlagsOf(flags, aa, w.thin), col, w.width);
 		} break;
 		case CT_StrokePathGradient: { // float width, uint32 flags, uint16 handle, uint16 handle flags (:2671-2681); ctxStrokePathGradient :3494-3576
 			if (!need(12)) { return VGX_E_INVALID_ARG; }
@@ -507,7 +509,55 @@ int Decoder::run(const uint8_t* p, uint32_t size, uint32_t listFlags)
 			const int rc = run((const uint8_t*)L.bytes, L.size, L.flags);
 			if (rc != VGX_OK) { return rc; }
 		} break;
-		default: ++nskipped; break; // Text, TextBox, IndexedTriList
+		case CT_IndexedTriList: { // uint32 nv, float2 pos[nv], uint32 nuv, uv_t2 uv[nuv], uint32 nc, Color col[nc], uint32 ni, uint16 idx[ni], uint16 image
+			// (clIndexedTriList vg.cpp:2566-2611; interpreter :4461-4477 -> ctxIndexedTriList :4129-4175)
+			const uint32_t uvBytes = (st0->flags & VGX_CL_UV_FLOAT) ? 8u : 4u;
+			uint64_t off = 0;
+			if (!need(4)) { return VGX_E_INVALID_ARG; }
+			const uint32_t nv = u32at(0); off = 4;
+			if (nv > 65536u || off + (uint64_t)nv * 8 + 4 > psize) { return VGX_E_INVALID_ARG; }
+			const uint32_t oPos = (uint32_t)off; off += (uint64_t)nv * 8;
+			const uint32_t nuv = u32at((uint32_t)off); off += 4;
+			if ((nuv != 0 && nuv != nv) || off + (uint64_t)nuv * uvBytes + 4 > psize) { return VGX_E_INVALID_ARG; }
+			const uint32_t oUv = (uint32_t)off; off += (uint64_t)nuv * uvBytes;
+			const uint32_t nc = u32at((uint32_t)off); off += 4;
+			if ((nc != nv && nc != 1) || off + (uint64_t)nc * 4 + 4 > psize) { return VGX_E_INVALID_ARG; } // VG_CHECK(numColors == 1), :4163
+			const uint32_t oCol = (uint32_t)off; off += (uint64_t)nc * 4;
+			const uint32_t ni = u32at((uint32_t)off); off += 4;
+			if (off + (uint64_t)ni * 2 + 2 > psize) { return VGX_E_INVALID_ARG; }
+			const uint32_t oIdx = (uint32_t)off; off += (uint64_t)ni * 2;
+			const uint16_t img = u16at((uint32_t)off);
+			rawColor = 0;
+			const uint32_t handle = img == 0xFFFFu ? st0->font_image : (uint32_t)img; // !isValid(img): the font atlas (:4131-4133)
+			if (store) { // no tri_* arrays in the store pass = capacity 0: VGX_E_NOSPACE, never a silently dropped mesh
+				if (!out->tri_meshes || !out->tri_pos || !out->tri_color || !out->tri_idx || ntriM >= out->cap_tri_meshes || (uint64_t)ntriV + nv > out->cap_tri_vertices || (uint64_t)ntriI + ni > out->cap_tri_indices) { overflow = true; }
+				else {
+					const float* m = S().m; // the state's transform at the command, not the path's latch
+					for (uint32_t k = 0; k < nv; ++k) { // vgutil::batchTransformPositions, vg_util.cpp:266-272 (transformPos2D)
+						const float x = f32at(oPos + 8 * k), y = f32at(oPos + 8 * k + 4);
+						out->tri_pos[2 * (ntriV + k)] = m[0] * x + m[2] * y + m[4]; out->tri_pos[2 * (ntriV + k) + 1] = m[1] * x + m[3] * y + m[5];
+						out->tri_color[ntriV + k] = u32at(oCol + (nc == nv ? 4 * k : 0));
+					}
+					if (out->tri_uv) {
+						uint8_t* dst = (uint8_t*)out->tri_uv + (size_t)ntriV * uvBytes;
+						if (nuv) { memcpy(dst, d + oUv, (size_t)nv * uvBytes); }
+						else { for (uint32_t k = 0; k < nv; ++k) { memcpy(dst + (size_t)k * uvBytes, st0->white_uv, uvBytes); } }
+					}
+					if (ni) { memcpy(out->tri_idx + ntriI, d + oIdx, (size_t)ni * 2); }
+					vgx_mesh& mr = out->tri_meshes[ntriM];
+					mr.first_vertex = ntriV; mr.first_index = ntriI; mr.num_vertices = nv; mr.num_indices = ni;
+					mr.draw = ndraws; mr.subpath_kind = (uint32_t)VGX_MESH_TRILIST << 28;
+				}
+			}
+			++ntriM; ntriV += nv; ntriI += ni;
+			if (!havePath) { beginPath(); } // the draw record needs SOME valid path index: an empty path when none is open
+			emitHasMesh = true; // allocDrawCommand runs whatever the mesh holds (:4137): the PopState rule sees a draw command
+			emit(DT_Textured, handle, VGX_FILL_TRILIST, 0, 0, 0, 0.0f);
+			emitHasMesh = false;
+			// the draw record carries the state transform (informative: the positions above are already transformed)
+			if (store && ndraws - 1 < out->cap_draws) { memcpy(out->draws[ndraws - 1].mtx, S().m, sizeof(float) * 6); }
+		} break;
+		default: ++nskipped; break; // Text, TextBox
 		}
 	}
 	--depth;
@@ -556,6 +606,7 @@ extern "C" int vgx_cmdlist_decode(const void* bytes, uint32_t size, const vgx_cm
 	D.closePathRecord();
 	out->num_paths = D.npaths; out->num_cmds = D.ncmd; out->num_args = D.nargs; out->num_draws = D.ndraws; out->num_paints = D.npaints;
 	out->num_skipped = D.nskipped;
+	out->num_tri_meshes = D.ntriM; out->num_tri_vertices = D.ntriV; out->num_tri_indices = D.ntriI;
 	out->next_gradient = D.nextGradient; out->next_image_pattern = D.nextImagePattern;
 	out->next_generation = D.generation + (D.forceNew ? 1u : 0u);
 	memcpy(out->end_mtx, D.S().m, sizeof(float) * 6);

@@ -138,6 +138,9 @@ struct VgxMergeArgs
 	uint32_t* color;
 	uint16_t* idx;
 	const uint32_t* mesh_base; // assembly armed: index base per merged mesh; else null
+	const void* b_uv;          // per-vertex UVs of sequence B (may be null), uv_bytes each
+	void* uv_out;              // the armed assembly's UV stream (null: none)
+	uint32_t uv_bytes;
 	VgxTotals* totals;
 	VgxCaps caps;
 };

@@ -100,6 +100,12 @@ __global__ __launch_bounds__(256) void k_merge_copy(VgxMergeArgs A)
 		for (uint32_t i = lane; i < sm.num_indices; i += 64) {
 			A.idx[dm.first_index + i] = (uint16_t)(S.idx[sm.first_index + i] + base); // uint16 wrap = the reference's cast, vg_util.cpp:447
 		}
+		if (fromB && A.b_uv && A.uv_out) { // user meshes with texture coordinates: over the white-pixel UV the assembly step wrote
+			const uint32_t words = A.uv_bytes / 4;
+			const uint32_t* src = (const uint32_t*)A.b_uv + (size_t)sm.first_vertex * words;
+			uint32_t* dst = (uint32_t*)A.uv_out + (size_t)dm.first_vertex * words;
+			for (uint32_t i = lane; i < sm.num_vertices * words; i += 64) { dst[i] = src[i]; }
+		}
 	}
 }
 

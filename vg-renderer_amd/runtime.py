@@ -338,10 +338,12 @@ def mesh_seq(bufs, nv, ni, nm):
     return capi.CacheDesc(bufs.pos.data_ptr(), bufs.color.data_ptr(), bufs.idx.data_ptr(), bufs.meshes.data_ptr(), int(nm), int(nv), int(ni))
 
 
-def merge(ctx, seq_a, seq_b, b_draw_dev, draws_dev, ndraws, bufs):
+def merge(ctx, seq_a, seq_b, b_draw_dev, draws_dev, ndraws, bufs, b_uv_dev=None):
     """Both sequences interleaved by draw index into `bufs` (honours an armed assembly). b_draw_dev: int32 device tensor, the
-    frame draw of every mesh of seq_b (or None). Asynchronous; totals / status land in bufs.dev_*."""
+    frame draw of every mesh of seq_b (or None). b_uv_dev: per-vertex UVs of seq_b (IndexedTriList meshes), copied into the
+    armed assembly's UV stream. Asynchronous; totals / status land in bufs.dev_*."""
     out = bufs.out_struct()
-    _check(lib().vgx_merge(ctx.handle, C.byref(seq_a), C.byref(seq_b), b_draw_dev.data_ptr() if b_draw_dev is not None else None,
-                           draws_dev.data_ptr() if draws_dev is not None else None, ndraws, C.byref(out),
-                           bufs.dev_sizes.data_ptr(), bufs.dev_status.data_ptr(), _stream_ptr()), "vgx_merge")
+    _check(lib().vgx_merge_uv(ctx.handle, C.byref(seq_a), C.byref(seq_b), b_draw_dev.data_ptr() if b_draw_dev is not None else None,
+                              b_uv_dev.data_ptr() if b_uv_dev is not None else None,
+                              draws_dev.data_ptr() if draws_dev is not None else None, ndraws, C.byref(out),
+                              bufs.dev_sizes.data_ptr(), bufs.dev_status.data_ptr(), _stream_ptr()), "vgx_merge_uv")

@@ -114,6 +114,10 @@ struct VgxTessApi
 void vgxCompatSetTessellator(const VgxTessApi* api); // copied; nullptr removes it
 // Device used by subsequently created Path / Stroker objects (default 0). Last status of an object (vgx_status).
 void vgxCompatSetDevice(int device);
+// 0 = auto (host; the device for vertex lists of at least VGX_COMPAT_DEVICE_MIN vertices), 1 = host, 2 = device. Default: the
+// environment variable VGX_COMPAT_BACKEND (host | device | auto). Host = the product's per-lane code executed on the CPU, ~1 us per
+// call and no GPU needed; device = one C-ABI call sequence per call. Same bits either way.
+void vgxCompatSetBackend(int backend);
 int vgxCompatLastStatus(const Path* path);
 int vgxCompatLastStatus(const Stroker* stroker);
 }

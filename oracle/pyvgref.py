@@ -50,6 +50,9 @@ def available():
 
 
 PATH_UV_FLOAT = os.path.join(_HERE, "_ref", "libvgref_vg_uvf.so")  # the same sources with -DVG_CONFIG_UV_INT16=0 (float UVs)
+# the reference's Context with its path.cpp / stroker.cpp replaced by the product's libvgx_compat.so (oracle/Makefile): the
+# drop-in check of SURVEY 8(b), played by tests/test_compat_context.py
+PATH_COMPAT = os.path.join(_HERE, "_ref", "libvgref_vg_compat.so")
 _libs = {}
 
 
@@ -117,8 +120,8 @@ class RefContext:
     """One vg::Context of the reference. `cl` arguments: IMMEDIATE plays a call on the Context (vg::xxx), a command
     list handle records it with the reference's own vg::clXxx writer."""
 
-    def __init__(self, max_vb_vertices=65536, max_command_lists=256, max_gradients=64, max_image_patterns=64, uv_float=False):
-        self.lib = load(PATH_UV_FLOAT if uv_float else None)
+    def __init__(self, max_vb_vertices=65536, max_command_lists=256, max_gradients=64, max_image_patterns=64, uv_float=False, compat=False):
+        self.lib = load(PATH_COMPAT if compat else (PATH_UV_FLOAT if uv_float else None))
         self.uv_dtype = np.float32 if uv_float else np.int16
         self.h = self.lib.vgr_create(max_vb_vertices, max_command_lists, max_gradients, max_image_patterns)
 

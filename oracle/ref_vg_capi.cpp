@@ -18,6 +18,21 @@
 
 #include <bx/allocator.h>
 
+#if VGR_WITH_COMPAT
+// oracle/_ref/libvgref_vg_compat.so: the same Context, but vg::createPath .. vg::strokerConcaveFillEndAA resolve to the PRODUCT's
+// libvgx_compat.so instead of the reference's path.cpp / stroker.cpp (which are not linked); libtess2 is the caller's, as in an
+// application: handed over once.
+#include "vgx_compat.hpp"
+#include "libtess2/tesselator.h"
+static void vgrInstallTess()
+{
+	static const vg::VgxTessApi api = { (void* (*)(void*))tessNewTess, (void (*)(void*))tessDeleteTess, (void (*)(void*, int, const void*, int, int))tessAddContour,
+		(int (*)(void*, int, int, int, int, const float*))tessTesselate, (int (*)(void*))tessGetVertexCount, (const float* (*)(void*))tessGetVertices,
+		(int (*)(void*))tessGetElementCount, (const unsigned short* (*)(void*))tessGetElements };
+	vg::vgxCompatSetTessellator(&api);
+}
+#endif
+
 namespace {
 struct Ref
 {
@@ -72,6 +87,9 @@ void* vgr_create(uint32_t maxVBVertices, uint32_t maxCommandLists, uint32_t maxG
 {
 	Ref* r = new Ref;
 	++g_liveContexts;
+#if VGR_WITH_COMPAT
+	vgrInstallTess();
+#endif
 	vg::ContextConfig cfg;
 	cfg.m_MaxGradients = (uint16_t)(maxGradients ? maxGradients : 64);
 	cfg.m_MaxImagePatterns = (uint16_t)(maxImagePatterns ? maxImagePatterns : 64);

@@ -29,8 +29,49 @@ static void compareMesh(const M1& a, const M2& b, bool posAliased, const char* w
 	(void)posAliased;
 }
 
+#include <chrono>
+// VGX_COMPAT_TIMING=1: the cost of one drawing (a path of 8 cubics: reset + moveTo + 8 cubicTo + close + the getters, then
+// convexFillAA + polylineStrokeAA of the result) through the product's API and through the oracle, per call sequence.
+template<class FN>
+static double timeIt(FN fn, int reps)
+{
+	fn();
+	const auto t0 = std::chrono::steady_clock::now();
+	for (int i = 0; i < reps; ++i) { fn(); }
+	return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+}
+static void timing()
+{
+	bx::ShimAllocator alloc;
+	vg::Path* gp = vg::createPath(&alloc); vg::Stroker* gs = vg::createStroker(&alloc);
+	vgo::Path* op = vgo::createPath(&alloc); vgo::Stroker* os = vgo::createStroker(&alloc);
+	if (!gp || !gs) { printf("timing: no backend\n"); return; }
+	float c[8][6];
+	for (int k = 0; k < 8; ++k) { const float a0 = 0.785398f * k, a1 = 0.785398f * (k + 1); c[k][0] = 100 + 60 * cosf(a0) - 20 * sinf(a0); c[k][1] = 100 + 60 * sinf(a0) + 20 * cosf(a0); c[k][2] = 100 + 60 * cosf(a1) + 20 * sinf(a1); c[k][3] = 100 + 60 * sinf(a1) - 20 * cosf(a1); c[k][4] = 100 + 60 * cosf(a1); c[k][5] = 100 + 60 * sinf(a1); }
+	uint32_t sink = 0;
+	const double tg = timeIt([&]() {
+		vg::pathReset(gp, 1.0f, 0.25f); vg::pathMoveTo(gp, 160, 100);
+		for (int k = 0; k < 8; ++k) { vg::pathCubicTo(gp, c[k][0], c[k][1], c[k][2], c[k][3], c[k][4], c[k][5]); }
+		vg::pathClose(gp);
+		const vg::SubPath* sp = vg::pathGetSubPaths(gp); const float* v = vg::pathGetVertices(gp);
+		vg::Mesh m; vg::strokerConvexFillAA(gs, &m, v, sp[0].m_NumVertices, 0xFF112233u); sink += m.m_NumIndices;
+		vg::strokerPolylineStrokeAA(gs, &m, v, sp[0].m_NumVertices, true, 0xFF445566u, 3.0f, vg::LineCap::Butt, vg::LineJoin::Miter); sink += m.m_NumIndices;
+	}, 20000);
+	const double to = timeIt([&]() {
+		vgo::pathReset(op, 1.0f, 0.25f); vgo::pathMoveTo(op, 160, 100);
+		for (int k = 0; k < 8; ++k) { vgo::pathCubicTo(op, c[k][0], c[k][1], c[k][2], c[k][3], c[k][4], c[k][5]); }
+		vgo::pathClose(op);
+		const vgo::SubPath* sp = vgo::pathGetSubPaths(op); const float* v = vgo::pathGetVertices(op);
+		vgo::Mesh m; vgo::strokerConvexFillAA(os, &m, v, sp[0].m_NumVertices, 0xFF112233u); sink += m.m_NumIndices;
+		vgo::strokerPolylineStrokeAA(os, &m, v, sp[0].m_NumVertices, true, 0xFF445566u, 3.0f, vgo::LineCap::Butt, vgo::LineJoin::Miter); sink += m.m_NumIndices;
+	}, 20000);
+	printf("timing: one drawing (14 API calls, %u path vertices): product %.2f us, oracle restatement %.2f us (%u)\n", vg::pathGetNumVertices(gp), tg, to, sink);
+	vg::destroyStroker(gs); vg::destroyPath(gp); vgo::destroyStroker(os); vgo::destroyPath(op);
+}
+
 int main()
 {
+	if (getenv("VGX_COMPAT_TIMING")) { timing(); return 0; }
 	bx::ShimAllocator alloc;
 	// the caller's allocator (bx::AllocatorI, path.cpp:23-30 / stroker.cpp:194-200): object + host arrays must come from it
 	struct Counting : public bx::ShimAllocator

@@ -35,10 +35,11 @@ def reference_frames(script, pres, canvas=(1280, 720), max_vb=65536, flags=0):
     return outs
 
 
-def reference_frame(script, canvas=(1280, 720), max_vb=65536, flags=0, children=(), immediate=False, pre=None, frames=1, uv_float=False, images=0):
+def reference_frame(script, canvas=(1280, 720), max_vb=65536, flags=0, children=(), immediate=False, pre=None, frames=1, uv_float=False, images=0, compat=False):
     """Play one frame on the reference. children: [(Script, flags)] recorded first (handles 0..), the root list after
     them. Returns dict(frame=Frame, bytes=root bytes, lists={handle: (bytes, flags)}, root=handle, params, state0)."""
-    with R.RefContext(max_vb_vertices=max_vb, uv_float=uv_float) as rc:  # uv_float: the VG_CONFIG_UV_INT16=0 build of the reference
+    # uv_float: the VG_CONFIG_UV_INT16=0 build of the reference; compat: the reference's vg.cpp over the product's libvgx_compat.so
+    with R.RefContext(max_vb_vertices=max_vb, uv_float=uv_float, compat=compat) as rc:
         lists = {}
         img = [rc.create_image(8, 8) for _ in range(images)]  # user images (handles after the font atlas) for IndexedTriList
         assert all(h != 0xFFFF for h in img)

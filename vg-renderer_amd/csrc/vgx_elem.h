@@ -9,6 +9,12 @@
 #include "vgx_internal.h"
 #include "vgx_wave.h"
 
+// Per-element functions (one lane = one polyline vertex of one mesh) are host + device: the kernels of vgx_stroke.hip /
+// vgx_tmpl.hip run them one element per lane, the host backend of the per-call compat layer (host/vgx_host_backend.hip)
+// runs the same functions element after element. The wave-level drivers (stroke_chunk*, fill_emit_chunk, round_mesh_size)
+// are device only.
+#define VGX_EL __host__ __device__ __forceinline__
+
 namespace {
 
 // Tuning builds only (profiles/ab_variants.sh): VGX_EXP_NOSTORE makes every output store of the element kernels conditional
@@ -22,9 +28,9 @@ namespace {
 
 struct Rails { uint32_t a, b, c, d; }; // AA: laa,l,r,raa   non-AA: l,r,-,-   thin: laa,m,raa,-
 
-__device__ __forceinline__ Rails rails(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { Rails r; r.a = a; r.b = b; r.c = c; r.d = d; return r; }
-__device__ __forceinline__ uint64_t rails_pack(Rails r) { return (uint64_t)(r.a & 0xFFFFu) | ((uint64_t)(r.b & 0xFFFFu) << 16) | ((uint64_t)(r.c & 0xFFFFu) << 32) | ((uint64_t)(r.d & 0xFFFFu) << 48); }
-__device__ __forceinline__ Rails rails_unpack(uint64_t p) { return rails((uint32_t)(p & 0xFFFFu), (uint32_t)((p >> 16) & 0xFFFFu), (uint32_t)((p >> 32) & 0xFFFFu), (uint32_t)(p >> 48)); }
+VGX_EL Rails rails(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { Rails r; r.a = a; r.b = b; r.c = c; r.d = d; return r; }
+VGX_EL uint64_t rails_pack(Rails r) { return (uint64_t)(r.a & 0xFFFFu) | ((uint64_t)(r.b & 0xFFFFu) << 16) | ((uint64_t)(r.c & 0xFFFFu) << 32) | ((uint64_t)(r.d & 0xFFFFu) << 48); }
+VGX_EL Rails rails_unpack(uint64_t p) { return rails((uint32_t)(p & 0xFFFFu), (uint32_t)((p >> 16) & 0xFFFFu), (uint32_t)((p >> 32) & 0xFFFFu), (uint32_t)(p >> 48)); }
 
 // Unaligned wide stores: the output streams are only element-aligned (8 / 4 / 2 bytes); gfx950 global stores handle
 // that natively (unaligned access mode), so one lane can issue ONE dwordx4 for two positions, ONE dwordx3 for six
@@ -50,40 +56,40 @@ struct StrokeWriter
 	uint32_t sc[4];
 	uint32_t si[24];
 	uint32_t nvS, niS; // staged vertex / index counts (niS is a multiple of 6)
-	__device__ __forceinline__ void reset()
+	VGX_EL void reset()
 	{
 		for (int i = 0; i < 4; ++i) { sx[i] = 0.0f; sy[i] = 0.0f; sc[i] = 0; }
 		for (int i = 0; i < 24; ++i) { si[i] = 0; }
 		nvS = 0; niS = 0;
 	}
 	// ---- staged (slot = compile-time constant at every call site) ----
-	__device__ __forceinline__ void sv(uint32_t slot, V2 p, uint32_t c)
+	VGX_EL void sv(uint32_t slot, V2 p, uint32_t c)
 	{
 		sx[slot] = p.x; sy[slot] = p.y; sc[slot] = c;
 		nvS = nvS > slot + 1 ? nvS : slot + 1;
 	}
-	__device__ __forceinline__ void stri(uint32_t slot, uint32_t a, uint32_t b, uint32_t c)
+	VGX_EL void stri(uint32_t slot, uint32_t a, uint32_t b, uint32_t c)
 	{
 		si[slot] = a; si[slot + 1] = b; si[slot + 2] = c;
 		niS = niS > slot + 3 ? niS : slot + 3;
 	}
-	__device__ __forceinline__ void sbridge4(uint32_t slot, Rails p, Rails c) // stroker.cpp:1557-1564, 1714-1721, 1973-1980
+	VGX_EL void sbridge4(uint32_t slot, Rails p, Rails c) // stroker.cpp:1557-1564, 1714-1721, 1973-1980
 	{
 		stri(slot, p.a, p.b, c.b); stri(slot + 3, p.a, c.b, c.a);
 		stri(slot + 6, p.b, p.c, c.c); stri(slot + 9, p.b, c.c, c.b);
 		stri(slot + 12, p.c, p.d, c.d); stri(slot + 15, p.c, c.d, c.c);
 	}
-	__device__ __forceinline__ void sbridge2(uint32_t slot, Rails p, Rails c) // stroker.cpp:1119-1122, 1217-1220, 1374-1377
+	VGX_EL void sbridge2(uint32_t slot, Rails p, Rails c) // stroker.cpp:1119-1122, 1217-1220, 1374-1377
 	{
 		stri(slot, p.a, p.b, c.b); stri(slot + 3, p.a, c.b, c.a);
 	}
-	__device__ __forceinline__ void sbridge3(uint32_t slot, Rails p, Rails c) // stroker.cpp:2093-2098, 2175-2180, 2299-2304
+	VGX_EL void sbridge3(uint32_t slot, Rails p, Rails c) // stroker.cpp:2093-2098, 2175-2180, 2299-2304
 	{
 		stri(slot, p.a, p.b, c.b); stri(slot + 3, p.a, c.b, c.a);
 		stri(slot + 6, p.b, p.c, c.c); stri(slot + 9, p.b, c.c, c.b);
 	}
 	// ---- direct ----
-	__device__ __forceinline__ void v(uint32_t i, V2 p, uint32_t c) const
+	VGX_EL void v(uint32_t i, V2 p, uint32_t c) const
 	{
 		VGX_ST_GUARD(c) {
 		*(float2*)(pos + 2 * (size_t)i) = make_float2(p.x, p.y);
@@ -91,7 +97,7 @@ struct StrokeWriter
 		}
 	}
 	// two consecutive vertices in one 16-byte + one 8-byte store (the arc loops of Round joins / caps write pairs)
-	__device__ __forceinline__ void v2(uint32_t i, V2 p, uint32_t c, V2 q, uint32_t d) const
+	VGX_EL void v2(uint32_t i, V2 p, uint32_t c, V2 q, uint32_t d) const
 	{
 		VGX_ST_GUARD(c ^ d) {
 		PosPair pp; pp.x0 = p.x; pp.y0 = p.y; pp.x1 = q.x; pp.y1 = q.y;
@@ -101,7 +107,7 @@ struct StrokeWriter
 		}
 	}
 	// three consecutive triangles (18 contiguous bytes) in one 16-byte + one 2-byte store
-	__device__ __forceinline__ void tri3(uint32_t k, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t c0, uint32_t c1, uint32_t c2) const
+	VGX_EL void tri3(uint32_t k, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t c0, uint32_t c1, uint32_t c2) const
 	{
 		Idx9 t;
 		t.a = ((a0 + ib) & 0xFFFFu) | ((a1 + ib) << 16); t.b = ((a2 + ib) & 0xFFFFu) | ((b0 + ib) << 16);
@@ -109,32 +115,32 @@ struct StrokeWriter
 		t.e = (uint16_t)(c2 + ib);
 		VGX_ST_GUARD(t.a ^ t.d) { *(Idx9*)(idx + k) = t; }
 	}
-	__device__ __forceinline__ void tri(uint32_t k, uint32_t a, uint32_t b, uint32_t c) const
+	VGX_EL void tri(uint32_t k, uint32_t a, uint32_t b, uint32_t c) const
 	{
 		Idx3 t; t.a = ((a + ib) & 0xFFFFu) | ((b + ib) << 16); t.b = (uint16_t)(c + ib);
 		VGX_ST_GUARD(t.a) { *(Idx3*)(idx + k) = t; }
 	}
-	__device__ __forceinline__ void bridge4(uint32_t k, Rails p, Rails c) const
+	VGX_EL void bridge4(uint32_t k, Rails p, Rails c) const
 	{
 		tri(k, p.a, p.b, c.b); tri(k + 3, p.a, c.b, c.a);
 		tri(k + 6, p.b, p.c, c.c); tri(k + 9, p.b, c.c, c.b);
 		tri(k + 12, p.c, p.d, c.d); tri(k + 15, p.c, c.d, c.c);
 	}
-	__device__ __forceinline__ void bridge2(uint32_t k, Rails p, Rails c) const
+	VGX_EL void bridge2(uint32_t k, Rails p, Rails c) const
 	{
 		tri(k, p.a, p.b, c.b); tri(k + 3, p.a, c.b, c.a);
 	}
-	__device__ __forceinline__ void bridge3(uint32_t k, Rails p, Rails c) const
+	VGX_EL void bridge3(uint32_t k, Rails p, Rails c) const
 	{
 		tri(k, p.a, p.b, c.b); tri(k + 3, p.a, c.b, c.a);
 		tri(k + 6, p.b, p.c, c.c); tri(k + 9, p.b, c.c, c.b);
 	}
 	// the staged part of the element whose first vertex is b and first index k
-	__device__ __forceinline__ void flush(uint32_t b, uint32_t k) const
+	VGX_EL void flush(uint32_t b, uint32_t k) const
 	{
 		VGX_ST_GUARD(sc[0] ^ si[0] ^ si[7] ^ __float_as_uint(sx[3]) ^ __float_as_uint(sy[1]) ^ sc[3] ^ si[23] ^ si[13]) { flush_(b, k); }
 	}
-	__device__ __forceinline__ void flush_(uint32_t b, uint32_t k) const
+	VGX_EL void flush_(uint32_t b, uint32_t k) const
 	{
 		float* pp = pos + 2 * (size_t)b;
 		uint32_t* pc = col + b;
@@ -189,9 +195,9 @@ struct VtxGlobal
 {
 	const float2* p;
 #ifdef VGX_EXP_NOLOAD
-	__device__ __forceinline__ V2 ld(uint32_t i) const { const uint32_t h = (i + (uint32_t)(size_t)p) * 2654435761u; return v2((float)(h & 1023u), (float)((h >> 10) & 1023u)); }
+	VGX_EL V2 ld(uint32_t i) const { const uint32_t h = (i + (uint32_t)(size_t)p) * 2654435761u; return v2((float)(h & 1023u), (float)((h >> 10) & 1023u)); }
 #else
-	__device__ __forceinline__ V2 ld(uint32_t i) const { const float2 t = p[i]; return v2(t.x, t.y); }
+	VGX_EL V2 ld(uint32_t i) const { const float2 t = p[i]; return v2(t.x, t.y); }
 #endif
 };
 template<class VS>
@@ -205,7 +211,7 @@ struct MeshCtxT
 };
 typedef MeshCtxT<VtxGlobal> MeshCtx;
 
-__device__ __forceinline__ V2 ldv(const float* vtx, uint32_t i)
+VGX_EL V2 ldv(const float* vtx, uint32_t i)
 {
 #ifdef VGX_EXP_NOLOAD
 	{ const uint32_t h = (i + (uint32_t)(size_t)vtx) * 2654435761u; return v2((float)(h & 1023u), (float)((h >> 10) & 1023u)); }
@@ -215,12 +221,12 @@ __device__ __forceinline__ V2 ldv(const float* vtx, uint32_t i)
 }
 
 template<class VS>
-__device__ __forceinline__ float mesh_da(const MeshCtxT<VS>& m) // stroker.cpp:1013, 1398 (da uses hsw WITHOUT the fringe)
+VGX_EL float mesh_da(const MeshCtxT<VS>& m) // stroker.cpp:1013, 1398 (da uses hsw WITHOUT the fringe)
 {
 	return vgx_step_angle(m.dr->scale, m.hsw, m.dr->tess_tol);
 }
 
-__device__ __forceinline__ MeshCtx make_mesh_ctx(const VgxMeshDesc& md, const VgxMeshPrep& pr, const vgx_draw* draws, uint32_t j, const float* poly)
+VGX_EL MeshCtx make_mesh_ctx(const VgxMeshDesc& md, const VgxMeshPrep& pr, const vgx_draw* draws, uint32_t j, const float* poly)
 {
 	MeshCtx mc;
 	mc.kind = VGX_MD_KIND(md.kind);
@@ -238,7 +244,7 @@ __device__ __forceinline__ MeshCtx make_mesh_ctx(const VgxMeshDesc& md, const Vg
 // ---- step A (strokes) --------------------------------------------------------------------------------
 // p1 = the element's polyline vertex, dPrev = vec2Dir(previous vertex, p1), d12 = vec2Dir(p1, next vertex) (cyclic).
 template<class VS>
-__device__ __forceinline__ Elem elem_geometry(const MeshCtxT<VS>& m, V2 p1, V2 dPrev, V2 d12)
+VGX_EL Elem elem_geometry(const MeshCtxT<VS>& m, V2 p1, V2 dPrev, V2 d12)
 {
 	Elem e;
 	e.nv = 0; e.ni = 0; e.et = ET_JOIN; e.leftInner = true; e.hasConnect = false; e.closesLoop = false;
@@ -307,7 +313,7 @@ __device__ __forceinline__ Elem elem_geometry(const MeshCtxT<VS>& m, V2 p1, V2 d
 }
 
 template<class VS>
-__device__ __forceinline__ uint32_t elem_total_indices(const MeshCtxT<VS>& m, const Elem& e)
+VGX_EL uint32_t elem_total_indices(const MeshCtxT<VS>& m, const Elem& e)
 {
 	const uint32_t bridgeIdx = (m.kind == VGX_MESH_STROKE) ? 6u : (m.kind == VGX_MESH_STROKE_AA ? 18u : 12u);
 	return e.ni + (e.hasConnect ? bridgeIdx : 0u) + (e.closesLoop ? bridgeIdx : 0u);
@@ -315,7 +321,7 @@ __device__ __forceinline__ uint32_t elem_total_indices(const MeshCtxT<VS>& m, co
 
 // ---- exit rails (what the next element connects to) ---------------------------------------------------
 template<class VS>
-__device__ __forceinline__ Rails elem_exit_rails(const MeshCtxT<VS>& m, const Elem& e, uint32_t b)
+VGX_EL Rails elem_exit_rails(const MeshCtxT<VS>& m, const Elem& e, uint32_t b)
 {
 	if (m.kind == VGX_MESH_STROKE_AA) {
 		if (e.et == ET_CAP_FIRST) {
@@ -351,7 +357,7 @@ __device__ __forceinline__ Rails elem_exit_rails(const MeshCtxT<VS>& m, const El
 
 // entry rails of join 0 of a closed stroke = the firstSegment*ID of the reference
 template<class VS>
-__device__ __forceinline__ Rails first_join_entry(const MeshCtxT<VS>& m, bool leftInner0)
+VGX_EL Rails first_join_entry(const MeshCtxT<VS>& m, bool leftInner0)
 {
 	if (m.kind == VGX_MESH_STROKE_AA) { return leftInner0 ? rails(0, 1, 2, 3) : rails(3, 2, 1, 0); }
 	if (m.kind == VGX_MESH_STROKE) { return leftInner0 ? rails(0, 1, 0, 0) : rails(1, 0, 0, 0); }
@@ -363,7 +369,7 @@ __device__ __forceinline__ Rails first_join_entry(const MeshCtxT<VS>& m, bool le
 // writer's register stage (sv / stri / sbridgeN, slot numbers relative to b / k) and leave in a handful of wide stores
 // after the call; variable-size pieces (Round caps and joins, the closing bridge) are written directly.
 template<class VS, class W>
-__device__ __forceinline__ void elem_emit(const MeshCtxT<VS>& m, const Elem& e, uint32_t b, uint32_t k, Rails prev, W& w)
+VGX_EL void elem_emit(const MeshCtxT<VS>& m, const Elem& e, uint32_t b, uint32_t k, Rails prev, W& w)
 {
 	const uint32_t N = m.N;
 	const uint32_t color = w.color, c0 = w.c0;
@@ -640,7 +646,7 @@ __device__ __forceinline__ void elem_emit(const MeshCtxT<VS>& m, const Elem& e, 
 }
 
 // ---- per-mesh preparation ------------------------------------------------------------------------------
-__device__ __forceinline__ VgxMeshPrep mesh_prep(const VgxMeshDesc& md, const vgx_draw* dr, const float* poly)
+VGX_EL VgxMeshPrep mesh_prep(const VgxMeshDesc& md, const vgx_draw* dr, const float* poly)
 {
 	VgxMeshPrep pr;
 	const uint32_t kind = VGX_MD_KIND(md.kind);
@@ -745,7 +751,7 @@ __device__ __forceinline__ void stroke_chunk(bool valid, bool laneHasNext, int n
 // register stage of step D fall away: positions, colours and indices are computed and stored directly, same values and
 // same addresses as stroke_chunk (which handles a chunk as soon as one of its elements is anything else; the carry
 // both maintain makes the two interchangeable chunk by chunk). 568 -> ~250 VALU instructions per chunk on the tiger.
-__device__ __forceinline__ bool stroke_elem_is_simple(uint32_t kind, bool closed, uint32_t join)
+VGX_EL bool stroke_elem_is_simple(uint32_t kind, bool closed, uint32_t join)
 {
 	return closed && join == VGX_JOIN_MITER && (kind == VGX_MESH_STROKE_AA || kind == VGX_MESH_STROKE_AA_THIN);
 }
@@ -903,7 +909,7 @@ struct FillFetch
 };
 
 // The nine index values [9j, 9j+9) of a convex AA fill mesh with N corners (element j), scalar or SSE order.
-__device__ __forceinline__ void fill_idx9(uint32_t j, uint32_t N, uint32_t ibase, bool sseOrder, uint32_t* val)
+VGX_EL void fill_idx9(uint32_t j, uint32_t N, uint32_t ibase, bool sseOrder, uint32_t* val)
 {
 	struct { uint32_t ibase; bool sseOrder; } F; F.ibase = ibase; F.sseOrder = sseOrder;
 #ifdef VGX_EXP_CHEAPMATH
@@ -940,7 +946,7 @@ __device__ __forceinline__ void fill_idx9(uint32_t j, uint32_t N, uint32_t ibase
 #endif
 }
 
-__device__ __forceinline__ void fill_emit_store(float* pos, uint32_t* color_out, uint16_t* idx_out, const FillFetch& F, V2 dPrev, V2 d12);
+VGX_EL void fill_emit_store(float* pos, uint32_t* color_out, uint16_t* idx_out, const FillFetch& F, V2 dPrev, V2 d12);
 
 __device__ __forceinline__ void fill_emit_chunk(float* pos, uint32_t* color_out, uint16_t* idx_out, const FillFetch& F)
 {
@@ -967,7 +973,7 @@ __device__ __forceinline__ void fill_emit_chunk(float* pos, uint32_t* color_out,
 // The stores of one fill element whose two edge directions are known (dPrev = vec2Dir(previous corner, p1), d12 =
 // vec2Dir(p1, next corner)); fill_emit_chunk gets them from the neighbouring lanes, the template emitter (vgx_tmpl.hip)
 // computes them per lane.
-__device__ __forceinline__ void fill_emit_store(float* pos, uint32_t* color_out, uint16_t* idx_out, const FillFetch& F, V2 dPrev, V2 d12)
+VGX_EL void fill_emit_store(float* pos, uint32_t* color_out, uint16_t* idx_out, const FillFetch& F, V2 dPrev, V2 d12)
 {
 	const bool valid = F.valid;
 	const uint32_t j = F.j, N = F.N, color = F.color;

@@ -1,8 +1,15 @@
-// vgx_compat.cpp -- vg::pathXXX / vg::strokerXXX (include/vgx_compat.hpp) implemented on the C-ABI of libvgx.so.
-// Host plumbing only: command recording, staging buffers, one vgx_* call sequence per API call. Geometry is
-// computed by the HIP kernels; there is no CPU implementation here.
+// vgx_compat.cpp -- vg::pathXXX / vg::strokerXXX (include/vgx_compat.hpp): the reference's per-call API (include/vg/path.h:19-38,
+// include/vg/stroker.h:11-85) over the product. Two ways to serve a call ("implement them on the host -- one GPU
+// launch per strokerXXX call would be ~10 us for ~1 us of work"):
+//   host   the product's lane code (csrc/vgx_pathsim.h, vgx_elem.h, vgx_concave_lane.h -- what the kernels run per lane)
+//          executed element after element by host/vgx_host_backend.hip: ~1 us per call, no device needed;
+//   device one vgx_* call sequence on the C-ABI of libvgx.so per API call (staging copies + HIP kernels).
+// VGX_COMPAT_BACKEND=host|device|auto (or vgxCompatSetBackend) picks; auto = host, and the device for vertex lists of at least
+// VGX_COMPAT_DEVICE_MIN vertices (default 16384). Both produce the same bits (tests/compat_test.cpp runs every call on both).
+// This file is plumbing: command recording, arrays from the caller's allocator, the libtess2 hand-over. Nothing under oracle/.
 #include "../../include/vgx_compat.hpp"
 #include "../../include/vgx.h"
+#include "vgx_host_backend.h"
 #include <hip/hip_runtime_api.h>
 #include <vector>
 #include <new>
@@ -53,6 +60,27 @@ struct BxAlloc
 template<class T> using Vec = std::vector<T, BxAlloc<T>>;
 
 int g_device = 0;
+enum { kBackendAuto = 0, kBackendHost = 1, kBackendDevice = 2 };
+int g_backend = -1;          // -1: not read from the environment yet
+uint32_t g_deviceMin = 16384;
+int backend()
+{
+	if (g_backend < 0) {
+		const char* e = getenv("VGX_COMPAT_BACKEND");
+		g_backend = (e && !strcmp(e, "host")) ? kBackendHost : ((e && !strcmp(e, "device")) ? kBackendDevice : kBackendAuto);
+		const char* m = getenv("VGX_COMPAT_DEVICE_MIN");
+		if (m && *m) { g_deviceMin = (uint32_t)strtoul(m, nullptr, 10); }
+	}
+	return g_backend;
+}
+bool onDevice(uint32_t numVertices) { const int b = backend(); return b == kBackendDevice || (b == kBackendAuto && numVertices >= g_deviceMin); }
+void* bxRealloc(void* user, void* ptr, size_t bytes) // vgxh::ReallocFn over the caller's bx::AllocatorI (nullptr: the C heap)
+{
+	bx::AllocatorI* a = (bx::AllocatorI*)user;
+	if (a) { return a->realloc(ptr, bytes, 0, __FILE__, __LINE__); }
+	if (!bytes) { free(ptr); return nullptr; }
+	return realloc(ptr, bytes);
+}
 VgxTessApi g_tess = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
 bool g_hasTess = false;
 // libtess2's public constants (src/libtess2/tesselator.h:41-48, 110-115)
@@ -95,15 +123,48 @@ struct Path
 	Vec<uint8_t> types;
 	Vec<uint32_t> argOff;
 	Vec<float> args;
-	// flattened result (lazy)
+	vgxh::Path* host = nullptr; // host backend: the builder executes every command as it arrives (like the reference)
+	bool useDevice = false;     // fixed at creation / reset: a path is built by one backend from its first command on
+	bool open = false, bad = false; // host backend: a sub-path can take more vertices / the path broke the grammar (empty until reset)
+	uint32_t ncmd = 0;
+	// device backend: flattened result (lazy)
 	bool dirty = true;
 	Vec<float> verts;
 	Vec<SubPath> subs;
 	DevBuf dDraw, dPoly, dSubs;
 	explicit Path(bx::AllocatorI* a) : alloc(a), types(BxAlloc<uint8_t>(a)), argOff(BxAlloc<uint32_t>(a)), args(BxAlloc<float>(a)), verts(BxAlloc<float>(a)), subs(BxAlloc<SubPath>(a)) {}
 
+	bool ensureCtx()
+	{
+		if (ctx) { return true; }
+		status = vgx_create(g_device, &ctx);
+		return status == VGX_OK;
+	}
 	void cmd(uint8_t t, const float* a, uint32_t n)
 	{
+		if (!useDevice) {
+			// the command grammar of vgx_pathset_create (include/vgx.h; what the reference leaves undefined -- lineTo before
+			// moveTo, appending to a closed sub-path, non-finite operands -- ends as a status and an empty path on both backends)
+			if (bad) { return; }
+			int st = VGX_OK;
+			for (uint32_t i = 0; i < n; ++i) { if (!(a[i] - a[i] == 0.0f)) { st = VGX_E_NONFINITE; } }
+			const bool isShape = t >= VGX_CMD_RECT && t <= VGX_CMD_ELLIPSE;
+			if (st == VGX_OK) {
+				if (t == VGX_CMD_ARC) {
+					if (!(a[3] <= 1.0e5f && a[3] >= -1.0e5f && a[4] <= 1.0e5f && a[4] >= -1.0e5f)) { st = VGX_E_INVALID_ARG; }
+					else if (!open && ncmd != 0) { st = VGX_E_INVALID_PATH; }
+				} else if (t != VGX_CMD_MOVE_TO && !isShape && !open) {
+					st = VGX_E_INVALID_PATH;
+				} else if (t == VGX_CMD_POLYLINE && n < 2) {
+					st = VGX_E_INVALID_ARG;
+				}
+			}
+			if (st != VGX_OK) { status = st; bad = true; vgxh::pathReset(host, scale, tol); return; }
+			open = !(t == VGX_CMD_CLOSE || isShape);
+			++ncmd;
+			if (!vgxh::pathCommand(host, t, a, n)) { status = VGX_E_HIP; bad = true; vgxh::pathReset(host, scale, tol); }
+			return;
+		}
 		types.push_back(t);
 		args.insert(args.end(), a, a + n);
 		argOff.push_back((uint32_t)args.size());
@@ -117,6 +178,7 @@ struct Path
 		subs.clear();
 		status = VGX_OK;
 		if (types.empty()) { return; }
+		if (!ensureCtx()) { return; }
 		const uint32_t pcb[2] = { 0, (uint32_t)types.size() };
 		vgx_pathset_desc desc;
 		desc.cmd_type = types.data(); desc.cmd_arg_off = argOff.data(); desc.args = args.empty() ? nullptr : args.data();
@@ -158,12 +220,15 @@ struct Path
 };
 
 void vgxCompatSetDevice(int device) { g_device = device; }
+void vgxCompatSetBackend(int b) { g_backend = (b == kBackendHost || b == kBackendDevice) ? b : kBackendAuto; (void)backend(); }
 int vgxCompatLastStatus(const Path* path) { return path ? path->status : VGX_E_INVALID_ARG; }
 
 Path* createPath(bx::AllocatorI* allocator) // path.cpp:23-30: the object and its arrays come from `allocator`
 {
 	Path* p = ::new (hostAlloc(allocator, sizeof(Path))) Path(allocator);
-	if (vgx_create(g_device, &p->ctx) != VGX_OK) { p->~Path(); hostFree(allocator, p); return nullptr; }
+	p->useDevice = backend() == kBackendDevice;
+	p->host = vgxh::pathCreate(bxRealloc, allocator);
+	if (!p->host || (p->useDevice && !p->ensureCtx())) { destroyPath(p); return nullptr; } // forced device backend without a device: loud
 	p->argOff.push_back(0);
 	return p;
 }
@@ -173,9 +238,10 @@ void destroyPath(Path* path)
 	if (!path) { return; }
 	vgx_ctx* c = path->ctx;
 	bx::AllocatorI* a = path->alloc;
+	vgxh::pathDestroy(path->host);
 	path->~Path();
 	hostFree(a, path);
-	(void)vgx_destroy(c);
+	if (c) { (void)vgx_destroy(c); }
 }
 
 void pathReset(Path* path, float scale, float tol) // path.cpp:44-60
@@ -183,6 +249,10 @@ void pathReset(Path* path, float scale, float tol) // path.cpp:44-60
 	path->scale = scale; path->tol = tol;
 	path->types.clear(); path->args.clear(); path->argOff.assign(1, 0u);
 	path->dirty = true;
+	path->status = VGX_OK;
+	path->useDevice = backend() == kBackendDevice;
+	path->open = false; path->bad = false; path->ncmd = 0;
+	vgxh::pathReset(path->host, scale, tol);
 }
 
 void pathMoveTo(Path* p, float x, float y) { const float a[] = { x, y }; p->cmd(VGX_CMD_MOVE_TO, a, 2); }
@@ -199,10 +269,11 @@ void pathArc(Path* p, float x, float y, float r, float a0, float a1, Winding::En
 void pathPolyline(Path* p, const float* coords, uint32_t numPoints) { p->cmd(VGX_CMD_POLYLINE, coords, numPoints * 2); }
 void pathClose(Path* p) { p->cmd(VGX_CMD_CLOSE, nullptr, 0); }
 
-const float* pathGetVertices(const Path* path) { Path* p = const_cast<Path*>(path); p->flatten(); return p->verts.data(); }
-uint32_t pathGetNumVertices(const Path* path) { Path* p = const_cast<Path*>(path); p->flatten(); return (uint32_t)(p->verts.size() / 2); }
-const SubPath* pathGetSubPaths(const Path* path) { Path* p = const_cast<Path*>(path); p->flatten(); return p->subs.data(); }
-uint32_t pathGetNumSubPaths(const Path* path) { Path* p = const_cast<Path*>(path); p->flatten(); return (uint32_t)p->subs.size(); }
+static_assert(sizeof(SubPath) == sizeof(vgxh::SubRec) && offsetof(SubPath, m_NumVertices) == offsetof(vgxh::SubRec, n) && offsetof(SubPath, m_IsClosed) == offsetof(vgxh::SubRec, closed), "SubPath layout");
+const float* pathGetVertices(const Path* path) { Path* p = const_cast<Path*>(path); if (!p->useDevice) { return vgxh::pathVertices(p->host); } p->flatten(); return p->verts.data(); }
+uint32_t pathGetNumVertices(const Path* path) { Path* p = const_cast<Path*>(path); if (!p->useDevice) { return vgxh::pathNumVertices(p->host); } p->flatten(); return (uint32_t)(p->verts.size() / 2); }
+const SubPath* pathGetSubPaths(const Path* path) { Path* p = const_cast<Path*>(path); if (!p->useDevice) { return (const SubPath*)vgxh::pathSubPaths(p->host); } p->flatten(); return p->subs.data(); }
+uint32_t pathGetNumSubPaths(const Path* path) { Path* p = const_cast<Path*>(path); if (!p->useDevice) { return vgxh::pathNumSubPaths(p->host); } p->flatten(); return (uint32_t)p->subs.size(); }
 
 // ---------------------------------------------------------------------------------------------------
 struct Stroker
@@ -217,13 +288,35 @@ struct Stroker
 	DevBuf dPoly, dSub, dSubDraw, dDraw, dPos, dCol, dIdx;
 	void* tess = nullptr;                    // strokerConcaveFill*: the host's libtess2 object
 	DevBuf dContour, dCont, dFill, dMoved, dTessPos, dTessIdx;
-	Vec<float> moved;
-	explicit Stroker(bx::AllocatorI* a) : alloc(a), pos(BxAlloc<float>(a)), col(BxAlloc<uint32_t>(a)), idx(BxAlloc<uint16_t>(a)), moved(BxAlloc<float>(a)) {}
+	Vec<float> moved, contourCopy;
+	explicit Stroker(bx::AllocatorI* a) : alloc(a), pos(BxAlloc<float>(a)), col(BxAlloc<uint32_t>(a)), idx(BxAlloc<uint16_t>(a)), moved(BxAlloc<float>(a)), contourCopy(BxAlloc<float>(a)) {}
 
+	bool ensureCtx()
+	{
+		if (ctx) { return true; }
+		status = vgx_create(g_device, &ctx);
+		return status == VGX_OK;
+	}
+	// host backend: the element code of the kernels, one element after the other (host/vgx_host_backend.hip)
+	void runHost(Mesh* mesh, const float* vertexList, uint32_t n, bool closed, const vgx_draw& d, uint32_t kind, bool wantColor, bool aliasPos)
+	{
+		uint32_t nv = 0, ni = 0;
+		status = vgxh::meshSize(vertexList, n, closed, &d, kind, &nv, &ni);
+		if (status != VGX_OK) { return; } // mesh untouched, like the reference's invalid-configuration path (stroker.cpp:269-271)
+		pos.resize((size_t)nv * 2 + 4); col.resize((size_t)nv + 2); idx.resize((size_t)ni + 8); // slack: the element code stores pairs / triples
+		vgxh::meshEmit(vertexList, n, closed, &d, kind, pos.data(), col.data(), idx.data());
+		mesh->m_PosBuffer = aliasPos ? vertexList : pos.data();
+		mesh->m_ColorBuffer = wantColor ? col.data() : nullptr;
+		mesh->m_IndexBuffer = idx.data();
+		mesh->m_NumVertices = nv;
+		mesh->m_NumIndices = ni;
+	}
 	// One strokerXXX call = one vertex list, one op.
-	void run(Mesh* mesh, const float* vertexList, uint32_t n, bool closed, const vgx_draw& d, bool wantColor, bool aliasPos)
+	void run(Mesh* mesh, const float* vertexList, uint32_t n, bool closed, const vgx_draw& d, uint32_t kind, bool wantColor, bool aliasPos)
 	{
 		status = VGX_OK;
+		if (!onDevice(n)) { runHost(mesh, vertexList, n, closed, d, kind, wantColor, aliasPos); return; }
+		if (!ensureCtx()) { return; }
 		vgx_subpath sp;
 		sp.first_vertex = 0; sp.num_vertices = n; sp.flags = closed ? 1u : 0u;
 		const uint32_t zero = 0;
@@ -267,7 +360,7 @@ int vgxCompatLastStatus(const Stroker* s) { return s ? s->status : VGX_E_INVALID
 Stroker* createStroker(bx::AllocatorI* allocator) // stroker.cpp:194-200
 {
 	Stroker* s = ::new (hostAlloc(allocator, sizeof(Stroker))) Stroker(allocator);
-	if (vgx_create(g_device, &s->ctx) != VGX_OK) { s->~Stroker(); hostFree(allocator, s); return nullptr; }
+	if (backend() == kBackendDevice && !s->ensureCtx()) { s->~Stroker(); hostFree(allocator, s); return nullptr; } // forced device backend without a device: loud
 	return s;
 }
 
@@ -279,7 +372,7 @@ void destroyStroker(Stroker* s)
 	bx::AllocatorI* a = s->alloc;
 	s->~Stroker();
 	hostFree(a, s);
-	(void)vgx_destroy(c);
+	if (c) { (void)vgx_destroy(c); }
 }
 
 void strokerReset(Stroker* s, float scale, float tol, float fringe) { s->scale = scale; s->tol = tol; s->fringe = fringe; } // stroker.cpp:232-237
@@ -292,7 +385,7 @@ void strokerPolylineStroke(Stroker* s, Mesh* mesh, const float* vertexList, uint
 	vgx_draw d = defaultDraw(s->scale, s->tol, s->fringe);
 	d.stroke_flags = VGX_STROKE_FLAGS(cap, join, 0, 0);
 	d.stroke_width = strokeWidth;
-	s->run(mesh, vertexList, n, closed, d, false, false);
+	s->run(mesh, vertexList, n, closed, d, VGX_MESH_STROKE, false, false);
 }
 
 void strokerPolylineStrokeAA(Stroker* s, Mesh* mesh, const float* vertexList, uint32_t n, bool closed, Color color, float strokeWidth, LineCap::Enum cap, LineJoin::Enum join)
@@ -302,7 +395,7 @@ void strokerPolylineStrokeAA(Stroker* s, Mesh* mesh, const float* vertexList, ui
 	d.stroke_flags = VGX_STROKE_FLAGS(cap, join, 1, 0);
 	d.stroke_width = strokeWidth;
 	d.stroke_color = color;
-	s->run(mesh, vertexList, n, closed, d, true, false);
+	s->run(mesh, vertexList, n, closed, d, VGX_MESH_STROKE_AA, true, false);
 }
 
 void strokerPolylineStrokeAAThin(Stroker* s, Mesh* mesh, const float* vertexList, uint32_t n, bool closed, Color color, LineCap::Enum cap, LineJoin::Enum join)
@@ -312,7 +405,7 @@ void strokerPolylineStrokeAAThin(Stroker* s, Mesh* mesh, const float* vertexList
 	d.stroke_flags = VGX_STROKE_FLAGS(cap, join, 1, 1);
 	d.stroke_width = s->fringe;
 	d.stroke_color = color;
-	s->run(mesh, vertexList, n, closed, d, true, false);
+	s->run(mesh, vertexList, n, closed, d, VGX_MESH_STROKE_AA_THIN, true, false);
 }
 
 void strokerConvexFill(Stroker* s, Mesh* mesh, const float* vertexList, uint32_t n)
@@ -320,7 +413,7 @@ void strokerConvexFill(Stroker* s, Mesh* mesh, const float* vertexList, uint32_t
 	if (n < 3) { return; }
 	vgx_draw d = defaultDraw(s->scale, s->tol, s->fringe);
 	d.fill_flags = VGX_FILL_ENABLE;
-	s->run(mesh, vertexList, n, false, d, false, true); // positions alias the caller's list (stroker.cpp:360)
+	s->run(mesh, vertexList, n, false, d, VGX_MESH_FILL, false, true); // positions alias the caller's list (stroker.cpp:360)
 }
 
 void strokerConvexFillAA(Stroker* s, Mesh* mesh, const float* vertexList, uint32_t n, uint32_t color)
@@ -329,7 +422,7 @@ void strokerConvexFillAA(Stroker* s, Mesh* mesh, const float* vertexList, uint32
 	vgx_draw d = defaultDraw(s->scale, s->tol, s->fringe);
 	d.fill_flags = VGX_FILL_ENABLE | VGX_FILL_AA;
 	d.fill_color = color;
-	s->run(mesh, vertexList, n, false, d, true, false);
+	s->run(mesh, vertexList, n, false, d, VGX_MESH_FILL_AA, true, false);
 }
 
 // ---- concave fills (include/vg/stroker.h:73-85, src/stroker.cpp:809-1006) ---------------------------------------------
@@ -385,9 +478,14 @@ bool strokerConcaveFillEndAA(Stroker* s, Mesh* mesh, uint32_t color, FillRule::E
 	vgx_concave_fill fill;
 	memset(&fill, 0, sizeof(fill));
 	fill.first_contour = 0; fill.num_contours = (uint32_t)numContours; fill.color = color; fill.fringe = s->fringe;
-	// (2) moved contours: device
+	// (2) moved contours
 	s->moved.assign((size_t)numContourVerts * 2, 0.0f);
-	if (numContours > 0) {
+	const bool dev = onDevice(numContourVerts);
+	if (dev && !s->ensureCtx()) { return false; }
+	if (!dev) { // host backend: the same per-vertex function the kernels run (csrc/vgx_concave_lane.h)
+		s->contourCopy.assign(contourVerts, contourVerts + (size_t)numContourVerts * 2); // the tessellator's arrays die in step (3)
+		vgxh::concaveMove(s->contourCopy.data(), contours.data(), (uint32_t)numContours, s->fringe, s->moved.data());
+	} else if (numContours > 0) {
 		if (!s->dContour.ensure((size_t)numContourVerts * 8) || !s->dMoved.ensure((size_t)numContourVerts * 8) || !s->dCont.ensure(contours.size() * sizeof(vgx_contour)) || !s->dFill.ensure(sizeof(fill)) ||
 		    hipMemcpy(s->dContour.p, contourVerts, (size_t)numContourVerts * 8, hipMemcpyHostToDevice) != hipSuccess ||
 		    hipMemcpy(s->dCont.p, contours.data(), contours.size() * sizeof(vgx_contour), hipMemcpyHostToDevice) != hipSuccess ||
@@ -403,6 +501,18 @@ bool strokerConcaveFillEndAA(Stroker* s, Mesh* mesh, uint32_t color, FillRule::E
 	fill.num_tess_vertices = (uint32_t)g_tess.getVertexCount(s->tess);
 	fill.num_tess_indices = (uint32_t)g_tess.getElementCount(s->tess) * 3;
 	const uint32_t nv = 2 * used + fill.num_tess_vertices, ni = 6 * used + fill.num_tess_indices;
+	if (!dev) {
+		if (nv > 65536u) { s->status = VGX_E_MESH_TOO_LARGE; return false; }
+		s->pos.resize((size_t)nv * 2); s->col.resize(nv); s->idx.resize(ni);
+		vgxh::concaveEmit(s->contourCopy.data(), contours.data(), (uint32_t)numContours, s->fringe, color, g_tess.getVertices(s->tess), fill.num_tess_vertices,
+		                  g_tess.getElements(s->tess), fill.num_tess_indices, s->pos.data(), s->col.data(), s->idx.data());
+		mesh->m_PosBuffer = s->pos.data();
+		mesh->m_ColorBuffer = s->col.data();
+		mesh->m_IndexBuffer = s->idx.data();
+		mesh->m_NumVertices = nv;
+		mesh->m_NumIndices = ni;
+		return true;
+	}
 	// (2) + (4) the mesh: device
 	if (!s->dTessPos.ensure((size_t)fill.num_tess_vertices * 8 + 8) || !s->dTessIdx.ensure((size_t)fill.num_tess_indices * 2 + 8) ||
 	    !s->dPos.ensure((size_t)nv * 8 + 16) || !s->dCol.ensure((size_t)nv * 4 + 16) || !s->dIdx.ensure((size_t)ni * 2 + 16) || !s->dFill.ensure(sizeof(fill)) ||

@@ -203,6 +203,68 @@ def make_workload(wl, name, instances, rank):
     raise SystemExit("unknown --config %s (one of %s)" % (name, ", ".join(WORKLOADS)))
 
 
+def hetero_leg(rt, torch, wl, dev, local_rank, rank, world, red_dev, instances=4000, steps=5):
+    import numpy as np
+    parts = world if world > 1 else 8
+    info, err = {}, None
+    bal, nai = [(float("nan"), 0)], [(float("nan"), 0)]
+    try:  # local work only: the collective below runs whatever happens here, so that one failing rank cannot hang the others
+        ps, ops = wl.tiger_paths()
+        d = wl.tiger_varied_draws(ops, instances, first_instance=0)
+        npth = len(ops)
+        inst_scale = d["scale"].reshape(instances, npth)[:, 0]
+        order = np.argsort(inst_scale, kind="stable")  # whole instances, small scales (coarse subdivisions, few vertices) first
+        d = d.reshape(instances, npth)[order].reshape(-1)
+        n = int(d.shape[0])
+        ctx = rt.Context(local_rank)  # its own context: the headline's scratch and template stay as they are
+        pset = rt.PathSet(ctx, ps)
+        dd = rt.upload_draws(d, local_rank)
+        bounds, weights = rt.partition(ctx, pset, dd, n, parts)
+        naive = [n * k // parts for k in range(parts + 1)]
+
+        def time_range(lo, hi):
+            if hi <= lo:
+                return 0.0, 0
+            sl = dd[lo * 64:hi * 64]
+            sz = rt.tessellate_count(ctx, pset, sl, hi - lo)
+            bufs = rt.MeshBuffers(dev, sz["num_vertices"], sz["num_indices"], sz["num_meshes"])
+            for _ in range(2):
+                rt.tessellate_async(ctx, pset, sl, hi - lo, bufs)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                rt.tessellate_async(ctx, pset, sl, hi - lo, bufs)
+            torch.cuda.synchronize(dev)
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            assert int(bufs.dev_status.item()) == 0
+            return ms, int(sz["num_vertices"])
+
+        mine = [rank] if world > 1 else list(range(parts))
+        bal = [time_range(bounds[k], bounds[k + 1]) for k in mine]
+        nai = [time_range(naive[k], naive[k + 1]) for k in mine]
+        pset.close()
+        ctx.close()
+        info = {"workload": "Tiger x%d at 7 scales (0.5 .. 3.5), instances sorted by scale (%d draws)" % (instances, n), "parts": parts,
+                "how": "one rank per part" if world > 1 else "parts timed one after the other on one GPU",
+                "vgx_partition_bounds": [int(b) for b in bounds], "predicted_weight_max_over_min": round(max(weights) / max(1, min(weights)), 4)}
+    except Exception as e:  # noqa: BLE001
+        err = repr(e)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([bal[0][0], float(bal[0][1]), nai[0][0], float(nai[0][1])], dtype=torch.float64, device=red_dev)
+        each = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(each, t)
+        bal = [(float(e[0]), int(e[1])) for e in each]
+        nai = [(float(e[2]), int(e[3])) for e in each]
+    if err is not None:
+        return {"error": err}
+    bm, nm = [round(x[0], 3) for x in bal], [round(x[0], 3) for x in nai]
+    info.update({"balanced_ms": bm, "balanced_verts": [x[1] for x in bal], "balanced_max_over_min": round(max(bm) / max(1e-9, min(bm)), 3),
+                 "equal_count_ms": nm, "equal_count_verts": [x[1] for x in nai], "equal_count_max_over_min": round(max(nm) / max(1e-9, min(nm)), 3),
+                 "slowest_rank_gain": round(max(nm) / max(1e-9, max(bm)), 3)})
+    return info
+
+
 def run_config(rt, torch, ctx, local_rank, name, ps, draws, kind, steps, warmup, barrier, placements=1):
     """Times `steps` steps of one workload (inputs resident in HBM) between barriers. Returns a dict with the wall time,
     the output sizes, the per-kernel HIP-event times (averaged over a few extra steps outside the timed region) and the
@@ -499,50 +561,59 @@ def main():
                 # base + the tiles in front) runs on the second stream while tile t + 1 is tessellated. One frame's latency,
                 # gather included, without a second set of output buffers. Tiles have the same shape (same drawing per instance),
                 # so one count call sizes them all.
-                try:
-                    T = int(os.environ.get("VGX_BENCH_GATHER_TILES", "4"))
-                    if args.config.startswith("tiger") and K % T == 0 and ndraws % T == 0:
-                        nd_t = ndraws // T
-                        dd_tiles = [dd[t * nd_t * 64:(t + 1) * nd_t * 64] for t in range(T)]
-                        st = rt.tessellate_count(ctx, pset, dd_tiles[0], nd_t)
-                        tv, ti, tm = st["num_vertices"], st["num_indices"], st["num_meshes"]
-                        if (tv * T, ti * T, tm * T) == (sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]):
-                            views = [bufs.view(t * tv, tv, t * ti, ti, t * tm, tm) for t in range(T)]
-                            RS = rt.capi.RankSizes
-                            tile_all = (RS * world)(*[RS(tv, ti, tm, nd_t) for _ in range(world)])
-                            places = []
-                            for t in range(T):
-                                places.append((RS * world)(*[RS(r * tv * T + t * tv, r * ti * T + t * ti, r * tm * T + t * tm, r * ndraws + t * nd_t) for r in range(world)]))
-                            gb2 = rt.MeshBuffers(dev, tv * T * world, ti * T * world, tm * T * world) if rank == 0 else None
-                            side = torch.cuda.Stream(device=dev)
-                            main = torch.cuda.current_stream(dev)
+                # VGX_BENCH_GATHER_TILES: one tile count or a comma list swept in this run (default 1,2,4,8 with more than one rank);
+                # the best one is reported as ms_per_step_with_tiled_gather, all of them in tiled_gather_sweep
+                tile_counts = [int(x) for x in os.environ.get("VGX_BENCH_GATHER_TILES", "1,2,4,8" if world > 1 else "4").split(",") if x.strip()]
+                sweep = {}
+                for T in tile_counts:
+                  try:
+                    if args.config.startswith("tiger") and T >= 1 and K % T == 0 and ndraws % T == 0:
+                          nd_t = ndraws // T
+                          dd_tiles = [dd[t * nd_t * 64:(t + 1) * nd_t * 64] for t in range(T)]
+                          st = rt.tessellate_count(ctx, pset, dd_tiles[0], nd_t)
+                          tv, ti, tm = st["num_vertices"], st["num_indices"], st["num_meshes"]
+                          if (tv * T, ti * T, tm * T) == (sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]):
+                              views = [bufs.view(t * tv, tv, t * ti, ti, t * tm, tm) for t in range(T)]
+                              RS = rt.capi.RankSizes
+                              tile_all = (RS * world)(*[RS(tv, ti, tm, nd_t) for _ in range(world)])
+                              places = []
+                              for t in range(T):
+                                  places.append((RS * world)(*[RS(r * tv * T + t * tv, r * ti * T + t * ti, r * tm * T + t * tm, r * ndraws + t * nd_t) for r in range(world)]))
+                              gb2 = rt.MeshBuffers(dev, tv * T * world, ti * T * world, tm * T * world) if rank == 0 else None
+                              side = torch.cuda.Stream(device=dev)
+                              main = torch.cuda.current_stream(dev)
 
-                            def tiled_frame():
-                                for t in range(T):
-                                    rt.tessellate_async(ctx, pset, dd_tiles[t], nd_t, views[t])
-                                    ready = torch.cuda.Event()
-                                    ready.record(main)
-                                    side.wait_event(ready)
-                                    with torch.cuda.stream(side):
-                                        cg.gather_at(views[t], tile_all, places[t], 0, gb2)
-                                fin = torch.cuda.Event()
-                                fin.record(side)
-                                main.wait_event(fin)
-                            tiled_frame()  # warm-up
-                            barrier()
-                            o1 = time.perf_counter()
-                            for it in range(args.steps):
-                                tiled_frame()
-                            barrier()
-                            box["tiled_ms_per_step"] = (time.perf_counter() - o1) / args.steps * 1e3
-                            box["tiles"] = T
-                            if rank == 0 and world == 1:
-                                nv = sizes["num_vertices"]
-                                box["tiled_check"] = bool(torch.equal(gb2.pos[:nv], bufs.pos[:nv]) and int(views[-1].dev_status.item()) == 0)
-                            del gb2, views
-                            rt.tessellate_count(ctx, pset, dd, ndraws)  # scratch back to the whole-frame shape
-                except Exception as e:  # noqa: BLE001
+                              def tiled_frame():
+                                  for t in range(T):
+                                      rt.tessellate_async(ctx, pset, dd_tiles[t], nd_t, views[t])
+                                      ready = torch.cuda.Event()
+                                      ready.record(main)
+                                      side.wait_event(ready)
+                                      with torch.cuda.stream(side):
+                                          cg.gather_at(views[t], tile_all, places[t], 0, gb2)
+                                  fin = torch.cuda.Event()
+                                  fin.record(side)
+                                  main.wait_event(fin)
+                              tiled_frame()  # warm-up
+                              barrier()
+                              o1 = time.perf_counter()
+                              for it in range(args.steps):
+                                  tiled_frame()
+                              barrier()
+                              t_ms = (time.perf_counter() - o1) / args.steps * 1e3
+                              sweep[T] = round(t_ms, 3)
+                              box["tiled_sweep"] = dict(sweep)
+                              if box.get("tiled_ms_per_step") is None or t_ms < box["tiled_ms_per_step"]:
+                                  box["tiled_ms_per_step"] = t_ms
+                                  box["tiles"] = T
+                              if rank == 0 and world == 1:
+                                  nv = sizes["num_vertices"]
+                                  box["tiled_check"] = bool(torch.equal(gb2.pos[:nv], bufs.pos[:nv]) and int(views[-1].dev_status.item()) == 0)
+                              del gb2, views
+                              rt.tessellate_count(ctx, pset, dd, ndraws)  # scratch back to the whole-frame shape
+                  except Exception as e:  # noqa: BLE001
                     box["tiled_err"] = repr(e)
+                    break
                 del gb
                 cg.close()
             except Exception as e:  # noqa: BLE001 -- any failure falls back to the torch.distributed gather
@@ -576,7 +647,7 @@ def main():
         res["gather_check"] = box.get("check")
         res["overlap_ms_per_step"] = box.get("overlap_ms_per_step")
         res["overlap_err"] = box.get("overlap_err")
-        for k in ("tiled_ms_per_step", "tiles", "tiled_check", "tiled_err"):
+        for k in ("tiled_ms_per_step", "tiles", "tiled_check", "tiled_err", "tiled_sweep"):
             res[k] = box.get(k)
 
     # ---- next rows, measured beside the headline on rank 0 of a 1-GPU run: not part of `value` ----
@@ -672,6 +743,17 @@ def main():
                 ctx2.close()
             torch.cuda.empty_cache()
 
+    # ---- heterogeneous batch through vgx_partition (SURVEY 8e "for heterogeneous batches balance on the count-pass result") ----
+    # Every rank holds the same batch (Tiger instances at 7 scales, sorted by scale: equal instance counts per rank would be
+    # unbalanced), runs vgx_partition and tessellates its own range. Reported: per-rank times of the balanced and of the
+    # equal-count split. One rank: the parts are timed one after the other on the one GPU (what each rank of an 8-GPU run would do).
+    hetero = None
+    if args.config == "tiger10k" and not args.no_configs and not bail:
+        try:
+            hetero = hetero_leg(rt, torch, wl, dev, local_rank, rank, world, red_dev)
+        except Exception as e:  # noqa: BLE001 -- a diagnostic leg must not take the headline line with it
+            hetero = {"error": repr(e)}
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = total_units * args.steps / dt / 1e6
@@ -702,6 +784,11 @@ def main():
             "next_rows": next_rows,
             "configs": other,
         }
+        if hetero is not None:
+            out["heterogeneous_partition"] = hetero
+        if world > 1 and args.config == "tiger10k":
+            # BASELINE.json configs[4] is "Tiger x80k sharded across 8 MI355X": 10k instances per GPU = this leg at N = 8
+            out["config"]["baseline_config"] = ("configs[4]: Tiger x%dk in total, %d ranks" % (K * world // 1000, world)) if K * world == 80000 else ("configs[2] per GPU x %d ranks" % world)
         if by_rank is not None:
             out["ms_per_step_by_rank"] = by_rank
         if gather_ms is not None:
@@ -720,6 +807,8 @@ def main():
             out["ms_per_step_with_tiled_gather"] = round(res["tiled_ms_per_step"], 3)
             out["value_with_tiled_gather"] = round(total_units / (res["tiled_ms_per_step"] * 1e-3) / 1e6, 2)
             out["gather_tiles"] = res["tiles"]
+            if res.get("tiled_sweep"):
+                out["tiled_gather_sweep_ms"] = {str(k): v for k, v in sorted(res["tiled_sweep"].items())}
             if res.get("tiled_check") is not None:
                 out["tiled_gather_check"] = res["tiled_check"]
         elif res.get("tiled_err"):

@@ -166,14 +166,15 @@ WORKLOADS = {
     "tiger10k": "BASELINE configs[2]: Tiger x10k, convexFillAA + polylineStrokeAA (the headline)",
     "cubics1m": "BASELINE configs[1]: 1M independent cubics, adaptive flatten only",
     "round10k": "BASELINE configs[3]: 10k polylines x 1k segments, Round joins + Round caps",
-    "tiger10k_varied": "Tiger x10k with per-instance scale (0.5 .. 3.5) and rotation: the instanced flatten without its lock-step walk",
+    "tiger10k_varied": "Tiger x10k at 7 scales (0.5 .. 3.5; 18 distinct avgScale values after rounding) under rotations: template mode with one template per class",
     "tigerspec10k": "SURVEY 8(d) config 3 as specified: 240 paths x (1-4 sub-paths x 8-60 cubics), x10k instances",
     # honesty configs: the headline batch WITHOUT the template mode (every instance flattened, polyline through HBM), and without
     # any instancing shortcut (what a batch of 2.4 M unrelated draws costs)
     "tiger10k_per_instance_flatten": "Tiger x10k with VGX_TMPL=0: k_flatten_inst (one lane per instance) + k_fill + k_stroke, the round-3 pipeline",
     "tiger10k_command_parallel": "Tiger x10k with VGX_INST=0: k_flatten_build (one lane per path command) + k_fill + k_stroke, no instancing at all",
+    "tiger10k_varied_per_instance_flatten": "the tiger10k_varied batch with VGX_TMPL_CLASSES=0: what instances cost when they share no subdivision (k_flatten_inst with the instances sorted by tolerance class + k_fill + k_stroke)",
 }
-CONFIG_ENV = {"tiger10k_per_instance_flatten": {"VGX_TMPL": "0"}, "tiger10k_command_parallel": {"VGX_INST": "0"}}
+CONFIG_ENV = {"tiger10k_per_instance_flatten": {"VGX_TMPL": "0"}, "tiger10k_command_parallel": {"VGX_INST": "0"}, "tiger10k_varied_per_instance_flatten": {"VGX_TMPL_CLASSES": "0"}}
 CONFIG_CPU = {"cubics1m": "cubics", "round10k": "round"}  # configs that get their own cpu_baseline (the tiger ones share the headline's)
 
 
@@ -184,7 +185,7 @@ def make_workload(wl, name, instances, rank):
         d = wl.tiger_draws(ops, instances, first_instance=rank * instances)
         return ps, d, ("tiger-like 240-path drawing (seed 2024) x %d instances per GPU: convexFillAA on every sub-path + "
                        "polylineStrokeAA/AAThin (Butt/Miter) on 1/3 of the paths" % instances), "tessellate"
-    if name == "tiger10k_varied":
+    if name in ("tiger10k_varied", "tiger10k_varied_per_instance_flatten"):
         ps, ops = wl.tiger_paths()
         d = wl.tiger_varied_draws(ops, instances, first_instance=rank * instances)
         return ps, d, ("tiger-like drawing (seed 2024) x %d instances per GPU, every instance at its own scale in {0.5 .. 3.5} and "
@@ -734,7 +735,7 @@ def main():
                            "value": round(r2["units"] / (ms2 * 1e-3) / 1e6, 2), "unit": "M %s/s" % r2["unit_name"], "ms_per_step": round(ms2, 3), "steps": steps2,
                            "verts_per_gpu": r2["sizes"].get("num_vertices", 0), "indices_per_gpu": r2["sizes"].get("num_indices", 0),
                            "poly_verts_per_gpu": r2["sizes"]["num_poly_vertices"], "meshes_per_gpu": r2["sizes"].get("num_meshes", 0),
-                           "flatten_kernel": {0: "k_flatten_build", 1: "k_flatten_inst", 2: "k_flatten_inst (grouped)", 3: "k_flatten_inst (grouped by path and tolerance class)", 4: "k_flatten_inst (instances sorted by tolerance class)", 5: "none per step (template mode: first period flattened once by vgx_tessellate_count)"}.get(r2.get("flatten_mode"), "k_flatten"),
+                           "flatten_kernel": {0: "k_flatten_build", 1: "k_flatten_inst", 2: "k_flatten_inst (grouped)", 3: "k_flatten_inst (grouped by path and tolerance class)", 4: "k_flatten_inst (instances sorted by tolerance class)", 5: "none per step (template mode: the class representatives flattened once by vgx_tessellate_count)"}.get(r2.get("flatten_mode"), "k_flatten"),
                            "roofline": roofline(r2, steps2, traffic_for=name), "stage_ms": {k: round(v, 3) for k, v in r2["stage"].items()},
                            "cpu_baseline": other_cpu.get(name)}
             r2["pset"].close()

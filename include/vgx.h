@@ -546,7 +546,9 @@ int vgx_get_failure_info(vgx_ctx* ctx, vgx_failure_info* out, void* stream);
  *   out_bounds[0] = 0 <= out_bounds[1] <= ... <= out_bounds[nparts] = ndraws   (HOST, nparts + 1 entries)
  *   out_weights[k] = predicted weight of part k (HOST, nparts entries; may be NULL)
  * Rank r then tessellates draws [out_bounds[r], out_bounds[r + 1]); rank order = draw order, so the gathered streams are the
- * single-GPU result. Homogeneous batches (Tiger x K) come out as equal instance counts. Synchronises the stream.
+ * single-GPU result. Homogeneous batches (Tiger x K) come out as equal instance counts; when the draws repeat one sequence of
+ * paths (a drawing submitted for many instances, at whatever scales) every cut falls BETWEEN instances, so that each part is
+ * again a batch of whole instances for the instanced / template paths of vgx_tessellate. Synchronises the stream.
  * vgx_partition is a count call over the WHOLE batch: it replaces what an earlier vgx_tessellate_count left in the context
  * (scratch sizes, the instanced / template classification). Every rank calls vgx_tessellate_count on its own range afterwards. */
 int vgx_partition(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, uint32_t nparts, uint64_t* out_bounds, uint64_t* out_weights, void* stream);

@@ -31,10 +31,12 @@ def test_one_rank_line():
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert set(r["by_kernel"]) == {"tmpl_emit"} and r["kernel"] == "tmpl_emit"  # the headline batch is a template batch: one kernel per step
     assert d["config"]["flatten_kernel"].startswith("none per step: template mode")
-    assert set(d["configs"]) == {"cubics1m", "round10k", "tiger10k_varied", "tigerspec10k", "tiger10k_per_instance_flatten", "tiger10k_command_parallel"}
+    assert set(d["configs"]) == {"cubics1m", "round10k", "tiger10k_varied", "tigerspec10k", "tiger10k_per_instance_flatten", "tiger10k_command_parallel",
+                                 "tiger10k_varied_per_instance_flatten"}
     for name, c in d["configs"].items():
         assert c["value"] > 0 and c["roofline"]["frac"] > 0, name
-    assert d["configs"]["tiger10k_varied"]["flatten_kernel"] == "k_flatten_inst (instances sorted by tolerance class)"
+    assert d["configs"]["tiger10k_varied"]["flatten_kernel"].startswith("none per step")  # one template per scale class
+    assert d["configs"]["tiger10k_varied_per_instance_flatten"]["flatten_kernel"] == "k_flatten_inst (instances sorted by tolerance class)"
     # the honesty configs really run the other pipelines
     assert d["configs"]["tiger10k_per_instance_flatten"]["flatten_kernel"] == "k_flatten_inst" and "fill_emit" in d["configs"]["tiger10k_per_instance_flatten"]["stage_ms"]
     assert d["configs"]["tiger10k_command_parallel"]["flatten_kernel"] == "k_flatten_build"

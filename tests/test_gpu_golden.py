@@ -152,10 +152,11 @@ def test_full_size_tiger_properties(rt, gpu_ctx, wl, oracle, monkeypatch):
 
 
 def test_full_size_tiger_varied_scales(rt, wl, oracle, monkeypatch):
-    """bench.py's tiger10k_varied at full size (every instance at its own scale and rotation: 2.4 M draws, ~0.63 G vertices):
-    the count pass must keep the instanced kernel's periodic mapping with the instances sorted by tolerance class (flatten mode 4); the streams of the
-    asynchronous entry point are compared byte for byte with the command-parallel kernel's (VGX_INST=0: k_flatten_build, an
-    independent implementation of the flatten) and, instance by instance for a sample, with the reference oracle."""
+    """bench.py's tiger10k_varied at full size (every instance at one of 7 scales -- 18 distinct avgScale values -- and its own
+    rotation: 2.4 M draws, ~0.63 G vertices). Three pipelines, byte for byte the same streams: template mode with one template
+    per class (mode 5, the default), the instanced kernel's periodic mapping with the instances sorted by tolerance class
+    (VGX_TMPL_CLASSES=0: mode 4) and the command-parallel kernel (VGX_INST=0: k_flatten_build, an independent implementation of
+    the flatten); instance by instance for a sample, the reference oracle."""
     import torch
     K = 10000
     ps, ops = wl.tiger_paths()
@@ -165,7 +166,7 @@ def test_full_size_tiger_varied_scales(rt, wl, oracle, monkeypatch):
     pset = rt.PathSet(ctx, ps)
     dd = rt.upload_draws(draws)
     sizes = rt.tessellate_count(ctx, pset, dd, draws.shape[0])
-    assert ctx.failure_info()["segment_items"] == 4
+    assert ctx.failure_info()["segment_items"] == 5
     nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
     b = rt.MeshBuffers(dd.device, nv, ni, nm)
     for _ in range(2):
@@ -188,21 +189,27 @@ def test_full_size_tiger_varied_scales(rt, wl, oracle, monkeypatch):
         assert np.array_equal(b.pos[v0:v1].cpu().numpy().view(np.uint32), ref.pos.view(np.uint32)), inst
         assert np.array_equal(b.idx[i0:i1].cpu().numpy().view(np.uint16), ref.idx), inst
         assert np.array_equal(b.color[v0:v1].cpu().numpy().view(np.uint32), ref.color), inst
-    monkeypatch.setenv("VGX_INST", "0")
-    ctx0 = rt.Context(0)
-    pset0 = rt.PathSet(ctx0, ps)
-    rt.tessellate_count(ctx0, pset0, dd, draws.shape[0])
-    assert ctx0.failure_info()["segment_items"] == 0
-    b0 = rt.MeshBuffers(dd.device, nv, ni, nm)
-    rt.tessellate_async(ctx0, pset0, dd, draws.shape[0], b0)
-    torch.cuda.synchronize()
-    assert int(b0.dev_status.item()) == 0
-    assert torch.equal(b0.pos[:nv].view(torch.int32), b.pos[:nv].view(torch.int32))
-    assert torch.equal(b0.color[:nv], b.color[:nv])
-    assert torch.equal(b0.idx[:ni], b.idx[:ni])
-    assert torch.equal(b0.meshes[:nm * 32], b.meshes[:nm * 32])
-    pset0.close(); ctx0.close(); pset.close(); ctx.close()
-    del b, b0
+    for var, mode in (("VGX_TMPL_CLASSES", 4), ("VGX_INST", 0)):
+        monkeypatch.setenv(var, "0")
+        ctx0 = rt.Context(0)
+        monkeypatch.delenv(var)
+        pset0 = rt.PathSet(ctx0, ps)
+        s0 = rt.tessellate_count(ctx0, pset0, dd, draws.shape[0])
+        assert ctx0.failure_info()["segment_items"] == mode, (var, ctx0.failure_info()["segment_items"])
+        assert (s0["num_vertices"], s0["num_indices"], s0["num_meshes"]) == (nv, ni, nm)
+        b0 = rt.MeshBuffers(dd.device, nv, ni, nm)
+        rt.tessellate_async(ctx0, pset0, dd, draws.shape[0], b0)
+        torch.cuda.synchronize()
+        assert int(b0.dev_status.item()) == 0
+        assert torch.equal(b0.pos[:nv].view(torch.int32), b.pos[:nv].view(torch.int32)), var
+        assert torch.equal(b0.color[:nv], b.color[:nv]), var
+        assert torch.equal(b0.idx[:ni], b.idx[:ni]), var
+        assert torch.equal(b0.meshes[:nm * 32], b.meshes[:nm * 32]), var
+        pset0.close(); ctx0.close()
+        del b0
+        torch.cuda.empty_cache()
+    pset.close(); ctx.close()
+    del b
     torch.cuda.empty_cache()
 
 

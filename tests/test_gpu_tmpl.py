@@ -168,7 +168,7 @@ def test_template_capacity_is_checked_on_the_device(rt, wl):
 
 
 def test_batches_that_are_not_templates_take_the_ordinary_path(rt, wl, oracle):
-    """Open strokes (caps), Bevel / Round joins, non-AA strokes, instances of different scale, fewer than 32 instances:
+    """Open strokes (caps), Bevel / Round joins, non-AA strokes, every instance different, fewer than 32 instances:
     the ordinary pipeline, same results."""
     ps = wl.closed_fuzz_paths(930, npaths=72)
     ctx = rt.Context(0)
@@ -184,14 +184,20 @@ def test_batches_that_are_not_templates_take_the_ordinary_path(rt, wl, oracle):
     d = base.copy()
     d["stroke_flags"][sel] &= ~np.uint32(2 | 4)  # non-AA strokes
     cases.append(("non-AA strokes", d))
-    d = base.copy()
-    d["scale"][-ps.npaths:] *= np.float32(1.5)
-    cases.append(("one instance at another scale", d))
+    d = wl.template_draws(ps, 930, 80)
+    d["scale"][::ps.npaths] *= (np.float32(1.0) + np.arange(80, dtype=np.float32) / np.float32(128.0))
+    cases.append(("every instance at a scale of its own (more flavours than classes)", d))
     for name, d in cases:
         got = _run(rt, ctx, ps, d)
         assert got.mode != MODE_TEMPLATE and "tmpl_emit" not in got.stages, name
         assert got.status == 0, name
         assert_mesh_equal(got, oracle.tessellate(ps, d), name)
+    # one instance at another scale: a second class (since the classes exist), still the same results
+    d = base.copy()
+    d["scale"][-ps.npaths:] *= np.float32(1.5)
+    got = _run(rt, ctx, ps, d)
+    assert got.mode == MODE_TEMPLATE and got.status == 0
+    assert_mesh_equal(got, oracle.tessellate(ps, d), "one instance at another scale")
     ctx.close()
 
 
@@ -286,3 +292,98 @@ def test_template_mode_with_draw_command_assembly(rt, wl, oracle, monkeypatch, s
     st, rcmds, ridx = oracle.assemble(ref.meshes, ref.idx, max_vb, mesh_keys=keys)
     assert st == 0 and rcmds.shape[0] == got.ncmd
     assert np.array_equal(got.idx, ridx)
+
+
+# ---- several classes: every instance repeats ONE OF a few flavours of the period ---------------------------------------------
+@pytest.mark.parametrize("seed,ninst,ncls,tile", [(970, 48, 2, None), (971, 40, 5, "128"), (972, 64, 16, "960"), (974, 140, 64, None), (973, 36, 3, "64")])
+def test_template_classes_fuzz(rt, wl, oracle, monkeypatch, seed, ninst, ncls, tile):
+    """The same fuzz drawings in several flavours (own scales / tolerances / fringes / fill kinds / stroke widths per class, so
+    the classes have different polylines, mesh counts and sizes), instances of the flavours mixed at random: one template per
+    class, every instance emitted from its class's tables at its own place. == the reference, == the ordinary pipeline."""
+    if tile:
+        monkeypatch.setenv("VGX_TMPL_TILE", tile)
+    ps = wl.closed_fuzz_paths(seed, npaths=72)
+    d, pick = wl.template_class_draws(ps, seed, ninst, ncls)
+    ref = oracle.tessellate(ps, d)
+    ctx = rt.Context(0)
+    got = _run(rt, ctx, ps, d)
+    assert got.mode == MODE_TEMPLATE and got.stages == ["tmpl_emit"], (got.mode, got.stages)
+    assert got.status == 0
+    assert_mesh_equal(got, ref, "template classes seed=%d x%d / %d classes" % (seed, ninst, ncls))
+    assert int(got.dev_sizes[3]) == ref.sizes["num_vertices"] and int(got.dev_sizes[4]) == ref.sizes["num_indices"]
+    # two-phase entry on the same context
+    got2 = _run(rt, ctx, ps, d, two_phase=True)
+    assert_mesh_equal(got2, ref, "template classes, two-phase")
+    ctx.close()
+    monkeypatch.setenv("VGX_TMPL_CLASSES", "0")
+    ctx = rt.Context(0)
+    old = _run(rt, ctx, ps, d)
+    assert old.mode != MODE_TEMPLATE
+    for k in ("pos", "color", "idx", "meshes"):
+        assert bytes_equal(getattr(got, k), getattr(old, k)), k
+    ctx.close()
+
+
+def test_template_classes_tiger_at_seven_scales(rt, wl, oracle):
+    """The bench's `tiger10k_varied` drawing (Tiger instances at 7 scales under rotations: 7 subdivisions, 7 sets of stroke
+    widths) x 64: seven classes."""
+    ps, ops = wl.tiger_paths()
+    d = wl.tiger_varied_draws(ops, 64)
+    ref = oracle.tessellate(ps, d)
+    ctx = rt.Context(0)
+    got = _run(rt, ctx, ps, d)
+    assert got.mode == MODE_TEMPLATE and got.stages == ["tmpl_emit"], (got.mode, got.stages)
+    assert got.status == 0
+    assert_mesh_equal(got, ref, "tiger at 7 scales")
+    ctx.close()
+
+
+def test_template_classes_stale_and_limits(rt, wl, oracle, monkeypatch):
+    """An instance that changes its class after the count, or a different batch size: VGX_E_STALE / the ordinary path. More
+    flavours than VGX_TMPL_MAX_CLASSES (64): the ordinary pipeline from the start."""
+    ps = wl.closed_fuzz_paths(975, npaths=72)
+    d, pick = wl.template_class_draws(ps, 975, 40, 3)
+    P = ps.npaths
+    ctx = rt.Context(0)
+    moved = d.copy()
+    a, b = int(np.flatnonzero(pick == 0)[-1]), int(np.flatnonzero(pick == 1)[-1])
+    tmp = moved[a * P:(a + 1) * P].copy()
+    moved[a * P:(a + 1) * P] = moved[b * P:(b + 1) * P]  # the two instances swap flavours: sizes change under the table's feet
+    moved[b * P:(b + 1) * P] = tmp
+    got = _run(rt, ctx, ps, d, d_steady=moved)
+    assert got.mode == MODE_TEMPLATE and got.status == VGX_E_STALE
+    # transforms and colours stay free
+    free = d.copy()
+    free["mtx"][:, 4] += np.float32(3.0)
+    free["fill_color"] ^= np.uint32(0x00FF00FF)
+    got = _run(rt, ctx, ps, d, d_steady=free)
+    assert got.status == 0
+    assert_mesh_equal(got, oracle.tessellate(ps, free), "classes: transforms / colours changed")
+    ctx.close()
+    many, _ = wl.template_class_draws(ps, 976, 100, 65)
+    ctx = rt.Context(0)
+    got = _run(rt, ctx, ps, many)
+    assert got.mode != MODE_TEMPLATE and got.status == 0
+    assert_mesh_equal(got, oracle.tessellate(ps, many), "65 flavours: ordinary pipeline")
+    ctx.close()
+
+
+@pytest.mark.parametrize("seed,ninst,ncls,max_vb,split", [(980, 40, 3, 65536, False), (981, 36, 4, 2048, True)])
+def test_template_classes_with_draw_command_assembly(rt, wl, oracle, monkeypatch, seed, ninst, ncls, max_vb, split):
+    ps = wl.closed_fuzz_paths(seed, npaths=72)
+    d, _ = wl.template_class_draws(ps, seed, ninst, ncls)
+    ctx = rt.Context(0)
+    rs = np.random.RandomState(seed)
+    d["state_key"] = np.repeat(rs.randint(0, 3, size=(d.shape[0] + 6) // 7), 7)[:d.shape[0]].astype(np.uint32)
+    a = _assembled(rt, ctx, ps, d, max_vb, split)
+    assert a.mode == MODE_TEMPLATE and a.status == 0 and a.stages[-1] == "tmpl_emit", (a.mode, a.status, a.stages)
+    ctx.close()
+    monkeypatch.setenv("VGX_TMPL", "0")
+    ctx = rt.Context(0)
+    b = _assembled(rt, ctx, ps, d, max_vb, split)
+    assert b.mode != MODE_TEMPLATE and b.status == 0
+    ctx.close()
+    assert a.ncmd == b.ncmd
+    for k in ("pos", "color", "idx", "meshes", "cmds"):
+        assert bytes_equal(getattr(a, k), getattr(b, k)), k
+

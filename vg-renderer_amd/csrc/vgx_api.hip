@@ -93,6 +93,13 @@ struct vgx_ctx
 	uint32_t tmplPeriod;
 	vgx_sizes tmplInst;                  // sizes of one instance
 	DevBuf tmplPoly, tmplMesh, tmplMtab, tmplElem, tmplDraws;
+	// ... in several flavours ("classes", e.g. the same drawing at a few scales): one template over the concatenated class
+	// representatives, a per-instance table of output places, a per-workgroup table (instance, tile)
+	int optTmplClasses;
+	uint32_t tmplClasses;                // 1: every instance repeats the first period
+	uint64_t tmplNumWg, tmplNDraws;      // several classes: workgroups of one step; the batch size the per-instance table was built for
+	vgx_sizes tmplTotal;                 // sizes of the whole batch
+	DevBuf tmplHash, tmplInstCls, tmplClsRep, tmplCls, tmplIinfo, tmplWg;
 	hipStream_t sideStream; hipEvent_t forkEv, joinEv; // optConcurrentEmit only
 	VgxCaps caps; // element capacities matching the buffers above
 	uint64_t capDraws;
@@ -713,6 +720,8 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	if (const char* e = getenv("VGX_INST_BLOCK")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { ctx->optInstBlock = (uint32_t)v; } }
 	ctx->optTmpl = 1; ctx->optTmplTile = VGX_TMPL_MAX_TILE; // VGX_TMPL=0: no template mode (instanced batches through k_flatten_inst + k_fill + k_stroke)
 	if (const char* e = getenv("VGX_TMPL")) { ctx->optTmpl = atoi(e) != 0; }
+	ctx->optTmplClasses = 1; // VGX_TMPL_CLASSES=0: template mode only for batches whose instances all repeat the first period
+	if (const char* e = getenv("VGX_TMPL_CLASSES")) { ctx->optTmplClasses = atoi(e) != 0; }
 	if (const char* e = getenv("VGX_TMPL_TILE")) { const int v = atoi(e); if (v >= 64 && v <= VGX_TMPL_MAX_TILE) { ctx->optTmplTile = (uint32_t)v / 64u * 64u; } } // testing: elements per tile (<= the LDS stage of k_tmpl_emit)
 	ctx->optPoolWalk = 0; // VGX_WALK=pool: the wave-cooperative walk of vgx_walk.h (same output, same speed: DESIGN.md section 4)
 	if (const char* e = getenv("VGX_WALK")) { ctx->optPoolWalk = strcmp(e, "pool") == 0; }
@@ -1089,26 +1098,26 @@ int vgx_flatten_emit(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 
 // ---- partition (contiguous ranges per GPU, balanced on the count pass for heterogeneous batches) -------------
 namespace {
-__global__ void k_partition_bounds(const uint64_t* prefix, uint64_t ndraws, uint32_t nparts, uint64_t* bounds, uint64_t* weights)
+// cut k of nparts: the first draw whose weight prefix reaches k / nparts of the total; `align` > 1 (the draws repeat a sequence of
+// `align` paths: a drawing submitted for many instances): rounded to the nearest whole instance, so that every part stays a batch
+// of whole instances (what the instanced / template paths of vgx_tessellate need)
+__device__ __forceinline__ uint64_t partition_cut(const uint64_t* prefix, uint64_t ndraws, uint32_t nparts, uint32_t k, uint64_t align)
+{
+	if (k >= nparts) { return ndraws; }
+	const uint64_t total = prefix[ndraws];
+	const uint64_t target = (uint64_t)(((unsigned __int128)total * k) / nparts);
+	uint64_t lo = 0, hi = ndraws;
+	while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (prefix[mid] < target) { lo = mid + 1; } else { hi = mid; } }
+	if (align > 1) { lo = (lo + align / 2) / align * align; if (lo > ndraws) { lo = ndraws; } }
+	return lo;
+}
+__global__ void k_partition_bounds(const uint64_t* prefix, uint64_t ndraws, uint32_t nparts, uint64_t align, uint64_t* bounds, uint64_t* weights)
 {
 	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k > nparts) { return; }
-	const uint64_t total = prefix[ndraws];
-	// bounds[k] = first draw whose prefix reaches k / nparts of the total (draw granularity; 128-bit product avoided: total < 2^40)
-	uint64_t b = ndraws;
-	if (k < nparts) {
-		const uint64_t target = (uint64_t)(((unsigned __int128)total * k) / nparts);
-		uint64_t lo = 0, hi = ndraws;
-		while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (prefix[mid] < target) { lo = mid + 1; } else { hi = mid; } }
-		b = lo;
-	}
+	const uint64_t b = partition_cut(prefix, ndraws, nparts, k, align);
 	bounds[k] = b;
-	if (weights && k < nparts) {
-		const uint64_t target2 = (uint64_t)(((unsigned __int128)total * (k + 1)) / nparts);
-		uint64_t lo = 0, hi = ndraws;
-		if (k + 1 < nparts) { while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (prefix[mid] < target2) { lo = mid + 1; } else { hi = mid; } } } else { lo = ndraws; }
-		weights[k] = prefix[lo] - prefix[b];
-	}
+	if (weights && k < nparts) { weights[k] = prefix[partition_cut(prefix, ndraws, nparts, k + 1, align)] - prefix[b]; }
 }
 }
 
@@ -1121,7 +1130,19 @@ int vgx_partition(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, ui
 	hipStream_t s = (hipStream_t)stream;
 	markBegin(ctx, s);
 	ctx->lastStage = 0;
-	int st = flattenCountCommon(ctx, ps, draws, ndraws, s, false); // per-draw polyline vertex counts in dinfo
+	int st;
+	uint64_t align = 1;
+	if (ctx->optInst && ndraws > VGX_SMALL_DRAWS) { // a drawing submitted for many instances? Then the cuts fall between instances
+		if ((st = ensure(ctx, ctx->totals, sizeof(VgxTotals))) != VGX_OK) { return st; }
+		noteHip(ctx, hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s));
+		vgx_launch_inst_detect(draws, ndraws, (VgxTotals*)ctx->totals.p, s);
+		if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
+		if (ctx->hostTotals->inst_detect_inv != 0 && !ctx->hostTotals->inst_detect_bad) {
+			const unsigned long long P = ~0ull - ctx->hostTotals->inst_detect_inv;
+			if (P > 1 && ndraws % P == 0 && ndraws / P >= nparts) { align = P; }
+		}
+	}
+	st = flattenCountCommon(ctx, ps, draws, ndraws, s, false); // per-draw polyline vertex counts in dinfo
 	if (st != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->partBounds, ((size_t)nparts + 1) * 2 * sizeof(uint64_t))) != VGX_OK) { return st; }
 	OpPartWeight op;
@@ -1129,7 +1150,7 @@ int vgx_partition(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, ui
 	vgx_device_scan(op, (Sum3*)ctx->partial.p, s, ndraws);
 	uint64_t* dBounds = (uint64_t*)ctx->partBounds.p;
 	uint64_t* dWeights = dBounds + nparts + 1;
-	hipLaunchKernelGGL(k_partition_bounds, dim3((nparts + 1 + 255) / 256), dim3(256), 0, s, (const uint64_t*)ctx->cmdPrefix.p, ndraws, nparts, dBounds, dWeights);
+	hipLaunchKernelGGL(k_partition_bounds, dim3((nparts + 1 + 255) / 256), dim3(256), 0, s, (const uint64_t*)ctx->cmdPrefix.p, ndraws, nparts, align, dBounds, dWeights);
 	HIPCHK(ctx, hipMemcpyAsync(out_bounds, dBounds, ((size_t)nparts + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
 	if (out_weights) { HIPCHK(ctx, hipMemcpyAsync(out_weights, dWeights, (size_t)nparts * sizeof(uint64_t), hipMemcpyDeviceToHost, s)); }
 	HIPCHK(ctx, hipStreamSynchronize(s));
@@ -1152,16 +1173,27 @@ static int runTmpl(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 	a.pos = out->pos; a.color = out->color; a.idx = out->idx; a.meshes_out = out->meshes;
 	a.caps = ctx->caps; a.caps.vertices = out->cap_vertices; a.caps.indices = out->cap_indices; a.caps.meshes = out->cap_meshes;
 	a.totals = (VgxTotals*)ctx->totals.p;
-	if (a.ninst * (uint64_t)a.tiles_per_inst > 0x7FFFFFFFull) { return VGX_E_RANGE; } // one workgroup per (instance, tile)
+	if (ctx->tmplClasses > 1) {
+		a.iinfo = (const VgxTmplInst*)ctx->tmplIinfo.p; a.wg = (const uint2*)ctx->tmplWg.p; a.num_wg = ctx->tmplNumWg;
+		a.total = ctx->tmplTotal;
+	} else {
+		const vgx_sizes& i1 = ctx->tmplInst;
+		vgx_sizes z;
+		z.num_poly_vertices = a.ninst * i1.num_poly_vertices; z.num_subpaths = a.ninst * i1.num_subpaths; z.num_meshes = a.ninst * i1.num_meshes;
+		z.num_vertices = a.ninst * i1.num_vertices; z.num_indices = a.ninst * i1.num_indices; z.num_serial_draws = a.ninst * i1.num_serial_draws;
+		z.num_cmd_instances = a.ninst * i1.num_cmd_instances; z.num_elements = a.ninst * i1.num_elements; z.num_fill_elements = a.ninst * i1.num_fill_elements;
+		z.num_drawcmds = 0;
+		a.total = z;
+		a.num_wg = a.ninst * (uint64_t)a.tiles_per_inst;
+	}
+	if (a.num_wg > 0x7FFFFFFFull) { return VGX_E_RANGE; } // one workgroup per (instance, tile)
 	noteHip(ctx, hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s));
 	{
 		// every size is known on the host: a batch that does not fit the caller's buffers ends here, with the need in dev_sizes
-		const uint64_t nv = a.ninst * a.inst.num_vertices, ni = a.ninst * a.inst.num_indices, nm = a.ninst * a.inst.num_meshes;
+		const uint64_t nv = a.total.num_vertices, ni = a.total.num_indices, nm = a.total.num_meshes;
 		const uint32_t aux = (nv > out->cap_vertices ? 1u : 0u) | (ni > out->cap_indices ? 2u : 0u) | ((out->meshes && nm > out->cap_meshes) ? 4u : 0u);
 		if (aux) {
-			vgx_sizes z = a.inst;
-			z.num_poly_vertices *= a.ninst; z.num_subpaths *= a.ninst; z.num_meshes *= a.ninst; z.num_vertices *= a.ninst; z.num_indices *= a.ninst;
-			z.num_serial_draws *= a.ninst; z.num_cmd_instances *= a.ninst; z.num_elements *= a.ninst; z.num_fill_elements *= a.ninst; z.num_drawcmds = 0;
+			const vgx_sizes z = a.total;
 			hipLaunchKernelGGL(k_tmpl_nospace, dim3(1), dim3(1), 0, s, (VgxTotals*)ctx->totals.p, z, aux);
 			if (dev_sizes || dev_status) { hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, s, (const VgxTotals*)ctx->totals.p, dev_sizes, dev_status); }
 			return launchStatus(ctx);
@@ -1169,7 +1201,7 @@ static int runTmpl(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 	}
 	if (ctx->asmArmed) {
 		// draw-command assembly: the partition kernels need the whole batch's mesh table and every mesh's draw in memory
-		const uint64_t nm = a.ninst * a.inst.num_meshes;
+		const uint64_t nm = a.total.num_meshes;
 		int st;
 		if ((st = ensure(ctx, ctx->mtab, (nm + 1) * sizeof(vgx_mesh))) != VGX_OK) { return st; }
 		if ((st = ensure(ctx, ctx->mdesc, (nm + 1) * sizeof(VgxMeshDesc))) != VGX_OK) { return st; }
@@ -1188,14 +1220,43 @@ static int runTmpl(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 
 static bool tmplFor(const vgx_ctx* ctx, const vgx_pathset* ps, uint64_t ndraws)
 {
-	return ctx->tmplOn && ctx->optTmpl && ps == ctx->tmplPs && ctx->tmplPeriod && ndraws % ctx->tmplPeriod == 0 && ndraws >= ctx->tmplPeriod;
+	return ctx->tmplOn && ctx->optTmpl && ps == ctx->tmplPs && ctx->tmplPeriod && ndraws % ctx->tmplPeriod == 0 && ndraws >= ctx->tmplPeriod
+		&& (ctx->tmplClasses == 1 || ndraws == ctx->tmplNDraws); // several classes: the per-instance table belongs to ONE batch size
 }
 
-// vgx_tessellate_count, first thing: do the draws repeat their first period in everything but transform and colours, and are
-// that period's meshes all of the kinds k_tmpl_emit writes (fills; closed Miter AA / Thin strokes)? Then the period is
-// flattened ONCE, in local space, by the ordinary two-phase kernels and kept as the context's template. Returns VGX_OK with
-// ctx->tmplOn set (out_sizes filled), VGX_OK with it clear (not such a batch: the caller continues with the ordinary count),
-// or an error.
+// The ordinary count + two-phase flatten in LOCAL space (apply_transform = 0) + mesh sizing of `n` draws: what a template is built
+// from. Sizes and the mesh-kind flags end up in ctx->hostTotals.
+static int tmplPipeline(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* d, uint64_t n, hipStream_t s)
+{
+	int st;
+	if ((st = flattenCountCommon(ctx, ps, d, n, s, false)) != VGX_OK) { return st; }
+	const vgx_sizes fsz = ctx->hostTotals->sizes;
+	if ((st = ensureMeshBuffers(ctx, fsz.num_poly_vertices, fsz.num_subpaths, fsz.num_meshes)) != VGX_OK) { return st; }
+	{
+		VgxFlattenArgs a = flattenArgs(ctx, ps, d, n, 0);
+		vgx_launch_flatten(true, a, VGX_GRID_BLOCKS, s);
+	}
+	VgxCaps outCaps = ctx->caps;
+	outCaps.vertices = ~0ull; outCaps.indices = ~0ull;
+	runStrokeCount(ctx, d, outCaps, 0, s);
+	if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
+	if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; }
+	return VGX_OK;
+}
+// one instance of a class: only the mesh kinds k_tmpl_emit writes, every output stream of the instance below 4 GB
+static bool tmplEligible(const VgxTotals& ht)
+{
+	const vgx_sizes& z = ht.sizes;
+	return !(ht.has_general_stroke || ht.num_round_meshes || z.num_elements == 0 || z.num_elements >= (1ull << 31) || z.num_vertices >= (1ull << 29)
+		|| z.num_indices >= (1ull << 31) || z.num_poly_vertices >= (1ull << 32) || z.num_meshes >= (1ull << 32));
+}
+
+// vgx_tessellate_count, first thing: do the draws repeat their first period in everything but transform and colours -- or a FEW
+// flavours of it ("classes": every instance equals one of at most VGX_TMPL_MAX_CLASSES representatives, e.g. one drawing at a
+// handful of scales) --, and are the meshes all of the kinds k_tmpl_emit writes (fills; closed Miter AA / Thin strokes)? Then the
+// representatives are flattened ONCE, in local space, by the ordinary two-phase kernels and kept as the context's template.
+// Returns VGX_OK with ctx->tmplOn set (out_sizes filled), VGX_OK with it clear (not such a batch: the caller continues with the
+// ordinary count), or an error.
 static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, vgx_sizes* out_sizes, hipStream_t s)
 {
 	ctx->tmplOn = false;
@@ -1207,57 +1268,146 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	vgx_launch_tmpl_check(draws, ndraws, ps->dev.npaths, (VgxTotals*)ctx->totals.p, s);
 	if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
 	if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; }
-	if (ctx->hostTotals->inst_detect_inv == 0 || ctx->hostTotals->inst_detect_bad || ctx->hostTotals->tmpl_bad) { return VGX_OK; }
+	if (ctx->hostTotals->inst_detect_inv == 0 || ctx->hostTotals->inst_detect_bad) { return VGX_OK; }
 	const unsigned long long P = ~0ull - ctx->hostTotals->inst_detect_inv;
 	if (P == 0 || P > (1ull << 24) || ndraws % P != 0 || ndraws / P < VGX_INST_MIN_INSTANCES) { return VGX_OK; }
-	// the first period through the ordinary count + two-phase flatten (local space) + mesh sizing
-	if ((st = flattenCountCommon(ctx, ps, draws, P, s, false)) != VGX_OK) { return st; }
-	const vgx_sizes fsz = ctx->hostTotals->sizes;
-	if ((st = ensureMeshBuffers(ctx, fsz.num_poly_vertices, fsz.num_subpaths, fsz.num_meshes)) != VGX_OK) { return st; }
+	const uint64_t ninst = ndraws / P;
+	uint32_t T = 1;
+	std::vector<uint32_t> instCls, reps(1, 0u);
+	if (ctx->hostTotals->tmpl_bad) {
+		// not ONE period repeated. A few flavours of it? Candidates by hash of the template fields, then compared bit by bit.
+		if (!ctx->optTmplClasses || ninst > 0x7FFFFFFFull) { return VGX_OK; }
+		if ((st = ensure(ctx, ctx->tmplHash, ninst * sizeof(unsigned long long))) != VGX_OK) { return st; }
+		noteHip(ctx, hipMemsetAsync(ctx->tmplHash.p, 0, ninst * sizeof(unsigned long long), s));
+		vgx_launch_tmpl_hash(draws, ndraws, P, (unsigned long long*)ctx->tmplHash.p, s);
+		std::vector<unsigned long long> hashes(ninst);
+		HIPCHK(ctx, hipMemcpyAsync(hashes.data(), ctx->tmplHash.p, ninst * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+		HIPCHK(ctx, hipStreamSynchronize(s));
+		instCls.resize(ninst);
+		reps.clear();
+		unsigned long long seen[VGX_TMPL_MAX_CLASSES];
+		for (uint64_t k = 0; k < ninst; ++k) {
+			uint32_t c = 0;
+			while (c < reps.size() && seen[c] != hashes[k]) { ++c; }
+			if (c == reps.size()) {
+				if (c == VGX_TMPL_MAX_CLASSES) { return VGX_OK; } // too many flavours: the ordinary pipeline
+				seen[c] = hashes[k];
+				reps.push_back((uint32_t)k);
+			}
+			instCls[k] = c;
+		}
+		T = (uint32_t)reps.size();
+		if ((st = ensure(ctx, ctx->tmplInstCls, ninst * sizeof(uint32_t))) != VGX_OK) { return st; }
+		if ((st = ensure(ctx, ctx->tmplClsRep, (size_t)T * sizeof(uint32_t))) != VGX_OK) { return st; }
+		HIPCHK(ctx, hipMemcpyAsync(ctx->tmplInstCls.p, instCls.data(), ninst * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+		HIPCHK(ctx, hipMemcpyAsync(ctx->tmplClsRep.p, reps.data(), (size_t)T * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+		noteHip(ctx, hipMemsetAsync(&((VgxTotals*)ctx->totals.p)->tmpl_bad, 0, sizeof(uint32_t), s));
+		vgx_launch_tmpl_check_cls(draws, ndraws, P, (const uint32_t*)ctx->tmplInstCls.p, (const uint32_t*)ctx->tmplClsRep.p, (VgxTotals*)ctx->totals.p, s);
+		if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
+		if (ctx->hostTotals->tmpl_bad) { return VGX_OK; } // equal hashes, different records
+	}
+	// the class representatives' draw records, back to back (the saved records every step verifies the batch against)
+	const uint64_t PT = P * T;
+	if ((st = ensure(ctx, ctx->tmplDraws, (size_t)PT * sizeof(vgx_draw))) != VGX_OK) { return st; }
+	for (uint32_t c = 0; c < T; ++c) {
+		HIPCHK(ctx, hipMemcpyAsync((vgx_draw*)ctx->tmplDraws.p + (uint64_t)c * P, draws + (uint64_t)reps[c] * P, (size_t)P * sizeof(vgx_draw), hipMemcpyDeviceToDevice, s));
+	}
+	const vgx_draw* rdraws = (const vgx_draw*)ctx->tmplDraws.p;
+	// sizes of one instance of every class (several classes: each representative through the pipeline on its own first)
+	std::vector<vgx_sizes> csz(T);
+	if (T > 1) {
+		for (uint32_t c = 0; c < T; ++c) {
+			if ((st = tmplPipeline(ctx, ps, rdraws + (uint64_t)c * P, P, s)) != VGX_OK) { return st; }
+			if (!tmplEligible(*ctx->hostTotals)) { return VGX_OK; }
+			csz[c] = ctx->hostTotals->sizes;
+		}
+	}
+	// all representatives as one batch: the template
+	if ((st = tmplPipeline(ctx, ps, rdraws, PT, s)) != VGX_OK) { return st; }
 	{
-		VgxFlattenArgs a = flattenArgs(ctx, ps, draws, P, 0);
-		vgx_launch_flatten(true, a, VGX_GRID_BLOCKS, s);
+		const VgxTotals& ht = *ctx->hostTotals;
+		if (T == 1) {
+			if (!tmplEligible(ht)) { return VGX_OK; } // open / Bevel / Round strokes (or nothing to emit): the ordinary pipeline
+			csz[0] = ht.sizes;
+		} else if (ht.has_general_stroke || ht.num_round_meshes || ht.sizes.num_poly_vertices >= (1ull << 32) || ht.sizes.num_meshes >= (1ull << 32) || ht.sizes.num_elements >= (1ull << 36)) {
+			return VGX_OK;
+		}
 	}
-	VgxCaps outCaps = ctx->caps;
-	outCaps.vertices = ~0ull; outCaps.indices = ~0ull;
-	runStrokeCount(ctx, draws, outCaps, 0, s);
-	if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
-	if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; }
-	const VgxTotals& ht = *ctx->hostTotals;
-	const vgx_sizes isz = ht.sizes;
-	if (ht.has_general_stroke || ht.num_round_meshes || isz.num_elements == 0 || isz.num_elements >= (1ull << 31) || isz.num_vertices >= (1ull << 29)
-		|| isz.num_indices >= (1ull << 31) || isz.num_poly_vertices >= (1ull << 32) || isz.num_meshes >= (1ull << 32)) { // one instance: < 4 GB per output stream
-		return VGX_OK; // open / Bevel / Round strokes (or nothing to emit): the ordinary pipeline
+	const vgx_sizes all = ctx->hostTotals->sizes;
+	const uint64_t M = all.num_meshes, E = all.num_elements, V = all.num_poly_vertices;
+	const uint32_t tileSize = ctx->optTmplTile;
+	if ((st = ensure(ctx, ctx->tmplCls, ((size_t)T + 1) * sizeof(VgxTmplClass))) != VGX_OK) { return st; }
+	VgxTmplBuild b;
+	memset(&b, 0, sizeof(b));
+	b.draws = rdraws; b.poly = (const float2*)ctx->poly.p; b.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; b.mprep = (const VgxMeshPrep*)ctx->mprep.p; b.mtab = (const vgx_mesh*)ctx->mtab.p;
+	b.prefix_fill = (const uint64_t*)ctx->elemPrefix.p; b.prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
+	b.num_meshes = M; b.num_elems = E; b.tile = tileSize; b.period = (uint32_t)P; b.nclasses = T;
+	b.num_vertices = all.num_vertices; b.num_indices = all.num_indices; b.cls = (VgxTmplClass*)ctx->tmplCls.p;
+	vgx_launch_tmpl_classes(b, s);
+	std::vector<VgxTmplClass> cls((size_t)T + 1);
+	HIPCHK(ctx, hipMemcpyAsync(cls.data(), ctx->tmplCls.p, ((size_t)T + 1) * sizeof(VgxTmplClass), hipMemcpyDeviceToHost, s));
+	HIPCHK(ctx, hipStreamSynchronize(s));
+	for (uint32_t c = 0; c < T; ++c) { // the concatenated batch is the classes back to back: anything else means the template cannot be trusted
+		if (cls[c + 1].mesh0 - cls[c].mesh0 != csz[c].num_meshes || cls[c + 1].elem0 - cls[c].elem0 != csz[c].num_elements
+			|| cls[c + 1].v0 - cls[c].v0 != csz[c].num_vertices || cls[c + 1].i0 - cls[c].i0 != csz[c].num_indices) { return VGX_OK; }
 	}
-	const uint64_t M = isz.num_meshes, E = isz.num_elements, V = isz.num_poly_vertices;
+	const uint64_t tiles = cls[T].tile0;
 	if ((st = ensure(ctx, ctx->tmplPoly, (V + 1) * 2 * sizeof(float))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->tmplMesh, (M + 1) * sizeof(VgxTmplMesh))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->tmplMtab, (M + 1) * sizeof(vgx_mesh))) != VGX_OK) { return st; }
-	if ((st = ensure(ctx, ctx->tmplElem, (E + 64) * sizeof(VgxTmplElem))) != VGX_OK) { return st; }
-	if ((st = ensure(ctx, ctx->tmplDraws, (size_t)P * sizeof(vgx_draw))) != VGX_OK) { return st; }
-	const uint32_t tileSize = ctx->optTmplTile;
-	if ((st = ensure(ctx, ctx->tmplTile, ((E + tileSize - 1) / tileSize + 1) * sizeof(VgxTmplTile))) != VGX_OK) { return st; }
-	VgxTmplBuild b;
-	b.draws = draws; b.poly = (const float2*)ctx->poly.p; b.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; b.mprep = (const VgxMeshPrep*)ctx->mprep.p; b.mtab = (const vgx_mesh*)ctx->mtab.p;
-	b.prefix_fill = (const uint64_t*)ctx->elemPrefix.p; b.prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
-	b.num_meshes = M; b.num_elems = E; b.tile = tileSize; b.ttile = (VgxTmplTile*)ctx->tmplTile.p; b.period = (uint32_t)P;
+	if ((st = ensure(ctx, ctx->tmplElem, (tiles * tileSize + 64) * sizeof(VgxTmplElem))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->tmplTile, (tiles + 1) * sizeof(VgxTmplTile))) != VGX_OK) { return st; }
+	b.ttile = (VgxTmplTile*)ctx->tmplTile.p;
 	b.tmesh = (VgxTmplMesh*)ctx->tmplMesh.p; b.tmtab = (vgx_mesh*)ctx->tmplMtab.p; b.telem = (VgxTmplElem*)ctx->tmplElem.p;
 	vgx_launch_tmpl_build(b, s);
 	HIPCHK(ctx, hipMemcpyAsync(ctx->tmplPoly.p, ctx->poly.p, V * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
-	HIPCHK(ctx, hipMemcpyAsync(ctx->tmplDraws.p, draws, (size_t)P * sizeof(vgx_draw), hipMemcpyDeviceToDevice, s));
+	// the batch: instances x their class's sizes
+	std::vector<uint64_t> cnt(T, 0);
+	if (T == 1) { cnt[0] = ninst; } else { for (uint64_t k = 0; k < ninst; ++k) { ++cnt[instCls[k]]; } }
+	vgx_sizes z;
+	memset(&z, 0, sizeof(z));
+	uint64_t numWg = 0;
+	for (uint32_t c = 0; c < T; ++c) {
+		const vgx_sizes& q = csz[c];
+		z.num_poly_vertices += cnt[c] * q.num_poly_vertices; z.num_subpaths += cnt[c] * q.num_subpaths; z.num_meshes += cnt[c] * q.num_meshes;
+		z.num_vertices += cnt[c] * q.num_vertices; z.num_indices += cnt[c] * q.num_indices; z.num_serial_draws += cnt[c] * q.num_serial_draws;
+		z.num_cmd_instances += cnt[c] * q.num_cmd_instances; z.num_elements += cnt[c] * q.num_elements; z.num_fill_elements += cnt[c] * q.num_fill_elements;
+		numWg += cnt[c] * (uint64_t)(cls[c + 1].tile0 - cls[c].tile0);
+	}
+	if (T > 1) {
+		if (numWg > 0x7FFFFFFFull || z.num_meshes >= (1ull << 32)) { return VGX_OK; }
+		std::vector<VgxTmplInst> ii(ninst + 1);
+		std::vector<uint2> wg((size_t)numWg);
+		uint64_t v = 0, i = 0, m = 0, w = 0;
+		for (uint64_t k = 0; k <= ninst; ++k) {
+			VgxTmplInst r;
+			memset(&r, 0, sizeof(r));
+			r.v = v; r.i = i; r.m = (uint32_t)m;
+			if (k < ninst) {
+				const uint32_t c = instCls[k];
+				r.cls = c; r.cmesh0 = cls[c].mesh0;
+				for (uint32_t t = cls[c].tile0; t < cls[c + 1].tile0; ++t) { wg[(size_t)w++] = make_uint2((uint32_t)k, t); }
+				v += csz[c].num_vertices; i += csz[c].num_indices; m += csz[c].num_meshes;
+			}
+			ii[(size_t)k] = r;
+		}
+		if ((st = ensure(ctx, ctx->tmplIinfo, (ninst + 1) * sizeof(VgxTmplInst))) != VGX_OK) { return st; }
+		if ((st = ensure(ctx, ctx->tmplWg, ((size_t)numWg + 1) * sizeof(uint2))) != VGX_OK) { return st; }
+		HIPCHK(ctx, hipMemcpyAsync(ctx->tmplIinfo.p, ii.data(), (ninst + 1) * sizeof(VgxTmplInst), hipMemcpyHostToDevice, s));
+		HIPCHK(ctx, hipMemcpyAsync(ctx->tmplWg.p, wg.data(), (size_t)numWg * sizeof(uint2), hipMemcpyHostToDevice, s));
+		HIPCHK(ctx, hipStreamSynchronize(s)); // the host vectors go away
+	}
 	HIPCHK(ctx, hipStreamSynchronize(s));
 	if ((st = launchStatus(ctx)) != VGX_OK) { return st; }
-	ctx->tmplInst = isz;
+	ctx->tmplInst = csz[0];
 	ctx->tmplTileSize = tileSize;
 	ctx->tmplPeriod = (uint32_t)P;
 	ctx->tmplPs = ps;
+	ctx->tmplClasses = T;
+	ctx->tmplNumWg = numWg;
+	ctx->tmplNDraws = ndraws;
+	ctx->tmplTotal = z;
 	ctx->tmplOn = true;
-	const uint64_t ninst = ndraws / P;
-	vgx_sizes z;
-	z.num_poly_vertices = ninst * isz.num_poly_vertices; z.num_subpaths = ninst * isz.num_subpaths; z.num_meshes = ninst * isz.num_meshes;
-	z.num_vertices = ninst * isz.num_vertices; z.num_indices = ninst * isz.num_indices; z.num_serial_draws = ninst * isz.num_serial_draws;
-	z.num_cmd_instances = ninst * isz.num_cmd_instances; z.num_elements = ninst * isz.num_elements; z.num_fill_elements = ninst * isz.num_fill_elements;
-	z.num_drawcmds = 0;
 	*out_sizes = z;
 	ctx->hostTotals->sizes = z; // what vgx_tessellate_emit checks the caller's capacities against
 	return VGX_OK;

@@ -95,6 +95,9 @@ struct VgxTmplBuild // count pass: the first period's ordinary count + emit resu
 	VgxTmplElem* telem;
 	VgxTmplTile* ttile;          // [tiles]
 	uint32_t period;
+	uint32_t nclasses;           // the draws are `nclasses` representatives of `period` draws each
+	uint64_t num_vertices, num_indices; // output totals of the concatenated representatives
+	VgxTmplClass* cls;           // [nclasses + 1], written by the first build kernel
 };
 struct VgxTmplArgs // one step
 {
@@ -119,10 +122,18 @@ struct VgxTmplArgs // one step
 	const uint32_t* mesh_base;   // assembly armed: [ninst * meshes] vertices in front of each mesh inside its draw command; else null
 	VgxCaps caps;                // vertices / indices / meshes of the caller's buffers
 	VgxTotals* totals;
+	// several classes (else null / 0): instance k = class iinfo[k].cls, workgroup b = tile wg[b].y (of the concatenated template) of instance wg[b].x
+	const VgxTmplInst* iinfo;    // [ninst + 1]; the last entry = the batch totals
+	const uint2* wg;             // [num_wg]
+	uint64_t num_wg;
+	vgx_sizes total;             // sizes of the whole batch
 };
 void vgx_launch_tmpl_mtab(const VgxTmplArgs& a, vgx_mesh* mtab, VgxMeshDesc* mdesc, hipStream_t s); // assembly armed: the whole batch's mesh table + mesh -> draw
 void vgx_launch_tmpl_check(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, VgxTotals* totals, hipStream_t s); // after vgx_launch_inst_detect
-void vgx_launch_tmpl_build(const VgxTmplBuild& b, hipStream_t s);
+void vgx_launch_tmpl_classes(const VgxTmplBuild& b, hipStream_t s); // fills b.cls from the representatives' count + emit results
+void vgx_launch_tmpl_build(const VgxTmplBuild& b, hipStream_t s);   // after vgx_launch_tmpl_classes
+void vgx_launch_tmpl_hash(const vgx_draw* draws, uint64_t ndraws, uint64_t period, unsigned long long* hashes, hipStream_t s); // hashes[instance], zeroed by the caller
+void vgx_launch_tmpl_check_cls(const vgx_draw* draws, uint64_t ndraws, uint64_t period, const uint32_t* inst_cls, const uint32_t* cls_rep, VgxTotals* totals, hipStream_t s);
 void vgx_launch_tmpl_emit(const VgxTmplArgs& a, hipStream_t s);
 
 // merging two mesh sequences of a frame (vgx_merge.hip)

@@ -165,13 +165,38 @@ struct VgxTmplElem // one element (polyline vertex j of template mesh `mesh`), i
 	uint32_t jq;   // j | (position of the element inside its tile, in OUTPUT order) << 16
 	float lx, ly;  // its LOCAL vertex (= local polyline[mesh.poly_first + j]): one record is all an element reads from memory
 };
-struct VgxTmplTile // one tile of the instance's element stream = one workgroup of k_tmpl_emit. 16 bytes
+struct VgxTmplTile // one tile of an instance's element stream = one workgroup of k_tmpl_emit. 32 bytes
 {
 	uint32_t mesh0;     // template mesh that owns the tile's first element; bit 31: that element is the mesh's element 0
 	uint32_t mesh_last; // last mesh with an element in the tile
 	uint32_t draw0;     // draws of the period whose records the tile reads (and verifies): [draw0, draw0 + ndraws)
 	uint32_t ndraws;
+	uint32_t nel;       // elements in the tile (the last tile of a class is short)
+	uint32_t cmesh0;    // first template mesh of the tile's class (mesh numbers inside an instance = mesh - cmesh0)
+	uint32_t cdraw0;    // first saved draw record of the tile's class (= class * period)
+	uint32_t pad;
 };
+// A batch may repeat its period in a FEW flavours ("classes": the same drawing at a handful of scales, say): every instance equals
+// one of the class representatives in every field the template depends on. The classes' templates are built as ONE template over
+// the concatenated representatives (period * classes draws); this table says where each class lies in it. [classes + 1] entries,
+// the last one = the totals.
+struct VgxTmplClass // 40 bytes
+{
+	uint64_t elem0;  // first element (output order of the concatenated representatives)
+	uint64_t v0, i0; // first output vertex / index
+	uint32_t mesh0;  // first mesh
+	uint32_t tile0;  // first tile
+	uint32_t pad[2];
+};
+struct VgxTmplInst // multi-class batches: where instance k's output lies, and its class. 32 bytes
+{
+	uint64_t v, i;   // first output vertex / index of the instance
+	uint32_t m;      // first mesh of the instance in the batch's mesh sequence
+	uint32_t cls;
+	uint32_t cmesh0; // first template mesh of its class
+	uint32_t pad;
+};
+#define VGX_TMPL_MAX_CLASSES 64
 
 // Capacities the device-side checks compare against.
 struct VgxCaps

@@ -91,20 +91,86 @@ __global__ __launch_bounds__(256) void k_tmpl_check(const vgx_draw* draws, uint6
 	if (err != VGX_OK) { set_status(totals, err); }
 }
 
-// ---- count pass: the template's tables from the first period's ordinary count + emit --------------------------------
+// ---- count pass: several classes? -------------------------------------------------------------------------------------
+// hashes[instance] = sum over the instance's draws of a hash of (position in the period, the template fields): instances with the
+// same hash are CANDIDATES for one class; k_tmpl_check_cls then compares every draw with its class representative bit by bit.
+__device__ __forceinline__ unsigned long long tmpl_mix(unsigned long long h, uint32_t v)
+{
+	h ^= v; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29;
+	return h;
+}
+__global__ __launch_bounds__(256) void k_tmpl_hash(const vgx_draw* draws, uint64_t ndraws, uint64_t P, unsigned long long* hashes)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ndraws; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint4* q = (const uint4*)(draws + i);
+		const uint4 q0 = q[0], q1 = q[1], q2 = q[2];
+		const uint64_t inst = i / P;
+		unsigned long long h = tmpl_mix(0x243F6A8885A308D3ull, (uint32_t)(i - inst * P));
+		h = tmpl_mix(h, q0.x); h = tmpl_mix(h, q0.y); h = tmpl_mix(h, q0.w); h = tmpl_mix(h, q1.y); h = tmpl_mix(h, q1.z); h = tmpl_mix(h, q1.w); h = tmpl_mix(h, q2.x);
+		atomicAdd(&hashes[inst], h);
+	}
+}
+__global__ __launch_bounds__(256) void k_tmpl_check_cls(const vgx_draw* draws, uint64_t ndraws, uint64_t P, const uint32_t* inst_cls, const uint32_t* cls_rep, VgxTotals* totals)
+{
+	bool bad = false;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ndraws; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t inst = i / P;
+		const uint64_t k = i - inst * P;
+		const uint4* q = (const uint4*)(draws + i);
+		const uint4* t = (const uint4*)(draws + (uint64_t)cls_rep[inst_cls[inst]] * P + k);
+		bad = bad || !tmpl_same(q[0], q[1], q[2], t[0], t[1], t[2]);
+	}
+	if (bad) { totals->tmpl_bad = 1u; }
+}
+
+// ---- count pass: the template's tables from the representatives' ordinary count + emit ------------------------------
+// (one representative = the batch's first period for a batch of one class)
+// Where each class lies in the concatenated template. One thread: the class count is tiny.
+__global__ void k_tmpl_classes(VgxTmplBuild B)
+{
+	const uint64_t M = B.num_meshes;
+	uint32_t tile0 = 0;
+	for (uint32_t c = 0; c <= B.nclasses; ++c) {
+		// first mesh whose draw belongs to class c or a later one (meshes are in draw order)
+		uint64_t lo = 0, hi = M;
+		const uint64_t d0 = (uint64_t)c * B.period;
+		while (lo < hi) {
+			const uint64_t mid = (lo + hi) >> 1;
+			if (B.mdesc[mid].draw < d0) { lo = mid + 1; } else { hi = mid; }
+		}
+		VgxTmplClass r;
+		r.mesh0 = (uint32_t)lo;
+		r.elem0 = B.prefix_fill[lo] + B.prefix_stroke[lo];
+		r.v0 = lo < M ? B.mtab[lo].first_vertex : B.num_vertices;
+		r.i0 = lo < M ? B.mtab[lo].first_index : B.num_indices;
+		r.tile0 = tile0;
+		r.pad[0] = 0; r.pad[1] = 0;
+		B.cls[c] = r;
+		if (c > 0) {
+			const uint64_t e = r.elem0 - B.cls[c - 1].elem0;
+			B.cls[c].tile0 = B.cls[c - 1].tile0 + (uint32_t)((e + B.tile - 1) / B.tile);
+		}
+		tile0 = B.cls[c].tile0;
+	}
+}
+__device__ __forceinline__ uint32_t tmpl_class_of_draw(const VgxTmplBuild& B, uint32_t draw) { return draw / B.period; }
+
 __global__ __launch_bounds__(256) void k_tmpl_meshes(VgxTmplBuild B)
 {
 	const uint64_t M = B.num_meshes;
 	for (uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (uint64_t)gridDim.x * blockDim.x) {
 		const VgxMeshDesc md = B.mdesc[m];
 		const VgxMeshPrep pr = B.mprep[m];
-		const vgx_mesh mt = B.mtab[m];
+		vgx_mesh mt = B.mtab[m];
+		const uint32_t ci = tmpl_class_of_draw(B, md.draw);
+		const VgxTmplClass cl = B.cls[ci];
+		mt.first_vertex -= cl.v0; mt.first_index -= cl.i0; mt.draw -= ci * B.period; // relative to ONE instance of the class
 		VgxTmplMesh t;
 		t.poly_first = (uint32_t)md.poly_first;
 		t.n = md.poly_n;
 		t.v_off = (uint32_t)mt.first_vertex;
 		t.i_off = (uint32_t)mt.first_index;
-		t.drawk = md.draw;
+		t.drawk = mt.draw;
 		t.kind = md.kind;
 		if (VGX_MD_KIND(md.kind) >= VGX_MESH_STROKE) { t.f0 = pr.f0; t.f1 = pr.f1; } // hsw / hswAA (thin: fringe, fringe)
 		else { t.f0 = B.draws[md.draw].fringe * 0.5f; t.f1 = 0.0f; }                // |aa| = fringe / 2 (stroker.cpp:723); the sign is per instance
@@ -118,7 +184,8 @@ __global__ __launch_bounds__(256) void k_tmpl_meshes(VgxTmplBuild B)
 }
 
 // Element table in processing order: tiles of `tile` elements of the instance's output-ordered element stream; inside a
-// tile the fill elements first, then the stroke elements (both in output order).
+// tile the fill elements first, then the stroke elements (both in output order). Every class starts a tile of its own
+// (tile cls.tile0, table slot cls.tile0 * tile): a tile never holds elements of two classes.
 __global__ __launch_bounds__(256) void k_tmpl_elems(VgxTmplBuild B)
 {
 	const uint64_t M = B.num_meshes;
@@ -145,10 +212,17 @@ __global__ __launch_bounds__(256) void k_tmpl_elems(VgxTmplBuild B)
 		uint32_t j, j0, j1;
 		bool isFill, d0, d1;
 		locate(e, &m, &f, &s, &j, &isFill);
-		const uint64_t x0 = e / T * T;
+		const uint32_t c = tmpl_class_of_draw(B, B.mdesc[m].draw);
+		const VgxTmplClass cl = B.cls[c];
+		const uint64_t cEnd = B.cls[c + 1].elem0;
+		const uint64_t el = e - cl.elem0;              // element inside its class
+		const uint64_t tl = el / T;                    // tile inside its class
+		const uint64_t x0 = cl.elem0 + tl * T;         // the tile's first element (output order of the concatenated template)
+		const uint64_t x1 = x0 + T < cEnd ? x0 + T : cEnd;
 		locate(x0, &m0, &f0, &s0, &j0, &d0);
-		locate(x0 + T, &m1, &f1, &s1, &j1, &d1);
-		const uint64_t slot = x0 + (isFill ? f - f0 : (f1 - f0) + (s - s0));
+		locate(x1, &m1, &f1, &s1, &j1, &d1);
+		const uint64_t tile = cl.tile0 + tl;
+		const uint64_t slot = tile * T + (isFill ? f - f0 : (f1 - f0) + (s - s0));
 		VgxTmplElem r;
 		r.mesh = (uint32_t)m;
 		r.jq = j | ((uint32_t)(e - x0) << 16); // j < 65536 (a mesh holds at most 65536 vertices), position in the tile < tile <= 65536
@@ -156,7 +230,8 @@ __global__ __launch_bounds__(256) void k_tmpl_elems(VgxTmplBuild B)
 		r.lx = lv.x; r.ly = lv.y;
 		B.telem[slot] = r;
 		if (e == x0) { // tile record, first half: the mesh that owns the tile's first element; bit 31: it begins exactly here
-			B.ttile[e / T].mesh0 = (uint32_t)m | (j == 0 ? 0x80000000u : 0u);
+			B.ttile[tile].mesh0 = (uint32_t)m | (j == 0 ? 0x80000000u : 0u);
+			B.ttile[tile].nel = (uint32_t)(x1 - x0);
 		}
 	}
 }
@@ -166,17 +241,24 @@ __global__ __launch_bounds__(256) void k_tmpl_elems(VgxTmplBuild B)
 // (every draw record is verified by some workgroup of every instance).
 __global__ __launch_bounds__(256) void k_tmpl_tiles(VgxTmplBuild B)
 {
-	const uint32_t nt = (uint32_t)((B.num_elems + B.tile - 1) / B.tile);
+	const uint32_t nt = B.cls[B.nclasses].tile0;
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= nt) { return; }
+	uint32_t c = 0;
+	while (c + 1 < B.nclasses && B.cls[c + 1].tile0 <= t) { ++c; }
+	const bool first = t == B.cls[c].tile0, last = t + 1 == B.cls[c + 1].tile0; // of its class
 	const uint32_t mA = B.ttile[t].mesh0 & 0x7FFFFFFFu;
-	uint32_t mB = (uint32_t)B.num_meshes - 1;
-	if (t + 1 < nt) { const uint32_t nx = B.ttile[t + 1].mesh0; mB = (nx & 0x7FFFFFFFu) - (nx >> 31); }
-	const uint32_t dA = t == 0 ? 0u : B.mdesc[mA].draw;
-	const uint32_t dB = t + 1 == nt ? B.period - 1 : B.mdesc[mB].draw;
+	uint32_t mB = B.cls[c + 1].mesh0 - 1;
+	if (!last) { const uint32_t nx = B.ttile[t + 1].mesh0; mB = (nx & 0x7FFFFFFFu) - (nx >> 31); }
+	const uint32_t d0 = c * B.period;
+	const uint32_t dA = first ? 0u : B.mdesc[mA].draw - d0;
+	const uint32_t dB = last ? B.period - 1 : B.mdesc[mB].draw - d0;
 	B.ttile[t].mesh_last = mB;
 	B.ttile[t].draw0 = dA;
 	B.ttile[t].ndraws = dB - dA + 1;
+	B.ttile[t].cmesh0 = B.cls[c].mesh0;
+	B.ttile[t].cdraw0 = d0;
+	B.ttile[t].pad = 0;
 }
 
 // ---- step ------------------------------------------------------------------------------------------------------------
@@ -223,10 +305,10 @@ __device__ __forceinline__ TmplXf tmpl_draw_xf(const TmplDraw* d)
 
 // One draw record of the instance: checks (the ordinary path's finiteness checks + equality with the saved first period in
 // every field the template depends on) and the part the emit needs.
-__device__ __forceinline__ TmplDraw tmpl_load_draw(const VgxTmplArgs& A, const vgx_draw* idraws, uint32_t k)
+__device__ __forceinline__ TmplDraw tmpl_load_draw(const VgxTmplArgs& A, const vgx_draw* idraws, const vgx_draw* tdraws, uint32_t k)
 {
 	const uint4* q = (const uint4*)(idraws + k);
-	const uint4* t = (const uint4*)(A.tdraws + k);
+	const uint4* t = (const uint4*)(tdraws + k);
 	const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
 	const uint4 t0 = t[0], t1 = t[1], t2 = t[2];
 	const uint32_t e = tmpl_validate(q0, q1, q2, q3, A.npaths);
@@ -378,14 +460,24 @@ __device__ __forceinline__ void tmpl_stroke_elem(const TmplOut& O, uint32_t kind
 	}
 }
 
+// Where one instance lies in the batch (workgroup-uniform): output bases, first mesh, first draw; its class's saved draw records
+// and first template mesh.
+struct TmplPlace
+{
+	uint64_t v, i;     // first output vertex / index
+	uint64_t m;        // first mesh in the batch's mesh sequence
+	uint32_t draw0;    // first draw (= instance * period)
+	uint32_t cmesh0;   // first template mesh of the class
+	const vgx_draw* tdraws; // the class representative's draw records
+};
 // the caller's mesh table: the template's record moved to this instance
-__device__ __forceinline__ void tmpl_mesh_out(const VgxTmplArgs& A, uint64_t inst, uint32_t mesh)
+__device__ __forceinline__ void tmpl_mesh_out(const VgxTmplArgs& A, const TmplPlace& P, uint32_t mesh)
 {
 	vgx_mesh mr = A.tmtab[mesh];
-	mr.first_vertex += inst * A.inst.num_vertices;
-	mr.first_index += inst * A.inst.num_indices;
-	mr.draw += (uint32_t)(inst * A.period);
-	A.meshes_out[inst * A.inst.num_meshes + mesh] = mr;
+	mr.first_vertex += P.v;
+	mr.first_index += P.i;
+	mr.draw += P.draw0;
+	A.meshes_out[P.m + (mesh - P.cmesh0)] = mr;
 }
 
 // One element given its mesh's constants, its transformed vertex, its own edge direction and a way to get the mesh's other
@@ -420,21 +512,28 @@ __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uin
 // (template record + instance offsets) before the assembly kernels run. k_tmpl_emit then adds each mesh's base to its indices.
 __global__ __launch_bounds__(256) void k_tmpl_mtab(VgxTmplArgs A, vgx_mesh* mtab, VgxMeshDesc* mdesc)
 {
-	const uint64_t M = A.inst.num_meshes, total = A.ninst * M;
-	if (blockIdx.x == 0 && threadIdx.x == 0) {
-		vgx_sizes z;
-		z.num_poly_vertices = A.ninst * A.inst.num_poly_vertices; z.num_subpaths = A.ninst * A.inst.num_subpaths; z.num_meshes = total;
-		z.num_vertices = A.ninst * A.inst.num_vertices; z.num_indices = A.ninst * A.inst.num_indices; z.num_serial_draws = A.ninst * A.inst.num_serial_draws;
-		z.num_cmd_instances = A.ninst * A.inst.num_cmd_instances; z.num_elements = A.ninst * A.inst.num_elements; z.num_fill_elements = A.ninst * A.inst.num_fill_elements;
-		z.num_drawcmds = 0;
-		A.totals->sizes = z;
-	}
+	const uint64_t M = A.inst.num_meshes, total = A.total.num_meshes;
+	if (blockIdx.x == 0 && threadIdx.x == 0) { A.totals->sizes = A.total; }
 	for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (uint64_t)gridDim.x * blockDim.x) {
-		const uint64_t inst = k / M;
-		const uint32_t m = (uint32_t)(k - inst * M);
+		uint64_t inst, vb, ib;
+		uint32_t m;
+		if (A.iinfo) { // several classes: the instance that owns mesh k = the last one whose first mesh is <= k
+			uint64_t lo = 0, hi = A.ninst;
+			while (hi - lo > 1) {
+				const uint64_t mid = (lo + hi) >> 1;
+				if (A.iinfo[mid].m <= k) { lo = mid; } else { hi = mid; }
+			}
+			const VgxTmplInst ii = A.iinfo[lo];
+			inst = lo; vb = ii.v; ib = ii.i;
+			m = (uint32_t)(k - ii.m) + ii.cmesh0;
+		} else {
+			inst = k / M;
+			m = (uint32_t)(k - inst * M);
+			vb = inst * A.inst.num_vertices; ib = inst * A.inst.num_indices;
+		}
 		vgx_mesh r = A.tmtab[m];
-		r.first_vertex += inst * A.inst.num_vertices;
-		r.first_index += inst * A.inst.num_indices;
+		r.first_vertex += vb;
+		r.first_index += ib;
 		r.draw += (uint32_t)(inst * A.period);
 		mtab[k] = r;
 		mdesc[k].draw = r.draw;
@@ -455,39 +554,46 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 	__shared__ float2 s_dir[VGX_TMPL_MAX_TILE];
 	__shared__ uint32_t s_status;
 	const uint32_t tid = threadIdx.x;
-	const uint32_t inst32 = blockIdx.x / A.tiles_per_inst;
-	const uint32_t t = blockIdx.x - inst32 * A.tiles_per_inst;
+	// workgroup -> (instance, tile of the template), all workgroup-uniform (scalar loads)
+	uint32_t inst32, t;
+	TmplPlace P;
+	if (A.wg) { // several classes: the tiles of an instance are its class's, the output places come from the per-instance table
+		const uint2 w = A.wg[blockIdx.x];
+		inst32 = w.x; t = w.y;
+		const VgxTmplInst ii = A.iinfo[inst32];
+		P.v = ii.v; P.i = ii.i; P.m = ii.m;
+	} else {
+		inst32 = blockIdx.x / A.tiles_per_inst;
+		t = blockIdx.x - inst32 * A.tiles_per_inst;
+		P.v = (uint64_t)inst32 * A.inst.num_vertices; P.i = (uint64_t)inst32 * A.inst.num_indices; P.m = (uint64_t)inst32 * A.inst.num_meshes;
+	}
 	const uint64_t inst = inst32;
-	const VgxTmplTile tl = A.ttile[t]; // workgroup-uniform: scalar loads
-	const uint32_t E = (uint32_t)A.inst.num_elements;
+	const VgxTmplTile tl = A.ttile[t];
+	P.draw0 = (uint32_t)(inst * A.period); P.cmesh0 = tl.cmesh0; P.tdraws = A.tdraws + tl.cdraw0;
 	const uint32_t x0 = t * A.tile;
-	const uint32_t nel = x0 + A.tile < E ? A.tile : E - x0;
+	const uint32_t nel = tl.nel;
 	const uint32_t mA = tl.mesh0 & 0x7FFFFFFFu;
 	const bool firstWhole = (tl.mesh0 >> 31) != 0; // mesh mA begins in this tile (else in an earlier one)
 	const uint32_t nm = tl.mesh_last - mA + 1;
 	const uint32_t dA = tl.draw0, nd = tl.ndraws;
 	const vgx_draw* idraws = A.draws + inst * A.period;
 	const VgxTmplElem* telem = A.telem + x0;
+	const uint32_t* meshBase = A.mesh_base ? A.mesh_base + (P.m - P.cmesh0) : nullptr; // indexed by template mesh number
 	TmplOut O;
-	O.pos = (char*)(A.pos + 2 * (inst * A.inst.num_vertices));
-	O.col = (char*)(A.color + inst * A.inst.num_vertices);
-	O.idx = (char*)(A.idx + inst * A.inst.num_indices);
-	if (t == 0 && inst == 0 && tid == 0 && !A.mesh_base) { // (assembly armed: k_tmpl_mtab wrote them already) totals of the batch = instances x template (the memset in front of this kernel zeroed them)
-		vgx_sizes z;
-		z.num_poly_vertices = A.ninst * A.inst.num_poly_vertices; z.num_subpaths = A.ninst * A.inst.num_subpaths; z.num_meshes = A.ninst * A.inst.num_meshes;
-		z.num_vertices = A.ninst * A.inst.num_vertices; z.num_indices = A.ninst * A.inst.num_indices; z.num_serial_draws = A.ninst * A.inst.num_serial_draws;
-		z.num_cmd_instances = A.ninst * A.inst.num_cmd_instances; z.num_elements = A.ninst * A.inst.num_elements; z.num_fill_elements = A.ninst * A.inst.num_fill_elements;
-		z.num_drawcmds = 0;
-		A.totals->sizes = z;
+	O.pos = (char*)(A.pos + 2 * P.v);
+	O.col = (char*)(A.color + P.v);
+	O.idx = (char*)(A.idx + P.i);
+	if (blockIdx.x == 0 && tid == 0 && !A.mesh_base) { // (assembly armed: k_tmpl_mtab wrote them already) totals of the batch (the memset in front of this kernel zeroed them)
+		A.totals->sizes = A.total;
 	}
 	if (nm > VGX_TMPL_MAXM || nd > VGX_TMPL_MAXM) {
 		// workgroup-uniform. Many tiny meshes (or many draws without a mesh) in one tile: the draw records are verified in a loop,
 		// every lane fetches its own records and neighbours
-		for (uint32_t k = tid; k < nd; k += VGX_TMPL_THREADS) { (void)tmpl_load_draw(A, idraws, dA + k); }
+		for (uint32_t k = tid; k < nd; k += VGX_TMPL_THREADS) { (void)tmpl_load_draw(A, idraws, P.tdraws, dA + k); }
 		for (uint32_t s = tid; s < nel; s += VGX_TMPL_THREADS) {
 			const VgxTmplElem er = telem[s];
 			const VgxTmplMesh tm = A.tmesh[er.mesh];
-			const TmplDraw dr = tmpl_load_draw(A, idraws, tm.drawk);
+			const TmplDraw dr = tmpl_load_draw(A, idraws, P.tdraws, tm.drawk);
 			const TmplXf xf = tmpl_draw_xf(&dr);
 			const float2* vt = A.tpoly + tm.poly_first;
 			const uint32_t kind = VGX_MD_KIND(tm.kind);
@@ -495,8 +601,8 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 			float f0 = tm.f0;
 			if (kind == VGX_MESH_FILL_AA) { f0 = tmpl_fill_aa(xf, vt[0], vt[1], vt[2], tm.f0); }
 			auto dir = [&](uint32_t jj) { return v2dir(tmpl_xf(xf, vt[jj]), tmpl_xf(xf, vt[jj + 1 < N ? jj + 1 : 0u])); };
-			if (j == 0 && A.meshes_out) { tmpl_mesh_out(A, inst, er.mesh); }
-			const uint32_t ibase = A.mesh_base ? A.mesh_base[inst * A.inst.num_meshes + er.mesh] : 0u;
+			if (j == 0 && A.meshes_out) { tmpl_mesh_out(A, P, er.mesh); }
+			const uint32_t ibase = meshBase ? meshBase[er.mesh] : 0u;
 			tmpl_elem_emit(O, j, tm.kind, N, tm.v_off, tm.i_off, ibase, kind < VGX_MESH_STROKE ? dr.fill_color : dr.stroke_color, f0, tm.f1, tmpl_xf(xf, vt[j]), dir(j), dir);
 		}
 		return;
@@ -521,9 +627,9 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 	uint32_t ibase = 0;
 	if (tid < nm) {
 		tm = A.tmesh[mA + tid];
-		if (A.mesh_base) { ibase = A.mesh_base[inst * A.inst.num_meshes + mA + tid]; }
+		if (meshBase) { ibase = meshBase[mA + tid]; }
 	}
-	if (tid < nd) { s_draw[tid] = tmpl_load_draw(A, idraws, dA + tid); }
+	if (tid < nd) { s_draw[tid] = tmpl_load_draw(A, idraws, P.tdraws, dA + tid); }
 	if (tid == 0) { s_status = A.totals->status; } // an earlier workgroup may have found the batch stale; ONE value for the whole workgroup (the exit below must be uniform)
 	__syncthreads();
 	const uint32_t status = s_status;
@@ -537,7 +643,7 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 		if (kind == VGX_MESH_FILL_AA) { r.f0 = tmpl_fill_aa(tmpl_draw_xf(d), make_float2(tm.l0[0], tm.l0[1]), make_float2(tm.l1[0], tm.l1[1]), make_float2(tm.l2[0], tm.l2[1]), tm.f0); }
 		s_rec[tid] = r;
 		// the caller's mesh table for the meshes that BEGIN in this tile (every mesh of the range but possibly the first)
-		if ((tid > 0 || firstWhole) && A.meshes_out && status == VGX_OK) { tmpl_mesh_out(A, inst, mA + tid); }
+		if ((tid > 0 || firstWhole) && A.meshes_out && status == VGX_OK) { tmpl_mesh_out(A, P, mA + tid); }
 	}
 	__syncthreads();
 	TMPL_PROF(0);
@@ -613,10 +719,25 @@ void vgx_launch_tmpl_check(const vgx_draw* draws, uint64_t ndraws, uint32_t npat
 	hipLaunchKernelGGL(k_tmpl_check, dim3(1024), dim3(256), 0, s, draws, ndraws, npaths, totals);
 }
 
+void vgx_launch_tmpl_hash(const vgx_draw* draws, uint64_t ndraws, uint64_t period, unsigned long long* hashes, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_tmpl_hash, dim3(1024), dim3(256), 0, s, draws, ndraws, period, hashes);
+}
+
+void vgx_launch_tmpl_check_cls(const vgx_draw* draws, uint64_t ndraws, uint64_t period, const uint32_t* inst_cls, const uint32_t* cls_rep, VgxTotals* totals, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_tmpl_check_cls, dim3(1024), dim3(256), 0, s, draws, ndraws, period, inst_cls, cls_rep, totals);
+}
+
+void vgx_launch_tmpl_classes(const VgxTmplBuild& b, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_tmpl_classes, dim3(1), dim3(1), 0, s, b);
+}
+
 void vgx_launch_tmpl_build(const VgxTmplBuild& b, hipStream_t s)
 {
 	const uint64_t gm = (b.num_meshes + 255) / 256, ge = (b.num_elems + 255) / 256;
-	const uint64_t nt = (b.num_elems + b.tile - 1) / b.tile;
+	const uint64_t nt = (b.num_elems + b.tile - 1) / b.tile + b.nclasses; // >= the tile count (every class rounds up on its own)
 	if (b.num_meshes) { hipLaunchKernelGGL(k_tmpl_meshes, dim3((unsigned)(gm > 4096 ? 4096 : gm)), dim3(256), 0, s, b); }
 	if (b.num_elems) {
 		hipLaunchKernelGGL(k_tmpl_elems, dim3((unsigned)(ge > 4096 ? 4096 : ge)), dim3(256), 0, s, b);
@@ -631,6 +752,6 @@ void vgx_launch_tmpl_mtab(const VgxTmplArgs& a, vgx_mesh* mtab, VgxMeshDesc* mde
 
 void vgx_launch_tmpl_emit(const VgxTmplArgs& a, hipStream_t s)
 {
-	const uint64_t blocks = a.ninst * a.tiles_per_inst; // the host checked < 2^31
+	const uint64_t blocks = a.wg ? a.num_wg : a.ninst * a.tiles_per_inst; // the host checked < 2^31
 	if (blocks) { hipLaunchKernelGGL(k_tmpl_emit, dim3((unsigned)blocks), dim3(VGX_TMPL_THREADS), 0, s, a); }
 }

@@ -441,3 +441,21 @@ def template_draws(ps, seed, instances, same_colors=False):
             d["fill_color"][s] = rs.randint(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
             d["stroke_color"][s] = rs.randint(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
     return d
+
+
+def template_class_draws(ps, seed, instances, nclasses):
+    """template_draws in `nclasses` flavours: flavour c is the same drawing with its own per-path scale / tolerance / fringe,
+    fill kinds and stroke widths (as if recorded under another State); every instance takes one flavour at random (the first
+    `nclasses` instances one each, so that all occur) and its own transform and colours. What the template mode handles with
+    one template per class."""
+    rs = np.random.RandomState(seed + 9191)
+    n = ps.npaths
+    flav = [template_draws(ps, seed + 31 * c, 1, same_colors=True) for c in range(nclasses)]
+    pick = np.concatenate([np.arange(nclasses), rs.randint(0, nclasses, size=max(0, instances - nclasses))])[:instances]
+    base = template_draws(ps, seed, instances)  # transforms / colours per instance
+    d = np.concatenate([flav[int(c)] for c in pick])
+    d["mtx"] = base["mtx"]
+    d["fill_color"] = base["fill_color"]
+    d["stroke_color"] = base["stroke_color"]
+    return d, pick
+

@@ -653,7 +653,7 @@ def main():
 
     # ---- next rows, measured beside the headline on rank 0 of a 1-GPU run: not part of `value` ----
     next_rows = None
-    if rank == 0 and world == 1 and args.config == "tiger10k":
+    if rank == 0 and world == 1 and args.config == "tiger10k" and not args.no_configs:
         nv_all, ni_all = sizes["num_vertices"], sizes["num_indices"]
         # draw-command assembly armed: cost of the partition kernels inside one step
         cap = 2 * (nv_all // 65536) + 2

@@ -1,6 +1,7 @@
 """GPU soak of the template mode (not collected by pytest): N random closed-shape drawings (every path command, serial shapes,
 fills AA / plain / SSE index order, hairline and regular closed Miter strokes, many-small-mesh drawings that take the per-lane
-fallback) x 32..90 instances under random affine transforms and colours, through vgx_tessellate against the reference oracle:
+fallback) x 32..90 instances under random affine transforms and colours -- every other seed in 2..9 classes (flavours of the drawing
+with their own scales / tolerances / fill kinds / stroke widths) --, through vgx_tessellate against the reference oracle:
 default tiles, small / odd tile sizes, with draw-command assembly armed on a third of the seeds (assembled indices against the
 oracle's assembly). `python tests/soak_gpu_tmpl.py 300`."""
 import importlib, sys, os, numpy as np, torch
@@ -43,7 +44,10 @@ for seed in range(7000, 7000 + n):
     ninst = int(rs.randint(32, 91))
     while ninst * npaths <= 2048:
         ninst += 13
-    d = wl.template_draws(ps, seed, ninst, same_colors=bool(seed % 7 == 0))
+    if seed % 2:  # several classes: 2..9 flavours of the drawing, instances mixed at random
+        d, _ = wl.template_class_draws(ps, seed, ninst, int(rs.randint(2, 10)))
+    else:
+        d = wl.template_draws(ps, seed, ninst, same_colors=bool(seed % 7 == 0))
     ctx = ctxs[seed % len(ctxs)]
     armed = seed % 3 == 0
     ref = pyoracle.tessellate(ps, d)

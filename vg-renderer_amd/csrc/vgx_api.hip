@@ -1386,10 +1386,18 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 			if (k < ninst) {
 				const uint32_t c = instCls[k];
 				r.cls = c; r.cmesh0 = cls[c].mesh0;
-				for (uint32_t t = cls[c].tile0; t < cls[c + 1].tile0; ++t) { wg[(size_t)w++] = make_uint2((uint32_t)k, t); }
 				v += csz[c].num_vertices; i += csz[c].num_indices; m += csz[c].num_meshes;
 			}
 			ii[(size_t)k] = r;
+		}
+		// Workgroup order: class after class (the instances of a class in draw order). The output places are the instances' own
+		// whatever the order; running one class's instances together keeps ONE class's tables hot in L2 instead of all of them
+		// (instances in draw order: 3.9 GB of table re-reads from HBM for Tiger x 10k in 18 classes).
+		for (uint32_t c = 0; c < T; ++c) {
+			for (uint64_t k = 0; k < ninst; ++k) {
+				if (instCls[k] != c) { continue; }
+				for (uint32_t t = cls[c].tile0; t < cls[c + 1].tile0; ++t) { wg[(size_t)w++] = make_uint2((uint32_t)k, t); }
+			}
 		}
 		if ((st = ensure(ctx, ctx->tmplIinfo, (ninst + 1) * sizeof(VgxTmplInst))) != VGX_OK) { return st; }
 		if ((st = ensure(ctx, ctx->tmplWg, ((size_t)numWg + 1) * sizeof(uint2))) != VGX_OK) { return st; }

@@ -282,7 +282,11 @@ int vgx_tessellate_emit(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* dra
  * vg.cpp:4957-4975) and vgx_tessellate on this path set with any whole number of periods is one kernel: per instance the
  * template's vertices through the instance's transform, the stroker's per-element arithmetic, stores. Every call re-checks all
  * draw records against the counted period on the device; a draw that differs in another field ends the call with
- * VGX_E_STALE in dev_status (outputs undefined): count again. VGX_TMPL=0 in the environment at vgx_create turns the mode off. */
+ * VGX_E_STALE in dev_status (outputs undefined): count again. VGX_TMPL=0 in the environment at vgx_create turns the mode off.
+ * The period may also come in a FEW flavours ("classes", at most 64: the same drawing at a handful of scales, say): every
+ * instance then equals one class representative in the fields above, each class gets its own template, instances of different
+ * classes have different sizes. Such a template belongs to the counted batch: vgx_tessellate takes it for the same number of
+ * draws, with every instance still of the class it had at the count (else VGX_E_STALE). VGX_TMPL_CLASSES=0 turns this off. */
 int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream);
 
 /* ---- stroker level: polylines in, meshes out ----------------------------------------------------- */

@@ -630,7 +630,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 								sink.prev = start; sink.n = 0; sink.slow = false; sink.out = out; sink.writeLimit = limit; sink.mtx = mtx;
 								wave_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tol / (scale * scale), stack, sink);
 							}
-						} else if (type == VGX_CMD_POLYLINE) {
+						} else if (type == VGX_CMD_POLYLINE && limit < VGX_WAVE) { // (longer ones: the whole wave, below)
 							const uint32_t skip = (na >> 1) - (uint32_t)rawCnt;
 							for (uint32_t i = 0; i < limit; ++i) {
 								const V2 p = v2xform(v2(pa[2 * (i + skip)], pa[2 * (i + skip) + 1]), mtx);
@@ -641,6 +641,27 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 							VgxSubRec sr;
 							sr.first = g - (uint64_t)spBefore; sr.info = (uint32_t)spTotal | (closedHere ? 0x80000000u : 0u); sr.pad = 0;
 							A.sub_rec[A.sub_prefix[d] + (uint64_t)(subsIncl - 1)] = sr; // dense, in draw order: record j of draw d at sub_prefix[d] + j
+						}
+					}
+					{
+						// Long POLYLINE commands (pathPolyline copies its points verbatim behind the one epsilon test on the first,
+						// path.cpp:684-705): the wave moves them together, 64 consecutive points per step -- coalesced 512-byte loads
+						// and stores instead of one lane walking a thousand points while 63 wait (10k polylines x 1k points: one lane
+						// per command is 157 waves on the whole chip).
+						uint64_t longMask = wave_ballot(valid && !serialDraw && type == VGX_CMD_POLYLINE && limit >= (uint32_t)VGX_WAVE);
+						while (longMask) {
+							const int src = __builtin_ctzll(longMask);
+							longMask &= longMask - 1;
+							const uint64_t gS = wave_bcast_u64(g, src);
+							const float* paS = (const float*)wave_bcast_u64((uint64_t)(pa + 2 * ((na >> 1) - (uint32_t)rawCnt)), src);
+							const float* mS = (const float*)wave_bcast_u64((uint64_t)mtx, src);
+							const uint32_t limS = (uint32_t)wave_bcast((int)limit, src);
+							const float m0 = mS[0], m1 = mS[1], m2 = mS[2], m3 = mS[3], m4 = mS[4], m5 = mS[5];
+							float2* outS = (float2*)A.poly + gS;
+							for (uint32_t i = (uint32_t)lane; i < limS; i += VGX_WAVE) {
+								const float2 q = *(const float2*)(paS + 2 * (size_t)i);
+								outS[i] = make_float2(m0 * q.x + m2 * q.y + m4, m1 * q.x + m3 * q.y + m5); // transformPos2D, vg_util.h:24-28
+							}
 						}
 					}
 					{ // draws the serial kernel has to (re)do: static serial paths and degenerate draws, wave-aggregated append

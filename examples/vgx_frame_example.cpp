@@ -1,7 +1,9 @@
 // vgx_frame_example.cpp -- one frame from a recorded vg::CommandList to bgfx-ready buffers, in plain C++ on the C-ABI:
 //   bytes of a command list (written here by hand in the reference's wire format, vg.cpp:243-247, 2403-2690)
 //   -> vgx_cmdlist_decode (host: paths + draws + per-draw state)          [replaces ctxSubmitCommandList's interpreter]
-//   -> vgx_pathset_create, vgx_set_assembly, vgx_tessellate_count, vgx_tessellate (device)
+//   -> vgx_pathset_create, vgx_tessellate_count, vgx_tessellate (device): the meshes of the path draws
+//   -> vgx_set_assembly + vgx_merge_uv (device): the user meshes of the list's IndexedTriList commands (vg::indexedTriList,
+//      vg.cpp:4129-4175; the decoder hands them over) put at their draws' places, the frame assembled
 //   -> vertex streams (pos / uv / colour), ONE index buffer rebased per draw command, the draw-command table
 //      (what createDrawCommand_VertexColor / allocDrawCommand leave for vg::end to upload, vg.cpp:5207-5460, 1076-1288).
 //   hipcc -O2 -I include examples/vgx_frame_example.cpp -L vg-renderer_amd -lvgx -Wl,-rpath,$PWD/vg-renderer_amd -o vgx_frame_example
@@ -23,7 +25,7 @@
 // vg::CommandType values used here (vg.cpp:177-241) and the record layout: CommandHeader{uint32 type, uint32 size}
 // padded to 16 bytes, then the payload padded to 16 bytes (clAllocCommand, vg.cpp:5694-5723)
 enum { CT_BeginPath = 0, CT_MoveTo = 1, CT_LineTo = 2, CT_CubicTo = 3, CT_Rect = 7, CT_Circle = 10, CT_ClosePath = 13, CT_FillPathColor = 14,
-       CT_StrokePathColor = 17, CT_PushState = 28, CT_PopState = 29, CT_SetScissor = 31, CT_TransformTranslate = 35 };
+       CT_StrokePathColor = 17, CT_IndexedTriList = 20, CT_PushState = 28, CT_PopState = 29, CT_SetScissor = 31, CT_TransformTranslate = 35 };
 struct ListWriter
 {
 	std::vector<uint8_t> b;
@@ -37,6 +39,16 @@ struct ListWriter
 	}
 	void f(uint32_t type, std::initializer_list<float> v) { std::vector<float> a(v); cmd(type, a.data(), (uint32_t)a.size() * 4); }
 	void fill(uint32_t color, bool aa) { const uint32_t p[2] = { aa ? 4u : 0u, color }; cmd(CT_FillPathColor, p, 8); }           // VG_FILL_FLAGS
+	// clIndexedTriList (vg.cpp:2566-2611): uint32 nv, float2 pos[nv], uint32 nuv, int16x2 uv[nuv], uint32 nc, Color col[nc], uint32 ni, uint16 idx[ni], uint16 image
+	void triList(const float* pos, const int16_t* uv, uint32_t nv, const uint32_t* col, uint32_t nc, const uint16_t* idx, uint32_t ni, uint16_t image)
+	{
+		std::vector<uint8_t> p;
+		auto put = [&](const void* src, size_t n) { p.insert(p.end(), (const uint8_t*)src, (const uint8_t*)src + n); };
+		const uint32_t nuv = uv ? nv : 0u;
+		put(&nv, 4); put(pos, (size_t)nv * 8); put(&nuv, 4); if (uv) { put(uv, (size_t)nv * 4); }
+		put(&nc, 4); put(col, (size_t)nc * 4); put(&ni, 4); put(idx, (size_t)ni * 2); put(&image, 2);
+		cmd(CT_IndexedTriList, p.data(), (uint32_t)p.size());
+	}
 	void stroke(uint32_t color, float w, uint32_t cap, uint32_t join, bool aa)                                                       // VG_STROKE_FLAGS
 	{
 		uint8_t p[12]; const uint32_t flags = ((aa ? 1u : 0u) << 4) | (cap << 2) | join;
@@ -58,6 +70,13 @@ int main()
 		L.fill(0xFF2060C0u + (uint32_t)i, true);
 		if (i % 2) { L.stroke(0xFF000000u, 2.0f, 0, 0, true); }
 		if (i == 150) { L.f(CT_SetScissor, { 0.0f, 0.0f, 640.0f, 720.0f }); } // a scissor change: a new draw command from here on
+		if (i % 100 == 50) { // a user mesh between the paths: a textured quad on image 3 with its own UVs and per-vertex colours
+			const float q[8] = { x, y, x + 30.0f, y, x + 30.0f, y + 30.0f, x, y + 30.0f };
+			const int16_t uv[8] = { 0, 0, 32767, 0, 32767, 32767, 0, 32767 };
+			const uint32_t col[4] = { 0xFFFFFFFFu, 0xFF0000FFu, 0xFF00FF00u, 0xFFFF0000u };
+			const uint16_t idx[6] = { 0, 1, 2, 0, 2, 3 };
+			L.triList(q, uv, 4, col, 4, idx, 6, 3);
+		}
 	}
 
 	// ---- host: decode (count pass, then store pass) ----
@@ -74,8 +93,16 @@ int main()
 	o.cmd_type = cmdType.data(); o.cmd_arg_off = argOff.data(); o.args = args.data(); o.path_cmd_begin = pathBegin.data();
 	o.draws = draws.data(); o.draw_state = dstate.data();
 	o.cap_cmds = o.num_cmds; o.cap_args = o.num_args; o.cap_paths = o.num_paths; o.cap_draws = o.num_draws;
+	// the list's user meshes (IndexedTriList): positions through the state transform, colours, UVs, mesh-local indices, one record each
+	std::vector<float> triPos(o.num_tri_vertices * 2 + 2);
+	std::vector<uint32_t> triCol(o.num_tri_vertices + 1), triUV(o.num_tri_vertices + 1);
+	std::vector<uint16_t> triIdx(o.num_tri_indices + 1);
+	std::vector<vgx_mesh> triMesh(o.num_tri_meshes + 1);
+	o.tri_pos = triPos.data(); o.tri_color = triCol.data(); o.tri_uv = triUV.data(); o.tri_idx = triIdx.data(); o.tri_meshes = triMesh.data();
+	o.cap_tri_vertices = o.num_tri_vertices; o.cap_tri_indices = o.num_tri_indices; o.cap_tri_meshes = o.num_tri_meshes;
+	st.white_uv[0] = 0x003F003Fu; st.font_image = 0; // getWhitePixelUV / m_FontImages[0] of the Context the list is submitted to
 	CHECK(vgx_cmdlist_decode(L.b.data(), (uint32_t)L.b.size(), &st, &o));
-	printf("list: %zu bytes -> %u paths, %u path commands, %u draws, %u skipped\n", L.b.size(), o.num_paths, o.num_cmds, o.num_draws, o.num_skipped);
+	printf("list: %zu bytes -> %u paths, %u path commands, %u draws (%u of them user meshes), %u skipped\n", L.b.size(), o.num_paths, o.num_cmds, o.num_draws, o.num_tri_meshes, o.num_skipped);
 
 	// ---- device: tessellate with draw-command assembly armed ----
 	vgx_ctx* ctx = nullptr;
@@ -90,6 +117,26 @@ int main()
 	CHECK(vgx_tessellate_count(ctx, ps, devDraws, o.num_draws, &sz, nullptr));
 
 	const uint32_t maxVB = 4096; // Config::m_MaxVBVertices: small, so that the frame needs several vertex buffers
+	// sequence A: the meshes of the path draws (the user-mesh draws have none here)
+	vgx_mesh_out seqA = {};
+	seqA.cap_vertices = sz.num_vertices; seqA.cap_indices = sz.num_indices; seqA.cap_meshes = sz.num_meshes;
+	(void)hipMalloc(&seqA.pos, (sz.num_vertices + 1) * 2 * sizeof(float));
+	(void)hipMalloc(&seqA.color, (sz.num_vertices + 1) * sizeof(uint32_t));
+	(void)hipMalloc(&seqA.idx, (sz.num_indices + 1) * sizeof(uint16_t));
+	(void)hipMalloc(&seqA.meshes, (sz.num_meshes + 1) * sizeof(vgx_mesh));
+	CHECK(vgx_tessellate_emit(ctx, ps, devDraws, o.num_draws, &seqA, nullptr));
+	// sequence B: the user meshes, uploaded as they came out of the decoder
+	vgx_cache_desc a = {}, b = {};
+	a.pos = seqA.pos; a.color = seqA.color; a.idx = seqA.idx; a.meshes = seqA.meshes; a.num_meshes = sz.num_meshes; a.num_vertices = sz.num_vertices; a.num_indices = sz.num_indices;
+	float* bPos = nullptr; uint32_t* bCol = nullptr; uint32_t* bUV = nullptr; uint16_t* bIdx = nullptr; vgx_mesh* bMesh = nullptr;
+	(void)hipMalloc(&bPos, triPos.size() * 4); (void)hipMalloc(&bCol, triCol.size() * 4); (void)hipMalloc(&bUV, triUV.size() * 4);
+	(void)hipMalloc(&bIdx, triIdx.size() * 2); (void)hipMalloc(&bMesh, triMesh.size() * sizeof(vgx_mesh));
+	(void)hipMemcpy(bPos, triPos.data(), triPos.size() * 4, hipMemcpyHostToDevice); (void)hipMemcpy(bCol, triCol.data(), triCol.size() * 4, hipMemcpyHostToDevice);
+	(void)hipMemcpy(bUV, triUV.data(), triUV.size() * 4, hipMemcpyHostToDevice); (void)hipMemcpy(bIdx, triIdx.data(), triIdx.size() * 2, hipMemcpyHostToDevice);
+	(void)hipMemcpy(bMesh, triMesh.data(), triMesh.size() * sizeof(vgx_mesh), hipMemcpyHostToDevice);
+	b.pos = bPos; b.color = bCol; b.idx = bIdx; b.meshes = bMesh; b.num_meshes = o.num_tri_meshes; b.num_vertices = o.num_tri_vertices; b.num_indices = o.num_tri_indices;
+	// the frame: both sequences interleaved by draw, assembled
+	sz.num_vertices += o.num_tri_vertices; sz.num_indices += o.num_tri_indices; sz.num_meshes += o.num_tri_meshes;
 	vgx_mesh_out out = {};
 	out.cap_vertices = sz.num_vertices; out.cap_indices = sz.num_indices; out.cap_meshes = sz.num_meshes;
 	(void)hipMalloc(&out.pos, sz.num_vertices * 2 * sizeof(float));
@@ -105,7 +152,7 @@ int main()
 	CHECK(vgx_set_assembly(ctx, &as));
 	vgx_sizes* devSizes = nullptr; uint32_t* devStatus = nullptr;
 	(void)hipMalloc(&devSizes, sizeof(vgx_sizes)); (void)hipMalloc(&devStatus, sizeof(uint32_t));
-	CHECK(vgx_tessellate(ctx, ps, devDraws, o.num_draws, &out, devSizes, devStatus, nullptr)); // asynchronous: no host round trip inside
+	CHECK(vgx_merge_uv(ctx, &a, &b, nullptr, bUV, devDraws, o.num_draws, &out, devSizes, devStatus, nullptr)); // asynchronous: no host round trip inside
 	(void)hipDeviceSynchronize();
 	uint32_t status = 1; uint64_t ncmd = 0;
 	(void)hipMemcpy(&status, devStatus, 4, hipMemcpyDeviceToHost);

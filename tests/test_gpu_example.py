@@ -20,10 +20,11 @@ def test_cpp_example_runs(tmp_path):
 
 
 def test_cpp_frame_example_runs(tmp_path):
-    """examples/vgx_frame_example.cpp: command-list bytes -> vgx_cmdlist_decode -> vgx_tessellate with assembly armed, all from C++."""
+    """examples/vgx_frame_example.cpp: command-list bytes (paths + IndexedTriList user meshes) -> vgx_cmdlist_decode -> vgx_tessellate + vgx_merge_uv
+    with assembly armed, all from C++."""
     exe = str(tmp_path / "vgx_frame_example")
     pkg = os.path.join(ROOT, "vg-renderer_amd")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "vgx_frame_example.cpp"),
                            "-L", pkg, "-lvgx", "-Wl,-rpath," + pkg, "-o", exe])
     out = subprocess.check_output([exe], text=True)
-    assert "300 paths" in out and "450 draws, 0 skipped" in out and "consistent" in out and "INCONSISTENT" not in out, out
+    assert "300 paths" in out and "453 draws (3 of them user meshes), 0 skipped" in out and "consistent" in out and "INCONSISTENT" not in out, out

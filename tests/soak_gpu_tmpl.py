@@ -44,7 +44,10 @@ for seed in range(7000, 7000 + n):
     ninst = int(rs.randint(32, 91))
     while ninst * npaths <= 2048:
         ninst += 13
-    if seed % 2:  # several classes: 2..9 flavours of the drawing, instances mixed at random
+    if seed % 4 == 2:  # general strokes: open sub-paths, every cap, Bevel joins, non-AA / hairline strokes
+        ps = wl.fuzz_paths(seed, npaths=npaths, with_shapes=True, degenerate=bool(seed % 8 == 2))
+        d = wl.template_general_draws(ps, seed, ninst)
+    elif seed % 2:  # several classes: 2..9 flavours of the drawing, instances mixed at random
         d, _ = wl.template_class_draws(ps, seed, ninst, int(rs.randint(2, 10)))
     else:
         d = wl.template_draws(ps, seed, ninst, same_colors=bool(seed % 7 == 0))

@@ -168,22 +168,16 @@ def test_template_capacity_is_checked_on_the_device(rt, wl):
 
 
 def test_batches_that_are_not_templates_take_the_ordinary_path(rt, wl, oracle):
-    """Open strokes (caps), Bevel / Round joins, non-AA strokes, every instance different, fewer than 32 instances:
-    the ordinary pipeline, same results."""
+    """Round joins (their point counts depend on the transformed geometry), every instance different: the ordinary pipeline,
+    same results."""
     ps = wl.closed_fuzz_paths(930, npaths=72)
     ctx = rt.Context(0)
     base = wl.template_draws(ps, 930, 40)
     cases = []
     d = base.copy()
     sel = (d["stroke_flags"] & 1) != 0
-    d["stroke_flags"][sel] |= np.uint32(rt.capi.JOIN_BEVEL << 6)
-    cases.append(("bevel joins", d))
-    d = base.copy()
     d["stroke_flags"][sel] |= np.uint32(rt.capi.JOIN_ROUND << 6)
     cases.append(("round joins", d))
-    d = base.copy()
-    d["stroke_flags"][sel] &= ~np.uint32(2 | 4)  # non-AA strokes
-    cases.append(("non-AA strokes", d))
     d = wl.template_draws(ps, 930, 80)
     d["scale"][::ps.npaths] *= (np.float32(1.0) + np.arange(80, dtype=np.float32) / np.float32(128.0))
     cases.append(("every instance at a scale of its own (more flavours than classes)", d))
@@ -386,4 +380,41 @@ def test_template_classes_with_draw_command_assembly(rt, wl, oracle, monkeypatch
     assert a.ncmd == b.ncmd
     for k in ("pos", "color", "idx", "meshes", "cmds"):
         assert bytes_equal(getattr(a, k), getattr(b, k)), k
+
+
+# ---- general strokes: everything but Round joins -------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed,ninst,tile,closed_only", [(990, 40, None, False), (991, 36, "128", False), (992, 48, "960", True), (993, 33, "64", False)])
+def test_template_general_strokes(rt, wl, oracle, monkeypatch, seed, ninst, tile, closed_only):
+    """Open sub-paths with Butt / Square / Round caps, Bevel joins, non-AA and hairline strokes next to the closed Miter AA ones and
+    the fills: all of them have closed-form sizes, so the batch is a template batch; the general element code (elem_geometry /
+    elem_emit, what k_stroke runs) works on the staged vertices with bases and previous-element rails in closed form. == the
+    reference, == the ordinary pipeline byte for byte."""
+    if tile:
+        monkeypatch.setenv("VGX_TMPL_TILE", tile)
+    ps = wl.closed_fuzz_paths(seed, npaths=72) if closed_only else wl.fuzz_paths(seed, npaths=72, with_shapes=True, degenerate=False)
+    d = wl.template_general_draws(ps, seed, ninst)
+    ref = oracle.tessellate(ps, d)
+    ctx = rt.Context(0)
+    got = _run(rt, ctx, ps, d)
+    assert got.mode == MODE_TEMPLATE and got.stages == ["tmpl_emit"], (got.mode, got.stages)
+    assert got.status == 0
+    assert_mesh_equal(got, ref, "template general strokes seed=%d" % seed)
+    ctx.close()
+    monkeypatch.setenv("VGX_TMPL", "0")
+    ctx = rt.Context(0)
+    old = _run(rt, ctx, ps, d)
+    assert old.mode != MODE_TEMPLATE
+    for k in ("pos", "color", "idx", "meshes"):
+        assert bytes_equal(getattr(got, k), getattr(old, k)), k
+    ctx.close()
+
+
+def test_template_general_strokes_round_joins_stay_ordinary(rt, wl, oracle):
+    ps = wl.fuzz_paths(995, npaths=72, with_shapes=True, degenerate=False)
+    d = wl.template_general_draws(ps, 995, 40, round_joins=True)
+    ctx = rt.Context(0)
+    got = _run(rt, ctx, ps, d)
+    assert got.mode != MODE_TEMPLATE and got.status == 0
+    assert_mesh_equal(got, oracle.tessellate(ps, d), "round joins: ordinary pipeline")
+    ctx.close()
 

@@ -97,6 +97,7 @@ struct vgx_ctx
 	// representatives, a per-instance table of output places, a per-workgroup table (instance, tile)
 	int optTmplClasses;
 	uint32_t tmplClasses;                // 1: every instance repeats the first period
+	bool tmplGeneral;                    // the template holds strokes other than closed Miter AA / Thin
 	uint64_t tmplNumWg, tmplNDraws;      // several classes: workgroups of one step; the batch size the per-instance table was built for
 	vgx_sizes tmplTotal;                 // sizes of the whole batch
 	DevBuf tmplHash, tmplInstCls, tmplClsRep, tmplCls, tmplIinfo, tmplWg;
@@ -1173,6 +1174,7 @@ static int runTmpl(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 	a.pos = out->pos; a.color = out->color; a.idx = out->idx; a.meshes_out = out->meshes;
 	a.caps = ctx->caps; a.caps.vertices = out->cap_vertices; a.caps.indices = out->cap_indices; a.caps.meshes = out->cap_meshes;
 	a.totals = (VgxTotals*)ctx->totals.p;
+	a.general = ctx->tmplGeneral ? 1u : 0u;
 	if (ctx->tmplClasses > 1) {
 		a.iinfo = (const VgxTmplInst*)ctx->tmplIinfo.p; a.wg = (const uint2*)ctx->tmplWg.p; a.num_wg = ctx->tmplNumWg;
 		a.total = ctx->tmplTotal;
@@ -1247,7 +1249,7 @@ static int tmplPipeline(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* d, 
 static bool tmplEligible(const VgxTotals& ht)
 {
 	const vgx_sizes& z = ht.sizes;
-	return !(ht.has_general_stroke || ht.num_round_meshes || z.num_elements == 0 || z.num_elements >= (1ull << 31) || z.num_vertices >= (1ull << 29)
+	return !(ht.num_round_meshes || z.num_elements == 0 || z.num_elements >= (1ull << 31) || z.num_vertices >= (1ull << 29)
 		|| z.num_indices >= (1ull << 31) || z.num_poly_vertices >= (1ull << 32) || z.num_meshes >= (1ull << 32));
 }
 
@@ -1329,13 +1331,14 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 		if (T == 1) {
 			if (!tmplEligible(ht)) { return VGX_OK; } // open / Bevel / Round strokes (or nothing to emit): the ordinary pipeline
 			csz[0] = ht.sizes;
-		} else if (ht.has_general_stroke || ht.num_round_meshes || ht.sizes.num_poly_vertices >= (1ull << 32) || ht.sizes.num_meshes >= (1ull << 32) || ht.sizes.num_elements >= (1ull << 36)) {
+		} else if (ht.num_round_meshes || ht.sizes.num_poly_vertices >= (1ull << 32) || ht.sizes.num_meshes >= (1ull << 32) || ht.sizes.num_elements >= (1ull << 36)) {
 			return VGX_OK;
 		}
 	}
 	const vgx_sizes all = ctx->hostTotals->sizes;
+	const bool general = ctx->hostTotals->has_general_stroke != 0;
 	const uint64_t M = all.num_meshes, E = all.num_elements, V = all.num_poly_vertices;
-	const uint32_t tileSize = ctx->optTmplTile;
+	const uint32_t tileSize = (general && ctx->optTmplTile > VGX_TMPL_GENERAL_TILE) ? (uint32_t)VGX_TMPL_GENERAL_TILE : ctx->optTmplTile;
 	if ((st = ensure(ctx, ctx->tmplCls, ((size_t)T + 1) * sizeof(VgxTmplClass))) != VGX_OK) { return st; }
 	VgxTmplBuild b;
 	memset(&b, 0, sizeof(b));
@@ -1415,6 +1418,7 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	ctx->tmplNumWg = numWg;
 	ctx->tmplNDraws = ndraws;
 	ctx->tmplTotal = z;
+	ctx->tmplGeneral = general;
 	ctx->tmplOn = true;
 	*out_sizes = z;
 	ctx->hostTotals->sizes = z; // what vgx_tessellate_emit checks the caller's capacities against

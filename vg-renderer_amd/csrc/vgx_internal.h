@@ -127,6 +127,7 @@ struct VgxTmplArgs // one step
 	const uint2* wg;             // [num_wg]
 	uint64_t num_wg;
 	vgx_sizes total;             // sizes of the whole batch
+	uint32_t general;            // the template holds strokes other than closed Miter AA / Thin: the general instantiation of k_tmpl_emit
 };
 void vgx_launch_tmpl_mtab(const VgxTmplArgs& a, vgx_mesh* mtab, VgxMeshDesc* mdesc, hipStream_t s); // assembly armed: the whole batch's mesh table + mesh -> draw
 void vgx_launch_tmpl_check(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, VgxTotals* totals, hipStream_t s); // after vgx_launch_inst_detect
@@ -135,6 +136,7 @@ void vgx_launch_tmpl_build(const VgxTmplBuild& b, hipStream_t s);   // after vgx
 void vgx_launch_tmpl_hash(const vgx_draw* draws, uint64_t ndraws, uint64_t period, unsigned long long* hashes, hipStream_t s); // hashes[instance], zeroed by the caller
 void vgx_launch_tmpl_check_cls(const vgx_draw* draws, uint64_t ndraws, uint64_t period, const uint32_t* inst_cls, const uint32_t* cls_rep, VgxTotals* totals, hipStream_t s);
 void vgx_launch_tmpl_emit(const VgxTmplArgs& a, hipStream_t s);
+#define VGX_TMPL_GENERAL_TILE 1024 /* tile size of templates that hold general strokes (the LDS stages of that instantiation of k_tmpl_emit) */
 
 // merging two mesh sequences of a frame (vgx_merge.hip)
 struct VgxMergeArgs

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_tmpl_meshes(VgxTmplBuild B)
 		const float2* v = B.poly + md.poly_first;
 		const float2 a = v[0], b = v[md.poly_n > 1 ? 1 : 0], c = v[md.poly_n > 2 ? 2 : 0];
 		t.l0[0] = a.x; t.l0[1] = a.y; t.l1[0] = b.x; t.l1[1] = b.y; t.l2[0] = c.x; t.l2[1] = c.y;
-		t.pad[0] = 0; t.pad[1] = 0;
+		t.pad[0] = __float_as_uint(pr.f2); t.pad[1] = 0; // the draw's fringe (general strokes: Butt-cap fringes, thin strokes)
 		B.tmesh[m] = t;
 		B.tmtab[m] = mt;
 	}
@@ -480,11 +480,70 @@ __device__ __forceinline__ void tmpl_mesh_out(const VgxTmplArgs& A, const TmplPl
 	A.meshes_out[P.m + (mesh - P.cmesh0)] = mr;
 }
 
+// ---- every other stroke whose SIZES do not depend on the geometry: open strokes with Butt / Square / Round caps, Bevel joins,
+// non-AA strokes (only Round JOINS count their points on the transformed polyline, stroker.cpp:1146, 1592). The general element
+// code of vgx_elem.h (elem_geometry / elem_emit, what k_stroke runs) on the staged vertices, with what the sequential stroker
+// carries from element to element in closed form: the element's first vertex / index inside its mesh, and the previous
+// element's exit rails recomputed from ITS geometry (same inputs, same bits).
+struct TmplVtx01 { V2 v0, v1; __device__ __forceinline__ V2 ld(uint32_t i) const { return i == 0 ? v0 : v1; } }; // elem_emit reads vertices 0 and 1 only (closing bridge)
+
+// vertices / own indices of a cap and of a join of this stroke flavour (elem_geometry's counts, vgx_elem.h), H = numPointsHalfCircle
+__device__ __forceinline__ void tmpl_stroke_counts(uint32_t kind, uint32_t cap, uint32_t join, uint32_t H, uint32_t* capNv, uint32_t* capNiFirst, uint32_t* joinNv, uint32_t* joinNi, uint32_t* bridge)
+{
+	const uint32_t R = (kind == VGX_MESH_STROKE) ? 2u : (kind == VGX_MESH_STROKE_AA ? 4u : 3u);
+	*bridge = (R - 1) * 6;
+	const bool roundCap = cap == VGX_CAP_ROUND && kind != VGX_MESH_STROKE_AA_THIN;
+	if (roundCap) {
+		*capNv = kind == VGX_MESH_STROKE_AA ? 2 * H : H;
+		*capNiFirst = kind == VGX_MESH_STROKE_AA ? 9 * H - 12 : 3 * (H - 2);
+	} else {
+		*capNv = R;
+		*capNiFirst = kind == VGX_MESH_STROKE_AA ? 6u : 0u;
+	}
+	if (kind == VGX_MESH_STROKE_AA_THIN) { const bool bevel = join != VGX_JOIN_MITER; *joinNv = bevel ? 4u : 3u; *joinNi = bevel ? 3u : 0u; }
+	else if (join == VGX_JOIN_MITER) { *joinNv = R; *joinNi = 0; }
+	else if (kind == VGX_MESH_STROKE_AA) { *joinNv = 6; *joinNi = 9; } // Bevel = an arc of one segment: 2n + 4, 9n (stroker.cpp:1599, 1675)
+	else { *joinNv = 3; *joinNi = 3; }                                  // n + 2, 3n (:1156, 1186)
+}
+
+// A real function (not inlined): the general element body is ~130 VGPRs of branches; inlined four times into the unrolled element
+// loop of the kernel it spilled. Everything it needs comes by value: own vertex, previous vertex, the three edge directions around
+// the element, the mesh's first two vertices (closing bridge).
+__device__ __noinline__ void tmpl_stroke_general(char* opos, char* ocol, char* oidx, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color,
+	float hsw, float hswAA, float fringe, const vgx_draw* tdraw, uint32_t j, V2 p1, V2 pPrev, V2 d12, V2 dPrev, V2 dPrev2, V2 v0, V2 v1)
+{
+	MeshCtxT<TmplVtx01> mc;
+	mc.kind = VGX_MD_KIND(kindWord); mc.closed = VGX_MD_CLOSED(kindWord) != 0; mc.cap = VGX_MD_CAP(kindWord); mc.join = VGX_MD_JOIN(kindWord);
+	mc.N = N; mc.j = j; mc.hsw = hsw; mc.hswAA = hswAA; mc.fringe = fringe; mc.dr = tdraw; mc.vtx.v0 = v0; mc.vtx.v1 = v1;
+	uint32_t H = 2;
+	if (!mc.closed && mc.cap == VGX_CAP_ROUND && mc.kind != VGX_MESH_STROKE_AA_THIN) { H = vgx_half_circle_points(mesh_da(mc)); }
+	uint32_t capNv, capNi, joinNv, joinNi, bridge;
+	tmpl_stroke_counts(mc.kind, mc.cap, mc.join, H, &capNv, &capNi, &joinNv, &joinNi, &bridge);
+	// first vertex / index of element jj inside the mesh
+	auto vbase = [&](uint32_t jj) { return mc.closed ? jj * joinNv : (jj == 0 ? 0u : capNv + (jj - 1) * joinNv); };
+	auto ibaseOf = [&](uint32_t jj) { return jj == 0 ? 0u : (mc.closed ? joinNi : capNi) + (jj - 1) * (bridge + joinNi); };
+	const Elem e = elem_geometry(mc, p1, dPrev, d12);
+	Rails prev = rails(0, 0, 0, 0);
+	if (e.hasConnect) { // the previous element's exit rails (prevSegment*ID, stroker.cpp:1401-1410), from its own geometry
+		MeshCtxT<TmplVtx01> mp = mc;
+		mp.j = j - 1;
+		const Elem ep = elem_geometry(mp, pPrev, dPrev2, dPrev);
+		prev = elem_exit_rails(mp, ep, vbase(j - 1));
+	}
+	StrokeWriter w;
+	w.pos = (float*)(opos + (size_t)vOff * 8u); w.col = (uint32_t*)(ocol + (size_t)vOff * 4u); w.idx = (uint16_t*)(oidx + (size_t)iOff * 2u);
+	w.color = color; w.c0 = color & 0x00FFFFFFu; w.ib = ibase;
+	w.reset();
+	const uint32_t b = vbase(j), k = ibaseOf(j);
+	elem_emit(mc, e, b, k, prev, w);
+	w.flush(b, k);
+}
+
 // One element given its mesh's constants, its transformed vertex, its own edge direction and a way to get the mesh's other
-// edge directions (dir(jj) = direction of the edge jj -> jj + 1, cyclic).
-template<class DF>
+// edge directions (dir(jj) = direction of the edge jj -> jj + 1, cyclic) and vertices (vtx(jj), general strokes only).
+template<bool GENERAL, class DF, class VF>
 __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color, float f0, float f1,
-	V2 p1, V2 d12, const DF& dir)
+	V2 p1, V2 d12, const DF& dir, const VF& vtx, float fringe, const vgx_draw* tdraw)
 {
 	const uint32_t kind = VGX_MD_KIND(kindWord);
 	const uint32_t jp1 = j > 0 ? j - 1 : N - 1;
@@ -492,6 +551,13 @@ __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uin
 		V2 dPrev = d12;
 		if (kind == VGX_MESH_FILL_AA) { dPrev = dir(jp1); }
 		tmpl_fill_elem(O, kindWord, N, vOff, iOff, ibase, color, f0, j, p1, dPrev, d12);
+	} else if (GENERAL && !stroke_elem_is_simple(kind, VGX_MD_CLOSED(kindWord) != 0, VGX_MD_JOIN(kindWord))) {
+		const bool closed = VGX_MD_CLOSED(kindWord) != 0;
+		const V2 dPrev = dir(jp1);
+		V2 pPrev = p1, dPrev2 = dPrev, v0 = p1, v1 = p1;
+		if (j > 0) { pPrev = vtx(jp1); dPrev2 = dir(jp1 > 0 ? jp1 - 1 : N - 1); } // the previous element's geometry: only when a bridge connects to it
+		if (closed && j + 1 == N) { v0 = vtx(0u); v1 = vtx(N > 1 ? 1u : 0u); }      // join 0's inner side: only the closing bridge asks
+		tmpl_stroke_general(O.pos, O.col, O.idx, kindWord, N, vOff, iOff, ibase, color, f0, f1, fringe, tdraw, j, p1, pPrev, d12, dPrev, dPrev2, v0, v1);
 	} else {
 		const V2 dPrev = dir(jp1);
 		V2 dPrev2 = dPrev, dFirst = dPrev;
@@ -505,7 +571,6 @@ __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uin
 #ifndef VGX_TMPL_MAXM
 #define VGX_TMPL_MAXM 160      /* meshes / draws per tile the LDS tables hold; a tile that needs more takes the per-lane fallback */
 #endif
-#define VGX_TMPL_CH (VGX_TMPL_MAX_TILE / VGX_TMPL_THREADS)
 
 // Draw-command assembly armed: the partition of the mesh sequence into vertex buffers / draw commands (vgx_assemble.hip) reads
 // the WHOLE batch's mesh table and each mesh's draw; in template mode neither exists in memory, so this pass writes them
@@ -542,16 +607,24 @@ __global__ __launch_bounds__(256) void k_tmpl_mtab(VgxTmplArgs A, vgx_mesh* mtab
 #ifndef VGX_TMPL_OCC
 #define VGX_TMPL_OCC
 #endif
+// GENERAL: the template holds stroke meshes that are not closed Miter AA / Thin (open strokes, Bevel joins, non-AA): those take
+// tmpl_stroke_general; the instantiation without them is the headline's kernel, unchanged.
+// THREADS x MAXTILE: the workgroup shape (MAXTILE / THREADS elements per thread). The general instantiation is the shape of k_stroke
+// (128 VGPRs, 4-wave workgroups, 1024-element tiles: four workgroups per CU); the other one is VGX_TMPL_THREADS x VGX_TMPL_MAX_TILE.
+#define VGX_TMPL_G_THREADS 256
+#define VGX_TMPL_G_TILE 1024
+template<bool GENERAL, int THREADS, int MAXTILE>
 #ifdef VGX_TMPL_MINWAVES
-__global__ __launch_bounds__(VGX_TMPL_THREADS, VGX_TMPL_MINWAVES) void k_tmpl_emit(VgxTmplArgs A)
+__global__ __launch_bounds__(THREADS, VGX_TMPL_MINWAVES) void k_tmpl_emit(VgxTmplArgs A)
 #else
-__global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(VgxTmplArgs A)
+__global__ __launch_bounds__(THREADS) VGX_TMPL_OCC void k_tmpl_emit(VgxTmplArgs A)
 #endif
 {
+	constexpr int CH = MAXTILE / THREADS;
 	__shared__ TmplDraw s_draw[VGX_TMPL_MAXM];
 	__shared__ TmplRec s_rec[VGX_TMPL_MAXM];
-	__shared__ float2 s_vtx[VGX_TMPL_MAX_TILE];
-	__shared__ float2 s_dir[VGX_TMPL_MAX_TILE];
+	__shared__ float2 s_vtx[MAXTILE];
+	__shared__ float2 s_dir[MAXTILE];
 	__shared__ uint32_t s_status;
 	const uint32_t tid = threadIdx.x;
 	// workgroup -> (instance, tile of the template), all workgroup-uniform (scalar loads)
@@ -589,8 +662,8 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 	if (nm > VGX_TMPL_MAXM || nd > VGX_TMPL_MAXM) {
 		// workgroup-uniform. Many tiny meshes (or many draws without a mesh) in one tile: the draw records are verified in a loop,
 		// every lane fetches its own records and neighbours
-		for (uint32_t k = tid; k < nd; k += VGX_TMPL_THREADS) { (void)tmpl_load_draw(A, idraws, P.tdraws, dA + k); }
-		for (uint32_t s = tid; s < nel; s += VGX_TMPL_THREADS) {
+		for (uint32_t k = tid; k < nd; k += THREADS) { (void)tmpl_load_draw(A, idraws, P.tdraws, dA + k); }
+		for (uint32_t s = tid; s < nel; s += THREADS) {
 			const VgxTmplElem er = telem[s];
 			const VgxTmplMesh tm = A.tmesh[er.mesh];
 			const TmplDraw dr = tmpl_load_draw(A, idraws, P.tdraws, tm.drawk);
@@ -601,9 +674,11 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 			float f0 = tm.f0;
 			if (kind == VGX_MESH_FILL_AA) { f0 = tmpl_fill_aa(xf, vt[0], vt[1], vt[2], tm.f0); }
 			auto dir = [&](uint32_t jj) { return v2dir(tmpl_xf(xf, vt[jj]), tmpl_xf(xf, vt[jj + 1 < N ? jj + 1 : 0u])); };
+			auto vtx = [&](uint32_t jj) { return tmpl_xf(xf, vt[jj]); };
 			if (j == 0 && A.meshes_out) { tmpl_mesh_out(A, P, er.mesh); }
 			const uint32_t ibase = meshBase ? meshBase[er.mesh] : 0u;
-			tmpl_elem_emit(O, j, tm.kind, N, tm.v_off, tm.i_off, ibase, kind < VGX_MESH_STROKE ? dr.fill_color : dr.stroke_color, f0, tm.f1, tmpl_xf(xf, vt[j]), dir(j), dir);
+			tmpl_elem_emit<GENERAL>(O, j, tm.kind, N, tm.v_off, tm.i_off, ibase, kind < VGX_MESH_STROKE ? dr.fill_color : dr.stroke_color, f0, tm.f1, tmpl_xf(xf, vt[j]), dir(j), dir, vtx,
+				__uint_as_float(tm.pad[0]), P.tdraws + tm.drawk);
 		}
 		return;
 	}
@@ -614,10 +689,10 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 #define TMPL_PROF(i)
 #endif
 	// ---- phase 0a: every load the workgroup needs, requested at once
-	VgxTmplElem er[VGX_TMPL_CH];
+	VgxTmplElem er[CH];
 #pragma unroll
-	for (int c = 0; c < VGX_TMPL_CH; ++c) {
-		const uint32_t s = (uint32_t)c * VGX_TMPL_THREADS + tid; // interleaved: the tile's stroke chunks (the heavier ones, at the tile's end) spread over the waves
+	for (int c = 0; c < CH; ++c) {
+		const uint32_t s = (uint32_t)c * THREADS + tid; // interleaved: the tile's stroke chunks (the heavier ones, at the tile's end) spread over the waves
 		er[c].mesh = mA; er[c].jq = 0; er[c].lx = 0.0f; er[c].ly = 0.0f;
 		if (s < nel) { er[c] = telem[s]; }
 	}
@@ -651,10 +726,10 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 		return;
 	}
 	// ---- phase 1: own vertex, transformed once
-	V2 p1[VGX_TMPL_CH];
+	V2 p1[CH];
 #pragma unroll
-	for (int c = 0; c < VGX_TMPL_CH; ++c) {
-		const uint32_t s = (uint32_t)c * VGX_TMPL_THREADS + tid;
+	for (int c = 0; c < CH; ++c) {
+		const uint32_t s = (uint32_t)c * THREADS + tid;
 		p1[c] = v2(0.0f, 0.0f);
 		if (s < nel) {
 			const TmplRec* r = &s_rec[er[c].mesh - mA];
@@ -672,10 +747,10 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 		return tmpl_xf(tmpl_draw_xf(&s_draw[TMPL_REC_DK(rp)]), A.tpoly[A.tmesh[mesh].poly_first + jj]);
 	};
 	// ---- phase 2: own edge direction vec2Dir(p[j], p[j + 1]) (stroker.cpp:31-38), once per element
-	V2 d12[VGX_TMPL_CH];
+	V2 d12[CH];
 #pragma unroll
-	for (int c = 0; c < VGX_TMPL_CH; ++c) {
-		const uint32_t s = (uint32_t)c * VGX_TMPL_THREADS + tid;
+	for (int c = 0; c < CH; ++c) {
+		const uint32_t s = (uint32_t)c * THREADS + tid;
 		d12[c] = v2(0.0f, 0.0f);
 		if (s < nel) {
 			const TmplRec* rp = &s_rec[er[c].mesh - mA];
@@ -689,8 +764,8 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 	TMPL_PROF(2);
 	// ---- phase 3: the element
 #pragma unroll
-	for (int c = 0; c < VGX_TMPL_CH; ++c) {
-		const uint32_t s = (uint32_t)c * VGX_TMPL_THREADS + tid;
+	for (int c = 0; c < CH; ++c) {
+		const uint32_t s = (uint32_t)c * THREADS + tid;
 		if (s < nel) {
 			const uint32_t mesh = er[c].mesh;
 			const TmplRec* rp = &s_rec[mesh - mA];
@@ -701,7 +776,11 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 				if (qq < nel) { const float2 v = s_dir[qq]; return v2(v.x, v.y); }
 				return v2dir(vtxAt(mesh, rp, q0, jj), vtxAt(mesh, rp, q0, jj + 1 < N ? jj + 1 : 0u)); // the edge belongs to another tile
 			};
-			tmpl_elem_emit(O, j, rp->kind & 0xFFFFu, N, rp->v_off, rp->i_off, rp->ibase, rp->color, rp->f0, rp->f1, p1[c], d12[c], dir);
+			auto vtx = [&](uint32_t jj) { return vtxAt(mesh, rp, q0, jj); };
+			float fringe = 0.0f;
+			const vgx_draw* tdraw = P.tdraws;
+			if (GENERAL) { const VgxTmplMesh* tmm = A.tmesh + mesh; fringe = __uint_as_float(tmm->pad[0]); tdraw = P.tdraws + (dA + TMPL_REC_DK(rp)); }
+			tmpl_elem_emit<GENERAL>(O, j, rp->kind & 0xFFFFu, N, rp->v_off, rp->i_off, rp->ibase, rp->color, rp->f0, rp->f1, p1[c], d12[c], dir, vtx, fringe, tdraw);
 		}
 	}
 	TMPL_PROF(3);
@@ -753,5 +832,7 @@ void vgx_launch_tmpl_mtab(const VgxTmplArgs& a, vgx_mesh* mtab, VgxMeshDesc* mde
 void vgx_launch_tmpl_emit(const VgxTmplArgs& a, hipStream_t s)
 {
 	const uint64_t blocks = a.wg ? a.num_wg : a.ninst * a.tiles_per_inst; // the host checked < 2^31
-	if (blocks) { hipLaunchKernelGGL(k_tmpl_emit, dim3((unsigned)blocks), dim3(VGX_TMPL_THREADS), 0, s, a); }
+	if (!blocks) { return; }
+	if (a.general) { hipLaunchKernelGGL((k_tmpl_emit<true, VGX_TMPL_G_THREADS, VGX_TMPL_G_TILE>), dim3((unsigned)blocks), dim3(VGX_TMPL_G_THREADS), 0, s, a); }
+	else { hipLaunchKernelGGL((k_tmpl_emit<false, VGX_TMPL_THREADS, VGX_TMPL_MAX_TILE>), dim3((unsigned)blocks), dim3(VGX_TMPL_THREADS), 0, s, a); }
 }

@@ -459,3 +459,21 @@ def template_class_draws(ps, seed, instances, nclasses):
     d["stroke_color"] = base["stroke_color"]
     return d, pick
 
+
+def template_general_draws(ps, seed, instances, round_joins=False):
+    """template_draws with every stroke style whose mesh sizes do not depend on the geometry: open and closed sub-paths (whatever
+    `ps` holds), Butt / Square / Round caps, Miter / Bevel joins, AA / non-AA / hairline (Thin) strokes."""
+    rs = np.random.RandomState(seed + 777)
+    d = template_draws(ps, seed, instances)
+    n = ps.npaths
+    one = d[:n].copy()
+    for i in range(n):
+        if rs.uniform() < 0.85:
+            sc = float(one["scale"][i])
+            join = int(rs.choice([capi.JOIN_MITER, capi.JOIN_BEVEL, capi.JOIN_ROUND])) if round_joins else int(rs.choice([capi.JOIN_MITER, capi.JOIN_BEVEL]))
+            set_stroke(one, i, int(rs.randint(0, 1 << 32, dtype=np.uint64)), float(rs.choice([0.3, 0.9, 1.5, 3.0, 12.0])),
+                       int(rs.choice([capi.CAP_BUTT, capi.CAP_SQUARE, capi.CAP_ROUND])), join, aa=bool(rs.uniform() < 0.75), avg_scale=sc, fringe=float(one["fringe"][i]))
+    for k in ("stroke_flags", "stroke_width"):
+        d[k] = np.tile(one[k], instances)
+    return d
+

@@ -1278,7 +1278,7 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	std::vector<uint32_t> instCls, reps(1, 0u);
 	if (ctx->hostTotals->tmpl_bad) {
 		// not ONE period repeated. A few flavours of it? Candidates by hash of the template fields, then compared bit by bit.
-		if (!ctx->optTmplClasses || ninst > 0x7FFFFFFFull) { return VGX_OK; }
+		if (!ctx->optTmplClasses || ninst > (1ull << 24)) { return VGX_OK; } // (per-instance tables: 40 bytes per instance and tile on host and device)
 		if ((st = ensure(ctx, ctx->tmplHash, ninst * sizeof(unsigned long long))) != VGX_OK) { return st; }
 		noteHip(ctx, hipMemsetAsync(ctx->tmplHash.p, 0, ninst * sizeof(unsigned long long), s));
 		vgx_launch_tmpl_hash(draws, ndraws, P, (unsigned long long*)ctx->tmplHash.p, s);

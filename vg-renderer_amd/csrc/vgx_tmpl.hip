@@ -609,16 +609,12 @@ __global__ __launch_bounds__(256) void k_tmpl_mtab(VgxTmplArgs A, vgx_mesh* mtab
 #endif
 // GENERAL: the template holds stroke meshes that are not closed Miter AA / Thin (open strokes, Bevel joins, non-AA): those take
 // tmpl_stroke_general; the instantiation without them is the headline's kernel, unchanged.
-// THREADS x MAXTILE: the workgroup shape (MAXTILE / THREADS elements per thread). The general instantiation is the shape of k_stroke
-// (128 VGPRs, 4-wave workgroups, 1024-element tiles: four workgroups per CU); the other one is VGX_TMPL_THREADS x VGX_TMPL_MAX_TILE.
+// THREADS x MAXTILE: the workgroup shape (MAXTILE / THREADS elements per thread). The general instantiation (k_tmpl_emit_general) has the
+// shape of k_stroke (128 VGPRs, 4-wave workgroups, 1024-element tiles: four workgroups per CU); k_tmpl_emit is VGX_TMPL_THREADS x VGX_TMPL_MAX_TILE.
 #define VGX_TMPL_G_THREADS 256
 #define VGX_TMPL_G_TILE 1024
 template<bool GENERAL, int THREADS, int MAXTILE>
-#ifdef VGX_TMPL_MINWAVES
-__global__ __launch_bounds__(THREADS, VGX_TMPL_MINWAVES) void k_tmpl_emit(VgxTmplArgs A)
-#else
-__global__ __launch_bounds__(THREADS) VGX_TMPL_OCC void k_tmpl_emit(VgxTmplArgs A)
-#endif
+__device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 {
 	constexpr int CH = MAXTILE / THREADS;
 	__shared__ TmplDraw s_draw[VGX_TMPL_MAXM];
@@ -791,6 +787,23 @@ __global__ __launch_bounds__(THREADS) VGX_TMPL_OCC void k_tmpl_emit(VgxTmplArgs 
 #endif
 }
 
+#ifdef VGX_TMPL_MINWAVES
+__global__ __launch_bounds__(VGX_TMPL_THREADS, VGX_TMPL_MINWAVES) void k_tmpl_emit(VgxTmplArgs A)
+#else
+__global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(VgxTmplArgs A)
+#endif
+{
+	tmpl_emit_body<false, VGX_TMPL_THREADS, VGX_TMPL_MAX_TILE>(A);
+}
+// the instantiation with the general stroke body: at least 4 waves per SIMD (<= 128 VGPRs), as k_stroke
+#ifndef VGX_TMPL_G_MINWAVES
+#define VGX_TMPL_G_MINWAVES 4
+#endif
+__global__ __launch_bounds__(VGX_TMPL_G_THREADS, VGX_TMPL_G_MINWAVES) void k_tmpl_emit_general(VgxTmplArgs A)
+{
+	tmpl_emit_body<true, VGX_TMPL_G_THREADS, VGX_TMPL_G_TILE>(A);
+}
+
 } // namespace
 
 void vgx_launch_tmpl_check(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, VgxTotals* totals, hipStream_t s)
@@ -833,6 +846,6 @@ void vgx_launch_tmpl_emit(const VgxTmplArgs& a, hipStream_t s)
 {
 	const uint64_t blocks = a.wg ? a.num_wg : a.ninst * a.tiles_per_inst; // the host checked < 2^31
 	if (!blocks) { return; }
-	if (a.general) { hipLaunchKernelGGL((k_tmpl_emit<true, VGX_TMPL_G_THREADS, VGX_TMPL_G_TILE>), dim3((unsigned)blocks), dim3(VGX_TMPL_G_THREADS), 0, s, a); }
-	else { hipLaunchKernelGGL((k_tmpl_emit<false, VGX_TMPL_THREADS, VGX_TMPL_MAX_TILE>), dim3((unsigned)blocks), dim3(VGX_TMPL_THREADS), 0, s, a); }
+	if (a.general) { hipLaunchKernelGGL(k_tmpl_emit_general, dim3((unsigned)blocks), dim3(VGX_TMPL_G_THREADS), 0, s, a); }
+	else { hipLaunchKernelGGL(k_tmpl_emit, dim3((unsigned)blocks), dim3(VGX_TMPL_THREADS), 0, s, a); }
 }

@@ -504,6 +504,18 @@ def main():
     res["dt"] = dt
     total_units = float(vtot.item())
 
+    # ---- heterogeneous batch through vgx_partition (SURVEY 8e "for heterogeneous batches balance on the count-pass result") ----
+    # Every rank holds the same batch (Tiger instances at 7 scales, sorted by scale: equal instance counts per rank would be
+    # unbalanced), runs vgx_partition and tessellates its own range. Reported: per-rank times of the balanced and of the
+    # equal-count split. One rank: the parts are timed one after the other on the one GPU (what each rank of an 8-GPU run would do).
+    # Runs right after the headline's timing, while all ranks are still in step (the gather legs below can time out on a rank).
+    hetero = None
+    if args.config == "tiger10k" and not args.no_configs:
+        try:
+            hetero = hetero_leg(rt, torch, wl, dev, local_rank, rank, world, red_dev)
+        except Exception as e:  # noqa: BLE001 -- a diagnostic leg must not take the headline line with it
+            hetero = {"error": repr(e)}
+
     # ---- multi-GPU: the gather of the final streams to rank 0, timed by default, reported beside `value` ----
     # Preferred: libvgx's own RCCL gather behind the C-ABI (vgx_gather) on a dedicated communicator; the torch.distributed
     # version of the same layout (vg-renderer_amd/dist.py) when that cannot be set up (e.g. the shared-GPU test mode).
@@ -753,17 +765,6 @@ def main():
             if ctx2 is not ctx:
                 ctx2.close()
             torch.cuda.empty_cache()
-
-    # ---- heterogeneous batch through vgx_partition (SURVEY 8e "for heterogeneous batches balance on the count-pass result") ----
-    # Every rank holds the same batch (Tiger instances at 7 scales, sorted by scale: equal instance counts per rank would be
-    # unbalanced), runs vgx_partition and tessellates its own range. Reported: per-rank times of the balanced and of the
-    # equal-count split. One rank: the parts are timed one after the other on the one GPU (what each rank of an 8-GPU run would do).
-    hetero = None
-    if args.config == "tiger10k" and not args.no_configs and not bail:
-        try:
-            hetero = hetero_leg(rt, torch, wl, dev, local_rank, rank, world, red_dev)
-        except Exception as e:  # noqa: BLE001 -- a diagnostic leg must not take the headline line with it
-            hetero = {"error": repr(e)}
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3

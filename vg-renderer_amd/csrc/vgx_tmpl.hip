@@ -28,6 +28,7 @@
 // Results are identical to the ordinary path's by construction and by test (tests/test_gpu_tmpl.py: VGX_TMPL=0 vs 1
 // byte for byte, both against the reference).
 #include <stddef.h>
+#include <type_traits>
 #include "vgx_internal.h"
 #include "vgx_wave.h"
 #include "vgx_elem.h"
@@ -506,10 +507,11 @@ __device__ __forceinline__ void tmpl_stroke_counts(uint32_t kind, uint32_t cap, 
 	else { *joinNv = 3; *joinNi = 3; }                                  // n + 2, 3n (:1156, 1186)
 }
 
-// A real function (not inlined): the general element body is ~130 VGPRs of branches; inlined four times into the unrolled element
-// loop of the kernel it spilled. Everything it needs comes by value: own vertex, previous vertex, the three edge directions around
-// the element, the mesh's first two vertices (closing bridge).
-__device__ __noinline__ void tmpl_stroke_general(char* opos, char* ocol, char* oidx, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color,
+// Inlined ONCE per kernel (the tile loop calls it from a rolled loop, see tmpl_elem_emit's PASS): inlined four times into the
+// unrolled element loop it spilled, as a real function its callee-saved registers went through scratch on every call. Everything
+// it needs comes by value: own vertex, previous vertex, the three edge directions around the element, the mesh's first two
+// vertices (closing bridge).
+__device__ __forceinline__ void tmpl_stroke_general(char* opos, char* ocol, char* oidx, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color,
 	float hsw, float hswAA, float fringe, const vgx_draw* tdraw, uint32_t j, V2 p1, V2 pPrev, V2 d12, V2 dPrev, V2 dPrev2, V2 v0, V2 v1)
 {
 	MeshCtxT<TmplVtx01> mc;
@@ -541,17 +543,21 @@ __device__ __noinline__ void tmpl_stroke_general(char* opos, char* ocol, char* o
 
 // One element given its mesh's constants, its transformed vertex, its own edge direction and a way to get the mesh's other
 // edge directions (dir(jj) = direction of the edge jj -> jj + 1, cyclic) and vertices (vtx(jj), general strokes only).
-template<bool GENERAL, class DF, class VF>
+// PASS (GENERAL only): 0 = every element, 1 = everything but the general strokes, 2 = the general strokes only -- the tile loop runs
+// pass 1 unrolled and pass 2 as a rolled loop, so that the general element body (~120 VGPRs of branches) is in the kernel once.
+template<bool GENERAL, int PASS, class DF, class VF>
 __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color, float f0, float f1,
 	V2 p1, V2 d12, const DF& dir, const VF& vtx, float fringe, const vgx_draw* tdraw)
 {
 	const uint32_t kind = VGX_MD_KIND(kindWord);
 	const uint32_t jp1 = j > 0 ? j - 1 : N - 1;
+	const bool general = GENERAL && kind >= VGX_MESH_STROKE && !stroke_elem_is_simple(kind, VGX_MD_CLOSED(kindWord) != 0, VGX_MD_JOIN(kindWord));
+	if (GENERAL && ((PASS == 1 && general) || (PASS == 2 && !general))) { return; }
 	if (kind < VGX_MESH_STROKE) {
 		V2 dPrev = d12;
 		if (kind == VGX_MESH_FILL_AA) { dPrev = dir(jp1); }
 		tmpl_fill_elem(O, kindWord, N, vOff, iOff, ibase, color, f0, j, p1, dPrev, d12);
-	} else if (GENERAL && !stroke_elem_is_simple(kind, VGX_MD_CLOSED(kindWord) != 0, VGX_MD_JOIN(kindWord))) {
+	} else if (general) {
 		const bool closed = VGX_MD_CLOSED(kindWord) != 0;
 		const V2 dPrev = dir(jp1);
 		V2 pPrev = p1, dPrev2 = dPrev, v0 = p1, v1 = p1;
@@ -673,7 +679,7 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 			auto vtx = [&](uint32_t jj) { return tmpl_xf(xf, vt[jj]); };
 			if (j == 0 && A.meshes_out) { tmpl_mesh_out(A, P, er.mesh); }
 			const uint32_t ibase = meshBase ? meshBase[er.mesh] : 0u;
-			tmpl_elem_emit<GENERAL>(O, j, tm.kind, N, tm.v_off, tm.i_off, ibase, kind < VGX_MESH_STROKE ? dr.fill_color : dr.stroke_color, f0, tm.f1, tmpl_xf(xf, vt[j]), dir(j), dir, vtx,
+			tmpl_elem_emit<GENERAL, 0>(O, j, tm.kind, N, tm.v_off, tm.i_off, ibase, kind < VGX_MESH_STROKE ? dr.fill_color : dr.stroke_color, f0, tm.f1, tmpl_xf(xf, vt[j]), dir(j), dir, vtx,
 				__uint_as_float(tm.pad[0]), P.tdraws + tm.drawk);
 		}
 		return;
@@ -759,14 +765,12 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 	__syncthreads();
 	TMPL_PROF(2);
 	// ---- phase 3: the element
-#pragma unroll
-	for (int c = 0; c < CH; ++c) {
-		const uint32_t s = (uint32_t)c * THREADS + tid;
+	auto element = [&](auto passTag, uint32_t s, const VgxTmplElem& e, V2 pv, V2 dv) {
 		if (s < nel) {
-			const uint32_t mesh = er[c].mesh;
+			const uint32_t mesh = e.mesh;
 			const TmplRec* rp = &s_rec[mesh - mA];
-			const uint32_t j = er[c].jq & 0xFFFFu, N = rp->n;
-			const int q0 = (int)(er[c].jq >> 16) - (int)j;
+			const uint32_t j = e.jq & 0xFFFFu, N = rp->n;
+			const int q0 = (int)(e.jq >> 16) - (int)j;
 			auto dir = [&](uint32_t jj) {
 				const uint32_t qq = (uint32_t)(q0 + (int)jj);
 				if (qq < nel) { const float2 v = s_dir[qq]; return v2(v.x, v.y); }
@@ -775,8 +779,21 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 			auto vtx = [&](uint32_t jj) { return vtxAt(mesh, rp, q0, jj); };
 			float fringe = 0.0f;
 			const vgx_draw* tdraw = P.tdraws;
-			if (GENERAL) { const VgxTmplMesh* tmm = A.tmesh + mesh; fringe = __uint_as_float(tmm->pad[0]); tdraw = P.tdraws + (dA + TMPL_REC_DK(rp)); }
-			tmpl_elem_emit<GENERAL>(O, j, rp->kind & 0xFFFFu, N, rp->v_off, rp->i_off, rp->ibase, rp->color, rp->f0, rp->f1, p1[c], d12[c], dir, vtx, fringe, tdraw);
+			if (GENERAL && decltype(passTag)::value == 2) { const VgxTmplMesh* tmm = A.tmesh + mesh; fringe = __uint_as_float(tmm->pad[0]); tdraw = P.tdraws + (dA + TMPL_REC_DK(rp)); }
+			tmpl_elem_emit<GENERAL, decltype(passTag)::value>(O, j, rp->kind & 0xFFFFu, N, rp->v_off, rp->i_off, rp->ibase, rp->color, rp->f0, rp->f1, pv, dv, dir, vtx, fringe, tdraw);
+		}
+	};
+#pragma unroll
+	for (int c = 0; c < CH; ++c) {
+		element(std::integral_constant<int, GENERAL ? 1 : 0>(), (uint32_t)c * THREADS + tid, er[c], p1[c], d12[c]);
+	}
+	if (GENERAL) { // the general strokes of the tile, one element per trip: the body exists once
+#pragma unroll 1
+		for (int c = 0; c < CH; ++c) {
+			VgxTmplElem e = er[0]; V2 pv = p1[0], dv = d12[0];
+#pragma unroll
+			for (int k = 1; k < CH; ++k) { if (c == k) { e = er[k]; pv = p1[k]; dv = d12[k]; } }
+			element(std::integral_constant<int, 2>(), (uint32_t)c * THREADS + tid, e, pv, dv);
 		}
 	}
 	TMPL_PROF(3);

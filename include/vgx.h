@@ -277,8 +277,8 @@ int vgx_tessellate_emit(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* dra
  * capacities are checked on the device; `dev_sizes` (DEVICE vgx_sizes, may be NULL) receives the
  * totals and `dev_status` (DEVICE uint32, may be NULL) receives VGX_OK / VGX_E_NOSPACE / ... .
  * Template mode: when the last vgx_tessellate_count found that the draws repeat their first P draws (>= 32 times, > 2048 draws)
- * in everything but mtx, fill_color, stroke_color and state_key, and every mesh of that period is a convex fill or a closed
- * Miter AA / Thin stroke, it flattened the period ONCE in local space (the reference flattens before it transforms,
+ * in everything but mtx, fill_color, stroke_color and state_key, and no mesh of that period has Round joins (their point counts
+ * depend on the transformed geometry), it flattened the period ONCE in local space (the reference flattens before it transforms,
  * vg.cpp:4957-4975) and vgx_tessellate on this path set with any whole number of periods is one kernel: per instance the
  * template's vertices through the instance's transform, the stroker's per-element arithmetic, stores. Every call re-checks all
  * draw records against the counted period on the device; a draw that differs in another field ends the call with

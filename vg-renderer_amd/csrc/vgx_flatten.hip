@@ -160,6 +160,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 							ex = a[4]; ey = a[5];
 						}
 						wave_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tol / (scale * scale), stack, sink);
+						sink.flush();
 						cnt = (int)sink.n;
 						slow = sink.slow;
 					} break;
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 					case VGX_CMD_CUBIC_TO:
 					case VGX_CMD_QUAD_TO: {
 						FastCubicSink<true, XFORM> sink;
-						sink.prev = start; sink.n = 0; sink.slow = false; sink.out = out; sink.writeLimit = limit; sink.mtx = mtx;
+						sink.prev = start; sink.n = 0; sink.slow = false; sink.out = out; sink.writeLimit = limit; sink.mtx = mtx; sink.begin();
 						float c1x = a[0], c1y = a[1], c2x = a[2], c2y = a[3], ex, ey;
 						if (type == VGX_CMD_QUAD_TO) {
 							ex = a[2]; ey = a[3];
@@ -278,6 +279,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 							ex = a[4]; ey = a[5];
 						}
 						wave_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tol / (scale * scale), stack, sink);
+						sink.flush();
 					} break;
 					case VGX_CMD_POLYLINE: {
 						const uint32_t npts = na >> 1;
@@ -503,6 +505,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 								FastCubicSink<false, false> sink;
 								sink.prev = start; sink.n = 0; sink.slow = false;
 								wave_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tessTol, stack, sink);
+								sink.flush();
 								cnt = (int)sink.n;
 								slow = sink.slow;
 							}
@@ -609,8 +612,9 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 							if (POOL) {
 								if (poolDeep) {
 									FastCubicSink<true, true> sink;
-									sink.prev = start; sink.n = 0; sink.slow = false; sink.out = out; sink.writeLimit = limit; sink.mtx = mtx;
+									sink.prev = start; sink.n = 0; sink.slow = false; sink.out = out; sink.writeLimit = limit; sink.mtx = mtx; sink.begin();
 									wave_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tol / (scale * scale), stack, sink);
+									sink.flush();
 								}
 							} else if ((uint32_t)rawCnt <= VGX_LEAF_SLOTS + VGX_BUILD_OVERFLOW) {
 								const uint32_t nl = limit < VGX_LEAF_SLOTS ? limit : VGX_LEAF_SLOTS;
@@ -627,8 +631,9 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 								}
 							} else { // more leaves than slots + overflow area: subdivide again, straight to memory
 								FastCubicSink<true, true> sink;
-								sink.prev = start; sink.n = 0; sink.slow = false; sink.out = out; sink.writeLimit = limit; sink.mtx = mtx;
+								sink.prev = start; sink.n = 0; sink.slow = false; sink.out = out; sink.writeLimit = limit; sink.mtx = mtx; sink.begin();
 								wave_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tol / (scale * scale), stack, sink);
+								sink.flush();
 							}
 						} else if (type == VGX_CMD_POLYLINE && limit < VGX_WAVE) { // (longer ones: the whole wave, below)
 							const uint32_t skip = (na >> 1) - (uint32_t)rawCnt;

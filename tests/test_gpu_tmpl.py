@@ -418,3 +418,22 @@ def test_template_general_strokes_round_joins_stay_ordinary(rt, wl, oracle):
     assert_mesh_equal(got, oracle.tessellate(ps, d), "round joins: ordinary pipeline")
     ctx.close()
 
+
+@pytest.mark.parametrize("seed,ninst,tile", [(996, 40, None), (997, 36, "192"), (998, 50, "64")])
+def test_template_open_miter_strokes(rt, wl, oracle, monkeypatch, seed, ninst, tile):
+    """The commonest open style -- Miter joins with Butt or Square caps, AA or hairline -- has an element routine of its own in
+    the general kernel (fixed sizes, like the closed one): open and closed fuzz paths, half of the strokes with Square caps."""
+    if tile:
+        monkeypatch.setenv("VGX_TMPL_TILE", tile)
+    ps = wl.fuzz_paths(seed, npaths=72, with_shapes=True, degenerate=False)
+    d = wl.template_draws(ps, seed, ninst)
+    sq = (np.arange(d.shape[0]) % ps.npaths) % 2 == 1
+    stroked = (d["stroke_flags"] & 1) != 0
+    d["stroke_flags"][sq & stroked] |= np.uint32(rt.capi.CAP_SQUARE << 4)
+    ref = oracle.tessellate(ps, d)
+    ctx = rt.Context(0)
+    got = _run(rt, ctx, ps, d)
+    assert got.mode == MODE_TEMPLATE and got.status == 0
+    assert_mesh_equal(got, ref, "template open Miter strokes seed=%d" % seed)
+    ctx.close()
+

@@ -461,6 +461,126 @@ __device__ __forceinline__ void tmpl_stroke_elem(const TmplOut& O, uint32_t kind
 	}
 }
 
+// One element of an OPEN stroke with MITER joins and Butt / Square caps, AA (4 rails) or Thin (3 rails; its caps are Butt or
+// "everything else", stroker.cpp:2012-2058): the commonest open style, fixed sizes like the closed one -- R vertices per element,
+// AA caps two triangles of their own (stroker.cpp:1422-1474, 1858-1916), a bridge from every element to the next. Same arithmetic
+// as elem_emit (vgx_elem.h) for these cases, without its register stage; only the general kernel instantiation contains it.
+__device__ __forceinline__ void tmpl_stroke_elem_open(const TmplOut& O, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color, float hsw, float hswAA,
+	const VgxTmplMesh* tmm, uint32_t j, V2 p1, V2 dPrev2, V2 dPrev, V2 d12)
+{
+	const bool thin = VGX_MD_KIND(kindWord) == VGX_MESH_STROKE_AA_THIN;
+	const uint32_t cap = VGX_MD_CAP(kindWord);
+	const uint32_t R = thin ? 3u : 4u;
+	const uint32_t bridgeIdx = thin ? 12u : 18u;
+	const uint32_t capNi = thin ? 0u : 6u;
+	const float sideWidth = thin ? hsw : hswAA; // fringe : hswAA
+	const bool first = j == 0, last = j + 1 == N;
+	const uint32_t b = R * j;
+	const uint32_t bi = b + ibase, top = bi + R - 1;
+	const uint32_t c0 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
+	bool L = true; // caps connect like a join whose left side is the inner one (rails b .. b + R - 1 in order)
+	V2 q0, q1, q2, q3;
+	if (first || last) {
+		const V2 d = first ? d12 : dPrev;
+		const V2 l = v2ccw(d);
+		if (thin) { // :2012-2058, 2242-2294
+			const V2 lf = v2mul(l, hsw);
+			q1 = p1;
+			if (cap == VGX_CAP_BUTT) { q0 = v2add(p1, lf); q2 = v2sub(p1, lf); }
+			else {
+				const V2 df = v2mul(d, hsw);
+				q0 = first ? v2add(p1, v2sub(lf, df)) : v2add(p1, v2add(lf, df));
+				q2 = first ? v2sub(p1, v2add(lf, df)) : v2sub(p1, v2sub(lf, df));
+			}
+			q3 = q2;
+		} else {
+			const V2 lh = v2mul(l, hsw);
+			const V2 lhaa = v2mul(l, hswAA);
+			if (cap == VGX_CAP_BUTT) { // :1422-1447, 1858-1886
+				const V2 daa = v2mul(d, __uint_as_float(tmm->pad[0])); // the draw's fringe
+				q0 = first ? v2add(p1, v2sub(lhaa, daa)) : v2add(p1, v2add(lhaa, daa));
+				q1 = v2add(p1, lh);
+				q2 = v2sub(p1, lh);
+				q3 = first ? v2sub(p1, v2add(lhaa, daa)) : v2sub(p1, v2sub(lhaa, daa));
+			} else { // Square, :1448-1474, 1887-1916
+				const V2 dh = v2mul(d, hsw);
+				const V2 dhaa = v2mul(d, hswAA);
+				q0 = first ? v2add(p1, v2sub(lhaa, dhaa)) : v2add(p1, v2add(lhaa, dhaa));
+				q1 = first ? v2add(p1, v2sub(lh, dh)) : v2add(p1, v2add(lh, dh));
+				q2 = first ? v2sub(p1, v2add(lh, dh)) : v2sub(p1, v2sub(lh, dh));
+				q3 = first ? v2sub(p1, v2add(lhaa, dhaa)) : v2sub(p1, v2sub(lhaa, dhaa));
+			}
+		}
+	} else {
+		const VgxJoin jn = vgx_join_dirs(dPrev, d12, sideWidth);
+		L = jn.leftInner;
+		if (thin) { // :2060-2110
+			const V2 vf = v2mul(jn.v, hsw);
+			q0 = L ? v2add(p1, vf) : v2sub(p1, vf);
+			q1 = p1;
+			q2 = L ? v2sub(p1, vf) : v2add(p1, vf);
+			q3 = q2;
+		} else { // :1524-1579
+			const V2 vhaa = v2mul(jn.v, hswAA);
+			const V2 vh = v2mul(jn.v, hsw);
+			q0 = L ? v2add(p1, vhaa) : v2sub(p1, vhaa);
+			q1 = L ? v2add(p1, vh) : v2sub(p1, vh);
+			q2 = L ? v2sub(p1, vh) : v2add(p1, vh);
+			q3 = L ? v2sub(p1, vhaa) : v2add(p1, vhaa);
+		}
+	}
+	const Rails mine = thin ? (L ? rails(bi, bi + 1, bi + 2, 0) : rails(top, bi + 1, bi, 0)) : (L ? rails(bi, bi + 1, bi + 2, bi + 3) : rails(top, bi + 2, bi + 1, bi));
+	char* pp = O.pos + (vOff + b) * 8u;
+	char* pc = O.col + (vOff + b) * 4u;
+	if (thin) {
+		PosPair q; q.x0 = q0.x; q.y0 = q0.y; q.x1 = q1.x; q.y1 = q1.y;
+		ColPair c; c.c0 = c0; c.c1 = color;
+		*(PosPair*)pp = q;
+		*(float2*)(pp + 16) = make_float2(q2.x, q2.y);
+		*(ColPair*)pc = c;
+		*(uint32_t*)(pc + 8) = c0;
+	} else {
+		PosPair q; q.x0 = q0.x; q.y0 = q0.y; q.x1 = q1.x; q.y1 = q1.y;
+		PosPair r; r.x0 = q2.x; r.y0 = q2.y; r.x1 = q3.x; r.y1 = q3.y;
+		ColPair c; c.c0 = c0; c.c1 = color;
+		ColPair d; d.c0 = color; d.c1 = c0;
+		*(PosPair*)pp = q;
+		*(PosPair*)(pp + 16) = r;
+		*(ColPair*)pc = c;
+		*(ColPair*)(pc + 8) = d;
+	}
+	if (first && !thin) { // the cap's quad (0, 2, 1) (0, 3, 2), :1443-1446
+		Idx6 t; t.a = (bi & 0xFFFFu) | ((bi + 2) << 16); t.b = ((bi + 1) & 0xFFFFu) | (bi << 16); t.c = ((bi + 3) & 0xFFFFu) | ((bi + 2) << 16);
+		*(Idx6*)(O.idx + iOff * 2u) = t;
+	}
+	if (j > 0) { // the bridge from the previous element (stroker.cpp:1557-1564, 1876-1883; thin :2093-2098, 2262-2267)
+		bool pL = true;
+		if (j > 1) { pL = vgx_join_dirs(dPrev2, dPrev, sideWidth).leftInner; }
+		const uint32_t pb = R * (j - 1) + ibase, ptop = pb + R - 1;
+		const Rails p = thin ? (pL ? rails(pb, pb + 1, pb + 2, 0) : rails(ptop, pb + 1, pb, 0))
+		                     : (pL ? rails(pb, pb + 1, pb + 2, pb + 3) : rails(ptop, pb + 2, pb + 1, pb));
+		char* pi = O.idx + (iOff + capNi + bridgeIdx * (j - 1)) * 2u;
+		Idx6 t0; t0.a = (p.a & 0xFFFFu) | (p.b << 16); t0.b = (mine.b & 0xFFFFu) | (p.a << 16); t0.c = (mine.b & 0xFFFFu) | (mine.a << 16);
+		Idx6 t1; t1.a = (p.b & 0xFFFFu) | (p.c << 16); t1.b = (mine.c & 0xFFFFu) | (p.b << 16); t1.c = (mine.c & 0xFFFFu) | (mine.b << 16);
+		*(Idx6*)pi = t0;
+		*(Idx6*)(pi + 12) = t1;
+		if (!thin) {
+			Idx6 t2; t2.a = (p.c & 0xFFFFu) | (p.d << 16); t2.b = (mine.d & 0xFFFFu) | (p.c << 16); t2.c = (mine.d & 0xFFFFu) | (mine.c << 16);
+			*(Idx6*)(pi + 24) = t2;
+			if (last) { // the end cap's quad (b, b + 1, b + 2) (b, b + 2, b + 3), :1884-1885
+				Idx6 t; t.a = (bi & 0xFFFFu) | ((bi + 1) << 16); t.b = ((bi + 2) & 0xFFFFu) | (bi << 16); t.c = ((bi + 2) & 0xFFFFu) | ((bi + 3) << 16);
+				*(Idx6*)(pi + 36) = t;
+			}
+		}
+	}
+}
+__device__ __forceinline__ bool tmpl_stroke_is_open_fast(uint32_t kindWord)
+{
+	const uint32_t kind = VGX_MD_KIND(kindWord);
+	return VGX_MD_CLOSED(kindWord) == 0 && VGX_MD_JOIN(kindWord) == VGX_JOIN_MITER
+		&& (kind == VGX_MESH_STROKE_AA_THIN || (kind == VGX_MESH_STROKE_AA && VGX_MD_CAP(kindWord) != VGX_CAP_ROUND));
+}
+
 // Where one instance lies in the batch (workgroup-uniform): output bases, first mesh, first draw; its class's saved draw records
 // and first template mesh.
 struct TmplPlace
@@ -547,11 +667,12 @@ __device__ __forceinline__ void tmpl_stroke_general(char* opos, char* ocol, char
 // pass 1 unrolled and pass 2 as a rolled loop, so that the general element body (~120 VGPRs of branches) is in the kernel once.
 template<bool GENERAL, int PASS, class DF, class VF>
 __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color, float f0, float f1,
-	V2 p1, V2 d12, const DF& dir, const VF& vtx, float fringe, const vgx_draw* tdraw)
+	V2 p1, V2 d12, const DF& dir, const VF& vtx, float fringe, const vgx_draw* tdraw, const VgxTmplMesh* tmm)
 {
 	const uint32_t kind = VGX_MD_KIND(kindWord);
 	const uint32_t jp1 = j > 0 ? j - 1 : N - 1;
-	const bool general = GENERAL && kind >= VGX_MESH_STROKE && !stroke_elem_is_simple(kind, VGX_MD_CLOSED(kindWord) != 0, VGX_MD_JOIN(kindWord));
+	const bool openFast = GENERAL && kind >= VGX_MESH_STROKE && tmpl_stroke_is_open_fast(kindWord);
+	const bool general = GENERAL && kind >= VGX_MESH_STROKE && !openFast && !stroke_elem_is_simple(kind, VGX_MD_CLOSED(kindWord) != 0, VGX_MD_JOIN(kindWord));
 	if (GENERAL && ((PASS == 1 && general) || (PASS == 2 && !general))) { return; }
 	if (kind < VGX_MESH_STROKE) {
 		V2 dPrev = d12;
@@ -564,6 +685,11 @@ __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uin
 		if (j > 0) { pPrev = vtx(jp1); dPrev2 = dir(jp1 > 0 ? jp1 - 1 : N - 1); } // the previous element's geometry: only when a bridge connects to it
 		if (closed && j + 1 == N) { v0 = vtx(0u); v1 = vtx(N > 1 ? 1u : 0u); }      // join 0's inner side: only the closing bridge asks
 		tmpl_stroke_general(O.pos, O.col, O.idx, kindWord, N, vOff, iOff, ibase, color, f0, f1, fringe, tdraw, j, p1, pPrev, d12, dPrev, dPrev2, v0, v1);
+	} else if (openFast) {
+		const V2 dPrev = dir(jp1);
+		V2 dPrev2 = dPrev;
+		if (j > 1) { dPrev2 = dir(jp1 - 1); }
+		tmpl_stroke_elem_open(O, kindWord, N, vOff, iOff, ibase, color, f0, f1, tmm, j, p1, dPrev2, dPrev, d12);
 	} else {
 		const V2 dPrev = dir(jp1);
 		V2 dPrev2 = dPrev, dFirst = dPrev;
@@ -680,7 +806,7 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 			if (j == 0 && A.meshes_out) { tmpl_mesh_out(A, P, er.mesh); }
 			const uint32_t ibase = meshBase ? meshBase[er.mesh] : 0u;
 			tmpl_elem_emit<GENERAL, 0>(O, j, tm.kind, N, tm.v_off, tm.i_off, ibase, kind < VGX_MESH_STROKE ? dr.fill_color : dr.stroke_color, f0, tm.f1, tmpl_xf(xf, vt[j]), dir(j), dir, vtx,
-				__uint_as_float(tm.pad[0]), P.tdraws + tm.drawk);
+				__uint_as_float(tm.pad[0]), P.tdraws + tm.drawk, A.tmesh + er.mesh);
 		}
 		return;
 	}
@@ -780,7 +906,7 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 			float fringe = 0.0f;
 			const vgx_draw* tdraw = P.tdraws;
 			if (GENERAL && decltype(passTag)::value == 2) { const VgxTmplMesh* tmm = A.tmesh + mesh; fringe = __uint_as_float(tmm->pad[0]); tdraw = P.tdraws + (dA + TMPL_REC_DK(rp)); }
-			tmpl_elem_emit<GENERAL, decltype(passTag)::value>(O, j, rp->kind & 0xFFFFu, N, rp->v_off, rp->i_off, rp->ibase, rp->color, rp->f0, rp->f1, pv, dv, dir, vtx, fringe, tdraw);
+			tmpl_elem_emit<GENERAL, decltype(passTag)::value>(O, j, rp->kind & 0xFFFFu, N, rp->v_off, rp->i_off, rp->ibase, rp->color, rp->f0, rp->f1, pv, dv, dir, vtx, fringe, tdraw, A.tmesh + mesh);
 		}
 	};
 #pragma unroll

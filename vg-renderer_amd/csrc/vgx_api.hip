@@ -12,6 +12,7 @@
 #include "vgx_pathsim.h"
 #include "vgx_inst.h"
 #include <vector>
+#include <unordered_map>
 #include <string.h>
 #include <math.h>
 #include <new>
@@ -1287,13 +1288,15 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 		HIPCHK(ctx, hipStreamSynchronize(s));
 		instCls.resize(ninst);
 		reps.clear();
-		unsigned long long seen[VGX_TMPL_MAX_CLASSES];
+		std::unordered_map<unsigned long long, uint32_t> seen;
 		for (uint64_t k = 0; k < ninst; ++k) {
-			uint32_t c = 0;
-			while (c < reps.size() && seen[c] != hashes[k]) { ++c; }
-			if (c == reps.size()) {
+			const auto it = seen.find(hashes[k]);
+			uint32_t c;
+			if (it != seen.end()) { c = it->second; }
+			else {
+				c = (uint32_t)reps.size();
 				if (c == VGX_TMPL_MAX_CLASSES) { return VGX_OK; } // too many flavours: the ordinary pipeline
-				seen[c] = hashes[k];
+				seen.emplace(hashes[k], c);
 				reps.push_back((uint32_t)k);
 			}
 			instCls[k] = c;
@@ -1396,11 +1399,11 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 		// Workgroup order: class after class (the instances of a class in draw order). The output places are the instances' own
 		// whatever the order; running one class's instances together keeps ONE class's tables hot in L2 instead of all of them
 		// (instances in draw order: 3.9 GB of table re-reads from HBM for Tiger x 10k in 18 classes).
-		for (uint32_t c = 0; c < T; ++c) {
-			for (uint64_t k = 0; k < ninst; ++k) {
-				if (instCls[k] != c) { continue; }
-				for (uint32_t t = cls[c].tile0; t < cls[c + 1].tile0; ++t) { wg[(size_t)w++] = make_uint2((uint32_t)k, t); }
-			}
+		std::vector<uint64_t> cursor(T, 0);
+		for (uint32_t c = 0; c < T; ++c) { cursor[c] = w; w += cnt[c] * (uint64_t)(cls[c + 1].tile0 - cls[c].tile0); }
+		for (uint64_t k = 0; k < ninst; ++k) {
+			const uint32_t c = instCls[k];
+			for (uint32_t t = cls[c].tile0; t < cls[c + 1].tile0; ++t) { wg[(size_t)cursor[c]++] = make_uint2((uint32_t)k, t); }
 		}
 		if ((st = ensure(ctx, ctx->tmplIinfo, (ninst + 1) * sizeof(VgxTmplInst))) != VGX_OK) { return st; }
 		if ((st = ensure(ctx, ctx->tmplWg, ((size_t)numWg + 1) * sizeof(uint2))) != VGX_OK) { return st; }

@@ -3,6 +3,7 @@ the restatement) over units [first, first + count) of a BASELINE workload and wr
 (tests/hashutil.py) to an .npy file. One process per host core (the reference's subdivision stack is a function-local
 static, src/path.cpp:91).
   python tests/ref_hash_worker.py tiger|tigerspec <first instance> <count> out.npy     rows: [count, 3, 4] (pos, colour, idx)
+  python tests/ref_hash_worker.py varied <first instance> <count> out.npy               rows: [count, 3, 4] + sizes [count, 2] (instances of different sizes)
   python tests/ref_hash_worker.py round <first polyline> <count> out.npy               rows: [count, 3, 4] + sizes [count, 2]
   python tests/ref_hash_worker.py cubics <first path> <count> out.npy                  rows: [count, 1, 4] + sizes [count, 1]"""
 import importlib
@@ -33,6 +34,26 @@ def main():
             r = pyoracle.tessellate(ps, d)
             rows.append(np.stack([hu.digest_uniform_np(r.pos.view(np.uint32).reshape(-1), n), hu.digest_uniform_np(r.color, n),
                                   hu.digest_uniform_np(r.idx.astype(np.uint32), n)], axis=1))
+        np.save(out, np.concatenate(rows))
+    elif which == "varied":
+        ps, ops = wl.tiger_paths()
+        P = len(ops)
+        rows = []
+        B = 16
+        whole = wl.tiger_varied_draws(ops, 10000)  # the batch the test tessellates (the generator's angles depend on the batch size)
+        for a in range(first, first + count, B):
+            n = min(B, first + count - a)
+            d = whole[a * P:(a + n) * P]
+            r = pyoracle.tessellate(ps, d)
+            m = r.meshes
+            m0 = np.searchsorted(m["draw"], np.arange(n + 1, dtype=np.int64) * P, side="left")  # first mesh of every instance
+            fvm = np.concatenate([m["first_vertex"].astype(np.int64), [r.pos.shape[0]]])
+            fim = np.concatenate([m["first_index"].astype(np.int64), [r.idx.shape[0]]])
+            fv, fi = fvm[m0[:-1]], fim[m0[:-1]]
+            nv, ni = fvm[m0[1:]] - fv, fim[m0[1:]] - fi
+            part = np.stack([hu.digest_ragged_np(r.pos.view(np.uint32).reshape(-1), 2 * fv, 2 * nv), hu.digest_ragged_np(r.color, fv, nv),
+                             hu.digest_ragged_np(r.idx.astype(np.uint32), fi, ni)], axis=1)
+            rows.append(np.concatenate([part.reshape(n, 12), nv[:, None], ni[:, None]], axis=1))
         np.save(out, np.concatenate(rows))
     elif which == "round":
         ps, d = wl.random_walk_polylines(10000, 1000, seed=5678)

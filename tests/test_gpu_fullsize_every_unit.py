@@ -84,6 +84,42 @@ def test_every_instance_of_tiger_x10k_matches_the_reference(rt, wl, which):
     ctx.close()
 
 
+def test_every_instance_of_tiger_at_seven_scales_matches_the_reference(rt, wl):
+    """bench.py's tiger10k_varied at full size (18 template classes: instances of different sizes): digests of positions / colours /
+    indices and the sizes of all 10 000 instances against the reference's."""
+    import torch
+    K = 10000
+    ps, ops = wl.tiger_paths()
+    P = len(ops)
+    d = wl.tiger_varied_draws(ops, K)
+    ctx = rt.Context(0)
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(d)
+    sizes = rt.tessellate_count(ctx, pset, dd, d.shape[0])
+    assert ctx.failure_info()["segment_items"] == 5
+    nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
+    bufs = rt.MeshBuffers(dd.device, nv, ni, nm)
+    bufs.pos.fill_(float("nan"))
+    rt.tessellate_async(ctx, pset, dd, d.shape[0], bufs)
+    torch.cuda.synchronize()
+    assert int(bufs.dev_status.item()) == 0
+    ref = _reference_rows("varied", K)  # [K, 12 + 2]
+    mt = bufs.meshes[:nm * 32].view(torch.int64).view(-1, 4)
+    draw = (mt[:, 3] & 0xFFFFFFFF).contiguous()
+    m0 = torch.searchsorted(draw, torch.arange(K + 1, dtype=torch.int64, device=draw.device) * P)  # first mesh of every instance
+    fvm = torch.cat([mt[:, 0], torch.tensor([nv], dtype=torch.int64, device=draw.device)])
+    fim = torch.cat([mt[:, 1], torch.tensor([ni], dtype=torch.int64, device=draw.device)])
+    fv, fi = fvm[m0[:-1]], fim[m0[:-1]]
+    cv, ci = fvm[m0[1:]] - fv, fim[m0[1:]] - fi
+    assert np.array_equal(cv.cpu().numpy(), ref[:, 12]) and np.array_equal(ci.cpu().numpy(), ref[:, 13])
+    got = np.concatenate([hu.digest_ragged_torch(bufs.pos[:nv].view(torch.int32), 2 * fv, 2 * cv), hu.digest_ragged_torch(bufs.color[:nv], fv, cv),
+                          hu.digest_ragged_torch(bufs.idx[:ni], fi, ci, is_u16=True)], axis=1)
+    bad = np.flatnonzero((got != ref[:, :12]).any(axis=1))
+    assert bad.shape[0] == 0, ("instances that differ from the reference", bad[:10].tolist(), bad.shape[0])
+    pset.close()
+    ctx.close()
+
+
 def test_every_mesh_of_the_round_join_polylines_matches_the_reference(rt, wl):
     """BASELINE configs[3]: 10 000 polylines x 1 000 segments, Round joins + Round caps (data-dependent mesh sizes)."""
     import torch

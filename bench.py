@@ -167,6 +167,7 @@ WORKLOADS = {
     "cubics1m": "BASELINE configs[1]: 1M independent cubics, adaptive flatten only",
     "round10k": "BASELINE configs[3]: 10k polylines x 1k segments, Round joins + Round caps",
     "tiger10k_varied": "Tiger x10k at 7 scales (0.5 .. 3.5; 18 distinct avgScale values after rounding) under rotations: template mode with one template per class",
+    "tiger10k_open": "Tiger x10k with every sub-path left open (no pathClose): open Miter strokes with Butt caps, template mode's general kernel",
     "tigerspec10k": "SURVEY 8(d) config 3 as specified: 240 paths x (1-4 sub-paths x 8-60 cubics), x10k instances",
     # honesty configs: the headline batch WITHOUT the template mode (every instance flattened, polyline through HBM), and without
     # any instancing shortcut (what a batch of 2.4 M unrelated draws costs)
@@ -190,6 +191,11 @@ def make_workload(wl, name, instances, rank):
         d = wl.tiger_varied_draws(ops, instances, first_instance=rank * instances)
         return ps, d, ("tiger-like drawing (seed 2024) x %d instances per GPU, every instance at its own scale in {0.5 .. 3.5} and "
                        "rotation (tolerance and stroke widths follow the scale)" % instances), "tessellate"
+    if name == "tiger10k_open":
+        ps, ops = wl.tiger_paths(closed=False)
+        d = wl.tiger_draws(ops, instances, first_instance=rank * instances)
+        return ps, d, ("the tiger-like drawing (seed 2024) with open sub-paths x %d instances per GPU: convexFillAA + polylineStrokeAA/AAThin "
+                       "with Butt caps and Miter joins on 1/3 of the paths" % instances), "tessellate"
     if name == "tigerspec10k":
         ps, ops = wl.tiger_spec_paths()
         d = wl.tiger_draws(ops, instances, first_instance=rank * instances)

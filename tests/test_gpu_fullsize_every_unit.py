@@ -56,13 +56,13 @@ def _reference_rows(which, units):
     return np.concatenate(parts)
 
 
-@pytest.mark.parametrize("which", ["tiger", "tigerspec"])
+@pytest.mark.parametrize("which", ["tiger", "tigerspec", "tigeropen"])
 def test_every_instance_of_tiger_x10k_matches_the_reference(rt, wl, which):
     """BASELINE configs[2] (and the SURVEY 8(d) drawing as specified, bench.py's tigerspec10k) at full size through the entry
     point bench.py times; digests of positions / colours / indices of all 10 000 instances against the reference's."""
     import torch
     K = 10000
-    ps, ops = wl.tiger_paths() if which == "tiger" else wl.tiger_spec_paths()
+    ps, ops = wl.tiger_spec_paths() if which == "tigerspec" else wl.tiger_paths(closed=which == "tiger")  # tigeropen: open strokes (general kernel)
     d = wl.tiger_draws(ops, K)
     ctx = rt.Context(0)
     pset = rt.PathSet(ctx, ps)

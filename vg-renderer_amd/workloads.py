@@ -84,9 +84,10 @@ TIGER_PALETTE = [_color(*c) for c in [
     (153, 38, 0), (234, 142, 81), (76, 76, 76), (204, 204, 204)]]
 
 
-def tiger_paths(seed=2024, npaths=240):
+def tiger_paths(seed=2024, npaths=240, closed=True):
     """Seeded tiger-like drawing: returns (PathSetArrays, per-path op table).
-    ops[p] = dict(fill_color, stroke (bool), stroke_color, stroke_width)."""
+    ops[p] = dict(fill_color, stroke (bool), stroke_color, stroke_width). closed=False: the same outlines without their
+    pathClose (open sub-paths: the strokes get caps; the fills are the same polygons)."""
     rs = np.random.RandomState(seed)
     b = PathSetBuilder()
     ops = []
@@ -110,7 +111,8 @@ def tiger_paths(seed=2024, npaths=240):
                 c1 = p1 + (p2 - p0) / 6.0
                 c2 = p2 - (p3 - p1) / 6.0
                 b.cubic_to(c1[0], c1[1], c2[0], c2[1], p2[0], p2[1])
-            b.close()
+            if closed:
+                b.close()
         b.end_path()
         stroke = bool(rs.uniform() < (1.0 / 3.0))
         ops.append(dict(fill_color=TIGER_PALETTE[int(rs.randint(0, 16))], stroke=stroke,

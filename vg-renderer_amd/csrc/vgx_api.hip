@@ -98,7 +98,7 @@ struct vgx_ctx
 	// representatives, a per-instance table of output places, a per-workgroup table (instance, tile)
 	int optTmplClasses;
 	uint32_t tmplClasses;                // 1: every instance repeats the first period
-	bool tmplGeneral;                    // the template holds strokes other than closed Miter AA / Thin
+	uint32_t tmplGeneral;                // stroke styles of the template: 0 closed Miter AA / Thin only, 1 + open Miter with Butt / Square caps, 2 + general
 	uint64_t tmplNumWg, tmplNDraws;      // several classes: workgroups of one step; the batch size the per-instance table was built for
 	vgx_sizes tmplTotal;                 // sizes of the whole batch
 	DevBuf tmplHash, tmplInstCls, tmplClsRep, tmplCls, tmplIinfo, tmplWg;
@@ -1175,7 +1175,7 @@ static int runTmpl(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 	a.pos = out->pos; a.color = out->color; a.idx = out->idx; a.meshes_out = out->meshes;
 	a.caps = ctx->caps; a.caps.vertices = out->cap_vertices; a.caps.indices = out->cap_indices; a.caps.meshes = out->cap_meshes;
 	a.totals = (VgxTotals*)ctx->totals.p;
-	a.general = ctx->tmplGeneral ? 1u : 0u;
+	a.general = ctx->tmplGeneral;
 	if (ctx->tmplClasses > 1) {
 		a.iinfo = (const VgxTmplInst*)ctx->tmplIinfo.p; a.wg = (const uint2*)ctx->tmplWg.p; a.num_wg = ctx->tmplNumWg;
 		a.total = ctx->tmplTotal;
@@ -1341,10 +1341,22 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	const vgx_sizes all = ctx->hostTotals->sizes;
 	const bool general = ctx->hostTotals->has_general_stroke != 0;
 	const uint64_t M = all.num_meshes, E = all.num_elements, V = all.num_poly_vertices;
-	const uint32_t tileSize = (general && ctx->optTmplTile > VGX_TMPL_GENERAL_TILE) ? (uint32_t)VGX_TMPL_GENERAL_TILE : ctx->optTmplTile;
 	if ((st = ensure(ctx, ctx->tmplCls, ((size_t)T + 1) * sizeof(VgxTmplClass))) != VGX_OK) { return st; }
 	VgxTmplBuild b;
 	memset(&b, 0, sizeof(b));
+	// which stroke styles does the template hold? (decides the emit kernel and, with it, the tile size)
+	uint32_t styles = 0;
+	if (general) {
+		b.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; b.num_meshes = M; b.nclasses = T; b.cls = (VgxTmplClass*)ctx->tmplCls.p;
+		noteHip(ctx, hipMemsetAsync(ctx->tmplCls.p, 0, ((size_t)T + 1) * sizeof(VgxTmplClass), s));
+		vgx_launch_tmpl_styles(b, s);
+		HIPCHK(ctx, hipMemcpyAsync(&styles, &((VgxTmplClass*)ctx->tmplCls.p)[T].pad[0], sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+		HIPCHK(ctx, hipStreamSynchronize(s));
+	} else {
+		noteHip(ctx, hipMemsetAsync(ctx->tmplCls.p, 0, ((size_t)T + 1) * sizeof(VgxTmplClass), s));
+	}
+	const uint32_t kernelKind = (styles & 2u) ? 2u : ((styles & 1u) ? 1u : 0u);
+	const uint32_t tileSize = (kernelKind == 2u && ctx->optTmplTile > VGX_TMPL_GENERAL_TILE) ? (uint32_t)VGX_TMPL_GENERAL_TILE : ctx->optTmplTile;
 	b.draws = rdraws; b.poly = (const float2*)ctx->poly.p; b.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; b.mprep = (const VgxMeshPrep*)ctx->mprep.p; b.mtab = (const vgx_mesh*)ctx->mtab.p;
 	b.prefix_fill = (const uint64_t*)ctx->elemPrefix.p; b.prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
 	b.num_meshes = M; b.num_elems = E; b.tile = tileSize; b.period = (uint32_t)P; b.nclasses = T;
@@ -1421,7 +1433,7 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	ctx->tmplNumWg = numWg;
 	ctx->tmplNDraws = ndraws;
 	ctx->tmplTotal = z;
-	ctx->tmplGeneral = general;
+	ctx->tmplGeneral = kernelKind; // which instantiation of the emit kernel the template needs
 	ctx->tmplOn = true;
 	*out_sizes = z;
 	ctx->hostTotals->sizes = z; // what vgx_tessellate_emit checks the caller's capacities against

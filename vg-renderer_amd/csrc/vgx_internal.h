@@ -127,10 +127,11 @@ struct VgxTmplArgs // one step
 	const uint2* wg;             // [num_wg]
 	uint64_t num_wg;
 	vgx_sizes total;             // sizes of the whole batch
-	uint32_t general;            // the template holds strokes other than closed Miter AA / Thin: the general instantiation of k_tmpl_emit
+	uint32_t general;            // stroke styles of the template: 0 = closed Miter AA / Thin (k_tmpl_emit), 1 = + open Miter, Butt / Square caps (k_tmpl_emit_open), 2 = any (k_tmpl_emit_general)
 };
 void vgx_launch_tmpl_mtab(const VgxTmplArgs& a, vgx_mesh* mtab, VgxMeshDesc* mdesc, hipStream_t s); // assembly armed: the whole batch's mesh table + mesh -> draw
 void vgx_launch_tmpl_check(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, VgxTotals* totals, hipStream_t s); // after vgx_launch_inst_detect
+void vgx_launch_tmpl_styles(const VgxTmplBuild& b, hipStream_t s);  // stroke styles of the template -> b.cls[nclasses].pad[0] (zeroed by the caller), needs mdesc only
 void vgx_launch_tmpl_classes(const VgxTmplBuild& b, hipStream_t s); // fills b.cls from the representatives' count + emit results
 void vgx_launch_tmpl_build(const VgxTmplBuild& b, hipStream_t s);   // after vgx_launch_tmpl_classes
 void vgx_launch_tmpl_hash(const vgx_draw* draws, uint64_t ndraws, uint64_t period, unsigned long long* hashes, hipStream_t s); // hashes[instance], zeroed by the caller

@@ -145,7 +145,7 @@ __global__ void k_tmpl_classes(VgxTmplBuild B)
 		r.v0 = lo < M ? B.mtab[lo].first_vertex : B.num_vertices;
 		r.i0 = lo < M ? B.mtab[lo].first_index : B.num_indices;
 		r.tile0 = tile0;
-		r.pad[0] = 0; r.pad[1] = 0;
+		r.pad[0] = B.cls[c].pad[0]; r.pad[1] = 0; // (entry [nclasses]: the style bits k_tmpl_styles left there)
 		B.cls[c] = r;
 		if (c > 0) {
 			const uint64_t e = r.elem0 - B.cls[c - 1].elem0;
@@ -155,6 +155,20 @@ __global__ void k_tmpl_classes(VgxTmplBuild B)
 	}
 }
 __device__ __forceinline__ uint32_t tmpl_class_of_draw(const VgxTmplBuild& B, uint32_t draw) { return draw / B.period; }
+
+// which stroke styles the template holds -> cls[nclasses].pad[0]: bit 0 = open Miter strokes with Butt / Square caps, bit 1 = any other
+// stroke that is not closed Miter AA / Thin (the host zeroes the table first; k_tmpl_classes keeps the word)
+__device__ __forceinline__ bool tmpl_stroke_is_open_fast(uint32_t kindWord);
+__global__ __launch_bounds__(256) void k_tmpl_styles(VgxTmplBuild B)
+{
+	uint32_t f = 0;
+	for (uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; m < B.num_meshes; m += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t kw = B.mdesc[m].kind;
+		const uint32_t kind = VGX_MD_KIND(kw);
+		if (kind >= VGX_MESH_STROKE && !stroke_elem_is_simple(kind, VGX_MD_CLOSED(kw) != 0, VGX_MD_JOIN(kw))) { f |= tmpl_stroke_is_open_fast(kw) ? 1u : 2u; }
+	}
+	if (f) { atomicOr(&B.cls[B.nclasses].pad[0], f); }
+}
 
 __global__ __launch_bounds__(256) void k_tmpl_meshes(VgxTmplBuild B)
 {
@@ -665,13 +679,16 @@ __device__ __forceinline__ void tmpl_stroke_general(char* opos, char* ocol, char
 // edge directions (dir(jj) = direction of the edge jj -> jj + 1, cyclic) and vertices (vtx(jj), general strokes only).
 // PASS (GENERAL only): 0 = every element, 1 = everything but the general strokes, 2 = the general strokes only -- the tile loop runs
 // pass 1 unrolled and pass 2 as a rolled loop, so that the general element body (~120 VGPRs of branches) is in the kernel once.
-template<bool GENERAL, int PASS, class DF, class VF>
+// KIND: what stroke styles the template holds: 0 = closed Miter AA / Thin only (the headline's kernel), 1 = + open Miter strokes with
+// Butt / Square caps (tmpl_stroke_elem_open), 2 = + everything else without Round joins (the general body).
+template<int KIND, int PASS, class DF, class VF>
 __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color, float f0, float f1,
 	V2 p1, V2 d12, const DF& dir, const VF& vtx, float fringe, const vgx_draw* tdraw, const VgxTmplMesh* tmm)
 {
 	const uint32_t kind = VGX_MD_KIND(kindWord);
 	const uint32_t jp1 = j > 0 ? j - 1 : N - 1;
-	const bool openFast = GENERAL && kind >= VGX_MESH_STROKE && tmpl_stroke_is_open_fast(kindWord);
+	constexpr bool GENERAL = KIND == 2, OPEN = KIND >= 1;
+	const bool openFast = OPEN && kind >= VGX_MESH_STROKE && tmpl_stroke_is_open_fast(kindWord);
 	const bool general = GENERAL && kind >= VGX_MESH_STROKE && !openFast && !stroke_elem_is_simple(kind, VGX_MD_CLOSED(kindWord) != 0, VGX_MD_JOIN(kindWord));
 	if (GENERAL && ((PASS == 1 && general) || (PASS == 2 && !general))) { return; }
 	if (kind < VGX_MESH_STROKE) {
@@ -745,9 +762,10 @@ __global__ __launch_bounds__(256) void k_tmpl_mtab(VgxTmplArgs A, vgx_mesh* mtab
 // shape of k_stroke (128 VGPRs, 4-wave workgroups, 1024-element tiles: four workgroups per CU); k_tmpl_emit is VGX_TMPL_THREADS x VGX_TMPL_MAX_TILE.
 #define VGX_TMPL_G_THREADS 256
 #define VGX_TMPL_G_TILE 1024
-template<bool GENERAL, int THREADS, int MAXTILE>
+template<int KIND, int THREADS, int MAXTILE>
 __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 {
+	constexpr bool GENERAL = KIND == 2;
 	constexpr int CH = MAXTILE / THREADS;
 	__shared__ TmplDraw s_draw[VGX_TMPL_MAXM];
 	__shared__ TmplRec s_rec[VGX_TMPL_MAXM];
@@ -805,7 +823,7 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 			auto vtx = [&](uint32_t jj) { return tmpl_xf(xf, vt[jj]); };
 			if (j == 0 && A.meshes_out) { tmpl_mesh_out(A, P, er.mesh); }
 			const uint32_t ibase = meshBase ? meshBase[er.mesh] : 0u;
-			tmpl_elem_emit<GENERAL, 0>(O, j, tm.kind, N, tm.v_off, tm.i_off, ibase, kind < VGX_MESH_STROKE ? dr.fill_color : dr.stroke_color, f0, tm.f1, tmpl_xf(xf, vt[j]), dir(j), dir, vtx,
+			tmpl_elem_emit<KIND, 0>(O, j, tm.kind, N, tm.v_off, tm.i_off, ibase, kind < VGX_MESH_STROKE ? dr.fill_color : dr.stroke_color, f0, tm.f1, tmpl_xf(xf, vt[j]), dir(j), dir, vtx,
 				__uint_as_float(tm.pad[0]), P.tdraws + tm.drawk, A.tmesh + er.mesh);
 		}
 		return;
@@ -906,7 +924,7 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 			float fringe = 0.0f;
 			const vgx_draw* tdraw = P.tdraws;
 			if (GENERAL && decltype(passTag)::value == 2) { const VgxTmplMesh* tmm = A.tmesh + mesh; fringe = __uint_as_float(tmm->pad[0]); tdraw = P.tdraws + (dA + TMPL_REC_DK(rp)); }
-			tmpl_elem_emit<GENERAL, decltype(passTag)::value>(O, j, rp->kind & 0xFFFFu, N, rp->v_off, rp->i_off, rp->ibase, rp->color, rp->f0, rp->f1, pv, dv, dir, vtx, fringe, tdraw, A.tmesh + mesh);
+			tmpl_elem_emit<KIND, decltype(passTag)::value>(O, j, rp->kind & 0xFFFFu, N, rp->v_off, rp->i_off, rp->ibase, rp->color, rp->f0, rp->f1, pv, dv, dir, vtx, fringe, tdraw, A.tmesh + mesh);
 		}
 	};
 #pragma unroll
@@ -936,7 +954,12 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS, VGX_TMPL_MINWAVES) void k_tmpl_em
 __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(VgxTmplArgs A)
 #endif
 {
-	tmpl_emit_body<false, VGX_TMPL_THREADS, VGX_TMPL_MAX_TILE>(A);
+	tmpl_emit_body<0, VGX_TMPL_THREADS, VGX_TMPL_MAX_TILE>(A);
+}
+// the same shape with the open-stroke routine: templates whose only non-closed strokes are open Miter ones with Butt / Square caps
+__global__ __launch_bounds__(VGX_TMPL_THREADS) void k_tmpl_emit_open(VgxTmplArgs A)
+{
+	tmpl_emit_body<1, VGX_TMPL_THREADS, VGX_TMPL_MAX_TILE>(A);
 }
 // the instantiation with the general stroke body: at least 4 waves per SIMD (<= 128 VGPRs), as k_stroke
 #ifndef VGX_TMPL_G_MINWAVES
@@ -944,7 +967,7 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) VGX_TMPL_OCC void k_tmpl_emit(Vgx
 #endif
 __global__ __launch_bounds__(VGX_TMPL_G_THREADS, VGX_TMPL_G_MINWAVES) void k_tmpl_emit_general(VgxTmplArgs A)
 {
-	tmpl_emit_body<true, VGX_TMPL_G_THREADS, VGX_TMPL_G_TILE>(A);
+	tmpl_emit_body<2, VGX_TMPL_G_THREADS, VGX_TMPL_G_TILE>(A);
 }
 
 } // namespace
@@ -962,6 +985,12 @@ void vgx_launch_tmpl_hash(const vgx_draw* draws, uint64_t ndraws, uint64_t perio
 void vgx_launch_tmpl_check_cls(const vgx_draw* draws, uint64_t ndraws, uint64_t period, const uint32_t* inst_cls, const uint32_t* cls_rep, VgxTotals* totals, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_tmpl_check_cls, dim3(1024), dim3(256), 0, s, draws, ndraws, period, inst_cls, cls_rep, totals);
+}
+
+void vgx_launch_tmpl_styles(const VgxTmplBuild& b, hipStream_t s)
+{
+	const uint64_t gm = (b.num_meshes + 255) / 256;
+	if (b.num_meshes) { hipLaunchKernelGGL(k_tmpl_styles, dim3((unsigned)(gm > 1024 ? 1024 : gm)), dim3(256), 0, s, b); }
 }
 
 void vgx_launch_tmpl_classes(const VgxTmplBuild& b, hipStream_t s)
@@ -989,6 +1018,7 @@ void vgx_launch_tmpl_emit(const VgxTmplArgs& a, hipStream_t s)
 {
 	const uint64_t blocks = a.wg ? a.num_wg : a.ninst * a.tiles_per_inst; // the host checked < 2^31
 	if (!blocks) { return; }
-	if (a.general) { hipLaunchKernelGGL(k_tmpl_emit_general, dim3((unsigned)blocks), dim3(VGX_TMPL_G_THREADS), 0, s, a); }
+	if (a.general == 2) { hipLaunchKernelGGL(k_tmpl_emit_general, dim3((unsigned)blocks), dim3(VGX_TMPL_G_THREADS), 0, s, a); }
+	else if (a.general == 1) { hipLaunchKernelGGL(k_tmpl_emit_open, dim3((unsigned)blocks), dim3(VGX_TMPL_THREADS), 0, s, a); }
 	else { hipLaunchKernelGGL(k_tmpl_emit, dim3((unsigned)blocks), dim3(VGX_TMPL_THREADS), 0, s, a); }
 }

@@ -797,7 +797,7 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 	const uint32_t dA = tl.draw0, nd = tl.ndraws;
 	const vgx_draw* idraws = A.draws + inst * A.period;
 	const VgxTmplElem* telem = A.telem + x0;
-	const uint32_t* meshBase = A.mesh_base ? A.mesh_base + (P.m - P.cmesh0) : nullptr; // indexed by template mesh number
+	const uint32_t* meshBase = A.mesh_base ? A.mesh_base + P.m : nullptr; // the instance's meshes: indexed by (template mesh number - P.cmesh0)
 	TmplOut O;
 	O.pos = (char*)(A.pos + 2 * P.v);
 	O.col = (char*)(A.color + P.v);
@@ -822,7 +822,7 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 			auto dir = [&](uint32_t jj) { return v2dir(tmpl_xf(xf, vt[jj]), tmpl_xf(xf, vt[jj + 1 < N ? jj + 1 : 0u])); };
 			auto vtx = [&](uint32_t jj) { return tmpl_xf(xf, vt[jj]); };
 			if (j == 0 && A.meshes_out) { tmpl_mesh_out(A, P, er.mesh); }
-			const uint32_t ibase = meshBase ? meshBase[er.mesh] : 0u;
+			const uint32_t ibase = meshBase ? meshBase[er.mesh - P.cmesh0] : 0u;
 			tmpl_elem_emit<KIND, 0>(O, j, tm.kind, N, tm.v_off, tm.i_off, ibase, kind < VGX_MESH_STROKE ? dr.fill_color : dr.stroke_color, f0, tm.f1, tmpl_xf(xf, vt[j]), dir(j), dir, vtx,
 				__uint_as_float(tm.pad[0]), P.tdraws + tm.drawk, A.tmesh + er.mesh);
 		}
@@ -848,7 +848,7 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 	uint32_t ibase = 0;
 	if (tid < nm) {
 		tm = A.tmesh[mA + tid];
-		if (meshBase) { ibase = meshBase[mA + tid]; }
+		if (meshBase) { ibase = meshBase[mA - P.cmesh0 + tid]; }
 	}
 	if (tid < nd) { s_draw[tid] = tmpl_load_draw(A, idraws, P.tdraws, dA + tid); }
 	if (tid == 0) { s_status = A.totals->status; } // an earlier workgroup may have found the batch stale; ONE value for the whole workgroup (the exit below must be uniform)

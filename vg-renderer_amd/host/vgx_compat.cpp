@@ -63,15 +63,19 @@ int g_device = 0;
 enum { kBackendAuto = 0, kBackendHost = 1, kBackendDevice = 2 };
 int g_backend = -1;          // -1: not read from the environment yet
 uint32_t g_deviceMin = 16384;
+bool g_envRead = false;
 int backend()
 {
-	if (g_backend < 0) {
-		const char* e = getenv("VGX_COMPAT_BACKEND");
-		g_backend = (e && !strcmp(e, "host")) ? kBackendHost : ((e && !strcmp(e, "device")) ? kBackendDevice : kBackendAuto);
+	if (!g_envRead) { // the environment once; vgxCompatSetBackend overrides the backend, not the threshold
+		g_envRead = true;
 		const char* m = getenv("VGX_COMPAT_DEVICE_MIN");
 		if (m && *m) { g_deviceMin = (uint32_t)strtoul(m, nullptr, 10); }
+		if (g_backend < 0) {
+			const char* e = getenv("VGX_COMPAT_BACKEND");
+			g_backend = (e && !strcmp(e, "host")) ? kBackendHost : ((e && !strcmp(e, "device")) ? kBackendDevice : kBackendAuto);
+		}
 	}
-	return g_backend;
+	return g_backend < 0 ? (int)kBackendAuto : g_backend;
 }
 bool onDevice(uint32_t numVertices) { const int b = backend(); return b == kBackendDevice || (b == kBackendAuto && numVertices >= g_deviceMin); }
 void* bxRealloc(void* user, void* ptr, size_t bytes) // vgxh::ReallocFn over the caller's bx::AllocatorI (nullptr: the C heap)

@@ -364,9 +364,26 @@ __device__ __forceinline__ void tmpl_fill_elem(const TmplOut& O, uint32_t kindWo
 		const uint32_t gv = vOff + 2u * j;
 		PosPair pp; pp.x0 = vin.x; pp.y0 = vin.y; pp.x1 = vout.x; pp.y1 = vout.y;
 		ColPair cp; cp.c0 = color; cp.c1 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
+		if (VGX_MD_SSE_ORDER(kindWord) == 0) {
+			// Scalar index order (stroker.cpp:769-795): [N - 2 fan triangles (0, 2t + 2, 2t + 4)][N fringe quads, edge e:
+			// (2e, 2e + 1, nextOuter) (2e, nextOuter, nextInner)]. Corner j writes ITS OWN fan triangle (j < N - 2) and the quad of its
+			// own edge -- two short runs per lane, both lane-consecutive in memory, and a dozen integer operations, where a
+			// contiguous nine-index slice per corner (fill_idx9, what k_fill writes) costs ~75: the same bytes at the same places.
+			const uint32_t b2 = 2u * j + ibase; // + ibase: command relative when assembly is armed (uint16 wrap = the reference's cast, vg_util.cpp:447)
+			const uint32_t ni = (j + 1 == N) ? ibase : b2 + 2u, no = ni + 1u;
+			Idx6 quad; quad.a = (b2 & 0xFFFFu) | ((b2 + 1u) << 16); quad.b = (no & 0xFFFFu) | (b2 << 16); quad.c = (no & 0xFFFFu) | (ni << 16);
+			*(PosPair*)(O.pos + gv * 8u) = pp;
+			*(ColPair*)(O.col + gv * 4u) = cp;
+			TMPL_IDX_ON *(Idx6*)(O.idx + (iOff + 3u * (N - 2u) + 6u * j) * 2u) = quad;
+			if (j + 2 < N) {
+				Idx3 fan; fan.a = (ibase & 0xFFFFu) | ((b2 + 2u) << 16); fan.b = (uint16_t)(b2 + 4u);
+				TMPL_IDX_ON *(Idx3*)(O.idx + (iOff + 3u * j) * 2u) = fan;
+			}
+			return;
+		}
 		const uint32_t ib = (iOff + 9u * j) * 2u;
 		uint32_t val[9];
-		fill_idx9(j, N, ibase, VGX_MD_SSE_ORDER(kindWord) != 0, val); // + ibase: command relative when assembly is armed (uint16 wrap = the reference's cast, vg_util.cpp:447)
+		fill_idx9(j, N, ibase, true, val); // VGX_FILL_INDEX_ORDER_SSE: the quad of edge j, then fan triangle j -- contiguous per corner by itself
 		VGX_ST_GUARD(cp.c0 ^ __float_as_uint(pp.x0)) {
 		*(PosPair*)(O.pos + gv * 8u) = pp;
 		*(ColPair*)(O.col + gv * 4u) = cp;

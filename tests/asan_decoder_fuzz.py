@@ -1,11 +1,12 @@
 """Memory-safety fuzz of vgx_cmdlist_decode (host code, parses bytes from outside): the decoder compiled with g++
 -fsanitize=address,undefined and fed valid and malformed streams (nested lists included). Not collected by pytest:
     bash tests/asan_decoder_fuzz.sh
-Round 3: 3 120 decodes, no sanitizer report."""
+Round 3: 3 120 decodes, no sanitizer report; round 4: + streams with IndexedTriList commands, same."""
 import sys, importlib, ctypes as C, numpy as np
 sys.path[:0]=['/root/repo','/root/repo/oracle','/root/repo/tests']
 import pyvgref as R, frameref as F, cmdlist_util as cu
 import test_cmdlist_ref as T
+import trilist_frame as TF
 rt = importlib.import_module("vg-renderer_amd.runtime")
 asan = C.CDLL("/tmp/asan/libcl_asan.so")
 asan.vgx_cmdlist_decode.restype = C.c_int
@@ -22,7 +23,10 @@ for seed in range(120):
         lists = {}
         for cs, cf in children:
             h, b = F.record(rc, cs, cf); lists[h] = (b, cf)
-        h, data = F.record(rc, T.s_random(80000 + seed, nchildren=nchild))
+        for _ in range(6):
+            rc.create_image(8, 8)
+        # every third stream: user meshes (IndexedTriList payloads: counts, UV / colour / index arrays) between the paths
+        h, data = F.record(rc, TF.s_random(80000 + seed) if (seed % 6 == 0) else T.s_random(80000 + seed, nchildren=nchild))
     # the valid stream first (sanitizer sees the normal paths), then mutations
     r = cu.decode(FakeRt, data, lists=lists); codes[r[0]] = codes.get(r[0], 0) + 1
     for trial in range(25):

@@ -10,21 +10,20 @@
 // instance is transformPos2D of every polyline vertex (vg_util.h:24-28) and everything the stroker derives from the
 // transformed vertices (directions, extrusion vectors, inner side of every join, fill orientation).
 //
-// So vgx_tessellate_count flattens the FIRST period of such a batch once, with the ordinary two-phase kernels and
-// apply_transform = 0, and keeps the result as a template (a few hundred KB, L2 resident): local polyline, per-mesh
-// records with closed-form output offsets inside one instance, and an element table in processing order. One step of
-// vgx_tessellate is then
-//   k_tmpl_verify   every draw record against its image in the saved first period (fields above, bit patterns) + the
-//                   finiteness checks of the ordinary path; a mismatch ends the call with VGX_E_STALE
-//   k_tmpl_emit     one lane per ELEMENT (polyline vertex of one mesh of one instance): three template vertices from
-//                   L2, transformPos2D with the instance's matrix in registers, the stroker's per-element arithmetic
-//                   (strokerConvexFillAA stroker.cpp:713-807; closed Miter polylineStrokeAA / AAThin :1524-1579,
-//                   1970-1984, 2060-2110, 2295-2306), stores at closed-form addresses -- no polyline heap, no scans, no
-//                   mesh descriptors in HBM. The elements of an instance are processed in tiles; inside a tile the fill
-//                   elements come first, then the stroke elements, so a wave's chunks are (almost) pure and the two
-//                   mesh kinds of a draw, which interleave in the output streams, are written by the same wave within
-//                   a few chunks (the hole pattern DESIGN.md section 9 measured at 2.4 TB/s when two kernels wrote them
-//                   milliseconds apart).
+// So vgx_tessellate_count flattens the FIRST period of such a batch once -- or, when the instances come in a few flavours
+// ("classes": the same drawing at a handful of scales), one representative per class --, with the ordinary two-phase kernels
+// and apply_transform = 0, and keeps the result as a template (a few hundred KB per class, L2 resident): local polyline,
+// per-mesh records with closed-form output offsets inside one instance, and an element table in processing order. One step of
+// vgx_tessellate is then ONE kernel (k_tmpl_emit; k_tmpl_emit_open / k_tmpl_emit_general when the template holds open Miter
+// strokes / any other style without Round joins): one workgroup per TILE of one instance's elements -- the instance's draw
+// records verified against the saved ones (a mismatch ends the call with VGX_E_STALE; the finiteness checks of the ordinary
+// path), template vertices through transformPos2D with the instance's matrix ONCE (staged in LDS), edge directions once
+// (staged in LDS), the stroker's per-element arithmetic (strokerConvexFillAA stroker.cpp:713-807; closed Miter polylineStrokeAA
+// / AAThin :1524-1579, 1970-1984, 2060-2110, 2295-2306; open and general strokes through tmpl_stroke_elem_open / the element
+// code of vgx_elem.h), stores at closed-form addresses -- no polyline heap, no scans, no mesh descriptors in HBM. Inside a tile
+// the fill elements come first, then the stroke elements, so a wave's chunks are (almost) pure and the two mesh kinds of a
+// draw, which interleave in the output streams, are written by the same workgroup within microseconds (the hole pattern
+// DESIGN.md section 9 measured at 2.4 TB/s when two kernels wrote them milliseconds apart).
 // Results are identical to the ordinary path's by construction and by test (tests/test_gpu_tmpl.py: VGX_TMPL=0 vs 1
 // byte for byte, both against the reference).
 #include <stddef.h>

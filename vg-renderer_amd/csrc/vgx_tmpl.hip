@@ -408,11 +408,11 @@ __device__ __forceinline__ void tmpl_fill_elem(const TmplOut& O, uint32_t kindWo
 }
 
 // One element of a CLOSED stroke with MITER joins, AA (4 rails) or Thin (3 rails): stroke_chunk_simple (vgx_elem.h) without
-// its neighbour lanes. dPrev2 = direction of the edge in front of the previous vertex (the previous join's inner side is
-// recomputed from it), dFirst = direction of edge 0 (join 0's inner side, for the closing bridge of the last element): same
+// its neighbour lanes. dPrev2 = direction of the edge in front of the (cyclically) previous vertex (that join's inner side is
+// recomputed from it): same
 // inputs, same arithmetic, same bits as the values the sequential stroker carries along (stroker.cpp:1401-1410).
 __device__ __forceinline__ void tmpl_stroke_elem(const TmplOut& O, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color, float hsw, float hswAA,
-	uint32_t j, V2 p1, V2 dPrev2, V2 dPrev, V2 d12, V2 dFirst)
+	uint32_t j, V2 p1, V2 dPrev2, V2 dPrev, V2 d12)
 {
 	const bool thin = VGX_MD_KIND(kindWord) == VGX_MESH_STROKE_AA_THIN;
 	const uint32_t R = thin ? 3u : 4u;
@@ -456,12 +456,18 @@ __device__ __forceinline__ void tmpl_stroke_elem(const TmplOut& O, uint32_t kind
 		*(ColPair*)(pc + 8) = d;
 		}
 	}
-	if (j > 0) { // the bridge from the previous join (stroker.cpp:1557-1564, 1714-1721; thin :2093-2098, 2175-2180)
+	{
+		// The bridge that ENDS at this join: from join j - 1 (stroker.cpp:1557-1564, 1714-1721; thin :2093-2098, 2175-2180) or,
+		// for join 0, from the LAST join -- the closing bridge, which the reference appends behind the last join's own bridge
+		// (:1970-1984, 2295-2306: prevSegment = the last join's rails, first = join 0's: the same six triangles as any bridge).
+		// Every element so writes exactly one bridge (element 0 at the END of the mesh's index range) and recomputes exactly
+		// one neighbouring join's inner side, instead of the last element doing two of each.
+		const uint32_t jm = j > 0 ? j - 1 : N - 1;
 		const VgxJoin jp = vgx_join_dirs(dPrev2, dPrev, sideWidth);
-		const uint32_t pb = R * (j - 1) + ibase, ptop = pb + R - 1;
+		const uint32_t pb = R * jm + ibase, ptop = pb + R - 1;
 		const Rails p = thin ? (jp.leftInner ? rails(pb, pb + 1, pb + 2, 0) : rails(ptop, pb + 1, pb, 0))
 		                     : (jp.leftInner ? rails(pb, pb + 1, pb + 2, pb + 3) : rails(ptop, pb + 2, pb + 1, pb));
-		char* pi = O.idx + (iOff + bridgeIdx * (j - 1)) * 2u;
+		char* pi = O.idx + (iOff + bridgeIdx * jm) * 2u;
 		Idx6 t0; t0.a = (p.a & 0xFFFFu) | (p.b << 16); t0.b = (mine.b & 0xFFFFu) | (p.a << 16); t0.c = (mine.b & 0xFFFFu) | (mine.a << 16);
 		Idx6 t1; t1.a = (p.b & 0xFFFFu) | (p.c << 16); t1.b = (mine.c & 0xFFFFu) | (p.b << 16); t1.c = (mine.c & 0xFFFFu) | (mine.b << 16);
 		VGX_ST_GUARD(t0.a ^ t1.c) TMPL_IDX_ON {
@@ -469,22 +475,6 @@ __device__ __forceinline__ void tmpl_stroke_elem(const TmplOut& O, uint32_t kind
 		*(Idx6*)(pi + 12) = t1;
 		if (!thin) {
 			Idx6 t2; t2.a = (p.c & 0xFFFFu) | (p.d << 16); t2.b = (mine.d & 0xFFFFu) | (p.c << 16); t2.c = (mine.d & 0xFFFFu) | (mine.c << 16);
-			*(Idx6*)(pi + 24) = t2;
-		}
-		}
-	}
-	if (j + 1 == N) { // closing bridge to join 0 (:1970-1984, 2295-2306); d12 = vec2Dir(last vertex, vertex 0)
-		const VgxJoin j0 = vgx_join_dirs(d12, dFirst, sideWidth);
-		const uint32_t z = ibase;
-		const Rails f = thin ? (j0.leftInner ? rails(z, z + 1, z + 2, 0) : rails(z + 2, z + 1, z, 0)) : (j0.leftInner ? rails(z, z + 1, z + 2, z + 3) : rails(z + 3, z + 2, z + 1, z));
-		char* pi = O.idx + (iOff + bridgeIdx * (N - 1)) * 2u;
-		Idx6 t0; t0.a = (mine.a & 0xFFFFu) | (mine.b << 16); t0.b = (f.b & 0xFFFFu) | (mine.a << 16); t0.c = (f.b & 0xFFFFu) | (f.a << 16);
-		Idx6 t1; t1.a = (mine.b & 0xFFFFu) | (mine.c << 16); t1.b = (f.c & 0xFFFFu) | (mine.b << 16); t1.c = (f.c & 0xFFFFu) | (f.b << 16);
-		VGX_ST_GUARD(t0.a ^ t1.c) TMPL_IDX_ON {
-		*(Idx6*)pi = t0;
-		*(Idx6*)(pi + 12) = t1;
-		if (!thin) {
-			Idx6 t2; t2.a = (mine.c & 0xFFFFu) | (mine.d << 16); t2.b = (f.d & 0xFFFFu) | (mine.c << 16); t2.c = (f.d & 0xFFFFu) | (f.c << 16);
 			*(Idx6*)(pi + 24) = t2;
 		}
 		}
@@ -725,10 +715,8 @@ __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uin
 		tmpl_stroke_elem_open(O, kindWord, N, vOff, iOff, ibase, color, f0, f1, tmm, j, p1, dPrev2, dPrev, d12);
 	} else {
 		const V2 dPrev = dir(jp1);
-		V2 dPrev2 = dPrev, dFirst = dPrev;
-		if (j > 0) { dPrev2 = dir(jp1 > 0 ? jp1 - 1 : N - 1); }
-		if (j + 1 == N) { dFirst = dir(0u); }
-		tmpl_stroke_elem(O, kindWord, N, vOff, iOff, ibase, color, f0, f1, j, p1, dPrev2, dPrev, d12, dFirst);
+		const V2 dPrev2 = dir(jp1 > 0 ? jp1 - 1 : N - 1); // cyclic: element 0's previous join is the last one
+		tmpl_stroke_elem(O, kindWord, N, vOff, iOff, ibase, color, f0, f1, j, p1, dPrev2, dPrev, d12);
 	}
 }
 

@@ -168,6 +168,7 @@ WORKLOADS = {
     "round10k": "BASELINE configs[3]: 10k polylines x 1k segments, Round joins + Round caps",
     "tiger10k_varied": "Tiger x10k at 7 scales (0.5 .. 3.5; 18 distinct avgScale values after rounding) under rotations: template mode with one template per class",
     "tiger10k_open": "Tiger x10k with every sub-path left open (no pathClose): open Miter strokes with Butt caps, template mode's general kernel",
+    "tiger10k_bevel": "Tiger x10k with Bevel joins on the strokes: template mode's general element body (k_tmpl_emit_general)",
     "tigerspec10k": "SURVEY 8(d) config 3 as specified: 240 paths x (1-4 sub-paths x 8-60 cubics), x10k instances",
     # honesty configs: the headline batch WITHOUT the template mode (every instance flattened, polyline through HBM), and without
     # any instancing shortcut (what a batch of 2.4 M unrelated draws costs)
@@ -196,6 +197,11 @@ def make_workload(wl, name, instances, rank):
         d = wl.tiger_draws(ops, instances, first_instance=rank * instances)
         return ps, d, ("the tiger-like drawing (seed 2024) with open sub-paths x %d instances per GPU: convexFillAA + polylineStrokeAA/AAThin "
                        "with Butt caps and Miter joins on 1/3 of the paths" % instances), "tessellate"
+    if name == "tiger10k_bevel":
+        ps, ops = wl.tiger_paths()
+        d = wl.tiger_draws(ops, instances, first_instance=rank * instances, join=2)  # vg::LineJoin::Bevel
+        return ps, d, ("the tiger-like drawing (seed 2024) x %d instances per GPU: convexFillAA + polylineStrokeAA/AAThin with Bevel joins "
+                       "on 1/3 of the paths" % instances), "tessellate"
     if name == "tigerspec10k":
         ps, ops = wl.tiger_spec_paths()
         d = wl.tiger_draws(ops, instances, first_instance=rank * instances)

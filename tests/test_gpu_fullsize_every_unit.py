@@ -56,14 +56,14 @@ def _reference_rows(which, units):
     return np.concatenate(parts)
 
 
-@pytest.mark.parametrize("which", ["tiger", "tigerspec", "tigeropen"])
+@pytest.mark.parametrize("which", ["tiger", "tigerspec", "tigeropen", "tigerbevel"])
 def test_every_instance_of_tiger_x10k_matches_the_reference(rt, wl, which):
     """BASELINE configs[2] (and the SURVEY 8(d) drawing as specified, bench.py's tigerspec10k) at full size through the entry
     point bench.py times; digests of positions / colours / indices of all 10 000 instances against the reference's."""
     import torch
     K = 10000
-    ps, ops = wl.tiger_spec_paths() if which == "tigerspec" else wl.tiger_paths(closed=which == "tiger")  # tigeropen: open strokes (general kernel)
-    d = wl.tiger_draws(ops, K)
+    ps, ops = wl.tiger_spec_paths() if which == "tigerspec" else wl.tiger_paths(closed=which != "tigeropen")  # tigeropen: open strokes (k_tmpl_emit_open)
+    d = wl.tiger_draws(ops, K, join=2 if which == "tigerbevel" else 0)  # tigerbevel: Bevel joins (the general element body, k_tmpl_emit_general)
     ctx = rt.Context(0)
     pset = rt.PathSet(ctx, ps)
     dd = rt.upload_draws(d)

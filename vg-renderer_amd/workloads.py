@@ -121,16 +121,16 @@ def tiger_paths(seed=2024, npaths=240, closed=True):
     return b.arrays(), ops
 
 
-def tiger_draws(ops, instances, first_instance=0):
+def tiger_draws(ops, instances, first_instance=0, join=capi.JOIN_MITER):
     """Draw records for `instances` copies of the drawing; instance i is translated by
-    (37*(i%100), 41*(i//100)) at scale 1 (SURVEY 8d config 3). Draw order = instance-major."""
+    (37*(i%100), 41*(i//100)) at scale 1 (SURVEY 8d config 3). Draw order = instance-major. join: the strokes' LineJoin."""
     npaths = len(ops)
     one = make_draws(npaths)
     one["path"] = np.arange(npaths, dtype=np.uint32)
     for p, op in enumerate(ops):
         set_fill(one, p, op["fill_color"], aa=True)
         if op["stroke"]:
-            set_stroke(one, p, op["stroke_color"], op["stroke_width"], capi.CAP_BUTT, capi.JOIN_MITER, aa=True)
+            set_stroke(one, p, op["stroke_color"], op["stroke_width"], capi.CAP_BUTT, join, aa=True)
     d = np.tile(one, instances)
     inst = np.repeat(np.arange(first_instance, first_instance + instances, dtype=np.int64), npaths)
     d["mtx"][:, 4] = (37.0 * (inst % 100)).astype(np.float32)

@@ -86,6 +86,9 @@ def main():
     elif which == "varied":       # Tiger x10k, every instance at its own scale (0.5 .. 3.5) and rotation
         ps, ops = wl.tiger_paths()
         draws = wl.tiger_varied_draws(ops, 10000)
+    elif which == "bevel":        # Tiger x10k with Bevel joins: the general element body of template mode
+        ps, ops = wl.tiger_paths()
+        draws = wl.tiger_draws(ops, 10000, join=2)
     elif which == "fillonly":     # Tiger x10k without its strokes: the fill meshes' output streams have no gaps
         ps, ops = wl.tiger_paths()
         draws = wl.tiger_draws(ops, 10000)

@@ -137,7 +137,9 @@ void vgx_launch_tmpl_build(const VgxTmplBuild& b, hipStream_t s);   // after vgx
 void vgx_launch_tmpl_hash(const vgx_draw* draws, uint64_t ndraws, uint64_t period, unsigned long long* hashes, hipStream_t s); // hashes[instance], zeroed by the caller
 void vgx_launch_tmpl_check_cls(const vgx_draw* draws, uint64_t ndraws, uint64_t period, const uint32_t* inst_cls, const uint32_t* cls_rep, VgxTotals* totals, hipStream_t s);
 void vgx_launch_tmpl_emit(const VgxTmplArgs& a, hipStream_t s);
-#define VGX_TMPL_GENERAL_TILE 1024 /* tile size of templates that hold general strokes (the LDS stages of that instantiation of k_tmpl_emit) */
+#ifndef VGX_TMPL_GENERAL_TILE
+#define VGX_TMPL_GENERAL_TILE 2048 /* tile size of templates that hold general strokes (the LDS stages of k_tmpl_emit_general) */
+#endif
 
 // merging two mesh sequences of a frame (vgx_merge.hip)
 struct VgxMergeArgs

@@ -762,10 +762,12 @@ __global__ __launch_bounds__(256) void k_tmpl_mtab(VgxTmplArgs A, vgx_mesh* mtab
 #endif
 // GENERAL: the template holds stroke meshes that are not closed Miter AA / Thin (open strokes, Bevel joins, non-AA): those take
 // tmpl_stroke_general; the instantiation without them is the headline's kernel, unchanged.
-// THREADS x MAXTILE: the workgroup shape (MAXTILE / THREADS elements per thread). The general instantiation (k_tmpl_emit_general) has the
-// shape of k_stroke (128 VGPRs, 4-wave workgroups, 1024-element tiles: four workgroups per CU); k_tmpl_emit is VGX_TMPL_THREADS x VGX_TMPL_MAX_TILE.
+// THREADS x MAXTILE: the workgroup shape (MAXTILE / THREADS elements per thread). The general instantiation (k_tmpl_emit_general) runs
+// 4-wave workgroups over 2048-element tiles; k_tmpl_emit / k_tmpl_emit_open are VGX_TMPL_THREADS x VGX_TMPL_MAX_TILE.
+#ifndef VGX_TMPL_G_THREADS
 #define VGX_TMPL_G_THREADS 256
-#define VGX_TMPL_G_TILE 1024
+#endif
+#define VGX_TMPL_G_TILE VGX_TMPL_GENERAL_TILE
 template<int KIND, int THREADS, int MAXTILE>
 __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 {
@@ -965,9 +967,10 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) void k_tmpl_emit_open(VgxTmplArgs
 {
 	tmpl_emit_body<1, VGX_TMPL_THREADS, VGX_TMPL_MAX_TILE>(A);
 }
-// the instantiation with the general stroke body: at least 4 waves per SIMD (<= 128 VGPRs), as k_stroke
+// the instantiation with the general stroke body: 256 threads x 2048-element tiles (eight elements per thread, ~145 VGPRs, three
+// waves per SIMD): same-box A/B on the Tiger with Bevel joins 3.53 ms against 4.20 (256 x 1024), 3.80 (512 x 2048), 4.85 (512 x 1024)
 #ifndef VGX_TMPL_G_MINWAVES
-#define VGX_TMPL_G_MINWAVES 4
+#define VGX_TMPL_G_MINWAVES 3
 #endif
 __global__ __launch_bounds__(VGX_TMPL_G_THREADS, VGX_TMPL_G_MINWAVES) void k_tmpl_emit_general(VgxTmplArgs A)
 {

@@ -279,7 +279,12 @@ VGX_EL Elem elem_geometry(const MeshCtxT<VS>& m, V2 p1, V2 dPrev, V2 d12)
 		return e;
 	}
 	e.et = ET_JOIN;
-	const float sideWidth = (m.kind == VGX_MESH_STROKE) ? m.hsw : (m.kind == VGX_MESH_STROKE_AA ? m.hswAA : m.fringe);
+	// (three selects on VALUES: `kind == A ? m.hsw : (kind == B ? m.hswAA : m.fringe)` was compiled into an indexed load from the
+	// context structure, which then had to live in scratch memory wherever it was built field by field)
+	const float wS = m.hsw, wA = m.hswAA, wT = m.fringe;
+	float sideWidth = wT;
+	sideWidth = m.kind == VGX_MESH_STROKE_AA ? wA : sideWidth;
+	sideWidth = m.kind == VGX_MESH_STROKE ? wS : sideWidth;
 	const VgxJoin jn = vgx_join_dirs(dPrev, d12, sideWidth);
 	e.d01 = jn.d01; e.d12 = jn.d12; e.v = jn.v; e.leftInner = jn.leftInner;
 	e.hasConnect = !(m.closed && j == 0);

@@ -626,7 +626,11 @@ __device__ __forceinline__ void tmpl_mesh_out(const VgxTmplArgs& A, const TmplPl
 // code of vgx_elem.h (elem_geometry / elem_emit, what k_stroke runs) on the staged vertices, with what the sequential stroker
 // carries from element to element in closed form: the element's first vertex / index inside its mesh, and the previous
 // element's exit rails recomputed from ITS geometry (same inputs, same bits).
-struct TmplVtx01 { V2 v0, v1; __device__ __forceinline__ V2 ld(uint32_t i) const { return i == 0 ? v0 : v1; } }; // elem_emit reads vertices 0 and 1 only (closing bridge)
+struct TmplVtx01 // elem_emit reads vertices 0 and 1 only (closing bridge); scalar members + selects: a `cond ? v0 : v1` of two V2 members became an
+{                // indexed load and put the whole mesh context into scratch memory (1.9 GB read + 4.9 GB written per step on the Tiger with Bevel joins)
+	float x0, y0, x1, y1;
+	__device__ __forceinline__ V2 ld(uint32_t i) const { const bool z = i == 0; return v2(z ? x0 : x1, z ? y0 : y1); }
+};
 
 // vertices / own indices of a cap and of a join of this stroke flavour (elem_geometry's counts, vgx_elem.h), H = numPointsHalfCircle
 __device__ __forceinline__ void tmpl_stroke_counts(uint32_t kind, uint32_t cap, uint32_t join, uint32_t H, uint32_t* capNv, uint32_t* capNiFirst, uint32_t* joinNv, uint32_t* joinNi, uint32_t* bridge)
@@ -656,7 +660,7 @@ __device__ __forceinline__ void tmpl_stroke_general(char* opos, char* ocol, char
 {
 	MeshCtxT<TmplVtx01> mc;
 	mc.kind = VGX_MD_KIND(kindWord); mc.closed = VGX_MD_CLOSED(kindWord) != 0; mc.cap = VGX_MD_CAP(kindWord); mc.join = VGX_MD_JOIN(kindWord);
-	mc.N = N; mc.j = j; mc.hsw = hsw; mc.hswAA = hswAA; mc.fringe = fringe; mc.dr = tdraw; mc.vtx.v0 = v0; mc.vtx.v1 = v1;
+	mc.N = N; mc.j = j; mc.hsw = hsw; mc.hswAA = hswAA; mc.fringe = fringe; mc.dr = tdraw; mc.vtx.x0 = v0.x; mc.vtx.y0 = v0.y; mc.vtx.x1 = v1.x; mc.vtx.y1 = v1.y;
 	uint32_t H = 2;
 	if (!mc.closed && mc.cap == VGX_CAP_ROUND && mc.kind != VGX_MESH_STROKE_AA_THIN) { H = vgx_half_circle_points(mesh_da(mc)); }
 	uint32_t capNv, capNi, joinNv, joinNi, bridge;
@@ -667,10 +671,10 @@ __device__ __forceinline__ void tmpl_stroke_general(char* opos, char* ocol, char
 	const Elem e = elem_geometry(mc, p1, dPrev, d12);
 	Rails prev = rails(0, 0, 0, 0);
 	if (e.hasConnect) { // the previous element's exit rails (prevSegment*ID, stroker.cpp:1401-1410), from its own geometry
-		MeshCtxT<TmplVtx01> mp = mc;
-		mp.j = j - 1;
-		const Elem ep = elem_geometry(mp, pPrev, dPrev2, dPrev);
-		prev = elem_exit_rails(mp, ep, vbase(j - 1));
+		mc.j = j - 1;
+		const Elem ep = elem_geometry(mc, pPrev, dPrev2, dPrev);
+		prev = elem_exit_rails(mc, ep, vbase(j - 1));
+		mc.j = j;
 	}
 	StrokeWriter w;
 	w.pos = (float*)(opos + (size_t)vOff * 8u); w.col = (uint32_t*)(ocol + (size_t)vOff * 4u); w.idx = (uint16_t*)(oidx + (size_t)iOff * 2u);

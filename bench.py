@@ -774,6 +774,22 @@ def main():
                            "cpu_baseline": other_cpu.get(name)}
             r2["pset"].close()
             del r2, ps2, d2
+            if name == "cubics1m":
+                # "also run boxes 10 / 100 / 10 000 to sweep the output size" (coordinates uniform in
+                # [0, box): ~5 / ~14 / ~145 segments per cubic against ~45 at box 1000). Parity at every box:
+                # tests/test_gpu_fullsize_every_unit.py::test_cubics_box_sweep_matches_the_reference
+                sweep = {}
+                for box in (10.0, 100.0, 10000.0):
+                    ps3, d3 = wl.random_cubics(1000000, seed=1234, box=box)
+                    r3 = run_config(rt, torch, ctx2, local_rank, name, ps3, d3, "flatten", 3, 1, barrier)
+                    ms3 = r3["dt"] / 3 * 1e3
+                    sweep["%g" % box] = {"ms_per_step": round(ms3, 3), "poly_verts": r3["units"], "segments_per_cubic": round(r3["units"] / 1e6 - 1.0, 2),
+                                         "value": round(r3["units"] / (ms3 * 1e-3) / 1e6, 2), "unit": "M polyline vertices/s",
+                                         "stage_ms": {k: round(v, 3) for k, v in r3["stage"].items()}}
+                    r3["pset"].close()
+                    del r3, ps3, d3
+                    torch.cuda.empty_cache()
+                other[name]["box_sweep"] = sweep
             if ctx2 is not ctx:
                 ctx2.close()
             torch.cuda.empty_cache()

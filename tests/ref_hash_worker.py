@@ -5,7 +5,8 @@ static, src/path.cpp:91).
   python tests/ref_hash_worker.py tiger|tigerspec|tigeropen|tigerbevel <first instance> <count> out.npy     rows: [count, 3, 4] (pos, colour, idx)
   python tests/ref_hash_worker.py varied <first instance> <count> out.npy               rows: [count, 3, 4] + sizes [count, 2] (instances of different sizes)
   python tests/ref_hash_worker.py round <first polyline> <count> out.npy               rows: [count, 3, 4] + sizes [count, 2]
-  python tests/ref_hash_worker.py cubics <first path> <count> out.npy                  rows: [count, 1, 4] + sizes [count, 1]"""
+  python tests/ref_hash_worker.py cubics <first path> <count> out.npy                  rows: [count, 1, 4] + sizes [count, 1]
+  python tests/ref_hash_worker.py cubics@<box>:<paths> <first path> <count> out.npy    the same for `paths` cubics in [0, box) (SURVEY 8(d) config 2's box sweep)"""
 import importlib
 import os
 import sys
@@ -65,8 +66,12 @@ def main():
         rows = np.stack([hu.digest_ragged_np(r.pos.view(np.uint32).reshape(-1), 2 * fv, 2 * nv), hu.digest_ragged_np(r.color, fv, nv),
                          hu.digest_ragged_np(r.idx.astype(np.uint32), fi, ni)], axis=1)
         np.save(out, np.concatenate([rows.reshape(count, 12), nv[:, None], ni[:, None]], axis=1))
-    elif which == "cubics":
-        ps, d = wl.random_cubics(1000000, seed=1234, box=1000.0)
+    elif which.startswith("cubics"):
+        box, paths = 1000.0, 1000000
+        if "@" in which:
+            b, n = which.split("@")[1].split(":")
+            box, paths = float(b), int(n)
+        ps, d = wl.random_cubics(paths, seed=1234, box=box)
         r = pyoracle.flatten(ps, d[first:first + count], apply_transform=True)
         di = r.draw_info
         fv, nv = di["first_poly_vertex"].astype(np.int64), di["num_poly_vertices"].astype(np.int64)

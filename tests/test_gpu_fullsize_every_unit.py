@@ -165,3 +165,27 @@ def test_every_path_of_the_million_cubics_matches_the_reference(rt, wl):
     assert bad.shape[0] == 0, ("paths that differ from the reference", bad[:10].tolist(), bad.shape[0])
     pset.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("box", [10.0, 100.0, 10000.0])
+def test_cubics_box_sweep_matches_the_reference(rt, wl, box):
+    """SURVEY 8(d) config 2, "also run boxes 10 / 100 / 10 000 to sweep the output size": 250 000 cubics with coordinates in
+    [0, box) -- ~5, ~14 and ~145 segments per cubic (the deepest trees the walk sees) -- every path against the reference
+    (bench.py reports the same sweep at 1 M paths under configs.cubics1m.box_sweep)."""
+    import torch
+    paths = 250000
+    ps, d = wl.random_cubics(paths, seed=1234, box=box)
+    ctx = rt.Context(0)
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(d)
+    r = rt.flatten(ctx, pset, dd, d.shape[0], apply_transform=True, to_host=False)
+    ref = _reference_rows("cubics@%g:%d" % (box, paths), paths)  # [paths, 4 + 1]
+    di = r.dinfo_dev[:d.shape[0] * 40].view(torch.int64).view(-1, 5)
+    fv, cv = di[:, 0], di[:, 3] & 0xFFFFFFFF
+    assert np.array_equal(cv.cpu().numpy(), ref[:, 4])
+    npv = r.sizes["num_poly_vertices"]
+    got = hu.digest_ragged_torch(r.poly_dev[:npv].view(torch.int32), 2 * fv, 2 * cv)
+    bad = np.flatnonzero((got != ref[:, :4]).any(axis=1))
+    assert bad.shape[0] == 0, ("paths that differ from the reference", bad[:10].tolist(), bad.shape[0])
+    pset.close()
+    ctx.close()

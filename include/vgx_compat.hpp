@@ -111,7 +111,8 @@ struct VgxTessApi
 	int (*getElementCount)(void* tess);
 	const unsigned short* (*getElements)(void* tess);
 };
-void vgxCompatSetTessellator(const VgxTessApi* api); // copied; nullptr removes it
+void vgxCompatSetTessellator(const VgxTessApi* api); // copied; nullptr removes it. A Stroker's tessellator object is deleted (next Begin /
+                                                     // destroyStroker) with the deleteTess of the table that made it: keep that libtess2 loaded while Strokers live
 // Device used by subsequently created Path / Stroker objects (default 0). Last status of an object (vgx_status).
 void vgxCompatSetDevice(int device);
 // 0 = auto (host; the device for vertex lists of at least VGX_COMPAT_DEVICE_MIN vertices), 1 = host, 2 = device. Default: the

@@ -291,6 +291,7 @@ struct Stroker
 	Vec<uint16_t> idx;
 	DevBuf dPoly, dSub, dSubDraw, dDraw, dPos, dCol, dIdx;
 	void* tess = nullptr;                    // strokerConcaveFill*: the host's libtess2 object
+	void (*tessDelete)(void*) = nullptr;     // ... and the deleteTess of the table that made it (the table may be replaced / removed while the object lives)
 	DevBuf dContour, dCont, dFill, dMoved, dTessPos, dTessIdx;
 	Vec<float> moved, contourCopy;
 	explicit Stroker(bx::AllocatorI* a) : alloc(a), pos(BxAlloc<float>(a)), col(BxAlloc<uint32_t>(a)), idx(BxAlloc<uint16_t>(a)), moved(BxAlloc<float>(a)), contourCopy(BxAlloc<float>(a)) {}
@@ -371,7 +372,7 @@ Stroker* createStroker(bx::AllocatorI* allocator) // stroker.cpp:194-200
 void destroyStroker(Stroker* s)
 {
 	if (!s) { return; }
-	if (s->tess && g_hasTess) { g_tess.deleteTess(s->tess); }
+	if (s->tess && s->tessDelete) { s->tessDelete(s->tess); }
 	vgx_ctx* c = s->ctx;
 	bx::AllocatorI* a = s->alloc;
 	s->~Stroker();
@@ -438,20 +439,22 @@ void vgxCompatSetTessellator(const VgxTessApi* api)
 
 bool strokerConcaveFillBegin(Stroker* s) // stroker.cpp:809-845 (the scratch allocator is the host library's business)
 {
+	if (s->tess && s->tessDelete) { s->tessDelete(s->tess); }
+	s->tess = nullptr; s->tessDelete = nullptr;
 	if (!g_hasTess) { s->status = VGX_E_INVALID_ARG; return false; }
-	if (s->tess) { g_tess.deleteTess(s->tess); }
 	s->tess = g_tess.newTess(nullptr);
+	s->tessDelete = g_tess.deleteTess;
 	return s->tess != nullptr;
 }
 
 void strokerConcaveFillAddContour(Stroker* s, const float* vertexList, uint32_t numVertices) // stroker.cpp:847-850
 {
-	if (s->tess) { g_tess.addContour(s->tess, 2, vertexList, (int)(sizeof(float) * 2), (int)numVertices); }
+	if (s->tess && g_hasTess) { g_tess.addContour(s->tess, 2, vertexList, (int)(sizeof(float) * 2), (int)numVertices); }
 }
 
 bool strokerConcaveFillEnd(Stroker* s, Mesh* mesh, FillRule::Enum fillRule) // stroker.cpp:852-866: libtess2 only
 {
-	if (!s->tess) { return false; }
+	if (!s->tess || !g_hasTess) { return false; }
 	if (!g_tess.tesselate(s->tess, fillRule == FillRule::NonZero ? kTessWindingNonZero : kTessWindingOdd, kTessPolygons, 3, 2, nullptr)) { return false; }
 	mesh->m_PosBuffer = g_tess.getVertices(s->tess);
 	mesh->m_ColorBuffer = nullptr;
@@ -463,7 +466,7 @@ bool strokerConcaveFillEnd(Stroker* s, Mesh* mesh, FillRule::Enum fillRule) // s
 
 bool strokerConcaveFillEndAA(Stroker* s, Mesh* mesh, uint32_t color, FillRule::Enum fillRule) // stroker.cpp:868-1006
 {
-	if (!s->tess) { return false; }
+	if (!s->tess || !g_hasTess) { return false; }
 	const int rule = fillRule == FillRule::NonZero ? kTessWindingNonZero : kTessWindingOdd;
 	const float normal[3] = { 0.0f, 0.0f, 1.0f };
 	s->status = VGX_OK;

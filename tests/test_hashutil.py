@@ -22,3 +22,29 @@ def test_digest_forms_agree():
     assert (hu.digest_uniform_np(w2, 12) != a).any()
     w3 = w.copy(); w3[10], w3[11] = w[11], w[10]
     assert (hu.digest_uniform_np(w3, 12) != a).any()
+
+
+def test_reference_worker_rows_of_the_cubic_box_sweep(tmp_path, wl, oracle):
+    """tests/ref_hash_worker.py in its `cubics@<box>:<paths>` mode (the reference side of the GPU box-sweep test): the rows of a
+    sub-range equal the digests of the oracle's polylines computed here path by path, and the ranges of two workers concatenate."""
+    import importlib
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    paths, box = 300, 10.0
+    outs = []
+    for first, count in ((0, 200), (200, 100)):
+        out = str(tmp_path / ("rows%d.npy" % first))
+        subprocess.check_call([sys.executable, os.path.join(here, "ref_hash_worker.py"), "cubics@%g:%d" % (box, paths), str(first), str(count), out])
+        outs.append(np.load(out))
+    rows = np.concatenate(outs)
+    assert rows.shape == (paths, 5)
+    pyoracle = importlib.import_module("pyoracle")
+    ps, d = wl.random_cubics(paths, seed=1234, box=box)
+    r = pyoracle.flatten(ps, d, apply_transform=True)
+    di = r.draw_info
+    fv, nv = di["first_poly_vertex"].astype(np.int64), di["num_poly_vertices"].astype(np.int64)
+    assert (rows[:, 4] == nv).all() and 4 < nv.mean() < 8  # ~4.7 segments per cubic at box 10 (SURVEY 8(d))
+    want = hu.digest_ragged_np(r.poly.view(np.uint32).reshape(-1), 2 * fv, 2 * nv)
+    assert (rows[:, :4] == want).all()

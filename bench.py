@@ -104,8 +104,10 @@ def cpu_baseline(budget_seconds=10.0, max_procs=256, which="tiger"):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libvgoracle.so"], stdout=subprocess.DEVNULL)
     procs = max(1, min(effective_cores(), max_procs))
     worker = os.path.join(ROOT, "oracle", "cpu_bench.py")
-    shard = {"tiger": 16, "cubics": 20000, "round": 8}[which]
-    what = {"tiger": "Tiger x16 instances", "cubics": "20 000 independent cubics (flatten + transform only)", "round": "8 polylines x 1000 segments, Round joins + caps"}[which]
+    shard = {"tiger": 16, "cubics": 20000, "round": 8, "tigerspec": 4, "varied": 21, "tigeropen": 16, "tigerbevel": 16}[which]
+    what = {"tiger": "Tiger x16 instances", "cubics": "20 000 independent cubics (flatten + transform only)", "round": "8 polylines x 1000 segments, Round joins + caps",
+            "tigerspec": "the SURVEY-spec drawing x4 instances", "varied": "Tiger x21 instances at 7 scales under rotations",
+            "tigeropen": "Tiger with open sub-paths x16 instances", "tigerbevel": "Tiger with Bevel joins x16 instances"}[which]
     unit = "M polyline verts/s" if which == "cubics" else "M verts/s"
 
     def run(k, nproc, budget):
@@ -177,7 +179,9 @@ WORKLOADS = {
     "tiger10k_varied_per_instance_flatten": "the tiger10k_varied batch with VGX_TMPL_CLASSES=0: what instances cost when they share no subdivision (k_flatten_inst with the instances sorted by tolerance class + k_fill + k_stroke)",
 }
 CONFIG_ENV = {"tiger10k_per_instance_flatten": {"VGX_TMPL": "0"}, "tiger10k_command_parallel": {"VGX_INST": "0"}, "tiger10k_varied_per_instance_flatten": {"VGX_TMPL_CLASSES": "0"}}
-CONFIG_CPU = {"cubics1m": "cubics", "round10k": "round"}  # configs that get their own cpu_baseline (the tiger ones share the headline's)
+# configs that get their own cpu_baseline (the honesty configs are the headline's batch: they share its baseline)
+CONFIG_CPU = {"cubics1m": "cubics", "round10k": "round", "tigerspec10k": "tigerspec", "tiger10k_varied": "varied", "tiger10k_open": "tigeropen", "tiger10k_bevel": "tigerbevel"}
+CONFIG_CPU_BUDGET = {"cubics": 4.0, "round": 4.0}  # seconds of wall time per config (the tiger variants: 2.5 s)
 
 
 def make_workload(wl, name, instances, rank):
@@ -484,7 +488,7 @@ def main():
         cpu = cpu_baseline()  # before any GPU work, in separate processes
         if not args.no_configs:
             for name, which in CONFIG_CPU.items():  # the reference beside every BASELINE config, on a bounded sample (4 s each)
-                other_cpu[name] = cpu_baseline(budget_seconds=4.0, which=which)
+                other_cpu[name] = cpu_baseline(budget_seconds=CONFIG_CPU_BUDGET.get(which, 2.5), which=which)
     genv = gpu_environment() if rank == 0 else None
 
     def barrier():

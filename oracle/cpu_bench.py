@@ -21,7 +21,7 @@ sys.path.insert(0, HERE)
 
 def main():
     kind, instances, first, budget = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4])
-    which = sys.argv[5] if len(sys.argv) > 5 else "tiger"  # tiger | cubics | round: the BASELINE config the shard belongs to
+    which = sys.argv[5] if len(sys.argv) > 5 else "tiger"  # tiger | cubics | round | tigerspec | varied | tigeropen | tigerbevel: the bench config the shard belongs to
     wl = importlib.import_module("vg-renderer_amd.workloads")
     import pyoracle
     unit = "num_vertices"
@@ -32,6 +32,18 @@ def main():
         run = pyoracle.flatten_timed
     elif which == "round":   # configs[3]: `instances` polylines x 1000 segments, Round joins + Round caps
         ps, draws = wl.random_walk_polylines(instances, 1000, seed=5678 + first)
+    elif which == "tigerspec":   # SURVEY 8(d) config 3 as specified: 240 paths, 1-4 closed sub-paths of 8-60 cubics
+        ps, ops = wl.tiger_spec_paths()
+        draws = wl.tiger_draws(ops, instances, first_instance=first)
+    elif which == "varied":      # the tiger at 7 scales under rotations (flatten tolerance and stroke widths follow the scale)
+        ps, ops = wl.tiger_paths()
+        draws = wl.tiger_varied_draws(ops, instances, first_instance=first)
+    elif which == "tigeropen":   # every sub-path left open: Butt caps at both ends of every stroke
+        ps, ops = wl.tiger_paths(closed=False)
+        draws = wl.tiger_draws(ops, instances, first_instance=first)
+    elif which == "tigerbevel":  # Bevel joins on the strokes
+        ps, ops = wl.tiger_paths()
+        draws = wl.tiger_draws(ops, instances, first_instance=first, join=2)
     else:
         ps, draws = wl.tiger(instances, first_instance=first)
     run(ps, draws, kind=kind, reps=1)  # load the library, touch the buffers

@@ -267,6 +267,15 @@ int vgx_pathset_destroy(vgx_ctx* ctx, vgx_pathset* ps);
  * _emit must follow with the same arguments and DEVICE output buffers of at least those sizes. */
 int vgx_flatten_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, vgx_sizes* out_sizes, void* stream);
 int vgx_flatten_emit(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, int apply_transform, const vgx_flat_out* out, void* stream);
+/* Single asynchronous call, the form for steady state (like vgx_tessellate): the same ordered output as _count + _emit from ONE
+ * walk over every cubic, no host round trip. `out` carries the caller's capacities (out->poly and out->subpaths must be given;
+ * out->draw_info may be NULL); `dev_sizes` (DEVICE vgx_sizes, may be NULL) receives the totals -- num_poly_vertices,
+ * num_subpaths, num_meshes, num_cmd_instances, num_serial_draws -- and `dev_status` (DEVICE uint32, may be NULL) VGX_OK /
+ * VGX_E_NOSPACE (a capacity was too small: the totals say what is needed, the buffers' contents are undefined) / ... .
+ * Replaces pathReset + the path commands + pathGetVertices / pathGetSubPaths (+ transformPath) for every draw, reference
+ * src/path.cpp:44-78, 86-201, 684-726, src/vg.cpp:4957-4975. */
+int vgx_flatten(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, int apply_transform, const vgx_flat_out* out,
+                vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream);
 
 /* ---- tessellate: flatten + transformPath + one strokerXXX call per sub-path per op --------- */
 /* _count: flatten into context scratch, size every mesh, scan; returns totals (one stream sync).

@@ -2,10 +2,14 @@
 //
 // Drop-in replacement for <vg/path.h> (reference include/vg/path.h:19-38) and <vg/stroker.h>
 // (include/vg/stroker.h:11-72): same namespace, names, argument order and POD layouts, so the call sites in the
-// reference's src/vg.cpp compile unchanged. Every call is served by the HIP kernels of libvgx.so with a batch of
-// ONE path / ONE vertex list (a launch + copy round trip per call, ~0.1 ms): this layer exists for source
-// compatibility and incremental adoption; throughput comes from batching through vgx.h.
-// There is no CPU implementation behind it: without a gfx950 device the create functions return nullptr.
+// reference's src/vg.cpp compile unchanged. A call is served in one of two ways (vgxCompatSetBackend below): by the
+// product's own per-lane code compiled for the host (host/vgx_host_backend.hip: the functions the kernels run one per lane,
+// driven element after element; ~1 us per call, no GPU needed -- the default, because one launch per strokerXXX call would cost
+// ~10 us for ~1 us of work), or by the HIP kernels of libvgx.so with a batch of ONE path / ONE vertex list (a launch + copy
+// round trip per call, ~0.1 ms; auto mode takes it for vertex lists of at least VGX_COMPAT_DEVICE_MIN vertices and falls back
+// to the host code when no gfx950 device is usable; a FORCED device backend without a device fails loudly: the create
+// functions return nullptr). Same bits either way. This layer exists for source compatibility and incremental adoption;
+// throughput comes from batching through vgx.h. Nothing under oracle/ is behind it.
 //
 // createPath / createStroker honour the caller's bx::AllocatorI (bx/allocator.h's interface: a virtual destructor and realloc(ptr,
 // size, align, file, line)): the object and every host-side array come from it, nullptr = the C heap; device buffers are hipMalloc.

@@ -1,0 +1,206 @@
+"""vgx_flatten (csrc/vgx_flat1.hip): the ordered ONE-WALK flatten, single asynchronous call -- pathReset + path commands +
+pathGetVertices / pathGetSubPaths (+ transformPath) for every draw, reference src/path.cpp:44-78, 86-201, 684-726,
+src/vg.cpp:4957-4975.
+
+Every caller of `rt.flatten` already compares vgx_flatten's bytes with the two-phase entry (vg-renderer_amd/runtime.py, entry
+"both"), i.e. the whole flatten parity / golden / full-size suite pins it. This file adds what is specific to the new kernel: its
+own comparison with the oracle, segments of several chunks (draws longer than 64 commands), the leaf list overflowing, deep and
+degenerate cubics (the second run), serial paths between ordinary ones, empty paths / batches, the look-back across few and many
+waves, and the capacity verdict."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from util import assert_flat_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rt():
+    return importlib.import_module("vg-renderer_amd.runtime")
+
+
+def _ctx_with(rt, **env):
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return rt.Context(0)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _one_walk(rt, ctx, ps, d, xform, **kw):
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(d)
+    r = rt.flatten(ctx, pset, dd, d.shape[0], apply_transform=xform, entry="both", **kw)
+    pset.close()
+    return r
+
+
+@pytest.mark.parametrize("box", [10.0, 1000.0, 10000.0])
+@pytest.mark.parametrize("xform", [False, True])
+def test_one_walk_random_cubics_vs_oracle(rt, gpu_ctx, wl, oracle, box, xform):
+    ps, d = wl.random_cubics(6000, seed=99, box=box)
+    if xform:
+        d["mtx"][:, 0] = 0.75; d["mtx"][:, 1] = 0.25; d["mtx"][:, 2] = -0.5; d["mtx"][:, 3] = 1.25
+        d["mtx"][:, 4] = np.arange(d.shape[0], dtype=np.float32) % 97; d["mtx"][:, 5] = 3.5
+    got = _one_walk(rt, gpu_ctx, ps, d, xform)
+    ref = oracle.flatten(ps, d, apply_transform=xform)
+    assert_flat_equal(got, ref, "one-walk cubics box=%g xform=%s" % (box, xform))
+
+
+@pytest.mark.parametrize("seed", [3, 4, 5, 6])
+def test_one_walk_fuzz_all_commands_vs_oracle(rt, gpu_ctx, wl, oracle, seed):
+    """Every path command, serial paths (arcs, closed shapes) between lane-parallel ones, fills and strokes enabled at random
+    (the per-draw mesh counts / first_mesh come from the same look-back)."""
+    ps = wl.fuzz_paths(300 + seed, npaths=160)
+    d = wl.fuzz_draws(ps, 300 + seed)
+    for xform in (False, True):
+        got = _one_walk(rt, gpu_ctx, ps, d, xform)
+        ref = oracle.flatten(ps, d, apply_transform=xform)
+        assert_flat_equal(got, ref, "one-walk fuzz seed=%d xform=%s" % (seed, xform))
+
+
+def _long_paths(rs, npaths, ncmd_lo, ncmd_hi, box=400.0):
+    pm = importlib.import_module("vg-renderer_amd.pathset")
+    b = pm.PathSetBuilder()
+    for _ in range(npaths):
+        b.begin_path()
+        left = int(rs.randint(ncmd_lo, ncmd_hi))
+        while left > 0:
+            m = min(left, int(rs.randint(3, 40)))
+            p = rs.uniform(0, box, size=2)
+            b.move_to(*p)
+            for _ in range(m):
+                k = rs.randint(0, 4)
+                q = rs.uniform(0, box, size=6)
+                if k == 0:
+                    b.line_to(q[0], q[1])
+                elif k == 1:
+                    b.quadratic_to(q[0], q[1], q[2], q[3])
+                else:
+                    b.cubic_to(*q)
+            if rs.uniform() < 0.6:
+                b.close()
+            left -= m + 2
+        b.end_path()
+    return b.arrays()
+
+
+@pytest.mark.parametrize("seed,lo,hi", [(1, 60, 70), (2, 65, 200), (3, 300, 900), (4, 1, 140)])
+def test_one_walk_draws_longer_than_a_chunk(rt, gpu_ctx, wl, oracle, seed, lo, hi):
+    """Segments of several 64-command chunks: counted first, published, walked again chunk by chunk; sub-paths and pathClose pops
+    across chunk borders."""
+    pm = importlib.import_module("vg-renderer_amd.pathset")
+    rs = np.random.RandomState(seed)
+    ps = _long_paths(rs, 40, lo, hi)
+    d = pm.make_draws(300)
+    d["path"] = rs.randint(0, ps.npaths, size=300)
+    d["fill_flags"] = rs.choice([0, 1, 3], size=300)
+    d["stroke_flags"] = rs.choice([0, 3], size=300)
+    d["stroke_width"] = 2.0
+    d["scale"] = rs.choice([0.5, 1.0, 2.0], size=300).astype(np.float32)
+    d["mtx"][:, 4] = rs.uniform(-50, 50, size=300).astype(np.float32)
+    for xform in (False, True):
+        got = _one_walk(rt, gpu_ctx, ps, d, xform)
+        ref = oracle.flatten(ps, d, apply_transform=xform)
+        assert_flat_equal(got, ref, "long draws seed=%d xform=%s" % (seed, xform))
+
+
+def test_one_walk_leaf_list_overflow_and_small_grids(rt, wl, oracle):
+    """VGX_F1_CAP=1024: a chunk of 32 cubics x ~45 leaves does not fit the list -> its cubics are walked again, straight to memory.
+    VGX_F1_WAVES=3 / 7: the look-back reaches far back (few waves, many tickets each) and must not depend on the grid."""
+    ps, d = wl.random_cubics(20000, seed=7, box=1000.0)
+    ref = oracle.flatten(ps, d, apply_transform=True)
+    for env in ({"VGX_F1_CAP": 1024}, {"VGX_F1_WAVES": 3}, {"VGX_F1_WAVES": 7, "VGX_F1_CAP": 3072}, {"VGX_F1_WAVES": 4096}):
+        ctx = _ctx_with(rt, **env)
+        got = _one_walk(rt, ctx, ps, d, True)
+        assert_flat_equal(got, ref, "one-walk %r" % (env,))
+        ctx.close()
+
+
+def test_one_walk_deep_and_degenerate_cubics(rt, gpu_ctx, wl, oracle):
+    """Tolerances small enough for ten levels of subdivision (the LDS levels overflow -> full-depth redo; the reference's silent
+    drop at depth 10, path.cpp:168-179) and cubics small enough for pathAddVertex's epsilon test (path.cpp:767-777): such draws
+    are listed, counted by the exact serial builder and the kernel runs a second time."""
+    pm = importlib.import_module("vg-renderer_amd.pathset")
+    ps, d = wl.random_cubics(3000, seed=11, box=3000.0)
+    d["tess_tol"][::7] = 1e-5     # very deep
+    d["scale"][::11] = 16.0       # tol / scale^2
+    ps2, d2 = wl.random_cubics(2000, seed=12, box=0.02)  # tiny: consecutive vertices closer than sqrt(1e-5)
+    both = pm.concat([ps, ps2])
+    d2["path"] += ps.npaths
+    dd = np.concatenate([d, d2])
+    rs = np.random.RandomState(5)
+    dd = dd[rs.permutation(dd.shape[0])]
+    got = _one_walk(rt, gpu_ctx, both, dd, True)
+    ref = oracle.flatten(both, dd, apply_transform=True)
+    assert got.sizes["num_serial_draws"] > 0
+    assert_flat_equal(got, ref, "deep / degenerate cubics")
+
+
+def test_one_walk_empty_paths_and_batches(rt, gpu_ctx, wl, oracle):
+    pm = importlib.import_module("vg-renderer_amd.pathset")
+    b = pm.PathSetBuilder()
+    b.begin_path(); b.end_path()                                   # empty path
+    b.begin_path(); b.move_to(1, 2); b.end_path()                  # one vertex
+    b.begin_path(); b.move_to(0, 0); b.cubic_to(10, 30, 40, 30, 50, 0); b.close(); b.end_path()
+    b.begin_path(); b.end_path()
+    ps = b.arrays()
+    d = pm.make_draws(200)
+    d["path"] = np.arange(200) % 4
+    d["fill_flags"] = 3
+    got = _one_walk(rt, gpu_ctx, ps, d, False)
+    ref = oracle.flatten(ps, d, apply_transform=False)
+    assert_flat_equal(got, ref, "empty paths")
+    d0 = pm.make_draws(8)
+    d0["path"] = 0  # a batch without a single command
+    got = _one_walk(rt, gpu_ctx, ps, d0, False)
+    assert got.sizes["num_poly_vertices"] == 0 and got.sizes["num_subpaths"] == 0
+
+
+def test_one_walk_capacity_verdict(rt, gpu_ctx, wl):
+    import torch
+    ps, d = wl.random_cubics(5000, seed=21, box=1000.0)
+    pset = rt.PathSet(gpu_ctx, ps)
+    dd = rt.upload_draws(d)
+    full = rt.flatten(gpu_ctx, pset, dd, d.shape[0], entry="two_phase")
+    npv, nsp = full.sizes["num_poly_vertices"], full.sizes["num_subpaths"]
+    for cap_poly, cap_subs in ((npv - 1, nsp), (npv, nsp - 1), (npv // 3, nsp)):
+        bufs = rt.FlatBuffers(dd.device, cap_poly, cap_subs, d.shape[0])
+        guard = torch.full((16, 2), 7.0, dtype=torch.float32, device=dd.device)
+        rt.flatten_async(gpu_ctx, pset, dd, d.shape[0], bufs)
+        torch.cuda.synchronize()
+        assert int(bufs.dev_status.item()) == 4  # VGX_E_NOSPACE
+        z = bufs.dev_sizes.cpu().numpy()
+        assert int(z[0]) == npv and int(z[1]) == nsp  # the totals say what is needed
+        assert bool((guard == 7.0).all())
+    # and exact capacities pass
+    bufs = rt.FlatBuffers(dd.device, npv, nsp, d.shape[0])
+    rt.flatten_async(gpu_ctx, pset, dd, d.shape[0], bufs)
+    torch.cuda.synchronize()
+    assert int(bufs.dev_status.item()) == 0
+    assert torch.equal(bufs.poly[:npv].view(torch.int32), full.poly_dev[:npv].view(torch.int32))
+    pset.close()
+
+
+def test_one_walk_tiger_instances(rt, gpu_ctx, wl, oracle):
+    """The tiger-like drawing (25-command draws, 1-3 closed sub-paths): most segments are one chunk, some two."""
+    ps, d = wl.tiger(40)
+    got = _one_walk(rt, gpu_ctx, ps, d, True)
+    ref = oracle.flatten(ps, d, apply_transform=True)
+    assert_flat_equal(got, ref, "tiger x40")
+
+
+def test_one_walk_long_polylines(rt, gpu_ctx, wl, oracle):
+    ps, d = wl.random_walk_polylines(n=60, nseg=1000, seed=5)
+    got = _one_walk(rt, gpu_ctx, ps, d, True)
+    ref = oracle.flatten(ps, d, apply_transform=True)
+    assert_flat_equal(got, ref, "long polylines")

@@ -194,6 +194,7 @@ VGX_SYMBOLS = {
     "vgx_pathset_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vgx_flatten_count": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Sizes), C.c_void_p]),
     "vgx_flatten_emit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(FlatOut), C.c_void_p]),
+    "vgx_flatten": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(FlatOut), C.c_void_p, C.c_void_p, C.c_void_p]),
     "vgx_tessellate_count": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Sizes), C.c_void_p]),
     "vgx_tessellate_emit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(MeshOut), C.c_void_p]),
     "vgx_tessellate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(MeshOut), C.c_void_p, C.c_void_p, C.c_void_p]),

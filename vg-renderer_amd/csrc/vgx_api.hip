@@ -11,7 +11,9 @@
 #include "vgx_scan_ops.h"
 #include "vgx_pathsim.h"
 #include "vgx_inst.h"
+#include "vgx_flat1.h"
 #include <vector>
+#include <atomic>
 #include <unordered_map>
 #include <string.h>
 #include <math.h>
@@ -43,6 +45,9 @@ struct vgx_pathset
 	void* blob; // single device allocation holding every array
 	size_t blobBytes;
 	uint32_t maxCmdsPerPath;
+	bool hasSerial; // some path takes the exact serial builder (ARC / ARC_TO / closed shapes)
+	bool hasEmpty;  // some path has no commands
+	uint64_t gen; // unique per vgx_pathset_create (process-wide counter): identifies the path set where an address could be reused
 };
 
 struct DevBuf
@@ -62,6 +67,8 @@ struct vgx_ctx
 	bool asmArmed;
 	DevBuf subPrefix; // exclusive scan of the draws' static sub-path counts
 	DevBuf cmdPrefix, cmdCnt, subFirst, leafOverflow, serialList, dinfo, poly, subs, mdesc, elemPrefix, elemPrefixS, mprep, mtab, partial, totals;
+	DevBuf f1SegDraw, f1Segs;            // vgx_flatten (vgx_flat1.hip): segment table, look-back records
+	int optF1Waves, optF1Cap;            // its grid (persistent one-wave workgroups) and the leaf-list capacity of the kernel instance (0 = chosen per batch)
 	DevBuf gatherSizes;                  // vgx_gather_sizes: [nranks][4] uint64
 	DevBuf partBounds;                   // vgx_partition: [nparts + 1] bounds + [nparts] weights
 	struct VgxRccl* rccl;                // RCCL entry points, bound at the first vgx_gather* call
@@ -91,6 +98,7 @@ struct vgx_ctx
 	DevBuf tmplTile;                     // [tiles] VgxTmplTile
 	bool tmplOn;
 	const vgx_pathset* tmplPs;
+	uint64_t tmplPsGen;                  // generation id of tmplPs when the template was built (an address can be reused by a later path set)
 	uint32_t tmplPeriod;
 	vgx_sizes tmplInst;                  // sizes of one instance
 	DevBuf tmplPoly, tmplMesh, tmplMtab, tmplElem, tmplDraws;
@@ -727,6 +735,9 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	if (const char* e = getenv("VGX_TMPL_TILE")) { const int v = atoi(e); if (v >= 64 && v <= VGX_TMPL_MAX_TILE) { ctx->optTmplTile = (uint32_t)v / 64u * 64u; } } // testing: elements per tile (<= the LDS stage of k_tmpl_emit)
 	ctx->optPoolWalk = 0; // VGX_WALK=pool: the wave-cooperative walk of vgx_walk.h (same output, same speed: DESIGN.md section 4)
 	if (const char* e = getenv("VGX_WALK")) { ctx->optPoolWalk = strcmp(e, "pool") == 0; }
+	ctx->optF1Waves = 0; ctx->optF1Cap = 0;
+	if (const char* e = getenv("VGX_F1_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { ctx->optF1Waves = v; } }
+	if (const char* e = getenv("VGX_F1_CAP")) { ctx->optF1Cap = atoi(e); }
 	if (const char* e = getenv("VGX_BUILD_WAVES")) { const int v = atoi(e); if (v >= 1 && v < VGX_BUILD_WAVES) { ctx->optBuildWaves = v; } }
 	*out_ctx = ctx;
 	return VGX_OK;
@@ -738,7 +749,7 @@ int vgx_destroy(vgx_ctx* ctx)
 		return VGX_E_INVALID_ARG;
 	}
 	DeviceGuard guard(ctx);
-	DevBuf* bufs[] = { &ctx->tmplTile, &ctx->tmplPoly, &ctx->tmplMesh, &ctx->tmplMtab, &ctx->tmplElem, &ctx->tmplDraws, &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DevBuf* bufs[] = { &ctx->f1SegDraw, &ctx->f1Segs, &ctx->tmplHash, &ctx->tmplInstCls, &ctx->tmplClsRep, &ctx->tmplCls, &ctx->tmplIinfo, &ctx->tmplWg, &ctx->tmplTile, &ctx->tmplPoly, &ctx->tmplMesh, &ctx->tmplMtab, &ctx->tmplElem, &ctx->tmplDraws, &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
@@ -759,7 +770,7 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx)
 	if (!ctx) {
 		return 0;
 	}
-	return ctx->tmplTile.cap + ctx->tmplPoly.cap + ctx->tmplMesh.cap + ctx->tmplMtab.cap + ctx->tmplElem.cap + ctx->tmplDraws.cap + ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
+	return ctx->f1SegDraw.cap + ctx->f1Segs.cap + ctx->tmplHash.cap + ctx->tmplInstCls.cap + ctx->tmplClsRep.cap + ctx->tmplCls.cap + ctx->tmplIinfo.cap + ctx->tmplWg.cap + ctx->tmplTile.cap + ctx->tmplPoly.cap + ctx->tmplMesh.cap + ctx->tmplMtab.cap + ctx->tmplElem.cap + ctx->tmplDraws.cap + ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
 }
 
 // ---- path set ---------------------------------------------------------------------------------------
@@ -942,6 +953,12 @@ int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset**
 	ps->blob = nullptr;
 	ps->blobBytes = total;
 	ps->maxCmdsPerPath = maxCmds;
+	ps->hasSerial = false;
+	ps->hasEmpty = false;
+	for (uint32_t i = 0; i < npaths; ++i) {
+		if (pathFlags[i] & VGX_PF_SERIAL) { ps->hasSerial = true; }
+		if (desc->path_cmd_begin[i + 1] == desc->path_cmd_begin[i]) { ps->hasEmpty = true; }
+	}
 	hipError_t e = hipMalloc(&ps->blob, total);
 	if (e == hipSuccess) { e = hipMemcpy(ps->blob, host.data(), total, hipMemcpyHostToDevice); }
 	if (e != hipSuccess) {
@@ -963,6 +980,8 @@ int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset**
 	ps->dev.sub_last_cmd = (const uint32_t*)(b + oSubLast);
 	ps->dev.npaths = npaths;
 	ps->dev.ncmd = ncmd;
+	static std::atomic<uint64_t> s_pathsetGen{0};
+	ps->gen = ++s_pathsetGen;
 	*out_ps = ps;
 	return VGX_OK;
 }
@@ -974,6 +993,7 @@ int vgx_pathset_destroy(vgx_ctx* ctx, vgx_pathset* ps)
 		return VGX_E_INVALID_ARG;
 	}
 	if (ctx->lastPs == ps) { ctx->lastPs = nullptr; ctx->lastStage = 0; }
+	if (ctx->tmplPs == ps) { ctx->tmplOn = false; ctx->tmplPs = nullptr; ctx->tmplPsGen = 0; } // a later path set at the same address must not match the template
 	if (ps->blob) { (void)hipFree(ps->blob); }
 	delete ps;
 	return VGX_OK;
@@ -1096,6 +1116,62 @@ int vgx_flatten_emit(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 		HIPCHK(ctx, hipMemcpyAsync(out->draw_info, ctx->dinfo.p, ndraws * sizeof(vgx_draw_info), hipMemcpyDeviceToDevice, s));
 	}
 	return VGX_OK;
+}
+
+// ---- vgx_flatten: the ordered one-walk flatten (vgx_flat1.hip), asynchronous ---------------------------------------------
+int vgx_flatten(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, int apply_transform, const vgx_flat_out* out,
+                vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream)
+{
+	DeviceGuard guard(ctx);
+	if (!ctx || !ps || !out || !out->poly || !out->subpaths || (!draws && ndraws)) {
+		return VGX_E_INVALID_ARG;
+	}
+	hipStream_t s = (hipStream_t)stream;
+	markBegin(ctx, s);
+	ctx->lastStage = 0;
+	ctx->tmplOn = false;
+	int st;
+	if ((st = ensureDrawBuffers(ctx, ndraws)) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->serialList, (ndraws + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
+	// Segments: buckets of at least 32 command instances. The command total is not known on the host without a round trip;
+	// ndraws x (longest path) bounds it (a batch whose bound is absurdly far above its real size asks once, synchronously).
+	uint64_t cmdBound = ndraws * (uint64_t)(ps->maxCmdsPerPath ? ps->maxCmdsPerPath : 1);
+	ctx->caps.cmd_instances = ~0ull;
+	runCmdPrefix(ctx, ps, draws, ndraws, s);
+	if (cmdBound / 32 > (1ull << 26)) {
+		if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
+		if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; }
+		cmdBound = ctx->hostTotals->sizes.num_cmd_instances;
+	}
+	const uint64_t segBound = cmdBound / 32 + 2;
+	if ((st = ensure(ctx, ctx->f1SegDraw, (segBound + 1) * sizeof(uint64_t))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->f1Segs, (segBound + segBound / 64 + 2) * sizeof(VgxF1Seg))) != VGX_OK) { return st; }
+	VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, apply_transform);
+	a.poly = out->poly;
+	a.subs = out->subpaths;
+	a.mdesc = nullptr; a.mtab = nullptr;
+	a.caps.poly_vertices = ~0ull; a.caps.subpaths = ~0ull; a.caps.meshes = ~0ull;
+	VgxF1Args x;
+	x.seg_draw = (uint64_t*)ctx->f1SegDraw.p; x.segs = (VgxF1Seg*)ctx->f1Segs.p; x.grps = x.segs + segBound;
+	x.cap_poly = out->cap_poly_vertices; x.cap_subs = out->cap_subpaths; x.pass = 0; x.read_flags = 0; x.has_empty = ps->hasEmpty ? 1 : 0;
+	if (ps->hasSerial) { // statically serial paths: the exact builder counts their draws first (it marks them in dinfo)
+		noteHip(ctx, hipMemsetAsync(ctx->dinfo.p, 0, ndraws * sizeof(vgx_draw_info), s));
+		vgx_launch_flatten_serial(false, a, s);
+	}
+	// leaf-list capacity of the kernel instance: sized for 64 cubics of ~45 segments unless the caller knows better (VGX_F1_CAP)
+	const int cap = ctx->optF1Cap ? ctx->optF1Cap : 1664;
+	const int waves = ctx->optF1Waves ? ctx->optF1Waves : 2048;
+	vgx_launch_flat1(a, x, waves, cap, ps->hasSerial, s);
+	// draws of the exact builder: every draw is inspected when the set has serial paths, else only the draws the kernel listed
+	VgxFlattenArgs ae = a;
+	ae.build_mode = ps->hasSerial ? 0 : 1;
+	vgx_launch_flatten_serial(true, ae, s);
+	vgx_launch_flat1_publish(a, x, dev_sizes, dev_status, s);
+	mark(ctx, s, "flatten_one_walk");
+	if (out->draw_info && ndraws) {
+		HIPCHK(ctx, hipMemcpyAsync(out->draw_info, ctx->dinfo.p, ndraws * sizeof(vgx_draw_info), hipMemcpyDeviceToDevice, s));
+	}
+	return launchStatus(ctx);
 }
 
 // ---- partition (contiguous ranges per GPU, balanced on the count pass for heterogeneous batches) -------------
@@ -1223,7 +1299,7 @@ static int runTmpl(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 
 static bool tmplFor(const vgx_ctx* ctx, const vgx_pathset* ps, uint64_t ndraws)
 {
-	return ctx->tmplOn && ctx->optTmpl && ps == ctx->tmplPs && ctx->tmplPeriod && ndraws % ctx->tmplPeriod == 0 && ndraws >= ctx->tmplPeriod
+	return ctx->tmplOn && ctx->optTmpl && ps == ctx->tmplPs && ps->gen == ctx->tmplPsGen && ctx->tmplPeriod && ndraws % ctx->tmplPeriod == 0 && ndraws >= ctx->tmplPeriod
 		&& (ctx->tmplClasses == 1 || ndraws == ctx->tmplNDraws); // several classes: the per-instance table belongs to ONE batch size
 }
 
@@ -1429,6 +1505,7 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	ctx->tmplTileSize = tileSize;
 	ctx->tmplPeriod = (uint32_t)P;
 	ctx->tmplPs = ps;
+	ctx->tmplPsGen = ps->gen;
 	ctx->tmplClasses = T;
 	ctx->tmplNumWg = numWg;
 	ctx->tmplNDraws = ndraws;

@@ -30,6 +30,7 @@
 #include "vgx_elem.h"
 #include "vgx_scan_ops.h"
 #include "vgx_inst.h"
+#include "vgx_flat1.h"
 
 namespace {
 
@@ -965,6 +966,16 @@ void vgx_launch_flatten_gather(const VgxFlattenArgs& a, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_flatten_gather, dim3(2048), dim3(256), 0, s, a);
 	hipLaunchKernelGGL((k_flatten_serial<true, true>), dim3(1024), dim3(256), 0, s, a);
+}
+
+// k_flatten_serial alone (vgx_flatten's one-walk kernel, vgx_flat1.hip, does the lane-parallel part): count = every draw of a
+// statically serial path; emit = the draws flagged in dinfo (a.build_mode: only the listed ones)
+void vgx_launch_flatten_serial(bool emit, const VgxFlattenArgs& a, hipStream_t s)
+{
+	const int sb = a.build_mode ? 64 : 1024;
+	if (!emit) { hipLaunchKernelGGL((k_flatten_serial<false, false>), dim3(sb), dim3(256), 0, s, a); }
+	else if (a.apply_transform) { hipLaunchKernelGGL((k_flatten_serial<true, true>), dim3(sb), dim3(256), 0, s, a); }
+	else { hipLaunchKernelGGL((k_flatten_serial<true, false>), dim3(sb), dim3(256), 0, s, a); }
 }
 
 void vgx_launch_flatten(bool emit, const VgxFlattenArgs& a, int numBlocks, hipStream_t s)

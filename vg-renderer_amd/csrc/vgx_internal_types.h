@@ -122,7 +122,10 @@ struct VgxTotals
 	uint32_t cache_has_uniform;          // vgx_cache_submit: some submitted mesh was cached without per-vertex colours (k_cache_meshes -> k_cache_uniform_colors)
 	uint32_t tmpl_bad;                   // vgx_tessellate_count (k_tmpl_check): some draw differs from its image in the first period in a field the
 	                                     // flattener or the mesh sizes depend on -> no template mode (vgx_tmpl.hip)
-	uint32_t pad_u32[2];
+	uint32_t flat_redo;                  // vgx_flatten (vgx_flat1.hip): the first run found degenerate draws -> serial count of the listed draws, second run
+	uint32_t pad_u32[1];
+	unsigned long long flat_ticket;      // vgx_flatten: next segment (ticket order = output order)
+	unsigned long long flat_serial_draws;// vgx_flatten: draws that went through the exact serial builder
 	// diagnostics of the first failure (vgx_get_failure_info)
 	uint32_t fail_reason;  // VGX_FAIL_*
 	uint32_t fail_aux;

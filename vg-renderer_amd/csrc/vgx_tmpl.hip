@@ -265,7 +265,13 @@ __global__ __launch_bounds__(256) void k_tmpl_tiles(VgxTmplBuild B)
 	uint32_t mB = B.cls[c + 1].mesh0 - 1;
 	if (!last) { const uint32_t nx = B.ttile[t + 1].mesh0; mB = (nx & 0x7FFFFFFFu) - (nx >> 31); }
 	const uint32_t d0 = c * B.period;
-	const uint32_t dA = first ? 0u : B.mdesc[mA].draw - d0;
+	// A tile whose first mesh begins exactly here also takes the mesh-less draws in front of it (behind the previous tile's last
+	// mesh): the tiles' draw ranges partition [0, period), so a change to ANY draw record is seen by some workgroup.
+	uint32_t dA = first ? 0u : B.mdesc[mA].draw - d0;
+	if (!first && (B.ttile[t].mesh0 >> 31) != 0 && mA > B.cls[c].mesh0) {
+		const uint32_t prev = B.mdesc[mA - 1].draw - d0 + 1;
+		dA = prev < dA ? prev : dA;
+	}
 	const uint32_t dB = last ? B.period - 1 : B.mdesc[mB].draw - d0;
 	B.ttile[t].mesh_last = mB;
 	B.ttile[t].draw0 = dA;

@@ -321,7 +321,12 @@ struct Stroker
 	{
 		status = VGX_OK;
 		if (!onDevice(n)) { runHost(mesh, vertexList, n, closed, d, kind, wantColor, aliasPos); return; }
-		if (!ensureCtx()) { return; }
+		if (!ensureCtx()) {
+			// auto backend on a box without a usable GPU: the host lane code serves the call (same arithmetic); only a FORCED
+			// device backend fails loudly (mesh untouched, vgxCompatLastStatus says why)
+			if (backend() == kBackendAuto) { status = VGX_OK; runHost(mesh, vertexList, n, closed, d, kind, wantColor, aliasPos); }
+			return;
+		}
 		vgx_subpath sp;
 		sp.first_vertex = 0; sp.num_vertices = n; sp.flags = closed ? 1u : 0u;
 		const uint32_t zero = 0;
@@ -487,8 +492,11 @@ bool strokerConcaveFillEndAA(Stroker* s, Mesh* mesh, uint32_t color, FillRule::E
 	fill.first_contour = 0; fill.num_contours = (uint32_t)numContours; fill.color = color; fill.fringe = s->fringe;
 	// (2) moved contours
 	s->moved.assign((size_t)numContourVerts * 2, 0.0f);
-	const bool dev = onDevice(numContourVerts);
-	if (dev && !s->ensureCtx()) { return false; }
+	bool dev = onDevice(numContourVerts);
+	if (dev && !s->ensureCtx()) {
+		if (backend() != kBackendAuto) { return false; } // forced device backend without a device: loud
+		dev = false; s->status = VGX_OK;                 // auto: the host lane code serves the call
+	}
 	if (!dev) { // host backend: the same per-vertex function the kernels run (csrc/vgx_concave_lane.h)
 		s->contourCopy.assign(contourVerts, contourVerts + (size_t)numContourVerts * 2); // the tessellator's arrays die in step (3)
 		vgxh::concaveMove(s->contourCopy.data(), contours.data(), (uint32_t)numContours, s->fringe, s->moved.data());

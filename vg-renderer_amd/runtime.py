@@ -160,8 +160,28 @@ class MeshResult:
     pass
 
 
-def flatten(ctx, pset, draws_dev, ndraws, apply_transform=False, to_host=True):
-    """vgx_flatten_count + vgx_flatten_emit. draws_dev: uint8 torch tensor from upload_draws."""
+def flatten(ctx, pset, draws_dev, ndraws, apply_transform=False, to_host=True, entry=None):
+    """The flatten entry points. draws_dev: uint8 torch tensor from upload_draws.
+    entry "two_phase": vgx_flatten_count + vgx_flatten_emit; "one_walk": vgx_flatten into buffers of exactly the counted sizes;
+    "both" (default; VGX_FLATTEN_ENTRY overrides): the two-phase result, after checking that vgx_flatten produced the same
+    bytes -- polyline, sub-path records, per-draw records, totals -- so that every caller of this helper pins both entry points."""
+    import torch
+    entry = entry or os.environ.get("VGX_FLATTEN_ENTRY", "both")
+    if entry in ("one_walk", "both"):
+        r2 = _flatten_two_phase(ctx, pset, draws_dev, ndraws, apply_transform, to_host=False)
+        r1 = flatten_one_walk(ctx, pset, draws_dev, ndraws, apply_transform, cap_poly=r2.sizes["num_poly_vertices"], cap_subs=r2.sizes["num_subpaths"], to_host=to_host)
+        if entry == "both":
+            for k in ("num_poly_vertices", "num_subpaths", "num_meshes", "num_serial_draws", "num_cmd_instances"):
+                assert r1.sizes[k] == r2.sizes[k], ("vgx_flatten vs two-phase", k, r1.sizes[k], r2.sizes[k])
+            npv, nsp = r2.sizes["num_poly_vertices"], r2.sizes["num_subpaths"]
+            assert torch.equal(r1.poly_dev[:npv].view(torch.int32), r2.poly_dev[:npv].view(torch.int32)), "vgx_flatten: polyline differs from the two-phase entry"
+            assert torch.equal(r1.subs_dev[:nsp * 16], r2.subs_dev[:nsp * 16]), "vgx_flatten: sub-path records differ from the two-phase entry"
+            assert torch.equal(r1.dinfo_dev[:ndraws * 40], r2.dinfo_dev[:ndraws * 40]), "vgx_flatten: per-draw records differ from the two-phase entry"
+        return r1
+    return _flatten_two_phase(ctx, pset, draws_dev, ndraws, apply_transform, to_host)
+
+
+def _flatten_two_phase(ctx, pset, draws_dev, ndraws, apply_transform=False, to_host=True):
     import torch
     L = lib()
     sizes = capi.Sizes()
@@ -182,6 +202,62 @@ def flatten(ctx, pset, draws_dev, ndraws, apply_transform=False, to_host=True):
         r.poly = poly[:npv].cpu().numpy()
         r.subpaths = subs[:nsp * 16].cpu().numpy().view(capi.subpath_dtype)
         r.draw_info = dinfo[:ndraws * 40].cpu().numpy().view(capi.draw_info_dtype)
+    return r
+
+
+class FlatBuffers:
+    """Caller-owned output buffers of vgx_flatten in HBM (vgx_flat_out) + the device-side totals / status words."""
+
+    def __init__(self, device, npoly, nsubs, ndraws):
+        import torch
+        self.cap = (int(npoly), int(nsubs))
+        self.poly = torch.empty((max(int(npoly), 1), 2), dtype=torch.float32, device=device)
+        self.subs = torch.empty(max(int(nsubs), 1) * 16, dtype=torch.uint8, device=device)
+        self.dinfo = torch.empty(max(int(ndraws), 1) * 40, dtype=torch.uint8, device=device)
+        self.dev_sizes = torch.zeros(10, dtype=torch.int64, device=device)
+        self.dev_status = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def out_struct(self):
+        return capi.FlatOut(self.poly.data_ptr(), self.subs.data_ptr(), self.dinfo.data_ptr(), self.cap[0], self.cap[1])
+
+
+def flatten_async(ctx, pset, draws_dev, ndraws, bufs, apply_transform=False):
+    """vgx_flatten: the ordered one-walk flatten, single asynchronous call; totals / status land in bufs.dev_*."""
+    out = bufs.out_struct()
+    _check(lib().vgx_flatten(ctx.handle, pset.handle, draws_dev.data_ptr(), ndraws, int(apply_transform), C.byref(out),
+                             bufs.dev_sizes.data_ptr(), bufs.dev_status.data_ptr(), _stream_ptr()), "vgx_flatten")
+
+
+def flatten_one_walk(ctx, pset, draws_dev, ndraws, apply_transform=False, cap_poly=None, cap_subs=None, to_host=True):
+    """vgx_flatten into buffers of the given capacities (default: generous), results like `flatten`. Raises VgxError with the
+    device status when it is not VGX_OK (the sizes of the failed call stay available as `.sizes` on the exception)."""
+    import torch
+    dev = draws_dev.device
+    if cap_poly is None or cap_subs is None:
+        # sizes from the two-phase entry: callers that know their capacities pass them
+        z = capi.Sizes()
+        _check(lib().vgx_flatten_count(ctx.handle, pset.handle, draws_dev.data_ptr(), ndraws, C.byref(z), _stream_ptr()), "vgx_flatten_count")
+        cap_poly = int(z.num_poly_vertices) if cap_poly is None else cap_poly
+        cap_subs = int(z.num_subpaths) if cap_subs is None else cap_subs
+    bufs = FlatBuffers(dev, cap_poly, cap_subs, ndraws)
+    flatten_async(ctx, pset, draws_dev, ndraws, bufs, apply_transform)
+    torch.cuda.synchronize()
+    st = int(bufs.dev_status.item())
+    z = bufs.dev_sizes.cpu().numpy()
+    names = [k for k, _ in capi.Sizes._fields_]
+    sizes = {k: int(z[i]) for i, k in enumerate(names)}
+    if st != capi.VGX_OK:
+        e = VgxError(st, "vgx_flatten")
+        e.sizes = sizes
+        raise e
+    r = FlatResult()
+    r.sizes = sizes
+    r.poly_dev, r.subs_dev, r.dinfo_dev = bufs.poly, bufs.subs, bufs.dinfo
+    if to_host:
+        npv, nsp = sizes["num_poly_vertices"], sizes["num_subpaths"]
+        r.poly = bufs.poly[:npv].cpu().numpy()
+        r.subpaths = bufs.subs[:nsp * 16].cpu().numpy().view(capi.subpath_dtype)
+        r.draw_info = bufs.dinfo[:ndraws * 40].cpu().numpy().view(capi.draw_info_dtype)
     return r
 
 

@@ -68,7 +68,11 @@ struct vgx_ctx
 	DevBuf subPrefix; // exclusive scan of the draws' static sub-path counts
 	DevBuf cmdPrefix, cmdCnt, subFirst, leafOverflow, serialList, dinfo, poly, subs, mdesc, elemPrefix, elemPrefixS, mprep, mtab, partial, totals;
 	DevBuf f1SegDraw, f1Segs;            // vgx_flatten (vgx_flat1.hip): segment table, look-back records
-	int optF1Waves, optF1Cap;            // its grid (persistent one-wave workgroups) and the leaf-list capacity of the kernel instance (0 = chosen per batch)
+	int optF1Waves, optF1Cap, optF1Seg;  // its grid (persistent one-wave workgroups), the leaf-list capacity of the kernel instance and the segment bucket (0 = chosen per batch)
+	// what the last vgx_flatten call produced (copied to pinned memory behind the call, read by the next call WITHOUT waiting for
+	// it): polyline vertices per command instance decide how many commands a segment may hold before its leaves overflow the list
+	unsigned long long* hostF1;          // pinned: [0] vertices, [1] command instances, [2] tag of the batch they belong to
+	uint64_t f1Tag;
 	DevBuf gatherSizes;                  // vgx_gather_sizes: [nranks][4] uint64
 	DevBuf partBounds;                   // vgx_partition: [nparts + 1] bounds + [nparts] weights
 	struct VgxRccl* rccl;                // RCCL entry points, bound at the first vgx_gather* call
@@ -735,7 +739,8 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	if (const char* e = getenv("VGX_TMPL_TILE")) { const int v = atoi(e); if (v >= 64 && v <= VGX_TMPL_MAX_TILE) { ctx->optTmplTile = (uint32_t)v / 64u * 64u; } } // testing: elements per tile (<= the LDS stage of k_tmpl_emit)
 	ctx->optPoolWalk = 0; // VGX_WALK=pool: the wave-cooperative walk of vgx_walk.h (same output, same speed: DESIGN.md section 4)
 	if (const char* e = getenv("VGX_WALK")) { ctx->optPoolWalk = strcmp(e, "pool") == 0; }
-	ctx->optF1Waves = 0; ctx->optF1Cap = 0;
+	ctx->optF1Waves = 0; ctx->optF1Cap = 0; ctx->optF1Seg = 0;
+	if (const char* e = getenv("VGX_F1_SEG")) { const int v = atoi(e); if (v >= 2 && v <= 64) { ctx->optF1Seg = v; } }
 	if (const char* e = getenv("VGX_F1_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { ctx->optF1Waves = v; } }
 	if (const char* e = getenv("VGX_F1_CAP")) { ctx->optF1Cap = atoi(e); }
 	if (const char* e = getenv("VGX_BUILD_WAVES")) { const int v = atoi(e); if (v >= 1 && v < VGX_BUILD_WAVES) { ctx->optBuildWaves = v; } }
@@ -754,6 +759,7 @@ int vgx_destroy(vgx_ctx* ctx)
 		if (b->p) { (void)hipFree(b->p); }
 	}
 	if (ctx->hostTotals) { (void)hipHostFree(ctx->hostTotals); }
+	if (ctx->hostF1) { (void)hipHostFree(ctx->hostF1); }
 	vgx_rccl_release(ctx);
 	if (ctx->sideStream) { (void)hipStreamDestroy(ctx->sideStream); (void)hipEventDestroy(ctx->forkEv); (void)hipEventDestroy(ctx->joinEv); }
 	if (ctx->evCreated) {
@@ -1133,17 +1139,43 @@ int vgx_flatten(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint
 	int st;
 	if ((st = ensureDrawBuffers(ctx, ndraws)) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->serialList, (ndraws + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
-	// Segments: buckets of at least 32 command instances. The command total is not known on the host without a round trip;
-	// ndraws x (longest path) bounds it (a batch whose bound is absurdly far above its real size asks once, synchronously).
+	// Leaf-list capacity of the kernel instance and commands per segment bucket. A 64-command chunk of ~45-segment cubics stages
+	// ~1450 leaves (the 1664-entry instance: six waves per CU); lighter batches take the 1024-entry instance (eight waves per CU),
+	// heavier ones (long curves: 145 segments per cubic) the 3072-entry instance with smaller buckets, so that a chunk's leaves
+	// still fit (a chunk that overflows the list is placed by walking its cubics a second time). The batch's leaves per command are
+	// taken from the LAST call on this context with the same path set and draw count, when that call's result has arrived.
+	int cap = 1664; uint32_t segMax = 64;
+	const uint64_t tag = ps->gen * 0x9E3779B97F4A7C15ull + ndraws;
+	if (!ctx->hostF1) {
+		if (hipHostMalloc((void**)&ctx->hostF1, 4 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess) { ctx->hostF1[0] = 0; ctx->hostF1[1] = 0; ctx->hostF1[2] = 0; ctx->hostF1[3] = 0; }
+		else { ctx->hostF1 = nullptr; }
+	}
+	if (ctx->hostF1 && ctx->f1Tag == tag && ctx->hostF1[1] != 0 && ctx->hostF1[2] == tag) {
+		const double perCmd = (double)ctx->hostF1[0] / (double)ctx->hostF1[1];
+		if (perCmd * 64.0 <= 800.0) { cap = 1024; }
+		else if (perCmd * 64.0 > 1500.0) {
+			// long curves (145 segments per cubic at box 10 000): the 3072-entry instance with buckets of a power of two -- 2^k cubics
+			// become 64 tasks after whole rounds of cutting (17 cubics would stay at 34 half-cubic tasks). Measured on 1 M such
+			// cubics: 3072 entries x 32 commands 3.4 ms, 1664 x 16 4.1 ms, 1664 x 8 6.2 ms (two-phase entry: 6.0 ms).
+			cap = 3072;
+			const double m = 0.8 * 3072.0 / perCmd;
+			segMax = m >= 64.0 ? 64u : (m >= 32.0 ? 32u : (m >= 16.0 ? 16u : 8u));
+		}
+	}
+	if (ctx->optF1Cap) { cap = ctx->optF1Cap; }
+	if (ctx->optF1Seg) { segMax = (uint32_t)ctx->optF1Seg; }
+	// Segments: buckets of at least min(32, segMax) command instances. The command total is not known on the host without a round
+	// trip; ndraws x (longest path) bounds it (a batch whose bound is absurdly far above its real size asks once, synchronously).
+	const uint64_t minItems = segMax < 32 ? segMax : 32;
 	uint64_t cmdBound = ndraws * (uint64_t)(ps->maxCmdsPerPath ? ps->maxCmdsPerPath : 1);
 	ctx->caps.cmd_instances = ~0ull;
 	runCmdPrefix(ctx, ps, draws, ndraws, s);
-	if (cmdBound / 32 > (1ull << 26)) {
+	if (cmdBound / minItems > (1ull << 26)) {
 		if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
 		if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; }
 		cmdBound = ctx->hostTotals->sizes.num_cmd_instances;
 	}
-	const uint64_t segBound = cmdBound / 32 + 2;
+	const uint64_t segBound = cmdBound / minItems + 2;
 	if ((st = ensure(ctx, ctx->f1SegDraw, (segBound + 1) * sizeof(uint64_t))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->f1Segs, (segBound + segBound / 64 + 2) * sizeof(VgxF1Seg))) != VGX_OK) { return st; }
 	VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, apply_transform);
@@ -1153,13 +1185,11 @@ int vgx_flatten(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint
 	a.caps.poly_vertices = ~0ull; a.caps.subpaths = ~0ull; a.caps.meshes = ~0ull;
 	VgxF1Args x;
 	x.seg_draw = (uint64_t*)ctx->f1SegDraw.p; x.segs = (VgxF1Seg*)ctx->f1Segs.p; x.grps = x.segs + segBound;
-	x.cap_poly = out->cap_poly_vertices; x.cap_subs = out->cap_subpaths; x.pass = 0; x.read_flags = 0; x.has_empty = ps->hasEmpty ? 1 : 0;
+	x.cap_poly = out->cap_poly_vertices; x.cap_subs = out->cap_subpaths; x.pass = 0; x.read_flags = 0; x.has_empty = ps->hasEmpty ? 1 : 0; x.seg_max = segMax; x.tag = tag;
 	if (ps->hasSerial) { // statically serial paths: the exact builder counts their draws first (it marks them in dinfo)
 		noteHip(ctx, hipMemsetAsync(ctx->dinfo.p, 0, ndraws * sizeof(vgx_draw_info), s));
 		vgx_launch_flatten_serial(false, a, s);
 	}
-	// leaf-list capacity of the kernel instance: sized for 64 cubics of ~45 segments unless the caller knows better (VGX_F1_CAP)
-	const int cap = ctx->optF1Cap ? ctx->optF1Cap : 1664;
 	const int waves = ctx->optF1Waves ? ctx->optF1Waves : 2048;
 	vgx_launch_flat1(a, x, waves, cap, ps->hasSerial, s);
 	// draws of the exact builder: every draw is inspected when the set has serial paths, else only the draws the kernel listed
@@ -1168,6 +1198,13 @@ int vgx_flatten(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint
 	vgx_launch_flatten_serial(true, ae, s);
 	vgx_launch_flat1_publish(a, x, dev_sizes, dev_status, s);
 	mark(ctx, s, "flatten_one_walk");
+	if (ctx->hostF1) { // for the next call's choice of instance / bucket (never waited for)
+		VgxTotals* T = (VgxTotals*)ctx->totals.p;
+		ctx->f1Tag = tag;
+		noteHip(ctx, hipMemcpyAsync(&ctx->hostF1[0], &T->sizes.num_poly_vertices, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+		noteHip(ctx, hipMemcpyAsync(&ctx->hostF1[1], &T->sizes.num_cmd_instances, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+		noteHip(ctx, hipMemcpyAsync(&ctx->hostF1[2], &T->flat_tag, sizeof(unsigned long long), hipMemcpyDeviceToHost, s)); // the tag lands behind the two values
+	}
 	if (out->draw_info && ndraws) {
 		HIPCHK(ctx, hipMemcpyAsync(out->draw_info, ctx->dinfo.p, ndraws * sizeof(vgx_draw_info), hipMemcpyDeviceToDevice, s));
 	}

@@ -19,16 +19,19 @@ struct VgxF1Args
 	int pass;             // 0: the normal run; 1: the second run of a batch in which the first one found degenerate draws
 	int read_flags;       // dinfo[d].flags may already mark serial draws
 	int has_empty;        // the path set has paths without commands: their draws' records are written by the neighbours
+	unsigned long long tag; // identifies the batch (path set generation, draw count) in the host's copy of the totals
+	uint32_t seg_max;     // command instances per segment bucket at most (64; less for batches whose chunks would overflow the leaf list)
 };
 
 // Command instances per segment bucket. Draws are bucketed whole by their FIRST command instance, so a segment is longer than
 // its bucket by what its last draw hangs over: buckets of 64 minus the mean draw length keep most segments inside ONE 64-command
 // chunk (one walk); paths of one or two commands (a million moveTo + cubicTo pairs) fill the chunk exactly.
-__host__ __device__ inline uint64_t vgx_f1_segment_items(uint64_t totalCmds, uint64_t ndraws)
+__host__ __device__ inline uint64_t vgx_f1_segment_items(uint64_t totalCmds, uint64_t ndraws, uint32_t segMax)
 {
 	const uint64_t avg = totalCmds / (ndraws ? ndraws : 1);
-	if (avg <= 2) { return 64; }
-	return avg >= 32 ? 32 : 64 - avg;
+	uint64_t s = avg <= 2 ? 64 : (avg >= 32 ? 32 : 64 - avg);
+	if (segMax >= 2 && s > segMax) { s = segMax; }
+	return s;
 }
 
 // Private-memory pending stack for the exact serial builder (k_f1_serial_count_list only; k_flat1 itself has no scratch).

@@ -47,12 +47,16 @@ __device__ unsigned long long g_f1_dbg_n = 0;
 #define F1_CLK() ((unsigned long long)clock64())
 #define F1_ACC(i, v) (prof##i += (v))
 #else
-#define F1_DBG(t, i, v) ((void)0)
+#define F1_DBG(t, i, v) ((void)(v))
 #define F1_WALL() 0ull
 #define F1_CLK() 0ull
 #define F1_ACC(i, v) ((void)(v))
 #endif
 
+// Registers: the leaf list leaves room for 1.5 waves per SIMD; the kernel must not need more registers than two waves per SIMD get.
+#ifndef F1_MIN_WAVES_PER_EU
+#define F1_MIN_WAVES_PER_EU 2
+#endif
 #ifndef VGX_F1_LV
 #define VGX_F1_LV 6 /* pending right halves per lane kept in LDS by the hot loop; a task that nests deeper is redone with all 10 */
 #endif
@@ -135,6 +139,53 @@ __device__ __forceinline__ void f1_sum2(uint64_t v, uint64_t sm, uint64_t* av, u
 	*am += wave_sum_u64(sm & (F1_SM_LIMIT - 1));
 }
 
+// ---- the NEXT segment's front, requested while this segment waits for its place ---------------------------------------------
+// A segment's first four memory round trips (ticket -> segment table -> command prefix / draw window -> the window's paths) as a
+// little state machine, one dependent stage per call. Two ways of running it in the shadow of the previous segment were measured
+// and NOT kept: (a) one stage per poll of the look-back -- a ticket taken before the look-back's wait is worked on only after that
+// wait, whose length varies from wave to wave, so the segment arrives late for its place in the order and the waves behind it
+// wait even longer: 0.90 -> 1.66 ms; (b) one stage every other step of the placement loop -- every commit waits for the
+// scattered stores issued before it (vmcnt counts loads and stores in order): placement 13 600 -> 31 000 cycles per segment,
+// 0.90 -> 1.07 ms. The stages run back to back at the top of a segment.
+struct F1Next
+{
+	uint32_t stage;   // 0 nothing; 1 ticket taken; 2 + segment table; 3 + command prefix and the window's prefix / path; 4 complete
+	unsigned long long t;
+	uint64_t d0, d1, C0, C1;
+	DrawWindow W;     // window over draws [d0, d0 + 64)
+	uint32_t wpath;
+};
+
+struct F1NextRaw { unsigned long long a, b, c; uint32_t u, v; };
+
+// issue the loads of the next stage (nothing of their results is used here)
+__device__ __forceinline__ F1NextRaw f1_next_issue(const F1Next& N, const VgxFlattenArgs& A, const VgxF1Args& X, VgxTotals* T, int lane, uint64_t numSegments)
+{
+	F1NextRaw R; R.a = 0; R.b = 0; R.c = 0; R.u = 0; R.v = 0;
+	if (N.stage == 0) {
+		if (lane == 0) { R.a = atomicAdd(&T->flat_ticket, 1ull); }
+	} else if (N.stage == 1) {
+		if (N.t < numSegments) { R.a = X.seg_draw[N.t]; R.b = X.seg_draw[N.t + 1]; }
+	} else if (N.stage == 2) {
+		if (N.d0 < N.d1) { R.a = A.cmd_prefix[N.d0]; R.b = A.cmd_prefix[N.d1]; }
+		const uint64_t idx = N.d0 + (uint64_t)lane;
+		R.c = (idx <= A.ndraws) ? A.cmd_prefix[idx] : ~0ull;
+		if (idx < A.ndraws) { R.u = A.draws[idx].path; }
+	} else if (N.stage == 3) {
+		const uint64_t idx = N.d0 + (uint64_t)lane;
+		if (idx < A.ndraws) { R.u = A.ps.path_cmd_begin[N.wpath]; R.v = A.ps.path_flags[N.wpath] & VGX_PF_SERIAL; }
+	}
+	return R;
+}
+
+__device__ __forceinline__ void f1_next_commit(F1Next& N, const F1NextRaw& R, uint64_t numSegments)
+{
+	if (N.stage == 0) { N.t = wave_bcast_u64(R.a, 0); N.stage = N.t < numSegments ? 1u : 4u; }
+	else if (N.stage == 1) { N.d0 = R.a; N.d1 = R.b; N.C0 = 0; N.C1 = 0; N.stage = 2; }
+	else if (N.stage == 2) { if (N.d0 < N.d1) { N.C0 = R.a; N.C1 = R.b; } N.W.prefix = R.c; N.wpath = R.u; N.W.pc0 = 0; N.W.serial = 0; N.stage = 3; }
+	else if (N.stage == 3) { N.W.pc0 = R.u; N.W.serial = R.v; N.stage = 4; }
+}
+
 // myV / myS / myM: the segment's own totals (already published as A(t)); lastOfGroup: this wave also publishes the group records.
 // A record that was seen published is not read again: a waiting wave re-reads only what it still waits for (1300 waves re-reading
 // their whole windows every microsecond made the few memory channels that hold the live records the bottleneck of the kernel).
@@ -215,7 +266,7 @@ struct F1Lds
 	unsigned short tag[CAP + 8];
 	uint2 tinfo[VGX_WAVE];
 };
-static_assert(F1_PARAM_WORDS * VGX_WAVE * 4 <= 512 * 8, "the task records alias the leaf list");
+static_assert(2 * F1_PARAM_WORDS * VGX_WAVE * 4 <= 1024 * 8, "the two task-record buffers alias the leaf list");
 
 // One task walk per lane. Same arithmetic as build_flatten_hot (vgx_walk.h) = path.cpp:105-129; leaves go to the shared list
 // when `stage`. Returns the number of list entries the wave appended in total (it may exceed CAP: nothing is stored past it).
@@ -294,7 +345,7 @@ __device__ __forceinline__ uint32_t f1_task_walk(F1Lds<CAP>& L, int lane, bool a
 }
 
 template<int CAP, bool XFORM>
-__global__ __launch_bounds__(VGX_WAVE) void k_flat1(VgxFlattenArgs A, VgxF1Args X)
+__global__ __launch_bounds__(VGX_WAVE, (CAP > 2048 ? 1 : F1_MIN_WAVES_PER_EU)) void k_flat1(VgxFlattenArgs A, VgxF1Args X)
 {
 	__shared__ __attribute__((aligned(16))) F1Lds<CAP> L;
 	const int lane = threadIdx.x;
@@ -302,13 +353,15 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flat1(VgxFlattenArgs A, VgxF1Args 
 	VgxTotals* T = A.totals;
 	if (X.pass == 1 && T->flat_redo == 0u) { return; } // the second run is only for batches in which the first found degenerate draws
 	const uint64_t totalCmds = A.cmd_prefix[A.ndraws];
-	const uint64_t segItems = vgx_f1_segment_items(totalCmds, A.ndraws);
+	const uint64_t segItems = vgx_f1_segment_items(totalCmds, A.ndraws, X.seg_max);
 	const uint64_t numSegments = (totalCmds + segItems - 1) / segItems;
 	const bool readFlags = X.read_flags != 0; // some draws may already be marked serial in dinfo (static serial paths counted up front / pass 1)
 
 	uint64_t wbase = 0;
 	DrawWindow W;
 	W.prefix = ~0ull; W.pc0 = 0; W.serial = 0;
+	F1Next N;
+	N.stage = 0; N.t = 0; N.d0 = 0; N.d1 = 0; N.C0 = 0; N.C1 = 0; N.W = W; N.wpath = 0;
 #ifdef VGX_F1_PROFILE
 	unsigned long long prof0 = 0, prof1 = 0, prof2 = 0, prof3 = 0, prof4 = 0, prof5 = 0, prof6 = 0, prof7 = 0, prof8 = 0;
 #define F1_FLUSH() do { if (lane == 0) { atomicAdd(&T->prof[0], prof0); atomicAdd(&T->prof[1], prof1); atomicAdd(&T->prof[2], prof2); atomicAdd(&T->prof[3], prof3); \
@@ -320,17 +373,18 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flat1(VgxFlattenArgs A, VgxF1Args 
 	for (;;) {
 		// ---- next segment ---------------------------------------------------------------------------------------------
 		const unsigned long long c0 = F1_CLK();
-		unsigned long long t = 0;
-		if (lane == 0) { t = atomicAdd(&T->flat_ticket, 1ull); }
-		t = wave_bcast_u64(t, 0);
+		const unsigned long long w0 = F1_WALL();
+		while (N.stage < 4) { // what the last segment's wait did not cover (all of it for the wave's first segment)
+			const F1NextRaw NR = f1_next_issue(N, A, X, T, lane, numSegments);
+			f1_next_commit(N, NR, numSegments);
+		}
+		const unsigned long long t = N.t;
 		if (t >= numSegments) { F1_FLUSH(); return; }
-		F1_DBG(t, 0, F1_WALL());
-		F1_DBG(t, 3, (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)blockIdx.x << 32)); // HW_ID
-		if (f1_fatal(__hip_atomic_load(&T->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { return; } // an error anywhere ends the call (nobody waits for us: they see it too)
-		const uint64_t d0 = X.seg_draw[t];
-		const uint64_t d1 = X.seg_draw[t + 1];
-		uint64_t C0 = 0, C1 = 0;
-		if (d0 < d1) { C0 = A.cmd_prefix[d0]; C1 = A.cmd_prefix[d1]; }
+		F1_DBG(t, 0, w0);
+		if (f1_fatal(__hip_atomic_load(&T->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { F1_FLUSH(); return; } // an error anywhere ends the call (nobody waits for us: they see it too)
+		const uint64_t d0 = N.d0, d1 = N.d1, C0 = N.C0, C1 = N.C1;
+		const DrawWindow W0 = N.W;
+		N.stage = 0; // the next front starts in this segment's look-back
 		const bool single = C1 - C0 <= (uint64_t)VGX_WAVE;
 		const bool lastOfGroup = (t & 63ull) == 63ull || t + 1 == numSegments; // this wave publishes the group's records
 		long long totV = 0; uint64_t totS = 0, totM = 0;   // the segment's totals
@@ -342,7 +396,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flat1(VgxFlattenArgs A, VgxF1Args 
 			long long runV = 0; uint64_t runS = 0, runM = 0;  // placed in front of the current chunk, inside the segment
 			uint64_t dcur = d0;
 			int carryDrawVerts = 0, carrySpVerts = 0, carrySubs = 0, carryFill = 0, carryStroke = 0, carrySlow = 0, carrySpExists = 0;
-			wbase = d0; W = draw_window_load(A, wbase, lane); // (tickets are not consecutive per wave: nothing to keep from the last segment)
+			wbase = d0; W = W0; // the window over the segment's first draws came with the segment's front
 
 			for (uint64_t chunk = C0; chunk < C1 || (chunk == C0 && !published && pass == 1); chunk += VGX_WAVE) {
 				const uint64_t ci = chunk + lane;
@@ -371,9 +425,8 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flat1(VgxFlattenArgs A, VgxF1Args 
 				VgxCmdRec rec;
 				rec.type = VGX_CMD_CLOSE; rec.flags = 0; rec.na = 0; rec.arg_off = 0; rec.start[0] = 0.0f; rec.start[1] = 0.0f;
 				for (int i = 0; i < 8; ++i) { rec.a[i] = 0.0f; }
-				vgx_draw_info serialInfo;
-				serialInfo.first_poly_vertex = 0; serialInfo.first_subpath = 0; serialInfo.first_mesh = 0;
-				serialInfo.num_poly_vertices = 0; serialInfo.num_subpaths = 0; serialInfo.num_meshes = 0; serialInfo.flags = 0;
+				uint32_t serV = 0, serS = 0, serM = 0, serF = 0; // a serial draw's counts (k_flatten_serial<count>), at its last command
+				uint32_t recIndex = 0;
 				if (valid) {
 					if (windowCovers) {
 						d = wbase + (uint64_t)ownerOfs;
@@ -386,7 +439,8 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flat1(VgxFlattenArgs A, VgxF1Args 
 					}
 					dr = A.draws + d;
 					const uint32_t k = (uint32_t)(ci - ownerBase);
-					rec = ps.cmdrec[pc0 + k];
+					recIndex = pc0 + k;
+					rec = ps.cmdrec[recIndex];
 					type = rec.type; cflags = rec.flags; na = rec.na;
 					drawHead = (k == 0);
 					drawLast = (cflags & VGX_CF_LAST_IN_PATH) != 0;
@@ -396,13 +450,28 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flat1(VgxFlattenArgs A, VgxF1Args 
 					if (readFlags) {
 						const uint32_t fl = A.dinfo[d].flags;
 						serialDraw = serialDraw || (fl & 1u) != 0;
-						if (serialDraw && drawLast) { serialInfo = A.dinfo[d]; } // counted by k_flatten_serial: the draw is one opaque block here
+						if (serialDraw && drawLast) { // counted by k_flatten_serial: the draw is one opaque block here
+							const vgx_draw_info si = A.dinfo[d];
+							serV = si.num_poly_vertices; serS = si.num_subpaths; serM = si.num_meshes; serF = si.flags;
+						}
 					}
 				}
 				const float* a = rec.a;
 				const float* pa = ps.args + rec.arg_off;
 				const float* mtx = dr->mtx;
 				const V2 start = v2(rec.start[0], rec.start[1]);
+				// what the phases behind the walk need of the command record, so that the record itself does not stay in registers
+				// across the walk (the kernel must fit two waves per SIMD): the point of a MOVE_TO / LINE_TO, and the two epsilon
+				// tests of pathClose (path.cpp:716-722) -- my end point against the sub-path's first point (a[6..7] of every record)
+				const float ptx = a[0], pty = a[1];
+				bool endNearFirst = false, startNearFirst = false, lineSlow = false;
+				if (valid) {
+					const V2 firstPt = v2(rec.a[6], rec.a[7]);
+					const V2 endp = (type == VGX_CMD_POLYLINE) ? (na >= 2 ? v2(pa[na - 2], pa[na - 1]) : v2(0.0f, 0.0f)) : (type == VGX_CMD_CUBIC_TO ? v2(a[4], a[5]) : (type == VGX_CMD_QUAD_TO ? v2(a[2], a[3]) : v2(a[0], a[1])));
+					endNearFirst = (cflags & VGX_CF_NEXT_IS_CLOSE) != 0 && v2near(endp, firstPt);
+					startNearFirst = v2near(start, firstPt);
+					lineSlow = v2near(start, v2(a[0], a[1]));
+				}
 
 				// ---- tasks: the chunk's cubics, compacted; non-flat roots cut in two while lanes are free ----------------
 				float c1x = a[0], c1y = a[1], c2x = a[2], c2y = a[3], ex = a[4], ey = a[5];
@@ -414,60 +483,74 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flat1(VgxFlattenArgs A, VgxF1Args 
 				const float tessTol = tol / (scale * scale);
 				const uint64_t cubicMask = wave_ballot(isCubic);
 				const unsigned long long c1 = F1_CLK();
+				if (chunk == C0) { F1_DBG(t, 3, F1_WALL() | ((unsigned long long)blockIdx.x << 40)); }
 				F1_ACC(0, c1 - (chunk == C0 && (pass == 1) == single ? c0 : c1)); // ticket + segment table + draw window + command records (first chunk of a segment)
 				F1_ACC(6, 1ull);
 				int cnt = 0;
 				bool slow = false, exists = false, closedHere = false, deep = false;
-				uint32_t listN = 0, myTask0 = 0, k0 = 0, k1 = 0;
-				bool split = false;
+				uint32_t listN = 0, myTask0 = 0, myTasks = 0;
 				if (cubicMask) { // wave-uniform
-					v2f R1, R2, R3, R4;
-					R1.x = start.x; R1.y = start.y; R2.x = c1x; R2.y = c1y; R3.x = c2x; R3.y = c2y; R4.x = ex; R4.y = ey;
-					// root step by the owner (path.cpp:105-129): decides who is cut in two
-					const v2f rd = R4 - R1;
-					const v2f ra2 = R2 - R4, ra3 = R3 - R4;
-					const v2f rsw = rd.yx;
-					const v2f rm2 = ra2 * rsw, rm3 = ra3 * rsw;
-					const float rd2 = __builtin_fabsf(rm2.x - rm2.y), rd3 = __builtin_fabsf(rm3.x - rm3.y);
-					const float rd23 = rd2 + rd3;
-					const v2f rdd = rd * rd;
-					const bool rootFlat = rd23 * rd23 <= tessTol * (rdd.x + rdd.y);
-					const v2f R12 = (R1 + R2) * 0.5f, R23 = (R2 + R3) * 0.5f, R34 = (R3 + R4) * 0.5f;
-					const v2f R123 = (R12 + R23) * 0.5f, R234 = (R23 + R34) * 0.5f;
-					const v2f R1234 = (R123 + R234) * 0.5f;
-					const int C = __popcll(cubicMask);
-					const uint64_t nfMask = wave_ballot(isCubic && !rootFlat);
-					const int NF = __popcll(nfMask);
-					const int S = NF < VGX_WAVE - C ? NF : VGX_WAVE - C; // cubics that are cut: the first S with a non-flat root
-					const int r = __popcll(cubicMask & lanemask_lt(lane));
-					const int nfr = __popcll(nfMask & lanemask_lt(lane));
-					split = isCubic && !rootFlat && nfr < S;
-					myTask0 = (uint32_t)(r + (nfr < S ? nfr : S));
-					const int numTasks = C + S;
-					float* prm = (float*)L.list; // [F1_PARAM_WORDS][64]
+					// ---- task records: every cubic starts as one task; while at most half of the lanes hold a task, every task whose
+					// node is not flat is cut in two (path.cpp:105-129, the walk's own step) -- 32 cubics become 64 tasks in one round,
+					// a lone 145-segment cubic 64 tasks in six. The records live in the (still empty) leaf list, two buffers.
+					float* prmA = (float*)L.list;                       // [F1_PARAM_WORDS][64]
+					float* prmB = prmA + F1_PARAM_WORDS * VGX_WAVE;
+					int numTasks = __popcll(cubicMask);
 					if (isCubic) {
-						const uint32_t t0 = myTask0;
-						if (split) {
-							prm[0 * 64 + t0] = R1.x; prm[1 * 64 + t0] = R1.y; prm[2 * 64 + t0] = R12.x; prm[3 * 64 + t0] = R12.y;
-							prm[4 * 64 + t0] = R123.x; prm[5 * 64 + t0] = R123.y; prm[6 * 64 + t0] = R1234.x; prm[7 * 64 + t0] = R1234.y;
-							prm[8 * 64 + t0] = tessTol;
-							prm[0 * 64 + t0 + 1] = R1234.x; prm[1 * 64 + t0 + 1] = R1234.y; prm[2 * 64 + t0 + 1] = R234.x; prm[3 * 64 + t0 + 1] = R234.y;
-							prm[4 * 64 + t0 + 1] = R34.x; prm[5 * 64 + t0 + 1] = R34.y; prm[6 * 64 + t0 + 1] = R4.x; prm[7 * 64 + t0 + 1] = R4.y;
-							prm[8 * 64 + t0 + 1] = tessTol;
-						} else {
-							prm[0 * 64 + t0] = R1.x; prm[1 * 64 + t0] = R1.y; prm[2 * 64 + t0] = R2.x; prm[3 * 64 + t0] = R2.y;
-							prm[4 * 64 + t0] = R3.x; prm[5 * 64 + t0] = R3.y; prm[6 * 64 + t0] = R4.x; prm[7 * 64 + t0] = R4.y;
-							prm[8 * 64 + t0] = tessTol;
-						}
+						const int r = __popcll(cubicMask & lanemask_lt(lane));
+						prmA[0 * 64 + r] = start.x; prmA[1 * 64 + r] = start.y; prmA[2 * 64 + r] = c1x; prmA[3 * 64 + r] = c1y;
+						prmA[4 * 64 + r] = c2x; prmA[5 * 64 + r] = c2y; prmA[6 * 64 + r] = ex; prmA[7 * 64 + r] = ey;
+						prmA[8 * 64 + r] = tessTol; prmA[9 * 64 + r] = __int_as_float(lane);
 					}
 					__syncthreads(); // one-wave workgroup: LDS wait only
-					const bool taskActive = lane < numTasks;
-					v2f Q1, Q2, Q3, Q4; float qtol = 1.0f;
+					v2f Q1, Q2, Q3, Q4; float qtol = 1.0f; int qown = 0;
 					Q1.x = 0.0f; Q1.y = 0.0f; Q2 = Q1; Q3 = Q1; Q4 = Q1;
-					if (taskActive) {
-						Q1.x = prm[0 * 64 + lane]; Q1.y = prm[1 * 64 + lane]; Q2.x = prm[2 * 64 + lane]; Q2.y = prm[3 * 64 + lane];
-						Q3.x = prm[4 * 64 + lane]; Q3.y = prm[5 * 64 + lane]; Q4.x = prm[6 * 64 + lane]; Q4.y = prm[7 * 64 + lane];
-						qtol = prm[8 * 64 + lane];
+					for (;;) {
+						const bool ta = lane < numTasks;
+						if (ta) {
+							Q1.x = prmA[0 * 64 + lane]; Q1.y = prmA[1 * 64 + lane]; Q2.x = prmA[2 * 64 + lane]; Q2.y = prmA[3 * 64 + lane];
+							Q3.x = prmA[4 * 64 + lane]; Q3.y = prmA[5 * 64 + lane]; Q4.x = prmA[6 * 64 + lane]; Q4.y = prmA[7 * 64 + lane];
+							qtol = prmA[8 * 64 + lane]; qown = __float_as_int(prmA[9 * 64 + lane]);
+						}
+						if (numTasks > VGX_WAVE / 2) { break; }
+						const v2f rd = Q4 - Q1;
+						const v2f ra2 = Q2 - Q4, ra3 = Q3 - Q4;
+						const v2f rsw = rd.yx;
+						const v2f rm2 = ra2 * rsw, rm3 = ra3 * rsw;
+						const float rd2 = __builtin_fabsf(rm2.x - rm2.y), rd3 = __builtin_fabsf(rm3.x - rm3.y);
+						const float rd23 = rd2 + rd3;
+						const v2f rdd = rd * rd;
+						const bool nf = ta && !(rd23 * rd23 <= qtol * (rdd.x + rdd.y));
+						const uint64_t nfMask = wave_ballot(nf);
+						if (!nfMask) { break; }
+						const v2f R12 = (Q1 + Q2) * 0.5f, R23 = (Q2 + Q3) * 0.5f, R34 = (Q3 + Q4) * 0.5f;
+						const v2f R123 = (R12 + R23) * 0.5f, R234 = (R23 + R34) * 0.5f;
+						const v2f R1234 = (R123 + R234) * 0.5f;
+						const int ni = lane + __popcll(nfMask & lanemask_lt(lane));
+						if (ta) {
+							const float ownf = __int_as_float(qown);
+							if (nf) {
+								prmB[0 * 64 + ni] = Q1.x; prmB[1 * 64 + ni] = Q1.y; prmB[2 * 64 + ni] = R12.x; prmB[3 * 64 + ni] = R12.y;
+								prmB[4 * 64 + ni] = R123.x; prmB[5 * 64 + ni] = R123.y; prmB[6 * 64 + ni] = R1234.x; prmB[7 * 64 + ni] = R1234.y;
+								prmB[8 * 64 + ni] = qtol; prmB[9 * 64 + ni] = ownf;
+								prmB[0 * 64 + ni + 1] = R1234.x; prmB[1 * 64 + ni + 1] = R1234.y; prmB[2 * 64 + ni + 1] = R234.x; prmB[3 * 64 + ni + 1] = R234.y;
+								prmB[4 * 64 + ni + 1] = R34.x; prmB[5 * 64 + ni + 1] = R34.y; prmB[6 * 64 + ni + 1] = Q4.x; prmB[7 * 64 + ni + 1] = Q4.y;
+								prmB[8 * 64 + ni + 1] = qtol; prmB[9 * 64 + ni + 1] = ownf;
+							} else {
+								prmB[0 * 64 + ni] = Q1.x; prmB[1 * 64 + ni] = Q1.y; prmB[2 * 64 + ni] = Q2.x; prmB[3 * 64 + ni] = Q2.y;
+								prmB[4 * 64 + ni] = Q3.x; prmB[5 * 64 + ni] = Q3.y; prmB[6 * 64 + ni] = Q4.x; prmB[7 * 64 + ni] = Q4.y;
+								prmB[8 * 64 + ni] = qtol; prmB[9 * 64 + ni] = ownf;
+							}
+						}
+						numTasks += __popcll(nfMask);
+						__syncthreads();
+						float* sw = prmA; prmA = prmB; prmB = sw;
+					}
+					const bool taskActive = lane < numTasks;
+					// first task of every owner -> tinfo[owner].y (tasks are in owner order)
+					{
+						const uint32_t prevOwn = wave_from_prev_u32((uint32_t)qown, 0xFFFFFFFFu);
+						if (taskActive && (lane == 0 || prevOwn != (uint32_t)qown)) { L.tinfo[qown].y = (uint32_t)lane; }
 					}
 					__syncthreads(); // the records are read: the list may take leaves
 					uint32_t kT = 0; bool slowT = false, abortT = false;
@@ -476,15 +559,18 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flat1(VgxFlattenArgs A, VgxF1Args 
 #else
 					listN = f1_task_walk<CAP>(L, lane, taskActive, Q1, Q2, Q3, Q4, qtol, stage, &kT, &slowT, &abortT);
 #endif
-					L.tinfo[lane] = make_uint2(kT | (slowT ? F1_TF_SLOW : 0u) | (abortT ? F1_TF_ABORT : 0u), 0u);
+					L.tinfo[lane].x = kT | (slowT ? F1_TF_SLOW : 0u) | (abortT ? F1_TF_ABORT : 0u);
 					__syncthreads();
 					if (isCubic) {
-						const uint32_t i0 = L.tinfo[myTask0].x;
-						const uint32_t i1 = split ? L.tinfo[myTask0 + 1].x : 0u;
-						k0 = i0 & 0xFFFFFFu; k1 = i1 & 0xFFFFFFu;
-						cnt = (int)(k0 + k1);
-						slow = ((i0 | i1) & F1_TF_SLOW) != 0;
-						deep = ((i0 | i1) & F1_TF_ABORT) != 0;
+						const uint64_t later = cubicMask & ~lanemask_le(lane);
+						myTask0 = L.tinfo[lane].y;
+						const uint32_t t1 = later ? L.tinfo[__builtin_ctzll(later)].y : (uint32_t)numTasks;
+						myTasks = t1 - myTask0;
+						uint32_t sum = 0, fl = 0;
+						for (uint32_t j = 0; j < myTasks; ++j) { const uint32_t w = L.tinfo[myTask0 + j].x; sum += w & 0xFFFFFFu; fl |= w; }
+						cnt = (int)sum;
+						slow = (fl & F1_TF_SLOW) != 0;
+						deep = (fl & F1_TF_ABORT) != 0;
 					}
 					// cubics a task gave up on: counted by the owner with the full-depth walk, 32 owners at a time (two stack columns each)
 					uint64_t deepMask = wave_ballot(deep);
@@ -511,6 +597,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flat1(VgxFlattenArgs A, VgxF1Args 
 				if (g_f1_dbg && t < g_f1_dbg_n) { // flags of the timeline record: a cubic took the full-depth redo / the list overflowed
 					const unsigned long long fl = (wave_ballot(deep) ? (1ull << 63) : 0ull) | ((stage && !staged) ? (1ull << 62) : 0ull);
 					if (lane == 0 && fl) { atomicOr(&g_f1_dbg[t * 4 + 3], fl); }
+					if (lane == 0 && stage) { atomicOr(&g_f1_dbg[t * 4 + 3], (unsigned long long)(listN & 0xFFFu) << 50); } // leaves of the chunk (12 bits)
 				}
 #endif
 				const unsigned long long c2 = F1_CLK();
@@ -518,7 +605,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flat1(VgxFlattenArgs A, VgxF1Args 
 				if (valid && !serialDraw) {
 					switch (type) {
 					case VGX_CMD_MOVE_TO: cnt = 1; exists = true; break;
-					case VGX_CMD_LINE_TO: cnt = 1; slow = v2near(start, v2(a[0], a[1])); break;
+					case VGX_CMD_LINE_TO: cnt = 1; slow = lineSlow; break;
 					case VGX_CMD_POLYLINE: {
 						const uint32_t npts = na >> 1;
 						cnt = (int)npts - ((npts > 0 && v2near(start, v2(pa[0], pa[1]))) ? 1 : 0);
@@ -539,11 +626,11 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flat1(VgxFlattenArgs A, VgxF1Args 
 					const int spBefore1 = seg_rel(incl1 - cnt, sh, carrySpVerts);
 					if (valid && !serialDraw && type == VGX_CMD_CLOSE && spBefore1 > 2) { // pathClose, path.cpp:707-726
 						closedHere = true;
-						if (v2near(start, v2(rec.a[6], rec.a[7]))) { cnt = -1; }
+						if (startNearFirst) { cnt = -1; }
 					}
 				}
 				const bool serialTail = valid && serialDraw && drawLast; // carries the whole serial draw's counts
-				const int cntAll = serialTail ? (int)serialInfo.num_poly_vertices : cnt;
+				const int cntAll = serialTail ? (int)serV : cnt;
 				const int incl = wave_incl_scan(cntAll, lane);
 				const int excl = incl - cntAll;
 				const int inDrawBefore = seg_rel(excl, dh, carryDrawVerts);
@@ -563,8 +650,8 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flat1(VgxFlattenArgs A, VgxF1Args 
 				const uint64_t slowMask = wave_ballot(valid && slow);
 				const bool slowDraw = ((slowMask & mine) != 0) || (dh < 0 && carrySlow);
 				// sub-paths / meshes in front of me inside the chunk (serial draws count as blocks at their last command)
-				const int subAll = serialTail ? (int)serialInfo.num_subpaths : (exists ? 1 : 0);
-				const int meshAll = serialTail ? (int)serialInfo.num_meshes : ((fillHere ? 1 : 0) + (strokeHere ? 1 : 0));
+				const int subAll = serialTail ? (int)serS : (exists ? 1 : 0);
+				const int meshAll = serialTail ? (int)serM : ((fillHere ? 1 : 0) + (strokeHere ? 1 : 0));
 				const int subInclC = wave_incl_scan(subAll, lane);
 				const int meshInclC = wave_incl_scan(meshAll, lane);
 
@@ -627,20 +714,20 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flat1(VgxFlattenArgs A, VgxF1Args 
 						// ---- place --------------------------------------------------------------------------------------
 						const long long gl = (long long)baseV + runV + (long long)excl; // output index of my first vertex
 						uint32_t limit = (valid && !serialDraw) ? (uint32_t)(rawCnt < 0 ? 0 : rawCnt) : 0u;
-						if ((cflags & VGX_CF_NEXT_IS_CLOSE) && limit > 0 && spTotal > 2) { // my last vertex is the one pathClose removes
-							const V2 endp = (type == VGX_CMD_POLYLINE) ? v2(pa[na - 2], pa[na - 1]) : (type == VGX_CMD_CUBIC_TO ? v2(a[4], a[5]) : (type == VGX_CMD_QUAD_TO ? v2(a[2], a[3]) : v2(a[0], a[1])));
-							if (v2near(endp, v2(rec.a[6], rec.a[7]))) { --limit; }
-						}
+						if (endNearFirst && limit > 0 && spTotal > 2) { --limit; } // my last vertex is the one pathClose removes
 						float* out = A.poly + 2 * gl;
 						if (cubicMask) {
 							if (staged) {
 								// per task: place relative to the chunk's first vertex (+ 64: a pathClose pop makes excl -1 at most), limit, owner lane
 								if (isCubic) {
-									const uint32_t pl = (uint32_t)(excl + 64);
-									const uint32_t l0 = deep ? 0u : (limit < k0 ? limit : k0);
+									uint32_t pl = (uint32_t)(excl + 64), left = deep ? 0u : limit;
 									const uint32_t own = (uint32_t)lane << 24; // a task has at most 2^10 leaves: the limit leaves room for the owner's lane
-									L.tinfo[myTask0] = make_uint2(pl, l0 | own);
-									if (split) { L.tinfo[myTask0 + 1] = make_uint2(pl + k0, (deep ? 0u : (limit > k0 ? limit - k0 : 0u)) | own); }
+									for (uint32_t j = 0; j < myTasks; ++j) {
+										const uint32_t kj = L.tinfo[myTask0 + j].x & 0xFFFFFFu;
+										const uint32_t lj = left < kj ? left : kj;
+										L.tinfo[myTask0 + j] = make_uint2(pl, lj | own);
+										pl += kj; left -= lj;
+									}
 								}
 								__syncthreads();
 								float2* obase = (float2*)A.poly + ((long long)baseV + runV - 64);
@@ -668,7 +755,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flat1(VgxFlattenArgs A, VgxF1Args 
 						if (valid && !serialDraw) {
 							if (type == VGX_CMD_MOVE_TO || type == VGX_CMD_LINE_TO) {
 								if (limit > 0) {
-									V2 p = v2(a[0], a[1]);
+									V2 p = v2(ptx, pty);
 									if (XFORM) { p = v2xform(p, mtx); }
 									*(float2*)out = make_float2(p.x, p.y);
 								}
@@ -689,11 +776,17 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flat1(VgxFlattenArgs A, VgxF1Args 
 								const int ar = __popcll(againMask & lanemask_lt(lane));
 								const bool me = isCubic && (!staged || deep) && ar < 32 && ((againMask >> lane) & 1ull);
 								if (me) {
+									const VgxCmdRec rr = ps.cmdrec[recIndex]; // (read again: rare path, and the record is not kept across the walk)
+									float q1x = rr.a[0], q1y = rr.a[1], q2x = rr.a[2], q2y = rr.a[3], qex = rr.a[4], qey = rr.a[5];
+									if (rr.type == VGX_CMD_QUAD_TO) {
+										qex = rr.a[2]; qey = rr.a[3];
+										vgx_quad_to_cubic(rr.start[0], rr.start[1], rr.a[0], rr.a[1], qex, qey, &q1x, &q1y, &q2x, &q2y);
+									}
 									LdsStack2<VGX_F1_LV> st2;
 									st2.a = &L.stack[2 * ar]; st2.b = &L.stack[2 * ar + 1];
 									FastCubicSink<true, XFORM> sink;
-									sink.prev = start; sink.n = 0; sink.slow = false; sink.out = out; sink.writeLimit = limit; sink.mtx = mtx; sink.begin();
-									vgx_flatten_cubic(start.x, start.y, c1x, c1y, c2x, c2y, ex, ey, tessTol, st2, sink);
+									sink.prev = v2(rr.start[0], rr.start[1]); sink.n = 0; sink.slow = false; sink.out = out; sink.writeLimit = limit; sink.mtx = mtx; sink.begin();
+									vgx_flatten_cubic(rr.start[0], rr.start[1], q1x, q1y, q2x, q2y, qex, qey, tessTol, st2, sink);
 									sink.flush();
 								}
 								uint64_t m = againMask; int dropped = 0;
@@ -740,10 +833,10 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flat1(VgxFlattenArgs A, VgxF1Args 
 						if (valid && drawLast) {
 							vgx_draw_info di;
 							if (serialDraw) {
-								di = serialInfo; // counts from k_flatten_serial<count>; places from here
+								di.num_poly_vertices = serV; di.num_subpaths = serS; di.num_meshes = serM; di.flags = serF; // counts from k_flatten_serial<count>; places from here
 								di.first_poly_vertex = (uint64_t)gl;
-								di.first_subpath = subsGlobalIncl - serialInfo.num_subpaths;
-								di.first_mesh = meshGlobalIncl - serialInfo.num_meshes;
+								di.first_subpath = subsGlobalIncl - serS;
+								di.first_mesh = meshGlobalIncl - serM;
 								A.dinfo[d] = di;
 							} else if (!slowDraw) {
 								di.first_poly_vertex = (uint64_t)(gl - (long long)inDrawBefore);
@@ -817,7 +910,7 @@ __global__ __launch_bounds__(256) void k_f1_seg_table(VgxFlattenArgs A, VgxF1Arg
 {
 	const uint64_t n = A.ndraws;
 	const uint64_t totalCmds = A.cmd_prefix[n];
-	const uint64_t S = vgx_f1_segment_items(totalCmds, n);
+	const uint64_t S = vgx_f1_segment_items(totalCmds, n, X.seg_max);
 	const uint64_t numSegments = (totalCmds + S - 1) / S;
 	{ // the look-back records of this batch's segments start empty (the buffer is sized by a host-side bound, not cleared whole)
 		unsigned long long* w = (unsigned long long*)X.segs;
@@ -842,7 +935,7 @@ __global__ __launch_bounds__(256) void k_f1_redo_clear(VgxFlattenArgs A, VgxF1Ar
 	VgxTotals* T = A.totals;
 	if (T->flat_redo == 0u) { return; }
 	const uint64_t totalCmds = A.cmd_prefix[A.ndraws];
-	const uint64_t S = vgx_f1_segment_items(totalCmds, A.ndraws);
+	const uint64_t S = vgx_f1_segment_items(totalCmds, A.ndraws, X.seg_max);
 	const uint64_t numSegments = (totalCmds + S - 1) / S;
 	unsigned long long* w = (unsigned long long*)X.segs;
 	const uint64_t nw = numSegments * (sizeof(VgxF1Seg) / 8);
@@ -890,7 +983,7 @@ __global__ __launch_bounds__(256) void k_f1_publish(VgxFlattenArgs A, VgxF1Args 
 {
 	VgxTotals* T = A.totals;
 	const uint64_t totalCmds = A.cmd_prefix[A.ndraws];
-	const uint64_t S = vgx_f1_segment_items(totalCmds, A.ndraws);
+	const uint64_t S = vgx_f1_segment_items(totalCmds, A.ndraws, X.seg_max);
 	const uint64_t numSegments = (totalCmds + S - 1) / S;
 	uint32_t st = T->status;
 	vgx_sizes z = T->sizes; // num_cmd_instances from the scan
@@ -904,6 +997,7 @@ __global__ __launch_bounds__(256) void k_f1_publish(VgxFlattenArgs A, VgxF1Args 
 	if (threadIdx.x == 0) {
 		T->sizes = z;
 		T->status = st;
+		T->flat_tag = X.tag;
 		if (devSizes) { *devSizes = z; }
 		if (devStatus) { *devStatus = st; }
 	}
@@ -943,6 +1037,16 @@ void vgx_launch_flat1(const VgxFlattenArgs& a, const VgxF1Args& x, int waves, in
 }
 
 #ifdef VGX_F1_PROFILE
+extern "C" int vgx_f1_debug_occupancy(int cap)
+{
+	int n = -1;
+	hipError_t e;
+	if (cap >= 3072) { e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_flat1<3072, true>, VGX_WAVE, 0); }
+	else if (cap >= 2048) { e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_flat1<2048, true>, VGX_WAVE, 0); }
+	else if (cap >= 1664) { e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_flat1<1664, true>, VGX_WAVE, 0); }
+	else { e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_flat1<1024, true>, VGX_WAVE, 0); }
+	return e == hipSuccess ? n : -(int)e;
+}
 extern "C" int vgx_f1_debug_buffer(void* p, unsigned long long n)
 {
 	unsigned long long* q = (unsigned long long*)p;

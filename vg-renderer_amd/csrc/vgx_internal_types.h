@@ -126,6 +126,7 @@ struct VgxTotals
 	uint32_t pad_u32[1];
 	unsigned long long flat_ticket;      // vgx_flatten: next segment (ticket order = output order)
 	unsigned long long flat_serial_draws;// vgx_flatten: draws that went through the exact serial builder
+	unsigned long long flat_tag;         // vgx_flatten: the batch these totals belong to (VgxF1Args::tag)
 	// diagnostics of the first failure (vgx_get_failure_info)
 	uint32_t fail_reason;  // VGX_FAIL_*
 	uint32_t fail_aux;

@@ -32,9 +32,25 @@ def test_one_rank_line():
     assert set(r["by_kernel"]) == {"tmpl_emit"} and r["kernel"] == "tmpl_emit"  # the headline batch is a template batch: one kernel per step
     assert d["config"]["flatten_kernel"].startswith("none per step: template mode")
     assert set(d["configs"]) == {"cubics1m", "round10k", "tiger10k_varied", "tigerspec10k", "tiger10k_per_instance_flatten", "tiger10k_command_parallel",
-                                 "tiger10k_varied_per_instance_flatten", "tiger10k_open", "tiger10k_bevel"}
+                                 "tiger10k_varied_per_instance_flatten", "tiger10k_open", "tiger10k_bevel", "tiger10k_animated"}
     for name, c in d["configs"].items():
-        assert c["value"] > 0 and c["roofline"]["frac"] > 0, name
+        assert "error" not in c, (name, c)
+        assert c["value"] > 0, name
+        if name != "tiger10k_animated":
+            assert c["roofline"]["frac"] > 0, name
+            assert set(c["setup_ms"]) >= {"pathset_create", "h2d_draws", "first_count"}, name
+    # round 5: the flattener and the count are back inside what the line reports
+    assert d["ms_per_step_cold"] > d["ms_per_step"] * 0.9 and d["value_cold"] > 0 and d["cold_count_ms"] > 0
+    assert set(d["setup_ms"]) >= {"pathset_create", "h2d_draws", "first_count"}
+    an = d["configs"]["tiger10k_animated"]
+    assert set(an["split_ms"]) == {"pathset_destroy_create", "tessellate_count", "tessellate_and_wait"} and an["flatten_modes_seen"] == [5]  # the template is rebuilt every step
+    assert d["configs"]["cubics1m"]["entry"].startswith("vgx_flatten (one walk") and d["configs"]["cubics1m"]["two_phase_ms_per_step"] > 0
+    assert "flatten_one_walk" in d["configs"]["cubics1m"]["stage_ms"]
+    # the compact summary sits right behind the contract keys and once more at the very end of the line
+    keys = list(d.keys())
+    assert keys.index("summary") == 15 and keys[-1] == "summary_tail" and d["summary"] == d["summary_tail"]
+    assert set(d["summary"]) == set(d["configs"]) | {"tiger10k"}
+    assert d["config"]["cubics1m_ms_per_step"] == d["configs"]["cubics1m"]["ms_per_step"] and d["config"]["round10k_ms_per_step"] == d["configs"]["round10k"]["ms_per_step"]
     assert d["configs"]["tiger10k_varied"]["flatten_kernel"].startswith("none per step")  # one template per scale class
     assert d["configs"]["tiger10k_varied_per_instance_flatten"]["flatten_kernel"] == "k_flatten_inst (instances sorted by tolerance class)"
     # the honesty configs really run the other pipelines

@@ -914,7 +914,8 @@ int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset**
 	pathSubBegin[npaths] = (uint32_t)subLastCmd.size();
 	const size_t oSubBegin = align(oRec + (size_t)(ncmd + 1) * sizeof(VgxCmdRec));
 	const size_t oSubLast = align(oSubBegin + (npaths + 1) * sizeof(uint32_t));
-	const size_t total = align(oSubLast + (subLastCmd.size() + 1) * sizeof(uint32_t));
+	const size_t oThin = align(oSubLast + (subLastCmd.size() + 1) * sizeof(uint32_t));
+	const size_t total = align(oThin + (size_t)(ncmd + 3) * sizeof(VgxCmdThin));
 	std::vector<uint8_t> host(total, 0);
 	memcpy(&host[oSubBegin], pathSubBegin.data(), (npaths + 1) * sizeof(uint32_t));
 	if (!subLastCmd.empty()) { memcpy(&host[oSubLast], subLastCmd.data(), subLastCmd.size() * sizeof(uint32_t)); }
@@ -926,7 +927,30 @@ int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset**
 		memcpy(&host[oFlags], cmdFlags.data(), ncmd);
 	}
 	memcpy(&host[oPathBegin], desc->path_cmd_begin, (npaths + 1) * sizeof(uint32_t));
+	// paths of moveTo / lineTo / close only: thin records (VgxCmdThin)
+	for (uint32_t p = 0; p < npaths; ++p) {
+		bool thin = !(pathFlags[p] & VGX_PF_SERIAL) && desc->path_cmd_begin[p + 1] > desc->path_cmd_begin[p];
+		for (uint32_t c = desc->path_cmd_begin[p]; thin && c < desc->path_cmd_begin[p + 1]; ++c) {
+			const uint32_t t = desc->cmd_type[c];
+			if (t != VGX_CMD_MOVE_TO && t != VGX_CMD_LINE_TO && t != VGX_CMD_CLOSE) { thin = false; }
+		}
+		if (thin) { pathFlags[p] |= VGX_PF_THIN; }
+	}
 	if (npaths) { memcpy(&host[oPathFlags], pathFlags.data(), npaths); }
+	{
+		VgxCmdThin* th = (VgxCmdThin*)&host[oThin] + 1; // th[-1]: padding record
+		for (uint32_t c = 0; c < ncmd; ++c) {
+			const uint32_t t = desc->cmd_type[c];
+			const uint32_t ao = desc->cmd_arg_off[c];
+			th[c].meta = t | ((uint32_t)cmdFlags[c] << 8);
+			th[c].x = 0.0f; th[c].y = 0.0f; th[c].pad = 0;
+			if (t == VGX_CMD_MOVE_TO || t == VGX_CMD_LINE_TO) { th[c].x = desc->args[ao]; th[c].y = desc->args[ao + 1]; }
+			else if (t == VGX_CMD_CLOSE) {
+				const uint32_t hc = spStart[c];
+				if (desc->cmd_type[hc] == VGX_CMD_MOVE_TO) { const uint32_t ho = desc->cmd_arg_off[hc]; th[c].x = desc->args[ho]; th[c].y = desc->args[ho + 1]; }
+			}
+		}
+	}
 	{
 		VgxCmdRec* rec = (VgxCmdRec*)&host[oRec];
 		for (uint32_t c = 0; c < ncmd; ++c) {
@@ -982,6 +1006,7 @@ int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset**
 	ps->dev.cmd_flags = b + oFlags;
 	ps->dev.path_flags = b + oPathFlags;
 	ps->dev.cmdrec = (const VgxCmdRec*)(b + oRec);
+	ps->dev.cmdthin = (const VgxCmdThin*)(b + oThin) + 1;
 	ps->dev.path_sub_begin = (const uint32_t*)(b + oSubBegin);
 	ps->dev.sub_last_cmd = (const uint32_t*)(b + oSubLast);
 	ps->dev.npaths = npaths;

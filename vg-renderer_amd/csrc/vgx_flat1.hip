@@ -173,7 +173,7 @@ __device__ __forceinline__ F1NextRaw f1_next_issue(const F1Next& N, const VgxFla
 		if (idx < A.ndraws) { R.u = A.draws[idx].path; }
 	} else if (N.stage == 3) {
 		const uint64_t idx = N.d0 + (uint64_t)lane;
-		if (idx < A.ndraws) { R.u = A.ps.path_cmd_begin[N.wpath]; R.v = A.ps.path_flags[N.wpath] & VGX_PF_SERIAL; }
+		if (idx < A.ndraws) { R.u = A.ps.path_cmd_begin[N.wpath]; R.v = A.ps.path_flags[N.wpath] & (VGX_PF_SERIAL | VGX_PF_THIN); }
 	}
 	return R;
 }
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(VGX_WAVE, (CAP > 2048 ? 1 : F1_MIN_WAVES_PER_EU)) v
 				const uint32_t orel = (uint32_t)__shfl((int)wrel, ownerOfs);
 				const int firstOwner = __popcll(wave_ballot(W.prefix <= chunk)) - 1;
 				uint64_t ownerBase = orel > 0 ? chunk + orel : wave_bcast_u64(W.prefix, firstOwner < 0 ? 0 : firstOwner);
-				uint32_t pc0 = (uint32_t)__shfl((int)(W.pc0 | (W.serial << 31)), ownerOfs);
+				uint32_t pc0 = (uint32_t)__shfl((int)(W.pc0 | ((W.serial & 1u) << 31)), ownerOfs);
 				uint32_t serialStatic = pc0 >> 31;
 				pc0 &= 0x7FFFFFFFu;
 				VgxCmdRec rec;

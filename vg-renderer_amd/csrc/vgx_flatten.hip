@@ -104,7 +104,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 			const uint32_t orel = (uint32_t)__shfl((int)wrel, ownerOfs);
 			const int firstOwner = __popcll(wave_ballot(W.prefix <= chunk)) - 1; // draw that owns the chunk's first command
 			uint64_t ownerBase = orel > 0 ? chunk + orel : wave_bcast_u64(W.prefix, firstOwner < 0 ? 0 : firstOwner);
-			uint32_t pc0 = (uint32_t)__shfl((int)(W.pc0 | (W.serial << 31)), ownerOfs);
+			uint32_t pc0 = (uint32_t)__shfl((int)(W.pc0 | ((W.serial & 1u) << 31)), ownerOfs);
 			uint32_t serialStatic = pc0 >> 31;
 			pc0 &= 0x7FFFFFFFu;
 			VgxCmdRec rec;
@@ -430,9 +430,10 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 				const uint32_t orel = (uint32_t)__shfl((int)wrel, ownerOfs);
 				const int firstOwner = __popcll(wave_ballot(W.prefix <= chunk)) - 1; // draw that owns the chunk's first command
 				uint64_t ownerBase = orel > 0 ? chunk + orel : wave_bcast_u64(W.prefix, firstOwner < 0 ? 0 : firstOwner);
-				uint32_t pc0 = (uint32_t)__shfl((int)(W.pc0 | (W.serial << 31)), ownerOfs);
+				uint32_t pc0 = (uint32_t)__shfl((int)(W.pc0 | ((W.serial & 1u) << 31)), ownerOfs);
 				uint32_t serialStatic = pc0 >> 31;
 				pc0 &= 0x7FFFFFFFu;
+				uint32_t thinPath = ((uint32_t)__shfl((int)W.serial, ownerOfs) >> 1) & 1u; // a moveTo / lineTo / close path: 16-byte thin records
 				uint64_t d = d0;
 				uint32_t type = VGX_CMD_CLOSE, cflags = 0, na = 0;
 				bool drawHead = false, drawLast = false;
@@ -451,10 +452,26 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 						const uint32_t path = A.draws[d].path;
 						pc0 = ps.path_cmd_begin[path];
 						serialStatic = ps.path_flags[path] & VGX_PF_SERIAL;
+						thinPath = (ps.path_flags[path] >> 1) & 1u;
 					}
 					dr = A.draws + d;
 					const uint32_t k = (uint32_t)(ci - ownerBase);
-					rec = ps.cmdrec[pc0 + k];
+					if (thinPath) {
+						// my record, the one in front (its point = my start point) and, in front of a CLOSE, the one behind (the
+						// sub-path's first point): neighbours of a 1 KB run the wave reads anyway
+						const VgxCmdThin t0 = ps.cmdthin[pc0 + k];
+						const VgxCmdThin tp = ps.cmdthin[(long long)(pc0 + k) - 1]; // (command 0 of the set reads the padding record; a path's first command never uses it)
+						rec.type = t0.meta & 0xFFu; rec.flags = (t0.meta >> 8) & 0xFFu;
+						rec.na = rec.type == VGX_CMD_CLOSE ? 0u : 2u;
+						rec.start[0] = tp.x; rec.start[1] = tp.y;
+						if (rec.type == VGX_CMD_CLOSE) { rec.a[6] = t0.x; rec.a[7] = t0.y; }
+						else {
+							rec.a[0] = t0.x; rec.a[1] = t0.y;
+							if (rec.flags & VGX_CF_NEXT_IS_CLOSE) { const VgxCmdThin tn = ps.cmdthin[pc0 + k + 1]; rec.a[6] = tn.x; rec.a[7] = tn.y; }
+						}
+					} else {
+						rec = ps.cmdrec[pc0 + k];
+					}
 					type = rec.type; cflags = rec.flags; na = rec.na;
 					drawHead = (k == 0);
 					drawLast = (cflags & VGX_CF_LAST_IN_PATH) != 0;

@@ -20,6 +20,19 @@
 #define VGX_CF_NEXT_IS_CLOSE 0x4u
 #define VGX_CF_LAST_IN_PATH 0x8u
 #define VGX_PF_SERIAL 0x1u
+#define VGX_PF_THIN 0x2u   // every command of the path is MOVE_TO / LINE_TO / CLOSE: its lanes read the 16-byte thin records
+
+// Thin record, one per command (used for VGX_PF_THIN paths only): a polyline drawn with lineTo calls -- 10 000 paths x 1 000
+// segments -- read a 64-byte VgxCmdRec per 8-byte output vertex (FETCH 4-8x the command bytes, round 4). 16 bytes:
+//   meta  type | flags << 8
+//   x, y  MOVE_TO / LINE_TO: the command's point (= the NEXT command's start point);  CLOSE: the first point of its sub-path
+// so a lane finds its start point in the record in front of it and pathClose's first point in the record behind it.
+struct VgxCmdThin
+{
+	uint32_t meta;
+	float x, y;
+	uint32_t pad;
+};
 
 // One fixed-size record per path command, built on the host at upload: everything a lane needs for its command in
 // ONE 64-byte load (the SoA arrays above stay for the serial path and for POLYLINE's variable arguments).
@@ -37,6 +50,7 @@ struct VgxCmdRec
 struct VgxPathSetDev
 {
 	const VgxCmdRec* cmdrec;
+	const VgxCmdThin* cmdthin;      // [ncmd + 2] (one padding record in front: command 0 reads its predecessor's)
 	const uint8_t* cmd_type;
 	const uint8_t* cmd_flags;
 	const uint32_t* cmd_arg_off;

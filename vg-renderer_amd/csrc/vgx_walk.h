@@ -144,7 +144,7 @@ struct DrawWindow
 {
 	uint64_t prefix; // cmd_prefix[wbase + lane] (or ~0 past the end)
 	uint32_t pc0;    // first command of the draw's path
-	uint32_t serial; // path must take the serial lane path (ARC / ARC_TO)
+	uint32_t serial; // bit 0: path must take the serial lane path (ARC / ARC_TO / shapes); bit 1: VGX_PF_THIN
 };
 
 __device__ __forceinline__ DrawWindow draw_window_load(const VgxFlattenArgs& A, uint64_t wbase, int lane)
@@ -156,7 +156,7 @@ __device__ __forceinline__ DrawWindow draw_window_load(const VgxFlattenArgs& A, 
 	if (idx < A.ndraws) {
 		const uint32_t path = A.draws[idx].path;
 		w.pc0 = A.ps.path_cmd_begin[path];
-		w.serial = A.ps.path_flags[path] & VGX_PF_SERIAL;
+		w.serial = A.ps.path_flags[path] & (VGX_PF_SERIAL | VGX_PF_THIN); // bit 0: serial lane path; bit 1: thin records
 	}
 	return w;
 }

@@ -204,3 +204,34 @@ def test_one_walk_long_polylines(rt, gpu_ctx, wl, oracle):
     got = _one_walk(rt, gpu_ctx, ps, d, True)
     ref = oracle.flatten(ps, d, apply_transform=True)
     assert_flat_equal(got, ref, "long polylines")
+
+
+@pytest.mark.parametrize("box,n", [(10.0, 40000), (1000.0, 20000), (10000.0, 6000)])
+def test_one_walk_repeated_calls_adapt_and_stay_exact(rt, wl, box, n):
+    """vgx_flatten chooses its kernel instance / segment size (and, for very short curves, the two-walk kernels) from what the LAST
+    call on the same batch produced: the first, second and third call on one path set take different routes and must write the
+    same bytes."""
+    import torch
+    ps, d = wl.random_cubics(n, seed=31, box=box)
+    ctx = rt.Context(0)
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(d)
+    ref = rt.flatten(ctx, pset, dd, n, apply_transform=True, entry="two_phase", to_host=False)
+    npv, nsp = ref.sizes["num_poly_vertices"], ref.sizes["num_subpaths"]
+    for call in range(4):
+        bufs = rt.FlatBuffers(dd.device, npv, nsp, n)
+        rt.flatten_async(ctx, pset, dd, n, bufs, apply_transform=True)
+        torch.cuda.synchronize()
+        assert int(bufs.dev_status.item()) == 0, call
+        z = bufs.dev_sizes.cpu().numpy()
+        assert int(z[0]) == npv and int(z[1]) == nsp, call
+        assert torch.equal(bufs.poly[:npv].view(torch.int32), ref.poly_dev[:npv].view(torch.int32)), call
+        assert torch.equal(bufs.subs[:nsp * 16], ref.subs_dev[:nsp * 16]), call
+        assert torch.equal(bufs.dinfo[:n * 40], ref.dinfo_dev[:n * 40]), call
+    # a capacity that is too small is still reported on the adapted route
+    small = rt.FlatBuffers(dd.device, npv - 1, nsp, n)
+    rt.flatten_async(ctx, pset, dd, n, small, apply_transform=True)
+    torch.cuda.synchronize()
+    assert int(small.dev_status.item()) == 4
+    pset.close()
+    ctx.close()

@@ -1189,6 +1189,37 @@ int vgx_flatten(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint
 	}
 	if (ctx->optF1Cap) { cap = ctx->optF1Cap; }
 	if (ctx->optF1Seg) { segMax = (uint32_t)ctx->optF1Seg; }
+	// Very short curves (a handful of segments per cubic: a chunk of 64 commands yields a few hundred vertices) are bound by what
+	// a SEGMENT costs in the one-walk kernel -- its dependent loads and its place in the order, ~40 000 cycles whatever it holds --
+	// not by the walk: the two-walk kernels (count -> scan over draws -> emit, vgx_flatten.hip) are faster there (1 M cubics of
+	// ~5 segments: 0.43 against 0.63 ms), and they need no host round trip either once the batch's command total is known from
+	// the last call. Same output.
+	if (ctx->hostF1 && ctx->f1Tag == tag && ctx->hostF1[1] != 0 && ctx->hostF1[2] == tag && !ctx->optF1Cap && !ctx->optF1Seg && !ps->hasEmpty
+		&& (double)ctx->hostF1[0] / (double)ctx->hostF1[1] * 64.0 <= 384.0) {
+		const uint64_t ncmdInst = ctx->hostF1[1];
+		if ((st = ensure(ctx, ctx->cmdCnt, (ncmdInst + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
+		ctx->caps.cmd_instances = ctx->cmdCnt.cap / sizeof(uint32_t) - 1; // checked on the device (a batch that grew: VGX_E_NOSPACE)
+		runCmdPrefix(ctx, ps, draws, ndraws, s);
+		const VgxCaps saved = ctx->caps;
+		ctx->caps.poly_vertices = out->cap_poly_vertices; ctx->caps.subpaths = out->cap_subpaths; ctx->caps.meshes = ~0ull;
+		runFlattenCount(ctx, ps, draws, ndraws, s); // the scan over the draws compares the totals with the caller's capacities
+		ctx->caps = saved;
+		VgxFlattenArgs a2 = flattenArgs(ctx, ps, draws, ndraws, apply_transform);
+		a2.poly = out->poly; a2.subs = out->subpaths; a2.mdesc = nullptr; a2.mtab = nullptr;
+		a2.caps.poly_vertices = ~0ull; a2.caps.subpaths = ~0ull; a2.caps.meshes = ~0ull;
+		vgx_launch_flatten(true, a2, VGX_GRID_BLOCKS, s);
+		mark(ctx, s, "flatten_emit");
+		hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, s, (const VgxTotals*)ctx->totals.p, dev_sizes, dev_status);
+		{
+			VgxTotals* T = (VgxTotals*)ctx->totals.p;
+			noteHip(ctx, hipMemcpyAsync(&ctx->hostF1[0], &T->sizes.num_poly_vertices, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+			noteHip(ctx, hipMemcpyAsync(&ctx->hostF1[1], &T->sizes.num_cmd_instances, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+		}
+		if (out->draw_info && ndraws) {
+			HIPCHK(ctx, hipMemcpyAsync(out->draw_info, ctx->dinfo.p, ndraws * sizeof(vgx_draw_info), hipMemcpyDeviceToDevice, s));
+		}
+		return launchStatus(ctx);
+	}
 	// Segments: buckets of at least min(32, segMax) command instances. The command total is not known on the host without a round
 	// trip; ndraws x (longest path) bounds it (a batch whose bound is absurdly far above its real size asks once, synchronously).
 	const uint64_t minItems = segMax < 32 ? segMax : 32;

@@ -40,7 +40,8 @@ def traffic(fetch_db, write_db, label):
     correction for wide coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE (raw), from two separate --pmc passes."""
     import json
     names = {"k_tmpl_emit": "tmpl_emit", "k_tmpl_emit_general": "tmpl_emit", "k_tmpl_emit_open": "tmpl_emit", "k_flatten_build": "flatten_build", "k_flatten_inst": "flatten_build", "k_fill": "fill_emit", "k_stroke": "stroke_emit", "k_stroke_simple": "stroke_emit", "k_flatten_gather": "flatten_gather", "k_mesh_prepare": "mesh_prepare",
-             "k_flatten<false": "flatten_count", "k_flatten<true": "flatten_emit"}  # vgx_flatten (config 0 / cubics1m): count pass, emit pass
+             "k_flatten<false": "flatten_count", "k_flatten<true": "flatten_emit",  # vgx_flatten_count / _emit (two walks): count pass, emit pass
+             "k_flat1": "flatten_one_walk", "k_f1_seg_table": "flatten_one_walk"}   # vgx_flatten (cubics1m, round 5): the one-walk kernel (+ its segment table; the REDO instance exits at once)
     out = {"source": label, "instances_per_gpu": 10000, "kernels": {}}
     for db, ctr, mul in ((fetch_db, "FETCH_SIZE", 2.0), (write_db, "WRITE_SIZE", 1.0)):
         c = sqlite3.connect(db).cursor()

@@ -344,14 +344,16 @@ __device__ __forceinline__ uint32_t f1_task_walk(F1Lds<CAP>& L, int lane, bool a
 	return listN;
 }
 
-template<int CAP, bool XFORM>
+// REDO: the second run of a batch in which the first found degenerate draws -- the same code as its own kernel, so that a kernel
+// trace shows the run that does the work apart from the one that (normally) exits at once.
+template<int CAP, bool XFORM, bool REDO>
 __global__ __launch_bounds__(VGX_WAVE, (CAP > 2048 ? 1 : F1_MIN_WAVES_PER_EU)) void k_flat1(VgxFlattenArgs A, VgxF1Args X)
 {
 	__shared__ __attribute__((aligned(16))) F1Lds<CAP> L;
 	const int lane = threadIdx.x;
 	const VgxPathSetDev& ps = A.ps;
 	VgxTotals* T = A.totals;
-	if (X.pass == 1 && T->flat_redo == 0u) { return; } // the second run is only for batches in which the first found degenerate draws
+	if (REDO && T->flat_redo == 0u) { return; } // the second run is only for batches in which the first found degenerate draws
 	const uint64_t totalCmds = A.cmd_prefix[A.ndraws];
 	const uint64_t segItems = vgx_f1_segment_items(totalCmds, A.ndraws, X.seg_max);
 	const uint64_t numSegments = (totalCmds + segItems - 1) / segItems;
@@ -1016,24 +1018,21 @@ void vgx_launch_flat1(const VgxFlattenArgs& a, const VgxF1Args& x, int waves, in
 	VgxF1Args x0 = x; x0.pass = 0; x0.read_flags = hasStaticSerial ? 1 : 0;
 	VgxF1Args x1 = x; x1.pass = 1; x1.read_flags = 1;
 	hipLaunchKernelGGL(k_f1_seg_table, dim3(1024), dim3(256), 0, s, a, x0);
-	auto launch = [&](const VgxF1Args& xx) {
+	auto launch = [&](const VgxF1Args& xx, bool redo) {
+#define F1_LAUNCH(C, XF) do { if (redo) { hipLaunchKernelGGL((k_flat1<C, XF, true>), dim3(waves), dim3(VGX_WAVE), 0, s, a, xx); } \
+	else { hipLaunchKernelGGL((k_flat1<C, XF, false>), dim3(waves), dim3(VGX_WAVE), 0, s, a, xx); } } while (0)
 		if (a.apply_transform) {
-			if (cap >= 3072) { hipLaunchKernelGGL((k_flat1<3072, true>), dim3(waves), dim3(VGX_WAVE), 0, s, a, xx); }
-			else if (cap >= 2048) { hipLaunchKernelGGL((k_flat1<2048, true>), dim3(waves), dim3(VGX_WAVE), 0, s, a, xx); }
-			else if (cap >= 1664) { hipLaunchKernelGGL((k_flat1<1664, true>), dim3(waves), dim3(VGX_WAVE), 0, s, a, xx); }
-			else { hipLaunchKernelGGL((k_flat1<1024, true>), dim3(waves), dim3(VGX_WAVE), 0, s, a, xx); }
+			if (cap >= 3072) { F1_LAUNCH(3072, true); } else if (cap >= 2048) { F1_LAUNCH(2048, true); } else if (cap >= 1664) { F1_LAUNCH(1664, true); } else { F1_LAUNCH(1024, true); }
 		} else {
-			if (cap >= 3072) { hipLaunchKernelGGL((k_flat1<3072, false>), dim3(waves), dim3(VGX_WAVE), 0, s, a, xx); }
-			else if (cap >= 2048) { hipLaunchKernelGGL((k_flat1<2048, false>), dim3(waves), dim3(VGX_WAVE), 0, s, a, xx); }
-			else if (cap >= 1664) { hipLaunchKernelGGL((k_flat1<1664, false>), dim3(waves), dim3(VGX_WAVE), 0, s, a, xx); }
-			else { hipLaunchKernelGGL((k_flat1<1024, false>), dim3(waves), dim3(VGX_WAVE), 0, s, a, xx); }
+			if (cap >= 3072) { F1_LAUNCH(3072, false); } else if (cap >= 2048) { F1_LAUNCH(2048, false); } else if (cap >= 1664) { F1_LAUNCH(1664, false); } else { F1_LAUNCH(1024, false); }
 		}
+#undef F1_LAUNCH
 	};
-	launch(x0);
+	launch(x0, false);
 	// degenerate draws found by the first run (none, normally: these three exit at once)
 	hipLaunchKernelGGL(k_f1_serial_count_list, dim3(64), dim3(256), 0, s, a);
 	hipLaunchKernelGGL(k_f1_redo_clear, dim3(256), dim3(256), 0, s, a, x1);
-	launch(x1);
+	launch(x1, true);
 }
 
 #ifdef VGX_F1_PROFILE
@@ -1041,10 +1040,10 @@ extern "C" int vgx_f1_debug_occupancy(int cap)
 {
 	int n = -1;
 	hipError_t e;
-	if (cap >= 3072) { e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_flat1<3072, true>, VGX_WAVE, 0); }
-	else if (cap >= 2048) { e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_flat1<2048, true>, VGX_WAVE, 0); }
-	else if (cap >= 1664) { e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_flat1<1664, true>, VGX_WAVE, 0); }
-	else { e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_flat1<1024, true>, VGX_WAVE, 0); }
+	if (cap >= 3072) { e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_flat1<3072, true, false>, VGX_WAVE, 0); }
+	else if (cap >= 2048) { e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_flat1<2048, true, false>, VGX_WAVE, 0); }
+	else if (cap >= 1664) { e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_flat1<1664, true, false>, VGX_WAVE, 0); }
+	else { e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_flat1<1024, true, false>, VGX_WAVE, 0); }
 	return e == hipSuccess ? n : -(int)e;
 }
 extern "C" int vgx_f1_debug_buffer(void* p, unsigned long long n)

@@ -540,6 +540,131 @@ def run_animated(rt, torch, ctx, local_rank, wl, instances, steps, warmup, barri
             "flatten_modes_seen": sorted(modes)}
 
 
+def frame_leg(rt, torch, ctx, local_rank):
+    """ONE real frame: the tiger-like drawing recorded by the reference's own command-list writers
+    (tests/golden/frame_tiger_x1.npz, made by tests/golden/make_frame_fixture.py) -> vgx_cmdlist_decode (host) -> path set + draw
+    records uploaded -> vgx_tessellate_count -> vgx_tessellate with draw-command assembly armed, in microseconds, checked against
+    what the reference's Context handed to bgfx for the same list; beside it the reference Context itself on one host core."""
+    import numpy as np
+    cm = importlib.import_module("vg-renderer_amd.cmdlist")
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "frame_tiger_x1.npz"))
+    data = fx["bytes"].tobytes()
+    kw = dict(mtx=[float(x) for x in fx["mtx"]], global_alpha=float(fx["global_alpha"]), tess_tol=float(fx["tess_tol"]), fringe=float(fx["fringe"]),
+              canvas=(float(fx["canvas"][0]), float(fx["canvas"][1])), white_uv=[int(x) for x in fx["white_uv"]], font_image=int(fx["font_image"]))
+    dev = torch.device("cuda", local_rank)
+    extra = {}
+    rc, ps, draws, n = cm.decode(rt, data, extra=extra, time_reps=50, **kw)
+    assert rc == 0 and n["skipped"] == 0
+    dec_us = extra["decode_seconds"] * 1e6
+    t0 = time.perf_counter()
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(draws, local_rank)
+    torch.cuda.synchronize()
+    up_us = (time.perf_counter() - t0) * 1e6
+    nd = int(draws.shape[0])
+    t0 = time.perf_counter()
+    sizes = rt.tessellate_count(ctx, pset, dd, nd)
+    cnt_us = (time.perf_counter() - t0) * 1e6
+    nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
+    bufs = rt.MeshBuffers(dev, nv, ni, nm)
+    cmds = torch.zeros((nm + 2) * 48, dtype=torch.uint8, device=dev)
+    ncmd = torch.zeros(1, dtype=torch.int64, device=dev)
+    uv = torch.zeros((max(nv, 1), 2), dtype=torch.int16, device=dev)
+    ctx.set_assembly(cmds, 65536, ncmd, split_state=True, uv=uv, uv_value=(int(fx["white_uv"][0]), 0))
+    out = {}
+    try:
+        for _ in range(5):
+            rt.tessellate_async(ctx, pset, dd, nd, bufs)
+        torch.cuda.synchronize()
+        assert int(bufs.dev_status.item()) == 0
+        # the frame equals the reference Context's (sizes and exact stream sums of the fixture; the byte-for-byte comparison is
+        # tests/test_cmdlist_ref.py's)
+        ok = (nv == int(fx["ref_num_vertices"]) and ni == int(fx["ref_num_indices"]) and int(ncmd.item()) == int(fx["ref_num_drawcmds"])
+              and int(bufs.idx[:ni].to(torch.int64).bitwise_and(0xFFFF).sum().item()) == int(fx["ref_idx_sum"])
+              and int(bufs.color[:nv].to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) == int(fx["ref_col_sum"])
+              and float(bufs.pos[:nv].to(torch.float64).sum().item()) == float(fx["ref_pos_sum"]))
+        R = 200
+        t0 = time.perf_counter()
+        for _ in range(R):
+            rt.tessellate_async(ctx, pset, dd, nd, bufs)
+        torch.cuda.synchronize()
+        b2b_us = (time.perf_counter() - t0) / R * 1e6
+        t0 = time.perf_counter()
+        for _ in range(R):
+            rt.tessellate_async(ctx, pset, dd, nd, bufs)
+            torch.cuda.synchronize()
+        sync_us = (time.perf_counter() - t0) / R * 1e6
+        graph_us = None
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                rt.tessellate_async(ctx, pset, dd, nd, bufs)
+            g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(R):
+                g.replay()
+            torch.cuda.synchronize()
+            graph_us = (time.perf_counter() - t0) / R * 1e6
+            del g
+        except Exception as e:  # noqa: BLE001
+            out["graph_error"] = repr(e)[:120]
+        # a whole frame from the recorded bytes, nothing kept from the last one but the buffers: decode, new path set, uploads,
+        # count, tessellate + assemble, wait
+        Rw = 20
+        t0 = time.perf_counter()
+        for _ in range(Rw):
+            rc2, ps2, dr2, _n2 = cm.decode(rt, data, **kw)
+            p2 = rt.PathSet(ctx, ps2)
+            d2 = rt.upload_draws(dr2, local_rank)
+            rt.tessellate_count(ctx, p2, d2, nd)
+            rt.tessellate_async(ctx, p2, d2, nd, bufs)
+            torch.cuda.synchronize()
+            p2.close()
+        whole_us = (time.perf_counter() - t0) / Rw * 1e6
+    finally:
+        ctx.set_assembly(None)
+    pset.close()
+    out.update({"workload": "one frame: the tiger-like 240-path drawing (convexFillAA + strokes) recorded by the reference's vg::clXxx writers, %d bytes of commands -> %d draws, %d vertices, %d indices, %d draw command(s)" % (len(data), nd, nv, ni, int(ncmd.item())),
+                "equals_reference_frame": bool(ok),
+                "decode_us": round(dec_us, 1), "decode_MB_per_s": round(len(data) / extra["decode_seconds"] / 1e6, 1),
+                "pathset_create_and_uploads_us": round(up_us, 1), "tessellate_count_us": round(cnt_us, 1),
+                "tessellate_assembled_us_back_to_back": round(b2b_us, 1), "tessellate_assembled_us_with_sync": round(sync_us, 1),
+                "tessellate_assembled_us_hip_graph_replay": None if graph_us is None else round(graph_us, 1),
+                "whole_frame_us_from_recorded_bytes": round(whole_us, 1)})
+    # the reference's own Context playing the same list on ONE host core (submitCommandList -> Path / Stroker -> vg::end)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyvgref as RV
+        if RV.available():
+            with RV.RefContext(max_vb_vertices=65536) as rcx:
+                cl = rcx.create_command_list(0)
+                # replay the recorded bytes into a list of the reference: the fixture's script again
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from vgscript import Script, add_path
+                wl = importlib.import_module("vg-renderer_amd.workloads")
+                pst, ops = wl.tiger_paths()
+                sc = Script()
+                sc.push().translate(12.0, 7.0)
+                for p, o in enumerate(ops):
+                    add_path(sc, pst, p)
+                    sc.fill(o["fill_color"], RV.fill_flags(True))
+                    if o["stroke"]:
+                        sc.stroke(o["stroke_color"], o["stroke_width"], RV.stroke_flags(0, 0, True))
+                sc.pop()
+                sc.play(rcx, cl)
+                for _ in range(3):
+                    rcx.begin(1280, 720, 1.0); rcx.op(RV.IMMEDIATE, RV.SubmitCommandList, (), (cl,)); rcx.lib.vgr_end(rcx.h); rcx.next_frame()
+                Rc = 100
+                t0 = time.perf_counter()
+                for _ in range(Rc):
+                    rcx.begin(1280, 720, 1.0); rcx.op(RV.IMMEDIATE, RV.SubmitCommandList, (), (cl,)); rcx.lib.vgr_end(rcx.h); rcx.next_frame()
+                out["reference_context_us_per_frame_one_core"] = round((time.perf_counter() - t0) / Rc * 1e6, 1)
+    except Exception as e:  # noqa: BLE001
+        out["reference_context_error"] = repr(e)[:160]
+    return out
+
+
 def roofline(res, steps, traffic_for=None):
     """Roofline object of the dominant kernel (by HIP-event time) + the per-kernel table."""
     stage_sum, ab = res["stage"], res["ab"]
@@ -870,6 +995,10 @@ def main():
                                    "workload": "one tiger-like drawing tessellated once, submitted %d times (vgx_cache_submit)" % K},
         }
         del cache, cb, raw
+        try:
+            next_rows["frame_tiger_x1"] = frame_leg(rt, torch, ctx, local_rank)
+        except Exception as e:  # noqa: BLE001 -- a companion leg must not take the line with it
+            next_rows["frame_tiger_x1"] = {"error": repr(e)[:200]}
 
     # ---- the other BASELINE configs north_star names ("N cubics, M-segment strokes"), 1-GPU runs, beside the headline ----
     other = None
@@ -1036,6 +1165,12 @@ def main():
                                   {"split_ms": o["split_ms"]} if "split_ms" in o else None)
             if "box_sweep" in o:
                 summary[name]["box_sweep_ms"] = {k: v["ms_per_step"] for k, v in o["box_sweep"].items()}
+        fr1 = (next_rows or {}).get("frame_tiger_x1")
+        if fr1 and "error" not in fr1:  # one real frame, microseconds (next_rows.frame_tiger_x1 has the workload and every step)
+            summary["frame_tiger_x1"] = {k: fr1.get(k) for k in ("decode_us", "decode_MB_per_s", "tessellate_assembled_us_back_to_back", "tessellate_assembled_us_with_sync",
+                                                                 "tessellate_assembled_us_hip_graph_replay", "whole_frame_us_from_recorded_bytes", "reference_context_us_per_frame_one_core", "equals_reference_frame")}
+            out["config"]["frame_tiger_x1_us_hip_graph_replay"] = fr1.get("tessellate_assembled_us_hip_graph_replay")
+            out["config"]["frame_tiger_x1_us_reference_one_core"] = fr1.get("reference_context_us_per_frame_one_core")
         for name in ("cubics1m", "round10k", "tiger10k_animated", "tiger10k_command_parallel", "tiger10k_per_instance_flatten"):
             if name in summary and "ms" in summary[name]:
                 out["config"]["%s_ms_per_step" % name] = summary[name]["ms"]

@@ -49,7 +49,9 @@ def test_one_rank_line():
     # the compact summary sits right behind the contract keys and once more at the very end of the line
     keys = list(d.keys())
     assert keys.index("summary") == 15 and keys[-1] == "summary_tail" and d["summary"] == d["summary_tail"]
-    assert set(d["summary"]) == set(d["configs"]) | {"tiger10k"}
+    assert set(d["summary"]) == set(d["configs"]) | {"tiger10k", "frame_tiger_x1"}
+    f1 = d["next_rows"]["frame_tiger_x1"]
+    assert "error" not in f1 and f1["equals_reference_frame"] is True and f1["decode_us"] > 0 and f1["tessellate_assembled_us_back_to_back"] > 0
     assert d["config"]["cubics1m_ms_per_step"] == d["configs"]["cubics1m"]["ms_per_step"] and d["config"]["round10k_ms_per_step"] == d["configs"]["round10k"]["ms_per_step"]
     assert d["configs"]["tiger10k_varied"]["flatten_kernel"].startswith("none per step")  # one template per scale class
     assert d["configs"]["tiger10k_varied_per_instance_flatten"]["flatten_kernel"] == "k_flatten_inst (instances sorted by tolerance class)"

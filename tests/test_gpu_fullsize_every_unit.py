@@ -80,6 +80,20 @@ def test_every_instance_of_tiger_x10k_matches_the_reference(rt, wl, which):
                     hu.digest_uniform_torch(bufs.idx[:ni], K)], axis=1)
     bad = np.flatnonzero((got != ref).any(axis=(1, 2)))
     assert bad.shape[0] == 0, ("instances that differ from the reference", bad[:10].tolist(), bad.shape[0])
+    # the caller's MESH TABLE of the asynchronous (template) entry, every record of every instance (VERDICT r4 "Weak" 1a): instance 0's
+    # records equal the oracle's for one instance of the drawing, and instance k's are instance 0's moved by k instances
+    import pyoracle
+    P = len(ops)
+    one = pyoracle.tessellate(ps, d[:P], kind="reference" if pyoracle.available("reference") else None)
+    mpi = nm // K
+    assert nm % K == 0 and mpi == one.sizes["num_meshes"]
+    mt = bufs.meshes[:nm * 32].view(torch.int64).view(K, mpi, 4)  # first_vertex, first_index, (num_vertices | num_indices << 32), (draw | subpath_kind << 32)
+    m0 = torch.from_numpy(np.ascontiguousarray(one.meshes).view(np.int64).reshape(mpi, 4).copy()).to(mt.device)
+    k = torch.arange(K, dtype=torch.int64, device=mt.device).view(K, 1)
+    assert torch.equal(mt[:, :, 0], m0[:, 0].view(1, mpi) + k * (nv // K)), "mesh table: first_vertex"
+    assert torch.equal(mt[:, :, 1], m0[:, 1].view(1, mpi) + k * (ni // K)), "mesh table: first_index"
+    assert torch.equal(mt[:, :, 2], m0[:, 2].view(1, mpi).expand(K, mpi)), "mesh table: num_vertices / num_indices"
+    assert torch.equal(mt[:, :, 3], m0[:, 3].view(1, mpi) + k * P), "mesh table: draw / sub-path / kind"
     pset.close()
     ctx.close()
 
@@ -163,6 +177,15 @@ def test_every_path_of_the_million_cubics_matches_the_reference(rt, wl):
     got = hu.digest_ragged_torch(r.poly_dev[:npv].view(torch.int32), 2 * fv, 2 * cv)
     bad = np.flatnonzero((got != ref[:, :4]).any(axis=1))
     assert bad.shape[0] == 0, ("paths that differ from the reference", bad[:10].tolist(), bad.shape[0])
+    # the per-draw records and the sub-path records of all 1 M paths (rt.flatten returned vgx_flatten's -- the one-walk kernel's --
+    # buffers after comparing them with the two-phase entry's): one open sub-path per path, places = the running sums of the counts
+    n = d.shape[0]
+    assert r.sizes["num_subpaths"] == n
+    ex = torch.cumsum(cv, 0) - cv
+    assert torch.equal(fv, ex) and torch.equal(di[:, 1], torch.arange(n, dtype=torch.int64, device=di.device)) and bool((di[:, 2] == 0).all())
+    assert bool(((di[:, 3] >> 32) == 1).all()) and bool((di[:, 4] == 0).all())  # num_subpaths 1; num_meshes 0, flags 0 (no draw took the serial path)
+    sp = r.subs_dev[:n * 16].view(torch.int64).view(-1, 2)  # first_vertex, (num_vertices | flags << 32)
+    assert torch.equal(sp[:, 0], ex) and torch.equal(sp[:, 1], cv)
     pset.close()
     ctx.close()
 

@@ -437,3 +437,61 @@ def test_template_open_miter_strokes(rt, wl, oracle, monkeypatch, seed, ninst, t
     assert_mesh_equal(got, ref, "template open Miter strokes seed=%d" % seed)
     ctx.close()
 
+
+
+def test_template_meshless_draws_between_tiles_are_verified(rt, wl, oracle, monkeypatch):
+    """a draw WITHOUT a mesh (fill and stroke disabled) that sits between the last mesh of one tile and the first mesh of
+    the next one must still be read by some workgroup -- enabling its fill after the count ends the step with VGX_E_STALE, never
+    with a frame in which that mesh is silently missing. Small tiles, every draw position tried."""
+    monkeypatch.setenv("VGX_TMPL_TILE", "64")
+    ps = wl.closed_fuzz_paths(975, npaths=48)
+    NI = 64                                           # (a template needs more than 2048 draws)
+    d = wl.template_draws(ps, 975, NI)
+    P = ps.npaths
+    one = d[:P].copy()
+    off = np.arange(P) % 3 == 1                       # every third draw of the period: no mesh at all
+    d = d.copy()
+    for k in range(NI):
+        d["fill_flags"][k * P:(k + 1) * P][off] = 0
+        d["stroke_flags"][k * P:(k + 1) * P][off] = 0
+    ctx = rt.Context(0)
+    got = _run(rt, ctx, ps, d)
+    assert got.mode == MODE_TEMPLATE and got.status == 0
+    assert_mesh_equal(got, oracle.tessellate(ps, d), "mesh-less draws")
+    for j in np.flatnonzero(off):
+        d3 = d.copy()
+        d3["fill_flags"][17 * P + j] = one["fill_flags"][j] | 1  # the draw gets its fill back in ONE instance
+        assert _run(rt, ctx, ps, d, d_steady=d3).status == VGX_E_STALE, int(j)
+    ctx.close()
+
+
+def test_template_does_not_survive_its_path_set(rt, wl, oracle):
+    """a path set destroyed and another one created (possibly at the same address) between the count and the step: the
+    template of the old set must not be used for draws that merely look the same."""
+    import torch
+    psA = wl.closed_fuzz_paths(981, npaths=40)
+    psB = wl.closed_fuzz_paths(982, npaths=40)  # same number of paths, other geometry
+    d = wl.template_draws(psA, 981, 64)  # (a template needs more than 2048 draws)
+    ctx = rt.Context(0)
+    for _ in range(6):  # several rounds: the allocator is free to hand the old address out again
+        pa = rt.PathSet(ctx, psA)
+        dd = rt.upload_draws(d)
+        sizes = rt.tessellate_count(ctx, pa, dd, d.shape[0])
+        assert ctx.failure_info()["segment_items"] == MODE_TEMPLATE
+        pa.close()
+        pb = rt.PathSet(ctx, psB)
+        ref = oracle.tessellate(psB, d)
+        bufs = rt.MeshBuffers(dd.device, max(sizes["num_vertices"], ref.sizes["num_vertices"]), max(sizes["num_indices"], ref.sizes["num_indices"]),
+                              max(sizes["num_meshes"], ref.sizes["num_meshes"]))
+        try:
+            rt.tessellate_async(ctx, pb, dd, d.shape[0], bufs)
+            torch.cuda.synchronize()
+            st = int(bufs.dev_status.item())
+        except rt.VgxError as e:  # "run vgx_tessellate_count once": also fine, nothing was written
+            st = e.status
+        if st == 0:  # the ordinary pipeline ran on the NEW set: then the output is the new set's
+            nv = ref.sizes["num_vertices"]
+            assert int(bufs.dev_sizes.cpu().numpy()[3]) == nv
+            assert np.array_equal(bufs.pos[:nv].cpu().numpy().view(np.uint32), ref.pos.view(np.uint32))
+        pb.close()
+    ctx.close()

@@ -105,10 +105,10 @@ def cpu_baseline(budget_seconds=10.0, max_procs=256, which="tiger"):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libvgoracle.so"], stdout=subprocess.DEVNULL)
     procs = max(1, min(effective_cores(), max_procs))
     worker = os.path.join(ROOT, "oracle", "cpu_bench.py")
-    shard = {"tiger": 16, "cubics": 20000, "round": 8, "tigerspec": 4, "varied": 21, "tigeropen": 16, "tigerbevel": 16}[which]
+    shard = {"tiger": 16, "cubics": 20000, "round": 8, "tigerspec": 4, "varied": 21, "tigeropen": 16, "tigerbevel": 16, "tigerround": 16}[which]
     what = {"tiger": "Tiger x16 instances", "cubics": "20 000 independent cubics (flatten + transform only)", "round": "8 polylines x 1000 segments, Round joins + caps",
             "tigerspec": "the SURVEY-spec drawing x4 instances", "varied": "Tiger x21 instances at 7 scales under rotations",
-            "tigeropen": "Tiger with open sub-paths x16 instances", "tigerbevel": "Tiger with Bevel joins x16 instances"}[which]
+            "tigeropen": "Tiger with open sub-paths x16 instances", "tigerbevel": "Tiger with Bevel joins x16 instances", "tigerround": "Tiger with Round joins x16 instances"}[which]
     unit = "M polyline verts/s" if which == "cubics" else "M verts/s"
 
     def run(k, nproc, budget):
@@ -172,6 +172,8 @@ WORKLOADS = {
     "tiger10k_varied": "Tiger x10k at 7 scales (0.5 .. 3.5; 18 distinct avgScale values after rounding) under rotations: template mode with one template per class",
     "tiger10k_open": "Tiger x10k with every sub-path left open (no pathClose): open Miter strokes with Butt caps, template mode's general kernel",
     "tiger10k_bevel": "Tiger x10k with Bevel joins on the strokes: template mode's general element body (k_tmpl_emit_general)",
+    "tiger10k_round": "Tiger x10k with Round joins on the strokes (arc points counted on every instance's transformed polyline): template mode with per-step sizes (k_tmpl_round_sizes + k_tmpl_emit_round)",
+    "tiger10k_round_ordinary": "the tiger10k_round batch with VGX_TMPL_ROUND=0: the ordinary pipeline (k_flatten_inst + k_fill + k_round_sizes + k_stroke), what Round joins cost before round 5",
     "tigerspec10k": "SURVEY 8(d) config 3 as specified: 240 paths x (1-4 sub-paths x 8-60 cubics), x10k instances",
     "tiger10k_animated": "Tiger x10k whose path ARGUMENTS change every step: new path set (validated + uploaded) -> vgx_tessellate_count (template rebuilt: the flattener runs) -> vgx_tessellate, all inside the timed region",
     # honesty configs: the headline batch WITHOUT the template mode (every instance flattened, polyline through HBM), and without
@@ -180,9 +182,9 @@ WORKLOADS = {
     "tiger10k_command_parallel": "Tiger x10k with VGX_INST=0: k_flatten_build (one lane per path command) + k_fill + k_stroke, no instancing at all",
     "tiger10k_varied_per_instance_flatten": "the tiger10k_varied batch with VGX_TMPL_CLASSES=0: what instances cost when they share no subdivision (k_flatten_inst with the instances sorted by tolerance class + k_fill + k_stroke)",
 }
-CONFIG_ENV = {"tiger10k_per_instance_flatten": {"VGX_TMPL": "0"}, "tiger10k_command_parallel": {"VGX_INST": "0"}, "tiger10k_varied_per_instance_flatten": {"VGX_TMPL_CLASSES": "0"}}
+CONFIG_ENV = {"tiger10k_round_ordinary": {"VGX_TMPL_ROUND": "0"}, "tiger10k_per_instance_flatten": {"VGX_TMPL": "0"}, "tiger10k_command_parallel": {"VGX_INST": "0"}, "tiger10k_varied_per_instance_flatten": {"VGX_TMPL_CLASSES": "0"}}
 # configs that get their own cpu_baseline (the honesty configs are the headline's batch: they share its baseline)
-CONFIG_CPU = {"cubics1m": "cubics", "round10k": "round", "tigerspec10k": "tigerspec", "tiger10k_varied": "varied", "tiger10k_open": "tigeropen", "tiger10k_bevel": "tigerbevel"}
+CONFIG_CPU = {"cubics1m": "cubics", "round10k": "round", "tigerspec10k": "tigerspec", "tiger10k_varied": "varied", "tiger10k_open": "tigeropen", "tiger10k_bevel": "tigerbevel", "tiger10k_round": "tigerround"}
 CONFIG_CPU_BUDGET = {"cubics": 4.0, "round": 4.0}  # seconds of wall time per config (the tiger variants: 2.5 s)
 
 
@@ -207,6 +209,11 @@ def make_workload(wl, name, instances, rank):
         ps, ops = wl.tiger_paths()
         d = wl.tiger_draws(ops, instances, first_instance=rank * instances, join=2)  # vg::LineJoin::Bevel
         return ps, d, ("the tiger-like drawing (seed 2024) x %d instances per GPU: convexFillAA + polylineStrokeAA/AAThin with Bevel joins "
+                       "on 1/3 of the paths" % instances), "tessellate"
+    if name in ("tiger10k_round", "tiger10k_round_ordinary"):
+        ps, ops = wl.tiger_paths()
+        d = wl.tiger_draws(ops, instances, first_instance=rank * instances, join=1)  # vg::LineJoin::Round
+        return ps, d, ("the tiger-like drawing (seed 2024) x %d instances per GPU: convexFillAA + polylineStrokeAA (Round joins) / AAThin "
                        "on 1/3 of the paths" % instances), "tessellate"
     if name == "tigerspec10k":
         ps, ops = wl.tiger_spec_paths()

@@ -44,6 +44,9 @@ def main():
     elif which == "tigerbevel":  # Bevel joins on the strokes
         ps, ops = wl.tiger_paths()
         draws = wl.tiger_draws(ops, instances, first_instance=first, join=2)
+    elif which == "tigerround":  # Round joins on the strokes (mesh sizes follow the transformed geometry)
+        ps, ops = wl.tiger_paths()
+        draws = wl.tiger_draws(ops, instances, first_instance=first, join=1)
     else:
         ps, draws = wl.tiger(instances, first_instance=first)
     run(ps, draws, kind=kind, reps=1)  # load the library, touch the buffers

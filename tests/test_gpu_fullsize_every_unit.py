@@ -134,6 +134,50 @@ def test_every_instance_of_tiger_at_seven_scales_matches_the_reference(rt, wl):
     ctx.close()
 
 
+def test_every_instance_of_tiger_x10k_with_round_joins_matches_the_reference(rt, wl):
+    """bench.py's tiger10k_round at full size: Round joins count their arc points on every instance's transformed polyline, so the
+    sizes are the instance's (on this drawing -- thin strokes over gently turning polylines -- every join's arc happens to be one segment,
+    so the instances come out equal; instances of different sizes: tests/test_gpu_tmpl.py); template mode with per-step sizes
+    (k_tmpl_round_sizes + k_tmpl_emit_round). Digests of positions / colours
+    / indices and the sizes of all 10 000 instances against the reference's, and the caller's mesh table against the streams."""
+    import torch
+    K = 10000
+    ps, ops = wl.tiger_paths()
+    P = len(ops)
+    d = wl.tiger_draws(ops, K, join=1)
+    ctx = rt.Context(0)
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(d)
+    sizes = rt.tessellate_count(ctx, pset, dd, d.shape[0])
+    assert ctx.failure_info()["segment_items"] == 5  # template mode
+    nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
+    bufs = rt.MeshBuffers(dd.device, nv, ni, nm)
+    bufs.pos.fill_(float("nan"))
+    ctx.set_profiling(True)
+    rt.tessellate_async(ctx, pset, dd, d.shape[0], bufs)
+    torch.cuda.synchronize()
+    assert [n for n, _ in ctx.stage_times()] == ["tmpl_round_sizes", "tmpl_emit"]
+    ctx.set_profiling(False)
+    assert int(bufs.dev_status.item()) == 0
+    ref = _reference_rows("tigerround", K)  # [K, 12 + 2]
+    mt = bufs.meshes[:nm * 32].view(torch.int64).view(-1, 4)
+    draw = (mt[:, 3] & 0xFFFFFFFF).contiguous()
+    m0 = torch.searchsorted(draw, torch.arange(K + 1, dtype=torch.int64, device=draw.device) * P)  # first mesh of every instance
+    fvm = torch.cat([mt[:, 0], torch.tensor([nv], dtype=torch.int64, device=draw.device)])
+    fim = torch.cat([mt[:, 1], torch.tensor([ni], dtype=torch.int64, device=draw.device)])
+    # the table is consistent with itself: every mesh begins where the one in front of it ends
+    assert torch.equal(fvm[1:], fvm[:-1] + (mt[:, 2] & 0xFFFFFFFF)) and torch.equal(fim[1:], fim[:-1] + ((mt[:, 2] >> 32) & 0xFFFFFFFF))
+    fv, fi = fvm[m0[:-1]], fim[m0[:-1]]
+    cv, ci = fvm[m0[1:]] - fv, fim[m0[1:]] - fi
+    assert np.array_equal(cv.cpu().numpy(), ref[:, 12]) and np.array_equal(ci.cpu().numpy(), ref[:, 13])
+    got = np.concatenate([hu.digest_ragged_torch(bufs.pos[:nv].view(torch.int32), 2 * fv, 2 * cv), hu.digest_ragged_torch(bufs.color[:nv], fv, cv),
+                          hu.digest_ragged_torch(bufs.idx[:ni], fi, ci, is_u16=True)], axis=1)
+    bad = np.flatnonzero((got != ref[:, :12]).any(axis=1))
+    assert bad.shape[0] == 0, ("instances that differ from the reference", bad[:10].tolist(), bad.shape[0])
+    pset.close()
+    ctx.close()
+
+
 def test_every_mesh_of_the_round_join_polylines_matches_the_reference(rt, wl):
     """BASELINE configs[3]: 10 000 polylines x 1 000 segments, Round joins + Round caps (data-dependent mesh sizes)."""
     import torch

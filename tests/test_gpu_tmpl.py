@@ -409,13 +409,123 @@ def test_template_general_strokes(rt, wl, oracle, monkeypatch, seed, ninst, tile
     ctx.close()
 
 
-def test_template_general_strokes_round_joins_stay_ordinary(rt, wl, oracle):
-    ps = wl.fuzz_paths(995, npaths=72, with_shapes=True, degenerate=False)
-    d = wl.template_general_draws(ps, 995, 40, round_joins=True)
+# ---- Round joins: sizes that belong to the instance --------------------------------------------------------------------------------
+ROUND_STAGES = ["tmpl_round_sizes", "tmpl_emit"]
+
+
+@pytest.mark.parametrize("seed,ninst,tile,closed_only", [(995, 40, None, False), (1995, 36, "128", False), (2995, 48, "960", True), (3995, 33, "64", False), (4995, 64, "2048", True)])
+def test_template_round_joins(rt, wl, oracle, monkeypatch, seed, ninst, tile, closed_only):
+    """Round joins count their arc points on the TRANSFORMED polyline (stroker.cpp:1146, 1592): mesh sizes -- and every output place
+    behind such a mesh -- differ from instance to instance. Template mode counts them per step (k_tmpl_round_sizes: the emit kernel's
+    phases on the same staged values, sums instead of stores; places by scans) and emits with those places (k_tmpl_emit_round).
+    == the reference, == the ordinary pipeline (VGX_TMPL_ROUND=0) byte for byte, mesh table included."""
+    if tile:
+        monkeypatch.setenv("VGX_TMPL_TILE", tile)
+    ps = wl.closed_fuzz_paths(seed, npaths=72) if closed_only else wl.fuzz_paths(seed, npaths=72, with_shapes=True, degenerate=False)
+    d = wl.template_general_draws(ps, seed, ninst, round_joins=True)
+    ref = oracle.tessellate(ps, d)
     ctx = rt.Context(0)
     got = _run(rt, ctx, ps, d)
+    assert got.mode == MODE_TEMPLATE and got.stages == ROUND_STAGES, (got.mode, got.stages)
+    assert got.status == 0
+    assert_mesh_equal(got, ref, "template round joins seed=%d" % seed)
+    ctx.close()
+    monkeypatch.setenv("VGX_TMPL_ROUND", "0")
+    ctx = rt.Context(0)
+    old = _run(rt, ctx, ps, d)
+    assert old.mode != MODE_TEMPLATE
+    for k in ("pos", "color", "idx", "meshes"):
+        assert bytes_equal(getattr(got, k), getattr(old, k)), k
+    ctx.close()
+
+
+def test_template_round_joins_sizes_follow_the_transforms(rt, wl, oracle):
+    """The steady-state call of a Round-join template with OTHER transforms than the count saw: other arcs, other sizes -- counted on the
+    device for this very batch (dev_sizes), checked against the caller's capacities there (VGX_E_NOSPACE with the need; nothing written
+    past the buffers), and equal to the reference's when they fit."""
+    ps = wl.closed_fuzz_paths(5995, npaths=72)
+    d = wl.template_general_draws(ps, 5995, 40, round_joins=True)
+    d2 = d.copy()
+    d2["mtx"][:, :4] *= np.float32(0.37)  # smaller on screen: the same step angle spans the same arc... but rounding differs; and
+    d2["mtx"][:, 1] += np.float32(0.21)   # a shear changes the angles between the segments themselves
+    ref2 = oracle.tessellate(ps, d2)
+    ctx = rt.Context(0)
+    got = _run(rt, ctx, ps, d, d_steady=d2)  # buffers sized for d
+    need = (int(ref2.pos.shape[0]), int(ref2.idx.shape[0]))
+    assert need != (got.sizes["num_vertices"], got.sizes["num_indices"]), "the test wants a batch whose sizes differ from the counted one's"
+    assert (int(got.dev_sizes[3]), int(got.dev_sizes[4])) == need, (got.dev_sizes, need)  # vgx_sizes: num_vertices, num_indices
+    if need[0] > got.sizes["num_vertices"] or need[1] > got.sizes["num_indices"]:
+        assert got.status == rt.capi.VGX_E_NOSPACE
+        assert np.isnan(got.pos).all(), "nothing is written when the batch does not fit"
+    else:
+        assert got.status == 0
+        assert bytes_equal(got.pos[:need[0]], ref2.pos) and bytes_equal(got.idx[:need[1]], ref2.idx)
+    ctx.close()
+    # and with room for it: the reference's bytes
+    import torch
+    ctx = rt.Context(0)
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(d)
+    rt.tessellate_count(ctx, pset, dd, d.shape[0])
+    dd2 = rt.upload_draws(d2)
+    bufs = rt.MeshBuffers(dd2.device, need[0] + 64, need[1] + 64, int(ref2.meshes.shape[0]))
+    rt.tessellate_async(ctx, pset, dd2, d2.shape[0], bufs)
+    torch.cuda.synchronize()
+    assert int(bufs.dev_status.item()) == 0
+    g = _G()
+    g.pos = bufs.pos[:need[0]].cpu().numpy(); g.color = bufs.color[:need[0]].cpu().numpy().view(np.uint32)
+    g.idx = bufs.idx[:need[1]].cpu().numpy().view(np.uint16); g.meshes = bufs.meshes[:ref2.meshes.shape[0] * 32].cpu().numpy().view(rt.capi.mesh_dtype)
+    g.sizes = {"num_vertices": need[0], "num_indices": need[1], "num_meshes": int(ref2.meshes.shape[0])}
+    assert_mesh_equal(g, ref2, "round joins, other transforms")
+    pset.close()
+    ctx.close()
+
+
+def test_template_round_joins_tiger_stretched_wide(rt, wl, oracle):
+    """The Tiger with Round joins, strokes six times as wide (arcs of several points) and every instance stretched by its own
+    (1 + e, 1 - e) (avgScale stays 1): 300 instances of different sizes, tiles of 2048 elements with meshes that span tiles."""
+    ps, ops = wl.tiger_paths()
+    ops = [dict(op, stroke_width=op["stroke_width"] * 6.0) for op in ops]
+    d = wl.tiger_draws(ops, 300, join=1, stretch=True)
+    ref = oracle.tessellate(ps, d)
+    P = len(ops)
+    m0 = np.searchsorted(ref.meshes["draw"], np.arange(301, dtype=np.int64) * P)
+    fv = np.concatenate([ref.meshes["first_vertex"].astype(np.int64), [ref.pos.shape[0]]])[m0]
+    assert len(np.unique(np.diff(fv))) > 8, "the instances differ in size"
+    ctx = rt.Context(0)
+    got = _run(rt, ctx, ps, d)
+    assert got.mode == MODE_TEMPLATE and got.stages == ROUND_STAGES and got.status == 0
+    assert_mesh_equal(got, ref, "tiger, round joins, stretched")
+    ctx.close()
+
+
+def test_template_round_joins_with_draw_command_assembly_stay_ordinary(rt, wl, oracle):
+    """Draw-command assembly needs every mesh's size before the emit kernel runs; with Round joins those are per instance. Such batches keep
+    the ordinary pipeline -- also when the assembly is armed AFTER a template was built."""
+    ps = wl.closed_fuzz_paths(6995, npaths=72)
+    d = wl.template_general_draws(ps, 6995, 40, round_joins=True)
+    ref = oracle.tessellate(ps, d)
+    ctx = rt.Context(0)
+    got = _assembled(rt, ctx, ps, d, 65536, False)
     assert got.mode != MODE_TEMPLATE and got.status == 0
-    assert_mesh_equal(got, oracle.tessellate(ps, d), "round joins: ordinary pipeline")
+    assert bytes_equal(got.pos, ref.pos) and bytes_equal(got.color, ref.color)
+    ctx.close()
+    # armed after the count: the asynchronous entry refuses (no scratch was sized for the ordinary pipeline) instead of running the template
+    import torch
+    ctx = rt.Context(0)
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(d)
+    sizes = rt.tessellate_count(ctx, pset, dd, d.shape[0])
+    assert ctx.failure_info()["segment_items"] == MODE_TEMPLATE
+    cmds = torch.zeros(200000 * 48, dtype=torch.uint8, device=dd.device)
+    ncmd = torch.zeros(1, dtype=torch.int64, device=dd.device)
+    ctx.set_assembly(cmds, 65536, ncmd)
+    bufs = rt.MeshBuffers(dd.device, sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"])
+    with pytest.raises(rt.VgxError) as ei:
+        rt.tessellate_async(ctx, pset, dd, d.shape[0], bufs)
+    assert ei.value.status == rt.capi.VGX_E_NOSPACE
+    ctx.set_assembly(None)
+    pset.close()
     ctx.close()
 
 

@@ -109,11 +109,14 @@ struct vgx_ctx
 	// ... in several flavours ("classes", e.g. the same drawing at a few scales): one template over the concatenated class
 	// representatives, a per-instance table of output places, a per-workgroup table (instance, tile)
 	int optTmplClasses;
+	int optTmplRound;                    // VGX_TMPL_ROUND=0: batches with Round joins keep the ordinary pipeline
 	uint32_t tmplClasses;                // 1: every instance repeats the first period
 	uint32_t tmplGeneral;                // stroke styles of the template: 0 closed Miter AA / Thin only, 1 + open Miter with Butt / Square caps, 2 + general
 	uint64_t tmplNumWg, tmplNDraws;      // several classes: workgroups of one step; the batch size the per-instance table was built for
 	vgx_sizes tmplTotal;                 // sizes of the whole batch
 	DevBuf tmplHash, tmplInstCls, tmplClsRep, tmplCls, tmplIinfo, tmplWg;
+	uint32_t tmplRound;                  // Round-join stroke meshes per instance (tmplGeneral == 3): their sizes, and every place behind them, are counted per step
+	DevBuf tmplRsz, tmplTpart, tmplTcarry, tmplMinfo, tmplItot, tmplIplace; // the per-step tables of such a template (VgxTmplArgs)
 	hipStream_t sideStream; hipEvent_t forkEv, joinEv; // optConcurrentEmit only
 	VgxCaps caps; // element capacities matching the buffers above
 	uint64_t capDraws;
@@ -736,6 +739,8 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	if (const char* e = getenv("VGX_TMPL")) { ctx->optTmpl = atoi(e) != 0; }
 	ctx->optTmplClasses = 1; // VGX_TMPL_CLASSES=0: template mode only for batches whose instances all repeat the first period
 	if (const char* e = getenv("VGX_TMPL_CLASSES")) { ctx->optTmplClasses = atoi(e) != 0; }
+	ctx->optTmplRound = 1;
+	if (const char* e = getenv("VGX_TMPL_ROUND")) { ctx->optTmplRound = atoi(e) != 0; }
 	if (const char* e = getenv("VGX_TMPL_TILE")) { const int v = atoi(e); if (v >= 64 && v <= VGX_TMPL_MAX_TILE) { ctx->optTmplTile = (uint32_t)v / 64u * 64u; } } // testing: elements per tile (<= the LDS stage of k_tmpl_emit)
 	ctx->optPoolWalk = 0; // VGX_WALK=pool: the wave-cooperative walk of vgx_walk.h (same output, same speed: DESIGN.md section 4)
 	if (const char* e = getenv("VGX_WALK")) { ctx->optPoolWalk = strcmp(e, "pool") == 0; }
@@ -754,7 +759,7 @@ int vgx_destroy(vgx_ctx* ctx)
 		return VGX_E_INVALID_ARG;
 	}
 	DeviceGuard guard(ctx);
-	DevBuf* bufs[] = { &ctx->f1SegDraw, &ctx->f1Segs, &ctx->tmplHash, &ctx->tmplInstCls, &ctx->tmplClsRep, &ctx->tmplCls, &ctx->tmplIinfo, &ctx->tmplWg, &ctx->tmplTile, &ctx->tmplPoly, &ctx->tmplMesh, &ctx->tmplMtab, &ctx->tmplElem, &ctx->tmplDraws, &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DevBuf* bufs[] = { &ctx->f1SegDraw, &ctx->f1Segs, &ctx->tmplHash, &ctx->tmplInstCls, &ctx->tmplClsRep, &ctx->tmplCls, &ctx->tmplIinfo, &ctx->tmplWg, &ctx->tmplRsz, &ctx->tmplTpart, &ctx->tmplTcarry, &ctx->tmplMinfo, &ctx->tmplItot, &ctx->tmplIplace, &ctx->tmplTile, &ctx->tmplPoly, &ctx->tmplMesh, &ctx->tmplMtab, &ctx->tmplElem, &ctx->tmplDraws, &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
@@ -776,7 +781,7 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx)
 	if (!ctx) {
 		return 0;
 	}
-	return ctx->f1SegDraw.cap + ctx->f1Segs.cap + ctx->tmplHash.cap + ctx->tmplInstCls.cap + ctx->tmplClsRep.cap + ctx->tmplCls.cap + ctx->tmplIinfo.cap + ctx->tmplWg.cap + ctx->tmplTile.cap + ctx->tmplPoly.cap + ctx->tmplMesh.cap + ctx->tmplMtab.cap + ctx->tmplElem.cap + ctx->tmplDraws.cap + ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
+	return ctx->f1SegDraw.cap + ctx->f1Segs.cap + ctx->tmplHash.cap + ctx->tmplInstCls.cap + ctx->tmplClsRep.cap + ctx->tmplCls.cap + ctx->tmplIinfo.cap + ctx->tmplWg.cap + ctx->tmplRsz.cap + ctx->tmplTpart.cap + ctx->tmplTcarry.cap + ctx->tmplMinfo.cap + ctx->tmplItot.cap + ctx->tmplIplace.cap + ctx->tmplTile.cap + ctx->tmplPoly.cap + ctx->tmplMesh.cap + ctx->tmplMtab.cap + ctx->tmplElem.cap + ctx->tmplDraws.cap + ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
 }
 
 // ---- path set ---------------------------------------------------------------------------------------
@@ -1330,10 +1335,30 @@ int vgx_partition(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, ui
 
 // ---- template mode (vgx_tmpl.hip) ---------------------------------------------------------------------
 // One step in template mode: verify every draw against the saved first period, emit. No scratch besides the template.
-static int runTmpl(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, hipStream_t s)
+// Round-join templates: the per-step tables (sized for this batch) and the kernels that fill them -- sizes of every Round-join mesh of
+// every instance, places of meshes and instances, the batch totals in totals->sizes, VGX_E_NOSPACE against a.caps.
+static int tmplRoundSizes(vgx_ctx* ctx, VgxTmplArgs& a, hipStream_t s)
 {
-	VgxTmplArgs a;
-	memset(&a, 0, sizeof(a));
+	int st;
+	const uint64_t n = a.ninst, tiles = n * a.tiles_per_inst;
+	a.num_round = ctx->tmplRound;
+	if ((st = ensure(ctx, ctx->tmplRsz, (n * a.num_round + 1) * 2 * sizeof(unsigned long long))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->tmplTpart, (tiles + 1) * sizeof(uint2))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->tmplTcarry, (tiles + 1) * sizeof(uint2))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->tmplMinfo, (n * a.inst.num_meshes + 1) * sizeof(uint4))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->tmplItot, (n + 1) * 2 * sizeof(unsigned long long))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->tmplIplace, (n + 1) * 2 * sizeof(unsigned long long))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->partial, VGX_SCAN_BLOCKS * sizeof(Sum3))) != VGX_OK) { return st; }
+	a.rsz = (unsigned long long*)ctx->tmplRsz.p; a.tpart = (uint2*)ctx->tmplTpart.p; a.tcarry = (uint2*)ctx->tmplTcarry.p;
+	a.minfo = (uint4*)ctx->tmplMinfo.p; a.itot = (unsigned long long*)ctx->tmplItot.p; a.iplace = (unsigned long long*)ctx->tmplIplace.p;
+	vgx_launch_tmpl_round_sizes(a, (Sum3*)ctx->partial.p, s);
+	mark(ctx, s, "tmpl_round_sizes");
+	return VGX_OK;
+}
+
+// the step's arguments but the caller's buffers
+static void tmplArgs(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, VgxTmplArgs& a)
+{
 	a.draws = draws; a.ndraws = ndraws; a.period = ctx->tmplPeriod; a.ninst = ndraws / ctx->tmplPeriod; a.npaths = ps->dev.npaths;
 	a.tdraws = (const vgx_draw*)ctx->tmplDraws.p; a.tpoly = (const float2*)ctx->tmplPoly.p; a.tmesh = (const VgxTmplMesh*)ctx->tmplMesh.p;
 	a.tmtab = (const vgx_mesh*)ctx->tmplMtab.p; a.telem = (const VgxTmplElem*)ctx->tmplElem.p;
@@ -1341,8 +1366,7 @@ static int runTmpl(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 	a.ttile = (const VgxTmplTile*)ctx->tmplTile.p;
 	a.tile = ctx->tmplTileSize;
 	a.tiles_per_inst = (uint32_t)((ctx->tmplInst.num_elements + a.tile - 1) / a.tile);
-	a.pos = out->pos; a.color = out->color; a.idx = out->idx; a.meshes_out = out->meshes;
-	a.caps = ctx->caps; a.caps.vertices = out->cap_vertices; a.caps.indices = out->cap_indices; a.caps.meshes = out->cap_meshes;
+	a.caps = ctx->caps;
 	a.totals = (VgxTotals*)ctx->totals.p;
 	a.general = ctx->tmplGeneral;
 	if (ctx->tmplClasses > 1) {
@@ -1358,9 +1382,23 @@ static int runTmpl(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 		a.total = z;
 		a.num_wg = a.ninst * (uint64_t)a.tiles_per_inst;
 	}
+}
+
+static int runTmpl(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, hipStream_t s)
+{
+	VgxTmplArgs a;
+	memset(&a, 0, sizeof(a));
+	tmplArgs(ctx, ps, draws, ndraws, a);
+	a.pos = out->pos; a.color = out->color; a.idx = out->idx; a.meshes_out = out->meshes;
+	a.caps.vertices = out->cap_vertices; a.caps.indices = out->cap_indices; a.caps.meshes = out->cap_meshes;
 	if (a.num_wg > 0x7FFFFFFFull) { return VGX_E_RANGE; } // one workgroup per (instance, tile)
 	noteHip(ctx, hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s));
-	{
+	if (a.general == 3) {
+		// Round joins: vertices / indices are the instances' own -- counted on the device, checked against the capacities there
+		a.total.num_vertices = 0; a.total.num_indices = 0;
+		int st;
+		if ((st = tmplRoundSizes(ctx, a, s)) != VGX_OK) { return st; }
+	} else {
 		// every size is known on the host: a batch that does not fit the caller's buffers ends here, with the need in dev_sizes
 		const uint64_t nv = a.total.num_vertices, ni = a.total.num_indices, nm = a.total.num_meshes;
 		const uint32_t aux = (nv > out->cap_vertices ? 1u : 0u) | (ni > out->cap_indices ? 2u : 0u) | ((out->meshes && nm > out->cap_meshes) ? 4u : 0u);
@@ -1393,7 +1431,8 @@ static int runTmpl(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 static bool tmplFor(const vgx_ctx* ctx, const vgx_pathset* ps, uint64_t ndraws)
 {
 	return ctx->tmplOn && ctx->optTmpl && ps == ctx->tmplPs && ps->gen == ctx->tmplPsGen && ctx->tmplPeriod && ndraws % ctx->tmplPeriod == 0 && ndraws >= ctx->tmplPeriod
-		&& (ctx->tmplClasses == 1 || ndraws == ctx->tmplNDraws); // several classes: the per-instance table belongs to ONE batch size
+		&& (ctx->tmplClasses == 1 || ndraws == ctx->tmplNDraws) // several classes: the per-instance table belongs to ONE batch size
+		&& !(ctx->tmplGeneral == 3 && ctx->asmArmed);           // Round joins + draw-command assembly: the ordinary pipeline (the next count builds no template)
 }
 
 // The ordinary count + two-phase flatten in LOCAL space (apply_transform = 0) + mesh sizing of `n` draws: what a template is built
@@ -1416,10 +1455,10 @@ static int tmplPipeline(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* d, 
 	return VGX_OK;
 }
 // one instance of a class: only the mesh kinds k_tmpl_emit writes, every output stream of the instance below 4 GB
-static bool tmplEligible(const VgxTotals& ht)
+static bool tmplEligible(const VgxTotals& ht, bool roundOk)
 {
 	const vgx_sizes& z = ht.sizes;
-	return !(ht.num_round_meshes || z.num_elements == 0 || z.num_elements >= (1ull << 31) || z.num_vertices >= (1ull << 29)
+	return !((ht.num_round_meshes && !roundOk) || z.num_elements == 0 || z.num_elements >= (1ull << 31) || z.num_vertices >= (1ull << 29)
 		|| z.num_indices >= (1ull << 31) || z.num_poly_vertices >= (1ull << 32) || z.num_meshes >= (1ull << 32));
 }
 
@@ -1492,7 +1531,7 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	if (T > 1) {
 		for (uint32_t c = 0; c < T; ++c) {
 			if ((st = tmplPipeline(ctx, ps, rdraws + (uint64_t)c * P, P, s)) != VGX_OK) { return st; }
-			if (!tmplEligible(*ctx->hostTotals)) { return VGX_OK; }
+			if (!tmplEligible(*ctx->hostTotals, false)) { return VGX_OK; }
 			csz[c] = ctx->hostTotals->sizes;
 		}
 	}
@@ -1501,7 +1540,8 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	{
 		const VgxTotals& ht = *ctx->hostTotals;
 		if (T == 1) {
-			if (!tmplEligible(ht)) { return VGX_OK; } // open / Bevel / Round strokes (or nothing to emit): the ordinary pipeline
+			// Round joins (their sizes are the instance's): templates of one class, without draw-command assembly; else the ordinary pipeline
+			if (!tmplEligible(ht, ctx->optTmplRound && !ctx->asmArmed)) { return VGX_OK; }
 			csz[0] = ht.sizes;
 		} else if (ht.num_round_meshes || ht.sizes.num_poly_vertices >= (1ull << 32) || ht.sizes.num_meshes >= (1ull << 32) || ht.sizes.num_elements >= (1ull << 36)) {
 			return VGX_OK;
@@ -1524,8 +1564,9 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	} else {
 		noteHip(ctx, hipMemsetAsync(ctx->tmplCls.p, 0, ((size_t)T + 1) * sizeof(VgxTmplClass), s));
 	}
-	const uint32_t kernelKind = (styles & 2u) ? 2u : ((styles & 1u) ? 1u : 0u);
-	const uint32_t tileSize = (kernelKind == 2u && ctx->optTmplTile > VGX_TMPL_GENERAL_TILE) ? (uint32_t)VGX_TMPL_GENERAL_TILE : ctx->optTmplTile;
+	const uint32_t kernelKind = (styles & 4u) ? 3u : ((styles & 2u) ? 2u : ((styles & 1u) ? 1u : 0u));
+	if (kernelKind == 3u && T != 1) { return VGX_OK; }
+	const uint32_t tileSize = (kernelKind >= 2u && ctx->optTmplTile > VGX_TMPL_GENERAL_TILE) ? (uint32_t)VGX_TMPL_GENERAL_TILE : ctx->optTmplTile;
 	b.draws = rdraws; b.poly = (const float2*)ctx->poly.p; b.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; b.mprep = (const VgxMeshPrep*)ctx->mprep.p; b.mtab = (const vgx_mesh*)ctx->mtab.p;
 	b.prefix_fill = (const uint64_t*)ctx->elemPrefix.p; b.prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
 	b.num_meshes = M; b.num_elems = E; b.tile = tileSize; b.period = (uint32_t)P; b.nclasses = T;
@@ -1592,8 +1633,12 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 		HIPCHK(ctx, hipMemcpyAsync(ctx->tmplWg.p, wg.data(), (size_t)numWg * sizeof(uint2), hipMemcpyHostToDevice, s));
 		HIPCHK(ctx, hipStreamSynchronize(s)); // the host vectors go away
 	}
+	uint32_t roundWord = 0;
+	if (kernelKind == 3u) { HIPCHK(ctx, hipMemcpyAsync(&roundWord, &((VgxTmplClass*)ctx->tmplCls.p)[T].pad[1], sizeof(uint32_t), hipMemcpyDeviceToHost, s)); }
 	HIPCHK(ctx, hipStreamSynchronize(s));
 	if ((st = launchStatus(ctx)) != VGX_OK) { return st; }
+	if (kernelKind == 3u && ((roundWord >> 31) != 0 || (roundWord & 0x7FFFFFFFu) == 0)) { return VGX_OK; } // a tile with more meshes / draws than the LDS tables hold: the ordinary pipeline
+	ctx->tmplRound = roundWord & 0x7FFFFFFFu;
 	ctx->tmplInst = csz[0];
 	ctx->tmplTileSize = tileSize;
 	ctx->tmplPeriod = (uint32_t)P;
@@ -1604,6 +1649,21 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	ctx->tmplNDraws = ndraws;
 	ctx->tmplTotal = z;
 	ctx->tmplGeneral = kernelKind; // which instantiation of the emit kernel the template needs
+	if (kernelKind == 3u) {
+		// Round joins: this batch's vertices / indices -- the count of one step, read back
+		VgxTmplArgs a;
+		memset(&a, 0, sizeof(a));
+		tmplArgs(ctx, ps, draws, ndraws, a);
+		a.caps.vertices = ~0ull; a.caps.indices = ~0ull; a.caps.meshes = ~0ull;
+		a.total.num_vertices = 0; a.total.num_indices = 0;
+		if (a.num_wg > 0x7FFFFFFFull) { return VGX_OK; }
+		noteHip(ctx, hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s));
+		if ((st = tmplRoundSizes(ctx, a, s)) != VGX_OK) { return st; }
+		if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
+		if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; }
+		z = ctx->hostTotals->sizes;
+		ctx->tmplTotal = z;
+	}
 	ctx->tmplOn = true;
 	*out_sizes = z;
 	ctx->hostTotals->sizes = z; // what vgx_tessellate_emit checks the caller's capacities against

@@ -127,8 +127,20 @@ struct VgxTmplArgs // one step
 	const uint2* wg;             // [num_wg]
 	uint64_t num_wg;
 	vgx_sizes total;             // sizes of the whole batch
-	uint32_t general;            // stroke styles of the template: 0 = closed Miter AA / Thin (k_tmpl_emit), 1 = + open Miter, Butt / Square caps (k_tmpl_emit_open), 2 = any (k_tmpl_emit_general)
+	uint32_t general;            // stroke styles of the template: 0 = closed Miter AA / Thin (k_tmpl_emit), 1 = + open Miter, Butt / Square caps (k_tmpl_emit_open), 2 = any (k_tmpl_emit_general), 3 = + Round joins (k_tmpl_emit_round)
+	// Round joins (templates of ONE class): the arc of every join is counted on the instance's TRANSFORMED polyline (stroker.cpp:1146, 1592), so the
+	// sizes of those meshes -- and with them every output place behind them -- belong to the instance. Per-step tables, written by
+	// vgx_launch_tmpl_round_sizes and read by k_tmpl_emit_round:
+	uint32_t num_round;          // Round-join stroke meshes per instance (VgxTmplMesh::pad[1] = the mesh's number among them + 1)
+	unsigned long long* rsz;     // [ninst * num_round * 2] vertices, indices of every such mesh (zeroed, then summed tile by tile)
+	uint2* tpart;                // [ninst * tiles_per_inst] vertices / indices the tile's LAST mesh holds inside the tile, when that mesh goes on in the next tile
+	uint2* tcarry;               // [ninst * tiles_per_inst] vertices / indices of the tile's FIRST mesh in front of the tile
+	uint4* minfo;                // [ninst * meshes] per mesh: first vertex, first index inside the instance; vertices, indices
+	unsigned long long* itot;    // [ninst * 2] vertices, indices of the instance
+	unsigned long long* iplace;  // [ninst * 2] first vertex, first index of the instance in the batch
 };
+struct Sum3;
+void vgx_launch_tmpl_round_sizes(const VgxTmplArgs& a, Sum3* partial, hipStream_t s); // Round-join templates, in front of vgx_launch_tmpl_emit: the tables above, totals->sizes, VGX_E_NOSPACE against a.caps
 void vgx_launch_tmpl_mtab(const VgxTmplArgs& a, vgx_mesh* mtab, VgxMeshDesc* mdesc, hipStream_t s); // assembly armed: the whole batch's mesh table + mesh -> draw
 void vgx_launch_tmpl_check(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, VgxTotals* totals, hipStream_t s); // after vgx_launch_inst_detect
 void vgx_launch_tmpl_styles(const VgxTmplBuild& b, hipStream_t s);  // stroke styles of the template -> b.cls[nclasses].pad[0] (zeroed by the caller), needs mdesc only

@@ -175,7 +175,7 @@ struct VgxTmplMesh // one mesh of the template. 64 bytes
 	uint32_t kind;       // VgxMeshDesc::kind word
 	float f0, f1;        // fills: fringe / 2 (the sign is per instance), -; strokes: hsw, hswAA (thin: fringe, fringe)
 	float l0[2], l1[2], l2[2]; // its first three LOCAL vertices: the fill orientation (stroker.cpp:721-723) is the sign of their transformed triangle
-	uint32_t pad[2];
+	uint32_t pad[2];     // [0]: the draw's fringe (bits); [1]: Round-join stroke meshes: the mesh's number among the instance's Round-join meshes + 1, else 0
 };
 struct VgxTmplElem // one element (polyline vertex j of template mesh `mesh`), in processing order. 16 bytes
 {
@@ -192,7 +192,7 @@ struct VgxTmplTile // one tile of an instance's element stream = one workgroup o
 	uint32_t nel;       // elements in the tile (the last tile of a class is short)
 	uint32_t cmesh0;    // first template mesh of the tile's class (mesh numbers inside an instance = mesh - cmesh0)
 	uint32_t cdraw0;    // first saved draw record of the tile's class (= class * period)
-	uint32_t pad;
+	uint32_t pad;       // bit 0: the tile holds elements of Round-join meshes
 };
 // A batch may repeat its period in a FEW flavours ("classes": the same drawing at a handful of scales, say): every instance equals
 // one of the class representatives in every field the template depends on. The classes' templates are built as ONE template over

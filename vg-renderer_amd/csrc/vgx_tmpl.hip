@@ -156,8 +156,18 @@ __global__ void k_tmpl_classes(VgxTmplBuild B)
 __device__ __forceinline__ uint32_t tmpl_class_of_draw(const VgxTmplBuild& B, uint32_t draw) { return draw / B.period; }
 
 // which stroke styles the template holds -> cls[nclasses].pad[0]: bit 0 = open Miter strokes with Butt / Square caps, bit 1 = any other
-// stroke that is not closed Miter AA / Thin (the host zeroes the table first; k_tmpl_classes keeps the word)
+// stroke that is not closed Miter AA / Thin, bit 2 = Round joins (the host zeroes the table first; k_tmpl_classes keeps the word)
 __device__ __forceinline__ bool tmpl_stroke_is_open_fast(uint32_t kindWord);
+// the meshes whose sizes depend on the transformed geometry: Round joins count their arc points there (stroker.cpp:1146, 1592);
+// thin strokes turn Round joins into Bevel ones (:318-327)
+__device__ __forceinline__ bool tmpl_is_round(uint32_t kindWord)
+{
+	const uint32_t kind = VGX_MD_KIND(kindWord);
+	return (kind == VGX_MESH_STROKE || kind == VGX_MESH_STROKE_AA) && VGX_MD_JOIN(kindWord) == VGX_JOIN_ROUND;
+}
+#ifndef VGX_TMPL_MAXM
+#define VGX_TMPL_MAXM 160      /* meshes / draws per tile the LDS tables hold; a tile that needs more takes the per-lane fallback */
+#endif
 __global__ __launch_bounds__(256) void k_tmpl_styles(VgxTmplBuild B)
 {
 	uint32_t f = 0;
@@ -165,6 +175,7 @@ __global__ __launch_bounds__(256) void k_tmpl_styles(VgxTmplBuild B)
 		const uint32_t kw = B.mdesc[m].kind;
 		const uint32_t kind = VGX_MD_KIND(kw);
 		if (kind >= VGX_MESH_STROKE && !stroke_elem_is_simple(kind, VGX_MD_CLOSED(kw) != 0, VGX_MD_JOIN(kw))) { f |= tmpl_stroke_is_open_fast(kw) ? 1u : 2u; }
+		if (tmpl_is_round(kw)) { f |= 4u; }
 	}
 	if (f) { atomicOr(&B.cls[B.nclasses].pad[0], f); }
 }
@@ -195,6 +206,32 @@ __global__ __launch_bounds__(256) void k_tmpl_meshes(VgxTmplBuild B)
 		B.tmesh[m] = t;
 		B.tmtab[m] = mt;
 	}
+}
+
+// Round-join meshes numbered in mesh order (one block; after k_tmpl_meshes): tmesh[m].pad[1] = number + 1, their count -> cls[nclasses].pad[1]
+__global__ __launch_bounds__(256) void k_tmpl_round_index(VgxTmplBuild B)
+{
+	__shared__ uint32_t s_wave[4];
+	__shared__ uint32_t s_run;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	if (threadIdx.x == 0) { s_run = 0; }
+	__syncthreads();
+	for (uint64_t m0 = 0; m0 < B.num_meshes; m0 += 256) {
+		const uint64_t m = m0 + threadIdx.x;
+		const uint32_t f = (m < B.num_meshes && tmpl_is_round(B.mdesc[m].kind)) ? 1u : 0u;
+		uint32_t v = f;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(v, d); if (lane >= d) { v += t; } }
+		if (lane == 63) { s_wave[wave] = v; }
+		__syncthreads();
+		uint32_t base = s_run, tot = 0;
+		for (int w = 0; w < 4; ++w) { const uint32_t t = s_wave[w]; if (w < wave) { base += t; } tot += t; }
+		if (m < B.num_meshes) { B.tmesh[m].pad[1] = f ? base + v : 0u; }
+		__syncthreads();
+		if (threadIdx.x == 0) { s_run += tot; }
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) { B.cls[B.nclasses].pad[1] = s_run; }
 }
 
 // Element table in processing order: tiles of `tile` elements of the instance's output-ordered element stream; inside a
@@ -278,7 +315,13 @@ __global__ __launch_bounds__(256) void k_tmpl_tiles(VgxTmplBuild B)
 	B.ttile[t].ndraws = dB - dA + 1;
 	B.ttile[t].cmesh0 = B.cls[c].mesh0;
 	B.ttile[t].cdraw0 = d0;
-	B.ttile[t].pad = 0;
+	uint32_t flags = 0;
+	if (B.cls[B.nclasses].pad[0] & 4u) { // Round joins somewhere: does this tile hold any?
+		for (uint32_t m = mA; m <= mB && !flags; ++m) { flags = B.tmesh[m].pad[1] ? 1u : 0u; }
+		// the Round-join kernels have no per-lane fallback for tiles whose meshes / draws do not fit the LDS tables: the host then keeps the ordinary pipeline
+		if (mB - mA + 1 > VGX_TMPL_MAXM || dB - dA + 1 > VGX_TMPL_MAXM) { atomicOr(&B.cls[B.nclasses].pad[1], 0x80000000u); }
+	}
+	B.ttile[t].pad = flags;
 }
 
 // ---- step ------------------------------------------------------------------------------------------------------------
@@ -627,6 +670,18 @@ __device__ __forceinline__ void tmpl_mesh_out(const VgxTmplArgs& A, const TmplPl
 	A.meshes_out[P.m + (mesh - P.cmesh0)] = mr;
 }
 
+// Round joins: the places and sizes are the instance's (per-step table)
+__device__ __forceinline__ void tmpl_mesh_out_placed(const VgxTmplArgs& A, const TmplPlace& P, uint32_t mesh, uint4 mi)
+{
+	vgx_mesh mr = A.tmtab[mesh];
+	mr.first_vertex = P.v + mi.x;
+	mr.first_index = P.i + mi.y;
+	mr.num_vertices = mi.z;
+	mr.num_indices = mi.w;
+	mr.draw += P.draw0;
+	A.meshes_out[P.m + (mesh - P.cmesh0)] = mr;
+}
+
 // ---- every other stroke whose SIZES do not depend on the geometry: open strokes with Butt / Square / Round caps, Bevel joins,
 // non-AA strokes (only Round JOINS count their points on the transformed polyline, stroker.cpp:1146, 1592). The general element
 // code of vgx_elem.h (elem_geometry / elem_emit, what k_stroke runs) on the staged vertices, with what the sequential stroker
@@ -662,7 +717,7 @@ __device__ __forceinline__ void tmpl_stroke_counts(uint32_t kind, uint32_t cap, 
 // it needs comes by value: own vertex, previous vertex, the three edge directions around the element, the mesh's first two
 // vertices (closing bridge).
 __device__ __forceinline__ void tmpl_stroke_general(char* opos, char* ocol, char* oidx, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color,
-	float hsw, float hswAA, float fringe, const vgx_draw* tdraw, uint32_t j, V2 p1, V2 pPrev, V2 d12, V2 dPrev, V2 dPrev2, V2 v0, V2 v1)
+	float hsw, float hswAA, float fringe, const vgx_draw* tdraw, uint32_t j, V2 p1, V2 pPrev, V2 d12, V2 dPrev, V2 dPrev2, V2 v0, V2 v1, bool placed, uint32_t bPlaced, uint32_t kPlaced)
 {
 	MeshCtxT<TmplVtx01> mc;
 	mc.kind = VGX_MD_KIND(kindWord); mc.closed = VGX_MD_CLOSED(kindWord) != 0; mc.cap = VGX_MD_CAP(kindWord); mc.join = VGX_MD_JOIN(kindWord);
@@ -679,14 +734,14 @@ __device__ __forceinline__ void tmpl_stroke_general(char* opos, char* ocol, char
 	if (e.hasConnect) { // the previous element's exit rails (prevSegment*ID, stroker.cpp:1401-1410), from its own geometry
 		mc.j = j - 1;
 		const Elem ep = elem_geometry(mc, pPrev, dPrev2, dPrev);
-		prev = elem_exit_rails(mc, ep, vbase(j - 1));
+		prev = elem_exit_rails(mc, ep, placed ? bPlaced - ep.nv : vbase(j - 1)); // (Round joins: the previous element ends where this one begins)
 		mc.j = j;
 	}
 	StrokeWriter w;
 	w.pos = (float*)(opos + (size_t)vOff * 8u); w.col = (uint32_t*)(ocol + (size_t)vOff * 4u); w.idx = (uint16_t*)(oidx + (size_t)iOff * 2u);
 	w.color = color; w.c0 = color & 0x00FFFFFFu; w.ib = ibase;
 	w.reset();
-	const uint32_t b = vbase(j), k = ibaseOf(j);
+	const uint32_t b = placed ? bPlaced : vbase(j), k = placed ? kPlaced : ibaseOf(j);
 	elem_emit(mc, e, b, k, prev, w);
 	w.flush(b, k);
 }
@@ -699,7 +754,7 @@ __device__ __forceinline__ void tmpl_stroke_general(char* opos, char* ocol, char
 // Butt / Square caps (tmpl_stroke_elem_open), 2 = + everything else without Round joins (the general body).
 template<int KIND, int PASS, class DF, class VF>
 __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color, float f0, float f1,
-	V2 p1, V2 d12, const DF& dir, const VF& vtx, float fringe, const vgx_draw* tdraw, const VgxTmplMesh* tmm)
+	V2 p1, V2 d12, const DF& dir, const VF& vtx, float fringe, const vgx_draw* tdraw, const VgxTmplMesh* tmm, bool placed = false, uint32_t bPlaced = 0, uint32_t kPlaced = 0)
 {
 	const uint32_t kind = VGX_MD_KIND(kindWord);
 	const uint32_t jp1 = j > 0 ? j - 1 : N - 1;
@@ -717,7 +772,7 @@ __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uin
 		V2 pPrev = p1, dPrev2 = dPrev, v0 = p1, v1 = p1;
 		if (j > 0) { pPrev = vtx(jp1); dPrev2 = dir(jp1 > 0 ? jp1 - 1 : N - 1); } // the previous element's geometry: only when a bridge connects to it
 		if (closed && j + 1 == N) { v0 = vtx(0u); v1 = vtx(N > 1 ? 1u : 0u); }      // join 0's inner side: only the closing bridge asks
-		tmpl_stroke_general(O.pos, O.col, O.idx, kindWord, N, vOff, iOff, ibase, color, f0, f1, fringe, tdraw, j, p1, pPrev, d12, dPrev, dPrev2, v0, v1);
+		tmpl_stroke_general(O.pos, O.col, O.idx, kindWord, N, vOff, iOff, ibase, color, f0, f1, fringe, tdraw, j, p1, pPrev, d12, dPrev, dPrev2, v0, v1, placed, bPlaced, kPlaced);
 	} else if (openFast) {
 		const V2 dPrev = dir(jp1);
 		V2 dPrev2 = dPrev;
@@ -731,10 +786,6 @@ __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uin
 }
 
 // VGX_TMPL_THREADS / VGX_TMPL_MAX_TILE (vgx_internal.h): threads per workgroup, elements per tile the LDS stages hold
-#ifndef VGX_TMPL_MAXM
-#define VGX_TMPL_MAXM 160      /* meshes / draws per tile the LDS tables hold; a tile that needs more takes the per-lane fallback */
-#endif
-
 // Draw-command assembly armed: the partition of the mesh sequence into vertex buffers / draw commands (vgx_assemble.hip) reads
 // the WHOLE batch's mesh table and each mesh's draw; in template mode neither exists in memory, so this pass writes them
 // (template record + instance offsets) before the assembly kernels run. k_tmpl_emit then adds each mesh's base to its indices.
@@ -778,16 +829,24 @@ __global__ __launch_bounds__(256) void k_tmpl_mtab(VgxTmplArgs A, vgx_mesh* mtab
 #define VGX_TMPL_G_THREADS 256
 #endif
 #define VGX_TMPL_G_TILE VGX_TMPL_GENERAL_TILE
-template<int KIND, int THREADS, int MAXTILE>
+// ROUND: 0 = no Round joins; 1 = Round joins, emit: the places of the instance / its meshes come from the per-step tables and the elements
+// of Round-join meshes are placed by a scan over the tile (phase 2b); 2 = Round joins, SIZES only: phases 0 - 2b, then the sums into the
+// per-step tables instead of phase 3 (k_tmpl_round_sizes). Both run the same phases on the same staged values: the arcs counted = the arcs emitted.
+template<int KIND, int THREADS, int MAXTILE, int ROUND = 0>
 __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 {
 	constexpr bool GENERAL = KIND == 2;
+	constexpr bool SIZES = ROUND == 2;
+	static_assert(ROUND == 0 || GENERAL, "Round joins take the general element body");
 	constexpr int CH = MAXTILE / THREADS;
 	__shared__ TmplDraw s_draw[VGX_TMPL_MAXM];
 	__shared__ TmplRec s_rec[VGX_TMPL_MAXM];
 	__shared__ float2 s_vtx[MAXTILE];
 	__shared__ float2 s_dir[MAXTILE];
 	__shared__ uint32_t s_status;
+	__shared__ uint2 s_carry;                                        // ROUND: vertices / indices of the tile's first mesh in front of the tile
+	__shared__ uint2 s_wtot[ROUND ? CH * (THREADS / 64) : 1];        // ROUND: sums of the wave's chunks (phase 2b)
+	__shared__ uint2 s_base[ROUND ? VGX_TMPL_MAXM : 1];              // ROUND: per mesh of the tile: (prefix at its first element in the tile) - (what it holds in front of the tile)
 	const uint32_t tid = threadIdx.x;
 	// workgroup -> (instance, tile of the template), all workgroup-uniform (scalar loads)
 	uint32_t inst32, t;
@@ -801,7 +860,9 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 		inst32 = blockIdx.x / A.tiles_per_inst;
 		t = blockIdx.x - inst32 * A.tiles_per_inst;
 		P.v = (uint64_t)inst32 * A.inst.num_vertices; P.i = (uint64_t)inst32 * A.inst.num_indices; P.m = (uint64_t)inst32 * A.inst.num_meshes;
+		if (ROUND == 1) { P.v = A.iplace[2 * (uint64_t)inst32]; P.i = A.iplace[2 * (uint64_t)inst32 + 1]; }
 	}
+	if (SIZES && (A.ttile[t].pad & 1u) == 0) { return; } // no Round-join element here: nothing to count (its draw records are verified by the emit kernel)
 	const uint64_t inst = inst32;
 	const VgxTmplTile tl = A.ttile[t];
 	P.draw0 = (uint32_t)(inst * A.period); P.cmesh0 = tl.cmesh0; P.tdraws = A.tdraws + tl.cdraw0;
@@ -818,9 +879,14 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 	O.pos = (char*)(A.pos + 2 * P.v);
 	O.col = (char*)(A.color + P.v);
 	O.idx = (char*)(A.idx + P.i);
-	if (blockIdx.x == 0 && tid == 0 && !A.mesh_base) { // (assembly armed: k_tmpl_mtab wrote them already) totals of the batch (the memset in front of this kernel zeroed them)
+	if (ROUND == 0 && blockIdx.x == 0 && tid == 0 && !A.mesh_base) { // (assembly armed: k_tmpl_mtab wrote them already; Round joins: the scan over the instances did) totals of the batch (the memset in front of this kernel zeroed them)
 		A.totals->sizes = A.total;
 	}
+	if (ROUND != 0 && (nm > VGX_TMPL_MAXM || nd > VGX_TMPL_MAXM)) { // (the host builds no Round-join template with such a tile: k_tmpl_tiles)
+		if (tid == 0) { set_status(A.totals, VGX_E_INTERNAL); }
+		return;
+	}
+	const uint4* minfo = ROUND == 1 ? A.minfo + (uint64_t)inst32 * A.inst.num_meshes : nullptr; // indexed by (template mesh number - P.cmesh0); P.cmesh0 = 0 (one class)
 	if (nm > VGX_TMPL_MAXM || nd > VGX_TMPL_MAXM) {
 		// workgroup-uniform. Many tiny meshes (or many draws without a mesh) in one tile: the draw records are verified in a loop,
 		// every lane fetches its own records and neighbours
@@ -862,12 +928,17 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 	memset(&tm, 0, sizeof(tm));
 	tm.n = 3; tm.drawk = dA; tm.kind = VGX_MESH_FILL;
 	uint32_t ibase = 0;
+	uint4 mi = make_uint4(0u, 0u, 0u, 0u);
 	if (tid < nm) {
 		tm = A.tmesh[mA + tid];
 		if (meshBase) { ibase = meshBase[mA - P.cmesh0 + tid]; }
+		if (ROUND == 1) { mi = minfo[mA + tid]; tm.v_off = mi.x; tm.i_off = mi.y; } // this instance's places
 	}
 	if (tid < nd) { s_draw[tid] = tmpl_load_draw(A, idraws, P.tdraws, dA + tid); }
-	if (tid == 0) { s_status = A.totals->status; } // an earlier workgroup may have found the batch stale; ONE value for the whole workgroup (the exit below must be uniform)
+	if (tid == 0) {
+		s_status = A.totals->status; // an earlier workgroup may have found the batch stale; ONE value for the whole workgroup (the exit below must be uniform)
+		if (ROUND == 1) { s_carry = firstWhole ? make_uint2(0u, 0u) : A.tcarry[(uint64_t)inst32 * A.tiles_per_inst + t]; }
+	}
 	__syncthreads();
 	const uint32_t status = s_status;
 	// ---- phase 0b: per-mesh records
@@ -880,7 +951,9 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 		if (kind == VGX_MESH_FILL_AA) { r.f0 = tmpl_fill_aa(tmpl_draw_xf(d), make_float2(tm.l0[0], tm.l0[1]), make_float2(tm.l1[0], tm.l1[1]), make_float2(tm.l2[0], tm.l2[1]), tm.f0); }
 		s_rec[tid] = r;
 		// the caller's mesh table for the meshes that BEGIN in this tile (every mesh of the range but possibly the first)
-		if ((tid > 0 || firstWhole) && A.meshes_out && status == VGX_OK) { tmpl_mesh_out(A, P, mA + tid); }
+		if ((tid > 0 || firstWhole) && A.meshes_out && status == VGX_OK && !SIZES) {
+			if (ROUND == 1) { tmpl_mesh_out_placed(A, P, mA + tid, mi); } else { tmpl_mesh_out(A, P, mA + tid); }
+		}
 	}
 	__syncthreads();
 	TMPL_PROF(0);
@@ -924,8 +997,109 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 	}
 	__syncthreads();
 	TMPL_PROF(2);
+	// ---- phase 2b (Round joins): what every element of a Round-join mesh emits (elem_geometry on the staged values: the arc of its join),
+	// prefix sums over the tile in processing order (= output order among the strokes) -> the element's first vertex / index inside its mesh
+	uint32_t rb[ROUND ? CH : 1], rk[ROUND ? CH : 1], cv[ROUND ? CH : 1], ci[ROUND ? CH : 1];
+	if (ROUND != 0) {
+		constexpr int NW = THREADS / 64;
+		const uint32_t lane = tid & 63u, wave = tid >> 6;
+#pragma unroll
+		for (int c = 0; c < CH; ++c) { cv[c] = 0; ci[c] = 0; }
+#pragma unroll 1
+		for (int c = 0; c < CH; ++c) { // rolled: elem_geometry is in the kernel once here (and twice in the general body)
+			VgxTmplElem e = er[0]; V2 pv = p1[0], dv = d12[0];
+#pragma unroll
+			for (int k = 1; k < CH; ++k) { if (c == k) { e = er[k]; pv = p1[k]; dv = d12[k]; } }
+			const uint32_t s = (uint32_t)c * THREADS + tid;
+			uint32_t nvE = 0, niE = 0;
+			if (s < nel) {
+				const TmplRec* rp = &s_rec[e.mesh - mA];
+				const uint32_t kw = rp->kind & 0xFFFFu;
+				if (tmpl_is_round(kw)) {
+					const uint32_t j = e.jq & 0xFFFFu, N = rp->n;
+					const int q0 = (int)(e.jq >> 16) - (int)j;
+					const uint32_t jp1 = j > 0 ? j - 1 : N - 1;
+					const uint32_t qq = (uint32_t)(q0 + (int)jp1);
+					V2 dPrev;
+					if (qq < nel) { const float2 v = s_dir[qq]; dPrev = v2(v.x, v.y); }
+					else { dPrev = v2dir(vtxAt(e.mesh, rp, q0, jp1), vtxAt(e.mesh, rp, q0, jp1 + 1 < N ? jp1 + 1 : 0u)); }
+					MeshCtxT<TmplVtx01> mc;
+					mc.kind = VGX_MD_KIND(kw); mc.closed = VGX_MD_CLOSED(kw) != 0; mc.cap = VGX_MD_CAP(kw); mc.join = VGX_MD_JOIN(kw);
+					mc.N = N; mc.j = j; mc.hsw = rp->f0; mc.hswAA = rp->f1; mc.fringe = 0.0f; // (the fringe: thin strokes only, never a Round-join mesh)
+					mc.dr = P.tdraws + (dA + TMPL_REC_DK(rp));
+					mc.vtx.x0 = 0.0f; mc.vtx.y0 = 0.0f; mc.vtx.x1 = 0.0f; mc.vtx.y1 = 0.0f;
+					const Elem g = elem_geometry(mc, pv, dPrev, dv);
+					nvE = g.nv; niE = elem_total_indices(mc, g);
+				}
+			}
+#pragma unroll
+			for (int k = 0; k < CH; ++k) { if (c == k) { cv[k] = nvE; ci[k] = niE; } }
+		}
+		// inclusive sums inside the wave, chunk by chunk; the chunks' totals through LDS
+#pragma unroll
+		for (int c = 0; c < CH; ++c) {
+			uint32_t v = cv[c], i = ci[c];
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) {
+				const uint32_t tv = __shfl_up(v, d), ti = __shfl_up(i, d);
+				if (lane >= (uint32_t)d) { v += tv; i += ti; }
+			}
+			rb[c] = v; rk[c] = i;
+			if (lane == 63u) { s_wtot[c * NW + wave] = make_uint2(v, i); }
+		}
+		__syncthreads();
+		{
+			uint32_t runV = 0, runI = 0;
+#pragma unroll
+			for (int c = 0; c < CH; ++c) {
+				uint32_t preV = 0, preI = 0, totV = 0, totI = 0;
+#pragma unroll
+				for (int w = 0; w < NW; ++w) {
+					const uint2 tw = s_wtot[c * NW + w];
+					if ((uint32_t)w < wave) { preV += tw.x; preI += tw.y; }
+					totV += tw.x; totI += tw.y;
+				}
+				rb[c] = runV + preV + rb[c] - cv[c]; // exclusive: what the tile's Round-join elements in front of this one emit
+				rk[c] = runI + preI + rk[c] - ci[c];
+				runV += totV; runI += totI;
+			}
+		}
+		// the mesh's base: the prefix at its first element in the tile, less what the mesh holds in front of the tile (only the tile's
+		// first mesh can begin earlier: it owns output position 0)
+#pragma unroll
+		for (int c = 0; c < CH; ++c) {
+			if (cv[c] != 0) { // (an element of a Round-join mesh: it emits >= 2 vertices)
+				const uint32_t j = er[c].jq & 0xFFFFu, q = er[c].jq >> 16;
+				if (j == 0 || q == 0) {
+					const uint2 cr = (SIZES || j == 0) ? make_uint2(0u, 0u) : s_carry;
+					s_base[er[c].mesh - mA] = make_uint2(rb[c] - cr.x, rk[c] - cr.y);
+				}
+			}
+		}
+		__syncthreads();
+#pragma unroll
+		for (int c = 0; c < CH; ++c) {
+			if (cv[c] != 0) {
+				const uint2 bs = s_base[er[c].mesh - mA];
+				if (SIZES) {
+					const uint32_t j = er[c].jq & 0xFFFFu, q = er[c].jq >> 16, N = s_rec[er[c].mesh - mA].n;
+					if (j + 1 == N || q + 1 == nel) { // the mesh's last element in this tile: what the mesh holds here
+						const uint32_t pv = rb[c] + cv[c] - bs.x, pi = rk[c] + ci[c] - bs.y;
+						const uint32_t ridx = A.tmesh[er[c].mesh].pad[1] - 1u;
+						unsigned long long* z = A.rsz + ((uint64_t)inst32 * A.num_round + ridx) * 2;
+						atomicAdd(z, (unsigned long long)pv);
+						atomicAdd(z + 1, (unsigned long long)pi);
+						if (j + 1 != N) { A.tpart[(uint64_t)inst32 * A.tiles_per_inst + t] = make_uint2(pv, pi); } // it goes on in the next tile
+					}
+				} else {
+					rb[c] -= bs.x; rk[c] -= bs.y;
+				}
+			}
+		}
+		if (SIZES) { return; }
+	}
 	// ---- phase 3: the element
-	auto element = [&](auto passTag, uint32_t s, const VgxTmplElem& e, V2 pv, V2 dv) {
+	auto element = [&](auto passTag, uint32_t s, const VgxTmplElem& e, V2 pv, V2 dv, bool placed, uint32_t bPlaced, uint32_t kPlaced) {
 		if (s < nel) {
 			const uint32_t mesh = e.mesh;
 			const TmplRec* rp = &s_rec[mesh - mA];
@@ -940,20 +1114,22 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 			float fringe = 0.0f;
 			const vgx_draw* tdraw = P.tdraws;
 			if (GENERAL && decltype(passTag)::value == 2) { const VgxTmplMesh* tmm = A.tmesh + mesh; fringe = __uint_as_float(tmm->pad[0]); tdraw = P.tdraws + (dA + TMPL_REC_DK(rp)); }
-			tmpl_elem_emit<KIND, decltype(passTag)::value>(O, j, rp->kind & 0xFFFFu, N, rp->v_off, rp->i_off, rp->ibase, rp->color, rp->f0, rp->f1, pv, dv, dir, vtx, fringe, tdraw, A.tmesh + mesh);
+			tmpl_elem_emit<KIND, decltype(passTag)::value>(O, j, rp->kind & 0xFFFFu, N, rp->v_off, rp->i_off, rp->ibase, rp->color, rp->f0, rp->f1, pv, dv, dir, vtx, fringe, tdraw, A.tmesh + mesh,
+				placed, bPlaced, kPlaced);
 		}
 	};
 #pragma unroll
 	for (int c = 0; c < CH; ++c) {
-		element(std::integral_constant<int, GENERAL ? 1 : 0>(), (uint32_t)c * THREADS + tid, er[c], p1[c], d12[c]);
+		element(std::integral_constant<int, GENERAL ? 1 : 0>(), (uint32_t)c * THREADS + tid, er[c], p1[c], d12[c], false, 0u, 0u);
 	}
 	if (GENERAL) { // the general strokes of the tile, one element per trip: the body exists once
 #pragma unroll 1
 		for (int c = 0; c < CH; ++c) {
 			VgxTmplElem e = er[0]; V2 pv = p1[0], dv = d12[0];
+			uint32_t pb = ROUND ? rb[0] : 0u, pk = ROUND ? rk[0] : 0u, pc = ROUND ? cv[0] : 0u;
 #pragma unroll
-			for (int k = 1; k < CH; ++k) { if (c == k) { e = er[k]; pv = p1[k]; dv = d12[k]; } }
-			element(std::integral_constant<int, 2>(), (uint32_t)c * THREADS + tid, e, pv, dv);
+			for (int k = 1; k < CH; ++k) { if (c == k) { e = er[k]; pv = p1[k]; dv = d12[k]; if (ROUND) { pb = rb[k]; pk = rk[k]; pc = cv[k]; } } }
+			element(std::integral_constant<int, 2>(), (uint32_t)c * THREADS + tid, e, pv, dv, ROUND != 0 && pc != 0, pb, pk);
 		}
 	}
 	TMPL_PROF(3);
@@ -987,7 +1163,110 @@ __global__ __launch_bounds__(VGX_TMPL_G_THREADS, VGX_TMPL_G_MINWAVES) void k_tmp
 	tmpl_emit_body<2, VGX_TMPL_G_THREADS, VGX_TMPL_G_TILE>(A);
 }
 
+// ---- Round joins: the instantiation with the per-step places, and the kernels that make them --------------------------------
+#ifndef VGX_TMPL_R_MINWAVES
+#define VGX_TMPL_R_MINWAVES 2
+#endif
+__global__ __launch_bounds__(VGX_TMPL_G_THREADS, VGX_TMPL_R_MINWAVES) void k_tmpl_emit_round(VgxTmplArgs A)
+{
+	tmpl_emit_body<2, VGX_TMPL_G_THREADS, VGX_TMPL_G_TILE, 1>(A);
+}
+// sizes: the same tiles, the same staged values, the same elem_geometry -- sums instead of stores
+__global__ __launch_bounds__(VGX_TMPL_G_THREADS, VGX_TMPL_R_MINWAVES) void k_tmpl_round_sizes(VgxTmplArgs A)
+{
+	tmpl_emit_body<2, VGX_TMPL_G_THREADS, VGX_TMPL_G_TILE, 2>(A);
+}
+
+// One wave per instance, after k_tmpl_round_sizes: every mesh's place inside the instance (the template's sizes for the meshes without
+// Round joins, the counted ones for the others), the instance's totals, and for every tile what its first mesh holds in front of it.
+__global__ __launch_bounds__(64) void k_tmpl_round_inst(VgxTmplArgs A)
+{
+	const uint32_t lane = threadIdx.x;
+	const uint32_t M = (uint32_t)A.inst.num_meshes, R = A.num_round, TPI = A.tiles_per_inst;
+	for (uint64_t inst = blockIdx.x; inst < A.ninst; inst += gridDim.x) {
+		unsigned long long runV = 0, runI = 0; // wave-uniform
+		bool tooLarge = false;
+		for (uint32_t m0 = 0; m0 < M; m0 += 64) {
+			const uint32_t m = m0 + lane;
+			uint32_t nv = 0, ni = 0;
+			if (m < M) {
+				const uint32_t r1 = A.tmesh[m].pad[1];
+				if (r1) {
+					const unsigned long long* z = A.rsz + (inst * R + (r1 - 1u)) * 2;
+					const unsigned long long v = z[0], i = z[1];
+					tooLarge = tooLarge || v > 65536ull; // what OpMeshOffsets reports for such a mesh (16-bit indices, vgx_scan_ops.h)
+					nv = vgx_sat_nv(v); ni = vgx_sat_ni(i);
+				} else {
+					const vgx_mesh mr = A.tmtab[m];
+					nv = mr.num_vertices; ni = mr.num_indices;
+				}
+			}
+			unsigned long long v = nv, i = ni;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) {
+				const unsigned long long tv = __shfl_up(v, d), ti = __shfl_up(i, d);
+				if (lane >= (uint32_t)d) { v += tv; i += ti; }
+			}
+			const unsigned long long ev = runV + v - nv, ei = runI + i - ni;
+			if (m < M) { A.minfo[inst * M + m] = make_uint4((uint32_t)ev, (uint32_t)ei, nv, ni); }
+			runV += __shfl(v, 63); runI += __shfl(i, 63);
+		}
+		if (tooLarge) { set_status(A.totals, VGX_E_MESH_TOO_LARGE); }
+		if (runV >= (1ull << 32) || runI >= (1ull << 32)) { if (lane == 0) { set_status(A.totals, VGX_E_RANGE); } } // the places inside an instance are 32-bit
+		if (lane == 0) { A.itot[2 * inst] = runV; A.itot[2 * inst + 1] = runI; }
+		// tile t's first mesh in front of the tile: what the tiles behind hold of it, back to the tile it begins in
+		for (uint32_t t0 = 0; t0 < TPI; t0 += 64) {
+			const uint32_t t = t0 + lane;
+			if (t >= TPI) { continue; }
+			uint32_t cvv = 0, cii = 0;
+			const uint32_t first = A.ttile[t].mesh0;
+			if ((first >> 31) == 0 && A.tmesh[first].pad[1] != 0) { // (bit 31 clear: `first` is the mesh number)
+				for (uint32_t u = t; u > 0; ) {
+					--u;
+					const uint2 pt = A.tpart[inst * TPI + u];
+					cvv += pt.x; cii += pt.y;
+					if (A.ttile[u].mesh0 != first) { break; } // the mesh begins in tile u (another first mesh, or this one with bit 31 set)
+				}
+			}
+			A.tcarry[inst * TPI + t] = make_uint2(cvv, cii);
+		}
+	}
+}
+
+// The instances' places in the batch: exclusive sums of their totals; the batch's sizes; the caller's capacities.
+struct OpTmplRoundPlace
+{
+	VgxTmplArgs A;
+	__device__ uint64_t size() const { return A.ninst; }
+	__device__ Sum3 load(uint64_t k) const { Sum3 r = sum3_zero(); r.a = A.itot[2 * k]; r.b = A.itot[2 * k + 1]; return r; }
+	__device__ void store(uint64_t k, Sum3 e) const { A.iplace[2 * k] = e.a; A.iplace[2 * k + 1] = e.b; }
+	__device__ void finish(Sum3 tot) const
+	{
+		vgx_sizes z = A.total;
+		z.num_vertices = tot.a; z.num_indices = tot.b;
+		A.totals->sizes = z;
+		const uint32_t aux = (tot.a > A.caps.vertices ? 1u : 0u) | (tot.b > A.caps.indices ? 2u : 0u) | ((A.meshes_out && z.num_meshes > A.caps.meshes) ? 4u : 0u);
+		if (aux && A.totals->status == VGX_OK) { // the need is in sizes; nothing is emitted (k_tmpl_emit_round leaves when the status is set)
+			A.totals->status = VGX_E_NOSPACE;
+			A.totals->fail_reason = VGX_FAIL_OUT_CAPACITY;
+			A.totals->fail_aux = aux;
+		}
+	}
+};
+
 } // namespace
+
+void vgx_launch_tmpl_round_sizes(const VgxTmplArgs& a, Sum3* partial, hipStream_t s)
+{
+	const uint64_t blocks = a.ninst * a.tiles_per_inst; // the host checked < 2^31
+	if (!blocks) { return; }
+	(void)hipMemsetAsync(a.rsz, 0, (size_t)a.ninst * a.num_round * 2 * sizeof(unsigned long long), s);
+	hipLaunchKernelGGL(k_tmpl_round_sizes, dim3((unsigned)blocks), dim3(VGX_TMPL_G_THREADS), 0, s, a);
+	hipLaunchKernelGGL(k_tmpl_round_inst, dim3((unsigned)(a.ninst > 65536 ? 65536 : a.ninst)), dim3(64), 0, s, a);
+	OpTmplRoundPlace op;
+	op.A = a;
+	vgx_device_scan(op, partial, s, a.ninst);
+}
 
 void vgx_launch_tmpl_check(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, VgxTotals* totals, hipStream_t s)
 {
@@ -1019,7 +1298,10 @@ void vgx_launch_tmpl_build(const VgxTmplBuild& b, hipStream_t s)
 {
 	const uint64_t gm = (b.num_meshes + 255) / 256, ge = (b.num_elems + 255) / 256;
 	const uint64_t nt = (b.num_elems + b.tile - 1) / b.tile + b.nclasses; // >= the tile count (every class rounds up on its own)
-	if (b.num_meshes) { hipLaunchKernelGGL(k_tmpl_meshes, dim3((unsigned)(gm > 4096 ? 4096 : gm)), dim3(256), 0, s, b); }
+	if (b.num_meshes) {
+		hipLaunchKernelGGL(k_tmpl_meshes, dim3((unsigned)(gm > 4096 ? 4096 : gm)), dim3(256), 0, s, b);
+		hipLaunchKernelGGL(k_tmpl_round_index, dim3(1), dim3(256), 0, s, b);
+	}
 	if (b.num_elems) {
 		hipLaunchKernelGGL(k_tmpl_elems, dim3((unsigned)(ge > 4096 ? 4096 : ge)), dim3(256), 0, s, b);
 		hipLaunchKernelGGL(k_tmpl_tiles, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, b);
@@ -1035,7 +1317,8 @@ void vgx_launch_tmpl_emit(const VgxTmplArgs& a, hipStream_t s)
 {
 	const uint64_t blocks = a.wg ? a.num_wg : a.ninst * a.tiles_per_inst; // the host checked < 2^31
 	if (!blocks) { return; }
-	if (a.general == 2) { hipLaunchKernelGGL(k_tmpl_emit_general, dim3((unsigned)blocks), dim3(VGX_TMPL_G_THREADS), 0, s, a); }
+	if (a.general == 3) { hipLaunchKernelGGL(k_tmpl_emit_round, dim3((unsigned)blocks), dim3(VGX_TMPL_G_THREADS), 0, s, a); }
+	else if (a.general == 2) { hipLaunchKernelGGL(k_tmpl_emit_general, dim3((unsigned)blocks), dim3(VGX_TMPL_G_THREADS), 0, s, a); }
 	else if (a.general == 1) { hipLaunchKernelGGL(k_tmpl_emit_open, dim3((unsigned)blocks), dim3(VGX_TMPL_THREADS), 0, s, a); }
 	else { hipLaunchKernelGGL(k_tmpl_emit, dim3((unsigned)blocks), dim3(VGX_TMPL_THREADS), 0, s, a); }
 }

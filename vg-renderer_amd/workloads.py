@@ -121,9 +121,13 @@ def tiger_paths(seed=2024, npaths=240, closed=True):
     return b.arrays(), ops
 
 
-def tiger_draws(ops, instances, first_instance=0, join=capi.JOIN_MITER):
+def tiger_draws(ops, instances, first_instance=0, join=capi.JOIN_MITER, stretch=False):
     """Draw records for `instances` copies of the drawing; instance i is translated by
-    (37*(i%100), 41*(i//100)) at scale 1 (SURVEY 8d config 3). Draw order = instance-major. join: the strokes' LineJoin."""
+    (37*(i%100), 41*(i//100)) at scale 1 (SURVEY 8d config 3). Draw order = instance-major. join: the strokes' LineJoin.
+    stretch: instance i is also stretched by (1 + e, 1 - e), e in {-16 .. 16} / 64 -- what a caller's transformScale(1 + e, 1 - e) leaves in
+    the State; avgScale stays exactly 1 (vg.cpp:4927-4935), so flatten tolerance and stroke widths stay the template's. It changes the
+    angles between the segments, i.e. what Round joins count their arc points on (the transformed polyline, stroker.cpp:1146, 1592): the
+    instances then differ in SIZE."""
     npaths = len(ops)
     one = make_draws(npaths)
     one["path"] = np.arange(npaths, dtype=np.uint32)
@@ -135,6 +139,10 @@ def tiger_draws(ops, instances, first_instance=0, join=capi.JOIN_MITER):
     inst = np.repeat(np.arange(first_instance, first_instance + instances, dtype=np.int64), npaths)
     d["mtx"][:, 4] = (37.0 * (inst % 100)).astype(np.float32)
     d["mtx"][:, 5] = (41.0 * (inst // 100)).astype(np.float32)
+    if stretch:
+        e = (((inst * 37) % 33) - 16).astype(np.float32) / np.float32(64.0)
+        d["mtx"][:, 0] = np.float32(1.0) + e
+        d["mtx"][:, 3] = np.float32(1.0) - e
     return d
 
 

@@ -758,6 +758,8 @@ def main():
 
     K = args.instances
     ps, draws, workload_desc, kind = make_workload(wl, args.config, K, rank)
+    if args.config in CONFIG_ENV:  # library options are read at vgx_create
+        os.environ.update(CONFIG_ENV[args.config])
     ctx = rt.Context(local_rank)
     res = run_config(rt, torch, ctx, local_rank, args.config, ps, draws, kind, args.steps, args.warmup, barrier, placements=max(1, args.placements))
     del draws

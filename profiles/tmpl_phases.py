@@ -11,7 +11,9 @@ import torch  # noqa: E402
 rt = importlib.import_module("vg-renderer_amd.runtime")
 wl = importlib.import_module("vg-renderer_amd.workloads")
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-ps, d = wl.tiger(K)
+JOIN = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # the strokes' LineJoin: 0 Miter (k_tmpl_emit), 2 Bevel (k_tmpl_emit_general), 1 Round (k_tmpl_emit_round)
+ps, ops = wl.tiger_paths()
+d = wl.tiger_draws(ops, K, join=JOIN)
 ctx = rt.Context(0)
 pset = rt.PathSet(ctx, ps)
 dd = rt.upload_draws(d)

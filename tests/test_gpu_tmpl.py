@@ -26,6 +26,9 @@ class _G:
     pass
 
 
+ROUND_STAGES = ["tmpl_round_sizes", "tmpl_emit"]  # a step of a template with Round joins
+
+
 def _run(rt, ctx, ps, d, d_steady=None, nd_steady=None, shrink=None, two_phase=False):
     """vgx_tessellate_count on d, then vgx_tessellate on d_steady (default d; nd_steady draws of it)."""
     import torch
@@ -168,8 +171,8 @@ def test_template_capacity_is_checked_on_the_device(rt, wl):
 
 
 def test_batches_that_are_not_templates_take_the_ordinary_path(rt, wl, oracle):
-    """Round joins (their point counts depend on the transformed geometry), every instance different: the ordinary pipeline,
-    same results."""
+    """Round joins in SEVERAL classes (their sizes are per instance; the per-step tables exist for one class only), every instance
+    different: the ordinary pipeline, same results."""
     ps = wl.closed_fuzz_paths(930, npaths=72)
     ctx = rt.Context(0)
     base = wl.template_draws(ps, 930, 40)
@@ -177,7 +180,8 @@ def test_batches_that_are_not_templates_take_the_ordinary_path(rt, wl, oracle):
     d = base.copy()
     sel = (d["stroke_flags"] & 1) != 0
     d["stroke_flags"][sel] |= np.uint32(rt.capi.JOIN_ROUND << 6)
-    cases.append(("round joins", d))
+    d["scale"][-ps.npaths:] *= np.float32(1.5)  # the last instance at another scale: a second class
+    cases.append(("round joins in two classes", d))
     d = wl.template_draws(ps, 930, 80)
     d["scale"][::ps.npaths] *= (np.float32(1.0) + np.arange(80, dtype=np.float32) / np.float32(128.0))
     cases.append(("every instance at a scale of its own (more flavours than classes)", d))
@@ -195,9 +199,11 @@ def test_batches_that_are_not_templates_take_the_ordinary_path(rt, wl, oracle):
     ctx.close()
 
 
-def test_template_tiles_with_many_small_meshes(rt, wl, oracle):
+@pytest.mark.parametrize("round_joins", [False, True])
+def test_template_tiles_with_many_small_meshes(rt, wl, oracle, round_joins):
     """Rectangles and triangles only: a 1024-element tile touches more meshes than the LDS record table holds and takes the
-    per-lane fallback of k_tmpl_emit; mixed with larger shapes so that both forms run in one launch."""
+    per-lane fallback of k_tmpl_emit; mixed with larger shapes so that both forms run in one launch. round_joins: the same through
+    k_tmpl_emit_round (places from the per-step tables in the fallback as well)."""
     pm = __import__("importlib").import_module("vg-renderer_amd.pathset")
     rs = np.random.RandomState(77)
     b = pm.PathSetBuilder()
@@ -217,9 +223,13 @@ def test_template_tiles_with_many_small_meshes(rt, wl, oracle):
         b.end_path()
     ps = b.arrays()
     d = wl.template_draws(ps, 940, 35)
+    if round_joins:
+        sel = (d["stroke_flags"] & 1) != 0
+        d["stroke_flags"][sel] |= np.uint32(rt.capi.JOIN_ROUND << 6)
     ctx = rt.Context(0)
     got = _run(rt, ctx, ps, d)
     assert got.mode == MODE_TEMPLATE and got.status == 0
+    assert got.stages == (ROUND_STAGES if round_joins else ["tmpl_emit"])
     assert_mesh_equal(got, oracle.tessellate(ps, d), "small meshes")
     ctx.close()
 
@@ -410,9 +420,6 @@ def test_template_general_strokes(rt, wl, oracle, monkeypatch, seed, ninst, tile
 
 
 # ---- Round joins: sizes that belong to the instance --------------------------------------------------------------------------------
-ROUND_STAGES = ["tmpl_round_sizes", "tmpl_emit"]
-
-
 @pytest.mark.parametrize("seed,ninst,tile,closed_only", [(995, 40, None, False), (1995, 36, "128", False), (2995, 48, "960", True), (3995, 33, "64", False), (4995, 64, "2048", True)])
 def test_template_round_joins(rt, wl, oracle, monkeypatch, seed, ninst, tile, closed_only):
     """Round joins count their arc points on the TRANSFORMED polyline (stroker.cpp:1146, 1592): mesh sizes -- and every output place

@@ -116,7 +116,9 @@ struct vgx_ctx
 	vgx_sizes tmplTotal;                 // sizes of the whole batch
 	DevBuf tmplHash, tmplInstCls, tmplClsRep, tmplCls, tmplIinfo, tmplWg;
 	uint32_t tmplRound;                  // Round-join stroke meshes per instance (tmplGeneral == 3): their sizes, and every place behind them, are counted per step
-	DevBuf tmplRsz, tmplTpart, tmplTcarry, tmplMinfo, tmplItot, tmplIplace; // the per-step tables of such a template (VgxTmplArgs)
+	uint32_t tmplRoundElems;             // their elements per instance
+	DevBuf tmplTrmesh, tmplTrix;         // template: the Round-join meshes; per element slot its number among the Round-join elements
+	DevBuf tmplRsz, tmplRelem, tmplMinfo, tmplItot, tmplIplace; // the per-step tables of such a template (VgxTmplArgs)
 	hipStream_t sideStream; hipEvent_t forkEv, joinEv; // optConcurrentEmit only
 	VgxCaps caps; // element capacities matching the buffers above
 	uint64_t capDraws;
@@ -759,7 +761,7 @@ int vgx_destroy(vgx_ctx* ctx)
 		return VGX_E_INVALID_ARG;
 	}
 	DeviceGuard guard(ctx);
-	DevBuf* bufs[] = { &ctx->f1SegDraw, &ctx->f1Segs, &ctx->tmplHash, &ctx->tmplInstCls, &ctx->tmplClsRep, &ctx->tmplCls, &ctx->tmplIinfo, &ctx->tmplWg, &ctx->tmplRsz, &ctx->tmplTpart, &ctx->tmplTcarry, &ctx->tmplMinfo, &ctx->tmplItot, &ctx->tmplIplace, &ctx->tmplTile, &ctx->tmplPoly, &ctx->tmplMesh, &ctx->tmplMtab, &ctx->tmplElem, &ctx->tmplDraws, &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DevBuf* bufs[] = { &ctx->f1SegDraw, &ctx->f1Segs, &ctx->tmplHash, &ctx->tmplInstCls, &ctx->tmplClsRep, &ctx->tmplCls, &ctx->tmplIinfo, &ctx->tmplWg, &ctx->tmplTrmesh, &ctx->tmplTrix, &ctx->tmplRsz, &ctx->tmplRelem, &ctx->tmplMinfo, &ctx->tmplItot, &ctx->tmplIplace, &ctx->tmplTile, &ctx->tmplPoly, &ctx->tmplMesh, &ctx->tmplMtab, &ctx->tmplElem, &ctx->tmplDraws, &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
@@ -781,7 +783,7 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx)
 	if (!ctx) {
 		return 0;
 	}
-	return ctx->f1SegDraw.cap + ctx->f1Segs.cap + ctx->tmplHash.cap + ctx->tmplInstCls.cap + ctx->tmplClsRep.cap + ctx->tmplCls.cap + ctx->tmplIinfo.cap + ctx->tmplWg.cap + ctx->tmplRsz.cap + ctx->tmplTpart.cap + ctx->tmplTcarry.cap + ctx->tmplMinfo.cap + ctx->tmplItot.cap + ctx->tmplIplace.cap + ctx->tmplTile.cap + ctx->tmplPoly.cap + ctx->tmplMesh.cap + ctx->tmplMtab.cap + ctx->tmplElem.cap + ctx->tmplDraws.cap + ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
+	return ctx->f1SegDraw.cap + ctx->f1Segs.cap + ctx->tmplHash.cap + ctx->tmplInstCls.cap + ctx->tmplClsRep.cap + ctx->tmplCls.cap + ctx->tmplIinfo.cap + ctx->tmplWg.cap + ctx->tmplTrmesh.cap + ctx->tmplTrix.cap + ctx->tmplRsz.cap + ctx->tmplRelem.cap + ctx->tmplMinfo.cap + ctx->tmplItot.cap + ctx->tmplIplace.cap + ctx->tmplTile.cap + ctx->tmplPoly.cap + ctx->tmplMesh.cap + ctx->tmplMtab.cap + ctx->tmplElem.cap + ctx->tmplDraws.cap + ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
 }
 
 // ---- path set ---------------------------------------------------------------------------------------
@@ -1340,16 +1342,17 @@ int vgx_partition(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, ui
 static int tmplRoundSizes(vgx_ctx* ctx, VgxTmplArgs& a, hipStream_t s)
 {
 	int st;
-	const uint64_t n = a.ninst, tiles = n * a.tiles_per_inst;
-	a.num_round = ctx->tmplRound;
+	const uint64_t n = a.ninst;
+	a.num_round = ctx->tmplRound; a.num_round_elems = ctx->tmplRoundElems;
+	a.trmesh = (const VgxTmplRoundMesh*)ctx->tmplTrmesh.p; a.trix = (const uint32_t*)ctx->tmplTrix.p;
+	if (n * a.num_round >= (1ull << 32)) { return VGX_E_RANGE; } // one wave per (instance, Round-join mesh), four to a workgroup
 	if ((st = ensure(ctx, ctx->tmplRsz, (n * a.num_round + 1) * 2 * sizeof(unsigned long long))) != VGX_OK) { return st; }
-	if ((st = ensure(ctx, ctx->tmplTpart, (tiles + 1) * sizeof(uint2))) != VGX_OK) { return st; }
-	if ((st = ensure(ctx, ctx->tmplTcarry, (tiles + 1) * sizeof(uint2))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->tmplRelem, (n * a.num_round_elems + 1) * sizeof(uint2))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->tmplMinfo, (n * a.inst.num_meshes + 1) * sizeof(uint4))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->tmplItot, (n + 1) * 2 * sizeof(unsigned long long))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->tmplIplace, (n + 1) * 2 * sizeof(unsigned long long))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->partial, VGX_SCAN_BLOCKS * sizeof(Sum3))) != VGX_OK) { return st; }
-	a.rsz = (unsigned long long*)ctx->tmplRsz.p; a.tpart = (uint2*)ctx->tmplTpart.p; a.tcarry = (uint2*)ctx->tmplTcarry.p;
+	a.rsz = (unsigned long long*)ctx->tmplRsz.p; a.relem = (uint2*)ctx->tmplRelem.p;
 	a.minfo = (uint4*)ctx->tmplMinfo.p; a.itot = (unsigned long long*)ctx->tmplItot.p; a.iplace = (unsigned long long*)ctx->tmplIplace.p;
 	vgx_launch_tmpl_round_sizes(a, (Sum3*)ctx->partial.p, s);
 	mark(ctx, s, "tmpl_round_sizes");
@@ -1585,6 +1588,9 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	if ((st = ensure(ctx, ctx->tmplMtab, (M + 1) * sizeof(vgx_mesh))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->tmplElem, (tiles * tileSize + 64) * sizeof(VgxTmplElem))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->tmplTile, (tiles + 1) * sizeof(VgxTmplTile))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->tmplTrmesh, (M + 2) * sizeof(VgxTmplRoundMesh))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->tmplTrix, (tiles * tileSize + 64) * sizeof(uint32_t))) != VGX_OK) { return st; }
+	b.trmesh = (VgxTmplRoundMesh*)ctx->tmplTrmesh.p; b.trix = (uint32_t*)ctx->tmplTrix.p;
 	b.ttile = (VgxTmplTile*)ctx->tmplTile.p;
 	b.tmesh = (VgxTmplMesh*)ctx->tmplMesh.p; b.tmtab = (vgx_mesh*)ctx->tmplMtab.p; b.telem = (VgxTmplElem*)ctx->tmplElem.p;
 	vgx_launch_tmpl_build(b, s);
@@ -1637,8 +1643,15 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	if (kernelKind == 3u) { HIPCHK(ctx, hipMemcpyAsync(&roundWord, &((VgxTmplClass*)ctx->tmplCls.p)[T].pad[1], sizeof(uint32_t), hipMemcpyDeviceToHost, s)); }
 	HIPCHK(ctx, hipStreamSynchronize(s));
 	if ((st = launchStatus(ctx)) != VGX_OK) { return st; }
-	if (kernelKind == 3u && ((roundWord >> 31) != 0 || (roundWord & 0x7FFFFFFFu) == 0)) { return VGX_OK; } // a tile with more meshes / draws than the LDS tables hold: the ordinary pipeline
-	ctx->tmplRound = roundWord & 0x7FFFFFFFu;
+	ctx->tmplRound = roundWord;
+	ctx->tmplRoundElems = 0;
+	if (kernelKind == 3u) {
+		if (roundWord == 0) { return VGX_OK; }
+		VgxTmplRoundMesh last;
+		HIPCHK(ctx, hipMemcpyAsync(&last, (const VgxTmplRoundMesh*)ctx->tmplTrmesh.p + roundWord, sizeof(last), hipMemcpyDeviceToHost, s));
+		HIPCHK(ctx, hipStreamSynchronize(s));
+		ctx->tmplRoundElems = last.elem0;
+	}
 	ctx->tmplInst = csz[0];
 	ctx->tmplTileSize = tileSize;
 	ctx->tmplPeriod = (uint32_t)P;

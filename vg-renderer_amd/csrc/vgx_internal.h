@@ -98,6 +98,8 @@ struct VgxTmplBuild // count pass: the first period's ordinary count + emit resu
 	uint32_t nclasses;           // the draws are `nclasses` representatives of `period` draws each
 	uint64_t num_vertices, num_indices; // output totals of the concatenated representatives
 	VgxTmplClass* cls;           // [nclasses + 1], written by the first build kernel
+	VgxTmplRoundMesh* trmesh;    // [num_meshes + 1] (used: Round-join meshes + 1)
+	uint32_t* trix;              // [telem slots] the element's number among the Round-join elements, or ~0
 };
 struct VgxTmplArgs // one step
 {
@@ -132,9 +134,11 @@ struct VgxTmplArgs // one step
 	// sizes of those meshes -- and with them every output place behind them -- belong to the instance. Per-step tables, written by
 	// vgx_launch_tmpl_round_sizes and read by k_tmpl_emit_round:
 	uint32_t num_round;          // Round-join stroke meshes per instance (VgxTmplMesh::pad[1] = the mesh's number among them + 1)
-	unsigned long long* rsz;     // [ninst * num_round * 2] vertices, indices of every such mesh (zeroed, then summed tile by tile)
-	uint2* tpart;                // [ninst * tiles_per_inst] vertices / indices the tile's LAST mesh holds inside the tile, when that mesh goes on in the next tile
-	uint2* tcarry;               // [ninst * tiles_per_inst] vertices / indices of the tile's FIRST mesh in front of the tile
+	uint32_t num_round_elems;    // their elements per instance
+	const VgxTmplRoundMesh* trmesh; // [num_round + 1]
+	const uint32_t* trix;        // [telem slots] the element's number among the instance's Round-join elements, or ~0
+	unsigned long long* rsz;     // [ninst * num_round * 2] vertices, indices of every such mesh
+	uint2* relem;                // [ninst * num_round_elems] first vertex / index of every such element inside its mesh
 	uint4* minfo;                // [ninst * meshes] per mesh: first vertex, first index inside the instance; vertices, indices
 	unsigned long long* itot;    // [ninst * 2] vertices, indices of the instance
 	unsigned long long* iplace;  // [ninst * 2] first vertex, first index of the instance in the batch

@@ -183,6 +183,11 @@ struct VgxTmplElem // one element (polyline vertex j of template mesh `mesh`), i
 	uint32_t jq;   // j | (position of the element inside its tile, in OUTPUT order) << 16
 	float lx, ly;  // its LOCAL vertex (= local polyline[mesh.poly_first + j]): one record is all an element reads from memory
 };
+struct VgxTmplRoundMesh // Round-join stroke meshes of the template, in mesh order. [count + 1]; the last entry: mesh = ~0, elem0 = all their elements
+{
+	uint32_t mesh;   // template mesh
+	uint32_t elem0;  // its first element among the instance's Round-join elements
+};
 struct VgxTmplTile // one tile of an instance's element stream = one workgroup of k_tmpl_emit. 32 bytes
 {
 	uint32_t mesh0;     // template mesh that owns the tile's first element; bit 31: that element is the mesh's element 0
@@ -192,7 +197,7 @@ struct VgxTmplTile // one tile of an instance's element stream = one workgroup o
 	uint32_t nel;       // elements in the tile (the last tile of a class is short)
 	uint32_t cmesh0;    // first template mesh of the tile's class (mesh numbers inside an instance = mesh - cmesh0)
 	uint32_t cdraw0;    // first saved draw record of the tile's class (= class * period)
-	uint32_t pad;       // bit 0: the tile holds elements of Round-join meshes
+	uint32_t pad;
 };
 // A batch may repeat its period in a FEW flavours ("classes": the same drawing at a handful of scales, say): every instance equals
 // one of the class representatives in every field the template depends on. The classes' templates are built as ONE template over

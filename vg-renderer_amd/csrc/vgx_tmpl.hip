@@ -208,30 +208,39 @@ __global__ __launch_bounds__(256) void k_tmpl_meshes(VgxTmplBuild B)
 	}
 }
 
-// Round-join meshes numbered in mesh order (one block; after k_tmpl_meshes): tmesh[m].pad[1] = number + 1, their count -> cls[nclasses].pad[1]
+// Round-join meshes numbered in mesh order (one block; after k_tmpl_meshes): tmesh[m].pad[1] = number + 1, trmesh[number] = (mesh, its first
+// element among the instance's Round-join elements); trmesh[count] = (~0, the total); the count -> cls[nclasses].pad[1]
 __global__ __launch_bounds__(256) void k_tmpl_round_index(VgxTmplBuild B)
 {
-	__shared__ uint32_t s_wave[4];
-	__shared__ uint32_t s_run;
+	__shared__ uint2 s_wave[4];
+	__shared__ uint2 s_run;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	if (threadIdx.x == 0) { s_run = 0; }
+	if (threadIdx.x == 0) { s_run = make_uint2(0u, 0u); }
 	__syncthreads();
 	for (uint64_t m0 = 0; m0 < B.num_meshes; m0 += 256) {
 		const uint64_t m = m0 + threadIdx.x;
-		const uint32_t f = (m < B.num_meshes && tmpl_is_round(B.mdesc[m].kind)) ? 1u : 0u;
-		uint32_t v = f;
+		const bool f = m < B.num_meshes && tmpl_is_round(B.mdesc[m].kind);
+		const uint32_t n = f ? B.mdesc[m].poly_n : 0u;
+		uint32_t v = f ? 1u : 0u, e = n;
 #pragma unroll
-		for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(v, d); if (lane >= d) { v += t; } }
-		if (lane == 63) { s_wave[wave] = v; }
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(v, d), te = __shfl_up(e, d); if (lane >= d) { v += t; e += te; } }
+		if (lane == 63) { s_wave[wave] = make_uint2(v, e); }
 		__syncthreads();
-		uint32_t base = s_run, tot = 0;
-		for (int w = 0; w < 4; ++w) { const uint32_t t = s_wave[w]; if (w < wave) { base += t; } tot += t; }
-		if (m < B.num_meshes) { B.tmesh[m].pad[1] = f ? base + v : 0u; }
+		uint2 base = s_run, tot = make_uint2(0u, 0u);
+		for (int w = 0; w < 4; ++w) { const uint2 t = s_wave[w]; if (w < wave) { base.x += t.x; base.y += t.y; } tot.x += t.x; tot.y += t.y; }
+		if (m < B.num_meshes) {
+			B.tmesh[m].pad[1] = f ? base.x + v : 0u;
+			if (f) { VgxTmplRoundMesh r; r.mesh = (uint32_t)m; r.elem0 = base.y + e - n; B.trmesh[base.x + v - 1u] = r; }
+		}
 		__syncthreads();
-		if (threadIdx.x == 0) { s_run += tot; }
+		if (threadIdx.x == 0) { s_run.x += tot.x; s_run.y += tot.y; }
 		__syncthreads();
 	}
-	if (threadIdx.x == 0) { B.cls[B.nclasses].pad[1] = s_run; }
+	if (threadIdx.x == 0) {
+		VgxTmplRoundMesh r; r.mesh = ~0u; r.elem0 = s_run.y;
+		B.trmesh[s_run.x] = r;
+		B.cls[B.nclasses].pad[1] = s_run.x;
+	}
 }
 
 // Element table in processing order: tiles of `tile` elements of the instance's output-ordered element stream; inside a
@@ -280,6 +289,10 @@ __global__ __launch_bounds__(256) void k_tmpl_elems(VgxTmplBuild B)
 		const float2 lv = B.poly[B.mdesc[m].poly_first + j];
 		r.lx = lv.x; r.ly = lv.y;
 		B.telem[slot] = r;
+		{ // Round-join meshes: the element's number among the instance's Round-join elements (where its place lies in the per-step table)
+			const uint32_t r1 = B.tmesh[m].pad[1];
+			B.trix[slot] = r1 ? B.trmesh[r1 - 1u].elem0 + j : ~0u;
+		}
 		if (e == x0) { // tile record, first half: the mesh that owns the tile's first element; bit 31: it begins exactly here
 			B.ttile[tile].mesh0 = (uint32_t)m | (j == 0 ? 0x80000000u : 0u);
 			B.ttile[tile].nel = (uint32_t)(x1 - x0);
@@ -315,13 +328,7 @@ __global__ __launch_bounds__(256) void k_tmpl_tiles(VgxTmplBuild B)
 	B.ttile[t].ndraws = dB - dA + 1;
 	B.ttile[t].cmesh0 = B.cls[c].mesh0;
 	B.ttile[t].cdraw0 = d0;
-	uint32_t flags = 0;
-	if (B.cls[B.nclasses].pad[0] & 4u) { // Round joins somewhere: does this tile hold any?
-		for (uint32_t m = mA; m <= mB && !flags; ++m) { flags = B.tmesh[m].pad[1] ? 1u : 0u; }
-		// the Round-join kernels have no per-lane fallback for tiles whose meshes / draws do not fit the LDS tables: the host then keeps the ordinary pipeline
-		if (mB - mA + 1 > VGX_TMPL_MAXM || dB - dA + 1 > VGX_TMPL_MAXM) { atomicOr(&B.cls[B.nclasses].pad[1], 0x80000000u); }
-	}
-	B.ttile[t].pad = flags;
+	B.ttile[t].pad = 0;
 }
 
 // ---- step ------------------------------------------------------------------------------------------------------------
@@ -717,7 +724,7 @@ __device__ __forceinline__ void tmpl_stroke_counts(uint32_t kind, uint32_t cap, 
 // it needs comes by value: own vertex, previous vertex, the three edge directions around the element, the mesh's first two
 // vertices (closing bridge).
 __device__ __forceinline__ void tmpl_stroke_general(char* opos, char* ocol, char* oidx, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color,
-	float hsw, float hswAA, float fringe, const vgx_draw* tdraw, uint32_t j, V2 p1, V2 pPrev, V2 d12, V2 dPrev, V2 dPrev2, V2 v0, V2 v1, bool placed, uint32_t bPlaced, uint32_t kPlaced)
+	float hsw, float hswAA, float fringe, const vgx_draw* tdraw, uint32_t j, V2 p1, V2 pPrev, V2 d12, V2 dPrev, V2 dPrev2, V2 v0, V2 v1, bool placed, uint32_t bPlaced, uint32_t kPlaced, uint32_t prevPlaced)
 {
 	MeshCtxT<TmplVtx01> mc;
 	mc.kind = VGX_MD_KIND(kindWord); mc.closed = VGX_MD_CLOSED(kindWord) != 0; mc.cap = VGX_MD_CAP(kindWord); mc.join = VGX_MD_JOIN(kindWord);
@@ -731,10 +738,23 @@ __device__ __forceinline__ void tmpl_stroke_general(char* opos, char* ocol, char
 	auto ibaseOf = [&](uint32_t jj) { return jj == 0 ? 0u : (mc.closed ? joinNi : capNi) + (jj - 1) * (bridge + joinNi); };
 	const Elem e = elem_geometry(mc, p1, dPrev, d12);
 	Rails prev = rails(0, 0, 0, 0);
-	if (e.hasConnect) { // the previous element's exit rails (prevSegment*ID, stroker.cpp:1401-1410), from its own geometry
+#ifndef VGX_TMPL_ROUND_PREV_TABLE
+#define VGX_TMPL_ROUND_PREV_TABLE 1 /* 0 (measurement): the previous element's geometry evaluated again, its place = own place - its vertices */
+#endif
+	if (VGX_TMPL_ROUND_PREV_TABLE && e.hasConnect && placed) {
+		// Round-join meshes: the previous element's place and inner side come from the per-step table (k_tmpl_round_sizes evaluated its
+		// geometry already), its arc's point count from its size -- what its exit rails are made of (elem_exit_rails)
+		const uint32_t bPrev = prevPlaced & 0x7FFFFFFFu, nvPrev = bPlaced - bPrev;
+		Elem ep = e;
+		ep.et = (!mc.closed && j == 1) ? ET_CAP_FIRST : ET_JOIN;
+		ep.leftInner = (prevPlaced >> 31) != 0;
+		ep.arc.n = mc.kind == VGX_MESH_STROKE_AA ? (nvPrev - 4u) >> 1 : nvPrev - 2u; // 2n + 4 / n + 2 vertices per join (stroker.cpp:1599, 1156)
+		ep.H = H;
+		prev = elem_exit_rails(mc, ep, bPrev);
+	} else if (e.hasConnect) { // the previous element's exit rails (prevSegment*ID, stroker.cpp:1401-1410), from its own geometry
 		mc.j = j - 1;
 		const Elem ep = elem_geometry(mc, pPrev, dPrev2, dPrev);
-		prev = elem_exit_rails(mc, ep, placed ? bPlaced - ep.nv : vbase(j - 1)); // (Round joins: the previous element ends where this one begins)
+		prev = elem_exit_rails(mc, ep, placed ? bPlaced - ep.nv : vbase(j - 1));
 		mc.j = j;
 	}
 	StrokeWriter w;
@@ -754,7 +774,7 @@ __device__ __forceinline__ void tmpl_stroke_general(char* opos, char* ocol, char
 // Butt / Square caps (tmpl_stroke_elem_open), 2 = + everything else without Round joins (the general body).
 template<int KIND, int PASS, class DF, class VF>
 __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color, float f0, float f1,
-	V2 p1, V2 d12, const DF& dir, const VF& vtx, float fringe, const vgx_draw* tdraw, const VgxTmplMesh* tmm, bool placed = false, uint32_t bPlaced = 0, uint32_t kPlaced = 0)
+	V2 p1, V2 d12, const DF& dir, const VF& vtx, float fringe, const vgx_draw* tdraw, const VgxTmplMesh* tmm, bool placed = false, uint32_t bPlaced = 0, uint32_t kPlaced = 0, uint32_t prevPlaced = 0)
 {
 	const uint32_t kind = VGX_MD_KIND(kindWord);
 	const uint32_t jp1 = j > 0 ? j - 1 : N - 1;
@@ -770,9 +790,9 @@ __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uin
 		const bool closed = VGX_MD_CLOSED(kindWord) != 0;
 		const V2 dPrev = dir(jp1);
 		V2 pPrev = p1, dPrev2 = dPrev, v0 = p1, v1 = p1;
-		if (j > 0) { pPrev = vtx(jp1); dPrev2 = dir(jp1 > 0 ? jp1 - 1 : N - 1); } // the previous element's geometry: only when a bridge connects to it
+		if (j > 0 && !(VGX_TMPL_ROUND_PREV_TABLE && placed)) { pPrev = vtx(jp1); dPrev2 = dir(jp1 > 0 ? jp1 - 1 : N - 1); } // the previous element's geometry: only when a bridge connects to it (Round-join meshes: from the per-step table)
 		if (closed && j + 1 == N) { v0 = vtx(0u); v1 = vtx(N > 1 ? 1u : 0u); }      // join 0's inner side: only the closing bridge asks
-		tmpl_stroke_general(O.pos, O.col, O.idx, kindWord, N, vOff, iOff, ibase, color, f0, f1, fringe, tdraw, j, p1, pPrev, d12, dPrev, dPrev2, v0, v1, placed, bPlaced, kPlaced);
+		tmpl_stroke_general(O.pos, O.col, O.idx, kindWord, N, vOff, iOff, ibase, color, f0, f1, fringe, tdraw, j, p1, pPrev, d12, dPrev, dPrev2, v0, v1, placed, bPlaced, kPlaced, prevPlaced);
 	} else if (openFast) {
 		const V2 dPrev = dir(jp1);
 		V2 dPrev2 = dPrev;
@@ -829,14 +849,12 @@ __global__ __launch_bounds__(256) void k_tmpl_mtab(VgxTmplArgs A, vgx_mesh* mtab
 #define VGX_TMPL_G_THREADS 256
 #endif
 #define VGX_TMPL_G_TILE VGX_TMPL_GENERAL_TILE
-// ROUND: 0 = no Round joins; 1 = Round joins, emit: the places of the instance / its meshes come from the per-step tables and the elements
-// of Round-join meshes are placed by a scan over the tile (phase 2b); 2 = Round joins, SIZES only: phases 0 - 2b, then the sums into the
-// per-step tables instead of phase 3 (k_tmpl_round_sizes). Both run the same phases on the same staged values: the arcs counted = the arcs emitted.
+// ROUND: the template holds Round-join meshes: the places of the instance, of its meshes and of every element of a Round-join mesh come from
+// the per-step tables (k_tmpl_round_sizes / k_tmpl_round_inst / the scan over the instances) instead of the template's closed forms.
 template<int KIND, int THREADS, int MAXTILE, int ROUND = 0>
 __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 {
 	constexpr bool GENERAL = KIND == 2;
-	constexpr bool SIZES = ROUND == 2;
 	static_assert(ROUND == 0 || GENERAL, "Round joins take the general element body");
 	constexpr int CH = MAXTILE / THREADS;
 	__shared__ TmplDraw s_draw[VGX_TMPL_MAXM];
@@ -844,9 +862,6 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 	__shared__ float2 s_vtx[MAXTILE];
 	__shared__ float2 s_dir[MAXTILE];
 	__shared__ uint32_t s_status;
-	__shared__ uint2 s_carry;                                        // ROUND: vertices / indices of the tile's first mesh in front of the tile
-	__shared__ uint2 s_wtot[ROUND ? CH * (THREADS / 64) : 1];        // ROUND: sums of the wave's chunks (phase 2b)
-	__shared__ uint2 s_base[ROUND ? VGX_TMPL_MAXM : 1];              // ROUND: per mesh of the tile: (prefix at its first element in the tile) - (what it holds in front of the tile)
 	const uint32_t tid = threadIdx.x;
 	// workgroup -> (instance, tile of the template), all workgroup-uniform (scalar loads)
 	uint32_t inst32, t;
@@ -860,9 +875,8 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 		inst32 = blockIdx.x / A.tiles_per_inst;
 		t = blockIdx.x - inst32 * A.tiles_per_inst;
 		P.v = (uint64_t)inst32 * A.inst.num_vertices; P.i = (uint64_t)inst32 * A.inst.num_indices; P.m = (uint64_t)inst32 * A.inst.num_meshes;
-		if (ROUND == 1) { P.v = A.iplace[2 * (uint64_t)inst32]; P.i = A.iplace[2 * (uint64_t)inst32 + 1]; }
+		if (ROUND) { P.v = A.iplace[2 * (uint64_t)inst32]; P.i = A.iplace[2 * (uint64_t)inst32 + 1]; }
 	}
-	if (SIZES && (A.ttile[t].pad & 1u) == 0) { return; } // no Round-join element here: nothing to count (its draw records are verified by the emit kernel)
 	const uint64_t inst = inst32;
 	const VgxTmplTile tl = A.ttile[t];
 	P.draw0 = (uint32_t)(inst * A.period); P.cmesh0 = tl.cmesh0; P.tdraws = A.tdraws + tl.cdraw0;
@@ -882,11 +896,9 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 	if (ROUND == 0 && blockIdx.x == 0 && tid == 0 && !A.mesh_base) { // (assembly armed: k_tmpl_mtab wrote them already; Round joins: the scan over the instances did) totals of the batch (the memset in front of this kernel zeroed them)
 		A.totals->sizes = A.total;
 	}
-	if (ROUND != 0 && (nm > VGX_TMPL_MAXM || nd > VGX_TMPL_MAXM)) { // (the host builds no Round-join template with such a tile: k_tmpl_tiles)
-		if (tid == 0) { set_status(A.totals, VGX_E_INTERNAL); }
-		return;
-	}
-	const uint4* minfo = ROUND == 1 ? A.minfo + (uint64_t)inst32 * A.inst.num_meshes : nullptr; // indexed by (template mesh number - P.cmesh0); P.cmesh0 = 0 (one class)
+	const uint4* minfo = ROUND ? A.minfo + (uint64_t)inst32 * A.inst.num_meshes : nullptr; // indexed by (template mesh number - P.cmesh0); P.cmesh0 = 0 (one class)
+	const uint2* relem = ROUND ? A.relem + (uint64_t)inst32 * A.num_round_elems : nullptr;  // indexed by trix[slot]
+	const uint32_t* trix = ROUND ? A.trix + x0 : nullptr;
 	if (nm > VGX_TMPL_MAXM || nd > VGX_TMPL_MAXM) {
 		// workgroup-uniform. Many tiny meshes (or many draws without a mesh) in one tile: the draw records are verified in a loop,
 		// every lane fetches its own records and neighbours
@@ -903,10 +915,17 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 			if (kind == VGX_MESH_FILL_AA) { f0 = tmpl_fill_aa(xf, vt[0], vt[1], vt[2], tm.f0); }
 			auto dir = [&](uint32_t jj) { return v2dir(tmpl_xf(xf, vt[jj]), tmpl_xf(xf, vt[jj + 1 < N ? jj + 1 : 0u])); };
 			auto vtx = [&](uint32_t jj) { return tmpl_xf(xf, vt[jj]); };
-			if (j == 0 && A.meshes_out) { tmpl_mesh_out(A, P, er.mesh); }
+			uint32_t vOff = tm.v_off, iOff = tm.i_off, bP = ~0u, kP = 0, pP = 0;
+			if (ROUND) {
+				const uint4 mi = minfo[er.mesh];
+				vOff = mi.x; iOff = mi.y;
+				if (j == 0 && A.meshes_out) { tmpl_mesh_out_placed(A, P, er.mesh, mi); }
+				const uint32_t rx = trix[s];
+				if (rx != ~0u) { const uint2 bk = relem[rx]; bP = bk.x & 0x7FFFFFFFu; kP = bk.y; if (j > 0) { pP = relem[rx - 1u].x; } }
+			} else if (j == 0 && A.meshes_out) { tmpl_mesh_out(A, P, er.mesh); }
 			const uint32_t ibase = meshBase ? meshBase[er.mesh - P.cmesh0] : 0u;
-			tmpl_elem_emit<KIND, 0>(O, j, tm.kind, N, tm.v_off, tm.i_off, ibase, kind < VGX_MESH_STROKE ? dr.fill_color : dr.stroke_color, f0, tm.f1, tmpl_xf(xf, vt[j]), dir(j), dir, vtx,
-				__uint_as_float(tm.pad[0]), P.tdraws + tm.drawk, A.tmesh + er.mesh);
+			tmpl_elem_emit<KIND, 0>(O, j, tm.kind, N, vOff, iOff, ibase, kind < VGX_MESH_STROKE ? dr.fill_color : dr.stroke_color, f0, tm.f1, tmpl_xf(xf, vt[j]), dir(j), dir, vtx,
+				__uint_as_float(tm.pad[0]), P.tdraws + tm.drawk, A.tmesh + er.mesh, ROUND != 0 && bP != ~0u, bP, kP, pP);
 		}
 		return;
 	}
@@ -918,11 +937,24 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 #endif
 	// ---- phase 0a: every load the workgroup needs, requested at once
 	VgxTmplElem er[CH];
+	uint32_t rb[ROUND ? CH : 1], rk[ROUND ? CH : 1], rp[ROUND ? CH : 1]; // ROUND: elements of Round-join meshes: first vertex / index inside the mesh (else rb = ~0); the previous element's table word
 #pragma unroll
 	for (int c = 0; c < CH; ++c) {
 		const uint32_t s = (uint32_t)c * THREADS + tid; // interleaved: the tile's stroke chunks (the heavier ones, at the tile's end) spread over the waves
 		er[c].mesh = mA; er[c].jq = 0; er[c].lx = 0.0f; er[c].ly = 0.0f;
 		if (s < nel) { er[c] = telem[s]; }
+		if (ROUND) { rb[c] = ~0u; rk[c] = 0; rp[c] = 0; if (s < nel) { rb[c] = trix[s]; } }
+	}
+	if (ROUND) {
+#pragma unroll
+		for (int c = 0; c < CH; ++c) {
+			if (rb[c] != ~0u) { // (table word: place | the join's inner side << 31; a place is <= 65536, so never ~0 with the bit masked off)
+				const uint32_t rx = rb[c];
+				const uint2 bk = relem[rx];
+				if ((er[c].jq & 0xFFFFu) != 0) { rp[c] = relem[rx - 1u].x; }
+				rb[c] = bk.x & 0x7FFFFFFFu; rk[c] = bk.y;
+			}
+		}
 	}
 	VgxTmplMesh tm;
 	memset(&tm, 0, sizeof(tm));
@@ -932,13 +964,10 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 	if (tid < nm) {
 		tm = A.tmesh[mA + tid];
 		if (meshBase) { ibase = meshBase[mA - P.cmesh0 + tid]; }
-		if (ROUND == 1) { mi = minfo[mA + tid]; tm.v_off = mi.x; tm.i_off = mi.y; } // this instance's places
+		if (ROUND) { mi = minfo[mA + tid]; tm.v_off = mi.x; tm.i_off = mi.y; } // this instance's places
 	}
 	if (tid < nd) { s_draw[tid] = tmpl_load_draw(A, idraws, P.tdraws, dA + tid); }
-	if (tid == 0) {
-		s_status = A.totals->status; // an earlier workgroup may have found the batch stale; ONE value for the whole workgroup (the exit below must be uniform)
-		if (ROUND == 1) { s_carry = firstWhole ? make_uint2(0u, 0u) : A.tcarry[(uint64_t)inst32 * A.tiles_per_inst + t]; }
-	}
+	if (tid == 0) { s_status = A.totals->status; } // an earlier workgroup may have found the batch stale; ONE value for the whole workgroup (the exit below must be uniform)
 	__syncthreads();
 	const uint32_t status = s_status;
 	// ---- phase 0b: per-mesh records
@@ -951,8 +980,8 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 		if (kind == VGX_MESH_FILL_AA) { r.f0 = tmpl_fill_aa(tmpl_draw_xf(d), make_float2(tm.l0[0], tm.l0[1]), make_float2(tm.l1[0], tm.l1[1]), make_float2(tm.l2[0], tm.l2[1]), tm.f0); }
 		s_rec[tid] = r;
 		// the caller's mesh table for the meshes that BEGIN in this tile (every mesh of the range but possibly the first)
-		if ((tid > 0 || firstWhole) && A.meshes_out && status == VGX_OK && !SIZES) {
-			if (ROUND == 1) { tmpl_mesh_out_placed(A, P, mA + tid, mi); } else { tmpl_mesh_out(A, P, mA + tid); }
+		if ((tid > 0 || firstWhole) && A.meshes_out && status == VGX_OK) {
+			if (ROUND) { tmpl_mesh_out_placed(A, P, mA + tid, mi); } else { tmpl_mesh_out(A, P, mA + tid); }
 		}
 	}
 	__syncthreads();
@@ -997,109 +1026,8 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 	}
 	__syncthreads();
 	TMPL_PROF(2);
-	// ---- phase 2b (Round joins): what every element of a Round-join mesh emits (elem_geometry on the staged values: the arc of its join),
-	// prefix sums over the tile in processing order (= output order among the strokes) -> the element's first vertex / index inside its mesh
-	uint32_t rb[ROUND ? CH : 1], rk[ROUND ? CH : 1], cv[ROUND ? CH : 1], ci[ROUND ? CH : 1];
-	if (ROUND != 0) {
-		constexpr int NW = THREADS / 64;
-		const uint32_t lane = tid & 63u, wave = tid >> 6;
-#pragma unroll
-		for (int c = 0; c < CH; ++c) { cv[c] = 0; ci[c] = 0; }
-#pragma unroll 1
-		for (int c = 0; c < CH; ++c) { // rolled: elem_geometry is in the kernel once here (and twice in the general body)
-			VgxTmplElem e = er[0]; V2 pv = p1[0], dv = d12[0];
-#pragma unroll
-			for (int k = 1; k < CH; ++k) { if (c == k) { e = er[k]; pv = p1[k]; dv = d12[k]; } }
-			const uint32_t s = (uint32_t)c * THREADS + tid;
-			uint32_t nvE = 0, niE = 0;
-			if (s < nel) {
-				const TmplRec* rp = &s_rec[e.mesh - mA];
-				const uint32_t kw = rp->kind & 0xFFFFu;
-				if (tmpl_is_round(kw)) {
-					const uint32_t j = e.jq & 0xFFFFu, N = rp->n;
-					const int q0 = (int)(e.jq >> 16) - (int)j;
-					const uint32_t jp1 = j > 0 ? j - 1 : N - 1;
-					const uint32_t qq = (uint32_t)(q0 + (int)jp1);
-					V2 dPrev;
-					if (qq < nel) { const float2 v = s_dir[qq]; dPrev = v2(v.x, v.y); }
-					else { dPrev = v2dir(vtxAt(e.mesh, rp, q0, jp1), vtxAt(e.mesh, rp, q0, jp1 + 1 < N ? jp1 + 1 : 0u)); }
-					MeshCtxT<TmplVtx01> mc;
-					mc.kind = VGX_MD_KIND(kw); mc.closed = VGX_MD_CLOSED(kw) != 0; mc.cap = VGX_MD_CAP(kw); mc.join = VGX_MD_JOIN(kw);
-					mc.N = N; mc.j = j; mc.hsw = rp->f0; mc.hswAA = rp->f1; mc.fringe = 0.0f; // (the fringe: thin strokes only, never a Round-join mesh)
-					mc.dr = P.tdraws + (dA + TMPL_REC_DK(rp));
-					mc.vtx.x0 = 0.0f; mc.vtx.y0 = 0.0f; mc.vtx.x1 = 0.0f; mc.vtx.y1 = 0.0f;
-					const Elem g = elem_geometry(mc, pv, dPrev, dv);
-					nvE = g.nv; niE = elem_total_indices(mc, g);
-				}
-			}
-#pragma unroll
-			for (int k = 0; k < CH; ++k) { if (c == k) { cv[k] = nvE; ci[k] = niE; } }
-		}
-		// inclusive sums inside the wave, chunk by chunk; the chunks' totals through LDS
-#pragma unroll
-		for (int c = 0; c < CH; ++c) {
-			uint32_t v = cv[c], i = ci[c];
-#pragma unroll
-			for (int d = 1; d < 64; d <<= 1) {
-				const uint32_t tv = __shfl_up(v, d), ti = __shfl_up(i, d);
-				if (lane >= (uint32_t)d) { v += tv; i += ti; }
-			}
-			rb[c] = v; rk[c] = i;
-			if (lane == 63u) { s_wtot[c * NW + wave] = make_uint2(v, i); }
-		}
-		__syncthreads();
-		{
-			uint32_t runV = 0, runI = 0;
-#pragma unroll
-			for (int c = 0; c < CH; ++c) {
-				uint32_t preV = 0, preI = 0, totV = 0, totI = 0;
-#pragma unroll
-				for (int w = 0; w < NW; ++w) {
-					const uint2 tw = s_wtot[c * NW + w];
-					if ((uint32_t)w < wave) { preV += tw.x; preI += tw.y; }
-					totV += tw.x; totI += tw.y;
-				}
-				rb[c] = runV + preV + rb[c] - cv[c]; // exclusive: what the tile's Round-join elements in front of this one emit
-				rk[c] = runI + preI + rk[c] - ci[c];
-				runV += totV; runI += totI;
-			}
-		}
-		// the mesh's base: the prefix at its first element in the tile, less what the mesh holds in front of the tile (only the tile's
-		// first mesh can begin earlier: it owns output position 0)
-#pragma unroll
-		for (int c = 0; c < CH; ++c) {
-			if (cv[c] != 0) { // (an element of a Round-join mesh: it emits >= 2 vertices)
-				const uint32_t j = er[c].jq & 0xFFFFu, q = er[c].jq >> 16;
-				if (j == 0 || q == 0) {
-					const uint2 cr = (SIZES || j == 0) ? make_uint2(0u, 0u) : s_carry;
-					s_base[er[c].mesh - mA] = make_uint2(rb[c] - cr.x, rk[c] - cr.y);
-				}
-			}
-		}
-		__syncthreads();
-#pragma unroll
-		for (int c = 0; c < CH; ++c) {
-			if (cv[c] != 0) {
-				const uint2 bs = s_base[er[c].mesh - mA];
-				if (SIZES) {
-					const uint32_t j = er[c].jq & 0xFFFFu, q = er[c].jq >> 16, N = s_rec[er[c].mesh - mA].n;
-					if (j + 1 == N || q + 1 == nel) { // the mesh's last element in this tile: what the mesh holds here
-						const uint32_t pv = rb[c] + cv[c] - bs.x, pi = rk[c] + ci[c] - bs.y;
-						const uint32_t ridx = A.tmesh[er[c].mesh].pad[1] - 1u;
-						unsigned long long* z = A.rsz + ((uint64_t)inst32 * A.num_round + ridx) * 2;
-						atomicAdd(z, (unsigned long long)pv);
-						atomicAdd(z + 1, (unsigned long long)pi);
-						if (j + 1 != N) { A.tpart[(uint64_t)inst32 * A.tiles_per_inst + t] = make_uint2(pv, pi); } // it goes on in the next tile
-					}
-				} else {
-					rb[c] -= bs.x; rk[c] -= bs.y;
-				}
-			}
-		}
-		if (SIZES) { return; }
-	}
 	// ---- phase 3: the element
-	auto element = [&](auto passTag, uint32_t s, const VgxTmplElem& e, V2 pv, V2 dv, bool placed, uint32_t bPlaced, uint32_t kPlaced) {
+	auto element = [&](auto passTag, uint32_t s, const VgxTmplElem& e, V2 pv, V2 dv, bool placed, uint32_t bPlaced, uint32_t kPlaced, uint32_t prevPlaced) {
 		if (s < nel) {
 			const uint32_t mesh = e.mesh;
 			const TmplRec* rp = &s_rec[mesh - mA];
@@ -1115,21 +1043,21 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 			const vgx_draw* tdraw = P.tdraws;
 			if (GENERAL && decltype(passTag)::value == 2) { const VgxTmplMesh* tmm = A.tmesh + mesh; fringe = __uint_as_float(tmm->pad[0]); tdraw = P.tdraws + (dA + TMPL_REC_DK(rp)); }
 			tmpl_elem_emit<KIND, decltype(passTag)::value>(O, j, rp->kind & 0xFFFFu, N, rp->v_off, rp->i_off, rp->ibase, rp->color, rp->f0, rp->f1, pv, dv, dir, vtx, fringe, tdraw, A.tmesh + mesh,
-				placed, bPlaced, kPlaced);
+				placed, bPlaced, kPlaced, prevPlaced);
 		}
 	};
 #pragma unroll
 	for (int c = 0; c < CH; ++c) {
-		element(std::integral_constant<int, GENERAL ? 1 : 0>(), (uint32_t)c * THREADS + tid, er[c], p1[c], d12[c], false, 0u, 0u);
+		element(std::integral_constant<int, GENERAL ? 1 : 0>(), (uint32_t)c * THREADS + tid, er[c], p1[c], d12[c], false, 0u, 0u, 0u);
 	}
 	if (GENERAL) { // the general strokes of the tile, one element per trip: the body exists once
 #pragma unroll 1
 		for (int c = 0; c < CH; ++c) {
 			VgxTmplElem e = er[0]; V2 pv = p1[0], dv = d12[0];
-			uint32_t pb = ROUND ? rb[0] : 0u, pk = ROUND ? rk[0] : 0u, pc = ROUND ? cv[0] : 0u;
+			uint32_t pb = ROUND ? rb[0] : 0u, pk = ROUND ? rk[0] : 0u, pp = ROUND ? rp[0] : 0u;
 #pragma unroll
-			for (int k = 1; k < CH; ++k) { if (c == k) { e = er[k]; pv = p1[k]; dv = d12[k]; if (ROUND) { pb = rb[k]; pk = rk[k]; pc = cv[k]; } } }
-			element(std::integral_constant<int, 2>(), (uint32_t)c * THREADS + tid, e, pv, dv, ROUND != 0 && pc != 0, pb, pk);
+			for (int k = 1; k < CH; ++k) { if (c == k) { e = er[k]; pv = p1[k]; dv = d12[k]; if (ROUND) { pb = rb[k]; pk = rk[k]; pp = rp[k]; } } }
+			element(std::integral_constant<int, 2>(), (uint32_t)c * THREADS + tid, e, pv, dv, ROUND != 0 && pb != ~0u, pb, pk, pp);
 		}
 	}
 	TMPL_PROF(3);
@@ -1165,24 +1093,70 @@ __global__ __launch_bounds__(VGX_TMPL_G_THREADS, VGX_TMPL_G_MINWAVES) void k_tmp
 
 // ---- Round joins: the instantiation with the per-step places, and the kernels that make them --------------------------------
 #ifndef VGX_TMPL_R_MINWAVES
-#define VGX_TMPL_R_MINWAVES 2
+#define VGX_TMPL_R_MINWAVES 3
 #endif
 __global__ __launch_bounds__(VGX_TMPL_G_THREADS, VGX_TMPL_R_MINWAVES) void k_tmpl_emit_round(VgxTmplArgs A)
 {
 	tmpl_emit_body<2, VGX_TMPL_G_THREADS, VGX_TMPL_G_TILE, 1>(A);
 }
-// sizes: the same tiles, the same staged values, the same elem_geometry -- sums instead of stores
-__global__ __launch_bounds__(VGX_TMPL_G_THREADS, VGX_TMPL_R_MINWAVES) void k_tmpl_round_sizes(VgxTmplArgs A)
+// Sizes: one wave per (instance, Round-join mesh). Lane = element: its vertex and both neighbours through transformPos2D with the
+// instance's matrix, the two edge directions, elem_geometry -- the very functions on the very inputs k_tmpl_emit_round's phases 1 - 3
+// evaluate (so: the same bits, the arcs counted = the arcs emitted) --, a running prefix over the mesh's elements -> every element's
+// first vertex / index inside its mesh (relem), the mesh's totals (rsz).
+__global__ __launch_bounds__(256) void k_tmpl_round_sizes(VgxTmplArgs A)
 {
-	tmpl_emit_body<2, VGX_TMPL_G_THREADS, VGX_TMPL_G_TILE, 2>(A);
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t R = A.num_round;
+	const uint64_t pairs = A.ninst * (uint64_t)R;
+	const uint64_t g = (uint64_t)blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	if (g >= pairs) { return; }
+	const uint64_t inst = g / R;
+	const uint32_t r = (uint32_t)(g - inst * R);
+	const VgxTmplRoundMesh rm = A.trmesh[r];
+	const VgxTmplMesh tm = A.tmesh[rm.mesh];
+	const TmplDraw dr = tmpl_load_draw(A, A.draws + inst * A.period, A.tdraws, tm.drawk); // (verified: a stale or non-finite record ends the call like in the emit kernel)
+	const TmplXf xf = tmpl_draw_xf(&dr);
+	const float2* vt = A.tpoly + tm.poly_first;
+	const uint32_t N = tm.n;
+	MeshCtxT<TmplVtx01> mc;
+	mc.kind = VGX_MD_KIND(tm.kind); mc.closed = VGX_MD_CLOSED(tm.kind) != 0; mc.cap = VGX_MD_CAP(tm.kind); mc.join = VGX_MD_JOIN(tm.kind);
+	mc.N = N; mc.hsw = tm.f0; mc.hswAA = tm.f1; mc.fringe = 0.0f; // (the fringe: thin strokes only, never a Round-join mesh)
+	mc.dr = A.tdraws + tm.drawk;
+	mc.vtx.x0 = 0.0f; mc.vtx.y0 = 0.0f; mc.vtx.x1 = 0.0f; mc.vtx.y1 = 0.0f;
+	uint2* out = A.relem + inst * A.num_round_elems + rm.elem0;
+	unsigned long long runV = 0, runI = 0;
+	for (uint32_t j0 = 0; j0 < N; j0 += 64) {
+		const uint32_t j = j0 + lane;
+		uint32_t nv = 0, ni = 0;
+		bool inner = false;
+		if (j < N) {
+			const V2 p1 = tmpl_xf(xf, vt[j]);
+			const V2 pn = tmpl_xf(xf, vt[j + 1 < N ? j + 1 : 0u]);
+			const V2 pp = tmpl_xf(xf, vt[j > 0 ? j - 1 : N - 1]);
+			mc.j = j;
+			const Elem e = elem_geometry(mc, p1, v2dir(pp, p1), v2dir(p1, pn));
+			nv = e.nv; ni = elem_total_indices(mc, e); inner = e.leftInner;
+		}
+		unsigned long long v = nv, i = ni;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const unsigned long long tv = __shfl_up(v, d), ti = __shfl_up(i, d);
+			if (lane >= (uint32_t)d) { v += tv; i += ti; }
+		}
+		// table word: the place | the join's inner side << 31 (what the NEXT element's bridge needs of this one: elem_exit_rails); places beyond
+		// 65536 vertices: the mesh is too large, k_tmpl_round_inst ends the call and nothing is emitted
+		if (j < N) { out[j] = make_uint2(((uint32_t)(runV + v - nv) & 0x7FFFFFFFu) | (inner ? 0x80000000u : 0u), (uint32_t)(runI + i - ni)); }
+		runV += __shfl(v, 63); runI += __shfl(i, 63);
+	}
+	if (lane == 0) { A.rsz[2 * g] = runV; A.rsz[2 * g + 1] = runI; }
 }
 
 // One wave per instance, after k_tmpl_round_sizes: every mesh's place inside the instance (the template's sizes for the meshes without
-// Round joins, the counted ones for the others), the instance's totals, and for every tile what its first mesh holds in front of it.
+// Round joins, the counted ones for the others) and the instance's totals.
 __global__ __launch_bounds__(64) void k_tmpl_round_inst(VgxTmplArgs A)
 {
 	const uint32_t lane = threadIdx.x;
-	const uint32_t M = (uint32_t)A.inst.num_meshes, R = A.num_round, TPI = A.tiles_per_inst;
+	const uint32_t M = (uint32_t)A.inst.num_meshes, R = A.num_round;
 	for (uint64_t inst = blockIdx.x; inst < A.ninst; inst += gridDim.x) {
 		unsigned long long runV = 0, runI = 0; // wave-uniform
 		bool tooLarge = false;
@@ -1214,22 +1188,6 @@ __global__ __launch_bounds__(64) void k_tmpl_round_inst(VgxTmplArgs A)
 		if (tooLarge) { set_status(A.totals, VGX_E_MESH_TOO_LARGE); }
 		if (runV >= (1ull << 32) || runI >= (1ull << 32)) { if (lane == 0) { set_status(A.totals, VGX_E_RANGE); } } // the places inside an instance are 32-bit
 		if (lane == 0) { A.itot[2 * inst] = runV; A.itot[2 * inst + 1] = runI; }
-		// tile t's first mesh in front of the tile: what the tiles behind hold of it, back to the tile it begins in
-		for (uint32_t t0 = 0; t0 < TPI; t0 += 64) {
-			const uint32_t t = t0 + lane;
-			if (t >= TPI) { continue; }
-			uint32_t cvv = 0, cii = 0;
-			const uint32_t first = A.ttile[t].mesh0;
-			if ((first >> 31) == 0 && A.tmesh[first].pad[1] != 0) { // (bit 31 clear: `first` is the mesh number)
-				for (uint32_t u = t; u > 0; ) {
-					--u;
-					const uint2 pt = A.tpart[inst * TPI + u];
-					cvv += pt.x; cii += pt.y;
-					if (A.ttile[u].mesh0 != first) { break; } // the mesh begins in tile u (another first mesh, or this one with bit 31 set)
-				}
-			}
-			A.tcarry[inst * TPI + t] = make_uint2(cvv, cii);
-		}
 	}
 }
 
@@ -1260,8 +1218,8 @@ void vgx_launch_tmpl_round_sizes(const VgxTmplArgs& a, Sum3* partial, hipStream_
 {
 	const uint64_t blocks = a.ninst * a.tiles_per_inst; // the host checked < 2^31
 	if (!blocks) { return; }
-	(void)hipMemsetAsync(a.rsz, 0, (size_t)a.ninst * a.num_round * 2 * sizeof(unsigned long long), s);
-	hipLaunchKernelGGL(k_tmpl_round_sizes, dim3((unsigned)blocks), dim3(VGX_TMPL_G_THREADS), 0, s, a);
+	const uint64_t pairs = a.ninst * (uint64_t)a.num_round; // the host checked < 2^32
+	hipLaunchKernelGGL(k_tmpl_round_sizes, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, a);
 	hipLaunchKernelGGL(k_tmpl_round_inst, dim3((unsigned)(a.ninst > 65536 ? 65536 : a.ninst)), dim3(64), 0, s, a);
 	OpTmplRoundPlace op;
 	op.A = a;

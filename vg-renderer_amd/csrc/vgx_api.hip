@@ -1567,9 +1567,10 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	} else {
 		noteHip(ctx, hipMemsetAsync(ctx->tmplCls.p, 0, ((size_t)T + 1) * sizeof(VgxTmplClass), s));
 	}
-	const uint32_t kernelKind = (styles & 4u) ? 3u : ((styles & 2u) ? 2u : ((styles & 1u) ? 1u : 0u));
+	// (bit 3: closed Bevel strokes -- a kernel of their own beside the closed Miter ones; with open strokes or anything else in the template, the general one)
+	const uint32_t kernelKind = (styles & 4u) ? 3u : ((styles & 2u) ? 2u : ((styles & 8u) ? ((styles & 1u) ? 2u : 4u) : ((styles & 1u) ? 1u : 0u)));
 	if (kernelKind == 3u && T != 1) { return VGX_OK; }
-	const uint32_t tileSize = (kernelKind >= 2u && ctx->optTmplTile > VGX_TMPL_GENERAL_TILE) ? (uint32_t)VGX_TMPL_GENERAL_TILE : ctx->optTmplTile;
+	const uint32_t tileSize = ((kernelKind == 2u || kernelKind == 3u) && ctx->optTmplTile > VGX_TMPL_GENERAL_TILE) ? (uint32_t)VGX_TMPL_GENERAL_TILE : ctx->optTmplTile;
 	b.draws = rdraws; b.poly = (const float2*)ctx->poly.p; b.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; b.mprep = (const VgxMeshPrep*)ctx->mprep.p; b.mtab = (const vgx_mesh*)ctx->mtab.p;
 	b.prefix_fill = (const uint64_t*)ctx->elemPrefix.p; b.prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
 	b.num_meshes = M; b.num_elems = E; b.tile = tileSize; b.period = (uint32_t)P; b.nclasses = T;

@@ -156,8 +156,10 @@ __global__ void k_tmpl_classes(VgxTmplBuild B)
 __device__ __forceinline__ uint32_t tmpl_class_of_draw(const VgxTmplBuild& B, uint32_t draw) { return draw / B.period; }
 
 // which stroke styles the template holds -> cls[nclasses].pad[0]: bit 0 = open Miter strokes with Butt / Square caps, bit 1 = any other
-// stroke that is not closed Miter AA / Thin, bit 2 = Round joins (the host zeroes the table first; k_tmpl_classes keeps the word)
+// stroke that is not closed Miter AA / Thin, bit 2 = Round joins, bit 3 = closed Bevel AA / Thin strokes (the host zeroes the table first;
+// k_tmpl_classes keeps the word)
 __device__ __forceinline__ bool tmpl_stroke_is_open_fast(uint32_t kindWord);
+__device__ __forceinline__ bool tmpl_stroke_is_closed_bevel(uint32_t kindWord);
 // the meshes whose sizes depend on the transformed geometry: Round joins count their arc points there (stroker.cpp:1146, 1592);
 // thin strokes turn Round joins into Bevel ones (:318-327)
 __device__ __forceinline__ bool tmpl_is_round(uint32_t kindWord)
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) void k_tmpl_styles(VgxTmplBuild B)
 	for (uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; m < B.num_meshes; m += (uint64_t)gridDim.x * blockDim.x) {
 		const uint32_t kw = B.mdesc[m].kind;
 		const uint32_t kind = VGX_MD_KIND(kw);
-		if (kind >= VGX_MESH_STROKE && !stroke_elem_is_simple(kind, VGX_MD_CLOSED(kw) != 0, VGX_MD_JOIN(kw))) { f |= tmpl_stroke_is_open_fast(kw) ? 1u : 2u; }
+		if (kind >= VGX_MESH_STROKE && !stroke_elem_is_simple(kind, VGX_MD_CLOSED(kw) != 0, VGX_MD_JOIN(kw))) { f |= tmpl_stroke_is_open_fast(kw) ? 1u : (tmpl_stroke_is_closed_bevel(kw) ? 8u : 2u); }
 		if (tmpl_is_round(kw)) { f |= 4u; }
 	}
 	if (f) { atomicOr(&B.cls[B.nclasses].pad[0], f); }
@@ -766,26 +768,144 @@ __device__ __forceinline__ void tmpl_stroke_general(char* opos, char* ocol, char
 	w.flush(b, k);
 }
 
+// Closed strokes with Bevel joins, AA (4 rails; stroker.cpp:1580-1691 with numArcPoints = 1, closing bridge :1970-1984) or Thin (3 rails;
+// :2112-2180, closing :2295-2306; the thin stroker turns Round joins into Bevel ones as well, :318-327): nothing is data dependent, so -- like
+// tmpl_stroke_elem for Miter joins -- every element writes its own join (6 / 4 vertices, one / three fan triangles of the bevel) and the bridge
+// that ENDS at it (join 0: the closing bridge, at the end of the mesh's index range), with the previous join's inner side recomputed from the
+// staged directions. Index layout of the mesh (elem_emit's): join 0's own triangles, then per join j >= 1 its bridge and its own triangles,
+// then the closing bridge. Same values at the same places as the general body (tests: VGX_TMPL=0 byte for byte), a third of its instructions.
+__device__ __forceinline__ bool tmpl_stroke_is_closed_bevel(uint32_t kindWord)
+{
+	const uint32_t kind = VGX_MD_KIND(kindWord), join = VGX_MD_JOIN(kindWord);
+	return VGX_MD_CLOSED(kindWord) != 0 && ((kind == VGX_MESH_STROKE_AA && join == VGX_JOIN_BEVEL) || (kind == VGX_MESH_STROKE_AA_THIN && join != VGX_JOIN_MITER));
+}
+__device__ __forceinline__ void tmpl_stroke_elem_bevel(const TmplOut& O, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color, float hsw, float hswAA,
+	float fringe, uint32_t j, V2 p1, V2 dPrev2, V2 dPrev, V2 d12)
+{
+	const bool thin = VGX_MD_KIND(kindWord) == VGX_MESH_STROKE_AA_THIN;
+	const uint32_t R = thin ? 4u : 6u;             // vertices per join
+	const uint32_t ownIdx = thin ? 3u : 9u;        // the bevel's own triangles
+	const uint32_t bridgeIdx = thin ? 12u : 18u;
+	const float sideWidth = thin ? fringe : hswAA; // elem_geometry
+	const VgxJoin jn = vgx_join_dirs(dPrev, d12, sideWidth);
+	const bool L = jn.leftInner;
+	const uint32_t b = R * j;
+	const uint32_t bi = b + ibase; // index VALUES carry the assembly base, positions in the streams do not
+	const uint32_t c0 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
+	const V2 n01 = L ? v2cw(jn.d01) : v2ccw(jn.d01);
+	const V2 n12 = L ? v2cw(jn.d12) : v2ccw(jn.d12);
+	char* pp = O.pos + (vOff + b) * 8u;
+	char* pc = O.col + (vOff + b) * 4u;
+	const uint32_t kOwn = j == 0 ? 0u : ownIdx + (j - 1u) * (bridgeIdx + ownIdx) + bridgeIdx; // behind the bridge that ends here
+	char* pio = O.idx + (iOff + kOwn) * 2u;
+	Rails mine; // entry rails
+	if (thin) {
+		const V2 vf = v2mul(jn.v, fringe);
+		const V2 q0 = L ? v2add(p1, vf) : v2sub(p1, vf);
+		const V2 q2 = v2add(p1, v2mul(n01, fringe));
+		const V2 q3 = v2add(p1, v2mul(n12, fringe));
+		PosPair q; q.x0 = q0.x; q.y0 = q0.y; q.x1 = p1.x; q.y1 = p1.y;
+		PosPair r; r.x0 = q2.x; r.y0 = q2.y; r.x1 = q3.x; r.y1 = q3.y;
+		ColPair c; c.c0 = c0; c.c1 = color;
+		ColPair d; d.c0 = c0; d.c1 = c0;
+		Idx3 t; // the bevel: (b+1, b+2, b+3) / (b+1, b+3, b+2)
+		t.a = ((bi + 1u) & 0xFFFFu) | ((L ? bi + 2u : bi + 3u) << 16); t.b = (uint16_t)(L ? bi + 3u : bi + 2u);
+		VGX_ST_GUARD(c0 ^ __float_as_uint(q.x0) ^ __float_as_uint(r.y1)) {
+		*(PosPair*)pp = q;
+		*(PosPair*)(pp + 16) = r;
+		*(ColPair*)pc = c;
+		*(ColPair*)(pc + 8) = d;
+		TMPL_IDX_ON *(Idx3*)pio = t;
+		}
+		mine = L ? rails(bi, bi + 1, bi + 2, 0) : rails(bi + 2, bi + 1, bi, 0);
+	} else {
+		const V2 vhaa = v2mul(jn.v, hswAA);
+		const V2 vh = v2mul(jn.v, hsw);
+		const V2 q0 = L ? v2add(p1, vhaa) : v2sub(p1, vhaa);
+		const V2 q1 = L ? v2add(p1, vh) : v2sub(p1, vh);
+		const float cosAngle = vgm_abs(v2dot(n01, n12));
+		const V2 q2 = v2sub(v2add(p1, v2mul(n01, hsw)), v2mul(jn.d01, cosAngle * fringe));
+		const V2 q3 = v2add(p1, v2mul(n01, hswAA));
+		const V2 q4 = v2add(v2add(p1, v2mul(n12, hsw)), v2mul(jn.d12, cosAngle * fringe));
+		const V2 q5 = v2add(p1, v2mul(n12, hswAA));
+		PosPair q; q.x0 = q0.x; q.y0 = q0.y; q.x1 = q1.x; q.y1 = q1.y;
+		PosPair r; r.x0 = q2.x; r.y0 = q2.y; r.x1 = q3.x; r.y1 = q3.y;
+		PosPair u; u.x0 = q4.x; u.y0 = q4.y; u.x1 = q5.x; u.y1 = q5.y;
+		ColPair c; c.c0 = c0; c.c1 = color;
+		ColPair d; d.c0 = color; d.c1 = c0;
+		const uint32_t a = bi + 2u; // arcID
+		Idx9 t; // the bevel as an arc of one segment (tri3 of the writer)
+		if (L) {
+			t.a = ((bi + 1u) & 0xFFFFu) | (a << 16); t.b = ((a + 2u) & 0xFFFFu) | (a << 16);
+			t.c = ((a + 1u) & 0xFFFFu) | ((a + 3u) << 16); t.d = (a & 0xFFFFu) | ((a + 3u) << 16);
+			t.e = (uint16_t)(a + 2u);
+		} else {
+			t.a = ((bi + 1u) & 0xFFFFu) | ((a + 2u) << 16); t.b = (a & 0xFFFFu) | (a << 16);
+			t.c = ((a + 3u) & 0xFFFFu) | ((a + 1u) << 16); t.d = (a & 0xFFFFu) | ((a + 2u) << 16);
+			t.e = (uint16_t)(a + 3u);
+		}
+		VGX_ST_GUARD(c0 ^ __float_as_uint(q.x0) ^ __float_as_uint(u.y1)) {
+		*(PosPair*)pp = q;
+		*(PosPair*)(pp + 16) = r;
+		*(PosPair*)(pp + 32) = u;
+		*(ColPair*)pc = c;
+		*(ColPair*)(pc + 8) = d;
+		*(ColPair*)(pc + 16) = d;
+		TMPL_IDX_ON *(Idx9*)pio = t;
+		}
+		mine = L ? rails(bi, bi + 1, bi + 2, bi + 3) : rails(bi + 3, bi + 2, bi + 1, bi);
+	}
+	{
+		// the bridge that ends at this join: from join j - 1's exit rails (elem_exit_rails), or -- join 0 -- the closing bridge from the last join's
+		const uint32_t jm = j > 0 ? j - 1 : N - 1;
+		const VgxJoin jp = vgx_join_dirs(dPrev2, dPrev, sideWidth);
+		const uint32_t pb = R * jm + ibase;
+		const Rails p = thin ? (jp.leftInner ? rails(pb, pb + 1, pb + 3, 0) : rails(pb + 3, pb + 1, pb, 0))
+		                     : (jp.leftInner ? rails(pb, pb + 1, pb + 4, pb + 5) : rails(pb + 5, pb + 4, pb + 1, pb));
+		const uint32_t kBridge = j > 0 ? kOwn - bridgeIdx : ownIdx + (N - 1u) * (bridgeIdx + ownIdx);
+		char* pi = O.idx + (iOff + kBridge) * 2u;
+		Idx6 t0; t0.a = (p.a & 0xFFFFu) | (p.b << 16); t0.b = (mine.b & 0xFFFFu) | (p.a << 16); t0.c = (mine.b & 0xFFFFu) | (mine.a << 16);
+		Idx6 t1; t1.a = (p.b & 0xFFFFu) | (p.c << 16); t1.b = (mine.c & 0xFFFFu) | (p.b << 16); t1.c = (mine.c & 0xFFFFu) | (mine.b << 16);
+		VGX_ST_GUARD(t0.a ^ t1.c) TMPL_IDX_ON {
+		*(Idx6*)pi = t0;
+		*(Idx6*)(pi + 12) = t1;
+		if (!thin) {
+			Idx6 t2; t2.a = (p.c & 0xFFFFu) | (p.d << 16); t2.b = (mine.d & 0xFFFFu) | (p.c << 16); t2.c = (mine.d & 0xFFFFu) | (mine.c << 16);
+			*(Idx6*)(pi + 24) = t2;
+		}
+		}
+	}
+}
+
 // One element given its mesh's constants, its transformed vertex, its own edge direction and a way to get the mesh's other
 // edge directions (dir(jj) = direction of the edge jj -> jj + 1, cyclic) and vertices (vtx(jj), general strokes only).
 // PASS (GENERAL only): 0 = every element, 1 = everything but the general strokes, 2 = the general strokes only -- the tile loop runs
 // pass 1 unrolled and pass 2 as a rolled loop, so that the general element body (~120 VGPRs of branches) is in the kernel once.
 // KIND: what stroke styles the template holds: 0 = closed Miter AA / Thin only (the headline's kernel), 1 = + open Miter strokes with
-// Butt / Square caps (tmpl_stroke_elem_open), 2 = + everything else without Round joins (the general body).
+// Butt / Square caps (tmpl_stroke_elem_open), 2 = + everything else (the general body; closed Bevel strokes take tmpl_stroke_elem_bevel there too),
+// 3 = closed Miter and closed Bevel strokes only (tmpl_stroke_elem_bevel beside tmpl_stroke_elem: no general body in the kernel).
+#ifndef VGX_TMPL_BEVEL_FAST
+#define VGX_TMPL_BEVEL_FAST 1 /* 0 (measurement): closed Bevel strokes through the general body */
+#endif
 template<int KIND, int PASS, class DF, class VF>
 __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color, float f0, float f1,
 	V2 p1, V2 d12, const DF& dir, const VF& vtx, float fringe, const vgx_draw* tdraw, const VgxTmplMesh* tmm, bool placed = false, uint32_t bPlaced = 0, uint32_t kPlaced = 0, uint32_t prevPlaced = 0)
 {
 	const uint32_t kind = VGX_MD_KIND(kindWord);
 	const uint32_t jp1 = j > 0 ? j - 1 : N - 1;
-	constexpr bool GENERAL = KIND == 2, OPEN = KIND >= 1;
+	constexpr bool GENERAL = KIND == 2, OPEN = KIND == 1 || KIND == 2, BEVEL = KIND == 3;
 	const bool openFast = OPEN && kind >= VGX_MESH_STROKE && tmpl_stroke_is_open_fast(kindWord);
 	const bool general = GENERAL && kind >= VGX_MESH_STROKE && !openFast && !stroke_elem_is_simple(kind, VGX_MD_CLOSED(kindWord) != 0, VGX_MD_JOIN(kindWord));
 	if (GENERAL && ((PASS == 1 && general) || (PASS == 2 && !general))) { return; }
+	const bool closedBevel = (BEVEL || (general && VGX_TMPL_BEVEL_FAST)) && kind >= VGX_MESH_STROKE && tmpl_stroke_is_closed_bevel(kindWord);
 	if (kind < VGX_MESH_STROKE) {
 		V2 dPrev = d12;
 		if (kind == VGX_MESH_FILL_AA) { dPrev = dir(jp1); }
 		tmpl_fill_elem(O, kindWord, N, vOff, iOff, ibase, color, f0, j, p1, dPrev, d12);
+	} else if (closedBevel) {
+		const V2 dPrev = dir(jp1);
+		const V2 dPrev2 = dir(jp1 > 0 ? jp1 - 1 : N - 1); // cyclic: element 0's previous join is the last one
+		tmpl_stroke_elem_bevel(O, kindWord, N, vOff, iOff, ibase, color, f0, f1, fringe, j, p1, dPrev2, dPrev, d12);
 	} else if (general) {
 		const bool closed = VGX_MD_CLOSED(kindWord) != 0;
 		const V2 dPrev = dir(jp1);
@@ -862,6 +982,7 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 	__shared__ float2 s_vtx[MAXTILE];
 	__shared__ float2 s_dir[MAXTILE];
 	__shared__ uint32_t s_status;
+	__shared__ float s_fringe[KIND >= 2 ? VGX_TMPL_MAXM : 1]; // per mesh of the tile: the draw's fringe (Bevel joins, Butt caps, thin strokes: kernels with those only)
 	const uint32_t tid = threadIdx.x;
 	// workgroup -> (instance, tile of the template), all workgroup-uniform (scalar loads)
 	uint32_t inst32, t;
@@ -977,6 +1098,7 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 		TmplRec r;
 		r.ibase = ibase; r.n = tm.n; r.v_off = tm.v_off; r.i_off = tm.i_off;
 		r.kind = (tm.kind & 0xFFFFu) | ((tm.drawk - dA) << 16); r.color = kind < VGX_MESH_STROKE ? d->fill_color : d->stroke_color; r.f0 = tm.f0; r.f1 = tm.f1;
+		if (KIND >= 2) { s_fringe[tid] = __uint_as_float(tm.pad[0]); }
 		if (kind == VGX_MESH_FILL_AA) { r.f0 = tmpl_fill_aa(tmpl_draw_xf(d), make_float2(tm.l0[0], tm.l0[1]), make_float2(tm.l1[0], tm.l1[1]), make_float2(tm.l2[0], tm.l2[1]), tm.f0); }
 		s_rec[tid] = r;
 		// the caller's mesh table for the meshes that BEGIN in this tile (every mesh of the range but possibly the first)
@@ -1039,9 +1161,9 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 				return v2dir(vtxAt(mesh, rp, q0, jj), vtxAt(mesh, rp, q0, jj + 1 < N ? jj + 1 : 0u)); // the edge belongs to another tile
 			};
 			auto vtx = [&](uint32_t jj) { return vtxAt(mesh, rp, q0, jj); };
-			float fringe = 0.0f;
+			const float fringe = KIND >= 2 ? s_fringe[mesh - mA] : 0.0f;
 			const vgx_draw* tdraw = P.tdraws;
-			if (GENERAL && decltype(passTag)::value == 2) { const VgxTmplMesh* tmm = A.tmesh + mesh; fringe = __uint_as_float(tmm->pad[0]); tdraw = P.tdraws + (dA + TMPL_REC_DK(rp)); }
+			if (GENERAL && decltype(passTag)::value == 2) { tdraw = P.tdraws + (dA + TMPL_REC_DK(rp)); }
 			tmpl_elem_emit<KIND, decltype(passTag)::value>(O, j, rp->kind & 0xFFFFu, N, rp->v_off, rp->i_off, rp->ibase, rp->color, rp->f0, rp->f1, pv, dv, dir, vtx, fringe, tdraw, A.tmesh + mesh,
 				placed, bPlaced, kPlaced, prevPlaced);
 		}
@@ -1086,6 +1208,11 @@ __global__ __launch_bounds__(VGX_TMPL_THREADS) void k_tmpl_emit_open(VgxTmplArgs
 #ifndef VGX_TMPL_G_MINWAVES
 #define VGX_TMPL_G_MINWAVES 3
 #endif
+// closed strokes with Miter and Bevel joins only: the headline kernel's shape with the Bevel routine beside the Miter one
+__global__ __launch_bounds__(VGX_TMPL_THREADS) void k_tmpl_emit_bevel(VgxTmplArgs A)
+{
+	tmpl_emit_body<3, VGX_TMPL_THREADS, VGX_TMPL_MAX_TILE>(A);
+}
 __global__ __launch_bounds__(VGX_TMPL_G_THREADS, VGX_TMPL_G_MINWAVES) void k_tmpl_emit_general(VgxTmplArgs A)
 {
 	tmpl_emit_body<2, VGX_TMPL_G_THREADS, VGX_TMPL_G_TILE>(A);
@@ -1275,7 +1402,8 @@ void vgx_launch_tmpl_emit(const VgxTmplArgs& a, hipStream_t s)
 {
 	const uint64_t blocks = a.wg ? a.num_wg : a.ninst * a.tiles_per_inst; // the host checked < 2^31
 	if (!blocks) { return; }
-	if (a.general == 3) { hipLaunchKernelGGL(k_tmpl_emit_round, dim3((unsigned)blocks), dim3(VGX_TMPL_G_THREADS), 0, s, a); }
+	if (a.general == 4) { hipLaunchKernelGGL(k_tmpl_emit_bevel, dim3((unsigned)blocks), dim3(VGX_TMPL_THREADS), 0, s, a); }
+	else if (a.general == 3) { hipLaunchKernelGGL(k_tmpl_emit_round, dim3((unsigned)blocks), dim3(VGX_TMPL_G_THREADS), 0, s, a); }
 	else if (a.general == 2) { hipLaunchKernelGGL(k_tmpl_emit_general, dim3((unsigned)blocks), dim3(VGX_TMPL_G_THREADS), 0, s, a); }
 	else if (a.general == 1) { hipLaunchKernelGGL(k_tmpl_emit_open, dim3((unsigned)blocks), dim3(VGX_TMPL_THREADS), 0, s, a); }
 	else { hipLaunchKernelGGL(k_tmpl_emit, dim3((unsigned)blocks), dim3(VGX_TMPL_THREADS), 0, s, a); }

@@ -117,7 +117,7 @@ struct vgx_ctx
 	DevBuf tmplHash, tmplInstCls, tmplClsRep, tmplCls, tmplIinfo, tmplWg;
 	uint32_t tmplRound;                  // Round-join stroke meshes per instance (tmplGeneral == 3): their sizes, and every place behind them, are counted per step
 	uint32_t tmplRoundElems;             // their elements per instance
-	DevBuf tmplTrmesh, tmplTrix;         // template: the Round-join meshes; per element slot its number among the Round-join elements
+	DevBuf tmplTrmesh;                   // template: the Round-join meshes (mesh, first element among the Round-join elements)
 	DevBuf tmplRsz, tmplRelem, tmplMinfo, tmplItot, tmplIplace; // the per-step tables of such a template (VgxTmplArgs)
 	hipStream_t sideStream; hipEvent_t forkEv, joinEv; // optConcurrentEmit only
 	VgxCaps caps; // element capacities matching the buffers above
@@ -761,7 +761,7 @@ int vgx_destroy(vgx_ctx* ctx)
 		return VGX_E_INVALID_ARG;
 	}
 	DeviceGuard guard(ctx);
-	DevBuf* bufs[] = { &ctx->f1SegDraw, &ctx->f1Segs, &ctx->tmplHash, &ctx->tmplInstCls, &ctx->tmplClsRep, &ctx->tmplCls, &ctx->tmplIinfo, &ctx->tmplWg, &ctx->tmplTrmesh, &ctx->tmplTrix, &ctx->tmplRsz, &ctx->tmplRelem, &ctx->tmplMinfo, &ctx->tmplItot, &ctx->tmplIplace, &ctx->tmplTile, &ctx->tmplPoly, &ctx->tmplMesh, &ctx->tmplMtab, &ctx->tmplElem, &ctx->tmplDraws, &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DevBuf* bufs[] = { &ctx->f1SegDraw, &ctx->f1Segs, &ctx->tmplHash, &ctx->tmplInstCls, &ctx->tmplClsRep, &ctx->tmplCls, &ctx->tmplIinfo, &ctx->tmplWg, &ctx->tmplTrmesh, &ctx->tmplRsz, &ctx->tmplRelem, &ctx->tmplMinfo, &ctx->tmplItot, &ctx->tmplIplace, &ctx->tmplTile, &ctx->tmplPoly, &ctx->tmplMesh, &ctx->tmplMtab, &ctx->tmplElem, &ctx->tmplDraws, &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
@@ -783,7 +783,7 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx)
 	if (!ctx) {
 		return 0;
 	}
-	return ctx->f1SegDraw.cap + ctx->f1Segs.cap + ctx->tmplHash.cap + ctx->tmplInstCls.cap + ctx->tmplClsRep.cap + ctx->tmplCls.cap + ctx->tmplIinfo.cap + ctx->tmplWg.cap + ctx->tmplTrmesh.cap + ctx->tmplTrix.cap + ctx->tmplRsz.cap + ctx->tmplRelem.cap + ctx->tmplMinfo.cap + ctx->tmplItot.cap + ctx->tmplIplace.cap + ctx->tmplTile.cap + ctx->tmplPoly.cap + ctx->tmplMesh.cap + ctx->tmplMtab.cap + ctx->tmplElem.cap + ctx->tmplDraws.cap + ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
+	return ctx->f1SegDraw.cap + ctx->f1Segs.cap + ctx->tmplHash.cap + ctx->tmplInstCls.cap + ctx->tmplClsRep.cap + ctx->tmplCls.cap + ctx->tmplIinfo.cap + ctx->tmplWg.cap + ctx->tmplTrmesh.cap + ctx->tmplRsz.cap + ctx->tmplRelem.cap + ctx->tmplMinfo.cap + ctx->tmplItot.cap + ctx->tmplIplace.cap + ctx->tmplTile.cap + ctx->tmplPoly.cap + ctx->tmplMesh.cap + ctx->tmplMtab.cap + ctx->tmplElem.cap + ctx->tmplDraws.cap + ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
 }
 
 // ---- path set ---------------------------------------------------------------------------------------
@@ -1344,7 +1344,7 @@ static int tmplRoundSizes(vgx_ctx* ctx, VgxTmplArgs& a, hipStream_t s)
 	int st;
 	const uint64_t n = a.ninst;
 	a.num_round = ctx->tmplRound; a.num_round_elems = ctx->tmplRoundElems;
-	a.trmesh = (const VgxTmplRoundMesh*)ctx->tmplTrmesh.p; a.trix = (const uint32_t*)ctx->tmplTrix.p;
+	a.trmesh = (const VgxTmplRoundMesh*)ctx->tmplTrmesh.p;
 	if (n * a.num_round >= (1ull << 32)) { return VGX_E_RANGE; } // one wave per (instance, Round-join mesh), four to a workgroup
 	if ((st = ensure(ctx, ctx->tmplRsz, (n * a.num_round + 1) * 2 * sizeof(unsigned long long))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->tmplRelem, (n * a.num_round_elems + 1) * sizeof(uint2))) != VGX_OK) { return st; }
@@ -1396,7 +1396,7 @@ static int runTmpl(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 	a.caps.vertices = out->cap_vertices; a.caps.indices = out->cap_indices; a.caps.meshes = out->cap_meshes;
 	if (a.num_wg > 0x7FFFFFFFull) { return VGX_E_RANGE; } // one workgroup per (instance, tile)
 	noteHip(ctx, hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s));
-	if (a.general == 3) {
+	if (a.general == 3 || a.general == 5) {
 		// Round joins: vertices / indices are the instances' own -- counted on the device, checked against the capacities there
 		a.total.num_vertices = 0; a.total.num_indices = 0;
 		int st;
@@ -1435,7 +1435,7 @@ static bool tmplFor(const vgx_ctx* ctx, const vgx_pathset* ps, uint64_t ndraws)
 {
 	return ctx->tmplOn && ctx->optTmpl && ps == ctx->tmplPs && ps->gen == ctx->tmplPsGen && ctx->tmplPeriod && ndraws % ctx->tmplPeriod == 0 && ndraws >= ctx->tmplPeriod
 		&& (ctx->tmplClasses == 1 || ndraws == ctx->tmplNDraws) // several classes: the per-instance table belongs to ONE batch size
-		&& !(ctx->tmplGeneral == 3 && ctx->asmArmed);           // Round joins + draw-command assembly: the ordinary pipeline (the next count builds no template)
+		&& !((ctx->tmplGeneral == 3 || ctx->tmplGeneral == 5) && ctx->asmArmed);           // Round joins + draw-command assembly: the ordinary pipeline (the next count builds no template)
 }
 
 // The ordinary count + two-phase flatten in LOCAL space (apply_transform = 0) + mesh sizing of `n` draws: what a template is built
@@ -1568,9 +1568,12 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 		noteHip(ctx, hipMemsetAsync(ctx->tmplCls.p, 0, ((size_t)T + 1) * sizeof(VgxTmplClass), s));
 	}
 	// (bit 3: closed Bevel strokes -- a kernel of their own beside the closed Miter ones; with open strokes or anything else in the template, the general one)
-	const uint32_t kernelKind = (styles & 4u) ? 3u : ((styles & 2u) ? 2u : ((styles & 8u) ? ((styles & 1u) ? 2u : 4u) : ((styles & 1u) ? 1u : 0u)));
-	if (kernelKind == 3u && T != 1) { return VGX_OK; }
-	const uint32_t tileSize = ((kernelKind == 2u || kernelKind == 3u) && ctx->optTmplTile > VGX_TMPL_GENERAL_TILE) ? (uint32_t)VGX_TMPL_GENERAL_TILE : ctx->optTmplTile;
+	// (bit 4: closed AA strokes with Round joins -- with nothing but closed strokes in the template, kernel 5: no general body)
+	const uint32_t kernelKind = (styles & 4u) ? ((styles & 3u) ? 3u : 5u) : ((styles & 2u) ? 2u : ((styles & 8u) ? ((styles & 1u) ? 2u : 4u) : ((styles & 1u) ? 1u : 0u)));
+	const bool roundTmpl = kernelKind == 3u || kernelKind == 5u;
+	if (roundTmpl && T != 1) { return VGX_OK; }
+	uint32_t tileSize = ((kernelKind == 2u || kernelKind == 3u) && ctx->optTmplTile > VGX_TMPL_GENERAL_TILE) ? (uint32_t)VGX_TMPL_GENERAL_TILE : ctx->optTmplTile;
+	if (kernelKind == 5u && ctx->optTmplTile == VGX_TMPL_MAX_TILE) { tileSize = VGX_TMPL_RC_TILE; } // (its own workgroup shape; a VGX_TMPL_TILE override stands)
 	b.draws = rdraws; b.poly = (const float2*)ctx->poly.p; b.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; b.mprep = (const VgxMeshPrep*)ctx->mprep.p; b.mtab = (const vgx_mesh*)ctx->mtab.p;
 	b.prefix_fill = (const uint64_t*)ctx->elemPrefix.p; b.prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
 	b.num_meshes = M; b.num_elems = E; b.tile = tileSize; b.period = (uint32_t)P; b.nclasses = T;
@@ -1590,8 +1593,7 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	if ((st = ensure(ctx, ctx->tmplElem, (tiles * tileSize + 64) * sizeof(VgxTmplElem))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->tmplTile, (tiles + 1) * sizeof(VgxTmplTile))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->tmplTrmesh, (M + 2) * sizeof(VgxTmplRoundMesh))) != VGX_OK) { return st; }
-	if ((st = ensure(ctx, ctx->tmplTrix, (tiles * tileSize + 64) * sizeof(uint32_t))) != VGX_OK) { return st; }
-	b.trmesh = (VgxTmplRoundMesh*)ctx->tmplTrmesh.p; b.trix = (uint32_t*)ctx->tmplTrix.p;
+	b.trmesh = (VgxTmplRoundMesh*)ctx->tmplTrmesh.p;
 	b.ttile = (VgxTmplTile*)ctx->tmplTile.p;
 	b.tmesh = (VgxTmplMesh*)ctx->tmplMesh.p; b.tmtab = (vgx_mesh*)ctx->tmplMtab.p; b.telem = (VgxTmplElem*)ctx->tmplElem.p;
 	vgx_launch_tmpl_build(b, s);
@@ -1641,12 +1643,12 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 		HIPCHK(ctx, hipStreamSynchronize(s)); // the host vectors go away
 	}
 	uint32_t roundWord = 0;
-	if (kernelKind == 3u) { HIPCHK(ctx, hipMemcpyAsync(&roundWord, &((VgxTmplClass*)ctx->tmplCls.p)[T].pad[1], sizeof(uint32_t), hipMemcpyDeviceToHost, s)); }
+	if (roundTmpl) { HIPCHK(ctx, hipMemcpyAsync(&roundWord, &((VgxTmplClass*)ctx->tmplCls.p)[T].pad[1], sizeof(uint32_t), hipMemcpyDeviceToHost, s)); }
 	HIPCHK(ctx, hipStreamSynchronize(s));
 	if ((st = launchStatus(ctx)) != VGX_OK) { return st; }
 	ctx->tmplRound = roundWord;
 	ctx->tmplRoundElems = 0;
-	if (kernelKind == 3u) {
+	if (roundTmpl) {
 		if (roundWord == 0) { return VGX_OK; }
 		VgxTmplRoundMesh last;
 		HIPCHK(ctx, hipMemcpyAsync(&last, (const VgxTmplRoundMesh*)ctx->tmplTrmesh.p + roundWord, sizeof(last), hipMemcpyDeviceToHost, s));
@@ -1663,7 +1665,7 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	ctx->tmplNDraws = ndraws;
 	ctx->tmplTotal = z;
 	ctx->tmplGeneral = kernelKind; // which instantiation of the emit kernel the template needs
-	if (kernelKind == 3u) {
+	if (roundTmpl) {
 		// Round joins: this batch's vertices / indices -- the count of one step, read back
 		VgxTmplArgs a;
 		memset(&a, 0, sizeof(a));

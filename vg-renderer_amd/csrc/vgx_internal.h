@@ -99,7 +99,6 @@ struct VgxTmplBuild // count pass: the first period's ordinary count + emit resu
 	uint64_t num_vertices, num_indices; // output totals of the concatenated representatives
 	VgxTmplClass* cls;           // [nclasses + 1], written by the first build kernel
 	VgxTmplRoundMesh* trmesh;    // [num_meshes + 1] (used: Round-join meshes + 1)
-	uint32_t* trix;              // [telem slots] the element's number among the Round-join elements, or ~0
 };
 struct VgxTmplArgs // one step
 {
@@ -136,9 +135,8 @@ struct VgxTmplArgs // one step
 	uint32_t num_round;          // Round-join stroke meshes per instance (VgxTmplMesh::pad[1] = the mesh's number among them + 1)
 	uint32_t num_round_elems;    // their elements per instance
 	const VgxTmplRoundMesh* trmesh; // [num_round + 1]
-	const uint32_t* trix;        // [telem slots] the element's number among the instance's Round-join elements, or ~0
 	unsigned long long* rsz;     // [ninst * num_round * 2] vertices, indices of every such mesh
-	uint2* relem;                // [ninst * num_round_elems] first vertex / index of every such element inside its mesh
+	uint2* relem;                // [ninst * num_round_elems] per element of such a mesh: first vertex / index inside the mesh, size and inner side of the element in front (tmpl_round_word)
 	uint4* minfo;                // [ninst * meshes] per mesh: first vertex, first index inside the instance; vertices, indices
 	unsigned long long* itot;    // [ninst * 2] vertices, indices of the instance
 	unsigned long long* iplace;  // [ninst * 2] first vertex, first index of the instance in the batch
@@ -153,6 +151,13 @@ void vgx_launch_tmpl_build(const VgxTmplBuild& b, hipStream_t s);   // after vgx
 void vgx_launch_tmpl_hash(const vgx_draw* draws, uint64_t ndraws, uint64_t period, unsigned long long* hashes, hipStream_t s); // hashes[instance], zeroed by the caller
 void vgx_launch_tmpl_check_cls(const vgx_draw* draws, uint64_t ndraws, uint64_t period, const uint32_t* inst_cls, const uint32_t* cls_rep, VgxTotals* totals, hipStream_t s);
 void vgx_launch_tmpl_emit(const VgxTmplArgs& a, hipStream_t s);
+#ifndef VGX_TMPL_RC_THREADS
+#define VGX_TMPL_RC_THREADS 640 /* k_tmpl_emit_round_closed (templates of closed strokes with Round joins): threads per workgroup, */
+#define VGX_TMPL_RC_TILE 2560   /* elements per tile */
+#endif
+#ifndef VGX_TMPL_RC_WAVES
+#define VGX_TMPL_RC_WAVES 5     /* waves per SIMD its registers are limited for */
+#endif
 #ifndef VGX_TMPL_GENERAL_TILE
 #define VGX_TMPL_GENERAL_TILE 2048 /* tile size of templates that hold general strokes (the LDS stages of k_tmpl_emit_general) */
 #endif

@@ -175,6 +175,7 @@ struct VgxTmplMesh // one mesh of the template. 64 bytes
 	uint32_t kind;       // VgxMeshDesc::kind word
 	float f0, f1;        // fills: fringe / 2 (the sign is per instance), -; strokes: hsw, hswAA (thin: fringe, fringe)
 	float l0[2], l1[2], l2[2]; // its first three LOCAL vertices: the fill orientation (stroker.cpp:721-723) is the sign of their transformed triangle
+	                           // (Round-join stroke meshes: l2[0] = the arc step da, l2[1] = bits of the mesh's first element among the Round-join elements)
 	uint32_t pad[2];     // [0]: the draw's fringe (bits); [1]: Round-join stroke meshes: the mesh's number among the instance's Round-join meshes + 1, else 0
 };
 struct VgxTmplElem // one element (polyline vertex j of template mesh `mesh`), in processing order. 16 bytes

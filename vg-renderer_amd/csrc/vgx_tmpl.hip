@@ -160,6 +160,7 @@ __device__ __forceinline__ uint32_t tmpl_class_of_draw(const VgxTmplBuild& B, ui
 // k_tmpl_classes keeps the word)
 __device__ __forceinline__ bool tmpl_stroke_is_open_fast(uint32_t kindWord);
 __device__ __forceinline__ bool tmpl_stroke_is_closed_bevel(uint32_t kindWord);
+__device__ __forceinline__ bool tmpl_stroke_is_closed_round_aa(uint32_t kindWord); // bit 4
 // the meshes whose sizes depend on the transformed geometry: Round joins count their arc points there (stroker.cpp:1146, 1592);
 // thin strokes turn Round joins into Bevel ones (:318-327)
 __device__ __forceinline__ bool tmpl_is_round(uint32_t kindWord)
@@ -176,7 +177,9 @@ __global__ __launch_bounds__(256) void k_tmpl_styles(VgxTmplBuild B)
 	for (uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; m < B.num_meshes; m += (uint64_t)gridDim.x * blockDim.x) {
 		const uint32_t kw = B.mdesc[m].kind;
 		const uint32_t kind = VGX_MD_KIND(kw);
-		if (kind >= VGX_MESH_STROKE && !stroke_elem_is_simple(kind, VGX_MD_CLOSED(kw) != 0, VGX_MD_JOIN(kw))) { f |= tmpl_stroke_is_open_fast(kw) ? 1u : (tmpl_stroke_is_closed_bevel(kw) ? 8u : 2u); }
+		if (kind >= VGX_MESH_STROKE && !stroke_elem_is_simple(kind, VGX_MD_CLOSED(kw) != 0, VGX_MD_JOIN(kw))) {
+			f |= tmpl_stroke_is_open_fast(kw) ? 1u : (tmpl_stroke_is_closed_bevel(kw) ? 8u : (tmpl_stroke_is_closed_round_aa(kw) ? 16u : 2u));
+		}
 		if (tmpl_is_round(kw)) { f |= 4u; }
 	}
 	if (f) { atomicOr(&B.cls[B.nclasses].pad[0], f); }
@@ -232,7 +235,14 @@ __global__ __launch_bounds__(256) void k_tmpl_round_index(VgxTmplBuild B)
 		for (int w = 0; w < 4; ++w) { const uint2 t = s_wave[w]; if (w < wave) { base.x += t.x; base.y += t.y; } tot.x += t.x; tot.y += t.y; }
 		if (m < B.num_meshes) {
 			B.tmesh[m].pad[1] = f ? base.x + v : 0u;
-			if (f) { VgxTmplRoundMesh r; r.mesh = (uint32_t)m; r.elem0 = base.y + e - n; B.trmesh[base.x + v - 1u] = r; }
+			if (f) {
+				VgxTmplRoundMesh r; r.mesh = (uint32_t)m; r.elem0 = base.y + e - n; B.trmesh[base.x + v - 1u] = r;
+				// what the emit kernel needs of a Round-join mesh besides its record, in the record (l2: only AA fills read the three local vertices):
+				// the arc step da (stroker.cpp:1398 -- scale, half width and tolerance are the template's) and the mesh's first table word
+				const vgx_draw* td = B.draws + B.mdesc[m].draw;
+				B.tmesh[m].l2[0] = vgx_step_angle(td->scale, B.tmesh[m].f0, td->tess_tol);
+				B.tmesh[m].l2[1] = __uint_as_float(r.elem0);
+			}
 		}
 		__syncthreads();
 		if (threadIdx.x == 0) { s_run.x += tot.x; s_run.y += tot.y; }
@@ -291,10 +301,6 @@ __global__ __launch_bounds__(256) void k_tmpl_elems(VgxTmplBuild B)
 		const float2 lv = B.poly[B.mdesc[m].poly_first + j];
 		r.lx = lv.x; r.ly = lv.y;
 		B.telem[slot] = r;
-		{ // Round-join meshes: the element's number among the instance's Round-join elements (where its place lies in the per-step table)
-			const uint32_t r1 = B.tmesh[m].pad[1];
-			B.trix[slot] = r1 ? B.trmesh[r1 - 1u].elem0 + j : ~0u;
-		}
 		if (e == x0) { // tile record, first half: the mesh that owns the tile's first element; bit 31: it begins exactly here
 			B.ttile[tile].mesh0 = (uint32_t)m | (j == 0 ? 0x80000000u : 0u);
 			B.ttile[tile].nel = (uint32_t)(x1 - x0);
@@ -726,7 +732,7 @@ __device__ __forceinline__ void tmpl_stroke_counts(uint32_t kind, uint32_t cap, 
 // it needs comes by value: own vertex, previous vertex, the three edge directions around the element, the mesh's first two
 // vertices (closing bridge).
 __device__ __forceinline__ void tmpl_stroke_general(char* opos, char* ocol, char* oidx, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color,
-	float hsw, float hswAA, float fringe, const vgx_draw* tdraw, uint32_t j, V2 p1, V2 pPrev, V2 d12, V2 dPrev, V2 dPrev2, V2 v0, V2 v1, bool placed, uint32_t bPlaced, uint32_t kPlaced, uint32_t prevPlaced)
+	float hsw, float hswAA, float fringe, const vgx_draw* tdraw, uint32_t j, V2 p1, V2 pPrev, V2 d12, V2 dPrev, V2 dPrev2, V2 v0, V2 v1, bool placed, uint32_t bPlaced, uint32_t kPlaced, uint32_t nvPrevPlaced, bool prevInner)
 {
 	MeshCtxT<TmplVtx01> mc;
 	mc.kind = VGX_MD_KIND(kindWord); mc.closed = VGX_MD_CLOSED(kindWord) != 0; mc.cap = VGX_MD_CAP(kindWord); mc.join = VGX_MD_JOIN(kindWord);
@@ -746,10 +752,10 @@ __device__ __forceinline__ void tmpl_stroke_general(char* opos, char* ocol, char
 	if (VGX_TMPL_ROUND_PREV_TABLE && e.hasConnect && placed) {
 		// Round-join meshes: the previous element's place and inner side come from the per-step table (k_tmpl_round_sizes evaluated its
 		// geometry already), its arc's point count from its size -- what its exit rails are made of (elem_exit_rails)
-		const uint32_t bPrev = prevPlaced & 0x7FFFFFFFu, nvPrev = bPlaced - bPrev;
+		const uint32_t nvPrev = nvPrevPlaced, bPrev = bPlaced - nvPrev;
 		Elem ep = e;
 		ep.et = (!mc.closed && j == 1) ? ET_CAP_FIRST : ET_JOIN;
-		ep.leftInner = (prevPlaced >> 31) != 0;
+		ep.leftInner = prevInner;
 		ep.arc.n = mc.kind == VGX_MESH_STROKE_AA ? (nvPrev - 4u) >> 1 : nvPrev - 2u; // 2n + 4 / n + 2 vertices per join (stroker.cpp:1599, 1156)
 		ep.H = H;
 		prev = elem_exit_rails(mc, ep, bPrev);
@@ -877,6 +883,133 @@ __device__ __forceinline__ void tmpl_stroke_elem_bevel(const TmplOut& O, uint32_
 	}
 }
 
+// Closed AA strokes with Round joins (stroker.cpp:1580-1691, closing bridge :1970-1984), the places from the per-step table: the element
+// writes its own join -- inner pair, the arc's first pair, one pair per inner arc point (sincos), the arc's last pair; one fan triangle
+// + fringe quad (9 indices) per arc segment -- and the bridge that ENDS at it (join 0: the closing bridge, at the end of the mesh's index
+// range), whose far side is the previous join's exit rails: that join's place and inner side are its table word, its arc's point count the
+// difference of the two places. da (the arc step, stroker.cpp:1398) is the mesh's, evaluated once per mesh and tile. Same values at the same
+// places as elem_geometry + elem_emit (tests: VGX_TMPL_ROUND=0 byte for byte).
+__device__ __forceinline__ bool tmpl_stroke_is_closed_round_aa(uint32_t kindWord)
+{
+	return VGX_MD_CLOSED(kindWord) != 0 && VGX_MD_KIND(kindWord) == VGX_MESH_STROKE_AA && VGX_MD_JOIN(kindWord) == VGX_JOIN_ROUND;
+}
+// Per-step table word pair of one element of a Round-join mesh (k_tmpl_round_sizes writes, the emit kernels read): its first vertex b and
+// first index k inside the mesh, and what the bridge in front of it needs of the PREVIOUS element (join 0 of a closed stroke: of the last
+// join): its vertex count nvPrev (-> its place and, 2 n + 4 or n + 2, its arc's point count) and its inner side.
+//   x = b (16 bits) | prevInner << 16 | (nvPrev >> 1) << 17 (15 bits)        y = k (20 bits) | (nvPrev & 1) << 20
+// Meshes hold <= 65 536 vertices (16-bit indices; an element's place is < 65 535, an element's size <= 65 534) and so < 2^19 indices; a mesh
+// beyond that ends the call (k_tmpl_round_inst), nothing reads its words. A closed AA stroke needs x only: its joins have 2 n + 4 (even)
+// vertices, and k follows from b (k_j = 9 (b_j - 4 j) / 2 + 18 (j - 1): 9 indices per arc segment, one 18-index bridge per join in front).
+__device__ __forceinline__ uint2 tmpl_round_word(uint32_t b, uint32_t k, uint32_t nvPrev, bool prevInner)
+{
+	return make_uint2((b & 0xFFFFu) | (prevInner ? 0x10000u : 0u) | (((nvPrev >> 1) & 0x7FFFu) << 17), (k & 0xFFFFFu) | ((nvPrev & 1u) << 20));
+}
+__device__ __forceinline__ void tmpl_round_unword(uint32_t x, uint32_t y, uint32_t* b, uint32_t* k, uint32_t* nvPrev, bool* prevInner)
+{
+	*b = x & 0xFFFFu; *k = y & 0xFFFFFu; *nvPrev = ((x >> 17) << 1) | ((y >> 20) & 1u); *prevInner = (x & 0x10000u) != 0;
+}
+struct TmplRoundPlace // what an element of a Round-join mesh takes from the per-step tables
+{
+	bool placed;       // the element belongs to a Round-join mesh
+	uint32_t b, k;     // its first vertex / index inside the mesh
+	uint32_t nvPrev;   // vertices of the element in front (join 0 of a closed stroke: of the LAST join): its place = b - nvPrev (join 0: nv - nvPrev)
+	bool prevInner;    // that element's inner side (leftInner)
+	uint32_t nv, ni;   // the mesh's vertices / indices (closing bridge)
+	float da;          // the mesh's arc step
+};
+__device__ __forceinline__ void tmpl_stroke_elem_round(const TmplOut& O, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color, float hsw, float hswAA,
+	uint32_t j, V2 p1, V2 dPrev, V2 d12, const TmplRoundPlace& rp)
+{
+	const VgxJoin jn = vgx_join_dirs(dPrev, d12, hswAA);
+	const bool L = jn.leftInner;
+	const V2 n01 = L ? v2cw(jn.d01) : v2ccw(jn.d01);
+	const V2 n12 = L ? v2cw(jn.d12) : v2ccw(jn.d12);
+#ifdef VGX_EXP_FAKEARC /* measurement only: no atan2 pair, the arc's point count from the table */
+	VgxArc arc; arc.a01 = n01.x; arc.arcDa = n12.y * 0.01f; arc.n = 2;
+#else
+	const VgxArc arc = vgx_round_join_arc(n01, n12, L, rp.da);
+#endif
+#ifdef VGX_EXP_FIXEDN /* measurement only */
+	const uint32_t n = 2;
+#else
+	const uint32_t n = arc.n;
+#endif
+	const uint32_t b = rp.b, bi = b + ibase; // index VALUES carry the assembly base, positions in the streams do not
+	const uint32_t c0 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
+	char* pp = O.pos + (vOff + b) * 8u;
+	char* pc = O.col + (vOff + b) * 4u;
+	const V2 vhaa = v2mul(jn.v, hswAA);
+	const V2 vh = v2mul(jn.v, hsw);
+	const V2 q0 = L ? v2add(p1, vhaa) : v2sub(p1, vhaa);
+	const V2 q1 = L ? v2add(p1, vh) : v2sub(p1, vh);
+	const V2 q2 = v2add(p1, v2mul(n01, hsw));
+	const V2 q3 = v2add(p1, v2mul(n01, hswAA));
+	const V2 qa = v2add(p1, v2mul(n12, hsw));
+	const V2 qb = v2add(p1, v2mul(n12, hswAA));
+	PosPair q; q.x0 = q0.x; q.y0 = q0.y; q.x1 = q1.x; q.y1 = q1.y;
+	PosPair r; r.x0 = q2.x; r.y0 = q2.y; r.x1 = q3.x; r.y1 = q3.y;
+	PosPair u; u.x0 = qa.x; u.y0 = qa.y; u.x1 = qb.x; u.y1 = qb.y;
+	ColPair c; c.c0 = c0; c.c1 = color;
+	ColPair d; d.c0 = color; d.c1 = c0;
+	VGX_ST_GUARD(c0 ^ __float_as_uint(q.x0) ^ __float_as_uint(u.y1)) {
+	*(PosPair*)pp = q;
+	*(PosPair*)(pp + 16) = r;
+	*(PosPair*)(pp + 16 + 16 * n) = u;
+	*(ColPair*)pc = c;
+	*(ColPair*)(pc + 8) = d;
+	*(ColPair*)(pc + 8 + 8 * n) = d;
+	}
+	for (uint32_t i = 1; i < n; ++i) { // the arc's inner points (:1610-1627)
+		const float ang = arc.a01 + i * arc.arcDa;
+		float sa, ca;
+#ifdef VGX_EXP_FAKESIN
+		sa = ang; ca = 1.0f - ang;
+#else
+		vgm_sincos(ang, &sa, &ca);
+#endif
+		const V2 dir = v2(ca, sa);
+		const V2 w0 = v2add(p1, v2mul(dir, hsw)), w1 = v2add(p1, v2mul(dir, hswAA));
+		PosPair t; t.x0 = w0.x; t.y0 = w0.y; t.x1 = w1.x; t.y1 = w1.y;
+		VGX_ST_GUARD(c0 ^ __float_as_uint(t.x0)) {
+		*(PosPair*)(pp + 16 + 16 * i) = t;
+		*(ColPair*)(pc + 8 + 8 * i) = d;
+		}
+	}
+	const uint32_t k = j == 0 ? 0u : 9u * ((b - 4u * j) >> 1) + 18u * (j - 1u); // first index of the join's range = of the bridge that ends here
+	{ // own triangles: behind the bridge that ends here (join 0 has none in front)
+		char* pio = O.idx + (iOff + k + (j == 0 ? 0u : 18u)) * 2u;
+		uint32_t a = bi + 2u; // arcID
+		for (uint32_t i = 0; i < n; ++i, a += 2u, pio += 18) {
+			Idx9 t; // tri3 of the writer
+			if (L) {
+				t.a = ((bi + 1u) & 0xFFFFu) | (a << 16); t.b = ((a + 2u) & 0xFFFFu) | (a << 16);
+				t.c = ((a + 1u) & 0xFFFFu) | ((a + 3u) << 16); t.d = (a & 0xFFFFu) | ((a + 3u) << 16);
+				t.e = (uint16_t)(a + 2u);
+			} else {
+				t.a = ((bi + 1u) & 0xFFFFu) | ((a + 2u) << 16); t.b = (a & 0xFFFFu) | (a << 16);
+				t.c = ((a + 3u) & 0xFFFFu) | ((a + 1u) << 16); t.d = (a & 0xFFFFu) | ((a + 2u) << 16);
+				t.e = (uint16_t)(a + 3u);
+			}
+			VGX_ST_GUARD(t.a ^ t.d) TMPL_IDX_ON *(Idx9*)pio = t;
+		}
+	}
+	{ // the bridge that ends at this join (bridge4 of the writer): previous exit rails (elem_exit_rails) -> own entry rails
+		const Rails mine = L ? rails(bi, bi + 1, bi + 2, bi + 3) : rails(bi + 3, bi + 2, bi + 1, bi);
+		const uint32_t nvPrev = rp.nvPrev;                             // 2 n + 4 vertices (:1599)
+		const uint32_t pb = (j > 0 ? b : rp.nv) - nvPrev + ibase, pe = pb + nvPrev - 2u; // arcID behind its last segment = place + 2 + 2 n
+		const Rails p = rp.prevInner ? rails(pb, pb + 1, pe, pe + 1) : rails(pe + 1, pe, pb + 1, pb);
+		char* pi = O.idx + (iOff + (j > 0 ? k : rp.ni - 18u)) * 2u;
+		Idx6 t0; t0.a = (p.a & 0xFFFFu) | (p.b << 16); t0.b = (mine.b & 0xFFFFu) | (p.a << 16); t0.c = (mine.b & 0xFFFFu) | (mine.a << 16);
+		Idx6 t1; t1.a = (p.b & 0xFFFFu) | (p.c << 16); t1.b = (mine.c & 0xFFFFu) | (p.b << 16); t1.c = (mine.c & 0xFFFFu) | (mine.b << 16);
+		Idx6 t2; t2.a = (p.c & 0xFFFFu) | (p.d << 16); t2.b = (mine.d & 0xFFFFu) | (p.c << 16); t2.c = (mine.d & 0xFFFFu) | (mine.c << 16);
+		VGX_ST_GUARD(t0.a ^ t1.c) TMPL_IDX_ON {
+		*(Idx6*)pi = t0;
+		*(Idx6*)(pi + 12) = t1;
+		*(Idx6*)(pi + 24) = t2;
+		}
+	}
+}
+
 // One element given its mesh's constants, its transformed vertex, its own edge direction and a way to get the mesh's other
 // edge directions (dir(jj) = direction of the edge jj -> jj + 1, cyclic) and vertices (vtx(jj), general strokes only).
 // PASS (GENERAL only): 0 = every element, 1 = everything but the general strokes, 2 = the general strokes only -- the tile loop runs
@@ -884,13 +1017,20 @@ __device__ __forceinline__ void tmpl_stroke_elem_bevel(const TmplOut& O, uint32_
 // KIND: what stroke styles the template holds: 0 = closed Miter AA / Thin only (the headline's kernel), 1 = + open Miter strokes with
 // Butt / Square caps (tmpl_stroke_elem_open), 2 = + everything else (the general body; closed Bevel strokes take tmpl_stroke_elem_bevel there too),
 // 3 = closed Miter and closed Bevel strokes only (tmpl_stroke_elem_bevel beside tmpl_stroke_elem: no general body in the kernel).
+#ifndef VGX_TMPL_K3_ROLLED
+#define VGX_TMPL_K3_ROLLED 0 /* 1 (measured: bevel 2.22 -> 2.33 ms, round the same): one copy of the element routines, one element per trip */
+#endif
+#ifndef VGX_TMPL_RC_ROLLED
+#define VGX_TMPL_RC_ROLLED 1 /* k_tmpl_emit_round_closed: the Round-join elements in a rolled second pass (0: inlined into the unrolled one) */
+#endif
 #ifndef VGX_TMPL_BEVEL_FAST
 #define VGX_TMPL_BEVEL_FAST 1 /* 0 (measurement): closed Bevel strokes through the general body */
 #endif
 template<int KIND, int PASS, class DF, class VF>
 __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color, float f0, float f1,
-	V2 p1, V2 d12, const DF& dir, const VF& vtx, float fringe, const vgx_draw* tdraw, const VgxTmplMesh* tmm, bool placed = false, uint32_t bPlaced = 0, uint32_t kPlaced = 0, uint32_t prevPlaced = 0)
+	V2 p1, V2 d12, const DF& dir, const VF& vtx, float fringe, const vgx_draw* tdraw, const VgxTmplMesh* tmm, const TmplRoundPlace& rpl)
 {
+	const bool placed = rpl.placed;
 	const uint32_t kind = VGX_MD_KIND(kindWord);
 	const uint32_t jp1 = j > 0 ? j - 1 : N - 1;
 	constexpr bool GENERAL = KIND == 2, OPEN = KIND == 1 || KIND == 2, BEVEL = KIND == 3;
@@ -902,6 +1042,8 @@ __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uin
 		V2 dPrev = d12;
 		if (kind == VGX_MESH_FILL_AA) { dPrev = dir(jp1); }
 		tmpl_fill_elem(O, kindWord, N, vOff, iOff, ibase, color, f0, j, p1, dPrev, d12);
+	} else if (BEVEL && placed) { // (the kernel of closed strokes only: a Round-join mesh there is a closed AA one)
+		tmpl_stroke_elem_round(O, vOff, iOff, ibase, color, f0, f1, j, p1, dir(jp1), d12, rpl);
 	} else if (closedBevel) {
 		const V2 dPrev = dir(jp1);
 		const V2 dPrev2 = dir(jp1 > 0 ? jp1 - 1 : N - 1); // cyclic: element 0's previous join is the last one
@@ -912,7 +1054,7 @@ __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uin
 		V2 pPrev = p1, dPrev2 = dPrev, v0 = p1, v1 = p1;
 		if (j > 0 && !(VGX_TMPL_ROUND_PREV_TABLE && placed)) { pPrev = vtx(jp1); dPrev2 = dir(jp1 > 0 ? jp1 - 1 : N - 1); } // the previous element's geometry: only when a bridge connects to it (Round-join meshes: from the per-step table)
 		if (closed && j + 1 == N) { v0 = vtx(0u); v1 = vtx(N > 1 ? 1u : 0u); }      // join 0's inner side: only the closing bridge asks
-		tmpl_stroke_general(O.pos, O.col, O.idx, kindWord, N, vOff, iOff, ibase, color, f0, f1, fringe, tdraw, j, p1, pPrev, d12, dPrev, dPrev2, v0, v1, placed, bPlaced, kPlaced, prevPlaced);
+		tmpl_stroke_general(O.pos, O.col, O.idx, kindWord, N, vOff, iOff, ibase, color, f0, f1, fringe, tdraw, j, p1, pPrev, d12, dPrev, dPrev2, v0, v1, placed, rpl.b, rpl.k, rpl.nvPrev, rpl.prevInner);
 	} else if (openFast) {
 		const V2 dPrev = dir(jp1);
 		V2 dPrev2 = dPrev;
@@ -975,13 +1117,14 @@ template<int KIND, int THREADS, int MAXTILE, int ROUND = 0>
 __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 {
 	constexpr bool GENERAL = KIND == 2;
-	static_assert(ROUND == 0 || GENERAL, "Round joins take the general element body");
+	static_assert(ROUND == 0 || GENERAL || KIND == 3, "Round joins take the general element body, or -- closed AA strokes only -- tmpl_stroke_elem_round");
 	constexpr int CH = MAXTILE / THREADS;
 	__shared__ TmplDraw s_draw[VGX_TMPL_MAXM];
 	__shared__ TmplRec s_rec[VGX_TMPL_MAXM];
 	__shared__ float2 s_vtx[MAXTILE];
 	__shared__ float2 s_dir[MAXTILE];
 	__shared__ uint32_t s_status;
+	__shared__ float4 s_rmesh[ROUND ? VGX_TMPL_MAXM : 1]; // per mesh of the tile: vertices, indices (bits), arc step, first table word of a Round-join mesh (bits; ~0: none)
 	__shared__ float s_fringe[KIND >= 2 ? VGX_TMPL_MAXM : 1]; // per mesh of the tile: the draw's fringe (Bevel joins, Butt caps, thin strokes: kernels with those only)
 	const uint32_t tid = threadIdx.x;
 	// workgroup -> (instance, tile of the template), all workgroup-uniform (scalar loads)
@@ -1019,7 +1162,7 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 	}
 	const uint4* minfo = ROUND ? A.minfo + (uint64_t)inst32 * A.inst.num_meshes : nullptr; // indexed by (template mesh number - P.cmesh0); P.cmesh0 = 0 (one class)
 	const uint2* relem = ROUND ? A.relem + (uint64_t)inst32 * A.num_round_elems : nullptr;  // indexed by trix[slot]
-	const uint32_t* trix = ROUND ? A.trix + x0 : nullptr;
+
 	if (nm > VGX_TMPL_MAXM || nd > VGX_TMPL_MAXM) {
 		// workgroup-uniform. Many tiny meshes (or many draws without a mesh) in one tile: the draw records are verified in a loop,
 		// every lane fetches its own records and neighbours
@@ -1036,17 +1179,24 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 			if (kind == VGX_MESH_FILL_AA) { f0 = tmpl_fill_aa(xf, vt[0], vt[1], vt[2], tm.f0); }
 			auto dir = [&](uint32_t jj) { return v2dir(tmpl_xf(xf, vt[jj]), tmpl_xf(xf, vt[jj + 1 < N ? jj + 1 : 0u])); };
 			auto vtx = [&](uint32_t jj) { return tmpl_xf(xf, vt[jj]); };
-			uint32_t vOff = tm.v_off, iOff = tm.i_off, bP = ~0u, kP = 0, pP = 0;
+			uint32_t vOff = tm.v_off, iOff = tm.i_off;
+			TmplRoundPlace rpl;
+			rpl.placed = false; rpl.b = 0; rpl.k = 0; rpl.nvPrev = 0; rpl.prevInner = false; rpl.nv = 0; rpl.ni = 0; rpl.da = 0.0f;
 			if (ROUND) {
 				const uint4 mi = minfo[er.mesh];
 				vOff = mi.x; iOff = mi.y;
 				if (j == 0 && A.meshes_out) { tmpl_mesh_out_placed(A, P, er.mesh, mi); }
-				const uint32_t rx = trix[s];
-				if (rx != ~0u) { const uint2 bk = relem[rx]; bP = bk.x & 0x7FFFFFFFu; kP = bk.y; if (j > 0) { pP = relem[rx - 1u].x; } }
+				if (tm.pad[1] != 0) {
+					const uint2 bk = relem[__float_as_uint(tm.l2[1]) + j];
+					rpl.placed = true;
+					tmpl_round_unword(bk.x, bk.y, &rpl.b, &rpl.k, &rpl.nvPrev, &rpl.prevInner);
+					rpl.nv = mi.z; rpl.ni = mi.w;
+					rpl.da = tm.l2[0];
+				}
 			} else if (j == 0 && A.meshes_out) { tmpl_mesh_out(A, P, er.mesh); }
 			const uint32_t ibase = meshBase ? meshBase[er.mesh - P.cmesh0] : 0u;
 			tmpl_elem_emit<KIND, 0>(O, j, tm.kind, N, vOff, iOff, ibase, kind < VGX_MESH_STROKE ? dr.fill_color : dr.stroke_color, f0, tm.f1, tmpl_xf(xf, vt[j]), dir(j), dir, vtx,
-				__uint_as_float(tm.pad[0]), P.tdraws + tm.drawk, A.tmesh + er.mesh, ROUND != 0 && bP != ~0u, bP, kP, pP);
+				__uint_as_float(tm.pad[0]), P.tdraws + tm.drawk, A.tmesh + er.mesh, rpl);
 		}
 		return;
 	}
@@ -1058,24 +1208,12 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 #endif
 	// ---- phase 0a: every load the workgroup needs, requested at once
 	VgxTmplElem er[CH];
-	uint32_t rb[ROUND ? CH : 1], rk[ROUND ? CH : 1], rp[ROUND ? CH : 1]; // ROUND: elements of Round-join meshes: first vertex / index inside the mesh (else rb = ~0); the previous element's table word
+	uint32_t rb[ROUND ? CH : 1], rk[ROUND ? CH : 1]; // ROUND: elements of Round-join meshes: their table words (else rb = ~0)
 #pragma unroll
 	for (int c = 0; c < CH; ++c) {
 		const uint32_t s = (uint32_t)c * THREADS + tid; // interleaved: the tile's stroke chunks (the heavier ones, at the tile's end) spread over the waves
 		er[c].mesh = mA; er[c].jq = 0; er[c].lx = 0.0f; er[c].ly = 0.0f;
 		if (s < nel) { er[c] = telem[s]; }
-		if (ROUND) { rb[c] = ~0u; rk[c] = 0; rp[c] = 0; if (s < nel) { rb[c] = trix[s]; } }
-	}
-	if (ROUND) {
-#pragma unroll
-		for (int c = 0; c < CH; ++c) {
-			if (rb[c] != ~0u) { // (table word: place | the join's inner side << 31; a place is <= 65536, so never ~0 with the bit masked off)
-				const uint32_t rx = rb[c];
-				const uint2 bk = relem[rx];
-				if ((er[c].jq & 0xFFFFu) != 0) { rp[c] = relem[rx - 1u].x; }
-				rb[c] = bk.x & 0x7FFFFFFFu; rk[c] = bk.y;
-			}
-		}
 	}
 	VgxTmplMesh tm;
 	memset(&tm, 0, sizeof(tm));
@@ -1099,6 +1237,10 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 		r.ibase = ibase; r.n = tm.n; r.v_off = tm.v_off; r.i_off = tm.i_off;
 		r.kind = (tm.kind & 0xFFFFu) | ((tm.drawk - dA) << 16); r.color = kind < VGX_MESH_STROKE ? d->fill_color : d->stroke_color; r.f0 = tm.f0; r.f1 = tm.f1;
 		if (KIND >= 2) { s_fringe[tid] = __uint_as_float(tm.pad[0]); }
+		if (ROUND) { // Round-join meshes: the mesh's sizes (closing bridge), arc step (stroker.cpp:1398; the closed-stroke kernel's routine) and first table word, once per mesh
+			const bool rj = tm.pad[1] != 0; // (both from the mesh record: no load behind the first barrier)
+			s_rmesh[tid] = make_float4(__uint_as_float(mi.z), __uint_as_float(mi.w), rj ? tm.l2[0] : 0.0f, rj ? tm.l2[1] : __uint_as_float(~0u));
+		}
 		if (kind == VGX_MESH_FILL_AA) { r.f0 = tmpl_fill_aa(tmpl_draw_xf(d), make_float2(tm.l0[0], tm.l0[1]), make_float2(tm.l1[0], tm.l1[1]), make_float2(tm.l2[0], tm.l2[1]), tm.f0); }
 		s_rec[tid] = r;
 		// the caller's mesh table for the meshes that BEGIN in this tile (every mesh of the range but possibly the first)
@@ -1110,6 +1252,21 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 	TMPL_PROF(0);
 	if (status != VGX_OK) { // workgroup-uniform
 		return;
+	}
+	if (ROUND) {
+		// elements of Round-join meshes: their table words (place; the size and inner side of the element in front) -- requested here, used in phase 3
+#pragma unroll
+		for (int c = 0; c < CH; ++c) {
+			const uint32_t s = (uint32_t)c * THREADS + tid;
+			rb[c] = ~0u; rk[c] = 0;
+			if (s < nel) {
+				const uint32_t e0 = __float_as_uint(s_rmesh[er[c].mesh - mA].w);
+				if (e0 != ~0u) { // (x is never ~0: a place is < 65 535)
+					const uint2* w = relem + e0 + (er[c].jq & 0xFFFFu);
+					if (GENERAL) { const uint2 bk = *w; rb[c] = bk.x; rk[c] = bk.y; } else { rb[c] = w->x; }
+				}
+			}
+		}
 	}
 	// ---- phase 1: own vertex, transformed once
 	V2 p1[CH];
@@ -1149,7 +1306,11 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 	__syncthreads();
 	TMPL_PROF(2);
 	// ---- phase 3: the element
-	auto element = [&](auto passTag, uint32_t s, const VgxTmplElem& e, V2 pv, V2 dv, bool placed, uint32_t bPlaced, uint32_t kPlaced, uint32_t prevPlaced) {
+	auto element = [&](auto passTag, uint32_t s, const VgxTmplElem& e, V2 pv, V2 dv, bool placed, uint32_t wx, uint32_t wy) {
+		TmplRoundPlace rpl; // (wx, wy: the element's table words, tmpl_round_word)
+		rpl.placed = placed;
+		tmpl_round_unword(wx, wy, &rpl.b, &rpl.k, &rpl.nvPrev, &rpl.prevInner);
+		rpl.nv = 0; rpl.ni = 0; rpl.da = 0.0f;
 		if (s < nel) {
 			const uint32_t mesh = e.mesh;
 			const TmplRec* rp = &s_rec[mesh - mA];
@@ -1162,24 +1323,53 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 			};
 			auto vtx = [&](uint32_t jj) { return vtxAt(mesh, rp, q0, jj); };
 			const float fringe = KIND >= 2 ? s_fringe[mesh - mA] : 0.0f;
+			if (ROUND && KIND == 3 && placed) { const float4 rm = s_rmesh[mesh - mA]; rpl.nv = __float_as_uint(rm.x); rpl.ni = __float_as_uint(rm.y); rpl.da = rm.z; }
 			const vgx_draw* tdraw = P.tdraws;
 			if (GENERAL && decltype(passTag)::value == 2) { tdraw = P.tdraws + (dA + TMPL_REC_DK(rp)); }
 			tmpl_elem_emit<KIND, decltype(passTag)::value>(O, j, rp->kind & 0xFFFFu, N, rp->v_off, rp->i_off, rp->ibase, rp->color, rp->f0, rp->f1, pv, dv, dir, vtx, fringe, tdraw, A.tmesh + mesh,
-				placed, bPlaced, kPlaced, prevPlaced);
+				rpl);
 		}
 	};
+	if (KIND == 3 && VGX_TMPL_K3_ROLLED) {
+		// the kernels of closed strokes only: ONE copy of the element routines, one element per trip -- 4 x (fill + Miter + Bevel + Round)
+		// inlined is 45-67 KB of code per kernel, against an instruction cache of 64 KB shared by two CUs
+#pragma unroll 1
+		for (int c = 0; c < CH; ++c) {
+			VgxTmplElem e = er[0]; V2 pv = p1[0], dv = d12[0];
+			uint32_t pb = ROUND ? rb[0] : ~0u, pk = ROUND ? rk[0] : 0u;
+#pragma unroll
+			for (int k = 1; k < CH; ++k) { if (c == k) { e = er[k]; pv = p1[k]; dv = d12[k]; if (ROUND) { pb = rb[k]; pk = rk[k]; } } }
+			element(std::integral_constant<int, 0>(), (uint32_t)c * THREADS + tid, e, pv, dv, ROUND != 0 && pb != ~0u, pb, pk);
+		}
+	} else {
 #pragma unroll
 	for (int c = 0; c < CH; ++c) {
-		element(std::integral_constant<int, GENERAL ? 1 : 0>(), (uint32_t)c * THREADS + tid, er[c], p1[c], d12[c], false, 0u, 0u, 0u);
+		if (ROUND && !GENERAL) {
+			const uint32_t s = (uint32_t)c * THREADS + tid;
+			if (!VGX_TMPL_RC_ROLLED) { element(std::integral_constant<int, 0>(), s, er[c], p1[c], d12[c], rb[c] != ~0u, rb[c], rk[c]); }
+			else if (rb[c] == ~0u) { element(std::integral_constant<int, 0>(), s, er[c], p1[c], d12[c], false, 0u, 0u); }
+		}
+		else { element(std::integral_constant<int, GENERAL ? 1 : 0>(), (uint32_t)c * THREADS + tid, er[c], p1[c], d12[c], false, 0u, 0u); }
+	}
+	if (ROUND && !GENERAL && VGX_TMPL_RC_ROLLED) { // the Round-join elements of the tile, one per trip: tmpl_stroke_elem_round exists once
+#pragma unroll 1
+		for (int c = 0; c < CH; ++c) {
+			VgxTmplElem e = er[0]; V2 pv = p1[0], dv = d12[0];
+			uint32_t pb = rb[0], pk = rk[0];
+#pragma unroll
+			for (int k = 1; k < CH; ++k) { if (c == k) { e = er[k]; pv = p1[k]; dv = d12[k]; pb = rb[k]; pk = rk[k]; } }
+			if (pb != ~0u) { element(std::integral_constant<int, 0>(), (uint32_t)c * THREADS + tid, e, pv, dv, true, pb, pk); }
+		}
+	}
 	}
 	if (GENERAL) { // the general strokes of the tile, one element per trip: the body exists once
 #pragma unroll 1
 		for (int c = 0; c < CH; ++c) {
 			VgxTmplElem e = er[0]; V2 pv = p1[0], dv = d12[0];
-			uint32_t pb = ROUND ? rb[0] : 0u, pk = ROUND ? rk[0] : 0u, pp = ROUND ? rp[0] : 0u;
+			uint32_t pb = ROUND ? rb[0] : 0u, pk = ROUND ? rk[0] : 0u;
 #pragma unroll
-			for (int k = 1; k < CH; ++k) { if (c == k) { e = er[k]; pv = p1[k]; dv = d12[k]; if (ROUND) { pb = rb[k]; pk = rk[k]; pp = rp[k]; } } }
-			element(std::integral_constant<int, 2>(), (uint32_t)c * THREADS + tid, e, pv, dv, ROUND != 0 && pb != ~0u, pb, pk, pp);
+			for (int k = 1; k < CH; ++k) { if (c == k) { e = er[k]; pv = p1[k]; dv = d12[k]; if (ROUND) { pb = rb[k]; pk = rk[k]; } } }
+			element(std::integral_constant<int, 2>(), (uint32_t)c * THREADS + tid, e, pv, dv, ROUND != 0 && pb != ~0u, pb, pk);
 		}
 	}
 	TMPL_PROF(3);
@@ -1226,6 +1416,15 @@ __global__ __launch_bounds__(VGX_TMPL_G_THREADS, VGX_TMPL_R_MINWAVES) void k_tmp
 {
 	tmpl_emit_body<2, VGX_TMPL_G_THREADS, VGX_TMPL_G_TILE, 1>(A);
 }
+// templates whose strokes are all closed (Miter / Bevel joins, AA Round joins): the headline kernel's shape with the three closed routines
+// 85-90 VGPRs = five waves per SIMD = 20 per CU: workgroups of ten waves (two per CU) can use all of them, 8-wave workgroups only 16. Same box:
+// 640 x 2560 with the Round-join elements in a rolled second pass 3.35 ms, 512 x 2048 3.47, 512 x 2048 forced to 80 VGPRs (six waves,
+// 20 bytes of scratch) 3.95: what this kernel waits for is the third workgroup per CU the Bevel kernel (78 VGPRs) has
+__global__ __launch_bounds__(VGX_TMPL_RC_THREADS, VGX_TMPL_RC_WAVES) void k_tmpl_emit_round_closed(VgxTmplArgs A)
+{
+	tmpl_emit_body<3, VGX_TMPL_RC_THREADS, VGX_TMPL_RC_TILE, 1>(A);
+}
+
 // Sizes: one wave per (instance, Round-join mesh). Lane = element: its vertex and both neighbours through transformPos2D with the
 // instance's matrix, the two edge directions, elem_geometry -- the very functions on the very inputs k_tmpl_emit_round's phases 1 - 3
 // evaluate (so: the same bits, the arcs counted = the arcs emitted) --, a running prefix over the mesh's elements -> every element's
@@ -1252,6 +1451,7 @@ __global__ __launch_bounds__(256) void k_tmpl_round_sizes(VgxTmplArgs A)
 	mc.vtx.x0 = 0.0f; mc.vtx.y0 = 0.0f; mc.vtx.x1 = 0.0f; mc.vtx.y1 = 0.0f;
 	uint2* out = A.relem + inst * A.num_round_elems + rm.elem0;
 	unsigned long long runV = 0, runI = 0;
+	uint32_t carryNv = 0; bool carryInner = false; // the element in front of the chunk (wave-uniform)
 	for (uint32_t j0 = 0; j0 < N; j0 += 64) {
 		const uint32_t j = j0 + lane;
 		uint32_t nv = 0, ni = 0;
@@ -1270,12 +1470,19 @@ __global__ __launch_bounds__(256) void k_tmpl_round_sizes(VgxTmplArgs A)
 			const unsigned long long tv = __shfl_up(v, d), ti = __shfl_up(i, d);
 			if (lane >= (uint32_t)d) { v += tv; i += ti; }
 		}
-		// table word: the place | the join's inner side << 31 (what the NEXT element's bridge needs of this one: elem_exit_rails); places beyond
-		// 65536 vertices: the mesh is too large, k_tmpl_round_inst ends the call and nothing is emitted
-		if (j < N) { out[j] = make_uint2(((uint32_t)(runV + v - nv) & 0x7FFFFFFFu) | (inner ? 0x80000000u : 0u), (uint32_t)(runI + i - ni)); }
+		// the element in front: the lane below, or the last lane of the chunk before (join 0: patched below)
+		uint32_t nvP = __shfl_up(nv, 1);
+		int inP = __shfl_up((int)inner, 1);
+		if (lane == 0) { nvP = carryNv; inP = (int)carryInner; }
+		if (j < N) { out[j] = tmpl_round_word((uint32_t)(runV + v - nv), (uint32_t)(runI + i - ni), nvP, inP != 0); }
 		runV += __shfl(v, 63); runI += __shfl(i, 63);
+		const uint32_t lastLane = (N - j0 < 64u ? N - j0 : 64u) - 1u;
+		carryNv = __shfl(nv, (int)lastLane); carryInner = __shfl((int)inner, (int)lastLane) != 0;
 	}
-	if (lane == 0) { A.rsz[2 * g] = runV; A.rsz[2 * g + 1] = runI; }
+	if (lane == 0) {
+		A.rsz[2 * g] = runV; A.rsz[2 * g + 1] = runI;
+		if (mc.closed) { out[0] = tmpl_round_word(0u, 0u, carryNv, carryInner); } // join 0: the closing bridge starts at the LAST join (which is now known)
+	}
 }
 
 // One wave per instance, after k_tmpl_round_sizes: every mesh's place inside the instance (the template's sizes for the meshes without
@@ -1402,7 +1609,8 @@ void vgx_launch_tmpl_emit(const VgxTmplArgs& a, hipStream_t s)
 {
 	const uint64_t blocks = a.wg ? a.num_wg : a.ninst * a.tiles_per_inst; // the host checked < 2^31
 	if (!blocks) { return; }
-	if (a.general == 4) { hipLaunchKernelGGL(k_tmpl_emit_bevel, dim3((unsigned)blocks), dim3(VGX_TMPL_THREADS), 0, s, a); }
+	if (a.general == 5) { hipLaunchKernelGGL(k_tmpl_emit_round_closed, dim3((unsigned)blocks), dim3(VGX_TMPL_RC_THREADS), 0, s, a); }
+	else if (a.general == 4) { hipLaunchKernelGGL(k_tmpl_emit_bevel, dim3((unsigned)blocks), dim3(VGX_TMPL_THREADS), 0, s, a); }
 	else if (a.general == 3) { hipLaunchKernelGGL(k_tmpl_emit_round, dim3((unsigned)blocks), dim3(VGX_TMPL_G_THREADS), 0, s, a); }
 	else if (a.general == 2) { hipLaunchKernelGGL(k_tmpl_emit_general, dim3((unsigned)blocks), dim3(VGX_TMPL_G_THREADS), 0, s, a); }
 	else if (a.general == 1) { hipLaunchKernelGGL(k_tmpl_emit_open, dim3((unsigned)blocks), dim3(VGX_TMPL_THREADS), 0, s, a); }

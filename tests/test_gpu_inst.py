@@ -100,6 +100,7 @@ def test_instanced_is_what_runs_and_the_knob_turns_it_off(rt, wl, oracle, monkey
     ps = wl.fuzz_paths(710, npaths=72, with_shapes=False, with_polylines=True)
     d = _instances(wl, ps, 710, 48, vary=False)
     ref = oracle.tessellate(ps, d)
+    monkeypatch.setenv("VGX_TMPL", "0")  # (round 5: the batch -- Round joins among its strokes -- would otherwise be a template batch)
     ctx = rt.Context(0)
     got = _async(rt, ctx, ps, d)
     assert got.status == 0 and int(got.dev_sizes[NUM_SERIAL]) == 0
@@ -278,6 +279,7 @@ def test_instances_of_different_scales_are_sorted_by_tolerance_class(rt, wl, ora
     every cubic, so the count pass keeps the periodic mapping but sorts the INSTANCES by tolerance class (flatten mode 4);
     VGX_INST_PERM=0 sorts the draws by (path, tolerance class) instead (mode 3, what non-periodic batches get), VGX_INST_CLASSES=1
     switches both off; few / very many classes only change which instances share a wave. Same bits in all cases."""
+    monkeypatch.setenv("VGX_TMPL_ROUND", "0")  # (round 5: with its Round joins the uniform batch below would be a template batch; this test is about k_flatten_inst)
     if classes in ("perm0", "perm2"):  # perm2: the several-kernel form of the instance sort (used beyond 2^18 instances)
         monkeypatch.setenv("VGX_INST_PERM", classes[-1])
     elif classes is not None:

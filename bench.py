@@ -174,6 +174,8 @@ WORKLOADS = {
     "tiger10k_bevel": "Tiger x10k with Bevel joins on the strokes: template mode, closed Bevel routine beside the closed Miter one (k_tmpl_emit_bevel; round 4: the general element body)",
     "tiger10k_round": "Tiger x10k with Round joins on the strokes (arc points counted on every instance's transformed polyline): template mode with per-step sizes (k_tmpl_round_sizes + k_tmpl_emit_round_closed)",
     "tiger10k_round_ordinary": "the tiger10k_round batch with VGX_TMPL_ROUND=0: the ordinary pipeline (k_flatten_inst + k_fill + k_round_sizes + k_stroke), what Round joins cost before round 5",
+    "tiger10k_culled": "Tiger x10k after culling and reordering (a random 70 % of the draws, shuffled: no period left) with vgx_set_static_batches: the draw list flattened once by the count as ONE template, a step = the emit kernel (element tables from HBM instead of L2)",
+    "tiger10k_culled_ordinary": "the tiger10k_culled batch without static batches: k_flatten_inst grouped by path + k_fill + k_stroke, what such a scene cost before round 5",
     "tigerspec10k": "SURVEY 8(d) config 3 as specified: 240 paths x (1-4 sub-paths x 8-60 cubics), x10k instances",
     "tiger10k_animated": "Tiger x10k whose path ARGUMENTS change every step: new path set (validated + uploaded) -> vgx_tessellate_count (template rebuilt: the flattener runs) -> vgx_tessellate, all inside the timed region",
     # honesty configs: the headline batch WITHOUT the template mode (every instance flattened, polyline through HBM), and without
@@ -182,7 +184,7 @@ WORKLOADS = {
     "tiger10k_command_parallel": "Tiger x10k with VGX_INST=0: k_flatten_build (one lane per path command) + k_fill + k_stroke, no instancing at all",
     "tiger10k_varied_per_instance_flatten": "the tiger10k_varied batch with VGX_TMPL_CLASSES=0: what instances cost when they share no subdivision (k_flatten_inst with the instances sorted by tolerance class + k_fill + k_stroke)",
 }
-CONFIG_ENV = {"tiger10k_round_ordinary": {"VGX_TMPL_ROUND": "0"}, "tiger10k_per_instance_flatten": {"VGX_TMPL": "0"}, "tiger10k_command_parallel": {"VGX_INST": "0"}, "tiger10k_varied_per_instance_flatten": {"VGX_TMPL_CLASSES": "0"}}
+CONFIG_ENV = {"tiger10k_culled": {"VGX_TMPL_BATCH": "1"}, "tiger10k_culled_ordinary": {"VGX_TMPL_BATCH": "0"}, "tiger10k_round_ordinary": {"VGX_TMPL_ROUND": "0"}, "tiger10k_per_instance_flatten": {"VGX_TMPL": "0"}, "tiger10k_command_parallel": {"VGX_INST": "0"}, "tiger10k_varied_per_instance_flatten": {"VGX_TMPL_CLASSES": "0"}}
 # configs that get their own cpu_baseline (the honesty configs are the headline's batch: they share its baseline)
 CONFIG_CPU = {"cubics1m": "cubics", "round10k": "round", "tigerspec10k": "tigerspec", "tiger10k_varied": "varied", "tiger10k_open": "tigeropen", "tiger10k_bevel": "tigerbevel", "tiger10k_round": "tigerround"}
 CONFIG_CPU_BUDGET = {"cubics": 4.0, "round": 4.0}  # seconds of wall time per config (the tiger variants: 2.5 s)
@@ -215,6 +217,15 @@ def make_workload(wl, name, instances, rank):
         d = wl.tiger_draws(ops, instances, first_instance=rank * instances, join=1)  # vg::LineJoin::Round
         return ps, d, ("the tiger-like drawing (seed 2024) x %d instances per GPU: convexFillAA + polylineStrokeAA (Round joins) / AAThin "
                        "on 1/3 of the paths" % instances), "tessellate"
+    if name in ("tiger10k_culled", "tiger10k_culled_ordinary"):
+        ps, ops = wl.tiger_paths()
+        d = wl.tiger_draws(ops, instances, first_instance=rank * instances)
+        import numpy as np
+        rs = np.random.RandomState(4711 + rank)
+        d = d[rs.uniform(size=d.shape[0]) < 0.7]
+        d = d[rs.permutation(d.shape[0])]
+        return ps, d, ("the tiger-like drawing (seed 2024) x %d instances per GPU, a random 70 %% of the draws kept and shuffled (seed 4711): a culled, "
+                       "reordered instanced scene without a period" % instances), "tessellate"
     if name == "tigerspec10k":
         ps, ops = wl.tiger_spec_paths()
         d = wl.tiger_draws(ops, instances, first_instance=rank * instances)

@@ -603,6 +603,18 @@ int vgx_gather(vgx_ctx* ctx, void* rccl_comm, int root, const vgx_mesh_out* loca
 int vgx_gather_at(vgx_ctx* ctx, void* rccl_comm, int root, const vgx_mesh_out* local, const vgx_rank_sizes* all, const vgx_rank_sizes* place,
                   const vgx_mesh_out* global, void* stream);
 
+/* Static batches (default off; also VGX_TMPL_BATCH=1). The caller promises that the batches it submits between two vgx_tessellate_count
+ * calls keep their STRUCTURE -- the same paths with the same fill / stroke styles, widths, scale, tolerance and fringe at the same
+ * positions of the draw list -- and only move transforms, colours and state keys: the draw list a retained scene produces frame after
+ * frame (vg::submitCommandList of an unchanged list under a new camera; an instanced scene after culling, whose draws no longer repeat
+ * a period). vgx_tessellate_count then flattens the whole draw list ONCE, in local space (the reference flattens before transformPath,
+ * src/vg.cpp:4957-4975), and keeps it as one template (vgx_tmpl.hip: local polyline, mesh and element tables: ~30 bytes per output
+ * vertex of device memory); vgx_tessellate is then ONE kernel per call -- every draw record verified against the counted one,
+ * transformPos2D, the stroker -- instead of flatten + scans + fill + stroke. A structural change ends the call with VGX_E_STALE
+ * (nothing usable in the buffers): count again. Batches above 2^29 vertices or 2^31 indices / elements keep the ordinary pipeline.
+ * Results are the same bytes either way. */
+int vgx_set_static_batches(vgx_ctx* ctx, int enable);
+
 /* Per-kernel timing of the last vgx_tessellate.. / vgx_flatten.. sequence, measured with HIP events
  * on the stream the kernels ran on. Enable before the call; read after synchronising. */
 #define VGX_MAX_STAGES 16

@@ -677,3 +677,71 @@ def test_template_does_not_survive_its_path_set(rt, wl, oracle):
             assert np.array_equal(bufs.pos[:nv].cpu().numpy().view(np.uint32), ref.pos.view(np.uint32))
         pb.close()
     ctx.close()
+
+
+# ---- static batches: the whole draw list as one template (vgx_set_static_batches) ---------------------------------------------------
+def _scene(wl, ninst, seed, round_joins=False, keep=0.7):
+    """An instanced scene after culling and reordering: `ninst` tigers, a random `keep` of their draws, shuffled -- no period left."""
+    ps, ops = wl.tiger_paths()
+    d = wl.tiger_draws(ops, ninst, join=1 if round_joins else 0)
+    rs = np.random.RandomState(seed)
+    d = d[rs.uniform(size=d.shape[0]) < keep]
+    return ps, d[rs.permutation(d.shape[0])]
+
+
+@pytest.mark.parametrize("seed,round_joins,tile", [(11, False, None), (12, False, "192"), (13, True, None), (14, True, "64")])
+def test_static_batches_scene_without_a_period(rt, wl, oracle, monkeypatch, seed, round_joins, tile):
+    """A culled, shuffled instanced scene has no period: by default the ordinary pipeline (k_flatten_inst grouped by path). With
+    vgx_set_static_batches the count flattens the draw list once, in local space, and keeps it as ONE template of one instance; a
+    step is then the emit kernel alone (with Round joins: the per-step sizes in front of it). == the reference, == the ordinary
+    pipeline byte for byte; new transforms and colours are free, a structural change is VGX_E_STALE."""
+    if tile:
+        monkeypatch.setenv("VGX_TMPL_TILE", tile)
+    ps, d = _scene(wl, 24, seed, round_joins)
+    assert d.shape[0] > 2048
+    ref = oracle.tessellate(ps, d)
+    ctx = rt.Context(0)
+    old = _run(rt, ctx, ps, d)
+    assert old.mode != MODE_TEMPLATE and old.status == 0
+    ctx.set_static_batches(True)
+    got = _run(rt, ctx, ps, d)
+    assert got.mode == MODE_TEMPLATE and got.stages == (ROUND_STAGES if round_joins else ["tmpl_emit"]), (got.mode, got.stages)
+    assert got.status == 0
+    assert_mesh_equal(got, ref, "static batch seed=%d" % seed)
+    for k in ("pos", "color", "idx", "meshes"):
+        assert bytes_equal(getattr(got, k), getattr(old, k)), k
+    # the camera moves, colours change: the same template
+    d2 = d.copy()
+    rs = np.random.RandomState(seed + 100)
+    m = rs.uniform(-2, 2, size=6).astype(np.float32)
+    d2["mtx"][:] = m
+    d2["fill_color"] = rs.randint(0, 1 << 32, size=d.shape[0], dtype=np.uint64).astype(np.uint32)
+    if not round_joins:  # (Round joins: the sizes follow the transform -- covered by test_template_round_joins_sizes_follow_the_transforms)
+        got2 = _run(rt, ctx, ps, d, d_steady=d2)
+        assert got2.mode == MODE_TEMPLATE and got2.status == 0
+        assert_mesh_equal(got2, oracle.tessellate(ps, d2), "static batch, new camera")
+    # two draws swapped / one stroke width changed: stale
+    d3 = d.copy()
+    a, b = 5, d.shape[0] - 7
+    if d3["path"][a] == d3["path"][b]:
+        b -= 1
+    d3[[a, b]] = d3[[b, a]]
+    assert _run(rt, ctx, ps, d, d_steady=d3).status == VGX_E_STALE
+    ctx.set_static_batches(False)
+    back = _run(rt, ctx, ps, d)
+    assert back.mode != MODE_TEMPLATE and back.status == 0
+    ctx.close()
+
+
+def test_static_batches_every_draw_its_own_path(rt, wl, oracle):
+    """No draw shares a path with another (what a whole retained frame looks like): still one template."""
+    ps = wl.fuzz_paths(4242, npaths=2600, with_shapes=True, degenerate=False)
+    d = wl.template_general_draws(ps, 4242, 1, round_joins=True)
+    assert d.shape[0] == 2600
+    ref = oracle.tessellate(ps, d)
+    ctx = rt.Context(0)
+    ctx.set_static_batches(True)
+    got = _run(rt, ctx, ps, d)
+    assert got.mode == MODE_TEMPLATE and got.status == 0
+    assert_mesh_equal(got, ref, "static batch: one frame")
+    ctx.close()

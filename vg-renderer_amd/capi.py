@@ -209,6 +209,7 @@ VGX_SYMBOLS = {
     "vgx_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(MeshOut), C.POINTER(RankSizes), C.POINTER(MeshOut), C.c_void_p]),
     "vgx_gather_at": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(MeshOut), C.POINTER(RankSizes), C.POINTER(RankSizes), C.POINTER(MeshOut), C.c_void_p]),
     "vgx_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "vgx_set_static_batches": (C.c_int, [C.c_void_p, C.c_int]),
     "vgx_get_stage_times_avg": (C.c_int, [C.c_void_p, C.POINTER(StageTimes), C.c_uint32]),
     "vgx_get_stage_times": (C.c_int, [C.c_void_p, C.POINTER(StageTimes)]),
 }

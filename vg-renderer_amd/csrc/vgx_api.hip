@@ -110,6 +110,8 @@ struct vgx_ctx
 	// representatives, a per-instance table of output places, a per-workgroup table (instance, tile)
 	int optTmplClasses;
 	int optTmplRound;                    // VGX_TMPL_ROUND=0: batches with Round joins keep the ordinary pipeline
+	int optTmplBatch;                    // vgx_set_static_batches / VGX_TMPL_BATCH=1: a batch without a period becomes ONE template (the whole draw list = one instance)
+	bool tmplIsBatch;                    // the current template is such a batch-wide one
 	uint32_t tmplClasses;                // 1: every instance repeats the first period
 	uint32_t tmplGeneral;                // stroke styles of the template: 0 closed Miter AA / Thin only, 1 + open Miter with Butt / Square caps, 2 + general
 	uint64_t tmplNumWg, tmplNDraws;      // several classes: workgroups of one step; the batch size the per-instance table was built for
@@ -743,6 +745,8 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	if (const char* e = getenv("VGX_TMPL_CLASSES")) { ctx->optTmplClasses = atoi(e) != 0; }
 	ctx->optTmplRound = 1;
 	if (const char* e = getenv("VGX_TMPL_ROUND")) { ctx->optTmplRound = atoi(e) != 0; }
+	ctx->optTmplBatch = 0;
+	if (const char* e = getenv("VGX_TMPL_BATCH")) { ctx->optTmplBatch = atoi(e) != 0; }
 	if (const char* e = getenv("VGX_TMPL_TILE")) { const int v = atoi(e); if (v >= 64 && v <= VGX_TMPL_MAX_TILE) { ctx->optTmplTile = (uint32_t)v / 64u * 64u; } } // testing: elements per tile (<= the LDS stage of k_tmpl_emit)
 	ctx->optPoolWalk = 0; // VGX_WALK=pool: the wave-cooperative walk of vgx_walk.h (same output, same speed: DESIGN.md section 4)
 	if (const char* e = getenv("VGX_WALK")) { ctx->optPoolWalk = strcmp(e, "pool") == 0; }
@@ -1482,9 +1486,18 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	vgx_launch_tmpl_check(draws, ndraws, ps->dev.npaths, (VgxTotals*)ctx->totals.p, s);
 	if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
 	if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; }
-	if (ctx->hostTotals->inst_detect_inv == 0 || ctx->hostTotals->inst_detect_bad) { return VGX_OK; }
-	const unsigned long long P = ~0ull - ctx->hostTotals->inst_detect_inv;
-	if (P == 0 || P > (1ull << 24) || ndraws % P != 0 || ndraws / P < VGX_INST_MIN_INSTANCES) { return VGX_OK; }
+	ctx->tmplIsBatch = false;
+	unsigned long long P = (ctx->hostTotals->inst_detect_inv == 0 || ctx->hostTotals->inst_detect_bad) ? 0ull : ~0ull - ctx->hostTotals->inst_detect_inv;
+	if (P == 0 || P > (1ull << 24) || ndraws % P != 0 || ndraws / P < VGX_INST_MIN_INSTANCES) {
+		// no drawing repeated for many instances. A caller that keeps its batches' STRUCTURE from call to call (vgx_set_static_batches: the
+		// same paths and styles in the same order, only transforms and colours move -- a static scene under a moving camera, a culled or
+		// shuffled instanced scene) gets the whole draw list as ONE template of one instance: flattened once here, in local space; a step is
+		// then the emit kernel alone, and any structural change ends it with VGX_E_STALE (the caller counts again)
+		if (!ctx->optTmplBatch || ndraws >= (1ull << 31)) { return VGX_OK; }
+		P = ndraws;
+		ctx->tmplIsBatch = true;
+		ctx->hostTotals->tmpl_bad = 0;
+	}
 	const uint64_t ninst = ndraws / P;
 	uint32_t T = 1;
 	std::vector<uint32_t> instCls, reps(1, 0u);
@@ -2081,6 +2094,16 @@ int vgx_get_failure_info(vgx_ctx* ctx, vgx_failure_info* out, void* stream)
 	out->segment = ctx->hostTotals->fail_segment;
 	out->segment_items = ctx->tmplOn ? 5u : ctx->optInst ? (ctx->instPeriod ? (ctx->instPermOn ? 4u : 1u) : (ctx->instGrouped ? (ctx->instClasses > 1 ? 3u : 2u) : 0u)) : 0u; // flatten mode chosen by the last count call
 	for (int i = 0; i < 16; ++i) { out->prof[i] = ctx->hostTotals->prof[i]; }
+	return VGX_OK;
+}
+
+int vgx_set_static_batches(vgx_ctx* ctx, int enable)
+{
+	if (!ctx) {
+		return VGX_E_INVALID_ARG;
+	}
+	ctx->optTmplBatch = enable ? 1 : 0;
+	if (!enable && ctx->tmplIsBatch) { ctx->tmplOn = false; } // the next vgx_tessellate wants a count again
 	return VGX_OK;
 }
 

@@ -77,6 +77,11 @@ class Context:
     def set_profiling(self, on):
         _check(lib().vgx_set_profiling(self._h, 1 if on else 0), "vgx_set_profiling")
 
+    def set_static_batches(self, on):
+        """vgx_set_static_batches: batches keep their structure between counts (only transforms / colours move): the whole draw
+        list becomes one template at the next tessellate_count, a step is then one kernel; a structural change -> VGX_E_STALE."""
+        _check(lib().vgx_set_static_batches(self._h, 1 if on else 0), "vgx_set_static_batches")
+
     def set_assembly(self, drawcmds=None, max_vb_vertices=0, dev_num=None, split_state=False, uv=None, uv_value=None):
         """Arms draw-command assembly (vgx_set_assembly) with a uint8 device tensor of 48-byte vgx_drawcmd records,
         or disarms it (drawcmds=None). split_state: VGX_ASM_SPLIT_STATE. uv: device tensor of the UV stream (int16 [n,2]

@@ -174,6 +174,7 @@ WORKLOADS = {
     "tiger10k_bevel": "Tiger x10k with Bevel joins on the strokes: template mode, closed Bevel routine beside the closed Miter one (k_tmpl_emit_bevel; round 4: the general element body)",
     "tiger10k_round": "Tiger x10k with Round joins on the strokes (arc points counted on every instance's transformed polyline): template mode with per-step sizes (k_tmpl_round_sizes + k_tmpl_emit_round_closed)",
     "tiger10k_round_ordinary": "the tiger10k_round batch with VGX_TMPL_ROUND=0: the ordinary pipeline (k_flatten_inst + k_fill + k_round_sizes + k_stroke), what Round joins cost before round 5",
+    "round10k_static": "BASELINE configs[3]'s batch (10k polylines x 1k segments, Round joins + Round caps) with vgx_set_static_batches: the draw list flattened once by the count, a step = per-step Round-join sizes + the template emit kernel (no flatten, no scans)",
     "tiger10k_culled": "Tiger x10k after culling and reordering (a random 70 % of the draws, shuffled: no period left) with vgx_set_static_batches: the draw list flattened once by the count as ONE template, a step = the emit kernel (element tables from HBM instead of L2)",
     "tiger10k_culled_ordinary": "the tiger10k_culled batch without static batches: k_flatten_inst grouped by path + k_fill + k_stroke, what such a scene cost before round 5",
     "tigerspec10k": "SURVEY 8(d) config 3 as specified: 240 paths x (1-4 sub-paths x 8-60 cubics), x10k instances",
@@ -184,7 +185,7 @@ WORKLOADS = {
     "tiger10k_command_parallel": "Tiger x10k with VGX_INST=0: k_flatten_build (one lane per path command) + k_fill + k_stroke, no instancing at all",
     "tiger10k_varied_per_instance_flatten": "the tiger10k_varied batch with VGX_TMPL_CLASSES=0: what instances cost when they share no subdivision (k_flatten_inst with the instances sorted by tolerance class + k_fill + k_stroke)",
 }
-CONFIG_ENV = {"tiger10k_culled": {"VGX_TMPL_BATCH": "1"}, "tiger10k_culled_ordinary": {"VGX_TMPL_BATCH": "0"}, "tiger10k_round_ordinary": {"VGX_TMPL_ROUND": "0"}, "tiger10k_per_instance_flatten": {"VGX_TMPL": "0"}, "tiger10k_command_parallel": {"VGX_INST": "0"}, "tiger10k_varied_per_instance_flatten": {"VGX_TMPL_CLASSES": "0"}}
+CONFIG_ENV = {"round10k_static": {"VGX_TMPL_BATCH": "1"}, "tiger10k_culled": {"VGX_TMPL_BATCH": "1"}, "tiger10k_culled_ordinary": {"VGX_TMPL_BATCH": "0"}, "tiger10k_round_ordinary": {"VGX_TMPL_ROUND": "0"}, "tiger10k_per_instance_flatten": {"VGX_TMPL": "0"}, "tiger10k_command_parallel": {"VGX_INST": "0"}, "tiger10k_varied_per_instance_flatten": {"VGX_TMPL_CLASSES": "0"}}
 # configs that get their own cpu_baseline (the honesty configs are the headline's batch: they share its baseline)
 CONFIG_CPU = {"cubics1m": "cubics", "round10k": "round", "tigerspec10k": "tigerspec", "tiger10k_varied": "varied", "tiger10k_open": "tigeropen", "tiger10k_bevel": "tigerbevel", "tiger10k_round": "tigerround"}
 CONFIG_CPU_BUDGET = {"cubics": 4.0, "round": 4.0}  # seconds of wall time per config (the tiger variants: 2.5 s)
@@ -234,7 +235,7 @@ def make_workload(wl, name, instances, rank):
     if name == "cubics1m":
         ps, d = wl.random_cubics(1000000, seed=1234 + rank, box=1000.0)
         return ps, d, "1 000 000 independent paths (moveTo + cubicTo, 8 coordinates uniform in [0,1000)) per GPU: pathXXX only (vgx_flatten_count + vgx_flatten_emit)", "flatten"
-    if name == "round10k":
+    if name in ("round10k", "round10k_static"):
         ps, d = wl.random_walk_polylines(10000, 1000, seed=5678 + rank)
         return ps, d, "10 000 open polylines x 1000 segments per GPU, strokerPolylineStrokeAA with Round joins + Round caps, width 6", "tessellate"
     raise SystemExit("unknown --config %s (one of %s)" % (name, ", ".join(WORKLOADS)))

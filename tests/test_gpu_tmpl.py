@@ -745,3 +745,30 @@ def test_static_batches_every_draw_its_own_path(rt, wl, oracle):
     assert got.mode == MODE_TEMPLATE and got.status == 0
     assert_mesh_equal(got, ref, "static batch: one frame")
     ctx.close()
+
+
+def test_static_batches_long_round_join_polylines(rt, wl, oracle):
+    """BASELINE configs[3]'s shape (open polylines of a thousand segments, Round joins + Round caps) as a static batch: the per-step
+    sizes by one WORKGROUP per mesh (k_tmpl_round_sizes_block), meshes that span several tiles, general Round-join emit."""
+    ps, d = wl.random_walk_polylines(2100, 700, seed=99)
+    ref = oracle.tessellate(ps, d)
+    ctx = rt.Context(0)
+    ctx.set_static_batches(True)
+    got = _run(rt, ctx, ps, d)
+    assert got.mode == MODE_TEMPLATE and got.stages == ROUND_STAGES and got.status == 0
+    assert_mesh_equal(got, ref, "static batch: long round-join polylines")
+    d2 = d.copy()
+    d2["mtx"][:, 0] = np.float32(0.7); d2["mtx"][:, 3] = np.float32(1.3); d2["mtx"][:, 1] = np.float32(0.2)
+    ref2 = oracle.tessellate(ps, d2)
+    import torch
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(d)
+    rt.tessellate_count(ctx, pset, dd, d.shape[0])
+    dd2 = rt.upload_draws(d2)
+    bufs = rt.MeshBuffers(dd2.device, ref2.pos.shape[0] + 64, ref2.idx.shape[0] + 64, int(ref2.meshes.shape[0]))
+    rt.tessellate_async(ctx, pset, dd2, d2.shape[0], bufs)
+    torch.cuda.synchronize()
+    assert int(bufs.dev_status.item()) == 0
+    assert bytes_equal(bufs.pos[:ref2.pos.shape[0]].cpu().numpy(), ref2.pos) and bytes_equal(bufs.idx[:ref2.idx.shape[0]].cpu().numpy().view(np.uint16), ref2.idx)
+    pset.close()
+    ctx.close()

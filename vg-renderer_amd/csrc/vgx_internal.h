@@ -137,9 +137,7 @@ struct VgxTmplArgs // one step
 	const VgxTmplRoundMesh* trmesh; // [num_round + 1]
 	unsigned long long* rsz;     // [ninst * num_round * 2] vertices, indices of every such mesh
 	uint2* relem;                // [ninst * num_round_elems] per element of such a mesh: first vertex / index inside the mesh, size and inner side of the element in front (tmpl_round_word)
-	uint4* minfo;                // [ninst * meshes] per mesh: first vertex, first index inside the instance; vertices, indices
-	unsigned long long* itot;    // [ninst * 2] vertices, indices of the instance
-	unsigned long long* iplace;  // [ninst * 2] first vertex, first index of the instance in the batch
+	VgxTmplMeshPlace* mplace;    // [ninst * meshes] per mesh of the batch: first vertex, first index in the BATCH; vertices, indices
 };
 struct Sum3;
 void vgx_launch_tmpl_round_sizes(const VgxTmplArgs& a, Sum3* partial, hipStream_t s); // Round-join templates, in front of vgx_launch_tmpl_emit: the tables above, totals->sizes, VGX_E_NOSPACE against a.caps

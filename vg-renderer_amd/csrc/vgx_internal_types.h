@@ -189,6 +189,12 @@ struct VgxTmplRoundMesh // Round-join stroke meshes of the template, in mesh ord
 	uint32_t mesh;   // template mesh
 	uint32_t elem0;  // its first element among the instance's Round-join elements
 };
+struct VgxTmplMeshPlace // Round-join templates, per step: where one mesh of one instance lies in the batch's output. 32 bytes
+{
+	unsigned long long v, i; // first vertex / index
+	uint32_t nv, ni;         // vertices / indices
+	uint32_t pad[2];
+};
 struct VgxTmplTile // one tile of an instance's element stream = one workgroup of k_tmpl_emit. 32 bytes
 {
 	uint32_t mesh0;     // template mesh that owns the tile's first element; bit 31: that element is the mesh's element 0

@@ -898,7 +898,7 @@ __device__ __forceinline__ bool tmpl_stroke_is_closed_round_aa(uint32_t kindWord
 // join): its vertex count nvPrev (-> its place and, 2 n + 4 or n + 2, its arc's point count) and its inner side.
 //   x = b (16 bits) | prevInner << 16 | (nvPrev >> 1) << 17 (15 bits)        y = k (20 bits) | (nvPrev & 1) << 20
 // Meshes hold <= 65 536 vertices (16-bit indices; an element's place is < 65 535, an element's size <= 65 534) and so < 2^19 indices; a mesh
-// beyond that ends the call (k_tmpl_round_inst), nothing reads its words. A closed AA stroke needs x only: its joins have 2 n + 4 (even)
+// beyond that ends the call (the scan over the meshes), nothing reads its words. A closed AA stroke needs x only: its joins have 2 n + 4 (even)
 // vertices, and k follows from b (k_j = 9 (b_j - 4 j) / 2 + 18 (j - 1): 9 indices per arc segment, one 18-index bridge per join in front).
 __device__ __forceinline__ uint2 tmpl_round_word(uint32_t b, uint32_t k, uint32_t nvPrev, bool prevInner)
 {
@@ -1112,7 +1112,7 @@ __global__ __launch_bounds__(256) void k_tmpl_mtab(VgxTmplArgs A, vgx_mesh* mtab
 #endif
 #define VGX_TMPL_G_TILE VGX_TMPL_GENERAL_TILE
 // ROUND: the template holds Round-join meshes: the places of the instance, of its meshes and of every element of a Round-join mesh come from
-// the per-step tables (k_tmpl_round_sizes / k_tmpl_round_inst / the scan over the instances) instead of the template's closed forms.
+// the per-step tables (k_tmpl_round_sizes / the scan over the meshes) instead of the template's closed forms.
 template<int KIND, int THREADS, int MAXTILE, int ROUND = 0>
 __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 {
@@ -1139,7 +1139,7 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 		inst32 = blockIdx.x / A.tiles_per_inst;
 		t = blockIdx.x - inst32 * A.tiles_per_inst;
 		P.v = (uint64_t)inst32 * A.inst.num_vertices; P.i = (uint64_t)inst32 * A.inst.num_indices; P.m = (uint64_t)inst32 * A.inst.num_meshes;
-		if (ROUND) { P.v = A.iplace[2 * (uint64_t)inst32]; P.i = A.iplace[2 * (uint64_t)inst32 + 1]; }
+		if (ROUND) { const VgxTmplMeshPlace* mp = A.mplace + (uint64_t)inst32 * A.inst.num_meshes; P.v = mp->v; P.i = mp->i; } // the instance begins where its first mesh does
 	}
 	const uint64_t inst = inst32;
 	const VgxTmplTile tl = A.ttile[t];
@@ -1160,7 +1160,15 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 	if (ROUND == 0 && blockIdx.x == 0 && tid == 0 && !A.mesh_base) { // (assembly armed: k_tmpl_mtab wrote them already; Round joins: the scan over the instances did) totals of the batch (the memset in front of this kernel zeroed them)
 		A.totals->sizes = A.total;
 	}
-	const uint4* minfo = ROUND ? A.minfo + (uint64_t)inst32 * A.inst.num_meshes : nullptr; // indexed by (template mesh number - P.cmesh0); P.cmesh0 = 0 (one class)
+	// this instance's meshes in the per-step table: indexed by (template mesh number - P.cmesh0); P.cmesh0 = 0 (one class). Places inside the
+	// instance are 32-bit (the stores use workgroup-uniform stream bases + 32-bit offsets): an instance beyond that ends the call
+	const VgxTmplMeshPlace* mplace = ROUND ? A.mplace + (uint64_t)inst32 * A.inst.num_meshes : nullptr;
+	auto minfoOf = [&](uint32_t m) {
+		const VgxTmplMeshPlace q = mplace[m];
+		const unsigned long long dv = q.v - P.v, di = q.i - P.i;
+		if ((dv | di) >> 32) { set_status(A.totals, VGX_E_RANGE); }
+		return make_uint4((uint32_t)dv, (uint32_t)di, q.nv, q.ni);
+	};
 	const uint2* relem = ROUND ? A.relem + (uint64_t)inst32 * A.num_round_elems : nullptr;  // indexed by trix[slot]
 
 	if (nm > VGX_TMPL_MAXM || nd > VGX_TMPL_MAXM) {
@@ -1183,7 +1191,7 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 			TmplRoundPlace rpl;
 			rpl.placed = false; rpl.b = 0; rpl.k = 0; rpl.nvPrev = 0; rpl.prevInner = false; rpl.nv = 0; rpl.ni = 0; rpl.da = 0.0f;
 			if (ROUND) {
-				const uint4 mi = minfo[er.mesh];
+				const uint4 mi = minfoOf(er.mesh);
 				vOff = mi.x; iOff = mi.y;
 				if (j == 0 && A.meshes_out) { tmpl_mesh_out_placed(A, P, er.mesh, mi); }
 				if (tm.pad[1] != 0) {
@@ -1223,7 +1231,7 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 	if (tid < nm) {
 		tm = A.tmesh[mA + tid];
 		if (meshBase) { ibase = meshBase[mA - P.cmesh0 + tid]; }
-		if (ROUND) { mi = minfo[mA + tid]; tm.v_off = mi.x; tm.i_off = mi.y; } // this instance's places
+		if (ROUND) { mi = minfoOf(mA + tid); tm.v_off = mi.x; tm.i_off = mi.y; } // this instance's places
 	}
 	if (tid < nd) { s_draw[tid] = tmpl_load_draw(A, idraws, P.tdraws, dA + tid); }
 	if (tid == 0) { s_status = A.totals->status; } // an earlier workgroup may have found the batch stale; ONE value for the whole workgroup (the exit below must be uniform)
@@ -1485,60 +1493,116 @@ __global__ __launch_bounds__(256) void k_tmpl_round_sizes(VgxTmplArgs A)
 	}
 }
 
-// One wave per instance, after k_tmpl_round_sizes: every mesh's place inside the instance (the template's sizes for the meshes without
-// Round joins, the counted ones for the others) and the instance's totals.
-__global__ __launch_bounds__(64) void k_tmpl_round_inst(VgxTmplArgs A)
+// The same for templates of LONG Round-join meshes (a polyline of a thousand segments: one wave per mesh leaves the GPU to a few thousand
+// waves of sixteen sequential chunks each): one 256-thread workgroup per (instance, mesh), 256 elements per trip, the waves' sums through LDS.
+__global__ __launch_bounds__(256) void k_tmpl_round_sizes_block(VgxTmplArgs A)
 {
-	const uint32_t lane = threadIdx.x;
-	const uint32_t M = (uint32_t)A.inst.num_meshes, R = A.num_round;
-	for (uint64_t inst = blockIdx.x; inst < A.ninst; inst += gridDim.x) {
-		unsigned long long runV = 0, runI = 0; // wave-uniform
-		bool tooLarge = false;
-		for (uint32_t m0 = 0; m0 < M; m0 += 64) {
-			const uint32_t m = m0 + lane;
-			uint32_t nv = 0, ni = 0;
-			if (m < M) {
-				const uint32_t r1 = A.tmesh[m].pad[1];
-				if (r1) {
-					const unsigned long long* z = A.rsz + (inst * R + (r1 - 1u)) * 2;
-					const unsigned long long v = z[0], i = z[1];
-					tooLarge = tooLarge || v > 65536ull; // what OpMeshOffsets reports for such a mesh (16-bit indices, vgx_scan_ops.h)
-					nv = vgx_sat_nv(v); ni = vgx_sat_ni(i);
-				} else {
-					const vgx_mesh mr = A.tmtab[m];
-					nv = mr.num_vertices; ni = mr.num_indices;
-				}
-			}
-			unsigned long long v = nv, i = ni;
-#pragma unroll
-			for (int d = 1; d < 64; d <<= 1) {
-				const unsigned long long tv = __shfl_up(v, d), ti = __shfl_up(i, d);
-				if (lane >= (uint32_t)d) { v += tv; i += ti; }
-			}
-			const unsigned long long ev = runV + v - nv, ei = runI + i - ni;
-			if (m < M) { A.minfo[inst * M + m] = make_uint4((uint32_t)ev, (uint32_t)ei, nv, ni); }
-			runV += __shfl(v, 63); runI += __shfl(i, 63);
+	__shared__ unsigned long long s_wv[4], s_wi[4], s_runV, s_runI;
+	__shared__ uint32_t s_wlastNv[4], s_wlastIn[4], s_lastNv, s_lastIn;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const uint32_t R = A.num_round;
+	const uint64_t g = blockIdx.x;
+	const uint64_t inst = g / R;
+	const uint32_t r = (uint32_t)(g - inst * R);
+	const VgxTmplRoundMesh rm = A.trmesh[r];
+	const VgxTmplMesh tm = A.tmesh[rm.mesh];
+	const TmplDraw dr = tmpl_load_draw(A, A.draws + inst * A.period, A.tdraws, tm.drawk);
+	const TmplXf xf = tmpl_draw_xf(&dr);
+	const float2* vt = A.tpoly + tm.poly_first;
+	const uint32_t N = tm.n;
+	MeshCtxT<TmplVtx01> mc;
+	mc.kind = VGX_MD_KIND(tm.kind); mc.closed = VGX_MD_CLOSED(tm.kind) != 0; mc.cap = VGX_MD_CAP(tm.kind); mc.join = VGX_MD_JOIN(tm.kind);
+	mc.N = N; mc.hsw = tm.f0; mc.hswAA = tm.f1; mc.fringe = 0.0f;
+	mc.dr = A.tdraws + tm.drawk;
+	mc.vtx.x0 = 0.0f; mc.vtx.y0 = 0.0f; mc.vtx.x1 = 0.0f; mc.vtx.y1 = 0.0f;
+	uint2* out = A.relem + inst * A.num_round_elems + rm.elem0;
+	if (tid == 0) { s_runV = 0; s_runI = 0; s_lastNv = 0; s_lastIn = 0; }
+	__syncthreads();
+	for (uint32_t j0 = 0; j0 < N; j0 += 256) {
+		const uint32_t j = j0 + tid;
+		uint32_t nv = 0, ni = 0;
+		bool inner = false;
+		if (j < N) {
+			const V2 p1 = tmpl_xf(xf, vt[j]);
+			const V2 pn = tmpl_xf(xf, vt[j + 1 < N ? j + 1 : 0u]);
+			const V2 pp = tmpl_xf(xf, vt[j > 0 ? j - 1 : N - 1]);
+			mc.j = j;
+			const Elem e = elem_geometry(mc, p1, v2dir(pp, p1), v2dir(p1, pn));
+			nv = e.nv; ni = elem_total_indices(mc, e); inner = e.leftInner;
 		}
-		if (tooLarge) { set_status(A.totals, VGX_E_MESH_TOO_LARGE); }
-		if (runV >= (1ull << 32) || runI >= (1ull << 32)) { if (lane == 0) { set_status(A.totals, VGX_E_RANGE); } } // the places inside an instance are 32-bit
-		if (lane == 0) { A.itot[2 * inst] = runV; A.itot[2 * inst + 1] = runI; }
+		unsigned long long v = nv, i = ni;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const unsigned long long tv = __shfl_up(v, d), ti = __shfl_up(i, d);
+			if (lane >= (uint32_t)d) { v += tv; i += ti; }
+		}
+		uint32_t nvP = __shfl_up(nv, 1);
+		int inP = __shfl_up((int)inner, 1);
+		if (lane == 63u) { s_wv[wave] = v; s_wi[wave] = i; s_wlastNv[wave] = nv; s_wlastIn[wave] = inner ? 1u : 0u; }
+		__syncthreads();
+		unsigned long long baseV = s_runV, baseI = s_runI, totV = 0, totI = 0;
+#pragma unroll
+		for (uint32_t w = 0; w < 4; ++w) { if (w < wave) { baseV += s_wv[w]; baseI += s_wi[w]; } totV += s_wv[w]; totI += s_wi[w]; }
+		if (lane == 0) { nvP = wave > 0 ? s_wlastNv[wave - 1] : s_lastNv; inP = (int)(wave > 0 ? s_wlastIn[wave - 1] : s_lastIn); }
+		if (j < N) { out[j] = tmpl_round_word((uint32_t)(baseV + v - nv), (uint32_t)(baseI + i - ni), nvP, inP != 0); }
+		__syncthreads();
+		const uint32_t lastJ = (N - j0 < 256u ? N - j0 : 256u) - 1u; // the chunk's last element
+		if (tid == lastJ) { s_runV += totV; s_runI += totI; s_lastNv = nv; s_lastIn = inner ? 1u : 0u; }
+		__syncthreads();
+	}
+	if (tid == 0) {
+		A.rsz[2 * g] = s_runV; A.rsz[2 * g + 1] = s_runI;
+		if (mc.closed) { out[0] = tmpl_round_word(0u, 0u, s_lastNv, s_lastIn != 0); }
 	}
 }
 
-// The instances' places in the batch: exclusive sums of their totals; the batch's sizes; the caller's capacities.
-struct OpTmplRoundPlace
+// After the sizes: ONE scan over every mesh of every instance (instance-major, the batch's mesh order): its first vertex / index in the
+// batch (the template's sizes for the meshes without Round joins, the counted ones for the others; a mesh beyond 65 536 vertices ends the
+// call like the ordinary path's scan, vgx_scan_ops.h), the batch totals, the caller's capacities. Parallel whatever the shape of the batch
+// (ten thousand instances of a few hundred meshes, or one instance -- a static batch -- of millions).
+struct OpTmplRoundMeshes
 {
 	VgxTmplArgs A;
-	__device__ uint64_t size() const { return A.ninst; }
-	__device__ Sum3 load(uint64_t k) const { Sum3 r = sum3_zero(); r.a = A.itot[2 * k]; r.b = A.itot[2 * k + 1]; return r; }
-	__device__ void store(uint64_t k, Sum3 e) const { A.iplace[2 * k] = e.a; A.iplace[2 * k + 1] = e.b; }
+	__device__ uint64_t size() const { return A.ninst * A.inst.num_meshes; }
+	__device__ void sizes(uint64_t k, uint32_t* nv, uint32_t* ni, bool* tooLarge) const
+	{
+		const uint64_t M = A.inst.num_meshes;
+		const uint64_t inst = k / M;
+		const uint32_t m = (uint32_t)(k - inst * M);
+		const uint32_t r1 = A.tmesh[m].pad[1];
+		*tooLarge = false;
+		if (r1) {
+			const unsigned long long* z = A.rsz + (inst * A.num_round + (r1 - 1u)) * 2;
+			const unsigned long long v = z[0], i = z[1];
+			*tooLarge = v > 65536ull; // what OpMeshOffsets reports for such a mesh (16-bit indices)
+			*nv = vgx_sat_nv(v); *ni = vgx_sat_ni(i);
+		} else {
+			const vgx_mesh mr = A.tmtab[m];
+			*nv = mr.num_vertices; *ni = mr.num_indices;
+		}
+	}
+	__device__ Sum3 load(uint64_t k) const
+	{
+		uint32_t nv, ni; bool big;
+		sizes(k, &nv, &ni, &big);
+		Sum3 r = sum3_zero(); r.a = nv; r.b = ni; r.c = big ? 1u : 0u;
+		return r;
+	}
+	__device__ void store(uint64_t k, Sum3 e) const
+	{
+		uint32_t nv, ni; bool big;
+		sizes(k, &nv, &ni, &big);
+		VgxTmplMeshPlace q; q.v = e.a; q.i = e.b; q.nv = nv; q.ni = ni;
+		A.mplace[k] = q;
+	}
 	__device__ void finish(Sum3 tot) const
 	{
 		vgx_sizes z = A.total;
 		z.num_vertices = tot.a; z.num_indices = tot.b;
 		A.totals->sizes = z;
+		if (tot.c) { set_status(A.totals, VGX_E_MESH_TOO_LARGE); }
 		const uint32_t aux = (tot.a > A.caps.vertices ? 1u : 0u) | (tot.b > A.caps.indices ? 2u : 0u) | ((A.meshes_out && z.num_meshes > A.caps.meshes) ? 4u : 0u);
-		if (aux && A.totals->status == VGX_OK) { // the need is in sizes; nothing is emitted (k_tmpl_emit_round leaves when the status is set)
+		if (aux && A.totals->status == VGX_OK) { // the need is in sizes; nothing is emitted (the emit kernels leave when the status is set)
 			A.totals->status = VGX_E_NOSPACE;
 			A.totals->fail_reason = VGX_FAIL_OUT_CAPACITY;
 			A.totals->fail_aux = aux;
@@ -1552,12 +1616,12 @@ void vgx_launch_tmpl_round_sizes(const VgxTmplArgs& a, Sum3* partial, hipStream_
 {
 	const uint64_t blocks = a.ninst * a.tiles_per_inst; // the host checked < 2^31
 	if (!blocks) { return; }
-	const uint64_t pairs = a.ninst * (uint64_t)a.num_round; // the host checked < 2^32
-	hipLaunchKernelGGL(k_tmpl_round_sizes, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, a);
-	hipLaunchKernelGGL(k_tmpl_round_inst, dim3((unsigned)(a.ninst > 65536 ? 65536 : a.ninst)), dim3(64), 0, s, a);
-	OpTmplRoundPlace op;
+	const uint64_t pairs = a.ninst * (uint64_t)a.num_round; // the host checked < 2^31
+	if (a.num_round_elems / a.num_round > 128u) { hipLaunchKernelGGL(k_tmpl_round_sizes_block, dim3((unsigned)pairs), dim3(256), 0, s, a); } // long meshes: a workgroup each
+	else { hipLaunchKernelGGL(k_tmpl_round_sizes, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, a); }
+	OpTmplRoundMeshes op;
 	op.A = a;
-	vgx_device_scan(op, partial, s, a.ninst);
+	vgx_device_scan(op, partial, s, a.ninst * a.inst.num_meshes);
 }
 
 void vgx_launch_tmpl_check(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, VgxTotals* totals, hipStream_t s)

@@ -641,6 +641,50 @@ def frame_leg(rt, torch, ctx, local_rank):
             torch.cuda.synchronize()
             p2.close()
         whole_us = (time.perf_counter() - t0) / Rw * 1e6
+        # the same frame as a STATIC batch (vgx_set_static_batches: a retained command list re-submitted under a new camera): the count
+        # flattens the list once, a frame is then the template emit kernel (+ the assembly kernels while armed)
+        ctx.set_static_batches(True)
+        try:
+            t0 = time.perf_counter()
+            rt.tessellate_count(ctx, pset, dd, nd)
+            out["static_count_us"] = round((time.perf_counter() - t0) * 1e6, 1)
+            bufs.pos.zero_(); bufs.idx.zero_(); bufs.color.zero_()
+            for _ in range(5):
+                rt.tessellate_async(ctx, pset, dd, nd, bufs)
+            torch.cuda.synchronize()
+            ok_static = (int(bufs.dev_status.item()) == 0 and int(ncmd.item()) == int(fx["ref_num_drawcmds"])
+                         and int(bufs.idx[:ni].to(torch.int64).bitwise_and(0xFFFF).sum().item()) == int(fx["ref_idx_sum"])
+                         and int(bufs.color[:nv].to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) == int(fx["ref_col_sum"])
+                         and float(bufs.pos[:nv].to(torch.float64).sum().item()) == float(fx["ref_pos_sum"]))
+            t0 = time.perf_counter()
+            for _ in range(R):
+                rt.tessellate_async(ctx, pset, dd, nd, bufs)
+            torch.cuda.synchronize()
+            out["static_tessellate_assembled_us_back_to_back"] = round((time.perf_counter() - t0) / R * 1e6, 1)
+            t0 = time.perf_counter()
+            for _ in range(R):
+                rt.tessellate_async(ctx, pset, dd, nd, bufs)
+                torch.cuda.synchronize()
+            out["static_tessellate_assembled_us_with_sync"] = round((time.perf_counter() - t0) / R * 1e6, 1)
+            ctx.set_assembly(None)
+            for _ in range(5):
+                rt.tessellate_async(ctx, pset, dd, nd, bufs)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(R):
+                rt.tessellate_async(ctx, pset, dd, nd, bufs)
+            torch.cuda.synchronize()
+            out["static_tessellate_meshes_only_us_back_to_back"] = round((time.perf_counter() - t0) / R * 1e6, 1)
+            t0 = time.perf_counter()
+            for _ in range(R):
+                rt.tessellate_async(ctx, pset, dd, nd, bufs)
+                torch.cuda.synchronize()
+            out["static_tessellate_meshes_only_us_with_sync"] = round((time.perf_counter() - t0) / R * 1e6, 1)
+            out["static_equals_reference_frame"] = bool(ok_static)
+        except Exception as e:  # noqa: BLE001
+            out["static_error"] = repr(e)[:160]
+        finally:
+            ctx.set_static_batches(False)
     finally:
         ctx.set_assembly(None)
     pset.close()

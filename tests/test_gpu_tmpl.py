@@ -772,3 +772,25 @@ def test_static_batches_long_round_join_polylines(rt, wl, oracle):
     assert bytes_equal(bufs.pos[:ref2.pos.shape[0]].cpu().numpy(), ref2.pos) and bytes_equal(bufs.idx[:ref2.idx.shape[0]].cpu().numpy().view(np.uint16), ref2.idx)
     pset.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("max_vb,split", [(65536, False), (3000, True)])
+def test_static_batches_one_frame(rt, wl, oracle, max_vb, split):
+    """A frame-sized draw list (one tiger, 240 draws; below the 2 048 draws template mode otherwise asks for) as a static batch, meshes
+    only and with draw-command assembly armed: the reference's bytes, the ordinary frame path's draw commands."""
+    ps, d = wl.tiger(1)
+    d["state_key"] = (np.arange(d.shape[0]) // 50).astype(d["state_key"].dtype)
+    ref = oracle.tessellate(ps, d)
+    ctx = rt.Context(0)
+    old = _assembled(rt, ctx, ps, d, max_vb, split)
+    assert old.mode != MODE_TEMPLATE and old.status == 0
+    ctx.set_static_batches(True)
+    got = _run(rt, ctx, ps, d)
+    assert got.mode == MODE_TEMPLATE and got.stages == ["tmpl_emit"] and got.status == 0
+    assert_mesh_equal(got, ref, "static batch: one frame")
+    asm = _assembled(rt, ctx, ps, d, max_vb, split)
+    assert asm.mode == MODE_TEMPLATE and asm.status == 0 and "tmpl_emit" in asm.stages
+    assert asm.ncmd == old.ncmd
+    for k in ("pos", "color", "idx", "meshes", "cmds"):
+        assert bytes_equal(getattr(asm, k), getattr(old, k)), k
+    ctx.close()

@@ -1476,7 +1476,7 @@ static bool tmplEligible(const VgxTotals& ht, bool roundOk)
 static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, vgx_sizes* out_sizes, hipStream_t s)
 {
 	ctx->tmplOn = false;
-	if (!ctx->optTmpl || !ctx->optInst || ctx->optTwoPass || ndraws <= VGX_SMALL_DRAWS) { return VGX_OK; }
+	if (!ctx->optTmpl || !ctx->optInst || ctx->optTwoPass || (ndraws <= VGX_SMALL_DRAWS && !ctx->optTmplBatch) || ndraws == 0) { return VGX_OK; } // (static batches: frame-sized draw lists too)
 	int st;
 	if ((st = ensure(ctx, ctx->totals, sizeof(VgxTotals))) != VGX_OK) { return st; }
 	noteHip(ctx, hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s));

@@ -1233,10 +1233,12 @@ def main():
         fr1 = (next_rows or {}).get("frame_tiger_x1")
         if fr1 and "error" not in fr1:  # one real frame, microseconds (next_rows.frame_tiger_x1 has the workload and every step)
             summary["frame_tiger_x1"] = {k: fr1.get(k) for k in ("decode_us", "decode_MB_per_s", "tessellate_assembled_us_back_to_back", "tessellate_assembled_us_with_sync",
-                                                                 "tessellate_assembled_us_hip_graph_replay", "whole_frame_us_from_recorded_bytes", "reference_context_us_per_frame_one_core", "equals_reference_frame")}
+                                                                 "tessellate_assembled_us_hip_graph_replay", "static_tessellate_assembled_us_back_to_back", "static_tessellate_meshes_only_us_back_to_back", "static_equals_reference_frame",
+                                                                 "whole_frame_us_from_recorded_bytes", "reference_context_us_per_frame_one_core", "equals_reference_frame")}
+            out["config"]["frame_tiger_x1_us_static_batch"] = fr1.get("static_tessellate_assembled_us_back_to_back")
             out["config"]["frame_tiger_x1_us_hip_graph_replay"] = fr1.get("tessellate_assembled_us_hip_graph_replay")
             out["config"]["frame_tiger_x1_us_reference_one_core"] = fr1.get("reference_context_us_per_frame_one_core")
-        for name in ("cubics1m", "round10k", "tiger10k_animated", "tiger10k_command_parallel", "tiger10k_per_instance_flatten"):
+        for name in ("cubics1m", "round10k", "round10k_static", "tiger10k_round", "tiger10k_culled", "tiger10k_animated", "tiger10k_command_parallel", "tiger10k_per_instance_flatten"):
             if name in summary and "ms" in summary[name]:
                 out["config"]["%s_ms_per_step" % name] = summary[name]["ms"]
                 if summary[name].get("frac") is not None:

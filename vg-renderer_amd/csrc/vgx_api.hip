@@ -1605,6 +1605,9 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	if ((st = ensure(ctx, ctx->tmplTile, (tiles + 1) * sizeof(VgxTmplTile))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->tmplTrmesh, (M + 2) * sizeof(VgxTmplRoundMesh))) != VGX_OK) { return st; }
 	b.trmesh = (VgxTmplRoundMesh*)ctx->tmplTrmesh.p;
+	b.has_round = roundTmpl ? 1u : 0u;
+	if ((st = ensure(ctx, ctx->partial, VGX_SCAN_BLOCKS * sizeof(Sum3))) != VGX_OK) { return st; }
+	b.partial = (Sum3*)ctx->partial.p;
 	b.ttile = (VgxTmplTile*)ctx->tmplTile.p;
 	b.tmesh = (VgxTmplMesh*)ctx->tmplMesh.p; b.tmtab = (vgx_mesh*)ctx->tmplMtab.p; b.telem = (VgxTmplElem*)ctx->tmplElem.p;
 	vgx_launch_tmpl_build(b, s);

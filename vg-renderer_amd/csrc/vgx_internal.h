@@ -99,6 +99,8 @@ struct VgxTmplBuild // count pass: the first period's ordinary count + emit resu
 	uint64_t num_vertices, num_indices; // output totals of the concatenated representatives
 	VgxTmplClass* cls;           // [nclasses + 1], written by the first build kernel
 	VgxTmplRoundMesh* trmesh;    // [num_meshes + 1] (used: Round-join meshes + 1)
+	uint32_t has_round;          // the template holds Round-join meshes (k_tmpl_styles): number them
+	struct Sum3* partial;        // scratch of the device scan
 };
 struct VgxTmplArgs // one step
 {

@@ -213,47 +213,40 @@ __global__ __launch_bounds__(256) void k_tmpl_meshes(VgxTmplBuild B)
 	}
 }
 
-// Round-join meshes numbered in mesh order (one block; after k_tmpl_meshes): tmesh[m].pad[1] = number + 1, trmesh[number] = (mesh, its first
-// element among the instance's Round-join elements); trmesh[count] = (~0, the total); the count -> cls[nclasses].pad[1]
-__global__ __launch_bounds__(256) void k_tmpl_round_index(VgxTmplBuild B)
+// Round-join meshes numbered in mesh order (a device scan over the template's meshes; after k_tmpl_meshes): tmesh[m].pad[1] = number + 1,
+// trmesh[number] = (mesh, its first element among the instance's Round-join elements); trmesh[count] = (~0, the total); the count ->
+// cls[nclasses].pad[1]. Only launched for templates that hold Round joins (k_tmpl_meshes leaves pad[1] = 0).
+struct OpTmplRoundIndex
 {
-	__shared__ uint2 s_wave[4];
-	__shared__ uint2 s_run;
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	if (threadIdx.x == 0) { s_run = make_uint2(0u, 0u); }
-	__syncthreads();
-	for (uint64_t m0 = 0; m0 < B.num_meshes; m0 += 256) {
-		const uint64_t m = m0 + threadIdx.x;
-		const bool f = m < B.num_meshes && tmpl_is_round(B.mdesc[m].kind);
-		const uint32_t n = f ? B.mdesc[m].poly_n : 0u;
-		uint32_t v = f ? 1u : 0u, e = n;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(v, d), te = __shfl_up(e, d); if (lane >= d) { v += t; e += te; } }
-		if (lane == 63) { s_wave[wave] = make_uint2(v, e); }
-		__syncthreads();
-		uint2 base = s_run, tot = make_uint2(0u, 0u);
-		for (int w = 0; w < 4; ++w) { const uint2 t = s_wave[w]; if (w < wave) { base.x += t.x; base.y += t.y; } tot.x += t.x; tot.y += t.y; }
-		if (m < B.num_meshes) {
-			B.tmesh[m].pad[1] = f ? base.x + v : 0u;
-			if (f) {
-				VgxTmplRoundMesh r; r.mesh = (uint32_t)m; r.elem0 = base.y + e - n; B.trmesh[base.x + v - 1u] = r;
-				// what the emit kernel needs of a Round-join mesh besides its record, in the record (l2: only AA fills read the three local vertices):
-				// the arc step da (stroker.cpp:1398 -- scale, half width and tolerance are the template's) and the mesh's first table word
-				const vgx_draw* td = B.draws + B.mdesc[m].draw;
-				B.tmesh[m].l2[0] = vgx_step_angle(td->scale, B.tmesh[m].f0, td->tess_tol);
-				B.tmesh[m].l2[1] = __uint_as_float(r.elem0);
-			}
-		}
-		__syncthreads();
-		if (threadIdx.x == 0) { s_run.x += tot.x; s_run.y += tot.y; }
-		__syncthreads();
+	VgxTmplBuild B;
+	__device__ uint64_t size() const { return B.num_meshes; }
+	__device__ Sum3 load(uint64_t m) const
+	{
+		Sum3 r = sum3_zero();
+		const VgxMeshDesc md = B.mdesc[m];
+		if (tmpl_is_round(md.kind)) { r.a = 1; r.b = md.poly_n; }
+		return r;
 	}
-	if (threadIdx.x == 0) {
-		VgxTmplRoundMesh r; r.mesh = ~0u; r.elem0 = s_run.y;
-		B.trmesh[s_run.x] = r;
-		B.cls[B.nclasses].pad[1] = s_run.x;
+	__device__ void store(uint64_t m, Sum3 e) const
+	{
+		const VgxMeshDesc md = B.mdesc[m];
+		if (!tmpl_is_round(md.kind)) { return; }
+		B.tmesh[m].pad[1] = (uint32_t)e.a + 1u;
+		VgxTmplRoundMesh r; r.mesh = (uint32_t)m; r.elem0 = (uint32_t)e.b;
+		B.trmesh[e.a] = r;
+		// what the emit kernel needs of a Round-join mesh besides its record, in the record (l2: only AA fills read the three local vertices):
+		// the arc step da (stroker.cpp:1398 -- scale, half width and tolerance are the template's) and the mesh's first table word
+		const vgx_draw* td = B.draws + md.draw;
+		B.tmesh[m].l2[0] = vgx_step_angle(td->scale, B.tmesh[m].f0, td->tess_tol);
+		B.tmesh[m].l2[1] = __uint_as_float(r.elem0);
 	}
-}
+	__device__ void finish(Sum3 tot) const
+	{
+		VgxTmplRoundMesh r; r.mesh = ~0u; r.elem0 = (uint32_t)tot.b;
+		B.trmesh[tot.a] = r;
+		B.cls[B.nclasses].pad[1] = (uint32_t)tot.a;
+	}
+};
 
 // Element table in processing order: tiles of `tile` elements of the instance's output-ordered element stream; inside a
 // tile the fill elements first, then the stroke elements (both in output order). Every class starts a tile of its own
@@ -1656,7 +1649,7 @@ void vgx_launch_tmpl_build(const VgxTmplBuild& b, hipStream_t s)
 	const uint64_t nt = (b.num_elems + b.tile - 1) / b.tile + b.nclasses; // >= the tile count (every class rounds up on its own)
 	if (b.num_meshes) {
 		hipLaunchKernelGGL(k_tmpl_meshes, dim3((unsigned)(gm > 4096 ? 4096 : gm)), dim3(256), 0, s, b);
-		hipLaunchKernelGGL(k_tmpl_round_index, dim3(1), dim3(256), 0, s, b);
+		if (b.has_round) { OpTmplRoundIndex op; op.B = b; vgx_device_scan(op, b.partial, s, b.num_meshes); }
 	}
 	if (b.num_elems) {
 		hipLaunchKernelGGL(k_tmpl_elems, dim3((unsigned)(ge > 4096 ? 4096 : ge)), dim3(256), 0, s, b);

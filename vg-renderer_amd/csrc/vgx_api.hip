@@ -119,7 +119,7 @@ struct vgx_ctx
 	DevBuf tmplHash, tmplInstCls, tmplClsRep, tmplCls, tmplIinfo, tmplWg;
 	uint32_t tmplRound;                  // Round-join stroke meshes per instance (tmplGeneral == 3): their sizes, and every place behind them, are counted per step
 	uint32_t tmplRoundElems;             // their elements per instance
-	DevBuf tmplTrmesh;                   // template: the Round-join meshes (mesh, first element among the Round-join elements)
+	DevBuf tmplTrmesh, tmplTmsz;         // template: the Round-join meshes (mesh, first element among the Round-join elements); per mesh its sizes (VgxTmplArgs::tmsz)
 	DevBuf tmplRsz, tmplRelem, tmplMplace; // the per-step tables of such a template (VgxTmplArgs)
 	hipStream_t sideStream; hipEvent_t forkEv, joinEv; // optConcurrentEmit only
 	VgxCaps caps; // element capacities matching the buffers above
@@ -765,7 +765,7 @@ int vgx_destroy(vgx_ctx* ctx)
 		return VGX_E_INVALID_ARG;
 	}
 	DeviceGuard guard(ctx);
-	DevBuf* bufs[] = { &ctx->f1SegDraw, &ctx->f1Segs, &ctx->tmplHash, &ctx->tmplInstCls, &ctx->tmplClsRep, &ctx->tmplCls, &ctx->tmplIinfo, &ctx->tmplWg, &ctx->tmplTrmesh, &ctx->tmplRsz, &ctx->tmplRelem, &ctx->tmplMplace, &ctx->tmplTile, &ctx->tmplPoly, &ctx->tmplMesh, &ctx->tmplMtab, &ctx->tmplElem, &ctx->tmplDraws, &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DevBuf* bufs[] = { &ctx->f1SegDraw, &ctx->f1Segs, &ctx->tmplHash, &ctx->tmplInstCls, &ctx->tmplClsRep, &ctx->tmplCls, &ctx->tmplIinfo, &ctx->tmplWg, &ctx->tmplTrmesh, &ctx->tmplTmsz, &ctx->tmplRsz, &ctx->tmplRelem, &ctx->tmplMplace, &ctx->tmplTile, &ctx->tmplPoly, &ctx->tmplMesh, &ctx->tmplMtab, &ctx->tmplElem, &ctx->tmplDraws, &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
@@ -787,7 +787,7 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx)
 	if (!ctx) {
 		return 0;
 	}
-	return ctx->f1SegDraw.cap + ctx->f1Segs.cap + ctx->tmplHash.cap + ctx->tmplInstCls.cap + ctx->tmplClsRep.cap + ctx->tmplCls.cap + ctx->tmplIinfo.cap + ctx->tmplWg.cap + ctx->tmplTrmesh.cap + ctx->tmplRsz.cap + ctx->tmplRelem.cap + ctx->tmplMplace.cap + ctx->tmplTile.cap + ctx->tmplPoly.cap + ctx->tmplMesh.cap + ctx->tmplMtab.cap + ctx->tmplElem.cap + ctx->tmplDraws.cap + ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
+	return ctx->f1SegDraw.cap + ctx->f1Segs.cap + ctx->tmplHash.cap + ctx->tmplInstCls.cap + ctx->tmplClsRep.cap + ctx->tmplCls.cap + ctx->tmplIinfo.cap + ctx->tmplWg.cap + ctx->tmplTrmesh.cap + ctx->tmplTmsz.cap + ctx->tmplRsz.cap + ctx->tmplRelem.cap + ctx->tmplMplace.cap + ctx->tmplTile.cap + ctx->tmplPoly.cap + ctx->tmplMesh.cap + ctx->tmplMtab.cap + ctx->tmplElem.cap + ctx->tmplDraws.cap + ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
 }
 
 // ---- path set ---------------------------------------------------------------------------------------
@@ -1348,7 +1348,7 @@ static int tmplRoundSizes(vgx_ctx* ctx, VgxTmplArgs& a, hipStream_t s)
 	int st;
 	const uint64_t n = a.ninst;
 	a.num_round = ctx->tmplRound; a.num_round_elems = ctx->tmplRoundElems;
-	a.trmesh = (const VgxTmplRoundMesh*)ctx->tmplTrmesh.p;
+	a.trmesh = (const VgxTmplRoundMesh*)ctx->tmplTrmesh.p; a.tmsz = (const uint2*)ctx->tmplTmsz.p;
 	if (n * a.num_round >= (1ull << 31)) { return VGX_E_RANGE; } // one wave (long meshes: one workgroup) per (instance, Round-join mesh)
 	if ((st = ensure(ctx, ctx->tmplRsz, (n * a.num_round + 1) * 2 * sizeof(unsigned long long))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->tmplRelem, (n * a.num_round_elems + 1) * sizeof(uint2))) != VGX_OK) { return st; }
@@ -1604,6 +1604,8 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	if ((st = ensure(ctx, ctx->tmplElem, (tiles * tileSize + 64) * sizeof(VgxTmplElem))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->tmplTile, (tiles + 1) * sizeof(VgxTmplTile))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->tmplTrmesh, (M + 2) * sizeof(VgxTmplRoundMesh))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->tmplTmsz, (M + 1) * sizeof(uint2))) != VGX_OK) { return st; }
+	b.tmsz = (uint2*)ctx->tmplTmsz.p;
 	b.trmesh = (VgxTmplRoundMesh*)ctx->tmplTrmesh.p;
 	b.has_round = roundTmpl ? 1u : 0u;
 	if ((st = ensure(ctx, ctx->partial, VGX_SCAN_BLOCKS * sizeof(Sum3))) != VGX_OK) { return st; }

@@ -99,6 +99,7 @@ struct VgxTmplBuild // count pass: the first period's ordinary count + emit resu
 	uint64_t num_vertices, num_indices; // output totals of the concatenated representatives
 	VgxTmplClass* cls;           // [nclasses + 1], written by the first build kernel
 	VgxTmplRoundMesh* trmesh;    // [num_meshes + 1] (used: Round-join meshes + 1)
+	uint2* tmsz;                 // [num_meshes] vertices, indices of the mesh (Round joins: 0x80000000 | number among the Round-join meshes, 0)
 	uint32_t has_round;          // the template holds Round-join meshes (k_tmpl_styles): number them
 	struct Sum3* partial;        // scratch of the device scan
 };
@@ -137,6 +138,7 @@ struct VgxTmplArgs // one step
 	uint32_t num_round;          // Round-join stroke meshes per instance (VgxTmplMesh::pad[1] = the mesh's number among them + 1)
 	uint32_t num_round_elems;    // their elements per instance
 	const VgxTmplRoundMesh* trmesh; // [num_round + 1]
+	const uint2* tmsz;           // [meshes of the template] vertices, indices (Round joins: 0x80000000 | number among the Round-join meshes, 0): what the scan over the meshes reads
 	unsigned long long* rsz;     // [ninst * num_round * 2] vertices, indices of every such mesh
 	uint2* relem;                // [ninst * num_round_elems] per element of such a mesh: first vertex / index inside the mesh, size and inner side of the element in front (tmpl_round_word)
 	VgxTmplMeshPlace* mplace;    // [ninst * meshes] per mesh of the batch: first vertex, first index in the BATCH; vertices, indices
@@ -152,11 +154,11 @@ void vgx_launch_tmpl_hash(const vgx_draw* draws, uint64_t ndraws, uint64_t perio
 void vgx_launch_tmpl_check_cls(const vgx_draw* draws, uint64_t ndraws, uint64_t period, const uint32_t* inst_cls, const uint32_t* cls_rep, VgxTotals* totals, hipStream_t s);
 void vgx_launch_tmpl_emit(const VgxTmplArgs& a, hipStream_t s);
 #ifndef VGX_TMPL_RC_THREADS
-#define VGX_TMPL_RC_THREADS 640 /* k_tmpl_emit_round_closed (templates of closed strokes with Round joins): threads per workgroup, */
-#define VGX_TMPL_RC_TILE 2560   /* elements per tile */
+#define VGX_TMPL_RC_THREADS 512 /* k_tmpl_emit_round_closed (templates of closed strokes with Round joins): threads per workgroup, */
+#define VGX_TMPL_RC_TILE 2048   /* elements per tile */
 #endif
 #ifndef VGX_TMPL_RC_WAVES
-#define VGX_TMPL_RC_WAVES 5     /* waves per SIMD its registers are limited for */
+#define VGX_TMPL_RC_WAVES 6     /* waves per SIMD its registers are limited for (80 VGPRs: three workgroups per CU) */
 #endif
 #ifndef VGX_TMPL_GENERAL_TILE
 #define VGX_TMPL_GENERAL_TILE 2048 /* tile size of templates that hold general strokes (the LDS stages of k_tmpl_emit_general) */

@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256) void k_tmpl_meshes(VgxTmplBuild B)
 		t.pad[0] = __float_as_uint(pr.f2); t.pad[1] = 0; // the draw's fringe (general strokes: Butt-cap fringes, thin strokes)
 		B.tmesh[m] = t;
 		B.tmtab[m] = mt;
+		B.tmsz[m] = make_uint2(mt.num_vertices, mt.num_indices);
 	}
 }
 
@@ -232,6 +233,7 @@ struct OpTmplRoundIndex
 		const VgxMeshDesc md = B.mdesc[m];
 		if (!tmpl_is_round(md.kind)) { return; }
 		B.tmesh[m].pad[1] = (uint32_t)e.a + 1u;
+		B.tmsz[m] = make_uint2(0x80000000u | (uint32_t)e.a, 0u);
 		VgxTmplRoundMesh r; r.mesh = (uint32_t)m; r.elem0 = (uint32_t)e.b;
 		B.trmesh[e.a] = r;
 		// what the emit kernel needs of a Round-join mesh besides its record, in the record (l2: only AA fills read the three local vertices):
@@ -1014,7 +1016,7 @@ __device__ __forceinline__ void tmpl_stroke_elem_round(const TmplOut& O, uint32_
 #define VGX_TMPL_K3_ROLLED 0 /* 1 (measured: bevel 2.22 -> 2.33 ms, round the same): one copy of the element routines, one element per trip */
 #endif
 #ifndef VGX_TMPL_RC_ROLLED
-#define VGX_TMPL_RC_ROLLED 1 /* k_tmpl_emit_round_closed: the Round-join elements in a rolled second pass (0: inlined into the unrolled one) */
+#define VGX_TMPL_RC_ROLLED 0 /* k_tmpl_emit_round_closed: 1 = the Round-join elements in a rolled second pass (what the 640-thread shape liked), 0 = inlined into the unrolled one */
 #endif
 #ifndef VGX_TMPL_BEVEL_FAST
 #define VGX_TMPL_BEVEL_FAST 1 /* 0 (measurement): closed Bevel strokes through the general body */
@@ -1117,6 +1119,7 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 	__shared__ float2 s_vtx[MAXTILE];
 	__shared__ float2 s_dir[MAXTILE];
 	__shared__ uint32_t s_status;
+	__shared__ uint4 s_mi[ROUND ? VGX_TMPL_MAXM : 1];     // per mesh of the tile: first vertex / index inside the instance, vertices, indices (phase 0a -> 0b)
 	__shared__ float4 s_rmesh[ROUND ? VGX_TMPL_MAXM : 1]; // per mesh of the tile: vertices, indices (bits), arc step, first table word of a Round-join mesh (bits; ~0: none)
 	__shared__ float s_fringe[KIND >= 2 ? VGX_TMPL_MAXM : 1]; // per mesh of the tile: the draw's fringe (Bevel joins, Butt caps, thin strokes: kernels with those only)
 	const uint32_t tid = threadIdx.x;
@@ -1208,6 +1211,7 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 #define TMPL_PROF(i)
 #endif
 	// ---- phase 0a: every load the workgroup needs, requested at once
+	if (ROUND && tid < nm) { s_mi[tid] = minfoOf(mA + tid); } // requested FIRST and parked in LDS as soon as it is there (the loads below stay in flight): its registers are free again before the element and mesh records arrive
 	VgxTmplElem er[CH];
 	uint32_t rb[ROUND ? CH : 1], rk[ROUND ? CH : 1]; // ROUND: elements of Round-join meshes: their table words (else rb = ~0)
 #pragma unroll
@@ -1224,7 +1228,6 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 	if (tid < nm) {
 		tm = A.tmesh[mA + tid];
 		if (meshBase) { ibase = meshBase[mA - P.cmesh0 + tid]; }
-		if (ROUND) { mi = minfoOf(mA + tid); tm.v_off = mi.x; tm.i_off = mi.y; } // this instance's places
 	}
 	if (tid < nd) { s_draw[tid] = tmpl_load_draw(A, idraws, P.tdraws, dA + tid); }
 	if (tid == 0) { s_status = A.totals->status; } // an earlier workgroup may have found the batch stale; ONE value for the whole workgroup (the exit below must be uniform)
@@ -1232,6 +1235,7 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 	const uint32_t status = s_status;
 	// ---- phase 0b: per-mesh records
 	if (tid < nm) {
+		if (ROUND) { mi = s_mi[tid]; tm.v_off = mi.x; tm.i_off = mi.y; } // this instance's places
 		const uint32_t kind = VGX_MD_KIND(tm.kind);
 		const TmplDraw* d = &s_draw[tm.drawk - dA];
 		TmplRec r;
@@ -1418,9 +1422,11 @@ __global__ __launch_bounds__(VGX_TMPL_G_THREADS, VGX_TMPL_R_MINWAVES) void k_tmp
 	tmpl_emit_body<2, VGX_TMPL_G_THREADS, VGX_TMPL_G_TILE, 1>(A);
 }
 // templates whose strokes are all closed (Miter / Bevel joins, AA Round joins): the headline kernel's shape with the three closed routines
-// 85-90 VGPRs = five waves per SIMD = 20 per CU: workgroups of ten waves (two per CU) can use all of them, 8-wave workgroups only 16. Same box:
-// 640 x 2560 with the Round-join elements in a rolled second pass 3.35 ms, 512 x 2048 3.47, 512 x 2048 forced to 80 VGPRs (six waves,
-// 20 bytes of scratch) 3.95: what this kernel waits for is the third workgroup per CU the Bevel kernel (78 VGPRs) has
+// What this kernel waits for is the third workgroup per CU the Bevel kernel (78 VGPRs) has: at 85-90 VGPRs (five waves per SIMD) only two
+// 8-wave workgroups fit. Same box: 512 x 2048 at 87 VGPRs 3.47 ms; 640 x 2560 (two 10-wave workgroups = all five waves) with the
+// Round-join elements in a rolled second pass 3.35; forced to 80 VGPRs with 20-84 bytes of scratch 3.95-4.14; and, once the per-step
+// mesh places are parked in LDS in front of the other phase-0 loads (their registers free again before the records arrive), 80 VGPRs
+// WITHOUT scratch, 512 x 2048, six waves: 3.03 against 3.22 -- the shipped shape
 __global__ __launch_bounds__(VGX_TMPL_RC_THREADS, VGX_TMPL_RC_WAVES) void k_tmpl_emit_round_closed(VgxTmplArgs A)
 {
 	tmpl_emit_body<3, VGX_TMPL_RC_THREADS, VGX_TMPL_RC_TILE, 1>(A);
@@ -1562,16 +1568,15 @@ struct OpTmplRoundMeshes
 		const uint64_t M = A.inst.num_meshes;
 		const uint64_t inst = k / M;
 		const uint32_t m = (uint32_t)(k - inst * M);
-		const uint32_t r1 = A.tmesh[m].pad[1];
+		const uint2 ts = A.tmsz[m];
 		*tooLarge = false;
-		if (r1) {
-			const unsigned long long* z = A.rsz + (inst * A.num_round + (r1 - 1u)) * 2;
+		if (ts.x >> 31) {
+			const unsigned long long* z = A.rsz + (inst * A.num_round + (ts.x & 0x7FFFFFFFu)) * 2;
 			const unsigned long long v = z[0], i = z[1];
 			*tooLarge = v > 65536ull; // what OpMeshOffsets reports for such a mesh (16-bit indices)
 			*nv = vgx_sat_nv(v); *ni = vgx_sat_ni(i);
 		} else {
-			const vgx_mesh mr = A.tmtab[m];
-			*nv = mr.num_vertices; *ni = mr.num_indices;
+			*nv = ts.x; *ni = ts.y;
 		}
 	}
 	__device__ Sum3 load(uint64_t k) const

@@ -253,15 +253,15 @@ struct OpTmplRoundIndex
 // Element table in processing order: tiles of `tile` elements of the instance's output-ordered element stream; inside a
 // tile the fill elements first, then the stroke elements (both in output order). Every class starts a tile of its own
 // (tile cls.tile0, table slot cls.tile0 * tile): a tile never holds elements of two classes.
-__global__ __launch_bounds__(256) void k_tmpl_elems(VgxTmplBuild B)
+__global__ __launch_bounds__(256) void k_tmpl_elems(VgxTmplBuild B) // one workgroup per tile
 {
 	const uint64_t M = B.num_meshes;
 	const uint64_t E = B.num_elems;
 	const uint64_t T = B.tile;
-	// owner of output-ordered element x: last mesh with fillPrefix + strokePrefix <= x; returns (mesh, fill elements before x, stroke elements before x)
-	auto locate = [&](uint64_t x, uint64_t* mesh, uint64_t* fBefore, uint64_t* sBefore, uint32_t* j, bool* isFill) {
+	// owner of output-ordered element x among the meshes [lo, hi) (prefix[lo] <= x < prefix[hi]): last mesh with fillPrefix + strokePrefix <= x;
+	// returns (mesh, fill elements before x, stroke elements before x)
+	auto locate = [&](uint64_t x, uint64_t lo, uint64_t hi, uint64_t* mesh, uint64_t* fBefore, uint64_t* sBefore, uint32_t* j, bool* isFill) {
 		if (x >= E) { *mesh = M; *fBefore = B.prefix_fill[M]; *sBefore = B.prefix_stroke[M]; *j = 0; *isFill = false; return; }
-		uint64_t lo = 0, hi = M;
 		while (hi - lo > 1) {
 			const uint64_t mid = (lo + hi) >> 1;
 			if (B.prefix_fill[mid] + B.prefix_stroke[mid] <= x) { lo = mid; } else { hi = mid; }
@@ -274,31 +274,42 @@ __global__ __launch_bounds__(256) void k_tmpl_elems(VgxTmplBuild B)
 		*fBefore = pf + (f ? jj : 0u);
 		*sBefore = psk + (f ? 0u : jj);
 	};
-	for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (uint64_t)gridDim.x * blockDim.x) {
-		uint64_t m, f, s, m0, f0, s0, m1, f1, s1;
-		uint32_t j, j0, j1;
-		bool isFill, d0, d1;
-		locate(e, &m, &f, &s, &j, &isFill);
-		const uint32_t c = tmpl_class_of_draw(B, B.mdesc[m].draw);
+	__shared__ uint64_t s_b[6]; // m0, f0, s0, m1, f1, (unused)
+	for (uint64_t tile = blockIdx.x; tile < B.cls[B.nclasses].tile0; tile += gridDim.x) {
+		uint32_t c = 0;
+		while (c + 1 < B.nclasses && B.cls[c + 1].tile0 <= tile) { ++c; }
 		const VgxTmplClass cl = B.cls[c];
 		const uint64_t cEnd = B.cls[c + 1].elem0;
-		const uint64_t el = e - cl.elem0;              // element inside its class
-		const uint64_t tl = el / T;                    // tile inside its class
-		const uint64_t x0 = cl.elem0 + tl * T;         // the tile's first element (output order of the concatenated template)
+		const uint64_t x0 = cl.elem0 + (tile - cl.tile0) * T; // the tile's first element (output order of the concatenated template)
 		const uint64_t x1 = x0 + T < cEnd ? x0 + T : cEnd;
-		locate(x0, &m0, &f0, &s0, &j0, &d0);
-		locate(x1, &m1, &f1, &s1, &j1, &d1);
-		const uint64_t tile = cl.tile0 + tl;
-		const uint64_t slot = tile * T + (isFill ? f - f0 : (f1 - f0) + (s - s0));
-		VgxTmplElem r;
-		r.mesh = (uint32_t)m;
-		r.jq = j | ((uint32_t)(e - x0) << 16); // j < 65536 (a mesh holds at most 65536 vertices), position in the tile < tile <= 65536
-		const float2 lv = B.poly[B.mdesc[m].poly_first + j];
-		r.lx = lv.x; r.ly = lv.y;
-		B.telem[slot] = r;
-		if (e == x0) { // tile record, first half: the mesh that owns the tile's first element; bit 31: it begins exactly here
-			B.ttile[tile].mesh0 = (uint32_t)m | (j == 0 ? 0x80000000u : 0u);
+		__syncthreads();
+		if (threadIdx.x == 0) { // the tile's bounds, once: where its first element and the element behind its last lie
+			uint64_t m0, f0, s0, m1, f1, s1;
+			uint32_t j0, j1;
+			bool d0, d1;
+			locate(x0, 0, M, &m0, &f0, &s0, &j0, &d0);
+			locate(x1, m0, M, &m1, &f1, &s1, &j1, &d1);
+			s_b[0] = m0; s_b[1] = f0; s_b[2] = s0; s_b[3] = m1; s_b[4] = f1;
+			// tile record, first half: the mesh that owns the tile's first element; bit 31: it begins exactly here
+			B.ttile[tile].mesh0 = (uint32_t)m0 | (j0 == 0 ? 0x80000000u : 0u);
 			B.ttile[tile].nel = (uint32_t)(x1 - x0);
+		}
+		__syncthreads();
+		const uint64_t m0 = s_b[0], f0 = s_b[1], s0 = s_b[2], m1 = s_b[3], f1 = s_b[4];
+		const uint64_t hi = m1 < M ? m1 + 1 : M;
+		for (uint64_t e = x0 + threadIdx.x; e < x1; e += blockDim.x) {
+			uint64_t m, f, s;
+			uint32_t j;
+			bool isFill;
+			locate(e, m0, hi, &m, &f, &s, &j, &isFill);
+			// inside a tile the fill elements first, then the stroke elements (both in output order)
+			const uint64_t slot = tile * T + (isFill ? f - f0 : (f1 - f0) + (s - s0));
+			VgxTmplElem r;
+			r.mesh = (uint32_t)m;
+			r.jq = j | ((uint32_t)(e - x0) << 16); // j < 65536 (a mesh holds at most 65536 vertices), position in the tile < tile <= 65536
+			const float2 lv = B.poly[B.mdesc[m].poly_first + j];
+			r.lx = lv.x; r.ly = lv.y;
+			B.telem[slot] = r;
 		}
 	}
 }
@@ -1650,14 +1661,14 @@ void vgx_launch_tmpl_classes(const VgxTmplBuild& b, hipStream_t s)
 
 void vgx_launch_tmpl_build(const VgxTmplBuild& b, hipStream_t s)
 {
-	const uint64_t gm = (b.num_meshes + 255) / 256, ge = (b.num_elems + 255) / 256;
+	const uint64_t gm = (b.num_meshes + 255) / 256;
 	const uint64_t nt = (b.num_elems + b.tile - 1) / b.tile + b.nclasses; // >= the tile count (every class rounds up on its own)
 	if (b.num_meshes) {
 		hipLaunchKernelGGL(k_tmpl_meshes, dim3((unsigned)(gm > 4096 ? 4096 : gm)), dim3(256), 0, s, b);
 		if (b.has_round) { OpTmplRoundIndex op; op.B = b; vgx_device_scan(op, b.partial, s, b.num_meshes); }
 	}
 	if (b.num_elems) {
-		hipLaunchKernelGGL(k_tmpl_elems, dim3((unsigned)(ge > 4096 ? 4096 : ge)), dim3(256), 0, s, b);
+		hipLaunchKernelGGL(k_tmpl_elems, dim3((unsigned)(nt > 65536 ? 65536 : nt)), dim3(256), 0, s, b); // one workgroup per tile
 		hipLaunchKernelGGL(k_tmpl_tiles, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, b);
 	}
 }

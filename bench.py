@@ -172,7 +172,7 @@ WORKLOADS = {
     "tiger10k_varied": "Tiger x10k at 7 scales (0.5 .. 3.5; 18 distinct avgScale values after rounding) under rotations: template mode with one template per class",
     "tiger10k_open": "Tiger x10k with every sub-path left open (no pathClose): open Miter strokes with Butt caps, template mode's general kernel",
     "tiger10k_bevel": "Tiger x10k with Bevel joins on the strokes: template mode, closed Bevel routine beside the closed Miter one (k_tmpl_emit_bevel; round 4: the general element body)",
-    "tiger10k_round": "Tiger x10k with Round joins on the strokes (arc points counted on every instance's transformed polyline): template mode with per-step sizes (k_tmpl_round_sizes + k_tmpl_emit_round_closed)",
+    "tiger10k_round": "Tiger x10k with Round joins on the strokes (arc points counted on every instance's transformed polyline): template mode with per-step sizes (k_tmpl_round_sizes + k_tmpl_emit_round_aa)",
     "tiger10k_round_ordinary": "the tiger10k_round batch with VGX_TMPL_ROUND=0: the ordinary pipeline (k_flatten_inst + k_fill + k_round_sizes + k_stroke), what Round joins cost before round 5",
     "round10k_static": "BASELINE configs[3]'s batch (10k polylines x 1k segments, Round joins + Round caps) with vgx_set_static_batches: the draw list flattened once by the count, a step = per-step Round-join sizes + the template emit kernel (no flatten, no scans)",
     "tiger10k_culled": "Tiger x10k after culling and reordering (a random 70 % of the draws, shuffled: no period left) with vgx_set_static_batches: the draw list flattened once by the count as ONE template, a step = the emit kernel (element tables from HBM instead of L2)",

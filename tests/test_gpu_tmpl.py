@@ -794,3 +794,38 @@ def test_static_batches_one_frame(rt, wl, oracle, max_vb, split):
     for k in ("pos", "color", "idx", "meshes", "cmds"):
         assert bytes_equal(getattr(asm, k), getattr(old, k)), k
     ctx.close()
+
+
+@pytest.mark.parametrize("seed,ninst,tile", [(8101, 40, None), (8102, 36, "128"), (8103, 33, "64")])
+def test_template_open_and_closed_aa_strokes_with_round_joins_and_any_cap(rt, wl, oracle, monkeypatch, seed, ninst, tile):
+    """Every stroke AA (wider than the fringe) with Round joins, open and closed sub-paths, Butt / Square / Round caps: the template
+    kernel without the general body (tmpl_stroke_elem_round + tmpl_stroke_cap_aa beside the Miter / Bevel routines). == the reference,
+    == the ordinary pipeline byte for byte."""
+    if tile:
+        monkeypatch.setenv("VGX_TMPL_TILE", tile)
+    ps = wl.fuzz_paths(seed, npaths=72, with_shapes=True, degenerate=False)
+    d = wl.template_draws(ps, seed, ninst)
+    n = ps.npaths
+    rs = np.random.RandomState(seed)
+    one = d[:n].copy()
+    for i in range(n):
+        if one["stroke_flags"][i] & 1:
+            wl.set_stroke(one, i, int(rs.randint(0, 1 << 32, dtype=np.uint64)), float(rs.choice([2.5, 3.0, 6.0, 12.0])),
+                          int(rs.choice([rt.capi.CAP_BUTT, rt.capi.CAP_SQUARE, rt.capi.CAP_ROUND])), rt.capi.JOIN_ROUND, aa=True,
+                          avg_scale=float(one["scale"][i]), fringe=float(one["fringe"][i]))
+    for k in ("stroke_flags", "stroke_width", "stroke_color"):
+        d[k] = np.tile(one[k], ninst)
+    ref = oracle.tessellate(ps, d)
+    kinds = np.unique(ref.meshes["subpath_kind"] >> 24) if False else None
+    ctx = rt.Context(0)
+    got = _run(rt, ctx, ps, d)
+    assert got.mode == MODE_TEMPLATE and got.stages == ROUND_STAGES and got.status == 0
+    assert_mesh_equal(got, ref, "round joins, open + closed AA strokes seed=%d" % seed)
+    ctx.close()
+    monkeypatch.setenv("VGX_TMPL_ROUND", "0")
+    ctx = rt.Context(0)
+    old = _run(rt, ctx, ps, d)
+    assert old.mode != MODE_TEMPLATE
+    for k in ("pos", "color", "idx", "meshes"):
+        assert bytes_equal(getattr(got, k), getattr(old, k)), k
+    ctx.close()

@@ -154,7 +154,7 @@ void vgx_launch_tmpl_hash(const vgx_draw* draws, uint64_t ndraws, uint64_t perio
 void vgx_launch_tmpl_check_cls(const vgx_draw* draws, uint64_t ndraws, uint64_t period, const uint32_t* inst_cls, const uint32_t* cls_rep, VgxTotals* totals, hipStream_t s);
 void vgx_launch_tmpl_emit(const VgxTmplArgs& a, hipStream_t s);
 #ifndef VGX_TMPL_RC_THREADS
-#define VGX_TMPL_RC_THREADS 512 /* k_tmpl_emit_round_closed (templates of closed strokes with Round joins): threads per workgroup, */
+#define VGX_TMPL_RC_THREADS 512 /* k_tmpl_emit_round_aa (templates of closed strokes with Round joins): threads per workgroup, */
 #define VGX_TMPL_RC_TILE 2048   /* elements per tile */
 #endif
 #ifndef VGX_TMPL_RC_WAVES

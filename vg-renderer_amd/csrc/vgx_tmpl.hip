@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_tmpl_styles(VgxTmplBuild B)
 		const uint32_t kw = B.mdesc[m].kind;
 		const uint32_t kind = VGX_MD_KIND(kw);
 		if (kind >= VGX_MESH_STROKE && !stroke_elem_is_simple(kind, VGX_MD_CLOSED(kw) != 0, VGX_MD_JOIN(kw))) {
-			f |= tmpl_stroke_is_open_fast(kw) ? 1u : (tmpl_stroke_is_closed_bevel(kw) ? 8u : (tmpl_stroke_is_closed_round_aa(kw) ? 16u : 2u));
+			f |= tmpl_stroke_is_open_fast(kw) ? 1u : (tmpl_stroke_is_closed_bevel(kw) ? 8u : ((VGX_MD_KIND(kw) == VGX_MESH_STROKE_AA && VGX_MD_JOIN(kw) == VGX_JOIN_ROUND) ? 16u : 2u)); // (bit 4: AA strokes with Round joins, closed or open with any cap)
 		}
 		if (tmpl_is_round(kw)) { f |= 4u; }
 	}
@@ -923,9 +923,113 @@ struct TmplRoundPlace // what an element of a Round-join mesh takes from the per
 	uint32_t nv, ni;   // the mesh's vertices / indices (closing bridge)
 	float da;          // the mesh's arc step
 };
-__device__ __forceinline__ void tmpl_stroke_elem_round(const TmplOut& O, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color, float hsw, float hswAA,
+// An OPEN stroke's two caps (stroker.cpp:1419-1515 first, :1856-1968 last; Butt / Square: four vertices; Round: 2 H, H = the half circle's
+// points): the first cap's own triangles open the mesh's index range, the last cap writes the bridge that ends at it like a join does.
+__device__ __forceinline__ void tmpl_stroke_cap_aa(const TmplOut& O, uint32_t cap, bool first, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color, float hsw, float hswAA, float fringe,
+	V2 p1, V2 d, uint32_t H, uint32_t b, uint32_t k, Rails prev)
+{
+	const uint32_t c0 = color & 0x00FFFFFFu;
+	const uint32_t bi = b + ibase;
+	char* pp = O.pos + (vOff + b) * 8u;
+	char* pc = O.col + (vOff + b) * 4u;
+	char* pi = O.idx + (iOff + k) * 2u;
+	const V2 l = v2ccw(d);
+	auto tri = [&](char* at, uint32_t a0, uint32_t a1, uint32_t a2) {
+		Idx3 t; t.a = (a0 & 0xFFFFu) | (a1 << 16); t.b = (uint16_t)a2;
+		VGX_ST_GUARD(t.a) TMPL_IDX_ON *(Idx3*)at = t;
+	};
+	auto bridge = [&](char* at, Rails p, Rails c) { // bridge4 of the writer
+		Idx6 t0; t0.a = (p.a & 0xFFFFu) | (p.b << 16); t0.b = (c.b & 0xFFFFu) | (p.a << 16); t0.c = (c.b & 0xFFFFu) | (c.a << 16);
+		Idx6 t1; t1.a = (p.b & 0xFFFFu) | (p.c << 16); t1.b = (c.c & 0xFFFFu) | (p.b << 16); t1.c = (c.c & 0xFFFFu) | (c.b << 16);
+		Idx6 t2; t2.a = (p.c & 0xFFFFu) | (p.d << 16); t2.b = (c.d & 0xFFFFu) | (p.c << 16); t2.c = (c.d & 0xFFFFu) | (c.c << 16);
+		VGX_ST_GUARD(t0.a ^ t1.c) TMPL_IDX_ON { *(Idx6*)at = t0; *(Idx6*)(at + 12) = t1; *(Idx6*)(at + 24) = t2; }
+	};
+	ColPair cd; cd.c0 = color; cd.c1 = c0;
+	if (cap == VGX_CAP_ROUND) {
+		const float startAngle = vgm_atan2(l.y, l.x);
+		for (uint32_t i = 0; i < H; ++i) {
+			const float t = i * VGM_PI / (float)(H - 1);
+			const float a = first ? startAngle + t : startAngle - t;
+			float sa, ca;
+			vgm_sincos(a, &sa, &ca);
+			PosPair q; q.x0 = p1.x + ca * hsw; q.y0 = p1.y + sa * hsw; q.x1 = p1.x + ca * hswAA; q.y1 = p1.y + sa * hswAA;
+			VGX_ST_GUARD(c0 ^ __float_as_uint(q.x0)) { *(PosPair*)(pp + 16 * i) = q; *(ColPair*)(pc + 8 * i) = cd; }
+		}
+		if (first) { // fan + fringe quads, values relative to the mesh's vertex 0 (= b)
+			for (uint32_t i = 0; i + 2 < H; ++i, pi += 6) { tri(pi, bi, bi + (i << 1) + 2, bi + (i << 1) + 4); }
+			for (uint32_t i = 0; i + 1 < H; ++i, pi += 12) {
+				const uint32_t base = bi + (i << 1);
+				tri(pi, base, base + 1, base + 3);
+				tri(pi + 6, base, base + 3, base + 2);
+			}
+		} else {
+			const uint32_t en = bi + (H - 1) * 2;
+			bridge(pi, prev, rails(bi + 1, bi, en, en + 1));
+			pi += 36;
+			for (uint32_t i = 0; i + 2 < H; ++i, pi += 6) { const uint32_t base = bi + (i << 1); tri(pi, bi, base + 4, base + 2); }
+			for (uint32_t i = 0; i + 1 < H; ++i, pi += 12) {
+				const uint32_t base = bi + (i << 1);
+				tri(pi, base, base + 3, base + 1);
+				tri(pi + 6, base, base + 2, base + 3);
+			}
+		}
+		return;
+	}
+	const V2 lh = v2mul(l, hsw), lhaa = v2mul(l, hswAA);
+	V2 v0, v1, v2_, v3;
+	if (cap == VGX_CAP_BUTT) {
+		const V2 daa = v2mul(d, fringe);
+		v0 = first ? v2add(p1, v2sub(lhaa, daa)) : v2add(p1, v2add(lhaa, daa));
+		v1 = v2add(p1, lh); v2_ = v2sub(p1, lh);
+		v3 = first ? v2sub(p1, v2add(lhaa, daa)) : v2sub(p1, v2sub(lhaa, daa));
+	} else { // Square
+		const V2 dh = v2mul(d, hsw), dhaa = v2mul(d, hswAA);
+		v0 = first ? v2add(p1, v2sub(lhaa, dhaa)) : v2add(p1, v2add(lhaa, dhaa));
+		v1 = first ? v2add(p1, v2sub(lh, dh)) : v2add(p1, v2add(lh, dh));
+		v2_ = first ? v2sub(p1, v2add(lh, dh)) : v2sub(p1, v2sub(lh, dh));
+		v3 = first ? v2sub(p1, v2add(lhaa, dhaa)) : v2sub(p1, v2sub(lhaa, dhaa));
+	}
+	PosPair q; q.x0 = v0.x; q.y0 = v0.y; q.x1 = v1.x; q.y1 = v1.y;
+	PosPair r; r.x0 = v2_.x; r.y0 = v2_.y; r.x1 = v3.x; r.y1 = v3.y;
+	ColPair c; c.c0 = c0; c.c1 = color;
+	VGX_ST_GUARD(c0 ^ __float_as_uint(q.x0) ^ __float_as_uint(r.y1)) {
+	*(PosPair*)pp = q; *(PosPair*)(pp + 16) = r;
+	*(ColPair*)pc = c; *(ColPair*)(pc + 8) = cd;
+	}
+	if (first) {
+		tri(pi, bi, bi + 2, bi + 1);
+		tri(pi + 6, bi, bi + 3, bi + 2);
+	} else {
+		bridge(pi, prev, rails(bi, bi + 1, bi + 2, bi + 3));
+		tri(pi + 36, bi, bi + 1, bi + 2);
+		tri(pi + 42, bi, bi + 2, bi + 3);
+	}
+}
+
+__device__ __forceinline__ void tmpl_stroke_elem_round(const TmplOut& O, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color, float hsw, float hswAA, float fringe,
 	uint32_t j, V2 p1, V2 dPrev, V2 d12, const TmplRoundPlace& rp)
 {
+	const bool closed = VGX_MD_CLOSED(kindWord) != 0;
+	const uint32_t cap = VGX_MD_CAP(kindWord);
+	// open strokes: the caps' sizes (elem_geometry) -- what lies in front of the joins
+	const uint32_t H = (!closed && cap == VGX_CAP_ROUND) ? vgx_half_circle_points(rp.da) : 2u;
+	const uint32_t capNv = cap == VGX_CAP_ROUND ? 2u * H : 4u, capNi = cap == VGX_CAP_ROUND ? 9u * H - 12u : 6u;
+	// first index of the element's range (= of the bridge that ends at it), from its first vertex: 9 indices per arc segment of the joins in front
+	// (2 n + 4 vertices each), one 18-index bridge per element in front but the first
+	const uint32_t kJoin = closed ? (j == 0 ? 0u : 9u * ((rp.b - 4u * j) >> 1) + 18u * (j - 1u))
+	                              : (j == 0 ? 0u : capNi + 9u * ((rp.b - capNv - 4u * (j - 1u)) >> 1) + 18u * (j - 1u));
+	// the previous element's exit rails (elem_exit_rails): a join's from its place, size and inner side; the first cap's are fixed
+	Rails prev;
+	{
+		const uint32_t nvPrev = rp.nvPrev;
+		const uint32_t pb = (j > 0 ? rp.b : rp.nv) - nvPrev + ibase, pe = pb + nvPrev - 2u; // arcID behind its last segment = place + 2 + 2 n
+		prev = rp.prevInner ? rails(pb, pb + 1, pe, pe + 1) : rails(pe + 1, pe, pb + 1, pb);
+		if (!closed && j == 1) { prev = cap == VGX_CAP_ROUND ? rails(ibase + 1, ibase, ibase + (H - 1) * 2, ibase + (H - 1) * 2 + 1) : rails(ibase, ibase + 1, ibase + 2, ibase + 3); }
+	}
+	if (!closed && (j == 0 || j + 1 == N)) {
+		tmpl_stroke_cap_aa(O, cap, j == 0, vOff, iOff, ibase, color, hsw, hswAA, fringe, p1, j == 0 ? d12 : dPrev, H, rp.b, kJoin, prev);
+		return;
+	}
 	const VgxJoin jn = vgx_join_dirs(dPrev, d12, hswAA);
 	const bool L = jn.leftInner;
 	const V2 n01 = L ? v2cw(jn.d01) : v2ccw(jn.d01);
@@ -981,8 +1085,8 @@ __device__ __forceinline__ void tmpl_stroke_elem_round(const TmplOut& O, uint32_
 		*(ColPair*)(pc + 8 + 8 * i) = d;
 		}
 	}
-	const uint32_t k = j == 0 ? 0u : 9u * ((b - 4u * j) >> 1) + 18u * (j - 1u); // first index of the join's range = of the bridge that ends here
-	{ // own triangles: behind the bridge that ends here (join 0 has none in front)
+	const uint32_t k = kJoin;
+	{ // own triangles: behind the bridge that ends here (join 0 of a closed stroke has none in front)
 		char* pio = O.idx + (iOff + k + (j == 0 ? 0u : 18u)) * 2u;
 		uint32_t a = bi + 2u; // arcID
 		for (uint32_t i = 0; i < n; ++i, a += 2u, pio += 18) {
@@ -1001,9 +1105,7 @@ __device__ __forceinline__ void tmpl_stroke_elem_round(const TmplOut& O, uint32_
 	}
 	{ // the bridge that ends at this join (bridge4 of the writer): previous exit rails (elem_exit_rails) -> own entry rails
 		const Rails mine = L ? rails(bi, bi + 1, bi + 2, bi + 3) : rails(bi + 3, bi + 2, bi + 1, bi);
-		const uint32_t nvPrev = rp.nvPrev;                             // 2 n + 4 vertices (:1599)
-		const uint32_t pb = (j > 0 ? b : rp.nv) - nvPrev + ibase, pe = pb + nvPrev - 2u; // arcID behind its last segment = place + 2 + 2 n
-		const Rails p = rp.prevInner ? rails(pb, pb + 1, pe, pe + 1) : rails(pe + 1, pe, pb + 1, pb);
+		const Rails p = prev;
 		char* pi = O.idx + (iOff + (j > 0 ? k : rp.ni - 18u)) * 2u;
 		Idx6 t0; t0.a = (p.a & 0xFFFFu) | (p.b << 16); t0.b = (mine.b & 0xFFFFu) | (p.a << 16); t0.c = (mine.b & 0xFFFFu) | (mine.a << 16);
 		Idx6 t1; t1.a = (p.b & 0xFFFFu) | (p.c << 16); t1.b = (mine.c & 0xFFFFu) | (p.b << 16); t1.c = (mine.c & 0xFFFFu) | (mine.b << 16);
@@ -1027,7 +1129,7 @@ __device__ __forceinline__ void tmpl_stroke_elem_round(const TmplOut& O, uint32_
 #define VGX_TMPL_K3_ROLLED 0 /* 1 (measured: bevel 2.22 -> 2.33 ms, round the same): one copy of the element routines, one element per trip */
 #endif
 #ifndef VGX_TMPL_RC_ROLLED
-#define VGX_TMPL_RC_ROLLED 0 /* k_tmpl_emit_round_closed: 1 = the Round-join elements in a rolled second pass (what the 640-thread shape liked), 0 = inlined into the unrolled one */
+#define VGX_TMPL_RC_ROLLED 0 /* k_tmpl_emit_round_aa: 1 = the Round-join elements in a rolled second pass (what the 640-thread shape liked), 0 = inlined into the unrolled one */
 #endif
 #ifndef VGX_TMPL_BEVEL_FAST
 #define VGX_TMPL_BEVEL_FAST 1 /* 0 (measurement): closed Bevel strokes through the general body */
@@ -1049,7 +1151,7 @@ __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uin
 		if (kind == VGX_MESH_FILL_AA) { dPrev = dir(jp1); }
 		tmpl_fill_elem(O, kindWord, N, vOff, iOff, ibase, color, f0, j, p1, dPrev, d12);
 	} else if (BEVEL && placed) { // (the kernel of closed strokes only: a Round-join mesh there is a closed AA one)
-		tmpl_stroke_elem_round(O, vOff, iOff, ibase, color, f0, f1, j, p1, dir(jp1), d12, rpl);
+		tmpl_stroke_elem_round(O, kindWord, N, vOff, iOff, ibase, color, f0, f1, fringe, j, p1, (j == 0 && VGX_MD_CLOSED(kindWord) == 0) ? d12 : dir(jp1), d12, rpl);
 	} else if (closedBevel) {
 		const V2 dPrev = dir(jp1);
 		const V2 dPrev2 = dir(jp1 > 0 ? jp1 - 1 : N - 1); // cyclic: element 0's previous join is the last one
@@ -1438,7 +1540,7 @@ __global__ __launch_bounds__(VGX_TMPL_G_THREADS, VGX_TMPL_R_MINWAVES) void k_tmp
 // Round-join elements in a rolled second pass 3.35; forced to 80 VGPRs with 20-84 bytes of scratch 3.95-4.14; and, once the per-step
 // mesh places are parked in LDS in front of the other phase-0 loads (their registers free again before the records arrive), 80 VGPRs
 // WITHOUT scratch, 512 x 2048, six waves: 3.03 against 3.22 -- the shipped shape
-__global__ __launch_bounds__(VGX_TMPL_RC_THREADS, VGX_TMPL_RC_WAVES) void k_tmpl_emit_round_closed(VgxTmplArgs A)
+__global__ __launch_bounds__(VGX_TMPL_RC_THREADS, VGX_TMPL_RC_WAVES) void k_tmpl_emit_round_aa(VgxTmplArgs A)
 {
 	tmpl_emit_body<3, VGX_TMPL_RC_THREADS, VGX_TMPL_RC_TILE, 1>(A);
 }
@@ -1682,7 +1784,7 @@ void vgx_launch_tmpl_emit(const VgxTmplArgs& a, hipStream_t s)
 {
 	const uint64_t blocks = a.wg ? a.num_wg : a.ninst * a.tiles_per_inst; // the host checked < 2^31
 	if (!blocks) { return; }
-	if (a.general == 5) { hipLaunchKernelGGL(k_tmpl_emit_round_closed, dim3((unsigned)blocks), dim3(VGX_TMPL_RC_THREADS), 0, s, a); }
+	if (a.general == 5) { hipLaunchKernelGGL(k_tmpl_emit_round_aa, dim3((unsigned)blocks), dim3(VGX_TMPL_RC_THREADS), 0, s, a); }
 	else if (a.general == 4) { hipLaunchKernelGGL(k_tmpl_emit_bevel, dim3((unsigned)blocks), dim3(VGX_TMPL_THREADS), 0, s, a); }
 	else if (a.general == 3) { hipLaunchKernelGGL(k_tmpl_emit_round, dim3((unsigned)blocks), dim3(VGX_TMPL_G_THREADS), 0, s, a); }
 	else if (a.general == 2) { hipLaunchKernelGGL(k_tmpl_emit_general, dim3((unsigned)blocks), dim3(VGX_TMPL_G_THREADS), 0, s, a); }

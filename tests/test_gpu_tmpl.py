@@ -829,3 +829,22 @@ def test_template_open_and_closed_aa_strokes_with_round_joins_and_any_cap(rt, wl
     for k in ("pos", "color", "idx", "meshes"):
         assert bytes_equal(getattr(got, k), getattr(old, k)), k
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", [9001, 9002, 9003, 9004])
+def test_static_batches_fuzz_with_degenerate_paths(rt, wl, oracle, seed):
+    """Static batches over the full fuzz grammar -- degenerate steps inside the epsilon ball, sub-paths closing onto their start point,
+    every shape command, every stroke style (Round joins among them), draws without fill or stroke -- in a shuffled order: the count's
+    flatten takes the exact serial kernel for the degenerate draws, the template holds what it produced."""
+    ps = wl.fuzz_paths(seed, npaths=96, with_shapes=True, degenerate=True)
+    d = wl.template_general_draws(ps, seed, 30, round_joins=True)
+    rs = np.random.RandomState(seed)
+    d = d[rs.permutation(d.shape[0])]
+    d["mtx"] = rs.uniform(-2.5, 2.5, size=d["mtx"].shape).astype(np.float32)
+    ref = oracle.tessellate(ps, d)
+    ctx = rt.Context(0)
+    ctx.set_static_batches(True)
+    got = _run(rt, ctx, ps, d)
+    assert got.mode == MODE_TEMPLATE and got.status == 0
+    assert_mesh_equal(got, ref, "static batch fuzz seed=%d" % seed)
+    ctx.close()

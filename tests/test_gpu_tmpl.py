@@ -571,33 +571,29 @@ def test_template_round_joins_stale_nonfinite_and_meshes_too_large(rt, wl, oracl
     assert ordinary != 0 and got.status == ordinary, (got.status, ordinary)  # VGX_E_MESH_TOO_LARGE on both
 
 
-def test_template_round_joins_with_draw_command_assembly_stay_ordinary(rt, wl, oracle):
-    """Draw-command assembly needs every mesh's size before the emit kernel runs; with Round joins those are per instance. Such batches keep
-    the ordinary pipeline -- also when the assembly is armed AFTER a template was built."""
-    ps = wl.closed_fuzz_paths(6995, npaths=72)
-    d = wl.template_general_draws(ps, 6995, 40, round_joins=True)
-    ref = oracle.tessellate(ps, d)
+@pytest.mark.parametrize("seed,ninst,max_vb,split", [(6995, 40, 65536, False), (6996, 36, 2048, True), (6997, 50, 700, True)])
+def test_template_round_joins_with_draw_command_assembly(rt, wl, oracle, monkeypatch, seed, ninst, max_vb, split):
+    """Round-join templates with draw-command assembly armed: the assembly's partition reads this step's mesh table (k_tmpl_mtab from the
+    per-step places). Vertex / index buffers and draw commands == the ordinary pipeline's (VGX_TMPL_ROUND=0) byte for byte."""
+    ps = wl.closed_fuzz_paths(seed, npaths=72)
+    d = wl.template_general_draws(ps, seed, ninst, round_joins=True)
+    d["state_key"] = (np.arange(d.shape[0]) // 37).astype(d["state_key"].dtype)
     ctx = rt.Context(0)
-    got = _assembled(rt, ctx, ps, d, 65536, False)
-    assert got.mode != MODE_TEMPLATE and got.status == 0
-    assert bytes_equal(got.pos, ref.pos) and bytes_equal(got.color, ref.color)
+    got = _assembled(rt, ctx, ps, d, max_vb, split)
+    assert got.mode == MODE_TEMPLATE
+    assert got.stages[:2] == ["tmpl_round_sizes", "tmpl_mesh_table"], got.stages
     ctx.close()
-    # armed after the count: the asynchronous entry refuses (no scratch was sized for the ordinary pipeline) instead of running the template
-    import torch
+    monkeypatch.setenv("VGX_TMPL_ROUND", "0")
     ctx = rt.Context(0)
-    pset = rt.PathSet(ctx, ps)
-    dd = rt.upload_draws(d)
-    sizes = rt.tessellate_count(ctx, pset, dd, d.shape[0])
-    assert ctx.failure_info()["segment_items"] == MODE_TEMPLATE
-    cmds = torch.zeros(200000 * 48, dtype=torch.uint8, device=dd.device)
-    ncmd = torch.zeros(1, dtype=torch.int64, device=dd.device)
-    ctx.set_assembly(cmds, 65536, ncmd)
-    bufs = rt.MeshBuffers(dd.device, sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"])
-    with pytest.raises(rt.VgxError) as ei:
-        rt.tessellate_async(ctx, pset, dd, d.shape[0], bufs)
-    assert ei.value.status == rt.capi.VGX_E_NOSPACE
-    ctx.set_assembly(None)
-    pset.close()
+    old = _assembled(rt, ctx, ps, d, max_vb, split)
+    assert old.mode != MODE_TEMPLATE
+    assert got.status == old.status, (got.status, old.status)  # (700-vertex buffers: a Round-join mesh of a wide stroke does not fit one -- the same error either way)
+    if old.status != 0:
+        ctx.close()
+        return
+    assert got.stages[-1] == "tmpl_emit" and got.ncmd == old.ncmd
+    for k in ("pos", "color", "idx", "meshes", "cmds"):
+        assert bytes_equal(getattr(got, k), getattr(old, k)), k
     ctx.close()
 
 

@@ -1436,8 +1436,7 @@ static int runTmpl(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 static bool tmplFor(const vgx_ctx* ctx, const vgx_pathset* ps, uint64_t ndraws)
 {
 	return ctx->tmplOn && ctx->optTmpl && ps == ctx->tmplPs && ps->gen == ctx->tmplPsGen && ctx->tmplPeriod && ndraws % ctx->tmplPeriod == 0 && ndraws >= ctx->tmplPeriod
-		&& (ctx->tmplClasses == 1 || ndraws == ctx->tmplNDraws) // several classes: the per-instance table belongs to ONE batch size
-		&& !((ctx->tmplGeneral == 3 || ctx->tmplGeneral == 5) && ctx->asmArmed);           // Round joins + draw-command assembly: the ordinary pipeline (the next count builds no template)
+		&& (ctx->tmplClasses == 1 || ndraws == ctx->tmplNDraws); // several classes: the per-instance table belongs to ONE batch size
 }
 
 // The ordinary count + two-phase flatten in LOCAL space (apply_transform = 0) + mesh sizing of `n` draws: what a template is built
@@ -1554,8 +1553,8 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	{
 		const VgxTotals& ht = *ctx->hostTotals;
 		if (T == 1) {
-			// Round joins (their sizes are the instance's): templates of one class, without draw-command assembly; else the ordinary pipeline
-			if (!tmplEligible(ht, ctx->optTmplRound && !ctx->asmArmed)) { return VGX_OK; }
+			// Round joins (their sizes are the instance's): templates of one class; else the ordinary pipeline
+			if (!tmplEligible(ht, ctx->optTmplRound != 0)) { return VGX_OK; }
 			csz[0] = ht.sizes;
 		} else if (ht.num_round_meshes || ht.sizes.num_poly_vertices >= (1ull << 32) || ht.sizes.num_meshes >= (1ull << 32) || ht.sizes.num_elements >= (1ull << 36)) {
 			return VGX_OK;

@@ -1182,10 +1182,21 @@ __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uin
 __global__ __launch_bounds__(256) void k_tmpl_mtab(VgxTmplArgs A, vgx_mesh* mtab, VgxMeshDesc* mdesc)
 {
 	const uint64_t M = A.inst.num_meshes, total = A.total.num_meshes;
-	if (blockIdx.x == 0 && threadIdx.x == 0) { A.totals->sizes = A.total; }
+	if (blockIdx.x == 0 && threadIdx.x == 0 && !A.mplace) { A.totals->sizes = A.total; } // (Round joins: the scan over the meshes wrote them)
 	for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (uint64_t)gridDim.x * blockDim.x) {
 		uint64_t inst, vb, ib;
 		uint32_t m;
+		if (A.mplace) { // Round joins (one class): places and sizes are this step's (per-step table, batch mesh order = k)
+			inst = k / M;
+			m = (uint32_t)(k - inst * M);
+			const VgxTmplMeshPlace q = A.mplace[k];
+			vgx_mesh r = A.tmtab[m];
+			r.first_vertex = q.v; r.first_index = q.i; r.num_vertices = q.nv; r.num_indices = q.ni;
+			r.draw += (uint32_t)(inst * A.period);
+			mtab[k] = r;
+			mdesc[k].draw = r.draw;
+			continue;
+		}
 		if (A.iinfo) { // several classes: the instance that owns mesh k = the last one whose first mesh is <= k
 			uint64_t lo = 0, hi = A.ninst;
 			while (hi - lo > 1) {

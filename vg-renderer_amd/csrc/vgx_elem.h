@@ -896,6 +896,156 @@ __device__ __forceinline__ void round_mesh_size(MeshCtxT<VS> mc, int lane, uint3
 }
 
 // ------------------------------------------------------------------------------------------------
+// AA strokes with Round joins (strokerPolylineStrokeAA with LineJoin::Round, stroker.cpp:1580-1691; caps :1419-1515, 1856-1968): the
+// element code of elem_geometry + elem_emit cut down to this one style -- own join (inner pair, the arc's first pair, one sincos pair per
+// inner arc point, the arc's last pair; nine indices per arc segment) and the bridge from the previous element's exit rails --, with
+// direct wide stores. Used by the template kernels (vgx_tmpl.hip: tmpl_stroke_elem_round); as a chunk routine of k_stroke it ran no faster than the
+// general one (profiles/experiments/r05_k_stroke_round_aa.patch). pp / pc: the element's first vertex in the position / colour stream, bi: its number as an index VALUE
+// (mesh-relative + the assembly base), prev: the previous element's exit rails as index values.
+// ------------------------------------------------------------------------------------------------
+VGX_EL void raa_bridge(char* at, Rails p, Rails c) // bridge4 of the writer
+{
+	Idx6 t0; t0.a = (p.a & 0xFFFFu) | (p.b << 16); t0.b = (c.b & 0xFFFFu) | (p.a << 16); t0.c = (c.b & 0xFFFFu) | (c.a << 16);
+	Idx6 t1; t1.a = (p.b & 0xFFFFu) | (p.c << 16); t1.b = (c.c & 0xFFFFu) | (p.b << 16); t1.c = (c.c & 0xFFFFu) | (c.b << 16);
+	Idx6 t2; t2.a = (p.c & 0xFFFFu) | (p.d << 16); t2.b = (c.d & 0xFFFFu) | (p.c << 16); t2.c = (c.d & 0xFFFFu) | (c.c << 16);
+	VGX_ST_GUARD(t0.a ^ t1.c) { *(Idx6*)at = t0; *(Idx6*)(at + 12) = t1; *(Idx6*)(at + 24) = t2; }
+}
+VGX_EL void raa_tri(char* at, uint32_t a0, uint32_t a1, uint32_t a2)
+{
+	Idx3 t; t.a = (a0 & 0xFFFFu) | (a1 << 16); t.b = (uint16_t)a2;
+	VGX_ST_GUARD(t.a) { *(Idx3*)at = t; }
+}
+VGX_EL Rails raa_join_entry(uint32_t bi, bool L) { return L ? rails(bi, bi + 1, bi + 2, bi + 3) : rails(bi + 3, bi + 2, bi + 1, bi); }
+VGX_EL Rails raa_join_exit(uint32_t bi, uint32_t n, bool L) { const uint32_t pe = bi + 2u + 2u * n; return L ? rails(bi, bi + 1, pe, pe + 1) : rails(pe + 1, pe, bi + 1, bi); }
+VGX_EL Rails raa_cap_first_exit(uint32_t bi, uint32_t cap, uint32_t H) { return cap == VGX_CAP_ROUND ? rails(bi + 1, bi, bi + (H - 1) * 2, bi + (H - 1) * 2 + 1) : rails(bi, bi + 1, bi + 2, bi + 3); }
+// one join: pown = where its own triangles go, pbridge = where the bridge prev -> entry goes (nullptr: none)
+VGX_EL void raa_join_emit(char* pp, char* pc, char* pown, char* pbridge, uint32_t bi, uint32_t color, float hsw, float hswAA, V2 p1, const VgxJoin& jn, const VgxArc& arc, uint32_t n, Rails prev)
+{
+	const bool L = jn.leftInner;
+	const uint32_t c0 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
+	const V2 n01 = L ? v2cw(jn.d01) : v2ccw(jn.d01);
+	const V2 n12 = L ? v2cw(jn.d12) : v2ccw(jn.d12);
+	const V2 vhaa = v2mul(jn.v, hswAA);
+	const V2 vh = v2mul(jn.v, hsw);
+	const V2 q0 = L ? v2add(p1, vhaa) : v2sub(p1, vhaa);
+	const V2 q1 = L ? v2add(p1, vh) : v2sub(p1, vh);
+	const V2 q2 = v2add(p1, v2mul(n01, hsw));
+	const V2 q3 = v2add(p1, v2mul(n01, hswAA));
+	const V2 qa = v2add(p1, v2mul(n12, hsw));
+	const V2 qb = v2add(p1, v2mul(n12, hswAA));
+	PosPair q; q.x0 = q0.x; q.y0 = q0.y; q.x1 = q1.x; q.y1 = q1.y;
+	PosPair r; r.x0 = q2.x; r.y0 = q2.y; r.x1 = q3.x; r.y1 = q3.y;
+	PosPair u; u.x0 = qa.x; u.y0 = qa.y; u.x1 = qb.x; u.y1 = qb.y;
+	ColPair c; c.c0 = c0; c.c1 = color;
+	ColPair d; d.c0 = color; d.c1 = c0;
+	VGX_ST_GUARD(c0 ^ __float_as_uint(q.x0) ^ __float_as_uint(u.y1)) {
+	*(PosPair*)pp = q;
+	*(PosPair*)(pp + 16) = r;
+	*(PosPair*)(pp + 16 + 16 * n) = u;
+	*(ColPair*)pc = c;
+	*(ColPair*)(pc + 8) = d;
+	*(ColPair*)(pc + 8 + 8 * n) = d;
+	}
+	for (uint32_t i = 1; i < n; ++i) { // the arc's inner points (:1610-1627)
+		const float ang = arc.a01 + i * arc.arcDa;
+		float sa, ca;
+#ifdef VGX_EXP_FAKESIN
+		sa = ang; ca = 1.0f - ang;
+#else
+		vgm_sincos(ang, &sa, &ca);
+#endif
+		const V2 dir = v2(ca, sa);
+		const V2 w0 = v2add(p1, v2mul(dir, hsw)), w1 = v2add(p1, v2mul(dir, hswAA));
+		PosPair t; t.x0 = w0.x; t.y0 = w0.y; t.x1 = w1.x; t.y1 = w1.y;
+		VGX_ST_GUARD(c0 ^ __float_as_uint(t.x0)) {
+		*(PosPair*)(pp + 16 + 16 * i) = t;
+		*(ColPair*)(pc + 8 + 8 * i) = d;
+		}
+	}
+	uint32_t a = bi + 2u; // arcID
+	for (uint32_t i = 0; i < n; ++i, a += 2u, pown += 18) {
+		Idx9 t; // tri3 of the writer
+		if (L) {
+			t.a = ((bi + 1u) & 0xFFFFu) | (a << 16); t.b = ((a + 2u) & 0xFFFFu) | (a << 16);
+			t.c = ((a + 1u) & 0xFFFFu) | ((a + 3u) << 16); t.d = (a & 0xFFFFu) | ((a + 3u) << 16);
+			t.e = (uint16_t)(a + 2u);
+		} else {
+			t.a = ((bi + 1u) & 0xFFFFu) | ((a + 2u) << 16); t.b = (a & 0xFFFFu) | (a << 16);
+			t.c = ((a + 3u) & 0xFFFFu) | ((a + 1u) << 16); t.d = (a & 0xFFFFu) | ((a + 2u) << 16);
+			t.e = (uint16_t)(a + 3u);
+		}
+		VGX_ST_GUARD(t.a ^ t.d) { *(Idx9*)pown = t; }
+	}
+	if (pbridge) { raa_bridge(pbridge, prev, raa_join_entry(bi, L)); }
+}
+// one cap of an open stroke: the first cap's own triangles at pi; the last cap's bridge (prev -> its entry) at pi, its own triangles behind
+VGX_EL void raa_cap_emit(char* pp, char* pc, char* pi, uint32_t cap, bool first, uint32_t bi, uint32_t color, float hsw, float hswAA, float fringe, V2 p1, V2 d, uint32_t H, Rails prev)
+{
+	const uint32_t c0 = color & 0x00FFFFFFu;
+	const V2 l = v2ccw(d);
+	ColPair cd; cd.c0 = color; cd.c1 = c0;
+	if (cap == VGX_CAP_ROUND) {
+		const float startAngle = vgm_atan2(l.y, l.x);
+		for (uint32_t i = 0; i < H; ++i) {
+			const float t = i * VGM_PI / (float)(H - 1);
+			const float a = first ? startAngle + t : startAngle - t;
+			float sa, ca;
+			vgm_sincos(a, &sa, &ca);
+			PosPair q; q.x0 = p1.x + ca * hsw; q.y0 = p1.y + sa * hsw; q.x1 = p1.x + ca * hswAA; q.y1 = p1.y + sa * hswAA;
+			VGX_ST_GUARD(c0 ^ __float_as_uint(q.x0)) { *(PosPair*)(pp + 16 * i) = q; *(ColPair*)(pc + 8 * i) = cd; }
+		}
+		if (first) { // fan + fringe quads
+			for (uint32_t i = 0; i + 2 < H; ++i, pi += 6) { raa_tri(pi, bi, bi + (i << 1) + 2, bi + (i << 1) + 4); }
+			for (uint32_t i = 0; i + 1 < H; ++i, pi += 12) {
+				const uint32_t base = bi + (i << 1);
+				raa_tri(pi, base, base + 1, base + 3);
+				raa_tri(pi + 6, base, base + 3, base + 2);
+			}
+		} else {
+			const uint32_t en = bi + (H - 1) * 2;
+			raa_bridge(pi, prev, rails(bi + 1, bi, en, en + 1));
+			pi += 36;
+			for (uint32_t i = 0; i + 2 < H; ++i, pi += 6) { const uint32_t base = bi + (i << 1); raa_tri(pi, bi, base + 4, base + 2); }
+			for (uint32_t i = 0; i + 1 < H; ++i, pi += 12) {
+				const uint32_t base = bi + (i << 1);
+				raa_tri(pi, base, base + 3, base + 1);
+				raa_tri(pi + 6, base, base + 2, base + 3);
+			}
+		}
+		return;
+	}
+	const V2 lh = v2mul(l, hsw), lhaa = v2mul(l, hswAA);
+	V2 v0, v1, v2_, v3;
+	if (cap == VGX_CAP_BUTT) {
+		const V2 daa = v2mul(d, fringe);
+		v0 = first ? v2add(p1, v2sub(lhaa, daa)) : v2add(p1, v2add(lhaa, daa));
+		v1 = v2add(p1, lh); v2_ = v2sub(p1, lh);
+		v3 = first ? v2sub(p1, v2add(lhaa, daa)) : v2sub(p1, v2sub(lhaa, daa));
+	} else { // Square
+		const V2 dh = v2mul(d, hsw), dhaa = v2mul(d, hswAA);
+		v0 = first ? v2add(p1, v2sub(lhaa, dhaa)) : v2add(p1, v2add(lhaa, dhaa));
+		v1 = first ? v2add(p1, v2sub(lh, dh)) : v2add(p1, v2add(lh, dh));
+		v2_ = first ? v2sub(p1, v2add(lh, dh)) : v2sub(p1, v2sub(lh, dh));
+		v3 = first ? v2sub(p1, v2add(lhaa, dhaa)) : v2sub(p1, v2sub(lhaa, dhaa));
+	}
+	PosPair q; q.x0 = v0.x; q.y0 = v0.y; q.x1 = v1.x; q.y1 = v1.y;
+	PosPair r; r.x0 = v2_.x; r.y0 = v2_.y; r.x1 = v3.x; r.y1 = v3.y;
+	ColPair c; c.c0 = c0; c.c1 = color;
+	VGX_ST_GUARD(c0 ^ __float_as_uint(q.x0) ^ __float_as_uint(r.y1)) {
+	*(PosPair*)pp = q; *(PosPair*)(pp + 16) = r;
+	*(ColPair*)pc = c; *(ColPair*)(pc + 8) = cd;
+	}
+	if (first) {
+		raa_tri(pi, bi, bi + 2, bi + 1);
+		raa_tri(pi + 6, bi, bi + 3, bi + 2);
+	} else {
+		raa_bridge(pi, prev, rails(bi, bi + 1, bi + 2, bi + 3));
+		raa_tri(pi + 36, bi, bi + 1, bi + 2);
+		raa_tri(pi + 42, bi, bi + 2, bi + 3);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
 // Convex fills: strokerConvexFill / strokerConvexFillAA (stroker.cpp:334-365, 713-807), one polygon corner per lane.
 //   FILL_AA element j: vertices 2j (inner, colour c) and 2j+1 (outer, colour c0) and the 9 (last element: 3)
 //   index positions [9j, 9j+9) of the mesh, whose values are closed-form in (N, position).

@@ -923,89 +923,6 @@ struct TmplRoundPlace // what an element of a Round-join mesh takes from the per
 	uint32_t nv, ni;   // the mesh's vertices / indices (closing bridge)
 	float da;          // the mesh's arc step
 };
-// An OPEN stroke's two caps (stroker.cpp:1419-1515 first, :1856-1968 last; Butt / Square: four vertices; Round: 2 H, H = the half circle's
-// points): the first cap's own triangles open the mesh's index range, the last cap writes the bridge that ends at it like a join does.
-__device__ __forceinline__ void tmpl_stroke_cap_aa(const TmplOut& O, uint32_t cap, bool first, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color, float hsw, float hswAA, float fringe,
-	V2 p1, V2 d, uint32_t H, uint32_t b, uint32_t k, Rails prev)
-{
-	const uint32_t c0 = color & 0x00FFFFFFu;
-	const uint32_t bi = b + ibase;
-	char* pp = O.pos + (vOff + b) * 8u;
-	char* pc = O.col + (vOff + b) * 4u;
-	char* pi = O.idx + (iOff + k) * 2u;
-	const V2 l = v2ccw(d);
-	auto tri = [&](char* at, uint32_t a0, uint32_t a1, uint32_t a2) {
-		Idx3 t; t.a = (a0 & 0xFFFFu) | (a1 << 16); t.b = (uint16_t)a2;
-		VGX_ST_GUARD(t.a) TMPL_IDX_ON *(Idx3*)at = t;
-	};
-	auto bridge = [&](char* at, Rails p, Rails c) { // bridge4 of the writer
-		Idx6 t0; t0.a = (p.a & 0xFFFFu) | (p.b << 16); t0.b = (c.b & 0xFFFFu) | (p.a << 16); t0.c = (c.b & 0xFFFFu) | (c.a << 16);
-		Idx6 t1; t1.a = (p.b & 0xFFFFu) | (p.c << 16); t1.b = (c.c & 0xFFFFu) | (p.b << 16); t1.c = (c.c & 0xFFFFu) | (c.b << 16);
-		Idx6 t2; t2.a = (p.c & 0xFFFFu) | (p.d << 16); t2.b = (c.d & 0xFFFFu) | (p.c << 16); t2.c = (c.d & 0xFFFFu) | (c.c << 16);
-		VGX_ST_GUARD(t0.a ^ t1.c) TMPL_IDX_ON { *(Idx6*)at = t0; *(Idx6*)(at + 12) = t1; *(Idx6*)(at + 24) = t2; }
-	};
-	ColPair cd; cd.c0 = color; cd.c1 = c0;
-	if (cap == VGX_CAP_ROUND) {
-		const float startAngle = vgm_atan2(l.y, l.x);
-		for (uint32_t i = 0; i < H; ++i) {
-			const float t = i * VGM_PI / (float)(H - 1);
-			const float a = first ? startAngle + t : startAngle - t;
-			float sa, ca;
-			vgm_sincos(a, &sa, &ca);
-			PosPair q; q.x0 = p1.x + ca * hsw; q.y0 = p1.y + sa * hsw; q.x1 = p1.x + ca * hswAA; q.y1 = p1.y + sa * hswAA;
-			VGX_ST_GUARD(c0 ^ __float_as_uint(q.x0)) { *(PosPair*)(pp + 16 * i) = q; *(ColPair*)(pc + 8 * i) = cd; }
-		}
-		if (first) { // fan + fringe quads, values relative to the mesh's vertex 0 (= b)
-			for (uint32_t i = 0; i + 2 < H; ++i, pi += 6) { tri(pi, bi, bi + (i << 1) + 2, bi + (i << 1) + 4); }
-			for (uint32_t i = 0; i + 1 < H; ++i, pi += 12) {
-				const uint32_t base = bi + (i << 1);
-				tri(pi, base, base + 1, base + 3);
-				tri(pi + 6, base, base + 3, base + 2);
-			}
-		} else {
-			const uint32_t en = bi + (H - 1) * 2;
-			bridge(pi, prev, rails(bi + 1, bi, en, en + 1));
-			pi += 36;
-			for (uint32_t i = 0; i + 2 < H; ++i, pi += 6) { const uint32_t base = bi + (i << 1); tri(pi, bi, base + 4, base + 2); }
-			for (uint32_t i = 0; i + 1 < H; ++i, pi += 12) {
-				const uint32_t base = bi + (i << 1);
-				tri(pi, base, base + 3, base + 1);
-				tri(pi + 6, base, base + 2, base + 3);
-			}
-		}
-		return;
-	}
-	const V2 lh = v2mul(l, hsw), lhaa = v2mul(l, hswAA);
-	V2 v0, v1, v2_, v3;
-	if (cap == VGX_CAP_BUTT) {
-		const V2 daa = v2mul(d, fringe);
-		v0 = first ? v2add(p1, v2sub(lhaa, daa)) : v2add(p1, v2add(lhaa, daa));
-		v1 = v2add(p1, lh); v2_ = v2sub(p1, lh);
-		v3 = first ? v2sub(p1, v2add(lhaa, daa)) : v2sub(p1, v2sub(lhaa, daa));
-	} else { // Square
-		const V2 dh = v2mul(d, hsw), dhaa = v2mul(d, hswAA);
-		v0 = first ? v2add(p1, v2sub(lhaa, dhaa)) : v2add(p1, v2add(lhaa, dhaa));
-		v1 = first ? v2add(p1, v2sub(lh, dh)) : v2add(p1, v2add(lh, dh));
-		v2_ = first ? v2sub(p1, v2add(lh, dh)) : v2sub(p1, v2sub(lh, dh));
-		v3 = first ? v2sub(p1, v2add(lhaa, dhaa)) : v2sub(p1, v2sub(lhaa, dhaa));
-	}
-	PosPair q; q.x0 = v0.x; q.y0 = v0.y; q.x1 = v1.x; q.y1 = v1.y;
-	PosPair r; r.x0 = v2_.x; r.y0 = v2_.y; r.x1 = v3.x; r.y1 = v3.y;
-	ColPair c; c.c0 = c0; c.c1 = color;
-	VGX_ST_GUARD(c0 ^ __float_as_uint(q.x0) ^ __float_as_uint(r.y1)) {
-	*(PosPair*)pp = q; *(PosPair*)(pp + 16) = r;
-	*(ColPair*)pc = c; *(ColPair*)(pc + 8) = cd;
-	}
-	if (first) {
-		tri(pi, bi, bi + 2, bi + 1);
-		tri(pi + 6, bi, bi + 3, bi + 2);
-	} else {
-		bridge(pi, prev, rails(bi, bi + 1, bi + 2, bi + 3));
-		tri(pi + 36, bi, bi + 1, bi + 2);
-		tri(pi + 42, bi, bi + 2, bi + 3);
-	}
-}
-
 __device__ __forceinline__ void tmpl_stroke_elem_round(const TmplOut& O, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color, float hsw, float hswAA, float fringe,
 	uint32_t j, V2 p1, V2 dPrev, V2 d12, const TmplRoundPlace& rp)
 {
@@ -1016,106 +933,34 @@ __device__ __forceinline__ void tmpl_stroke_elem_round(const TmplOut& O, uint32_
 	const uint32_t capNv = cap == VGX_CAP_ROUND ? 2u * H : 4u, capNi = cap == VGX_CAP_ROUND ? 9u * H - 12u : 6u;
 	// first index of the element's range (= of the bridge that ends at it), from its first vertex: 9 indices per arc segment of the joins in front
 	// (2 n + 4 vertices each), one 18-index bridge per element in front but the first
-	const uint32_t kJoin = closed ? (j == 0 ? 0u : 9u * ((rp.b - 4u * j) >> 1) + 18u * (j - 1u))
-	                              : (j == 0 ? 0u : capNi + 9u * ((rp.b - capNv - 4u * (j - 1u)) >> 1) + 18u * (j - 1u));
+	const uint32_t b = rp.b, bi = b + ibase; // index VALUES carry the assembly base, positions in the streams do not
+	const uint32_t k = closed ? (j == 0 ? 0u : 9u * ((b - 4u * j) >> 1) + 18u * (j - 1u))
+	                          : (j == 0 ? 0u : capNi + 9u * ((b - capNv - 4u * (j - 1u)) >> 1) + 18u * (j - 1u));
 	// the previous element's exit rails (elem_exit_rails): a join's from its place, size and inner side; the first cap's are fixed
 	Rails prev;
 	{
 		const uint32_t nvPrev = rp.nvPrev;
-		const uint32_t pb = (j > 0 ? rp.b : rp.nv) - nvPrev + ibase, pe = pb + nvPrev - 2u; // arcID behind its last segment = place + 2 + 2 n
-		prev = rp.prevInner ? rails(pb, pb + 1, pe, pe + 1) : rails(pe + 1, pe, pb + 1, pb);
-		if (!closed && j == 1) { prev = cap == VGX_CAP_ROUND ? rails(ibase + 1, ibase, ibase + (H - 1) * 2, ibase + (H - 1) * 2 + 1) : rails(ibase, ibase + 1, ibase + 2, ibase + 3); }
+		const uint32_t pb = (j > 0 ? b : rp.nv) - nvPrev + ibase;
+		prev = raa_join_exit(pb, (nvPrev - 4u) >> 1, rp.prevInner); // 2 n + 4 vertices (:1599)
+		if (!closed && j == 1) { prev = raa_cap_first_exit(ibase, cap, H); }
 	}
+	char* pp = O.pos + (vOff + b) * 8u;
+	char* pc = O.col + (vOff + b) * 4u;
 	if (!closed && (j == 0 || j + 1 == N)) {
-		tmpl_stroke_cap_aa(O, cap, j == 0, vOff, iOff, ibase, color, hsw, hswAA, fringe, p1, j == 0 ? d12 : dPrev, H, rp.b, kJoin, prev);
+		raa_cap_emit(pp, pc, O.idx + (iOff + k) * 2u, cap, j == 0, bi, color, hsw, hswAA, fringe, p1, j == 0 ? d12 : dPrev, H, prev);
 		return;
 	}
 	const VgxJoin jn = vgx_join_dirs(dPrev, d12, hswAA);
-	const bool L = jn.leftInner;
-	const V2 n01 = L ? v2cw(jn.d01) : v2ccw(jn.d01);
-	const V2 n12 = L ? v2cw(jn.d12) : v2ccw(jn.d12);
-#ifdef VGX_EXP_FAKEARC /* measurement only: no atan2 pair, the arc's point count from the table */
+	const V2 n01 = jn.leftInner ? v2cw(jn.d01) : v2ccw(jn.d01);
+	const V2 n12 = jn.leftInner ? v2cw(jn.d12) : v2ccw(jn.d12);
+#ifdef VGX_EXP_FAKEARC /* measurement only: no atan2 pair */
 	VgxArc arc; arc.a01 = n01.x; arc.arcDa = n12.y * 0.01f; arc.n = 2;
 #else
-	const VgxArc arc = vgx_round_join_arc(n01, n12, L, rp.da);
+	const VgxArc arc = vgx_round_join_arc(n01, n12, jn.leftInner, rp.da);
 #endif
-#ifdef VGX_EXP_FIXEDN /* measurement only */
-	const uint32_t n = 2;
-#else
-	const uint32_t n = arc.n;
-#endif
-	const uint32_t b = rp.b, bi = b + ibase; // index VALUES carry the assembly base, positions in the streams do not
-	const uint32_t c0 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
-	char* pp = O.pos + (vOff + b) * 8u;
-	char* pc = O.col + (vOff + b) * 4u;
-	const V2 vhaa = v2mul(jn.v, hswAA);
-	const V2 vh = v2mul(jn.v, hsw);
-	const V2 q0 = L ? v2add(p1, vhaa) : v2sub(p1, vhaa);
-	const V2 q1 = L ? v2add(p1, vh) : v2sub(p1, vh);
-	const V2 q2 = v2add(p1, v2mul(n01, hsw));
-	const V2 q3 = v2add(p1, v2mul(n01, hswAA));
-	const V2 qa = v2add(p1, v2mul(n12, hsw));
-	const V2 qb = v2add(p1, v2mul(n12, hswAA));
-	PosPair q; q.x0 = q0.x; q.y0 = q0.y; q.x1 = q1.x; q.y1 = q1.y;
-	PosPair r; r.x0 = q2.x; r.y0 = q2.y; r.x1 = q3.x; r.y1 = q3.y;
-	PosPair u; u.x0 = qa.x; u.y0 = qa.y; u.x1 = qb.x; u.y1 = qb.y;
-	ColPair c; c.c0 = c0; c.c1 = color;
-	ColPair d; d.c0 = color; d.c1 = c0;
-	VGX_ST_GUARD(c0 ^ __float_as_uint(q.x0) ^ __float_as_uint(u.y1)) {
-	*(PosPair*)pp = q;
-	*(PosPair*)(pp + 16) = r;
-	*(PosPair*)(pp + 16 + 16 * n) = u;
-	*(ColPair*)pc = c;
-	*(ColPair*)(pc + 8) = d;
-	*(ColPair*)(pc + 8 + 8 * n) = d;
-	}
-	for (uint32_t i = 1; i < n; ++i) { // the arc's inner points (:1610-1627)
-		const float ang = arc.a01 + i * arc.arcDa;
-		float sa, ca;
-#ifdef VGX_EXP_FAKESIN
-		sa = ang; ca = 1.0f - ang;
-#else
-		vgm_sincos(ang, &sa, &ca);
-#endif
-		const V2 dir = v2(ca, sa);
-		const V2 w0 = v2add(p1, v2mul(dir, hsw)), w1 = v2add(p1, v2mul(dir, hswAA));
-		PosPair t; t.x0 = w0.x; t.y0 = w0.y; t.x1 = w1.x; t.y1 = w1.y;
-		VGX_ST_GUARD(c0 ^ __float_as_uint(t.x0)) {
-		*(PosPair*)(pp + 16 + 16 * i) = t;
-		*(ColPair*)(pc + 8 + 8 * i) = d;
-		}
-	}
-	const uint32_t k = kJoin;
-	{ // own triangles: behind the bridge that ends here (join 0 of a closed stroke has none in front)
-		char* pio = O.idx + (iOff + k + (j == 0 ? 0u : 18u)) * 2u;
-		uint32_t a = bi + 2u; // arcID
-		for (uint32_t i = 0; i < n; ++i, a += 2u, pio += 18) {
-			Idx9 t; // tri3 of the writer
-			if (L) {
-				t.a = ((bi + 1u) & 0xFFFFu) | (a << 16); t.b = ((a + 2u) & 0xFFFFu) | (a << 16);
-				t.c = ((a + 1u) & 0xFFFFu) | ((a + 3u) << 16); t.d = (a & 0xFFFFu) | ((a + 3u) << 16);
-				t.e = (uint16_t)(a + 2u);
-			} else {
-				t.a = ((bi + 1u) & 0xFFFFu) | ((a + 2u) << 16); t.b = (a & 0xFFFFu) | (a << 16);
-				t.c = ((a + 3u) & 0xFFFFu) | ((a + 1u) << 16); t.d = (a & 0xFFFFu) | ((a + 2u) << 16);
-				t.e = (uint16_t)(a + 3u);
-			}
-			VGX_ST_GUARD(t.a ^ t.d) TMPL_IDX_ON *(Idx9*)pio = t;
-		}
-	}
-	{ // the bridge that ends at this join (bridge4 of the writer): previous exit rails (elem_exit_rails) -> own entry rails
-		const Rails mine = L ? rails(bi, bi + 1, bi + 2, bi + 3) : rails(bi + 3, bi + 2, bi + 1, bi);
-		const Rails p = prev;
-		char* pi = O.idx + (iOff + (j > 0 ? k : rp.ni - 18u)) * 2u;
-		Idx6 t0; t0.a = (p.a & 0xFFFFu) | (p.b << 16); t0.b = (mine.b & 0xFFFFu) | (p.a << 16); t0.c = (mine.b & 0xFFFFu) | (mine.a << 16);
-		Idx6 t1; t1.a = (p.b & 0xFFFFu) | (p.c << 16); t1.b = (mine.c & 0xFFFFu) | (p.b << 16); t1.c = (mine.c & 0xFFFFu) | (mine.b << 16);
-		Idx6 t2; t2.a = (p.c & 0xFFFFu) | (p.d << 16); t2.b = (mine.d & 0xFFFFu) | (p.c << 16); t2.c = (mine.d & 0xFFFFu) | (mine.c << 16);
-		VGX_ST_GUARD(t0.a ^ t1.c) TMPL_IDX_ON {
-		*(Idx6*)pi = t0;
-		*(Idx6*)(pi + 12) = t1;
-		*(Idx6*)(pi + 24) = t2;
-		}
-	}
+	// own join; the bridge that ENDS at it: in front of its own triangles, or -- join 0 of a closed stroke -- the closing bridge at the end of the mesh's indices
+	char* pbridge = O.idx + (iOff + (j > 0 ? k : rp.ni - 18u)) * 2u;
+	raa_join_emit(pp, pc, O.idx + (iOff + k + (j == 0 ? 0u : 18u)) * 2u, pbridge, bi, color, hsw, hswAA, p1, jn, arc, arc.n, prev);
 }
 
 // One element given its mesh's constants, its transformed vertex, its own edge direction and a way to get the mesh's other

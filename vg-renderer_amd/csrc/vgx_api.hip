@@ -1398,7 +1398,7 @@ static int runTmpl(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 	a.caps.vertices = out->cap_vertices; a.caps.indices = out->cap_indices; a.caps.meshes = out->cap_meshes;
 	if (a.num_wg > 0x7FFFFFFFull) { return VGX_E_RANGE; } // one workgroup per (instance, tile)
 	noteHip(ctx, hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s));
-	if (a.general == 3 || a.general == 5) {
+	if (a.general == 3 || a.general == 5 || a.general == 6) {
 		// Round joins: vertices / indices are the instances' own -- counted on the device, checked against the capacities there
 		a.total.num_vertices = 0; a.total.num_indices = 0;
 		int st;
@@ -1579,11 +1579,11 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	}
 	// (bit 3: closed Bevel strokes -- a kernel of their own beside the closed Miter ones; with open strokes or anything else in the template, the general one)
 	// (bit 4: closed AA strokes with Round joins -- with nothing but closed strokes in the template, kernel 5: no general body)
-	const uint32_t kernelKind = (styles & 4u) ? ((styles & 3u) ? 3u : 5u) : ((styles & 2u) ? 2u : ((styles & 8u) ? ((styles & 1u) ? 2u : 4u) : ((styles & 1u) ? 1u : 0u)));
-	const bool roundTmpl = kernelKind == 3u || kernelKind == 5u;
+	const uint32_t kernelKind = (styles & 4u) ? ((styles & 3u) ? 3u : ((styles & 32u) ? 6u : 5u)) : ((styles & 2u) ? 2u : ((styles & 8u) ? ((styles & 1u) ? 2u : 4u) : ((styles & 1u) ? 1u : 0u)));
+	const bool roundTmpl = kernelKind == 3u || kernelKind == 5u || kernelKind == 6u;
 	if (roundTmpl && T != 1) { return VGX_OK; }
 	uint32_t tileSize = ((kernelKind == 2u || kernelKind == 3u) && ctx->optTmplTile > VGX_TMPL_GENERAL_TILE) ? (uint32_t)VGX_TMPL_GENERAL_TILE : ctx->optTmplTile;
-	if (kernelKind == 5u && ctx->optTmplTile == VGX_TMPL_MAX_TILE) { tileSize = VGX_TMPL_RC_TILE; } // (its own workgroup shape; a VGX_TMPL_TILE override stands)
+	if ((kernelKind == 5u || kernelKind == 6u) && ctx->optTmplTile == VGX_TMPL_MAX_TILE) { tileSize = VGX_TMPL_RC_TILE; } // (its own workgroup shape; a VGX_TMPL_TILE override stands)
 	b.draws = rdraws; b.poly = (const float2*)ctx->poly.p; b.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; b.mprep = (const VgxMeshPrep*)ctx->mprep.p; b.mtab = (const vgx_mesh*)ctx->mtab.p;
 	b.prefix_fill = (const uint64_t*)ctx->elemPrefix.p; b.prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
 	b.num_meshes = M; b.num_elems = E; b.tile = tileSize; b.period = (uint32_t)P; b.nclasses = T;

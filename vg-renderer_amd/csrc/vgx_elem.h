@@ -208,6 +208,7 @@ struct MeshCtxT
 	float hsw, hswAA, fringe;
 	const vgx_draw* dr; // scale / tolerance are only read where Round caps / joins need da
 	VS vtx;             // the mesh's polyline
+	float da = -1.0f;   // the mesh's arc step when the caller has it already (template kernels: once per mesh, with the template); else < 0: mesh_da evaluates it
 };
 typedef MeshCtxT<VtxGlobal> MeshCtx;
 
@@ -223,6 +224,7 @@ VGX_EL V2 ldv(const float* vtx, uint32_t i)
 template<class VS>
 VGX_EL float mesh_da(const MeshCtxT<VS>& m) // stroker.cpp:1013, 1398 (da uses hsw WITHOUT the fringe)
 {
+	if (m.da >= 0.0f) { return m.da; } // (the same function of the same three values, evaluated by whoever filled it in)
 	return vgx_step_angle(m.dr->scale, m.hsw, m.dr->tess_tol);
 }
 

@@ -131,7 +131,7 @@ struct VgxTmplArgs // one step
 	const uint2* wg;             // [num_wg]
 	uint64_t num_wg;
 	vgx_sizes total;             // sizes of the whole batch
-	uint32_t general;            // stroke styles of the template: 0 = closed Miter AA / Thin (k_tmpl_emit), 1 = + open Miter, Butt / Square caps (k_tmpl_emit_open), 2 = any (k_tmpl_emit_general), 3 = + Round joins (k_tmpl_emit_round), 4 = closed Miter + closed Bevel only (k_tmpl_emit_bevel)
+	uint32_t general;            // stroke styles of the template: 0 = closed Miter AA / Thin (k_tmpl_emit), 1 = + open Miter, Butt / Square caps (k_tmpl_emit_open), 2 = any (k_tmpl_emit_general), 3 = + Round joins (k_tmpl_emit_round), 4 = closed Miter + closed Bevel only (k_tmpl_emit_bevel), 5 / 6 = 4 + closed / + open AA strokes with Round joins (k_tmpl_emit_round_aa / _open)
 	// Round joins (templates of ONE class): the arc of every join is counted on the instance's TRANSFORMED polyline (stroker.cpp:1146, 1592), so the
 	// sizes of those meshes -- and with them every output place behind them -- belong to the instance. Per-step tables, written by
 	// vgx_launch_tmpl_round_sizes and read by k_tmpl_emit_round:

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_tmpl_styles(VgxTmplBuild B)
 		const uint32_t kw = B.mdesc[m].kind;
 		const uint32_t kind = VGX_MD_KIND(kw);
 		if (kind >= VGX_MESH_STROKE && !stroke_elem_is_simple(kind, VGX_MD_CLOSED(kw) != 0, VGX_MD_JOIN(kw))) {
-			f |= tmpl_stroke_is_open_fast(kw) ? 1u : (tmpl_stroke_is_closed_bevel(kw) ? 8u : ((VGX_MD_KIND(kw) == VGX_MESH_STROKE_AA && VGX_MD_JOIN(kw) == VGX_JOIN_ROUND) ? 16u : 2u)); // (bit 4: AA strokes with Round joins, closed or open with any cap)
+			f |= tmpl_stroke_is_open_fast(kw) ? 1u : (tmpl_stroke_is_closed_bevel(kw) ? 8u : ((VGX_MD_KIND(kw) == VGX_MESH_STROKE_AA && VGX_MD_JOIN(kw) == VGX_JOIN_ROUND) ? (VGX_MD_CLOSED(kw) ? 16u : 32u) : 2u)); // (bits 4 / 5: closed / open AA strokes with Round joins)
 		}
 		if (tmpl_is_round(kw)) { f |= 4u; }
 	}
@@ -738,9 +738,10 @@ __device__ __forceinline__ void tmpl_stroke_counts(uint32_t kind, uint32_t cap, 
 // it needs comes by value: own vertex, previous vertex, the three edge directions around the element, the mesh's first two
 // vertices (closing bridge).
 __device__ __forceinline__ void tmpl_stroke_general(char* opos, char* ocol, char* oidx, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color,
-	float hsw, float hswAA, float fringe, const vgx_draw* tdraw, uint32_t j, V2 p1, V2 pPrev, V2 d12, V2 dPrev, V2 dPrev2, V2 v0, V2 v1, bool placed, uint32_t bPlaced, uint32_t kPlaced, uint32_t nvPrevPlaced, bool prevInner)
+	float hsw, float hswAA, float fringe, const vgx_draw* tdraw, uint32_t j, V2 p1, V2 pPrev, V2 d12, V2 dPrev, V2 dPrev2, V2 v0, V2 v1, bool placed, uint32_t bPlaced, uint32_t kPlaced, uint32_t nvPrevPlaced, bool prevInner, float daPre)
 {
 	MeshCtxT<TmplVtx01> mc;
+	mc.da = daPre;
 	mc.kind = VGX_MD_KIND(kindWord); mc.closed = VGX_MD_CLOSED(kindWord) != 0; mc.cap = VGX_MD_CAP(kindWord); mc.join = VGX_MD_JOIN(kindWord);
 	mc.N = N; mc.j = j; mc.hsw = hsw; mc.hswAA = hswAA; mc.fringe = fringe; mc.dr = tdraw; mc.vtx.x0 = v0.x; mc.vtx.y0 = v0.y; mc.vtx.x1 = v1.x; mc.vtx.y1 = v1.y;
 	uint32_t H = 2;
@@ -923,10 +924,12 @@ struct TmplRoundPlace // what an element of a Round-join mesh takes from the per
 	uint32_t nv, ni;   // the mesh's vertices / indices (closing bridge)
 	float da;          // the mesh's arc step
 };
+// OPEN: the template holds open strokes of this style (else every one is closed: no cap code, no cap sizes in the kernel)
+template<bool OPEN>
 __device__ __forceinline__ void tmpl_stroke_elem_round(const TmplOut& O, uint32_t kindWord, uint32_t N, uint32_t vOff, uint32_t iOff, uint32_t ibase, uint32_t color, float hsw, float hswAA, float fringe,
 	uint32_t j, V2 p1, V2 dPrev, V2 d12, const TmplRoundPlace& rp)
 {
-	const bool closed = VGX_MD_CLOSED(kindWord) != 0;
+	const bool closed = !OPEN || VGX_MD_CLOSED(kindWord) != 0;
 	const uint32_t cap = VGX_MD_CAP(kindWord);
 	// open strokes: the caps' sizes (elem_geometry) -- what lies in front of the joins
 	const uint32_t H = (!closed && cap == VGX_CAP_ROUND) ? vgx_half_circle_points(rp.da) : 2u;
@@ -969,7 +972,8 @@ __device__ __forceinline__ void tmpl_stroke_elem_round(const TmplOut& O, uint32_
 // pass 1 unrolled and pass 2 as a rolled loop, so that the general element body (~120 VGPRs of branches) is in the kernel once.
 // KIND: what stroke styles the template holds: 0 = closed Miter AA / Thin only (the headline's kernel), 1 = + open Miter strokes with
 // Butt / Square caps (tmpl_stroke_elem_open), 2 = + everything else (the general body; closed Bevel strokes take tmpl_stroke_elem_bevel there too),
-// 3 = closed Miter and closed Bevel strokes only (tmpl_stroke_elem_bevel beside tmpl_stroke_elem: no general body in the kernel).
+// 3 = closed Miter and closed Bevel strokes only (tmpl_stroke_elem_bevel beside tmpl_stroke_elem: no general body in the kernel; with ROUND: + closed
+// AA strokes with Round joins, tmpl_stroke_elem_round), 4 = 3 + OPEN AA strokes with Round joins (their caps).
 #ifndef VGX_TMPL_K3_ROLLED
 #define VGX_TMPL_K3_ROLLED 0 /* 1 (measured: bevel 2.22 -> 2.33 ms, round the same): one copy of the element routines, one element per trip */
 #endif
@@ -986,7 +990,7 @@ __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uin
 	const bool placed = rpl.placed;
 	const uint32_t kind = VGX_MD_KIND(kindWord);
 	const uint32_t jp1 = j > 0 ? j - 1 : N - 1;
-	constexpr bool GENERAL = KIND == 2, OPEN = KIND == 1 || KIND == 2, BEVEL = KIND == 3;
+	constexpr bool GENERAL = KIND == 2, OPEN = KIND == 1 || KIND == 2, BEVEL = KIND == 3 || KIND == 4;
 	const bool openFast = OPEN && kind >= VGX_MESH_STROKE && tmpl_stroke_is_open_fast(kindWord);
 	const bool general = GENERAL && kind >= VGX_MESH_STROKE && !openFast && !stroke_elem_is_simple(kind, VGX_MD_CLOSED(kindWord) != 0, VGX_MD_JOIN(kindWord));
 	if (GENERAL && ((PASS == 1 && general) || (PASS == 2 && !general))) { return; }
@@ -996,7 +1000,7 @@ __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uin
 		if (kind == VGX_MESH_FILL_AA) { dPrev = dir(jp1); }
 		tmpl_fill_elem(O, kindWord, N, vOff, iOff, ibase, color, f0, j, p1, dPrev, d12);
 	} else if (BEVEL && placed) { // (the kernel of closed strokes only: a Round-join mesh there is a closed AA one)
-		tmpl_stroke_elem_round(O, kindWord, N, vOff, iOff, ibase, color, f0, f1, fringe, j, p1, (j == 0 && VGX_MD_CLOSED(kindWord) == 0) ? d12 : dir(jp1), d12, rpl);
+		tmpl_stroke_elem_round<KIND == 4>(O, kindWord, N, vOff, iOff, ibase, color, f0, f1, fringe, j, p1, (KIND == 4 && j == 0 && VGX_MD_CLOSED(kindWord) == 0) ? d12 : dir(jp1), d12, rpl);
 	} else if (closedBevel) {
 		const V2 dPrev = dir(jp1);
 		const V2 dPrev2 = dir(jp1 > 0 ? jp1 - 1 : N - 1); // cyclic: element 0's previous join is the last one
@@ -1007,7 +1011,7 @@ __device__ __forceinline__ void tmpl_elem_emit(const TmplOut& O, uint32_t j, uin
 		V2 pPrev = p1, dPrev2 = dPrev, v0 = p1, v1 = p1;
 		if (j > 0 && !(VGX_TMPL_ROUND_PREV_TABLE && placed)) { pPrev = vtx(jp1); dPrev2 = dir(jp1 > 0 ? jp1 - 1 : N - 1); } // the previous element's geometry: only when a bridge connects to it (Round-join meshes: from the per-step table)
 		if (closed && j + 1 == N) { v0 = vtx(0u); v1 = vtx(N > 1 ? 1u : 0u); }      // join 0's inner side: only the closing bridge asks
-		tmpl_stroke_general(O.pos, O.col, O.idx, kindWord, N, vOff, iOff, ibase, color, f0, f1, fringe, tdraw, j, p1, pPrev, d12, dPrev, dPrev2, v0, v1, placed, rpl.b, rpl.k, rpl.nvPrev, rpl.prevInner);
+		tmpl_stroke_general(O.pos, O.col, O.idx, kindWord, N, vOff, iOff, ibase, color, f0, f1, fringe, tdraw, j, p1, pPrev, d12, dPrev, dPrev2, v0, v1, placed, rpl.b, rpl.k, rpl.nvPrev, rpl.prevInner, placed ? rpl.da : -1.0f);
 	} else if (openFast) {
 		const V2 dPrev = dir(jp1);
 		V2 dPrev2 = dPrev;
@@ -1081,7 +1085,7 @@ template<int KIND, int THREADS, int MAXTILE, int ROUND = 0>
 __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 {
 	constexpr bool GENERAL = KIND == 2;
-	static_assert(ROUND == 0 || GENERAL || KIND == 3, "Round joins take the general element body, or -- closed AA strokes only -- tmpl_stroke_elem_round");
+	static_assert(ROUND == 0 || GENERAL || KIND == 3 || KIND == 4, "Round joins take the general element body, or -- closed AA strokes only -- tmpl_stroke_elem_round");
 	constexpr int CH = MAXTILE / THREADS;
 	__shared__ TmplDraw s_draw[VGX_TMPL_MAXM];
 	__shared__ TmplRec s_rec[VGX_TMPL_MAXM];
@@ -1297,14 +1301,14 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 			};
 			auto vtx = [&](uint32_t jj) { return vtxAt(mesh, rp, q0, jj); };
 			const float fringe = KIND >= 2 ? s_fringe[mesh - mA] : 0.0f;
-			if (ROUND && KIND == 3 && placed) { const float4 rm = s_rmesh[mesh - mA]; rpl.nv = __float_as_uint(rm.x); rpl.ni = __float_as_uint(rm.y); rpl.da = rm.z; }
+			if (ROUND && placed) { const float4 rm = s_rmesh[mesh - mA]; rpl.nv = __float_as_uint(rm.x); rpl.ni = __float_as_uint(rm.y); rpl.da = rm.z; }
 			const vgx_draw* tdraw = P.tdraws;
 			if (GENERAL && decltype(passTag)::value == 2) { tdraw = P.tdraws + (dA + TMPL_REC_DK(rp)); }
 			tmpl_elem_emit<KIND, decltype(passTag)::value>(O, j, rp->kind & 0xFFFFu, N, rp->v_off, rp->i_off, rp->ibase, rp->color, rp->f0, rp->f1, pv, dv, dir, vtx, fringe, tdraw, A.tmesh + mesh,
 				rpl);
 		}
 	};
-	if (KIND == 3 && VGX_TMPL_K3_ROLLED) {
+	if ((KIND == 3 || KIND == 4) && VGX_TMPL_K3_ROLLED) {
 		// the kernels of closed strokes only: ONE copy of the element routines, one element per trip -- 4 x (fill + Miter + Bevel + Round)
 		// inlined is 45-67 KB of code per kernel, against an instruction cache of 64 KB shared by two CUs
 #pragma unroll 1
@@ -1400,6 +1404,12 @@ __global__ __launch_bounds__(VGX_TMPL_RC_THREADS, VGX_TMPL_RC_WAVES) void k_tmpl
 {
 	tmpl_emit_body<3, VGX_TMPL_RC_THREADS, VGX_TMPL_RC_TILE, 1>(A);
 }
+// the same with OPEN strokes of that style among them (Butt / Square / Round caps): the cap code costs the registers of the third workgroup
+// per CU (80 VGPRs would spill): five waves per SIMD
+__global__ __launch_bounds__(VGX_TMPL_RC_THREADS, 5) void k_tmpl_emit_round_aa_open(VgxTmplArgs A)
+{
+	tmpl_emit_body<4, VGX_TMPL_RC_THREADS, VGX_TMPL_RC_TILE, 1>(A);
+}
 
 // Sizes: one wave per (instance, Round-join mesh). Lane = element: its vertex and both neighbours through transformPos2D with the
 // instance's matrix, the two edge directions, elem_geometry -- the very functions on the very inputs k_tmpl_emit_round's phases 1 - 3
@@ -1423,7 +1433,7 @@ __global__ __launch_bounds__(256) void k_tmpl_round_sizes(VgxTmplArgs A)
 	MeshCtxT<TmplVtx01> mc;
 	mc.kind = VGX_MD_KIND(tm.kind); mc.closed = VGX_MD_CLOSED(tm.kind) != 0; mc.cap = VGX_MD_CAP(tm.kind); mc.join = VGX_MD_JOIN(tm.kind);
 	mc.N = N; mc.hsw = tm.f0; mc.hswAA = tm.f1; mc.fringe = 0.0f; // (the fringe: thin strokes only, never a Round-join mesh)
-	mc.dr = A.tdraws + tm.drawk;
+	mc.dr = A.tdraws + tm.drawk; mc.da = tm.l2[0]; // (the arc step: in the mesh record since the template was built)
 	mc.vtx.x0 = 0.0f; mc.vtx.y0 = 0.0f; mc.vtx.x1 = 0.0f; mc.vtx.y1 = 0.0f;
 	uint2* out = A.relem + inst * A.num_round_elems + rm.elem0;
 	unsigned long long runV = 0, runI = 0;
@@ -1481,7 +1491,7 @@ __global__ __launch_bounds__(256) void k_tmpl_round_sizes_block(VgxTmplArgs A)
 	MeshCtxT<TmplVtx01> mc;
 	mc.kind = VGX_MD_KIND(tm.kind); mc.closed = VGX_MD_CLOSED(tm.kind) != 0; mc.cap = VGX_MD_CAP(tm.kind); mc.join = VGX_MD_JOIN(tm.kind);
 	mc.N = N; mc.hsw = tm.f0; mc.hswAA = tm.f1; mc.fringe = 0.0f;
-	mc.dr = A.tdraws + tm.drawk;
+	mc.dr = A.tdraws + tm.drawk; mc.da = tm.l2[0]; // (the arc step: in the mesh record since the template was built)
 	mc.vtx.x0 = 0.0f; mc.vtx.y0 = 0.0f; mc.vtx.x1 = 0.0f; mc.vtx.y1 = 0.0f;
 	uint2* out = A.relem + inst * A.num_round_elems + rm.elem0;
 	if (tid == 0) { s_runV = 0; s_runI = 0; s_lastNv = 0; s_lastIn = 0; }
@@ -1640,7 +1650,8 @@ void vgx_launch_tmpl_emit(const VgxTmplArgs& a, hipStream_t s)
 {
 	const uint64_t blocks = a.wg ? a.num_wg : a.ninst * a.tiles_per_inst; // the host checked < 2^31
 	if (!blocks) { return; }
-	if (a.general == 5) { hipLaunchKernelGGL(k_tmpl_emit_round_aa, dim3((unsigned)blocks), dim3(VGX_TMPL_RC_THREADS), 0, s, a); }
+	if (a.general == 6) { hipLaunchKernelGGL(k_tmpl_emit_round_aa_open, dim3((unsigned)blocks), dim3(VGX_TMPL_RC_THREADS), 0, s, a); }
+	else if (a.general == 5) { hipLaunchKernelGGL(k_tmpl_emit_round_aa, dim3((unsigned)blocks), dim3(VGX_TMPL_RC_THREADS), 0, s, a); }
 	else if (a.general == 4) { hipLaunchKernelGGL(k_tmpl_emit_bevel, dim3((unsigned)blocks), dim3(VGX_TMPL_THREADS), 0, s, a); }
 	else if (a.general == 3) { hipLaunchKernelGGL(k_tmpl_emit_round, dim3((unsigned)blocks), dim3(VGX_TMPL_G_THREADS), 0, s, a); }
 	else if (a.general == 2) { hipLaunchKernelGGL(k_tmpl_emit_general, dim3((unsigned)blocks), dim3(VGX_TMPL_G_THREADS), 0, s, a); }

@@ -1415,27 +1415,25 @@ __global__ __launch_bounds__(VGX_TMPL_RC_THREADS, 5) void k_tmpl_emit_round_aa_o
 // instance's matrix, the two edge directions, elem_geometry -- the very functions on the very inputs k_tmpl_emit_round's phases 1 - 3
 // evaluate (so: the same bits, the arcs counted = the arcs emitted) --, a running prefix over the mesh's elements -> every element's
 // first vertex / index inside its mesh (relem), the mesh's totals (rsz).
-__global__ __launch_bounds__(256) void k_tmpl_round_sizes(VgxTmplArgs A)
+// what a wave needs of one Round-join mesh of one instance
+struct TmplRoundRec // 48 bytes
 {
-	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t R = A.num_round;
-	const uint64_t pairs = A.ninst * (uint64_t)R;
-	const uint64_t g = (uint64_t)blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	if (g >= pairs) { return; }
-	const uint64_t inst = g / R;
-	const uint32_t r = (uint32_t)(g - inst * R);
-	const VgxTmplRoundMesh rm = A.trmesh[r];
-	const VgxTmplMesh tm = A.tmesh[rm.mesh];
-	const TmplDraw dr = tmpl_load_draw(A, A.draws + inst * A.period, A.tdraws, tm.drawk); // (verified: a stale or non-finite record ends the call like in the emit kernel)
-	const TmplXf xf = tmpl_draw_xf(&dr);
-	const float2* vt = A.tpoly + tm.poly_first;
-	const uint32_t N = tm.n;
+	TmplXf xf;                 // the instance's transform of the mesh's draw
+	uint32_t poly_first, n, kind, elem0;
+	float hsw, hswAA, da; uint32_t pad;
+};
+// one mesh: lanes = elements, 64 per trip
+__device__ __forceinline__ void tmpl_round_sizes_mesh(const VgxTmplArgs& A, uint64_t inst, uint32_t r, const TmplRoundRec& rc, uint32_t lane)
+{
+	const TmplXf xf = rc.xf;
+	const float2* vt = A.tpoly + rc.poly_first;
+	const uint32_t N = rc.n;
 	MeshCtxT<TmplVtx01> mc;
-	mc.kind = VGX_MD_KIND(tm.kind); mc.closed = VGX_MD_CLOSED(tm.kind) != 0; mc.cap = VGX_MD_CAP(tm.kind); mc.join = VGX_MD_JOIN(tm.kind);
-	mc.N = N; mc.hsw = tm.f0; mc.hswAA = tm.f1; mc.fringe = 0.0f; // (the fringe: thin strokes only, never a Round-join mesh)
-	mc.dr = A.tdraws + tm.drawk; mc.da = tm.l2[0]; // (the arc step: in the mesh record since the template was built)
+	mc.kind = VGX_MD_KIND(rc.kind); mc.closed = VGX_MD_CLOSED(rc.kind) != 0; mc.cap = VGX_MD_CAP(rc.kind); mc.join = VGX_MD_JOIN(rc.kind);
+	mc.N = N; mc.hsw = rc.hsw; mc.hswAA = rc.hswAA; mc.fringe = 0.0f; // (the fringe: thin strokes only, never a Round-join mesh)
+	mc.dr = A.tdraws; mc.da = rc.da; // (the arc step: in the mesh record since the template was built; dr is not read)
 	mc.vtx.x0 = 0.0f; mc.vtx.y0 = 0.0f; mc.vtx.x1 = 0.0f; mc.vtx.y1 = 0.0f;
-	uint2* out = A.relem + inst * A.num_round_elems + rm.elem0;
+	uint2* out = A.relem + inst * A.num_round_elems + rc.elem0;
 	unsigned long long runV = 0, runI = 0;
 	uint32_t carryNv = 0; bool carryInner = false; // the element in front of the chunk (wave-uniform)
 	for (uint32_t j0 = 0; j0 < N; j0 += 64) {
@@ -1466,9 +1464,51 @@ __global__ __launch_bounds__(256) void k_tmpl_round_sizes(VgxTmplArgs A)
 		carryNv = __shfl(nv, (int)lastLane); carryInner = __shfl((int)inner, (int)lastLane) != 0;
 	}
 	if (lane == 0) {
+		const uint64_t g = inst * A.num_round + r;
 		A.rsz[2 * g] = runV; A.rsz[2 * g + 1] = runI;
 		if (mc.closed) { out[0] = tmpl_round_word(0u, 0u, carryNv, carryInner); } // join 0: the closing bridge starts at the LAST join (which is now known)
 	}
+}
+__device__ __forceinline__ TmplRoundRec tmpl_round_rec(const VgxTmplArgs& A, uint64_t inst, uint32_t r)
+{
+	const VgxTmplRoundMesh rm = A.trmesh[r];
+	const VgxTmplMesh tm = A.tmesh[rm.mesh];
+	const TmplDraw dr = tmpl_load_draw(A, A.draws + inst * A.period, A.tdraws, tm.drawk); // (verified: a stale or non-finite record ends the call like in the emit kernel)
+	TmplRoundRec rc;
+	rc.xf = tmpl_draw_xf(&dr);
+	rc.poly_first = tm.poly_first; rc.n = tm.n; rc.kind = tm.kind; rc.elem0 = rm.elem0;
+	rc.hsw = tm.f0; rc.hswAA = tm.f1; rc.da = tm.l2[0]; rc.pad = 0;
+	return rc;
+}
+// One workgroup per INSTANCE (templates of up to VGX_TMPL_ROUND_MAXR Round-join meshes -- the Tiger has 110): the meshes' records and the
+// instance's transforms are fetched by all threads at once and parked in LDS (one memory round trip for the instance instead of three
+// dependent ones per mesh), then every wave takes every fourth mesh. One wave per mesh (the kernel below) spends its life in those round
+// trips: Tiger x 10k, same box, the whole sizes stage (this + the scan over the meshes) 0.50 -> 0.41 ms.
+#ifndef VGX_TMPL_ROUND_MAXR
+#define VGX_TMPL_ROUND_MAXR 640
+#endif
+__global__ __launch_bounds__(256) void k_tmpl_round_sizes_inst(VgxTmplArgs A)
+{
+	extern __shared__ TmplRoundRec s_rc[]; // [num_round] (dynamic: a template of a hundred such meshes takes 5 KB, not the 30 KB of the limit)
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const uint32_t R = A.num_round;
+	const uint64_t inst = blockIdx.x;
+	for (uint32_t r = threadIdx.x; r < R; r += 256) { s_rc[r] = tmpl_round_rec(A, inst, r); }
+	__syncthreads();
+	for (uint32_t r = wave; r < R; r += 4) { tmpl_round_sizes_mesh(A, inst, r, s_rc[r], lane); }
+}
+// one wave per (instance, mesh), four to a workgroup: templates with more Round-join meshes than the LDS table holds
+__global__ __launch_bounds__(256) void k_tmpl_round_sizes(VgxTmplArgs A)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t R = A.num_round;
+	const uint64_t pairs = A.ninst * (uint64_t)R;
+	const uint64_t g = (uint64_t)blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	if (g >= pairs) { return; }
+	const uint64_t inst = g / R;
+	const uint32_t r = (uint32_t)(g - inst * R);
+	tmpl_round_sizes_mesh(A, inst, r, tmpl_round_rec(A, inst, r), lane);
 }
 
 // The same for templates of LONG Round-join meshes (a polyline of a thousand segments: one wave per mesh leaves the GPU to a few thousand
@@ -1595,6 +1635,7 @@ void vgx_launch_tmpl_round_sizes(const VgxTmplArgs& a, Sum3* partial, hipStream_
 	if (!blocks) { return; }
 	const uint64_t pairs = a.ninst * (uint64_t)a.num_round; // the host checked < 2^31
 	if (a.num_round_elems / a.num_round > 128u) { hipLaunchKernelGGL(k_tmpl_round_sizes_block, dim3((unsigned)pairs), dim3(256), 0, s, a); } // long meshes: a workgroup each
+	else if (a.num_round <= VGX_TMPL_ROUND_MAXR && a.ninst >= 64) { hipLaunchKernelGGL(k_tmpl_round_sizes_inst, dim3((unsigned)a.ninst), dim3(256), a.num_round * sizeof(TmplRoundRec), s, a); } // a workgroup per instance
 	else { hipLaunchKernelGGL(k_tmpl_round_sizes, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, a); }
 	OpTmplRoundMeshes op;
 	op.A = a;

@@ -706,6 +706,10 @@ def test_static_batches_scene_without_a_period(rt, wl, oracle, monkeypatch, seed
     assert_mesh_equal(got, ref, "static batch seed=%d" % seed)
     for k in ("pos", "color", "idx", "meshes"):
         assert bytes_equal(getattr(got, k), getattr(old, k)), k
+    two = _run(rt, ctx, ps, d, two_phase=True)  # vgx_tessellate_count + vgx_tessellate_emit: the same template, the same bytes
+    assert two.mode == MODE_TEMPLATE
+    for k in ("pos", "color", "idx", "meshes"):
+        assert bytes_equal(getattr(two, k), getattr(old, k)), k
     # the camera moves, colours change: the same template
     d2 = d.copy()
     rs = np.random.RandomState(seed + 100)

@@ -120,7 +120,7 @@ struct vgx_ctx
 	uint32_t tmplRound;                  // Round-join stroke meshes per instance (tmplGeneral == 3): their sizes, and every place behind them, are counted per step
 	uint32_t tmplRoundElems;             // their elements per instance
 	DevBuf tmplTrmesh, tmplTmsz;         // template: the Round-join meshes (mesh, first element among the Round-join elements); per mesh its sizes (VgxTmplArgs::tmsz)
-	DevBuf tmplRsz, tmplRelem, tmplMplace; // the per-step tables of such a template (VgxTmplArgs)
+	DevBuf tmplRsz, tmplRelem, tmplMplace, tmplItot, tmplIplace; // the per-step tables of such a template (VgxTmplArgs)
 	hipStream_t sideStream; hipEvent_t forkEv, joinEv; // optConcurrentEmit only
 	VgxCaps caps; // element capacities matching the buffers above
 	uint64_t capDraws;
@@ -765,7 +765,7 @@ int vgx_destroy(vgx_ctx* ctx)
 		return VGX_E_INVALID_ARG;
 	}
 	DeviceGuard guard(ctx);
-	DevBuf* bufs[] = { &ctx->f1SegDraw, &ctx->f1Segs, &ctx->tmplHash, &ctx->tmplInstCls, &ctx->tmplClsRep, &ctx->tmplCls, &ctx->tmplIinfo, &ctx->tmplWg, &ctx->tmplTrmesh, &ctx->tmplTmsz, &ctx->tmplRsz, &ctx->tmplRelem, &ctx->tmplMplace, &ctx->tmplTile, &ctx->tmplPoly, &ctx->tmplMesh, &ctx->tmplMtab, &ctx->tmplElem, &ctx->tmplDraws, &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DevBuf* bufs[] = { &ctx->f1SegDraw, &ctx->f1Segs, &ctx->tmplHash, &ctx->tmplInstCls, &ctx->tmplClsRep, &ctx->tmplCls, &ctx->tmplIinfo, &ctx->tmplWg, &ctx->tmplTrmesh, &ctx->tmplTmsz, &ctx->tmplRsz, &ctx->tmplRelem, &ctx->tmplMplace, &ctx->tmplItot, &ctx->tmplIplace, &ctx->tmplTile, &ctx->tmplPoly, &ctx->tmplMesh, &ctx->tmplMtab, &ctx->tmplElem, &ctx->tmplDraws, &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
@@ -787,7 +787,7 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx)
 	if (!ctx) {
 		return 0;
 	}
-	return ctx->f1SegDraw.cap + ctx->f1Segs.cap + ctx->tmplHash.cap + ctx->tmplInstCls.cap + ctx->tmplClsRep.cap + ctx->tmplCls.cap + ctx->tmplIinfo.cap + ctx->tmplWg.cap + ctx->tmplTrmesh.cap + ctx->tmplTmsz.cap + ctx->tmplRsz.cap + ctx->tmplRelem.cap + ctx->tmplMplace.cap + ctx->tmplTile.cap + ctx->tmplPoly.cap + ctx->tmplMesh.cap + ctx->tmplMtab.cap + ctx->tmplElem.cap + ctx->tmplDraws.cap + ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
+	return ctx->f1SegDraw.cap + ctx->f1Segs.cap + ctx->tmplHash.cap + ctx->tmplInstCls.cap + ctx->tmplClsRep.cap + ctx->tmplCls.cap + ctx->tmplIinfo.cap + ctx->tmplWg.cap + ctx->tmplTrmesh.cap + ctx->tmplTmsz.cap + ctx->tmplRsz.cap + ctx->tmplRelem.cap + ctx->tmplMplace.cap + ctx->tmplItot.cap + ctx->tmplIplace.cap + ctx->tmplTile.cap + ctx->tmplPoly.cap + ctx->tmplMesh.cap + ctx->tmplMtab.cap + ctx->tmplElem.cap + ctx->tmplDraws.cap + ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
 }
 
 // ---- path set ---------------------------------------------------------------------------------------
@@ -1356,6 +1356,11 @@ static int tmplRoundSizes(vgx_ctx* ctx, VgxTmplArgs& a, hipStream_t s)
 	if ((st = ensure(ctx, ctx->partial, VGX_SCAN_BLOCKS * sizeof(Sum3))) != VGX_OK) { return st; }
 	a.rsz = (unsigned long long*)ctx->tmplRsz.p; a.relem = (uint2*)ctx->tmplRelem.p;
 	a.mplace = (VgxTmplMeshPlace*)ctx->tmplMplace.p;
+	if (vgx_tmpl_round_per_instance(a)) {
+		if ((st = ensure(ctx, ctx->tmplItot, (n + 1) * 2 * sizeof(unsigned long long))) != VGX_OK) { return st; }
+		if ((st = ensure(ctx, ctx->tmplIplace, (n + 1) * 2 * sizeof(unsigned long long))) != VGX_OK) { return st; }
+		a.itot = (unsigned long long*)ctx->tmplItot.p; a.iplace = (unsigned long long*)ctx->tmplIplace.p;
+	}
 	vgx_launch_tmpl_round_sizes(a, (Sum3*)ctx->partial.p, s);
 	mark(ctx, s, "tmpl_round_sizes");
 	return VGX_OK;

@@ -141,9 +141,12 @@ struct VgxTmplArgs // one step
 	const uint2* tmsz;           // [meshes of the template] vertices, indices (Round joins: 0x80000000 | number among the Round-join meshes, 0): what the scan over the meshes reads
 	unsigned long long* rsz;     // [ninst * num_round * 2] vertices, indices of every such mesh
 	uint2* relem;                // [ninst * num_round_elems] per element of such a mesh: first vertex / index inside the mesh, size and inner side of the element in front (tmpl_round_word)
-	VgxTmplMeshPlace* mplace;    // [ninst * meshes] per mesh of the batch: first vertex, first index in the BATCH; vertices, indices
+	VgxTmplMeshPlace* mplace;    // [ninst * meshes] per mesh of the batch: first vertex, first index in the BATCH (iplace set: inside its INSTANCE); vertices, indices
+	unsigned long long* itot;    // [ninst * 2] (per-instance shape of the sizes pass only, else null) vertices, indices of the instance
+	unsigned long long* iplace;  // [ninst * 2] ... first vertex, first index of the instance in the batch
 };
 struct Sum3;
+bool vgx_tmpl_round_per_instance(const VgxTmplArgs& a); // the sizes pass places the meshes per instance (many instances of a few hundred meshes): the caller sets a.itot / a.iplace
 void vgx_launch_tmpl_round_sizes(const VgxTmplArgs& a, Sum3* partial, hipStream_t s); // Round-join templates, in front of vgx_launch_tmpl_emit: the tables above, totals->sizes, VGX_E_NOSPACE against a.caps
 void vgx_launch_tmpl_mtab(const VgxTmplArgs& a, vgx_mesh* mtab, VgxMeshDesc* mdesc, hipStream_t s); // assembly armed: the whole batch's mesh table + mesh -> draw
 void vgx_launch_tmpl_check(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, VgxTotals* totals, hipStream_t s); // after vgx_launch_inst_detect

@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(256) void k_tmpl_mtab(VgxTmplArgs A, vgx_mesh* mtab
 			m = (uint32_t)(k - inst * M);
 			const VgxTmplMeshPlace q = A.mplace[k];
 			vgx_mesh r = A.tmtab[m];
-			r.first_vertex = q.v; r.first_index = q.i; r.num_vertices = q.nv; r.num_indices = q.ni;
+			r.first_vertex = q.v + (A.iplace ? A.iplace[2 * inst] : 0ull); r.first_index = q.i + (A.iplace ? A.iplace[2 * inst + 1] : 0ull); r.num_vertices = q.nv; r.num_indices = q.ni;
 			r.draw += (uint32_t)(inst * A.period);
 			mtab[k] = r;
 			mdesc[k].draw = r.draw;
@@ -1108,7 +1108,10 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 		inst32 = blockIdx.x / A.tiles_per_inst;
 		t = blockIdx.x - inst32 * A.tiles_per_inst;
 		P.v = (uint64_t)inst32 * A.inst.num_vertices; P.i = (uint64_t)inst32 * A.inst.num_indices; P.m = (uint64_t)inst32 * A.inst.num_meshes;
-		if (ROUND) { const VgxTmplMeshPlace* mp = A.mplace + (uint64_t)inst32 * A.inst.num_meshes; P.v = mp->v; P.i = mp->i; } // the instance begins where its first mesh does
+		if (ROUND) {
+			if (A.iplace) { P.v = A.iplace[2 * (uint64_t)inst32]; P.i = A.iplace[2 * (uint64_t)inst32 + 1]; } // (mplace: places inside the instance)
+			else { const VgxTmplMeshPlace* mp = A.mplace + (uint64_t)inst32 * A.inst.num_meshes; P.v = mp->v; P.i = mp->i; } // (mplace: places in the batch) the instance begins where its first mesh does
+		}
 	}
 	const uint64_t inst = inst32;
 	const VgxTmplTile tl = A.ttile[t];
@@ -1134,7 +1137,7 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 	const VgxTmplMeshPlace* mplace = ROUND ? A.mplace + (uint64_t)inst32 * A.inst.num_meshes : nullptr;
 	auto minfoOf = [&](uint32_t m) {
 		const VgxTmplMeshPlace q = mplace[m];
-		const unsigned long long dv = q.v - P.v, di = q.i - P.i;
+		const unsigned long long dv = A.iplace ? q.v : q.v - P.v, di = A.iplace ? q.i : q.i - P.i;
 		if ((dv | di) >> 32) { set_status(A.totals, VGX_E_RANGE); }
 		return make_uint4((uint32_t)dv, (uint32_t)di, q.nv, q.ni);
 	};
@@ -1423,7 +1426,7 @@ struct TmplRoundRec // 48 bytes
 	float hsw, hswAA, da; uint32_t pad;
 };
 // one mesh: lanes = elements, 64 per trip
-__device__ __forceinline__ void tmpl_round_sizes_mesh(const VgxTmplArgs& A, uint64_t inst, uint32_t r, const TmplRoundRec& rc, uint32_t lane)
+__device__ __forceinline__ void tmpl_round_sizes_mesh(const VgxTmplArgs& A, uint64_t inst, uint32_t r, const TmplRoundRec& rc, uint32_t lane, unsigned long long* meshV, unsigned long long* meshI)
 {
 	const TmplXf xf = rc.xf;
 	const float2* vt = A.tpoly + rc.poly_first;
@@ -1468,6 +1471,7 @@ __device__ __forceinline__ void tmpl_round_sizes_mesh(const VgxTmplArgs& A, uint
 		A.rsz[2 * g] = runV; A.rsz[2 * g + 1] = runI;
 		if (mc.closed) { out[0] = tmpl_round_word(0u, 0u, carryNv, carryInner); } // join 0: the closing bridge starts at the LAST join (which is now known)
 	}
+	*meshV = runV; *meshI = runI; // (wave-uniform)
 }
 __device__ __forceinline__ TmplRoundRec tmpl_round_rec(const VgxTmplArgs& A, uint64_t inst, uint32_t r)
 {
@@ -1496,7 +1500,53 @@ __global__ __launch_bounds__(256) void k_tmpl_round_sizes_inst(VgxTmplArgs A)
 	const uint64_t inst = blockIdx.x;
 	for (uint32_t r = threadIdx.x; r < R; r += 256) { s_rc[r] = tmpl_round_rec(A, inst, r); }
 	__syncthreads();
-	for (uint32_t r = wave; r < R; r += 4) { tmpl_round_sizes_mesh(A, inst, r, s_rc[r], lane); }
+	for (uint32_t r = wave; r < R; r += 4) {
+		unsigned long long mv, mi;
+		tmpl_round_sizes_mesh(A, inst, r, s_rc[r], lane, &mv, &mi);
+		if (lane == 0) { // the mesh's sizes stay here for the places below (the record's transform is not needed any more)
+			s_rc[r].xf.m0 = __uint_as_float(vgx_sat_nv(mv)); s_rc[r].xf.m1 = __uint_as_float(vgx_sat_ni(mi)); s_rc[r].xf.m2 = __uint_as_float(mv > 65536ull ? 1u : 0u);
+		}
+	}
+	__syncthreads();
+	// every mesh's place INSIDE the instance (the template's sizes for the meshes without Round joins, the counted ones for the others) and the
+	// instance's totals: the scan that follows runs over the instances, not over every mesh of the batch
+	__shared__ unsigned long long s_wv[4], s_wi[4], s_runV, s_runI;
+	__shared__ uint32_t s_big;
+	if (threadIdx.x == 0) { s_runV = 0; s_runI = 0; s_big = 0; }
+	__syncthreads();
+	const uint32_t M = (uint32_t)A.inst.num_meshes;
+	VgxTmplMeshPlace* mp = A.mplace + inst * M;
+	for (uint32_t m0 = 0; m0 < M; m0 += 256) {
+		const uint32_t m = m0 + threadIdx.x;
+		uint32_t nv = 0, ni = 0;
+		if (m < M) {
+			const uint2 ts = A.tmsz[m];
+			if (ts.x >> 31) {
+				const TmplRoundRec* rc = &s_rc[ts.x & 0x7FFFFFFFu];
+				nv = __float_as_uint(rc->xf.m0); ni = __float_as_uint(rc->xf.m1);
+				if (__float_as_uint(rc->xf.m2)) { s_big = 1u; } // what OpMeshOffsets reports for such a mesh (16-bit indices)
+			} else { nv = ts.x; ni = ts.y; }
+		}
+		unsigned long long v = nv, i = ni;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const unsigned long long tv = __shfl_up(v, d), ti = __shfl_up(i, d);
+			if (lane >= (uint32_t)d) { v += tv; i += ti; }
+		}
+		if (lane == 63u) { s_wv[wave] = v; s_wi[wave] = i; }
+		__syncthreads();
+		unsigned long long baseV = s_runV, baseI = s_runI, totV = 0, totI = 0;
+#pragma unroll
+		for (uint32_t w = 0; w < 4; ++w) { if (w < wave) { baseV += s_wv[w]; baseI += s_wi[w]; } totV += s_wv[w]; totI += s_wi[w]; }
+		if (m < M) { VgxTmplMeshPlace q; q.v = baseV + v - nv; q.i = baseI + i - ni; q.nv = nv; q.ni = ni; q.pad[0] = 0; q.pad[1] = 0; mp[m] = q; }
+		__syncthreads();
+		if (threadIdx.x == 0) { s_runV += totV; s_runI += totI; }
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		A.itot[2 * inst] = s_runV; A.itot[2 * inst + 1] = s_runI;
+		if (s_big) { set_status(A.totals, VGX_E_MESH_TOO_LARGE); }
+	}
 }
 // one wave per (instance, mesh), four to a workgroup: templates with more Round-join meshes than the LDS table holds
 __global__ __launch_bounds__(256) void k_tmpl_round_sizes(VgxTmplArgs A)
@@ -1508,7 +1558,8 @@ __global__ __launch_bounds__(256) void k_tmpl_round_sizes(VgxTmplArgs A)
 	if (g >= pairs) { return; }
 	const uint64_t inst = g / R;
 	const uint32_t r = (uint32_t)(g - inst * R);
-	tmpl_round_sizes_mesh(A, inst, r, tmpl_round_rec(A, inst, r), lane);
+	unsigned long long mv, mi;
+	tmpl_round_sizes_mesh(A, inst, r, tmpl_round_rec(A, inst, r), lane, &mv, &mi);
 }
 
 // The same for templates of LONG Round-join meshes (a polyline of a thousand segments: one wave per mesh leaves the GPU to a few thousand
@@ -1627,7 +1678,33 @@ struct OpTmplRoundMeshes
 	}
 };
 
+// (k_tmpl_round_sizes_inst placed the meshes inside their instances:) the instances' places in the batch, the batch totals, the capacities
+struct OpTmplRoundInst
+{
+	VgxTmplArgs A;
+	__device__ uint64_t size() const { return A.ninst; }
+	__device__ Sum3 load(uint64_t k) const { Sum3 r = sum3_zero(); r.a = A.itot[2 * k]; r.b = A.itot[2 * k + 1]; return r; }
+	__device__ void store(uint64_t k, Sum3 e) const { A.iplace[2 * k] = e.a; A.iplace[2 * k + 1] = e.b; }
+	__device__ void finish(Sum3 tot) const
+	{
+		vgx_sizes z = A.total;
+		z.num_vertices = tot.a; z.num_indices = tot.b;
+		A.totals->sizes = z;
+		const uint32_t aux = (tot.a > A.caps.vertices ? 1u : 0u) | (tot.b > A.caps.indices ? 2u : 0u) | ((A.meshes_out && z.num_meshes > A.caps.meshes) ? 4u : 0u);
+		if (aux && A.totals->status == VGX_OK) {
+			A.totals->status = VGX_E_NOSPACE;
+			A.totals->fail_reason = VGX_FAIL_OUT_CAPACITY;
+			A.totals->fail_aux = aux;
+		}
+	}
+};
+
 } // namespace
+
+bool vgx_tmpl_round_per_instance(const VgxTmplArgs& a) // which shape vgx_launch_tmpl_round_sizes takes: the host sets a.iplace / a.itot for this one
+{
+	return a.num_round != 0 && a.num_round_elems / a.num_round <= 128u && a.num_round <= VGX_TMPL_ROUND_MAXR && a.ninst >= 64;
+}
 
 void vgx_launch_tmpl_round_sizes(const VgxTmplArgs& a, Sum3* partial, hipStream_t s)
 {
@@ -1635,8 +1712,13 @@ void vgx_launch_tmpl_round_sizes(const VgxTmplArgs& a, Sum3* partial, hipStream_
 	if (!blocks) { return; }
 	const uint64_t pairs = a.ninst * (uint64_t)a.num_round; // the host checked < 2^31
 	if (a.num_round_elems / a.num_round > 128u) { hipLaunchKernelGGL(k_tmpl_round_sizes_block, dim3((unsigned)pairs), dim3(256), 0, s, a); } // long meshes: a workgroup each
-	else if (a.num_round <= VGX_TMPL_ROUND_MAXR && a.ninst >= 64) { hipLaunchKernelGGL(k_tmpl_round_sizes_inst, dim3((unsigned)a.ninst), dim3(256), a.num_round * sizeof(TmplRoundRec), s, a); } // a workgroup per instance
-	else { hipLaunchKernelGGL(k_tmpl_round_sizes, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, a); }
+	else if (vgx_tmpl_round_per_instance(a)) { // a workgroup per instance: sizes, the meshes' places inside the instance; then the scan over the instances
+		hipLaunchKernelGGL(k_tmpl_round_sizes_inst, dim3((unsigned)a.ninst), dim3(256), a.num_round * sizeof(TmplRoundRec), s, a);
+		OpTmplRoundInst opi;
+		opi.A = a;
+		vgx_device_scan(opi, partial, s, a.ninst);
+		return;
+	} else { hipLaunchKernelGGL(k_tmpl_round_sizes, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, a); }
 	OpTmplRoundMeshes op;
 	op.A = a;
 	vgx_device_scan(op, partial, s, a.ninst * a.inst.num_meshes);

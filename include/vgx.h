@@ -286,8 +286,7 @@ int vgx_tessellate_emit(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* dra
  * capacities are checked on the device; `dev_sizes` (DEVICE vgx_sizes, may be NULL) receives the
  * totals and `dev_status` (DEVICE uint32, may be NULL) receives VGX_OK / VGX_E_NOSPACE / ... .
  * Template mode: when the last vgx_tessellate_count found that the draws repeat their first P draws (>= 32 times, > 2048 draws)
- * in everything but mtx, fill_color, stroke_color and state_key, and no mesh of that period has Round joins (their point counts
- * depend on the transformed geometry), it flattened the period ONCE in local space (the reference flattens before it transforms,
+ * in everything but mtx, fill_color, stroke_color and state_key, it flattened the period ONCE in local space (the reference flattens before it transforms,
  * vg.cpp:4957-4975) and vgx_tessellate on this path set with any whole number of periods is one kernel: per instance the
  * template's vertices through the instance's transform, the stroker's per-element arithmetic, stores. Every call re-checks all
  * draw records against the counted period on the device; a draw that differs in another field ends the call with
@@ -295,7 +294,11 @@ int vgx_tessellate_emit(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* dra
  * The period may also come in a FEW flavours ("classes", at most 64: the same drawing at a handful of scales, say): every
  * instance then equals one class representative in the fields above, each class gets its own template, instances of different
  * classes have different sizes. Such a template belongs to the counted batch: vgx_tessellate takes it for the same number of
- * draws, with every instance still of the class it had at the count (else VGX_E_STALE). VGX_TMPL_CLASSES=0 turns this off. */
+ * draws, with every instance still of the class it had at the count (else VGX_E_STALE). VGX_TMPL_CLASSES=0 turns this off.
+ * Round joins (round 5): their arc points are counted on the TRANSFORMED polyline (stroker.cpp:1146, 1592), so a template batch with Round
+ * joins has no fixed size -- every call counts them for the transforms it is given (two small kernels in front of the emit), dev_sizes holds
+ * THIS call's totals, and a call whose output outgrows the caller's buffers ends with VGX_E_NOSPACE in dev_status (the need in dev_sizes,
+ * nothing written) although the counted batch fitted. Templates of one class only; VGX_TMPL_ROUND=0 keeps such batches on the ordinary path. */
 int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, const vgx_mesh_out* out, vgx_sizes* dev_sizes, uint32_t* dev_status, void* stream);
 
 /* ---- stroker level: polylines in, meshes out ----------------------------------------------------- */

@@ -848,3 +848,34 @@ def test_static_batches_fuzz_with_degenerate_paths(rt, wl, oracle, seed):
     assert got.mode == MODE_TEMPLATE and got.status == 0
     assert_mesh_equal(got, ref, "static batch fuzz seed=%d" % seed)
     ctx.close()
+
+
+def test_static_batches_beyond_the_size_limit_keep_the_ordinary_pipeline(rt, wl):
+    """One template instance addresses its streams with 32-bit offsets (2^29 vertices, 2^31 indices / elements): a static batch beyond that
+    is not made a template -- the ordinary pipeline runs, same call sequence, same bytes as without the promise."""
+    import torch
+    ps, ops = wl.tiger_spec_paths()
+    d = wl.tiger_draws(ops, 4200)
+    rs = np.random.RandomState(5)
+    d = d[rs.uniform(size=d.shape[0]) < 0.7]
+    d = d[rs.permutation(d.shape[0])]
+    outs = []
+    for static in (True, False):
+        ctx = rt.Context(0)
+        ctx.set_static_batches(static)
+        pset = rt.PathSet(ctx, ps)
+        dd = rt.upload_draws(d)
+        sizes = rt.tessellate_count(ctx, pset, dd, d.shape[0])
+        assert sizes["num_vertices"] > (1 << 29)
+        assert ctx.failure_info()["segment_items"] != MODE_TEMPLATE
+        bufs = rt.MeshBuffers(dd.device, sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"])
+        rt.tessellate_async(ctx, pset, dd, d.shape[0], bufs)
+        torch.cuda.synchronize()
+        assert int(bufs.dev_status.item()) == 0
+        outs.append((sizes, bufs))
+        pset.close()
+        ctx.close()
+    (sa, a), (sb, b) = outs
+    assert sa == sb
+    nv, ni = sa["num_vertices"], sa["num_indices"]
+    assert torch.equal(a.pos[:nv].view(torch.int32), b.pos[:nv].view(torch.int32)) and torch.equal(a.color[:nv], b.color[:nv]) and torch.equal(a.idx[:ni], b.idx[:ni])

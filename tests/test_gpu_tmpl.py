@@ -420,7 +420,8 @@ def test_template_general_strokes(rt, wl, oracle, monkeypatch, seed, ninst, tile
 
 
 # ---- Round joins: sizes that belong to the instance --------------------------------------------------------------------------------
-@pytest.mark.parametrize("seed,ninst,tile,closed_only", [(995, 40, None, False), (1995, 36, "128", False), (2995, 48, "960", True), (3995, 33, "64", False), (4995, 64, "2048", True)])
+@pytest.mark.parametrize("seed,ninst,tile,closed_only", [(995, 40, None, False), (1995, 36, "128", False), (2995, 48, "960", True), (3995, 33, "64", False), (4995, 64, "2048", True),
+                                                         (5995, 80, None, False), (5996, 130, "192", True)])  # (>= 64 instances: the sizes pass places the meshes per instance)
 def test_template_round_joins(rt, wl, oracle, monkeypatch, seed, ninst, tile, closed_only):
     """Round joins count their arc points on the TRANSFORMED polyline (stroker.cpp:1146, 1592): mesh sizes -- and every output place
     behind such a mesh -- differ from instance to instance. Template mode counts them per step (k_tmpl_round_sizes: the emit kernel's
@@ -571,7 +572,7 @@ def test_template_round_joins_stale_nonfinite_and_meshes_too_large(rt, wl, oracl
     assert ordinary != 0 and got.status == ordinary, (got.status, ordinary)  # VGX_E_MESH_TOO_LARGE on both
 
 
-@pytest.mark.parametrize("seed,ninst,max_vb,split", [(6995, 40, 65536, False), (6996, 36, 2048, True), (6997, 50, 700, True)])
+@pytest.mark.parametrize("seed,ninst,max_vb,split", [(6995, 40, 65536, False), (6996, 36, 2048, True), (6997, 50, 700, True), (6998, 70, 65536, True), (6999, 96, 3000, False)])
 def test_template_round_joins_with_draw_command_assembly(rt, wl, oracle, monkeypatch, seed, ninst, max_vb, split):
     """Round-join templates with draw-command assembly armed: the assembly's partition reads this step's mesh table (k_tmpl_mtab from the
     per-step places). Vertex / index buffers and draw commands == the ordinary pipeline's (VGX_TMPL_ROUND=0) byte for byte."""

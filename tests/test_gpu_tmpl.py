@@ -447,12 +447,13 @@ def test_template_round_joins(rt, wl, oracle, monkeypatch, seed, ninst, tile, cl
     ctx.close()
 
 
-def test_template_round_joins_sizes_follow_the_transforms(rt, wl, oracle):
+@pytest.mark.parametrize("ninst", [40, 70])  # (70: the per-instance shape of the sizes pass -- its own capacity check)
+def test_template_round_joins_sizes_follow_the_transforms(rt, wl, oracle, ninst):
     """The steady-state call of a Round-join template with OTHER transforms than the count saw: other arcs, other sizes -- counted on the
     device for this very batch (dev_sizes), checked against the caller's capacities there (VGX_E_NOSPACE with the need; nothing written
     past the buffers), and equal to the reference's when they fit."""
     ps = wl.closed_fuzz_paths(5995, npaths=72)
-    d = wl.template_general_draws(ps, 5995, 40, round_joins=True)
+    d = wl.template_general_draws(ps, 5995, ninst, round_joins=True)
     d2 = d.copy()
     d2["mtx"][:, :4] *= np.float32(0.37)  # smaller on screen: the same step angle spans the same arc... but rounding differs; and
     d2["mtx"][:, 1] += np.float32(0.21)   # a shear changes the angles between the segments themselves

@@ -571,6 +571,13 @@ def test_template_round_joins_stale_nonfinite_and_meshes_too_large(rt, wl, oracl
     pset.close()
     ctx.close()
     assert ordinary != 0 and got.status == ordinary, (got.status, ordinary)  # VGX_E_MESH_TOO_LARGE on both
+    # the same through the other shape of the sizes pass (ONE scan over all meshes: a static batch of 80 draws)
+    monkeypatch.delenv("VGX_TMPL_ROUND")
+    ctx = rt.Context(0)
+    ctx.set_static_batches(True)
+    got2 = _run(rt, ctx, ps2, d[:80], d_steady=d5[-80:], shrink=1.0)
+    assert got2.mode == MODE_TEMPLATE and got2.status == ordinary, (got2.mode, got2.status, ordinary)
+    ctx.close()
 
 
 @pytest.mark.parametrize("seed,ninst,max_vb,split", [(6995, 40, 65536, False), (6996, 36, 2048, True), (6997, 50, 700, True), (6998, 70, 65536, True), (6999, 96, 3000, False)])

@@ -565,7 +565,7 @@ void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps,
 	a.pos = nullptr; a.color = nullptr; a.idx = nullptr; a.meshes_out = nullptr; a.mesh_base = nullptr;
 	a.totals = (VgxTotals*)ctx->totals.p; a.caps = outCaps;
 	if (!prepDone) { vgx_launch_mesh_prepare(a, s); }
-	vgx_launch_stroke(false, a, 4096, s); // k_round_sizes: Round-join mesh sizes (exits immediately without Round joins)
+	vgx_launch_stroke(false, a, 32768, s); // k_round_sizes: Round-join mesh sizes (exits immediately without Round joins); one wave per mesh: 10 000 long polylines want more than 4 096 waves
 	mark(ctx, s, "mesh_prepare");
 	OpMeshAll op;
 	op.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; op.mtab = (vgx_mesh*)ctx->mtab.p;

@@ -879,6 +879,7 @@ __device__ __forceinline__ void round_mesh_size(MeshCtxT<VS> mc, int lane, uint3
 {
 	const uint32_t N = mc.N;
 	uint64_t nv = 0, ni = 0;
+	mc.da = mesh_da(mc); // once per mesh, not once per element (an acos and two draw-record loads each)
 	for (uint32_t j = lane; j < N; j += VGX_WAVE) {
 		mc.j = j;
 		const V2 p1 = mc.vtx.ld(j);

@@ -411,6 +411,12 @@ __device__ __forceinline__ void stroke_range(const VgxStrokeArgs& A, StrokeRec* 
 				r.hsw = pr.f0; r.hswAA = pr.f1; r.fringe = pr.f2; r.color = pr.color;
 				r.firstV = mr.first_vertex; r.firstI = mr.first_index;
 				if (A.mesh_base) { r.ibase = A.mesh_base[widx]; }
+				// Round joins / caps: the mesh's arc step (stroker.cpp:1013, 1398) once per mesh here, not once per element in elem_geometry
+				if (!ONLY_SIMPLE && VGX_MD_KIND(md.kind) != VGX_MESH_STROKE_AA_THIN && (VGX_MD_JOIN(md.kind) == VGX_JOIN_ROUND || (!VGX_MD_CLOSED(md.kind) && VGX_MD_CAP(md.kind) == VGX_CAP_ROUND))) {
+					const vgx_draw* dr = A.draws + md.draw;
+					r.pad1 = __float_as_uint(vgx_step_angle(dr->scale, pr.f0, dr->tess_tol));
+					r.pad2 = 1u;
+				}
 			}
 			__syncthreads(); // lanes may still be reading the previous window
 			s_win[lane] = r;
@@ -443,6 +449,7 @@ __device__ __forceinline__ void stroke_range(const VgxStrokeArgs& A, StrokeRec* 
 				r.hsw = pr.f0; r.hswAA = pr.f1; r.fringe = pr.f2; r.color = pr.color;
 				r.firstV = A.mtab[mi].first_vertex; r.firstI = A.mtab[mi].first_index;
 				r.ibase = A.mesh_base ? A.mesh_base[mi] : 0u;
+				r.pad1 = 0; r.pad2 = 0;
 			}
 			mc.kind = VGX_MD_KIND(r.kind);
 			mc.closed = VGX_MD_CLOSED(r.kind) != 0;
@@ -457,6 +464,7 @@ __device__ __forceinline__ void stroke_range(const VgxStrokeArgs& A, StrokeRec* 
 #endif
 			mc.hsw = r.hsw; mc.hswAA = r.hswAA; mc.fringe = r.fringe;
 			mc.dr = A.draws + r.draw;
+			if (r.pad2) { mc.da = __uint_as_float(r.pad1); } // (else < 0: evaluated where it is needed)
 			color = r.color;
 			firstV = r.firstV; firstI = r.firstI; idxBase = r.ibase;
 		}

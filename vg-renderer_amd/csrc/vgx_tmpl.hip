@@ -5,8 +5,8 @@
 // then applies the state transform to the finished polyline (transformPath -> vgutil::batchTransformPositions,
 // src/vg.cpp:4957-4975, src/vg_util.cpp:266-272) before the stroker sees it. Instances whose draw records agree in
 // everything the flattener and the stroker's SIZES depend on -- path, fill / stroke flags, stroke width, scale,
-// tolerance, fringe -- therefore share one local polyline, one set of sub-paths and one set of mesh sizes (no Round
-// joins: their point count depends on the transformed geometry, stroker.cpp:1146, 1592), bit for bit. What differs per
+// tolerance, fringe -- therefore share one local polyline, one set of sub-paths and -- Round joins apart, whose point count
+// depends on the transformed geometry (stroker.cpp:1146, 1592): see the end of this comment -- one set of mesh sizes, bit for bit. What differs per
 // instance is transformPos2D of every polyline vertex (vg_util.h:24-28) and everything the stroker derives from the
 // transformed vertices (directions, extrusion vectors, inner side of every join, fill orientation).
 //
@@ -26,6 +26,12 @@
 // DESIGN.md section 9 measured at 2.4 TB/s when two kernels wrote them milliseconds apart).
 // Results are identical to the ordinary path's by construction and by test (tests/test_gpu_tmpl.py: VGX_TMPL=0 vs 1
 // byte for byte, both against the reference).
+// Round 5: (1) Round joins. The sizes of such meshes -- and every output place behind them -- belong to the instance: a step first counts
+// them (k_tmpl_round_sizes*: the emit kernel's own functions on the same inputs, a per-element table of places), places meshes and instances
+// by scans (capacities checked on the device) and emits with those places: k_tmpl_emit_round_aa[_open] (AA strokes with Round joins beside
+// closed Miter / Bevel ones: tmpl_stroke_elem_round) or k_tmpl_emit_round (the general body). (2) Closed Bevel strokes have a routine and,
+// when the template holds nothing else, a kernel of their own (tmpl_stroke_elem_bevel, k_tmpl_emit_bevel). (3) Static batches
+// (vgx_set_static_batches): a draw list WITHOUT a period is a template of ONE instance -- the same kernels, the tables in HBM instead of L2.
 #include <stddef.h>
 #include <type_traits>
 #include "vgx_internal.h"

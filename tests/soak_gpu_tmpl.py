@@ -57,7 +57,9 @@ for seed in range(base, base + n):
         assert (int(z[3]), int(z[4])) == (nv, ni), ("sizes", int(z[3]), int(z[4]), nv, ni)
         assert_mesh_equal(g, ref, "tmpl soak %d" % seed)
     except AssertionError as e:
-        bad += 1; print("MISMATCH seed", seed, npaths, ninst, "static" if static else "periodic", "mode", mode, str(e)[:200])
+        bad += 1; print("MISMATCH seed", seed, npaths, ninst, "static" if static else "periodic", "mode", mode, str(e)[:200], flush=True)
     pset.close()
+    if (seed - base) % 100 == 99:  # (a run cut short by `timeout` still says how far it got)
+        print("... seeds", seed - base + 1, "mismatches", bad, flush=True)
 print("seeds", n, "mismatches", bad, "count modes", modes)
 sys.exit(1 if bad else 0)

@@ -1692,7 +1692,7 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 		tmplArgs(ctx, ps, draws, ndraws, a);
 		a.caps.vertices = ~0ull; a.caps.indices = ~0ull; a.caps.meshes = ~0ull;
 		a.total.num_vertices = 0; a.total.num_indices = 0;
-		if (a.num_wg > 0x7FFFFFFFull) { return VGX_OK; }
+		if (a.num_wg > 0x7FFFFFFFull || a.ninst * (uint64_t)roundWord >= (1ull << 31)) { return VGX_OK; } // beyond the sizes kernels' grids: the ordinary pipeline
 		noteHip(ctx, hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s));
 		if ((st = tmplRoundSizes(ctx, a, s)) != VGX_OK) { return st; }
 		if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }

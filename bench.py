@@ -481,9 +481,9 @@ def run_config(rt, torch, ctx, local_rank, name, ps, draws, kind, steps, warmup,
     else:
         sizes.setdefault("num_fill_elements", 0)
         sizes.setdefault("num_elements", 0)
-    mode = ctx.failure_info()["segment_items"] if kind != "flatten" else 0  # which flatten kernel the library chose (0 command-parallel, 1 / 2 / 3 instanced)
+    mode = ctx.failure_info()["segment_items"] if kind != "flatten" else 0  # which flatten kernel the library chose (0 command-parallel, 1 / 2 / 3 / 4 instanced, 5 template, 6 command-parallel with the static layout of lineTo-only path sets)
     res["flatten_mode"] = mode
-    ab = algorithmic_bytes(cmd_bytes, ndraws, sizes, fill_verts, fill_idx, fill_meshes, instanced=mode not in (0, 5), template=mode == 5)
+    ab = algorithmic_bytes(cmd_bytes, ndraws, sizes, fill_verts, fill_idx, fill_meshes, instanced=mode not in (0, 5, 6), template=mode == 5)
     if kind == "flatten":
         ab["pipeline"] = ab["flatten_emit"]
         if "two_phase_ms_per_step" in res:

@@ -547,7 +547,9 @@ typedef struct vgx_failure_info {
 	uint32_t segment_items; /* (historic name) flatten kernel the last vgx_tessellate_count chose for batches like its own:
 	                         * 0 = k_flatten_build (one lane per path command), 1 = k_flatten_inst, periodic draws, 2 = k_flatten_inst, draws
 	                         * sorted by path, 3 = k_flatten_inst, draws sorted by (path, tolerance class) -- instances of different scales,
-	                         * 4 = k_flatten_inst, periodic draws with the INSTANCES sorted by tolerance class */
+	                         * 4 = k_flatten_inst, periodic draws with the INSTANCES sorted by tolerance class, 5 = template mode (no flatten
+	                         * per call), 6 = k_flatten_thin: like 0 for a path set of moveTo / lineTo / close paths only, whose polyline
+	                         * layout was decided when the set was created */
 	uint64_t segment;       /* work item (segment / task) that failed first */
 	uint64_t prof[16];      /* -DVGX_INST_PROFILE builds of libvgx only (else 0): wave clock ticks (100 MHz) summed over all waves
 	                         * per phase of k_flatten_inst (profiles/inst_phases.py) */

@@ -532,3 +532,56 @@ def wl_without(d, flag):
     e = d.copy()
     e["fill_flags"] &= ~flag
     return e
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,npaths,degenerate", [(0, 2600, False), (1, 2600, True), (2, 5000, True), (3, 150, False), (4, 150, True), (5, 40, True)])
+def test_async_thin_path_sets_static_layout(rt, wl, oracle, seed, npaths, degenerate, monkeypatch):
+    """Path sets of moveTo / lineTo / close paths only take k_flatten_thin in vgx_tessellate (vgx_thin.h: the polyline layout of
+    such a path is decided when the set is created, the kernel is gather - transform - scatter): sub-paths of one and two
+    vertices, polygons closing onto their first point (the popped vertex), runs longer than a chunk, draws of degenerate paths
+    through the exact builder -- every path drawn once (no instancing), large-batch and frame-sized launch sequences, against
+    the oracle; and the same batch through k_flatten_build (VGX_THIN_STATIC=0) for the other side of the switch."""
+    ps = wl.thin_fuzz_paths(seed, npaths=npaths, degenerate=degenerate)
+    d = wl.fuzz_draws(ps, seed)
+    d = d[np.random.RandomState(seed).permutation(d.shape[0])]
+    ref = oracle.tessellate(ps, d)
+    for static in ("1", "0"):
+        monkeypatch.setenv("VGX_THIN_STATIC", static)
+        ctx = rt.Context(0)
+        got = _async_result(rt, ctx, ps, d)
+        assert got.status == 0
+        assert got.sizes["num_vertices"] == ref.sizes["num_vertices"]
+        assert_mesh_equal(got, ref, "thin set seed=%d static=%s" % (seed, static))
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_async_thin_path_set_steady_state_other_draws(rt, gpu_ctx, wl, oracle):
+    """k_flatten_thin in the steady state: counted with one draw list, called with another order, other transforms and other
+    fill / stroke switches (the draw's mesh counts come from the path's table and the draw's flags)."""
+    import torch
+    ps = wl.thin_fuzz_paths(11, npaths=3000, degenerate=True)
+    d = wl.fuzz_draws(ps, 11)
+    d2 = wl.fuzz_draws(ps, 12)[::-1].copy()
+    ref = oracle.tessellate(ps, d2)
+    pset = rt.PathSet(gpu_ctx, ps)
+    dd = rt.upload_draws(d); dd2 = rt.upload_draws(d2)
+    rt.tessellate_count(gpu_ctx, pset, dd, d.shape[0])
+    assert gpu_ctx.failure_info()["segment_items"] == 6  # k_flatten_thin builds batches like this one
+    nv, ni, nm = ref.sizes["num_vertices"], ref.sizes["num_indices"], ref.sizes["num_meshes"]
+    bufs = rt.MeshBuffers(dd.device, nv + 64, ni + 64, nm + 4)
+    rt.tessellate_async(gpu_ctx, pset, dd2, d2.shape[0], bufs)
+    torch.cuda.synchronize()
+    assert int(bufs.dev_status.item()) == 0
+
+    class G:
+        pass
+    got = G()
+    got.sizes = ref.sizes
+    got.pos = bufs.pos[:nv].cpu().numpy()
+    got.color = bufs.color[:nv].cpu().numpy().view(np.uint32)
+    got.idx = bufs.idx[:ni].cpu().numpy().view(np.uint16)
+    got.meshes = bufs.meshes[:nm * 32].cpu().numpy().view(rt.capi.mesh_dtype)
+    assert_mesh_equal(got, ref, "thin set, steady state with other draws")
+    pset.close()

@@ -136,3 +136,75 @@ def test_closed_form_mesh_sizes_match_oracle(hostlib, vgr, wl, oracle, seed):
         assert (nv.value, ni.value) == (int(m["num_vertices"]), int(m["num_indices"])), (seed, dr, kind, sp)
         checked += 1
     assert checked > 50
+
+
+@pytest.mark.parametrize("seed,degenerate", [(0, False), (1, False), (2, True), (3, True), (4, False), (5, True), (6, False), (7, True)])
+def test_thin_static_layout_matches_oracle(hostlib, vgr, wl, oracle, seed, degenerate):
+    """vgx_thin.h: the static polyline layout of moveTo / lineTo / close paths (tables built with the path set) and
+    k_flatten_thin's lane function, run on the host over every command instance of a batch: vertices, sub-path records and
+    per-draw counts against the oracle; draws of degenerate paths (a lineTo onto the current point) must be listed for the
+    exact builder, and only those."""
+    capi = vgr.capi
+    ps = wl.thin_fuzz_paths(seed, npaths=96, degenerate=degenerate)
+    d = wl.fuzz_draws(ps, seed, ndraws=160)
+    desc = ps.desc()
+    ref = oracle.flatten(ps, d, apply_transform=True)
+    pcb = ps.path_cmd_begin
+    ncmd = int(sum(int(pcb[p + 1] - pcb[p]) for p in d["path"]))
+    nsub_static = [int(sum(1 for c in range(int(pcb[p]), int(pcb[p + 1])) if ps.cmd_type[c] == capi.CMD_MOVE_TO)) for p in range(ps.npaths)]
+    poly = np.full((ncmd + 8, 2), 7777.0, dtype=np.float32)
+    rec = np.zeros(sum(nsub_static[int(p)] for p in d["path"]) + 4, dtype=SUBREC)
+    dinfo = np.zeros(d.shape[0], dtype=ref.draw_info.dtype)
+    serial = np.zeros(d.shape[0], dtype=np.uint8)
+    hostlib.vgxt_thin_flatten.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = hostlib.vgxt_thin_flatten(C.addressof(desc), d.ctypes.data, d.shape[0], poly.ctypes.data, rec.ctypes.data, dinfo.ctypes.data, serial.ctypes.data)
+    assert rc == 1
+    # which paths hold a zero-length lineTo (the epsilon test of pathLineTo on the command's start point)
+    args = ps.args.reshape(-1, 2) if ps.args.size else np.zeros((0, 2), np.float32)
+    degen_path = np.zeros(ps.npaths, dtype=bool)
+    for p in range(ps.npaths):
+        for c in range(int(pcb[p]) + 1, int(pcb[p + 1])):
+            if ps.cmd_type[c] == capi.CMD_LINE_TO:
+                a = ps.args[ps.cmd_arg_off[c]:ps.cmd_arg_off[c] + 2]
+                b = ps.args[ps.cmd_arg_off[c - 1]:ps.cmd_arg_off[c - 1] + 2]
+                dx, dy = np.float32(b[0] - a[0]), np.float32(b[1] - a[1])
+                if np.float32(np.float32(dx * dx) + np.float32(dy * dy)) < np.float32(1e-5):
+                    degen_path[p] = True
+    if degenerate:
+        assert degen_path.any()
+    cmd_prefix, sub_prefix, checked = 0, 0, 0
+    for i in range(d.shape[0]):
+        p = int(d["path"][i])
+        nc = int(pcb[p + 1] - pcb[p])
+        assert bool(serial[i]) == bool(degen_path[p]), (seed, i)
+        if not serial[i]:
+            n = int(ref.draw_info["num_poly_vertices"][i]); ns = int(ref.draw_info["num_subpaths"][i]); s0 = int(ref.draw_info["first_subpath"][i])
+            assert (int(dinfo["num_poly_vertices"][i]), int(dinfo["num_subpaths"][i]), int(dinfo["flags"][i]) & 1) == (n, ns, 0), (seed, i)
+            assert int(dinfo["first_poly_vertex"][i]) == cmd_prefix and ns == nsub_static[p]
+            subs = ref.subpaths[s0:s0 + ns]
+            nfill = int((subs["num_vertices"] >= 3).sum()) if (int(d["fill_flags"][i]) & 1) else 0
+            nstroke = int((subs["num_vertices"] >= 2).sum()) if (int(d["stroke_flags"][i]) & 1) else 0
+            assert (int(dinfo["num_meshes"][i]), int(dinfo["flags"][i]) >> 1) == (nfill + nstroke, nfill), (seed, i)
+            for j in range(ns):
+                sub = subs[j]
+                r = rec[sub_prefix + j]
+                cntv = int(r["info"]) & 0x7FFFFFFF
+                assert cntv == int(sub["num_vertices"]) and (int(r["info"]) >> 31) == int(sub["flags"] & 1) and int(r["pad"]) == 0, (seed, i, j)
+                f = int(r["first"]); a = int(sub["first_vertex"])
+                assert cmd_prefix <= f and f + cntv <= cmd_prefix + nc
+                assert np.array_equal(poly[f:f + cntv].view(np.uint32), ref.poly[a:a + cntv].view(np.uint32)), (seed, i, j)
+                checked += cntv
+        else:
+            assert (int(dinfo["num_poly_vertices"][i]), int(dinfo["num_meshes"][i]), int(dinfo["flags"][i])) == (0, 0, 1)
+        cmd_prefix += nc
+        sub_prefix += nsub_static[p]
+    assert checked > 1000 and poly[ncmd, 0] == 7777.0
+
+
+def test_thin_static_layout_needs_a_thin_set(hostlib, vgr, wl):
+    """A set with one curve in it is not eligible: the tables are not built (k_flatten_build keeps the set)."""
+    ps = wl.fuzz_paths(3, npaths=16, with_shapes=False)
+    d = wl.fuzz_draws(ps, 3)
+    desc = ps.desc()
+    hostlib.vgxt_thin_flatten.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert hostlib.vgxt_thin_flatten(C.addressof(desc), d.ctypes.data, d.shape[0], None, None, None, None) == 0

@@ -12,6 +12,7 @@
 #include "vgx_pathsim.h"
 #include "vgx_inst.h"
 #include "vgx_flat1.h"
+#include "vgx_thin.h"
 #include <vector>
 #include <atomic>
 #include <unordered_map>
@@ -47,6 +48,7 @@ struct vgx_pathset
 	uint32_t maxCmdsPerPath;
 	bool hasSerial; // some path takes the exact serial builder (ARC / ARC_TO / closed shapes)
 	bool hasEmpty;  // some path has no commands
+	bool thinStatic; // every path is MOVE_TO / LINE_TO / CLOSE only and the static layout tables are filled (vgx_thin.h): k_flatten_thin builds its batches
 	uint64_t gen; // unique per vgx_pathset_create (process-wide counter): identifies the path set where an address could be reused
 };
 
@@ -78,6 +80,7 @@ struct vgx_ctx
 	struct VgxRccl* rccl;                // RCCL entry points, bound at the first vgx_gather* call
 	// options, read from the environment ONCE at vgx_create (tuning / testing knobs)
 	int optTwoPass, optBuildWaves, optPoolWalk, optNoSmall, optConcurrentEmit;
+	int optThinStatic;                   // VGX_THIN_STATIC=0: lineTo-only path sets through k_flatten_build like any other (default: k_flatten_thin, vgx_thin.h)
 	int optInst, optInstWaves; uint32_t optInstBlock; // instanced flatten kernel (vgx_inst.hip): on / grid / lane block
 	int optInstPerm;                                  // periodic batches of different scales: permute instances (1, default) or sort draws by (path, class) (0)
 	uint32_t optInstClasses;                          // grouped mode: tolerance classes per path when the instances differ in scale (VGX_INST_CLASSES)
@@ -146,7 +149,6 @@ static void vgx_rccl_release(vgx_ctx* ctx);
 
 namespace {
 
-const int kArgCount[VGX_CMD_COUNT_] = { 2, 2, 6, 4, 0, 5, 6, 4, 5, 8, 3, 4, -1 };
 
 #define HIPCHK(ctx, call)                                 \
 	do {                                                  \
@@ -418,6 +420,7 @@ VgxFlattenArgs flattenArgs(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* 
 	a.sub_rec = (VgxSubRec*)ctx->subFirst.p;
 	a.build_mode = 0;
 	a.pool_walk = ctx->optPoolWalk;
+	a.thin_static = (ps->thinStatic && ctx->optThinStatic) ? 1 : 0;
 	a.leaf_overflow = (float*)ctx->leafOverflow.p;
 	a.serial_list = (uint32_t*)ctx->serialList.p;
 	a.inst_period = 0; a.inst_block = ctx->optInstBlock; a.inst_waves = ctx->optInstWaves; a.inst_perm = nullptr;
@@ -754,6 +757,8 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	if (const char* e = getenv("VGX_F1_SEG")) { const int v = atoi(e); if (v >= 2 && v <= 64) { ctx->optF1Seg = v; } }
 	if (const char* e = getenv("VGX_F1_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { ctx->optF1Waves = v; } }
 	if (const char* e = getenv("VGX_F1_CAP")) { ctx->optF1Cap = atoi(e); }
+	ctx->optThinStatic = 1;
+	if (const char* e = getenv("VGX_THIN_STATIC")) { ctx->optThinStatic = atoi(e) != 0; }
 	if (const char* e = getenv("VGX_BUILD_WAVES")) { const int v = atoi(e); if (v >= 1 && v < VGX_BUILD_WAVES) { ctx->optBuildWaves = v; } }
 	*out_ctx = ctx;
 	return VGX_OK;
@@ -795,88 +800,7 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx)
 // per-command structure the kernels use (sub-path heads / tails, serial-path flag).
 } // extern "C"
 
-static int vgx_pathset_validate_host(const vgx_pathset_desc* d, std::vector<uint8_t>* cmdFlags, std::vector<uint32_t>* spStart, std::vector<uint8_t>* pathFlags, uint32_t* maxCmds)
-{
-	if (!d || !d->path_cmd_begin || (d->ncmd && (!d->cmd_type || !d->cmd_arg_off)) || !d->cmd_arg_off) {
-		return VGX_E_INVALID_ARG;
-	}
-	if (d->path_cmd_begin[0] != 0 || d->path_cmd_begin[d->npaths] != d->ncmd || d->cmd_arg_off[0] != 0) {
-		return VGX_E_INVALID_ARG;
-	}
-	if (d->ncmd >= 0x7FFFFFFFu) { // bit 31 of a command index carries a flag in the draw window
-		return VGX_E_INVALID_ARG;
-	}
-	cmdFlags->assign(d->ncmd, 0);
-	spStart->assign(d->ncmd, 0);
-	pathFlags->assign(d->npaths ? d->npaths : 1, 0);
-	*maxCmds = 0;
-	const uint32_t nargs = d->cmd_arg_off[d->ncmd];
-	if (nargs && !d->args) {
-		return VGX_E_INVALID_ARG;
-	}
-	for (uint32_t i = 0; i < nargs; ++i) {
-		if (!isfinite(d->args[i])) {
-			return VGX_E_NONFINITE;
-		}
-	}
-	for (uint32_t p = 0; p < d->npaths; ++p) {
-		const uint32_t c0 = d->path_cmd_begin[p], c1 = d->path_cmd_begin[p + 1];
-		if (c1 < c0 || c1 > d->ncmd) {
-			return VGX_E_INVALID_ARG;
-		}
-		if (c1 - c0 > *maxCmds) { *maxCmds = c1 - c0; }
-		bool open = false; // a sub-path is open and may take more vertices
-		uint32_t head = c0;
-		for (uint32_t c = c0; c < c1; ++c) {
-			const uint32_t t = d->cmd_type[c];
-			if (t >= VGX_CMD_COUNT_) {
-				return VGX_E_INVALID_ARG;
-			}
-			if (d->cmd_arg_off[c + 1] < d->cmd_arg_off[c]) {
-				return VGX_E_INVALID_ARG;
-			}
-			const uint32_t na = d->cmd_arg_off[c + 1] - d->cmd_arg_off[c];
-			if (t == VGX_CMD_POLYLINE) {
-				if (na < 2 || (na & 1)) { return VGX_E_INVALID_ARG; }
-			} else if ((int)na != kArgCount[t]) {
-				return VGX_E_INVALID_ARG;
-			}
-			const bool isShape = t >= VGX_CMD_RECT && t <= VGX_CMD_ELLIPSE;
-			bool starts = false;
-			if (t == VGX_CMD_MOVE_TO || isShape) {
-				starts = true;
-			} else if (t == VGX_CMD_ARC) {
-				// pathArc wraps its angles with `while (a > 2pi) a -= 2pi` loops (path.cpp:637-652): beyond ~1e8 the
-				// subtraction no longer changes a float and the reference spins forever; keep them where the loops
-				// are short (the same loops run on the device, bit for bit)
-				const float* aa = d->args + d->cmd_arg_off[c];
-				if (fabsf(aa[3]) > 1.0e5f || fabsf(aa[4]) > 1.0e5f) { return VGX_E_INVALID_ARG; }
-				starts = !open; // pathArc: moveTo when there is no open sub-path, else lineTo (path.cpp:663-667)
-				if (!open && c != c0) {
-					// a leading arc is only well defined at the very start of a path or after MOVE_TO-less state;
-					// after CLOSE / a closed shape the reference would append to a closed sub-path
-					return VGX_E_INVALID_PATH;
-				}
-			} else if (!open) {
-				return VGX_E_INVALID_PATH; // LINE_TO/CUBIC_TO/... need an open sub-path (path.cpp:82,88)
-			}
-			if (starts) { head = c; }
-			(*spStart)[c] = head;
-			if (starts) { (*cmdFlags)[c] |= VGX_CF_STARTS_SUB; }
-			if (t == VGX_CMD_ARC || t == VGX_CMD_ARC_TO || isShape) { (*pathFlags)[p] |= VGX_PF_SERIAL; }
-			open = !(t == VGX_CMD_CLOSE || isShape);
-		}
-		for (uint32_t c = c0; c < c1; ++c) {
-			const bool last = (c + 1 == c1);
-			if (last) { (*cmdFlags)[c] |= VGX_CF_LAST_IN_PATH | VGX_CF_LAST_IN_SUB; }
-			else {
-				if ((*cmdFlags)[c + 1] & VGX_CF_STARTS_SUB) { (*cmdFlags)[c] |= VGX_CF_LAST_IN_SUB; }
-				if (d->cmd_type[c + 1] == VGX_CMD_CLOSE) { (*cmdFlags)[c] |= VGX_CF_NEXT_IS_CLOSE; }
-			}
-		}
-	}
-	return VGX_OK;
-}
+#include "vgx_pathset_host.h"
 
 extern "C" {
 
@@ -926,7 +850,9 @@ int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset**
 	const size_t oSubBegin = align(oRec + (size_t)(ncmd + 1) * sizeof(VgxCmdRec));
 	const size_t oSubLast = align(oSubBegin + (npaths + 1) * sizeof(uint32_t));
 	const size_t oThin = align(oSubLast + (subLastCmd.size() + 1) * sizeof(uint32_t));
-	const size_t total = align(oThin + (size_t)(ncmd + 3) * sizeof(VgxCmdThin));
+	const size_t oThinPath = align(oThin + (size_t)(ncmd + 3) * sizeof(VgxCmdThin));
+	const size_t oThinSub = align(oThinPath + (size_t)(npaths + 1) * sizeof(VgxThinPath));
+	const size_t total = align(oThinSub + (subLastCmd.size() + 1) * sizeof(VgxThinSub));
 	std::vector<uint8_t> host(total, 0);
 	memcpy(&host[oSubBegin], pathSubBegin.data(), (npaths + 1) * sizeof(uint32_t));
 	if (!subLastCmd.empty()) { memcpy(&host[oSubLast], subLastCmd.data(), subLastCmd.size() * sizeof(uint32_t)); }
@@ -938,30 +864,14 @@ int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset**
 		memcpy(&host[oFlags], cmdFlags.data(), ncmd);
 	}
 	memcpy(&host[oPathBegin], desc->path_cmd_begin, (npaths + 1) * sizeof(uint32_t));
-	// paths of moveTo / lineTo / close only: thin records (VgxCmdThin)
-	for (uint32_t p = 0; p < npaths; ++p) {
-		bool thin = !(pathFlags[p] & VGX_PF_SERIAL) && desc->path_cmd_begin[p + 1] > desc->path_cmd_begin[p];
-		for (uint32_t c = desc->path_cmd_begin[p]; thin && c < desc->path_cmd_begin[p + 1]; ++c) {
-			const uint32_t t = desc->cmd_type[c];
-			if (t != VGX_CMD_MOVE_TO && t != VGX_CMD_LINE_TO && t != VGX_CMD_CLOSE) { thin = false; }
-		}
-		if (thin) { pathFlags[p] |= VGX_PF_THIN; }
-	}
-	if (npaths) { memcpy(&host[oPathFlags], pathFlags.data(), npaths); }
+	// paths of moveTo / lineTo / close only: thin records (VgxCmdThin); a set of such paths only: the static layout tables (vgx_thin.h)
+	bool thinStatic = false;
 	{
 		VgxCmdThin* th = (VgxCmdThin*)&host[oThin] + 1; // th[-1]: padding record
-		for (uint32_t c = 0; c < ncmd; ++c) {
-			const uint32_t t = desc->cmd_type[c];
-			const uint32_t ao = desc->cmd_arg_off[c];
-			th[c].meta = t | ((uint32_t)cmdFlags[c] << 8);
-			th[c].x = 0.0f; th[c].y = 0.0f; th[c].pad = 0;
-			if (t == VGX_CMD_MOVE_TO || t == VGX_CMD_LINE_TO) { th[c].x = desc->args[ao]; th[c].y = desc->args[ao + 1]; }
-			else if (t == VGX_CMD_CLOSE) {
-				const uint32_t hc = spStart[c];
-				if (desc->cmd_type[hc] == VGX_CMD_MOVE_TO) { const uint32_t ho = desc->cmd_arg_off[hc]; th[c].x = desc->args[ho]; th[c].y = desc->args[ho + 1]; }
-			}
-		}
+		vgx_thin_fill(desc, cmdFlags.data(), spStart.data(), pathFlags.data(), th);
+		thinStatic = npaths != 0 && ncmd != 0 && vgx_thin_build(npaths, desc->path_cmd_begin, pathFlags.data(), pathSubBegin.data(), th, (VgxThinPath*)&host[oThinPath], (VgxThinSub*)&host[oThinSub]);
 	}
+	if (npaths) { memcpy(&host[oPathFlags], pathFlags.data(), npaths); }
 	{
 		VgxCmdRec* rec = (VgxCmdRec*)&host[oRec];
 		for (uint32_t c = 0; c < ncmd; ++c) {
@@ -1018,6 +928,9 @@ int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset**
 	ps->dev.path_flags = b + oPathFlags;
 	ps->dev.cmdrec = (const VgxCmdRec*)(b + oRec);
 	ps->dev.cmdthin = (const VgxCmdThin*)(b + oThin) + 1;
+	ps->dev.thin_path = (const VgxThinPath*)(b + oThinPath);
+	ps->dev.thin_sub = (const VgxThinSub*)(b + oThinSub);
+	ps->thinStatic = thinStatic;
 	ps->dev.path_sub_begin = (const uint32_t*)(b + oSubBegin);
 	ps->dev.sub_last_cmd = (const uint32_t*)(b + oSubLast);
 	ps->dev.npaths = npaths;
@@ -1730,6 +1643,9 @@ int vgx_tessellate_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* dr
 	// over the whole batch), the moved prefix of a spanning sub-path is < VGX_LONG_SUBPATH per >= VGX_BUILD_BLOCK block
 	// (<= 1/4), and longer sub-paths grow geometrically (<= 4x their own size). Plus every wave's last open block.
 	uint64_t heapVerts = sz.num_poly_vertices * 9 / 4 + 4 * ctx->hostTotals->long_subpath_vertices + 2 * (uint64_t)VGX_BUILD_WAVES * VGX_BUILD_BLOCK;
+	// k_flatten_thin (lineTo-only path sets) places draw d at its command prefix -- one slot per command instance -- and the exact
+	// builder's draws behind that
+	if (ps->thinStatic && heapVerts < 2 * sz.num_cmd_instances + 4096) { heapVerts = 2 * sz.num_cmd_instances + 4096; }
 	if (instPeriodFor(ctx, ndraws) || instGroupedFor(ctx, ps, ndraws)) {
 		// k_flatten_inst's lane-private blocks (vgx_inst.h): a block left behind wastes less than the one sub-path that did
 		// not fit (< the block's useful vertices while sub-paths are at most half a block long), longer sub-paths grow
@@ -2100,6 +2016,7 @@ int vgx_get_failure_info(vgx_ctx* ctx, vgx_failure_info* out, void* stream)
 	out->aux = ctx->hostTotals->fail_aux;
 	out->segment = ctx->hostTotals->fail_segment;
 	out->segment_items = ctx->tmplOn ? 5u : ctx->optInst ? (ctx->instPeriod ? (ctx->instPermOn ? 4u : 1u) : (ctx->instGrouped ? (ctx->instClasses > 1 ? 3u : 2u) : 0u)) : 0u; // flatten mode chosen by the last count call
+	if (out->segment_items == 0u && ctx->lastPs && ctx->lastPs->thinStatic && ctx->optThinStatic) { out->segment_items = 6u; } // k_flatten_thin in k_flatten_build's place
 	for (int i = 0; i < 16; ++i) { out->prof[i] = ctx->hostTotals->prof[i]; }
 	return VGX_OK;
 }

@@ -31,6 +31,7 @@
 #include "vgx_scan_ops.h"
 #include "vgx_inst.h"
 #include "vgx_flat1.h"
+#include "vgx_thin.h"
 
 namespace {
 
@@ -735,6 +736,118 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 	}
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_flatten_thin -- k_flatten_build's job for path sets of MOVE_TO / LINE_TO / CLOSE paths only (vgx_thin.h: every decision such a
+// path asks for was taken when the set was created). One lane per command instance, VGX_THIN_ITEMS of them per thread; a workgroup
+// owns a contiguous run of chunks of VGX_THIN_THREADS x VGX_THIN_ITEMS command instances: ONE binary search over the draws at its
+// start, then per chunk the command prefixes of the next (chunk + 1) draws in LDS (every draw has a command: a chunk's owners are
+// among them) and a search in LDS per lane. Vertex v of draw d goes to poly[cmd_prefix[d] + v]; the exact builder's draws
+// (degenerate paths) are listed and allocate behind poly_heap_cursor = the batch's command instances.
+#define VGX_THIN_THREADS 256
+#define VGX_THIN_ITEMS 4
+#define VGX_THIN_CHUNK (VGX_THIN_THREADS * VGX_THIN_ITEMS)
+__global__ __launch_bounds__(VGX_THIN_THREADS) void k_flatten_thin(VgxFlattenArgs A)
+{
+	__shared__ uint64_t s_pref[VGX_THIN_CHUNK + 1];
+	const VgxPathSetDev& ps = A.ps;
+	const uint32_t tid = threadIdx.x;
+	if (A.totals->status != VGX_OK) { return; }
+	if (A.inst_order != nullptr || (A.inst_period != 0 && A.totals->inst_mismatch == 0)) { return; } // instanced batch: k_flatten_inst builds it
+	const uint64_t totalCmds = A.cmd_prefix[A.ndraws];
+	if (totalCmds > A.caps.poly_vertices) {
+		if (blockIdx.x == 0 && tid == 0) { atomicCAS(&A.totals->status, (uint32_t)VGX_OK, (uint32_t)VGX_E_NOSPACE); }
+		return;
+	}
+	if (blockIdx.x == 0 && tid == 0) { atomicAdd(&A.totals->poly_heap_cursor, (unsigned long long)totalCmds); }
+	const uint64_t numChunks = (totalCmds + VGX_THIN_CHUNK - 1) / VGX_THIN_CHUNK;
+	const uint64_t per = (numChunks + gridDim.x - 1) / gridDim.x;
+	const uint64_t ch0 = (uint64_t)blockIdx.x * per;
+	const uint64_t ch1 = ch0 + per < numChunks ? ch0 + per : numChunks;
+	if (ch0 >= ch1) { return; }
+	// the draw that owns the run's first command instance: the last d with cmd_prefix[d] <= key. A 256-ary search by the whole
+	// workgroup (two or three dependent loads for any batch instead of log2(ndraws)): cmd_prefix[lo] <= key < cmd_prefix[hi] throughout
+	uint64_t dcur;
+	{
+		const uint64_t key = ch0 * VGX_THIN_CHUNK;
+		uint64_t lo = 0, hi = A.ndraws;
+		while (hi - lo > 1) {
+			const uint64_t step = (hi - lo + VGX_THIN_THREADS - 1) / VGX_THIN_THREADS;
+			uint64_t idx = lo + (uint64_t)(tid + 1) * step;
+			if (idx > hi) { idx = hi; }
+			const uint32_t cnt = (uint32_t)__syncthreads_count(A.cmd_prefix[idx] <= key ? 1 : 0); // the samples do not decrease with tid: the first cnt are <= key (never all: the last one is hi's)
+			uint64_t nhi = lo + (uint64_t)(cnt + 1) * step;
+			if (nhi > hi) { nhi = hi; }
+			lo = lo + (uint64_t)cnt * step;
+			hi = nhi;
+		}
+		dcur = lo;
+	}
+	for (uint64_t ch = ch0; ch < ch1; ++ch) {
+		const uint64_t c0 = ch * VGX_THIN_CHUNK;
+		__syncthreads(); // (the previous chunk's searches are done)
+		for (uint32_t i = tid; i <= VGX_THIN_CHUNK; i += VGX_THIN_THREADS) {
+			const uint64_t idx = dcur + i;
+			s_pref[i] = idx <= A.ndraws ? A.cmd_prefix[idx] : ~0ull;
+		}
+		__syncthreads();
+		uint32_t own[VGX_THIN_ITEMS];
+		uint64_t base[VGX_THIN_ITEMS];
+		bool valid[VGX_THIN_ITEMS];
+#pragma unroll
+		for (int it = 0; it < VGX_THIN_ITEMS; ++it) {
+			const uint64_t ci = c0 + (uint64_t)it * VGX_THIN_THREADS + tid;
+			valid[it] = ci < totalCmds;
+			const uint64_t key = valid[it] ? ci : c0;
+			uint32_t lo = 0, hi = VGX_THIN_CHUNK; // s_pref[0] <= c0 <= key; the owner is among the first VGX_THIN_CHUNK entries
+			while (lo < hi) {
+				const uint32_t mid = (lo + hi + 1) >> 1;
+				if (s_pref[mid] <= key) { lo = mid; } else { hi = mid - 1; }
+			}
+			own[it] = lo; base[it] = s_pref[lo];
+		}
+		uint32_t nextOwn; // owner of the next chunk's first command instance (uniform)
+		{
+			const uint64_t key = c0 + VGX_THIN_CHUNK;
+			uint32_t lo = 0, hi = VGX_THIN_CHUNK;
+			while (lo < hi) {
+				const uint32_t mid = (lo + hi + 1) >> 1;
+				if (s_pref[mid] <= key) { lo = mid; } else { hi = mid - 1; }
+			}
+			nextOwn = lo;
+		}
+		// the draws' words, then the paths' records, then the commands' records: all items' loads of a stage issued together
+		uint32_t path[VGX_THIN_ITEMS], ff[VGX_THIN_ITEMS], sf[VGX_THIN_ITEMS];
+		float m[VGX_THIN_ITEMS][6];
+#pragma unroll
+		for (int it = 0; it < VGX_THIN_ITEMS; ++it) {
+			const vgx_draw* dr = A.draws + (dcur + own[it]);
+			path[it] = dr->path; ff[it] = dr->fill_flags; sf[it] = dr->stroke_flags;
+#pragma unroll
+			for (int j = 0; j < 6; ++j) { m[it][j] = dr->mtx[j]; }
+		}
+		VgxThinPath q[VGX_THIN_ITEMS];
+#pragma unroll
+		for (int it = 0; it < VGX_THIN_ITEMS; ++it) { q[it] = ps.thin_path[path[it]]; }
+		VgxCmdThin t[VGX_THIN_ITEMS];
+#pragma unroll
+		for (int it = 0; it < VGX_THIN_ITEMS; ++it) {
+			const uint64_t ci = valid[it] ? c0 + (uint64_t)it * VGX_THIN_THREADS + tid : base[it];
+			t[it] = ps.cmdthin[q[it].pc0 + (uint32_t)(ci - base[it])];
+		}
+#pragma unroll
+		for (int it = 0; it < VGX_THIN_ITEMS; ++it) {
+			if (valid[it]) {
+				const uint64_t d = dcur + own[it];
+				if (vgx_thin_lane(q[it], t[it], ps.thin_sub, m[it], ff[it], sf[it], base[it], A.sub_prefix + d, A.poly, A.sub_rec, A.dinfo + d)) {
+					const unsigned long long at = atomicAdd(&A.totals->num_serial_list, 1ull);
+					A.serial_list[at] = (uint32_t)d;
+				}
+			}
+		}
+		dcur += nextOwn;
+	}
+}
+
 // One lane per draw, after the scan over draws: turns the sparse sub-path records of k_flatten_build into mesh
 // descriptors (+ closed-form mesh-table sizes) at their ORDERED indices: fill meshes by sub-path, then stroke meshes
 // (the reference's call order, vg.cpp:3099-3131 then 3448-3485). Serial draws were written by k_flatten_serial.
@@ -971,7 +1084,9 @@ void vgx_launch_flatten_build(const VgxFlattenArgs& a, int waves, hipStream_t s,
 	if (a.inst_period || a.inst_order) { vgx_launch_flatten_inst(a, a.inst_waves, s); } // one of the two exits at once (device-side check)
 	// waves < VGX_BUILD_WAVES is a testing knob (VGX_BUILD_WAVES in the environment at vgx_create): a handful of waves makes
 	// small batches run through the heap's block switches and sub-path moves that otherwise need > 8192 vertices per wave
-	if (a.pool_walk) {
+	if (a.thin_static) { // a set of MOVE_TO / LINE_TO / CLOSE paths: the static layout (vgx_thin.h)
+		hipLaunchKernelGGL(k_flatten_thin, dim3(a.ndraws <= VGX_SMALL_DRAWS ? 64 : 2048), dim3(VGX_THIN_THREADS), 0, s, a); // (frame-sized batches: workgroups that find no chunk still cost their first loads)
+	} else if (a.pool_walk) {
 		hipLaunchKernelGGL(k_flatten_build<true>, dim3(waves), dim3(VGX_WAVE), 0, s, a);
 	} else {
 		hipLaunchKernelGGL(k_flatten_build<false>, dim3(waves), dim3(VGX_WAVE), 0, s, a);

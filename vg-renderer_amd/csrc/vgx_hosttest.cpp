@@ -3,6 +3,8 @@
 // check the per-lane builder logic against the oracle without a GPU.
 #include "vgx_pathsim.h"
 #include "vgx_inst.h"
+#include "vgx_pathset_host.h"
+#include "vgx_thin.h"
 #include <string.h>
 
 namespace {
@@ -148,3 +150,47 @@ void vgxt_math_vec(int fn, const float* a, const float* b, float* out, uint64_t 
 }
 
 } // extern "C"
+
+extern "C" {
+
+// Path sets of MOVE_TO / LINE_TO / CLOSE paths (vgx_thin.h): the static layout tables as vgx_pathset_create builds them, then
+// k_flatten_thin's lane function over every command instance of the batch, one after the other. Outputs as the kernel leaves
+// them: poly [command instances][2] (vertex v of draw d at cmd_prefix[d] + v), sub_rec [static sub-paths of the batch] (record j of
+// draw d at sub_prefix[d] + j), dinfo [ndraws], serial [ndraws] (1: the draw is listed for the exact builder).
+// Returns 1, 0 when the set is not eligible, < 0 = -(validation error).
+int vgxt_thin_flatten(const vgx_pathset_desc* d, const vgx_draw* draws, uint64_t ndraws, float* poly, VgxSubRec* subRec, vgx_draw_info* dinfo, uint8_t* serial)
+{
+	std::vector<uint8_t> cmdFlags, pathFlags;
+	std::vector<uint32_t> spStart;
+	uint32_t maxCmds = 0;
+	const int st = vgx_pathset_validate_host(d, &cmdFlags, &spStart, &pathFlags, &maxCmds);
+	if (st != VGX_OK) { return -st; }
+	std::vector<uint32_t> pathSubBegin(d->npaths + 1, 0);
+	uint32_t nsub = 0;
+	for (uint32_t p = 0; p < d->npaths; ++p) {
+		pathSubBegin[p] = nsub;
+		for (uint32_t c = d->path_cmd_begin[p]; c < d->path_cmd_begin[p + 1]; ++c) { if (cmdFlags[c] & VGX_CF_LAST_IN_SUB) { ++nsub; } }
+	}
+	pathSubBegin[d->npaths] = nsub;
+	std::vector<VgxCmdThin> thv(d->ncmd + 3);
+	VgxCmdThin* th = thv.data() + 1;
+	std::vector<VgxThinPath> tp(d->npaths + 1);
+	std::vector<VgxThinSub> ts(nsub + 1);
+	vgx_thin_fill(d, cmdFlags.data(), spStart.data(), pathFlags.data(), th);
+	if (d->npaths == 0 || d->ncmd == 0 || !vgx_thin_build(d->npaths, d->path_cmd_begin, pathFlags.data(), pathSubBegin.data(), th, tp.data(), ts.data())) { return 0; }
+	uint64_t cmdPrefix = 0, subPrefix = 0;
+	for (uint64_t i = 0; i < ndraws; ++i) {
+		const vgx_draw* dr = draws + i;
+		const VgxThinPath q = tp[dr->path];
+		const uint32_t ncmd = d->path_cmd_begin[dr->path + 1] - d->path_cmd_begin[dr->path];
+		serial[i] = 0;
+		for (uint32_t k = 0; k < ncmd; ++k) {
+			if (vgx_thin_lane(q, th[q.pc0 + k], ts.data(), dr->mtx, dr->fill_flags, dr->stroke_flags, cmdPrefix, &subPrefix, poly, subRec, dinfo + i)) { serial[i] = 1; }
+		}
+		cmdPrefix += ncmd;
+		subPrefix += pathSubBegin[dr->path + 1] - pathSubBegin[dr->path];
+	}
+	return 1;
+}
+
+}

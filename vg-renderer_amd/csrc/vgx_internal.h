@@ -34,6 +34,7 @@ struct VgxFlattenArgs
 	uint32_t* serial_list;         // BUILD mode: draws for k_flatten_serial (static serial paths + degenerate draws), unordered
 	float* leaf_overflow;          // [VGX_BUILD_WAVES][VGX_BUILD_OVERFLOW][64][2] leaves that did not fit the LDS slots
 	int pool_walk;                 // k_flatten_build: pooled cubic walk (vgx_walk.h) instead of one cubic per lane
+	int thin_static;               // every path of the set is MOVE_TO / LINE_TO / CLOSE only: k_flatten_thin (vgx_thin.h) in k_flatten_build's place
 	// instanced batches (vgx_inst.hip): draws[i].path == draws[i % inst_period].path; 0 = not instanced. When set and the
 	// device-side check of this call agrees, k_flatten_inst builds the batch and k_flatten_build exits at once.
 	uint32_t inst_period;

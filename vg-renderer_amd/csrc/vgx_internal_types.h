@@ -51,6 +51,8 @@ struct VgxPathSetDev
 {
 	const VgxCmdRec* cmdrec;
 	const VgxCmdThin* cmdthin;      // [ncmd + 2] (one padding record in front: command 0 reads its predecessor's)
+	const struct VgxThinPath* thin_path; // [npaths] static polyline layout of MOVE_TO / LINE_TO / CLOSE paths (vgx_thin.h), filled when EVERY path of the set is one
+	const struct VgxThinSub* thin_sub;   // [sub-paths of the set] indexed like sub_last_cmd
 	const uint8_t* cmd_type;
 	const uint8_t* cmd_flags;
 	const uint32_t* cmd_arg_off;

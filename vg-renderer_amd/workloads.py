@@ -363,6 +363,39 @@ def fuzz_draws(ps, seed, ndraws=None):
     return d
 
 
+def thin_fuzz_paths(seed, npaths=64, degenerate=True):
+    """Random paths of moveTo / lineTo / close only (what vgx_thin.h lays out statically): one to four sub-paths, open and closed,
+    sub-paths of one or two vertices (a lone moveTo, moveTo + close, moveTo + lineTo + close), polygons that return exactly -- or
+    to within the epsilon of pathClose -- to their first point before closing (the vertex pathClose pops), long runs (more than
+    one 64-command chunk) and, with `degenerate`, lineTo commands onto the current point (pathLineTo drops them: the exact builder
+    takes such draws)."""
+    rs = np.random.RandomState(seed + 4242)
+    b = PathSetBuilder()
+    for p in range(npaths):
+        b.begin_path()
+        for s in range(int(rs.randint(1, 5))):
+            scale = float(rs.choice([1.0, 10.0, 100.0, 400.0]))
+            ox, oy = [float(np.float32(v)) for v in rs.uniform(-50, 50, size=2)]
+            b.move_to(ox, oy)
+            r = rs.uniform()
+            n = 0 if r < 0.12 else (1 if r < 0.25 else (int(rs.randint(2, 12)) if r < 0.9 else int(rs.randint(60, 300))))
+            x, y = ox, oy
+            for i in range(n):
+                x = float(np.float32(x + rs.uniform(-1, 1) * scale)); y = float(np.float32(y + rs.uniform(-1, 1) * scale))
+                b.line_to(x, y)
+                if degenerate and rs.uniform() < 0.02:
+                    b.line_to(x, y)  # zero-length segment
+            c = rs.uniform()
+            if c < 0.3:
+                b.close()
+            elif c < 0.5:
+                b.line_to(ox, oy); b.close()  # back onto the first point, then close: popped when the sub-path has more than two vertices
+            elif c < 0.6:
+                b.line_to(float(np.float32(ox + 1.0e-4)), oy); b.close()  # within pathClose's epsilon of the first point
+        b.end_path()
+    return b.arrays()
+
+
 # ---- closed-shape fuzz set (template mode: fills + closed Miter AA strokes) ----------------------
 def closed_fuzz_paths(seed, npaths=48):
     """Random paths whose sub-paths are all CLOSED with at least three distinct vertices: move / line / cubic / quad /

@@ -546,7 +546,9 @@ def test_async_thin_path_sets_static_layout(rt, wl, oracle, seed, npaths, degene
     d = wl.fuzz_draws(ps, seed)
     d = d[np.random.RandomState(seed).permutation(d.shape[0])]
     ref = oracle.tessellate(ps, d)
-    for static in ("1", "0"):
+    import os
+    on = os.environ.get("VGX_THIN_STATIC", "1")  # ("2": the kernel instance with two command instances per thread)
+    for static in (on if on != "0" else "1", "0"):
         monkeypatch.setenv("VGX_THIN_STATIC", static)
         ctx = rt.Context(0)
         got = _async_result(rt, ctx, ps, d)

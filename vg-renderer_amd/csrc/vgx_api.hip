@@ -420,7 +420,7 @@ VgxFlattenArgs flattenArgs(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* 
 	a.sub_rec = (VgxSubRec*)ctx->subFirst.p;
 	a.build_mode = 0;
 	a.pool_walk = ctx->optPoolWalk;
-	a.thin_static = (ps->thinStatic && ctx->optThinStatic) ? 1 : 0;
+	a.thin_static = ps->thinStatic ? ctx->optThinStatic : 0;
 	a.leaf_overflow = (float*)ctx->leafOverflow.p;
 	a.serial_list = (uint32_t*)ctx->serialList.p;
 	a.inst_period = 0; a.inst_block = ctx->optInstBlock; a.inst_waves = ctx->optInstWaves; a.inst_perm = nullptr;
@@ -758,7 +758,7 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	if (const char* e = getenv("VGX_F1_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 65536) { ctx->optF1Waves = v; } }
 	if (const char* e = getenv("VGX_F1_CAP")) { ctx->optF1Cap = atoi(e); }
 	ctx->optThinStatic = 1;
-	if (const char* e = getenv("VGX_THIN_STATIC")) { ctx->optThinStatic = atoi(e) != 0; }
+	if (const char* e = getenv("VGX_THIN_STATIC")) { const int v = atoi(e); ctx->optThinStatic = v == 2 ? 2 : (v != 0 ? 1 : 0); } // (2: the kernel instance with two command instances per thread)
 	if (const char* e = getenv("VGX_BUILD_WAVES")) { const int v = atoi(e); if (v >= 1 && v < VGX_BUILD_WAVES) { ctx->optBuildWaves = v; } }
 	*out_ctx = ctx;
 	return VGX_OK;

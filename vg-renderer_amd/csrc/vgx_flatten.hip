@@ -744,11 +744,12 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 // among them) and a search in LDS per lane. Vertex v of draw d goes to poly[cmd_prefix[d] + v]; the exact builder's draws
 // (degenerate paths) are listed and allocate behind poly_heap_cursor = the batch's command instances.
 #define VGX_THIN_THREADS 256
-#define VGX_THIN_ITEMS 4
-#define VGX_THIN_CHUNK (VGX_THIN_THREADS * VGX_THIN_ITEMS)
+template<int VGX_THIN_ITEMS>
 __global__ __launch_bounds__(VGX_THIN_THREADS) void k_flatten_thin(VgxFlattenArgs A)
 {
+	constexpr uint32_t VGX_THIN_CHUNK = VGX_THIN_THREADS * VGX_THIN_ITEMS;
 	__shared__ uint64_t s_pref[VGX_THIN_CHUNK + 1];
+	__shared__ uint32_t s_path[VGX_THIN_CHUNK + 1];
 	const VgxPathSetDev& ps = A.ps;
 	const uint32_t tid = threadIdx.x;
 	if (A.totals->status != VGX_OK) { return; }
@@ -785,11 +786,22 @@ __global__ __launch_bounds__(VGX_THIN_THREADS) void k_flatten_thin(VgxFlattenArg
 	for (uint64_t ch = ch0; ch < ch1; ++ch) {
 		const uint64_t c0 = ch * VGX_THIN_CHUNK;
 		__syncthreads(); // (the previous chunk's searches are done)
-		for (uint32_t i = tid; i <= VGX_THIN_CHUNK; i += VGX_THIN_THREADS) {
+		// The window: command prefix and path of draws dcur, dcur + 1, ... as far as the chunk reaches -- 256 entries at a time, counting
+		// the entries that begin at or before the NEXT chunk's first command instance (they are sorted: a prefix of the window). A
+		// block with fewer than 256 of them ends the window (long paths: one load per thread); entries behind it are never read.
+		const uint64_t keyNext = c0 + VGX_THIN_CHUNK;
+		uint32_t nextOwn = 0; // entries 1 .. nextOwn begin at or before keyNext: owner of the next chunk's first command instance (uniform)
+		if (tid == 0) { s_pref[0] = A.cmd_prefix[dcur]; s_path[0] = A.draws[dcur].path; }
+		for (uint32_t b0 = 0; b0 < VGX_THIN_CHUNK; b0 += VGX_THIN_THREADS) {
+			const uint32_t i = b0 + 1u + tid;
 			const uint64_t idx = dcur + i;
-			s_pref[i] = idx <= A.ndraws ? A.cmd_prefix[idx] : ~0ull;
+			const uint64_t v = idx <= A.ndraws ? A.cmd_prefix[idx] : ~0ull;
+			s_pref[i] = v;
+			s_path[i] = idx < A.ndraws ? A.draws[idx].path : 0u;
+			const uint32_t c = (uint32_t)__syncthreads_count(v <= keyNext ? 1 : 0); // (a barrier: the entries written so far are visible)
+			nextOwn += c;
+			if (c < VGX_THIN_THREADS) { break; }
 		}
-		__syncthreads();
 		uint32_t own[VGX_THIN_ITEMS];
 		uint64_t base[VGX_THIN_ITEMS];
 		bool valid[VGX_THIN_ITEMS];
@@ -798,30 +810,21 @@ __global__ __launch_bounds__(VGX_THIN_THREADS) void k_flatten_thin(VgxFlattenArg
 			const uint64_t ci = c0 + (uint64_t)it * VGX_THIN_THREADS + tid;
 			valid[it] = ci < totalCmds;
 			const uint64_t key = valid[it] ? ci : c0;
-			uint32_t lo = 0, hi = VGX_THIN_CHUNK; // s_pref[0] <= c0 <= key; the owner is among the first VGX_THIN_CHUNK entries
+			uint32_t lo = 0, hi = nextOwn; // s_pref[0] <= c0 <= key < keyNext: the owner is among entries 0 .. nextOwn
 			while (lo < hi) {
 				const uint32_t mid = (lo + hi + 1) >> 1;
 				if (s_pref[mid] <= key) { lo = mid; } else { hi = mid - 1; }
 			}
 			own[it] = lo; base[it] = s_pref[lo];
 		}
-		uint32_t nextOwn; // owner of the next chunk's first command instance (uniform)
-		{
-			const uint64_t key = c0 + VGX_THIN_CHUNK;
-			uint32_t lo = 0, hi = VGX_THIN_CHUNK;
-			while (lo < hi) {
-				const uint32_t mid = (lo + hi + 1) >> 1;
-				if (s_pref[mid] <= key) { lo = mid; } else { hi = mid - 1; }
-			}
-			nextOwn = lo;
-		}
-		// the draws' words, then the paths' records, then the commands' records: all items' loads of a stage issued together
+		// the draws' words and the paths' records (the path index came with the window), then the commands' records: all items' loads
+		// of a stage issued together
 		uint32_t path[VGX_THIN_ITEMS], ff[VGX_THIN_ITEMS], sf[VGX_THIN_ITEMS];
 		float m[VGX_THIN_ITEMS][6];
 #pragma unroll
 		for (int it = 0; it < VGX_THIN_ITEMS; ++it) {
 			const vgx_draw* dr = A.draws + (dcur + own[it]);
-			path[it] = dr->path; ff[it] = dr->fill_flags; sf[it] = dr->stroke_flags;
+			path[it] = s_path[own[it]]; ff[it] = dr->fill_flags; sf[it] = dr->stroke_flags;
 #pragma unroll
 			for (int j = 0; j < 6; ++j) { m[it][j] = dr->mtx[j]; }
 		}
@@ -1085,7 +1088,9 @@ void vgx_launch_flatten_build(const VgxFlattenArgs& a, int waves, hipStream_t s,
 	// waves < VGX_BUILD_WAVES is a testing knob (VGX_BUILD_WAVES in the environment at vgx_create): a handful of waves makes
 	// small batches run through the heap's block switches and sub-path moves that otherwise need > 8192 vertices per wave
 	if (a.thin_static) { // a set of MOVE_TO / LINE_TO / CLOSE paths: the static layout (vgx_thin.h)
-		hipLaunchKernelGGL(k_flatten_thin, dim3(a.ndraws <= VGX_SMALL_DRAWS ? 64 : 2048), dim3(VGX_THIN_THREADS), 0, s, a); // (frame-sized batches: workgroups that find no chunk still cost their first loads)
+		const dim3 grid(a.ndraws <= VGX_SMALL_DRAWS ? 64 : 2048); // (frame-sized batches: workgroups that find no chunk still cost their first loads)
+		if (a.thin_static == 2) { hipLaunchKernelGGL(k_flatten_thin<2>, grid, dim3(VGX_THIN_THREADS), 0, s, a); } // (VGX_THIN_STATIC=2: two command instances per thread)
+		else { hipLaunchKernelGGL(k_flatten_thin<4>, grid, dim3(VGX_THIN_THREADS), 0, s, a); }
 	} else if (a.pool_walk) {
 		hipLaunchKernelGGL(k_flatten_build<true>, dim3(waves), dim3(VGX_WAVE), 0, s, a);
 	} else {

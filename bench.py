@@ -1101,7 +1101,7 @@ def main():
                            "value": round(r2["units"] / (ms2 * 1e-3) / 1e6, 2), "unit": "M %s/s" % r2["unit_name"], "ms_per_step": round(ms2, 3), "ms_per_step_sustained": round(r2.get("sustained_ms_per_step", 0.0), 3), "steps": steps2,
                            "verts_per_gpu": r2["sizes"].get("num_vertices", 0), "indices_per_gpu": r2["sizes"].get("num_indices", 0),
                            "poly_verts_per_gpu": r2["sizes"]["num_poly_vertices"], "meshes_per_gpu": r2["sizes"].get("num_meshes", 0),
-                           "flatten_kernel": {0: "k_flatten_build", 1: "k_flatten_inst", 2: "k_flatten_inst (grouped)", 3: "k_flatten_inst (grouped by path and tolerance class)", 4: "k_flatten_inst (instances sorted by tolerance class)", 5: "none per step (template mode: the class representatives flattened once by vgx_tessellate_count)"}.get(r2.get("flatten_mode"), "k_flatten"),
+                           "flatten_kernel": {0: "k_flatten_build", 1: "k_flatten_inst", 2: "k_flatten_inst (grouped)", 3: "k_flatten_inst (grouped by path and tolerance class)", 4: "k_flatten_inst (instances sorted by tolerance class)", 5: "none per step (template mode: the class representatives flattened once by vgx_tessellate_count)", 6: "k_flatten_thin"}.get(r2.get("flatten_mode"), "k_flatten"),
                            "roofline": roofline(r2, steps2, traffic_for=name), "stage_ms": {k: round(v, 3) for k, v in r2["stage"].items()},
                            "setup_ms": r2.get("setup_ms"),
                            "cpu_baseline": other_cpu.get(name)}
@@ -1158,6 +1158,7 @@ def main():
                                           else "k_flatten_inst, grouped (draws sorted by path on the device)" if res.get("flatten_mode") == 2
                                           else "k_flatten_inst, grouped (draws sorted by path and tolerance class on the device)" if res.get("flatten_mode") == 3
                                           else "k_flatten_inst, periodic with the instances sorted by tolerance class on the device" if res.get("flatten_mode") == 4
+                                          else "k_flatten_thin (lineTo-only path set: polyline layout decided when the set was created, gather - transform - scatter per batch)" if res.get("flatten_mode") == 6
                                           else "k_flatten_build (one lane per path command)")},
             "roofline": roofline(res, args.steps, traffic_for=K if args.config == "tiger10k" else None),
             "stage_ms": {k: round(v, 3) for k, v in res["stage"].items()},

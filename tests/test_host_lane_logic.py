@@ -208,3 +208,33 @@ def test_thin_static_layout_needs_a_thin_set(hostlib, vgr, wl):
     desc = ps.desc()
     hostlib.vgxt_thin_flatten.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     assert hostlib.vgxt_thin_flatten(C.addressof(desc), d.ctypes.data, d.shape[0], None, None, None, None) == 0
+
+
+@pytest.mark.parametrize("nsub,eligible", [(65536, 1), (65537, 0)])
+def test_thin_static_layout_sub_path_ordinal_limit(hostlib, vgr, wl, nsub, eligible):
+    """The sub-path ordinal lives in 16 bits of the thin record: a path of more than 65 536 sub-paths makes its set ineligible
+    (k_flatten_build keeps it), one of exactly 65 536 is laid out -- the last record of the draw names sub-path 65 535."""
+    from importlib import import_module
+    pathset = import_module("vg-renderer_amd.pathset")
+    b = pathset.PathSetBuilder()
+    b.begin_path()
+    for i in range(nsub):
+        b.move_to(float(i), 1.0)
+        b.line_to(float(i), 2.0)
+    b.end_path()
+    ps = b.arrays()
+    d = wl.make_draws(1)
+    d["path"] = 0
+    wl.set_stroke(d, slice(None), 0xFF00FF00, 2.0)
+    desc = ps.desc()
+    poly = np.zeros((2 * nsub + 8, 2), dtype=np.float32)
+    rec = np.zeros(nsub + 4, dtype=SUBREC)
+    dinfo = np.zeros(1, dtype=[("first_poly_vertex", "<u8"), ("first_subpath", "<u8"), ("first_mesh", "<u8"), ("num_poly_vertices", "<u4"), ("num_subpaths", "<u4"), ("num_meshes", "<u4"), ("flags", "<u4")])
+    serial = np.zeros(1, dtype=np.uint8)
+    hostlib.vgxt_thin_flatten.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = hostlib.vgxt_thin_flatten(C.addressof(desc), d.ctypes.data, 1, poly.ctypes.data, rec.ctypes.data, dinfo.ctypes.data, serial.ctypes.data)
+    assert rc == eligible
+    if eligible:
+        assert (int(dinfo["num_poly_vertices"][0]), int(dinfo["num_subpaths"][0]), int(dinfo["num_meshes"][0])) == (2 * nsub, nsub, nsub)
+        assert (int(rec["first"][nsub - 1]), int(rec["info"][nsub - 1])) == (2 * (nsub - 1), 2)
+        assert np.array_equal(poly[2 * nsub - 1], np.float32([nsub - 1, 2.0]))

@@ -253,7 +253,11 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx);
 /* Validates (host) and uploads a path set. Grammar per path: first command must start a sub-path
  * (MOVE_TO, ARC, or a closed shape RECT, ROUNDED_RECT[_VARYING], CIRCLE, ELLIPSE); after CLOSE or a closed
  * shape the next command must start a sub-path again (the reference only VG_CHECKs this in debug
- * builds, path.cpp:82,88,764-765). Non-finite arguments are rejected. Synchronous. */
+ * builds, path.cpp:82,88,764-765). Non-finite arguments are rejected. Synchronous.
+ * A set whose paths are ALL made of MOVE_TO / LINE_TO / CLOSE only (polylines and polygons: pathMoveTo / pathLineTo /
+ * pathClose, path.cpp:64-85, 707-726) also gets the polyline layout of every path here -- which commands add a vertex,
+ * the vertex pathClose pops, the sub-path table: none of it depends on a draw -- and vgx_tessellate then moves such a
+ * set's vertices through the draws' transforms without deciding anything again (csrc/vgx_thin.h; same output). */
 int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset** out_ps);
 /* The validation step of vgx_pathset_create alone (host only, needs no device). */
 int vgx_pathset_validate(const vgx_pathset_desc* desc);

@@ -18,7 +18,9 @@ LIB = os.path.join(ROOT, "vg-renderer_amd", "libvgx_hosttest.so")
 @pytest.fixture(scope="module")
 def hostlib():
     src = os.path.join(ROOT, "vg-renderer_amd", "csrc", "vgx_hosttest.cpp")
-    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+    import glob
+    newest = max(os.path.getmtime(f) for f in [src] + glob.glob(os.path.join(os.path.dirname(src), "*.h")))  # (the lane code lives in the headers)
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-shared", "-o", LIB, src])
     lib = C.CDLL(LIB)
     lib.vgxt_math_vec.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]

@@ -314,18 +314,24 @@ def run_config(rt, torch, ctx, local_rank, name, ps, draws, kind, steps, warmup,
     # "H2D of commands excluded and reported separately" -- what happens once per batch, before any step, timed here:
     # vgx_pathset_create (grammar validation + derived tables on the host + the upload of the path set), the upload of the draw
     # records, and the first count call (sizes the library's scratch: includes its hipMalloc calls).
+    # Round 6: vgx_pathset_create uploads the caller's four arrays as they are (ordinary host memory) and builds every derived
+    # table on the device; the draw records are written by the caller into pinned memory (rt.pin_draws, untimed: it stands for the
+    # caller producing them) and h2d_draws is the copy from there.
+    pinned = rt.pin_draws(draws)
     torch.cuda.synchronize()
     ts0 = time.perf_counter()
     pset = rt.PathSet(ctx, ps)
     ts1 = time.perf_counter()
-    dd = rt.upload_draws(draws, local_rank)
+    dd = rt.upload_draws(pinned, local_rank)
     torch.cuda.synchronize()
     ts2 = time.perf_counter()
+    raw_bytes = int(ps.cmd_type.nbytes + ps.cmd_arg_off.nbytes + ps.args.nbytes + ps.path_cmd_begin.nbytes)
     res = {"ndraws": ndraws, "setup_ms": {"pathset_create": round((ts1 - ts0) * 1e3, 3), "h2d_draws": round((ts2 - ts1) * 1e3, 3),
-                                          "path_set_bytes": int(ps.cmd_type.nbytes + ps.cmd_arg_off.nbytes + ps.args.nbytes + ps.path_cmd_begin.nbytes), "draw_bytes": int(ndraws) * 64}}
+                                          "h2d_draws_GBps": round(ndraws * 64 / max(ts2 - ts1, 1e-9) / 1e9, 1),
+                                          "path_set_bytes": raw_bytes, "draw_bytes": int(ndraws) * 64}}
     stage_sum = {}
+    L, C, capi = rt.lib(), rt.C, rt.capi
     if kind == "flatten":
-        L, C, capi = rt.lib(), rt.C, rt.capi
         sizes_c = capi.Sizes()
         tc0 = time.perf_counter()
         rt._check(L.vgx_flatten_count(ctx.handle, pset.handle, dd.data_ptr(), ndraws, C.byref(sizes_c), rt._stream_ptr()), "vgx_flatten_count")
@@ -465,6 +471,44 @@ def run_config(rt, torch, ctx, local_rank, name, ps, draws, kind, steps, warmup,
         res["cold_ms_per_step"] = (time.perf_counter() - tcs) / ncold * 1e3
         res["cold_count_ms"] = count_s / ncold * 1e3
         res["cold_steps"] = ncold
+    # ONE-SHOT batch: everything a batch that is tessellated once pays, on a context whose scratch is warm (a
+    # renderer keeps its context) -- new path set from the caller's arrays, the draw records up from pinned memory, the count
+    # (output sizes: the caller has to allocate), one step, the wait. Outputs go to the buffers already allocated.
+    try:
+        nshot = 3
+        shots = []
+        for _ in range(nshot):
+            torch.cuda.synchronize()
+            o0 = time.perf_counter()
+            pset1 = rt.PathSet(ctx, ps)
+            o1 = time.perf_counter()
+            dd1 = rt.upload_draws(pinned, local_rank)
+            if kind == "flatten":
+                rt._check(L.vgx_flatten_count(ctx.handle, pset1.handle, dd1.data_ptr(), ndraws, C.byref(sizes_c), rt._stream_ptr()), "vgx_flatten_count")
+                o2 = time.perf_counter()
+                rt.flatten_async(ctx, pset1, dd1, ndraws, fb, apply_transform=True)
+            else:
+                rt.tessellate_count(ctx, pset1, dd1, ndraws)
+                o2 = time.perf_counter()
+                rt.tessellate_async(ctx, pset1, dd1, ndraws, bufs)
+            torch.cuda.synchronize()
+            o3 = time.perf_counter()
+            shots.append(((o3 - o0) * 1e3, (o1 - o0) * 1e3, (o2 - o1) * 1e3, (o3 - o2) * 1e3))
+            pset1.close()
+            del dd1
+        best = min(shots)
+        res["setup_ms"].update({"one_shot_ms": round(best[0], 3), "one_shot_split_ms": {"pathset_create": round(best[1], 3), "h2d_draws_and_count": round(best[2], 3), "step_and_wait": round(best[3], 3)},
+                                "one_shot_runs_ms": [round(x[0], 3) for x in shots]})
+        # leave the context as the timed steps left it (the count of the one-shot legs belongs to a path set that is gone)
+        if kind == "flatten":
+            rt._check(L.vgx_flatten_count(ctx.handle, pset.handle, dd.data_ptr(), ndraws, C.byref(sizes_c), rt._stream_ptr()), "vgx_flatten_count")
+        else:
+            rt.tessellate_count(ctx, pset, dd, ndraws)
+            rt.tessellate_async(ctx, pset, dd, ndraws, bufs)
+            torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001 -- a companion number must not take the config with it
+        res["setup_ms"]["one_shot_error"] = repr(e)[:160]
+    del pinned
     fill_verts = fill_idx = fill_meshes = 0
     if bufs is not None:
         assert int(bufs.dev_status.item()) == 0
@@ -759,6 +803,17 @@ def roofline(res, steps, traffic_for=None):
             "pipeline_achieved": round(ab["pipeline"] / (ms_per_step * 1e-3) / 1e9, 1)}
 
 
+def _finite(x):
+    """NaN / infinities -> None, recursively: the printed line must load with a strict JSON parser."""
+    if isinstance(x, float):
+        return x if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    return x
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -770,6 +825,7 @@ def main():
     ap.add_argument("--gather", action="store_true", help="(default for --gpus > 1) also time the RCCL gather of the streams to rank 0")
     ap.add_argument("--no-gather", action="store_true", help="multi-GPU: skip the gather leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--details", default=os.path.join(ROOT, "bench_details.json"), help="where the full record goes (every config, stage times, sweeps); stdout carries the short line only")
     ap.add_argument("--placements", type=int, default=1, help="output-buffer allocations to probe before the warm-up (default 1 = the first allocation is the one that is timed; "
                                                                "N > 1 reports every candidate and times the fastest -- a tuning aid, not the headline)")
     args = ap.parse_args()
@@ -1105,6 +1161,10 @@ def main():
                            "roofline": roofline(r2, steps2, traffic_for=name), "stage_ms": {k: round(v, 3) for k, v in r2["stage"].items()},
                            "setup_ms": r2.get("setup_ms"),
                            "cpu_baseline": other_cpu.get(name)}
+            cb2 = other_cpu.get(name)
+            if cb2 and other[name]["setup_ms"] is not None:
+                # what the reference on all host cores needs for the same batch, once (from its measured rate on the bounded sample)
+                other[name]["setup_ms"]["cpu_one_shot_ms"] = round(r2["units"] / (cb2["value"] * 1e6) * 1e3, 2)
             if r2.get("flatten_entry"):
                 other[name]["entry"] = r2["flatten_entry"]
                 if r2.get("two_phase_ms_per_step") is not None:
@@ -1168,6 +1228,8 @@ def main():
             "configs": other,
         }
         out["setup_ms"] = res.get("setup_ms")
+        if cpu and out["setup_ms"] is not None:
+            out["setup_ms"]["cpu_one_shot_ms"] = round(total_units / world / (cpu["value"] * 1e6) * 1e3, 2)
         if res.get("cold_ms_per_step") is not None and world == 1:
             # count + emit per step: the flattener and the sizing passes back inside what is reported
             out["ms_per_step_cold"] = round(res["cold_ms_per_step"], 3)
@@ -1247,21 +1309,80 @@ def main():
         if out.get("ms_per_step_cold") is not None:
             out["config"]["ms_per_step_cold"] = out["ms_per_step_cold"]
             out["config"]["value_cold"] = out["value_cold"]
-        # key order: contract keys, summary, details, summary again at the very end
-        head_keys = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
-        ordered = {k: out[k] for k in head_keys}
-        ordered["summary"] = summary
-        for k, v in out.items():
-            if k not in ordered:
-                ordered[k] = v
-        ordered["summary_tail"] = summary
-        out = ordered
+        # ---- what is printed (round 6). The driver parses ONE JSON line from stdout; round 5's 34.5 KB line came back unparsed. The
+        # line is now SHORT (< 8 KB, asserted by tests/test_gpu_bench_contract.py and here): the contract keys, `roofline`,
+        # `cpu_baseline`, and the other configs' numbers as flat scalars inside `config`. Everything else (`configs`, `next_rows`,
+        # `stage_ms`, sweeps, `summary`, the environment) goes to bench_details.json next to bench.py (--details PATH) and to stderr.
+        full = dict(out)
+        full["summary"] = summary
+        rf = dict(out["roofline"])
+        rf.pop("by_kernel", None)
+        cfg = out["config"]
+        for name, o in (other or {}).items():
+            if isinstance(o, dict) and "error" not in o:
+                cb = o.get("cpu_baseline")
+                if cb:
+                    cfg["%s_cpu_value" % name] = cb["value"]
+                su = o.get("setup_ms") or {}
+                if su.get("one_shot_ms") is not None:
+                    cfg["%s_one_shot_ms" % name] = su["one_shot_ms"]
+                if su.get("cpu_one_shot_ms") is not None:
+                    cfg["%s_cpu_one_shot_ms" % name] = su["cpu_one_shot_ms"]
+                r2f = o.get("roofline") or {}
+                if name in ("cubics1m", "round10k") and r2f.get("traffic_ratio") is not None:
+                    cfg["%s_traffic_ratio" % name] = r2f["traffic_ratio"]
+                if name in ("cubics1m", "round10k") and isinstance(r2f.get("secondary"), dict):
+                    cfg["%s_valu_issue_frac" % name] = r2f["secondary"].get("frac")
+        if (res.get("setup_ms") or {}).get("one_shot_ms") is not None:
+            cfg["one_shot_ms"] = res["setup_ms"]["one_shot_ms"]
+            if res["setup_ms"].get("cpu_one_shot_ms") is not None:
+                cfg["cpu_one_shot_ms"] = res["setup_ms"]["cpu_one_shot_ms"]
+        for name, o in (other or {}).items():
+            su = (o.get("setup_ms") or {}) if isinstance(o, dict) else {}
+            if name in ("cubics1m", "round10k") and su.get("pathset_create") is not None:
+                cfg["%s_pathset_create_ms" % name] = su["pathset_create"]
+                cfg["%s_h2d_draws_GBps" % name] = su.get("h2d_draws_GBps")
+        cpu_short = None
+        if cpu is not None:
+            cpu_short = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "sample", "value_sse_stroker", "single_core_value")}
+        head_keys = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"]
+        short = {k: out[k] for k in head_keys}
+        short["config"] = cfg
+        short["roofline"] = rf
+        short["cpu_baseline"] = cpu_short
+        for k in ("ms_per_step_cold", "value_cold", "ms_per_step_sustained", "value_sustained", "ms_per_step_by_rank", "gather_ms", "value_with_gather",
+                  "ms_per_step_with_overlapped_gather", "value_with_overlapped_gather", "ms_per_step_with_tiled_gather", "value_with_tiled_gather",
+                  "gather_tiles", "gather_check", "tiled_gather_check"):
+            if out.get(k) is not None:
+                short[k] = out[k]
+        if gather_via is not None:
+            short["gather_via"] = gather_via[:120]
+        if hetero is not None:
+            short["heterogeneous_partition"] = {k: hetero.get(k) for k in ("balanced_max_over_min", "equal_count_max_over_min", "slowest_rank_gain", "error") if hetero.get(k) is not None}
+        short["details"] = os.path.basename(args.details)
+        short = _finite(short)
+        line = json.dumps(short, allow_nan=False)
+        if len(line) >= 8192:  # never again: drop the optional scalars rather than print a line the driver cannot read
+            cfg = short["config"]
+            for k in [k for k in cfg if k not in ("workload", "name", "instances_per_gpu", "draws_per_gpu", "parallelism", "verts_per_gpu", "indices_per_gpu",
+                                                   "meshes_per_gpu", "cubics1m_ms_per_step", "round10k_ms_per_step", "cubics1m_dominant_frac", "round10k_dominant_frac")]:
+                cfg.pop(k)
+            line = json.dumps(short, allow_nan=False)
+        assert len(line) < 8192, len(line)
+        details = json.dumps(full)
+        try:
+            with open(args.details, "w") as f:
+                f.write(details + "\n")
+        except OSError as e:
+            sys.stderr.write("bench_details: could not write %s: %r\n" % (args.details, e))
         try:  # RCCL writes a version banner to the C stdout at communicator creation: get it out BEFORE the JSON line
             import ctypes
             ctypes.CDLL(None).fflush(None)
         except OSError:
             pass
-        print(json.dumps(out), flush=True)
+        sys.stderr.write("bench_details: " + details + "\n")
+        sys.stderr.flush()
+        print(line, flush=True)  # the LAST line of stdout
     if bail:
         os._exit(0)
     if world > 1:

@@ -250,7 +250,10 @@ uint32_t vgx_version(void);
 uint64_t vgx_scratch_bytes(const vgx_ctx* ctx);
 
 /* ---- path definitions --------------------------------------------------------------------- */
-/* Validates (host) and uploads a path set. Grammar per path: first command must start a sub-path
+/* Validates and uploads a path set (round 6: on the DEVICE -- the four arrays go up as they are, the grammar checks are a
+ * flagged reduction and every derived table is built by kernels, csrc/vgx_pathset.hip; what the reference does per command
+ * while a path is recorded, path.cpp:62-84, 684-726, 761-784. The host reads one 32-byte record at the end; an invalid set
+ * is handed to vgx_pathset_validate, which names the status). Grammar per path: first command must start a sub-path
  * (MOVE_TO, ARC, or a closed shape RECT, ROUNDED_RECT[_VARYING], CIRCLE, ELLIPSE); after CLOSE or a closed
  * shape the next command must start a sub-path again (the reference only VG_CHECKs this in debug
  * builds, path.cpp:82,88,764-765). Non-finite arguments are rejected. Synchronous.
@@ -259,6 +262,12 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx);
  * the vertex pathClose pops, the sub-path table: none of it depends on a draw -- and vgx_tessellate then moves such a
  * set's vertices through the draws' transforms without deciding anything again (csrc/vgx_thin.h; same output). */
 int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset** out_ps);
+/* Inspection (tests): one of the set's device tables copied to host memory; *bytes = its size (dst may be NULL to ask).
+ * VGX_PS_TABLE_SCALARS: uint32[8] = longest path in commands, has serial paths, has empty paths, static thin layout, sub-paths,
+ * npaths, ncmd, 0. */
+enum { VGX_PS_TABLE_CMD_FLAGS = 0, VGX_PS_TABLE_SP_START = 1, VGX_PS_TABLE_PATH_FLAGS = 2, VGX_PS_TABLE_CMDREC = 3, VGX_PS_TABLE_PATH_SUB_BEGIN = 4,
+       VGX_PS_TABLE_SUB_LAST_CMD = 5, VGX_PS_TABLE_CMDTHIN = 6, VGX_PS_TABLE_THIN_PATH = 7, VGX_PS_TABLE_THIN_SUB = 8, VGX_PS_TABLE_SCALARS = 9 };
+int vgx_pathset_read_table(vgx_ctx* ctx, const vgx_pathset* ps, int which, void* dst, uint64_t cap_bytes, uint64_t* bytes);
 /* The validation step of vgx_pathset_create alone (host only, needs no device). */
 int vgx_pathset_validate(const vgx_pathset_desc* desc);
 int vgx_pathset_destroy(vgx_ctx* ctx, vgx_pathset* ps);

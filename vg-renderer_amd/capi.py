@@ -191,6 +191,7 @@ VGX_SYMBOLS = {
     "vgx_pathset_create": (C.c_int, [C.c_void_p, C.POINTER(PathSetDesc), C.POINTER(C.c_void_p)]),
     "vgx_partition": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p]),
     "vgx_pathset_validate": (C.c_int, [C.POINTER(PathSetDesc)]),
+    "vgx_pathset_read_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vgx_pathset_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vgx_flatten_count": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Sizes), C.c_void_p]),
     "vgx_flatten_emit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(FlatOut), C.c_void_p]),

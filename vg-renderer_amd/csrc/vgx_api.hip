@@ -13,6 +13,8 @@
 #include "vgx_inst.h"
 #include "vgx_flat1.h"
 #include "vgx_thin.h"
+#include "vgx_pathset_dev.h"
+#include "vgx_mscan.h"
 #include <vector>
 #include <atomic>
 #include <unordered_map>
@@ -48,6 +50,7 @@ struct vgx_pathset
 	uint32_t maxCmdsPerPath;
 	bool hasSerial; // some path takes the exact serial builder (ARC / ARC_TO / closed shapes)
 	bool hasEmpty;  // some path has no commands
+	uint32_t numSubs; // sub-paths of the set (entries of sub_last_cmd / thin_sub)
 	bool thinStatic; // every path is MOVE_TO / LINE_TO / CLOSE only and the static layout tables are filled (vgx_thin.h): k_flatten_thin builds its batches
 	uint64_t gen; // unique per vgx_pathset_create (process-wide counter): identifies the path set where an address could be reused
 };
@@ -69,6 +72,10 @@ struct vgx_ctx
 	bool asmArmed;
 	DevBuf subPrefix; // exclusive scan of the draws' static sub-path counts
 	DevBuf cmdPrefix, cmdCnt, subFirst, leafOverflow, serialList, dinfo, poly, subs, mdesc, elemPrefix, elemPrefixS, mprep, mtab, partial, totals;
+	DevBuf psTemp;                       // vgx_pathset_create: temporaries of the device-side build (vgx_pathset.hip)
+	hipStream_t psStream;                // ... its stream (created at the first call)
+	struct VgxPsTotals* hostPs;          // ... pinned: what the build reports
+	void* psStage[2]; hipEvent_t psStageEv[2]; bool psStageBusy[2]; uint64_t psStageK; int optPsStage; // VGX_PS_UPLOAD=stage: own pinned staging
 	DevBuf f1SegDraw, f1Segs;            // vgx_flatten (vgx_flat1.hip): segment table, look-back records
 	int optF1Waves, optF1Cap, optF1Seg;  // its grid (persistent one-wave workgroups), the leaf-list capacity of the kernel instance and the segment bucket (0 = chosen per batch)
 	// what the last vgx_flatten call produced (copied to pinned memory behind the call, read by the next call WITHOUT waiting for
@@ -732,6 +739,7 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	}
 	// tuning / testing knobs: read once here, never on the call path
 	ctx->optTwoPass = getenv("VGX_TWO_PASS_FLATTEN") ? 1 : 0;
+	if (const char* e = getenv("VGX_PS_UPLOAD")) { ctx->optPsStage = strcmp(e, "stage") == 0; }
 	ctx->optBuildWaves = VGX_BUILD_WAVES;
 	ctx->optConcurrentEmit = getenv("VGX_EXP_CONCURRENT_EMIT") ? 1 : 0;
 	ctx->optNoSmall = getenv("VGX_NO_SMALL") ? 1 : 0; // testing knob: frame-sized batches through the large-batch launch sequence
@@ -770,12 +778,15 @@ int vgx_destroy(vgx_ctx* ctx)
 		return VGX_E_INVALID_ARG;
 	}
 	DeviceGuard guard(ctx);
-	DevBuf* bufs[] = { &ctx->f1SegDraw, &ctx->f1Segs, &ctx->tmplHash, &ctx->tmplInstCls, &ctx->tmplClsRep, &ctx->tmplCls, &ctx->tmplIinfo, &ctx->tmplWg, &ctx->tmplTrmesh, &ctx->tmplTmsz, &ctx->tmplRsz, &ctx->tmplRelem, &ctx->tmplMplace, &ctx->tmplItot, &ctx->tmplIplace, &ctx->tmplTile, &ctx->tmplPoly, &ctx->tmplMesh, &ctx->tmplMtab, &ctx->tmplElem, &ctx->tmplDraws, &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DevBuf* bufs[] = { &ctx->psTemp, &ctx->f1SegDraw, &ctx->f1Segs, &ctx->tmplHash, &ctx->tmplInstCls, &ctx->tmplClsRep, &ctx->tmplCls, &ctx->tmplIinfo, &ctx->tmplWg, &ctx->tmplTrmesh, &ctx->tmplTmsz, &ctx->tmplRsz, &ctx->tmplRelem, &ctx->tmplMplace, &ctx->tmplItot, &ctx->tmplIplace, &ctx->tmplTile, &ctx->tmplPoly, &ctx->tmplMesh, &ctx->tmplMtab, &ctx->tmplElem, &ctx->tmplDraws, &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
 	if (ctx->hostTotals) { (void)hipHostFree(ctx->hostTotals); }
 	if (ctx->hostF1) { (void)hipHostFree(ctx->hostF1); }
+	if (ctx->hostPs) { (void)hipHostFree(ctx->hostPs); }
+	if (ctx->psStream) { (void)hipStreamDestroy(ctx->psStream); }
+	for (int i = 0; i < 2; ++i) { if (ctx->psStage[i]) { (void)hipHostFree(ctx->psStage[i]); (void)hipEventDestroy(ctx->psStageEv[i]); } }
 	vgx_rccl_release(ctx);
 	if (ctx->sideStream) { (void)hipStreamDestroy(ctx->sideStream); (void)hipEventDestroy(ctx->forkEv); (void)hipEventDestroy(ctx->joinEv); }
 	if (ctx->evCreated) {
@@ -792,7 +803,7 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx)
 	if (!ctx) {
 		return 0;
 	}
-	return ctx->f1SegDraw.cap + ctx->f1Segs.cap + ctx->tmplHash.cap + ctx->tmplInstCls.cap + ctx->tmplClsRep.cap + ctx->tmplCls.cap + ctx->tmplIinfo.cap + ctx->tmplWg.cap + ctx->tmplTrmesh.cap + ctx->tmplTmsz.cap + ctx->tmplRsz.cap + ctx->tmplRelem.cap + ctx->tmplMplace.cap + ctx->tmplItot.cap + ctx->tmplIplace.cap + ctx->tmplTile.cap + ctx->tmplPoly.cap + ctx->tmplMesh.cap + ctx->tmplMtab.cap + ctx->tmplElem.cap + ctx->tmplDraws.cap + ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
+	return ctx->psTemp.cap + ctx->f1SegDraw.cap + ctx->f1Segs.cap + ctx->tmplHash.cap + ctx->tmplInstCls.cap + ctx->tmplClsRep.cap + ctx->tmplCls.cap + ctx->tmplIinfo.cap + ctx->tmplWg.cap + ctx->tmplTrmesh.cap + ctx->tmplTmsz.cap + ctx->tmplRsz.cap + ctx->tmplRelem.cap + ctx->tmplMplace.cap + ctx->tmplItot.cap + ctx->tmplIplace.cap + ctx->tmplTile.cap + ctx->tmplPoly.cap + ctx->tmplMesh.cap + ctx->tmplMtab.cap + ctx->tmplElem.cap + ctx->tmplDraws.cap + ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
 }
 
 // ---- path set ---------------------------------------------------------------------------------------
@@ -812,6 +823,68 @@ int vgx_pathset_validate(const vgx_pathset_desc* desc)
 	return vgx_pathset_validate_host(desc, &cmdFlags, &spStart, &pathFlags, &maxCmds);
 }
 
+// The caller's arrays are ordinary host memory: hipMemcpyAsync moves them (the runtime pins pageable ranges in place for large
+// copies: 22 GB/s cold, 55 GB/s for a range it has seen, profiles/micro/h2d_probe.hip), or -- VGX_PS_UPLOAD=stage at vgx_create --
+// two 8 MB pinned buffers of the context, filled by memcpy while the other one is on the wire (28 GB/s whatever the runtime does).
+static int psUpload(vgx_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s)
+{
+	if (!bytes) { return VGX_OK; }
+	if (!ctx->optPsStage) {
+		HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+		return VGX_OK;
+	}
+	const size_t chunk = (size_t)8 << 20;
+	for (int i = 0; i < 2; ++i) {
+		if (!ctx->psStage[i]) {
+			HIPCHK(ctx, hipHostMalloc(&ctx->psStage[i], chunk, hipHostMallocDefault));
+			HIPCHK(ctx, hipEventCreateWithFlags(&ctx->psStageEv[i], hipEventDisableTiming));
+			ctx->psStageBusy[i] = false;
+		}
+	}
+	for (size_t o = 0; o < bytes; o += chunk) {
+		const int i = (int)(ctx->psStageK++ & 1u);
+		const size_t n = bytes - o < chunk ? bytes - o : chunk;
+		if (ctx->psStageBusy[i]) { HIPCHK(ctx, hipEventSynchronize(ctx->psStageEv[i])); }
+		memcpy(ctx->psStage[i], (const uint8_t*)src + o, n);
+		HIPCHK(ctx, hipMemcpyAsync((uint8_t*)dst + o, ctx->psStage[i], n, hipMemcpyHostToDevice, s));
+		HIPCHK(ctx, hipEventRecord(ctx->psStageEv[i], s));
+		ctx->psStageBusy[i] = true;
+	}
+	return VGX_OK;
+}
+
+struct VgxPsLayout
+{
+	size_t oArgs, oArgOff, oSpStart, oPathBegin, oType, oFlags, oPathFlags, oRec, oSubBegin, oSubLast, oThin, oThinPath, oThinSub, total;
+};
+// One blob: [args (2 floats of padding in front: the start-point gather of command 0 reads args[-2..-1])] [arg offsets] ... The
+// sub-path tables are sized for the most sub-paths `ncmd` commands can hold (every command ends one): what the set really has is
+// known only after the scan, and 12 bytes per command of head room are nothing against 288 GB.
+static VgxPsLayout psLayout(uint32_t ncmd, uint32_t npaths, uint32_t nargs)
+{
+	auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	VgxPsLayout L;
+	L.oArgs = 0;
+	L.oArgOff = align(L.oArgs + ((size_t)nargs + 4) * sizeof(float));
+	L.oSpStart = align(L.oArgOff + ((size_t)ncmd + 1) * sizeof(uint32_t));
+	L.oPathBegin = align(L.oSpStart + ((size_t)ncmd + 1) * sizeof(uint32_t));
+	L.oType = align(L.oPathBegin + ((size_t)npaths + 1) * sizeof(uint32_t));
+	L.oFlags = align(L.oType + ncmd + 1);
+	L.oPathFlags = align(L.oFlags + ncmd + 1);
+	L.oRec = align(L.oPathFlags + npaths + 4);
+	L.oSubBegin = align(L.oRec + ((size_t)ncmd + 1) * sizeof(VgxCmdRec));
+	L.oSubLast = align(L.oSubBegin + ((size_t)npaths + 1) * sizeof(uint32_t));
+	L.oThin = align(L.oSubLast + ((size_t)ncmd + 1) * sizeof(uint32_t));
+	L.oThinPath = align(L.oThin + ((size_t)ncmd + 3) * sizeof(VgxCmdThin));
+	L.oThinSub = align(L.oThinPath + ((size_t)npaths + 1) * sizeof(VgxThinPath));
+	L.total = align(L.oThinSub + ((size_t)ncmd + 1) * sizeof(VgxThinSub));
+	return L;
+}
+
+// Round 6: the raw arrays go up as they are and the derived tables are built by kernels (vgx_pathset.hip): grammar checks as a
+// flagged reduction, sub-path heads / path of a command / sub-path ordinals by ONE scan over the commands, the 64-byte command
+// records and the thin records by a lane per command, the static polyline layout of lineTo-only sets by a second scan. The host
+// reads 32 bytes at the end. An invalid set takes the slow path: the host validator names the status.
 int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset** out_ps)
 {
 	DeviceGuard guard(ctx);
@@ -819,125 +892,122 @@ int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset**
 		return VGX_E_INVALID_ARG;
 	}
 	*out_ps = nullptr;
-	std::vector<uint8_t> cmdFlags, pathFlags;
-	std::vector<uint32_t> spStart;
-	uint32_t maxCmds = 0;
-	const int st = vgx_pathset_validate_host(desc, &cmdFlags, &spStart, &pathFlags, &maxCmds);
-	if (st != VGX_OK) {
-		return st;
-	}
+	// the O(1) checks of the validator's head (vgx_pathset_host.h): everything the layout below depends on
+	if (!desc->path_cmd_begin || !desc->cmd_arg_off || (desc->ncmd && !desc->cmd_type)) { return VGX_E_INVALID_ARG; }
+	if (desc->path_cmd_begin[0] != 0 || desc->path_cmd_begin[desc->npaths] != desc->ncmd || desc->cmd_arg_off[0] != 0) { return VGX_E_INVALID_ARG; }
+	if (desc->ncmd >= 0x7FFFFFFFu) { return VGX_E_INVALID_ARG; } // bit 31 of a command index carries a flag in the draw window
 	const uint32_t ncmd = desc->ncmd, npaths = desc->npaths;
 	const uint32_t nargs = desc->cmd_arg_off[ncmd];
-	// one blob: [args (2 floats of padding in front: start-point gather of command 0 reads args[-2..-1])]
-	auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
-	const size_t oArgs = 0;
-	const size_t oArgOff = align(oArgs + (nargs + 4) * sizeof(float));
-	const size_t oSpStart = align(oArgOff + (ncmd + 1) * sizeof(uint32_t));
-	const size_t oPathBegin = align(oSpStart + (ncmd + 1) * sizeof(uint32_t));
-	const size_t oType = align(oPathBegin + (npaths + 1) * sizeof(uint32_t));
-	const size_t oFlags = align(oType + ncmd + 1);
-	const size_t oPathFlags = align(oFlags + ncmd + 1);
-	const size_t oRec = align(oPathFlags + npaths + 1);
-	// per path: the commands that end a sub-path (k_flatten_gather walks these instead of every command)
-	std::vector<uint32_t> pathSubBegin(npaths + 1, 0), subLastCmd;
-	for (uint32_t p = 0; p < npaths; ++p) {
-		pathSubBegin[p] = (uint32_t)subLastCmd.size();
-		for (uint32_t c = desc->path_cmd_begin[p]; c < desc->path_cmd_begin[p + 1]; ++c) {
-			if (cmdFlags[c] & VGX_CF_LAST_IN_SUB) { subLastCmd.push_back(c - desc->path_cmd_begin[p]); }
-		}
-	}
-	pathSubBegin[npaths] = (uint32_t)subLastCmd.size();
-	const size_t oSubBegin = align(oRec + (size_t)(ncmd + 1) * sizeof(VgxCmdRec));
-	const size_t oSubLast = align(oSubBegin + (npaths + 1) * sizeof(uint32_t));
-	const size_t oThin = align(oSubLast + (subLastCmd.size() + 1) * sizeof(uint32_t));
-	const size_t oThinPath = align(oThin + (size_t)(ncmd + 3) * sizeof(VgxCmdThin));
-	const size_t oThinSub = align(oThinPath + (size_t)(npaths + 1) * sizeof(VgxThinPath));
-	const size_t total = align(oThinSub + (subLastCmd.size() + 1) * sizeof(VgxThinSub));
-	std::vector<uint8_t> host(total, 0);
-	memcpy(&host[oSubBegin], pathSubBegin.data(), (npaths + 1) * sizeof(uint32_t));
-	if (!subLastCmd.empty()) { memcpy(&host[oSubLast], subLastCmd.data(), subLastCmd.size() * sizeof(uint32_t)); }
-	if (nargs) { memcpy(&host[oArgs + 2 * sizeof(float)], desc->args, nargs * sizeof(float)); }
-	memcpy(&host[oArgOff], desc->cmd_arg_off, (ncmd + 1) * sizeof(uint32_t));
-	if (ncmd) {
-		memcpy(&host[oSpStart], spStart.data(), ncmd * sizeof(uint32_t));
-		memcpy(&host[oType], desc->cmd_type, ncmd);
-		memcpy(&host[oFlags], cmdFlags.data(), ncmd);
-	}
-	memcpy(&host[oPathBegin], desc->path_cmd_begin, (npaths + 1) * sizeof(uint32_t));
-	// paths of moveTo / lineTo / close only: thin records (VgxCmdThin); a set of such paths only: the static layout tables (vgx_thin.h)
-	bool thinStatic = false;
-	{
-		VgxCmdThin* th = (VgxCmdThin*)&host[oThin] + 1; // th[-1]: padding record
-		vgx_thin_fill(desc, cmdFlags.data(), spStart.data(), pathFlags.data(), th);
-		thinStatic = npaths != 0 && ncmd != 0 && vgx_thin_build(npaths, desc->path_cmd_begin, pathFlags.data(), pathSubBegin.data(), th, (VgxThinPath*)&host[oThinPath], (VgxThinSub*)&host[oThinSub]);
-	}
-	if (npaths) { memcpy(&host[oPathFlags], pathFlags.data(), npaths); }
-	{
-		VgxCmdRec* rec = (VgxCmdRec*)&host[oRec];
-		for (uint32_t c = 0; c < ncmd; ++c) {
-			VgxCmdRec& r = rec[c];
-			const uint32_t ao = desc->cmd_arg_off[c];
-			r.type = desc->cmd_type[c];
-			r.flags = cmdFlags[c];
-			r.na = desc->cmd_arg_off[c + 1] - ao;
-			r.arg_off = ao;
-			r.start[0] = ao >= 2 ? desc->args[ao - 2] : 0.0f;
-			r.start[1] = ao >= 2 ? desc->args[ao - 1] : 0.0f;
-			for (uint32_t i = 0; i < 8; ++i) { r.a[i] = (i < r.na && r.type != VGX_CMD_POLYLINE) ? desc->args[ao + i] : 0.0f; }
-			if (r.type <= VGX_CMD_CLOSE || r.type == VGX_CMD_POLYLINE) {
-				// first point of the command's sub-path (its MOVE_TO): pathClose's last-vs-first test (path.cpp:716-722)
-				// is evaluated by the CLOSE lane and by the lane in front of it
-				const uint32_t hc = spStart[c];
-				if (desc->cmd_type[hc] == VGX_CMD_MOVE_TO) {
-					const uint32_t ho = desc->cmd_arg_off[hc];
-					r.a[6] = desc->args[ho]; r.a[7] = desc->args[ho + 1];
-				}
-			}
-			r.pad[0] = 0.0f; r.pad[1] = 0.0f;
-		}
-	}
+	if (nargs && !desc->args) { return VGX_E_INVALID_ARG; }
+	const VgxPsLayout L = psLayout(ncmd, npaths, nargs);
+	int st;
+	// temporaries of the build (grow-only context scratch): four words per command, the scans' partials, the totals
+	auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	const size_t words = a256(((size_t)ncmd + 1) * sizeof(uint32_t));
+	const size_t tPartA = 4 * words, tPartB = tPartA + a256(VGX_MSCAN_BLOCKS * sizeof(VgxPsM)), tTot = tPartB + a256(VGX_SCAN_BLOCKS * sizeof(Sum3));
+	if ((st = ensure(ctx, ctx->psTemp, tTot + 256)) != VGX_OK) { return st; }
+	if (!ctx->psStream) { HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->psStream, hipStreamNonBlocking)); }
+	if (!ctx->hostPs) { HIPCHK(ctx, hipHostMalloc((void**)&ctx->hostPs, sizeof(VgxPsTotals), hipHostMallocDefault)); }
+	hipStream_t s = ctx->psStream;
 
 	vgx_pathset* ps = new (std::nothrow) vgx_pathset();
 	if (!ps) {
 		return VGX_E_INVALID_ARG;
 	}
 	ps->blob = nullptr;
-	ps->blobBytes = total;
-	ps->maxCmdsPerPath = maxCmds;
-	ps->hasSerial = false;
-	ps->hasEmpty = false;
-	for (uint32_t i = 0; i < npaths; ++i) {
-		if (pathFlags[i] & VGX_PF_SERIAL) { ps->hasSerial = true; }
-		if (desc->path_cmd_begin[i + 1] == desc->path_cmd_begin[i]) { ps->hasEmpty = true; }
-	}
-	hipError_t e = hipMalloc(&ps->blob, total);
-	if (e == hipSuccess) { e = hipMemcpy(ps->blob, host.data(), total, hipMemcpyHostToDevice); }
+	ps->blobBytes = L.total;
+	hipError_t e = hipMalloc(&ps->blob, L.total);
 	if (e != hipSuccess) {
 		ctx->lastHipError = (int)e;
-		if (ps->blob) { (void)hipFree(ps->blob); }
 		delete ps;
 		return VGX_E_HIP;
 	}
 	uint8_t* b = (uint8_t*)ps->blob;
-	ps->dev.args = (const float*)(b + oArgs) + 2;
-	ps->dev.cmd_arg_off = (const uint32_t*)(b + oArgOff);
-	ps->dev.cmd_sp_start = (const uint32_t*)(b + oSpStart);
-	ps->dev.path_cmd_begin = (const uint32_t*)(b + oPathBegin);
-	ps->dev.cmd_type = b + oType;
-	ps->dev.cmd_flags = b + oFlags;
-	ps->dev.path_flags = b + oPathFlags;
-	ps->dev.cmdrec = (const VgxCmdRec*)(b + oRec);
-	ps->dev.cmdthin = (const VgxCmdThin*)(b + oThin) + 1;
-	ps->dev.thin_path = (const VgxThinPath*)(b + oThinPath);
-	ps->dev.thin_sub = (const VgxThinSub*)(b + oThinSub);
-	ps->thinStatic = thinStatic;
-	ps->dev.path_sub_begin = (const uint32_t*)(b + oSubBegin);
-	ps->dev.sub_last_cmd = (const uint32_t*)(b + oSubLast);
+	uint8_t* t = (uint8_t*)ctx->psTemp.p;
+	auto fail = [&](int code) { (void)hipStreamSynchronize(s); (void)hipFree(ps->blob); delete ps; return code; };
+	// the derived part of the blob starts from zero (padding records, flag bytes the kernels OR into); the raw arrays land on top
+	e = hipMemsetAsync(b, 0, L.total, s);
+	if (e == hipSuccess) { e = hipMemsetAsync(t, 0, words, s); }                                  // pathAt
+	if (e == hipSuccess) { e = hipMemsetAsync(t + 2 * words, 0, sizeof(uint32_t), s); }          // lastSubEx[0] (a set without commands)
+	if (e == hipSuccess) { e = hipMemsetAsync(t + tTot, 0, sizeof(VgxPsTotals), s); }
+	if (e != hipSuccess) { ctx->lastHipError = (int)e; return fail(VGX_E_HIP); }
+	if ((st = psUpload(ctx, b + L.oArgs + 2 * sizeof(float), desc->args, (size_t)nargs * sizeof(float), s)) != VGX_OK) { return fail(st); }
+	if ((st = psUpload(ctx, b + L.oArgOff, desc->cmd_arg_off, ((size_t)ncmd + 1) * sizeof(uint32_t), s)) != VGX_OK) { return fail(st); }
+	if ((st = psUpload(ctx, b + L.oType, desc->cmd_type, ncmd, s)) != VGX_OK) { return fail(st); }
+	if ((st = psUpload(ctx, b + L.oPathBegin, desc->path_cmd_begin, ((size_t)npaths + 1) * sizeof(uint32_t), s)) != VGX_OK) { return fail(st); }
+	VgxPsBuild B;
+	B.type = b + L.oType; B.argOff = (const uint32_t*)(b + L.oArgOff); B.args = (const float*)(b + L.oArgs) + 2; B.pcb = (const uint32_t*)(b + L.oPathBegin);
+	B.ncmd = ncmd; B.npaths = npaths; B.nargs = nargs;
+	B.spStart = (uint32_t*)(b + L.oSpStart); B.flags = b + L.oFlags; B.pathFlags = b + L.oPathFlags; B.rec = (VgxCmdRec*)(b + L.oRec);
+	B.thin = (VgxCmdThin*)(b + L.oThin) + 1; // thin[-1]: padding record
+	B.subBegin = (uint32_t*)(b + L.oSubBegin); B.subLast = (uint32_t*)(b + L.oSubLast); B.tp = (VgxThinPath*)(b + L.oThinPath); B.ts = (VgxThinSub*)(b + L.oThinSub);
+	B.pathAt = (uint32_t*)t; B.pathOf = (uint32_t*)(t + words); B.lastSubEx = (uint32_t*)(t + 2 * words); B.nvEx = (uint32_t*)(t + 3 * words);
+	B.partialA = (VgxPsM*)(t + tPartA); B.partialB = (Sum3*)(t + tPartB); B.tot = (VgxPsTotals*)(t + tTot);
+	vgx_launch_pathset_build(B, s);
+	e = hipGetLastError();
+	if (e == hipSuccess) { e = hipMemcpyAsync(ctx->hostPs, B.tot, sizeof(VgxPsTotals), hipMemcpyDeviceToHost, s); }
+	if (e == hipSuccess) { e = hipStreamSynchronize(s); }
+	if (e != hipSuccess) { ctx->lastHipError = (int)e; return fail(VGX_E_HIP); }
+	const VgxPsTotals T = *ctx->hostPs;
+	if (T.err) {
+		(void)hipFree(ps->blob);
+		delete ps;
+		const int vst = vgx_pathset_validate(desc); // the slow path of an invalid set: which status it is
+		return vst != VGX_OK ? vst : VGX_E_INTERNAL;
+	}
+	ps->maxCmdsPerPath = T.maxCmds;
+	ps->hasSerial = T.hasSerial != 0;
+	ps->hasEmpty = T.hasEmpty != 0;
+	ps->numSubs = T.nsubs;
+	ps->thinStatic = npaths != 0 && ncmd != 0 && !T.notThin && !T.hasSerial && !T.hasEmpty && !T.thinIneligible;
+	ps->dev.args = (const float*)(b + L.oArgs) + 2;
+	ps->dev.cmd_arg_off = (const uint32_t*)(b + L.oArgOff);
+	ps->dev.cmd_sp_start = (const uint32_t*)(b + L.oSpStart);
+	ps->dev.path_cmd_begin = (const uint32_t*)(b + L.oPathBegin);
+	ps->dev.cmd_type = b + L.oType;
+	ps->dev.cmd_flags = b + L.oFlags;
+	ps->dev.path_flags = b + L.oPathFlags;
+	ps->dev.cmdrec = (const VgxCmdRec*)(b + L.oRec);
+	ps->dev.cmdthin = (const VgxCmdThin*)(b + L.oThin) + 1;
+	ps->dev.thin_path = (const VgxThinPath*)(b + L.oThinPath);
+	ps->dev.thin_sub = (const VgxThinSub*)(b + L.oThinSub);
+	ps->dev.path_sub_begin = (const uint32_t*)(b + L.oSubBegin);
+	ps->dev.sub_last_cmd = (const uint32_t*)(b + L.oSubLast);
 	ps->dev.npaths = npaths;
 	ps->dev.ncmd = ncmd;
 	static std::atomic<uint64_t> s_pathsetGen{0};
 	ps->gen = ++s_pathsetGen;
 	*out_ps = ps;
+	return VGX_OK;
+}
+
+// Testing / inspection: copies one of the set's device tables to host memory (tests/test_gpu_pathset_build.py compares every table
+// with the host restatement of csrc/vgx_pathset_host.h, byte for byte). `bytes` receives the table's size; dst may be NULL to ask.
+int vgx_pathset_read_table(vgx_ctx* ctx, const vgx_pathset* ps, int which, void* dst, uint64_t cap_bytes, uint64_t* bytes)
+{
+	DeviceGuard guard(ctx);
+	if (!ctx || !ps || !bytes) { return VGX_E_INVALID_ARG; }
+	const VgxPathSetDev& d = ps->dev;
+	const void* src = nullptr; uint64_t n = 0;
+	uint32_t scal[8] = { ps->maxCmdsPerPath, ps->hasSerial ? 1u : 0u, ps->hasEmpty ? 1u : 0u, ps->thinStatic ? 1u : 0u, ps->numSubs, d.npaths, d.ncmd, 0u };
+	switch (which) {
+	case VGX_PS_TABLE_CMD_FLAGS: src = d.cmd_flags; n = d.ncmd; break;
+	case VGX_PS_TABLE_SP_START: src = d.cmd_sp_start; n = (uint64_t)d.ncmd * 4; break;
+	case VGX_PS_TABLE_PATH_FLAGS: src = d.path_flags; n = d.npaths; break;
+	case VGX_PS_TABLE_CMDREC: src = d.cmdrec; n = (uint64_t)d.ncmd * sizeof(VgxCmdRec); break;
+	case VGX_PS_TABLE_PATH_SUB_BEGIN: src = d.path_sub_begin; n = ((uint64_t)d.npaths + 1) * 4; break;
+	case VGX_PS_TABLE_SUB_LAST_CMD: src = d.sub_last_cmd; n = (uint64_t)ps->numSubs * 4; break;
+	case VGX_PS_TABLE_CMDTHIN: src = d.cmdthin; n = (uint64_t)d.ncmd * sizeof(VgxCmdThin); break;
+	case VGX_PS_TABLE_THIN_PATH: src = d.thin_path; n = ps->thinStatic ? (uint64_t)d.npaths * sizeof(VgxThinPath) : 0; break;
+	case VGX_PS_TABLE_THIN_SUB: src = d.thin_sub; n = ps->thinStatic ? (uint64_t)ps->numSubs * sizeof(VgxThinSub) : 0; break;
+	case VGX_PS_TABLE_SCALARS: n = sizeof(scal); break;
+	default: return VGX_E_INVALID_ARG;
+	}
+	*bytes = n;
+	if (!dst) { return VGX_OK; }
+	if (cap_bytes < n) { return VGX_E_NOSPACE; }
+	if (which == VGX_PS_TABLE_SCALARS) { memcpy(dst, scal, sizeof(scal)); return VGX_OK; }
+	if (n) { HIPCHK(ctx, hipMemcpy(dst, src, n, hipMemcpyDeviceToHost)); }
 	return VGX_OK;
 }
 
@@ -1122,8 +1192,13 @@ int vgx_flatten(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint
 		&& (double)ctx->hostF1[0] / (double)ctx->hostF1[1] * 64.0 <= 384.0) {
 		const uint64_t ncmdInst = ctx->hostF1[1];
 		if ((st = ensure(ctx, ctx->cmdCnt, (ncmdInst + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
-		ctx->caps.cmd_instances = ctx->cmdCnt.cap / sizeof(uint32_t) - 1; // checked on the device (a batch that grew: VGX_E_NOSPACE)
+		// The device-side guard of THIS call only (a batch that grew: VGX_E_NOSPACE); the context's persistent cap -- what
+		// vgx_tessellate relies on for the scratch sized by the last count -- is put back right after the launch.
+		const uint64_t savedCmdCap = ctx->caps.cmd_instances;
+		ctx->caps.cmd_instances = ctx->cmdCnt.cap / sizeof(uint32_t) - 1;
+		// (the two-walk kernels write per-command words only -- no sub-path records: cmdCnt alone bounds this launch)
 		runCmdPrefix(ctx, ps, draws, ndraws, s);
+		ctx->caps.cmd_instances = savedCmdCap;
 		const VgxCaps saved = ctx->caps;
 		ctx->caps.poly_vertices = out->cap_poly_vertices; ctx->caps.subpaths = out->cap_subpaths; ctx->caps.meshes = ~0ull;
 		runFlattenCount(ctx, ps, draws, ndraws, s); // the scan over the draws compares the totals with the caller's capacities
@@ -1148,8 +1223,12 @@ int vgx_flatten(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint
 	// trip; ndraws x (longest path) bounds it (a batch whose bound is absurdly far above its real size asks once, synchronously).
 	const uint64_t minItems = segMax < 32 ? segMax : 32;
 	uint64_t cmdBound = ndraws * (uint64_t)(ps->maxCmdsPerPath ? ps->maxCmdsPerPath : 1);
-	ctx->caps.cmd_instances = ~0ull;
-	runCmdPrefix(ctx, ps, draws, ndraws, s);
+	{
+		const uint64_t savedCmdCap = ctx->caps.cmd_instances; // k_flat1 needs no per-command scratch: no guard for this launch, the
+		ctx->caps.cmd_instances = ~0ull;                       // persistent cap (vgx_tessellate's guard) stays what the last count made it
+		runCmdPrefix(ctx, ps, draws, ndraws, s);
+		ctx->caps.cmd_instances = savedCmdCap;
+	}
 	if (cmdBound / minItems > (1ull << 26)) {
 		if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }
 		if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; }

@@ -194,3 +194,56 @@ int vgxt_thin_flatten(const vgx_pathset_desc* d, const vgx_draw* draws, uint64_t
 }
 
 }
+
+extern "C" {
+
+// The derived tables of a path set as the host loops build them (vgx_pathset_host.h, vgx_thin.h): the oracle of the device-side
+// build of vgx_pathset_create (vgx_pathset.hip). `which` = VGX_PS_TABLE_* (include/vgx.h). Returns the table's size in bytes
+// (dst may be NULL to ask), < 0 = -(validation status).
+int64_t vgxt_pathset_table(const vgx_pathset_desc* d, int which, void* dst, uint64_t cap)
+{
+	std::vector<uint8_t> cmdFlags, pathFlags;
+	std::vector<uint32_t> spStart, pathSubBegin, subLastCmd;
+	uint32_t maxCmds = 0;
+	const int st = vgx_pathset_validate_host(d, &cmdFlags, &spStart, &pathFlags, &maxCmds);
+	if (st != VGX_OK) { return -(int64_t)st; }
+	vgx_pathset_subs_host(d, cmdFlags.data(), &pathSubBegin, &subLastCmd);
+	std::vector<VgxCmdThin> thv(d->ncmd + 3);
+	memset(thv.data(), 0, thv.size() * sizeof(VgxCmdThin));
+	VgxCmdThin* th = thv.data() + 1;
+	std::vector<VgxThinPath> tp(d->npaths + 1);
+	std::vector<VgxThinSub> ts(subLastCmd.size() + 1);
+	vgx_thin_fill(d, cmdFlags.data(), spStart.data(), pathFlags.data(), th);
+	const bool thinStatic = d->npaths != 0 && d->ncmd != 0 && vgx_thin_build(d->npaths, d->path_cmd_begin, pathFlags.data(), pathSubBegin.data(), th, tp.data(), ts.data());
+	bool hasSerial = false, hasEmpty = false;
+	for (uint32_t i = 0; i < d->npaths; ++i) {
+		if (pathFlags[i] & VGX_PF_SERIAL) { hasSerial = true; }
+		if (d->path_cmd_begin[i + 1] == d->path_cmd_begin[i]) { hasEmpty = true; }
+	}
+	std::vector<VgxCmdRec> rec;
+	const void* src = nullptr; uint64_t n = 0;
+	uint32_t scal[8] = { maxCmds, hasSerial ? 1u : 0u, hasEmpty ? 1u : 0u, thinStatic ? 1u : 0u, (uint32_t)subLastCmd.size(), d->npaths, d->ncmd, 0u };
+	switch (which) {
+	case VGX_PS_TABLE_CMD_FLAGS: src = cmdFlags.data(); n = d->ncmd; break;
+	case VGX_PS_TABLE_SP_START: src = spStart.data(); n = (uint64_t)d->ncmd * 4; break;
+	case VGX_PS_TABLE_PATH_FLAGS: src = pathFlags.data(); n = d->npaths; break;
+	case VGX_PS_TABLE_CMDREC:
+		rec.resize(d->ncmd + 1);
+		vgx_pathset_records_host(d, cmdFlags.data(), spStart.data(), rec.data());
+		src = rec.data(); n = (uint64_t)d->ncmd * sizeof(VgxCmdRec); break;
+	case VGX_PS_TABLE_PATH_SUB_BEGIN: src = pathSubBegin.data(); n = ((uint64_t)d->npaths + 1) * 4; break;
+	case VGX_PS_TABLE_SUB_LAST_CMD: src = subLastCmd.data(); n = (uint64_t)subLastCmd.size() * 4; break;
+	case VGX_PS_TABLE_CMDTHIN: src = th; n = (uint64_t)d->ncmd * sizeof(VgxCmdThin); break;
+	case VGX_PS_TABLE_THIN_PATH: src = tp.data(); n = thinStatic ? (uint64_t)d->npaths * sizeof(VgxThinPath) : 0; break;
+	case VGX_PS_TABLE_THIN_SUB: src = ts.data(); n = thinStatic ? (uint64_t)subLastCmd.size() * sizeof(VgxThinSub) : 0; break;
+	case VGX_PS_TABLE_SCALARS: src = scal; n = sizeof(scal); break;
+	default: return -(int64_t)VGX_E_INVALID_ARG;
+	}
+	if (dst) {
+		if (cap < n) { return -(int64_t)VGX_E_NOSPACE; }
+		if (n) { memcpy(dst, src, n); }
+	}
+	return (int64_t)n;
+}
+
+}

@@ -1,6 +1,9 @@
 // vgx_pathset_host.h -- host-side validation of the command grammar (see include/vgx.h) and derivation of the static
-// per-command structure the kernels use (sub-path heads / tails, serial-path flag). Plain C++: vgx_api.hip
-// (vgx_pathset_validate / vgx_pathset_create) and the CPU build of the lane code (csrc/vgx_hosttest.cpp) share it.
+// per-command structure the kernels use (sub-path heads / tails, serial-path flag). Plain C++. Round 6: vgx_pathset_create
+// builds these tables on the DEVICE (vgx_pathset.hip); what is left of this file in the product is the validator
+// (vgx_pathset_validate, and the slow path that names the status of an invalid set). The table builders below are the ORACLE of
+// the device build: csrc/vgx_hosttest.cpp exports them (vgxt_pathset_table), tests/test_gpu_pathset_build.py compares every
+// table of every set byte for byte.
 #ifndef VGX_PATHSET_HOST_H
 #define VGX_PATHSET_HOST_H
 
@@ -91,6 +94,46 @@ static int vgx_pathset_validate_host(const vgx_pathset_desc* d, std::vector<uint
 		}
 	}
 	return VGX_OK;
+}
+
+// The 64-byte command records (VgxCmdRec): what vgx_pathset_create's kernel k_ps_rec writes, as the host loop it replaced.
+static inline void vgx_pathset_records_host(const vgx_pathset_desc* desc, const uint8_t* cmdFlags, const uint32_t* spStart, VgxCmdRec* rec)
+{
+	for (uint32_t c = 0; c < desc->ncmd; ++c) {
+		VgxCmdRec& r = rec[c];
+		const uint32_t ao = desc->cmd_arg_off[c];
+		r.type = desc->cmd_type[c];
+		r.flags = cmdFlags[c];
+		r.na = desc->cmd_arg_off[c + 1] - ao;
+		r.arg_off = ao;
+		r.start[0] = ao >= 2 ? desc->args[ao - 2] : 0.0f;
+		r.start[1] = ao >= 2 ? desc->args[ao - 1] : 0.0f;
+		for (uint32_t i = 0; i < 8; ++i) { r.a[i] = (i < r.na && r.type != VGX_CMD_POLYLINE) ? desc->args[ao + i] : 0.0f; }
+		if (r.type <= VGX_CMD_CLOSE || r.type == VGX_CMD_POLYLINE) {
+			// first point of the command's sub-path (its MOVE_TO): pathClose's last-vs-first test (path.cpp:716-722)
+			// is evaluated by the CLOSE lane and by the lane in front of it
+			const uint32_t hc = spStart[c];
+			if (desc->cmd_type[hc] == VGX_CMD_MOVE_TO) {
+				const uint32_t ho = desc->cmd_arg_off[hc];
+				r.a[6] = desc->args[ho]; r.a[7] = desc->args[ho + 1];
+			}
+		}
+		r.pad[0] = 0.0f; r.pad[1] = 0.0f;
+	}
+}
+
+// Per path: the commands that end a sub-path (k_flatten_gather walks these instead of every command)
+static inline void vgx_pathset_subs_host(const vgx_pathset_desc* desc, const uint8_t* cmdFlags, std::vector<uint32_t>* pathSubBegin, std::vector<uint32_t>* subLastCmd)
+{
+	pathSubBegin->assign(desc->npaths + 1, 0);
+	subLastCmd->clear();
+	for (uint32_t p = 0; p < desc->npaths; ++p) {
+		(*pathSubBegin)[p] = (uint32_t)subLastCmd->size();
+		for (uint32_t c = desc->path_cmd_begin[p]; c < desc->path_cmd_begin[p + 1]; ++c) {
+			if (cmdFlags[c] & VGX_CF_LAST_IN_SUB) { subLastCmd->push_back(c - desc->path_cmd_begin[p]); }
+		}
+	}
+	(*pathSubBegin)[desc->npaths] = (uint32_t)subLastCmd->size();
 }
 
 #endif

@@ -1715,7 +1715,7 @@ bool vgx_tmpl_round_per_instance(const VgxTmplArgs& a) // which shape vgx_launch
 void vgx_launch_tmpl_round_sizes(const VgxTmplArgs& a, Sum3* partial, hipStream_t s)
 {
 	const uint64_t blocks = a.ninst * a.tiles_per_inst; // the host checked < 2^31
-	if (!blocks) { return; }
+	if (!blocks || a.num_round == 0) { return; } // (no Round-join mesh in the template: nothing to size, and no division by zero below)
 	const uint64_t pairs = a.ninst * (uint64_t)a.num_round; // the host checked < 2^31
 	if (a.num_round_elems / a.num_round > 128u) { hipLaunchKernelGGL(k_tmpl_round_sizes_block, dim3((unsigned)pairs), dim3(256), 0, s, a); } // long meshes: a workgroup each
 	else if (vgx_tmpl_round_per_instance(a)) { // a workgroup per instance: sizes, the meshes' places inside the instance; then the scan over the instances

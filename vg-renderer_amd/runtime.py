@@ -145,11 +145,23 @@ class PathSet:
         return self._h
 
 
-def upload_draws(draws, device=0):
-    """numpy draw records -> uint8 torch tensor in HBM (64 bytes per draw)."""
+def pin_draws(draws):
+    """numpy draw records -> uint8 torch tensor in PINNED host memory: where a caller that cares about the upload writes its draw
+    records in the first place (pageable memory reaches the device at 7-20 GB/s through the runtime's staging, pinned at ~55)."""
     import torch
     raw = np.ascontiguousarray(draws).view(np.uint8).reshape(-1)
-    return torch.from_numpy(raw.copy()).to("cuda:%d" % device)
+    t = torch.empty(raw.shape[0], dtype=torch.uint8, pin_memory=True)
+    t.numpy()[:] = raw
+    return t
+
+
+def upload_draws(draws, device=0):
+    """draw records (numpy, or a pinned uint8 tensor from pin_draws) -> uint8 torch tensor in HBM (64 bytes per draw)."""
+    import torch
+    if isinstance(draws, torch.Tensor):
+        return draws.to("cuda:%d" % device, non_blocking=True)
+    raw = np.ascontiguousarray(draws).view(np.uint8).reshape(-1)
+    return torch.from_numpy(raw).to("cuda:%d" % device)
 
 
 def _stream_ptr():

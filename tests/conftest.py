@@ -14,6 +14,27 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _oracle_kind():
+    import pyoracle
+    return "reference" if pyoracle.available("reference") else ("port" if pyoracle.available("port") else "none")
+
+
+def pytest_report_header(config):
+    return "parity oracle: %s (oracle/_ref/libvgref.so = /root/reference/src/{path,stroker,vg_util}.cpp compiled where they lie; 'port' = the restatement)" % _oracle_kind()
+
+
+def pytest_collection_modifyitems(config, items):
+    """The GPU parity tests are pinned on the reference compiled from its own sources (oracle/_ref). Without it pyoracle would fall
+    back to the builder's restatement SILENTLY: make that a failure of the whole -m gpu run unless VGX_ALLOW_PORT_ORACLE=1 says the
+    restatement is wanted."""
+    if os.environ.get("VGX_ALLOW_PORT_ORACLE") == "1":
+        return
+    if any(it.get_closest_marker("gpu") for it in items) and config.getoption("-m") and "not gpu" not in config.getoption("-m") and _oracle_kind() != "reference":
+        raise pytest.UsageError("oracle/_ref/libvgref.so is missing: the -m gpu parity tests would run against the restatement (oracle/libvgoracle.so), not "
+                                "the reference. Build it here (python -c 'import __graft_entry__ as g; g.build()' with /root/reference present) or set "
+                                "VGX_ALLOW_PORT_ORACLE=1.")
+
+
 @pytest.fixture(scope="session")
 def vgr():
     return importlib.import_module("vg-renderer_amd")

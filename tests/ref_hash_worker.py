@@ -3,7 +3,9 @@ the restatement) over units [first, first + count) of a BASELINE workload and wr
 (tests/hashutil.py) to an .npy file. One process per host core (the reference's subdivision stack is a function-local
 static, src/path.cpp:91).
   python tests/ref_hash_worker.py tiger|tigerspec|tigeropen|tigerbevel <first instance> <count> out.npy     rows: [count, 3, 4] (pos, colour, idx)
-  python tests/ref_hash_worker.py varied|tigerround <first instance> <count> out.npy    rows: [count, 3, 4] + sizes [count, 2] (instances of different sizes)
+  python tests/ref_hash_worker.py varied|tigerround|tigerroundwide|variedround <first instance> <count> out.npy    rows: [count, 3, 4] + sizes [count, 2] (instances of different sizes)
+      tigerroundwide: Round joins, strokes six times as wide, every instance stretched by its own (1 + e, 1 - e): the arcs of the joins have different
+      point counts from instance to instance;  variedround: the seven-scale batch with Round joins
   python tests/ref_hash_worker.py round <first polyline> <count> out.npy               rows: [count, 3, 4] + sizes [count, 2]
   python tests/ref_hash_worker.py cubics <first path> <count> out.npy                  rows: [count, 1, 4] + sizes [count, 1]
   python tests/ref_hash_worker.py cubics@<box>:<paths> <first path> <count> out.npy    the same for `paths` cubics in [0, box) (SURVEY 8(d) config 2's box sweep)"""
@@ -37,16 +39,18 @@ def main():
             rows.append(np.stack([hu.digest_uniform_np(r.pos.view(np.uint32).reshape(-1), n), hu.digest_uniform_np(r.color, n),
                                   hu.digest_uniform_np(r.idx.astype(np.uint32), n)], axis=1))
         np.save(out, np.concatenate(rows))
-    elif which in ("varied", "tigerround"):
+    elif which in ("varied", "tigerround", "tigerroundwide", "variedround"):
         ps, ops = wl.tiger_paths()
+        if which == "tigerroundwide":
+            ops = [dict(op, stroke_width=op["stroke_width"] * 6.0) for op in ops]
         P = len(ops)
         rows = []
         B = 16
         # the batch the test tessellates (varied: the generator's angles depend on the batch size; tigerround: Round joins, the instances' sizes differ)
-        whole = wl.tiger_varied_draws(ops, 10000) if which == "varied" else None
+        whole = wl.tiger_varied_draws(ops, 10000, join=1 if which == "variedround" else 0) if which in ("varied", "variedround") else None
         for a in range(first, first + count, B):
             n = min(B, first + count - a)
-            d = whole[a * P:(a + n) * P] if which == "varied" else wl.tiger_draws(ops, n, first_instance=a, join=1)
+            d = whole[a * P:(a + n) * P] if whole is not None else wl.tiger_draws(ops, n, first_instance=a, join=1, stretch=which == "tigerroundwide")
             r = pyoracle.tessellate(ps, d)
             m = r.meshes
             m0 = np.searchsorted(m["draw"], np.arange(n + 1, dtype=np.int64) * P, side="left")  # first mesh of every instance

@@ -178,6 +178,58 @@ def test_every_instance_of_tiger_x10k_with_round_joins_matches_the_reference(rt,
     ctx.close()
 
 
+@pytest.mark.parametrize("which", ["tigerroundwide", "variedround"])
+def test_every_instance_with_round_joins_of_different_sizes_matches_the_reference(rt, wl, which):
+    """Round joins where the sizes really differ, at full size. tigerroundwide: Tiger x10k, strokes six times as wide and
+    every instance stretched by its own (1 + e, 1 - e) (avgScale stays 1: ONE template class) -- the joins' arcs have different point counts
+    from instance to instance, so the per-step sizes pass, the scan over all meshes and the device-side capacity check of the Round-join
+    template see 10 000 instances of (33 distinct) sizes. variedround: Tiger x10k at seven scales (18 tolerance classes) with Round joins
+    -- Round-join templates are built for one class only, the batch takes the ordinary pipeline (k_flatten_inst + k_round_sizes + k_stroke).
+    Digests of positions / colours / indices and the sizes of every instance against the reference's; the mesh table against the streams."""
+    import torch
+    K = 10000
+    ps, ops = wl.tiger_paths()
+    P = len(ops)
+    if which == "tigerroundwide":
+        d = wl.tiger_draws([dict(op, stroke_width=op["stroke_width"] * 6.0) for op in ops], K, join=1, stretch=True)
+    else:
+        d = wl.tiger_varied_draws(ops, K, join=1)
+    ctx = rt.Context(0)
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(d)
+    sizes = rt.tessellate_count(ctx, pset, dd, d.shape[0])
+    mode = ctx.failure_info()["segment_items"]
+    assert mode == (5 if which == "tigerroundwide" else 4), mode  # template mode / instances sorted by tolerance class
+    nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
+    bufs = rt.MeshBuffers(dd.device, nv, ni, nm)
+    bufs.pos.fill_(float("nan"))
+    ctx.set_profiling(True)
+    rt.tessellate_async(ctx, pset, dd, d.shape[0], bufs)
+    torch.cuda.synchronize()
+    stages = [n for n, _ in ctx.stage_times()]
+    ctx.set_profiling(False)
+    if which == "tigerroundwide":
+        assert stages == ["tmpl_round_sizes", "tmpl_emit"], stages
+    assert int(bufs.dev_status.item()) == 0
+    ref = _reference_rows(which, K)  # [K, 12 + 2]
+    assert len(np.unique(ref[:, 12])) > 8, "the instances differ in size"
+    mt = bufs.meshes[:nm * 32].view(torch.int64).view(-1, 4)
+    draw = (mt[:, 3] & 0xFFFFFFFF).contiguous()
+    m0 = torch.searchsorted(draw, torch.arange(K + 1, dtype=torch.int64, device=draw.device) * P)  # first mesh of every instance
+    fvm = torch.cat([mt[:, 0], torch.tensor([nv], dtype=torch.int64, device=draw.device)])
+    fim = torch.cat([mt[:, 1], torch.tensor([ni], dtype=torch.int64, device=draw.device)])
+    assert torch.equal(fvm[1:], fvm[:-1] + (mt[:, 2] & 0xFFFFFFFF)) and torch.equal(fim[1:], fim[:-1] + ((mt[:, 2] >> 32) & 0xFFFFFFFF))
+    fv, fi = fvm[m0[:-1]], fim[m0[:-1]]
+    cv, ci = fvm[m0[1:]] - fv, fim[m0[1:]] - fi
+    assert np.array_equal(cv.cpu().numpy(), ref[:, 12]) and np.array_equal(ci.cpu().numpy(), ref[:, 13])
+    got = np.concatenate([hu.digest_ragged_torch(bufs.pos[:nv].view(torch.int32), 2 * fv, 2 * cv), hu.digest_ragged_torch(bufs.color[:nv], fv, cv),
+                          hu.digest_ragged_torch(bufs.idx[:ni], fi, ci, is_u16=True)], axis=1)
+    bad = np.flatnonzero((got != ref[:, :12]).any(axis=1))
+    assert bad.shape[0] == 0, ("instances that differ from the reference", bad[:10].tolist(), bad.shape[0])
+    pset.close()
+    ctx.close()
+
+
 def test_every_mesh_of_the_round_join_polylines_matches_the_reference(rt, wl):
     """BASELINE configs[3]: 10 000 polylines x 1 000 segments, Round joins + Round caps (data-dependent mesh sizes)."""
     import torch

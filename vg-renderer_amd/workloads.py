@@ -151,7 +151,7 @@ def tiger(instances, seed=2024, first_instance=0):
     return ps, tiger_draws(ops, instances, first_instance)
 
 
-def tiger_varied_draws(ops, instances, first_instance=0, seed=77):
+def tiger_varied_draws(ops, instances, first_instance=0, seed=77, join=capi.JOIN_MITER):
     """Tiger instances that do NOT share one subdivision: instance i is drawn at scale s_i in {0.5, 1, 1.5, 2, 2.5, 3, 3.5}
     under a rotation, i.e. what a caller's State would hold after transformScale / transformRotate / transformTranslate
     (updateState: avgScale = mean of the column norms, vg.cpp:4927-4935). The flatten tolerance and the stroke widths
@@ -179,7 +179,7 @@ def tiger_varied_draws(ops, instances, first_instance=0, seed=77):
         for p, op in enumerate(ops):
             set_fill(one, p, op["fill_color"], aa=True)
             if op["stroke"]:
-                set_stroke(one, p, op["stroke_color"], op["stroke_width"], capi.CAP_BUTT, capi.JOIN_MITER, aa=True, avg_scale=float(a))
+                set_stroke(one, p, op["stroke_color"], op["stroke_width"], capi.CAP_BUTT, join, aa=True, avg_scale=float(a))
         tables[float(a)] = one
     d = np.concatenate([tables[float(a)] for a in avg])
     d["mtx"] = np.repeat(m, npaths, axis=0)

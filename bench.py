@@ -685,6 +685,20 @@ def frame_leg(rt, torch, ctx, local_rank):
             torch.cuda.synchronize()
             p2.close()
         whole_us = (time.perf_counter() - t0) / Rw * 1e6
+        # ... and as a renderer in steady state runs it: the context's scratch and the output capacities are what the last frames
+        # needed (the reference's Path / Stroker / vertex buffers are grow-only too), so a frame is decode + new path set + uploads +
+        # ONE asynchronous vgx_tessellate (capacities checked on the device: VGX_E_NOSPACE in dev_status would ask for a count) + wait
+        t0 = time.perf_counter()
+        for _ in range(Rw):
+            rc2, ps2, dr2, _n2 = cm.decode(rt, data, **kw)
+            p2 = rt.PathSet(ctx, ps2)
+            d2 = rt.upload_draws(dr2, local_rank)
+            rt.tessellate_async(ctx, p2, d2, nd, bufs)
+            torch.cuda.synchronize()
+            p2.close()
+        whole1_us = (time.perf_counter() - t0) / Rw * 1e6
+        assert int(bufs.dev_status.item()) == 0
+        out["whole_frame_us_from_recorded_bytes_single_call"] = round(whole1_us, 1)
         # the same frame as a STATIC batch (vgx_set_static_batches: a retained command list re-submitted under a new camera): the count
         # flattens the list once, a frame is then the template emit kernel (+ the assembly kernels while armed)
         ctx.set_static_batches(True)
@@ -1297,10 +1311,12 @@ def main():
         if fr1 and "error" not in fr1:  # one real frame, microseconds (next_rows.frame_tiger_x1 has the workload and every step)
             summary["frame_tiger_x1"] = {k: fr1.get(k) for k in ("decode_us", "decode_MB_per_s", "tessellate_assembled_us_back_to_back", "tessellate_assembled_us_with_sync",
                                                                  "tessellate_assembled_us_hip_graph_replay", "static_tessellate_assembled_us_back_to_back", "static_tessellate_meshes_only_us_back_to_back", "static_equals_reference_frame",
-                                                                 "whole_frame_us_from_recorded_bytes", "reference_context_us_per_frame_one_core", "equals_reference_frame")}
+                                                                 "whole_frame_us_from_recorded_bytes", "whole_frame_us_from_recorded_bytes_single_call", "reference_context_us_per_frame_one_core", "equals_reference_frame")}
             out["config"]["frame_tiger_x1_us_static_batch"] = fr1.get("static_tessellate_assembled_us_back_to_back")
             out["config"]["frame_tiger_x1_us_hip_graph_replay"] = fr1.get("tessellate_assembled_us_hip_graph_replay")
             out["config"]["frame_tiger_x1_us_reference_one_core"] = fr1.get("reference_context_us_per_frame_one_core")
+            out["config"]["frame_tiger_x1_us_whole_from_bytes"] = fr1.get("whole_frame_us_from_recorded_bytes")
+            out["config"]["frame_tiger_x1_us_whole_from_bytes_single_call"] = fr1.get("whole_frame_us_from_recorded_bytes_single_call")
         for name in ("cubics1m", "round10k", "round10k_static", "tiger10k_round", "tiger10k_culled", "tiger10k_animated", "tiger10k_command_parallel", "tiger10k_per_instance_flatten"):
             if name in summary and "ms" in summary[name]:
                 out["config"]["%s_ms_per_step" % name] = summary[name]["ms"]

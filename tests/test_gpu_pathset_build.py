@@ -152,6 +152,27 @@ def test_sets_longer_than_one_scan_slice(rt, hostlib, gpu_ctx, wl):
     assert scal[3] == 1
 
 
+def test_frame_sized_sets_through_the_large_set_sequence(rt, hostlib, wl, monkeypatch):
+    """Frame-sized sets go up as one image into a recycled blob and skip the thin passes when the host sees a curve among their opcodes;
+    VGX_PS_NO_SMALL sends them the large sets' way (four uploads, fresh blob, every pass launched)."""
+    monkeypatch.setenv("VGX_PS_NO_SMALL", "1")
+    ctx = rt.Context(0)
+    monkeypatch.delenv("VGX_PS_NO_SMALL")
+    for seed in range(12):
+        check_set(rt, hostlib, ctx, wl.fuzz_paths(300 + seed, npaths=64, with_shapes=True, degenerate=True), ("fuzz, large sequence", seed))
+        check_set(rt, hostlib, ctx, wl.thin_fuzz_paths(300 + seed, npaths=40, degenerate=bool(seed & 1)), ("thin, large sequence", seed))
+    ctx.close()
+
+
+def test_dropped_sets_are_recycled(rt, hostlib, gpu_ctx, wl):
+    """Blobs of dropped frame-sized sets wait in the context for the next create: sets of different sizes made and dropped in turn keep
+    giving the host loops' tables (stale bytes of an earlier, larger set must not show)."""
+    for rnd in range(3):
+        for seed in (5, 1, 9, 3):
+            check_set(rt, hostlib, gpu_ctx, wl.fuzz_paths(seed, npaths=16 + 24 * seed), ("recycled", rnd, seed))
+            check_set(rt, hostlib, gpu_ctx, wl.thin_fuzz_paths(seed, npaths=8 + 9 * seed), ("recycled thin", rnd, seed))
+
+
 def test_empty_and_tiny_sets(rt, hostlib, gpu_ctx, vgr):
     b = vgr.PathSetBuilder()
     check_set(rt, hostlib, gpu_ctx, b.arrays(), "no paths")

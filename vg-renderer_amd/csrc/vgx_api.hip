@@ -22,6 +22,8 @@
 #include <math.h>
 #include <new>
 #include <stdlib.h>
+#include <time.h>
+#include <stdio.h>
 
 
 static int vgxGridBlocks()
@@ -55,6 +57,8 @@ struct vgx_pathset
 	uint64_t gen; // unique per vgx_pathset_create (process-wide counter): identifies the path set where an address could be reused
 };
 
+#define VGX_PS_POOL 8
+#define VGX_PS_POOL_MAX ((size_t)8 << 20)
 struct DevBuf
 {
 	void* p;
@@ -75,7 +79,9 @@ struct vgx_ctx
 	DevBuf psTemp;                       // vgx_pathset_create: temporaries of the device-side build (vgx_pathset.hip)
 	hipStream_t psStream;                // ... its stream (created at the first call)
 	struct VgxPsTotals* hostPs;          // ... pinned: what the build reports
-	void* psStage[2]; hipEvent_t psStageEv[2]; bool psStageBusy[2]; uint64_t psStageK; int optPsStage; // VGX_PS_UPLOAD=stage: own pinned staging
+	void* psImage; size_t psImageCap;    // ... pinned: the raw part of a frame-sized set, assembled here and uploaded in one copy
+	DevBuf psPool[VGX_PS_POOL];          // ... blobs of dropped frame-sized sets, recycled (hipFree synchronises)
+	void* psStage[2]; hipEvent_t psStageEv[2]; bool psStageBusy[2]; uint64_t psStageK; int optPsStage, optPsNoSmall; // VGX_PS_UPLOAD=stage: own pinned staging
 	DevBuf f1SegDraw, f1Segs;            // vgx_flatten (vgx_flat1.hip): segment table, look-back records
 	int optF1Waves, optF1Cap, optF1Seg;  // its grid (persistent one-wave workgroups), the leaf-list capacity of the kernel instance and the segment bucket (0 = chosen per batch)
 	// what the last vgx_flatten call produced (copied to pinned memory behind the call, read by the next call WITHOUT waiting for
@@ -740,6 +746,7 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	// tuning / testing knobs: read once here, never on the call path
 	ctx->optTwoPass = getenv("VGX_TWO_PASS_FLATTEN") ? 1 : 0;
 	if (const char* e = getenv("VGX_PS_UPLOAD")) { ctx->optPsStage = strcmp(e, "stage") == 0; }
+	ctx->optPsNoSmall = getenv("VGX_PS_NO_SMALL") ? 1 : 0; // testing knob: frame-sized path sets through the large-set launch sequence
 	ctx->optBuildWaves = VGX_BUILD_WAVES;
 	ctx->optConcurrentEmit = getenv("VGX_EXP_CONCURRENT_EMIT") ? 1 : 0;
 	ctx->optNoSmall = getenv("VGX_NO_SMALL") ? 1 : 0; // testing knob: frame-sized batches through the large-batch launch sequence
@@ -785,6 +792,8 @@ int vgx_destroy(vgx_ctx* ctx)
 	if (ctx->hostTotals) { (void)hipHostFree(ctx->hostTotals); }
 	if (ctx->hostF1) { (void)hipHostFree(ctx->hostF1); }
 	if (ctx->hostPs) { (void)hipHostFree(ctx->hostPs); }
+	if (ctx->psImage) { (void)hipHostFree(ctx->psImage); }
+	for (int i = 0; i < VGX_PS_POOL; ++i) { if (ctx->psPool[i].p) { (void)hipFree(ctx->psPool[i].p); } }
 	if (ctx->psStream) { (void)hipStreamDestroy(ctx->psStream); }
 	for (int i = 0; i < 2; ++i) { if (ctx->psStage[i]) { (void)hipHostFree(ctx->psStage[i]); (void)hipEventDestroy(ctx->psStageEv[i]); } }
 	vgx_rccl_release(ctx);
@@ -855,21 +864,23 @@ static int psUpload(vgx_ctx* ctx, void* dst, const void* src, size_t bytes, hipS
 
 struct VgxPsLayout
 {
-	size_t oArgs, oArgOff, oSpStart, oPathBegin, oType, oFlags, oPathFlags, oRec, oSubBegin, oSubLast, oThin, oThinPath, oThinSub, total;
+	size_t oArgs, oArgOff, oPathBegin, oType, rawEnd, oSpStart, oFlags, oPathFlags, oRec, oSubBegin, oSubLast, oThin, oThinPath, oThinSub, total;
 };
-// One blob: [args (2 floats of padding in front: the start-point gather of command 0 reads args[-2..-1])] [arg offsets] ... The
-// sub-path tables are sized for the most sub-paths `ncmd` commands can hold (every command ends one): what the set really has is
-// known only after the scan, and 12 bytes per command of head room are nothing against 288 GB.
+// One blob: the four raw arrays first, back to back ([args (2 floats of padding in front: the start-point gather of command 0
+// reads args[-2..-1])] [arg offsets] [path begins] [opcodes] -- a frame-sized set goes up as ONE image of this part), the derived
+// tables behind them. The sub-path tables are sized for the most sub-paths `ncmd` commands can hold (every command ends one): what
+// the set really has is known only after the scan, and 12 bytes per command of head room are nothing against 288 GB.
 static VgxPsLayout psLayout(uint32_t ncmd, uint32_t npaths, uint32_t nargs)
 {
 	auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
 	VgxPsLayout L;
 	L.oArgs = 0;
 	L.oArgOff = align(L.oArgs + ((size_t)nargs + 4) * sizeof(float));
-	L.oSpStart = align(L.oArgOff + ((size_t)ncmd + 1) * sizeof(uint32_t));
-	L.oPathBegin = align(L.oSpStart + ((size_t)ncmd + 1) * sizeof(uint32_t));
+	L.oPathBegin = align(L.oArgOff + ((size_t)ncmd + 1) * sizeof(uint32_t));
 	L.oType = align(L.oPathBegin + ((size_t)npaths + 1) * sizeof(uint32_t));
-	L.oFlags = align(L.oType + ncmd + 1);
+	L.rawEnd = align(L.oType + ncmd + 1);
+	L.oSpStart = L.rawEnd;
+	L.oFlags = align(L.oSpStart + ((size_t)ncmd + 1) * sizeof(uint32_t));
 	L.oPathFlags = align(L.oFlags + ncmd + 1);
 	L.oRec = align(L.oPathFlags + npaths + 4);
 	L.oSubBegin = align(L.oRec + ((size_t)ncmd + 1) * sizeof(VgxCmdRec));
@@ -879,6 +890,29 @@ static VgxPsLayout psLayout(uint32_t ncmd, uint32_t npaths, uint32_t nargs)
 	L.oThinSub = align(L.oThinPath + ((size_t)npaths + 1) * sizeof(VgxThinPath));
 	L.total = align(L.oThinSub + ((size_t)ncmd + 1) * sizeof(VgxThinSub));
 	return L;
+}
+
+// Blobs of frame-sized sets are recycled through the context (hipFree synchronises the device; a renderer makes and drops one
+// such set per frame): up to VGX_PS_POOL blobs of at most VGX_PS_POOL_MAX bytes wait here for the next vgx_pathset_create.
+static void* psPoolTake(vgx_ctx* ctx, size_t need, size_t* got)
+{
+	int best = -1;
+	for (int i = 0; i < VGX_PS_POOL; ++i) {
+		if (ctx->psPool[i].p && ctx->psPool[i].cap >= need && (best < 0 || ctx->psPool[i].cap < ctx->psPool[best].cap)) { best = i; }
+	}
+	if (best < 0) { return nullptr; }
+	void* p = ctx->psPool[best].p;
+	*got = ctx->psPool[best].cap;
+	ctx->psPool[best].p = nullptr; ctx->psPool[best].cap = 0;
+	return p;
+}
+static bool psPoolGive(vgx_ctx* ctx, void* p, size_t cap)
+{
+	if (cap > VGX_PS_POOL_MAX) { return false; }
+	for (int i = 0; i < VGX_PS_POOL; ++i) {
+		if (!ctx->psPool[i].p) { ctx->psPool[i].p = p; ctx->psPool[i].cap = cap; return true; }
+	}
+	return false;
 }
 
 // Round 6: the raw arrays go up as they are and the derived tables are built by kernels (vgx_pathset.hip): grammar checks as a
@@ -901,11 +935,16 @@ int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset**
 	if (nargs && !desc->args) { return VGX_E_INVALID_ARG; }
 	const VgxPsLayout L = psLayout(ncmd, npaths, nargs);
 	int st;
+	static const bool timing = getenv("VGX_PS_TIMING") != nullptr; // tuning aid: host clock after each stage of the call, to stderr
+	double tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
+	if (timing) { tq[0] = now(); }
 	// temporaries of the build (grow-only context scratch): four words per command, the scans' partials, the totals
 	auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+	// layout: [totals (256 B) | pathAt] (cleared by ONE memset) | pathOf | lastSubEx | nvEx | partials
 	const size_t words = a256(((size_t)ncmd + 1) * sizeof(uint32_t));
-	const size_t tPartA = 4 * words, tPartB = tPartA + a256(VGX_MSCAN_BLOCKS * sizeof(VgxPsM)), tTot = tPartB + a256(VGX_SCAN_BLOCKS * sizeof(Sum3));
-	if ((st = ensure(ctx, ctx->psTemp, tTot + 256)) != VGX_OK) { return st; }
+	const size_t tTot = 0, tW = 256, tPartA = tW + 4 * words, tPartB = tPartA + a256(VGX_MSCAN_BLOCKS * sizeof(VgxPsM)), tEnd = tPartB + a256(VGX_SCAN_BLOCKS * sizeof(Sum3));
+	if ((st = ensure(ctx, ctx->psTemp, tEnd)) != VGX_OK) { return st; }
 	if (!ctx->psStream) { HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->psStream, hipStreamNonBlocking)); }
 	if (!ctx->hostPs) { HIPCHK(ctx, hipHostMalloc((void**)&ctx->hostPs, sizeof(VgxPsTotals), hipHostMallocDefault)); }
 	hipStream_t s = ctx->psStream;
@@ -914,39 +953,71 @@ int vgx_pathset_create(vgx_ctx* ctx, const vgx_pathset_desc* desc, vgx_pathset**
 	if (!ps) {
 		return VGX_E_INVALID_ARG;
 	}
+	const bool small = !ctx->optPsNoSmall && vgx_pathset_is_small(ncmd, npaths, nargs);
 	ps->blob = nullptr;
 	ps->blobBytes = L.total;
-	hipError_t e = hipMalloc(&ps->blob, L.total);
+	if (small) { ps->blob = psPoolTake(ctx, L.total, &ps->blobBytes); }
+	hipError_t e = ps->blob ? hipSuccess : hipMalloc(&ps->blob, L.total);
 	if (e != hipSuccess) {
 		ctx->lastHipError = (int)e;
 		delete ps;
 		return VGX_E_HIP;
 	}
+	if (timing) { tq[1] = now(); }
 	uint8_t* b = (uint8_t*)ps->blob;
 	uint8_t* t = (uint8_t*)ctx->psTemp.p;
 	auto fail = [&](int code) { (void)hipStreamSynchronize(s); (void)hipFree(ps->blob); delete ps; return code; };
-	// the derived part of the blob starts from zero (padding records, flag bytes the kernels OR into); the raw arrays land on top
-	e = hipMemsetAsync(b, 0, L.total, s);
-	if (e == hipSuccess) { e = hipMemsetAsync(t, 0, words, s); }                                  // pathAt
-	if (e == hipSuccess) { e = hipMemsetAsync(t + 2 * words, 0, sizeof(uint32_t), s); }          // lastSubEx[0] (a set without commands)
-	if (e == hipSuccess) { e = hipMemsetAsync(t + tTot, 0, sizeof(VgxPsTotals), s); }
+	// totals and path marks start from zero (one memset: they are neighbours); what the passes OR into inside the blob and the padding
+	// records the flatten kernels read past the ends are cleared by the first kernel -- no memset of the blob (1 GB for configs[3])
+	e = hipMemsetAsync(t + tTot, 0, tW + words, s);
 	if (e != hipSuccess) { ctx->lastHipError = (int)e; return fail(VGX_E_HIP); }
-	if ((st = psUpload(ctx, b + L.oArgs + 2 * sizeof(float), desc->args, (size_t)nargs * sizeof(float), s)) != VGX_OK) { return fail(st); }
-	if ((st = psUpload(ctx, b + L.oArgOff, desc->cmd_arg_off, ((size_t)ncmd + 1) * sizeof(uint32_t), s)) != VGX_OK) { return fail(st); }
-	if ((st = psUpload(ctx, b + L.oType, desc->cmd_type, ncmd, s)) != VGX_OK) { return fail(st); }
-	if ((st = psUpload(ctx, b + L.oPathBegin, desc->path_cmd_begin, ((size_t)npaths + 1) * sizeof(uint32_t), s)) != VGX_OK) { return fail(st); }
+	bool maybeThin = true;
+	if (small) {
+		for (uint32_t c = 0; c < ncmd && maybeThin; ++c) { const uint8_t ty = desc->cmd_type[c]; maybeThin = ty == VGX_CMD_MOVE_TO || ty == VGX_CMD_LINE_TO || ty == VGX_CMD_CLOSE; }
+		// ONE image of the raw part, filled in pinned memory, one copy
+		if (L.rawEnd > ctx->psImageCap) {
+			if (ctx->psImage) { (void)hipHostFree(ctx->psImage); ctx->psImage = nullptr; ctx->psImageCap = 0; }
+			const size_t want = L.rawEnd * 2 > ((size_t)1 << 16) ? L.rawEnd * 2 : ((size_t)1 << 16);
+			e = hipHostMalloc(&ctx->psImage, want, hipHostMallocDefault);
+			if (e != hipSuccess) { ctx->lastHipError = (int)e; return fail(VGX_E_HIP); }
+			ctx->psImageCap = want;
+		}
+		uint8_t* im = (uint8_t*)ctx->psImage;
+		memset(im + L.oArgs, 0, 2 * sizeof(float));
+		if (nargs) { memcpy(im + L.oArgs + 2 * sizeof(float), desc->args, (size_t)nargs * sizeof(float)); }
+		memcpy(im + L.oArgOff, desc->cmd_arg_off, ((size_t)ncmd + 1) * sizeof(uint32_t));
+		memcpy(im + L.oPathBegin, desc->path_cmd_begin, ((size_t)npaths + 1) * sizeof(uint32_t));
+		if (ncmd) { memcpy(im + L.oType, desc->cmd_type, ncmd); }
+		im[L.oType + ncmd] = 0;
+		if (timing) { tq[2] = now(); }
+		e = hipMemcpyAsync(b, im, L.rawEnd, hipMemcpyHostToDevice, s);
+		if (e != hipSuccess) { ctx->lastHipError = (int)e; return fail(VGX_E_HIP); }
+	} else {
+		if ((st = psUpload(ctx, b + L.oArgs + 2 * sizeof(float), desc->args, (size_t)nargs * sizeof(float), s)) != VGX_OK) { return fail(st); }
+		if ((st = psUpload(ctx, b + L.oArgOff, desc->cmd_arg_off, ((size_t)ncmd + 1) * sizeof(uint32_t), s)) != VGX_OK) { return fail(st); }
+		if ((st = psUpload(ctx, b + L.oType, desc->cmd_type, ncmd, s)) != VGX_OK) { return fail(st); }
+		if ((st = psUpload(ctx, b + L.oPathBegin, desc->path_cmd_begin, ((size_t)npaths + 1) * sizeof(uint32_t), s)) != VGX_OK) { return fail(st); }
+	}
 	VgxPsBuild B;
 	B.type = b + L.oType; B.argOff = (const uint32_t*)(b + L.oArgOff); B.args = (const float*)(b + L.oArgs) + 2; B.pcb = (const uint32_t*)(b + L.oPathBegin);
 	B.ncmd = ncmd; B.npaths = npaths; B.nargs = nargs;
 	B.spStart = (uint32_t*)(b + L.oSpStart); B.flags = b + L.oFlags; B.pathFlags = b + L.oPathFlags; B.rec = (VgxCmdRec*)(b + L.oRec);
 	B.thin = (VgxCmdThin*)(b + L.oThin) + 1; // thin[-1]: padding record
 	B.subBegin = (uint32_t*)(b + L.oSubBegin); B.subLast = (uint32_t*)(b + L.oSubLast); B.tp = (VgxThinPath*)(b + L.oThinPath); B.ts = (VgxThinSub*)(b + L.oThinSub);
-	B.pathAt = (uint32_t*)t; B.pathOf = (uint32_t*)(t + words); B.lastSubEx = (uint32_t*)(t + 2 * words); B.nvEx = (uint32_t*)(t + 3 * words);
+	B.pathAt = (uint32_t*)(t + tW); B.pathOf = (uint32_t*)(t + tW + words); B.lastSubEx = (uint32_t*)(t + tW + 2 * words); B.nvEx = (uint32_t*)(t + tW + 3 * words);
 	B.partialA = (VgxPsM*)(t + tPartA); B.partialB = (Sum3*)(t + tPartB); B.tot = (VgxPsTotals*)(t + tTot);
-	vgx_launch_pathset_build(B, s);
+	if (timing) { tq[3] = now(); }
+	vgx_launch_pathset_build(B, maybeThin, s);
 	e = hipGetLastError();
+	if (timing) { tq[4] = now(); }
 	if (e == hipSuccess) { e = hipMemcpyAsync(ctx->hostPs, B.tot, sizeof(VgxPsTotals), hipMemcpyDeviceToHost, s); }
+	if (timing) { tq[5] = now(); }
 	if (e == hipSuccess) { e = hipStreamSynchronize(s); }
+	if (timing) {
+		tq[6] = now();
+		fprintf(stderr, "vgx_pathset_create ncmd=%u small=%d: alloc %.1f  image %.1f  h2d %.1f  launch %.1f  d2h %.1f  sync %.1f  total %.1f us\n", ncmd, (int)small,
+			tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[5] - tq[4], tq[6] - tq[5], tq[6] - tq[0]);
+	}
 	if (e != hipSuccess) { ctx->lastHipError = (int)e; return fail(VGX_E_HIP); }
 	const VgxPsTotals T = *ctx->hostPs;
 	if (T.err) {
@@ -1019,7 +1090,10 @@ int vgx_pathset_destroy(vgx_ctx* ctx, vgx_pathset* ps)
 	}
 	if (ctx->lastPs == ps) { ctx->lastPs = nullptr; ctx->lastStage = 0; }
 	if (ctx->tmplPs == ps) { ctx->tmplOn = false; ctx->tmplPs = nullptr; ctx->tmplPsGen = 0; } // a later path set at the same address must not match the template
-	if (ps->blob) { (void)hipFree(ps->blob); }
+	// hipFree waits for everything in flight (a caller may drop a set right behind an asynchronous call that reads it); a blob that
+	// goes back to the pool instead must be as idle: the same wait, without the allocator's work
+	if (ps->blob && ps->blobBytes <= VGX_PS_POOL_MAX) { (void)hipDeviceSynchronize(); }
+	if (ps->blob && !psPoolGive(ctx, ps->blob, ps->blobBytes)) { (void)hipFree(ps->blob); }
 	delete ps;
 	return VGX_OK;
 }

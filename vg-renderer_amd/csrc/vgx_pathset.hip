@@ -5,17 +5,17 @@
 // configs[3]'s 10 M -- more than the 16-core reference needs for the whole batch. Here the caller's four raw arrays are uploaded
 // as they are and everything else is a handful of HBM-bound passes over them:
 //
-//   k_ps_mark        one lane per path       path_cmd_begin monotone? first command of every non-empty path marked (pathAt),
+//   k_ps_front       one lane per path       path_cmd_begin monotone? first command of every non-empty path marked (pathAt),
 //                                            longest path, empty paths
-//   k_ps_args        one lane per argument   finite?
+//                    one lane per argument   finite?
 //   scan A (3 passes, vgx_mscan.h) over commands, monoid (max, max, +): per command from its own / its neighbours' opcodes --
 //                    the reference's "is a sub-path open" state is LOCAL: open after command c = !(CLOSE or a closed shape),
 //                    so STARTS_SUB / LAST_IN_SUB / NEXT_IS_CLOSE / LAST_IN_PATH and every grammar check need only c - 1, c, c + 1
 //                    -- and by the scan: the sub-path's first command (cmd_sp_start), the path of the command, the number of
 //                    sub-paths in front (-> path_sub_begin, sub_last_cmd, the sub-path ordinal)
-//   k_ps_rec         one lane per command    VgxCmdRec (64 B: arguments, start point = the previous command's last pair, the
+//   k_ps_back        one lane per command    VgxCmdRec (64 B: arguments, start point = the previous command's last pair, the
 //                                            sub-path's first point: gathers), VgxCmdThin, sub_last_cmd
-//   k_ps_pathfix     one lane per path       path_sub_begin, VGX_PF_THIN
+//                    one lane per path       path_sub_begin, VGX_PF_THIN
 //   thin sets only (every path MOVE_TO / LINE_TO / CLOSE; vgx_thin.h):
 //   scan B (vgx_scan.h) over commands        vertices in front of the command (+1 / 0 / -1 for the vertex pathClose pops, path.cpp:716-725)
 //   k_ps_thin_path, k_ps_thin_cmd            VgxThinPath, VgxThinSub, the vertex place and sub-path ordinal of every command
@@ -53,9 +53,8 @@ struct VgxPsMOps : VgxPsM
 	}
 };
 
-__global__ __launch_bounds__(256) void k_ps_mark(VgxPsBuild A)
+__device__ __forceinline__ void ps_mark(const VgxPsBuild& A, uint32_t p)
 {
-	const uint32_t p = blockIdx.x * 256u + threadIdx.x;
 	uint32_t len = 0;
 	bool empty = false, bad = false;
 	if (p < A.npaths) {
@@ -74,10 +73,10 @@ __global__ __launch_bounds__(256) void k_ps_mark(VgxPsBuild A)
 	}
 }
 
-__global__ __launch_bounds__(256) void k_ps_args(VgxPsBuild A)
+__device__ __forceinline__ void ps_args(const VgxPsBuild& A, uint32_t first, uint32_t stride)
 {
 	bool bad = false;
-	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < A.nargs; i += gridDim.x * 256u) {
+	for (uint32_t i = first; i < A.nargs; i += stride) {
 		const uint32_t u = __float_as_uint(A.args[i]);
 		bad |= (u & 0x7F800000u) == 0x7F800000u; // !isfinite
 	}
@@ -149,9 +148,8 @@ struct OpPsA
 	__device__ void finish(VgxPsMOps total) const { A.lastSubEx[A.ncmd] = total.nlast; A.tot->nsubs = total.nlast; }
 };
 
-__global__ __launch_bounds__(256) void k_ps_rec(VgxPsBuild A)
+__device__ __forceinline__ void ps_rec(const VgxPsBuild& A, uint32_t c)
 {
-	const uint32_t c = blockIdx.x * 256u + threadIdx.x;
 	if (c >= A.ncmd || A.tot->err) { return; } // (an invalid set: its offsets may point anywhere; the build ends without tables)
 	const uint32_t t = A.type[c], fl = A.flags[c];
 	const uint32_t ao = A.argOff[c];
@@ -182,13 +180,12 @@ __global__ __launch_bounds__(256) void k_ps_rec(VgxPsBuild A)
 	if (fl & VGX_CF_LAST_IN_SUB) { A.subLast[A.lastSubEx[c]] = c - A.pcb[A.pathOf[c]]; }
 }
 
-__global__ __launch_bounds__(256) void k_ps_pathfix(VgxPsBuild A)
+__device__ __forceinline__ void ps_pathfix(const VgxPsBuild& A, uint32_t p)
 {
-	const uint32_t p = blockIdx.x * 256u + threadIdx.x;
 	if (p > A.npaths || A.tot->err) { return; }
-	if (p == A.npaths) { A.subBegin[p] = A.lastSubEx[A.ncmd]; return; }
+	if (p == A.npaths) { A.subBegin[p] = A.ncmd ? A.lastSubEx[A.ncmd] : 0u; return; }
 	const uint32_t c0 = A.pcb[p], c1 = A.pcb[p + 1];
-	A.subBegin[p] = A.lastSubEx[c0]; // (an empty path: the count in front of the next command, or the total)
+	A.subBegin[p] = A.ncmd ? A.lastSubEx[c0] : 0u; // (an empty path: the count in front of the next command, or the total)
 	uint32_t f = A.pathFlags[p];
 	const bool thin = c1 > c0 && !(f & VGX_PF_SERIAL) && !(f & 0x80u);
 	A.pathFlags[p] = (uint8_t)((f & ~0x80u & ~VGX_PF_THIN) | (thin ? VGX_PF_THIN : 0u));
@@ -224,10 +221,8 @@ struct OpPsB // exclusive sum of ps_thin_cnt over the commands (vgx_scan.h; sums
 	__device__ void finish(Sum3 t) const { A.nvEx[A.ncmd] = (uint32_t)t.a; }
 };
 
-__global__ __launch_bounds__(256) void k_ps_thin_path(VgxPsBuild A)
+__device__ __forceinline__ void ps_thin_path(const VgxPsBuild& A, uint32_t p)
 {
-	if (!ps_all_thin(A)) { return; }
-	const uint32_t p = blockIdx.x * 256u + threadIdx.x;
 	if (p >= A.npaths) { return; }
 	const uint32_t c0 = A.pcb[p], c1 = A.pcb[p + 1];
 	VgxThinPath q;
@@ -235,11 +230,10 @@ __global__ __launch_bounds__(256) void k_ps_thin_path(VgxPsBuild A)
 	if (q.nsubs > 65536u) { A.tot->thinIneligible = 1u; }
 	A.tp[p] = q;
 }
+__global__ __launch_bounds__(256) void k_ps_thin_path(VgxPsBuild A) { if (ps_all_thin(A)) { ps_thin_path(A, blockIdx.x * 256u + threadIdx.x); } }
 
-__global__ __launch_bounds__(256) void k_ps_thin_cmd(VgxPsBuild A)
+__device__ __forceinline__ void ps_thin_cmd(const VgxPsBuild& A, uint32_t c)
 {
-	if (!ps_all_thin(A)) { return; }
-	const uint32_t c = blockIdx.x * 256u + threadIdx.x;
 	if (c >= A.ncmd) { return; }
 	const uint32_t p = A.pathOf[c];
 	const uint32_t c0 = A.pcb[p];
@@ -275,23 +269,57 @@ __global__ __launch_bounds__(256) void k_ps_thin_cmd(VgxPsBuild A)
 		if (spTotal >= 2u) { atomicAdd(&A.tp[p].nge2, 1u); }
 	}
 }
+__global__ __launch_bounds__(256) void k_ps_thin_cmd(VgxPsBuild A) { if (ps_all_thin(A)) { ps_thin_cmd(A, blockIdx.x * 256u + threadIdx.x); } }
+
+// Fused launches (a frame-sized set is bound by the NUMBER of dependent launches, each ~6 us on a GPU that idles between frames: a
+// single-workgroup kernel running every pass behind block barriers was built and measured -- 134 us per Tiger frame against 111 us
+// for the separate launches: one compute unit at idle clocks is slower than a dozen launches that each use the chip):
+//   k_ps_front  paths -> ps_mark; arguments -> ps_args; and the bytes the later passes OR into / the padding records the flatten
+//               kernels read past the ends (no memset of the blob)
+//   k_ps_back   commands -> ps_rec; paths -> ps_pathfix
+__global__ __launch_bounds__(256) void k_ps_front(VgxPsBuild A, uint32_t markBlocks)
+{
+	if (blockIdx.x < markBlocks) {
+		const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+		ps_mark(A, p);
+		if (p < (A.npaths + 4u) / 4u) { ((uint32_t*)A.pathFlags)[p] = 0u; } // (the blob keeps npaths + 4 bytes, 256-byte aligned)
+		if (p == 0) {
+			const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			*(float4*)(A.thin - 1) = z; *(float4*)(A.thin + A.ncmd) = z; *(float4*)(A.thin + A.ncmd + 1u) = z;
+			float4* r = (float4*)(A.rec + A.ncmd);
+			r[0] = z; r[1] = z; r[2] = z; r[3] = z;
+			A.spStart[A.ncmd] = 0u; A.flags[A.ncmd] = 0;
+			((float*)A.args)[-2] = 0.0f; ((float*)A.args)[-1] = 0.0f;
+			((uint8_t*)A.type)[A.ncmd] = 0;
+		}
+	} else {
+		ps_args(A, (blockIdx.x - markBlocks) * 256u + threadIdx.x, (gridDim.x - markBlocks) * 256u);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_ps_back(VgxPsBuild A, uint32_t recBlocks)
+{
+	if (blockIdx.x < recBlocks) { ps_rec(A, blockIdx.x * 256u + threadIdx.x); }
+	else { ps_pathfix(A, (blockIdx.x - recBlocks) * 256u + threadIdx.x); }
+}
 
 } // namespace
 
-void vgx_launch_pathset_build(const VgxPsBuild& a, hipStream_t s)
+// maybeThin: false when the host knows that some command is not MOVE_TO / LINE_TO / CLOSE (it looks at the opcodes of frame-sized
+// sets: a few KB); the thin passes then are not launched at all (they would find that out themselves and exit).
+void vgx_launch_pathset_build(const VgxPsBuild& a, bool maybeThin, hipStream_t s)
 {
-	if (a.npaths) { hipLaunchKernelGGL(k_ps_mark, dim3((a.npaths + 255u) / 256u), dim3(256), 0, s, a); }
-	if (a.nargs) {
-		const uint32_t want = (a.nargs + 255u) / 256u;
-		hipLaunchKernelGGL(k_ps_args, dim3(want < 4096u ? want : 4096u), dim3(256), 0, s, a);
-	}
+	const uint32_t markBlocks = (a.npaths + 1u + 255u) / 256u; // >= 1: block 0 also writes the padding records
+	uint32_t argBlocks = (a.nargs + 255u) / 256u;
+	if (argBlocks > 4096u) { argBlocks = 4096u; }
+	hipLaunchKernelGGL(k_ps_front, dim3(markBlocks + argBlocks), dim3(256), 0, s, a, markBlocks);
+	const uint32_t recBlocks = (a.ncmd + 255u) / 256u;
 	if (a.ncmd) {
 		OpPsA opA; opA.A = a;
 		vgx_monoid_scan<VgxPsMOps, OpPsA>(opA, (VgxPsMOps*)a.partialA, s);
-		hipLaunchKernelGGL(k_ps_rec, dim3((a.ncmd + 255u) / 256u), dim3(256), 0, s, a);
 	}
-	hipLaunchKernelGGL(k_ps_pathfix, dim3((a.npaths + 1u + 255u) / 256u), dim3(256), 0, s, a);
-	if (a.ncmd && a.npaths) {
+	hipLaunchKernelGGL(k_ps_back, dim3(recBlocks + (a.npaths + 1u + 255u) / 256u), dim3(256), 0, s, a, recBlocks);
+	if (a.ncmd && a.npaths && maybeThin) {
 		OpPsB opB; opB.A = a;
 		vgx_device_scan(opB, a.partialB, s, a.ncmd);
 		hipLaunchKernelGGL(k_ps_thin_path, dim3((a.npaths + 255u) / 256u), dim3(256), 0, s, a);

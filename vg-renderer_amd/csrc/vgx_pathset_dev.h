@@ -39,7 +39,7 @@ struct VgxPsBuild
 	uint32_t* spStart; uint8_t* flags; uint8_t* pathFlags; VgxCmdRec* rec; VgxCmdThin* thin /* record of command 0 */;
 	uint32_t* subBegin; uint32_t* subLast; VgxThinPath* tp; VgxThinSub* ts;
 	// temporaries (context scratch)
-	uint32_t* pathAt;    // [ncmd + 1] zeroed; p + 1 at the first command of every non-empty path
+	uint32_t* pathAt;    // [ncmd + 1] zeroed by the host together with `tot` (they are neighbours); p + 1 at the first command of every non-empty path
 	uint32_t* pathOf;    // [ncmd]
 	uint32_t* lastSubEx; // [ncmd + 1] LAST_IN_SUB commands in front of the command
 	uint32_t* nvEx;      // [ncmd + 1] thin sets: polyline vertices in front of the command (pops included)
@@ -48,6 +48,10 @@ struct VgxPsBuild
 	VgxPsTotals* tot;
 };
 
-void vgx_launch_pathset_build(const VgxPsBuild& a, hipStream_t s);
+// Frame-sized sets go up as ONE image of their raw arrays, their blobs are recycled through the context, and the host looks at their
+// opcodes (a few KB) to leave the thin passes out when some command is a curve.
+static inline bool vgx_pathset_is_small(uint32_t ncmd, uint32_t npaths, uint32_t nargs) { return ncmd <= 16384u && npaths <= 16384u && nargs <= 131072u; }
+
+void vgx_launch_pathset_build(const VgxPsBuild& a, bool maybeThin, hipStream_t s);
 
 #endif

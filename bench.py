@@ -60,6 +60,8 @@ def algorithmic_bytes(cmd_bytes, ndraws, sizes, fill_verts, fill_idx, fill_meshe
     b["flatten_one_walk"] = b["flatten_emit"]  # vgx_flatten: the same bytes, read and written once
     b["fill_emit"] = 8 * ef + 12 * fill_verts + 2 * fill_idx + 32 * fill_meshes
     b["stroke_emit"] = 8 * es + 12 * (nv - fill_verts) + 2 * (ni - fill_idx) + 32 * (nm - fill_meshes)
+    # round 6: batches of fills + closed Miter AA / Thin strokes are emitted by ONE draw-ordered tile kernel (k_emit_tiles): both kinds' bytes
+    b["tile_emit"] = 8 * (ef + es) + 12 * nv + 2 * ni + 32 * nm
     # the whole step: commands are read once per 64-instance task by the instanced flatten kernel, once per instance otherwise
     b["pipeline"] = (cmd_bytes // 64 if instanced else cmd_bytes) + 64 * ndraws + 12 * nv + 2 * ni + 32 * nm
     if template:
@@ -813,7 +815,7 @@ def roofline(res, steps, traffic_for=None):
             "kernel_ms": round(dom_ms, 3), "algorithmic_bytes": ab[dom],
             "by_kernel": {k: {"ms": round(stage_sum[k], 3), "achieved": round(ab[k] / (stage_sum[k] * 1e-3) / 1e9, 1),
                               "frac": round(ab[k] / (stage_sum[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-                          for k in ("flatten_build", "flatten_count", "flatten_emit", "flatten_one_walk", "fill_emit", "stroke_emit", "tmpl_verify", "tmpl_emit") if k in stage_sum and k in ab and stage_sum[k] > 0},
+                          for k in ("flatten_build", "flatten_count", "flatten_emit", "flatten_one_walk", "fill_emit", "stroke_emit", "tile_emit", "tmpl_verify", "tmpl_emit") if k in stage_sum and k in ab and stage_sum[k] > 0},
             "pipeline_achieved": round(ab["pipeline"] / (ms_per_step * 1e-3) / 1e9, 1)}
 
 

@@ -73,7 +73,7 @@ def test_one_rank_line(tmp_path):
     assert d["configs"]["tiger10k_varied"]["flatten_kernel"].startswith("none per step")  # one template per scale class
     assert d["configs"]["tiger10k_varied_per_instance_flatten"]["flatten_kernel"] == "k_flatten_inst (instances sorted by tolerance class)"
     # the honesty configs really run the other pipelines
-    assert d["configs"]["tiger10k_per_instance_flatten"]["flatten_kernel"] == "k_flatten_inst" and "fill_emit" in d["configs"]["tiger10k_per_instance_flatten"]["stage_ms"]
+    assert d["configs"]["tiger10k_per_instance_flatten"]["flatten_kernel"] == "k_flatten_inst" and "tile_emit" in d["configs"]["tiger10k_per_instance_flatten"]["stage_ms"]
     assert d["configs"]["tiger10k_command_parallel"]["flatten_kernel"] == "k_flatten_build"
     assert d["configs"]["tigerspec10k"]["flatten_kernel"].startswith("none per step")
     assert d["configs"]["tiger10k_open"]["flatten_kernel"].startswith("none per step")  # open strokes: template mode's general kernel

@@ -14,6 +14,7 @@
 #include "vgx_flat1.h"
 #include "vgx_thin.h"
 #include "vgx_pathset_dev.h"
+#include "vgx_tile.h"
 #include "vgx_mscan.h"
 #include <vector>
 #include <atomic>
@@ -76,6 +77,8 @@ struct vgx_ctx
 	bool asmArmed;
 	DevBuf subPrefix; // exclusive scan of the draws' static sub-path counts
 	DevBuf cmdPrefix, cmdCnt, subFirst, leafOverflow, serialList, dinfo, poly, subs, mdesc, elemPrefix, elemPrefixS, mprep, mtab, partial, totals;
+	DevBuf tileTab;                      // k_emit_tiles (vgx_tile.hip): the tile table of the current call
+	int optTileEmit;                     // VGX_TILE_EMIT=0: ordinary batches through k_fill + k_stroke_simple as before round 6
 	DevBuf psTemp;                       // vgx_pathset_create: temporaries of the device-side build (vgx_pathset.hip)
 	hipStream_t psStream;                // ... its stream (created at the first call)
 	struct VgxPsTotals* hostPs;          // ... pinned: what the build reports
@@ -579,7 +582,7 @@ void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps,
 	a.elem_prefix = nullptr; a.elem_prefix_fill = (const uint64_t*)ctx->elemPrefix.p; a.elem_prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
 	a.mprep = (VgxMeshPrep*)ctx->mprep.p; a.mtab = (vgx_mesh*)ctx->mtab.p;
 	a.pos = nullptr; a.color = nullptr; a.idx = nullptr; a.meshes_out = nullptr; a.mesh_base = nullptr;
-	a.totals = (VgxTotals*)ctx->totals.p; a.caps = outCaps;
+	a.totals = (VgxTotals*)ctx->totals.p; a.caps = outCaps; a.tile_mode = 0;
 	if (!prepDone) { vgx_launch_mesh_prepare(a, s); }
 	vgx_launch_stroke(false, a, 32768, s); // k_round_sizes: Round-join mesh sizes (exits immediately without Round joins); one wave per mesh: 10 000 long polylines want more than 4 096 waves
 	mark(ctx, s, "mesh_prepare");
@@ -642,6 +645,16 @@ int runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out, 
 	a.pos = out->pos; a.color = out->color; a.idx = out->idx; a.meshes_out = tableDone ? nullptr : out->meshes;
 	a.totals = (VgxTotals*)ctx->totals.p;
 	a.caps = ctx->caps;
+	a.tile_mode = 0;
+	// Batches of fills and closed Miter AA / Thin strokes (the scan over the meshes decides, on the device): one draw-ordered tile
+	// kernel instead of k_fill + k_stroke_simple (vgx_tile.hip). Not for frame-sized calls (two more launches than they are worth).
+	uint64_t capTiles = 0;
+	if (ctx->optTileEmit && !ctx->optConcurrentEmit && out->cap_vertices >= (1ull << 18) && out->cap_vertices / VGX_TILE_ELEMS + 2 < 0x7FFFFFFFull) {
+		capTiles = out->cap_vertices / VGX_TILE_ELEMS + 2; // every element emits at least one vertex
+		const int st = ensure(ctx, ctx->tileTab, capTiles * sizeof(VgxTileRec));
+		if (st != VGX_OK) { return st; }
+		a.tile_mode = 1;
+	}
 	if (ctx->optConcurrentEmit) {
 		// tuning experiment (VGX_EXP_CONCURRENT_EMIT=1 at vgx_create): k_stroke on a side stream beside k_fill (they write disjoint
 		// meshes); joined before the call returns control of `s`
@@ -663,11 +676,16 @@ int runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out, 
 		return launchStatus(ctx);
 	}
 	a.elem_prefix = a.elem_prefix_fill;
-	vgx_launch_fill(a, vgxElementGrid(out->cap_vertices), s);
+	vgx_launch_fill(a, vgxElementGrid(out->cap_vertices), s); // (tile mode: the mesh-table copy, and the kernel exits at once for the batches the tile kernel takes)
 	mark(ctx, s, "fill_emit");
 	a.elem_prefix = a.elem_prefix_stroke;
 	vgx_launch_stroke(true, a, vgxElementGrid(out->cap_vertices), s);
 	mark(ctx, s, "stroke_emit");
+	if (a.tile_mode) {
+		a.elem_prefix = nullptr;
+		vgx_launch_emit_tiles(a, (VgxTileRec*)ctx->tileTab.p, capTiles, s);
+		mark(ctx, s, "tile_emit");
+	}
 	return launchStatus(ctx);
 }
 
@@ -746,6 +764,8 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	// tuning / testing knobs: read once here, never on the call path
 	ctx->optTwoPass = getenv("VGX_TWO_PASS_FLATTEN") ? 1 : 0;
 	if (const char* e = getenv("VGX_PS_UPLOAD")) { ctx->optPsStage = strcmp(e, "stage") == 0; }
+	ctx->optTileEmit = 1;
+	if (const char* e = getenv("VGX_TILE_EMIT")) { ctx->optTileEmit = atoi(e) != 0; }
 	ctx->optPsNoSmall = getenv("VGX_PS_NO_SMALL") ? 1 : 0; // testing knob: frame-sized path sets through the large-set launch sequence
 	ctx->optBuildWaves = VGX_BUILD_WAVES;
 	ctx->optConcurrentEmit = getenv("VGX_EXP_CONCURRENT_EMIT") ? 1 : 0;
@@ -785,7 +805,7 @@ int vgx_destroy(vgx_ctx* ctx)
 		return VGX_E_INVALID_ARG;
 	}
 	DeviceGuard guard(ctx);
-	DevBuf* bufs[] = { &ctx->psTemp, &ctx->f1SegDraw, &ctx->f1Segs, &ctx->tmplHash, &ctx->tmplInstCls, &ctx->tmplClsRep, &ctx->tmplCls, &ctx->tmplIinfo, &ctx->tmplWg, &ctx->tmplTrmesh, &ctx->tmplTmsz, &ctx->tmplRsz, &ctx->tmplRelem, &ctx->tmplMplace, &ctx->tmplItot, &ctx->tmplIplace, &ctx->tmplTile, &ctx->tmplPoly, &ctx->tmplMesh, &ctx->tmplMtab, &ctx->tmplElem, &ctx->tmplDraws, &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DevBuf* bufs[] = { &ctx->tileTab, &ctx->psTemp, &ctx->f1SegDraw, &ctx->f1Segs, &ctx->tmplHash, &ctx->tmplInstCls, &ctx->tmplClsRep, &ctx->tmplCls, &ctx->tmplIinfo, &ctx->tmplWg, &ctx->tmplTrmesh, &ctx->tmplTmsz, &ctx->tmplRsz, &ctx->tmplRelem, &ctx->tmplMplace, &ctx->tmplItot, &ctx->tmplIplace, &ctx->tmplTile, &ctx->tmplPoly, &ctx->tmplMesh, &ctx->tmplMtab, &ctx->tmplElem, &ctx->tmplDraws, &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
@@ -812,7 +832,7 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx)
 	if (!ctx) {
 		return 0;
 	}
-	return ctx->psTemp.cap + ctx->f1SegDraw.cap + ctx->f1Segs.cap + ctx->tmplHash.cap + ctx->tmplInstCls.cap + ctx->tmplClsRep.cap + ctx->tmplCls.cap + ctx->tmplIinfo.cap + ctx->tmplWg.cap + ctx->tmplTrmesh.cap + ctx->tmplTmsz.cap + ctx->tmplRsz.cap + ctx->tmplRelem.cap + ctx->tmplMplace.cap + ctx->tmplItot.cap + ctx->tmplIplace.cap + ctx->tmplTile.cap + ctx->tmplPoly.cap + ctx->tmplMesh.cap + ctx->tmplMtab.cap + ctx->tmplElem.cap + ctx->tmplDraws.cap + ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
+	return ctx->tileTab.cap + ctx->psTemp.cap + ctx->f1SegDraw.cap + ctx->f1Segs.cap + ctx->tmplHash.cap + ctx->tmplInstCls.cap + ctx->tmplClsRep.cap + ctx->tmplCls.cap + ctx->tmplIinfo.cap + ctx->tmplWg.cap + ctx->tmplTrmesh.cap + ctx->tmplTmsz.cap + ctx->tmplRsz.cap + ctx->tmplRelem.cap + ctx->tmplMplace.cap + ctx->tmplItot.cap + ctx->tmplIplace.cap + ctx->tmplTile.cap + ctx->tmplPoly.cap + ctx->tmplMesh.cap + ctx->tmplMtab.cap + ctx->tmplElem.cap + ctx->tmplDraws.cap + ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
 }
 
 // ---- path set ---------------------------------------------------------------------------------------
@@ -1881,7 +1901,7 @@ int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 		sa.elem_prefix = nullptr; sa.elem_prefix_fill = (const uint64_t*)ctx->elemPrefix.p; sa.elem_prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
 		sa.mprep = (VgxMeshPrep*)ctx->mprep.p; sa.mtab = (vgx_mesh*)ctx->mtab.p;
 		sa.pos = nullptr; sa.color = nullptr; sa.idx = nullptr; sa.meshes_out = nullptr; sa.mesh_base = nullptr;
-		sa.totals = (VgxTotals*)ctx->totals.p; sa.caps = outCaps;
+		sa.totals = (VgxTotals*)ctx->totals.p; sa.caps = outCaps; sa.tile_mode = 0;
 		OpDrawInfo opD;
 		opD.dinfo = (vgx_draw_info*)ctx->dinfo.p; opD.ndraws = ndraws; opD.totals = (VgxTotals*)ctx->totals.p; opD.caps = ctx->caps; opD.keepPolyBase = 1;
 		OpMeshAll opM;

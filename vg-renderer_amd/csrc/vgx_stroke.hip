@@ -26,6 +26,7 @@
 #include "vgx_internal.h"
 #include "vgx_wave.h"
 #include "vgx_elem.h"
+#include "vgx_tile.h"
 
 namespace {
 
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(VGX_WAVE) VGX_FILL_OCC void k_fill(VgxStrokeArgs A)
 	__shared__ uint64_t s_pre[VGX_WAVE];
 	__shared__ float2 s_ring[VGX_FILL_RING + 4];
 	const int lane = threadIdx.x;
-	if (A.totals->status != VGX_OK) {
+	if (A.totals->status != VGX_OK || (A.tile_mode && vgx_tile_mode_on(A.totals))) { // (k_emit_tiles, vgx_tile.hip, writes such a batch's fills and strokes)
 		return;
 	}
 	const uint64_t numMeshes = A.totals->sizes.num_meshes;
@@ -558,7 +559,7 @@ void vgx_launch_fill(const VgxStrokeArgs& a, int numBlocks, hipStream_t s)
 void vgx_launch_stroke(bool emit, const VgxStrokeArgs& a, int numBlocks, hipStream_t s)
 {
 	if (emit) {
-		hipLaunchKernelGGL(k_stroke_simple, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a); // one of the two exits at once
+		if (!a.tile_mode) { hipLaunchKernelGGL(k_stroke_simple, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a); } // one of the two exits at once (tile mode: k_emit_tiles took the simple batches)
 		hipLaunchKernelGGL(k_stroke, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
 	} else { // sizes Round-join meshes; returns at once when the batch has none (every other size is closed-form)
 		hipLaunchKernelGGL(k_round_sizes, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);

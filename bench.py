@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0  # G wave64 VALU instructions / s: 1024 SIMDs, one instruction per 2 cycles, 2.4 GHz (MI355X_MICROARCH.md)
 
 
 def command_bytes(ps, draw_paths):
@@ -797,6 +798,7 @@ def roofline(res, steps, traffic_for=None):
     achieved = ab[dom] / (dom_ms * 1e-3) / 1e9
     ms_per_step = res["dt"] / steps * 1e3
     traffic = None
+    valu = None
     if traffic_for is not None:
         # HBM traffic of that kernel per launch: not measurable from inside the process; taken from the committed
         # rocprofv3 --pmc passes of this same command (profiles/traffic.json), only for the workload they were made on
@@ -805,12 +807,23 @@ def roofline(res, steps, traffic_for=None):
                 tj = json.load(f)
             if isinstance(traffic_for, str):
                 traffic = tj["configs"][traffic_for]["kernels"][dom]["traffic_bytes"]
+                valu = tj["configs"][traffic_for]["kernels"][dom].get("valu_insts")
             elif tj.get("instances_per_gpu") == traffic_for and dom in tj["kernels"]:
                 traffic = tj["kernels"][dom]["traffic_bytes"]
+                valu = tj["kernels"][dom].get("valu_insts")
         except (OSError, ValueError, KeyError):
             pass
+    # The second ruler ("VALU issue alongside"): vector instructions per launch (SQ_INSTS_VALU of the committed
+    # --pmc pass of this same command) / the live kernel time, against what the chip can issue -- 256 CUs x 4 SIMDs, one wave64 VALU
+    # instruction per SIMD every 2 cycles (MI355X_MICROARCH.md "Wave scheduling") at the 2.4 GHz maximum clock. For the kernels that HBM
+    # says nothing about (k_flat1: 0.07 of the HBM peak) this is the ruler that applies.
+    secondary = None
+    if valu:
+        ach = valu / (dom_ms * 1e-3) / 1e9
+        secondary = {"bound": "valu_issue", "achieved": round(ach, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": round(ach / VALU_PEAK_GINST, 4),
+                     "valu_insts_per_launch": valu}
     return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "secondary": secondary,
             "traffic_ratio": None if traffic is None else round(traffic / ab[dom], 3),
             "kernel_ms": round(dom_ms, 3), "algorithmic_bytes": ab[dom],
             "by_kernel": {k: {"ms": round(stage_sum[k], 3), "achieved": round(ab[k] / (stage_sum[k] * 1e-3) / 1e9, 1),
@@ -1050,7 +1063,7 @@ def main():
         if os.environ.get("VGX_BENCH_GATHER", "capi") == "capi" and not share_gpu:
             th = threading.Thread(target=capi_leg, daemon=True)
             th.start()
-            th.join(timeout=float(os.environ.get("VGX_BENCH_GATHER_TIMEOUT", "180")))
+            th.join(timeout=float(os.environ.get("VGX_BENCH_GATHER_TIMEOUT", "90")))
             if th.is_alive():
                 box["err"] = "timeout"
                 bail = True
@@ -1236,7 +1249,7 @@ def main():
                                           else "k_flatten_inst, periodic with the instances sorted by tolerance class on the device" if res.get("flatten_mode") == 4
                                           else "k_flatten_thin (lineTo-only path set: polyline layout decided when the set was created, gather - transform - scatter per batch)" if res.get("flatten_mode") == 6
                                           else "k_flatten_build (one lane per path command)")},
-            "roofline": roofline(res, args.steps, traffic_for=K if args.config == "tiger10k" else None),
+            "roofline": roofline(res, args.steps, traffic_for=K if args.config == "tiger10k" else args.config),
             "stage_ms": {k: round(v, 3) for k, v in res["stage"].items()},
             "cpu_baseline": cpu,
             "gpu_environment": genv,

@@ -35,13 +35,14 @@ def pmc(db, counter):
         print("%-90s %6d %14.1f %14.1f %12.1f" % (name[:90], n, kb, mb, dur / 1000.0))
 
 
-def traffic(fetch_db, write_db, label):
+def traffic(fetch_db, write_db, label, valu_db=None):
     """JSON for bench.py's roofline.traffic: HBM bytes per launch of the three big kernels = FETCH_SIZE x 2 (gfx950
     correction for wide coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE (raw), from two separate --pmc passes."""
     import json
     names = {"k_tmpl_emit": "tmpl_emit", "k_tmpl_emit_general": "tmpl_emit", "k_tmpl_emit_open": "tmpl_emit", "k_tmpl_emit_round": "tmpl_emit", "k_tmpl_emit_round_aa": "tmpl_emit", "k_tmpl_emit_round_aa_open": "tmpl_emit", "k_tmpl_emit_round_closed": "tmpl_emit", "k_tmpl_emit_bevel": "tmpl_emit", "k_tmpl_round_sizes": "tmpl_round_sizes", "k_tmpl_round_sizes_inst": "tmpl_round_sizes", "k_tmpl_round_sizes_block": "tmpl_round_sizes", "k_flatten_build": "flatten_build", "k_flatten_inst": "flatten_build", "k_fill": "fill_emit", "k_stroke": "stroke_emit", "k_stroke_simple": "stroke_emit", "k_flatten_gather": "flatten_gather", "k_mesh_prepare": "mesh_prepare",
              "k_flatten<false": "flatten_count", "k_flatten<true": "flatten_emit",  # vgx_flatten_count / _emit (two walks): count pass, emit pass
-             "k_flat1": "flatten_one_walk", "k_f1_seg_table": "flatten_one_walk"}   # vgx_flatten (cubics1m, round 5): the one-walk kernel (+ its segment table; the REDO instance exits at once)
+             "k_flat1": "flatten_one_walk", "k_f1_seg_table": "flatten_one_walk",
+             "k_emit_tiles": "tile_emit", "k_tile_table": "tile_emit"}  # round 6: the tile kernel of ordinary batches (+ its tile table)   # vgx_flatten (cubics1m, round 5): the one-walk kernel (+ its segment table; the REDO instance exits at once)
     out = {"source": label, "instances_per_gpu": 10000, "kernels": {}}
     for db, ctr, mul in ((fetch_db, "FETCH_SIZE", 2.0), (write_db, "WRITE_SIZE", 1.0)):
         c = sqlite3.connect(db).cursor()
@@ -50,6 +51,13 @@ def traffic(fetch_db, write_db, label):
                 if k + "(" in name or k + "<" in name or ("<" in k and k in name):
                     d = out["kernels"].setdefault(stage, {"fetch_bytes": 0, "write_bytes": 0})
                     d["fetch_bytes" if ctr == "FETCH_SIZE" else "write_bytes"] += int(kb * 1024 * mul)  # flatten_build = k_flatten_inst + the k_flatten_build launch that exits at once (or the other way round); stroke_emit = k_stroke_simple + k_stroke likewise
+    if valu_db:  # round 6: the second ruler (SURVEY 8d "VALU issue alongside"): vector instructions per launch, a --pmc SQ_INSTS_VALU pass of its own
+        c = sqlite3.connect(valu_db).cursor()
+        for name, v in c.execute("select kernel_name, avg(value) from counters_collection where counter_name='SQ_INSTS_VALU' group by kernel_name"):
+            for k, stage in names.items():
+                if k + "(" in name or k + "<" in name or ("<" in k and k in name):
+                    d = out["kernels"].setdefault(stage, {"fetch_bytes": 0, "write_bytes": 0})
+                    d["valu_insts"] = d.get("valu_insts", 0) + int(v)
     for d in out["kernels"].values():
         d["traffic_bytes"] = d["fetch_bytes"] + d["write_bytes"]
     print(json.dumps(out, indent=1))
@@ -75,6 +83,6 @@ if __name__ == "__main__":
     elif sys.argv[1] == "trace":
         trace(sys.argv[2])
     elif sys.argv[1] == "traffic":
-        traffic(sys.argv[2], sys.argv[3], sys.argv[4])
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else None)
     else:
         pmc(sys.argv[2], sys.argv[3])

@@ -78,6 +78,7 @@ struct vgx_ctx
 	DevBuf subPrefix; // exclusive scan of the draws' static sub-path counts
 	DevBuf cmdPrefix, cmdCnt, subFirst, leafOverflow, serialList, dinfo, poly, subs, mdesc, elemPrefix, elemPrefixS, mprep, mtab, partial, totals;
 	DevBuf tileTab;                      // k_emit_tiles (vgx_tile.hip): the tile table of the current call
+	bool tileHint;                       // the last ordinary vgx_tessellate_count saw fills and closed Miter AA / Thin strokes only (the tile kernel's batches)
 	int optTileEmit;                     // VGX_TILE_EMIT=0: ordinary batches through k_fill + k_stroke_simple as before round 6
 	DevBuf psTemp;                       // vgx_pathset_create: temporaries of the device-side build (vgx_pathset.hip)
 	hipStream_t psStream;                // ... its stream (created at the first call)
@@ -649,7 +650,7 @@ int runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out, 
 	// Batches of fills and closed Miter AA / Thin strokes (the scan over the meshes decides, on the device): one draw-ordered tile
 	// kernel instead of k_fill + k_stroke_simple (vgx_tile.hip). Not for frame-sized calls (two more launches than they are worth).
 	uint64_t capTiles = 0;
-	if (ctx->optTileEmit && !ctx->optConcurrentEmit && out->cap_vertices >= (1ull << 18) && out->cap_vertices / VGX_TILE_ELEMS + 2 < 0x7FFFFFFFull) {
+	if (ctx->optTileEmit && ctx->tileHint && !ctx->optConcurrentEmit && out->cap_vertices >= (1ull << 18) && out->cap_vertices / VGX_TILE_ELEMS + 2 < 0x7FFFFFFFull) {
 		capTiles = out->cap_vertices / VGX_TILE_ELEMS + 2; // every element emits at least one vertex
 		const int st = ensure(ctx, ctx->tileTab, capTiles * sizeof(VgxTileRec));
 		if (st != VGX_OK) { return st; }
@@ -1282,9 +1283,13 @@ int vgx_flatten(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint
 	// not by the walk: the two-walk kernels (count -> scan over draws -> emit, vgx_flatten.hip) are faster there (1 M cubics of
 	// ~5 segments: 0.43 against 0.63 ms), and they need no host round trip either once the batch's command total is known from
 	// the last call. Same output.
+	// The per-command words of the two walks are sized for ndraws x (longest path): what ANY draw list of this size can need on this path
+	// set (the tag only says that the set and the number of draws are the last call's -- the draws' paths may have changed).
+	// A set whose longest path is far above its mean (the bound above twice the last call's total) takes the one-walk route instead.
+	const uint64_t cmdBoundAll = ndraws * (uint64_t)(ps->maxCmdsPerPath ? ps->maxCmdsPerPath : 1);
 	if (ctx->hostF1 && ctx->f1Tag == tag && ctx->hostF1[1] != 0 && ctx->hostF1[2] == tag && !ctx->optF1Cap && !ctx->optF1Seg && !ps->hasEmpty
-		&& (double)ctx->hostF1[0] / (double)ctx->hostF1[1] * 64.0 <= 384.0) {
-		const uint64_t ncmdInst = ctx->hostF1[1];
+		&& (double)ctx->hostF1[0] / (double)ctx->hostF1[1] * 64.0 <= 384.0 && cmdBoundAll <= 2 * ctx->hostF1[1] + 4096) {
+		const uint64_t ncmdInst = cmdBoundAll;
 		if ((st = ensure(ctx, ctx->cmdCnt, (ncmdInst + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
 		// The device-side guard of THIS call only (a batch that grew: VGX_E_NOSPACE); the context's persistent cap -- what
 		// vgx_tessellate relies on for the scratch sized by the last count -- is put back right after the launch.
@@ -1839,6 +1844,9 @@ int vgx_tessellate_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* dr
 	*out_sizes = ctx->hostTotals->sizes;
 	if (ctx->hostTotals->status != VGX_OK) { return (int)ctx->hostTotals->status; } // _emit must not follow a failed count
 	ctx->lastPs = ps; ctx->lastDraws = draws; ctx->lastNDraws = ndraws; ctx->lastStage = 2;
+	// what the scan over the counted meshes found: a batch with open / Bevel / Round / non-AA strokes is k_fill's and k_stroke's, and the
+	// calls that follow a count like that do not launch the tile kernel at all (its 200 000 workgroups would only find that out again)
+	ctx->tileHint = ctx->hostTotals->has_general_stroke == 0u;
 	return VGX_OK;
 }
 

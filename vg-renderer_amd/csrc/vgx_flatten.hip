@@ -387,6 +387,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 	const uint64_t totalCmds = A.cmd_prefix[A.ndraws];
 	if (A.totals->status != VGX_OK) { return; }
 	if (A.inst_order != nullptr || (A.inst_period != 0 && A.totals->inst_mismatch == 0)) { return; } // instanced batch: k_flatten_inst builds it
+	if (A.thin_static && totalCmds <= A.caps.poly_vertices) { return; } // k_flatten_thin built it (this launch is its fallback: see there)
 	const uint64_t segItems = vgx_segment_items(totalCmds, gridDim.x);
 	const uint64_t numSegments = (totalCmds + segItems - 1) / segItems;
 	const uint64_t segsPerWave = (numSegments + gridDim.x - 1) / gridDim.x;
@@ -755,10 +756,10 @@ __global__ __launch_bounds__(VGX_THIN_THREADS) void k_flatten_thin(VgxFlattenArg
 	if (A.totals->status != VGX_OK) { return; }
 	if (A.inst_order != nullptr || (A.inst_period != 0 && A.totals->inst_mismatch == 0)) { return; } // instanced batch: k_flatten_inst builds it
 	const uint64_t totalCmds = A.cmd_prefix[A.ndraws];
-	if (totalCmds > A.caps.poly_vertices) {
-		if (blockIdx.x == 0 && tid == 0) { atomicCAS(&A.totals->status, (uint32_t)VGX_OK, (uint32_t)VGX_E_NOSPACE); }
-		return;
-	}
+	// This kernel places vertex k of draw d at cmd_prefix[d] + k: one heap vertex per COMMAND. A scratch that was sized by a count on
+	// another kind of batch may hold the batch's vertices and still not its commands: k_flatten_build (launched behind this kernel,
+	// it exits at once otherwise) builds such a batch from the real vertex counts
+	if (totalCmds > A.caps.poly_vertices) { return; }
 	if (blockIdx.x == 0 && tid == 0) { atomicAdd(&A.totals->poly_heap_cursor, (unsigned long long)totalCmds); }
 	const uint64_t numChunks = (totalCmds + VGX_THIN_CHUNK - 1) / VGX_THIN_CHUNK;
 	const uint64_t per = (numChunks + gridDim.x - 1) / gridDim.x;
@@ -1091,6 +1092,7 @@ void vgx_launch_flatten_build(const VgxFlattenArgs& a, int waves, hipStream_t s,
 		const dim3 grid(a.ndraws <= VGX_SMALL_DRAWS ? 64 : 2048); // (frame-sized batches: workgroups that find no chunk still cost their first loads)
 		if (a.thin_static == 2) { hipLaunchKernelGGL(k_flatten_thin<2>, grid, dim3(VGX_THIN_THREADS), 0, s, a); } // (VGX_THIN_STATIC=2: two command instances per thread)
 		else { hipLaunchKernelGGL(k_flatten_thin<4>, grid, dim3(VGX_THIN_THREADS), 0, s, a); }
+		hipLaunchKernelGGL(k_flatten_build<false>, dim3(a.ndraws <= VGX_SMALL_DRAWS ? 64 : waves), dim3(VGX_WAVE), 0, s, a); // (exits at once unless the scratch holds fewer vertices than the batch has commands)
 	} else if (a.pool_walk) {
 		hipLaunchKernelGGL(k_flatten_build<true>, dim3(waves), dim3(VGX_WAVE), 0, s, a);
 	} else {

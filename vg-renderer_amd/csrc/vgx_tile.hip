@@ -174,8 +174,13 @@ __global__ __launch_bounds__(TILE_THREADS) void k_emit_tiles(VgxStrokeArgs A, co
 		const uint32_t s = (uint32_t)c * TILE_THREADS + tid; // interleaved: consecutive lanes = consecutive vertices of the heap
 		em[c] = 0; ej[c] = 0; p1[c] = v2(0.0f, 0.0f);
 		if (s < nel) {
-			uint32_t lo = 0, hi = nm; // s_start[lo] <= s < s_start[hi]  (s_start[0] <= 0, s_start[nm] = +inf)
-			while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_start[mid] <= (int)s) { lo = mid; } else { hi = mid; } }
+			// the mesh that owns tile position s: s_start[lo] <= s < s_start[lo + 1] (s_start[0] <= 0, s_start[nm] = +inf). Meshes of a
+			// drawing are of similar length: start where equal lengths would put it and walk (one to three steps instead of the eight of a
+			// bisection, each a dependent LDS round trip on the workgroup's critical path)
+			uint32_t lo = (uint32_t)(((uint64_t)s * nm) / nel);
+			lo = lo < nm ? lo : nm - 1;
+			while (s_start[lo] > (int)s) { --lo; }
+			while (s_start[lo + 1] <= (int)s) { ++lo; }
 			em[c] = lo;
 			ej[c] = (uint32_t)((int)s - s_start[lo]);
 			const float2 v = poly[s_poly[lo] + ej[c]];

@@ -625,6 +625,7 @@ int runAssemble(vgx_ctx* ctx, const vgx_mesh_out* out, hipStream_t s, const vgx_
 	a.mesh_cmd = a.jump0;
 	a.partial = ctx->partial.p;
 	a.max_meshes = meshCap;
+	a.scan_bound = (out->meshes && out->cap_meshes && out->cap_meshes < meshCap) ? out->cap_meshes : meshCap; // (more meshes than the caller's table holds: VGX_E_NOSPACE was set by the scan over the meshes, the scan here covers nothing)
 	a.uv = ctx->asmCfg.uv; a.uv_bytes = ctx->asmCfg.uv ? ctx->asmCfg.uv_bytes : 0u; a.uv_value[0] = ctx->asmCfg.uv_value[0]; a.uv_value[1] = ctx->asmCfg.uv_value[1];
 	vgx_launch_assemble(a, s);
 	mark(ctx, s, "assemble");
@@ -1891,7 +1892,7 @@ int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 	outCaps.vertices = out->cap_vertices;
 	outCaps.indices = out->cap_indices;
 	if (out->meshes && out->cap_meshes < outCaps.meshes) { outCaps.meshes = out->cap_meshes; }
-	if (ndraws <= VGX_SMALL_DRAWS && !ctx->asmArmed && !ctx->optTwoPass && !ctx->optNoSmall) {
+	if (ndraws <= VGX_SMALL_DRAWS && !ctx->optTwoPass && !ctx->optNoSmall) { // (round 6: also with draw-command assembly armed -- runStrokeEmit runs the partition kernels in front of the emit either way)
 		// frame-sized batch: five launches instead of seventeen (vgx_flatten.hip, "Frame-sized batches")
 		OpCmdPrefix opC;
 		opC.draws = draws; opC.pathCmdBegin = ps->dev.path_cmd_begin; opC.npaths = ps->dev.npaths; opC.ndraws = ndraws;
@@ -1918,7 +1919,12 @@ int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 		opM.totals = (VgxTotals*)ctx->totals.p; opM.caps = outCaps; opM.checkCaps = 1; opM.fixedSize = 0; opM.fixedCount = 0;
 		vgx_launch_small_middle(f, sa, &opD, &opM, dev_sizes, dev_status, s);
 		mark(ctx, s, "small_middle");
-		return runStrokeEmit(ctx, draws, out, s, nullptr, true);
+		const int est = runStrokeEmit(ctx, draws, out, s, nullptr, true);
+		if (est != VGX_OK) { return est; }
+		if (ctx->asmArmed && (dev_sizes || dev_status)) { // the partition kernels may have ended the call (a mesh beyond any vertex buffer, the command table full): the verdict once more
+			hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, s, (const VgxTotals*)ctx->totals.p, dev_sizes, dev_status);
+		}
+		return launchStatus(ctx);
 	}
 	runCmdPrefix(ctx, ps, draws, ndraws, s, ctx->optTwoPass ? 0u : instPeriodFor(ctx, ndraws));
 	if (ctx->optTwoPass) { // tuning / debugging knob: the ordered two-pass flatten

@@ -36,13 +36,12 @@ namespace {
 // The answer moves with i (next[i] - i ~ maxVB / average mesh size), so the search gallops outwards from that estimate
 // and finishes with a binary search inside the bracket: ~2 log2(error) probes that neighbouring threads share in cache,
 // instead of log2(M) scattered ones.
-__global__ __launch_bounds__(256) void k_asm_next(VgxAsmArgs A)
+__device__ __forceinline__ void asm_next(const VgxAsmArgs& A, uint64_t tid, uint64_t stride)
 {
-	if (A.totals->status != VGX_OK) { return; }
 	const uint64_t M = A.totals->sizes.num_meshes;
 	const uint64_t totalV = A.totals->sizes.num_vertices;
 	const uint64_t est = M && totalV ? (uint64_t)A.max_vb * M / totalV : 1; // meshes per vertex buffer, on average
-	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= M; i += (uint64_t)gridDim.x * blockDim.x) {
+	for (uint64_t i = tid; i <= M; i += stride) {
 		if (i == M) { A.jump0[M] = (uint32_t)M; continue; }
 		const uint64_t limit = A.mtab[i].first_vertex + (uint64_t)A.max_vb;
 		// meshes i..j-1 fit iff end(j-1) = V[j-1] + nv[j-1] <= limit; ends are non-decreasing.
@@ -78,20 +77,29 @@ __global__ __launch_bounds__(256) void k_asm_next(VgxAsmArgs A)
 		A.jump0[i] = (uint32_t)lo;
 	}
 }
-
-// one doubling round: n = number of buffer starts known so far (a power of two), J = next^n
-__global__ __launch_bounds__(256) void k_asm_round(VgxAsmArgs A, const uint32_t* J, uint32_t* Jout, uint32_t n)
+__global__ __launch_bounds__(256) void k_asm_next(VgxAsmArgs A)
 {
 	if (A.totals->status != VGX_OK) { return; }
+	asm_next(A, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
+}
+
+// one doubling round: n = number of buffer starts known so far (a power of two), J = next^n
+__device__ __forceinline__ void asm_round(const VgxAsmArgs& A, const uint32_t* J, uint32_t* Jout, uint32_t n, uint64_t tid, uint64_t stride)
+{
 	const uint64_t M = A.totals->sizes.num_meshes;
-	if (M == 0 || A.start[n - 1] >= M) { return; } // the chain already ran off the end: nothing left to extend
-	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= M; i += (uint64_t)gridDim.x * blockDim.x) {
+	if (M == 0 || A.start[n - 1] >= M) { return; } // the chain already ran off the end: nothing left to extend (uniform: start[n - 1] was written a round ago)
+	for (uint64_t i = tid; i <= M; i += stride) {
 		if (i < n) {
 			const uint32_t s = A.start[i];
 			A.start[n + i] = s >= M ? (uint32_t)M : J[s];
 		}
 		Jout[i] = J[J[i]];
 	}
+}
+__global__ __launch_bounds__(256) void k_asm_round(VgxAsmArgs A, const uint32_t* J, uint32_t* Jout, uint32_t n)
+{
+	if (A.totals->status != VGX_OK) { return; }
+	asm_round(A, J, Jout, n, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
 }
 
 __global__ __launch_bounds__(256) void k_asm_init(VgxAsmArgs A)
@@ -100,9 +108,8 @@ __global__ __launch_bounds__(256) void k_asm_init(VgxAsmArgs A)
 	if (i < A.cap_start) { A.start[i] = i == 0 ? 0u : 0xFFFFFFFFu; }
 }
 
-__global__ __launch_bounds__(256) void k_asm_assign(VgxAsmArgs A)
+__device__ __forceinline__ void asm_assign(const VgxAsmArgs& A, const uint64_t tid, const uint64_t stride)
 {
-	if (A.totals->status != VGX_OK) { return; }
 	const uint64_t M = A.totals->sizes.num_meshes;
 	// number of vertex buffers T = entries of start[] below M (start[] is increasing until it saturates at M / unset)
 	uint64_t lo = 0, hi = A.cap_start;
@@ -111,14 +118,13 @@ __global__ __launch_bounds__(256) void k_asm_assign(VgxAsmArgs A)
 		if ((uint64_t)A.start[mid] < M) { lo = mid + 1; } else { hi = mid; }
 	}
 	const uint64_t T = lo;
-	const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (tid == 0) {
 		A.totals->sizes.num_drawcmds = T;
 		if (T > A.cap_drawcmds) { atomicCAS(&A.totals->status, (uint32_t)VGX_OK, (uint32_t)VGX_E_NOSPACE); }
 		if (A.dev_num_drawcmds) { *A.dev_num_drawcmds = T; }
 	}
 	if (T > A.cap_drawcmds) { return; }
-	for (uint64_t i = tid; i < M; i += (uint64_t)gridDim.x * blockDim.x) {
+	for (uint64_t i = tid; i < M; i += stride) {
 		uint64_t a = 0, b = T; // last t with start[t] <= i
 		while (b - a > 1) {
 			const uint64_t mid = (a + b) >> 1;
@@ -146,6 +152,11 @@ __global__ __launch_bounds__(256) void k_asm_assign(VgxAsmArgs A)
 		}
 	}
 }
+__global__ __launch_bounds__(256) void k_asm_assign(VgxAsmArgs A)
+{
+	if (A.totals->status != VGX_OK) { return; }
+	asm_assign(A, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
+}
 
 // ---- VGX_ASM_SPLIT_STATE -------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t asm_num_vbs(const VgxAsmArgs& A, uint64_t M)
@@ -159,12 +170,11 @@ __device__ __forceinline__ uint64_t asm_num_vbs(const VgxAsmArgs& A, uint64_t M)
 }
 
 // per mesh: its vertex buffer (bit 31: the mesh starts it). Written over jump1 (the doubling is done).
-__global__ __launch_bounds__(256) void k_asm_vb(VgxAsmArgs A, uint32_t* meshVb)
+__device__ __forceinline__ void asm_vb(const VgxAsmArgs& A, uint32_t* meshVb, uint64_t tid, uint64_t stride)
 {
-	if (A.totals->status != VGX_OK) { return; }
 	const uint64_t M = A.totals->sizes.num_meshes;
 	const uint64_t T = asm_num_vbs(A, M);
-	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (uint64_t)gridDim.x * blockDim.x) {
+	for (uint64_t i = tid; i < M; i += stride) {
 		uint64_t a = 0, b = T; // last t with start[t] <= i
 		while (b - a > 1) {
 			const uint64_t mid = (a + b) >> 1;
@@ -174,12 +184,18 @@ __global__ __launch_bounds__(256) void k_asm_vb(VgxAsmArgs A, uint32_t* meshVb)
 		if (A.mtab[i].num_vertices > A.max_vb) { atomicCAS(&A.totals->status, (uint32_t)VGX_OK, (uint32_t)VGX_E_MESH_TOO_LARGE); }
 	}
 }
+__global__ __launch_bounds__(256) void k_asm_vb(VgxAsmArgs A, uint32_t* meshVb)
+{
+	if (A.totals->status != VGX_OK) { return; }
+	asm_vb(A, meshVb, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
+}
 
 struct OpAsmCmd // scan over the meshes of "this mesh starts a draw command"
 {
 	VgxAsmArgs A;
 	const uint32_t* meshVb;
-	__device__ uint64_t size() const { return A.totals->status == VGX_OK ? A.totals->sizes.num_meshes : 0; }
+	int fixedSize; uint64_t fixedCount; // single-workgroup caller: the count every thread must agree on (read once, uniformly)
+	__device__ uint64_t size() const { return fixedSize ? fixedCount : (A.totals->status == VGX_OK ? A.totals->sizes.num_meshes : 0); }
 	__device__ uint32_t key(uint64_t i) const { return A.draws[A.mdesc[i].draw].state_key; }
 	__device__ bool starts(uint64_t i) const { return (meshVb[i] >> 31) != 0 || i == 0 || key(i) != key(i - 1); }
 	__device__ Sum3 load(uint64_t i) const { Sum3 r = sum3_zero(); r.a = starts(i) ? 1 : 0; return r; }
@@ -208,16 +224,15 @@ struct OpAsmCmd // scan over the meshes of "this mesh starts a draw command"
 	}
 };
 
-__global__ __launch_bounds__(256) void k_asm_cmd_finish(VgxAsmArgs A)
+__device__ __forceinline__ void asm_cmd_finish(const VgxAsmArgs& A, uint64_t tid, uint64_t stride)
 {
-	if (A.totals->status != VGX_OK) { return; }
 	const uint64_t M = A.totals->sizes.num_meshes;
 	const uint64_t T = A.totals->sizes.num_drawcmds;
-	const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	for (uint64_t i = tid; i < M; i += (uint64_t)gridDim.x * blockDim.x) {
+	if (T > A.cap_drawcmds) { return; } // (the table is full: VGX_E_NOSPACE is set, nothing past its end is touched)
+	for (uint64_t i = tid; i < M; i += stride) {
 		A.mesh_base[i] = (uint32_t)(A.mtab[i].first_vertex - A.drawcmds[A.mesh_cmd[i]].first_vertex);
 	}
-	for (uint64_t c = tid; c < T; c += (uint64_t)gridDim.x * blockDim.x) {
+	for (uint64_t c = tid; c < T; c += stride) {
 		vgx_drawcmd d = A.drawcmds[c];
 		const bool last = c + 1 == T;
 		const uint64_t endV = last ? A.totals->sizes.num_vertices : A.drawcmds[c + 1].first_vertex;
@@ -228,18 +243,21 @@ __global__ __launch_bounds__(256) void k_asm_cmd_finish(VgxAsmArgs A)
 		A.drawcmds[c].num_meshes = (uint32_t)(endM - d.first_mesh);
 	}
 }
-
-// vgutil::memset32 / memset64 of the white-pixel UV over the frame's vertices (vg.cpp:5218-5225)
-__global__ __launch_bounds__(256) void k_asm_uv(VgxAsmArgs A)
+__global__ __launch_bounds__(256) void k_asm_cmd_finish(VgxAsmArgs A)
 {
 	if (A.totals->status != VGX_OK) { return; }
+	asm_cmd_finish(A, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
+}
+
+// vgutil::memset32 / memset64 of the white-pixel UV over the frame's vertices (vg.cpp:5218-5225)
+__device__ __forceinline__ void asm_uv(const VgxAsmArgs& A, const uint64_t tid, const uint64_t stride)
+{
 	const uint64_t n = A.totals->sizes.num_vertices;
 	const uint64_t words = A.uv_bytes == 8 ? 2 * n : n; // 32-bit words
 	const uint64_t quads = words / 4;
 	uint32_t* p = (uint32_t*)A.uv;
 	const uint32_t v0 = A.uv_value[0], v1 = A.uv_bytes == 8 ? A.uv_value[1] : A.uv_value[0];
 	const uint4 q = make_uint4(v0, v1, v0, v1);
-	const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
 	if (((uintptr_t)p & 15u) == 0) {
 		for (uint64_t i = tid; i < quads; i += stride) { ((uint4*)p)[i] = q; }
 		for (uint64_t i = quads * 4 + tid; i < words; i += stride) { p[i] = (i & 1) ? v1 : v0; }
@@ -247,11 +265,61 @@ __global__ __launch_bounds__(256) void k_asm_uv(VgxAsmArgs A)
 		for (uint64_t i = tid; i < words; i += stride) { p[i] = (i & 1) ? v1 : v0; }
 	}
 }
+__global__ __launch_bounds__(256) void k_asm_uv(VgxAsmArgs A)
+{
+	if (A.totals->status != VGX_OK) { return; }
+	asm_uv(A, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
+}
+
+// Frame-sized batches (a few hundred meshes, a handful of vertex buffers): every pass above by ONE workgroup, block barriers in
+// place of the eight to ten dependent launches (each ~7 us on a GPU that idles between frames; the passes themselves are a few
+// loads per mesh). The status is read ONCE, uniformly: a verdict reached inside (a mesh beyond any vertex buffer, the command table
+// full) lets the remaining passes run to their ends -- they stay inside their tables -- and is published by the caller.
+#define VGX_ASM_SMALL_THREADS 1024
+__global__ __launch_bounds__(VGX_ASM_SMALL_THREADS) void k_asm_small(VgxAsmArgs A)
+{
+	__shared__ Sum3 s_wave[VGX_ASM_SMALL_THREADS / 64];
+	__shared__ uint32_t s_status;
+	__shared__ unsigned long long s_meshes;
+	const uint64_t tid = threadIdx.x, T = VGX_ASM_SMALL_THREADS;
+	if (tid == 0) {
+		s_status = __hip_atomic_load(&A.totals->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		s_meshes = A.totals->sizes.num_meshes;
+	}
+	for (uint64_t i = tid; i < A.cap_start; i += T) { A.start[i] = i == 0 ? 0u : 0xFFFFFFFFu; }
+	__syncthreads();
+	if (s_status != VGX_OK) { return; }
+	asm_next(A, tid, T);
+	__syncthreads();
+	const uint32_t* J = A.jump0;
+	uint32_t* Jn = A.jump1;
+	for (uint32_t n = 1; n < A.cap_start; n <<= 1) {
+		asm_round(A, J, Jn, n, tid, T);
+		__syncthreads();
+		const uint32_t* t = J; J = Jn; Jn = (uint32_t*)t;
+	}
+	// (the host's loop swaps the tables the same number of times: jump1 holds dead doubling data at this point either way)
+	if ((A.flags & VGX_ASM_SPLIT_STATE) && A.draws) {
+		asm_vb(A, A.jump1, tid, T);
+		__syncthreads();
+		OpAsmCmd op;
+		op.A = A; op.meshVb = A.jump1; op.fixedSize = 1; op.fixedCount = s_meshes;
+		block_scan_all<OpAsmCmd, VGX_ASM_SMALL_THREADS>(op, s_wave);
+		asm_cmd_finish(A, tid, T);
+	} else {
+		asm_assign(A, tid, T);
+	}
+	if (A.uv && A.uv_bytes) { asm_uv(A, tid, T); }
+}
 
 } // namespace
 
 void vgx_launch_assemble(const VgxAsmArgs& a, hipStream_t s)
 {
+	if (a.scan_bound <= 8192 && a.cap_start <= 1024) { // a frame: one launch
+		hipLaunchKernelGGL(k_asm_small, dim3(1), dim3(VGX_ASM_SMALL_THREADS), 0, s, a);
+		return;
+	}
 	hipLaunchKernelGGL(k_asm_init, dim3((unsigned)((a.cap_start + 255) / 256)), dim3(256), 0, s, a);
 	hipLaunchKernelGGL(k_asm_next, dim3(2048), dim3(256), 0, s, a);
 	const uint32_t* J = a.jump0;
@@ -264,8 +332,8 @@ void vgx_launch_assemble(const VgxAsmArgs& a, hipStream_t s)
 		// the jump tables are dead now: jump1 holds every mesh's vertex buffer, jump0 (= mesh_cmd) its draw command
 		hipLaunchKernelGGL(k_asm_vb, dim3(2048), dim3(256), 0, s, a, a.jump1);
 		OpAsmCmd op;
-		op.A = a; op.meshVb = a.jump1;
-		vgx_device_scan(op, (Sum3*)a.partial, s, a.max_meshes);
+		op.A = a; op.meshVb = a.jump1; op.fixedSize = 0; op.fixedCount = 0;
+		vgx_device_scan(op, (Sum3*)a.partial, s, a.scan_bound); // (a frame's few hundred meshes: one launch instead of three)
 		hipLaunchKernelGGL(k_asm_cmd_finish, dim3(2048), dim3(256), 0, s, a);
 	} else {
 		hipLaunchKernelGGL(k_asm_assign, dim3(2048), dim3(256), 0, s, a);

@@ -256,7 +256,8 @@ struct VgxAsmArgs
 	const vgx_draw* draws;     // draw -> state_key (null: no draws at this level, e.g. the shape cache)
 	uint32_t* mesh_cmd;        // [meshes] scratch: draw command of every mesh (aliases jump0 once the doubling is done)
 	void* partial;             // scan partials (Sum3[VGX_SCAN_BLOCKS])
-	uint64_t max_meshes;       // host-known bound of the mesh count (launch shape of the scan)
+	uint64_t max_meshes;       // capacity of the per-mesh scratch
+	uint64_t scan_bound;       // host-known bound of the mesh count (launch shape of the scan over the meshes): the caller's mesh capacity when it gave a table
 	// white-pixel UV stream (vg.cpp:5218-5225)
 	void* uv; uint32_t uv_bytes; uint32_t uv_value[2];
 };

@@ -11,7 +11,7 @@ mkdir -p vg-renderer_amd/dbg
 for spec in "$@"; do
   name=${spec%% *}; extra=${spec#* }; [ "$extra" = "$spec" ] && extra=""
   obj=vg-renderer_amd/dbg/obj_$name; mkdir -p $obj
-  for f in vgx_api vgx_flatten vgx_flat1 vgx_inst vgx_tmpl vgx_stroke vgx_concave vgx_merge vgx_cmdlist vgx_assemble vgx_cache; do
+  for f in vgx_api vgx_pathset vgx_tile vgx_flatten vgx_flat1 vgx_inst vgx_tmpl vgx_stroke vgx_concave vgx_merge vgx_cmdlist vgx_assemble vgx_cache; do
     slp=""; case $f in vgx_flatten|vgx_flat1|vgx_inst) slp="-fno-slp-vectorize";; esac
     /opt/rocm/bin/hipcc $FLAGS $slp $extra -c $SRC/$f.hip -o $obj/$f.o &
   done

@@ -6,7 +6,7 @@ import importlib
 import numpy as np
 import pytest
 
-from util import assert_flat_equal, assert_mesh_equal
+from util import assert_flat_equal, assert_mesh_equal, run_async
 
 pytestmark = pytest.mark.gpu
 
@@ -587,3 +587,37 @@ def test_async_thin_path_set_steady_state_other_draws(rt, gpu_ctx, wl, oracle):
     got.meshes = bufs.meshes[:nm * 32].cpu().numpy().view(rt.capi.mesh_dtype)
     assert_mesh_equal(got, ref, "thin set, steady state with other draws")
     pset.close()
+
+
+@pytest.mark.parametrize("style", ["round_round", "round_butt_wide", "bevel_square", "miter_round_nonaa", "closed_round"])
+def test_long_polylines_through_the_staged_stroke_kernel(rt, wl, oracle, style):
+    """Batches whose stroke meshes are ALL long (>= 128 elements) are emitted by k_stroke_long: a chunk that lies inside one mesh writes its
+    colours and indices into LDS and the wave copies them out as dense runs (round 6). Long polylines in every general style -- arcs of one
+    to many points (wide strokes: chunks that outgrow the stage fall back to per-lane stores), Bevel joins, Round / Square / Butt caps, non-AA
+    strokes, closed polygons with Round joins --, enough of them for the large-batch launch sequence; chunks at a mesh's ends span two meshes
+    (per-lane stores there). Bit-exact against the reference."""
+    capi = rt.capi
+    cap, join, width, aa, sigma = {"round_round": (capi.CAP_ROUND, capi.JOIN_ROUND, 6.0, True, 0.5), "round_butt_wide": (capi.CAP_BUTT, capi.JOIN_ROUND, 60.0, True, 1.2),
+                                   "bevel_square": (capi.CAP_SQUARE, capi.JOIN_BEVEL, 4.0, True, 0.7), "miter_round_nonaa": (capi.CAP_ROUND, capi.JOIN_MITER, 5.0, False, 0.4),
+                                   "closed_round": (capi.CAP_BUTT, capi.JOIN_ROUND, 8.0, True, 0.6)}[style]
+    ps, d = wl.random_walk_polylines(700, 333, seed=77, width=width, cap=cap, join=join, turn_sigma=sigma)
+    if not aa:
+        d["stroke_flags"] = capi.stroke_flags(cap, join, aa=False)
+    if style == "closed_round":  # the same polylines closed: pathClose behind every path
+        b = importlib.import_module("vg-renderer_amd").PathSetBuilder()
+        pts = ps.args.reshape(700, 334, 2)
+        for k in range(700):
+            b.begin_path()
+            b.move_to(float(pts[k, 0, 0]), float(pts[k, 0, 1]))
+            for q in pts[k, 1:]:
+                b.line_to(float(q[0]), float(q[1]))
+            b.close()
+            b.end_path()
+        ps = b.arrays()
+    ctx = rt.Context(0)
+    got = run_async(rt, ctx, ps, d, profile=True)
+    ref = oracle.tessellate(ps, d)
+    assert ref.pos.shape[0] > (1 << 18), "large enough for the large-batch sequence (k_stroke_long is not launched for frame-sized calls)"
+    assert got.status == 0
+    assert_mesh_equal(got, ref, "long polylines, " + style)
+    ctx.close()

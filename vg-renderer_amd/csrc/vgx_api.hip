@@ -79,6 +79,7 @@ struct vgx_ctx
 	DevBuf cmdPrefix, cmdCnt, subFirst, leafOverflow, serialList, dinfo, poly, subs, mdesc, elemPrefix, elemPrefixS, mprep, mtab, partial, totals;
 	DevBuf tileTab;                      // k_emit_tiles (vgx_tile.hip): the tile table of the current call
 	bool tileHint;                       // the last ordinary vgx_tessellate_count saw fills and closed Miter AA / Thin strokes only (the tile kernel's batches)
+	int optStrokeLong;                   // VGX_STROKE_LONG=0: batches of long polylines through k_stroke like any other (no LDS-staged stores)
 	int optTileEmit;                     // VGX_TILE_EMIT=0: ordinary batches through k_fill + k_stroke_simple as before round 6
 	DevBuf psTemp;                       // vgx_pathset_create: temporaries of the device-side build (vgx_pathset.hip)
 	hipStream_t psStream;                // ... its stream (created at the first call)
@@ -583,7 +584,7 @@ void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps,
 	a.elem_prefix = nullptr; a.elem_prefix_fill = (const uint64_t*)ctx->elemPrefix.p; a.elem_prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
 	a.mprep = (VgxMeshPrep*)ctx->mprep.p; a.mtab = (vgx_mesh*)ctx->mtab.p;
 	a.pos = nullptr; a.color = nullptr; a.idx = nullptr; a.meshes_out = nullptr; a.mesh_base = nullptr;
-	a.totals = (VgxTotals*)ctx->totals.p; a.caps = outCaps; a.tile_mode = 0;
+	a.totals = (VgxTotals*)ctx->totals.p; a.caps = outCaps; a.tile_mode = 0; a.no_long = 0;
 	if (!prepDone) { vgx_launch_mesh_prepare(a, s); }
 	vgx_launch_stroke(false, a, 32768, s); // k_round_sizes: Round-join mesh sizes (exits immediately without Round joins); one wave per mesh: 10 000 long polylines want more than 4 096 waves
 	mark(ctx, s, "mesh_prepare");
@@ -648,6 +649,7 @@ int runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out, 
 	a.totals = (VgxTotals*)ctx->totals.p;
 	a.caps = ctx->caps;
 	a.tile_mode = 0;
+	a.no_long = (out->cap_vertices < (1ull << 18) || !ctx->optStrokeLong) ? 1 : 0; // frame-sized: one stroke kernel less to launch
 	// Batches of fills and closed Miter AA / Thin strokes (the scan over the meshes decides, on the device): one draw-ordered tile
 	// kernel instead of k_fill + k_stroke_simple (vgx_tile.hip). Not for frame-sized calls (two more launches than they are worth).
 	uint64_t capTiles = 0;
@@ -766,6 +768,8 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	// tuning / testing knobs: read once here, never on the call path
 	ctx->optTwoPass = getenv("VGX_TWO_PASS_FLATTEN") ? 1 : 0;
 	if (const char* e = getenv("VGX_PS_UPLOAD")) { ctx->optPsStage = strcmp(e, "stage") == 0; }
+	ctx->optStrokeLong = 1;
+	if (const char* e = getenv("VGX_STROKE_LONG")) { ctx->optStrokeLong = atoi(e) != 0; }
 	ctx->optTileEmit = 1;
 	if (const char* e = getenv("VGX_TILE_EMIT")) { ctx->optTileEmit = atoi(e) != 0; }
 	ctx->optPsNoSmall = getenv("VGX_PS_NO_SMALL") ? 1 : 0; // testing knob: frame-sized path sets through the large-set launch sequence
@@ -1910,7 +1914,7 @@ int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 		sa.elem_prefix = nullptr; sa.elem_prefix_fill = (const uint64_t*)ctx->elemPrefix.p; sa.elem_prefix_stroke = (const uint64_t*)ctx->elemPrefixS.p;
 		sa.mprep = (VgxMeshPrep*)ctx->mprep.p; sa.mtab = (vgx_mesh*)ctx->mtab.p;
 		sa.pos = nullptr; sa.color = nullptr; sa.idx = nullptr; sa.meshes_out = nullptr; sa.mesh_base = nullptr;
-		sa.totals = (VgxTotals*)ctx->totals.p; sa.caps = outCaps; sa.tile_mode = 0;
+		sa.totals = (VgxTotals*)ctx->totals.p; sa.caps = outCaps; sa.tile_mode = 0; sa.no_long = 1;
 		OpDrawInfo opD;
 		opD.dinfo = (vgx_draw_info*)ctx->dinfo.p; opD.ndraws = ndraws; opD.totals = (VgxTotals*)ctx->totals.p; opD.caps = ctx->caps; opD.keepPolyBase = 1;
 		OpMeshAll opM;

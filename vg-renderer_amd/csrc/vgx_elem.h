@@ -52,6 +52,7 @@ struct StrokeWriter
 	uint16_t* idx;
 	uint32_t color, c0;
 	uint32_t ib; // added to every index written (assembly: vertices in front of the mesh inside its vertex buffer)
+	uint32_t vo = 0, io = 0; // subtracted from every vertex / index POSITION (not value): pos / col / idx may point at the LDS stage of ONE chunk, which begins at the chunk's first vertex / index (stroke_chunk)
 	float sx[4], sy[4];
 	uint32_t sc[4];
 	uint32_t si[24];
@@ -92,8 +93,8 @@ struct StrokeWriter
 	VGX_EL void v(uint32_t i, V2 p, uint32_t c) const
 	{
 		VGX_ST_GUARD(c) {
-		*(float2*)(pos + 2 * (size_t)i) = make_float2(p.x, p.y);
-		col[i] = c;
+		*(float2*)(pos + 2 * (size_t)(i - vo)) = make_float2(p.x, p.y);
+		col[i - vo] = c;
 		}
 	}
 	// two consecutive vertices in one 16-byte + one 8-byte store (the arc loops of Round joins / caps write pairs)
@@ -101,9 +102,9 @@ struct StrokeWriter
 	{
 		VGX_ST_GUARD(c ^ d) {
 		PosPair pp; pp.x0 = p.x; pp.y0 = p.y; pp.x1 = q.x; pp.y1 = q.y;
-		*(PosPair*)(pos + 2 * (size_t)i) = pp;
+		*(PosPair*)(pos + 2 * (size_t)(i - vo)) = pp;
 		ColPair cp; cp.c0 = c; cp.c1 = d;
-		*(ColPair*)(col + i) = cp;
+		*(ColPair*)(col + (i - vo)) = cp;
 		}
 	}
 	// three consecutive triangles (18 contiguous bytes) in one 16-byte + one 2-byte store
@@ -113,12 +114,12 @@ struct StrokeWriter
 		t.a = ((a0 + ib) & 0xFFFFu) | ((a1 + ib) << 16); t.b = ((a2 + ib) & 0xFFFFu) | ((b0 + ib) << 16);
 		t.c = ((b1 + ib) & 0xFFFFu) | ((b2 + ib) << 16); t.d = ((c0 + ib) & 0xFFFFu) | ((c1 + ib) << 16);
 		t.e = (uint16_t)(c2 + ib);
-		VGX_ST_GUARD(t.a ^ t.d) { *(Idx9*)(idx + k) = t; }
+		VGX_ST_GUARD(t.a ^ t.d) { *(Idx9*)(idx + (k - io)) = t; }
 	}
 	VGX_EL void tri(uint32_t k, uint32_t a, uint32_t b, uint32_t c) const
 	{
 		Idx3 t; t.a = ((a + ib) & 0xFFFFu) | ((b + ib) << 16); t.b = (uint16_t)(c + ib);
-		VGX_ST_GUARD(t.a) { *(Idx3*)(idx + k) = t; }
+		VGX_ST_GUARD(t.a) { *(Idx3*)(idx + (k - io)) = t; }
 	}
 	VGX_EL void bridge4(uint32_t k, Rails p, Rails c) const
 	{
@@ -142,8 +143,8 @@ struct StrokeWriter
 	}
 	VGX_EL void flush_(uint32_t b, uint32_t k) const
 	{
-		float* pp = pos + 2 * (size_t)b;
-		uint32_t* pc = col + b;
+		float* pp = pos + 2 * (size_t)(b - vo);
+		uint32_t* pc = col + (b - vo);
 		if (nvS >= 2) {
 			PosPair q; q.x0 = sx[0]; q.y0 = sy[0]; q.x1 = sx[1]; q.y1 = sy[1];
 			*(PosPair*)pp = q;
@@ -160,7 +161,7 @@ struct StrokeWriter
 			*(float2*)(pp + 4) = make_float2(sx[2], sy[2]);
 			pc[2] = sc[2];
 		}
-		uint16_t* pi = idx + k;
+		uint16_t* pi = idx + (k - io);
 #pragma unroll
 		for (uint32_t g = 0; g < 4; ++g) {
 			if (niS > 6 * g) {
@@ -685,9 +686,24 @@ VGX_EL VgxMeshPrep mesh_prep(const VgxMeshDesc& md, const vgx_draw* dr, const fl
 // ------------------------------------------------------------------------------------------------
 struct StrokeCarry { uint32_t v, i; uint64_t rails; };
 
-template<class VS>
+// LDS stage of one chunk's output (k_stroke, round 6): a chunk whose elements all belong to ONE mesh writes its vertices / colours /
+// indices into LDS (the element code is the same: its stores go through generic pointers that point there) and the wave copies them
+// out as dense runs. Why: with per-lane stores a Round-join chunk is ~15 write requests per element of ~11 bytes each (PMC on BASELINE
+// configs[3]: 137 M TCP -> TCC write requests for 1.9 GB, the L1 stalled 80 % of the kernel's time, profiles/r06_pmc_sq_round10k.txt);
+// copied out 16 bytes per lane, consecutive lanes consecutive, the same bytes are ~1/4 of the requests.
+// SCOL / SIDX: capacities of the stage in vertices / indices (0: the stream is stored directly). k_stroke_long (vgx_stroke.hip) stages
+// colours and indices -- 11 of a Round-join element's 15 requests -- in 8.9 KB; positions too would leave two waves per SIMD
+// (measured, same box, BASELINE configs[3]: nothing staged 0.735 ms, indices 0.617, indices + colours 0.585, all three 0.665).
+template<int SCOL, int SIDX>
+struct __attribute__((aligned(16))) StrokeStageT
+{
+	uint32_t col[SCOL ? SCOL : 4];
+	uint16_t idx[SIDX ? SIDX : 8];
+};
+
+template<class VS, int SCOL = 0, int SIDX = 0>
 __device__ __forceinline__ void stroke_chunk(bool valid, bool laneHasNext, int nvalid, int lane, const MeshCtxT<VS>& mc, uint32_t color,
-	float* posMesh, uint32_t* colMesh, uint16_t* idxMesh, uint32_t idxBase, StrokeCarry& carry)
+	float* posMesh, uint32_t* colMesh, uint16_t* idxMesh, uint32_t idxBase, StrokeCarry& carry, StrokeStageT<SCOL, SIDX>* stage = nullptr, bool oneMesh = false)
 {
 	// step A
 	V2 p1 = v2(0.0f, 0.0f);
@@ -727,11 +743,25 @@ __device__ __forceinline__ void stroke_chunk(bool valid, bool laneHasNext, int n
 
 	// step D
 	const bool meshLast = valid && (mc.j == mc.N - 1);
+	const int Lz = nvalid - 1;
+	const uint32_t endV = wave_read_u32(vbase + e.nv, Lz);
+	const uint32_t endI = wave_read_u32(ibase + totalIdx, Lz);
+	// the chunk's output ranges inside its mesh (one mesh: lane 0 holds the first element): [v0, endV) vertices, [i0, endI) indices
+	const uint32_t v0 = wave_read_u32(vbase, 0), i0 = wave_read_u32(ibase, 0);
+	const bool staged = (SCOL || SIDX) && stage != nullptr && oneMesh && nvalid == VGX_WAVE
+		&& (!SCOL || endV - v0 <= (uint32_t)SCOL) && (!SIDX || endI - i0 <= (uint32_t)SIDX); // wave-uniform
 	if (valid) {
 		StrokeWriter w;
 		w.pos = posMesh;
 		w.col = colMesh;
 		w.idx = idxMesh;
+		if (staged) { // generic pointers at the stage + the chunk's first vertex / index as the writer's position bias (a biased POINTER would not do: the
+			// compiler knows the stage is LDS and does that arithmetic in 32 bits)
+			w.vo = v0; w.io = i0;
+			w.pos = posMesh + 2 * (size_t)v0;
+			w.col = SCOL ? (uint32_t*)stage->col : colMesh + (size_t)v0;
+			w.idx = SIDX ? (uint16_t*)stage->idx : idxMesh + (size_t)i0;
+		}
 		w.color = color;
 		w.c0 = color & 0x00FFFFFFu; // colorSetAlpha(color, 0), vg.inl:95-98
 		w.ib = idxBase;
@@ -739,12 +769,32 @@ __device__ __forceinline__ void stroke_chunk(bool valid, bool laneHasNext, int n
 		elem_emit(mc, e, vbase, ibase, rails_unpack(prevPacked), w);
 		w.flush(vbase, ibase);
 	}
+	if (staged) { // wave-uniform: dense copy-out, 16 bytes per lane and step
+		__syncthreads(); // (one-wave workgroup: the LDS writes above have landed)
+		const uint64_t cm = wave_bcast_u64((uint64_t)colMesh, 0), im = wave_bcast_u64((uint64_t)idxMesh, 0);
+		if (SCOL) {
+			const uint32_t bytes = (endV - v0) * 4u;
+			char* dst = (char*)((uint32_t*)cm + (size_t)v0);
+			const char* src = (const char*)stage->col;
+			for (uint32_t o = (uint32_t)lane * 16u; o < bytes; o += VGX_WAVE * 16u) {
+				if (o + 16u <= bytes) { struct __attribute__((packed, aligned(4))) C4 { uint32_t a, b, c, d; }; *(C4*)(dst + o) = *(const C4*)(src + o); }
+				else { for (uint32_t q = o; q < bytes; q += 4u) { *(uint32_t*)(dst + q) = *(const uint32_t*)(src + q); } }
+			}
+		}
+		if (SIDX) {
+			const uint32_t bytes = (endI - i0) * 2u;
+			char* dst = (char*)((uint16_t*)im + (size_t)i0);
+			const char* src = (const char*)stage->idx;
+			for (uint32_t o = (uint32_t)lane * 16u; o < bytes; o += VGX_WAVE * 16u) {
+				if (o + 16u <= bytes) { struct __attribute__((packed, aligned(2))) I8 { uint32_t a, b, c, d; }; *(I8*)(dst + o) = *(const I8*)(src + o); }
+				else { for (uint32_t q = o; q < bytes; q += 2u) { *(uint16_t*)(dst + q) = *(const uint16_t*)(src + q); } }
+			}
+		}
+		__syncthreads(); // the stage is free for the next chunk
+	}
 
 	// carries (from the last valid lane)
-	const int Lz = nvalid - 1;
 	const int lastIsMeshLast = wave_bcast((int)meshLast, Lz);
-	const uint32_t endV = wave_read_u32(vbase + e.nv, Lz);
-	const uint32_t endI = wave_read_u32(ibase + totalIdx, Lz);
 	const uint64_t endRails = wave_bcast_u64(myExit, Lz);
 	carry.v = lastIsMeshLast ? 0u : endV;
 	carry.i = lastIsMeshLast ? 0u : endI;

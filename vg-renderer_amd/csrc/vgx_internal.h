@@ -69,6 +69,7 @@ struct VgxStrokeArgs
 	const uint32_t* mesh_base;   // assembly armed: vertices in front of each mesh inside its vertex buffer (added to every index); else null
 	VgxTotals* totals;
 	VgxCaps caps;
+	int no_long;                 // frame-sized call: k_stroke takes the strokes whatever their length (k_stroke_long is not launched)
 	int tile_mode;               // the host also launches k_emit_tiles (vgx_tile.hip): k_fill leaves the batches that kernel takes alone
 };
 

@@ -99,6 +99,7 @@ struct VgxMeshPrep
 	uint32_t color;
 };
 
+#define VGX_LONG_STROKE 128u
 #define VGX_MESH_NEEDS_COUNT 0xFFFFFFFFu // mtab.num_vertices marker: Round joins, sized by k_round_sizes
 
 // Sub-path record of the single-pass flatten, stored sparsely at the command-instance index of the sub-path's last
@@ -139,7 +140,7 @@ struct VgxTotals
 	uint32_t tmpl_bad;                   // vgx_tessellate_count (k_tmpl_check): some draw differs from its image in the first period in a field the
 	                                     // flattener or the mesh sizes depend on -> no template mode (vgx_tmpl.hip)
 	uint32_t flat_redo;                  // vgx_flatten (vgx_flat1.hip): the first run found degenerate draws -> serial count of the listed draws, second run
-	uint32_t pad_u32[1];
+	uint32_t has_short_stroke;           // scan over the meshes: some stroke mesh has fewer than VGX_LONG_STROKE elements -> k_stroke emits the general strokes (else k_stroke_long: LDS-staged stores)
 	unsigned long long flat_ticket;      // vgx_flatten: next segment (ticket order = output order)
 	unsigned long long flat_serial_draws;// vgx_flatten: draws that went through the exact serial builder
 	unsigned long long flat_tag;         // vgx_flatten: the batch these totals belong to (VgxF1Args::tag)

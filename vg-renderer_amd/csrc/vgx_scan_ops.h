@@ -169,6 +169,7 @@ struct OpMeshAll
 			const uint32_t key = kindWord & 0x19FFu;
 			const bool simple = key == (0x100u | VGX_MESH_STROKE_AA) || key == (0x100u | VGX_MESH_STROKE_AA_THIN);
 			if (!simple) { totals->has_general_stroke = 1u; }
+			if (polyN < VGX_LONG_STROKE) { totals->has_short_stroke = 1u; }
 		} else { r.a = polyN; }
 		r.c = nv;
 		r.d = (uint64_t)nidx + (nv > 65536u ? (1ull << 48) : 0ull);

@@ -383,9 +383,11 @@ struct __attribute__((aligned(16))) StrokeRec
 
 // The stroke meshes [m0, m1) (whole meshes; A.elem_prefix = the strokes' prefix): elements walked in 64-element chunks with
 // the carries of a mesh that spans chunks. wbase / wv = the LDS window of 64 mesh records (s_win), kept between calls.
-template<bool ONLY_SIMPLE>
+#define VGX_STROKE_STAGE_COL 704   /* k_stroke_long: colours (vertices) and indices of one chunk the LDS stage holds; a chunk that needs more is stored per lane */
+#define VGX_STROKE_STAGE_IDX 3072
+template<bool ONLY_SIMPLE, int SCOL, int SIDX>
 __device__ __forceinline__ void stroke_range(const VgxStrokeArgs& A, StrokeRec* s_win, uint64_t& wbase, uint64_t& wv, const uint64_t m0, const uint64_t m1,
-	const uint64_t numMeshes, const int lane)
+	const uint64_t numMeshes, const int lane, StrokeStageT<SCOL, SIDX>* stage)
 {
 	const uint64_t E0 = A.elem_prefix[m0];
 	const uint64_t E1 = A.elem_prefix[m1];
@@ -476,7 +478,9 @@ __device__ __forceinline__ void stroke_range(const VgxStrokeArgs& A, StrokeRec* 
 		} else if (wave_ballot(valid && !stroke_elem_is_simple(mc.kind, mc.closed, mc.join)) == 0) { // wave-uniform
 			stroke_chunk_simple(valid, lane < VGX_WAVE - 1 && ei + 1 < E1, nvalid, lane, mc, color, A.pos + 2 * firstV, A.color + firstV, A.idx + firstI, idxBase, carry);
 		} else {
-			stroke_chunk(valid, lane < VGX_WAVE - 1 && ei + 1 < E1, nvalid, lane, mc, color, A.pos + 2 * firstV, A.color + firstV, A.idx + firstI, idxBase, carry);
+			// one mesh in the whole chunk (lane 0's is everybody's): its output may go through the LDS stage (long polylines: all but the chunks at a mesh's ends)
+			const bool oneMesh = stage != nullptr && wave_ballot(valid && mi != wave_bcast_u64(mi, 0)) == 0;
+			stroke_chunk(valid, lane < VGX_WAVE - 1 && ei + 1 < E1, nvalid, lane, mc, color, A.pos + 2 * firstV, A.color + firstV, A.idx + firstI, idxBase, carry, stage, oneMesh);
 		}
 		mcur = wave_bcast_u64(mi, Lz);
 	}
@@ -486,11 +490,17 @@ __device__ __forceinline__ void stroke_range(const VgxStrokeArgs& A, StrokeRec* 
 //   k_stroke         every kind of stroke (128 VGPRs, 4 waves per SIMD)
 //   k_stroke_simple  batches whose strokes are all closed, Miter, AA or Thin -- e.g. the tiger: stroke_chunk_simple only, 56 VGPRs,
 //                    8 waves per SIMD: 1.21 ms against 1.29 ms on the same box
-template<bool ONLY_SIMPLE>
-__device__ __forceinline__ void stroke_kernel_body(const VgxStrokeArgs& A, StrokeRec* s_win)
+// k_stroke_long (SIDX != 0) takes the batches whose stroke meshes ALL have VGX_LONG_STROKE elements or more (found by the scan over
+// the meshes: long polylines, where nearly every chunk lies inside one mesh), k_stroke the others (a drawing's short sub-paths, several
+// meshes per chunk: the stage would never be used and costs a wave per SIMD); frame-sized calls (A.no_long) launch k_stroke only.
+template<bool ONLY_SIMPLE, int SCOL, int SIDX>
+__device__ __forceinline__ void stroke_kernel_body(const VgxStrokeArgs& A, StrokeRec* s_win, StrokeStageT<SCOL, SIDX>* stage)
 {
 	const int lane = threadIdx.x;
 	if (A.totals->status != VGX_OK || (A.totals->has_general_stroke != 0u) == ONLY_SIMPLE) {
+		return;
+	}
+	if (!ONLY_SIMPLE && !A.no_long && (A.totals->has_short_stroke == 0u) != (SIDX != 0)) {
 		return;
 	}
 	const uint64_t numMeshes = A.totals->sizes.num_meshes;
@@ -513,20 +523,32 @@ __device__ __forceinline__ void stroke_kernel_body(const VgxStrokeArgs& A, Strok
 		if (m0 == m1) {
 			continue;
 		}
-		stroke_range<ONLY_SIMPLE>(A, s_win, wbase, wv, m0, m1, numMeshes, lane);
+		stroke_range<ONLY_SIMPLE, SCOL, SIDX>(A, s_win, wbase, wv, m0, m1, numMeshes, lane, stage);
 	}
 }
 
 __global__ __launch_bounds__(VGX_WAVE) VGX_STROKE_OCC void k_stroke(VgxStrokeArgs A)
 {
 	__shared__ StrokeRec s_win[VGX_WAVE];
-	stroke_kernel_body<false>(A, s_win);
+	stroke_kernel_body<false, 0, 0>(A, s_win, (StrokeStageT<0, 0>*)nullptr);
+}
+
+// The same kernel with the LDS stage (vgx_elem.h, stroke_chunk): batches of LONG polylines, where nearly every chunk lies inside one
+// mesh. 12.9 KB of LDS = three waves per SIMD, and the registers of three (no spills: at four the stage costs six).
+#ifndef VGX_STROKE_LONG_OCC
+#define VGX_STROKE_LONG_OCC __attribute__((amdgpu_waves_per_eu(3, 3)))
+#endif
+__global__ __launch_bounds__(VGX_WAVE) VGX_STROKE_LONG_OCC void k_stroke_long(VgxStrokeArgs A)
+{
+	__shared__ StrokeRec s_win[VGX_WAVE];
+	__shared__ StrokeStageT<VGX_STROKE_STAGE_COL, VGX_STROKE_STAGE_IDX> s_stage;
+	stroke_kernel_body<false, VGX_STROKE_STAGE_COL, VGX_STROKE_STAGE_IDX>(A, s_win, &s_stage);
 }
 
 __global__ __launch_bounds__(VGX_WAVE) void k_stroke_simple(VgxStrokeArgs A)
 {
 	__shared__ StrokeRec s_win[VGX_WAVE];
-	stroke_kernel_body<true>(A, s_win);
+	stroke_kernel_body<true, 0, 0>(A, s_win, (StrokeStageT<0, 0>*)nullptr);
 }
 
 // The caller's mesh table = the internal one once the scan over meshes has filled first_vertex / first_index.
@@ -561,6 +583,7 @@ void vgx_launch_stroke(bool emit, const VgxStrokeArgs& a, int numBlocks, hipStre
 	if (emit) {
 		if (!a.tile_mode) { hipLaunchKernelGGL(k_stroke_simple, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a); } // one of the two exits at once (tile mode: k_emit_tiles took the simple batches)
 		hipLaunchKernelGGL(k_stroke, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
+		if (!a.no_long) { hipLaunchKernelGGL(k_stroke_long, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a); } // (one of k_stroke / k_stroke_long exits at once)
 	} else { // sizes Round-join meshes; returns at once when the batch has none (every other size is closed-form)
 		hipLaunchKernelGGL(k_round_sizes, dim3(numBlocks), dim3(VGX_WAVE), 0, s, a);
 	}

@@ -113,13 +113,19 @@ __device__ __forceinline__ void tmpl_stroke_elem(const TmplOut& O, uint32_t kind
 		const V2 q3 = L ? v2sub(p1, vhaa) : v2add(p1, vhaa);
 		PosPair q; q.x0 = q0.x; q.y0 = q0.y; q.x1 = q1.x; q.y1 = q1.y;
 		PosPair r; r.x0 = q2.x; r.y0 = q2.y; r.x1 = q3.x; r.y1 = q3.y;
-		ColPair c; c.c0 = c0; c.c1 = color;
-		ColPair d; d.c0 = color; d.c1 = c0;
+		struct __attribute__((packed, aligned(4))) ColQuad { uint32_t a, b, c, d; };
+		ColQuad cq; cq.a = c0; cq.b = color; cq.c = color; cq.d = c0; // ONE 16-byte store: consecutive lanes, consecutive 16 bytes (two 8-byte stores at a 16-byte stride made every line a target of two instructions = two write requests of half a line each)
 		VGX_ST_GUARD(c0 ^ __float_as_uint(q.x0) ^ __float_as_uint(r.y1)) {
 		*(PosPair*)pp = q;
 		*(PosPair*)(pp + 16) = r;
+#ifdef VGX_EXP_COL2X8
+		ColPair c; c.c0 = c0; c.c1 = color;
+		ColPair d; d.c0 = color; d.c1 = c0;
 		*(ColPair*)pc = c;
 		*(ColPair*)(pc + 8) = d;
+#else
+		*(ColQuad*)pc = cq;
+#endif
 		}
 	}
 	{

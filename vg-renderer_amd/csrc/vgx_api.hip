@@ -137,7 +137,7 @@ struct vgx_ctx
 	uint32_t tmplGeneral;                // stroke styles of the template: 0 closed Miter AA / Thin only, 1 + open Miter with Butt / Square caps, 2 + general
 	uint64_t tmplNumWg, tmplNDraws;      // several classes: workgroups of one step; the batch size the per-instance table was built for
 	vgx_sizes tmplTotal;                 // sizes of the whole batch
-	DevBuf tmplHash, tmplInstCls, tmplClsRep, tmplCls, tmplIinfo, tmplWg;
+	DevBuf tmplHash, tmplInstCls, tmplClsRep, tmplCls, tmplIinfo, tmplWg, tmplClsSum;
 	uint32_t tmplRound;                  // Round-join stroke meshes per instance (tmplGeneral == 3): their sizes, and every place behind them, are counted per step
 	uint32_t tmplRoundElems;             // their elements per instance
 	DevBuf tmplTrmesh, tmplTmsz;         // template: the Round-join meshes (mesh, first element among the Round-join elements); per mesh its sizes (VgxTmplArgs::tmsz)
@@ -811,7 +811,7 @@ int vgx_destroy(vgx_ctx* ctx)
 		return VGX_E_INVALID_ARG;
 	}
 	DeviceGuard guard(ctx);
-	DevBuf* bufs[] = { &ctx->tileTab, &ctx->psTemp, &ctx->f1SegDraw, &ctx->f1Segs, &ctx->tmplHash, &ctx->tmplInstCls, &ctx->tmplClsRep, &ctx->tmplCls, &ctx->tmplIinfo, &ctx->tmplWg, &ctx->tmplTrmesh, &ctx->tmplTmsz, &ctx->tmplRsz, &ctx->tmplRelem, &ctx->tmplMplace, &ctx->tmplItot, &ctx->tmplIplace, &ctx->tmplTile, &ctx->tmplPoly, &ctx->tmplMesh, &ctx->tmplMtab, &ctx->tmplElem, &ctx->tmplDraws, &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
+	DevBuf* bufs[] = { &ctx->tmplClsSum, &ctx->tileTab, &ctx->psTemp, &ctx->f1SegDraw, &ctx->f1Segs, &ctx->tmplHash, &ctx->tmplInstCls, &ctx->tmplClsRep, &ctx->tmplCls, &ctx->tmplIinfo, &ctx->tmplWg, &ctx->tmplTrmesh, &ctx->tmplTmsz, &ctx->tmplRsz, &ctx->tmplRelem, &ctx->tmplMplace, &ctx->tmplItot, &ctx->tmplIplace, &ctx->tmplTile, &ctx->tmplPoly, &ctx->tmplMesh, &ctx->tmplMtab, &ctx->tmplElem, &ctx->tmplDraws, &ctx->partBounds, &ctx->instPerm, &ctx->instPermHist, &ctx->instHist, &ctx->instCursor, &ctx->instKeyStart, &ctx->instStart, &ctx->instTaskStart, &ctx->instTaskPath, &ctx->instOrder, &ctx->gatherSizes, &ctx->asmJump0, &ctx->asmJump1, &ctx->asmStart, &ctx->meshBase, &ctx->subPrefix, &ctx->cmdPrefix, &ctx->cmdCnt, &ctx->subFirst, &ctx->leafOverflow, &ctx->serialList, &ctx->dinfo, &ctx->poly, &ctx->subs, &ctx->mdesc, &ctx->elemPrefix, &ctx->elemPrefixS, &ctx->mprep, &ctx->mtab, &ctx->partial, &ctx->totals };
 	for (DevBuf* b : bufs) {
 		if (b->p) { (void)hipFree(b->p); }
 	}
@@ -838,7 +838,7 @@ uint64_t vgx_scratch_bytes(const vgx_ctx* ctx)
 	if (!ctx) {
 		return 0;
 	}
-	return ctx->tileTab.cap + ctx->psTemp.cap + ctx->f1SegDraw.cap + ctx->f1Segs.cap + ctx->tmplHash.cap + ctx->tmplInstCls.cap + ctx->tmplClsRep.cap + ctx->tmplCls.cap + ctx->tmplIinfo.cap + ctx->tmplWg.cap + ctx->tmplTrmesh.cap + ctx->tmplTmsz.cap + ctx->tmplRsz.cap + ctx->tmplRelem.cap + ctx->tmplMplace.cap + ctx->tmplItot.cap + ctx->tmplIplace.cap + ctx->tmplTile.cap + ctx->tmplPoly.cap + ctx->tmplMesh.cap + ctx->tmplMtab.cap + ctx->tmplElem.cap + ctx->tmplDraws.cap + ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
+	return ctx->tmplClsSum.cap + ctx->tileTab.cap + ctx->psTemp.cap + ctx->f1SegDraw.cap + ctx->f1Segs.cap + ctx->tmplHash.cap + ctx->tmplInstCls.cap + ctx->tmplClsRep.cap + ctx->tmplCls.cap + ctx->tmplIinfo.cap + ctx->tmplWg.cap + ctx->tmplTrmesh.cap + ctx->tmplTmsz.cap + ctx->tmplRsz.cap + ctx->tmplRelem.cap + ctx->tmplMplace.cap + ctx->tmplItot.cap + ctx->tmplIplace.cap + ctx->tmplTile.cap + ctx->tmplPoly.cap + ctx->tmplMesh.cap + ctx->tmplMtab.cap + ctx->tmplElem.cap + ctx->tmplDraws.cap + ctx->gatherSizes.cap + ctx->asmJump0.cap + ctx->asmJump1.cap + ctx->asmStart.cap + ctx->meshBase.cap + ctx->subPrefix.cap + ctx->cmdPrefix.cap + ctx->cmdCnt.cap + ctx->subFirst.cap + ctx->leafOverflow.cap + ctx->serialList.cap + ctx->dinfo.cap + ctx->poly.cap + ctx->subs.cap + ctx->mdesc.cap + ctx->elemPrefix.cap + ctx->elemPrefixS.cap + ctx->mprep.cap + ctx->mtab.cap + ctx->partial.cap + ctx->totals.cap;
 }
 
 // ---- path set ---------------------------------------------------------------------------------------
@@ -1641,14 +1641,9 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	}
 	const vgx_draw* rdraws = (const vgx_draw*)ctx->tmplDraws.p;
 	// sizes of one instance of every class (several classes: each representative through the pipeline on its own first)
+	// (several classes, round 6: NOT one pipeline per representative -- their sizes are differences of the prefixes the one concatenated
+	// run leaves behind, k_tmpl_class_sums below; the Tiger at seven scales = 18 classes: count 4.2 -> ~1 ms)
 	std::vector<vgx_sizes> csz(T);
-	if (T > 1) {
-		for (uint32_t c = 0; c < T; ++c) {
-			if ((st = tmplPipeline(ctx, ps, rdraws + (uint64_t)c * P, P, s)) != VGX_OK) { return st; }
-			if (!tmplEligible(*ctx->hostTotals, false)) { return VGX_OK; }
-			csz[c] = ctx->hostTotals->sizes;
-		}
-	}
 	// all representatives as one batch: the template
 	if ((st = tmplPipeline(ctx, ps, rdraws, PT, s)) != VGX_OK) { return st; }
 	{
@@ -1691,11 +1686,29 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	b.num_vertices = all.num_vertices; b.num_indices = all.num_indices; b.cls = (VgxTmplClass*)ctx->tmplCls.p;
 	vgx_launch_tmpl_classes(b, s);
 	std::vector<VgxTmplClass> cls((size_t)T + 1);
+	std::vector<unsigned long long> csum(((size_t)T + 1) * 5, 0ull);
+	if (T > 1) {
+		if ((st = ensure(ctx, ctx->tmplClsSum, ((size_t)T + 1) * 5 * sizeof(unsigned long long))) != VGX_OK) { return st; }
+		vgx_launch_tmpl_class_sums(b, (const vgx_draw_info*)ctx->dinfo.p, (const uint64_t*)ctx->cmdPrefix.p, PT, all, (unsigned long long*)ctx->tmplClsSum.p, s);
+		HIPCHK(ctx, hipMemcpyAsync(csum.data(), ctx->tmplClsSum.p, csum.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+	}
 	HIPCHK(ctx, hipMemcpyAsync(cls.data(), ctx->tmplCls.p, ((size_t)T + 1) * sizeof(VgxTmplClass), hipMemcpyDeviceToHost, s));
 	HIPCHK(ctx, hipStreamSynchronize(s));
-	for (uint32_t c = 0; c < T; ++c) { // the concatenated batch is the classes back to back: anything else means the template cannot be trusted
-		if (cls[c + 1].mesh0 - cls[c].mesh0 != csz[c].num_meshes || cls[c + 1].elem0 - cls[c].elem0 != csz[c].num_elements
-			|| cls[c + 1].v0 - cls[c].v0 != csz[c].num_vertices || cls[c + 1].i0 - cls[c].i0 != csz[c].num_indices) { return VGX_OK; }
+	if (T > 1) { // sizes of ONE instance of every class = what the concatenated run holds between the class's first draw and the next class's
+		for (uint32_t c = 0; c < T; ++c) {
+			vgx_sizes q;
+			memset(&q, 0, sizeof(q));
+			q.num_meshes = cls[c + 1].mesh0 - cls[c].mesh0; q.num_elements = cls[c + 1].elem0 - cls[c].elem0;
+			q.num_vertices = cls[c + 1].v0 - cls[c].v0; q.num_indices = cls[c + 1].i0 - cls[c].i0;
+			const unsigned long long* a0 = &csum[(size_t)c * 5]; const unsigned long long* a1 = &csum[(size_t)(c + 1) * 5];
+			q.num_poly_vertices = a1[0] - a0[0]; q.num_subpaths = a1[1] - a0[1]; q.num_cmd_instances = a1[2] - a0[2];
+			q.num_fill_elements = a1[3] - a0[3]; q.num_serial_draws = a1[4]; // (entry c + 1 holds class c's own count)
+			csz[c] = q;
+			VgxTotals one; // the limits of one instance (tmplEligible), per class as before
+			memset(&one, 0, sizeof(one));
+			one.sizes = q;
+			if (!tmplEligible(one, false)) { return VGX_OK; }
+		}
 	}
 	const uint64_t tiles = cls[T].tile0;
 	if ((st = ensure(ctx, ctx->tmplPoly, (V + 1) * 2 * sizeof(float))) != VGX_OK) { return st; }

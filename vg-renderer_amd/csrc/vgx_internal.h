@@ -155,6 +155,7 @@ void vgx_launch_tmpl_mtab(const VgxTmplArgs& a, vgx_mesh* mtab, VgxMeshDesc* mde
 void vgx_launch_tmpl_check(const vgx_draw* draws, uint64_t ndraws, uint32_t npaths, VgxTotals* totals, hipStream_t s); // after vgx_launch_inst_detect
 void vgx_launch_tmpl_styles(const VgxTmplBuild& b, hipStream_t s);  // stroke styles of the template -> b.cls[nclasses].pad[0] (zeroed by the caller), needs mdesc only
 void vgx_launch_tmpl_classes(const VgxTmplBuild& b, hipStream_t s); // fills b.cls from the representatives' count + emit results
+void vgx_launch_tmpl_class_sums(const VgxTmplBuild& b, const vgx_draw_info* dinfo, const uint64_t* cmdPrefix, uint64_t numDraws, const vgx_sizes& all, unsigned long long* sums, hipStream_t s); // after vgx_launch_tmpl_classes: [nclasses + 1][5] prefixes in front of every class
 void vgx_launch_tmpl_build(const VgxTmplBuild& b, hipStream_t s);   // after vgx_launch_tmpl_classes
 void vgx_launch_tmpl_hash(const vgx_draw* draws, uint64_t ndraws, uint64_t period, unsigned long long* hashes, hipStream_t s); // hashes[instance], zeroed by the caller
 void vgx_launch_tmpl_check_cls(const vgx_draw* draws, uint64_t ndraws, uint64_t period, const uint32_t* inst_cls, const uint32_t* cls_rep, VgxTotals* totals, hipStream_t s);

@@ -160,6 +160,34 @@ __global__ void k_tmpl_classes(VgxTmplBuild B)
 		tile0 = B.cls[c].tile0;
 	}
 }
+// Per class what the concatenated count holds in front of its first draw (round 6: the classes used to go through the count pipeline one
+// by one for their sizes -- eighteen pipelines of three host round trips each for the Tiger at seven scales; the sizes of a class are
+// differences of prefixes the ONE concatenated run has already made). sums[c] = { polyline vertices, sub-paths, command instances, fill
+// elements, serial draws } in front of class c; entry [nclasses] = the totals. One workgroup per entry.
+__global__ __launch_bounds__(256) void k_tmpl_class_sums(VgxTmplBuild B, const vgx_draw_info* dinfo, const uint64_t* cmdPrefix, uint64_t numDraws, vgx_sizes all, unsigned long long* sums)
+{
+	__shared__ unsigned long long s_serial;
+	const uint32_t c = blockIdx.x;
+	const uint64_t d0 = (uint64_t)c * B.period;
+	if (threadIdx.x == 0) { s_serial = 0ull; }
+	__syncthreads();
+	// serial draws IN FRONT of the class: counted per class, summed by the host (entry c holds class c - 1's count, entry 0 none)
+	if (c > 0) {
+		unsigned long long n = 0;
+		for (uint64_t d = d0 - B.period + threadIdx.x; d < d0; d += 256) { n += (dinfo[d].flags & 1u) ? 1ull : 0ull; }
+		if (n) { atomicAdd(&s_serial, n); }
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned long long* o = sums + 5ull * c;
+		const bool end = d0 >= numDraws;
+		o[0] = end ? all.num_poly_vertices : dinfo[d0].first_poly_vertex;
+		o[1] = end ? all.num_subpaths : dinfo[d0].first_subpath;
+		o[2] = cmdPrefix[end ? numDraws : d0];
+		o[3] = B.prefix_fill[B.cls[c].mesh0];
+		o[4] = s_serial;
+	}
+}
 __device__ __forceinline__ uint32_t tmpl_class_of_draw(const VgxTmplBuild& B, uint32_t draw) { return draw / B.period; }
 
 // which stroke styles the template holds -> cls[nclasses].pad[0]: bit 0 = open Miter strokes with Butt / Square caps, bit 1 = any other
@@ -1617,6 +1645,11 @@ void vgx_launch_tmpl_styles(const VgxTmplBuild& b, hipStream_t s)
 void vgx_launch_tmpl_classes(const VgxTmplBuild& b, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_tmpl_classes, dim3(1), dim3(1), 0, s, b);
+}
+
+void vgx_launch_tmpl_class_sums(const VgxTmplBuild& b, const vgx_draw_info* dinfo, const uint64_t* cmdPrefix, uint64_t numDraws, const vgx_sizes& all, unsigned long long* sums, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_tmpl_class_sums, dim3(b.nclasses + 1), dim3(256), 0, s, b, dinfo, cmdPrefix, numDraws, all, sums);
 }
 
 void vgx_launch_tmpl_build(const VgxTmplBuild& b, hipStream_t s)

@@ -79,6 +79,7 @@ struct vgx_ctx
 	DevBuf cmdPrefix, cmdCnt, subFirst, leafOverflow, serialList, dinfo, poly, subs, mdesc, elemPrefix, elemPrefixS, mprep, mtab, partial, totals;
 	DevBuf tileTab;                      // k_emit_tiles (vgx_tile.hip): the tile table of the current call
 	bool tileHint;                       // the last ordinary vgx_tessellate_count saw fills and closed Miter AA / Thin strokes only (the tile kernel's batches)
+	uint64_t optBigEmitMin;              // vertex capacity from which a call launches the tile kernel / k_stroke_long (2^18; VGX_BIG_EMIT_MIN: testing knob, 0 = every call)
 	int optStrokeLong;                   // VGX_STROKE_LONG=0: batches of long polylines through k_stroke like any other (no LDS-staged stores)
 	int optTileEmit;                     // VGX_TILE_EMIT=0: ordinary batches through k_fill + k_stroke_simple as before round 6
 	DevBuf psTemp;                       // vgx_pathset_create: temporaries of the device-side build (vgx_pathset.hip)
@@ -649,11 +650,11 @@ int runStrokeEmit(vgx_ctx* ctx, const vgx_draw* draws, const vgx_mesh_out* out, 
 	a.totals = (VgxTotals*)ctx->totals.p;
 	a.caps = ctx->caps;
 	a.tile_mode = 0;
-	a.no_long = (out->cap_vertices < (1ull << 18) || !ctx->optStrokeLong) ? 1 : 0; // frame-sized: one stroke kernel less to launch
+	a.no_long = (out->cap_vertices < ctx->optBigEmitMin || !ctx->optStrokeLong) ? 1 : 0; // frame-sized: one stroke kernel less to launch
 	// Batches of fills and closed Miter AA / Thin strokes (the scan over the meshes decides, on the device): one draw-ordered tile
 	// kernel instead of k_fill + k_stroke_simple (vgx_tile.hip). Not for frame-sized calls (two more launches than they are worth).
 	uint64_t capTiles = 0;
-	if (ctx->optTileEmit && ctx->tileHint && !ctx->optConcurrentEmit && out->cap_vertices >= (1ull << 18) && out->cap_vertices / VGX_TILE_ELEMS + 2 < 0x7FFFFFFFull) {
+	if (ctx->optTileEmit && ctx->tileHint && !ctx->optConcurrentEmit && out->cap_vertices >= ctx->optBigEmitMin && out->cap_vertices / VGX_TILE_ELEMS + 2 < 0x7FFFFFFFull) {
 		capTiles = out->cap_vertices / VGX_TILE_ELEMS + 2; // every element emits at least one vertex
 		const int st = ensure(ctx, ctx->tileTab, capTiles * sizeof(VgxTileRec));
 		if (st != VGX_OK) { return st; }
@@ -768,6 +769,8 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	// tuning / testing knobs: read once here, never on the call path
 	ctx->optTwoPass = getenv("VGX_TWO_PASS_FLATTEN") ? 1 : 0;
 	if (const char* e = getenv("VGX_PS_UPLOAD")) { ctx->optPsStage = strcmp(e, "stage") == 0; }
+	ctx->optBigEmitMin = 1ull << 18;
+	if (const char* e = getenv("VGX_BIG_EMIT_MIN")) { ctx->optBigEmitMin = strtoull(e, nullptr, 10); }
 	ctx->optStrokeLong = 1;
 	if (const char* e = getenv("VGX_STROKE_LONG")) { ctx->optStrokeLong = atoi(e) != 0; }
 	ctx->optTileEmit = 1;

@@ -684,7 +684,13 @@ VGX_EL VgxMeshPrep mesh_prep(const VgxMeshDesc& md, const vgx_draw* dr, const fl
 //   C. previous element's exit rails (prevSegment*ID, stroker.cpp:1401-1410), D. the stores.
 // laneHasNext: the next lane holds the next element of the same contiguous element range.
 // ------------------------------------------------------------------------------------------------
-struct StrokeCarry { uint32_t v, i; uint64_t rails; };
+struct StrokeCarry
+{
+	uint32_t v, i; uint64_t rails;
+#ifdef VGX_STROKE_PROFILE
+	unsigned long long tw, tg, te; // clocks: the wait for a chunk's vertices (behind the stores of the chunk in front), geometry + scans, emit + copy-out
+#endif
+};
 
 // LDS stage of one chunk's output (k_stroke, round 6): a chunk whose elements all belong to ONE mesh writes its vertices / colours /
 // indices into LDS (the element code is the same: its stores go through generic pointers that point there) and the wave copies them
@@ -706,10 +712,17 @@ __device__ __forceinline__ void stroke_chunk(bool valid, bool laneHasNext, int n
 	float* posMesh, uint32_t* colMesh, uint16_t* idxMesh, uint32_t idxBase, StrokeCarry& carry, StrokeStageT<SCOL, SIDX>* stage = nullptr, bool oneMesh = false)
 {
 	// step A
+#ifdef VGX_STROKE_PROFILE
+	const unsigned long long tp0 = clock64();
+#endif
 	V2 p1 = v2(0.0f, 0.0f);
 	if (valid) { p1 = mc.vtx.ld(mc.j); }
 	const bool prevInWave = lane > 0 && mc.j > 0;
 	const bool nextInWave = laneHasNext && mc.j + 1 < mc.N;
+#ifdef VGX_STROKE_PROFILE
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (waits for the stores of the chunk in front as well: one in-order counter)
+	const unsigned long long tp1 = clock64();
+#endif
 	V2 pNext;
 	pNext.x = wave_from_next(p1.x, 0.0f); pNext.y = wave_from_next(p1.y, 0.0f);
 	if (valid && !nextInWave) { pNext = mc.vtx.ld(mc.j + 1 < mc.N ? mc.j + 1 : 0); }
@@ -750,6 +763,9 @@ __device__ __forceinline__ void stroke_chunk(bool valid, bool laneHasNext, int n
 	const uint32_t v0 = wave_read_u32(vbase, 0), i0 = wave_read_u32(ibase, 0);
 	const bool staged = (SCOL || SIDX) && stage != nullptr && oneMesh && nvalid == VGX_WAVE
 		&& (!SCOL || endV - v0 <= (uint32_t)SCOL) && (!SIDX || endI - i0 <= (uint32_t)SIDX); // wave-uniform
+#ifdef VGX_STROKE_PROFILE
+	const unsigned long long tp2 = clock64();
+#endif
 	if (valid) {
 		StrokeWriter w;
 		w.pos = posMesh;
@@ -793,6 +809,9 @@ __device__ __forceinline__ void stroke_chunk(bool valid, bool laneHasNext, int n
 		__syncthreads(); // the stage is free for the next chunk
 	}
 
+#ifdef VGX_STROKE_PROFILE
+	carry.tw += tp1 - tp0; carry.tg += tp2 - tp1; carry.te += clock64() - tp2;
+#endif
 	// carries (from the last valid lane)
 	const int lastIsMeshLast = wave_bcast((int)meshLast, Lz);
 	const uint64_t endRails = wave_bcast_u64(myExit, Lz);

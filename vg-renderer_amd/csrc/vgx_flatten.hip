@@ -372,8 +372,37 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten(VgxFlattenArgs A)
 #define VGX_BUILD_LEAF_SLOTS 8
 #endif
 #define BLS VGX_BUILD_LEAF_SLOTS
+#ifndef VGX_BUILD_UNROLL
+#define VGX_BUILD_UNROLL 1 /* the slot leaves of a lane requested together, in front of its stores (0: one LDS round trip per leaf) */
+#endif
+#ifndef VGX_BUILD_PREFETCH
+#define VGX_BUILD_PREFETCH 0 /* 1: the next chunk's records requested in front of this chunk's stores (see `decode`): measured, not kept */
+#endif
+// -DVGX_BUILD_PROFILE: shader-clock ticks per phase of k_flatten_build summed over all waves into VgxTotals::prof (vgx_get_failure_info)
+#ifdef VGX_BUILD_PROFILE
+#define FB_CLK() ((unsigned long long)clock64())
+#define FB_ACC(i, v) (fbProf[i] += (v))
+#else
+#define FB_CLK() 0ull
+#define FB_ACC(i, v) ((void)(v))
+#endif
+#ifndef VGX_BUILD_OCC
+#define VGX_BUILD_OCC
+#endif
+struct BuildDec // what a lane of k_flatten_build knows about its command instance before the walk
+{
+	uint64_t d;            // draw
+	const vgx_draw* dr;
+	uint64_t subBase;      // sub_prefix[d]
+	VgxCmdRec rec;
+	float mloc[6];         // the draw's matrix
+	float scale, tol;
+	uint32_t fillFlags, strokeFlags, serialStatic;
+	bool drawHead;
+};
+
 template<bool POOL>
-__global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
+__global__ __launch_bounds__(VGX_WAVE) VGX_BUILD_OCC void k_flatten_build(VgxFlattenArgs A)
 {
 	__shared__ __attribute__((aligned(16))) unsigned char s_mem[POOL ? ((VGX_LDS_LEVELS * 3 + BLS) * VGX_WAVE * 8 > VGX_POOL_BYTES ? (VGX_LDS_LEVELS * 3 + BLS) * VGX_WAVE * 8 : VGX_POOL_BYTES) : (VGX_LDS_LEVELS * 3 + BLS) * VGX_WAVE * 8];
 	float2* s_stack = (float2*)s_mem;                            // per-lane walk: pending stack, then the leaf slots
@@ -400,6 +429,10 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 	uint64_t wbase = dNext;
 	DrawWindow W = draw_window_load(A, wbase, lane);
 	uint64_t blockCur = 0, blockEnd = 0; // wave-private heap block [blockCur, blockEnd)
+#ifdef VGX_BUILD_PROFILE
+	unsigned long long fbProf[6] = {0, 0, 0, 0, 0, 0};
+	const unsigned long long fbT0 = FB_CLK();
+#endif
 
 	for (uint64_t seg = seg0; seg < seg1; ++seg) {
 		const uint64_t d0 = dNext;
@@ -416,13 +449,16 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 			uint64_t dcur = d0;
 			int carryDrawVerts = 0, carrySpVerts = 0, carrySubs = 0, carryFill = 0, carryStroke = 0, carrySlow = 0;
 
-			for (uint64_t chunk = C0; chunk < C1; chunk += VGX_WAVE) {
+			// A chunk's records: window + owner search, command record, the draw's fields. Run for chunk k + 1 BEFORE chunk k's vertices are
+			// stored (round 6): loads and stores share one in-order counter, so records requested behind the stores waited until the last of
+			// them had reached L2 -- every chunk began with a drained memory pipeline. Requested in front of them they arrive first, and the
+			// stores drain under the next walk.
+			auto decode = [&](uint64_t chunk, uint64_t dcurAt) {
 				const uint64_t ci = chunk + lane;
 				const bool valid = ci < C1;
-				// ---- decode (same as k_flatten) ------------------------------------------------------
 				const uint64_t lastKey = chunk + (VGX_WAVE - 1);
-				if (!(wave_bcast_u64(W.prefix, VGX_WAVE - 1) > lastKey) || dcur < wbase) {
-					wbase = dcur;
+				if (!(wave_bcast_u64(W.prefix, VGX_WAVE - 1) > lastKey) || dcurAt < wbase) {
+					wbase = dcurAt;
 					W = draw_window_load(A, wbase, lane);
 				}
 				const bool windowCovers = wave_bcast_u64(W.prefix, VGX_WAVE - 1) > lastKey;
@@ -434,58 +470,82 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 				uint64_t ownerBase = orel > 0 ? chunk + orel : wave_bcast_u64(W.prefix, firstOwner < 0 ? 0 : firstOwner);
 				uint32_t pc0 = (uint32_t)__shfl((int)(W.pc0 | ((W.serial & 1u) << 31)), ownerOfs);
 				uint32_t serialStatic = pc0 >> 31;
+				BuildDec D;
+				D.d = d0; D.drawHead = false; D.scale = 1.0f; D.tol = 0.25f; D.fillFlags = 0; D.strokeFlags = 0; D.dr = A.draws; D.subBase = 0;
+				D.mloc[0] = 1.0f; D.mloc[1] = 0.0f; D.mloc[2] = 0.0f; D.mloc[3] = 1.0f; D.mloc[4] = 0.0f; D.mloc[5] = 0.0f;
 				pc0 &= 0x7FFFFFFFu;
 				uint32_t thinPath = ((uint32_t)__shfl((int)W.serial, ownerOfs) >> 1) & 1u; // a moveTo / lineTo / close path: 16-byte thin records
-				uint64_t d = d0;
-				uint32_t type = VGX_CMD_CLOSE, cflags = 0, na = 0;
-				bool drawHead = false, drawLast = false;
-				float scale = 1.0f, tol = 0.25f;
-				uint32_t fillFlags = 0, strokeFlags = 0;
-				const vgx_draw* dr = A.draws;
-				VgxCmdRec rec;
-				rec.type = VGX_CMD_CLOSE; rec.flags = 0; rec.na = 0; rec.arg_off = 0; rec.start[0] = 0.0f; rec.start[1] = 0.0f;
-				for (int i = 0; i < 8; ++i) { rec.a[i] = 0.0f; }
+				D.rec.type = VGX_CMD_CLOSE; D.rec.flags = 0; D.rec.na = 0; D.rec.arg_off = 0; D.rec.start[0] = 0.0f; D.rec.start[1] = 0.0f;
+				for (int i = 0; i < 8; ++i) { D.rec.a[i] = 0.0f; }
 				if (valid) {
 					if (windowCovers) {
-						d = wbase + (uint64_t)ownerOfs;
+						D.d = wbase + (uint64_t)ownerOfs;
 					} else {
-						d = find_owner_u64(A.cmd_prefix, d0, d1, ci);
-						ownerBase = A.cmd_prefix[d];
-						const uint32_t path = A.draws[d].path;
+						D.d = find_owner_u64(A.cmd_prefix, d0, d1, ci);
+						ownerBase = A.cmd_prefix[D.d];
+						const uint32_t path = A.draws[D.d].path;
 						pc0 = ps.path_cmd_begin[path];
 						serialStatic = ps.path_flags[path] & VGX_PF_SERIAL;
 						thinPath = (ps.path_flags[path] >> 1) & 1u;
 					}
-					dr = A.draws + d;
+					D.dr = A.draws + D.d;
 					const uint32_t k = (uint32_t)(ci - ownerBase);
 					if (thinPath) {
 						// my record, the one in front (its point = my start point) and, in front of a CLOSE, the one behind (the
 						// sub-path's first point): neighbours of a 1 KB run the wave reads anyway
 						const VgxCmdThin t0 = ps.cmdthin[pc0 + k];
 						const VgxCmdThin tp = ps.cmdthin[(long long)(pc0 + k) - 1]; // (command 0 of the set reads the padding record; a path's first command never uses it)
-						rec.type = t0.meta & 0xFFu; rec.flags = (t0.meta >> 8) & 0xFFu;
-						rec.na = rec.type == VGX_CMD_CLOSE ? 0u : 2u;
-						rec.start[0] = tp.x; rec.start[1] = tp.y;
-						if (rec.type == VGX_CMD_CLOSE) { rec.a[6] = t0.x; rec.a[7] = t0.y; }
+						D.rec.type = t0.meta & 0xFFu; D.rec.flags = (t0.meta >> 8) & 0xFFu;
+						D.rec.na = D.rec.type == VGX_CMD_CLOSE ? 0u : 2u;
+						D.rec.start[0] = tp.x; D.rec.start[1] = tp.y;
+						if (D.rec.type == VGX_CMD_CLOSE) { D.rec.a[6] = t0.x; D.rec.a[7] = t0.y; }
 						else {
-							rec.a[0] = t0.x; rec.a[1] = t0.y;
-							if (rec.flags & VGX_CF_NEXT_IS_CLOSE) { const VgxCmdThin tn = ps.cmdthin[pc0 + k + 1]; rec.a[6] = tn.x; rec.a[7] = tn.y; }
+							D.rec.a[0] = t0.x; D.rec.a[1] = t0.y;
+							if (D.rec.flags & VGX_CF_NEXT_IS_CLOSE) { const VgxCmdThin tn = ps.cmdthin[pc0 + k + 1]; D.rec.a[6] = tn.x; D.rec.a[7] = tn.y; }
 						}
 					} else {
-						rec = ps.cmdrec[pc0 + k];
+						D.rec = ps.cmdrec[pc0 + k];
 					}
-					type = rec.type; cflags = rec.flags; na = rec.na;
-					drawHead = (k == 0);
-					drawLast = (cflags & VGX_CF_LAST_IN_PATH) != 0;
-					scale = dr->scale; tol = dr->tess_tol;
-					fillFlags = dr->fill_flags; strokeFlags = dr->stroke_flags;
+					D.drawHead = (k == 0);
+					D.scale = D.dr->scale; D.tol = D.dr->tess_tol;
+					D.fillFlags = D.dr->fill_flags; D.strokeFlags = D.dr->stroke_flags;
+					// requested here, used by the placement: behind the walk they cost nothing; issued there they wait behind the stores
+					// in front of them (one counter for loads and stores, in order)
+#pragma unroll
+					for (int i = 0; i < 6; ++i) { D.mloc[i] = D.dr->mtx[i]; }
+					D.subBase = A.sub_prefix[D.d];
 				}
+				D.serialStatic = serialStatic;
+				return D;
+			};
+			BuildDec DN; // the next chunk's records (valid when haveNext)
+			bool haveNext = false;
+			for (uint64_t chunk = C0; chunk < C1; chunk += VGX_WAVE) {
+				const uint64_t ci = chunk + lane;
+				const bool valid = ci < C1;
+				const unsigned long long fc0 = FB_CLK();
+				const BuildDec DC = haveNext ? DN : decode(chunk, dcur);
+				const uint64_t d = DC.d;
+				const VgxCmdRec& rec = DC.rec;
+				const uint32_t type = rec.type, cflags = rec.flags, na = rec.na;
+				const bool drawHead = DC.drawHead, drawLast = (cflags & VGX_CF_LAST_IN_PATH) != 0;
+				const float scale = DC.scale, tol = DC.tol;
+				const uint32_t fillFlags = DC.fillFlags, strokeFlags = DC.strokeFlags;
+				const vgx_draw* dr = DC.dr;
+				const float* mloc = DC.mloc;
+				const uint64_t subBase = DC.subBase;
+				const uint32_t serialStatic = DC.serialStatic;
 				const bool serialDraw = serialStatic != 0;
 				const float* a = rec.a;
 				const float* pa = ps.args + rec.arg_off;
 				const float* mtx = dr->mtx;
 				const V2 start = v2(rec.start[0], rec.start[1]);
 
+#ifdef VGX_BUILD_PROFILE
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the records are here
+#endif
+				const unsigned long long fc1 = FB_CLK();
+				FB_ACC(0, fc1 - fc0); // window + owner search + draw and command records
 				// ---- subdivide ONCE: count, detect degenerate cases, keep the first leaves in LDS -------
 				int cnt = 0;
 				bool slow = false, exists = false, closedHere = false;
@@ -551,6 +611,8 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 					}
 				}
 				const int rawCnt = cnt;
+				const unsigned long long fc2 = FB_CLK();
+				FB_ACC(1, fc2 - fc1); // the walk
 
 				// ---- segmented bookkeeping (same as the count pass of k_flatten) ---------------------------
 				const uint64_t drawHeads = wave_ballot(valid && drawHead);
@@ -584,6 +646,8 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 				const int nvalid = (int)((C1 - chunk) < (uint64_t)VGX_WAVE ? (C1 - chunk) : (uint64_t)VGX_WAVE);
 				const int L = nvalid - 1;
 				const int chunkTotal = wave_bcast(incl, L);
+				const unsigned long long fc3 = FB_CLK();
+				FB_ACC(2, fc3 - fc2); // scans + bookkeeping
 				if (cur + (uint64_t)(chunkTotal > 0 ? chunkTotal : 0) > blockEnd) {
 					// The chunk does not fit the wave's block: continue in a fresh one. Only a sub-path's vertices must be
 					// contiguous, so the vertices the sub-path that spans into this chunk already has are moved along;
@@ -608,6 +672,10 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 					cur = base + carry;
 					blockEnd = base + want;
 				}
+				// the next chunk's records, requested in front of this chunk's stores
+				const uint64_t dcurNext = wave_bcast_u64(d, L); // draw of the last command: the next window (if needed) starts here
+				haveNext = VGX_BUILD_PREFETCH && chunk + VGX_WAVE < C1;
+				if (haveNext) { DN = decode(chunk + VGX_WAVE, dcurNext); }
 				{
 					const uint64_t g = cur + (uint64_t)excl; // heap index of my first vertex
 					// my last vertex is the one pathClose removes (same decision the CLOSE lane takes)
@@ -625,7 +693,7 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 						float* out = A.poly + 2 * g;
 						if (type == VGX_CMD_MOVE_TO || type == VGX_CMD_LINE_TO) {
 							if (limit > 0) {
-								const V2 p = v2xform(v2(a[0], a[1]), mtx);
+								const V2 p = v2xform(v2(a[0], a[1]), mloc);
 								*(float2*)out = make_float2(p.x, p.y);
 							}
 						} else if (type == VGX_CMD_CUBIC_TO || type == VGX_CMD_QUAD_TO) {
@@ -638,15 +706,25 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 								}
 							} else if ((uint32_t)rawCnt <= VGX_LEAF_SLOTS + VGX_BUILD_OVERFLOW) {
 								const uint32_t nl = limit < VGX_LEAF_SLOTS ? limit : VGX_LEAF_SLOTS;
+#if VGX_BUILD_UNROLL
+								float2 lq[VGX_LEAF_SLOTS]; // every slot requested before the first store (one LDS round trip instead of one per leaf)
+#pragma unroll
+								for (uint32_t i = 0; i < VGX_LEAF_SLOTS; ++i) { lq[i] = s_leaf[i * VGX_WAVE + lane]; }
+#pragma unroll
+								for (uint32_t i = 0; i < VGX_LEAF_SLOTS; ++i) {
+									if (i < nl) { const V2 p = v2xform(v2(lq[i].x, lq[i].y), mloc); *(float2*)(out + 2 * i) = make_float2(p.x, p.y); }
+								}
+#else
 								for (uint32_t i = 0; i < nl; ++i) {
 									const float2 q = s_leaf[i * VGX_WAVE + lane];
-									const V2 p = v2xform(v2(q.x, q.y), mtx);
+									const V2 p = v2xform(v2(q.x, q.y), mloc);
 									*(float2*)(out + 2 * i) = make_float2(p.x, p.y);
 								}
+#endif
 								const float2* ov = (const float2*)A.leaf_overflow + (size_t)blockIdx.x * VGX_BUILD_OVERFLOW * VGX_WAVE + lane;
 								for (uint32_t i = VGX_LEAF_SLOTS; i < limit; ++i) { // same lane wrote these during its subdivision
 									const float2 q = ov[(i - VGX_LEAF_SLOTS) * VGX_WAVE];
-									const V2 p = v2xform(v2(q.x, q.y), mtx);
+									const V2 p = v2xform(v2(q.x, q.y), mloc);
 									*(float2*)(out + 2 * i) = make_float2(p.x, p.y);
 								}
 							} else { // more leaves than slots + overflow area: subdivide again, straight to memory
@@ -658,14 +736,14 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 						} else if (type == VGX_CMD_POLYLINE && limit < VGX_WAVE) { // (longer ones: the whole wave, below)
 							const uint32_t skip = (na >> 1) - (uint32_t)rawCnt;
 							for (uint32_t i = 0; i < limit; ++i) {
-								const V2 p = v2xform(v2(pa[2 * (i + skip)], pa[2 * (i + skip) + 1]), mtx);
+								const V2 p = v2xform(v2(pa[2 * (i + skip)], pa[2 * (i + skip) + 1]), mloc);
 								*(float2*)(out + 2 * i) = make_float2(p.x, p.y);
 							}
 						}
 						if (lastInSub) { // sub-path record, consumed by k_flatten_gather
 							VgxSubRec sr;
 							sr.first = g - (uint64_t)spBefore; sr.info = (uint32_t)spTotal | (closedHere ? 0x80000000u : 0u); sr.pad = 0;
-							A.sub_rec[A.sub_prefix[d] + (uint64_t)(subsIncl - 1)] = sr; // dense, in draw order: record j of draw d at sub_prefix[d] + j
+							A.sub_rec[subBase + (uint64_t)(subsIncl - 1)] = sr; // dense, in draw order: record j of draw d at sub_prefix[d] + j
 						}
 					}
 					{
@@ -714,6 +792,8 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 					}
 					cur += (uint64_t)(chunkTotal > 0 ? chunkTotal : 0);
 				}
+				FB_ACC(3, FB_CLK() - fc3); // block switch + placement (stores issued, not waited for) + records
+				FB_ACC(4, 1ull);
 
 				// carries into the next chunk
 				const int lastIsDrawLast = wave_bcast((int)drawLast, L);
@@ -730,11 +810,15 @@ __global__ __launch_bounds__(VGX_WAVE) void k_flatten_build(VgxFlattenArgs A)
 				carryStroke = lastIsDrawLast ? 0 : nStroke;
 				carrySlow = lastIsDrawLast ? 0 : nSlow;
 				carrySpVerts = (lastIsDrawLast || lastIsSubLast) ? 0 : nSp;
-				dcur = wave_bcast_u64(d, L);
+				dcur = dcurNext;
 			}
 			blockCur = cur;
 		}
 	}
+#ifdef VGX_BUILD_PROFILE
+	fbProf[5] = FB_CLK() - fbT0;
+	if (lane == 0) { for (int i = 0; i < 6; ++i) { atomicAdd(&A.totals->prof[i], fbProf[i]); } atomicAdd(&A.totals->prof[6], 1ull); }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -232,7 +232,9 @@ struct VgxStrokeArgs;
 void vgx_launch_small_front(const void* opCmdPrefix, vgx_draw_info* dinfo, hipStream_t s);
 void vgx_launch_small_middle(const VgxFlattenArgs& f, const VgxStrokeArgs& st, const void* opDraws, const void* opMeshes, vgx_sizes* devSizes, uint32_t* devStatus, hipStream_t s);
 void vgx_launch_flatten_gather(const VgxFlattenArgs& a, hipStream_t s);  // after the draw scan: ordered mesh descriptors
+#ifndef VGX_BUILD_WAVES
 #define VGX_BUILD_WAVES 4096
+#endif
 #define VGX_BUILD_BLOCK 8192 /* polyline vertices per wave-private heap block */
 #define VGX_BUILD_OVERFLOW 120 /* leaves per lane beyond the LDS slots kept in the wave's global overflow area */
 void vgx_launch_stroke(bool emit, const VgxStrokeArgs& a, int numBlocks, hipStream_t s);

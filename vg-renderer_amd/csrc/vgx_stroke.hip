@@ -394,6 +394,11 @@ __device__ __forceinline__ void stroke_range(const VgxStrokeArgs& A, StrokeRec* 
 	StrokeCarry carry;
 	carry.v = 0; carry.i = 0; carry.rails = 0;
 	uint64_t mcur = m0; // mesh that owns the chunk's first element
+#ifdef VGX_STROKE_PROFILE
+	carry.tw = 0; carry.tg = 0; carry.te = 0;
+	const unsigned long long tr0 = clock64();
+	unsigned long long nch = 0;
+#endif
 
 	for (uint64_t chunk = E0; chunk < E1; chunk += VGX_WAVE) {
 		const uint64_t ei = chunk + lane;
@@ -483,7 +488,16 @@ __device__ __forceinline__ void stroke_range(const VgxStrokeArgs& A, StrokeRec* 
 			stroke_chunk(valid, lane < VGX_WAVE - 1 && ei + 1 < E1, nvalid, lane, mc, color, A.pos + 2 * firstV, A.color + firstV, A.idx + firstI, idxBase, carry, stage, oneMesh);
 		}
 		mcur = wave_bcast_u64(mi, Lz);
+#ifdef VGX_STROKE_PROFILE
+		++nch;
+#endif
 	}
+#ifdef VGX_STROKE_PROFILE
+	if (lane == 0) {
+		atomicAdd(&A.totals->prof[0], carry.tw); atomicAdd(&A.totals->prof[1], carry.tg); atomicAdd(&A.totals->prof[2], carry.te);
+		atomicAdd(&A.totals->prof[3], clock64() - tr0); atomicAdd(&A.totals->prof[4], nch);
+	}
+#endif
 }
 
 // Two instantiations, both launched, one exits at once (the scan over the meshes decided: totals->has_general_stroke):

@@ -11,7 +11,9 @@ namespace {
 // ---- pending stack of the cubic DFS: the first VGX_LDS_LEVELS levels in LDS as [level][3 points][64 lanes]
 // float2 (lane-interleaved -> conflict free for any mix of levels), deeper levels (only very fine subdivisions
 // reach them) in per-lane private memory. Fewer LDS bytes per wave = more resident waves to hide latency.
+#ifndef VGX_LDS_LEVELS
 #define VGX_LDS_LEVELS 4
+#endif
 template<int LV>
 struct LdsLevelsT // the first VGX_LDS_LEVELS levels only (hot loop: no private-memory branch)
 {
@@ -161,7 +163,9 @@ __device__ __forceinline__ DrawWindow draw_window_load(const VgxFlattenArgs& A, 
 	return w;
 }
 
+#ifndef VGX_LEAF_SLOTS
 #define VGX_LEAF_SLOTS 8
+#endif
 
 template<int SLOTS>
 struct BuildCubicSinkT // counts leaves, detects the serial-path cases, keeps the first leaves in the lane's LDS slots

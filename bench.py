@@ -799,6 +799,7 @@ def roofline(res, steps, traffic_for=None):
     ms_per_step = res["dt"] / steps * 1e3
     traffic = None
     valu = None
+    valu_active = None
     if traffic_for is not None:
         # HBM traffic of that kernel per launch: not measurable from inside the process; taken from the committed
         # rocprofv3 --pmc passes of this same command (profiles/traffic.json), only for the workload they were made on
@@ -808,9 +809,11 @@ def roofline(res, steps, traffic_for=None):
             if isinstance(traffic_for, str):
                 traffic = tj["configs"][traffic_for]["kernels"][dom]["traffic_bytes"]
                 valu = tj["configs"][traffic_for]["kernels"][dom].get("valu_insts")
+                valu_active = tj["configs"][traffic_for]["kernels"][dom].get("valu_active_quads")
             elif tj.get("instances_per_gpu") == traffic_for and dom in tj["kernels"]:
                 traffic = tj["kernels"][dom]["traffic_bytes"]
                 valu = tj["kernels"][dom].get("valu_insts")
+                valu_active = tj["kernels"][dom].get("valu_active_quads")
         except (OSError, ValueError, KeyError):
             pass
     # The second ruler ("VALU issue alongside"): vector instructions per launch (SQ_INSTS_VALU of the committed
@@ -822,6 +825,11 @@ def roofline(res, steps, traffic_for=None):
         ach = valu / (dom_ms * 1e-3) / 1e9
         secondary = {"bound": "valu_issue", "achieved": round(ach, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": round(ach / VALU_PEAK_GINST, 4),
                      "valu_insts_per_launch": valu}
+        if valu_active:
+            # how busy the vector ALUs are, whatever the instructions cost (packed, transcendental and dependent instructions hold a SIMD
+            # longer than the 2 issue cycles the `frac` above prices them at): cycles with a vector instruction executing
+            # (SQ_ACTIVE_INST_VALU, quad-cycles summed over the waves) / the cycles the 1 024 SIMDs had at 2.4 GHz
+            secondary["busy_frac"] = round(valu_active * 4.0 / (1024.0 * dom_ms * 1e-3 * 2.4e9), 4)
     return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "secondary": secondary,
             "traffic_ratio": None if traffic is None else round(traffic / ab[dom], 3),

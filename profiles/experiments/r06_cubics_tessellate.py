@@ -1,0 +1,30 @@
+"""What vgx_tessellate costs on a batch of many DISTINCT paths with long curves (BASELINE configs[1]'s million cubics, stroked): stage times of
+the ordinary pipeline (k_flatten_build) beside vgx_flatten's one-walk kernel on the same path set."""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+rt = importlib.import_module("vg-renderer_amd.runtime")
+wl = importlib.import_module("vg-renderer_amd.workloads")
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+ps, d = wl.random_cubics(N, seed=1234, box=1000.0)
+wl.set_stroke(d, slice(None), 0xFF2060A0, 2.0, rt.capi.CAP_BUTT, rt.capi.JOIN_MITER, aa=True)
+ctx = rt.Context(0)
+pset = rt.PathSet(ctx, ps)
+dd = rt.upload_draws(d)
+sizes = rt.tessellate_count(ctx, pset, dd, d.shape[0])
+print({k: sizes[k] for k in ("num_vertices", "num_indices", "num_meshes", "num_poly_vertices")})
+bufs = rt.MeshBuffers(dd.device, sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"])
+for _ in range(3):
+    rt.tessellate_async(ctx, pset, dd, d.shape[0], bufs)
+torch.cuda.synchronize()
+ctx.set_profiling(True)
+for _ in range(5):
+    rt.tessellate_async(ctx, pset, dd, d.shape[0], bufs)
+torch.cuda.synchronize()
+st = ctx.stage_times_avg() if hasattr(ctx, "stage_times_avg") else ctx.stage_times()
+print({k: round(v, 3) for k, v in dict(st).items()})

@@ -23,13 +23,14 @@ for CFG in $CONFIGS; do
   timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace$SFX.log 2>&1
   timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- $BENCH > $OUT/fetch$SFX.log 2>&1
   timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o write -- $BENCH > $OUT/write$SFX.log 2>&1
-  timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU -d $OUT/valu -o valu -- $BENCH > $OUT/valu$SFX.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU -d $OUT/valu -o valu -- $BENCH > $OUT/valu$SFX.log 2>&1
   grep '^{' $OUT/trace$SFX.log > $OUT/bench_profiled$SFX.json  # the bench line of the traced run itself (HIP-event times to compare the trace with)
   T=$(find $OUT/trace -name '*_results.db' | head -1); F=$(find $OUT/fetch -name '*_results.db' | head -1); W=$(find $OUT/write -name '*_results.db' | head -1); V=$(find $OUT/valu -name '*_results.db' | head -1)
   python profiles/summarize.py trace $T > $OUT/kernel_stats$SFX.txt 2>&1
   python profiles/summarize.py pmc $F FETCH_SIZE > $OUT/pmc_fetch$SFX.txt 2>&1
   python profiles/summarize.py pmc $W WRITE_SIZE > $OUT/pmc_write$SFX.txt 2>&1
   python profiles/summarize.py pmc $V SQ_INSTS_VALU > $OUT/pmc_valu$SFX.txt 2>&1
+  python profiles/summarize.py pmc $V SQ_ACTIVE_INST_VALU >> $OUT/pmc_valu$SFX.txt 2>&1
   python profiles/summarize.py traffic $F $W "$TAG" $V > $OUT/traffic$SFX.json 2>&1
   PARTS="$PARTS $CFG=$OUT/traffic$SFX.json"
   rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/valu

@@ -53,11 +53,14 @@ def traffic(fetch_db, write_db, label, valu_db=None):
                     d["fetch_bytes" if ctr == "FETCH_SIZE" else "write_bytes"] += int(kb * 1024 * mul)  # flatten_build = k_flatten_inst + the k_flatten_build launch that exits at once (or the other way round); stroke_emit = k_stroke_simple + k_stroke likewise
     if valu_db:  # round 6: the second ruler (SURVEY 8d "VALU issue alongside"): vector instructions per launch, a --pmc SQ_INSTS_VALU pass of its own
         c = sqlite3.connect(valu_db).cursor()
-        for name, v in c.execute("select kernel_name, avg(value) from counters_collection where counter_name='SQ_INSTS_VALU' group by kernel_name"):
-            for k, stage in names.items():
-                if k + "(" in name or k + "<" in name or ("<" in k and k in name):
-                    d = out["kernels"].setdefault(stage, {"fetch_bytes": 0, "write_bytes": 0})
-                    d["valu_insts"] = d.get("valu_insts", 0) + int(v)
+        # SQ_INSTS_VALU: wave-instructions; SQ_ACTIVE_INST_VALU: quad-cycles (MI355X_MICROARCH.md: SQ_ACTIVE_INST_* count quad-cycles) during which
+        # a wave has a vector instruction executing, summed over the waves -- collected in the same pass since round 6's last profile
+        for ctr, key in (("SQ_INSTS_VALU", "valu_insts"), ("SQ_ACTIVE_INST_VALU", "valu_active_quads")):
+            for name, v in c.execute("select kernel_name, avg(value) from counters_collection where counter_name=? group by kernel_name", (ctr,)):
+                for k, stage in names.items():
+                    if k + "(" in name or k + "<" in name or ("<" in k and k in name):
+                        d = out["kernels"].setdefault(stage, {"fetch_bytes": 0, "write_bytes": 0})
+                        d[key] = d.get(key, 0) + int(v)
     for d in out["kernels"].values():
         d["traffic_bytes"] = d["fetch_bytes"] + d["write_bytes"]
     print(json.dumps(out, indent=1))

@@ -178,16 +178,21 @@ def test_every_instance_of_tiger_x10k_with_round_joins_matches_the_reference(rt,
     ctx.close()
 
 
-@pytest.mark.parametrize("which", ["tigerroundwide", "variedround"])
-def test_every_instance_with_round_joins_of_different_sizes_matches_the_reference(rt, wl, which):
+@pytest.mark.parametrize("which", ["tigerroundwide", "variedround", "variedround_ordinary"])
+def test_every_instance_with_round_joins_of_different_sizes_matches_the_reference(rt, wl, which, monkeypatch):
     """Round joins where the sizes really differ, at full size. tigerroundwide: Tiger x10k, strokes six times as wide and
     every instance stretched by its own (1 + e, 1 - e) (avgScale stays 1: ONE template class) -- the joins' arcs have different point counts
     from instance to instance, so the per-step sizes pass, the scan over all meshes and the device-side capacity check of the Round-join
     template see 10 000 instances of (33 distinct) sizes. variedround: Tiger x10k at seven scales (18 tolerance classes) with Round joins
-    -- Round-join templates are built for one class only, the batch takes the ordinary pipeline (k_flatten_inst + k_round_sizes + k_stroke).
+    -- first through the ordinary pipeline (variedround_ordinary: VGX_TMPL_ROUND=0, k_flatten_inst + k_round_sizes + k_stroke), then through
+    the class-aware Round-join templates of round 6 (one template per class, per-step tables addressed per instance).
     Digests of positions / colours / indices and the sizes of every instance against the reference's; the mesh table against the streams."""
     import torch
     K = 10000
+    ordinary = which.endswith("_ordinary")
+    if ordinary:
+        monkeypatch.setenv("VGX_TMPL_ROUND", "0")
+        which = which[:-len("_ordinary")]
     ps, ops = wl.tiger_paths()
     P = len(ops)
     if which == "tigerroundwide":
@@ -199,7 +204,7 @@ def test_every_instance_with_round_joins_of_different_sizes_matches_the_referenc
     dd = rt.upload_draws(d)
     sizes = rt.tessellate_count(ctx, pset, dd, d.shape[0])
     mode = ctx.failure_info()["segment_items"]
-    assert mode == (5 if which == "tigerroundwide" else 4), mode  # template mode / instances sorted by tolerance class
+    assert mode == (4 if ordinary else 5), mode  # instances sorted by tolerance class / template mode
     nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
     bufs = rt.MeshBuffers(dd.device, nv, ni, nm)
     bufs.pos.fill_(float("nan"))
@@ -208,7 +213,7 @@ def test_every_instance_with_round_joins_of_different_sizes_matches_the_referenc
     torch.cuda.synchronize()
     stages = [n for n, _ in ctx.stage_times()]
     ctx.set_profiling(False)
-    if which == "tigerroundwide":
+    if not ordinary:
         assert stages == ["tmpl_round_sizes", "tmpl_emit"], stages
     assert int(bufs.dev_status.item()) == 0
     ref = _reference_rows(which, K)  # [K, 12 + 2]

@@ -447,6 +447,64 @@ def test_template_round_joins(rt, wl, oracle, monkeypatch, seed, ninst, tile, cl
     ctx.close()
 
 
+@pytest.mark.parametrize("seed,ninst,ncls,tile,closed_only", [(6101, 70, 2, None, False), (6102, 96, 5, "128", False), (6103, 130, 16, "960", True), (6104, 80, 3, "64", False),
+                                                              (6105, 200, 7, None, True)])
+def test_template_round_joins_in_several_classes(rt, wl, oracle, monkeypatch, seed, ninst, ncls, tile, closed_only):
+    """Round joins in a template of SEVERAL classes (round 6; /root/reference/src/stroker.cpp:1580-1691, arc count from the transformed
+    geometry): every instance repeats one of a few flavours of the period (other scales, widths, tolerances and stroke styles per flavour),
+    the sizes of its Round-join meshes are its own. One template per class, the per-step tables addressed per instance (VgxTmplInst::m /
+    ::rel), the sizes pass in its workgroup-per-instance shape. == the reference, == the ordinary pipeline byte for byte, and the steady
+    state follows other transforms (other arcs, other sizes)."""
+    if tile:
+        monkeypatch.setenv("VGX_TMPL_TILE", tile)
+    ps = wl.closed_fuzz_paths(seed, npaths=72) if closed_only else wl.fuzz_paths(seed, npaths=72, with_shapes=True, degenerate=False)
+    d, pick = wl.template_class_round_draws(ps, seed, ninst, ncls, closed_aa_only=closed_only)
+    assert len(set(pick.tolist())) == ncls
+    ref = oracle.tessellate(ps, d)
+    ctx = rt.Context(0)
+    got = _run(rt, ctx, ps, d)
+    assert got.mode == MODE_TEMPLATE and got.stages == ROUND_STAGES, (got.mode, got.stages)
+    assert got.status == 0
+    assert_mesh_equal(got, ref, "round joins in %d classes, seed=%d" % (ncls, seed))
+    # other transforms in the steady state: the sizes are counted again, per instance
+    d2 = d.copy()
+    rs = np.random.RandomState(seed)
+    ang = rs.uniform(0, 2 * np.pi, size=ninst)
+    sx, sy = rs.uniform(0.6, 1.7, size=ninst), rs.uniform(0.6, 1.7, size=ninst)
+    P = ps.npaths
+    m = d2["mtx"].reshape(ninst, P, 6)
+    m[:, :, 0] = (np.cos(ang) * sx)[:, None]; m[:, :, 1] = (np.sin(ang) * sx)[:, None]
+    m[:, :, 2] = (-np.sin(ang) * sy)[:, None]; m[:, :, 3] = (np.cos(ang) * sy)[:, None]
+    ref2 = oracle.tessellate(ps, d2)
+    need = (int(ref2.pos.shape[0]), int(ref2.idx.shape[0]))
+    assert need != (int(ref.pos.shape[0]), int(ref.idx.shape[0]))
+    import torch
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(d)
+    rt.tessellate_count(ctx, pset, dd, d.shape[0])
+    dd2 = rt.upload_draws(d2)
+    bufs = rt.MeshBuffers(dd2.device, need[0] + 64, need[1] + 64, int(ref2.meshes.shape[0]))
+    rt.tessellate_async(ctx, pset, dd2, d2.shape[0], bufs)
+    torch.cuda.synchronize()
+    assert int(bufs.dev_status.item()) == 0
+    ds = bufs.dev_sizes.cpu().numpy().view(np.uint64)
+    assert (int(ds[3]), int(ds[4])) == need
+    g = _G()
+    g.pos = bufs.pos[:need[0]].cpu().numpy(); g.color = bufs.color[:need[0]].cpu().numpy().view(np.uint32)
+    g.idx = bufs.idx[:need[1]].cpu().numpy().view(np.uint16); g.meshes = bufs.meshes[:ref2.meshes.shape[0] * 32].cpu().numpy().view(rt.capi.mesh_dtype)
+    g.sizes = {"num_vertices": need[0], "num_indices": need[1], "num_meshes": int(ref2.meshes.shape[0])}
+    assert_mesh_equal(g, ref2, "round joins in classes, other transforms")
+    pset.close()
+    ctx.close()
+    monkeypatch.setenv("VGX_TMPL_ROUND", "0")
+    ctx = rt.Context(0)
+    old = _run(rt, ctx, ps, d)
+    assert old.mode != MODE_TEMPLATE
+    for k in ("pos", "color", "idx", "meshes"):
+        assert bytes_equal(getattr(got, k), getattr(old, k)), k
+    ctx.close()
+
+
 @pytest.mark.parametrize("ninst", [40, 70])  # (70: the per-instance shape of the sizes pass -- its own capacity check)
 def test_template_round_joins_sizes_follow_the_transforms(rt, wl, oracle, ninst):
     """The steady-state call of a Round-join template with OTHER transforms than the count saw: other arcs, other sizes -- counted on the
@@ -597,6 +655,31 @@ def test_template_round_joins_with_draw_command_assembly(rt, wl, oracle, monkeyp
     old = _assembled(rt, ctx, ps, d, max_vb, split)
     assert old.mode != MODE_TEMPLATE
     assert got.status == old.status, (got.status, old.status)  # (700-vertex buffers: a Round-join mesh of a wide stroke does not fit one -- the same error either way)
+    if old.status != 0:
+        ctx.close()
+        return
+    assert got.stages[-1] == "tmpl_emit" and got.ncmd == old.ncmd
+    for k in ("pos", "color", "idx", "meshes", "cmds"):
+        assert bytes_equal(getattr(got, k), getattr(old, k)), k
+    ctx.close()
+
+
+@pytest.mark.parametrize("seed,ninst,ncls,max_vb,split", [(7101, 70, 3, 65536, False), (7102, 96, 6, 2048, True), (7103, 130, 12, 3000, True)])
+def test_template_round_joins_in_several_classes_with_draw_command_assembly(rt, wl, oracle, monkeypatch, seed, ninst, ncls, max_vb, split):
+    """The same with several classes: k_tmpl_mtab finds a mesh's instance through VgxTmplInst::m and its place in the per-step table."""
+    ps = wl.closed_fuzz_paths(seed, npaths=72)
+    d, pick = wl.template_class_round_draws(ps, seed, ninst, ncls, closed_aa_only=bool(seed & 1))
+    d["state_key"] = (np.arange(d.shape[0]) // 37).astype(d["state_key"].dtype)
+    ctx = rt.Context(0)
+    got = _assembled(rt, ctx, ps, d, max_vb, split)
+    assert got.mode == MODE_TEMPLATE
+    assert got.stages[:2] == ["tmpl_round_sizes", "tmpl_mesh_table"], got.stages
+    ctx.close()
+    monkeypatch.setenv("VGX_TMPL_ROUND", "0")
+    ctx = rt.Context(0)
+    old = _assembled(rt, ctx, ps, d, max_vb, split)
+    assert old.mode != MODE_TEMPLATE
+    assert got.status == old.status, (got.status, old.status)
     if old.status != 0:
         ctx.close()
         return

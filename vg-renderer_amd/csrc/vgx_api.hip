@@ -141,6 +141,8 @@ struct vgx_ctx
 	DevBuf tmplHash, tmplInstCls, tmplClsRep, tmplCls, tmplIinfo, tmplWg, tmplClsSum;
 	uint32_t tmplRound;                  // Round-join stroke meshes per instance (tmplGeneral == 3): their sizes, and every place behind them, are counted per step
 	uint32_t tmplRoundElems;             // their elements per instance
+	uint32_t tmplRoundLds;               // Round-join meshes of the largest class (several classes; else = tmplRound)
+	uint64_t tmplRelemWords;             // several classes: table words of the whole batch (sum over the instances of their class's Round-join elements)
 	DevBuf tmplTrmesh, tmplTmsz;         // template: the Round-join meshes (mesh, first element among the Round-join elements); per mesh its sizes (VgxTmplArgs::tmsz)
 	DevBuf tmplRsz, tmplRelem, tmplMplace, tmplItot, tmplIplace; // the per-step tables of such a template (VgxTmplArgs)
 	hipStream_t sideStream; hipEvent_t forkEv, joinEv; // optConcurrentEmit only
@@ -1449,11 +1451,12 @@ static int tmplRoundSizes(vgx_ctx* ctx, VgxTmplArgs& a, hipStream_t s)
 	a.num_round = ctx->tmplRound; a.num_round_elems = ctx->tmplRoundElems;
 	a.trmesh = (const VgxTmplRoundMesh*)ctx->tmplTrmesh.p; a.tmsz = (const uint2*)ctx->tmplTmsz.p;
 	if (n * a.num_round >= (1ull << 31)) { return VGX_E_RANGE; } // one wave (long meshes: one workgroup) per (instance, Round-join mesh)
-	if ((st = ensure(ctx, ctx->tmplRsz, (n * a.num_round + 1) * 2 * sizeof(unsigned long long))) != VGX_OK) { return st; }
-	if ((st = ensure(ctx, ctx->tmplRelem, (n * a.num_round_elems + 1) * sizeof(uint2))) != VGX_OK) { return st; }
-	if ((st = ensure(ctx, ctx->tmplMplace, (n * a.inst.num_meshes + 1) * sizeof(VgxTmplMeshPlace))) != VGX_OK) { return st; }
+	const bool classes = a.cls != nullptr; // several classes: the tables' rows are the instances' own (VgxTmplInst::m / ::rel), the sizes stay in LDS
+	if (!classes && (st = ensure(ctx, ctx->tmplRsz, (n * a.num_round + 1) * 2 * sizeof(unsigned long long))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->tmplRelem, ((classes ? ctx->tmplRelemWords : n * a.num_round_elems) + 1) * sizeof(uint2))) != VGX_OK) { return st; }
+	if ((st = ensure(ctx, ctx->tmplMplace, ((classes ? a.total.num_meshes : n * a.inst.num_meshes) + 1) * sizeof(VgxTmplMeshPlace))) != VGX_OK) { return st; }
 	if ((st = ensure(ctx, ctx->partial, VGX_SCAN_BLOCKS * sizeof(Sum3))) != VGX_OK) { return st; }
-	a.rsz = (unsigned long long*)ctx->tmplRsz.p; a.relem = (uint2*)ctx->tmplRelem.p;
+	a.rsz = classes ? nullptr : (unsigned long long*)ctx->tmplRsz.p; a.relem = (uint2*)ctx->tmplRelem.p;
 	a.mplace = (VgxTmplMeshPlace*)ctx->tmplMplace.p;
 	if (vgx_tmpl_round_per_instance(a)) {
 		if ((st = ensure(ctx, ctx->tmplItot, (n + 1) * 2 * sizeof(unsigned long long))) != VGX_OK) { return st; }
@@ -1480,6 +1483,7 @@ static void tmplArgs(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 	a.general = ctx->tmplGeneral;
 	if (ctx->tmplClasses > 1) {
 		a.iinfo = (const VgxTmplInst*)ctx->tmplIinfo.p; a.wg = (const uint2*)ctx->tmplWg.p; a.num_wg = ctx->tmplNumWg;
+		a.cls = (const VgxTmplClass*)ctx->tmplCls.p; a.round_lds = ctx->tmplRoundLds;
 		a.total = ctx->tmplTotal;
 	} else {
 		const vgx_sizes& i1 = ctx->tmplInst;
@@ -1655,7 +1659,7 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 			// Round joins (their sizes are the instance's): templates of one class; else the ordinary pipeline
 			if (!tmplEligible(ht, ctx->optTmplRound != 0)) { return VGX_OK; }
 			csz[0] = ht.sizes;
-		} else if (ht.num_round_meshes || ht.sizes.num_poly_vertices >= (1ull << 32) || ht.sizes.num_meshes >= (1ull << 32) || ht.sizes.num_elements >= (1ull << 36)) {
+		} else if ((ht.num_round_meshes && !ctx->optTmplRound) || ht.sizes.num_poly_vertices >= (1ull << 32) || ht.sizes.num_meshes >= (1ull << 32) || ht.sizes.num_elements >= (1ull << 36)) {
 			return VGX_OK;
 		}
 	}
@@ -1680,7 +1684,8 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	// (bit 4: closed AA strokes with Round joins -- with nothing but closed strokes in the template, kernel 5: no general body)
 	const uint32_t kernelKind = (styles & 4u) ? ((styles & 3u) ? 3u : ((styles & 32u) ? 6u : 5u)) : ((styles & 2u) ? 2u : ((styles & 8u) ? ((styles & 1u) ? 2u : 4u) : ((styles & 1u) ? 1u : 0u)));
 	const bool roundTmpl = kernelKind == 3u || kernelKind == 5u || kernelKind == 6u;
-	if (roundTmpl && T != 1) { return VGX_OK; }
+	// (Round joins in a template of several classes, round 6: the per-step tables are addressed per instance -- VgxTmplInst::m / ::rel --, the
+	// sizes pass runs in its workgroup-per-instance shape; a batch that does not fit that shape takes the ordinary pipeline, see below)
 	uint32_t tileSize = ((kernelKind == 2u || kernelKind == 3u) && ctx->optTmplTile > VGX_TMPL_GENERAL_TILE) ? (uint32_t)VGX_TMPL_GENERAL_TILE : ctx->optTmplTile;
 	if ((kernelKind == 5u || kernelKind == 6u) && ctx->optTmplTile == VGX_TMPL_MAX_TILE) { tileSize = VGX_TMPL_RC_TILE; } // (its own workgroup shape; a VGX_TMPL_TILE override stands)
 	b.draws = rdraws; b.poly = (const float2*)ctx->poly.p; b.mdesc = (const VgxMeshDesc*)ctx->mdesc.p; b.mprep = (const VgxMeshPrep*)ctx->mprep.p; b.mtab = (const vgx_mesh*)ctx->mtab.p;
@@ -1730,6 +1735,29 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 	b.tmesh = (VgxTmplMesh*)ctx->tmplMesh.p; b.tmtab = (vgx_mesh*)ctx->tmplMtab.p; b.telem = (VgxTmplElem*)ctx->tmplElem.p;
 	vgx_launch_tmpl_build(b, s);
 	HIPCHK(ctx, hipMemcpyAsync(ctx->tmplPoly.p, ctx->poly.p, V * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+	// Round joins: how many such meshes the template holds and their elements; several classes: where each class's begin (k_tmpl_round_classes)
+	uint32_t roundWord = 0, roundElems = 0, roundLds = 0;
+	std::vector<uint64_t> clsRelems(T, 0); // Round-join elements of one instance of every class
+	if (roundTmpl) {
+		HIPCHK(ctx, hipMemcpyAsync(cls.data(), ctx->tmplCls.p, ((size_t)T + 1) * sizeof(VgxTmplClass), hipMemcpyDeviceToHost, s));
+		HIPCHK(ctx, hipStreamSynchronize(s));
+		roundWord = cls[T].pad[1];
+		if (roundWord == 0) { return VGX_OK; }
+		VgxTmplRoundMesh last;
+		HIPCHK(ctx, hipMemcpyAsync(&last, (const VgxTmplRoundMesh*)ctx->tmplTrmesh.p + roundWord, sizeof(last), hipMemcpyDeviceToHost, s));
+		HIPCHK(ctx, hipStreamSynchronize(s));
+		roundElems = last.elem0;
+		roundLds = roundWord;
+		clsRelems[0] = roundElems;
+		if (T > 1) {
+			roundLds = 0;
+			for (uint32_t c = 0; c < T; ++c) {
+				const uint32_t r1 = c + 1 < T ? cls[c + 1].pad[1] : roundWord, e1 = c + 1 < T ? cls[c + 1].pad[0] : roundElems;
+				clsRelems[c] = e1 - cls[c].pad[0];
+				if (r1 - cls[c].pad[1] > roundLds) { roundLds = r1 - cls[c].pad[1]; }
+			}
+		}
+	}
 	// the batch: instances x their class's sizes
 	std::vector<uint64_t> cnt(T, 0);
 	if (T == 1) { cnt[0] = ninst; } else { for (uint64_t k = 0; k < ninst; ++k) { ++cnt[instCls[k]]; } }
@@ -1747,7 +1775,7 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 		if (numWg > 0x7FFFFFFFull || z.num_meshes >= (1ull << 32)) { return VGX_OK; }
 		std::vector<VgxTmplInst> ii(ninst + 1);
 		std::vector<uint2> wg((size_t)numWg);
-		uint64_t v = 0, i = 0, m = 0, w = 0;
+		uint64_t v = 0, i = 0, m = 0, w = 0, re = 0;
 		for (uint64_t k = 0; k <= ninst; ++k) {
 			VgxTmplInst r;
 			memset(&r, 0, sizeof(r));
@@ -1755,7 +1783,8 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 			if (k < ninst) {
 				const uint32_t c = instCls[k];
 				r.cls = c; r.cmesh0 = cls[c].mesh0;
-				v += csz[c].num_vertices; i += csz[c].num_indices; m += csz[c].num_meshes;
+				r.rel = roundTmpl ? re - (uint64_t)cls[c].pad[0] : 0ull; // (the element numbers in the mesh records run over the whole template)
+				v += csz[c].num_vertices; i += csz[c].num_indices; m += csz[c].num_meshes; re += clsRelems[c];
 			}
 			ii[(size_t)k] = r;
 		}
@@ -1774,19 +1803,13 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 		HIPCHK(ctx, hipMemcpyAsync(ctx->tmplWg.p, wg.data(), (size_t)numWg * sizeof(uint2), hipMemcpyHostToDevice, s));
 		HIPCHK(ctx, hipStreamSynchronize(s)); // the host vectors go away
 	}
-	uint32_t roundWord = 0;
-	if (roundTmpl) { HIPCHK(ctx, hipMemcpyAsync(&roundWord, &((VgxTmplClass*)ctx->tmplCls.p)[T].pad[1], sizeof(uint32_t), hipMemcpyDeviceToHost, s)); }
 	HIPCHK(ctx, hipStreamSynchronize(s));
 	if ((st = launchStatus(ctx)) != VGX_OK) { return st; }
 	ctx->tmplRound = roundWord;
-	ctx->tmplRoundElems = 0;
-	if (roundTmpl) {
-		if (roundWord == 0) { return VGX_OK; }
-		VgxTmplRoundMesh last;
-		HIPCHK(ctx, hipMemcpyAsync(&last, (const VgxTmplRoundMesh*)ctx->tmplTrmesh.p + roundWord, sizeof(last), hipMemcpyDeviceToHost, s));
-		HIPCHK(ctx, hipStreamSynchronize(s));
-		ctx->tmplRoundElems = last.elem0;
-	}
+	ctx->tmplRoundElems = roundElems;
+	ctx->tmplRoundLds = roundLds;
+	ctx->tmplRelemWords = 0;
+	for (uint32_t c = 0; c < T; ++c) { ctx->tmplRelemWords += cnt[c] * clsRelems[c]; }
 	ctx->tmplInst = csz[0];
 	ctx->tmplTileSize = tileSize;
 	ctx->tmplPeriod = (uint32_t)P;
@@ -1805,6 +1828,10 @@ static int tryTemplate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draw
 		a.caps.vertices = ~0ull; a.caps.indices = ~0ull; a.caps.meshes = ~0ull;
 		a.total.num_vertices = 0; a.total.num_indices = 0;
 		if (a.num_wg > 0x7FFFFFFFull || a.ninst * (uint64_t)roundWord >= (1ull << 31)) { return VGX_OK; } // beyond the sizes kernels' grids: the ordinary pipeline
+		if (T > 1) { // several classes: only the workgroup-per-instance shape of the sizes pass addresses its tables per instance
+			a.num_round = roundWord; a.num_round_elems = roundElems;
+			if (!vgx_tmpl_round_per_instance(a) || ctx->tmplRelemWords >= (1ull << 40)) { return VGX_OK; }
+		}
 		noteHip(ctx, hipMemsetAsync(ctx->totals.p, 0, sizeof(VgxTotals), s));
 		if ((st = tmplRoundSizes(ctx, a, s)) != VGX_OK) { return st; }
 		if ((st = readTotals(ctx, s)) != VGX_OK) { return st; }

@@ -147,6 +147,10 @@ struct VgxTmplArgs // one step
 	VgxTmplMeshPlace* mplace;    // [ninst * meshes] per mesh of the batch: first vertex, first index in the BATCH (iplace set: inside its INSTANCE); vertices, indices
 	unsigned long long* itot;    // [ninst * 2] (per-instance shape of the sizes pass only, else null) vertices, indices of the instance
 	unsigned long long* iplace;  // [ninst * 2] ... first vertex, first index of the instance in the batch
+	// Round joins, several classes (round 6; the per-instance shape of the sizes pass only): class c's Round-join meshes are trmesh[cls[c].pad[1] ..
+	// cls[c + 1].pad[1]) (entry [nclasses]: all of them), an instance's tables lie at iinfo[k].m (mplace) and iinfo[k].rel (relem)
+	const VgxTmplClass* cls;     // [nclasses + 1] (null: one class)
+	uint32_t round_lds;          // Round-join meshes of the largest class (k_tmpl_round_sizes_inst's LDS table)
 };
 struct Sum3;
 bool vgx_tmpl_round_per_instance(const VgxTmplArgs& a); // the sizes pass places the meshes per instance (many instances of a few hundred meshes): the caller sets a.itot / a.iplace

@@ -221,13 +221,15 @@ struct VgxTmplClass // 40 bytes
 	uint32_t tile0;  // first tile
 	uint32_t pad[2];
 };
-struct VgxTmplInst // multi-class batches: where instance k's output lies, and its class. 32 bytes
+struct VgxTmplInst // multi-class batches: where instance k's output lies, and its class. 40 bytes
 {
-	uint64_t v, i;   // first output vertex / index of the instance
+	uint64_t v, i;   // first output vertex / index of the instance (templates with Round joins: the per-step table iplace instead)
 	uint32_t m;      // first mesh of the instance in the batch's mesh sequence
 	uint32_t cls;
 	uint32_t cmesh0; // first template mesh of its class
 	uint32_t pad;
+	uint64_t rel;    // Round-join templates: relem + rel + (an element's number among the TEMPLATE's Round-join elements) = the element's table word
+	                 // (= the instance's first word minus its class's first element number; wraps, the sum does not)
 };
 #define VGX_TMPL_MAX_CLASSES 64
 

@@ -285,6 +285,22 @@ struct OpTmplRoundIndex
 	}
 };
 
+// Several classes: where each class's Round-join meshes begin in trmesh (they are numbered across the concatenated template) -> cls[c].pad[1],
+// and the element number of its first one -> cls[c].pad[0], c < nclasses (entry [nclasses] keeps the totals / the style bits). One thread.
+__global__ void k_tmpl_round_classes(VgxTmplBuild B)
+{
+	const uint32_t R = B.cls[B.nclasses].pad[1];
+	for (uint32_t c = 0; c < B.nclasses; ++c) {
+		uint32_t lo = 0, hi = R; // first Round-join mesh at or behind the class's first mesh
+		while (lo < hi) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if (B.trmesh[mid].mesh < B.cls[c].mesh0) { lo = mid + 1; } else { hi = mid; }
+		}
+		B.cls[c].pad[1] = lo;
+		B.cls[c].pad[0] = B.trmesh[lo].elem0; // (trmesh[R] = the total)
+	}
+}
+
 // Element table in processing order: tiles of `tile` elements of the instance's output-ordered element stream; inside a
 // tile the fill elements first, then the stroke elements (both in output order). Every class starts a tile of its own
 // (tile cls.tile0, table slot cls.tile0 * tile): a tile never holds elements of two classes.
@@ -932,9 +948,18 @@ __global__ __launch_bounds__(256) void k_tmpl_mtab(VgxTmplArgs A, vgx_mesh* mtab
 	for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (uint64_t)gridDim.x * blockDim.x) {
 		uint64_t inst, vb, ib;
 		uint32_t m;
-		if (A.mplace) { // Round joins (one class): places and sizes are this step's (per-step table, batch mesh order = k)
+		if (A.mplace) { // Round joins: places and sizes are this step's (per-step table, batch mesh order = k)
 			inst = k / M;
 			m = (uint32_t)(k - inst * M);
+			if (A.iinfo) { // several classes: the instance that owns mesh k = the last one whose first mesh is <= k
+				uint64_t lo = 0, hi = A.ninst;
+				while (hi - lo > 1) {
+					const uint64_t mid = (lo + hi) >> 1;
+					if (A.iinfo[mid].m <= k) { lo = mid; } else { hi = mid; }
+				}
+				inst = lo;
+				m = (uint32_t)(k - A.iinfo[lo].m) + A.iinfo[lo].cmesh0;
+			}
 			const VgxTmplMeshPlace q = A.mplace[k];
 			vgx_mesh r = A.tmtab[m];
 			r.first_vertex = q.v + (A.iplace ? A.iplace[2 * inst] : 0ull); r.first_index = q.i + (A.iplace ? A.iplace[2 * inst + 1] : 0ull); r.num_vertices = q.nv; r.num_indices = q.ni;
@@ -996,11 +1021,13 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 	// workgroup -> (instance, tile of the template), all workgroup-uniform (scalar loads)
 	uint32_t inst32, t;
 	TmplPlace P;
+	uint64_t relemAt = 0; // ROUND: where the instance's table words begin (minus its class's first element number)
 	if (A.wg) { // several classes: the tiles of an instance are its class's, the output places come from the per-instance table
 		const uint2 w = A.wg[blockIdx.x];
 		inst32 = w.x; t = w.y;
 		const VgxTmplInst ii = A.iinfo[inst32];
 		P.v = ii.v; P.i = ii.i; P.m = ii.m;
+		if (ROUND) { P.v = A.iplace[2 * (uint64_t)inst32]; P.i = A.iplace[2 * (uint64_t)inst32 + 1]; relemAt = ii.rel; } // (several classes: the per-instance shape of the sizes pass)
 	} else {
 		inst32 = blockIdx.x / A.tiles_per_inst;
 		t = blockIdx.x - inst32 * A.tiles_per_inst;
@@ -1008,6 +1035,7 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 		if (ROUND) {
 			if (A.iplace) { P.v = A.iplace[2 * (uint64_t)inst32]; P.i = A.iplace[2 * (uint64_t)inst32 + 1]; } // (mplace: places inside the instance)
 			else { const VgxTmplMeshPlace* mp = A.mplace + (uint64_t)inst32 * A.inst.num_meshes; P.v = mp->v; P.i = mp->i; } // (mplace: places in the batch) the instance begins where its first mesh does
+			relemAt = (uint64_t)inst32 * A.num_round_elems;
 		}
 	}
 	const uint64_t inst = inst32;
@@ -1031,14 +1059,14 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 	}
 	// this instance's meshes in the per-step table: indexed by (template mesh number - P.cmesh0); P.cmesh0 = 0 (one class). Places inside the
 	// instance are 32-bit (the stores use workgroup-uniform stream bases + 32-bit offsets): an instance beyond that ends the call
-	const VgxTmplMeshPlace* mplace = ROUND ? A.mplace + (uint64_t)inst32 * A.inst.num_meshes : nullptr;
+	const VgxTmplMeshPlace* mplace = ROUND ? A.mplace + P.m : nullptr; // (P.m = instance x meshes per instance for one class)
 	auto minfoOf = [&](uint32_t m) {
-		const VgxTmplMeshPlace q = mplace[m];
+		const VgxTmplMeshPlace q = mplace[m - P.cmesh0];
 		const unsigned long long dv = A.iplace ? q.v : q.v - P.v, di = A.iplace ? q.i : q.i - P.i;
 		if ((dv | di) >> 32) { set_status(A.totals, VGX_E_RANGE); }
 		return make_uint4((uint32_t)dv, (uint32_t)di, q.nv, q.ni);
 	};
-	const uint2* relem = ROUND ? A.relem + (uint64_t)inst32 * A.num_round_elems : nullptr;  // indexed by trix[slot]
+	const uint2* relem = ROUND ? A.relem + relemAt : nullptr;  // indexed by the element's number among the template's Round-join elements
 
 	if (nm > VGX_TMPL_MAXM || nd > VGX_TMPL_MAXM) {
 		// workgroup-uniform. Many tiny meshes (or many draws without a mesh) in one tile: the draw records are verified in a loop,
@@ -1323,7 +1351,8 @@ struct TmplRoundRec // 48 bytes
 	float hsw, hswAA, da; uint32_t pad;
 };
 // one mesh: lanes = elements, 64 per trip
-__device__ __forceinline__ void tmpl_round_sizes_mesh(const VgxTmplArgs& A, uint64_t inst, uint32_t r, const TmplRoundRec& rc, uint32_t lane, unsigned long long* meshV, unsigned long long* meshI)
+__device__ __forceinline__ void tmpl_round_sizes_mesh(const VgxTmplArgs& A, uint64_t inst, uint32_t r, const TmplRoundRec& rc, uint32_t lane, unsigned long long* meshV, unsigned long long* meshI,
+	uint64_t relemAt, bool writeRsz = true) // relemAt: where the instance's table words begin (one class: instance x elements per instance)
 {
 	const TmplXf xf = rc.xf;
 	const float2* vt = A.tpoly + rc.poly_first;
@@ -1333,7 +1362,7 @@ __device__ __forceinline__ void tmpl_round_sizes_mesh(const VgxTmplArgs& A, uint
 	mc.N = N; mc.hsw = rc.hsw; mc.hswAA = rc.hswAA; mc.fringe = 0.0f; // (the fringe: thin strokes only, never a Round-join mesh)
 	mc.dr = A.tdraws; mc.da = rc.da; // (the arc step: in the mesh record since the template was built; dr is not read)
 	mc.vtx.x0 = 0.0f; mc.vtx.y0 = 0.0f; mc.vtx.x1 = 0.0f; mc.vtx.y1 = 0.0f;
-	uint2* out = A.relem + inst * A.num_round_elems + rc.elem0;
+	uint2* out = A.relem + relemAt + rc.elem0;
 	unsigned long long runV = 0, runI = 0;
 	uint32_t carryNv = 0; bool carryInner = false; // the element in front of the chunk (wave-uniform)
 	for (uint32_t j0 = 0; j0 < N; j0 += 64) {
@@ -1364,17 +1393,19 @@ __device__ __forceinline__ void tmpl_round_sizes_mesh(const VgxTmplArgs& A, uint
 		carryNv = __shfl(nv, (int)lastLane); carryInner = __shfl((int)inner, (int)lastLane) != 0;
 	}
 	if (lane == 0) {
-		const uint64_t g = inst * A.num_round + r;
-		A.rsz[2 * g] = runV; A.rsz[2 * g + 1] = runI;
+		if (writeRsz) { // (the per-instance shape keeps the sizes in LDS)
+			const uint64_t g = inst * A.num_round + r;
+			A.rsz[2 * g] = runV; A.rsz[2 * g + 1] = runI;
+		}
 		if (mc.closed) { out[0] = tmpl_round_word(0u, 0u, carryNv, carryInner); } // join 0: the closing bridge starts at the LAST join (which is now known)
 	}
 	*meshV = runV; *meshI = runI; // (wave-uniform)
 }
-__device__ __forceinline__ TmplRoundRec tmpl_round_rec(const VgxTmplArgs& A, uint64_t inst, uint32_t r)
+__device__ __forceinline__ TmplRoundRec tmpl_round_rec(const VgxTmplArgs& A, uint64_t inst, uint32_t r, const vgx_draw* tdraws) // r: number in trmesh; tdraws: the class representative's records
 {
 	const VgxTmplRoundMesh rm = A.trmesh[r];
 	const VgxTmplMesh tm = A.tmesh[rm.mesh];
-	const TmplDraw dr = tmpl_load_draw(A, A.draws + inst * A.period, A.tdraws, tm.drawk); // (verified: a stale or non-finite record ends the call like in the emit kernel)
+	const TmplDraw dr = tmpl_load_draw(A, A.draws + inst * A.period, tdraws, tm.drawk); // (verified: a stale or non-finite record ends the call like in the emit kernel)
 	TmplRoundRec rc;
 	rc.xf = tmpl_draw_xf(&dr);
 	rc.poly_first = tm.poly_first; rc.n = tm.n; rc.kind = tm.kind; rc.elem0 = rm.elem0;
@@ -1393,13 +1424,24 @@ __global__ __launch_bounds__(256) void k_tmpl_round_sizes_inst(VgxTmplArgs A)
 	extern __shared__ TmplRoundRec s_rc[]; // [num_round] (dynamic: a template of a hundred such meshes takes 5 KB, not the 30 KB of the limit)
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	const uint32_t R = A.num_round;
 	const uint64_t inst = blockIdx.x;
-	for (uint32_t r = threadIdx.x; r < R; r += 256) { s_rc[r] = tmpl_round_rec(A, inst, r); }
+	// the instance's class (one class: the whole template): its Round-join meshes trmesh[R0, R0 + R), its meshes [cmesh0, cmesh0 + M) of the
+	// template, its saved draw records, and where the instance's rows of the per-step tables begin
+	uint32_t R = A.num_round, R0 = 0, M = (uint32_t)A.inst.num_meshes, cmesh0 = 0;
+	const vgx_draw* tdraws = A.tdraws;
+	uint64_t relemAt = inst * A.num_round_elems, mplaceAt = inst * M;
+	if (A.iinfo) {
+		const VgxTmplInst ii = A.iinfo[inst];
+		const VgxTmplClass c0 = A.cls[ii.cls], c1 = A.cls[ii.cls + 1];
+		R0 = c0.pad[1]; R = c1.pad[1] - R0; cmesh0 = c0.mesh0; M = c1.mesh0 - cmesh0;
+		tdraws = A.tdraws + (uint64_t)ii.cls * A.period;
+		relemAt = ii.rel; mplaceAt = ii.m;
+	}
+	for (uint32_t r = threadIdx.x; r < R; r += 256) { s_rc[r] = tmpl_round_rec(A, inst, R0 + r, tdraws); }
 	__syncthreads();
 	for (uint32_t r = wave; r < R; r += 4) {
 		unsigned long long mv, mi;
-		tmpl_round_sizes_mesh(A, inst, r, s_rc[r], lane, &mv, &mi);
+		tmpl_round_sizes_mesh(A, inst, r, s_rc[r], lane, &mv, &mi, relemAt, false);
 		if (lane == 0) { // the mesh's sizes stay here for the places below (the record's transform is not needed any more)
 			s_rc[r].xf.m0 = __uint_as_float(vgx_sat_nv(mv)); s_rc[r].xf.m1 = __uint_as_float(vgx_sat_ni(mi)); s_rc[r].xf.m2 = __uint_as_float(mv > 65536ull ? 1u : 0u);
 		}
@@ -1411,15 +1453,14 @@ __global__ __launch_bounds__(256) void k_tmpl_round_sizes_inst(VgxTmplArgs A)
 	__shared__ uint32_t s_big;
 	if (threadIdx.x == 0) { s_runV = 0; s_runI = 0; s_big = 0; }
 	__syncthreads();
-	const uint32_t M = (uint32_t)A.inst.num_meshes;
-	VgxTmplMeshPlace* mp = A.mplace + inst * M;
+	VgxTmplMeshPlace* mp = A.mplace + mplaceAt;
 	for (uint32_t m0 = 0; m0 < M; m0 += 256) {
 		const uint32_t m = m0 + threadIdx.x;
 		uint32_t nv = 0, ni = 0;
 		if (m < M) {
-			const uint2 ts = A.tmsz[m];
+			const uint2 ts = A.tmsz[cmesh0 + m];
 			if (ts.x >> 31) {
-				const TmplRoundRec* rc = &s_rc[ts.x & 0x7FFFFFFFu];
+				const TmplRoundRec* rc = &s_rc[(ts.x & 0x7FFFFFFFu) - R0];
 				nv = __float_as_uint(rc->xf.m0); ni = __float_as_uint(rc->xf.m1);
 				if (__float_as_uint(rc->xf.m2)) { s_big = 1u; } // what OpMeshOffsets reports for such a mesh (16-bit indices)
 			} else { nv = ts.x; ni = ts.y; }
@@ -1456,7 +1497,7 @@ __global__ __launch_bounds__(256) void k_tmpl_round_sizes(VgxTmplArgs A)
 	const uint64_t inst = g / R;
 	const uint32_t r = (uint32_t)(g - inst * R);
 	unsigned long long mv, mi;
-	tmpl_round_sizes_mesh(A, inst, r, tmpl_round_rec(A, inst, r), lane, &mv, &mi);
+	tmpl_round_sizes_mesh(A, inst, r, tmpl_round_rec(A, inst, r, A.tdraws), lane, &mv, &mi, inst * A.num_round_elems);
 }
 
 // The same for templates of LONG Round-join meshes (a polyline of a thousand segments: one wave per mesh leaves the GPU to a few thousand
@@ -1600,7 +1641,8 @@ struct OpTmplRoundInst
 
 bool vgx_tmpl_round_per_instance(const VgxTmplArgs& a) // which shape vgx_launch_tmpl_round_sizes takes: the host sets a.iplace / a.itot for this one
 {
-	return a.num_round != 0 && a.num_round_elems / a.num_round <= 128u && a.num_round <= VGX_TMPL_ROUND_MAXR && a.ninst >= 64;
+	// (several classes: num_round / num_round_elems are the sums over the classes -- the mean mesh length is the template's -- and round_lds the largest class)
+	return a.num_round != 0 && a.num_round_elems / a.num_round <= 128u && (a.cls ? a.round_lds : a.num_round) <= VGX_TMPL_ROUND_MAXR && a.ninst >= 64;
 }
 
 void vgx_launch_tmpl_round_sizes(const VgxTmplArgs& a, Sum3* partial, hipStream_t s)
@@ -1610,7 +1652,7 @@ void vgx_launch_tmpl_round_sizes(const VgxTmplArgs& a, Sum3* partial, hipStream_
 	const uint64_t pairs = a.ninst * (uint64_t)a.num_round; // the host checked < 2^31
 	if (a.num_round_elems / a.num_round > 128u) { hipLaunchKernelGGL(k_tmpl_round_sizes_block, dim3((unsigned)pairs), dim3(256), 0, s, a); } // long meshes: a workgroup each
 	else if (vgx_tmpl_round_per_instance(a)) { // a workgroup per instance: sizes, the meshes' places inside the instance; then the scan over the instances
-		hipLaunchKernelGGL(k_tmpl_round_sizes_inst, dim3((unsigned)a.ninst), dim3(256), a.num_round * sizeof(TmplRoundRec), s, a);
+		hipLaunchKernelGGL(k_tmpl_round_sizes_inst, dim3((unsigned)a.ninst), dim3(256), (a.cls ? a.round_lds : a.num_round) * sizeof(TmplRoundRec), s, a);
 		OpTmplRoundInst opi;
 		opi.A = a;
 		vgx_device_scan(opi, partial, s, a.ninst);
@@ -1658,7 +1700,10 @@ void vgx_launch_tmpl_build(const VgxTmplBuild& b, hipStream_t s)
 	const uint64_t nt = (b.num_elems + b.tile - 1) / b.tile + b.nclasses; // >= the tile count (every class rounds up on its own)
 	if (b.num_meshes) {
 		hipLaunchKernelGGL(k_tmpl_meshes, dim3((unsigned)(gm > 4096 ? 4096 : gm)), dim3(256), 0, s, b);
-		if (b.has_round) { OpTmplRoundIndex op; op.B = b; vgx_device_scan(op, b.partial, s, b.num_meshes); }
+		if (b.has_round) {
+			OpTmplRoundIndex op; op.B = b; vgx_device_scan(op, b.partial, s, b.num_meshes);
+			if (b.nclasses > 1) { hipLaunchKernelGGL(k_tmpl_round_classes, dim3(1), dim3(1), 0, s, b); }
+		}
 	}
 	if (b.num_elems) {
 		hipLaunchKernelGGL(k_tmpl_elems, dim3((unsigned)(nt > 65536 ? 65536 : nt)), dim3(256), 0, s, b); // one workgroup per tile

@@ -503,6 +503,32 @@ def template_class_draws(ps, seed, instances, nclasses):
     return d, pick
 
 
+def template_class_round_draws(ps, seed, instances, nclasses, closed_aa_only=False):
+    """template_class_draws whose flavours hold Round joins (template_general_draws(round_joins=True) per flavour: other scales, widths,
+    tolerances AND other stroke styles from class to class): mesh sizes belong to the instance, tables to its class. closed_aa_only: AA
+    strokes with Miter / Bevel / Round joins only (with closed paths: the closed-stroke kernels)."""
+    rs = np.random.RandomState(seed + 4242)
+    flav = []
+    for c in range(nclasses):
+        if closed_aa_only:
+            one = template_draws(ps, seed + 31 * c, 1, same_colors=True)
+            r2 = np.random.RandomState(seed + 17 * c)
+            for i in range(ps.npaths):
+                if r2.uniform() < 0.85:
+                    set_stroke(one, i, 0xFF102030, float(r2.choice([1.5, 3.0, 12.0])), capi.CAP_BUTT, int(r2.choice([capi.JOIN_MITER, capi.JOIN_BEVEL, capi.JOIN_ROUND])), aa=True,
+                               avg_scale=float(one["scale"][i]), fringe=float(one["fringe"][i]))
+            flav.append(one)
+        else:
+            flav.append(template_general_draws(ps, seed + 31 * c, 1, round_joins=True))
+    pick = np.concatenate([np.arange(nclasses), rs.randint(0, nclasses, size=max(0, instances - nclasses))])[:instances]
+    base = template_draws(ps, seed, instances)
+    d = np.concatenate([flav[int(c)] for c in pick])
+    d["mtx"] = base["mtx"]
+    d["fill_color"] = base["fill_color"]
+    d["stroke_color"] = base["stroke_color"]
+    return d, pick
+
+
 def template_general_draws(ps, seed, instances, round_joins=False):
     """template_draws with every stroke style whose mesh sizes do not depend on the geometry: open and closed sub-paths (whatever
     `ps` holds), Butt / Square / Round caps, Miter / Bevel joins, AA / non-AA / hairline (Thin) strokes."""

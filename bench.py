@@ -177,6 +177,8 @@ WORKLOADS = {
     "tiger10k_bevel": "Tiger x10k with Bevel joins on the strokes: template mode, closed Bevel routine beside the closed Miter one (k_tmpl_emit_bevel; round 4: the general element body)",
     "tiger10k_round": "Tiger x10k with Round joins on the strokes (arc points counted on every instance's transformed polyline): template mode with per-step sizes (k_tmpl_round_sizes + k_tmpl_emit_round_aa)",
     "tiger10k_round_ordinary": "the tiger10k_round batch with VGX_TMPL_ROUND=0: the ordinary pipeline (k_flatten_inst + k_fill + k_round_sizes + k_stroke), what Round joins cost before round 5",
+    "tiger10k_varied_round": "the tiger10k_varied batch (7 scales, 18 classes) with Round joins on the strokes: class-aware Round-join templates (round 6) -- one template per class, per-step sizes counted per instance",
+    "tiger10k_varied_round_ordinary": "the same batch with VGX_TMPL_ROUND=0: the ordinary pipeline (k_flatten_inst with the instances sorted by tolerance class + k_fill + k_round_sizes + k_stroke), what it cost before",
     "round10k_static": "BASELINE configs[3]'s batch (10k polylines x 1k segments, Round joins + Round caps) with vgx_set_static_batches: the draw list flattened once by the count, a step = per-step Round-join sizes + the template emit kernel (no flatten, no scans)",
     "tiger10k_culled": "Tiger x10k after culling and reordering (a random 70 % of the draws, shuffled: no period left) with vgx_set_static_batches: the draw list flattened once by the count as ONE template, a step = the emit kernel (element tables from HBM instead of L2)",
     "tiger10k_culled_ordinary": "the tiger10k_culled batch without static batches: k_flatten_inst grouped by path + k_fill + k_stroke, what such a scene cost before round 5",
@@ -188,7 +190,7 @@ WORKLOADS = {
     "tiger10k_command_parallel": "Tiger x10k with VGX_INST=0: k_flatten_build (one lane per path command) + k_fill + k_stroke, no instancing at all",
     "tiger10k_varied_per_instance_flatten": "the tiger10k_varied batch with VGX_TMPL_CLASSES=0: what instances cost when they share no subdivision (k_flatten_inst with the instances sorted by tolerance class + k_fill + k_stroke)",
 }
-CONFIG_ENV = {"round10k_static": {"VGX_TMPL_BATCH": "1"}, "tiger10k_culled": {"VGX_TMPL_BATCH": "1"}, "tiger10k_culled_ordinary": {"VGX_TMPL_BATCH": "0"}, "tiger10k_round_ordinary": {"VGX_TMPL_ROUND": "0"}, "tiger10k_per_instance_flatten": {"VGX_TMPL": "0"}, "tiger10k_command_parallel": {"VGX_INST": "0"}, "tiger10k_varied_per_instance_flatten": {"VGX_TMPL_CLASSES": "0"}}
+CONFIG_ENV = {"round10k_static": {"VGX_TMPL_BATCH": "1"}, "tiger10k_culled": {"VGX_TMPL_BATCH": "1"}, "tiger10k_culled_ordinary": {"VGX_TMPL_BATCH": "0"}, "tiger10k_round_ordinary": {"VGX_TMPL_ROUND": "0"}, "tiger10k_varied_round_ordinary": {"VGX_TMPL_ROUND": "0"}, "tiger10k_per_instance_flatten": {"VGX_TMPL": "0"}, "tiger10k_command_parallel": {"VGX_INST": "0"}, "tiger10k_varied_per_instance_flatten": {"VGX_TMPL_CLASSES": "0"}}
 # configs that get their own cpu_baseline (the honesty configs are the headline's batch: they share its baseline)
 CONFIG_CPU = {"cubics1m": "cubics", "round10k": "round", "tigerspec10k": "tigerspec", "tiger10k_varied": "varied", "tiger10k_open": "tigeropen", "tiger10k_bevel": "tigerbevel", "tiger10k_round": "tigerround"}
 CONFIG_CPU_BUDGET = {"cubics": 4.0, "round": 4.0}  # seconds of wall time per config (the tiger variants: 2.5 s)
@@ -206,6 +208,11 @@ def make_workload(wl, name, instances, rank):
         d = wl.tiger_varied_draws(ops, instances, first_instance=rank * instances)
         return ps, d, ("tiger-like drawing (seed 2024) x %d instances per GPU, every instance at its own scale in {0.5 .. 3.5} and "
                        "rotation (tolerance and stroke widths follow the scale)" % instances), "tessellate"
+    if name in ("tiger10k_varied_round", "tiger10k_varied_round_ordinary"):
+        ps, ops = wl.tiger_paths()
+        d = wl.tiger_varied_draws(ops, instances, first_instance=rank * instances, join=1)  # vg::LineJoin::Round
+        return ps, d, ("tiger-like drawing (seed 2024) x %d instances per GPU, every instance at its own scale in {0.5 .. 3.5} and rotation, "
+                       "Round joins on the strokes" % instances), "tessellate"
     if name == "tiger10k_open":
         ps, ops = wl.tiger_paths(closed=False)
         d = wl.tiger_draws(ops, instances, first_instance=rank * instances)
@@ -826,10 +833,10 @@ def roofline(res, steps, traffic_for=None):
         secondary = {"bound": "valu_issue", "achieved": round(ach, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": round(ach / VALU_PEAK_GINST, 4),
                      "valu_insts_per_launch": valu}
         if valu_active:
-            # how busy the vector ALUs are, whatever the instructions cost (packed, transcendental and dependent instructions hold a SIMD
-            # longer than the 2 issue cycles the `frac` above prices them at): cycles with a vector instruction executing
-            # (SQ_ACTIVE_INST_VALU, quad-cycles summed over the waves) / the cycles the 1 024 SIMDs had at 2.4 GHz
-            secondary["busy_frac"] = round(valu_active * 4.0 / (1024.0 * dom_ms * 1e-3 * 2.4e9), 4)
+            # SQ_ACTIVE_INST_VALU of the same pass (quad-cycles with a vector instruction executing, summed over the waves). On every kernel of
+            # this library it comes to 1.00-1.05 quad-cycles per instruction: the counter's granularity, not a second measurement -- reported
+            # as it is, no fraction derived from it (at 4 cycles per instruction every `frac` above would double)
+            secondary["valu_active_quad_cycles_per_launch"] = valu_active
     return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "secondary": secondary,
             "traffic_ratio": None if traffic is None else round(traffic / ab[dom], 3),

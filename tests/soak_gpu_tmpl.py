@@ -1,6 +1,6 @@
 """GPU soak of template mode (not collected by pytest): N random drawings through vgx_tessellate against the reference oracle --
 periodic batches (33..140 instances) and static batches (vgx_set_static_batches: the draws shuffled, a random part dropped), every
-stroke style (Round joins in two thirds of the seeds), random affine transforms per instance, random tile sizes (read at vgx_create:
+stroke style (Round joins in two thirds of the seeds; a quarter of the periodic seeds in several class flavours with Round joins), random affine transforms per instance, random tile sizes (read at vgx_create:
 a few contexts), the steady-state call with OTHER transforms than the counted ones (Round joins: other sizes).
 `python tests/soak_gpu_tmpl.py 200`."""
 import importlib, sys, os, numpy as np, torch
@@ -29,6 +29,9 @@ for seed in range(base, base + n):
         ninst += 17
     d = wl.template_general_draws(ps, seed, ninst, round_joins=(seed % 3 != 0))
     static = seed % 2 == 1
+    if not static and seed % 8 in (2, 6):  # round 6: Round joins in a template of several classes (64+ instances: the sizes pass per instance; fewer: the ordinary pipeline)
+        ninst = max(ninst, 64 if seed % 16 == 2 else 40)
+        d, _ = wl.template_class_round_draws(ps, seed, ninst, int(rs.randint(2, 9)), closed_aa_only=closed_only)
     if static:
         d = d[rs.uniform(size=d.shape[0]) < 0.8]
         d = d[rs.permutation(d.shape[0])]

@@ -1066,7 +1066,8 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 		if ((dv | di) >> 32) { set_status(A.totals, VGX_E_RANGE); }
 		return make_uint4((uint32_t)dv, (uint32_t)di, q.nv, q.ni);
 	};
-	const uint2* relem = ROUND ? A.relem + relemAt : nullptr;  // indexed by the element's number among the template's Round-join elements
+	// table word of element number e among the template's Round-join elements (relemAt may be "negative" -- it wraps --: the sum is formed first, then the pointer)
+	auto relemOf = [&](uint32_t e) { return A.relem + (relemAt + (uint64_t)e); };
 
 	if (nm > VGX_TMPL_MAXM || nd > VGX_TMPL_MAXM) {
 		// workgroup-uniform. Many tiny meshes (or many draws without a mesh) in one tile: the draw records are verified in a loop,
@@ -1092,7 +1093,7 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 				vOff = mi.x; iOff = mi.y;
 				if (j == 0 && A.meshes_out) { tmpl_mesh_out_placed(A, P, er.mesh, mi); }
 				if (tm.pad[1] != 0) {
-					const uint2 bk = relem[__float_as_uint(tm.l2[1]) + j];
+					const uint2 bk = *relemOf(__float_as_uint(tm.l2[1]) + j);
 					rpl.placed = true;
 					tmpl_round_unword(bk.x, bk.y, &rpl.b, &rpl.k, &rpl.nvPrev, &rpl.prevInner);
 					rpl.nv = mi.z; rpl.ni = mi.w;
@@ -1168,7 +1169,7 @@ __device__ __forceinline__ void tmpl_emit_body(const VgxTmplArgs& A)
 			if (s < nel) {
 				const uint32_t e0 = __float_as_uint(s_rmesh[er[c].mesh - mA].w);
 				if (e0 != ~0u) { // (x is never ~0: a place is < 65 535)
-					const uint2* w = relem + e0 + (er[c].jq & 0xFFFFu);
+					const uint2* w = relemOf(e0 + (er[c].jq & 0xFFFFu));
 					if (GENERAL) { const uint2 bk = *w; rb[c] = bk.x; rk[c] = bk.y; } else { rb[c] = w->x; }
 				}
 			}
@@ -1362,7 +1363,7 @@ __device__ __forceinline__ void tmpl_round_sizes_mesh(const VgxTmplArgs& A, uint
 	mc.N = N; mc.hsw = rc.hsw; mc.hswAA = rc.hswAA; mc.fringe = 0.0f; // (the fringe: thin strokes only, never a Round-join mesh)
 	mc.dr = A.tdraws; mc.da = rc.da; // (the arc step: in the mesh record since the template was built; dr is not read)
 	mc.vtx.x0 = 0.0f; mc.vtx.y0 = 0.0f; mc.vtx.x1 = 0.0f; mc.vtx.y1 = 0.0f;
-	uint2* out = A.relem + relemAt + rc.elem0;
+	uint2* out = A.relem + (relemAt + (uint64_t)rc.elem0); // (relemAt wraps for all but a template's first class: the sum first)
 	unsigned long long runV = 0, runI = 0;
 	uint32_t carryNv = 0; bool carryInner = false; // the element in front of the chunk (wave-uniform)
 	for (uint32_t j0 = 0; j0 < N; j0 += 64) {

@@ -304,28 +304,37 @@ __global__ void k_tmpl_round_classes(VgxTmplBuild B)
 // Element table in processing order: tiles of `tile` elements of the instance's output-ordered element stream; inside a
 // tile the fill elements first, then the stroke elements (both in output order). Every class starts a tile of its own
 // (tile cls.tile0, table slot cls.tile0 * tile): a tile never holds elements of two classes.
+#define VGX_TMPL_ELEMS_MAXM 1032 /* meshes of one tile k_tmpl_elems keeps in LDS (a mesh has >= 2 elements: a 2 048-element tile holds <= 1 025) */
 __global__ __launch_bounds__(256) void k_tmpl_elems(VgxTmplBuild B) // one workgroup per tile
 {
 	const uint64_t M = B.num_meshes;
 	const uint64_t E = B.num_elems;
 	const uint64_t T = B.tile;
-	// owner of output-ordered element x among the meshes [lo, hi) (prefix[lo] <= x < prefix[hi]): last mesh with fillPrefix + strokePrefix <= x;
-	// returns (mesh, fill elements before x, stroke elements before x)
-	auto locate = [&](uint64_t x, uint64_t lo, uint64_t hi, uint64_t* mesh, uint64_t* fBefore, uint64_t* sBefore, uint32_t* j, bool* isFill) {
-		if (x >= E) { *mesh = M; *fBefore = B.prefix_fill[M]; *sBefore = B.prefix_stroke[M]; *j = 0; *isFill = false; return; }
-		while (hi - lo > 1) {
-			const uint64_t mid = (lo + hi) >> 1;
-			if (B.prefix_fill[mid] + B.prefix_stroke[mid] <= x) { lo = mid; } else { hi = mid; }
-		}
-		// zero-length entries cannot occur (every mesh has >= 2 elements), so lo owns x
-		const uint64_t pf = B.prefix_fill[lo], psk = B.prefix_stroke[lo];
-		const uint32_t jj = (uint32_t)(x - (pf + psk));
-		const bool f = VGX_MD_KIND(B.mdesc[lo].kind) < VGX_MESH_STROKE;
-		*mesh = lo; *j = jj; *isFill = f;
-		*fBefore = pf + (f ? jj : 0u);
-		*sBefore = psk + (f ? 0u : jj);
-	};
+	const uint32_t tid = threadIdx.x;
+	// first output-ordered element of mesh m (= elements in front of it); zero-length entries cannot occur (every mesh has >= 2 elements)
+	auto first = [&](uint64_t m) { return B.prefix_fill[m] + B.prefix_stroke[m]; };
+	__shared__ unsigned long long s_pf[VGX_TMPL_ELEMS_MAXM], s_ps[VGX_TMPL_ELEMS_MAXM]; // the tile's meshes: fill / stroke elements in front (bit 63 of s_ps: a fill mesh)
+	__shared__ unsigned long long s_poly[VGX_TMPL_ELEMS_MAXM];                          // ... first vertex of the mesh's polyline
+	__shared__ uint32_t s_pick;
 	__shared__ uint64_t s_b[6]; // m0, f0, s0, m1, f1, (unused)
+	// the last mesh in [lo, hi) whose first element is <= x (first(lo) <= x): the whole workgroup searches, 256 probes per round trip -- one
+	// thread walking a binary search over the millions of meshes of a static batch was 22 dependent round trips per tile, with 255 threads
+	// waiting (round 6: k_tmpl_elems 2.0 ms of a 7.4 ms count)
+	auto lastLe = [&](uint64_t x, uint64_t lo, uint64_t hi) {
+		while (hi - lo > 1) { // workgroup-uniform
+			const uint64_t step = (hi - lo + 255) / 256;
+			const uint64_t m = lo + (uint64_t)tid * step;
+			if (tid == 0) { s_pick = 0; }
+			__syncthreads();
+			if (tid > 0 && m < hi && first(m) <= x) { atomicMax(&s_pick, tid); }
+			__syncthreads();
+			const uint32_t k = s_pick;
+			__syncthreads();
+			lo += (uint64_t)k * step;
+			hi = lo + step < hi ? lo + step : hi;
+		}
+		return lo;
+	};
 	for (uint64_t tile = blockIdx.x; tile < B.cls[B.nclasses].tile0; tile += gridDim.x) {
 		uint32_t c = 0;
 		while (c + 1 < B.nclasses && B.cls[c + 1].tile0 <= tile) { ++c; }
@@ -333,35 +342,70 @@ __global__ __launch_bounds__(256) void k_tmpl_elems(VgxTmplBuild B) // one workg
 		const uint64_t cEnd = B.cls[c + 1].elem0;
 		const uint64_t x0 = cl.elem0 + (tile - cl.tile0) * T; // the tile's first element (output order of the concatenated template)
 		const uint64_t x1 = x0 + T < cEnd ? x0 + T : cEnd;
+		// the tile's bounds: the mesh that owns its first element, and the one that owns the element behind its last (M: none)
+		const uint64_t m0 = lastLe(x0, 0, M);
+		const uint64_t m1 = x1 >= E ? M : lastLe(x1, m0, (m0 + T / 2 + 2 < M) ? m0 + T / 2 + 2 : M);
+		const uint64_t hi = m1 < M ? m1 + 1 : M;
+		const bool inLds = hi - m0 <= (uint64_t)VGX_TMPL_ELEMS_MAXM;
 		__syncthreads();
-		if (threadIdx.x == 0) { // the tile's bounds, once: where its first element and the element behind its last lie
-			uint64_t m0, f0, s0, m1, f1, s1;
+		if (inLds) {
+			for (uint64_t m = m0 + tid; m < hi; m += 256) {
+				const VgxMeshDesc md = B.mdesc[m];
+				s_pf[m - m0] = B.prefix_fill[m];
+				s_ps[m - m0] = B.prefix_stroke[m] | (VGX_MD_KIND(md.kind) < VGX_MESH_STROKE ? (1ull << 63) : 0ull);
+				s_poly[m - m0] = md.poly_first;
+			}
+		}
+		if (tid == 0) {
+			// fill / stroke elements in front of element x that mesh m owns (m = M: the totals)
+			auto before = [&](uint64_t x, uint64_t m, uint64_t* fB, uint64_t* sB, uint32_t* j) {
+				if (m >= M) { *fB = B.prefix_fill[M]; *sB = B.prefix_stroke[M]; *j = 0; return; }
+				const uint64_t pf = B.prefix_fill[m], psk = B.prefix_stroke[m];
+				const uint32_t jj = (uint32_t)(x - (pf + psk));
+				const bool f = VGX_MD_KIND(B.mdesc[m].kind) < VGX_MESH_STROKE;
+				*j = jj; *fB = pf + (f ? jj : 0u); *sB = psk + (f ? 0u : jj);
+			};
+			uint64_t f0, s0, f1, s1;
 			uint32_t j0, j1;
-			bool d0, d1;
-			locate(x0, 0, M, &m0, &f0, &s0, &j0, &d0);
-			locate(x1, m0, M, &m1, &f1, &s1, &j1, &d1);
+			before(x0, m0, &f0, &s0, &j0);
+			before(x1, x1 >= E ? M : m1, &f1, &s1, &j1);
 			s_b[0] = m0; s_b[1] = f0; s_b[2] = s0; s_b[3] = m1; s_b[4] = f1;
 			// tile record, first half: the mesh that owns the tile's first element; bit 31: it begins exactly here
 			B.ttile[tile].mesh0 = (uint32_t)m0 | (j0 == 0 ? 0x80000000u : 0u);
 			B.ttile[tile].nel = (uint32_t)(x1 - x0);
 		}
 		__syncthreads();
-		const uint64_t m0 = s_b[0], f0 = s_b[1], s0 = s_b[2], m1 = s_b[3], f1 = s_b[4];
-		const uint64_t hi = m1 < M ? m1 + 1 : M;
-		for (uint64_t e = x0 + threadIdx.x; e < x1; e += blockDim.x) {
-			uint64_t m, f, s;
-			uint32_t j;
+		const uint64_t f0 = s_b[1], s0 = s_b[2], f1 = s_b[4];
+		for (uint64_t e = x0 + tid; e < x1; e += blockDim.x) {
+			// owner of element e among the tile's meshes [m0, hi): the last one whose first element is <= e
+			uint64_t lo = m0, up = hi, pf, psk, polyFirst;
 			bool isFill;
-			locate(e, m0, hi, &m, &f, &s, &j, &isFill);
+			if (inLds) {
+				while (up - lo > 1) {
+					const uint64_t mid = (lo + up) >> 1;
+					if (s_pf[mid - m0] + (s_ps[mid - m0] & ~(1ull << 63)) <= e) { lo = mid; } else { up = mid; }
+				}
+				pf = s_pf[lo - m0]; psk = s_ps[lo - m0] & ~(1ull << 63); isFill = (s_ps[lo - m0] >> 63) != 0; polyFirst = s_poly[lo - m0];
+			} else { // (tiles of a tile size above 2 048: the same search in memory)
+				while (up - lo > 1) {
+					const uint64_t mid = (lo + up) >> 1;
+					if (first(mid) <= e) { lo = mid; } else { up = mid; }
+				}
+				pf = B.prefix_fill[lo]; psk = B.prefix_stroke[lo]; isFill = VGX_MD_KIND(B.mdesc[lo].kind) < VGX_MESH_STROKE; polyFirst = B.mdesc[lo].poly_first;
+			}
+			const uint64_t m = lo;
+			const uint32_t j = (uint32_t)(e - (pf + psk));
+			const uint64_t f = pf + (isFill ? j : 0u), sk = psk + (isFill ? 0u : j);
 			// inside a tile the fill elements first, then the stroke elements (both in output order)
-			const uint64_t slot = tile * T + (isFill ? f - f0 : (f1 - f0) + (s - s0));
+			const uint64_t slot = tile * T + (isFill ? f - f0 : (f1 - f0) + (sk - s0));
 			VgxTmplElem r;
 			r.mesh = (uint32_t)m;
 			r.jq = j | ((uint32_t)(e - x0) << 16); // j < 65536 (a mesh holds at most 65536 vertices), position in the tile < tile <= 65536
-			const float2 lv = B.poly[B.mdesc[m].poly_first + j];
+			const float2 lv = B.poly[polyFirst + j];
 			r.lx = lv.x; r.ly = lv.y;
 			B.telem[slot] = r;
 		}
+		__syncthreads(); // the LDS tables are the next tile's
 	}
 }
 

@@ -2,6 +2,7 @@
   (a) k_emit_tiles: fuzz drawings of fills + closed Miter strokes, ordinary pipeline, the tile kernel armed for every call (VGX_BIG_EMIT_MIN=0);
   (b) k_stroke_long: batches of long polylines in random general styles (Round / Bevel / Miter joins, all caps, AA and not, closed and open);
   (c) vgx_pathset_create on the device: every table of random path sets (every command / lineTo-only) against the host loops (libvgx_hosttest.so);
+  (d) every fourth seed: vgx_tessellate's one-walk flatten route on a fuzz path set of 2 100 - 3 200 paths (every command, shapes, degenerate draws);
 all against the reference (oracle/_ref) bit for bit.   python tests/soak_gpu_r06.py 300"""
 import ctypes as C, importlib, os, sys
 import numpy as np, torch
@@ -29,6 +30,7 @@ def ctx_with(**env):
 bad = 0
 ctx_tile = [ctx_with(VGX_TMPL=0, VGX_INST=0, VGX_BIG_EMIT_MIN=0), ctx_with(VGX_TMPL=0, VGX_INST=1, VGX_BIG_EMIT_MIN=0)]
 ctx_long = ctx_with(VGX_BIG_EMIT_MIN=0)
+ctx_f1 = ctx_with(VGX_TESS_FLAT1=2, VGX_BIG_EMIT_MIN=0)
 hostlib = C.CDLL(os.path.join(ROOT, "vg-renderer_amd", "libvgx_hosttest.so"))
 hostlib.vgxt_pathset_table.restype = C.c_int64
 hostlib.vgxt_pathset_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
@@ -75,6 +77,13 @@ for seed in range(BASE, BASE + N):
                 a[:, 0] &= 0xFFFF; b[:, 0] &= 0xFFFF; a[:, 3] = 0; b[:, 3] = 0
             assert np.array_equal(a, b), ("path-set table", which, seed)
         pset.close()
+        # (d) vgx_tessellate's one-walk flatten route (k_flat1 + k_flatten_gather_ordered), every eligible batch: every draw its own path
+        if seed % 4 == 0:
+            ps = wl.fuzz_paths(seed, npaths=int(rs.randint(2100, 3200)), with_shapes=bool(seed & 4), degenerate=bool(seed & 8))
+            d = wl.template_general_draws(ps, seed, 1, round_joins=True)
+            got = run_async(rt, ctx_f1, ps, d, profile=True)
+            assert got.status == 0 and "flatten_one_walk" in got.stages, got.stages
+            assert_mesh_equal(got, pyoracle.tessellate(ps, d), "one-walk route %d" % seed)
     except AssertionError as e:
         bad += 1
         print("MISMATCH seed", seed, str(e)[:300], flush=True)

@@ -1,0 +1,166 @@
+"""vgx_tessellate's ONE-WALK flatten route (round 6; VERDICT r5 item 3, /root/reference/src/path.cpp:86-182): batches of unrelated draws whose
+curves are long (the count finds >= 8 polyline vertices per command instance) are flattened by k_flat1 -- vgx_flatten's ordered one-walk
+kernel -- in k_flatten_build's place: the polyline lands dense and in draw order in the scratch, the per-draw and sub-path records are
+complete, the mesh descriptors come from them (k_flatten_gather_ordered). Bit-exact against the reference and byte for byte against the
+heap route (VGX_TESS_FLAT1=0); every path command, statically serial shapes, degenerate draws (the kernel's second run), paths without
+commands, draw-command assembly, the scratch guards of the steady state."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from util import assert_mesh_equal, bytes_equal, run_async
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rt():
+    return importlib.import_module("vg-renderer_amd.runtime")
+
+
+def _ctx_with(rt, **env):
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return rt.Context(0)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _styled_cubics(wl, rt, n, seed, box):
+    ps, d = wl.random_cubics(n, seed=seed, box=box)
+    rs = np.random.RandomState(seed)
+    wl.set_fill(d, np.flatnonzero(rs.uniform(size=n) < 0.5), 0xFF3060C0, aa=True)
+    for sel, (w, cap, join, aa) in zip(np.array_split(rs.permutation(n), 4), [(2.0, rt.capi.CAP_BUTT, rt.capi.JOIN_MITER, True), (0.7, rt.capi.CAP_ROUND, rt.capi.JOIN_ROUND, True),
+                                                                              (5.0, rt.capi.CAP_SQUARE, rt.capi.JOIN_BEVEL, False), (1.5, rt.capi.CAP_ROUND, rt.capi.JOIN_ROUND, True)]):
+        wl.set_stroke(d, sel, 0xFF10A040, w, cap, join, aa=aa)
+    d["mtx"][:, 0] = rs.uniform(0.5, 1.5, size=n).astype(np.float32)
+    d["mtx"][:, 3] = rs.uniform(0.5, 1.5, size=n).astype(np.float32)
+    d["mtx"][:, 4] = rs.uniform(-50, 50, size=n).astype(np.float32)
+    return ps, d
+
+
+@pytest.mark.parametrize("n,box", [(6000, 1000.0), (20000, 300.0), (3000, 10000.0)])
+def test_long_curves_take_the_one_walk_route_and_match_the_reference(rt, wl, oracle, n, box):
+    ps, d = _styled_cubics(wl, rt, n, 77 + n, box)
+    ref = oracle.tessellate(ps, d)
+    ctx = rt.Context(0)
+    got = run_async(rt, ctx, ps, d, profile=True)
+    assert "flatten_one_walk" in got.stages and "flatten_build" not in got.stages, got.stages
+    assert got.status == 0
+    assert_mesh_equal(got, ref, "one-walk route, %d cubics in a %g box" % (n, box))
+    ctx.close()
+    ctx0 = _ctx_with(rt, VGX_TESS_FLAT1=0)
+    old = run_async(rt, ctx0, ps, d, profile=True)
+    assert "flatten_build" in old.stages and "flatten_one_walk" not in old.stages, old.stages
+    for k in ("pos", "color", "idx", "meshes"):
+        assert bytes_equal(getattr(got, k), getattr(old, k)), k
+    ctx0.close()
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33, 34])
+def test_every_path_command_serial_shapes_and_degenerate_draws_through_the_one_walk_route(rt, wl, oracle, seed):
+    """VGX_TESS_FLAT1=2: every eligible batch whatever its curves' length. Fuzz path sets with arcs / closed shapes (the exact builder's
+    draws: counted in front of k_flat1, emitted behind it WITH their mesh descriptors), degenerate draws (found during the walk: the
+    kernel's second run), paths without commands; every draw its own path (no instancing)."""
+    ps = wl.fuzz_paths(seed, npaths=2600, with_shapes=True, degenerate=bool(seed & 1))
+    d = wl.template_general_draws(ps, seed, 1, round_joins=True)
+    assert d.shape[0] > 2048
+    ref = oracle.tessellate(ps, d)
+    ctx = _ctx_with(rt, VGX_TESS_FLAT1=2)
+    got = run_async(rt, ctx, ps, d, profile=True)
+    assert "flatten_one_walk" in got.stages, got.stages
+    assert got.status == 0
+    assert_mesh_equal(got, ref, "one-walk route, fuzz set %d" % seed)
+    ctx.close()
+
+
+def test_one_walk_route_with_draw_command_assembly_and_two_phase_entry(rt, wl, oracle):
+    import torch
+    ps, d = _styled_cubics(wl, rt, 5000, 5, 800.0)
+    d["state_key"] = (np.arange(d.shape[0]) // 61).astype(d["state_key"].dtype)
+    ref = oracle.tessellate(ps, d)
+    max_vb = 4096
+    st, rcmds, ridx = oracle.assemble(ref.meshes, ref.idx, max_vb, mesh_keys=d["state_key"][ref.meshes["draw"]])
+    assert st == 0
+    ctx = rt.Context(0)
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(d)
+    sizes = rt.tessellate_count(ctx, pset, dd, d.shape[0])
+    nv, ni, nm = sizes["num_vertices"], sizes["num_indices"], sizes["num_meshes"]
+    for use_async in (True, False):
+        bufs = rt.MeshBuffers(dd.device, nv, ni, nm)
+        cmds = torch.zeros((2 * (nv // max_vb) + 2 + d.shape[0]) * 48, dtype=torch.uint8, device=dd.device)
+        ncmd = torch.zeros(1, dtype=torch.int64, device=dd.device)
+        ctx.set_assembly(cmds, max_vb, ncmd, split_state=True)
+        ctx.set_profiling(True)
+        try:
+            if use_async:
+                rt.tessellate_async(ctx, pset, dd, d.shape[0], bufs)
+            else:
+                rt.tessellate_count(ctx, pset, dd, d.shape[0])
+                rt.tessellate_emit(ctx, pset, dd, d.shape[0], bufs)
+            torch.cuda.synchronize()
+            stages = [n for n, _ in ctx.stage_times()]
+        finally:
+            ctx.set_assembly(None)
+            ctx.set_profiling(False)
+        assert ("flatten_one_walk" in stages) == use_async and "assemble" in stages, stages
+        assert int(ncmd.item()) == len(rcmds)
+        assert np.array_equal(bufs.idx[:ni].cpu().numpy().view(np.uint16), ridx), "command-relative indices"
+        assert np.array_equal(bufs.pos[:nv].cpu().numpy().view(np.uint32), ref.pos.view(np.uint32))
+    pset.close()
+    ctx.close()
+
+
+def test_one_walk_route_steady_state_guards(rt, wl, oracle):
+    """The route belongs to the path set and the scratch the last count sized: the same draws at a finer tolerance (eight times the
+    vertices) are flattened into what the scratch holds or end with VGX_E_NOSPACE from the device, and a call on another path set takes
+    the heap route."""
+    import torch
+    ps, d = _styled_cubics(wl, rt, 6000, 9, 1000.0)
+    ctx = rt.Context(0)
+    pset = rt.PathSet(ctx, ps)
+    dd = rt.upload_draws(d)
+    sizes = rt.tessellate_count(ctx, pset, dd, d.shape[0])
+    d2 = d.copy()
+    d2["tess_tol"] = np.float32(0.25 / 4096.0)  # 8x the vertices per curve
+    ref2 = oracle.tessellate(ps, d2)
+    assert ref2.sizes["num_poly_vertices"] > 3 * sizes["num_poly_vertices"]
+    bufs = rt.MeshBuffers(dd.device, ref2.pos.shape[0], ref2.idx.shape[0], ref2.meshes.shape[0])
+    dd2 = rt.upload_draws(d2)
+    ctx.set_profiling(True)
+    rt.tessellate_async(ctx, pset, dd2, d2.shape[0], bufs)
+    torch.cuda.synchronize()
+    assert "flatten_one_walk" in [n for n, _ in ctx.stage_times()]
+    st2 = int(bufs.dev_status.item())
+    if st2 == 0:  # (the scratch doubles as the heap route's heap: it has room for several times the counted polyline)
+        assert np.array_equal(bufs.pos[:ref2.pos.shape[0]].cpu().numpy().view(np.uint32), ref2.pos.view(np.uint32))
+        assert np.array_equal(bufs.idx[:ref2.idx.shape[0]].cpu().numpy().view(np.uint16), ref2.idx)
+    else:
+        assert st2 == rt.capi.VGX_E_NOSPACE
+    # another path set (same draws): the heap route, the reference's bytes
+    ps3, d3 = _styled_cubics(wl, rt, 6000, 10, 1000.0)
+    pset3 = rt.PathSet(ctx, ps3)
+    dd3 = rt.upload_draws(d3)
+    ref3 = oracle.tessellate(ps3, d3)
+    bufs3 = rt.MeshBuffers(dd.device, ref3.pos.shape[0], ref3.idx.shape[0], ref3.meshes.shape[0])
+    rt.tessellate_async(ctx, pset3, dd3, d3.shape[0], bufs3)
+    torch.cuda.synchronize()
+    stages = [n for n, _ in ctx.stage_times()]
+    ctx.set_profiling(False)
+    assert "flatten_build" in stages and "flatten_one_walk" not in stages, stages
+    st = int(bufs3.dev_status.item())
+    if st == 0:
+        assert np.array_equal(bufs3.pos[:ref3.pos.shape[0]].cpu().numpy().view(np.uint32), ref3.pos.view(np.uint32))
+    else:
+        assert st == rt.capi.VGX_E_NOSPACE  # (its polyline may not fit the scratch sized for the other set either)
+    pset.close()
+    pset3.close()
+    ctx.close()

@@ -99,6 +99,10 @@ struct vgx_ctx
 	struct VgxRccl* rccl;                // RCCL entry points, bound at the first vgx_gather* call
 	// options, read from the environment ONCE at vgx_create (tuning / testing knobs)
 	int optTwoPass, optBuildWaves, optPoolWalk, optNoSmall, optConcurrentEmit;
+	int optTessFlat1;                    // VGX_TESS_FLAT1: 1 (default) = vgx_tessellate flattens batches of long curves with the one-walk kernel (k_flat1), 0 = never, 2 = every eligible batch
+	// vgx_tessellate's one-walk route, decided and sized by the last vgx_tessellate_count (f1Route*): the path set it is for, the kernel
+	// instance / bucket size, the segments the look-back tables hold
+	bool f1Route; const vgx_pathset* f1RoutePs; uint64_t f1RoutePsGen; int f1RouteCap; uint32_t f1RouteSegMax; uint64_t f1RouteSegBound;
 	int optThinStatic;                   // VGX_THIN_STATIC=0: lineTo-only path sets through k_flatten_build like any other (default: k_flatten_thin, vgx_thin.h)
 	int optInst, optInstWaves; uint32_t optInstBlock; // instanced flatten kernel (vgx_inst.hip): on / grid / lane block
 	int optInstPerm;                                  // periodic batches of different scales: permute instances (1, default) or sort draws by (path, class) (0)
@@ -579,6 +583,49 @@ void runFlattenBuild(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 	mark(ctx, s, "flatten_gather");
 }
 
+// vgx_tessellate's flatten stage through the ordered one-walk kernel (vgx_flat1.hip; round 6): command prefix -> k_flat1
+// (tasks cut at the roots, leaves staged in LDS, places by look-back: the polyline lands dense and in draw order in the scratch, the per-draw and
+// sub-path records complete) -> the exact builder's draws -> totals -> mesh descriptors from the ordered records. No heap, no scan over the
+// draws. For batches of LONG curves (the count decides: >= 8 polyline vertices per command instance), where k_flatten_build's lanes spill
+// their leaves past the LDS slots and walk in lock-step with the deepest cubic of the chunk.
+void runFlattenOneWalk(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, hipStream_t s)
+{
+	{
+		const uint64_t savedCmdCap = ctx->caps.cmd_instances; // k_flat1 needs no per-command scratch (see vgx_flatten)
+		ctx->caps.cmd_instances = ~0ull;
+		runCmdPrefix(ctx, ps, draws, ndraws, s);
+		ctx->caps.cmd_instances = savedCmdCap;
+	}
+	VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, 1);
+	a.mprep = (VgxMeshPrep*)ctx->mprep.p; // k_flatten_serial / the gather write the per-mesh constants with the descriptors
+	const uint64_t segBound = ctx->f1RouteSegBound;
+	VgxF1Args x;
+	x.seg_draw = (uint64_t*)ctx->f1SegDraw.p; x.segs = (VgxF1Seg*)ctx->f1Segs.p; x.grps = x.segs + segBound;
+	x.cap_poly = ctx->caps.poly_vertices; x.cap_subs = ctx->caps.subpaths; x.pass = 0; x.read_flags = 0; x.has_empty = ps->hasEmpty ? 1 : 0;
+	x.seg_max = ctx->f1RouteSegMax; x.tag = 0;
+	if (ps->hasSerial) { // statically serial paths: the exact builder counts their draws first (it marks them in dinfo)
+		noteHip(ctx, hipMemsetAsync(ctx->dinfo.p, 0, ndraws * sizeof(vgx_draw_info), s));
+		VgxFlattenArgs ac = a;
+		ac.mdesc = nullptr; ac.mtab = nullptr; ac.mprep = nullptr;
+		vgx_launch_flatten_serial(false, ac, s);
+	}
+	vgx_launch_flat1(a, x, ctx->optF1Waves ? ctx->optF1Waves : 2048, ctx->f1RouteCap, ps->hasSerial, s);
+	VgxFlattenArgs ae = a; // the exact builder's draws: vertices, sub-path records AND mesh descriptors at the places k_flat1 gave them
+	ae.build_mode = ps->hasSerial ? 0 : 1;
+	vgx_launch_flatten_serial(true, ae, s);
+	vgx_launch_flat1_publish(a, x, nullptr, nullptr, s);
+	mark(ctx, s, "flatten_one_walk");
+	vgx_launch_flatten_gather_ordered(a, s);
+	mark(ctx, s, "flatten_gather");
+}
+
+// segments the look-back tables of the one-walk route must hold for ANY draw list of `ndraws` draws on this path set
+static uint64_t f1RouteSegmentsFor(const vgx_pathset* ps, uint64_t ndraws, uint32_t segMax)
+{
+	const uint64_t minItems = segMax < 32 ? segMax : 32;
+	return ndraws * (uint64_t)(ps->maxCmdsPerPath ? ps->maxCmdsPerPath : 1) / minItems + 2;
+}
+
 // prepDone: the flatten stage already wrote the per-mesh constants (single-pass pipeline), no k_mesh_prepare pass
 void runStrokeCount(vgx_ctx* ctx, const vgx_draw* draws, const VgxCaps& outCaps, int checkCaps, hipStream_t s, const float* poly = nullptr, bool prepDone = false, vgx_mesh* meshesOut = nullptr)
 {
@@ -797,6 +844,8 @@ int vgx_create(int device, vgx_ctx** out_ctx)
 	ctx->optTmplBatch = 0;
 	if (const char* e = getenv("VGX_TMPL_BATCH")) { ctx->optTmplBatch = atoi(e) != 0; }
 	if (const char* e = getenv("VGX_TMPL_TILE")) { const int v = atoi(e); if (v >= 64 && v <= VGX_TMPL_MAX_TILE) { ctx->optTmplTile = (uint32_t)v / 64u * 64u; } } // testing: elements per tile (<= the LDS stage of k_tmpl_emit)
+	ctx->optTessFlat1 = 1; ctx->f1Route = false; ctx->f1RoutePs = nullptr; ctx->f1RoutePsGen = 0; ctx->f1RouteCap = 1664; ctx->f1RouteSegMax = 64; ctx->f1RouteSegBound = 0;
+	if (const char* e = getenv("VGX_TESS_FLAT1")) { const int v = atoi(e); if (v >= 0 && v <= 2) { ctx->optTessFlat1 = v; } }
 	ctx->optPoolWalk = 0; // VGX_WALK=pool: the wave-cooperative walk of vgx_walk.h (same output, same speed: DESIGN.md section 4)
 	if (const char* e = getenv("VGX_WALK")) { ctx->optPoolWalk = strcmp(e, "pool") == 0; }
 	ctx->optF1Waves = 0; ctx->optF1Cap = 0; ctx->optF1Seg = 0;
@@ -1882,6 +1931,30 @@ int vgx_tessellate_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* dr
 		if (instVerts > heapVerts) { heapVerts = instVerts; }
 	}
 	if ((st = ensureMeshBuffers(ctx, heapVerts, sz.num_subpaths, sz.num_meshes)) != VGX_OK) { return st; }
+	// the one-walk route for vgx_tessellate's flatten stage? Unrelated draws (no instancing), curves (not a lineTo-only set), and long ones:
+	// >= 8 polyline vertices per command instance (VGX_TESS_FLAT1=2: whatever their length). Sized here, so that the steady state allocates nothing.
+	ctx->f1Route = false;
+	if (ctx->optTessFlat1 && !ctx->optTwoPass && ndraws > VGX_SMALL_DRAWS && !instPeriodFor(ctx, ndraws) && !instGroupedFor(ctx, ps, ndraws)
+		&& !(ps->thinStatic && ctx->optThinStatic) && sz.num_cmd_instances != 0
+		&& (ctx->optTessFlat1 == 2 || sz.num_poly_vertices >= 8 * sz.num_cmd_instances)) {
+		int cap = 1664; uint32_t segMax = 64; // as vgx_flatten picks them, from the count's own figures
+		const double perChunk = (double)sz.num_poly_vertices / (double)sz.num_cmd_instances * 64.0;
+		if (perChunk <= 800.0) { cap = 1024; }
+		else if (perChunk > 1500.0) {
+			cap = 3072;
+			const double m = 0.8 * 3072.0 / (perChunk / 64.0);
+			segMax = m >= 64.0 ? 64u : (m >= 32.0 ? 32u : (m >= 16.0 ? 16u : 8u));
+		}
+		if (ctx->optF1Cap) { cap = ctx->optF1Cap; }
+		if (ctx->optF1Seg) { segMax = (uint32_t)ctx->optF1Seg; }
+		const uint64_t segBound = f1RouteSegmentsFor(ps, ctx->capDraws > ndraws ? ctx->capDraws : ndraws, segMax);
+		if (segBound <= (1ull << 24)) {
+			if ((st = ensure(ctx, ctx->f1SegDraw, (segBound + 1) * sizeof(uint64_t))) != VGX_OK) { return st; }
+			if ((st = ensure(ctx, ctx->f1Segs, (segBound + segBound / 64 + 2) * sizeof(VgxF1Seg))) != VGX_OK) { return st; }
+			if ((st = ensure(ctx, ctx->serialList, (ctx->capDraws + 1) * sizeof(uint32_t))) != VGX_OK) { return st; }
+			ctx->f1Route = true; ctx->f1RoutePs = ps; ctx->f1RoutePsGen = ps->gen; ctx->f1RouteCap = cap; ctx->f1RouteSegMax = segMax; ctx->f1RouteSegBound = segBound;
+		}
+	}
 	VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, 1);
 	vgx_launch_flatten(true, a, VGX_GRID_BLOCKS, s);
 	mark(ctx, s, "flatten_emit");
@@ -1973,8 +2046,12 @@ int vgx_tessellate(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, u
 		}
 		return launchStatus(ctx);
 	}
-	runCmdPrefix(ctx, ps, draws, ndraws, s, ctx->optTwoPass ? 0u : instPeriodFor(ctx, ndraws));
-	if (ctx->optTwoPass) { // tuning / debugging knob: the ordered two-pass flatten
+	const bool oneWalk = ctx->f1Route && ps == ctx->f1RoutePs && ps->gen == ctx->f1RoutePsGen && !ctx->optTwoPass && !instPeriodFor(ctx, ndraws) && !instGroupedFor(ctx, ps, ndraws)
+		&& f1RouteSegmentsFor(ps, ndraws, ctx->f1RouteSegMax) <= ctx->f1RouteSegBound; // (what the last count decided and sized, for this path set)
+	if (!oneWalk) { runCmdPrefix(ctx, ps, draws, ndraws, s, ctx->optTwoPass ? 0u : instPeriodFor(ctx, ndraws)); }
+	if (oneWalk) {
+		runFlattenOneWalk(ctx, ps, draws, ndraws, s);
+	} else if (ctx->optTwoPass) { // tuning / debugging knob: the ordered two-pass flatten
 		runFlattenCount(ctx, ps, draws, ndraws, s);
 		VgxFlattenArgs a = flattenArgs(ctx, ps, draws, ndraws, 1);
 		vgx_launch_flatten(true, a, VGX_GRID_BLOCKS, s);

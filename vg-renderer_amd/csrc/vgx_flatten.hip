@@ -993,6 +993,48 @@ __global__ __launch_bounds__(256) void k_flatten_gather(VgxFlattenArgs A)
 	flatten_gather_body(A, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
 }
 
+// The same behind k_flat1 (vgx_tessellate's one-walk route, round 6): the draws' records are complete and ordered already (places from the
+// look-back), the sub-path records are the flatten API's vgx_subpath at the draw's first_subpath; checks the batch's meshes against the
+// scratch the last count sized (k_flat1 knows the caller's polyline / sub-path capacities only).
+__global__ __launch_bounds__(256) void k_flatten_gather_ordered(VgxFlattenArgs A)
+{
+	if (A.totals->status != VGX_OK) { return; }
+	if (A.totals->sizes.num_meshes > A.caps.meshes) { // (uniform: every thread reads the same words)
+		if (blockIdx.x == 0 && threadIdx.x == 0) { atomicCAS(&A.totals->status, (uint32_t)VGX_OK, (uint32_t)VGX_E_NOSPACE); }
+		return;
+	}
+	for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < A.ndraws; d += (uint64_t)gridDim.x * blockDim.x) {
+		const vgx_draw_info di = A.dinfo[d];
+		if ((di.flags & 1u) || di.num_meshes == 0) { continue; } // (serial draws: k_flatten_serial wrote their meshes)
+		const vgx_draw drLocal = A.draws[d]; // (loaded in front of the first store: see flatten_gather_body)
+		const vgx_draw* dr = &drLocal;
+		const uint32_t fillFlags = dr->fill_flags, strokeFlags = dr->stroke_flags;
+		const uint32_t numFill = di.flags >> 1;
+		uint32_t f = 0, sk = 0;
+		vgx_subpath pre[4];
+#pragma unroll
+		for (uint32_t j = 0; j < 4; ++j) { if (j < di.num_subpaths) { pre[j] = A.subs[di.first_subpath + j]; } }
+		for (uint32_t j = 0; j < di.num_subpaths; ++j) {
+			vgx_subpath r;
+			if (j == 0) { r = pre[0]; } else if (j == 1) { r = pre[1]; } else if (j == 2) { r = pre[2]; } else if (j == 3) { r = pre[3]; }
+			else { r = A.subs[di.first_subpath + j]; }
+			const uint32_t n = r.num_vertices;
+			const bool closed = (r.flags & 1u) != 0;
+			if ((fillFlags & VGX_FILL_ENABLE) && n >= 3) {
+				vgx_write_mesh(A.mdesc, A.mtab, di.first_mesh + f, dr, (uint32_t)d, j, (fillFlags & VGX_FILL_AA) ? VGX_MESH_FILL_AA : VGX_MESH_FILL, closed, r.first_vertex, n, A.mprep, A.poly, 0u);
+				++f;
+			}
+			if ((strokeFlags & VGX_STROKE_ENABLE) && n >= 2) {
+				const uint32_t kd = !(strokeFlags & VGX_STROKE_AA) ? VGX_MESH_STROKE : ((strokeFlags & VGX_STROKE_THIN) ? VGX_MESH_STROKE_AA_THIN : VGX_MESH_STROKE_AA);
+				if (vgx_write_mesh(A.mdesc, A.mtab, di.first_mesh + numFill + sk, dr, (uint32_t)d, j, kd, closed, r.first_vertex, n, A.mprep, A.poly)) {
+					atomicAdd(&A.totals->num_round_meshes, 1u);
+				}
+				++sk;
+			}
+		}
+	}
+}
+
 // ---- private (per-lane) pending stack for the serial kernel ---------------------------------------------
 struct PrivStack
 {
@@ -1183,6 +1225,11 @@ void vgx_launch_flatten_build(const VgxFlattenArgs& a, int waves, hipStream_t s,
 		hipLaunchKernelGGL(k_flatten_build<false>, dim3(waves), dim3(VGX_WAVE), 0, s, a);
 	}
 	if (serialCount) { hipLaunchKernelGGL((k_flatten_serial<false, false>), dim3(1024), dim3(256), 0, s, a); } // count + heap allocation
+}
+
+void vgx_launch_flatten_gather_ordered(const VgxFlattenArgs& a, hipStream_t s) // behind k_flat1 (+ its k_flatten_serial emit)
+{
+	hipLaunchKernelGGL(k_flatten_gather_ordered, dim3(2048), dim3(256), 0, s, a);
 }
 
 void vgx_launch_flatten_gather(const VgxFlattenArgs& a, hipStream_t s)

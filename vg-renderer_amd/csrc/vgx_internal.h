@@ -236,6 +236,7 @@ struct VgxStrokeArgs;
 void vgx_launch_small_front(const void* opCmdPrefix, vgx_draw_info* dinfo, hipStream_t s);
 void vgx_launch_small_middle(const VgxFlattenArgs& f, const VgxStrokeArgs& st, const void* opDraws, const void* opMeshes, vgx_sizes* devSizes, uint32_t* devStatus, hipStream_t s);
 void vgx_launch_flatten_gather(const VgxFlattenArgs& a, hipStream_t s);  // after the draw scan: ordered mesh descriptors
+void vgx_launch_flatten_gather_ordered(const VgxFlattenArgs& a, hipStream_t s); // vgx_tessellate's one-walk route: mesh descriptors from k_flat1's ordered records
 #ifndef VGX_BUILD_WAVES
 #define VGX_BUILD_WAVES 4096
 #endif

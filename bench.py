@@ -179,6 +179,8 @@ WORKLOADS = {
     "tiger10k_round_ordinary": "the tiger10k_round batch with VGX_TMPL_ROUND=0: the ordinary pipeline (k_flatten_inst + k_fill + k_round_sizes + k_stroke), what Round joins cost before round 5",
     "tiger10k_varied_round": "the tiger10k_varied batch (7 scales, 18 classes) with Round joins on the strokes: class-aware Round-join templates (round 6) -- one template per class, per-step sizes counted per instance",
     "tiger10k_varied_round_ordinary": "the same batch with VGX_TMPL_ROUND=0: the ordinary pipeline (k_flatten_inst with the instances sorted by tolerance class + k_fill + k_round_sizes + k_stroke), what it cost before",
+    "cubics1m_stroked": "BASELINE configs[1]'s million cubics STROKED (2 px, Butt / Miter, AA) through vgx_tessellate: unrelated draws with long curves -- the one-walk flatten route (k_flat1 under vgx_tessellate, round 6)",
+    "cubics1m_stroked_heap_route": "the same batch with VGX_TESS_FLAT1=0: k_flatten_build (one lane per path command, leaves through a heap), what it cost before",
     "round10k_static": "BASELINE configs[3]'s batch (10k polylines x 1k segments, Round joins + Round caps) with vgx_set_static_batches: the draw list flattened once by the count, a step = per-step Round-join sizes + the template emit kernel (no flatten, no scans)",
     "tiger10k_culled": "Tiger x10k after culling and reordering (a random 70 % of the draws, shuffled: no period left) with vgx_set_static_batches: the draw list flattened once by the count as ONE template, a step = the emit kernel (element tables from HBM instead of L2)",
     "tiger10k_culled_ordinary": "the tiger10k_culled batch without static batches: k_flatten_inst grouped by path + k_fill + k_stroke, what such a scene cost before round 5",
@@ -190,7 +192,7 @@ WORKLOADS = {
     "tiger10k_command_parallel": "Tiger x10k with VGX_INST=0: k_flatten_build (one lane per path command) + k_fill + k_stroke, no instancing at all",
     "tiger10k_varied_per_instance_flatten": "the tiger10k_varied batch with VGX_TMPL_CLASSES=0: what instances cost when they share no subdivision (k_flatten_inst with the instances sorted by tolerance class + k_fill + k_stroke)",
 }
-CONFIG_ENV = {"round10k_static": {"VGX_TMPL_BATCH": "1"}, "tiger10k_culled": {"VGX_TMPL_BATCH": "1"}, "tiger10k_culled_ordinary": {"VGX_TMPL_BATCH": "0"}, "tiger10k_round_ordinary": {"VGX_TMPL_ROUND": "0"}, "tiger10k_varied_round_ordinary": {"VGX_TMPL_ROUND": "0"}, "tiger10k_per_instance_flatten": {"VGX_TMPL": "0"}, "tiger10k_command_parallel": {"VGX_INST": "0"}, "tiger10k_varied_per_instance_flatten": {"VGX_TMPL_CLASSES": "0"}}
+CONFIG_ENV = {"round10k_static": {"VGX_TMPL_BATCH": "1"}, "tiger10k_culled": {"VGX_TMPL_BATCH": "1"}, "tiger10k_culled_ordinary": {"VGX_TMPL_BATCH": "0"}, "tiger10k_round_ordinary": {"VGX_TMPL_ROUND": "0"}, "tiger10k_varied_round_ordinary": {"VGX_TMPL_ROUND": "0"}, "cubics1m_stroked_heap_route": {"VGX_TESS_FLAT1": "0"}, "tiger10k_per_instance_flatten": {"VGX_TMPL": "0"}, "tiger10k_command_parallel": {"VGX_INST": "0"}, "tiger10k_varied_per_instance_flatten": {"VGX_TMPL_CLASSES": "0"}}
 # configs that get their own cpu_baseline (the honesty configs are the headline's batch: they share its baseline)
 CONFIG_CPU = {"cubics1m": "cubics", "round10k": "round", "tigerspec10k": "tigerspec", "tiger10k_varied": "varied", "tiger10k_open": "tigeropen", "tiger10k_bevel": "tigerbevel", "tiger10k_round": "tigerround"}
 CONFIG_CPU_BUDGET = {"cubics": 4.0, "round": 4.0}  # seconds of wall time per config (the tiger variants: 2.5 s)
@@ -245,6 +247,10 @@ def make_workload(wl, name, instances, rank):
     if name == "cubics1m":
         ps, d = wl.random_cubics(1000000, seed=1234 + rank, box=1000.0)
         return ps, d, "1 000 000 independent paths (moveTo + cubicTo, 8 coordinates uniform in [0,1000)) per GPU: pathXXX only (vgx_flatten_count + vgx_flatten_emit)", "flatten"
+    if name in ("cubics1m_stroked", "cubics1m_stroked_heap_route"):
+        ps, d = wl.random_cubics(1000000, seed=1234 + rank, box=1000.0)
+        wl.set_stroke(d, slice(None), 0xFF2060A0, 2.0, wl.capi.CAP_BUTT, wl.capi.JOIN_MITER, aa=True)
+        return ps, d, "1 000 000 independent paths (moveTo + cubicTo, coordinates uniform in [0,1000)) per GPU, each stroked 2 px wide (Butt caps, Miter joins, AA)", "tessellate"
     if name in ("round10k", "round10k_static"):
         ps, d = wl.random_walk_polylines(10000, 1000, seed=5678 + rank)
         return ps, d, "10 000 open polylines x 1000 segments per GPU, strokerPolylineStrokeAA with Round joins + Round caps, width 6", "tessellate"

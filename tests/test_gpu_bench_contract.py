@@ -52,7 +52,7 @@ def test_one_rank_line(tmp_path):
     assert set(r["by_kernel"]) == {"tmpl_emit"} and r["kernel"] == "tmpl_emit"  # the headline batch is a template batch: one kernel per step
     assert d["config"]["flatten_kernel"].startswith("none per step: template mode")
     assert set(d["configs"]) == {"cubics1m", "round10k", "tiger10k_varied", "tigerspec10k", "tiger10k_per_instance_flatten", "tiger10k_command_parallel",
-                                 "tiger10k_varied_per_instance_flatten", "tiger10k_open", "tiger10k_bevel", "tiger10k_round", "tiger10k_round_ordinary", "tiger10k_varied_round", "tiger10k_varied_round_ordinary", "tiger10k_culled", "tiger10k_culled_ordinary", "round10k_static", "tiger10k_animated"}
+                                 "tiger10k_varied_per_instance_flatten", "tiger10k_open", "tiger10k_bevel", "tiger10k_round", "tiger10k_round_ordinary", "tiger10k_varied_round", "tiger10k_varied_round_ordinary", "cubics1m_stroked", "cubics1m_stroked_heap_route", "tiger10k_culled", "tiger10k_culled_ordinary", "round10k_static", "tiger10k_animated"}
     for name, c in d["configs"].items():
         assert "error" not in c, (name, c)
         assert c["value"] > 0, name

@@ -11,7 +11,8 @@ import torch  # noqa: E402
 rt = importlib.import_module("vg-renderer_amd.runtime")
 wl = importlib.import_module("vg-renderer_amd.workloads")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
-ps, d = wl.random_cubics(N, seed=1234, box=1000.0)
+BOX = float(sys.argv[2]) if len(sys.argv) > 2 else 1000.0
+ps, d = wl.random_cubics(N, seed=1234, box=BOX)
 wl.set_stroke(d, slice(None), 0xFF2060A0, 2.0, rt.capi.CAP_BUTT, rt.capi.JOIN_MITER, aa=True)
 ctx = rt.Context(0)
 pset = rt.PathSet(ctx, ps)

@@ -1,5 +1,5 @@
 """vgx_tessellate's ONE-WALK flatten route (round 6; VERDICT r5 item 3, /root/reference/src/path.cpp:86-182): batches of unrelated draws whose
-curves are long (the count finds >= 8 polyline vertices per command instance) are flattened by k_flat1 -- vgx_flatten's ordered one-walk
+curves are long (the count finds >= 10 polyline vertices per command instance) are flattened by k_flat1 -- vgx_flatten's ordered one-walk
 kernel -- in k_flatten_build's place: the polyline lands dense and in draw order in the scratch, the per-draw and sub-path records are
 complete, the mesh descriptors come from them (k_flatten_gather_ordered). Bit-exact against the reference and byte for byte against the
 heap route (VGX_TESS_FLAT1=0); every path command, statically serial shapes, degenerate draws (the kernel's second run), paths without

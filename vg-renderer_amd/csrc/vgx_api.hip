@@ -586,8 +586,8 @@ void runFlattenBuild(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws,
 // vgx_tessellate's flatten stage through the ordered one-walk kernel (vgx_flat1.hip; round 6): command prefix -> k_flat1
 // (tasks cut at the roots, leaves staged in LDS, places by look-back: the polyline lands dense and in draw order in the scratch, the per-draw and
 // sub-path records complete) -> the exact builder's draws -> totals -> mesh descriptors from the ordered records. No heap, no scan over the
-// draws. For batches of LONG curves (the count decides: >= 8 polyline vertices per command instance), where k_flatten_build's lanes spill
-// their leaves past the LDS slots and walk in lock-step with the deepest cubic of the chunk.
+// draws. For batches of LONG curves, where k_flatten_build's lanes spill
+// their leaves past the LDS slots and walk in lock-step with the deepest cubic of the chunk (the count decides: >= 10 polyline vertices per command instance).
 void runFlattenOneWalk(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* draws, uint64_t ndraws, hipStream_t s)
 {
 	{
@@ -1932,11 +1932,11 @@ int vgx_tessellate_count(vgx_ctx* ctx, const vgx_pathset* ps, const vgx_draw* dr
 	}
 	if ((st = ensureMeshBuffers(ctx, heapVerts, sz.num_subpaths, sz.num_meshes)) != VGX_OK) { return st; }
 	// the one-walk route for vgx_tessellate's flatten stage? Unrelated draws (no instancing), curves (not a lineTo-only set), and long ones:
-	// >= 8 polyline vertices per command instance (VGX_TESS_FLAT1=2: whatever their length). Sized here, so that the steady state allocates nothing.
+	// >= 10 polyline vertices per command instance (VGX_TESS_FLAT1=2: whatever their length; the two routes cross between 7.5 and 12.6, profiles/experiments/r06_cubics_tessellate_boxes.txt). Sized here, so that the steady state allocates nothing.
 	ctx->f1Route = false;
 	if (ctx->optTessFlat1 && !ctx->optTwoPass && ndraws > VGX_SMALL_DRAWS && !instPeriodFor(ctx, ndraws) && !instGroupedFor(ctx, ps, ndraws)
 		&& !(ps->thinStatic && ctx->optThinStatic) && sz.num_cmd_instances != 0
-		&& (ctx->optTessFlat1 == 2 || sz.num_poly_vertices >= 8 * sz.num_cmd_instances)) {
+		&& (ctx->optTessFlat1 == 2 || sz.num_poly_vertices >= 10 * sz.num_cmd_instances)) {
 		int cap = 1664; uint32_t segMax = 64; // as vgx_flatten picks them, from the count's own figures
 		const double perChunk = (double)sz.num_poly_vertices / (double)sz.num_cmd_instances * 64.0;
 		if (perChunk <= 800.0) { cap = 1024; }

@@ -39,7 +39,7 @@ def traffic(fetch_db, write_db, label, valu_db=None):
     """JSON for bench.py's roofline.traffic: HBM bytes per launch of the three big kernels = FETCH_SIZE x 2 (gfx950
     correction for wide coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE (raw), from two separate --pmc passes."""
     import json
-    names = {"k_tmpl_emit": "tmpl_emit", "k_tmpl_emit_general": "tmpl_emit", "k_tmpl_emit_open": "tmpl_emit", "k_tmpl_emit_round": "tmpl_emit", "k_tmpl_emit_round_aa": "tmpl_emit", "k_tmpl_emit_round_aa_open": "tmpl_emit", "k_tmpl_emit_round_closed": "tmpl_emit", "k_tmpl_emit_bevel": "tmpl_emit", "k_tmpl_round_sizes": "tmpl_round_sizes", "k_tmpl_round_sizes_inst": "tmpl_round_sizes", "k_tmpl_round_sizes_block": "tmpl_round_sizes", "k_flatten_build": "flatten_build", "k_flatten_inst": "flatten_build", "k_fill": "fill_emit", "k_stroke": "stroke_emit", "k_stroke_long": "stroke_emit", "k_stroke_simple": "stroke_emit", "k_flatten_gather": "flatten_gather", "k_mesh_prepare": "mesh_prepare",
+    names = {"k_tmpl_emit": "tmpl_emit", "k_tmpl_emit_general": "tmpl_emit", "k_tmpl_emit_open": "tmpl_emit", "k_tmpl_emit_round": "tmpl_emit", "k_tmpl_emit_round_aa": "tmpl_emit", "k_tmpl_emit_round_aa_open": "tmpl_emit", "k_tmpl_emit_round_closed": "tmpl_emit", "k_tmpl_emit_bevel": "tmpl_emit", "k_tmpl_round_sizes": "tmpl_round_sizes", "k_tmpl_round_sizes_inst": "tmpl_round_sizes", "k_tmpl_round_sizes_block": "tmpl_round_sizes", "k_flatten_build": "flatten_build", "k_flatten_inst": "flatten_build", "k_fill": "fill_emit", "k_stroke": "stroke_emit", "k_stroke_long": "stroke_emit", "k_stroke_simple": "stroke_emit", "k_flatten_gather": "flatten_gather", "k_flatten_gather_ordered": "flatten_gather", "k_mesh_prepare": "mesh_prepare",
              "k_flatten<false": "flatten_count", "k_flatten<true": "flatten_emit",  # vgx_flatten_count / _emit (two walks): count pass, emit pass
              "k_flat1": "flatten_one_walk", "k_f1_seg_table": "flatten_one_walk",
              "k_emit_tiles": "tile_emit", "k_tile_table": "tile_emit"}  # round 6: the tile kernel of ordinary batches (+ its tile table)   # vgx_flatten (cubics1m, round 5): the one-walk kernel (+ its segment table; the REDO instance exits at once)

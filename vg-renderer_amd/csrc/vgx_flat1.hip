@@ -344,6 +344,21 @@ __device__ __forceinline__ uint32_t f1_task_walk(F1Lds<CAP>& L, int lane, bool a
 	return listN;
 }
 
+// What the placement of a chunk needs of one lane's command instance (k_flat1: placeChunk). 31 dwords.
+struct F1Pend
+{
+	uint32_t flags; // bit 0 valid, 1 serialDraw, 2 endNearFirst, 3 isCubic, 4 deep, 5 lastInSub, 6 closedHere, 7 drawHead, 8 drawLast, 9 slowDraw, 10 serialTail
+	int excl, rawCnt, spTotal;
+	uint32_t myTasks, myTask0, type;
+	float ptx, pty;
+	uint32_t na, argOff, recIndex;
+	float tessTol;
+	int spBefore, subInclC, meshInclC, subAll, meshAll;
+	uint32_t serV, serS, serM, serF;
+	int inDrawBefore, cnt, subsIncl, fillIncl, strokeIncl;
+	uint64_t d, ownerBase;
+};
+
 // REDO: the second run of a batch in which the first found degenerate draws -- the same code as its own kernel, so that a kernel
 // trace shows the run that does the work apart from the one that (normally) exits at once.
 template<int CAP, bool XFORM, bool REDO>
@@ -371,6 +386,161 @@ __global__ __launch_bounds__(VGX_WAVE, (CAP > 2048 ? 1 : F1_MIN_WAVES_PER_EU)) v
 #else
 #define F1_FLUSH() ((void)0)
 #endif
+
+	// ---- placement of ONE chunk (vertices from the leaf list / the commands, sub-path and per-draw records) from what its lanes knew after the
+	// bookkeeping (F1Pend) and the places of the segment (bases: the sums in front of it; run*: placed in front of the chunk inside it). A
+	// function of its arguments and the LDS list only, so that it can run LATER than the walk that filled the list (round 6: see `defer`).
+	auto placeChunk = [&](const F1Pend& q, uint64_t cubicMask, bool staged, uint32_t listN, uint64_t baseV, uint64_t baseS, uint64_t baseM, long long runV, uint64_t runS, uint64_t runM) {
+		const bool valid = (q.flags & 1u) != 0, serialDraw = (q.flags & 2u) != 0, endNearFirst = (q.flags & 4u) != 0, isCubic = (q.flags & 8u) != 0, deep = (q.flags & 16u) != 0;
+		const bool lastInSub = (q.flags & 32u) != 0, closedHere = (q.flags & 64u) != 0, drawHead = (q.flags & 128u) != 0, drawLast = (q.flags & 256u) != 0, slowDraw = (q.flags & 512u) != 0, serialTail = (q.flags & 1024u) != 0;
+		const int excl = q.excl, rawCnt = q.rawCnt, spTotal = q.spTotal, spBefore = q.spBefore, subInclC = q.subInclC, meshInclC = q.meshInclC, subAll = q.subAll, meshAll = q.meshAll;
+		const int inDrawBefore = q.inDrawBefore, cnt = q.cnt, subsIncl = q.subsIncl, fillIncl = q.fillIncl, strokeIncl = q.strokeIncl;
+		const uint32_t myTasks = q.myTasks, myTask0 = q.myTask0, type = q.type, na = q.na, recIndex = q.recIndex, serV = q.serV, serS = q.serS, serM = q.serM, serF = q.serF;
+		const float ptx = q.ptx, pty = q.pty, tessTol = q.tessTol;
+		const uint64_t d = q.d, ownerBase = q.ownerBase;
+		const float* pa = ps.args + q.argOff;
+		const float* mtx = A.draws[valid ? d : 0].mtx;
+			// ---- place --------------------------------------------------------------------------------------
+			const long long gl = (long long)baseV + runV + (long long)excl; // output index of my first vertex
+			uint32_t limit = (valid && !serialDraw) ? (uint32_t)(rawCnt < 0 ? 0 : rawCnt) : 0u;
+			if (endNearFirst && limit > 0 && spTotal > 2) { --limit; } // my last vertex is the one pathClose removes
+			float* out = A.poly + 2 * gl;
+			if (cubicMask) {
+				if (staged) {
+					// per task: place relative to the chunk's first vertex (+ 64: a pathClose pop makes excl -1 at most), limit, owner lane
+					if (isCubic) {
+						uint32_t pl = (uint32_t)(excl + 64), left = deep ? 0u : limit;
+						const uint32_t own = (uint32_t)lane << 24; // a task has at most 2^10 leaves: the limit leaves room for the owner's lane
+						for (uint32_t j = 0; j < myTasks; ++j) {
+							const uint32_t kj = L.tinfo[myTask0 + j].x & 0xFFFFFFu;
+							const uint32_t lj = left < kj ? left : kj;
+							L.tinfo[myTask0 + j] = make_uint2(pl, lj | own);
+							pl += kj; left -= lj;
+						}
+					}
+					__syncthreads();
+					float2* obase = (float2*)A.poly + ((long long)baseV + runV - 64);
+					const float m0 = mtx[0], m1 = mtx[1], m2 = mtx[2], m3 = mtx[3], m4 = mtx[4], m5 = mtx[5];
+					for (uint32_t l0 = 0; l0 < listN; l0 += 2 * VGX_WAVE) { // two entries per lane and step: their LDS chains run side by side
+						const uint32_t liA = l0 + (uint32_t)lane, liB = liA + VGX_WAVE;
+						const bool lvA = liA < listN, lvB = liB < listN;
+						const float2 qA = L.list[lvA ? liA : (uint32_t)CAP], qB = L.list[lvB ? liB : (uint32_t)CAP];
+						const uint32_t tgA = lvA ? (uint32_t)L.tag[liA] : 0u, tgB = lvB ? (uint32_t)L.tag[liB] : 0u;
+						const uint2 tiA = L.tinfo[tgA & 63u], tiB = L.tinfo[tgB & 63u];
+						float ax = qA.x, ay = qA.y, bx = qB.x, by = qB.y;
+						if (XFORM) { // the owner's transform comes through shuffles (all lanes take part)
+							const int oA = (int)(tiA.y >> 24), oB = (int)(tiB.y >> 24);
+							const float a0 = __shfl(m0, oA), a1 = __shfl(m1, oA), a2 = __shfl(m2, oA), a3 = __shfl(m3, oA), a4 = __shfl(m4, oA), a5 = __shfl(m5, oA);
+							const float b0 = __shfl(m0, oB), b1 = __shfl(m1, oB), b2 = __shfl(m2, oB), b3 = __shfl(m3, oB), b4 = __shfl(m4, oB), b5 = __shfl(m5, oB);
+							const float nax = a0 * ax + a2 * ay + a4, nay = a1 * ax + a3 * ay + a5; // transformPos2D, vg_util.h:24-28
+							const float nbx = b0 * bx + b2 * by + b4, nby = b1 * bx + b3 * by + b5;
+							ax = nax; ay = nay; bx = nbx; by = nby;
+						}
+						if (lvA && (tgA >> 6) < (tiA.y & 0xFFFFFFu)) { obase[tiA.x + (tgA >> 6)] = make_float2(ax, ay); }
+						if (lvB && (tgB >> 6) < (tiB.y & 0xFFFFFFu)) { obase[tiB.x + (tgB >> 6)] = make_float2(bx, by); }
+					}
+				}
+			}
+			if (valid && !serialDraw) {
+				if (type == VGX_CMD_MOVE_TO || type == VGX_CMD_LINE_TO) {
+					if (limit > 0) {
+						V2 p = v2(ptx, pty);
+						if (XFORM) { p = v2xform(p, mtx); }
+						*(float2*)out = make_float2(p.x, p.y);
+					}
+				} else if (isCubic && (!staged || deep)) {
+					(void)0; // walked again below, 32 owners at a time
+				} else if (type == VGX_CMD_POLYLINE && limit < (uint32_t)VGX_WAVE) {
+					const uint32_t skip = (na >> 1) - (uint32_t)rawCnt;
+					for (uint32_t i = 0; i < limit; ++i) {
+						V2 p = v2(pa[2 * (i + skip)], pa[2 * (i + skip) + 1]);
+						if (XFORM) { p = v2xform(p, mtx); }
+						*(float2*)(out + 2 * i) = make_float2(p.x, p.y);
+					}
+				}
+			}
+			{ // cubics that are not in the list (the chunk overflowed it, or the cubic nests deeper than the LDS levels)
+				uint64_t againMask = wave_ballot(isCubic && (!staged || deep));
+				while (againMask) {
+					const int ar = __popcll(againMask & lanemask_lt(lane));
+					const bool me = isCubic && (!staged || deep) && ar < 32 && ((againMask >> lane) & 1ull);
+					if (me) {
+						const VgxCmdRec rr = ps.cmdrec[recIndex]; // (read again: rare path, and the record is not kept across the walk)
+						float q1x = rr.a[0], q1y = rr.a[1], q2x = rr.a[2], q2y = rr.a[3], qex = rr.a[4], qey = rr.a[5];
+						if (rr.type == VGX_CMD_QUAD_TO) {
+							qex = rr.a[2]; qey = rr.a[3];
+							vgx_quad_to_cubic(rr.start[0], rr.start[1], rr.a[0], rr.a[1], qex, qey, &q1x, &q1y, &q2x, &q2y);
+						}
+						LdsStack2<VGX_F1_LV> st2;
+						st2.a = &L.stack[2 * ar]; st2.b = &L.stack[2 * ar + 1];
+						FastCubicSink<true, XFORM> sink;
+						sink.prev = v2(rr.start[0], rr.start[1]); sink.n = 0; sink.slow = false; sink.out = out; sink.writeLimit = limit; sink.mtx = mtx; sink.begin();
+						vgx_flatten_cubic(rr.start[0], rr.start[1], q1x, q1y, q2x, q2y, qex, qey, tessTol, st2, sink);
+						sink.flush();
+					}
+					uint64_t m = againMask; int dropped = 0;
+					while (m && dropped < 32) { m &= m - 1; ++dropped; }
+					againMask = m;
+				}
+			}
+			{ // long POLYLINE commands: the wave moves them together (path.cpp:684-705 copies the points verbatim)
+				uint64_t longMask = wave_ballot(valid && !serialDraw && type == VGX_CMD_POLYLINE && limit >= (uint32_t)VGX_WAVE);
+				while (longMask) {
+					const int src = __builtin_ctzll(longMask);
+					longMask &= longMask - 1;
+					const uint64_t gS = wave_bcast_u64((uint64_t)gl, src);
+					const float* paS = (const float*)wave_bcast_u64((uint64_t)(pa + 2 * ((na >> 1) - (uint32_t)rawCnt)), src);
+					const float* mS = (const float*)wave_bcast_u64((uint64_t)mtx, src);
+					const uint32_t limS = (uint32_t)wave_bcast((int)limit, src);
+					const float m0 = mS[0], m1 = mS[1], m2 = mS[2], m3 = mS[3], m4 = mS[4], m5 = mS[5];
+					float2* outS = (float2*)A.poly + gS;
+					for (uint32_t i = (uint32_t)lane; i < limS; i += VGX_WAVE) {
+						const float2 q = *(const float2*)(paS + 2 * (size_t)i);
+						outS[i] = XFORM ? make_float2(m0 * q.x + m2 * q.y + m4, m1 * q.x + m3 * q.y + m5) : q;
+					}
+				}
+			}
+			// ---- sub-path records, per-draw records ---------------------------------------------------------------
+			const uint64_t subsGlobalIncl = baseS + runS + (uint64_t)subInclC;   // sub-paths up to and including my lane
+			const uint64_t meshGlobalIncl = baseM + runM + (uint64_t)meshInclC;
+			if (lastInSub) {
+				vgx_subpath r;
+				r.first_vertex = (uint64_t)(gl - (long long)spBefore);
+				r.num_vertices = (uint32_t)spTotal;
+				r.flags = closedHere ? 1u : 0u;
+				// my sub-path's number: the sub-paths that exist up to my lane end with mine (its head is at or before my lane)
+				A.subs[subsGlobalIncl - 1] = r;
+			}
+			if (X.has_empty && valid && drawHead) {
+				// draws of EMPTY paths in front of my draw (no lane ever sees them): their records hold the running totals,
+				// as the scan over draws of the two-phase entry gives them
+				vgx_draw_info de;
+				de.first_poly_vertex = (uint64_t)gl; de.first_subpath = subsGlobalIncl - (uint64_t)subAll; de.first_mesh = meshGlobalIncl - (uint64_t)meshAll;
+				de.num_poly_vertices = 0; de.num_subpaths = 0; de.num_meshes = 0; de.flags = 0;
+				for (uint64_t e = d; e > 0 && A.cmd_prefix[e - 1] == ownerBase; --e) { A.dinfo[e - 1] = de; }
+			}
+			if (valid && drawLast) {
+				vgx_draw_info di;
+				if (serialDraw) {
+					di.num_poly_vertices = serV; di.num_subpaths = serS; di.num_meshes = serM; di.flags = serF; // counts from k_flatten_serial<count>; places from here
+					di.first_poly_vertex = (uint64_t)gl;
+					di.first_subpath = subsGlobalIncl - serS;
+					di.first_mesh = meshGlobalIncl - serM;
+					A.dinfo[d] = di;
+				} else if (!slowDraw) {
+					di.first_poly_vertex = (uint64_t)(gl - (long long)inDrawBefore);
+					di.first_subpath = subsGlobalIncl - (uint64_t)subsIncl;
+					di.first_mesh = meshGlobalIncl - (uint64_t)(fillIncl + strokeIncl);
+					di.num_poly_vertices = (uint32_t)(inDrawBefore + cnt);
+					di.num_subpaths = (uint32_t)subsIncl;
+					di.num_meshes = (uint32_t)(fillIncl + strokeIncl);
+					di.flags = ((uint32_t)fillIncl << 1);
+					A.dinfo[d] = di;
+				}
+			}
+			const uint64_t serialTails = wave_ballot(serialTail);
+			if (serialTails && lane == 0) { atomicAdd(&T->flat_serial_draws, (unsigned long long)__popcll(serialTails)); }
+	};
 
 	for (;;) {
 		// ---- next segment ---------------------------------------------------------------------------------------------
@@ -460,7 +630,6 @@ __global__ __launch_bounds__(VGX_WAVE, (CAP > 2048 ? 1 : F1_MIN_WAVES_PER_EU)) v
 				}
 				const float* a = rec.a;
 				const float* pa = ps.args + rec.arg_off;
-				const float* mtx = dr->mtx;
 				const V2 start = v2(rec.start[0], rec.start[1]);
 				// what the phases behind the walk need of the command record, so that the record itself does not stay in registers
 				// across the walk (the kernel must fit two waves per SIMD): the point of a MOVE_TO / LINE_TO, and the two epsilon
@@ -713,146 +882,14 @@ __global__ __launch_bounds__(VGX_WAVE, (CAP > 2048 ? 1 : F1_MIN_WAVES_PER_EU)) v
 					const unsigned long long c4 = F1_CLK();
 					F1_ACC(3, c4 - c3); // publish + look-back
 					if (writeOk && nvalid > 0) {
-						// ---- place --------------------------------------------------------------------------------------
-						const long long gl = (long long)baseV + runV + (long long)excl; // output index of my first vertex
-						uint32_t limit = (valid && !serialDraw) ? (uint32_t)(rawCnt < 0 ? 0 : rawCnt) : 0u;
-						if (endNearFirst && limit > 0 && spTotal > 2) { --limit; } // my last vertex is the one pathClose removes
-						float* out = A.poly + 2 * gl;
-						if (cubicMask) {
-							if (staged) {
-								// per task: place relative to the chunk's first vertex (+ 64: a pathClose pop makes excl -1 at most), limit, owner lane
-								if (isCubic) {
-									uint32_t pl = (uint32_t)(excl + 64), left = deep ? 0u : limit;
-									const uint32_t own = (uint32_t)lane << 24; // a task has at most 2^10 leaves: the limit leaves room for the owner's lane
-									for (uint32_t j = 0; j < myTasks; ++j) {
-										const uint32_t kj = L.tinfo[myTask0 + j].x & 0xFFFFFFu;
-										const uint32_t lj = left < kj ? left : kj;
-										L.tinfo[myTask0 + j] = make_uint2(pl, lj | own);
-										pl += kj; left -= lj;
-									}
-								}
-								__syncthreads();
-								float2* obase = (float2*)A.poly + ((long long)baseV + runV - 64);
-								const float m0 = mtx[0], m1 = mtx[1], m2 = mtx[2], m3 = mtx[3], m4 = mtx[4], m5 = mtx[5];
-								for (uint32_t l0 = 0; l0 < listN; l0 += 2 * VGX_WAVE) { // two entries per lane and step: their LDS chains run side by side
-									const uint32_t liA = l0 + (uint32_t)lane, liB = liA + VGX_WAVE;
-									const bool lvA = liA < listN, lvB = liB < listN;
-									const float2 qA = L.list[lvA ? liA : (uint32_t)CAP], qB = L.list[lvB ? liB : (uint32_t)CAP];
-									const uint32_t tgA = lvA ? (uint32_t)L.tag[liA] : 0u, tgB = lvB ? (uint32_t)L.tag[liB] : 0u;
-									const uint2 tiA = L.tinfo[tgA & 63u], tiB = L.tinfo[tgB & 63u];
-									float ax = qA.x, ay = qA.y, bx = qB.x, by = qB.y;
-									if (XFORM) { // the owner's transform comes through shuffles (all lanes take part)
-										const int oA = (int)(tiA.y >> 24), oB = (int)(tiB.y >> 24);
-										const float a0 = __shfl(m0, oA), a1 = __shfl(m1, oA), a2 = __shfl(m2, oA), a3 = __shfl(m3, oA), a4 = __shfl(m4, oA), a5 = __shfl(m5, oA);
-										const float b0 = __shfl(m0, oB), b1 = __shfl(m1, oB), b2 = __shfl(m2, oB), b3 = __shfl(m3, oB), b4 = __shfl(m4, oB), b5 = __shfl(m5, oB);
-										const float nax = a0 * ax + a2 * ay + a4, nay = a1 * ax + a3 * ay + a5; // transformPos2D, vg_util.h:24-28
-										const float nbx = b0 * bx + b2 * by + b4, nby = b1 * bx + b3 * by + b5;
-										ax = nax; ay = nay; bx = nbx; by = nby;
-									}
-									if (lvA && (tgA >> 6) < (tiA.y & 0xFFFFFFu)) { obase[tiA.x + (tgA >> 6)] = make_float2(ax, ay); }
-									if (lvB && (tgB >> 6) < (tiB.y & 0xFFFFFFu)) { obase[tiB.x + (tgB >> 6)] = make_float2(bx, by); }
-								}
-							}
-						}
-						if (valid && !serialDraw) {
-							if (type == VGX_CMD_MOVE_TO || type == VGX_CMD_LINE_TO) {
-								if (limit > 0) {
-									V2 p = v2(ptx, pty);
-									if (XFORM) { p = v2xform(p, mtx); }
-									*(float2*)out = make_float2(p.x, p.y);
-								}
-							} else if (isCubic && (!staged || deep)) {
-								(void)0; // walked again below, 32 owners at a time
-							} else if (type == VGX_CMD_POLYLINE && limit < (uint32_t)VGX_WAVE) {
-								const uint32_t skip = (na >> 1) - (uint32_t)rawCnt;
-								for (uint32_t i = 0; i < limit; ++i) {
-									V2 p = v2(pa[2 * (i + skip)], pa[2 * (i + skip) + 1]);
-									if (XFORM) { p = v2xform(p, mtx); }
-									*(float2*)(out + 2 * i) = make_float2(p.x, p.y);
-								}
-							}
-						}
-						{ // cubics that are not in the list (the chunk overflowed it, or the cubic nests deeper than the LDS levels)
-							uint64_t againMask = wave_ballot(isCubic && (!staged || deep));
-							while (againMask) {
-								const int ar = __popcll(againMask & lanemask_lt(lane));
-								const bool me = isCubic && (!staged || deep) && ar < 32 && ((againMask >> lane) & 1ull);
-								if (me) {
-									const VgxCmdRec rr = ps.cmdrec[recIndex]; // (read again: rare path, and the record is not kept across the walk)
-									float q1x = rr.a[0], q1y = rr.a[1], q2x = rr.a[2], q2y = rr.a[3], qex = rr.a[4], qey = rr.a[5];
-									if (rr.type == VGX_CMD_QUAD_TO) {
-										qex = rr.a[2]; qey = rr.a[3];
-										vgx_quad_to_cubic(rr.start[0], rr.start[1], rr.a[0], rr.a[1], qex, qey, &q1x, &q1y, &q2x, &q2y);
-									}
-									LdsStack2<VGX_F1_LV> st2;
-									st2.a = &L.stack[2 * ar]; st2.b = &L.stack[2 * ar + 1];
-									FastCubicSink<true, XFORM> sink;
-									sink.prev = v2(rr.start[0], rr.start[1]); sink.n = 0; sink.slow = false; sink.out = out; sink.writeLimit = limit; sink.mtx = mtx; sink.begin();
-									vgx_flatten_cubic(rr.start[0], rr.start[1], q1x, q1y, q2x, q2y, qex, qey, tessTol, st2, sink);
-									sink.flush();
-								}
-								uint64_t m = againMask; int dropped = 0;
-								while (m && dropped < 32) { m &= m - 1; ++dropped; }
-								againMask = m;
-							}
-						}
-						{ // long POLYLINE commands: the wave moves them together (path.cpp:684-705 copies the points verbatim)
-							uint64_t longMask = wave_ballot(valid && !serialDraw && type == VGX_CMD_POLYLINE && limit >= (uint32_t)VGX_WAVE);
-							while (longMask) {
-								const int src = __builtin_ctzll(longMask);
-								longMask &= longMask - 1;
-								const uint64_t gS = wave_bcast_u64((uint64_t)gl, src);
-								const float* paS = (const float*)wave_bcast_u64((uint64_t)(pa + 2 * ((na >> 1) - (uint32_t)rawCnt)), src);
-								const float* mS = (const float*)wave_bcast_u64((uint64_t)mtx, src);
-								const uint32_t limS = (uint32_t)wave_bcast((int)limit, src);
-								const float m0 = mS[0], m1 = mS[1], m2 = mS[2], m3 = mS[3], m4 = mS[4], m5 = mS[5];
-								float2* outS = (float2*)A.poly + gS;
-								for (uint32_t i = (uint32_t)lane; i < limS; i += VGX_WAVE) {
-									const float2 q = *(const float2*)(paS + 2 * (size_t)i);
-									outS[i] = XFORM ? make_float2(m0 * q.x + m2 * q.y + m4, m1 * q.x + m3 * q.y + m5) : q;
-								}
-							}
-						}
-						// ---- sub-path records, per-draw records ---------------------------------------------------------------
-						const uint64_t subsGlobalIncl = baseS + runS + (uint64_t)subInclC;   // sub-paths up to and including my lane
-						const uint64_t meshGlobalIncl = baseM + runM + (uint64_t)meshInclC;
-						if (lastInSub) {
-							vgx_subpath r;
-							r.first_vertex = (uint64_t)(gl - (long long)spBefore);
-							r.num_vertices = (uint32_t)spTotal;
-							r.flags = closedHere ? 1u : 0u;
-							// my sub-path's number: the sub-paths that exist up to my lane end with mine (its head is at or before my lane)
-							A.subs[subsGlobalIncl - 1] = r;
-						}
-						if (X.has_empty && valid && drawHead) {
-							// draws of EMPTY paths in front of my draw (no lane ever sees them): their records hold the running totals,
-							// as the scan over draws of the two-phase entry gives them
-							vgx_draw_info de;
-							de.first_poly_vertex = (uint64_t)gl; de.first_subpath = subsGlobalIncl - (uint64_t)subAll; de.first_mesh = meshGlobalIncl - (uint64_t)meshAll;
-							de.num_poly_vertices = 0; de.num_subpaths = 0; de.num_meshes = 0; de.flags = 0;
-							for (uint64_t e = d; e > 0 && A.cmd_prefix[e - 1] == ownerBase; --e) { A.dinfo[e - 1] = de; }
-						}
-						if (valid && drawLast) {
-							vgx_draw_info di;
-							if (serialDraw) {
-								di.num_poly_vertices = serV; di.num_subpaths = serS; di.num_meshes = serM; di.flags = serF; // counts from k_flatten_serial<count>; places from here
-								di.first_poly_vertex = (uint64_t)gl;
-								di.first_subpath = subsGlobalIncl - serS;
-								di.first_mesh = meshGlobalIncl - serM;
-								A.dinfo[d] = di;
-							} else if (!slowDraw) {
-								di.first_poly_vertex = (uint64_t)(gl - (long long)inDrawBefore);
-								di.first_subpath = subsGlobalIncl - (uint64_t)subsIncl;
-								di.first_mesh = meshGlobalIncl - (uint64_t)(fillIncl + strokeIncl);
-								di.num_poly_vertices = (uint32_t)(inDrawBefore + cnt);
-								di.num_subpaths = (uint32_t)subsIncl;
-								di.num_meshes = (uint32_t)(fillIncl + strokeIncl);
-								di.flags = ((uint32_t)fillIncl << 1);
-								A.dinfo[d] = di;
-							}
-						}
-						const uint64_t serialTails = wave_ballot(serialTail);
-						if (serialTails && lane == 0) { atomicAdd(&T->flat_serial_draws, (unsigned long long)__popcll(serialTails)); }
+						F1Pend q;
+						q.flags = (valid ? 1u : 0u) | (serialDraw ? 2u : 0u) | (endNearFirst ? 4u : 0u) | (isCubic ? 8u : 0u) | (deep ? 16u : 0u) | (lastInSub ? 32u : 0u) | (closedHere ? 64u : 0u)
+							| (drawHead ? 128u : 0u) | (drawLast ? 256u : 0u) | (slowDraw ? 512u : 0u) | (serialTail ? 1024u : 0u);
+						q.excl = excl; q.rawCnt = rawCnt; q.spTotal = spTotal; q.myTasks = myTasks; q.myTask0 = myTask0; q.type = type; q.ptx = ptx; q.pty = pty; q.na = na;
+						q.argOff = rec.arg_off; q.recIndex = recIndex; q.tessTol = tessTol; q.spBefore = spBefore; q.subInclC = subInclC; q.meshInclC = meshInclC; q.subAll = subAll; q.meshAll = meshAll;
+						q.serV = serV; q.serS = serS; q.serM = serM; q.serF = serF; q.inDrawBefore = inDrawBefore; q.cnt = cnt; q.subsIncl = subsIncl; q.fillIncl = fillIncl; q.strokeIncl = strokeIncl;
+						q.d = d; q.ownerBase = ownerBase;
+						placeChunk(q, cubicMask, staged, listN, baseV, baseS, baseM, runV, runS, runM);
 					}
 					runV += chunkV; runS += (uint64_t)chunkS; runM += (uint64_t)chunkM;
 					F1_ACC(4, F1_CLK() - c4); // placement + records
